@@ -1,0 +1,184 @@
+/* newton_hip.h -- C ABI of libnewton_hip.so: the MI355X (gfx950) batched rigid-body stepper that
+ * drops in behind Newton's Model/State/Control/Contacts + CollisionPipeline.collide() + Solver.step().
+ *
+ * Each entry point names the reference interface it replaces (paths relative to /root/reference):
+ *   nt_collide            <- CollisionPipeline.collide(state, contacts)          newton/_src/sim/collide.py:1765-2207
+ *   nt_xpbd_step          <- SolverXPBD.step(state_in, state_out, control, contacts, dt)
+ *                                                                                newton/_src/solvers/xpbd/solver_xpbd.py:329-862
+ *   nt_semi_implicit_step <- SolverSemiImplicit.step(...)                        newton/_src/solvers/semi_implicit/solver_semi_implicit.py:123-217
+ *   nt_xpbd_rollout       <- the CUDA-graph-captured simulate() loop             newton/examples/basic/example_basic_urdf.py:117-141
+ *                            (clear_forces + collide + step + swap, N substeps, one launch)
+ *   nt_clear_forces       <- State.clear_forces()                                newton/_src/sim/state.py:189-200
+ *   nt_eval_fk            <- newton.eval_fk(model, joint_q, joint_qd, state)     newton/_src/sim/articulation.py:500-573
+ *   nt_pack_aos / nt_unpack_aos <- the implicit AoS wp.array views of Model/State/Contacts
+ *                                                                                newton/_src/sim/state.py:113-171, contacts.py:227-277
+ *   nt_contacts_export    <- the flat, atomically-appended Contacts arrays       newton/_src/sim/collide.py:166-254
+ *
+ * Conventions (identical to Newton's, docs/concepts/conventions.rst:105-146): transforms are
+ * (px,py,pz,qx,qy,qz,qw); spatial vectors are (linear, angular); body_qd linear part is the COM
+ * velocity in world frame; contact normals point shape0 -> shape1; contact points are body-frame.
+ *
+ * Memory: every pointer below is a DEVICE pointer owned by the caller (the Python host allocates
+ * them as torch tensors; any other host can use hipMalloc).  The library keeps no global state and
+ * never allocates.  All entry points enqueue work on `stream` and return without synchronising.
+ *
+ * Layout: env-major SoA.  A quantity with C components for slot s (body / joint / dof / shape /
+ * contact slot) of environment e lives at  base[(c * NSLOT + s) * env_stride + e]  -- environment
+ * index fastest, so a wave64 touching one (component, slot) reads 256 contiguous bytes.
+ * All environments share one topology (same bodies / joints / shapes / candidate pairs -- what
+ * ModelBuilder.replicate() produces); parameters may differ per environment.
+ *
+ * Return value: 0 = ok, <0 = error (see nt_error_string).
+ */
+#ifndef NEWTON_HIP_H
+#define NEWTON_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t nt_status;
+#define NT_OK 0
+#define NT_ERR_INVALID_ARG (-1)
+#define NT_ERR_LAUNCH (-2)
+#define NT_ERR_UNSUPPORTED (-3)
+
+#define NT_MAX_CONTACTS_PER_PAIR 5   /* <=4 analytic (narrow_phase.py:871) or <=5 manifold (multicontact.py:852-956) */
+#define NT_CONTACT_FLOATS 17     /* point0[3] point1[3] offset0[3] offset1[3] normal[3] margin0 margin1 */
+#define NT_BODY_PARAM_FLOATS 23  /* com[3] inv_mass inertia[9] inv_inertia[9] mass */
+#define NT_JOINT_PARAM_FLOATS 14 /* X_p[7] X_c[7] */
+#define NT_DOF_PARAM_FLOATS 10   /* axis[3] limit_lower limit_upper target_ke target_kd limit_ke limit_kd armature */
+#define NT_SHAPE_PARAM_FLOATS 19 /* xform[7] scale[3] margin gap mu mu_torsional mu_rolling ke kd kf ka */
+
+/* Model: env-uniform topology + per-env parameters (Newton: newton/_src/sim/model.py:808-1364) */
+typedef struct {
+    int32_t env_count;   /* E  = Model.world_count */
+    int32_t env_stride;  /* ES >= E, multiple of 64 */
+    int32_t nb;          /* bodies per env */
+    int32_t nj;          /* joints per env */
+    int32_t nd;          /* dofs per env   (joint_qd) */
+    int32_t nc;          /* coords per env (joint_q) */
+    int32_t ntq;         /* joint_target_q entries per env (coords or dofs, model.py:1584-1591) */
+    int32_t ns;          /* env-local shapes per env */
+    int32_t ng;          /* global (world -1, static) shapes, shared by every env */
+    int32_t np;          /* candidate shape pairs per env (Model.shape_contact_pairs, one env's slice) */
+    int32_t cpp;         /* contact slots per pair: 4 (all pairs analytic) or 5 (some pair uses the convex manifold) */
+    /* topology, int32, env-uniform */
+    const int32_t* body_flags;          /* [nb]   BodyFlags */
+    const int32_t* joint_type;          /* [nj]   JointType */
+    const int32_t* joint_enabled;       /* [nj] */
+    const int32_t* joint_parent;        /* [nj]   env-local body index or -1 */
+    const int32_t* joint_child;         /* [nj] */
+    const int32_t* joint_q_start;       /* [nj]   env-local */
+    const int32_t* joint_qd_start;      /* [nj] */
+    const int32_t* joint_tq_start;      /* [nj]   joint_target_q_start */
+    const int32_t* joint_lin_count;     /* [nj]   joint_dof_dim[:,0] */
+    const int32_t* joint_ang_count;     /* [nj]   joint_dof_dim[:,1] */
+    const int32_t* shape_body;          /* [ns+ng] env-local body or -1 */
+    const int32_t* shape_type;          /* [ns+ng] GeoType */
+    const int32_t* shape_flags;         /* [ns+ng] ShapeFlags */
+    const int32_t* shape_group;         /* [ns+ng] collision group */
+    const int32_t* pair_a;              /* [np] shape index (0..ns-1 local, ns..ns+ng-1 global), pair_a < pair_b in Newton ids */
+    const int32_t* pair_b;              /* [np] */
+    /* ordered incidence lists (CSR) used for deterministic, tid-ordered reductions */
+    const int32_t* body_joint_start;    /* [nb+1] */
+    const int32_t* body_joint_list;     /* joint*2 + (1 if body is the child else 0), ascending joint; parent entry first */
+    const int32_t* body_pair_start;     /* [nb+1] */
+    const int32_t* body_pair_list;      /* pair*2 + (1 if the body owns pair_b's shape else 0), ascending pair */
+    /* per-env parameters, float SoA */
+    const float* body_param;            /* [NT_BODY_PARAM_FLOATS][nb][ES] */
+    const float* gravity;               /* [3][ES] */
+    const float* joint_param;           /* [NT_JOINT_PARAM_FLOATS][nj][ES] */
+    const float* dof_param;             /* [NT_DOF_PARAM_FLOATS][nd][ES] */
+    const float* shape_param;           /* [NT_SHAPE_PARAM_FLOATS][ns][ES] */
+    const float* gshape_param;          /* [ng][NT_SHAPE_PARAM_FLOATS] (AoS, tiny, env-uniform) */
+} nt_model;
+
+/* State (newton/_src/sim/state.py:113-171) */
+typedef struct {
+    float* body_q;   /* [7][nb][ES] */
+    float* body_qd;  /* [6][nb][ES] */
+    float* body_f;   /* [6][nb][ES] */
+    float* joint_q;  /* [nc][ES]   (may be NULL for maximal-coordinate solvers) */
+    float* joint_qd; /* [nd][ES] */
+} nt_state;
+
+/* Control (newton/_src/sim/control.py:31-68) */
+typedef struct {
+    const float* joint_f;         /* [nd][ES] */
+    const float* joint_target_q;  /* [ntq][ES] */
+    const float* joint_target_qd; /* [nd][ES] */
+} nt_control;
+
+/* Contacts (newton/_src/sim/contacts.py:227-277), fixed slots: slot = pair * cpp + k.
+ * Unused slots carry shape0 = shape1 = -1, which every reference consumer skips
+ * (xpbd/kernels.py:2201, semi_implicit/kernels_contact.py:425). */
+typedef struct {
+    int32_t* shape0;      /* [np*cpp][ES] Newton global shape id or -1 */
+    int32_t* shape1;      /* [np*cpp][ES] */
+    float* data;          /* [NT_CONTACT_FLOATS][np*cpp][ES] */
+    int32_t* env_count;   /* [ES] contacts emitted per env (== per-env slice of rigid_contact_count) */
+    uint8_t* pair_hit;    /* [np][ES] 1 if the pair passed the broad phase (candidate pair set, per env) */
+} nt_contacts;
+
+typedef struct {
+    int32_t iterations;
+    float joint_linear_relaxation, joint_angular_relaxation;
+    float joint_linear_compliance, joint_angular_compliance;
+    float rigid_contact_relaxation;
+    int32_t rigid_contact_con_weighting;
+    float angular_damping;
+    int32_t enable_restitution; /* must be 0 (NT_ERR_UNSUPPORTED otherwise) */
+} nt_xpbd_params;
+
+typedef struct {
+    float angular_damping;
+    float friction_smoothing;
+    float joint_attach_ke, joint_attach_kd;
+} nt_semi_implicit_params;
+
+typedef struct {
+    int32_t broad_phase;  /* 0 explicit pairs (default), 1 nxn, 2 sap -- all emit the same per-env pair set */
+    int32_t envs_per_block; /* 0 = auto; otherwise 16, 32 or 64 */
+} nt_collide_params;
+
+/* -------- hot path -------- */
+nt_status nt_clear_forces(const nt_model* m, nt_state* s, void* stream);
+nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const nt_collide_params* p, void* stream);
+nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_in, nt_state* s_out,
+                       const nt_control* ctrl, const nt_contacts* c /*nullable*/, float dt, int32_t envs_per_block,
+                       void* stream);
+nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params* p, nt_state* s_in, nt_state* s_out,
+                                const nt_control* ctrl, const nt_contacts* c /*nullable*/, float dt,
+                                int32_t envs_per_block, void* stream);
+/* substeps x {clear_forces; collide; xpbd step; swap}: the result is in s0 when substeps is even, s1 when odd,
+ * exactly like the reference loop's pointer swap. */
+nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, nt_state* s0,
+                          nt_state* s1, const nt_control* ctrl, nt_contacts* c, float dt, int32_t substeps, void* stream);
+
+/* -------- boundary helpers -------- */
+nt_status nt_eval_fk(const nt_model* m, const float* joint_q /*[nc][ES]*/, const float* joint_qd /*[nd][ES]*/,
+                     nt_state* out, void* stream);
+/* AoS [E*nslot][ncomp] (Newton flat array) <-> SoA [ncomp][nslot][ES] */
+nt_status nt_pack_aos(const float* aos, float* soa, int32_t ncomp, int32_t nslot, int32_t env_count, int32_t env_stride,
+                      void* stream);
+nt_status nt_unpack_aos(const float* soa, float* aos, int32_t ncomp, int32_t nslot, int32_t env_count, int32_t env_stride,
+                        void* stream);
+/* Compact the fixed-slot contacts into Newton's flat append order (env, pair, sub-contact).
+ * out_* are AoS arrays with capacity `cap`; out_count[0] receives the total (it keeps counting past cap,
+ * like the reference's atomic counter, collide.py:176-177). Uses `scan_tmp` ([ES+1] int32) as scratch. */
+nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t cap, int32_t* out_count, int32_t* out_shape0,
+                             int32_t* out_shape1, float* out_point0, float* out_point1, float* out_offset0,
+                             float* out_offset1, float* out_normal, float* out_margin0, float* out_margin1,
+                             int32_t* scan_tmp, void* stream);
+
+/* -------- introspection -------- */
+const char* nt_error_string(nt_status s);
+const char* nt_build_info(void);                 /* "gfx950 ..." */
+int32_t nt_lds_bytes_per_env(const nt_model* m); /* LDS footprint of one env in the step kernels */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+"""ctypes binding of libnewton_hip.so (the C ABI declared in include/newton_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or cannot be loaded, every
+solver / collision entry point raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnewton_hip.so")
+
+NT_CONTACT_FLOATS = 17
+NT_BODY_PARAM_FLOATS = 23
+NT_JOINT_PARAM_FLOATS = 14
+NT_DOF_PARAM_FLOATS = 10
+NT_SHAPE_PARAM_FLOATS = 19
+
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class nt_model(C.Structure):
+    _fields_ = [
+        ("env_count", C.c_int32), ("env_stride", C.c_int32), ("nb", C.c_int32), ("nj", C.c_int32), ("nd", C.c_int32),
+        ("nc", C.c_int32), ("ntq", C.c_int32), ("ns", C.c_int32), ("ng", C.c_int32), ("np", C.c_int32),
+        ("cpp", C.c_int32),
+        ("body_flags", C.c_void_p), ("joint_type", C.c_void_p), ("joint_enabled", C.c_void_p),
+        ("joint_parent", C.c_void_p), ("joint_child", C.c_void_p), ("joint_q_start", C.c_void_p),
+        ("joint_qd_start", C.c_void_p), ("joint_tq_start", C.c_void_p), ("joint_lin_count", C.c_void_p),
+        ("joint_ang_count", C.c_void_p), ("shape_body", C.c_void_p), ("shape_type", C.c_void_p),
+        ("shape_flags", C.c_void_p), ("shape_group", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p),
+        ("body_joint_start", C.c_void_p), ("body_joint_list", C.c_void_p), ("body_pair_start", C.c_void_p),
+        ("body_pair_list", C.c_void_p),
+        ("body_param", C.c_void_p), ("gravity", C.c_void_p), ("joint_param", C.c_void_p), ("dof_param", C.c_void_p),
+        ("shape_param", C.c_void_p), ("gshape_param", C.c_void_p),
+    ]
+
+
+class nt_state(C.Structure):
+    _fields_ = [("body_q", C.c_void_p), ("body_qd", C.c_void_p), ("body_f", C.c_void_p), ("joint_q", C.c_void_p),
+                ("joint_qd", C.c_void_p)]
+
+
+class nt_control(C.Structure):
+    _fields_ = [("joint_f", C.c_void_p), ("joint_target_q", C.c_void_p), ("joint_target_qd", C.c_void_p)]
+
+
+class nt_contacts(C.Structure):
+    _fields_ = [("shape0", C.c_void_p), ("shape1", C.c_void_p), ("data", C.c_void_p), ("env_count", C.c_void_p),
+                ("pair_hit", C.c_void_p)]
+
+
+class nt_xpbd_params(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("joint_linear_relaxation", C.c_float),
+                ("joint_angular_relaxation", C.c_float), ("joint_linear_compliance", C.c_float),
+                ("joint_angular_compliance", C.c_float), ("rigid_contact_relaxation", C.c_float),
+                ("rigid_contact_con_weighting", C.c_int32), ("angular_damping", C.c_float),
+                ("enable_restitution", C.c_int32)]
+
+
+class nt_semi_implicit_params(C.Structure):
+    _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float), ("joint_attach_ke", C.c_float),
+                ("joint_attach_kd", C.c_float)]
+
+
+class nt_collide_params(C.Structure):
+    _fields_ = [("broad_phase", C.c_int32), ("envs_per_block", C.c_int32)]
+
+
+# every symbol include/newton_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "nt_clear_forces": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), _P]),
+    "nt_collide": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
+                                C.POINTER(nt_collide_params), _P]),
+    "nt_xpbd_step": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_xpbd_params), C.POINTER(nt_state), C.POINTER(nt_state),
+                                  C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),
+    "nt_semi_implicit_step": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_semi_implicit_params), C.POINTER(nt_state),
+                                           C.POINTER(nt_state), C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float,
+                                           C.c_int32, _P]),
+    "nt_xpbd_rollout": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_xpbd_params), C.POINTER(nt_collide_params),
+                                     C.POINTER(nt_state), C.POINTER(nt_state), C.POINTER(nt_control),
+                                     C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),
+    "nt_eval_fk": (C.c_int32, [C.POINTER(nt_model), _P, _P, C.POINTER(nt_state), _P]),
+    "nt_pack_aos": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "nt_unpack_aos": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "nt_contacts_export": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_contacts), C.c_int32, _P, _P, _P, _P, _P, _P, _P,
+                                        _P, _P, _P, _P, _P]),
+    "nt_error_string": (C.c_char_p, [C.c_int32]),
+    "nt_build_info": (C.c_char_p, []),
+    "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
+}
+
+_lib = None
+
+
+class NewtonHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnewton_hip.so (once). Raises NewtonHipError loudly if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NewtonHipError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc). There is no CPU fallback for the product path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise NewtonHipError(f"could not load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().nt_error_string(status).decode()
+        raise NewtonHipError(f"{what} failed: {msg} (status {status})")

@@ -1,0 +1,137 @@
+"""eval_fk: joint coordinates -> maximal coordinates (newton/_src/sim/articulation.py:236-573).
+
+Host implementation (numpy, vectorised over environments) used to seed ``body_q`` / ``body_qd`` before stepping;
+it is model-preparation code, not part of the per-substep hot path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .enums import JointType
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bx + bw * ax + ay * bz - by * az, aw * by + bw * ay + az * bx - bz * ax,
+                     aw * bz + bw * az + ax * by - bx * ay, aw * bw - ax * bx - ay * by - az * bz], axis=-1)
+
+
+def _qrot(q, v):
+    qv, w = q[..., :3], q[..., 3:4]
+    return v * (2.0 * w * w - 1.0) + np.cross(qv, v) * w * 2.0 + qv * np.sum(qv * v, axis=-1, keepdims=True) * 2.0
+
+
+def _qinv(q):
+    return q * np.array([-1.0, -1.0, -1.0, 1.0])
+
+
+def _xmul(a, b):
+    return np.concatenate([_qrot(a[..., 3:], b[..., :3]) + a[..., :3], _qmul(a[..., 3:], b[..., 3:])], axis=-1)
+
+
+def _xinv(t):
+    qi = _qinv(t[..., 3:])
+    return np.concatenate([-_qrot(qi, t[..., :3]), qi], axis=-1)
+
+
+def eval_fk_numpy(model, joint_q, joint_qd):
+    """Returns (body_q [B,7], body_qd [B,6]) as float32 arrays."""
+    t = model.env
+    E, nb, nj = t.env_count, t.nb, t.nj
+    jq = np.asarray(joint_q, dtype=np.float64).reshape(E, t.nc)
+    jqd = np.asarray(joint_qd, dtype=np.float64).reshape(E, t.nd)
+    body_q = np.asarray(model.body_q, dtype=np.float64).reshape(E, nb, 7).copy()
+    body_qd = np.asarray(model.body_qd, dtype=np.float64).reshape(E, nb, 6).copy()
+    com = np.asarray(model.body_com, dtype=np.float64).reshape(E, nb, 3)
+    X_p = np.asarray(model.joint_X_p, dtype=np.float64).reshape(E, nj, 7)
+    X_c = np.asarray(model.joint_X_c, dtype=np.float64).reshape(E, nj, 7)
+    axis_all = np.asarray(model.joint_axis, dtype=np.float64).reshape(E, t.nd, 3)
+    art = np.asarray(model.joint_articulation).reshape(E, nj)[0] if nj else []
+    ident = np.tile(np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]), (E, 1))
+    for j in range(nj):
+        if art[j] == -1:
+            continue
+        jt = int(t.joint_type[j])
+        parent, child = int(t.joint_parent[j]), int(t.joint_child[j])
+        qs, qds = int(t.joint_q_start[j]), int(t.joint_qd_start[j])
+        lin, ang = int(t.joint_lin_count[j]), int(t.joint_ang_count[j])
+        X_j = ident.copy()
+        v_lin = np.zeros((E, 3))
+        v_ang = np.zeros((E, 3))
+        if jt == JointType.PRISMATIC:
+            ax = axis_all[:, qds]
+            X_j[:, :3] = ax * jq[:, qs:qs + 1]
+            v_lin = ax * jqd[:, qds:qds + 1]
+        elif jt == JointType.REVOLUTE:
+            ax = axis_all[:, qds]
+            h = 0.5 * jq[:, qs:qs + 1]
+            X_j[:, 3:6] = ax * np.sin(h)
+            X_j[:, 6:7] = np.cos(h)
+            v_ang = ax * jqd[:, qds:qds + 1]
+        elif jt == JointType.BALL:
+            X_j[:, 3:7] = jq[:, qs:qs + 4]
+            v_ang = jqd[:, qds:qds + 3]
+        elif jt in (JointType.FREE, JointType.DISTANCE):
+            X_j = jq[:, qs:qs + 7].copy()
+            v_lin = jqd[:, qds:qds + 3]
+            v_ang = jqd[:, qds + 3:qds + 6]
+        elif jt == JointType.D6:
+            pos = np.zeros((E, 3))
+            for k in range(lin):
+                pos += axis_all[:, qds + k] * jq[:, qs + k:qs + k + 1]
+                v_lin = v_lin + axis_all[:, qds + k] * jqd[:, qds + k:qds + k + 1]
+            X_j[:, :3] = pos
+            if ang == 1:
+                ax = axis_all[:, qds + lin]
+                h = 0.5 * jq[:, qs + lin:qs + lin + 1]
+                X_j[:, 3:6] = ax * np.sin(h)
+                X_j[:, 6:7] = np.cos(h)
+                v_ang = ax * jqd[:, qds + lin:qds + lin + 1]
+            elif ang > 1:
+                raise NotImplementedError("eval_fk: D6 joints with >1 angular axis are not supported yet")
+        elif jt == JointType.FIXED:
+            pass
+        else:
+            continue
+        X_wpj = X_p[:, j]
+        if parent >= 0:
+            X_wp = body_q[:, parent]
+            X_wpj = _xmul(X_wp, X_wpj)
+        X_wcj = _xmul(X_wpj, X_j)
+        X_wc = _xmul(X_wcj, _xinv(X_c[:, j]))
+        x_child = X_wc[:, :3]
+        v_parent = np.zeros((E, 3))
+        w_parent = np.zeros((E, 3))
+        if parent >= 0:
+            qd_p = body_qd[:, parent]
+            w_parent = qd_p[:, 3:]
+            r = x_child - (X_wp[:, :3] + _qrot(X_wp[:, 3:], com[:, parent]))
+            v_parent = np.cross(w_parent, r) + qd_p[:, :3]
+        lin_w = _qrot(X_wpj[:, 3:], v_lin)
+        ang_w = _qrot(X_wpj[:, 3:], v_ang)
+        com_w = _qrot(X_wc[:, 3:], com[:, child])
+        if jt in (JointType.FREE, JointType.DISTANCE):
+            lin_origin = lin_w - np.cross(ang_w, com_w)
+        else:
+            lin_origin = lin_w + np.cross(ang_w, x_child - X_wcj[:, :3])
+        v_o = v_parent + lin_origin
+        w_o = w_parent + ang_w
+        body_q[:, child] = X_wc
+        body_qd[:, child, :3] = np.cross(w_o, com_w) + v_o
+        body_qd[:, child, 3:] = w_o
+    return body_q.reshape(-1, 7).astype(np.float32), body_qd.reshape(-1, 6).astype(np.float32)
+
+
+def eval_fk(model, joint_q, joint_qd, state, mask=None, indices=None):
+    """newton.eval_fk(model, joint_q, joint_qd, state): writes state.body_q / state.body_qd.
+    ``state`` may be a State or the Model itself (as in example_basic_urdf.py:88)."""
+    if mask is not None or indices is not None:
+        raise NotImplementedError("eval_fk(mask=..., indices=...) is not supported")
+
+    def host(x):
+        return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+    bq, bqd = eval_fk_numpy(model, host(joint_q), host(joint_qd))
+    state.body_q = bq
+    state.body_qd = bqd

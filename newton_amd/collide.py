@@ -1,0 +1,182 @@
+"""Contacts + CollisionPipeline (newton/_src/sim/contacts.py:118-420, newton/_src/sim/collide.py:1065-2207).
+
+``CollisionPipeline.collide(state, contacts)`` runs the gfx950 collide kernel (AABBs -> broad phase ->
+narrow phase -> contact writer) through the C ABI ``nt_collide``.  Contacts live in fixed per-env slots
+(slot = pair * cpp + k, env-major SoA); the Newton-shaped flat arrays (``rigid_contact_shape0`` ...,
+in the reference's append order) are produced on read by ``nt_contacts_export``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .enums import GeoType, ShapeFlags
+
+_RIGID_CONTACT_MIN_CAPACITY = 1000  # collide.py: _estimate_rigid_contact_max floor
+
+
+def _torch():
+    import torch  # noqa: PLC0415
+
+    return torch
+
+
+class Contacts:
+    """Rigid contact buffers (contacts.py:227-277).  ``rigid_contact_max`` = env_count * pairs_per_env * cpp."""
+
+    def __init__(self, model, rigid_contact_max: int | None = None):
+        torch = _torch()
+        self.model = model
+        dm = model.device_model()
+        t = model.env
+        self._slots = t.np * t.cpp
+        self.rigid_contact_max = t.env_count * self._slots if rigid_contact_max is None else int(rigid_contact_max)
+        self.soft_contact_max = 0
+        ns = max(self._slots, 1)
+        dev = dm.device
+        self._shape0 = torch.full((ns, t.env_stride), -1, dtype=torch.int32, device=dev)
+        self._shape1 = torch.full((ns, t.env_stride), -1, dtype=torch.int32, device=dev)
+        self._data = torch.zeros((_lib.NT_CONTACT_FLOATS, ns, t.env_stride), dtype=torch.float32, device=dev)
+        self._env_count = torch.zeros(t.env_stride, dtype=torch.int32, device=dev)
+        self._pair_hit = torch.zeros((max(t.np, 1), t.env_stride), dtype=torch.uint8, device=dev)
+        self._scan = torch.zeros(t.env_stride + 1, dtype=torch.int32, device=dev)
+        self._export = None
+        self._generation = 0
+        self._export_generation = -1
+        self.force = None
+
+    def _desc(self) -> _lib.nt_contacts:
+        d = _lib.nt_contacts()
+        d.shape0 = self._shape0.data_ptr()
+        d.shape1 = self._shape1.data_ptr()
+        d.data = self._data.data_ptr()
+        d.env_count = self._env_count.data_ptr()
+        d.pair_hit = self._pair_hit.data_ptr()
+        return d
+
+    # -- Newton-shaped flat views (append order = env, pair, sub-contact; collide.py:166-254) ---------------
+    def _exported(self):
+        if self._export is not None and self._export_generation == self._generation:
+            return self._export
+        torch = _torch()
+        dm = self.model.device_model()
+        cap = max(self.rigid_contact_max, 1)
+        dev = dm.device
+        e = {
+            "count": torch.zeros(1, dtype=torch.int32, device=dev),
+            "shape0": torch.full((cap,), -1, dtype=torch.int32, device=dev),
+            "shape1": torch.full((cap,), -1, dtype=torch.int32, device=dev),
+            "point0": torch.zeros((cap, 3), dtype=torch.float32, device=dev),
+            "point1": torch.zeros((cap, 3), dtype=torch.float32, device=dev),
+            "offset0": torch.zeros((cap, 3), dtype=torch.float32, device=dev),
+            "offset1": torch.zeros((cap, 3), dtype=torch.float32, device=dev),
+            "normal": torch.zeros((cap, 3), dtype=torch.float32, device=dev),
+            "margin0": torch.zeros((cap,), dtype=torch.float32, device=dev),
+            "margin1": torch.zeros((cap,), dtype=torch.float32, device=dev),
+        }
+        d = self._desc()
+        _lib.check(dm.lib.nt_contacts_export(
+            C.byref(dm.desc), C.byref(d), self.rigid_contact_max, e["count"].data_ptr(), e["shape0"].data_ptr(),
+            e["shape1"].data_ptr(), e["point0"].data_ptr(), e["point1"].data_ptr(), e["offset0"].data_ptr(),
+            e["offset1"].data_ptr(), e["normal"].data_ptr(), e["margin0"].data_ptr(), e["margin1"].data_ptr(),
+            self._scan.data_ptr(), dm.stream()), "nt_contacts_export")
+        self._export, self._export_generation = e, self._generation
+        return e
+
+    rigid_contact_count = property(lambda self: self._exported()["count"])
+    rigid_contact_shape0 = property(lambda self: self._exported()["shape0"])
+    rigid_contact_shape1 = property(lambda self: self._exported()["shape1"])
+    rigid_contact_point0 = property(lambda self: self._exported()["point0"])
+    rigid_contact_point1 = property(lambda self: self._exported()["point1"])
+    rigid_contact_offset0 = property(lambda self: self._exported()["offset0"])
+    rigid_contact_offset1 = property(lambda self: self._exported()["offset1"])
+    rigid_contact_normal = property(lambda self: self._exported()["normal"])
+    rigid_contact_margin0 = property(lambda self: self._exported()["margin0"])
+    rigid_contact_margin1 = property(lambda self: self._exported()["margin1"])
+
+    @property
+    def rigid_contact_count_per_env(self):
+        """[E] int32: contacts emitted per environment (bit-exact parity target)."""
+        return self._env_count[: self.model.env.env_count]
+
+    @property
+    def candidate_pair_mask(self):
+        """[E, pairs_per_env] bool: broad-phase candidate pair set per environment."""
+        t = self.model.env
+        return self._pair_hit[: t.np, : t.env_count].T.bool()
+
+    def clear(self):
+        self._shape0.fill_(-1)
+        self._shape1.fill_(-1)
+        self._env_count.zero_()
+        self._generation += 1
+
+
+def estimate_rigid_contact_max(model) -> int:
+    """Capacity heuristic of the reference (collide.py:553-652) for models with precomputed pairs:
+    max(1000, min(neighbor-budget heuristic, pairs * contacts_per_pair))."""
+    types = np.asarray(model.shape_type)
+    colliding = (np.asarray(model.shape_flags) & int(ShapeFlags.COLLIDE_SHAPES)) != 0
+    plane = colliding & (types == int(GeoType.PLANE))
+    non_plane = colliding & ~plane
+    n_non_planes = int(non_plane.sum())
+    cpp_prim, neighbors = 5, 20
+    non_plane_contacts = (n_non_planes * neighbors * cpp_prim) // 2
+    world = np.asarray(model.shape_world)
+    n_worlds = max(model.world_count, 1)
+    glob = world == -1
+    per_world_planes = np.bincount(world[~glob & plane], minlength=n_worlds)[:n_worlds] + int((glob & plane).sum())
+    per_world_non = np.bincount(world[~glob & non_plane], minlength=n_worlds)[:n_worlds] + int((glob & non_plane).sum())
+    plane_pairs = int(np.sum(per_world_planes * per_world_non))
+    if n_worlds > 1:
+        plane_pairs -= (n_worlds - 1) * int((glob & plane).sum()) * int((glob & non_plane).sum())
+    total = non_plane_contacts + plane_pairs * (cpp_prim if n_non_planes else 0)
+    if model.shape_contact_pair_count > 0:
+        total = min(total, int(model.shape_contact_pair_count) * cpp_prim)
+    return max(_RIGID_CONTACT_MIN_CAPACITY, total)
+
+
+class CollisionPipeline:
+    """newton.CollisionPipeline(model, *, broad_phase=..., rigid_contact_max=None, ...)  (collide.py:1104-1133).
+
+    All three broad-phase modes emit the same per-env candidate set (the reference's tests assert exactly that,
+    newton/tests/test_broad_phase.py:91-145); with one workgroup per group of environments the per-env pair list
+    is small, so every mode evaluates the precomputed per-env pair template against the fresh AABBs.
+    """
+
+    _BROAD_PHASES = {"explicit": 0, "nxn": 1, "sap": 2, None: 0}
+
+    def __init__(self, model, *, broad_phase=None, rigid_contact_max=None, reduce_contacts=True, deterministic=False,
+                 sdf_hydroelastic_config=None, envs_per_block: int = 0, **unsupported):
+        if unsupported:
+            raise NotImplementedError(f"CollisionPipeline options not supported: {sorted(unsupported)}")
+        if sdf_hydroelastic_config is not None:
+            raise NotImplementedError("hydroelastic contacts are not implemented yet (SURVEY.md section 8, row a25)")
+        if broad_phase not in self._BROAD_PHASES:
+            raise ValueError(f"broad_phase must be one of 'nxn', 'sap', 'explicit', got {broad_phase!r}")
+        self.model = model
+        self.dm = model.device_model()  # raises loudly without GPU / extension
+        self.broad_phase = broad_phase or "explicit"
+        self.params = _lib.nt_collide_params(self._BROAD_PHASES[broad_phase], int(envs_per_block))
+        t = model.env
+        self._rigid_contact_max = t.env_count * t.np * t.cpp
+        model.rigid_contact_max = self._rigid_contact_max
+        self.deterministic = True  # fixed slots + ordered reductions: deterministic by construction
+
+    @property
+    def rigid_contact_max(self):
+        return self._rigid_contact_max
+
+    def contacts(self) -> Contacts:
+        return Contacts(self.model)
+
+    def collide(self, state, contacts: Contacts, *, soft_contact_margin=None, dt=None):
+        if contacts.model is not self.model:
+            raise ValueError("contacts were created for a different model")
+        d_state = state._desc()
+        d_ct = contacts._desc()
+        _lib.check(self.dm.lib.nt_collide(C.byref(self.dm.desc), C.byref(d_state), C.byref(d_ct), C.byref(self.params),
+                                          self.dm.stream()), "nt_collide")
+        contacts._generation += 1

@@ -1,0 +1,143 @@
+// nt_math.hpp -- fp32 vector / quaternion / transform arithmetic for the gfx950 kernels.
+// Semantics follow the warp-lang builtins Newton's kernels call (quat xyzw, transform = (p, q),
+// zero-safe normalize) -- see DESIGN.md "arithmetic conventions".  Compiled with -ffp-contract=off:
+// every +,-,*,/ and sqrt is a single correctly-rounded IEEE operation, in source order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nt {
+
+#define NT_DI __device__ __forceinline__
+
+struct vec3 {
+    float x, y, z;
+    NT_DI vec3() : x(0.f), y(0.f), z(0.f) {}
+    NT_DI vec3(float a, float b, float c) : x(a), y(b), z(c) {}
+    NT_DI explicit vec3(float s) : x(s), y(s), z(s) {}
+};
+NT_DI float vget(const vec3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+NT_DI void vset(vec3& v, int i, float s) {
+    if (i == 0) v.x = s;
+    else if (i == 1) v.y = s;
+    else v.z = s;
+}
+NT_DI vec3 operator+(vec3 a, vec3 b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+NT_DI vec3 operator-(vec3 a, vec3 b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+NT_DI vec3 operator-(vec3 a) { return vec3(-a.x, -a.y, -a.z); }
+NT_DI vec3 operator*(vec3 a, float s) { return vec3(a.x * s, a.y * s, a.z * s); }
+NT_DI vec3 operator*(float s, vec3 a) { return vec3(a.x * s, a.y * s, a.z * s); }
+NT_DI vec3 operator/(vec3 a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
+NT_DI vec3& operator+=(vec3& a, vec3 b) { a = a + b; return a; }
+NT_DI vec3& operator-=(vec3& a, vec3 b) { a = a - b; return a; }
+NT_DI vec3& operator*=(vec3& a, float s) { a = a * s; return a; }
+NT_DI float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+NT_DI vec3 cross(vec3 a, vec3 b) { return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+NT_DI float length_sq(vec3 a) { return dot(a, a); }
+NT_DI float length(vec3 a) { return __fsqrt_rn(dot(a, a)); }
+NT_DI vec3 normalize(vec3 a) {
+    float l = length(a);
+    if (l > 0.0f) return a / l;
+    return vec3();
+}
+NT_DI vec3 cw_mul(vec3 a, vec3 b) { return vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+NT_DI float fminw(float a, float b) { return a < b ? a : b; }
+NT_DI float fmaxw(float a, float b) { return a > b ? a : b; }
+NT_DI vec3 vmin(vec3 a, vec3 b) { return vec3(fminw(a.x, b.x), fminw(a.y, b.y), fminw(a.z, b.z)); }
+NT_DI vec3 vmax(vec3 a, vec3 b) { return vec3(fmaxw(a.x, b.x), fmaxw(a.y, b.y), fmaxw(a.z, b.z)); }
+NT_DI vec3 vabs(vec3 a) { return vec3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+NT_DI float clampf(float x, float lo, float hi) { return fminw(fmaxw(x, lo), hi); }
+NT_DI float signf(float x) { return x < 0.0f ? -1.0f : 1.0f; }
+NT_DI float nonzero(float x) { return x != 0.0f ? 1.0f : 0.0f; }
+
+struct quat {
+    float x, y, z, w;
+    NT_DI quat() : x(0.f), y(0.f), z(0.f), w(0.f) {}
+    NT_DI quat(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    NT_DI quat(vec3 v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+};
+NT_DI quat quat_identity() { return quat(0.f, 0.f, 0.f, 1.f); }
+NT_DI quat operator+(quat a, quat b) { return quat(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+NT_DI quat operator*(quat a, float s) { return quat(a.x * s, a.y * s, a.z * s, a.w * s); }
+NT_DI quat operator*(float s, quat a) { return quat(a.x * s, a.y * s, a.z * s, a.w * s); }
+NT_DI quat operator*(quat a, quat b) {
+    return quat(a.w * b.x + b.w * a.x + a.y * b.z - b.y * a.z,
+                a.w * b.y + b.w * a.y + a.z * b.x - b.z * a.x,
+                a.w * b.z + b.w * a.z + a.x * b.y - b.x * a.y,
+                a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
+}
+NT_DI float dot(quat a, quat b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+NT_DI float length(quat a) { return __fsqrt_rn(dot(a, a)); }
+NT_DI quat normalize(quat q) {
+    float l = length(q);
+    if (l > 0.0f) {
+        float inv = 1.0f / l;
+        return q * inv;
+    }
+    return quat(0.f, 0.f, 0.f, 1.f);
+}
+NT_DI quat quat_inverse(quat q) { return quat(-q.x, -q.y, -q.z, q.w); }
+NT_DI vec3 quat_rotate(quat q, vec3 v) {
+    vec3 qv(q.x, q.y, q.z);
+    return v * (2.0f * q.w * q.w - 1.0f) + cross(qv, v) * q.w * 2.0f + qv * dot(qv, v) * 2.0f;
+}
+NT_DI vec3 quat_rotate_inv(quat q, vec3 v) {
+    vec3 qv(q.x, q.y, q.z);
+    return v * (2.0f * q.w * q.w - 1.0f) - cross(qv, v) * q.w * 2.0f + qv * dot(qv, v) * 2.0f;
+}
+NT_DI quat quat_from_axis_angle(vec3 axis, float angle) {
+    float half = angle * 0.5f;
+    float w = cosf(half);
+    float s = sinf(half);
+    vec3 v = axis * s;
+    return quat(v.x, v.y, v.z, w);
+}
+
+struct mat33 {
+    float m00, m01, m02, m10, m11, m12, m20, m21, m22;
+    NT_DI mat33() : m00(0.f), m01(0.f), m02(0.f), m10(0.f), m11(0.f), m12(0.f), m20(0.f), m21(0.f), m22(0.f) {}
+    NT_DI mat33(float a00, float a01, float a02, float a10, float a11, float a12, float a20, float a21, float a22)
+        : m00(a00), m01(a01), m02(a02), m10(a10), m11(a11), m12(a12), m20(a20), m21(a21), m22(a22) {}
+};
+NT_DI vec3 operator*(const mat33& A, vec3 v) {
+    return vec3(A.m00 * v.x + A.m01 * v.y + A.m02 * v.z, A.m10 * v.x + A.m11 * v.y + A.m12 * v.z,
+                A.m20 * v.x + A.m21 * v.y + A.m22 * v.z);
+}
+NT_DI mat33 operator*(float s, const mat33& A) {
+    return mat33(A.m00 * s, A.m01 * s, A.m02 * s, A.m10 * s, A.m11 * s, A.m12 * s, A.m20 * s, A.m21 * s, A.m22 * s);
+}
+NT_DI mat33 transpose(const mat33& A) { return mat33(A.m00, A.m10, A.m20, A.m01, A.m11, A.m21, A.m02, A.m12, A.m22); }
+NT_DI mat33 matrix_from_cols(vec3 c0, vec3 c1, vec3 c2) {
+    return mat33(c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z);
+}
+NT_DI vec3 mat_col(const mat33& A, int j) {
+    return j == 0 ? vec3(A.m00, A.m10, A.m20) : (j == 1 ? vec3(A.m01, A.m11, A.m21) : vec3(A.m02, A.m12, A.m22));
+}
+NT_DI mat33 quat_to_matrix(quat q) {
+    vec3 c0 = quat_rotate(q, vec3(1.f, 0.f, 0.f));
+    vec3 c1 = quat_rotate(q, vec3(0.f, 1.f, 0.f));
+    vec3 c2 = quat_rotate(q, vec3(0.f, 0.f, 1.f));
+    return matrix_from_cols(c0, c1, c2);
+}
+
+struct xform {
+    vec3 p;
+    quat q;
+    NT_DI xform() : p(), q(0.f, 0.f, 0.f, 1.f) {}
+    NT_DI xform(vec3 p_, quat q_) : p(p_), q(q_) {}
+};
+NT_DI xform operator*(const xform& a, const xform& b) { return xform(quat_rotate(a.q, b.p) + a.p, a.q * b.q); }
+NT_DI xform xform_inverse(const xform& t) {
+    quat qi = quat_inverse(t.q);
+    return xform(-quat_rotate(qi, t.p), qi);
+}
+NT_DI vec3 xform_point(const xform& t, vec3 x) { return t.p + quat_rotate(t.q, x); }
+NT_DI vec3 xform_vector(const xform& t, vec3 x) { return quat_rotate(t.q, x); }
+
+struct spatial {
+    vec3 top, bottom;  // (linear, angular)
+    NT_DI spatial() {}
+    NT_DI spatial(vec3 a, vec3 b) : top(a), bottom(b) {}
+};
+NT_DI vec3 velocity_at_point(const spatial& qd, vec3 r) { return cross(qd.bottom, r) + qd.top; }
+
+}  // namespace nt

@@ -1,0 +1,328 @@
+"""Model / State / Control: the reference's flat-array data model (the drop-in boundary).
+
+Attribute names, shapes and dtypes follow newton/_src/sim/model.py:808-1364, state.py:113-171 and
+control.py:31-68.  On the host every array is a numpy AoS array exactly as Newton lays it out
+(``body_q[B,7]``, ``body_qd[B,6]`` ...).  On an MI355X the *resident* representation is env-major SoA
+(``[component][slot][env]``, include/newton_hip.h) and the AoS arrays are materialised on demand.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .enums import GeoType, JointType, ShapeFlags
+
+
+def _is_gpu(device) -> bool:
+    return device is not None and str(device).startswith(("cuda", "hip"))
+
+
+def _torch():
+    import torch  # noqa: PLC0415
+
+    return torch
+
+
+class EnvTemplate:
+    """Env-uniform topology extracted from a replicated model (what ModelBuilder.replicate() produces)."""
+
+    def __init__(self, model: Model):
+        m = model
+        E = m.world_count if m.world_count > 0 else 1
+        self.env_count = E
+        self.env_stride = ((E + 63) // 64) * 64
+
+        def per_env(world_arr, what):
+            world_arr = np.asarray(world_arr)
+            if m.world_count == 0:
+                return np.arange(len(world_arr)), np.zeros(0, dtype=np.int64)
+            local = np.flatnonzero(world_arr >= 0)
+            glob = np.flatnonzero(world_arr < 0)
+            if len(local) % E != 0:
+                raise NotImplementedError(f"heterogeneous worlds: {what} count is not a multiple of world_count")
+            n = len(local) // E
+            expect = np.repeat(np.arange(E), n)
+            if not np.array_equal(world_arr[local], expect) or (len(local) and not np.array_equal(local, np.arange(len(local)))):
+                raise NotImplementedError(
+                    f"{what}s must be ordered world-major with global (world -1) entries at the tail")
+            return local, glob
+
+        body_local, body_glob = per_env(m.body_world, "body")
+        if len(body_glob):
+            raise NotImplementedError("bodies in the global world (-1) are not supported together with worlds")
+        joint_local, joint_glob = per_env(m.joint_world, "joint")
+        if len(joint_glob):
+            raise NotImplementedError("joints in the global world (-1) are not supported together with worlds")
+        if m.world_count == 0:
+            sw = np.where(np.asarray(m.shape_body) >= 0, 0, -1)  # body-attached shapes are env-local
+            shape_world = sw
+            order = np.concatenate([np.flatnonzero(sw >= 0), np.flatnonzero(sw < 0)])
+            if not np.array_equal(order, np.arange(len(sw))):
+                raise NotImplementedError("static shapes must come after body-attached shapes")
+        else:
+            shape_world = np.asarray(m.shape_world)
+        shape_local = np.flatnonzero(shape_world >= 0)
+        shape_glob = np.flatnonzero(shape_world < 0)
+        if len(shape_local) % E or (len(shape_local) and not np.array_equal(shape_local, np.arange(len(shape_local)))):
+            raise NotImplementedError("shapes must be ordered world-major with global shapes at the tail")
+        if np.any(np.asarray(m.shape_body)[shape_glob] >= 0):
+            raise NotImplementedError("global shapes must be static (shape_body == -1)")
+
+        self.nb = len(body_local) // E
+        self.nj = len(joint_local) // E
+        self.ns = len(shape_local) // E
+        self.ng = len(shape_glob)
+        self.nd = m.joint_dof_count // E
+        self.nc = m.joint_coord_count // E
+        self.ntq = len(m.joint_target_q) // E
+        nb, nj, ns = self.nb, self.nj, self.ns
+
+        def uniform(a, n, what, offset=None):
+            a = np.asarray(a).reshape(E, n, *np.asarray(a).shape[1:]) if n else np.zeros((E, 0), dtype=np.int32)
+            if offset is not None:
+                a = a - offset
+            if E > 1 and not np.all(a == a[0:1]):
+                raise NotImplementedError(f"heterogeneous worlds: {what} differs between worlds")
+            return np.ascontiguousarray(a[0]).astype(np.int32)
+
+        env_ids = np.arange(E).reshape(E, 1)
+        self.body_flags = uniform(m.body_flags, nb, "body_flags")
+        self.joint_type = uniform(m.joint_type, nj, "joint_type")
+        self.joint_enabled = uniform(np.asarray(m.joint_enabled, dtype=np.int32), nj, "joint_enabled")
+        jp = np.asarray(m.joint_parent).reshape(E, nj) if nj else np.zeros((E, 0), dtype=np.int32)
+        jp = np.where(jp >= 0, jp - env_ids * nb, -1)
+        if E > 1 and not np.all(jp == jp[0:1]):
+            raise NotImplementedError("heterogeneous worlds: joint_parent differs between worlds")
+        self.joint_parent = jp[0].astype(np.int32)
+        self.joint_child = uniform(m.joint_child, nj, "joint_child", env_ids * nb)
+        self.joint_q_start = uniform(m.joint_q_start, nj, "joint_q_start", env_ids * self.nc)
+        self.joint_qd_start = uniform(m.joint_qd_start, nj, "joint_qd_start", env_ids * self.nd)
+        self.joint_tq_start = uniform(m.joint_target_q_start, nj, "joint_target_q_start", env_ids * self.ntq)
+        dd = np.asarray(m.joint_dof_dim).reshape(E, nj, 2) if nj else np.zeros((E, 0, 2), dtype=np.int32)
+        if E > 1 and not np.all(dd == dd[0:1]):
+            raise NotImplementedError("heterogeneous worlds: joint_dof_dim differs between worlds")
+        self.joint_lin_count = dd[0, :, 0].astype(np.int32)
+        self.joint_ang_count = dd[0, :, 1].astype(np.int32)
+
+        sb = np.asarray(m.shape_body)[:E * ns].reshape(E, ns) if ns else np.zeros((E, 0), dtype=np.int32)
+        sb = np.where(sb >= 0, sb - env_ids * nb, -1)
+        if E > 1 and not np.all(sb == sb[0:1]):
+            raise NotImplementedError("heterogeneous worlds: shape_body differs between worlds")
+        glob_minus1 = -np.ones(self.ng, dtype=np.int32)
+        self.shape_body = np.concatenate([sb[0].astype(np.int32), glob_minus1])
+
+        def shape_uniform(a, what):
+            a = np.asarray(a)
+            loc = a[:E * ns].reshape(E, ns) if ns else np.zeros((E, 0), dtype=a.dtype)
+            if E > 1 and not np.all(loc == loc[0:1]):
+                raise NotImplementedError(f"heterogeneous worlds: {what} differs between worlds")
+            return np.concatenate([loc[0], a[E * ns:]]).astype(np.int32)
+
+        self.shape_type = shape_uniform(m.shape_type, "shape_type")
+        self.shape_flags = shape_uniform(m.shape_flags, "shape_flags")
+        self.shape_group = shape_uniform(m.shape_collision_group, "shape_collision_group")
+
+        # candidate pairs, per env, in Newton's order
+        pairs = np.asarray(m.shape_contact_pairs, dtype=np.int64).reshape(-1, 2)
+        eg = E * ns
+        if len(pairs):
+            wa = np.where(pairs[:, 0] < eg, pairs[:, 0] // max(ns, 1), -1)
+            wb = np.where(pairs[:, 1] < eg, pairs[:, 1] // max(ns, 1), -1)
+            pw = np.maximum(wa, wb)
+            keep = pw >= 0  # global-vs-global pairs are static-static: no consumer, dropped
+            pairs, pw = pairs[keep], pw[keep]
+            if np.any((wa[keep] >= 0) & (wb[keep] >= 0) & (wa[keep] != wb[keep])):
+                raise ValueError("shape_contact_pairs contains a cross-world pair")
+            if len(pairs) % E:
+                raise NotImplementedError("heterogeneous worlds: candidate pair count differs between worlds")
+            npair = len(pairs) // E
+            if not np.array_equal(pw, np.repeat(np.arange(E), npair)):
+                raise NotImplementedError("shape_contact_pairs must be ordered world-major")
+
+            def to_local(col):
+                w = pw
+                return np.where(col < eg, col - w * ns, ns + (col - eg))
+
+            la = to_local(pairs[:, 0]).reshape(E, npair)
+            lb = to_local(pairs[:, 1]).reshape(E, npair)
+            if E > 1 and not (np.all(la == la[0:1]) and np.all(lb == lb[0:1])):
+                raise NotImplementedError("heterogeneous worlds: candidate pairs differ between worlds")
+            self.pair_a, self.pair_b = la[0].astype(np.int32), lb[0].astype(np.int32)
+        else:
+            self.pair_a = np.zeros(0, dtype=np.int32)
+            self.pair_b = np.zeros(0, dtype=np.int32)
+        self.np = len(self.pair_a)
+
+        # contact slots per pair: 4 if every pair has an analytic path (narrow_phase.py:642-655), else 5
+        self.cpp = 4
+        for a, b in zip(self.pair_a, self.pair_b):
+            ta, tb = sorted((int(self.shape_type[a]), int(self.shape_type[b])))
+            if ta >= GeoType.ELLIPSOID or tb == GeoType.CONE or (ta == GeoType.CAPSULE and tb > GeoType.CAPSULE):
+                self.cpp = 5
+
+        # ordered incidence lists
+        bj = [[] for _ in range(nb)]
+        for j in range(nj):
+            p, c = int(self.joint_parent[j]), int(self.joint_child[j])
+            if p >= 0:
+                bj[p].append(2 * j)
+            if c >= 0:
+                bj[c].append(2 * j + 1)
+        self.body_joint_start = np.cumsum([0] + [len(x) for x in bj]).astype(np.int32)
+        self.body_joint_list = np.asarray([c for x in bj for c in x], dtype=np.int32)
+        bp = [[] for _ in range(nb)]
+        for p in range(self.np):
+            ba, bb = int(self.shape_body[self.pair_a[p]]), int(self.shape_body[self.pair_b[p]])
+            if ba >= 0:
+                bp[ba].append(2 * p)
+            if bb >= 0:
+                bp[bb].append(2 * p + 1)
+        self.body_pair_start = np.cumsum([0] + [len(x) for x in bp]).astype(np.int32)
+        self.body_pair_list = np.asarray([c for x in bp for c in x], dtype=np.int32)
+
+
+class DeviceModel:
+    """Device-resident env-major SoA copy of a Model + the nt_model descriptor passed across the C ABI."""
+
+    def __init__(self, model: Model):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.NewtonHipError("no GPU visible: the HIP path needs an MI355X (there is no CPU fallback)")
+        self.device = torch.device(model.device)
+        t = model.env
+        self.t = t
+        E, ES = t.env_count, t.env_stride
+        self._keep = []
+
+        def dev_i32(a):
+            x = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+            if x.numel() == 0:
+                x = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._keep.append(x)
+            return x
+
+        def dev_f32(a):
+            x = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+            if x.numel() == 0:
+                x = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._keep.append(x)
+            return x
+
+        self.topology = {k: dev_i32(getattr(t, k)) for k in (
+            "body_flags", "joint_type", "joint_enabled", "joint_parent", "joint_child", "joint_q_start",
+            "joint_qd_start", "joint_tq_start", "joint_lin_count", "joint_ang_count", "shape_body", "shape_type",
+            "shape_flags", "shape_group", "pair_a", "pair_b", "body_joint_start", "body_joint_list", "body_pair_start",
+            "body_pair_list")}
+        self.params = {}
+        self.upload_params(model)
+        d = _lib.nt_model()
+        d.env_count, d.env_stride = E, ES
+        d.nb, d.nj, d.nd, d.nc, d.ntq, d.ns, d.ng, d.np, d.cpp = t.nb, t.nj, t.nd, t.nc, t.ntq, t.ns, t.ng, t.np, t.cpp
+        for k, v in self.topology.items():
+            setattr(d, k, v.data_ptr())
+        for k, v in self.params.items():
+            setattr(d, k, v.data_ptr())
+        self.desc = d
+
+    def upload_params(self, model: Model):
+        """(Re)build the per-env parameter SoA arrays from the model's AoS numpy arrays."""
+        torch = _torch()
+        t = self.t
+        E, ES = t.env_count, t.env_stride
+
+        def soa(aos, n):  # aos [E*n, comp] -> [comp, n, ES]
+            aos = np.asarray(aos, dtype=np.float32).reshape(E, n, -1)
+            out = np.zeros((aos.shape[2], n, ES), dtype=np.float32)
+            out[:, :, :E] = aos.transpose(2, 1, 0)
+            return out
+
+        m = model
+        nb, nj, nd, ns = t.nb, t.nj, t.nd, t.ns
+        body = np.concatenate([
+            m.body_com.reshape(-1, 3), m.body_inv_mass.reshape(-1, 1), m.body_inertia.reshape(-1, 9),
+            m.body_inv_inertia.reshape(-1, 9), m.body_mass.reshape(-1, 1)], axis=1)
+        grav = np.zeros((3, ES), dtype=np.float32)
+        body_world = np.asarray(m.body_world).reshape(E, nb)[:, 0] if nb else np.zeros(E, dtype=np.int32)
+        grav[:, :E] = m.gravity[body_world].T  # gravity[-1] is the global world (model.py:1300-1304)
+        joint = np.concatenate([m.joint_X_p, m.joint_X_c], axis=1) if nj else np.zeros((0, 14), dtype=np.float32)
+        dof = np.concatenate([
+            m.joint_axis.reshape(-1, 3), m.joint_limit_lower[:, None], m.joint_limit_upper[:, None],
+            m.joint_target_ke[:, None], m.joint_target_kd[:, None], m.joint_limit_ke[:, None], m.joint_limit_kd[:, None],
+            m.joint_armature[:, None]], axis=1) if nd else np.zeros((0, 10), dtype=np.float32)
+        shape_all = np.concatenate([
+            m.shape_transform, m.shape_scale, m.shape_margin[:, None], m.shape_gap[:, None], m.shape_material_mu[:, None],
+            m.shape_material_mu_torsional[:, None], m.shape_material_mu_rolling[:, None], m.shape_material_ke[:, None],
+            m.shape_material_kd[:, None], m.shape_material_kf[:, None], m.shape_material_ka[:, None]], axis=1)
+        new = {
+            "body_param": soa(body, nb), "gravity": grav, "joint_param": soa(joint, nj), "dof_param": soa(dof, nd),
+            "shape_param": soa(shape_all[:E * ns], ns),
+            "gshape_param": np.ascontiguousarray(shape_all[E * ns:], dtype=np.float32),
+        }
+        for k, v in new.items():
+            if v.size == 0:
+                v = np.zeros(1, dtype=np.float32)
+            if k in self.params and self.params[k].numel() == v.size:
+                self.params[k].copy_(torch.from_numpy(v).reshape(self.params[k].shape))
+            else:
+                self.params[k] = torch.from_numpy(v).to(self.device)
+
+    def stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+
+class Model:
+    """Flat-array simulation model (newton/_src/sim/model.py:808-1364, rigid subset)."""
+
+    def __init__(self, device=None):
+        self.device = device if device is not None else "cpu"
+        self.requires_grad = False
+        self.world_count = 0
+        self.particle_count = 0
+        self.rigid_contact_max = 0
+        self.env: EnvTemplate | None = None
+        self._dev: DeviceModel | None = None
+
+    # -- construction helpers -------------------------------------------------------------------
+    def _build_env_template(self):
+        self.env = EnvTemplate(self)
+
+    @property
+    def is_gpu(self):
+        return _is_gpu(self.device)
+
+    def device_model(self) -> DeviceModel:
+        if not self.is_gpu:
+            raise _lib.NewtonHipError(
+                f"Model is on device '{self.device}': the solvers / collision pipeline of newton_amd run only on an "
+                "MI355X through libnewton_hip.so (no CPU fallback). Finalize with device='cuda:0'.")
+        if self._dev is None:
+            self._dev = DeviceModel(self)
+        return self._dev
+
+    def notify_model_changed(self):
+        """Re-upload per-env parameters after the host arrays were edited."""
+        if self._dev is not None:
+            self._dev.upload_params(self)
+
+    # -- factories (model.py:1779-1863) --------------------------------------------------------------
+    def state(self) -> State:
+        from .state import State  # noqa: PLC0415
+
+        return State(self)
+
+    def control(self, clone_variables: bool = True) -> Control:
+        from .state import Control  # noqa: PLC0415
+
+        return Control(self)
+
+    def contacts(self):
+        from .collide import CollisionPipeline  # noqa: PLC0415
+
+        return CollisionPipeline(self).contacts()
+
+    def shape_collision_filter_mask(self, pairs):
+        pairs = np.asarray(pairs).reshape(-1, 2)
+        return np.asarray([(min(a, b), max(a, b)) in self.shape_collision_filter_pairs for a, b in pairs], dtype=bool)

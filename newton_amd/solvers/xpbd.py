@@ -1,0 +1,73 @@
+"""SolverXPBD -- drop-in for newton.solvers.SolverXPBD (newton/_src/solvers/xpbd/solver_xpbd.py:100-862), rigid bodies.
+
+``step`` is one launch of the gfx950 kernel ``xpbd_step_kernel`` through the C ABI ``nt_xpbd_step``;
+``rollout`` is the fused replacement for the CUDA-graph-captured substep loop
+(newton/examples/basic/example_basic_urdf.py:117-141) through ``nt_xpbd_rollout``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from .. import _lib
+from .solver import SolverBase
+
+
+class SolverXPBD(SolverBase):
+    def __init__(self, model, *, iterations: int = 2, soft_body_relaxation: float = 0.9, soft_contact_relaxation: float = 0.9,
+                 joint_linear_relaxation: float = 0.7, joint_angular_relaxation: float = 0.4,
+                 joint_linear_compliance: float = 0.0, joint_angular_compliance: float = 0.0,
+                 rigid_contact_relaxation: float = 0.8, rigid_contact_con_weighting: bool = True,
+                 angular_damping: float = 0.0, enable_restitution: bool = False, deterministic=None,
+                 envs_per_block: int = 0):
+        super().__init__(model)
+        if enable_restitution:
+            raise NotImplementedError("enable_restitution is not implemented yet (SURVEY.md section 8, row a12)")
+        self.iterations = iterations
+        self.soft_body_relaxation = soft_body_relaxation
+        self.soft_contact_relaxation = soft_contact_relaxation
+        self.joint_linear_relaxation = joint_linear_relaxation
+        self.joint_angular_relaxation = joint_angular_relaxation
+        self.joint_linear_compliance = joint_linear_compliance
+        self.joint_angular_compliance = joint_angular_compliance
+        self.rigid_contact_relaxation = rigid_contact_relaxation
+        self.rigid_contact_con_weighting = rigid_contact_con_weighting
+        self.angular_damping = angular_damping
+        self.enable_restitution = enable_restitution
+        self.envs_per_block = int(envs_per_block)
+
+    def _params(self) -> _lib.nt_xpbd_params:
+        return _lib.nt_xpbd_params(int(self.iterations), float(self.joint_linear_relaxation),
+                                   float(self.joint_angular_relaxation), float(self.joint_linear_compliance),
+                                   float(self.joint_angular_compliance), float(self.rigid_contact_relaxation),
+                                   int(bool(self.rigid_contact_con_weighting)), float(self.angular_damping),
+                                   int(bool(self.enable_restitution)))
+
+    def step(self, state_in, state_out, control, contacts, dt: float) -> None:
+        dm = self.dm
+        if control is None:
+            control = self._default_control()
+        p = self._params()
+        d_in, d_out, d_c = state_in._desc(), state_out._desc(), control._desc()
+        d_ct = contacts._desc() if contacts is not None else None
+        _lib.check(dm.lib.nt_xpbd_step(C.byref(dm.desc), C.byref(p), C.byref(d_in), C.byref(d_out), C.byref(d_c),
+                                       C.byref(d_ct) if d_ct is not None else None, float(dt), self.envs_per_block,
+                                       dm.stream()), "nt_xpbd_step")
+
+    def rollout(self, state_0, state_1, control, contacts, dt: float, substeps: int, collide_params=None):
+        """substeps x {clear_forces; collide; step; swap} in one launch.  Returns the state object holding the
+        result (state_0 for an even number of substeps, state_1 for odd -- the reference loop's swap)."""
+        dm = self.dm
+        if control is None:
+            control = self._default_control()
+        p = self._params()
+        cp = collide_params if collide_params is not None else _lib.nt_collide_params(0, self.envs_per_block)
+        d0, d1, d_c, d_ct = state_0._desc(), state_1._desc(), control._desc(), contacts._desc()
+        _lib.check(dm.lib.nt_xpbd_rollout(C.byref(dm.desc), C.byref(p), C.byref(cp), C.byref(d0), C.byref(d1), C.byref(d_c),
+                                          C.byref(d_ct), float(dt), int(substeps), dm.stream()), "nt_xpbd_rollout")
+        contacts._generation += 1
+        return state_1 if substeps % 2 else state_0
+
+    def _default_control(self):
+        if not hasattr(self, "_control"):
+            self._control = self.model.control()
+        return self._control

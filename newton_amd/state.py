@@ -1,0 +1,170 @@
+"""State and Control containers (newton/_src/sim/state.py:113-262, control.py:31-68).
+
+Host models (device 'cpu') hold numpy AoS arrays.  GPU models hold env-major SoA torch tensors
+(``_soa[name]`` with shape [comp, slots_per_env, env_stride]); the Newton-shaped AoS arrays
+(``body_q[B,7]`` ...) are produced on read and packed on write through nt_unpack_aos / nt_pack_aos.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch  # noqa: PLC0415
+
+    return torch
+
+
+class _SoAContainer:
+    """Shared AoS <-> SoA plumbing. ``_FIELDS``: name -> (ncomp, slots attr on EnvTemplate, model default attr)."""
+
+    _FIELDS: dict = {}
+
+    def __init__(self, model):
+        self.model = model
+        self.requires_grad = False
+        self._soa = {}
+        self._host = {}
+        t = model.env
+        if model.is_gpu:
+            torch = _torch()
+            dm = model.device_model()
+            for name, (ncomp, slots, default) in self._FIELDS.items():
+                n = getattr(t, slots)
+                self._soa[name] = torch.zeros((ncomp, max(n, 1), t.env_stride), dtype=torch.float32, device=dm.device)
+                if default is not None and n > 0:
+                    self._set(name, getattr(model, default))
+        else:
+            for name, (ncomp, slots, default) in self._FIELDS.items():
+                n = getattr(t, slots) * t.env_count
+                shape = (n, ncomp) if ncomp > 1 else (n,)
+                src = getattr(model, default) if default is not None else None
+                self._host[name] = np.array(src, dtype=np.float32).reshape(shape) if src is not None else np.zeros(shape, np.float32)
+
+    def _get(self, name):
+        if not self.model.is_gpu:
+            return self._host[name]
+        torch = _torch()
+        ncomp, slots, _ = self._FIELDS[name]
+        t = self.model.env
+        n = getattr(t, slots)
+        dm = self.model.device_model()
+        shape = (t.env_count * n, ncomp) if ncomp > 1 else (t.env_count * n,)
+        out = torch.empty(shape, dtype=torch.float32, device=dm.device)
+        if n > 0:
+            _lib.check(dm.lib.nt_unpack_aos(self._soa[name].data_ptr(), out.data_ptr(), ncomp, n, t.env_count, t.env_stride,
+                                            dm.stream()), "nt_unpack_aos")
+        return out
+
+    def _set(self, name, value):
+        ncomp, slots, _ = self._FIELDS[name]
+        t = self.model.env
+        n = getattr(t, slots)
+        if not self.model.is_gpu:
+            shape = (t.env_count * n, ncomp) if ncomp > 1 else (t.env_count * n,)
+            self._host[name] = np.array(value, dtype=np.float32).reshape(shape)
+            return
+        torch = _torch()
+        dm = self.model.device_model()
+        if not isinstance(value, torch.Tensor):
+            value = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32))
+        value = value.to(device=dm.device, dtype=torch.float32).contiguous()
+        if value.numel() != t.env_count * n * ncomp:
+            raise ValueError(f"{name}: expected {t.env_count * n * ncomp} values, got {value.numel()}")
+        if n > 0:
+            _lib.check(dm.lib.nt_pack_aos(value.data_ptr(), self._soa[name].data_ptr(), ncomp, n, t.env_count, t.env_stride,
+                                          dm.stream()), "nt_pack_aos")
+            torch.cuda.current_stream(dm.device).synchronize()  # `value` may be a temporary
+
+
+def _aos_property(name):
+    def getter(self):
+        return self._get(name)
+
+    def setter(self, value):
+        self._set(name, value)
+
+    return property(getter, setter)
+
+
+class State(_SoAContainer):
+    """Time-varying simulation state (state.py:113-171): body_q [B,7], body_qd [B,6], body_f [B,6], joint_q, joint_qd."""
+
+    _FIELDS = {
+        "body_q": (7, "nb", "body_q"),
+        "body_qd": (6, "nb", "body_qd"),
+        "body_f": (6, "nb", None),
+        "joint_q": (1, "nc", "joint_q"),
+        "joint_qd": (1, "nd", "joint_qd"),
+    }
+    body_q = _aos_property("body_q")
+    body_qd = _aos_property("body_qd")
+    body_f = _aos_property("body_f")
+    joint_q = _aos_property("joint_q")
+    joint_qd = _aos_property("joint_qd")
+
+    def __init__(self, model):
+        super().__init__(model)
+        self.body_parent_f = None
+        self.particle_count = 0
+
+    @property
+    def body_count(self):
+        return self.model.body_count
+
+    def clear_forces(self):
+        """state.py:189-200"""
+        if not self.model.is_gpu:
+            self._host["body_f"][...] = 0.0
+            return
+        dm = self.model.device_model()
+        d = self._desc()
+        _lib.check(dm.lib.nt_clear_forces(C.byref(dm.desc), C.byref(d), dm.stream()), "nt_clear_forces")
+
+    def assign(self, other: State):
+        """state.py:202-262"""
+        if self.model.is_gpu:
+            for k in self._soa:
+                self._soa[k].copy_(other._soa[k])
+        else:
+            for k in self._host:
+                self._host[k] = other._host[k].copy()
+
+    def _desc(self) -> _lib.nt_state:
+        d = _lib.nt_state()
+        d.body_q = self._soa["body_q"].data_ptr()
+        d.body_qd = self._soa["body_qd"].data_ptr()
+        d.body_f = self._soa["body_f"].data_ptr()
+        d.joint_q = self._soa["joint_q"].data_ptr()
+        d.joint_qd = self._soa["joint_qd"].data_ptr()
+        return d
+
+
+class Control(_SoAContainer):
+    """Control inputs (control.py:31-68): joint_f [D], joint_target_q [coords or D], joint_target_qd [D]."""
+
+    _FIELDS = {
+        "joint_f": (1, "nd", "joint_f"),
+        "joint_target_q": (1, "ntq", "joint_target_q"),
+        "joint_target_qd": (1, "nd", "joint_target_qd"),
+    }
+    joint_f = _aos_property("joint_f")
+    joint_target_q = _aos_property("joint_target_q")
+    joint_target_qd = _aos_property("joint_target_qd")
+
+    def clear(self):
+        if self.model.is_gpu:
+            self._soa["joint_f"].zero_()
+        else:
+            self._host["joint_f"][...] = 0.0
+
+    def _desc(self) -> _lib.nt_control:
+        d = _lib.nt_control()
+        d.joint_f = self._soa["joint_f"].data_ptr()
+        d.joint_target_q = self._soa["joint_target_q"].data_ptr()
+        d.joint_target_qd = self._soa["joint_target_qd"].data_ptr()
+        return d

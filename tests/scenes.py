@@ -1,0 +1,122 @@
+"""Synthetic scenes shared by tests, bench.py and smoke().
+
+The quadruped URDF below restates the *numbers* of newton/examples/assets/quadruped.urdf (13 links, cylinder
+colliders, 12 revolute joints) -- geometry/topology data, generated programmatically, not a file copy.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import newton_amd as nt
+
+_LEGS = [("LF", 0.2999, 0.104, 1.0), ("RF", 0.2999, -0.104, -1.0), ("LH", -0.2999, 0.104, 1.0), ("RH", -0.2999, -0.104, -1.0)]
+_HALF_PI = "1.57079632679"
+
+
+def quadruped_urdf() -> str:
+    """Anymal-class stand-in: base cylinder + 4 x {HAA, THIGH, SHANK}."""
+    out = ['<?xml version="1.0" encoding="utf-8"?>', '<robot name="quadruped">',
+           '<link name="base"><collision><origin rpy="0 %s 0" xyz="0 0 0"/><geometry><cylinder length="0.75" radius="0.1"/>'
+           '</geometry></collision></link>' % _HALF_PI]
+    for leg, x, y, sgn in _LEGS:
+        out.append(f'<joint name="{leg}_HAA" type="revolute"><parent link="base"/><child link="{leg}_HAA"/><axis xyz="1 0 0"/>'
+                   f'<limit effort="80.0" velocity="20."/><origin rpy="0 0 0" xyz="{x} {y} 0.0"/></joint>')
+        out.append(f'<link name="{leg}_HAA"><collision><origin rpy="{_HALF_PI} 0 0" xyz="0 0 0"/><geometry>'
+                   '<cylinder length="0.05" radius="0.04"/></geometry></collision></link>')
+        yaw = _HALF_PI if sgn > 0 else "-" + _HALF_PI
+        out.append(f'<joint name="{leg}_HFE" type="revolute"><parent link="{leg}_HAA"/><child link="{leg}_THIGH"/>'
+                   f'<origin rpy="0 0 {yaw}" xyz="0 {0.05 * sgn} 0"/><axis xyz="1 0 0"/><limit effort="80.0" velocity="20."/>'
+                   '<dynamics damping="0.0" friction="0.0"/></joint>')
+        out.append(f'<link name="{leg}_THIGH"><collision><origin rpy="0 0 0" xyz="0 0 -0.125"/><geometry>'
+                   '<cylinder length="0.25" radius="0.02"/></geometry></collision></link>')
+        out.append(f'<joint name="{leg}_KFE" type="revolute"><parent link="{leg}_THIGH"/><child link="{leg}_SHANK"/>'
+                   '<origin rpy="0 0 0" xyz="0 0.0 -0.25"/><axis xyz="1 0 0"/><limit effort="80.0" velocity="20."/>'
+                   '<dynamics damping="0.0" friction="0.0"/></joint>')
+        out.append(f'<link name="{leg}_SHANK"><collision><origin rpy="0 0 0" xyz="0 0 -0.125"/><geometry>'
+                   '<cylinder length="0.25" radius="0.02"/></geometry></collision></link>')
+    out.append("</robot>")
+    return "\n".join(out)
+
+
+def quadruped_builder():
+    """The per-world builder of newton/examples/basic/example_basic_urdf.py:38-75 (XPBD branch)."""
+    q = nt.ModelBuilder()
+    q.default_joint_cfg.armature = 0.01
+    q.default_joint_cfg.target_ke = 2000.0
+    q.default_joint_cfg.target_kd = 1.0
+    q.default_shape_cfg.mu = 1.0
+    q.add_urdf(quadruped_urdf(), xform=[0.0, 0.0, 0.7, 0.0, 0.0, 0.0, 1.0], floating=True, enable_self_collisions=False,
+               ignore_inertial_definitions=True)
+    for b in range(q.body_count):
+        q.body_inertia[b] = q.body_inertia[b] + np.eye(3) * 0.01
+        # (the example edits body_inertia only; body_inv_inertia keeps the pre-armature value, builder semantics)
+    pose = [0.2, 0.4, -0.6, -0.2, -0.4, 0.6, -0.2, 0.4, -0.6, 0.2, -0.4, 0.6]
+    q.joint_q[-12:] = pose
+    q.joint_target_q[-12:] = pose
+    return q
+
+
+def quadruped_scene(world_count: int, device=None, seed: int | None = 1, height_jitter: float = 0.05):
+    """C3/C4 scene: `world_count` quadrupeds + one global ground plane.  Per-env root-height jitter U(0, jitter)
+    (seeded) de-correlates the environments."""
+    q = quadruped_builder()
+    scene = nt.ModelBuilder()
+    scene.replicate(q, world_count)
+    scene.add_ground_plane(cfg=q.default_shape_cfg)
+    model = scene.finalize(device=device)
+    if seed is not None and height_jitter > 0.0:
+        rng = np.random.default_rng(seed)
+        jq = model.joint_q.reshape(world_count, -1)
+        jq[:, 2] += rng.uniform(0.0, height_jitter, size=world_count).astype(np.float32)
+    bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+    model.body_q, model.body_qd = bq, bqd
+    return model
+
+
+def box_stack_scene(world_count: int, n_boxes: int = 8, device=None, seed: int | None = 0, jitter: float = 1e-3):
+    """C2 scene: `n_boxes` boxes (h = 0.5) stacked at z = 0.5 + k on an infinite plane
+    (pattern of newton/tests/test_solver_xpbd.py:1798-1804)."""
+    env = nt.ModelBuilder()
+    for k in range(n_boxes):
+        b = env.add_body(xform=[0.0, 0.0, 0.5 + k, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_box(b, hx=0.5, hy=0.5, hz=0.5)
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    scene.add_ground_plane()
+    model = scene.finalize(device=device)
+    if seed is not None and jitter > 0.0:
+        rng = np.random.default_rng(seed)
+        off = rng.uniform(-jitter, jitter, size=(model.body_count, 2)).astype(np.float32)
+        model.body_q[:, :2] += off
+        model.joint_q.reshape(-1, 7)[:, :2] += off
+    return model
+
+
+def mixed_primitive_scene(world_count: int, device=None, seed: int = 3):
+    """Free bodies with sphere / capsule / box / cylinder / ellipsoid colliders dropped near a ground plane:
+    exercises every analytic plane-* pair plus sphere-sphere / sphere-capsule / capsule-capsule / sphere-box."""
+    rng = np.random.default_rng(seed)
+    env = nt.ModelBuilder()
+    specs = ["sphere", "capsule", "box", "cylinder", "ellipsoid", "sphere", "capsule"]
+    for k, kind in enumerate(specs):
+        ang = rng.uniform(-1.0, 1.0, size=3)
+        q = nt._np_math.quat_rpy(*ang)
+        b = env.add_body(xform=[0.35 * (k % 3) - 0.3, 0.4 * (k // 3) - 0.3, 0.12 + 0.02 * k, *q])
+        if kind == "sphere":
+            env.add_shape_sphere(b, radius=0.1)
+        elif kind == "capsule":
+            env.add_shape_capsule(b, radius=0.07, half_height=0.15)
+        elif kind == "box":
+            env.add_shape_box(b, hx=0.1, hy=0.08, hz=0.06)
+        elif kind == "cylinder":
+            env.add_shape_cylinder(b, radius=0.08, half_height=0.1)
+        else:
+            env.add_shape_ellipsoid(b, rx=0.12, ry=0.08, rz=0.06)
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    scene.add_ground_plane()
+    model = scene.finalize(device=device)
+    off = rng.uniform(-0.02, 0.02, size=(model.body_count, 3)).astype(np.float32)
+    model.body_q[:, :3] += off
+    model.joint_q.reshape(-1, 7)[:, :3] += off
+    return model
