@@ -41,7 +41,7 @@ def algorithmic_bytes_per_env_step(t, contacts_per_env: float) -> float:
     return (76 + 52 + 24 + 100) * B + 85 * J + 40 * D + 72 * S + 8 * P + 160.0 * contacts_per_env
 
 
-def cpu_baseline(sample_envs=256, sample_substeps=400):
+def cpu_baseline(sample_envs=512, sample_substeps=3000):
     """The C++ oracle (a restatement of Newton's kernels, NOT Newton/Warp itself) on one host core."""
     from oracle_bridge import Oracle, OracleState
     from scenes import quadruped_scene
@@ -116,10 +116,9 @@ def main():
     T = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream (torch current stream)
 
-    if dist is not None:
-        tt = torch.tensor([T], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        T = float(tt.item())
+    from newton_amd.sharding import max_over_ranks
+
+    T = max_over_ranks(T, device=f"cuda:{local_rank}")  # MAX over ranks (no-op at N=1)
 
     # validity gate of the reference benchmark (asv/benchmarks/benchmark_metrics.py:67-99): finite state,
     # normalised quaternions

@@ -1,0 +1,119 @@
+"""Host logic (no GPU): builder / URDF importer / contact-pair rules / env template / C ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import newton_amd as nt
+from newton_amd import _lib
+from newton_amd.enums import GeoType, JointType
+from scenes import box_stack_scene, mixed_primitive_scene, quadruped_builder, quadruped_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_quadruped_model_matches_survey_counts():
+    """per env B=13, J=13, D=18, coords=19, S=13 + 1 global plane, exactly 13 (shape, ground) pairs."""
+    q = quadruped_builder()
+    assert (q.body_count, q.joint_count, q.shape_count, q.joint_dof_count, q.joint_coord_count) == (13, 13, 13, 18, 19)
+    model = quadruped_scene(4, seed=None)
+    t = model.env
+    assert (t.env_count, t.nb, t.nj, t.nd, t.nc, t.ns, t.ng, t.np, t.cpp) == (4, 13, 13, 18, 19, 13, 1, 13, 4)
+    ground = model.shape_count - 1
+    want = [(w * 13 + s, ground) for w in range(4) for s in range(13)]
+    assert [tuple(p) for p in model.shape_contact_pairs] == want
+    assert t.joint_type[0] == JointType.FREE and np.all(t.joint_type[1:] == JointType.REVOLUTE)
+    # density-1000 cylinder masses (builder.py:491 default density, inertia.py:151-190)
+    assert abs(model.body_mass[0] - 1000 * np.pi * 0.1 ** 2 * 0.75) < 1e-3
+    # inverse inertia is recomputed at finalize from the armature-augmented inertia (inertia.py:1096-1110)
+    assert np.allclose(model.body_inv_inertia[1] @ model.body_inertia[1], np.eye(3), atol=1e-4)
+    assert model.gravity.shape == (5, 3) and np.allclose(model.gravity[:, 2], -9.81)
+
+
+def test_box_stack_pairs_and_cpp():
+    model = box_stack_scene(2, n_boxes=8, seed=None)
+    t = model.env
+    assert (t.nb, t.nj, t.ns, t.np) == (8, 8, 8, 36)  # 8 ground pairs + 28 box-box pairs
+    assert t.cpp == 5  # box-box goes through the convex manifold (<= 5 contacts)
+    # reference order per world: (global, local) pairs first, then local pairs (builder.py:12935-12962)
+    first = [tuple(p) for p in model.shape_contact_pairs[:9]]
+    ground = model.shape_count - 1
+    assert first[:8] == [(s, ground) for s in range(8)] and first[8] == (0, 1)
+
+
+def test_collision_filters():
+    b = nt.ModelBuilder()
+    a = b.add_link()
+    c = b.add_link()
+    b.add_shape_box(a)
+    b.add_shape_box(a)  # same body -> filtered (builder.py:6638-6643)
+    b.add_shape_sphere(c)
+    j0 = b.add_joint_fixed(-1, a)
+    j1 = b.add_joint_revolute(a, c)  # parent/child filtered (collision_filter_parent default True)
+    b.add_articulation([j0, j1])
+    m = b.finalize()
+    assert len(m.shape_contact_pairs) == 0
+    b2 = nt.ModelBuilder()
+    x = b2.add_body()
+    y = b2.add_body()
+    b2.add_shape_sphere(x)
+    cfg = nt.ShapeConfig(collision_group=2)
+    b2.add_shape_sphere(y, cfg=cfg)  # different positive groups never pair (broad_phase_common.py:220-240)
+    assert len(b2.finalize().shape_contact_pairs) == 0
+
+
+def test_heterogeneous_worlds_rejected_loudly():
+    a = nt.ModelBuilder()
+    a.add_shape_sphere(a.add_body())
+    b = nt.ModelBuilder()
+    b.add_shape_box(b.add_body())
+    scene = nt.ModelBuilder()
+    scene.add_world(a)
+    scene.add_world(b)
+    with pytest.raises(NotImplementedError):
+        scene.finalize()
+
+
+def test_mixed_scene_template():
+    model = mixed_primitive_scene(3)
+    t = model.env
+    assert t.nb == 7 and t.ns == 7 and t.ng == 1
+    assert t.np == 7 + 21  # ground pairs + all local pairs
+    assert t.cpp == 5      # box-capsule etc. are routed to the convex path
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/newton_hip.h declares."""
+    header = open(os.path.join(ROOT, "include", "newton_hip.h")).read()
+    declared = set(re.findall(r"\b(nt_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b"gfx950" in lib.nt_build_info()
+    assert lib.nt_error_string(0) == b"ok"
+    # struct layouts agree with the header (field count + size)
+    assert C.sizeof(_lib.nt_model) == 11 * 4 + 4 + 26 * 8
+    m = _lib.nt_model()
+    m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
+    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (13 * 13 + max(12 * 13 + max(14 * 13, 6 * 13), 13 * 13 + 13))
+
+
+def test_no_silent_cpu_fallback():
+    model = quadruped_scene(1, seed=None)
+    with pytest.raises(_lib.NewtonHipError):
+        nt.solvers.SolverXPBD(model)
+    with pytest.raises(_lib.NewtonHipError):
+        nt.CollisionPipeline(model)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under newton_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "newton_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower() or f == "_lib.py" and "oracle" not in text.lower(), (dirpath, f)
