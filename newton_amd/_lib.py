@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnewton_hip.so")
+LIB_PATH = os.environ.get("NEWTON_HIP_LIB", os.path.join(_HERE, "libnewton_hip.so"))  # override: A/B kernel builds
 
 NT_CONTACT_FLOATS = 17
 NT_BODY_PARAM_FLOATS = 23

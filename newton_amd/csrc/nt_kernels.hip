@@ -1,21 +1,26 @@
 // nt_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI of libnewton_hip.so.
 //
 // Design (DESIGN.md has the long form):
-//  * env-major SoA in HBM: base[(comp * nslot + slot) * ES + env]; a wave reads 64 consecutive envs of one
-//    (component, slot) = one 256 B coalesced request.
+//  * env-major SoA in HBM: base[(comp * nslot + slot) * ES + env]; a wave reads consecutive envs of one
+//    (component, slot) = one coalesced request.
 //  * one workgroup owns EPB environments for a whole substep (or a whole rollout): thread -> (env, slot) with
-//    env = blockIdx * EPB + tid % EPB and slot = tid / EPB.  A "slot" thread plays body `slot`, joint `slot`,
-//    shape `slot` and candidate pair `slot` in the respective phases, so with EPB == 64 every branch on joint
-//    or shape type is wave-uniform.
-//  * body state lives in LDS ([comp][slot][EPB], conflict-free: lanes of a wave differ in env first);
-//    constraint threads publish their per-joint / per-pair corrections in LDS and the owning body thread sums
-//    them in ascending joint / pair order through a CSR incidence list -- no float atomics, deterministic,
-//    and the same order a serial ascending-tid Warp-CPU launch uses for wp.atomic_add.
+//    env = blockIdx * EPB + tid % EPB and slot = tid / EPB.  A slot-thread plays, phase by phase, body `slot`,
+//    shape `slot`, candidate pair `slot`, contact slot `slot`, and joint part `slot` ([0,nj) linear rows,
+//    [nj,2nj) angular rows), so every constraint row of every environment is solved by its own lane and lanes of a
+//    wave run the same code path.
+//  * everything an environment needs during a substep is LDS-resident ([row][EPB], conflict-free because lanes of
+//    a wave differ in env first): body state, per-body mass properties (the 3x3 inertia tiles), joint frames, dof
+//    limits/gains, shape parameters and the control targets.  HBM is touched once per kernel for state/params
+//    and once per substep for the Contacts boundary.
+//  * constraint threads publish per-joint / per-contact corrections in LDS and the owning body thread sums
+//    them in ascending joint / contact order through a CSR incidence list -- no float atomics, deterministic,
+//    and the same order a serial ascending-tid Warp-CPU launch produces for wp.atomic_add.
 //  * no MFMA: the largest dense object on this path is a 3x3 inertia.
 //
 // Reference behaviour (file:line under /root/reference) is cited per phase.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/newton_hip.h"
 #include "nt_math.hpp"
@@ -28,40 +33,61 @@ namespace {
 enum JointType : int { JT_PRISMATIC = 0, JT_REVOLUTE = 1, JT_BALL = 2, JT_FIXED = 3, JT_FREE = 4, JT_DISTANCE = 5, JT_D6 = 6, JT_ROD = 7 };
 constexpr int BODY_KINEMATIC = 2;
 
-// body_param component indices
+// body_param rows
 constexpr int BP_COM = 0, BP_INV_MASS = 3, BP_INERTIA = 4, BP_INV_INERTIA = 13, BP_MASS = 22;
-// dof_param
+// dof_param rows
 constexpr int DP_AXIS = 0, DP_LIMIT_LOWER = 3, DP_LIMIT_UPPER = 4, DP_TARGET_KE = 5, DP_TARGET_KD = 6;
-// shape_param
+// shape_param rows
 constexpr int SP_XFORM = 0, SP_SCALE = 7, SP_MARGIN = 10, SP_GAP = 11, SP_MU = 12, SP_MU_TORSIONAL = 13, SP_MU_ROLLING = 14;
-// contact data
+// contact data rows
 constexpr int CD_POINT0 = 0, CD_POINT1 = 3, CD_OFFSET0 = 6, CD_OFFSET1 = 9, CD_NORMAL = 12, CD_MARGIN0 = 15, CD_MARGIN1 = 16;
-
-struct LdsLayout {
-    int bq, bqd;      // persistent: body_q [7][nb], body_qd [6][nb]
-    int u;            // union region
-    int jw, pw, bf;   // step view of u: joint wrench/delta [12][nj], pair delta [14][np], body_f_tmp [6][nb] (aliases pw)
-    int sx, sa;       // collide view of u: shape world xform [7][ns], shape aabb [6][ns]
-    int pc;           // collide: per-pair contact count [np] (after sa)
-    int floats_per_env;
-};
+// per-contact correction record in LDS: lin_a, ang_a, lin_b, ang_b, has_a, has_b, shape0_is_pair_a
+constexpr int CW_FLOATS = 15;
 
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 
-__host__ __device__ inline LdsLayout make_layout(int nb, int nj, int np, int ns) {
+// LDS layout, in float rows per environment (each row is EPB floats wide)
+struct LdsLayout {
+    // persistent
+    int bq, bqd;       // body_q [7][nb], body_qd [6][nb]
+    int bp;            // body params [23][nb] (inverse mass / inertia already "effective": zero for kinematic bodies)
+    int jp;            // joint params [14][nj]
+    int dp;            // dof params [10][nd]
+    int sp;            // shape params [19][ns]
+    int cf, ctq, ctqd; // control: joint_f [nd], joint_target_q [ntq], joint_target_qd [nd]
+    int grav;          // gravity [3]
+    // scratch union
+    int u;
+    int sx, sa, pc;    // collide: shape world xform [7][ns], aabb [6][ns], per-pair contact count [np]
+    int bf, jf;        // forces: body_f_tmp [6][nb], joint wrenches [12][nj]
+    int jl, ja;        // joints: linear-part corrections [12][nj], angular-part child terms [9][nj]
+    int cw;            // contacts: per-contact corrections [CW_FLOATS][np*cpp]
+    int rows_per_env;
+};
+
+__host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     LdsLayout L;
-    L.bq = 0;
-    L.bqd = 7 * nb;
-    L.u = 13 * nb;
-    L.jw = L.u;
-    L.pw = L.u + 12 * nj;
-    L.bf = L.pw;
-    L.sx = L.u;
-    L.sa = L.u + 7 * ns;
-    L.pc = L.u + 13 * ns;
-    int step_sz = 12 * nj + imax(14 * np, 6 * nb);
-    int coll_sz = 13 * ns + np;
-    L.floats_per_env = 13 * nb + imax(step_sz, coll_sz);
+    int o = 0;
+    L.bq = o; o += 7 * m.nb;
+    L.bqd = o; o += 6 * m.nb;
+    L.bp = o; o += NT_BODY_PARAM_FLOATS * m.nb;
+    L.jp = o; o += NT_JOINT_PARAM_FLOATS * m.nj;
+    L.dp = o; o += NT_DOF_PARAM_FLOATS * m.nd;
+    L.sp = o; o += NT_SHAPE_PARAM_FLOATS * m.ns;
+    L.cf = o; o += m.nd;
+    L.ctq = o; o += m.ntq;
+    L.ctqd = o; o += m.nd;
+    L.grav = o; o += 3;
+    L.u = o;
+    L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
+    int coll = 13 * m.ns + m.np;
+    L.bf = L.u; L.jf = L.bf + 6 * m.nb;
+    int forces = 6 * m.nb + 12 * m.nj;
+    L.jl = L.u; L.ja = L.jl + 12 * m.nj;
+    int joints = 21 * m.nj;
+    L.cw = L.u;
+    int contacts = CW_FLOATS * m.np * m.cpp;
+    L.rows_per_env = L.u + imax(imax(coll, forces), imax(joints, contacts));
     return L;
 }
 
@@ -74,7 +100,8 @@ struct KArgs {
     float dt;
     int substeps;
     int has_contacts;
-    int nslot;  // slot-threads per environment
+    int nslot;       // slot-threads per environment
+    int debug_skip;  // ablation bitmask (NT_DEBUG_SKIP env var): 1 collide, 2 forces+integrate, 4 contacts, 8 joints, 16 apply
 };
 
 template <int EPB>
@@ -87,7 +114,7 @@ struct Ctx {
     bool valid;
 
     NT_DI Ctx(const KArgs& a_, float* lds_) : a(a_), lds(lds_) {
-        L = make_layout(a.m.nb, a.m.nj, a.m.np, a.m.ns);
+        L = make_layout(a.m);
         e = threadIdx.x % EPB;
         slot = threadIdx.x / EPB;
         nslot = a.nslot;
@@ -95,55 +122,50 @@ struct Ctx {
         ES = a.m.env_stride;
         valid = env < a.m.env_count && slot < nslot;
     }
-    // LDS element (field offset, component, slots in field, slot)
-    NT_DI float& l(int off, int comp, int nslot, int s) const { return lds[(off + comp * nslot + s) * EPB + e]; }
-    // global SoA element
-    NT_DI size_t g(int comp, int nslot, int s) const { return (size_t)(comp * nslot + s) * ES + env; }
+    // LDS element: row = field offset + comp * slots_in_field + slot
+    NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * EPB + e]; }
+    NT_DI size_t g(int comp, int n, int s) const { return (size_t)(comp * n + s) * ES + env; }
 
-    NT_DI xform lds_xform(int off, int nslot, int s) const {
-        return xform(vec3(l(off, 0, nslot, s), l(off, 1, nslot, s), l(off, 2, nslot, s)),
-                     quat(l(off, 3, nslot, s), l(off, 4, nslot, s), l(off, 5, nslot, s), l(off, 6, nslot, s)));
+    NT_DI vec3 lv3(int off, int comp0, int n, int s) const {
+        return vec3(l(off, comp0, n, s), l(off, comp0 + 1, n, s), l(off, comp0 + 2, n, s));
     }
-    NT_DI void st_lds_xform(int off, int nslot, int s, const xform& t) const {
-        l(off, 0, nslot, s) = t.p.x; l(off, 1, nslot, s) = t.p.y; l(off, 2, nslot, s) = t.p.z;
-        l(off, 3, nslot, s) = t.q.x; l(off, 4, nslot, s) = t.q.y; l(off, 5, nslot, s) = t.q.z; l(off, 6, nslot, s) = t.q.w;
+    NT_DI void st_lv3(int off, int comp0, int n, int s, vec3 v) const {
+        l(off, comp0, n, s) = v.x; l(off, comp0 + 1, n, s) = v.y; l(off, comp0 + 2, n, s) = v.z;
     }
-    NT_DI vec3 lds_vec3(int off, int comp0, int nslot, int s) const {
-        return vec3(l(off, comp0, nslot, s), l(off, comp0 + 1, nslot, s), l(off, comp0 + 2, nslot, s));
+    NT_DI xform lxf(int off, int comp0, int n, int s) const {
+        return xform(lv3(off, comp0, n, s),
+                     quat(l(off, comp0 + 3, n, s), l(off, comp0 + 4, n, s), l(off, comp0 + 5, n, s), l(off, comp0 + 6, n, s)));
     }
-    NT_DI void st_lds_vec3(int off, int comp0, int nslot, int s, vec3 v) const {
-        l(off, comp0, nslot, s) = v.x; l(off, comp0 + 1, nslot, s) = v.y; l(off, comp0 + 2, nslot, s) = v.z;
+    NT_DI void st_lxf(int off, int n, int s, const xform& t) const {
+        l(off, 0, n, s) = t.p.x; l(off, 1, n, s) = t.p.y; l(off, 2, n, s) = t.p.z;
+        l(off, 3, n, s) = t.q.x; l(off, 4, n, s) = t.q.y; l(off, 5, n, s) = t.q.z; l(off, 6, n, s) = t.q.w;
     }
-    NT_DI vec3 g_vec3(const float* base, int comp0, int nslot, int s) const {
-        return vec3(base[g(comp0, nslot, s)], base[g(comp0 + 1, nslot, s)], base[g(comp0 + 2, nslot, s)]);
+    NT_DI mat33 lm33(int off, int comp0, int n, int s) const {
+        return mat33(l(off, comp0, n, s), l(off, comp0 + 1, n, s), l(off, comp0 + 2, n, s), l(off, comp0 + 3, n, s),
+                     l(off, comp0 + 4, n, s), l(off, comp0 + 5, n, s), l(off, comp0 + 6, n, s), l(off, comp0 + 7, n, s),
+                     l(off, comp0 + 8, n, s));
     }
-    NT_DI mat33 g_mat33(const float* base, int comp0, int nslot, int s) const {
-        return mat33(base[g(comp0, nslot, s)], base[g(comp0 + 1, nslot, s)], base[g(comp0 + 2, nslot, s)],
-                     base[g(comp0 + 3, nslot, s)], base[g(comp0 + 4, nslot, s)], base[g(comp0 + 5, nslot, s)],
-                     base[g(comp0 + 6, nslot, s)], base[g(comp0 + 7, nslot, s)], base[g(comp0 + 8, nslot, s)]);
+    NT_DI vec3 gv3(const float* base, int comp0, int n, int s) const {
+        return vec3(base[g(comp0, n, s)], base[g(comp0 + 1, n, s)], base[g(comp0 + 2, n, s)]);
     }
-    NT_DI xform g_xform(const float* base, int comp0, int nslot, int s) const {
-        return xform(g_vec3(base, comp0, nslot, s), quat(base[g(comp0 + 3, nslot, s)], base[g(comp0 + 4, nslot, s)],
-                                                          base[g(comp0 + 5, nslot, s)], base[g(comp0 + 6, nslot, s)]));
-    }
-    NT_DI xform body_q(int b) const { return lds_xform(L.bq, a.m.nb, b); }
-    NT_DI spatial body_qd(int b) const {
-        return spatial(lds_vec3(L.bqd, 0, a.m.nb, b), lds_vec3(L.bqd, 3, a.m.nb, b));
-    }
-    // effective inverse mass / inertia: zero for kinematic bodies (solver.py:173-187)
-    NT_DI float inv_mass(int b) const {
-        if (a.m.body_flags[b] & BODY_KINEMATIC) return 0.0f;
-        return a.m.body_param[g(BP_INV_MASS, a.m.nb, b)];
-    }
-    NT_DI mat33 inv_inertia(int b) const {
-        if (a.m.body_flags[b] & BODY_KINEMATIC) return mat33();
-        return g_mat33(a.m.body_param, BP_INV_INERTIA, a.m.nb, b);
-    }
-    NT_DI vec3 com(int b) const { return g_vec3(a.m.body_param, BP_COM, a.m.nb, b); }
 
-    // shape accessors: s < ns local (per-env params), otherwise global table
+    NT_DI xform body_q(int b) const { return lxf(L.bq, 0, a.m.nb, b); }
+    NT_DI quat body_rot(int b) const {
+        const int nb = a.m.nb;
+        return quat(l(L.bq, 3, nb, b), l(L.bq, 4, nb, b), l(L.bq, 5, nb, b), l(L.bq, 6, nb, b));
+    }
+    NT_DI vec3 body_v(int b) const { return lv3(L.bqd, 0, a.m.nb, b); }
+    NT_DI vec3 body_w(int b) const { return lv3(L.bqd, 3, a.m.nb, b); }
+    NT_DI float inv_mass(int b) const { return l(L.bp, BP_INV_MASS, a.m.nb, b); }
+    NT_DI mat33 inv_inertia(int b) const { return lm33(L.bp, BP_INV_INERTIA, a.m.nb, b); }
+    NT_DI mat33 inertia(int b) const { return lm33(L.bp, BP_INERTIA, a.m.nb, b); }
+    NT_DI vec3 com(int b) const { return lv3(L.bp, BP_COM, a.m.nb, b); }
+    NT_DI float dof(int row, int d) const { return l(L.dp, row, a.m.nd, d); }
+    NT_DI vec3 dof_axis(int d) const { return lv3(L.dp, DP_AXIS, a.m.nd, d); }
+
+    // shape accessors: s < ns local (per-env params in LDS), otherwise the env-uniform global table
     NT_DI float shape_f(int s, int comp) const {
-        if (s < a.m.ns) return a.m.shape_param[g(comp, a.m.ns, s)];
+        if (s < a.m.ns) return l(L.sp, comp, a.m.ns, s);
         return a.m.gshape_param[(s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp];
     }
     NT_DI vec3 shape_scale(int s) const { return vec3(shape_f(s, SP_SCALE), shape_f(s, SP_SCALE + 1), shape_f(s, SP_SCALE + 2)); }
@@ -160,28 +182,51 @@ struct Ctx {
 };
 
 // ------------------------------------------------------------------------------------------------
-// state load / store
+// HBM <-> LDS staging
 // ------------------------------------------------------------------------------------------------
 template <int EPB>
+NT_DI void stage_rows(const Ctx<EPB>& c, int lds_off, const float* src, int rows) {
+    for (int r = c.slot; r < rows; r += c.nslot) c.lds[(lds_off + r) * EPB + c.e] = src[(size_t)r * c.ES + c.env];
+}
+template <int EPB>
+NT_DI void unstage_rows(const Ctx<EPB>& c, int lds_off, float* dst, int rows) {
+    for (int r = c.slot; r < rows; r += c.nslot) dst[(size_t)r * c.ES + c.env] = c.lds[(lds_off + r) * EPB + c.e];
+}
+
+template <int EPB>
 NT_DI void load_state(const Ctx<EPB>& c, const nt_state& s) {
-    const int nb = c.a.m.nb;
     if (!c.valid) return;
-    for (int b = c.slot; b < nb; b += c.nslot) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) c.l(c.L.bq, k, nb, b) = s.body_q[c.g(k, nb, b)];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c.l(c.L.bqd, k, nb, b) = s.body_qd[c.g(k, nb, b)];
-    }
+    stage_rows(c, c.L.bq, s.body_q, 7 * c.a.m.nb);
+    stage_rows(c, c.L.bqd, s.body_qd, 6 * c.a.m.nb);
 }
 template <int EPB>
 NT_DI void store_state(const Ctx<EPB>& c, const nt_state& s) {
-    const int nb = c.a.m.nb;
     if (!c.valid) return;
-    for (int b = c.slot; b < nb; b += c.nslot) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) s.body_q[c.g(k, nb, b)] = c.l(c.L.bq, k, nb, b);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s.body_qd[c.g(k, nb, b)] = c.l(c.L.bqd, k, nb, b);
+    unstage_rows(c, c.L.bq, s.body_q, 7 * c.a.m.nb);
+    unstage_rows(c, c.L.bqd, s.body_qd, 6 * c.a.m.nb);
+}
+// parameters and controls: read once per kernel
+template <int EPB>
+NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
+    if (!c.valid) return;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    // body params, with effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
+    for (int r = c.slot; r < NT_BODY_PARAM_FLOATS * nb; r += c.nslot) {
+        int comp = r / nb, b = r - comp * nb;
+        float v = m.body_param[(size_t)r * c.ES + c.env];
+        bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
+        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;
+        c.lds[(c.L.bp + r) * EPB + c.e] = v;
+    }
+    stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS * m.nj);
+    stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS * m.nd);
+    stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS * m.ns);
+    stage_rows(c, c.L.grav, m.gravity, 3);
+    if (with_control) {
+        stage_rows(c, c.L.cf, c.a.c.joint_f, m.nd);
+        stage_rows(c, c.L.ctq, c.a.c.joint_target_q, m.ntq);
+        stage_rows(c, c.L.ctqd, c.a.c.joint_target_qd, m.nd);
     }
 }
 
@@ -257,9 +302,9 @@ NT_DI void phase_shapes(const Ctx<EPB>& c) {
         if (body >= 0) X = c.body_q(body) * X;
         vec3 lo, hi;
         shape_aabb(m.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
-        c.st_lds_xform(c.L.sx, m.ns, s, X);
-        c.st_lds_vec3(c.L.sa, 0, m.ns, s, lo);
-        c.st_lds_vec3(c.L.sa, 3, m.ns, s, hi);
+        c.st_lxf(c.L.sx, m.ns, s, X);
+        c.st_lv3(c.L.sa, 0, m.ns, s, lo);
+        c.st_lv3(c.L.sa, 3, m.ns, s, hi);
     }
 }
 
@@ -267,9 +312,9 @@ template <int EPB>
 NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {
     const nt_model& m = c.a.m;
     if (s < m.ns) {
-        X = c.lds_xform(c.L.sx, m.ns, s);
-        lo = c.lds_vec3(c.L.sa, 0, m.ns, s);
-        hi = c.lds_vec3(c.L.sa, 3, m.ns, s);
+        X = c.lxf(c.L.sx, 0, m.ns, s);
+        lo = c.lv3(c.L.sa, 0, m.ns, s);
+        hi = c.lv3(c.L.sa, 3, m.ns, s);
     } else {
         X = c.shape_local_xform(s);  // global shapes are static (shape_body == -1)
         shape_aabb(m.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
@@ -371,22 +416,20 @@ NT_DI void phase_contact_count(const Ctx<EPB>& c) {
 // XPBD: apply_joint_forces (xpbd/kernels.py:945-1075)
 // ------------------------------------------------------------------------------------------------
 template <int EPB>
-NT_DI void phase_joint_forces(const Ctx<EPB>& c) {
+NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
     const int nb = m.nb, nj = m.nj;
-    // body threads seed body_f_tmp with state_in.body_f (solver_xpbd.py:423: wp.clone)
     if (!c.valid) return;
-    for (int b = c.slot; b < nb; b += c.nslot) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c.l(c.L.bf, k, nb, b) = c.a.s_in.body_f[c.g(k, nb, b)];
-    }
+    // body threads seed body_f_tmp with state_in.body_f (solver_xpbd.py:423: wp.clone)
+    for (int r = c.slot; r < 6 * nb; r += c.nslot)
+        c.lds[(c.L.bf + r) * EPB + c.e] = forces_are_zero ? 0.0f : c.a.s_in.body_f[(size_t)r * c.ES + c.env];
     for (int j = c.slot; j < nj; j += c.nslot) {
         vec3 fp, tp, fc, tc;  // parent wrench (subtracted), child wrench (added)
         int type = m.joint_type[j];
         if (m.joint_enabled[j] && type != JT_FIXED && type != JT_ROD) {
             int id_c = m.joint_child[j], id_p = m.joint_parent[j];
-            xform X_pj = c.g_xform(m.joint_param, 0, nj, j);
-            xform X_cj = c.g_xform(m.joint_param, 7, nj, j);
+            xform X_pj = c.lxf(c.L.jp, 0, nj, j);
+            xform X_cj = c.lxf(c.L.jp, 7, nj, j);
             xform X_wp = X_pj, pose_p = X_pj;
             vec3 com_p(0.0f);
             if (id_p >= 0) {
@@ -400,36 +443,31 @@ NT_DI void phase_joint_forces(const Ctx<EPB>& c) {
             vec3 r_c = X_wc.p - xform_point(pose_c, c.com(id_c));
             int qd_start = m.joint_qd_start[j];
             int lin = m.joint_lin_count[j], ang = m.joint_ang_count[j];
-            const float* JF = c.a.c.joint_f;
             vec3 f_total, t_total;
             if (type == JT_FREE || type == JT_DISTANCE) {
-                f_total = vec3(JF[c.g(0, 1, qd_start)], JF[c.g(0, 1, qd_start + 1)], JF[c.g(0, 1, qd_start + 2)]);
-                t_total = vec3(JF[c.g(0, 1, qd_start + 3)], JF[c.g(0, 1, qd_start + 4)], JF[c.g(0, 1, qd_start + 5)]);
+                // joint_f rows qd_start .. qd_start+5 (n = 1 => comp is the row step)
+                f_total = c.lv3(c.L.cf, 0, 1, qd_start);
+                t_total = c.lv3(c.L.cf, 0, 1, qd_start + 3);
                 fc = f_total; tc = t_total;
                 fp = f_total; tp = t_total;
             } else {
                 if (type == JT_BALL) {
-                    t_total = vec3(JF[c.g(0, 1, qd_start)], JF[c.g(0, 1, qd_start + 1)], JF[c.g(0, 1, qd_start + 2)]);
+                    t_total = c.lv3(c.L.cf, 0, 1, qd_start);
                 } else if (type == JT_REVOLUTE || type == JT_PRISMATIC || type == JT_D6) {
                     for (int k = 0; k < 3; ++k)
-                        if (lin > k) {
-                            vec3 axis = c.g_vec3(m.dof_param, DP_AXIS, m.nd, qd_start + k);
-                            f_total += JF[c.g(0, 1, qd_start + k)] * xform_vector(X_wp, axis);
-                        }
+                        if (lin > k) f_total += c.l(c.L.cf, 0, 1, qd_start + k) * xform_vector(X_wp, c.dof_axis(qd_start + k));
                     for (int k = 0; k < 3; ++k)
-                        if (ang > k) {
-                            vec3 axis = c.g_vec3(m.dof_param, DP_AXIS, m.nd, qd_start + lin + k);
-                            t_total += JF[c.g(0, 1, qd_start + lin + k)] * xform_vector(X_wp, axis);
-                        }
+                        if (ang > k)
+                            t_total += c.l(c.L.cf, 0, 1, qd_start + lin + k) * xform_vector(X_wp, c.dof_axis(qd_start + lin + k));
                 }
                 fc = f_total; tc = t_total + cross(r_c, f_total);
                 fp = f_total; tp = t_total + cross(r_p, f_total);
             }
         }
-        c.st_lds_vec3(c.L.jw, 0, nj, j, fp);
-        c.st_lds_vec3(c.L.jw, 3, nj, j, tp);
-        c.st_lds_vec3(c.L.jw, 6, nj, j, fc);
-        c.st_lds_vec3(c.L.jw, 9, nj, j, tc);
+        c.st_lv3(c.L.jf, 0, nj, j, fp);
+        c.st_lv3(c.L.jf, 3, nj, j, tp);
+        c.st_lv3(c.L.jf, 6, nj, j, fc);
+        c.st_lv3(c.L.jf, 9, nj, j, tc);
     }
 }
 
@@ -439,32 +477,32 @@ template <int EPB>
 NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int nb = m.nb, nj = m.nj;
-    vec3 f0 = c.lds_vec3(c.L.bf, 0, nb, b), t0 = c.lds_vec3(c.L.bf, 3, nb, b);
+    vec3 f0 = c.lv3(c.L.bf, 0, nb, b), t0 = c.lv3(c.L.bf, 3, nb, b);
     for (int i = m.body_joint_start[b]; i < m.body_joint_start[b + 1]; ++i) {
         int code = m.body_joint_list[i];
         int j = code >> 1;
         if (code & 1) {
-            f0 += c.lds_vec3(c.L.jw, 6, nj, j);
-            t0 += c.lds_vec3(c.L.jw, 9, nj, j);
+            f0 += c.lv3(c.L.jf, 6, nj, j);
+            t0 += c.lv3(c.L.jf, 9, nj, j);
         } else {
-            f0 -= c.lds_vec3(c.L.jw, 0, nj, j);
-            t0 -= c.lds_vec3(c.L.jw, 3, nj, j);
+            f0 -= c.lv3(c.L.jf, 0, nj, j);
+            t0 -= c.lv3(c.L.jf, 3, nj, j);
         }
     }
     if (m.body_flags[b] & BODY_KINEMATIC) return;  // pass through unchanged
 
     xform q = c.body_q(b);
-    spatial qd = c.body_qd(b);
-    float inv_mass = m.body_param[c.g(BP_INV_MASS, nb, b)];
-    mat33 inertia = c.g_mat33(m.body_param, BP_INERTIA, nb, b);
-    mat33 inv_inertia = c.g_mat33(m.body_param, BP_INV_INERTIA, nb, b);
+    vec3 v0 = c.body_v(b), w0 = c.body_w(b);
+    // integrate_bodies uses the raw model inverse mass/inertia; for non-kinematic bodies raw == effective
+    float inv_mass = c.inv_mass(b);
+    mat33 inertia = c.inertia(b);
+    mat33 inv_inertia = c.inv_inertia(b);
     vec3 com = c.com(b);
-    vec3 gravity(m.gravity[c.g(0, 1, 0)], m.gravity[c.g(1, 1, 0)], m.gravity[c.g(2, 1, 0)]);
+    vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
     const float dt = c.a.dt;
 
     vec3 x0 = q.p;
     quat r0 = q.q;
-    vec3 w0 = qd.bottom, v0 = qd.top;
     vec3 x_com = x0 + quat_rotate(r0, com);
     vec3 v1 = v0 + (f0 * inv_mass + gravity * nonzero(inv_mass)) * dt;
     vec3 x1 = x_com + v1 * dt;
@@ -473,9 +511,9 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     vec3 w1 = quat_rotate(r0, wb + inv_inertia * tb * dt);
     quat r1 = normalize(r0 + quat(w1, 0.0f) * r0 * 0.5f * dt);
     w1 *= 1.0f - c.a.p.angular_damping * dt;
-    c.st_lds_xform(c.L.bq, nb, b, xform(x1 - quat_rotate(r1, com), r1));
-    c.st_lds_vec3(c.L.bqd, 0, nb, b, v1);
-    c.st_lds_vec3(c.L.bqd, 3, nb, b, w1);
+    c.st_lxf(c.L.bq, nb, b, xform(x1 - quat_rotate(r1, com), r1));
+    c.st_lv3(c.L.bqd, 0, nb, b, v1);
+    c.st_lv3(c.L.bqd, 3, nb, b, w1);
 }
 template <int EPB>
 NT_DI void phase_integrate(const Ctx<EPB>& c) {
@@ -533,171 +571,167 @@ NT_DI float angular_correction(float err, float derr, quat qa, quat qb, const ma
 }
 
 // ------------------------------------------------------------------------------------------------
-// XPBD: solve_body_contact_positions (xpbd/kernels.py:2164-2399); one thread per candidate pair walks the
-// pair's contact slots in order and publishes the two bodies' summed corrections + active-contact counts.
+// XPBD: solve_body_contact_positions (xpbd/kernels.py:2164-2399); one lane per contact slot.
 // ------------------------------------------------------------------------------------------------
 template <int EPB>
-NT_DI void contacts_item(const Ctx<EPB>& c, const int p) {
+NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
     const int cpp = m.cpp, ncs = m.np * cpp;
     const float dt = c.a.dt, relaxation = c.a.p.rigid_contact_relaxation;
-    const int pa = m.pair_a[p];
-    vec3 dl0, da0, dl1, da1;  // side 0 = body of pair_a's shape, side 1 = body of pair_b's shape
-    float cnt0 = 0.0f, cnt1 = 0.0f;
     const float* D = ct.data;
+    float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
+    vec3 lin_delta_a, ang_delta_a, lin_delta_b, ang_delta_b;
 
-    for (int k = 0; k < cpp; ++k) {
-        int slot = p * cpp + k;
-        size_t gi = (size_t)slot * c.ES + c.env;
-        int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
-        if (gid_a == gid_b) continue;
-        int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
-        int shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
-        int body_a = shape_a >= 0 ? m.shape_body[shape_a] : -1;
-        int body_b = shape_b >= 0 ? m.shape_body[shape_b] : -1;
-        if (body_a == body_b) continue;
-
+    size_t gi = (size_t)slot * c.ES + c.env;
+    int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+    bool live = gid_a != gid_b;
+    int shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
+    if (live) {
+        shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
+        shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+        body_a = shape_a >= 0 ? m.shape_body[shape_a] : -1;
+        body_b = shape_b >= 0 ? m.shape_body[shape_b] : -1;
+        live = body_a != body_b;
+    }
+    if (live) {
         xform X_wb_a, X_wb_b;
         if (body_a >= 0) X_wb_a = c.body_q(body_a);
         if (body_b >= 0) X_wb_b = c.body_q(body_b);
-        vec3 point0 = c.g_vec3(D, CD_POINT0, ncs, slot), point1 = c.g_vec3(D, CD_POINT1, ncs, slot);
+        vec3 point0 = c.gv3(D, CD_POINT0, ncs, slot), point1 = c.gv3(D, CD_POINT1, ncs, slot);
         vec3 bx_a = xform_point(X_wb_a, point0);
         vec3 bx_b = xform_point(X_wb_b, point1);
-        vec3 n = c.g_vec3(D, CD_NORMAL, ncs, slot);
+        vec3 n = c.gv3(D, CD_NORMAL, ncs, slot);
         float d = dot(n, bx_b - bx_a) - (D[c.g(CD_MARGIN0, ncs, slot)] + D[c.g(CD_MARGIN1, ncs, slot)]);
-        if (d >= 0.0f) continue;
+        if (d < 0.0f) {
+            float m_inv_a = 0.0f, m_inv_b = 0.0f;
+            mat33 I_inv_a, I_inv_b;
+            vec3 com_a(0.0f), com_b(0.0f), omega_a(0.0f), omega_b(0.0f);
+            if (body_a >= 0) {
+                com_a = c.com(body_a);
+                m_inv_a = c.inv_mass(body_a);
+                I_inv_a = c.inv_inertia(body_a);
+                omega_a = c.body_w(body_a);
+            }
+            if (body_b >= 0) {
+                com_b = c.com(body_b);
+                m_inv_b = c.inv_mass(body_b);
+                I_inv_b = c.inv_inertia(body_b);
+                omega_b = c.body_w(body_b);
+            }
+            int mat_nonzero = 0;
+            float mu = 0.0f, mu_torsional = 0.0f, mu_rolling = 0.0f;
+            if (shape_a >= 0) {
+                mat_nonzero += 1;
+                mu += c.shape_f(shape_a, SP_MU);
+                mu_torsional += c.shape_f(shape_a, SP_MU_TORSIONAL);
+                mu_rolling += c.shape_f(shape_a, SP_MU_ROLLING);
+            }
+            if (shape_b >= 0) {
+                mat_nonzero += 1;
+                mu += c.shape_f(shape_b, SP_MU);
+                mu_torsional += c.shape_f(shape_b, SP_MU_TORSIONAL);
+                mu_rolling += c.shape_f(shape_b, SP_MU_ROLLING);
+            }
+            if (mat_nonzero > 0) {
+                mu /= float(mat_nonzero);
+                mu_torsional /= float(mat_nonzero);
+                mu_rolling /= float(mat_nonzero);
+            }
+            vec3 r_a = bx_a - xform_point(X_wb_a, com_a);
+            vec3 r_b = bx_b - xform_point(X_wb_b, com_b);
+            vec3 angular_a = -cross(r_a, n);
+            vec3 angular_b = cross(r_b, n);
 
-        float m_inv_a = 0.0f, m_inv_b = 0.0f;
-        mat33 I_inv_a, I_inv_b;
-        vec3 com_a(0.0f), com_b(0.0f), omega_a(0.0f), omega_b(0.0f);
-        if (body_a >= 0) {
-            com_a = c.com(body_a);
-            m_inv_a = c.inv_mass(body_a);
-            I_inv_a = c.inv_inertia(body_a);
-            omega_a = c.lds_vec3(c.L.bqd, 3, m.nb, body_a);
-        }
-        if (body_b >= 0) {
-            com_b = c.com(body_b);
-            m_inv_b = c.inv_mass(body_b);
-            I_inv_b = c.inv_inertia(body_b);
-            omega_b = c.lds_vec3(c.L.bqd, 3, m.nb, body_b);
-        }
-        int mat_nonzero = 0;
-        float mu = 0.0f, mu_torsional = 0.0f, mu_rolling = 0.0f;
-        if (shape_a >= 0) {
-            mat_nonzero += 1;
-            mu += c.shape_f(shape_a, SP_MU);
-            mu_torsional += c.shape_f(shape_a, SP_MU_TORSIONAL);
-            mu_rolling += c.shape_f(shape_a, SP_MU_ROLLING);
-        }
-        if (shape_b >= 0) {
-            mat_nonzero += 1;
-            mu += c.shape_f(shape_b, SP_MU);
-            mu_torsional += c.shape_f(shape_b, SP_MU_TORSIONAL);
-            mu_rolling += c.shape_f(shape_b, SP_MU_ROLLING);
-        }
-        if (mat_nonzero > 0) {
-            mu /= float(mat_nonzero);
-            mu_torsional /= float(mat_nonzero);
-            mu_rolling /= float(mat_nonzero);
-        }
-        vec3 r_a = bx_a - xform_point(X_wb_a, com_a);
-        vec3 r_b = bx_b - xform_point(X_wb_b, com_b);
-        vec3 angular_a = -cross(r_a, n);
-        vec3 angular_b = cross(r_b, n);
+            float lambda_n = contact_constraint_delta(d, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, -n, n,
+                                                      angular_a, angular_b, relaxation, dt);
+            lin_delta_a = -n * lambda_n;
+            lin_delta_b = n * lambda_n;
+            ang_delta_a = angular_a * lambda_n;
+            ang_delta_b = angular_b * lambda_n;
 
-        float lambda_n = contact_constraint_delta(d, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, -n, n,
-                                                  angular_a, angular_b, relaxation, dt);
-        vec3 lin_delta_a = -n * lambda_n;
-        vec3 lin_delta_b = n * lambda_n;
-        vec3 ang_delta_a = angular_a * lambda_n;
-        vec3 ang_delta_b = angular_b * lambda_n;
-
-        if (mu > 0.0f) {
-            vec3 offset_a = c.g_vec3(D, CD_OFFSET0, ncs, slot), offset_b = c.g_vec3(D, CD_OFFSET1, ncs, slot);
-            bx_a = xform_point(X_wb_a, point0 + offset_a);
-            bx_b = xform_point(X_wb_b, point1 + offset_b);
-            vec3 delta = bx_b - bx_a;
-            vec3 friction_delta = delta - dot(n, delta) * n;
-            r_a = bx_a - xform_point(X_wb_a, com_a);
-            r_b = bx_b - xform_point(X_wb_b, com_b);
-            vec3 rel_v_kin_t(0.0f);
-            if (body_a >= 0 && (m.body_flags[body_a] & BODY_KINEMATIC) != 0) {
-                vec3 v_a = velocity_at_point(c.body_qd(body_a), r_a);
-                rel_v_kin_t = rel_v_kin_t - (v_a - dot(n, v_a) * n);
+            if (mu > 0.0f) {
+                vec3 offset_a = c.gv3(D, CD_OFFSET0, ncs, slot), offset_b = c.gv3(D, CD_OFFSET1, ncs, slot);
+                bx_a = xform_point(X_wb_a, point0 + offset_a);
+                bx_b = xform_point(X_wb_b, point1 + offset_b);
+                vec3 delta = bx_b - bx_a;
+                vec3 friction_delta = delta - dot(n, delta) * n;
+                r_a = bx_a - xform_point(X_wb_a, com_a);
+                r_b = bx_b - xform_point(X_wb_b, com_b);
+                vec3 rel_v_kin_t(0.0f);
+                if (body_a >= 0 && (m.body_flags[body_a] & BODY_KINEMATIC) != 0) {
+                    vec3 v_a = velocity_at_point(spatial(c.body_v(body_a), omega_a), r_a);
+                    rel_v_kin_t = rel_v_kin_t - (v_a - dot(n, v_a) * n);
+                }
+                if (body_b >= 0 && (m.body_flags[body_b] & BODY_KINEMATIC) != 0) {
+                    vec3 v_b = velocity_at_point(spatial(c.body_v(body_b), omega_b), r_b);
+                    rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
+                }
+                friction_delta += rel_v_kin_t * dt;
+                vec3 perp = normalize(friction_delta);
+                angular_a = -cross(r_a, perp);
+                angular_b = cross(r_b, perp);
+                float err = length(friction_delta);
+                if (err > 0.0f) {
+                    float lambda_fr = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b,
+                                                               -perp, perp, angular_a, angular_b, relaxation, dt);
+                    lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
+                    lin_delta_a -= perp * lambda_fr;
+                    lin_delta_b += perp * lambda_fr;
+                    ang_delta_a += angular_a * lambda_fr;
+                    ang_delta_b += angular_b * lambda_fr;
+                }
             }
-            if (body_b >= 0 && (m.body_flags[body_b] & BODY_KINEMATIC) != 0) {
-                vec3 v_b = velocity_at_point(c.body_qd(body_b), r_b);
-                rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
+            vec3 delta_omega = omega_b - omega_a;
+            if (mu_torsional > 0.0f) {
+                float err = dot(delta_omega, n) * dt;
+                if (fabsf(err) > 0.0f) {
+                    vec3 lin(0.0f);
+                    float lt = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, lin, lin,
+                                                        -n, n, relaxation, dt);
+                    lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
+                    ang_delta_a -= n * lt;
+                    ang_delta_b += n * lt;
+                }
             }
-            friction_delta += rel_v_kin_t * dt;
-            vec3 perp = normalize(friction_delta);
-            angular_a = -cross(r_a, perp);
-            angular_b = cross(r_b, perp);
-            float err = length(friction_delta);
-            if (err > 0.0f) {
-                float lambda_fr = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b,
-                                                           -perp, perp, angular_a, angular_b, relaxation, dt);
-                lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
-                lin_delta_a -= perp * lambda_fr;
-                lin_delta_b += perp * lambda_fr;
-                ang_delta_a += angular_a * lambda_fr;
-                ang_delta_b += angular_b * lambda_fr;
+            if (mu_rolling > 0.0f) {
+                delta_omega -= dot(n, delta_omega) * n;
+                float err = length(delta_omega) * dt;
+                if (err > 0.0f) {
+                    vec3 lin(0.0f);
+                    vec3 roll_n = normalize(delta_omega);
+                    float lr = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, lin, lin,
+                                                        -roll_n, roll_n, relaxation, dt);
+                    lr = fmaxw(lr, -lambda_n * mu_rolling);
+                    ang_delta_a -= roll_n * lr;
+                    ang_delta_b += roll_n * lr;
+                }
             }
-        }
-        vec3 delta_omega = omega_b - omega_a;
-        if (mu_torsional > 0.0f) {
-            float err = dot(delta_omega, n) * dt;
-            if (fabsf(err) > 0.0f) {
-                vec3 lin(0.0f);
-                float lt = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, lin, lin,
-                                                    -n, n, relaxation, dt);
-                lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
-                ang_delta_a -= n * lt;
-                ang_delta_b += n * lt;
-            }
-        }
-        if (mu_rolling > 0.0f) {
-            delta_omega -= dot(n, delta_omega) * n;
-            float err = length(delta_omega) * dt;
-            if (err > 0.0f) {
-                vec3 lin(0.0f);
-                vec3 roll_n = normalize(delta_omega);
-                float lr = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, lin, lin,
-                                                    -roll_n, roll_n, relaxation, dt);
-                lr = fmaxw(lr, -lambda_n * mu_rolling);
-                ang_delta_a -= roll_n * lr;
-                ang_delta_b += roll_n * lr;
-            }
-        }
-        // shape0 is the type-sorted first shape; map back to the pair's (a, b) sides
-        if (shape_a == pa) {
-            if (body_a >= 0) { dl0 += lin_delta_a; da0 += ang_delta_a; cnt0 += 1.0f; }
-            if (body_b >= 0) { dl1 += lin_delta_b; da1 += ang_delta_b; cnt1 += 1.0f; }
-        } else {
-            if (body_a >= 0) { dl1 += lin_delta_a; da1 += ang_delta_a; cnt1 += 1.0f; }
-            if (body_b >= 0) { dl0 += lin_delta_b; da0 += ang_delta_b; cnt0 += 1.0f; }
+            has_a = body_a >= 0 ? 1.0f : 0.0f;
+            has_b = body_b >= 0 ? 1.0f : 0.0f;
+            a_is_pair_a = (shape_a == m.pair_a[slot / cpp]) ? 1.0f : 0.0f;
         }
     }
-    c.st_lds_vec3(c.L.pw, 0, m.np, p, dl0);
-    c.st_lds_vec3(c.L.pw, 3, m.np, p, da0);
-    c.st_lds_vec3(c.L.pw, 6, m.np, p, dl1);
-    c.st_lds_vec3(c.L.pw, 9, m.np, p, da1);
-    c.l(c.L.pw, 12, m.np, p) = cnt0;
-    c.l(c.L.pw, 13, m.np, p) = cnt1;
+    c.st_lv3(c.L.cw, 0, ncs, slot, lin_delta_a);
+    c.st_lv3(c.L.cw, 3, ncs, slot, ang_delta_a);
+    c.st_lv3(c.L.cw, 6, ncs, slot, lin_delta_b);
+    c.st_lv3(c.L.cw, 9, ncs, slot, ang_delta_b);
+    c.l(c.L.cw, 12, ncs, slot) = has_a;
+    c.l(c.L.cw, 13, ncs, slot) = has_b;
+    c.l(c.L.cw, 14, ncs, slot) = a_is_pair_a;
 }
 template <int EPB>
 NT_DI void phase_contacts(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int p = c.slot; p < c.a.m.np; p += c.nslot) contacts_item(c, p);
+    const int ncs = c.a.m.np * c.a.m.cpp;
+    for (int s = c.slot; s < ncs; s += c.nslot) contact_item(c, s);
 }
 
 // ------------------------------------------------------------------------------------------------
-// XPBD: apply_body_deltas (xpbd/kernels.py:864-933).  FROM_PAIRS: sum pair corrections (+ contact counts),
-// otherwise sum joint corrections.
+// XPBD: apply_body_deltas (xpbd/kernels.py:864-933).  FROM_CONTACTS: sum contact corrections (+ contact counts)
+// in ascending contact order; otherwise sum joint corrections in ascending joint order.
 // ------------------------------------------------------------------------------------------------
-template <int EPB, bool FROM_PAIRS>
+template <int EPB, bool FROM_CONTACTS>
 NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int nb = m.nb;
@@ -706,32 +740,46 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
 
     vec3 dlin, dang;
     float inv_weight = 0.0f;
-    if (FROM_PAIRS) {
+    if (FROM_CONTACTS) {
+        const int cpp = m.cpp, ncs = m.np * cpp;
         for (int i = m.body_pair_start[b]; i < m.body_pair_start[b + 1]; ++i) {
             int code = m.body_pair_list[i];
-            int p = code >> 1, side = code & 1;
-            dlin += c.lds_vec3(c.L.pw, side * 6, m.np, p);
-            dang += c.lds_vec3(c.L.pw, side * 6 + 3, m.np, p);
-            inv_weight += c.l(c.L.pw, 12 + side, m.np, p);
+            int p = code >> 1, side = code & 1;  // side 0: this body owns pair_a's shape
+            for (int k = 0; k < cpp; ++k) {
+                int slot = p * cpp + k;
+                // this body is the contact's "a" iff (side == 0) == (shape0 is pair_a's shape)
+                bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
+                float has = c.l(c.L.cw, is_a ? 12 : 13, ncs, slot);
+                if (has != 0.0f) {
+                    dlin += c.lv3(c.L.cw, is_a ? 0 : 6, ncs, slot);
+                    dang += c.lv3(c.L.cw, is_a ? 3 : 9, ncs, slot);
+                    inv_weight += 1.0f;
+                }
+            }
         }
     } else {
+        const int nj = m.nj;
         for (int i = m.body_joint_start[b]; i < m.body_joint_start[b + 1]; ++i) {
             int code = m.body_joint_list[i];
-            int j = code >> 1, side = code & 1;
-            dlin += c.lds_vec3(c.L.jw, side * 6, m.nj, j);
-            dang += c.lds_vec3(c.L.jw, side * 6 + 3, m.nj, j);
+            int j = code >> 1, side = code & 1;  // side 1: this body is the joint's child
+            vec3 jl = c.lv3(c.L.jl, side * 6, nj, j);
+            vec3 ja = c.lv3(c.L.jl, side * 6 + 3, nj, j);
+            vec3 t0 = c.lv3(c.L.ja, 0, nj, j), t1 = c.lv3(c.L.ja, 3, nj, j), t2 = c.lv3(c.L.ja, 6, nj, j);
+            if (side == 0) { t0 = -t0; t1 = -t1; t2 = -t2; }  // angular_p = -angular_c
+            ja = ((ja + t0) + t1) + t2;
+            dlin += jl;
+            dang += ja;
         }
     }
     mat33 inv_I = c.inv_inertia(b);
-    mat33 body_I = c.g_mat33(m.body_param, BP_INERTIA, nb, b);
+    mat33 body_I = c.inertia(b);
     xform tf = c.body_q(b);
-    spatial qd = c.body_qd(b);
+    vec3 v0 = c.body_v(b), w0 = c.body_w(b);
     const float dt = c.a.dt;
-    vec3 v0 = qd.top, w0 = qd.bottom;
     vec3 p0 = tf.p;
     quat q0 = tf.q;
     float weight = 1.0f;
-    if (FROM_PAIRS && c.a.p.rigid_contact_con_weighting) {
+    if (FROM_CONTACTS && c.a.p.rigid_contact_con_weighting) {
         if (inv_weight > 0.0f) weight = 1.0f / inv_weight;
     }
     vec3 dp = dlin * (inv_m * weight);
@@ -746,22 +794,22 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     vec3 x_com = p0 + quat_rotate(q0, com);
     vec3 p1 = x_com + dp * dt;
     p1 -= quat_rotate(q1, com);
-    c.st_lds_xform(c.L.bq, nb, b, xform(p1, q1));
+    c.st_lxf(c.L.bq, nb, b, xform(p1, q1));
     vec3 v1 = v0 + dp;
     vec3 w1 = w0 + dw1;
     if (length(v1) < 1e-4f) v1 = vec3(0.0f);
     if (length(w1) < 1e-4f) w1 = vec3(0.0f);
-    c.st_lds_vec3(c.L.bqd, 0, nb, b, v1);
-    c.st_lds_vec3(c.L.bqd, 3, nb, b, w1);
+    c.st_lv3(c.L.bqd, 0, nb, b, v1);
+    c.st_lv3(c.L.bqd, 3, nb, b, w1);
 }
-template <int EPB, bool FROM_PAIRS>
+template <int EPB, bool FROM_CONTACTS>
 NT_DI void phase_apply(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_PAIRS>(c, b);
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS>(c, b);
 }
 
 // ------------------------------------------------------------------------------------------------
-// XPBD: solve_body_joints (xpbd/kernels.py:1513-2044)
+// XPBD: solve_body_joints (xpbd/kernels.py:1513-2044), split into a linear-rows lane and an angular-rows lane
 // ------------------------------------------------------------------------------------------------
 struct AxisData {
     vec3 lower, upper, target_pos, stiffness, target_vel, damping;
@@ -769,24 +817,23 @@ struct AxisData {
 
 template <int EPB>
 NT_DI AxisData gather_axes(const Ctx<EPB>& c, int count, int axis_idx0, int target_idx0) {
-    const nt_model& m = c.a.m;
     AxisData A;
     vec3 tp, ke_w, tv, kd_w;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (count > k) {
             int ai = axis_idx0 + k, ti = target_idx0 + k;
-            vec3 axis = c.g_vec3(m.dof_param, DP_AXIS, m.nd, ai);
-            float lower = m.dof_param[c.g(DP_LIMIT_LOWER, m.nd, ai)];
-            float upper = m.dof_param[c.g(DP_LIMIT_UPPER, m.nd, ai)];
+            vec3 axis = c.dof_axis(ai);
+            float lower = c.dof(DP_LIMIT_LOWER, ai);
+            float upper = c.dof(DP_LIMIT_UPPER, ai);
             vec3 lo_t = axis * lower, up_t = axis * upper;
             vec3 lo = vmin(lo_t, up_t), up = vmax(lo_t, up_t);
             if (k == 0) { A.lower = lo; A.upper = up; }
             else { A.lower = vmin(A.lower, lo); A.upper = vmax(A.upper, up); }
-            float ke = m.dof_param[c.g(DP_TARGET_KE, m.nd, ai)];
-            float kd = m.dof_param[c.g(DP_TARGET_KD, m.nd, ai)];
-            float target_pos = c.a.c.joint_target_q[c.g(0, 1, ti)];
-            float target_vel = c.a.c.joint_target_qd[c.g(0, 1, ai)];
+            float ke = c.dof(DP_TARGET_KE, ai);
+            float kd = c.dof(DP_TARGET_KD, ai);
+            float target_pos = c.l(c.L.ctq, 0, 1, ti);
+            float target_vel = c.l(c.L.ctqd, 0, 1, ai);
             if (ke > 0.0f) {
                 vec3 wa = axis * ke;
                 tp += wa * target_pos;
@@ -809,202 +856,243 @@ NT_DI AxisData gather_axes(const Ctx<EPB>& c, int count, int axis_idx0, int targ
     return A;
 }
 
+// true if the joint is solved at all (enabled, not FREE, not between two immovable bodies)
 template <int EPB>
-NT_DI void joints_item(const Ctx<EPB>& c, const int j) {
+NT_DI bool joint_live(const Ctx<EPB>& c, int j, int& id_p, int& id_c, float& m_inv_p, float& m_inv_c) {
+    const nt_model& m = c.a.m;
+    const int type = m.joint_type[j];
+    if (!m.joint_enabled[j] || type == JT_FREE) return false;
+    id_c = m.joint_child[j];
+    id_p = m.joint_parent[j];
+    m_inv_p = id_p >= 0 ? c.inv_mass(id_p) : 0.0f;
+    m_inv_c = c.inv_mass(id_c);
+    return !(m_inv_p == 0.0f && m_inv_c == 0.0f);
+}
+
+template <int EPB>
+NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
     const nt_model& m = c.a.m;
     const int nj = m.nj;
     const nt_xpbd_params& P = c.a.p;
     const float dt = c.a.dt;
     vec3 lin_delta_p, ang_delta_p, lin_delta_c, ang_delta_c;
-
-    const int type = m.joint_type[j];
-    bool active = m.joint_enabled[j] && type != JT_FREE;
-    if (active) {
-        int id_c = m.joint_child[j], id_p = m.joint_parent[j];
-        xform X_pj = c.g_xform(m.joint_param, 0, nj, j);
-        xform X_cj = c.g_xform(m.joint_param, 7, nj, j);
+    int id_p, id_c;
+    float m_inv_p, m_inv_c;
+    if (joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
+        const int type = m.joint_type[j];
+        xform X_pj = c.lxf(c.L.jp, 0, nj, j);
+        xform X_cj = c.lxf(c.L.jp, 7, nj, j);
         xform X_wp = X_pj, pose_p = X_pj;
-        float m_inv_p = 0.0f;
         mat33 I_inv_p;
         vec3 com_p(0.0f), vel_p(0.0f), omega_p(0.0f);
         if (id_p >= 0) {
             pose_p = c.body_q(id_p);
             X_wp = pose_p * X_wp;
             com_p = c.com(id_p);
-            m_inv_p = c.inv_mass(id_p);
             I_inv_p = c.inv_inertia(id_p);
-            spatial qd = c.body_qd(id_p);
-            vel_p = qd.top;
-            omega_p = qd.bottom;
+            vel_p = c.body_v(id_p);
+            omega_p = c.body_w(id_p);
         }
         xform pose_c = c.body_q(id_c);
         xform X_wc = pose_c * X_cj;
         vec3 com_c = c.com(id_c);
-        float m_inv_c = c.inv_mass(id_c);
         mat33 I_inv_c = c.inv_inertia(id_c);
-        spatial qdc = c.body_qd(id_c);
-        vec3 vel_c = qdc.top, omega_c = qdc.bottom;
+        vec3 vel_c = c.body_v(id_c), omega_c = c.body_w(id_c);
 
-        if (!(m_inv_p == 0.0f && m_inv_c == 0.0f)) {
-            xform rel_pose = xform_inverse(X_wp) * X_wc;
-            vec3 rel_p = rel_pose.p;
-            vec3 x_p = X_wp.p, x_c = X_wc.p;
-            int axis_start = m.joint_qd_start[j];
-            int target_axis_start = m.joint_tq_start[j];
-            int lin_count = m.joint_lin_count[j], ang_count = m.joint_ang_count[j];
-            vec3 world_com_p = xform_point(pose_p, com_p);
-            vec3 world_com_c = xform_point(pose_c, com_c);
-            bool early_out = false;
+        xform rel_pose = xform_inverse(X_wp) * X_wc;
+        vec3 rel_p = rel_pose.p;
+        vec3 x_p = X_wp.p, x_c = X_wc.p;
+        int axis_start = m.joint_qd_start[j];
+        int target_axis_start = m.joint_tq_start[j];
+        int lin_count = m.joint_lin_count[j];
+        vec3 world_com_p = xform_point(pose_p, com_p);
+        vec3 world_com_c = xform_point(pose_c, com_c);
 
-            if (type == JT_DISTANCE) {
-                vec3 r_p = x_p - world_com_p, r_c = x_c - world_com_c;
-                float lower = m.dof_param[c.g(DP_LIMIT_LOWER, m.nd, axis_start)];
-                float upper = m.dof_param[c.g(DP_LIMIT_UPPER, m.nd, axis_start)];
-                if (lower < 0.0f && upper < 0.0f) {
-                    early_out = true;
-                } else {
-                    vec3 anchor_delta = x_c - x_p;
-                    float d = length(anchor_delta);
-                    float err = 0.0f;
-                    if (lower >= 0.0f && d < lower) err = d - lower;
-                    else if (upper >= 0.0f && d > upper) err = d - upper;
-                    if (fabsf(err) > 1e-9f) {
-                        vec3 linear_c;
-                        if (d > 1e-9f) {
-                            linear_c = anchor_delta / d;
-                        } else {
-                            vec3 com_delta = world_com_c - world_com_p;
-                            if (length_sq(com_delta) > 1e-18f) linear_c = normalize(com_delta);
-                            else linear_c = xform_vector(X_wp, vec3(1.0f, 0.0f, 0.0f));
-                        }
-                        vec3 linear_p = -linear_c;
-                        vec3 angular_p = -cross(r_p, linear_c);
-                        vec3 angular_c = cross(r_c, linear_c);
-                        float derr = dot(linear_p, vel_p) + dot(linear_c, vel_c) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
-                        float compliance = P.joint_linear_compliance;
-                        float ke = m.dof_param[c.g(DP_TARGET_KE, m.nd, axis_start)];
-                        if (ke > 0.0f) compliance = 1.0f / ke;
-                        float damping = m.dof_param[c.g(DP_TARGET_KD, m.nd, axis_start)];
-                        float d_lambda = positional_correction(err, derr, pose_p.q, pose_c.q, m_inv_p, m_inv_c, I_inv_p, I_inv_c,
-                                                               linear_p, linear_c, angular_p, angular_c, 0.0f, compliance, damping, dt);
-                        lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
-                        ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
-                        lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
-                        ang_delta_c += angular_c * (d_lambda * P.joint_angular_relaxation);
+        if (type == JT_DISTANCE) {
+            vec3 r_p = x_p - world_com_p, r_c = x_c - world_com_c;
+            float lower = c.dof(DP_LIMIT_LOWER, axis_start);
+            float upper = c.dof(DP_LIMIT_UPPER, axis_start);
+            if (!(lower < 0.0f && upper < 0.0f)) {
+                vec3 anchor_delta = x_c - x_p;
+                float d = length(anchor_delta);
+                float err = 0.0f;
+                if (lower >= 0.0f && d < lower) err = d - lower;
+                else if (upper >= 0.0f && d > upper) err = d - upper;
+                if (fabsf(err) > 1e-9f) {
+                    vec3 linear_c;
+                    if (d > 1e-9f) {
+                        linear_c = anchor_delta / d;
+                    } else {
+                        vec3 com_delta = world_com_c - world_com_p;
+                        if (length_sq(com_delta) > 1e-18f) linear_c = normalize(com_delta);
+                        else linear_c = xform_vector(X_wp, vec3(1.0f, 0.0f, 0.0f));
                     }
-                }
-            } else {
-                AxisData A = gather_axes(c, lin_count, axis_start, target_axis_start);
-                vec3 projected_rel_p = rel_p;
-#pragma unroll
-                for (int dim = 0; dim < 3; ++dim) {
-                    float lower = vget(A.lower, dim), upper = vget(A.upper, dim), r = vget(rel_p, dim);
-                    if (r < lower) vset(projected_rel_p, dim, lower);
-                    else if (r > upper) vset(projected_rel_p, dim, upper);
-                    else if (vget(A.stiffness, dim) > 0.0f) vset(projected_rel_p, dim, clampf(vget(A.target_pos, dim), lower, upper));
-                }
-                mat33 frame_p = quat_to_matrix(X_wp.q);
-                vec3 r_p = xform_point(X_wp, projected_rel_p) - world_com_p;
-                vec3 r_c = x_c - world_com_c;
-#pragma unroll
-                for (int dim = 0; dim < 3; ++dim) {
-                    float e = vget(rel_p, dim);
-                    vec3 linear_c = mat_col(frame_p, dim);
                     vec3 linear_p = -linear_c;
                     vec3 angular_p = -cross(r_p, linear_c);
                     vec3 angular_c = cross(r_c, linear_c);
                     float derr = dot(linear_p, vel_p) + dot(linear_c, vel_c) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
-                    float err = 0.0f;
                     float compliance = P.joint_linear_compliance;
-                    float damping = 0.0f;
-                    float derr_rel = derr - vget(A.target_vel, dim);
-                    float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
-                    if (e < lower) err = e - lower;
-                    else if (e > upper) err = e - upper;
-                    else {
-                        float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
-                        float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
-                        if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
-                        else if (dm > 0.0f) { compliance = 1.0f / dm; damping = dm; }
-                    }
-                    if (fabsf(err) > 1e-9f || fabsf(derr_rel) > 1e-9f) {
-                        float d_lambda = positional_correction(err, derr_rel, pose_p.q, pose_c.q, m_inv_p, m_inv_c, I_inv_p, I_inv_c,
-                                                               linear_p, linear_c, angular_p, angular_c, 0.0f, compliance, damping, dt);
-                        lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
-                        ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
-                        lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
-                        ang_delta_c += angular_c * (d_lambda * P.joint_angular_relaxation);
-                    }
+                    float ke = c.dof(DP_TARGET_KE, axis_start);
+                    if (ke > 0.0f) compliance = 1.0f / ke;
+                    float damping = c.dof(DP_TARGET_KD, axis_start);
+                    float d_lambda = positional_correction(err, derr, pose_p.q, pose_c.q, m_inv_p, m_inv_c, I_inv_p, I_inv_c,
+                                                           linear_p, linear_c, angular_p, angular_c, 0.0f, compliance, damping, dt);
+                    lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
+                    lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_c += angular_c * (d_lambda * P.joint_angular_relaxation);
                 }
             }
-
-            if (!early_out && (type == JT_FIXED || type == JT_PRISMATIC || type == JT_REVOLUTE || type == JT_D6)) {
-                quat q_p = X_wp.q, q_c = X_wc.q;
-                if (dot(q_p, q_c) < 0.0f) q_c = q_c * -1.0f;
-                quat rel_q = quat_inverse(q_p) * q_c;
-                quat qtwist = normalize(quat(rel_q.x, 0.0f, 0.0f, rel_q.w));
-                quat qswing = rel_q * quat_inverse(qtwist);
-                float s = __fsqrt_rn(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
-                float invs = 1.0f / s;
-                float invscube = invs * invs * invs;
-                float err_0 = 2.0f * asinf(clampf(qtwist.x, -1.0f, 1.0f));
-                float err_1 = qswing.y, err_2 = qswing.z;
-                quat grad_0(invs - rel_q.x * rel_q.x * invscube, 0.0f, 0.0f, -(rel_q.w * rel_q.x) * invscube);
-                quat grad_1(-rel_q.w * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube, rel_q.w * invs, -rel_q.x * invs,
-                            rel_q.x * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube);
-                quat grad_2(rel_q.w * (rel_q.w * rel_q.y - rel_q.x * rel_q.z) * invscube, rel_q.x * invs, rel_q.w * invs,
-                            rel_q.x * (rel_q.z * rel_q.x - rel_q.w * rel_q.y) * invscube);
-                grad_0 = grad_0 * (2.0f / fabsf(qtwist.w));
-                float swing_sq = qswing.w * qswing.w;
-                if (swing_sq + 1.0e-4f < 1.0f) {
-                    float d = __fsqrt_rn(1.0f - qswing.w * qswing.w);
-                    float theta = 2.0f * acosf(clampf(qswing.w, -1.0f, 1.0f));
-                    float scale = theta / d;
-                    err_1 *= scale;
-                    err_2 *= scale;
-                    grad_1 = grad_1 * scale;
-                    grad_2 = grad_2 * scale;
-                }
-                AxisData A = gather_axes(c, ang_count, axis_start + lin_count, target_axis_start + lin_count);
+        } else {
+            AxisData A = gather_axes(c, lin_count, axis_start, target_axis_start);
+            vec3 projected_rel_p = rel_p;
 #pragma unroll
-                for (int dim = 0; dim < 3; ++dim) {
-                    float e = dim == 0 ? err_0 : (dim == 1 ? err_1 : err_2);
-                    quat grad = dim == 0 ? grad_0 : (dim == 1 ? grad_1 : grad_2);
-                    quat quat_c = 0.5f * q_p * grad * quat_inverse(q_c);
-                    vec3 angular_c(quat_c.x, quat_c.y, quat_c.z);
-                    vec3 angular_p = -angular_c;
-                    float derr = dot(angular_p, omega_p) + dot(angular_c, omega_c);
-                    float err = 0.0f;
-                    float compliance = P.joint_angular_compliance;
-                    float damping = 0.0f;
-                    float derr_rel = derr - vget(A.target_vel, dim) * length(angular_c);
-                    float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
-                    if (e < lower) err = e - lower;
-                    else if (e > upper) err = e - upper;
-                    else {
-                        float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
-                        float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
-                        if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
-                        else if (dm > 0.0f) { damping = dm; compliance = 1.0f / dm; }
-                    }
-                    float d_lambda = angular_correction(err, derr_rel, pose_p.q, pose_c.q, I_inv_p, I_inv_c, angular_p, angular_c,
-                                                        0.0f, compliance, damping, dt) * P.joint_angular_relaxation;
-                    ang_delta_p += angular_p * d_lambda;
-                    ang_delta_c += angular_c * d_lambda;
+            for (int dim = 0; dim < 3; ++dim) {
+                float lower = vget(A.lower, dim), upper = vget(A.upper, dim), r = vget(rel_p, dim);
+                if (r < lower) vset(projected_rel_p, dim, lower);
+                else if (r > upper) vset(projected_rel_p, dim, upper);
+                else if (vget(A.stiffness, dim) > 0.0f) vset(projected_rel_p, dim, clampf(vget(A.target_pos, dim), lower, upper));
+            }
+            mat33 frame_p = quat_to_matrix(X_wp.q);
+            vec3 r_p = xform_point(X_wp, projected_rel_p) - world_com_p;
+            vec3 r_c = x_c - world_com_c;
+#pragma unroll
+            for (int dim = 0; dim < 3; ++dim) {
+                float e = vget(rel_p, dim);
+                vec3 linear_c = mat_col(frame_p, dim);
+                vec3 linear_p = -linear_c;
+                vec3 angular_p = -cross(r_p, linear_c);
+                vec3 angular_c = cross(r_c, linear_c);
+                float derr = dot(linear_p, vel_p) + dot(linear_c, vel_c) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
+                float err = 0.0f;
+                float compliance = P.joint_linear_compliance;
+                float damping = 0.0f;
+                float derr_rel = derr - vget(A.target_vel, dim);
+                float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
+                if (e < lower) err = e - lower;
+                else if (e > upper) err = e - upper;
+                else {
+                    float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
+                    float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
+                    if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
+                    else if (dm > 0.0f) { compliance = 1.0f / dm; damping = dm; }
+                }
+                if (fabsf(err) > 1e-9f || fabsf(derr_rel) > 1e-9f) {
+                    float d_lambda = positional_correction(err, derr_rel, pose_p.q, pose_c.q, m_inv_p, m_inv_c, I_inv_p, I_inv_c,
+                                                           linear_p, linear_c, angular_p, angular_c, 0.0f, compliance, damping, dt);
+                    lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
+                    lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_c += angular_c * (d_lambda * P.joint_angular_relaxation);
                 }
             }
-            if (early_out) { lin_delta_p = vec3(); ang_delta_p = vec3(); lin_delta_c = vec3(); ang_delta_c = vec3(); }
         }
     }
-    c.st_lds_vec3(c.L.jw, 0, nj, j, lin_delta_p);
-    c.st_lds_vec3(c.L.jw, 3, nj, j, ang_delta_p);
-    c.st_lds_vec3(c.L.jw, 6, nj, j, lin_delta_c);
-    c.st_lds_vec3(c.L.jw, 9, nj, j, ang_delta_c);
+    c.st_lv3(c.L.jl, 0, nj, j, lin_delta_p);
+    c.st_lv3(c.L.jl, 3, nj, j, ang_delta_p);
+    c.st_lv3(c.L.jl, 6, nj, j, lin_delta_c);
+    c.st_lv3(c.L.jl, 9, nj, j, ang_delta_c);
 }
+
+template <int EPB>
+NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
+    const nt_model& m = c.a.m;
+    const int nj = m.nj;
+    const nt_xpbd_params& P = c.a.p;
+    const float dt = c.a.dt;
+    vec3 t0, t1, t2;  // angular_c * d_lambda for the three angular rows (parent gets the negation)
+    int id_p, id_c;
+    float m_inv_p, m_inv_c;
+    const int type = m.joint_type[j];
+    bool angular_type = type == JT_FIXED || type == JT_PRISMATIC || type == JT_REVOLUTE || type == JT_D6;
+    if (angular_type && joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
+        xform X_pj = c.lxf(c.L.jp, 0, nj, j);
+        xform X_cj = c.lxf(c.L.jp, 7, nj, j);
+        quat q_p = X_pj.q, rot_p = X_pj.q;  // pose_p defaults to X_pj for world-attached joints
+        mat33 I_inv_p;
+        vec3 omega_p(0.0f);
+        if (id_p >= 0) {
+            rot_p = c.body_rot(id_p);
+            q_p = rot_p * X_pj.q;
+            I_inv_p = c.inv_inertia(id_p);
+            omega_p = c.body_w(id_p);
+        }
+        quat rot_c = c.body_rot(id_c);
+        quat q_c = rot_c * X_cj.q;
+        mat33 I_inv_c = c.inv_inertia(id_c);
+        vec3 omega_c = c.body_w(id_c);
+        int axis_start = m.joint_qd_start[j];
+        int target_axis_start = m.joint_tq_start[j];
+        int lin_count = m.joint_lin_count[j], ang_count = m.joint_ang_count[j];
+
+        if (dot(q_p, q_c) < 0.0f) q_c = q_c * -1.0f;
+        quat rel_q = quat_inverse(q_p) * q_c;
+        quat qtwist = normalize(quat(rel_q.x, 0.0f, 0.0f, rel_q.w));
+        quat qswing = rel_q * quat_inverse(qtwist);
+        float s = __fsqrt_rn(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
+        float invs = 1.0f / s;
+        float invscube = invs * invs * invs;
+        float err_0 = 2.0f * asinf(clampf(qtwist.x, -1.0f, 1.0f));
+        float err_1 = qswing.y, err_2 = qswing.z;
+        quat grad_0(invs - rel_q.x * rel_q.x * invscube, 0.0f, 0.0f, -(rel_q.w * rel_q.x) * invscube);
+        quat grad_1(-rel_q.w * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube, rel_q.w * invs, -rel_q.x * invs,
+                    rel_q.x * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube);
+        quat grad_2(rel_q.w * (rel_q.w * rel_q.y - rel_q.x * rel_q.z) * invscube, rel_q.x * invs, rel_q.w * invs,
+                    rel_q.x * (rel_q.z * rel_q.x - rel_q.w * rel_q.y) * invscube);
+        grad_0 = grad_0 * (2.0f / fabsf(qtwist.w));
+        float swing_sq = qswing.w * qswing.w;
+        if (swing_sq + 1.0e-4f < 1.0f) {
+            float d = __fsqrt_rn(1.0f - qswing.w * qswing.w);
+            float theta = 2.0f * acosf(clampf(qswing.w, -1.0f, 1.0f));
+            float scale = theta / d;
+            err_1 *= scale;
+            err_2 *= scale;
+            grad_1 = grad_1 * scale;
+            grad_2 = grad_2 * scale;
+        }
+        AxisData A = gather_axes(c, ang_count, axis_start + lin_count, target_axis_start + lin_count);
+#pragma unroll
+        for (int dim = 0; dim < 3; ++dim) {
+            float e = dim == 0 ? err_0 : (dim == 1 ? err_1 : err_2);
+            quat grad = dim == 0 ? grad_0 : (dim == 1 ? grad_1 : grad_2);
+            quat quat_c = 0.5f * q_p * grad * quat_inverse(q_c);
+            vec3 angular_c(quat_c.x, quat_c.y, quat_c.z);
+            vec3 angular_p = -angular_c;
+            float derr = dot(angular_p, omega_p) + dot(angular_c, omega_c);
+            float err = 0.0f;
+            float compliance = P.joint_angular_compliance;
+            float damping = 0.0f;
+            float derr_rel = derr - vget(A.target_vel, dim) * length(angular_c);
+            float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
+            if (e < lower) err = e - lower;
+            else if (e > upper) err = e - upper;
+            else {
+                float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
+                float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
+                if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
+                else if (dm > 0.0f) { damping = dm; compliance = 1.0f / dm; }
+            }
+            float d_lambda = angular_correction(err, derr_rel, rot_p, rot_c, I_inv_p, I_inv_c, angular_p, angular_c, 0.0f,
+                                                compliance, damping, dt) * P.joint_angular_relaxation;
+            vec3 t = angular_c * d_lambda;
+            if (dim == 0) t0 = t;
+            else if (dim == 1) t1 = t;
+            else t2 = t;
+        }
+    }
+    c.st_lv3(c.L.ja, 0, nj, j, t0);
+    c.st_lv3(c.L.ja, 3, nj, j, t1);
+    c.st_lv3(c.L.ja, 6, nj, j, t2);
+}
+
 template <int EPB>
 NT_DI void phase_joints(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int j = c.slot; j < c.a.m.nj; j += c.nslot) joints_item(c, j);
+    const int nj = c.a.m.nj;
+    for (int i = c.slot; i < 2 * nj; i += c.nslot) {
+        if (i < nj) joint_linear_item(c, i);
+        else joint_angular_item(c, i - nj);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1012,78 +1100,82 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
 // ------------------------------------------------------------------------------------------------
 template <int EPB>
 NT_DI void do_collide(const Ctx<EPB>& c) {
+    if (c.a.debug_skip & 1) return;
     phase_shapes(c);
     __syncthreads();
     phase_pairs(c);
-    __syncthreads();
+    __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
     phase_contact_count(c);
     __syncthreads();
 }
 
 // SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
 template <int EPB>
-NT_DI void do_xpbd_step(const Ctx<EPB>& c) {
+NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
-    phase_joint_forces(c);
-    __syncthreads();
-    phase_integrate(c);
-    __syncthreads();
+    const int skip = c.a.debug_skip;
+    if (!(skip & 2)) {
+        phase_joint_forces(c, forces_are_zero);
+        __syncthreads();
+        phase_integrate(c);
+        __syncthreads();
+    }
     for (int it = 0; it < c.a.p.iterations; ++it) {
         if (c.a.has_contacts) {
-            phase_contacts(c);
+            if (!(skip & 4)) phase_contacts(c);
             __syncthreads();
-            phase_apply<EPB, true>(c);
+            if (!(skip & 16)) phase_apply<EPB, true>(c);
             __syncthreads();
         }
         if (m.nj > 0) {
-            phase_joints(c);
+            if (!(skip & 8)) phase_joints(c);
             __syncthreads();
-            phase_apply<EPB, false>(c);
+            if (!(skip & 16)) phase_apply<EPB, false>(c);
             __syncthreads();
         }
     }
 }
 
 template <int EPB>
-__global__ void __launch_bounds__(EPB * 16 > 512 ? 1024 : 512) collide_kernel(KArgs a) {
+__global__ void __launch_bounds__(512) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
     load_state(c, a.s_in);
+    load_params(c, false);
     __syncthreads();
     do_collide(c);
 }
 
 template <int EPB>
-__global__ void __launch_bounds__(EPB * 16 > 512 ? 1024 : 512) xpbd_step_kernel(KArgs a) {
+__global__ void __launch_bounds__(512) xpbd_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
     load_state(c, a.s_in);
+    load_params(c, true);
     __syncthreads();
-    do_xpbd_step(c);
+    do_xpbd_step(c, false);
     store_state(c, a.s_out);
 }
 
-// substeps x { clear_forces; collide; step; swap } with the state resident in LDS across substeps.
+// substeps x { clear_forces; collide; step; swap } with state and parameters resident in LDS across substeps.
 // Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
 // pointer swap); body_f of both states is zeroed as clear_forces would leave it.
 template <int EPB>
-__global__ void __launch_bounds__(EPB * 16 > 512 ? 1024 : 512) xpbd_rollout_kernel(KArgs a) {
+__global__ void __launch_bounds__(512) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
     const int nb = a.m.nb;
     load_state(c, a.s_in);
+    load_params(c, true);
     if (c.valid)
-        for (int b = c.slot; b < nb; b += c.nslot) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                a.s_in.body_f[c.g(k, nb, b)] = 0.0f;
-                a.s_out.body_f[c.g(k, nb, b)] = 0.0f;
-            }
+        for (int r = c.slot; r < 6 * nb; r += c.nslot) {
+            a.s_in.body_f[(size_t)r * c.ES + c.env] = 0.0f;
+            a.s_out.body_f[(size_t)r * c.ES + c.env] = 0.0f;
         }
     __syncthreads();
     for (int s = 0; s < a.substeps; ++s) {
         do_collide(c);
-        do_xpbd_step(c);
+        do_xpbd_step(c, true);
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
 }
@@ -1174,40 +1266,50 @@ __global__ void contacts_export_kernel(ExportArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-// slot-threads per env: enough for the widest per-env population, capped so a block stays <= 512 threads
-// (<= 1024 at EPB 64); phases with more items than slot-threads loop.
+constexpr int MAX_THREADS = 512;
+constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
+
+// slot-threads per env: enough for the widest per-env population (contact slots, joint parts, bodies, shapes,
+// pairs), capped by the block size; phases with more items than slot-threads loop.
 int slots_for(const nt_model& m, int epb) {
-    int want = imax(imax(m.nb, m.nj), imax(m.ns, m.np));
-    int cap = (epb == 64 ? 1024 : 512) / epb;
+    int want = imax(imax(m.nb, 2 * m.nj), imax(imax(m.ns, m.np), m.np * m.cpp));
+    int cap = MAX_THREADS / epb;
     return want < cap ? want : cap;
 }
 
+bool epb_fits(const nt_model& m, int epb) {
+    return (size_t)make_layout(m).rows_per_env * 4 * epb <= LDS_BYTES_PER_CU;
+}
+
 int pick_epb(const nt_model& m, int requested) {
-    LdsLayout L = make_layout(m.nb, m.nj, m.np, m.ns);
-    auto fits = [&](int epb) { return (size_t)L.floats_per_env * 4 * epb <= 160 * 1024; };
-    if (requested == 16 || requested == 32 || requested == 64) return fits(requested) ? requested : 0;
-    // auto: the widest tile that still gives >= 2 workgroups per CU worth of blocks (256 CUs), else the smallest
-    const int cands[3] = {64, 32, 16};
-    for (int i = 0; i < 3; ++i) {
+    if (requested == 8 || requested == 16 || requested == 32 || requested == 64) return epb_fits(m, requested) ? requested : 0;
+    // auto: the widest tile (best coalescing) that still yields >= 256 workgroups (one per CU); else the narrowest
+    const int cands[4] = {64, 32, 16, 8};
+    for (int i = 0; i < 4; ++i) {
         int epb = cands[i];
-        if (!fits(epb)) continue;
+        if (!epb_fits(m, epb)) continue;
         int blocks = (m.env_count + epb - 1) / epb;
-        if (blocks >= 512 || epb == 16) return epb;
+        if (blocks >= 256 || epb == 8) return epb;
     }
-    for (int i = 2; i >= 0; --i)
-        if (fits(cands[i])) return cands[i];
+    for (int i = 3; i >= 0; --i)
+        if (epb_fits(m, cands[i])) return cands[i];
     return 0;
 }
 
 template <typename K>
 nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
-    LdsLayout L = make_layout(a.m.nb, a.m.nj, a.m.np, a.m.ns);
+    LdsLayout L = make_layout(a.m);
     int nslot = slots_for(a.m, epb);
     a.nslot = nslot;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("NT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; }
+        a.debug_skip = dbg;
+    }
     int threads = ((nslot * epb + 63) / 64) * 64;
-    size_t lds_bytes = (size_t)L.floats_per_env * 4 * epb;
+    size_t lds_bytes = (size_t)L.rows_per_env * 4 * epb;
     int blocks = (a.m.env_count + epb - 1) / epb;
-    if (lds_bytes > 64 * 1024) {
+    if (lds_bytes > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return NT_ERR_LAUNCH;
     }
@@ -1215,9 +1317,10 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 
-#define NT_DISPATCH_EPB(KERNEL, args, epb, stream)                                \
-    ((epb) == 64 ? launch(KERNEL<64>, args, 64, stream)                           \
-                 : ((epb) == 32 ? launch(KERNEL<32>, args, 32, stream) : launch(KERNEL<16>, args, 16, stream)))
+#define NT_DISPATCH_EPB(KERNEL, args, epb, stream)                                      \
+    ((epb) == 64 ? launch(KERNEL<64>, args, 64, stream)                                 \
+     : (epb) == 32 ? launch(KERNEL<32>, args, 32, stream)                               \
+     : (epb) == 16 ? launch(KERNEL<16>, args, 16, stream) : launch(KERNEL<8>, args, 8, stream))
 
 bool model_ok(const nt_model* m) {
     return m && m->env_count > 0 && m->env_stride >= m->env_count && (m->env_stride % 64) == 0 && m->nb > 0 &&
@@ -1245,7 +1348,7 @@ const char* nt_build_info(void) { return "libnewton_hip gfx950 (CDNA4) fp32, -ff
 
 int32_t nt_lds_bytes_per_env(const nt_model* m) {
     if (!m) return -1;
-    return make_layout(m->nb, m->nj, m->np, m->ns).floats_per_env * 4;
+    return make_layout(*m).rows_per_env * 4;
 }
 
 nt_status nt_clear_forces(const nt_model* m, nt_state* s, void* stream) {

@@ -56,7 +56,7 @@ def _compare_contacts(model, contacts, oc, pairs_oracle):
         assert np.max(np.abs(g - w)) <= 1e-5, name
 
 
-@pytest.mark.parametrize("n_env,epb", [(1, 0), (5, 16), (64, 32), (130, 64), (257, 0)])
+@pytest.mark.parametrize("n_env,epb", [(1, 0), (5, 16), (64, 8), (130, 16), (257, 0)])
 def test_quadruped_single_step(n_env, epb):
     from oracle_bridge import OracleState
     from scenes import quadruped_scene
