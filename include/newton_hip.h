@@ -83,9 +83,9 @@ typedef struct {
     const int32_t* pair_b;              /* [np] */
     /* ordered incidence lists (CSR) used for deterministic, tid-ordered reductions */
     const int32_t* body_joint_start;    /* [nb+1] */
-    const int32_t* body_joint_list;     /* joint*2 + (1 if body is the child else 0), ascending joint; parent entry first */
+    const int32_t* body_joint_list;     /* [2*nj] (padded) joint*2 + (1 if body is the child else 0), ascending joint; parent entry first */
     const int32_t* body_pair_start;     /* [nb+1] */
-    const int32_t* body_pair_list;      /* pair*2 + (1 if the body owns pair_b's shape else 0), ascending pair */
+    const int32_t* body_pair_list;      /* [2*np] (padded) pair*2 + (1 if the body owns pair_b's shape else 0), ascending pair */
     /* per-env parameters, float SoA */
     const float* body_param;            /* [NT_BODY_PARAM_FLOATS][nb][ES] */
     const float* gravity;               /* [3][ES] */

@@ -56,6 +56,7 @@ struct LdsLayout {
     int sp;            // shape params [19][ns]
     int cf, ctq, ctqd; // control: joint_f [nd], joint_target_q [ntq], joint_target_qd [nd]
     int grav;          // gravity [3]
+    int bd;            // body-derived [9][nb]: world COM (3) + world-frame inverse inertia R I^-1 R^T (xx xy xz yy yz zz)
     // scratch union
     int u;
     int sx, sa, pc;    // collide: shape world xform [7][ns], aabb [6][ns], per-pair contact count [np]
@@ -78,6 +79,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     L.ctq = o; o += m.ntq;
     L.ctqd = o; o += m.nd;
     L.grav = o; o += 3;
+    L.bd = o; o += 9 * m.nb;
     L.u = o;
     L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
     int coll = 13 * m.ns + m.np;
@@ -104,9 +106,20 @@ struct KArgs {
     int debug_skip;  // ablation bitmask (NT_DEBUG_SKIP env var): 1 collide, 2 forces+integrate, 4 contacts, 8 joints, 16 apply
 };
 
+// env-uniform topology, staged once per workgroup into LDS (block-shared ints behind the per-env rows)
+struct Topo {
+    const int *body_flags, *joint_type, *joint_enabled, *joint_parent, *joint_child, *joint_q_start, *joint_qd_start,
+        *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
+        *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list;
+};
+__host__ __device__ inline int topo_ints(const nt_model& m) {
+    return m.nb + 9 * m.nj + 4 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np;
+}
+
 template <int EPB>
 struct Ctx {
     const KArgs& a;
+    Topo T;
     float* lds;
     LdsLayout L;
     int e, slot, env, nslot;
@@ -121,6 +134,34 @@ struct Ctx {
         env = blockIdx.x * EPB + e;
         ES = a.m.env_stride;
         valid = env < a.m.env_count && slot < nslot;
+        const nt_model& m = a.m;
+        int* ti = reinterpret_cast<int*>(lds + (size_t)L.rows_per_env * EPB);
+        int o = 0;
+        auto take = [&](const int*& dst, const int32_t* src, int n) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) ti[o + i] = src[i];
+            dst = ti + o;
+            o += n;
+        };
+        take(T.body_flags, m.body_flags, m.nb);
+        take(T.joint_type, m.joint_type, m.nj);
+        take(T.joint_enabled, m.joint_enabled, m.nj);
+        take(T.joint_parent, m.joint_parent, m.nj);
+        take(T.joint_child, m.joint_child, m.nj);
+        take(T.joint_q_start, m.joint_q_start, m.nj);
+        take(T.joint_qd_start, m.joint_qd_start, m.nj);
+        take(T.joint_tq_start, m.joint_tq_start, m.nj);
+        take(T.joint_lin_count, m.joint_lin_count, m.nj);
+        take(T.joint_ang_count, m.joint_ang_count, m.nj);
+        take(T.shape_body, m.shape_body, m.ns + m.ng);
+        take(T.shape_type, m.shape_type, m.ns + m.ng);
+        take(T.shape_flags, m.shape_flags, m.ns + m.ng);
+        take(T.shape_group, m.shape_group, m.ns + m.ng);
+        take(T.pair_a, m.pair_a, m.np);
+        take(T.pair_b, m.pair_b, m.np);
+        take(T.body_joint_start, m.body_joint_start, m.nb + 1);
+        take(T.body_joint_list, m.body_joint_list, 2 * m.nj);  // padded to 2*nj entries by the host
+        take(T.body_pair_start, m.body_pair_start, m.nb + 1);
+        take(T.body_pair_list, m.body_pair_list, 2 * m.np);    // padded to 2*np entries by the host
     }
     // LDS element: row = field offset + comp * slots_in_field + slot
     NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * EPB + e]; }
@@ -160,6 +201,27 @@ struct Ctx {
     NT_DI mat33 inv_inertia(int b) const { return lm33(L.bp, BP_INV_INERTIA, a.m.nb, b); }
     NT_DI mat33 inertia(int b) const { return lm33(L.bp, BP_INERTIA, a.m.nb, b); }
     NT_DI vec3 com(int b) const { return lv3(L.bp, BP_COM, a.m.nb, b); }
+    NT_DI vec3 world_com(int b) const { return lv3(L.bd, 0, a.m.nb, b); }
+    // a^T (R I^-1 R^T) a for body b (world-frame inverse inertia, symmetric 6-float tile in LDS)
+    NT_DI float w_quad(int b, vec3 v) const {
+        const int nb = a.m.nb;
+        float xx = l(L.bd, 3, nb, b), xy = l(L.bd, 4, nb, b), xz = l(L.bd, 5, nb, b);
+        float yy = l(L.bd, 6, nb, b), yz = l(L.bd, 7, nb, b), zz = l(L.bd, 8, nb, b);
+        vec3 wv(xx * v.x + xy * v.y + xz * v.z, xy * v.x + yy * v.y + yz * v.z, xz * v.x + yz * v.y + zz * v.z);
+        return dot(v, wv);
+    }
+    NT_DI void update_body_derived(int b) const {
+        const int nb = a.m.nb;
+        xform X = body_q(b);
+        st_lv3(L.bd, 0, nb, b, xform_point(X, com(b)));
+        mat33 R = quat_to_matrix(X.q);
+        mat33 Ii = inv_inertia(b);
+        // T = I^-1 R^T ; W = R T
+        vec3 t0 = Ii * vec3(R.m00, R.m01, R.m02), t1 = Ii * vec3(R.m10, R.m11, R.m12), t2 = Ii * vec3(R.m20, R.m21, R.m22);
+        vec3 r0(R.m00, R.m01, R.m02), r1(R.m10, R.m11, R.m12), r2(R.m20, R.m21, R.m22);
+        l(L.bd, 3, nb, b) = dot(r0, t0); l(L.bd, 4, nb, b) = dot(r0, t1); l(L.bd, 5, nb, b) = dot(r0, t2);
+        l(L.bd, 6, nb, b) = dot(r1, t1); l(L.bd, 7, nb, b) = dot(r1, t2); l(L.bd, 8, nb, b) = dot(r2, t2);
+    }
     NT_DI float dof(int row, int d) const { return l(L.dp, row, a.m.nd, d); }
     NT_DI vec3 dof_axis(int d) const { return lv3(L.dp, DP_AXIS, a.m.nd, d); }
 
@@ -216,7 +278,7 @@ NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
         int comp = r / nb, b = r - comp * nb;
         float v = m.body_param[(size_t)r * c.ES + c.env];
         bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
-        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;
+        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
         c.lds[(c.L.bp + r) * EPB + c.e] = v;
     }
     stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS * m.nj);
@@ -297,11 +359,11 @@ NT_DI void phase_shapes(const Ctx<EPB>& c) {
     const nt_model& m = c.a.m;
     if (!c.valid) return;
     for (int s = c.slot; s < m.ns; s += c.nslot) {
-        int body = m.shape_body[s];
+        int body = c.T.shape_body[s];
         xform X = c.shape_local_xform(s);
         if (body >= 0) X = c.body_q(body) * X;
         vec3 lo, hi;
-        shape_aabb(m.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
         c.st_lxf(c.L.sx, m.ns, s, X);
         c.st_lv3(c.L.sa, 0, m.ns, s, lo);
         c.st_lv3(c.L.sa, 3, m.ns, s, hi);
@@ -317,29 +379,34 @@ NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {
         hi = c.lv3(c.L.sa, 3, m.ns, s);
     } else {
         X = c.shape_local_xform(s);  // global shapes are static (shape_body == -1)
-        shape_aabb(m.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
     }
 }
 
 // broad phase test (broad_phase_common.py:20-38, cutoff 0: AABBs are pre-expanded) + narrow phase primitive
-// dispatch (narrow_phase.py:458-1014) + contact writer (collide.py:166-254)
+// dispatch (narrow_phase.py:458-1014) + contact writer (collide.py:166-254).
+// One lane per CONTACT SLOT (pair p = slot / cpp, sub-contact k = slot % cpp): the cpp lanes of a pair evaluate the
+// same analytic pair redundantly (they are otherwise idle) and lane k writes the k-th admitted contact, so the
+// world->body conversion and the 19 stores per contact run in parallel instead of 4-deep in one thread.
 template <int EPB>
-NT_DI void pair_item(const Ctx<EPB>& c, const int p) {
+NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
     const int cpp = m.cpp;
     const int ncs = m.np * cpp;
-    int sa = m.pair_a[p], sb = m.pair_b[p];
+    const int p = slot / cpp, k = slot - p * cpp;
+    int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
     xform Xa, Xb;
     vec3 loa, hia, lob, hib;
     shape_world(c, sa, Xa, loa, hia);
     shape_world(c, sb, Xb, lob, hib);
     bool hit = loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z;
-    ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+    if (k == 0) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
 
     int nvalid = 0;
+    bool wrote = false;
     if (hit) {
-        int ta = m.shape_type[sa], tb = m.shape_type[sb];
+        int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
         if (ta > tb) {  // sort by type (narrow_phase.py:525-528)
             int t = sa; sa = sb; sb = t;
             t = ta; ta = tb; tb = t;
@@ -356,24 +423,33 @@ NT_DI void pair_item(const Ctx<EPB>& c, const int p) {
             primitive_pair(ta, tb, Xa, Xb, scale_a, scale_b, gap_sum + margin_a + margin_b, k4);
             float total_sep = ra + rb + margin_a + margin_b;
             vec3 n = normalize(k4.normal);
-            int ba = m.shape_body[sa], bb = m.shape_body[sb];
-            xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q(ba));
-            xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q(bb));
-            float off_a = ra + margin_a, off_b = rb + margin_b;
-            int gid_a = c.newton_shape_id(sa), gid_b = c.newton_shape_id(sb);
+            // admission test for all four candidates (contact_data.py:139-157); lane k keeps the k-th admitted one
+            float my_dist = 0.0f;
+            vec3 my_center;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float dist = k4.dist(k);
-                if (!(dist < NT_MAXVAL)) continue;
-                vec3 center = k4.pos(k);
-                vec3 aw = center - n * (0.5f * dist + ra);
-                vec3 bw = center + n * (0.5f * dist + rb);
-                float d = dot(bw - aw, n) - total_sep;
-                if (!(d <= gap_sum)) continue;
-                int slot = p * cpp + nvalid;
+            for (int i = 0; i < 4; ++i) {
+                float dist = k4.dist(i);
+                bool ok = dist < NT_MAXVAL;
+                if (ok) {
+                    vec3 center = k4.pos(i);
+                    vec3 aw = center - n * (0.5f * dist + ra);
+                    vec3 bw = center + n * (0.5f * dist + rb);
+                    float d = dot(bw - aw, n) - total_sep;
+                    ok = d <= gap_sum;
+                    if (ok && nvalid == k) { my_dist = dist; my_center = center; wrote = true; }
+                }
+                nvalid += ok ? 1 : 0;
+            }
+            if (wrote) {
+                int ba = c.T.shape_body[sa], bb = c.T.shape_body[sb];
+                xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q(ba));
+                xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q(bb));
+                float off_a = ra + margin_a, off_b = rb + margin_b;
+                vec3 aw = my_center - n * (0.5f * my_dist + ra);
+                vec3 bw = my_center + n * (0.5f * my_dist + rb);
                 size_t gi = (size_t)slot * c.ES + c.env;
-                ct.shape0[gi] = gid_a;
-                ct.shape1[gi] = gid_b;
+                ct.shape0[gi] = c.newton_shape_id(sa);
+                ct.shape1[gi] = c.newton_shape_id(sb);
                 float* D = ct.data;
                 vec3 p0 = xform_point(Xbw_a, aw), p1 = xform_point(Xbw_b, bw);
                 vec3 o0 = xform_vector(Xbw_a, off_a * n), o1 = xform_vector(Xbw_b, -off_b * n);
@@ -384,22 +460,22 @@ NT_DI void pair_item(const Ctx<EPB>& c, const int p) {
                 D[c.g(CD_NORMAL + 0, ncs, slot)] = n.x; D[c.g(CD_NORMAL + 1, ncs, slot)] = n.y; D[c.g(CD_NORMAL + 2, ncs, slot)] = n.z;
                 D[c.g(CD_MARGIN0, ncs, slot)] = off_a;
                 D[c.g(CD_MARGIN1, ncs, slot)] = off_b;
-                nvalid += 1;
             }
         }
         // pairs routed to the convex (MPR/GJK) path are handled by nt_convex (next round): no contacts yet
     }
-    for (int k = nvalid; k < cpp; ++k) {
-        size_t gi = (size_t)(p * cpp + k) * c.ES + c.env;
+    if (!wrote) {
+        size_t gi = (size_t)slot * c.ES + c.env;
         ct.shape0[gi] = -1;
         ct.shape1[gi] = -1;
     }
-    c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+    if (k == 0) c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
 }
 template <int EPB>
 NT_DI void phase_pairs(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int p = c.slot; p < c.a.m.np; p += c.nslot) pair_item(c, p);
+    const int ncs = c.a.m.np * c.a.m.cpp;
+    for (int s = c.slot; s < ncs; s += c.nslot) collide_slot_item(c, s);
 }
 
 template <int EPB>
@@ -425,9 +501,9 @@ NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
         c.lds[(c.L.bf + r) * EPB + c.e] = forces_are_zero ? 0.0f : c.a.s_in.body_f[(size_t)r * c.ES + c.env];
     for (int j = c.slot; j < nj; j += c.nslot) {
         vec3 fp, tp, fc, tc;  // parent wrench (subtracted), child wrench (added)
-        int type = m.joint_type[j];
-        if (m.joint_enabled[j] && type != JT_FIXED && type != JT_ROD) {
-            int id_c = m.joint_child[j], id_p = m.joint_parent[j];
+        int type = c.T.joint_type[j];
+        if (c.T.joint_enabled[j] && type != JT_FIXED && type != JT_ROD) {
+            int id_c = c.T.joint_child[j], id_p = c.T.joint_parent[j];
             xform X_pj = c.lxf(c.L.jp, 0, nj, j);
             xform X_cj = c.lxf(c.L.jp, 7, nj, j);
             xform X_wp = X_pj, pose_p = X_pj;
@@ -441,8 +517,8 @@ NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
             xform pose_c = c.body_q(id_c);
             xform X_wc = pose_c * X_cj;
             vec3 r_c = X_wc.p - xform_point(pose_c, c.com(id_c));
-            int qd_start = m.joint_qd_start[j];
-            int lin = m.joint_lin_count[j], ang = m.joint_ang_count[j];
+            int qd_start = c.T.joint_qd_start[j];
+            int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
             vec3 f_total, t_total;
             if (type == JT_FREE || type == JT_DISTANCE) {
                 // joint_f rows qd_start .. qd_start+5 (n = 1 => comp is the row step)
@@ -478,8 +554,8 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int nb = m.nb, nj = m.nj;
     vec3 f0 = c.lv3(c.L.bf, 0, nb, b), t0 = c.lv3(c.L.bf, 3, nb, b);
-    for (int i = m.body_joint_start[b]; i < m.body_joint_start[b + 1]; ++i) {
-        int code = m.body_joint_list[i];
+    for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
+        int code = c.T.body_joint_list[i];
         int j = code >> 1;
         if (code & 1) {
             f0 += c.lv3(c.L.jf, 6, nj, j);
@@ -489,7 +565,7 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
             t0 -= c.lv3(c.L.jf, 3, nj, j);
         }
     }
-    if (m.body_flags[b] & BODY_KINEMATIC) return;  // pass through unchanged
+    if (c.T.body_flags[b] & BODY_KINEMATIC) return;  // pass through unchanged
 
     xform q = c.body_q(b);
     vec3 v0 = c.body_v(b), w0 = c.body_w(b);
@@ -514,6 +590,12 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     c.st_lxf(c.L.bq, nb, b, xform(x1 - quat_rotate(r1, com), r1));
     c.st_lv3(c.L.bqd, 0, nb, b, v1);
     c.st_lv3(c.L.bqd, 3, nb, b, w1);
+    c.update_body_derived(b);
+}
+template <int EPB>
+NT_DI void phase_body_derived(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) c.update_body_derived(b);
 }
 template <int EPB>
 NT_DI void phase_integrate(const Ctx<EPB>& c) {
@@ -524,31 +606,29 @@ NT_DI void phase_integrate(const Ctx<EPB>& c) {
 // ------------------------------------------------------------------------------------------------
 // XPBD constraint helpers (xpbd/kernels.py:2047-2161)
 // ------------------------------------------------------------------------------------------------
-NT_DI float contact_constraint_delta(float err, quat qa, quat qb, float m_inv_a, float m_inv_b, const mat33& I_inv_a,
-                                     const mat33& I_inv_b, vec3 lin_a, vec3 lin_b, vec3 ang_a, vec3 ang_b,
+// Generalised inverse mass of a constraint row: sum |lin|^2 m^-1 + ang^T (R I^-1 R^T) ang.  The reference rotates `ang`
+// into the body frame and applies the body-frame inverse inertia (xpbd/kernels.py:2064-2077); here the body thread has
+// already rotated the inverse inertia into the world frame (Ctx::update_body_derived), which is the same quantity up to
+// fp32 rounding and saves two quaternion rotations + a full 3x3 product per row.  wq_a / wq_b are those angular terms.
+NT_DI float contact_constraint_delta(float err, float m_inv_a, float m_inv_b, vec3 lin_a, vec3 lin_b, float wq_a, float wq_b,
                                      float relaxation, float dt) {
     float denom = 0.0f;
     denom += length_sq(lin_a) * m_inv_a;
     denom += length_sq(lin_b) * m_inv_b;
-    vec3 ra = quat_rotate_inv(qa, ang_a);
-    vec3 rb = quat_rotate_inv(qb, ang_b);
-    denom += dot(ra, I_inv_a * ra);
-    denom += dot(rb, I_inv_b * rb);
+    denom += wq_a;
+    denom += wq_b;
     float delta_lambda = -err;
     if (denom > 0.0f) delta_lambda /= dt * denom;
     return delta_lambda * relaxation;
 }
 
-NT_DI float positional_correction(float err, float derr, quat qa, quat qb, float m_inv_a, float m_inv_b,
-                                  const mat33& I_inv_a, const mat33& I_inv_b, vec3 lin_a, vec3 lin_b, vec3 ang_a,
-                                  vec3 ang_b, float lambda_in, float compliance, float damping, float dt) {
+NT_DI float positional_correction(float err, float derr, float m_inv_a, float m_inv_b, vec3 lin_a, vec3 lin_b, float wq_a,
+                                  float wq_b, float lambda_in, float compliance, float damping, float dt) {
     float denom = 0.0f;
     denom += length_sq(lin_a) * m_inv_a;
     denom += length_sq(lin_b) * m_inv_b;
-    vec3 ra = quat_rotate_inv(qa, ang_a);
-    vec3 rb = quat_rotate_inv(qb, ang_b);
-    denom += dot(ra, I_inv_a * ra);
-    denom += dot(rb, I_inv_b * rb);
+    denom += wq_a;
+    denom += wq_b;
     float alpha = compliance;
     float gamma = compliance * damping;
     float delta_lambda = -(err + alpha * lambda_in + gamma * derr);
@@ -556,13 +636,11 @@ NT_DI float positional_correction(float err, float derr, quat qa, quat qb, float
     return delta_lambda;
 }
 
-NT_DI float angular_correction(float err, float derr, quat qa, quat qb, const mat33& I_inv_a, const mat33& I_inv_b,
-                               vec3 ang_a, vec3 ang_b, float lambda_in, float compliance, float damping, float dt) {
+NT_DI float angular_correction(float err, float derr, float wq_a, float wq_b, float lambda_in, float compliance,
+                               float damping, float dt) {
     float denom = 0.0f;
-    vec3 ra = quat_rotate_inv(qa, ang_a);
-    vec3 rb = quat_rotate_inv(qb, ang_b);
-    denom += dot(ra, I_inv_a * ra);
-    denom += dot(rb, I_inv_b * rb);
+    denom += wq_a;
+    denom += wq_b;
     float alpha = compliance;
     float gamma = compliance * damping;
     float delta_lambda = -(err + alpha * lambda_in + gamma * derr);
@@ -590,8 +668,8 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
     if (live) {
         shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
         shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
-        body_a = shape_a >= 0 ? m.shape_body[shape_a] : -1;
-        body_b = shape_b >= 0 ? m.shape_body[shape_b] : -1;
+        body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1;
+        body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         live = body_a != body_b;
     }
     if (live) {
@@ -605,20 +683,19 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
         float d = dot(n, bx_b - bx_a) - (D[c.g(CD_MARGIN0, ncs, slot)] + D[c.g(CD_MARGIN1, ncs, slot)]);
         if (d < 0.0f) {
             float m_inv_a = 0.0f, m_inv_b = 0.0f;
-            mat33 I_inv_a, I_inv_b;
-            vec3 com_a(0.0f), com_b(0.0f), omega_a(0.0f), omega_b(0.0f);
+            vec3 wc_a(0.0f), wc_b(0.0f), omega_a(0.0f), omega_b(0.0f);  // world COM (origin for static shapes)
             if (body_a >= 0) {
-                com_a = c.com(body_a);
+                wc_a = c.world_com(body_a);
                 m_inv_a = c.inv_mass(body_a);
-                I_inv_a = c.inv_inertia(body_a);
                 omega_a = c.body_w(body_a);
             }
             if (body_b >= 0) {
-                com_b = c.com(body_b);
+                wc_b = c.world_com(body_b);
                 m_inv_b = c.inv_mass(body_b);
-                I_inv_b = c.inv_inertia(body_b);
                 omega_b = c.body_w(body_b);
             }
+            auto wq_a = [&](vec3 v) { return body_a >= 0 ? c.w_quad(body_a, v) : 0.0f; };
+            auto wq_b = [&](vec3 v) { return body_b >= 0 ? c.w_quad(body_b, v) : 0.0f; };
             int mat_nonzero = 0;
             float mu = 0.0f, mu_torsional = 0.0f, mu_rolling = 0.0f;
             if (shape_a >= 0) {
@@ -638,13 +715,12 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
                 mu_torsional /= float(mat_nonzero);
                 mu_rolling /= float(mat_nonzero);
             }
-            vec3 r_a = bx_a - xform_point(X_wb_a, com_a);
-            vec3 r_b = bx_b - xform_point(X_wb_b, com_b);
+            vec3 r_a = bx_a - wc_a;
+            vec3 r_b = bx_b - wc_b;
             vec3 angular_a = -cross(r_a, n);
             vec3 angular_b = cross(r_b, n);
 
-            float lambda_n = contact_constraint_delta(d, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, -n, n,
-                                                      angular_a, angular_b, relaxation, dt);
+            float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, wq_a(angular_a), wq_b(angular_b), relaxation, dt);
             lin_delta_a = -n * lambda_n;
             lin_delta_b = n * lambda_n;
             ang_delta_a = angular_a * lambda_n;
@@ -656,14 +732,14 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
                 bx_b = xform_point(X_wb_b, point1 + offset_b);
                 vec3 delta = bx_b - bx_a;
                 vec3 friction_delta = delta - dot(n, delta) * n;
-                r_a = bx_a - xform_point(X_wb_a, com_a);
-                r_b = bx_b - xform_point(X_wb_b, com_b);
+                r_a = bx_a - wc_a;
+                r_b = bx_b - wc_b;
                 vec3 rel_v_kin_t(0.0f);
-                if (body_a >= 0 && (m.body_flags[body_a] & BODY_KINEMATIC) != 0) {
+                if (body_a >= 0 && (c.T.body_flags[body_a] & BODY_KINEMATIC) != 0) {
                     vec3 v_a = velocity_at_point(spatial(c.body_v(body_a), omega_a), r_a);
                     rel_v_kin_t = rel_v_kin_t - (v_a - dot(n, v_a) * n);
                 }
-                if (body_b >= 0 && (m.body_flags[body_b] & BODY_KINEMATIC) != 0) {
+                if (body_b >= 0 && (c.T.body_flags[body_b] & BODY_KINEMATIC) != 0) {
                     vec3 v_b = velocity_at_point(spatial(c.body_v(body_b), omega_b), r_b);
                     rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
                 }
@@ -673,8 +749,8 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
                 angular_b = cross(r_b, perp);
                 float err = length(friction_delta);
                 if (err > 0.0f) {
-                    float lambda_fr = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b,
-                                                               -perp, perp, angular_a, angular_b, relaxation, dt);
+                    float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, wq_a(angular_a),
+                                                               wq_b(angular_b), relaxation, dt);
                     lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
                     lin_delta_a -= perp * lambda_fr;
                     lin_delta_b += perp * lambda_fr;
@@ -687,8 +763,7 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
                 float err = dot(delta_omega, n) * dt;
                 if (fabsf(err) > 0.0f) {
                     vec3 lin(0.0f);
-                    float lt = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, lin, lin,
-                                                        -n, n, relaxation, dt);
+                    float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-n), wq_b(n), relaxation, dt);
                     lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
                     ang_delta_a -= n * lt;
                     ang_delta_b += n * lt;
@@ -700,8 +775,7 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
                 if (err > 0.0f) {
                     vec3 lin(0.0f);
                     vec3 roll_n = normalize(delta_omega);
-                    float lr = contact_constraint_delta(err, X_wb_a.q, X_wb_b.q, m_inv_a, m_inv_b, I_inv_a, I_inv_b, lin, lin,
-                                                        -roll_n, roll_n, relaxation, dt);
+                    float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-roll_n), wq_b(roll_n), relaxation, dt);
                     lr = fmaxw(lr, -lambda_n * mu_rolling);
                     ang_delta_a -= roll_n * lr;
                     ang_delta_b += roll_n * lr;
@@ -709,7 +783,7 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
             }
             has_a = body_a >= 0 ? 1.0f : 0.0f;
             has_b = body_b >= 0 ? 1.0f : 0.0f;
-            a_is_pair_a = (shape_a == m.pair_a[slot / cpp]) ? 1.0f : 0.0f;
+            a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
         }
     }
     c.st_lv3(c.L.cw, 0, ncs, slot, lin_delta_a);
@@ -742,8 +816,8 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     float inv_weight = 0.0f;
     if (FROM_CONTACTS) {
         const int cpp = m.cpp, ncs = m.np * cpp;
-        for (int i = m.body_pair_start[b]; i < m.body_pair_start[b + 1]; ++i) {
-            int code = m.body_pair_list[i];
+        for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+            int code = c.T.body_pair_list[i];
             int p = code >> 1, side = code & 1;  // side 0: this body owns pair_a's shape
             for (int k = 0; k < cpp; ++k) {
                 int slot = p * cpp + k;
@@ -759,8 +833,8 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
         }
     } else {
         const int nj = m.nj;
-        for (int i = m.body_joint_start[b]; i < m.body_joint_start[b + 1]; ++i) {
-            int code = m.body_joint_list[i];
+        for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
+            int code = c.T.body_joint_list[i];
             int j = code >> 1, side = code & 1;  // side 1: this body is the joint's child
             vec3 jl = c.lv3(c.L.jl, side * 6, nj, j);
             vec3 ja = c.lv3(c.L.jl, side * 6 + 3, nj, j);
@@ -801,6 +875,7 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     if (length(w1) < 1e-4f) w1 = vec3(0.0f);
     c.st_lv3(c.L.bqd, 0, nb, b, v1);
     c.st_lv3(c.L.bqd, 3, nb, b, w1);
+    c.update_body_derived(b);
 }
 template <int EPB, bool FROM_CONTACTS>
 NT_DI void phase_apply(const Ctx<EPB>& c) {
@@ -860,10 +935,10 @@ NT_DI AxisData gather_axes(const Ctx<EPB>& c, int count, int axis_idx0, int targ
 template <int EPB>
 NT_DI bool joint_live(const Ctx<EPB>& c, int j, int& id_p, int& id_c, float& m_inv_p, float& m_inv_c) {
     const nt_model& m = c.a.m;
-    const int type = m.joint_type[j];
-    if (!m.joint_enabled[j] || type == JT_FREE) return false;
-    id_c = m.joint_child[j];
-    id_p = m.joint_parent[j];
+    const int type = c.T.joint_type[j];
+    if (!c.T.joint_enabled[j] || type == JT_FREE) return false;
+    id_c = c.T.joint_child[j];
+    id_p = c.T.joint_parent[j];
     m_inv_p = id_p >= 0 ? c.inv_mass(id_p) : 0.0f;
     m_inv_c = c.inv_mass(id_c);
     return !(m_inv_p == 0.0f && m_inv_c == 0.0f);
@@ -879,34 +954,30 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
     int id_p, id_c;
     float m_inv_p, m_inv_c;
     if (joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
-        const int type = m.joint_type[j];
+        const int type = c.T.joint_type[j];
         xform X_pj = c.lxf(c.L.jp, 0, nj, j);
         xform X_cj = c.lxf(c.L.jp, 7, nj, j);
-        xform X_wp = X_pj, pose_p = X_pj;
-        mat33 I_inv_p;
-        vec3 com_p(0.0f), vel_p(0.0f), omega_p(0.0f);
+        xform X_wp = X_pj;
+        vec3 world_com_p = X_pj.p;  // transform_point(pose_p = X_pj, com_p = 0) for world-attached joints
+        vec3 vel_p(0.0f), omega_p(0.0f);
         if (id_p >= 0) {
-            pose_p = c.body_q(id_p);
-            X_wp = pose_p * X_wp;
-            com_p = c.com(id_p);
-            I_inv_p = c.inv_inertia(id_p);
+            X_wp = c.body_q(id_p) * X_wp;
+            world_com_p = c.world_com(id_p);
             vel_p = c.body_v(id_p);
             omega_p = c.body_w(id_p);
         }
-        xform pose_c = c.body_q(id_c);
-        xform X_wc = pose_c * X_cj;
-        vec3 com_c = c.com(id_c);
-        mat33 I_inv_c = c.inv_inertia(id_c);
+        xform X_wc = c.body_q(id_c) * X_cj;
+        vec3 world_com_c = c.world_com(id_c);
         vec3 vel_c = c.body_v(id_c), omega_c = c.body_w(id_c);
+        auto wq_p = [&](vec3 v) { return id_p >= 0 ? c.w_quad(id_p, v) : 0.0f; };
+        auto wq_c = [&](vec3 v) { return c.w_quad(id_c, v); };
 
         xform rel_pose = xform_inverse(X_wp) * X_wc;
         vec3 rel_p = rel_pose.p;
         vec3 x_p = X_wp.p, x_c = X_wc.p;
-        int axis_start = m.joint_qd_start[j];
-        int target_axis_start = m.joint_tq_start[j];
-        int lin_count = m.joint_lin_count[j];
-        vec3 world_com_p = xform_point(pose_p, com_p);
-        vec3 world_com_c = xform_point(pose_c, com_c);
+        int axis_start = c.T.joint_qd_start[j];
+        int target_axis_start = c.T.joint_tq_start[j];
+        int lin_count = c.T.joint_lin_count[j];
 
         if (type == JT_DISTANCE) {
             vec3 r_p = x_p - world_com_p, r_c = x_c - world_com_c;
@@ -935,8 +1006,8 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
                     float ke = c.dof(DP_TARGET_KE, axis_start);
                     if (ke > 0.0f) compliance = 1.0f / ke;
                     float damping = c.dof(DP_TARGET_KD, axis_start);
-                    float d_lambda = positional_correction(err, derr, pose_p.q, pose_c.q, m_inv_p, m_inv_c, I_inv_p, I_inv_c,
-                                                           linear_p, linear_c, angular_p, angular_c, 0.0f, compliance, damping, dt);
+                    float d_lambda = positional_correction(err, derr, m_inv_p, m_inv_c, linear_p, linear_c, wq_p(angular_p),
+                                                           wq_c(angular_c), 0.0f, compliance, damping, dt);
                     lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
                     ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
                     lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
@@ -978,8 +1049,8 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
                     else if (dm > 0.0f) { compliance = 1.0f / dm; damping = dm; }
                 }
                 if (fabsf(err) > 1e-9f || fabsf(derr_rel) > 1e-9f) {
-                    float d_lambda = positional_correction(err, derr_rel, pose_p.q, pose_c.q, m_inv_p, m_inv_c, I_inv_p, I_inv_c,
-                                                           linear_p, linear_c, angular_p, angular_c, 0.0f, compliance, damping, dt);
+                    float d_lambda = positional_correction(err, derr_rel, m_inv_p, m_inv_c, linear_p, linear_c, wq_p(angular_p),
+                                                           wq_c(angular_c), 0.0f, compliance, damping, dt);
                     lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
                     ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
                     lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
@@ -1003,27 +1074,22 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
     vec3 t0, t1, t2;  // angular_c * d_lambda for the three angular rows (parent gets the negation)
     int id_p, id_c;
     float m_inv_p, m_inv_c;
-    const int type = m.joint_type[j];
+    const int type = c.T.joint_type[j];
     bool angular_type = type == JT_FIXED || type == JT_PRISMATIC || type == JT_REVOLUTE || type == JT_D6;
     if (angular_type && joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
         xform X_pj = c.lxf(c.L.jp, 0, nj, j);
         xform X_cj = c.lxf(c.L.jp, 7, nj, j);
-        quat q_p = X_pj.q, rot_p = X_pj.q;  // pose_p defaults to X_pj for world-attached joints
-        mat33 I_inv_p;
+        quat q_p = X_pj.q;
         vec3 omega_p(0.0f);
         if (id_p >= 0) {
-            rot_p = c.body_rot(id_p);
-            q_p = rot_p * X_pj.q;
-            I_inv_p = c.inv_inertia(id_p);
+            q_p = c.body_rot(id_p) * X_pj.q;
             omega_p = c.body_w(id_p);
         }
-        quat rot_c = c.body_rot(id_c);
-        quat q_c = rot_c * X_cj.q;
-        mat33 I_inv_c = c.inv_inertia(id_c);
+        quat q_c = c.body_rot(id_c) * X_cj.q;
         vec3 omega_c = c.body_w(id_c);
-        int axis_start = m.joint_qd_start[j];
-        int target_axis_start = m.joint_tq_start[j];
-        int lin_count = m.joint_lin_count[j], ang_count = m.joint_ang_count[j];
+        int axis_start = c.T.joint_qd_start[j];
+        int target_axis_start = c.T.joint_tq_start[j];
+        int lin_count = c.T.joint_lin_count[j], ang_count = c.T.joint_ang_count[j];
 
         if (dot(q_p, q_c) < 0.0f) q_c = q_c * -1.0f;
         quat rel_q = quat_inverse(q_p) * q_c;
@@ -1072,8 +1138,9 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
                 if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
                 else if (dm > 0.0f) { damping = dm; compliance = 1.0f / dm; }
             }
-            float d_lambda = angular_correction(err, derr_rel, rot_p, rot_c, I_inv_p, I_inv_c, angular_p, angular_c, 0.0f,
-                                                compliance, damping, dt) * P.joint_angular_relaxation;
+            float wqp = id_p >= 0 ? c.w_quad(id_p, angular_p) : 0.0f;
+            float d_lambda = angular_correction(err, derr_rel, wqp, c.w_quad(id_c, angular_c), 0.0f, compliance, damping, dt) *
+                             P.joint_angular_relaxation;
             vec3 t = angular_c * d_lambda;
             if (dim == 0) t0 = t;
             else if (dim == 1) t1 = t;
@@ -1099,14 +1166,16 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
 // kernels
 // ------------------------------------------------------------------------------------------------
 template <int EPB>
-NT_DI void do_collide(const Ctx<EPB>& c) {
+NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
     if (c.a.debug_skip & 1) return;
     phase_shapes(c);
     __syncthreads();
     phase_pairs(c);
     __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
-    phase_contact_count(c);
-    __syncthreads();
+    if (count_contacts) {  // per-env totals are an API-boundary output, not needed by the solver
+        phase_contact_count(c);
+        __syncthreads();
+    }
 }
 
 // SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
@@ -1137,21 +1206,23 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
 }
 
 template <int EPB>
-__global__ void __launch_bounds__(512) collide_kernel(KArgs a) {
+__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
     load_state(c, a.s_in);
     load_params(c, false);
     __syncthreads();
-    do_collide(c);
+    do_collide(c, true);
 }
 
 template <int EPB>
-__global__ void __launch_bounds__(512) xpbd_step_kernel(KArgs a) {
+__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
     load_state(c, a.s_in);
     load_params(c, true);
+    __syncthreads();
+    phase_body_derived(c);
     __syncthreads();
     do_xpbd_step(c, false);
     store_state(c, a.s_out);
@@ -1161,7 +1232,7 @@ __global__ void __launch_bounds__(512) xpbd_step_kernel(KArgs a) {
 // Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
 // pointer swap); body_f of both states is zeroed as clear_forces would leave it.
 template <int EPB>
-__global__ void __launch_bounds__(512) xpbd_rollout_kernel(KArgs a) {
+__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
     const int nb = a.m.nb;
@@ -1173,8 +1244,10 @@ __global__ void __launch_bounds__(512) xpbd_rollout_kernel(KArgs a) {
             a.s_out.body_f[(size_t)r * c.ES + c.env] = 0.0f;
         }
     __syncthreads();
+    phase_body_derived(c);
+    __syncthreads();
     for (int s = 0; s < a.substeps; ++s) {
-        do_collide(c);
+        do_collide(c, s == a.substeps - 1);
         do_xpbd_step(c, true);
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
@@ -1266,19 +1339,20 @@ __global__ void contacts_export_kernel(ExportArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-constexpr int MAX_THREADS = 512;
+constexpr int MAX_THREADS = 512;  // 256 for EPB <= 8 (see max_threads_for)
+inline int max_threads_for(int epb) { return epb <= 8 ? 256 : 512; }
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
 // slot-threads per env: enough for the widest per-env population (contact slots, joint parts, bodies, shapes,
 // pairs), capped by the block size; phases with more items than slot-threads loop.
 int slots_for(const nt_model& m, int epb) {
     int want = imax(imax(m.nb, 2 * m.nj), imax(imax(m.ns, m.np), m.np * m.cpp));
-    int cap = MAX_THREADS / epb;
+    int cap = max_threads_for(epb) / epb;
     return want < cap ? want : cap;
 }
 
 bool epb_fits(const nt_model& m, int epb) {
-    return (size_t)make_layout(m).rows_per_env * 4 * epb <= LDS_BYTES_PER_CU;
+    return (size_t)make_layout(m).rows_per_env * 4 * epb + (size_t)topo_ints(m) * 4 <= LDS_BYTES_PER_CU;
 }
 
 int pick_epb(const nt_model& m, int requested) {
@@ -1307,7 +1381,7 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
         a.debug_skip = dbg;
     }
     int threads = ((nslot * epb + 63) / 64) * 64;
-    size_t lds_bytes = (size_t)L.rows_per_env * 4 * epb;
+    size_t lds_bytes = (size_t)L.rows_per_env * 4 * epb + (size_t)topo_ints(a.m) * 4;
     int blocks = (a.m.env_count + epb - 1) / epb;
     if (lds_bytes > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)

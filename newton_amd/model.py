@@ -171,7 +171,9 @@ class EnvTemplate:
             if c >= 0:
                 bj[c].append(2 * j + 1)
         self.body_joint_start = np.cumsum([0] + [len(x) for x in bj]).astype(np.int32)
-        self.body_joint_list = np.asarray([c for x in bj for c in x], dtype=np.int32)
+        self.body_joint_list = np.zeros(2 * nj, dtype=np.int32)  # padded to 2*nj (C-ABI contract)
+        flat = [c for x in bj for c in x]
+        self.body_joint_list[:len(flat)] = flat
         bp = [[] for _ in range(nb)]
         for p in range(self.np):
             ba, bb = int(self.shape_body[self.pair_a[p]]), int(self.shape_body[self.pair_b[p]])
@@ -180,7 +182,9 @@ class EnvTemplate:
             if bb >= 0:
                 bp[bb].append(2 * p + 1)
         self.body_pair_start = np.cumsum([0] + [len(x) for x in bp]).astype(np.int32)
-        self.body_pair_list = np.asarray([c for x in bp for c in x], dtype=np.int32)
+        self.body_pair_list = np.zeros(2 * self.np, dtype=np.int32)  # padded to 2*np (C-ABI contract)
+        flat = [c for x in bp for c in x]
+        self.body_pair_list[:len(flat)] = flat
 
 
 class DeviceModel:
