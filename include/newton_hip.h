@@ -177,6 +177,8 @@ nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t ca
 const char* nt_error_string(nt_status s);
 const char* nt_build_info(void);                 /* "gfx950 ..." */
 int32_t nt_lds_bytes_per_env(const nt_model* m); /* LDS footprint of one env in the step kernels */
+/* dst[i] = src[i], 4 B/lane coalesced: known-byte-count kernel used to calibrate the HBM PMC counters */
+nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,7 @@ SYMBOLS = {
     "nt_error_string": (C.c_char_p, [C.c_int32]),
     "nt_build_info": (C.c_char_p, []),
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
+    "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
 }
 
 _lib = None

@@ -1259,6 +1259,14 @@ __global__ void clear_forces_kernel(float* body_f, size_t n) {
     for (; i < n; i += stride) body_f[i] = 0.0f;
 }
 
+// 4 B/lane coalesced copy with a known byte count: calibrates the FETCH_SIZE / WRITE_SIZE PMC counters for this
+// access pattern (MI355X_MICROARCH.md, HBM section)
+__global__ void calibration_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 // AoS [E*nslot][ncomp] <-> SoA [ncomp][nslot][ES]
 __global__ void pack_kernel(const float* __restrict__ aos, float* __restrict__ soa, int ncomp, int nslot, int E, int ES) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1489,6 +1497,12 @@ nt_status nt_semi_implicit_step(const nt_model*, const nt_semi_implicit_params*,
 }
 
 nt_status nt_eval_fk(const nt_model*, const float*, const float*, nt_state*, void*) { return NT_ERR_UNSUPPORTED; }
+
+nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return NT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(calibration_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, src, dst, (size_t)n);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
 
 nt_status nt_pack_aos(const float* aos, float* soa, int32_t ncomp, int32_t nslot, int32_t env_count, int32_t env_stride,
                       void* stream) {
