@@ -48,7 +48,7 @@ typedef int32_t nt_status;
 #define NT_CONTACT_FLOATS 17     /* point0[3] point1[3] offset0[3] offset1[3] normal[3] margin0 margin1 */
 #define NT_BODY_PARAM_FLOATS 23  /* com[3] inv_mass inertia[9] inv_inertia[9] mass */
 #define NT_JOINT_PARAM_FLOATS 14 /* X_p[7] X_c[7] */
-#define NT_DOF_PARAM_FLOATS 10   /* axis[3] limit_lower limit_upper target_ke target_kd limit_ke limit_kd armature */
+#define NT_DOF_PARAM_FLOATS 11   /* axis[3] limit_lower limit_upper target_ke target_kd limit_ke limit_kd armature damping */
 #define NT_SHAPE_PARAM_FLOATS 19 /* xform[7] scale[3] margin gap mu mu_torsional mu_rolling ke kd kf ka */
 
 /* Model: env-uniform topology + per-env parameters (Newton: newton/_src/sim/model.py:808-1364) */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NEWTON_HIP_LIB", os.path.join(_HERE, "libnewton_hip.s
 NT_CONTACT_FLOATS = 17
 NT_BODY_PARAM_FLOATS = 23
 NT_JOINT_PARAM_FLOATS = 14
-NT_DOF_PARAM_FLOATS = 10
+NT_DOF_PARAM_FLOATS = 11
 NT_SHAPE_PARAM_FLOATS = 19
 
 _i32p = C.POINTER(C.c_int32)

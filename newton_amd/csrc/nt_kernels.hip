@@ -36,9 +36,11 @@ constexpr int BODY_KINEMATIC = 2;
 // body_param rows
 constexpr int BP_COM = 0, BP_INV_MASS = 3, BP_INERTIA = 4, BP_INV_INERTIA = 13, BP_MASS = 22;
 // dof_param rows
-constexpr int DP_AXIS = 0, DP_LIMIT_LOWER = 3, DP_LIMIT_UPPER = 4, DP_TARGET_KE = 5, DP_TARGET_KD = 6;
+constexpr int DP_AXIS = 0, DP_LIMIT_LOWER = 3, DP_LIMIT_UPPER = 4, DP_TARGET_KE = 5, DP_TARGET_KD = 6, DP_LIMIT_KE = 7,
+              DP_LIMIT_KD = 8, DP_ARMATURE = 9, DP_DAMPING = 10;
 // shape_param rows
-constexpr int SP_XFORM = 0, SP_SCALE = 7, SP_MARGIN = 10, SP_GAP = 11, SP_MU = 12, SP_MU_TORSIONAL = 13, SP_MU_ROLLING = 14;
+constexpr int SP_XFORM = 0, SP_SCALE = 7, SP_MARGIN = 10, SP_GAP = 11, SP_MU = 12, SP_MU_TORSIONAL = 13, SP_MU_ROLLING = 14,
+              SP_KE = 15, SP_KD = 16, SP_KF = 17, SP_KA = 18;
 // contact data rows
 constexpr int CD_POINT0 = 0, CD_POINT1 = 3, CD_OFFSET0 = 6, CD_OFFSET1 = 9, CD_NORMAL = 12, CD_MARGIN0 = 15, CD_MARGIN1 = 16;
 // per-contact correction record in LDS: lin_a, ang_a, lin_b, ang_b, has_a, has_b, shape0_is_pair_a
@@ -63,6 +65,7 @@ struct LdsLayout {
     int bf, jf;        // forces: body_f_tmp [6][nb], joint wrenches [12][nj]
     int jl, ja;        // joints: linear-part corrections [12][nj], angular-part child terms [9][nj]
     int cw;            // contacts: per-contact corrections [CW_FLOATS][np*cpp]
+    int si_jf, si_cw;  // semi-implicit: joint wrenches + contact wrenches live together with body_f_tmp
     int rows_per_env;
 };
 
@@ -89,7 +92,9 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     int joints = 21 * m.nj;
     L.cw = L.u;
     int contacts = CW_FLOATS * m.np * m.cpp;
-    L.rows_per_env = L.u + imax(imax(coll, forces), imax(joints, contacts));
+    L.si_jf = L.bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
+    int semi = 6 * m.nb + 12 * m.nj + contacts;
+    L.rows_per_env = L.u + imax(imax(imax(coll, forces), imax(joints, contacts)), semi);
     return L;
 }
 
@@ -99,6 +104,8 @@ struct KArgs {
     nt_control c;
     nt_contacts ct;
     nt_xpbd_params p;
+    nt_semi_implicit_params sp;
+    float angular_damping;  // integrate_bodies damping of the active solver
     float dt;
     int substeps;
     int has_contacts;
@@ -549,7 +556,10 @@ NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
 
 // body thread: fold joint wrenches into body_f_tmp in ascending-joint order, then integrate_bodies
 // (solver.py:63-170)
-template <int EPB>
+// SEMI = false: XPBD (apply_joint_forces wrenches: parent subtracted, child added).
+// SEMI = true : SolverSemiImplicit (eval_body_joints: parent added, child subtracted; then eval_body_contact: shape0's
+//               body subtracted, shape1's body added), all in ascending joint / contact order.
+template <int EPB, bool SEMI>
 NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int nb = m.nb, nj = m.nj;
@@ -557,12 +567,26 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
         int code = c.T.body_joint_list[i];
         int j = code >> 1;
-        if (code & 1) {
-            f0 += c.lv3(c.L.jf, 6, nj, j);
-            t0 += c.lv3(c.L.jf, 9, nj, j);
-        } else {
-            f0 -= c.lv3(c.L.jf, 0, nj, j);
-            t0 -= c.lv3(c.L.jf, 3, nj, j);
+        bool add = SEMI ? !(code & 1) : (code & 1);
+        int row = (code & 1) ? 6 : 0;
+        vec3 f = c.lv3(c.L.jf, row, nj, j), t = c.lv3(c.L.jf, row + 3, nj, j);
+        if (add) { f0 += f; t0 += t; }
+        else { f0 -= f; t0 -= t; }
+    }
+    if (SEMI && c.a.has_contacts) {
+        const int cpp = m.cpp, ncs = m.np * cpp;
+        for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+            int code = c.T.body_pair_list[i];
+            int p = code >> 1, side = code & 1;
+            for (int k = 0; k < cpp; ++k) {
+                int slot = p * cpp + k;
+                bool is_a = (side == 0) == (c.l(c.L.si_cw, 14, ncs, slot) != 0.0f);
+                if (c.l(c.L.si_cw, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                    vec3 f = c.lv3(c.L.si_cw, is_a ? 0 : 6, ncs, slot), t = c.lv3(c.L.si_cw, is_a ? 3 : 9, ncs, slot);
+                    if (is_a) { f0 -= f; t0 -= t; }
+                    else { f0 += f; t0 += t; }
+                }
+            }
         }
     }
     if (c.T.body_flags[b] & BODY_KINEMATIC) return;  // pass through unchanged
@@ -586,7 +610,7 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     vec3 tb = quat_rotate_inv(r0, t0) - cross(wb, inertia * wb);
     vec3 w1 = quat_rotate(r0, wb + inv_inertia * tb * dt);
     quat r1 = normalize(r0 + quat(w1, 0.0f) * r0 * 0.5f * dt);
-    w1 *= 1.0f - c.a.p.angular_damping * dt;
+    w1 *= 1.0f - c.a.angular_damping * dt;
     c.st_lxf(c.L.bq, nb, b, xform(x1 - quat_rotate(r1, com), r1));
     c.st_lv3(c.L.bqd, 0, nb, b, v1);
     c.st_lv3(c.L.bqd, 3, nb, b, w1);
@@ -597,10 +621,10 @@ NT_DI void phase_body_derived(const Ctx<EPB>& c) {
     if (!c.valid) return;
     for (int b = c.slot; b < c.a.m.nb; b += c.nslot) c.update_body_derived(b);
 }
-template <int EPB>
+template <int EPB, bool SEMI>
 NT_DI void phase_integrate(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) integrate_item(c, b);
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) integrate_item<EPB, SEMI>(c, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1186,7 +1210,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     if (!(skip & 2)) {
         phase_joint_forces(c, forces_are_zero);
         __syncthreads();
-        phase_integrate(c);
+        phase_integrate<EPB, false>(c);
         __syncthreads();
     }
     for (int it = 0; it < c.a.p.iterations; ++it) {
@@ -1251,6 +1275,256 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArg
         do_xpbd_step(c, true);
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// SolverSemiImplicit (solver_semi_implicit.py:123-217): penalty joints + penalty contacts -> integrate_bodies
+// ------------------------------------------------------------------------------------------------
+// joint_force (semi_implicit/kernels_body.py:17-52)
+NT_DI float si_joint_force(float q, float qd, float target_q, float target_qd, float target_ke, float target_kd,
+                           float limit_lower, float limit_upper, float limit_ke, float limit_kd, float damping) {
+    float limit_f = 0.0f, damping_f = 0.0f;
+    float target_f = target_ke * (target_q - q) + target_kd * (target_qd - qd);
+    if (q < limit_lower) {
+        limit_f = limit_ke * (limit_lower - q);
+        damping_f = -limit_kd * qd;
+        target_f = 0.0f;
+    } else if (q > limit_upper) {
+        limit_f = limit_ke * (limit_upper - q);
+        damping_f = -limit_kd * qd;
+        target_f = 0.0f;
+    }
+    float passive_f = -damping * qd;
+    return limit_f + damping_f + target_f + passive_f;
+}
+template <int EPB>
+NT_DI float si_dof_force(const Ctx<EPB>& c, int dof, int tq, float q, float qd) {
+    return si_joint_force(q, qd, c.l(c.L.ctq, 0, 1, tq), c.l(c.L.ctqd, 0, 1, dof), c.dof(DP_TARGET_KE, dof), c.dof(DP_TARGET_KD, dof),
+                          c.dof(DP_LIMIT_LOWER, dof), c.dof(DP_LIMIT_UPPER, dof), c.dof(DP_LIMIT_KE, dof), c.dof(DP_LIMIT_KD, dof),
+                          c.dof(DP_DAMPING, dof));
+}
+// signed twist angle of q about `axis`, wrapped to [-pi, pi] (wp.quat_twist_angle_signed, kernels_body.py:206)
+NT_DI float quat_twist_angle_signed(vec3 axis, quat q) {
+    const float pi = 3.14159265358979323846f;
+    float a = q.x * axis.x + q.y * axis.y + q.z * axis.z;
+    float angle = 2.0f * atan2f(a, q.w);
+    if (angle > pi) angle -= 2.0f * pi;
+    if (angle < -pi) angle += 2.0f * pi;
+    return angle;
+}
+
+// eval_body_joints (semi_implicit/kernels_body.py:55-520): publishes (f, t_parent) and (f, t_child); the body lane adds
+// the parent wrench and subtracts the child wrench.  FREE/DISTANCE joints add joint_f to the child: stored negated.
+template <int EPB>
+NT_DI void si_joint_item(const Ctx<EPB>& c, const int j) {
+    const nt_model& m = c.a.m;
+    const int nj = m.nj;
+    const float ke_att = c.a.sp.joint_attach_ke, kd_att = c.a.sp.joint_attach_kd;
+    vec3 f_total, t_total, r_p, r_c;
+    const int type = c.T.joint_type[j];
+    if (c.T.joint_enabled[j]) {
+        const int c_child = c.T.joint_child[j], c_parent = c.T.joint_parent[j];
+        const int qd_start = c.T.joint_qd_start[j], tq_start = c.T.joint_tq_start[j];
+        if (type == JT_FREE || type == JT_DISTANCE) {
+            f_total = -c.lv3(c.L.cf, 0, 1, qd_start);
+            t_total = -c.lv3(c.L.cf, 0, 1, qd_start + 3);
+        } else {
+            xform X_pj = c.lxf(c.L.jp, 0, nj, j), X_cj = c.lxf(c.L.jp, 7, nj, j);
+            xform X_wp = X_pj;
+            vec3 w_p, v_p;
+            if (c_parent >= 0) {
+                xform bq = c.body_q(c_parent);
+                X_wp = bq * X_wp;
+                r_p = X_wp.p - xform_point(bq, c.com(c_parent));
+                w_p = c.body_w(c_parent);
+                v_p = c.body_v(c_parent) + cross(w_p, r_p);
+            }
+            xform bqc = c.body_q(c_child);
+            xform X_wc = bqc * X_cj;
+            r_c = X_wc.p - xform_point(bqc, c.com(c_child));
+            vec3 w_c = c.body_w(c_child);
+            vec3 v_c = c.body_v(c_child) + cross(w_c, r_c);
+            const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
+            vec3 x_err = X_wc.p - X_wp.p;
+            quat r_err = quat_inverse(X_wp.q) * X_wc.q;
+            vec3 v_err = v_c - v_p;
+            vec3 w_err = w_c - w_p;
+            const float ads = 0.01f;  // angular_damping_scale
+            if (type == JT_FIXED) {
+                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(r_err.w) * 2.0f;
+                f_total += x_err * ke_att + v_err * kd_att;
+                t_total += xform_vector(X_wp, ang_err) * ke_att + w_err * kd_att * ads;
+            }
+            if (type == JT_PRISMATIC) {
+                vec3 axis_p = xform_vector(X_wp, c.dof_axis(qd_start));
+                float q = dot(x_err, axis_p), qd = dot(v_err, axis_p);
+                f_total = axis_p * (-c.l(c.L.cf, 0, 1, qd_start) - si_dof_force(c, qd_start, tq_start, q, qd));
+                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(r_err.w) * 2.0f;
+                f_total += (x_err - q * axis_p) * ke_att + (v_err - qd * axis_p) * kd_att;
+                t_total += xform_vector(X_wp, ang_err) * ke_att + w_err * kd_att * ads;
+            }
+            if (type == JT_REVOLUTE) {
+                vec3 axis = c.dof_axis(qd_start);
+                vec3 axis_p = xform_vector(X_wp, axis), axis_c = xform_vector(X_wc, axis);
+                float q = quat_twist_angle_signed(axis, r_err);
+                float qd = dot(w_err, axis_p);
+                t_total = axis_p * (-c.l(c.L.cf, 0, 1, qd_start) - si_dof_force(c, qd_start, tq_start, q, qd));
+                vec3 swing_err = cross(axis_p, axis_c);
+                f_total += x_err * ke_att + v_err * kd_att;
+                t_total += swing_err * ke_att + (w_err - qd * axis_p) * kd_att * ads;
+            }
+            if (type == JT_BALL) {
+                f_total += x_err * ke_att + v_err * kd_att;
+                for (int k = 0; k < 3; ++k) {
+                    vec3 axis_k = xform_vector(X_wp, c.dof_axis(qd_start + k));
+                    t_total += axis_k * (-c.l(c.L.cf, 0, 1, qd_start + k) + c.dof(DP_DAMPING, qd_start + k) * dot(axis_k, w_err));
+                }
+            }
+            if (type == JT_D6) {
+                vec3 pos(0.0f), vel(0.0f);
+                for (int k = 0; k < 3; ++k) {
+                    bool take = (k == 0 && lin >= 1) || (k == 1 && lin >= 2) || (k == 2 && lin == 3);
+                    if (!take) continue;
+                    vec3 axis_k = xform_vector(X_wp, c.dof_axis(qd_start + k));
+                    float qk = dot(x_err, axis_k), qdk = dot(v_err, axis_k);
+                    f_total += axis_k * (-c.l(c.L.cf, 0, 1, qd_start + k) - si_dof_force(c, qd_start + k, tq_start + k, qk, qdk));
+                    pos += qk * axis_k;
+                    vel += qdk * axis_k;
+                }
+                f_total += (x_err - pos) * ke_att + (v_err - vel) * kd_att;
+                if (ang == 0) {
+                    vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(r_err.w) * 2.0f;
+                    t_total += xform_vector(X_wp, ang_err) * ke_att + w_err * kd_att * ads;
+                }
+                if (ang == 1) {
+                    int i_0 = lin + qd_start, i_0_q = lin + tq_start;
+                    vec3 axis = c.dof_axis(i_0);
+                    vec3 axis_p = xform_vector(X_wp, axis), axis_c = xform_vector(X_wc, axis);
+                    float q = quat_twist_angle_signed(axis, r_err);
+                    float qd = dot(w_err, axis_p);
+                    t_total = axis_p * (-c.l(c.L.cf, 0, 1, i_0) - si_dof_force(c, i_0, i_0_q, q, qd));
+                    vec3 swing_err = cross(axis_p, axis_c);
+                    t_total += swing_err * ke_att + (w_err - qd * axis_p) * kd_att * ads;
+                }
+                // 2 / 3 angular axes need wp.quat_to_euler: rejected on the host (NotImplementedError)
+            }
+        }
+    }
+    c.st_lv3(c.L.si_jf, 0, nj, j, f_total);
+    c.st_lv3(c.L.si_jf, 3, nj, j, t_total + cross(r_p, f_total));
+    c.st_lv3(c.L.si_jf, 6, nj, j, f_total);
+    c.st_lv3(c.L.si_jf, 9, nj, j, t_total + cross(r_c, f_total));
+}
+
+// eval_body_contact (semi_implicit/kernels_contact.py:381-556), one lane per contact slot: publishes f_total and the
+// torques about both bodies' COMs; the body lane subtracts for shape0's body and adds for shape1's body.
+template <int EPB>
+NT_DI void si_contact_item(const Ctx<EPB>& c, const int slot) {
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    const float* D = ct.data;
+    float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
+    vec3 f_total, tq_a, tq_b;
+    size_t gi = (size_t)slot * c.ES + c.env;
+    int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+    if (gid_a != gid_b) {
+        float ke = 0.0f, kd = 0.0f, kf = 0.0f, ka = 0.0f, mu = 0.0f;
+        int mat_nonzero = 0, shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
+        if (gid_a >= 0) {
+            shape_a = c.local_shape_id(gid_a);
+            mat_nonzero += 1;
+            ke += c.shape_f(shape_a, SP_KE); kd += c.shape_f(shape_a, SP_KD); kf += c.shape_f(shape_a, SP_KF);
+            ka += c.shape_f(shape_a, SP_KA); mu += c.shape_f(shape_a, SP_MU);
+            body_a = c.T.shape_body[shape_a];
+        }
+        if (gid_b >= 0) {
+            shape_b = c.local_shape_id(gid_b);
+            mat_nonzero += 1;
+            ke += c.shape_f(shape_b, SP_KE); kd += c.shape_f(shape_b, SP_KD); kf += c.shape_f(shape_b, SP_KF);
+            ka += c.shape_f(shape_b, SP_KA); mu += c.shape_f(shape_b, SP_MU);
+            body_b = c.T.shape_body[shape_b];
+        }
+        if (mat_nonzero > 0) {
+            ke /= float(mat_nonzero); kd /= float(mat_nonzero); kf /= float(mat_nonzero);
+            ka /= float(mat_nonzero); mu /= float(mat_nonzero);
+        }
+        vec3 n = -c.gv3(D, CD_NORMAL, ncs, slot);
+        vec3 bx_a = c.gv3(D, CD_POINT0, ncs, slot), bx_b = c.gv3(D, CD_POINT1, ncs, slot);
+        float margin_a = D[c.g(CD_MARGIN0, ncs, slot)], margin_b = D[c.g(CD_MARGIN1, ncs, slot)];
+        vec3 r_a(0.0f), r_b(0.0f);
+        if (body_a >= 0) {
+            xform X = c.body_q(body_a);
+            bx_a = xform_point(X, bx_a) - margin_a * n;
+            r_a = bx_a - xform_point(X, c.com(body_a));
+        }
+        if (body_b >= 0) {
+            xform X = c.body_q(body_b);
+            bx_b = xform_point(X, bx_b) + margin_b * n;
+            r_b = bx_b - xform_point(X, c.com(body_b));
+        }
+        float d = dot(n, bx_a - bx_b);
+        if (d < ka) {
+            vec3 bv_a(0.0f), bv_b(0.0f);
+            if (body_a >= 0) bv_a = c.body_v(body_a) + cross(c.body_w(body_a), r_a);
+            if (body_b >= 0) bv_b = c.body_v(body_b) + cross(c.body_w(body_b), r_b);
+            vec3 v = bv_a - bv_b;
+            float vn = dot(n, v);
+            vec3 vt = v - n * vn;
+            float fn = d * ke;
+            float fd = fminw(vn, 0.0f) * kd * (d < 0.0f ? 1.0f : 0.0f);
+            vec3 ft(0.0f);
+            if (d < 0.0f) {
+                float delta = c.a.sp.friction_smoothing;
+                float a2 = dot(vt, vt);  // wp.norm_huber
+                float vs = a2 <= delta * delta ? 0.5f * a2 : delta * (__fsqrt_rn(a2) - 0.5f * delta);
+                if (vs > 0.0f) {
+                    vec3 fr = vt / vs;
+                    ft = fr * fminw(kf * vs, -mu * (fn + fd));
+                }
+            }
+            f_total = n * (fn + fd) + ft;
+            tq_a = cross(r_a, f_total);
+            tq_b = cross(r_b, f_total);
+            has_a = body_a >= 0 ? 1.0f : 0.0f;
+            has_b = body_b >= 0 ? 1.0f : 0.0f;
+            a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
+        }
+    }
+    c.st_lv3(c.L.si_cw, 0, ncs, slot, f_total);
+    c.st_lv3(c.L.si_cw, 3, ncs, slot, tq_a);
+    c.st_lv3(c.L.si_cw, 6, ncs, slot, f_total);
+    c.st_lv3(c.L.si_cw, 9, ncs, slot, tq_b);
+    c.l(c.L.si_cw, 12, ncs, slot) = has_a;
+    c.l(c.L.si_cw, 13, ncs, slot) = has_b;
+    c.l(c.L.si_cw, 14, ncs, slot) = a_is_pair_a;
+}
+
+template <int EPB>
+__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    Ctx<EPB> c(a, lds);
+    load_state(c, a.s_in);
+    load_params(c, true);
+    __syncthreads();
+    if (c.valid) {
+        const nt_model& m = a.m;
+        for (int r = c.slot; r < 6 * m.nb; r += c.nslot) c.lds[(c.L.bf + r) * EPB + c.e] = a.s_in.body_f[(size_t)r * c.ES + c.env];
+        // joints and contacts are independent force evaluations on the input state: one phase
+        const int ncs = a.has_contacts ? m.np * m.cpp : 0;
+        for (int i = c.slot; i < m.nj + ncs; i += c.nslot) {
+            if (i < m.nj) si_joint_item(c, i);
+            else si_contact_item(c, i - m.nj);
+        }
+    }
+    __syncthreads();
+    // the integrator reads joint wrenches through L.jf: alias it to the semi-implicit region
+    Ctx<EPB> ci = c;
+    ci.L.jf = c.L.si_jf;
+    phase_integrate<EPB, true>(ci);
+    __syncthreads();
+    store_state(c, a.s_out);
 }
 
 __global__ void clear_forces_kernel(float* body_f, size_t n) {
@@ -1354,7 +1628,7 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 // slot-threads per env: enough for the widest per-env population (contact slots, joint parts, bodies, shapes,
 // pairs), capped by the block size; phases with more items than slot-threads loop.
 int slots_for(const nt_model& m, int epb) {
-    int want = imax(imax(m.nb, 2 * m.nj), imax(imax(m.ns, m.np), m.np * m.cpp));
+    int want = imax(imax(m.nb, 2 * m.nj), imax(imax(m.ns, m.np), m.np * m.cpp + m.nj));
     int cap = max_threads_for(epb) / epb;
     return want < cap ? want : cap;
 }
@@ -1466,6 +1740,7 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
     if (c) a.ct = *c;
     a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
     a.p = *p;
+    a.angular_damping = p->angular_damping;
     a.dt = dt;
     int epb = pick_epb(*m, envs_per_block);
     if (!epb) return NT_ERR_UNSUPPORTED;
@@ -1484,6 +1759,7 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     a.ct = *c;
     a.has_contacts = m->np > 0 ? 1 : 0;
     a.p = *p;
+    a.angular_damping = p->angular_damping;
     a.dt = dt;
     a.substeps = substeps;
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0);
@@ -1491,9 +1767,22 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     return NT_DISPATCH_EPB(xpbd_rollout_kernel, a, epb, (hipStream_t)stream);
 }
 
-nt_status nt_semi_implicit_step(const nt_model*, const nt_semi_implicit_params*, nt_state*, nt_state*, const nt_control*,
-                                const nt_contacts*, float, int32_t, void*) {
-    return NT_ERR_UNSUPPORTED;
+nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params* p, nt_state* s_in, nt_state* s_out,
+                                const nt_control* ctrl, const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
+    if (!model_ok(m) || !p || !s_in || !s_out || !ctrl) return NT_ERR_INVALID_ARG;
+    KArgs a = {};
+    a.m = *m;
+    a.s_in = *s_in;
+    a.s_out = *s_out;
+    a.c = *ctrl;
+    if (c) a.ct = *c;
+    a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
+    a.sp = *p;
+    a.angular_damping = p->angular_damping;
+    a.dt = dt;
+    int epb = pick_epb(*m, envs_per_block);
+    if (!epb) return NT_ERR_UNSUPPORTED;
+    return NT_DISPATCH_EPB(semi_implicit_step_kernel, a, epb, (hipStream_t)stream);
 }
 
 nt_status nt_eval_fk(const nt_model*, const float*, const float*, nt_state*, void*) { return NT_ERR_UNSUPPORTED; }

@@ -255,7 +255,7 @@ class DeviceModel:
         dof = np.concatenate([
             m.joint_axis.reshape(-1, 3), m.joint_limit_lower[:, None], m.joint_limit_upper[:, None],
             m.joint_target_ke[:, None], m.joint_target_kd[:, None], m.joint_limit_ke[:, None], m.joint_limit_kd[:, None],
-            m.joint_armature[:, None]], axis=1) if nd else np.zeros((0, 10), dtype=np.float32)
+            m.joint_armature[:, None], m.joint_damping[:, None]], axis=1) if nd else np.zeros((0, 11), dtype=np.float32)
         shape_all = np.concatenate([
             m.shape_transform, m.shape_scale, m.shape_margin[:, None], m.shape_gap[:, None], m.shape_material_mu[:, None],
             m.shape_material_mu_torsional[:, None], m.shape_material_mu_rolling[:, None], m.shape_material_ke[:, None],

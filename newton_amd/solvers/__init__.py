@@ -1,5 +1,6 @@
 """newton_amd.solvers -- MI355X-native drop-ins for newton.solvers (newton/_src/solvers/__init__.py:35-58)."""
+from .semi_implicit import SolverSemiImplicit
 from .solver import SolverBase
 from .xpbd import SolverXPBD
 
-__all__ = ["SolverBase", "SolverXPBD"]
+__all__ = ["SolverBase", "SolverSemiImplicit", "SolverXPBD"]

@@ -49,6 +49,7 @@ typedef struct {
     const float* joint_target_ke;  /* [D] */
     const float* joint_target_kd;  /* [D] */
     const float* joint_armature;   /* [D] */
+    const float* joint_damping;    /* [D] */
     /* articulations */
     int articulation_count;
     const int32_t* articulation_start; /* [A] */

@@ -28,7 +28,7 @@ class o_model(C.Structure):
         ("joint_X_c", _f), ("joint_q_start", _i), ("joint_qd_start", _i), ("joint_target_q_start", _i),
         ("joint_dof_dim", _i), ("joint_articulation", _i), ("joint_axis", _f), ("joint_limit_lower", _f),
         ("joint_limit_upper", _f), ("joint_limit_ke", _f), ("joint_limit_kd", _f), ("joint_target_ke", _f),
-        ("joint_target_kd", _f), ("joint_armature", _f),
+        ("joint_target_kd", _f), ("joint_armature", _f), ("joint_damping", _f),
         ("articulation_count", C.c_int), ("articulation_start", _i), ("articulation_end", _i),
         ("shape_transform", _f), ("shape_body", _i), ("shape_type", _i), ("shape_scale", _f), ("shape_margin", _f),
         ("shape_gap", _f), ("shape_flags", _i), ("shape_world", _i), ("shape_collision_group", _i),
@@ -130,7 +130,7 @@ class OracleModel:
         m.joint_target_q_start, m.joint_dof_dim = i32("joint_target_q_start"), i32("joint_dof_dim")
         m.joint_articulation = i32("joint_articulation")
         for n in ("joint_axis", "joint_limit_lower", "joint_limit_upper", "joint_limit_ke", "joint_limit_kd",
-                  "joint_target_ke", "joint_target_kd", "joint_armature"):
+                  "joint_target_ke", "joint_target_kd", "joint_armature", "joint_damping"):
             setattr(m, n, f32(n))
         m.articulation_count = model.articulation_count
         m.articulation_start, m.articulation_end = i32("articulation_start"), i32("articulation_end")
@@ -235,6 +235,13 @@ class Oracle:
         si, so = s_in.struct, s_out.struct
         self.L.o_xpbd_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
                            C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))
+
+    def semi_implicit_step(self, s_in: OracleState, s_out: OracleState, control, contacts, dt, angular_damping=0.05,
+                           friction_smoothing=1.0, joint_attach_ke=1.0e4, joint_attach_kd=1.0e2):
+        p = o_semi_implicit_params(angular_damping, friction_smoothing, joint_attach_ke, joint_attach_kd, 0)
+        si, so = s_in.struct, s_out.struct
+        self.L.o_semi_implicit_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
+                                    C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))
 
     def eval_fk(self, joint_q, joint_qd):
         m = self.model

@@ -120,3 +120,33 @@ def mixed_primitive_scene(world_count: int, device=None, seed: int = 3):
     model.body_q[:, :3] += off
     model.joint_q.reshape(-1, 7)[:, :3] += off
     return model
+
+
+def pendulum_scene(world_count: int, device=None, seed: int | None = None):
+    """C1 scene: double pendulum of newton/examples/basic/example_basic_pendulum.py:34-64 (2 box links hx=1, hy=hz=0.1,
+    revolute-Y joints, first anchor at (0,0,5) rotated -90 deg about Z) + ground plane; optional per-env joint-angle jitter."""
+    from newton_amd import _np_math as nm
+
+    hx, hy, hz = 1.0, 0.1, 0.1
+    env = nt.ModelBuilder()
+    l0 = env.add_link()
+    env.add_shape_box(l0, hx=hx, hy=hy, hz=hz)
+    l1 = env.add_link()
+    env.add_shape_box(l1, hx=hx, hy=hy, hz=hz)
+    rot = nm.quat_from_axis_angle([0.0, 0.0, 1.0], -np.pi * 0.5)
+    j0 = env.add_joint_revolute(-1, l0, axis=[0.0, 1.0, 0.0], parent_xform=nm.transform([0.0, 0.0, 5.0], rot),
+                                child_xform=nm.transform([-hx, 0.0, 0.0]))
+    j1 = env.add_joint_revolute(l0, l1, axis=[0.0, 1.0, 0.0], parent_xform=nm.transform([hx, 0.0, 0.0]),
+                                child_xform=nm.transform([-hx, 0.0, 0.0]))
+    env.add_articulation([j0, j1])
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    scene.add_ground_plane()
+    model = scene.finalize(device=device)
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+        model.joint_q[:] = rng.uniform(-0.5, 0.5, size=model.joint_q.shape).astype(np.float32)
+        model.joint_qd[:] = rng.uniform(-1.0, 1.0, size=model.joint_qd.shape).astype(np.float32)
+    bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+    model.body_q, model.body_qd = bq, bqd
+    return model

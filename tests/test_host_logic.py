@@ -99,9 +99,9 @@ def test_c_abi_exports_every_declared_symbol():
     m = _lib.nt_model()
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp = 18, 18, 4
-    # persistent rows 1251 (state 169 + body 299 + joint 182 + dof 180 + shape 247 + control 54 + gravity 3 + derived 117)
-    # + scratch max(collide 182, forces 234, joints 273, contacts 15*52 = 780)
-    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1251 + 780)
+    # persistent rows 1269 (state 169 + body 299 + joint 182 + dof 198 + shape 247 + control 54 + gravity 3 + derived 117)
+    # + scratch max(collide 182, forces 234, joints 273, contacts 15*52 = 780, semi-implicit 78 + 156 + 780 = 1014)
+    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1269 + 1014)
 
 
 def test_no_silent_cpu_fallback():

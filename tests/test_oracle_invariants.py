@@ -112,3 +112,23 @@ def test_fk_numpy_matches_oracle():
     obq, obqd = Oracle(model).eval_fk(jq, jqd)
     assert np.max(np.abs(bq - obq)) < 1e-5
     assert np.max(np.abs(bqd - obqd)) < 1e-4
+
+
+def test_pendulum_example_final_state():
+    """newton/examples/basic/example_basic_pendulum.py:113-137 (`test_final`, 100 frames x 10 substeps, SolverSemiImplicit
+    defaults): links stay in the swing plane and inside the reachable area, velocities bounded."""
+    from scenes import pendulum_scene
+
+    model = pendulum_scene(1)
+    o = Oracle(model)
+    s0, s1 = OracleState(model), OracleState(model)
+    ct, c = o.contacts(), o.control()
+    for _ in range(1000):
+        s0.body_f[:] = 0
+        o.collide(s0.body_q, ct)
+        o.semi_implicit_step(s0, s1, c, ct, 1e-3)
+        s0, s1 = s1, s0
+    for b in range(2):
+        q, qd = s0.body_q[b], s0.body_qd[b]
+        assert abs(q[0]) < 1e-5 and abs(q[1]) < 1.0 and 0.0 < q[2] < 5.0
+        assert abs(qd[0]) < 1e-4 and abs(qd[1]) < 10.0 and abs(qd[2]) < 5.0 and abs(qd[3]) < 10.0 and abs(qd[4]) < 10.0
