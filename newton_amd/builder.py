@@ -406,7 +406,8 @@ class ModelBuilder:
         cfg = self.default_shape_cfg if cfg is None else cfg
         xform = nm.transform() if xform is None else np.asarray(xform, dtype=np.float64)
         scale = (1.0, 1.0, 1.0) if scale is None else scale
-        if type in (GeoType.SPHERE, GeoType.BOX, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.ELLIPSOID, GeoType.PLANE):
+        if type in (GeoType.SPHERE, GeoType.BOX, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.ELLIPSOID, GeoType.PLANE,
+                    GeoType.CONE):
             scale = tuple(abs(float(s)) for s in scale)
         self.shape_body.append(body)
         shape = self.shape_count  # shape_type not yet appended
@@ -486,6 +487,11 @@ class ModelBuilder:
 
     def add_shape_cylinder(self, body, *, xform=None, radius=1.0, half_height=0.5, cfg=None, label=None) -> int:
         return self.add_shape(body=body, type=GeoType.CYLINDER, xform=xform, cfg=cfg, scale=(radius, half_height, 0.0),
+                              label=label)
+
+    def add_shape_cone(self, body, *, xform=None, radius=1.0, half_height=0.5, cfg=None, label=None) -> int:
+        """Cone along +Z: base at -half_height, apex at +half_height (builder.py:7102-7156)."""
+        return self.add_shape(body=body, type=GeoType.CONE, xform=xform, cfg=cfg, scale=(radius, half_height, 0.0),
                               label=label)
 
     # ------------------------------------------------------------------ importers

@@ -22,6 +22,7 @@ namespace orc {
 int convex_pair_contacts(const o_model* m, int shape_a, int shape_b, const float* geom_data /*[S][4]*/,
                          const float* geom_xform /*[S][7]*/, const float* aabb_lower, const float* aabb_upper,
                          const float* body_q, o_contacts* ct);
+vec3 support_map_generic(int type, vec3 scale, vec3 direction);  // support_function.py:131-350
 }  // namespace orc
 
 struct vec4f {
@@ -443,20 +444,22 @@ static void compute_shape_aabbs(const o_model* m, const float* body_q, float* aa
                               radius * std::sqrt(r0[2] * r0[2] + r1[2] * r1[2]) + half_height * std::fabs(r2[2]));
             lo = pos - half_extents - margin_vec;
             hi = pos + half_extents + margin_vec;
-        } else if (geo_type == GEO_ELLIPSOID) {
-            // compute_tight_aabb_from_support (collision_core.py) for an ellipsoid: the support extent along
-            // world axis i is |R^T e_i * scale| -- evaluated through the support map in the reference.
-            mat33 R = quat_to_matrix(orientation);
-            vec3 half_extents;
-            for (int i = 0; i < 3; ++i) {
-                vec3 d(R(i, 0) * scale[0], R(i, 1) * scale[1], R(i, 2) * scale[2]);
-                half_extents[i] = length(d);
-            }
-            lo = pos - half_extents - margin_vec;
-            hi = pos + half_extents + margin_vec;
+        } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE) {
+            // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space
+            mat33 rot_mat_t = transpose(quat_to_matrix(orientation));
+            vec3 local_x(rot_mat_t(0, 0), rot_mat_t(1, 0), rot_mat_t(2, 0));
+            vec3 local_y(rot_mat_t(0, 1), rot_mat_t(1, 1), rot_mat_t(2, 1));
+            vec3 local_z(rot_mat_t(0, 2), rot_mat_t(1, 2), rot_mat_t(2, 2));
+            float max_x = dot(local_x, support_map_generic(geo_type, geom_scale, local_x));
+            float max_y = dot(local_y, support_map_generic(geo_type, geom_scale, local_y));
+            float max_z = dot(local_z, support_map_generic(geo_type, geom_scale, local_z));
+            float min_x = dot(local_x, support_map_generic(geo_type, geom_scale, -local_x));
+            float min_y = dot(local_y, support_map_generic(geo_type, geom_scale, -local_y));
+            float min_z = dot(local_z, support_map_generic(geo_type, geom_scale, -local_z));
+            lo = vec3(min_x, min_y, min_z) + pos - margin_vec;
+            hi = vec3(max_x, max_y, max_z) + pos + margin_vec;
         } else {
-            // finite plane & other support-map shapes: conservative bounding sphere (not on the
-            // tested configs; documented gap in DESIGN.md)
+            // finite planes / meshes: not restated (conservative bounding sphere; rejected by the product host)
             float r = m->shape_collision_radius[shape_id];
             if (geo_type == GEO_PLANE) geom_scale = vec3(scale[0] * 0.5f, scale[1] * 0.5f, 0.0f);
             vec3 half_extents(r, r, r);
