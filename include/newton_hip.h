@@ -64,6 +64,9 @@ typedef struct {
     int32_t ng;          /* global (world -1, static) shapes, shared by every env */
     int32_t np;          /* candidate shape pairs per env (Model.shape_contact_pairs, one env's slice) */
     int32_t cpp;         /* contact slots per pair: 4 (all pairs analytic) or 5 (some pair uses the convex manifold) */
+    int32_t np_analytic; /* pairs [0, np_analytic) have an analytic primitive path, pairs [np_analytic, np) go through
+                            MPR/GJK + manifold (narrow_phase.py:642-655,1004-1014): the reference appends all analytic
+                            contacts before all convex ones, and the pair table is stored in that order */
     /* topology, int32, env-uniform */
     const int32_t* body_flags;          /* [nb]   BodyFlags */
     const int32_t* joint_type;          /* [nj]   JointType */
@@ -167,7 +170,8 @@ nt_status nt_unpack_aos(const float* soa, float* aos, int32_t ncomp, int32_t nsl
                         void* stream);
 /* Compact the fixed-slot contacts into Newton's flat append order (env, pair, sub-contact).
  * out_* are AoS arrays with capacity `cap`; out_count[0] receives the total (it keeps counting past cap,
- * like the reference's atomic counter, collide.py:176-177). Uses `scan_tmp` ([ES+1] int32) as scratch. */
+ * like the reference's atomic counter, collide.py:176-177). Order: every env's analytic contacts (env, pair, k), then every env's convex contacts, like the
+ * reference's two narrow-phase launches. Uses `scan_tmp` ([4*(env_count+1)] int32) as scratch. */
 nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t cap, int32_t* out_count, int32_t* out_shape0,
                              int32_t* out_shape1, float* out_point0, float* out_point1, float* out_offset0,
                              float* out_offset1, float* out_normal, float* out_margin0, float* out_margin1,

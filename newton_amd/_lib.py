@@ -27,6 +27,7 @@ class nt_model(C.Structure):
         ("env_count", C.c_int32), ("env_stride", C.c_int32), ("nb", C.c_int32), ("nj", C.c_int32), ("nd", C.c_int32),
         ("nc", C.c_int32), ("ntq", C.c_int32), ("ns", C.c_int32), ("ng", C.c_int32), ("np", C.c_int32),
         ("cpp", C.c_int32),
+        ("np_analytic", C.c_int32),
         ("body_flags", C.c_void_p), ("joint_type", C.c_void_p), ("joint_enabled", C.c_void_p),
         ("joint_parent", C.c_void_p), ("joint_child", C.c_void_p), ("joint_q_start", C.c_void_p),
         ("joint_qd_start", C.c_void_p), ("joint_tq_start", C.c_void_p), ("joint_lin_count", C.c_void_p),

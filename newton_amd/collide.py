@@ -41,7 +41,7 @@ class Contacts:
         self._data = torch.zeros((_lib.NT_CONTACT_FLOATS, ns, t.env_stride), dtype=torch.float32, device=dev)
         self._env_count = torch.zeros(t.env_stride, dtype=torch.int32, device=dev)
         self._pair_hit = torch.zeros((max(t.np, 1), t.env_stride), dtype=torch.uint8, device=dev)
-        self._scan = torch.zeros(t.env_stride + 1, dtype=torch.int32, device=dev)
+        self._scan = torch.zeros(4 * (t.env_stride + 1), dtype=torch.int32, device=dev)
         self._export = None
         self._generation = 0
         self._export_generation = -1
@@ -103,9 +103,13 @@ class Contacts:
 
     @property
     def candidate_pair_mask(self):
-        """[E, pairs_per_env] bool: broad-phase candidate pair set per environment."""
+        """[E, pairs_per_env] bool: broad-phase candidate pair set per environment, in Model.shape_contact_pairs order."""
         t = self.model.env
-        return self._pair_hit[: t.np, : t.env_count].T.bool()
+        torch = _torch()
+        hit = self._pair_hit[: t.np, : t.env_count].T.bool()
+        out = torch.zeros_like(hit)
+        out[:, torch.as_tensor(t.pair_order, device=hit.device)] = hit
+        return out
 
     def clear(self):
         self._shape0.fill_(-1)

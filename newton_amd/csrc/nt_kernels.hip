@@ -25,6 +25,7 @@
 #include "../../include/newton_hip.h"
 #include "nt_math.hpp"
 #include "nt_primitives.hpp"
+#include "nt_convex.hpp"
 
 using namespace nt;
 
@@ -340,13 +341,13 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
         he = vec3(scale.x, scale.x, scale.x) + vabs(axis) * scale.y;
     } else if (geo_type == GEO_CYLINDER) {
         float radius = scale.x, hh = scale.y, barrel = scale.z;
-        if (barrel >= hh && barrel > 0.0f) radius += (hh * hh) / (barrel + __fsqrt_rn(barrel * barrel - hh * hh));
+        if (barrel >= hh && barrel > 0.0f) radius += (hh * hh) / (barrel + sqrtf(barrel * barrel - hh * hh));
         vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
         vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
         vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
-        he = vec3(radius * __fsqrt_rn(r0.x * r0.x + r1.x * r1.x) + hh * fabsf(r2.x),
-                  radius * __fsqrt_rn(r0.y * r0.y + r1.y * r1.y) + hh * fabsf(r2.y),
-                  radius * __fsqrt_rn(r0.z * r0.z + r1.z * r1.z) + hh * fabsf(r2.z));
+        he = vec3(radius * sqrtf(r0.x * r0.x + r1.x * r1.x) + hh * fabsf(r2.x),
+                  radius * sqrtf(r0.y * r0.y + r1.y * r1.y) + hh * fabsf(r2.y),
+                  radius * sqrtf(r0.z * r0.z + r1.z * r1.z) + hh * fabsf(r2.z));
     } else if (geo_type == GEO_ELLIPSOID) {
         mat33 R = quat_to_matrix(q);
         he = vec3(length(vec3(R.m00 * scale.x, R.m01 * scale.y, R.m02 * scale.z)),
@@ -354,7 +355,7 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
                   length(vec3(R.m20 * scale.x, R.m21 * scale.y, R.m22 * scale.z)));
     } else {
         // finite planes / cones: conservative bounding sphere
-        float r = (geo_type == GEO_PLANE) ? 0.5f * __fsqrt_rn(scale.x * scale.x + scale.y * scale.y) : scale.x + scale.y;
+        float r = (geo_type == GEO_PLANE) ? 0.5f * sqrtf(scale.x * scale.x + scale.y * scale.y) : scale.x + scale.y;
         he = vec3(r, r, r);
     }
     lo = pos - he - mv;
@@ -395,7 +396,34 @@ NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {
 // One lane per CONTACT SLOT (pair p = slot / cpp, sub-contact k = slot % cpp): the cpp lanes of a pair evaluate the
 // same analytic pair redundantly (they are otherwise idle) and lane k writes the k-th admitted contact, so the
 // world->body conversion and the 19 stores per contact run in parallel instead of 4-deep in one thread.
+// Writes one contact record (world -> body frames, collide.py:166-204) into fixed slot `slot`.
 template <int EPB>
+NT_DI void write_contact_slot(const Ctx<EPB>& c, int slot, int sa, int sb, vec3 center, vec3 n, float dist, float ra, float rb,
+                              float margin_a, float margin_b) {
+    const nt_contacts& ct = c.a.ct;
+    const int ncs = c.a.m.np * c.a.m.cpp;
+    int ba = c.T.shape_body[sa], bb = c.T.shape_body[sb];
+    xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q(ba));
+    xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q(bb));
+    float off_a = ra + margin_a, off_b = rb + margin_b;
+    vec3 aw = center - n * (0.5f * dist + ra);
+    vec3 bw = center + n * (0.5f * dist + rb);
+    size_t gi = (size_t)slot * c.ES + c.env;
+    ct.shape0[gi] = c.newton_shape_id(sa);
+    ct.shape1[gi] = c.newton_shape_id(sb);
+    float* D = ct.data;
+    vec3 p0 = xform_point(Xbw_a, aw), p1 = xform_point(Xbw_b, bw);
+    vec3 o0 = xform_vector(Xbw_a, off_a * n), o1 = xform_vector(Xbw_b, -off_b * n);
+    D[c.g(CD_POINT0 + 0, ncs, slot)] = p0.x; D[c.g(CD_POINT0 + 1, ncs, slot)] = p0.y; D[c.g(CD_POINT0 + 2, ncs, slot)] = p0.z;
+    D[c.g(CD_POINT1 + 0, ncs, slot)] = p1.x; D[c.g(CD_POINT1 + 1, ncs, slot)] = p1.y; D[c.g(CD_POINT1 + 2, ncs, slot)] = p1.z;
+    D[c.g(CD_OFFSET0 + 0, ncs, slot)] = o0.x; D[c.g(CD_OFFSET0 + 1, ncs, slot)] = o0.y; D[c.g(CD_OFFSET0 + 2, ncs, slot)] = o0.z;
+    D[c.g(CD_OFFSET1 + 0, ncs, slot)] = o1.x; D[c.g(CD_OFFSET1 + 1, ncs, slot)] = o1.y; D[c.g(CD_OFFSET1 + 2, ncs, slot)] = o1.z;
+    D[c.g(CD_NORMAL + 0, ncs, slot)] = n.x; D[c.g(CD_NORMAL + 1, ncs, slot)] = n.y; D[c.g(CD_NORMAL + 2, ncs, slot)] = n.z;
+    D[c.g(CD_MARGIN0, ncs, slot)] = off_a;
+    D[c.g(CD_MARGIN1, ncs, slot)] = off_b;
+}
+
+template <int EPB, bool CVX>
 NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
@@ -447,29 +475,32 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
                 }
                 nvalid += ok ? 1 : 0;
             }
-            if (wrote) {
-                int ba = c.T.shape_body[sa], bb = c.T.shape_body[sb];
-                xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q(ba));
-                xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q(bb));
-                float off_a = ra + margin_a, off_b = rb + margin_b;
-                vec3 aw = my_center - n * (0.5f * my_dist + ra);
-                vec3 bw = my_center + n * (0.5f * my_dist + rb);
-                size_t gi = (size_t)slot * c.ES + c.env;
-                ct.shape0[gi] = c.newton_shape_id(sa);
-                ct.shape1[gi] = c.newton_shape_id(sb);
-                float* D = ct.data;
-                vec3 p0 = xform_point(Xbw_a, aw), p1 = xform_point(Xbw_b, bw);
-                vec3 o0 = xform_vector(Xbw_a, off_a * n), o1 = xform_vector(Xbw_b, -off_b * n);
-                D[c.g(CD_POINT0 + 0, ncs, slot)] = p0.x; D[c.g(CD_POINT0 + 1, ncs, slot)] = p0.y; D[c.g(CD_POINT0 + 2, ncs, slot)] = p0.z;
-                D[c.g(CD_POINT1 + 0, ncs, slot)] = p1.x; D[c.g(CD_POINT1 + 1, ncs, slot)] = p1.y; D[c.g(CD_POINT1 + 2, ncs, slot)] = p1.z;
-                D[c.g(CD_OFFSET0 + 0, ncs, slot)] = o0.x; D[c.g(CD_OFFSET0 + 1, ncs, slot)] = o0.y; D[c.g(CD_OFFSET0 + 2, ncs, slot)] = o0.z;
-                D[c.g(CD_OFFSET1 + 0, ncs, slot)] = o1.x; D[c.g(CD_OFFSET1 + 1, ncs, slot)] = o1.y; D[c.g(CD_OFFSET1 + 2, ncs, slot)] = o1.z;
-                D[c.g(CD_NORMAL + 0, ncs, slot)] = n.x; D[c.g(CD_NORMAL + 1, ncs, slot)] = n.y; D[c.g(CD_NORMAL + 2, ncs, slot)] = n.z;
-                D[c.g(CD_MARGIN0, ncs, slot)] = off_a;
-                D[c.g(CD_MARGIN1, ncs, slot)] = off_b;
+            if (wrote) write_contact_slot(c, slot, sa, sb, my_center, n, my_dist, ra, rb, margin_a, margin_b);
+        }
+        if constexpr (CVX) {
+            // pairs [np_analytic, np): MPR/GJK + manifold. Lane k == 0 of the pair runs the whole (serial, divergent)
+            // algorithm and fills the pair's slots in emission order; the other lanes of the pair leave them alone.
+            if (p >= m.np_analytic) {
+                if (k != 0) return;
+                ConvexContacts cc;
+                convex_pair(ta, tb, Xa, Xb, scale_a, scale_b, margin_a, margin_b, gap_sum, cc);
+                float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
+                float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
+                vec3 n = normalize(cc.normal);
+                nvalid = cc.count < cpp ? cc.count : cpp;
+                for (int i = 0; i < cpp; ++i) {
+                    if (i < nvalid) {
+                        write_contact_slot(c, slot + i, sa, sb, cc.center[i], n, cc.distance[i], ra, rb, margin_a, margin_b);
+                    } else {
+                        size_t gi = (size_t)(slot + i) * c.ES + c.env;
+                        ct.shape0[gi] = -1;
+                        ct.shape1[gi] = -1;
+                    }
+                }
+                c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+                return;
             }
         }
-        // pairs routed to the convex (MPR/GJK) path are handled by nt_convex (next round): no contacts yet
     }
     if (!wrote) {
         size_t gi = (size_t)slot * c.ES + c.env;
@@ -478,11 +509,11 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
     }
     if (k == 0) c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
 }
-template <int EPB>
+template <int EPB, bool CVX>
 NT_DI void phase_pairs(const Ctx<EPB>& c) {
     if (!c.valid) return;
     const int ncs = c.a.m.np * c.a.m.cpp;
-    for (int s = c.slot; s < ncs; s += c.nslot) collide_slot_item(c, s);
+    for (int s = c.slot; s < ncs; s += c.nslot) collide_slot_item<EPB, CVX>(c, s);
 }
 
 template <int EPB>
@@ -1119,7 +1150,7 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
         quat rel_q = quat_inverse(q_p) * q_c;
         quat qtwist = normalize(quat(rel_q.x, 0.0f, 0.0f, rel_q.w));
         quat qswing = rel_q * quat_inverse(qtwist);
-        float s = __fsqrt_rn(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
+        float s = sqrtf(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
         float invs = 1.0f / s;
         float invscube = invs * invs * invs;
         float err_0 = 2.0f * asinf(clampf(qtwist.x, -1.0f, 1.0f));
@@ -1132,7 +1163,7 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
         grad_0 = grad_0 * (2.0f / fabsf(qtwist.w));
         float swing_sq = qswing.w * qswing.w;
         if (swing_sq + 1.0e-4f < 1.0f) {
-            float d = __fsqrt_rn(1.0f - qswing.w * qswing.w);
+            float d = sqrtf(1.0f - qswing.w * qswing.w);
             float theta = 2.0f * acosf(clampf(qswing.w, -1.0f, 1.0f));
             float scale = theta / d;
             err_1 *= scale;
@@ -1189,12 +1220,12 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <int EPB>
+template <int EPB, bool CVX>
 NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
     if (c.a.debug_skip & 1) return;
     phase_shapes(c);
     __syncthreads();
-    phase_pairs(c);
+    phase_pairs<EPB, CVX>(c);
     __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
     if (count_contacts) {  // per-env totals are an API-boundary output, not needed by the solver
         phase_contact_count(c);
@@ -1229,14 +1260,14 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
 }
 
-template <int EPB>
+template <int EPB, bool CVX>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
     load_state(c, a.s_in);
     load_params(c, false);
     __syncthreads();
-    do_collide(c, true);
+    do_collide<EPB, CVX>(c, true);
 }
 
 template <int EPB>
@@ -1255,7 +1286,7 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_step_kernel(KArgs a
 // substeps x { clear_forces; collide; step; swap } with state and parameters resident in LDS across substeps.
 // Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
 // pointer swap); body_f of both states is zeroed as clear_forces would leave it.
-template <int EPB>
+template <int EPB, bool CVX>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds);
@@ -1271,7 +1302,7 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArg
     phase_body_derived(c);
     __syncthreads();
     for (int s = 0; s < a.substeps; ++s) {
-        do_collide(c, s == a.substeps - 1);
+        do_collide<EPB, CVX>(c, s == a.substeps - 1);
         do_xpbd_step(c, true);
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
@@ -1478,7 +1509,7 @@ NT_DI void si_contact_item(const Ctx<EPB>& c, const int slot) {
             if (d < 0.0f) {
                 float delta = c.a.sp.friction_smoothing;
                 float a2 = dot(vt, vt);  // wp.norm_huber
-                float vs = a2 <= delta * delta ? 0.5f * a2 : delta * (__fsqrt_rn(a2) - 0.5f * delta);
+                float vs = a2 <= delta * delta ? 0.5f * a2 : delta * (sqrtf(a2) - 0.5f * delta);
                 if (vs > 0.0f) {
                     vec3 fr = vt / vs;
                     ft = fr * fminw(kf * vs, -mu * (fn + fd));
@@ -1562,24 +1593,49 @@ __global__ void unpack_kernel(const float* __restrict__ soa, float* __restrict__
 }
 
 // contacts export: exclusive scan of per-env counts (single block), then scatter in (env, pair, k) order
-__global__ void contacts_scan_kernel(const int32_t* env_count, int E, int32_t* scan, int32_t* out_count) {
-    __shared__ int32_t part[1024];
+// scan_tmp layout ([4*(E+1)] int32): scanA[E+1] | scanC[E+1] | cntA[E+1] | cntC[E+1]
+__global__ void contacts_count_kernel(nt_model m, nt_contacts c, int32_t* scan_tmp) {
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int E = m.env_count;
+    if (env >= E) return;
+    const int ES = m.env_stride, ncs = m.np * m.cpp, nas = m.np_analytic * m.cpp;
+    int na = 0, nc = 0;
+    for (int slot = 0; slot < ncs; ++slot) {
+        if (c.shape0[(size_t)slot * ES + env] < 0) continue;
+        if (slot < nas) na += 1;
+        else nc += 1;
+    }
+    scan_tmp[2 * (E + 1) + env] = na;
+    scan_tmp[3 * (E + 1) + env] = nc;
+}
+__global__ void contacts_scan_kernel(int E, int32_t* scan_tmp, int32_t* out_count) {
+    __shared__ int32_t partA[1024], partC[1024];
+    const int32_t *cntA = scan_tmp + 2 * (E + 1), *cntC = scan_tmp + 3 * (E + 1);
+    int32_t *scanA = scan_tmp, *scanC = scan_tmp + (E + 1);
     int t = threadIdx.x, T = blockDim.x;
     int per = (E + T - 1) / T;
     int beg = t * per, end = beg + per < E ? beg + per : E;
-    int sum = 0;
-    for (int i = beg; i < end; ++i) sum += env_count[i];
-    part[t] = sum;
+    int sumA = 0, sumC = 0;
+    for (int i = beg; i < end; ++i) { sumA += cntA[i]; sumC += cntC[i]; }
+    partA[t] = sumA;
+    partC[t] = sumC;
     __syncthreads();
     if (t == 0) {
-        int acc = 0;
-        for (int i = 0; i < T; ++i) { int v = part[i]; part[i] = acc; acc += v; }
-        out_count[0] = acc;
-        scan[E] = acc;
+        int accA = 0, accC = 0;
+        for (int i = 0; i < T; ++i) {
+            int v = partA[i]; partA[i] = accA; accA += v;
+            v = partC[i]; partC[i] = accC; accC += v;
+        }
+        out_count[0] = accA + accC;
+        scanA[E] = accA;  // = first index of the convex section
+        scanC[E] = accC;
     }
     __syncthreads();
-    int acc = part[t];
-    for (int i = beg; i < end; ++i) { scan[i] = acc; acc += env_count[i]; }
+    int accA = partA[t], accC = partC[t];
+    for (int i = beg; i < end; ++i) {
+        scanA[i] = accA; accA += cntA[i];
+        scanC[i] = accC; accC += cntC[i];
+    }
 }
 
 struct ExportArgs {
@@ -1592,13 +1648,16 @@ struct ExportArgs {
 };
 __global__ void contacts_export_kernel(ExportArgs a) {
     int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= a.m.env_count) return;
-    const int ES = a.m.env_stride, ncs = a.m.np * a.m.cpp;
-    int idx = a.scan[env];
+    const int E = a.m.env_count;
+    if (env >= E) return;
+    const int ES = a.m.env_stride, ncs = a.m.np * a.m.cpp, nas = a.m.np_analytic * a.m.cpp;
+    int idxA = a.scan[env];
+    int idxC = a.scan[E] + a.scan[(E + 1) + env];
     for (int slot = 0; slot < ncs; ++slot) {
         size_t gi = (size_t)slot * ES + env;
         int s0 = a.c.shape0[gi];
         if (s0 < 0) continue;
+        int idx = slot < nas ? idxA++ : idxC++;
         if (idx < a.cap) {
             a.shape0[idx] = s0;
             a.shape1[idx] = a.c.shape1[gi];
@@ -1614,7 +1673,6 @@ __global__ void contacts_export_kernel(ExportArgs a) {
             a.margin0[idx] = ld(CD_MARGIN0);
             a.margin1[idx] = ld(CD_MARGIN1);
         }
-        idx += 1;
     }
 }
 
@@ -1678,9 +1736,20 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
      : (epb) == 32 ? launch(KERNEL<32>, args, 32, stream)                               \
      : (epb) == 16 ? launch(KERNEL<16>, args, 16, stream) : launch(KERNEL<8>, args, 8, stream))
 
+#define NT_DISPATCH_EPB2(KERNEL, B, args, epb, stream)                                  \
+    ((epb) == 64 ? launch(KERNEL<64, B>, args, 64, stream)                              \
+     : (epb) == 32 ? launch(KERNEL<32, B>, args, 32, stream)                            \
+     : (epb) == 16 ? launch(KERNEL<16, B>, args, 16, stream) : launch(KERNEL<8, B>, args, 8, stream))
+// kernels that collide are compiled twice: the convex (MPR/GJK) code only exists in the variant used by models
+// that have convex-routed pairs, so analytic-only models keep their register budget
+#define NT_DISPATCH_EPB_CVX(KERNEL, m, args, epb, stream)                                              \
+    ((m).np_analytic < (m).np ? NT_DISPATCH_EPB2(KERNEL, true, args, epb, stream)                      \
+                              : NT_DISPATCH_EPB2(KERNEL, false, args, epb, stream))
+
 bool model_ok(const nt_model* m) {
     return m && m->env_count > 0 && m->env_stride >= m->env_count && (m->env_stride % 64) == 0 && m->nb > 0 &&
-           (m->cpp == 4 || m->cpp == 5);
+           (m->cpp == 4 || m->cpp == 5) && m->np_analytic >= 0 && m->np_analytic <= m->np &&
+           (m->np_analytic == m->np || m->cpp == 5);
 }
 
 }  // namespace
@@ -1725,7 +1794,7 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
     a.ct = *c;
     int epb = pick_epb(*m, p ? p->envs_per_block : 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
-    return NT_DISPATCH_EPB(collide_kernel, a, epb, (hipStream_t)stream);
+    return NT_DISPATCH_EPB_CVX(collide_kernel, *m, a, epb, (hipStream_t)stream);
 }
 
 nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_in, nt_state* s_out, const nt_control* ctrl,
@@ -1764,7 +1833,7 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     a.substeps = substeps;
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
-    return NT_DISPATCH_EPB(xpbd_rollout_kernel, a, epb, (hipStream_t)stream);
+    return NT_DISPATCH_EPB_CVX(xpbd_rollout_kernel, *m, a, epb, (hipStream_t)stream);
 }
 
 nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params* p, nt_state* s_in, nt_state* s_out,
@@ -1816,8 +1885,8 @@ nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t ca
                              float* out_offset1, float* out_normal, float* out_margin0, float* out_margin1,
                              int32_t* scan_tmp, void* stream) {
     if (!model_ok(m) || !c || !out_count || !scan_tmp) return NT_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(contacts_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, c->env_count, m->env_count, scan_tmp,
-                       out_count);
+    hipLaunchKernelGGL(contacts_count_kernel, dim3((m->env_count + 63) / 64), dim3(64), 0, (hipStream_t)stream, *m, *c, scan_tmp);
+    hipLaunchKernelGGL(contacts_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, m->env_count, scan_tmp, out_count);
     ExportArgs a;
     a.m = *m;
     a.c = *c;

@@ -33,7 +33,7 @@ NT_DI vec3& operator*=(vec3& a, float s) { a = a * s; return a; }
 NT_DI float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 NT_DI vec3 cross(vec3 a, vec3 b) { return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 NT_DI float length_sq(vec3 a) { return dot(a, a); }
-NT_DI float length(vec3 a) { return __fsqrt_rn(dot(a, a)); }
+NT_DI float length(vec3 a) { return sqrtf(dot(a, a)); }
 NT_DI vec3 normalize(vec3 a) {
     float l = length(a);
     if (l > 0.0f) return a / l;
@@ -66,7 +66,7 @@ NT_DI quat operator*(quat a, quat b) {
                 a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
 }
 NT_DI float dot(quat a, quat b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-NT_DI float length(quat a) { return __fsqrt_rn(dot(a, a)); }
+NT_DI float length(quat a) { return sqrtf(dot(a, a)); }
 NT_DI quat normalize(quat q) {
     float l = length(q);
     if (l > 0.0f) {

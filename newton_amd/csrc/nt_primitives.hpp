@@ -138,7 +138,7 @@ NT_DI void sphere_cylinder(vec3 sp, float sr, vec3 cp, vec3 axis, float cr, floa
     bool collide_cap = p_proj_sqr < (cr * cr);
     if (collide_side && collide_cap) {
         float dist_cap = ch - fabsf(x);
-        float dist_radius = cr - __fsqrt_rn(p_proj_sqr);
+        float dist_radius = cr - sqrtf(p_proj_sqr);
         if (dist_cap < dist_radius) collide_side = false;
         else collide_cap = false;
     }
@@ -151,7 +151,7 @@ NT_DI void sphere_cylinder(vec3 sp, float sr, vec3 cp, vec3 axis, float cr, floa
         plane_sphere(pn, pos_cap, sp, sr, dist, pos);
         n = -pn;
     } else {
-        float l = __fsqrt_rn(p_proj_sqr);
+        float l = sqrtf(p_proj_sqr);
         float inv_len = 1.0f / (l != 0.0f ? l : 1e-15f);
         p_proj = p_proj * (cr * inv_len);
         vec3 cap_offset = axis * (signf(x) * ch);
@@ -168,7 +168,7 @@ NT_DI void plane_cylinder(vec3 n, vec3 plane_pos, vec3 cp, vec3 cyl_axis, float 
     vec3 perp_align = -n + axis * dot_na;
     float pl2 = dot(perp_align, perp_align);
     bool has_align = pl2 > 1e-10f;
-    if (has_align) perp_align = perp_align * (1.0f / __fsqrt_rn(pl2));
+    if (has_align) perp_align = perp_align * (1.0f / sqrtf(pl2));
     float abs_dot = -dot_na;
     bool flat_mode = abs_dot >= 0.9238795325112867f;  // cos(22.5 deg)
     vec3 perp_fixed;

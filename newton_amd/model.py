@@ -155,12 +155,30 @@ class EnvTemplate:
             self.pair_b = np.zeros(0, dtype=np.int32)
         self.np = len(self.pair_a)
 
-        # contact slots per pair: 4 if every pair has an analytic path (narrow_phase.py:642-655), else 5
-        self.cpp = 4
-        for a, b in zip(self.pair_a, self.pair_b):
+        # The reference writes analytic-primitive contacts in its first narrow-phase kernel and queues every other
+        # pair for the GJK/MPR kernel (narrow_phase.py:642-655,1004-1014), so in append order all analytic contacts
+        # precede all convex ones.  Device pairs are stored in that order (stable partition); `pair_order` maps a
+        # device pair index back to the per-env position in Model.shape_contact_pairs.
+        def analytic(a, b):
             ta, tb = sorted((int(self.shape_type[a]), int(self.shape_type[b])))
-            if ta >= GeoType.ELLIPSOID or tb == GeoType.CONE or (ta == GeoType.CAPSULE and tb > GeoType.CAPSULE):
-                self.cpp = 5
+            if ta == GeoType.PLANE:
+                return tb in (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX)
+            if ta == GeoType.SPHERE:
+                return tb in (GeoType.SPHERE, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.BOX)
+            return ta == GeoType.CAPSULE and tb == GeoType.CAPSULE
+
+        convex_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE)
+        is_analytic = np.array([analytic(a, b) for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
+        for a, b, ok in zip(self.pair_a, self.pair_b, is_analytic):
+            if not ok and not (int(self.shape_type[a]) in convex_types and int(self.shape_type[b]) in convex_types):
+                raise NotImplementedError(
+                    f"collision pair ({GeoType(int(self.shape_type[a])).name}, {GeoType(int(self.shape_type[b])).name}) "
+                    "has no analytic path and is outside the convex (MPR/GJK) scope of this build")
+        self.pair_order = np.concatenate([np.flatnonzero(is_analytic), np.flatnonzero(~is_analytic)]).astype(np.int64)
+        self.pair_a, self.pair_b = self.pair_a[self.pair_order], self.pair_b[self.pair_order]
+        self.np_analytic = int(is_analytic.sum())
+        # contact slots per pair: 4 if every pair has an analytic path, else 5 (manifold of 4 + deepest point)
+        self.cpp = 4 if self.np_analytic == self.np else 5
 
         # ordered incidence lists
         bj = [[] for _ in range(nb)]
@@ -225,6 +243,7 @@ class DeviceModel:
         d = _lib.nt_model()
         d.env_count, d.env_stride = E, ES
         d.nb, d.nj, d.nd, d.nc, d.ntq, d.ns, d.ng, d.np, d.cpp = t.nb, t.nj, t.nd, t.nc, t.ntq, t.ns, t.ng, t.np, t.cpp
+        d.np_analytic = t.np_analytic
         for k, v in self.topology.items():
             setattr(d, k, v.data_ptr())
         for k, v in self.params.items():

@@ -84,8 +84,9 @@ def test_articulation_does_not_drift():
 
 
 def test_plane_box_half_of_stack_scene():
-    """C2 scene, plane-box half only (box-box goes through MPR/GJK, not restated yet): the bottom box of each
-    stack gets exactly 4 ground contacts, candidate pairs = ground pair + adjacent boxes."""
+    """C2 scene: the bottom box of each stack gets exactly 4 ground contacts (analytic kernel, appended first), every
+    touching box-box face gets a 4-point manifold (MPR kernel, appended after); candidate pairs = ground pair +
+    adjacent boxes."""
     model = box_stack_scene(3, n_boxes=3, seed=0)
     o = Oracle(model)
     ct = o.contacts()
@@ -95,9 +96,11 @@ def test_plane_box_half_of_stack_scene():
     for w in range(3):
         assert (3 * w, ground) in got
         assert (3 * w, 3 * w + 1) in got and (3 * w + 1, 3 * w + 2) in got
-    assert ct.count[0] == 3 * 4
+    assert ct.count[0] == 3 * 4 + 3 * 2 * 4
     assert np.all(ct.shape0[:12] == ground)
     assert np.allclose(ct.normal[:12], [0, 0, 1])
+    assert np.all(ct.shape0[12:36] != ground) and np.all(ct.shape1[12:36] != ground)
+    assert np.allclose(ct.normal[12:36], [0, 0, 1], atol=1e-5)
 
 
 def test_fk_numpy_matches_oracle():
