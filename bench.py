@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--envs-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["quadruped", "box_stack"], default="quadruped",
+                    help="quadruped = the BASELINE.json metric (default); box_stack = config C2 (convex MPR/GJK path), "
+                         "a secondary measurement that is never the headline value")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,12 +94,21 @@ def main():
     from scenes import quadruped_scene
 
     # every rank owns its own shard of environments (distinct seed => distinct per-env jitter)
-    model = quadruped_scene(args.envs_per_gpu, device=f"cuda:{local_rank}", seed=1 + rank)
+    if args.workload == "quadruped":
+        model = quadruped_scene(args.envs_per_gpu, device=f"cuda:{local_rank}", seed=1 + rank)
+        iterations, workload_name = 2, (
+            "Anymal-class quadruped (in-repo stand-in geometry: 13 bodies, 12 revolute + free base, "
+            "13 cylinder colliders + ground plane)")
+    else:
+        from scenes import box_stack_scene
+
+        model = box_stack_scene(args.envs_per_gpu, device=f"cuda:{local_rank}", seed=1 + rank)
+        iterations, workload_name = 4, "C2: 8-box stack on a ground plane (box-box pairs through MPR/GJK + manifold)"
     s0, s1 = model.state(), model.state()
     ctrl = model.control()
     pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block)
     contacts = pipe.contacts()
-    solver = nt.solvers.SolverXPBD(model, envs_per_block=args.envs_per_block)
+    solver = nt.solvers.SolverXPBD(model, iterations=iterations, envs_per_block=args.envs_per_block)
 
     def barrier():
         if dist is not None:
@@ -146,8 +158,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "valid_state": ok,
             "config": {
-                "workload": "Anymal-class quadruped (in-repo stand-in geometry: 13 bodies, 12 revolute + free base, "
-                            "13 cylinder colliders + ground plane), SolverXPBD iterations=2, dt=1e-3, "
+                "workload": f"{workload_name}, SolverXPBD iterations={iterations}, dt=1e-3, "
                             f"{args.envs_per_gpu} envs per GPU, 1 step = 1 frame = {SUBSTEPS} substeps of "
                             "clear_forces+collide+step fused in one rollout launch",
                 "envs_per_gpu": args.envs_per_gpu, "substeps_per_step": SUBSTEPS, "parallelism": f"env-shard x{world}",
@@ -159,7 +170,9 @@ def main():
                 "algorithmic_bytes_per_env_step": bytes_per_env_step, "algorithmic_bytes_per_launch": launch_bytes,
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.workload != "quadruped":
+            out["metric"] = f"env-steps/sec, {args.workload} (secondary; not the BASELINE.json metric)"
+        if not args.no_cpu_baseline and world == 1 and args.workload == "quadruped":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
