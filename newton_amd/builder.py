@@ -665,6 +665,8 @@ class ModelBuilder:
         m.joint_X_p = arr(self.joint_X_p, f32, (J, 7))
         m.joint_X_c = arr(self.joint_X_c, f32, (J, 7))
         m.joint_q_start = arr(self.joint_q_start, i32, (J,))
+        child_to_joint = {int(c): i for i, c in enumerate(self.joint_child)}  # builder.py:12341-12348
+        m.joint_ancestor = arr([child_to_joint.get(int(p), -1) for p in self.joint_parent], i32, (J,))
         m.joint_qd_start = arr(self.joint_qd_start, i32, (J,))
         m.joint_target_q_start = arr(self.joint_target_q_start, i32, (J,))
         m.joint_dof_dim = arr(self.joint_dof_dim, i32, (J, 2))

@@ -69,6 +69,7 @@ typedef struct {
     const float* shape_material_mu, *shape_material_mu_torsional, *shape_material_mu_rolling;
     const float* shape_material_restitution;
     const int32_t* shape_contact_pairs; /* [P][2] */
+    const int32_t* joint_ancestor;      /* [J] joint whose child is this joint's parent body, or -1 (builder.py:12341-12348) */
 } o_model;
 
 typedef struct {
@@ -117,6 +118,11 @@ typedef struct {
     int enable_tri_contact;
 } o_semi_implicit_params;
 
+typedef struct {
+    float angular_damping; /* accepted for API parity; unused by the reference step */
+    float friction_smoothing;
+} o_featherstone_params;
+
 /* broad phase kinds */
 enum { O_BP_EXPLICIT = 0, O_BP_NXN = 1, O_BP_SAP = 2 };
 
@@ -127,6 +133,8 @@ void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s_in, o_stat
                  const o_control* c, const o_contacts* contacts /*nullable*/, float dt);
 void o_semi_implicit_step(const o_model* m, const o_semi_implicit_params* p, o_state* s_in, o_state* s_out,
                           const o_control* c, const o_contacts* contacts /*nullable*/, float dt);
+void o_featherstone_step(const o_model* m, const o_featherstone_params* p, o_state* s_in, o_state* s_out,
+                         const o_control* c, const o_contacts* contacts /*nullable*/, float dt);
 /* collide: returns number of candidate pairs; candidate pairs written to out_pairs (cap pairs) if non-null */
 int o_collide(const o_model* m, const float* body_q, int broad_phase, o_contacts* contacts,
               int32_t* out_pairs, int out_pairs_cap, float* out_aabb_lower, float* out_aabb_upper);

@@ -13,7 +13,8 @@
 
 using namespace orc;
 
-static float joint_force(float q, float qd, float joint_target_q, float joint_target_qd, float target_ke, float target_kd,
+namespace orc {
+float joint_force(float q, float qd, float joint_target_q, float joint_target_qd, float target_ke, float target_kd,
                          float limit_lower, float limit_upper, float limit_ke, float limit_kd, float damping) {
     float limit_f = 0.0f, damping_f = 0.0f, target_f = 0.0f;
     target_f = target_ke * (joint_target_q - q) + target_kd * (joint_target_qd - qd);
@@ -29,6 +30,7 @@ static float joint_force(float q, float qd, float joint_target_q, float joint_ta
     float passive_f = -damping * qd;
     return limit_f + damping_f + target_f + passive_f;
 }
+}  // namespace orc
 
 // signed twist angle of q about `axis`, wrapped to [-pi, pi]
 static float quat_twist_angle_signed(vec3 axis, quat q) {
@@ -165,8 +167,9 @@ static void eval_body_joints(const o_model* m, const o_control* c, const float* 
     }
 }
 
-static void eval_body_contact(const o_model* m, const o_contacts* ct, const float* body_q, const float* body_qd,
-                              float friction_smoothing, float* body_f) {
+namespace orc {
+void eval_body_contact(const o_model* m, const o_contacts* ct, const float* body_q, const float* body_qd,
+                       float friction_smoothing, float* body_f) {
     int count = ct->rigid_contact_count[0];
     for (int tid = 0; tid < ct->rigid_contact_max; ++tid) {
         if (tid >= count) break;
@@ -234,6 +237,7 @@ static void eval_body_contact(const o_model* m, const o_contacts* ct, const floa
         if (body_b >= 0) adds(body_f, body_b, spatial(f_total, cross(r_b, f_total)));
     }
 }
+}  // namespace orc
 
 extern "C" void o_semi_implicit_step(const o_model* m, const o_semi_implicit_params* p, o_state* s_in, o_state* s_out,
                                      const o_control* c, const o_contacts* contacts, float dt) {

@@ -130,6 +130,18 @@ inline mat33 operator*(const mat33& A, float s) { return s * A; }
 inline mat33 transpose(const mat33& A) {
     return mat33(A.m[0][0], A.m[1][0], A.m[2][0], A.m[0][1], A.m[1][1], A.m[2][1], A.m[0][2], A.m[1][2], A.m[2][2]);
 }
+// wp.skew / mat33 @ mat33 (newton/_src/solvers/featherstone/kernels.py:95-96)
+inline mat33 skew(vec3 v) { return mat33(0.0f, -v.z, v.y, v.z, 0.0f, -v.x, -v.y, v.x, 0.0f); }
+inline mat33 operator*(const mat33& A, const mat33& B) {
+    mat33 C;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float sum = 0.0f;
+            for (int k = 0; k < 3; ++k) sum += A(i, k) * B(k, j);
+            C.m[i][j] = sum;
+        }
+    return C;
+}
 inline mat33 matrix_from_cols(vec3 c0, vec3 c1, vec3 c2) {
     return mat33(c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z);
 }
@@ -168,6 +180,7 @@ struct spatial {
 inline spatial operator+(spatial a, spatial b) { return spatial(a.top + b.top, a.bottom + b.bottom); }
 inline spatial operator-(spatial a, spatial b) { return spatial(a.top - b.top, a.bottom - b.bottom); }
 inline spatial operator*(spatial a, float s) { return spatial(a.top * s, a.bottom * s); }
+inline spatial operator-(spatial a) { return spatial(-a.top, -a.bottom); }
 
 // newton/_src/math/spatial.py:53-78  v_p = v + w x r  (Newton layout)
 inline vec3 velocity_at_point(const spatial& qd, vec3 r) { return cross(qd.bottom, r) + qd.top; }

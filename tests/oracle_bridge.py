@@ -34,7 +34,7 @@ class o_model(C.Structure):
         ("shape_gap", _f), ("shape_flags", _i), ("shape_world", _i), ("shape_collision_group", _i),
         ("shape_collision_radius", _f), ("shape_material_ke", _f), ("shape_material_kd", _f), ("shape_material_kf", _f),
         ("shape_material_ka", _f), ("shape_material_mu", _f), ("shape_material_mu_torsional", _f),
-        ("shape_material_mu_rolling", _f), ("shape_material_restitution", _f), ("shape_contact_pairs", _i),
+        ("shape_material_mu_rolling", _f), ("shape_material_restitution", _f), ("shape_contact_pairs", _i), ("joint_ancestor", _i),
     ]
 
 
@@ -62,6 +62,10 @@ class o_xpbd_params(C.Structure):
 class o_semi_implicit_params(C.Structure):
     _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float), ("joint_attach_ke", C.c_float),
                 ("joint_attach_kd", C.c_float), ("enable_tri_contact", C.c_int)]
+
+
+class o_featherstone_params(C.Structure):
+    _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float)]
 
 
 _lib = None
@@ -142,6 +146,7 @@ class OracleModel:
                   "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_restitution"):
             setattr(m, n, f32(n))
         m.shape_contact_pairs = i32("shape_contact_pairs")
+        m.joint_ancestor = i32("joint_ancestor")
         self.struct = m
 
 
@@ -242,6 +247,14 @@ class Oracle:
         si, so = s_in.struct, s_out.struct
         self.L.o_semi_implicit_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
                                     C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))
+
+    def featherstone_step(self, s_in: OracleState, s_out: OracleState, control, contacts, dt, angular_damping=0.05,
+                          friction_smoothing=1.0):
+        """SolverFeatherstone.step: advances joint_q/joint_qd and rebuilds body_q/body_qd (s_in.body_q is refreshed by FK)."""
+        p = o_featherstone_params(angular_damping, friction_smoothing)
+        si, so = s_in.struct, s_out.struct
+        self.L.o_featherstone_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
+                                   C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))
 
     def eval_fk(self, joint_q, joint_qd):
         m = self.model

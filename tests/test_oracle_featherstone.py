@@ -1,0 +1,142 @@
+"""Pin the oracle's SolverFeatherstone restatement against the reference's physics-verification invariants
+(newton/tests/test_physics_verification.py:48-537, solver_fn = SolverFeatherstone(angular_damping=0.0)), with the
+reference's own tolerances, plus a contact sanity check on the C3 quadruped."""
+import numpy as np
+
+import newton_amd as nt
+from newton_amd import _np_math as nm
+from oracle_bridge import Oracle, OracleState
+from scenes import quadruped_scene
+
+I4 = [0.0, 0.0, 0.0, 1.0]
+
+
+def _run(o, s0, s1, c, n, dt, contacts=None, collide=False, each=None):
+    for i in range(1, n + 1):
+        s0.body_f[:] = 0
+        if collide:
+            o.collide(s0.body_q, contacts)
+        o.featherstone_step(s0, s1, c, contacts, dt)
+        s0, s1 = s1, s0
+        if each is not None:
+            each(i, s0)
+    return s0, s1
+
+
+def test_free_fall(oracle_lib):
+    g, h0, dt = -10.0, 5.0, 1e-3
+    b = nt.ModelBuilder(up_axis=1, gravity=g)
+    body = b.add_body(xform=[0.0, h0, 0.0, *I4])
+    b.add_shape_sphere(body, radius=0.1)
+    m = b.finalize()
+    o = Oracle(m)
+    s0, s1 = OracleState(m), OracleState(m)
+
+    def check(i, s):
+        if i % 100:
+            return
+        t = i * dt
+        pos, vel = s.body_q[0, :3], s.body_qd[0, :3]
+        assert abs(pos[1] - (h0 + 0.5 * g * t * t)) < max(2.0 * 0.5 * abs(g) * dt * t, 1e-3)
+        assert abs(vel[1] - g * t) < max(abs(g) * dt, 1e-3)
+        assert abs(pos[0]) < 1e-4 and abs(pos[2]) < 1e-4
+
+    _run(o, s0, s1, o.control(), 500, dt, each=check)
+
+
+def _pendulum(initial_angle, g=-10.0, L=1.0):
+    b = nt.ModelBuilder(up_axis=1, gravity=g)
+    link = b.add_link()
+    b.add_shape_sphere(link, radius=0.01)
+    j = b.add_joint_revolute(-1, link, axis=(0, 0, 1), parent_xform=[0, 0, 0, *I4], child_xform=[0, L, 0, *I4], armature=0.0)
+    b.add_articulation([j])
+    m = b.finalize()
+    m.joint_q[0] = initial_angle
+    mass = float(m.body_mass[0])
+    I_pivot = float(np.asarray(m.body_inertia[0]).reshape(3, 3)[2, 2]) + mass * L * L
+    return m, mass, I_pivot
+
+
+def test_pendulum_period(oracle_lib):
+    g, L, a0, dt = -10.0, 1.0, 0.05, 1e-3
+    m, mass, I_pivot = _pendulum(a0, g, L)
+    T = 2.0 * np.pi * np.sqrt(I_pivot / (mass * abs(g) * L))
+    o = Oracle(m)
+    s0, s1 = OracleState(m), OracleState(m)
+    n = int(3.5 * T / dt)
+    angles = []
+    _run(o, s0, s1, o.control(), n, dt, each=lambda i, s: angles.append(float(s.joint_q[0])))
+    t = np.arange(1, n + 1) * dt
+    err = np.mean(np.abs(np.array(angles) - a0 * np.cos(2.0 * np.pi / T * t))) / a0
+    assert err < 0.01
+
+
+def test_energy_conservation(oracle_lib):
+    g, L, dt = -10.0, 1.0, 1e-3
+    m, mass, I_pivot = _pendulum(1.0, g, L)
+    o = Oracle(m)
+    s0, s1 = OracleState(m), OracleState(m)
+
+    def energy(s):
+        return 0.5 * I_pivot * float(s.joint_qd[0]) ** 2, mass * abs(g) * (-L * np.cos(float(s.joint_q[0])))
+
+    ke0, pe0 = energy(s0)
+    E0 = ke0 + pe0
+    kes, es = [], []
+
+    def rec(i, s):
+        ke, pe = energy(s)
+        kes.append(ke)
+        es.append(ke + pe)
+
+    _run(o, s0, s1, o.control(), int(2.0 / dt), dt, each=rec)
+    assert min(kes) / abs(E0) < 0.01
+    assert np.max(np.abs(np.array(es) - E0)) / abs(E0) < 0.005
+
+
+def test_momentum_conservation(oracle_lib):
+    positions = [(0.0, 0.0, 0.0), (100.0, 0.0, 0.0), (0.0, 100.0, 0.0), (0.0, 0.0, 100.0)]
+    velocities = [(1.0, 0.0, 0.0, 0.0, 0.0, 0.5), (0.0, -1.0, 0.0, 0.3, 0.0, 0.0), (0.0, 0.0, 1.5, 0.0, -0.2, 0.0),
+                  (-0.5, 0.5, -0.5, 0.0, 0.0, -0.3)]
+    b = nt.ModelBuilder(up_axis=1, gravity=0.0)
+    for p in positions:
+        body = b.add_body(xform=[*p, *I4])
+        b.add_shape_box(body, hx=0.5, hy=0.5, hz=0.5)
+    m = b.finalize()
+    m.joint_qd[:] = np.asarray(velocities, dtype=np.float32).reshape(-1)
+    o = Oracle(m)
+    bq, bqd = o.eval_fk(m.joint_q, m.joint_qd)
+    s0, s1 = OracleState(m, body_q=bq, body_qd=bqd), OracleState(m)
+
+    def momenta(s):
+        p, Lm = np.zeros(3), np.zeros(3)
+        for i in range(4):
+            mass = float(m.body_mass[i])
+            v, w, r = s.body_qd[i, :3].astype(np.float64), s.body_qd[i, 3:].astype(np.float64), s.body_q[i, :3].astype(np.float64)
+            R = nm.quat_to_matrix(s.body_q[i, 3:7])
+            p += mass * v
+            Lm += np.cross(r, mass * v) + R @ np.asarray(m.body_inertia[i]).reshape(3, 3) @ R.T @ w
+        return p, Lm
+
+    p0, L0 = momenta(s0)
+    assert np.linalg.norm(p0) > 0.1 and np.linalg.norm(L0) > 0.1
+    s0, _ = _run(o, s0, s1, o.control(), 1000, 1e-3)
+    p1, L1 = momenta(s0)
+    assert np.linalg.norm(p1 - p0) / np.linalg.norm(p0) < 5e-4
+    assert np.linalg.norm(L1 - L0) / np.linalg.norm(L0) < 5e-4
+    assert np.linalg.norm(s0.body_q[:4, :3] - np.asarray(positions)) > 0.1
+
+
+def test_quadruped_contact_drop_stays_sane(oracle_lib):
+    """C3: quadruped dropped on the plane under SolverFeatherstone defaults: finite state, penalty contacts hold the
+    feet near the ground, joint_q/joint_qd stay consistent with body_q (FK round trip)."""
+    m = quadruped_scene(2, seed=1)
+    o = Oracle(m)
+    ct, c = o.contacts(), o.control()
+    s0, s1 = OracleState(m), OracleState(m)
+    s0, s1 = _run(o, s0, s1, c, 400, 1e-3, contacts=ct, collide=True)
+    assert np.all(np.isfinite(s0.body_q)) and np.all(np.isfinite(s0.joint_q))
+    z = s0.body_q.reshape(2, 13, 7)[:, :, 2]
+    assert np.all(z > 0.0) and np.all(z < 1.0)
+    bq, _ = o.eval_fk(s0.joint_q, s0.joint_qd)
+    assert np.max(np.abs(bq - s0.body_q)) < 1e-5
