@@ -67,6 +67,8 @@ typedef struct {
     int32_t np_analytic; /* pairs [0, np_analytic) have an analytic primitive path, pairs [np_analytic, np) go through
                             MPR/GJK + manifold (narrow_phase.py:642-655,1004-1014): the reference appends all analytic
                             contacts before all convex ones, and the pair table is stored in that order */
+    int32_t na;          /* articulations per env (SolverFeatherstone only; 0 otherwise) */
+    int32_t max_art_dofs;/* widest articulation, in dofs (row width of the LDS-resident joint-space inertia H) */
     /* topology, int32, env-uniform */
     const int32_t* body_flags;          /* [nb]   BodyFlags */
     const int32_t* joint_type;          /* [nj]   JointType */
@@ -89,6 +91,7 @@ typedef struct {
     const int32_t* body_joint_list;     /* [2*nj] (padded) joint*2 + (1 if body is the child else 0), ascending joint; parent entry first */
     const int32_t* body_pair_start;     /* [nb+1] */
     const int32_t* body_pair_list;      /* [2*np] (padded) pair*2 + (1 if the body owns pair_b's shape else 0), ascending pair */
+    const int32_t* art_start;           /* [na+1] first env-local joint of each articulation (Model.articulation_start / _end) */
     /* per-env parameters, float SoA */
     const float* body_param;            /* [NT_BODY_PARAM_FLOATS][nb][ES] */
     const float* gravity;               /* [3][ES] */
@@ -141,6 +144,13 @@ typedef struct {
     float joint_attach_ke, joint_attach_kd;
 } nt_semi_implicit_params;
 
+/* SolverFeatherstone(model, angular_damping=0.05, friction_smoothing=1.0, ...) solver_featherstone.py:136-146.
+ * update_mass_matrix_interval is fixed at 1; use_tile_gemm / fuse_cholesky have no meaning here (H never leaves LDS). */
+typedef struct {
+    float angular_damping; /* accepted like the reference constructor; the reference step does not use it either */
+    float friction_smoothing;
+} nt_featherstone_params;
+
 typedef struct {
     int32_t broad_phase;  /* 0 explicit pairs (default), 1 nxn, 2 sap -- all emit the same per-env pair set */
     int32_t envs_per_block; /* 0 = auto; otherwise 16, 32 or 64 */
@@ -155,6 +165,12 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
 nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params* p, nt_state* s_in, nt_state* s_out,
                                 const nt_control* ctrl, const nt_contacts* c /*nullable*/, float dt,
                                 int32_t envs_per_block, void* stream);
+/* SolverFeatherstone.step (newton/_src/solvers/featherstone/solver_featherstone.py:462-1066): advances joint_q / joint_qd and
+ * rebuilds body_q / body_qd of s_out; like the reference it also refreshes s_in->body_q from s_in->joint_q (FK).
+ * Scope: PRISMATIC, REVOLUTE, BALL, FIXED, root FREE, D6 with <= 1 angular axis; child body of env-local joint j is body j. */
+nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* p, nt_state* s_in, nt_state* s_out,
+                               const nt_control* ctrl, const nt_contacts* c /*nullable*/, float dt,
+                               int32_t envs_per_block, void* stream);
 /* substeps x {clear_forces; collide; xpbd step; swap}: the result is in s0 when substeps is even, s1 when odd,
  * exactly like the reference loop's pointer swap. */
 nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, nt_state* s0,
@@ -180,6 +196,7 @@ nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t ca
 /* -------- introspection -------- */
 const char* nt_error_string(nt_status s);
 const char* nt_build_info(void);                 /* "gfx950 ..." */
+int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m);
 int32_t nt_lds_bytes_per_env(const nt_model* m); /* LDS footprint of one env in the step kernels */
 /* dst[i] = src[i], 4 B/lane coalesced: known-byte-count kernel used to calibrate the HBM PMC counters */
 nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream);

@@ -27,14 +27,14 @@ class nt_model(C.Structure):
         ("env_count", C.c_int32), ("env_stride", C.c_int32), ("nb", C.c_int32), ("nj", C.c_int32), ("nd", C.c_int32),
         ("nc", C.c_int32), ("ntq", C.c_int32), ("ns", C.c_int32), ("ng", C.c_int32), ("np", C.c_int32),
         ("cpp", C.c_int32),
-        ("np_analytic", C.c_int32),
+        ("np_analytic", C.c_int32), ("na", C.c_int32), ("max_art_dofs", C.c_int32),
         ("body_flags", C.c_void_p), ("joint_type", C.c_void_p), ("joint_enabled", C.c_void_p),
         ("joint_parent", C.c_void_p), ("joint_child", C.c_void_p), ("joint_q_start", C.c_void_p),
         ("joint_qd_start", C.c_void_p), ("joint_tq_start", C.c_void_p), ("joint_lin_count", C.c_void_p),
         ("joint_ang_count", C.c_void_p), ("shape_body", C.c_void_p), ("shape_type", C.c_void_p),
         ("shape_flags", C.c_void_p), ("shape_group", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p),
         ("body_joint_start", C.c_void_p), ("body_joint_list", C.c_void_p), ("body_pair_start", C.c_void_p),
-        ("body_pair_list", C.c_void_p),
+        ("body_pair_list", C.c_void_p), ("art_start", C.c_void_p),
         ("body_param", C.c_void_p), ("gravity", C.c_void_p), ("joint_param", C.c_void_p), ("dof_param", C.c_void_p),
         ("shape_param", C.c_void_p), ("gshape_param", C.c_void_p),
     ]
@@ -67,6 +67,10 @@ class nt_semi_implicit_params(C.Structure):
                 ("joint_attach_kd", C.c_float)]
 
 
+class nt_featherstone_params(C.Structure):
+    _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float)]
+
+
 class nt_collide_params(C.Structure):
     _fields_ = [("broad_phase", C.c_int32), ("envs_per_block", C.c_int32)]
 
@@ -82,6 +86,10 @@ SYMBOLS = {
     "nt_semi_implicit_step": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_semi_implicit_params), C.POINTER(nt_state),
                                            C.POINTER(nt_state), C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float,
                                            C.c_int32, _P]),
+    "nt_featherstone_step": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_featherstone_params), C.POINTER(nt_state),
+                                          C.POINTER(nt_state), C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float,
+                                          C.c_int32, _P]),
+    "nt_featherstone_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
     "nt_xpbd_rollout": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_xpbd_params), C.POINTER(nt_collide_params),
                                      C.POINTER(nt_state), C.POINTER(nt_state), C.POINTER(nt_control),
                                      C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),

@@ -1,0 +1,765 @@
+// SolverFeatherstone for gfx950: one workgroup owns EPB environments; generalized state, motion subspaces, spatial
+// inertias, the articulation's joint-space inertia H and its Cholesky factor all live in LDS (the reference streams
+// J, M, P = M J, H and L through HBM: solver_featherstone.py:771-934).
+// Included inside nt_kernels.hip's anonymous namespace (uses Ctx / KArgs / LdsLayout / si_contact_item / si_dof_force).
+//
+// Reference (restated):
+//   jcalc_transform / jcalc_motion / jcalc_tau / jcalc_integrate   newton/_src/solvers/featherstone/kernels.py:142-630
+//   eval_rigid_fk / compute_link_velocity / eval_rigid_id          kernels.py:633-866,1241-1317
+//   public <-> internal FREE-joint velocity conversions            kernels.py:924-1088
+//   eval_rigid_tau / eval_rigid_jacobian / eval_rigid_mass         kernels.py:1320-1501
+//   dense_gemm / dense_cholesky / dense_subs                       kernels.py:1504-1565,1690-1797
+//   integrate_generalized_joints + FK with velocity conversion     kernels.py:1849-1893,1987-2150
+//   SolverFeatherstone.step                                        solver_featherstone.py:462-1066
+// Summation orders follow the reference: H[i][j] = sum over bodies (ascending) and spatial rows (ascending) of
+// J[b,r,i] * (I_b S_j)[r] -- the zero entries of the dense J / M the reference multiplies through add exact zeros.
+// Scope: PRISMATIC, REVOLUTE, BALL, FIXED, root FREE, D6 with <= 1 angular axis; body l of an articulation is the child
+// of its joint l (the reference's eval_rigid_mass indexes body_I_s by joint index, kernels.py:1466-1480).
+
+struct FsLayout {
+    int jq, qdi, qdo, jfi, tau, qdd;  // joint_q [nc], internal qd in / out [nd], joint_f internal, tau, qdd [nd]
+    int qcom, org;                    // body COM world position [3][nb], solve origin [3][nb]
+    int S;                            // motion subspace columns [6][nd]
+    int Is;                           // spatial inertia in the solve frame [36][nb]
+    int vs, as, fs, ft;               // v_s, a_s, (f_b - f_g), total subtree wrench per joint [6][nb] each
+    int bfx;                          // external wrench buffer body_f_ext [6][nb]
+    int cw;                           // contact wrenches [CW_FLOATS][np*cpp]        (union with P/H)
+    int P, H;                         // P[b][jl] = I_b S_j [6][nb][W];  H / L [nd][W]
+    int rows;
+};
+__host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsLayout& L) {
+    FsLayout F;
+    int o = L.u;
+    F.jq = o; o += m.nc;
+    F.qdi = o; o += m.nd;
+    F.qdo = o; o += m.nd;
+    F.jfi = o; o += m.nd;
+    F.tau = o; o += m.nd;
+    F.qdd = o; o += m.nd;
+    F.qcom = o; o += 3 * m.nb;
+    F.org = o; o += 3 * m.nb;
+    F.S = o; o += 6 * m.nd;
+    F.Is = o; o += 36 * m.nb;
+    F.vs = o; o += 6 * m.nb;
+    F.as = o; o += 6 * m.nb;
+    F.fs = o; o += 6 * m.nb;
+    F.ft = o; o += 6 * m.nb;
+    F.bfx = o; o += 6 * m.nb;
+    F.cw = o;
+    F.P = o;
+    F.H = F.P + 6 * m.nb * m.max_art_dofs;
+    int solve = 6 * m.nb * m.max_art_dofs + m.nd * m.max_art_dofs;
+    int contacts = CW_FLOATS * m.np * m.cpp;
+    o += imax(solve, contacts);
+    F.rows = o;
+    return F;
+}
+// block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint  (3 * nj)
+__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj; }
+
+template <int EPB>
+struct FsCtx {
+    const Ctx<EPB>& c;
+    FsLayout F;
+    const int *anc, *depth, *art;  // [nj] each (LDS)
+    int max_depth;
+    NT_DI FsCtx(const Ctx<EPB>& c_, int* extra) : c(c_) {
+        F = make_fs_layout(c.a.m, c.L);
+        anc = extra;
+        depth = extra + c.a.m.nj;
+        art = extra + 2 * c.a.m.nj;
+    }
+    NT_DI float& f(int off, int idx) const { return c.lds[(off + idx) * EPB + c.e]; }
+    NT_DI vec3 v3(int off, int comp0, int n, int s) const { return c.lv3(off, comp0, n, s); }
+    NT_DI spatial sp6(int off, int n, int s) const { return spatial(c.lv3(off, 0, n, s), c.lv3(off, 3, n, s)); }
+    NT_DI void st6(int off, int n, int s, const spatial& x) const {
+        c.st_lv3(off, 0, n, s, x.top);
+        c.st_lv3(off, 3, n, s, x.bottom);
+    }
+};
+
+// (linear, angular) twist transform (math/spatial.py:82-104)
+NT_DI spatial fs_transform_twist(const xform& t, const spatial& x) {
+    vec3 w = quat_rotate(t.q, x.bottom);
+    vec3 v = quat_rotate(t.q, x.top) + cross(t.p, w);
+    return spatial(v, w);
+}
+NT_DI spatial fs_spatial_cross(const spatial& a, const spatial& b) {
+    return spatial(cross(a.bottom, b.top) + cross(a.top, b.bottom), cross(a.bottom, b.bottom));
+}
+NT_DI spatial fs_spatial_cross_dual(const spatial& a, const spatial& b) {
+    return spatial(cross(a.bottom, b.top), cross(a.bottom, b.bottom) + cross(a.top, b.top));
+}
+NT_DI float fs_sget(const spatial& s, int i) { return i < 3 ? vget(s.top, i) : vget(s.bottom, i - 3); }
+
+struct mat66 {
+    float a[6][6];
+};
+NT_DI spatial fs_mul(const mat66& A, const spatial& v) {
+    float r[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sum += A.a[i][j] * fs_sget(v, j);
+        r[i] = sum;
+    }
+    return spatial(vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]));
+}
+
+// jcalc_transform (kernels.py:142-239)
+template <int EPB>
+NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int lin, int ang, int q_off, int q_start) {
+    const Ctx<EPB>& c = f.c;
+    if (type == JT_PRISMATIC) return xform(c.dof_axis(qd_start) * f.f(q_off, q_start), quat_identity());
+    if (type == JT_REVOLUTE) return xform(vec3(), quat_from_axis_angle(c.dof_axis(qd_start), f.f(q_off, q_start)));
+    if (type == JT_BALL)
+        return xform(vec3(), quat(f.f(q_off, q_start), f.f(q_off, q_start + 1), f.f(q_off, q_start + 2), f.f(q_off, q_start + 3)));
+    if (type == JT_FREE || type == JT_DISTANCE)
+        return xform(vec3(f.f(q_off, q_start), f.f(q_off, q_start + 1), f.f(q_off, q_start + 2)),
+                     quat(f.f(q_off, q_start + 3), f.f(q_off, q_start + 4), f.f(q_off, q_start + 5), f.f(q_off, q_start + 6)));
+    if (type == JT_D6) {
+        vec3 pos(0.0f);
+        quat rot = quat_identity();
+        if (lin > 0) pos += c.dof_axis(qd_start + 0) * f.f(q_off, q_start + 0);
+        if (lin > 1) pos += c.dof_axis(qd_start + 1) * f.f(q_off, q_start + 1);
+        if (lin > 2) pos += c.dof_axis(qd_start + 2) * f.f(q_off, q_start + 2);
+        if (ang == 1) rot = quat_from_axis_angle(c.dof_axis(qd_start + lin), f.f(q_off, q_start + lin));
+        return xform(pos, rot);
+    }
+    return xform();
+}
+
+// compute_link_transform (kernels.py:633-684): body_q[child], COM world position
+template <int EPB>
+NT_DI void fs_fk_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int parent = c.T.joint_parent[j], child = c.T.joint_child[j];
+    xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
+    if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
+    xform X_j = fs_joint_transform(f, c.T.joint_type[j], c.T.joint_qd_start[j], c.T.joint_lin_count[j], c.T.joint_ang_count[j],
+                                   f.F.jq, c.T.joint_q_start[j]);
+    xform X_wcj = X_wpj * X_j;
+    xform X_wc = X_wcj * xform_inverse(c.lxf(c.L.jp, 7, m.nj, j));
+    c.st_lxf(c.L.bq, m.nb, child, X_wc);
+    xform X_sm = X_wc * xform(c.com(child), quat_identity());
+    c.st_lv3(f.F.qcom, 0, m.nb, child, X_sm.p);
+}
+
+// FREE/DISTANCE anchor offset r_child_com_parent (kernels.py:946-954,1037-1044), on the body poses currently in LDS
+template <int EPB>
+NT_DI vec3 fs_free_com_offset(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const int parent = c.T.joint_parent[j], child = c.T.joint_child[j];
+    xform X_wpj = c.lxf(c.L.jp, 0, c.a.m.nj, j);
+    if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
+    vec3 x_child_com_world = xform_point(c.body_q(child), c.com(child));
+    return quat_rotate_inv(X_wpj.q, x_child_com_world - X_wpj.p);
+}
+
+// convert_free_distance_joint_qd_public_to_internal + joint_f_public_to_internal (kernels.py:924-975,1069-1088)
+template <int EPB>
+NT_DI void fs_to_internal_item(const FsCtx<EPB>& f, int j, const float* joint_qd_public) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int qs = c.T.joint_qd_start[j], type = c.T.joint_type[j];
+    const int qe = j + 1 < m.nj ? c.T.joint_qd_start[j + 1] : m.nd;
+    auto pub = [&](int i) { return joint_qd_public[(size_t)i * c.ES + c.env]; };
+    if (type != JT_FREE && type != JT_DISTANCE) {
+        for (int i = qs; i < qe; ++i) {
+            f.f(f.F.qdi, i) = pub(i);
+            f.f(f.F.jfi, i) = c.l(c.L.cf, 0, 1, i);
+        }
+        return;
+    }
+    vec3 r = fs_free_com_offset(f, j);
+    vec3 v_com(pub(qs), pub(qs + 1), pub(qs + 2)), omega(pub(qs + 3), pub(qs + 4), pub(qs + 5));
+    vec3 v_int = v_com - cross(omega, r);
+    f.f(f.F.qdi, qs + 0) = v_int.x; f.f(f.F.qdi, qs + 1) = v_int.y; f.f(f.F.qdi, qs + 2) = v_int.z;
+    f.f(f.F.qdi, qs + 3) = omega.x; f.f(f.F.qdi, qs + 4) = omega.y; f.f(f.F.qdi, qs + 5) = omega.z;
+    for (int i = qs; i < qe; ++i) f.f(f.F.jfi, i) = 0.0f;
+}
+
+// transform_spatial_inertia (kernels.py:66-139): T^T I T with T = [[R, skew(p) R], [0, R]] of the inverse transform
+NT_DI void fs_transform_spatial_inertia(const xform& t, float mass, const mat33& Ib, mat66& out) {
+    xform t_inv = xform_inverse(t);
+    quat q = t_inv.q;
+    vec3 p = t_inv.p;
+    vec3 r1 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
+    vec3 r2 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
+    vec3 r3 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+    float R[3][3] = {{r1.x, r2.x, r3.x}, {r1.y, r2.y, r3.y}, {r1.z, r2.z, r3.z}};
+    float K[3][3] = {{0.0f, -p.z, p.y}, {p.z, 0.0f, -p.x}, {-p.y, p.x, 0.0f}};
+    float S[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sum += K[i][k] * R[k][j];
+            S[i][j] = sum;
+        }
+    mat66 T, I;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            T.a[i][j] = 0.0f;
+            I.a[i][j] = 0.0f;
+        }
+    const float Im[3][3] = {{Ib.m00, Ib.m01, Ib.m02}, {Ib.m10, Ib.m11, Ib.m12}, {Ib.m20, Ib.m21, Ib.m22}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        I.a[i][i] = mass;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T.a[i][j] = R[i][j];
+            T.a[i][j + 3] = S[i][j];
+            T.a[i + 3][j + 3] = R[i][j];
+            I.a[i + 3][j + 3] = Im[i][j];
+        }
+    }
+    mat66 A;  // T^T I
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sum += T.a[k][i] * I.a[k][j];
+            A.a[i][j] = sum;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sum += A.a[i][k] * T.a[k][j];
+            out.a[i][j] = sum;
+        }
+}
+
+// compute_link_velocity (kernels.py:764-866) incl. jcalc_motion (kernels.py:242-380)
+template <int EPB>
+NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nd = m.nd;
+    const int type = c.T.joint_type[j], child = c.T.joint_child[j], parent = c.T.joint_parent[j];
+    const int qd_start = c.T.joint_qd_start[j];
+    const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
+    // solve origin: COM of the articulation root's child when the root is FREE/DISTANCE (kernels.py:1280-1288)
+    int root = j;
+    while (f.anc[root] >= 0) root = f.anc[root];
+    vec3 solve_origin;
+    {
+        int rt = c.T.joint_type[root];
+        if (rt == JT_FREE || rt == JT_DISTANCE) solve_origin = f.v3(f.F.qcom, 0, nb, c.T.joint_child[root]);
+    }
+    xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
+    if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
+    xform X_sc(X_wpj.p - solve_origin, X_wpj.q);
+
+    spatial v_j_s;
+    auto qd = [&](int i) { return f.f(f.F.qdi, i); };
+    auto put_S = [&](int d, const spatial& S_s) { f.st6(f.F.S, nd, d, S_s); };
+    if (type == JT_PRISMATIC) {
+        spatial S_s = fs_transform_twist(X_sc, spatial(c.dof_axis(qd_start), vec3()));
+        put_S(qd_start, S_s);
+        v_j_s = S_s * qd(qd_start);
+    } else if (type == JT_REVOLUTE) {
+        spatial S_s = fs_transform_twist(X_sc, spatial(vec3(), c.dof_axis(qd_start)));
+        put_S(qd_start, S_s);
+        v_j_s = S_s * qd(qd_start);
+    } else if (type == JT_D6) {
+        for (int k = 0; k < 3; ++k)
+            if (lin > k) {
+                spatial S_s = fs_transform_twist(X_sc, spatial(c.dof_axis(qd_start + k), vec3()));
+                v_j_s = v_j_s + S_s * qd(qd_start + k);
+                put_S(qd_start + k, S_s);
+            }
+        if (ang == 1) {
+            int iqd = qd_start + lin;
+            spatial S_s = fs_transform_twist(X_sc, spatial(vec3(), c.dof_axis(iqd)));
+            v_j_s = v_j_s + S_s * qd(iqd);
+            put_S(iqd, S_s);
+        }
+    } else if (type == JT_BALL) {
+        spatial S_0 = fs_transform_twist(X_sc, spatial(vec3(), vec3(1.0f, 0.0f, 0.0f)));
+        spatial S_1 = fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 1.0f, 0.0f)));
+        spatial S_2 = fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 0.0f, 1.0f)));
+        put_S(qd_start + 0, S_0);
+        put_S(qd_start + 1, S_1);
+        put_S(qd_start + 2, S_2);
+        v_j_s = S_0 * qd(qd_start + 0) + S_1 * qd(qd_start + 1) + S_2 * qd(qd_start + 2);
+    } else if (type == JT_FREE || type == JT_DISTANCE) {
+        v_j_s = fs_transform_twist(X_sc, spatial(vec3(qd(qd_start), qd(qd_start + 1), qd(qd_start + 2)),
+                                                 vec3(qd(qd_start + 3), qd(qd_start + 4), qd(qd_start + 5))));
+        put_S(qd_start + 0, fs_transform_twist(X_sc, spatial(vec3(1.0f, 0.0f, 0.0f), vec3())));
+        put_S(qd_start + 1, fs_transform_twist(X_sc, spatial(vec3(0.0f, 1.0f, 0.0f), vec3())));
+        put_S(qd_start + 2, fs_transform_twist(X_sc, spatial(vec3(0.0f, 0.0f, 1.0f), vec3())));
+        put_S(qd_start + 3, fs_transform_twist(X_sc, spatial(vec3(), vec3(1.0f, 0.0f, 0.0f))));
+        put_S(qd_start + 4, fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 1.0f, 0.0f))));
+        put_S(qd_start + 5, fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 0.0f, 1.0f))));
+    }
+    spatial v_parent_s, a_parent_s;
+    if (parent >= 0) {
+        v_parent_s = f.sp6(f.F.vs, nb, parent);
+        a_parent_s = f.sp6(f.F.as, nb, parent);
+    }
+    spatial v_s = v_parent_s + v_j_s;
+    spatial a_s = a_parent_s + fs_spatial_cross(v_s, v_j_s) + spatial();
+
+    vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - solve_origin;
+    c.st_lv3(f.F.org, 0, nb, child, solve_origin);
+    float mass = c.l(c.L.bp, BP_MASS, nb, child);
+    vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
+    vec3 f_g = mass * gravity;
+    spatial f_g_s(f_g, cross(x_com_s, f_g));
+    mat66 I_s;
+    fs_transform_spatial_inertia(xform(x_com_s, c.body_rot(child)), mass, c.inertia(child), I_s);
+    spatial f_b_s = fs_mul(I_s, a_s) + fs_spatial_cross_dual(v_s, fs_mul(I_s, v_s));
+    vec3 omega_world = v_s.bottom;
+    vec3 v_com_world = v_s.top + cross(omega_world, x_com_s);
+    // body_qd_fk lives in the body_qd rows until the final FK overwrites them with the public output twist
+    c.st_lv3(c.L.bqd, 0, nb, child, v_com_world);
+    c.st_lv3(c.L.bqd, 3, nb, child, omega_world);
+    f.st6(f.F.vs, nb, child, v_s);
+    f.st6(f.F.as, nb, child, a_s);
+    f.st6(f.F.fs, nb, child, f_b_s - f_g_s);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c.l(f.F.Is, i * 6 + k, nb, child) = I_s.a[i][k];
+}
+
+// body_f_ext = state_in.body_f + FREE/DISTANCE joint_f (kernels.py:893-921) + contact wrenches in contact order
+template <int EPB>
+NT_DI void fs_body_force_item(const FsCtx<EPB>& f, int b) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    vec3 f0, t0;
+    if (c.a.s_in.body_f) {
+        f0 = c.gv3(c.a.s_in.body_f, 0, nb, b);
+        t0 = c.gv3(c.a.s_in.body_f, 3, nb, b);
+    }
+    for (int j = 0; j < m.nj; ++j) {
+        int type = c.T.joint_type[j];
+        if ((type == JT_FREE || type == JT_DISTANCE) && c.T.joint_child[j] == b) {
+            int qs = c.T.joint_qd_start[j];
+            f0 += vec3(c.l(c.L.cf, 0, 1, qs), c.l(c.L.cf, 0, 1, qs + 1), c.l(c.L.cf, 0, 1, qs + 2));
+            t0 += vec3(c.l(c.L.cf, 0, 1, qs + 3), c.l(c.L.cf, 0, 1, qs + 4), c.l(c.L.cf, 0, 1, qs + 5));
+        }
+    }
+    if (c.a.has_contacts) {
+        const int cpp = m.cpp, ncs = m.np * cpp;
+        for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+            int code = c.T.body_pair_list[i];
+            int p = code >> 1, side = code & 1;
+            for (int k = 0; k < cpp; ++k) {
+                int slot = p * cpp + k;
+                bool is_a = (side == 0) == (c.l(f.F.cw, 14, ncs, slot) != 0.0f);
+                if (c.l(f.F.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                    vec3 ff = c.lv3(f.F.cw, is_a ? 0 : 6, ncs, slot), tt = c.lv3(f.F.cw, is_a ? 3 : 9, ncs, slot);
+                    if (is_a) { f0 -= ff; t0 -= tt; }
+                    else { f0 += ff; t0 += tt; }
+                }
+            }
+        }
+    }
+    c.st_lv3(f.F.bfx, 0, nb, b, f0);
+    c.st_lv3(f.F.bfx, 3, nb, b, t0);
+}
+
+// eval_rigid_tau for one joint (kernels.py:1320-1419); children of the joint's body were processed one level deeper
+template <int EPB>
+NT_DI void fs_tau_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nd = m.nd;
+    const int type = c.T.joint_type[j], child = c.T.joint_child[j];
+    const int dof_start = c.T.joint_qd_start[j], coord_start = c.T.joint_q_start[j], tq_start = c.T.joint_tq_start[j];
+    const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
+    // body_ft_s[child]: the reference walks joints in descending index and accumulates into the parent
+    spatial f_t_s;
+    for (int k = m.nj - 1; k > j; --k)
+        if (f.anc[k] == j) f_t_s = f_t_s + f.sp6(f.F.ft, nb, k);
+    vec3 force = f.v3(f.F.bfx, 0, nb, child), torque_com = f.v3(f.F.bfx, 3, nb, child);
+    vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - f.v3(f.F.org, 0, nb, child);
+    spatial f_ext(-force, -(torque_com + cross(x_com_s, force)));
+    spatial f_s = f.sp6(f.F.fs, nb, child) + f_t_s + f_ext;
+    f.st6(f.F.ft, nb, j, f_s);
+    auto sdot = [&](int d) {
+        spatial S = f.sp6(f.F.S, nd, d);
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s += fs_sget(S, i) * fs_sget(f_s, i);
+        return s;
+    };
+    if (type == JT_BALL) {
+        for (int i = 0; i < 3; ++i) {
+            int d = dof_start + i;
+            float passive_f = -c.dof(DP_DAMPING, d) * f.f(f.F.qdi, d);
+            f.f(f.F.tau, d) = -sdot(d) + f.f(f.F.jfi, d) + passive_f;
+        }
+    } else if (type == JT_FREE || type == JT_DISTANCE) {
+        for (int i = 0; i < 6; ++i) f.f(f.F.tau, dof_start + i) = -sdot(dof_start + i) + f.f(f.F.jfi, dof_start + i);
+    } else if (type == JT_PRISMATIC || type == JT_REVOLUTE || type == JT_D6) {
+        for (int i = 0; i < lin + ang; ++i) {
+            int d = dof_start + i;
+            float drive_f = si_dof_force(c, d, tq_start + i, f.f(f.F.jq, coord_start + i), f.f(f.F.qdi, d));
+            f.f(f.F.tau, d) = -sdot(d) + drive_f + f.f(f.F.jfi, d);
+        }
+    }
+}
+
+// is joint `a` an ancestor-or-self of joint `j`?
+template <int EPB>
+NT_DI bool fs_on_path(const FsCtx<EPB>& f, int a, int j) {
+    while (j >= 0) {
+        if (j == a) return true;
+        j = f.anc[j];
+    }
+    return false;
+}
+template <int EPB>
+NT_DI int fs_joint_of_dof(const FsCtx<EPB>& f, int d) {
+    const nt_model& m = f.c.a.m;
+    int j = 0;
+    for (int k = 1; k < m.nj; ++k)
+        if (f.c.T.joint_qd_start[k] <= d) j = k;
+    return j;
+}
+
+// P[b][dl] = I_b S_d for every dof d on the path root..joint(b); item = b * W + dl
+template <int EPB>
+NT_DI void fs_P_item(const FsCtx<EPB>& f, int item) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int W = m.max_art_dofs, nb = m.nb, nd = m.nd;
+    const int l = item / W, dl = item - l * W;  // l: joint (== body) index
+    const int a = f.art[l];
+    const int art_j0 = m.art_start[a];
+    const int d0 = c.T.joint_qd_start[art_j0];
+    const int d = d0 + dl;
+    const int art_j1 = m.art_start[a + 1];
+    const int d1 = art_j1 < m.nj ? c.T.joint_qd_start[art_j1] : nd;
+    if (d >= d1) return;
+    if (!fs_on_path(f, fs_joint_of_dof(f, d), l)) return;
+    const int b = l;  // body l of the articulation == child of joint l (host-checked)
+    spatial S = f.sp6(f.F.S, nd, d);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum += c.l(f.F.Is, i * 6 + k, nb, b) * fs_sget(S, k);
+        c.l(f.F.P, i, nb * W, l * W + dl) = sum;
+    }
+}
+// H[i][jl] (lower triangle, jl <= il): sum over bodies whose path holds both dofs; item = i * W + jl
+template <int EPB>
+NT_DI void fs_H_item(const FsCtx<EPB>& f, int item) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int W = m.max_art_dofs, nb = m.nb, nd = m.nd;
+    const int i = item / W, jl = item - i * W;
+    const int ji = fs_joint_of_dof(f, i);
+    const int a = f.art[ji];
+    const int art_j0 = m.art_start[a], art_j1 = m.art_start[a + 1];
+    const int d0 = c.T.joint_qd_start[art_j0];
+    const int il = i - d0;
+    if (jl > il) return;
+    const int jj = fs_joint_of_dof(f, d0 + jl);
+    spatial S_i = f.sp6(f.F.S, nd, i);
+    float sum = 0.0f;
+    for (int l = art_j0; l < art_j1; ++l) {
+        if (!fs_on_path(f, ji, l) || !fs_on_path(f, jj, l)) continue;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sum += fs_sget(S_i, r) * c.l(f.F.P, r, nb * W, l * W + jl);
+    }
+    c.l(f.F.H, 0, 1, i * W + jl) = sum;
+}
+
+// dense_cholesky (in place over the lower triangle of H) + dense_subs for one articulation (kernels.py:1690-1797)
+template <int EPB>
+NT_DI void fs_solve_item(const FsCtx<EPB>& f, int a) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int W = m.max_art_dofs, nd = m.nd;
+    const int art_j0 = m.art_start[a], art_j1 = m.art_start[a + 1];
+    const int d0 = c.T.joint_qd_start[art_j0];
+    const int d1 = art_j1 < m.nj ? c.T.joint_qd_start[art_j1] : nd;
+    const int n = d1 - d0;
+    auto A = [&](int i, int j) -> float& { return c.l(f.F.H, 0, 1, (d0 + i) * W + j); };
+    for (int j = 0; j < n; ++j) {
+        float s = A(j, j) + c.dof(DP_ARMATURE, d0 + j);
+        for (int k = 0; k < j; ++k) {
+            float r = A(j, k);
+            s -= r * r;
+        }
+        s = sqrtf(s);
+        float invS = 1.0f / s;
+        A(j, j) = s;
+        for (int i = j + 1; i < n; ++i) {
+            s = A(i, j);
+            for (int k = 0; k < j; ++k) s -= A(i, k) * A(j, k);
+            A(i, j) = s * invS;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        float s = f.f(f.F.tau, d0 + i);
+        for (int j = 0; j < i; ++j) s -= A(i, j) * f.f(f.F.qdd, d0 + j);
+        f.f(f.F.qdd, d0 + i) = s / A(i, i);
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        float s = f.f(f.F.qdd, d0 + i);
+        for (int j = i + 1; j < n; ++j) s -= A(j, i) * f.f(f.F.qdd, d0 + j);
+        f.f(f.F.qdd, d0 + i) = s / A(i, i);
+    }
+}
+
+// jcalc_integrate (kernels.py:464-630): writes joint_q (in place) and the internal output velocity
+template <int EPB>
+NT_DI void fs_integrate_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int type = c.T.joint_type[j], child = c.T.joint_child[j];
+    const int cs = c.T.joint_q_start[j], ds = c.T.joint_qd_start[j];
+    const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
+    const float dt = c.a.dt;
+    auto q = [&](int i) -> float& { return f.f(f.F.jq, i); };
+    auto qd = [&](int i) { return f.f(f.F.qdi, i); };
+    auto qdd = [&](int i) { return f.f(f.F.qdd, i); };
+    auto qdn = [&](int i) -> float& { return f.f(f.F.qdo, i); };
+    if (type == JT_FIXED) return;
+    if (type == JT_PRISMATIC || type == JT_REVOLUTE) {
+        float qd_new = qd(ds) + qdd(ds) * dt;
+        float q_new = q(cs) + qd_new * dt;
+        qdn(ds) = qd_new;
+        q(cs) = q_new;
+        return;
+    }
+    if (type == JT_BALL) {
+        vec3 m_j(qdd(ds), qdd(ds + 1), qdd(ds + 2)), w_j(qd(ds), qd(ds + 1), qd(ds + 2));
+        quat r_j(q(cs), q(cs + 1), q(cs + 2), q(cs + 3));
+        vec3 w_j_new = w_j + m_j * dt;
+        quat drdt_j = quat(w_j_new, 0.0f) * r_j * 0.5f;
+        quat r_j_new = normalize(r_j + drdt_j * dt);
+        q(cs) = r_j_new.x; q(cs + 1) = r_j_new.y; q(cs + 2) = r_j_new.z; q(cs + 3) = r_j_new.w;
+        qdn(ds) = w_j_new.x; qdn(ds + 1) = w_j_new.y; qdn(ds + 2) = w_j_new.z;
+        return;
+    }
+    if (type == JT_FREE || type == JT_DISTANCE) {  // root branch (parent < 0); descendants are rejected by the host
+        vec3 a_parent(qdd(ds), qdd(ds + 1), qdd(ds + 2)), alpha(qdd(ds + 3), qdd(ds + 4), qdd(ds + 5));
+        vec3 v_parent(qd(ds), qd(ds + 1), qd(ds + 2)), omega(qd(ds + 3), qd(ds + 4), qd(ds + 5));
+        vec3 p(q(cs), q(cs + 1), q(cs + 2));
+        quat r(q(cs + 3), q(cs + 4), q(cs + 5), q(cs + 6));
+        vec3 r_com_joint = xform_point(xform_inverse(c.lxf(c.L.jp, 7, m.nj, j)), c.com(child));
+        vec3 x_com = p + quat_rotate(r, r_com_joint);
+        vec3 v_com = v_parent + cross(omega, x_com);
+        vec3 a_com = a_parent + cross(alpha, x_com) + cross(omega, v_com);
+        vec3 omega_new = omega + alpha * dt;
+        vec3 v_com_new = v_com + a_com * dt;
+        quat drdt = quat(omega_new, 0.0f) * r * 0.5f;
+        quat r_new = normalize(r + drdt * dt);
+        vec3 x_com_new = x_com + v_com_new * dt;
+        vec3 p_new = x_com_new - quat_rotate(r_new, r_com_joint);
+        vec3 v_parent_new = v_com_new - cross(omega_new, x_com_new);
+        q(cs) = p_new.x; q(cs + 1) = p_new.y; q(cs + 2) = p_new.z;
+        q(cs + 3) = r_new.x; q(cs + 4) = r_new.y; q(cs + 5) = r_new.z; q(cs + 6) = r_new.w;
+        qdn(ds) = v_parent_new.x; qdn(ds + 1) = v_parent_new.y; qdn(ds + 2) = v_parent_new.z;
+        qdn(ds + 3) = omega_new.x; qdn(ds + 4) = omega_new.y; qdn(ds + 5) = omega_new.z;
+        return;
+    }
+    if (type == JT_D6) {
+        for (int i = 0; i < lin + ang; ++i) {
+            float qd_new = qd(ds + i) + qdd(ds + i) * dt;
+            float q_new = q(cs + i) + qd_new * dt;
+            qdn(ds + i) = qd_new;
+            q(cs + i) = q_new;
+        }
+    }
+}
+
+// eval_single_articulation_fk_with_velocity_conversion for one joint (kernels.py:1987-2150): final body_q / body_qd
+template <int EPB>
+NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    const int parent = c.T.joint_parent[j], child = c.T.joint_child[j], type = c.T.joint_type[j];
+    const int qs = c.T.joint_qd_start[j];
+    const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
+    auto qd = [&](int i) { return f.f(f.F.qdo, i); };
+    xform X_j = fs_joint_transform(f, type, qs, lin, ang, f.F.jq, c.T.joint_q_start[j]);
+    spatial v_j;
+    if (type == JT_PRISMATIC) v_j = spatial(c.dof_axis(qs) * qd(qs), vec3());
+    if (type == JT_REVOLUTE) v_j = spatial(vec3(), c.dof_axis(qs) * qd(qs));
+    if (type == JT_BALL) v_j = spatial(vec3(), vec3(qd(qs), qd(qs + 1), qd(qs + 2)));
+    if (type == JT_FREE || type == JT_DISTANCE)
+        v_j = spatial(vec3(qd(qs), qd(qs + 1), qd(qs + 2)), vec3(qd(qs + 3), qd(qs + 4), qd(qs + 5)));
+    if (type == JT_D6) {
+        vec3 vel_v(0.0f), vel_w(0.0f);
+        for (int k = 0; k < 3; ++k)
+            if (lin > k) vel_v += c.dof_axis(qs + k) * qd(qs + k);
+        if (ang == 1) vel_w = qd(qs + lin) * c.dof_axis(qs + lin);
+        v_j = spatial(vel_v, vel_w);
+    }
+    xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
+    xform X_wp;
+    if (parent >= 0) {
+        X_wp = c.body_q(parent);
+        X_wpj = X_wp * X_wpj;
+    }
+    xform X_wcj = X_wpj * X_j;
+    xform X_wc = X_wcj * xform_inverse(c.lxf(c.L.jp, 7, m.nj, j));
+    vec3 x_child_origin = X_wc.p;
+    vec3 v_parent_origin, w_parent;
+    if (parent >= 0) {
+        w_parent = c.body_w(parent);
+        vec3 r = x_child_origin - xform_point(X_wp, c.com(parent));
+        v_parent_origin = cross(w_parent, r) + c.body_v(parent);
+    }
+    vec3 linear_joint_world = xform_vector(X_wpj, v_j.top);
+    vec3 angular_joint_world = xform_vector(X_wpj, v_j.bottom);
+    vec3 linear_joint_origin;
+    if (type == JT_FREE || type == JT_DISTANCE) {
+        spatial v_j_world = fs_transform_twist(X_wpj, v_j);
+        linear_joint_origin = cross(v_j_world.bottom, x_child_origin) + v_j_world.top;
+        angular_joint_world = v_j_world.bottom;
+    } else {
+        vec3 child_origin_offset_world = x_child_origin - X_wcj.p;
+        linear_joint_origin = linear_joint_world + cross(angular_joint_world, child_origin_offset_world);
+    }
+    vec3 v_origin = v_parent_origin + linear_joint_origin, w = w_parent + angular_joint_world;
+    c.st_lxf(c.L.bq, nb, child, X_wc);
+    c.st_lv3(c.L.bqd, 0, nb, child, cross(w, xform_vector(X_wc, c.com(child))) + v_origin);
+    c.st_lv3(c.L.bqd, 3, nb, child, w);
+}
+
+// convert_free_distance_joint_qd_internal_to_public (kernels.py:1015-1066) straight into state_out.joint_qd
+template <int EPB>
+NT_DI void fs_to_public_item(const FsCtx<EPB>& f, int j, float* joint_qd_public) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int qs = c.T.joint_qd_start[j], type = c.T.joint_type[j];
+    const int qe = j + 1 < m.nj ? c.T.joint_qd_start[j + 1] : m.nd;
+    auto out = [&](int i) -> float& { return joint_qd_public[(size_t)i * c.ES + c.env]; };
+    if (type != JT_FREE && type != JT_DISTANCE) {
+        for (int i = qs; i < qe; ++i) out(i) = f.f(f.F.qdo, i);
+        return;
+    }
+    vec3 r = fs_free_com_offset(f, j);
+    vec3 v_int(f.f(f.F.qdo, qs), f.f(f.F.qdo, qs + 1), f.f(f.F.qdo, qs + 2));
+    vec3 omega(f.f(f.F.qdo, qs + 3), f.f(f.F.qdo, qs + 4), f.f(f.F.qdo, qs + 5));
+    vec3 v_com = v_int + cross(omega, r);
+    out(qs) = v_com.x; out(qs + 1) = v_com.y; out(qs + 2) = v_com.z;
+    out(qs + 3) = omega.x; out(qs + 4) = omega.y; out(qs + 5) = omega.z;
+}
+
+// One SolverFeatherstone.step for EPB environments.
+template <int EPB>
+__global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const nt_model& m = a.m;
+    const int nj = m.nj, nb = m.nb;
+    const FsLayout F = make_fs_layout(m, make_layout(m));
+    Ctx<EPB> c(a, lds, F.rows);  // topology ints are staged behind the Featherstone rows
+    // block-shared tree tables behind the per-env rows and the staged topology
+    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+        int p = c.T.joint_parent[j], anc = -1;
+        if (p >= 0)
+            for (int k = 0; k < nj; ++k)
+                if (c.T.joint_child[k] == p) anc = k;
+        extra[j] = anc;
+        int art = 0;
+        for (int k = 0; k < m.na; ++k)
+            if (m.art_start[k] <= j) art = k;
+        extra[2 * nj + j] = art;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+        int d = 0, k = extra[j];
+        while (k >= 0) { d += 1; k = extra[k]; }
+        extra[nj + j] = d;
+    }
+    __syncthreads();
+    FsCtx<EPB> f(c, extra);
+    int max_depth = 0;
+    for (int j = 0; j < nj; ++j) max_depth = imax(max_depth, f.depth[j]);
+
+    load_params(c, true);
+    if (c.valid) stage_rows(c, F.jq, a.s_in.joint_q, m.nc);
+    __syncthreads();
+
+    // eval_rigid_fk, level by level (a joint's parent body is final one level earlier)
+    for (int lvl = 0; lvl <= max_depth; ++lvl) {
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot)
+                if (f.depth[j] == lvl) fs_fk_item(f, j);
+        __syncthreads();
+    }
+    // state_in.body_q is refreshed by the reference step (solver_featherstone.py:492-514): publish it when distinct
+    if (c.valid && a.s_in.body_q != a.s_out.body_q) unstage_rows(c, c.L.bq, a.s_in.body_q, 7 * nb);
+    if (c.valid)
+        for (int j = c.slot; j < nj; j += c.nslot) fs_to_internal_item(f, j, a.s_in.joint_qd);
+    __syncthreads();
+    // eval_rigid_id
+    for (int lvl = 0; lvl <= max_depth; ++lvl) {
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot)
+                if (f.depth[j] == lvl) fs_motion_item(f, j);
+        __syncthreads();
+    }
+    // eval_body_contact on (body_q, body_qd_fk)
+    if (a.has_contacts) {
+        Ctx<EPB> cc = c;
+        cc.L.si_cw = F.cw;
+        if (c.valid)
+            for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) si_contact_item(cc, s);
+        __syncthreads();
+    }
+    if (c.valid)
+        for (int b = c.slot; b < nb; b += c.nslot) fs_body_force_item(f, b);
+    __syncthreads();
+    // eval_rigid_tau, deepest level first
+    for (int lvl = max_depth; lvl >= 0; --lvl) {
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot)
+                if (f.depth[j] == lvl) fs_tau_item(f, j);
+        __syncthreads();
+    }
+    // P = M J (non-zero blocks), H = J^T P (lower triangle), Cholesky, solve
+    const int W = m.max_art_dofs;
+    if (c.valid)
+        for (int i = c.slot; i < nj * W; i += c.nslot) fs_P_item(f, i);
+    __syncthreads();
+    if (c.valid)
+        for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
+    __syncthreads();
+    if (c.valid)
+        for (int k = c.slot; k < m.na; k += c.nslot) fs_solve_item(f, k);
+    __syncthreads();
+    // integrate_generalized_joints
+    if (c.valid)
+        for (int j = c.slot; j < nj; j += c.nslot) fs_integrate_item(f, j);
+    __syncthreads();
+    // FK with velocity conversion -> public body_q / body_qd
+    for (int lvl = 0; lvl <= max_depth; ++lvl) {
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot)
+                if (f.depth[j] == lvl) fs_fk_vel_item(f, j);
+        __syncthreads();
+    }
+    if (c.valid) {
+        for (int j = c.slot; j < nj; j += c.nslot) fs_to_public_item(f, j, a.s_out.joint_qd);
+        unstage_rows(c, F.jq, a.s_out.joint_q, m.nc);
+    }
+    store_state(c, a.s_out);
+}

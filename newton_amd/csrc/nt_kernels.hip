@@ -134,8 +134,10 @@ struct Ctx {
     int ES;
     bool valid;
 
-    NT_DI Ctx(const KArgs& a_, float* lds_) : a(a_), lds(lds_) {
+    // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
+    NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1) : a(a_), lds(lds_) {
         L = make_layout(a.m);
+        if (rows < 0) rows = L.rows_per_env;
         e = threadIdx.x % EPB;
         slot = threadIdx.x / EPB;
         nslot = a.nslot;
@@ -143,7 +145,7 @@ struct Ctx {
         ES = a.m.env_stride;
         valid = env < a.m.env_count && slot < nslot;
         const nt_model& m = a.m;
-        int* ti = reinterpret_cast<int*>(lds + (size_t)L.rows_per_env * EPB);
+        int* ti = reinterpret_cast<int*>(lds + (size_t)rows * EPB);
         int o = 0;
         auto take = [&](const int*& dst, const int32_t* src, int n) {
             for (int i = threadIdx.x; i < n; i += blockDim.x) ti[o + i] = src[i];
@@ -1558,6 +1560,8 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kerne
     store_state(c, a.s_out);
 }
 
+#include "nt_featherstone.hpp"
+
 __global__ void clear_forces_kernel(float* body_f, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1852,6 +1856,58 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
     int epb = pick_epb(*m, envs_per_block);
     if (!epb) return NT_ERR_UNSUPPORTED;
     return NT_DISPATCH_EPB(semi_implicit_step_kernel, a, epb, (hipStream_t)stream);
+}
+
+nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* p, nt_state* s_in, nt_state* s_out,
+                                const nt_control* ctrl, const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
+    if (!model_ok(m) || !p || !s_in || !s_out || !ctrl) return NT_ERR_INVALID_ARG;
+    if (!s_in->joint_q || !s_in->joint_qd || !s_out->joint_q || !s_out->joint_qd || !s_in->body_q || !s_out->body_q ||
+        !s_out->body_qd)
+        return NT_ERR_INVALID_ARG;
+    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs <= 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
+    KArgs a = {};
+    a.m = *m;
+    a.s_in = *s_in;
+    a.s_out = *s_out;
+    a.c = *ctrl;
+    if (c) a.ct = *c;
+    a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
+    a.sp.friction_smoothing = p->friction_smoothing;
+    a.angular_damping = p->angular_damping;
+    a.dt = dt;
+    const FsLayout F = make_fs_layout(*m, make_layout(*m));
+    const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
+    auto fits = [&](int epb) { return (size_t)F.rows * 4 * epb + shared_ints * 4 <= LDS_BYTES_PER_CU; };
+    int epb = 0;
+    if (envs_per_block == 4 || envs_per_block == 8 || envs_per_block == 16) {
+        epb = fits(envs_per_block) ? envs_per_block : 0;
+    } else {
+        const int cands[3] = {16, 8, 4};
+        for (int i = 0; i < 3 && !epb; ++i)
+            if (fits(cands[i])) epb = cands[i];
+    }
+    if (!epb) return NT_ERR_UNSUPPORTED;
+    int want = imax(imax(m->nb, m->nj), imax(m->np * m->cpp, imax(m->nj, m->nd) * m->max_art_dofs));
+    int cap = 256 / epb;
+    a.nslot = want < cap ? want : cap;
+    int threads = ((a.nslot * epb + 63) / 64) * 64;
+    size_t lds_bytes = (size_t)F.rows * 4 * epb + shared_ints * 4;
+    int blocks = (m->env_count + epb - 1) / epb;
+    auto go = [&](auto kernel) -> nt_status {
+        if (lds_bytes > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return NT_ERR_LAUNCH;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, a);
+        return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+    };
+    if (epb == 16) return go(featherstone_step_kernel<16>);
+    if (epb == 8) return go(featherstone_step_kernel<8>);
+    return go(featherstone_step_kernel<4>);
+}
+
+int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m) {
+    if (!m) return -1;
+    return make_fs_layout(*m, make_layout(*m)).rows * 4;
 }
 
 nt_status nt_eval_fk(const nt_model*, const float*, const float*, nt_state*, void*) { return NT_ERR_UNSUPPORTED; }

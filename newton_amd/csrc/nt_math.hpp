@@ -138,6 +138,9 @@ struct spatial {
     NT_DI spatial() {}
     NT_DI spatial(vec3 a, vec3 b) : top(a), bottom(b) {}
 };
+NT_DI spatial operator+(const spatial& a, const spatial& b) { return spatial(a.top + b.top, a.bottom + b.bottom); }
+NT_DI spatial operator-(const spatial& a, const spatial& b) { return spatial(a.top - b.top, a.bottom - b.bottom); }
+NT_DI spatial operator*(const spatial& a, float s) { return spatial(a.top * s, a.bottom * s); }
 NT_DI vec3 velocity_at_point(const spatial& qd, vec3 r) { return cross(qd.bottom, r) + qd.top; }
 
 }  // namespace nt

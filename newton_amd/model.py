@@ -106,6 +106,27 @@ class EnvTemplate:
         self.joint_lin_count = dd[0, :, 0].astype(np.int32)
         self.joint_ang_count = dd[0, :, 1].astype(np.int32)
 
+        # articulations (SolverFeatherstone): env-local joint ranges, same in every world
+        A = int(getattr(m, "articulation_count", 0))
+        if A and nj and A % E == 0:
+            na = A // E
+            starts = np.asarray(m.articulation_start).reshape(E, na) - env_ids * nj
+            ends = np.asarray(m.articulation_end).reshape(E, na) - env_ids * nj
+            if E > 1 and not (np.all(starts == starts[0:1]) and np.all(ends == ends[0:1])):
+                raise NotImplementedError("heterogeneous worlds: articulations differ between worlds")
+            contiguous = na > 0 and starts[0, 0] == 0 and ends[0, -1] == nj and np.all(starts[0, 1:] == ends[0, :-1])
+            self.na = na if contiguous else 0
+        else:
+            self.na = 0
+        if self.na:
+            self.art_start = np.concatenate([starts[0], [nj]]).astype(np.int32)
+            dof_edges = np.concatenate([self.joint_qd_start, [self.nd]])
+            self.max_art_dofs = int(max(dof_edges[self.art_start[k + 1]] - dof_edges[self.art_start[k]]
+                                        for k in range(self.na)))
+        else:
+            self.art_start = np.zeros(1, dtype=np.int32)
+            self.max_art_dofs = 0
+
         sb = np.asarray(m.shape_body)[:E * ns].reshape(E, ns) if ns else np.zeros((E, 0), dtype=np.int32)
         sb = np.where(sb >= 0, sb - env_ids * nb, -1)
         if E > 1 and not np.all(sb == sb[0:1]):
@@ -237,13 +258,14 @@ class DeviceModel:
             "body_flags", "joint_type", "joint_enabled", "joint_parent", "joint_child", "joint_q_start",
             "joint_qd_start", "joint_tq_start", "joint_lin_count", "joint_ang_count", "shape_body", "shape_type",
             "shape_flags", "shape_group", "pair_a", "pair_b", "body_joint_start", "body_joint_list", "body_pair_start",
-            "body_pair_list")}
+            "body_pair_list", "art_start")}
         self.params = {}
         self.upload_params(model)
         d = _lib.nt_model()
         d.env_count, d.env_stride = E, ES
         d.nb, d.nj, d.nd, d.nc, d.ntq, d.ns, d.ng, d.np, d.cpp = t.nb, t.nj, t.nd, t.nc, t.ntq, t.ns, t.ng, t.np, t.cpp
         d.np_analytic = t.np_analytic
+        d.na, d.max_art_dofs = t.na, t.max_art_dofs
         for k, v in self.topology.items():
             setattr(d, k, v.data_ptr())
         for k, v in self.params.items():

@@ -1,0 +1,64 @@
+"""SolverFeatherstone -- drop-in for newton.solvers.SolverFeatherstone
+(newton/_src/solvers/featherstone/solver_featherstone.py:136-1066), rigid articulations only.
+
+One ``nt_featherstone_step`` launch replaces the reference's ~20 launches per step: FK, the RNEA passes, penalty contacts
+(``eval_body_contact``), the joint-space inertia ``H = J^T M J``, its Cholesky factorisation and solve, generalized
+integration and the final FK all run in one gfx950 kernel with every intermediate (S, I_s, H, L ...) resident in LDS.
+
+Like the reference, ``step`` integrates ``joint_q`` / ``joint_qd``, rebuilds ``body_q`` / ``body_qd`` of ``state_out`` and
+refreshes ``state_in.body_q`` from ``state_in.joint_q``.  ``state_in is state_out`` is allowed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..enums import BodyFlags, JointType
+from .solver import SolverBase
+
+
+class SolverFeatherstone(SolverBase):
+    def __init__(self, model, *, angular_damping: float = 0.05, update_mass_matrix_interval: int = 1,
+                 friction_smoothing: float = 1.0, use_tile_gemm: bool = False, fuse_cholesky: bool = True,
+                 envs_per_block: int = 0):
+        super().__init__(model)
+        t = model.env
+        if update_mass_matrix_interval != 1:
+            raise NotImplementedError("SolverFeatherstone: update_mass_matrix_interval must be 1 (H is rebuilt in LDS "
+                                      "every step; there is no cached factorisation to reuse)")
+        if t.nj == 0 or t.na == 0:
+            raise NotImplementedError("SolverFeatherstone needs articulated bodies (every body behind a joint, "
+                                      "articulations contiguous and identical in every world)")
+        jt = np.asarray(t.joint_type)
+        if np.any(jt == int(JointType.DISTANCE)) or np.any(jt == int(JointType.ROD)):
+            raise NotImplementedError("SolverFeatherstone: DISTANCE / ROD joints are not supported")
+        if np.any((jt == int(JointType.FREE)) & (np.asarray(t.joint_parent) >= 0)):
+            raise NotImplementedError("SolverFeatherstone: FREE joints are supported at articulation roots only")
+        if np.any((jt == int(JointType.D6)) & (np.asarray(t.joint_ang_count) > 1)):
+            raise NotImplementedError("SolverFeatherstone: D6 joints with 2 or 3 angular axes are not supported")
+        if not np.array_equal(np.asarray(t.joint_child), np.arange(t.nj)) or t.nb != t.nj:
+            # the reference's eval_rigid_mass indexes body_I_s by joint index (kernels.py:1466-1480)
+            raise NotImplementedError("SolverFeatherstone: body j must be the child of joint j")
+        if np.any(np.asarray(t.body_flags) & int(BodyFlags.KINEMATIC)):
+            raise NotImplementedError("SolverFeatherstone: kinematic bodies are not supported")
+        self.angular_damping = angular_damping
+        self.update_mass_matrix_interval = 1
+        self.friction_smoothing = friction_smoothing
+        self.use_tile_gemm = use_tile_gemm      # accepted for signature parity; H never leaves LDS here
+        self.fuse_cholesky = fuse_cholesky
+        self.envs_per_block = int(envs_per_block)
+
+    def step(self, state_in, state_out, control, contacts, dt: float) -> None:
+        dm = self.dm
+        if control is None:
+            if not hasattr(self, "_control"):
+                self._control = self.model.control()
+            control = self._control
+        p = _lib.nt_featherstone_params(float(self.angular_damping), float(self.friction_smoothing))
+        d_in, d_out, d_c = state_in._desc(), state_out._desc(), control._desc()
+        d_ct = contacts._desc() if contacts is not None else None
+        _lib.check(dm.lib.nt_featherstone_step(C.byref(dm.desc), C.byref(p), C.byref(d_in), C.byref(d_out), C.byref(d_c),
+                                               C.byref(d_ct) if d_ct is not None else None, float(dt),
+                                               self.envs_per_block, dm.stream()), "nt_featherstone_step")

@@ -1,0 +1,146 @@
+"""GPU parity: SolverFeatherstone (one gfx950 kernel through nt_featherstone_step) vs the CPU oracle (config C3).
+Single step <= 1e-5 rel on body_q / joint_q, velocities within the dt-amplified bound; 100-step rollout <= 1e-4 rel."""
+import numpy as np
+import pytest
+
+from test_gpu_parity_xpbd import _lower_quadrupeds, _rel, _setup
+
+pytestmark = pytest.mark.gpu
+
+
+def _step_both(nt, model, o, n_steps, dt, epb=0, with_contacts=True, jf=None):
+    from oracle_bridge import OracleState
+
+    s0, s1 = model.state(), model.state()
+    ctrl = model.control()
+    if jf is not None:
+        ctrl.joint_f = jf
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts() if with_contacts else None
+    solver = nt.solvers.SolverFeatherstone(model, envs_per_block=epb)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts() if with_contacts else None
+    c = o.control(joint_f=jf)
+    for _ in range(n_steps):
+        s0.clear_forces()
+        if with_contacts:
+            pipe.collide(s0, contacts)
+        solver.step(s0, s1, ctrl, contacts, dt)
+        s0, s1 = s1, s0
+        os0.body_f[:] = 0
+        if with_contacts:
+            o.collide(os0.body_q, oc)
+        o.featherstone_step(os0, os1, c, oc, dt)
+        os0, os1 = os1, os0
+    return s0, os0, oc
+
+
+@pytest.mark.parametrize("n_env,epb", [(1, 0), (5, 4), (67, 8), (130, 0)])
+def test_quadruped_single_step(n_env, epb):
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, n_env)
+    _lower_quadrupeds(nt, model, 0.24)
+    rng = np.random.default_rng(11)
+    model.joint_qd = (model.joint_qd + rng.normal(0, 0.3, size=model.joint_qd.shape)).astype(np.float32)
+    jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
+    s, os_, oc = _step_both(nt, model, o, 1, 1e-3, epb=epb, jf=jf)
+    assert oc.count[0] > 0
+    assert _rel(s.joint_q.cpu().numpy(), os_.joint_q) <= 1e-5
+    assert _rel(s.body_q.cpu().numpy(), os_.body_q) <= 1e-5
+    assert _rel(s.joint_qd.cpu().numpy(), os_.joint_qd) <= 2e-4
+    assert _rel(s.body_qd.cpu().numpy(), os_.body_qd) <= 2e-4
+
+
+def test_quadruped_rollout_100_steps():
+    """100 steps of free flight + PD hold (contacts are emitted through the 0.1 gap but stay inactive)."""
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, 24)
+    _lower_quadrupeds(nt, model, 0.08)
+    s, os_, oc = _step_both(nt, model, o, 100, 1e-3)
+    assert oc.count[0] > 0
+    assert _rel(s.joint_q.cpu().numpy(), os_.joint_q) <= 1e-4
+    assert _rel(s.body_q.cpu().numpy(), os_.body_q) <= 1e-4
+    assert _rel(s.joint_qd.cpu().numpy(), os_.joint_qd) <= 1e-4
+    assert _rel(s.body_qd.cpu().numpy(), os_.body_qd) <= 1e-4
+
+
+def test_quadruped_impact_phase_stepwise():
+    """Through touchdown the penalty contacts (ke ~ 1e4 on light feet, explicit integration) amplify rounding noise by
+    ~3-10x per step, so trajectories are compared step by step from the oracle's state: 120 consecutive single steps
+    covering free flight, impact and rebound, each <= 1e-5 / dt-amplified velocity bound."""
+    from oracle_bridge import OracleState
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, 6)
+    _lower_quadrupeds(nt, model, 0.2)
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverFeatherstone(model)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc, c = o.contacts(), o.control()
+    deepest = 0.0
+    for _ in range(120):
+        s0.joint_q, s0.joint_qd, s0.body_q, s0.body_qd = os0.joint_q, os0.joint_qd, os0.body_q, os0.body_qd
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, None, contacts, 1e-3)
+        os0.body_f[:] = 0
+        o.collide(os0.body_q, oc)
+        o.featherstone_step(os0, os1, c, oc, 1e-3)
+        assert _rel(s1.joint_q.cpu().numpy(), os1.joint_q) <= 1e-5
+        assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+        assert _rel(s1.joint_qd.cpu().numpy(), os1.joint_qd) <= 5e-4
+        assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 5e-4
+        deepest = max(deepest, float(np.max(np.abs(os1.joint_qd))))
+        os0, os1 = os1, os0
+    assert deepest > 1.0  # the impact really happened inside the window
+
+
+def test_free_bodies_single_step():
+    """8 free boxes per env (one articulation each): exercises the FREE-root branch and na > 1."""
+    from scenes import box_stack_scene
+
+    nt, model, o = _setup(box_stack_scene, 19)
+    rng = np.random.default_rng(5)
+    model.joint_qd = rng.normal(0, 0.5, size=model.joint_qd.shape).astype(np.float32)
+    s, os_, _ = _step_both(nt, model, o, 3, 1e-3, with_contacts=False)
+    assert _rel(s.joint_q.cpu().numpy(), os_.joint_q) <= 1e-5
+    assert _rel(s.body_q.cpu().numpy(), os_.body_q) <= 1e-5
+    assert _rel(s.joint_qd.cpu().numpy(), os_.joint_qd) <= 1e-4
+    assert _rel(s.body_qd.cpu().numpy(), os_.body_qd) <= 1e-4
+
+
+def test_pendulum_period_and_energy():
+    """test_physics_verification.py:112-186 through the HIP path (revolute pendulum, gravity -10, 64 envs)."""
+    import newton_amd as nt
+
+    g, L, a0, dt = -10.0, 1.0, 0.05, 1e-3
+    env = nt.ModelBuilder(up_axis=1, gravity=g)
+    link = env.add_link()
+    env.add_shape_sphere(link, radius=0.01)
+    j = env.add_joint_revolute(-1, link, axis=(0, 0, 1), parent_xform=[0, 0, 0, 0, 0, 0, 1], child_xform=[0, L, 0, 0, 0, 0, 1],
+                               armature=0.0)
+    env.add_articulation([j])
+    scene = nt.ModelBuilder(up_axis=1, gravity=g)
+    scene.replicate(env, 64)
+    model = scene.finalize(device="cuda:0")
+    model.joint_q[:] = a0
+    mass = float(model.body_mass[0])
+    I_pivot = float(np.asarray(model.body_inertia[0]).reshape(3, 3)[2, 2]) + mass * L * L
+    T = 2.0 * np.pi * np.sqrt(I_pivot / (mass * abs(g) * L))
+    s0, s1 = model.state(), model.state()
+    solver = nt.solvers.SolverFeatherstone(model, angular_damping=0.0)
+    n = int(1.5 * T / dt)
+    angles = []
+    for _ in range(n):
+        solver.step(s0, s1, None, None, dt)
+        s0, s1 = s1, s0
+        angles.append(s0.joint_q.cpu().numpy().copy())
+    angles = np.array(angles)
+    t = np.arange(1, n + 1) * dt
+    err = np.mean(np.abs(angles - (a0 * np.cos(2.0 * np.pi / T * t))[:, None])) / a0
+    assert err < 0.01
+    assert np.max(np.abs(angles - angles[:, :1])) == 0.0  # identical envs stay bit-identical
