@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--envs-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["quadruped", "box_stack"], default="quadruped",
+    ap.add_argument("--workload", choices=["quadruped", "box_stack", "quadruped_featherstone"], default="quadruped",
                     help="quadruped = the BASELINE.json metric (default); box_stack = config C2 (convex MPR/GJK path), "
                          "a secondary measurement that is never the headline value")
     args = ap.parse_args()
@@ -94,7 +94,7 @@ def main():
     from scenes import quadruped_scene
 
     # every rank owns its own shard of environments (distinct seed => distinct per-env jitter)
-    if args.workload == "quadruped":
+    if args.workload in ("quadruped", "quadruped_featherstone"):
         model = quadruped_scene(args.envs_per_gpu, device=f"cuda:{local_rank}", seed=1 + rank)
         iterations, workload_name = 2, (
             "Anymal-class quadruped (in-repo stand-in geometry: 13 bodies, 12 revolute + free base, "
@@ -108,7 +108,23 @@ def main():
     ctrl = model.control()
     pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block)
     contacts = pipe.contacts()
-    solver = nt.solvers.SolverXPBD(model, iterations=iterations, envs_per_block=args.envs_per_block)
+    if args.workload == "quadruped_featherstone":
+        # C3: the reference loop itself (clear_forces; collide; SolverFeatherstone.step; swap), 3 launches per substep
+        fs = nt.solvers.SolverFeatherstone(model, envs_per_block=args.envs_per_block)
+        workload_name = workload_name.replace("SolverXPBD", "SolverFeatherstone")
+
+        class _Loop:
+            def rollout(self, a, b, ctrl_, contacts_, dt, n):
+                for _ in range(n):
+                    a.clear_forces()
+                    pipe.collide(a, contacts_)
+                    fs.step(a, b, ctrl_, contacts_, dt)
+                    a, b = b, a
+                return a
+
+        solver = _Loop()
+    else:
+        solver = nt.solvers.SolverXPBD(model, iterations=iterations, envs_per_block=args.envs_per_block)
 
     def barrier():
         if dist is not None:
@@ -158,7 +174,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "valid_state": ok,
             "config": {
-                "workload": f"{workload_name}, SolverXPBD iterations={iterations}, dt=1e-3, "
+                "workload": f"{workload_name}, " + ("SolverFeatherstone defaults" if args.workload == "quadruped_featherstone"
+                                                    else f"SolverXPBD iterations={iterations}") + ", dt=1e-3, "
                             f"{args.envs_per_gpu} envs per GPU, 1 step = 1 frame = {SUBSTEPS} substeps of "
                             "clear_forces+collide+step fused in one rollout launch",
                 "envs_per_gpu": args.envs_per_gpu, "substeps_per_step": SUBSTEPS, "parallelism": f"env-shard x{world}",

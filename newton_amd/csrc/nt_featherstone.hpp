@@ -694,13 +694,14 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     int max_depth = 0;
     for (int j = 0; j < nj; ++j) max_depth = imax(max_depth, f.depth[j]);
 
+    const int skip = a.debug_skip;  // timing ablation only (NT_DEBUG_SKIP): results are meaningless when set
     load_params(c, true);
     if (c.valid) stage_rows(c, F.jq, a.s_in.joint_q, m.nc);
     __syncthreads();
 
     // eval_rigid_fk, level by level (a joint's parent body is final one level earlier)
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
-        if (c.valid)
+        if (c.valid && !(skip & 1))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_fk_item(f, j);
         __syncthreads();
@@ -712,7 +713,7 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     __syncthreads();
     // eval_rigid_id
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
-        if (c.valid)
+        if (c.valid && !(skip & 2))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_motion_item(f, j);
         __syncthreads();
@@ -721,7 +722,7 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     if (a.has_contacts) {
         Ctx<EPB> cc = c;
         cc.L.si_cw = F.cw;
-        if (c.valid)
+        if (c.valid && !(skip & 4))
             for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) si_contact_item(cc, s);
         __syncthreads();
     }
@@ -730,20 +731,20 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     __syncthreads();
     // eval_rigid_tau, deepest level first
     for (int lvl = max_depth; lvl >= 0; --lvl) {
-        if (c.valid)
+        if (c.valid && !(skip & 8))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_tau_item(f, j);
         __syncthreads();
     }
     // P = M J (non-zero blocks), H = J^T P (lower triangle), Cholesky, solve
     const int W = m.max_art_dofs;
-    if (c.valid)
+    if (c.valid && !(skip & 16))
         for (int i = c.slot; i < nj * W; i += c.nslot) fs_P_item(f, i);
     __syncthreads();
-    if (c.valid)
+    if (c.valid && !(skip & 32))
         for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
     __syncthreads();
-    if (c.valid)
+    if (c.valid && !(skip & 64))
         for (int k = c.slot; k < m.na; k += c.nslot) fs_solve_item(f, k);
     __syncthreads();
     // integrate_generalized_joints
@@ -752,7 +753,7 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     __syncthreads();
     // FK with velocity conversion -> public body_q / body_qd
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
-        if (c.valid)
+        if (c.valid && !(skip & 128))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_fk_vel_item(f, j);
         __syncthreads();

@@ -1875,6 +1875,10 @@ nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* 
     a.sp.friction_smoothing = p->friction_smoothing;
     a.angular_damping = p->angular_damping;
     a.dt = dt;
+    {
+        const char* e = getenv("NT_DEBUG_SKIP");
+        a.debug_skip = e ? atoi(e) : 0;
+    }
     const FsLayout F = make_fs_layout(*m, make_layout(*m));
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     auto fits = [&](int epb) { return (size_t)F.rows * 4 * epb + shared_ints * 4 <= LDS_BYTES_PER_CU; };
