@@ -54,21 +54,31 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
     F.rows = o;
     return F;
 }
-// block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint  (3 * nj)
-__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj; }
+// block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint (3 * nj), joint of
+// each dof (nd), and per joint a bit mask of the joints on its root path, itself included (nj * ceil(nj / 32))
+__host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }
+__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + m.nj * fs_mask_words(m); }
 
 template <int EPB>
 struct FsCtx {
     const Ctx<EPB>& c;
     FsLayout F;
     const int *anc, *depth, *art;  // [nj] each (LDS)
-    int max_depth;
+    const int* dof_joint;          // [nd]
+    const unsigned* pathmask;      // [nj][words]
+    int words;
     NT_DI FsCtx(const Ctx<EPB>& c_, int* extra) : c(c_) {
         F = make_fs_layout(c.a.m, c.L);
+        const int nj = c.a.m.nj;
         anc = extra;
-        depth = extra + c.a.m.nj;
-        art = extra + 2 * c.a.m.nj;
+        depth = extra + nj;
+        art = extra + 2 * nj;
+        dof_joint = extra + 3 * nj;
+        pathmask = reinterpret_cast<const unsigned*>(extra + 3 * nj + c.a.m.nd);
+        words = fs_mask_words(c.a.m);
     }
+    // is joint `a` on the root path of joint `l` (or `l` itself)?
+    NT_DI bool on_path(int a, int l) const { return (pathmask[l * words + (a >> 5)] >> (a & 31)) & 1u; }
     NT_DI float& f(int off, int idx) const { return c.lds[(off + idx) * EPB + c.e]; }
     NT_DI vec3 v3(int off, int comp0, int n, int s) const { return c.lv3(off, comp0, n, s); }
     NT_DI spatial sp6(int off, int n, int s) const { return spatial(c.lv3(off, 0, n, s), c.lv3(off, 3, n, s)); }
@@ -242,9 +252,11 @@ NT_DI void fs_transform_spatial_inertia(const xform& t, float mass, const mat33&
         }
 }
 
-// compute_link_velocity (kernels.py:764-866) incl. jcalc_motion (kernels.py:242-380)
+// compute_link_velocity (kernels.py:764-866) incl. jcalc_motion (kernels.py:242-380), split in two:
+// (1) everything that does not depend on the parent's velocity -- motion subspace columns S, the joint velocity v_j_s
+//     and the solve-frame spatial inertia I_s -- runs for all joints at once;
 template <int EPB>
-NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
+NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int nb = m.nb, nd = m.nd;
@@ -305,6 +317,25 @@ NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
         put_S(qd_start + 4, fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 1.0f, 0.0f))));
         put_S(qd_start + 5, fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 0.0f, 1.0f))));
     }
+    f.st6(f.F.ft, nb, j, v_j_s);  // parked in the (still unused) subtree-wrench rows until the level pass picks it up
+    vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - solve_origin;
+    c.st_lv3(f.F.org, 0, nb, child, solve_origin);
+    mat66 I_s;
+    fs_transform_spatial_inertia(xform(x_com_s, c.body_rot(child)), c.l(c.L.bp, BP_MASS, nb, child), c.inertia(child), I_s);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c.l(f.F.Is, i * 6 + k, nb, child) = I_s.a[i][k];
+}
+
+// (2) the velocity / acceleration / bias-force recurrence, one tree level at a time.
+template <int EPB>
+NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    const int child = c.T.joint_child[j], parent = c.T.joint_parent[j];
+    spatial v_j_s = f.sp6(f.F.ft, nb, j);
     spatial v_parent_s, a_parent_s;
     if (parent >= 0) {
         v_parent_s = f.sp6(f.F.vs, nb, parent);
@@ -312,15 +343,16 @@ NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
     }
     spatial v_s = v_parent_s + v_j_s;
     spatial a_s = a_parent_s + fs_spatial_cross(v_s, v_j_s) + spatial();
-
-    vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - solve_origin;
-    c.st_lv3(f.F.org, 0, nb, child, solve_origin);
+    vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - f.v3(f.F.org, 0, nb, child);
     float mass = c.l(c.L.bp, BP_MASS, nb, child);
     vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
     vec3 f_g = mass * gravity;
     spatial f_g_s(f_g, cross(x_com_s, f_g));
     mat66 I_s;
-    fs_transform_spatial_inertia(xform(x_com_s, c.body_rot(child)), mass, c.inertia(child), I_s);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) I_s.a[i][k] = c.l(f.F.Is, i * 6 + k, nb, child);
     spatial f_b_s = fs_mul(I_s, a_s) + fs_spatial_cross_dual(v_s, fs_mul(I_s, v_s));
     vec3 omega_world = v_s.bottom;
     vec3 v_com_world = v_s.top + cross(omega_world, x_com_s);
@@ -330,10 +362,6 @@ NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
     f.st6(f.F.vs, nb, child, v_s);
     f.st6(f.F.as, nb, child, a_s);
     f.st6(f.F.fs, nb, child, f_b_s - f_g_s);
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c.l(f.F.Is, i * 6 + k, nb, child) = I_s.a[i][k];
 }
 
 // body_f_ext = state_in.body_f + FREE/DISTANCE joint_f (kernels.py:893-921) + contact wrenches in contact order
@@ -417,24 +445,6 @@ NT_DI void fs_tau_item(const FsCtx<EPB>& f, int j) {
     }
 }
 
-// is joint `a` an ancestor-or-self of joint `j`?
-template <int EPB>
-NT_DI bool fs_on_path(const FsCtx<EPB>& f, int a, int j) {
-    while (j >= 0) {
-        if (j == a) return true;
-        j = f.anc[j];
-    }
-    return false;
-}
-template <int EPB>
-NT_DI int fs_joint_of_dof(const FsCtx<EPB>& f, int d) {
-    const nt_model& m = f.c.a.m;
-    int j = 0;
-    for (int k = 1; k < m.nj; ++k)
-        if (f.c.T.joint_qd_start[k] <= d) j = k;
-    return j;
-}
-
 // P[b][dl] = I_b S_d for every dof d on the path root..joint(b); item = b * W + dl
 template <int EPB>
 NT_DI void fs_P_item(const FsCtx<EPB>& f, int item) {
@@ -449,7 +459,7 @@ NT_DI void fs_P_item(const FsCtx<EPB>& f, int item) {
     const int art_j1 = m.art_start[a + 1];
     const int d1 = art_j1 < m.nj ? c.T.joint_qd_start[art_j1] : nd;
     if (d >= d1) return;
-    if (!fs_on_path(f, fs_joint_of_dof(f, d), l)) return;
+    if (!f.on_path(f.dof_joint[d], l)) return;
     const int b = l;  // body l of the articulation == child of joint l (host-checked)
     spatial S = f.sp6(f.F.S, nd, d);
 #pragma unroll
@@ -467,26 +477,37 @@ NT_DI void fs_H_item(const FsCtx<EPB>& f, int item) {
     const nt_model& m = c.a.m;
     const int W = m.max_art_dofs, nb = m.nb, nd = m.nd;
     const int i = item / W, jl = item - i * W;
-    const int ji = fs_joint_of_dof(f, i);
+    const int ji = f.dof_joint[i];
     const int a = f.art[ji];
     const int art_j0 = m.art_start[a], art_j1 = m.art_start[a + 1];
     const int d0 = c.T.joint_qd_start[art_j0];
     const int il = i - d0;
     if (jl > il) return;
-    const int jj = fs_joint_of_dof(f, d0 + jl);
+    const int jj = f.dof_joint[d0 + jl];
     spatial S_i = f.sp6(f.F.S, nd, i);
     float sum = 0.0f;
     for (int l = art_j0; l < art_j1; ++l) {
-        if (!fs_on_path(f, ji, l) || !fs_on_path(f, jj, l)) continue;
+        if (!f.on_path(ji, l) || !f.on_path(jj, l)) continue;
 #pragma unroll
         for (int r = 0; r < 6; ++r) sum += fs_sget(S_i, r) * c.l(f.F.P, r, nb * W, l * W + jl);
     }
     c.l(f.F.H, 0, 1, i * W + jl) = sum;
 }
 
-// dense_cholesky (in place over the lower triangle of H) + dense_subs for one articulation (kernels.py:1690-1797)
+// dense_cholesky (in place over the lower triangle of H) + dense_subs for one articulation (kernels.py:1690-1797),
+// worked by the G = 64 / EPB slot-lanes of the environment that share wavefront 0 (tid = env + EPB * slot): the lanes
+// run in lockstep, LDS operations of one wave complete in order, so a value written by one lane is visible to the
+// others at the next instruction without a workgroup barrier.  Row i belongs to lane i % G.  Every sum runs in the
+// reference's order (k ascending), so the factor and the solution are bit-identical to the serial algorithm.
+// compiler-level ordering of LDS traffic between lanes of one wave (no hardware barrier is needed: see below)
+#define FS_WAVE_SYNC()                                        \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+
 template <int EPB>
-NT_DI void fs_solve_item(const FsCtx<EPB>& f, int a) {
+NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int W = m.max_art_dofs, nd = m.nd;
@@ -494,31 +515,45 @@ NT_DI void fs_solve_item(const FsCtx<EPB>& f, int a) {
     const int d0 = c.T.joint_qd_start[art_j0];
     const int d1 = art_j1 < m.nj ? c.T.joint_qd_start[art_j1] : nd;
     const int n = d1 - d0;
-    auto A = [&](int i, int j) -> float& { return c.l(f.F.H, 0, 1, (d0 + i) * W + j); };
+    float* lds = c.lds;
+    const int e = c.e;
+    auto A = [&](int i, int j) -> float& { return lds[(f.F.H + (d0 + i) * W + j) * EPB + e]; };
+    auto X = [&](int i) -> float& { return lds[(f.F.qdd + d0 + i) * EPB + e]; };
     for (int j = 0; j < n; ++j) {
-        float s = A(j, j) + c.dof(DP_ARMATURE, d0 + j);
+        float s = A(j, j) + c.dof(DP_ARMATURE, d0 + j);  // every lane evaluates the pivot (no broadcast needed)
         for (int k = 0; k < j; ++k) {
             float r = A(j, k);
             s -= r * r;
         }
         s = sqrtf(s);
         float invS = 1.0f / s;
-        A(j, j) = s;
-        for (int i = j + 1; i < n; ++i) {
-            s = A(i, j);
-            for (int k = 0; k < j; ++k) s -= A(i, k) * A(j, k);
-            A(i, j) = s * invS;
+        FS_WAVE_SYNC();
+        if (lane == 0) A(j, j) = s;
+        for (int i = j + 1 + lane; i < n; i += G) {
+            float t = A(i, j);
+            for (int k = 0; k < j; ++k) t -= A(i, k) * A(j, k);
+            A(i, j) = t * invS;
         }
+        FS_WAVE_SYNC();
     }
-    for (int i = 0; i < n; ++i) {
-        float s = f.f(f.F.tau, d0 + i);
-        for (int j = 0; j < i; ++j) s -= A(i, j) * f.f(f.F.qdd, d0 + j);
-        f.f(f.F.qdd, d0 + i) = s / A(i, i);
+    // forward substitution, column oriented: x_j is final once rows < j have been subtracted (ascending j per row)
+    for (int i = lane; i < n; i += G) X(i) = f.f(f.F.tau, d0 + i);
+    FS_WAVE_SYNC();
+    for (int j = 0; j < n; ++j) {
+        float xj = X(j) / A(j, j);
+        FS_WAVE_SYNC();
+        if (lane == 0) X(j) = xj;
+        for (int i = j + 1 + lane; i < n; i += G) X(i) = X(i) - A(i, j) * xj;
+        FS_WAVE_SYNC();
     }
+    // back substitution: each x_i needs the ascending-j sum over the rows below it; evaluated by every lane
     for (int i = n - 1; i >= 0; --i) {
-        float s = f.f(f.F.qdd, d0 + i);
-        for (int j = i + 1; j < n; ++j) s -= A(j, i) * f.f(f.F.qdd, d0 + j);
-        f.f(f.F.qdd, d0 + i) = s / A(i, i);
+        float s = X(i);
+        for (int j = i + 1; j < n; ++j) s -= A(j, i) * X(j);
+        float xi = s / A(i, i);
+        FS_WAVE_SYNC();
+        if (lane == 0) X(i) = xi;
+        FS_WAVE_SYNC();
     }
 }
 
@@ -684,10 +719,24 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
         extra[2 * nj + j] = art;
     }
     __syncthreads();
+    const int words = fs_mask_words(m);
     for (int j = threadIdx.x; j < nj; j += blockDim.x) {
         int d = 0, k = extra[j];
-        while (k >= 0) { d += 1; k = extra[k]; }
+        unsigned* mask = reinterpret_cast<unsigned*>(extra + 3 * nj + m.nd) + j * words;
+        for (int w = 0; w < words; ++w) mask[w] = 0u;
+        mask[j >> 5] |= 1u << (j & 31);
+        while (k >= 0) {
+            d += 1;
+            mask[k >> 5] |= 1u << (k & 31);
+            k = extra[k];
+        }
         extra[nj + j] = d;
+    }
+    for (int d = threadIdx.x; d < m.nd; d += blockDim.x) {
+        int j = 0;
+        for (int k = 1; k < nj; ++k)
+            if (c.T.joint_qd_start[k] <= d) j = k;
+        extra[3 * nj + d] = j;
     }
     __syncthreads();
     FsCtx<EPB> f(c, extra);
@@ -712,6 +761,9 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
         for (int j = c.slot; j < nj; j += c.nslot) fs_to_internal_item(f, j, a.s_in.joint_qd);
     __syncthreads();
     // eval_rigid_id
+    if (c.valid && !(skip & 2))
+        for (int j = c.slot; j < nj; j += c.nslot) fs_motion_pre_item(f, j);
+    __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid && !(skip & 2))
             for (int j = c.slot; j < nj; j += c.nslot)
@@ -744,8 +796,11 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     if (c.valid && !(skip & 32))
         for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
     __syncthreads();
-    if (c.valid && !(skip & 64))
-        for (int k = c.slot; k < m.na; k += c.nslot) fs_solve_item(f, k);
+    {
+        const int G = (64 / EPB) < c.nslot ? (64 / EPB) : c.nslot;
+        if (c.valid && !(skip & 64) && c.slot < G)
+            for (int k = 0; k < m.na; ++k) fs_solve_coop(f, k, c.slot, G);
+    }
     __syncthreads();
     // integrate_generalized_joints
     if (c.valid)

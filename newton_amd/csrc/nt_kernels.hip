@@ -1886,7 +1886,9 @@ nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* 
     if (envs_per_block == 4 || envs_per_block == 8 || envs_per_block == 16) {
         epb = fits(envs_per_block) ? envs_per_block : 0;
     } else {
-        const int cands[3] = {16, 8, 4};
+        // measured on MI355X (4096 quadrupeds): 4 envs per workgroup (16 cooperating lanes per env in the Cholesky wave,
+        // two resident workgroups per CU) beats 8; 16 rarely fits
+        const int cands[3] = {4, 8, 16};
         for (int i = 0; i < 3 && !epb; ++i)
             if (fits(cands[i])) epb = cands[i];
     }
