@@ -132,6 +132,23 @@ def eval_fk(model, joint_q, joint_qd, state, mask=None, indices=None):
     def host(x):
         return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
+    from .state import State, pack_soa  # noqa: PLC0415
+
+    t = model.env
+    on_device = getattr(model, "is_gpu", False) and isinstance(state, State) and t.nj > 0
+    if on_device and not np.any(np.asarray(model.joint_articulation) == -1):
+        # device path: one launch of eval_fk_kernel through the C ABI (nt_eval_fk)
+        import ctypes as C  # noqa: PLC0415
+
+        from . import _lib  # noqa: PLC0415
+
+        dm = model.device_model()
+        jq = pack_soa(model, joint_q, 1, t.nc)
+        jqd = pack_soa(model, joint_qd, 1, t.nd)
+        d = state._desc()
+        _lib.check(dm.lib.nt_eval_fk(C.byref(dm.desc), jq.data_ptr(), jqd.data_ptr(), C.byref(d), dm.stream()), "nt_eval_fk")
+        return
+
     bq, bqd = eval_fk_numpy(model, host(joint_q), host(joint_qd))
     state.body_q = bq
     state.body_qd = bqd

@@ -621,7 +621,9 @@ NT_DI void fs_integrate_item(const FsCtx<EPB>& f, int j) {
 }
 
 // eval_single_articulation_fk_with_velocity_conversion for one joint (kernels.py:1987-2150): final body_q / body_qd
-template <int EPB>
+// PUBLIC = true: newton.eval_fk semantics (eval_single_articulation_fk, newton/_src/sim/articulation.py:236-420): FREE /
+// DISTANCE joint_qd is the child's COM twist in the parent anchor frame.
+template <int EPB, bool PUBLIC>
 NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
@@ -663,9 +665,14 @@ NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
     vec3 angular_joint_world = xform_vector(X_wpj, v_j.bottom);
     vec3 linear_joint_origin;
     if (type == JT_FREE || type == JT_DISTANCE) {
-        spatial v_j_world = fs_transform_twist(X_wpj, v_j);
-        linear_joint_origin = cross(v_j_world.bottom, x_child_origin) + v_j_world.top;
-        angular_joint_world = v_j_world.bottom;
+        if (PUBLIC) {
+            // com_twist_to_origin_twist (articulation.py:29-33)
+            linear_joint_origin = linear_joint_world - cross(angular_joint_world, xform_vector(X_wc, c.com(child)));
+        } else {
+            spatial v_j_world = fs_transform_twist(X_wpj, v_j);
+            linear_joint_origin = cross(v_j_world.bottom, x_child_origin) + v_j_world.top;
+            angular_joint_world = v_j_world.bottom;
+        }
     } else {
         vec3 child_origin_offset_world = x_child_origin - X_wcj.p;
         linear_joint_origin = linear_joint_world + cross(angular_joint_world, child_origin_offset_world);
@@ -810,12 +817,55 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid && !(skip & 128))
             for (int j = c.slot; j < nj; j += c.nslot)
-                if (f.depth[j] == lvl) fs_fk_vel_item(f, j);
+                if (f.depth[j] == lvl) fs_fk_vel_item<EPB, false>(f, j);
         __syncthreads();
     }
     if (c.valid) {
         for (int j = c.slot; j < nj; j += c.nslot) fs_to_public_item(f, j, a.s_out.joint_qd);
         unstage_rows(c, F.jq, a.s_out.joint_q, m.nc);
+    }
+    store_state(c, a.s_out);
+}
+
+// newton.eval_fk(model, joint_q, joint_qd, state) (newton/_src/sim/articulation.py:423-573): body_q / body_qd from
+// generalized coordinates, all articulations, level by level.
+template <int EPB>
+__global__ void __launch_bounds__(256) eval_fk_kernel(KArgs a, const float* joint_q, const float* joint_qd) {
+    extern __shared__ __align__(16) float lds[];
+    const nt_model& m = a.m;
+    const int nj = m.nj;
+    const FsLayout F = make_fs_layout(m, make_layout(m));
+    Ctx<EPB> c(a, lds, F.rows);
+    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+        int p = c.T.joint_parent[j], anc = -1;
+        if (p >= 0)
+            for (int k = 0; k < nj; ++k)
+                if (c.T.joint_child[k] == p) anc = k;
+        extra[j] = anc;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+        int d = 0, k = extra[j];
+        while (k >= 0) { d += 1; k = extra[k]; }
+        extra[nj + j] = d;
+    }
+    __syncthreads();
+    FsCtx<EPB> f(c, extra);
+    int max_depth = 0;
+    for (int j = 0; j < nj; ++j) max_depth = imax(max_depth, f.depth[j]);
+    load_params(c, false);
+    if (c.valid) {
+        stage_rows(c, F.jq, joint_q, m.nc);
+        stage_rows(c, F.qdo, joint_qd, m.nd);
+    }
+    __syncthreads();
+    for (int lvl = 0; lvl <= max_depth; ++lvl) {
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot)
+                if (f.depth[j] == lvl) fs_fk_vel_item<EPB, true>(f, j);
+        __syncthreads();
     }
     store_state(c, a.s_out);
 }

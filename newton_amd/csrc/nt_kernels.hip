@@ -1916,7 +1916,35 @@ int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m) {
     return make_fs_layout(*m, make_layout(*m)).rows * 4;
 }
 
-nt_status nt_eval_fk(const nt_model*, const float*, const float*, nt_state*, void*) { return NT_ERR_UNSUPPORTED; }
+nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint_qd, nt_state* out, void* stream) {
+    if (!model_ok(m) || !joint_q || !joint_qd || !out || !out->body_q || !out->body_qd) return NT_ERR_INVALID_ARG;
+    if (m->nj <= 0) return NT_ERR_UNSUPPORTED;
+    KArgs a = {};
+    a.m = *m;
+    a.s_out = *out;
+    const FsLayout F = make_fs_layout(*m, make_layout(*m));
+    const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
+    int epb = 0;
+    const int cands[3] = {16, 8, 4};
+    for (int i = 0; i < 3 && !epb; ++i)
+        if ((size_t)F.rows * 4 * cands[i] + shared_ints * 4 <= LDS_BYTES_PER_CU) epb = cands[i];
+    if (!epb) return NT_ERR_UNSUPPORTED;
+    int want = imax(m->nb, m->nj), cap = 256 / epb;
+    a.nslot = want < cap ? want : cap;
+    int threads = ((a.nslot * epb + 63) / 64) * 64;
+    size_t lds_bytes = (size_t)F.rows * 4 * epb + shared_ints * 4;
+    int blocks = (m->env_count + epb - 1) / epb;
+    auto go = [&](auto kernel) -> nt_status {
+        if (lds_bytes > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return NT_ERR_LAUNCH;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, a, joint_q, joint_qd);
+        return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+    };
+    if (epb == 16) return go(eval_fk_kernel<16>);
+    if (epb == 8) return go(eval_fk_kernel<8>);
+    return go(eval_fk_kernel<4>);
+}
 
 nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream) {
     if (!src || !dst || n <= 0) return NT_ERR_INVALID_ARG;

@@ -81,6 +81,24 @@ class _SoAContainer:
             torch.cuda.current_stream(dm.device).synchronize()  # `value` may be a temporary
 
 
+def pack_soa(model, value, ncomp: int, n: int):
+    """Newton flat AoS array ([E*n, ncomp] or [E*n]) -> a fresh env-major SoA device tensor [ncomp, n, ES]."""
+    torch = _torch()
+    t = model.env
+    dm = model.device_model()
+    out = torch.zeros((ncomp, max(n, 1), t.env_stride), dtype=torch.float32, device=dm.device)
+    if not isinstance(value, torch.Tensor):
+        value = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32))
+    value = value.to(device=dm.device, dtype=torch.float32).contiguous()
+    if value.numel() != t.env_count * n * ncomp:
+        raise ValueError(f"expected {t.env_count * n * ncomp} values, got {value.numel()}")
+    if n > 0:
+        _lib.check(dm.lib.nt_pack_aos(value.data_ptr(), out.data_ptr(), ncomp, n, t.env_count, t.env_stride, dm.stream()),
+                   "nt_pack_aos")
+        torch.cuda.current_stream(dm.device).synchronize()  # `value` may be a temporary
+    return out
+
+
 def _aos_property(name):
     def getter(self):
         return self._get(name)

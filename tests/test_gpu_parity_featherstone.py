@@ -144,3 +144,22 @@ def test_pendulum_period_and_energy():
     err = np.mean(np.abs(angles - (a0 * np.cos(2.0 * np.pi / T * t))[:, None])) / a0
     assert err < 0.01
     assert np.max(np.abs(angles - angles[:, :1])) == 0.0  # identical envs stay bit-identical
+
+
+def test_eval_fk_device_matches_oracle():
+    """newton.eval_fk on the device (nt_eval_fk) vs the oracle's eval_fk restatement, random joint state."""
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, 37)
+    rng = np.random.default_rng(2)
+    E = model.world_count
+    jq = model.joint_q.copy()
+    jq.reshape(E, -1)[:, 7:] += rng.normal(0, 0.4, size=(E, 12)).astype(np.float32)
+    q = rng.normal(size=(E, 4))
+    jq.reshape(E, -1)[:, 3:7] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    jqd = rng.normal(0, 1.0, size=model.joint_qd.shape).astype(np.float32)
+    state = model.state()
+    nt.eval_fk(model, jq, jqd, state)
+    bq, bqd = o.eval_fk(jq, jqd)
+    assert _rel(state.body_q.cpu().numpy(), bq) <= 1e-5
+    assert _rel(state.body_qd.cpu().numpy(), bqd) <= 1e-5
