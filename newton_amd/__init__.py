@@ -9,6 +9,7 @@ from .articulation import eval_fk
 from .builder import JointDofConfig, ModelBuilder, ShapeConfig
 from .collide import CollisionPipeline, Contacts
 from .enums import BodyFlags, GeoType, JointType, ModelFlags, ShapeFlags, StateFlags
+from .mesh import Mesh
 from .model import Model
 from .state import Control, State
 
@@ -26,6 +27,6 @@ def set_use_coord_layout_targets(value: bool):
     _builder_mod.use_coord_layout_targets = bool(value)
 
 
-__all__ = ["BodyFlags", "CollisionPipeline", "Contacts", "Control", "GeoType", "JointDofConfig", "JointType", "Model",
+__all__ = ["BodyFlags", "CollisionPipeline", "Contacts", "Control", "GeoType", "JointDofConfig", "JointType", "Mesh", "Model",
            "ModelBuilder", "ModelFlags", "ShapeConfig", "ShapeFlags", "State", "StateFlags", "eval_fk", "solvers",
            "set_use_coord_layout_targets"]

@@ -22,6 +22,7 @@ import numpy as np
 from . import _np_math as nm
 from .enums import MAXVAL, BodyFlags, GeoType, JointType, ShapeFlags
 from .inertia import compute_inertia_shape, compute_shape_radius, transform_inertia
+from .mesh import Mesh, deduplicate_vertices  # noqa: F401
 
 # module flag mirrored from newton/__init__.py:15 (coord-shaped joint_target_q when True)
 use_coord_layout_targets = False
@@ -148,6 +149,7 @@ class ModelBuilder:
         self.shape_body, self.shape_type, self.shape_scale, self.shape_transform = [], [], [], []
         self.shape_flags, self.shape_margin, self.shape_gap, self.shape_world, self.shape_label = [], [], [], [], []
         self.shape_collision_group, self.shape_collision_radius = [], []
+        self.shape_source: list = []  # Mesh for CONVEX_MESH shapes, else None (shared, never copied)
         self.shape_material_ke, self.shape_material_kd, self.shape_material_kf, self.shape_material_ka = [], [], [], []
         self.shape_material_mu, self.shape_material_restitution = [], []
         self.shape_material_mu_torsional, self.shape_material_mu_rolling, self.shape_material_kh = [], [], []
@@ -402,7 +404,7 @@ class ModelBuilder:
         self.body_inv_mass[i] = 1.0 / new_mass if new_mass > 0.0 else 0.0
         self.body_inv_inertia[i] = np.linalg.inv(new_inertia) if new_inertia.any() else new_inertia.copy()
 
-    def add_shape(self, *, body, type, xform=None, cfg=None, scale=None, is_static=False, label=None) -> int:
+    def add_shape(self, *, body, type, xform=None, cfg=None, scale=None, is_static=False, label=None, src=None) -> int:
         cfg = self.default_shape_cfg if cfg is None else cfg
         xform = nm.transform() if xform is None else np.asarray(xform, dtype=np.float64)
         scale = (1.0, 1.0, 1.0) if scale is None else scale
@@ -433,7 +435,8 @@ class ModelBuilder:
         self.shape_material_kh.append(cfg.kh)
         self.shape_gap.append(cfg.gap if cfg.gap is not None else self.rigid_gap)
         self.shape_collision_group.append(cfg.collision_group)
-        self.shape_collision_radius.append(compute_shape_radius(type, scale))
+        self.shape_collision_radius.append(compute_shape_radius(type, scale, src))
+        self.shape_source.append(src)
         self.shape_world.append(self.current_world)
 
         if cfg.has_shape_collision and cfg.collision_filter_parent:
@@ -451,7 +454,7 @@ class ModelBuilder:
                         self.add_shape_collision_filter_pair(shape, cs)
 
         if not is_static and cfg.density > 0.0 and body >= 0 and not self.body_lock_inertia[body]:
-            m, c, inertia = compute_inertia_shape(type, scale, cfg.density)
+            m, c, inertia = compute_inertia_shape(type, scale, cfg.density, src)
             com_body = nm.transform_point(xform, c)
             self._update_body_mass(body, m, inertia, com_body, xform[3:])
         return shape
@@ -494,6 +497,12 @@ class ModelBuilder:
         return self.add_shape(body=body, type=GeoType.CONE, xform=xform, cfg=cfg, scale=(radius, half_height, 0.0),
                               label=label)
 
+    def add_shape_convex_hull(self, body, *, xform=None, mesh=None, scale=None, cfg=None, label=None) -> int:
+        """Convex collision shape from the vertex set of ``mesh`` (builder.py:7201-7241); the support map scans every vertex."""
+        if mesh is None:
+            raise ValueError("add_shape_convex_hull() requires a Mesh")
+        return self.add_shape(body=body, type=GeoType.CONVEX_MESH, xform=xform, cfg=cfg, scale=scale, label=label, src=mesh)
+
     # ------------------------------------------------------------------ importers
     def add_urdf(self, source, **kwargs):
         from .urdf import parse_urdf  # noqa: PLC0415
@@ -526,6 +535,7 @@ class ModelBuilder:
         self.body_world.extend([w] * other.body_count)
         self.joint_world.extend([w] * other.joint_count)
         self.shape_world.extend([w] * other.shape_count)
+        self.shape_source.extend(other.shape_source)
         self.joint_parent.extend([p + b0 if p >= 0 else -1 for p in other.joint_parent])
         self.joint_child.extend([c + b0 for c in other.joint_child])
         self.joint_q_start.extend([q + q0 for q in other.joint_q_start])
@@ -696,6 +706,31 @@ class ModelBuilder:
         m.shape_world = arr(self.shape_world, i32, (S,))
         m.shape_collision_group = arr(self.shape_collision_group, i32, (S,))
         m.shape_label = list(self.shape_label)
+        # convex-hull vertex tables: each distinct Mesh once (exact-duplicate vertices removed, first-occurrence order),
+        # local AABBs with the per-shape scale baked in (builder.py:11575-11612)
+        m.shape_source = list(self.shape_source)
+        uniq, starts, counts, points = {}, [], [], []
+        lo_all, hi_all = np.zeros((S, 3), dtype=f32), np.zeros((S, 3), dtype=f32)
+        for i, src in enumerate(self.shape_source):
+            if self.shape_type[i] != GeoType.CONVEX_MESH or src is None:
+                starts.append(-1)
+                counts.append(0)
+                continue
+            if id(src) not in uniq:
+                v = deduplicate_vertices(src)
+                uniq[id(src)] = (sum(len(p) for p in points), len(v))
+                points.append(v)
+            st, ct = uniq[id(src)]
+            starts.append(st)
+            counts.append(ct)
+            v = points[[k for k, key in enumerate(uniq) if key == id(src)][0]].astype(np.float64)
+            sc = np.asarray(self.shape_scale[i], dtype=np.float64)
+            lo, hi = v.min(axis=0) * sc, v.max(axis=0) * sc
+            lo_all[i], hi_all[i] = np.minimum(lo, hi), np.maximum(lo, hi)
+        m.shape_mesh_start = np.asarray(starts, dtype=i32).reshape(S)
+        m.shape_mesh_count = np.asarray(counts, dtype=i32).reshape(S)
+        m.mesh_points = (np.concatenate(points) if points else np.zeros((0, 3))).astype(f32).reshape(-1, 3)
+        m.shape_collision_aabb_lower, m.shape_collision_aabb_upper = lo_all, hi_all
         for name in ("shape_margin", "shape_gap", "shape_collision_radius", "shape_material_ke", "shape_material_kd",
                      "shape_material_kf", "shape_material_ka", "shape_material_mu", "shape_material_restitution",
                      "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_kh"):

@@ -1220,6 +1220,24 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// optional per-phase cycle accounting (-DNT_PHASE_TIMING, tools/phase_timing.py): workgroup 0 / thread 0 accumulates the
+// s_memtime delta of every phase; never compiled into the product library
+// ------------------------------------------------------------------------------------------------
+#ifdef NT_PHASE_TIMING
+__device__ unsigned long long nt_phase_clock[32];
+#define NT_TICK(slot)                                                                  \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            unsigned long long now = __builtin_readcyclecounter();                     \
+            nt_phase_clock[slot] += now - nt_phase_clock[31];                          \
+            nt_phase_clock[31] = now;                                                  \
+        }                                                                              \
+    } while (0)
+#else
+#define NT_TICK(slot) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
 template <int EPB, bool CVX>
@@ -1227,8 +1245,10 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
     if (c.a.debug_skip & 1) return;
     phase_shapes(c);
     __syncthreads();
+    NT_TICK(1);
     phase_pairs<EPB, CVX>(c);
     __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
+    NT_TICK(2);
     if (count_contacts) {  // per-env totals are an API-boundary output, not needed by the solver
         phase_contact_count(c);
         __syncthreads();
@@ -1243,21 +1263,27 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     if (!(skip & 2)) {
         phase_joint_forces(c, forces_are_zero);
         __syncthreads();
+        NT_TICK(3);
         phase_integrate<EPB, false>(c);
         __syncthreads();
+        NT_TICK(4);
     }
     for (int it = 0; it < c.a.p.iterations; ++it) {
         if (c.a.has_contacts) {
             if (!(skip & 4)) phase_contacts(c);
             __syncthreads();
+            NT_TICK(5);
             if (!(skip & 16)) phase_apply<EPB, true>(c);
             __syncthreads();
+            NT_TICK(6);
         }
         if (m.nj > 0) {
             if (!(skip & 8)) phase_joints(c);
             __syncthreads();
+            NT_TICK(7);
             if (!(skip & 16)) phase_apply<EPB, false>(c);
             __syncthreads();
+            NT_TICK(8);
         }
     }
 }
@@ -1303,11 +1329,13 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArg
     __syncthreads();
     phase_body_derived(c);
     __syncthreads();
+    NT_TICK(0);
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(c, s == a.substeps - 1);
         do_xpbd_step(c, true);
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
+    NT_TICK(9);
 }
 
 
@@ -1945,6 +1973,15 @@ nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint
     if (epb == 8) return go(eval_fk_kernel<8>);
     return go(eval_fk_kernel<4>);
 }
+
+#ifdef NT_PHASE_TIMING
+// debug build only: read and reset the phase cycle counters
+int nt_debug_phase_clocks(unsigned long long* out) {
+    unsigned long long zero[32] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nt_phase_clock), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(nt_phase_clock), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream) {
     if (!src || !dst || n <= 0) return NT_ERR_INVALID_ARG;

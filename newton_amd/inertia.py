@@ -9,7 +9,7 @@ from ._np_math import quat_to_matrix
 from .enums import GeoType
 
 
-def compute_inertia_shape(geo_type, scale, density):
+def compute_inertia_shape(geo_type, scale, density, src=None):
     """(mass, com[3], inertia[3,3]) of a solid primitive about its own COM, z-up local axes."""
     if density == 0.0 or geo_type == GeoType.PLANE:
         return 0.0, np.zeros(3), np.zeros((3, 3))
@@ -54,6 +54,24 @@ def compute_inertia_shape(geo_type, scale, density):
         Ia = 3 / 20 * m * r * r + 3 / 80 * m * h * h
         Ib = 3 / 10 * m * r * r
         return m, np.array([0.0, 0.0, -h / 4.0]), np.diag([Ia, Ia, Ib])
+    if geo_type == GeoType.CONVEX_MESH:
+        # scaled unit-density mass properties of the source mesh (newton/_src/geometry/inertia.py:726-757)
+        if src is None:
+            raise ValueError("convex hull shapes need a Mesh")
+        if not src.has_inertia:  # fall back to the mass properties of the scaled geometry (inertia.py:759-764)
+            from .mesh import solid_mesh_mass_properties  # noqa: PLC0415
+
+            V, com, I = solid_mesh_mass_properties(np.asarray(src.vertices, dtype=np.float64) * np.array([sx, sy, sz]),
+                                                   src.indices)
+            return density * V, com, density * I
+        mass_ratio = abs(sx * sy * sz) * density
+        I = np.asarray(src.inertia, dtype=np.float64)
+        Ixx = I[0, 0] * (sy ** 2 + sz ** 2) / 2 * mass_ratio
+        Iyy = I[1, 1] * (sx ** 2 + sz ** 2) / 2 * mass_ratio
+        Izz = I[2, 2] * (sx ** 2 + sy ** 2) / 2 * mass_ratio
+        Ixy, Ixz, Iyz = I[0, 1] * sx * sy * mass_ratio, I[0, 2] * sx * sz * mass_ratio, I[1, 2] * sy * sz * mass_ratio
+        return (src.mass * mass_ratio, np.asarray(src.com, dtype=np.float64) * np.array([sx, sy, sz]),
+                np.array([[Ixx, Ixy, Ixz], [Ixy, Iyy, Iyz], [Ixz, Iyz, Izz]]))
     raise NotImplementedError(f"inertia for shape type {geo_type} not supported")
 
 
@@ -64,7 +82,10 @@ def transform_inertia(mass, inertia, offset, quat):
     return R @ inertia @ R.T + mass * (np.dot(offset, offset) * np.eye(3) - np.outer(offset, offset))
 
 
-def compute_shape_radius(geo_type, scale):
+def compute_shape_radius(geo_type, scale, src=None):
+    if geo_type == GeoType.CONVEX_MESH:  # bounding sphere of the scaled local AABB (geometry/utils.py:86-98)
+        verts = np.asarray(src.vertices, dtype=np.float64) * np.asarray(scale, dtype=np.float64)
+        return float(0.5 * np.linalg.norm(verts.max(axis=0) - verts.min(axis=0)))
     sx, sy, sz = (abs(float(s)) for s in scale)
     if geo_type == GeoType.SPHERE:
         return sx

@@ -1,0 +1,107 @@
+"""Triangle mesh asset (host only): the subset of newton.Mesh (newton/_src/geometry/types.py) that convex-hull collision
+shapes need -- vertices, triangles, solid mass properties at unit density, an optional hull reduction."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def solid_mesh_mass_properties(vertices, indices):
+    """(volume, com[3], inertia about the COM [3,3]) of the closed triangle mesh at unit density: signed tetrahedra against
+    the origin, like compute_solid_mesh_inertia / compute_inertia_mesh (newton/_src/geometry/inertia.py:307-470,473-600)."""
+    v = np.asarray(vertices, dtype=np.float64)
+    tri = np.asarray(indices, dtype=np.int64).reshape(-1, 3)
+    a, b, c = v[tri[:, 0]], v[tri[:, 1]], v[tri[:, 2]]
+    vol6 = np.einsum("ij,ij->i", a, np.cross(b, c))
+    V = vol6.sum() / 6.0
+    F = ((a + b + c) / 4.0 * (vol6 / 6.0)[:, None]).sum(axis=0)  # first moment
+    # second moment  S = integral x x^T dV  over each tetrahedron (0, a, b, c)
+    S = np.zeros((3, 3))
+    for p, q in ((a, a), (b, b), (c, c)):
+        S += np.einsum("i,ij,ik->jk", vol6 / 60.0, p, q)
+    for p, q in ((a, b), (a, c), (b, c)):
+        S += np.einsum("i,ij,ik->jk", vol6 / 120.0, p, q) + np.einsum("i,ij,ik->jk", vol6 / 120.0, q, p)
+    if V < 0.0:  # inward winding
+        V, F, S = -V, -F, -S
+    com = F / V if V > 0.0 else F
+    I_origin = np.trace(S) * np.eye(3) - S
+    I_com = I_origin - V * (np.dot(com, com) * np.eye(3) - np.outer(com, com))
+    return float(V), com, I_com
+
+
+class Mesh:
+    """newton.Mesh(vertices, indices, compute_inertia=True, is_solid=True)."""
+
+    def __init__(self, vertices, indices, compute_inertia: bool = True, is_solid: bool = True, maxhullvert: int = 64):
+        self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+        self.is_solid = is_solid
+        self.maxhullvert = maxhullvert
+        self.has_inertia = False
+        self.mass, self.com, self.inertia = 1.0, np.zeros(3), np.eye(3)
+        if compute_inertia:
+            if not is_solid:
+                raise NotImplementedError("hollow meshes are not supported")
+            self.mass, self.com, self.inertia = solid_mesh_mass_properties(self.vertices, self.indices)
+            self.has_inertia = True
+
+    @staticmethod
+    def create_box(hx: float, hy: float, hz: float) -> Mesh:
+        s = np.array([hx, hy, hz], dtype=np.float64)
+        v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float64) * s
+        return Mesh.convex_hull_of(v)
+
+    @staticmethod
+    def create_sphere(radius: float = 1.0, num_latitudes: int = 32, num_longitudes: int = 32, compute_inertia: bool = True) -> Mesh:
+        """UV sphere (poles + latitude rings), outward winding -- the vertex set newton.Mesh.create_sphere produces."""
+        verts = [(0.0, 0.0, radius)]
+        for i in range(1, num_latitudes):
+            th = np.pi * i / num_latitudes
+            for j in range(num_longitudes):
+                ph = 2.0 * np.pi * j / num_longitudes
+                verts.append((radius * np.sin(th) * np.cos(ph), radius * np.sin(th) * np.sin(ph), radius * np.cos(th)))
+        verts.append((0.0, 0.0, -radius))
+        south = len(verts) - 1
+
+        def ring(i, j):
+            return 1 + (i - 1) * num_longitudes + (j % num_longitudes)
+
+        tris = []
+        for j in range(num_longitudes):
+            tris.append((0, ring(1, j), ring(1, j + 1)))
+            tris.append((south, ring(num_latitudes - 1, j + 1), ring(num_latitudes - 1, j)))
+        for i in range(1, num_latitudes - 1):
+            for j in range(num_longitudes):
+                a, b, c, d = ring(i, j), ring(i, j + 1), ring(i + 1, j), ring(i + 1, j + 1)
+                tris.append((a, c, d))
+                tris.append((a, d, b))
+        return Mesh(np.asarray(verts), np.asarray(tris, dtype=np.int32), compute_inertia=compute_inertia)
+
+    @staticmethod
+    def convex_hull_of(points) -> Mesh:
+        """Mesh of the convex hull of a point cloud, outward winding (scipy.spatial.ConvexHull)."""
+        from scipy.spatial import ConvexHull  # noqa: PLC0415
+
+        pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+        hull = ConvexHull(pts)
+        used = np.unique(hull.simplices)
+        remap = -np.ones(len(pts), dtype=np.int64)
+        remap[used] = np.arange(len(used))
+        verts = pts[used]
+        center = verts.mean(axis=0)
+        tris = []
+        for simplex, eq in zip(hull.simplices, hull.equations):
+            i, j, k = remap[simplex]
+            n = np.cross(verts[j] - verts[i], verts[k] - verts[i])
+            if np.dot(n, eq[:3]) < 0.0:  # make the winding agree with the outward facet normal
+                j, k = k, j
+            tris.append((i, j, k))
+        del center
+        return Mesh(verts, np.asarray(tris, dtype=np.int32))
+
+
+def deduplicate_vertices(mesh: Mesh) -> np.ndarray:
+    """Collision vertex set: each exact position once, first-occurrence order
+    (_deduplicate_convex_collision_mesh, newton/_src/sim/builder.py:104-137)."""
+    v = mesh.vertices
+    _, first = np.unique(v, axis=0, return_index=True)
+    return v[np.sort(first)]

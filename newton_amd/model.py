@@ -188,10 +188,20 @@ class EnvTemplate:
                 return tb in (GeoType.SPHERE, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.BOX)
             return ta == GeoType.CAPSULE and tb == GeoType.CAPSULE
 
-        convex_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE)
+        convex_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE,
+                        GeoType.CONVEX_MESH)
         is_analytic = np.array([analytic(a, b) for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
+
+        def convex_ok(s):
+            ty = int(self.shape_type[s])
+            if ty == GeoType.PLANE:  # infinite planes become a box proxy under the other shape (collision_core.py:562-625)
+                sc = np.asarray(m.shape_scale).reshape(-1, 3)[s if s < ns else E * ns + (s - ns)]
+                return sc[0] == 0.0 and sc[1] == 0.0
+            return ty in convex_types
+
         for a, b, ok in zip(self.pair_a, self.pair_b, is_analytic):
-            if not ok and not (int(self.shape_type[a]) in convex_types and int(self.shape_type[b]) in convex_types):
+            both_planes = int(self.shape_type[a]) == GeoType.PLANE and int(self.shape_type[b]) == GeoType.PLANE
+            if not ok and (both_planes or not (convex_ok(a) and convex_ok(b))):
                 raise NotImplementedError(
                     f"collision pair ({GeoType(int(self.shape_type[a])).name}, {GeoType(int(self.shape_type[b])).name}) "
                     "has no analytic path and is outside the convex (MPR/GJK) scope of this build")

@@ -70,6 +70,12 @@ typedef struct {
     const float* shape_material_restitution;
     const int32_t* shape_contact_pairs; /* [P][2] */
     const int32_t* joint_ancestor;      /* [J] joint whose child is this joint's parent body, or -1 (builder.py:12341-12348) */
+    /* convex-hull shapes (GeoType.CONVEX_MESH): shared vertex table + per-shape slice, local AABB with the scale baked in */
+    const float* mesh_points;           /* [V][3] */
+    const int32_t* shape_mesh_start;    /* [S] first vertex or -1 */
+    const int32_t* shape_mesh_count;    /* [S] */
+    const float* shape_collision_aabb_lower; /* [S][3] (builder.py:11575-11612) */
+    const float* shape_collision_aabb_upper; /* [S][3] */
 } o_model;
 
 typedef struct {

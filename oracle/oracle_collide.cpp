@@ -444,6 +444,20 @@ static void compute_shape_aabbs(const o_model* m, const float* body_q, float* aa
                               radius * std::sqrt(r0[2] * r0[2] + r1[2] * r1[2]) + half_height * std::fabs(r2[2]));
             lo = pos - half_extents - margin_vec;
             hi = pos + half_extents + margin_vec;
+        } else if (geo_type == GEO_CONVEX_MESH) {
+            // pre-computed local AABB (scale baked in) rotated to the world frame (collide.py:421-445)
+            vec3 local_lo = ld3(m->shape_collision_aabb_lower, shape_id), local_hi = ld3(m->shape_collision_aabb_upper, shape_id);
+            vec3 center = (local_lo + local_hi) * 0.5f;
+            vec3 half = (local_hi - local_lo) * 0.5f;
+            vec3 world_center = quat_rotate(orientation, center) + pos;
+            vec3 r0 = quat_rotate(orientation, vec3(1.0f, 0.0f, 0.0f));
+            vec3 r1 = quat_rotate(orientation, vec3(0.0f, 1.0f, 0.0f));
+            vec3 r2 = quat_rotate(orientation, vec3(0.0f, 0.0f, 1.0f));
+            vec3 world_half(std::fabs(r0[0]) * half[0] + std::fabs(r1[0]) * half[1] + std::fabs(r2[0]) * half[2],
+                            std::fabs(r0[1]) * half[0] + std::fabs(r1[1]) * half[1] + std::fabs(r2[1]) * half[2],
+                            std::fabs(r0[2]) * half[0] + std::fabs(r1[2]) * half[1] + std::fabs(r2[2]) * half[2]);
+            lo = world_center - world_half - margin_vec;
+            hi = world_center + world_half + margin_vec;
         } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE) {
             // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space
             mat33 rot_mat_t = transpose(quat_to_matrix(orientation));

@@ -27,6 +27,9 @@ namespace {
 struct Geom {
     int type;
     vec3 scale;
+    const float* points = nullptr;  // CONVEX_MESH: vertex slice [count][3] (unscaled)
+    int count = 0;
+    vec3 center;                    // interior point used to seed MPR / GJK (collision_core.py:690, narrow_phase.py:1102-1105)
 };
 struct vec2 {
     float x, y;
@@ -60,7 +63,20 @@ vec3 support_map_box(const Geom& g, vec3 d) {
 vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
-    if (g.type == GEO_BOX) {
+    if (g.type == GEO_CONVEX_MESH) {
+        // support_function.py:152-171: furthest vertex; ties keep the first one
+        vec3 scaled_dir = cw_mul(direction, g.scale);
+        float max_dot = -1.0e10f;
+        int best_idx = 0;
+        for (int i = 0; i < g.count; ++i) {
+            float dot_val = dot(ld3(g.points, i), scaled_dir);
+            if (dot_val > max_dot) {
+                max_dot = dot_val;
+                best_idx = i;
+            }
+        }
+        result = g.count > 0 ? cw_mul(ld3(g.points, best_idx), g.scale) : vec3(0.0f);
+    } else if (g.type == GEO_BOX) {
         result = support_map_box(g, direction);
     } else if (g.type == GEO_SPHERE) {
         float radius = g.scale.x;
@@ -167,9 +183,9 @@ bool solve_mpr_core(const Geom& ga, const Geom& gb, quat orientation_b, vec3 pos
     penetration = 0.0f;
     point_a = vec3(0.0f);
     point_b = vec3(0.0f);
-    Vert v0;
-    v0.B = position_b;
-    v0.BtoA = vec3(0.0f) - v0.B;
+    Vert v0;  // create_shape_center_function(use_precomputed_center=True) (support_function.py:541-598)
+    v0.B = position_b + quat_rotate(orientation_b, gb.center);
+    v0.BtoA = ga.center - v0.B;
     normal = v0.BtoA;
     if (length_sq(normal) < NUMERIC_EPSILON) {
         v0.BtoA = vec3(0.0f);  // fallback() is zero for non-triangle shapes
@@ -438,7 +454,7 @@ bool solve_closest_distance_core(const Geom& ga, const Geom& gb, quat orientatio
     vec4f4 bary;
     uint32_t usage = 0;
     int iter_count = MAX_ITER;
-    vec3 v = vec3(0.0f) - position_b;  // center.BtoA
+    vec3 v = ga.center - (position_b + quat_rotate(orientation_b, gb.center));  // center.BtoA
     float dist_sq = length_sq(v);
     vec3 last_search_dir(1.0f, 0.0f, 0.0f);
     while (iter_count > 0) {
@@ -986,32 +1002,69 @@ int build_manifold(PairCtx& P, quat orientation_a, vec3 position_a_world, quat r
 }
 
 bool supported_type(int t) {
-    return t == GEO_BOX || t == GEO_SPHERE || t == GEO_CAPSULE || t == GEO_ELLIPSOID || t == GEO_CYLINDER || t == GEO_CONE;
+    return t == GEO_BOX || t == GEO_SPHERE || t == GEO_CAPSULE || t == GEO_ELLIPSOID || t == GEO_CYLINDER || t == GEO_CONE ||
+           t == GEO_CONVEX_MESH;
+}
+void bind_mesh(const o_model* m, int shape, Geom& g) {
+    if (g.type != GEO_CONVEX_MESH) return;
+    g.points = m->mesh_points + 3 * m->shape_mesh_start[shape];
+    g.count = m->shape_mesh_count[shape];
+    g.center = 0.5f * (ld3(m->shape_collision_aabb_lower, shape) + ld3(m->shape_collision_aabb_upper, shape));
 }
 
 }  // namespace
 
 namespace orc {
 vec3 support_map_generic(int type, vec3 scale, vec3 direction) {
-    Geom g{type, scale};
+    Geom g;
+    g.type = type;
+    g.scale = scale;
     return support_map(g, direction);
 }
 int convex_pair_contacts(const o_model* m, int shape_a, int shape_b, const float* geom_data, const float* geom_xform,
-                         const float* /*aabb_lower*/, const float* /*aabb_upper*/, const float* body_q, o_contacts* ct) {
+                         const float* aabb_lower, const float* aabb_upper, const float* body_q, o_contacts* ct) {
     if (shape_a == shape_b || shape_a < 0 || shape_b < 0) return 0;
     PairCtx P;
     P.m = m; P.body_q = body_q; P.ct = ct; P.shape_a = shape_a; P.shape_b = shape_b; P.written = 0;
     P.ga.type = m->shape_type[shape_a];
     P.gb.type = m->shape_type[shape_b];
-    if (!supported_type(P.ga.type) || !supported_type(P.gb.type)) return 0;  // plane proxies / meshes: not restated
-    if (P.ga.type == GEO_CYLINDER && geom_data[4 * shape_a + 2] != 0.0f) return 0;  // barrel cylinders: not restated
-    if (P.gb.type == GEO_CYLINDER && geom_data[4 * shape_b + 2] != 0.0f) return 0;
     P.ga.scale = vec3(geom_data[4 * shape_a], geom_data[4 * shape_a + 1], geom_data[4 * shape_a + 2]);
     P.gb.scale = vec3(geom_data[4 * shape_b], geom_data[4 * shape_b + 1], geom_data[4 * shape_b + 2]);
+    // pairs arrive type-sorted, so an infinite plane (PLANE = 1) can only be shape A
+    bool is_infinite_plane_a = P.ga.type == GEO_PLANE && P.ga.scale.x == 0.0f && P.ga.scale.y == 0.0f;
+    bool is_infinite_plane_b = P.gb.type == GEO_PLANE && P.gb.scale.x == 0.0f && P.gb.scale.y == 0.0f;
+    if (is_infinite_plane_a && is_infinite_plane_b) return 0;  // narrow_phase.py:1111-1112
+    if (is_infinite_plane_b) return 0;                          // cannot happen after type sorting
+    if (!(is_infinite_plane_a || supported_type(P.ga.type)) || !supported_type(P.gb.type)) return 0;  // meshes etc.: not restated
+    if (P.ga.type == GEO_CYLINDER && P.ga.scale.z != 0.0f) return 0;  // barrel cylinders: not restated
+    if (P.gb.type == GEO_CYLINDER && P.gb.scale.z != 0.0f) return 0;
+    bind_mesh(m, shape_a, P.ga);
+    bind_mesh(m, shape_b, P.gb);
     P.margin_a = geom_data[4 * shape_a + 3];
     P.margin_b = geom_data[4 * shape_b + 3];
     transform Xa = ldx(geom_xform, shape_a), Xb = ldx(geom_xform, shape_b);
     float rigid_gap = m->shape_gap[shape_a] + m->shape_gap[shape_b];
+    if (is_infinite_plane_a) {
+        // bounding-sphere half-space cull on the broad-phase AABB of the other shape (narrow_phase.py:1117-1194,
+        // collision_core.py:549-560,628-683; external_aabb = True, speculative = False)
+        vec3 lo = ld3(aabb_lower, shape_b), hi = ld3(aabb_upper, shape_b);
+        vec3 bsphere_center_b = 0.5f * (lo + hi);
+        float bsphere_radius_b = length(0.5f * (hi - lo));
+        vec3 plane_normal = quat_rotate(Xa.q, vec3(0.0f, 0.0f, 1.0f));
+        float center_dist = dot(bsphere_center_b - Xa.p, plane_normal);
+        if (!(center_dist <= bsphere_radius_b)) return 0;
+        if (ct->rigid_contact_count[0] >= ct->rigid_contact_max) return 0;
+        // convert_infinite_plane_to_cube (collision_core.py:562-625)
+        float other_radius = bsphere_radius_b + rigid_gap;
+        float lateral_size = other_radius * 10.0f, depth = other_radius * 10.0f;
+        P.ga.type = GEO_BOX;
+        P.ga.scale = vec3(lateral_size, lateral_size, depth);
+        P.ga.center = vec3(0.0f);
+        vec3 to_other = Xb.p - Xa.p;
+        float distance_along_normal = dot(to_other, plane_normal);
+        vec3 plane_surface_point = Xb.p - plane_normal * distance_along_normal;
+        Xa.p = plane_surface_point - plane_normal * depth;
+    }
     if (ct->rigid_contact_count[0] >= ct->rigid_contact_max) return 0;  // find_contacts early-out
 
     // compute_gjk_mpr_contacts (collision_core.py:347-450)
@@ -1066,7 +1119,9 @@ int convex_pair_contacts(const o_model* m, int shape_a, int shape_b, const float
 // probes for the known-answer tests (reference: newton/tests/test_mpr.py, test_gjk.py)
 extern "C" int o_probe_mpr(int type_a, int type_b, const float* xf_a, const float* xf_b, const float* scale_a, const float* scale_b,
                            float* out /* collision, signed_distance, point[3], normal[3] (world) */) {
-    Geom ga{type_a, ld3(scale_a, 0)}, gb{type_b, ld3(scale_b, 0)};
+    Geom ga, gb;
+    ga.type = type_a; ga.scale = ld3(scale_a, 0);
+    gb.type = type_b; gb.scale = ld3(scale_b, 0);
     transform Xa = ldx(xf_a, 0), Xb = ldx(xf_b, 0);
     quat rel_q = quat_inverse(Xa.q) * Xb.q;
     vec3 rel_p = quat_rotate_inv(Xa.q, Xb.p - Xa.p);
@@ -1083,7 +1138,9 @@ extern "C" int o_probe_mpr(int type_a, int type_b, const float* xf_a, const floa
 }
 extern "C" int o_probe_gjk(int type_a, int type_b, const float* xf_a, const float* xf_b, const float* scale_a, const float* scale_b,
                            float* out /* collision, distance, point[3], normal[3] (world) */) {
-    Geom ga{type_a, ld3(scale_a, 0)}, gb{type_b, ld3(scale_b, 0)};
+    Geom ga, gb;
+    ga.type = type_a; ga.scale = ld3(scale_a, 0);
+    gb.type = type_b; gb.scale = ld3(scale_b, 0);
     transform Xa = ldx(xf_a, 0), Xb = ldx(xf_b, 0);
     quat rel_q = quat_inverse(Xa.q) * Xb.q;
     vec3 rel_p = quat_rotate_inv(Xa.q, Xb.p - Xa.p);

@@ -35,6 +35,8 @@ class o_model(C.Structure):
         ("shape_collision_radius", _f), ("shape_material_ke", _f), ("shape_material_kd", _f), ("shape_material_kf", _f),
         ("shape_material_ka", _f), ("shape_material_mu", _f), ("shape_material_mu_torsional", _f),
         ("shape_material_mu_rolling", _f), ("shape_material_restitution", _f), ("shape_contact_pairs", _i), ("joint_ancestor", _i),
+        ("mesh_points", _f), ("shape_mesh_start", _i), ("shape_mesh_count", _i), ("shape_collision_aabb_lower", _f),
+        ("shape_collision_aabb_upper", _f),
     ]
 
 
@@ -147,6 +149,11 @@ class OracleModel:
             setattr(m, n, f32(n))
         m.shape_contact_pairs = i32("shape_contact_pairs")
         m.joint_ancestor = i32("joint_ancestor")
+        m.mesh_points = f32("mesh_points")
+        m.shape_mesh_start = i32("shape_mesh_start")
+        m.shape_mesh_count = i32("shape_mesh_count")
+        m.shape_collision_aabb_lower = f32("shape_collision_aabb_lower")
+        m.shape_collision_aabb_upper = f32("shape_collision_aabb_upper")
         self.struct = m
 
 

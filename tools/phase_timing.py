@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Per-phase cycle accounting of xpbd_rollout_kernel (run ON the GPU box).
+
+Builds a throw-away debug library with -DNT_PHASE_TIMING (workgroup 0 / thread 0 accumulates cycle deltas at every
+phase barrier), runs the bench workload through it (NEWTON_HIP_LIB override) and prints the share of each phase.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dbg = "/tmp/libnewton_hip_timing.so"
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                "-DNT_PHASE_TIMING", os.path.join(ROOT, "newton_amd/csrc/nt_kernels.hip"), "-o", dbg], check=True)
+os.environ["NEWTON_HIP_LIB"] = dbg
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import newton_amd as nt  # noqa: E402
+from newton_amd import _lib  # noqa: E402
+from scenes import quadruped_scene  # noqa: E402
+
+lib = _lib.load()
+model = quadruped_scene(4096, device="cuda:0", seed=1)
+s0, s1 = model.state(), model.state()
+pipe = nt.CollisionPipeline(model)
+contacts = pipe.contacts()
+solver = nt.solvers.SolverXPBD(model)
+for _ in range(100):
+    solver.rollout(s0, s1, None, contacts, 1e-3, 10)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 32)()
+raw = C.CDLL(dbg)
+raw.nt_debug_phase_clocks(buf)
+N = 50
+for _ in range(N):
+    solver.rollout(s0, s1, None, contacts, 1e-3, 10)
+torch.cuda.synchronize()
+raw.nt_debug_phase_clocks(buf)
+names = {0: "prologue (load + derived)", 1: "shapes/AABB", 2: "pairs (broad+narrow+write)", 3: "joint forces", 4: "integrate",
+         5: "contacts", 6: "apply (contacts)", 7: "joints", 8: "apply (joints)", 9: "epilogue (count + store)"}
+tot = sum(buf[i] for i in range(10))
+for i in range(10):
+    print(f"{names[i]:32s} {buf[i] / N:12.0f} cycles/launch  {100.0 * buf[i] / tot:5.1f} %")
+print(f"{'total':32s} {tot / N:12.0f} cycles/launch (s_memtime ticks of workgroup 0)")
