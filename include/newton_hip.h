@@ -92,6 +92,11 @@ typedef struct {
     const int32_t* body_pair_start;     /* [nb+1] */
     const int32_t* body_pair_list;      /* [2*np] (padded) pair*2 + (1 if the body owns pair_b's shape else 0), ascending pair */
     const int32_t* art_start;           /* [na+1] first env-local joint of each articulation (Model.articulation_start / _end) */
+    /* convex-hull shapes (GeoType.CONVEX_MESH, support_function.py:152-171): env-uniform vertex table */
+    const int32_t* shape_mesh_start;    /* [ns+ng] first vertex of the shape's hull in mesh_points, -1 for other types */
+    const int32_t* shape_mesh_count;    /* [ns+ng] */
+    const float* mesh_points;           /* [V][3] unscaled vertices (AoS); the per-env shape scale is applied on the fly */
+    const float* shape_mesh_bounds;     /* [ns+ng][6] unscaled min xyz, max xyz of the hull (local AABB = bounds * scale) */
     /* per-env parameters, float SoA */
     const float* body_param;            /* [NT_BODY_PARAM_FLOATS][nb][ES] */
     const float* gravity;               /* [3][ES] */

@@ -35,6 +35,8 @@ class nt_model(C.Structure):
         ("shape_flags", C.c_void_p), ("shape_group", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p),
         ("body_joint_start", C.c_void_p), ("body_joint_list", C.c_void_p), ("body_pair_start", C.c_void_p),
         ("body_pair_list", C.c_void_p), ("art_start", C.c_void_p),
+        ("shape_mesh_start", C.c_void_p), ("shape_mesh_count", C.c_void_p), ("mesh_points", C.c_void_p),
+        ("shape_mesh_bounds", C.c_void_p),
         ("body_param", C.c_void_p), ("gravity", C.c_void_p), ("joint_param", C.c_void_p), ("dof_param", C.c_void_p),
         ("shape_param", C.c_void_p), ("gshape_param", C.c_void_p),
     ]

@@ -724,7 +724,7 @@ class ModelBuilder:
             starts.append(st)
             counts.append(ct)
             v = points[[k for k, key in enumerate(uniq) if key == id(src)][0]].astype(np.float64)
-            sc = np.asarray(self.shape_scale[i], dtype=np.float64)
+            sc = np.asarray(self.shape_scale[i], dtype=f32).astype(np.float64)  # the device multiplies in fp32
             lo, hi = v.min(axis=0) * sc, v.max(axis=0) * sc
             lo_all[i], hi_all[i] = np.minimum(lo, hi), np.maximum(lo, hi)
         m.shape_mesh_start = np.asarray(starts, dtype=i32).reshape(S)

@@ -20,6 +20,10 @@ NT_DI int imin(int a, int b) { return a < b ? a : b; }
 struct Geom {
     int type;
     vec3 scale;
+    const float* points;  // CONVEX_MESH: vertex slice [count][3] (unscaled, env-uniform, global memory)
+    int count;
+    vec3 center;          // interior point that seeds MPR / GJK (collision_core.py:690, narrow_phase.py:1102-1105)
+    NT_DI Geom() : type(0), points(nullptr), count(0) {}
 };
 struct vec2 {
     float x, y;
@@ -53,7 +57,21 @@ NT_DEV vec3 support_map_box(const Geom& g, vec3 d) {
 NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
-    if (g.type == GEO_BOX) {
+    if (g.type == GEO_CONVEX_MESH) {
+        // support_function.py:152-171: furthest vertex; ties keep the first one
+        vec3 scaled_dir = cw_mul(direction, g.scale);
+        float max_dot = -1.0e10f;
+        int best_idx = 0;
+        for (int i = 0; i < g.count; ++i) {
+            float dot_val = dot(vec3(g.points[3 * i], g.points[3 * i + 1], g.points[3 * i + 2]), scaled_dir);
+            if (dot_val > max_dot) {
+                max_dot = dot_val;
+                best_idx = i;
+            }
+        }
+        if (g.count > 0)
+            result = cw_mul(vec3(g.points[3 * best_idx], g.points[3 * best_idx + 1], g.points[3 * best_idx + 2]), g.scale);
+    } else if (g.type == GEO_BOX) {
         result = support_map_box(g, direction);
     } else if (g.type == GEO_SPHERE) {
         float radius = g.scale.x;
@@ -160,9 +178,9 @@ NT_DEV bool solve_mpr_core(const Geom& ga, const Geom& gb, quat orientation_b, v
     penetration = 0.0f;
     point_a = vec3(0.0f);
     point_b = vec3(0.0f);
-    Vert v0;
-    v0.B = position_b;
-    v0.BtoA = vec3(0.0f) - v0.B;
+    Vert v0;  // create_shape_center_function(use_precomputed_center=True) (support_function.py:541-598)
+    v0.B = position_b + quat_rotate(orientation_b, gb.center);
+    v0.BtoA = ga.center - v0.B;
     normal = v0.BtoA;
     if (length_sq(normal) < NUMERIC_EPSILON) {
         v0.BtoA = vec3(0.0f);  // fallback() is zero for non-triangle shapes
@@ -431,7 +449,7 @@ NT_DEV bool solve_closest_distance_core(const Geom& ga, const Geom& gb, quat ori
     vec4f4 bary;
     unsigned usage = 0;
     int iter_count = MAX_ITER;
-    vec3 v = vec3(0.0f) - position_b;  // center.BtoA
+    vec3 v = ga.center - (position_b + quat_rotate(orientation_b, gb.center));  // center.BtoA
     float dist_sq = length_sq(v);
     vec3 last_search_dir(1.0f, 0.0f, 0.0f);
     while (iter_count > 0) {
@@ -985,15 +1003,36 @@ NT_DEV int build_manifold(PairCtx& P, quat orientation_a, vec3 position_a_world,
 
 // compute_gjk_mpr_contacts + solve_convex_multi_contact (collision_core.py:325-452, collision_convex.py:110-232).
 // Shapes arrive type-sorted (type_a <= type_b) with world transforms; contacts come back in the reference's emission order.
-NT_DEV void convex_pair(int type_a, int type_b, const xform& Xa, const xform& Xb, vec3 scale_a, vec3 scale_b, float margin_a,
-                        float margin_b, float rigid_gap, ConvexContacts& out) {
+NT_DEV void convex_pair(const Geom& geom_a, const Geom& geom_b, xform Xa, const xform& Xb, float margin_a, float margin_b,
+                        float rigid_gap, vec3 aabb_lower_b, vec3 aabb_upper_b, ConvexContacts& out) {
     out.count = 0;
     PairCtx P;
     P.out = &out;
-    P.ga.type = type_a; P.ga.scale = scale_a;
-    P.gb.type = type_b; P.gb.scale = scale_b;
+    P.ga = geom_a;
+    P.gb = geom_b;
     P.margin_a = margin_a; P.margin_b = margin_b;
     P.contact_gap = rigid_gap;
+    // pairs arrive type-sorted, so an infinite plane (PLANE = 1) can only be shape A
+    if (P.ga.type == GEO_PLANE) {
+        // bounding-sphere half-space cull on the other shape's broad-phase AABB (narrow_phase.py:1117-1194,
+        // collision_core.py:549-560,628-683), then the box proxy of convert_infinite_plane_to_cube (collision_core.py:562-625)
+        vec3 bsphere_center_b = 0.5f * (aabb_lower_b + aabb_upper_b);
+        float bsphere_radius_b = length(0.5f * (aabb_upper_b - aabb_lower_b));
+        vec3 plane_normal = quat_rotate(Xa.q, vec3(0.0f, 0.0f, 1.0f));
+        float center_dist = dot(bsphere_center_b - Xa.p, plane_normal);
+        if (!(center_dist <= bsphere_radius_b)) return;
+        float other_radius = bsphere_radius_b + rigid_gap;
+        float lateral_size = other_radius * 10.0f, depth = other_radius * 10.0f;
+        P.ga.type = GEO_BOX;
+        P.ga.scale = vec3(lateral_size, lateral_size, depth);
+        P.ga.center = vec3(0.0f);
+        vec3 to_other = Xb.p - Xa.p;
+        float distance_along_normal = dot(to_other, plane_normal);
+        vec3 plane_surface_point = Xb.p - plane_normal * distance_along_normal;
+        Xa.p = plane_surface_point - plane_normal * depth;
+    }
+    const int type_a = P.ga.type, type_b = P.gb.type;
+    const vec3 scale_a = P.ga.scale, scale_b = P.gb.scale;
     P.radius_eff_a = 0.0f;
     P.radius_eff_b = 0.0f;
     const float small_radius = 0.0001f;

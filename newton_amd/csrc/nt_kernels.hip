@@ -118,10 +118,10 @@ struct KArgs {
 struct Topo {
     const int *body_flags, *joint_type, *joint_enabled, *joint_parent, *joint_child, *joint_q_start, *joint_qd_start,
         *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
-        *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list;
+        *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count;
 };
 __host__ __device__ inline int topo_ints(const nt_model& m) {
-    return m.nb + 9 * m.nj + 4 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np;
+    return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np;
 }
 
 template <int EPB>
@@ -172,6 +172,8 @@ struct Ctx {
         take(T.body_joint_list, m.body_joint_list, 2 * m.nj);  // padded to 2*nj entries by the host
         take(T.body_pair_start, m.body_pair_start, m.nb + 1);
         take(T.body_pair_list, m.body_pair_list, 2 * m.np);    // padded to 2*np entries by the host
+        take(T.shape_mesh_start, m.shape_mesh_start, m.ns + m.ng);
+        take(T.shape_mesh_count, m.shape_mesh_count, m.ns + m.ng);
     }
     // LDS element: row = field offset + comp * slots_in_field + slot
     NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * EPB + e]; }
@@ -305,7 +307,8 @@ NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
 // ------------------------------------------------------------------------------------------------
 // collide: compute_shape_aabbs (collide.py:283-472)
 // ------------------------------------------------------------------------------------------------
-NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_gap, vec3& lo, vec3& hi) {
+NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_gap, const float* mesh_bounds, vec3& lo,
+                      vec3& hi) {
     vec3 pos = X.p;
     quat q = X.q;
     vec3 mv(effective_gap, effective_gap, effective_gap);
@@ -350,14 +353,42 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
         he = vec3(radius * sqrtf(r0.x * r0.x + r1.x * r1.x) + hh * fabsf(r2.x),
                   radius * sqrtf(r0.y * r0.y + r1.y * r1.y) + hh * fabsf(r2.y),
                   radius * sqrtf(r0.z * r0.z + r1.z * r1.z) + hh * fabsf(r2.z));
-    } else if (geo_type == GEO_ELLIPSOID) {
-        mat33 R = quat_to_matrix(q);
-        he = vec3(length(vec3(R.m00 * scale.x, R.m01 * scale.y, R.m02 * scale.z)),
-                  length(vec3(R.m10 * scale.x, R.m11 * scale.y, R.m12 * scale.z)),
-                  length(vec3(R.m20 * scale.x, R.m21 * scale.y, R.m22 * scale.z)));
+    } else if (geo_type == GEO_CONVEX_MESH) {
+        // pre-computed local AABB (scale baked in) rotated to the world frame (collide.py:421-445)
+        vec3 a = cw_mul(vec3(mesh_bounds[0], mesh_bounds[1], mesh_bounds[2]), scale);
+        vec3 b = cw_mul(vec3(mesh_bounds[3], mesh_bounds[4], mesh_bounds[5]), scale);
+        vec3 local_lo = vmin(a, b), local_hi = vmax(a, b);
+        vec3 center = (local_lo + local_hi) * 0.5f;
+        vec3 half = (local_hi - local_lo) * 0.5f;
+        vec3 world_center = quat_rotate(q, center) + pos;
+        vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
+        vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
+        vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        vec3 world_half(fabsf(r0.x) * half.x + fabsf(r1.x) * half.y + fabsf(r2.x) * half.z,
+                        fabsf(r0.y) * half.x + fabsf(r1.y) * half.y + fabsf(r2.y) * half.z,
+                        fabsf(r0.z) * half.x + fabsf(r1.z) * half.y + fabsf(r2.z) * half.z);
+        lo = world_center - world_half - mv;
+        hi = world_center + world_half + mv;
+        return;
+    } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE) {
+        // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space
+        mat33 Rt = transpose(quat_to_matrix(q));
+        vec3 local_x(Rt.m00, Rt.m10, Rt.m20), local_y(Rt.m01, Rt.m11, Rt.m21), local_z(Rt.m02, Rt.m12, Rt.m22);
+        Geom g;
+        g.type = geo_type;
+        g.scale = scale;
+        float max_x = dot(local_x, support_map(g, local_x));
+        float max_y = dot(local_y, support_map(g, local_y));
+        float max_z = dot(local_z, support_map(g, local_z));
+        float min_x = dot(local_x, support_map(g, -local_x));
+        float min_y = dot(local_y, support_map(g, -local_y));
+        float min_z = dot(local_z, support_map(g, -local_z));
+        lo = vec3(min_x, min_y, min_z) + pos - mv;
+        hi = vec3(max_x, max_y, max_z) + pos + mv;
+        return;
     } else {
-        // finite planes / cones: conservative bounding sphere
-        float r = (geo_type == GEO_PLANE) ? 0.5f * sqrtf(scale.x * scale.x + scale.y * scale.y) : scale.x + scale.y;
+        // finite planes: conservative bounding sphere (rejected by the host for collision)
+        float r = 0.5f * sqrtf(scale.x * scale.x + scale.y * scale.y);
         he = vec3(r, r, r);
     }
     lo = pos - he - mv;
@@ -373,7 +404,8 @@ NT_DI void phase_shapes(const Ctx<EPB>& c) {
         xform X = c.shape_local_xform(s);
         if (body >= 0) X = c.body_q(body) * X;
         vec3 lo, hi;
-        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP),
+                   m.shape_mesh_bounds + 6 * s, lo, hi);
         c.st_lxf(c.L.sx, m.ns, s, X);
         c.st_lv3(c.L.sa, 0, m.ns, s, lo);
         c.st_lv3(c.L.sa, 3, m.ns, s, hi);
@@ -389,7 +421,8 @@ NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {
         hi = c.lv3(c.L.sa, 3, m.ns, s);
     } else {
         X = c.shape_local_xform(s);  // global shapes are static (shape_body == -1)
-        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), lo, hi);
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP),
+                   m.shape_mesh_bounds + 6 * s, lo, hi);
     }
 }
 
@@ -448,6 +481,8 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
             int t = sa; sa = sb; sb = t;
             t = ta; ta = tb; tb = t;
             xform X = Xa; Xa = Xb; Xb = X;
+            vec3 v = loa; loa = lob; lob = v;
+            v = hia; hia = hib; hib = v;
         }
         vec3 scale_a = c.shape_scale(sa), scale_b = c.shape_scale(sb);
         float margin_a = c.shape_f(sa, SP_MARGIN), margin_b = c.shape_f(sb, SP_MARGIN);
@@ -485,7 +520,24 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
             if (p >= m.np_analytic) {
                 if (k != 0) return;
                 ConvexContacts cc;
-                convex_pair(ta, tb, Xa, Xb, scale_a, scale_b, margin_a, margin_b, gap_sum, cc);
+                Geom ga, gb;
+                ga.type = ta; ga.scale = scale_a;
+                gb.type = tb; gb.scale = scale_b;
+                if (ta == GEO_CONVEX_MESH) {
+                    ga.points = m.mesh_points + 3 * c.T.shape_mesh_start[sa];
+                    ga.count = c.T.shape_mesh_count[sa];
+                    const float* mb = m.shape_mesh_bounds + 6 * sa;
+                    ga.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)) +
+                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)));
+                }
+                if (tb == GEO_CONVEX_MESH) {
+                    gb.points = m.mesh_points + 3 * c.T.shape_mesh_start[sb];
+                    gb.count = c.T.shape_mesh_count[sb];
+                    const float* mb = m.shape_mesh_bounds + 6 * sb;
+                    gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +
+                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)));
+                }
+                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
                 float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
                 vec3 n = normalize(cc.normal);

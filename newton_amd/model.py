@@ -144,6 +144,18 @@ class EnvTemplate:
         self.shape_type = shape_uniform(m.shape_type, "shape_type")
         self.shape_flags = shape_uniform(m.shape_flags, "shape_flags")
         self.shape_group = shape_uniform(m.shape_collision_group, "shape_collision_group")
+        # convex-hull vertex slices (shared Mesh assets => identical in every world) + unscaled hull bounds per shape
+        n_all = len(np.asarray(m.shape_type))
+        mesh_start = np.asarray(getattr(m, "shape_mesh_start", -np.ones(n_all)), dtype=np.int32)
+        mesh_count = np.asarray(getattr(m, "shape_mesh_count", np.zeros(n_all)), dtype=np.int32)
+        self.shape_mesh_start = shape_uniform(mesh_start, "convex hull mesh")
+        self.shape_mesh_count = shape_uniform(mesh_count, "convex hull mesh")
+        self.mesh_points = np.asarray(getattr(m, "mesh_points", np.zeros((0, 3))), dtype=np.float32).reshape(-1, 3)
+        self.shape_mesh_bounds = np.zeros((ns + self.ng, 6), dtype=np.float32)
+        for k in range(ns + self.ng):
+            if self.shape_mesh_count[k] > 0:
+                v = self.mesh_points[self.shape_mesh_start[k]:self.shape_mesh_start[k] + self.shape_mesh_count[k]]
+                self.shape_mesh_bounds[k, :3], self.shape_mesh_bounds[k, 3:] = v.min(axis=0), v.max(axis=0)
 
         # candidate pairs, per env, in Newton's order
         pairs = np.asarray(m.shape_contact_pairs, dtype=np.int64).reshape(-1, 2)
@@ -268,7 +280,8 @@ class DeviceModel:
             "body_flags", "joint_type", "joint_enabled", "joint_parent", "joint_child", "joint_q_start",
             "joint_qd_start", "joint_tq_start", "joint_lin_count", "joint_ang_count", "shape_body", "shape_type",
             "shape_flags", "shape_group", "pair_a", "pair_b", "body_joint_start", "body_joint_list", "body_pair_start",
-            "body_pair_list", "art_start")}
+            "body_pair_list", "art_start", "shape_mesh_start", "shape_mesh_count")}
+        self.mesh_tables = {"mesh_points": dev_f32(t.mesh_points), "shape_mesh_bounds": dev_f32(t.shape_mesh_bounds)}
         self.params = {}
         self.upload_params(model)
         d = _lib.nt_model()
@@ -279,6 +292,8 @@ class DeviceModel:
         for k, v in self.topology.items():
             setattr(d, k, v.data_ptr())
         for k, v in self.params.items():
+            setattr(d, k, v.data_ptr())
+        for k, v in self.mesh_tables.items():
             setattr(d, k, v.data_ptr())
         self.desc = d
 

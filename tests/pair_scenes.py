@@ -57,6 +57,15 @@ def cone(r, hh, pos, quat=I4, margin=0.0, gap=0.0):
     return ("cone", dict(radius=r, half_height=hh), [*pos, *quat], margin, gap)
 
 
+def hull_box(h, pos, quat=I4, margin=0.0, gap=0.0, scale=(1.0, 1.0, 1.0)):
+    h = [h] * 3 if np.isscalar(h) else h
+    return ("convex_hull", dict(mesh=nt.Mesh.create_box(*h), scale=scale), [*pos, *quat], margin, gap)
+
+
+def hull_sphere(r, pos, quat=I4, margin=0.0, gap=0.0, scale=(1.0, 1.0, 1.0)):
+    return ("convex_hull", dict(mesh=nt.Mesh.create_sphere(r, 10, 12), scale=scale), [*pos, *quat], margin, gap)
+
+
 def quat_z(angle):
     return [0.0, 0.0, float(np.sin(angle / 2.0)), float(np.cos(angle / 2.0))]
 
@@ -84,5 +93,10 @@ CONVEX_CASES = {
     "cylinder_cylinder": [cylinder(0.2, 0.3, [0, 0, 0]), cylinder(0.15, 0.2, [0.05, 0, 0.48])],
     "cone_box": [cone(0.2, 0.3, [0, 0, 0.79]), box(0.5, [0, 0, 0])],
     "sphere_cone": [sphere(0.2, [0, 0, 0.42]), cone(0.3, 0.25, [0, 0, 0])],
+    "hull_hull_face": [hull_box(0.5, [0, 0, 0]), hull_box(0.5, [0.2, 0.1, 0.99])],
+    "hull_box_tilted": [hull_box([0.3, 0.2, 0.1], [0, 0, 0]), box([0.2, 0.25, 0.15], [0.1, 0.05, 0.22], [0.1, 0.2, 0.05, 0.97])],
+    "hull_sphere_scaled": [hull_sphere(0.5, [0, 0, 0], scale=(1.0, 0.6, 0.4)), sphere(0.3, [0.1, 0.05, 0.45])],
+    "hull_capsule": [hull_sphere(0.4, [0, 0, 0]), capsule(0.1, 0.3, [0.3, 0, 0.42], [0.7071068, 0, 0, 0.7071068])],
+    "hull_hull_separated_gap": [hull_box(0.5, [0, 0, 0], gap=0.05), hull_box(0.5, [0, 0, 1.05], quat_z(0.3), gap=0.05)],
     "capsule_cylinder": [capsule(0.1, 0.2, [0.25, 0, 0], [0, 0.7071068, 0, 0.7071068]), cylinder(0.2, 0.3, [0, 0, 0])],
 }

@@ -103,3 +103,66 @@ def test_aligned_box_stack_remains_stable():
     assert np.allclose(q[:, :, 2], 0.5 + np.arange(5), atol=2e-2)
     assert np.max(np.linalg.norm(q[:, :, :2], axis=-1)) < 1e-2
     assert np.max(np.linalg.norm(q[:, :, 3:5], axis=-1)) < 1e-3
+
+
+def _hull_pile_scene(world_count, device=None):
+    """Per env: a hull box, a scaled hull 'pebble', a cone and a primitive box dropped close together on the ground plane:
+    plane-hull / plane-cone pairs go through the infinite-plane box proxy, hull-hull / hull-box / cone-* through MPR."""
+    import newton_amd as nt
+
+    env = nt.ModelBuilder()
+    cube = nt.Mesh.create_box(0.2, 0.15, 0.1)
+    pebble = nt.Mesh.create_sphere(0.15, 8, 10)
+    b = env.add_body(xform=[0.0, 0.0, 0.095, 0.0, 0.0, 0.0, 1.0])
+    env.add_shape_convex_hull(b, mesh=cube)
+    b = env.add_body(xform=[0.05, 0.03, 0.30, *nt._np_math.quat_rpy(0.2, -0.1, 0.4)])
+    env.add_shape_convex_hull(b, mesh=pebble, scale=(1.0, 0.8, 0.7))
+    b = env.add_body(xform=[0.5, 0.0, 0.19, 0.0, 0.0, 0.0, 1.0])
+    env.add_shape_cone(b, radius=0.15, half_height=0.2)
+    b = env.add_body(xform=[0.3, 0.25, 0.09, *nt._np_math.quat_rpy(0.0, 0.0, 0.5)])
+    env.add_shape_box(b, hx=0.15, hy=0.1, hz=0.1)
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    scene.add_ground_plane()
+    return scene.finalize(device=device)
+
+
+@pytest.mark.parametrize("n_env", [1, 21])
+def test_hull_pile_collide_and_step(n_env):
+    from oracle_bridge import OracleState
+
+    nt, model, o = _setup(_hull_pile_scene, n_env)
+    rng = np.random.default_rng(4)
+    off = rng.uniform(-0.004, 0.004, size=(model.body_count, 3)).astype(np.float32)
+    model.body_q[:, :3] += off
+    model.joint_q.reshape(-1, 7)[:, :3] += off
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=3)
+    pipe.collide(s0, contacts)
+    solver.step(s0, s1, None, contacts, 1.0 / 240.0)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+    pairs, _, _ = o.collide(os0.body_q, oc)
+    assert oc.count[0] >= n_env * 10
+    o.xpbd_step(os0, os1, o.control(), oc, 1.0 / 240.0, iterations=3)
+    _compare_contacts(model, contacts, oc, pairs)
+    assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+    assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 2e-4
+
+
+def test_hull_pile_settles():
+    """The pile comes to rest on the plane: finite state, nothing sinks below the ground, speeds decay."""
+    nt, model, _ = _setup(_hull_pile_scene, 32)
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=4)
+    for _ in range(120):
+        res = solver.rollout(s0, s1, None, contacts, 1.0 / 480.0, 8)
+        assert res is s0
+    q, qd = s0.body_q.cpu().numpy(), s0.body_qd.cpu().numpy()
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(qd))
+    assert np.all(q[:, 2] > 0.03)
+    assert np.max(np.abs(qd[:, :3])) < 0.5  # the scaled pebble may still be rolling off the box

@@ -95,7 +95,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.nt_build_info()
     assert lib.nt_error_string(0) == b"ok"
     # struct layouts agree with the header (field count + size)
-    assert C.sizeof(_lib.nt_model) == 14 * 4 + 27 * 8
+    assert C.sizeof(_lib.nt_model) == 14 * 4 + 31 * 8
     m = _lib.nt_model()
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp = 18, 18, 4
