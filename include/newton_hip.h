@@ -49,7 +49,7 @@ typedef int32_t nt_status;
 #define NT_BODY_PARAM_FLOATS 23  /* com[3] inv_mass inertia[9] inv_inertia[9] mass */
 #define NT_JOINT_PARAM_FLOATS 14 /* X_p[7] X_c[7] */
 #define NT_DOF_PARAM_FLOATS 11   /* axis[3] limit_lower limit_upper target_ke target_kd limit_ke limit_kd armature damping */
-#define NT_SHAPE_PARAM_FLOATS 19 /* xform[7] scale[3] margin gap mu mu_torsional mu_rolling ke kd kf ka */
+#define NT_SHAPE_PARAM_FLOATS 20 /* xform[7] scale[3] margin gap mu mu_torsional mu_rolling ke kd kf ka restitution */
 
 /* Model: env-uniform topology + per-env parameters (Newton: newton/_src/sim/model.py:808-1364) */
 typedef struct {
@@ -140,7 +140,7 @@ typedef struct {
     float rigid_contact_relaxation;
     int32_t rigid_contact_con_weighting;
     float angular_damping;
-    int32_t enable_restitution; /* must be 0 (NT_ERR_UNSUPPORTED otherwise) */
+    int32_t enable_restitution; /* apply_rigid_restitution after the iterations (xpbd/kernels.py:2583-2728) */
 } nt_xpbd_params;
 
 typedef struct {

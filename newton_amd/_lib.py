@@ -15,7 +15,7 @@ NT_CONTACT_FLOATS = 17
 NT_BODY_PARAM_FLOATS = 23
 NT_JOINT_PARAM_FLOATS = 14
 NT_DOF_PARAM_FLOATS = 11
-NT_SHAPE_PARAM_FLOATS = 19
+NT_SHAPE_PARAM_FLOATS = 20
 
 _i32p = C.POINTER(C.c_int32)
 _f32p = C.POINTER(C.c_float)

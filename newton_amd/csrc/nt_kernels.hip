@@ -41,7 +41,7 @@ constexpr int DP_AXIS = 0, DP_LIMIT_LOWER = 3, DP_LIMIT_UPPER = 4, DP_TARGET_KE 
               DP_LIMIT_KD = 8, DP_ARMATURE = 9, DP_DAMPING = 10;
 // shape_param rows
 constexpr int SP_XFORM = 0, SP_SCALE = 7, SP_MARGIN = 10, SP_GAP = 11, SP_MU = 12, SP_MU_TORSIONAL = 13, SP_MU_ROLLING = 14,
-              SP_KE = 15, SP_KD = 16, SP_KF = 17, SP_KA = 18;
+              SP_KE = 15, SP_KD = 16, SP_KF = 17, SP_KA = 18, SP_RESTITUTION = 19;
 // contact data rows
 constexpr int CD_POINT0 = 0, CD_POINT1 = 3, CD_OFFSET0 = 6, CD_OFFSET1 = 9, CD_NORMAL = 12, CD_MARGIN0 = 15, CD_MARGIN1 = 16;
 // per-contact correction record in LDS: lin_a, ang_a, lin_b, ang_b, has_a, has_b, shape0_is_pair_a
@@ -67,6 +67,7 @@ struct LdsLayout {
     int jl, ja;        // joints: linear-part corrections [12][nj], angular-part child terms [9][nj]
     int cw;            // contacts: per-contact corrections [CW_FLOATS][np*cpp]
     int si_jf, si_cw;  // semi-implicit: joint wrenches + contact wrenches live together with body_f_tmp
+    int xi;            // XPBD restitution: pre-step body_q / body_qd [13][nb], behind the XPBD scratch (solver_xpbd.py:414-416)
     int rows_per_env;
 };
 
@@ -95,7 +96,9 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     int contacts = CW_FLOATS * m.np * m.cpp;
     L.si_jf = L.bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
     int semi = 6 * m.nb + 12 * m.nj + contacts;
-    L.rows_per_env = L.u + imax(imax(imax(coll, forces), imax(joints, contacts)), semi);
+    int xpbd = imax(imax(coll, forces), imax(joints, contacts));
+    L.xi = L.u + xpbd;
+    L.rows_per_env = L.u + imax(xpbd + 13 * m.nb, semi);
     return L;
 }
 
@@ -1261,6 +1264,125 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
     c.st_lv3(c.L.ja, 6, nj, j, t2);
 }
 
+// apply_rigid_restitution (xpbd/kernels.py:2583-2728) for one contact slot; velocity deltas go to the per-contact record
+template <int EPB>
+NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    const int cpp = m.cpp, ncs = m.np * cpp, nb = m.nb;
+    const float dt = c.a.dt;
+    const float* D = ct.data;
+    float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
+    vec3 lin_a, ang_a, lin_b, ang_b;
+    size_t gi = (size_t)slot * c.ES + c.env;
+    int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+    if (gid_a != gid_b) {
+        int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
+        int shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+        int body_a = -1, body_b = -1, mat_nonzero = 0;
+        float restitution = 0.0f;
+        if (shape_a >= 0) {
+            mat_nonzero += 1;
+            restitution += c.shape_f(shape_a, SP_RESTITUTION);
+            body_a = c.T.shape_body[shape_a];
+        }
+        if (shape_b >= 0) {
+            mat_nonzero += 1;
+            restitution += c.shape_f(shape_b, SP_RESTITUTION);
+            body_b = c.T.shape_body[shape_b];
+        }
+        if (mat_nonzero > 0) restitution /= float(mat_nonzero);
+        if (body_a != body_b) {
+            float m_inv_a = 0.0f, m_inv_b = 0.0f;
+            mat33 I_inv_a, I_inv_b;
+            xform X_a_prev, X_b_prev;
+            vec3 com_a(0.0f), com_b(0.0f);
+            auto prev_q = [&](int b) { return c.lxf(c.L.xi, 0, nb, b); };
+            auto prev_qd = [&](int b) { return spatial(c.lv3(c.L.xi, 7, nb, b), c.lv3(c.L.xi, 10, nb, b)); };
+            if (body_a >= 0) {
+                X_a_prev = prev_q(body_a);
+                m_inv_a = c.inv_mass(body_a);
+                I_inv_a = c.inv_inertia(body_a);
+                com_a = c.com(body_a);
+            }
+            if (body_b >= 0) {
+                X_b_prev = prev_q(body_b);
+                m_inv_b = c.inv_mass(body_b);
+                I_inv_b = c.inv_inertia(body_b);
+                com_b = c.com(body_b);
+            }
+            vec3 bx_a = xform_point(X_a_prev, c.gv3(D, CD_POINT0, ncs, slot) + c.gv3(D, CD_OFFSET0, ncs, slot));
+            vec3 bx_b = xform_point(X_b_prev, c.gv3(D, CD_POINT1, ncs, slot) + c.gv3(D, CD_OFFSET1, ncs, slot));
+            vec3 n = c.gv3(D, CD_NORMAL, ncs, slot);
+            float d = dot(n, bx_b - bx_a);
+            if (d < 0.0f) {
+                vec3 r_a = bx_a - xform_point(X_a_prev, com_a);
+                vec3 r_b = bx_b - xform_point(X_b_prev, com_b);
+                vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
+                vec3 rxn_a(0.0f), rxn_b(0.0f), v_a(0.0f), v_b(0.0f), v_a_new(0.0f), v_b_new(0.0f);
+                float inv_mass = 0.0f;
+                if (body_a >= 0) {
+                    v_a = velocity_at_point(prev_qd(body_a), r_a) + gravity * dt;
+                    v_a_new = velocity_at_point(spatial(c.body_v(body_a), c.body_w(body_a)), r_a);
+                    rxn_a = quat_rotate_inv(X_a_prev.q, cross(r_a, n));
+                    inv_mass += m_inv_a + dot(rxn_a, I_inv_a * rxn_a);
+                }
+                if (body_b >= 0) {
+                    v_b = velocity_at_point(prev_qd(body_b), r_b) + gravity * dt;
+                    v_b_new = velocity_at_point(spatial(c.body_v(body_b), c.body_w(body_b)), r_b);
+                    rxn_b = quat_rotate_inv(X_b_prev.q, cross(r_b, n));
+                    inv_mass += m_inv_b + dot(rxn_b, I_inv_b * rxn_b);
+                }
+                float rel_vel_old = dot(n, v_b - v_a);
+                float rel_vel_new = dot(n, v_b_new - v_a_new);
+                if (inv_mass != 0.0f && rel_vel_old < 0.0f) {
+                    float dv = (-rel_vel_new - restitution * rel_vel_old) / inv_mass;
+                    if (body_a >= 0) {
+                        float dv_a = -dv;
+                        lin_a = n * m_inv_a * dv_a;
+                        ang_a = quat_rotate(X_a_prev.q, I_inv_a * rxn_a * dv_a);
+                        has_a = 1.0f;
+                    }
+                    if (body_b >= 0) {
+                        lin_b = n * m_inv_b * dv;
+                        ang_b = quat_rotate(X_b_prev.q, I_inv_b * rxn_b * dv);
+                        has_b = 1.0f;
+                    }
+                    a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
+                }
+            }
+        }
+    }
+    c.st_lv3(c.L.cw, 0, ncs, slot, lin_a);
+    c.st_lv3(c.L.cw, 3, ncs, slot, ang_a);
+    c.st_lv3(c.L.cw, 6, ncs, slot, lin_b);
+    c.st_lv3(c.L.cw, 9, ncs, slot, ang_b);
+    c.l(c.L.cw, 12, ncs, slot) = has_a;
+    c.l(c.L.cw, 13, ncs, slot) = has_b;
+    c.l(c.L.cw, 14, ncs, slot) = a_is_pair_a;
+}
+// apply_body_delta_velocities (xpbd/kernels.py:936-942): body lane sums its contacts' velocity deltas in contact order
+template <int EPB>
+NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp, ncs = m.np * cpp, nb = m.nb;
+    vec3 dv, dw;
+    for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+        int code = c.T.body_pair_list[i];
+        int p = code >> 1, side = code & 1;
+        for (int k = 0; k < cpp; ++k) {
+            int slot = p * cpp + k;
+            bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
+            if (c.l(c.L.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                dv += c.lv3(c.L.cw, is_a ? 0 : 6, ncs, slot);
+                dw += c.lv3(c.L.cw, is_a ? 3 : 9, ncs, slot);
+            }
+        }
+    }
+    c.st_lv3(c.L.bqd, 0, nb, b, c.body_v(b) + dv);
+    c.st_lv3(c.L.bqd, 3, nb, b, c.body_w(b) + dw);
+}
+
 template <int EPB>
 NT_DI void phase_joints(const Ctx<EPB>& c) {
     if (!c.valid) return;
@@ -1312,6 +1434,9 @@ template <int EPB>
 NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
     const int skip = c.a.debug_skip;
+    const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
+    if (restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
+        for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * EPB + c.e] = c.lds[(c.L.bq + r) * EPB + c.e];
     if (!(skip & 2)) {
         phase_joint_forces(c, forces_are_zero);
         __syncthreads();
@@ -1337,6 +1462,15 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             __syncthreads();
             NT_TICK(8);
         }
+    }
+    if (restitution) {  // solver_xpbd.py:784-858
+        if (c.valid)
+            for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) restitution_item(c, s);
+        __syncthreads();
+        if (c.valid)
+            for (int b = c.slot; b < m.nb; b += c.nslot)
+                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item(c, b);
+        __syncthreads();
     }
 }
 
@@ -1884,7 +2018,6 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
 nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_in, nt_state* s_out, const nt_control* ctrl,
                        const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
     if (!model_ok(m) || !p || !s_in || !s_out || !ctrl) return NT_ERR_INVALID_ARG;
-    if (p->enable_restitution) return NT_ERR_UNSUPPORTED;
     KArgs a = {};
     a.m = *m;
     a.s_in = *s_in;
@@ -1903,7 +2036,6 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
 nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, nt_state* s0, nt_state* s1,
                           const nt_control* ctrl, nt_contacts* c, float dt, int32_t substeps, void* stream) {
     if (!model_ok(m) || !p || !s0 || !s1 || !ctrl || !c || substeps < 1) return NT_ERR_INVALID_ARG;
-    if (p->enable_restitution) return NT_ERR_UNSUPPORTED;
     KArgs a = {};
     a.m = *m;
     a.s_in = *s0;

@@ -325,7 +325,8 @@ class DeviceModel:
         shape_all = np.concatenate([
             m.shape_transform, m.shape_scale, m.shape_margin[:, None], m.shape_gap[:, None], m.shape_material_mu[:, None],
             m.shape_material_mu_torsional[:, None], m.shape_material_mu_rolling[:, None], m.shape_material_ke[:, None],
-            m.shape_material_kd[:, None], m.shape_material_kf[:, None], m.shape_material_ka[:, None]], axis=1)
+            m.shape_material_kd[:, None], m.shape_material_kf[:, None], m.shape_material_ka[:, None],
+            m.shape_material_restitution[:, None]], axis=1)
         new = {
             "body_param": soa(body, nb), "gravity": grav, "joint_param": soa(joint, nj), "dof_param": soa(dof, nd),
             "shape_param": soa(shape_all[:E * ns], ns),

@@ -20,8 +20,6 @@ class SolverXPBD(SolverBase):
                  angular_damping: float = 0.0, enable_restitution: bool = False, deterministic=None,
                  envs_per_block: int = 0):
         super().__init__(model)
-        if enable_restitution:
-            raise NotImplementedError("enable_restitution is not implemented yet (SURVEY.md section 8, row a12)")
         self.iterations = iterations
         self.soft_body_relaxation = soft_body_relaxation
         self.soft_contact_relaxation = soft_contact_relaxation

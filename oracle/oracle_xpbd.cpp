@@ -752,10 +752,99 @@ static void solve_body_contact_positions(const o_model* m, const o_contacts* ct,
 }
 
 // ---------------------------------------------------------------- solver_xpbd.py:329-862 (rigid-only model)
+// apply_rigid_restitution (xpbd/kernels.py:2583-2728): velocity-level restitution impulses from the pre-step state
+static void apply_rigid_restitution(const o_model* m, const o_contacts* ct, const float* body_q, const float* body_qd,
+                                    const float* body_q_prev, const float* body_qd_prev, float dt, float* deltas) {
+    (void)body_q;
+    int count = ct->rigid_contact_count[0];
+    for (int tid = 0; tid < ct->rigid_contact_max; ++tid) {
+        if (tid >= count) break;
+        int shape_a = ct->shape0[tid], shape_b = ct->shape1[tid];
+        if (shape_a == shape_b) continue;
+        int body_a = -1, body_b = -1, mat_nonzero = 0;
+        float restitution = 0.0f;
+        if (shape_a >= 0) {
+            mat_nonzero += 1;
+            restitution += m->shape_material_restitution[shape_a];
+            body_a = m->shape_body[shape_a];
+        }
+        if (shape_b >= 0) {
+            mat_nonzero += 1;
+            restitution += m->shape_material_restitution[shape_b];
+            body_b = m->shape_body[shape_b];
+        }
+        if (mat_nonzero > 0) restitution /= float(mat_nonzero);
+        if (body_a == body_b) continue;
+        float m_inv_a = 0.0f, m_inv_b = 0.0f;
+        mat33 I_inv_a, I_inv_b;
+        transform X_wb_a_prev = transform_identity(), X_wb_b_prev = transform_identity();
+        vec3 com_a(0.0f), com_b(0.0f), v_a(0.0f), v_b(0.0f), v_a_new(0.0f), v_b_new(0.0f);
+        float inv_mass = 0.0f;
+        if (body_a >= 0) {
+            X_wb_a_prev = ldx(body_q_prev, body_a);
+            m_inv_a = m->body_inv_mass[body_a];
+            I_inv_a = ldm(m->body_inv_inertia, body_a);
+            com_a = ld3(m->body_com, body_a);
+        }
+        if (body_b >= 0) {
+            X_wb_b_prev = ldx(body_q_prev, body_b);
+            m_inv_b = m->body_inv_mass[body_b];
+            I_inv_b = ldm(m->body_inv_inertia, body_b);
+            com_b = ld3(m->body_com, body_b);
+        }
+        // contact_surface_point (sim/contacts.py:97-115)
+        vec3 bx_a = transform_point(X_wb_a_prev, ld3(ct->point0, tid) + ld3(ct->offset0, tid));
+        vec3 bx_b = transform_point(X_wb_b_prev, ld3(ct->point1, tid) + ld3(ct->offset1, tid));
+        vec3 n = ld3(ct->normal, tid);
+        float d = dot(n, bx_b - bx_a);
+        if (d >= 0.0f) continue;
+        vec3 r_a = bx_a - transform_point(X_wb_a_prev, com_a);
+        vec3 r_b = bx_b - transform_point(X_wb_b_prev, com_b);
+        vec3 rxn_a(0.0f), rxn_b(0.0f);
+        if (body_a >= 0) {
+            int w = m->body_world[body_a];
+            if (w < 0) w += m->world_count + 1;
+            v_a = velocity_at_point(lds(body_qd_prev, body_a), r_a) + ld3(m->gravity, w) * dt;
+            v_a_new = velocity_at_point(lds(body_qd, body_a), r_a);
+            rxn_a = quat_rotate_inv(X_wb_a_prev.q, cross(r_a, n));
+            inv_mass += m_inv_a + dot(rxn_a, I_inv_a * rxn_a);
+        }
+        if (body_b >= 0) {
+            int w = m->body_world[body_b];
+            if (w < 0) w += m->world_count + 1;
+            v_b = velocity_at_point(lds(body_qd_prev, body_b), r_b) + ld3(m->gravity, w) * dt;
+            v_b_new = velocity_at_point(lds(body_qd, body_b), r_b);
+            rxn_b = quat_rotate_inv(X_wb_b_prev.q, cross(r_b, n));
+            inv_mass += m_inv_b + dot(rxn_b, I_inv_b * rxn_b);
+        }
+        if (inv_mass == 0.0f) continue;
+        float rel_vel_old = dot(n, v_b - v_a);
+        float rel_vel_new = dot(n, v_b_new - v_a_new);
+        if (rel_vel_old >= 0.0f) continue;
+        float dv = (-rel_vel_new - restitution * rel_vel_old) / inv_mass;
+        if (body_a >= 0) {
+            float dv_a = -dv;
+            vec3 dq = quat_rotate(X_wb_a_prev.q, I_inv_a * rxn_a * dv_a);
+            adds(deltas, body_a, spatial(n * m_inv_a * dv_a, dq));
+        }
+        if (body_b >= 0) {
+            float dv_b = dv;
+            vec3 dq = quat_rotate(X_wb_b_prev.q, I_inv_b * rxn_b * dv_b);
+            adds(deltas, body_b, spatial(n * m_inv_b * dv_b, dq));
+        }
+    }
+}
+
 extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s_in, o_state* s_out, const o_control* c,
                             const o_contacts* contacts, float dt) {
     const int B = m->body_count;
     if (B == 0) return;
+    // body_q_init / body_qd_init (solver_xpbd.py:414-416)
+    std::vector<float> body_q_init, body_qd_init;
+    if (p->enable_restitution) {
+        body_q_init.assign(s_in->body_q, s_in->body_q + 7 * B);
+        body_qd_init.assign(s_in->body_qd, s_in->body_qd + 6 * B);
+    }
     std::vector<float> body_deltas(6 * B, 0.0f);
     std::vector<float> inv_weight;
     if (contacts && p->rigid_contact_con_weighting) inv_weight.assign(B, 0.0f);
@@ -806,6 +895,14 @@ extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s
     if (body_q != s_out->body_q) {
         std::memcpy(s_out->body_q, body_q, sizeof(float) * 7 * B);
         std::memcpy(s_out->body_qd, body_qd, sizeof(float) * 6 * B);
+    }
+
+    // restitution (solver_xpbd.py:784-858): uses the effective (kinematic -> 0) inverse mass / inertia of the model
+    if (p->enable_restitution && contacts) {
+        std::fill(body_deltas.begin(), body_deltas.end(), 0.0f);
+        apply_rigid_restitution(m, contacts, s_out->body_q, s_out->body_qd, body_q_init.data(), body_qd_init.data(), dt,
+                                body_deltas.data());
+        for (int tid = 0; tid < B; ++tid) adds(s_out->body_qd, tid, lds(body_deltas.data(), tid));  // apply_body_delta_velocities
     }
 
     // copy_kinematic_body_state (kernels.py:19-32)

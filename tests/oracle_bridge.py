@@ -243,7 +243,8 @@ class Oracle:
         p = o_xpbd_params(params.get("iterations", 2), params.get("joint_linear_relaxation", 0.7),
                           params.get("joint_angular_relaxation", 0.4), params.get("joint_linear_compliance", 0.0),
                           params.get("joint_angular_compliance", 0.0), params.get("rigid_contact_relaxation", 0.8),
-                          int(params.get("rigid_contact_con_weighting", True)), params.get("angular_damping", 0.0), 0)
+                          int(params.get("rigid_contact_con_weighting", True)), params.get("angular_damping", 0.0),
+                          int(params.get("enable_restitution", False)))
         si, so = s_in.struct, s_out.struct
         self.L.o_xpbd_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
                            C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))

@@ -176,3 +176,80 @@ def test_product_path_has_no_cpu_fallback():
         nt.solvers.SolverXPBD(model)
     with pytest.raises(NewtonHipError):
         nt.CollisionPipeline(model)
+
+
+def _bounce_scene(world_count, device=None, e=0.8):
+    import newton_amd as nt
+
+    cfg = nt.ModelBuilder.ShapeConfig(mu=0.3, restitution=e, margin=0.001, gap=0.02)
+    env = nt.ModelBuilder()
+    b = env.add_body(xform=[0.0, 0.0, 0.06, 0.0, 0.0, 0.0, 1.0])
+    env.add_shape_sphere(b, radius=0.05, cfg=cfg)
+    b = env.add_body(xform=[0.3, 0.0, 0.11, 0.1, 0.05, 0.0, 0.99373])
+    env.add_shape_box(b, hx=0.1, hy=0.08, hz=0.1, cfg=cfg)
+    b = env.add_body(xform=[0.02, 0.01, 0.20, 0.0, 0.0, 0.0, 1.0])
+    env.add_shape_sphere(b, radius=0.07, cfg=cfg)
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    scene.add_ground_plane(cfg=cfg)
+    return scene.finalize(device=device)
+
+
+def test_restitution_single_steps_match_oracle():
+    """enable_restitution=True (apply_rigid_restitution, xpbd/kernels.py:2583-2728): approaching bodies in contact,
+    20 consecutive steps compared step by step from the oracle's state."""
+    from oracle_bridge import OracleState
+
+    nt, model, o = _setup(_bounce_scene, 9)
+    rng = np.random.default_rng(3)
+    model.body_qd[:, 2] = -1.0 + rng.normal(0, 0.1, size=model.body_count).astype(np.float32)
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=2, enable_restitution=True)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc, c = o.contacts(), o.control()
+    bounced = False
+    for _ in range(20):
+        s0.body_q, s0.body_qd = os0.body_q, os0.body_qd
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, None, contacts, 2e-3)
+        o.collide(os0.body_q, oc)
+        o.xpbd_step(os0, os1, c, oc, 2e-3, iterations=2, enable_restitution=True)
+        assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+        assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 2e-4
+        bounced = bounced or bool(np.any(os1.body_qd[:, 2] > 0.3))
+        os0, os1 = os1, os0
+    assert bounced  # the restitution impulse really fired
+
+
+def test_restitution_rebound_height():
+    """test_physics_verification.py:612-690 through the fused rollout: rebound height = e^2 * drop height within 1 %."""
+    import newton_amd as nt
+
+    g, h_drop, radius = -10.0, 1.0, 0.05
+    got = {}
+    for e in (0.5, 0.8):
+        cfg = nt.ModelBuilder.ShapeConfig(mu=0.0, restitution=e, ke=1e4, kd=100.0, kf=0.0, margin=0.001, gap=0.0)
+        env = nt.ModelBuilder(up_axis=1, gravity=g)
+        b = env.add_body(xform=[0.0, radius + h_drop, 0.0, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_sphere(b, radius=radius, cfg=cfg)
+        scene = nt.ModelBuilder(up_axis=1, gravity=g)
+        scene.replicate(env, 64)
+        scene.add_ground_plane(cfg=cfg)
+        model = scene.finalize(device="cuda:0")
+        pipe = nt.CollisionPipeline(model)
+        contacts = pipe.contacts()
+        solver = nt.solvers.SolverXPBD(model, enable_restitution=True)
+        s0, s1 = model.state(), model.state()
+        n = int(3.0 * np.sqrt(2.0 * h_drop / abs(g)) / 1e-3)
+        ys = []
+        for _ in range(n // 2):
+            res = solver.rollout(s0, s1, None, contacts, 1e-3, 2)
+            ys.append(float(res.body_q[0, 1]))
+        y = np.array(ys)
+        assert y.min() > -0.01
+        impact = next(i for i in range(1, len(y) - 1) if y[i] < y[i - 1] and y[i] <= y[i + 1])
+        got[e] = np.max(y[impact:]) - radius
+        assert abs(got[e] - e * e * h_drop) < 0.012 * e * e * h_drop
+    assert abs(got[0.8] / got[0.5] - 2.56) < 0.02 * 2.56

@@ -135,3 +135,35 @@ def test_pendulum_example_final_state():
         q, qd = s0.body_q[b], s0.body_qd[b]
         assert abs(q[0]) < 1e-5 and abs(q[1]) < 1.0 and 0.0 < q[2] < 5.0
         assert abs(qd[0]) < 1e-4 and abs(qd[1]) < 10.0 and abs(qd[2]) < 5.0 and abs(qd[3]) < 10.0 and abs(qd[4]) < 10.0
+
+
+def test_restitution_rebound_height():
+    """test_physics_verification.py:612-690 (SolverXPBD(enable_restitution=True)): a sphere dropped from 1 m rebounds to
+    e^2 m within 1 %, and the two restitution values keep the 2.56 ratio."""
+    import newton_amd as nt
+
+    g, h_drop, radius = -10.0, 1.0, 0.05
+    got = {}
+    for e in (0.5, 0.8):
+        cfg = nt.ModelBuilder.ShapeConfig(mu=0.0, restitution=e, ke=1e4, kd=100.0, kf=0.0, margin=0.001, gap=0.0)
+        b = nt.ModelBuilder(up_axis=1, gravity=g)
+        body = b.add_body(xform=[0.0, radius + h_drop, 0.0, 0.0, 0.0, 0.0, 1.0])
+        b.add_shape_sphere(body, radius=radius, cfg=cfg)
+        b.add_ground_plane(cfg=cfg)
+        m = b.finalize()
+        o = Oracle(m)
+        ct, c = o.contacts(), o.control()
+        s0, s1 = OracleState(m), OracleState(m)
+        ys = []
+        for _ in range(int(3.0 * np.sqrt(2.0 * h_drop / abs(g)) / 1e-3)):
+            s0.body_f[:] = 0
+            o.collide(s0.body_q, ct)
+            o.xpbd_step(s0, s1, c, ct, 1e-3, enable_restitution=True)
+            s0, s1 = s1, s0
+            ys.append(float(s0.body_q[0, 1]))
+        y = np.array(ys)
+        assert y.min() > -0.01
+        impact = next(i for i in range(1, len(y) - 1) if y[i] < y[i - 1] and y[i] <= y[i + 1])
+        got[e] = np.max(y[impact:]) - radius
+        assert abs(got[e] - e * e * h_drop) < 0.01 * e * e * h_drop
+    assert abs(got[0.8] / got[0.5] - 2.56) < 0.01 * 2.56
