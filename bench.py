@@ -109,20 +109,11 @@ def main():
     pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block)
     contacts = pipe.contacts()
     if args.workload == "quadruped_featherstone":
-        # C3: the reference loop itself (clear_forces; collide; SolverFeatherstone.step; swap), 3 launches per substep
+        # C3: clear_forces; collide; SolverFeatherstone.step; swap
         fs = nt.solvers.SolverFeatherstone(model, envs_per_block=args.envs_per_block)
         workload_name = workload_name.replace("SolverXPBD", "SolverFeatherstone")
 
-        class _Loop:
-            def rollout(self, a, b, ctrl_, contacts_, dt, n):
-                for _ in range(n):
-                    a.clear_forces()
-                    pipe.collide(a, contacts_)
-                    fs.step(a, b, ctrl_, contacts_, dt)
-                    a, b = b, a
-                return a
-
-        solver = _Loop()
+        solver = fs  # SolverFeatherstone.rollout: the same loop fused into one launch
     else:
         solver = nt.solvers.SolverXPBD(model, iterations=iterations, envs_per_block=args.envs_per_block)
 

@@ -176,6 +176,10 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
 nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* p, nt_state* s_in, nt_state* s_out,
                                const nt_control* ctrl, const nt_contacts* c /*nullable*/, float dt,
                                int32_t envs_per_block, void* stream);
+/* substeps x {clear_forces; collide; featherstone step; swap} in one launch (result in s0 for even substeps, s1 for odd) */
+nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_params* p, const nt_collide_params* cp,
+                                  nt_state* s0, nt_state* s1, const nt_control* ctrl, nt_contacts* c, float dt,
+                                  int32_t substeps, void* stream);
 /* substeps x {clear_forces; collide; xpbd step; swap}: the result is in s0 when substeps is even, s1 when odd,
  * exactly like the reference loop's pointer swap. */
 nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, nt_state* s0,
@@ -184,6 +188,9 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
 /* -------- boundary helpers -------- */
 nt_status nt_eval_fk(const nt_model* m, const float* joint_q /*[nc][ES]*/, const float* joint_qd /*[nd][ES]*/,
                      nt_state* out, void* stream);
+/* RL-style reset (newton/_src/solvers/solver.py:344-375, core/reset.py:13-60): for every env whose world_mask byte is
+ * non-zero, overwrite all of dst's state arrays with src's (e.g. a default state).  world_mask: [env_count] uint8. */
+nt_status nt_state_reset(const nt_model* m, nt_state* dst, const nt_state* src, const uint8_t* world_mask, void* stream);
 /* AoS [E*nslot][ncomp] (Newton flat array) <-> SoA [ncomp][nslot][ES] */
 nt_status nt_pack_aos(const float* aos, float* soa, int32_t ncomp, int32_t nslot, int32_t env_count, int32_t env_stride,
                       void* stream);

@@ -91,10 +91,14 @@ SYMBOLS = {
     "nt_featherstone_step": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_featherstone_params), C.POINTER(nt_state),
                                           C.POINTER(nt_state), C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float,
                                           C.c_int32, _P]),
+    "nt_featherstone_rollout": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_featherstone_params), C.POINTER(nt_collide_params),
+                                             C.POINTER(nt_state), C.POINTER(nt_state), C.POINTER(nt_control),
+                                             C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),
     "nt_featherstone_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
     "nt_xpbd_rollout": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_xpbd_params), C.POINTER(nt_collide_params),
                                      C.POINTER(nt_state), C.POINTER(nt_state), C.POINTER(nt_control),
                                      C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),
+    "nt_state_reset": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_state), _P, _P]),
     "nt_eval_fk": (C.c_int32, [C.POINTER(nt_model), _P, _P, C.POINTER(nt_state), _P]),
     "nt_pack_aos": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "nt_unpack_aos": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -18,6 +18,7 @@
 
 struct FsLayout {
     int jq, qdi, qdo, jfi, tau, qdd;  // joint_q [nc], internal qd in / out [nd], joint_f internal, tau, qdd [nd]
+    int qdp;                          // public joint_qd [nd] (stays in LDS across the substeps of a rollout)
     int qcom, org;                    // body COM world position [3][nb], solve origin [3][nb]
     int S;                            // motion subspace columns [6][nd]
     int Is;                           // spatial inertia in the solve frame [36][nb]
@@ -36,6 +37,7 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
     F.jfi = o; o += m.nd;
     F.tau = o; o += m.nd;
     F.qdd = o; o += m.nd;
+    F.qdp = o; o += m.nd;
     F.qcom = o; o += 3 * m.nb;
     F.org = o; o += 3 * m.nb;
     F.S = o; o += 6 * m.nd;
@@ -170,12 +172,12 @@ NT_DI vec3 fs_free_com_offset(const FsCtx<EPB>& f, int j) {
 
 // convert_free_distance_joint_qd_public_to_internal + joint_f_public_to_internal (kernels.py:924-975,1069-1088)
 template <int EPB>
-NT_DI void fs_to_internal_item(const FsCtx<EPB>& f, int j, const float* joint_qd_public) {
+NT_DI void fs_to_internal_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int qs = c.T.joint_qd_start[j], type = c.T.joint_type[j];
     const int qe = j + 1 < m.nj ? c.T.joint_qd_start[j + 1] : m.nd;
-    auto pub = [&](int i) { return joint_qd_public[(size_t)i * c.ES + c.env]; };
+    auto pub = [&](int i) { return f.f(f.F.qdp, i); };
     if (type != JT_FREE && type != JT_DISTANCE) {
         for (int i = qs; i < qe; ++i) {
             f.f(f.F.qdi, i) = pub(i);
@@ -366,12 +368,12 @@ NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
 
 // body_f_ext = state_in.body_f + FREE/DISTANCE joint_f (kernels.py:893-921) + contact wrenches in contact order
 template <int EPB>
-NT_DI void fs_body_force_item(const FsCtx<EPB>& f, int b) {
+NT_DI void fs_body_force_item(const FsCtx<EPB>& f, int b, bool forces_are_zero) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int nb = m.nb;
     vec3 f0, t0;
-    if (c.a.s_in.body_f) {
+    if (!forces_are_zero && c.a.s_in.body_f) {
         f0 = c.gv3(c.a.s_in.body_f, 0, nb, b);
         t0 = c.gv3(c.a.s_in.body_f, 3, nb, b);
     }
@@ -685,12 +687,12 @@ NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
 
 // convert_free_distance_joint_qd_internal_to_public (kernels.py:1015-1066) straight into state_out.joint_qd
 template <int EPB>
-NT_DI void fs_to_public_item(const FsCtx<EPB>& f, int j, float* joint_qd_public) {
+NT_DI void fs_to_public_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int qs = c.T.joint_qd_start[j], type = c.T.joint_type[j];
     const int qe = j + 1 < m.nj ? c.T.joint_qd_start[j + 1] : m.nd;
-    auto out = [&](int i) -> float& { return joint_qd_public[(size_t)i * c.ES + c.env]; };
+    auto out = [&](int i) -> float& { return f.f(f.F.qdp, i); };
     if (type != JT_FREE && type != JT_DISTANCE) {
         for (int i = qs; i < qe; ++i) out(i) = f.f(f.F.qdo, i);
         return;
@@ -703,17 +705,11 @@ NT_DI void fs_to_public_item(const FsCtx<EPB>& f, int j, float* joint_qd_public)
     out(qs + 3) = omega.x; out(qs + 4) = omega.y; out(qs + 5) = omega.z;
 }
 
-// One SolverFeatherstone.step for EPB environments.
+// block-shared tree tables (joint ancestor / depth / articulation, joint of each dof, root-path bit masks)
 template <int EPB>
-__global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    const nt_model& m = a.m;
-    const int nj = m.nj, nb = m.nb;
-    const FsLayout F = make_fs_layout(m, make_layout(m));
-    Ctx<EPB> c(a, lds, F.rows);  // topology ints are staged behind the Featherstone rows
-    // block-shared tree tables behind the per-env rows and the staged topology
-    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
-    __syncthreads();
+NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
+    const nt_model& m = c.a.m;
+    const int nj = m.nj;
     for (int j = threadIdx.x; j < nj; j += blockDim.x) {
         int p = c.T.joint_parent[j], anc = -1;
         if (p >= 0)
@@ -746,15 +742,16 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
         extra[3 * nj + d] = j;
     }
     __syncthreads();
-    FsCtx<EPB> f(c, extra);
-    int max_depth = 0;
-    for (int j = 0; j < nj; ++j) max_depth = imax(max_depth, f.depth[j]);
+}
 
+// One SolverFeatherstone.step on the state resident in LDS (joint_q in F.jq, public joint_qd in F.qdp).
+template <int EPB>
+NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F, int max_depth, bool forces_are_zero,
+                      bool publish_fk) {
+    const KArgs& a = c.a;
+    const nt_model& m = a.m;
+    const int nj = m.nj, nb = m.nb;
     const int skip = a.debug_skip;  // timing ablation only (NT_DEBUG_SKIP): results are meaningless when set
-    load_params(c, true);
-    if (c.valid) stage_rows(c, F.jq, a.s_in.joint_q, m.nc);
-    __syncthreads();
-
     // eval_rigid_fk, level by level (a joint's parent body is final one level earlier)
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid && !(skip & 1))
@@ -763,9 +760,9 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
         __syncthreads();
     }
     // state_in.body_q is refreshed by the reference step (solver_featherstone.py:492-514): publish it when distinct
-    if (c.valid && a.s_in.body_q != a.s_out.body_q) unstage_rows(c, c.L.bq, a.s_in.body_q, 7 * nb);
+    if (publish_fk && c.valid && a.s_in.body_q != a.s_out.body_q) unstage_rows(c, c.L.bq, a.s_in.body_q, 7 * nb);
     if (c.valid)
-        for (int j = c.slot; j < nj; j += c.nslot) fs_to_internal_item(f, j, a.s_in.joint_qd);
+        for (int j = c.slot; j < nj; j += c.nslot) fs_to_internal_item(f, j);
     __syncthreads();
     // eval_rigid_id
     if (c.valid && !(skip & 2))
@@ -786,7 +783,7 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
         __syncthreads();
     }
     if (c.valid)
-        for (int b = c.slot; b < nb; b += c.nslot) fs_body_force_item(f, b);
+        for (int b = c.slot; b < nb; b += c.nslot) fs_body_force_item(f, b, forces_are_zero);
     __syncthreads();
     // eval_rigid_tau, deepest level first
     for (int lvl = max_depth; lvl >= 0; --lvl) {
@@ -820,11 +817,78 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
                 if (f.depth[j] == lvl) fs_fk_vel_item<EPB, false>(f, j);
         __syncthreads();
     }
+    if (c.valid)
+        for (int j = c.slot; j < nj; j += c.nslot) fs_to_public_item(f, j);
+    __syncthreads();
+}
+
+template <int EPB>
+__global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const nt_model& m = a.m;
+    const FsLayout F = make_fs_layout(m, make_layout(m));
+    Ctx<EPB> c(a, lds, F.rows);  // topology ints are staged behind the Featherstone rows
+    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
+    __syncthreads();
+    fs_build_tables(c, extra);
+    FsCtx<EPB> f(c, extra);
+    int max_depth = 0;
+    for (int j = 0; j < m.nj; ++j) max_depth = imax(max_depth, f.depth[j]);
+    load_params(c, true);
     if (c.valid) {
-        for (int j = c.slot; j < nj; j += c.nslot) fs_to_public_item(f, j, a.s_out.joint_qd);
+        stage_rows(c, F.jq, a.s_in.joint_q, m.nc);
+        stage_rows(c, F.qdp, a.s_in.joint_qd, m.nd);
+    }
+    __syncthreads();
+    fs_substep(c, f, F, max_depth, false, true);
+    if (c.valid) {
         unstage_rows(c, F.jq, a.s_out.joint_q, m.nc);
+        unstage_rows(c, F.qdp, a.s_out.joint_qd, m.nd);
     }
     store_state(c, a.s_out);
+}
+
+// substeps x { clear_forces; CollisionPipeline.collide; SolverFeatherstone.step; swap } in one launch: generalized and
+// maximal state, parameters and all Featherstone intermediates stay in LDS; only the contacts touch HBM per substep.
+// The result lands in s_in (= s0) for an even number of substeps and in s_out (= s1) for an odd one.
+template <int EPB, bool CVX>
+__global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const nt_model& m = a.m;
+    const FsLayout F = make_fs_layout(m, make_layout(m));
+    Ctx<EPB> c(a, lds, F.rows);
+    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
+    __syncthreads();
+    fs_build_tables(c, extra);
+    FsCtx<EPB> f(c, extra);
+    int max_depth = 0;
+    for (int j = 0; j < m.nj; ++j) max_depth = imax(max_depth, f.depth[j]);
+    load_state(c, a.s_in);
+    load_params(c, true);
+    if (c.valid) {
+        stage_rows(c, F.jq, a.s_in.joint_q, m.nc);
+        stage_rows(c, F.qdp, a.s_in.joint_qd, m.nd);
+        for (int r = c.slot; r < 6 * m.nb; r += c.nslot) {
+            a.s_in.body_f[(size_t)r * c.ES + c.env] = 0.0f;
+            a.s_out.body_f[(size_t)r * c.ES + c.env] = 0.0f;
+        }
+    }
+    __syncthreads();
+    // the collide phases use the (dead at that point) P / H / contact-wrench union as their scratch
+    Ctx<EPB> cc = c;
+    cc.L.sx = F.cw;
+    cc.L.sa = F.cw + 7 * m.ns;
+    cc.L.pc = F.cw + 13 * m.ns;
+    for (int s = 0; s < a.substeps; ++s) {
+        do_collide<EPB, CVX>(cc, s == a.substeps - 1);
+        fs_substep(c, f, F, max_depth, true, false);
+    }
+    const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
+    if (c.valid) {
+        unstage_rows(c, F.jq, res.joint_q, m.nc);
+        unstage_rows(c, F.qdp, res.joint_qd, m.nd);
+    }
+    store_state(c, res);
 }
 
 // newton.eval_fk(model, joint_q, joint_qd, state) (newton/_src/sim/articulation.py:423-573): body_q / body_qd from

@@ -1790,6 +1790,16 @@ __global__ void calibration_copy_kernel(const float* __restrict__ src, float* __
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// masked env-column copy: dst[row][env] = src[row][env] for every env whose mask byte is non-zero (RL-style world reset)
+__global__ void masked_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, const uint8_t* __restrict__ mask,
+                                   int rows, int E, int ES) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)rows * ES;
+    if (i >= n) return;
+    int env = i % ES;
+    if (env < E && mask[env]) dst[i] = src[i];
+}
+
 // AoS [E*nslot][ncomp] <-> SoA [ncomp][nslot][ES]
 __global__ void pack_kernel(const float* __restrict__ aos, float* __restrict__ soa, int ncomp, int nslot, int E, int ES) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2070,23 +2080,8 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
     return NT_DISPATCH_EPB(semi_implicit_step_kernel, a, epb, (hipStream_t)stream);
 }
 
-nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* p, nt_state* s_in, nt_state* s_out,
-                                const nt_control* ctrl, const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
-    if (!model_ok(m) || !p || !s_in || !s_out || !ctrl) return NT_ERR_INVALID_ARG;
-    if (!s_in->joint_q || !s_in->joint_qd || !s_out->joint_q || !s_out->joint_qd || !s_in->body_q || !s_out->body_q ||
-        !s_out->body_qd)
-        return NT_ERR_INVALID_ARG;
-    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs <= 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
-    KArgs a = {};
-    a.m = *m;
-    a.s_in = *s_in;
-    a.s_out = *s_out;
-    a.c = *ctrl;
-    if (c) a.ct = *c;
-    a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
-    a.sp.friction_smoothing = p->friction_smoothing;
-    a.angular_damping = p->angular_damping;
-    a.dt = dt;
+// shared launch logic of the Featherstone kernels (step / rollout)
+static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, bool rollout, hipStream_t stream) {
     {
         const char* e = getenv("NT_DEBUG_SKIP");
         a.debug_skip = e ? atoi(e) : 0;
@@ -2115,12 +2110,57 @@ nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* 
         if (lds_bytes > 48 * 1024 &&
             hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return NT_ERR_LAUNCH;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, a);
         return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
     };
-    if (epb == 16) return go(featherstone_step_kernel<16>);
-    if (epb == 8) return go(featherstone_step_kernel<8>);
-    return go(featherstone_step_kernel<4>);
+    if (!rollout) {
+        if (epb == 16) return go(featherstone_step_kernel<16>);
+        if (epb == 8) return go(featherstone_step_kernel<8>);
+        return go(featherstone_step_kernel<4>);
+    }
+    const bool cvx = m->np_analytic < m->np;
+    if (epb == 16) return cvx ? go(featherstone_rollout_kernel<16, true>) : go(featherstone_rollout_kernel<16, false>);
+    if (epb == 8) return cvx ? go(featherstone_rollout_kernel<8, true>) : go(featherstone_rollout_kernel<8, false>);
+    return cvx ? go(featherstone_rollout_kernel<4, true>) : go(featherstone_rollout_kernel<4, false>);
+}
+
+static bool fs_state_ok(const nt_state* s) { return s && s->joint_q && s->joint_qd && s->body_q && s->body_qd; }
+
+nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* p, nt_state* s_in, nt_state* s_out,
+                                const nt_control* ctrl, const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
+    if (!model_ok(m) || !p || !ctrl || !fs_state_ok(s_in) || !fs_state_ok(s_out)) return NT_ERR_INVALID_ARG;
+    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs <= 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
+    KArgs a = {};
+    a.m = *m;
+    a.s_in = *s_in;
+    a.s_out = *s_out;
+    a.c = *ctrl;
+    if (c) a.ct = *c;
+    a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
+    a.sp.friction_smoothing = p->friction_smoothing;
+    a.angular_damping = p->angular_damping;
+    a.dt = dt;
+    return fs_launch(m, a, envs_per_block, false, (hipStream_t)stream);
+}
+
+nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_params* p, const nt_collide_params* cp, nt_state* s0,
+                                   nt_state* s1, const nt_control* ctrl, nt_contacts* c, float dt, int32_t substeps,
+                                   void* stream) {
+    if (!model_ok(m) || !p || !ctrl || !c || !fs_state_ok(s0) || !fs_state_ok(s1) || !s0->body_f || !s1->body_f || substeps <= 0)
+        return NT_ERR_INVALID_ARG;
+    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs <= 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
+    KArgs a = {};
+    a.m = *m;
+    a.s_in = *s0;
+    a.s_out = *s1;
+    a.c = *ctrl;
+    a.ct = *c;
+    a.has_contacts = m->np > 0 ? 1 : 0;
+    a.sp.friction_smoothing = p->friction_smoothing;
+    a.angular_damping = p->angular_damping;
+    a.dt = dt;
+    a.substeps = substeps;
+    return fs_launch(m, a, cp ? cp->envs_per_block : 0, true, (hipStream_t)stream);
 }
 
 int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m) {
@@ -2166,6 +2206,22 @@ int nt_debug_phase_clocks(unsigned long long* out) {
     return hipMemcpyToSymbol(HIP_SYMBOL(nt_phase_clock), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+nt_status nt_state_reset(const nt_model* m, nt_state* dst, const nt_state* src, const uint8_t* world_mask, void* stream) {
+    if (!model_ok(m) || !dst || !src || !world_mask) return NT_ERR_INVALID_ARG;
+    auto go = [&](float* d, const float* s_, int rows) {
+        if (!d || !s_ || rows <= 0) return;
+        size_t n = (size_t)rows * m->env_stride;
+        hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, s_,
+                           world_mask, rows, m->env_count, m->env_stride);
+    };
+    go(dst->body_q, src->body_q, 7 * m->nb);
+    go(dst->body_qd, src->body_qd, 6 * m->nb);
+    go(dst->body_f, src->body_f, 6 * m->nb);
+    go(dst->joint_q, src->joint_q, m->nc);
+    go(dst->joint_qd, src->joint_qd, m->nd);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
 
 nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream) {
     if (!src || !dst || n <= 0) return NT_ERR_INVALID_ARG;

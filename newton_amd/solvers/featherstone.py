@@ -62,3 +62,20 @@ class SolverFeatherstone(SolverBase):
         _lib.check(dm.lib.nt_featherstone_step(C.byref(dm.desc), C.byref(p), C.byref(d_in), C.byref(d_out), C.byref(d_c),
                                                C.byref(d_ct) if d_ct is not None else None, float(dt),
                                                self.envs_per_block, dm.stream()), "nt_featherstone_step")
+
+    def rollout(self, state_0, state_1, control, contacts, dt: float, substeps: int):
+        """substeps x {clear_forces; collide; step; swap} in ONE launch (``nt_featherstone_rollout``); returns the state
+        object holding the result (state_0 for an even number of substeps, state_1 for odd -- the reference loop's swap)."""
+        dm = self.dm
+        if control is None:
+            if not hasattr(self, "_control"):
+                self._control = self.model.control()
+            control = self._control
+        p = _lib.nt_featherstone_params(float(self.angular_damping), float(self.friction_smoothing))
+        cp = _lib.nt_collide_params(0, self.envs_per_block)
+        d0, d1, d_c, d_ct = state_0._desc(), state_1._desc(), control._desc(), contacts._desc()
+        _lib.check(dm.lib.nt_featherstone_rollout(C.byref(dm.desc), C.byref(p), C.byref(cp), C.byref(d0), C.byref(d1),
+                                                  C.byref(d_c), C.byref(d_ct), float(dt), int(substeps), dm.stream()),
+                   "nt_featherstone_rollout")
+        contacts._generation += 1
+        return state_1 if substeps % 2 else state_0

@@ -152,6 +152,38 @@ class State(_SoAContainer):
             for k in self._host:
                 self._host[k] = other._host[k].copy()
 
+    def reset(self, source: State, world_mask=None):
+        """RL-style reset: copy ``source`` (e.g. a default state) into the worlds selected by ``world_mask``
+        (bool, shape (world_count,) or the reference's (world_count + 1,) with the trailing global-entity slot;
+        None = every world).  newton/_src/solvers/solver.py:344-375, core/reset.py:13-60."""
+        t = self.model.env
+        if world_mask is None:
+            return self.assign(source)
+        if self.model.is_gpu:
+            torch = _torch()
+            dm = self.model.device_model()
+            mask = torch.as_tensor(world_mask, device=dm.device).to(torch.uint8).contiguous()
+        else:
+            mask = np.asarray(world_mask).astype(np.uint8)
+        if mask.ndim != 1 or mask.shape[0] not in (t.env_count, t.env_count + 1):
+            raise ValueError(f"'world_mask' length {mask.shape[0]} must equal model.world_count + 1 ({t.env_count + 1})")
+        mask = mask[: t.env_count]
+        if not self.model.is_gpu:
+            sel = mask.astype(bool)
+            for name, (ncomp, slots, _) in self._FIELDS.items():
+                n = getattr(t, slots)
+                if n == 0:
+                    continue
+                dst = self._host[name].reshape(t.env_count, -1)
+                dst[sel] = source._host[name].reshape(t.env_count, -1)[sel]
+            return None
+        mask = mask.contiguous()
+        d, s_ = self._desc(), source._desc()
+        _lib.check(dm.lib.nt_state_reset(C.byref(dm.desc), C.byref(d), C.byref(s_), mask.data_ptr(), dm.stream()),
+                   "nt_state_reset")
+        _torch().cuda.current_stream(dm.device).synchronize()  # `mask` may be a temporary
+        return None
+
     def _desc(self) -> _lib.nt_state:
         d = _lib.nt_state()
         d.body_q = self._soa["body_q"].data_ptr()

@@ -163,3 +163,25 @@ def test_eval_fk_device_matches_oracle():
     bq, bqd = o.eval_fk(jq, jqd)
     assert _rel(state.body_q.cpu().numpy(), bq) <= 1e-5
     assert _rel(state.body_qd.cpu().numpy(), bqd) <= 1e-5
+
+
+def test_rollout_bitwise_equals_api_loop():
+    """nt_featherstone_rollout == the per-call loop {clear_forces; collide; step; swap}, bit for bit (20 steps, contacts on)."""
+    from scenes import quadruped_scene
+
+    nt, model, _ = _setup(quadruped_scene, 21)
+    _lower_quadrupeds(nt, model, 0.21)
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverFeatherstone(model)
+    s0, s1 = model.state(), model.state()
+    for _ in range(21):
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, None, contacts, 1e-3)
+        s0, s1 = s1, s0
+    r0, r1 = model.state(), model.state()
+    res = solver.rollout(r0, r1, None, contacts, 1e-3, 21)
+    assert res is r1
+    for name in ("joint_q", "joint_qd", "body_q", "body_qd"):
+        assert np.array_equal(getattr(res, name).cpu().numpy(), getattr(s0, name).cpu().numpy()), name

@@ -253,3 +253,25 @@ def test_restitution_rebound_height():
         got[e] = np.max(y[impact:]) - radius
         assert abs(got[e] - e * e * h_drop) < 0.012 * e * e * h_drop
     assert abs(got[0.8] / got[0.5] - 2.56) < 0.02 * 2.56
+
+
+def test_state_reset_masked_device():
+    """nt_state_reset: masked env-column copy of every state array."""
+    from scenes import quadruped_scene
+
+    nt, model, _ = _setup(quadruped_scene, 70)
+    default = model.state()
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model)
+    res = solver.rollout(s0, s1, None, contacts, 1e-3, 20)
+    moved = res.body_q.cpu().numpy().reshape(70, -1).copy()
+    mask = np.zeros(71, dtype=bool)
+    mask[[0, 5, 64, 69]] = True
+    res.reset(default, world_mask=mask)
+    q = res.body_q.cpu().numpy().reshape(70, -1)
+    d = default.body_q.cpu().numpy().reshape(70, -1)
+    sel = mask[:70]
+    assert np.array_equal(q[sel], d[sel]) and np.array_equal(q[~sel], moved[~sel])
+    assert np.array_equal(res.body_qd.cpu().numpy().reshape(70, -1)[sel], default.body_qd.cpu().numpy().reshape(70, -1)[sel])

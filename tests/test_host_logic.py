@@ -102,10 +102,10 @@ def test_c_abi_exports_every_declared_symbol():
     # persistent rows 1282 (state 169 + body 299 + joint 182 + dof 198 + shape 260 + control 54 + gravity 3 + derived 117)
     # + scratch max(collide 182, forces 234, joints 273, contacts 15*52 = 780, semi-implicit 78 + 156 + 780 = 1014)
     assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1282 + 1014)
-    # Featherstone: generalized state 109 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1153,
+    # Featherstone: generalized state 127 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1171,
     # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780)
     m.nc, m.na, m.max_art_dofs = 19, 1, 18
-    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1282 + 1153 + 1728)
+    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1282 + 1171 + 1728)
 
 
 def test_no_silent_cpu_fallback():
@@ -124,3 +124,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower() or f == "_lib.py" and "oracle" not in text.lower(), (dirpath, f)
+
+
+def test_state_reset_masked_host():
+    """State.reset(source, world_mask): only the selected worlds are overwritten (host path of the RL-style reset)."""
+    model = quadruped_scene(4, seed=3)
+    default = model.state()
+    s = model.state()
+    s.body_q = s.body_q + 1.0
+    s.joint_q = s.joint_q + 2.0
+    before = s.body_q.copy()
+    s.reset(default, world_mask=[True, False, True, False, False])  # reference shape: world_count + 1
+    q = s.body_q.reshape(4, -1)
+    assert np.array_equal(q[0], default.body_q.reshape(4, -1)[0]) and np.array_equal(q[2], default.body_q.reshape(4, -1)[2])
+    assert np.array_equal(q[1], before.reshape(4, -1)[1]) and np.array_equal(q[3], before.reshape(4, -1)[3])
+    jq = s.joint_q.reshape(4, -1)
+    assert np.array_equal(jq[0], default.joint_q.reshape(4, -1)[0]) and not np.array_equal(jq[1], default.joint_q.reshape(4, -1)[1])
+    with pytest.raises(ValueError):
+        s.reset(default, world_mask=[True, False])
