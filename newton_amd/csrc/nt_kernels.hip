@@ -122,9 +122,11 @@ struct Topo {
     const int *body_flags, *joint_type, *joint_enabled, *joint_parent, *joint_child, *joint_q_start, *joint_qd_start,
         *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
         *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count;
+    const float* gshape;  // [ng][NT_SHAPE_PARAM_FLOATS] parameters of the global (world -1) shapes, block-shared copy
 };
 __host__ __device__ inline int topo_ints(const nt_model& m) {
-    return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np;
+    return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np +
+           NT_SHAPE_PARAM_FLOATS * m.ng;
 }
 
 template <int EPB>
@@ -177,6 +179,12 @@ struct Ctx {
         take(T.body_pair_list, m.body_pair_list, 2 * m.np);    // padded to 2*np entries by the host
         take(T.shape_mesh_start, m.shape_mesh_start, m.ns + m.ng);
         take(T.shape_mesh_count, m.shape_mesh_count, m.ns + m.ng);
+        {
+            float* g = reinterpret_cast<float*>(ti + o);
+            for (int i = threadIdx.x; i < NT_SHAPE_PARAM_FLOATS * m.ng; i += blockDim.x) g[i] = m.gshape_param[i];
+            T.gshape = g;
+            o += NT_SHAPE_PARAM_FLOATS * m.ng;
+        }
     }
     // LDS element: row = field offset + comp * slots_in_field + slot
     NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * EPB + e]; }
@@ -243,7 +251,7 @@ struct Ctx {
     // shape accessors: s < ns local (per-env params in LDS), otherwise the env-uniform global table
     NT_DI float shape_f(int s, int comp) const {
         if (s < a.m.ns) return l(L.sp, comp, a.m.ns, s);
-        return a.m.gshape_param[(s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp];
+        return T.gshape[(s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp];
     }
     NT_DI vec3 shape_scale(int s) const { return vec3(shape_f(s, SP_SCALE), shape_f(s, SP_SCALE + 1), shape_f(s, SP_SCALE + 2)); }
     NT_DI xform shape_local_xform(int s) const {
