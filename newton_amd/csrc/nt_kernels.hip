@@ -1395,9 +1395,14 @@ template <int EPB>
 NT_DI void phase_joints(const Ctx<EPB>& c) {
     if (!c.valid) return;
     const int nj = c.a.m.nj;
-    for (int i = c.slot; i < 2 * nj; i += c.nslot) {
+    // linear rows on slots [0, nj), angular rows on slots [A0, A0 + nj) with A0 rounded up to a wave boundary (a wave
+    // holds 64 / EPB slots): no wavefront then mixes the two code paths, so the phase costs max(linear, angular)
+    // instead of their sum in the wave that used to straddle the boundary
+    const int spw = 64 / EPB > 0 ? 64 / EPB : 1;
+    const int A0 = ((nj + spw - 1) / spw) * spw;
+    for (int i = c.slot; i < A0 + nj; i += c.nslot) {
         if (i < nj) joint_linear_item(c, i);
-        else joint_angular_item(c, i - nj);
+        else if (i >= A0) joint_angular_item(c, i - A0);
     }
 }
 
@@ -1768,9 +1773,11 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kerne
         for (int r = c.slot; r < 6 * m.nb; r += c.nslot) c.lds[(c.L.bf + r) * EPB + c.e] = a.s_in.body_f[(size_t)r * c.ES + c.env];
         // joints and contacts are independent force evaluations on the input state: one phase
         const int ncs = a.has_contacts ? m.np * m.cpp : 0;
-        for (int i = c.slot; i < m.nj + ncs; i += c.nslot) {
+        const int spw = 64 / EPB > 0 ? 64 / EPB : 1;  // contact items start on a wave boundary (no mixed-path wave)
+        const int C0 = ((m.nj + spw - 1) / spw) * spw;
+        for (int i = c.slot; i < C0 + ncs; i += c.nslot) {
             if (i < m.nj) si_joint_item(c, i);
-            else si_contact_item(c, i - m.nj);
+            else if (i >= C0) si_contact_item(c, i - C0);
         }
     }
     __syncthreads();
