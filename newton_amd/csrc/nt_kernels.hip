@@ -1612,7 +1612,7 @@ NT_DI void si_joint_item(const Ctx<EPB>& c, const int j) {
             vec3 w_err = w_c - w_p;
             const float ads = 0.01f;  // angular_damping_scale
             if (type == JT_FIXED) {
-                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(r_err.w) * 2.0f;
+                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(clampf(r_err.w, -1.0f, 1.0f)) * 2.0f;
                 f_total += x_err * ke_att + v_err * kd_att;
                 t_total += xform_vector(X_wp, ang_err) * ke_att + w_err * kd_att * ads;
             }
@@ -1620,7 +1620,7 @@ NT_DI void si_joint_item(const Ctx<EPB>& c, const int j) {
                 vec3 axis_p = xform_vector(X_wp, c.dof_axis(qd_start));
                 float q = dot(x_err, axis_p), qd = dot(v_err, axis_p);
                 f_total = axis_p * (-c.l(c.L.cf, 0, 1, qd_start) - si_dof_force(c, qd_start, tq_start, q, qd));
-                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(r_err.w) * 2.0f;
+                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(clampf(r_err.w, -1.0f, 1.0f)) * 2.0f;
                 f_total += (x_err - q * axis_p) * ke_att + (v_err - qd * axis_p) * kd_att;
                 t_total += xform_vector(X_wp, ang_err) * ke_att + w_err * kd_att * ads;
             }
@@ -1654,7 +1654,7 @@ NT_DI void si_joint_item(const Ctx<EPB>& c, const int j) {
                 }
                 f_total += (x_err - pos) * ke_att + (v_err - vel) * kd_att;
                 if (ang == 0) {
-                    vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(r_err.w) * 2.0f;
+                    vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * acosf(clampf(r_err.w, -1.0f, 1.0f)) * 2.0f;
                     t_total += xform_vector(X_wp, ang_err) * ke_att + w_err * kd_att * ads;
                 }
                 if (ang == 1) {
@@ -1985,9 +1985,11 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
      : (epb) == 16 ? launch(KERNEL<16, B>, args, 16, stream) : launch(KERNEL<8, B>, args, 8, stream))
 // kernels that collide are compiled twice: the convex (MPR/GJK) code only exists in the variant used by models
 // that have convex-routed pairs, so analytic-only models keep their register budget
+// the convex variants are only instantiated for 8 / 16 envs per workgroup (build time): wider tiles fall back to 16
 #define NT_DISPATCH_EPB_CVX(KERNEL, m, args, epb, stream)                                              \
-    ((m).np_analytic < (m).np ? NT_DISPATCH_EPB2(KERNEL, true, args, epb, stream)                      \
-                              : NT_DISPATCH_EPB2(KERNEL, false, args, epb, stream))
+    ((m).np_analytic < (m).np                                                                          \
+         ? ((epb) >= 16 ? launch(KERNEL<16, true>, args, 16, stream) : launch(KERNEL<8, true>, args, 8, stream)) \
+         : NT_DISPATCH_EPB2(KERNEL, false, args, epb, stream))
 
 bool model_ok(const nt_model* m) {
     return m && m->env_count > 0 && m->env_stride >= m->env_count && (m->env_stride % 64) == 0 && m->nb > 0 &&
@@ -2115,6 +2117,8 @@ static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, 
             if (fits(cands[i])) epb = cands[i];
     }
     if (!epb) return NT_ERR_UNSUPPORTED;
+    const bool cvx = m->np_analytic < m->np;
+    if (rollout && cvx && epb == 16) epb = 8;  // the convex rollout is only instantiated for 4 / 8 envs per workgroup
     int want = imax(imax(m->nb, m->nj), imax(m->np * m->cpp, imax(m->nj, m->nd) * m->max_art_dofs));
     int cap = 256 / epb;
     a.nslot = want < cap ? want : cap;
@@ -2133,10 +2137,10 @@ static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, 
         if (epb == 8) return go(featherstone_step_kernel<8>);
         return go(featherstone_step_kernel<4>);
     }
-    const bool cvx = m->np_analytic < m->np;
-    if (epb == 16) return cvx ? go(featherstone_rollout_kernel<16, true>) : go(featherstone_rollout_kernel<16, false>);
-    if (epb == 8) return cvx ? go(featherstone_rollout_kernel<8, true>) : go(featherstone_rollout_kernel<8, false>);
-    return cvx ? go(featherstone_rollout_kernel<4, true>) : go(featherstone_rollout_kernel<4, false>);
+    if (cvx) return epb == 8 ? go(featherstone_rollout_kernel<8, true>) : go(featherstone_rollout_kernel<4, true>);
+    if (epb == 16) return go(featherstone_rollout_kernel<16, false>);
+    if (epb == 8) return go(featherstone_rollout_kernel<8, false>);
+    return go(featherstone_rollout_kernel<4, false>);
 }
 
 static bool fs_state_ok(const nt_state* s) { return s && s->joint_q && s->joint_qd && s->body_q && s->body_qd; }

@@ -6,6 +6,8 @@
 //   integrate_bodies                   newton/_src/solvers/solver.py:63-170 (shared, oracle_xpbd.cpp)
 // warp builtins restated here: wp.quat_twist_angle_signed (kernels_body.py:206), wp.norm_huber
 // (kernels_contact.py:537), wp.step -- PARITY UNPINNED (see wp_builtins.h).
+// wp.acos clamps its argument to [-1, 1] (Warp builtin semantics), which keeps the FIXED / PRISMATIC / BALL angular
+// error finite when a normalised quaternion's w drifts a few ulp above 1.
 // D6 joints with 2 or 3 angular axes need wp.quat_to_euler (math/spatial.py:170) and are not restated.
 #include <vector>
 
@@ -99,7 +101,7 @@ static void eval_body_joints(const o_model* m, const o_control* c, const float* 
         const float angular_damping_scale = 0.01f;
 
         if (type == FIXED) {
-            vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * std::acos(r_err.w) * 2.0f;
+            vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * std::acos(clampf(r_err.w, -1.0f, 1.0f)) * 2.0f;
             f_total += x_err * joint_attach_ke + v_err * joint_attach_kd;
             t_total += transform_vector(X_wp, ang_err) * joint_attach_ke + w_err * joint_attach_kd * angular_damping_scale;
         }
@@ -109,7 +111,7 @@ static void eval_body_joints(const o_model* m, const o_control* c, const float* 
             float q = dot(x_err, axis_p);
             float qd = dot(v_err, axis_p);
             f_total = axis_p * (-joint_f[qd_start] - dof_force(m, c, qd_start, target_q_start, q, qd));
-            vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * std::acos(r_err.w) * 2.0f;
+            vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * std::acos(clampf(r_err.w, -1.0f, 1.0f)) * 2.0f;
             f_total += (x_err - q * axis_p) * joint_attach_ke + (v_err - qd * axis_p) * joint_attach_kd;
             t_total += transform_vector(X_wp, ang_err) * joint_attach_ke + w_err * joint_attach_kd * angular_damping_scale;
         }
@@ -145,7 +147,7 @@ static void eval_body_joints(const o_model* m, const o_control* c, const float* 
             }
             f_total += (x_err - pos) * joint_attach_ke + (v_err - vel) * joint_attach_kd;
             if (ang_axis_count == 0) {
-                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * std::acos(r_err.w) * 2.0f;
+                vec3 ang_err = normalize(vec3(r_err.x, r_err.y, r_err.z)) * std::acos(clampf(r_err.w, -1.0f, 1.0f)) * 2.0f;
                 t_total += transform_vector(X_wp, ang_err) * joint_attach_ke + w_err * joint_attach_kd * angular_damping_scale;
             }
             int i_0 = lin_axis_count + qd_start;

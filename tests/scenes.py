@@ -150,3 +150,64 @@ def pendulum_scene(world_count: int, device=None, seed: int | None = None):
     bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
     model.body_q, model.body_qd = bq, bqd
     return model
+
+
+def joint_zoo_scene(world_count: int, device=None, seed: int | None = 0, free_root: bool = False):
+    """One articulation per env exercising every supported joint type:
+    (world | FREE) -> revolute -> prismatic -> ball -> fixed -> D6(linear x, angular z), plus limits, drives and damping."""
+    from newton_amd import _np_math as nm
+
+    env = nt.ModelBuilder()
+    cfg = nt.ModelBuilder.ShapeConfig(has_shape_collision=False)
+    links = []
+    for k in range(6):
+        b = env.add_link(xform=[0.3 * k, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_box(b, hx=0.12, hy=0.05 + 0.01 * k, hz=0.04, cfg=cfg)
+        links.append(b)
+    X = lambda p, q=(0.0, 0.0, 0.0, 1.0): nm.transform(p, q)  # noqa: E731
+    joints = []
+    if free_root:
+        joints.append(env.add_joint_free(links[0]))
+    else:
+        joints.append(env.add_joint_revolute(-1, links[0], axis=[0.0, 1.0, 0.0], parent_xform=X([0.0, 0.0, 1.0]),
+                                             child_xform=X([-0.15, 0.0, 0.0]), target_ke=50.0, target_kd=2.0))
+    joints.append(env.add_joint_revolute(links[0], links[1], axis=[0.0, 0.0, 1.0], parent_xform=X([0.15, 0.0, 0.0]),
+                                         child_xform=X([-0.15, 0.0, 0.0]), limit_lower=-0.2, limit_upper=0.4,
+                                         target_ke=100.0, target_kd=1.0, armature=0.01))
+    joints.append(env.add_joint_prismatic(links[1], links[2], axis=[1.0, 0.0, 0.0], parent_xform=X([0.15, 0.0, 0.0]),
+                                          child_xform=X([-0.15, 0.0, 0.0]), limit_lower=-0.05, limit_upper=0.1,
+                                          target_ke=200.0, target_kd=5.0, armature=0.02))
+    joints.append(env.add_joint_ball(links[2], links[3], parent_xform=X([0.15, 0.0, 0.0]), child_xform=X([-0.15, 0.0, 0.0])))
+    joints.append(env.add_joint_fixed(links[3], links[4], parent_xform=X([0.15, 0.0, 0.0], nm.quat_rpy(0.1, 0.0, 0.2)),
+                                      child_xform=X([-0.15, 0.0, 0.0])))
+    D = nt.ModelBuilder.JointDofConfig
+    joints.append(env.add_joint_d6(links[4], links[5], linear_axes=[D(axis=0, limit_lower=-0.05, limit_upper=0.05, armature=0.01)],
+                                   angular_axes=[D(axis=2, target_ke=20.0, target_kd=0.5, armature=0.01)],
+                                   parent_xform=X([0.15, 0.0, 0.0]), child_xform=X([-0.15, 0.0, 0.0])))
+    env.add_articulation(joints)
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    model = scene.finalize(device=device)
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+        E = world_count
+        jq = model.joint_q.reshape(E, -1).copy()
+        jqd = rng.normal(0.0, 0.5, size=model.joint_qd.shape).astype(np.float32)
+        t = model.env
+        for j in range(t.nj):
+            qs, jt = int(t.joint_q_start[j]), int(t.joint_type[j])
+            if jt == nt.JointType.BALL:
+                q = rng.normal(size=(E, 4)) * 0.2 + np.array([0, 0, 0, 1.0])
+                jq[:, qs:qs + 4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+            elif jt == nt.JointType.FREE:
+                q = rng.normal(size=(E, 4)) * 0.3 + np.array([0, 0, 0, 1.0])
+                jq[:, qs + 3:qs + 7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+                jq[:, qs:qs + 3] += rng.normal(0, 0.05, size=(E, 3))
+            elif jt != nt.JointType.FIXED:
+                n = int(t.joint_lin_count[j] + t.joint_ang_count[j])
+                jq[:, qs:qs + n] = rng.uniform(-0.15, 0.15, size=(E, n))
+        model.joint_q = jq.reshape(-1).astype(np.float32)
+        model.joint_qd = jqd
+        bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+        model.body_q, model.body_qd = bq, bqd
+    return model
