@@ -59,7 +59,7 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
 // block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint (3 * nj), joint of
 // each dof (nd), and per joint a bit mask of the joints on its root path, itself included (nj * ceil(nj / 32))
 __host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }
-__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + m.nj * fs_mask_words(m); }
+__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m); }
 
 template <int EPB>
 struct FsCtx {
@@ -68,6 +68,7 @@ struct FsCtx {
     const int *anc, *depth, *art;  // [nj] each (LDS)
     const int* dof_joint;          // [nd]
     const unsigned* pathmask;      // [nj][words]
+    const unsigned* childmask;     // [nj][words] joints whose parent body is this joint's child
     int words;
     NT_DI FsCtx(const Ctx<EPB>& c_, int* extra) : c(c_) {
         F = make_fs_layout(c.a.m, c.L);
@@ -78,6 +79,7 @@ struct FsCtx {
         dof_joint = extra + 3 * nj;
         pathmask = reinterpret_cast<const unsigned*>(extra + 3 * nj + c.a.m.nd);
         words = fs_mask_words(c.a.m);
+        childmask = pathmask + nj * words;
     }
     // is joint `a` on the root path of joint `l` (or `l` itself)?
     NT_DI bool on_path(int a, int l) const { return (pathmask[l * words + (a >> 5)] >> (a & 31)) & 1u; }
@@ -142,6 +144,16 @@ NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int 
     return xform();
 }
 
+// jcalc_transform for every joint at once (the sin / cos of the joint angles are the expensive part of FK and do not
+// depend on the tree level); parked in the v_s / a_s rows, which are dead during both FK passes
+template <int EPB>
+NT_DI void fs_joint_xform_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    xform X_j = fs_joint_transform(f, c.T.joint_type[j], c.T.joint_qd_start[j], c.T.joint_lin_count[j], c.T.joint_ang_count[j],
+                                   f.F.jq, c.T.joint_q_start[j]);
+    c.st_lxf(f.F.vs, c.a.m.nj, j, X_j);
+}
+
 // compute_link_transform (kernels.py:633-684): body_q[child], COM world position
 template <int EPB>
 NT_DI void fs_fk_item(const FsCtx<EPB>& f, int j) {
@@ -150,8 +162,7 @@ NT_DI void fs_fk_item(const FsCtx<EPB>& f, int j) {
     const int parent = c.T.joint_parent[j], child = c.T.joint_child[j];
     xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
     if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
-    xform X_j = fs_joint_transform(f, c.T.joint_type[j], c.T.joint_qd_start[j], c.T.joint_lin_count[j], c.T.joint_ang_count[j],
-                                   f.F.jq, c.T.joint_q_start[j]);
+    xform X_j = c.lxf(f.F.vs, 0, m.nj, j);
     xform X_wcj = X_wpj * X_j;
     xform X_wc = X_wcj * xform_inverse(c.lxf(c.L.jp, 7, m.nj, j));
     c.st_lxf(c.L.bq, m.nb, child, X_wc);
@@ -330,12 +341,11 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
         for (int k = 0; k < 6; ++k) c.l(f.F.Is, i * 6 + k, nb, child) = I_s.a[i][k];
 }
 
-// (2) the velocity / acceleration / bias-force recurrence, one tree level at a time.
+// (2) the velocity / acceleration recurrence, one tree level at a time (a handful of adds and two cross products);
 template <int EPB>
 NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
-    const nt_model& m = c.a.m;
-    const int nb = m.nb;
+    const int nb = c.a.m.nb;
     const int child = c.T.joint_child[j], parent = c.T.joint_parent[j];
     spatial v_j_s = f.sp6(f.F.ft, nb, j);
     spatial v_parent_s, a_parent_s;
@@ -345,6 +355,18 @@ NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
     }
     spatial v_s = v_parent_s + v_j_s;
     spatial a_s = a_parent_s + fs_spatial_cross(v_s, v_j_s) + spatial();
+    f.st6(f.F.vs, nb, child, v_s);
+    f.st6(f.F.as, nb, child, a_s);
+}
+
+// (3) bias forces f_b = I a + v x* (I v) minus gravity, and the FK body twist, for all bodies at once.
+template <int EPB>
+NT_DI void fs_motion_post_item(const FsCtx<EPB>& f, int j) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    const int child = c.T.joint_child[j];
+    spatial v_s = f.sp6(f.F.vs, nb, child), a_s = f.sp6(f.F.as, nb, child);
     vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - f.v3(f.F.org, 0, nb, child);
     float mass = c.l(c.L.bp, BP_MASS, nb, child);
     vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
@@ -361,8 +383,6 @@ NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
     // body_qd_fk lives in the body_qd rows until the final FK overwrites them with the public output twist
     c.st_lv3(c.L.bqd, 0, nb, child, v_com_world);
     c.st_lv3(c.L.bqd, 3, nb, child, omega_world);
-    f.st6(f.F.vs, nb, child, v_s);
-    f.st6(f.F.as, nb, child, a_s);
     f.st6(f.F.fs, nb, child, f_b_s - f_g_s);
 }
 
@@ -416,8 +436,14 @@ NT_DI void fs_tau_item(const FsCtx<EPB>& f, int j) {
     const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
     // body_ft_s[child]: the reference walks joints in descending index and accumulates into the parent
     spatial f_t_s;
-    for (int k = m.nj - 1; k > j; --k)
-        if (f.anc[k] == j) f_t_s = f_t_s + f.sp6(f.F.ft, nb, k);
+    for (int w = f.words - 1; w >= 0; --w) {  // children in descending joint order, straight from the bit mask
+        unsigned bits = f.childmask[j * f.words + w];
+        while (bits) {
+            int hi = 31 - __builtin_clz(bits);
+            bits &= ~(1u << hi);
+            f_t_s = f_t_s + f.sp6(f.F.ft, nb, w * 32 + hi);
+        }
+    }
     vec3 force = f.v3(f.F.bfx, 0, nb, child), torque_com = f.v3(f.F.bfx, 3, nb, child);
     vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - f.v3(f.F.org, 0, nb, child);
     spatial f_ext(-force, -(torque_com + cross(x_com_s, force)));
@@ -487,11 +513,22 @@ NT_DI void fs_H_item(const FsCtx<EPB>& f, int item) {
     if (jl > il) return;
     const int jj = f.dof_joint[d0 + jl];
     spatial S_i = f.sp6(f.F.S, nd, i);
+    // bodies off the common path contribute an exact zero (the dense product's J entries are zero there): every P row
+    // is fetched unconditionally so the loads pipeline, and the partial dot product is selected away
     float sum = 0.0f;
-    for (int l = art_j0; l < art_j1; ++l) {
-        if (!f.on_path(ji, l) || !f.on_path(jj, l)) continue;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) sum += fs_sget(S_i, r) * c.l(f.F.P, r, nb * W, l * W + jl);
+#pragma unroll 2
+    for (int l = ji > jj ? ji : jj; l < art_j1; ++l) {  // a body below both dofs has an index >= both joints
+        const bool on = f.on_path(ji, l) && f.on_path(jj, l);
+        float p0 = c.l(f.F.P, 0, nb * W, l * W + jl), p1 = c.l(f.F.P, 1, nb * W, l * W + jl), p2 = c.l(f.F.P, 2, nb * W, l * W + jl);
+        float p3 = c.l(f.F.P, 3, nb * W, l * W + jl), p4 = c.l(f.F.P, 4, nb * W, l * W + jl), p5 = c.l(f.F.P, 5, nb * W, l * W + jl);
+        if (on) {
+            sum += S_i.top.x * p0;
+            sum += S_i.top.y * p1;
+            sum += S_i.top.z * p2;
+            sum += S_i.bottom.x * p3;
+            sum += S_i.bottom.y * p4;
+            sum += S_i.bottom.z * p5;
+        }
     }
     c.l(f.F.H, 0, 1, i * W + jl) = sum;
 }
@@ -523,9 +560,19 @@ NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G) {
     auto X = [&](int i) -> float& { return lds[(f.F.qdd + d0 + i) * EPB + e]; };
     for (int j = 0; j < n; ++j) {
         float s = A(j, j) + c.dof(DP_ARMATURE, d0 + j);  // every lane evaluates the pivot (no broadcast needed)
-        for (int k = 0; k < j; ++k) {
-            float r = A(j, k);
-            s -= r * r;
+        {
+            int k = 0;
+            for (; k + 4 <= j; k += 4) {  // four LDS reads in flight; the subtraction order stays k ascending
+                float r0 = A(j, k), r1 = A(j, k + 1), r2 = A(j, k + 2), r3 = A(j, k + 3);
+                s -= r0 * r0;
+                s -= r1 * r1;
+                s -= r2 * r2;
+                s -= r3 * r3;
+            }
+            for (; k < j; ++k) {
+                float r = A(j, k);
+                s -= r * r;
+            }
         }
         s = sqrtf(s);
         float invS = 1.0f / s;
@@ -533,7 +580,16 @@ NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G) {
         if (lane == 0) A(j, j) = s;
         for (int i = j + 1 + lane; i < n; i += G) {
             float t = A(i, j);
-            for (int k = 0; k < j; ++k) t -= A(i, k) * A(j, k);
+            int k = 0;
+            for (; k + 4 <= j; k += 4) {
+                float a0 = A(i, k), a1 = A(i, k + 1), a2 = A(i, k + 2), a3 = A(i, k + 3);
+                float b0 = A(j, k), b1 = A(j, k + 1), b2 = A(j, k + 2), b3 = A(j, k + 3);
+                t -= a0 * b0;
+                t -= a1 * b1;
+                t -= a2 * b2;
+                t -= a3 * b3;
+            }
+            for (; k < j; ++k) t -= A(i, k) * A(j, k);
             A(i, j) = t * invS;
         }
         FS_WAVE_SYNC();
@@ -551,7 +607,18 @@ NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G) {
     // back substitution: each x_i needs the ascending-j sum over the rows below it; evaluated by every lane
     for (int i = n - 1; i >= 0; --i) {
         float s = X(i);
-        for (int j = i + 1; j < n; ++j) s -= A(j, i) * X(j);
+        {
+            int j = i + 1;
+            for (; j + 4 <= n; j += 4) {
+                float a0 = A(j, i), a1 = A(j + 1, i), a2 = A(j + 2, i), a3 = A(j + 3, i);
+                float x0 = X(j), x1 = X(j + 1), x2 = X(j + 2), x3 = X(j + 3);
+                s -= a0 * x0;
+                s -= a1 * x1;
+                s -= a2 * x2;
+                s -= a3 * x3;
+            }
+            for (; j < n; ++j) s -= A(j, i) * X(j);
+        }
         float xi = s / A(i, i);
         FS_WAVE_SYNC();
         if (lane == 0) X(i) = xi;
@@ -634,7 +701,7 @@ NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
     const int qs = c.T.joint_qd_start[j];
     const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
     auto qd = [&](int i) { return f.f(f.F.qdo, i); };
-    xform X_j = fs_joint_transform(f, type, qs, lin, ang, f.F.jq, c.T.joint_q_start[j]);
+    xform X_j = c.lxf(f.F.vs, 0, m.nj, j);  // fs_joint_xform_item
     spatial v_j;
     if (type == JT_PRISMATIC) v_j = spatial(c.dof_axis(qs) * qd(qs), vec3());
     if (type == JT_REVOLUTE) v_j = spatial(vec3(), c.dof_axis(qs) * qd(qs));
@@ -741,6 +808,12 @@ NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
             if (c.T.joint_qd_start[k] <= d) j = k;
         extra[3 * nj + d] = j;
     }
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+        unsigned* cm = reinterpret_cast<unsigned*>(extra + 3 * nj + m.nd) + nj * words + j * words;
+        for (int w = 0; w < words; ++w) cm[w] = 0u;
+        for (int k = 0; k < nj; ++k)
+            if (extra[k] == j) cm[k >> 5] |= 1u << (k & 31);
+    }
     __syncthreads();
 }
 
@@ -752,18 +825,25 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     const nt_model& m = a.m;
     const int nj = m.nj, nb = m.nb;
     const int skip = a.debug_skip;  // timing ablation only (NT_DEBUG_SKIP): results are meaningless when set
-    // eval_rigid_fk, level by level (a joint's parent body is final one level earlier)
+    NT_TICK(10);
+    // eval_rigid_fk: joint transforms for all joints at once, then level by level (a joint's parent body is final one
+    // level earlier)
+    if (c.valid && !(skip & 1))
+        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
+    __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid && !(skip & 1))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_fk_item(f, j);
         __syncthreads();
     }
+    NT_TICK(11);
     // state_in.body_q is refreshed by the reference step (solver_featherstone.py:492-514): publish it when distinct
     if (publish_fk && c.valid && a.s_in.body_q != a.s_out.body_q) unstage_rows(c, c.L.bq, a.s_in.body_q, 7 * nb);
     if (c.valid)
         for (int j = c.slot; j < nj; j += c.nslot) fs_to_internal_item(f, j);
     __syncthreads();
+    NT_TICK(12);
     // eval_rigid_id
     if (c.valid && !(skip & 2))
         for (int j = c.slot; j < nj; j += c.nslot) fs_motion_pre_item(f, j);
@@ -774,6 +854,10 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
                 if (f.depth[j] == lvl) fs_motion_item(f, j);
         __syncthreads();
     }
+    if (c.valid && !(skip & 2))
+        for (int j = c.slot; j < nj; j += c.nslot) fs_motion_post_item(f, j);
+    __syncthreads();
+    NT_TICK(13);
     // eval_body_contact on (body_q, body_qd_fk)
     if (a.has_contacts) {
         Ctx<EPB> cc = c;
@@ -785,6 +869,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     if (c.valid)
         for (int b = c.slot; b < nb; b += c.nslot) fs_body_force_item(f, b, forces_are_zero);
     __syncthreads();
+    NT_TICK(14);
     // eval_rigid_tau, deepest level first
     for (int lvl = max_depth; lvl >= 0; --lvl) {
         if (c.valid && !(skip & 8))
@@ -792,34 +877,44 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
                 if (f.depth[j] == lvl) fs_tau_item(f, j);
         __syncthreads();
     }
+    NT_TICK(15);
     // P = M J (non-zero blocks), H = J^T P (lower triangle), Cholesky, solve
     const int W = m.max_art_dofs;
     if (c.valid && !(skip & 16))
         for (int i = c.slot; i < nj * W; i += c.nslot) fs_P_item(f, i);
     __syncthreads();
+    NT_TICK(16);
     if (c.valid && !(skip & 32))
         for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
     __syncthreads();
+    NT_TICK(17);
     {
         const int G = (64 / EPB) < c.nslot ? (64 / EPB) : c.nslot;
         if (c.valid && !(skip & 64) && c.slot < G)
             for (int k = 0; k < m.na; ++k) fs_solve_coop(f, k, c.slot, G);
     }
     __syncthreads();
+    NT_TICK(18);
     // integrate_generalized_joints
     if (c.valid)
         for (int j = c.slot; j < nj; j += c.nslot) fs_integrate_item(f, j);
     __syncthreads();
+    NT_TICK(19);
     // FK with velocity conversion -> public body_q / body_qd
+    if (c.valid && !(skip & 128))
+        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
+    __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid && !(skip & 128))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_fk_vel_item<EPB, false>(f, j);
         __syncthreads();
     }
+    NT_TICK(20);
     if (c.valid)
         for (int j = c.slot; j < nj; j += c.nslot) fs_to_public_item(f, j);
     __syncthreads();
+    NT_TICK(21);
 }
 
 template <int EPB>
@@ -924,6 +1019,9 @@ __global__ void __launch_bounds__(256) eval_fk_kernel(KArgs a, const float* join
         stage_rows(c, F.jq, joint_q, m.nc);
         stage_rows(c, F.qdo, joint_qd, m.nd);
     }
+    __syncthreads();
+    if (c.valid)
+        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
     __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid)

@@ -27,7 +27,8 @@ model = quadruped_scene(4096, device="cuda:0", seed=1)
 s0, s1 = model.state(), model.state()
 pipe = nt.CollisionPipeline(model)
 contacts = pipe.contacts()
-solver = nt.solvers.SolverXPBD(model)
+FS = len(sys.argv) > 1 and sys.argv[1] == "featherstone"
+solver = nt.solvers.SolverFeatherstone(model) if FS else nt.solvers.SolverXPBD(model)
 for _ in range(100):
     solver.rollout(s0, s1, None, contacts, 1e-3, 10)
 torch.cuda.synchronize()
@@ -39,6 +40,15 @@ for _ in range(N):
     solver.rollout(s0, s1, None, contacts, 1e-3, 10)
 torch.cuda.synchronize()
 raw.nt_debug_phase_clocks(buf)
+if FS:
+    names = {10: "collide (+ previous tail)", 11: "FK", 12: "to internal qd", 13: "RNEA forward (pre + levels)", 14: "contacts + f_ext",
+             15: "RNEA backward (tau)", 16: "P = I S", 17: "H = S^T P", 18: "Cholesky + solve", 19: "integrate", 20: "FK + velocities",
+             21: "to public qd"}
+    tot = sum(buf[i] for i in names)
+    for i in sorted(names):
+        print(f"{names[i]:32s} {buf[i] / N:12.0f} cycles/launch  {100.0 * buf[i] / tot:5.1f} %")
+    print(f"{'total':32s} {tot / N:12.0f} cycles/launch")
+    sys.exit(0)
 names = {0: "prologue (load + derived)", 1: "shapes/AABB", 2: "pairs (broad+narrow+write)", 3: "joint forces", 4: "integrate",
          5: "contacts", 6: "apply (contacts)", 7: "joints", 8: "apply (joints)", 9: "epilogue (count + store)"}
 tot = sum(buf[i] for i in range(10))
