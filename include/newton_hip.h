@@ -69,6 +69,9 @@ typedef struct {
                             contacts before all convex ones, and the pair table is stored in that order */
     int32_t na;          /* articulations per env (SolverFeatherstone only; 0 otherwise) */
     int32_t max_art_dofs;/* widest articulation, in dofs (row width of the LDS-resident joint-space inertia H) */
+    int32_t shape_local0;/* Newton shape id of env 0's first local shape: env-local shapes occupy ids
+                            [shape_local0, shape_local0 + env_count*ns), global shapes sit before and / or after (gshape_id) */
+    int32_t reserved0;
     /* topology, int32, env-uniform */
     const int32_t* body_flags;          /* [nb]   BodyFlags */
     const int32_t* joint_type;          /* [nj]   JointType */
@@ -95,6 +98,7 @@ typedef struct {
     /* convex-hull shapes (GeoType.CONVEX_MESH, support_function.py:152-171): env-uniform vertex table */
     const int32_t* shape_mesh_start;    /* [ns+ng] first vertex of the shape's hull in mesh_points, -1 for other types */
     const int32_t* shape_mesh_count;    /* [ns+ng] */
+    const int32_t* gshape_id;           /* [ng] Newton shape ids of the global shapes, ascending */
     const float* mesh_points;           /* [V][3] unscaled vertices (AoS); the per-env shape scale is applied on the fly */
     const float* shape_mesh_bounds;     /* [ns+ng][6] unscaled min xyz, max xyz of the hull (local AABB = bounds * scale) */
     /* per-env parameters, float SoA */

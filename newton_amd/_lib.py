@@ -27,7 +27,8 @@ class nt_model(C.Structure):
         ("env_count", C.c_int32), ("env_stride", C.c_int32), ("nb", C.c_int32), ("nj", C.c_int32), ("nd", C.c_int32),
         ("nc", C.c_int32), ("ntq", C.c_int32), ("ns", C.c_int32), ("ng", C.c_int32), ("np", C.c_int32),
         ("cpp", C.c_int32),
-        ("np_analytic", C.c_int32), ("na", C.c_int32), ("max_art_dofs", C.c_int32),
+        ("np_analytic", C.c_int32), ("na", C.c_int32), ("max_art_dofs", C.c_int32), ("shape_local0", C.c_int32),
+        ("reserved0", C.c_int32),
         ("body_flags", C.c_void_p), ("joint_type", C.c_void_p), ("joint_enabled", C.c_void_p),
         ("joint_parent", C.c_void_p), ("joint_child", C.c_void_p), ("joint_q_start", C.c_void_p),
         ("joint_qd_start", C.c_void_p), ("joint_tq_start", C.c_void_p), ("joint_lin_count", C.c_void_p),
@@ -35,7 +36,8 @@ class nt_model(C.Structure):
         ("shape_flags", C.c_void_p), ("shape_group", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p),
         ("body_joint_start", C.c_void_p), ("body_joint_list", C.c_void_p), ("body_pair_start", C.c_void_p),
         ("body_pair_list", C.c_void_p), ("art_start", C.c_void_p),
-        ("shape_mesh_start", C.c_void_p), ("shape_mesh_count", C.c_void_p), ("mesh_points", C.c_void_p),
+        ("shape_mesh_start", C.c_void_p), ("shape_mesh_count", C.c_void_p), ("gshape_id", C.c_void_p),
+        ("mesh_points", C.c_void_p),
         ("shape_mesh_bounds", C.c_void_p),
         ("body_param", C.c_void_p), ("gravity", C.c_void_p), ("joint_param", C.c_void_p), ("dof_param", C.c_void_p),
         ("shape_param", C.c_void_p), ("gshape_param", C.c_void_p),

@@ -121,11 +121,11 @@ struct KArgs {
 struct Topo {
     const int *body_flags, *joint_type, *joint_enabled, *joint_parent, *joint_child, *joint_q_start, *joint_qd_start,
         *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
-        *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count;
+        *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count, *gshape_id;
     const float* gshape;  // [ng][NT_SHAPE_PARAM_FLOATS] parameters of the global (world -1) shapes, block-shared copy
 };
 __host__ __device__ inline int topo_ints(const nt_model& m) {
-    return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np +
+    return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np + m.ng +
            NT_SHAPE_PARAM_FLOATS * m.ng;
 }
 
@@ -179,6 +179,7 @@ struct Ctx {
         take(T.body_pair_list, m.body_pair_list, 2 * m.np);    // padded to 2*np entries by the host
         take(T.shape_mesh_start, m.shape_mesh_start, m.ns + m.ng);
         take(T.shape_mesh_count, m.shape_mesh_count, m.ns + m.ng);
+        take(T.gshape_id, m.gshape_id, m.ng);
         {
             float* g = reinterpret_cast<float*>(ti + o);
             for (int i = threadIdx.x; i < NT_SHAPE_PARAM_FLOATS * m.ng; i += blockDim.x) g[i] = m.gshape_param[i];
@@ -257,12 +258,16 @@ struct Ctx {
     NT_DI xform shape_local_xform(int s) const {
         return xform(vec3(shape_f(s, 0), shape_f(s, 1), shape_f(s, 2)), quat(shape_f(s, 3), shape_f(s, 4), shape_f(s, 5), shape_f(s, 6)));
     }
-    NT_DI int newton_shape_id(int s) const {  // flat Newton shape index (world-major locals, then globals)
-        return s < a.m.ns ? env * a.m.ns + s : a.m.env_count * a.m.ns + (s - a.m.ns);
+    NT_DI int newton_shape_id(int s) const {  // flat Newton shape index
+        return s < a.m.ns ? a.m.shape_local0 + env * a.m.ns + s : T.gshape_id[s - a.m.ns];
     }
     NT_DI int local_shape_id(int gid) const {
-        int eg = a.m.env_count * a.m.ns;
-        return gid >= eg ? a.m.ns + (gid - eg) : gid - env * a.m.ns;
+        int rel = gid - a.m.shape_local0 - env * a.m.ns;
+        if (rel >= 0 && rel < a.m.ns) return rel;
+        int g = 0;
+        for (int k = 0; k < a.m.ng; ++k)
+            if (T.gshape_id[k] == gid) g = k;
+        return a.m.ns + g;
     }
 };
 

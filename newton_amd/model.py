@@ -56,19 +56,24 @@ class EnvTemplate:
         if len(joint_glob):
             raise NotImplementedError("joints in the global world (-1) are not supported together with worlds")
         if m.world_count == 0:
-            sw = np.where(np.asarray(m.shape_body) >= 0, 0, -1)  # body-attached shapes are env-local
-            shape_world = sw
-            order = np.concatenate([np.flatnonzero(sw >= 0), np.flatnonzero(sw < 0)])
-            if not np.array_equal(order, np.arange(len(sw))):
-                raise NotImplementedError("static shapes must come after body-attached shapes")
+            shape_world = np.where(np.asarray(m.shape_body) >= 0, 0, -1)  # body-attached shapes are env-local
         else:
             shape_world = np.asarray(m.shape_world)
         shape_local = np.flatnonzero(shape_world >= 0)
         shape_glob = np.flatnonzero(shape_world < 0)
-        if len(shape_local) % E or (len(shape_local) and not np.array_equal(shape_local, np.arange(len(shape_local)))):
-            raise NotImplementedError("shapes must be ordered world-major with global shapes at the tail")
+        # local shapes must form one contiguous world-major block; global (static) shapes may sit before and / or after
+        # it (the reference's examples call add_ground_plane() first as often as last)
+        L0 = int(shape_local[0]) if len(shape_local) else 0
+        if len(shape_local) % E or (len(shape_local) and not np.array_equal(shape_local, np.arange(L0, L0 + len(shape_local)))):
+            raise NotImplementedError("env-local shapes must form one contiguous, world-major block")
+        if m.world_count > 0 and len(shape_local):
+            expect = np.repeat(np.arange(E), len(shape_local) // E)
+            if not np.array_equal(shape_world[shape_local], expect):
+                raise NotImplementedError("shapes must be ordered world-major")
         if np.any(np.asarray(m.shape_body)[shape_glob] >= 0):
             raise NotImplementedError("global shapes must be static (shape_body == -1)")
+        self.shape_local0 = L0
+        self.gshape_id = shape_glob.astype(np.int32)
 
         self.nb = len(body_local) // E
         self.nj = len(joint_local) // E
@@ -127,7 +132,7 @@ class EnvTemplate:
             self.art_start = np.zeros(1, dtype=np.int32)
             self.max_art_dofs = 0
 
-        sb = np.asarray(m.shape_body)[:E * ns].reshape(E, ns) if ns else np.zeros((E, 0), dtype=np.int32)
+        sb = np.asarray(m.shape_body)[L0:L0 + E * ns].reshape(E, ns) if ns else np.zeros((E, 0), dtype=np.int32)
         sb = np.where(sb >= 0, sb - env_ids * nb, -1)
         if E > 1 and not np.all(sb == sb[0:1]):
             raise NotImplementedError("heterogeneous worlds: shape_body differs between worlds")
@@ -136,10 +141,10 @@ class EnvTemplate:
 
         def shape_uniform(a, what):
             a = np.asarray(a)
-            loc = a[:E * ns].reshape(E, ns) if ns else np.zeros((E, 0), dtype=a.dtype)
+            loc = a[L0:L0 + E * ns].reshape(E, ns) if ns else np.zeros((E, 0), dtype=a.dtype)
             if E > 1 and not np.all(loc == loc[0:1]):
                 raise NotImplementedError(f"heterogeneous worlds: {what} differs between worlds")
-            return np.concatenate([loc[0], a[E * ns:]]).astype(np.int32)
+            return np.concatenate([loc[0], a[shape_glob]]).astype(np.int32)
 
         self.shape_type = shape_uniform(m.shape_type, "shape_type")
         self.shape_flags = shape_uniform(m.shape_flags, "shape_flags")
@@ -159,10 +164,15 @@ class EnvTemplate:
 
         # candidate pairs, per env, in Newton's order
         pairs = np.asarray(m.shape_contact_pairs, dtype=np.int64).reshape(-1, 2)
-        eg = E * ns
+        glob_rank = -np.ones(len(np.asarray(m.shape_type)) + 1, dtype=np.int64)
+        glob_rank[shape_glob] = np.arange(len(shape_glob))
+
+        def is_local(col):
+            return (col >= L0) & (col < L0 + E * ns)
+
         if len(pairs):
-            wa = np.where(pairs[:, 0] < eg, pairs[:, 0] // max(ns, 1), -1)
-            wb = np.where(pairs[:, 1] < eg, pairs[:, 1] // max(ns, 1), -1)
+            wa = np.where(is_local(pairs[:, 0]), (pairs[:, 0] - L0) // max(ns, 1), -1)
+            wb = np.where(is_local(pairs[:, 1]), (pairs[:, 1] - L0) // max(ns, 1), -1)
             pw = np.maximum(wa, wb)
             keep = pw >= 0  # global-vs-global pairs are static-static: no consumer, dropped
             pairs, pw = pairs[keep], pw[keep]
@@ -176,7 +186,7 @@ class EnvTemplate:
 
             def to_local(col):
                 w = pw
-                return np.where(col < eg, col - w * ns, ns + (col - eg))
+                return np.where(is_local(col), col - L0 - w * ns, ns + glob_rank[col])
 
             la = to_local(pairs[:, 0]).reshape(E, npair)
             lb = to_local(pairs[:, 1]).reshape(E, npair)
@@ -207,7 +217,7 @@ class EnvTemplate:
         def convex_ok(s):
             ty = int(self.shape_type[s])
             if ty == GeoType.PLANE:  # infinite planes become a box proxy under the other shape (collision_core.py:562-625)
-                sc = np.asarray(m.shape_scale).reshape(-1, 3)[s if s < ns else E * ns + (s - ns)]
+                sc = np.asarray(m.shape_scale).reshape(-1, 3)[L0 + s if s < ns else shape_glob[s - ns]]
                 return sc[0] == 0.0 and sc[1] == 0.0
             return ty in convex_types
 
@@ -280,7 +290,7 @@ class DeviceModel:
             "body_flags", "joint_type", "joint_enabled", "joint_parent", "joint_child", "joint_q_start",
             "joint_qd_start", "joint_tq_start", "joint_lin_count", "joint_ang_count", "shape_body", "shape_type",
             "shape_flags", "shape_group", "pair_a", "pair_b", "body_joint_start", "body_joint_list", "body_pair_start",
-            "body_pair_list", "art_start", "shape_mesh_start", "shape_mesh_count")}
+            "body_pair_list", "art_start", "shape_mesh_start", "shape_mesh_count", "gshape_id")}
         self.mesh_tables = {"mesh_points": dev_f32(t.mesh_points), "shape_mesh_bounds": dev_f32(t.shape_mesh_bounds)}
         self.params = {}
         self.upload_params(model)
@@ -289,6 +299,7 @@ class DeviceModel:
         d.nb, d.nj, d.nd, d.nc, d.ntq, d.ns, d.ng, d.np, d.cpp = t.nb, t.nj, t.nd, t.nc, t.ntq, t.ns, t.ng, t.np, t.cpp
         d.np_analytic = t.np_analytic
         d.na, d.max_art_dofs = t.na, t.max_art_dofs
+        d.shape_local0 = t.shape_local0
         for k, v in self.topology.items():
             setattr(d, k, v.data_ptr())
         for k, v in self.params.items():
@@ -329,8 +340,8 @@ class DeviceModel:
             m.shape_material_restitution[:, None]], axis=1)
         new = {
             "body_param": soa(body, nb), "gravity": grav, "joint_param": soa(joint, nj), "dof_param": soa(dof, nd),
-            "shape_param": soa(shape_all[:E * ns], ns),
-            "gshape_param": np.ascontiguousarray(shape_all[E * ns:], dtype=np.float32),
+            "shape_param": soa(shape_all[t.shape_local0:t.shape_local0 + E * ns], ns),
+            "gshape_param": np.ascontiguousarray(shape_all[t.gshape_id], dtype=np.float32),
         }
         for k, v in new.items():
             if v.size == 0:

@@ -44,7 +44,9 @@ def _compare_contacts(model, contacts, oc, pairs_oracle):
     # per env counts
     s0 = oc.shape0[:n_or]
     s1 = oc.shape1[:n_or]
-    env_of = np.where(s0 < E * t.ns, s0 // max(t.ns, 1), s1 // max(t.ns, 1))
+    L0, nloc = t.shape_local0, max(t.ns, 1)
+    loc0 = (s0 >= L0) & (s0 < L0 + E * t.ns)
+    env_of = np.where(loc0, (s0 - L0) // nloc, (s1 - L0) // nloc)
     want_counts = np.bincount(env_of, minlength=E)
     assert np.array_equal(contacts.rigid_contact_count_per_env.cpu().numpy(), want_counts)
     # flat arrays in the reference's append order
@@ -275,3 +277,40 @@ def test_state_reset_masked_device():
     sel = mask[:70]
     assert np.array_equal(q[sel], d[sel]) and np.array_equal(q[~sel], moved[~sel])
     assert np.array_equal(res.body_qd.cpu().numpy().reshape(70, -1)[sel], default.body_qd.cpu().numpy().reshape(70, -1)[sel])
+
+
+def test_ground_plane_first_scene_matches_oracle():
+    """Global shape in front of the env-local block (add_ground_plane() before replicate): ids, pairs and contacts line up."""
+    from oracle_bridge import OracleState
+
+    def scene(n, device=None):
+        import newton_amd as nt
+
+        env = nt.ModelBuilder()
+        b = env.add_body(xform=[0.0, 0.0, 0.095, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_box(b, hx=0.2, hy=0.15, hz=0.1)
+        b = env.add_body(xform=[0.05, 0.02, 0.29, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_sphere(b, radius=0.1)
+        b = env.add_body(xform=[0.5, 0.0, 0.14, 0.7071068, 0.0, 0.0, 0.7071068])
+        env.add_shape_capsule(b, radius=0.05, half_height=0.1)
+        sc = nt.ModelBuilder()
+        sc.add_ground_plane()
+        sc.replicate(env, n)
+        return sc.finalize(device=device)
+
+    nt, model, o = _setup(scene, 19)
+    assert model.env.shape_local0 == 1
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    pipe.collide(s0, contacts)
+    solver.step(s0, s1, None, contacts, 1.0 / 240.0)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+    pairs, _, _ = o.collide(os0.body_q, oc)
+    assert oc.count[0] >= 19 * 5
+    o.xpbd_step(os0, os1, o.control(), oc, 1.0 / 240.0, iterations=2)
+    _compare_contacts(model, contacts, oc, pairs)
+    assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+    assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 2e-4

@@ -95,7 +95,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.nt_build_info()
     assert lib.nt_error_string(0) == b"ok"
     # struct layouts agree with the header (field count + size)
-    assert C.sizeof(_lib.nt_model) == 14 * 4 + 31 * 8
+    assert C.sizeof(_lib.nt_model) == 16 * 4 + 32 * 8
     m = _lib.nt_model()
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp = 18, 18, 4
@@ -142,3 +142,29 @@ def test_state_reset_masked_host():
     assert np.array_equal(jq[0], default.joint_q.reshape(4, -1)[0]) and not np.array_equal(jq[1], default.joint_q.reshape(4, -1)[1])
     with pytest.raises(ValueError):
         s.reset(default, world_mask=[True, False])
+
+
+def test_ground_plane_first_is_accepted():
+    """The reference's examples call add_ground_plane() before the bodies as often as after: global shapes may sit in
+    front of the env-local block (shape_local0), alone or replicated."""
+    b = nt.ModelBuilder()
+    b.add_ground_plane()
+    for k in range(3):
+        body = b.add_body(xform=[0, 0, 0.5 + k, 0, 0, 0, 1])
+        b.add_shape_box(body, hx=0.5, hy=0.5, hz=0.5)
+    m = b.finalize()
+    t = m.env
+    assert t.shape_local0 == 1 and t.ns == 3 and t.ng == 1 and list(t.gshape_id) == [0]
+    assert t.np == 3 + 3
+    env = nt.ModelBuilder()
+    for k in range(2):
+        body = env.add_body(xform=[0, 0, 0.5 + k, 0, 0, 0, 1])
+        env.add_shape_sphere(body, radius=0.5)
+    scene = nt.ModelBuilder()
+    scene.add_ground_plane()
+    scene.replicate(env, 4)
+    m = scene.finalize()
+    t = m.env
+    assert t.shape_local0 == 1 and t.ns == 2 and t.ng == 1 and t.env_count == 4
+    # Newton ids: ground 0 < locals, so the ground (template index ns + 0 = 2) is the pair's first shape
+    assert sorted(zip(t.pair_a.tolist(), t.pair_b.tolist())) == [(0, 1), (2, 0), (2, 1)]
