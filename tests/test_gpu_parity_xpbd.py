@@ -314,3 +314,52 @@ def test_ground_plane_first_scene_matches_oracle():
     _compare_contacts(model, contacts, oc, pairs)
     assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
     assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 2e-4
+
+
+def test_kinematic_platform_stepwise():
+    """A kinematic (prescribed-motion) platform carrying dynamic bodies: kinematic bodies pass through every kernel
+    unchanged and feed the friction rows through their velocity (xpbd/kernels.py:2318-2334); 40 steps vs the oracle."""
+    from oracle_bridge import OracleState
+
+    def scene(n, device=None):
+        import newton_amd as nt
+
+        env = nt.ModelBuilder()
+        plat = env.add_body(xform=[0.0, 0.0, 0.5, 0.0, 0.0, 0.0, 1.0], is_kinematic=True)
+        env.add_shape_box(plat, hx=1.0, hy=1.0, hz=0.05)
+        b = env.add_body(xform=[0.1, 0.0, 0.649, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_box(b, hx=0.1, hy=0.1, hz=0.1)
+        b = env.add_body(xform=[-0.3, 0.2, 0.629, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_sphere(b, radius=0.08)
+        sc = nt.ModelBuilder()
+        sc.replicate(env, n)
+        sc.add_ground_plane()
+        return sc.finalize(device=device)
+
+    nt, model, o = _setup(scene, 13)
+    E = 13
+    qd = model.body_qd.reshape(E, 3, 6)
+    qd[:, 0, 0] = 0.5   # the platform slides along +x ...
+    qd[:, 0, 5] = 0.3   # ... and yaws
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=3)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc, c = o.contacts(), o.control()
+    dragged = False
+    for _ in range(40):
+        s0.body_q, s0.body_qd = os0.body_q, os0.body_qd
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, None, contacts, 2e-3)
+        os0.body_f[:] = 0
+        pairs, _, _ = o.collide(os0.body_q, oc)
+        o.xpbd_step(os0, os1, c, oc, 2e-3, iterations=3)
+        assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+        assert _rel(s1.body_qd.cpu().numpy(), os1.body_qd) <= 3e-4
+        # the platform itself is passed through untouched
+        assert np.array_equal(os1.body_q.reshape(E, 3, 7)[:, 0], os0.body_q.reshape(E, 3, 7)[:, 0])
+        dragged = dragged or bool(np.any(os1.body_qd.reshape(E, 3, 6)[:, 1, 0] > 0.05))
+        os0, os1 = os1, os0
+    assert dragged  # friction against the moving platform accelerated the box
