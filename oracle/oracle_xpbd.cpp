@@ -912,3 +912,17 @@ extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s
         sts(s_out->body_qd, tid, lds(s_in->body_qd, tid));
     }
 }
+
+// substeps x { clear_forces; collide; xpbd step; swap } entirely in C (bench.py's cpu_baseline leg: one foreign call per
+// env shard, so host threads scale without Python in the loop).  The result is in s0 for even substeps, s1 for odd.
+extern "C" void o_xpbd_rollout(const o_model* m, const o_xpbd_params* p, o_state* s0, o_state* s1, const o_control* c,
+                               o_contacts* contacts, float dt, int substeps) {
+    o_state* a = s0;
+    o_state* b = s1;
+    for (int s = 0; s < substeps; ++s) {
+        std::fill(a->body_f, a->body_f + 6 * m->body_count, 0.0f);
+        o_collide(m, a->body_q, O_BP_EXPLICIT, contacts, nullptr, 0, nullptr, nullptr);
+        o_xpbd_step(m, p, a, b, c, contacts, dt);
+        std::swap(a, b);
+    }
+}

@@ -249,6 +249,18 @@ class Oracle:
         self.L.o_xpbd_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
                            C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))
 
+    def xpbd_rollout(self, s0: OracleState, s1: OracleState, control, contacts, dt, substeps, **params):
+        """substeps x {clear_forces; collide; xpbd step; swap} in one foreign call; returns the state holding the result."""
+        p = o_xpbd_params(params.get("iterations", 2), params.get("joint_linear_relaxation", 0.7),
+                          params.get("joint_angular_relaxation", 0.4), params.get("joint_linear_compliance", 0.0),
+                          params.get("joint_angular_compliance", 0.0), params.get("rigid_contact_relaxation", 0.8),
+                          int(params.get("rigid_contact_con_weighting", True)), params.get("angular_damping", 0.0),
+                          int(params.get("enable_restitution", False)))
+        a, b = s0.struct, s1.struct
+        self.L.o_xpbd_rollout(C.byref(self.om.struct), C.byref(p), C.byref(a), C.byref(b), C.byref(control),
+                              C.byref(contacts.struct), C.c_float(dt), int(substeps))
+        return s1 if substeps % 2 else s0
+
     def semi_implicit_step(self, s_in: OracleState, s_out: OracleState, control, contacts, dt, angular_damping=0.05,
                            friction_smoothing=1.0, joint_attach_ke=1.0e4, joint_attach_kd=1.0e2):
         p = o_semi_implicit_params(angular_damping, friction_smoothing, joint_attach_ke, joint_attach_kd, 0)
