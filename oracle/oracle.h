@@ -76,6 +76,9 @@ typedef struct {
     const int32_t* shape_mesh_count;    /* [S] */
     const float* shape_collision_aabb_lower; /* [S][3] (builder.py:11575-11612) */
     const float* shape_collision_aabb_upper; /* [S][3] */
+    /* explicitly excluded shape pairs, canonical (min, max), lexicographically sorted (broad_phase_common.py:132-162) */
+    int filter_pair_count;
+    const int32_t* shape_collision_filter_pairs; /* [F][2] */
 } o_model;
 
 typedef struct {

@@ -519,8 +519,18 @@ static void broadphase_explicit(const o_model* m, const float* lo, const float* 
 }
 
 // broad_phase_nxn.py:132-218 driven by precompute_world_map (broad_phase_common.py:271-388).
-// NOTE: no explicit filter-pair list is modelled (oracle models pass filters through collision groups /
-// shape_contact_pairs); tests compare NXN and EXPLICIT only on scenes where the two coincide.
+// is_pair_excluded: binary search in the sorted exclusion list (broad_phase_common.py:132-162)
+static bool is_pair_excluded(const o_model* m, int s1, int s2) {
+    int low = 0, high = m->filter_pair_count - 1;
+    while (low <= high) {
+        int mid = (low + high) >> 1;
+        int a = m->shape_collision_filter_pairs[2 * mid], b = m->shape_collision_filter_pairs[2 * mid + 1];
+        if (a == s1 && b == s2) return true;
+        if (s1 < a || (s1 == a && s2 < b)) high = mid - 1;
+        else low = mid + 1;
+    }
+    return false;
+}
 static void broadphase_nxn(const o_model* m, const float* lo, const float* hi, std::vector<int>& pairs) {
     const int S = m->shape_count;
     std::vector<int> shared, worlds;
@@ -553,6 +563,7 @@ static void broadphase_nxn(const o_model* m, const float* lo, const float* hi, s
                 if (w1 == -1 && w2 == -1 && !dedicated) continue;
                 if (!test_world_and_group_pair(w1, w2, m->shape_collision_group[s1], m->shape_collision_group[s2])) continue;
                 if (check_aabb_overlap(ld3(lo, s1), ld3(hi, s1), ld3(lo, s2), ld3(hi, s2))) {
+                    if (m->filter_pair_count > 0 && is_pair_excluded(m, s1, s2)) continue;
                     pairs.push_back(s1);
                     pairs.push_back(s2);
                 }

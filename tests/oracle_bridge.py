@@ -36,7 +36,7 @@ class o_model(C.Structure):
         ("shape_material_ka", _f), ("shape_material_mu", _f), ("shape_material_mu_torsional", _f),
         ("shape_material_mu_rolling", _f), ("shape_material_restitution", _f), ("shape_contact_pairs", _i), ("joint_ancestor", _i),
         ("mesh_points", _f), ("shape_mesh_start", _i), ("shape_mesh_count", _i), ("shape_collision_aabb_lower", _f),
-        ("shape_collision_aabb_upper", _f),
+        ("shape_collision_aabb_upper", _f), ("filter_pair_count", C.c_int), ("shape_collision_filter_pairs", _i),
     ]
 
 
@@ -154,6 +154,9 @@ class OracleModel:
         m.shape_mesh_count = i32("shape_mesh_count")
         m.shape_collision_aabb_lower = f32("shape_collision_aabb_lower")
         m.shape_collision_aabb_upper = f32("shape_collision_aabb_upper")
+        fp = np.asarray(sorted(getattr(model, "shape_collision_filter_pairs", [])), dtype=np.int32).reshape(-1, 2)
+        m.filter_pair_count = len(fp)
+        m.shape_collision_filter_pairs = i32("shape_collision_filter_pairs", fp)
         self.struct = m
 
 
