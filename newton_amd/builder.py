@@ -697,6 +697,7 @@ class ModelBuilder:
         ends = list(self.articulation_start[1:]) + [J]
         m.articulation_end = arr(ends if m.articulation_count else [], i32, (m.articulation_count,))
         m.articulation_world = arr(self.articulation_world, i32, (m.articulation_count,))
+        m.articulation_label = list(self.articulation_label)
 
         m.shape_transform = arr(self.shape_transform, f32, (S, 7))
         m.shape_body = arr(self.shape_body, i32, (S,))

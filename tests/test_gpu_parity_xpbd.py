@@ -363,3 +363,30 @@ def test_kinematic_platform_stepwise():
         dragged = dragged or bool(np.any(os1.body_qd.reshape(E, 3, 6)[:, 1, 0] > 0.05))
         os0, os1 = os1, os0
     assert dragged  # friction against the moving platform accelerated the box
+
+
+def test_articulation_view_device():
+    """ArticulationView on a device state: getters are strided views of the env-major buffers (no copy), masked setters and
+    masked FK only touch the selected worlds, and the result matches the host implementation."""
+    import torch
+    from newton_amd.selection import ArticulationView
+    from scenes import quadruped_scene
+
+    nt, model, _ = _setup(quadruped_scene, 70)
+    host = quadruped_scene(70)
+    view, hview = ArticulationView(model, "*"), ArticulationView(host, "*")
+    s, hs = model.state(), host.state()
+    q = view.get_dof_positions(s)
+    assert q.shape == (70, 19) and q.data_ptr() == s._soa["joint_q"].data_ptr()  # a view, not a copy
+    rng = np.random.default_rng(0)
+    new_q = hview.get_dof_positions(hs).copy()
+    new_q[:, 7:] += rng.normal(0, 0.2, size=(70, 12)).astype(np.float32)
+    mask = rng.random(70) < 0.4
+    view.set_dof_positions(s, new_q, mask=mask)
+    hview.set_dof_positions(hs, new_q, mask=mask)
+    assert np.array_equal(view.get_dof_positions(s).cpu().numpy(), hview.get_dof_positions(hs))
+    view.eval_fk(s, mask=mask)
+    hview.eval_fk(hs, mask=mask)
+    assert np.max(np.abs(s.body_q.cpu().numpy() - hs.body_q)) <= 1e-5
+    assert view.get_link_transforms(s).shape == (70, 13, 7)
+    assert torch.equal(view.get_root_transforms(s), view.get_dof_positions(s)[:, :7])

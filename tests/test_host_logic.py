@@ -168,3 +168,27 @@ def test_ground_plane_first_is_accepted():
     assert t.shape_local0 == 1 and t.ns == 2 and t.ng == 1 and t.env_count == 4
     # Newton ids: ground 0 < locals, so the ground (template index ns + 0 = 2) is the pair's first shape
     assert sorted(zip(t.pair_a.tolist(), t.pair_b.tolist())) == [(0, 1), (2, 0), (2, 1)]
+
+
+def test_articulation_view_host():
+    """newton.selection.ArticulationView subset: per-world getters / masked setters / masked FK on a host model."""
+    from newton_amd.selection import ArticulationView
+
+    model = quadruped_scene(4, seed=2)
+    view = ArticulationView(model, "*")
+    assert view.count == 4 and view.joint_dof_count == 18 and view.joint_coord_count == 19 and view.link_count == 13
+    assert view.is_floating_base
+    s = model.state()
+    assert view.get_root_transforms(s).shape == (4, 7) and view.get_link_transforms(s).shape == (4, 13, 7)
+    q = view.get_dof_positions(s).copy()
+    q[:, 7:] += 0.1
+    before = s.body_q.copy()
+    view.set_dof_positions(s, q, mask=[True, False, True, False])
+    got = view.get_dof_positions(s)
+    assert np.allclose(got[0, 7:], q[0, 7:]) and np.allclose(got[1, 7:], q[1, 7:] - 0.1)
+    view.eval_fk(s, mask=[True, False, True, False])
+    moved = np.abs(s.body_q - before).reshape(4, -1).max(axis=1)
+    assert moved[0] > 1e-3 and moved[2] > 1e-3 and moved[1] == 0.0 and moved[3] == 0.0
+    ctrl = model.control()
+    view.set_dof_forces(ctrl, np.ones((4, 18), dtype=np.float32), mask=[False, True, False, False])
+    assert np.array_equal(view.get_dof_forces(ctrl).sum(axis=1), [0.0, 18.0, 0.0, 0.0])
