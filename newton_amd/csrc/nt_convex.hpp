@@ -35,6 +35,18 @@ NT_DI vec2 operator+(vec2 a, vec2 b) { return vec2(a.x + b.x, a.y + b.y); }
 NT_DI vec2 operator*(float s, vec2 a) { return vec2(a.x * s, a.y * s); }
 NT_DEV float length_sq2(vec2 a) { return a.x * a.x + a.y * a.y; }
 
+// strided view of a 10 x vec2 polygon buffer in LDS: element i = (base[2 i stride], base[(2 i + 1) stride])
+struct PolyRef {
+    float* base;
+    int stride;
+    NT_DI vec2 get(int i) const { return vec2(base[(2 * i) * stride], base[(2 * i + 1) * stride]); }
+    NT_DI void set(int i, vec2 v) const {
+        base[(2 * i) * stride] = v.x;
+        base[(2 * i + 1) * stride] = v.y;
+    }
+    NT_DI PolyRef operator+(int k) const { return PolyRef{base + 2 * k * stride, stride}; }
+};
+
 struct Vert {
     vec3 B, BtoA;
 };
@@ -623,26 +635,26 @@ NT_DEV vec2 intersection_point(vec2 s0, vec2 s1, vec2 a, vec2 b) {
     float t = fabsf(sa) / fabsf(sa - sb);
     return (1.0f - t) * a + t * b;
 }
-NT_DEV void insert_vec2(vec2* arr, int arr_count, int index, vec2 element) {
+NT_DEV void insert_vec2(PolyRef arr, int arr_count, int index, vec2 element) {
     int i = arr_count;
     while (i > index) {
-        arr[i] = arr[i - 1];
+        arr.set(i, arr.get(i - 1));
         i -= 1;
     }
-    arr[index] = element;
+    arr.set(index, element);
 }
 // multicontact.py:311-381
-NT_DEV int trim_in_place(vec2 s0, vec2 s1, vec2* loop, int loop_count) {
+NT_DEV int trim_in_place(vec2 s0, vec2 s1, PolyRef loop, int loop_count) {
     if (loop_count < 3) return loop_count;
     vec2 intersection_a, intersection_b;
     int change_a = -1, change_b = -1;
     bool keep = false;
-    bool prev_outside = signed_area(s0, s1, loop[0]) <= 0.0f;
+    bool prev_outside = signed_area(s0, s1, loop.get(0)) <= 0.0f;
     for (int i = 0; i < loop_count; ++i) {
         int next_idx = (i + 1) % loop_count;
-        bool outside = signed_area(s0, s1, loop[next_idx]) <= 0.0f;
+        bool outside = signed_area(s0, s1, loop.get(next_idx)) <= 0.0f;
         if (outside != prev_outside) {
-            vec2 ip = intersection_point(s0, s1, loop[i], loop[next_idx]);
+            vec2 ip = intersection_point(s0, s1, loop.get(i), loop.get(next_idx));
             if (change_a < 0) {
                 change_a = i;
                 keep = !prev_outside;
@@ -662,7 +674,7 @@ NT_DEV int trim_in_place(vec2 s0, vec2 s1, vec2* loop, int loop_count) {
         while (i < loop_count) {
             if (keep) {
                 loop_indexer += 1;
-                loop[loop_indexer] = loop[i];
+                loop.set(loop_indexer, loop.get(i));
             }
             if (i == change_a || i == change_b) {
                 vec2 pt = i == change_a ? intersection_a : intersection_b;
@@ -675,7 +687,7 @@ NT_DEV int trim_in_place(vec2 s0, vec2 s1, vec2* loop, int loop_count) {
                     loop_count += 1;
                 } else {
                     loop_indexer += 1;
-                    loop[loop_indexer] = pt;
+                    loop.set(loop_indexer, pt);
                 }
                 keep = !keep;
             }
@@ -689,75 +701,75 @@ NT_DEV int trim_in_place(vec2 s0, vec2 s1, vec2* loop, int loop_count) {
     }
     return new_loop_count;
 }
-// multicontact.py:384-484; trim_poly aliases loop[5..9]
-NT_DEV int trim_all_in_place(vec2* trim_poly, int trim_poly_count, vec2* loop, int loop_count) {
+// multicontact.py:384-484; trim_poly aliases loop.get(5..9)
+NT_DEV int trim_all_in_place(PolyRef trim_poly, int trim_poly_count, PolyRef loop, int loop_count) {
     if (trim_poly_count <= 1) return imin(1, loop_count);
     const float move_distance = 1e-5f;
     if (trim_poly_count == 2) {
-        vec2 p0 = trim_poly[0], p1 = trim_poly[1];
+        vec2 p0 = trim_poly.get(0), p1 = trim_poly.get(1);
         float dx = p1.x - p0.x, dy = p1.y - p0.y;
         float dir_len = sqrtf(dx * dx + dy * dy);
         if (dir_len > 1e-10f) {
             float inv = 1.0f / dir_len;
             float ox = -dy * inv * move_distance, oy = dx * inv * move_distance;
-            trim_poly[0] = vec2(p0.x - ox, p0.y - oy);
-            trim_poly[1] = vec2(p1.x - ox, p1.y - oy);
-            trim_poly[2] = vec2(p1.x + ox, p1.y + oy);
-            trim_poly[3] = vec2(p0.x + ox, p0.y + oy);
+            trim_poly.set(0, vec2(p0.x - ox, p0.y - oy));
+            trim_poly.set(1, vec2(p1.x - ox, p1.y - oy));
+            trim_poly.set(2, vec2(p1.x + ox, p1.y + oy));
+            trim_poly.set(3, vec2(p0.x + ox, p0.y + oy));
             trim_poly_count = 4;
         } else {
             return imin(1, loop_count);
         }
     }
     if (loop_count == 2) {
-        vec2 p0 = loop[0], p1 = loop[1];
+        vec2 p0 = loop.get(0), p1 = loop.get(1);
         float dx = p1.x - p0.x, dy = p1.y - p0.y;
         float dir_len = sqrtf(dx * dx + dy * dy);
         if (dir_len > 1e-10f) {
             float inv = 1.0f / dir_len;
             float ox = -dy * inv * move_distance, oy = dx * inv * move_distance;
-            loop[0] = vec2(p0.x - ox, p0.y - oy);
-            loop[1] = vec2(p1.x - ox, p1.y - oy);
-            loop[2] = vec2(p1.x + ox, p1.y + oy);
-            loop[3] = vec2(p0.x + ox, p0.y + oy);
+            loop.set(0, vec2(p0.x - ox, p0.y - oy));
+            loop.set(1, vec2(p1.x - ox, p1.y - oy));
+            loop.set(2, vec2(p1.x + ox, p1.y + oy));
+            loop.set(3, vec2(p0.x + ox, p0.y + oy));
             loop_count = 4;
         } else {
             return imin(1, loop_count);
         }
     }
     int current = loop_count;
-    vec2 trim_poly_0 = trim_poly[0];
+    vec2 trim_poly_0 = trim_poly.get(0);
     for (int i = 0; i < trim_poly_count; ++i) {
-        vec2 s0 = trim_poly[i];
-        vec2 s1 = i == trim_poly_count - 1 ? trim_poly_0 : trim_poly[i + 1];
+        vec2 s0 = trim_poly.get(i);
+        vec2 s1 = i == trim_poly_count - 1 ? trim_poly_0 : trim_poly.get(i + 1);
         current = trim_in_place(s0, s1, loop, current);
     }
     return current;
 }
 // multicontact.py:487-580
-NT_DEV void approx_max_quad(const vec2* hull, int n, int out[4]) {
+NT_DEV void approx_max_quad(PolyRef hull, int n, int out[4]) {
     int p1 = 0, p3 = 1;
-    vec2 diff = hull[p1] - hull[p3];
+    vec2 diff = hull.get(p1) - hull.get(p3);
     float max_dist_sq = diff.x * diff.x + diff.y * diff.y;
     const float tie = 1.0e-3f;
     int j = 1;
     for (int i = 0; i < n; ++i) {
-        vec2 hi = hull[i], hi1 = hull[(i + 1) % n];
+        vec2 hi = hull.get(i), hi1 = hull.get((i + 1) % n);
         while (true) {
-            float area_j1 = signed_area(hi, hi1, hull[(j + 1) % n]);
-            float area_j = signed_area(hi, hi1, hull[j]);
+            float area_j1 = signed_area(hi, hi1, hull.get((j + 1) % n));
+            float area_j = signed_area(hi, hi1, hull.get(j));
             if (area_j1 > area_j) j = (j + 1) % n;
             else break;
         }
-        vec2 hj = hull[j];
-        vec2 d1 = hull[i] - hj;
+        vec2 hj = hull.get(j);
+        vec2 d1 = hull.get(i) - hj;
         float ds1 = d1.x * d1.x + d1.y * d1.y;
         if (ds1 > max_dist_sq * (1.0f + tie)) {
             max_dist_sq = ds1;
             p1 = i;
             p3 = j;
         }
-        vec2 d2 = hull[(i + 1) % n] - hj;
+        vec2 d2 = hull.get((i + 1) % n) - hj;
         float ds2 = d2.x * d2.x + d2.y * d2.y;
         if (ds2 > max_dist_sq * (1.0f + tie)) {
             max_dist_sq = ds2;
@@ -767,9 +779,9 @@ NT_DEV void approx_max_quad(const vec2* hull, int n, int out[4]) {
     }
     int p2 = 0, p4 = 0;
     float max_area_1 = 0.0f, max_area_2 = 0.0f;
-    vec2 hp1 = hull[p1], hp3 = hull[p3];
+    vec2 hp1 = hull.get(p1), hp3 = hull.get(p3);
     for (int i = 0; i < n; ++i) {
-        float area = signed_area(hp1, hp3, hull[i]);
+        float area = signed_area(hp1, hp3, hull.get(i));
         if (area > max_area_1 * (1.0f + tie)) {
             max_area_1 = area;
             p2 = i;
@@ -781,19 +793,19 @@ NT_DEV void approx_max_quad(const vec2* hull, int n, int out[4]) {
     out[0] = p1; out[1] = p2; out[2] = p3; out[3] = p4;
 }
 // multicontact.py:583-620
-NT_DEV int remove_zero_length_edges(vec2* loop, int loop_count, float eps) {
+NT_DEV int remove_zero_length_edges(PolyRef loop, int loop_count, float eps) {
     if (loop_count < 2) return 0;
     int write_idx = 0;
     for (int read_idx = 1; read_idx < loop_count; ++read_idx) {
-        vec2 diff = loop[read_idx] - loop[write_idx];
+        vec2 diff = loop.get(read_idx) - loop.get(write_idx);
         if (length_sq2(diff) > eps) {
             write_idx += 1;
-            loop[write_idx] = loop[read_idx];
+            loop.set(write_idx, loop.get(read_idx));
         }
     }
     int new_count;
     if (write_idx > 0) {
-        vec2 diff = loop[write_idx] - loop[0];
+        vec2 diff = loop.get(write_idx) - loop.get(0);
         new_count = length_sq2(diff) < eps ? write_idx : write_idx + 1;
     } else {
         new_count = write_idx + 1;
@@ -801,10 +813,10 @@ NT_DEV int remove_zero_length_edges(vec2* loop, int loop_count, float eps) {
     if (new_count < 2) new_count = 0;
     return new_count;
 }
-NT_DEV bool add_avoid_duplicates(vec2* arr, int& count, vec2 v, float eps) {
-    if (count > 0 && length_sq2(arr[0] - v) < eps) return false;
-    if (count > 1 && length_sq2(arr[count - 1] - v) < eps) return false;
-    arr[count] = v;
+NT_DEV bool add_avoid_duplicates(PolyRef arr, int& count, vec2 v, float eps) {
+    if (count > 0 && length_sq2(arr.get(0) - v) < eps) return false;
+    if (count > 1 && length_sq2(arr.get(count - 1) - v) < eps) return false;
+    arr.set(count, v);
     count += 1;
     return true;
 }
@@ -829,18 +841,30 @@ struct ContactOut {
     float distance;
 };
 
-// contacts admitted for one pair (world frame, before the world->body conversion of the writer)
+// contacts admitted for one pair (world frame, before the world->body conversion of the writer); named fields with
+// select-style access keep the record in registers
 struct ConvexContacts {
-    vec3 center[5];
-    float distance[5];
+    vec3 c0, c1, c2, c3, c4;
+    float d0, d1, d2, d3, d4;
     vec3 normal;  // shared by every contact of the pair (world frame, as generated)
     int count;
+    NT_DI void push(vec3 c, float d) {
+        if (count == 0) { c0 = c; d0 = d; }
+        else if (count == 1) { c1 = c; d1 = d; }
+        else if (count == 2) { c2 = c; d2 = d; }
+        else if (count == 3) { c3 = c; d3 = d; }
+        else if (count == 4) { c4 = c; d4 = d; }
+        count += 1;
+    }
+    NT_DI vec3 center(int i) const { return i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : (i == 3 ? c3 : c4))); }
+    NT_DI float distance(int i) const { return i == 0 ? d0 : (i == 1 ? d1 : (i == 2 ? d2 : (i == 3 ? d3 : d4))); }
 };
 
 struct PairCtx {
     Geom ga, gb;  // geometry as seen by GJK/MPR (sphere/capsule radii shrunk to 1e-4)
     float radius_eff_a, radius_eff_b, margin_a, margin_b, contact_gap;
     ConvexContacts* out;
+    PolyRef poly;  // LDS scratch for the manifold clipper
 };
 
 // collision_core.py:173-278
@@ -909,12 +933,8 @@ NT_DEV void emit(PairCtx& P, ContactOut c, vec3 pos_a, quat rot_a, vec3 pos_b, q
     float d = distance - total_separation_needed;
     if (d > P.contact_gap) return;
     ConvexContacts& o = *P.out;
-    if (o.count < 5) {
-        o.center[o.count] = c.center;
-        o.distance[o.count] = c.distance;
-        o.normal = c.normal;
-    }
-    o.count += 1;
+    o.normal = c.normal;
+    o.push(c.center, c.distance);
 }
 
 // multicontact.py:758-956 (+ extract_4_point_contact_manifolds :641-756)
@@ -926,8 +946,10 @@ NT_DEV int build_manifold(PairCtx& P, quat orientation_a, vec3 position_a_world,
     orthonormal_basis(normal, tangent_a, tangent_b);
     PlaneTracker tracker_a, tracker_b;
     vec3 center = 0.5f * (p_a + p_b);
-    vec2 b_buffer[10];
-    vec2* a_buffer = b_buffer + 5;
+    // 10-vertex polygon scratch (a aliases b[5..9], multicontact.py:841-843) lives in LDS: a dynamically indexed private
+    // array would be placed in scratch (HBM-backed) memory
+    PolyRef b_buffer = P.poly;
+    PolyRef a_buffer = b_buffer + 5;
     vec3 local_normal_b = quat_rotate_inv(rel_q, -normal);
     vec3 local_ta_b = quat_rotate_inv(rel_q, -tangent_a);
     vec3 local_tb_b = quat_rotate_inv(rel_q, -tangent_b);
@@ -969,9 +991,10 @@ NT_DEV int build_manifold(PairCtx& P, quat orientation_a, vec3 position_a_world,
                     approx_max_quad(b_buffer, loop_count, result);
                     loop_count = 4;
                 }
+                const int r0 = result[0], r1 = result[1], r2 = result[2], r3 = result[3];
                 for (int i = 0; i < loop_count; ++i) {
-                    int ia = result[i];
-                    vec3 p_local = b_buffer[ia].x * tangent_a + b_buffer[ia].y * tangent_b + center;
+                    int ia = i == 0 ? r0 : (i == 1 ? r1 : (i == 2 ? r2 : r3));
+                    vec3 p_local = b_buffer.get(ia).x * tangent_a + b_buffer.get(ia).y * tangent_b + center;
                     vec3 a = ray_plane_intersection(p_local, normal, projector_a.plane_d, projector_a.normal);
                     vec3 b = ray_plane_intersection(p_local, normal, projector_b.plane_d, projector_b.normal);
                     vec3 contact_point_local = 0.5f * (a + b);
@@ -1004,10 +1027,11 @@ NT_DEV int build_manifold(PairCtx& P, quat orientation_a, vec3 position_a_world,
 // compute_gjk_mpr_contacts + solve_convex_multi_contact (collision_core.py:325-452, collision_convex.py:110-232).
 // Shapes arrive type-sorted (type_a <= type_b) with world transforms; contacts come back in the reference's emission order.
 NT_DEV void convex_pair(const Geom& geom_a, const Geom& geom_b, xform Xa, const xform& Xb, float margin_a, float margin_b,
-                        float rigid_gap, vec3 aabb_lower_b, vec3 aabb_upper_b, ConvexContacts& out) {
+                        float rigid_gap, vec3 aabb_lower_b, vec3 aabb_upper_b, PolyRef poly, ConvexContacts& out) {
     out.count = 0;
     PairCtx P;
     P.out = &out;
+    P.poly = poly;
     P.ga = geom_a;
     P.gb = geom_b;
     P.margin_a = margin_a; P.margin_b = margin_b;

@@ -98,8 +98,9 @@ NT_DI void plane_ellipsoid(vec3 n, vec3 plane_pos, vec3 c, const mat33& rot, vec
 // keeps the (up to) 4 deepest corners, tracking the worst kept contact by index
 NT_DI void plane_box(vec3 n, vec3 plane_pos, vec3 c, const mat33& rot, vec3 size, float margin, Contacts4& out) {
     float center_dist = dot(c - plane_pos, n);
-    float dist[4] = {NT_MAXVAL, NT_MAXVAL, NT_MAXVAL, NT_MAXVAL};
-    vec3 pos[4];
+    // the kept set lives directly in `out` (select-style set / dist keep it in registers; a dynamically indexed
+    // private array would go to scratch memory)
+    out = Contacts4();
     int ncontact = 0, worst_idx = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -110,21 +111,17 @@ NT_DI void plane_box(vec3 n, vec3 plane_pos, vec3 c, const mat33& rot, vec3 size
         if (cdist > margin) continue;
         vec3 cpos = corner + c - 0.5f * n * cdist;
         if (ncontact < 4) {
-            dist[ncontact] = cdist;
-            pos[ncontact] = cpos;
-            if (ncontact == 0 || cdist > dist[worst_idx]) worst_idx = ncontact;
+            out.set(ncontact, cdist, cpos);
+            if (ncontact == 0 || cdist > out.dist(worst_idx)) worst_idx = ncontact;
             ncontact += 1;
-        } else if (cdist < dist[worst_idx]) {
-            dist[worst_idx] = cdist;
-            pos[worst_idx] = cpos;
+        } else if (cdist < out.dist(worst_idx)) {
+            out.set(worst_idx, cdist, cpos);
             worst_idx = 0;
-            if (dist[1] > dist[worst_idx]) worst_idx = 1;
-            if (dist[2] > dist[worst_idx]) worst_idx = 2;
-            if (dist[3] > dist[worst_idx]) worst_idx = 3;
+            if (out.d1 > out.dist(worst_idx)) worst_idx = 1;
+            if (out.d2 > out.dist(worst_idx)) worst_idx = 2;
+            if (out.d3 > out.dist(worst_idx)) worst_idx = 3;
         }
     }
-    out.d0 = dist[0]; out.d1 = dist[1]; out.d2 = dist[2]; out.d3 = dist[3];
-    out.p0 = pos[0]; out.p1 = pos[1]; out.p2 = pos[2]; out.p3 = pos[3];
     out.normal = n;
 }
 

@@ -23,12 +23,18 @@ from newton_amd import _lib  # noqa: E402
 from scenes import quadruped_scene  # noqa: E402
 
 lib = _lib.load()
-model = quadruped_scene(4096, device="cuda:0", seed=1)
+BOX = len(sys.argv) > 1 and sys.argv[1] == "box_stack"
+if BOX:
+    from scenes import box_stack_scene  # noqa: E402
+
+    model = box_stack_scene(int(sys.argv[2]) if len(sys.argv) > 2 else 256, device="cuda:0", seed=1)
+else:
+    model = quadruped_scene(4096, device="cuda:0", seed=1)
 s0, s1 = model.state(), model.state()
 pipe = nt.CollisionPipeline(model)
 contacts = pipe.contacts()
 FS = len(sys.argv) > 1 and sys.argv[1] == "featherstone"
-solver = nt.solvers.SolverFeatherstone(model) if FS else nt.solvers.SolverXPBD(model)
+solver = nt.solvers.SolverFeatherstone(model) if FS else nt.solvers.SolverXPBD(model, iterations=4 if BOX else 2)
 for _ in range(100):
     solver.rollout(s0, s1, None, contacts, 1e-3, 10)
 torch.cuda.synchronize()
