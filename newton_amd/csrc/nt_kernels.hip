@@ -87,7 +87,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     L.bd = o; o += 9 * m.nb;
     L.u = o;
     L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
-    int coll = 13 * m.ns + m.np;
+    int coll = 13 * m.ns + m.np + 20 * (m.np - m.np_analytic);  // + manifold polygon scratch of the convex pairs
     L.bf = L.u; L.jf = L.bf + 6 * m.nb;
     int forces = 6 * m.nb + 12 * m.nj;
     L.jl = L.u; L.ja = L.jl + 12 * m.nj;
@@ -553,14 +553,19 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
                     gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +
                                         vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)));
                 }
-                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, cc);
+                // polygon scratch: 20 rows per convex pair in the part of the scratch union that the collide phases do not
+                // use (behind shape transforms / AABBs / pair counts)
+                PolyRef poly;
+                poly.base = &c.lds[(c.L.pc + m.np + 20 * (p - m.np_analytic)) * EPB + c.e];
+                poly.stride = EPB;
+                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
                 float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
                 vec3 n = normalize(cc.normal);
                 nvalid = cc.count < cpp ? cc.count : cpp;
                 for (int i = 0; i < cpp; ++i) {
                     if (i < nvalid) {
-                        write_contact_slot(c, slot + i, sa, sb, cc.center[i], n, cc.distance[i], ra, rb, margin_a, margin_b);
+                        write_contact_slot(c, slot + i, sa, sb, cc.center(i), n, cc.distance(i), ra, rb, margin_a, margin_b);
                     } else {
                         size_t gi = (size_t)(slot + i) * c.ES + c.env;
                         ct.shape0[gi] = -1;
