@@ -146,6 +146,7 @@ void o_semi_implicit_step(const o_model* m, const o_semi_implicit_params* p, o_s
                           const o_control* c, const o_contacts* contacts /*nullable*/, float dt);
 void o_featherstone_step(const o_model* m, const o_featherstone_params* p, o_state* s_in, o_state* s_out,
                          const o_control* c, const o_contacts* contacts /*nullable*/, float dt);
+void o_featherstone_probe_H(float* out, int cap); /* test probe: H of articulation 0 from the next step */
 /* collide: returns number of candidate pairs; candidate pairs written to out_pairs (cap pairs) if non-null */
 int o_collide(const o_model* m, const float* body_q, int broad_phase, o_contacts* contacts,
               int32_t* out_pairs, int out_pairs_cap, float* out_aabb_lower, float* out_aabb_upper);

@@ -305,6 +305,16 @@ vec3 free_joint_com_offset(const o_model* m, int joint_id, const float* body_q) 
 
 }  // namespace
 
+// test probe: when armed, the next step copies the joint-space inertia H of articulation 0 (before the armature is added
+// and before factorisation) into the caller's buffer -- pinned against the closed forms of
+// newton/tests/test_jacobian_mass_matrix.py:413-470
+static float* g_probe_H = nullptr;
+static int g_probe_cap = 0;
+extern "C" void o_featherstone_probe_H(float* out, int cap) {
+    g_probe_H = out;
+    g_probe_cap = cap;
+}
+
 extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_params* prm, o_state* s_in, o_state* s_out,
                                     const o_control* c, const o_contacts* contacts, float dt) {
     const int B = m->body_count, J = m->joint_count, D = m->dof_count;
@@ -481,6 +491,10 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
                 for (int k = 0; k < rows; ++k) sum += Jm[size_t(k) * n + i] * P[size_t(k) * n + j];
                 H[size_t(i) * n + j] = sum;
             }
+        if (a == 0 && g_probe_H) {
+            for (int i = 0; i < n * n && i < g_probe_cap; ++i) g_probe_H[i] = H[i];
+            g_probe_H = nullptr;
+        }
         const float* R = m->joint_armature + dof_start;
         for (int j = 0; j < n; ++j) {
             float s = H[size_t(j) * n + j] + R[j];

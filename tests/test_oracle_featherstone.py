@@ -140,3 +140,47 @@ def test_quadruped_contact_drop_stays_sane(oracle_lib):
     assert np.all(z > 0.0) and np.all(z < 1.0)
     bq, _ = o.eval_fk(s0.joint_q, s0.joint_qd)
     assert np.max(np.abs(bq - s0.body_q)) < 1e-5
+
+
+def _probe_H(model, n):
+    import ctypes as C
+
+    o = Oracle(model)
+    H = np.zeros(n * n, dtype=np.float32)
+    o.L.o_featherstone_probe_H(H.ctypes.data_as(C.POINTER(C.c_float)), n * n)
+    s0, s1 = OracleState(model), OracleState(model)
+    o.featherstone_step(s0, s1, o.control(), None, 1e-3)
+    return H.reshape(n, n).astype(np.float64)
+
+
+def test_mass_matrix_fixed_base_pendulum_closed_form(oracle_lib):
+    """test_jacobian_mass_matrix.py:413-439: H = I_zz + m L^2 for a fixed-base z-revolute pendulum."""
+    mass, length, izz = 2.0, 0.75, 0.2
+    b = nt.ModelBuilder(gravity=0.0)
+    body = b.add_link(mass=mass, inertia=np.diag([0.1, 0.15, izz]))
+    j = b.add_joint_revolute(-1, body, axis=(0, 0, 1), child_xform=[-length, 0.0, 0.0, *I4], armature=0.0)
+    b.add_articulation([j])
+    H = _probe_H(b.finalize(), 1)
+    assert abs(H[0, 0] - (izz + mass * length ** 2)) < 1e-6 * (izz + mass * length ** 2) + 1e-6
+
+
+def test_mass_matrix_floating_base_pendulum_closed_form(oracle_lib):
+    """test_jacobian_mass_matrix.py:442-470: 7x7 H of a free base with one revolute child at identity pose."""
+    base_mass, child_mass, length = 3.0, 2.0, 0.6
+    base_inertia, child_inertia = (0.4, 0.5, 0.6), (0.2, 0.25, 0.3)
+    b = nt.ModelBuilder(gravity=0.0)
+    base = b.add_link(mass=base_mass, inertia=np.diag(base_inertia))
+    child = b.add_link(mass=child_mass, inertia=np.diag(child_inertia))
+    jf = b.add_joint_free(base)
+    jr = b.add_joint_revolute(base, child, axis=(0, 0, 1), child_xform=[-length, 0.0, 0.0, *I4], armature=0.0)
+    b.add_articulation([jf, jr])
+    H = _probe_H(b.finalize(), 7)
+    T = np.zeros((6, 7))
+    T[0, 0] = T[1, 1] = T[2, 2] = 1.0
+    T[2, 4], T[1, 5], T[1, 6] = -length, length, length
+    T[3, 3] = T[4, 4] = T[5, 5] = 1.0
+    T[5, 6] = 1.0
+    expected = T.T @ np.diag([child_mass] * 3 + list(child_inertia)) @ T
+    expected[np.arange(3), np.arange(3)] += base_mass
+    expected[np.arange(3, 6), np.arange(3, 6)] += np.asarray(base_inertia)
+    assert np.allclose(H, expected, rtol=1e-6, atol=1e-6)
