@@ -60,6 +60,7 @@ struct LdsLayout {
     int cf, ctq, ctqd; // control: joint_f [nd], joint_target_q [ntq], joint_target_qd [nd]
     int grav;          // gravity [3]
     int bd;            // body-derived [9][nb]: world COM (3) + world-frame inverse inertia R I^-1 R^T (xx xy xz yy yz zz)
+    int pm;            // live contacts per pair [np] (written by the collide phase, read by the fused solver phases)
     // scratch union
     int u;
     int sx, sa, pc;    // collide: shape world xform [7][ns], aabb [6][ns], per-pair contact count [np]
@@ -85,6 +86,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     L.ctqd = o; o += m.nd;
     L.grav = o; o += 3;
     L.bd = o; o += 9 * m.nb;
+    L.pm = o; o += m.np;
     L.u = o;
     L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
     int coll = 13 * m.ns + m.np + 20 * (m.np - m.np_analytic);  // + manifold polygon scratch of the convex pairs
@@ -573,6 +575,7 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
                     }
                 }
                 c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+                c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
                 return;
             }
         }
@@ -582,7 +585,10 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
         ct.shape0[gi] = -1;
         ct.shape1[gi] = -1;
     }
-    if (k == 0) c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+    if (k == 0) {
+        c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+        c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
+    }
 }
 template <int EPB, bool CVX>
 NT_DI void phase_pairs(const Ctx<EPB>& c) {
@@ -781,7 +787,9 @@ NT_DI float angular_correction(float err, float derr, float wq_a, float wq_b, fl
 // ------------------------------------------------------------------------------------------------
 // XPBD: solve_body_contact_positions (xpbd/kernels.py:2164-2399); one lane per contact slot.
 // ------------------------------------------------------------------------------------------------
-template <int EPB>
+// FUSED: the collide phase of the same kernel left the live-contact count of every pair in LDS, and the (type-sorted)
+// shape order of a pair is static, so neither the liveness test nor the shape ids need the global contact arrays.
+template <int EPB, bool FUSED>
 NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
@@ -791,13 +799,28 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
     float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
     vec3 lin_delta_a, ang_delta_a, lin_delta_b, ang_delta_b;
 
-    size_t gi = (size_t)slot * c.ES + c.env;
-    int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
-    bool live = gid_a != gid_b;
+    bool live;
     int shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
+    if (FUSED) {
+        const int p = slot / cpp, k = slot - p * cpp;
+        live = k < (int)c.l(c.L.pm, 0, m.np, p);
+        if (live) {
+            shape_a = c.T.pair_a[p];
+            shape_b = c.T.pair_b[p];
+            if (c.T.shape_type[shape_a] > c.T.shape_type[shape_b]) {  // narrow_phase.py:525-528
+                int t = shape_a; shape_a = shape_b; shape_b = t;
+            }
+        }
+    } else {
+        size_t gi = (size_t)slot * c.ES + c.env;
+        int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+        live = gid_a != gid_b;
+        if (live) {
+            shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
+            shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+        }
+    }
     if (live) {
-        shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
-        shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
         body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1;
         body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         live = body_a != body_b;
@@ -924,11 +947,11 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
     c.l(c.L.cw, 13, ncs, slot) = has_b;
     c.l(c.L.cw, 14, ncs, slot) = a_is_pair_a;
 }
-template <int EPB>
+template <int EPB, bool FUSED>
 NT_DI void phase_contacts(const Ctx<EPB>& c) {
     if (!c.valid) return;
     const int ncs = c.a.m.np * c.a.m.cpp;
-    for (int s = c.slot; s < ncs; s += c.nslot) contact_item(c, s);
+    for (int s = c.slot; s < ncs; s += c.nslot) contact_item<EPB, FUSED>(c, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1453,7 +1476,7 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
 }
 
 // SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
-template <int EPB>
+template <int EPB, bool FUSED>
 NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
     const int skip = c.a.debug_skip;
@@ -1470,7 +1493,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
     for (int it = 0; it < c.a.p.iterations; ++it) {
         if (c.a.has_contacts) {
-            if (!(skip & 4)) phase_contacts(c);
+            if (!(skip & 4)) phase_contacts<EPB, FUSED>(c);
             __syncthreads();
             NT_TICK(5);
             if (!(skip & 16)) phase_apply<EPB, true>(c);
@@ -1516,7 +1539,7 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_step_kernel(KArgs a
     __syncthreads();
     phase_body_derived(c);
     __syncthreads();
-    do_xpbd_step(c, false);
+    do_xpbd_step<EPB, false>(c, false);
     store_state(c, a.s_out);
 }
 
@@ -1541,7 +1564,7 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArg
     NT_TICK(0);
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(c, s == a.substeps - 1);
-        do_xpbd_step(c, true);
+        do_xpbd_step<EPB, true>(c, true);
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
     NT_TICK(9);

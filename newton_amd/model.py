@@ -315,6 +315,8 @@ class DeviceModel:
         E, ES = t.env_count, t.env_stride
 
         def soa(aos, n):  # aos [E*n, comp] -> [comp, n, ES]
+            if n == 0:  # e.g. a model without shapes or joints
+                return np.zeros((1, 1, ES), dtype=np.float32)
             aos = np.asarray(aos, dtype=np.float32).reshape(E, n, -1)
             out = np.zeros((aos.shape[2], n, ES), dtype=np.float32)
             out[:, :, :E] = aos.transpose(2, 1, 0)

@@ -99,13 +99,14 @@ def test_c_abi_exports_every_declared_symbol():
     m = _lib.nt_model()
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp = 18, 18, 4
-    # persistent rows 1282 (state 169 + body 299 + joint 182 + dof 198 + shape 260 + control 54 + gravity 3 + derived 117)
+    # persistent rows 1295 (state 169 + body 299 + joint 182 + dof 198 + shape 260 + control 54 + gravity 3 + derived 117
+    # + per-pair live counts 13)
     # + scratch max(collide 182, forces 234, joints 273, contacts 15*52 = 780, semi-implicit 78 + 156 + 780 = 1014)
-    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1282 + 1014)
+    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1295 + 1014)
     # Featherstone: generalized state 127 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1171,
     # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780)
     m.nc, m.na, m.max_art_dofs = 19, 1, 18
-    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1282 + 1171 + 1728)
+    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1295 + 1171 + 1728)
 
 
 def test_no_silent_cpu_fallback():
