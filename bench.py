@@ -77,8 +77,8 @@ def cpu_baseline(envs_per_core=256, sample_substeps=2500, max_cores=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--envs-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
