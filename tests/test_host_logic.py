@@ -193,3 +193,33 @@ def test_articulation_view_host():
     ctrl = model.control()
     view.set_dof_forces(ctrl, np.ones((4, 18), dtype=np.float32), mask=[False, True, False, False])
     assert np.array_equal(view.get_dof_forces(ctrl).sum(axis=1), [0.0, 18.0, 0.0, 0.0])
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Error behaviour of the boundary: malformed descriptors come back as negative nt_status codes (never a crash)
+    before any launch is attempted, so this runs on a GPU-less host."""
+    lib = _lib.load()
+    NT_ERR_INVALID_ARG = -1
+    m = _lib.nt_model()          # all zeros: env_count == 0
+    s = _lib.nt_state()
+    ctl = _lib.nt_control()
+    ct = _lib.nt_contacts()
+    xp = _lib.nt_xpbd_params(2, 0.7, 0.4, 0.0, 0.0, 0.8, 1, 0.0, 0)
+    cp = _lib.nt_collide_params(0, 0)
+    fp = _lib.nt_featherstone_params(0.05, 1.0)
+    sp = _lib.nt_semi_implicit_params(0.05, 1.0, 1e4, 1e2)
+    assert lib.nt_collide(C.byref(m), C.byref(s), C.byref(ct), C.byref(cp), None) == NT_ERR_INVALID_ARG
+    assert lib.nt_xpbd_step(C.byref(m), C.byref(xp), C.byref(s), C.byref(s), C.byref(ctl), None, 1e-3, 0, None) == NT_ERR_INVALID_ARG
+    assert lib.nt_xpbd_rollout(C.byref(m), C.byref(xp), C.byref(cp), C.byref(s), C.byref(s), C.byref(ctl), C.byref(ct), 1e-3, 4,
+                               None) == NT_ERR_INVALID_ARG
+    assert lib.nt_semi_implicit_step(C.byref(m), C.byref(sp), C.byref(s), C.byref(s), C.byref(ctl), None, 1e-3, 0, None) == NT_ERR_INVALID_ARG
+    assert lib.nt_featherstone_step(C.byref(m), C.byref(fp), C.byref(s), C.byref(s), C.byref(ctl), None, 1e-3, 0, None) == NT_ERR_INVALID_ARG
+    assert lib.nt_clear_forces(C.byref(m), C.byref(s), None) == NT_ERR_INVALID_ARG
+    assert lib.nt_state_reset(C.byref(m), C.byref(s), C.byref(s), None, None) == NT_ERR_INVALID_ARG
+    # a well-formed descriptor with an unaligned env_stride / bad cpp is rejected too
+    m.env_count, m.env_stride, m.nb, m.cpp = 10, 10, 1, 4
+    assert lib.nt_clear_forces(C.byref(m), C.byref(s), None) == NT_ERR_INVALID_ARG
+    m.env_stride, m.cpp = 64, 7
+    assert lib.nt_collide(C.byref(m), C.byref(s), C.byref(ct), C.byref(cp), None) == NT_ERR_INVALID_ARG
+    assert lib.nt_error_string(NT_ERR_INVALID_ARG) == b"invalid argument"
+    assert lib.nt_error_string(-3) == b"unsupported configuration"
