@@ -350,6 +350,16 @@ class ModelBuilder:
         return self.add_joint(JointType.FIXED, parent, child, parent_xform=parent_xform, child_xform=child_xform,
                               label=label, collision_filter_parent=collision_filter_parent, enabled=enabled)
 
+    def add_joint_distance(self, parent, child, *, parent_xform=None, child_xform=None, min_distance=-1.0, max_distance=1.0,
+                           label=None, collision_filter_parent=None, enabled=True) -> int:
+        """Distance joint (builder.py:5128-5187): anchor distance kept in [min, max] (a negative bound is inactive); only
+        SolverXPBD supports it."""
+        ax = JointDofConfig(axis=0, limit_lower=min_distance, limit_upper=max_distance)
+        return self.add_joint(JointType.DISTANCE, parent, child, parent_xform=parent_xform, child_xform=child_xform, label=label,
+                              linear_axes=[ax, JointDofConfig.create_unlimited(1), JointDofConfig.create_unlimited(2)],
+                              angular_axes=[JointDofConfig.create_unlimited(a) for a in range(3)],
+                              collision_filter_parent=collision_filter_parent, enabled=enabled)
+
     def add_joint_d6(self, parent, child, *, linear_axes=None, angular_axes=None, parent_xform=None, child_xform=None,
                      label=None, collision_filter_parent=None, enabled=True) -> int:
         return self.add_joint(JointType.D6, parent, child, parent_xform=parent_xform, child_xform=child_xform,
