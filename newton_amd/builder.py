@@ -115,9 +115,16 @@ class ModelBuilder:
     ShapeConfig = ShapeConfig
     JointDofConfig = JointDofConfig
 
-    def __init__(self, up_axis: int = 2, gravity: float = -9.81):
+    def __init__(self, up_axis: int = 2, gravity=-9.81):
+        """``gravity``: a 3-vector [m/s^2] like the reference (builder.py gravity=(gx, gy, gz)), or a scalar along ``up_axis``."""
         self.up_axis = up_axis
-        self._gravity_scalar = gravity
+        if np.ndim(gravity) == 0:
+            self._gravity_scalar, self._gravity_vec = float(gravity), None
+        else:
+            g = np.asarray(gravity, dtype=np.float64)
+            if g.shape != (3,):
+                raise ValueError(f"gravity must be a scalar or have shape (3,), got {g.shape}")
+            self._gravity_scalar, self._gravity_vec = float(g[up_axis]), g
         self.default_shape_cfg = ShapeConfig()
         self.default_joint_cfg = JointDofConfig()
         self.rigid_gap = 0.1  # builder.py:1596
@@ -187,6 +194,8 @@ class ModelBuilder:
         return tuple(v)
 
     def _gravity_vector(self):
+        if self._gravity_vec is not None:
+            return self._gravity_vec.copy()
         return np.asarray(self.up_vector) * self._gravity_scalar
 
     # ------------------------------------------------------------------ worlds

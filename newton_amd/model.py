@@ -386,6 +386,27 @@ class Model:
             self._dev = DeviceModel(self)
         return self._dev
 
+    def set_gravity(self, gravity, world: int | None = None) -> None:
+        """Runtime gravity change (model.py:1908-1960): one vector for every world, one per local world, or one per local
+        world plus the global entry; ``world`` selects a single world (-1 = global).  Call
+        ``solver.notify_model_changed(ModelFlags.MODEL_PROPERTIES)`` afterwards."""
+        g = np.asarray(gravity, dtype=np.float32)
+        W = self.world_count
+        if world is not None:
+            if g.shape != (3,):
+                raise ValueError("Expected single gravity vector (3,) when world is specified")
+            if world < -1 or world >= W:
+                raise IndexError(f"world {world} out of range; expected -1 or [0, {W})")
+            self.gravity[world if world >= 0 else W] = g
+        elif g.shape == (3,):
+            self.gravity[:] = g
+        elif g.shape == (W, 3):
+            self.gravity[:W] = g
+        elif g.shape == (W + 1, 3):
+            self.gravity[:] = g
+        else:
+            raise ValueError(f"gravity must have shape (3,), ({W}, 3) or ({W + 1}, 3), got {g.shape}")
+
     def notify_model_changed(self):
         """Re-upload per-env parameters after the host arrays were edited."""
         if self._dev is not None:
