@@ -117,6 +117,9 @@ typedef struct {
     float* body_f;   /* [6][nb][ES] */
     float* joint_q;  /* [nc][ES]   (may be NULL for maximal-coordinate solvers) */
     float* joint_qd; /* [nd][ES] */
+    float* body_parent_f; /* [6][nb][ES] or NULL: extended attribute State.body_parent_f (state.py:77,156-163), the incoming
+                           * joint wrench at the body COM, world frame; written into the output state by nt_xpbd_step
+                           * (xpbd/kernels.py:2497-2544) and nt_featherstone_step / _rollout (featherstone/kernels.py:2371-2416) */
 } nt_state;
 
 /* Control (newton/_src/sim/control.py:31-68) */
@@ -147,6 +150,15 @@ typedef struct {
     int32_t enable_restitution; /* apply_rigid_restitution after the iterations (xpbd/kernels.py:2583-2728) */
 } nt_xpbd_params;
 
+/* Optional reporting buffers of nt_xpbd_step (solver_xpbd.py:368-386): NULL members are skipped. */
+typedef struct {
+    float* contact_impulse; /* [6][np*cpp][ES] out: per contact slot, the 1/N-weighted impulse on shape0's body accumulated
+                             * over the iterations (xpbd/kernels.py:2398-2461); nt_contacts_export_force turns it into
+                             * Contacts.force */
+    float* joint_impulse;   /* [6][nj][ES] scratch: per-joint child-side impulse; required when s_out->body_parent_f is set
+                             * and the model has joints */
+} nt_xpbd_report;
+
 typedef struct {
     float angular_damping;
     float friction_smoothing;
@@ -170,7 +182,7 @@ nt_status nt_clear_forces(const nt_model* m, nt_state* s, void* stream);
 nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const nt_collide_params* p, void* stream);
 nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_in, nt_state* s_out,
                        const nt_control* ctrl, const nt_contacts* c /*nullable*/, float dt, int32_t envs_per_block,
-                       void* stream);
+                       const nt_xpbd_report* report /*nullable*/, void* stream);
 nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params* p, nt_state* s_in, nt_state* s_out,
                                 const nt_control* ctrl, const nt_contacts* c /*nullable*/, float dt,
                                 int32_t envs_per_block, void* stream);
@@ -208,6 +220,10 @@ nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t ca
                              int32_t* out_shape1, float* out_point0, float* out_point1, float* out_offset0,
                              float* out_offset1, float* out_normal, float* out_margin0, float* out_margin1,
                              int32_t* scan_tmp, void* stream);
+/* SolverXPBD.update_contacts (solver_xpbd.py:864-921, xpbd/kernels.py:2464-2494): Contacts.force[i] = impulse / dt for the
+ * i-th exported contact (same order as nt_contacts_export), zero beyond the count.  out_force: AoS [cap][6]. */
+nt_status nt_contacts_export_force(const nt_model* m, const nt_contacts* c, const float* contact_impulse, float dt,
+                                   int32_t cap, float* out_force, int32_t* scan_tmp, void* stream);
 
 /* -------- introspection -------- */
 const char* nt_error_string(nt_status s);

@@ -46,7 +46,7 @@ class nt_model(C.Structure):
 
 class nt_state(C.Structure):
     _fields_ = [("body_q", C.c_void_p), ("body_qd", C.c_void_p), ("body_f", C.c_void_p), ("joint_q", C.c_void_p),
-                ("joint_qd", C.c_void_p)]
+                ("joint_qd", C.c_void_p), ("body_parent_f", C.c_void_p)]
 
 
 class nt_control(C.Structure):
@@ -64,6 +64,10 @@ class nt_xpbd_params(C.Structure):
                 ("joint_angular_compliance", C.c_float), ("rigid_contact_relaxation", C.c_float),
                 ("rigid_contact_con_weighting", C.c_int32), ("angular_damping", C.c_float),
                 ("enable_restitution", C.c_int32)]
+
+
+class nt_xpbd_report(C.Structure):
+    _fields_ = [("contact_impulse", C.c_void_p), ("joint_impulse", C.c_void_p)]
 
 
 class nt_semi_implicit_params(C.Structure):
@@ -86,7 +90,8 @@ SYMBOLS = {
     "nt_collide": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
                                 C.POINTER(nt_collide_params), _P]),
     "nt_xpbd_step": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_xpbd_params), C.POINTER(nt_state), C.POINTER(nt_state),
-                                  C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),
+                                  C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float, C.c_int32,
+                                  C.POINTER(nt_xpbd_report), _P]),
     "nt_semi_implicit_step": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_semi_implicit_params), C.POINTER(nt_state),
                                            C.POINTER(nt_state), C.POINTER(nt_control), C.POINTER(nt_contacts), C.c_float,
                                            C.c_int32, _P]),
@@ -106,6 +111,7 @@ SYMBOLS = {
     "nt_unpack_aos": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "nt_contacts_export": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_contacts), C.c_int32, _P, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P, _P, _P]),
+    "nt_contacts_export_force": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_contacts), _P, C.c_float, C.c_int32, _P, _P, _P]),
     "nt_error_string": (C.c_char_p, [C.c_int32]),
     "nt_build_info": (C.c_char_p, []),
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),

@@ -127,6 +127,8 @@ class ModelBuilder:
             self._gravity_scalar, self._gravity_vec = float(g[up_axis]), g
         self.default_shape_cfg = ShapeConfig()
         self.default_joint_cfg = JointDofConfig()
+        self._requested_state_attributes: set[str] = set()
+        self._requested_contact_attributes: set[str] = set()
         self.rigid_gap = 0.1  # builder.py:1596
         self.current_world = -1
         self.world_count = 0
@@ -542,8 +544,24 @@ class ModelBuilder:
                     "shape_material_restitution", "shape_material_mu_torsional", "shape_material_mu_rolling",
                     "shape_material_kh"]
 
+    def request_state_attributes(self, *attributes: str) -> None:
+        """Extended State attributes to allocate (builder.py request_state_attributes; state.py:77): 'body_parent_f'."""
+        from .model import Model  # noqa: PLC0415
+
+        Model._check_requested(attributes, Model.EXTENDED_STATE_ATTRIBUTES, "state")
+        self._requested_state_attributes.update(attributes)
+
+    def request_contact_attributes(self, *attributes: str) -> None:
+        """Extended Contacts attributes to allocate (contacts.py:170-226): 'force'."""
+        from .model import Model  # noqa: PLC0415
+
+        Model._check_requested(attributes, Model.EXTENDED_CONTACT_ATTRIBUTES, "contact")
+        self._requested_contact_attributes.update(attributes)
+
     def add_builder(self, other: ModelBuilder, xform=None, world: int | None = None):
         """Append a copy of ``other`` (builder.py:4261-4313); entities go to ``world`` (default: current world)."""
+        self._requested_state_attributes |= other._requested_state_attributes
+        self._requested_contact_attributes |= other._requested_contact_attributes
         w = self.current_world if world is None else world
         b0, j0, s0 = self.body_count, self.joint_count, self.shape_count
         q0, qd0, tq0, a0 = len(self.joint_q), len(self.joint_qd), len(self.joint_target_q), self.articulation_count
@@ -650,6 +668,8 @@ class ModelBuilder:
             raise RuntimeError("finalize() called inside a world context")
         f32, i32 = np.float32, np.int32
         m = Model(device)
+        m._requested_state_attributes = set(self._requested_state_attributes)
+        m._requested_contact_attributes = set(self._requested_contact_attributes)
         m.world_count = max(self.world_count, 0)
         m.body_count, m.joint_count, m.shape_count = self.body_count, self.joint_count, self.shape_count
         m.joint_dof_count, m.joint_coord_count = self.joint_dof_count, self.joint_coord_count

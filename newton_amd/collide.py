@@ -45,7 +45,13 @@ class Contacts:
         self._export = None
         self._generation = 0
         self._export_generation = -1
+        # extended attribute (contacts.py:170-226): [rigid_contact_max, 6] force / torque on shape0's body, filled by
+        # solver.update_contacts(); _impulse holds the solver's per-slot accumulated impulses of the last step
         self.force = None
+        self._impulse = None
+        if "force" in model.get_requested_contact_attributes():
+            self.force = torch.zeros((max(self.rigid_contact_max, 1), 6), dtype=torch.float32, device=dev)
+            self._impulse = torch.zeros((6, ns, t.env_stride), dtype=torch.float32, device=dev)
 
     def _desc(self) -> _lib.nt_contacts:
         d = _lib.nt_contacts()

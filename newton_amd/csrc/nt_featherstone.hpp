@@ -820,7 +820,7 @@ NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
 // One SolverFeatherstone.step on the state resident in LDS (joint_q in F.jq, public joint_qd in F.qdp).
 template <int EPB>
 NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F, int max_depth, bool forces_are_zero,
-                      bool publish_fk) {
+                      bool publish_fk, float* parent_f_out) {
     const KArgs& a = c.a;
     const nt_model& m = a.m;
     const int nj = m.nj, nb = m.nb;
@@ -878,6 +878,16 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         __syncthreads();
     }
     NT_TICK(15);
+    // compute_body_parent_f (kernels.py:2371-2416): f_s of the body's inbound joint (left in `ft` by the pass above),
+    // moved from the solve origin to the body COM
+    if (parent_f_out && c.valid)
+        for (int b = c.slot; b < nb; b += c.nslot) {
+            spatial f_s = f.sp6(F.ft, nb, b);
+            vec3 r_com = f.v3(F.qcom, 0, nb, b) - f.v3(F.org, 0, nb, b);
+            vec3 t = f_s.bottom - cross(r_com, f_s.top);
+            parent_f_out[c.g(0, nb, b)] = f_s.top.x; parent_f_out[c.g(1, nb, b)] = f_s.top.y; parent_f_out[c.g(2, nb, b)] = f_s.top.z;
+            parent_f_out[c.g(3, nb, b)] = t.x; parent_f_out[c.g(4, nb, b)] = t.y; parent_f_out[c.g(5, nb, b)] = t.z;
+        }
     // P = M J (non-zero blocks), H = J^T P (lower triangle), Cholesky, solve
     const int W = m.max_art_dofs;
     if (c.valid && !(skip & 16))
@@ -935,7 +945,7 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
         stage_rows(c, F.qdp, a.s_in.joint_qd, m.nd);
     }
     __syncthreads();
-    fs_substep(c, f, F, max_depth, false, true);
+    fs_substep(c, f, F, max_depth, false, true, a.s_out.body_parent_f);
     if (c.valid) {
         unstage_rows(c, F.jq, a.s_out.joint_q, m.nc);
         unstage_rows(c, F.qdp, a.s_out.joint_qd, m.nd);
@@ -974,11 +984,11 @@ __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     cc.L.sx = F.cw;
     cc.L.sa = F.cw + 7 * m.ns;
     cc.L.pc = F.cw + 13 * m.ns;
+    const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(cc, s == a.substeps - 1);
-        fs_substep(c, f, F, max_depth, true, false);
+        fs_substep(c, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr);
     }
-    const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     if (c.valid) {
         unstage_rows(c, F.jq, res.joint_q, m.nc);
         unstage_rows(c, F.qdp, res.joint_qd, m.nd);

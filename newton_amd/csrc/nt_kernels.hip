@@ -110,6 +110,7 @@ struct KArgs {
     nt_control c;
     nt_contacts ct;
     nt_xpbd_params p;
+    nt_xpbd_report rep;  // optional reporting outputs of nt_xpbd_step (all NULL on the hot path)
     nt_semi_implicit_params sp;
     float angular_damping;  // integrate_bodies damping of the active solver
     float dt;
@@ -1424,6 +1425,120 @@ NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
     c.st_lv3(c.L.bqd, 3, nb, b, c.body_w(b) + dw);
 }
 
+// ------------------------------------------------------------------------------------------------
+// optional reporting (never compiled into the fused rollout): per-joint child-side impulse -> State.body_parent_f
+// (xpbd/kernels.py:1018-1019,1074-1075,2043-2044,2497-2544) and per-contact weighted impulse -> Contacts.force
+// (xpbd/kernels.py:2398-2461).  Accumulators live in HBM (env-major SoA); lane <-> item mapping is the same in every
+// phase, so a lane only ever re-reads its own partial sums.
+// ------------------------------------------------------------------------------------------------
+// after phase_joint_forces: joint_impulse[j] = child_wrench_at_com * dt (initialises the accumulator)
+template <int EPB>
+NT_DI void report_joint_forces(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nj = c.a.m.nj;
+    float* J = c.a.rep.joint_impulse;
+    const float dt = c.a.dt;
+    for (int j = c.slot; j < nj; j += c.nslot) {
+        vec3 fc = c.lv3(c.L.jf, 6, nj, j) * dt, tc = c.lv3(c.L.jf, 9, nj, j) * dt;
+        J[c.g(0, nj, j)] = fc.x; J[c.g(1, nj, j)] = fc.y; J[c.g(2, nj, j)] = fc.z;
+        J[c.g(3, nj, j)] = tc.x; J[c.g(4, nj, j)] = tc.y; J[c.g(5, nj, j)] = tc.z;
+    }
+}
+// after phase_joints: joint_impulse[j] += (lin_delta_c, ang_delta_c), the child-side correction of this iteration
+template <int EPB>
+NT_DI void report_joint_iteration(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nj = c.a.m.nj;
+    float* J = c.a.rep.joint_impulse;
+    for (int j = c.slot; j < nj; j += c.nslot) {
+        int id_p, id_c;
+        float m_inv_p, m_inv_c;
+        if (!joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) continue;
+        vec3 jl = c.lv3(c.L.jl, 6, nj, j);
+        vec3 ja = ((c.lv3(c.L.jl, 9, nj, j) + c.lv3(c.L.ja, 0, nj, j)) + c.lv3(c.L.ja, 3, nj, j)) + c.lv3(c.L.ja, 6, nj, j);
+        J[c.g(0, nj, j)] += jl.x; J[c.g(1, nj, j)] += jl.y; J[c.g(2, nj, j)] += jl.z;
+        J[c.g(3, nj, j)] += ja.x; J[c.g(4, nj, j)] += ja.y; J[c.g(5, nj, j)] += ja.z;
+    }
+}
+// end of step: body_parent_f[b] = sum over enabled non-FREE inbound joints (ascending) of joint_impulse / dt
+template <int EPB>
+NT_DI void report_parent_f(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nj = m.nj;
+    const float* J = c.a.rep.joint_impulse;
+    float* out = c.a.s_out.body_parent_f;
+    const float inv_dt = 1.0f / c.a.dt;
+    for (int b = c.slot; b < nb; b += c.nslot) {
+        vec3 f, t;
+        if (J)
+            for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
+                int code = c.T.body_joint_list[i];
+                int j = code >> 1;
+                if (!(code & 1) || !c.T.joint_enabled[j] || c.T.joint_type[j] == JT_FREE) continue;
+                f += vec3(J[c.g(0, nj, j)], J[c.g(1, nj, j)], J[c.g(2, nj, j)]) * inv_dt;
+                t += vec3(J[c.g(3, nj, j)], J[c.g(4, nj, j)], J[c.g(5, nj, j)]) * inv_dt;
+            }
+        out[c.g(0, nb, b)] = f.x; out[c.g(1, nb, b)] = f.y; out[c.g(2, nb, b)] = f.z;
+        out[c.g(3, nb, b)] = t.x; out[c.g(4, nb, b)] = t.y; out[c.g(5, nb, b)] = t.z;
+    }
+}
+// number of active contacts on body b in this iteration (constraint_inv_weight[b], xpbd/kernels.py:2287-2291)
+template <int EPB>
+NT_DI float report_body_contact_count(const Ctx<EPB>& c, int b) {
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    float n = 0.0f;
+    for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+        int code = c.T.body_pair_list[i];
+        int p = code >> 1, side = code & 1;
+        for (int k = 0; k < cpp; ++k) {
+            int slot = p * cpp + k;
+            bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
+            if (c.l(c.L.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) n += 1.0f;
+        }
+    }
+    return n;
+}
+// contact_impulse[slot] (+)= (lin_delta_a, ang_delta_a) * weight   (accumulate_weighted_contact_impulse)
+template <int EPB>
+NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
+    if (!c.valid) return;
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    float* I = c.a.rep.contact_impulse;
+    for (int slot = c.slot; slot < ncs; slot += c.nslot) {
+        float has_a = c.l(c.L.cw, 12, ncs, slot), has_b = c.l(c.L.cw, 13, ncs, slot);
+        vec3 lin, ang;
+        if (has_a != 0.0f || has_b != 0.0f) {
+            float weight = 1.0f;
+            if (c.a.p.rigid_contact_con_weighting) {
+                const int p = slot / cpp;
+                int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
+                if (c.l(c.L.cw, 14, ncs, slot) == 0.0f) { int t = sa; sa = sb; sb = t; }
+                int body_a = c.T.shape_body[sa], body_b = c.T.shape_body[sb];
+                float n_a = body_a >= 0 ? report_body_contact_count(c, body_a) : 0.0f;
+                float n_b = body_b >= 0 ? report_body_contact_count(c, body_b) : 0.0f;
+                float n_sum = n_a + n_b;
+                if (n_sum > 0.0f) {
+                    if (n_a == 0.0f) weight = 1.0f / n_b;
+                    else if (n_b == 0.0f) weight = 1.0f / n_a;
+                    else weight = 2.0f / n_sum;
+                }
+            }
+            lin = c.lv3(c.L.cw, 0, ncs, slot) * weight;
+            ang = c.lv3(c.L.cw, 3, ncs, slot) * weight;
+        }
+        if (first) {
+            I[c.g(0, ncs, slot)] = lin.x; I[c.g(1, ncs, slot)] = lin.y; I[c.g(2, ncs, slot)] = lin.z;
+            I[c.g(3, ncs, slot)] = ang.x; I[c.g(4, ncs, slot)] = ang.y; I[c.g(5, ncs, slot)] = ang.z;
+        } else if (has_a != 0.0f || has_b != 0.0f) {
+            I[c.g(0, ncs, slot)] += lin.x; I[c.g(1, ncs, slot)] += lin.y; I[c.g(2, ncs, slot)] += lin.z;
+            I[c.g(3, ncs, slot)] += ang.x; I[c.g(4, ncs, slot)] += ang.y; I[c.g(5, ncs, slot)] += ang.z;
+        }
+    }
+}
+
 template <int EPB>
 NT_DI void phase_joints(const Ctx<EPB>& c) {
     if (!c.valid) return;
@@ -1483,10 +1598,13 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
     if (restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
         for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * EPB + c.e] = c.lds[(c.L.bq + r) * EPB + c.e];
+    const bool rep_joints = !FUSED && c.a.rep.joint_impulse != nullptr;
+    const bool rep_contacts = !FUSED && c.a.rep.contact_impulse != nullptr && c.a.has_contacts;
     if (!(skip & 2)) {
         phase_joint_forces(c, forces_are_zero);
         __syncthreads();
         NT_TICK(3);
+        if (rep_joints) report_joint_forces(c);
         phase_integrate<EPB, false>(c);
         __syncthreads();
         NT_TICK(4);
@@ -1496,6 +1614,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             if (!(skip & 4)) phase_contacts<EPB, FUSED>(c);
             __syncthreads();
             NT_TICK(5);
+            if (rep_contacts) report_contact_iteration(c, it == 0);
             if (!(skip & 16)) phase_apply<EPB, true>(c);
             __syncthreads();
             NT_TICK(6);
@@ -1504,6 +1623,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             if (!(skip & 8)) phase_joints(c);
             __syncthreads();
             NT_TICK(7);
+            if (rep_joints) report_joint_iteration(c);
             if (!(skip & 16)) phase_apply<EPB, false>(c);
             __syncthreads();
             NT_TICK(8);
@@ -1517,6 +1637,11 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             for (int b = c.slot; b < m.nb; b += c.nslot)
                 if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item(c, b);
         __syncthreads();
+    }
+    if (!FUSED && c.a.s_out.body_parent_f) {
+        __threadfence_block();  // joint lanes' accumulators -> body lanes
+        __syncthreads();
+        report_parent_f(c);
     }
 }
 
@@ -1952,6 +2077,24 @@ __global__ void contacts_export_kernel(ExportArgs a) {
     }
 }
 
+// convert_contact_impulse_to_force in export order; entries beyond the live count are zeroed
+__global__ void contacts_export_force_kernel(nt_model m, nt_contacts c, const float* __restrict__ impulse, float inv_dt, int cap,
+                                             const int32_t* __restrict__ scan, float* __restrict__ out) {
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int E = m.env_count;
+    if (env >= E) return;
+    const int ES = m.env_stride, ncs = m.np * m.cpp, nas = m.np_analytic * m.cpp;
+    int idxA = scan[env];
+    int idxC = scan[E] + scan[(E + 1) + env];
+    for (int slot = 0; slot < ncs; ++slot) {
+        size_t gi = (size_t)slot * ES + env;
+        if (c.shape0[gi] < 0) continue;
+        int idx = slot < nas ? idxA++ : idxC++;
+        if (idx < cap)
+            for (int k = 0; k < 6; ++k) out[6 * (size_t)idx + k] = impulse[((size_t)k * ncs + slot) * ES + env] * inv_dt;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
@@ -2076,9 +2219,12 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
 }
 
 nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_in, nt_state* s_out, const nt_control* ctrl,
-                       const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
+                       const nt_contacts* c, float dt, int32_t envs_per_block, const nt_xpbd_report* report, void* stream) {
     if (!model_ok(m) || !p || !s_in || !s_out || !ctrl) return NT_ERR_INVALID_ARG;
+    if (s_out->body_parent_f && m->nj > 0 && !(report && report->joint_impulse)) return NT_ERR_INVALID_ARG;
     KArgs a = {};
+    if (report) a.rep = *report;
+    if (!s_out->body_parent_f || m->nj == 0) a.rep.joint_impulse = nullptr;
     a.m = *m;
     a.s_in = *s_in;
     a.s_out = *s_out;
@@ -2316,6 +2462,20 @@ nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t ca
     a.offset0 = out_offset0; a.offset1 = out_offset1;
     a.normal = out_normal; a.margin0 = out_margin0; a.margin1 = out_margin1;
     hipLaunchKernelGGL(contacts_export_kernel, dim3((m->env_count + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_contacts_export_force(const nt_model* m, const nt_contacts* c, const float* contact_impulse, float dt, int32_t cap,
+                                   float* out_force, int32_t* scan_tmp, void* stream) {
+    if (!model_ok(m) || !c || !contact_impulse || !out_force || !scan_tmp || cap < 0 || !(dt > 0.0f)) return NT_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int E = m->env_count;
+    if (hipMemsetAsync(out_force, 0, sizeof(float) * 6 * (size_t)cap, st) != hipSuccess) return NT_ERR_LAUNCH;
+    hipLaunchKernelGGL(contacts_count_kernel, dim3((E + 63) / 64), dim3(64), 0, st, *m, *c, scan_tmp);
+    // the total goes into the spare last entry of the cntA section
+    hipLaunchKernelGGL(contacts_scan_kernel, dim3(1), dim3(1024), 0, st, E, scan_tmp, scan_tmp + 2 * (E + 1) + E);
+    hipLaunchKernelGGL(contacts_export_force_kernel, dim3((E + 63) / 64), dim3(64), 0, st, *m, *c, contact_impulse, 1.0f / dt, cap,
+                       scan_tmp, out_force);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

@@ -360,9 +360,14 @@ class DeviceModel:
 class Model:
     """Flat-array simulation model (newton/_src/sim/model.py:808-1364, rigid subset)."""
 
+    EXTENDED_STATE_ATTRIBUTES = ("body_parent_f",)  # state.py:73-79, rigid subset
+    EXTENDED_CONTACT_ATTRIBUTES = ("force",)  # contacts.py:170-226
+
     def __init__(self, device=None):
         self.device = device if device is not None else "cpu"
         self.requires_grad = False
+        self._requested_state_attributes: set[str] = set()
+        self._requested_contact_attributes: set[str] = set()
         self.world_count = 0
         self.particle_count = 0
         self.rigid_contact_max = 0
@@ -385,6 +390,28 @@ class Model:
         if self._dev is None:
             self._dev = DeviceModel(self)
         return self._dev
+
+    @staticmethod
+    def _check_requested(attributes, known, kind):
+        unknown = [a for a in attributes if a not in known]
+        if unknown:
+            raise ValueError(f"Unknown extended {kind} attribute(s): {unknown}; supported: {list(known)}")
+
+    def request_state_attributes(self, *attributes: str) -> None:
+        """model.py:2068-2078: allocate these extended attributes in every State created afterwards."""
+        self._check_requested(attributes, self.EXTENDED_STATE_ATTRIBUTES, "state")
+        self._requested_state_attributes.update(attributes)
+
+    def request_contact_attributes(self, *attributes: str) -> None:
+        """model.py:2080-2088: allocate these extended attributes in every Contacts created afterwards."""
+        self._check_requested(attributes, self.EXTENDED_CONTACT_ATTRIBUTES, "contact")
+        self._requested_contact_attributes.update(attributes)
+
+    def get_requested_state_attributes(self) -> list[str]:
+        return sorted(self._requested_state_attributes)
+
+    def get_requested_contact_attributes(self) -> set[str]:
+        return set(self._requested_contact_attributes)
 
     def set_gravity(self, gravity, world: int | None = None) -> None:
         """Runtime gravity change (model.py:1908-1960): one vector for every world, one per local world, or one per local

@@ -32,6 +32,10 @@ class SolverXPBD(SolverBase):
         self.angular_damping = angular_damping
         self.enable_restitution = enable_restitution
         self.envs_per_block = int(envs_per_block)
+        self._contact_impulse = None
+        self._contact_impulse_capacity = 0
+        self._last_dt = None
+        self._joint_impulse = None
 
     def _params(self) -> _lib.nt_xpbd_params:
         return _lib.nt_xpbd_params(int(self.iterations), float(self.joint_linear_relaxation),
@@ -47,9 +51,44 @@ class SolverXPBD(SolverBase):
         p = self._params()
         d_in, d_out, d_c = state_in._desc(), state_out._desc(), control._desc()
         d_ct = contacts._desc() if contacts is not None else None
+        # optional reporting (solver_xpbd.py:368-386): per-contact impulses when contacts.force was requested, per-joint
+        # impulses when state_out carries body_parent_f
+        rep = _lib.nt_xpbd_report()
+        reporting = False
+        self._contact_impulse = None
+        if contacts is not None and contacts.force is not None:
+            rep.contact_impulse = contacts._impulse.data_ptr()
+            self._contact_impulse = contacts._impulse
+            reporting = True
+        self._contact_impulse_capacity = contacts.rigid_contact_max if contacts is not None else 0
+        self._last_dt = float(dt)
+        if state_out._parent_f is not None and self.model.env.nj > 0:
+            if self._joint_impulse is None:
+                import torch  # noqa: PLC0415
+
+                t = self.model.env
+                self._joint_impulse = torch.zeros((6, t.nj, t.env_stride), dtype=torch.float32, device=dm.device)
+            rep.joint_impulse = self._joint_impulse.data_ptr()
+            reporting = True
         _lib.check(dm.lib.nt_xpbd_step(C.byref(dm.desc), C.byref(p), C.byref(d_in), C.byref(d_out), C.byref(d_c),
                                        C.byref(d_ct) if d_ct is not None else None, float(dt), self.envs_per_block,
-                                       dm.stream()), "nt_xpbd_step")
+                                       C.byref(rep) if reporting else None, dm.stream()), "nt_xpbd_step")
+
+    def update_contacts(self, contacts, state=None) -> None:
+        """Fill ``contacts.force`` from the impulses of the last ``step`` (solver_xpbd.py:864-921)."""
+        if contacts.force is None:
+            raise ValueError("contacts.force is not allocated. Call model.request_contact_attributes('force') before "
+                             "creating the Contacts object.")
+        if self._contact_impulse is None:
+            raise ValueError("No contact impulse data available. Call step() before update_contacts().")
+        if contacts.rigid_contact_max != self._contact_impulse_capacity or contacts._impulse is not self._contact_impulse:
+            raise ValueError("Contacts mismatch: pass the same Contacts instance to both step() and update_contacts().")
+        dm = self.dm
+        d_ct = contacts._desc()
+        _lib.check(dm.lib.nt_contacts_export_force(C.byref(dm.desc), C.byref(d_ct), self._contact_impulse.data_ptr(),
+                                                   float(self._last_dt), int(contacts.rigid_contact_max),
+                                                   contacts.force.data_ptr(), contacts._scan.data_ptr(), dm.stream()),
+                   "nt_contacts_export_force")
 
     def rollout(self, state_0, state_1, control, contacts, dt: float, substeps: int, collide_params=None):
         """substeps x {clear_forces; collide; step; swap} in one launch.  Returns the state object holding the
@@ -57,8 +96,19 @@ class SolverXPBD(SolverBase):
         dm = self.dm
         if control is None:
             control = self._default_control()
-        p = self._params()
         cp = collide_params if collide_params is not None else _lib.nt_collide_params(0, self.envs_per_block)
+        if contacts.force is not None or state_0._parent_f is not None or state_1._parent_f is not None:
+            # the reporting outputs only exist in the per-substep kernel: run the reference loop launch by launch
+            for _ in range(int(substeps)):
+                state_0.clear_forces()
+                d_s, d_ct = state_0._desc(), contacts._desc()
+                _lib.check(dm.lib.nt_collide(C.byref(dm.desc), C.byref(d_s), C.byref(d_ct), C.byref(cp), dm.stream()),
+                           "nt_collide")
+                contacts._generation += 1
+                self.step(state_0, state_1, control, contacts, dt)
+                state_0, state_1 = state_1, state_0
+            return state_0
+        p = self._params()
         d0, d1, d_c, d_ct = state_0._desc(), state_1._desc(), control._desc(), contacts._desc()
         _lib.check(dm.lib.nt_xpbd_rollout(C.byref(dm.desc), C.byref(p), C.byref(cp), C.byref(d0), C.byref(d1), C.byref(d_c),
                                           C.byref(d_ct), float(dt), int(substeps), dm.stream()), "nt_xpbd_rollout")

@@ -127,8 +127,28 @@ class State(_SoAContainer):
 
     def __init__(self, model):
         super().__init__(model)
-        self.body_parent_f = None
+        # extended attribute (state.py:77,156-163): allocated only when requested on the model / builder
+        self._parent_f = None
+        if "body_parent_f" in model.get_requested_state_attributes():
+            t = model.env
+            if model.is_gpu:
+                self._parent_f = _torch().zeros((6, max(t.nb, 1), t.env_stride), dtype=_torch().float32,
+                                                device=model.device_model().device)
+            else:
+                self._parent_f = np.zeros((t.env_count * t.nb, 6), dtype=np.float32)
         self.particle_count = 0
+
+    @property
+    def body_parent_f(self):
+        """[body_count, 6] incoming joint wrench per body (world frame, at the COM), or None when not requested."""
+        if self._parent_f is None or not self.model.is_gpu:
+            return self._parent_f
+        t = self.model.env
+        dm = self.model.device_model()
+        out = _torch().empty((t.env_count * t.nb, 6), dtype=_torch().float32, device=dm.device)
+        _lib.check(dm.lib.nt_unpack_aos(self._parent_f.data_ptr(), out.data_ptr(), 6, t.nb, t.env_count, t.env_stride,
+                                        dm.stream()), "nt_unpack_aos")
+        return out
 
     @property
     def body_count(self):
@@ -191,6 +211,8 @@ class State(_SoAContainer):
         d.body_f = self._soa["body_f"].data_ptr()
         d.joint_q = self._soa["joint_q"].data_ptr()
         d.joint_qd = self._soa["joint_qd"].data_ptr()
+        if self._parent_f is not None:
+            d.body_parent_f = self._parent_f.data_ptr()
         return d
 
 

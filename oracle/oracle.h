@@ -87,6 +87,7 @@ typedef struct {
     float* body_f;   /* [B][6] */
     float* joint_q;  /* [coords] */
     float* joint_qd; /* [D] */
+    float* body_parent_f; /* [B][6] nullable: extended state attribute (state.py:77,156-163), written by XPBD / Featherstone */
 } o_state;
 
 typedef struct {
@@ -140,6 +141,8 @@ void o_integrate_bodies(const o_model* m, const float* body_q, const float* body
                         float angular_damping, float dt, float* body_q_new, float* body_qd_new);
 void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s_in, o_state* s_out,
                  const o_control* c, const o_contacts* contacts /*nullable*/, float dt);
+void o_xpbd_step_report(const o_model* m, const o_xpbd_params* p, o_state* s_in, o_state* s_out, const o_control* c,
+                        const o_contacts* contacts /*nullable*/, float dt, float* contact_force_out /*nullable [Cmax][6]*/);
 void o_xpbd_rollout(const o_model* m, const o_xpbd_params* p, o_state* s0, o_state* s1, const o_control* c,
                     o_contacts* contacts, float dt, int substeps);
 void o_semi_implicit_step(const o_model* m, const o_semi_implicit_params* p, o_state* s_in, o_state* s_out,

@@ -451,6 +451,18 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
         }
     }
 
+    // compute_body_parent_f (kernels.py:2371-2416, solver_featherstone.py:691-757): incoming joint wrench at the body COM
+    if (s_out->body_parent_f) {
+        std::fill(s_out->body_parent_f, s_out->body_parent_f + 6 * B, 0.0f);
+        if (m->articulation_count)
+            for (int tid = 0; tid < B; ++tid) {
+                spatial f_s = body_f_s[tid] + body_ft_s[tid] + lds(body_f.data(), tid);
+                vec3 f_lin = f_s.top, f_ang_at_origin = f_s.bottom;
+                vec3 r_com = body_q_com[tid].p - body_solve_origin[tid];
+                sts(s_out->body_parent_f, tid, spatial(f_lin, f_ang_at_origin - cross(r_com, f_lin)));
+            }
+    }
+
     // J, M, P = M J, H = J^T P, L = chol(H + diag(armature)), solve (kernels.py:1422-1565,1655-1846)
     for (int a = 0; a < m->articulation_count; ++a) {
         int joint_start = m->articulation_start[a], joint_end = m->articulation_end[a];

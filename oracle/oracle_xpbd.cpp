@@ -131,7 +131,8 @@ static void apply_body_deltas(const o_model* m, const float* q_in, const float* 
 }
 
 // ---------------------------------------------------------------- xpbd/kernels.py:945-1075
-static void apply_joint_forces(const o_model* m, const float* body_q, const float* joint_f, float dt, float* body_f) {
+static void apply_joint_forces(const o_model* m, const float* body_q, const float* joint_f, float dt, float* body_f,
+                               float* joint_impulse /*nullable, [J][6]*/) {
     for (int tid = 0; tid < m->joint_count; ++tid) {
         int type = m->joint_type[tid];
         if (!m->joint_enabled[tid]) continue;
@@ -169,6 +170,7 @@ static void apply_joint_forces(const o_model* m, const float* body_q, const floa
             t_total = vec3(joint_f[qd_start + 3], joint_f[qd_start + 4], joint_f[qd_start + 5]);
             adds(body_f, id_c, spatial(f_total, t_total));
             if (id_p >= 0) subs(body_f, id_p, spatial(f_total, t_total));
+            if (joint_impulse) adds(joint_impulse, tid, spatial(f_total, t_total) * dt);  // kernels.py:1018-1019
             continue;
         } else if (type == BALL) {
             t_total = vec3(joint_f[qd_start + 0], joint_f[qd_start + 1], joint_f[qd_start + 2]);
@@ -194,6 +196,7 @@ static void apply_joint_forces(const o_model* m, const float* body_q, const floa
         spatial child_wrench_at_com(f_total, t_total + cross(r_c, f_total));
         if (id_p >= 0) subs(body_f, id_p, spatial(f_total, t_total + cross(r_p, f_total)));
         adds(body_f, id_c, child_wrench_at_com);
+        if (joint_impulse) adds(joint_impulse, tid, child_wrench_at_com * dt);  // kernels.py:1074-1075
     }
 }
 
@@ -312,7 +315,7 @@ static void gather_axes(const o_model* m, const o_control* c, int count, int axi
 
 // ---------------------------------------------------------------- xpbd/kernels.py:1513-2044
 static void solve_body_joints(const o_model* m, const o_xpbd_params* prm, const o_control* c, const float* body_q,
-                              const float* body_qd, float dt, float* deltas) {
+                              const float* body_qd, float dt, float* deltas, float* joint_impulse /*nullable, [J][6]*/) {
     const float joint_linear_compliance = prm->joint_linear_compliance;
     const float joint_angular_compliance = prm->joint_angular_compliance;
     const float angular_relaxation = prm->joint_angular_relaxation;
@@ -585,12 +588,14 @@ static void solve_body_joints(const o_model* m, const o_xpbd_params* prm, const 
 
         if (id_p >= 0) adds(deltas, id_p, spatial(lin_delta_p, ang_delta_p));
         if (id_c >= 0) adds(deltas, id_c, spatial(lin_delta_c, ang_delta_c));
+        if (joint_impulse) adds(joint_impulse, tid, spatial(lin_delta_c, ang_delta_c));  // kernels.py:2043-2044
     }
 }
 
 // ---------------------------------------------------------------- xpbd/kernels.py:2164-2399
 static void solve_body_contact_positions(const o_model* m, const o_contacts* ct, const float* body_q, const float* body_qd,
-                                         float relaxation, float dt, float* deltas, float* contact_inv_weight /*nullable*/) {
+                                         float relaxation, float dt, float* deltas, float* contact_inv_weight /*nullable*/,
+                                         float* contact_impulse /*nullable, [Cmax][6]*/) {
     int count = ct->rigid_contact_count[0];
     for (int tid = 0; tid < ct->rigid_contact_max; ++tid) {
         if (tid >= count) break;
@@ -748,6 +753,38 @@ static void solve_body_contact_positions(const o_model* m, const o_contacts* ct,
 
         if (body_a >= 0) adds(deltas, body_a, spatial(lin_delta_a, ang_delta_a));
         if (body_b >= 0) adds(deltas, body_b, spatial(lin_delta_b, ang_delta_b));
+        if (contact_impulse) adds(contact_impulse, tid, spatial(lin_delta_a, ang_delta_a));  // kernels.py:2398-2399
+    }
+}
+
+// ---------------------------------------------------------------- xpbd/kernels.py:2402-2461
+static void accumulate_weighted_contact_impulse(const o_model* m, const o_contacts* ct, const float* contact_impulse_iter,
+                                                const float* constraint_inv_weight /*nullable*/, float* contact_impulse) {
+    int count = ct->rigid_contact_count[0];
+    for (int tid = 0; tid < ct->rigid_contact_max; ++tid) {
+        if (tid >= count) break;
+        spatial impulse = lds(contact_impulse_iter, tid);
+        float weight = 1.0f;
+        if (constraint_inv_weight) {
+            float n_a = 0.0f, n_b = 0.0f;
+            int shape_a = ct->shape0[tid];
+            if (shape_a >= 0) {
+                int body_a = m->shape_body[shape_a];
+                if (body_a >= 0) n_a = constraint_inv_weight[body_a];
+            }
+            int shape_b = ct->shape1[tid];
+            if (shape_b >= 0) {
+                int body_b = m->shape_body[shape_b];
+                if (body_b >= 0) n_b = constraint_inv_weight[body_b];
+            }
+            float n_sum = n_a + n_b;
+            if (n_sum > 0.0f) {
+                if (n_a == 0.0f) weight = 1.0f / n_b;
+                else if (n_b == 0.0f) weight = 1.0f / n_a;
+                else weight = 2.0f / n_sum;
+            }
+        }
+        adds(contact_impulse, tid, spatial(impulse.top * weight, impulse.bottom * weight));
     }
 }
 
@@ -835,10 +872,19 @@ static void apply_rigid_restitution(const o_model* m, const o_contacts* ct, cons
     }
 }
 
-extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s_in, o_state* s_out, const o_control* c,
-                            const o_contacts* contacts, float dt) {
+// contact_force_out (nullable, [Cmax][6]): what SolverXPBD.update_contacts would write into contacts.force after this step
+// (solver_xpbd.py:864-921, kernels.py:2464-2494); s_out->body_parent_f (nullable): kernels.py:2497-2544.
+extern "C" void o_xpbd_step_report(const o_model* m, const o_xpbd_params* p, o_state* s_in, o_state* s_out,
+                                   const o_control* c, const o_contacts* contacts, float dt, float* contact_force_out) {
     const int B = m->body_count;
     if (B == 0) return;
+    std::vector<float> contact_impulse, contact_impulse_iter, joint_impulse;
+    if (contacts && contact_force_out) {
+        contact_impulse.assign(6 * (size_t)contacts->rigid_contact_max, 0.0f);
+        contact_impulse_iter.assign(6 * (size_t)contacts->rigid_contact_max, 0.0f);
+    }
+    if (s_out->body_parent_f && m->joint_count > 0) joint_impulse.assign(6 * (size_t)m->joint_count, 0.0f);
+    float* ji = joint_impulse.empty() ? nullptr : joint_impulse.data();
     // body_q_init / body_qd_init (solver_xpbd.py:414-416)
     std::vector<float> body_q_init, body_qd_init;
     if (p->enable_restitution) {
@@ -851,7 +897,7 @@ extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s
 
     // apply_joint_forces into a clone of state_in.body_f  (solver_xpbd.py:420-451)
     std::vector<float> body_f_tmp(s_in->body_f, s_in->body_f + 6 * B);
-    if (m->joint_count) apply_joint_forces(m, s_in->body_q, c->joint_f, dt, body_f_tmp.data());
+    if (m->joint_count) apply_joint_forces(m, s_in->body_q, c->joint_f, dt, body_f_tmp.data(), ji);
 
     // integrate_bodies state_in -> state_out  (solver_xpbd.py:453-459)
     o_integrate_bodies(m, s_in->body_q, s_in->body_qd, body_f_tmp.data(), p->angular_damping, dt, s_out->body_q,
@@ -881,13 +927,18 @@ extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s
         std::fill(body_deltas.begin(), body_deltas.end(), 0.0f);
         if (contacts) {
             if (!inv_weight.empty()) std::fill(inv_weight.begin(), inv_weight.end(), 0.0f);
+            if (!contact_impulse_iter.empty()) std::fill(contact_impulse_iter.begin(), contact_impulse_iter.end(), 0.0f);
             solve_body_contact_positions(m, contacts, body_q, body_qd, p->rigid_contact_relaxation, dt, body_deltas.data(),
-                                         inv_weight.empty() ? nullptr : inv_weight.data());
+                                         inv_weight.empty() ? nullptr : inv_weight.data(),
+                                         contact_impulse_iter.empty() ? nullptr : contact_impulse_iter.data());
+            if (!contact_impulse_iter.empty())
+                accumulate_weighted_contact_impulse(m, contacts, contact_impulse_iter.data(),
+                                                    inv_weight.empty() ? nullptr : inv_weight.data(), contact_impulse.data());
             apply(inv_weight.empty() ? nullptr : inv_weight.data());
         }
         if (m->joint_count) {
             std::fill(body_deltas.begin(), body_deltas.end(), 0.0f);
-            solve_body_joints(m, p, c, body_q, body_qd, dt, body_deltas.data());
+            solve_body_joints(m, p, c, body_q, body_qd, dt, body_deltas.data(), ji);
             apply(nullptr);
         }
     }
@@ -911,6 +962,39 @@ extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s
         stx(s_out->body_q, tid, ldx(s_in->body_q, tid));
         sts(s_out->body_qd, tid, lds(s_in->body_qd, tid));
     }
+
+    // convert_joint_impulse_to_parent_f (kernels.py:2497-2544, solver_xpbd.py:736-754)
+    if (s_out->body_parent_f) {
+        std::fill(s_out->body_parent_f, s_out->body_parent_f + 6 * B, 0.0f);
+        if (ji) {
+            float inv_dt = 1.0f / dt;
+            for (int tid = 0; tid < m->joint_count; ++tid) {
+                if (!m->joint_enabled[tid] || m->joint_type[tid] == FREE) continue;
+                int id_c = m->joint_child[tid];
+                if (id_c < 0) continue;
+                spatial impulse = lds(ji, tid);
+                adds(s_out->body_parent_f, id_c, spatial(impulse.top * inv_dt, impulse.bottom * inv_dt));
+            }
+        }
+    }
+    // convert_contact_impulse_to_force (kernels.py:2464-2494), as SolverXPBD.update_contacts does right after the step
+    if (contact_force_out && contacts) {
+        int count = contacts->rigid_contact_count[0];
+        float inv_dt = 1.0f / dt;
+        for (int tid = 0; tid < contacts->rigid_contact_max; ++tid) {
+            spatial f;
+            if (tid < count) {
+                spatial impulse = lds(contact_impulse.data(), tid);
+                f = spatial(impulse.top * inv_dt, impulse.bottom * inv_dt);
+            }
+            sts(contact_force_out, tid, f);
+        }
+    }
+}
+
+extern "C" void o_xpbd_step(const o_model* m, const o_xpbd_params* p, o_state* s_in, o_state* s_out, const o_control* c,
+                            const o_contacts* contacts, float dt) {
+    o_xpbd_step_report(m, p, s_in, s_out, c, contacts, dt, nullptr);
 }
 
 // substeps x { clear_forces; collide; xpbd step; swap } entirely in C (bench.py's cpu_baseline leg: one foreign call per

@@ -41,7 +41,7 @@ class o_model(C.Structure):
 
 
 class o_state(C.Structure):
-    _fields_ = [("body_q", _f), ("body_qd", _f), ("body_f", _f), ("joint_q", _f), ("joint_qd", _f)]
+    _fields_ = [("body_q", _f), ("body_qd", _f), ("body_f", _f), ("joint_q", _f), ("joint_qd", _f), ("body_parent_f", _f)]
 
 
 class o_control(C.Structure):
@@ -197,12 +197,16 @@ class OracleState:
             self.joint_q = np.zeros(1, dtype=np.float32)
         if self.joint_qd.size == 0:
             self.joint_qd = np.zeros(1, dtype=np.float32)
+        requested = getattr(model, "get_requested_state_attributes", lambda: [])()
+        self.body_parent_f = np.zeros((B, 6), dtype=np.float32) if "body_parent_f" in requested else None
 
     @property
     def struct(self):
         s = o_state()
         s.body_q, s.body_qd, s.body_f = _fp(self.body_q), _fp(self.body_qd), _fp(self.body_f)
         s.joint_q, s.joint_qd = _fp(self.joint_q), _fp(self.joint_qd)
+        if self.body_parent_f is not None:
+            s.body_parent_f = _fp(self.body_parent_f)
         return s
 
 
@@ -249,8 +253,10 @@ class Oracle:
                           int(params.get("rigid_contact_con_weighting", True)), params.get("angular_damping", 0.0),
                           int(params.get("enable_restitution", False)))
         si, so = s_in.struct, s_out.struct
-        self.L.o_xpbd_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
-                           C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))
+        force = params.get("contact_force_out")  # [Cmax, 6] float32: what update_contacts would write into contacts.force
+        self.L.o_xpbd_step_report(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
+                                  C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt),
+                                  _fp(force) if force is not None else None)
 
     def xpbd_rollout(self, s0: OracleState, s1: OracleState, control, contacts, dt, substeps, **params):
         """substeps x {clear_forces; collide; xpbd step; swap} in one foreign call; returns the state holding the result."""

@@ -185,3 +185,36 @@ def test_rollout_bitwise_equals_api_loop():
     assert res is r1
     for name in ("joint_q", "joint_qd", "body_q", "body_qd"):
         assert np.array_equal(getattr(res, name).cpu().numpy(), getattr(s0, name).cpu().numpy()), name
+
+
+def test_body_parent_f_matches_oracle_step_and_rollout():
+    """State.body_parent_f (compute_body_parent_f, featherstone/kernels.py:2371-2416) of a contact-loaded quadruped step vs
+    the oracle (<= 1e-4 of the largest wrench); the fused rollout reports the last substep's wrenches bit-identically."""
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, 37)
+    model.request_state_attributes("body_parent_f")
+    _lower_quadrupeds(nt, model, 0.24)
+    rng = np.random.default_rng(5)
+    model.joint_qd = (model.joint_qd + rng.normal(0, 0.3, size=model.joint_qd.shape)).astype(np.float32)
+    jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
+    s, os_, oc = _step_both(nt, model, o, 1, 1e-3, jf=jf)
+    assert oc.count[0] > 0
+    want = os_.body_parent_f
+    got = s.body_parent_f.cpu().numpy()
+    assert np.abs(want).max() > 1.0
+    assert np.max(np.abs(got - want)) <= 1e-4 * np.abs(want).max()
+
+    solver = nt.solvers.SolverFeatherstone(model)
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    r0, r1 = model.state(), model.state()
+    out = solver.rollout(r0, r1, None, contacts, 1e-3, 3)
+    t0, t1 = model.state(), model.state()
+    for _ in range(3):
+        t0.clear_forces()
+        pipe.collide(t0, contacts)
+        solver.step(t0, t1, None, contacts, 1e-3)
+        t0, t1 = t1, t0
+    assert np.array_equal(out.body_q.cpu().numpy(), t0.body_q.cpu().numpy())
+    assert np.array_equal(out.body_parent_f.cpu().numpy(), t0.body_parent_f.cpu().numpy())

@@ -390,3 +390,59 @@ def test_articulation_view_device():
     assert np.max(np.abs(s.body_q.cpu().numpy() - hs.body_q)) <= 1e-5
     assert view.get_link_transforms(s).shape == (70, 13, 7)
     assert torch.equal(view.get_root_transforms(s), view.get_dof_positions(s)[:, :7])
+
+
+@pytest.mark.parametrize("n_env,epb", [(3, 0), (70, 16)])
+def test_reported_contact_force_and_parent_force_match_oracle(n_env, epb):
+    """contacts.force (update_contacts) and state_out.body_parent_f of one XPBD step vs the oracle, with joint_f drive,
+    external body_f and ground contacts in play: <= 1e-4 of the largest wrench."""
+    from oracle_bridge import OracleState
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, n_env)
+    model.request_state_attributes("body_parent_f")
+    model.request_contact_attributes("force")
+    _lower_quadrupeds(nt, model, 0.24)
+    rng = np.random.default_rng(11)
+    model.body_qd = (model.body_qd + rng.normal(0, 0.2, size=model.body_qd.shape)).astype(np.float32)
+    joint_f = rng.normal(0, 5.0, size=model.joint_dof_count).astype(np.float32)
+    body_f = rng.normal(0, 3.0, size=(model.body_count, 6)).astype(np.float32)
+    s0, s1 = model.state(), model.state()
+    s0.body_f = body_f
+    ctrl = model.control()
+    ctrl.joint_f = joint_f
+    pipe = nt.CollisionPipeline(model, envs_per_block=epb)
+    contacts = pipe.contacts()
+    pipe.collide(s0, contacts)
+    solver = nt.solvers.SolverXPBD(model, envs_per_block=epb)
+    solver.step(s0, s1, ctrl, contacts, 1e-3)
+    solver.update_contacts(contacts, s1)
+
+    os0, os1 = OracleState(model, body_f=body_f), OracleState(model)
+    oc = o.contacts()
+    o.collide(os0.body_q, oc)
+    n = int(oc.count[0])
+    assert n > 0
+    force = np.zeros((oc.max, 6), dtype=np.float32)
+    o.xpbd_step(os0, os1, o.control(joint_f=joint_f), oc, 1e-3, contact_force_out=force)
+
+    assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 1e-5
+    got_f = contacts.force.cpu().numpy()
+    assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == n
+    assert np.abs(force[:n]).max() > 1.0
+    assert np.max(np.abs(got_f[:n] - force[:n])) <= 1e-4 * np.abs(force[:n]).max()
+    assert np.all(got_f[n:] == 0.0)
+    got_p = s1.body_parent_f.cpu().numpy()
+    assert np.abs(os1.body_parent_f).max() > 1.0
+    assert np.max(np.abs(got_p - os1.body_parent_f)) <= 1e-4 * np.abs(os1.body_parent_f).max()
+    # the fused rollout falls back to the per-substep loop when reporting is requested: same numbers as stepping
+    r0, r1 = model.state(), model.state()
+    out = solver.rollout(r0, r1, ctrl, contacts, 1e-3, 3)
+    t0, t1 = model.state(), model.state()
+    for _ in range(3):
+        t0.clear_forces()
+        pipe.collide(t0, contacts)
+        solver.step(t0, t1, ctrl, contacts, 1e-3)
+        t0, t1 = t1, t0
+    assert np.array_equal(out.body_q.cpu().numpy(), t0.body_q.cpu().numpy())
+    assert np.array_equal(out.body_parent_f.cpu().numpy(), t0.body_parent_f.cpu().numpy())

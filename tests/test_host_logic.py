@@ -209,7 +209,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     fp = _lib.nt_featherstone_params(0.05, 1.0)
     sp = _lib.nt_semi_implicit_params(0.05, 1.0, 1e4, 1e2)
     assert lib.nt_collide(C.byref(m), C.byref(s), C.byref(ct), C.byref(cp), None) == NT_ERR_INVALID_ARG
-    assert lib.nt_xpbd_step(C.byref(m), C.byref(xp), C.byref(s), C.byref(s), C.byref(ctl), None, 1e-3, 0, None) == NT_ERR_INVALID_ARG
+    assert lib.nt_xpbd_step(C.byref(m), C.byref(xp), C.byref(s), C.byref(s), C.byref(ctl), None, 1e-3, 0, None, None) == NT_ERR_INVALID_ARG
     assert lib.nt_xpbd_rollout(C.byref(m), C.byref(xp), C.byref(cp), C.byref(s), C.byref(s), C.byref(ctl), C.byref(ct), 1e-3, 4,
                                None) == NT_ERR_INVALID_ARG
     assert lib.nt_semi_implicit_step(C.byref(m), C.byref(sp), C.byref(s), C.byref(s), C.byref(ctl), None, 1e-3, 0, None) == NT_ERR_INVALID_ARG
