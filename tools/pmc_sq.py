@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Issue / stall breakdown of the dominant kernel from one rocprofv3 SQ counter pass (run ON the GPU box).
+
+SQ has 8 counter slots per pass on gfx950 (MI355X_MICROARCH.md "rocprofv3 PMC slots").  WAIT_ANY (wave parked on
+s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~= WAVE_CYCLES, all in quad-cycles summed over waves.
+Writes gpurun_out/pmc_sq_<workload>.json.
+
+usage:  python tools/pmc_sq.py [quadruped|box_stack|quadruped_featherstone]
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+COUNTERS = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
+            "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS"]
+
+
+def main():
+    workload = sys.argv[1] if len(sys.argv) > 1 else "quadruped"
+    counters = sys.argv[2].split(",") if len(sys.argv) > 2 else COUNTERS
+    os.makedirs(OUT, exist_ok=True)
+    d = os.path.join(OUT, f"pmc_sq_{workload}")
+    env = dict(os.environ, TMPDIR="/tmp")
+    log = open(os.path.join(OUT, f"pmc_sq_{workload}.log"), "w")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                    sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "10", "--warmup", "10",
+                    "--no-cpu-baseline"], check=True, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=240)
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = defaultdict(lambda: defaultdict(float))
+    launches = defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "rollout" not in k:
+            continue
+        k = k[k.index("rollout") - 5:].split("(")[0]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[k].add(r["Dispatch_Id"])
+    res = {}
+    for k, c in acc.items():
+        n = max(len(launches[k]), 1)
+        per = {name: v / n for name, v in c.items()}
+        wc = per.get("SQ_WAVE_CYCLES", 0.0)
+        if wc:
+            per["frac_wait_any"] = per.get("SQ_WAIT_ANY", 0.0) / wc
+            per["frac_wait_inst_any"] = per.get("SQ_WAIT_INST_ANY", 0.0) / wc
+            per["frac_active_any"] = per.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+            per["frac_active_valu"] = per.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
+        res[k] = {"launches": n, "per_launch": per}
+    json.dump(res, open(os.path.join(OUT, f"pmc_sq_{workload}.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
