@@ -42,6 +42,17 @@ def _axis_vec(axis):
     return v / n if n > 0 else v
 
 
+def _clone(x):
+    """Cheap deep copy of the builder's per-entity records (numbers, tuples, nested lists, numpy arrays)."""
+    if isinstance(x, np.ndarray):
+        return x.copy()
+    if isinstance(x, list):
+        return [_clone(e) for e in x]
+    if isinstance(x, (int, float, str, tuple, bool, type(None), np.generic)):
+        return x
+    return copy.deepcopy(x)
+
+
 @dataclass
 class ShapeConfig:
     """Per-shape collision / material settings (builder.py:491-590 defaults)."""
@@ -566,7 +577,7 @@ class ModelBuilder:
         b0, j0, s0 = self.body_count, self.joint_count, self.shape_count
         q0, qd0, tq0, a0 = len(self.joint_q), len(self.joint_qd), len(self.joint_target_q), self.articulation_count
         for name in self._BODY_LISTS + self._DOF_LISTS + self._JOINT_LISTS + self._SHAPE_LISTS:
-            getattr(self, name).extend(copy.deepcopy(getattr(other, name)))
+            getattr(self, name).extend(_clone(x) for x in getattr(other, name))
         self.joint_q.extend(other.joint_q)
         self.joint_target_q.extend(other.joint_target_q)
         self.body_world.extend([w] * other.body_count)
@@ -645,8 +656,12 @@ class ModelBuilder:
                     p = (min(a, b), max(a, b))
                     if p not in filt:
                         pairs.append(p)
+        # shape indices grouped by world in one pass (ascending inside each world)
+        coll_idx = np.flatnonzero(np.asarray(colliding, dtype=bool)) if S else np.zeros(0, dtype=np.int64)
+        order = coll_idx[np.argsort(world[coll_idx], kind="stable")]
+        bounds = np.searchsorted(world[order], np.arange(self.world_count + 1))
         for w in range(self.world_count):
-            local = [i for i in range(S) if world[i] == w and colliding[i]]
+            local = order[bounds[w]:bounds[w + 1]].tolist()
             for g in globals_:
                 for l in local:
                     if self._test_group_pair(self.shape_collision_group[g], self.shape_collision_group[l]):

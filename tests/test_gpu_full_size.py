@@ -1,0 +1,147 @@
+"""Parity at BASELINE.json's full sizes (configs C4 / C3 / C2), through the C ABI, on exactly the bench workloads.
+
+The environments are independent, so the serial C++ oracle can still walk all of them in seconds: every environment of the
+4096-env quadruped batch and of the 256-env box-stack batch is compared with the oracle (state within the stated fp32
+tolerance, per-env contact counts and contact shape ids bit-exact).  On top of that, size-independent properties: an
+environment's result does not depend on the batch it is simulated in (bitwise, different workgroup / tile position), nor on
+envs_per_block; quaternions stay normalised; two identical launches are bit-identical."""
+import numpy as np
+import pytest
+
+from test_gpu_parity_xpbd import _compare_contacts, _lower_quadrupeds, _rel, _setup
+
+pytestmark = pytest.mark.gpu
+DT = 1e-3
+
+
+def _per_env_counts(model, oc):
+    t = model.env
+    n = int(oc.count[0])
+    s0, s1 = oc.shape0[:n], oc.shape1[:n]
+    L0, nloc = t.shape_local0, max(t.ns, 1)
+    loc0 = (s0 >= L0) & (s0 < L0 + t.env_count * t.ns)
+    env_of = np.where(loc0, (s0 - L0) // nloc, (s1 - L0) // nloc)
+    return np.bincount(env_of, minlength=t.env_count)
+
+
+@pytest.mark.parametrize("lowered", [False, True])
+def test_c4_4096_quadrupeds_one_frame_vs_oracle(lowered):
+    """bench.py's N=1 workload (4096 envs, XPBD iterations=2, one frame = 10 fused substeps); `lowered` puts the feet into
+    the ground so the contact solve is active in every environment."""
+    from oracle_bridge import OracleState
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, 4096, seed=1)
+    if lowered:
+        _lower_quadrupeds(nt, model, 0.24)
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+
+    # identical inputs: the whole contact set of all 4096 environments is bit-exact (pairs, counts, ids), geometry <= 1e-5
+    pipe.collide(s0, contacts)
+    pairs, _, _ = o.collide(os0.body_q, oc)
+    _compare_contacts(model, contacts, oc, pairs)
+    if lowered:
+        assert int(oc.count[0]) >= 4096 * 4
+
+    out = nt.solvers.SolverXPBD(model, iterations=2).rollout(s0, s1, None, contacts, DT, 10)
+    oout = o.xpbd_rollout(os0, os1, o.control(), oc, DT, 10, iterations=2)
+    q, qd = out.body_q.cpu().numpy(), out.body_qd.cpu().numpy()
+    assert _rel(q, oout.body_q) <= 1e-4
+    # XPBD velocities are position differences / dt: a 1e-6 position rounding shows up as 1e-3 in velocity
+    assert _rel(qd, oout.body_qd) <= 5e-3
+    assert np.all(np.abs(np.linalg.norm(q[:, 3:], axis=1) - 1.0) < 1e-5)
+    # contacts of the 10th substep come from states that already differ by rounding: a contact sitting within ~1e-6 of
+    # the gap threshold may flip in a handful of the 4096 x 13 pairs, everything else must agree exactly
+    got, want = contacts.rigid_contact_count_per_env.cpu().numpy(), _per_env_counts(model, oc)
+    assert np.mean(got == want) >= 0.999
+    assert abs(int(got.sum()) - int(want.sum())) <= 8
+
+
+def test_c4_env_result_is_independent_of_batch_and_tile():
+    """Environment k of the 4096-env batch == the same environment simulated in a 96-env batch (same seed => same
+    per-env jitter), bitwise, and for every envs_per_block; a relaunch is bit-identical."""
+    from scenes import quadruped_scene
+
+    import newton_amd as nt
+
+    def run(n, epb):
+        model = quadruped_scene(n, device="cuda:0", seed=1)
+        _lower_quadrupeds(nt, model, 0.22)
+        s0, s1 = model.state(), model.state()
+        contacts = nt.CollisionPipeline(model, envs_per_block=epb).contacts()
+        out = nt.solvers.SolverXPBD(model, iterations=2, envs_per_block=epb).rollout(s0, s1, None, contacts, DT, 10)
+        nb = model.env.nb
+        return out.body_q.cpu().numpy().reshape(n, nb, 7), out.body_qd.cpu().numpy().reshape(n, nb, 6)
+
+    q_full, qd_full = run(4096, 0)
+    q_again, qd_again = run(4096, 0)
+    assert np.array_equal(q_full, q_again) and np.array_equal(qd_full, qd_again)
+    for n, epb in ((96, 0), (96, 8), (40, 16)):  # wider tiles do not fit this model's LDS footprint
+        q, qd = run(n, epb)
+        assert np.array_equal(q, q_full[:n]), (n, epb)
+        assert np.array_equal(qd, qd_full[:n]), (n, epb)
+
+
+def test_c3_4096_quadrupeds_featherstone_frame_vs_oracle():
+    """Config C3 at full size: SolverFeatherstone, 4096 envs, 10 fused substeps of PD hold in free flight (the feet touch down
+    later: the chaotic impact phase is covered step-wise in test_gpu_parity_featherstone.py)."""
+    from oracle_bridge import OracleState
+    from scenes import quadruped_scene
+
+    nt, model, o = _setup(quadruped_scene, 4096, seed=1)
+    s0, s1 = model.state(), model.state()
+    contacts = nt.CollisionPipeline(model).contacts()
+    out = nt.solvers.SolverFeatherstone(model).rollout(s0, s1, None, contacts, DT, 10)
+
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+    c = o.control()
+    for _ in range(10):
+        os0.body_f[:] = 0
+        o.collide(os0.body_q, oc)
+        o.featherstone_step(os0, os1, c, oc, DT)
+        os0, os1 = os1, os0
+    assert _rel(out.joint_q.cpu().numpy(), os0.joint_q) <= 1e-4
+    assert _rel(out.body_q.cpu().numpy(), os0.body_q) <= 1e-4
+    assert _rel(out.joint_qd.cpu().numpy(), os0.joint_qd) <= 1e-3
+    assert np.array_equal(contacts.rigid_contact_count_per_env.cpu().numpy(), _per_env_counts(model, oc))
+
+
+@pytest.mark.parametrize("broad_phase", ["explicit", "nxn"])
+def test_c2_256_box_stacks_vs_oracle(broad_phase):
+    """Config C2 at full size: 256 envs x 8 stacked boxes, XPBD iterations=4, dt=1/240, box-box through MPR/GJK + manifold."""
+    from oracle_bridge import OracleState
+    from scenes import box_stack_scene
+
+    nt, model, o = _setup(box_stack_scene, 256, seed=0)
+    dt = 1.0 / 240.0
+    s0, s1 = model.state(), model.state()
+    pipe = nt.CollisionPipeline(model, broad_phase=broad_phase)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=4)
+    os0, os1 = OracleState(model), OracleState(model)
+    oc = o.contacts()
+    c = o.control()
+    for _ in range(3):
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, None, contacts, dt)
+        s0, s1 = s1, s0
+        os0.body_f[:] = 0
+        pairs, _, _ = o.collide(os0.body_q, oc, broad_phase=broad_phase)
+        o.xpbd_step(os0, os1, c, oc, dt, iterations=4)
+        os0, os1 = os1, os0
+    n = int(oc.count[0])
+    assert n >= 256 * 8 * 4
+    assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == n
+    assert np.array_equal(contacts.rigid_contact_count_per_env.cpu().numpy(), _per_env_counts(model, oc))
+    t = model.env
+    mask = contacts.candidate_pair_mask.cpu().numpy()
+    got = {tuple(p) for p in np.asarray(model.shape_contact_pairs).reshape(t.env_count, t.np, 2)[mask]}
+    assert got == {tuple(p) for p in pairs}
+    assert _rel(s0.body_q.cpu().numpy(), os0.body_q) <= 1e-4
+    assert _rel(s0.body_qd.cpu().numpy(), os0.body_qd, floor=1.0) <= 1e-3
