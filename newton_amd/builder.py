@@ -410,6 +410,15 @@ class ModelBuilder:
             raise ValueError("articulation needs at least one joint")
         if joints != list(range(joints[0], joints[0] + len(joints))):
             raise ValueError("articulation joints must be contiguous and ascending")
+        child_to_parent = {}
+        for j in joints:  # builder.py:3151-3163
+            child, parent = self.joint_child[j], self.joint_parent[j]
+            if child_to_parent.setdefault(child, parent) != parent:
+                raise ValueError(f"Body {child} has multiple parents in this articulation: loop-closing joints must not "
+                                 "be part of an articulation.")
+            if parent != -1 and int(self.body_flags[child]) & int(BodyFlags.KINEMATIC):
+                raise ValueError(f"Body {child} ('{self.body_label[child]}') is kinematic but is attached to parent body "
+                                 f"{parent}. Only root bodies (whose joint parent is the world) can be kinematic.")
         aid = self.articulation_count
         self.articulation_start.append(joints[0])
         self.articulation_world.append(self.current_world)
@@ -710,7 +719,7 @@ class ModelBuilder:
             I = 0.5 * (np.asarray(I, dtype=np.float64) + np.asarray(I, dtype=np.float64).T)
             if mass > 0.0:
                 inv_mass.append(1.0 / mass)
-                inv_inertia.append(np.linalg.inv(I))
+                inv_inertia.append(np.linalg.inv(I) if I.any() else np.zeros((3, 3)))  # point mass without shapes
             else:
                 inv_mass.append(0.0)
                 inv_inertia.append(np.zeros((3, 3)))

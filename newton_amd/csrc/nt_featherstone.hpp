@@ -421,6 +421,7 @@ NT_DI void fs_body_force_item(const FsCtx<EPB>& f, int b, bool forces_are_zero) 
             }
         }
     }
+    if (c.T.body_flags[b] & BODY_KINEMATIC) { f0 = vec3(0.0f); t0 = vec3(0.0f); }  // zero_kinematic_body_forces (kernels.py:54-63)
     c.st_lv3(f.F.bfx, 0, nb, b, f0);
     c.st_lv3(f.F.bfx, 3, nb, b, t0);
 }
@@ -640,6 +641,13 @@ NT_DI void fs_integrate_item(const FsCtx<EPB>& f, int j) {
     auto qdd = [&](int i) { return f.f(f.F.qdd, i); };
     auto qdn = [&](int i) -> float& { return f.f(f.F.qdo, i); };
     if (type == JT_FIXED) return;
+    if (c.T.body_flags[child] & BODY_KINEMATIC) {
+        // zero_kinematic_joint_qdd + copy_kinematic_joint_state (kernels.py:1932-1976): the prescribed joint state passes
+        // through the solve unchanged (joint_q stays, the internal speeds are copied)
+        const int nd_j = (type == JT_FREE || type == JT_DISTANCE) ? 6 : (type == JT_BALL ? 3 : lin + ang);
+        for (int i = 0; i < nd_j; ++i) qdn(ds + i) = qd(ds + i);
+        return;
+    }
     if (type == JT_PRISMATIC || type == JT_REVOLUTE) {
         float qd_new = qd(ds) + qdd(ds) * dt;
         float q_new = q(cs) + qd_new * dt;

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .enums import GeoType, JointType, ShapeFlags
+from .enums import BodyFlags, GeoType, JointType, ShapeFlags
 
 
 def _is_gpu(device) -> bool:
@@ -331,10 +331,17 @@ class DeviceModel:
         body_world = np.asarray(m.body_world).reshape(E, nb)[:, 0] if nb else np.zeros(E, dtype=np.int32)
         grav[:, :E] = m.gravity[body_world].T  # gravity[-1] is the global world (model.py:1300-1304)
         joint = np.concatenate([m.joint_X_p, m.joint_X_c], axis=1) if nj else np.zeros((0, 14), dtype=np.float32)
+        # joint_armature_effective (solver_featherstone.py:269-282): 1e10 on the dofs of joints whose child body is
+        # kinematic; the armature is only read by the Featherstone kernels
+        armature = np.array(m.joint_armature, dtype=np.float32)
+        if nd and nj:
+            kin = (np.asarray(m.body_flags)[np.asarray(m.joint_child)] & int(BodyFlags.KINEMATIC)) != 0
+            dof_joint = np.searchsorted(np.asarray(m.joint_qd_start), np.arange(len(armature)), side="right") - 1
+            armature[kin[dof_joint]] = 1.0e10
         dof = np.concatenate([
             m.joint_axis.reshape(-1, 3), m.joint_limit_lower[:, None], m.joint_limit_upper[:, None],
             m.joint_target_ke[:, None], m.joint_target_kd[:, None], m.joint_limit_ke[:, None], m.joint_limit_kd[:, None],
-            m.joint_armature[:, None], m.joint_damping[:, None]], axis=1) if nd else np.zeros((0, 11), dtype=np.float32)
+            armature[:, None], m.joint_damping[:, None]], axis=1) if nd else np.zeros((0, 11), dtype=np.float32)
         shape_all = np.concatenate([
             m.shape_transform, m.shape_scale, m.shape_margin[:, None], m.shape_gap[:, None], m.shape_material_mu[:, None],
             m.shape_material_mu_torsional[:, None], m.shape_material_mu_rolling[:, None], m.shape_material_ke[:, None],

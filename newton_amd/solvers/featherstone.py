@@ -41,8 +41,9 @@ class SolverFeatherstone(SolverBase):
         if not np.array_equal(np.asarray(t.joint_child), np.arange(t.nj)) or t.nb != t.nj:
             # the reference's eval_rigid_mass indexes body_I_s by joint index (kernels.py:1466-1480)
             raise NotImplementedError("SolverFeatherstone: body j must be the child of joint j")
-        if np.any(np.asarray(t.body_flags) & int(BodyFlags.KINEMATIC)):
-            raise NotImplementedError("SolverFeatherstone: kinematic bodies are not supported")
+        kin = (np.asarray(t.body_flags) & int(BodyFlags.KINEMATIC)) != 0
+        if np.any(kin & (np.asarray(t.joint_parent) >= 0)):  # child of joint j is body j (checked above)
+            raise ValueError("SolverFeatherstone: only root bodies (joint parent = world) can be kinematic")
         self.angular_damping = angular_damping
         self.update_mass_matrix_interval = 1
         self.friction_smoothing = friction_smoothing

@@ -432,6 +432,11 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
         eval_body_contact(m, contacts, body_q, qd_fk.data(), prm->friction_smoothing, body_f.data());
     }
 
+    // zero_kinematic_body_forces (kernels.py:54-63, solver_featherstone.py:682-689)
+    auto kinematic_joint = [&](int j) { return (m->body_flags[m->joint_child[j]] & BODY_KINEMATIC) != 0; };
+    for (int b = 0; b < B; ++b)
+        if (m->body_flags[b] & BODY_KINEMATIC) sts(body_f.data(), b, spatial());
+
     // eval_rigid_tau (kernels.py:1320-1419)
     for (int a = 0; a < m->articulation_count; ++a) {
         int start = m->articulation_start[a], end = m->articulation_end[a];
@@ -507,7 +512,11 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
             for (int i = 0; i < n * n && i < g_probe_cap; ++i) g_probe_H[i] = H[i];
             g_probe_H = nullptr;
         }
-        const float* R = m->joint_armature + dof_start;
+        // joint_armature_effective: 1e10 on the dofs of joints whose child is kinematic (solver_featherstone.py:269-282)
+        std::vector<float> R(m->joint_armature + dof_start, m->joint_armature + dof_start + n);
+        for (int j = joint_start; j < joint_end; ++j)
+            if (kinematic_joint(j))
+                for (int d = m->joint_qd_start[j]; d < dof_end(m, j); ++d) R[d - dof_start] = 1.0e10f;
         for (int j = 0; j < n; ++j) {
             float s = H[size_t(j) * n + j] + R[j];
             for (int k = 0; k < j; ++k) {
@@ -537,11 +546,24 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
         }
     }
 
+    // zero_kinematic_joint_qdd (kernels.py:1932-1948)
+    for (int j = 0; j < J; ++j)
+        if (kinematic_joint(j))
+            for (int d = m->joint_qd_start[j]; d < dof_end(m, j); ++d) joint_qdd[d] = 0.0f;
+
     // integrate_generalized_joints (kernels.py:1849-1893)
     for (int j = 0; j < J; ++j)
         jcalc_integrate(m, m->joint_parent[j], ldx(m->joint_X_c, j), ld3(m->body_com, m->joint_child[j]), m->joint_type[j],
                         s_in->joint_q, qd_internal_in.data(), joint_qdd.data(), m->joint_q_start[j], m->joint_qd_start[j],
                         m->joint_dof_dim[2 * j], m->joint_dof_dim[2 * j + 1], dt, s_out->joint_q, qd_internal_out.data());
+
+    // copy_kinematic_joint_state (kernels.py:1951-1976): prescribed joint state passes through the solve
+    for (int j = 0; j < J; ++j) {
+        if (!kinematic_joint(j)) continue;
+        int q_end = j + 1 < J ? m->joint_q_start[j + 1] : m->coord_count;
+        for (int i = m->joint_q_start[j]; i < q_end; ++i) s_out->joint_q[i] = s_in->joint_q[i];
+        for (int d = m->joint_qd_start[j]; d < dof_end(m, j); ++d) qd_internal_out[d] = qd_internal_in[d];
+    }
 
     // eval_fk_with_velocity_conversion (kernels.py:1987-2150) -> state_out.body_q / body_qd
     float* out_q = s_out->body_q;
