@@ -174,7 +174,7 @@ typedef struct {
 
 typedef struct {
     int32_t broad_phase;  /* 0 explicit pairs (default), 1 nxn, 2 sap -- all emit the same per-env pair set */
-    int32_t envs_per_block; /* 0 = auto; otherwise 16, 32 or 64 */
+    int32_t envs_per_block; /* 0 = auto (widest tile that fits LDS and still fills the CUs; 1 for scenes over 20 KB of LDS per env); otherwise 1, 8, 16, 32 or 64 */
 } nt_collide_params;
 
 /* -------- hot path -------- */

@@ -2115,7 +2115,8 @@ bool epb_fits(const nt_model& m, int epb) {
 }
 
 int pick_epb(const nt_model& m, int requested) {
-    if (requested == 8 || requested == 16 || requested == 32 || requested == 64) return epb_fits(m, requested) ? requested : 0;
+    if (requested == 1 || requested == 8 || requested == 16 || requested == 32 || requested == 64)
+        return epb_fits(m, requested) ? requested : 0;
     // auto: the widest tile (best coalescing) that still yields >= 256 workgroups (one per CU); else the narrowest
     const int cands[4] = {64, 32, 16, 8};
     for (int i = 0; i < 4; ++i) {
@@ -2126,7 +2127,9 @@ int pick_epb(const nt_model& m, int requested) {
     }
     for (int i = 3; i >= 0; --i)
         if (epb_fits(m, cands[i])) return cands[i];
-    return 0;
+    // scenes too large for 8 environments per workgroup (> 20 KB of LDS each): one environment per workgroup, 256 lanes
+    // on its items, several workgroups resident per CU while their LDS fits
+    return epb_fits(m, 1) ? 1 : 0;
 }
 
 template <typename K>
@@ -2153,18 +2156,21 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
 #define NT_DISPATCH_EPB(KERNEL, args, epb, stream)                                      \
     ((epb) == 64 ? launch(KERNEL<64>, args, 64, stream)                                 \
      : (epb) == 32 ? launch(KERNEL<32>, args, 32, stream)                               \
-     : (epb) == 16 ? launch(KERNEL<16>, args, 16, stream) : launch(KERNEL<8>, args, 8, stream))
+     : (epb) == 16 ? launch(KERNEL<16>, args, 16, stream)                               \
+     : (epb) == 8 ? launch(KERNEL<8>, args, 8, stream) : launch(KERNEL<1>, args, 1, stream))
 
 #define NT_DISPATCH_EPB2(KERNEL, B, args, epb, stream)                                  \
     ((epb) == 64 ? launch(KERNEL<64, B>, args, 64, stream)                              \
      : (epb) == 32 ? launch(KERNEL<32, B>, args, 32, stream)                            \
-     : (epb) == 16 ? launch(KERNEL<16, B>, args, 16, stream) : launch(KERNEL<8, B>, args, 8, stream))
+     : (epb) == 16 ? launch(KERNEL<16, B>, args, 16, stream)                            \
+     : (epb) == 8 ? launch(KERNEL<8, B>, args, 8, stream) : launch(KERNEL<1, B>, args, 1, stream))
 // kernels that collide are compiled twice: the convex (MPR/GJK) code only exists in the variant used by models
 // that have convex-routed pairs, so analytic-only models keep their register budget
-// the convex variants are only instantiated for 8 / 16 envs per workgroup (build time): wider tiles fall back to 16
+// the convex variants are only instantiated for 1 / 8 / 16 envs per workgroup (build time): wider tiles fall back to 16
 #define NT_DISPATCH_EPB_CVX(KERNEL, m, args, epb, stream)                                              \
     ((m).np_analytic < (m).np                                                                          \
-         ? ((epb) >= 16 ? launch(KERNEL<16, true>, args, 16, stream) : launch(KERNEL<8, true>, args, 8, stream)) \
+         ? ((epb) >= 16 ? launch(KERNEL<16, true>, args, 16, stream)                                   \
+            : (epb) == 8 ? launch(KERNEL<8, true>, args, 8, stream) : launch(KERNEL<1, true>, args, 1, stream)) \
          : NT_DISPATCH_EPB2(KERNEL, false, args, epb, stream))
 
 bool model_ok(const nt_model* m) {

@@ -45,7 +45,10 @@ class Mesh:
             self.has_inertia = True
 
     @staticmethod
-    def create_box(hx: float, hy: float, hz: float) -> Mesh:
+    def create_box(hx: float, hy: float, hz: float, *, duplicate_vertices: bool = False, compute_normals: bool = False,
+                   compute_uvs: bool = False, compute_inertia: bool = True) -> Mesh:
+        """newton.Mesh.create_box signature (geometry/types.py); only the 8 corners matter for collision, so the rendering
+        options (duplicated per-face vertices, normals, uvs) are accepted and ignored."""
         s = np.array([hx, hy, hz], dtype=np.float64)
         v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float64) * s
         return Mesh.convex_hull_of(v)

@@ -80,7 +80,7 @@ def test_c4_env_result_is_independent_of_batch_and_tile():
     q_full, qd_full = run(4096, 0)
     q_again, qd_again = run(4096, 0)
     assert np.array_equal(q_full, q_again) and np.array_equal(qd_full, qd_again)
-    for n, epb in ((96, 0), (96, 8), (40, 16)):  # wider tiles do not fit this model's LDS footprint
+    for n, epb in ((96, 0), (96, 8), (40, 16), (24, 1)):  # wider tiles do not fit this model's LDS footprint
         q, qd = run(n, epb)
         assert np.array_equal(q, q_full[:n]), (n, epb)
         assert np.array_equal(qd, qd_full[:n]), (n, epb)

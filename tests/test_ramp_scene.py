@@ -1,0 +1,123 @@
+"""newton/tests/test_rigid_contact.py:236-512 (test_shape_collisions_gjk_mpr_multicontact): boxes, spheres, a capsule, a
+cylinder, cones and convex-hull cubes lined up on a 30-degree ramp (tilted infinite plane, two guide rails, an end wall),
+XPBD iterations=2, 100 frames x 10 substeps.  Every body must stay put (< 0.15 cube sizes, < 10 degrees): a whole-pipeline
+known answer for the MPR/GJK + manifold restatement (box-box, box-hull, cone-plane, cylinder-box, ...).  CPU oracle."""
+import numpy as np
+
+import newton_amd as nt
+from newton_amd import _np_math as nm
+
+
+def _build_on(device):
+    return _build(device)
+
+
+def _build(device=None):
+    L, T, ang, wall_h = 10.0, 0.5, np.radians(30.0), 2.0
+    cube = 1.0 * 0.99
+    width = cube * 2.01
+    b = nt.ModelBuilder()
+    b.default_shape_cfg.ke, b.default_shape_cfg.kd, b.default_shape_cfg.kf = 2e4, 500.0, 0.5
+    center = np.array([0.0, L / 2 * np.cos(ang), L / 2 * np.sin(ang)])
+    rq = nm.quat_from_axis_angle([1.0, 0.0, 0.0], float(ang))
+    b.add_shape_plane(body=-1, xform=[*center, *rq], width=0.0, length=0.0)
+    fwd, up, right = (nm.quat_rotate(rq, v) for v in ([0.0, -1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]))
+    gh, gt = 0.3, 0.1
+    for sgn in (1.0, -1.0):
+        c = center + sgn * (width / 2 + gt / 2) * right + (gh / 2) * up
+        b.add_shape_box(body=-1, xform=[*c, *rq], hx=gt / 2, hy=L / 2, hz=gh / 2)
+    shift = 0.6 * L
+    tmp = center + 0.5 * cube * (up + shift * fwd)
+    b.add_shape_box(body=-1, xform=[0.0, tmp[1] - cube / 2 * 1.4 - T / 2, tmp[2], 0.0, 0.0, 0.0, 1.0], hx=width / 2, hy=T / 2,
+                    hz=wall_h / 2)
+
+    def at(side, along):
+        return center + 0.5 * cube * (up + side * right + (shift - along) * fwd)
+
+    def pair(along, add):
+        for side in (1.0, -1.0):
+            body = b.add_body(xform=[*at(side, along), *rq])
+            add(body)
+
+    pair(0.0, lambda body: b.add_shape_box(body, hx=cube / 2, hy=cube / 2, hz=cube / 2))
+    pair(2.01, lambda body: b.add_shape_sphere(body, radius=cube / 2))
+    z_to_x = nm.quat_from_axis_angle([0.0, 1.0, 0.0], 0.5 * np.pi)
+    lying = nm.quat_mul(rq, z_to_x)
+    body = b.add_body(xform=[*at(0.0, 4.02), *lying])
+    b.add_shape_capsule(body, radius=cube / 2, half_height=cube / 2)
+    body = b.add_body(xform=[*at(0.0, 6.03), *lying])
+    b.add_shape_cylinder(body, radius=cube / 2, half_height=cube)
+    pair(8.04, lambda body: b.add_shape_box(body, hx=cube / 2, hy=cube / 2, hz=cube / 2))
+    pair(10.05, lambda body: b.add_shape_cone(body, radius=cube / 2, half_height=cube / 2))
+    pair(12.06, lambda body: b.add_shape_box(body, hx=cube / 2, hy=cube / 2, hz=cube / 2))
+    mesh = nt.Mesh.create_box(cube / 2, cube / 2, cube / 2, duplicate_vertices=False, compute_normals=False, compute_uvs=False,
+                              compute_inertia=False)
+    pair(14.07, lambda body: b.add_shape_convex_hull(body, mesh=mesh, scale=(1.0, 1.0, 1.0)))
+    b.add_ground_plane()
+    return b.finalize(device=device), cube
+
+
+def test_ramp_lineup_stays_put(oracle_lib):
+    from oracle_bridge import Oracle, OracleState
+
+    model, cube = _build()
+    assert model.body_count == 14
+    o = Oracle(model)
+    s0, s1, oc = OracleState(model), OracleState(model), o.contacts()
+    q_initial = s0.body_q.copy()
+    dt = 1.0 / 60.0 / 10
+    for _ in range(100 * 10):
+        s0.body_f[:] = 0
+        o.collide(s0.body_q, oc)
+        o.xpbd_step(s0, s1, o.control(), oc, dt, iterations=2)
+        s0, s1 = s1, s0
+    for i in range(model.body_count):
+        disp = np.linalg.norm(s0.body_q[i, :3] - q_initial[i, :3])
+        dot = np.clip(abs(float(np.dot(q_initial[i, 3:], s0.body_q[i, 3:]))), 0.0, 1.0)
+        assert disp < 0.15 * cube, (i, disp)
+        assert 2.0 * np.arccos(dot) < np.radians(10.0), (i, np.degrees(2.0 * np.arccos(dot)))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_ramp_lineup_hip_matches_oracle_and_stays_put():
+    """161 candidate pairs (118 through MPR/GJK) need 59 KB of LDS per environment: the scene runs with one environment per
+    workgroup (envs_per_block = 1, picked automatically).  20 teacher-forced single steps vs the oracle, then the reference's
+    100-frame stability criterion on the HIP path itself."""
+    from oracle_bridge import Oracle, OracleState
+
+    model, cube = _build()
+    model_gpu, _ = _build_on("cuda:0")
+    o = Oracle(model)
+    pipe = nt.CollisionPipeline(model_gpu)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model_gpu, iterations=2)
+    s0, s1 = model_gpu.state(), model_gpu.state()
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    dt = 1.0 / 600.0
+    for k in range(20):
+        s0.body_q, s0.body_qd = os0.body_q, os0.body_qd  # teacher forcing: both start every step from the oracle's state
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, None, contacts, dt)
+        os0.body_f[:] = 0
+        o.collide(os0.body_q, oc)
+        o.xpbd_step(os0, os1, o.control(), oc, dt, iterations=2)
+        assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == int(oc.count[0]), k
+        got, want = s1.body_q.cpu().numpy(), os1.body_q
+        assert np.max(np.abs(got - want)) <= 2e-5, k
+        os0, os1 = os1, os0
+    # stability on the HIP path
+    s0, s1 = model_gpu.state(), model_gpu.state()
+    q_initial = s0.body_q.cpu().numpy().copy()
+    for _ in range(100):
+        out = solver.rollout(s0, s1, None, contacts, dt, 10)
+        if out is s1:
+            s0, s1 = s1, s0
+    q = s0.body_q.cpu().numpy()
+    for i in range(model.body_count):
+        dot = np.clip(abs(float(np.dot(q_initial[i, 3:], q[i, 3:]))), 0.0, 1.0)
+        assert np.linalg.norm(q[i, :3] - q_initial[i, :3]) < 0.15 * cube, i
+        assert 2.0 * np.arccos(dot) < np.radians(10.0), i
