@@ -225,6 +225,37 @@ nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t ca
 nt_status nt_contacts_export_force(const nt_model* m, const nt_contacts* c, const float* contact_impulse, float dt,
                                    int32_t cap, float* out_force, int32_t* scan_tmp, void* stream);
 
+/* -------- standalone broad phases (newton.geometry.BroadPhaseAllPairs / BroadPhaseSAP / BroadPhaseExplicit) --------
+ * World-aware candidate-pair search on arbitrary AABB arrays (newton/_src/geometry/broad_phase_nxn.py:29-535,
+ * broad_phase_sap.py:44-848, broad_phase_common.py:20-388).  All arrays are device pointers in Newton's flat AoS layout.
+ * Output: canonical pairs (min, max) appended in unspecified order (the reference appends atomically too);
+ * count[0] is ADDED to (zero it first) and keeps counting past `cap` (broad_phase_common.py:204-218). */
+typedef struct {
+    const float* lower;           /* [n][3] AABB lower bounds */
+    const float* upper;           /* [n][3] */
+    const float* gap;             /* [n] per-shape cutoff added to both sides, or NULL when the AABBs are pre-expanded */
+    const int32_t* group;         /* [n] collision groups (0 off, >0 exclusive, <0 collides with other groups) */
+    const int32_t* world;         /* [n] world ids, -1 = shared by every world */
+    const int32_t* filter_pairs;  /* [num_filter_pairs][2] excluded pairs, canonical and lexicographically sorted; may be NULL */
+    int32_t num_filter_pairs;
+    int32_t include_static_kinematic_pairs; /* 0: drop pairs whose two bodies are static / kinematic (needs shape_body) */
+    const int32_t* shape_body;    /* [n] or NULL (no immovable filtering) */
+    const int32_t* body_flags;    /* [bodies] or NULL (static-static filtering only) */
+} nt_broadphase_in;
+
+/* index_map / slice_ends: precompute_world_map (broad_phase_common.py:271-388): per world its shapes followed by the shared
+ * ones, plus a trailing segment holding only the shared shapes; num_regular_worlds = segments - 1. */
+nt_status nt_broadphase_nxn(const nt_broadphase_in* in, const int32_t* index_map, const int32_t* slice_ends, int32_t segments,
+                            int32_t num_regular_worlds, int32_t map_len, int32_t* pairs /*[cap][2]*/, int32_t* count,
+                            int32_t cap, void* stream);
+/* sorted_map: index_map with every segment ordered by ascending (lower.x - gap); same pair set as nt_broadphase_nxn */
+nt_status nt_broadphase_sap(const nt_broadphase_in* in, const int32_t* sorted_map, const int32_t* slice_ends, int32_t segments,
+                            int32_t num_regular_worlds, int32_t map_len, int32_t* pairs, int32_t* count, int32_t cap,
+                            void* stream);
+/* pair_list: [n_pairs][2] precomputed shape pairs (Model.shape_contact_pairs); only the AABB (and immovable) test remains */
+nt_status nt_broadphase_explicit(const nt_broadphase_in* in, const int32_t* pair_list, int32_t n_pairs, int32_t* pairs,
+                                 int32_t* count, int32_t cap, void* stream);
+
 /* -------- introspection -------- */
 const char* nt_error_string(nt_status s);
 const char* nt_build_info(void);                 /* "gfx950 ..." */

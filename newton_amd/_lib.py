@@ -70,6 +70,12 @@ class nt_xpbd_report(C.Structure):
     _fields_ = [("contact_impulse", C.c_void_p), ("joint_impulse", C.c_void_p)]
 
 
+class nt_broadphase_in(C.Structure):
+    _fields_ = [("lower", C.c_void_p), ("upper", C.c_void_p), ("gap", C.c_void_p), ("group", C.c_void_p), ("world", C.c_void_p),
+                ("filter_pairs", C.c_void_p), ("num_filter_pairs", C.c_int32), ("include_static_kinematic_pairs", C.c_int32),
+                ("shape_body", C.c_void_p), ("body_flags", C.c_void_p)]
+
+
 class nt_semi_implicit_params(C.Structure):
     _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float), ("joint_attach_ke", C.c_float),
                 ("joint_attach_kd", C.c_float)]
@@ -112,6 +118,9 @@ SYMBOLS = {
     "nt_contacts_export": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_contacts), C.c_int32, _P, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P, _P, _P]),
     "nt_contacts_export_force": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_contacts), _P, C.c_float, C.c_int32, _P, _P, _P]),
+    "nt_broadphase_nxn": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
+    "nt_broadphase_sap": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
+    "nt_broadphase_explicit": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, C.c_int32, _P, _P, C.c_int32, _P]),
     "nt_error_string": (C.c_char_p, [C.c_int32]),
     "nt_build_info": (C.c_char_p, []),
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
