@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dbg = "/tmp/libnewton_hip_timing.so"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                 "-DNT_PHASE_TIMING", os.path.join(ROOT, "newton_amd/csrc/nt_kernels.hip"),
                 os.path.join(ROOT, "newton_amd/csrc/nt_broadphase.hip"), "-o", dbg], check=True)
 os.environ["NEWTON_HIP_LIB"] = dbg
