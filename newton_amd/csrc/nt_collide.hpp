@@ -1,0 +1,290 @@
+// nt_collide.hpp -- collide phases: compute_shape_aabbs, per-env broad phase test, narrow phase routing (analytic primitives /
+// MPR-GJK manifold), contact writer.
+// Included by nt_kernels.hip inside its anonymous namespace, in this order: nt_layout.hpp, nt_collide.hpp, nt_xpbd.hpp,
+// nt_semi_implicit.hpp, nt_featherstone.hpp (one translation unit; the split is for reading, not for separate compilation).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// collide: compute_shape_aabbs (collide.py:283-472)
+// ------------------------------------------------------------------------------------------------
+NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_gap, const float* mesh_bounds, vec3& lo,
+                      vec3& hi) {
+    vec3 pos = X.p;
+    quat q = X.q;
+    vec3 mv(effective_gap, effective_gap, effective_gap);
+    bool infinite_plane = (geo_type == GEO_PLANE) && (scale.x == 0.0f && scale.y == 0.0f);
+    if (infinite_plane) {
+        vec3 normal = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        const float H = 1.0e6f;
+        vec3 he(H, H, H);
+        lo = pos - he - mv;
+        hi = pos + he + mv;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float n_i = vget(normal, i);
+            if (fabsf(n_i) > 0.5f) {
+                float lateral = fabsf(vget(normal, (i + 1) % 3)) + fabsf(vget(normal, (i + 2) % 3));
+                float rise = lateral * H / fabsf(n_i);
+                if (n_i > 0.0f) vset(hi, i, fminw(vget(hi, i), vget(pos, i) + rise + effective_gap));
+                else vset(lo, i, fmaxw(vget(lo, i), vget(pos, i) - rise - effective_gap));
+            }
+        }
+        return;
+    }
+    vec3 he;
+    if (geo_type == GEO_SPHERE) {
+        he = vec3(scale.x, scale.x, scale.x);
+    } else if (geo_type == GEO_BOX) {
+        vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
+        vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
+        vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        he = vec3(fabsf(r0.x) * scale.x + fabsf(r1.x) * scale.y + fabsf(r2.x) * scale.z,
+                  fabsf(r0.y) * scale.x + fabsf(r1.y) * scale.y + fabsf(r2.y) * scale.z,
+                  fabsf(r0.z) * scale.x + fabsf(r1.z) * scale.y + fabsf(r2.z) * scale.z);
+    } else if (geo_type == GEO_CAPSULE) {
+        vec3 axis = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        he = vec3(scale.x, scale.x, scale.x) + vabs(axis) * scale.y;
+    } else if (geo_type == GEO_CYLINDER) {
+        float radius = scale.x, hh = scale.y, barrel = scale.z;
+        if (barrel >= hh && barrel > 0.0f) radius += (hh * hh) / (barrel + sqrtf(barrel * barrel - hh * hh));
+        vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
+        vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
+        vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        he = vec3(radius * sqrtf(r0.x * r0.x + r1.x * r1.x) + hh * fabsf(r2.x),
+                  radius * sqrtf(r0.y * r0.y + r1.y * r1.y) + hh * fabsf(r2.y),
+                  radius * sqrtf(r0.z * r0.z + r1.z * r1.z) + hh * fabsf(r2.z));
+    } else if (geo_type == GEO_CONVEX_MESH) {
+        // pre-computed local AABB (scale baked in) rotated to the world frame (collide.py:421-445)
+        vec3 a = cw_mul(vec3(mesh_bounds[0], mesh_bounds[1], mesh_bounds[2]), scale);
+        vec3 b = cw_mul(vec3(mesh_bounds[3], mesh_bounds[4], mesh_bounds[5]), scale);
+        vec3 local_lo = vmin(a, b), local_hi = vmax(a, b);
+        vec3 center = (local_lo + local_hi) * 0.5f;
+        vec3 half = (local_hi - local_lo) * 0.5f;
+        vec3 world_center = quat_rotate(q, center) + pos;
+        vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
+        vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
+        vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        vec3 world_half(fabsf(r0.x) * half.x + fabsf(r1.x) * half.y + fabsf(r2.x) * half.z,
+                        fabsf(r0.y) * half.x + fabsf(r1.y) * half.y + fabsf(r2.y) * half.z,
+                        fabsf(r0.z) * half.x + fabsf(r1.z) * half.y + fabsf(r2.z) * half.z);
+        lo = world_center - world_half - mv;
+        hi = world_center + world_half + mv;
+        return;
+    } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE) {
+        // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space
+        mat33 Rt = transpose(quat_to_matrix(q));
+        vec3 local_x(Rt.m00, Rt.m10, Rt.m20), local_y(Rt.m01, Rt.m11, Rt.m21), local_z(Rt.m02, Rt.m12, Rt.m22);
+        Geom g;
+        g.type = geo_type;
+        g.scale = scale;
+        float max_x = dot(local_x, support_map(g, local_x));
+        float max_y = dot(local_y, support_map(g, local_y));
+        float max_z = dot(local_z, support_map(g, local_z));
+        float min_x = dot(local_x, support_map(g, -local_x));
+        float min_y = dot(local_y, support_map(g, -local_y));
+        float min_z = dot(local_z, support_map(g, -local_z));
+        lo = vec3(min_x, min_y, min_z) + pos - mv;
+        hi = vec3(max_x, max_y, max_z) + pos + mv;
+        return;
+    } else {
+        // finite planes: conservative bounding sphere (rejected by the host for collision)
+        float r = 0.5f * sqrtf(scale.x * scale.x + scale.y * scale.y);
+        he = vec3(r, r, r);
+    }
+    lo = pos - he - mv;
+    hi = pos + he + mv;
+}
+
+template <int EPB>
+NT_DI void phase_shapes(const Ctx<EPB>& c) {
+    const nt_model& m = c.a.m;
+    if (!c.valid) return;
+    for (int s = c.slot; s < m.ns; s += c.nslot) {
+        int body = c.T.shape_body[s];
+        xform X = c.shape_local_xform(s);
+        if (body >= 0) X = c.body_q(body) * X;
+        vec3 lo, hi;
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP),
+                   m.shape_mesh_bounds + 6 * s, lo, hi);
+        c.st_lxf(c.L.sx, m.ns, s, X);
+        c.st_lv3(c.L.sa, 0, m.ns, s, lo);
+        c.st_lv3(c.L.sa, 3, m.ns, s, hi);
+    }
+}
+
+template <int EPB>
+NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {
+    const nt_model& m = c.a.m;
+    if (s < m.ns) {
+        X = c.lxf(c.L.sx, 0, m.ns, s);
+        lo = c.lv3(c.L.sa, 0, m.ns, s);
+        hi = c.lv3(c.L.sa, 3, m.ns, s);
+    } else {
+        X = c.shape_local_xform(s);  // global shapes are static (shape_body == -1)
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP),
+                   m.shape_mesh_bounds + 6 * s, lo, hi);
+    }
+}
+
+// broad phase test (broad_phase_common.py:20-38, cutoff 0: AABBs are pre-expanded) + narrow phase primitive
+// dispatch (narrow_phase.py:458-1014) + contact writer (collide.py:166-254).
+// One lane per CONTACT SLOT (pair p = slot / cpp, sub-contact k = slot % cpp): the cpp lanes of a pair evaluate the
+// same analytic pair redundantly (they are otherwise idle) and lane k writes the k-th admitted contact, so the
+// world->body conversion and the 19 stores per contact run in parallel instead of 4-deep in one thread.
+// Writes one contact record (world -> body frames, collide.py:166-204) into fixed slot `slot`.
+template <int EPB>
+NT_DI void write_contact_slot(const Ctx<EPB>& c, int slot, int sa, int sb, vec3 center, vec3 n, float dist, float ra, float rb,
+                              float margin_a, float margin_b) {
+    const nt_contacts& ct = c.a.ct;
+    const int ncs = c.a.m.np * c.a.m.cpp;
+    int ba = c.T.shape_body[sa], bb = c.T.shape_body[sb];
+    xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q(ba));
+    xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q(bb));
+    float off_a = ra + margin_a, off_b = rb + margin_b;
+    vec3 aw = center - n * (0.5f * dist + ra);
+    vec3 bw = center + n * (0.5f * dist + rb);
+    size_t gi = (size_t)slot * c.ES + c.env;
+    ct.shape0[gi] = c.newton_shape_id(sa);
+    ct.shape1[gi] = c.newton_shape_id(sb);
+    float* D = ct.data;
+    vec3 p0 = xform_point(Xbw_a, aw), p1 = xform_point(Xbw_b, bw);
+    vec3 o0 = xform_vector(Xbw_a, off_a * n), o1 = xform_vector(Xbw_b, -off_b * n);
+    D[c.g(CD_POINT0 + 0, ncs, slot)] = p0.x; D[c.g(CD_POINT0 + 1, ncs, slot)] = p0.y; D[c.g(CD_POINT0 + 2, ncs, slot)] = p0.z;
+    D[c.g(CD_POINT1 + 0, ncs, slot)] = p1.x; D[c.g(CD_POINT1 + 1, ncs, slot)] = p1.y; D[c.g(CD_POINT1 + 2, ncs, slot)] = p1.z;
+    D[c.g(CD_OFFSET0 + 0, ncs, slot)] = o0.x; D[c.g(CD_OFFSET0 + 1, ncs, slot)] = o0.y; D[c.g(CD_OFFSET0 + 2, ncs, slot)] = o0.z;
+    D[c.g(CD_OFFSET1 + 0, ncs, slot)] = o1.x; D[c.g(CD_OFFSET1 + 1, ncs, slot)] = o1.y; D[c.g(CD_OFFSET1 + 2, ncs, slot)] = o1.z;
+    D[c.g(CD_NORMAL + 0, ncs, slot)] = n.x; D[c.g(CD_NORMAL + 1, ncs, slot)] = n.y; D[c.g(CD_NORMAL + 2, ncs, slot)] = n.z;
+    D[c.g(CD_MARGIN0, ncs, slot)] = off_a;
+    D[c.g(CD_MARGIN1, ncs, slot)] = off_b;
+}
+
+template <int EPB, bool CVX>
+NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    const int cpp = m.cpp;
+    const int ncs = m.np * cpp;
+    const int p = slot / cpp, k = slot - p * cpp;
+    int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
+    xform Xa, Xb;
+    vec3 loa, hia, lob, hib;
+    shape_world(c, sa, Xa, loa, hia);
+    shape_world(c, sb, Xb, lob, hib);
+    bool hit = loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z;
+    if (k == 0) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+
+    int nvalid = 0;
+    bool wrote = false;
+    if (hit) {
+        int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
+        if (ta > tb) {  // sort by type (narrow_phase.py:525-528)
+            int t = sa; sa = sb; sb = t;
+            t = ta; ta = tb; tb = t;
+            xform X = Xa; Xa = Xb; Xb = X;
+            vec3 v = loa; loa = lob; lob = v;
+            v = hia; hia = hib; hib = v;
+        }
+        vec3 scale_a = c.shape_scale(sa), scale_b = c.shape_scale(sb);
+        float margin_a = c.shape_f(sa, SP_MARGIN), margin_b = c.shape_f(sb, SP_MARGIN);
+        float gap_sum = c.shape_f(sa, SP_GAP) + c.shape_f(sb, SP_GAP);
+        bool to_gjk = ta >= GEO_ELLIPSOID || tb == GEO_CONE || (ta == GEO_CAPSULE && tb > GEO_CAPSULE);
+        if (!to_gjk) {
+            float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
+            float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
+            Contacts4 k4;
+            primitive_pair(ta, tb, Xa, Xb, scale_a, scale_b, gap_sum + margin_a + margin_b, k4);
+            float total_sep = ra + rb + margin_a + margin_b;
+            vec3 n = normalize(k4.normal);
+            // admission test for all four candidates (contact_data.py:139-157); lane k keeps the k-th admitted one
+            float my_dist = 0.0f;
+            vec3 my_center;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float dist = k4.dist(i);
+                bool ok = dist < NT_MAXVAL;
+                if (ok) {
+                    vec3 center = k4.pos(i);
+                    vec3 aw = center - n * (0.5f * dist + ra);
+                    vec3 bw = center + n * (0.5f * dist + rb);
+                    float d = dot(bw - aw, n) - total_sep;
+                    ok = d <= gap_sum;
+                    if (ok && nvalid == k) { my_dist = dist; my_center = center; wrote = true; }
+                }
+                nvalid += ok ? 1 : 0;
+            }
+            if (wrote) write_contact_slot(c, slot, sa, sb, my_center, n, my_dist, ra, rb, margin_a, margin_b);
+        }
+        if constexpr (CVX) {
+            // pairs [np_analytic, np): MPR/GJK + manifold. Lane k == 0 of the pair runs the whole (serial, divergent)
+            // algorithm and fills the pair's slots in emission order; the other lanes of the pair leave them alone.
+            if (p >= m.np_analytic) {
+                if (k != 0) return;
+                ConvexContacts cc;
+                Geom ga, gb;
+                ga.type = ta; ga.scale = scale_a;
+                gb.type = tb; gb.scale = scale_b;
+                if (ta == GEO_CONVEX_MESH) {
+                    ga.points = m.mesh_points + 3 * c.T.shape_mesh_start[sa];
+                    ga.count = c.T.shape_mesh_count[sa];
+                    const float* mb = m.shape_mesh_bounds + 6 * sa;
+                    ga.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)) +
+                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)));
+                }
+                if (tb == GEO_CONVEX_MESH) {
+                    gb.points = m.mesh_points + 3 * c.T.shape_mesh_start[sb];
+                    gb.count = c.T.shape_mesh_count[sb];
+                    const float* mb = m.shape_mesh_bounds + 6 * sb;
+                    gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +
+                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)));
+                }
+                // polygon scratch: 20 rows per convex pair in the part of the scratch union that the collide phases do not
+                // use (behind shape transforms / AABBs / pair counts)
+                PolyRef poly;
+                poly.base = &c.lds[(c.L.pc + m.np + 20 * (p - m.np_analytic)) * EPB + c.e];
+                poly.stride = EPB;
+                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
+                float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
+                float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
+                vec3 n = normalize(cc.normal);
+                nvalid = cc.count < cpp ? cc.count : cpp;
+                for (int i = 0; i < cpp; ++i) {
+                    if (i < nvalid) {
+                        write_contact_slot(c, slot + i, sa, sb, cc.center(i), n, cc.distance(i), ra, rb, margin_a, margin_b);
+                    } else {
+                        size_t gi = (size_t)(slot + i) * c.ES + c.env;
+                        ct.shape0[gi] = -1;
+                        ct.shape1[gi] = -1;
+                    }
+                }
+                c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+                c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
+                return;
+            }
+        }
+    }
+    if (!wrote) {
+        size_t gi = (size_t)slot * c.ES + c.env;
+        ct.shape0[gi] = -1;
+        ct.shape1[gi] = -1;
+    }
+    if (k == 0) {
+        c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+        c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
+    }
+}
+template <int EPB, bool CVX>
+NT_DI void phase_pairs(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int ncs = c.a.m.np * c.a.m.cpp;
+    for (int s = c.slot; s < ncs; s += c.nslot) collide_slot_item<EPB, CVX>(c, s);
+}
+
+template <int EPB>
+NT_DI void phase_contact_count(const Ctx<EPB>& c) {
+    const nt_model& m = c.a.m;
+    if (c.slot == 0 && c.valid) {
+        int n = 0;
+        for (int p = 0; p < m.np; ++p) n += (int)c.l(c.L.pc, 0, m.np, p);
+        c.a.ct.env_count[c.env] = n;
+    }
+}

@@ -1,0 +1,297 @@
+// nt_layout.hpp -- row constants, LDS layout, kernel arguments, block-shared topology tables, the per-lane context (Ctx) and the
+// HBM <-> LDS staging helpers of the fused gfx950 kernels.
+// Included by nt_kernels.hip inside its anonymous namespace, in this order: nt_layout.hpp, nt_collide.hpp, nt_xpbd.hpp,
+// nt_semi_implicit.hpp, nt_featherstone.hpp (one translation unit; the split is for reading, not for separate compilation).
+#pragma once
+
+enum JointType : int { JT_PRISMATIC = 0, JT_REVOLUTE = 1, JT_BALL = 2, JT_FIXED = 3, JT_FREE = 4, JT_DISTANCE = 5, JT_D6 = 6, JT_ROD = 7 };
+constexpr int BODY_KINEMATIC = 2;
+
+// body_param rows
+constexpr int BP_COM = 0, BP_INV_MASS = 3, BP_INERTIA = 4, BP_INV_INERTIA = 13, BP_MASS = 22;
+// dof_param rows
+constexpr int DP_AXIS = 0, DP_LIMIT_LOWER = 3, DP_LIMIT_UPPER = 4, DP_TARGET_KE = 5, DP_TARGET_KD = 6, DP_LIMIT_KE = 7,
+              DP_LIMIT_KD = 8, DP_ARMATURE = 9, DP_DAMPING = 10;
+// shape_param rows
+constexpr int SP_XFORM = 0, SP_SCALE = 7, SP_MARGIN = 10, SP_GAP = 11, SP_MU = 12, SP_MU_TORSIONAL = 13, SP_MU_ROLLING = 14,
+              SP_KE = 15, SP_KD = 16, SP_KF = 17, SP_KA = 18, SP_RESTITUTION = 19;
+// contact data rows
+constexpr int CD_POINT0 = 0, CD_POINT1 = 3, CD_OFFSET0 = 6, CD_OFFSET1 = 9, CD_NORMAL = 12, CD_MARGIN0 = 15, CD_MARGIN1 = 16;
+// per-contact correction record in LDS: lin_a, ang_a, lin_b, ang_b, has_a, has_b, shape0_is_pair_a
+constexpr int CW_FLOATS = 15;
+
+__host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
+
+// LDS layout, in float rows per environment (each row is EPB floats wide)
+struct LdsLayout {
+    // persistent
+    int bq, bqd;       // body_q [7][nb], body_qd [6][nb]
+    int bp;            // body params [23][nb] (inverse mass / inertia already "effective": zero for kinematic bodies)
+    int jp;            // joint params [14][nj]
+    int dp;            // dof params [10][nd]
+    int sp;            // shape params [19][ns]
+    int cf, ctq, ctqd; // control: joint_f [nd], joint_target_q [ntq], joint_target_qd [nd]
+    int grav;          // gravity [3]
+    int bd;            // body-derived [9][nb]: world COM (3) + world-frame inverse inertia R I^-1 R^T (xx xy xz yy yz zz)
+    int pm;            // live contacts per pair [np] (written by the collide phase, read by the fused solver phases)
+    // scratch union
+    int u;
+    int sx, sa, pc;    // collide: shape world xform [7][ns], aabb [6][ns], per-pair contact count [np]
+    int bf, jf;        // forces: body_f_tmp [6][nb], joint wrenches [12][nj]
+    int jl, ja;        // joints: linear-part corrections [12][nj], angular-part child terms [9][nj]
+    int cw;            // contacts: per-contact corrections [CW_FLOATS][np*cpp]
+    int si_jf, si_cw;  // semi-implicit: joint wrenches + contact wrenches live together with body_f_tmp
+    int xi;            // XPBD restitution: pre-step body_q / body_qd [13][nb], behind the XPBD scratch (solver_xpbd.py:414-416)
+    int rows_per_env;
+};
+
+__host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
+    LdsLayout L;
+    int o = 0;
+    L.bq = o; o += 7 * m.nb;
+    L.bqd = o; o += 6 * m.nb;
+    L.bp = o; o += NT_BODY_PARAM_FLOATS * m.nb;
+    L.jp = o; o += NT_JOINT_PARAM_FLOATS * m.nj;
+    L.dp = o; o += NT_DOF_PARAM_FLOATS * m.nd;
+    L.sp = o; o += NT_SHAPE_PARAM_FLOATS * m.ns;
+    L.cf = o; o += m.nd;
+    L.ctq = o; o += m.ntq;
+    L.ctqd = o; o += m.nd;
+    L.grav = o; o += 3;
+    L.bd = o; o += 9 * m.nb;
+    L.pm = o; o += m.np;
+    L.u = o;
+    L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
+    int coll = 13 * m.ns + m.np + 20 * (m.np - m.np_analytic);  // + manifold polygon scratch of the convex pairs
+    L.bf = L.u; L.jf = L.bf + 6 * m.nb;
+    int forces = 6 * m.nb + 12 * m.nj;
+    L.jl = L.u; L.ja = L.jl + 12 * m.nj;
+    int joints = 21 * m.nj;
+    L.cw = L.u;
+    int contacts = CW_FLOATS * m.np * m.cpp;
+    L.si_jf = L.bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
+    int semi = 6 * m.nb + 12 * m.nj + contacts;
+    int xpbd = imax(imax(coll, forces), imax(joints, contacts));
+    L.xi = L.u + xpbd;
+    L.rows_per_env = L.u + imax(xpbd + 13 * m.nb, semi);
+    return L;
+}
+
+struct KArgs {
+    nt_model m;
+    nt_state s_in, s_out;
+    nt_control c;
+    nt_contacts ct;
+    nt_xpbd_params p;
+    nt_xpbd_report rep;  // optional reporting outputs of nt_xpbd_step (all NULL on the hot path)
+    nt_semi_implicit_params sp;
+    float angular_damping;  // integrate_bodies damping of the active solver
+    float dt;
+    int substeps;
+    int has_contacts;
+    int nslot;       // slot-threads per environment
+    int debug_skip;  // ablation bitmask (NT_DEBUG_SKIP env var): 1 collide, 2 forces+integrate, 4 contacts, 8 joints, 16 apply
+};
+
+// env-uniform topology, staged once per workgroup into LDS (block-shared ints behind the per-env rows)
+struct Topo {
+    const int *body_flags, *joint_type, *joint_enabled, *joint_parent, *joint_child, *joint_q_start, *joint_qd_start,
+        *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
+        *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count, *gshape_id;
+    const float* gshape;  // [ng][NT_SHAPE_PARAM_FLOATS] parameters of the global (world -1) shapes, block-shared copy
+};
+__host__ __device__ inline int topo_ints(const nt_model& m) {
+    return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np + m.ng +
+           NT_SHAPE_PARAM_FLOATS * m.ng;
+}
+
+template <int EPB>
+struct Ctx {
+    const KArgs& a;
+    Topo T;
+    float* lds;
+    LdsLayout L;
+    int e, slot, env, nslot;
+    int ES;
+    bool valid;
+
+    // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
+    NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1) : a(a_), lds(lds_) {
+        L = make_layout(a.m);
+        if (rows < 0) rows = L.rows_per_env;
+        e = threadIdx.x % EPB;
+        slot = threadIdx.x / EPB;
+        nslot = a.nslot;
+        env = blockIdx.x * EPB + e;
+        ES = a.m.env_stride;
+        valid = env < a.m.env_count && slot < nslot;
+        const nt_model& m = a.m;
+        int* ti = reinterpret_cast<int*>(lds + (size_t)rows * EPB);
+        int o = 0;
+        auto take = [&](const int*& dst, const int32_t* src, int n) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) ti[o + i] = src[i];
+            dst = ti + o;
+            o += n;
+        };
+        take(T.body_flags, m.body_flags, m.nb);
+        take(T.joint_type, m.joint_type, m.nj);
+        take(T.joint_enabled, m.joint_enabled, m.nj);
+        take(T.joint_parent, m.joint_parent, m.nj);
+        take(T.joint_child, m.joint_child, m.nj);
+        take(T.joint_q_start, m.joint_q_start, m.nj);
+        take(T.joint_qd_start, m.joint_qd_start, m.nj);
+        take(T.joint_tq_start, m.joint_tq_start, m.nj);
+        take(T.joint_lin_count, m.joint_lin_count, m.nj);
+        take(T.joint_ang_count, m.joint_ang_count, m.nj);
+        take(T.shape_body, m.shape_body, m.ns + m.ng);
+        take(T.shape_type, m.shape_type, m.ns + m.ng);
+        take(T.shape_flags, m.shape_flags, m.ns + m.ng);
+        take(T.shape_group, m.shape_group, m.ns + m.ng);
+        take(T.pair_a, m.pair_a, m.np);
+        take(T.pair_b, m.pair_b, m.np);
+        take(T.body_joint_start, m.body_joint_start, m.nb + 1);
+        take(T.body_joint_list, m.body_joint_list, 2 * m.nj);  // padded to 2*nj entries by the host
+        take(T.body_pair_start, m.body_pair_start, m.nb + 1);
+        take(T.body_pair_list, m.body_pair_list, 2 * m.np);    // padded to 2*np entries by the host
+        take(T.shape_mesh_start, m.shape_mesh_start, m.ns + m.ng);
+        take(T.shape_mesh_count, m.shape_mesh_count, m.ns + m.ng);
+        take(T.gshape_id, m.gshape_id, m.ng);
+        {
+            float* g = reinterpret_cast<float*>(ti + o);
+            for (int i = threadIdx.x; i < NT_SHAPE_PARAM_FLOATS * m.ng; i += blockDim.x) g[i] = m.gshape_param[i];
+            T.gshape = g;
+            o += NT_SHAPE_PARAM_FLOATS * m.ng;
+        }
+    }
+    // LDS element: row = field offset + comp * slots_in_field + slot
+    NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * EPB + e]; }
+    NT_DI size_t g(int comp, int n, int s) const { return (size_t)(comp * n + s) * ES + env; }
+
+    NT_DI vec3 lv3(int off, int comp0, int n, int s) const {
+        return vec3(l(off, comp0, n, s), l(off, comp0 + 1, n, s), l(off, comp0 + 2, n, s));
+    }
+    NT_DI void st_lv3(int off, int comp0, int n, int s, vec3 v) const {
+        l(off, comp0, n, s) = v.x; l(off, comp0 + 1, n, s) = v.y; l(off, comp0 + 2, n, s) = v.z;
+    }
+    NT_DI xform lxf(int off, int comp0, int n, int s) const {
+        return xform(lv3(off, comp0, n, s),
+                     quat(l(off, comp0 + 3, n, s), l(off, comp0 + 4, n, s), l(off, comp0 + 5, n, s), l(off, comp0 + 6, n, s)));
+    }
+    NT_DI void st_lxf(int off, int n, int s, const xform& t) const {
+        l(off, 0, n, s) = t.p.x; l(off, 1, n, s) = t.p.y; l(off, 2, n, s) = t.p.z;
+        l(off, 3, n, s) = t.q.x; l(off, 4, n, s) = t.q.y; l(off, 5, n, s) = t.q.z; l(off, 6, n, s) = t.q.w;
+    }
+    NT_DI mat33 lm33(int off, int comp0, int n, int s) const {
+        return mat33(l(off, comp0, n, s), l(off, comp0 + 1, n, s), l(off, comp0 + 2, n, s), l(off, comp0 + 3, n, s),
+                     l(off, comp0 + 4, n, s), l(off, comp0 + 5, n, s), l(off, comp0 + 6, n, s), l(off, comp0 + 7, n, s),
+                     l(off, comp0 + 8, n, s));
+    }
+    NT_DI vec3 gv3(const float* base, int comp0, int n, int s) const {
+        return vec3(base[g(comp0, n, s)], base[g(comp0 + 1, n, s)], base[g(comp0 + 2, n, s)]);
+    }
+
+    NT_DI xform body_q(int b) const { return lxf(L.bq, 0, a.m.nb, b); }
+    NT_DI quat body_rot(int b) const {
+        const int nb = a.m.nb;
+        return quat(l(L.bq, 3, nb, b), l(L.bq, 4, nb, b), l(L.bq, 5, nb, b), l(L.bq, 6, nb, b));
+    }
+    NT_DI vec3 body_v(int b) const { return lv3(L.bqd, 0, a.m.nb, b); }
+    NT_DI vec3 body_w(int b) const { return lv3(L.bqd, 3, a.m.nb, b); }
+    NT_DI float inv_mass(int b) const { return l(L.bp, BP_INV_MASS, a.m.nb, b); }
+    NT_DI mat33 inv_inertia(int b) const { return lm33(L.bp, BP_INV_INERTIA, a.m.nb, b); }
+    NT_DI mat33 inertia(int b) const { return lm33(L.bp, BP_INERTIA, a.m.nb, b); }
+    NT_DI vec3 com(int b) const { return lv3(L.bp, BP_COM, a.m.nb, b); }
+    NT_DI vec3 world_com(int b) const { return lv3(L.bd, 0, a.m.nb, b); }
+    // a^T (R I^-1 R^T) a for body b (world-frame inverse inertia, symmetric 6-float tile in LDS)
+    NT_DI float w_quad(int b, vec3 v) const {
+        const int nb = a.m.nb;
+        float xx = l(L.bd, 3, nb, b), xy = l(L.bd, 4, nb, b), xz = l(L.bd, 5, nb, b);
+        float yy = l(L.bd, 6, nb, b), yz = l(L.bd, 7, nb, b), zz = l(L.bd, 8, nb, b);
+        vec3 wv(xx * v.x + xy * v.y + xz * v.z, xy * v.x + yy * v.y + yz * v.z, xz * v.x + yz * v.y + zz * v.z);
+        return dot(v, wv);
+    }
+    NT_DI void update_body_derived(int b) const {
+        const int nb = a.m.nb;
+        xform X = body_q(b);
+        st_lv3(L.bd, 0, nb, b, xform_point(X, com(b)));
+        mat33 R = quat_to_matrix(X.q);
+        mat33 Ii = inv_inertia(b);
+        // T = I^-1 R^T ; W = R T
+        vec3 t0 = Ii * vec3(R.m00, R.m01, R.m02), t1 = Ii * vec3(R.m10, R.m11, R.m12), t2 = Ii * vec3(R.m20, R.m21, R.m22);
+        vec3 r0(R.m00, R.m01, R.m02), r1(R.m10, R.m11, R.m12), r2(R.m20, R.m21, R.m22);
+        l(L.bd, 3, nb, b) = dot(r0, t0); l(L.bd, 4, nb, b) = dot(r0, t1); l(L.bd, 5, nb, b) = dot(r0, t2);
+        l(L.bd, 6, nb, b) = dot(r1, t1); l(L.bd, 7, nb, b) = dot(r1, t2); l(L.bd, 8, nb, b) = dot(r2, t2);
+    }
+    NT_DI float dof(int row, int d) const { return l(L.dp, row, a.m.nd, d); }
+    NT_DI vec3 dof_axis(int d) const { return lv3(L.dp, DP_AXIS, a.m.nd, d); }
+
+    // shape accessors: s < ns local (per-env params in LDS), otherwise the env-uniform global table
+    NT_DI float shape_f(int s, int comp) const {
+        if (s < a.m.ns) return l(L.sp, comp, a.m.ns, s);
+        return T.gshape[(s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp];
+    }
+    NT_DI vec3 shape_scale(int s) const { return vec3(shape_f(s, SP_SCALE), shape_f(s, SP_SCALE + 1), shape_f(s, SP_SCALE + 2)); }
+    NT_DI xform shape_local_xform(int s) const {
+        return xform(vec3(shape_f(s, 0), shape_f(s, 1), shape_f(s, 2)), quat(shape_f(s, 3), shape_f(s, 4), shape_f(s, 5), shape_f(s, 6)));
+    }
+    NT_DI int newton_shape_id(int s) const {  // flat Newton shape index
+        return s < a.m.ns ? a.m.shape_local0 + env * a.m.ns + s : T.gshape_id[s - a.m.ns];
+    }
+    NT_DI int local_shape_id(int gid) const {
+        int rel = gid - a.m.shape_local0 - env * a.m.ns;
+        if (rel >= 0 && rel < a.m.ns) return rel;
+        int g = 0;
+        for (int k = 0; k < a.m.ng; ++k)
+            if (T.gshape_id[k] == gid) g = k;
+        return a.m.ns + g;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// HBM <-> LDS staging
+// ------------------------------------------------------------------------------------------------
+template <int EPB>
+NT_DI void stage_rows(const Ctx<EPB>& c, int lds_off, const float* src, int rows) {
+    for (int r = c.slot; r < rows; r += c.nslot) c.lds[(lds_off + r) * EPB + c.e] = src[(size_t)r * c.ES + c.env];
+}
+template <int EPB>
+NT_DI void unstage_rows(const Ctx<EPB>& c, int lds_off, float* dst, int rows) {
+    for (int r = c.slot; r < rows; r += c.nslot) dst[(size_t)r * c.ES + c.env] = c.lds[(lds_off + r) * EPB + c.e];
+}
+
+template <int EPB>
+NT_DI void load_state(const Ctx<EPB>& c, const nt_state& s) {
+    if (!c.valid) return;
+    stage_rows(c, c.L.bq, s.body_q, 7 * c.a.m.nb);
+    stage_rows(c, c.L.bqd, s.body_qd, 6 * c.a.m.nb);
+}
+template <int EPB>
+NT_DI void store_state(const Ctx<EPB>& c, const nt_state& s) {
+    if (!c.valid) return;
+    unstage_rows(c, c.L.bq, s.body_q, 7 * c.a.m.nb);
+    unstage_rows(c, c.L.bqd, s.body_qd, 6 * c.a.m.nb);
+}
+// parameters and controls: read once per kernel
+template <int EPB>
+NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
+    if (!c.valid) return;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    // body params, with effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
+    for (int r = c.slot; r < NT_BODY_PARAM_FLOATS * nb; r += c.nslot) {
+        int comp = r / nb, b = r - comp * nb;
+        float v = m.body_param[(size_t)r * c.ES + c.env];
+        bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
+        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
+        c.lds[(c.L.bp + r) * EPB + c.e] = v;
+    }
+    stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS * m.nj);
+    stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS * m.nd);
+    stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS * m.ns);
+    stage_rows(c, c.L.grav, m.gravity, 3);
+    if (with_control) {
+        stage_rows(c, c.L.cf, c.a.c.joint_f, m.nd);
+        stage_rows(c, c.L.ctq, c.a.c.joint_target_q, m.ntq);
+        stage_rows(c, c.L.ctqd, c.a.c.joint_target_qd, m.nd);
+    }
+}

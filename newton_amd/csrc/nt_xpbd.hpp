@@ -1,0 +1,1092 @@
+// nt_xpbd.hpp -- SolverXPBD phases (joint forces, integrate, contacts, apply, joints, restitution, optional reporting) and the
+// collide / step / rollout kernels.
+// Included by nt_kernels.hip inside its anonymous namespace, in this order: nt_layout.hpp, nt_collide.hpp, nt_xpbd.hpp,
+// nt_semi_implicit.hpp, nt_featherstone.hpp (one translation unit; the split is for reading, not for separate compilation).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// XPBD: apply_joint_forces (xpbd/kernels.py:945-1075)
+// ------------------------------------------------------------------------------------------------
+template <int EPB>
+NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nj = m.nj;
+    if (!c.valid) return;
+    // body threads seed body_f_tmp with state_in.body_f (solver_xpbd.py:423: wp.clone)
+    for (int r = c.slot; r < 6 * nb; r += c.nslot)
+        c.lds[(c.L.bf + r) * EPB + c.e] = forces_are_zero ? 0.0f : c.a.s_in.body_f[(size_t)r * c.ES + c.env];
+    for (int j = c.slot; j < nj; j += c.nslot) {
+        vec3 fp, tp, fc, tc;  // parent wrench (subtracted), child wrench (added)
+        int type = c.T.joint_type[j];
+        if (c.T.joint_enabled[j] && type != JT_FIXED && type != JT_ROD) {
+            int id_c = c.T.joint_child[j], id_p = c.T.joint_parent[j];
+            xform X_pj = c.lxf(c.L.jp, 0, nj, j);
+            xform X_cj = c.lxf(c.L.jp, 7, nj, j);
+            xform X_wp = X_pj, pose_p = X_pj;
+            vec3 com_p(0.0f);
+            if (id_p >= 0) {
+                pose_p = c.body_q(id_p);
+                X_wp = pose_p * X_wp;
+                com_p = c.com(id_p);
+            }
+            vec3 r_p = X_wp.p - xform_point(pose_p, com_p);
+            xform pose_c = c.body_q(id_c);
+            xform X_wc = pose_c * X_cj;
+            vec3 r_c = X_wc.p - xform_point(pose_c, c.com(id_c));
+            int qd_start = c.T.joint_qd_start[j];
+            int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
+            vec3 f_total, t_total;
+            if (type == JT_FREE || type == JT_DISTANCE) {
+                // joint_f rows qd_start .. qd_start+5 (n = 1 => comp is the row step)
+                f_total = c.lv3(c.L.cf, 0, 1, qd_start);
+                t_total = c.lv3(c.L.cf, 0, 1, qd_start + 3);
+                fc = f_total; tc = t_total;
+                fp = f_total; tp = t_total;
+            } else {
+                if (type == JT_BALL) {
+                    t_total = c.lv3(c.L.cf, 0, 1, qd_start);
+                } else if (type == JT_REVOLUTE || type == JT_PRISMATIC || type == JT_D6) {
+                    for (int k = 0; k < 3; ++k)
+                        if (lin > k) f_total += c.l(c.L.cf, 0, 1, qd_start + k) * xform_vector(X_wp, c.dof_axis(qd_start + k));
+                    for (int k = 0; k < 3; ++k)
+                        if (ang > k)
+                            t_total += c.l(c.L.cf, 0, 1, qd_start + lin + k) * xform_vector(X_wp, c.dof_axis(qd_start + lin + k));
+                }
+                fc = f_total; tc = t_total + cross(r_c, f_total);
+                fp = f_total; tp = t_total + cross(r_p, f_total);
+            }
+        }
+        c.st_lv3(c.L.jf, 0, nj, j, fp);
+        c.st_lv3(c.L.jf, 3, nj, j, tp);
+        c.st_lv3(c.L.jf, 6, nj, j, fc);
+        c.st_lv3(c.L.jf, 9, nj, j, tc);
+    }
+}
+
+// body thread: fold joint wrenches into body_f_tmp in ascending-joint order, then integrate_bodies
+// (solver.py:63-170)
+// SEMI = false: XPBD (apply_joint_forces wrenches: parent subtracted, child added).
+// SEMI = true : SolverSemiImplicit (eval_body_joints: parent added, child subtracted; then eval_body_contact: shape0's
+//               body subtracted, shape1's body added), all in ascending joint / contact order.
+template <int EPB, bool SEMI>
+NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nj = m.nj;
+    vec3 f0 = c.lv3(c.L.bf, 0, nb, b), t0 = c.lv3(c.L.bf, 3, nb, b);
+    for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
+        int code = c.T.body_joint_list[i];
+        int j = code >> 1;
+        bool add = SEMI ? !(code & 1) : (code & 1);
+        int row = (code & 1) ? 6 : 0;
+        vec3 f = c.lv3(c.L.jf, row, nj, j), t = c.lv3(c.L.jf, row + 3, nj, j);
+        if (add) { f0 += f; t0 += t; }
+        else { f0 -= f; t0 -= t; }
+    }
+    if (SEMI && c.a.has_contacts) {
+        const int cpp = m.cpp, ncs = m.np * cpp;
+        for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+            int code = c.T.body_pair_list[i];
+            int p = code >> 1, side = code & 1;
+            for (int k = 0; k < cpp; ++k) {
+                int slot = p * cpp + k;
+                bool is_a = (side == 0) == (c.l(c.L.si_cw, 14, ncs, slot) != 0.0f);
+                if (c.l(c.L.si_cw, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                    vec3 f = c.lv3(c.L.si_cw, is_a ? 0 : 6, ncs, slot), t = c.lv3(c.L.si_cw, is_a ? 3 : 9, ncs, slot);
+                    if (is_a) { f0 -= f; t0 -= t; }
+                    else { f0 += f; t0 += t; }
+                }
+            }
+        }
+    }
+    if (c.T.body_flags[b] & BODY_KINEMATIC) return;  // pass through unchanged
+
+    xform q = c.body_q(b);
+    vec3 v0 = c.body_v(b), w0 = c.body_w(b);
+    // integrate_bodies uses the raw model inverse mass/inertia; for non-kinematic bodies raw == effective
+    float inv_mass = c.inv_mass(b);
+    mat33 inertia = c.inertia(b);
+    mat33 inv_inertia = c.inv_inertia(b);
+    vec3 com = c.com(b);
+    vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
+    const float dt = c.a.dt;
+
+    vec3 x0 = q.p;
+    quat r0 = q.q;
+    vec3 x_com = x0 + quat_rotate(r0, com);
+    vec3 v1 = v0 + (f0 * inv_mass + gravity * nonzero(inv_mass)) * dt;
+    vec3 x1 = x_com + v1 * dt;
+    vec3 wb = quat_rotate_inv(r0, w0);
+    vec3 tb = quat_rotate_inv(r0, t0) - cross(wb, inertia * wb);
+    vec3 w1 = quat_rotate(r0, wb + inv_inertia * tb * dt);
+    quat r1 = normalize(r0 + quat(w1, 0.0f) * r0 * 0.5f * dt);
+    w1 *= 1.0f - c.a.angular_damping * dt;
+    c.st_lxf(c.L.bq, nb, b, xform(x1 - quat_rotate(r1, com), r1));
+    c.st_lv3(c.L.bqd, 0, nb, b, v1);
+    c.st_lv3(c.L.bqd, 3, nb, b, w1);
+    c.update_body_derived(b);
+}
+template <int EPB>
+NT_DI void phase_body_derived(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) c.update_body_derived(b);
+}
+template <int EPB, bool SEMI>
+NT_DI void phase_integrate(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) integrate_item<EPB, SEMI>(c, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// XPBD constraint helpers (xpbd/kernels.py:2047-2161)
+// ------------------------------------------------------------------------------------------------
+// Generalised inverse mass of a constraint row: sum |lin|^2 m^-1 + ang^T (R I^-1 R^T) ang.  The reference rotates `ang`
+// into the body frame and applies the body-frame inverse inertia (xpbd/kernels.py:2064-2077); here the body thread has
+// already rotated the inverse inertia into the world frame (Ctx::update_body_derived), which is the same quantity up to
+// fp32 rounding and saves two quaternion rotations + a full 3x3 product per row.  wq_a / wq_b are those angular terms.
+NT_DI float contact_constraint_delta(float err, float m_inv_a, float m_inv_b, vec3 lin_a, vec3 lin_b, float wq_a, float wq_b,
+                                     float relaxation, float dt) {
+    float denom = 0.0f;
+    denom += length_sq(lin_a) * m_inv_a;
+    denom += length_sq(lin_b) * m_inv_b;
+    denom += wq_a;
+    denom += wq_b;
+    float delta_lambda = -err;
+    if (denom > 0.0f) delta_lambda /= dt * denom;
+    return delta_lambda * relaxation;
+}
+
+NT_DI float positional_correction(float err, float derr, float m_inv_a, float m_inv_b, vec3 lin_a, vec3 lin_b, float wq_a,
+                                  float wq_b, float lambda_in, float compliance, float damping, float dt) {
+    float denom = 0.0f;
+    denom += length_sq(lin_a) * m_inv_a;
+    denom += length_sq(lin_b) * m_inv_b;
+    denom += wq_a;
+    denom += wq_b;
+    float alpha = compliance;
+    float gamma = compliance * damping;
+    float delta_lambda = -(err + alpha * lambda_in + gamma * derr);
+    if (denom + alpha > 0.0f) delta_lambda /= (dt + gamma) * denom + alpha / dt;
+    return delta_lambda;
+}
+
+NT_DI float angular_correction(float err, float derr, float wq_a, float wq_b, float lambda_in, float compliance,
+                               float damping, float dt) {
+    float denom = 0.0f;
+    denom += wq_a;
+    denom += wq_b;
+    float alpha = compliance;
+    float gamma = compliance * damping;
+    float delta_lambda = -(err + alpha * lambda_in + gamma * derr);
+    if (denom + alpha > 0.0f) delta_lambda /= (dt + gamma) * denom + alpha / dt;
+    return delta_lambda;
+}
+
+// ------------------------------------------------------------------------------------------------
+// XPBD: solve_body_contact_positions (xpbd/kernels.py:2164-2399); one lane per contact slot.
+// ------------------------------------------------------------------------------------------------
+// FUSED: the collide phase of the same kernel left the live-contact count of every pair in LDS, and the (type-sorted)
+// shape order of a pair is static, so neither the liveness test nor the shape ids need the global contact arrays.
+template <int EPB, bool FUSED>
+NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    const float dt = c.a.dt, relaxation = c.a.p.rigid_contact_relaxation;
+    const float* D = ct.data;
+    float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
+    vec3 lin_delta_a, ang_delta_a, lin_delta_b, ang_delta_b;
+
+    bool live;
+    int shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
+    if (FUSED) {
+        const int p = slot / cpp, k = slot - p * cpp;
+        live = k < (int)c.l(c.L.pm, 0, m.np, p);
+        if (live) {
+            shape_a = c.T.pair_a[p];
+            shape_b = c.T.pair_b[p];
+            if (c.T.shape_type[shape_a] > c.T.shape_type[shape_b]) {  // narrow_phase.py:525-528
+                int t = shape_a; shape_a = shape_b; shape_b = t;
+            }
+        }
+    } else {
+        size_t gi = (size_t)slot * c.ES + c.env;
+        int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+        live = gid_a != gid_b;
+        if (live) {
+            shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
+            shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+        }
+    }
+    if (live) {
+        body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1;
+        body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
+        live = body_a != body_b;
+    }
+    if (live) {
+        xform X_wb_a, X_wb_b;
+        if (body_a >= 0) X_wb_a = c.body_q(body_a);
+        if (body_b >= 0) X_wb_b = c.body_q(body_b);
+        vec3 point0 = c.gv3(D, CD_POINT0, ncs, slot), point1 = c.gv3(D, CD_POINT1, ncs, slot);
+        vec3 bx_a = xform_point(X_wb_a, point0);
+        vec3 bx_b = xform_point(X_wb_b, point1);
+        vec3 n = c.gv3(D, CD_NORMAL, ncs, slot);
+        float d = dot(n, bx_b - bx_a) - (D[c.g(CD_MARGIN0, ncs, slot)] + D[c.g(CD_MARGIN1, ncs, slot)]);
+        if (d < 0.0f) {
+            float m_inv_a = 0.0f, m_inv_b = 0.0f;
+            vec3 wc_a(0.0f), wc_b(0.0f), omega_a(0.0f), omega_b(0.0f);  // world COM (origin for static shapes)
+            if (body_a >= 0) {
+                wc_a = c.world_com(body_a);
+                m_inv_a = c.inv_mass(body_a);
+                omega_a = c.body_w(body_a);
+            }
+            if (body_b >= 0) {
+                wc_b = c.world_com(body_b);
+                m_inv_b = c.inv_mass(body_b);
+                omega_b = c.body_w(body_b);
+            }
+            auto wq_a = [&](vec3 v) { return body_a >= 0 ? c.w_quad(body_a, v) : 0.0f; };
+            auto wq_b = [&](vec3 v) { return body_b >= 0 ? c.w_quad(body_b, v) : 0.0f; };
+            int mat_nonzero = 0;
+            float mu = 0.0f, mu_torsional = 0.0f, mu_rolling = 0.0f;
+            if (shape_a >= 0) {
+                mat_nonzero += 1;
+                mu += c.shape_f(shape_a, SP_MU);
+                mu_torsional += c.shape_f(shape_a, SP_MU_TORSIONAL);
+                mu_rolling += c.shape_f(shape_a, SP_MU_ROLLING);
+            }
+            if (shape_b >= 0) {
+                mat_nonzero += 1;
+                mu += c.shape_f(shape_b, SP_MU);
+                mu_torsional += c.shape_f(shape_b, SP_MU_TORSIONAL);
+                mu_rolling += c.shape_f(shape_b, SP_MU_ROLLING);
+            }
+            if (mat_nonzero > 0) {
+                mu /= float(mat_nonzero);
+                mu_torsional /= float(mat_nonzero);
+                mu_rolling /= float(mat_nonzero);
+            }
+            vec3 r_a = bx_a - wc_a;
+            vec3 r_b = bx_b - wc_b;
+            vec3 angular_a = -cross(r_a, n);
+            vec3 angular_b = cross(r_b, n);
+
+            float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, wq_a(angular_a), wq_b(angular_b), relaxation, dt);
+            lin_delta_a = -n * lambda_n;
+            lin_delta_b = n * lambda_n;
+            ang_delta_a = angular_a * lambda_n;
+            ang_delta_b = angular_b * lambda_n;
+
+            if (mu > 0.0f) {
+                vec3 offset_a = c.gv3(D, CD_OFFSET0, ncs, slot), offset_b = c.gv3(D, CD_OFFSET1, ncs, slot);
+                bx_a = xform_point(X_wb_a, point0 + offset_a);
+                bx_b = xform_point(X_wb_b, point1 + offset_b);
+                vec3 delta = bx_b - bx_a;
+                vec3 friction_delta = delta - dot(n, delta) * n;
+                r_a = bx_a - wc_a;
+                r_b = bx_b - wc_b;
+                vec3 rel_v_kin_t(0.0f);
+                if (body_a >= 0 && (c.T.body_flags[body_a] & BODY_KINEMATIC) != 0) {
+                    vec3 v_a = velocity_at_point(spatial(c.body_v(body_a), omega_a), r_a);
+                    rel_v_kin_t = rel_v_kin_t - (v_a - dot(n, v_a) * n);
+                }
+                if (body_b >= 0 && (c.T.body_flags[body_b] & BODY_KINEMATIC) != 0) {
+                    vec3 v_b = velocity_at_point(spatial(c.body_v(body_b), omega_b), r_b);
+                    rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
+                }
+                friction_delta += rel_v_kin_t * dt;
+                vec3 perp = normalize(friction_delta);
+                angular_a = -cross(r_a, perp);
+                angular_b = cross(r_b, perp);
+                float err = length(friction_delta);
+                if (err > 0.0f) {
+                    float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, wq_a(angular_a),
+                                                               wq_b(angular_b), relaxation, dt);
+                    lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
+                    lin_delta_a -= perp * lambda_fr;
+                    lin_delta_b += perp * lambda_fr;
+                    ang_delta_a += angular_a * lambda_fr;
+                    ang_delta_b += angular_b * lambda_fr;
+                }
+            }
+            vec3 delta_omega = omega_b - omega_a;
+            if (mu_torsional > 0.0f) {
+                float err = dot(delta_omega, n) * dt;
+                if (fabsf(err) > 0.0f) {
+                    vec3 lin(0.0f);
+                    float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-n), wq_b(n), relaxation, dt);
+                    lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
+                    ang_delta_a -= n * lt;
+                    ang_delta_b += n * lt;
+                }
+            }
+            if (mu_rolling > 0.0f) {
+                delta_omega -= dot(n, delta_omega) * n;
+                float err = length(delta_omega) * dt;
+                if (err > 0.0f) {
+                    vec3 lin(0.0f);
+                    vec3 roll_n = normalize(delta_omega);
+                    float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-roll_n), wq_b(roll_n), relaxation, dt);
+                    lr = fmaxw(lr, -lambda_n * mu_rolling);
+                    ang_delta_a -= roll_n * lr;
+                    ang_delta_b += roll_n * lr;
+                }
+            }
+            has_a = body_a >= 0 ? 1.0f : 0.0f;
+            has_b = body_b >= 0 ? 1.0f : 0.0f;
+            a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
+        }
+    }
+    c.st_lv3(c.L.cw, 0, ncs, slot, lin_delta_a);
+    c.st_lv3(c.L.cw, 3, ncs, slot, ang_delta_a);
+    c.st_lv3(c.L.cw, 6, ncs, slot, lin_delta_b);
+    c.st_lv3(c.L.cw, 9, ncs, slot, ang_delta_b);
+    c.l(c.L.cw, 12, ncs, slot) = has_a;
+    c.l(c.L.cw, 13, ncs, slot) = has_b;
+    c.l(c.L.cw, 14, ncs, slot) = a_is_pair_a;
+}
+template <int EPB, bool FUSED>
+NT_DI void phase_contacts(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int ncs = c.a.m.np * c.a.m.cpp;
+    for (int s = c.slot; s < ncs; s += c.nslot) contact_item<EPB, FUSED>(c, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// XPBD: apply_body_deltas (xpbd/kernels.py:864-933).  FROM_CONTACTS: sum contact corrections (+ contact counts)
+// in ascending contact order; otherwise sum joint corrections in ascending joint order.
+// ------------------------------------------------------------------------------------------------
+template <int EPB, bool FROM_CONTACTS>
+NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    float inv_m = c.inv_mass(b);
+    if (inv_m == 0.0f) return;  // pass-through
+
+    vec3 dlin, dang;
+    float inv_weight = 0.0f;
+    if (FROM_CONTACTS) {
+        const int cpp = m.cpp, ncs = m.np * cpp;
+        for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+            int code = c.T.body_pair_list[i];
+            int p = code >> 1, side = code & 1;  // side 0: this body owns pair_a's shape
+            for (int k = 0; k < cpp; ++k) {
+                int slot = p * cpp + k;
+                // this body is the contact's "a" iff (side == 0) == (shape0 is pair_a's shape)
+                bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
+                float has = c.l(c.L.cw, is_a ? 12 : 13, ncs, slot);
+                if (has != 0.0f) {
+                    dlin += c.lv3(c.L.cw, is_a ? 0 : 6, ncs, slot);
+                    dang += c.lv3(c.L.cw, is_a ? 3 : 9, ncs, slot);
+                    inv_weight += 1.0f;
+                }
+            }
+        }
+    } else {
+        const int nj = m.nj;
+        for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
+            int code = c.T.body_joint_list[i];
+            int j = code >> 1, side = code & 1;  // side 1: this body is the joint's child
+            vec3 jl = c.lv3(c.L.jl, side * 6, nj, j);
+            vec3 ja = c.lv3(c.L.jl, side * 6 + 3, nj, j);
+            vec3 t0 = c.lv3(c.L.ja, 0, nj, j), t1 = c.lv3(c.L.ja, 3, nj, j), t2 = c.lv3(c.L.ja, 6, nj, j);
+            if (side == 0) { t0 = -t0; t1 = -t1; t2 = -t2; }  // angular_p = -angular_c
+            ja = ((ja + t0) + t1) + t2;
+            dlin += jl;
+            dang += ja;
+        }
+    }
+    mat33 inv_I = c.inv_inertia(b);
+    mat33 body_I = c.inertia(b);
+    xform tf = c.body_q(b);
+    vec3 v0 = c.body_v(b), w0 = c.body_w(b);
+    const float dt = c.a.dt;
+    vec3 p0 = tf.p;
+    quat q0 = tf.q;
+    float weight = 1.0f;
+    if (FROM_CONTACTS && c.a.p.rigid_contact_con_weighting) {
+        if (inv_weight > 0.0f) weight = 1.0f / inv_weight;
+    }
+    vec3 dp = dlin * (inv_m * weight);
+    vec3 dq = dang * weight;
+    vec3 wb = quat_rotate_inv(q0, w0);
+    vec3 dwb = inv_I * quat_rotate_inv(q0, dq);
+    vec3 tb = cross(dwb, body_I * (wb + dwb)) + cross(wb, body_I * dwb);
+    vec3 dw1 = quat_rotate(q0, dwb - (dt * inv_I) * tb);
+    quat q1 = q0 + 0.5f * quat(dw1 * dt, 0.0f) * q0;
+    q1 = normalize(q1);
+    vec3 com = c.com(b);
+    vec3 x_com = p0 + quat_rotate(q0, com);
+    vec3 p1 = x_com + dp * dt;
+    p1 -= quat_rotate(q1, com);
+    c.st_lxf(c.L.bq, nb, b, xform(p1, q1));
+    vec3 v1 = v0 + dp;
+    vec3 w1 = w0 + dw1;
+    if (length(v1) < 1e-4f) v1 = vec3(0.0f);
+    if (length(w1) < 1e-4f) w1 = vec3(0.0f);
+    c.st_lv3(c.L.bqd, 0, nb, b, v1);
+    c.st_lv3(c.L.bqd, 3, nb, b, w1);
+    c.update_body_derived(b);
+}
+template <int EPB, bool FROM_CONTACTS>
+NT_DI void phase_apply(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS>(c, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// XPBD: solve_body_joints (xpbd/kernels.py:1513-2044), split into a linear-rows lane and an angular-rows lane
+// ------------------------------------------------------------------------------------------------
+struct AxisData {
+    vec3 lower, upper, target_pos, stiffness, target_vel, damping;
+};
+
+template <int EPB>
+NT_DI AxisData gather_axes(const Ctx<EPB>& c, int count, int axis_idx0, int target_idx0) {
+    AxisData A;
+    vec3 tp, ke_w, tv, kd_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (count > k) {
+            int ai = axis_idx0 + k, ti = target_idx0 + k;
+            vec3 axis = c.dof_axis(ai);
+            float lower = c.dof(DP_LIMIT_LOWER, ai);
+            float upper = c.dof(DP_LIMIT_UPPER, ai);
+            vec3 lo_t = axis * lower, up_t = axis * upper;
+            vec3 lo = vmin(lo_t, up_t), up = vmax(lo_t, up_t);
+            if (k == 0) { A.lower = lo; A.upper = up; }
+            else { A.lower = vmin(A.lower, lo); A.upper = vmax(A.upper, up); }
+            float ke = c.dof(DP_TARGET_KE, ai);
+            float kd = c.dof(DP_TARGET_KD, ai);
+            float target_pos = c.l(c.L.ctq, 0, 1, ti);
+            float target_vel = c.l(c.L.ctqd, 0, 1, ai);
+            if (ke > 0.0f) {
+                vec3 wa = axis * ke;
+                tp += wa * target_pos;
+                ke_w += vabs(wa);
+            }
+            if (kd > 0.0f) {
+                vec3 wa = axis * kd;
+                tv += wa * target_vel;
+                kd_w += vabs(wa);
+            }
+        }
+    }
+    if (ke_w.x > 0.0f) tp.x /= ke_w.x;
+    if (ke_w.y > 0.0f) tp.y /= ke_w.y;
+    if (ke_w.z > 0.0f) tp.z /= ke_w.z;
+    if (kd_w.x > 0.0f) tv.x /= kd_w.x;
+    if (kd_w.y > 0.0f) tv.y /= kd_w.y;
+    if (kd_w.z > 0.0f) tv.z /= kd_w.z;
+    A.target_pos = tp; A.stiffness = ke_w; A.target_vel = tv; A.damping = kd_w;
+    return A;
+}
+
+// true if the joint is solved at all (enabled, not FREE, not between two immovable bodies)
+template <int EPB>
+NT_DI bool joint_live(const Ctx<EPB>& c, int j, int& id_p, int& id_c, float& m_inv_p, float& m_inv_c) {
+    const nt_model& m = c.a.m;
+    const int type = c.T.joint_type[j];
+    if (!c.T.joint_enabled[j] || type == JT_FREE) return false;
+    id_c = c.T.joint_child[j];
+    id_p = c.T.joint_parent[j];
+    m_inv_p = id_p >= 0 ? c.inv_mass(id_p) : 0.0f;
+    m_inv_c = c.inv_mass(id_c);
+    return !(m_inv_p == 0.0f && m_inv_c == 0.0f);
+}
+
+template <int EPB>
+NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
+    const nt_model& m = c.a.m;
+    const int nj = m.nj;
+    const nt_xpbd_params& P = c.a.p;
+    const float dt = c.a.dt;
+    vec3 lin_delta_p, ang_delta_p, lin_delta_c, ang_delta_c;
+    int id_p, id_c;
+    float m_inv_p, m_inv_c;
+    if (joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
+        const int type = c.T.joint_type[j];
+        xform X_pj = c.lxf(c.L.jp, 0, nj, j);
+        xform X_cj = c.lxf(c.L.jp, 7, nj, j);
+        xform X_wp = X_pj;
+        vec3 world_com_p = X_pj.p;  // transform_point(pose_p = X_pj, com_p = 0) for world-attached joints
+        vec3 vel_p(0.0f), omega_p(0.0f);
+        if (id_p >= 0) {
+            X_wp = c.body_q(id_p) * X_wp;
+            world_com_p = c.world_com(id_p);
+            vel_p = c.body_v(id_p);
+            omega_p = c.body_w(id_p);
+        }
+        xform X_wc = c.body_q(id_c) * X_cj;
+        vec3 world_com_c = c.world_com(id_c);
+        vec3 vel_c = c.body_v(id_c), omega_c = c.body_w(id_c);
+        auto wq_p = [&](vec3 v) { return id_p >= 0 ? c.w_quad(id_p, v) : 0.0f; };
+        auto wq_c = [&](vec3 v) { return c.w_quad(id_c, v); };
+
+        xform rel_pose = xform_inverse(X_wp) * X_wc;
+        vec3 rel_p = rel_pose.p;
+        vec3 x_p = X_wp.p, x_c = X_wc.p;
+        int axis_start = c.T.joint_qd_start[j];
+        int target_axis_start = c.T.joint_tq_start[j];
+        int lin_count = c.T.joint_lin_count[j];
+
+        if (type == JT_DISTANCE) {
+            vec3 r_p = x_p - world_com_p, r_c = x_c - world_com_c;
+            float lower = c.dof(DP_LIMIT_LOWER, axis_start);
+            float upper = c.dof(DP_LIMIT_UPPER, axis_start);
+            if (!(lower < 0.0f && upper < 0.0f)) {
+                vec3 anchor_delta = x_c - x_p;
+                float d = length(anchor_delta);
+                float err = 0.0f;
+                if (lower >= 0.0f && d < lower) err = d - lower;
+                else if (upper >= 0.0f && d > upper) err = d - upper;
+                if (fabsf(err) > 1e-9f) {
+                    vec3 linear_c;
+                    if (d > 1e-9f) {
+                        linear_c = anchor_delta / d;
+                    } else {
+                        vec3 com_delta = world_com_c - world_com_p;
+                        if (length_sq(com_delta) > 1e-18f) linear_c = normalize(com_delta);
+                        else linear_c = xform_vector(X_wp, vec3(1.0f, 0.0f, 0.0f));
+                    }
+                    vec3 linear_p = -linear_c;
+                    vec3 angular_p = -cross(r_p, linear_c);
+                    vec3 angular_c = cross(r_c, linear_c);
+                    float derr = dot(linear_p, vel_p) + dot(linear_c, vel_c) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
+                    float compliance = P.joint_linear_compliance;
+                    float ke = c.dof(DP_TARGET_KE, axis_start);
+                    if (ke > 0.0f) compliance = 1.0f / ke;
+                    float damping = c.dof(DP_TARGET_KD, axis_start);
+                    float d_lambda = positional_correction(err, derr, m_inv_p, m_inv_c, linear_p, linear_c, wq_p(angular_p),
+                                                           wq_c(angular_c), 0.0f, compliance, damping, dt);
+                    lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
+                    lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_c += angular_c * (d_lambda * P.joint_angular_relaxation);
+                }
+            }
+        } else {
+            AxisData A = gather_axes(c, lin_count, axis_start, target_axis_start);
+            vec3 projected_rel_p = rel_p;
+#pragma unroll
+            for (int dim = 0; dim < 3; ++dim) {
+                float lower = vget(A.lower, dim), upper = vget(A.upper, dim), r = vget(rel_p, dim);
+                if (r < lower) vset(projected_rel_p, dim, lower);
+                else if (r > upper) vset(projected_rel_p, dim, upper);
+                else if (vget(A.stiffness, dim) > 0.0f) vset(projected_rel_p, dim, clampf(vget(A.target_pos, dim), lower, upper));
+            }
+            mat33 frame_p = quat_to_matrix(X_wp.q);
+            vec3 r_p = xform_point(X_wp, projected_rel_p) - world_com_p;
+            vec3 r_c = x_c - world_com_c;
+#pragma unroll
+            for (int dim = 0; dim < 3; ++dim) {
+                float e = vget(rel_p, dim);
+                vec3 linear_c = mat_col(frame_p, dim);
+                vec3 linear_p = -linear_c;
+                vec3 angular_p = -cross(r_p, linear_c);
+                vec3 angular_c = cross(r_c, linear_c);
+                float derr = dot(linear_p, vel_p) + dot(linear_c, vel_c) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
+                float err = 0.0f;
+                float compliance = P.joint_linear_compliance;
+                float damping = 0.0f;
+                float derr_rel = derr - vget(A.target_vel, dim);
+                float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
+                if (e < lower) err = e - lower;
+                else if (e > upper) err = e - upper;
+                else {
+                    float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
+                    float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
+                    if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
+                    else if (dm > 0.0f) { compliance = 1.0f / dm; damping = dm; }
+                }
+                if (fabsf(err) > 1e-9f || fabsf(derr_rel) > 1e-9f) {
+                    float d_lambda = positional_correction(err, derr_rel, m_inv_p, m_inv_c, linear_p, linear_c, wq_p(angular_p),
+                                                           wq_c(angular_c), 0.0f, compliance, damping, dt);
+                    lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
+                    lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
+                    ang_delta_c += angular_c * (d_lambda * P.joint_angular_relaxation);
+                }
+            }
+        }
+    }
+    c.st_lv3(c.L.jl, 0, nj, j, lin_delta_p);
+    c.st_lv3(c.L.jl, 3, nj, j, ang_delta_p);
+    c.st_lv3(c.L.jl, 6, nj, j, lin_delta_c);
+    c.st_lv3(c.L.jl, 9, nj, j, ang_delta_c);
+}
+
+template <int EPB>
+NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
+    const nt_model& m = c.a.m;
+    const int nj = m.nj;
+    const nt_xpbd_params& P = c.a.p;
+    const float dt = c.a.dt;
+    vec3 t0, t1, t2;  // angular_c * d_lambda for the three angular rows (parent gets the negation)
+    int id_p, id_c;
+    float m_inv_p, m_inv_c;
+    const int type = c.T.joint_type[j];
+    bool angular_type = type == JT_FIXED || type == JT_PRISMATIC || type == JT_REVOLUTE || type == JT_D6;
+    if (angular_type && joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
+        xform X_pj = c.lxf(c.L.jp, 0, nj, j);
+        xform X_cj = c.lxf(c.L.jp, 7, nj, j);
+        quat q_p = X_pj.q;
+        vec3 omega_p(0.0f);
+        if (id_p >= 0) {
+            q_p = c.body_rot(id_p) * X_pj.q;
+            omega_p = c.body_w(id_p);
+        }
+        quat q_c = c.body_rot(id_c) * X_cj.q;
+        vec3 omega_c = c.body_w(id_c);
+        int axis_start = c.T.joint_qd_start[j];
+        int target_axis_start = c.T.joint_tq_start[j];
+        int lin_count = c.T.joint_lin_count[j], ang_count = c.T.joint_ang_count[j];
+
+        if (dot(q_p, q_c) < 0.0f) q_c = q_c * -1.0f;
+        quat rel_q = quat_inverse(q_p) * q_c;
+        quat qtwist = normalize(quat(rel_q.x, 0.0f, 0.0f, rel_q.w));
+        quat qswing = rel_q * quat_inverse(qtwist);
+        float s = sqrtf(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
+        float invs = 1.0f / s;
+        float invscube = invs * invs * invs;
+        float err_0 = 2.0f * asinf(clampf(qtwist.x, -1.0f, 1.0f));
+        float err_1 = qswing.y, err_2 = qswing.z;
+        quat grad_0(invs - rel_q.x * rel_q.x * invscube, 0.0f, 0.0f, -(rel_q.w * rel_q.x) * invscube);
+        quat grad_1(-rel_q.w * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube, rel_q.w * invs, -rel_q.x * invs,
+                    rel_q.x * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube);
+        quat grad_2(rel_q.w * (rel_q.w * rel_q.y - rel_q.x * rel_q.z) * invscube, rel_q.x * invs, rel_q.w * invs,
+                    rel_q.x * (rel_q.z * rel_q.x - rel_q.w * rel_q.y) * invscube);
+        grad_0 = grad_0 * (2.0f / fabsf(qtwist.w));
+        float swing_sq = qswing.w * qswing.w;
+        if (swing_sq + 1.0e-4f < 1.0f) {
+            float d = sqrtf(1.0f - qswing.w * qswing.w);
+            float theta = 2.0f * acosf(clampf(qswing.w, -1.0f, 1.0f));
+            float scale = theta / d;
+            err_1 *= scale;
+            err_2 *= scale;
+            grad_1 = grad_1 * scale;
+            grad_2 = grad_2 * scale;
+        }
+        AxisData A = gather_axes(c, ang_count, axis_start + lin_count, target_axis_start + lin_count);
+#pragma unroll
+        for (int dim = 0; dim < 3; ++dim) {
+            float e = dim == 0 ? err_0 : (dim == 1 ? err_1 : err_2);
+            quat grad = dim == 0 ? grad_0 : (dim == 1 ? grad_1 : grad_2);
+            quat quat_c = 0.5f * q_p * grad * quat_inverse(q_c);
+            vec3 angular_c(quat_c.x, quat_c.y, quat_c.z);
+            vec3 angular_p = -angular_c;
+            float derr = dot(angular_p, omega_p) + dot(angular_c, omega_c);
+            float err = 0.0f;
+            float compliance = P.joint_angular_compliance;
+            float damping = 0.0f;
+            float derr_rel = derr - vget(A.target_vel, dim) * length(angular_c);
+            float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
+            if (e < lower) err = e - lower;
+            else if (e > upper) err = e - upper;
+            else {
+                float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
+                float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
+                if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
+                else if (dm > 0.0f) { damping = dm; compliance = 1.0f / dm; }
+            }
+            float wqp = id_p >= 0 ? c.w_quad(id_p, angular_p) : 0.0f;
+            float d_lambda = angular_correction(err, derr_rel, wqp, c.w_quad(id_c, angular_c), 0.0f, compliance, damping, dt) *
+                             P.joint_angular_relaxation;
+            vec3 t = angular_c * d_lambda;
+            if (dim == 0) t0 = t;
+            else if (dim == 1) t1 = t;
+            else t2 = t;
+        }
+    }
+    c.st_lv3(c.L.ja, 0, nj, j, t0);
+    c.st_lv3(c.L.ja, 3, nj, j, t1);
+    c.st_lv3(c.L.ja, 6, nj, j, t2);
+}
+
+// apply_rigid_restitution (xpbd/kernels.py:2583-2728) for one contact slot; velocity deltas go to the per-contact record
+template <int EPB>
+NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    const int cpp = m.cpp, ncs = m.np * cpp, nb = m.nb;
+    const float dt = c.a.dt;
+    const float* D = ct.data;
+    float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
+    vec3 lin_a, ang_a, lin_b, ang_b;
+    size_t gi = (size_t)slot * c.ES + c.env;
+    int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+    if (gid_a != gid_b) {
+        int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
+        int shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+        int body_a = -1, body_b = -1, mat_nonzero = 0;
+        float restitution = 0.0f;
+        if (shape_a >= 0) {
+            mat_nonzero += 1;
+            restitution += c.shape_f(shape_a, SP_RESTITUTION);
+            body_a = c.T.shape_body[shape_a];
+        }
+        if (shape_b >= 0) {
+            mat_nonzero += 1;
+            restitution += c.shape_f(shape_b, SP_RESTITUTION);
+            body_b = c.T.shape_body[shape_b];
+        }
+        if (mat_nonzero > 0) restitution /= float(mat_nonzero);
+        if (body_a != body_b) {
+            float m_inv_a = 0.0f, m_inv_b = 0.0f;
+            mat33 I_inv_a, I_inv_b;
+            xform X_a_prev, X_b_prev;
+            vec3 com_a(0.0f), com_b(0.0f);
+            auto prev_q = [&](int b) { return c.lxf(c.L.xi, 0, nb, b); };
+            auto prev_qd = [&](int b) { return spatial(c.lv3(c.L.xi, 7, nb, b), c.lv3(c.L.xi, 10, nb, b)); };
+            if (body_a >= 0) {
+                X_a_prev = prev_q(body_a);
+                m_inv_a = c.inv_mass(body_a);
+                I_inv_a = c.inv_inertia(body_a);
+                com_a = c.com(body_a);
+            }
+            if (body_b >= 0) {
+                X_b_prev = prev_q(body_b);
+                m_inv_b = c.inv_mass(body_b);
+                I_inv_b = c.inv_inertia(body_b);
+                com_b = c.com(body_b);
+            }
+            vec3 bx_a = xform_point(X_a_prev, c.gv3(D, CD_POINT0, ncs, slot) + c.gv3(D, CD_OFFSET0, ncs, slot));
+            vec3 bx_b = xform_point(X_b_prev, c.gv3(D, CD_POINT1, ncs, slot) + c.gv3(D, CD_OFFSET1, ncs, slot));
+            vec3 n = c.gv3(D, CD_NORMAL, ncs, slot);
+            float d = dot(n, bx_b - bx_a);
+            if (d < 0.0f) {
+                vec3 r_a = bx_a - xform_point(X_a_prev, com_a);
+                vec3 r_b = bx_b - xform_point(X_b_prev, com_b);
+                vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
+                vec3 rxn_a(0.0f), rxn_b(0.0f), v_a(0.0f), v_b(0.0f), v_a_new(0.0f), v_b_new(0.0f);
+                float inv_mass = 0.0f;
+                if (body_a >= 0) {
+                    v_a = velocity_at_point(prev_qd(body_a), r_a) + gravity * dt;
+                    v_a_new = velocity_at_point(spatial(c.body_v(body_a), c.body_w(body_a)), r_a);
+                    rxn_a = quat_rotate_inv(X_a_prev.q, cross(r_a, n));
+                    inv_mass += m_inv_a + dot(rxn_a, I_inv_a * rxn_a);
+                }
+                if (body_b >= 0) {
+                    v_b = velocity_at_point(prev_qd(body_b), r_b) + gravity * dt;
+                    v_b_new = velocity_at_point(spatial(c.body_v(body_b), c.body_w(body_b)), r_b);
+                    rxn_b = quat_rotate_inv(X_b_prev.q, cross(r_b, n));
+                    inv_mass += m_inv_b + dot(rxn_b, I_inv_b * rxn_b);
+                }
+                float rel_vel_old = dot(n, v_b - v_a);
+                float rel_vel_new = dot(n, v_b_new - v_a_new);
+                if (inv_mass != 0.0f && rel_vel_old < 0.0f) {
+                    float dv = (-rel_vel_new - restitution * rel_vel_old) / inv_mass;
+                    if (body_a >= 0) {
+                        float dv_a = -dv;
+                        lin_a = n * m_inv_a * dv_a;
+                        ang_a = quat_rotate(X_a_prev.q, I_inv_a * rxn_a * dv_a);
+                        has_a = 1.0f;
+                    }
+                    if (body_b >= 0) {
+                        lin_b = n * m_inv_b * dv;
+                        ang_b = quat_rotate(X_b_prev.q, I_inv_b * rxn_b * dv);
+                        has_b = 1.0f;
+                    }
+                    a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
+                }
+            }
+        }
+    }
+    c.st_lv3(c.L.cw, 0, ncs, slot, lin_a);
+    c.st_lv3(c.L.cw, 3, ncs, slot, ang_a);
+    c.st_lv3(c.L.cw, 6, ncs, slot, lin_b);
+    c.st_lv3(c.L.cw, 9, ncs, slot, ang_b);
+    c.l(c.L.cw, 12, ncs, slot) = has_a;
+    c.l(c.L.cw, 13, ncs, slot) = has_b;
+    c.l(c.L.cw, 14, ncs, slot) = a_is_pair_a;
+}
+// apply_body_delta_velocities (xpbd/kernels.py:936-942): body lane sums its contacts' velocity deltas in contact order
+template <int EPB>
+NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp, ncs = m.np * cpp, nb = m.nb;
+    vec3 dv, dw;
+    for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+        int code = c.T.body_pair_list[i];
+        int p = code >> 1, side = code & 1;
+        for (int k = 0; k < cpp; ++k) {
+            int slot = p * cpp + k;
+            bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
+            if (c.l(c.L.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                dv += c.lv3(c.L.cw, is_a ? 0 : 6, ncs, slot);
+                dw += c.lv3(c.L.cw, is_a ? 3 : 9, ncs, slot);
+            }
+        }
+    }
+    c.st_lv3(c.L.bqd, 0, nb, b, c.body_v(b) + dv);
+    c.st_lv3(c.L.bqd, 3, nb, b, c.body_w(b) + dw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// optional reporting (never compiled into the fused rollout): per-joint child-side impulse -> State.body_parent_f
+// (xpbd/kernels.py:1018-1019,1074-1075,2043-2044,2497-2544) and per-contact weighted impulse -> Contacts.force
+// (xpbd/kernels.py:2398-2461).  Accumulators live in HBM (env-major SoA); lane <-> item mapping is the same in every
+// phase, so a lane only ever re-reads its own partial sums.
+// ------------------------------------------------------------------------------------------------
+// after phase_joint_forces: joint_impulse[j] = child_wrench_at_com * dt (initialises the accumulator)
+template <int EPB>
+NT_DI void report_joint_forces(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nj = c.a.m.nj;
+    float* J = c.a.rep.joint_impulse;
+    const float dt = c.a.dt;
+    for (int j = c.slot; j < nj; j += c.nslot) {
+        vec3 fc = c.lv3(c.L.jf, 6, nj, j) * dt, tc = c.lv3(c.L.jf, 9, nj, j) * dt;
+        J[c.g(0, nj, j)] = fc.x; J[c.g(1, nj, j)] = fc.y; J[c.g(2, nj, j)] = fc.z;
+        J[c.g(3, nj, j)] = tc.x; J[c.g(4, nj, j)] = tc.y; J[c.g(5, nj, j)] = tc.z;
+    }
+}
+// after phase_joints: joint_impulse[j] += (lin_delta_c, ang_delta_c), the child-side correction of this iteration
+template <int EPB>
+NT_DI void report_joint_iteration(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nj = c.a.m.nj;
+    float* J = c.a.rep.joint_impulse;
+    for (int j = c.slot; j < nj; j += c.nslot) {
+        int id_p, id_c;
+        float m_inv_p, m_inv_c;
+        if (!joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) continue;
+        vec3 jl = c.lv3(c.L.jl, 6, nj, j);
+        vec3 ja = ((c.lv3(c.L.jl, 9, nj, j) + c.lv3(c.L.ja, 0, nj, j)) + c.lv3(c.L.ja, 3, nj, j)) + c.lv3(c.L.ja, 6, nj, j);
+        J[c.g(0, nj, j)] += jl.x; J[c.g(1, nj, j)] += jl.y; J[c.g(2, nj, j)] += jl.z;
+        J[c.g(3, nj, j)] += ja.x; J[c.g(4, nj, j)] += ja.y; J[c.g(5, nj, j)] += ja.z;
+    }
+}
+// end of step: body_parent_f[b] = sum over enabled non-FREE inbound joints (ascending) of joint_impulse / dt
+template <int EPB>
+NT_DI void report_parent_f(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nj = m.nj;
+    const float* J = c.a.rep.joint_impulse;
+    float* out = c.a.s_out.body_parent_f;
+    const float inv_dt = 1.0f / c.a.dt;
+    for (int b = c.slot; b < nb; b += c.nslot) {
+        vec3 f, t;
+        if (J)
+            for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
+                int code = c.T.body_joint_list[i];
+                int j = code >> 1;
+                if (!(code & 1) || !c.T.joint_enabled[j] || c.T.joint_type[j] == JT_FREE) continue;
+                f += vec3(J[c.g(0, nj, j)], J[c.g(1, nj, j)], J[c.g(2, nj, j)]) * inv_dt;
+                t += vec3(J[c.g(3, nj, j)], J[c.g(4, nj, j)], J[c.g(5, nj, j)]) * inv_dt;
+            }
+        out[c.g(0, nb, b)] = f.x; out[c.g(1, nb, b)] = f.y; out[c.g(2, nb, b)] = f.z;
+        out[c.g(3, nb, b)] = t.x; out[c.g(4, nb, b)] = t.y; out[c.g(5, nb, b)] = t.z;
+    }
+}
+// number of active contacts on body b in this iteration (constraint_inv_weight[b], xpbd/kernels.py:2287-2291)
+template <int EPB>
+NT_DI float report_body_contact_count(const Ctx<EPB>& c, int b) {
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    float n = 0.0f;
+    for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
+        int code = c.T.body_pair_list[i];
+        int p = code >> 1, side = code & 1;
+        for (int k = 0; k < cpp; ++k) {
+            int slot = p * cpp + k;
+            bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
+            if (c.l(c.L.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) n += 1.0f;
+        }
+    }
+    return n;
+}
+// contact_impulse[slot] (+)= (lin_delta_a, ang_delta_a) * weight   (accumulate_weighted_contact_impulse)
+template <int EPB>
+NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
+    if (!c.valid) return;
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    float* I = c.a.rep.contact_impulse;
+    for (int slot = c.slot; slot < ncs; slot += c.nslot) {
+        float has_a = c.l(c.L.cw, 12, ncs, slot), has_b = c.l(c.L.cw, 13, ncs, slot);
+        vec3 lin, ang;
+        if (has_a != 0.0f || has_b != 0.0f) {
+            float weight = 1.0f;
+            if (c.a.p.rigid_contact_con_weighting) {
+                const int p = slot / cpp;
+                int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
+                if (c.l(c.L.cw, 14, ncs, slot) == 0.0f) { int t = sa; sa = sb; sb = t; }
+                int body_a = c.T.shape_body[sa], body_b = c.T.shape_body[sb];
+                float n_a = body_a >= 0 ? report_body_contact_count(c, body_a) : 0.0f;
+                float n_b = body_b >= 0 ? report_body_contact_count(c, body_b) : 0.0f;
+                float n_sum = n_a + n_b;
+                if (n_sum > 0.0f) {
+                    if (n_a == 0.0f) weight = 1.0f / n_b;
+                    else if (n_b == 0.0f) weight = 1.0f / n_a;
+                    else weight = 2.0f / n_sum;
+                }
+            }
+            lin = c.lv3(c.L.cw, 0, ncs, slot) * weight;
+            ang = c.lv3(c.L.cw, 3, ncs, slot) * weight;
+        }
+        if (first) {
+            I[c.g(0, ncs, slot)] = lin.x; I[c.g(1, ncs, slot)] = lin.y; I[c.g(2, ncs, slot)] = lin.z;
+            I[c.g(3, ncs, slot)] = ang.x; I[c.g(4, ncs, slot)] = ang.y; I[c.g(5, ncs, slot)] = ang.z;
+        } else if (has_a != 0.0f || has_b != 0.0f) {
+            I[c.g(0, ncs, slot)] += lin.x; I[c.g(1, ncs, slot)] += lin.y; I[c.g(2, ncs, slot)] += lin.z;
+            I[c.g(3, ncs, slot)] += ang.x; I[c.g(4, ncs, slot)] += ang.y; I[c.g(5, ncs, slot)] += ang.z;
+        }
+    }
+}
+
+template <int EPB>
+NT_DI void phase_joints(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nj = c.a.m.nj;
+    // linear rows on slots [0, nj), angular rows on slots [A0, A0 + nj) with A0 rounded up to a wave boundary (a wave
+    // holds 64 / EPB slots): no wavefront then mixes the two code paths, so the phase costs max(linear, angular)
+    // instead of their sum in the wave that used to straddle the boundary
+    const int spw = 64 / EPB > 0 ? 64 / EPB : 1;
+    const int A0 = ((nj + spw - 1) / spw) * spw;
+    for (int i = c.slot; i < A0 + nj; i += c.nslot) {
+        if (i < nj) joint_linear_item(c, i);
+        else if (i >= A0) joint_angular_item(c, i - A0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optional per-phase cycle accounting (-DNT_PHASE_TIMING, tools/phase_timing.py): workgroup 0 / thread 0 accumulates the
+// s_memtime delta of every phase; never compiled into the product library
+// ------------------------------------------------------------------------------------------------
+#ifdef NT_PHASE_TIMING
+__device__ unsigned long long nt_phase_clock[32];
+#define NT_TICK(slot)                                                                  \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            unsigned long long now = __builtin_readcyclecounter();                     \
+            nt_phase_clock[slot] += now - nt_phase_clock[31];                          \
+            nt_phase_clock[31] = now;                                                  \
+        }                                                                              \
+    } while (0)
+#else
+#define NT_TICK(slot) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <int EPB, bool CVX>
+NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
+    if (c.a.debug_skip & 1) return;
+    phase_shapes(c);
+    __syncthreads();
+    NT_TICK(1);
+    phase_pairs<EPB, CVX>(c);
+    __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
+    NT_TICK(2);
+    if (count_contacts) {  // per-env totals are an API-boundary output, not needed by the solver
+        phase_contact_count(c);
+        __syncthreads();
+    }
+}
+
+// SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
+template <int EPB, bool FUSED>
+NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
+    const nt_model& m = c.a.m;
+    const int skip = c.a.debug_skip;
+    const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
+    if (restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
+        for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * EPB + c.e] = c.lds[(c.L.bq + r) * EPB + c.e];
+    const bool rep_joints = !FUSED && c.a.rep.joint_impulse != nullptr;
+    const bool rep_contacts = !FUSED && c.a.rep.contact_impulse != nullptr && c.a.has_contacts;
+    if (!(skip & 2)) {
+        phase_joint_forces(c, forces_are_zero);
+        __syncthreads();
+        NT_TICK(3);
+        if (rep_joints) report_joint_forces(c);
+        phase_integrate<EPB, false>(c);
+        __syncthreads();
+        NT_TICK(4);
+    }
+    for (int it = 0; it < c.a.p.iterations; ++it) {
+        if (c.a.has_contacts) {
+            if (!(skip & 4)) phase_contacts<EPB, FUSED>(c);
+            __syncthreads();
+            NT_TICK(5);
+            if (rep_contacts) report_contact_iteration(c, it == 0);
+            if (!(skip & 16)) phase_apply<EPB, true>(c);
+            __syncthreads();
+            NT_TICK(6);
+        }
+        if (m.nj > 0) {
+            if (!(skip & 8)) phase_joints(c);
+            __syncthreads();
+            NT_TICK(7);
+            if (rep_joints) report_joint_iteration(c);
+            if (!(skip & 16)) phase_apply<EPB, false>(c);
+            __syncthreads();
+            NT_TICK(8);
+        }
+    }
+    if (restitution) {  // solver_xpbd.py:784-858
+        if (c.valid)
+            for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) restitution_item(c, s);
+        __syncthreads();
+        if (c.valid)
+            for (int b = c.slot; b < m.nb; b += c.nslot)
+                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item(c, b);
+        __syncthreads();
+    }
+    if (!FUSED && c.a.s_out.body_parent_f) {
+        __threadfence_block();  // joint lanes' accumulators -> body lanes
+        __syncthreads();
+        report_parent_f(c);
+    }
+}
+
+template <int EPB, bool CVX>
+__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) collide_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    Ctx<EPB> c(a, lds);
+    load_state(c, a.s_in);
+    load_params(c, false);
+    __syncthreads();
+    do_collide<EPB, CVX>(c, true);
+}
+
+template <int EPB>
+__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_step_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    Ctx<EPB> c(a, lds);
+    load_state(c, a.s_in);
+    load_params(c, true);
+    __syncthreads();
+    phase_body_derived(c);
+    __syncthreads();
+    do_xpbd_step<EPB, false>(c, false);
+    store_state(c, a.s_out);
+}
+
+// substeps x { clear_forces; collide; step; swap } with state and parameters resident in LDS across substeps.
+// Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
+// pointer swap); body_f of both states is zeroed as clear_forces would leave it.
+template <int EPB, bool CVX>
+__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    Ctx<EPB> c(a, lds);
+    const int nb = a.m.nb;
+    load_state(c, a.s_in);
+    load_params(c, true);
+    if (c.valid)
+        for (int r = c.slot; r < 6 * nb; r += c.nslot) {
+            a.s_in.body_f[(size_t)r * c.ES + c.env] = 0.0f;
+            a.s_out.body_f[(size_t)r * c.ES + c.env] = 0.0f;
+        }
+    __syncthreads();
+    phase_body_derived(c);
+    __syncthreads();
+    NT_TICK(0);
+    for (int s = 0; s < a.substeps; ++s) {
+        do_collide<EPB, CVX>(c, s == a.substeps - 1);
+        do_xpbd_step<EPB, true>(c, true);
+    }
+    store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
+    NT_TICK(9);
+}
