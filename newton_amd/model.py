@@ -258,6 +258,52 @@ class EnvTemplate:
         self.body_pair_list[:len(flat)] = flat
 
 
+def pack_param_arrays(model, t) -> dict:
+    """Per-env parameter tables as env-major SoA numpy arrays ([comp, slots, env_stride]; gravity [3, env_stride]; the
+    shared global-shape table in AoS): what DeviceModel uploads and what the nt_model descriptor points at."""
+    E, ES = t.env_count, t.env_stride
+
+    def soa(aos, n):  # aos [E*n, comp] -> [comp, n, ES]
+        if n == 0:  # e.g. a model without shapes or joints
+            return np.zeros((1, 1, ES), dtype=np.float32)
+        aos = np.asarray(aos, dtype=np.float32).reshape(E, n, -1)
+        out = np.zeros((aos.shape[2], n, ES), dtype=np.float32)
+        out[:, :, :E] = aos.transpose(2, 1, 0)
+        return out
+
+    m = model
+    nb, nj, nd, ns = t.nb, t.nj, t.nd, t.ns
+    body = np.concatenate([
+        m.body_com.reshape(-1, 3), m.body_inv_mass.reshape(-1, 1), m.body_inertia.reshape(-1, 9),
+        m.body_inv_inertia.reshape(-1, 9), m.body_mass.reshape(-1, 1)], axis=1)
+    grav = np.zeros((3, ES), dtype=np.float32)
+    body_world = np.asarray(m.body_world).reshape(E, nb)[:, 0] if nb else np.zeros(E, dtype=np.int32)
+    grav[:, :E] = m.gravity[body_world].T  # gravity[-1] is the global world (model.py:1300-1304)
+    joint = np.concatenate([m.joint_X_p, m.joint_X_c], axis=1) if nj else np.zeros((0, 14), dtype=np.float32)
+    # joint_armature_effective (solver_featherstone.py:269-282): 1e10 on the dofs of joints whose child body is
+    # kinematic; the armature is only read by the Featherstone kernels
+    armature = np.array(m.joint_armature, dtype=np.float32)
+    if nd and nj:
+        kin = (np.asarray(m.body_flags)[np.asarray(m.joint_child)] & int(BodyFlags.KINEMATIC)) != 0
+        dof_joint = np.searchsorted(np.asarray(m.joint_qd_start), np.arange(len(armature)), side="right") - 1
+        armature[kin[dof_joint]] = 1.0e10
+    dof = np.concatenate([
+        m.joint_axis.reshape(-1, 3), m.joint_limit_lower[:, None], m.joint_limit_upper[:, None],
+        m.joint_target_ke[:, None], m.joint_target_kd[:, None], m.joint_limit_ke[:, None], m.joint_limit_kd[:, None],
+        armature[:, None], m.joint_damping[:, None]], axis=1) if nd else np.zeros((0, 11), dtype=np.float32)
+    shape_all = np.concatenate([
+        m.shape_transform, m.shape_scale, m.shape_margin[:, None], m.shape_gap[:, None], m.shape_material_mu[:, None],
+        m.shape_material_mu_torsional[:, None], m.shape_material_mu_rolling[:, None], m.shape_material_ke[:, None],
+        m.shape_material_kd[:, None], m.shape_material_kf[:, None], m.shape_material_ka[:, None],
+        m.shape_material_restitution[:, None]], axis=1)
+    new = {
+        "body_param": soa(body, nb), "gravity": grav, "joint_param": soa(joint, nj), "dof_param": soa(dof, nd),
+        "shape_param": soa(shape_all[t.shape_local0:t.shape_local0 + E * ns], ns),
+        "gshape_param": np.ascontiguousarray(shape_all[t.gshape_id], dtype=np.float32),
+    }
+    return new
+
+
 class DeviceModel:
     """Device-resident env-major SoA copy of a Model + the nt_model descriptor passed across the C ABI."""
 
@@ -311,47 +357,7 @@ class DeviceModel:
     def upload_params(self, model: Model):
         """(Re)build the per-env parameter SoA arrays from the model's AoS numpy arrays."""
         torch = _torch()
-        t = self.t
-        E, ES = t.env_count, t.env_stride
-
-        def soa(aos, n):  # aos [E*n, comp] -> [comp, n, ES]
-            if n == 0:  # e.g. a model without shapes or joints
-                return np.zeros((1, 1, ES), dtype=np.float32)
-            aos = np.asarray(aos, dtype=np.float32).reshape(E, n, -1)
-            out = np.zeros((aos.shape[2], n, ES), dtype=np.float32)
-            out[:, :, :E] = aos.transpose(2, 1, 0)
-            return out
-
-        m = model
-        nb, nj, nd, ns = t.nb, t.nj, t.nd, t.ns
-        body = np.concatenate([
-            m.body_com.reshape(-1, 3), m.body_inv_mass.reshape(-1, 1), m.body_inertia.reshape(-1, 9),
-            m.body_inv_inertia.reshape(-1, 9), m.body_mass.reshape(-1, 1)], axis=1)
-        grav = np.zeros((3, ES), dtype=np.float32)
-        body_world = np.asarray(m.body_world).reshape(E, nb)[:, 0] if nb else np.zeros(E, dtype=np.int32)
-        grav[:, :E] = m.gravity[body_world].T  # gravity[-1] is the global world (model.py:1300-1304)
-        joint = np.concatenate([m.joint_X_p, m.joint_X_c], axis=1) if nj else np.zeros((0, 14), dtype=np.float32)
-        # joint_armature_effective (solver_featherstone.py:269-282): 1e10 on the dofs of joints whose child body is
-        # kinematic; the armature is only read by the Featherstone kernels
-        armature = np.array(m.joint_armature, dtype=np.float32)
-        if nd and nj:
-            kin = (np.asarray(m.body_flags)[np.asarray(m.joint_child)] & int(BodyFlags.KINEMATIC)) != 0
-            dof_joint = np.searchsorted(np.asarray(m.joint_qd_start), np.arange(len(armature)), side="right") - 1
-            armature[kin[dof_joint]] = 1.0e10
-        dof = np.concatenate([
-            m.joint_axis.reshape(-1, 3), m.joint_limit_lower[:, None], m.joint_limit_upper[:, None],
-            m.joint_target_ke[:, None], m.joint_target_kd[:, None], m.joint_limit_ke[:, None], m.joint_limit_kd[:, None],
-            armature[:, None], m.joint_damping[:, None]], axis=1) if nd else np.zeros((0, 11), dtype=np.float32)
-        shape_all = np.concatenate([
-            m.shape_transform, m.shape_scale, m.shape_margin[:, None], m.shape_gap[:, None], m.shape_material_mu[:, None],
-            m.shape_material_mu_torsional[:, None], m.shape_material_mu_rolling[:, None], m.shape_material_ke[:, None],
-            m.shape_material_kd[:, None], m.shape_material_kf[:, None], m.shape_material_ka[:, None],
-            m.shape_material_restitution[:, None]], axis=1)
-        new = {
-            "body_param": soa(body, nb), "gravity": grav, "joint_param": soa(joint, nj), "dof_param": soa(dof, nd),
-            "shape_param": soa(shape_all[t.shape_local0:t.shape_local0 + E * ns], ns),
-            "gshape_param": np.ascontiguousarray(shape_all[t.gshape_id], dtype=np.float32),
-        }
+        new = pack_param_arrays(model, self.t)
         for k, v in new.items():
             if v.size == 0:
                 v = np.zeros(1, dtype=np.float32)

@@ -1,0 +1,54 @@
+"""TEST INFRASTRUCTURE ONLY -- builds tests/emu/_build/libnewton_emu.so: the gfx950 kernel sources of newton_amd/csrc compiled
+for the host against tests/emu/hip_emu.h (one OS thread per GPU thread, std::barrier for __syncthreads).
+
+The product sources are not modified: they are copied into the build directory with three textual substitutions
+(HIP runtime include -> the shim, the dynamic-LDS declaration -> the shim's buffer, the wave-level fence of the Featherstone
+Cholesky -> a rendezvous of the participating lanes).  nt_broadphase.hip (wave ballots) is not part of the emulated library.
+Used by tests/test_emu_*.py to run the kernels' logic against the oracle without a GPU; never loadable from newton_amd."""
+import hashlib
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "newton_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libnewton_emu.so")
+FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_collide.hpp", "nt_xpbd.hpp",
+         "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_kernels.hip"]
+
+WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
+WAVE_SYNC_EMU = ("#define FS_WAVE_SYNC() emu_wave_sync((unsigned)(G * (((int)c.a.m.env_count - (int)blockIdx.x * EPB) < EPB ? "
+                 "((int)c.a.m.env_count - (int)blockIdx.x * EPB) : EPB)))")
+
+
+def transform(text: str) -> str:
+    text = text.replace("#include <hip/hip_runtime.h>", '#include "hip_emu.h"')
+    text = text.replace("extern __shared__ __align__(16) float lds[];", "float* lds = emu::dynamic_lds();")
+    text = text.replace('#include "../../include/newton_hip.h"', f'#include "{os.path.join(ROOT, "include", "newton_hip.h")}"')
+    text, n = WAVE_SYNC.subn(WAVE_SYNC_EMU, text)
+    return text
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OUT, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in FILES] + [os.path.join(HERE, "hip_emu.h"), os.path.abspath(__file__),
+                                                     os.path.join(ROOT, "include", "newton_hip.h")]
+    digest = hashlib.sha1(b"".join(open(s, "rb").read() for s in srcs)).hexdigest()
+    stamp = os.path.join(OUT, "stamp")
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return LIB
+    for f in FILES:
+        text = transform(open(os.path.join(CSRC, f)).read())
+        assert "hip_runtime" not in text and "__builtin_amdgcn" not in text, f
+        open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w").write(text)
+    cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
+           f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), "-o", LIB]
+    subprocess.run(cmd, check=True)
+    open(stamp, "w").write(digest)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

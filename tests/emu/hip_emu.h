@@ -1,0 +1,100 @@
+// hip_emu.h -- TEST INFRASTRUCTURE ONLY: a minimal host stand-in for the HIP runtime pieces the gfx950 kernels use, so that the
+// very same kernel sources can be executed on the CPU by the `-m "not gpu"` tests (tests/emu/build.py compiles them with g++
+// into tests/emu/_build/libnewton_emu.so).  One OS thread per GPU thread, one workgroup at a time; __syncthreads() is a
+// std::barrier.  Nothing under newton_amd/ can load this library: the product path has no CPU fallback.
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __align__(x) alignas(x)
+#define __restrict__ __restrict
+#define __shared__ static  // static LDS arrays: one workgroup runs at a time, so a single copy is the workgroup's copy
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+typedef void* hipStream_t;
+enum hipError_t { hipSuccess = 0, hipErrorEmu = 1 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+namespace emu {
+struct Block {
+    std::unique_ptr<std::barrier<>> bar;       // __syncthreads
+    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;  // wave-level rendezvous (FS_WAVE_SYNC), sized on first use
+    std::vector<float> lds;
+    unsigned threads = 0;
+};
+inline Block*& current() {
+    static Block* b = nullptr;
+    return b;
+}
+inline float* dynamic_lds() { return current()->lds.data(); }
+}  // namespace emu
+
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+inline void __syncthreads() {
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    emu::current()->bar->arrive_and_wait();
+}
+inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+// rendezvous of `participants` lanes of the calling lane's wave (the Featherstone Cholesky wave)
+inline void emu_wave_sync(unsigned participants) {
+    emu::Block* b = emu::current();
+    unsigned wave = threadIdx.x / 64;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    b->wave_bar[wave * 65 + participants]->arrive_and_wait();
+}
+
+template <typename K>
+inline hipError_t hipFuncSetAttribute(K, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    memset(p, v, n);
+    return hipSuccess;
+}
+template <typename T>
+inline hipError_t hipMemcpyFromSymbol(void* dst, const T& sym, size_t n) { memcpy(dst, &sym, n); return hipSuccess; }
+template <typename T>
+inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n) { memcpy(&sym, src, n); return hipSuccess; }
+
+template <typename K, typename... A>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t, A... args) {
+    emu::Block blk;
+    blk.threads = block.x;
+    blk.lds.assign(lds_bytes / 4 + 64, 0.0f);
+    const unsigned waves = (block.x + 63) / 64;
+    blk.wave_bar.resize(waves * 65);
+    for (unsigned w = 0; w < waves; ++w)
+        for (unsigned p = 1; p <= 64; ++p) blk.wave_bar[w * 65 + p] = std::make_unique<std::barrier<>>(p);
+    emu::current() = &blk;
+    for (unsigned b = 0; b < grid.x; ++b) {
+        blk.bar = std::make_unique<std::barrier<>>(block.x);
+        std::vector<std::thread> th;
+        th.reserve(block.x);
+        for (unsigned t = 0; t < block.x; ++t)
+            th.emplace_back([&, t, b] {
+                threadIdx = dim3(t);
+                blockIdx = dim3(b);
+                blockDim = block;
+                gridDim = grid;
+                kernel(args...);
+                blk.bar->arrive_and_drop();  // a lane that returned early must not block the others' barriers
+            });
+        for (auto& x : th) x.join();
+    }
+    emu::current() = nullptr;
+}

@@ -1,0 +1,278 @@
+"""The gfx950 kernel SOURCES, executed on the CPU, against the oracle -- without a GPU.
+
+tests/emu compiles newton_amd/csrc/*.hpp + nt_kernels.hip for the host against a small HIP shim (one OS thread per GPU thread,
+std::barrier for __syncthreads, workgroups one after the other) and these tests drive the resulting library through the same C
+ABI and the same env-major SoA layout as the product.  Both sides then run on the same x86 arithmetic with FMA contraction
+off, so wherever the kernels restate the oracle operation for operation the results are bit-identical (collision geometry,
+Featherstone); where a kernel splits a reduction differently from the serial oracle (XPBD joint rows on two lanes) the
+tolerances of the GPU parity tests apply: 1e-5 on positions, 2e-4 on the dt-amplified XPBD velocities.  What this does NOT cover: the real wave scheduling, LDS bank behaviour, register
+allocation and the device's libm (ocml) -- that is what the `-m gpu` tests are for.  The emulated library is test
+infrastructure; nothing under newton_amd/ can load it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+import newton_amd as nt  # noqa: E402
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def H(oracle_lib):
+    import harness
+
+    harness.lib()  # builds tests/emu/_build/libnewton_emu.so on first use (g++, ~15 s)
+    return harness
+
+
+def _lower(model, dz):
+    E = model.world_count
+    model.joint_q.reshape(E, -1)[:, 2] -= dz
+    bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+    model.body_q, model.body_qd = bq, bqd
+
+
+def _close(a, b, tol=TOL):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b) / np.maximum(np.abs(b), 1.0))) <= tol
+
+
+def _same_contacts(ct, oc, tol=TOL):
+    e = ct.export()
+    n = int(oc.count[0])
+    assert int(e["count"][0]) == n
+    assert np.array_equal(e["shape0"][:n], oc.shape0[:n]) and np.array_equal(e["shape1"][:n], oc.shape1[:n])
+    for k in ("point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
+        assert n == 0 or np.max(np.abs(e[k][:n] - getattr(oc, k)[:n])) <= tol, k
+    return n
+
+
+@pytest.mark.parametrize("n_env,epb", [(5, 16), (9, 8), (3, 1), (70, 0)])
+def test_xpbd_quadruped_step(H, n_env, epb):
+    from oracle_bridge import Oracle, OracleState
+    from scenes import quadruped_scene
+
+    model = quadruped_scene(n_env)
+    _lower(model, 0.24)
+    rng = np.random.default_rng(7)
+    model.body_qd = (model.body_qd + rng.normal(0, 0.2, size=model.body_qd.shape)).astype(np.float32)
+    jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
+    em = H.EmuModel(model)
+    s0, s1, ct = H.EmuState(em), H.EmuState(em), H.EmuContacts(em)
+    H.collide(em, s0, ct, epb=epb)
+    H.xpbd_step(em, s0, s1, H.EmuControl(em, joint_f=jf), ct, 1e-3, epb=epb)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    o.collide(os0.body_q, oc)
+    o.xpbd_step(os0, os1, o.control(joint_f=jf), oc, 1e-3)
+    assert _same_contacts(ct, oc) > 0
+    assert _close(s1.aos("body_q"), os1.body_q, 1e-5) and _close(s1.aos("body_qd"), os1.body_qd, 2e-4)
+
+
+def test_xpbd_rollout_equals_loop_and_oracle(H):
+    from oracle_bridge import Oracle, OracleState
+    from scenes import quadruped_scene
+
+    model = quadruped_scene(20)
+    _lower(model, 0.22)
+    em = H.EmuModel(model)
+    ctrl, ct = H.EmuControl(em), H.EmuContacts(em)
+    out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1e-3, 7)
+    a, b = H.EmuState(em), H.EmuState(em)
+    for _ in range(7):
+        a.body_f[:] = 0
+        H.collide(em, a, ct)
+        H.xpbd_step(em, a, b, ctrl, ct, 1e-3)
+        a, b = b, a
+    assert np.array_equal(out.body_q, a.body_q) and np.array_equal(out.body_qd, a.body_qd)  # fused == launch by launch
+    o = Oracle(model)
+    oout = o.xpbd_rollout(OracleState(model), OracleState(model), o.control(), o.contacts(), 1e-3, 7)
+    assert _close(out.aos("body_q"), oout.body_q, 1e-5) and _close(out.aos("body_qd"), oout.body_qd, 1e-3)
+
+
+@pytest.mark.parametrize("name", sorted(__import__("pair_scenes").CONVEX_CASES))
+def test_convex_pair_contacts(H, name):
+    from oracle_bridge import Oracle
+    from pair_scenes import CONVEX_CASES, pair_model
+
+    model = pair_model(CONVEX_CASES[name])
+    em = H.EmuModel(model)
+    ct = H.EmuContacts(em)
+    H.collide(em, H.EmuState(em), ct)
+    o = Oracle(model)
+    oc = o.contacts()
+    o.collide(model.body_q, oc)
+    _same_contacts(ct, oc)
+
+
+def test_box_stack_and_mixed_primitives(H):
+    from oracle_bridge import Oracle, OracleState
+    from scenes import box_stack_scene, mixed_primitive_scene
+
+    for model, kw in ((box_stack_scene(5), dict(iterations=4)), (mixed_primitive_scene(4), dict(iterations=2))):
+        em = H.EmuModel(model)
+        s0, s1, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+        o = Oracle(model)
+        os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+        for _ in range(3):
+            s0.body_f[:] = 0
+            H.collide(em, s0, ct)
+            H.xpbd_step(em, s0, s1, ctrl, ct, 1.0 / 240.0, **kw)
+            os0.body_f[:] = 0
+            o.collide(os0.body_q, oc)
+            o.xpbd_step(os0, os1, o.control(), oc, 1.0 / 240.0, **kw)
+            assert _same_contacts(ct, oc, 2e-5) > 0
+            s0, s1, os0, os1 = s1, s0, os1, os0
+        assert _close(s0.aos("body_q"), os0.body_q, 1e-5) and _close(s0.aos("body_qd"), os0.body_qd, 2e-4)
+
+
+def test_large_scene_runs_one_environment_per_workgroup(H):
+    """The reference's ramp line-up (161 pairs, 59 KB of LDS): envs_per_block = 1 is picked automatically."""
+    from oracle_bridge import Oracle, OracleState
+    from test_ramp_scene import _build
+
+    model, _ = _build()
+    em = H.EmuModel(model)
+    s0, s1, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    for _ in range(2):
+        H.collide(em, s0, ct)
+        H.xpbd_step(em, s0, s1, ctrl, ct, 1.0 / 600.0)
+        o.collide(os0.body_q, oc)
+        o.xpbd_step(os0, os1, o.control(), oc, 1.0 / 600.0)
+        assert _same_contacts(ct, oc, 2e-5) > 20  # the second step starts from states that differ by rounding
+        s0, s1, os0, os1 = s1, s0, os1, os0
+    assert _close(s0.aos("body_q"), os0.body_q, 1e-5)
+
+
+def test_restitution_and_reporting(H):
+    from oracle_bridge import Oracle, OracleState
+    from scenes import quadruped_scene
+
+    from newton_amd import _lib as L
+
+    model = quadruped_scene(6)
+    model.request_state_attributes("body_parent_f")
+    _lower(model, 0.24)
+    rng = np.random.default_rng(3)
+    model.body_qd = (model.body_qd + rng.normal(0, 0.3, size=model.body_qd.shape)).astype(np.float32)
+    jf = rng.normal(0, 5.0, size=model.joint_dof_count).astype(np.float32)
+    em = H.EmuModel(model)
+    t = em.t
+    s0, s1, ct = H.EmuState(em), H.EmuState(em, parent_f=True), H.EmuContacts(em)
+    impulse = np.zeros((6, t.np * t.cpp, t.env_stride), dtype=np.float32)
+    joint_impulse = np.zeros((6, t.nj, t.env_stride), dtype=np.float32)
+    rep = L.nt_xpbd_report(impulse.ctypes.data, joint_impulse.ctypes.data)
+    H.collide(em, s0, ct)
+    H.xpbd_step(em, s0, s1, H.EmuControl(em, joint_f=jf), ct, 1e-3, report=rep, enable_restitution=True)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    o.collide(os0.body_q, oc)
+    force = np.zeros((oc.max, 6), dtype=np.float32)
+    o.xpbd_step(os0, os1, o.control(joint_f=jf), oc, 1e-3, enable_restitution=True, contact_force_out=force)
+    assert _close(s1.aos("body_q"), os1.body_q, 1e-5) and _close(s1.aos("body_qd"), os1.body_qd, 2e-4)
+    assert np.abs(os1.body_parent_f).max() > 1.0
+    assert np.max(np.abs(s1.aos("body_parent_f") - os1.body_parent_f)) <= 1e-4 * np.abs(os1.body_parent_f).max()
+    # contacts.force through nt_contacts_export_force
+    n = int(oc.count[0])
+    out = np.zeros((ct.rigid_contact_max, 6), dtype=np.float32)
+    d = ct.desc()
+    import ctypes as C
+
+    H.check(H.lib().nt_contacts_export_force(C.byref(em.desc), C.byref(d), impulse.ctypes.data, 1e-3, ct.rigid_contact_max,
+                                             out.ctypes.data, ct.scan.ctypes.data, None), "nt_contacts_export_force")
+    assert np.abs(force[:n]).max() > 1.0
+    assert np.max(np.abs(out[:n] - force[:n])) <= 1e-4 * np.abs(force[:n]).max() and np.all(out[n:] == 0.0)
+
+
+def test_semi_implicit_pendulum_and_joint_zoo(H):
+    from oracle_bridge import Oracle, OracleState
+    from scenes import joint_zoo_scene, pendulum_scene
+
+    for model, dt, steps in ((pendulum_scene(3), 1e-3, 30), (joint_zoo_scene(2), 1e-4, 30)):
+        em = H.EmuModel(model)
+        s0, s1, ctrl = H.EmuState(em), H.EmuState(em), H.EmuControl(em)
+        o = Oracle(model)
+        os0, os1 = OracleState(model), OracleState(model)
+        for _ in range(steps):
+            s0.body_f[:] = 0
+            H.semi_implicit_step(em, s0, s1, ctrl, None, dt)
+            os0.body_f[:] = 0
+            o.semi_implicit_step(os0, os1, o.control(), None, dt)
+            s0, s1, os0, os1 = s1, s0, os1, os0
+        assert _close(s0.aos("body_q"), os0.body_q, 1e-5) and _close(s0.aos("body_qd"), os0.body_qd, 1e-4)
+
+
+@pytest.mark.parametrize("n_env,epb", [(6, 0), (5, 8), (16, 4)])
+def test_featherstone_step_and_rollout(H, n_env, epb):
+    """Includes the wave-cooperative Cholesky: its wavefront fence becomes a rendezvous of the participating lanes."""
+    from oracle_bridge import Oracle, OracleState
+    from scenes import quadruped_scene
+
+    model = quadruped_scene(n_env)
+    model.request_state_attributes("body_parent_f")
+    _lower(model, 0.24)
+    rng = np.random.default_rng(11)
+    model.joint_qd = (model.joint_qd + rng.normal(0, 0.3, size=model.joint_qd.shape)).astype(np.float32)
+    jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
+    em = H.EmuModel(model)
+    ctrl, ct = H.EmuControl(em, joint_f=jf), H.EmuContacts(em)
+    s0, s1 = H.EmuState(em), H.EmuState(em, parent_f=True)
+    H.collide(em, s0, ct, epb=0)
+    H.featherstone_step(em, s0, s1, ctrl, ct, 1e-3, epb=epb)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    o.collide(os0.body_q, oc)
+    o.featherstone_step(os0, os1, o.control(joint_f=jf), oc, 1e-3)
+    assert oc.count[0] > 0
+    for name, tol in (("joint_q", TOL), ("body_q", TOL), ("joint_qd", 1e-5), ("body_qd", 1e-5)):
+        assert _close(s1.aos(name), getattr(os1, name), tol), name
+    assert np.max(np.abs(s1.aos("body_parent_f") - os1.body_parent_f)) <= 1e-5 * np.abs(os1.body_parent_f).max()
+    # fused rollout == launch-by-launch loop (bitwise) and tracks the oracle
+    a, b = H.EmuState(em), H.EmuState(em)
+    out = H.featherstone_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1e-3, 3, epb=epb)
+    for _ in range(3):
+        a.body_f[:] = 0
+        H.collide(em, a, ct)
+        H.featherstone_step(em, a, b, ctrl, ct, 1e-3, epb=epb)
+        a, b = b, a
+    assert np.array_equal(out.joint_q, a.joint_q) and np.array_equal(out.body_q, a.body_q)
+
+
+def test_featherstone_kinematic_root_and_zoo(H):
+    from oracle_bridge import Oracle, OracleState
+    from scenes import joint_zoo_scene
+    from test_kinematic_links import _pendulum_on_kinematic_root
+
+    for model in (_pendulum_on_kinematic_root(None, "revolute")[0], joint_zoo_scene(3, free_root=True)):
+        em = H.EmuModel(model)
+        s0, s1, ctrl = H.EmuState(em), H.EmuState(em), H.EmuControl(em)
+        o = Oracle(model)
+        os0, os1 = OracleState(model), OracleState(model)
+        for k in range(25):
+            if model.joint_count == 2:  # prescribed motion of the kinematic root joint
+                q, qd = 0.4 * np.sin(0.025 * k), 0.4 * 6.0 * np.cos(0.025 * k)
+                s0.joint_q[0, 0, :em.t.env_count], s0.joint_qd[0, 0, :em.t.env_count] = q, qd
+                os0.joint_q[0], os0.joint_qd[0] = q, qd
+            s0.body_f[:] = 0
+            H.featherstone_step(em, s0, s1, ctrl, None, 1e-3)
+            os0.body_f[:] = 0
+            o.featherstone_step(os0, os1, o.control(), None, 1e-3)
+            s0, s1, os0, os1 = s1, s0, os1, os0
+        assert _close(s0.aos("joint_q"), os0.joint_q, 1e-5) and _close(s0.aos("body_q"), os0.body_q, 1e-5)
+
+
+def test_emulated_library_is_test_only():
+    """The product loader resolves only newton_amd/libnewton_hip.so (or an explicit NEWTON_HIP_LIB override)."""
+    from newton_amd import _lib
+
+    assert "emu" not in os.path.basename(_lib.LIB_PATH)
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "newton_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                assert "libnewton_emu" not in open(os.path.join(dirpath, f)).read(), f
