@@ -879,7 +879,9 @@ NT_DEV ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a,
         c.center = c.center - normal * (P.radius_eff_b * 0.5f);
         c.distance = c.distance - P.radius_eff_b;
     }
-    bool is_discrete_a = type_a == GEO_BOX || type_a == GEO_PLANE, is_discrete_b = type_b == GEO_BOX || type_b == GEO_PLANE;
+    // is_discrete_shape (collision_core.py:39-48): shapes with flat polygon faces
+    bool is_discrete_a = type_a == GEO_BOX || type_a == GEO_CONVEX_MESH || type_a == GEO_PLANE;
+    bool is_discrete_b = type_b == GEO_BOX || type_b == GEO_CONVEX_MESH || type_b == GEO_PLANE;
     bool is_axial_a = type_a == GEO_CYLINDER || type_a == GEO_CONE;
     bool is_axial_b = type_b == GEO_CYLINDER || type_b == GEO_CONE;
     if ((is_discrete_a && is_axial_b) || (is_discrete_b && is_axial_a)) {

@@ -99,4 +99,8 @@ CONVEX_CASES = {
     "hull_capsule": [hull_sphere(0.4, [0, 0, 0]), capsule(0.1, 0.3, [0.3, 0, 0.42], [0.7071068, 0, 0, 0.7071068])],
     "hull_hull_separated_gap": [hull_box(0.5, [0, 0, 0], gap=0.05), hull_box(0.5, [0, 0, 1.05], quat_z(0.3), gap=0.05)],
     "capsule_cylinder": [capsule(0.1, 0.2, [0.25, 0, 0], [0, 0.7071068, 0, 0.7071068]), cylinder(0.2, 0.3, [0, 0, 0])],
+    # rolling stabilisation also applies on convex hulls (is_discrete_shape, collision_core.py:39-48): a cylinder lying on a
+    # hull box (axis perpendicular to the normal) and a cone lying on its slant line
+    "cylinder_hull_rolling": [cylinder(0.2, 0.3, [0.03, 0.02, 0.69], [0.7071068, 0, 0, 0.7071068]), hull_box(0.5, [0, 0, 0])],
+    "cone_hull_rolling": [cone(0.2, 0.2, [0.0, 0.05, 0.5 + 0.0894427 - 0.004], [0.8506508, 0, 0, 0.5257311]), hull_box(0.5, [0, 0, 0])],
 }
