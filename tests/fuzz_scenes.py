@@ -34,7 +34,7 @@ def _add_random_shape(env, rng, body, cfg, allow_hull=True):
         env.add_shape_convex_hull(body, xform=xf, mesh=nt.Mesh.convex_hull_of(pts), cfg=cfg)
 
 
-def random_scene(seed, world_count=None, articulated=True, allow_hull=True, featherstone_compatible=False):
+def random_scene(seed, world_count=None, articulated=True, allow_hull=True, featherstone_compatible=False, param_jitter=False):
     rng = np.random.default_rng(seed)
     env = nt.ModelBuilder(gravity=(0.0, 0.0, -9.81) if rng.random() < 0.8 else tuple(rng.normal(0, 5.0, size=3)))
     nb = int(rng.integers(2, 7))
@@ -112,6 +112,24 @@ def random_scene(seed, world_count=None, articulated=True, allow_hull=True, feat
     model.body_mass *= rng.uniform(0.8, 1.25, size=model.body_mass.shape).astype(np.float32)
     model.body_inv_mass = np.where(model.body_mass > 0, 1.0 / np.maximum(model.body_mass, 1e-12), 0.0).astype(np.float32)
     model.shape_material_mu *= rng.uniform(0.7, 1.3, size=model.shape_material_mu.shape).astype(np.float32)
+    if param_jitter:  # domain randomisation: every world gets its own geometry / frames / gains / gravity
+        S = model.shape_count
+        sc = rng.uniform(0.8, 1.25, size=(S, 1)).astype(np.float32)
+        sc[np.asarray(model.shape_type) == int(nt.GeoType.PLANE)] = 1.0
+        model.shape_scale = (model.shape_scale * sc).astype(np.float32)
+        # the local AABBs carry the scale (builder.py:11575-11612): keep them consistent, like a re-finalize would
+        model.shape_collision_aabb_lower = (model.shape_collision_aabb_lower * sc).astype(np.float32)
+        model.shape_collision_aabb_upper = (model.shape_collision_aabb_upper * sc).astype(np.float32)
+        model.shape_gap = (model.shape_gap * rng.uniform(0.5, 1.5, size=S)).astype(np.float32)
+        model.shape_margin = (model.shape_margin * rng.uniform(0.5, 1.5, size=S)).astype(np.float32)
+        loc = np.asarray(model.shape_body) >= 0
+        model.shape_transform[loc, :3] += rng.normal(0, 0.01, size=(int(loc.sum()), 3)).astype(np.float32)
+        model.body_com += rng.normal(0, 0.01, size=model.body_com.shape).astype(np.float32)
+        if model.joint_count:
+            model.joint_X_p[:, :3] += rng.normal(0, 0.01, size=(model.joint_count, 3)).astype(np.float32)
+            model.joint_limit_lower -= rng.uniform(0, 0.05, size=model.joint_limit_lower.shape).astype(np.float32)
+            model.joint_target_ke *= rng.uniform(0.5, 2.0, size=model.joint_target_ke.shape).astype(np.float32)
+        model.gravity[:-1] += rng.normal(0, 1.0, size=model.gravity[:-1].shape).astype(np.float32)
     if articulated:
         t = model.env
         jq = model.joint_q.reshape(E, -1).copy()

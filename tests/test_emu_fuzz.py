@@ -26,7 +26,8 @@ def _run(H, mode, seed):
     from oracle_bridge import Oracle, OracleState
 
     try:
-        model = random_scene(seed, articulated=(mode != "free"), featherstone_compatible=(mode == "featherstone"))
+        model = random_scene(seed, articulated=(mode != "free"), featherstone_compatible=(mode == "featherstone"),
+                             param_jitter=(mode == "xpbd_jitter"))
     except NotImplementedError:  # e.g. D6 joints with several angular axes: rejected by the host FK, not part of the kernels
         pytest.skip("scene uses a joint configuration the host rejects")
     t = model.env
@@ -88,3 +89,9 @@ def test_semi_implicit(H, seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_featherstone(H, seed):
     _run(H, "featherstone", seed)
+
+
+@pytest.mark.parametrize("seed", range(1, 21, 2))
+def test_xpbd_per_world_parameters(H, seed):
+    """Domain randomisation: shape sizes (hull scales included), frames, COMs, gains and gravity differ per world."""
+    _run(H, "xpbd_jitter", seed)
