@@ -34,7 +34,8 @@ def _add_random_shape(env, rng, body, cfg, allow_hull=True):
         env.add_shape_convex_hull(body, xform=xf, mesh=nt.Mesh.convex_hull_of(pts), cfg=cfg)
 
 
-def random_scene(seed, world_count=None, articulated=True, allow_hull=True, featherstone_compatible=False, param_jitter=False):
+def random_scene(seed, world_count=None, articulated=True, allow_hull=True, featherstone_compatible=False, param_jitter=False,
+                 extras=False):
     rng = np.random.default_rng(seed)
     env = nt.ModelBuilder(gravity=(0.0, 0.0, -9.81) if rng.random() < 0.8 else tuple(rng.normal(0, 5.0, size=3)))
     nb = int(rng.integers(2, 7))
@@ -51,14 +52,28 @@ def random_scene(seed, world_count=None, articulated=True, allow_hull=True, feat
         if not env.body_shapes[b]:  # massless link: give it inertia so that it can be simulated
             env.body_mass[b] = 0.3
             env.body_inertia[b] = np.eye(3) * 2e-3
+    split = int(rng.integers(1, nb)) if (extras and nb >= 3) else nb  # bodies [split, nb) form a second articulation
+    if extras and rng.random() < 0.5:
+        env.body_flags[bodies[0]] = int(nt.BodyFlags.KINEMATIC)
+    if extras:
+        for _ in range(int(rng.integers(1, 3))):  # static shapes that belong to the world (body -1) of every env
+            cfg = nt.ModelBuilder.ShapeConfig(collision_group=int(rng.choice([1, -1, -2])), gap=float(rng.uniform(0.0, 0.03)))
+            xf = [rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(0.0, 0.2), *_rand_quat(rng, 0.4)]
+            if rng.random() < 0.5:
+                env.add_shape_box(-1, xform=xf, hx=0.15, hy=0.1, hz=0.05, cfg=cfg)
+            else:
+                env.add_shape_sphere(-1, xform=xf, radius=0.1, cfg=cfg)
     if articulated:
         joints = []
         for k, b in enumerate(bodies):
-            parent = -1 if k == 0 else int(bodies[rng.integers(0, k)]) if not featherstone_compatible else int(bodies[rng.integers(0, k)])
+            first = 0 if k < split else split
+            parent = -1 if k == first else int(bodies[rng.integers(first, k)])
             Xp = [*rng.uniform(-0.15, 0.15, size=3), *_rand_quat(rng, 0.5)]
             Xc = [*rng.uniform(-0.1, 0.1, size=3), *_rand_quat(rng, 0.5)]
-            if k == 0:
+            if k == first:
                 kind = rng.choice(["free", "revolute", "fixed"])
+                if int(env.body_flags[b]) & int(nt.BodyFlags.KINEMATIC):
+                    kind = rng.choice(["free", "fixed"])
             else:
                 kinds = ["revolute", "prismatic", "ball", "fixed", "d6"]
                 if not featherstone_compatible:
@@ -90,7 +105,9 @@ def random_scene(seed, world_count=None, articulated=True, allow_hull=True, feat
                                      angular_axes=[D(axis=0), D(axis=1, limit_lower=-0.3, limit_upper=0.3), D(axis=2)],
                                      parent_xform=Xp, child_xform=Xc)
             joints.append(j)
-        env.add_articulation(joints)
+        env.add_articulation(joints[:split])
+        if split < nb:
+            env.add_articulation(joints[split:])
         if not featherstone_compatible and rng.random() < 0.3 and len(joints) > 2:
             env.joint_enabled[joints[-1]] = False
     if rng.random() < 0.4 and env.shape_count >= 3:

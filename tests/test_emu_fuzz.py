@@ -22,12 +22,12 @@ def H(oracle_lib):
     return harness
 
 
-def _run(H, mode, seed):
+def _run(H, mode, seed, extras=False):
     from oracle_bridge import Oracle, OracleState
 
     try:
         model = random_scene(seed, articulated=(mode != "free"), featherstone_compatible=(mode == "featherstone"),
-                             param_jitter=(mode == "xpbd_jitter"))
+                             param_jitter=(mode == "xpbd_jitter"), extras=extras)
     except NotImplementedError:  # e.g. D6 joints with several angular axes: rejected by the host FK, not part of the kernels
         pytest.skip("scene uses a joint configuration the host rejects")
     t = model.env
@@ -95,3 +95,10 @@ def test_featherstone(H, seed):
 def test_xpbd_per_world_parameters(H, seed):
     """Domain randomisation: shape sizes (hull scales included), frames, COMs, gains and gravity differ per world."""
     _run(H, "xpbd_jitter", seed)
+
+
+@pytest.mark.parametrize("seed", range(40, 50))
+@pytest.mark.parametrize("mode", ["xpbd", "featherstone"])
+def test_kinematic_roots_local_statics_two_articulations(H, mode, seed):
+    """Kinematic root links, static shapes owned by each world (body -1), two articulations per world."""
+    _run(H, mode, seed, extras=True)
