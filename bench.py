@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--envs-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["quadruped", "box_stack", "quadruped_featherstone"], default="quadruped",
+    ap.add_argument("--workload", choices=["quadruped", "box_stack", "quadruped_featherstone", "hull_bin"], default="quadruped",
                     help="quadruped = the BASELINE.json metric (default); box_stack = config C2 (convex MPR/GJK path), "
                          "a secondary measurement that is never the headline value")
     args = ap.parse_args()
@@ -109,6 +109,14 @@ def main():
         iterations, workload_name = 2, (
             "Anymal-class quadruped (in-repo stand-in geometry: 13 bodies, 12 revolute + free base, "
             "13 cylinder colliders + ground plane)")
+    elif args.workload == "hull_bin":
+        from scenes import hull_bin_scene
+
+        # C5 without the SDF / hydroelastic contact models: 64 hulls in a five-wall bin, 2 336 candidate pairs per env
+        # (pass --envs-per-gpu 2048 for the BASELINE.json size; contact records then take ~3 GB of HBM)
+        model = hull_bin_scene(args.envs_per_gpu, 64, device=f"cuda:{local_rank}", seed=2 + rank)
+        iterations, workload_name = 2, ("C5 geometry without SDF / hydroelastic: 64 convex hulls (16-32 vertices) in a five-wall "
+                                        "bin, all 2 336 pairs per env through MPR/GJK + manifold, contact records in HBM")
     else:
         from scenes import box_stack_scene
 

@@ -71,7 +71,9 @@ typedef struct {
     int32_t max_art_dofs;/* widest articulation, in dofs (row width of the LDS-resident joint-space inertia H) */
     int32_t shape_local0;/* Newton shape id of env 0's first local shape: env-local shapes occupy ids
                             [shape_local0, shape_local0 + env_count*ns), global shapes sit before and / or after (gshape_id) */
-    int32_t reserved0;
+    int32_t contact_scratch_in_hbm; /* 0: the per-contact correction records of the solvers live in LDS (default).
+                            1: pair-heavy scenes whose records do not fit the CU's LDS keep them in nt_contacts.cw (HBM, L2
+                            resident); the stepping kernels then run one environment per workgroup.  XPBD / collide only. */
     /* topology, int32, env-uniform */
     const int32_t* body_flags;          /* [nb]   BodyFlags */
     const int32_t* joint_type;          /* [nj]   JointType */
@@ -138,6 +140,7 @@ typedef struct {
     float* data;          /* [NT_CONTACT_FLOATS][np*cpp][ES] */
     int32_t* env_count;   /* [ES] contacts emitted per env (== per-env slice of rigid_contact_count) */
     uint8_t* pair_hit;    /* [np][ES] 1 if the pair passed the broad phase (candidate pair set, per env) */
+    float* cw;            /* [15][np*cpp][ES] solver scratch, only when nt_model.contact_scratch_in_hbm (else NULL) */
 } nt_contacts;
 
 typedef struct {
@@ -259,6 +262,9 @@ nt_status nt_broadphase_explicit(const nt_broadphase_in* in, const int32_t* pair
 /* -------- introspection -------- */
 const char* nt_error_string(nt_status s);
 const char* nt_build_info(void);                 /* "gfx950 ..." */
+/* environments per workgroup the stepping kernels would use for this model (requested: 0 = auto), 0 if the working set
+ * does not fit the CU's LDS in the model's current contact_scratch_in_hbm mode */
+int32_t nt_pick_envs_per_block(const nt_model* m, int32_t requested);
 int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m);
 int32_t nt_lds_bytes_per_env(const nt_model* m); /* LDS footprint of one env in the step kernels */
 /* dst[i] = src[i], 4 B/lane coalesced: known-byte-count kernel used to calibrate the HBM PMC counters */

@@ -28,7 +28,7 @@ class nt_model(C.Structure):
         ("nc", C.c_int32), ("ntq", C.c_int32), ("ns", C.c_int32), ("ng", C.c_int32), ("np", C.c_int32),
         ("cpp", C.c_int32),
         ("np_analytic", C.c_int32), ("na", C.c_int32), ("max_art_dofs", C.c_int32), ("shape_local0", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("contact_scratch_in_hbm", C.c_int32),
         ("body_flags", C.c_void_p), ("joint_type", C.c_void_p), ("joint_enabled", C.c_void_p),
         ("joint_parent", C.c_void_p), ("joint_child", C.c_void_p), ("joint_q_start", C.c_void_p),
         ("joint_qd_start", C.c_void_p), ("joint_tq_start", C.c_void_p), ("joint_lin_count", C.c_void_p),
@@ -55,7 +55,7 @@ class nt_control(C.Structure):
 
 class nt_contacts(C.Structure):
     _fields_ = [("shape0", C.c_void_p), ("shape1", C.c_void_p), ("data", C.c_void_p), ("env_count", C.c_void_p),
-                ("pair_hit", C.c_void_p)]
+                ("pair_hit", C.c_void_p), ("cw", C.c_void_p)]
 
 
 class nt_xpbd_params(C.Structure):
@@ -124,6 +124,7 @@ SYMBOLS = {
     "nt_error_string": (C.c_char_p, [C.c_int32]),
     "nt_build_info": (C.c_char_p, []),
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
+    "nt_pick_envs_per_block": (C.c_int32, [C.POINTER(nt_model), C.c_int32]),
     "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
 }
 

@@ -42,6 +42,9 @@ class Contacts:
         self._env_count = torch.zeros(t.env_stride, dtype=torch.int32, device=dev)
         self._pair_hit = torch.zeros((max(t.np, 1), t.env_stride), dtype=torch.uint8, device=dev)
         self._scan = torch.zeros(4 * (t.env_stride + 1), dtype=torch.int32, device=dev)
+        # pair-heavy scenes keep the solvers' per-contact records here instead of LDS (nt_model.contact_scratch_in_hbm)
+        self._cw = (torch.zeros((15, ns, t.env_stride), dtype=torch.float32, device=dev)
+                    if dm.desc.contact_scratch_in_hbm else None)
         self._export = None
         self._generation = 0
         self._export_generation = -1
@@ -60,6 +63,8 @@ class Contacts:
         d.data = self._data.data_ptr()
         d.env_count = self._env_count.data_ptr()
         d.pair_hit = self._pair_hit.data_ptr()
+        if self._cw is not None:
+            d.cw = self._cw.data_ptr()
         return d
 
     # -- Newton-shaped flat views (append order = env, pair, sub-contact; collide.py:166-254) ---------------

@@ -240,7 +240,7 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
                 // polygon scratch: 20 rows per convex pair in the part of the scratch union that the collide phases do not
                 // use (behind shape transforms / AABBs / pair counts)
                 PolyRef poly;
-                poly.base = &c.lds[(c.L.pc + m.np + 20 * (p - m.np_analytic)) * EPB + c.e];
+                poly.base = &c.lds[(c.L.pc + m.np + 20 * (c.big ? c.slot : p - m.np_analytic)) * EPB + c.e];
                 poly.stride = EPB;
                 convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;

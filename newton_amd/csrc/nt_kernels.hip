@@ -199,10 +199,12 @@ int slots_for(const nt_model& m, int epb) {
 }
 
 bool epb_fits(const nt_model& m, int epb) {
-    return (size_t)make_layout(m).rows_per_env * 4 * epb + (size_t)topo_ints(m) * 4 <= LDS_BYTES_PER_CU;
+    return (size_t)make_layout_host(m).rows_per_env * 4 * epb + (size_t)topo_ints(m) * 4 <= LDS_BYTES_PER_CU;
 }
 
 int pick_epb(const nt_model& m, int requested) {
+    // pair-heavy scenes (contact records in HBM) only have the one-environment-per-workgroup kernels
+    if (m.contact_scratch_in_hbm) return (requested == 0 || requested == 1) && epb_fits(m, 1) ? 1 : 0;
     if (requested == 1 || requested == 8 || requested == 16 || requested == 32 || requested == 64)
         return epb_fits(m, requested) ? requested : 0;
     // auto: the widest tile (best coalescing) that still yields >= 256 workgroups (one per CU); else the narrowest
@@ -222,7 +224,7 @@ int pick_epb(const nt_model& m, int requested) {
 
 template <typename K>
 nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
-    LdsLayout L = make_layout(a.m);
+    LdsLayout L = make_layout_host(a.m);
     int nslot = slots_for(a.m, epb);
     a.nslot = nslot;
     {
@@ -288,7 +290,12 @@ const char* nt_build_info(void) { return "libnewton_hip gfx950 (CDNA4) fp32, -ff
 
 int32_t nt_lds_bytes_per_env(const nt_model* m) {
     if (!m) return -1;
-    return make_layout(*m).rows_per_env * 4;
+    return make_layout_host(*m).rows_per_env * 4;
+}
+
+int32_t nt_pick_envs_per_block(const nt_model* m, int32_t requested) {
+    if (!model_ok(m)) return 0;
+    return pick_epb(*m, requested);
 }
 
 nt_status nt_clear_forces(const nt_model* m, nt_state* s, void* stream) {
@@ -309,6 +316,9 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
     a.ct = *c;
     int epb = pick_epb(*m, p ? p->envs_per_block : 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
+    if (m->contact_scratch_in_hbm)
+        return m->np_analytic < m->np ? launch(collide_kernel<1, true, true>, a, 1, (hipStream_t)stream)
+                                      : launch(collide_kernel<1, false, true>, a, 1, (hipStream_t)stream);
     return NT_DISPATCH_EPB_CVX(collide_kernel, *m, a, epb, (hipStream_t)stream);
 }
 
@@ -330,6 +340,10 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
     a.dt = dt;
     int epb = pick_epb(*m, envs_per_block);
     if (!epb) return NT_ERR_UNSUPPORTED;
+    if (m->contact_scratch_in_hbm) {
+        if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
+        return launch(xpbd_step_kernel<1, true>, a, 1, (hipStream_t)stream);
+    }
     return NT_DISPATCH_EPB(xpbd_step_kernel, a, epb, (hipStream_t)stream);
 }
 
@@ -349,6 +363,11 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     a.substeps = substeps;
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
+    if (m->contact_scratch_in_hbm) {
+        if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
+        return m->np_analytic < m->np ? launch(xpbd_rollout_kernel<1, true, true>, a, 1, (hipStream_t)stream)
+                                      : launch(xpbd_rollout_kernel<1, false, true>, a, 1, (hipStream_t)stream);
+    }
     return NT_DISPATCH_EPB_CVX(xpbd_rollout_kernel, *m, a, epb, (hipStream_t)stream);
 }
 
@@ -365,6 +384,7 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
     a.sp = *p;
     a.angular_damping = p->angular_damping;
     a.dt = dt;
+    if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;  // XPBD / collide only
     int epb = pick_epb(*m, envs_per_block);
     if (!epb) return NT_ERR_UNSUPPORTED;
     return NT_DISPATCH_EPB(semi_implicit_step_kernel, a, epb, (hipStream_t)stream);
@@ -372,11 +392,12 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
 
 // shared launch logic of the Featherstone kernels (step / rollout)
 static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, bool rollout, hipStream_t stream) {
+    if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;  // XPBD / collide only
     {
         const char* e = getenv("NT_DEBUG_SKIP");
         a.debug_skip = e ? atoi(e) : 0;
     }
-    const FsLayout F = make_fs_layout(*m, make_layout(*m));
+    const FsLayout F = make_fs_layout(*m, make_layout(*m, false));
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     auto fits = [&](int epb) { return (size_t)F.rows * 4 * epb + shared_ints * 4 <= LDS_BYTES_PER_CU; };
     int epb = 0;
@@ -457,7 +478,7 @@ nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_param
 
 int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m) {
     if (!m) return -1;
-    return make_fs_layout(*m, make_layout(*m)).rows * 4;
+    return make_fs_layout(*m, make_layout(*m, false)).rows * 4;
 }
 
 nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint_qd, nt_state* out, void* stream) {
@@ -466,7 +487,7 @@ nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint
     KArgs a = {};
     a.m = *m;
     a.s_out = *out;
-    const FsLayout F = make_fs_layout(*m, make_layout(*m));
+    const FsLayout F = make_fs_layout(*m, make_layout(*m, false));
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     int epb = 0;
     const int cands[3] = {16, 8, 4};

@@ -45,7 +45,11 @@ struct LdsLayout {
     int rows_per_env;
 };
 
-__host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
+constexpr int NT_BIG_SCENE_LANES = 256;  // workgroup size of the one-environment-per-workgroup tile
+
+// big: pair-heavy scenes (nt_model.contact_scratch_in_hbm).  Device code passes a compile-time constant so that the
+// default kernels carry no trace of the second mode.
+__host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big) {
     LdsLayout L;
     int o = 0;
     L.bq = o; o += 7 * m.nb;
@@ -62,13 +66,14 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     L.pm = o; o += m.np;
     L.u = o;
     L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
-    int coll = 13 * m.ns + m.np + 20 * (m.np - m.np_analytic);  // + manifold polygon scratch of the convex pairs
+    // + manifold polygon scratch: 20 rows per convex pair, or (pair-heavy scenes, one environment per workgroup) per lane
+    int coll = 13 * m.ns + m.np + 20 * (big ? NT_BIG_SCENE_LANES : (m.np - m.np_analytic));
     L.bf = L.u; L.jf = L.bf + 6 * m.nb;
     int forces = 6 * m.nb + 12 * m.nj;
     L.jl = L.u; L.ja = L.jl + 12 * m.nj;
     int joints = 21 * m.nj;
     L.cw = L.u;
-    int contacts = CW_FLOATS * m.np * m.cpp;
+    int contacts = big ? 0 : CW_FLOATS * m.np * m.cpp;  // big: the records live in nt_contacts.cw (HBM)
     L.si_jf = L.bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
     int semi = 6 * m.nb + 12 * m.nj + contacts;
     int xpbd = imax(imax(coll, forces), imax(joints, contacts));
@@ -76,6 +81,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m) {
     L.rows_per_env = L.u + imax(xpbd + 13 * m.nb, semi);
     return L;
 }
+inline LdsLayout make_layout_host(const nt_model& m) { return make_layout(m, m.contact_scratch_in_hbm != 0); }
 
 struct KArgs {
     nt_model m;
@@ -112,12 +118,13 @@ struct Ctx {
     float* lds;
     LdsLayout L;
     int e, slot, env, nslot;
+    bool big;  // contact records in HBM, manifold polygon scratch per lane (compile-time constant at every construction site)
     int ES;
     bool valid;
 
     // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
-    NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1) : a(a_), lds(lds_) {
-        L = make_layout(a.m);
+    NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
+        L = make_layout(a.m, big_);
         if (rows < 0) rows = L.rows_per_env;
         e = threadIdx.x % EPB;
         slot = threadIdx.x / EPB;

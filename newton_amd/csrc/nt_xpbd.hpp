@@ -182,11 +182,34 @@ NT_DI float angular_correction(float err, float derr, float wq_a, float wq_b, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// where the per-contact correction records (CW_FLOATS rows per contact slot) live: in LDS (default), or -- for pair-heavy
+// scenes whose records do not fit the CU's LDS (nt_model.contact_scratch_in_hbm) -- in nt_contacts.cw, env-major in HBM
+// ------------------------------------------------------------------------------------------------
+struct CwLds {
+    template <int EPB>
+    static NT_DI float& at(const Ctx<EPB>& c, int comp, int ncs, int slot) { return c.l(c.L.cw, comp, ncs, slot); }
+};
+struct CwHbm {
+    template <int EPB>
+    static NT_DI float& at(const Ctx<EPB>& c, int comp, int ncs, int slot) { return c.a.ct.cw[c.g(comp, ncs, slot)]; }
+};
+template <class CW, int EPB>
+NT_DI vec3 cw_v3(const Ctx<EPB>& c, int comp, int ncs, int slot) {
+    return vec3(CW::at(c, comp, ncs, slot), CW::at(c, comp + 1, ncs, slot), CW::at(c, comp + 2, ncs, slot));
+}
+template <class CW, int EPB>
+NT_DI void cw_st3(const Ctx<EPB>& c, int comp, int ncs, int slot, vec3 v) {
+    CW::at(c, comp, ncs, slot) = v.x;
+    CW::at(c, comp + 1, ncs, slot) = v.y;
+    CW::at(c, comp + 2, ncs, slot) = v.z;
+}
+
+// ------------------------------------------------------------------------------------------------
 // XPBD: solve_body_contact_positions (xpbd/kernels.py:2164-2399); one lane per contact slot.
 // ------------------------------------------------------------------------------------------------
 // FUSED: the collide phase of the same kernel left the live-contact count of every pair in LDS, and the (type-sorted)
 // shape order of a pair is static, so neither the liveness test nor the shape ids need the global contact arrays.
-template <int EPB, bool FUSED>
+template <int EPB, bool FUSED, class CW = CwLds>
 NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
@@ -336,26 +359,26 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
             a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
         }
     }
-    c.st_lv3(c.L.cw, 0, ncs, slot, lin_delta_a);
-    c.st_lv3(c.L.cw, 3, ncs, slot, ang_delta_a);
-    c.st_lv3(c.L.cw, 6, ncs, slot, lin_delta_b);
-    c.st_lv3(c.L.cw, 9, ncs, slot, ang_delta_b);
-    c.l(c.L.cw, 12, ncs, slot) = has_a;
-    c.l(c.L.cw, 13, ncs, slot) = has_b;
-    c.l(c.L.cw, 14, ncs, slot) = a_is_pair_a;
+    cw_st3<CW>(c, 0, ncs, slot, lin_delta_a);
+    cw_st3<CW>(c, 3, ncs, slot, ang_delta_a);
+    cw_st3<CW>(c, 6, ncs, slot, lin_delta_b);
+    cw_st3<CW>(c, 9, ncs, slot, ang_delta_b);
+    CW::at(c, 12, ncs, slot) = has_a;
+    CW::at(c, 13, ncs, slot) = has_b;
+    CW::at(c, 14, ncs, slot) = a_is_pair_a;
 }
-template <int EPB, bool FUSED>
+template <int EPB, bool FUSED, class CW = CwLds>
 NT_DI void phase_contacts(const Ctx<EPB>& c) {
     if (!c.valid) return;
     const int ncs = c.a.m.np * c.a.m.cpp;
-    for (int s = c.slot; s < ncs; s += c.nslot) contact_item<EPB, FUSED>(c, s);
+    for (int s = c.slot; s < ncs; s += c.nslot) contact_item<EPB, FUSED, CW>(c, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // XPBD: apply_body_deltas (xpbd/kernels.py:864-933).  FROM_CONTACTS: sum contact corrections (+ contact counts)
 // in ascending contact order; otherwise sum joint corrections in ascending joint order.
 // ------------------------------------------------------------------------------------------------
-template <int EPB, bool FROM_CONTACTS>
+template <int EPB, bool FROM_CONTACTS, class CW = CwLds>
 NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int nb = m.nb;
@@ -372,11 +395,11 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
             for (int k = 0; k < cpp; ++k) {
                 int slot = p * cpp + k;
                 // this body is the contact's "a" iff (side == 0) == (shape0 is pair_a's shape)
-                bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
-                float has = c.l(c.L.cw, is_a ? 12 : 13, ncs, slot);
+                bool is_a = (side == 0) == (CW::at(c, 14, ncs, slot) != 0.0f);
+                float has = CW::at(c, is_a ? 12 : 13, ncs, slot);
                 if (has != 0.0f) {
-                    dlin += c.lv3(c.L.cw, is_a ? 0 : 6, ncs, slot);
-                    dang += c.lv3(c.L.cw, is_a ? 3 : 9, ncs, slot);
+                    dlin += cw_v3<CW>(c, is_a ? 0 : 6, ncs, slot);
+                    dang += cw_v3<CW>(c, is_a ? 3 : 9, ncs, slot);
                     inv_weight += 1.0f;
                 }
             }
@@ -427,10 +450,10 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     c.st_lv3(c.L.bqd, 3, nb, b, w1);
     c.update_body_derived(b);
 }
-template <int EPB, bool FROM_CONTACTS>
+template <int EPB, bool FROM_CONTACTS, class CW = CwLds>
 NT_DI void phase_apply(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS>(c, b);
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW>(c, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -703,7 +726,7 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
 }
 
 // apply_rigid_restitution (xpbd/kernels.py:2583-2728) for one contact slot; velocity deltas go to the per-contact record
-template <int EPB>
+template <int EPB, class CW = CwLds>
 NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
@@ -791,16 +814,16 @@ NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
             }
         }
     }
-    c.st_lv3(c.L.cw, 0, ncs, slot, lin_a);
-    c.st_lv3(c.L.cw, 3, ncs, slot, ang_a);
-    c.st_lv3(c.L.cw, 6, ncs, slot, lin_b);
-    c.st_lv3(c.L.cw, 9, ncs, slot, ang_b);
-    c.l(c.L.cw, 12, ncs, slot) = has_a;
-    c.l(c.L.cw, 13, ncs, slot) = has_b;
-    c.l(c.L.cw, 14, ncs, slot) = a_is_pair_a;
+    cw_st3<CW>(c, 0, ncs, slot, lin_a);
+    cw_st3<CW>(c, 3, ncs, slot, ang_a);
+    cw_st3<CW>(c, 6, ncs, slot, lin_b);
+    cw_st3<CW>(c, 9, ncs, slot, ang_b);
+    CW::at(c, 12, ncs, slot) = has_a;
+    CW::at(c, 13, ncs, slot) = has_b;
+    CW::at(c, 14, ncs, slot) = a_is_pair_a;
 }
 // apply_body_delta_velocities (xpbd/kernels.py:936-942): body lane sums its contacts' velocity deltas in contact order
-template <int EPB>
+template <int EPB, class CW = CwLds>
 NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int cpp = m.cpp, ncs = m.np * cpp, nb = m.nb;
@@ -810,10 +833,10 @@ NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
         int p = code >> 1, side = code & 1;
         for (int k = 0; k < cpp; ++k) {
             int slot = p * cpp + k;
-            bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
-            if (c.l(c.L.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) {
-                dv += c.lv3(c.L.cw, is_a ? 0 : 6, ncs, slot);
-                dw += c.lv3(c.L.cw, is_a ? 3 : 9, ncs, slot);
+            bool is_a = (side == 0) == (CW::at(c, 14, ncs, slot) != 0.0f);
+            if (CW::at(c, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                dv += cw_v3<CW>(c, is_a ? 0 : 6, ncs, slot);
+                dw += cw_v3<CW>(c, is_a ? 3 : 9, ncs, slot);
             }
         }
     }
@@ -880,7 +903,7 @@ NT_DI void report_parent_f(const Ctx<EPB>& c) {
     }
 }
 // number of active contacts on body b in this iteration (constraint_inv_weight[b], xpbd/kernels.py:2287-2291)
-template <int EPB>
+template <int EPB, class CW = CwLds>
 NT_DI float report_body_contact_count(const Ctx<EPB>& c, int b) {
     const nt_model& m = c.a.m;
     const int cpp = m.cpp, ncs = m.np * cpp;
@@ -890,31 +913,31 @@ NT_DI float report_body_contact_count(const Ctx<EPB>& c, int b) {
         int p = code >> 1, side = code & 1;
         for (int k = 0; k < cpp; ++k) {
             int slot = p * cpp + k;
-            bool is_a = (side == 0) == (c.l(c.L.cw, 14, ncs, slot) != 0.0f);
-            if (c.l(c.L.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) n += 1.0f;
+            bool is_a = (side == 0) == (CW::at(c, 14, ncs, slot) != 0.0f);
+            if (CW::at(c, is_a ? 12 : 13, ncs, slot) != 0.0f) n += 1.0f;
         }
     }
     return n;
 }
 // contact_impulse[slot] (+)= (lin_delta_a, ang_delta_a) * weight   (accumulate_weighted_contact_impulse)
-template <int EPB>
+template <int EPB, class CW = CwLds>
 NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
     if (!c.valid) return;
     const nt_model& m = c.a.m;
     const int cpp = m.cpp, ncs = m.np * cpp;
     float* I = c.a.rep.contact_impulse;
     for (int slot = c.slot; slot < ncs; slot += c.nslot) {
-        float has_a = c.l(c.L.cw, 12, ncs, slot), has_b = c.l(c.L.cw, 13, ncs, slot);
+        float has_a = CW::at(c, 12, ncs, slot), has_b = CW::at(c, 13, ncs, slot);
         vec3 lin, ang;
         if (has_a != 0.0f || has_b != 0.0f) {
             float weight = 1.0f;
             if (c.a.p.rigid_contact_con_weighting) {
                 const int p = slot / cpp;
                 int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
-                if (c.l(c.L.cw, 14, ncs, slot) == 0.0f) { int t = sa; sa = sb; sb = t; }
+                if (CW::at(c, 14, ncs, slot) == 0.0f) { int t = sa; sa = sb; sb = t; }
                 int body_a = c.T.shape_body[sa], body_b = c.T.shape_body[sb];
-                float n_a = body_a >= 0 ? report_body_contact_count(c, body_a) : 0.0f;
-                float n_b = body_b >= 0 ? report_body_contact_count(c, body_b) : 0.0f;
+                float n_a = body_a >= 0 ? report_body_contact_count<EPB, CW>(c, body_a) : 0.0f;
+                float n_b = body_b >= 0 ? report_body_contact_count<EPB, CW>(c, body_b) : 0.0f;
                 float n_sum = n_a + n_b;
                 if (n_sum > 0.0f) {
                     if (n_a == 0.0f) weight = 1.0f / n_b;
@@ -922,8 +945,8 @@ NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
                     else weight = 2.0f / n_sum;
                 }
             }
-            lin = c.lv3(c.L.cw, 0, ncs, slot) * weight;
-            ang = c.lv3(c.L.cw, 3, ncs, slot) * weight;
+            lin = cw_v3<CW>(c, 0, ncs, slot) * weight;
+            ang = cw_v3<CW>(c, 3, ncs, slot) * weight;
         }
         if (first) {
             I[c.g(0, ncs, slot)] = lin.x; I[c.g(1, ncs, slot)] = lin.y; I[c.g(2, ncs, slot)] = lin.z;
@@ -987,7 +1010,7 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
 }
 
 // SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
-template <int EPB, bool FUSED>
+template <int EPB, bool FUSED, class CW = CwLds>
 NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
     const int skip = c.a.debug_skip;
@@ -1007,11 +1030,11 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
     for (int it = 0; it < c.a.p.iterations; ++it) {
         if (c.a.has_contacts) {
-            if (!(skip & 4)) phase_contacts<EPB, FUSED>(c);
+            if (!(skip & 4)) phase_contacts<EPB, FUSED, CW>(c);
             __syncthreads();
             NT_TICK(5);
-            if (rep_contacts) report_contact_iteration(c, it == 0);
-            if (!(skip & 16)) phase_apply<EPB, true>(c);
+            if (rep_contacts) report_contact_iteration<EPB, CW>(c, it == 0);
+            if (!(skip & 16)) phase_apply<EPB, true, CW>(c);
             __syncthreads();
             NT_TICK(6);
         }
@@ -1027,11 +1050,11 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
     if (restitution) {  // solver_xpbd.py:784-858
         if (c.valid)
-            for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) restitution_item(c, s);
+            for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) restitution_item<EPB, CW>(c, s);
         __syncthreads();
         if (c.valid)
             for (int b = c.slot; b < m.nb; b += c.nslot)
-                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item(c, b);
+                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item<EPB, CW>(c, b);
         __syncthreads();
     }
     if (!FUSED && c.a.s_out.body_parent_f) {
@@ -1041,36 +1064,37 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
 }
 
-template <int EPB, bool CVX>
+template <int EPB, bool CVX, bool BIG = false>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds);
+    Ctx<EPB> c(a, lds, -1, BIG);
     load_state(c, a.s_in);
     load_params(c, false);
     __syncthreads();
     do_collide<EPB, CVX>(c, true);
 }
 
-template <int EPB>
+template <int EPB, bool BIG = false>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds);
+    Ctx<EPB> c(a, lds, -1, BIG);
     load_state(c, a.s_in);
     load_params(c, true);
     __syncthreads();
     phase_body_derived(c);
     __syncthreads();
-    do_xpbd_step<EPB, false>(c, false);
+    if constexpr (BIG) do_xpbd_step<EPB, false, CwHbm>(c, false);
+    else do_xpbd_step<EPB, false>(c, false);
     store_state(c, a.s_out);
 }
 
 // substeps x { clear_forces; collide; step; swap } with state and parameters resident in LDS across substeps.
 // Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
 // pointer swap); body_f of both states is zeroed as clear_forces would leave it.
-template <int EPB, bool CVX>
+template <int EPB, bool CVX, bool BIG = false>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds);
+    Ctx<EPB> c(a, lds, -1, BIG);
     const int nb = a.m.nb;
     load_state(c, a.s_in);
     load_params(c, true);
@@ -1085,7 +1109,8 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArg
     NT_TICK(0);
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(c, s == a.substeps - 1);
-        do_xpbd_step<EPB, true>(c, true);
+        if constexpr (BIG) do_xpbd_step<EPB, true, CwHbm>(c, true);
+        else do_xpbd_step<EPB, true>(c, true);
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
     NT_TICK(9);

@@ -304,6 +304,16 @@ def pack_param_arrays(model, t) -> dict:
     return new
 
 
+def choose_contact_scratch(lib, desc) -> None:
+    """Pair-heavy scenes: when the per-contact solver records do not fit the CU's LDS even with one environment per
+    workgroup, keep them in HBM (nt_model.contact_scratch_in_hbm; Contacts then allocates nt_contacts.cw)."""
+    desc.contact_scratch_in_hbm = 0
+    if lib.nt_pick_envs_per_block(C.byref(desc), 0) == 0:
+        desc.contact_scratch_in_hbm = 1
+        if lib.nt_pick_envs_per_block(C.byref(desc), 0) == 0:
+            desc.contact_scratch_in_hbm = 0  # does not fit either way: the launches report NT_ERR_UNSUPPORTED
+
+
 class DeviceModel:
     """Device-resident env-major SoA copy of a Model + the nt_model descriptor passed across the C ABI."""
 
@@ -352,6 +362,7 @@ class DeviceModel:
             setattr(d, k, v.data_ptr())
         for k, v in self.mesh_tables.items():
             setattr(d, k, v.data_ptr())
+        choose_contact_scratch(self.lib, d)
         self.desc = d
 
     def upload_params(self, model: Model):

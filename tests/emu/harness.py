@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 from newton_amd import _lib as L  # noqa: E402  (struct layouts + signatures only; the product library is NOT loaded)
-from newton_amd.model import pack_param_arrays  # noqa: E402
+from newton_amd.model import choose_contact_scratch, pack_param_arrays  # noqa: E402
 
 _emu = None
 
@@ -72,6 +72,7 @@ class EmuModel:
             self.keep[k] = f32(v)
         for k, v in self.keep.items():
             setattr(d, k, _ptr(v))
+        choose_contact_scratch(lib(), d)
         self.desc = d
 
     # env-major SoA <-> Newton's flat AoS
@@ -138,12 +139,15 @@ class EmuContacts:
         self.env_count = np.zeros(t.env_stride, dtype=np.int32)
         self.pair_hit = np.zeros((max(t.np, 1), t.env_stride), dtype=np.uint8)
         self.scan = np.zeros(4 * (t.env_stride + 1), dtype=np.int32)
+        self.cw = np.zeros((15, ns, t.env_stride), dtype=np.float32) if em.desc.contact_scratch_in_hbm else None
         self.rigid_contact_max = t.env_count * t.np * t.cpp
 
     def desc(self):
         d = L.nt_contacts()
         d.shape0, d.shape1, d.data = _ptr(self.shape0), _ptr(self.shape1), _ptr(self.data)
         d.env_count, d.pair_hit = _ptr(self.env_count), _ptr(self.pair_hit)
+        if self.cw is not None:
+            d.cw = _ptr(self.cw)
         return d
 
     def export(self):

@@ -211,3 +211,27 @@ def joint_zoo_scene(world_count: int, device=None, seed: int | None = 0, free_ro
         bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
         model.body_q, model.body_qd = bq, bqd
     return model
+
+
+def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2):
+    """Config C5 without the SDF / hydroelastic contact models: `n_hulls` random convex hulls (16-32 vertices, radius
+    U(0.03, 0.06)) dropped into a five-wall bin (ground plane + four static boxes); every hull pair and every hull-wall pair
+    is a candidate, so one environment has n(n-1)/2 + 5n pairs (2 336 for 64 hulls) and its per-contact solver records no
+    longer fit LDS (nt_model.contact_scratch_in_hbm)."""
+    rng = np.random.default_rng(seed)
+    env = nt.ModelBuilder()
+    side = 0.07 * np.ceil(np.sqrt(n_hulls))
+    for _ in range(n_hulls):
+        pts = rng.normal(size=(int(rng.integers(16, 33)), 3))
+        pts *= rng.uniform(0.03, 0.06) / np.linalg.norm(pts, axis=1).max()
+        b = env.add_body(xform=[*rng.uniform(-0.5 * side, 0.5 * side, size=2), rng.uniform(0.05, 0.5),
+                                *nt._np_math.quat_rpy(*rng.uniform(-1.0, 1.0, size=3))])
+        env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(pts))
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    scene.add_ground_plane()
+    w = 0.5 * side + 0.1
+    for sx, sy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+        scene.add_shape_box(-1, xform=[w * sx, w * sy, 0.3, 0.0, 0.0, 0.0, 1.0], hx=0.03 if sx else w + 0.03,
+                            hy=0.03 if sy else w + 0.03, hz=0.3)
+    return scene.finalize(device=device)

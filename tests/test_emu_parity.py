@@ -276,3 +276,41 @@ def test_emulated_library_is_test_only():
         for f in files:
             if f.endswith(".py"):
                 assert "libnewton_emu" not in open(os.path.join(dirpath, f)).read(), f
+
+
+@pytest.mark.parametrize("n_hulls,n_env", [(40, 3), (64, 1)])
+def test_pair_heavy_scene_keeps_contact_records_in_hbm(H, n_hulls, n_env):
+    """Config C5 without SDF / hydroelastic: hulls in a five-wall bin, n(n-1)/2 + 5n candidate pairs per environment (2 336
+    for 64 hulls).  The per-contact solver records no longer fit LDS, so nt_model.contact_scratch_in_hbm is chosen and the
+    one-environment-per-workgroup kernels keep them in nt_contacts.cw."""
+    from oracle_bridge import Oracle, OracleState
+    from scenes import hull_bin_scene
+
+    model = hull_bin_scene(n_env, n_hulls)
+    em = H.EmuModel(model)
+    assert em.desc.contact_scratch_in_hbm == 1 and model.env.np == n_hulls * (n_hulls - 1) // 2 + 5 * n_hulls
+    s0, s1, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    for step in range(2):
+        s0.body_f[:] = 0
+        H.collide(em, s0, ct)
+        H.xpbd_step(em, s0, s1, ctrl, ct, 1.0 / 600.0, enable_restitution=(step == 1))
+        os0.body_f[:] = 0
+        o.collide(os0.body_q, oc)
+        o.xpbd_step(os0, os1, o.control(), oc, 1.0 / 600.0, enable_restitution=(step == 1))
+        assert _same_contacts(ct, oc, TOL if step == 0 else 2e-5) > 5 * n_hulls
+        s0, s1, os0, os1 = s1, s0, os1, os0
+    assert _close(s0.aos("body_q"), os0.body_q, 1e-5) and _close(s0.aos("body_qd"), os0.body_qd, 2e-4)
+    if n_env > 1:  # fused rollout == launch-by-launch loop, bitwise
+        out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1.0 / 600.0, 3)
+        a, b = H.EmuState(em), H.EmuState(em)
+        for _ in range(3):
+            a.body_f[:] = 0
+            H.collide(em, a, ct)
+            H.xpbd_step(em, a, b, ctrl, ct, 1.0 / 600.0)
+            a, b = b, a
+        assert np.array_equal(out.body_q, a.body_q) and np.array_equal(out.body_qd, a.body_qd)
+    # the other solvers refuse this mode instead of overflowing LDS
+    with pytest.raises(RuntimeError):
+        H.semi_implicit_step(em, s0, s1, ctrl, ct, 1e-4)
