@@ -26,6 +26,39 @@ def _qinv(q):
     return q * np.array([-1.0, -1.0, -1.0, 1.0])
 
 
+def _quat_axis_angle(axis, angle):
+    h = 0.5 * np.asarray(angle)[..., None]
+    return np.concatenate([axis * np.sin(h), np.cos(h)], axis=-1)
+
+
+def _quat_from_cols(c0, c1, c2):
+    """wp.quat_from_matrix(wp.matrix_from_cols(c0, c1, c2)) for a batch of (near-)orthonormal column triples."""
+    m = np.stack([c0, c1, c2], axis=-1)  # [..., row, col]
+    out = np.zeros(m.shape[:-2] + (4,))
+    for idx in np.ndindex(m.shape[:-2]):
+        a = m[idx]
+        tr = a[0, 0] + a[1, 1] + a[2, 2]
+        if tr >= 0.0:
+            h = np.sqrt(tr + 1.0)
+            w = 0.5 * h
+            h = 0.5 / h
+            x, y, z = (a[2, 1] - a[1, 2]) * h, (a[0, 2] - a[2, 0]) * h, (a[1, 0] - a[0, 1]) * h
+        else:
+            k = int(np.argmax(np.diag(a)))
+            i, j = (k + 1) % 3, (k + 2) % 3
+            h = np.sqrt((a[k, k] - (a[i, i] + a[j, j])) + 1.0)
+            v = [0.0, 0.0, 0.0]
+            v[k] = 0.5 * h
+            h = 0.5 / h
+            v[i] = (a[k, i] + a[i, k]) * h
+            v[j] = (a[j, k] + a[k, j]) * h
+            w = (a[j, i] - a[i, j]) * h
+            x, y, z = v
+        q = np.array([x, y, z, w])
+        out[idx] = q / np.linalg.norm(q)
+    return out
+
+
 def _xmul(a, b):
     return np.concatenate([_qrot(a[..., 3:], b[..., :3]) + a[..., :3], _qmul(a[..., 3:], b[..., 3:])], axis=-1)
 
@@ -88,8 +121,27 @@ def eval_fk_numpy(model, joint_q, joint_qd):
                 X_j[:, 3:6] = ax * np.sin(h)
                 X_j[:, 6:7] = np.cos(h)
                 v_ang = ax * jqd[:, qds + lin:qds + lin + 1]
-            elif ang > 1:
-                raise NotImplementedError("eval_fk: D6 joints with >1 angular axis are not supported yet")
+            elif ang == 2:  # compute_2d_rotational_dofs (articulation.py:36-83)
+                ax0, ax1 = axis_all[:, qds + lin], axis_all[:, qds + lin + 1]
+                q_off = _quat_from_cols(ax0, ax1, np.cross(ax0, ax1))
+                a0 = _qrot(q_off, np.broadcast_to([1.0, 0.0, 0.0], (E, 3)))
+                local_1 = _qrot(q_off, np.broadcast_to([0.0, 1.0, 0.0], (E, 3)))
+                q_0 = _quat_axis_angle(a0, jq[:, qs + lin])
+                a1 = _qrot(q_0, local_1)
+                q_1 = _quat_axis_angle(a1, jq[:, qs + lin + 1])
+                X_j[:, 3:7] = _qmul(q_1, q_0)
+                v_ang = a0 * jqd[:, qds + lin:qds + lin + 1] + a1 * jqd[:, qds + lin + 1:qds + lin + 2]
+            elif ang == 3:  # compute_3d_rotational_dofs (articulation.py:127-178)
+                ax0, ax1, ax2 = (axis_all[:, qds + lin + k] for k in range(3))
+                q_0 = _quat_axis_angle(ax0, jq[:, qs + lin])
+                a1 = _qrot(q_0, ax1)
+                q_1 = _quat_axis_angle(a1, jq[:, qs + lin + 1])
+                q_10 = _qmul(q_1, q_0)
+                a2 = _qrot(q_10, ax2)
+                q_2 = _quat_axis_angle(a2, jq[:, qs + lin + 2])
+                X_j[:, 3:7] = _qmul(q_2, q_10)
+                v_ang = (ax0 * jqd[:, qds + lin:qds + lin + 1] + a1 * jqd[:, qds + lin + 1:qds + lin + 2]
+                         + a2 * jqd[:, qds + lin + 2:qds + lin + 3])
         elif jt == JointType.FIXED:
             pass
         else:

@@ -121,8 +121,32 @@ NT_DI spatial fs_mul(const mat66& A, const spatial& v) {
     return spatial(vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]));
 }
 
+// rotation and transported angular axes of a D6 joint with two or three angular axes (compute_2d_rotational_dofs /
+// compute_3d_rotational_dofs, newton/_src/sim/articulation.py:36-83,127-178); only newton.eval_fk needs it: the
+// Featherstone solver rejects such joints
+NT_DI quat d6_multi_angular(int ang, vec3 axis_0, vec3 axis_1, vec3 axis_2, float q0, float q1, float q2, vec3& a0, vec3& a1,
+                            vec3& a2) {
+    if (ang == 2) {
+        quat q_off = quat_from_matrix(matrix_from_cols(axis_0, axis_1, cross(axis_0, axis_1)));
+        vec3 local_0 = quat_rotate(q_off, vec3(1.0f, 0.0f, 0.0f)), local_1 = quat_rotate(q_off, vec3(0.0f, 1.0f, 0.0f));
+        a0 = local_0;
+        quat q_0 = quat_from_axis_angle(a0, q0);
+        a1 = quat_rotate(q_0, local_1);
+        a2 = vec3();
+        quat q_1 = quat_from_axis_angle(a1, q1);
+        return q_1 * q_0;
+    }
+    a0 = axis_0;
+    quat q_0 = quat_from_axis_angle(a0, q0);
+    a1 = quat_rotate(q_0, axis_1);
+    quat q_1 = quat_from_axis_angle(a1, q1);
+    a2 = quat_rotate(q_1 * q_0, axis_2);
+    quat q_2 = quat_from_axis_angle(a2, q2);
+    return q_2 * q_1 * q_0;
+}
+
 // jcalc_transform (kernels.py:142-239)
-template <int EPB>
+template <int EPB, bool MULTI_ANGULAR = false>
 NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int lin, int ang, int q_off, int q_start) {
     const Ctx<EPB>& c = f.c;
     if (type == JT_PRISMATIC) return xform(c.dof_axis(qd_start) * f.f(q_off, q_start), quat_identity());
@@ -139,6 +163,14 @@ NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int 
         if (lin > 1) pos += c.dof_axis(qd_start + 1) * f.f(q_off, q_start + 1);
         if (lin > 2) pos += c.dof_axis(qd_start + 2) * f.f(q_off, q_start + 2);
         if (ang == 1) rot = quat_from_axis_angle(c.dof_axis(qd_start + lin), f.f(q_off, q_start + lin));
+        if constexpr (MULTI_ANGULAR) {
+            if (ang >= 2) {
+                vec3 a0, a1, a2;
+                rot = d6_multi_angular(ang, c.dof_axis(qd_start + lin), c.dof_axis(qd_start + lin + 1),
+                                       ang == 3 ? c.dof_axis(qd_start + lin + 2) : vec3(), f.f(q_off, q_start + lin),
+                                       f.f(q_off, q_start + lin + 1), ang == 3 ? f.f(q_off, q_start + lin + 2) : 0.0f, a0, a1, a2);
+            }
+        }
         return xform(pos, rot);
     }
     return xform();
@@ -146,10 +178,10 @@ NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int 
 
 // jcalc_transform for every joint at once (the sin / cos of the joint angles are the expensive part of FK and do not
 // depend on the tree level); parked in the v_s / a_s rows, which are dead during both FK passes
-template <int EPB>
+template <int EPB, bool MULTI_ANGULAR = false>
 NT_DI void fs_joint_xform_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
-    xform X_j = fs_joint_transform(f, c.T.joint_type[j], c.T.joint_qd_start[j], c.T.joint_lin_count[j], c.T.joint_ang_count[j],
+    xform X_j = fs_joint_transform<EPB, MULTI_ANGULAR>(f, c.T.joint_type[j], c.T.joint_qd_start[j], c.T.joint_lin_count[j], c.T.joint_ang_count[j],
                                    f.F.jq, c.T.joint_q_start[j]);
     c.st_lxf(f.F.vs, c.a.m.nj, j, X_j);
 }
@@ -721,6 +753,17 @@ NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
         for (int k = 0; k < 3; ++k)
             if (lin > k) vel_v += c.dof_axis(qs + k) * qd(qs + k);
         if (ang == 1) vel_w = qd(qs + lin) * c.dof_axis(qs + lin);
+        if constexpr (PUBLIC) {
+            if (ang >= 2) {
+                const int cs = c.T.joint_q_start[j];
+                vec3 a0, a1, a2;
+                d6_multi_angular(ang, c.dof_axis(qs + lin), c.dof_axis(qs + lin + 1), ang == 3 ? c.dof_axis(qs + lin + 2) : vec3(),
+                                 f.f(f.F.jq, cs + lin), f.f(f.F.jq, cs + lin + 1), ang == 3 ? f.f(f.F.jq, cs + lin + 2) : 0.0f, a0,
+                                 a1, a2);
+                vel_w = a0 * qd(qs + lin) + a1 * qd(qs + lin + 1);
+                if (ang == 3) vel_w = vel_w + a2 * qd(qs + lin + 2);
+            }
+        }
         v_j = spatial(vel_v, vel_w);
     }
     xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
@@ -1039,7 +1082,7 @@ __global__ void __launch_bounds__(256) eval_fk_kernel(KArgs a, const float* join
     }
     __syncthreads();
     if (c.valid)
-        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
+        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item<EPB, true>(f, j);
     __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid)

@@ -119,6 +119,47 @@ NT_DI mat33 quat_to_matrix(quat q) {
     return matrix_from_cols(c0, c1, c2);
 }
 
+// wp.quat_from_matrix (trace / largest-diagonal branches, normalised result)
+NT_DI quat quat_from_matrix(const mat33& m) {
+    const float tr = m.m00 + m.m11 + m.m22;
+    float x, y, z, w, h;
+    if (tr >= 0.0f) {
+        h = sqrtf(tr + 1.0f);
+        w = 0.5f * h;
+        h = 0.5f / h;
+        x = (m.m21 - m.m12) * h;
+        y = (m.m02 - m.m20) * h;
+        z = (m.m10 - m.m01) * h;
+    } else {
+        int max_diag = 0;
+        if (m.m11 > m.m00) max_diag = 1;
+        if (m.m22 > (max_diag == 0 ? m.m00 : m.m11)) max_diag = 2;
+        if (max_diag == 0) {
+            h = sqrtf((m.m00 - (m.m11 + m.m22)) + 1.0f);
+            x = 0.5f * h;
+            h = 0.5f / h;
+            y = (m.m01 + m.m10) * h;
+            z = (m.m20 + m.m02) * h;
+            w = (m.m21 - m.m12) * h;
+        } else if (max_diag == 1) {
+            h = sqrtf((m.m11 - (m.m22 + m.m00)) + 1.0f);
+            y = 0.5f * h;
+            h = 0.5f / h;
+            z = (m.m12 + m.m21) * h;
+            x = (m.m01 + m.m10) * h;
+            w = (m.m02 - m.m20) * h;
+        } else {
+            h = sqrtf((m.m22 - (m.m00 + m.m11)) + 1.0f);
+            z = 0.5f * h;
+            h = 0.5f / h;
+            x = (m.m20 + m.m02) * h;
+            y = (m.m12 + m.m21) * h;
+            w = (m.m10 - m.m01) * h;
+        }
+    }
+    return normalize(quat(x, y, z, w));
+}
+
 struct xform {
     vec3 p;
     quat q;

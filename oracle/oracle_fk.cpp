@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE ONLY -- CPU oracle: forward kinematics.
 // Literal restatement of eval_single_articulation_fk / eval_articulation_fk
-//   newton/_src/sim/articulation.py:14-33,236-470 (PRISMATIC/REVOLUTE/BALL/FREE/DISTANCE/FIXED; D6 with <=1 angular axis)
+//   newton/_src/sim/articulation.py:14-33,236-470 (PRISMATIC/REVOLUTE/BALL/FREE/DISTANCE/FIXED; D6 with up to three angular axes)
 #include "oracle_common.h"
 using namespace orc;
 
@@ -61,6 +61,27 @@ extern "C" void o_eval_fk(const o_model* m, const float* joint_q, const float* j
                     vec3 axis = ld3(m->joint_axis, iqd);
                     rot = quat_from_axis_angle(axis, joint_q[iq]);
                     vel_w = joint_qd[iqd] * axis;
+                }
+                if (ang_axis_count == 2) {  // compute_2d_rotational_dofs (articulation.py:36-83)
+                    vec3 axis_0 = ld3(m->joint_axis, iqd), axis_1 = ld3(m->joint_axis, iqd + 1);
+                    quat q_off = quat_from_matrix(matrix_from_cols(axis_0, axis_1, cross(axis_0, axis_1)));
+                    vec3 local_0 = quat_rotate(q_off, vec3(1.0f, 0.0f, 0.0f)), local_1 = quat_rotate(q_off, vec3(0.0f, 1.0f, 0.0f));
+                    vec3 a0 = local_0;
+                    quat q_0 = quat_from_axis_angle(a0, joint_q[iq]);
+                    vec3 a1 = quat_rotate(q_0, local_1);
+                    quat q_1 = quat_from_axis_angle(a1, joint_q[iq + 1]);
+                    rot = q_1 * q_0;
+                    vel_w = a0 * joint_qd[iqd] + a1 * joint_qd[iqd + 1];
+                }
+                if (ang_axis_count == 3) {  // compute_3d_rotational_dofs (articulation.py:127-178)
+                    vec3 axis_0 = ld3(m->joint_axis, iqd), axis_1 = ld3(m->joint_axis, iqd + 1), axis_2 = ld3(m->joint_axis, iqd + 2);
+                    quat q_0 = quat_from_axis_angle(axis_0, joint_q[iq]);
+                    vec3 axis_1_w = quat_rotate(q_0, axis_1);
+                    quat q_1 = quat_from_axis_angle(axis_1_w, joint_q[iq + 1]);
+                    vec3 axis_2_w = quat_rotate(q_1 * q_0, axis_2);
+                    quat q_2 = quat_from_axis_angle(axis_2_w, joint_q[iq + 2]);
+                    rot = q_2 * q_1 * q_0;
+                    vel_w = axis_0 * joint_qd[iqd] + axis_1_w * joint_qd[iqd + 1] + axis_2_w * joint_qd[iqd + 2];
                 }
                 X_j = transform(pos, rot);
                 v_j = spatial(vel_v, vel_w);

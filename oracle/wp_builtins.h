@@ -152,6 +152,46 @@ inline mat33 quat_to_matrix(quat q) {
     vec3 c2 = quat_rotate(q, vec3(0.f, 0.f, 1.f));
     return matrix_from_cols(c0, c1, c2);
 }
+// wp.quat_from_matrix (warp/native/quat.h, un-vendored): trace / largest-diagonal branches, normalised result
+inline quat quat_from_matrix(const mat33& m) {
+    const float tr = m(0, 0) + m(1, 1) + m(2, 2);
+    float x, y, z, w, h = 0.0f;
+    if (tr >= 0.0f) {
+        h = std::sqrt(tr + 1.0f);
+        w = 0.5f * h;
+        h = 0.5f / h;
+        x = (m(2, 1) - m(1, 2)) * h;
+        y = (m(0, 2) - m(2, 0)) * h;
+        z = (m(1, 0) - m(0, 1)) * h;
+    } else {
+        int max_diag = 0;
+        if (m(1, 1) > m(0, 0)) max_diag = 1;
+        if (m(2, 2) > m(max_diag, max_diag)) max_diag = 2;
+        if (max_diag == 0) {
+            h = std::sqrt((m(0, 0) - (m(1, 1) + m(2, 2))) + 1.0f);
+            x = 0.5f * h;
+            h = 0.5f / h;
+            y = (m(0, 1) + m(1, 0)) * h;
+            z = (m(2, 0) + m(0, 2)) * h;
+            w = (m(2, 1) - m(1, 2)) * h;
+        } else if (max_diag == 1) {
+            h = std::sqrt((m(1, 1) - (m(2, 2) + m(0, 0))) + 1.0f);
+            y = 0.5f * h;
+            h = 0.5f / h;
+            z = (m(1, 2) + m(2, 1)) * h;
+            x = (m(0, 1) + m(1, 0)) * h;
+            w = (m(0, 2) - m(2, 0)) * h;
+        } else {
+            h = std::sqrt((m(2, 2) - (m(0, 0) + m(1, 1))) + 1.0f);
+            z = 0.5f * h;
+            h = 0.5f / h;
+            x = (m(2, 0) + m(0, 2)) * h;
+            y = (m(1, 2) + m(2, 1)) * h;
+            w = (m(1, 0) - m(0, 1)) * h;
+        }
+    }
+    return normalize(quat(x, y, z, w));
+}
 
 struct transform {
     vec3 p;

@@ -91,3 +91,50 @@ def test_planar_arm_closed_form_hip():
 @pytest.mark.parametrize("prismatic", [False, True])
 def test_descendant_velocity_matches_finite_difference_hip(prismatic):
     _check_fd("hip", prismatic, device="cuda:0")
+
+
+def test_d6_with_two_and_three_angular_axes_fk(oracle_lib):
+    """D6 joints with several angular axes compose intrinsic rotations about transported axes (compute_2d/3d_rotational_dofs,
+    newton/_src/sim/articulation.py:36-83,127-178): for axes X, Y, Z the joint rotation is scipy's intrinsic 'XYZ' Euler
+    rotation; body_qd is the time derivative of the pose (finite differences); host FK == oracle FK."""
+    from scipy.spatial.transform import Rotation
+
+    import newton_amd as nt
+    from newton_amd import _np_math as nm
+    from oracle_bridge import Oracle
+
+    D = nt.ModelBuilder.JointDofConfig
+    rng = np.random.default_rng(5)
+    for ang_axes in ([0, 1], [2, 0], [0, 1, 2], [0, 2, 1]):
+        b = nt.ModelBuilder()
+        l0 = b.add_link()
+        b.add_shape_box(l0, hx=0.1, hy=0.1, hz=0.1)
+        l1 = b.add_link()
+        b.add_shape_box(l1, hx=0.1, hy=0.1, hz=0.1)
+        j0 = b.add_joint_fixed(-1, l0, parent_xform=[0.0, 0.0, 1.0, *nm.quat_rpy(0.3, 0.2, 0.1)])
+        j1 = b.add_joint_d6(l0, l1, linear_axes=[D(axis=0)], angular_axes=[D(axis=a) for a in ang_axes],
+                            parent_xform=[0.2, 0.0, 0.0, *nm.quat_rpy(0.1, -0.3, 0.2)], child_xform=[-0.1, 0.05, 0.0, 0.0, 0.0, 0.0, 1.0])
+        b.add_articulation([j0, j1])
+        model = b.finalize()
+        n = len(ang_axes)
+        q = rng.uniform(-0.8, 0.8, size=1 + n).astype(np.float32)
+        qd = rng.normal(size=1 + n).astype(np.float32)
+        bq, bqd = nt.articulation.eval_fk_numpy(model, q, qd)
+        oq, oqd = Oracle(model).eval_fk(q, qd)
+        assert np.max(np.abs(bq - oq)) <= 2e-6 and np.max(np.abs(bqd - oqd)) <= 2e-6
+        # joint rotation == intrinsic Euler rotation about the listed axes
+        X_wp = nm.transform_mul(bq[0].astype(np.float64), np.asarray(model.joint_X_p)[1].astype(np.float64))
+        X_wc = nm.transform_mul(bq[1].astype(np.float64), np.asarray(model.joint_X_c)[1].astype(np.float64))
+        rel = nm.transform_mul(nm.transform_inverse(X_wp), X_wc)
+        want = Rotation.from_euler("".join("XYZ"[a] for a in ang_axes), q[1:].astype(np.float64)).as_quat()
+        assert min(np.abs(rel[3:] - want).max(), np.abs(rel[3:] + want).max()) <= 1e-6
+        assert np.allclose(rel[:3], [q[0], 0.0, 0.0], atol=1e-6)
+        # velocities: finite difference of the child's COM position and orientation along qd
+        h = 1e-3
+        bq2, _ = nt.articulation.eval_fk_numpy(model, (q + h * qd).astype(np.float32), qd)
+        com = np.asarray(model.body_com)[1].astype(np.float64)
+        c0 = nm.transform_point(bq[1].astype(np.float64), com)
+        c1 = nm.transform_point(bq2[1].astype(np.float64), com)
+        assert np.allclose((c1 - c0) / h, bqd[1, :3], atol=5e-3)
+        dq = nm.quat_mul(bq2[1, 3:].astype(np.float64), nm.quat_inverse(bq[1, 3:].astype(np.float64)))
+        assert np.allclose(2.0 * dq[:3] / h, bqd[1, 3:], atol=5e-3)
