@@ -160,6 +160,25 @@ NT_DI quat quat_from_matrix(const mat33& m) {
     return normalize(quat(x, y, z, w));
 }
 
+// newton.math.quat_decompose (math/spatial.py:150-176): wrapped XYZ Euler coordinates (a0, a1, a2) with
+// q = Rx(a0) Ry(a1) Rz(a2), the intrinsic chain compute_3d_rotational_dofs composes (the reference: wp.quat_to_euler(q, 2, 1, 0))
+NT_DI vec3 quat_decompose(quat q) {
+    mat33 R = quat_to_matrix(q);
+    float sb = clampf(R.m02, -1.0f, 1.0f);
+    float a, b = asinf(sb), c;
+    if (fabsf(sb) < 0.9999999f) {
+        a = atan2f(-R.m12, R.m22);
+        c = atan2f(-R.m01, R.m00);
+    } else {
+        a = atan2f(R.m21, R.m11);
+        c = 0.0f;
+    }
+    const float pi = 3.14159265358979323846f;
+    if (a >= pi) a -= 2.0f * pi;
+    if (c >= pi) c -= 2.0f * pi;
+    return vec3(a, b, c);
+}
+
 struct xform {
     vec3 p;
     quat q;

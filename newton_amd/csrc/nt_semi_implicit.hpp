@@ -132,7 +132,27 @@ NT_DI void si_joint_item(const Ctx<EPB>& c, const int j) {
                     vec3 swing_err = cross(axis_p, axis_c);
                     t_total += swing_err * ke_att + (w_err - qd * axis_p) * kd_att * ads;
                 }
-                // 2 / 3 angular axes need wp.quat_to_euler: rejected on the host (NotImplementedError)
+                if (ang >= 2) {  // kernels_body.py:371-515: decompose the relative rotation, transport the axes like FK
+                    int i_0 = lin + qd_start, i_0_q = lin + tq_start;
+                    vec3 angles = quat_decompose(r_err);  // r_err = inverse(q_p) * q_c
+                    vec3 orig_axis_0 = c.dof_axis(i_0), orig_axis_1 = c.dof_axis(i_0 + 1);
+                    vec3 orig_axis_2 = ang == 3 ? c.dof_axis(i_0 + 2) : cross(orig_axis_0, orig_axis_1);
+                    vec3 axis_0 = orig_axis_0;
+                    quat q_0 = quat_from_axis_angle(axis_0, angles.x);
+                    vec3 axis_1 = quat_rotate(q_0, orig_axis_1);
+                    quat q_1 = quat_from_axis_angle(axis_1, angles.y);
+                    vec3 axis_2 = quat_rotate(q_1 * q_0, orig_axis_2);
+                    axis_0 = xform_vector(X_wp, axis_0);
+                    axis_1 = xform_vector(X_wp, axis_1);
+                    axis_2 = xform_vector(X_wp, axis_2);
+                    t_total += axis_0 * (-c.l(c.L.cf, 0, 1, i_0) - si_dof_force(c, i_0, i_0_q, angles.x, dot(axis_0, w_err)));
+                    t_total += axis_1 * (-c.l(c.L.cf, 0, 1, i_0 + 1) - si_dof_force(c, i_0 + 1, i_0_q + 1, angles.y, dot(axis_1, w_err)));
+                    if (ang == 3)
+                        t_total += axis_2 * (-c.l(c.L.cf, 0, 1, i_0 + 2) - si_dof_force(c, i_0 + 2, i_0_q + 2, angles.z, dot(axis_2, w_err)));
+                    else  // last axis (fixed)
+                        t_total += axis_2 * -si_joint_force(angles.z, dot(axis_2, w_err), 0.0f, 0.0f, ke_att, kd_att * ads, 0.0f, 0.0f,
+                                                            0.0f, 0.0f, 0.0f);
+                }
             }
         }
     }

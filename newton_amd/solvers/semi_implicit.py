@@ -10,10 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-import numpy as np
-
 from .. import _lib
-from ..enums import JointType
 from .solver import SolverBase
 
 
@@ -21,11 +18,6 @@ class SolverSemiImplicit(SolverBase):
     def __init__(self, model, *, angular_damping: float = 0.05, friction_smoothing: float = 1.0, joint_attach_ke: float = 1.0e4,
                  joint_attach_kd: float = 1.0e2, enable_tri_contact: bool = True, envs_per_block: int = 0):
         super().__init__(model)
-        t = model.env
-        d6 = (np.asarray(t.joint_type) == int(JointType.D6)) & (np.asarray(t.joint_ang_count) > 1)
-        if np.any(d6):
-            raise NotImplementedError("SolverSemiImplicit: D6 joints with 2 or 3 angular axes are not supported "
-                                      "(they need wp.quat_to_euler semantics, newton/_src/math/spatial.py:170)")
         self.angular_damping = angular_damping
         self.friction_smoothing = friction_smoothing
         self.joint_attach_ke = joint_attach_ke

@@ -8,7 +8,7 @@
 // (kernels_contact.py:537), wp.step -- PARITY UNPINNED (see wp_builtins.h).
 // wp.acos clamps its argument to [-1, 1] (Warp builtin semantics), which keeps the FIXED / PRISMATIC / BALL angular
 // error finite when a normalised quaternion's w drifts a few ulp above 1.
-// D6 joints with 2 or 3 angular axes need wp.quat_to_euler (math/spatial.py:170) and are not restated.
+// D6 joints with 2 or 3 angular axes decompose the relative rotation with quat_decompose (wp_builtins.h).
 #include <vector>
 
 #include "oracle_common.h"
@@ -162,7 +162,28 @@ static void eval_body_joints(const o_model* m, const o_control* c, const float* 
                 vec3 swing_err = cross(axis_p, axis_c);
                 t_total += swing_err * joint_attach_ke + (w_err - qd * axis_p) * joint_attach_kd * angular_damping_scale;
             }
-            // ang_axis_count 2 / 3: needs wp.quat_to_euler -- not restated
+            if (ang_axis_count == 2 || ang_axis_count == 3) {  // kernels_body.py:371-515
+                quat q_pc = quat_inverse(q_p) * q_c;
+                vec3 angles = quat_decompose(q_pc);
+                vec3 orig_axis_0 = ld3(m->joint_axis, i_0), orig_axis_1 = ld3(m->joint_axis, i_0 + 1);
+                vec3 orig_axis_2 = ang_axis_count == 3 ? ld3(m->joint_axis, i_0 + 2) : cross(orig_axis_0, orig_axis_1);
+                vec3 axis_0 = orig_axis_0;
+                quat q_0 = quat_from_axis_angle(axis_0, angles.x);
+                vec3 axis_1 = quat_rotate(q_0, orig_axis_1);
+                quat q_1 = quat_from_axis_angle(axis_1, angles.y);
+                vec3 axis_2 = quat_rotate(q_1 * q_0, orig_axis_2);
+                axis_0 = transform_vector(X_wp, axis_0);
+                axis_1 = transform_vector(X_wp, axis_1);
+                axis_2 = transform_vector(X_wp, axis_2);
+                t_total += axis_0 * (-joint_f[i_0] - dof_force(m, c, i_0, i_0_q, angles.x, dot(axis_0, w_err)));
+                t_total += axis_1 * (-joint_f[i_0 + 1] - dof_force(m, c, i_0 + 1, i_0_q + 1, angles.y, dot(axis_1, w_err)));
+                if (ang_axis_count == 3) {
+                    t_total += axis_2 * (-joint_f[i_0 + 2] - dof_force(m, c, i_0 + 2, i_0_q + 2, angles.z, dot(axis_2, w_err)));
+                } else {  // last axis (fixed): a stiff attachment spring
+                    t_total += axis_2 * -orc::joint_force(angles.z, dot(axis_2, w_err), 0.0f, 0.0f, joint_attach_ke,
+                                                          joint_attach_kd * angular_damping_scale, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
         }
         if (c_parent >= 0) adds(body_f, c_parent, spatial(f_total, t_total + cross(r_p, f_total)));
         subs(body_f, c_child, spatial(f_total, t_total + cross(r_c, f_total)));

@@ -152,6 +152,26 @@ inline mat33 quat_to_matrix(quat q) {
     vec3 c2 = quat_rotate(q, vec3(0.f, 0.f, 1.f));
     return matrix_from_cols(c0, c1, c2);
 }
+// newton.math.quat_decompose (math/spatial.py:150-176): wrapped XYZ Euler coordinates (a0, a1, a2) with
+// q = Rx(a0) * Ry(a1) * Rz(a2), i.e. the intrinsic X-Y'-Z'' chain that compute_3d_rotational_dofs composes.  The reference gets
+// them from wp.quat_to_euler(q, 2, 1, 0) (un-vendored Warp builtin, Bernardes & Viollet 2022); restated here through the
+// rotation matrix, same angles up to rounding away from the gimbal lock |a1| = pi/2.
+inline vec3 quat_decompose(quat q) {
+    mat33 R = quat_to_matrix(q);
+    float sb = clampf(R(0, 2), -1.0f, 1.0f);
+    float a, b = std::asin(sb), c;
+    if (std::fabs(sb) < 0.9999999f) {
+        a = std::atan2(-R(1, 2), R(2, 2));
+        c = std::atan2(-R(0, 1), R(0, 0));
+    } else {
+        a = std::atan2(R(2, 1), R(1, 1));
+        c = 0.0f;
+    }
+    const float pi = 3.14159265358979323846f;
+    if (a >= pi) a -= 2.0f * pi;
+    if (c >= pi) c -= 2.0f * pi;
+    return vec3(a, b, c);
+}
 // wp.quat_from_matrix (warp/native/quat.h, un-vendored): trace / largest-diagonal branches, normalised result
 inline quat quat_from_matrix(const mat33& m) {
     const float tr = m(0, 0) + m(1, 1) + m(2, 2);
