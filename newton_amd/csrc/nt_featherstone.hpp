@@ -122,8 +122,8 @@ NT_DI spatial fs_mul(const mat66& A, const spatial& v) {
 }
 
 // rotation and transported angular axes of a D6 joint with two or three angular axes (compute_2d_rotational_dofs /
-// compute_3d_rotational_dofs, newton/_src/sim/articulation.py:36-83,127-178); only newton.eval_fk needs it: the
-// Featherstone solver rejects such joints
+// compute_3d_rotational_dofs, newton/_src/sim/articulation.py:36-83,127-178); used by newton.eval_fk and by the
+// Featherstone passes (jcalc_transform / jcalc_motion, featherstone/kernels.py:186-232,266-335)
 NT_DI quat d6_multi_angular(int ang, vec3 axis_0, vec3 axis_1, vec3 axis_2, float q0, float q1, float q2, vec3& a0, vec3& a1,
                             vec3& a2) {
     if (ang == 2) {
@@ -146,7 +146,7 @@ NT_DI quat d6_multi_angular(int ang, vec3 axis_0, vec3 axis_1, vec3 axis_2, floa
 }
 
 // jcalc_transform (kernels.py:142-239)
-template <int EPB, bool MULTI_ANGULAR = false>
+template <int EPB>
 NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int lin, int ang, int q_off, int q_start) {
     const Ctx<EPB>& c = f.c;
     if (type == JT_PRISMATIC) return xform(c.dof_axis(qd_start) * f.f(q_off, q_start), quat_identity());
@@ -163,13 +163,11 @@ NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int 
         if (lin > 1) pos += c.dof_axis(qd_start + 1) * f.f(q_off, q_start + 1);
         if (lin > 2) pos += c.dof_axis(qd_start + 2) * f.f(q_off, q_start + 2);
         if (ang == 1) rot = quat_from_axis_angle(c.dof_axis(qd_start + lin), f.f(q_off, q_start + lin));
-        if constexpr (MULTI_ANGULAR) {
-            if (ang >= 2) {
-                vec3 a0, a1, a2;
-                rot = d6_multi_angular(ang, c.dof_axis(qd_start + lin), c.dof_axis(qd_start + lin + 1),
-                                       ang == 3 ? c.dof_axis(qd_start + lin + 2) : vec3(), f.f(q_off, q_start + lin),
-                                       f.f(q_off, q_start + lin + 1), ang == 3 ? f.f(q_off, q_start + lin + 2) : 0.0f, a0, a1, a2);
-            }
+        if (ang >= 2) {
+            vec3 a0, a1, a2;
+            rot = d6_multi_angular(ang, c.dof_axis(qd_start + lin), c.dof_axis(qd_start + lin + 1),
+                                   ang == 3 ? c.dof_axis(qd_start + lin + 2) : vec3(), f.f(q_off, q_start + lin),
+                                   f.f(q_off, q_start + lin + 1), ang == 3 ? f.f(q_off, q_start + lin + 2) : 0.0f, a0, a1, a2);
         }
         return xform(pos, rot);
     }
@@ -178,10 +176,10 @@ NT_DI xform fs_joint_transform(const FsCtx<EPB>& f, int type, int qd_start, int 
 
 // jcalc_transform for every joint at once (the sin / cos of the joint angles are the expensive part of FK and do not
 // depend on the tree level); parked in the v_s / a_s rows, which are dead during both FK passes
-template <int EPB, bool MULTI_ANGULAR = false>
+template <int EPB>
 NT_DI void fs_joint_xform_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
-    xform X_j = fs_joint_transform<EPB, MULTI_ANGULAR>(f, c.T.joint_type[j], c.T.joint_qd_start[j], c.T.joint_lin_count[j], c.T.joint_ang_count[j],
+    xform X_j = fs_joint_transform(f, c.T.joint_type[j], c.T.joint_qd_start[j], c.T.joint_lin_count[j], c.T.joint_ang_count[j],
                                    f.F.jq, c.T.joint_q_start[j]);
     c.st_lxf(f.F.vs, c.a.m.nj, j, X_j);
 }
@@ -320,7 +318,7 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
     if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
     xform X_sc(X_wpj.p - solve_origin, X_wpj.q);
 
-    spatial v_j_s;
+    spatial v_j_s, c_app_s;
     auto qd = [&](int i) { return f.f(f.F.qdi, i); };
     auto put_S = [&](int d, const spatial& S_s) { f.st6(f.F.S, nd, d, S_s); };
     if (type == JT_PRISMATIC) {
@@ -344,6 +342,30 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
             v_j_s = v_j_s + S_s * qd(iqd);
             put_S(iqd, S_s);
         }
+        if (ang >= 2) {  // FK-transported axes; their dependence on q gives the apparent derivative c_app
+            const int iqd = qd_start + lin, iq = c.T.joint_q_start[j] + lin;
+            vec3 a0, a1, a2;
+            d6_multi_angular(ang, c.dof_axis(iqd), c.dof_axis(iqd + 1), ang == 3 ? c.dof_axis(iqd + 2) : vec3(), f.f(f.F.jq, iq),
+                             f.f(f.F.jq, iq + 1), ang == 3 ? f.f(f.F.jq, iq + 2) : 0.0f, a0, a1, a2);
+            float qd0 = qd(iqd), qd1 = qd(iqd + 1);
+            spatial S_0 = fs_transform_twist(X_sc, spatial(vec3(), a0)), S_1 = fs_transform_twist(X_sc, spatial(vec3(), a1));
+            vec3 c_app_ang;
+            put_S(iqd, S_0);
+            put_S(iqd + 1, S_1);
+            if (ang == 2) {
+                v_j_s = v_j_s + (S_0 * qd0 + S_1 * qd1);
+                c_app_ang += cross(a0, a1) * (qd0 * qd1);
+            } else {
+                float qd2 = qd(iqd + 2);
+                spatial S_2 = fs_transform_twist(X_sc, spatial(vec3(), a2));
+                put_S(iqd + 2, S_2);
+                v_j_s = v_j_s + (S_0 * qd0 + S_1 * qd1 + S_2 * qd2);
+                c_app_ang += cross(a0, a1) * (qd0 * qd1);
+                c_app_ang += cross(a0, a2) * (qd0 * qd2);
+                c_app_ang += cross(a1, a2) * (qd1 * qd2);
+            }
+            c_app_s = fs_transform_twist(X_sc, spatial(vec3(), c_app_ang));
+        }
     } else if (type == JT_BALL) {
         spatial S_0 = fs_transform_twist(X_sc, spatial(vec3(), vec3(1.0f, 0.0f, 0.0f)));
         spatial S_1 = fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 1.0f, 0.0f)));
@@ -363,6 +385,7 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
         put_S(qd_start + 5, fs_transform_twist(X_sc, spatial(vec3(), vec3(0.0f, 0.0f, 1.0f))));
     }
     f.st6(f.F.ft, nb, j, v_j_s);  // parked in the (still unused) subtree-wrench rows until the level pass picks it up
+    f.st6(f.F.as, nb, child, c_app_s);  // the level pass adds it to the child's acceleration (zero except multi-angular D6)
     vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - solve_origin;
     c.st_lv3(f.F.org, 0, nb, child, solve_origin);
     mat66 I_s;
@@ -386,7 +409,7 @@ NT_DI void fs_motion_item(const FsCtx<EPB>& f, int j) {
         a_parent_s = f.sp6(f.F.as, nb, parent);
     }
     spatial v_s = v_parent_s + v_j_s;
-    spatial a_s = a_parent_s + fs_spatial_cross(v_s, v_j_s) + spatial();
+    spatial a_s = a_parent_s + fs_spatial_cross(v_s, v_j_s) + f.sp6(f.F.as, nb, child);  // + c_app_s (pre-pass)
     f.st6(f.F.vs, nb, child, v_s);
     f.st6(f.F.as, nb, child, a_s);
 }
@@ -753,7 +776,7 @@ NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
         for (int k = 0; k < 3; ++k)
             if (lin > k) vel_v += c.dof_axis(qs + k) * qd(qs + k);
         if (ang == 1) vel_w = qd(qs + lin) * c.dof_axis(qs + lin);
-        if constexpr (PUBLIC) {
+        {
             if (ang >= 2) {
                 const int cs = c.T.joint_q_start[j];
                 vec3 a0, a1, a2;
@@ -1082,7 +1105,7 @@ __global__ void __launch_bounds__(256) eval_fk_kernel(KArgs a, const float* join
     }
     __syncthreads();
     if (c.valid)
-        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item<EPB, true>(f, j);
+        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
     __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid)

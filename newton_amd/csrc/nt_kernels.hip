@@ -442,7 +442,7 @@ static bool fs_state_ok(const nt_state* s) { return s && s->joint_q && s->joint_
 nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* p, nt_state* s_in, nt_state* s_out,
                                 const nt_control* ctrl, const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
     if (!model_ok(m) || !p || !ctrl || !fs_state_ok(s_in) || !fs_state_ok(s_out)) return NT_ERR_INVALID_ARG;
-    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs <= 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
+    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs < 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
     KArgs a = {};
     a.m = *m;
     a.s_in = *s_in;
@@ -461,7 +461,7 @@ nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_param
                                    void* stream) {
     if (!model_ok(m) || !p || !ctrl || !c || !fs_state_ok(s0) || !fs_state_ok(s1) || !s0->body_f || !s1->body_f || substeps <= 0)
         return NT_ERR_INVALID_ARG;
-    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs <= 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
+    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs < 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
     KArgs a = {};
     a.m = *m;
     a.s_in = *s0;

@@ -36,8 +36,6 @@ class SolverFeatherstone(SolverBase):
             raise NotImplementedError("SolverFeatherstone: DISTANCE / ROD joints are not supported")
         if np.any((jt == int(JointType.FREE)) & (np.asarray(t.joint_parent) >= 0)):
             raise NotImplementedError("SolverFeatherstone: FREE joints are supported at articulation roots only")
-        if np.any((jt == int(JointType.D6)) & (np.asarray(t.joint_ang_count) > 1)):
-            raise NotImplementedError("SolverFeatherstone: D6 joints with 2 or 3 angular axes are not supported")
         if not np.array_equal(np.asarray(t.joint_child), np.arange(t.nj)) or t.nb != t.nj:
             # the reference's eval_rigid_mass indexes body_I_s by joint index (kernels.py:1466-1480)
             raise NotImplementedError("SolverFeatherstone: body j must be the child of joint j")

@@ -15,7 +15,7 @@
 //   SolverFeatherstone.step                                   solver_featherstone.py:462-1066
 //   eval_body_contact (shared with SolverSemiImplicit)        semi_implicit/kernels_contact.py:381-556
 //   transform_twist / velocity_at_point                       newton/_src/math/spatial.py:53-130
-// Scope: PRISMATIC, REVOLUTE, BALL, FIXED, root FREE, D6 with <= 1 angular axis; no kinematic bodies, no descendant
+// Scope: PRISMATIC, REVOLUTE, BALL, FIXED, root FREE, D6 (up to three angular axes), kinematic roots; no descendant
 // FREE/DISTANCE joints, update_mass_matrix_interval = 1.  PARITY UNPINNED at bit level (see wp_builtins.h).
 #include <vector>
 
@@ -117,6 +117,30 @@ spatial spatial_cross_dual(const spatial& a, const spatial& b) {
 
 int dof_end(const o_model* m, int j) { return j + 1 < m->joint_count ? m->joint_qd_start[j + 1] : m->dof_count; }
 
+// rotation and transported angular axes of a D6 joint with 2 / 3 angular axes (transform_2d/3d_rotational_axes,
+// compute_2d/3d_rotational_dofs: newton/_src/sim/articulation.py:36-83,127-178)
+quat d6_multi_angular(const o_model* m, int ang, int ia, const float* joint_q, int iq, vec3& a0, vec3& a1, vec3& a2) {
+    vec3 axis_0 = ld3(m->joint_axis, ia), axis_1 = ld3(m->joint_axis, ia + 1);
+    if (ang == 2) {
+        quat q_off = quat_from_matrix(matrix_from_cols(axis_0, axis_1, cross(axis_0, axis_1)));
+        vec3 local_0 = quat_rotate(q_off, vec3(1.0f, 0.0f, 0.0f)), local_1 = quat_rotate(q_off, vec3(0.0f, 1.0f, 0.0f));
+        a0 = local_0;
+        quat q_0 = quat_from_axis_angle(a0, joint_q[iq]);
+        a1 = quat_rotate(q_0, local_1);
+        a2 = vec3();
+        quat q_1 = quat_from_axis_angle(a1, joint_q[iq + 1]);
+        return q_1 * q_0;
+    }
+    vec3 axis_2 = ld3(m->joint_axis, ia + 2);
+    a0 = axis_0;
+    quat q_0 = quat_from_axis_angle(a0, joint_q[iq]);
+    a1 = quat_rotate(q_0, axis_1);
+    quat q_1 = quat_from_axis_angle(a1, joint_q[iq + 1]);
+    a2 = quat_rotate(q_1 * q_0, axis_2);
+    quat q_2 = quat_from_axis_angle(a2, joint_q[iq + 2]);
+    return q_2 * q_1 * q_0;
+}
+
 // kernels.py:142-239
 transform jcalc_transform(const o_model* m, int type, int axis_start, int lin, int ang, const float* joint_q, int q_start) {
     if (type == PRISMATIC) return transform(ld3(m->joint_axis, axis_start) * joint_q[q_start], quat_identity());
@@ -134,14 +158,20 @@ transform jcalc_transform(const o_model* m, int type, int axis_start, int lin, i
         if (lin > 1) pos += ld3(m->joint_axis, axis_start + 1) * joint_q[q_start + 1];
         if (lin > 2) pos += ld3(m->joint_axis, axis_start + 2) * joint_q[q_start + 2];
         if (ang == 1) rot = quat_from_axis_angle(ld3(m->joint_axis, axis_start + lin), joint_q[q_start + lin]);
+        if (ang >= 2) {
+            vec3 a0, a1, a2;
+            rot = d6_multi_angular(m, ang, axis_start + lin, joint_q, q_start + lin, a0, a1, a2);
+        }
         return transform(pos, rot);
     }
     return transform_identity();
 }
 
-// kernels.py:242-380; returns v_j_s (the apparent derivative c_app_s is zero for every joint type in scope)
-spatial jcalc_motion(const o_model* m, int type, int lin, int ang, const transform& X_sc, const float* joint_qd, int qd_start,
-                     spatial* joint_S_s) {
+// kernels.py:242-380; returns v_j_s; c_app_s = the apparent derivative of the motion subspace (non-zero only for D6 joints
+// with >= 2 angular axes, whose transported axes depend on the joint coordinates)
+spatial jcalc_motion(const o_model* m, int type, int lin, int ang, const transform& X_sc, const float* joint_q, int q_start,
+                     const float* joint_qd, int qd_start, spatial* joint_S_s, spatial& c_app_s) {
+    c_app_s = spatial();
     if (type == PRISMATIC) {
         spatial S_s = transform_twist(X_sc, spatial(ld3(m->joint_axis, qd_start), vec3()));
         joint_S_s[qd_start] = S_s;
@@ -165,6 +195,30 @@ spatial jcalc_motion(const o_model* m, int type, int lin, int ang, const transfo
             spatial S_s = transform_twist(X_sc, spatial(vec3(), ld3(m->joint_axis, iqd)));
             v_j_s = v_j_s + S_s * joint_qd[iqd];
             joint_S_s[iqd] = S_s;
+        }
+        if (ang >= 2) {
+            vec3 a0, a1, a2;
+            d6_multi_angular(m, ang, iqd, joint_q, q_start + lin, a0, a1, a2);
+            float qd0 = joint_qd[iqd], qd1 = joint_qd[iqd + 1];
+            spatial S_0 = transform_twist(X_sc, spatial(vec3(), a0)), S_1 = transform_twist(X_sc, spatial(vec3(), a1));
+            vec3 c_app_ang;
+            if (ang == 2) {
+                v_j_s = v_j_s + (S_0 * qd0 + S_1 * qd1);
+                joint_S_s[iqd] = S_0;
+                joint_S_s[iqd + 1] = S_1;
+                c_app_ang += cross(a0, a1) * (qd0 * qd1);
+            } else {
+                float qd2 = joint_qd[iqd + 2];
+                spatial S_2 = transform_twist(X_sc, spatial(vec3(), a2));
+                v_j_s = v_j_s + (S_0 * qd0 + S_1 * qd1 + S_2 * qd2);
+                joint_S_s[iqd] = S_0;
+                joint_S_s[iqd + 1] = S_1;
+                joint_S_s[iqd + 2] = S_2;
+                c_app_ang += cross(a0, a1) * (qd0 * qd1);
+                c_app_ang += cross(a0, a2) * (qd0 * qd2);
+                c_app_ang += cross(a1, a2) * (qd1 * qd2);
+            }
+            c_app_s = transform_twist(X_sc, spatial(vec3(), c_app_ang));
         }
         return v_j_s;
     }
@@ -394,15 +448,16 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
             transform X_wpj = ldx(m->joint_X_p, i);
             if (parent >= 0) X_wpj = ldx(body_q, parent) * X_wpj;
             transform X_wpj_s(X_wpj.p - solve_origin, X_wpj.q);
-            spatial v_j_s = jcalc_motion(m, type, m->joint_dof_dim[2 * i], m->joint_dof_dim[2 * i + 1], X_wpj_s,
-                                         qd_internal_in.data(), qd_start, joint_S_s.data());
+            spatial c_app_s;
+            spatial v_j_s = jcalc_motion(m, type, m->joint_dof_dim[2 * i], m->joint_dof_dim[2 * i + 1], X_wpj_s, s_in->joint_q,
+                                         m->joint_q_start[i], qd_internal_in.data(), qd_start, joint_S_s.data(), c_app_s);
             spatial v_parent_s, a_parent_s;
             if (parent >= 0) {
                 v_parent_s = body_v_s[parent];
                 a_parent_s = body_a_s[parent];
             }
             spatial v_s = v_parent_s + v_j_s;
-            spatial a_s = a_parent_s + spatial_cross(v_s, v_j_s) + spatial();
+            spatial a_s = a_parent_s + spatial_cross(v_s, v_j_s) + c_app_s;
             transform X_sm = body_q_com[child];
             vec3 x_com_s = X_sm.p - solve_origin;
             body_solve_origin[child] = solve_origin;
@@ -588,6 +643,12 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
                 for (int k = 0; k < 3; ++k)
                     if (lin > k) vel_v += ld3(m->joint_axis, qd_start + k) * jqd[qd_start + k];
                 if (ang == 1) vel_w = jqd[qd_start + lin] * ld3(m->joint_axis, qd_start + lin);
+                if (ang >= 2) {
+                    vec3 a0, a1, a2;
+                    d6_multi_angular(m, ang, qd_start + lin, jq, q_start + lin, a0, a1, a2);
+                    vel_w = a0 * jqd[qd_start + lin] + a1 * jqd[qd_start + lin + 1];
+                    if (ang == 3) vel_w = vel_w + a2 * jqd[qd_start + lin + 2];
+                }
                 v_j = spatial(vel_v, vel_w);
             }
             transform X_wpj = ldx(m->joint_X_p, i);

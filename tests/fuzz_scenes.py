@@ -75,9 +75,9 @@ def random_scene(seed, world_count=None, articulated=True, allow_hull=True, feat
                 if int(env.body_flags[b]) & int(nt.BodyFlags.KINEMATIC):
                     kind = rng.choice(["free", "fixed"])
             else:
-                kinds = ["revolute", "prismatic", "ball", "fixed", "d6"]
+                kinds = ["revolute", "prismatic", "ball", "fixed", "d6", "d6_full"]
                 if not featherstone_compatible:
-                    kinds += ["distance", "d6_full"]
+                    kinds += ["distance"]
                 kind = rng.choice(kinds)
             axis = rng.normal(size=3)
             axis /= np.linalg.norm(axis)

@@ -31,8 +31,6 @@ def _run(H, mode, seed, extras=False):
     except NotImplementedError:  # e.g. D6 joints with several angular axes: rejected by the host FK, not part of the kernels
         pytest.skip("scene uses a joint configuration the host rejects")
     t = model.env
-    if mode == "featherstone" and t.max_art_dofs == 0:
-        pytest.skip("articulation without degrees of freedom")
     em = H.EmuModel(model)
     ctrl, ct = H.EmuControl(em), H.EmuContacts(em)
     o = Oracle(model)

@@ -184,3 +184,38 @@ def test_mass_matrix_floating_base_pendulum_closed_form(oracle_lib):
     expected[np.arange(3), np.arange(3)] += base_mass
     expected[np.arange(3, 6), np.arange(3, 6)] += np.asarray(base_inertia)
     assert np.allclose(H, expected, rtol=1e-6, atol=1e-6)
+
+
+def test_d6_with_three_angular_axes_moves_like_a_ball_joint(oracle_lib):
+    """A spinning asymmetric pendulum on a D6 joint with three angular axes follows the same motion as on a BALL joint
+    (featherstone/kernels.py:266-335: FK-transported axes as motion subspace + the apparent derivative of that subspace);
+    different coordinates, same physics, 0.5 s at dt = 2e-4."""
+    import newton_amd as nt
+    from oracle_bridge import Oracle, OracleState
+
+    D = nt.ModelBuilder.JointDofConfig
+    w0 = np.array([1.5, -0.8, 2.0], dtype=np.float32)
+    out = {}
+    for kind in ("ball", "d6"):
+        b = nt.ModelBuilder(gravity=(0.0, 0.0, -9.81))
+        link = b.add_link()
+        b.add_shape_box(link, hx=0.05, hy=0.1, hz=0.2, xform=[0.0, 0.0, -0.25, 0.0, 0.0, 0.0, 1.0])
+        if kind == "ball":
+            j = b.add_joint_ball(-1, link, parent_xform=[0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0])
+        else:
+            j = b.add_joint_d6(-1, link, linear_axes=[], angular_axes=[D(axis=0), D(axis=1), D(axis=2)],
+                               parent_xform=[0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0])
+        b.add_articulation([j])
+        model = b.finalize()
+        o = Oracle(model)
+        s0, s1 = OracleState(model), OracleState(model)
+        s0.joint_qd[:3] = w0  # at q = 0 the transported axes are X, Y, Z: joint speeds == angular velocity
+        for _ in range(2500):
+            s0.body_f[:] = 0
+            o.featherstone_step(s0, s1, o.control(), None, 2e-4, angular_damping=0.0)
+            s0, s1 = s1, s0
+        out[kind] = (s0.body_q[0].copy(), s0.body_qd[0].copy())
+    qa, qb = out["ball"][0][3:], out["d6"][0][3:]
+    assert min(np.abs(qa - qb).max(), np.abs(qa + qb).max()) < 5e-4
+    assert np.abs(out["ball"][1][3:] - out["d6"][1][3:]).max() < 3e-3
+    assert np.linalg.norm(out["ball"][1][3:]) > 1.0  # still spinning
