@@ -71,7 +71,7 @@ def random_scene(seed, world_count=None, articulated=True, allow_hull=True, feat
             Xp = [*rng.uniform(-0.15, 0.15, size=3), *_rand_quat(rng, 0.5)]
             Xc = [*rng.uniform(-0.1, 0.1, size=3), *_rand_quat(rng, 0.5)]
             if k == first:
-                kind = rng.choice(["free", "revolute", "fixed"])
+                kind = rng.choice(["free", "revolute", "fixed", "distance"] if featherstone_compatible else ["free", "revolute", "fixed"])
                 if int(env.body_flags[b]) & int(nt.BodyFlags.KINEMATIC):
                     kind = rng.choice(["free", "fixed"])
             else:
