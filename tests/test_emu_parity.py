@@ -314,3 +314,50 @@ def test_pair_heavy_scene_keeps_contact_records_in_hbm(H, n_hulls, n_env):
     # the other solvers refuse this mode instead of overflowing LDS
     with pytest.raises(RuntimeError):
         H.semi_implicit_step(em, s0, s1, ctrl, ct, 1e-4)
+
+
+def test_boundary_helpers(H):
+    """nt_state_reset (masked env columns), nt_contacts_export with a capacity below the count (the counter keeps counting,
+    writes are clamped), nt_pack_aos / nt_unpack_aos round trip."""
+    import ctypes as C
+
+    from scenes import mixed_primitive_scene
+
+    rng = np.random.default_rng(0)
+    for E in (1, 7, 33):
+        model = mixed_primitive_scene(E)
+        em = H.EmuModel(model)
+        t = em.t
+        src, dst = H.EmuState(em), H.EmuState(em)
+        names = ("body_q", "body_qd", "joint_q", "joint_qd", "body_f")
+        for n in names:
+            getattr(dst, n)[...] = rng.normal(size=getattr(dst, n).shape).astype(np.float32)
+        before = {n: getattr(dst, n).copy() for n in names}
+        mask = (rng.random(E) < 0.5).astype(np.uint8)
+        dd, ds = dst.desc(), src.desc()
+        H.check(H.lib().nt_state_reset(C.byref(em.desc), C.byref(dd), C.byref(ds), mask.ctypes.data, None), "nt_state_reset")
+        for n in names:
+            want = before[n].copy()
+            want[..., :E][..., mask.astype(bool)] = getattr(src, n)[..., :E][..., mask.astype(bool)]
+            assert np.array_equal(getattr(dst, n)[..., :E], want[..., :E]), n
+        ct = H.EmuContacts(em)
+        H.collide(em, H.EmuState(em), ct)
+        full = ct.export()
+        n = int(full["count"][0])
+        assert n > 3
+        cap = n // 2
+        out = {"count": np.zeros(1, np.int32), "shape0": np.full(cap, -7, np.int32), "shape1": np.full(cap, -7, np.int32)}
+        for k in ("point0", "point1", "offset0", "offset1", "normal"):
+            out[k] = np.zeros((cap, 3), np.float32)
+        out["margin0"], out["margin1"] = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        d = ct.desc()
+        H.check(H.lib().nt_contacts_export(C.byref(em.desc), C.byref(d), cap, *(out[k].ctypes.data for k in (
+            "count", "shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")),
+            ct.scan.ctypes.data, None), "nt_contacts_export")
+        assert int(out["count"][0]) == n  # keeps counting past the capacity (collide.py:176-177)
+        assert np.array_equal(out["shape0"], full["shape0"][:cap]) and np.array_equal(out["point0"], full["point0"][:cap])
+        aos = rng.normal(size=(E * t.nb, 7)).astype(np.float32)
+        soa, back = np.zeros((7, t.nb, t.env_stride), np.float32), np.zeros((E * t.nb, 7), np.float32)
+        H.check(H.lib().nt_pack_aos(aos.ctypes.data, soa.ctypes.data, 7, t.nb, E, t.env_stride, None), "nt_pack_aos")
+        H.check(H.lib().nt_unpack_aos(soa.ctypes.data, back.ctypes.data, 7, t.nb, E, t.env_stride, None), "nt_unpack_aos")
+        assert np.array_equal(back, aos) and np.array_equal(soa, em.to_soa(aos, 7, t.nb))
