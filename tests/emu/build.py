@@ -33,7 +33,8 @@ def transform(text: str) -> str:
 
 def build(force: bool = False) -> str:
     os.makedirs(OUT, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in FILES] + [os.path.join(HERE, "hip_emu.h"), os.path.abspath(__file__),
+    srcs = [os.path.join(CSRC, f) for f in FILES] + [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "broadphase_stub.cpp"),
+                                                     os.path.abspath(__file__),
                                                      os.path.join(ROOT, "include", "newton_hip.h")]
     digest = hashlib.sha1(b"".join(open(s, "rb").read() for s in srcs)).hexdigest()
     stamp = os.path.join(OUT, "stamp")
@@ -44,7 +45,7 @@ def build(force: bool = False) -> str:
         assert "hip_runtime" not in text and "__builtin_amdgcn" not in text, f
         open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w").write(text)
     cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
-           f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), "-o", LIB]
+           f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(HERE, "broadphase_stub.cpp"), "-o", LIB]
     subprocess.run(cmd, check=True)
     open(stamp, "w").write(digest)
     return LIB
