@@ -61,6 +61,23 @@ class _Stream:
         pass
 
 
+class _Event:
+    def __init__(self, enable_timing=False):
+        self.t = 0.0
+
+    def record(self, stream=None):
+        import time
+
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+    def synchronize(self):
+        pass
+
+
+torch.cuda.Event = _Event
 torch.cuda.is_available = lambda: True
 torch.cuda.current_stream = lambda device=None: _Stream()
 torch.cuda.synchronize = lambda device=None: None
