@@ -70,13 +70,14 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
         lo = world_center - world_half - mv;
         hi = world_center + world_half + mv;
         return;
-    } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE) {
-        // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space
+    } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE || geo_type == GEO_PLANE) {
+        // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space; a finite
+        // plane is a rectangle with half extents scale / 2 (collide.py:452-453)
         mat33 Rt = transpose(quat_to_matrix(q));
         vec3 local_x(Rt.m00, Rt.m10, Rt.m20), local_y(Rt.m01, Rt.m11, Rt.m21), local_z(Rt.m02, Rt.m12, Rt.m22);
         Geom g;
         g.type = geo_type;
-        g.scale = scale;
+        g.scale = geo_type == GEO_PLANE ? vec3(scale.x * 0.5f, scale.y * 0.5f, 0.0f) : scale;
         float max_x = dot(local_x, support_map(g, local_x));
         float max_y = dot(local_y, support_map(g, local_y));
         float max_z = dot(local_z, support_map(g, local_z));
@@ -86,10 +87,6 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
         lo = vec3(min_x, min_y, min_z) + pos - mv;
         hi = vec3(max_x, max_y, max_z) + pos + mv;
         return;
-    } else {
-        // finite planes: conservative bounding sphere (rejected by the host for collision)
-        float r = 0.5f * sqrtf(scale.x * scale.x + scale.y * scale.y);
-        he = vec3(r, r, r);
     }
     lo = pos - he - mv;
     hi = pos + he + mv;
@@ -223,6 +220,9 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
                 Geom ga, gb;
                 ga.type = ta; ga.scale = scale_a;
                 gb.type = tb; gb.scale = scale_b;
+                // a (finite) plane enters the convex path as a rectangle with half extents scale / 2 (collide.py:452-453)
+                if (ta == GEO_PLANE) ga.scale = vec3(scale_a.x * 0.5f, scale_a.y * 0.5f, 0.0f);
+                if (tb == GEO_PLANE) gb.scale = vec3(scale_b.x * 0.5f, scale_b.y * 0.5f, 0.0f);
                 if (ta == GEO_CONVEX_MESH) {
                     ga.points = m.mesh_points + 3 * c.T.shape_mesh_start[sa];
                     ga.count = c.T.shape_mesh_count[sa];

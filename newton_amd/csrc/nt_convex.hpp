@@ -69,6 +69,12 @@ NT_DEV vec3 support_map_box(const Geom& g, vec3 d) {
 NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
+    if (g.type == GEO_PLANE) {
+        // support_function.py:334-345: finite rectangle in XY (half-width scale.x, half-length scale.y), normal +Z
+        float sx = direction.x >= 0.0f ? 1.0f : -1.0f;
+        float sy = direction.y >= 0.0f ? 1.0f : -1.0f;
+        return vec3(sx * g.scale.x, sy * g.scale.y, 0.0f);
+    }
     if (g.type == GEO_CONVEX_MESH) {
         // support_function.py:152-171: furthest vertex; ties keep the first one
         vec3 scaled_dir = cw_mul(direction, g.scale);
@@ -1038,8 +1044,9 @@ NT_DEV void convex_pair(const Geom& geom_a, const Geom& geom_b, xform Xa, const 
     P.gb = geom_b;
     P.margin_a = margin_a; P.margin_b = margin_b;
     P.contact_gap = rigid_gap;
-    // pairs arrive type-sorted, so an infinite plane (PLANE = 1) can only be shape A
-    if (P.ga.type == GEO_PLANE) {
+    // pairs arrive type-sorted, so a plane (PLANE = 1) can only be shape A; a finite plane (non-zero half extents) is an
+    // ordinary convex shape, the rectangle of support_map
+    if (P.ga.type == GEO_PLANE && P.ga.scale.x == 0.0f && P.ga.scale.y == 0.0f) {
         // bounding-sphere half-space cull on the other shape's broad-phase AABB (narrow_phase.py:1117-1194,
         // collision_core.py:549-560,628-683), then the box proxy of convert_infinite_plane_to_cube (collision_core.py:562-625)
         vec3 bsphere_center_b = 0.5f * (aabb_lower_b + aabb_upper_b);

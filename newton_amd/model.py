@@ -216,10 +216,9 @@ class EnvTemplate:
 
         def convex_ok(s):
             ty = int(self.shape_type[s])
-            if ty == GeoType.PLANE:  # infinite planes become a box proxy under the other shape (collision_core.py:562-625)
-                sc = np.asarray(m.shape_scale).reshape(-1, 3)[L0 + s if s < ns else shape_glob[s - ns]]
-                return sc[0] == 0.0 and sc[1] == 0.0
-            return ty in convex_types
+            # infinite planes become a box proxy under the other shape (collision_core.py:562-625), finite ones are
+            # rectangles with their own support map (support_function.py:334-345)
+            return ty == GeoType.PLANE or ty in convex_types
 
         for a, b, ok in zip(self.pair_a, self.pair_b, is_analytic):
             both_planes = int(self.shape_type[a]) == GeoType.PLANE and int(self.shape_type[b]) == GeoType.PLANE

@@ -458,7 +458,9 @@ static void compute_shape_aabbs(const o_model* m, const float* body_q, float* aa
                             std::fabs(r0[2]) * half[0] + std::fabs(r1[2]) * half[1] + std::fabs(r2[2]) * half[2]);
             lo = world_center - world_half - margin_vec;
             hi = world_center + world_half + margin_vec;
-        } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE) {
+        } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE || geo_type == GEO_PLANE) {
+            // finite plane: a rectangle with half extents scale / 2 (collide.py:452-453)
+            if (geo_type == GEO_PLANE) geom_scale = vec3(scale[0] * 0.5f, scale[1] * 0.5f, 0.0f);
             // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space
             mat33 rot_mat_t = transpose(quat_to_matrix(orientation));
             vec3 local_x(rot_mat_t(0, 0), rot_mat_t(1, 0), rot_mat_t(2, 0));
@@ -473,9 +475,8 @@ static void compute_shape_aabbs(const o_model* m, const float* body_q, float* aa
             lo = vec3(min_x, min_y, min_z) + pos - margin_vec;
             hi = vec3(max_x, max_y, max_z) + pos + margin_vec;
         } else {
-            // finite planes / meshes: not restated (conservative bounding sphere; rejected by the product host)
+            // triangle meshes: not restated (conservative bounding sphere; rejected by the product host)
             float r = m->shape_collision_radius[shape_id];
-            if (geo_type == GEO_PLANE) geom_scale = vec3(scale[0] * 0.5f, scale[1] * 0.5f, 0.0f);
             vec3 half_extents(r, r, r);
             lo = pos - half_extents - margin_vec;
             hi = pos + half_extents + margin_vec;

@@ -63,6 +63,12 @@ vec3 support_map_box(const Geom& g, vec3 d) {
 vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
+    if (g.type == GEO_PLANE) {
+        // support_function.py:334-345: finite rectangle in XY (half-width scale.x, half-length scale.y), normal +Z
+        float sx = direction[0] >= 0.0f ? 1.0f : -1.0f;
+        float sy = direction[1] >= 0.0f ? 1.0f : -1.0f;
+        return vec3(sx * g.scale.x, sy * g.scale.y, 0.0f);
+    }
     if (g.type == GEO_CONVEX_MESH) {
         // support_function.py:152-171: furthest vertex; ties keep the first one
         vec3 scaled_dir = cw_mul(direction, g.scale);
@@ -1035,7 +1041,8 @@ int convex_pair_contacts(const o_model* m, int shape_a, int shape_b, const float
     bool is_infinite_plane_b = P.gb.type == GEO_PLANE && P.gb.scale.x == 0.0f && P.gb.scale.y == 0.0f;
     if (is_infinite_plane_a && is_infinite_plane_b) return 0;  // narrow_phase.py:1111-1112
     if (is_infinite_plane_b) return 0;                          // cannot happen after type sorting
-    if (!(is_infinite_plane_a || supported_type(P.ga.type)) || !supported_type(P.gb.type)) return 0;  // meshes etc.: not restated
+    // finite planes are rectangles with their own support map (support_function.py:334-345); meshes etc. are not restated
+    if (!(P.ga.type == GEO_PLANE || supported_type(P.ga.type)) || !supported_type(P.gb.type)) return 0;
     if (P.ga.type == GEO_CYLINDER && P.ga.scale.z != 0.0f) return 0;  // barrel cylinders: not restated
     if (P.gb.type == GEO_CYLINDER && P.gb.scale.z != 0.0f) return 0;
     bind_mesh(m, shape_a, P.ga);

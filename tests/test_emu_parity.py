@@ -361,3 +361,49 @@ def test_boundary_helpers(H):
         H.check(H.lib().nt_pack_aos(aos.ctypes.data, soa.ctypes.data, 7, t.nb, E, t.env_stride, None), "nt_pack_aos")
         H.check(H.lib().nt_unpack_aos(soa.ctypes.data, back.ctypes.data, 7, t.nb, E, t.env_stride, None), "nt_unpack_aos")
         assert np.array_equal(back, aos) and np.array_equal(soa, em.to_soa(aos, 7, t.nb))
+
+
+def test_finite_plane(H):
+    """A finite plane is a rectangle: tight AABB through its support map (collide.py:448-465, support_function.py:334-345), so
+    shapes beyond its edges are no candidates; the analytic plane-primitive contacts ignore the extents like the reference's
+    collide_plane_* functions; cones and hulls meet it through MPR/GJK without the infinite-plane box proxy."""
+    from oracle_bridge import Oracle, OracleState
+
+    from newton_amd import _np_math as nm
+
+    rng = np.random.default_rng(1)
+    env = nt.ModelBuilder()
+    kinds = ["sphere", "box", "capsule", "cylinder", "ellipsoid", "cone", "hull", "box", "sphere", "cone", "hull", "cylinder"]
+    for k, kind in enumerate(kinds):
+        b = env.add_body(xform=[-1.6 + 0.3 * k, rng.uniform(-0.9, 0.9), 0.12, *nm.quat_rpy(*rng.uniform(-0.5, 0.5, size=3))])
+        if kind == "sphere":
+            env.add_shape_sphere(b, radius=0.1)
+        elif kind == "box":
+            env.add_shape_box(b, hx=0.1, hy=0.08, hz=0.06)
+        elif kind == "capsule":
+            env.add_shape_capsule(b, radius=0.06, half_height=0.1)
+        elif kind == "cylinder":
+            env.add_shape_cylinder(b, radius=0.08, half_height=0.1)
+        elif kind == "ellipsoid":
+            env.add_shape_ellipsoid(b, rx=0.12, ry=0.08, rz=0.06)
+        elif kind == "cone":
+            env.add_shape_cone(b, radius=0.08, half_height=0.1)
+        else:
+            env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(rng.normal(size=(14, 3)) * 0.06))
+    scene = nt.ModelBuilder()
+    scene.replicate(env, 3)
+    plane = scene.add_shape_plane(xform=[0.0, 0.0, 0.0, *nm.quat_rpy(0.05, -0.03, 0.4)], width=2.0, length=1.0)
+    model = scene.finalize()
+    em = H.EmuModel(model)
+    s0, s1, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    H.collide(em, s0, ct)
+    pairs, lo, hi = o.collide(os0.body_q, oc)
+    assert _same_contacts(ct, oc) > 30
+    assert np.all(hi[plane] - lo[plane] < [2.6, 2.1, 0.5])  # the rectangle, not a half space
+    with_plane = {int(p[0]) for p in pairs if p[1] == plane}
+    assert 0 not in with_plane and 11 not in with_plane and {3, 5, 6} <= with_plane  # bodies past the short edges are culled
+    H.xpbd_step(em, s0, s1, ctrl, ct, 1e-3)
+    o.xpbd_step(os0, os1, o.control(), oc, 1e-3)
+    assert _close(s1.aos("body_q"), os1.body_q, 1e-5)
