@@ -3,7 +3,7 @@ for the host against tests/emu/hip_emu.h (one OS thread per GPU thread, std::bar
 
 The product sources are not modified: they are copied into the build directory with three textual substitutions
 (HIP runtime include -> the shim, the dynamic-LDS declaration -> the shim's buffer, the wave-level fence of the Featherstone
-Cholesky -> a rendezvous of the participating lanes).  nt_broadphase.hip (wave ballots) is not part of the emulated library.
+Cholesky -> a rendezvous of the participating lanes).  The wave ballots / shuffles of nt_broadphase.hip are shim functions.
 Used by tests/test_emu_*.py to run the kernels' logic against the oracle without a GPU; never loadable from newton_amd."""
 import hashlib
 import os
@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "newton_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
 FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_collide.hpp", "nt_xpbd.hpp",
-         "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_kernels.hip"]
+         "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip"]
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
 WAVE_SYNC_EMU = ("#define FS_WAVE_SYNC() emu_wave_sync((unsigned)(G * (((int)c.a.m.env_count - (int)blockIdx.x * EPB) < EPB ? "
@@ -33,7 +33,7 @@ def transform(text: str) -> str:
 
 def build(force: bool = False) -> str:
     os.makedirs(OUT, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in FILES] + [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "broadphase_stub.cpp"),
+    srcs = [os.path.join(CSRC, f) for f in FILES] + [os.path.join(HERE, "hip_emu.h"),
                                                      os.path.abspath(__file__),
                                                      os.path.join(ROOT, "include", "newton_hip.h")]
     digest = hashlib.sha1(b"".join(open(s, "rb").read() for s in srcs)).hexdigest()
@@ -41,11 +41,11 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
         return LIB
     for f in FILES:
-        text = transform(open(os.path.join(CSRC, f)).read())
+        text = transform(open(os.path.join(CSRC, f)).read()).replace('#include "nt_broadphase_core.hpp"', '#include "nt_broadphase_core.hpp"')
         assert "hip_runtime" not in text and "__builtin_amdgcn" not in text, f
         open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w").write(text)
     cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
-           f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(HERE, "broadphase_stub.cpp"), "-o", LIB]
+           f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(OUT, "nt_broadphase.cpp"), "-o", LIB]
     subprocess.run(cmd, check=True)
     open(stamp, "w").write(digest)
     return LIB

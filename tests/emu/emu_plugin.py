@@ -51,6 +51,7 @@ def _to(self, *args, **kwargs):
 
 torch.Tensor.to = _to
 torch.Tensor.cuda = lambda self, *a, **k: self
+torch.Tensor.is_cuda = property(lambda self: True)  # the product's argument checks ask for device tensors
 _real_device = torch.device
 
 

@@ -59,6 +59,44 @@ inline void emu_wave_sync(unsigned participants) {
     b->wave_bar[wave * 65 + participants]->arrive_and_wait();
 }
 
+// ---- wave-level intrinsics (nt_broadphase.hip): the 64 lanes of a wave are 64 OS threads that meet at a wave barrier.  Every
+// lane of the wave must execute the call (the kernels only use them in wave-uniform control flow).
+namespace emu {
+struct WaveSlot {
+    std::atomic<unsigned long long> mask{0};
+    int values[64];
+};
+inline WaveSlot* wave_slots() {
+    static WaveSlot slots[16];  // up to 1024 threads per workgroup
+    return slots;
+}
+}  // namespace emu
+inline unsigned __lane_id() { return threadIdx.x % 64; }
+inline unsigned long long __ballot(int pred) {
+    emu::WaveSlot& w = emu::wave_slots()[threadIdx.x / 64];
+    const unsigned lanes = blockDim.x - (threadIdx.x / 64) * 64 < 64 ? blockDim.x - (threadIdx.x / 64) * 64 : 64;
+    if (pred) w.mask.fetch_or(1ull << __lane_id());
+    emu_wave_sync(lanes);
+    unsigned long long m = w.mask.load();
+    emu_wave_sync(lanes);
+    if (__lane_id() == 0) w.mask.store(0);
+    emu_wave_sync(lanes);
+    return m;
+}
+inline int __any(int pred) { return __ballot(pred) != 0ull; }
+inline int __shfl(int var, int src_lane) {
+    emu::WaveSlot& w = emu::wave_slots()[threadIdx.x / 64];
+    const unsigned lanes = blockDim.x - (threadIdx.x / 64) * 64 < 64 ? blockDim.x - (threadIdx.x / 64) * 64 : 64;
+    w.values[__lane_id()] = var;
+    emu_wave_sync(lanes);
+    int v = w.values[src_lane];
+    emu_wave_sync(lanes);
+    return v;
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
 template <typename K>
 inline hipError_t hipFuncSetAttribute(K, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }

@@ -13,8 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 TESTS = os.path.dirname(HERE)
 ROOT = os.path.dirname(TESTS)
-SKIP = {"test_gpu_full_size.py",            # 4096 environments: hours in emulation
-        "test_broad_phase_standalone.py"}   # wave-ballot kernels are not part of the emulated library
+SKIP = {"test_gpu_full_size.py"}  # 4096 environments: hours in emulation
 
 
 def main():

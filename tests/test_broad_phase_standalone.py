@@ -302,3 +302,44 @@ def test_hip_broad_phase_filters_capacity_explicit_and_scale():
 
     ocount, opairs = _oracle(lib(), "nxn", lower, upper, gap, group, world, None, cap=cap)
     assert res["BroadPhaseAllPairs"] == {tuple(p) for p in opairs} and ocount == len(opairs)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("entry", ["nt_broadphase_nxn", "nt_broadphase_sap"])
+def test_emulated_kernels_match_brute_force(oracle_lib, entry, case):
+    """nt_broadphase.hip itself (wave-aggregated append included), executed on the CPU by tests/emu with ballots / shuffles as
+    lane rendezvous."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import harness as H
+
+    from newton_amd import _lib as L
+
+    lower, upper, gap, group, world, flags = make_case(case)
+    want = brute_force(lower, upper, gap, group, world, flags)
+    filt = np.array(sorted(want)[::5], dtype=np.int32).reshape(-1, 2)
+    index_map, ends = precompute_world_map(world, flags)
+    m = index_map
+    if entry.endswith("sap"):
+        key = lower[index_map, 0] - gap[index_map]
+        seg = np.searchsorted(ends, np.arange(len(index_map)), side="right")
+        order = np.argsort(key, kind="stable")
+        m = np.ascontiguousarray(index_map[order[np.argsort(seg[order], kind="stable")]])
+    v = L.nt_broadphase_in()
+    v.lower, v.upper, v.gap = lower.ctypes.data, upper.ctypes.data, gap.ctypes.data
+    v.group, v.world = group.ctypes.data, world.ctypes.data
+    v.filter_pairs, v.num_filter_pairs, v.include_static_kinematic_pairs = filt.ctypes.data, len(filt), 1
+    cap = 5  # smaller than the result: the counter keeps counting
+    pairs = np.full((len(want) + 8, 2), -1, dtype=np.int32)
+    count = np.zeros(1, dtype=np.int32)
+    fn = getattr(H.lib(), entry)
+    for c in (len(pairs), cap):
+        count[:] = 0
+        pairs[:] = -1
+        H.check(fn(C.byref(v), m.ctypes.data, ends.ctypes.data, len(ends), max(0, len(ends) - 1), len(m), pairs.ctypes.data,
+                   count.ctypes.data, c, None), entry)
+        expect = want - {tuple(p) for p in filt}
+        assert int(count[0]) == len(expect)
+        got = {tuple(p) for p in pairs[: min(c, len(expect))]}
+        assert got <= expect and len(got) == min(c, len(expect)) and (c == cap or got == expect)
