@@ -1,0 +1,26 @@
+"""The product's Python path (DeviceModel, State, Contacts, CollisionPipeline, the solver classes, __graft_entry__.smoke) on a
+machine without a GPU: a subprocess loads tests/emu/emu_plugin.py, which redirects "cuda" tensors to host memory and points
+the product loader at the emulated kernel library, then runs a few of the `-m gpu` test files and smoke() unchanged.
+tests/emu/run_gpu_tests_emulated.py does the same for the whole GPU suite (slow; a pre-flight check, not part of this suite)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TESTS = os.path.join(ROOT, "tests")
+ENV = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(TESTS, "emu"), ROOT, os.environ.get("PYTHONPATH", "")]))
+ENV.pop("NEWTON_HIP_LIB", None)
+
+
+def test_gpu_test_files_dry_run(oracle_lib):
+    files = ["test_xpbd_joint_recovery.py", "test_kinematics.py", "test_gpu_parity_semi_implicit.py", "test_body_force.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-p", "emu_plugin", "-m", "gpu", "-q", "-x", *files], cwd=TESTS, env=ENV,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_smoke_dry_run(oracle_lib):
+    r = subprocess.run([sys.executable, "-c", "import emu_plugin\nimport __graft_entry__ as g\ng.smoke()"], cwd=ROOT, env=ENV,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "[smoke] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
