@@ -175,11 +175,63 @@ def eval_fk_numpy(model, joint_q, joint_qd):
     return body_q.reshape(-1, 7).astype(np.float32), body_qd.reshape(-1, 6).astype(np.float32)
 
 
-def eval_fk(model, joint_q, joint_qd, state, mask=None, indices=None):
-    """newton.eval_fk(model, joint_q, joint_qd, state): writes state.body_q / state.body_qd.
-    ``state`` may be a State or the Model itself (as in example_basic_urdf.py:88)."""
-    if mask is not None or indices is not None:
-        raise NotImplementedError("eval_fk(mask=..., indices=...) is not supported")
+def _host_array(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+def _fk_body_selection(model, mask, indices, body_flag_filter):
+    """bool [body_count]: bodies whose inbound joint belongs to a selected articulation and whose flags pass the filter."""
+    A = int(model.articulation_count)
+    if mask is not None and indices is not None:
+        raise ValueError("eval_fk: 'mask' and 'indices' cannot be used together")
+    art_sel = np.ones(A, dtype=bool)
+    if mask is not None:
+        art_sel = np.asarray(mask.detach().cpu().numpy() if hasattr(mask, "detach") else mask).astype(bool).reshape(-1)
+        if art_sel.shape[0] != A:
+            raise ValueError(f"eval_fk: mask has {art_sel.shape[0]} entries, the model has {A} articulations")
+    if indices is not None:
+        idx = np.asarray(indices.detach().cpu().numpy() if hasattr(indices, "detach") else indices, dtype=np.int64).reshape(-1)
+        art_sel = np.zeros(A, dtype=bool)
+        art_sel[idx] = True
+    joint_art = np.asarray(model.joint_articulation)
+    sel = np.zeros(model.body_count, dtype=bool)
+    ok = joint_art >= 0
+    sel[np.asarray(model.joint_child)[ok]] = art_sel[joint_art[ok]]
+    if body_flag_filter is not None:
+        sel &= (np.asarray(model.body_flags) & int(body_flag_filter)) != 0
+    return sel
+
+
+def eval_fk(model, joint_q, joint_qd, state, mask=None, indices=None, body_flag_filter=None):
+    """newton.eval_fk(model, joint_q, joint_qd, state, mask=None, indices=None, body_flag_filter=BodyFlags.ALL)
+    (newton/_src/sim/articulation.py:500-573): writes state.body_q / state.body_qd.  ``mask`` (bool per articulation) or
+    ``indices`` (articulation ids) restrict the update to some articulations, ``body_flag_filter`` to bodies whose flags
+    match (e.g. BodyFlags.KINEMATIC to re-pose only the prescribed bodies).  ``state`` may be a State or the Model itself (as
+    in example_basic_urdf.py:88)."""
+    if mask is not None or indices is not None or body_flag_filter is not None:
+        sel = _fk_body_selection(model, mask, indices, body_flag_filter)
+        if sel.all():
+            return eval_fk(model, joint_q, joint_qd, state)
+        from .state import State as _State  # noqa: PLC0415
+
+        scratch = _State(model) if isinstance(state, _State) else None
+        if scratch is not None and getattr(model, "is_gpu", False):
+            # full FK into a scratch state (one kernel launch), then copy the selected bodies
+            import torch  # noqa: PLC0415
+
+            eval_fk(model, joint_q, joint_qd, scratch)
+            rows = torch.as_tensor(np.flatnonzero(sel), device=scratch.body_q.device)
+            for name in ("body_q", "body_qd"):
+                cur, new = getattr(state, name), getattr(scratch, name)
+                cur[rows] = new[rows]
+                setattr(state, name, cur)
+            return
+        bq, bqd = eval_fk_numpy(model, _host_array(joint_q), _host_array(joint_qd))
+        cur_q = np.array(_host_array(state.body_q), dtype=np.float32).reshape(-1, 7)
+        cur_qd = np.array(_host_array(state.body_qd), dtype=np.float32).reshape(-1, 6)
+        cur_q[sel], cur_qd[sel] = bq[sel], bqd[sel]
+        state.body_q, state.body_qd = cur_q, cur_qd
+        return
 
     def host(x):
         return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
