@@ -5,7 +5,7 @@ Model / State / Control / Contacts / ModelBuilder / CollisionPipeline / eval_fk 
 """
 from . import builder as _builder_mod
 from . import solvers
-from . import geometry, selection, utils
+from . import geometry, selection, utils, viewer
 from .articulation import eval_fk
 from .builder import JointDofConfig, ModelBuilder, ShapeConfig
 from .collide import CollisionPipeline, Contacts
@@ -29,6 +29,6 @@ def set_use_coord_layout_targets(value: bool):
 
 
 __all__ = ["BodyFlags", "CollisionPipeline", "Contacts", "Control", "GeoType", "JointDofConfig", "JointType", "Mesh", "Model",
-           "ModelBuilder", "ModelFlags", "ShapeConfig", "ShapeFlags", "State", "StateFlags", "eval_fk", "geometry", "selection",
+           "ModelBuilder", "ModelFlags", "ShapeConfig", "ShapeFlags", "State", "StateFlags", "eval_fk", "geometry", "selection", "viewer",
            "solvers",
            "set_use_coord_layout_targets"]

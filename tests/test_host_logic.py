@@ -223,3 +223,51 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.nt_collide(C.byref(m), C.byref(s), C.byref(ct), C.byref(cp), None) == NT_ERR_INVALID_ARG
     assert lib.nt_error_string(NT_ERR_INVALID_ARG) == b"invalid argument"
     assert lib.nt_error_string(-3) == b"unsupported configuration"
+
+
+def test_viewer_null_and_state_recorder(tmp_path):
+    """ViewerNull frame accounting / benchmark result and the ViewerFile state recorder round trip
+    (newton/_src/viewer/viewer_null.py, viewer_file.py:1176-1260,1479-1533)."""
+    import newton_amd as nt
+    from scenes import pendulum_scene
+
+    v = nt.viewer.ViewerNull(num_frames=5, benchmark=True, benchmark_start_frame=2)
+    n = 0
+    while v.is_running():
+        v.begin_frame(0.01 * n)
+        v.log_scalar("x", n)
+        v.end_frame()
+        n += 1
+    assert n == 5 and v.frame_count == 5
+    res = v.benchmark_result()
+    assert res["frames"] == 3 and res["elapsed"] > 0.0 and res["fps"] > 0.0
+    assert nt.viewer.ViewerNull().benchmark_result() is None
+
+    model = pendulum_scene(2)
+    rec = nt.viewer.ViewerFile(str(tmp_path / "run.npz"))
+    rec.set_model(model)
+    states = []
+    s = model.state()
+    for k in range(4):
+        s.body_q = np.asarray(s.body_q) + np.float32(0.01 * (k + 1))
+        s.joint_q = np.asarray(s.joint_q) + np.float32(0.1)
+        rec.begin_frame(0.5 * k)
+        rec.log_state(s)
+        rec.end_frame()
+        states.append((np.array(s.body_q).copy(), np.array(s.joint_q).copy()))
+    assert rec.get_frame_count() == 4 and rec.has_model()
+    rec.close()  # auto-save
+    back = nt.viewer.ViewerFile()
+    back.load_recording(str(tmp_path / "run.npz"))
+    assert back.get_frame_count() == 4
+    t = model.state()
+    back.load_state(t, 2)
+    assert np.array_equal(np.asarray(t.body_q), states[2][0]) and np.array_equal(np.asarray(t.joint_q), states[2][1])
+    import pytest as _pytest
+
+    with _pytest.raises(IndexError):
+        back.load_state(t, 9)
+    ring = nt.viewer.ViewerFile(max_history_size=2)
+    for k in range(5):
+        ring.record(s)
+    assert ring.get_frame_count() == 2
