@@ -26,9 +26,12 @@ def _torch():
 class Contacts:
     """Rigid contact buffers (contacts.py:227-277).  ``rigid_contact_max`` = env_count * pairs_per_env * cpp."""
 
-    def __init__(self, model, rigid_contact_max: int | None = None):
+    def __init__(self, model, rigid_contact_max: int | None = None, sort_by_key: bool = False):
         torch = _torch()
         self.model = model
+        # CollisionPipeline(deterministic=True): the flat arrays come out in the reference's sorted order, ascending
+        # make_contact_sort_key = (shape0, shape1, sub-contact index) (contact_data.py:60-90, contact_sort.py)
+        self.sort_by_key = bool(sort_by_key)
         dm = model.device_model()
         t = model.env
         self._slots = t.np * t.cpp
@@ -93,6 +96,16 @@ class Contacts:
             e["shape1"].data_ptr(), e["point0"].data_ptr(), e["point1"].data_ptr(), e["offset0"].data_ptr(),
             e["offset1"].data_ptr(), e["normal"].data_ptr(), e["margin0"].data_ptr(), e["margin1"].data_ptr(),
             self._scan.data_ptr(), dm.stream()), "nt_contacts_export")
+        if self.sort_by_key:
+            n = min(int(e["count"].item()), cap)
+            if n > 1:
+                # a pair's contacts are exported consecutively in sub-contact order, so a stable sort on (shape0, shape1)
+                # is the sort on the full key
+                key = e["shape0"][:n].to(torch.int64) * (1 << 20) + e["shape1"][:n].to(torch.int64)
+                order = torch.sort(key, stable=True).indices
+                for k, v in e.items():
+                    if k != "count":
+                        v[:n] = v[:n][order]
         self._export, self._export_generation = e, self._generation
         return e
 
@@ -178,14 +191,16 @@ class CollisionPipeline:
         t = model.env
         self._rigid_contact_max = t.env_count * t.np * t.cpp
         model.rigid_contact_max = self._rigid_contact_max
-        self.deterministic = True  # fixed slots + ordered reductions: deterministic by construction
+        # fixed slots + ordered reductions: results are reproducible either way; deterministic=True additionally orders the
+        # flat contact arrays by the reference's contact sort key (collide.py deterministic mode, contact_sort.py)
+        self.deterministic = bool(deterministic)
 
     @property
     def rigid_contact_max(self):
         return self._rigid_contact_max
 
     def contacts(self) -> Contacts:
-        return Contacts(self.model)
+        return Contacts(self.model, sort_by_key=self.deterministic)
 
     def collide(self, state, contacts: Contacts, *, soft_contact_margin=None, dt=None):
         if contacts.model is not self.model:
