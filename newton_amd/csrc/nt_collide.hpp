@@ -70,14 +70,28 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
         lo = world_center - world_half - mv;
         hi = world_center + world_half + mv;
         return;
-    } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE || geo_type == GEO_PLANE) {
-        // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space; a finite
-        // plane is a rectangle with half extents scale / 2 (collide.py:452-453)
+    } else if (geo_type == GEO_PLANE) {
+        // finite plane: compute_tight_aabb_from_support on the rectangle with half extents scale / 2 (collide.py:448-465);
+        // its own branch so that the generic support map is not inlined six more times into every kernel
+        mat33 Rt = transpose(quat_to_matrix(q));
+        vec3 local_x(Rt.m00, Rt.m10, Rt.m20), local_y(Rt.m01, Rt.m11, Rt.m21), local_z(Rt.m02, Rt.m12, Rt.m22);
+        vec3 half(scale.x * 0.5f, scale.y * 0.5f, 0.0f);
+        float max_x = dot(local_x, support_map_plane(half, local_x));
+        float max_y = dot(local_y, support_map_plane(half, local_y));
+        float max_z = dot(local_z, support_map_plane(half, local_z));
+        float min_x = dot(local_x, support_map_plane(half, -local_x));
+        float min_y = dot(local_y, support_map_plane(half, -local_y));
+        float min_z = dot(local_z, support_map_plane(half, -local_z));
+        lo = vec3(min_x, min_y, min_z) + pos - mv;
+        hi = vec3(max_x, max_y, max_z) + pos + mv;
+        return;
+    } else if (geo_type == GEO_ELLIPSOID || geo_type == GEO_CONE) {
+        // compute_tight_aabb_from_support (collision_core.py:454-547): six support evaluations in local space
         mat33 Rt = transpose(quat_to_matrix(q));
         vec3 local_x(Rt.m00, Rt.m10, Rt.m20), local_y(Rt.m01, Rt.m11, Rt.m21), local_z(Rt.m02, Rt.m12, Rt.m22);
         Geom g;
         g.type = geo_type;
-        g.scale = geo_type == GEO_PLANE ? vec3(scale.x * 0.5f, scale.y * 0.5f, 0.0f) : scale;
+        g.scale = scale;
         float max_x = dot(local_x, support_map(g, local_x));
         float max_y = dot(local_y, support_map(g, local_y));
         float max_z = dot(local_z, support_map(g, local_z));

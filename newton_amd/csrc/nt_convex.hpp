@@ -65,16 +65,18 @@ NT_DEV vec3 support_map_box(const Geom& g, vec3 d) {
     return vec3(sx * g.scale.x, sy * g.scale.y, sz * g.scale.z);
 }
 
+// support_function.py:334-345: finite plane = rectangle in XY (half-width scale.x, half-length scale.y), normal +Z
+NT_DEV vec3 support_map_plane(vec3 half, vec3 direction) {
+    float sx = direction.x >= 0.0f ? 1.0f : -1.0f;
+    float sy = direction.y >= 0.0f ? 1.0f : -1.0f;
+    return vec3(sx * half.x, sy * half.y, 0.0f);
+}
+
 // support_function.py:131-350
 NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
-    if (g.type == GEO_PLANE) {
-        // support_function.py:334-345: finite rectangle in XY (half-width scale.x, half-length scale.y), normal +Z
-        float sx = direction.x >= 0.0f ? 1.0f : -1.0f;
-        float sy = direction.y >= 0.0f ? 1.0f : -1.0f;
-        return vec3(sx * g.scale.x, sy * g.scale.y, 0.0f);
-    }
+    if (g.type == GEO_PLANE) return support_map_plane(g.scale, direction);
     if (g.type == GEO_CONVEX_MESH) {
         // support_function.py:152-171: furthest vertex; ties keep the first one
         vec3 scaled_dir = cw_mul(direction, g.scale);

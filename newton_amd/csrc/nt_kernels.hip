@@ -401,13 +401,14 @@ static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, 
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     auto fits = [&](int epb) { return (size_t)F.rows * 4 * epb + shared_ints * 4 <= LDS_BYTES_PER_CU; };
     int epb = 0;
-    if (envs_per_block == 4 || envs_per_block == 8 || envs_per_block == 16) {
+    if (envs_per_block == 1 || envs_per_block == 4 || envs_per_block == 8 || envs_per_block == 16) {
         epb = fits(envs_per_block) ? envs_per_block : 0;
     } else {
         // measured on MI355X (4096 quadrupeds): 4 envs per workgroup (16 cooperating lanes per env in the Cholesky wave,
-        // two resident workgroups per CU) beats 8; 16 rarely fits
-        const int cands[3] = {4, 8, 16};
-        for (int i = 0; i < 3 && !epb; ++i)
+        // two resident workgroups per CU) beats 8; 16 rarely fits; articulations too large for 4 (P + H alone are
+        // (6 nj + nd) x max_art_dofs floats per environment) run one environment per workgroup, 64 lanes in the Cholesky wave
+        const int cands[4] = {4, 8, 16, 1};
+        for (int i = 0; i < 4 && !epb; ++i)
             if (fits(cands[i])) epb = cands[i];
     }
     if (!epb) return NT_ERR_UNSUPPORTED;
@@ -429,12 +430,17 @@ static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, 
     if (!rollout) {
         if (epb == 16) return go(featherstone_step_kernel<16>);
         if (epb == 8) return go(featherstone_step_kernel<8>);
-        return go(featherstone_step_kernel<4>);
+        if (epb == 4) return go(featherstone_step_kernel<4>);
+        return go(featherstone_step_kernel<1>);
     }
-    if (cvx) return epb == 8 ? go(featherstone_rollout_kernel<8, true>) : go(featherstone_rollout_kernel<4, true>);
+    if (cvx) {
+        if (epb == 8) return go(featherstone_rollout_kernel<8, true>);
+        return epb == 4 ? go(featherstone_rollout_kernel<4, true>) : go(featherstone_rollout_kernel<1, true>);
+    }
     if (epb == 16) return go(featherstone_rollout_kernel<16, false>);
     if (epb == 8) return go(featherstone_rollout_kernel<8, false>);
-    return go(featherstone_rollout_kernel<4, false>);
+    if (epb == 4) return go(featherstone_rollout_kernel<4, false>);
+    return go(featherstone_rollout_kernel<1, false>);
 }
 
 static bool fs_state_ok(const nt_state* s) { return s && s->joint_q && s->joint_qd && s->body_q && s->body_qd; }
@@ -490,8 +496,8 @@ nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint
     const FsLayout F = make_fs_layout(*m, make_layout(*m, false));
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     int epb = 0;
-    const int cands[3] = {16, 8, 4};
-    for (int i = 0; i < 3 && !epb; ++i)
+    const int cands[4] = {16, 8, 4, 1};
+    for (int i = 0; i < 4 && !epb; ++i)
         if ((size_t)F.rows * 4 * cands[i] + shared_ints * 4 <= LDS_BYTES_PER_CU) epb = cands[i];
     if (!epb) return NT_ERR_UNSUPPORTED;
     int want = imax(m->nb, m->nj), cap = 256 / epb;
@@ -508,7 +514,8 @@ nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint
     };
     if (epb == 16) return go(eval_fk_kernel<16>);
     if (epb == 8) return go(eval_fk_kernel<8>);
-    return go(eval_fk_kernel<4>);
+    if (epb == 4) return go(eval_fk_kernel<4>);
+    return go(eval_fk_kernel<1>);
 }
 
 #ifdef NT_PHASE_TIMING

@@ -407,3 +407,40 @@ def test_finite_plane(H):
     H.xpbd_step(em, s0, s1, ctrl, ct, 1e-3)
     o.xpbd_step(os0, os1, o.control(), oc, 1e-3)
     assert _close(s1.aos("body_q"), os1.body_q, 1e-5)
+
+
+def test_featherstone_large_articulation_one_environment_per_workgroup(H):
+    """A 40-link serial chain (40 dofs): P and H alone are (6 nj + nd) x 40 floats, 73 KB of LDS per environment, so the solver
+    runs one environment per workgroup with all 64 lanes of the Cholesky wave on it; bit-identical to the oracle."""
+    import ctypes as C
+
+    from oracle_bridge import Oracle, OracleState
+
+    b = nt.ModelBuilder()
+    prev, joints = -1, []
+    rng = np.random.default_rng(0)
+    cfg = nt.ModelBuilder.ShapeConfig(has_shape_collision=False)
+    for k in range(40):
+        link = b.add_link()
+        b.add_shape_capsule(link, radius=0.02, half_height=0.05, cfg=cfg)
+        joints.append(b.add_joint_revolute(prev, link, axis=[(1, 0, 0), (0, 1, 0), (0, 0, 1)][k % 3],
+                                           parent_xform=[0.0, 0.0, 0.12 if k else 2.0, 0.0, 0.0, 0.0, 1.0],
+                                           target_ke=5.0, target_kd=0.5, armature=0.01))
+        prev = link
+    b.add_articulation(joints)
+    scene = nt.ModelBuilder()
+    scene.replicate(b, 3)
+    model = scene.finalize()
+    model.joint_q = rng.uniform(-0.3, 0.3, size=model.joint_coord_count).astype(np.float32)
+    model.joint_qd = rng.normal(0.0, 0.3, size=model.joint_dof_count).astype(np.float32)
+    em = H.EmuModel(model)
+    assert 4 * H.lib().nt_featherstone_lds_bytes_per_env(C.byref(em.desc)) > 160 * 1024  # four environments do not fit
+    s0, s1, ctrl = H.EmuState(em), H.EmuState(em), H.EmuControl(em)
+    o = Oracle(model)
+    os0, os1 = OracleState(model), OracleState(model)
+    for _ in range(3):
+        H.featherstone_step(em, s0, s1, ctrl, None, 1e-3)
+        o.featherstone_step(os0, os1, o.control(), None, 1e-3)
+        s0, s1, os0, os1 = s1, s0, os1, os0
+    for name in ("joint_q", "joint_qd", "body_q", "body_qd"):
+        assert _close(s0.aos(name), getattr(os0, name), TOL), name
