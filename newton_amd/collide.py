@@ -186,6 +186,8 @@ class CollisionPipeline:
             raise ValueError(f"broad_phase must be one of 'nxn', 'sap', 'explicit', got {broad_phase!r}")
         self.model = model
         self.dm = model.device_model()  # raises loudly without GPU / extension
+        if model.env.np > 0:
+            self.dm.require_fit("CollisionPipeline")
         self.broad_phase = broad_phase or "explicit"
         self.params = _lib.nt_collide_params(self._BROAD_PHASES[broad_phase], int(envs_per_block))
         t = model.env

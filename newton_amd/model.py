@@ -363,6 +363,17 @@ class DeviceModel:
             setattr(d, k, v.data_ptr())
         choose_contact_scratch(self.lib, d)
         self.desc = d
+        # environments per workgroup the collide / XPBD / SemiImplicit kernels will use (0: the working set of one
+        # environment does not fit the CU's LDS in either mode)
+        self.envs_per_block = int(self.lib.nt_pick_envs_per_block(C.byref(d), 0))
+        self.lds_bytes_per_env = int(self.lib.nt_lds_bytes_per_env(C.byref(d)))
+
+    def require_fit(self, what: str):
+        if self.envs_per_block == 0:
+            raise NotImplementedError(
+                f"{what}: one environment of this model needs {self.lds_bytes_per_env / 1024:.0f} KB of LDS (plus its topology "
+                "tables) and the CU has 160 KB; the scene is too large for the LDS-resident kernels of this build "
+                f"({self.t.nb} bodies, {self.t.ns} shapes, {self.t.np} candidate pairs per environment)")
 
     def upload_params(self, model: Model):
         """(Re)build the per-env parameter SoA arrays from the model's AoS numpy arrays."""

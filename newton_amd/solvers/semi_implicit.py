@@ -18,6 +18,7 @@ class SolverSemiImplicit(SolverBase):
     def __init__(self, model, *, angular_damping: float = 0.05, friction_smoothing: float = 1.0, joint_attach_ke: float = 1.0e4,
                  joint_attach_kd: float = 1.0e2, enable_tri_contact: bool = True, envs_per_block: int = 0):
         super().__init__(model)
+        self.dm.require_fit("SolverSemiImplicit")
         self.angular_damping = angular_damping
         self.friction_smoothing = friction_smoothing
         self.joint_attach_ke = joint_attach_ke

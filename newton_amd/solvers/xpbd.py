@@ -20,6 +20,7 @@ class SolverXPBD(SolverBase):
                  angular_damping: float = 0.0, enable_restitution: bool = False, deterministic=None,
                  envs_per_block: int = 0):
         super().__init__(model)
+        self.dm.require_fit("SolverXPBD")
         self.iterations = iterations
         self.soft_body_relaxation = soft_body_relaxation
         self.soft_contact_relaxation = soft_contact_relaxation

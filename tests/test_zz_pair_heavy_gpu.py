@@ -43,3 +43,15 @@ def test_hull_bin_collide_step_and_rollout(n_hulls, n_env):
         solver.step(a, b, None, contacts, dt)
         a, b = b, a
     assert np.array_equal(out.body_q.cpu().numpy(), a.body_q.cpu().numpy())
+
+
+def test_scene_too_large_for_lds_is_rejected_with_numbers():
+    from scenes import hull_bin_scene
+
+    import newton_amd as nt
+
+    model = hull_bin_scene(1, 150, device="cuda:0")  # 11 925 pairs: the topology tables alone exceed the LDS
+    with pytest.raises(NotImplementedError, match="KB of LDS"):
+        nt.CollisionPipeline(model)
+    with pytest.raises(NotImplementedError, match="candidate pairs"):
+        nt.solvers.SolverXPBD(model)
