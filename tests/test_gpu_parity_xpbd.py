@@ -446,26 +446,3 @@ def test_reported_contact_force_and_parent_force_match_oracle(n_env, epb):
         t0, t1 = t1, t0
     assert np.array_equal(out.body_q.cpu().numpy(), t0.body_q.cpu().numpy())
     assert np.array_equal(out.body_parent_f.cpu().numpy(), t0.body_parent_f.cpu().numpy())
-
-
-def test_deterministic_mode_orders_contacts_by_sort_key():
-    """CollisionPipeline(deterministic=True): the flat contact arrays are sorted by the reference's contact key
-    (shape0, shape1, sub-contact index: contact_data.py:60-90); same contacts as the default append order."""
-    from scenes import mixed_primitive_scene
-
-    nt, model, o = _setup(mixed_primitive_scene, 6)
-    s0 = model.state()
-    plain, det = nt.CollisionPipeline(model), nt.CollisionPipeline(model, deterministic=True)
-    c0, c1 = plain.contacts(), det.contacts()
-    plain.collide(s0, c0)
-    det.collide(s0, c1)
-    n = int(c0.rigid_contact_count.cpu().numpy()[0])
-    assert n > 20 and int(c1.rigid_contact_count.cpu().numpy()[0]) == n
-    a0, a1 = c0.rigid_contact_shape0.cpu().numpy()[:n], c0.rigid_contact_shape1.cpu().numpy()[:n]
-    order = np.lexsort((np.arange(n), a1, a0))  # stable: sub-contact order inside a pair is the export order
-    assert not np.array_equal(order, np.arange(n))  # the append order (analytic first, then convex) is a different order
-    for name in ("shape0", "shape1", "point0", "point1", "normal", "margin0"):
-        want = getattr(c0, "rigid_contact_" + name).cpu().numpy()[:n][order]
-        assert np.array_equal(getattr(c1, "rigid_contact_" + name).cpu().numpy()[:n], want), name
-    key = c1.rigid_contact_shape0.cpu().numpy()[:n].astype(np.int64) * (1 << 20) + c1.rigid_contact_shape1.cpu().numpy()[:n]
-    assert np.all(np.diff(key) >= 0)

@@ -175,36 +175,3 @@ def test_eval_fk_mask_indices_and_body_flag_filter():
 
     with _pytest.raises(ValueError):
         run(mask=np.array([True, False, True]), indices=[0])
-
-
-@pytest.mark.gpu
-def test_eval_fk_selection_on_device():
-    """Same selections through the device path: full FK into a scratch State (one eval_fk_kernel launch), then the selected
-    body rows are copied."""
-    import newton_amd as nt
-
-    env = nt.ModelBuilder()
-    for k in range(2):
-        link = env.add_link(is_kinematic=(k == 1), mass=1.0)
-        env.add_shape_box(link, hx=0.1, hy=0.1, hz=0.1)
-        j = env.add_joint_revolute(-1, link, axis=(0, 0, 1), parent_xform=[float(k), 0.0, 0.0, 0.0, 0.0, 0.0, 1.0],
-                                   child_xform=[-0.5, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
-        env.add_articulation([j])
-    scene = nt.ModelBuilder()
-    scene.replicate(env, 5)
-    model = scene.finalize(device="cuda:0")
-    rng = np.random.default_rng(0)
-    q = rng.uniform(-1.0, 1.0, size=10).astype(np.float32)
-    qd = rng.normal(size=10).astype(np.float32)
-    full_q, full_qd = nt.articulation.eval_fk_numpy(model, q, qd)
-    base = model.state()
-    base_q = base.body_q.cpu().numpy().copy()
-    mask = rng.random(10) < 0.5
-    mask[0], mask[1] = True, False
-    for kw, sel in ((dict(mask=mask), mask), (dict(indices=np.flatnonzero(mask)), mask),
-                    (dict(body_flag_filter=nt.BodyFlags.KINEMATIC), np.arange(10) % 2 == 1)):
-        s = model.state()
-        nt.eval_fk(model, q, qd, s, **kw)
-        got_q, got_qd = s.body_q.cpu().numpy(), s.body_qd.cpu().numpy()
-        assert np.allclose(got_q[sel], full_q[sel], atol=1e-6) and np.allclose(got_qd[sel], full_qd[sel], atol=1e-5)
-        assert np.array_equal(got_q[~sel], base_q[~sel])
