@@ -8,9 +8,20 @@ frame of the reference's caller loop (newton/examples/basic/example_basic_urdf.p
 gfx950 rollout kernel (the CUDA-graph replacement).  env-steps/s = envs * substeps * steps / T  (Newton's
 world-steps/s, docs/guide/development.rst:818-824).
 
+The scene is PRE-SETTLED before any warm-up or timed step: the robots are lowered so that their feet touch the ground and
+--settle-frames untimed frames are run, so even a 20-step run measures the standing regime (16 live contacts per
+environment), not free fall.  The validity gate is the reference benchmark's (asv/benchmarks/simulation/
+bench_quadruped_xpbd.py:58-66 + example_basic_urdf.py:145-162): finite state, unit quaternions, body speeds <= 0.3,
+root height 0.46 +- 0.01.
+
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
-Environments shard embarrassingly: each rank owns its own 4096 envs, no data-path collective (weak scaling).
+Environments shard embarrassingly: ONE global model of N x 4096 environments is built (same seed on every rank) and rank r
+keeps worlds shard_range(total, r, N) of it (newton_amd.sharding.shard_model); no data-path collective (weak scaling).
+
+Secondary workloads (--workload; never the headline value): quadruped_convex (config C4's convex-convex variant),
+box_stack (C2), quadruped_featherstone (C3), hull_bin (C5's geometry through MPR/GJK).  --sweep runs the BASELINE.md
+section 5 env-count sweep of the headline workload and writes a table instead of the single JSON line.
 """
 from __future__ import annotations
 
@@ -29,16 +40,56 @@ import torch  # noqa: E402
 
 ENVS_PER_GPU = 4096
 SUBSTEPS = 10
-DT = 1e-3
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+BASE_ENVS = 4096        # larger shards are tiled from a 4096-env build (the Python builder needs ~0.7 ms per env)
+
+# name -> (scene function, solver, iterations, dt, dominant kernel, root drop [m], default settle frames, description)
+WORKLOADS = {
+    "quadruped": dict(solver="xpbd", iterations=2, dt=1e-3, kernel="xpbd_rollout_kernel<16,false>", drop=0.22, settle=100,
+                      name="Anymal-class quadruped (in-repo stand-in geometry: 13 bodies, 12 revolute + free base, "
+                           "13 cylinder colliders + ground plane)"),
+    "quadruped_convex": dict(solver="xpbd", iterations=2, dt=1e-3, kernel="xpbd_rollout_kernel<16,true>", drop=0.22, settle=100,
+                             name="C4 convex-convex variant: the same quadruped with box links on a static box slab "
+                                  "(13 box-box pairs per env through MPR/GJK + manifold)"),
+    "quadruped_featherstone": dict(solver="featherstone", iterations=0, dt=1e-3, kernel="featherstone_rollout_kernel<4,false>",
+                                   drop=0.22, settle=100,
+                                   name="C3: Anymal-class quadruped, SolverFeatherstone (generalized coordinates, LDS-resident "
+                                        "mass matrix), cylinder colliders + ground plane"),
+    "box_stack": dict(solver="xpbd", iterations=4, dt=1.0 / 240.0, kernel="xpbd_rollout_kernel<16,true>", drop=0.0, settle=10,
+                      name="C2: 8-box stack on a ground plane (box-box pairs through MPR/GJK + manifold)"),
+    "hull_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 600.0, kernel="xpbd_rollout_kernel<1,true,true>", drop=0.0, settle=30,
+                     name="C5 geometry without SDF / hydroelastic: 64 convex hulls (16-32 vertices) in a five-wall bin, all "
+                          "2 336 pairs per env through MPR/GJK + manifold, contact records in HBM"),
+}
 
 
-def algorithmic_bytes_per_env_step(t, contacts_per_env: float) -> float:
+def algorithmic_bytes_per_env_step(t, contacts_per_env: float, generalized: bool = False) -> float:
     """Compulsory HBM bytes if each env's working set is touched once per substep:
     state_in 76B + state_out 52B + clear_forces 24B + body params 100B per body, 85 B/joint, 40 B/dof,
-    72 B/shape (incl. the shared plane), 8 B/pair, 2*80 B per contact (write + read of the Contacts boundary)."""
+    72 B/shape (incl. the shared plane), 8 B/pair, 2*80 B per contact (write + read of the Contacts boundary);
+    generalized-coordinate solvers add joint_q / joint_qd in + out."""
     B, J, D, S, P = t.nb, t.nj, t.nd, t.ns + t.ng, t.np
-    return (76 + 52 + 24 + 100) * B + 85 * J + 40 * D + 72 * S + 8 * P + 160.0 * contacts_per_env
+    extra = 2 * (t.nc + t.nd) * 4 if generalized else 0
+    return (76 + 52 + 24 + 100) * B + 85 * J + 40 * D + 72 * S + 8 * P + 160.0 * contacts_per_env + extra
+
+
+def build_id() -> str:
+    from newton_amd import _lib
+
+    return _lib.load().nt_build_info().decode()
+
+
+def measured_traffic(workload: str, envs: int):
+    """HBM bytes per launch from the PMC passes (tools/pmc_traffic.py), only if they were taken on THIS build of the
+    library (same nt_build_info source hash) for this workload and env count; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(f"{workload}@{envs}")
+        if rec and rec.get("build_id") == build_id():
+            return rec
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(envs_per_core=256, sample_substeps=2500, max_cores=32):
@@ -58,7 +109,7 @@ def cpu_baseline(envs_per_core=256, sample_substeps=2500, max_cores=32):
 
     def run(shard):
         o, s0, s1, ct, ctrl = shard
-        o.xpbd_rollout(s0, s1, ctrl, ct, DT, sample_substeps)  # the whole loop in one foreign call (GIL released)
+        o.xpbd_rollout(s0, s1, ctrl, ct, 1e-3, sample_substeps)  # the whole loop in one foreign call (GIL released)
 
     threads = [threading.Thread(target=run, args=(sh,)) for sh in shards]
     t0 = time.perf_counter()
@@ -74,6 +125,139 @@ def cpu_baseline(envs_per_core=256, sample_substeps=2500, max_cores=32):
     }
 
 
+def build_shard(workload: str, envs_per_gpu: int, rank: int, world: int, device: str):
+    """This rank's shard of ONE global model (same seeds on every rank), sliced with shard_range; shards above BASE_ENVS
+    environments are tiled from the rank's BASE_ENVS-env slice (10^5..10^6 envs would take minutes in the Python builder)."""
+    import newton_amd as nt
+    from newton_amd.sharding import shard_model
+    from newton_amd.worlds import tile_worlds
+    import scenes
+
+    base = min(envs_per_gpu, BASE_ENVS)
+    if envs_per_gpu % base:
+        raise SystemExit(f"--envs-per-gpu above {BASE_ENVS} must be a multiple of it")
+    total = base * world
+    if workload in ("quadruped", "quadruped_featherstone"):
+        g = scenes.quadruped_scene(total, seed=1)
+    elif workload == "quadruped_convex":
+        g = scenes.quadruped_convex_scene(total, seed=1)
+    elif workload == "box_stack":
+        g = scenes.box_stack_scene(total, seed=1)
+    else:
+        g = scenes.hull_bin_scene(total, 64, seed=2)
+    drop = WORKLOADS[workload]["drop"]
+    if drop > 0.0:  # feet onto the ground: the free fall from z = 0.7 is not the regime the metric is quoted on
+        g.joint_q.reshape(total, -1)[:, 2] -= drop
+        g.body_q, g.body_qd = nt.articulation.eval_fk_numpy(g, g.joint_q, g.joint_qd)
+    m = shard_model(g, rank, world, device=device)
+    if envs_per_gpu > base:
+        m = tile_worlds(m, envs_per_gpu // base, device=device, filter_pairs=False)
+    return m
+
+
+def validity_gate(workload: str, model, state) -> dict:
+    """asv/benchmarks/benchmark_metrics.py:67-99 (finite, |quat| = 1 +- 1e-3, speed bounds 0.3 from
+    bench_quadruped_xpbd.py:58-66) + example_basic_urdf.py:145-162 (root height 0.46 +- 0.01) for the quadruped workloads."""
+    q, qd = state.body_q, state.body_qd
+    finite = bool(torch.isfinite(q).all()) and bool(torch.isfinite(qd).all())
+    quat_err = float((q[:, 3:].norm(dim=1) - 1.0).abs().max())
+    lin = float(qd[:, :3].norm(dim=1).max())
+    ang = float(qd[:, 3:].norm(dim=1).max())
+    gate = {"finite": finite, "max_quat_norm_error": quat_err, "max_linear_speed": lin, "max_angular_speed": ang}
+    ok = finite and quat_err < 1e-3
+    if workload.startswith("quadruped"):
+        nb = model.env.nb
+        root_z = q[::nb, 2]
+        gate["root_height_min"], gate["root_height_max"] = float(root_z.min()), float(root_z.max())
+        gate["speed_limit"], gate["root_height_target"] = 0.3, [0.45, 0.47]
+        if workload == "quadruped":  # the reference's gate is stated for this scene
+            ok = ok and lin <= 0.3 and ang <= 0.3 and gate["root_height_min"] > 0.45 and gate["root_height_max"] < 0.47
+    gate["ok"] = bool(ok)
+    return gate
+
+
+def run(args, rank, local_rank, world, dist):
+    import newton_amd as nt
+    from newton_amd.sharding import max_over_ranks
+
+    W = WORKLOADS[args.workload]
+    device = f"cuda:{local_rank}"
+    model = build_shard(args.workload, args.envs_per_gpu, rank, world, device)
+    dt = W["dt"]
+    s0, s1 = model.state(), model.state()
+    ctrl = model.control()
+    pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block)
+    contacts = pipe.contacts()
+    if W["solver"] == "featherstone":
+        solver = nt.solvers.SolverFeatherstone(model, envs_per_block=args.envs_per_block)
+    else:
+        solver = nt.solvers.SolverXPBD(model, iterations=W["iterations"], envs_per_block=args.envs_per_block)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    settle = W["settle"] if args.settle_frames < 0 else args.settle_frames
+    for _ in range(settle):  # untimed, outside warm-up: reach the standing regime
+        solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
+    for _ in range(args.warmup):
+        solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
+    ev1.record()
+    barrier()
+    T = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream (torch current stream)
+    T = max_over_ranks(T, device=device)  # MAX over ranks (no-op at N=1)
+
+    gate = validity_gate(args.workload, model, s0)
+    c_per_env = float(contacts.rigid_contact_count_per_env.float().mean().item())
+    if rank != 0:
+        return None
+    t = model.env
+    total_env_steps = world * args.envs_per_gpu * SUBSTEPS * args.steps
+    bytes_per_env_step = algorithmic_bytes_per_env_step(t, c_per_env, W["solver"] == "featherstone")
+    launch_bytes = bytes_per_env_step * args.envs_per_gpu * SUBSTEPS
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    epb = int(model.device_model().envs_per_block) if W["solver"] != "featherstone" else 4
+    kernel = W["kernel"].replace("<16,", f"<{epb},") if W["solver"] != "featherstone" else W["kernel"]
+    roof = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms,
+        "frac_algorithmic": achieved / HBM_PEAK_GBPS, "frac_measured": None,
+        "algorithmic_bytes_per_env_step": bytes_per_env_step, "algorithmic_bytes_per_launch": launch_bytes,
+        "build_id": build_id(),
+    }
+    rec = measured_traffic(args.workload, args.envs_per_gpu)
+    if rec is not None:  # counters taken on this very build (tools/pmc_traffic.py): bytes that really moved
+        roof["traffic"] = rec["bytes_per_launch"]
+        roof["frac_measured"] = min(rec["bytes_per_launch"], launch_bytes) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        roof["traffic_source"] = "profiles/r02_pmc_traffic.json"
+    out = {
+        "metric": "env-steps/sec at 4096 batched envs (Anymal, XPBD)", "value": total_env_steps / T, "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * T / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "valid_state": gate["ok"], "validity_gate": gate,
+        "config": {
+            "workload": f"{W['name']}, " + ("SolverFeatherstone defaults" if W["solver"] == "featherstone"
+                                            else f"SolverXPBD iterations={W['iterations']}") + f", dt={dt:.6g}, "
+                        f"{args.envs_per_gpu} envs per GPU, pre-settled ({settle} untimed frames, feet on the ground), "
+                        f"1 step = 1 frame = {SUBSTEPS} substeps of clear_forces+collide+step fused in one rollout launch",
+            "envs_per_gpu": args.envs_per_gpu, "substeps_per_step": SUBSTEPS, "parallelism": f"env-shard x{world}",
+            "mean_contacts_per_env": c_per_env, "settle_frames": settle,
+        },
+        "roofline": roof,
+    }
+    if args.workload != "quadruped":
+        out["metric"] = f"env-steps/sec, {args.workload} (secondary; not the BASELINE.json metric)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,10 +265,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--envs-per-block", type=int, default=0)
+    ap.add_argument("--settle-frames", type=int, default=-1, help="untimed frames before warm-up (-1: the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["quadruped", "box_stack", "quadruped_featherstone", "hull_bin"], default="quadruped",
-                    help="quadruped = the BASELINE.json metric (default); box_stack = config C2 (convex MPR/GJK path), "
-                         "a secondary measurement that is never the headline value")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="quadruped",
+                    help="quadruped = the BASELINE.json metric (default); the others are secondary measurements")
+    ap.add_argument("--sweep", default="", help="comma-separated env counts (e.g. 4096,16384,65536,262144,1048576): run the "
+                    "headline workload at each size on one GPU and print one JSON line per size + write --sweep-out")
+    ap.add_argument("--sweep-out", default=os.path.join(ROOT, "gpurun_out", "env_sweep.json"))
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,107 +287,31 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    import newton_amd as nt
-    from scenes import quadruped_scene
-
-    # every rank owns its own shard of environments (distinct seed => distinct per-env jitter)
-    if args.workload in ("quadruped", "quadruped_featherstone"):
-        model = quadruped_scene(args.envs_per_gpu, device=f"cuda:{local_rank}", seed=1 + rank)
-        iterations, workload_name = 2, (
-            "Anymal-class quadruped (in-repo stand-in geometry: 13 bodies, 12 revolute + free base, "
-            "13 cylinder colliders + ground plane)")
-    elif args.workload == "hull_bin":
-        from scenes import hull_bin_scene
-
-        # C5 without the SDF / hydroelastic contact models: 64 hulls in a five-wall bin, 2 336 candidate pairs per env
-        # (pass --envs-per-gpu 2048 for the BASELINE.json size; contact records then take ~3 GB of HBM)
-        model = hull_bin_scene(args.envs_per_gpu, 64, device=f"cuda:{local_rank}", seed=2 + rank)
-        iterations, workload_name = 2, ("C5 geometry without SDF / hydroelastic: 64 convex hulls (16-32 vertices) in a five-wall "
-                                        "bin, all 2 336 pairs per env through MPR/GJK + manifold, contact records in HBM")
+    if args.sweep:
+        rows = []
+        for n in [int(x) for x in args.sweep.split(",")]:
+            args.envs_per_gpu = n
+            steps = max(20, min(args.steps, int(2.0e8 / (n * SUBSTEPS))))  # ~2e8 env-steps per size
+            a = argparse.Namespace(**{**vars(args), "steps": steps, "warmup": min(args.warmup, 20)})
+            out = run(a, rank, local_rank, world, dist)
+            torch.cuda.empty_cache()
+            if out is not None:
+                r = out["roofline"]
+                rows.append({"envs_per_gpu": n, "steps": steps, "env_steps_per_s": out["value"], "kernel_ms": r["kernel_ms"],
+                             "frac_algorithmic": r["frac_algorithmic"], "frac_measured": r["frac_measured"],
+                             "traffic": r["traffic"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                             "mean_contacts_per_env": out["config"]["mean_contacts_per_env"], "valid_state": out["valid_state"],
+                             "kernel": r["kernel"]})
+                print(json.dumps(rows[-1]), flush=True)
+        if rank == 0:
+            os.makedirs(os.path.dirname(args.sweep_out), exist_ok=True)
+            json.dump({"workload": args.workload, "build_id": build_id(), "rows": rows}, open(args.sweep_out, "w"), indent=1)
     else:
-        from scenes import box_stack_scene
-
-        model = box_stack_scene(args.envs_per_gpu, device=f"cuda:{local_rank}", seed=1 + rank)
-        iterations, workload_name = 4, "C2: 8-box stack on a ground plane (box-box pairs through MPR/GJK + manifold)"
-    s0, s1 = model.state(), model.state()
-    ctrl = model.control()
-    pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block)
-    contacts = pipe.contacts()
-    if args.workload == "quadruped_featherstone":
-        # C3: clear_forces; collide; SolverFeatherstone.step; swap
-        fs = nt.solvers.SolverFeatherstone(model, envs_per_block=args.envs_per_block)
-        workload_name = workload_name.replace("SolverXPBD", "SolverFeatherstone")
-
-        solver = fs  # SolverFeatherstone.rollout: the same loop fused into one launch
-    else:
-        solver = nt.solvers.SolverXPBD(model, iterations=iterations, envs_per_block=args.envs_per_block)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        solver.rollout(s0, s1, ctrl, contacts, DT, SUBSTEPS)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        solver.rollout(s0, s1, ctrl, contacts, DT, SUBSTEPS)
-    ev1.record()
-    barrier()
-    T = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream (torch current stream)
-
-    from newton_amd.sharding import max_over_ranks
-
-    T = max_over_ranks(T, device=f"cuda:{local_rank}")  # MAX over ranks (no-op at N=1)
-
-    # validity gate of the reference benchmark (asv/benchmarks/benchmark_metrics.py:67-99): finite state,
-    # normalised quaternions
-    q = s0.body_q
-    ok = bool(torch.isfinite(q).all()) and bool(((q[:, 3:].norm(dim=1) - 1.0).abs() < 1e-3).all())
-    c_per_env = float(contacts.rigid_contact_count_per_env.float().mean().item())
-
-    if rank == 0:
-        t = model.env
-        total_env_steps = world * args.envs_per_gpu * SUBSTEPS * args.steps
-        value = total_env_steps / T
-        bytes_per_env_step = algorithmic_bytes_per_env_step(t, c_per_env)
-        launch_bytes = bytes_per_env_step * args.envs_per_gpu * SUBSTEPS
-        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("xpbd_rollout_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "env-steps/sec at 4096 batched envs (Anymal, XPBD)", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * T / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "valid_state": ok,
-            "config": {
-                "workload": f"{workload_name}, " + ("SolverFeatherstone defaults" if args.workload == "quadruped_featherstone"
-                                                    else f"SolverXPBD iterations={iterations}") + ", dt=1e-3, "
-                            f"{args.envs_per_gpu} envs per GPU, 1 step = 1 frame = {SUBSTEPS} substeps of "
-                            "clear_forces+collide+step fused in one rollout launch",
-                "envs_per_gpu": args.envs_per_gpu, "substeps_per_step": SUBSTEPS, "parallelism": f"env-shard x{world}",
-                "mean_contacts_per_env": c_per_env,
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "kernel": "xpbd_rollout_kernel", "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_env_step": bytes_per_env_step, "algorithmic_bytes_per_launch": launch_bytes,
-            },
-        }
-        if args.workload != "quadruped":
-            out["metric"] = f"env-steps/sec, {args.workload} (secondary; not the BASELINE.json metric)"
-        if not args.no_cpu_baseline and world == 1 and args.workload == "quadruped":
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        out = run(args, rank, local_rank, world, dist)
+        if out is not None:
+            if not args.no_cpu_baseline and world == 1 and args.workload == "quadruped":
+                out["cpu_baseline"] = cpu_baseline()
+            print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -96,18 +96,27 @@ class Contacts:
             e["shape1"].data_ptr(), e["point0"].data_ptr(), e["point1"].data_ptr(), e["offset0"].data_ptr(),
             e["offset1"].data_ptr(), e["normal"].data_ptr(), e["margin0"].data_ptr(), e["margin1"].data_ptr(),
             self._scan.data_ptr(), dm.stream()), "nt_contacts_export")
+        self._sort_order = None
         if self.sort_by_key:
             n = min(int(e["count"].item()), cap)
             if n > 1:
                 # a pair's contacts are exported consecutively in sub-contact order, so a stable sort on (shape0, shape1)
-                # is the sort on the full key
-                key = e["shape0"][:n].to(torch.int64) * (1 << 20) + e["shape1"][:n].to(torch.int64)
+                # is the sort on the full key; 32 bits per id (the reference packs 20: contact_data.py:60-90, which
+                # aliases beyond 2^20 shapes)
+                key = e["shape0"][:n].to(torch.int64) * (1 << 32) + e["shape1"][:n].to(torch.int64)
                 order = torch.sort(key, stable=True).indices
                 for k, v in e.items():
                     if k != "count":
                         v[:n] = v[:n][order]
+                self._sort_order = order  # SolverXPBD.update_contacts applies the same permutation to Contacts.force
         self._export, self._export_generation = e, self._generation
         return e
+
+    def export_order(self):
+        """Permutation from the raw append order to the order of the rigid_contact_* arrays (None = identity): row i of the
+        flat arrays is raw row export_order()[i].  Non-trivial only with CollisionPipeline(deterministic=True)."""
+        self._exported()
+        return self._sort_order
 
     rigid_contact_count = property(lambda self: self._exported()["count"])
     rigid_contact_shape0 = property(lambda self: self._exported()["shape0"])

@@ -375,9 +375,42 @@ class DeviceModel:
                 "tables) and the CU has 160 KB; the scene is too large for the LDS-resident kernels of this build "
                 f"({self.t.nb} bodies, {self.t.ns} shapes, {self.t.np} candidate pairs per environment)")
 
+    def refresh_flags(self, model: Model):
+        """Re-derive the env-uniform flag tables a runtime edit may touch (body_flags, joint_enabled, shape_flags,
+        shape_collision_group) and copy them into the resident topology tensors; edits that break the uniformity or change
+        the topology itself (parents, types, pairs) raise, because the kernels' tables were built for the old one."""
+        t = self.t
+        E, nb, nj, ns = t.env_count, t.nb, t.nj, t.ns
+        L0 = t.shape_local0
+
+        def uniform(a, n, what):
+            a = np.asarray(a).reshape(E, n) if n else np.zeros((E, 0), dtype=np.int32)
+            if E > 1 and not np.all(a == a[0:1]):
+                raise NotImplementedError(f"heterogeneous worlds: {what} differs between worlds after a runtime edit")
+            return a[0].astype(np.int32)
+
+        def shape_tab(a, what):
+            a = np.asarray(a)
+            return np.concatenate([uniform(a[L0:L0 + E * ns], ns, what), a[t.gshape_id].astype(np.int32)])
+
+        new = {"body_flags": uniform(model.body_flags, nb, "body_flags"),
+               "joint_enabled": uniform(np.asarray(model.joint_enabled, dtype=np.int32), nj, "joint_enabled"),
+               "shape_flags": shape_tab(model.shape_flags, "shape_flags"),
+               "shape_group": shape_tab(model.shape_collision_group, "shape_collision_group")}
+        torch = _torch()
+        for k, v in new.items():
+            if not np.array_equal(v, getattr(t, k)):
+                setattr(t, k, v)
+                if v.size:
+                    self.topology[k][: v.size].copy_(torch.from_numpy(v))
+        if nj and not np.array_equal(uniform(model.joint_type, nj, "joint_type"), t.joint_type):
+            raise NotImplementedError("joint_type changed after finalize(): rebuild the model (the kernels' topology tables "
+                                      "are static)")
+
     def upload_params(self, model: Model):
         """(Re)build the per-env parameter SoA arrays from the model's AoS numpy arrays."""
         torch = _torch()
+        self.refresh_flags(model)
         new = pack_param_arrays(model, self.t)
         for k, v in new.items():
             if v.size == 0:

@@ -24,6 +24,18 @@ def shard_range(total_envs: int, rank: int, world: int) -> tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def shard_model(model, rank: int, world: int, device=None):
+    """Rank `rank`'s shard of a global model: worlds shard_range(world_count, rank, world) plus the shared (world -1) shapes,
+    as a self-contained Model (newton_amd.worlds.slice_worlds).  Stepping the shards independently and concatenating their
+    states in rank order is bitwise the unsharded result (tests/test_shard_equivalence.py)."""
+    from .worlds import slice_worlds  # noqa: PLC0415
+
+    b, e = shard_range(model.world_count, rank, world)
+    if e <= b:
+        raise ValueError(f"rank {rank} of {world} owns no environment of a {model.world_count}-world model")
+    return slice_worlds(model, b, e, device=device)
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """MAX all-reduce of a host scalar (the bench's timing contract). No-op without a process group."""
     import torch  # noqa: PLC0415

@@ -90,6 +90,12 @@ class SolverXPBD(SolverBase):
                                                    float(self._last_dt), int(contacts.rigid_contact_max),
                                                    contacts.force.data_ptr(), contacts._scan.data_ptr(), dm.stream()),
                    "nt_contacts_export_force")
+        # CollisionPipeline(deterministic=True) re-orders the rigid_contact_* rows by the contact key: force[i] must stay the
+        # force of rigid_contact_shape0/1[i] (the reference sorts before the solver runs, so its indices agree by construction)
+        order = contacts.export_order()
+        if order is not None:
+            n = order.numel()
+            contacts.force[:n] = contacts.force[:n][order]
 
     def rollout(self, state_0, state_1, control, contacts, dt: float, substeps: int, collide_params=None):
         """substeps x {clear_forces; collide; step; swap} in one launch.  Returns the state object holding the

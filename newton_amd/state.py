@@ -110,7 +110,12 @@ def _aos_property(name):
 
 
 class State(_SoAContainer):
-    """Time-varying simulation state (state.py:113-171): body_q [B,7], body_qd [B,6], body_f [B,6], joint_q, joint_qd."""
+    """Time-varying simulation state (state.py:113-171): body_q [B,7], body_qd [B,6], body_f [B,6], joint_q, joint_qd.
+
+    On a GPU model the resident arrays are env-major SoA and READING an attribute (``state.body_q``) materialises a fresh AoS
+    copy: in-place edits of that copy (``state.body_q[i] = x``, ``.copy_()``) do NOT reach the device state.  Write whole
+    arrays through the setter (``state.body_q = new_q``), or use ``State.reset`` / ``ArticulationView`` setters for masked
+    updates; host models hold plain numpy arrays that are writable in place."""
 
     _FIELDS = {
         "body_q": (7, "nb", "body_q"),
@@ -171,6 +176,11 @@ class State(_SoAContainer):
         else:
             for k in self._host:
                 self._host[k] = other._host[k].copy()
+        if self._parent_f is not None and other._parent_f is not None:  # extended attribute travels with the state
+            if self.model.is_gpu:
+                self._parent_f.copy_(other._parent_f)
+            else:
+                self._parent_f[...] = other._parent_f
 
     def reset(self, source: State, world_mask=None):
         """RL-style reset: copy ``source`` (e.g. a default state) into the worlds selected by ``world_mask``
@@ -228,11 +238,21 @@ class Control(_SoAContainer):
     joint_target_q = _aos_property("joint_target_q")
     joint_target_qd = _aos_property("joint_target_qd")
 
-    def clear(self):
-        if self.model.is_gpu:
-            self._soa["joint_f"].zero_()
+    def clear(self, model=None):
+        """control.py:76-105: zero joint_f and joint_target_qd; joint_target_q is restored from ``model.joint_target_q`` when a
+        model is passed (zeroing it would corrupt the quaternion slots of FREE / BALL / DISTANCE joints under the coord
+        layout) and zero-filled otherwise."""
+        for name in ("joint_f", "joint_target_qd"):
+            if self.model.is_gpu:
+                self._soa[name].zero_()
+            else:
+                self._host[name][...] = 0.0
+        if model is not None and getattr(model, "joint_target_q", None) is not None:
+            self.joint_target_q = model.joint_target_q
+        elif self.model.is_gpu:
+            self._soa["joint_target_q"].zero_()
         else:
-            self._host["joint_f"][...] = 0.0
+            self._host["joint_target_q"][...] = 0.0
 
     def _desc(self) -> _lib.nt_control:
         d = _lib.nt_control()

@@ -13,8 +13,24 @@ _LEGS = [("LF", 0.2999, 0.104, 1.0), ("RF", 0.2999, -0.104, -1.0), ("LH", -0.299
 _HALF_PI = "1.57079632679"
 
 
-def quadruped_urdf() -> str:
-    """Anymal-class stand-in: base cylinder + 4 x {HAA, THIGH, SHANK}."""
+def quadruped_urdf(colliders: str = "cylinder") -> str:
+    """Anymal-class stand-in: base cylinder + 4 x {HAA, THIGH, SHANK}.  colliders="box" swaps every
+    cylinder for its bounding box (config C4's convex-convex variant)."""
+    urdf = _quadruped_urdf_cylinders()
+    if colliders == "cylinder":
+        return urdf
+    if colliders != "box":
+        raise ValueError(colliders)
+    import re
+
+    def box(m):
+        length, radius = float(m.group(1)), float(m.group(2))
+        return f'<box size="{2 * radius} {2 * radius} {length}"/>'
+
+    return re.sub(r'<cylinder length="([0-9.]+)" radius="([0-9.]+)"/>', box, urdf)
+
+
+def _quadruped_urdf_cylinders() -> str:
     out = ['<?xml version="1.0" encoding="utf-8"?>', '<robot name="quadruped">',
            '<link name="base"><collision><origin rpy="0 %s 0" xyz="0 0 0"/><geometry><cylinder length="0.75" radius="0.1"/>'
            '</geometry></collision></link>' % _HALF_PI]
@@ -38,14 +54,14 @@ def quadruped_urdf() -> str:
     return "\n".join(out)
 
 
-def quadruped_builder():
+def quadruped_builder(colliders: str = "cylinder"):
     """The per-world builder of newton/examples/basic/example_basic_urdf.py:38-75 (XPBD branch)."""
     q = nt.ModelBuilder()
     q.default_joint_cfg.armature = 0.01
     q.default_joint_cfg.target_ke = 2000.0
     q.default_joint_cfg.target_kd = 1.0
     q.default_shape_cfg.mu = 1.0
-    q.add_urdf(quadruped_urdf(), xform=[0.0, 0.0, 0.7, 0.0, 0.0, 0.0, 1.0], floating=True, enable_self_collisions=False,
+    q.add_urdf(quadruped_urdf(colliders), xform=[0.0, 0.0, 0.7, 0.0, 0.0, 0.0, 1.0], floating=True, enable_self_collisions=False,
                ignore_inertial_definitions=True)
     for b in range(q.body_count):
         q.body_inertia[b] = q.body_inertia[b] + np.eye(3) * 0.01
@@ -56,13 +72,22 @@ def quadruped_builder():
     return q
 
 
-def quadruped_scene(world_count: int, device=None, seed: int | None = 1, height_jitter: float = 0.05):
+def quadruped_scene(world_count: int, device=None, seed: int | None = 1, height_jitter: float = 0.05,
+                    colliders: str = "cylinder", ground: str = "plane"):
     """C3/C4 scene: `world_count` quadrupeds + one global ground plane.  Per-env root-height jitter U(0, jitter)
-    (seeded) de-correlates the environments."""
-    q = quadruped_builder()
+    (seeded) de-correlates the environments.  colliders="box" + ground="box" is C4's convex-convex
+    variant: box links on a static 2 m x 2 m x 0.5 m slab whose top face is z = 0 (MPR portals on a 100 m slab are
+    conditioned 1e4 : 1 in fp32 -- a 6e-8 pose difference moved its contact normals by 7e-4), so all 13 candidate pairs of an
+    environment are box-box and go through MPR/GJK + the manifold (narrow_phase.py:642-655)."""
+    q = quadruped_builder(colliders)
     scene = nt.ModelBuilder()
     scene.replicate(q, world_count)
-    scene.add_ground_plane(cfg=q.default_shape_cfg)
+    if ground == "plane":
+        scene.add_ground_plane(cfg=q.default_shape_cfg)
+    elif ground == "box":
+        scene.add_shape_box(-1, xform=[0.0, 0.0, -0.25, 0.0, 0.0, 0.0, 1.0], hx=1.0, hy=1.0, hz=0.25, cfg=q.default_shape_cfg)
+    else:
+        raise ValueError(ground)
     model = scene.finalize(device=device)
     if seed is not None and height_jitter > 0.0:
         rng = np.random.default_rng(seed)
@@ -71,6 +96,11 @@ def quadruped_scene(world_count: int, device=None, seed: int | None = 1, height_
     bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
     model.body_q, model.body_qd = bq, bqd
     return model
+
+
+def quadruped_convex_scene(world_count: int, device=None, seed: int | None = 1, height_jitter: float = 0.05):
+    """Config C4, convex-convex variant (box links on a box slab)."""
+    return quadruped_scene(world_count, device=device, seed=seed, height_jitter=height_jitter, colliders="box", ground="box")
 
 
 def box_stack_scene(world_count: int, n_boxes: int = 8, device=None, seed: int | None = 0, jitter: float = 1e-3):
@@ -213,11 +243,16 @@ def joint_zoo_scene(world_count: int, device=None, seed: int | None = 0, free_ro
     return model
 
 
-def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2):
+def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.01):
     """Config C5 without the SDF / hydroelastic contact models: `n_hulls` random convex hulls (16-32 vertices, radius
     U(0.03, 0.06)) dropped into a five-wall bin (ground plane + four static boxes); every hull pair and every hull-wall pair
     is a candidate, so one environment has n(n-1)/2 + 5n pairs (2 336 for 64 hulls) and its per-contact solver records no
-    longer fit LDS (nt_model.contact_scratch_in_hbm)."""
+    longer fit LDS (nt_model.contact_scratch_in_hbm).  Every environment shares the hull set; `jitter` moves each hull of
+    each environment by U(-jitter, jitter) m in x, y, z (seeded), so the environments' contact sets differ.  More than 32
+    environments are produced by tiling a 32-environment build (newton_amd.worlds.tile_worlds) -- the Python builder
+    would spend minutes on 131 072 bodies."""
+    from newton_amd.worlds import slice_worlds, tile_worlds
+
     rng = np.random.default_rng(seed)
     env = nt.ModelBuilder()
     side = 0.07 * np.ceil(np.sqrt(n_hulls))
@@ -227,11 +262,22 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
         b = env.add_body(xform=[*rng.uniform(-0.5 * side, 0.5 * side, size=2), rng.uniform(0.05, 0.5),
                                 *nt._np_math.quat_rpy(*rng.uniform(-1.0, 1.0, size=3))])
         env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(pts))
+    base_count = min(world_count, 32)
     scene = nt.ModelBuilder()
-    scene.replicate(env, world_count)
+    scene.replicate(env, base_count)
     scene.add_ground_plane()
     w = 0.5 * side + 0.1
     for sx, sy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
         scene.add_shape_box(-1, xform=[w * sx, w * sy, 0.3, 0.0, 0.0, 0.0, 1.0], hx=0.03 if sx else w + 0.03,
                             hy=0.03 if sy else w + 0.03, hz=0.3)
-    return scene.finalize(device=device)
+    model = scene.finalize(device=device)
+    if world_count > base_count:
+        reps = -(-world_count // base_count)
+        model = tile_worlds(model, reps, device=device, filter_pairs=False)
+        if model.world_count != world_count:
+            model = slice_worlds(model, 0, world_count, device=device)
+    if jitter > 0.0:
+        off = np.random.default_rng(seed + 1000).uniform(-jitter, jitter, size=(model.body_count, 3)).astype(np.float32)
+        model.body_q[:, :3] += off
+        model.joint_q.reshape(-1, 7)[:, :3] += off
+    return model

@@ -1,0 +1,71 @@
+"""Parity metrics with TRUE relative errors (test infrastructure).
+
+north_star: body q/qd trajectories within 1e-4 rel of the reference.  Per field, the error of a body is measured on the
+vector, relative to the vector's own magnitude, with an explicit absolute floor below which "relative" has no meaning:
+
+  pos      |dp| / max(|p|, POS_FLOOR)        POS_FLOOR = 0.05 m   (a link of the scenes is 0.05-0.75 m long)
+  rot      |dq| (sign-aligned unit quaternions: the magnitude is 1, so absolute == relative)
+  lin_vel  |dv| / max(|v|, LIN_FLOOR)        LIN_FLOOR = 0.05 m/s
+  ang_vel  |dw| / max(|w|, ANG_FLOOR)        ANG_FLOOR = 0.5 rad/s
+
+XPBD velocities are position differences divided by dt (xpbd/kernels.py:896-931), so one fp32 ulp of a position
+(6e-8 at |x| ~ 0.5 m) is 6e-5 m/s at dt = 1e-3 -- on a body creeping at 0.05 m/s that alone is 1.2e-3 relative.  Velocity
+gates are therefore stated as a multiple of that amplification (see `velocity_ulp_bound`) and the measured max / median of
+every field is recorded next to the gate (`record`), so the bound is justified by printed numbers, not widened blindly.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+POS_FLOOR, LIN_FLOOR, ANG_FLOOR = 0.05, 0.05, 0.5
+_OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def field_errors(q, qd, q_ref, qd_ref):
+    """max / median / p99 of the per-body relative errors defined above; inputs are [B,7] / [B,6] AoS arrays."""
+    q, qd = np.asarray(q, dtype=np.float64), np.asarray(qd, dtype=np.float64)
+    q_ref, qd_ref = np.asarray(q_ref, dtype=np.float64), np.asarray(qd_ref, dtype=np.float64)
+    out = {}
+
+    def stats(e):
+        return {"max": float(e.max()), "median": float(np.median(e)), "p99": float(np.percentile(e, 99.0))}
+
+    out["pos"] = stats(np.linalg.norm(q[:, :3] - q_ref[:, :3], axis=1) / np.maximum(np.linalg.norm(q_ref[:, :3], axis=1), POS_FLOOR))
+    sign = np.where(np.sum(q[:, 3:] * q_ref[:, 3:], axis=1, keepdims=True) < 0.0, -1.0, 1.0)
+    out["rot"] = stats(np.linalg.norm(q[:, 3:] * sign - q_ref[:, 3:], axis=1))
+    out["lin_vel"] = stats(np.linalg.norm(qd[:, :3] - qd_ref[:, :3], axis=1) /
+                           np.maximum(np.linalg.norm(qd_ref[:, :3], axis=1), LIN_FLOOR))
+    out["ang_vel"] = stats(np.linalg.norm(qd[:, 3:] - qd_ref[:, 3:], axis=1) /
+                           np.maximum(np.linalg.norm(qd_ref[:, 3:], axis=1), ANG_FLOOR))
+    out["lin_vel_abs"] = stats(np.linalg.norm(qd[:, :3] - qd_ref[:, :3], axis=1))
+    out["ang_vel_abs"] = stats(np.linalg.norm(qd[:, 3:] - qd_ref[:, 3:], axis=1))
+    return out
+
+
+def velocity_ulp_bound(pos_scale: float, dt: float, ulps: float) -> float:
+    """|dv| that `ulps` fp32 ulps of a position of magnitude `pos_scale` turn into after the division by dt."""
+    return ulps * float(np.spacing(np.float32(pos_scale))) / dt
+
+
+def record(name: str, errs: dict, gates: dict):
+    """Print the measured distribution next to its gates and append it to gpurun_out/parity_numbers.jsonl (when the
+    directory exists, i.e. on the GPU box) so DESIGN.md's table can be regenerated from a run."""
+    line = {"test": name, "errors": errs, "gates": gates}
+    print("[parity]", json.dumps(line))
+    if os.path.isdir(_OUT):
+        with open(os.path.join(_OUT, "parity_numbers.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+
+
+def check(name, q, qd, q_ref, qd_ref, *, pos=1e-4, rot=1e-4, lin_vel=None, ang_vel=None, lin_vel_abs=None, ang_vel_abs=None):
+    """Assert every given gate on the max error of its field; always records the full distribution."""
+    errs = field_errors(q, qd, q_ref, qd_ref)
+    gates = {k: v for k, v in dict(pos=pos, rot=rot, lin_vel=lin_vel, ang_vel=ang_vel, lin_vel_abs=lin_vel_abs,
+                                   ang_vel_abs=ang_vel_abs).items() if v is not None}
+    record(name, errs, gates)
+    for k, g in gates.items():
+        assert errs[k]["max"] <= g, f"{name}: {k} max {errs[k]['max']:.3e} > gate {g:.1e} (median {errs[k]['median']:.3e})"
+    return errs
