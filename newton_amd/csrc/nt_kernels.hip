@@ -20,6 +20,7 @@
 // Reference behaviour (file:line under /root/reference) is cited per phase.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/newton_hip.h"
@@ -186,46 +187,47 @@ __global__ void contacts_export_force_kernel(nt_model m, nt_contacts c, const fl
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-constexpr int MAX_THREADS = 512;  // 256 for EPB <= 8 (see max_threads_for)
 inline int max_threads_for(int epb) { return epb <= 8 ? 256 : 512; }
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
 // slot-threads per env: enough for the widest per-env population (contact slots, joint parts, bodies, shapes,
 // pairs), capped by the block size; phases with more items than slot-threads loop.
-int slots_for(const nt_model& m, int epb) {
+int slots_for(const nt_model& m, int epb, int max_threads) {
     int want = imax(imax(m.nb, 2 * m.nj), imax(imax(m.ns, m.np), m.np * m.cpp + m.nj));
-    int cap = max_threads_for(epb) / epb;
+    int cap = max_threads / epb;
     return want < cap ? want : cap;
 }
 
-bool epb_fits(const nt_model& m, int epb) {
-    return (size_t)make_layout_host(m).rows_per_env * 4 * epb + (size_t)topo_ints(m) * 4 <= LDS_BYTES_PER_CU;
+bool epb_fits(const nt_model& m, int epb, bool restitution = false) {
+    return (size_t)make_layout_host(m, restitution).rows_per_env * 4 * epb + (size_t)topo_ints(m) * 4 <= LDS_BYTES_PER_CU;
 }
 
-int pick_epb(const nt_model& m, int requested) {
+int pick_epb(const nt_model& m, int requested, bool restitution = false) {
     // pair-heavy scenes (contact records in HBM) only have the one-environment-per-workgroup kernels
-    if (m.contact_scratch_in_hbm) return (requested == 0 || requested == 1) && epb_fits(m, 1) ? 1 : 0;
-    if (requested == 1 || requested == 8 || requested == 16 || requested == 32 || requested == 64)
-        return epb_fits(m, requested) ? requested : 0;
+    if (m.contact_scratch_in_hbm) return (requested == 0 || requested == 1) && epb_fits(m, 1, restitution) ? 1 : 0;
+    if (requested == 1 || requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64)
+        return epb_fits(m, requested, restitution) ? requested : 0;
     // auto: the widest tile (best coalescing) that still yields >= 256 workgroups (one per CU); else the narrowest
     const int cands[4] = {64, 32, 16, 8};
     for (int i = 0; i < 4; ++i) {
         int epb = cands[i];
-        if (!epb_fits(m, epb)) continue;
+        if (!epb_fits(m, epb, restitution)) continue;
         int blocks = (m.env_count + epb - 1) / epb;
         if (blocks >= 256 || epb == 8) return epb;
     }
     for (int i = 3; i >= 0; --i)
-        if (epb_fits(m, cands[i])) return cands[i];
+        if (epb_fits(m, cands[i], restitution)) return cands[i];
     // scenes too large for 8 environments per workgroup (> 20 KB of LDS each): one environment per workgroup, 256 lanes
     // on its items, several workgroups resident per CU while their LDS fits
-    return epb_fits(m, 1) ? 1 : 0;
+    return epb_fits(m, 1, restitution) ? 1 : 0;
 }
 
+// semi: the SolverSemiImplicit kernel (own scratch layout); max_threads: the kernel's THREADS template argument
 template <typename K>
-nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
-    LdsLayout L = make_layout_host(a.m);
-    int nslot = slots_for(a.m, epb);
+nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false) {
+    LdsLayout L = make_layout_host(a.m, a.p.enable_restitution != 0);
+    if (max_threads <= 0) max_threads = max_threads_for(epb);
+    int nslot = slots_for(a.m, epb, max_threads);
     a.nslot = nslot;
     {
         static int dbg = -1;
@@ -233,7 +235,8 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
         a.debug_skip = dbg;
     }
     int threads = ((nslot * epb + 63) / 64) * 64;
-    size_t lds_bytes = (size_t)L.rows_per_env * 4 * epb + (size_t)topo_ints(a.m) * 4;
+    size_t lds_bytes = (size_t)(semi ? L.rows_semi : L.rows_per_env) * 4 * epb + (size_t)topo_ints(a.m) * 4;
+    if (lds_bytes > LDS_BYTES_PER_CU) return NT_ERR_UNSUPPORTED;
     int blocks = (a.m.env_count + epb - 1) / epb;
     if (lds_bytes > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
@@ -243,24 +246,43 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 
+// Launch shape of the analytic (non-convex) fused XPBD rollout: environments per workgroup, workgroup size, minimum waves
+// per SIMD (register cap).  NT_XPBD_CFG="epb,threads,minw" selects one of the compiled shapes for A/B measurements.
+struct XpbdCfg { int epb, threads, minw; };
+inline bool xpbd_cfg_override(XpbdCfg& c) {
+    const char* e = getenv("NT_XPBD_CFG");
+    if (!e) return false;
+    return sscanf(e, "%d,%d,%d", &c.epb, &c.threads, &c.minw) == 3;
+}
+#define NT_XPBD_ROLLOUT_SHAPES(X) \
+    X(16, 512, 1) X(16, 512, 4) X(16, 1024, 4) X(8, 256, 1) X(8, 256, 2) X(8, 256, 4) X(8, 512, 2) X(8, 512, 4) \
+    X(4, 256, 2) X(4, 256, 4) X(4, 128, 4) X(4, 128, 8)
+nt_status launch_xpbd_rollout_shape(const KArgs& a, XpbdCfg c, hipStream_t stream) {
+#define X(E, T, W) \
+    if (c.epb == E && c.threads == T && c.minw == W) return launch(xpbd_rollout_kernel<E, false, false, T, W>, a, E, stream, T);
+    NT_XPBD_ROLLOUT_SHAPES(X)
+#undef X
+    return NT_ERR_UNSUPPORTED;
+}
+
 #define NT_DISPATCH_EPB(KERNEL, args, epb, stream)                                      \
     ((epb) == 64 ? launch(KERNEL<64>, args, 64, stream)                                 \
      : (epb) == 32 ? launch(KERNEL<32>, args, 32, stream)                               \
      : (epb) == 16 ? launch(KERNEL<16>, args, 16, stream)                               \
-     : (epb) == 8 ? launch(KERNEL<8>, args, 8, stream) : launch(KERNEL<1>, args, 1, stream))
+     : ((epb) == 8 || (epb) == 4) ? launch(KERNEL<8>, args, 8, stream) : launch(KERNEL<1>, args, 1, stream))
 
 #define NT_DISPATCH_EPB2(KERNEL, B, args, epb, stream)                                  \
     ((epb) == 64 ? launch(KERNEL<64, B>, args, 64, stream)                              \
      : (epb) == 32 ? launch(KERNEL<32, B>, args, 32, stream)                            \
      : (epb) == 16 ? launch(KERNEL<16, B>, args, 16, stream)                            \
-     : (epb) == 8 ? launch(KERNEL<8, B>, args, 8, stream) : launch(KERNEL<1, B>, args, 1, stream))
+     : ((epb) == 8 || (epb) == 4) ? launch(KERNEL<8, B>, args, 8, stream) : launch(KERNEL<1, B>, args, 1, stream))
 // kernels that collide are compiled twice: the convex (MPR/GJK) code only exists in the variant used by models
 // that have convex-routed pairs, so analytic-only models keep their register budget
 // the convex variants are only instantiated for 1 / 8 / 16 envs per workgroup (build time): wider tiles fall back to 16
 #define NT_DISPATCH_EPB_CVX(KERNEL, m, args, epb, stream)                                              \
     ((m).np_analytic < (m).np                                                                          \
          ? ((epb) >= 16 ? launch(KERNEL<16, true>, args, 16, stream)                                   \
-            : (epb) == 8 ? launch(KERNEL<8, true>, args, 8, stream) : launch(KERNEL<1, true>, args, 1, stream)) \
+            : ((epb) == 8 || (epb) == 4) ? launch(KERNEL<8, true>, args, 8, stream) : launch(KERNEL<1, true>, args, 1, stream)) \
          : NT_DISPATCH_EPB2(KERNEL, false, args, epb, stream))
 
 bool model_ok(const nt_model* m) {
@@ -342,7 +364,7 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
     a.p = *p;
     a.angular_damping = p->angular_damping;
     a.dt = dt;
-    int epb = pick_epb(*m, envs_per_block);
+    int epb = pick_epb(*m, envs_per_block, p->enable_restitution != 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
     if (m->contact_scratch_in_hbm) {
         if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
@@ -365,12 +387,20 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     a.substeps = substeps;
-    int epb = pick_epb(*m, cp ? cp->envs_per_block : 0);
+    const bool rest = p->enable_restitution != 0;
+    int epb = pick_epb(*m, cp ? cp->envs_per_block : 0, rest);
     if (!epb) return NT_ERR_UNSUPPORTED;
     if (m->contact_scratch_in_hbm) {
         if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
         return m->np_analytic < m->np ? launch(xpbd_rollout_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(xpbd_rollout_kernel<1, false, true>, a, 1, (hipStream_t)stream);
+    }
+    if (m->np_analytic == m->np) {  // analytic-only models: the tuned launch shapes
+        XpbdCfg c;
+        if (xpbd_cfg_override(c)) {
+            if (!epb_fits(*m, c.epb, rest)) return NT_ERR_UNSUPPORTED;
+            return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
+        }
     }
     return NT_DISPATCH_EPB_CVX(xpbd_rollout_kernel, *m, a, epb, (hipStream_t)stream);
 }
@@ -391,7 +421,16 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
     if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;  // XPBD / collide only
     int epb = pick_epb(*m, envs_per_block);
     if (!epb) return NT_ERR_UNSUPPORTED;
-    return NT_DISPATCH_EPB(semi_implicit_step_kernel, a, epb, (hipStream_t)stream);
+    if ((size_t)make_layout_host(*m).rows_semi * 4 * epb + (size_t)topo_ints(*m) * 4 > LDS_BYTES_PER_CU) {
+        // the wrench records of SolverSemiImplicit make its tile heavier than the collide / XPBD one: narrow it
+        while (epb > 8 && (size_t)make_layout_host(*m).rows_semi * 4 * epb + (size_t)topo_ints(*m) * 4 > LDS_BYTES_PER_CU) epb /= 2;
+        if ((size_t)make_layout_host(*m).rows_semi * 4 * epb + (size_t)topo_ints(*m) * 4 > LDS_BYTES_PER_CU) epb = 1;
+    }
+    return epb == 64 ? launch(semi_implicit_step_kernel<64>, a, 64, (hipStream_t)stream, 0, true)
+         : epb == 32 ? launch(semi_implicit_step_kernel<32>, a, 32, (hipStream_t)stream, 0, true)
+         : epb == 16 ? launch(semi_implicit_step_kernel<16>, a, 16, (hipStream_t)stream, 0, true)
+         : epb == 8 ? launch(semi_implicit_step_kernel<8>, a, 8, (hipStream_t)stream, 0, true)
+                    : launch(semi_implicit_step_kernel<1>, a, 1, (hipStream_t)stream, 0, true);
 }
 
 // shared launch logic of the Featherstone kernels (step / rollout)

@@ -17,8 +17,13 @@ constexpr int SP_XFORM = 0, SP_SCALE = 7, SP_MARGIN = 10, SP_GAP = 11, SP_MU = 1
               SP_KE = 15, SP_KD = 16, SP_KF = 17, SP_KA = 18, SP_RESTITUTION = 19;
 // contact data rows
 constexpr int CD_POINT0 = 0, CD_POINT1 = 3, CD_OFFSET0 = 6, CD_OFFSET1 = 9, CD_NORMAL = 12, CD_MARGIN0 = 15, CD_MARGIN1 = 16;
-// per-contact correction record in LDS: lin_a, ang_a, lin_b, ang_b, has_a, has_b, shape0_is_pair_a
+// per-contact wrench record of SolverSemiImplicit / SolverFeatherstone and of XPBD's restitution pass:
+// lin_a, ang_a, lin_b, ang_b, has_a, has_b, shape0_is_pair_a
 constexpr int CW_FLOATS = 15;
+// per-contact correction record of the XPBD position solve: lin_a (lin_b is its exact negation: -n l_n - t l_f vs n l_n + t l_f),
+// ang_a, ang_b, flags (bit 0 has_a, bit 1 has_b, bit 2 shape0_is_pair_a, stored as a small float)
+constexpr int CWX_FLOATS = 10;
+constexpr int CWX_ANG_A = 3, CWX_ANG_B = 6, CWX_FLAGS = 9;
 
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 
@@ -42,14 +47,16 @@ struct LdsLayout {
     int cw;            // contacts: per-contact corrections [CW_FLOATS][np*cpp]
     int si_jf, si_cw;  // semi-implicit: joint wrenches + contact wrenches live together with body_f_tmp
     int xi;            // XPBD restitution: pre-step body_q / body_qd [13][nb], behind the XPBD scratch (solver_xpbd.py:414-416)
-    int rows_per_env;
+    int rows_per_env;  // collide / XPBD kernels
+    int rows_semi;     // SolverSemiImplicit kernel (its wrench records share the scratch with body_f_tmp + joint wrenches)
 };
 
 constexpr int NT_BIG_SCENE_LANES = 256;  // workgroup size of the one-environment-per-workgroup tile
 
 // big: pair-heavy scenes (nt_model.contact_scratch_in_hbm).  Device code passes a compile-time constant so that the
 // default kernels carry no trace of the second mode.
-__host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big) {
+// restitution: SolverXPBD(enable_restitution=True) keeps the pre-step state and 15-float velocity records per contact slot
+__host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false) {
     LdsLayout L;
     int o = 0;
     L.bq = o; o += 7 * m.nb;
@@ -73,15 +80,19 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.jl = L.u; L.ja = L.jl + 12 * m.nj;
     int joints = 21 * m.nj;
     L.cw = L.u;
-    int contacts = big ? 0 : CW_FLOATS * m.np * m.cpp;  // big: the records live in nt_contacts.cw (HBM)
+    // big: the records live in nt_contacts.cw (HBM)
+    int contacts = big ? 0 : (restitution ? CW_FLOATS : CWX_FLOATS) * m.np * m.cpp;
     L.si_jf = L.bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
-    int semi = 6 * m.nb + 12 * m.nj + contacts;
+    int semi = 6 * m.nb + 12 * m.nj + CW_FLOATS * m.np * m.cpp;
     int xpbd = imax(imax(coll, forces), imax(joints, contacts));
     L.xi = L.u + xpbd;
-    L.rows_per_env = L.u + imax(xpbd + 13 * m.nb, semi);
+    L.rows_per_env = L.u + xpbd + (restitution ? 13 * m.nb : 0);
+    L.rows_semi = L.u + semi;
     return L;
 }
-inline LdsLayout make_layout_host(const nt_model& m) { return make_layout(m, m.contact_scratch_in_hbm != 0); }
+inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false) {
+    return make_layout(m, m.contact_scratch_in_hbm != 0, restitution);
+}
 
 struct KArgs {
     nt_model m;
@@ -124,7 +135,7 @@ struct Ctx {
 
     // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
     NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
-        L = make_layout(a.m, big_);
+        L = make_layout(a.m, big_, a.p.enable_restitution != 0);
         if (rows < 0) rows = L.rows_per_env;
         e = threadIdx.x % EPB;
         slot = threadIdx.x / EPB;

@@ -249,7 +249,7 @@ NT_DI void si_contact_item(const Ctx<EPB>& c, const int slot) {
 template <int EPB>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds);
+    Ctx<EPB> c(a, lds, make_layout(a.m, false).rows_semi);
     load_state(c, a.s_in);
     load_params(c, true);
     __syncthreads();

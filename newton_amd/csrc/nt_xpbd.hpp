@@ -359,13 +359,22 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
             a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
         }
     }
+    // lin_delta_b == -lin_delta_a bit for bit (IEEE negation commutes with every rounding above), so only one is stored
     cw_st3<CW>(c, 0, ncs, slot, lin_delta_a);
-    cw_st3<CW>(c, 3, ncs, slot, ang_delta_a);
-    cw_st3<CW>(c, 6, ncs, slot, lin_delta_b);
-    cw_st3<CW>(c, 9, ncs, slot, ang_delta_b);
-    CW::at(c, 12, ncs, slot) = has_a;
-    CW::at(c, 13, ncs, slot) = has_b;
-    CW::at(c, 14, ncs, slot) = a_is_pair_a;
+    cw_st3<CW>(c, CWX_ANG_A, ncs, slot, ang_delta_a);
+    cw_st3<CW>(c, CWX_ANG_B, ncs, slot, ang_delta_b);
+    CW::at(c, CWX_FLAGS, ncs, slot) = has_a + 2.0f * has_b + 4.0f * a_is_pair_a;
+}
+// flags of an XPBD correction record: does it touch the body on `side` of its pair (0: owner of pair_a's shape), and as
+// the contact's shape0 ("a") or shape1?
+struct CwxSide { bool has, is_a; };
+template <class CW, int EPB>
+NT_DI CwxSide cwx_side(const Ctx<EPB>& c, int ncs, int slot, int side) {
+    const int f = (int)CW::at(c, CWX_FLAGS, ncs, slot);
+    CwxSide r;
+    r.is_a = (side == 0) == ((f & 4) != 0);  // this body is the contact's "a" iff (side == 0) == (shape0 is pair_a's shape)
+    r.has = (f & (r.is_a ? 1 : 2)) != 0;
+    return r;
 }
 template <int EPB, bool FUSED, class CW = CwLds>
 NT_DI void phase_contacts(const Ctx<EPB>& c) {
@@ -394,12 +403,11 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
             int p = code >> 1, side = code & 1;  // side 0: this body owns pair_a's shape
             for (int k = 0; k < cpp; ++k) {
                 int slot = p * cpp + k;
-                // this body is the contact's "a" iff (side == 0) == (shape0 is pair_a's shape)
-                bool is_a = (side == 0) == (CW::at(c, 14, ncs, slot) != 0.0f);
-                float has = CW::at(c, is_a ? 12 : 13, ncs, slot);
-                if (has != 0.0f) {
-                    dlin += cw_v3<CW>(c, is_a ? 0 : 6, ncs, slot);
-                    dang += cw_v3<CW>(c, is_a ? 3 : 9, ncs, slot);
+                const CwxSide sd = cwx_side<CW>(c, ncs, slot, side);
+                if (sd.has) {
+                    vec3 lin = cw_v3<CW>(c, 0, ncs, slot);
+                    dlin += sd.is_a ? lin : -lin;
+                    dang += cw_v3<CW>(c, sd.is_a ? CWX_ANG_A : CWX_ANG_B, ncs, slot);
                     inv_weight += 1.0f;
                 }
             }
@@ -913,8 +921,7 @@ NT_DI float report_body_contact_count(const Ctx<EPB>& c, int b) {
         int p = code >> 1, side = code & 1;
         for (int k = 0; k < cpp; ++k) {
             int slot = p * cpp + k;
-            bool is_a = (side == 0) == (CW::at(c, 14, ncs, slot) != 0.0f);
-            if (CW::at(c, is_a ? 12 : 13, ncs, slot) != 0.0f) n += 1.0f;
+            if (cwx_side<CW>(c, ncs, slot, side).has) n += 1.0f;
         }
     }
     return n;
@@ -927,14 +934,15 @@ NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
     const int cpp = m.cpp, ncs = m.np * cpp;
     float* I = c.a.rep.contact_impulse;
     for (int slot = c.slot; slot < ncs; slot += c.nslot) {
-        float has_a = CW::at(c, 12, ncs, slot), has_b = CW::at(c, 13, ncs, slot);
+        const int flags = (int)CW::at(c, CWX_FLAGS, ncs, slot);
+        float has_a = (flags & 1) ? 1.0f : 0.0f, has_b = (flags & 2) ? 1.0f : 0.0f;
         vec3 lin, ang;
         if (has_a != 0.0f || has_b != 0.0f) {
             float weight = 1.0f;
             if (c.a.p.rigid_contact_con_weighting) {
                 const int p = slot / cpp;
                 int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
-                if (CW::at(c, 14, ncs, slot) == 0.0f) { int t = sa; sa = sb; sb = t; }
+                if (!(flags & 4)) { int t = sa; sa = sb; sb = t; }
                 int body_a = c.T.shape_body[sa], body_b = c.T.shape_body[sb];
                 float n_a = body_a >= 0 ? report_body_contact_count<EPB, CW>(c, body_a) : 0.0f;
                 float n_b = body_b >= 0 ? report_body_contact_count<EPB, CW>(c, body_b) : 0.0f;
@@ -946,7 +954,7 @@ NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
                 }
             }
             lin = cw_v3<CW>(c, 0, ncs, slot) * weight;
-            ang = cw_v3<CW>(c, 3, ncs, slot) * weight;
+            ang = cw_v3<CW>(c, CWX_ANG_A, ncs, slot) * weight;
         }
         if (first) {
             I[c.g(0, ncs, slot)] = lin.x; I[c.g(1, ncs, slot)] = lin.y; I[c.g(2, ncs, slot)] = lin.z;
@@ -1064,8 +1072,10 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
 }
 
-template <int EPB, bool CVX, bool BIG = false>
-__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) collide_kernel(KArgs a) {
+// THREADS / MINW: workgroup size and minimum waves per SIMD the register allocator must leave room for
+// (k workgroups of THREADS threads per CU <=> MINW = k * THREADS / 256); chosen per model by the launch code
+template <int EPB, bool CVX, bool BIG = false, int THREADS = (EPB <= 8 ? 256 : 512), int MINW = 1>
+__global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
     load_state(c, a.s_in);
@@ -1074,8 +1084,8 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) collide_kernel(KArgs a) 
     do_collide<EPB, CVX>(c, true);
 }
 
-template <int EPB, bool BIG = false>
-__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_step_kernel(KArgs a) {
+template <int EPB, bool BIG = false, int THREADS = (EPB <= 8 ? 256 : 512), int MINW = 1>
+__global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
     load_state(c, a.s_in);
@@ -1091,8 +1101,8 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_step_kernel(KArgs a
 // substeps x { clear_forces; collide; step; swap } with state and parameters resident in LDS across substeps.
 // Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
 // pointer swap); body_f of both states is zeroed as clear_forces would leave it.
-template <int EPB, bool CVX, bool BIG = false>
-__global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) xpbd_rollout_kernel(KArgs a) {
+template <int EPB, bool CVX, bool BIG = false, int THREADS = (EPB <= 8 ? 256 : 512), int MINW = 1>
+__global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
     const int nb = a.m.nb;
