@@ -107,10 +107,16 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
 }
 
 template <int EPB>
+NT_DI void shape_item(const Ctx<EPB>& c, const int s);
+template <int EPB>
 NT_DI void phase_shapes(const Ctx<EPB>& c) {
-    const nt_model& m = c.a.m;
     if (!c.valid) return;
-    for (int s = c.slot; s < m.ns; s += c.nslot) {
+    for (int s = c.slot; s < c.a.m.ns; s += c.nslot) shape_item(c, s);
+}
+template <int EPB>
+NT_DI void shape_item(const Ctx<EPB>& c, const int s) {
+    const nt_model& m = c.a.m;
+    {
         int body = c.T.shape_body[s];
         xform X = c.shape_local_xform(s);
         if (body >= 0) X = c.body_q(body) * X;
@@ -293,12 +299,197 @@ NT_DI void phase_pairs(const Ctx<EPB>& c) {
     for (int s = c.slot; s < ncs; s += c.nslot) collide_slot_item<EPB, CVX>(c, s);
 }
 
-template <int EPB>
-NT_DI void phase_contact_count(const Ctx<EPB>& c) {
+// ------------------------------------------------------------------------------------------------
+// Staged variant of the pair phase (every tile except the pair-heavy one-environment-per-workgroup mode): ONE lane per
+// pair runs the broad-phase test + the analytic primitive pair + the admission test and parks the admitted candidates in
+// LDS (L.st: normal[3], then (center[3], dist) x 4 per pair); after a barrier one lane per contact SLOT turns its candidate
+// into the body-frame record (19 stores).  Same arithmetic, same emission order as collide_slot_item -- the per-slot
+// variant evaluated the pair once per slot lane (4x redundantly).  Convex pairs keep their single lane (it writes its
+// slots itself) and skip the second stage.
+// ------------------------------------------------------------------------------------------------
+constexpr int ST_FLOATS = 19;
+template <int EPB, bool CVX>
+NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
     const nt_model& m = c.a.m;
-    if (c.slot == 0 && c.valid) {
-        int n = 0;
-        for (int p = 0; p < m.np; ++p) n += (int)c.l(c.L.pc, 0, m.np, p);
-        c.a.ct.env_count[c.env] = n;
+    const nt_contacts& ct = c.a.ct;
+    const int cpp = m.cpp;
+    int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
+    xform Xa, Xb;
+    vec3 loa, hia, lob, hib;
+    shape_world(c, sa, Xa, loa, hia);
+    shape_world(c, sb, Xb, lob, hib);
+    bool hit = loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z;
+    ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+    int nvalid = 0;
+    if (hit) {
+        int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
+        if (ta > tb) {  // sort by type (narrow_phase.py:525-528)
+            int t = sa; sa = sb; sb = t;
+            t = ta; ta = tb; tb = t;
+            xform X = Xa; Xa = Xb; Xb = X;
+            vec3 v = loa; loa = lob; lob = v;
+            v = hia; hia = hib; hib = v;
+        }
+        vec3 scale_a = c.shape_scale(sa), scale_b = c.shape_scale(sb);
+        float margin_a = c.shape_f(sa, SP_MARGIN), margin_b = c.shape_f(sb, SP_MARGIN);
+        float gap_sum = c.shape_f(sa, SP_GAP) + c.shape_f(sb, SP_GAP);
+        bool to_gjk = ta >= GEO_ELLIPSOID || tb == GEO_CONE || (ta == GEO_CAPSULE && tb > GEO_CAPSULE);
+        if (!to_gjk) {
+            float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
+            float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
+            Contacts4 k4;
+            primitive_pair(ta, tb, Xa, Xb, scale_a, scale_b, gap_sum + margin_a + margin_b, k4);
+            float total_sep = ra + rb + margin_a + margin_b;
+            vec3 n = normalize(k4.normal);
+            c.st_lv3(c.L.st, 0, m.np, p, n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float dist = k4.dist(i);
+                bool ok = dist < NT_MAXVAL;
+                if (ok) {
+                    vec3 center = k4.pos(i);
+                    vec3 aw = center - n * (0.5f * dist + ra);
+                    vec3 bw = center + n * (0.5f * dist + rb);
+                    float d = dot(bw - aw, n) - total_sep;
+                    ok = d <= gap_sum;
+                    if (ok) {  // the nvalid-th admitted candidate
+                        c.st_lv3(c.L.st, 3 + 4 * nvalid, m.np, p, center);
+                        c.l(c.L.st, 6 + 4 * nvalid, m.np, p) = dist;
+                    }
+                }
+                nvalid += ok ? 1 : 0;
+            }
+        }
+        if constexpr (CVX) {
+            if (p >= m.np_analytic) {
+                ConvexContacts cc;
+                Geom ga, gb;
+                ga.type = ta; ga.scale = scale_a;
+                gb.type = tb; gb.scale = scale_b;
+                if (ta == GEO_PLANE) ga.scale = vec3(scale_a.x * 0.5f, scale_a.y * 0.5f, 0.0f);
+                if (tb == GEO_PLANE) gb.scale = vec3(scale_b.x * 0.5f, scale_b.y * 0.5f, 0.0f);
+                if (ta == GEO_CONVEX_MESH) {
+                    ga.points = m.mesh_points + 3 * c.T.shape_mesh_start[sa];
+                    ga.count = c.T.shape_mesh_count[sa];
+                    const float* mb = m.shape_mesh_bounds + 6 * sa;
+                    ga.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)) +
+                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)));
+                }
+                if (tb == GEO_CONVEX_MESH) {
+                    gb.points = m.mesh_points + 3 * c.T.shape_mesh_start[sb];
+                    gb.count = c.T.shape_mesh_count[sb];
+                    const float* mb = m.shape_mesh_bounds + 6 * sb;
+                    gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +
+                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)));
+                }
+                PolyRef poly;
+                poly.base = &c.lds[(c.L.pc + m.np + 20 * (p - m.np_analytic)) * EPB + c.e];
+                poly.stride = EPB;
+                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
+                float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
+                float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
+                vec3 n = normalize(cc.normal);
+                nvalid = cc.count < cpp ? cc.count : cpp;
+                for (int i = 0; i < cpp; ++i) {
+                    if (i < nvalid) {
+                        write_contact_slot(c, p * cpp + i, sa, sb, cc.center(i), n, cc.distance(i), ra, rb, margin_a, margin_b);
+                    } else {
+                        size_t gi = (size_t)(p * cpp + i) * c.ES + c.env;
+                        ct.shape0[gi] = -1;
+                        ct.shape1[gi] = -1;
+                    }
+                }
+            }
+        }
+    } else if (CVX && p >= m.np_analytic) {
+        for (int i = 0; i < cpp; ++i) {
+            size_t gi = (size_t)(p * cpp + i) * c.ES + c.env;
+            ct.shape0[gi] = -1;
+            ct.shape1[gi] = -1;
+        }
     }
+    c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
+    c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
+}
+// second stage, analytic pairs only: contact slot (p, k) <- the pair's k-th admitted candidate
+template <int EPB>
+NT_DI void contact_write_item(const Ctx<EPB>& c, const int slot) {
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp;
+    const int p = slot / cpp, k = slot - p * cpp;
+    if (p >= m.np_analytic) return;  // convex pairs wrote their slots in the first stage
+    if (k < (int)c.l(c.L.pm, 0, m.np, p)) {
+        int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
+        int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
+        if (ta > tb) {
+            int t = sa; sa = sb; sb = t;
+            t = ta; ta = tb; tb = t;
+        }
+        float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? c.shape_f(sa, SP_SCALE) : 0.0f;
+        float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? c.shape_f(sb, SP_SCALE) : 0.0f;
+        vec3 n = c.lv3(c.L.st, 0, m.np, p);
+        vec3 center = c.lv3(c.L.st, 3 + 4 * k, m.np, p);
+        float dist = c.l(c.L.st, 6 + 4 * k, m.np, p);
+        write_contact_slot(c, slot, sa, sb, center, n, dist, ra, rb, c.shape_f(sa, SP_MARGIN), c.shape_f(sb, SP_MARGIN));
+    } else {
+        size_t gi = (size_t)slot * c.ES + c.env;
+        c.a.ct.shape0[gi] = -1;
+        c.a.ct.shape1[gi] = -1;
+    }
+}
+template <int EPB, bool CVX>
+NT_DI void phase_pair_eval(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    for (int p = c.slot; p < c.a.m.np; p += c.nslot) pair_eval_item<EPB, CVX>(c, p);
+}
+template <int EPB>
+NT_DI void phase_contact_write(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nas = c.a.m.np_analytic * c.a.m.cpp;
+    for (int s = c.slot; s < nas; s += c.nslot) contact_write_item(c, s);
+}
+
+// Exclusive prefix of the per-pair live-contact counts (L.pm -> L.px[0..np]) so that the fused solver phases can hand the
+// i-th LIVE contact of an environment to lane i instead of visiting every fixed slot (pair-heavy scenes have ~250 live
+// contacts in 11 680 slots).  Two-level: up to 16 lanes of the environment sum one chunk of pairs each, then each turns
+// its chunk into prefixes.  `partial` = 8 scratch rows that are free between the pair phase and the solver phases (the shape
+// transforms of the collide scratch: 13 rows per shape, dead once the pairs are done).
+constexpr int NT_PREFIX_LANES = 8;
+template <int EPB>
+NT_DI void phase_pair_prefix_partials(const Ctx<EPB>& c, int partial) {
+    const int np = c.a.m.np;
+    if (!c.valid || c.slot >= NT_PREFIX_LANES) return;
+    const int lanes = c.nslot < NT_PREFIX_LANES ? c.nslot : NT_PREFIX_LANES;
+    const int chunk = (np + lanes - 1) / lanes;
+    if (c.slot >= lanes) return;
+    int sum = 0;
+    for (int p = c.slot * chunk; p < np && p < (c.slot + 1) * chunk; ++p) sum += (int)c.l(c.L.pm, 0, np, p);
+    c.lds[(partial + c.slot) * EPB + c.e] = (float)sum;
+}
+// prefix lane `lane` (0 .. NT_PREFIX_LANES-1) of the calling lane's environment
+template <int EPB>
+NT_DI void prefix_lane(const Ctx<EPB>& c, int lane, int partial, bool store_env_count, bool one_level) {
+    const int np = c.a.m.np;
+    const int lanes = c.nslot < NT_PREFIX_LANES ? c.nslot : NT_PREFIX_LANES;
+    const int chunk = (np + lanes - 1) / lanes;
+    if (lane >= lanes) return;
+    int acc = 0;
+    if (one_level) {  // few pairs: every lane sums the counts in front of its chunk itself (no partials, one barrier less)
+        for (int p = 0; p < np && p < lane * chunk; ++p) acc += (int)c.l(c.L.pm, 0, np, p);
+    } else {
+        for (int s = 0; s < lane; ++s) acc += (int)c.lds[(partial + s) * EPB + c.e];
+    }
+    for (int p = lane * chunk; p < np && p < (lane + 1) * chunk; ++p) {
+        c.lds[(c.L.px + p) * EPB + c.e] = (float)acc;
+        acc += (int)c.l(c.L.pm, 0, np, p);
+    }
+    if (lane == lanes - 1) {  // the last chunk ends at np (chunks past np are empty, their running sum is the total too)
+        c.lds[(c.L.px + np) * EPB + c.e] = (float)acc;
+        if (store_env_count) c.a.ct.env_count[c.env] = acc;  // per-env totals: an API-boundary output
+    }
+}
+template <int EPB>
+NT_DI void phase_pair_prefix_scan(const Ctx<EPB>& c, int partial, bool store_env_count, bool one_level) {
+    if (!c.valid || c.slot >= NT_PREFIX_LANES) return;
+    prefix_lane(c, c.slot, partial, store_env_count, one_level);
 }

@@ -52,7 +52,10 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
     F.H = F.P + 6 * m.nb * m.max_art_dofs;
     int solve = 6 * m.nb * m.max_art_dofs + m.nd * m.max_art_dofs;
     int contacts = CW_FLOATS * m.np * m.cpp;
-    o += imax(solve, contacts);
+    // the fused rollout runs the collide phases on this union too (shape transforms / AABBs, pair counts, manifold polygon
+    // scratch, staged candidates)
+    int coll = 13 * m.ns + m.np + 20 * (m.np - m.np_analytic) + 19 * m.np;
+    o += imax(imax(solve, contacts), coll);
     F.rows = o;
     return F;
 }
@@ -1058,6 +1061,7 @@ __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     cc.L.sx = F.cw;
     cc.L.sa = F.cw + 7 * m.ns;
     cc.L.pc = F.cw + 13 * m.ns;
+    cc.L.st = cc.L.pc + m.np + 20 * (m.np - m.np_analytic);
     const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(cc, s == a.substeps - 1);

@@ -39,19 +39,22 @@ struct LdsLayout {
     int grav;          // gravity [3]
     int bd;            // body-derived [9][nb]: world COM (3) + world-frame inverse inertia R I^-1 R^T (xx xy xz yy yz zz)
     int pm;            // live contacts per pair [np] (written by the collide phase, read by the fused solver phases)
+    int px;            // exclusive prefix of pm [np + 1]: live contact i of the env is (pair p, sub-contact i - px[p])
     // scratch union
     int u;
     int sx, sa, pc;    // collide: shape world xform [7][ns], aabb [6][ns], per-pair contact count [np]
+    int st;            // collide: admitted candidates of the analytic pairs [19][np] (normal, 4 x (center, dist)); staged tiles
     int bf, jf;        // forces: body_f_tmp [6][nb], joint wrenches [12][nj]
     int jl, ja;        // joints: linear-part corrections [12][nj], angular-part child terms [9][nj]
     int cw;            // contacts: per-contact corrections [CW_FLOATS][np*cpp]
-    int si_jf, si_cw;  // semi-implicit: joint wrenches + contact wrenches live together with body_f_tmp
+    int si_bf, si_jf, si_cw;  // semi-implicit: body_f_tmp + joint wrenches + contact wrenches, all live together
     int xi;            // XPBD restitution: pre-step body_q / body_qd [13][nb], behind the XPBD scratch (solver_xpbd.py:414-416)
     int rows_per_env;  // collide / XPBD kernels
     int rows_semi;     // SolverSemiImplicit kernel (its wrench records share the scratch with body_f_tmp + joint wrenches)
 };
 
-constexpr int NT_BIG_SCENE_LANES = 256;  // workgroup size of the one-environment-per-workgroup tile
+constexpr int NT_BIG_SCENE_LANES = 256;
+constexpr int NT_MIN_SCRATCH_ROWS = 8;  // the live-contact prefix parks up to 8 partial sums in the scratch union  // workgroup size of the one-environment-per-workgroup tile
 
 // big: pair-heavy scenes (nt_model.contact_scratch_in_hbm).  Device code passes a compile-time constant so that the
 // default kernels carry no trace of the second mode.
@@ -71,20 +74,25 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.grav = o; o += 3;
     L.bd = o; o += 9 * m.nb;
     L.pm = o; o += m.np;
+    L.px = o; o += m.np + 1;
     L.u = o;
     L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
     // + manifold polygon scratch: 20 rows per convex pair, or (pair-heavy scenes, one environment per workgroup) per lane
     int coll = 13 * m.ns + m.np + 20 * (big ? NT_BIG_SCENE_LANES : (m.np - m.np_analytic));
-    L.bf = L.u; L.jf = L.bf + 6 * m.nb;
-    int forces = 6 * m.nb + 12 * m.nj;
+    L.st = L.u + coll;
+    if (!big) coll += 19 * m.np;
+    // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase
+    // and the joint-force phase in the same barrier interval (different waves); the pair-heavy tile keeps the overlap
+    L.bf = big ? L.u : L.u + coll; L.jf = L.bf + 6 * m.nb;
+    int forces = (big ? 0 : coll) + 6 * m.nb + 12 * m.nj;
     L.jl = L.u; L.ja = L.jl + 12 * m.nj;
     int joints = 21 * m.nj;
     L.cw = L.u;
     // big: the records live in nt_contacts.cw (HBM)
     int contacts = big ? 0 : (restitution ? CW_FLOATS : CWX_FLOATS) * m.np * m.cpp;
-    L.si_jf = L.bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
+    L.si_bf = L.u; L.si_jf = L.si_bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
     int semi = 6 * m.nb + 12 * m.nj + CW_FLOATS * m.np * m.cpp;
-    int xpbd = imax(imax(coll, forces), imax(joints, contacts));
+    int xpbd = imax(imax(imax(coll, forces), imax(joints, contacts)), NT_MIN_SCRATCH_ROWS);
     L.xi = L.u + xpbd;
     L.rows_per_env = L.u + xpbd + (restitution ? 13 * m.nb : 0);
     L.rows_semi = L.u + semi;

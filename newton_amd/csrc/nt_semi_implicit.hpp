@@ -250,6 +250,7 @@ template <int EPB>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, make_layout(a.m, false).rows_semi);
+    c.L.bf = c.L.si_bf;  // this solver's force scratch: body_f_tmp | joint wrenches | contact wrenches
     load_state(c, a.s_in);
     load_params(c, true);
     __syncthreads();

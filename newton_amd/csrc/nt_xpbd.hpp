@@ -8,14 +8,24 @@
 // XPBD: apply_joint_forces (xpbd/kernels.py:945-1075)
 // ------------------------------------------------------------------------------------------------
 template <int EPB>
-NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
-    const nt_model& m = c.a.m;
-    const int nb = m.nb, nj = m.nj;
-    if (!c.valid) return;
+NT_DI void joint_force_item(const Ctx<EPB>& c, const int j);
+template <int EPB>
+NT_DI void seed_body_forces(const Ctx<EPB>& c, bool forces_are_zero) {
     // body threads seed body_f_tmp with state_in.body_f (solver_xpbd.py:423: wp.clone)
-    for (int r = c.slot; r < 6 * nb; r += c.nslot)
+    for (int r = c.slot; r < 6 * c.a.m.nb; r += c.nslot)
         c.lds[(c.L.bf + r) * EPB + c.e] = forces_are_zero ? 0.0f : c.a.s_in.body_f[(size_t)r * c.ES + c.env];
-    for (int j = c.slot; j < nj; j += c.nslot) {
+}
+template <int EPB>
+NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
+    if (!c.valid) return;
+    seed_body_forces(c, forces_are_zero);
+    for (int j = c.slot; j < c.a.m.nj; j += c.nslot) joint_force_item(c, j);
+}
+template <int EPB>
+NT_DI void joint_force_item(const Ctx<EPB>& c, const int j) {
+    const nt_model& m = c.a.m;
+    const int nj = m.nj;
+    {
         vec3 fp, tp, fc, tc;  // parent wrench (subtracted), child wrench (added)
         int type = c.T.joint_type[j];
         if (c.T.joint_enabled[j] && type != JT_FIXED && type != JT_ROD) {
@@ -379,15 +389,30 @@ NT_DI CwxSide cwx_side(const Ctx<EPB>& c, int ncs, int slot, int side) {
 template <int EPB, bool FUSED, class CW = CwLds>
 NT_DI void phase_contacts(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    const int ncs = c.a.m.np * c.a.m.cpp;
-    for (int s = c.slot; s < ncs; s += c.nslot) contact_item<EPB, FUSED, CW>(c, s);
+    const int np = c.a.m.np, cpp = c.a.m.cpp;
+    if constexpr (FUSED) {
+        // lane i takes the environment's i-th live contact (L.px: exclusive prefix of the per-pair live counts); records
+        // of dead slots are never written and never read (apply_item stops at the pair's live count)
+        const int total = (int)c.lds[(c.L.px + np) * EPB + c.e];
+        for (int i = c.slot; i < total; i += c.nslot) {
+            int lo = 0, hi = np;  // the last pair whose prefix is <= i
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if ((int)c.lds[(c.L.px + mid) * EPB + c.e] <= i) lo = mid;
+                else hi = mid;
+            }
+            contact_item<EPB, FUSED, CW>(c, lo * cpp + (i - (int)c.lds[(c.L.px + lo) * EPB + c.e]));
+        }
+    } else {
+        for (int s = c.slot; s < np * cpp; s += c.nslot) contact_item<EPB, FUSED, CW>(c, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // XPBD: apply_body_deltas (xpbd/kernels.py:864-933).  FROM_CONTACTS: sum contact corrections (+ contact counts)
 // in ascending contact order; otherwise sum joint corrections in ascending joint order.
 // ------------------------------------------------------------------------------------------------
-template <int EPB, bool FROM_CONTACTS, class CW = CwLds>
+template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false>
 NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int nb = m.nb;
@@ -401,7 +426,8 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
         for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
             int code = c.T.body_pair_list[i];
             int p = code >> 1, side = code & 1;  // side 0: this body owns pair_a's shape
-            for (int k = 0; k < cpp; ++k) {
+            const int live = FUSED ? (int)c.l(c.L.pm, 0, m.np, p) : cpp;  // fused: only live slots carry a record
+            for (int k = 0; k < live; ++k) {
                 int slot = p * cpp + k;
                 const CwxSide sd = cwx_side<CW>(c, ncs, slot, side);
                 if (sd.has) {
@@ -458,10 +484,10 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     c.st_lv3(c.L.bqd, 3, nb, b, w1);
     c.update_body_derived(b);
 }
-template <int EPB, bool FROM_CONTACTS, class CW = CwLds>
+template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false>
 NT_DI void phase_apply(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW>(c, b);
+    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1008,26 +1034,38 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
     phase_shapes(c);
     __syncthreads();
     NT_TICK(1);
-    phase_pairs<EPB, CVX>(c);
+    if (c.big) {
+        phase_pairs<EPB, CVX>(c);  // pair-heavy tile: one lane per contact slot, no candidate staging (19 rows per pair)
+    } else {
+        phase_pair_eval<EPB, CVX>(c);
+        __syncthreads();
+        phase_contact_write(c);
+    }
     __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
     NT_TICK(2);
-    if (count_contacts) {  // per-env totals are an API-boundary output, not needed by the solver
-        phase_contact_count(c);
+    // live-contact prefix for the fused solver phases + (last substep / standalone collide) the per-env totals; scratch =
+    // the shape-transform rows of the collide scratch, dead once the pairs are done
+    const bool one_level = c.a.m.np <= 64;
+    if (!one_level) {
+        phase_pair_prefix_partials(c, c.L.sx);
         __syncthreads();
     }
+    phase_pair_prefix_scan(c, c.L.sx, count_contacts, one_level);
+    __syncthreads();
 }
 
 // SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
-template <int EPB, bool FUSED, class CW = CwLds>
+// PROLOGUE_DONE: the caller (do_fused_substep) already saved the pre-step state, applied the joint forces and integrated
+template <int EPB, bool FUSED, class CW = CwLds, bool PROLOGUE_DONE = false>
 NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
     const int skip = c.a.debug_skip;
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
-    if (restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
+    if (!PROLOGUE_DONE && restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
         for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * EPB + c.e] = c.lds[(c.L.bq + r) * EPB + c.e];
     const bool rep_joints = !FUSED && c.a.rep.joint_impulse != nullptr;
     const bool rep_contacts = !FUSED && c.a.rep.contact_impulse != nullptr && c.a.has_contacts;
-    if (!(skip & 2)) {
+    if (!PROLOGUE_DONE && !(skip & 2)) {
         phase_joint_forces(c, forces_are_zero);
         __syncthreads();
         NT_TICK(3);
@@ -1042,7 +1080,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             __syncthreads();
             NT_TICK(5);
             if (rep_contacts) report_contact_iteration<EPB, CW>(c, it == 0);
-            if (!(skip & 16)) phase_apply<EPB, true, CW>(c);
+            if (!(skip & 16)) phase_apply<EPB, true, CW, FUSED>(c);
             __syncthreads();
             NT_TICK(6);
         }
@@ -1074,6 +1112,66 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
 
 // THREADS / MINW: workgroup size and minimum waves per SIMD the register allocator must leave room for
 // (k workgroups of THREADS threads per CU <=> MINW = k * THREADS / 256); chosen per model by the launch code
+// One substep of the fused rollout on the staged tiles: { clear_forces; collide; SolverXPBD.step } with the independent
+// 13-item phases of the two halves sharing barrier intervals.  The shape phase and the joint-force phase both read only the
+// incoming state (collide.py:283-472 / xpbd/kernels.py:945-1075) and write disjoint scratch (layout: forces behind the
+// collide scratch), so they run side by side on different waves; the contact-record stage, the live-contact prefix and
+// nothing else follow; integrate_bodies comes last because the records are converted into the frames of the incoming
+// body poses (collide.py:166-204).  Arithmetic and summation orders are those of do_collide + do_xpbd_step, bit for bit.
+template <int EPB, bool CVX>
+NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
+    const nt_model& m = c.a.m;
+    const int skip = c.a.debug_skip;
+    const int spw = 64 / EPB > 0 ? 64 / EPB : 1;  // slots per wave
+    const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
+    // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
+    if (c.valid) {
+        if (restitution)
+            for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * EPB + c.e] = c.lds[(c.L.bq + r) * EPB + c.e];
+        if (!(skip & 2)) seed_body_forces(c, true);
+        const int S0 = ((m.ns + spw - 1) / spw) * spw;
+        for (int i = c.slot; i < S0 + m.nj; i += c.nslot) {
+            if (i < m.ns) {
+                if (!(skip & 1)) shape_item(c, i);
+            } else if (i >= S0) {
+                if (!(skip & 2)) joint_force_item(c, i - S0);
+            }
+        }
+    }
+    __syncthreads();
+    NT_TICK(1);
+    // -- interval 2: one lane per candidate pair (broad phase test, primitive pair / MPR-GJK manifold, admission)
+    if (!(skip & 1)) phase_pair_eval<EPB, CVX>(c);
+    __syncthreads();
+    NT_TICK(2);
+    // -- interval 3: contact records of the analytic pairs (one lane per slot) || live-contact prefix (few lanes per env)
+    if (!(skip & 1) && c.valid) {
+        const int nas = m.np_analytic * m.cpp;
+        const int P0 = ((nas + spw - 1) / spw) * spw;
+        const bool one_level = m.np <= 64;
+        if (one_level) {
+            for (int i = c.slot; i < P0 + NT_PREFIX_LANES; i += c.nslot) {
+                if (i < nas) contact_write_item(c, i);
+                else if (i >= P0) prefix_lane(c, i - P0, c.L.sx, last_substep, true);
+            }
+        } else {
+            for (int s = c.slot; s < nas; s += c.nslot) contact_write_item(c, s);
+            phase_pair_prefix_partials(c, c.L.sx);
+        }
+    }
+    __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
+    if (!(skip & 1) && m.np > 64) {
+        phase_pair_prefix_scan(c, c.L.sx, last_substep, false);
+        __syncthreads();
+    }
+    NT_TICK(3);
+    // -- interval 4: integrate_bodies
+    if (!(skip & 2)) phase_integrate<EPB, false>(c);
+    __syncthreads();
+    NT_TICK(4);
+    do_xpbd_step<EPB, true, CwLds, true>(c, true);
+}
+
 template <int EPB, bool CVX, bool BIG = false, int THREADS = (EPB <= 8 ? 256 : 512), int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
@@ -1118,9 +1216,12 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     __syncthreads();
     NT_TICK(0);
     for (int s = 0; s < a.substeps; ++s) {
-        do_collide<EPB, CVX>(c, s == a.substeps - 1);
-        if constexpr (BIG) do_xpbd_step<EPB, true, CwHbm>(c, true);
-        else do_xpbd_step<EPB, true>(c, true);
+        if constexpr (BIG) {
+            do_collide<EPB, CVX>(c, s == a.substeps - 1);
+            do_xpbd_step<EPB, true, CwHbm>(c, true);
+        } else {
+            do_fused_substep<EPB, CVX>(c, s == a.substeps - 1);
+        }
     }
     store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
     NT_TICK(9);

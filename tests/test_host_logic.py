@@ -98,15 +98,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert C.sizeof(_lib.nt_model) == 16 * 4 + 32 * 8
     m = _lib.nt_model()
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
-    m.nd, m.ntq, m.cpp = 18, 18, 4
-    # persistent rows 1295 (state 169 + body 299 + joint 182 + dof 198 + shape 260 + control 54 + gravity 3 + derived 117
-    # + per-pair live counts 13)
-    # + scratch max(collide 182, forces 234, joints 273, contacts 15*52 = 780, semi-implicit 78 + 156 + 780 = 1014)
-    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1295 + 1014)
+    m.nd, m.ntq, m.cpp, m.np_analytic = 18, 18, 4, 13
+    # persistent rows 1309 (state 169 + body 299 + joint 182 + dof 198 + shape 260 + control 54 + gravity 3 + derived 117
+    # + per-pair live counts 13 + their exclusive prefix 14)
+    # + XPBD scratch max(collide 182 + staged candidates 19*13 = 429, the forces 78 + 156 behind it = 663, joints 273,
+    #   correction records 10*52 = 520); the restitution scratch (169 + 15-float records) only exists when enabled
+    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1309 + 663)
     # Featherstone: generalized state 127 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1171,
-    # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780)
+    # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780, collide scratch 429)
     m.nc, m.na, m.max_art_dofs = 19, 1, 18
-    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1295 + 1171 + 1728)
+    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1309 + 1171 + 1728)
 
 
 def test_no_silent_cpu_fallback():

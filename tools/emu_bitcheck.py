@@ -45,7 +45,7 @@ def outputs(libpath):
             fn.restype, fn.argtypes = restype, argtypes
     H._emu = lib
     import newton_amd as nt
-    from scenes import box_stack_scene, joint_zoo_scene, mixed_primitive_scene, pendulum_scene, quadruped_scene
+    from scenes import box_stack_scene, hull_bin_scene, joint_zoo_scene, mixed_primitive_scene, pendulum_scene, quadruped_scene
 
     res = {}
 
@@ -75,6 +75,18 @@ def outputs(libpath):
         ct = H.EmuContacts(em)
         out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), H.EmuControl(em), ct, 1.0 / 240.0, 4, **kw)
         res[name] = [out.body_q.copy(), out.body_qd.copy(), ct.data.copy()]
+    # fused rollout with restitution; pair-heavy scene (contact records in HBM, one environment per workgroup)
+    m = quadruped_scene(9, seed=5)
+    lower(m, 0.24)
+    em = H.EmuModel(m)
+    ct = H.EmuContacts(em)
+    out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), H.EmuControl(em), ct, 1e-3, 4, enable_restitution=True)
+    res["quad_rollout_restitution"] = [out.body_q.copy(), out.body_qd.copy(), ct.env_count.copy()]
+    m = hull_bin_scene(2, 40)
+    em = H.EmuModel(m)
+    ct = H.EmuContacts(em)
+    out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), H.EmuControl(em), ct, 1.0 / 600.0, 3)
+    res["hull_bin_rollout"] = [out.body_q.copy(), out.body_qd.copy(), ct.shape0.copy(), ct.data.copy(), ct.env_count.copy()]
     m = pendulum_scene(5, seed=4)
     em = H.EmuModel(m)
     a, b = H.EmuState(em), H.EmuState(em)
