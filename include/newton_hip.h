@@ -259,6 +259,52 @@ nt_status nt_broadphase_sap(const nt_broadphase_in* in, const int32_t* sorted_ma
 nt_status nt_broadphase_explicit(const nt_broadphase_in* in, const int32_t* pair_list, int32_t n_pairs, int32_t* pairs,
                                  int32_t* count, int32_t cap, void* stream);
 
+/* -------- sparse "texture" SDFs (newton/_src/geometry/sdf_texture.py) --------
+ * TextureSDFData (:126-160) with the CUDA textures replaced by the plain arrays they hold: a coarse float grid sampled at the
+ * subgrid corners, packed (subgrid_size+1)^3 blocks for the narrow band (float32 / uint16 / uint8, :487-690) and the
+ * indirection slots (10-bit block coordinates, 0xFFFFFFFF = empty, 0xFFFFFFFE = "use the coarse grid", :44-45).
+ * Built on the host by newton_amd.sdf (create_texture_sdf_from_mesh / _primitive). All pointers are device pointers. */
+typedef struct {
+    const float* coarse;       /* [cz+1][cy+1][cx+1] */
+    const void* subgrid;       /* [tex_size]^3, z-major; element type by `quantization` */
+    const uint32_t* slots;     /* [cx][cy][cz] */
+    int32_t cx, cy, cz;        /* coarse cells per axis (= subgrids per axis) */
+    int32_t tex_size;
+    int32_t subgrid_size;      /* fine cells per subgrid edge (8) */
+    int32_t quantization;      /* 4 float32, 2 uint16, 1 uint8 (QuantizationMode) */
+    int32_t scale_baked;       /* the shape scale is already inside the SDF values */
+    float box_lower[3], box_upper[3], inv_dx[3], voxel_size[3];
+    float voxel_radius, min_value, value_range;
+} nt_sdf;
+/* texture_sample_sdf (:1129-1135) and the centred-difference gradient of the narrow phase (:1619-1697) at local points
+ * [n][3]; either output may be NULL. */
+nt_status nt_sdf_sample(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist /*[n]*/, float* out_grad /*[n][3]*/,
+                        void* stream);
+
+/* mesh_sdf_collision_kernel (sdf_contact.py:1098-1515, reduce_contacts=False): every edge of one shape of a pair against the
+ * SDF of the other, both ways.  Flat Newton arrays; contacts are appended (atomic counter, which keeps counting past
+ * `capacity`) as ContactData rows: out_pair = index into `pairs`, out_key = (edge << 2) | (mode << 1) (contact_data.py:60-90
+ * sub-key), out_data = centre[3] (world), normal[3] (shape0 -> shape1), distance, margin0, margin1. */
+typedef struct {
+    const int32_t* pairs;            /* [pair_count][2] shape ids */
+    int32_t pair_count;
+    const float* shape_transform;    /* [S][7] world transform of every shape (body_q * shape_transform) */
+    const float* shape_data;         /* [S][4] scale xyz, margin */
+    const float* shape_gap;          /* [S] */
+    const int32_t* shape_sdf_index;  /* [S] index into sdf_table or -1 */
+    const nt_sdf* sdf_table;         /* [sdf_count] (device memory) */
+    int32_t sdf_count;
+    const int32_t* shape_edge_range; /* [S][2] (start, count) into the edge tables (Model.shape_edge_range) */
+    const float* edge_centers;       /* [E][4] scaled local centre, radius      (Model.mesh_edge_centers) */
+    const float* edge_halves;        /* [E][4] scaled local half vector, corner ownership code (Model.mesh_edge_halves) */
+    int32_t* out_count;              /* [1], zero it first */
+    int32_t* out_pair;               /* [capacity] */
+    int32_t* out_key;                /* [capacity] */
+    float* out_data;                 /* [capacity][9] */
+    int32_t capacity;
+} nt_mesh_sdf_args;
+nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
+
 /* -------- introspection -------- */
 const char* nt_error_string(nt_status s);
 const char* nt_build_info(void);                 /* "gfx950 ..." */

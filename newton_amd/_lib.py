@@ -76,6 +76,22 @@ class nt_broadphase_in(C.Structure):
                 ("shape_body", C.c_void_p), ("body_flags", C.c_void_p)]
 
 
+class nt_sdf(C.Structure):
+    _fields_ = [("coarse", C.c_void_p), ("subgrid", C.c_void_p), ("slots", C.c_void_p), ("cx", C.c_int32), ("cy", C.c_int32),
+                ("cz", C.c_int32), ("tex_size", C.c_int32), ("subgrid_size", C.c_int32), ("quantization", C.c_int32),
+                ("scale_baked", C.c_int32), ("box_lower", C.c_float * 3), ("box_upper", C.c_float * 3),
+                ("inv_dx", C.c_float * 3), ("voxel_size", C.c_float * 3), ("voxel_radius", C.c_float),
+                ("min_value", C.c_float), ("value_range", C.c_float)]
+
+
+class nt_mesh_sdf_args(C.Structure):
+    _fields_ = [("pairs", C.c_void_p), ("pair_count", C.c_int32), ("shape_transform", C.c_void_p), ("shape_data", C.c_void_p),
+                ("shape_gap", C.c_void_p), ("shape_sdf_index", C.c_void_p), ("sdf_table", C.c_void_p), ("sdf_count", C.c_int32),
+                ("shape_edge_range", C.c_void_p), ("edge_centers", C.c_void_p), ("edge_halves", C.c_void_p),
+                ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_data", C.c_void_p),
+                ("capacity", C.c_int32)]
+
+
 class nt_semi_implicit_params(C.Structure):
     _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float), ("joint_attach_ke", C.c_float),
                 ("joint_attach_kd", C.c_float)]
@@ -126,6 +142,8 @@ SYMBOLS = {
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
     "nt_pick_envs_per_block": (C.c_int32, [C.POINTER(nt_model), C.c_int32]),
     "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
+    "nt_sdf_sample": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P, _P]),
+    "nt_mesh_sdf_collide": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), _P]),
 }
 
 _lib = None

@@ -308,7 +308,18 @@ NT_DI void phase_pairs(const Ctx<EPB>& c) {
 // slots itself) and skip the second stage.
 // ------------------------------------------------------------------------------------------------
 constexpr int ST_FLOATS = 19;
-template <int EPB, bool CVX>
+// the candidate test of one pair (broad_phase_common.py:20-38) on the staged shape transforms / AABBs
+template <int EPB>
+NT_DI bool pair_aabb_hit(const Ctx<EPB>& c, const int p) {
+    xform Xa, Xb;
+    vec3 loa, hia, lob, hib;
+    shape_world(c, c.T.pair_a[p], Xa, loa, hia);
+    shape_world(c, c.T.pair_b[p], Xb, lob, hib);
+    return loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z;
+}
+// STAGED: admitted analytic candidates go to LDS (L.st) for the per-slot record stage; otherwise (pair-heavy tile) the
+// pair lane writes its analytic records itself.  KNOWN_HIT: the pair comes from the compacted candidate list.
+template <int EPB, bool CVX, bool STAGED = true, bool KNOWN_HIT = false>
 NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
@@ -318,8 +329,8 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
     vec3 loa, hia, lob, hib;
     shape_world(c, sa, Xa, loa, hia);
     shape_world(c, sb, Xb, lob, hib);
-    bool hit = loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z;
-    ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+    bool hit = KNOWN_HIT || (loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z);
+    if (!KNOWN_HIT) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
     int nvalid = 0;
     if (hit) {
         int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
@@ -341,7 +352,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
             primitive_pair(ta, tb, Xa, Xb, scale_a, scale_b, gap_sum + margin_a + margin_b, k4);
             float total_sep = ra + rb + margin_a + margin_b;
             vec3 n = normalize(k4.normal);
-            c.st_lv3(c.L.st, 0, m.np, p, n);
+            if constexpr (STAGED) c.st_lv3(c.L.st, 0, m.np, p, n);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float dist = k4.dist(i);
@@ -353,12 +364,22 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                     float d = dot(bw - aw, n) - total_sep;
                     ok = d <= gap_sum;
                     if (ok) {  // the nvalid-th admitted candidate
-                        c.st_lv3(c.L.st, 3 + 4 * nvalid, m.np, p, center);
-                        c.l(c.L.st, 6 + 4 * nvalid, m.np, p) = dist;
+                        if constexpr (STAGED) {
+                            c.st_lv3(c.L.st, 3 + 4 * nvalid, m.np, p, center);
+                            c.l(c.L.st, 6 + 4 * nvalid, m.np, p) = dist;
+                        } else {
+                            write_contact_slot(c, p * cpp + nvalid, sa, sb, center, n, dist, ra, rb, margin_a, margin_b);
+                        }
                     }
                 }
                 nvalid += ok ? 1 : 0;
             }
+            if constexpr (!STAGED)
+                for (int i = nvalid; i < cpp; ++i) {
+                    size_t gi = (size_t)(p * cpp + i) * c.ES + c.env;
+                    ct.shape0[gi] = -1;
+                    ct.shape1[gi] = -1;
+                }
         }
         if constexpr (CVX) {
             if (p >= m.np_analytic) {
@@ -382,8 +403,8 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                     gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +
                                         vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)));
                 }
-                PolyRef poly;
-                poly.base = &c.lds[(c.L.pc + m.np + 20 * (p - m.np_analytic)) * EPB + c.e];
+                PolyRef poly;  // manifold polygon scratch: per convex pair, or (pair-heavy tile) per lane
+                poly.base = &c.lds[(c.L.pc + m.np + 20 * (c.big ? c.slot : p - m.np_analytic)) * EPB + c.e];
                 poly.stride = EPB;
                 convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
@@ -437,10 +458,45 @@ NT_DI void contact_write_item(const Ctx<EPB>& c, const int slot) {
         c.a.ct.shape1[gi] = -1;
     }
 }
+// Pair-heavy tile (one environment per workgroup, contact records in HBM): stage 1 tests every candidate pair's AABBs
+// (one lane per pair) and appends the hits to a block-shared list (LDS atomic counter; the order of the list is
+// irrelevant: every pair owns its fixed contact slots), misses clear their slots; stage 2 deals the hits densely to the
+// lanes, so the narrow phase runs with full waves on ~250 live candidates instead of 2 336 mostly-empty pair lanes.
+template <int EPB>
+NT_DI void phase_pairs_big_broad(const Ctx<EPB>& c) {
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    if (threadIdx.x == 0) *c.T.hit_count = 0;
+    __syncthreads();
+    if (c.valid)
+        for (int p = c.slot; p < m.np; p += c.nslot) {
+            const bool hit = pair_aabb_hit(c, p);
+            ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+            if (hit) {
+                c.T.hit_list[atomicAdd(c.T.hit_count, 1)] = p;
+            } else {
+                for (int i = 0; i < m.cpp; ++i) {
+                    size_t gi = (size_t)(p * m.cpp + i) * c.ES + c.env;
+                    ct.shape0[gi] = -1;
+                    ct.shape1[gi] = -1;
+                }
+                c.l(c.L.pc, 0, m.np, p) = 0.0f;
+                c.l(c.L.pm, 0, m.np, p) = 0.0f;
+            }
+        }
+    __syncthreads();
+}
+template <int EPB, bool CVX>
+NT_DI void phase_pairs_big_narrow(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nhit = *c.T.hit_count;
+    for (int i = c.slot; i < nhit; i += c.nslot) pair_eval_item<EPB, CVX, false, true>(c, c.T.hit_list[i]);
+}
+
 template <int EPB, bool CVX>
 NT_DI void phase_pair_eval(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int p = c.slot; p < c.a.m.np; p += c.nslot) pair_eval_item<EPB, CVX>(c, p);
+    for (int p = c.tslot; p < c.a.m.np; p += c.nslot) pair_eval_item<EPB, CVX>(c, p);
 }
 template <int EPB>
 NT_DI void phase_contact_write(const Ctx<EPB>& c) {

@@ -308,12 +308,6 @@ const char* nt_error_string(nt_status s) {
     }
 }
 
-#ifndef NT_BUILD_ID
-#define NT_BUILD_ID "unknown"
-#endif
-// the source hash (kernel sources + header + compiler flags, __graft_entry__.source_hash) names the build a profile was taken on
-const char* nt_build_info(void) { return "libnewton_hip gfx950 (CDNA4) fp32, -ffp-contract=off, src " NT_BUILD_ID; }
-
 int32_t nt_lds_bytes_per_env(const nt_model* m) {
     if (!m) return -1;
     return make_layout_host(*m).rows_per_env * 4;

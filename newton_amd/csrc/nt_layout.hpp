@@ -124,10 +124,11 @@ struct Topo {
         *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
         *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count, *gshape_id;
     const float* gshape;  // [ng][NT_SHAPE_PARAM_FLOATS] parameters of the global (world -1) shapes, block-shared copy
+    int *hit_count, *hit_list;  // pair-heavy tile only: the environment's compacted candidate list (1 + np ints)
 };
 __host__ __device__ inline int topo_ints(const nt_model& m) {
     return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np + m.ng +
-           NT_SHAPE_PARAM_FLOATS * m.ng;
+           NT_SHAPE_PARAM_FLOATS * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 0);
 }
 
 template <int EPB>
@@ -137,6 +138,9 @@ struct Ctx {
     float* lds;
     LdsLayout L;
     int e, slot, env, nslot;
+    int tslot;  // start of the item loop of phases with fewer items than slot-threads.  Identity: dealing consecutive items to
+                // DIFFERENT waves (13 bodies x 16 envs on all 8 waves instead of 4) was measured and lost 13 % on the headline
+                // (87.4 vs 100.8 M env-steps/s) -- twice the wave-instructions cost more than the second wave per SIMD hides
     bool big;  // contact records in HBM, manifold polygon scratch per lane (compile-time constant at every construction site)
     int ES;
     bool valid;
@@ -151,6 +155,7 @@ struct Ctx {
         env = blockIdx.x * EPB + e;
         ES = a.m.env_stride;
         valid = env < a.m.env_count && slot < nslot;
+        tslot = slot;
         const nt_model& m = a.m;
         int* ti = reinterpret_cast<int*>(lds + (size_t)rows * EPB);
         int o = 0;
@@ -188,6 +193,8 @@ struct Ctx {
             T.gshape = g;
             o += NT_SHAPE_PARAM_FLOATS * m.ng;
         }
+        T.hit_count = ti + o;
+        T.hit_list = ti + o + 1;
     }
     // LDS element: row = field offset + comp * slots_in_field + slot
     NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * EPB + e]; }

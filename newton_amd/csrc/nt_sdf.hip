@@ -1,0 +1,347 @@
+// nt_sdf.hip -- sparse "texture" SDF sampling and the mesh-vs-SDF narrow phase for gfx950.
+//
+// Reference behaviour (paths under /root/reference/newton/_src/geometry):
+//   sampling        sdf_texture.py:786-828 (_locate_cell_coords), :1008-1126 (_texture_sample_sdf_variant: software trilinear
+//                   over point-sampled texels, |p - clamp(p)| extension outside the box), :1619-1697 (centred-difference
+//                   gradient with half-voxel steps, clamp-direction gradient outside the box)
+//   edge search     sdf_contact.py:704-938 (do_edge_sdf_collision: symmetric golden pair + <= 3 Brent steps + endpoint checks)
+//   pair kernel     sdf_contact.py:1098-1515 (mesh_sdf_collision_kernel, reduce_contacts=False variant: both modes of a pair,
+//                   edge bounding-sphere cull against the SDF box and the midpoint value, inner-cull consistency, corner
+//                   ownership, contact = (point, -/+ normalised gradient, distance))
+//
+// MI355X design: the reference stores the grids in CUDA 3-D textures and point-samples them at texel centres; here they are
+// plain linear arrays (coarse float grid, packed (subgrid_size+1)^3 blocks in float / uint16 / uint8, indirection slots) read
+// with ordinary global loads -- eight texels of a cell sit in two 64-B segments of an x-row pair.  Where the reference's CUDA
+// path takes hardware-filtered fetches (8-bit weights), this path interpolates in full fp32 like its Warp-CPU path.
+// One workgroup walks the pairs with stride gridDim.x; its 256 lanes take the edges of the "triangle" shape of the pair (both
+// modes), cull, search and append contacts through a device-wide atomic counter (the reference appends atomically too); the
+// sort key (pair, edge, mode) rides along so the host can order them deterministically.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/newton_hip.h"
+#include "nt_math.hpp"
+
+using namespace nt;
+
+namespace {
+
+constexpr uint32_t SLOT_LINEAR = 0xFFFFFFFEu;
+
+NT_DI float texel(const nt_sdf& s, int x, int y, int z) {  // subgrid "texture" read at texel (x, y, z), normalised formats -> [0,1]
+    const size_t i = ((size_t)z * s.tex_size + y) * s.tex_size + x;
+    if (s.quantization == 4) return reinterpret_cast<const float*>(s.subgrid)[i];
+    if (s.quantization == 2) return (float)reinterpret_cast<const uint16_t*>(s.subgrid)[i] * (1.0f / 65535.0f);
+    return (float)reinterpret_cast<const uint8_t*>(s.subgrid)[i] * (1.0f / 255.0f);
+}
+
+struct Cell {
+    int ix, iy, iz, bx, by, bz;
+    float tx, ty, tz;
+    uint32_t slot;
+};
+NT_DI int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+NT_DI Cell locate(const nt_sdf& s, vec3 f) {  // _locate_cell
+    Cell c;
+    const float ssf = (float)s.subgrid_size;
+    const float fvx = (float)s.cx * ssf, fvy = (float)s.cy * ssf, fvz = (float)s.cz * ssf;
+    const float fx = clampf(f.x, 0.0f, fvx), fy = clampf(f.y, 0.0f, fvy), fz = clampf(f.z, 0.0f, fvz);
+    c.ix = clampi((int)floorf(fx), 0, (int)fvx - 1);
+    c.iy = clampi((int)floorf(fy), 0, (int)fvy - 1);
+    c.iz = clampi((int)floorf(fz), 0, (int)fvz - 1);
+    c.tx = fx - (float)c.ix;
+    c.ty = fy - (float)c.iy;
+    c.tz = fz - (float)c.iz;
+    const float f2c = 1.0f / ssf;
+    c.bx = clampi((int)((float)c.ix * f2c), 0, s.cx - 1);
+    c.by = clampi((int)((float)c.iy * f2c), 0, s.cy - 1);
+    c.bz = clampi((int)((float)c.iz * f2c), 0, s.cz - 1);
+    c.slot = s.slots[((size_t)c.bx * s.cy + c.by) * s.cz + c.bz];
+    return c;
+}
+
+// value at a point already clamped to the SDF box (+ the caller's |p - clamped| extension)
+NT_DI float sample_clamped(const nt_sdf& s, vec3 clamped, float diff_mag) {
+    const vec3 lo(s.box_lower[0], s.box_lower[1], s.box_lower[2]);
+    vec3 f = cw_mul(clamped - lo, vec3(s.inv_dx[0], s.inv_dx[1], s.inv_dx[2]));
+    Cell c = locate(s, f);
+    float v000, v100, v010, v110, v001, v101, v011, v111;
+    float tx = c.tx, ty = c.ty, tz = c.tz;
+    bool needs_scale = false;
+    if (c.slot >= SLOT_LINEAR) {
+        const float f2c = 1.0f / (float)s.subgrid_size;
+        tx = ((float)c.ix + c.tx) * f2c - (float)c.bx;
+        ty = ((float)c.iy + c.ty) * f2c - (float)c.by;
+        tz = ((float)c.iz + c.tz) * f2c - (float)c.bz;
+        const int sx = s.cx + 1, sy = s.cy + 1;
+        const float* g = s.coarse + ((size_t)c.bz * sy + c.by) * sx + c.bx;
+        v000 = g[0]; v100 = g[1]; v010 = g[sx]; v110 = g[sx + 1];
+        g += (size_t)sx * sy;
+        v001 = g[0]; v101 = g[1]; v011 = g[sx]; v111 = g[sx + 1];
+    } else {
+        needs_scale = true;
+        const int spd = s.subgrid_size + 1;
+        const int ox = (int)(c.slot & 0x3FFu) * spd + (c.ix - c.bx * s.subgrid_size);
+        const int oy = (int)((c.slot >> 10) & 0x3FFu) * spd + (c.iy - c.by * s.subgrid_size);
+        const int oz = (int)((c.slot >> 20) & 0x3FFu) * spd + (c.iz - c.bz * s.subgrid_size);
+        v000 = texel(s, ox, oy, oz); v100 = texel(s, ox + 1, oy, oz);
+        v010 = texel(s, ox, oy + 1, oz); v110 = texel(s, ox + 1, oy + 1, oz);
+        v001 = texel(s, ox, oy, oz + 1); v101 = texel(s, ox + 1, oy, oz + 1);
+        v011 = texel(s, ox, oy + 1, oz + 1); v111 = texel(s, ox + 1, oy + 1, oz + 1);
+    }
+    float c00 = v000 + (v100 - v000) * tx;
+    float c10 = v010 + (v110 - v010) * tx;
+    float c01 = v001 + (v101 - v001) * tx;
+    float c11 = v011 + (v111 - v011) * tx;
+    float c0 = c00 + (c10 - c00) * ty;
+    float c1 = c01 + (c11 - c01) * ty;
+    float val = c0 + (c1 - c0) * tz;
+    if (needs_scale) val = val * s.value_range + s.min_value;
+    return val + diff_mag;
+}
+
+NT_DI vec3 clamp_to_box(const nt_sdf& s, vec3 p) {
+    return vec3(clampf(p.x, s.box_lower[0], s.box_upper[0]), clampf(p.y, s.box_lower[1], s.box_upper[1]),
+                clampf(p.z, s.box_lower[2], s.box_upper[2]));
+}
+NT_DI float sample(const nt_sdf& s, vec3 p) {  // texture_sample_sdf
+    vec3 c = clamp_to_box(s, p);
+    vec3 d = p - c;
+    return sample_clamped(s, c, sqrtf(dot(d, d)));
+}
+// _texture_sample_sdf_grad_hw_impl_variant: centred differences with half-voxel steps inside the box, the clamp direction outside
+NT_DI vec3 sample_grad(const nt_sdf& s, vec3 p) {
+    vec3 c = clamp_to_box(s, p);
+    vec3 d = p - c;
+    if (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f) {
+        float m = length(d);
+        if (m > 0.0f) return d / m;
+    }
+    vec3 g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float h = 0.5f / s.inv_dx[a];
+        vec3 p0 = p, p1 = p;
+        vset(p0, a, vget(p, a) + h);
+        vset(p1, a, vget(p, a) - h);
+        const float c0 = clampf(vget(p0, a), s.box_lower[a], s.box_upper[a]);
+        const float c1 = clampf(vget(p1, a), s.box_lower[a], s.box_upper[a]);
+        const float d0 = vget(p0, a) - c0, d1 = vget(p1, a) - c1;
+        vec3 q0 = p0, q1 = p1;
+        vset(q0, a, c0);
+        vset(q1, a, c1);
+        const float v0 = sample_clamped(s, q0, sqrtf(d0 * d0)), v1 = sample_clamped(s, q1, sqrtf(d1 * d1));
+        vset(g, a, (v0 - v1) * s.inv_dx[a]);
+    }
+    return g;
+}
+
+__global__ void sdf_sample_kernel(nt_sdf s, const float* __restrict__ pts, int n, float* __restrict__ dist, float* __restrict__ grad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vec3 p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    if (dist) dist[i] = sample(s, p);
+    if (grad) {
+        vec3 g = sample_grad(s, p);
+        grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z;
+    }
+}
+
+// do_edge_sdf_collision (texture path): deepest point of the edge v0 -> v1 in the SDF; returns (distance, t, endpoint code)
+NT_DI void edge_search(const nt_sdf& s, vec3 v0, vec3 v1, float midpoint_sdf, float precision_target, float& best_f, vec3& best_p,
+                       int& best_endpoint) {
+    const float golden = 0.3819660112501051f;
+    const vec3 dir = v1 - v0;
+    const float len_sq = length_sq(dir);
+    float inv_len = 1.0e12f;
+    if (len_sq > 0.0f) inv_len = 1.0f / sqrtf(len_sq);
+    const float tol_floor = 0.5f * precision_target * inv_len;
+    float a = 0.0f, b = 1.0f, x = 0.5f, w = 0.5f, v = 0.5f;
+    float fx = midpoint_sdf, fw = fx, fv = fx, d_step = 0.0f, e_step = 0.0f;
+    if (tol_floor < 0.25f) {
+        const float offset = 0.5f * golden, left = 0.5f - offset, right = 0.5f + offset;
+        const float f_left = sample(s, v0 + dir * left), f_right = sample(s, v0 + dir * right);
+        if (f_left < fx && f_left <= f_right) {
+            b = 0.5f; x = left; fx = f_left; w = 0.5f; fw = midpoint_sdf; v = right; fv = f_right;
+        } else if (f_right < fx) {
+            a = 0.5f; x = right; fx = f_right; w = 0.5f; fw = midpoint_sdf; v = left; fv = f_left;
+        } else {
+            a = left; b = right; w = left; fw = f_left; v = right; fv = f_right;
+        }
+    }
+    for (int it = 0; it < 3; ++it) {
+        const float m = 0.5f * (a + b);
+        const float tol = fmaxw(1.0e-2f * fabsf(x) + 1.0e-8f, tol_floor);
+        const float tol2 = 2.0f * tol;
+        if (fabsf(x - m) <= tol2 - 0.5f * (b - a)) break;
+        bool parabolic = false;
+        float trial = 0.0f;
+        if (fabsf(e_step) > tol) {
+            const float r = (x - w) * (fx - fv);
+            float q = (x - v) * (fx - fw);
+            float pnum = (x - v) * q - (x - w) * r;
+            q = 2.0f * (q - r);
+            if (q > 0.0f) pnum = -pnum;
+            else q = -q;
+            if (fabsf(pnum) < 0.5f * fabsf(q * e_step)) {
+                trial = pnum / q;
+                const float u_trial = x + trial;
+                if (u_trial - a >= tol2 && b - u_trial >= tol2) parabolic = true;
+            }
+        }
+        if (parabolic) {
+            e_step = d_step;
+            d_step = trial;
+        } else {
+            e_step = x >= m ? a - x : b - x;
+            d_step = golden * e_step;
+        }
+        float u;
+        if (fabsf(d_step) >= tol) u = x + d_step;
+        else u = d_step > 0.0f ? x + tol : x - tol;
+        const float fu = sample(s, v0 + dir * u);
+        if (fu <= fx) {
+            if (u < x) b = x;
+            else a = x;
+            v = w; fv = fw; w = x; fw = fx; x = u; fx = fu;
+        } else {
+            if (u < x) a = u;
+            else b = u;
+            if (fu <= fw || w == x) {
+                v = w; fv = fw; w = u; fw = fu;
+            } else if (fu <= fv || v == x || v == w) {
+                v = u; fv = fu;
+            }
+        }
+    }
+    best_endpoint = 0;
+    float best_t = x;
+    best_f = fx;
+    if (a == 0.0f) {
+        const float fe = sample(s, v0);
+        if (fe < best_f) { best_t = 0.0f; best_f = fe; best_endpoint = 1; }
+    }
+    if (b == 1.0f) {
+        const float fe = sample(s, v0 + dir * 1.0f);
+        if (fe < best_f) { best_t = 1.0f; best_f = fe; best_endpoint = 2; }
+    }
+    best_p = v0 + dir * best_t;
+}
+
+NT_DI xform load_xform(const float* p) { return xform(vec3(p[0], p[1], p[2]), quat(p[3], p[4], p[5], p[6])); }
+
+__global__ void __launch_bounds__(256) mesh_sdf_collide_kernel(nt_mesh_sdf_args a) {
+    for (int pair_idx = blockIdx.x; pair_idx < a.pair_count; pair_idx += gridDim.x) {
+        const int s0 = a.pairs[2 * pair_idx], s1 = a.pairs[2 * pair_idx + 1];
+        const float gap_sum = a.shape_gap[s0] + a.shape_gap[s1];
+        for (int mode = 0; mode < 2; ++mode) {
+            const int tri_shape = mode == 0 ? s0 : s1, sdf_shape = mode == 0 ? s1 : s0;
+            const int sdf_idx = a.shape_sdf_index[sdf_shape];
+            const int e0 = a.shape_edge_range[2 * tri_shape], ne = a.shape_edge_range[2 * tri_shape + 1];
+            if (sdf_idx < 0 || sdf_idx >= a.sdf_count || ne <= 0) continue;  // no SDF on that side / no edges on this side
+            const nt_sdf s = a.sdf_table[sdf_idx];
+            if (s.cx <= 0) continue;
+            const float* dt = a.shape_data + 4 * tri_shape;
+            const float* ds = a.shape_data + 4 * sdf_shape;
+            vec3 sdf_scale(ds[0], ds[1], ds[2]);
+            if (s.scale_baked) sdf_scale = vec3(1.0f, 1.0f, 1.0f);
+            const xform X_tri = load_xform(a.shape_transform + 7 * tri_shape), X_sdf = load_xform(a.shape_transform + 7 * sdf_shape);
+            const xform X_m2s = xform_inverse(X_sdf) * X_tri;
+            const float tri_margin = dt[3], sdf_margin = ds[3];
+            // safe_sdf_scale_inverse
+            const float eps = 1.0e-10f;
+            auto guard = [&](float v) { return fabsf(v) > eps ? v : (v >= 0.0f ? eps : -eps); };
+            const float sx = guard(sdf_scale.x), sy = guard(sdf_scale.y), sz = guard(sdf_scale.z);
+            const vec3 inv_scale(1.0f / sx, 1.0f / sy, 1.0f / sz);
+            const float min_scale = fminw(fminw(fabsf(sx), fabsf(sy)), fabsf(sz));
+            const float radius_scale = fmaxw(fmaxw(fabsf(inv_scale.x), fabsf(inv_scale.y)), fabsf(inv_scale.z));
+            const float contact_threshold = gap_sum + tri_margin + sdf_margin;
+            const float thr_unscaled = contact_threshold / min_scale;
+            const float inner = tri_margin + sdf_margin;
+            const float precision = fminw(inner / min_scale, s.voxel_radius);  // mesh_sdf_contact_search_precision
+            const vec3 blo(s.box_lower[0], s.box_lower[1], s.box_lower[2]), bhi(s.box_upper[0], s.box_upper[1], s.box_upper[2]);
+            for (int e = threadIdx.x; e < ne; e += blockDim.x) {
+                const float* ec = a.edge_centers + 4 * (size_t)(e0 + e);
+                const float* eh = a.edge_halves + 4 * (size_t)(e0 + e);
+                // cull: bounding sphere of the edge against the SDF box, then against the midpoint value
+                const vec3 center = cw_mul(xform_point(X_m2s, vec3(ec[0], ec[1], ec[2])), inv_scale);
+                const float threshold = ec[3] * radius_scale + thr_unscaled;
+                const vec3 cl = vmin(vmax(center, blo), bhi);
+                const float d2 = length_sq(center - cl);
+                if (d2 > threshold * threshold) continue;
+                const float mid = sample_clamped(s, cl, d2 > 0.0f ? sqrtf(d2) : 0.0f);
+                if (!(mid <= threshold)) continue;
+                // the edge in the SDF's unscaled space + its corner ownership
+                const vec3 c_loc = xform_point(X_m2s, vec3(ec[0], ec[1], ec[2]));
+                const vec3 h_loc = xform_vector(X_m2s, vec3(eh[0], eh[1], eh[2]));
+                const int ownership = (int)eh[3];
+                const vec3 v0 = cw_mul(c_loc - h_loc, inv_scale), v1 = cw_mul(c_loc + h_loc, inv_scale);
+                float dist_u;
+                vec3 p_u;
+                int endpoint;
+                edge_search(s, v0, v1, mid, precision, dist_u, p_u, endpoint);
+                const float dist_approx = dist_u * min_scale;
+                // mesh_sdf_contact_passes_inner_cull_consistency
+                bool consistent = true;
+                if (dist_approx < inner) {
+                    const vec3 ic = (v0 + v1) * 0.5f;
+                    const float ir = length(v1 - v0) * 0.5f;
+                    const float cr = ir + inner / min_scale;
+                    const vec3 icl = vmin(vmax(ic, blo), bhi);
+                    if (length_sq(ic - icl) > cr * cr) consistent = false;
+                    else consistent = mid <= cr;
+                }
+                const bool owns = endpoint == 0 || ownership == 0 || (ownership & endpoint) != 0;
+                if (!(dist_approx < contact_threshold && consistent && owns)) continue;
+                vec3 dir_u = sample_grad(s, p_u);
+                // scale_sdf_result_to_world (sdf_contact.py:155-182): gradient back through the anisotropic scale
+                const float dist = dist_u * min_scale;        // conservative distance through the smallest scale
+                const vec3 dir = cw_mul(dir_u, inv_scale);     // normalised after the rigid rotation below
+                const vec3 point = cw_mul(p_u, sdf_scale);
+                const vec3 pw = xform_point(X_sdf, point);
+                vec3 dw = xform_vector(X_sdf, dir);
+                const float dl2 = length_sq(dw);
+                if (dl2 > 0.0f) dw = dw * (1.0f / sqrtf(dl2));
+                else {
+                    vec3 fb = pw - X_sdf.p;
+                    const float fl2 = length_sq(fb);
+                    dw = fl2 > 0.0f ? fb * (1.0f / sqrtf(fl2)) : vec3(0.0f, 1.0f, 0.0f);
+                }
+                const vec3 n = mode == 0 ? -dw : dw;
+                const int slot = atomicAdd(a.out_count, 1);
+                if (slot < a.capacity) {
+                    a.out_pair[slot] = pair_idx;
+                    a.out_key[slot] = (e << 2) | (mode << 1);
+                    float* o = a.out_data + 9 * (size_t)slot;
+                    o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+                    o[3] = n.x; o[4] = n.y; o[5] = n.z;
+                    o[6] = dist;
+                    o[7] = a.shape_data[4 * s0 + 3];
+                    o[8] = a.shape_data[4 * s1 + 3];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+nt_status nt_sdf_sample(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist, float* out_grad, void* stream) {
+    if (!sdf || !points || n <= 0 || (!out_dist && !out_grad) || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;
+    if (sdf->quantization != 4 && sdf->quantization != 2 && sdf->quantization != 1) return NT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sdf_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *sdf, points, n, out_dist, out_grad);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* a, void* stream) {
+    if (!a || a->pair_count < 0 || !a->out_count || !a->out_pair || !a->out_key || !a->out_data || a->capacity <= 0) return NT_ERR_INVALID_ARG;
+    if (a->pair_count == 0) return NT_OK;
+    int blocks = a->pair_count < 2048 ? a->pair_count : 2048;
+    hipLaunchKernelGGL(mesh_sdf_collide_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+}  // extern "C"

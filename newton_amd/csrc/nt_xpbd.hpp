@@ -138,12 +138,12 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
 template <int EPB>
 NT_DI void phase_body_derived(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) c.update_body_derived(b);
+    for (int b = c.tslot; b < c.a.m.nb; b += c.nslot) c.update_body_derived(b);
 }
 template <int EPB, bool SEMI>
 NT_DI void phase_integrate(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) integrate_item<EPB, SEMI>(c, b);
+    for (int b = c.tslot; b < c.a.m.nb; b += c.nslot) integrate_item<EPB, SEMI>(c, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,7 +394,7 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
         // lane i takes the environment's i-th live contact (L.px: exclusive prefix of the per-pair live counts); records
         // of dead slots are never written and never read (apply_item stops at the pair's live count)
         const int total = (int)c.lds[(c.L.px + np) * EPB + c.e];
-        for (int i = c.slot; i < total; i += c.nslot) {
+        for (int i = c.tslot; i < total; i += c.nslot) {
             int lo = 0, hi = np;  // the last pair whose prefix is <= i
             while (hi - lo > 1) {
                 int mid = (lo + hi) >> 1;
@@ -487,7 +487,7 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
 template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false>
 NT_DI void phase_apply(const Ctx<EPB>& c) {
     if (!c.valid) return;
-    for (int b = c.slot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, b);
+    for (int b = c.tslot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1035,7 +1035,8 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
     __syncthreads();
     NT_TICK(1);
     if (c.big) {
-        phase_pairs<EPB, CVX>(c);  // pair-heavy tile: one lane per contact slot, no candidate staging (19 rows per pair)
+        phase_pairs_big_broad(c);  // pair-heavy tile: compact the candidates first, no candidate staging (19 rows per pair)
+        phase_pairs_big_narrow<EPB, CVX>(c);
     } else {
         phase_pair_eval<EPB, CVX>(c);
         __syncthreads();

@@ -108,3 +108,53 @@ def deduplicate_vertices(mesh: Mesh) -> np.ndarray:
     v = mesh.vertices
     _, first = np.unique(v, axis=0, return_index=True)
     return v[np.sort(first)]
+
+
+def canonical_vertex_ids(vertices) -> np.ndarray:
+    """Per-vertex ids that fold geometrically coincident vertices (1e-7 m buckets) together
+    (Mesh._canonical_vertex_ids, newton/_src/geometry/types.py:1172-1180)."""
+    q = np.ascontiguousarray(np.round(np.asarray(vertices, dtype=np.float32) * 1e7).astype(np.int64))
+    void = q.view(np.dtype((np.void, q.dtype.itemsize * q.shape[1])))
+    _, canonical = np.unique(void, return_inverse=True)
+    return canonical.ravel()
+
+
+def mesh_edges(vertices, indices) -> np.ndarray:
+    """Unique edges [N,2] (original vertex indices, first occurrence order) with geometric de-duplication
+    (Mesh.edges, newton/_src/geometry/types.py:1183-1212)."""
+    tris = np.asarray(indices, dtype=np.int32).reshape(-1, 3)
+    if tris.size == 0:
+        return np.empty((0, 2), dtype=np.int32)
+    c = canonical_vertex_ids(vertices)[tris]
+    n = len(tris)
+    canon = np.empty((n * 3, 2), dtype=np.int64)
+    orig = np.empty((n * 3, 2), dtype=np.int32)
+    for k, (a, b) in enumerate(((0, 1), (1, 2), (0, 2))):
+        canon[k::3, 0], canon[k::3, 1] = np.minimum(c[:, a], c[:, b]), np.maximum(c[:, a], c[:, b])
+        orig[k::3, 0], orig[k::3, 1] = tris[:, a], tris[:, b]
+    canon = np.ascontiguousarray(canon)
+    _, first = np.unique(canon.view(np.dtype((np.void, canon.dtype.itemsize * 2))), return_index=True)
+    first.sort()
+    return orig[first]
+
+
+def mesh_edge_tables(vertices, indices, scale=(1.0, 1.0, 1.0)):
+    """(edge_centers [N,4], edge_halves [N,4]) of one shape: scaled local centre + radius, scaled half vector + corner
+    ownership code 4 + owns_v0 + 2 * owns_v1 (the first edge that touches a canonical vertex owns it), as the reference's
+    finalize() packs them (newton/_src/sim/builder.py:12088-12116)."""
+    edges = mesh_edges(vertices, indices)
+    v = np.asarray(vertices, dtype=np.float32) * np.asarray(scale, dtype=np.float32)
+    if len(edges) == 0:
+        return np.zeros((0, 4), dtype=np.float32), np.zeros((0, 4), dtype=np.float32)
+    v0, v1 = v[edges[:, 0]], v[edges[:, 1]]
+    halves = np.ascontiguousarray((v1 - v0) * 0.5, dtype=np.float32)
+    centers = np.ascontiguousarray((v0 + v1) * 0.5, dtype=np.float32)
+    radii = np.linalg.norm(halves, axis=1, keepdims=True)
+    canon = canonical_vertex_ids(vertices)[edges].reshape(-1)
+    ends = np.arange(2 * len(edges), dtype=np.int64)
+    first = np.full(int(canon.max()) + 1, 2 * len(edges), dtype=np.int64)
+    np.minimum.at(first, canon, ends)
+    owns = (first[canon] == ends).reshape(-1, 2)
+    code = (4.0 + owns[:, 0].astype(np.float32) + 2.0 * owns[:, 1]).reshape(-1, 1)
+    return (np.ascontiguousarray(np.concatenate([centers, radii], axis=1), dtype=np.float32),
+            np.ascontiguousarray(np.concatenate([halves, code], axis=1), dtype=np.float32))

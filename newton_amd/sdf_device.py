@@ -1,0 +1,108 @@
+"""Device side of the texture SDFs: upload a newton_amd.sdf.TextureSDF, sample it on the MI355X (nt_sdf_sample) and run the
+mesh-vs-SDF narrow phase (nt_mesh_sdf_collide, newton/_src/geometry/sdf_contact.py:1098-1515 with reduce_contacts=False).
+
+The inputs are Newton's flat arrays (world shape transforms, shape_data = scale + margin, shape_gap, shape_sdf_index,
+shape_edge_range / mesh_edge_centers / mesh_edge_halves); the outputs are ContactData rows appended through an atomic counter
+and ordered afterwards by the reference's contact sort key (pair, edge, mode) -- contact_data.py:60-90."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .sdf import QuantizationMode, TextureSDF
+
+
+def _torch():
+    import torch  # noqa: PLC0415
+
+    return torch
+
+
+class DeviceSDF:
+    """A TextureSDF resident in HBM + its nt_sdf descriptor."""
+
+    def __init__(self, sdf: TextureSDF, device="cuda:0"):
+        torch = _torch()
+        self.host = sdf
+        self.device = torch.device(device)
+        self.coarse = torch.from_numpy(np.ascontiguousarray(sdf.coarse)).to(self.device)
+        sub = np.ascontiguousarray(sdf.subgrid)
+        if sub.dtype == np.uint16:  # torch has no uint16 arithmetic, but the bytes are all the kernel needs
+            self.subgrid = torch.from_numpy(sub.view(np.int16)).to(self.device)
+        else:
+            self.subgrid = torch.from_numpy(sub).to(self.device)
+        self.slots = torch.from_numpy(np.ascontiguousarray(sdf.slots).view(np.int32)).to(self.device)
+        d = _lib.nt_sdf()
+        d.coarse, d.subgrid, d.slots = self.coarse.data_ptr(), self.subgrid.data_ptr(), self.slots.data_ptr()
+        d.cx, d.cy, d.cz = (int(x) for x in sdf.slots.shape)
+        d.tex_size, d.subgrid_size = int(sdf.subgrid.shape[0]), int(sdf.subgrid_size)
+        d.quantization, d.scale_baked = int(sdf.quantization_mode), int(bool(sdf.scale_baked))
+        for k in range(3):
+            d.box_lower[k], d.box_upper[k] = float(sdf.box_lower[k]), float(sdf.box_upper[k])
+            d.inv_dx[k], d.voxel_size[k] = float(sdf.inv_dx[k]), float(sdf.voxel_size[k])
+        d.voxel_radius, d.min_value, d.value_range = float(sdf.voxel_radius), float(sdf.min_value), float(sdf.value_range)
+        self.desc = d
+
+    def sample(self, points, grad: bool = False):
+        """texture_sample_sdf (and the narrow phase's centred-difference gradient) at local points [N,3] (tensor or array)."""
+        torch = _torch()
+        lib = _lib.load()
+        p = torch.as_tensor(np.ascontiguousarray(points, dtype=np.float32) if not isinstance(points, torch.Tensor) else points,
+                            dtype=torch.float32, device=self.device).contiguous()
+        n = p.shape[0]
+        dist = torch.empty(n, dtype=torch.float32, device=self.device)
+        g = torch.empty((n, 3), dtype=torch.float32, device=self.device) if grad else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(lib.nt_sdf_sample(C.byref(self.desc), p.data_ptr(), n, dist.data_ptr(), g.data_ptr() if grad else None, stream),
+                   "nt_sdf_sample")
+        return (dist, g) if grad else dist
+
+
+def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_index, sdfs, shape_edge_range, edge_centers,
+                     edge_halves, capacity: int | None = None, device="cuda:0"):
+    """Run nt_mesh_sdf_collide; returns a dict of numpy arrays sorted by (pair, key): pair, key, center [n,3], normal [n,3],
+    distance, margin0, margin1, plus `count` (the atomic counter, which keeps counting past the capacity).
+    `sdfs`: list of DeviceSDF (or None) indexed by shape_sdf_index."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = torch.device(device)
+
+    def up(a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return torch.from_numpy(a if a.size else np.zeros(1, dtype=dtype)).to(dev)
+
+    pairs_np = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    t_pairs, t_X = up(pairs_np, np.int32), up(shape_transform, np.float32)
+    t_data, t_gap, t_idx = up(shape_data, np.float32), up(shape_gap, np.float32), up(shape_sdf_index, np.int32)
+    t_er, t_ec, t_eh = up(shape_edge_range, np.int32), up(edge_centers, np.float32), up(edge_halves, np.float32)
+    table = (_lib.nt_sdf * max(len(sdfs), 1))()
+    for k, s in enumerate(sdfs):
+        if s is not None:
+            table[k] = s.desc
+    t_table = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(dev)
+    if capacity is None:
+        er = np.asarray(shape_edge_range, dtype=np.int64).reshape(-1, 2)
+        capacity = int(sum(er[a, 1] + er[b, 1] for a, b in pairs_np)) + 1  # unreduced: at most one contact per edge and mode
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    o_pair = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
+    o_key = torch.zeros(capacity, dtype=torch.int32, device=dev)
+    o_data = torch.zeros((capacity, 9), dtype=torch.float32, device=dev)
+    a = _lib.nt_mesh_sdf_args()
+    a.pairs, a.pair_count = t_pairs.data_ptr(), len(pairs_np)
+    a.shape_transform, a.shape_data, a.shape_gap = t_X.data_ptr(), t_data.data_ptr(), t_gap.data_ptr()
+    a.shape_sdf_index, a.sdf_table, a.sdf_count = t_idx.data_ptr(), t_table.data_ptr(), len(sdfs)
+    a.shape_edge_range, a.edge_centers, a.edge_halves = t_er.data_ptr(), t_ec.data_ptr(), t_eh.data_ptr()
+    a.out_count, a.out_pair, a.out_key, a.out_data, a.capacity = (count.data_ptr(), o_pair.data_ptr(), o_key.data_ptr(),
+                                                                   o_data.data_ptr(), capacity)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.nt_mesh_sdf_collide(C.byref(a), stream), "nt_mesh_sdf_collide")
+    torch.cuda.current_stream(dev).synchronize()
+    n_total = int(count.item())
+    n = min(n_total, capacity)
+    pair, key, data = o_pair[:n].cpu().numpy(), o_key[:n].cpu().numpy(), o_data[:n].cpu().numpy()
+    order = np.lexsort((key, pair))
+    pair, key, data = pair[order], key[order], data[order]
+    return {"count": n_total, "pair": pair, "key": key, "center": data[:, 0:3], "normal": data[:, 3:6], "distance": data[:, 6],
+            "margin0": data[:, 7], "margin1": data[:, 8]}

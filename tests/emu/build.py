@@ -16,7 +16,8 @@ CSRC = os.path.join(ROOT, "newton_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
 FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_collide.hpp", "nt_xpbd.hpp",
-         "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip"]
+         "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip",
+         "nt_sdf.hip", "nt_build_id.hip"]
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
 WAVE_SYNC_EMU = ("#define FS_WAVE_SYNC() emu_wave_sync((unsigned)(G * (((int)c.a.m.env_count - (int)blockIdx.x * EPB) < EPB ? "
@@ -33,19 +34,22 @@ def transform(text: str) -> str:
 
 def build(force: bool = False) -> str:
     os.makedirs(OUT, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in FILES] + [os.path.join(HERE, "hip_emu.h"),
+    files = [f for f in FILES if os.path.exists(os.path.join(CSRC, f))]  # (tools/emu_bitcheck.py builds older revisions too)
+    srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "hip_emu.h"),
                                                      os.path.abspath(__file__),
                                                      os.path.join(ROOT, "include", "newton_hip.h")]
     digest = hashlib.sha1(b"".join(open(s, "rb").read() for s in srcs)).hexdigest()
     stamp = os.path.join(OUT, "stamp")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
         return LIB
-    for f in FILES:
+    for f in files:
         text = transform(open(os.path.join(CSRC, f)).read()).replace('#include "nt_broadphase_core.hpp"', '#include "nt_broadphase_core.hpp"')
         assert "hip_runtime" not in text and "__builtin_amdgcn" not in text, f
         open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w").write(text)
     cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
-           f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(OUT, "nt_broadphase.cpp"), "-o", LIB]
+           f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(OUT, "nt_broadphase.cpp"),
+           *([os.path.join(OUT, "nt_sdf.cpp")] if "nt_sdf.hip" in files else []),
+           *([os.path.join(OUT, "nt_build_id.cpp")] if "nt_build_id.hip" in files else []), "-o", LIB]
     subprocess.run(cmd, check=True)
     open(stamp, "w").write(digest)
     return LIB

@@ -243,7 +243,7 @@ def joint_zoo_scene(world_count: int, device=None, seed: int | None = 0, free_ro
     return model
 
 
-def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.005):
+def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.005, mu=None):
     """Config C5 without the SDF / hydroelastic contact models: `n_hulls` random convex hulls (16-32 vertices, radius
     U(0.03, 0.06)) dropped into a five-wall bin (ground plane + four static boxes); every hull pair and every hull-wall pair
     is a candidate, so one environment has n(n-1)/2 + 5n pairs (2 336 for 64 hulls) and its per-contact solver records no
@@ -255,6 +255,8 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
 
     rng = np.random.default_rng(seed)
     env = nt.ModelBuilder()
+    if mu is not None:
+        env.default_shape_cfg.mu = float(mu)
     side = 0.07 * np.ceil(np.sqrt(n_hulls))
     # hulls start on a lattice with 0.135 m pitch (> twice the largest hull radius): no initial interpenetration -- randomly
     # overlapping hulls make XPBD eject them at 10^3 rad/s (oracle and device alike) until the state overflows

@@ -61,84 +61,21 @@ def _contacts(name):
                                ct.margin0[:n], ct.margin1[:n])
 
 
-def _sd_box(p, center, half):
-    q = np.abs(np.asarray(p) - center) - half
-    return np.linalg.norm(np.maximum(q, 0.0)) + min(q.max(), 0.0)
+import convex_known_answers as KA
 
 
-def test_box_box_face(oracle_lib):
-    _, cs = _contacts("box_box_face")
-    assert len(cs) == 4
-    for c, n, d in cs:
-        assert abs(np.linalg.norm(n) - 1.0) < 1e-5 and n[0] > 0.9
-        assert abs(d + 0.2) < 1e-4
-        assert abs(_sd_box(c - n * d / 2, [0, 0, 0], 1.0)) < 5e-5 and abs(_sd_box(c + n * d / 2, [1.8, 0, 0], 1.0)) < 5e-5
+def _cs(name):
+    return _contacts(name)[1]
 
 
-def test_box_box_edge(oracle_lib):
-    _, cs = _contacts("box_box_edge")
-    assert len(cs) > 0
-    assert abs(np.linalg.norm(cs[0][1]) - 1.0) < 1e-5
-    assert abs(min(d for _, _, d in cs) - (1.2 - 0.5 - np.sqrt(0.5))) < 1e-4
+@pytest.mark.parametrize("check", KA.CHECKS, ids=lambda f: f.__name__)
+def test_convex_known_answers(oracle_lib, check):
+    check(_cs)
 
 
-@pytest.mark.parametrize("name,expected", [("box_box_overlap_0p01", -0.01), ("box_box_touching", 0.0),
-                                           ("box_box_small_thickness", -(0.01 + 5e-5)), ("box_box_large_thickness", -0.02)])
+@pytest.mark.parametrize("name,expected", KA.PENETRATION_CASES)
 def test_box_box_penetration_accuracy(oracle_lib, name, expected):
-    """test_narrow_phase.py:2739-2807,2869-2951: deepest penetration within 5e-5 for each `enlarge` branch."""
-    _, cs = _contacts(name)
-    assert len(cs) > 0
-    assert abs(min(d for _, _, d in cs) - expected) < 5e-5
-
-
-def test_box_box_contact_point_on_surface(oracle_lib):
-    _, cs = _contacts("box_box_overlap_0p05")
-    ok = 0
-    for c, n, d in cs:
-        if d >= 0:
-            continue
-        assert abs(_sd_box(c - n * d / 2, [0, 0, 0], 0.5)) < 5e-5
-        assert abs(_sd_box(c + n * d / 2, [0, 0, 0.95], 0.5)) < 5e-5
-        ok += 1
-    assert ok > 0
-
-
-def test_ellipsoid_family(oracle_lib):
-    _, cs = _contacts("ell_ell_separated")
-    assert len(cs) == 0 or cs[0][2] > 0.0
-    _, cs = _contacts("ell_ell_penetrating")
-    assert len(cs) == 1 and cs[0][2] < 0 and abs(np.linalg.norm(cs[0][1]) - 1) < 1e-5 and cs[0][1][0] > 0
-    assert abs(cs[0][2] + 0.2) < 1e-3
-    # type sorting puts the sphere first (SPHERE < ELLIPSOID): normal points sphere -> ellipsoid = -x
-    _, cs = _contacts("ell_sphere")
-    assert len(cs) == 1 and cs[0][2] < 0 and cs[0][1][0] < -0.9 and abs(cs[0][2] + 0.1) < 1e-3
-    _, cs = _contacts("ell_box")
-    assert len(cs) == 1 and cs[0][1][0] > 0.9 and abs(cs[0][2] + 0.1) < 1e-3
-    _, cs = _contacts("ell_capsule")
-    assert len(cs) == 1 and abs(np.linalg.norm(cs[0][1]) - 1) < 1e-5
-    _, cs = _contacts("ell_ell_spherelike")
-    assert len(cs) == 1 and abs(cs[0][2] + 0.2) < 1e-3 and cs[0][1][0] > 0.99
-
-
-def test_axial_shapes(oracle_lib):
-    """Cylinder / cone / capsule manifolds: counts and depths from plain geometry."""
-    _, cs = _contacts("capsule_box")       # capsule lying on the box top: 2 end contacts, depth 0.05
-    assert len(cs) >= 2
-    assert abs(min(d for _, _, d in cs) + 0.05) < 2e-4
-    _, cs = _contacts("cylinder_box_flat")  # cap face on box top: depth 0.02
-    assert len(cs) >= 3
-    assert all(abs(d + 0.02) < 2e-4 for _, _, d in cs)
-    _, cs = _contacts("cylinder_box_rolling")  # cylinder on its side: line contact, depth 0.01
-    assert len(cs) >= 2
-    assert abs(min(d for _, _, d in cs) + 0.01) < 2e-4
-    for c, n, d in cs:  # rolling projection keeps contacts in the plane through the axis
-        assert abs(c[0]) < 1e-4
-    _, cs = _contacts("cone_box")  # base on the box top, depth 0.01
-    assert len(cs) >= 3 and all(abs(d + 0.01) < 2e-4 for _, _, d in cs)
-    _, cs = _contacts("sphere_cone")
-    assert len(cs) == 1
-    _, cs = _contacts("cylinder_cylinder")
-    assert len(cs) >= 3 and all(abs(d + 0.02) < 2e-4 for _, _, d in cs)
+    KA.check_box_box_penetration_accuracy(_cs, name, expected)
 
 
 def test_aligned_box_stack_remains_stable(oracle_lib):
