@@ -57,7 +57,7 @@ WORKLOADS = {
                                         "mass matrix), cylinder colliders + ground plane"),
     "box_stack": dict(solver="xpbd", iterations=4, dt=1.0 / 240.0, kernel="xpbd_rollout_kernel<16,true>", drop=0.0, settle=10,
                       name="C2: 8-box stack on a ground plane (box-box pairs through MPR/GJK + manifold)"),
-    "hull_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 240.0, kernel="xpbd_rollout_kernel<1,true,true>", drop=0.0, settle=30,
+    "hull_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 1200.0, kernel="xpbd_rollout_kernel<1,true,true>", drop=0.0, settle=30,
                      name="C5 geometry without SDF / hydroelastic: 64 convex hulls (16-32 vertices) in a five-wall bin, all "
                           "2 336 pairs per env through MPR/GJK + manifold, contact records in HBM"),
 }

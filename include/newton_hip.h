@@ -255,6 +255,14 @@ nt_status nt_broadphase_nxn(const nt_broadphase_in* in, const int32_t* index_map
 nt_status nt_broadphase_sap(const nt_broadphase_in* in, const int32_t* sorted_map, const int32_t* slice_ends, int32_t segments,
                             int32_t num_regular_worlds, int32_t map_len, int32_t* pairs, int32_t* count, int32_t cap,
                             void* stream);
+/* BroadPhaseSAP.launch entirely on the device (broad_phase_sap.py:395-848): projects the gap-widened AABBs on the reference's
+ * fixed axis normalize(0.5935, 0.7790, 0.1235), sorts every world segment in LDS (one workgroup per segment, bitonic, stable on
+ * the map position) and sweeps.  index_map / slice_ends as for nt_broadphase_nxn; max_segment = longest segment (<= 4096, else
+ * NT_ERR_UNSUPPORTED); sorted_map [map_len] and projections [2][map_len] are caller-provided scratch / outputs. */
+nt_status nt_broadphase_sap_device(const nt_broadphase_in* in, const int32_t* index_map, const int32_t* slice_ends,
+                                   int32_t segments, int32_t num_regular_worlds, int32_t map_len, int32_t max_segment,
+                                   int32_t* sorted_map, float* projections, int32_t* pairs, int32_t* count, int32_t cap,
+                                   void* stream);
 /* pair_list: [n_pairs][2] precomputed shape pairs (Model.shape_contact_pairs); only the AABB (and immovable) test remains */
 nt_status nt_broadphase_explicit(const nt_broadphase_in* in, const int32_t* pair_list, int32_t n_pairs, int32_t* pairs,
                                  int32_t* count, int32_t cap, void* stream);

@@ -136,6 +136,8 @@ SYMBOLS = {
     "nt_contacts_export_force": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_contacts), _P, C.c_float, C.c_int32, _P, _P, _P]),
     "nt_broadphase_nxn": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
     "nt_broadphase_sap": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
+    "nt_broadphase_sap_device": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P,
+                                               _P, _P, C.c_int32, _P]),
     "nt_broadphase_explicit": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, C.c_int32, _P, _P, C.c_int32, _P]),
     "nt_error_string": (C.c_char_p, [C.c_int32]),
     "nt_build_info": (C.c_char_p, []),

@@ -81,6 +81,105 @@ __global__ void __launch_bounds__(256) broadphase_segment_kernel(BpArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device SAP (broad_phase_sap.py:44-79 projection, :787-811 per-world sort, :221-300 range + sweep): one workgroup per world
+// segment projects the gap-widened AABBs on the reference's fixed axis normalize(0.5935, 0.7790, 0.1235)
+// (_sap_project_aabb: centre +- |d| . (half_size + gap)), sorts (projection_lower, map position) with a bitonic network in
+// LDS (padding keys 1e30 like the reference's tile sort) and writes the sorted map plus the projected interval of every
+// sorted position; the sweep kernel below then walks forward until a later interval starts past its own end.
+// ------------------------------------------------------------------------------------------------
+constexpr int SAP_TILE = 4096;  // shapes per world segment that fit the LDS sort (32 KB of keys + positions)
+
+__device__ inline void sap_project(const BpView& v, int s, float& lo, float& hi) {
+    const float dx = 0.5935f, dy = 0.7790f, dz = 0.1235f;
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float ax = dx * inv, ay = dy * inv, az = dz * inv;
+    const float* l = v.lower + 3 * s;
+    const float* u = v.upper + 3 * s;
+    const float g = v.gap ? v.gap[s] : 0.0f;
+    const float hx = 0.5f * (u[0] - l[0]) + g, hy = 0.5f * (u[1] - l[1]) + g, hz = 0.5f * (u[2] - l[2]) + g;
+    const float radius = fabsf(ax) * hx + fabsf(ay) * hy + fabsf(az) * hz;
+    const float center = ax * (0.5f * (l[0] + u[0])) + ay * (0.5f * (l[1] + u[1])) + az * (0.5f * (l[2] + u[2]));
+    lo = center - radius;
+    hi = center + radius;
+}
+
+__global__ void __launch_bounds__(256) sap_sort_kernel(BpView v, const int32_t* __restrict__ map, const int32_t* __restrict__ slice_ends,
+                                                       int32_t* __restrict__ sorted_map, float* __restrict__ proj /*[2][map_len]*/,
+                                                       int map_len) {
+    __shared__ float key[SAP_TILE];
+    __shared__ int pos[SAP_TILE];
+    const int seg = blockIdx.x;
+    const int begin = seg == 0 ? 0 : slice_ends[seg - 1], end = slice_ends[seg];
+    const int n = end - begin;
+    if (n <= 0) return;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        float lo = 1.0e30f, hi;
+        if (i < n) sap_project(v, map[begin + i], lo, hi);
+        key[i] = lo;
+        pos[i] = i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const float ki = key[i], kl = key[l];
+                    const int pi = pos[i], pl = pos[l];
+                    const bool gt = ki > kl || (ki == kl && pi > pl);  // (key, original position): a stable order
+                    if (gt == up) {
+                        key[i] = kl; key[l] = ki;
+                        pos[i] = pl; pos[l] = pi;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int s = map[begin + pos[i]];
+        float lo, hi;
+        sap_project(v, s, lo, hi);
+        sorted_map[begin + i] = s;
+        proj[begin + i] = lo;
+        proj[map_len + begin + i] = hi;
+    }
+}
+
+__global__ void __launch_bounds__(256) sap_sweep_kernel(BpArgs a, const float* __restrict__ proj) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = t < a.map_len;
+    int seg_end = 0, si = 0;
+    bool dedicated = false;
+    float hi_i = 0.0f;
+    if (active) {
+        int seg = bp_segment_of(a.slice_ends, a.segments, t);
+        seg_end = a.slice_ends[seg];
+        dedicated = seg >= a.num_regular;
+        si = a.map[t];
+        hi_i = proj[a.map_len + t];
+    }
+    int q = t + 1;
+    bool running = active && q < seg_end;
+    while (__any(running)) {
+        bool hit = false;
+        int s1 = 0, s2 = 0;
+        if (running) {
+            if (bp_sap_past(proj[q], hi_i)) {
+                running = false;
+            } else {
+                hit = bp_candidate(a.v, si, a.map[q], dedicated, s1, s2);
+                q += 1;
+                if (q >= seg_end) running = false;
+            }
+        }
+        bp_append(hit, s1, s2, a.pairs, a.count, a.cap);
+    }
+}
+
 // _nxn_broadphase_precomputed_pairs (broad_phase_nxn.py:29-69): one lane per listed pair
 __global__ void __launch_bounds__(256) broadphase_explicit_kernel(BpView v, const int32_t* list, int n_pairs, int32_t* pairs,
                                                                   int32_t* count, int32_t cap) {
@@ -137,6 +236,24 @@ nt_status nt_broadphase_sap(const nt_broadphase_in* in, const int32_t* sorted_ma
                             int32_t num_regular_worlds, int32_t map_len, int32_t* pairs, int32_t* count, int32_t cap,
                             void* stream) {
     return launch_segments<true>(in, sorted_map, slice_ends, segments, num_regular_worlds, map_len, pairs, count, cap, stream);
+}
+
+nt_status nt_broadphase_sap_device(const nt_broadphase_in* in, const int32_t* index_map, const int32_t* slice_ends,
+                                   int32_t segments, int32_t num_regular_worlds, int32_t map_len, int32_t max_segment,
+                                   int32_t* sorted_map, float* projections, int32_t* pairs, int32_t* count, int32_t cap,
+                                   void* stream) {
+    if (!bp_in_ok(in) || !count || cap < 0 || (cap > 0 && !pairs) || segments < 0 || map_len < 0) return NT_ERR_INVALID_ARG;
+    if (map_len == 0 || segments == 0) return NT_OK;
+    if (!index_map || !slice_ends || !sorted_map || !projections) return NT_ERR_INVALID_ARG;
+    if (max_segment > SAP_TILE) return NT_ERR_UNSUPPORTED;  // a world with more shapes than the LDS sort tile
+    BpArgs a;
+    a.v = make_view(in);
+    a.map = sorted_map; a.slice_ends = slice_ends; a.segments = segments; a.num_regular = num_regular_worlds; a.map_len = map_len;
+    a.pairs = pairs; a.count = count; a.cap = cap;
+    hipLaunchKernelGGL(sap_sort_kernel, dim3(segments), dim3(256), 0, (hipStream_t)stream, a.v, index_map, slice_ends, sorted_map,
+                       projections, map_len);
+    hipLaunchKernelGGL(sap_sweep_kernel, dim3((map_len + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, projections);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 
 nt_status nt_broadphase_explicit(const nt_broadphase_in* in, const int32_t* pair_list, int32_t n_pairs, int32_t* pairs,

@@ -172,36 +172,37 @@ class BroadPhaseAllPairs(_BroadPhaseBase):
 
 
 class BroadPhaseSAP(BroadPhaseAllPairs):
-    """Sort and sweep inside every world segment (broad_phase_sap.py:395-848): the map is re-sorted by the start of the
-    gap-widened x interval every launch (a segmented sort = two stable device sorts), then each shape sweeps forward until
-    the intervals stop overlapping.  Emits the same pair set as ``BroadPhaseAllPairs``."""
-
-    _entry = "nt_broadphase_sap"
+    """Sort and sweep inside every world segment (broad_phase_sap.py:395-848), entirely on the device: the gap-widened AABBs
+    are projected on the reference's fixed axis, every world segment is sorted in LDS by one workgroup (bitonic network,
+    padding keys 1e30 like the reference's tile sort) and each shape sweeps forward until the projected intervals stop
+    overlapping (nt_broadphase_sap_device).  Emits the same pair set as ``BroadPhaseAllPairs``; worlds with more than 4096
+    colliding shapes are outside the LDS tile and raise."""
 
     def __init__(self, shape_world, shape_flags=None, sweep_thread_count_multiplier: int = 5, sort_type="segmented",
                  tile_block_dim=None, device=None):
         if sort_type not in ("segmented", "tile"):
             raise ValueError(f"sort_type must be 'segmented' or 'tile', got {sort_type!r}")
         super().__init__(shape_world, shape_flags, device)
-        self.sort_type = sort_type  # both names run the same segmented device sort here
-        ends = self.world_slice_ends.to(_torch().int64)
-        pos = _torch().arange(self.world_index_map.shape[0], device=self.device)
-        self._segment_of_pos = _torch().searchsorted(ends, pos, right=True)
-
-    def launch(self, *args, sort_axis_displacement_limit=None, **kwargs):
-        return super().launch(*args, **kwargs)
-
-    def _map_for_launch(self, keep, lower, gap):
+        self.sort_type = sort_type  # both names run the same per-segment LDS sort here
         torch = _torch()
-        idx = self.world_index_map.to(torch.int64)
-        key = lower[:, 0][idx]
-        if gap is not None and gap.numel() > 0:
-            key = key - gap[idx]
-        order = torch.sort(key, stable=True).indices
-        order = order[torch.sort(self._segment_of_pos[order], stable=True).indices]
-        m = self.world_index_map[order].contiguous()
-        keep.append(m)
-        return m
+        ends = self.world_slice_ends.cpu().numpy().astype(np.int64)
+        self._max_segment = int(np.max(np.diff(np.concatenate([[0], ends])))) if len(ends) else 0
+        n = int(self.world_index_map.shape[0])
+        self._sorted_map = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        self._proj = torch.zeros((2, max(n, 1)), dtype=torch.float32, device=self.device)
+
+    def launch(self, shape_lower, shape_upper, shape_gap, shape_collision_group, shape_world, shape_count, candidate_pair,
+               candidate_pair_count, device=None, filter_pairs=None, num_filter_pairs=None, skip_count_zero=False, *,
+               shape_body=None, body_flags=None, include_static_kinematic_pairs=True, shape_displacement=None,
+               sort_axis_displacement_limit=None):
+        cap = self._out(candidate_pair, candidate_pair_count, skip_count_zero)
+        v, keep = self._view(shape_lower, shape_upper, shape_gap, shape_collision_group, shape_world, filter_pairs,
+                             num_filter_pairs, shape_body, body_flags, include_static_kinematic_pairs, shape_displacement)
+        _lib.check(self._lib.nt_broadphase_sap_device(
+            C.byref(v), self.world_index_map.data_ptr(), self.world_slice_ends.data_ptr(), int(self.world_slice_ends.shape[0]),
+            int(self.num_regular_worlds), int(self.world_index_map.shape[0]), self._max_segment, self._sorted_map.data_ptr(),
+            self._proj.data_ptr(), candidate_pair.data_ptr(), candidate_pair_count.data_ptr(), cap, self._stream()),
+            "nt_broadphase_sap_device")
 
 
 class BroadPhaseExplicit(_BroadPhaseBase):

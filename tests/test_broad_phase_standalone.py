@@ -343,3 +343,44 @@ def test_emulated_kernels_match_brute_force(oracle_lib, entry, case):
         assert int(count[0]) == len(expect)
         got = {tuple(p) for p in pairs[: min(c, len(expect))]}
         assert got <= expect and len(got) == min(c, len(expect)) and (c == cap or got == expect)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_emulated_device_sap_sorts_in_lds_and_matches_brute_force(oracle_lib, case):
+    """nt_broadphase_sap_device: projection on the reference's axis + per-segment bitonic sort (LDS) + sweep, all inside the
+    library -- no host sort.  The sorted map must be a permutation of every segment ordered by the projected interval start
+    (broad_phase_sap.py:44-79,787-811) and the pair set the brute-force one."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import harness as H
+
+    from newton_amd import _lib as L
+
+    lower, upper, gap, group, world, flags = make_case(case)
+    want = brute_force(lower, upper, gap, group, world, flags)
+    index_map, ends = precompute_world_map(world, flags)
+    v = L.nt_broadphase_in()
+    v.lower, v.upper, v.gap = lower.ctypes.data, upper.ctypes.data, gap.ctypes.data
+    v.group, v.world = group.ctypes.data, world.ctypes.data
+    v.filter_pairs, v.num_filter_pairs, v.include_static_kinematic_pairs = None, 0, 1
+    n = len(index_map)
+    sorted_map = np.full(max(n, 1), -1, dtype=np.int32)
+    proj = np.zeros((2, max(n, 1)), dtype=np.float32)
+    pairs = np.full((len(want) + 8, 2), -1, dtype=np.int32)
+    count = np.zeros(1, dtype=np.int32)
+    seg_len = np.diff(np.concatenate([[0], ends])) if len(ends) else np.zeros(0, dtype=np.int64)
+    H.check(H.lib().nt_broadphase_sap_device(C.byref(v), index_map.ctypes.data, ends.ctypes.data, len(ends), max(0, len(ends) - 1), n,
+                                             int(seg_len.max()) if len(seg_len) else 0, sorted_map.ctypes.data, proj.ctypes.data,
+                                             pairs.ctypes.data, count.ctypes.data, len(pairs), None), "nt_broadphase_sap_device")
+    assert int(count[0]) == len(want) and {tuple(p) for p in pairs[: len(want)]} == want
+    d = np.array([0.5935, 0.7790, 0.1235], dtype=np.float32)
+    d = d / np.float32(np.sqrt(np.sum(d * d)))
+    begin = 0
+    for end in ends:
+        seg = sorted_map[begin:end]
+        assert sorted(seg.tolist()) == sorted(index_map[begin:end].tolist())
+        half = 0.5 * (upper[seg] - lower[seg]) + gap[seg, None]
+        lo = (0.5 * (lower[seg] + upper[seg])) @ d - np.abs(d) @ half.T
+        assert np.all(np.diff(proj[0, begin:end]) >= 0.0) and np.allclose(proj[0, begin:end], lo, atol=1e-5)
+        begin = end
