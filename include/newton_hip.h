@@ -141,6 +141,11 @@ typedef struct {
     int32_t* env_count;   /* [ES] contacts emitted per env (== per-env slice of rigid_contact_count) */
     uint8_t* pair_hit;    /* [np][ES] 1 if the pair passed the broad phase (candidate pair set, per env) */
     float* cw;            /* [15][np*cpp][ES] solver scratch, only when nt_model.contact_scratch_in_hbm (else NULL) */
+    const float* prop;    /* [3][np*cpp][ES] or NULL: per-contact stiffness, damping, friction scale
+                           * (Contacts.rigid_contact_stiffness / _damping / _friction, contacts.py:227-277); a value > 0
+                           * overrides the shape-material ke / kd and scales mu in eval_body_contact
+                           * (semi_implicit/kernels_contact.py:452-459) -- SolverSemiImplicit and SolverFeatherstone; SolverXPBD
+                           * ignores them like the reference (solver_xpbd.py:619-651) */
 } nt_contacts;
 
 typedef struct {
@@ -228,6 +233,24 @@ nt_status nt_contacts_export(const nt_model* m, const nt_contacts* c, int32_t ca
 nt_status nt_contacts_export_force(const nt_model* m, const nt_contacts* c, const float* contact_impulse, float dt,
                                    int32_t cap, float* out_force, int32_t* scan_tmp, void* stream);
 
+/* -------- frame-to-frame contact matching (newton/_src/geometry/contact_match.py:266-391 match + resolve, :442-480 save) --------
+ * History of the previous frame in the fixed-slot layout: world-space midpoint 0.5 (world(point0) + world(point1)) and normal of
+ * every live slot.  nt_contacts_match writes, per slot of the CURRENT contacts: the matched previous slot index (same pair,
+ * closest midpoint within pos_threshold whose normal passes dot >= normal_dot_threshold; one previous contact is claimed by at
+ * most one new contact: smallest distance, ties by the smaller sub-contact index), -1 = the pair had no contact last frame
+ * (MATCH_NOT_FOUND), -2 = no candidate within the thresholds or the race was lost (MATCH_BROKEN).  reset_world_mask [env_count]
+ * (nullable): contacts of those worlds report -1.  Call order per frame: collide -> nt_contacts_match -> ... ->
+ * nt_contacts_save_history (with the state the contacts were generated on). */
+typedef struct {
+    float* prev_pos_world;  /* [3][np*cpp][ES] */
+    float* prev_normal;     /* [3][np*cpp][ES] */
+    uint8_t* prev_live;     /* [np*cpp][ES] */
+} nt_contact_history;
+nt_status nt_contacts_match(const nt_model* m, const nt_state* s, const nt_contacts* c, const nt_contact_history* h,
+                            float pos_threshold /*0.0005*/, float normal_dot_threshold /*0.995*/, const uint8_t* reset_world_mask,
+                            int32_t* match_index /*[np*cpp][ES]*/, void* stream);
+nt_status nt_contacts_save_history(const nt_model* m, const nt_state* s, const nt_contacts* c, nt_contact_history* h, void* stream);
+
 /* -------- standalone broad phases (newton.geometry.BroadPhaseAllPairs / BroadPhaseSAP / BroadPhaseExplicit) --------
  * World-aware candidate-pair search on arbitrary AABB arrays (newton/_src/geometry/broad_phase_nxn.py:29-535,
  * broad_phase_sap.py:44-848, broad_phase_common.py:20-388).  All arrays are device pointers in Newton's flat AoS layout.
@@ -312,6 +335,36 @@ typedef struct {
     int32_t capacity;
 } nt_mesh_sdf_args;
 nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
+
+/* HydroelasticSDF contact generation, unreduced (sdf_hydroelastic.py:905-1296 launch, :1982-2140 generate, :1823-1928 decode):
+ * marching cubes on the iso-pressure surface p_a == p_b (p = -kh * signed depth) of every SDF pair; one contact per face with
+ * the per-contact stiffness area * pressure / |separation| (penetrating) or margin_contact_area * k_a k_b / (k_a + k_b)
+ * (inside the gap band) that Contacts.rigid_contact_stiffness carries to eval_body_contact
+ * (semi_implicit/kernels_contact.py:453-455).  tri_range / flat_edge_verts: marching-cubes case tables (newton_amd.mc_tables).
+ * Rows are appended: out_pair, out_key = voxel * 5 + face (the reference's face fingerprint), out_shapes = (shape_a, shape_b)
+ * after the finer-SDF-is-B normalisation, out_data = centre[3] (world), normal[3] (a -> b), separation, stiffness, area, pressure. */
+typedef struct {
+    const int32_t* pairs;            /* [pair_count][2] */
+    int32_t pair_count;
+    const float* shape_transform;    /* [S][7] world */
+    const float* shape_data;         /* [S][4] scale xyz, margin */
+    const float* shape_gap;          /* [S] */
+    const float* shape_kh;           /* [S] Model.shape_material_kh */
+    const int32_t* shape_sdf_index;  /* [S] */
+    const nt_sdf* sdf_table;
+    int32_t sdf_count;
+    const int32_t* tri_range;        /* [257] */
+    const uint8_t* flat_edge_verts;  /* [n][2] */
+    float margin_contact_area;       /* HydroelasticSDF.Config.margin_contact_area (1e-2) */
+    float edge_clamp_min;            /* Config.mc_edge_clamp_min (0.02) */
+    int32_t* out_count;
+    int32_t* out_pair;
+    int32_t* out_key;
+    int32_t* out_shapes;             /* [capacity][2] */
+    float* out_data;                 /* [capacity][10] */
+    int32_t capacity;
+} nt_hydro_args;
+nt_status nt_hydro_collide(const nt_hydro_args* args, void* stream);
 
 /* -------- introspection -------- */
 const char* nt_error_string(nt_status s);

@@ -55,7 +55,7 @@ class nt_control(C.Structure):
 
 class nt_contacts(C.Structure):
     _fields_ = [("shape0", C.c_void_p), ("shape1", C.c_void_p), ("data", C.c_void_p), ("env_count", C.c_void_p),
-                ("pair_hit", C.c_void_p), ("cw", C.c_void_p)]
+                ("pair_hit", C.c_void_p), ("cw", C.c_void_p), ("prop", C.c_void_p)]
 
 
 class nt_xpbd_params(C.Structure):
@@ -89,6 +89,19 @@ class nt_mesh_sdf_args(C.Structure):
                 ("shape_gap", C.c_void_p), ("shape_sdf_index", C.c_void_p), ("sdf_table", C.c_void_p), ("sdf_count", C.c_int32),
                 ("shape_edge_range", C.c_void_p), ("edge_centers", C.c_void_p), ("edge_halves", C.c_void_p),
                 ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_data", C.c_void_p),
+                ("capacity", C.c_int32)]
+
+
+class nt_contact_history(C.Structure):
+    _fields_ = [("prev_pos_world", C.c_void_p), ("prev_normal", C.c_void_p), ("prev_live", C.c_void_p)]
+
+
+class nt_hydro_args(C.Structure):
+    _fields_ = [("pairs", C.c_void_p), ("pair_count", C.c_int32), ("shape_transform", C.c_void_p), ("shape_data", C.c_void_p),
+                ("shape_gap", C.c_void_p), ("shape_kh", C.c_void_p), ("shape_sdf_index", C.c_void_p), ("sdf_table", C.c_void_p),
+                ("sdf_count", C.c_int32), ("tri_range", C.c_void_p), ("flat_edge_verts", C.c_void_p),
+                ("margin_contact_area", C.c_float), ("edge_clamp_min", C.c_float), ("out_count", C.c_void_p),
+                ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_shapes", C.c_void_p), ("out_data", C.c_void_p),
                 ("capacity", C.c_int32)]
 
 
@@ -146,6 +159,11 @@ SYMBOLS = {
     "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
     "nt_sdf_sample": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P, _P]),
     "nt_mesh_sdf_collide": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), _P]),
+    "nt_contacts_match": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts), C.POINTER(nt_contact_history),
+                                       C.c_float, C.c_float, _P, _P, _P]),
+    "nt_contacts_save_history": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
+                                              C.POINTER(nt_contact_history), _P]),
+    "nt_hydro_collide": (C.c_int32, [C.POINTER(nt_hydro_args), _P]),
 }
 
 _lib = None

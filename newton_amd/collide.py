@@ -26,7 +26,8 @@ def _torch():
 class Contacts:
     """Rigid contact buffers (contacts.py:227-277).  ``rigid_contact_max`` = env_count * pairs_per_env * cpp."""
 
-    def __init__(self, model, rigid_contact_max: int | None = None, sort_by_key: bool = False):
+    def __init__(self, model, rigid_contact_max: int | None = None, sort_by_key: bool = False,
+                 per_contact_shape_properties: bool = False):
         torch = _torch()
         self.model = model
         # CollisionPipeline(deterministic=True): the flat arrays come out in the reference's sorted order, ascending
@@ -48,6 +49,11 @@ class Contacts:
         # pair-heavy scenes keep the solvers' per-contact records here instead of LDS (nt_model.contact_scratch_in_hbm)
         self._cw = (torch.zeros((15, ns, t.env_stride), dtype=torch.float32, device=dev)
                     if dm.desc.contact_scratch_in_hbm else None)
+        # optional per-contact stiffness / damping / friction scale (contacts.py:227-277: rigid_contact_stiffness, _damping,
+        # _friction; allocated with per_contact_shape_properties, e.g. for hydroelastic faces), slot layout [3][slots][ES];
+        # a positive entry overrides the shape materials in eval_body_contact (SemiImplicit / Featherstone)
+        self._prop = (torch.zeros((3, ns, t.env_stride), dtype=torch.float32, device=dev)
+                      if per_contact_shape_properties else None)
         self._export = None
         self._generation = 0
         self._export_generation = -1
@@ -68,7 +74,22 @@ class Contacts:
         d.pair_hit = self._pair_hit.data_ptr()
         if self._cw is not None:
             d.cw = self._cw.data_ptr()
+        if self._prop is not None:
+            d.prop = self._prop.data_ptr()
         return d
+
+    def set_slot_properties(self, stiffness=None, damping=None, friction_scale=None):
+        """Fill the per-contact overrides for every contact slot ([pairs_per_env * cpp, env_count] arrays or scalars; slot =
+        pair * cpp + sub-contact in the device pair order).  Requires per_contact_shape_properties=True."""
+        if self._prop is None:
+            raise ValueError("Contacts were created without per_contact_shape_properties")
+        torch = _torch()
+        t = self.model.env
+        for k, v in enumerate((stiffness, damping, friction_scale)):
+            if v is None:
+                continue
+            v = torch.as_tensor(v, dtype=torch.float32, device=self._prop.device)
+            self._prop[k, : self._slots, : t.env_count] = v if v.ndim == 0 else v.reshape(self._slots, t.env_count)
 
     # -- Newton-shaped flat views (append order = env, pair, sub-contact; collide.py:166-254) ---------------
     def _exported(self):
@@ -151,6 +172,103 @@ class Contacts:
         self._generation += 1
 
 
+class ContactMatcher:
+    """Frame-to-frame contact matching (newton/_src/geometry/contact_match.py:602-1055, non-sticky subset): for every contact of
+    the current frame the index of the same physical contact in the previous frame's (deterministically ordered) flat arrays,
+    MATCH_NOT_FOUND (-1) when its shape pair had no contact, MATCH_BROKEN (-2) when nothing lies within the position / normal
+    thresholds or a closer new contact claimed the candidate.  The device kernels work on the fixed-slot layout
+    (nt_contacts_match / nt_contacts_save_history: a pair's slots are its key range, no sort, no atomics)."""
+
+    MATCH_NOT_FOUND, MATCH_BROKEN = -1, -2
+
+    def __init__(self, model, pos_threshold: float = 0.0005, normal_dot_threshold: float = 0.995):
+        torch = _torch()
+        self.model = model
+        self.dm = model.device_model()
+        t = model.env
+        ns, dev = max(t.np * t.cpp, 1), self.dm.device
+        self.pos_threshold, self.normal_dot_threshold = float(pos_threshold), float(normal_dot_threshold)
+        self._pos = torch.zeros((3, ns, t.env_stride), dtype=torch.float32, device=dev)
+        self._normal = torch.zeros((3, ns, t.env_stride), dtype=torch.float32, device=dev)
+        self._live = torch.zeros((ns, t.env_stride), dtype=torch.uint8, device=dev)
+        self._match = torch.full((ns, t.env_stride), -1, dtype=torch.int32, device=dev)
+        self._prev_flat = None  # flat (export-order) index of every previous slot
+        self._reset_mask = None
+        h = _lib.nt_contact_history()
+        h.prev_pos_world, h.prev_normal, h.prev_live = self._pos.data_ptr(), self._normal.data_ptr(), self._live.data_ptr()
+        self._h = h
+
+    def reset(self, world_mask=None):
+        """Forget the history of the selected worlds (all when None): their next contacts report MATCH_NOT_FOUND."""
+        torch = _torch()
+        t = self.model.env
+        if world_mask is None:
+            self._live.zero_()
+            self._reset_mask = None
+        else:
+            m = torch.as_tensor(world_mask, device=self.dm.device).to(torch.uint8)[: t.env_count].contiguous()
+            self._reset_mask = m
+            self._live[:, : t.env_count] *= (1 - m)[None, :]
+
+    def _flat_index(self, live):
+        """Export-order index of every live slot: all envs' analytic contacts in (env, slot) order, then the convex ones."""
+        torch = _torch()
+        t = self.model.env
+        E, nas = t.env_count, t.np_analytic * t.cpp
+        live = live[:, :E].bool()
+        out = torch.full(live.shape, -1, dtype=torch.int64, device=live.device)
+        base = 0
+        for lo, hi in ((0, nas), (nas, t.np * t.cpp)):
+            part = live[lo:hi].T.contiguous()  # [E, slots]
+            idx = torch.cumsum(part.reshape(-1).to(torch.int64), 0) - 1 + base
+            out[lo:hi] = torch.where(part, idx.reshape(part.shape), torch.full_like(idx.reshape(part.shape), -1)).T
+            base += int(part.sum().item())
+        return out
+
+    def match(self, state, contacts):
+        """-> int32 tensor over the CURRENT frame's flat contacts (export order): previous flat index, -1 or -2.  With
+        CollisionPipeline(deterministic=True) both orders are the reference's key-sorted order."""
+        torch = _torch()
+        dm, t = self.dm, self.model.env
+        d_s, d_c = state._desc(), contacts._desc()
+        mask_ptr = self._reset_mask.data_ptr() if self._reset_mask is not None else None
+        _lib.check(dm.lib.nt_contacts_match(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h), self.pos_threshold,
+                                            self.normal_dot_threshold, mask_ptr, self._match.data_ptr(), dm.stream()),
+                   "nt_contacts_match")
+        self._reset_mask = None
+        E = t.env_count
+        live_now = (contacts._shape0[: t.np * t.cpp] >= 0) & (contacts._shape0[: t.np * t.cpp] != contacts._shape1[: t.np * t.cpp])
+        flat_now = self._flat_index(live_now.to(torch.uint8))
+        m = self._match[: t.np * t.cpp, :E].to(torch.int64)
+        if self._prev_flat is not None:
+            slot = m.clamp(min=0)
+            env = torch.arange(E, device=m.device)[None, :].expand_as(slot)
+            m = torch.where(m >= 0, self._prev_flat[slot, env], m)
+        n = int(live_now[:, :E].sum().item())
+        out = torch.full((max(n, 1),), -1, dtype=torch.int32, device=m.device)
+        sel = flat_now >= 0
+        out[flat_now[sel]] = m[sel].to(torch.int32)
+        order = contacts.export_order()  # deterministic mode re-orders the flat rows: follow it
+        if order is not None:
+            out[: order.numel()] = out[: order.numel()][order]
+        return out[:n]
+
+    def save_sorted_state(self, state, contacts):
+        """Persist this frame's contacts as the next frame's history (call after match, with the state they were made on)."""
+        dm, t = self.dm, self.model.env
+        d_s, d_c = state._desc(), contacts._desc()
+        _lib.check(dm.lib.nt_contacts_save_history(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h), dm.stream()),
+                   "nt_contacts_save_history")
+        self._prev_flat = self._flat_index(self._live[: t.np * t.cpp])
+        order = contacts.export_order()
+        if order is not None:  # flat rows were permuted by the key sort: rank of every raw row in the sorted order
+            torch = _torch()
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(order.numel(), device=order.device)
+            ok = self._prev_flat >= 0
+            self._prev_flat[ok] = rank[self._prev_flat[ok]]
+
+
 def estimate_rigid_contact_max(model) -> int:
     """Capacity heuristic of the reference (collide.py:553-652) for models with precomputed pairs:
     max(1000, min(neighbor-budget heuristic, pairs * contacts_per_pair))."""
@@ -210,8 +328,8 @@ class CollisionPipeline:
     def rigid_contact_max(self):
         return self._rigid_contact_max
 
-    def contacts(self) -> Contacts:
-        return Contacts(self.model, sort_by_key=self.deterministic)
+    def contacts(self, per_contact_shape_properties: bool = False) -> Contacts:
+        return Contacts(self.model, sort_by_key=self.deterministic, per_contact_shape_properties=per_contact_shape_properties)
 
     def collide(self, state, contacts: Contacts, *, soft_contact_margin=None, dt=None):
         if contacts.model is not self.model:

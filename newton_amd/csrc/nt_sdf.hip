@@ -325,9 +325,188 @@ __global__ void __launch_bounds__(256) mesh_sdf_collide_kernel(nt_mesh_sdf_args 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hydroelastic contacts between two SDF shapes (sdf_hydroelastic.py): the contact surface is the iso-surface p_a == p_b of the
+// two pressure fields p = -kh * signed_depth, extracted with marching cubes over the finer SDF's voxels; every face becomes a
+// contact (centre, normal a -> b, margin-relative separation) with stiffness area * pressure / |separation|
+// (decode_contacts_kernel :1823-1928).  Unreduced path.  One workgroup per pair; its lanes take the voxels of shape B's fine
+// grid that lie inside shape A's SDF box (the reference reaches the same voxels through a block broad phase + octree, :1026-1170).
+// ------------------------------------------------------------------------------------------------
+NT_DI float sample_at_voxel(const nt_sdf& s, int ix, int iy, int iz) {  // texture_sample_sdf_at_voxel :949-1004
+    const float f2c = 1.0f / (float)s.subgrid_size;
+    const int bx = clampi((int)((float)ix * f2c), 0, s.cx - 1), by = clampi((int)((float)iy * f2c), 0, s.cy - 1),
+              bz = clampi((int)((float)iz * f2c), 0, s.cz - 1);
+    const uint32_t slot = s.slots[((size_t)bx * s.cy + by) * s.cz + bz];
+    if (slot < SLOT_LINEAR) {
+        const int spd = s.subgrid_size + 1;
+        const int ox = (int)(slot & 0x3FFu) * spd + (ix - bx * s.subgrid_size);
+        const int oy = (int)((slot >> 10) & 0x3FFu) * spd + (iy - by * s.subgrid_size);
+        const int oz = (int)((slot >> 20) & 0x3FFu) * spd + (iz - bz * s.subgrid_size);
+        return texel(s, ox, oy, oz) * s.value_range + s.min_value;
+    }
+    return sample(s, vec3(s.box_lower[0] + (float)ix * s.voxel_size[0], s.box_lower[1] + (float)iy * s.voxel_size[1],
+                          s.box_lower[2] + (float)iz * s.voxel_size[2]));
+}
+NT_DI float triangle_fraction(float a0, float a1, float a2, int num_inside) {  // sdf_mc.py:112-162
+    if (num_inside == 3) return 1.0f;
+    if (num_inside == 0) return 0.0f;
+    float d0 = a0, d1 = a1, d2 = a2;
+    if (num_inside == 1) {
+        if (a1 < 0.0f) { d0 = a1; d1 = a2; d2 = a0; }
+        else if (a2 < 0.0f) { d0 = a2; d1 = a0; d2 = a1; }
+    } else {
+        if (a1 >= 0.0f) { d0 = a1; d1 = a2; d2 = a0; }
+        else if (a2 >= 0.0f) { d0 = a2; d1 = a0; d2 = a1; }
+    }
+    const float denom = (d0 - d1) * (d0 - d2);
+    if (fabsf(denom) < 1e-8f) return num_inside == 1 ? 0.0f : 1.0f;
+    const float fr = clampf((d0 * d0) / denom, 0.0f, 1.0f);
+    return num_inside == 2 ? 1.0f - fr : fr;
+}
+NT_DI int mc_cx(int i) { return ((i & 3) ^ ((i & 3) >> 1)) & 1; }  // _mc_corner_offset :206-213
+NT_DI int mc_cy(int i) { return (i >> 1) & 1; }
+NT_DI int mc_cz(int i) { return (i >> 2) & 1; }
+
+__global__ void __launch_bounds__(256) hydro_collide_kernel(nt_hydro_args a) {
+    __shared__ int range[6];
+    for (int pair_idx = blockIdx.x; pair_idx < a.pair_count; pair_idx += gridDim.x) {
+        int sa = a.pairs[2 * pair_idx], sb = a.pairs[2 * pair_idx + 1];
+        int ia = a.shape_sdf_index[sa], ib = a.shape_sdf_index[sb];
+        if (ia < 0 || ib < 0 || ia >= a.sdf_count || ib >= a.sdf_count) continue;
+        if (a.sdf_table[ib].voxel_radius > a.sdf_table[ia].voxel_radius) {  // keep the finer SDF as shape B (:1362-1366)
+            int t = sa; sa = sb; sb = t;
+            t = ia; ia = ib; ib = t;
+        }
+        const nt_sdf A = a.sdf_table[ia], B = a.sdf_table[ib];
+        if (A.cx <= 0 || B.cx <= 0) continue;
+        const float gap_sum = a.shape_gap[sa] + a.shape_gap[sb];
+        const float margin_a = a.shape_data[4 * sa + 3], margin_b = a.shape_data[4 * sb + 3];
+        const float kh_a = a.shape_kh[sa], kh_b = a.shape_kh[sb];
+        const xform X_b = load_xform(a.shape_transform + 7 * sb);
+        const xform X_b2a = xform_inverse(load_xform(a.shape_transform + 7 * sa)) * X_b;
+        const vec3 vs(B.voxel_size[0], B.voxel_size[1], B.voxel_size[2]), blo(B.box_lower[0], B.box_lower[1], B.box_lower[2]);
+        const int nx = B.cx * B.subgrid_size, ny = B.cy * B.subgrid_size, nz = B.cz * B.subgrid_size;
+        __syncthreads();
+        if (threadIdx.x == 0) {  // candidate voxel range: A's SDF box (widened by the gap) seen from B's grid
+            const xform X_a2b = xform_inverse(X_b2a);
+            vec3 lo(1e30f, 1e30f, 1e30f), hi(-1e30f, -1e30f, -1e30f);
+            for (int k = 0; k < 8; ++k) {
+                vec3 c((k & 1) ? A.box_upper[0] : A.box_lower[0], (k & 2) ? A.box_upper[1] : A.box_lower[1],
+                       (k & 4) ? A.box_upper[2] : A.box_lower[2]);
+                vec3 q = xform_point(X_a2b, c);
+                lo = vmin(lo, q);
+                hi = vmax(hi, q);
+            }
+            const int n[3] = {nx, ny, nz};
+            for (int k = 0; k < 3; ++k) {
+                int l = (int)floorf((vget(lo, k) - gap_sum - vget(blo, k)) / vget(vs, k)) - 1;
+                int h = (int)ceilf((vget(hi, k) + gap_sum - vget(blo, k)) / vget(vs, k)) + 1;
+                range[k] = l < 0 ? 0 : l;
+                range[3 + k] = h > n[k] ? n[k] : h;
+            }
+        }
+        __syncthreads();
+        const int x0 = range[0], y0 = range[1], z0 = range[2];
+        const int wx = range[3] - x0, wy = range[4] - y0, wz = range[5] - z0;
+        if (wx <= 0 || wy <= 0 || wz <= 0) continue;
+        const vec3 step_x = xform_vector(X_b2a, vec3(vs.x, 0.0f, 0.0f)), step_y = xform_vector(X_b2a, vec3(0.0f, vs.y, 0.0f)),
+                   step_z = xform_vector(X_b2a, vec3(0.0f, 0.0f, vs.z));
+        const float cmin = a.edge_clamp_min, cmax = 1.0f - a.edge_clamp_min;
+        for (int v = threadIdx.x; v < wx * wy * wz; v += blockDim.x) {
+            const int x = x0 + v % wx, y = y0 + (v / wx) % wy, z = z0 + v / (wx * wy);
+            // mc_iterate_voxel_vertices (:1716-1798)
+            const vec3 base_b = blo + cw_mul(vec3((float)x, (float)y, (float)z), vs);
+            const vec3 base_a = xform_point(X_b2a, base_b);
+            float cv[8], cself[8], cother[8];
+            int cube = 0;
+            bool any_gap = false, valid = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ox = mc_cx(i), oy = mc_cy(i), oz = mc_cz(i);
+                const vec3 pa = base_a + (float)ox * step_x + (float)oy * step_y + (float)oz * step_z;
+                const float v_self = sample_at_voxel(B, x + ox, y + oy, z + oz);
+                const float v_other = sample(A, pa);
+                if (v_self != v_self || v_other != v_other) valid = false;
+                const float es = v_self - margin_b, eo = v_other - margin_a;
+                const float vd = (-kh_a * eo) - (-kh_b * es);  // p_other - p_self, linear_pressure :237-248
+                cv[i] = vd; cself[i] = es; cother[i] = eo;
+                if (vd < 0.0f) cube |= 1 << i;
+                if (es + eo <= gap_sum) any_gap = true;
+            }
+            if (!valid || !any_gap) continue;
+            const int t0 = a.tri_range[cube], t1 = a.tri_range[cube + 1];
+            for (int fi = 0; fi < (t1 - t0) / 3; ++fi) {
+                // mc_calc_face_texture (:282-362)
+                vec3 fv[3];
+                float vsdf[3], vsep[3];
+                int n_in = 0;
+#pragma unroll
+                for (int vi = 0; vi < 3; ++vi) {
+                    const int ca = a.flat_edge_verts[2 * (t0 + 3 * fi + vi)], cb = a.flat_edge_verts[2 * (t0 + 3 * fi + vi) + 1];
+                    const float vd = cv[cb] - cv[ca];
+                    const float t = fabsf(vd) < 1.0e-10f ? 0.5f : clampf((0.0f - cv[ca]) / vd, cmin, cmax);
+                    const vec3 p0((float)mc_cx(ca), (float)mc_cy(ca), (float)mc_cz(ca)), p1((float)mc_cx(cb), (float)mc_cy(cb), (float)mc_cz(cb));
+                    const vec3 vol = p0 + t * (p1 - p0) + vec3((float)x, (float)y, (float)z);
+                    fv[vi] = blo + cw_mul(vol, vs);
+                    const float s_self = cself[ca] + t * (cself[cb] - cself[ca]);
+                    const float s_other = cother[ca] + t * (cother[cb] - cother[ca]);
+                    vsdf[vi] = s_self;
+                    vsep[vi] = s_self + s_other;
+                    if (vsep[vi] < 0.0f) n_in += 1;
+                }
+                const vec3 n = cross(fv[1] - fv[0], fv[2] - fv[0]);
+                const float n_sq = dot(n, n);
+                float garea = 0.0f;
+                vec3 normal(0.0f, 0.0f, 1.0f);
+                if (!(n_sq < 1.0e-20f)) {
+                    const float inv = 1.0f / sqrtf(n_sq);
+                    normal = n * inv;
+                    garea = (n_sq * inv) * 0.5f;
+                }
+                const vec3 center = ((fv[0] + fv[1]) + fv[2]) / 3.0f;
+                const float adj = ((vsdf[0] + vsdf[1]) + vsdf[2]) / 3.0f;
+                const float sep = ((vsep[0] + vsep[1]) + vsep[2]) / 3.0f;
+                const float farea = garea * triangle_fraction(vsep[0], vsep[1], vsep[2], n_in);
+                if (garea <= 0.0f) continue;
+                if (!(sep < 0.0f) && sep > gap_sum) continue;  // classify_hydroelastic_contact > 0: outside the gap band
+                const float pressure = sep < 0.0f ? fmaxw(-kh_b * adj, 0.0f) : 0.0f;
+                const float area = sep < 0.0f ? farea : garea;
+                float stiff;
+                if (sep < 0.0f) stiff = (area * pressure) / fmaxw(-sep, 1e-20f);
+                else {
+                    const float den = kh_a + kh_b;
+                    stiff = a.margin_contact_area * (den <= 0.0f ? 0.0f : (kh_a * kh_b) / den);
+                }
+                const int slot = atomicAdd(a.out_count, 1);
+                if (slot < a.capacity) {
+                    a.out_pair[slot] = pair_idx;
+                    a.out_key[slot] = ((z * ny + y) * nx + x) * 5 + fi;
+                    a.out_shapes[2 * slot] = sa;
+                    a.out_shapes[2 * slot + 1] = sb;
+                    const vec3 pw = xform_point(X_b, center), nw = xform_vector(X_b, normal);
+                    float* o = a.out_data + 10 * (size_t)slot;
+                    o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; o[3] = nw.x; o[4] = nw.y; o[5] = nw.z;
+                    o[6] = sep; o[7] = stiff; o[8] = area; o[9] = pressure;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+nt_status nt_hydro_collide(const nt_hydro_args* a, void* stream) {
+    if (!a || a->pair_count < 0 || !a->out_count || !a->out_pair || !a->out_key || !a->out_shapes || !a->out_data || a->capacity <= 0 ||
+        !a->tri_range || !a->flat_edge_verts || !a->shape_kh)
+        return NT_ERR_INVALID_ARG;
+    if (!(a->edge_clamp_min >= 0.0f && a->edge_clamp_min <= 0.5f)) return NT_ERR_INVALID_ARG;
+    if (a->pair_count == 0) return NT_OK;
+    int blocks = a->pair_count < 2048 ? a->pair_count : 2048;
+    hipLaunchKernelGGL(hydro_collide_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
 
 nt_status nt_sdf_sample(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist, float* out_grad, void* stream) {
     if (!sdf || !points || n <= 0 || (!out_dist && !out_grad) || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;

@@ -195,6 +195,13 @@ NT_DI void si_contact_item(const Ctx<EPB>& c, const int slot) {
             ke /= float(mat_nonzero); kd /= float(mat_nonzero); kf /= float(mat_nonzero);
             ka /= float(mat_nonzero); mu /= float(mat_nonzero);
         }
+        if (ct.prop) {  // per-contact stiffness / damping / friction scale (kernels_contact.py:452-459), e.g. hydroelastic faces
+            const float contact_ke = ct.prop[c.g(0, ncs, slot)], contact_kd = ct.prop[c.g(1, ncs, slot)],
+                        contact_mu = ct.prop[c.g(2, ncs, slot)];
+            ke = contact_ke > 0.0f ? contact_ke : ke;
+            kd = contact_kd > 0.0f ? contact_kd : kd;
+            mu = contact_mu > 0.0f ? mu * contact_mu : mu;
+        }
         vec3 n = -c.gv3(D, CD_NORMAL, ncs, slot);
         vec3 bx_a = c.gv3(D, CD_POINT0, ncs, slot), bx_b = c.gv3(D, CD_POINT1, ncs, slot);
         float margin_a = D[c.g(CD_MARGIN0, ncs, slot)], margin_b = D[c.g(CD_MARGIN1, ncs, slot)];

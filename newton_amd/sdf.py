@@ -14,7 +14,7 @@ Restates newton/_src/geometry/sdf_texture.py:
 The reference bakes on the GPU with Warp kernels and stores the grids in CUDA 3-D textures that it then point-samples at
 texel centres; here the bake is vectorised numpy on the host (it runs once per asset) and the "textures" are the plain 3-D
 arrays they always were semantically.  `TextureSDF.sample / sample_grad` restate the sampler in
-float32 numpy; the device samplers (csrc/nt_sdf.hpp, C ABI nt_sdf_sample) and the C oracle follow the same operation order.
+float32 numpy; the device samplers (csrc/nt_sdf.hpp, C ABI nt_sdf_sample) and the test-side checker follow the same operation order.
 Mesh sources use exact point-triangle distances with the generalized winding number for the sign (the reference's default
 SIGN_MODE_WINDING, `get_distance_to_mesh`), brute force over the triangles -- a host job for assets of 10^2..10^4 faces.
 """

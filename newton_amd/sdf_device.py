@@ -106,3 +106,54 @@ def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_in
     pair, key, data = pair[order], key[order], data[order]
     return {"count": n_total, "pair": pair, "key": key, "center": data[:, 0:3], "normal": data[:, 3:6], "distance": data[:, 6],
             "margin0": data[:, 7], "margin1": data[:, 8]}
+
+
+def hydro_collide(pairs, shape_transform, shape_data, shape_gap, shape_kh, shape_sdf_index, sdfs, capacity: int = 1 << 18,
+                  margin_contact_area: float = 1.0e-2, edge_clamp_min: float = 0.02, device="cuda:0"):
+    """Run nt_hydro_collide (HydroelasticSDF.launch, unreduced): returns numpy arrays sorted by (pair, fingerprint): pair, key,
+    shape_a, shape_b, center [n,3], normal [n,3] (a -> b), distance (margin-relative separation), stiffness
+    (Contacts.rigid_contact_stiffness), area, pressure, and `count`."""
+    from .mc_tables import tables  # noqa: PLC0415
+
+    torch = _torch()
+    lib = _lib.load()
+    dev = torch.device(device)
+
+    def up(a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return torch.from_numpy(a if a.size else np.zeros(1, dtype=dtype)).to(dev)
+
+    pairs_np = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    tri_range, flat = tables()
+    t_pairs, t_X, t_data = up(pairs_np, np.int32), up(shape_transform, np.float32), up(shape_data, np.float32)
+    t_gap, t_kh, t_idx = up(shape_gap, np.float32), up(shape_kh, np.float32), up(shape_sdf_index, np.int32)
+    t_tr, t_fe = up(tri_range, np.int32), up(flat, np.uint8)
+    table = (_lib.nt_sdf * max(len(sdfs), 1))()
+    for k, s in enumerate(sdfs):
+        if s is not None:
+            table[k] = s.desc
+    t_table = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    o_pair = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
+    o_key = torch.zeros(capacity, dtype=torch.int32, device=dev)
+    o_shapes = torch.zeros((capacity, 2), dtype=torch.int32, device=dev)
+    o_data = torch.zeros((capacity, 10), dtype=torch.float32, device=dev)
+    a = _lib.nt_hydro_args()
+    a.pairs, a.pair_count = t_pairs.data_ptr(), len(pairs_np)
+    a.shape_transform, a.shape_data, a.shape_gap, a.shape_kh = t_X.data_ptr(), t_data.data_ptr(), t_gap.data_ptr(), t_kh.data_ptr()
+    a.shape_sdf_index, a.sdf_table, a.sdf_count = t_idx.data_ptr(), t_table.data_ptr(), len(sdfs)
+    a.tri_range, a.flat_edge_verts = t_tr.data_ptr(), t_fe.data_ptr()
+    a.margin_contact_area, a.edge_clamp_min = float(margin_contact_area), float(edge_clamp_min)
+    a.out_count, a.out_pair, a.out_key, a.out_shapes, a.out_data, a.capacity = (count.data_ptr(), o_pair.data_ptr(), o_key.data_ptr(),
+                                                                                 o_shapes.data_ptr(), o_data.data_ptr(), capacity)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.nt_hydro_collide(C.byref(a), stream), "nt_hydro_collide")
+    torch.cuda.current_stream(dev).synchronize()
+    n_total = int(count.item())
+    n = min(n_total, capacity)
+    pair, key = o_pair[:n].cpu().numpy(), o_key[:n].cpu().numpy()
+    shapes, data = o_shapes[:n].cpu().numpy(), o_data[:n].cpu().numpy()
+    order = np.lexsort((key, pair))
+    pair, key, shapes, data = pair[order], key[order], shapes[order], data[order]
+    return {"count": n_total, "pair": pair, "key": key, "shape_a": shapes[:, 0], "shape_b": shapes[:, 1], "center": data[:, 0:3],
+            "normal": data[:, 3:6], "distance": data[:, 6], "stiffness": data[:, 7], "area": data[:, 8], "pressure": data[:, 9]}

@@ -109,6 +109,10 @@ typedef struct {
     float* margin0;                 /* [Cmax] */
     float* margin1;
     int32_t* tids;
+    /* optional per-contact overrides (contacts.py:227-277; kernels_contact.py:452-459): NULL = use the shape materials */
+    const float* stiffness;         /* [Cmax] > 0 replaces ke */
+    const float* damping;           /* [Cmax] > 0 replaces kd */
+    const float* friction_scale;    /* [Cmax] > 0 scales mu */
 } o_contacts;
 
 typedef struct {

@@ -218,6 +218,15 @@ void eval_body_contact(const o_model* m, const o_contacts* ct, const float* body
             ke /= float(mat_nonzero); kd /= float(mat_nonzero); kf /= float(mat_nonzero);
             ka /= float(mat_nonzero); mu /= float(mat_nonzero);
         }
+        // per-contact stiffness / damping / friction (kernels_contact.py:452-459)
+        if (ct->stiffness) {
+            float contact_ke = ct->stiffness[tid];
+            ke = contact_ke > 0.0f ? contact_ke : ke;
+            float contact_kd = ct->damping[tid];
+            kd = contact_kd > 0.0f ? contact_kd : kd;
+            float contact_mu = ct->friction_scale[tid];
+            mu = contact_mu > 0.0f ? mu * contact_mu : mu;
+        }
         vec3 n = -ld3(ct->normal, tid);
         vec3 bx_a = ld3(ct->point0, tid), bx_b = ld3(ct->point1, tid);
         vec3 r_a(0.0f), r_b(0.0f);

@@ -141,6 +141,7 @@ class EmuContacts:
         self.scan = np.zeros(4 * (t.env_stride + 1), dtype=np.int32)
         self.cw = np.zeros((15, ns, t.env_stride), dtype=np.float32) if em.desc.contact_scratch_in_hbm else None
         self.rigid_contact_max = t.env_count * t.np * t.cpp
+        self.prop = None  # optional per-slot stiffness / damping / friction scale [3][ns][ES]
 
     def desc(self):
         d = L.nt_contacts()
@@ -148,6 +149,8 @@ class EmuContacts:
         d.env_count, d.pair_hit = _ptr(self.env_count), _ptr(self.pair_hit)
         if self.cw is not None:
             d.cw = _ptr(self.cw)
+        if self.prop is not None:
+            d.prop = _ptr(self.prop)
         return d
 
     def export(self):

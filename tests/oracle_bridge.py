@@ -51,7 +51,7 @@ class o_control(C.Structure):
 class o_contacts(C.Structure):
     _fields_ = [("rigid_contact_max", C.c_int), ("rigid_contact_count", _i), ("shape0", _i), ("shape1", _i), ("point0", _f),
                 ("point1", _f), ("offset0", _f), ("offset1", _f), ("normal", _f), ("margin0", _f), ("margin1", _f),
-                ("tids", _i)]
+                ("tids", _i), ("stiffness", _f), ("damping", _f), ("friction_scale", _f)]
 
 
 class o_xpbd_params(C.Structure):
@@ -183,6 +183,16 @@ class OracleContacts:
         s.offset0, s.offset1 = _fp(self.offset0), _fp(self.offset1)
         s.normal, s.margin0, s.margin1, s.tids = _fp(self.normal), _fp(self.margin0), _fp(self.margin1), _ip(self.tids)
         self.struct = s
+        self.stiffness = self.damping = self.friction_scale = None
+
+    def set_properties(self, stiffness, damping, friction_scale):
+        """Optional per-contact overrides (Contacts.rigid_contact_stiffness / _damping / _friction), flat append order."""
+        n = max(self.max, 1)
+        self.stiffness = np.ascontiguousarray(np.resize(np.asarray(stiffness, dtype=np.float32), n))
+        self.damping = np.ascontiguousarray(np.resize(np.asarray(damping, dtype=np.float32), n))
+        self.friction_scale = np.ascontiguousarray(np.resize(np.asarray(friction_scale, dtype=np.float32), n))
+        self.struct.stiffness, self.struct.damping = _fp(self.stiffness), _fp(self.damping)
+        self.struct.friction_scale = _fp(self.friction_scale)
 
 
 class OracleState:

@@ -1,0 +1,148 @@
+"""Frame-to-frame contact matching: the slot-space gfx950 kernels (emulated here; device test in
+tests/test_zx_round2_gpu.py) against oracle/oracle_match.py, the restatement of the reference's key-sorted matcher
+(newton/_src/geometry/contact_match.py:266-391).  Scenes: a box stack (5-slot manifolds whose points move a little) advanced by
+a few XPBD steps, plus hand-made cases for the thresholds and the one-to-one race."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+@pytest.fixture(scope="module")
+def H(oracle_lib):
+    import harness
+
+    harness.lib()
+    return harness
+
+
+def _history(em):
+    from newton_amd import _lib as L
+
+    t = em.t
+    ns = max(t.np * t.cpp, 1)
+    keep = [np.zeros((3, ns, t.env_stride), np.float32), np.zeros((3, ns, t.env_stride), np.float32), np.zeros((ns, t.env_stride), np.uint8)]
+    h = L.nt_contact_history()
+    h.prev_pos_world, h.prev_normal, h.prev_live = (k.ctypes.data for k in keep)
+    return h, keep
+
+
+def _flat(em, ct, state_q):
+    """Key-sorted flat view of the fixed slots: (keys, midpoints, normals, slot ids [n,2] = (env, slot))."""
+    import oracle_match as O
+
+    t, model = em.t, em.model
+    ns = t.np * t.cpp
+    rows = []
+    for env in range(t.env_count):
+        for slot in range(ns):
+            s0, s1 = int(ct.shape0[slot, env]), int(ct.shape1[slot, env])
+            if s0 < 0 or s0 == s1:
+                continue
+            rows.append((O.sort_key(s0, s1, slot % t.cpp), env, slot, s0, s1))
+    rows.sort()
+    keys = np.array([r[0] for r in rows], dtype=np.int64)
+    p0 = np.array([[ct.data[c, r[2], r[1]] for c in range(0, 3)] for r in rows], dtype=np.float32).reshape(-1, 3)
+    p1 = np.array([[ct.data[c, r[2], r[1]] for c in range(3, 6)] for r in rows], dtype=np.float32).reshape(-1, 3)
+    nrm = np.array([[ct.data[c, r[2], r[1]] for c in range(12, 15)] for r in rows], dtype=np.float32).reshape(-1, 3)
+    mid = O.midpoints(state_q, np.asarray(model.shape_body), [r[3] for r in rows], [r[4] for r in rows], p0, p1)
+    return keys, mid, nrm, [(r[1], r[2]) for r in rows]
+
+
+def _emu_match(H, em, state, ct, hist, pos_thr=0.0005, ndot=0.995, mask=None):
+    t = em.t
+    out = np.full((max(t.np * t.cpp, 1), t.env_stride), -7, dtype=np.int32)
+    ds, dc = state.desc(), ct.desc()
+    H.check(H.lib().nt_contacts_match(C.byref(em.desc), C.byref(ds), C.byref(dc), C.byref(hist), pos_thr, ndot,
+                                      mask.ctypes.data if mask is not None else None, out.ctypes.data, None), "nt_contacts_match")
+    return out
+
+
+def test_box_stack_manifolds_match_across_frames(H):
+    import oracle_match as O
+    from scenes import box_stack_scene
+
+    model = box_stack_scene(4, n_boxes=4, seed=2, jitter=2e-3)
+    em = H.EmuModel(model)
+    a, b, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+    hist, keep = _history(em)
+    prev = None
+    for frame in range(3):
+        a.body_f[:] = 0
+        H.collide(em, a, ct)
+        q = a.aos("body_q")
+        slots = _emu_match(H, em, a, ct, hist)
+        keys, mid, nrm, ids = _flat(em, ct, q)
+        if prev is None:
+            assert all(slots[s, e] == -1 for e, s in ids)  # no history yet: MATCH_NOT_FOUND everywhere
+        else:
+            want = O.match(keys, mid, nrm, *prev[:3])
+            prev_flat = {es: i for i, es in enumerate(prev[3])}
+            got = np.array([slots[s, e] if slots[s, e] < 0 else prev_flat[(e, int(slots[s, e]))] for e, s in ids], dtype=np.int32)
+            assert np.array_equal(got, want)
+            assert (want >= 0).sum() > 0.5 * len(want)  # resting stack: most manifold points persist
+        ds, dc = a.desc(), ct.desc()
+        H.check(H.lib().nt_contacts_save_history(C.byref(em.desc), C.byref(ds), C.byref(dc), C.byref(hist), None), "save")
+        prev = (keys, mid, nrm, ids)
+        H.xpbd_step(em, a, b, ctrl, ct, 1.0 / 240.0, iterations=4)
+        a, b = b, a
+
+
+def test_thresholds_race_and_world_reset(H):
+    """Hand-made history: (1) a candidate beyond the position threshold or with a turned normal is MATCH_BROKEN, (2) two new
+    contacts closest to the same previous one: the nearer wins, the other is MATCH_BROKEN (no second choice), (3) a pair without
+    previous contacts is MATCH_NOT_FOUND, (4) reset worlds report MATCH_NOT_FOUND."""
+    import oracle_match as O
+    from scenes import box_stack_scene
+
+    model = box_stack_scene(3, n_boxes=2, seed=None, jitter=0.0)
+    em = H.EmuModel(model)
+    a, ct = H.EmuState(em), H.EmuContacts(em)
+    H.collide(em, a, ct)
+    t = em.t
+    hist, (ppos, pnrm, plive) = _history(em)
+    ds, dc = a.desc(), ct.desc()
+    H.check(H.lib().nt_contacts_save_history(C.byref(em.desc), C.byref(ds), C.byref(dc), C.byref(hist), None), "save")
+    base = _emu_match(H, em, a, ct, hist)
+    ids = [(e, s) for e in range(t.env_count) for s in range(t.np * t.cpp) if ct.shape0[s, e] >= 0]
+    assert all(base[s, e] == s for e, s in ids)  # identical frame: every contact matches itself
+    # (1) move env 0's history of its first live slot by 1 mm; turn the normal of the second
+    e0 = [s for e, s in ids if e == 0]
+    ppos[0, e0[0], 0] += 1e-3
+    pnrm[:, e0[1], 0] = [1.0, 0.0, 0.0]
+    m = _emu_match(H, em, a, ct, hist)
+    assert m[e0[0], 0] == -2 and m[e0[1], 0] == -2 and all(m[s, 0] == s for s in e0[2:])
+    # (2) env 1: make two history entries of one pair coincide with new contact k: both new contacts k and k+1 then see the same
+    # closest previous slot only if their own is gone -> drop new k+1's own history entry
+    e1 = [s for e, s in ids if e == 1]
+    k, k1 = e1[0], e1[1]
+    assert k // t.cpp == k1 // t.cpp
+    plive[k1, 1] = 0
+    m = _emu_match(H, em, a, ct, hist, pos_thr=10.0)  # huge threshold: k+1 now reaches for k's entry, k is nearer (distance 0)
+    assert m[k, 1] == k and m[k1, 1] == -2
+    # (3) env 2: no history at all for one pair
+    p = e1[0] // t.cpp
+    plive[p * t.cpp:(p + 1) * t.cpp, 2] = 0
+    m = _emu_match(H, em, a, ct, hist)
+    assert all(m[s, 2] == -1 for s in range(p * t.cpp, (p + 1) * t.cpp) if ct.shape0[s, 2] >= 0)
+    # (4) reset mask
+    mask = np.array([0, 1, 0], dtype=np.uint8)
+    m = _emu_match(H, em, a, ct, hist, mask=mask)
+    assert all(m[s, 1] == -1 for e, s in ids if e == 1)
+    # the oracle agrees on the flat view of case (2)
+    keys, mid, nrm, fid = _flat(em, ct, a.aos("body_q"))
+    live_prev = [(e, s) for e, s in fid if plive[s, e]]
+    sel = [i for i, es in enumerate(fid) if plive[es[1], es[0]]]
+    pk, pm, pn = keys[sel], np.array([[ppos[c, s, e] for c in range(3)] for e, s in live_prev], np.float32), \
+        np.array([[pnrm[c, s, e] for c in range(3)] for e, s in live_prev], np.float32)
+    want = O.match(keys, mid, nrm, pk, pm, pn, pos_threshold=10.0)
+    m = _emu_match(H, em, a, ct, hist, pos_thr=10.0)
+    prev_flat = {es: i for i, es in enumerate(live_prev)}
+    got = np.array([m[s, e] if m[s, e] < 0 else prev_flat[(e, int(m[s, e]))] for e, s in fid], dtype=np.int32)
+    assert np.array_equal(got, want)

@@ -99,3 +99,73 @@ def test_device_mesh_sdf_many_pairs_scales_and_stays_deterministic():
     want = O.mesh_sdf_collide(pairs[sample], X, data, gap, idx, [t], er, ec, eh)
     got = {(int(p), int(k)) for p, k in zip(a["pair"], a["key"]) if p in set(sample.tolist())}
     assert got == {(int(sample[p]), int(k)) for p, k, *_ in want}
+
+
+@pytest.mark.parametrize("kh,margin", [((1e6, 1e6), 0.0), ((3e6, 5e5), 0.001)])
+def test_device_hydroelastic_faces_vs_oracle(kh, margin):
+    """nt_hydro_collide on the device: the iso-pressure faces of a ball pressed into a slab -- the face set (voxel, face) equals
+    the oracle's, geometry / separation / stiffness / area / pressure within fp32 tolerance; the patch carries the closed-form
+    force for equal stiffness."""
+    from test_hydroelastic import oracle_faces, sphere_on_slab
+
+    from newton_amd.sdf_device import DeviceSDF, hydro_collide
+
+    sc = sphere_on_slab(res=16, kh=kh, margin=margin)
+    want = oracle_faces(sc)
+    got = hydro_collide(sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["kh"], np.array([0, 1], dtype=np.int32),
+                        [DeviceSDF(t) for t in sc["sdfs"]])
+    assert got["count"] == len(want) > 10
+    assert list(zip(got["pair"].tolist(), got["key"].tolist())) == [(p, k) for p, k, *_ in want]
+    for i, w in enumerate(want):
+        assert (int(got["shape_a"][i]), int(got["shape_b"][i])) == (w[2], w[3])
+        assert np.max(np.abs(got["center"][i] - w[4])) <= 1e-5 and np.max(np.abs(got["normal"][i] - w[5])) <= 1e-4
+        assert abs(got["distance"][i] - w[6]) <= 1e-6 and abs(got["stiffness"][i] - w[7]) <= 1e-3 * max(1.0, abs(w[7]))
+        assert abs(got["area"][i] - w[8]) <= 1e-8 + 1e-4 * w[8] and abs(got["pressure"][i] - w[9]) <= 1e-2 + 1e-4 * w[9]
+
+
+def test_device_hydroelastic_patch_closed_form_at_resolution_48():
+    from test_hydroelastic import sphere_on_slab
+
+    from newton_amd.sdf_device import DeviceSDF, hydro_collide
+
+    R, delta, kh = 0.1, 0.005, 1e6
+    sc = sphere_on_slab(delta=delta, res=48)
+    got = hydro_collide(sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["kh"], np.array([0, 1], dtype=np.int32),
+                        [DeviceSDF(t) for t in sc["sdfs"]])
+    pen = got["distance"] < 0
+    area, force = got["area"][pen].sum(), (got["stiffness"][pen] * -got["distance"][pen]).sum()
+    assert abs(area - 2 * np.pi * R * delta) / (2 * np.pi * R * delta) < 0.08
+    assert abs(force - kh * np.pi * R * delta ** 2 / 2) / (kh * np.pi * R * delta ** 2 / 2) < 0.08
+
+
+def test_device_eval_body_contact_consumes_per_contact_stiffness():
+    """Contacts(per_contact_shape_properties=True): SolverSemiImplicit on the device vs the oracle with per-slot overrides."""
+    import newton_amd as nt
+    from oracle_bridge import Oracle, OracleState
+    from scenes import mixed_primitive_scene
+
+    model = mixed_primitive_scene(5, device="cuda:0")
+    model.body_q[:, 2] -= 0.03
+    pipe = nt.CollisionPipeline(model)
+    ct = pipe.contacts(per_contact_shape_properties=True)
+    s0, s1 = model.state(), model.state()
+    pipe.collide(s0, ct)
+    t = model.env
+    ns = t.np * t.cpp
+    rng = np.random.default_rng(5)
+    ke = rng.choice([0.0, 2.0e4, 7.5e3], size=(ns, t.env_count)).astype(np.float32)
+    kd = rng.choice([0.0, 30.0], size=(ns, t.env_count)).astype(np.float32)
+    mu = rng.choice([0.0, 0.5, 2.0], size=(ns, t.env_count)).astype(np.float32)
+    ct.set_slot_properties(ke, kd, mu)
+    nt.solvers.SolverSemiImplicit(model).step(s0, s1, None, ct, 1e-3)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    o.collide(os0.body_q, oc)
+    shape0 = ct._shape0[:ns, : t.env_count].cpu().numpy()
+    nas = t.np_analytic * t.cpp
+    live = [(env, s) for env in range(t.env_count) for s in range(nas) if shape0[s, env] >= 0] + \
+           [(env, s) for env in range(t.env_count) for s in range(nas, ns) if shape0[s, env] >= 0]
+    assert len(live) == int(oc.count[0]) > 0
+    oc.set_properties([ke[s, env] for env, s in live], [kd[s, env] for env, s in live], [mu[s, env] for env, s in live])
+    o.semi_implicit_step(os0, os1, o.control(), oc, 1e-3)
+    assert np.max(np.abs(s1.body_qd.cpu().numpy() - os1.body_qd)) <= 2e-4 * max(1.0, np.abs(os1.body_qd).max())

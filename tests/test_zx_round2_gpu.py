@@ -90,3 +90,67 @@ def test_control_clear_matches_reference_semantics():
     assert np.array_equal(ctrl.joint_target_q.cpu().numpy(), model.joint_target_q)
     ctrl.clear()
     assert float(ctrl.joint_target_q.abs().max()) == 0.0
+
+
+def test_contact_matcher_follows_the_reference_matcher_on_a_box_stack(oracle_lib):
+    """ContactMatcher (device kernels nt_contacts_match / nt_contacts_save_history on the fixed slots, flat indices in the
+    deterministic export order) against oracle/oracle_match.py on three consecutive frames of a settling box stack."""
+    import os
+    import sys
+
+    import torch
+    from scenes import box_stack_scene
+
+    import newton_amd as nt
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_match as O
+
+    model = box_stack_scene(8, n_boxes=4, seed=2, jitter=2e-3, device="cuda:0")
+    pipe = nt.CollisionPipeline(model, deterministic=True)
+    contacts = pipe.contacts()
+    matcher = nt.ContactMatcher(model)
+    solver = nt.solvers.SolverXPBD(model, iterations=4)
+    s0, s1 = model.state(), model.state()
+    shape_body = np.asarray(model.shape_body)
+    prev = None
+    for frame in range(3):
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        got = matcher.match(s0, contacts).cpu().numpy()
+        torch.cuda.synchronize()
+        n = int(contacts.rigid_contact_count.cpu().numpy()[0])
+        sh0 = contacts.rigid_contact_shape0.cpu().numpy()[:n]
+        sh1 = contacts.rigid_contact_shape1.cpu().numpy()[:n]
+        p0 = contacts.rigid_contact_point0.cpu().numpy()[:n]
+        p1 = contacts.rigid_contact_point1.cpu().numpy()[:n]
+        nrm = contacts.rigid_contact_normal.cpu().numpy()[:n]
+        assert len(got) == n > 0
+        pair = sh0.astype(np.int64) * (1 << 32) + sh1
+        assert np.all(np.diff(pair) >= 0)
+        sub = np.zeros(n, dtype=np.int64)  # rank inside the pair's run == manifold slot order
+        for i in range(1, n):
+            sub[i] = sub[i - 1] + 1 if pair[i] == pair[i - 1] else 0
+        keys = np.array([O.sort_key(a, b, k) for a, b, k in zip(sh0, sh1, sub)], dtype=np.int64)
+        mid = O.midpoints(s0.body_q.cpu().numpy(), shape_body, sh0, sh1, p0, p1)
+        if prev is None:
+            assert np.all(got == -1)
+        else:
+            want = O.match(keys, mid, nrm, *prev)
+            assert np.array_equal(got, want)
+            assert (want >= 0).sum() > 0.5 * n
+        matcher.save_sorted_state(s0, contacts)
+        prev = (keys, mid, nrm)
+        solver.step(s0, s1, None, contacts, 1.0 / 240.0)
+        s0, s1 = s1, s0
+    # a reset world forgets its history
+    s0.clear_forces()
+    pipe.collide(s0, contacts)
+    mask = np.zeros(8, dtype=bool)
+    mask[3] = True
+    matcher.reset(mask)
+    got = matcher.match(s0, contacts).cpu().numpy()
+    n = len(got)
+    sw = np.asarray(model.shape_world)
+    world = np.maximum(sw[contacts.rigid_contact_shape0.cpu().numpy()[:n]], sw[contacts.rigid_contact_shape1.cpu().numpy()[:n]])
+    assert np.all(got[world == 3] == -1) and np.any(got[world != 3] >= 0)
