@@ -74,6 +74,9 @@ typedef struct {
     int32_t contact_scratch_in_hbm; /* 0: the per-contact correction records of the solvers live in LDS (default).
                             1: pair-heavy scenes whose records do not fit the CU's LDS keep them in nt_contacts.cw (HBM, L2
                             resident); the stepping kernels then run one environment per workgroup.  XPBD / collide only. */
+    int32_t params_uniform; /* 1: body_param / joint_param / dof_param / shape_param hold the same values in every environment
+                            (replicated worlds, newton.ModelBuilder.replicate without per-world randomisation).  The XPBD rollout
+                            then keeps ONE block-shared copy per workgroup in LDS; 0 is always valid */
     /* topology, int32, env-uniform */
     const int32_t* body_flags;          /* [nb]   BodyFlags */
     const int32_t* joint_type;          /* [nj]   JointType */

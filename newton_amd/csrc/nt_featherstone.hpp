@@ -193,11 +193,11 @@ NT_DI void fs_fk_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int parent = c.T.joint_parent[j], child = c.T.joint_child[j];
-    xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
+    xform X_wpj = c.plxf(c.L.jp, 0, m.nj, j);
     if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
     xform X_j = c.lxf(f.F.vs, 0, m.nj, j);
     xform X_wcj = X_wpj * X_j;
-    xform X_wc = X_wcj * xform_inverse(c.lxf(c.L.jp, 7, m.nj, j));
+    xform X_wc = X_wcj * xform_inverse(c.plxf(c.L.jp, 7, m.nj, j));
     c.st_lxf(c.L.bq, m.nb, child, X_wc);
     xform X_sm = X_wc * xform(c.com(child), quat_identity());
     c.st_lv3(f.F.qcom, 0, m.nb, child, X_sm.p);
@@ -208,7 +208,7 @@ template <int EPB>
 NT_DI vec3 fs_free_com_offset(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
     const int parent = c.T.joint_parent[j], child = c.T.joint_child[j];
-    xform X_wpj = c.lxf(c.L.jp, 0, c.a.m.nj, j);
+    xform X_wpj = c.plxf(c.L.jp, 0, c.a.m.nj, j);
     if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
     vec3 x_child_com_world = xform_point(c.body_q(child), c.com(child));
     return quat_rotate_inv(X_wpj.q, x_child_com_world - X_wpj.p);
@@ -317,7 +317,7 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
         int rt = c.T.joint_type[root];
         if (rt == JT_FREE || rt == JT_DISTANCE) solve_origin = f.v3(f.F.qcom, 0, nb, c.T.joint_child[root]);
     }
-    xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
+    xform X_wpj = c.plxf(c.L.jp, 0, m.nj, j);
     if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
     xform X_sc(X_wpj.p - solve_origin, X_wpj.q);
 
@@ -392,7 +392,7 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
     vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - solve_origin;
     c.st_lv3(f.F.org, 0, nb, child, solve_origin);
     mat66 I_s;
-    fs_transform_spatial_inertia(xform(x_com_s, c.body_rot(child)), c.l(c.L.bp, BP_MASS, nb, child), c.inertia(child), I_s);
+    fs_transform_spatial_inertia(xform(x_com_s, c.body_rot(child)), c.pl(c.L.bp, BP_MASS, nb, child), c.inertia(child), I_s);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -426,7 +426,7 @@ NT_DI void fs_motion_post_item(const FsCtx<EPB>& f, int j) {
     const int child = c.T.joint_child[j];
     spatial v_s = f.sp6(f.F.vs, nb, child), a_s = f.sp6(f.F.as, nb, child);
     vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - f.v3(f.F.org, 0, nb, child);
-    float mass = c.l(c.L.bp, BP_MASS, nb, child);
+    float mass = c.pl(c.L.bp, BP_MASS, nb, child);
     vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
     vec3 f_g = mass * gravity;
     spatial f_g_s(f_g, cross(x_com_s, f_g));
@@ -728,7 +728,7 @@ NT_DI void fs_integrate_item(const FsCtx<EPB>& f, int j) {
         vec3 v_parent(qd(ds), qd(ds + 1), qd(ds + 2)), omega(qd(ds + 3), qd(ds + 4), qd(ds + 5));
         vec3 p(q(cs), q(cs + 1), q(cs + 2));
         quat r(q(cs + 3), q(cs + 4), q(cs + 5), q(cs + 6));
-        vec3 r_com_joint = xform_point(xform_inverse(c.lxf(c.L.jp, 7, m.nj, j)), c.com(child));
+        vec3 r_com_joint = xform_point(xform_inverse(c.plxf(c.L.jp, 7, m.nj, j)), c.com(child));
         vec3 x_com = p + quat_rotate(r, r_com_joint);
         vec3 v_com = v_parent + cross(omega, x_com);
         vec3 a_com = a_parent + cross(alpha, x_com) + cross(omega, v_com);
@@ -792,14 +792,14 @@ NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
         }
         v_j = spatial(vel_v, vel_w);
     }
-    xform X_wpj = c.lxf(c.L.jp, 0, m.nj, j);
+    xform X_wpj = c.plxf(c.L.jp, 0, m.nj, j);
     xform X_wp;
     if (parent >= 0) {
         X_wp = c.body_q(parent);
         X_wpj = X_wp * X_wpj;
     }
     xform X_wcj = X_wpj * X_j;
-    xform X_wc = X_wcj * xform_inverse(c.lxf(c.L.jp, 7, m.nj, j));
+    xform X_wc = X_wcj * xform_inverse(c.plxf(c.L.jp, 7, m.nj, j));
     vec3 x_child_origin = X_wc.p;
     vec3 v_parent_origin, w_parent;
     if (parent >= 0) {

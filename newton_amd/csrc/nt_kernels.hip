@@ -198,8 +198,12 @@ int slots_for(const nt_model& m, int epb, int max_threads) {
     return want < cap ? want : cap;
 }
 
-bool epb_fits(const nt_model& m, int epb, bool restitution = false) {
-    return (size_t)make_layout_host(m, restitution).rows_per_env * 4 * epb + (size_t)topo_ints(m) * 4 <= LDS_BYTES_PER_CU;
+size_t tile_lds_bytes(const nt_model& m, int epb, bool restitution, bool uni) {
+    LdsLayout L = make_layout_host(m, restitution, uni);
+    return (size_t)L.rows_per_env * 4 * epb + (size_t)topo_ints(m) * 4 + (size_t)L.uni_floats * 4;
+}
+bool epb_fits(const nt_model& m, int epb, bool restitution = false, bool uni = false) {
+    return tile_lds_bytes(m, epb, restitution, uni) <= LDS_BYTES_PER_CU;
 }
 
 int pick_epb(const nt_model& m, int requested, bool restitution = false) {
@@ -224,8 +228,8 @@ int pick_epb(const nt_model& m, int requested, bool restitution = false) {
 
 // semi: the SolverSemiImplicit kernel (own scratch layout); max_threads: the kernel's THREADS template argument
 template <typename K>
-nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false) {
-    LdsLayout L = make_layout_host(a.m, a.p.enable_restitution != 0);
+nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false, bool uni = false) {
+    LdsLayout L = make_layout_host(a.m, a.p.enable_restitution != 0, uni);
     if (max_threads <= 0) max_threads = max_threads_for(epb);
     int nslot = slots_for(a.m, epb, max_threads);
     a.nslot = nslot;
@@ -235,7 +239,7 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
         a.debug_skip = dbg;
     }
     int threads = ((nslot * epb + 63) / 64) * 64;
-    size_t lds_bytes = (size_t)(semi ? L.rows_semi : L.rows_per_env) * 4 * epb + (size_t)topo_ints(a.m) * 4;
+    size_t lds_bytes = (size_t)(semi ? L.rows_semi : L.rows_per_env) * 4 * epb + (size_t)topo_ints(a.m) * 4 + (size_t)L.uni_floats * 4;
     if (lds_bytes > LDS_BYTES_PER_CU) return NT_ERR_UNSUPPORTED;
     int blocks = (a.m.env_count + epb - 1) / epb;
     if (lds_bytes > 48 * 1024) {
@@ -247,19 +251,26 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
 }
 
 // Launch shape of the analytic (non-convex) fused XPBD rollout: environments per workgroup, workgroup size, minimum waves
-// per SIMD (register cap).  NT_XPBD_CFG="epb,threads,minw" selects one of the compiled shapes for A/B measurements.
-struct XpbdCfg { int epb, threads, minw; };
+// per SIMD (register cap), uniform-parameter tile.  NT_XPBD_CFG="epb,threads,minw[,uni]" selects one of the compiled shapes
+// for A/B measurements.
+struct XpbdCfg { int epb, threads, minw, uni; };
 inline bool xpbd_cfg_override(XpbdCfg& c) {
     const char* e = getenv("NT_XPBD_CFG");
     if (!e) return false;
-    return sscanf(e, "%d,%d,%d", &c.epb, &c.threads, &c.minw) == 3;
+    c.uni = 0;
+    return sscanf(e, "%d,%d,%d,%d", &c.epb, &c.threads, &c.minw, &c.uni) >= 3;
 }
 #define NT_XPBD_ROLLOUT_SHAPES(X) \
-    X(16, 512, 1) X(16, 512, 4) X(16, 1024, 4) X(8, 256, 1) X(8, 256, 2) X(8, 256, 4) X(8, 512, 2) X(8, 512, 4) \
-    X(4, 256, 2) X(4, 256, 4) X(4, 128, 4) X(4, 128, 8)
+    X(16, 512, 1, 0) X(16, 256, 1, 0) X(8, 256, 2, 0) \
+    X(16, 256, 2, 1) X(16, 512, 2, 1) X(16, 512, 4, 1) X(32, 512, 1, 1) X(8, 128, 4, 1) X(8, 256, 4, 1)
+// the shape uniform-parameter models run by default once there are enough environments to give every CU a tile of 32 (measured,
+// MI355X, quadruped: 4096 envs 78 vs 92 M env-steps/s for the 16-env per-environment tile -- half the CUs idle; 8192 envs 158
+// vs 101 M; 65536 envs 157 vs 99 M.  2 x (16, 256) per CU: 144-149 M)
+constexpr XpbdCfg NT_XPBD_UNI_DEFAULT = {32, 512, 1, 1};
 nt_status launch_xpbd_rollout_shape(const KArgs& a, XpbdCfg c, hipStream_t stream) {
-#define X(E, T, W) \
-    if (c.epb == E && c.threads == T && c.minw == W) return launch(xpbd_rollout_kernel<E, false, false, T, W>, a, E, stream, T);
+#define X(E, T, W, U) \
+    if (c.epb == E && c.threads == T && c.minw == W && c.uni == U) \
+        return launch(xpbd_rollout_kernel<E + U * NT_UNI, false, false, T, W>, a, E, stream, T, false, U != 0);
     NT_XPBD_ROLLOUT_SHAPES(X)
 #undef X
     return NT_ERR_UNSUPPORTED;
@@ -392,9 +403,13 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     if (m->np_analytic == m->np) {  // analytic-only models: the tuned launch shapes
         XpbdCfg c;
         if (xpbd_cfg_override(c)) {
-            if (!epb_fits(*m, c.epb, rest)) return NT_ERR_UNSUPPORTED;
+            if ((c.uni && (!m->params_uniform || rest)) || !epb_fits(*m, c.epb, rest, c.uni != 0)) return NT_ERR_UNSUPPORTED;
             return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
         }
+        c = NT_XPBD_UNI_DEFAULT;
+        if (m->params_uniform && !rest && m->env_count >= 256 * c.epb && epb_fits(*m, c.epb, rest, true) &&
+            (cp == nullptr || cp->envs_per_block == 0))
+            return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
     }
     return NT_DISPATCH_EPB_CVX(xpbd_rollout_kernel, *m, a, epb, (hipStream_t)stream);
 }

@@ -50,6 +50,7 @@ struct LdsLayout {
     int si_bf, si_jf, si_cw;  // semi-implicit: body_f_tmp + joint wrenches + contact wrenches, all live together
     int xi;            // XPBD restitution: pre-step body_q / body_qd [13][nb], behind the XPBD scratch (solver_xpbd.py:414-416)
     int rows_per_env;  // collide / XPBD kernels
+    int uni_floats;    // uniform-parameter tiles: bp / jp / dp / sp index ONE block-shared copy of this many floats instead of rows
     int rows_semi;     // SolverSemiImplicit kernel (its wrench records share the scratch with body_f_tmp + joint wrenches)
 };
 
@@ -59,15 +60,21 @@ constexpr int NT_MIN_SCRATCH_ROWS = 8;  // the live-contact prefix parks up to 8
 // big: pair-heavy scenes (nt_model.contact_scratch_in_hbm).  Device code passes a compile-time constant so that the
 // default kernels carry no trace of the second mode.
 // restitution: SolverXPBD(enable_restitution=True) keeps the pre-step state and 15-float velocity records per contact slot
-__host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false) {
+// uni: nt_model.params_uniform models on a uniform-parameter tile -- the body / joint / dof / shape parameters are identical
+// in every environment, so the workgroup keeps ONE copy (block-shared, broadcast reads) and an environment's LDS footprint
+// drops from 1309 + 663 to 401 + 663 rows on the headline quadruped: two workgroups fit a CU instead of one
+__host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false,
+                                                 const bool uni = false) {
     LdsLayout L;
-    int o = 0;
+    int o = 0, ou = 0;
     L.bq = o; o += 7 * m.nb;
     L.bqd = o; o += 6 * m.nb;
-    L.bp = o; o += NT_BODY_PARAM_FLOATS * m.nb;
-    L.jp = o; o += NT_JOINT_PARAM_FLOATS * m.nj;
-    L.dp = o; o += NT_DOF_PARAM_FLOATS * m.nd;
-    L.sp = o; o += NT_SHAPE_PARAM_FLOATS * m.ns;
+    int& po = uni ? ou : o;
+    L.bp = po; po += NT_BODY_PARAM_FLOATS * m.nb;
+    L.jp = po; po += NT_JOINT_PARAM_FLOATS * m.nj;
+    L.dp = po; po += NT_DOF_PARAM_FLOATS * m.nd;
+    L.sp = po; po += NT_SHAPE_PARAM_FLOATS * m.ns;
+    L.uni_floats = ou;
     L.cf = o; o += m.nd;
     L.ctq = o; o += m.ntq;
     L.ctqd = o; o += m.nd;
@@ -98,8 +105,8 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.rows_semi = L.u + semi;
     return L;
 }
-inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false) {
-    return make_layout(m, m.contact_scratch_in_hbm != 0, restitution);
+inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false, bool uni = false) {
+    return make_layout(m, m.contact_scratch_in_hbm != 0, restitution, uni);
 }
 
 struct KArgs {
@@ -131,11 +138,17 @@ __host__ __device__ inline int topo_ints(const nt_model& m) {
            NT_SHAPE_PARAM_FLOATS * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 0);
 }
 
+// The tile code EPB of every kernel template carries the environments per workgroup in its low byte and the
+// uniform-parameter flag NT_UNI in bit 8: Ctx<EPB>::N is the count, Ctx<EPB>::UNI the flag.
+constexpr int NT_UNI = 256;
 template <int EPB>
 struct Ctx {
+    static constexpr int N = EPB & 255;
+    static constexpr bool UNI = (EPB & NT_UNI) != 0;
     const KArgs& a;
     Topo T;
     float* lds;
+    float* up;  // UNI: the block-shared parameter copy [L.uni_floats], behind the topology
     LdsLayout L;
     int e, slot, env, nslot;
     int tslot;  // start of the item loop of phases with fewer items than slot-threads.  Identity: dealing consecutive items to
@@ -147,17 +160,17 @@ struct Ctx {
 
     // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
     NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
-        L = make_layout(a.m, big_, a.p.enable_restitution != 0);
+        L = make_layout(a.m, big_, a.p.enable_restitution != 0, UNI);
         if (rows < 0) rows = L.rows_per_env;
-        e = threadIdx.x % EPB;
-        slot = threadIdx.x / EPB;
+        e = threadIdx.x % N;
+        slot = threadIdx.x / N;
         nslot = a.nslot;
-        env = blockIdx.x * EPB + e;
+        env = blockIdx.x * N + e;
         ES = a.m.env_stride;
         valid = env < a.m.env_count && slot < nslot;
         tslot = slot;
         const nt_model& m = a.m;
-        int* ti = reinterpret_cast<int*>(lds + (size_t)rows * EPB);
+        int* ti = reinterpret_cast<int*>(lds + (size_t)rows * N);
         int o = 0;
         auto take = [&](const int*& dst, const int32_t* src, int n) {
             for (int i = threadIdx.x; i < n; i += blockDim.x) ti[o + i] = src[i];
@@ -195,9 +208,27 @@ struct Ctx {
         }
         T.hit_count = ti + o;
         T.hit_list = ti + o + 1;
+        up = reinterpret_cast<float*>(ti + topo_ints(m));
     }
     // LDS element: row = field offset + comp * slots_in_field + slot
-    NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * EPB + e]; }
+    NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * N + e]; }
+    // parameter element (fields bp / jp / dp / sp): per-environment row, or the block-shared copy of a uniform tile
+    NT_DI float pl(int off, int comp, int n, int s) const {
+        if constexpr (UNI) return up[off + comp * n + s];
+        else return lds[(off + comp * n + s) * N + e];
+    }
+    NT_DI vec3 plv3(int off, int comp0, int n, int s) const {
+        return vec3(pl(off, comp0, n, s), pl(off, comp0 + 1, n, s), pl(off, comp0 + 2, n, s));
+    }
+    NT_DI xform plxf(int off, int comp0, int n, int s) const {
+        return xform(plv3(off, comp0, n, s),
+                     quat(pl(off, comp0 + 3, n, s), pl(off, comp0 + 4, n, s), pl(off, comp0 + 5, n, s), pl(off, comp0 + 6, n, s)));
+    }
+    NT_DI mat33 plm33(int off, int comp0, int n, int s) const {
+        return mat33(pl(off, comp0, n, s), pl(off, comp0 + 1, n, s), pl(off, comp0 + 2, n, s), pl(off, comp0 + 3, n, s),
+                     pl(off, comp0 + 4, n, s), pl(off, comp0 + 5, n, s), pl(off, comp0 + 6, n, s), pl(off, comp0 + 7, n, s),
+                     pl(off, comp0 + 8, n, s));
+    }
     NT_DI size_t g(int comp, int n, int s) const { return (size_t)(comp * n + s) * ES + env; }
 
     NT_DI vec3 lv3(int off, int comp0, int n, int s) const {
@@ -230,10 +261,10 @@ struct Ctx {
     }
     NT_DI vec3 body_v(int b) const { return lv3(L.bqd, 0, a.m.nb, b); }
     NT_DI vec3 body_w(int b) const { return lv3(L.bqd, 3, a.m.nb, b); }
-    NT_DI float inv_mass(int b) const { return l(L.bp, BP_INV_MASS, a.m.nb, b); }
-    NT_DI mat33 inv_inertia(int b) const { return lm33(L.bp, BP_INV_INERTIA, a.m.nb, b); }
-    NT_DI mat33 inertia(int b) const { return lm33(L.bp, BP_INERTIA, a.m.nb, b); }
-    NT_DI vec3 com(int b) const { return lv3(L.bp, BP_COM, a.m.nb, b); }
+    NT_DI float inv_mass(int b) const { return pl(L.bp, BP_INV_MASS, a.m.nb, b); }
+    NT_DI mat33 inv_inertia(int b) const { return plm33(L.bp, BP_INV_INERTIA, a.m.nb, b); }
+    NT_DI mat33 inertia(int b) const { return plm33(L.bp, BP_INERTIA, a.m.nb, b); }
+    NT_DI vec3 com(int b) const { return plv3(L.bp, BP_COM, a.m.nb, b); }
     NT_DI vec3 world_com(int b) const { return lv3(L.bd, 0, a.m.nb, b); }
     // a^T (R I^-1 R^T) a for body b (world-frame inverse inertia, symmetric 6-float tile in LDS)
     NT_DI float w_quad(int b, vec3 v) const {
@@ -255,12 +286,12 @@ struct Ctx {
         l(L.bd, 3, nb, b) = dot(r0, t0); l(L.bd, 4, nb, b) = dot(r0, t1); l(L.bd, 5, nb, b) = dot(r0, t2);
         l(L.bd, 6, nb, b) = dot(r1, t1); l(L.bd, 7, nb, b) = dot(r1, t2); l(L.bd, 8, nb, b) = dot(r2, t2);
     }
-    NT_DI float dof(int row, int d) const { return l(L.dp, row, a.m.nd, d); }
-    NT_DI vec3 dof_axis(int d) const { return lv3(L.dp, DP_AXIS, a.m.nd, d); }
+    NT_DI float dof(int row, int d) const { return pl(L.dp, row, a.m.nd, d); }
+    NT_DI vec3 dof_axis(int d) const { return plv3(L.dp, DP_AXIS, a.m.nd, d); }
 
     // shape accessors: s < ns local (per-env params in LDS), otherwise the env-uniform global table
     NT_DI float shape_f(int s, int comp) const {
-        if (s < a.m.ns) return l(L.sp, comp, a.m.ns, s);
+        if (s < a.m.ns) return pl(L.sp, comp, a.m.ns, s);
         return T.gshape[(s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp];
     }
     NT_DI vec3 shape_scale(int s) const { return vec3(shape_f(s, SP_SCALE), shape_f(s, SP_SCALE + 1), shape_f(s, SP_SCALE + 2)); }
@@ -285,11 +316,11 @@ struct Ctx {
 // ------------------------------------------------------------------------------------------------
 template <int EPB>
 NT_DI void stage_rows(const Ctx<EPB>& c, int lds_off, const float* src, int rows) {
-    for (int r = c.slot; r < rows; r += c.nslot) c.lds[(lds_off + r) * EPB + c.e] = src[(size_t)r * c.ES + c.env];
+    for (int r = c.slot; r < rows; r += c.nslot) c.lds[(lds_off + r) * Ctx<EPB>::N + c.e] = src[(size_t)r * c.ES + c.env];
 }
 template <int EPB>
 NT_DI void unstage_rows(const Ctx<EPB>& c, int lds_off, float* dst, int rows) {
-    for (int r = c.slot; r < rows; r += c.nslot) dst[(size_t)r * c.ES + c.env] = c.lds[(lds_off + r) * EPB + c.e];
+    for (int r = c.slot; r < rows; r += c.nslot) dst[(size_t)r * c.ES + c.env] = c.lds[(lds_off + r) * Ctx<EPB>::N + c.e];
 }
 
 template <int EPB>
@@ -307,20 +338,36 @@ NT_DI void store_state(const Ctx<EPB>& c, const nt_state& s) {
 // parameters and controls: read once per kernel
 template <int EPB>
 NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
-    if (!c.valid) return;
     const nt_model& m = c.a.m;
     const int nb = m.nb;
-    // body params, with effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
-    for (int r = c.slot; r < NT_BODY_PARAM_FLOATS * nb; r += c.nslot) {
-        int comp = r / nb, b = r - comp * nb;
-        float v = m.body_param[(size_t)r * c.ES + c.env];
-        bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
-        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
-        c.lds[(c.L.bp + r) * EPB + c.e] = v;
+    if constexpr (Ctx<EPB>::UNI) {
+        // one copy per workgroup, read from the tile's first environment (the host vouches that all columns are equal)
+        const size_t col = (size_t)blockIdx.x * Ctx<EPB>::N;
+        for (int r = threadIdx.x; r < NT_BODY_PARAM_FLOATS * nb; r += blockDim.x) {
+            int comp = r / nb, b = r - comp * nb;
+            float v = m.body_param[(size_t)r * c.ES + col];
+            bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
+            if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;
+            c.up[c.L.bp + r] = v;
+        }
+        for (int r = threadIdx.x; r < NT_JOINT_PARAM_FLOATS * m.nj; r += blockDim.x) c.up[c.L.jp + r] = m.joint_param[(size_t)r * c.ES + col];
+        for (int r = threadIdx.x; r < NT_DOF_PARAM_FLOATS * m.nd; r += blockDim.x) c.up[c.L.dp + r] = m.dof_param[(size_t)r * c.ES + col];
+        for (int r = threadIdx.x; r < NT_SHAPE_PARAM_FLOATS * m.ns; r += blockDim.x) c.up[c.L.sp + r] = m.shape_param[(size_t)r * c.ES + col];
     }
-    stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS * m.nj);
-    stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS * m.nd);
-    stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS * m.ns);
+    if (!c.valid) return;
+    if constexpr (!Ctx<EPB>::UNI) {
+        // body params, with effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
+        for (int r = c.slot; r < NT_BODY_PARAM_FLOATS * nb; r += c.nslot) {
+            int comp = r / nb, b = r - comp * nb;
+            float v = m.body_param[(size_t)r * c.ES + c.env];
+            bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
+            if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
+            c.lds[(c.L.bp + r) * Ctx<EPB>::N + c.e] = v;
+        }
+        stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS * m.nj);
+        stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS * m.nd);
+        stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS * m.ns);
+    }
     stage_rows(c, c.L.grav, m.gravity, 3);
     if (with_control) {
         stage_rows(c, c.L.cf, c.a.c.joint_f, m.nd);

@@ -16,10 +16,10 @@ struct vec3 {
     NT_DI explicit vec3(float s) : x(s), y(s), z(s) {}
 };
 NT_DI float vget(const vec3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-NT_DI void vset(vec3& v, int i, float s) {
-    if (i == 0) v.x = s;
-    else if (i == 1) v.y = s;
-    else v.z = s;
+NT_DI void vset(vec3& v, int i, float s) {  // value selects, not an if-chain of stores (see vsel)
+    v.x = i == 0 ? s : v.x;
+    v.y = i == 1 ? s : v.y;
+    v.z = (i != 0 && i != 1) ? s : v.z;
 }
 NT_DI vec3 operator+(vec3 a, vec3 b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
 NT_DI vec3 operator-(vec3 a, vec3 b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -42,6 +42,10 @@ NT_DI vec3 normalize(vec3 a) {
 NT_DI vec3 cw_mul(vec3 a, vec3 b) { return vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
 NT_DI float fminw(float a, float b) { return a < b ? a : b; }
 NT_DI float fmaxw(float a, float b) { return a > b ? a : b; }
+// component-wise select.  `cond ? a : b` on two vec3 LVALUES compiles to a select between their ADDRESSES plus a copy, which
+// pins both operands (and any struct they live in) in scratch memory; this form stays in registers
+NT_DI float fsel(bool k, float a, float b) { return k ? a : b; }
+NT_DI vec3 vsel(bool k, vec3 a, vec3 b) { return vec3(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z); }
 NT_DI vec3 vmin(vec3 a, vec3 b) { return vec3(fminw(a.x, b.x), fminw(a.y, b.y), fminw(a.z, b.z)); }
 NT_DI vec3 vmax(vec3 a, vec3 b) { return vec3(fmaxw(a.x, b.x), fmaxw(a.y, b.y), fmaxw(a.z, b.z)); }
 NT_DI vec3 vabs(vec3 a) { return vec3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }

@@ -21,14 +21,29 @@ struct Contacts4 {
     vec3 p0, p1, p2, p3;
     vec3 normal;
     NT_DI Contacts4() : d0(NT_MAXVAL), d1(NT_MAXVAL), d2(NT_MAXVAL), d3(NT_MAXVAL) {}
+    // (every field assigned through a value select: an if-chain of stores is merged by the compiler into ONE store through a
+    // selected address, which again pins the struct in scratch memory)
     NT_DI void set(int i, float d, vec3 p) {
-        if (i == 0) { d0 = d; p0 = p; }
-        else if (i == 1) { d1 = d; p1 = p; }
-        else if (i == 2) { d2 = d; p2 = p; }
-        else { d3 = d; p3 = p; }
+        d0 = i == 0 ? d : d0; p0 = vsel(i == 0, p, p0);
+        d1 = i == 1 ? d : d1; p1 = vsel(i == 1, p, p1);
+        d2 = i == 2 ? d : d2; p2 = vsel(i == 2, p, p2);
+        d3 = i > 2 || i < 0 ? d : d3; p3 = vsel(i > 2 || i < 0, p, p3);
     }
-    NT_DI float dist(int i) const { return i == 0 ? d0 : (i == 1 ? d1 : (i == 2 ? d2 : d3)); }
-    NT_DI vec3 pos(int i) const { return i == 0 ? p0 : (i == 1 ? p1 : (i == 2 ? p2 : p3)); }
+    NT_DI float dist(int i) const { return fsel(i == 0, d0, fsel(i == 1, d1, fsel(i == 2, d2, d3))); }
+    NT_DI vec3 pos(int i) const { return vsel(i == 0, p0, vsel(i == 1, p1, vsel(i == 2, p2, p3))); }
+    // slots 1..3 = the kept ones of three candidates, in order.  Same result as `if (keep) set(n++, ...)`, but written with
+    // selects: a run-time slot index makes the compiler keep the whole struct in scratch memory (measured: 166 scratch
+    // instructions in the fused rollout, the pair phase waits on every one of them)
+    NT_DI void append3(bool k0, float e0, vec3 q0, bool k1, float e1, vec3 q1, bool k2, float e2, vec3 q2) {
+        const vec3 z;
+        const bool two = (k0 && k1) || ((k0 != k1) && k2);
+        d1 = k0 ? e0 : (k1 ? e1 : (k2 ? e2 : NT_MAXVAL));
+        p1 = vsel(k0, q0, vsel(k1, q1, vsel(k2, q2, z)));
+        d2 = two ? ((k0 && k1) ? e1 : e2) : NT_MAXVAL;
+        p2 = vsel(two, vsel(k0 && k1, q1, q2), z);
+        d3 = (k0 && k1 && k2) ? e2 : NT_MAXVAL;
+        p3 = vsel(k0 && k1 && k2, q2, z);
+    }
 };
 
 NT_DI vec3 closest_segment_point(vec3 a, vec3 b, vec3 pt) {
@@ -175,13 +190,12 @@ NT_DI void plane_cylinder(vec3 n, vec3 plane_pos, vec3 cp, vec3 cyl_axis, float 
         perp_fixed = ref - axis * dot(axis, ref);
         perp_fixed = normalize(perp_fixed);
     }
-    vec3 deepest_perp = has_align ? perp_align : perp_fixed;
+    vec3 deepest_perp = vsel(has_align, perp_align, perp_fixed);
     vec3 deepest_pt = cap_center + deepest_perp * cr;
     float deepest_d = dot(deepest_pt - plane_pos, n);
     vec3 deepest_pos = deepest_pt - n * (deepest_d * 0.5f);
     out.d0 = deepest_d;
     out.p0 = deepest_pos;
-    int nc = 1;
     float mt = 0.01f * fmaxw(cr, ch);
     float mt2 = mt * mt;
     if (flat_mode) {
@@ -191,32 +205,30 @@ NT_DI void plane_cylinder(vec3 n, vec3 plane_pos, vec3 cp, vec3 cyl_axis, float 
         vec3 pt0 = cap_center + u_fixed;
         float d0 = dot(pt0 - plane_pos, n);
         vec3 pos0 = pt0 - n * (d0 * 0.5f);
-        if (nc < 4 && length_sq(pos0 - deepest_pos) > mt2) { out.set(nc, d0, pos0); nc += 1; }
         vec3 pt1 = cap_center + c120 * u_fixed + s120 * v_fixed;
         float d1 = dot(pt1 - plane_pos, n);
         vec3 pos1 = pt1 - n * (d1 * 0.5f);
-        if (nc < 4 && length_sq(pos1 - deepest_pos) > mt2) { out.set(nc, d1, pos1); nc += 1; }
         vec3 pt2 = cap_center + c120 * u_fixed - s120 * v_fixed;
         float d2 = dot(pt2 - plane_pos, n);
         vec3 pos2 = pt2 - n * (d2 * 0.5f);
-        if (nc < 4 && length_sq(pos2 - deepest_pos) > mt2) { out.set(nc, d2, pos2); nc += 1; }
+        out.append3(length_sq(pos0 - deepest_pos) > mt2, d0, pos0, length_sq(pos1 - deepest_pos) > mt2, d1, pos1,
+                    length_sq(pos2 - deepest_pos) > mt2, d2, pos2);
     } else {
-        vec3 perp_roll = has_align ? perp_align : perp_fixed;
+        vec3 perp_roll = vsel(has_align, perp_align, perp_fixed);
         vec3 u = perp_roll * cr;
         vec3 v = cross(axis, perp_roll) * cr;
         vec3 pt = cp - axis * ch + u;
         float d = dot(pt - plane_pos, n);
         vec3 pos = pt - n * (d * 0.5f);
-        if (nc < 4 && length_sq(pos - deepest_pos) > mt2) { out.set(nc, d, pos); nc += 1; }
         vec3 pt_pos_v = cap_center + v;
         float d_pos_v = dot(pt_pos_v - plane_pos, n);
         vec3 pt_neg_v = cap_center - v;
         float d_neg_v = dot(pt_neg_v - plane_pos, n);
         bool use_pos_v = d_pos_v <= d_neg_v;
-        pt = use_pos_v ? pt_pos_v : pt_neg_v;
-        d = use_pos_v ? d_pos_v : d_neg_v;
-        pos = pt - n * (d * 0.5f);
-        if (nc < 4 && length_sq(pos - deepest_pos) > mt2) { out.set(nc, d, pos); nc += 1; }
+        vec3 ptv = vsel(use_pos_v, pt_pos_v, pt_neg_v);
+        float dv = use_pos_v ? d_pos_v : d_neg_v;
+        vec3 posv = ptv - n * (dv * 0.5f);
+        out.append3(length_sq(pos - deepest_pos) > mt2, d, pos, length_sq(posv - deepest_pos) > mt2, dv, posv, false, 0.0f, vec3());
     }
     out.normal = n;
 }

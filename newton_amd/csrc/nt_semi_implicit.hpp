@@ -55,7 +55,7 @@ NT_DI void si_joint_item(const Ctx<EPB>& c, const int j) {
             f_total = -c.lv3(c.L.cf, 0, 1, qd_start);
             t_total = -c.lv3(c.L.cf, 0, 1, qd_start + 3);
         } else {
-            xform X_pj = c.lxf(c.L.jp, 0, nj, j), X_cj = c.lxf(c.L.jp, 7, nj, j);
+            xform X_pj = c.plxf(c.L.jp, 0, nj, j), X_cj = c.plxf(c.L.jp, 7, nj, j);
             xform X_wp = X_pj;
             vec3 w_p, v_p;
             if (c_parent >= 0) {

@@ -13,7 +13,7 @@ template <int EPB>
 NT_DI void seed_body_forces(const Ctx<EPB>& c, bool forces_are_zero) {
     // body threads seed body_f_tmp with state_in.body_f (solver_xpbd.py:423: wp.clone)
     for (int r = c.slot; r < 6 * c.a.m.nb; r += c.nslot)
-        c.lds[(c.L.bf + r) * EPB + c.e] = forces_are_zero ? 0.0f : c.a.s_in.body_f[(size_t)r * c.ES + c.env];
+        c.lds[(c.L.bf + r) * Ctx<EPB>::N + c.e] = forces_are_zero ? 0.0f : c.a.s_in.body_f[(size_t)r * c.ES + c.env];
 }
 template <int EPB>
 NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
@@ -30,8 +30,8 @@ NT_DI void joint_force_item(const Ctx<EPB>& c, const int j) {
         int type = c.T.joint_type[j];
         if (c.T.joint_enabled[j] && type != JT_FIXED && type != JT_ROD) {
             int id_c = c.T.joint_child[j], id_p = c.T.joint_parent[j];
-            xform X_pj = c.lxf(c.L.jp, 0, nj, j);
-            xform X_cj = c.lxf(c.L.jp, 7, nj, j);
+            xform X_pj = c.plxf(c.L.jp, 0, nj, j);
+            xform X_cj = c.plxf(c.L.jp, 7, nj, j);
             xform X_wp = X_pj, pose_p = X_pj;
             vec3 com_p(0.0f);
             if (id_p >= 0) {
@@ -117,7 +117,7 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     mat33 inertia = c.inertia(b);
     mat33 inv_inertia = c.inv_inertia(b);
     vec3 com = c.com(b);
-    vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
+    vec3 gravity(c.lds[(c.L.grav + 0) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 1) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 2) * Ctx<EPB>::N + c.e]);
     const float dt = c.a.dt;
 
     vec3 x0 = q.p;
@@ -393,15 +393,15 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
     if constexpr (FUSED) {
         // lane i takes the environment's i-th live contact (L.px: exclusive prefix of the per-pair live counts); records
         // of dead slots are never written and never read (apply_item stops at the pair's live count)
-        const int total = (int)c.lds[(c.L.px + np) * EPB + c.e];
+        const int total = (int)c.lds[(c.L.px + np) * Ctx<EPB>::N + c.e];
         for (int i = c.tslot; i < total; i += c.nslot) {
             int lo = 0, hi = np;  // the last pair whose prefix is <= i
             while (hi - lo > 1) {
                 int mid = (lo + hi) >> 1;
-                if ((int)c.lds[(c.L.px + mid) * EPB + c.e] <= i) lo = mid;
+                if ((int)c.lds[(c.L.px + mid) * Ctx<EPB>::N + c.e] <= i) lo = mid;
                 else hi = mid;
             }
-            contact_item<EPB, FUSED, CW>(c, lo * cpp + (i - (int)c.lds[(c.L.px + lo) * EPB + c.e]));
+            contact_item<EPB, FUSED, CW>(c, lo * cpp + (i - (int)c.lds[(c.L.px + lo) * Ctx<EPB>::N + c.e]));
         }
     } else {
         for (int s = c.slot; s < np * cpp; s += c.nslot) contact_item<EPB, FUSED, CW>(c, s);
@@ -562,8 +562,8 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
     float m_inv_p, m_inv_c;
     if (joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
         const int type = c.T.joint_type[j];
-        xform X_pj = c.lxf(c.L.jp, 0, nj, j);
-        xform X_cj = c.lxf(c.L.jp, 7, nj, j);
+        xform X_pj = c.plxf(c.L.jp, 0, nj, j);
+        xform X_cj = c.plxf(c.L.jp, 7, nj, j);
         xform X_wp = X_pj;
         vec3 world_com_p = X_pj.p;  // transform_point(pose_p = X_pj, com_p = 0) for world-attached joints
         vec3 vel_p(0.0f), omega_p(0.0f);
@@ -684,8 +684,8 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
     const int type = c.T.joint_type[j];
     bool angular_type = type == JT_FIXED || type == JT_PRISMATIC || type == JT_REVOLUTE || type == JT_D6;
     if (angular_type && joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) {
-        xform X_pj = c.lxf(c.L.jp, 0, nj, j);
-        xform X_cj = c.lxf(c.L.jp, 7, nj, j);
+        xform X_pj = c.plxf(c.L.jp, 0, nj, j);
+        xform X_cj = c.plxf(c.L.jp, 7, nj, j);
         quat q_p = X_pj.q;
         vec3 omega_p(0.0f);
         if (id_p >= 0) {
@@ -813,7 +813,7 @@ NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
             if (d < 0.0f) {
                 vec3 r_a = bx_a - xform_point(X_a_prev, com_a);
                 vec3 r_b = bx_b - xform_point(X_b_prev, com_b);
-                vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
+                vec3 gravity(c.lds[(c.L.grav + 0) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 1) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 2) * Ctx<EPB>::N + c.e]);
                 vec3 rxn_a(0.0f), rxn_b(0.0f), v_a(0.0f), v_b(0.0f), v_a_new(0.0f), v_b_new(0.0f);
                 float inv_mass = 0.0f;
                 if (body_a >= 0) {
@@ -999,7 +999,7 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
     // linear rows on slots [0, nj), angular rows on slots [A0, A0 + nj) with A0 rounded up to a wave boundary (a wave
     // holds 64 / EPB slots): no wavefront then mixes the two code paths, so the phase costs max(linear, angular)
     // instead of their sum in the wave that used to straddle the boundary
-    const int spw = 64 / EPB > 0 ? 64 / EPB : 1;
+    const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;
     const int A0 = ((nj + spw - 1) / spw) * spw;
     for (int i = c.slot; i < A0 + nj; i += c.nslot) {
         if (i < nj) joint_linear_item(c, i);
@@ -1063,7 +1063,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const int skip = c.a.debug_skip;
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
     if (!PROLOGUE_DONE && restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
-        for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * EPB + c.e] = c.lds[(c.L.bq + r) * EPB + c.e];
+        for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq + r) * Ctx<EPB>::N + c.e];
     const bool rep_joints = !FUSED && c.a.rep.joint_impulse != nullptr;
     const bool rep_contacts = !FUSED && c.a.rep.contact_impulse != nullptr && c.a.has_contacts;
     if (!PROLOGUE_DONE && !(skip & 2)) {
@@ -1123,12 +1123,12 @@ template <int EPB, bool CVX>
 NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     const nt_model& m = c.a.m;
     const int skip = c.a.debug_skip;
-    const int spw = 64 / EPB > 0 ? 64 / EPB : 1;  // slots per wave
+    const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;  // slots per wave
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
     // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
     if (c.valid) {
         if (restitution)
-            for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * EPB + c.e] = c.lds[(c.L.bq + r) * EPB + c.e];
+            for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq + r) * Ctx<EPB>::N + c.e];
         if (!(skip & 2)) seed_body_forces(c, true);
         const int S0 = ((m.ns + spw - 1) / spw) * spw;
         for (int i = c.slot; i < S0 + m.nj; i += c.nslot) {
@@ -1173,7 +1173,7 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     do_xpbd_step<EPB, true, CwLds, true>(c, true);
 }
 
-template <int EPB, bool CVX, bool BIG = false, int THREADS = (EPB <= 8 ? 256 : 512), int MINW = 1>
+template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     do_collide<EPB, CVX>(c, true);
 }
 
-template <int EPB, bool BIG = false, int THREADS = (EPB <= 8 ? 256 : 512), int MINW = 1>
+template <int EPB, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
@@ -1200,7 +1200,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
 // substeps x { clear_forces; collide; step; swap } with state and parameters resident in LDS across substeps.
 // Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
 // pointer swap); body_f of both states is zeroed as clear_forces would leave it.
-template <int EPB, bool CVX, bool BIG = false, int THREADS = (EPB <= 8 ? 256 : 512), int MINW = 1>
+template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);

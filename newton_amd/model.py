@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -303,6 +305,20 @@ def pack_param_arrays(model, t) -> dict:
     return new
 
 
+def params_uniform(packed: dict, env_count: int) -> int:
+    """1 when the body / joint / dof / shape parameter rows of `pack_param_arrays` are bit-identical in every environment
+    (replicated worlds without per-world randomisation): nt_model.params_uniform then lets the XPBD rollout keep one
+    block-shared copy in LDS instead of one per environment.  NT_PARAMS_UNIFORM=0 forces the per-environment tile (A/B)."""
+    if os.environ.get("NT_PARAMS_UNIFORM", "1") == "0":
+        return 0
+    for k in ("body_param", "joint_param", "dof_param", "shape_param"):
+        a = np.ascontiguousarray(packed[k], dtype=np.float32).view(np.int32)
+        a = a.reshape(-1, a.shape[-1])[:, :env_count]
+        if a.shape[1] > 1 and not np.array_equal(a, np.broadcast_to(a[:, :1], a.shape)):
+            return 0
+    return 1
+
+
 def choose_contact_scratch(lib, desc) -> None:
     """Pair-heavy scenes: when the per-contact solver records do not fit the CU's LDS even with one environment per
     workgroup, keep them in HBM (nt_model.contact_scratch_in_hbm; Contacts then allocates nt_contacts.cw)."""
@@ -361,6 +377,7 @@ class DeviceModel:
             setattr(d, k, v.data_ptr())
         for k, v in self.mesh_tables.items():
             setattr(d, k, v.data_ptr())
+        d.params_uniform = self._params_uniform
         choose_contact_scratch(self.lib, d)
         self.desc = d
         # environments per workgroup the collide / XPBD / SemiImplicit kernels will use (0: the working set of one
@@ -412,6 +429,9 @@ class DeviceModel:
         torch = _torch()
         self.refresh_flags(model)
         new = pack_param_arrays(model, self.t)
+        self._params_uniform = params_uniform(new, self.t.env_count)
+        if getattr(self, "desc", None) is not None:
+            self.desc.params_uniform = self._params_uniform
         for k, v in new.items():
             if v.size == 0:
                 v = np.zeros(1, dtype=np.float32)

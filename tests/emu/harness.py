@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 from newton_amd import _lib as L  # noqa: E402  (struct layouts + signatures only; the product library is NOT loaded)
-from newton_amd.model import choose_contact_scratch, pack_param_arrays  # noqa: E402
+from newton_amd.model import choose_contact_scratch, pack_param_arrays, params_uniform  # noqa: E402
 
 _emu = None
 
@@ -68,7 +68,9 @@ class EmuModel:
         for k in self.TOPOLOGY:
             self.keep[k] = i32(getattr(t, k))
         self.keep["mesh_points"], self.keep["shape_mesh_bounds"] = f32(t.mesh_points), f32(t.shape_mesh_bounds)
-        for k, v in pack_param_arrays(model, t).items():
+        packed = pack_param_arrays(model, t)
+        d.params_uniform = params_uniform(packed, t.env_count)
+        for k, v in packed.items():
             self.keep[k] = f32(v)
         for k, v in self.keep.items():
             setattr(d, k, _ptr(v))

@@ -1,0 +1,70 @@
+"""Uniform-parameter tile of the fused XPBD rollout (nt_model.params_uniform; one block-shared parameter copy per workgroup,
+SURVEY.md section 8 row (a)1-3 / DESIGN.md "uniform tile"): emulated kernels, bitwise against the per-environment tile, plus the
+host-side detection.  The GPU twin lives in tests/test_zx_round2_gpu.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+
+@pytest.fixture(scope="module")
+def H():
+    import harness
+
+    harness.lib()
+    return harness
+
+
+def _rollout(H, model, cfg, substeps=6, uniform=None):
+    em = H.EmuModel(model)
+    if uniform is not None:
+        em.desc.params_uniform = uniform
+    a, b, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+    ctrl.joint_f[:] = 0.3  # exercise the control rows that stay per environment
+    old = os.environ.get("NT_XPBD_CFG")
+    try:
+        if cfg:
+            os.environ["NT_XPBD_CFG"] = cfg
+        else:
+            os.environ.pop("NT_XPBD_CFG", None)
+        H.xpbd_rollout(em, a, b, ctrl, ct, 1e-3, substeps, iterations=2)
+    finally:
+        if old is None:
+            os.environ.pop("NT_XPBD_CFG", None)
+        else:
+            os.environ["NT_XPBD_CFG"] = old
+    out = a if substeps % 2 == 0 else b
+    return em, out.body_q.copy(), out.body_qd.copy(), ct.data.copy(), ct.shape0.copy()
+
+
+@pytest.mark.parametrize("cfg", ["16,256,2,1", "32,512,1,1", "8,128,4,1"])
+def test_uniform_tile_is_bitwise_the_per_environment_tile(H, cfg):
+    from scenes import quadruped_scene
+
+    model = quadruped_scene(40, seed=5)  # 40 envs: ragged last tile for every shape; seed: per-env STATE jitter, same parameters
+    em, q0, qd0, cd0, s0 = _rollout(H, model, "16,512,1,0")
+    assert em.desc.params_uniform == 1
+    _, q1, qd1, cd1, s1 = _rollout(H, model, cfg)
+    assert np.array_equal(q0.view(np.int32), q1.view(np.int32)) and np.array_equal(qd0.view(np.int32), qd1.view(np.int32))
+    assert np.array_equal(s0, s1) and np.array_equal(cd0.view(np.int32), cd1.view(np.int32))
+    assert np.abs(qd0).max() > 0.0
+
+
+def test_randomised_worlds_are_detected_and_refused_by_the_uniform_tile(H):
+    from scenes import quadruped_scene
+
+    from newton_amd import _lib
+
+    model = quadruped_scene(8, seed=5)
+    model.body_mass = np.array(model.body_mass, copy=True)
+    model.body_mass[13 * 3 + 2] *= 1.25  # one link of world 3
+    model.body_inv_mass = np.where(model.body_mass > 0, 1.0 / np.maximum(model.body_mass, 1e-30), 0.0).astype(np.float32)
+    em = H.EmuModel(model)
+    assert em.desc.params_uniform == 0
+    with pytest.raises(Exception):
+        _rollout(H, model, "16,256,2,1")  # NT_ERR_UNSUPPORTED: the shape is only valid for uniform models
+    _rollout(H, model, None)  # the default dispatch takes the per-environment tile

@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B of the launch shapes of the analytic fused XPBD rollout (NT_XPBD_CFG = envs per workgroup, workgroup size, min waves per
-# SIMD) on the headline workload; prints env-steps/s and kernel ms per shape.  usage: tools/xpbd_shape_ab.sh [envs] [shapes...]
+# SIMD, uniform-parameter tile) on the headline workload; prints env-steps/s and kernel ms per shape.  usage: tools/xpbd_shape_ab.sh [envs] [shapes...]
 ENVS=${1:-4096}; shift
-SHAPES=${@:-"16,512,1 16,512,4 16,1024,4 8,256,2 8,256,4 8,512,2 8,512,4 4,256,2 4,256,4 4,128,4 4,128,8"}
+SHAPES=${@:-"16,512,1,0 16,256,1,0 8,256,2,0 16,256,2,1 16,512,2,1 16,512,4,1 32,512,1,1 8,128,4,1 8,256,4,1"}
 STEPS=$(( 4096 * 300 / ENVS )); [ $STEPS -lt 20 ] && STEPS=20
 for s in $SHAPES; do
   echo -n "shape=$s envs=$ENVS "
