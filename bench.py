@@ -226,6 +226,15 @@ def run(args, rank, local_rank, world, dist):
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     epb = int(model.device_model().envs_per_block) if W["solver"] != "featherstone" else 4
     kernel = W["kernel"].replace("<16,", f"<{epb},") if W["solver"] != "featherstone" else W["kernel"]
+    if W["solver"] == "xpbd":  # the launch shape the library really dispatches for this model (name as profilers print it)
+        import ctypes as C
+        from newton_amd import _lib
+        dm, shape = model.device_model(), (C.c_int32 * 5)()
+        p_ = solver._params()
+        _lib.check(dm.lib.nt_xpbd_rollout_shape(C.byref(dm.desc), C.byref(p_), None, shape), "nt_xpbd_rollout_shape")
+        b = lambda x: "true" if x else "false"  # noqa: E731
+        kernel = (f"xpbd_rollout_kernel<{shape[0] + 256 * shape[3]}, {b(shape[4] & 1)}, {b(shape[4] & 2)}, {shape[1]}, "
+                  f"{shape[2]}>")
     roof = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms,

@@ -211,6 +211,10 @@ nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_param
  * exactly like the reference loop's pointer swap. */
 nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, nt_state* s0,
                           nt_state* s1, const nt_control* ctrl, nt_contacts* c, float dt, int32_t substeps, void* stream);
+/* The launch shape nt_xpbd_rollout would take for this model: out = {environments per workgroup, workgroup size, minimum
+ * waves per SIMD, uniform-parameter tile (nt_model.params_uniform), bit 0 convex code present | bit 1 pair-heavy tile};
+ * the kernel is xpbd_rollout_kernel<out[0] + 256 * out[3], convex, pair-heavy, out[1], out[2]> (profilers print that name) */
+nt_status nt_xpbd_rollout_shape(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, int32_t out[5]);
 
 /* -------- boundary helpers -------- */
 nt_status nt_eval_fk(const nt_model* m, const float* joint_q /*[nc][ES]*/, const float* joint_qd /*[nd][ES]*/,

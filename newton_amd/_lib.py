@@ -138,6 +138,8 @@ SYMBOLS = {
                                              C.POINTER(nt_state), C.POINTER(nt_state), C.POINTER(nt_control),
                                              C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),
     "nt_featherstone_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
+    "nt_xpbd_rollout_shape": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_xpbd_params), C.POINTER(nt_collide_params),
+                              C.POINTER(C.c_int32)]),
     "nt_xpbd_rollout": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_xpbd_params), C.POINTER(nt_collide_params),
                                      C.POINTER(nt_state), C.POINTER(nt_state), C.POINTER(nt_control),
                                      C.POINTER(nt_contacts), C.c_float, C.c_int32, _P]),

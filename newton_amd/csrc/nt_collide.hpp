@@ -260,7 +260,7 @@ NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
                 // polygon scratch: 20 rows per convex pair in the part of the scratch union that the collide phases do not
                 // use (behind shape transforms / AABBs / pair counts)
                 PolyRef poly;
-                poly.base = &c.lds[(c.L.pc + m.np + 20 * (c.big ? c.slot : p - m.np_analytic)) * Ctx<EPB>::N + c.e];
+                poly.base = &c.lds[(c.L.poly + 20 * (c.big ? c.slot : p - m.np_analytic)) * Ctx<EPB>::N + c.e];
                 poly.stride = Ctx<EPB>::N;
                 convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
@@ -404,7 +404,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                                         vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)));
                 }
                 PolyRef poly;  // manifold polygon scratch: per convex pair, or (pair-heavy tile) per lane
-                poly.base = &c.lds[(c.L.pc + m.np + 20 * (c.big ? c.slot : p - m.np_analytic)) * Ctx<EPB>::N + c.e];
+                poly.base = &c.lds[(c.L.poly + 20 * (c.big ? c.slot : p - m.np_analytic)) * Ctx<EPB>::N + c.e];
                 poly.stride = Ctx<EPB>::N;
                 convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
@@ -536,11 +536,11 @@ NT_DI void prefix_lane(const Ctx<EPB>& c, int lane, int partial, bool store_env_
         for (int s = 0; s < lane; ++s) acc += (int)c.lds[(partial + s) * Ctx<EPB>::N + c.e];
     }
     for (int p = lane * chunk; p < np && p < (lane + 1) * chunk; ++p) {
-        c.lds[(c.L.px + p) * Ctx<EPB>::N + c.e] = (float)acc;
+        c.l(c.L.px, 0, 1, p) = (float)acc;
         acc += (int)c.l(c.L.pm, 0, np, p);
     }
     if (lane == lanes - 1) {  // the last chunk ends at np (chunks past np are empty, their running sum is the total too)
-        c.lds[(c.L.px + np) * Ctx<EPB>::N + c.e] = (float)acc;
+        c.l(c.L.px, 0, 1, np) = (float)acc;
         if (store_env_count) c.a.ct.env_count[c.env] = acc;  // per-env totals: an API-boundary output
     }
 }

@@ -51,10 +51,11 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
     F.P = o;
     F.H = F.P + 6 * m.nb * m.max_art_dofs;
     int solve = 6 * m.nb * m.max_art_dofs + m.nd * m.max_art_dofs;
-    int contacts = CW_FLOATS * m.np * m.cpp;
+    int contacts = NC_CW * m.np * m.cpp;
     // the fused rollout runs the collide phases on this union too (shape transforms / AABBs, pair counts, manifold polygon
     // scratch, staged candidates)
-    int coll = 13 * m.ns + m.np + 20 * (m.np - m.np_analytic) + 19 * m.np;
+    LdsLayout tmp = L;
+    int coll = place_collide_scratch(tmp, m, F.cw, false);
     o += imax(imax(solve, contacts), coll);
     F.rows = o;
     return F;
@@ -427,7 +428,7 @@ NT_DI void fs_motion_post_item(const FsCtx<EPB>& f, int j) {
     spatial v_s = f.sp6(f.F.vs, nb, child), a_s = f.sp6(f.F.as, nb, child);
     vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - f.v3(f.F.org, 0, nb, child);
     float mass = c.pl(c.L.bp, BP_MASS, nb, child);
-    vec3 gravity(c.lds[(c.L.grav + 0) * EPB + c.e], c.lds[(c.L.grav + 1) * EPB + c.e], c.lds[(c.L.grav + 2) * EPB + c.e]);
+    vec3 gravity = c.gravity();
     vec3 f_g = mass * gravity;
     spatial f_g_s(f_g, cross(x_com_s, f_g));
     mat66 I_s;
@@ -470,9 +471,10 @@ NT_DI void fs_body_force_item(const FsCtx<EPB>& f, int b, bool forces_are_zero) 
             int p = code >> 1, side = code & 1;
             for (int k = 0; k < cpp; ++k) {
                 int slot = p * cpp + k;
-                bool is_a = (side == 0) == (c.l(f.F.cw, 14, ncs, slot) != 0.0f);
-                if (c.l(f.F.cw, is_a ? 12 : 13, ncs, slot) != 0.0f) {
-                    vec3 ff = c.lv3(f.F.cw, is_a ? 0 : 6, ncs, slot), tt = c.lv3(f.F.cw, is_a ? 3 : 9, ncs, slot);
+                const Fld<NC_CW> rec{f.F.cw};  // written by the shared contact phase as slot-major 15-float records
+                bool is_a = (side == 0) == (c.l(rec, 14, ncs, slot) != 0.0f);
+                if (c.l(rec, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                    vec3 ff = c.lv3(rec, is_a ? 0 : 6, ncs, slot), tt = c.lv3(rec, is_a ? 3 : 9, ncs, slot);
                     if (is_a) { f0 -= ff; t0 -= tt; }
                     else { f0 += ff; t0 += tt; }
                 }
@@ -916,7 +918,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     }
     NT_TICK(11);
     // state_in.body_q is refreshed by the reference step (solver_featherstone.py:492-514): publish it when distinct
-    if (publish_fk && c.valid && a.s_in.body_q != a.s_out.body_q) unstage_rows(c, c.L.bq, a.s_in.body_q, 7 * nb);
+    if (publish_fk && c.valid && a.s_in.body_q != a.s_out.body_q) unstage_rows(c, c.L.bq, a.s_in.body_q, 7, nb);
     if (c.valid)
         for (int j = c.slot; j < nj; j += c.nslot) fs_to_internal_item(f, j);
     __syncthreads();
@@ -938,7 +940,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     // eval_body_contact on (body_q, body_qd_fk)
     if (a.has_contacts) {
         Ctx<EPB> cc = c;
-        cc.L.si_cw = F.cw;
+        cc.L.si_cw.off = F.cw;
         if (c.valid && !(skip & 4))
             for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) si_contact_item(cc, s);
         __syncthreads();
@@ -1058,10 +1060,7 @@ __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     __syncthreads();
     // the collide phases use the (dead at that point) P / H / contact-wrench union as their scratch
     Ctx<EPB> cc = c;
-    cc.L.sx = F.cw;
-    cc.L.sa = F.cw + 7 * m.ns;
-    cc.L.pc = F.cw + 13 * m.ns;
-    cc.L.st = cc.L.pc + m.np + 20 * (m.np - m.np_analytic);
+    place_collide_scratch(cc.L, m, F.cw, false);
     const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(cc, s == a.substeps - 1);

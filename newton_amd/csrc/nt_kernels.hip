@@ -414,6 +414,29 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     return NT_DISPATCH_EPB_CVX(xpbd_rollout_kernel, *m, a, epb, (hipStream_t)stream);
 }
 
+nt_status nt_xpbd_rollout_shape(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, int32_t out[5]) {
+    if (!model_ok(m) || !p || !out) return NT_ERR_INVALID_ARG;
+    const bool rest = p->enable_restitution != 0;
+    int epb = pick_epb(*m, cp ? cp->envs_per_block : 0, rest);
+    if (!epb) return NT_ERR_UNSUPPORTED;
+    const bool cvx = m->np_analytic < m->np, big = m->contact_scratch_in_hbm != 0;
+    XpbdCfg c = {epb, max_threads_for(epb), 1, 0};
+    if (big) c = {1, 256, 1, 0};
+    else if (!cvx) {
+        XpbdCfg o;
+        if (xpbd_cfg_override(o)) c = o;
+        else if (m->params_uniform && !rest && m->env_count >= 256 * NT_XPBD_UNI_DEFAULT.epb &&
+                 epb_fits(*m, NT_XPBD_UNI_DEFAULT.epb, rest, true) && (cp == nullptr || cp->envs_per_block == 0))
+            c = NT_XPBD_UNI_DEFAULT;
+        else if (epb == 4) c.epb = 8;
+    } else {
+        c.epb = epb >= 16 ? 16 : (epb >= 4 ? 8 : 1);
+        c.threads = max_threads_for(c.epb);
+    }
+    out[0] = c.epb; out[1] = c.threads; out[2] = c.minw; out[3] = c.uni; out[4] = (cvx ? 1 : 0) | (big ? 2 : 0);
+    return NT_OK;
+}
+
 nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params* p, nt_state* s_in, nt_state* s_out,
                                 const nt_control* ctrl, const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
     if (!model_ok(m) || !p || !s_in || !s_out || !ctrl) return NT_ERR_INVALID_ARG;

@@ -27,81 +27,107 @@ constexpr int CWX_ANG_A = 3, CWX_ANG_B = 6, CWX_FLAGS = 9;
 
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 
-// LDS layout, in float rows per environment (each row is EPB floats wide)
+// LDS layout, in float rows per environment (each row is EPB floats wide).
+// A field is SLOT-MAJOR with a compile-time, ODD stride: element (comp, s) of Fld<NC> sits in row off + s * NC + comp.
+//  * one address per (field, item): the components of an item are DS immediate offsets (comp * EPB * 4 bytes) instead of one
+//    integer multiply-add each (comp * n + s with a run-time n), and neighbouring components pair into ds_read2_b32;
+//  * conflict-free: a wavefront holds 64 / EPB consecutive slots of the same EPB environments, bank = (s * NC * EPB + e) mod 64,
+//    and s * NC mod (64 / EPB) is a permutation of the slots because NC is odd (even component counts are padded by one row).
+template <int NC>
+struct Fld {
+    int off;
+    static constexpr int nc = NC;
+};
+constexpr int odd_up(int n) { return n | 1; }
+constexpr int NC_JP = odd_up(NT_JOINT_PARAM_FLOATS), NC_DP = odd_up(NT_DOF_PARAM_FLOATS), NC_SP = odd_up(NT_SHAPE_PARAM_FLOATS),
+              NC_BP = odd_up(NT_BODY_PARAM_FLOATS), NC_CWX = odd_up(CWX_FLOATS), NC_CW = odd_up(CW_FLOATS);
 struct LdsLayout {
     // persistent
-    int bq, bqd;       // body_q [7][nb], body_qd [6][nb]
-    int bp;            // body params [23][nb] (inverse mass / inertia already "effective": zero for kinematic bodies)
-    int jp;            // joint params [14][nj]
-    int dp;            // dof params [10][nd]
-    int sp;            // shape params [19][ns]
-    int cf, ctq, ctqd; // control: joint_f [nd], joint_target_q [ntq], joint_target_qd [nd]
-    int grav;          // gravity [3]
-    int bd;            // body-derived [9][nb]: world COM (3) + world-frame inverse inertia R I^-1 R^T (xx xy xz yy yz zz)
-    int pm;            // live contacts per pair [np] (written by the collide phase, read by the fused solver phases)
-    int px;            // exclusive prefix of pm [np + 1]: live contact i of the env is (pair p, sub-contact i - px[p])
+    Fld<7> bq, bqd;    // body_q [nb][7], body_qd [nb][6 (+1)]  (adjacent: the restitution snapshot copies both at once)
+    Fld<NC_BP> bp;     // body params [nb][23] (inverse mass / inertia already "effective": zero for kinematic bodies)
+    Fld<NC_JP> jp;     // joint params [nj][14 (+1)]
+    Fld<NC_DP> dp;     // dof params [nd][11]
+    Fld<NC_SP> sp;     // shape params [ns][20 (+1)]
+    Fld<1> cf, ctq, ctqd;  // control: joint_f [nd], joint_target_q [ntq], joint_target_qd [nd]
+    Fld<3> grav;       // gravity [1][3]
+    Fld<9> bd;         // body-derived [nb][9]: world COM (3) + world-frame inverse inertia R I^-1 R^T (xx xy xz yy yz zz)
+    Fld<1> pm;         // live contacts per pair [np] (written by the collide phase, read by the fused solver phases)
+    Fld<1> px;         // exclusive prefix of pm [np + 1]: live contact i of the env is (pair p, sub-contact i - px[p])
     // scratch union
     int u;
-    int sx, sa, pc;    // collide: shape world xform [7][ns], aabb [6][ns], per-pair contact count [np]
-    int st;            // collide: admitted candidates of the analytic pairs [19][np] (normal, 4 x (center, dist)); staged tiles
-    int bf, jf;        // forces: body_f_tmp [6][nb], joint wrenches [12][nj]
-    int jl, ja;        // joints: linear-part corrections [12][nj], angular-part child terms [9][nj]
-    int cw;            // contacts: per-contact corrections [CW_FLOATS][np*cpp]
-    int si_bf, si_jf, si_cw;  // semi-implicit: body_f_tmp + joint wrenches + contact wrenches, all live together
-    int xi;            // XPBD restitution: pre-step body_q / body_qd [13][nb], behind the XPBD scratch (solver_xpbd.py:414-416)
+    Fld<7> sx, sa;     // collide: shape world xform [ns][7], aabb [ns][6 (+1)]
+    Fld<1> pc;         // collide: per-pair contact count [np]
+    int poly;          // collide: manifold polygon scratch, 20 rows per convex pair (or per lane: pair-heavy tile)
+    Fld<19> st;        // collide: admitted candidates of the analytic pairs [np][19] (normal, 4 x (center, dist)); staged tiles
+    Fld<7> bf;         // forces: body_f_tmp [nb][6 (+1)]
+    Fld<13> jf;        // forces: joint wrenches [nj][12 (+1)]
+    Fld<13> jl;        // joints: linear-part corrections [nj][12 (+1)]
+    Fld<9> ja;         // joints: angular-part child terms [nj][9]
+    Fld<NC_CWX> cw;    // contacts: XPBD per-contact corrections [np*cpp][10 (+1)]
+    Fld<NC_CW> cwr;    // the same rows as 15-float records (XPBD restitution pass)
+    Fld<7> si_bf; Fld<13> si_jf; Fld<NC_CW> si_cw;  // semi-implicit: body_f_tmp + joint wrenches + contact wrenches, all live together
+    Fld<7> xiq, xiqd;  // XPBD restitution: pre-step body_q / body_qd, behind the XPBD scratch (solver_xpbd.py:414-416)
     int rows_per_env;  // collide / XPBD kernels
     int uni_floats;    // uniform-parameter tiles: bp / jp / dp / sp index ONE block-shared copy of this many floats instead of rows
     int rows_semi;     // SolverSemiImplicit kernel (its wrench records share the scratch with body_f_tmp + joint wrenches)
 };
 
-constexpr int NT_BIG_SCENE_LANES = 256;
-constexpr int NT_MIN_SCRATCH_ROWS = 8;  // the live-contact prefix parks up to 8 partial sums in the scratch union  // workgroup size of the one-environment-per-workgroup tile
+constexpr int NT_BIG_SCENE_LANES = 256;  // workgroup size of the one-environment-per-workgroup tile
+constexpr int NT_MIN_SCRATCH_ROWS = 8;   // the live-contact prefix parks up to 8 partial sums in the scratch union
+
+// collide scratch at row `base`: shape transforms / AABBs, pair counts, manifold polygon scratch (+ staged candidates);
+// returns its size in rows.  SolverFeatherstone's fused rollout places the same block inside its own union
+__host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_model& m, const int base, const bool big) {
+    L.sx.off = base; L.sa.off = L.sx.off + 7 * m.ns; L.pc.off = L.sa.off + 7 * m.ns;
+    L.poly = L.pc.off + m.np;
+    // manifold polygon scratch: 20 rows per convex pair, or (pair-heavy scenes, one environment per workgroup) per lane
+    int coll = 14 * m.ns + m.np + 20 * (big ? NT_BIG_SCENE_LANES : (m.np - m.np_analytic));
+    L.st.off = base + coll;
+    if (!big) coll += 19 * m.np;
+    return coll;
+}
 
 // big: pair-heavy scenes (nt_model.contact_scratch_in_hbm).  Device code passes a compile-time constant so that the
 // default kernels carry no trace of the second mode.
 // restitution: SolverXPBD(enable_restitution=True) keeps the pre-step state and 15-float velocity records per contact slot
 // uni: nt_model.params_uniform models on a uniform-parameter tile -- the body / joint / dof / shape parameters are identical
 // in every environment, so the workgroup keeps ONE copy (block-shared, broadcast reads) and an environment's LDS footprint
-// drops from 1309 + 663 to 401 + 663 rows on the headline quadruped: two workgroups fit a CU instead of one
+// drops by 936 rows on the headline quadruped: 32 environments fit a CU instead of 16
 __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false,
                                                  const bool uni = false) {
     LdsLayout L;
     int o = 0, ou = 0;
-    L.bq = o; o += 7 * m.nb;
-    L.bqd = o; o += 6 * m.nb;
+    L.bq.off = o; o += 7 * m.nb;
+    L.bqd.off = o; o += 7 * m.nb;
     int& po = uni ? ou : o;
-    L.bp = po; po += NT_BODY_PARAM_FLOATS * m.nb;
-    L.jp = po; po += NT_JOINT_PARAM_FLOATS * m.nj;
-    L.dp = po; po += NT_DOF_PARAM_FLOATS * m.nd;
-    L.sp = po; po += NT_SHAPE_PARAM_FLOATS * m.ns;
+    L.bp.off = po; po += NC_BP * m.nb;
+    L.jp.off = po; po += NC_JP * m.nj;
+    L.dp.off = po; po += NC_DP * m.nd;
+    L.sp.off = po; po += NC_SP * m.ns;
     L.uni_floats = ou;
-    L.cf = o; o += m.nd;
-    L.ctq = o; o += m.ntq;
-    L.ctqd = o; o += m.nd;
-    L.grav = o; o += 3;
-    L.bd = o; o += 9 * m.nb;
-    L.pm = o; o += m.np;
-    L.px = o; o += m.np + 1;
+    L.cf.off = o; o += m.nd;
+    L.ctq.off = o; o += m.ntq;
+    L.ctqd.off = o; o += m.nd;
+    L.grav.off = o; o += 3;
+    L.bd.off = o; o += 9 * m.nb;
+    L.pm.off = o; o += m.np;
+    L.px.off = o; o += m.np + 1;
     L.u = o;
-    L.sx = L.u; L.sa = L.sx + 7 * m.ns; L.pc = L.sa + 6 * m.ns;
-    // + manifold polygon scratch: 20 rows per convex pair, or (pair-heavy scenes, one environment per workgroup) per lane
-    int coll = 13 * m.ns + m.np + 20 * (big ? NT_BIG_SCENE_LANES : (m.np - m.np_analytic));
-    L.st = L.u + coll;
-    if (!big) coll += 19 * m.np;
+    const int coll = place_collide_scratch(L, m, L.u, big);
     // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase
     // and the joint-force phase in the same barrier interval (different waves); the pair-heavy tile keeps the overlap
-    L.bf = big ? L.u : L.u + coll; L.jf = L.bf + 6 * m.nb;
-    int forces = (big ? 0 : coll) + 6 * m.nb + 12 * m.nj;
-    L.jl = L.u; L.ja = L.jl + 12 * m.nj;
-    int joints = 21 * m.nj;
-    L.cw = L.u;
+    L.bf.off = big ? L.u : L.u + coll; L.jf.off = L.bf.off + 7 * m.nb;
+    int forces = (big ? 0 : coll) + 7 * m.nb + 13 * m.nj;
+    L.jl.off = L.u; L.ja.off = L.jl.off + 13 * m.nj;
+    int joints = 22 * m.nj;
+    L.cw.off = L.u; L.cwr.off = L.u;
     // big: the records live in nt_contacts.cw (HBM)
-    int contacts = big ? 0 : (restitution ? CW_FLOATS : CWX_FLOATS) * m.np * m.cpp;
-    L.si_bf = L.u; L.si_jf = L.si_bf + 6 * m.nb; L.si_cw = L.si_jf + 12 * m.nj;
-    int semi = 6 * m.nb + 12 * m.nj + CW_FLOATS * m.np * m.cpp;
+    int contacts = big ? 0 : (restitution ? NC_CW : NC_CWX) * m.np * m.cpp;
+    L.si_bf.off = L.u; L.si_jf.off = L.si_bf.off + 7 * m.nb; L.si_cw.off = L.si_jf.off + 13 * m.nj;
+    int semi = 7 * m.nb + 13 * m.nj + NC_CW * m.np * m.cpp;
     int xpbd = imax(imax(imax(coll, forces), imax(joints, contacts)), NT_MIN_SCRATCH_ROWS);
-    L.xi = L.u + xpbd;
-    L.rows_per_env = L.u + xpbd + (restitution ? 13 * m.nb : 0);
+    L.xiq.off = L.u + xpbd; L.xiqd.off = L.xiq.off + 7 * m.nb;
+    L.rows_per_env = L.u + xpbd + (restitution ? 14 * m.nb : 0);
     L.rows_semi = L.u + semi;
     return L;
 }
@@ -210,27 +236,60 @@ struct Ctx {
         T.hit_list = ti + o + 1;
         up = reinterpret_cast<float*>(ti + topo_ints(m));
     }
-    // LDS element: row = field offset + comp * slots_in_field + slot
-    NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * N + e]; }
+    // LDS element (comp, s) of a slot-major field.  `n` (the slot count of the [comp][n] HBM twin) is not needed here; the
+    // argument stays so that every access reads like its global-memory counterpart g(comp, n, s)
+    template <int NC>
+    NT_DI float& l(Fld<NC> f, int comp, int /*n*/, int s) const { return lds[(f.off + s * NC + comp) * N + e]; }
     // parameter element (fields bp / jp / dp / sp): per-environment row, or the block-shared copy of a uniform tile
-    NT_DI float pl(int off, int comp, int n, int s) const {
-        if constexpr (UNI) return up[off + comp * n + s];
-        else return lds[(off + comp * n + s) * N + e];
+    template <int NC>
+    NT_DI float pl(Fld<NC> f, int comp, int /*n*/, int s) const {
+        if constexpr (UNI) return up[f.off + s * NC + comp];
+        else return lds[(f.off + s * NC + comp) * N + e];
     }
-    NT_DI vec3 plv3(int off, int comp0, int n, int s) const {
-        return vec3(pl(off, comp0, n, s), pl(off, comp0 + 1, n, s), pl(off, comp0 + 2, n, s));
+    template <int NC>
+    NT_DI vec3 plv3(Fld<NC> f, int comp0, int n, int s) const {
+        return vec3(pl(f, comp0, n, s), pl(f, comp0 + 1, n, s), pl(f, comp0 + 2, n, s));
     }
-    NT_DI xform plxf(int off, int comp0, int n, int s) const {
-        return xform(plv3(off, comp0, n, s),
-                     quat(pl(off, comp0 + 3, n, s), pl(off, comp0 + 4, n, s), pl(off, comp0 + 5, n, s), pl(off, comp0 + 6, n, s)));
+    template <int NC>
+    NT_DI xform plxf(Fld<NC> f, int comp0, int n, int s) const {
+        return xform(plv3(f, comp0, n, s),
+                     quat(pl(f, comp0 + 3, n, s), pl(f, comp0 + 4, n, s), pl(f, comp0 + 5, n, s), pl(f, comp0 + 6, n, s)));
     }
-    NT_DI mat33 plm33(int off, int comp0, int n, int s) const {
-        return mat33(pl(off, comp0, n, s), pl(off, comp0 + 1, n, s), pl(off, comp0 + 2, n, s), pl(off, comp0 + 3, n, s),
-                     pl(off, comp0 + 4, n, s), pl(off, comp0 + 5, n, s), pl(off, comp0 + 6, n, s), pl(off, comp0 + 7, n, s),
-                     pl(off, comp0 + 8, n, s));
+    template <int NC>
+    NT_DI mat33 plm33(Fld<NC> f, int comp0, int n, int s) const {
+        return mat33(pl(f, comp0, n, s), pl(f, comp0 + 1, n, s), pl(f, comp0 + 2, n, s), pl(f, comp0 + 3, n, s),
+                     pl(f, comp0 + 4, n, s), pl(f, comp0 + 5, n, s), pl(f, comp0 + 6, n, s), pl(f, comp0 + 7, n, s),
+                     pl(f, comp0 + 8, n, s));
     }
     NT_DI size_t g(int comp, int n, int s) const { return (size_t)(comp * n + s) * ES + env; }
 
+    template <int NC>
+    NT_DI vec3 lv3(Fld<NC> f, int comp0, int n, int s) const {
+        return vec3(l(f, comp0, n, s), l(f, comp0 + 1, n, s), l(f, comp0 + 2, n, s));
+    }
+    template <int NC>
+    NT_DI void st_lv3(Fld<NC> f, int comp0, int n, int s, vec3 v) const {
+        l(f, comp0, n, s) = v.x; l(f, comp0 + 1, n, s) = v.y; l(f, comp0 + 2, n, s) = v.z;
+    }
+    template <int NC>
+    NT_DI xform lxf(Fld<NC> f, int comp0, int n, int s) const {
+        return xform(lv3(f, comp0, n, s),
+                     quat(l(f, comp0 + 3, n, s), l(f, comp0 + 4, n, s), l(f, comp0 + 5, n, s), l(f, comp0 + 6, n, s)));
+    }
+    template <int NC>
+    NT_DI void st_lxf(Fld<NC> f, int n, int s, const xform& t) const {
+        l(f, 0, n, s) = t.p.x; l(f, 1, n, s) = t.p.y; l(f, 2, n, s) = t.p.z;
+        l(f, 3, n, s) = t.q.x; l(f, 4, n, s) = t.q.y; l(f, 5, n, s) = t.q.z; l(f, 6, n, s) = t.q.w;
+    }
+    template <int NC>
+    NT_DI mat33 lm33(Fld<NC> f, int comp0, int n, int s) const {
+        return mat33(l(f, comp0, n, s), l(f, comp0 + 1, n, s), l(f, comp0 + 2, n, s), l(f, comp0 + 3, n, s),
+                     l(f, comp0 + 4, n, s), l(f, comp0 + 5, n, s), l(f, comp0 + 6, n, s), l(f, comp0 + 7, n, s),
+                     l(f, comp0 + 8, n, s));
+    }
+    NT_DI vec3 gravity() const { return lv3(L.grav, 0, 1, 0); }
+    // component-major [comp][n] arrays at a plain row offset (a solver's own scratch, e.g. SolverFeatherstone's)
+    NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * N + e]; }
     NT_DI vec3 lv3(int off, int comp0, int n, int s) const {
         return vec3(l(off, comp0, n, s), l(off, comp0 + 1, n, s), l(off, comp0 + 2, n, s));
     }
@@ -244,11 +303,6 @@ struct Ctx {
     NT_DI void st_lxf(int off, int n, int s, const xform& t) const {
         l(off, 0, n, s) = t.p.x; l(off, 1, n, s) = t.p.y; l(off, 2, n, s) = t.p.z;
         l(off, 3, n, s) = t.q.x; l(off, 4, n, s) = t.q.y; l(off, 5, n, s) = t.q.z; l(off, 6, n, s) = t.q.w;
-    }
-    NT_DI mat33 lm33(int off, int comp0, int n, int s) const {
-        return mat33(l(off, comp0, n, s), l(off, comp0 + 1, n, s), l(off, comp0 + 2, n, s), l(off, comp0 + 3, n, s),
-                     l(off, comp0 + 4, n, s), l(off, comp0 + 5, n, s), l(off, comp0 + 6, n, s), l(off, comp0 + 7, n, s),
-                     l(off, comp0 + 8, n, s));
     }
     NT_DI vec3 gv3(const float* base, int comp0, int n, int s) const {
         return vec3(base[g(comp0, n, s)], base[g(comp0 + 1, n, s)], base[g(comp0 + 2, n, s)]);
@@ -314,6 +368,18 @@ struct Ctx {
 // ------------------------------------------------------------------------------------------------
 // HBM <-> LDS staging
 // ------------------------------------------------------------------------------------------------
+// field [ncomp][n][ES] in HBM <-> slot-major rows in LDS
+template <int EPB, int NC>
+NT_DI void stage_rows(const Ctx<EPB>& c, Fld<NC> f, const float* src, int ncomp, int n) {
+    for (int comp = 0; comp < ncomp; ++comp)
+        for (int s = c.slot; s < n; s += c.nslot) c.l(f, comp, n, s) = src[c.g(comp, n, s)];
+}
+template <int EPB, int NC>
+NT_DI void unstage_rows(const Ctx<EPB>& c, Fld<NC> f, float* dst, int ncomp, int n) {
+    for (int comp = 0; comp < ncomp; ++comp)
+        for (int s = c.slot; s < n; s += c.nslot) dst[c.g(comp, n, s)] = c.l(f, comp, n, s);
+}
+// plain rows (a solver's own [row] arrays)
 template <int EPB>
 NT_DI void stage_rows(const Ctx<EPB>& c, int lds_off, const float* src, int rows) {
     for (int r = c.slot; r < rows; r += c.nslot) c.lds[(lds_off + r) * Ctx<EPB>::N + c.e] = src[(size_t)r * c.ES + c.env];
@@ -326,52 +392,59 @@ NT_DI void unstage_rows(const Ctx<EPB>& c, int lds_off, float* dst, int rows) {
 template <int EPB>
 NT_DI void load_state(const Ctx<EPB>& c, const nt_state& s) {
     if (!c.valid) return;
-    stage_rows(c, c.L.bq, s.body_q, 7 * c.a.m.nb);
-    stage_rows(c, c.L.bqd, s.body_qd, 6 * c.a.m.nb);
+    stage_rows(c, c.L.bq, s.body_q, 7, c.a.m.nb);
+    stage_rows(c, c.L.bqd, s.body_qd, 6, c.a.m.nb);
 }
 template <int EPB>
 NT_DI void store_state(const Ctx<EPB>& c, const nt_state& s) {
     if (!c.valid) return;
-    unstage_rows(c, c.L.bq, s.body_q, 7 * c.a.m.nb);
-    unstage_rows(c, c.L.bqd, s.body_qd, 6 * c.a.m.nb);
+    unstage_rows(c, c.L.bq, s.body_q, 7, c.a.m.nb);
+    unstage_rows(c, c.L.bqd, s.body_qd, 6, c.a.m.nb);
 }
 // parameters and controls: read once per kernel
 template <int EPB>
 NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
     const nt_model& m = c.a.m;
     const int nb = m.nb;
+    // body params carry the effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
+    auto body_value = [&](int comp, int b, size_t col) {
+        float v = m.body_param[(size_t)(comp * nb + b) * c.ES + col];
+        bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
+        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
+        return v;
+    };
     if constexpr (Ctx<EPB>::UNI) {
         // one copy per workgroup, read from the tile's first environment (the host vouches that all columns are equal)
         const size_t col = (size_t)blockIdx.x * Ctx<EPB>::N;
         for (int r = threadIdx.x; r < NT_BODY_PARAM_FLOATS * nb; r += blockDim.x) {
             int comp = r / nb, b = r - comp * nb;
-            float v = m.body_param[(size_t)r * c.ES + col];
-            bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
-            if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;
-            c.up[c.L.bp + r] = v;
+            c.up[c.L.bp.off + b * NC_BP + comp] = body_value(comp, b, col);
         }
-        for (int r = threadIdx.x; r < NT_JOINT_PARAM_FLOATS * m.nj; r += blockDim.x) c.up[c.L.jp + r] = m.joint_param[(size_t)r * c.ES + col];
-        for (int r = threadIdx.x; r < NT_DOF_PARAM_FLOATS * m.nd; r += blockDim.x) c.up[c.L.dp + r] = m.dof_param[(size_t)r * c.ES + col];
-        for (int r = threadIdx.x; r < NT_SHAPE_PARAM_FLOATS * m.ns; r += blockDim.x) c.up[c.L.sp + r] = m.shape_param[(size_t)r * c.ES + col];
+        for (int r = threadIdx.x; r < NT_JOINT_PARAM_FLOATS * m.nj; r += blockDim.x) {
+            int comp = r / m.nj, j = r - comp * m.nj;
+            c.up[c.L.jp.off + j * NC_JP + comp] = m.joint_param[(size_t)r * c.ES + col];
+        }
+        for (int r = threadIdx.x; r < NT_DOF_PARAM_FLOATS * m.nd; r += blockDim.x) {
+            int comp = r / m.nd, d = r - comp * m.nd;
+            c.up[c.L.dp.off + d * NC_DP + comp] = m.dof_param[(size_t)r * c.ES + col];
+        }
+        for (int r = threadIdx.x; r < NT_SHAPE_PARAM_FLOATS * m.ns; r += blockDim.x) {
+            int comp = r / m.ns, sh = r - comp * m.ns;
+            c.up[c.L.sp.off + sh * NC_SP + comp] = m.shape_param[(size_t)r * c.ES + col];
+        }
     }
     if (!c.valid) return;
     if constexpr (!Ctx<EPB>::UNI) {
-        // body params, with effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
-        for (int r = c.slot; r < NT_BODY_PARAM_FLOATS * nb; r += c.nslot) {
-            int comp = r / nb, b = r - comp * nb;
-            float v = m.body_param[(size_t)r * c.ES + c.env];
-            bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
-            if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
-            c.lds[(c.L.bp + r) * Ctx<EPB>::N + c.e] = v;
-        }
-        stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS * m.nj);
-        stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS * m.nd);
-        stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS * m.ns);
+        for (int comp = 0; comp < NT_BODY_PARAM_FLOATS; ++comp)
+            for (int b = c.slot; b < nb; b += c.nslot) c.lds[(c.L.bp.off + b * NC_BP + comp) * Ctx<EPB>::N + c.e] = body_value(comp, b, c.env);
+        stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS, m.nj);
+        stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS, m.nd);
+        stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS, m.ns);
     }
-    stage_rows(c, c.L.grav, m.gravity, 3);
+    stage_rows(c, c.L.grav, m.gravity, 3, 1);
     if (with_control) {
-        stage_rows(c, c.L.cf, c.a.c.joint_f, m.nd);
-        stage_rows(c, c.L.ctq, c.a.c.joint_target_q, m.ntq);
-        stage_rows(c, c.L.ctqd, c.a.c.joint_target_qd, m.nd);
+        stage_rows(c, c.L.cf, c.a.c.joint_f, 1, m.nd);
+        stage_rows(c, c.L.ctq, c.a.c.joint_target_q, 1, m.ntq);
+        stage_rows(c, c.L.ctqd, c.a.c.joint_target_qd, 1, m.nd);
     }
 }

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kerne
     __syncthreads();
     if (c.valid) {
         const nt_model& m = a.m;
-        for (int r = c.slot; r < 6 * m.nb; r += c.nslot) c.lds[(c.L.bf + r) * EPB + c.e] = a.s_in.body_f[(size_t)r * c.ES + c.env];
+        stage_rows(c, c.L.bf, a.s_in.body_f, 6, m.nb);
         // joints and contacts are independent force evaluations on the input state: one phase
         const int ncs = a.has_contacts ? m.np * m.cpp : 0;
         const int spw = 64 / EPB > 0 ? 64 / EPB : 1;  // contact items start on a wave boundary (no mixed-path wave)

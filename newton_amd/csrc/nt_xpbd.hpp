@@ -12,8 +12,12 @@ NT_DI void joint_force_item(const Ctx<EPB>& c, const int j);
 template <int EPB>
 NT_DI void seed_body_forces(const Ctx<EPB>& c, bool forces_are_zero) {
     // body threads seed body_f_tmp with state_in.body_f (solver_xpbd.py:423: wp.clone)
-    for (int r = c.slot; r < 6 * c.a.m.nb; r += c.nslot)
-        c.lds[(c.L.bf + r) * Ctx<EPB>::N + c.e] = forces_are_zero ? 0.0f : c.a.s_in.body_f[(size_t)r * c.ES + c.env];
+    const int nb = c.a.m.nb;
+    if (forces_are_zero) {  // (rows, not elements: the pad row is cleared with the rest)
+        for (int r = c.slot; r < 7 * nb; r += c.nslot) c.lds[(c.L.bf.off + r) * Ctx<EPB>::N + c.e] = 0.0f;
+    } else {
+        stage_rows(c, c.L.bf, c.a.s_in.body_f, 6, nb);
+    }
 }
 template <int EPB>
 NT_DI void phase_joint_forces(const Ctx<EPB>& c, bool forces_are_zero) {
@@ -117,7 +121,7 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     mat33 inertia = c.inertia(b);
     mat33 inv_inertia = c.inv_inertia(b);
     vec3 com = c.com(b);
-    vec3 gravity(c.lds[(c.L.grav + 0) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 1) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 2) * Ctx<EPB>::N + c.e]);
+    vec3 gravity = c.gravity();
     const float dt = c.a.dt;
 
     vec3 x0 = q.p;
@@ -195,23 +199,25 @@ NT_DI float angular_correction(float err, float derr, float wq_a, float wq_b, fl
 // where the per-contact correction records (CW_FLOATS rows per contact slot) live: in LDS (default), or -- for pair-heavy
 // scenes whose records do not fit the CU's LDS (nt_model.contact_scratch_in_hbm) -- in nt_contacts.cw, env-major in HBM
 // ------------------------------------------------------------------------------------------------
+// NC: record stride of the LDS copy (NC_CWX for the position solve, NC_CW for the restitution pass)
 struct CwLds {
-    template <int EPB>
-    static NT_DI float& at(const Ctx<EPB>& c, int comp, int ncs, int slot) { return c.l(c.L.cw, comp, ncs, slot); }
+    template <int NC, int EPB>
+    static NT_DI float& at(const Ctx<EPB>& c, int comp, int ncs, int slot) { return c.l(Fld<NC>{c.L.cw.off}, comp, ncs, slot); }
 };
 struct CwHbm {
-    template <int EPB>
+    template <int NC, int EPB>
     static NT_DI float& at(const Ctx<EPB>& c, int comp, int ncs, int slot) { return c.a.ct.cw[c.g(comp, ncs, slot)]; }
 };
-template <class CW, int EPB>
+template <class CW, int NC, int EPB>
 NT_DI vec3 cw_v3(const Ctx<EPB>& c, int comp, int ncs, int slot) {
-    return vec3(CW::at(c, comp, ncs, slot), CW::at(c, comp + 1, ncs, slot), CW::at(c, comp + 2, ncs, slot));
+    return vec3(CW::template at<NC>(c, comp, ncs, slot), CW::template at<NC>(c, comp + 1, ncs, slot),
+                CW::template at<NC>(c, comp + 2, ncs, slot));
 }
-template <class CW, int EPB>
+template <class CW, int NC, int EPB>
 NT_DI void cw_st3(const Ctx<EPB>& c, int comp, int ncs, int slot, vec3 v) {
-    CW::at(c, comp, ncs, slot) = v.x;
-    CW::at(c, comp + 1, ncs, slot) = v.y;
-    CW::at(c, comp + 2, ncs, slot) = v.z;
+    CW::template at<NC>(c, comp, ncs, slot) = v.x;
+    CW::template at<NC>(c, comp + 1, ncs, slot) = v.y;
+    CW::template at<NC>(c, comp + 2, ncs, slot) = v.z;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -370,17 +376,17 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
         }
     }
     // lin_delta_b == -lin_delta_a bit for bit (IEEE negation commutes with every rounding above), so only one is stored
-    cw_st3<CW>(c, 0, ncs, slot, lin_delta_a);
-    cw_st3<CW>(c, CWX_ANG_A, ncs, slot, ang_delta_a);
-    cw_st3<CW>(c, CWX_ANG_B, ncs, slot, ang_delta_b);
-    CW::at(c, CWX_FLAGS, ncs, slot) = has_a + 2.0f * has_b + 4.0f * a_is_pair_a;
+    cw_st3<CW, NC_CWX>(c, 0, ncs, slot, lin_delta_a);
+    cw_st3<CW, NC_CWX>(c, CWX_ANG_A, ncs, slot, ang_delta_a);
+    cw_st3<CW, NC_CWX>(c, CWX_ANG_B, ncs, slot, ang_delta_b);
+    CW::template at<NC_CWX>(c, CWX_FLAGS, ncs, slot) = has_a + 2.0f * has_b + 4.0f * a_is_pair_a;
 }
 // flags of an XPBD correction record: does it touch the body on `side` of its pair (0: owner of pair_a's shape), and as
 // the contact's shape0 ("a") or shape1?
 struct CwxSide { bool has, is_a; };
 template <class CW, int EPB>
 NT_DI CwxSide cwx_side(const Ctx<EPB>& c, int ncs, int slot, int side) {
-    const int f = (int)CW::at(c, CWX_FLAGS, ncs, slot);
+    const int f = (int)CW::template at<NC_CWX>(c, CWX_FLAGS, ncs, slot);
     CwxSide r;
     r.is_a = (side == 0) == ((f & 4) != 0);  // this body is the contact's "a" iff (side == 0) == (shape0 is pair_a's shape)
     r.has = (f & (r.is_a ? 1 : 2)) != 0;
@@ -393,15 +399,15 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
     if constexpr (FUSED) {
         // lane i takes the environment's i-th live contact (L.px: exclusive prefix of the per-pair live counts); records
         // of dead slots are never written and never read (apply_item stops at the pair's live count)
-        const int total = (int)c.lds[(c.L.px + np) * Ctx<EPB>::N + c.e];
+        const int total = (int)c.l(c.L.px, 0, 1, np);
         for (int i = c.tslot; i < total; i += c.nslot) {
             int lo = 0, hi = np;  // the last pair whose prefix is <= i
             while (hi - lo > 1) {
                 int mid = (lo + hi) >> 1;
-                if ((int)c.lds[(c.L.px + mid) * Ctx<EPB>::N + c.e] <= i) lo = mid;
+                if ((int)c.l(c.L.px, 0, 1, mid) <= i) lo = mid;
                 else hi = mid;
             }
-            contact_item<EPB, FUSED, CW>(c, lo * cpp + (i - (int)c.lds[(c.L.px + lo) * Ctx<EPB>::N + c.e]));
+            contact_item<EPB, FUSED, CW>(c, lo * cpp + (i - (int)c.l(c.L.px, 0, 1, lo)));
         }
     } else {
         for (int s = c.slot; s < np * cpp; s += c.nslot) contact_item<EPB, FUSED, CW>(c, s);
@@ -431,9 +437,9 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
                 int slot = p * cpp + k;
                 const CwxSide sd = cwx_side<CW>(c, ncs, slot, side);
                 if (sd.has) {
-                    vec3 lin = cw_v3<CW>(c, 0, ncs, slot);
+                    vec3 lin = cw_v3<CW, NC_CWX>(c, 0, ncs, slot);
                     dlin += sd.is_a ? lin : -lin;
-                    dang += cw_v3<CW>(c, sd.is_a ? CWX_ANG_A : CWX_ANG_B, ncs, slot);
+                    dang += cw_v3<CW, NC_CWX>(c, sd.is_a ? CWX_ANG_A : CWX_ANG_B, ncs, slot);
                     inv_weight += 1.0f;
                 }
             }
@@ -792,8 +798,8 @@ NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
             mat33 I_inv_a, I_inv_b;
             xform X_a_prev, X_b_prev;
             vec3 com_a(0.0f), com_b(0.0f);
-            auto prev_q = [&](int b) { return c.lxf(c.L.xi, 0, nb, b); };
-            auto prev_qd = [&](int b) { return spatial(c.lv3(c.L.xi, 7, nb, b), c.lv3(c.L.xi, 10, nb, b)); };
+            auto prev_q = [&](int b) { return c.lxf(c.L.xiq, 0, nb, b); };
+            auto prev_qd = [&](int b) { return spatial(c.lv3(c.L.xiqd, 0, nb, b), c.lv3(c.L.xiqd, 3, nb, b)); };
             if (body_a >= 0) {
                 X_a_prev = prev_q(body_a);
                 m_inv_a = c.inv_mass(body_a);
@@ -813,7 +819,7 @@ NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
             if (d < 0.0f) {
                 vec3 r_a = bx_a - xform_point(X_a_prev, com_a);
                 vec3 r_b = bx_b - xform_point(X_b_prev, com_b);
-                vec3 gravity(c.lds[(c.L.grav + 0) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 1) * Ctx<EPB>::N + c.e], c.lds[(c.L.grav + 2) * Ctx<EPB>::N + c.e]);
+                vec3 gravity = c.gravity();
                 vec3 rxn_a(0.0f), rxn_b(0.0f), v_a(0.0f), v_b(0.0f), v_a_new(0.0f), v_b_new(0.0f);
                 float inv_mass = 0.0f;
                 if (body_a >= 0) {
@@ -848,13 +854,13 @@ NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
             }
         }
     }
-    cw_st3<CW>(c, 0, ncs, slot, lin_a);
-    cw_st3<CW>(c, 3, ncs, slot, ang_a);
-    cw_st3<CW>(c, 6, ncs, slot, lin_b);
-    cw_st3<CW>(c, 9, ncs, slot, ang_b);
-    CW::at(c, 12, ncs, slot) = has_a;
-    CW::at(c, 13, ncs, slot) = has_b;
-    CW::at(c, 14, ncs, slot) = a_is_pair_a;
+    cw_st3<CW, NC_CW>(c, 0, ncs, slot, lin_a);
+    cw_st3<CW, NC_CW>(c, 3, ncs, slot, ang_a);
+    cw_st3<CW, NC_CW>(c, 6, ncs, slot, lin_b);
+    cw_st3<CW, NC_CW>(c, 9, ncs, slot, ang_b);
+    CW::template at<NC_CW>(c, 12, ncs, slot) = has_a;
+    CW::template at<NC_CW>(c, 13, ncs, slot) = has_b;
+    CW::template at<NC_CW>(c, 14, ncs, slot) = a_is_pair_a;
 }
 // apply_body_delta_velocities (xpbd/kernels.py:936-942): body lane sums its contacts' velocity deltas in contact order
 template <int EPB, class CW = CwLds>
@@ -867,10 +873,10 @@ NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
         int p = code >> 1, side = code & 1;
         for (int k = 0; k < cpp; ++k) {
             int slot = p * cpp + k;
-            bool is_a = (side == 0) == (CW::at(c, 14, ncs, slot) != 0.0f);
-            if (CW::at(c, is_a ? 12 : 13, ncs, slot) != 0.0f) {
-                dv += cw_v3<CW>(c, is_a ? 0 : 6, ncs, slot);
-                dw += cw_v3<CW>(c, is_a ? 3 : 9, ncs, slot);
+            bool is_a = (side == 0) == (CW::template at<NC_CW>(c, 14, ncs, slot) != 0.0f);
+            if (CW::template at<NC_CW>(c, is_a ? 12 : 13, ncs, slot) != 0.0f) {
+                dv += cw_v3<CW, NC_CW>(c, is_a ? 0 : 6, ncs, slot);
+                dw += cw_v3<CW, NC_CW>(c, is_a ? 3 : 9, ncs, slot);
             }
         }
     }
@@ -960,7 +966,7 @@ NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
     const int cpp = m.cpp, ncs = m.np * cpp;
     float* I = c.a.rep.contact_impulse;
     for (int slot = c.slot; slot < ncs; slot += c.nslot) {
-        const int flags = (int)CW::at(c, CWX_FLAGS, ncs, slot);
+        const int flags = (int)CW::template at<NC_CWX>(c, CWX_FLAGS, ncs, slot);
         float has_a = (flags & 1) ? 1.0f : 0.0f, has_b = (flags & 2) ? 1.0f : 0.0f;
         vec3 lin, ang;
         if (has_a != 0.0f || has_b != 0.0f) {
@@ -979,8 +985,8 @@ NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
                     else weight = 2.0f / n_sum;
                 }
             }
-            lin = cw_v3<CW>(c, 0, ncs, slot) * weight;
-            ang = cw_v3<CW>(c, CWX_ANG_A, ncs, slot) * weight;
+            lin = cw_v3<CW, NC_CWX>(c, 0, ncs, slot) * weight;
+            ang = cw_v3<CW, NC_CWX>(c, CWX_ANG_A, ncs, slot) * weight;
         }
         if (first) {
             I[c.g(0, ncs, slot)] = lin.x; I[c.g(1, ncs, slot)] = lin.y; I[c.g(2, ncs, slot)] = lin.z;
@@ -1048,10 +1054,10 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
     // the shape-transform rows of the collide scratch, dead once the pairs are done
     const bool one_level = c.a.m.np <= 64;
     if (!one_level) {
-        phase_pair_prefix_partials(c, c.L.sx);
+        phase_pair_prefix_partials(c, c.L.sx.off);
         __syncthreads();
     }
-    phase_pair_prefix_scan(c, c.L.sx, count_contacts, one_level);
+    phase_pair_prefix_scan(c, c.L.sx.off, count_contacts, one_level);
     __syncthreads();
 }
 
@@ -1063,7 +1069,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const int skip = c.a.debug_skip;
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
     if (!PROLOGUE_DONE && restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
-        for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq + r) * Ctx<EPB>::N + c.e];
+        for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
     const bool rep_joints = !FUSED && c.a.rep.joint_impulse != nullptr;
     const bool rep_contacts = !FUSED && c.a.rep.contact_impulse != nullptr && c.a.has_contacts;
     if (!PROLOGUE_DONE && !(skip & 2)) {
@@ -1128,7 +1134,7 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
     if (c.valid) {
         if (restitution)
-            for (int r = c.slot; r < 13 * m.nb; r += c.nslot) c.lds[(c.L.xi + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq + r) * Ctx<EPB>::N + c.e];
+            for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
         if (!(skip & 2)) seed_body_forces(c, true);
         const int S0 = ((m.ns + spw - 1) / spw) * spw;
         for (int i = c.slot; i < S0 + m.nj; i += c.nslot) {
@@ -1153,16 +1159,16 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
         if (one_level) {
             for (int i = c.slot; i < P0 + NT_PREFIX_LANES; i += c.nslot) {
                 if (i < nas) contact_write_item(c, i);
-                else if (i >= P0) prefix_lane(c, i - P0, c.L.sx, last_substep, true);
+                else if (i >= P0) prefix_lane(c, i - P0, c.L.sx.off, last_substep, true);
             }
         } else {
             for (int s = c.slot; s < nas; s += c.nslot) contact_write_item(c, s);
-            phase_pair_prefix_partials(c, c.L.sx);
+            phase_pair_prefix_partials(c, c.L.sx.off);
         }
     }
     __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
     if (!(skip & 1) && m.np > 64) {
-        phase_pair_prefix_scan(c, c.L.sx, last_substep, false);
+        phase_pair_prefix_scan(c, c.L.sx.off, last_substep, false);
         __syncthreads();
     }
     NT_TICK(3);

@@ -95,19 +95,20 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.nt_build_info()
     assert lib.nt_error_string(0) == b"ok"
     # struct layouts agree with the header (field count + size)
-    assert C.sizeof(_lib.nt_model) == 16 * 4 + 32 * 8
+    assert C.sizeof(_lib.nt_model) == 17 * 4 + 4 + 32 * 8  # 17 int32 (+ 4 B alignment pad) and 32 pointers
     m = _lib.nt_model()
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp, m.np_analytic = 18, 18, 4, 13
-    # persistent rows 1309 (state 169 + body 299 + joint 182 + dof 198 + shape 260 + control 54 + gravity 3 + derived 117
-    # + per-pair live counts 13 + their exclusive prefix 14)
-    # + XPBD scratch max(collide 182 + staged candidates 19*13 = 429, the forces 78 + 156 behind it = 663, joints 273,
-    #   correction records 10*52 = 520); the restitution scratch (169 + 15-float records) only exists when enabled
-    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1309 + 663)
+    # slot-major fields with odd strides (even component counts padded by one row):
+    # persistent rows 1348 (state (7 + 7) * 13 = 182 + body 23 * 13 = 299 + joint 15 * 13 = 195 + dof 11 * 18 = 198 + shape 21 * 13 = 273
+    # + control 54 + gravity 3 + derived 117 + per-pair live counts 13 + their exclusive prefix 14)
+    # + XPBD scratch max(collide 14 * 13 + 13 = 195 + staged candidates 19 * 13 = 442, the forces 7 * 13 + 13 * 13 behind it = 702,
+    #   joints 22 * 13 = 286, correction records 11 * 52 = 572); the restitution scratch (182 + 15-float records) only when enabled
+    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1348 + 702)
     # Featherstone: generalized state 127 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1171,
     # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780, collide scratch 429)
     m.nc, m.na, m.max_art_dofs = 19, 1, 18
-    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1309 + 1171 + 1728)
+    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1348 + 1171 + 1728)
 
 
 def test_no_silent_cpu_fallback():
