@@ -374,6 +374,84 @@ typedef struct {
 nt_status nt_hydro_collide(const nt_hydro_args* args, void* stream);
 
 /* -------- introspection -------- */
+/* ---- building the descriptor from Newton's own arrays ------------------------------------------------------------------
+ * nt_model above is the device-side view (env-major SoA, env-uniform topology).  A binding that holds a finalized
+ * newton.Model does not have to derive it: nt_model_create takes the flat arrays newton.Model already owns
+ * (newton/_src/sim/model.py:808-1364, rigid subset; HOST pointers, e.g. wp.array.numpy()) and returns a handle whose
+ * descriptor points at tables in HIP device memory (on_device = 1) or host memory (0: inspection / tests).
+ * Requirements are those of the kernels: homogeneous worlds as ModelBuilder.replicate() produces them, bodies / joints /
+ * env-local shapes world-major, static shapes in the global world (-1); anything else returns NT_ERR_UNSUPPORTED and
+ * nt_model_last_error() says which array differs.  Counts are totals over all worlds. */
+typedef struct {
+    int32_t world_count;               /* Model.world_count (0: one implicit world) */
+    int32_t body_count, joint_count, shape_count;
+    int32_t joint_dof_count, joint_coord_count, joint_target_q_count;
+    int32_t articulation_count, shape_contact_pair_count, mesh_point_count, gravity_count;
+    /* bodies */
+    const int32_t* body_world;         /* [body_count] */
+    const int32_t* body_flags;
+    const float* body_com;             /* [body_count][3] */
+    const float* body_mass;
+    const float* body_inv_mass;
+    const float* body_inertia;         /* [body_count][9] */
+    const float* body_inv_inertia;
+    /* joints */
+    const int32_t* joint_world;        /* [joint_count] */
+    const int32_t* joint_type;
+    const int32_t* joint_enabled;
+    const int32_t* joint_parent;
+    const int32_t* joint_child;
+    const int32_t* joint_q_start;
+    const int32_t* joint_qd_start;
+    const int32_t* joint_target_q_start;
+    const int32_t* joint_dof_dim;      /* [joint_count][2] linear, angular */
+    const float* joint_X_p;            /* [joint_count][7] */
+    const float* joint_X_c;
+    const float* joint_axis;           /* [joint_dof_count][3] */
+    const float* joint_limit_lower;    /* [joint_dof_count] ... */
+    const float* joint_limit_upper;
+    const float* joint_target_ke;
+    const float* joint_target_kd;
+    const float* joint_limit_ke;
+    const float* joint_limit_kd;
+    const float* joint_armature;
+    const float* joint_damping;
+    const int32_t* articulation_start; /* [articulation_count] first joint */
+    const int32_t* articulation_end;   /* [articulation_count] one past the last joint */
+    /* shapes */
+    const int32_t* shape_world;        /* [shape_count] */
+    const int32_t* shape_body;
+    const int32_t* shape_type;
+    const int32_t* shape_flags;
+    const int32_t* shape_collision_group;
+    const float* shape_transform;      /* [shape_count][7] */
+    const float* shape_scale;          /* [shape_count][3] */
+    const float* shape_margin;
+    const float* shape_gap;
+    const float* shape_material_mu;
+    const float* shape_material_mu_torsional;
+    const float* shape_material_mu_rolling;
+    const float* shape_material_ke;
+    const float* shape_material_kd;
+    const float* shape_material_kf;
+    const float* shape_material_ka;
+    const float* shape_material_restitution;
+    const int32_t* shape_contact_pairs; /* [shape_contact_pair_count][2] Model.shape_contact_pairs */
+    const int32_t* shape_mesh_start;   /* [shape_count] or NULL: first hull vertex of a CONVEX_MESH shape in mesh_points, else -1 */
+    const int32_t* shape_mesh_count;   /* [shape_count] or NULL */
+    const float* mesh_points;          /* [mesh_point_count][3] unscaled hull vertices of the shared Mesh assets */
+    const float* gravity;              /* [gravity_count][3]: one row per world, the last one for the global world (model.py:1300-1304) */
+} nt_newton_model;
+typedef struct nt_model_handle nt_model_handle;
+nt_status nt_model_create(const nt_newton_model* src, int32_t on_device, nt_model_handle** out);
+const nt_model* nt_model_get(const nt_model_handle* h);
+/* position of every device pair in one world's slice of Model.shape_contact_pairs ([np] int64; analytic pairs come first) */
+nt_status nt_model_pair_order(const nt_model_handle* h, int64_t* out);
+/* Model.notify_model_changed(): re-pack the parameter tables (same topology) and refresh params_uniform */
+nt_status nt_model_refresh_params(nt_model_handle* h, const nt_newton_model* src);
+void nt_model_destroy(nt_model_handle* h);
+const char* nt_model_last_error(void);           /* detail of the last NT_ERR_* of the nt_model_* calls on this thread */
+
 const char* nt_error_string(nt_status s);
 const char* nt_build_info(void);                 /* "gfx950 ..." */
 /* environments per workgroup the stepping kernels would use for this model (requested: 0 = auto), 0 if the working set

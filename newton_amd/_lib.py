@@ -121,7 +121,81 @@ class nt_collide_params(C.Structure):
 
 # every symbol include/newton_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class nt_newton_model(C.Structure):
+    """Flat newton.Model arrays handed to nt_model_create (host pointers), include/newton_hip.h."""
+    _fields_ = [
+        ("world_count", C.c_int32),
+        ("body_count", C.c_int32),
+        ("joint_count", C.c_int32),
+        ("shape_count", C.c_int32),
+        ("joint_dof_count", C.c_int32),
+        ("joint_coord_count", C.c_int32),
+        ("joint_target_q_count", C.c_int32),
+        ("articulation_count", C.c_int32),
+        ("shape_contact_pair_count", C.c_int32),
+        ("mesh_point_count", C.c_int32),
+        ("gravity_count", C.c_int32),
+        ("body_world", _P),
+        ("body_flags", _P),
+        ("body_com", _P),
+        ("body_mass", _P),
+        ("body_inv_mass", _P),
+        ("body_inertia", _P),
+        ("body_inv_inertia", _P),
+        ("joint_world", _P),
+        ("joint_type", _P),
+        ("joint_enabled", _P),
+        ("joint_parent", _P),
+        ("joint_child", _P),
+        ("joint_q_start", _P),
+        ("joint_qd_start", _P),
+        ("joint_target_q_start", _P),
+        ("joint_dof_dim", _P),
+        ("joint_X_p", _P),
+        ("joint_X_c", _P),
+        ("joint_axis", _P),
+        ("joint_limit_lower", _P),
+        ("joint_limit_upper", _P),
+        ("joint_target_ke", _P),
+        ("joint_target_kd", _P),
+        ("joint_limit_ke", _P),
+        ("joint_limit_kd", _P),
+        ("joint_armature", _P),
+        ("joint_damping", _P),
+        ("articulation_start", _P),
+        ("articulation_end", _P),
+        ("shape_world", _P),
+        ("shape_body", _P),
+        ("shape_type", _P),
+        ("shape_flags", _P),
+        ("shape_collision_group", _P),
+        ("shape_transform", _P),
+        ("shape_scale", _P),
+        ("shape_margin", _P),
+        ("shape_gap", _P),
+        ("shape_material_mu", _P),
+        ("shape_material_mu_torsional", _P),
+        ("shape_material_mu_rolling", _P),
+        ("shape_material_ke", _P),
+        ("shape_material_kd", _P),
+        ("shape_material_kf", _P),
+        ("shape_material_ka", _P),
+        ("shape_material_restitution", _P),
+        ("shape_contact_pairs", _P),
+        ("shape_mesh_start", _P),
+        ("shape_mesh_count", _P),
+        ("mesh_points", _P),
+        ("gravity", _P),
+    ]
+
+
 SYMBOLS = {
+    "nt_model_create": (C.c_int32, [C.POINTER(nt_newton_model), C.c_int32, C.POINTER(_P)]),
+    "nt_model_get": (C.POINTER(nt_model), [_P]),
+    "nt_model_pair_order": (C.c_int32, [_P, C.POINTER(C.c_int64)]),
+    "nt_model_refresh_params": (C.c_int32, [_P, C.POINTER(nt_newton_model)]),
+    "nt_model_destroy": (None, [_P]),
+    "nt_model_last_error": (C.c_char_p, []),
     "nt_clear_forces": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), _P]),
     "nt_collide": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
                                 C.POINTER(nt_collide_params), _P]),

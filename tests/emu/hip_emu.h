@@ -100,6 +100,10 @@ inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_S
 template <typename K>
 inline hipError_t hipFuncSetAttribute(K, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorEmu; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) { memcpy(dst, src, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
     memset(p, v, n);
     return hipSuccess;

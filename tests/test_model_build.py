@@ -1,0 +1,140 @@
+"""nt_model_create (include/newton_hip.h, newton_amd/csrc/nt_model_build.hip): the C helper that derives the nt_model descriptor
+from newton.Model's flat arrays, against the Python host logic that does the same for the Python binding
+(newton_amd/model.py: EnvTemplate, pack_param_arrays, params_uniform) -- every table, on several scenes, in host memory
+(on_device = 0: no GPU needed).  The reference arrays it consumes are the Model attributes of newton/_src/sim/model.py:808-1364."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from newton_amd import _lib
+from newton_amd.model import pack_param_arrays, params_uniform
+
+
+def _newton_arrays(model):
+    """nt_newton_model over the flat arrays of a finalized Model (+ the numpy buffers that must stay alive)."""
+    keep = []
+
+    def i32(a, shape=None):
+        x = np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+        keep.append(x)
+        return x.ctypes.data
+
+    def f32(a):
+        x = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+        keep.append(x)
+        return x.ctypes.data
+
+    m, s = model, _lib.nt_newton_model()
+    s.world_count = m.world_count
+    s.body_count, s.joint_count, s.shape_count = len(m.body_world), len(m.joint_world), len(m.shape_type)
+    s.joint_dof_count, s.joint_coord_count, s.joint_target_q_count = m.joint_dof_count, m.joint_coord_count, len(m.joint_target_q)
+    s.articulation_count = int(getattr(m, "articulation_count", 0))
+    pairs = np.asarray(m.shape_contact_pairs, dtype=np.int32).reshape(-1, 2)
+    s.shape_contact_pair_count = len(pairs)
+    pts = np.asarray(getattr(m, "mesh_points", np.zeros((0, 3))), dtype=np.float32).reshape(-1, 3)
+    s.mesh_point_count = len(pts)
+    g = np.asarray(m.gravity, dtype=np.float32).reshape(-1, 3)
+    s.gravity_count = len(g)
+    for k in ("body_world", "body_flags", "joint_world", "joint_type", "joint_parent", "joint_child", "joint_q_start",
+              "joint_qd_start", "joint_target_q_start", "joint_dof_dim", "shape_world", "shape_body", "shape_type", "shape_flags",
+              "shape_collision_group"):
+        setattr(s, k, i32(getattr(m, k)))
+    s.joint_enabled = i32(np.asarray(m.joint_enabled, dtype=np.int32))
+    if s.articulation_count:
+        s.articulation_start, s.articulation_end = i32(m.articulation_start), i32(m.articulation_end)
+    for k in ("body_com", "body_mass", "body_inv_mass", "body_inertia", "body_inv_inertia", "joint_X_p", "joint_X_c", "joint_axis",
+              "joint_limit_lower", "joint_limit_upper", "joint_target_ke", "joint_target_kd", "joint_limit_ke", "joint_limit_kd",
+              "joint_armature", "joint_damping", "shape_transform", "shape_scale", "shape_margin", "shape_gap", "shape_material_mu",
+              "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_ke", "shape_material_kd",
+              "shape_material_kf", "shape_material_ka", "shape_material_restitution"):
+        setattr(s, k, f32(getattr(m, k)))
+    s.shape_contact_pairs = i32(pairs)
+    if hasattr(m, "shape_mesh_start"):
+        s.shape_mesh_start, s.shape_mesh_count = i32(m.shape_mesh_start), i32(m.shape_mesh_count)
+    s.mesh_points, s.gravity = f32(pts), f32(g)
+    return s, keep
+
+
+def _arr(ptr, n, ctype=C.c_int32):
+    if n == 0:
+        return np.zeros(0, dtype=np.int32 if ctype is C.c_int32 else np.float32)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).copy()
+
+
+def _scenes():
+    from scenes import box_stack_scene, hull_bin_scene, mixed_primitive_scene, pendulum_scene, quadruped_scene
+
+    return {
+        "quadruped": lambda: quadruped_scene(5, seed=3),
+        "quadruped_convex": lambda: quadruped_scene(3, seed=None, colliders="box"),
+        "mixed_primitives": lambda: mixed_primitive_scene(4),
+        "box_stack": lambda: box_stack_scene(3, n_boxes=4, seed=1),
+        "pendulum": lambda: pendulum_scene(6, seed=2),
+        "hull_bin": lambda: hull_bin_scene(2, n_hulls=6),
+    }
+
+
+@pytest.mark.parametrize("name", list(_scenes()))
+def test_c_helper_reproduces_the_python_descriptor(name):
+    lib = _lib.load()
+    model = _scenes()[name]()
+    t = model.env
+    src, keep = _newton_arrays(model)
+    h = C.c_void_p()
+    rc = lib.nt_model_create(C.byref(src), 0, C.byref(h))
+    assert rc == 0, lib.nt_model_last_error()
+    try:
+        d = lib.nt_model_get(h).contents
+        for k in ("env_count", "env_stride", "nb", "nj", "nd", "nc", "ntq", "ns", "ng", "np", "cpp", "np_analytic", "na",
+                  "max_art_dofs", "shape_local0"):
+            assert getattr(d, k) == getattr(t, k), k
+        sizes = {"body_flags": t.nb, "joint_type": t.nj, "joint_enabled": t.nj, "joint_parent": t.nj, "joint_child": t.nj,
+                 "joint_q_start": t.nj, "joint_qd_start": t.nj, "joint_tq_start": t.nj, "joint_lin_count": t.nj,
+                 "joint_ang_count": t.nj, "shape_body": t.ns + t.ng, "shape_type": t.ns + t.ng, "shape_flags": t.ns + t.ng,
+                 "shape_group": t.ns + t.ng, "pair_a": t.np, "pair_b": t.np, "body_joint_start": t.nb + 1,
+                 "body_joint_list": 2 * t.nj, "body_pair_start": t.nb + 1, "body_pair_list": 2 * t.np, "art_start": t.na + 1,
+                 "shape_mesh_start": t.ns + t.ng, "shape_mesh_count": t.ns + t.ng, "gshape_id": t.ng}
+        for k, n in sizes.items():
+            assert np.array_equal(_arr(getattr(d, k), n), np.asarray(getattr(t, k), dtype=np.int32)[:n]), k
+        assert np.array_equal(_arr(d.mesh_points, 3 * len(t.mesh_points), C.c_float), t.mesh_points.reshape(-1))
+        assert np.array_equal(_arr(d.shape_mesh_bounds, 6 * (t.ns + t.ng), C.c_float), t.shape_mesh_bounds.reshape(-1))
+        packed = pack_param_arrays(model, t)
+        for k, v in packed.items():
+            got = _arr(getattr(d, k), v.size, C.c_float)
+            assert np.array_equal(got.view(np.int32), np.ascontiguousarray(v, dtype=np.float32).reshape(-1).view(np.int32)), k
+        assert d.params_uniform == params_uniform(packed, t.env_count)
+        order = np.zeros(t.np, dtype=np.int64)
+        assert lib.nt_model_pair_order(h, order.ctypes.data_as(C.POINTER(C.c_int64))) == 0
+        assert np.array_equal(order, t.pair_order)
+        # the mode choice for pair-heavy scenes is the library's own
+        from newton_amd.model import choose_contact_scratch
+
+        mine = _lib.nt_model()
+        C.memmove(C.byref(mine), C.byref(d), C.sizeof(mine))
+        choose_contact_scratch(lib, mine)
+        assert mine.contact_scratch_in_hbm == d.contact_scratch_in_hbm
+        # notify_model_changed: one world's link gets heavier -> the tables follow, the uniform flag drops
+        if t.nb and t.env_count > 1:
+            model.body_mass = np.array(model.body_mass, copy=True)
+            model.body_mass[t.nb] *= 2.0
+            src2, keep2 = _newton_arrays(model)
+            assert lib.nt_model_refresh_params(h, C.byref(src2)) == 0
+            packed = pack_param_arrays(model, t)
+            got = _arr(d.body_param, packed["body_param"].size, C.c_float)
+            assert np.array_equal(got, packed["body_param"].reshape(-1)) and d.params_uniform == 0
+    finally:
+        lib.nt_model_destroy(h)
+
+
+def test_heterogeneous_worlds_are_refused_with_a_reason():
+    from scenes import quadruped_scene
+
+    lib = _lib.load()
+    model = quadruped_scene(3, seed=None)
+    model.joint_type = np.array(model.joint_type, copy=True)
+    model.joint_type[model.env.nj + 2] = 3  # FIXED instead of REVOLUTE in world 1
+    src, keep = _newton_arrays(model)
+    h = C.c_void_p()
+    assert lib.nt_model_create(C.byref(src), 0, C.byref(h)) == -3 and not h.value
+    assert b"joint_type differs between worlds" in lib.nt_model_last_error()
