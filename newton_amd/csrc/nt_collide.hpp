@@ -175,135 +175,11 @@ NT_DI void write_contact_slot(const Ctx<EPB>& c, int slot, int sa, int sb, vec3 
     D[c.g(CD_MARGIN1, ncs, slot)] = off_b;
 }
 
-template <int EPB, bool CVX>
-NT_DI void collide_slot_item(const Ctx<EPB>& c, const int slot) {
-    const nt_model& m = c.a.m;
-    const nt_contacts& ct = c.a.ct;
-    const int cpp = m.cpp;
-    const int ncs = m.np * cpp;
-    const int p = slot / cpp, k = slot - p * cpp;
-    int sa = c.T.pair_a[p], sb = c.T.pair_b[p];
-    xform Xa, Xb;
-    vec3 loa, hia, lob, hib;
-    shape_world(c, sa, Xa, loa, hia);
-    shape_world(c, sb, Xb, lob, hib);
-    bool hit = loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z;
-    if (k == 0) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
-
-    int nvalid = 0;
-    bool wrote = false;
-    if (hit) {
-        int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
-        if (ta > tb) {  // sort by type (narrow_phase.py:525-528)
-            int t = sa; sa = sb; sb = t;
-            t = ta; ta = tb; tb = t;
-            xform X = Xa; Xa = Xb; Xb = X;
-            vec3 v = loa; loa = lob; lob = v;
-            v = hia; hia = hib; hib = v;
-        }
-        vec3 scale_a = c.shape_scale(sa), scale_b = c.shape_scale(sb);
-        float margin_a = c.shape_f(sa, SP_MARGIN), margin_b = c.shape_f(sb, SP_MARGIN);
-        float gap_sum = c.shape_f(sa, SP_GAP) + c.shape_f(sb, SP_GAP);
-        bool to_gjk = ta >= GEO_ELLIPSOID || tb == GEO_CONE || (ta == GEO_CAPSULE && tb > GEO_CAPSULE);
-        if (!to_gjk) {
-            float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
-            float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
-            Contacts4 k4;
-            primitive_pair(ta, tb, Xa, Xb, scale_a, scale_b, gap_sum + margin_a + margin_b, k4);
-            float total_sep = ra + rb + margin_a + margin_b;
-            vec3 n = normalize(k4.normal);
-            // admission test for all four candidates (contact_data.py:139-157); lane k keeps the k-th admitted one
-            float my_dist = 0.0f;
-            vec3 my_center;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float dist = k4.dist(i);
-                bool ok = dist < NT_MAXVAL;
-                if (ok) {
-                    vec3 center = k4.pos(i);
-                    vec3 aw = center - n * (0.5f * dist + ra);
-                    vec3 bw = center + n * (0.5f * dist + rb);
-                    float d = dot(bw - aw, n) - total_sep;
-                    ok = d <= gap_sum;
-                    if (ok && nvalid == k) { my_dist = dist; my_center = center; wrote = true; }
-                }
-                nvalid += ok ? 1 : 0;
-            }
-            if (wrote) write_contact_slot(c, slot, sa, sb, my_center, n, my_dist, ra, rb, margin_a, margin_b);
-        }
-        if constexpr (CVX) {
-            // pairs [np_analytic, np): MPR/GJK + manifold. Lane k == 0 of the pair runs the whole (serial, divergent)
-            // algorithm and fills the pair's slots in emission order; the other lanes of the pair leave them alone.
-            if (p >= m.np_analytic) {
-                if (k != 0) return;
-                ConvexContacts cc;
-                Geom ga, gb;
-                ga.type = ta; ga.scale = scale_a;
-                gb.type = tb; gb.scale = scale_b;
-                // a (finite) plane enters the convex path as a rectangle with half extents scale / 2 (collide.py:452-453)
-                if (ta == GEO_PLANE) ga.scale = vec3(scale_a.x * 0.5f, scale_a.y * 0.5f, 0.0f);
-                if (tb == GEO_PLANE) gb.scale = vec3(scale_b.x * 0.5f, scale_b.y * 0.5f, 0.0f);
-                if (ta == GEO_CONVEX_MESH) {
-                    ga.points = m.mesh_points + 3 * c.T.shape_mesh_start[sa];
-                    ga.count = c.T.shape_mesh_count[sa];
-                    const float* mb = m.shape_mesh_bounds + 6 * sa;
-                    ga.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)) +
-                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)));
-                }
-                if (tb == GEO_CONVEX_MESH) {
-                    gb.points = m.mesh_points + 3 * c.T.shape_mesh_start[sb];
-                    gb.count = c.T.shape_mesh_count[sb];
-                    const float* mb = m.shape_mesh_bounds + 6 * sb;
-                    gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +
-                                        vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)));
-                }
-                // polygon scratch: 20 rows per convex pair in the part of the scratch union that the collide phases do not
-                // use (behind shape transforms / AABBs / pair counts)
-                PolyRef poly;
-                poly.base = &c.lds[(c.L.poly + 20 * (c.big ? c.slot : p - m.np_analytic)) * Ctx<EPB>::N + c.e];
-                poly.stride = Ctx<EPB>::N;
-                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
-                float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
-                float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
-                vec3 n = normalize(cc.normal);
-                nvalid = cc.count < cpp ? cc.count : cpp;
-                for (int i = 0; i < cpp; ++i) {
-                    if (i < nvalid) {
-                        write_contact_slot(c, slot + i, sa, sb, cc.center(i), n, cc.distance(i), ra, rb, margin_a, margin_b);
-                    } else {
-                        size_t gi = (size_t)(slot + i) * c.ES + c.env;
-                        ct.shape0[gi] = -1;
-                        ct.shape1[gi] = -1;
-                    }
-                }
-                c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
-                c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
-                return;
-            }
-        }
-    }
-    if (!wrote) {
-        size_t gi = (size_t)slot * c.ES + c.env;
-        ct.shape0[gi] = -1;
-        ct.shape1[gi] = -1;
-    }
-    if (k == 0) {
-        c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
-        c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
-    }
-}
-template <int EPB, bool CVX>
-NT_DI void phase_pairs(const Ctx<EPB>& c) {
-    if (!c.valid) return;
-    const int ncs = c.a.m.np * c.a.m.cpp;
-    for (int s = c.slot; s < ncs; s += c.nslot) collide_slot_item<EPB, CVX>(c, s);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Staged variant of the pair phase (every tile except the pair-heavy one-environment-per-workgroup mode): ONE lane per
 // pair runs the broad-phase test + the analytic primitive pair + the admission test and parks the admitted candidates in
 // LDS (L.st: normal[3], then (center[3], dist) x 4 per pair); after a barrier one lane per contact SLOT turns its candidate
-// into the body-frame record (19 stores).  Same arithmetic, same emission order as collide_slot_item -- the per-slot
+// into the body-frame record (19 stores).  Same arithmetic and emission order as a one-lane-per-slot evaluation -- the per-slot
 // variant evaluated the pair once per slot lane (4x redundantly).  Convex pairs keep their single lane (it writes its
 // slots itself) and skip the second stage.
 // ------------------------------------------------------------------------------------------------

@@ -316,16 +316,30 @@ NT_DEV bool solve_mpr_core(const Geom& ga, const Geom& gb, quat orientation_b, v
 
 // ---------------------------------------------------------------- GJK (simplex_solver.py)
 const float GJK_EPSILON = 1e-8f;
+// up to four Minkowski vertices (B and B->A of each).  Named fields with select-style access: the slots are addressed with
+// run-time indices, and an indexed private array would live in scratch memory
 struct Simplex {
-    vec3 v[8];  // v[2i] = B, v[2i+1] = BtoA
+    vec3 b0, a0, b1, a1, b2, a2, b3, a3;
+    NT_DI vec3 B(int i) const { return vsel(i == 0, b0, vsel(i == 1, b1, vsel(i == 2, b2, b3))); }
+    NT_DI vec3 BtoA(int i) const { return vsel(i == 0, a0, vsel(i == 1, a1, vsel(i == 2, a2, a3))); }
+    NT_DI void set(int i, vec3 B_, vec3 BtoA_) {
+        b0 = vsel(i == 0, B_, b0); a0 = vsel(i == 0, BtoA_, a0);
+        b1 = vsel(i == 1, B_, b1); a1 = vsel(i == 1, BtoA_, a1);
+        b2 = vsel(i == 2, B_, b2); a2 = vsel(i == 2, BtoA_, a2);
+        b3 = vsel(i == 3, B_, b3); a3 = vsel(i == 3, BtoA_, a3);
+    }
 };
 struct vec4f4 {
-    float c[4];
-    NT_DI vec4f4() { c[0] = c[1] = c[2] = c[3] = 0.0f; }
+    float c0, c1, c2, c3;
+    NT_DI vec4f4() : c0(0.0f), c1(0.0f), c2(0.0f), c3(0.0f) {}
+    NT_DI float get(int i) const { return fsel(i == 0, c0, fsel(i == 1, c1, fsel(i == 2, c2, c3))); }
+    NT_DI void set(int i, float v) {
+        c0 = fsel(i == 0, v, c0); c1 = fsel(i == 1, v, c1); c2 = fsel(i == 2, v, c2); c3 = fsel(i == 3, v, c3);
+    }
 };
 
 NT_DEV void closest_segment(const Simplex& s, int i0, int i1, vec3& closest, vec4f4& bc, unsigned& mask) {
-    vec3 a = s.v[2 * i0 + 1], b = s.v[2 * i1 + 1];
+    vec3 a = s.BtoA(i0), b = s.BtoA(i1);
     vec3 edge = b - a;
     float vsq = length_sq(edge);
     bool degenerate = vsq < GJK_EPSILON;
@@ -343,13 +357,13 @@ NT_DEV void closest_segment(const Simplex& s, int i0, int i1, vec3& closest, vec
         lambda0 = 1.0f;
         lambda1 = 0.0f;
     }
-    bc.c[i0] = lambda0;
-    bc.c[i1] = lambda1;
+    bc.set(i0, lambda0);
+    bc.set(i1, lambda1);
     closest = lambda0 * a + lambda1 * b;
 }
 
 NT_DEV void closest_triangle(const Simplex& s, int i0, int i1, int i2, vec3& closest_out, vec4f4& bc_out, unsigned& mask_out) {
-    vec3 a = s.v[2 * i0 + 1], b = s.v[2 * i1 + 1], c = s.v[2 * i2 + 1];
+    vec3 a = s.BtoA(i0), b = s.BtoA(i1), c = s.BtoA(i2);
     vec3 u = a - b, w = a - c;
     vec3 normal = cross(u, w);
     float t = length_sq(normal);
@@ -386,9 +400,9 @@ NT_DEV void closest_triangle(const Simplex& s, int i0, int i1, int i2, vec3& clo
         closest_out = closest_pt; bc_out = bc; mask_out = mask;
         return;
     }
-    bc.c[i0] = lambda0;
-    bc.c[i1] = lambda1;
-    bc.c[i2] = lambda2;
+    bc.set(i0, lambda0);
+    bc.set(i1, lambda1);
+    bc.set(i2, lambda2);
     mask_out = (1u << i0) | (1u << i1) | (1u << i2);
     bc_out = bc;
     closest_out = lambda0 * a + lambda1 * b + lambda2 * c;
@@ -397,7 +411,7 @@ NT_DEV void closest_triangle(const Simplex& s, int i0, int i1, int i2, vec3& clo
 NT_DEV float determinant(vec3 a, vec3 b, vec3 c, vec3 d) { return dot(b - a, cross(c - a, d - a)); }
 
 NT_DEV void closest_tetrahedron(const Simplex& s, vec3& closest_out, vec4f4& bc_out, unsigned& mask_out) {
-    vec3 v0 = s.v[1], v1 = s.v[3], v2 = s.v[5], v3 = s.v[7];
+    vec3 v0 = s.a0, v1 = s.a1, v2 = s.a2, v3 = s.a3;
     float det_t = determinant(v0, v1, v2, v3);
     bool degenerate = fabsf(det_t) < GJK_EPSILON;
     float denom = degenerate ? GJK_EPSILON : det_t;
@@ -438,7 +452,7 @@ NT_DEV void closest_tetrahedron(const Simplex& s, vec3& closest_out, vec4f4& bc_
         closest_out = closest_pt; bc_out = bc; mask_out = mask;
         return;
     }
-    bc.c[0] = lambda0; bc.c[1] = lambda1; bc.c[2] = lambda2; bc.c[3] = lambda3;
+    bc.c0 = lambda0; bc.c1 = lambda1; bc.c2 = lambda2; bc.c3 = lambda3;
     bc_out = bc;
     mask_out = 15u;
     closest_out = zero;
@@ -449,8 +463,8 @@ NT_DEV void simplex_get_closest(const Simplex& s, const vec4f4& bc, unsigned mas
     point_b = vec3(0.0f);
     for (int i = 0; i < 4; ++i) {
         if ((mask & (1u << i)) == 0) continue;
-        vec3 B = s.v[2 * i], BtoA = s.v[2 * i + 1];
-        float w = bc.c[i];
+        vec3 B = s.B(i), BtoA = s.BtoA(i);
+        float w = bc.get(i);
         point_a = point_a + w * (B + BtoA);
         point_b = point_b + w * B;
     }
@@ -489,7 +503,7 @@ NT_DEV bool solve_closest_distance_core(const Geom& ga, const Geom& gb, quat ori
         bool is_duplicate = false;
         for (int i = 0; i < 4; ++i)
             if ((usage & (1u << i)) != 0)
-                if (length_sq(simplex.v[2 * i + 1] - w_v) < COLLIDE_EPSILON * COLLIDE_EPSILON) {
+                if (length_sq(simplex.BtoA(i) - w_v) < COLLIDE_EPSILON * COLLIDE_EPSILON) {
                     is_duplicate = true;
                     break;
                 }
@@ -506,15 +520,14 @@ NT_DEV bool solve_closest_distance_core(const Geom& ga, const Geom& gb, quat ori
         }
         indices[use_count] = free_slot;
         use_count += 1;
-        simplex.v[2 * free_slot] = w.B;
-        simplex.v[2 * free_slot + 1] = w.BtoA;
+        simplex.set(free_slot, w.B, w.BtoA);
         vec3 closest(0.0f);
         bool success = true;
         if (use_count == 1) {
             int i0 = indices[0];
-            closest = simplex.v[2 * i0 + 1];
+            closest = simplex.BtoA(i0);
             usage = 1u << i0;
-            bary.c[i0] = 1.0f;
+            bary.set(i0, 1.0f);
         } else if (use_count == 2) {
             closest_segment(simplex, indices[0], indices[1], closest, bary, usage);
         } else if (use_count == 3) {
@@ -856,16 +869,19 @@ struct ConvexContacts {
     float d0, d1, d2, d3, d4;
     vec3 normal;  // shared by every contact of the pair (world frame, as generated)
     int count;
+    // value selects on every field (see vsel in nt_math.hpp: an if-chain of stores or a ternary on lvalues turns into an
+    // address select and pins the record in scratch memory)
     NT_DI void push(vec3 c, float d) {
-        if (count == 0) { c0 = c; d0 = d; }
-        else if (count == 1) { c1 = c; d1 = d; }
-        else if (count == 2) { c2 = c; d2 = d; }
-        else if (count == 3) { c3 = c; d3 = d; }
-        else if (count == 4) { c4 = c; d4 = d; }
-        count += 1;
+        const int k = count;
+        c0 = vsel(k == 0, c, c0); d0 = fsel(k == 0, d, d0);
+        c1 = vsel(k == 1, c, c1); d1 = fsel(k == 1, d, d1);
+        c2 = vsel(k == 2, c, c2); d2 = fsel(k == 2, d, d2);
+        c3 = vsel(k == 3, c, c3); d3 = fsel(k == 3, d, d3);
+        c4 = vsel(k == 4, c, c4); d4 = fsel(k == 4, d, d4);
+        count = k + 1;
     }
-    NT_DI vec3 center(int i) const { return i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : (i == 3 ? c3 : c4))); }
-    NT_DI float distance(int i) const { return i == 0 ? d0 : (i == 1 ? d1 : (i == 2 ? d2 : (i == 3 ? d3 : d4))); }
+    NT_DI vec3 center(int i) const { return vsel(i == 0, c0, vsel(i == 1, c1, vsel(i == 2, c2, vsel(i == 3, c3, c4)))); }
+    NT_DI float distance(int i) const { return fsel(i == 0, d0, fsel(i == 1, d1, fsel(i == 2, d2, fsel(i == 3, d3, d4)))); }
 };
 
 struct PairCtx {
@@ -896,17 +912,19 @@ NT_DEV ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a,
         vec3 shape_axis, shape_pos, axial_normal;
         float shape_radius, shape_half_height;
         bool is_cone;
-        if (is_discrete_a && is_axial_b) {
+        // (both shapes' sizes read up front and selected by value: a load in each branch is merged into one load through a
+        // selected address, which keeps the shape records in scratch memory)
+        const bool b_axial = is_discrete_a && is_axial_b;
+        const float ra_x = P.ga.scale.x, ra_y = P.ga.scale.y, rb_x = P.gb.scale.x, rb_y = P.gb.scale.y;
+        shape_radius = fsel(b_axial, rb_x, ra_x);
+        shape_half_height = fsel(b_axial, rb_y, ra_y);
+        if (b_axial) {
             shape_axis = quat_rotate(rot_b, vec3(0.0f, 0.0f, 1.0f));
-            shape_radius = P.gb.scale.x;
-            shape_half_height = P.gb.scale.y;
             is_cone = type_b == GEO_CONE;
             shape_pos = pos_b;
             axial_normal = normal;
         } else {
             shape_axis = quat_rotate(rot_a, vec3(0.0f, 0.0f, 1.0f));
-            shape_radius = P.ga.scale.x;
-            shape_half_height = P.ga.scale.y;
             is_cone = type_a == GEO_CONE;
             shape_pos = pos_a;
             axial_normal = -normal;
@@ -1036,7 +1054,7 @@ NT_DEV int build_manifold(PairCtx& P, quat orientation_a, vec3 position_a_world,
 
 // compute_gjk_mpr_contacts + solve_convex_multi_contact (collision_core.py:325-452, collision_convex.py:110-232).
 // Shapes arrive type-sorted (type_a <= type_b) with world transforms; contacts come back in the reference's emission order.
-NT_DEV void convex_pair(const Geom& geom_a, const Geom& geom_b, xform Xa, const xform& Xb, float margin_a, float margin_b,
+NT_DI void convex_pair(const Geom& geom_a, const Geom& geom_b, xform Xa, const xform& Xb, float margin_a, float margin_b,
                         float rigid_gap, vec3 aabb_lower_b, vec3 aabb_upper_b, PolyRef poly, ConvexContacts& out) {
     out.count = 0;
     PairCtx P;

@@ -154,3 +154,48 @@ def test_contact_matcher_follows_the_reference_matcher_on_a_box_stack(oracle_lib
     sw = np.asarray(model.shape_world)
     world = np.maximum(sw[contacts.rigid_contact_shape0.cpu().numpy()[:n]], sw[contacts.rigid_contact_shape1.cpu().numpy()[:n]])
     assert np.all(got[world == 3] == -1) and np.any(got[world != 3] >= 0)
+
+
+def test_descriptor_built_by_the_c_helper_steps_like_the_python_built_one():
+    """nt_model_create(on_device=1) from the flat Model arrays: a fused rollout through its descriptor is bitwise the rollout
+    through the descriptor the Python host builds (same tables, same device kernels)."""
+    import ctypes as C
+
+    import torch
+    from scenes import quadruped_scene
+    from test_model_build import _newton_arrays
+
+    import newton_amd as nt
+    from newton_amd import _lib
+
+    model = quadruped_scene(96, device="cuda:0", seed=4)
+    model.joint_q.reshape(96, -1)[:, 2] -= 0.2
+    model.body_q, model.body_qd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    dm = model.device_model()
+
+    def run(desc):
+        s0, s1 = model.state(), model.state()
+        ctrl = model.control()
+        p = solver._params()
+        d0, d1, d_c, d_ct = s0._desc(), s1._desc(), ctrl._desc(), contacts._desc()
+        for _ in range(3):
+            _lib.check(dm.lib.nt_xpbd_rollout(C.byref(desc), C.byref(p), None, C.byref(d0), C.byref(d1), C.byref(d_c),
+                                              C.byref(d_ct), 1e-3, 10, dm.stream()), "nt_xpbd_rollout")
+        torch.cuda.synchronize()
+        return s0.body_q.cpu().numpy().copy(), s0.body_qd.cpu().numpy().copy()
+
+    q_ref, qd_ref = run(dm.desc)
+    src, keep = _newton_arrays(model)
+    h = C.c_void_p()
+    assert dm.lib.nt_model_create(C.byref(src), 1, C.byref(h)) == 0, dm.lib.nt_model_last_error()
+    try:
+        mine = dm.lib.nt_model_get(h).contents
+        assert mine.params_uniform == dm.desc.params_uniform and mine.np == dm.desc.np
+        q, qd = run(mine)
+    finally:
+        dm.lib.nt_model_destroy(h)
+    assert np.array_equal(q.view(np.int32), q_ref.view(np.int32)) and np.array_equal(qd.view(np.int32), qd_ref.view(np.int32))
+    assert np.abs(qd_ref).max() > 0.0
