@@ -199,8 +199,17 @@ def run(args, rank, local_rank, world, dist):
         torch.cuda.synchronize()
 
     settle = W["settle"] if args.settle_frames < 0 else args.settle_frames
+    t_settle = time.perf_counter()
     for _ in range(settle):  # untimed, outside warm-up: reach the standing regime
         solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
+    torch.cuda.synchronize()
+    # ... and keep the (settled) scene running until the GPU has been busy for half a second: a fresh box reaches its
+    # sustained clocks only after a few hundred milliseconds of load (same-box measurements: the first run after idle is
+    # 7 % slower than every later one)
+    while settle > 0 and time.perf_counter() - t_settle < 0.5:
+        for _ in range(20):
+            solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
     barrier()
@@ -255,7 +264,7 @@ def run(args, rank, local_rank, world, dist):
         "config": {
             "workload": f"{W['name']}, " + ("SolverFeatherstone defaults" if W["solver"] == "featherstone"
                                             else f"SolverXPBD iterations={W['iterations']}") + f", dt={dt:.6g}, "
-                        f"{args.envs_per_gpu} envs per GPU, pre-settled ({settle} untimed frames, feet on the ground), "
+                        f"{args.envs_per_gpu} envs per GPU, pre-settled ({settle} untimed frames + >= 0.5 s of the same frames for the clocks, feet on the ground), "
                         f"1 step = 1 frame = {SUBSTEPS} substeps of clear_forces+collide+step fused in one rollout launch",
             "envs_per_gpu": args.envs_per_gpu, "substeps_per_step": SUBSTEPS, "parallelism": f"env-shard x{world}",
             "mean_contacts_per_env": c_per_env, "settle_frames": settle,

@@ -5,7 +5,8 @@ SQ has 8 counter slots per pass on gfx950 (MI355X_MICROARCH.md "rocprofv3 PMC sl
 s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~= WAVE_CYCLES, all in quad-cycles summed over waves.
 Writes gpurun_out/pmc_sq_<workload>.json.
 
-usage:  python tools/pmc_sq.py [quadruped|box_stack|quadruped_featherstone]
+usage:  python tools/pmc_sq.py [workload[@envs]] [COUNTER,COUNTER,...|set2]
+        set2 = the instruction-mix set (scalar / branch / memory instruction counts), filtered by what `rocprofv3 -L` offers
 """
 import csv
 import glob
@@ -19,18 +20,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 COUNTERS = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
             "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS"]
+SET2 = ["SQ_WAVE_CYCLES", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+        "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_MISC", "SQ_WAVES", "SQ_BUSY_CYCLES"]
 
 
 def main():
-    workload = sys.argv[1] if len(sys.argv) > 1 else "quadruped"
+    spec = sys.argv[1] if len(sys.argv) > 1 else "quadruped"
+    workload, _, envs = spec.partition("@")
     counters = sys.argv[2].split(",") if len(sys.argv) > 2 else COUNTERS
+    tag = spec.replace("@", "_")
+    if counters == ["set2"]:
+        listing = subprocess.run(["rocprofv3", "-L"], capture_output=True, text=True, timeout=120, cwd="/tmp",
+                                 env=dict(os.environ, TMPDIR="/tmp")).stdout
+        counters = [c for c in SET2 if c in listing][:8]
+        tag += "_set2"
     os.makedirs(OUT, exist_ok=True)
-    d = os.path.join(OUT, f"pmc_sq_{workload}")
+    d = os.path.join(OUT, f"pmc_sq_{tag}")
     env = dict(os.environ, TMPDIR="/tmp")
-    log = open(os.path.join(OUT, f"pmc_sq_{workload}.log"), "w")
+    log = open(os.path.join(OUT, f"pmc_sq_{tag}.log"), "w")
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
                     sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "10", "--warmup", "10",
-                    "--no-cpu-baseline"], check=True, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=240)
+                    "--no-cpu-baseline", *(["--envs-per-gpu", envs] if envs else [])], check=True, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=240)
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     acc = defaultdict(lambda: defaultdict(float))
     launches = defaultdict(set)
@@ -52,7 +62,7 @@ def main():
             per["frac_active_any"] = per.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
             per["frac_active_valu"] = per.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
         res[k] = {"launches": n, "per_launch": per}
-    json.dump(res, open(os.path.join(OUT, f"pmc_sq_{workload}.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(OUT, f"pmc_sq_{tag}.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
