@@ -374,6 +374,42 @@ NT_DI void phase_pair_eval(const Ctx<EPB>& c) {
     if (!c.valid) return;
     for (int p = c.tslot; p < c.a.m.np; p += c.nslot) pair_eval_item<EPB, CVX>(c, p);
 }
+// Staged tiles with more candidate pairs than slot lanes (e.g. the 8-box stacks: 36 pairs, 32 lanes, ~8 AABB hits): the same
+// two-stage split per ENVIRONMENT.  Stage 1: one lane per pair tests the AABBs and appends the hits to the environment's list
+// in LDS (atomic counter, zeroed during the shape phase; the order of the list is irrelevant, every pair owns its slots);
+// misses retire here.  Stage 2 deals the hits densely to the lanes: one pass of the narrow phase instead of ceil(np / lanes).
+template <int EPB>
+NT_DI bool pairs_compacted(const Ctx<EPB>& c) { return !c.big && c.a.m.np > c.nslot; }
+template <int EPB>
+NT_DI void phase_pair_broad_staged(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    int* count = reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0));
+    for (int p = c.slot; p < m.np; p += c.nslot) {
+        const bool hit = pair_aabb_hit(c, p);
+        ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+        if (hit) {
+            *reinterpret_cast<int*>(&c.l(c.L.hl, 0, m.np, atomicAdd(count, 1))) = p;
+        } else {
+            if (p >= m.np_analytic)  // (analytic pairs: the record stage clears the slots of a pair without candidates)
+                for (int i = 0; i < m.cpp; ++i) {
+                    size_t gi = (size_t)(p * m.cpp + i) * c.ES + c.env;
+                    ct.shape0[gi] = -1;
+                    ct.shape1[gi] = -1;
+                }
+            c.l(c.L.pc, 0, m.np, p) = 0.0f;
+            c.l(c.L.pm, 0, m.np, p) = 0.0f;
+        }
+    }
+}
+template <int EPB, bool CVX>
+NT_DI void phase_pair_narrow_staged(const Ctx<EPB>& c) {
+    if (!c.valid) return;
+    const int nhit = *reinterpret_cast<const int*>(&c.l(c.L.hc, 0, 1, 0));
+    for (int i = c.slot; i < nhit; i += c.nslot)
+        pair_eval_item<EPB, CVX, true, true>(c, *reinterpret_cast<const int*>(&c.l(c.L.hl, 0, c.a.m.np, i)));
+}
 template <int EPB>
 NT_DI void phase_contact_write(const Ctx<EPB>& c) {
     if (!c.valid) return;

@@ -59,6 +59,7 @@ struct LdsLayout {
     Fld<1> pc;         // collide: per-pair contact count [np]
     int poly;          // collide: manifold polygon scratch, 20 rows per convex pair (or per lane: pair-heavy tile)
     Fld<19> st;        // collide: admitted candidates of the analytic pairs [np][19] (normal, 4 x (center, dist)); staged tiles
+    Fld<1> hl, hc;     // collide: the environment's compacted broad-phase hits [np] + their count [1] (staged tiles, int bits)
     Fld<7> bf;         // forces: body_f_tmp [nb][6 (+1)]
     Fld<13> jf;        // forces: joint wrenches [nj][12 (+1)]
     Fld<13> jl;        // joints: linear-part corrections [nj][12 (+1)]
@@ -84,6 +85,8 @@ __host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_mode
     int coll = 14 * m.ns + m.np + 20 * (big ? NT_BIG_SCENE_LANES : (m.np - m.np_analytic));
     L.st.off = base + coll;
     if (!big) coll += 19 * m.np;
+    L.hl.off = base + coll; L.hc.off = L.hl.off + m.np;
+    if (!big) coll += m.np + 1;
     return coll;
 }
 

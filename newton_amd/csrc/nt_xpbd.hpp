@@ -1037,6 +1037,8 @@ __device__ unsigned long long nt_phase_clock[32];
 template <int EPB, bool CVX>
 NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
     if (c.a.debug_skip & 1) return;
+    const bool compact = pairs_compacted(c);
+    if (compact && c.valid && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0)) = 0;
     phase_shapes(c);
     __syncthreads();
     NT_TICK(1);
@@ -1044,7 +1046,13 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
         phase_pairs_big_broad(c);  // pair-heavy tile: compact the candidates first, no candidate staging (19 rows per pair)
         phase_pairs_big_narrow<EPB, CVX>(c);
     } else {
-        phase_pair_eval<EPB, CVX>(c);
+        if (compact) {
+            phase_pair_broad_staged(c);
+            __syncthreads();
+            phase_pair_narrow_staged<EPB, CVX>(c);
+        } else {
+            phase_pair_eval<EPB, CVX>(c);
+        }
         __syncthreads();
         phase_contact_write(c);
     }
@@ -1132,7 +1140,9 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;  // slots per wave
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
     // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
+    const bool compact = pairs_compacted(c);
     if (c.valid) {
+        if (compact && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0)) = 0;
         if (restitution)
             for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
         if (!(skip & 2)) seed_body_forces(c, true);
@@ -1148,7 +1158,15 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     __syncthreads();
     NT_TICK(1);
     // -- interval 2: one lane per candidate pair (broad phase test, primitive pair / MPR-GJK manifold, admission)
-    if (!(skip & 1)) phase_pair_eval<EPB, CVX>(c);
+    if (!(skip & 1)) {
+        if (compact) {
+            phase_pair_broad_staged(c);
+            __syncthreads();
+            phase_pair_narrow_staged<EPB, CVX>(c);
+        } else {
+            phase_pair_eval<EPB, CVX>(c);
+        }
+    }
     __syncthreads();
     NT_TICK(2);
     // -- interval 3: contact records of the analytic pairs (one lane per slot) || live-contact prefix (few lanes per env)

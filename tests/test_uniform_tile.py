@@ -68,3 +68,22 @@ def test_randomised_worlds_are_detected_and_refused_by_the_uniform_tile(H):
     with pytest.raises(Exception):
         _rollout(H, model, "16,256,2,1")  # NT_ERR_UNSUPPORTED: the shape is only valid for uniform models
     _rollout(H, model, None)  # the default dispatch takes the per-environment tile
+
+
+def test_candidate_compaction_of_staged_tiles_is_bitwise_the_plain_pair_loop(H):
+    """8-box stacks: 36 candidate pairs per environment.  At 8 environments per workgroup (32 slot lanes) the pair interval
+    compacts each environment's AABB hits into an LDS list first (nt_collide.hpp: phase_pair_broad_staged); at 1 environment per
+    workgroup (256 lanes) every pair has its own lane and nothing is compacted.  Same contacts, same states, bit for bit."""
+    from scenes import box_stack_scene
+
+    model = box_stack_scene(11, n_boxes=8, seed=3, jitter=2e-3)
+    outs = []
+    for epb in (8, 1):
+        em = H.EmuModel(model)
+        assert em.t.np == 36
+        a, b, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+        H.xpbd_rollout(em, a, b, ctrl, ct, 1.0 / 240.0, 4, epb=epb, iterations=4)
+        outs.append((a.body_q.copy(), a.body_qd.copy(), ct.data.copy(), ct.shape0.copy(), ct.env_count.copy()))
+    for x, y in zip(*outs):
+        assert np.array_equal(x.view(np.int32) if x.dtype == np.float32 else x, y.view(np.int32) if y.dtype == np.float32 else y)
+    assert outs[0][4][:11].min() > 0
