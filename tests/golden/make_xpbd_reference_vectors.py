@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE -- generates tests/golden/xpbd_reference_vectors.npz by EXECUTING the reference's own SolverXPBD
+(/root/reference/newton/_src/solvers/xpbd/solver_xpbd.py + kernels.py + solvers/solver.py, unmodified) in this container.
+
+warp-lang is not available here, so the reference source runs on tests/golden/refshim (a pure-Python stand-in for the Warp API:
+fp32 scalars, builtins in the operation order of oracle/wp_builtins.h; kernels executed thread by thread in ascending tid
+order, atomics applied in that order -- the order a serial Warp-CPU launch uses).  Inputs: small scenes built with the in-repo
+ModelBuilder and the contacts of the in-repo C++ checker (collision has its own reference-held known answers); outputs: the
+states after every reference step.  tests/test_reference_vectors.py holds the C++ checker -- and the HIP path on the GPU --
+against these vectors.  Run from the repo root:  python tests/golden/make_xpbd_reference_vectors.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+import lazy_ref  # noqa: E402
+
+lazy_ref.install(dummies={"newton._src.sim": ("Contacts", "Control", "Model", "State", "ModelBuilder")})
+import warp as wp  # noqa: E402  (the shim)
+
+ref = importlib.import_module("newton._src.solvers.xpbd.solver_xpbd")
+
+
+def arr(a, dtype):
+    return wp.to_array(np.asarray(a), dtype)
+
+
+def ref_model(m):
+    """Duck-typed stand-in for newton.Model holding the attributes SolverXPBD reads, as shim arrays."""
+    r = types.SimpleNamespace()
+    r.device = wp.Device()
+    r.requires_grad = False
+    for k in ("particle_count", "spring_count", "edge_count", "tet_count", "tri_count"):
+        setattr(r, k, 0)
+    r.particle_grid = None
+    r.body_count, r.joint_count, r.shape_count = len(m.body_mass), len(m.joint_type), len(m.shape_type)
+    r.world_count = m.world_count
+    r.rigid_contact_count = None
+    r.body_com, r.body_mass, r.body_inv_mass = arr(m.body_com, wp.vec3), arr(m.body_mass, float), arr(m.body_inv_mass, float)
+    r.body_inertia, r.body_inv_inertia = arr(m.body_inertia, wp.mat33), arr(m.body_inv_inertia, wp.mat33)
+    r.body_flags, r.body_world = arr(m.body_flags, int), arr(m.body_world, int)
+    r.gravity = arr(np.asarray(m.gravity).reshape(-1, 3), wp.vec3)
+    for k in ("joint_type", "joint_parent", "joint_child", "joint_q_start", "joint_qd_start", "joint_target_q_start"):
+        setattr(r, k, arr(getattr(m, k), int))
+    r.joint_enabled = arr(np.asarray(m.joint_enabled).astype(bool), bool)
+    dd = np.asarray(m.joint_dof_dim).reshape(-1, 2)
+    r.joint_dof_dim = wp.Array2([[int(a), int(b)] for a, b in dd])
+    r.joint_X_p, r.joint_X_c = arr(m.joint_X_p, wp.transform), arr(m.joint_X_c, wp.transform)
+    r.joint_axis = arr(np.asarray(m.joint_axis).reshape(-1, 3), wp.vec3)
+    for k in ("joint_limit_lower", "joint_limit_upper", "joint_target_ke", "joint_target_kd"):
+        setattr(r, k, arr(getattr(m, k), float))
+    r.shape_body = arr(m.shape_body, int)
+    for k in ("shape_material_mu", "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_restitution"):
+        setattr(r, k, arr(getattr(m, k), float))
+    ctrl = types.SimpleNamespace(joint_f=arr(m.joint_f, float), joint_target_q=arr(m.joint_target_q, float),
+                                 joint_target_qd=arr(m.joint_target_qd, float), tet_activations=None)
+    r.control = lambda clone_variables=False: ctrl
+    r.request_contact_attributes = lambda *a: None
+    return r, ctrl
+
+
+def ref_state(body_q, body_qd, body_f=None):
+    s = types.SimpleNamespace(requires_grad=False, particle_q=None, particle_qd=None, particle_f=None, body_parent_f=None)
+    s.body_q, s.body_qd = arr(body_q, wp.transform), arr(body_qd, wp.spatial_vector)
+    s.body_f = arr(np.zeros((len(body_q), 6), np.float32) if body_f is None else body_f, wp.spatial_vector)
+    return s
+
+
+def ref_contacts(oc, n):
+    """Reference-shaped Contacts from the flat arrays of the in-repo checker's collide (first n rows are live)."""
+    c = types.SimpleNamespace(force=None, rigid_contact_max=max(n, 1), soft_contact_max=0)
+    c.rigid_contact_count = arr(np.array([n]), int)
+    c.rigid_contact_shape0, c.rigid_contact_shape1 = arr(oc["shape0"][:n], int), arr(oc["shape1"][:n], int)
+    for k in ("point0", "point1", "offset0", "offset1", "normal"):
+        setattr(c, "rigid_contact_" + k, arr(oc[k][:n], wp.vec3))
+    c.rigid_contact_margin0, c.rigid_contact_margin1 = arr(oc["margin0"][:n], float), arr(oc["margin1"][:n], float)
+    c.__bool__ = lambda: True
+    return c
+
+
+def to_np(a, n):
+    return np.array([[float(c) for c in x] for x in a], dtype=np.float32).reshape(len(a), n)
+
+
+def run_case(name, model, steps, dt, iterations, joint_f=None, lower=0.0, drop_speed=0.0, **solver_kw):
+    """Teacher-forced: every step starts from the REFERENCE state of the previous step; contacts from the in-repo checker's
+    collide on that state (exactly the arrays a Newton CollisionPipeline would hand to the solver)."""
+    import oracle_bridge as ob
+
+    if joint_f is not None:
+        model.joint_f = np.asarray(joint_f, dtype=np.float32)
+    if lower:
+        import newton_amd as nt
+
+        jq = np.array(model.joint_q, copy=True).reshape(model.world_count, -1)
+        jq[:, 2] -= lower
+        model.joint_q = jq.reshape(-1)
+        model.body_q, model.body_qd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+    if drop_speed:
+        model.body_qd = np.array(model.body_qd, np.float32, copy=True).reshape(-1, 6)
+        model.body_qd[:, 2] = -drop_speed
+    rm, ctrl = ref_model(model)
+    solver = ref.SolverXPBD(rm, iterations=iterations, **solver_kw)
+    q, qd = np.array(model.body_q, np.float32), np.array(model.body_qd, np.float32)
+    out = {"body_q0": q.copy(), "body_qd0": qd.copy()}
+    orc = ob.Oracle(model)
+    for k in range(steps):
+        ct = orc.contacts()
+        orc.collide(q, ct)
+        n = int(ct.count[0])
+        oc = {f: getattr(ct, f) for f in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")}
+        s_in, s_out = ref_state(q, qd), ref_state(q, qd)
+        solver.step(s_in, s_out, None, ref_contacts(oc, n) if n else None, dt)
+        q, qd = to_np(s_out.body_q, 7), to_np(s_out.body_qd, 6)
+        out[f"body_q{k + 1}"], out[f"body_qd{k + 1}"], out[f"contacts{k}"] = q.copy(), qd.copy(), np.array([n])
+        print(name, "step", k, "contacts", n, "max |qd|", float(np.abs(qd).max()), flush=True)
+    return out
+
+
+def main():
+    from scenes import box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene
+
+    cases = {}
+    m = quadruped_scene(2, seed=7)
+    nd = len(m.joint_f)
+    cases["quadruped_standing"] = dict(model=m, steps=6, dt=1e-3, iterations=2, lower=0.22,
+                                       joint_f=0.4 * np.sin(np.arange(nd)).astype(np.float32))
+    cases["quadruped_impact_restitution"] = dict(model=quadruped_scene(1, seed=3), steps=4, dt=1e-3, iterations=2, lower=0.2205,
+                                                 drop_speed=0.8, enable_restitution=True)
+    cases["joint_zoo"] = dict(model=joint_zoo_scene(1, seed=5), steps=5, dt=1e-3, iterations=3, joint_linear_compliance=1e-4,
+                              joint_angular_compliance=2e-4)
+    cases["joint_zoo_free_root"] = dict(model=joint_zoo_scene(1, seed=6, free_root=True), steps=4, dt=2e-3, iterations=2,
+                                        angular_damping=0.1)
+    cases["pendulum"] = dict(model=pendulum_scene(2, seed=2), steps=8, dt=2e-3, iterations=3)
+    cases["box_stack_no_weighting"] = dict(model=box_stack_scene(1, n_boxes=3, seed=1, jitter=2e-3), steps=4, dt=1.0 / 240.0,
+                                           iterations=4, rigid_contact_con_weighting=False, angular_damping=0.05)
+    blob = {}
+    for name, kw in cases.items():
+        model = kw.pop("model")
+        res = run_case(name, model, **kw)
+        for k, v in res.items():
+            blob[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "xpbd_reference_vectors.npz"), **blob)
+    print("wrote", len(blob), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,768 @@
+"""TEST INFRASTRUCTURE (fixture generation only) -- a pure-Python stand-in for the part of the warp-lang API that Newton's
+rigid-body solver kernels use, so that the REFERENCE kernel source under /root/reference can be executed here, thread by
+thread in ascending tid order, on small cases (tests/golden/make_*_reference_vectors.py).  warp-lang itself is not vendored
+with the reference and not installable in this container.
+
+Scalars are numpy float32 (every +, -, *, / and sqrt rounds to fp32 once, like the fp32 code Warp generates without
+contraction); the vector / quaternion / transform builtins follow the same operation order as oracle/wp_builtins.h, which
+restates Warp's native headers (vec.h, quat.h, mat.h, spatial.h).  Not a general Warp emulator: no codegen, no tapes, no
+devices; anything outside the listed API returns an inert placeholder so that importing reference modules does not fail."""
+import math as _math
+import sys as _sys
+import types as _types
+
+import numpy as _np
+
+f32 = _np.float32
+float32 = _np.float32
+float64 = _np.float64
+int32 = _np.int32
+int64 = _np.int64
+uint32 = _np.uint32
+uint64 = _np.uint64
+uint8 = _np.uint8
+int8 = _np.int8
+int16 = _np.int16
+uint16 = _np.uint16
+bool = bool  # noqa: A001
+pi = f32(_math.pi)
+PI = pi
+inf = f32(_np.inf)
+
+
+def _s(x):
+    return x if isinstance(x, _np.float32) else f32(x)
+
+
+# ------------------------------------------------------------------------------------------------ vectors
+class vec3:
+    __slots__ = ("x", "y", "z")
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            self.x = self.y = self.z = f32(0.0)
+        elif len(a) == 1:
+            if isinstance(a[0], vec3):
+                self.x, self.y, self.z = a[0].x, a[0].y, a[0].z
+            elif hasattr(a[0], "__len__"):
+                self.x, self.y, self.z = _s(a[0][0]), _s(a[0][1]), _s(a[0][2])
+            else:
+                self.x = self.y = self.z = _s(a[0])
+        else:
+            self.x, self.y, self.z = _s(a[0]), _s(a[1]), _s(a[2])
+
+    def __add__(self, o): return vec3(self.x + o.x, self.y + o.y, self.z + o.z)
+    def __sub__(self, o): return vec3(self.x - o.x, self.y - o.y, self.z - o.z)
+    def __neg__(self): return vec3(-self.x, -self.y, -self.z)
+    def __pos__(self): return self
+    def __mul__(self, s): return vec3(self.x * _s(s), self.y * _s(s), self.z * _s(s))
+    def __rmul__(self, s): return vec3(self.x * _s(s), self.y * _s(s), self.z * _s(s))
+    def __truediv__(self, s): return vec3(self.x / _s(s), self.y / _s(s), self.z / _s(s))
+    def __getitem__(self, i): return (self.x, self.y, self.z)[i]
+    def __setitem__(self, i, v): setattr(self, "xyz"[i], _s(v))
+    def __len__(self): return 3
+    def __iter__(self): return iter((self.x, self.y, self.z))
+    def __eq__(self, o): return isinstance(o, vec3) and self.x == o.x and self.y == o.y and self.z == o.z
+    def __repr__(self): return f"vec3({self.x}, {self.y}, {self.z})"
+    __hash__ = None
+
+
+vec3f = vec3
+
+
+class vec2:
+    __slots__ = ("x", "y")
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            self.x = self.y = f32(0.0)
+        elif len(a) == 1:
+            self.x = self.y = _s(a[0])
+        else:
+            self.x, self.y = _s(a[0]), _s(a[1])
+
+    def __add__(self, o): return vec2(self.x + o.x, self.y + o.y)
+    def __sub__(self, o): return vec2(self.x - o.x, self.y - o.y)
+    def __mul__(self, s): return vec2(self.x * _s(s), self.y * _s(s))
+    __rmul__ = __mul__
+    def __getitem__(self, i): return (self.x, self.y)[i]
+    def __setitem__(self, i, v): setattr(self, "xy"[i], _s(v))
+
+
+class _ivec:
+    def __init__(self, *a):
+        self.v = [int(x) for x in a] if a else [0] * self.N
+
+    def __getitem__(self, i): return self.v[i]
+    def __setitem__(self, i, x): self.v[i] = int(x)
+    def __len__(self): return self.N
+
+
+class vec2i(_ivec): N = 2
+class vec3i(_ivec): N = 3
+class vec4i(_ivec): N = 4
+
+
+def dot(a, b):
+    if isinstance(a, quat):
+        return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w
+    if isinstance(a, spatial_vector):
+        r = a.v[0] * b.v[0]
+        for k in range(1, 6):
+            r = r + a.v[k] * b.v[k]
+        return r
+    if isinstance(a, vec2):
+        return a.x * b.x + a.y * b.y
+    return a.x * b.x + a.y * b.y + a.z * b.z
+
+
+def cross(a, b): return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x)
+def length_sq(a): return dot(a, a)
+def length(a): return _np.sqrt(dot(a, a))
+
+
+def normalize(a):
+    l = length(a)
+    if isinstance(a, quat):
+        if l > 0.0:
+            inv = f32(1.0) / l
+            return a * inv
+        return quat(0.0, 0.0, 0.0, 1.0)
+    if l > 0.0:
+        return a / l
+    return vec3()
+
+
+def cw_mul(a, b): return vec3(a.x * b.x, a.y * b.y, a.z * b.z)
+def cw_div(a, b): return vec3(a.x / b.x, a.y / b.y, a.z / b.z)
+
+
+def _scalar_or(a, b, fs, fv):
+    if isinstance(a, vec3):
+        return vec3(fs(a.x, b.x), fs(a.y, b.y), fs(a.z, b.z))
+    return fs(a, b)
+
+
+def min(a, b=None):  # noqa: A001
+    if b is None:
+        m = a[0]
+        for k in range(1, len(a)):
+            m = a[k] if a[k] < m else m
+        return m
+    return _scalar_or(a, b, lambda x, y: x if x < y else y, None)
+
+
+def max(a, b=None):  # noqa: A001
+    if b is None:
+        m = a[0]
+        for k in range(1, len(a)):
+            m = a[k] if a[k] > m else m
+        return m
+    return _scalar_or(a, b, lambda x, y: x if x > y else y, None)
+
+
+def abs(a):  # noqa: A001
+    if isinstance(a, vec3):
+        return vec3(_np.abs(a.x), _np.abs(a.y), _np.abs(a.z))
+    return _np.abs(a) if isinstance(a, _np.floating) else __builtins__["abs"](a)
+
+
+def clamp(x, lo, hi): return min(max(x, lo), hi)
+def sign(x): return f32(-1.0) if x < 0.0 else f32(1.0)
+def nonzero(x): return f32(1.0) if x != 0.0 else f32(0.0)
+def step(x): return f32(1.0) if x < 0.0 else f32(0.0)
+def sqrt(x): return _np.sqrt(_s(x))
+def sin(x): return _np.sin(_s(x))
+def cos(x): return _np.cos(_s(x))
+def tan(x): return _np.tan(_s(x))
+def asin(x): return _np.arcsin(_s(x))
+def acos(x): return _np.arccos(_s(x))
+def atan(x): return _np.arctan(_s(x))
+def atan2(y, x): return _np.arctan2(_s(y), _s(x))
+def exp(x): return _np.exp(_s(x))
+def log(x): return _np.log(_s(x))
+def pow(x, y): return _np.power(_s(x), _s(y))  # noqa: A001
+def floor(x): return _np.floor(_s(x))
+def mod(a, b): return _np.fmod(a, b)
+def isnan(x): return _np.isnan(x)
+def isfinite(x): return _np.isfinite(x)
+def where(c, a, b): return a if c else b
+def select(c, a, b): return b if c else a
+def static(x): return x
+def mul(a, b): return a * b
+def printf(*a): pass
+
+
+# ------------------------------------------------------------------------------------------------ quaternions
+class quat:
+    __slots__ = ("x", "y", "z", "w")
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            self.x = self.y = self.z = self.w = f32(0.0)
+        elif len(a) == 2:
+            self.x, self.y, self.z, self.w = a[0].x, a[0].y, a[0].z, _s(a[1])
+        elif len(a) == 1:
+            q = a[0]
+            self.x, self.y, self.z, self.w = _s(q[0]), _s(q[1]), _s(q[2]), _s(q[3])
+        else:
+            self.x, self.y, self.z, self.w = _s(a[0]), _s(a[1]), _s(a[2]), _s(a[3])
+
+    def __add__(self, o): return quat(self.x + o.x, self.y + o.y, self.z + o.z, self.w + o.w)
+    def __sub__(self, o): return quat(self.x - o.x, self.y - o.y, self.z - o.z, self.w - o.w)
+    def __neg__(self): return quat(-self.x, -self.y, -self.z, -self.w)
+
+    def __mul__(self, b):
+        if isinstance(b, quat):
+            a = self  # Hamilton product, warp quat.h mul(quat, quat)
+            return quat(a.w * b.x + b.w * a.x + a.y * b.z - b.y * a.z,
+                        a.w * b.y + b.w * a.y + a.z * b.x - b.z * a.x,
+                        a.w * b.z + b.w * a.z + a.x * b.y - b.x * a.y,
+                        a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z)
+        s = _s(b)
+        return quat(self.x * s, self.y * s, self.z * s, self.w * s)
+
+    def __rmul__(self, s):
+        s = _s(s)
+        return quat(self.x * s, self.y * s, self.z * s, self.w * s)
+
+    def __getitem__(self, i): return (self.x, self.y, self.z, self.w)[i]
+    def __setitem__(self, i, v): setattr(self, "xyzw"[i], _s(v))
+    def __len__(self): return 4
+    def __iter__(self): return iter((self.x, self.y, self.z, self.w))
+    def __repr__(self): return f"quat({self.x}, {self.y}, {self.z}, {self.w})"
+
+
+quatf = quat
+
+
+def quat_identity(dtype=None): return quat(0.0, 0.0, 0.0, 1.0)
+def quat_inverse(q): return quat(-q.x, -q.y, -q.z, q.w)
+
+
+def quat_rotate(q, v):
+    qv = vec3(q.x, q.y, q.z)
+    return v * (f32(2.0) * q.w * q.w - f32(1.0)) + cross(qv, v) * q.w * f32(2.0) + qv * dot(qv, v) * f32(2.0)
+
+
+def quat_rotate_inv(q, v):
+    qv = vec3(q.x, q.y, q.z)
+    return v * (f32(2.0) * q.w * q.w - f32(1.0)) - cross(qv, v) * q.w * f32(2.0) + qv * dot(qv, v) * f32(2.0)
+
+
+def quat_from_axis_angle(axis, angle):
+    half = _s(angle) * f32(0.5)
+    w = _np.cos(half)
+    s = _np.sin(half)
+    v = axis * s
+    return quat(v.x, v.y, v.z, w)
+
+
+def quat_to_matrix(q):
+    return matrix_from_cols(quat_rotate(q, vec3(1.0, 0.0, 0.0)), quat_rotate(q, vec3(0.0, 1.0, 0.0)),
+                            quat_rotate(q, vec3(0.0, 0.0, 1.0)))
+
+
+def quat_to_axis_angle(q):
+    v = vec3(q.x, q.y, q.z)
+    axis = normalize(v) if q.w >= 0.0 else -normalize(v)
+    angle = f32(2.0) * _np.arctan2(length(v), _np.abs(q.w))
+    return axis, angle
+
+
+# ------------------------------------------------------------------------------------------------ matrices
+class mat33:
+    __slots__ = ("m",)
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            self.m = [[f32(0.0)] * 3 for _ in range(3)]
+        elif len(a) == 1 and not hasattr(a[0], "__len__"):
+            self.m = [[_s(a[0])] * 3 for _ in range(3)]
+        elif len(a) == 9:
+            self.m = [[_s(a[3 * i + j]) for j in range(3)] for i in range(3)]
+        elif len(a) == 3:  # three row vectors
+            self.m = [[_s(a[i][j]) for j in range(3)] for i in range(3)]
+        else:
+            flat = list(a[0])
+            if len(flat) == 3:
+                self.m = [[_s(flat[i][j]) for j in range(3)] for i in range(3)]
+            else:
+                self.m = [[_s(flat[3 * i + j]) for j in range(3)] for i in range(3)]
+
+    def __getitem__(self, ij):
+        if isinstance(ij, tuple):
+            return self.m[ij[0]][ij[1]]
+        return vec3(*self.m[ij])
+
+    def __setitem__(self, ij, v):
+        if isinstance(ij, tuple):
+            self.m[ij[0]][ij[1]] = _s(v)
+        else:
+            self.m[ij] = [_s(v[0]), _s(v[1]), _s(v[2])]
+
+    def __mul__(self, o):
+        A = self.m
+        if isinstance(o, vec3):
+            return vec3(A[0][0] * o.x + A[0][1] * o.y + A[0][2] * o.z, A[1][0] * o.x + A[1][1] * o.y + A[1][2] * o.z,
+                        A[2][0] * o.x + A[2][1] * o.y + A[2][2] * o.z)
+        if isinstance(o, mat33):
+            C = mat33()
+            for i in range(3):
+                for j in range(3):
+                    s = f32(0.0)
+                    for k in range(3):
+                        s = s + A[i][k] * o.m[k][j]
+                    C.m[i][j] = s
+            return C
+        s = _s(o)
+        return mat33(*[A[i][j] * s for i in range(3) for j in range(3)])
+
+    __matmul__ = __mul__
+
+    def __rmul__(self, s):
+        s = _s(s)
+        return mat33(*[self.m[i][j] * s for i in range(3) for j in range(3)])
+
+    def __add__(self, o): return mat33(*[self.m[i][j] + o.m[i][j] for i in range(3) for j in range(3)])
+    def __sub__(self, o): return mat33(*[self.m[i][j] - o.m[i][j] for i in range(3) for j in range(3)])
+    def __neg__(self): return mat33(*[-self.m[i][j] for i in range(3) for j in range(3)])
+
+
+mat33f = mat33
+
+
+def transpose(A): return mat33(*[A.m[j][i] for i in range(3) for j in range(3)])
+def matrix_from_cols(c0, c1, c2): return mat33(c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z)
+def matrix_from_rows(r0, r1, r2): return mat33(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z)
+def skew(v): return mat33(0.0, -v.z, v.y, v.z, 0.0, -v.x, -v.y, v.x, 0.0)
+def diag(v): return mat33(v.x, 0.0, 0.0, 0.0, v.y, 0.0, 0.0, 0.0, v.z)
+def outer(a, b): return mat33(*[a[i] * b[j] for i in range(3) for j in range(3)])
+
+
+def identity(n=3, dtype=None):
+    return mat33(1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+
+
+def determinant(A):
+    m = A.m
+    return (m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+            + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]))
+
+
+# ------------------------------------------------------------------------------------------------ transforms
+class transform:
+    __slots__ = ("p", "q")
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__
+
+    def __init__(self, *a, p=None, q=None):
+        if len(a) == 2:
+            self.p, self.q = vec3(a[0]), quat(*a[1]) if not isinstance(a[1], quat) else quat(a[1].x, a[1].y, a[1].z, a[1].w)
+        elif len(a) == 7:
+            self.p, self.q = vec3(a[0], a[1], a[2]), quat(a[3], a[4], a[5], a[6])
+        elif len(a) == 1:
+            t = a[0]
+            self.p, self.q = vec3(t[0], t[1], t[2]), quat(t[3], t[4], t[5], t[6])
+        else:
+            self.p = vec3(p) if p is not None else vec3()
+            self.q = quat(q.x, q.y, q.z, q.w) if q is not None else quat(0.0, 0.0, 0.0, 1.0)
+
+    def __mul__(self, b): return transform(quat_rotate(self.q, b.p) + self.p, self.q * b.q)
+    def __getitem__(self, i): return (self.p.x, self.p.y, self.p.z, self.q.x, self.q.y, self.q.z, self.q.w)[i]
+    def __len__(self): return 7
+    def __iter__(self): return iter([self[i] for i in range(7)])
+    def __repr__(self): return f"transform({self.p}, {self.q})"
+
+
+transformf = transform
+
+
+def transform_identity(dtype=None): return transform()
+def transform_get_translation(t): return t.p
+def transform_get_rotation(t): return t.q
+def transform_multiply(a, b): return a * b
+def transform_point(t, x): return t.p + quat_rotate(t.q, x)
+def transform_vector(t, x): return quat_rotate(t.q, x)
+
+
+def transform_inverse(t):
+    qi = quat_inverse(t.q)
+    return transform(-quat_rotate(qi, t.p), qi)
+
+
+# ------------------------------------------------------------------------------------------------ spatial vectors
+class spatial_vector:
+    __slots__ = ("v",)
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            self.v = [f32(0.0)] * 6
+        elif len(a) == 2:
+            self.v = [a[0].x, a[0].y, a[0].z, a[1].x, a[1].y, a[1].z]
+        elif len(a) == 1:
+            if hasattr(a[0], "__len__"):
+                self.v = [_s(x) for x in a[0]]
+            else:
+                self.v = [_s(a[0])] * 6
+        else:
+            self.v = [_s(x) for x in a]
+
+    def __add__(self, o): return spatial_vector(*[self.v[k] + o.v[k] for k in range(6)])
+    def __sub__(self, o): return spatial_vector(*[self.v[k] - o.v[k] for k in range(6)])
+    def __neg__(self): return spatial_vector(*[-self.v[k] for k in range(6)])
+    def __mul__(self, s): return spatial_vector(*[self.v[k] * _s(s) for k in range(6)])
+    __rmul__ = __mul__
+    def __truediv__(self, s): return spatial_vector(*[self.v[k] / _s(s) for k in range(6)])
+    def __getitem__(self, i): return self.v[i]
+    def __setitem__(self, i, x): self.v[i] = _s(x)
+    def __len__(self): return 6
+    def __iter__(self): return iter(self.v)
+    def __repr__(self): return f"spatial_vector({[float(x) for x in self.v]})"
+
+
+spatial_vectorf = spatial_vector
+
+
+def spatial_top(s): return vec3(s.v[0], s.v[1], s.v[2])
+def spatial_bottom(s): return vec3(s.v[3], s.v[4], s.v[5])
+
+
+# ------------------------------------------------------------------------------------------------ arrays, kernels, launch
+class _ArrayType:
+    """wp.array(dtype=...) in an annotation, or wp.array(data, dtype=...) at run time (-> a python list of shim values)."""
+
+    def __call__(self, data=None, dtype=None, ndim=1, **kw):
+        if data is None:
+            return self
+        return to_array(data, dtype)
+
+    def __getitem__(self, k):
+        return self
+
+    def __or__(self, o):
+        return self
+
+    def __ror__(self, o):
+        return self
+
+
+array = _ArrayType()
+array1d = array2d = array3d = array4d = array
+indexedarray = fabricarray = array
+
+
+class Array(list):
+    """1-d device array stand-in: a list of shim values (float32 / int / vec3 / quat / transform / ...)."""
+
+    dtype = None
+    device = "cpu"
+    requires_grad = False
+
+    @property
+    def shape(self): return (len(self),)
+
+    @property
+    def size(self): return len(self)
+
+    @property
+    def ptr(self): return id(self)
+
+    def numpy(self):
+        if len(self) and hasattr(self[0], "__iter__"):
+            return _np.array([[float(c) for c in x] for x in self], dtype=_np.float32)
+        return _np.array(list(self))
+
+    def zero_(self):
+        for i in range(len(self)):
+            self[i] = _zero_like(self[i])
+
+    def fill_(self, v):
+        for i in range(len(self)):
+            self[i] = v
+
+    def assign(self, o):
+        for i in range(len(self)):
+            self[i] = o[i]
+
+
+class Array2(Array):
+    """2-d array: list of rows; a[i, j] and a[i][j] both work."""
+
+    def __getitem__(self, ij):
+        if isinstance(ij, tuple):
+            return list.__getitem__(self, ij[0])[ij[1]]
+        return list.__getitem__(self, ij)
+
+    def __setitem__(self, ij, v):
+        if isinstance(ij, tuple):
+            list.__getitem__(self, ij[0])[ij[1]] = v
+        else:
+            list.__setitem__(self, ij, v)
+
+    @property
+    def shape(self): return (len(self), len(list.__getitem__(self, 0)) if len(self) else 0)
+
+
+def _zero_of(dtype):
+    if dtype in (float, float32, None):
+        return f32(0.0)
+    if dtype in (int, int32, int64, uint32, uint64, uint8):
+        return 0
+    if dtype is bool:
+        return False
+    return dtype()
+
+
+def _zero_like(v):
+    if isinstance(v, (vec3, quat, spatial_vector, mat33, vec2)):
+        return type(v)()
+    if isinstance(v, transform):
+        return transform(vec3(), quat())
+    if isinstance(v, (_np.floating, float)):
+        return f32(0.0)
+    return type(v)(0)
+
+
+def to_array(data, dtype=None):
+    out = Array()
+    data = _np.asarray(data) if not isinstance(data, list) else data
+    for x in data:
+        if dtype in (vec3,):
+            out.append(vec3(x[0], x[1], x[2]))
+        elif dtype is quat:
+            out.append(quat(x[0], x[1], x[2], x[3]))
+        elif dtype is transform:
+            out.append(transform(*[x[k] for k in range(7)]))
+        elif dtype is spatial_vector:
+            out.append(spatial_vector(*[x[k] for k in range(6)]))
+        elif dtype is mat33:
+            out.append(mat33(*_np.asarray(x).reshape(-1)))
+        elif dtype in (float, float32, None) and _np.asarray(x).dtype.kind == "f":
+            out.append(f32(x))
+        elif dtype is bool:
+            out.append(bool(x))
+        else:
+            out.append(int(x))
+    out.dtype = dtype
+    return out
+
+
+def zeros(shape=None, dtype=float, device=None, requires_grad=False, **kw):
+    if isinstance(shape, (tuple, list)) and len(shape) == 2:
+        out = Array2([[_zero_of(dtype) for _ in range(shape[1])] for _ in range(shape[0])])
+    else:
+        n = shape[0] if isinstance(shape, (tuple, list)) else int(shape)
+        out = Array([_zero_of(dtype) for _ in range(n)])
+    out.dtype = dtype
+    return out
+
+
+empty = zeros
+
+
+def full(shape=None, value=0, dtype=float, device=None, **kw):
+    out = zeros(shape, dtype)
+    for i in range(len(out)):
+        out[i] = value
+    return out
+
+
+def zeros_like(a, **kw):
+    out = type(a)([_zero_like(x) if not isinstance(x, list) else [_zero_like(y) for y in x] for x in a])
+    out.dtype = a.dtype
+    return out
+
+
+empty_like = zeros_like
+
+
+def clone(a, **kw):
+    import copy
+
+    out = type(a)(copy.deepcopy(list(a)))
+    out.dtype = a.dtype
+    return out
+
+
+def copy(dest, src, **kw):
+    import copy as _c
+
+    for i in range(len(src)):
+        dest[i] = _c.deepcopy(src[i])
+
+
+_tid = [0]
+
+
+def tid():
+    t = _tid[0]
+    return t
+
+
+def launch(kernel=None, dim=None, inputs=(), outputs=(), device=None, **kw):
+    fn = getattr(kernel, "__wrapped_kernel__", kernel)
+    n = dim if isinstance(dim, int) else dim[0] if len(dim) == 1 else dim
+    args = [f32(a) if isinstance(a, float) else a for a in list(inputs) + list(outputs)]  # kernel scalars are fp32
+    if isinstance(n, int):
+        for t in range(n):
+            _tid[0] = t
+            fn(*args)
+    else:
+        import itertools
+
+        for t in itertools.product(*[range(k) for k in n]):
+            _tid[0] = t
+            fn(*args)
+
+
+def _index(arr, idx):
+    return idx
+
+
+def atomic_add(arr, *a):
+    *idx, value = a
+    idx = idx[0] if len(idx) == 1 else tuple(idx)
+    old = arr[idx]
+    arr[idx] = old + value
+    return old
+
+
+def atomic_sub(arr, *a):
+    *idx, value = a
+    idx = idx[0] if len(idx) == 1 else tuple(idx)
+    old = arr[idx]
+    arr[idx] = old - value
+    return old
+
+
+def atomic_max(arr, i, value):
+    old = arr[i]
+    arr[i] = value if value > old else old
+    return old
+
+
+def atomic_min(arr, i, value):
+    old = arr[i]
+    arr[i] = value if value < old else old
+    return old
+
+
+_VALUE_TYPES = ()  # filled below: vec3, vec2, quat, mat33, transform, spatial_vector
+
+
+def _val(x):
+    """Value semantics of Warp's math types: a fresh copy for shim value types, anything else unchanged."""
+    if isinstance(x, _VALUE_TYPES):
+        import copy as _c
+
+        return _c.deepcopy(x)
+    return x
+
+
+def _by_value(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def call(*a, **k):
+        return fn(*[_val(x) for x in a], **{n: _val(v) for n, v in k.items()})
+
+    return call
+
+
+def _decorator(fn=None, **kw):
+    if fn is None:
+        return lambda f: _by_value(f)
+    return _by_value(fn)
+
+
+kernel = _decorator
+func = _decorator
+func_native = _decorator
+
+
+def struct(cls):
+    ann = dict(getattr(cls, "__annotations__", {}))
+
+    def __init__(self, **kw):
+        for k, t in ann.items():
+            setattr(self, k, _zero_of(t) if not isinstance(t, _ArrayType) else None)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    cls.__init__ = __init__
+    return cls
+
+
+_VALUE_TYPES = (vec3, vec2, quat, mat33, transform, spatial_vector)
+
+
+def constant(x): return x
+def overload(fn, *a, **k): return fn
+
+
+class ScopedTimer:
+    def __init__(self, *a, **k): pass
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+ScopedDevice = ScopedTimer
+ScopedStream = ScopedTimer
+
+
+class Device:
+    is_cuda = False
+    is_cpu = True
+    alias = "cpu"
+
+
+def get_device(*a, **k): return Device()
+def get_preferred_device(): return Device()
+def set_module_options(*a, **k): pass
+def get_module_options(*a, **k): return {}
+def init(): pass
+def synchronize(): pass
+
+
+class _Inert:
+    """Anything else the reference touches at import time."""
+
+    def __init__(self, name): self._n = name
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return _Inert(self._n + "()")
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Inert(self._n + "." + k)
+    def __getitem__(self, k): return self
+    def __or__(self, o): return self
+    def __ror__(self, o): return self
+    def __mro_entries__(self, bases): return (object,)
+    def __iter__(self): return iter(())
+
+
+def __getattr__(name):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    return _Inert("wp." + name)
+
+
+class _Sub(_types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Inert(self.__name__ + "." + k)
+
+
+for _n in ("types", "context", "config", "utils", "sim", "render", "sparse", "fem", "optim", "torch", "jax", "build",
+           "codegen", "math", "autograd", "_src", "_src.types", "_src.context", "_src.utils", "_src.codegen"):
+    _m = _Sub("warp." + _n)
+    _sys.modules["warp." + _n] = _m
+    setattr(_sys.modules[__name__], _n.split(".")[0], _sys.modules["warp." + _n.split(".")[0]])
