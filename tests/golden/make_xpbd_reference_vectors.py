@@ -27,6 +27,7 @@ lazy_ref.install(dummies={"newton._src.sim": ("Contacts", "Control", "Model", "S
 import warp as wp  # noqa: E402  (the shim)
 
 ref = importlib.import_module("newton._src.solvers.xpbd.solver_xpbd")
+ref_semi = importlib.import_module("newton._src.solvers.semi_implicit.solver_semi_implicit")
 
 
 def arr(a, dtype):
@@ -58,8 +59,13 @@ def ref_model(m):
     for k in ("joint_limit_lower", "joint_limit_upper", "joint_target_ke", "joint_target_kd"):
         setattr(r, k, arr(getattr(m, k), float))
     r.shape_body = arr(m.shape_body, int)
-    for k in ("shape_material_mu", "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_restitution"):
+    for k in ("shape_material_mu", "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_restitution",
+              "shape_material_ke", "shape_material_kd", "shape_material_kf", "shape_material_ka", "joint_limit_ke", "joint_limit_kd",
+              "joint_armature", "joint_damping"):
         setattr(r, k, arr(getattr(m, k), float))
+    r.joint_q, r.joint_qd = arr(m.joint_q, float), arr(m.joint_qd, float)
+    r.joint_dof_count, r.joint_coord_count = m.joint_dof_count, m.joint_coord_count
+    r.particle_max_radius = r.particle_cohesion = 0.0
     ctrl = types.SimpleNamespace(joint_f=arr(m.joint_f, float), joint_target_q=arr(m.joint_target_q, float),
                                  joint_target_qd=arr(m.joint_target_qd, float), tet_activations=None)
     r.control = lambda clone_variables=False: ctrl
@@ -68,13 +74,14 @@ def ref_model(m):
 
 
 def ref_state(body_q, body_qd, body_f=None):
-    s = types.SimpleNamespace(requires_grad=False, particle_q=None, particle_qd=None, particle_f=None, body_parent_f=None)
+    s = types.SimpleNamespace(requires_grad=False, particle_q=None, particle_qd=None, particle_f=None, body_parent_f=None,
+                              particle_count=0, body_count=len(body_q))
     s.body_q, s.body_qd = arr(body_q, wp.transform), arr(body_qd, wp.spatial_vector)
     s.body_f = arr(np.zeros((len(body_q), 6), np.float32) if body_f is None else body_f, wp.spatial_vector)
     return s
 
 
-def ref_contacts(oc, n):
+def ref_contacts(oc, n, props=None):
     """Reference-shaped Contacts from the flat arrays of the in-repo checker's collide (first n rows are live)."""
     c = types.SimpleNamespace(force=None, rigid_contact_max=max(n, 1), soft_contact_max=0)
     c.rigid_contact_count = arr(np.array([n]), int)
@@ -82,6 +89,10 @@ def ref_contacts(oc, n):
     for k in ("point0", "point1", "offset0", "offset1", "normal"):
         setattr(c, "rigid_contact_" + k, arr(oc[k][:n], wp.vec3))
     c.rigid_contact_margin0, c.rigid_contact_margin1 = arr(oc["margin0"][:n], float), arr(oc["margin1"][:n], float)
+    c.rigid_contact_stiffness = c.rigid_contact_damping = c.rigid_contact_friction = None
+    if props is not None:  # per-contact overrides (contacts.py:227-277), the same value on every contact
+        c.rigid_contact_stiffness, c.rigid_contact_damping = arr(np.full(n, props[0]), float), arr(np.full(n, props[1]), float)
+        c.rigid_contact_friction = arr(np.full(n, props[2]), float)
     c.__bool__ = lambda: True
     return c
 
@@ -90,35 +101,28 @@ def to_np(a, n):
     return np.array([[float(c) for c in x] for x in a], dtype=np.float32).reshape(len(a), n)
 
 
-def run_case(name, model, steps, dt, iterations, joint_f=None, lower=0.0, drop_speed=0.0, **solver_kw):
+def run_case(name, case):
     """Teacher-forced: every step starts from the REFERENCE state of the previous step; contacts from the in-repo checker's
     collide on that state (exactly the arrays a Newton CollisionPipeline would hand to the solver)."""
     import oracle_bridge as ob
+    import reference_cases as rc
 
-    if joint_f is not None:
-        model.joint_f = np.asarray(joint_f, dtype=np.float32)
-    if lower:
-        import newton_amd as nt
-
-        jq = np.array(model.joint_q, copy=True).reshape(model.world_count, -1)
-        jq[:, 2] -= lower
-        model.joint_q = jq.reshape(-1)
-        model.body_q, model.body_qd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
-    if drop_speed:
-        model.body_qd = np.array(model.body_qd, np.float32, copy=True).reshape(-1, 6)
-        model.body_qd[:, 2] = -drop_speed
+    model = rc.prepare(case)
     rm, ctrl = ref_model(model)
-    solver = ref.SolverXPBD(rm, iterations=iterations, **solver_kw)
-    q, qd = np.array(model.body_q, np.float32), np.array(model.body_qd, np.float32)
+    if case.get("solver", "xpbd") == "xpbd":
+        solver = ref.SolverXPBD(rm, **case["kw"])
+    else:
+        solver = ref_semi.SolverSemiImplicit(rm, **case["kw"])
+    q, qd = np.array(model.body_q, np.float32).reshape(-1, 7), np.array(model.body_qd, np.float32).reshape(-1, 6)
     out = {"body_q0": q.copy(), "body_qd0": qd.copy()}
     orc = ob.Oracle(model)
-    for k in range(steps):
+    for k in range(case["steps"]):
         ct = orc.contacts()
         orc.collide(q, ct)
         n = int(ct.count[0])
         oc = {f: getattr(ct, f) for f in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")}
         s_in, s_out = ref_state(q, qd), ref_state(q, qd)
-        solver.step(s_in, s_out, None, ref_contacts(oc, n) if n else None, dt)
+        solver.step(s_in, s_out, None, ref_contacts(oc, n, case.get("props")) if n else None, case["dt"])
         q, qd = to_np(s_out.body_q, 7), to_np(s_out.body_qd, 6)
         out[f"body_q{k + 1}"], out[f"body_qd{k + 1}"], out[f"contacts{k}"] = q.copy(), qd.copy(), np.array([n])
         print(name, "step", k, "contacts", n, "max |qd|", float(np.abs(qd).max()), flush=True)
@@ -126,27 +130,12 @@ def run_case(name, model, steps, dt, iterations, joint_f=None, lower=0.0, drop_s
 
 
 def main():
-    from scenes import box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene
+    sys.path.insert(0, HERE)
+    import reference_cases as rc
 
-    cases = {}
-    m = quadruped_scene(2, seed=7)
-    nd = len(m.joint_f)
-    cases["quadruped_standing"] = dict(model=m, steps=6, dt=1e-3, iterations=2, lower=0.22,
-                                       joint_f=0.4 * np.sin(np.arange(nd)).astype(np.float32))
-    cases["quadruped_impact_restitution"] = dict(model=quadruped_scene(1, seed=3), steps=4, dt=1e-3, iterations=2, lower=0.2205,
-                                                 drop_speed=0.8, enable_restitution=True)
-    cases["joint_zoo"] = dict(model=joint_zoo_scene(1, seed=5), steps=5, dt=1e-3, iterations=3, joint_linear_compliance=1e-4,
-                              joint_angular_compliance=2e-4)
-    cases["joint_zoo_free_root"] = dict(model=joint_zoo_scene(1, seed=6, free_root=True), steps=4, dt=2e-3, iterations=2,
-                                        angular_damping=0.1)
-    cases["pendulum"] = dict(model=pendulum_scene(2, seed=2), steps=8, dt=2e-3, iterations=3)
-    cases["box_stack_no_weighting"] = dict(model=box_stack_scene(1, n_boxes=3, seed=1, jitter=2e-3), steps=4, dt=1.0 / 240.0,
-                                           iterations=4, rigid_contact_con_weighting=False, angular_damping=0.05)
     blob = {}
-    for name, kw in cases.items():
-        model = kw.pop("model")
-        res = run_case(name, model, **kw)
-        for k, v in res.items():
+    for name, case in rc.cases().items():
+        for k, v in run_case(name, case).items():
             blob[f"{name}/{k}"] = v
     np.savez_compressed(os.path.join(HERE, "xpbd_reference_vectors.npz"), **blob)
     print("wrote", len(blob), "arrays")

@@ -1,0 +1,60 @@
+"""Case table shared by tests/golden/make_xpbd_reference_vectors.py (which runs the REFERENCE solver source on these cases) and
+tests/test_reference_vectors.py / the GPU twin (which hold the checker and the HIP path against the recorded vectors)."""
+import numpy as np
+
+
+def _scenes():
+    from scenes import box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene
+
+    return box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene
+
+
+def cases():
+    box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene = _scenes()
+    sin_f = lambda nd: 0.4 * np.sin(np.arange(nd)).astype(np.float32)  # noqa: E731
+    return {
+        # ---- SolverXPBD (solver_xpbd.py:329-862)
+        "quadruped_standing": dict(scene=lambda: quadruped_scene(2, seed=7), steps=6, dt=1e-3, kw=dict(iterations=2), lower=0.22,
+                                   joint_f=sin_f),
+        "quadruped_impact_restitution": dict(scene=lambda: quadruped_scene(1, seed=3), steps=4, dt=1e-3,
+                                             kw=dict(iterations=2, enable_restitution=True), lower=0.2205, drop_speed=0.8),
+        "pendulum": dict(scene=lambda: pendulum_scene(2, seed=2), steps=8, dt=2e-3, kw=dict(iterations=3)),
+        "joint_zoo": dict(scene=lambda: joint_zoo_scene(1, seed=5), steps=5, dt=1e-3,
+                          kw=dict(iterations=3, joint_linear_compliance=1e-4, joint_angular_compliance=2e-4)),
+        "joint_zoo_free_root": dict(scene=lambda: joint_zoo_scene(1, seed=6, free_root=True), steps=4, dt=2e-3,
+                                    kw=dict(iterations=2, angular_damping=0.1)),
+        "box_stack_no_weighting": dict(scene=lambda: box_stack_scene(1, n_boxes=3, seed=1, jitter=2e-3), steps=4, dt=1.0 / 240.0,
+                                       kw=dict(iterations=4, rigid_contact_con_weighting=False, angular_damping=0.05)),
+        "box_stack_sunk_restitution": dict(scene=lambda: box_stack_scene(1, n_boxes=3, seed=4, jitter=2e-3), steps=3, dt=1.0 / 240.0,
+                                           kw=dict(iterations=2, enable_restitution=True), sink=0.002, drop_speed=0.3),
+        # ---- SolverSemiImplicit (solver_semi_implicit.py:123-217)
+        "semi/pendulum": dict(scene=lambda: pendulum_scene(2, seed=4), steps=6, dt=5e-4, solver="semi_implicit", kw={}),
+        "semi/joint_zoo": dict(scene=lambda: joint_zoo_scene(1, seed=8), steps=4, dt=2e-4, solver="semi_implicit",
+                               kw=dict(angular_damping=0.1, joint_attach_ke=2.0e4, joint_attach_kd=50.0)),
+        "semi/box_stack": dict(scene=lambda: box_stack_scene(1, n_boxes=3, seed=2, jitter=3e-3), steps=4, dt=5e-4,
+                               solver="semi_implicit", kw=dict(friction_smoothing=0.5), sink=0.002, drop_speed=0.05),
+        "semi/box_stack_contact_props": dict(scene=lambda: box_stack_scene(1, n_boxes=2, seed=3, jitter=3e-3), steps=3, dt=5e-4,
+                                             solver="semi_implicit", kw={}, props=(3.0e4, 40.0, 0.5), sink=0.003, drop_speed=0.02),
+        "semi/quadruped": dict(scene=lambda: quadruped_scene(1, seed=9), steps=3, dt=2e-4, solver="semi_implicit", kw={}, lower=0.221),
+    }
+
+
+def prepare(case):
+    """Build the case's model and apply its initial-state edits (root lowering, sinking, drop speed, joint forces)."""
+    import newton_amd as nt
+
+    model = case["scene"]()
+    if case.get("joint_f") is not None:
+        model.joint_f = case["joint_f"](len(model.joint_f))
+    if case.get("lower"):
+        jq = np.array(model.joint_q, copy=True).reshape(model.world_count, -1)
+        jq[:, 2] -= case["lower"]
+        model.joint_q = jq.reshape(-1)
+        model.body_q, model.body_qd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
+    if case.get("sink"):  # free bodies: body k sinks by (k + 1) * sink, so that every contact of a stack penetrates
+        model.body_q = np.array(model.body_q, np.float32, copy=True).reshape(-1, 7)
+        model.body_q[:, 2] -= case["sink"] * (np.arange(len(model.body_q)) + 1)
+    if case.get("drop_speed"):
+        model.body_qd = np.array(model.body_qd, np.float32, copy=True).reshape(-1, 6)
+        model.body_qd[:, 2] = -case["drop_speed"]
+    return model

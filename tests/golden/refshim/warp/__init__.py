@@ -177,8 +177,8 @@ def sqrt(x): return _np.sqrt(_s(x))
 def sin(x): return _np.sin(_s(x))
 def cos(x): return _np.cos(_s(x))
 def tan(x): return _np.tan(_s(x))
-def asin(x): return _np.arcsin(_s(x))
-def acos(x): return _np.arccos(_s(x))
+def asin(x): return _np.arcsin(clamp(_s(x), f32(-1.0), f32(1.0)))
+def acos(x): return _np.arccos(clamp(_s(x), f32(-1.0), f32(1.0)))
 def atan(x): return _np.arctan(_s(x))
 def atan2(y, x): return _np.arctan2(_s(y), _s(x))
 def exp(x): return _np.exp(_s(x))
@@ -264,6 +264,35 @@ def quat_from_axis_angle(axis, angle):
 def quat_to_matrix(q):
     return matrix_from_cols(quat_rotate(q, vec3(1.0, 0.0, 0.0)), quat_rotate(q, vec3(0.0, 1.0, 0.0)),
                             quat_rotate(q, vec3(0.0, 0.0, 1.0)))
+
+
+def quat_twist_angle_signed(axis, q):
+    a = q.x * axis.x + q.y * axis.y + q.z * axis.z
+    angle = f32(2.0) * _np.arctan2(a, q.w)
+    if angle > pi:
+        angle = angle - f32(2.0) * pi
+    if angle < -pi:
+        angle = angle + f32(2.0) * pi
+    return angle
+
+
+def norm_huber(v, delta=1.0):
+    a = dot(v, v)
+    delta = _s(delta)
+    if a <= delta * delta:
+        return f32(0.5) * a
+    return delta * (_np.sqrt(a) - f32(0.5) * delta)
+
+
+def norm_l2(v): return length(v)
+
+
+def leaky_min(a, b, r):
+    return a if a < b else b
+
+
+def leaky_max(a, b, r):
+    return a if a > b else b
 
 
 def quat_to_axis_angle(q):
@@ -426,6 +455,11 @@ class spatial_vector:
 
 
 spatial_vectorf = spatial_vector
+
+
+def velocity_at_point(qd, r):
+    """Warp layout (angular, linear): w x r + v."""
+    return cross(vec3(qd.v[0], qd.v[1], qd.v[2]), r) + vec3(qd.v[3], qd.v[4], qd.v[5])
 
 
 def spatial_top(s): return vec3(s.v[0], s.v[1], s.v[2])
@@ -682,7 +716,23 @@ def _decorator(fn=None, **kw):
 
 kernel = _decorator
 func = _decorator
-func_native = _decorator
+
+# bodies of the reference's native snippets (CPU branch of the snippet, fp32)
+_NATIVE = {"_support_rsqrt_rn": lambda value: f32(1.0) / _np.sqrt(_s(value))}
+
+
+def func_replay(forward):
+    return lambda f: f
+
+
+func_grad = func_replay
+
+
+def func_native(snippet=None, **kw):
+    def deco(f):
+        return _NATIVE.get(f.__name__, f)
+
+    return deco
 
 
 def struct(cls):
