@@ -28,6 +28,7 @@ import warp as wp  # noqa: E402  (the shim)
 
 ref = importlib.import_module("newton._src.solvers.xpbd.solver_xpbd")
 ref_semi = importlib.import_module("newton._src.solvers.semi_implicit.solver_semi_implicit")
+ref_fs = importlib.import_module("newton._src.solvers.featherstone.solver_featherstone")
 
 
 def arr(a, dtype):
@@ -73,6 +74,19 @@ def ref_model(m):
     return r, ctrl
 
 
+def add_articulation_tables(r, m):
+    """What SolverFeatherstone reads beyond the maximal-coordinate solvers: terminal entries of the start arrays,
+    articulation ranges, joint_ancestor (builder.py: the joint whose child is this joint's parent)."""
+    r.joint_q_start = arr(np.concatenate([np.asarray(m.joint_q_start), [m.joint_coord_count]]), int)
+    r.joint_qd_start = arr(np.concatenate([np.asarray(m.joint_qd_start), [m.joint_dof_count]]), int)
+    r.articulation_count = int(m.articulation_count)
+    r.articulation_start, r.articulation_end = arr(m.articulation_start, int), arr(m.articulation_end, int)
+    parent, child = np.asarray(m.joint_parent), np.asarray(m.joint_child)
+    joint_of_child = {int(c): j for j, c in enumerate(child)}
+    r.joint_ancestor = arr(np.array([joint_of_child.get(int(p), -1) if p >= 0 else -1 for p in parent]), int)
+    r.body_q, r.body_qd = arr(m.body_q, wp.transform), arr(m.body_qd, wp.spatial_vector)
+
+
 def ref_state(body_q, body_qd, body_f=None):
     s = types.SimpleNamespace(requires_grad=False, particle_q=None, particle_qd=None, particle_f=None, body_parent_f=None,
                               particle_count=0, body_count=len(body_q))
@@ -109,12 +123,17 @@ def run_case(name, case):
 
     model = rc.prepare(case)
     rm, ctrl = ref_model(model)
-    if case.get("solver", "xpbd") == "xpbd":
+    kind = case.get("solver", "xpbd")
+    if kind == "xpbd":
         solver = ref.SolverXPBD(rm, **case["kw"])
-    else:
+    elif kind == "semi_implicit":
         solver = ref_semi.SolverSemiImplicit(rm, **case["kw"])
+    else:
+        add_articulation_tables(rm, model)
+        solver = ref_fs.SolverFeatherstone(rm, **case["kw"])
+    jq, jqd = np.array(model.joint_q, np.float32), np.array(model.joint_qd, np.float32)
     q, qd = np.array(model.body_q, np.float32).reshape(-1, 7), np.array(model.body_qd, np.float32).reshape(-1, 6)
-    out = {"body_q0": q.copy(), "body_qd0": qd.copy()}
+    out = {"body_q0": q.copy(), "body_qd0": qd.copy(), "joint_q0": jq.copy(), "joint_qd0": jqd.copy()}
     orc = ob.Oracle(model)
     for k in range(case["steps"]):
         ct = orc.contacts()
@@ -122,9 +141,14 @@ def run_case(name, case):
         n = int(ct.count[0])
         oc = {f: getattr(ct, f) for f in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")}
         s_in, s_out = ref_state(q, qd), ref_state(q, qd)
+        for s_ in (s_in, s_out):
+            s_.joint_q, s_.joint_qd = arr(jq, float), arr(jqd, float)
         solver.step(s_in, s_out, None, ref_contacts(oc, n, case.get("props")) if n else None, case["dt"])
         q, qd = to_np(s_out.body_q, 7), to_np(s_out.body_qd, 6)
+        if kind == "featherstone":
+            jq, jqd = np.array(s_out.joint_q, np.float32), np.array(s_out.joint_qd, np.float32)
         out[f"body_q{k + 1}"], out[f"body_qd{k + 1}"], out[f"contacts{k}"] = q.copy(), qd.copy(), np.array([n])
+        out[f"joint_q{k + 1}"], out[f"joint_qd{k + 1}"] = jq.copy(), jqd.copy()
         print(name, "step", k, "contacts", n, "max |qd|", float(np.abs(qd).max()), flush=True)
     return out
 

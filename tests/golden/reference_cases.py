@@ -36,6 +36,14 @@ def cases():
         "semi/box_stack_contact_props": dict(scene=lambda: box_stack_scene(1, n_boxes=2, seed=3, jitter=3e-3), steps=3, dt=5e-4,
                                              solver="semi_implicit", kw={}, props=(3.0e4, 40.0, 0.5), sink=0.003, drop_speed=0.02),
         "semi/quadruped": dict(scene=lambda: quadruped_scene(1, seed=9), steps=3, dt=2e-4, solver="semi_implicit", kw={}, lower=0.221),
+        # ---- SolverFeatherstone (solver_featherstone.py:462-1066), dense (non-tiled) mass-matrix path
+        "fs/pendulum": dict(scene=lambda: pendulum_scene(2, seed=5), steps=5, dt=1e-3, solver="featherstone", kw={}),
+        "fs/joint_zoo": dict(scene=lambda: joint_zoo_scene(1, seed=9), steps=4, dt=5e-4, solver="featherstone",
+                             kw=dict(angular_damping=0.1)),
+        "fs/joint_zoo_free_root": dict(scene=lambda: joint_zoo_scene(1, seed=10, free_root=True), steps=3, dt=5e-4,
+                                       solver="featherstone", kw={}),
+        "fs/quadruped": dict(scene=lambda: quadruped_scene(1, seed=11), steps=3, dt=5e-4, solver="featherstone",
+                             kw=dict(friction_smoothing=0.5), lower=0.221, joint_f=sin_f),
     }
 
 

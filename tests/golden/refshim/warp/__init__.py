@@ -365,7 +365,10 @@ class mat33:
 mat33f = mat33
 
 
-def transpose(A): return mat33(*[A.m[j][i] for i in range(3) for j in range(3)])
+def transpose(A):
+    if isinstance(A, spatial_matrix):
+        return spatial_matrix(*[A.a[j][i] for i in range(6) for j in range(6)])
+    return mat33(*[A.m[j][i] for i in range(3) for j in range(3)])
 def matrix_from_cols(c0, c1, c2): return mat33(c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z)
 def matrix_from_rows(r0, r1, r2): return mat33(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z)
 def skew(v): return mat33(0.0, -v.z, v.y, v.z, 0.0, -v.x, -v.y, v.x, 0.0)
@@ -455,6 +458,75 @@ class spatial_vector:
 
 
 spatial_vectorf = spatial_vector
+
+
+class spatial_matrix:
+    """6x6; products accumulate from 0.0 over ascending k (the order oracle_featherstone.cpp's mat66 uses)."""
+
+    __slots__ = ("a",)
+    __array_ufunc__ = None
+
+    def __init__(self, *x):
+        if len(x) == 0:
+            self.a = [[f32(0.0)] * 6 for _ in range(6)]
+        elif len(x) == 36:
+            self.a = [[_s(x[6 * i + j]) for j in range(6)] for i in range(6)]
+        elif len(x) == 1 and not hasattr(x[0], "__len__"):
+            self.a = [[_s(x[0])] * 6 for _ in range(6)]
+        else:
+            rows = x[0] if len(x) == 1 else x
+            self.a = [[_s(rows[i][j]) for j in range(6)] for i in range(6)]
+
+    def __getitem__(self, ij):
+        if isinstance(ij, tuple):
+            return self.a[ij[0]][ij[1]]
+        return self.a[ij]
+
+    def __setitem__(self, ij, v):
+        self.a[ij[0]][ij[1]] = _s(v)
+
+    def __mul__(self, o):
+        if isinstance(o, spatial_vector):
+            r = []
+            for i in range(6):
+                sm = f32(0.0)
+                for j in range(6):
+                    sm = sm + self.a[i][j] * o.v[j]
+                r.append(sm)
+            return spatial_vector(*r)
+        if isinstance(o, spatial_matrix):
+            C = spatial_matrix()
+            for i in range(6):
+                for j in range(6):
+                    sm = f32(0.0)
+                    for k in range(6):
+                        sm = sm + self.a[i][k] * o.a[k][j]
+                    C.a[i][j] = sm
+            return C
+        return spatial_matrix(*[self.a[i][j] * _s(o) for i in range(6) for j in range(6)])
+
+    __matmul__ = __mul__
+
+    def __rmul__(self, sc): return spatial_matrix(*[self.a[i][j] * _s(sc) for i in range(6) for j in range(6)])
+    def __add__(self, o): return spatial_matrix(*[self.a[i][j] + o.a[i][j] for i in range(6) for j in range(6)])
+    def __sub__(self, o): return spatial_matrix(*[self.a[i][j] - o.a[i][j] for i in range(6) for j in range(6)])
+
+
+spatial_matrixf = spatial_matrix
+
+
+def transform_twist(t, x):
+    """Warp layout (angular, linear): w' = R w, v' = R v + p x w'."""
+    w = quat_rotate(t.q, vec3(x.v[0], x.v[1], x.v[2]))
+    v = quat_rotate(t.q, vec3(x.v[3], x.v[4], x.v[5])) + cross(t.p, w)
+    return spatial_vector(w, v)
+
+
+def transform_wrench(t, x):
+    """Warp layout (torque, force): f' = R f, tau' = R tau + p x f'."""
+    f = quat_rotate(t.q, vec3(x.v[3], x.v[4], x.v[5]))
+    tau = quat_rotate(t.q, vec3(x.v[0], x.v[1], x.v[2])) + cross(t.p, f)
+    return spatial_vector(tau, f)
 
 
 def velocity_at_point(qd, r):
@@ -553,7 +625,7 @@ def _zero_of(dtype):
 
 
 def _zero_like(v):
-    if isinstance(v, (vec3, quat, spatial_vector, mat33, vec2)):
+    if isinstance(v, (vec3, quat, spatial_vector, mat33, vec2, spatial_matrix)):
         return type(v)()
     if isinstance(v, transform):
         return transform(vec3(), quat())
@@ -576,6 +648,8 @@ def to_array(data, dtype=None):
             out.append(spatial_vector(*[x[k] for k in range(6)]))
         elif dtype is mat33:
             out.append(mat33(*_np.asarray(x).reshape(-1)))
+        elif dtype is spatial_matrix:
+            out.append(spatial_matrix(*_np.asarray(x).reshape(-1)))
         elif dtype in (float, float32, None) and _np.asarray(x).dtype.kind == "f":
             out.append(f32(x))
         elif dtype is bool:
@@ -748,7 +822,7 @@ def struct(cls):
     return cls
 
 
-_VALUE_TYPES = (vec3, vec2, quat, mat33, transform, spatial_vector)
+_VALUE_TYPES = (vec3, vec2, quat, mat33, transform, spatial_vector, spatial_matrix)
 
 
 def constant(x): return x

@@ -33,7 +33,7 @@ def _errors(q, qd, q_ref, qd_ref):
 
 NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "joint_zoo", "joint_zoo_free_root",
          "box_stack_no_weighting", "box_stack_sunk_restitution", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
-         "semi/box_stack_contact_props", "semi/quadruped"]
+         "semi/box_stack_contact_props", "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped"]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -46,8 +46,8 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
     case = rc.cases()[name]
     model = rc.prepare(case)
     orc = ob.Oracle(model)
-    semi = case.get("solver") == "semi_implicit"
-    worst = np.zeros(4)
+    semi, fs = case.get("solver") == "semi_implicit", case.get("solver") == "featherstone"
+    worst, worst_joint = np.zeros(4), np.zeros(2)
     for k in range(case["steps"]):
         q, qd = ref[f"{name}/body_q{k}"], ref[f"{name}/body_qd{k}"]
         ct = orc.contacts()
@@ -57,7 +57,13 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
         if case.get("props") is not None:
             ct.set_properties(np.full(max(n, 1), case["props"][0]), np.full(max(n, 1), case["props"][1]), np.full(max(n, 1), case["props"][2]))
         s_in, s_out = ob.OracleState(model, q, qd), ob.OracleState(model, q, qd)
-        if semi:
+        if fs:
+            for s_ in (s_in, s_out):
+                s_.joint_q[:], s_.joint_qd[:] = ref[f"{name}/joint_q{k}"], ref[f"{name}/joint_qd{k}"]
+            orc.featherstone_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"])
+            worst_joint = np.maximum(worst_joint, [np.abs(s_out.joint_q - ref[f"{name}/joint_q{k + 1}"]).max(),
+                                                   np.abs(s_out.joint_qd - ref[f"{name}/joint_qd{k + 1}"]).max()])
+        elif semi:
             orc.semi_implicit_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"])
         else:
             orc.xpbd_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"])
@@ -67,3 +73,6 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
     # one step from identical inputs.  Measured: bit-identical positions and linear velocities in nearly every case; rotations
     # within 1.5e-8 and angular velocities within 3e-6 where asin / acos / atan2 enter (numpy float32 vs glibc)
     assert worst[0] <= 1e-7 and worst[1] <= 1e-7 and worst[2] <= 1e-6 and worst[3] <= 1e-5, worst
+    if fs:
+        print(name, "joint space: max abs error joint_q %.3g joint_qd %.3g" % tuple(worst_joint))
+        assert worst_joint[0] <= 1e-7 and worst_joint[1] <= 1e-5, worst_joint
