@@ -199,3 +199,76 @@ def test_descriptor_built_by_the_c_helper_steps_like_the_python_built_one():
         dm.lib.nt_model_destroy(h)
     assert np.array_equal(q.view(np.int32), q_ref.view(np.int32)) and np.array_equal(qd.view(np.int32), qd_ref.view(np.int32))
     assert np.abs(qd_ref).max() > 0.0
+
+
+_REF_NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "joint_zoo", "joint_zoo_free_root",
+              "box_stack_no_weighting", "box_stack_sunk_restitution", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
+              "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped"]
+
+
+@pytest.mark.parametrize("name", _REF_NAMES)
+def test_hip_path_against_reference_vectors(name):
+    """The HIP path (collide + step through the C ABI) against vectors recorded from the REFERENCE's own solver source
+    (tests/golden/make_xpbd_reference_vectors.py), teacher-forced step by step.  The C++ checker reproduces these vectors bit
+    for bit (tests/test_reference_vectors.py); the device path differs by its documented reorderings (world-frame inverse
+    inertia precomputed per body, two lanes per joint, OCML libm), hence tolerances instead of equality."""
+    import os
+    import sys
+
+    import torch
+
+    import newton_amd as nt
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import reference_cases as rc
+
+    case = rc.cases()[name]
+    ref = np.load(os.path.join(here, "golden", "xpbd_reference_vectors.npz"))
+    host = rc.prepare(case)
+    kind = case.get("solver", "xpbd")
+    # the same model on the device
+    case_dev = dict(case)
+    scene = case["scene"]
+    case_dev["scene"] = lambda: _to_device(scene())
+    model = rc.prepare(case_dev)
+    if kind == "xpbd":
+        solver = nt.solvers.SolverXPBD(model, **case["kw"])
+    elif kind == "semi_implicit":
+        solver = nt.solvers.SolverSemiImplicit(model, **case["kw"])
+    else:
+        solver = nt.solvers.SolverFeatherstone(model, **case["kw"])
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    s0, s1 = model.state(), model.state()
+    worst = np.zeros(4)
+    for k in range(case["steps"]):
+        s0.body_q, s0.body_qd = torch.from_numpy(ref[f"{name}/body_q{k}"]), torch.from_numpy(ref[f"{name}/body_qd{k}"])
+        if kind == "featherstone":
+            s0.joint_q, s0.joint_qd = torch.from_numpy(ref[f"{name}/joint_q{k}"]), torch.from_numpy(ref[f"{name}/joint_qd{k}"])
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        n = int(contacts.rigid_contact_count.cpu().numpy()[0])
+        assert n == int(ref[f"{name}/contacts{k}"][0])
+        solver.step(s0, s1, None, contacts, case["dt"])
+        torch.cuda.synchronize()
+        q, qd = s1.body_q.cpu().numpy(), s1.body_qd.cpu().numpy()
+        q_ref, qd_ref = ref[f"{name}/body_q{k + 1}"], ref[f"{name}/body_qd{k + 1}"]
+        rot = np.minimum(np.abs(q[:, 3:] - q_ref[:, 3:]).max(axis=1), np.abs(q[:, 3:] + q_ref[:, 3:]).max(axis=1)).max()
+        worst = np.maximum(worst, [np.abs(q[:, :3] - q_ref[:, :3]).max(), rot, np.abs(qd[:, :3] - qd_ref[:, :3]).max(),
+                                   np.abs(qd[:, 3:] - qd_ref[:, 3:]).max()])
+    print(name, "HIP vs reference run: pos %.3g rot %.3g lin vel %.3g ang vel %.3g" % tuple(worst))
+    scale = max(1.0, float(np.abs(ref[f"{name}/body_qd0"]).max()))
+    # one step from identical inputs: positions to a few fp32 ulps of a metre; XPBD velocities are position differences / dt
+    vel_tol = 4e-6 / case["dt"] if kind == "xpbd" else 2e-5 * scale
+    assert worst[0] <= 4e-6 and worst[1] <= 4e-6 and worst[2] <= vel_tol and worst[3] <= 10.0 * vel_tol, worst
+
+
+def _to_device(host_model):
+    """Re-finalize is not needed: the scene factories take `device`; this helper exists for factories called without it."""
+    import copy
+
+    m = copy.copy(host_model)
+    m.device = "cuda:0"
+    m._dev = None
+    return m
