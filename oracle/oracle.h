@@ -6,9 +6,11 @@
  * Kernels are executed in ascending-tid order, so wp.atomic_add accumulation order is
  * the serial order a Warp-CPU launch would produce.
  *
- * PARITY UNPINNED at bit level: warp-lang (the runtime that defines the fp32 op order of
- * quat_rotate & co.) is not present in /root/reference nor installable here; see
- * wp_builtins.h.  Pinned at tolerance level against the reference's known-answer tests.
+ * Pinning: the three solvers reproduce, bit for bit in positions and linear velocities, vectors recorded from the REFERENCE's
+ * own solver source executed on a pure-Python stand-in for Warp (tests/golden/make_xpbd_reference_vectors.py,
+ * tests/test_reference_vectors.py).  Still restated (PARITY UNPINNED at bit level): the fp32 operation order inside Warp's
+ * builtins (wp_builtins.h; warp-lang is not present in /root/reference nor installable here) and the collision pipeline,
+ * which is pinned at tolerance level by the reference's known-answer tests.
  */
 #ifndef NEWTON_ORACLE_H
 #define NEWTON_ORACLE_H

@@ -16,7 +16,7 @@
 //   eval_body_contact (shared with SolverSemiImplicit)        semi_implicit/kernels_contact.py:381-556
 //   transform_twist / velocity_at_point                       newton/_src/math/spatial.py:53-130
 // Scope: PRISMATIC, REVOLUTE, BALL, FIXED, root FREE, D6 (up to three angular axes), kinematic roots; no descendant
-// FREE/DISTANCE joints, update_mass_matrix_interval = 1.  PARITY UNPINNED at bit level (see wp_builtins.h).
+// FREE/DISTANCE joints, update_mass_matrix_interval = 1.  Pinned by execution of the reference solver source (tests/test_reference_vectors.py: fs/*); the Warp builtins underneath stay restated (wp_builtins.h).
 #include <vector>
 
 #include "oracle_common.h"

@@ -5,7 +5,8 @@
 //   SolverSemiImplicit.step            newton/_src/solvers/semi_implicit/solver_semi_implicit.py:123-217
 //   integrate_bodies                   newton/_src/solvers/solver.py:63-170 (shared, oracle_xpbd.cpp)
 // warp builtins restated here: wp.quat_twist_angle_signed (kernels_body.py:206), wp.norm_huber
-// (kernels_contact.py:537), wp.step -- PARITY UNPINNED (see wp_builtins.h).
+// (kernels_contact.py:537), wp.step -- restated builtins (wp_builtins.h); the solver itself is pinned by execution of the reference source
+// (tests/test_reference_vectors.py: semi/*).
 // wp.acos clamps its argument to [-1, 1] (Warp builtin semantics), which keeps the FIXED / PRISMATIC / BALL angular
 // error finite when a normalised quaternion's w drifts a few ulp above 1.
 // D6 joints with 2 or 3 angular axes decompose the relative rotation with quat_decompose (wp_builtins.h).
