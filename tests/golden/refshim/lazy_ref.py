@@ -88,12 +88,14 @@ class _Dummy:
 class _Finder:
     """Turns every reference PACKAGE into a _LazyPackage; plain modules are imported normally from the reference tree."""
 
-    def __init__(self, dummies, execute):
-        self.dummies, self.execute = dummies, set(execute)
+    def __init__(self, dummies, execute, dummy_modules=()):
+        self.dummies, self.execute, self.dummy_modules = dummies, set(execute), set(dummy_modules)
 
     def find_spec(self, fullname, path=None, target=None):
         if fullname != "newton" and not fullname.startswith("newton."):
             return None
+        if fullname in self.dummy_modules:  # modules that only contribute types to annotations on the paths executed here
+            return importlib.util.spec_from_loader(fullname, _DummyModuleLoader())
         rel = fullname.split(".")
         p = os.path.join(REF_ROOT, *rel)
         if os.path.isdir(p) and fullname in self.execute:  # packages whose __init__ holds real definitions: run it
@@ -141,6 +143,21 @@ class _ValueSemanticsLoader(importlib.abc.Loader):
         exec(compile(tree, self.path, "exec"), module.__dict__)
 
 
+class _DummyModule(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Dummy(self.__name__ + "." + k)
+
+
+class _DummyModuleLoader:
+    def create_module(self, spec):
+        return _DummyModule(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
 class _PkgLoader:
     def __init__(self, path, dummies):
         self.path, self.dummies = path, dummies
@@ -152,7 +169,7 @@ class _PkgLoader:
         pass
 
 
-def install(dummies=None, execute=("newton._src.math",)):
+def install(dummies=None, execute=("newton._src.math",), dummy_modules=()):
     here = os.path.dirname(os.path.abspath(__file__))
     if here not in sys.path:
         sys.path.insert(0, here)  # makes `import warp` find tests/golden/refshim/warp
@@ -161,4 +178,4 @@ def install(dummies=None, execute=("newton._src.math",)):
     import warp
 
     builtins.__wp_val__ = warp._val
-    sys.meta_path.insert(0, _Finder(dummies or {}, execute))
+    sys.meta_path.insert(0, _Finder(dummies or {}, execute, dummy_modules))

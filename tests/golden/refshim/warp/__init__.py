@@ -91,9 +91,37 @@ class vec2:
     def __setitem__(self, i, v): setattr(self, "xy"[i], _s(v))
 
 
+class vec4:
+    __slots__ = ("c",)
+    __array_ufunc__ = None
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            self.c = [f32(0.0)] * 4
+        elif len(a) == 1:
+            self.c = [_s(a[0])] * 4 if not hasattr(a[0], "__len__") else [_s(x) for x in a[0]]
+        elif len(a) == 2:
+            self.c = [a[0].x, a[0].y, a[0].z, _s(a[1])]
+        else:
+            self.c = [_s(x) for x in a]
+
+    def __getitem__(self, i): return self.c[i]
+    def __setitem__(self, i, v): self.c[i] = _s(v)
+    def __len__(self): return 4
+    def __iter__(self): return iter(self.c)
+
+
+vec4f = vec4
+
+
 class _ivec:
     def __init__(self, *a):
-        self.v = [int(x) for x in a] if a else [0] * self.N
+        if len(a) == 1 and not hasattr(a[0], "__len__"):
+            self.v = [int(a[0])] * self.N
+        elif len(a) == 1:
+            self.v = [int(x) for x in a[0]]
+        else:
+            self.v = [int(x) for x in a] if a else [0] * self.N
 
     def __getitem__(self, i): return self.v[i]
     def __setitem__(self, i, x): self.v[i] = int(x)
@@ -539,10 +567,47 @@ def spatial_bottom(s): return vec3(s.v[3], s.v[4], s.v[5])
 
 
 # ------------------------------------------------------------------------------------------------ arrays, kernels, launch
+_SIZEOF = {}
+
+
+class _Ptr:
+    """Array base address: supports the `ptr + byte_offset` / wp.array(ptr=...) aliasing idiom (multicontact.py:842-843)."""
+
+    def __init__(self, base, byte_offset=0):
+        self.base, self.off = base, int(byte_offset)
+
+    def __add__(self, b): return _Ptr(self.base, self.off + int(b))
+    def __eq__(self, o): return isinstance(o, _Ptr) and self.base is o.base and self.off == o.off
+    def __ne__(self, o): return not self.__eq__(o)
+    def __hash__(self): return id(self.base) ^ self.off
+
+
+class ArrayView:
+    """Window of `n` elements into another Array (shares storage)."""
+
+    device = "cpu"
+
+    def __init__(self, base, start, n, dtype):
+        self.base, self.start, self.n, self.dtype = base, start, n, dtype
+
+    def __getitem__(self, i): return self.base[self.start + i]
+    def __setitem__(self, i, v): self.base[self.start + i] = v
+    def __len__(self): return self.n
+
+    @property
+    def shape(self): return (self.n,)
+
+    @property
+    def ptr(self): return _Ptr(self.base, self.start * _SIZEOF.get(self.dtype, 4))
+
+
 class _ArrayType:
     """wp.array(dtype=...) in an annotation, or wp.array(data, dtype=...) at run time (-> a python list of shim values)."""
 
-    def __call__(self, data=None, dtype=None, ndim=1, **kw):
+    def __call__(self, data=None, dtype=None, ndim=1, ptr=None, shape=None, **kw):
+        if ptr is not None:
+            n = shape[0] if isinstance(shape, (tuple, list)) else int(shape)
+            return ArrayView(ptr.base, ptr.off // _SIZEOF.get(dtype, 4), n, dtype)
         if data is None:
             return self
         return to_array(data, dtype)
@@ -576,7 +641,7 @@ class Array(list):
     def size(self): return len(self)
 
     @property
-    def ptr(self): return id(self)
+    def ptr(self): return _Ptr(self, 0)
 
     def numpy(self):
         if len(self) and hasattr(self[0], "__iter__"):
@@ -625,10 +690,12 @@ def _zero_of(dtype):
 
 
 def _zero_like(v):
-    if isinstance(v, (vec3, quat, spatial_vector, mat33, vec2, spatial_matrix)):
+    if isinstance(v, (vec3, quat, spatial_vector, mat33, vec2, spatial_matrix, vec4, vec2i, vec3i, vec4i)):
         return type(v)()
     if isinstance(v, transform):
         return transform(vec3(), quat())
+    if hasattr(v, "SHAPE") or hasattr(v, "N"):
+        return type(v)()
     if isinstance(v, (_np.floating, float)):
         return f32(0.0)
     return type(v)(0)
@@ -650,6 +717,10 @@ def to_array(data, dtype=None):
             out.append(mat33(*_np.asarray(x).reshape(-1)))
         elif dtype is spatial_matrix:
             out.append(spatial_matrix(*_np.asarray(x).reshape(-1)))
+        elif dtype is vec4:
+            out.append(vec4(*[x[k] for k in range(4)]))
+        elif dtype in (vec2i, vec3i, vec4i):
+            out.append(dtype(*[int(v) for v in x]))
         elif dtype in (float, float32, None) and _np.asarray(x).dtype.kind == "f":
             out.append(f32(x))
         elif dtype is bool:
@@ -705,6 +776,9 @@ def copy(dest, src, **kw):
 
 
 _tid = [0]
+
+
+def block_dim(): return 1  # what CPU kernels observe (Warp GH-1413, narrow_phase.py:2296)
 
 
 def tid():
@@ -814,7 +888,17 @@ def struct(cls):
 
     def __init__(self, **kw):
         for k, t in ann.items():
-            setattr(self, k, _zero_of(t) if not isinstance(t, _ArrayType) else None)
+            if isinstance(t, str):  # `from __future__ import annotations`
+                try:
+                    t = eval(t, _sys.modules[cls.__module__].__dict__)  # noqa: S307
+                except Exception:
+                    t = None
+            if isinstance(t, _ArrayType) or t is None:
+                setattr(self, k, None)
+            elif isinstance(t, type) and hasattr(t, "__annotations__") and t not in _VALUE_TYPES:
+                setattr(self, k, t())  # nested struct
+            else:
+                setattr(self, k, _zero_of(t))
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -822,7 +906,9 @@ def struct(cls):
     return cls
 
 
-_VALUE_TYPES = (vec3, vec2, quat, mat33, transform, spatial_vector, spatial_matrix)
+vec2f = vec2
+_SIZEOF.update({vec2: 8, vec3: 12, vec4: 16, quat: 16, transform: 28, spatial_vector: 24, float: 4, int: 4, float32: 4, int32: 4})
+_VALUE_TYPES = (vec3, vec2, vec4, quat, mat33, transform, spatial_vector, spatial_matrix, vec2i, vec3i, vec4i)
 
 
 def constant(x): return x
@@ -885,8 +971,83 @@ class _Sub(_types.ModuleType):
         return _Inert(self.__name__ + "." + k)
 
 
+def _make_vector(length=None, dtype=None, *a, **k):
+    n = length if length is not None else a[0]
+
+    class _Vec:
+        __array_ufunc__ = None
+        N = n
+
+        def __init__(self, *x):
+            if len(x) == 0:
+                self.c = [f32(0.0)] * n
+            elif len(x) == 1 and not hasattr(x[0], "__len__"):
+                self.c = [_s(x[0])] * n
+            elif len(x) == 1:
+                self.c = [_s(v) for v in x[0]]
+            else:
+                self.c = [_s(v) for v in x]
+
+        def __getitem__(self, i): return self.c[i]
+        def __setitem__(self, i, v): self.c[i] = _s(v)
+        def __len__(self): return n
+        def __iter__(self): return iter(self.c)
+        def __add__(self, o): return type(self)(*[a_ + b_ for a_, b_ in zip(self.c, o.c)])
+        def __sub__(self, o): return type(self)(*[a_ - b_ for a_, b_ in zip(self.c, o.c)])
+        def __mul__(self, sc): return type(self)(*[a_ * _s(sc) for a_ in self.c])
+        __rmul__ = __mul__
+
+    _Vec.__name__ = f"vec{n}f"
+    _register_value_type(_Vec)
+    return _Vec
+
+
+def _make_matrix(shape=None, dtype=None, *a, **k):
+    r, c_ = shape
+
+    class _Mat:
+        __array_ufunc__ = None
+        SHAPE = (r, c_)
+
+        def __init__(self, *x):
+            if len(x) == 0:
+                self.m = [[f32(0.0)] * c_ for _ in range(r)]
+            elif len(x) == r * c_:
+                self.m = [[_s(x[i * c_ + j]) for j in range(c_)] for i in range(r)]
+            elif len(x) == 1 and not hasattr(x[0], "__len__"):
+                self.m = [[_s(x[0])] * c_ for _ in range(r)]
+            else:
+                rows = x if len(x) == r else x[0]
+                self.m = [[_s(rows[i][j]) for j in range(c_)] for i in range(r)]
+
+        def __getitem__(self, ij):
+            if isinstance(ij, tuple):
+                return self.m[ij[0]][ij[1]]
+            row = self.m[ij]
+            return vec3(*row) if c_ == 3 else (vec2(*row) if c_ == 2 else list(row))
+
+        def __setitem__(self, ij, v):
+            if isinstance(ij, tuple):
+                self.m[ij[0]][ij[1]] = _s(v)
+            else:
+                self.m[ij] = [_s(v[j]) for j in range(c_)]
+
+    _Mat.__name__ = f"mat{r}{c_}f"
+    _register_value_type(_Mat)
+    return _Mat
+
+
+def _register_value_type(t):
+    global _VALUE_TYPES
+    _VALUE_TYPES = (*_VALUE_TYPES, t)
+
+
 for _n in ("types", "context", "config", "utils", "sim", "render", "sparse", "fem", "optim", "torch", "jax", "build",
            "codegen", "math", "autograd", "_src", "_src.types", "_src.context", "_src.utils", "_src.codegen"):
     _m = _Sub("warp." + _n)
     _sys.modules["warp." + _n] = _m
     setattr(_sys.modules[__name__], _n.split(".")[0], _sys.modules["warp." + _n.split(".")[0]])
+_sys.modules["warp.types"].vector = _make_vector
+_sys.modules["warp.types"].matrix = _make_matrix
+vec = _make_vector
+mat = _make_matrix

@@ -76,3 +76,34 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
     if fs:
         print(name, "joint space: max abs error joint_q %.3g joint_qd %.3g" % tuple(worst_joint))
         assert worst_joint[0] <= 1e-7 and worst_joint[1] <= 1e-5, worst_joint
+
+
+COLLIDE_NAMES = ["pair_matrix_a", "pair_matrix_b", "mixed_primitives_a", "mixed_primitives_b", "mixed_primitives_c", "box_stack_a", "box_stack_b",
+                 "quadruped_cylinders", "quadruped_box_feet"]
+
+
+@pytest.mark.parametrize("name", COLLIDE_NAMES)
+def test_checker_collide_reproduces_the_reference_collision_kernels(oracle_lib, name):
+    """tests/golden/make_collide_reference_vectors.py ran the reference's compute_shape_aabbs, primitive narrow phase, GJK / MPR +
+    manifold narrow phase and write_contact (unmodified source, on the Warp stand-in) on these scenes; the checker's collide()
+    must produce the same AABBs and the same flat contact arrays in the same append order."""
+    import collide_cases as cc
+    import oracle_bridge as ob
+
+    assert sorted(COLLIDE_NAMES) == sorted(cc.cases())
+    ref = np.load(os.path.join(HERE, "golden", "collide_reference_vectors.npz"))
+    model, _ = cc.cases()[name]()
+    body_q = ref[f"{name}/body_q"]
+    orc = ob.Oracle(model)
+    ct = orc.contacts()
+    pairs, lo, hi = orc.collide(body_q, ct)
+    assert np.array_equal(np.asarray(pairs, np.int32), ref[f"{name}/pairs"])
+    n = int(ref[f"{name}/count"][0])
+    assert int(ct.count[0]) == n and n > 0
+    assert np.array_equal(ct.shape0[:n], ref[f"{name}/shape0"]) and np.array_equal(ct.shape1[:n], ref[f"{name}/shape1"])
+    finite = np.abs(ref[f"{name}/aabb_lower"]) < 1e5  # (infinite planes: +-1e6 boxes)
+    err = {"aabb": max(np.abs(lo - ref[f"{name}/aabb_lower"])[finite].max(), np.abs(hi - ref[f"{name}/aabb_upper"])[finite].max())}
+    for k in ("point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
+        err[k] = float(np.abs(getattr(ct, k)[:n] - ref[f"{name}/{k}"]).max())
+    print(name, "contacts", n, "max abs error vs the reference kernels:", {k: float("%.3g" % v) for k, v in err.items()})
+    assert all(v <= 2e-6 for v in err.values()), err
