@@ -9,8 +9,8 @@
  * Pinning: the three solvers reproduce, bit for bit in positions and linear velocities, vectors recorded from the REFERENCE's
  * own solver source executed on a pure-Python stand-in for Warp (tests/golden/make_xpbd_reference_vectors.py,
  * tests/test_reference_vectors.py).  Still restated (PARITY UNPINNED at bit level): the fp32 operation order inside Warp's
- * builtins (wp_builtins.h; warp-lang is not present in /root/reference nor installable here) and the collision pipeline,
- * which is pinned at tolerance level by the reference's known-answer tests.
+ * builtins (wp_builtins.h; warp-lang is not present in /root/reference nor installable here).  The collision pipeline is
+ * pinned the same way (make_collide_reference_vectors.py: AABBs and contact arrays bit-identical to the reference kernels).
  */
 #ifndef NEWTON_ORACLE_H
 #define NEWTON_ORACLE_H

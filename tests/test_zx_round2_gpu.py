@@ -272,3 +272,40 @@ def _to_device(host_model):
     m.device = "cuda:0"
     m._dev = None
     return m
+
+
+_COLLIDE_NAMES = ["pair_matrix_a", "pair_matrix_b", "mixed_primitives_a", "mixed_primitives_b", "mixed_primitives_c", "box_stack_a",
+                  "box_stack_b", "quadruped_cylinders", "quadruped_box_feet"]
+
+
+@pytest.mark.parametrize("name", _COLLIDE_NAMES)
+def test_hip_collide_against_reference_collision_vectors(name):
+    """CollisionPipeline.collide on the device against the contact arrays the REFERENCE's collision kernels produced
+    (tests/golden/make_collide_reference_vectors.py): same contacts in the same append order, geometry within 1e-5."""
+    import os
+    import sys
+
+    import torch
+
+    import newton_amd as nt
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import collide_cases as cc
+
+    ref = np.load(os.path.join(here, "golden", "collide_reference_vectors.npz"))
+    host, _ = cc.cases()[name]()
+    model = _to_device(host)
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    s = model.state()
+    s.body_q = torch.from_numpy(ref[f"{name}/body_q"])
+    pipe.collide(s, contacts)
+    torch.cuda.synchronize()
+    n = int(ref[f"{name}/count"][0])
+    assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == n
+    get = lambda k: getattr(contacts, "rigid_contact_" + k).cpu().numpy()[:n]  # noqa: E731
+    assert np.array_equal(get("shape0"), ref[f"{name}/shape0"]) and np.array_equal(get("shape1"), ref[f"{name}/shape1"])
+    err = {k: float(np.abs(get(k) - ref[f"{name}/{k}"]).max()) for k in ("point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")}
+    print(name, "HIP collide vs reference kernels:", {k: float("%.3g" % v) for k, v in err.items()})
+    assert all(v <= 1e-5 for v in err.values()), err
