@@ -153,11 +153,32 @@ def run_case(name, case):
     return out
 
 
+def run_fk(name, make):
+    """newton.eval_fk (newton/_src/sim/articulation.py:500-573) of the reference on a model's joint state."""
+    art = importlib.import_module("newton._src.sim.articulation")
+    model = make()
+    rm, _ = ref_model(model)
+    add_articulation_tables(rm, model)
+    nj = len(model.joint_type)
+    ja = np.zeros(nj, np.int32)
+    for a, (s0, s1) in enumerate(zip(np.asarray(model.articulation_start), np.asarray(model.articulation_end))):
+        ja[s0:s1] = a
+    rm.joint_articulation = arr(ja, int)
+    target = types.SimpleNamespace(body_q=wp.zeros(rm.body_count, dtype=wp.transform), body_qd=wp.zeros(rm.body_count, dtype=wp.spatial_vector))
+    art.eval_fk(rm, arr(model.joint_q, float), arr(model.joint_qd, float), target)
+    print(name, "fk bodies", rm.body_count, flush=True)
+    return {"joint_q": np.array(model.joint_q, np.float32), "joint_qd": np.array(model.joint_qd, np.float32),
+            "body_q": to_np(target.body_q, 7), "body_qd": to_np(target.body_qd, 6)}
+
+
 def main():
     sys.path.insert(0, HERE)
     import reference_cases as rc
 
     blob = {}
+    for name, make in rc.fk_cases().items():
+        for k, v in run_fk(name, make).items():
+            blob[f"fk/{name}/{k}"] = v
     for name, case in rc.cases().items():
         for k, v in run_case(name, case).items():
             blob[f"{name}/{k}"] = v

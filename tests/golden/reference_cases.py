@@ -47,6 +47,13 @@ def cases():
     }
 
 
+def fk_cases():
+    """Models whose (joint_q, joint_qd) go through newton.eval_fk."""
+    box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene = _scenes()
+    return {"joint_zoo": lambda: joint_zoo_scene(2, seed=21), "joint_zoo_free_root": lambda: joint_zoo_scene(2, seed=22, free_root=True),
+            "quadruped": lambda: quadruped_scene(2, seed=23), "pendulum": lambda: pendulum_scene(3, seed=24)}
+
+
 def prepare(case):
     """Build the case's model and apply its initial-state edits (root lowering, sinking, drop speed, joint forces)."""
     import newton_amd as nt

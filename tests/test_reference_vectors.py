@@ -107,3 +107,27 @@ def test_checker_collide_reproduces_the_reference_collision_kernels(oracle_lib, 
         err[k] = float(np.abs(getattr(ct, k)[:n] - ref[f"{name}/{k}"]).max())
     print(name, "contacts", n, "max abs error vs the reference kernels:", {k: float("%.3g" % v) for k, v in err.items()})
     assert all(v <= 2e-6 for v in err.values()), err
+
+
+@pytest.mark.parametrize("name", ["joint_zoo", "joint_zoo_free_root", "quadruped", "pendulum"])
+def test_checker_eval_fk_reproduces_the_reference(oracle_lib, name):
+    """newton.eval_fk of the reference (articulation.py:500-573, executed on the stand-in) vs the checker's o_eval_fk and the
+    host-side numpy FK the Python package uses for host models."""
+    import oracle_bridge as ob
+
+    import newton_amd as nt
+
+    rc = _cases()
+    ref = np.load(VEC)
+    model = rc.fk_cases()[name]()
+    jq, jqd = ref[f"fk/{name}/joint_q"], ref[f"fk/{name}/joint_qd"]
+    assert np.array_equal(jq, np.asarray(model.joint_q, np.float32))
+    bq, bqd = ob.Oracle(model).eval_fk(jq, jqd)
+    e = _errors(bq, bqd, ref[f"fk/{name}/body_q"], ref[f"fk/{name}/body_qd"])
+    print(name, "eval_fk checker vs reference: pos %.3g rot %.3g lin vel %.3g ang vel %.3g" % e)
+    assert max(e[:2]) <= 1e-7 and max(e[2:]) <= 1e-6, e
+    hq, hqd = nt.articulation.eval_fk_numpy(model, jq, jqd)
+    e = _errors(np.asarray(hq, np.float32).reshape(-1, 7), np.asarray(hqd, np.float32).reshape(-1, 6), ref[f"fk/{name}/body_q"],
+                ref[f"fk/{name}/body_qd"])
+    print(name, "eval_fk host numpy vs reference: pos %.3g rot %.3g lin vel %.3g ang vel %.3g" % e)
+    assert max(e[:2]) <= 2e-6 and max(e[2:]) <= 2e-5, e
