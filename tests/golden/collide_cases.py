@@ -94,6 +94,14 @@ def cases():
             return m, np.array(m.body_q, np.float32)
         return make
 
-    return {"pair_matrix_a": pair_matrix(11), "pair_matrix_b": pair_matrix(12), "mixed_primitives_a": mixed(3, 0), "mixed_primitives_b": mixed(4, 60), "mixed_primitives_c": mixed(5, 150),
+    def hulls(n, steps):
+        def make():
+            from scenes import hull_bin_scene
+
+            m = hull_bin_scene(1, n_hulls=n, seed=3)
+            return m, _settled(m, steps, dt=1.0 / 600.0)
+        return make
+
+    return {"hull_bin_a": hulls(6, 0), "hull_bin_b": hulls(8, 120), "pair_matrix_a": pair_matrix(11), "pair_matrix_b": pair_matrix(12), "mixed_primitives_a": mixed(3, 0), "mixed_primitives_b": mixed(4, 60), "mixed_primitives_c": mixed(5, 150),
             "box_stack_a": boxes(1, 0), "box_stack_b": boxes(2, 40), "quadruped_cylinders": quad(False, 30),
             "quadruped_box_feet": quad(True, 30)}

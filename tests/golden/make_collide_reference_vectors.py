@@ -45,11 +45,21 @@ def reference_collide(model, body_q, pairs, cmax):
     zero3 = arr(np.zeros((S, 3), np.float32), wp.vec3)
     shape_body, shape_type = arr(m.shape_body, int), arr(m.shape_type, int)
     shape_gap, shape_margin = arr(m.shape_gap, float), arr(m.shape_margin, float)
-    src = wp.to_array(np.zeros(S, np.int64), int)
+    # convex hulls: a Mesh of the unscaled vertices per shape, its id in shape_source_ptr, scaled local AABB (builder.py:11533-11686)
+    ids, loc_lo, loc_hi = np.zeros(S, np.int64), np.zeros((S, 3), np.float32), np.zeros((S, 3), np.float32)
+    ms, mc = np.asarray(getattr(m, "shape_mesh_start", -np.ones(S)), int), np.asarray(getattr(m, "shape_mesh_count", np.zeros(S)), int)
+    for k in range(S):
+        if mc[k] > 0:
+            v = np.asarray(m.mesh_points, np.float32).reshape(-1, 3)[ms[k]:ms[k] + mc[k]]
+            ids[k] = wp.Mesh(points=arr(v, wp.vec3)).id
+            sc = np.asarray(m.shape_scale, np.float32)[k]
+            loc_lo[k], loc_hi[k] = v.min(axis=0) * sc, v.max(axis=0) * sc
+    src = wp.to_array(ids, int)
+    zero3_lo, zero3_hi = arr(loc_lo, wp.vec3), arr(loc_hi, wp.vec3)
     radius = arr(getattr(m, "shape_collision_radius", np.zeros(S, np.float32)), float)
     wp.launch(collide.compute_shape_aabbs, dim=S,
               inputs=[bq, arr(m.shape_transform, wp.transform), shape_body, shape_type, arr(m.shape_scale, wp.vec3), radius, src,
-                      shape_margin, shape_gap, zero3, zero3, wp.zeros(1, dtype=int), wp.zeros(1, dtype=int), wp.zeros(1, dtype=int), 1],
+                      shape_margin, shape_gap, zero3_lo, zero3_hi, wp.zeros(1, dtype=int), wp.zeros(1, dtype=int), wp.zeros(1, dtype=int), 1],
               outputs=[lo, hi, geom_data, geom_xform])
     P = len(pairs)
     cand = arr(np.asarray(pairs, np.int32).reshape(-1, 2), wp.vec2i)
@@ -78,7 +88,7 @@ def reference_collide(model, body_q, pairs, cmax):
     G = int(gjk_count[0])
     if G:
         wp.launch(GJK_MPR, dim=G,
-                  inputs=[gjk_pairs, gjk_count, shape_type, geom_data, geom_xform, src, shape_gap, radius, lo, hi, zero3, zero3, w, G])
+                  inputs=[gjk_pairs, gjk_count, shape_type, geom_data, geom_xform, src, shape_gap, radius, lo, hi, zero3_lo, zero3_hi, w, G])
     n = int(w.contact_count[0])
     v3 = lambda a: np.array([[float(c) for c in x] for x in a[:n]], np.float32).reshape(n, 3)  # noqa: E731
     return {"count": np.array([n]), "count_analytic": np.array([n_analytic]), "gjk_pairs": np.array([[p[0], p[1]] for p in gjk_pairs[:G]], np.int32).reshape(G, 2),

@@ -971,6 +971,22 @@ class _Sub(_types.ModuleType):
         return _Inert(self.__name__ + "." + k)
 
 
+class Mesh:
+    """wp.Mesh stand-in: only what the convex-hull support map reads (points)."""
+
+    _registry = {}
+
+    def __init__(self, points=None, indices=None, **kw):
+        self.points = points
+        self.indices = indices
+        self.id = len(Mesh._registry) + 1
+        Mesh._registry[self.id] = self
+
+
+def mesh_get(mesh_id):
+    return Mesh._registry[int(mesh_id)]
+
+
 def _make_vector(length=None, dtype=None, *a, **k):
     n = length if length is not None else a[0]
 

@@ -78,7 +78,7 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
         assert worst_joint[0] <= 1e-7 and worst_joint[1] <= 1e-5, worst_joint
 
 
-COLLIDE_NAMES = ["pair_matrix_a", "pair_matrix_b", "mixed_primitives_a", "mixed_primitives_b", "mixed_primitives_c", "box_stack_a", "box_stack_b",
+COLLIDE_NAMES = ["hull_bin_a", "hull_bin_b", "pair_matrix_a", "pair_matrix_b", "mixed_primitives_a", "mixed_primitives_b", "mixed_primitives_c", "box_stack_a", "box_stack_b",
                  "quadruped_cylinders", "quadruped_box_feet"]
 
 

@@ -274,7 +274,7 @@ def _to_device(host_model):
     return m
 
 
-_COLLIDE_NAMES = ["pair_matrix_a", "pair_matrix_b", "mixed_primitives_a", "mixed_primitives_b", "mixed_primitives_c", "box_stack_a",
+_COLLIDE_NAMES = ["hull_bin_a", "hull_bin_b", "pair_matrix_a", "pair_matrix_b", "mixed_primitives_a", "mixed_primitives_b", "mixed_primitives_c", "box_stack_a",
                   "box_stack_b", "quadruped_cylinders", "quadruped_box_feet"]
 
 
