@@ -143,7 +143,17 @@ def run_case(name, case):
         s_in, s_out = ref_state(q, qd), ref_state(q, qd)
         for s_ in (s_in, s_out):
             s_.joint_q, s_.joint_qd = arr(jq, float), arr(jqd, float)
-        solver.step(s_in, s_out, None, ref_contacts(oc, n, case.get("props")) if n else None, case["dt"])
+        rcont = ref_contacts(oc, n, case.get("props")) if n else None
+        if case.get("report"):
+            s_out.body_parent_f = wp.zeros(len(q), dtype=wp.spatial_vector)
+            if rcont is not None:
+                rcont.force = wp.zeros(rcont.rigid_contact_max, dtype=wp.spatial_vector)
+        solver.step(s_in, s_out, None, rcont, case["dt"])
+        if case.get("report"):
+            out[f"body_parent_f{k + 1}"] = to_np(s_out.body_parent_f, 6)
+            if rcont is not None:
+                solver.update_contacts(rcont)
+                out[f"contact_force{k + 1}"] = to_np(rcont.force, 6)
         q, qd = to_np(s_out.body_q, 7), to_np(s_out.body_qd, 6)
         if kind == "featherstone":
             jq, jqd = np.array(s_out.joint_q, np.float32), np.array(s_out.joint_qd, np.float32)

@@ -27,6 +27,11 @@ def cases():
                                        kw=dict(iterations=4, rigid_contact_con_weighting=False, angular_damping=0.05)),
         "box_stack_sunk_restitution": dict(scene=lambda: box_stack_scene(1, n_boxes=3, seed=4, jitter=2e-3), steps=3, dt=1.0 / 240.0,
                                            kw=dict(iterations=2, enable_restitution=True), sink=0.002, drop_speed=0.3),
+        # with reporting: Contacts.force (update_contacts, solver_xpbd.py:864-921) and State.body_parent_f (:732-754)
+        "quadruped_report": dict(scene=lambda: quadruped_scene(1, seed=13, height_jitter=0.0), steps=3, dt=1e-3, kw=dict(iterations=2), lower=0.2225,
+                                 joint_f=sin_f, report=True),
+        "box_stack_report": dict(scene=lambda: box_stack_scene(1, n_boxes=3, seed=6, jitter=2e-3), steps=3, dt=1.0 / 240.0,
+                                 kw=dict(iterations=3), sink=0.001, report=True),
         # ---- SolverSemiImplicit (solver_semi_implicit.py:123-217)
         "semi/pendulum": dict(scene=lambda: pendulum_scene(2, seed=4), steps=6, dt=5e-4, solver="semi_implicit", kw={}),
         "semi/joint_zoo": dict(scene=lambda: joint_zoo_scene(1, seed=8), steps=4, dt=2e-4, solver="semi_implicit",

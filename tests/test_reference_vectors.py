@@ -32,7 +32,7 @@ def _errors(q, qd, q_ref, qd_ref):
 
 
 NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "joint_zoo", "joint_zoo_free_root",
-         "box_stack_no_weighting", "box_stack_sunk_restitution", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
+         "box_stack_no_weighting", "box_stack_sunk_restitution", "quadruped_report", "box_stack_report", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
          "semi/box_stack_contact_props", "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped"]
 
 
@@ -45,7 +45,11 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
     ref = np.load(VEC)
     case = rc.cases()[name]
     model = rc.prepare(case)
+    if case.get("report"):
+        model.request_state_attributes("body_parent_f")
+        model.request_contact_attributes("force")
     orc = ob.Oracle(model)
+    worst_report, force_seen = np.zeros(2), 0.0
     semi, fs = case.get("solver") == "semi_implicit", case.get("solver") == "featherstone"
     worst, worst_joint = np.zeros(4), np.zeros(2)
     for k in range(case["steps"]):
@@ -65,6 +69,12 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
                                                    np.abs(s_out.joint_qd - ref[f"{name}/joint_qd{k + 1}"]).max()])
         elif semi:
             orc.semi_implicit_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"])
+        elif case.get("report"):
+            force = np.zeros((ct.max, 6), np.float32)
+            orc.xpbd_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], contact_force_out=force, **case["kw"])
+            worst_report = np.maximum(worst_report, [np.abs(force[:n] - ref[f"{name}/contact_force{k + 1}"][:n]).max(),
+                                                     np.abs(s_out.body_parent_f - ref[f"{name}/body_parent_f{k + 1}"]).max()])
+            force_seen = max(force_seen, float(np.abs(ref[f"{name}/contact_force{k + 1}"][:n]).max()))
         else:
             orc.xpbd_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"])
         e = _errors(s_out.body_q, s_out.body_qd, ref[f"{name}/body_q{k + 1}"], ref[f"{name}/body_qd{k + 1}"])
@@ -73,6 +83,9 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
     # one step from identical inputs.  Measured: bit-identical positions and linear velocities in nearly every case; rotations
     # within 1.5e-8 and angular velocities within 3e-6 where asin / acos / atan2 enter (numpy float32 vs glibc)
     assert worst[0] <= 1e-7 and worst[1] <= 1e-7 and worst[2] <= 1e-6 and worst[3] <= 1e-5, worst
+    if case.get("report"):
+        print(name, "reporting: max abs error contacts.force %.3g [N], body_parent_f %.3g [N]" % tuple(worst_report))
+        assert worst_report[0] <= 1e-3 and worst_report[1] <= 1e-3 and force_seen > 1.0, (worst_report, force_seen)
     if fs:
         print(name, "joint space: max abs error joint_q %.3g joint_qd %.3g" % tuple(worst_joint))
         assert worst_joint[0] <= 1e-7 and worst_joint[1] <= 1e-5, worst_joint
