@@ -866,7 +866,13 @@ kernel = _decorator
 func = _decorator
 
 # bodies of the reference's native snippets (CPU branch of the snippet, fp32)
-_NATIVE = {"_support_rsqrt_rn": lambda value: f32(1.0) / _np.sqrt(_s(value))}
+def _float_flip(f):
+    i = int(_np.float32(f).view(_np.uint32))
+    mask = (0xFFFFFFFF if (i >> 31) else 0) | 0x80000000
+    return _np.uint32((i ^ mask) & 0xFFFFFFFF)
+
+
+_NATIVE = {"_support_rsqrt_rn": lambda value: f32(1.0) / _np.sqrt(_s(value)), "_float_flip": _float_flip}
 
 
 def func_replay(forward):

@@ -144,3 +144,31 @@ def test_checker_eval_fk_reproduces_the_reference(oracle_lib, name):
                 ref[f"fk/{name}/body_qd"])
     print(name, "eval_fk host numpy vs reference: pos %.3g rot %.3g lin vel %.3g ang vel %.3g" % e)
     assert max(e[:2]) <= 2e-6 and max(e[2:]) <= 2e-5, e
+
+
+@pytest.mark.parametrize("name,frames", [("box_stack", 6), ("mixed_primitives", 8)])
+def test_match_checker_reproduces_the_reference_contact_matcher(name, frames):
+    """tests/golden/make_match_reference_vectors.py ran the reference's ContactMatcher (contact_match.py:602-1055) frame by frame;
+    oracle/oracle_match.py must return the same match indices (including MATCH_NOT_FOUND / MATCH_BROKEN and claim races)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import oracle_match as om
+    from scenes import box_stack_scene, mixed_primitive_scene
+
+    ref = np.load(os.path.join(HERE, "golden", "match_reference_vectors.npz"))
+    model = box_stack_scene(1, n_boxes=4, seed=2, jitter=5e-3) if name == "box_stack" else mixed_primitive_scene(1, seed=4)
+    shape_body = np.asarray(model.shape_body)
+    prev = None
+    seen = set()
+    for k in range(frames):
+        g = lambda f: ref[f"{name}/{k}/{f}"]  # noqa: E731
+        mid = om.midpoints(g("body_q"), shape_body, g("shape0"), g("shape1"), g("point0"), g("point1"))
+        want = g("match")
+        if prev is None:
+            assert np.all(want == -1)
+        else:
+            got = om.match(g("keys"), mid, g("normal"), *prev)
+            assert np.array_equal(got, want), (k, got, want)
+            seen |= set(np.sign(want).tolist()) | ({-2} if np.any(want == -2) else set())
+        prev = (g("keys"), mid, g("normal"))
+    assert 1 in seen or 0 in seen
+    assert -2 in seen  # broken matches occur in both recordings
