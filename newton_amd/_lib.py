@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NEWTON_HIP_LIB", os.path.join(_HERE, "libnewton_hip.so"))  # override: A/B kernel builds
+_DEFAULT_LIB = os.path.join(_HERE, "libnewton_hip.so")
+# NEWTON_HIP_LIB: measurement / test use only (A/B of kernel builds, tools/phase_timing.py, the no-GPU dry run of the GPU test
+# files on tests/emu).  load() says so on stderr whenever the override is in effect; deployments use the in-tree library.
+LIB_PATH = os.environ.get("NEWTON_HIP_LIB", _DEFAULT_LIB)
 
 NT_CONTACT_FLOATS = 17
 NT_BODY_PARAM_FLOATS = 23
@@ -259,6 +262,10 @@ def load():
         raise NewtonHipError(
             f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(needs hipcc). There is no CPU fallback for the product path.")
+    if os.path.abspath(LIB_PATH) != os.path.abspath(_DEFAULT_LIB):
+        import sys
+
+        print(f"[newton_amd] NEWTON_HIP_LIB override in effect ({LIB_PATH}): measurement / test use only", file=sys.stderr)
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # missing libamdhip64 etc.
