@@ -253,27 +253,42 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
 // Launch shape of the analytic (non-convex) fused XPBD rollout: environments per workgroup, workgroup size, minimum waves
 // per SIMD (register cap), uniform-parameter tile.  NT_XPBD_CFG="epb,threads,minw[,uni]" selects one of the compiled shapes
 // for A/B measurements.
-struct XpbdCfg { int epb, threads, minw, uni; };
+struct XpbdCfg { int epb, threads, minw, uni, cvx; };
 inline bool xpbd_cfg_override(XpbdCfg& c) {
     const char* e = getenv("NT_XPBD_CFG");
     if (!e) return false;
-    c.uni = 0;
-    return sscanf(e, "%d,%d,%d,%d", &c.epb, &c.threads, &c.minw, &c.uni) >= 3;
+    c.uni = c.cvx = 0;
+    return sscanf(e, "%d,%d,%d,%d,%d", &c.epb, &c.threads, &c.minw, &c.uni, &c.cvx) >= 3;
 }
 #define NT_XPBD_ROLLOUT_SHAPES(X) \
     X(16, 512, 1, 0) X(16, 256, 1, 0) X(8, 256, 2, 0) \
     X(16, 256, 2, 1) X(16, 512, 2, 1) X(16, 512, 4, 1) X(32, 512, 1, 1) X(8, 128, 4, 1) X(8, 256, 4, 1)
+// convex (MPR / GJK) variants of the uniform-parameter tile: the parameter diet lets two 8-environment workgroups (or one of 16)
+// share a CU where the per-environment tile fits only 8 environments (8-box stacks: 13.6 -> 9.6 KB of LDS per environment)
+#define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1) X(16, 256, 2, 1)
 // the shape uniform-parameter models run by default once there are enough environments to give every CU a tile of 32 (measured,
 // MI355X, quadruped: 4096 envs 78 vs 92 M env-steps/s for the 16-env per-environment tile -- half the CUs idle; 8192 envs 158
 // vs 101 M; 65536 envs 157 vs 99 M.  2 x (16, 256) per CU: 144-149 M)
-constexpr XpbdCfg NT_XPBD_UNI_DEFAULT = {32, 512, 1, 1};
+constexpr XpbdCfg NT_XPBD_UNI_DEFAULT = {32, 512, 1, 1, 0};
 nt_status launch_xpbd_rollout_shape(const KArgs& a, XpbdCfg c, hipStream_t stream) {
 #define X(E, T, W, U) \
-    if (c.epb == E && c.threads == T && c.minw == W && c.uni == U) \
+    if (!c.cvx && c.epb == E && c.threads == T && c.minw == W && c.uni == U) \
         return launch(xpbd_rollout_kernel<E + U * NT_UNI, false, false, T, W>, a, E, stream, T, false, U != 0);
     NT_XPBD_ROLLOUT_SHAPES(X)
 #undef X
+#define X(E, T, W, U) \
+    if (c.cvx && c.epb == E && c.threads == T && c.minw == W && c.uni == U) \
+        return launch(xpbd_rollout_kernel<E + U * NT_UNI, true, false, T, W>, a, E, stream, T, false, U != 0);
+    NT_XPBD_ROLLOUT_SHAPES_CVX(X)
+#undef X
     return NT_ERR_UNSUPPORTED;
+}
+// convex models with uniform parameters: the widest uniform tile that fits, once every CU gets at least two of the narrow ones
+inline bool pick_cvx_uni_shape(const nt_model& m, bool rest, XpbdCfg& c) {
+    if (!m.params_uniform || rest || m.contact_scratch_in_hbm) return false;
+    if (m.env_count >= 256 * 16 && tile_lds_bytes(m, 16, rest, true) <= LDS_BYTES_PER_CU) { c = {16, 512, 1, 1, 1}; return true; }
+    if (m.env_count >= 256 * 16 && 2 * tile_lds_bytes(m, 8, rest, true) <= LDS_BYTES_PER_CU) { c = {8, 256, 2, 1, 1}; return true; }
+    return false;
 }
 
 #define NT_DISPATCH_EPB(KERNEL, args, epb, stream)                                      \
@@ -400,9 +415,18 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
         return m->np_analytic < m->np ? launch(xpbd_rollout_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(xpbd_rollout_kernel<1, false, true>, a, 1, (hipStream_t)stream);
     }
+    if (m->np_analytic < m->np) {  // convex models: uniform-parameter tiles when the parameters allow
+        XpbdCfg c;
+        if (xpbd_cfg_override(c) && c.cvx) {
+            if ((c.uni && (!m->params_uniform || rest)) || !epb_fits(*m, c.epb, rest, c.uni != 0)) return NT_ERR_UNSUPPORTED;
+            return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
+        }
+        if ((cp == nullptr || cp->envs_per_block == 0) && pick_cvx_uni_shape(*m, rest, c))
+            return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
+    }
     if (m->np_analytic == m->np) {  // analytic-only models: the tuned launch shapes
         XpbdCfg c;
-        if (xpbd_cfg_override(c)) {
+        if (xpbd_cfg_override(c) && !c.cvx) {
             if ((c.uni && (!m->params_uniform || rest)) || !epb_fits(*m, c.epb, rest, c.uni != 0)) return NT_ERR_UNSUPPORTED;
             return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
         }
@@ -420,18 +444,23 @@ nt_status nt_xpbd_rollout_shape(const nt_model* m, const nt_xpbd_params* p, cons
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0, rest);
     if (!epb) return NT_ERR_UNSUPPORTED;
     const bool cvx = m->np_analytic < m->np, big = m->contact_scratch_in_hbm != 0;
-    XpbdCfg c = {epb, max_threads_for(epb), 1, 0};
-    if (big) c = {1, 256, 1, 0};
+    XpbdCfg c = {epb, max_threads_for(epb), 1, 0, 0};
+    if (big) c = {1, 256, 1, 0, 0};
     else if (!cvx) {
         XpbdCfg o;
-        if (xpbd_cfg_override(o)) c = o;
+        if (xpbd_cfg_override(o) && !o.cvx) c = o;
         else if (m->params_uniform && !rest && m->env_count >= 256 * NT_XPBD_UNI_DEFAULT.epb &&
                  epb_fits(*m, NT_XPBD_UNI_DEFAULT.epb, rest, true) && (cp == nullptr || cp->envs_per_block == 0))
             c = NT_XPBD_UNI_DEFAULT;
         else if (epb == 4) c.epb = 8;
     } else {
-        c.epb = epb >= 16 ? 16 : (epb >= 4 ? 8 : 1);
-        c.threads = max_threads_for(c.epb);
+        XpbdCfg o;
+        if (xpbd_cfg_override(o) && o.cvx) c = o;
+        else if ((cp == nullptr || cp->envs_per_block == 0) && pick_cvx_uni_shape(*m, rest, o)) c = o;
+        else {
+            c.epb = epb >= 16 ? 16 : (epb >= 4 ? 8 : 1);
+            c.threads = max_threads_for(c.epb);
+        }
     }
     out[0] = c.epb; out[1] = c.threads; out[2] = c.minw; out[3] = c.uni; out[4] = (cvx ? 1 : 0) | (big ? 2 : 0);
     return NT_OK;

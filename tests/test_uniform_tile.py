@@ -87,3 +87,28 @@ def test_candidate_compaction_of_staged_tiles_is_bitwise_the_plain_pair_loop(H):
     for x, y in zip(*outs):
         assert np.array_equal(x.view(np.int32) if x.dtype == np.float32 else x, y.view(np.int32) if y.dtype == np.float32 else y)
     assert outs[0][4][:11].min() > 0
+
+
+@pytest.mark.parametrize("cfg", ["8,256,2,1,1", "16,512,1,1,1", "16,256,2,1,1"])
+def test_convex_uniform_tile_is_bitwise_the_per_environment_tile(H, cfg):
+    """Box stacks (MPR / GJK pairs): the uniform-parameter tiles of the convex rollout against the default per-environment tile."""
+    from scenes import box_stack_scene
+
+    model = box_stack_scene(19, n_boxes=5, seed=7, jitter=2e-3)
+    outs = []
+    for c in (None, cfg):
+        em = H.EmuModel(model)
+        assert em.desc.params_uniform == 1 and em.t.np_analytic < em.t.np
+        a, b, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+        old = os.environ.pop("NT_XPBD_CFG", None)
+        try:
+            if c:
+                os.environ["NT_XPBD_CFG"] = c
+            H.xpbd_rollout(em, a, b, ctrl, ct, 1.0 / 240.0, 4, epb=8 if c is None else 0, iterations=4)
+        finally:
+            os.environ.pop("NT_XPBD_CFG", None)
+            if old is not None:
+                os.environ["NT_XPBD_CFG"] = old
+        outs.append((a.body_q.copy(), a.body_qd.copy(), ct.data.copy(), ct.shape0.copy()))
+    for x, y in zip(*outs):
+        assert np.array_equal(x.view(np.int32) if x.dtype == np.float32 else x, y.view(np.int32) if y.dtype == np.float32 else y)
