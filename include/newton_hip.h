@@ -181,6 +181,14 @@ typedef struct {
 typedef struct {
     float angular_damping; /* accepted like the reference constructor; the reference step does not use it either */
     float friction_smoothing;
+    /* SolverFeatherstone(update_mass_matrix_interval = k) (solver_featherstone.py:141,767): substep s of a call rebuilds
+     * P / H and refactorises when mass_matrix_cache is NULL, force_update != 0 (first substep only: the reference's
+     * _mass_matrix_dirty), or (step_index + s) % k == 0; the Cholesky factor ([nd * max_art_dofs][ES], env-major) is stored
+     * to / reloaded from mass_matrix_cache in between.  Zero-initialised fields = rebuild every step (k = 1). */
+    int32_t update_mass_matrix_interval;
+    int32_t step_index;
+    int32_t force_update;
+    float* mass_matrix_cache;
 } nt_featherstone_params;
 
 typedef struct {

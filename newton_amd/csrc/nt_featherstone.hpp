@@ -606,8 +606,9 @@ NT_DI void fs_H_item(const FsCtx<EPB>& f, int item) {
         __builtin_amdgcn_wave_barrier();                      \
     } while (0)
 
+// factor = false: H holds the factor of an earlier step (update_mass_matrix_interval > 1), only the substitutions run
 template <int EPB>
-NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G) {
+NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G, const bool factor = true) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int W = m.max_art_dofs, nd = m.nd;
@@ -619,7 +620,7 @@ NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G) {
     const int e = c.e;
     auto A = [&](int i, int j) -> float& { return lds[(f.F.H + (d0 + i) * W + j) * EPB + e]; };
     auto X = [&](int i) -> float& { return lds[(f.F.qdd + d0 + i) * EPB + e]; };
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; factor && j < n; ++j) {
         float s = A(j, j) + c.dof(DP_ARMATURE, d0 + j);  // every lane evaluates the pivot (no broadcast needed)
         {
             int k = 0;
@@ -896,10 +897,18 @@ NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
     __syncthreads();
 }
 
+// update_mass: rebuild P / H and refactorise (else the factor comes back from nt_featherstone_params.mass_matrix_cache)
+template <int EPB>
+NT_DI bool fs_update_mass(const Ctx<EPB>& c, int substep) {
+    const nt_featherstone_params& p = c.a.fp;
+    if (!p.mass_matrix_cache || p.update_mass_matrix_interval <= 1) return true;
+    if (p.force_update && substep == 0) return true;
+    return ((p.step_index + substep) % p.update_mass_matrix_interval) == 0;
+}
 // One SolverFeatherstone.step on the state resident in LDS (joint_q in F.jq, public joint_qd in F.qdp).
 template <int EPB>
 NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F, int max_depth, bool forces_are_zero,
-                      bool publish_fk, float* parent_f_out) {
+                      bool publish_fk, float* parent_f_out, const int substep = 0) {
     const KArgs& a = c.a;
     const nt_model& m = a.m;
     const int nj = m.nj, nb = m.nb;
@@ -969,20 +978,28 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         }
     // P = M J (non-zero blocks), H = J^T P (lower triangle), Cholesky, solve
     const int W = m.max_art_dofs;
-    if (c.valid && !(skip & 16))
-        for (int i = c.slot; i < nj * W; i += c.nslot) fs_P_item(f, i);
-    __syncthreads();
-    NT_TICK(16);
-    if (c.valid && !(skip & 32))
-        for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
+    const bool update_mass = fs_update_mass(c, substep);
+    float* cache = a.fp.mass_matrix_cache;
+    if (update_mass) {
+        if (c.valid && !(skip & 16))
+            for (int i = c.slot; i < nj * W; i += c.nslot) fs_P_item(f, i);
+        __syncthreads();
+        NT_TICK(16);
+        if (c.valid && !(skip & 32))
+            for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
+    } else if (c.valid) {  // the factor of the last rebuild
+        for (int r = c.slot; r < m.nd * W; r += c.nslot) f.f(F.H, r) = cache[(size_t)r * c.ES + c.env];
+    }
     __syncthreads();
     NT_TICK(17);
     {
         const int G = (64 / EPB) < c.nslot ? (64 / EPB) : c.nslot;
         if (c.valid && !(skip & 64) && c.slot < G)
-            for (int k = 0; k < m.na; ++k) fs_solve_coop(f, k, c.slot, G);
+            for (int k = 0; k < m.na; ++k) fs_solve_coop(f, k, c.slot, G, update_mass);
     }
     __syncthreads();
+    if (update_mass && cache && a.fp.update_mass_matrix_interval > 1 && c.valid)
+        for (int r = c.slot; r < m.nd * W; r += c.nslot) cache[(size_t)r * c.ES + c.env] = f.f(F.H, r);
     NT_TICK(18);
     // integrate_generalized_joints
     if (c.valid)
@@ -1064,7 +1081,7 @@ __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(cc, s == a.substeps - 1);
-        fs_substep(c, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr);
+        fs_substep(c, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr, s);
     }
     if (c.valid) {
         unstage_rows(c, F.jq, res.joint_q, m.nc);

@@ -561,6 +561,7 @@ nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* 
     if (c) a.ct = *c;
     a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
     a.sp.friction_smoothing = p->friction_smoothing;
+    a.fp = *p;
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     return fs_launch(m, a, envs_per_block, false, (hipStream_t)stream);
@@ -580,6 +581,7 @@ nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_param
     a.ct = *c;
     a.has_contacts = m->np > 0 ? 1 : 0;
     a.sp.friction_smoothing = p->friction_smoothing;
+    a.fp = *p;
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     a.substeps = substeps;

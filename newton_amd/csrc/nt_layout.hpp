@@ -146,6 +146,7 @@ struct KArgs {
     nt_xpbd_params p;
     nt_xpbd_report rep;  // optional reporting outputs of nt_xpbd_step (all NULL on the hot path)
     nt_semi_implicit_params sp;
+    nt_featherstone_params fp;  // mass-matrix update cadence of SolverFeatherstone (zero: rebuild every step)
     float angular_damping;  // integrate_bodies damping of the active solver
     float dt;
     int substeps;

@@ -25,9 +25,8 @@ class SolverFeatherstone(SolverBase):
                  envs_per_block: int = 0):
         super().__init__(model)
         t = model.env
-        if update_mass_matrix_interval != 1:
-            raise NotImplementedError("SolverFeatherstone: update_mass_matrix_interval must be 1 (H is rebuilt in LDS "
-                                      "every step; there is no cached factorisation to reuse)")
+        if int(update_mass_matrix_interval) < 1:
+            raise ValueError("update_mass_matrix_interval must be >= 1")
         if t.nj == 0 or t.na == 0:
             raise NotImplementedError("SolverFeatherstone needs articulated bodies (every body behind a joint, "
                                       "articulations contiguous and identical in every world)")
@@ -44,7 +43,15 @@ class SolverFeatherstone(SolverBase):
         if np.any(kin & (np.asarray(t.joint_parent) >= 0)):  # child of joint j is body j (checked above)
             raise ValueError("SolverFeatherstone: only root bodies (joint parent = world) can be kinematic")
         self.angular_damping = angular_damping
-        self.update_mass_matrix_interval = 1
+        # every k-th step rebuilds P / H and refactorises; in between the kernels reuse the factor of the last rebuild, kept in
+        # HBM ([nd * max_art_dofs][ES]); solver_featherstone.py:141,767 (_step, _mass_matrix_dirty)
+        self.update_mass_matrix_interval = int(update_mass_matrix_interval)
+        self._step, self._mass_matrix_dirty, self._factor_cache = 0, False, None
+        if self.update_mass_matrix_interval > 1:
+            import torch
+
+            self._factor_cache = torch.zeros((max(t.nd * t.max_art_dofs, 1), t.env_stride), dtype=torch.float32,
+                                             device=self.dm.device)
         self.friction_smoothing = friction_smoothing
         self.use_tile_gemm = use_tile_gemm      # accepted for signature parity; H never leaves LDS here
         self.fuse_cholesky = fuse_cholesky
@@ -56,12 +63,26 @@ class SolverFeatherstone(SolverBase):
             if not hasattr(self, "_control"):
                 self._control = self.model.control()
             control = self._control
-        p = _lib.nt_featherstone_params(float(self.angular_damping), float(self.friction_smoothing))
+        p = self._params()
         d_in, d_out, d_c = state_in._desc(), state_out._desc(), control._desc()
         d_ct = contacts._desc() if contacts is not None else None
         _lib.check(dm.lib.nt_featherstone_step(C.byref(dm.desc), C.byref(p), C.byref(d_in), C.byref(d_out), C.byref(d_c),
                                                C.byref(d_ct) if d_ct is not None else None, float(dt),
                                                self.envs_per_block, dm.stream()), "nt_featherstone_step")
+        self._step += 1
+        self._mass_matrix_dirty = False
+
+    def _params(self):
+        p = _lib.nt_featherstone_params(float(self.angular_damping), float(self.friction_smoothing))
+        if self._factor_cache is not None:
+            p.update_mass_matrix_interval, p.step_index = self.update_mass_matrix_interval, self._step
+            p.force_update, p.mass_matrix_cache = int(self._mass_matrix_dirty), self._factor_cache.data_ptr()
+        return p
+
+    def notify_model_changed(self, flags) -> None:
+        """Body / joint-dof property edits invalidate the cached factor (solver_featherstone.py:284-288)."""
+        super().notify_model_changed(flags)
+        self._mass_matrix_dirty = True
 
     def rollout(self, state_0, state_1, control, contacts, dt: float, substeps: int):
         """substeps x {clear_forces; collide; step; swap} in ONE launch (``nt_featherstone_rollout``); returns the state
@@ -71,11 +92,13 @@ class SolverFeatherstone(SolverBase):
             if not hasattr(self, "_control"):
                 self._control = self.model.control()
             control = self._control
-        p = _lib.nt_featherstone_params(float(self.angular_damping), float(self.friction_smoothing))
+        p = self._params()
         cp = _lib.nt_collide_params(0, self.envs_per_block)
         d0, d1, d_c, d_ct = state_0._desc(), state_1._desc(), control._desc(), contacts._desc()
         _lib.check(dm.lib.nt_featherstone_rollout(C.byref(dm.desc), C.byref(p), C.byref(cp), C.byref(d0), C.byref(d1),
                                                   C.byref(d_c), C.byref(d_ct), float(dt), int(substeps), dm.stream()),
                    "nt_featherstone_rollout")
+        self._step += int(substeps)
+        self._mass_matrix_dirty = False
         contacts._generation += 1
         return state_1 if substeps % 2 else state_0

@@ -137,6 +137,11 @@ typedef struct {
 typedef struct {
     float angular_damping; /* accepted for API parity; unused by the reference step */
     float friction_smoothing;
+    /* SolverFeatherstone(update_mass_matrix_interval) (solver_featherstone.py:141,767): when mass_matrix_cache is non-NULL the
+     * Cholesky factors L of all articulations (concatenated n x n blocks, articulation order) are stored there on steps that
+     * rebuild J / M / H and reused on steps with update_mass_matrix == 0 */
+    int update_mass_matrix;
+    float* mass_matrix_cache;
 } o_featherstone_params;
 
 /* broad phase kinds */

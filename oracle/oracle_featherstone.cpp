@@ -523,7 +523,10 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
             }
     }
 
-    // J, M, P = M J, H = J^T P, L = chol(H + diag(armature)), solve (kernels.py:1422-1565,1655-1846)
+    // J, M, P = M J, H = J^T P, L = chol(H + diag(armature)), solve (kernels.py:1422-1565,1655-1846); every
+    // update_mass_matrix_interval-th step only (solver_featherstone.py:767), the factors are reused in between
+    const bool rebuild = prm->mass_matrix_cache == nullptr || prm->update_mass_matrix != 0;
+    size_t cache_off = 0;
     for (int a = 0; a < m->articulation_count; ++a) {
         int joint_start = m->articulation_start[a], joint_end = m->articulation_end[a];
         int joint_count = joint_end - joint_start;
@@ -532,6 +535,11 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
         int n = dof_stop - dof_start, rows = 6 * joint_count;
         std::vector<float> Jm(size_t(rows) * n, 0.0f), M(size_t(rows) * rows, 0.0f), P(size_t(rows) * n), H(size_t(n) * n),
             L(size_t(n) * n, 0.0f);
+        float* cached = prm->mass_matrix_cache ? prm->mass_matrix_cache + cache_off : nullptr;
+        cache_off += size_t(n) * n;
+        if (!rebuild) {
+            for (size_t i = 0; i < size_t(n) * n; ++i) L[i] = cached[i];
+        } else {
         for (int i = 0; i < joint_count; ++i) {
             int row_start = i * 6;
             int j = joint_start + i;
@@ -587,6 +595,9 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
                 L[size_t(i) * n + j] = s * invS;
             }
         }
+        if (cached)
+            for (size_t i = 0; i < size_t(n) * n; ++i) cached[i] = L[i];
+        }  // rebuild
         const float* b = joint_tau.data() + dof_start;
         float* x = joint_qdd.data() + dof_start;
         for (int i = 0; i < n; ++i) {

@@ -47,6 +47,10 @@ def cases():
                              kw=dict(angular_damping=0.1)),
         "fs/joint_zoo_free_root": dict(scene=lambda: joint_zoo_scene(1, seed=10, free_root=True), steps=3, dt=5e-4,
                                        solver="featherstone", kw={}),
+        "fs/quadruped_interval3": dict(scene=lambda: quadruped_scene(1, seed=12), steps=5, dt=5e-4, solver="featherstone",
+                                       kw=dict(update_mass_matrix_interval=3), lower=0.221),
+        "fs/joint_zoo_interval2": dict(scene=lambda: joint_zoo_scene(1, seed=14), steps=4, dt=5e-4, solver="featherstone",
+                                       kw=dict(update_mass_matrix_interval=2)),
         "fs/quadruped": dict(scene=lambda: quadruped_scene(1, seed=11), steps=3, dt=5e-4, solver="featherstone",
                              kw=dict(friction_smoothing=0.5), lower=0.221, joint_f=sin_f),
     }

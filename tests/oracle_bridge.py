@@ -67,7 +67,8 @@ class o_semi_implicit_params(C.Structure):
 
 
 class o_featherstone_params(C.Structure):
-    _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float)]
+    _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float), ("update_mass_matrix", C.c_int),
+                ("mass_matrix_cache", C.POINTER(C.c_float))]
 
 
 _lib = None
@@ -288,9 +289,16 @@ class Oracle:
                                     C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))
 
     def featherstone_step(self, s_in: OracleState, s_out: OracleState, control, contacts, dt, angular_damping=0.05,
-                          friction_smoothing=1.0):
-        """SolverFeatherstone.step: advances joint_q/joint_qd and rebuilds body_q/body_qd (s_in.body_q is refreshed by FK)."""
-        p = o_featherstone_params(angular_damping, friction_smoothing)
+                          friction_smoothing=1.0, update_mass_matrix_interval=1):
+        """SolverFeatherstone.step: advances joint_q/joint_qd and rebuilds body_q/body_qd (s_in.body_q is refreshed by FK).
+        update_mass_matrix_interval > 1: this facade keeps the step counter and the factor cache like the reference solver."""
+        p = o_featherstone_params(angular_damping, friction_smoothing, 1, None)
+        if update_mass_matrix_interval > 1:
+            if not hasattr(self, "_fs_cache"):
+                self._fs_cache, self._fs_step = np.zeros(max(self.model.joint_dof_count, 1) ** 2, dtype=np.float32), 0
+            p.update_mass_matrix = 1 if self._fs_step % update_mass_matrix_interval == 0 else 0
+            p.mass_matrix_cache = _fp(self._fs_cache)
+            self._fs_step += 1
         si, so = s_in.struct, s_out.struct
         self.L.o_featherstone_step(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
                                    C.byref(contacts.struct) if contacts is not None else None, C.c_float(dt))

@@ -33,7 +33,8 @@ def _errors(q, qd, q_ref, qd_ref):
 
 NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "joint_zoo", "joint_zoo_free_root",
          "box_stack_no_weighting", "box_stack_sunk_restitution", "quadruped_report", "box_stack_report", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
-         "semi/box_stack_contact_props", "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped"]
+         "semi/box_stack_contact_props", "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped", "fs/quadruped_interval3",
+         "fs/joint_zoo_interval2"]
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -203,7 +203,8 @@ def test_descriptor_built_by_the_c_helper_steps_like_the_python_built_one():
 
 _REF_NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "joint_zoo", "joint_zoo_free_root",
               "box_stack_no_weighting", "box_stack_sunk_restitution", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
-              "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped"]
+              "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped", "fs/quadruped_interval3",
+              "fs/joint_zoo_interval2"]
 
 
 @pytest.mark.parametrize("name", _REF_NAMES)
@@ -309,3 +310,37 @@ def test_hip_collide_against_reference_collision_vectors(name):
     err = {k: float(np.abs(get(k) - ref[f"{name}/{k}"]).max()) for k in ("point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")}
     print(name, "HIP collide vs reference kernels:", {k: float("%.3g" % v) for k, v in err.items()})
     assert all(v <= 1e-5 for v in err.values()), err
+
+
+def test_featherstone_rollout_with_a_mass_matrix_interval_is_the_step_loop():
+    """update_mass_matrix_interval = 3: the fused rollout (substep index inside the launch) and the launch-by-launch loop
+    rebuild the mass matrix on the same steps and agree bit for bit; interval 1 gives a different (fresher) result."""
+    import torch
+    from scenes import quadruped_scene
+
+    import newton_amd as nt
+
+    def run(interval, fused):
+        model = quadruped_scene(16, device="cuda:0", seed=3)
+        solver = nt.solvers.SolverFeatherstone(model, update_mass_matrix_interval=interval)
+        pipe = nt.CollisionPipeline(model)
+        contacts = pipe.contacts()
+        s0, s1 = model.state(), model.state()
+        if fused:
+            out = solver.rollout(s0, s1, None, contacts, 1e-3, 7)
+            out = solver.rollout(out, s1 if out is s0 else s0, None, contacts, 1e-3, 4)
+        else:
+            for _ in range(11):
+                s0.clear_forces()
+                pipe.collide(s0, contacts)
+                solver.step(s0, s1, None, contacts, 1e-3)
+                s0, s1 = s1, s0
+            out = s0
+        torch.cuda.synchronize()
+        return out.joint_q.cpu().numpy().copy(), out.joint_qd.cpu().numpy().copy()
+
+    q_loop, qd_loop = run(3, False)
+    q_fused, qd_fused = run(3, True)
+    assert np.array_equal(q_loop.view(np.int32), q_fused.view(np.int32)) and np.array_equal(qd_loop.view(np.int32), qd_fused.view(np.int32))
+    q1, qd1 = run(1, True)
+    assert not np.array_equal(qd1, qd_fused) and np.abs(qd1 - qd_fused).max() < 1e-2
