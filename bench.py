@@ -222,7 +222,8 @@ def run(args, rank, local_rank, world, dist):
     barrier()
     T = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream (torch current stream)
-    T = max_over_ranks(T, device=device)  # MAX over ranks (no-op at N=1)
+    dry = os.environ.get("NT_BENCH_DRY_SINGLE_GPU", "0") == "1"
+    T = max_over_ranks(T, device=None if dry else device)  # MAX over ranks (no-op at N=1)
 
     gate = validity_gate(args.workload, model, s0)
     c_per_env = float(contacts.rigid_contact_count_per_env.float().mean().item())
@@ -297,13 +298,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
+    # NT_BENCH_DRY_SINGLE_GPU=1 (logic check of the N > 1 path on a 1-GPU box, never a measurement): every rank uses cuda:0
+    # and the process group runs on gloo; the printed line carries "dry_run": true
+    dry = os.environ.get("NT_BENCH_DRY_SINGLE_GPU", "0") == "1"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     if args.sweep:
         rows = []
@@ -327,6 +336,8 @@ def main():
     else:
         out = run(args, rank, local_rank, world, dist)
         if out is not None:
+            if dry:
+                out["dry_run"] = True
             if not args.no_cpu_baseline and world == 1 and args.workload == "quadruped":
                 out["cpu_baseline"] = cpu_baseline()
             print(json.dumps(out), flush=True)
