@@ -260,12 +260,19 @@ inline bool xpbd_cfg_override(XpbdCfg& c) {
     c.uni = c.cvx = 0;
     return sscanf(e, "%d,%d,%d,%d,%d", &c.epb, &c.threads, &c.minw, &c.uni, &c.cvx) >= 3;
 }
+// Shapes the default dispatch can take are always compiled; the A/B shapes (NT_XPBD_CFG experiments, tests/test_uniform_tile.py on
+// the emulated library) only with -DNT_ALL_SHAPES: each fused-rollout instantiation costs ~25 s of hipcc time.
+#ifdef NT_ALL_SHAPES
 #define NT_XPBD_ROLLOUT_SHAPES(X) \
     X(16, 512, 1, 0) X(16, 256, 1, 0) X(8, 256, 2, 0) \
     X(16, 256, 2, 1) X(16, 512, 2, 1) X(16, 512, 4, 1) X(32, 512, 1, 1) X(8, 128, 4, 1) X(8, 256, 4, 1)
+#define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1) X(16, 256, 2, 1)
+#else
+#define NT_XPBD_ROLLOUT_SHAPES(X) X(16, 512, 1, 0) X(32, 512, 1, 1) X(16, 256, 2, 1)
+#define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1)
+#endif
 // convex (MPR / GJK) variants of the uniform-parameter tile: the parameter diet lets two 8-environment workgroups (or one of 16)
 // share a CU where the per-environment tile fits only 8 environments (8-box stacks: 13.6 -> 9.6 KB of LDS per environment)
-#define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1) X(16, 256, 2, 1)
 // the shape uniform-parameter models run by default once there are enough environments to give every CU a tile of 32 (measured,
 // MI355X, quadruped: 4096 envs 78 vs 92 M env-steps/s for the 16-env per-environment tile -- half the CUs idle; 8192 envs 158
 // vs 101 M; 65536 envs 157 vs 99 M.  2 x (16, 256) per CU: 144-149 M)
