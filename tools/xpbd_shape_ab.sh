@@ -2,7 +2,7 @@
 # A/B of the launch shapes of the analytic fused XPBD rollout (NT_XPBD_CFG = envs per workgroup, workgroup size, min waves per
 # SIMD, uniform-parameter tile) on the headline workload; prints env-steps/s and kernel ms per shape.  usage: tools/xpbd_shape_ab.sh [envs] [shapes...]
 ENVS=${1:-4096}; shift
-SHAPES=${@:-"16,512,1,0 16,256,1,0 8,256,2,0 16,256,2,1 16,512,2,1 16,512,4,1 32,512,1,1 8,128,4,1 8,256,4,1"}
+SHAPES=${@:-"16,512,1,0 32,512,1,1 16,256,2,1"}  # the shapes of the product build; the full A/B list needs a library built with -DNT_ALL_SHAPES
 STEPS=$(( 4096 * 300 / ENVS )); [ $STEPS -lt 20 ] && STEPS=20
 for s in $SHAPES; do
   echo -n "shape=$s envs=$ENVS "
