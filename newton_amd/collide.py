@@ -210,6 +210,16 @@ class ContactMatcher:
             self._reset_mask = m
             self._live[:, : t.env_count] *= (1 - m)[None, :]
 
+    def previous_rows_alive(self, n: int):
+        """bool [n] over the previous frame's flat rows: True while the row's history has not been reset."""
+        torch = _torch()
+        t = self.model.env
+        alive = torch.zeros(max(n, 1), dtype=torch.bool, device=self.dm.device)
+        if self._prev_flat is not None and n > 0:
+            keep = (self._prev_flat >= 0) & (self._live[: t.np * t.cpp, : t.env_count] != 0)
+            alive[self._prev_flat[keep]] = True
+        return alive[:n]
+
     def _flat_index(self, live):
         """Export-order index of every live slot: all envs' analytic contacts in (env, slot) order, then the convex ones."""
         torch = _torch()
@@ -304,9 +314,23 @@ class CollisionPipeline:
     _BROAD_PHASES = {"explicit": 0, "nxn": 1, "sap": 2, None: 0}
 
     def __init__(self, model, *, broad_phase=None, rigid_contact_max=None, reduce_contacts=True, deterministic=False,
-                 sdf_hydroelastic_config=None, envs_per_block: int = 0, **unsupported):
+                 sdf_hydroelastic_config=None, envs_per_block: int = 0, contact_matching: str = "disabled",
+                 contact_matching_pos_threshold: float = 0.0005, contact_matching_normal_dot_threshold: float = 0.995,
+                 contact_report: bool = False, **unsupported):
         if unsupported:
             raise NotImplementedError(f"CollisionPipeline options not supported: {sorted(unsupported)}")
+        # frame-to-frame matching (collide.py:1126-1129,1253-1268): "latest" fills contacts.rigid_contact_match_index every
+        # collide(); "sticky" (replaying the previous contact geometry on matched rows) is not implemented
+        if contact_matching not in ("disabled", "latest", "sticky"):
+            raise ValueError(f"contact_matching must be one of 'disabled', 'latest', 'sticky', got {contact_matching!r}")
+        if contact_matching == "sticky":
+            raise NotImplementedError('contact_matching="sticky" is not implemented (SURVEY.md section 8 row (f)3: "latest" only)')
+        if contact_matching_pos_threshold < 0.0:
+            raise ValueError(f"contact_matching_pos_threshold must be non-negative, got {contact_matching_pos_threshold}")
+        if not -1.0 <= contact_matching_normal_dot_threshold <= 1.0:
+            raise ValueError(f"contact_matching_normal_dot_threshold must be in [-1, 1], got {contact_matching_normal_dot_threshold}")
+        if contact_report and contact_matching == "disabled":
+            raise ValueError('contact_report=True requires contact_matching != "disabled"')
         if sdf_hydroelastic_config is not None:
             raise NotImplementedError("hydroelastic contacts are not implemented yet (SURVEY.md section 8, row a25)")
         if broad_phase not in self._BROAD_PHASES:
@@ -322,14 +346,65 @@ class CollisionPipeline:
         model.rigid_contact_max = self._rigid_contact_max
         # fixed slots + ordered reductions: results are reproducible either way; deterministic=True additionally orders the
         # flat contact arrays by the reference's contact sort key (collide.py deterministic mode, contact_sort.py)
-        self.deterministic = bool(deterministic)
+        # matching indexes the key-sorted rows of the previous frame, so it implies the deterministic order (the reference
+        # builds its ContactSorter for both, collide.py:1653-1667)
+        self.contact_matching, self.contact_report = contact_matching, bool(contact_report)
+        self.deterministic = bool(deterministic) or contact_matching != "disabled"
+        self._matcher = (ContactMatcher(model, contact_matching_pos_threshold, contact_matching_normal_dot_threshold)
+                         if contact_matching != "disabled" else None)
+        self._prev_count = 0
 
     @property
     def rigid_contact_max(self):
         return self._rigid_contact_max
 
     def contacts(self, per_contact_shape_properties: bool = False) -> Contacts:
-        return Contacts(self.model, sort_by_key=self.deterministic, per_contact_shape_properties=per_contact_shape_properties)
+        c = Contacts(self.model, sort_by_key=self.deterministic, per_contact_shape_properties=per_contact_shape_properties)
+        c._contact_matching_mode = self.contact_matching
+        if self._matcher is not None:
+            torch = _torch()
+            dev, n = self.dm.device, max(self._rigid_contact_max, 1)
+            c.rigid_contact_match_index = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            if self.contact_report:
+                c.rigid_contact_new_indices = torch.zeros(n, dtype=torch.int32, device=dev)
+                c.rigid_contact_new_count = torch.zeros(1, dtype=torch.int32, device=dev)
+                c.rigid_contact_broken_indices = torch.zeros(n, dtype=torch.int32, device=dev)
+                c.rigid_contact_broken_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        return c
+
+    def reset_contact_matching(self, world_mask=None) -> None:
+        """Forget the matching history of the selected worlds (all when None), collide.py:1732-1760."""
+        if self._matcher is None:
+            raise ValueError('reset_contact_matching requires contact_matching != "disabled"')
+        self._matcher.reset(world_mask)
+        if world_mask is None:
+            self._prev_count = 0
+
+    def _match(self, state, contacts):
+        """contacts.rigid_contact_match_index (+ the new / broken report) for this frame, then save the frame as history."""
+        torch = _torch()
+        if getattr(contacts, "rigid_contact_match_index", None) is None:
+            raise ValueError("CollisionPipeline has contact_matching enabled but the Contacts buffer was created without it. "
+                             "Use pipeline.contacts() to create a compatible buffer.")
+        m = self._matcher.match(state, contacts)
+        n = int(m.numel()) if int(contacts.rigid_contact_count[0].item()) > 0 else 0
+        contacts.rigid_contact_match_index.fill_(-1)
+        contacts.rigid_contact_match_index[:n] = m[:n]
+        if self.contact_report:
+            new = torch.nonzero(m[:n] < 0).flatten().to(torch.int32)
+            contacts.rigid_contact_new_indices[: new.numel()] = new
+            contacts.rigid_contact_new_count[0] = new.numel()
+            # broken: rows of the previous frame that no contact of this frame matched (worlds reset since are skipped by
+            # the matcher: their history is gone, so they report neither matches nor broken rows)
+            hit = torch.zeros(max(self._prev_count, 1), dtype=torch.bool, device=m.device)
+            ok = m[:n][m[:n] >= 0].to(torch.int64)
+            hit[ok] = True
+            live_prev = self._matcher.previous_rows_alive(self._prev_count)
+            broken = torch.nonzero(~hit[: self._prev_count] & live_prev).flatten().to(torch.int32)
+            contacts.rigid_contact_broken_indices[: broken.numel()] = broken
+            contacts.rigid_contact_broken_count[0] = broken.numel()
+        self._matcher.save_sorted_state(state, contacts)
+        self._prev_count = n
 
     def collide(self, state, contacts: Contacts, *, soft_contact_margin=None, dt=None):
         if contacts.model is not self.model:
@@ -339,3 +414,5 @@ class CollisionPipeline:
         _lib.check(self.dm.lib.nt_collide(C.byref(self.dm.desc), C.byref(d_state), C.byref(d_ct), C.byref(self.params),
                                           self.dm.stream()), "nt_collide")
         contacts._generation += 1
+        if self._matcher is not None:
+            self._match(state, contacts)

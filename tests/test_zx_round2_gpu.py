@@ -344,3 +344,67 @@ def test_featherstone_rollout_with_a_mass_matrix_interval_is_the_step_loop():
     assert np.array_equal(q_loop.view(np.int32), q_fused.view(np.int32)) and np.array_equal(qd_loop.view(np.int32), qd_fused.view(np.int32))
     q1, qd1 = run(1, True)
     assert not np.array_equal(qd1, qd_fused) and np.abs(qd1 - qd_fused).max() < 1e-2
+
+
+def test_collision_pipeline_contact_matching_latest_with_report():
+    """CollisionPipeline(contact_matching="latest", contact_report=True) (collide.py:1126-1129): rigid_contact_match_index is
+    filled by every collide(); new / broken reports are consistent with it; the indices equal oracle_match on the exported rows."""
+    import os
+    import sys
+
+    import torch
+    from scenes import box_stack_scene
+
+    import newton_amd as nt
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_match as O
+
+    model = box_stack_scene(6, n_boxes=4, seed=2, jitter=4e-3, device="cuda:0")
+    with pytest.raises(NotImplementedError):
+        nt.CollisionPipeline(model, contact_matching="sticky")
+    with pytest.raises(ValueError):
+        nt.CollisionPipeline(model, contact_report=True)
+    pipe = nt.CollisionPipeline(model, contact_matching="latest", contact_report=True)
+    assert pipe.deterministic
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=4)
+    s0, s1 = model.state(), model.state()
+    shape_body = np.asarray(model.shape_body)
+    prev = None
+    broken_total = 0
+    for frame in range(5):
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        torch.cuda.synchronize()
+        n = int(contacts.rigid_contact_count.cpu().numpy()[0])
+        got = contacts.rigid_contact_match_index.cpu().numpy()[:n]
+        sh0, sh1 = contacts.rigid_contact_shape0.cpu().numpy()[:n], contacts.rigid_contact_shape1.cpu().numpy()[:n]
+        pair = sh0.astype(np.int64) * (1 << 32) + sh1
+        sub = np.zeros(n, dtype=np.int64)
+        for i in range(1, n):
+            sub[i] = sub[i - 1] + 1 if pair[i] == pair[i - 1] else 0
+        keys = np.array([O.sort_key(a, b, k) for a, b, k in zip(sh0, sh1, sub)], dtype=np.int64)
+        mid = O.midpoints(s0.body_q.cpu().numpy(), shape_body, sh0, sh1, contacts.rigid_contact_point0.cpu().numpy()[:n],
+                          contacts.rigid_contact_point1.cpu().numpy()[:n])
+        nrm = contacts.rigid_contact_normal.cpu().numpy()[:n]
+        new_n = int(contacts.rigid_contact_new_count.cpu().numpy()[0])
+        new = np.sort(contacts.rigid_contact_new_indices.cpu().numpy()[:new_n])
+        assert np.array_equal(new, np.flatnonzero(got < 0))
+        if prev is None:
+            assert np.all(got == -1) and int(contacts.rigid_contact_broken_count.cpu().numpy()[0]) == 0
+        else:
+            want = O.match(keys, mid, nrm, *prev)
+            assert np.array_equal(got, want)
+            bn = int(contacts.rigid_contact_broken_count.cpu().numpy()[0])
+            broken = np.sort(contacts.rigid_contact_broken_indices.cpu().numpy()[:bn])
+            assert np.array_equal(broken, np.setdiff1d(np.arange(len(prev[0])), want[want >= 0]))
+            broken_total += bn
+        prev = (keys, mid, nrm)
+        solver.step(s0, s1, None, contacts, 1.0 / 240.0)
+        s0, s1 = s1, s0
+    pipe.reset_contact_matching()
+    s0.clear_forces()
+    pipe.collide(s0, contacts)
+    n = int(contacts.rigid_contact_count.cpu().numpy()[0])
+    assert np.all(contacts.rigid_contact_match_index.cpu().numpy()[:n] == -1)
