@@ -260,10 +260,15 @@ typedef struct {
     float* prev_pos_world;  /* [3][np*cpp][ES] */
     float* prev_normal;     /* [3][np*cpp][ES] */
     uint8_t* prev_live;     /* [np*cpp][ES] */
+    float* prev_body_frame; /* [12][np*cpp][ES] or NULL: sticky mode only -- point0, point1, offset0, offset1 of the record used */
 } nt_contact_history;
 nt_status nt_contacts_match(const nt_model* m, const nt_state* s, const nt_contacts* c, const nt_contact_history* h,
                             float pos_threshold /*0.0005*/, float normal_dot_threshold /*0.995*/, const uint8_t* reset_world_mask,
                             int32_t* match_index /*[np*cpp][ES]*/, void* stream);
+/* ContactMatcher.replay_matched (contact_match.py:530-562,933-996; CollisionPipeline(contact_matching="sticky")): matched
+ * contacts that still touch get last frame's body-frame points / offsets and normal back (call between match and save_history) */
+nt_status nt_contacts_replay_matched(const nt_model* m, const nt_state* s, nt_contacts* c, const nt_contact_history* h,
+                                     const int32_t* match_index /*[np*cpp][ES], slot space*/, void* stream);
 nt_status nt_contacts_save_history(const nt_model* m, const nt_state* s, const nt_contacts* c, nt_contact_history* h, void* stream);
 
 /* -------- standalone broad phases (newton.geometry.BroadPhaseAllPairs / BroadPhaseSAP / BroadPhaseExplicit) --------

@@ -97,7 +97,8 @@ class nt_mesh_sdf_args(C.Structure):
 
 
 class nt_contact_history(C.Structure):
-    _fields_ = [("prev_pos_world", C.c_void_p), ("prev_normal", C.c_void_p), ("prev_live", C.c_void_p)]
+    _fields_ = [("prev_pos_world", C.c_void_p), ("prev_normal", C.c_void_p), ("prev_live", C.c_void_p),
+                ("prev_body_frame", C.c_void_p)]
 
 
 class nt_hydro_args(C.Structure):
@@ -242,6 +243,8 @@ SYMBOLS = {
     "nt_mesh_sdf_collide": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), _P]),
     "nt_contacts_match": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts), C.POINTER(nt_contact_history),
                                        C.c_float, C.c_float, _P, _P, _P]),
+    "nt_contacts_replay_matched": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
+                                   C.POINTER(nt_contact_history), C.c_void_p, _P]),
     "nt_contacts_save_history": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
                                               C.POINTER(nt_contact_history), _P]),
     "nt_hydro_collide": (C.c_int32, [C.POINTER(nt_hydro_args), _P]),

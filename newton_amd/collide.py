@@ -181,7 +181,7 @@ class ContactMatcher:
 
     MATCH_NOT_FOUND, MATCH_BROKEN = -1, -2
 
-    def __init__(self, model, pos_threshold: float = 0.0005, normal_dot_threshold: float = 0.995):
+    def __init__(self, model, pos_threshold: float = 0.0005, normal_dot_threshold: float = 0.995, sticky: bool = False):
         torch = _torch()
         self.model = model
         self.dm = model.device_model()
@@ -196,6 +196,10 @@ class ContactMatcher:
         self._reset_mask = None
         h = _lib.nt_contact_history()
         h.prev_pos_world, h.prev_normal, h.prev_live = self._pos.data_ptr(), self._normal.data_ptr(), self._live.data_ptr()
+        self.sticky = bool(sticky)
+        if self.sticky:  # body-frame points / offsets of the record used last frame (contact_match.py:690-702)
+            self._body_frame = torch.zeros((12, ns, t.env_stride), dtype=torch.float32, device=dev)
+            h.prev_body_frame = self._body_frame.data_ptr()
         self._h = h
 
     def reset(self, world_mask=None):
@@ -263,6 +267,17 @@ class ContactMatcher:
             out[: order.numel()] = out[: order.numel()][order]
         return out[:n]
 
+    def replay_matched(self, state, contacts):
+        """Sticky mode (contact_match.py:933-996): matched contacts that still touch keep last frame's body-frame points,
+        offsets and normal.  Call after match() -- it uses that call's slot-space result -- and before save_sorted_state()."""
+        if not self.sticky:
+            raise ValueError("replay_matched requires ContactMatcher(sticky=True)")
+        dm = self.dm
+        d_s, d_c = state._desc(), contacts._desc()
+        _lib.check(dm.lib.nt_contacts_replay_matched(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h),
+                                                     self._match.data_ptr(), dm.stream()), "nt_contacts_replay_matched")
+        contacts._generation += 1
+
     def save_sorted_state(self, state, contacts):
         """Persist this frame's contacts as the next frame's history (call after match, with the state they were made on)."""
         dm, t = self.dm, self.model.env
@@ -320,11 +335,9 @@ class CollisionPipeline:
         if unsupported:
             raise NotImplementedError(f"CollisionPipeline options not supported: {sorted(unsupported)}")
         # frame-to-frame matching (collide.py:1126-1129,1253-1268): "latest" fills contacts.rigid_contact_match_index every
-        # collide(); "sticky" (replaying the previous contact geometry on matched rows) is not implemented
+        # collide(); "sticky" additionally replays last frame's contact geometry on matched rows that still touch
         if contact_matching not in ("disabled", "latest", "sticky"):
             raise ValueError(f"contact_matching must be one of 'disabled', 'latest', 'sticky', got {contact_matching!r}")
-        if contact_matching == "sticky":
-            raise NotImplementedError('contact_matching="sticky" is not implemented (SURVEY.md section 8 row (f)3: "latest" only)')
         if contact_matching_pos_threshold < 0.0:
             raise ValueError(f"contact_matching_pos_threshold must be non-negative, got {contact_matching_pos_threshold}")
         if not -1.0 <= contact_matching_normal_dot_threshold <= 1.0:
@@ -350,8 +363,8 @@ class CollisionPipeline:
         # builds its ContactSorter for both, collide.py:1653-1667)
         self.contact_matching, self.contact_report = contact_matching, bool(contact_report)
         self.deterministic = bool(deterministic) or contact_matching != "disabled"
-        self._matcher = (ContactMatcher(model, contact_matching_pos_threshold, contact_matching_normal_dot_threshold)
-                         if contact_matching != "disabled" else None)
+        self._matcher = (ContactMatcher(model, contact_matching_pos_threshold, contact_matching_normal_dot_threshold,
+                                        sticky=contact_matching == "sticky") if contact_matching != "disabled" else None)
         self._prev_count = 0
 
     @property
@@ -403,6 +416,8 @@ class CollisionPipeline:
             broken = torch.nonzero(~hit[: self._prev_count] & live_prev).flatten().to(torch.int32)
             contacts.rigid_contact_broken_indices[: broken.numel()] = broken
             contacts.rigid_contact_broken_count[0] = broken.numel()
+        if self.contact_matching == "sticky":
+            self._matcher.replay_matched(state, contacts)
         self._matcher.save_sorted_state(state, contacts)
         self._prev_count = n
 

@@ -123,10 +123,43 @@ __global__ void __launch_bounds__(256) contacts_save_kernel(MatchArgs a) {
     if (!live) return;
     const vec3 pos = midpoint(a, slot, env, slot / cpp);
     const vec3 n = ld3(a.c.data, 12, ncs, slot, ES, env);
+    if (a.h.prev_body_frame) {  // sticky mode: the body-frame points and offsets of the record actually used this frame
+        float* B = a.h.prev_body_frame;
+        for (int comp = 0; comp < 12; ++comp) B[((size_t)comp * ncs + slot) * ES + env] = a.c.data[((size_t)comp * ncs + slot) * ES + env];
+    }
     float* P = a.h.prev_pos_world;
     float* N = a.h.prev_normal;
     P[((size_t)0 * ncs + slot) * ES + env] = pos.x; P[((size_t)1 * ncs + slot) * ES + env] = pos.y; P[((size_t)2 * ncs + slot) * ES + env] = pos.z;
     N[((size_t)0 * ncs + slot) * ES + env] = n.x; N[((size_t)1 * ncs + slot) * ES + env] = n.y; N[((size_t)2 * ncs + slot) * ES + env] = n.z;
+}
+
+// _replay_matched_kernel (contact_match.py:530-562): a matched contact that still touches (fresh gap <= 0) keeps last
+// frame's body-frame points / offsets and normal; everything else of the row is key-derived or a per-shape constant
+__global__ void __launch_bounds__(256) contacts_replay_kernel(MatchArgs a) {
+    const int ES = a.m.env_stride, cpp = a.m.cpp, ncs = a.m.np * cpp;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ncs * ES) return;
+    const int env = (int)(i % ES), slot = (int)(i / ES);
+    if (env >= a.m.env_count) return;
+    const size_t gi = (size_t)slot * ES + env;
+    if (a.c.shape0[gi] < 0 || a.c.shape0[gi] == a.c.shape1[gi]) return;
+    const int idx = a.match_index[gi];
+    if (idx < 0) return;  // MATCH_NOT_FOUND or MATCH_BROKEN: keep the new frame's data
+    const int p = slot / cpp;
+    int sa = a.m.pair_a[p], sb = a.m.pair_b[p];
+    if (a.m.shape_type[sa] > a.m.shape_type[sb]) { int t = sa; sa = sb; sb = t; }
+    const int ba = a.m.shape_body[sa], bb = a.m.shape_body[sb];
+    float* D = a.c.data;
+    vec3 p0 = ld3(D, 0, ncs, slot, ES, env), p1 = ld3(D, 3, ncs, slot, ES, env);
+    if (ba >= 0) p0 = xform_point(body_xform(a.s, a.m.nb, ba, ES, env), p0);
+    if (bb >= 0) p1 = xform_point(body_xform(a.s, a.m.nb, bb, ES, env), p1);
+    const vec3 n = ld3(D, 12, ncs, slot, ES, env);
+    const float margins = D[((size_t)15 * ncs + slot) * ES + env] + D[((size_t)16 * ncs + slot) * ES + env];
+    const float fresh_gap = dot(p1 - p0, n) - margins;
+    if (fresh_gap > 0.0f) return;
+    const float* B = a.h.prev_body_frame;
+    for (int comp = 0; comp < 12; ++comp) D[((size_t)comp * ncs + slot) * ES + env] = B[((size_t)comp * ncs + idx) * ES + env];
+    for (int comp = 0; comp < 3; ++comp) D[((size_t)(12 + comp) * ncs + slot) * ES + env] = a.h.prev_normal[((size_t)comp * ncs + idx) * ES + env];
 }
 
 bool args_ok(const nt_model* m, const nt_state* s, const nt_contacts* c, const nt_contact_history* h) {
@@ -145,6 +178,15 @@ nt_status nt_contacts_match(const nt_model* m, const nt_state* s, const nt_conta
     MatchArgs a = {*m, *s, *c, *h, pos_threshold * pos_threshold, normal_dot_threshold, reset_world_mask, match_index};
     const size_t n = (size_t)m->np * m->cpp * m->env_stride;
     hipLaunchKernelGGL(contacts_match_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_contacts_replay_matched(const nt_model* m, const nt_state* s, nt_contacts* c, const nt_contact_history* h,
+                                     const int32_t* match_index, void* stream) {
+    if (!args_ok(m, s, c, h) || !match_index || !h->prev_body_frame) return NT_ERR_INVALID_ARG;
+    MatchArgs a = {*m, *s, *c, *h, 0.0f, 0.0f, nullptr, const_cast<int32_t*>(match_index)};
+    const size_t n = (size_t)m->np * m->cpp * m->env_stride;
+    hipLaunchKernelGGL(contacts_replay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

@@ -42,7 +42,8 @@ def sorted_frame(model, orc, body_q):
     keys = np.array([om.sort_key(a, b, k) for a, b, k in zip(ct.shape0[:n], ct.shape1[:n], sub)], np.int64)
     order = np.argsort(keys, kind="stable")
     return {"keys": keys[order], "shape0": ct.shape0[:n][order], "shape1": ct.shape1[:n][order], "point0": ct.point0[:n][order],
-            "point1": ct.point1[:n][order], "normal": ct.normal[:n][order]}
+            "point1": ct.point1[:n][order], "normal": ct.normal[:n][order], "offset0": ct.offset0[:n][order],
+            "offset1": ct.offset1[:n][order], "margin0": ct.margin0[:n][order], "margin1": ct.margin1[:n][order]}
 
 
 def main():
@@ -58,6 +59,9 @@ def main():
         cap = 256
         sorter = types.SimpleNamespace(scratch_pos_world=wp.zeros(cap, dtype=wp.vec3), scratch_normal=wp.zeros(cap, dtype=wp.vec3))
         matcher = cm.ContactMatcher(cap, sorter=sorter, shape_world=arr(model.shape_world, int), world_count=model.world_count)
+        sorter2 = types.SimpleNamespace(scratch_pos_world=wp.zeros(cap, dtype=wp.vec3), scratch_normal=wp.zeros(cap, dtype=wp.vec3))
+        sticky = cm.ContactMatcher(cap, sorter=sorter2, shape_world=arr(model.shape_world, int), world_count=model.world_count,
+                                   sticky=True)
         shape_body = arr(model.shape_body, int)
         for k in range(frames):
             fr = sorted_frame(model, orc, a.body_q)
@@ -69,6 +73,20 @@ def main():
                     pad(fr["shape0"], int), pad(fr["shape1"], int), pad(fr["normal"], wp.vec3), bq, shape_body)
             matcher.match(*args, out)
             matcher.save_sorted_state(*args)
+            # sticky mode on the same fresh contacts: match -> (already sorted) -> replay_matched -> save_sorted_state
+            sargs = (pad(fr["keys"], int), arr(np.array([n]), int), pad(fr["point0"], wp.vec3), pad(fr["point1"], wp.vec3),
+                     pad(fr["shape0"], int), pad(fr["shape1"], int), pad(fr["normal"], wp.vec3), bq, shape_body)
+            sout = wp.full(cap, -5, dtype=int)
+            sticky.match(*sargs, sout)
+            off0, off1 = pad(fr["offset0"], wp.vec3), pad(fr["offset1"], wp.vec3)
+            sticky.replay_matched(sargs[1], sout, point0=sargs[2], point1=sargs[3], offset0=off0, offset1=off1, normal=sargs[6],
+                                  shape0=sargs[4], shape1=sargs[5], margin0=pad(fr["margin0"], float), margin1=pad(fr["margin1"], float),
+                                  body_q=bq, shape_body=shape_body)
+            sticky.save_sorted_state(*sargs, sorted_offset0=off0, sorted_offset1=off1)
+            v3 = lambda a_: np.array([[float(c) for c in x] for x in a_[:n]], np.float32).reshape(n, 3)  # noqa: E731
+            blob[f"{name}/{k}/sticky_match"] = np.array(sout[:n], np.int32)
+            for f, a_ in (("point0", sargs[2]), ("point1", sargs[3]), ("offset0", off0), ("offset1", off1), ("normal", sargs[6])):
+                blob[f"{name}/{k}/sticky_{f}"] = v3(a_)
             for f, v in fr.items():
                 blob[f"{name}/{k}/{f}"] = v
             blob[f"{name}/{k}/body_q"] = np.array(a.body_q, np.float32)

@@ -146,3 +146,50 @@ def test_thresholds_race_and_world_reset(H):
     prev_flat = {es: i for i, es in enumerate(live_prev)}
     got = np.array([m[s, e] if m[s, e] < 0 else prev_flat[(e, int(m[s, e]))] for e, s in fid], dtype=np.int32)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,frames", [("box_stack", 6), ("mixed_primitives", 8)])
+def test_sticky_replay_reproduces_the_reference_matcher(H, name, frames):
+    """contact_matching="sticky" (contact_match.py:530-562,933-996): match -> replay_matched -> save_sorted_state on the fixed slots
+    (nt_contacts_match / nt_contacts_replay_matched / nt_contacts_save_history, emulated) against the reference ContactMatcher
+    executed frame by frame on the same contacts (tests/golden/make_match_reference_vectors.py): same match indices, same
+    replayed body-frame points / offsets / normals."""
+    import oracle_match as O
+    from scenes import box_stack_scene, mixed_primitive_scene
+
+    from newton_amd import _lib as L
+
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "match_reference_vectors.npz"))
+    model = box_stack_scene(1, n_boxes=4, seed=2, jitter=5e-3) if name == "box_stack" else mixed_primitive_scene(1, seed=4)
+    em = H.EmuModel(model)
+    t = em.t
+    ns = t.np * t.cpp
+    hist, keep = _history(em)
+    body_frame = np.zeros((12, ns, t.env_stride), np.float32)
+    hist.prev_body_frame = body_frame.ctypes.data
+    ct = H.EmuContacts(em)
+    prev_ids = None
+    replayed = 0
+    for k in range(frames):
+        st = H.EmuState(em, body_q=ref[f"{name}/{k}/body_q"])
+        H.collide(em, st, ct)
+        slots = _emu_match(H, em, st, ct, hist)
+        ds, dc = st.desc(), ct.desc()
+        H.check(H.lib().nt_contacts_replay_matched(C.byref(em.desc), C.byref(ds), C.byref(dc), C.byref(hist), slots.ctypes.data, None),
+                "nt_contacts_replay_matched")
+        keys, mid, nrm, ids = _flat(em, ct, st.aos("body_q"))
+        assert np.array_equal(keys, ref[f"{name}/{k}/keys"])
+        want = ref[f"{name}/{k}/sticky_match"]
+        if prev_ids is None:
+            assert np.all(want == -1) and all(slots[s, e] == -1 for e, s in ids)
+        else:
+            prev_flat = {es: i for i, es in enumerate(prev_ids)}
+            got = np.array([slots[s, e] if slots[s, e] < 0 else prev_flat[(e, int(slots[s, e]))] for e, s in ids], dtype=np.int32)
+            assert np.array_equal(got, want)
+        rows = lambda c0: np.array([[ct.data[c0 + c, s, e] for c in range(3)] for e, s in ids], np.float32).reshape(-1, 3)  # noqa: E731
+        for field, c0 in (("point0", 0), ("point1", 3), ("offset0", 6), ("offset1", 9), ("normal", 12)):
+            assert np.array_equal(rows(c0), ref[f"{name}/{k}/sticky_{field}"]), (k, field)
+        replayed += int((np.abs(ref[f"{name}/{k}/sticky_point0"] - ref[f"{name}/{k}/point0"]).max(axis=1) > 0).sum())
+        H.check(H.lib().nt_contacts_save_history(C.byref(em.desc), C.byref(ds), C.byref(dc), C.byref(hist), None), "save")
+        prev_ids = ids
+    assert replayed > 0 or name != "box_stack"

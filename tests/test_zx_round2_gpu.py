@@ -361,8 +361,8 @@ def test_collision_pipeline_contact_matching_latest_with_report():
     import oracle_match as O
 
     model = box_stack_scene(6, n_boxes=4, seed=2, jitter=4e-3, device="cuda:0")
-    with pytest.raises(NotImplementedError):
-        nt.CollisionPipeline(model, contact_matching="sticky")
+    with pytest.raises(ValueError):
+        nt.CollisionPipeline(model, contact_matching="always")
     with pytest.raises(ValueError):
         nt.CollisionPipeline(model, contact_report=True)
     pipe = nt.CollisionPipeline(model, contact_matching="latest", contact_report=True)
@@ -408,3 +408,32 @@ def test_collision_pipeline_contact_matching_latest_with_report():
     pipe.collide(s0, contacts)
     n = int(contacts.rigid_contact_count.cpu().numpy()[0])
     assert np.all(contacts.rigid_contact_match_index.cpu().numpy()[:n] == -1)
+
+
+@pytest.mark.parametrize("name,frames", [("box_stack", 6), ("mixed_primitives", 8)])
+def test_collision_pipeline_sticky_matching_against_the_reference_matcher(name, frames):
+    """CollisionPipeline(contact_matching="sticky") on the device, frame by frame on the recorded states, against the arrays the
+    reference ContactMatcher(sticky=True) left after match -> replay_matched (tests/golden/make_match_reference_vectors.py)."""
+    import os
+
+    import torch
+    from scenes import box_stack_scene, mixed_primitive_scene
+
+    import newton_amd as nt
+
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "match_reference_vectors.npz"))
+    host = box_stack_scene(1, n_boxes=4, seed=2, jitter=5e-3) if name == "box_stack" else mixed_primitive_scene(1, seed=4)
+    model = _to_device(host)
+    pipe = nt.CollisionPipeline(model, contact_matching="sticky")
+    contacts = pipe.contacts()
+    s = model.state()
+    for k in range(frames):
+        s.body_q = torch.from_numpy(ref[f"{name}/{k}/body_q"])
+        pipe.collide(s, contacts)
+        torch.cuda.synchronize()
+        n = len(ref[f"{name}/{k}/keys"])
+        assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == n
+        assert np.array_equal(contacts.rigid_contact_match_index.cpu().numpy()[:n], ref[f"{name}/{k}/sticky_match"])
+        for field in ("point0", "point1", "offset0", "offset1", "normal"):
+            got = getattr(contacts, "rigid_contact_" + field).cpu().numpy()[:n]
+            assert np.array_equal(got, ref[f"{name}/{k}/sticky_{field}"]), (k, field)
