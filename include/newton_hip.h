@@ -159,6 +159,8 @@ typedef struct {
     int32_t rigid_contact_con_weighting;
     float angular_damping;
     int32_t enable_restitution; /* apply_rigid_restitution after the iterations (xpbd/kernels.py:2583-2728) */
+    int32_t compute_body_velocity_from_position_delta; /* update_body_velocities after the iterations (xpbd/kernels.py:2547-2579;
+                                  the SolverXPBD attribute of the same name, off by default) */
 } nt_xpbd_params;
 
 /* Optional reporting buffers of nt_xpbd_step (solver_xpbd.py:368-386): NULL members are skipped. */

@@ -67,7 +67,7 @@ class nt_xpbd_params(C.Structure):
                 ("joint_angular_relaxation", C.c_float), ("joint_linear_compliance", C.c_float),
                 ("joint_angular_compliance", C.c_float), ("rigid_contact_relaxation", C.c_float),
                 ("rigid_contact_con_weighting", C.c_int32), ("angular_damping", C.c_float),
-                ("enable_restitution", C.c_int32)]
+                ("enable_restitution", C.c_int32), ("compute_body_velocity_from_position_delta", C.c_int32)]
 
 
 class nt_xpbd_report(C.Structure):

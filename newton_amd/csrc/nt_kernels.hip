@@ -229,7 +229,7 @@ int pick_epb(const nt_model& m, int requested, bool restitution = false) {
 // semi: the SolverSemiImplicit kernel (own scratch layout); max_threads: the kernel's THREADS template argument
 template <typename K>
 nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false, bool uni = false) {
-    LdsLayout L = make_layout_host(a.m, a.p.enable_restitution != 0, uni);
+    LdsLayout L = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni);
     if (max_threads <= 0) max_threads = max_threads_for(epb);
     int nslot = slots_for(a.m, epb, max_threads);
     a.nslot = nslot;
@@ -391,7 +391,7 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
     a.p = *p;
     a.angular_damping = p->angular_damping;
     a.dt = dt;
-    int epb = pick_epb(*m, envs_per_block, p->enable_restitution != 0);
+    int epb = pick_epb(*m, envs_per_block, xpbd_keeps_prestep_state(*p));
     if (!epb) return NT_ERR_UNSUPPORTED;
     if (m->contact_scratch_in_hbm) {
         if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
@@ -414,7 +414,7 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     a.substeps = substeps;
-    const bool rest = p->enable_restitution != 0;
+    const bool rest = xpbd_keeps_prestep_state(*p);
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0, rest);
     if (!epb) return NT_ERR_UNSUPPORTED;
     if (m->contact_scratch_in_hbm) {
@@ -447,7 +447,7 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
 
 nt_status nt_xpbd_rollout_shape(const nt_model* m, const nt_xpbd_params* p, const nt_collide_params* cp, int32_t out[5]) {
     if (!model_ok(m) || !p || !out) return NT_ERR_INVALID_ARG;
-    const bool rest = p->enable_restitution != 0;
+    const bool rest = xpbd_keeps_prestep_state(*p);
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0, rest);
     if (!epb) return NT_ERR_UNSUPPORTED;
     const bool cvx = m->np_analytic < m->np, big = m->contact_scratch_in_hbm != 0;

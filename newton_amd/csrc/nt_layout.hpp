@@ -138,6 +138,11 @@ inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false, b
     return make_layout(m, m.contact_scratch_in_hbm != 0, restitution, uni);
 }
 
+// the pre-step state snapshot (and the wide contact records) exist for restitution and for velocities from position deltas
+__host__ __device__ inline bool xpbd_keeps_prestep_state(const nt_xpbd_params& p) {
+    return p.enable_restitution != 0 || p.compute_body_velocity_from_position_delta != 0;
+}
+
 struct KArgs {
     nt_model m;
     nt_state s_in, s_out;
@@ -190,7 +195,7 @@ struct Ctx {
 
     // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
     NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
-        L = make_layout(a.m, big_, a.p.enable_restitution != 0, UNI);
+        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI);
         if (rows < 0) rows = L.rows_per_env;
         e = threadIdx.x % N;
         slot = threadIdx.x / N;

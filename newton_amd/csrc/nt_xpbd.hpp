@@ -1076,7 +1076,8 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
     const int skip = c.a.debug_skip;
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
-    if (!PROLOGUE_DONE && restitution && c.valid)  // body_q_init / body_qd_init: the state the step starts from
+    const bool vel_from_delta = c.a.p.compute_body_velocity_from_position_delta != 0;
+    if (!PROLOGUE_DONE && (restitution || vel_from_delta) && c.valid)  // body_q_init / body_qd_init: the state the step starts from
         for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
     const bool rep_joints = !FUSED && c.a.rep.joint_impulse != nullptr;
     const bool rep_contacts = !FUSED && c.a.rep.contact_impulse != nullptr && c.a.has_contacts;
@@ -1109,6 +1110,21 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             NT_TICK(8);
         }
     }
+    if (vel_from_delta) {  // update_body_velocities (xpbd/kernels.py:2547-2579, solver_xpbd.py:767-783)
+        if (c.valid)
+            for (int b = c.slot; b < m.nb; b += c.nslot) {
+                const xform pose = c.body_q(b), prev = c.lxf(c.L.xiq, 0, m.nb, b);
+                const vec3 com = c.com(b);
+                const vec3 x_com = pose.p + quat_rotate(pose.q, com), x_com_prev = prev.p + quat_rotate(prev.q, com);
+                const vec3 v = (x_com - x_com_prev) / c.a.dt;
+                const quat dq = pose.q * quat_inverse(prev.q);
+                vec3 omega = (2.0f / c.a.dt) * vec3(dq.x, dq.y, dq.z);
+                if (dq.w < 0.0f) omega = -omega;
+                c.st_lv3(c.L.bqd, 0, m.nb, b, v);
+                c.st_lv3(c.L.bqd, 3, m.nb, b, omega);
+            }
+        __syncthreads();
+    }
     if (restitution) {  // solver_xpbd.py:784-858
         if (c.valid)
             for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) restitution_item<EPB, CW>(c, s);
@@ -1138,7 +1154,7 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     const nt_model& m = c.a.m;
     const int skip = c.a.debug_skip;
     const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;  // slots per wave
-    const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
+    const bool restitution = (c.a.p.enable_restitution && c.a.has_contacts) || c.a.p.compute_body_velocity_from_position_delta != 0;
     // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
     const bool compact = pairs_compacted(c);
     if (c.valid) {

@@ -32,6 +32,7 @@ class SolverXPBD(SolverBase):
         self.rigid_contact_con_weighting = rigid_contact_con_weighting
         self.angular_damping = angular_damping
         self.enable_restitution = enable_restitution
+        self.compute_body_velocity_from_position_delta = False  # reference attribute (solver_xpbd.py:767): set after construction
         self.envs_per_block = int(envs_per_block)
         self._contact_impulse = None
         self._contact_impulse_capacity = 0
@@ -43,7 +44,8 @@ class SolverXPBD(SolverBase):
                                    float(self.joint_angular_relaxation), float(self.joint_linear_compliance),
                                    float(self.joint_angular_compliance), float(self.rigid_contact_relaxation),
                                    int(bool(self.rigid_contact_con_weighting)), float(self.angular_damping),
-                                   int(bool(self.enable_restitution)))
+                                   int(bool(self.enable_restitution)),
+                                   int(bool(self.compute_body_velocity_from_position_delta)))
 
     def step(self, state_in, state_out, control, contacts, dt: float) -> None:
         dm = self.dm

@@ -125,6 +125,7 @@ typedef struct {
     int rigid_contact_con_weighting;
     float angular_damping;
     int enable_restitution;
+    int compute_body_velocity_from_position_delta; /* SolverXPBD attribute, solver_xpbd.py:767-783 (update_body_velocities) */
 } o_xpbd_params;
 
 typedef struct {

@@ -15,8 +15,8 @@
 //   SolverFeatherstone.step                                   solver_featherstone.py:462-1066
 //   eval_body_contact (shared with SolverSemiImplicit)        semi_implicit/kernels_contact.py:381-556
 //   transform_twist / velocity_at_point                       newton/_src/math/spatial.py:53-130
-// Scope: PRISMATIC, REVOLUTE, BALL, FIXED, root FREE, D6 (up to three angular axes), kinematic roots; no descendant
-// FREE/DISTANCE joints, update_mass_matrix_interval = 1.  Pinned by execution of the reference solver source (tests/test_reference_vectors.py: fs/*); the Warp builtins underneath stay restated (wp_builtins.h).
+// Scope: PRISMATIC, REVOLUTE, BALL, FIXED, FREE / DISTANCE (root and descendant), D6 (up to three angular axes), kinematic
+// roots, update_mass_matrix_interval.  Pinned by execution of the reference solver source (tests/test_reference_vectors.py: fs/*); the Warp builtins underneath stay restated (wp_builtins.h).
 #include <vector>
 
 #include "oracle_common.h"
@@ -304,8 +304,37 @@ void jcalc_integrate(const o_model* m, int parent, const transform& joint_X_c, v
         joint_qd_new[dof_start + 2] = w_j_new.z;
         return;
     }
-    if (type == FREE || type == DISTANCE) {
-        // root (parent < 0) branch only: descendant FREE joints are outside the restated scope
+    if ((type == FREE || type == DISTANCE) && parent >= 0) {
+        // descendants stay in the internal parent-origin coordinates during the step (kernels.py:574-611); the public COM
+        // convention comes back at the solver boundary
+        vec3 a_s(joint_qdd[dof_start], joint_qdd[dof_start + 1], joint_qdd[dof_start + 2]);
+        vec3 m_s(joint_qdd[dof_start + 3], joint_qdd[dof_start + 4], joint_qdd[dof_start + 5]);
+        vec3 v_s(joint_qd[dof_start], joint_qd[dof_start + 1], joint_qd[dof_start + 2]);
+        vec3 w_s(joint_qd[dof_start + 3], joint_qd[dof_start + 4], joint_qd[dof_start + 5]);
+        w_s = w_s + m_s * dt;
+        v_s = v_s + a_s * dt;
+        vec3 p_s(joint_q[coord_start], joint_q[coord_start + 1], joint_q[coord_start + 2]);
+        vec3 dpdt_s = v_s + cross(w_s, p_s);
+        quat r_s(joint_q[coord_start + 3], joint_q[coord_start + 4], joint_q[coord_start + 5], joint_q[coord_start + 6]);
+        quat drdt_s = quat(w_s.x, w_s.y, w_s.z, 0.0f) * r_s * 0.5f;
+        vec3 p_s_new = p_s + dpdt_s * dt;
+        quat r_s_new = normalize(r_s + drdt_s * dt);
+        joint_q_new[coord_start + 0] = p_s_new.x;
+        joint_q_new[coord_start + 1] = p_s_new.y;
+        joint_q_new[coord_start + 2] = p_s_new.z;
+        joint_q_new[coord_start + 3] = r_s_new.x;
+        joint_q_new[coord_start + 4] = r_s_new.y;
+        joint_q_new[coord_start + 5] = r_s_new.z;
+        joint_q_new[coord_start + 6] = r_s_new.w;
+        joint_qd_new[dof_start + 0] = v_s.x;
+        joint_qd_new[dof_start + 1] = v_s.y;
+        joint_qd_new[dof_start + 2] = v_s.z;
+        joint_qd_new[dof_start + 3] = w_s.x;
+        joint_qd_new[dof_start + 4] = w_s.y;
+        joint_qd_new[dof_start + 5] = w_s.z;
+        return;
+    }
+    if (type == FREE || type == DISTANCE) {  // root (parent < 0)
         vec3 a_parent(joint_qdd[dof_start], joint_qdd[dof_start + 1], joint_qdd[dof_start + 2]);
         vec3 alpha(joint_qdd[dof_start + 3], joint_qdd[dof_start + 4], joint_qdd[dof_start + 5]);
         vec3 v_parent(joint_qd[dof_start], joint_qd[dof_start + 1], joint_qd[dof_start + 2]);
@@ -403,6 +432,9 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
             stx(body_q, child, X_wc);
             body_q_com[child] = X_wc * body_X_com[child];
         }
+
+    // descendant_body_q_prev (solver_featherstone.py:481,514-516): the poses of the start-of-step FK
+    std::vector<float> body_q_prev(body_q, body_q + 7 * B);
 
     // body_f_ext = state_in.body_f + FREE/DISTANCE joint_f routed as COM wrenches
     std::vector<float> body_f(s_in->body_f, s_in->body_f + 6 * B);
@@ -634,8 +666,8 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
     // eval_fk_with_velocity_conversion (kernels.py:1987-2150) -> state_out.body_q / body_qd
     float* out_q = s_out->body_q;
     float* out_qd = s_out->body_qd;
-    for (int a = 0; a < m->articulation_count; ++a)
-        for (int i = m->articulation_start[a]; i < m->articulation_end[a]; ++i) {
+    auto fk_with_velocity_conversion = [&](int joint_start, int joint_end) {
+        for (int i = joint_start; i < joint_end; ++i) {
             int parent = m->joint_parent[i], child = m->joint_child[i], type = m->joint_type[i];
             int q_start = m->joint_q_start[i], qd_start = m->joint_qd_start[i];
             int lin = m->joint_dof_dim[2 * i], ang = m->joint_dof_dim[2 * i + 1];
@@ -692,6 +724,60 @@ extern "C" void o_featherstone_step(const o_model* m, const o_featherstone_param
             stx(out_q, child, X_wc);
             sts(out_qd, child, origin_twist_to_com_twist(v_wc_origin, X_wc, ld3(m->body_com, child)));
         }
+    };
+    for (int a = 0; a < m->articulation_count; ++a) fk_with_velocity_conversion(m->articulation_start[a], m->articulation_end[a]);
+
+    // descendant FREE / DISTANCE joints (solver_featherstone.py:229-265,1006-1046): the child pose is re-integrated from its
+    // world COM twist, the joint coordinates are rebuilt from the poses, and the rest of the articulation is refreshed
+    auto descendant_free = [&](int j) {
+        int t = m->joint_type[j];
+        return (t == FREE || t == DISTANCE) && m->joint_parent[j] >= 0 && !kinematic_joint(j);
+    };
+    bool any_descendant = false;
+    for (int j = 0; j < J; ++j) any_descendant = any_descendant || descendant_free(j);
+    if (any_descendant) {
+        // correct_free_distance_body_pose_from_world_twist (kernels.py:1897-1929) on the poses of the start-of-step FK
+        for (int j = 0; j < J; ++j) {
+            if (!descendant_free(j)) continue;
+            int child = m->joint_child[j];
+            transform X_wb = ldx(body_q_prev.data(), child);
+            vec3 com = ld3(m->body_com, child);
+            spatial qd_com_world = lds(out_qd, child);
+            quat q = X_wb.q;
+            vec3 x_com = transform_point(X_wb, com);
+            vec3 v_com = qd_com_world.top, w = qd_com_world.bottom;
+            quat drdt = quat(w.x, w.y, w.z, 0.0f) * q * 0.5f;
+            quat q_new = normalize(q + drdt * dt);
+            vec3 x_com_new = x_com + v_com * dt;
+            vec3 x_origin_new = x_com_new - quat_rotate(q_new, com);
+            stx(out_q, child, transform(x_origin_new, q_new));
+        }
+        // reconstruct_free_distance_joint_q_from_body_pose (kernels.py:978-1012)
+        for (int j = 0; j < J; ++j) {
+            if (!descendant_free(j)) continue;
+            int parent = m->joint_parent[j], child = m->joint_child[j];
+            transform X_wpj = ldx(m->joint_X_p, j);
+            if (parent >= 0) X_wpj = ldx(out_q, parent) * X_wpj;
+            transform X_wcj = ldx(out_q, child) * ldx(m->joint_X_c, j);
+            vec3 x_err_c = quat_rotate_inv(X_wpj.q, X_wcj.p - X_wpj.p);
+            quat q_pc = quat_inverse(X_wpj.q) * X_wcj.q;
+            int q_start = m->joint_q_start[j];
+            s_out->joint_q[q_start + 0] = x_err_c.x;
+            s_out->joint_q[q_start + 1] = x_err_c.y;
+            s_out->joint_q[q_start + 2] = x_err_c.z;
+            s_out->joint_q[q_start + 3] = q_pc.x;
+            s_out->joint_q[q_start + 4] = q_pc.y;
+            s_out->joint_q[q_start + 5] = q_pc.z;
+            s_out->joint_q[q_start + 6] = q_pc.w;
+        }
+        // eval_fk_with_velocity_conversion_from_joint_starts (kernels.py:2332-2368): from the first such joint of each articulation
+        for (int a = 0; a < m->articulation_count; ++a)
+            for (int j = m->articulation_start[a]; j < m->articulation_end[a]; ++j)
+                if (descendant_free(j)) {
+                    fk_with_velocity_conversion(j, m->articulation_end[a]);
+                    break;
+                }
+    }
 
     // convert_free_distance_joint_qd_internal_to_public (kernels.py:1015-1066) on state_out.body_q
     for (int j = 0; j < J; ++j) {

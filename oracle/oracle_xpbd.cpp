@@ -887,7 +887,7 @@ extern "C" void o_xpbd_step_report(const o_model* m, const o_xpbd_params* p, o_s
     float* ji = joint_impulse.empty() ? nullptr : joint_impulse.data();
     // body_q_init / body_qd_init (solver_xpbd.py:414-416)
     std::vector<float> body_q_init, body_qd_init;
-    if (p->enable_restitution) {
+    if (p->enable_restitution || p->compute_body_velocity_from_position_delta) {
         body_q_init.assign(s_in->body_q, s_in->body_q + 7 * B);
         body_qd_init.assign(s_in->body_qd, s_in->body_qd + 6 * B);
     }
@@ -947,6 +947,20 @@ extern "C" void o_xpbd_step_report(const o_model* m, const o_xpbd_params* p, o_s
         std::memcpy(s_out->body_q, body_q, sizeof(float) * 7 * B);
         std::memcpy(s_out->body_qd, body_qd, sizeof(float) * 6 * B);
     }
+
+    // update_body_velocities (xpbd/kernels.py:2547-2579, solver_xpbd.py:767-783): velocities from the position change of the step
+    if (p->compute_body_velocity_from_position_delta)
+        for (int tid = 0; tid < B; ++tid) {
+            transform pose = ldx(s_out->body_q, tid), pose_prev = ldx(body_q_init.data(), tid);
+            vec3 com = ld3(m->body_com, tid);
+            vec3 x_com = pose.p + quat_rotate(pose.q, com);
+            vec3 x_com_prev = pose_prev.p + quat_rotate(pose_prev.q, com);
+            vec3 v = (x_com - x_com_prev) / dt;
+            quat dq = pose.q * quat_inverse(pose_prev.q);
+            vec3 omega = (2.0f / dt) * vec3(dq.x, dq.y, dq.z);
+            if (dq.w < 0.0f) omega = -omega;
+            sts(s_out->body_qd, tid, spatial(v, omega));
+        }
 
     // restitution (solver_xpbd.py:784-858): uses the effective (kinematic -> 0) inverse mass / inertia of the model
     if (p->enable_restitution && contacts) {

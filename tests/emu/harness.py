@@ -172,10 +172,10 @@ class EmuContacts:
 
 def xpbd_params(iterations=2, joint_linear_relaxation=0.7, joint_angular_relaxation=0.4, joint_linear_compliance=0.0,
                 joint_angular_compliance=0.0, rigid_contact_relaxation=0.8, rigid_contact_con_weighting=True, angular_damping=0.0,
-                enable_restitution=False):
+                enable_restitution=False, compute_body_velocity_from_position_delta=False):
     return L.nt_xpbd_params(iterations, joint_linear_relaxation, joint_angular_relaxation, joint_linear_compliance,
                             joint_angular_compliance, rigid_contact_relaxation, int(rigid_contact_con_weighting),
-                            angular_damping, int(enable_restitution))
+                            angular_damping, int(enable_restitution), int(compute_body_velocity_from_position_delta))
 
 
 def collide(em, state, contacts, epb=0):

@@ -126,6 +126,9 @@ def run_case(name, case):
     kind = case.get("solver", "xpbd")
     if kind == "xpbd":
         solver = ref.SolverXPBD(rm, **case["kw"])
+        for k_, v_ in case.get("attrs", {}).items():
+            assert hasattr(solver, k_), k_
+            setattr(solver, k_, v_)
     elif kind == "semi_implicit":
         solver = ref_semi.SolverSemiImplicit(rm, **case["kw"])
     else:

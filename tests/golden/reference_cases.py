@@ -27,6 +27,13 @@ def cases():
                                        kw=dict(iterations=4, rigid_contact_con_weighting=False, angular_damping=0.05)),
         "box_stack_sunk_restitution": dict(scene=lambda: box_stack_scene(1, n_boxes=3, seed=4, jitter=2e-3), steps=3, dt=1.0 / 240.0,
                                            kw=dict(iterations=2, enable_restitution=True), sink=0.002, drop_speed=0.3),
+        # attributes set after construction (solver_xpbd.py:171): velocities from the position change of the step (:767-783)
+        "quadruped_velocity_from_delta": dict(scene=lambda: quadruped_scene(2, seed=15), steps=4, dt=1e-3, kw=dict(iterations=2),
+                                              attrs=dict(compute_body_velocity_from_position_delta=True), lower=0.2205, joint_f=sin_f),
+        "box_stack_velocity_from_delta_restitution": dict(scene=lambda: box_stack_scene(1, n_boxes=3, seed=8, jitter=2e-3), steps=3,
+                                                          dt=1.0 / 240.0, kw=dict(iterations=2, enable_restitution=True),
+                                                          attrs=dict(compute_body_velocity_from_position_delta=True), sink=0.002,
+                                                          drop_speed=0.3),
         # with reporting: Contacts.force (update_contacts, solver_xpbd.py:864-921) and State.body_parent_f (:732-754)
         "quadruped_report": dict(scene=lambda: quadruped_scene(1, seed=13, height_jitter=0.0), steps=3, dt=1e-3, kw=dict(iterations=2), lower=0.2225,
                                  joint_f=sin_f, report=True),

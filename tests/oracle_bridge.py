@@ -58,7 +58,8 @@ class o_xpbd_params(C.Structure):
     _fields_ = [("iterations", C.c_int), ("joint_linear_relaxation", C.c_float), ("joint_angular_relaxation", C.c_float),
                 ("joint_linear_compliance", C.c_float), ("joint_angular_compliance", C.c_float),
                 ("rigid_contact_relaxation", C.c_float), ("rigid_contact_con_weighting", C.c_int),
-                ("angular_damping", C.c_float), ("enable_restitution", C.c_int)]
+                ("angular_damping", C.c_float), ("enable_restitution", C.c_int),
+                ("compute_body_velocity_from_position_delta", C.c_int)]
 
 
 class o_semi_implicit_params(C.Structure):
@@ -262,7 +263,8 @@ class Oracle:
                           params.get("joint_angular_relaxation", 0.4), params.get("joint_linear_compliance", 0.0),
                           params.get("joint_angular_compliance", 0.0), params.get("rigid_contact_relaxation", 0.8),
                           int(params.get("rigid_contact_con_weighting", True)), params.get("angular_damping", 0.0),
-                          int(params.get("enable_restitution", False)))
+                          int(params.get("enable_restitution", False)),
+                          int(params.get("compute_body_velocity_from_position_delta", False)))
         si, so = s_in.struct, s_out.struct
         force = params.get("contact_force_out")  # [Cmax, 6] float32: what update_contacts would write into contacts.force
         self.L.o_xpbd_step_report(C.byref(self.om.struct), C.byref(p), C.byref(si), C.byref(so), C.byref(control),
@@ -275,7 +277,8 @@ class Oracle:
                           params.get("joint_angular_relaxation", 0.4), params.get("joint_linear_compliance", 0.0),
                           params.get("joint_angular_compliance", 0.0), params.get("rigid_contact_relaxation", 0.8),
                           int(params.get("rigid_contact_con_weighting", True)), params.get("angular_damping", 0.0),
-                          int(params.get("enable_restitution", False)))
+                          int(params.get("enable_restitution", False)),
+                          int(params.get("compute_body_velocity_from_position_delta", False)))
         a, b = s0.struct, s1.struct
         self.L.o_xpbd_rollout(C.byref(self.om.struct), C.byref(p), C.byref(a), C.byref(b), C.byref(control),
                               C.byref(contacts.struct), C.c_float(dt), int(substeps))

@@ -444,3 +444,41 @@ def test_featherstone_large_articulation_one_environment_per_workgroup(H):
         s0, s1, os0, os1 = s1, s0, os1, os0
     for name in ("joint_q", "joint_qd", "body_q", "body_qd"):
         assert _close(s0.aos(name), getattr(os0, name), TOL), name
+
+
+def test_velocity_from_position_delta(H):
+    """SolverXPBD.compute_body_velocity_from_position_delta (solver_xpbd.py:767-783, update_body_velocities
+    xpbd/kernels.py:2547-2579): runs after the iterations and before restitution, on every tile kind; velocities are pose
+    differences over dt, so pose differences of 1e-6 between the two libms come back as 1e-3 at dt = 1e-3 -- the bitwise checks
+    (rollout == loop, poses unchanged by the flag) carry the weight."""
+    from oracle_bridge import Oracle, OracleState
+    from scenes import hull_bin_scene, pendulum_scene, quadruped_scene
+
+    flag = dict(compute_body_velocity_from_position_delta=True)
+    for model, dt, rest, lower in ((quadruped_scene(5, seed=21), 1e-3, False, True), (quadruped_scene(3, seed=22), 1e-3, True, True),
+                                   (pendulum_scene(3, seed=4), 2e-3, False, False), (hull_bin_scene(2, 40), 1.0 / 600.0, True, False)):
+        if lower:
+            _lower(model, 0.23)
+        em = H.EmuModel(model)
+        s0, s1, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+        plain = H.EmuState(em)
+        o = Oracle(model)
+        os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+        H.collide(em, s0, ct)
+        o.collide(os0.body_q, oc)
+        has = int(oc.count[0]) > 0
+        H.xpbd_step(em, s0, s1, ctrl, ct if has else None, dt, enable_restitution=rest, **flag)
+        H.xpbd_step(em, s0, plain, ctrl, ct if has else None, dt, enable_restitution=False)
+        o.xpbd_step(os0, os1, o.control(), oc if has else None, dt, enable_restitution=rest, **flag)
+        assert np.array_equal(s1.body_q, plain.body_q)  # the flag only rewrites velocities
+        assert not np.array_equal(s1.body_qd, plain.body_qd)
+        assert _close(s1.aos("body_q"), os1.body_q, 1e-5) and _close(s1.aos("body_qd"), os1.body_qd, 2e-5 / dt)
+        if model.env.np:  # fused rollout == launch-by-launch loop, bitwise
+            out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, dt, 3, enable_restitution=rest, **flag)
+            a, b = H.EmuState(em), H.EmuState(em)
+            for _ in range(3):
+                a.body_f[:] = 0
+                H.collide(em, a, ct)
+                H.xpbd_step(em, a, b, ctrl, ct, dt, enable_restitution=rest, **flag)
+                a, b = b, a
+            assert np.array_equal(out.body_q, a.body_q) and np.array_equal(out.body_qd, a.body_qd)

@@ -32,7 +32,8 @@ def _errors(q, qd, q_ref, qd_ref):
 
 
 NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "joint_zoo", "joint_zoo_free_root",
-         "box_stack_no_weighting", "box_stack_sunk_restitution", "quadruped_report", "box_stack_report", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
+         "box_stack_no_weighting", "box_stack_sunk_restitution", "quadruped_velocity_from_delta",
+         "box_stack_velocity_from_delta_restitution", "quadruped_report", "box_stack_report", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
          "semi/box_stack_contact_props", "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped", "fs/quadruped_interval3",
          "fs/joint_zoo_interval2"]
 
@@ -72,18 +73,23 @@ def test_checker_reproduces_the_reference_solver_step_by_step(oracle_lib, name):
             orc.semi_implicit_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"])
         elif case.get("report"):
             force = np.zeros((ct.max, 6), np.float32)
-            orc.xpbd_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], contact_force_out=force, **case["kw"])
+            orc.xpbd_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], contact_force_out=force, **case["kw"], **case.get("attrs", {}))
             worst_report = np.maximum(worst_report, [np.abs(force[:n] - ref[f"{name}/contact_force{k + 1}"][:n]).max(),
                                                      np.abs(s_out.body_parent_f - ref[f"{name}/body_parent_f{k + 1}"]).max()])
             force_seen = max(force_seen, float(np.abs(ref[f"{name}/contact_force{k + 1}"][:n]).max()))
         else:
-            orc.xpbd_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"])
+            orc.xpbd_step(s_in, s_out, orc.control(), ct if n else None, case["dt"], **case["kw"], **case.get("attrs", {}))
         e = _errors(s_out.body_q, s_out.body_qd, ref[f"{name}/body_q{k + 1}"], ref[f"{name}/body_qd{k + 1}"])
         worst = np.maximum(worst, e)
     print(name, "max abs error vs the reference run: pos %.3g rot %.3g lin vel %.3g ang vel %.3g" % tuple(worst))
     # one step from identical inputs.  Measured: bit-identical positions and linear velocities in nearly every case; rotations
     # within 1.5e-8 and angular velocities within 3e-6 where asin / acos / atan2 enter (numpy float32 vs glibc)
-    assert worst[0] <= 1e-7 and worst[1] <= 1e-7 and worst[2] <= 1e-6 and worst[3] <= 1e-5, worst
+    lin_tol, ang_tol = 1e-6, 1e-5
+    if case.get("attrs", {}).get("compute_body_velocity_from_position_delta"):
+        # velocities are finite differences of the poses: the sub-ulp libm differences in the poses come back times 1 / dt
+        # (measured 3.0e-5 / 5.9e-5 at dt = 1e-3 where the poses differ by 6e-8; bit-identical in the box-stack case)
+        lin_tol, ang_tol = max(lin_tol, 1e-7 / case["dt"]), max(ang_tol, 2e-7 / case["dt"])
+    assert worst[0] <= 1e-7 and worst[1] <= 1e-7 and worst[2] <= lin_tol and worst[3] <= ang_tol, worst
     if case.get("report"):
         print(name, "reporting: max abs error contacts.force %.3g [N], body_parent_f %.3g [N]" % tuple(worst_report))
         assert worst_report[0] <= 1e-3 and worst_report[1] <= 1e-3 and force_seen > 1.0, (worst_report, force_seen)

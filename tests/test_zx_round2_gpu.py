@@ -202,7 +202,8 @@ def test_descriptor_built_by_the_c_helper_steps_like_the_python_built_one():
 
 
 _REF_NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "joint_zoo", "joint_zoo_free_root",
-              "box_stack_no_weighting", "box_stack_sunk_restitution", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
+              "box_stack_no_weighting", "box_stack_sunk_restitution", "quadruped_velocity_from_delta",
+              "box_stack_velocity_from_delta_restitution", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
               "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped", "fs/quadruped_interval3",
               "fs/joint_zoo_interval2"]
 
@@ -235,6 +236,9 @@ def test_hip_path_against_reference_vectors(name):
     model = rc.prepare(case_dev)
     if kind == "xpbd":
         solver = nt.solvers.SolverXPBD(model, **case["kw"])
+        for k_, v_ in case.get("attrs", {}).items():
+            assert hasattr(solver, k_), k_
+            setattr(solver, k_, v_)
     elif kind == "semi_implicit":
         solver = nt.solvers.SolverSemiImplicit(model, **case["kw"])
     else:
