@@ -13,7 +13,7 @@
 //   SolverFeatherstone.step                                        solver_featherstone.py:462-1066
 // Summation orders follow the reference: H[i][j] = sum over bodies (ascending) and spatial rows (ascending) of
 // J[b,r,i] * (I_b S_j)[r] -- the zero entries of the dense J / M the reference multiplies through add exact zeros.
-// Scope: PRISMATIC, REVOLUTE, BALL, FIXED, root FREE, D6 with <= 1 angular axis; body l of an articulation is the child
+// Scope: PRISMATIC, REVOLUTE, BALL, FIXED, FREE / DISTANCE (root and descendant), D6; body l of an articulation is the child
 // of its joint l (the reference's eval_rigid_mass indexes body_I_s by joint index, kernels.py:1466-1480).
 
 struct FsLayout {
@@ -63,7 +63,8 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
 // block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint (3 * nj), joint of
 // each dof (nd), and per joint a bit mask of the joints on its root path, itself included (nj * ceil(nj / 32))
 __host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }
-__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m); }
+// then per joint whether the end-of-step refresh of descendant FREE / DISTANCE joints reaches it (nj) and whether any does (1)
+__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m) + m.nj + 1; }
 
 template <int EPB>
 struct FsCtx {
@@ -73,6 +74,7 @@ struct FsCtx {
     const int* dof_joint;          // [nd]
     const unsigned* pathmask;      // [nj][words]
     const unsigned* childmask;     // [nj][words] joints whose parent body is this joint's child
+    const int* refresh;            // [nj] joint index >= first descendant FREE / DISTANCE joint of its articulation; [nj] = any
     int words;
     NT_DI FsCtx(const Ctx<EPB>& c_, int* extra) : c(c_) {
         F = make_fs_layout(c.a.m, c.L);
@@ -84,7 +86,14 @@ struct FsCtx {
         pathmask = reinterpret_cast<const unsigned*>(extra + 3 * nj + c.a.m.nd);
         words = fs_mask_words(c.a.m);
         childmask = pathmask + nj * words;
+        refresh = reinterpret_cast<const int*>(childmask + nj * words);
     }
+    // FREE / DISTANCE joint below the root whose child is dynamic (solver_featherstone.py:229-237)
+    NT_DI bool descendant_free(int j) const {
+        const int t = c.T.joint_type[j];
+        return (t == JT_FREE || t == JT_DISTANCE) && c.T.joint_parent[j] >= 0 && !(c.T.body_flags[c.T.joint_child[j]] & BODY_KINEMATIC);
+    }
+    NT_DI bool any_descendant_free() const { return refresh[c.a.m.nj] != 0; }
     // is joint `a` on the root path of joint `l` (or `l` itself)?
     NT_DI bool on_path(int a, int l) const { return (pathmask[l * words + (a >> 5)] >> (a & 31)) & 1u; }
     NT_DI float& f(int off, int idx) const { return c.lds[(off + idx) * EPB + c.e]; }
@@ -726,7 +735,25 @@ NT_DI void fs_integrate_item(const FsCtx<EPB>& f, int j) {
         qdn(ds) = w_j_new.x; qdn(ds + 1) = w_j_new.y; qdn(ds + 2) = w_j_new.z;
         return;
     }
-    if (type == JT_FREE || type == JT_DISTANCE) {  // root branch (parent < 0); descendants are rejected by the host
+    if ((type == JT_FREE || type == JT_DISTANCE) && c.T.joint_parent[j] >= 0) {
+        // descendants stay in the internal parent-origin coordinates during the step (kernels.py:574-611)
+        vec3 a_s(qdd(ds), qdd(ds + 1), qdd(ds + 2)), m_s(qdd(ds + 3), qdd(ds + 4), qdd(ds + 5));
+        vec3 v_s(qd(ds), qd(ds + 1), qd(ds + 2)), w_s(qd(ds + 3), qd(ds + 4), qd(ds + 5));
+        w_s = w_s + m_s * dt;
+        v_s = v_s + a_s * dt;
+        vec3 p_s(q(cs), q(cs + 1), q(cs + 2));
+        vec3 dpdt_s = v_s + cross(w_s, p_s);
+        quat r_s(q(cs + 3), q(cs + 4), q(cs + 5), q(cs + 6));
+        quat drdt_s = quat(w_s, 0.0f) * r_s * 0.5f;
+        vec3 p_s_new = p_s + dpdt_s * dt;
+        quat r_s_new = normalize(r_s + drdt_s * dt);
+        q(cs) = p_s_new.x; q(cs + 1) = p_s_new.y; q(cs + 2) = p_s_new.z;
+        q(cs + 3) = r_s_new.x; q(cs + 4) = r_s_new.y; q(cs + 5) = r_s_new.z; q(cs + 6) = r_s_new.w;
+        qdn(ds) = v_s.x; qdn(ds + 1) = v_s.y; qdn(ds + 2) = v_s.z;
+        qdn(ds + 3) = w_s.x; qdn(ds + 4) = w_s.y; qdn(ds + 5) = w_s.z;
+        return;
+    }
+    if (type == JT_FREE || type == JT_DISTANCE) {  // root (parent < 0)
         vec3 a_parent(qdd(ds), qdd(ds + 1), qdd(ds + 2)), alpha(qdd(ds + 3), qdd(ds + 4), qdd(ds + 5));
         vec3 v_parent(qd(ds), qd(ds + 1), qd(ds + 2)), omega(qd(ds + 3), qd(ds + 4), qd(ds + 5));
         vec3 p(q(cs), q(cs + 1), q(cs + 2));
@@ -894,6 +921,25 @@ NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
         for (int k = 0; k < nj; ++k)
             if (extra[k] == j) cm[k >> 5] |= 1u << (k & 31);
     }
+    {   // descendant_free_distance_refresh_joint_starts (solver_featherstone.py:243-262) as a per-joint flag
+        int* refresh = extra + 3 * nj + m.nd + 2 * nj * words;
+        auto desc = [&](int k) {
+            const int t = c.T.joint_type[k];
+            return (t == JT_FREE || t == JT_DISTANCE) && c.T.joint_parent[k] >= 0 && !(c.T.body_flags[c.T.joint_child[k]] & BODY_KINEMATIC);
+        };
+        for (int j = threadIdx.x; j <= nj; j += blockDim.x) {
+            int flag = 0;
+            if (j < nj) {
+                int a0 = 0, a1 = nj;
+                for (int k = 0; k < m.na; ++k)
+                    if (m.art_start[k] <= j) { a0 = m.art_start[k]; a1 = k + 1 < m.na ? m.art_start[k + 1] : nj; }
+                for (int k = a0; k < a1 && k <= j; ++k) flag |= desc(k) ? 1 : 0;
+            } else {
+                for (int k = 0; k < nj; ++k) flag |= desc(k) ? 1 : 0;
+            }
+            refresh[j] = flag;
+        }
+    }
     __syncthreads();
 }
 
@@ -1002,8 +1048,13 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         for (int r = c.slot; r < m.nd * W; r += c.nslot) cache[(size_t)r * c.ES + c.env] = f.f(F.H, r);
     NT_TICK(18);
     // integrate_generalized_joints
-    if (c.valid)
+    const bool desc_free = f.any_descendant_free();  // block-uniform
+    const Fld<7> bq_prev{F.fs};                      // f_b - f_g and the subtree wrenches (12 nb rows) are dead by now
+    if (c.valid) {
         for (int j = c.slot; j < nj; j += c.nslot) fs_integrate_item(f, j);
+        if (desc_free)  // descendant_body_q_prev (solver_featherstone.py:481,514-516): the poses of the start-of-step FK
+            for (int r = c.slot; r < 7 * nb; r += c.nslot) c.lds[(bq_prev.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
+    }
     __syncthreads();
     NT_TICK(19);
     // FK with velocity conversion -> public body_q / body_qd
@@ -1015,6 +1066,44 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_fk_vel_item<EPB, false>(f, j);
         __syncthreads();
+    }
+    if (desc_free) {  // solver_featherstone.py:1006-1046
+        // correct_free_distance_body_pose_from_world_twist (kernels.py:1897-1929)
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot)
+                if (f.descendant_free(j)) {
+                    const int child = c.T.joint_child[j];
+                    const xform X_wb = c.lxf(bq_prev, 0, nb, child);
+                    const vec3 com = c.com(child);
+                    const vec3 x_com = xform_point(X_wb, com);
+                    const vec3 v_com = c.body_v(child), w = c.body_w(child);
+                    const quat drdt = quat(w, 0.0f) * X_wb.q * 0.5f;
+                    const quat q_new = normalize(X_wb.q + drdt * c.a.dt);
+                    const vec3 x_com_new = x_com + v_com * c.a.dt;
+                    c.st_lxf(c.L.bq, nb, child, xform(x_com_new - quat_rotate(q_new, com), q_new));
+                }
+        __syncthreads();
+        // reconstruct_free_distance_joint_q_from_body_pose (kernels.py:978-1012), then that joint's transform again
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot)
+                if (f.descendant_free(j)) {
+                    const int parent = c.T.joint_parent[j], child = c.T.joint_child[j], cs = c.T.joint_q_start[j];
+                    const xform X_wpj = c.body_q(parent) * c.plxf(c.L.jp, 0, nj, j);
+                    const xform X_wcj = c.body_q(child) * c.plxf(c.L.jp, 7, nj, j);
+                    const vec3 x_err_c = quat_rotate_inv(X_wpj.q, X_wcj.p - X_wpj.p);
+                    const quat q_pc = quat_inverse(X_wpj.q) * X_wcj.q;
+                    f.f(F.jq, cs) = x_err_c.x; f.f(F.jq, cs + 1) = x_err_c.y; f.f(F.jq, cs + 2) = x_err_c.z;
+                    f.f(F.jq, cs + 3) = q_pc.x; f.f(F.jq, cs + 4) = q_pc.y; f.f(F.jq, cs + 5) = q_pc.z; f.f(F.jq, cs + 6) = q_pc.w;
+                    fs_joint_xform_item(f, j);
+                }
+        __syncthreads();
+        // eval_fk_with_velocity_conversion_from_joint_starts (kernels.py:2332-2368): from the first such joint of the articulation on
+        for (int lvl = 1; lvl <= max_depth; ++lvl) {
+            if (c.valid)
+                for (int j = c.slot; j < nj; j += c.nslot)
+                    if (f.depth[j] == lvl && f.refresh[j]) fs_fk_vel_item<EPB, false>(f, j);
+            __syncthreads();
+        }
     }
     NT_TICK(20);
     if (c.valid)

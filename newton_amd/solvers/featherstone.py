@@ -33,9 +33,6 @@ class SolverFeatherstone(SolverBase):
         jt = np.asarray(t.joint_type)
         if np.any(jt == int(JointType.ROD)):
             raise NotImplementedError("SolverFeatherstone: ROD joints are not supported")
-        free_like = (jt == int(JointType.FREE)) | (jt == int(JointType.DISTANCE))  # DISTANCE moves like FREE here too
-        if np.any(free_like & (np.asarray(t.joint_parent) >= 0)):
-            raise NotImplementedError("SolverFeatherstone: FREE / DISTANCE joints are supported at articulation roots only")
         if not np.array_equal(np.asarray(t.joint_child), np.arange(t.nj)) or t.nb != t.nj:
             # the reference's eval_rigid_mass indexes body_I_s by joint index (kernels.py:1466-1480)
             raise NotImplementedError("SolverFeatherstone: body j must be the child of joint j")

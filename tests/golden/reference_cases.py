@@ -9,6 +9,12 @@ def _scenes():
     return box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene
 
 
+def _free_child_scene(*a, **k):
+    from scenes import free_child_scene
+
+    return free_child_scene(*a, **k)
+
+
 def cases():
     box_stack_scene, joint_zoo_scene, pendulum_scene, quadruped_scene = _scenes()
     sin_f = lambda nd: 0.4 * np.sin(np.arange(nd)).astype(np.float32)  # noqa: E731
@@ -58,6 +64,11 @@ def cases():
                                        kw=dict(update_mass_matrix_interval=3), lower=0.221),
         "fs/joint_zoo_interval2": dict(scene=lambda: joint_zoo_scene(1, seed=14), steps=4, dt=5e-4, solver="featherstone",
                                        kw=dict(update_mass_matrix_interval=2)),
+        # FREE / DISTANCE joints below the root (solver_featherstone.py:229-265,1006-1046)
+        "fs/free_child": dict(scene=lambda: _free_child_scene(2, seed=16), steps=4, dt=5e-4, solver="featherstone", kw={},
+                              joint_f=sin_f),
+        "fs/free_child_free_root": dict(scene=lambda: _free_child_scene(1, seed=17, free_root=True), steps=4, dt=5e-4,
+                                        solver="featherstone", kw=dict(angular_damping=0.05)),
         "fs/quadruped": dict(scene=lambda: quadruped_scene(1, seed=11), steps=3, dt=5e-4, solver="featherstone",
                              kw=dict(friction_smoothing=0.5), lower=0.221, joint_f=sin_f),
     }

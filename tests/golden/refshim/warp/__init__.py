@@ -601,28 +601,35 @@ class ArrayView:
     def ptr(self): return _Ptr(self.base, self.start * _SIZEOF.get(self.dtype, 4))
 
 
-class _ArrayType:
-    """wp.array(dtype=...) in an annotation, or wp.array(data, dtype=...) at run time (-> a python list of shim values)."""
+class _ArrayType(type):
+    """wp.array(dtype=...) in an annotation, wp.array(data, dtype=...) at run time (-> a python list of shim values), and
+    isinstance(x, wp.array)."""
 
-    def __call__(self, data=None, dtype=None, ndim=1, ptr=None, shape=None, **kw):
+    def __call__(cls, data=None, dtype=None, ndim=1, ptr=None, shape=None, **kw):
         if ptr is not None:
             n = shape[0] if isinstance(shape, (tuple, list)) else int(shape)
             return ArrayView(ptr.base, ptr.off // _SIZEOF.get(dtype, 4), n, dtype)
         if data is None:
-            return self
+            return cls
         return to_array(data, dtype)
 
-    def __getitem__(self, k):
-        return self
+    def __getitem__(cls, k):
+        return cls
 
-    def __or__(self, o):
-        return self
+    def __or__(cls, o):
+        return cls
 
-    def __ror__(self, o):
-        return self
+    def __ror__(cls, o):
+        return cls
+
+    def __instancecheck__(cls, x):
+        return isinstance(x, (Array, ArrayView))
 
 
-array = _ArrayType()
+class array(metaclass=_ArrayType):
+    pass
+
+
 array1d = array2d = array3d = array4d = array
 indexedarray = fabricarray = array
 
@@ -789,7 +796,8 @@ def tid():
 def launch(kernel=None, dim=None, inputs=(), outputs=(), device=None, **kw):
     fn = getattr(kernel, "__wrapped_kernel__", kernel)
     n = dim if isinstance(dim, int) else dim[0] if len(dim) == 1 else dim
-    args = [f32(a) if isinstance(a, float) else a for a in list(inputs) + list(outputs)]  # kernel scalars are fp32
+    # kernel scalars are fp32; a None array arrives as an empty array
+    args = [f32(a) if isinstance(a, float) else (Array() if a is None else a) for a in list(inputs) + list(outputs)]
     if isinstance(n, int):
         for t in range(n):
             _tid[0] = t
@@ -1070,6 +1078,38 @@ for _n in ("types", "context", "config", "utils", "sim", "render", "sparse", "fe
     _sys.modules["warp." + _n] = _m
     setattr(_sys.modules[__name__], _n.split(".")[0], _sys.modules["warp." + _n.split(".")[0]])
 _sys.modules["warp.types"].vector = _make_vector
+
+
+def _segmented_sort_pairs(keys, values, count, segment_start_indices, segment_end_indices=None):
+    """wp.utils.segmented_sort_pairs: every segment [start[s], end[s]) sorted by key, ascending and stable (radix sort); with
+    only the start array given, segment s ends where segment s + 1 starts (the array holds one more entry than segments)."""
+    nseg = len(segment_start_indices) - (1 if segment_end_indices is None else 0)
+    for s_ in range(nseg):
+        a = int(segment_start_indices[s_])
+        b = int(segment_end_indices[s_]) if segment_end_indices is not None else int(segment_start_indices[s_ + 1])
+        b = min(b, int(count))
+        order = sorted(range(a, b), key=lambda i: float(keys[i]))  # python's sort is stable
+        ks, vs = [keys[i] for i in order], [values[i] for i in order]
+        for k_, i in enumerate(range(a, b)):
+            keys[i], values[i] = ks[k_], vs[k_]
+
+
+def _array_scan(inp, out, inclusive=True):
+    """wp.utils.array_scan: prefix sum (int32 / fp32)."""
+    acc = _zero_like(inp[0]) if len(inp) else 0
+    for i in range(len(inp)):
+        if inclusive:
+            acc = acc + inp[i]
+            out[i] = acc
+        else:
+            out[i] = acc
+            acc = acc + inp[i]
+
+
+_sys.modules["warp.utils"].segmented_sort_pairs = _segmented_sort_pairs
+_sys.modules["warp.utils"].array_scan = _array_scan
+_sys.modules["warp._src.utils"].segmented_sort_pairs = _segmented_sort_pairs
+_sys.modules["warp._src.utils"].array_scan = _array_scan
 _sys.modules["warp.types"].matrix = _make_matrix
 vec = _make_vector
 mat = _make_matrix

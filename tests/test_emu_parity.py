@@ -482,3 +482,39 @@ def test_velocity_from_position_delta(H):
                 H.xpbd_step(em, a, b, ctrl, ct, dt, enable_restitution=rest, **flag)
                 a, b = b, a
             assert np.array_equal(out.body_q, a.body_q) and np.array_equal(out.body_qd, a.body_qd)
+
+
+@pytest.mark.parametrize("free_root", [False, True])
+def test_featherstone_free_and_distance_joints_below_the_root(H, free_root):
+    """solver_featherstone.py:229-265,1006-1046: descendant FREE / DISTANCE joints are integrated in internal parent-origin
+    coordinates, then the child pose is re-integrated from its world COM twist, joint_q rebuilt from the poses and the rest of
+    the articulation refreshed.  Emulated kernels vs the checker over 25 steps, and fused rollout == per-step loop bitwise."""
+    from oracle_bridge import Oracle, OracleState
+    from scenes import free_child_scene
+
+    model = free_child_scene(3, seed=31, free_root=free_root)
+    rng = np.random.default_rng(5)
+    jf = rng.normal(0, 0.5, size=model.joint_dof_count).astype(np.float32)
+    em = H.EmuModel(model)
+    s0, s1, ctrl = H.EmuState(em), H.EmuState(em), H.EmuControl(em, joint_f=jf)
+    o = Oracle(model)
+    os0, os1 = OracleState(model), OracleState(model)
+    for _ in range(25):
+        s0.body_f[:] = 0
+        H.featherstone_step(em, s0, s1, ctrl, None, 1e-3)
+        os0.body_f[:] = 0
+        o.featherstone_step(os0, os1, o.control(joint_f=jf), None, 1e-3)
+        s0, s1, os0, os1 = s1, s0, os1, os0
+    assert _close(s0.aos("joint_q"), os0.joint_q, 1e-5) and _close(s0.aos("joint_qd"), os0.joint_qd, 1e-4)
+    assert _close(s0.aos("body_q"), os0.body_q, 1e-5) and _close(s0.aos("body_qd"), os0.body_qd, 1e-4)
+    assert np.abs(os0.body_q - model.body_q).max() > 1e-3  # it moved
+    ct = H.EmuContacts(em)
+    out = H.featherstone_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1e-3, 3)
+    a, b = H.EmuState(em), H.EmuState(em)
+    for _ in range(3):
+        a.body_f[:] = 0
+        H.collide(em, a, ct)
+        H.featherstone_step(em, a, b, ctrl, ct, 1e-3)
+        a, b = b, a
+    for k in ("body_q", "body_qd", "joint_q", "joint_qd"):
+        assert np.array_equal(getattr(out, k), getattr(a, k)), k

@@ -35,7 +35,7 @@ NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", "join
          "box_stack_no_weighting", "box_stack_sunk_restitution", "quadruped_velocity_from_delta",
          "box_stack_velocity_from_delta_restitution", "quadruped_report", "box_stack_report", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
          "semi/box_stack_contact_props", "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped", "fs/quadruped_interval3",
-         "fs/joint_zoo_interval2"]
+         "fs/joint_zoo_interval2", "fs/free_child", "fs/free_child_free_root"]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -179,3 +179,45 @@ def test_match_checker_reproduces_the_reference_contact_matcher(name, frames):
         prev = (g("keys"), mid, g("normal"))
     assert 1 in seen or 0 in seen
     assert -2 in seen  # broken matches occur in both recordings
+
+
+BP_VEC = os.path.join(HERE, "golden", "broadphase_reference_vectors.npz")
+
+
+@pytest.mark.parametrize("variant", ["plain", "filtered", "immovable"])
+@pytest.mark.parametrize("name", ["single_world", "multiple_worlds", "shape_flags", "per_shape_gap"])
+def test_broad_phase_checker_reproduces_the_reference_classes(oracle_lib, name, variant):
+    """World map and candidate lists of the reference's own precompute_world_map / BroadPhaseAllPairs / BroadPhaseExplicit /
+    BroadPhaseSAP, executed on the stand-in (tests/golden/make_broadphase_reference_vectors.py): N x N and explicit in the
+    reference's append order (ascending tid), sort-and-sweep as a set (its order depends on the segmented sort)."""
+    import ctypes as C
+
+    import broadphase_cases as bc
+    from newton_amd.geometry import precompute_world_map
+    from test_broad_phase_standalone import _oracle
+
+    ref = np.load(BP_VEC)
+    v = bc.variants(name)[variant]
+    key = f"{name}/{variant}"
+    index_map, ends = precompute_world_map(v["world"], v["flags"])
+    assert np.array_equal(index_map, ref[f"{key}/index_map"]) and np.array_equal(ends, ref[f"{key}/slice_ends"])
+    kw = dict(filter_pairs=v["filter_pairs"], shape_body=v["shape_body"], body_flags=v["body_flags"], include=v["include"])
+    args = (v["lower"], v["upper"], v["gap"], v["group"], v["world"], v["flags"])
+    count, pairs = _oracle(oracle_lib, "nxn", *args, **kw)
+    want = ref[f"{key}/nxn_pairs"]
+    assert len(want) > 5 and count == len(want) and np.array_equal(pairs, want)
+    count, pairs = _oracle(oracle_lib, "sap", *args, **kw)
+    want = ref[f"{key}/sap_pairs"]
+    assert count == len(want) and len({tuple(p) for p in pairs}) == count
+    assert {tuple(p) for p in pairs} == {tuple(p) for p in want}
+    # explicit list (no group / world / excluded-pair test: broad_phase_nxn.py:444-535)
+    ep = np.ascontiguousarray(v["explicit_pairs"], np.int32)
+    out = np.zeros((len(ep) + 1, 2), np.int32)
+    fi, ii = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    p = lambda a, t: a.ctypes.data_as(t) if a is not None else None  # noqa: E731
+    oracle_lib.o_broadphase_explicit.restype = C.c_int
+    count = oracle_lib.o_broadphase_explicit(p(v["lower"], fi), p(v["upper"], fi), p(v["gap"], fi), p(ep, ii), len(ep),
+                                             p(v["shape_body"], ii), p(v["body_flags"], ii), int(v["include"]), p(out, ii),
+                                             len(out))
+    want = ref[f"{key}/explicit_pairs"]
+    assert count == len(want) and np.array_equal(out[:count], want)

@@ -205,7 +205,7 @@ _REF_NAMES = ["quadruped_standing", "quadruped_impact_restitution", "pendulum", 
               "box_stack_no_weighting", "box_stack_sunk_restitution", "quadruped_velocity_from_delta",
               "box_stack_velocity_from_delta_restitution", "semi/pendulum", "semi/joint_zoo", "semi/box_stack",
               "semi/quadruped", "fs/pendulum", "fs/joint_zoo", "fs/joint_zoo_free_root", "fs/quadruped", "fs/quadruped_interval3",
-              "fs/joint_zoo_interval2"]
+              "fs/joint_zoo_interval2", "fs/free_child", "fs/free_child_free_root"]
 
 
 @pytest.mark.parametrize("name", _REF_NAMES)
@@ -350,6 +350,49 @@ def test_featherstone_rollout_with_a_mass_matrix_interval_is_the_step_loop():
     assert not np.array_equal(qd1, qd_fused) and np.abs(qd1 - qd_fused).max() < 1e-2
 
 
+@pytest.mark.parametrize("free_root", [False, True])
+def test_featherstone_free_and_distance_joints_below_the_root_on_device(oracle_lib, free_root):
+    """Descendant FREE / DISTANCE joints (solver_featherstone.py:229-265,1006-1046) through the Python surface: 20 steps against
+    the checker, and the fused rollout against the launch-by-launch loop bit for bit."""
+    import torch
+    from oracle_bridge import Oracle, OracleState
+    from scenes import free_child_scene
+    from tolerances import record
+
+    import newton_amd as nt
+
+    model = free_child_scene(8, device="cuda:0", seed=33, free_root=free_root)
+    solver = nt.solvers.SolverFeatherstone(model, angular_damping=0.05)
+    s0, s1 = model.state(), model.state()
+    o = Oracle(model)
+    os0, os1 = OracleState(model), OracleState(model)
+    for _ in range(20):
+        s0.clear_forces()
+        solver.step(s0, s1, None, None, 1e-3)
+        os0.body_f[:] = 0
+        o.featherstone_step(os0, os1, o.control(), None, 1e-3, angular_damping=0.05)
+        s0, s1, os0, os1 = s1, s0, os1, os0
+    torch.cuda.synchronize()
+    errs = {k: float(np.abs(getattr(s0, k).cpu().numpy().reshape(-1) - getattr(os0, k).reshape(-1)).max())
+            for k in ("joint_q", "joint_qd", "body_q", "body_qd")}
+    record("featherstone_free_child" + ("_free_root" if free_root else ""), errs,
+           {"joint_q": 1e-5, "body_q": 1e-5, "joint_qd": 1e-4, "body_qd": 1e-4})
+    assert errs["joint_q"] < 1e-5 and errs["body_q"] < 1e-5 and errs["joint_qd"] < 1e-4 and errs["body_qd"] < 1e-4, errs
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    a, b = model.state(), model.state()
+    out = solver.rollout(a, b, None, contacts, 1e-3, 5)
+    c, d = model.state(), model.state()
+    for _ in range(5):
+        c.clear_forces()
+        pipe.collide(c, contacts)
+        solver.step(c, d, None, contacts, 1e-3)
+        c, d = d, c
+    torch.cuda.synchronize()
+    for k in ("joint_q", "joint_qd", "body_q", "body_qd"):
+        assert np.array_equal(getattr(out, k).cpu().numpy().view(np.int32), getattr(c, k).cpu().numpy().view(np.int32)), k
+
+
 def test_collision_pipeline_contact_matching_latest_with_report():
     """CollisionPipeline(contact_matching="latest", contact_report=True) (collide.py:1126-1129): rigid_contact_match_index is
     filled by every collide(); new / broken reports are consistent with it; the indices equal oracle_match on the exported rows."""
@@ -441,3 +484,44 @@ def test_collision_pipeline_sticky_matching_against_the_reference_matcher(name, 
         for field in ("point0", "point1", "offset0", "offset1", "normal"):
             got = getattr(contacts, "rigid_contact_" + field).cpu().numpy()[:n]
             assert np.array_equal(got, ref[f"{name}/{k}/sticky_{field}"]), (k, field)
+
+
+@pytest.mark.parametrize("variant", ["plain", "filtered", "immovable"])
+@pytest.mark.parametrize("name", ["single_world", "multiple_worlds", "shape_flags", "per_shape_gap"])
+def test_hip_broad_phase_against_the_reference_classes(name, variant):
+    """BroadPhaseAllPairs / BroadPhaseSAP (device projection + in-LDS segment sort + sweep) / BroadPhaseExplicit on the device
+    against the candidate lists the reference's own classes produced when executed
+    (tests/golden/make_broadphase_reference_vectors.py) -- as sets: the wave-aggregated append has no fixed order."""
+    import os
+    import sys
+
+    import torch
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import broadphase_cases as bc
+    from test_broad_phase_standalone import _gpu_run
+
+    from newton_amd import geometry
+
+    ref = np.load(os.path.join(here, "golden", "broadphase_reference_vectors.npz"))
+    v, key = bc.variants(name)[variant], f"{name}/{variant}"
+    kw = dict(include_static_kinematic_pairs=v["include"])
+    if v["shape_body"] is not None:
+        kw.update(shape_body=v["shape_body"], body_flags=v["body_flags"])
+    for cls_name, kind in (("BroadPhaseAllPairs", "nxn"), ("BroadPhaseSAP", "sap")):
+        count, pairs, _ = _gpu_run(cls_name, v["lower"], v["upper"], v["gap"], v["group"], v["world"], v["flags"],
+                                   filter_pairs=v["filter_pairs"], **kw)
+        want = {tuple(p) for p in ref[f"{key}/{kind}_pairs"]}
+        assert count == len(want) and {tuple(p) for p in pairs} == want, (cls_name, count, len(want))
+    dev = "cuda:0"
+    t = lambda a, d: torch.as_tensor(np.ascontiguousarray(a), dtype=d, device=dev)  # noqa: E731
+    ep = v["explicit_pairs"]
+    out = torch.full((len(ep) + 1, 2), -1, dtype=torch.int32, device=dev)
+    cnt = torch.full((1,), 77, dtype=torch.int32, device=dev)
+    extra = {k: t(x, torch.int32) if isinstance(x, np.ndarray) else x for k, x in kw.items()}
+    geometry.BroadPhaseExplicit().launch(t(v["lower"], torch.float32), t(v["upper"], torch.float32), t(v["gap"], torch.float32),
+                                         t(ep, torch.int32), len(ep), out, cnt, **extra)
+    c = int(cnt.cpu().numpy()[0])
+    want = {tuple(p) for p in ref[f"{key}/explicit_pairs"]}
+    assert c == len(want) and {tuple(p) for p in out.cpu().numpy()[:c]} == want
