@@ -836,6 +836,13 @@ def atomic_max(arr, i, value):
     return old
 
 
+def atomic_cas(arr, i, compare, value):
+    old = arr[i]
+    if old == compare:
+        arr[i] = value
+    return old
+
+
 def atomic_min(arr, i, value):
     old = arr[i]
     arr[i] = value if value < old else old
@@ -881,6 +888,31 @@ def _float_flip(f):
 
 
 _NATIVE = {"_support_rsqrt_rn": lambda value: f32(1.0) / _np.sqrt(_s(value)), "_float_flip": _float_flip}
+_NATIVE["float_flip"] = _float_flip  # contact_reduction.py
+_NATIVE["_unpack_contact_id_fast"] = lambda packed: int(int(packed) & 0xFFFFFFFF)  # contact_reduction_global.py
+_NATIVE["_unpack_contact_id_det"] = lambda packed: int(int(packed) & 0xFFFFF)
+_NATIVE["_sdf_rsqrt_rn"] = lambda value: f32(1.0) / _np.sqrt(_s(value))
+
+
+# tile primitives as one serial lane sees them (the export kernel of the global contact reducer does all of its work on lane 0
+# when `parallel_pairs == 0`; every lane gets its own tile here)
+def tile_zeros(shape=None, dtype=int, storage=None, **kw):
+    n = shape[0] if isinstance(shape, (tuple, list)) else int(shape)
+    return [_zero_of(dtype) for _ in range(n)]
+
+
+def tile_scatter_masked(tile, idx, value, mask):
+    if mask:
+        tile[idx] = value
+
+
+def tile_reduce(op, tile):
+    import functools
+
+    return [functools.reduce(op, tile)]
+
+
+def bit_or(a, b): return a | b
 
 
 def func_replay(forward):
