@@ -358,6 +358,45 @@ typedef struct {
 } nt_mesh_sdf_args;
 nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
 
+/* mesh_sdf_collision_global_reduce_kernel + GlobalContactReducer + export_reduced_contacts_kernel (sdf_contact.py:1534-1990,
+ * contact_reduction_global.py:1519-1752,2098-2290, deterministic packing): the same edge-vs-SDF contacts, reduced per shape
+ * pair to the winners of 20 normal bins x (6 spatial extremes + deepest) and 100 voxel-depth slots, roundoff twins dropped,
+ * every survivor once.  One contiguous block of rows per pair, ascending fingerprint ((edge << 2) | (mode << 1)) inside the
+ * block -- the order Newton's deterministic contact sort produces; out_data[3..5] is the normal after the reducer's
+ * octahedral round trip (what the reference exports).  Needs the per-shape tables the reference's Model carries for the voxel
+ * slots. */
+typedef struct {
+    const float* shape_aabb_lower;   /* [S][3] Model.shape_collision_aabb_lower (shape-local) */
+    const float* shape_aabb_upper;   /* [S][3] Model.shape_collision_aabb_upper */
+    const int32_t* shape_voxel_res;  /* [S][3] Model._shape_voxel_resolution (builder.py:11544-11570) */
+} nt_contact_reduce_shapes;
+nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* args, const nt_contact_reduce_shapes* shapes, void* stream);
+
+/* The reduction stage alone on an unreduced contact list (what export_and_reduce_contact_centered_two_spatial_depths is
+ * called with, contact_reduction_global.py:1519-1535), grouped by shape pair: contacts [segment_start[k], segment_start[k+1])
+ * belong to one pair; fingerprints are unique inside a pair and below 2^22.  Appends, per segment, the indices of the surviving
+ * contacts in ascending fingerprint order and their exported normals. */
+typedef struct {
+    const int32_t* segment_start;    /* [segments + 1] */
+    int32_t segments;
+    const float* pos;                /* [n][3] world point */
+    const float* normal;             /* [n][3] a -> b */
+    const float* depth;              /* [n] */
+    const int32_t* fp;               /* [n] fingerprint */
+    const float* centered;           /* [n][3] point relative to the pair's midpoint */
+    const float* inner;              /* [n] inner spatial depth */
+    const float* outer;              /* [n] outer spatial depth */
+    const float* local;              /* [n][3] point in the edge shape's frame */
+    const float* aabb_lo;            /* [n][3] that shape's local AABB */
+    const float* aabb_hi;            /* [n][3] */
+    const int32_t* res;              /* [n][3] and voxel resolution */
+    int32_t* out_count;              /* [1], zero it first */
+    int32_t* out_index;              /* [capacity] index into the list */
+    float* out_normal;               /* [capacity][3] */
+    int32_t capacity;
+} nt_contact_reduce_list;
+nt_status nt_contacts_reduce_list(const nt_contact_reduce_list* args, void* stream);
+
 /* HydroelasticSDF contact generation, unreduced (sdf_hydroelastic.py:905-1296 launch, :1982-2140 generate, :1823-1928 decode):
  * marching cubes on the iso-pressure surface p_a == p_b (p = -kh * signed depth) of every SDF pair; one contact per face with
  * the per-contact stiffness area * pressure / |separation| (penetrating) or margin_contact_area * k_a k_b / (k_a + k_b)

@@ -96,6 +96,17 @@ class nt_mesh_sdf_args(C.Structure):
                 ("capacity", C.c_int32)]
 
 
+class nt_contact_reduce_shapes(C.Structure):
+    _fields_ = [("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p)]
+
+
+class nt_contact_reduce_list(C.Structure):
+    _fields_ = [("segment_start", C.c_void_p), ("segments", C.c_int32), ("pos", C.c_void_p), ("normal", C.c_void_p),
+                ("depth", C.c_void_p), ("fp", C.c_void_p), ("centered", C.c_void_p), ("inner", C.c_void_p), ("outer", C.c_void_p),
+                ("local", C.c_void_p), ("aabb_lo", C.c_void_p), ("aabb_hi", C.c_void_p), ("res", C.c_void_p),
+                ("out_count", C.c_void_p), ("out_index", C.c_void_p), ("out_normal", C.c_void_p), ("capacity", C.c_int32)]
+
+
 class nt_contact_history(C.Structure):
     _fields_ = [("prev_pos_world", C.c_void_p), ("prev_normal", C.c_void_p), ("prev_live", C.c_void_p),
                 ("prev_body_frame", C.c_void_p)]
@@ -241,6 +252,8 @@ SYMBOLS = {
     "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
     "nt_sdf_sample": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P, _P]),
     "nt_mesh_sdf_collide": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), _P]),
+    "nt_mesh_sdf_collide_reduced": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), C.POINTER(nt_contact_reduce_shapes), _P]),
+    "nt_contacts_reduce_list": (C.c_int32, [C.POINTER(nt_contact_reduce_list), _P]),
     "nt_contacts_match": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts), C.POINTER(nt_contact_history),
                                        C.c_float, C.c_float, _P, _P, _P]),
     "nt_contacts_replay_matched": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),

@@ -231,84 +231,112 @@ NT_DI void edge_search(const nt_sdf& s, vec3 v0, vec3 v1, float midpoint_sdf, fl
 
 NT_DI xform load_xform(const float* p) { return xform(vec3(p[0], p[1], p[2]), quat(p[3], p[4], p[5], p[6])); }
 
+// Everything of one (pair, mode) that does not depend on the edge: the SDF side's grid, both transforms, the scale guards and the
+// thresholds (sdf_contact.py:1186-1262).  Wave-uniform.
+struct ModeCtx {
+    nt_sdf s;
+    int e0, ne;
+    vec3 sdf_scale, inv_scale, blo, bhi;
+    xform X_tri, X_sdf, X_m2s;
+    float tri_margin, sdf_margin, min_scale, radius_scale, contact_threshold, thr_unscaled, inner, precision, gap_sum;
+};
+NT_DI bool mode_setup(const nt_mesh_sdf_args& a, int s0, int s1, int mode, ModeCtx& c) {
+    const int tri_shape = mode == 0 ? s0 : s1, sdf_shape = mode == 0 ? s1 : s0;
+    const int sdf_idx = a.shape_sdf_index[sdf_shape];
+    c.e0 = a.shape_edge_range[2 * tri_shape];
+    c.ne = a.shape_edge_range[2 * tri_shape + 1];
+    if (sdf_idx < 0 || sdf_idx >= a.sdf_count || c.ne <= 0) return false;  // no SDF on that side / no edges on this side
+    c.s = a.sdf_table[sdf_idx];
+    if (c.s.cx <= 0) return false;
+    c.gap_sum = a.shape_gap[s0] + a.shape_gap[s1];
+    const float* dt = a.shape_data + 4 * tri_shape;
+    const float* ds = a.shape_data + 4 * sdf_shape;
+    c.sdf_scale = vec3(ds[0], ds[1], ds[2]);
+    if (c.s.scale_baked) c.sdf_scale = vec3(1.0f, 1.0f, 1.0f);
+    c.X_tri = load_xform(a.shape_transform + 7 * tri_shape);
+    c.X_sdf = load_xform(a.shape_transform + 7 * sdf_shape);
+    c.X_m2s = xform_inverse(c.X_sdf) * c.X_tri;
+    c.tri_margin = dt[3];
+    c.sdf_margin = ds[3];
+    // safe_sdf_scale_inverse
+    const float eps = 1.0e-10f;
+    auto guard = [&](float v) { return fabsf(v) > eps ? v : (v >= 0.0f ? eps : -eps); };
+    const float sx = guard(c.sdf_scale.x), sy = guard(c.sdf_scale.y), sz = guard(c.sdf_scale.z);
+    c.inv_scale = vec3(1.0f / sx, 1.0f / sy, 1.0f / sz);
+    c.min_scale = fminw(fminw(fabsf(sx), fabsf(sy)), fabsf(sz));
+    c.radius_scale = fmaxw(fmaxw(fabsf(c.inv_scale.x), fabsf(c.inv_scale.y)), fabsf(c.inv_scale.z));
+    c.contact_threshold = c.gap_sum + c.tri_margin + c.sdf_margin;
+    c.thr_unscaled = c.contact_threshold / c.min_scale;
+    c.inner = c.tri_margin + c.sdf_margin;
+    c.precision = fminw(c.inner / c.min_scale, c.s.voxel_radius);  // mesh_sdf_contact_search_precision
+    c.blo = vec3(c.s.box_lower[0], c.s.box_lower[1], c.s.box_lower[2]);
+    c.bhi = vec3(c.s.box_upper[0], c.s.box_upper[1], c.s.box_upper[2]);
+    return true;
+}
+// One edge of the "triangle" shape against the other shape's SDF (sdf_contact.py:1288-1480): cull, Brent search, inner-cull
+// consistency, corner ownership, gradient.  -> world point, normal shape0 -> shape1, distance.
+NT_DI bool edge_contact(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int mode, vec3& pw, vec3& n, float& dist) {
+    const nt_sdf& s = c.s;
+    const float* ec = a.edge_centers + 4 * (size_t)(c.e0 + e);
+    const float* eh = a.edge_halves + 4 * (size_t)(c.e0 + e);
+    // cull: bounding sphere of the edge against the SDF box, then against the midpoint value
+    const vec3 center = cw_mul(xform_point(c.X_m2s, vec3(ec[0], ec[1], ec[2])), c.inv_scale);
+    const float threshold = ec[3] * c.radius_scale + c.thr_unscaled;
+    const vec3 cl = vmin(vmax(center, c.blo), c.bhi);
+    const float d2 = length_sq(center - cl);
+    if (d2 > threshold * threshold) return false;
+    const float mid = sample_clamped(s, cl, d2 > 0.0f ? sqrtf(d2) : 0.0f);
+    if (!(mid <= threshold)) return false;
+    // the edge in the SDF's unscaled space + its corner ownership
+    const vec3 c_loc = xform_point(c.X_m2s, vec3(ec[0], ec[1], ec[2]));
+    const vec3 h_loc = xform_vector(c.X_m2s, vec3(eh[0], eh[1], eh[2]));
+    const int ownership = (int)eh[3];
+    const vec3 v0 = cw_mul(c_loc - h_loc, c.inv_scale), v1 = cw_mul(c_loc + h_loc, c.inv_scale);
+    float dist_u;
+    vec3 p_u;
+    int endpoint;
+    edge_search(s, v0, v1, mid, c.precision, dist_u, p_u, endpoint);
+    const float dist_approx = dist_u * c.min_scale;
+    // mesh_sdf_contact_passes_inner_cull_consistency
+    bool consistent = true;
+    if (dist_approx < c.inner) {
+        const vec3 ic = (v0 + v1) * 0.5f;
+        const float ir = length(v1 - v0) * 0.5f;
+        const float cr = ir + c.inner / c.min_scale;
+        const vec3 icl = vmin(vmax(ic, c.blo), c.bhi);
+        if (length_sq(ic - icl) > cr * cr) consistent = false;
+        else consistent = mid <= cr;
+    }
+    const bool owns = endpoint == 0 || ownership == 0 || (ownership & endpoint) != 0;
+    if (!(dist_approx < c.contact_threshold && consistent && owns)) return false;
+    vec3 dir_u = sample_grad(s, p_u);
+    // scale_sdf_result_to_world (sdf_contact.py:155-182): gradient back through the anisotropic scale
+    dist = dist_u * c.min_scale;                          // conservative distance through the smallest scale
+    const vec3 dir = cw_mul(dir_u, c.inv_scale);          // normalised after the rigid rotation below
+    const vec3 point = cw_mul(p_u, c.sdf_scale);
+    pw = xform_point(c.X_sdf, point);
+    vec3 dw = xform_vector(c.X_sdf, dir);
+    const float dl2 = length_sq(dw);
+    if (dl2 > 0.0f) dw = dw * (1.0f / sqrtf(dl2));
+    else {
+        vec3 fb = pw - c.X_sdf.p;
+        const float fl2 = length_sq(fb);
+        dw = fl2 > 0.0f ? fb * (1.0f / sqrtf(fl2)) : vec3(0.0f, 1.0f, 0.0f);
+    }
+    n = mode == 0 ? -dw : dw;
+    return true;
+}
+
 __global__ void __launch_bounds__(256) mesh_sdf_collide_kernel(nt_mesh_sdf_args a) {
     for (int pair_idx = blockIdx.x; pair_idx < a.pair_count; pair_idx += gridDim.x) {
         const int s0 = a.pairs[2 * pair_idx], s1 = a.pairs[2 * pair_idx + 1];
-        const float gap_sum = a.shape_gap[s0] + a.shape_gap[s1];
         for (int mode = 0; mode < 2; ++mode) {
-            const int tri_shape = mode == 0 ? s0 : s1, sdf_shape = mode == 0 ? s1 : s0;
-            const int sdf_idx = a.shape_sdf_index[sdf_shape];
-            const int e0 = a.shape_edge_range[2 * tri_shape], ne = a.shape_edge_range[2 * tri_shape + 1];
-            if (sdf_idx < 0 || sdf_idx >= a.sdf_count || ne <= 0) continue;  // no SDF on that side / no edges on this side
-            const nt_sdf s = a.sdf_table[sdf_idx];
-            if (s.cx <= 0) continue;
-            const float* dt = a.shape_data + 4 * tri_shape;
-            const float* ds = a.shape_data + 4 * sdf_shape;
-            vec3 sdf_scale(ds[0], ds[1], ds[2]);
-            if (s.scale_baked) sdf_scale = vec3(1.0f, 1.0f, 1.0f);
-            const xform X_tri = load_xform(a.shape_transform + 7 * tri_shape), X_sdf = load_xform(a.shape_transform + 7 * sdf_shape);
-            const xform X_m2s = xform_inverse(X_sdf) * X_tri;
-            const float tri_margin = dt[3], sdf_margin = ds[3];
-            // safe_sdf_scale_inverse
-            const float eps = 1.0e-10f;
-            auto guard = [&](float v) { return fabsf(v) > eps ? v : (v >= 0.0f ? eps : -eps); };
-            const float sx = guard(sdf_scale.x), sy = guard(sdf_scale.y), sz = guard(sdf_scale.z);
-            const vec3 inv_scale(1.0f / sx, 1.0f / sy, 1.0f / sz);
-            const float min_scale = fminw(fminw(fabsf(sx), fabsf(sy)), fabsf(sz));
-            const float radius_scale = fmaxw(fmaxw(fabsf(inv_scale.x), fabsf(inv_scale.y)), fabsf(inv_scale.z));
-            const float contact_threshold = gap_sum + tri_margin + sdf_margin;
-            const float thr_unscaled = contact_threshold / min_scale;
-            const float inner = tri_margin + sdf_margin;
-            const float precision = fminw(inner / min_scale, s.voxel_radius);  // mesh_sdf_contact_search_precision
-            const vec3 blo(s.box_lower[0], s.box_lower[1], s.box_lower[2]), bhi(s.box_upper[0], s.box_upper[1], s.box_upper[2]);
-            for (int e = threadIdx.x; e < ne; e += blockDim.x) {
-                const float* ec = a.edge_centers + 4 * (size_t)(e0 + e);
-                const float* eh = a.edge_halves + 4 * (size_t)(e0 + e);
-                // cull: bounding sphere of the edge against the SDF box, then against the midpoint value
-                const vec3 center = cw_mul(xform_point(X_m2s, vec3(ec[0], ec[1], ec[2])), inv_scale);
-                const float threshold = ec[3] * radius_scale + thr_unscaled;
-                const vec3 cl = vmin(vmax(center, blo), bhi);
-                const float d2 = length_sq(center - cl);
-                if (d2 > threshold * threshold) continue;
-                const float mid = sample_clamped(s, cl, d2 > 0.0f ? sqrtf(d2) : 0.0f);
-                if (!(mid <= threshold)) continue;
-                // the edge in the SDF's unscaled space + its corner ownership
-                const vec3 c_loc = xform_point(X_m2s, vec3(ec[0], ec[1], ec[2]));
-                const vec3 h_loc = xform_vector(X_m2s, vec3(eh[0], eh[1], eh[2]));
-                const int ownership = (int)eh[3];
-                const vec3 v0 = cw_mul(c_loc - h_loc, inv_scale), v1 = cw_mul(c_loc + h_loc, inv_scale);
-                float dist_u;
-                vec3 p_u;
-                int endpoint;
-                edge_search(s, v0, v1, mid, precision, dist_u, p_u, endpoint);
-                const float dist_approx = dist_u * min_scale;
-                // mesh_sdf_contact_passes_inner_cull_consistency
-                bool consistent = true;
-                if (dist_approx < inner) {
-                    const vec3 ic = (v0 + v1) * 0.5f;
-                    const float ir = length(v1 - v0) * 0.5f;
-                    const float cr = ir + inner / min_scale;
-                    const vec3 icl = vmin(vmax(ic, blo), bhi);
-                    if (length_sq(ic - icl) > cr * cr) consistent = false;
-                    else consistent = mid <= cr;
-                }
-                const bool owns = endpoint == 0 || ownership == 0 || (ownership & endpoint) != 0;
-                if (!(dist_approx < contact_threshold && consistent && owns)) continue;
-                vec3 dir_u = sample_grad(s, p_u);
-                // scale_sdf_result_to_world (sdf_contact.py:155-182): gradient back through the anisotropic scale
-                const float dist = dist_u * min_scale;        // conservative distance through the smallest scale
-                const vec3 dir = cw_mul(dir_u, inv_scale);     // normalised after the rigid rotation below
-                const vec3 point = cw_mul(p_u, sdf_scale);
-                const vec3 pw = xform_point(X_sdf, point);
-                vec3 dw = xform_vector(X_sdf, dir);
-                const float dl2 = length_sq(dw);
-                if (dl2 > 0.0f) dw = dw * (1.0f / sqrtf(dl2));
-                else {
-                    vec3 fb = pw - X_sdf.p;
-                    const float fl2 = length_sq(fb);
-                    dw = fl2 > 0.0f ? fb * (1.0f / sqrtf(fl2)) : vec3(0.0f, 1.0f, 0.0f);
-                }
-                const vec3 n = mode == 0 ? -dw : dw;
+            ModeCtx c;
+            if (!mode_setup(a, s0, s1, mode, c)) continue;
+            for (int e = threadIdx.x; e < c.ne; e += blockDim.x) {
+                vec3 pw, n;
+                float dist;
+                if (!edge_contact(a, c, e, mode, pw, n, dist)) continue;
                 const int slot = atomicAdd(a.out_count, 1);
                 if (slot < a.capacity) {
                     a.out_pair[slot] = pair_idx;
@@ -322,6 +350,289 @@ __global__ void __launch_bounds__(256) mesh_sdf_collide_kernel(nt_mesh_sdf_args 
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Global contact reduction (contact_reduction_global.py) in LDS.
+//
+// The reference buffers every mesh-SDF contact in global memory and races packed (rank, fingerprint, contact id) values into a
+// device-wide hashtable with 64-bit atomic maxima: per (shape pair, normal bin) six spatial-extreme slots + one deepest-contact
+// slot, per (shape pair, voxel group) seven deepest-contact slots; contacts inside the inner depth outrank outer ones in the
+// spatial slots (:1519-1752, deterministic packing :447-558).  An export pass walks the active entries, drops roundoff twins
+// within an entry and hands every surviving contact to the writer once (:2098-2290).
+// Here one workgroup owns a shape pair, so the pair's whole table -- (20 + 15) entries x 7 values = 245 x 8 B -- lives in LDS
+// and the maxima are ds_max_u64.  The packed value carries the fingerprint (edge, mode), which is unique inside a pair: no
+// contact buffer and no contact ids are needed, the <= 245 winners are recomputed from their fingerprint after the barrier
+// (same instructions, same bits), compared for roundoff twins, de-duplicated, ranked by fingerprint and written as one
+// contiguous block per pair -- already in the order `deterministic=True` sorts contacts into.  The outcome of the reference
+// does not depend on the arrival order either (every slot ends at the maximum); hashtable overflow and buffer exhaustion, the
+// two ways the reference can lose contacts, do not exist here.
+// ------------------------------------------------------------------------------------------------
+constexpr int RED_BINS = 20, RED_DIRS = 6, RED_VALUES = 7, RED_VOXELS = 100;
+constexpr int RED_ENTRIES = RED_BINS + (RED_VOXELS + RED_VALUES - 1) / RED_VALUES;  // 35
+constexpr int RED_SLOTS = RED_ENTRIES * RED_VALUES;                                 // 245
+constexpr unsigned long long RED_FP_MASK = (1ull << 22) - 1;
+
+__device__ const float RED_FACE[RED_BINS][3] = {  // contact_reduction.py:170-191 (icosahedron)
+    {0.49112338f, 0.79465455f, 0.35682216f},   {-0.18759243f, 0.79465450f, 0.57735026f},  {-0.60706190f, 0.79465450f, 0.0f},
+    {-0.18759237f, 0.79465450f, -0.57735026f}, {0.49112340f, 0.79465455f, -0.35682210f},  {0.98224690f, -0.18759257f, 0.0f},
+    {0.79465440f, 0.18759239f, -0.57735030f},  {0.30353096f, -0.18759252f, 0.93417233f},  {0.79465440f, 0.18759243f, 0.57735030f},
+    {-0.79465450f, -0.18759249f, 0.57735030f}, {-0.30353105f, 0.18759243f, 0.93417240f},  {-0.79465440f, -0.18759240f, -0.57735030f},
+    {-0.98224690f, 0.18759254f, 0.0f},         {0.30353096f, -0.18759250f, -0.93417233f}, {-0.30353084f, 0.18759246f, -0.93417240f},
+    {0.18759249f, -0.79465440f, 0.57735026f},  {-0.49112338f, -0.79465450f, 0.35682213f}, {-0.49112338f, -0.79465455f, -0.35682213f},
+    {0.18759243f, -0.79465440f, -0.57735026f}, {0.60706200f, -0.79465440f, 0.0f}};
+// get_spatial_direction_2d (:402-412): cos / sin of float(i) * (2 pi / 6), the float32 values as literals
+__device__ const float RED_DIR[RED_DIRS][2] = {{0x1p+0f, 0x0p+0f},
+                                               {0x1.fffffep-2f, 0x1.bb67bp-1f},
+                                               {-0x1.000002p-1f, 0x1.bb67aep-1f},
+                                               {-0x1p+0f, -0x1.777a5cp-24f},
+                                               {-0x1.fffffap-2f, -0x1.bb67bp-1f},
+                                               {0x1.fffffap-2f, -0x1.bb67bp-1f}};
+
+NT_DI vec3 red_face(int b) { return vec3(RED_FACE[b][0], RED_FACE[b][1], RED_FACE[b][2]); }
+NT_DI uint32_t red_float_flip(float f) {  // contact_reduction.py:99-107
+    uint32_t i;
+    __builtin_memcpy(&i, &f, 4);
+    return i ^ ((uint32_t)(-(int32_t)(i >> 31)) | 0x80000000u);
+}
+NT_DI unsigned long long red_value_depth(float score, int fp) {  // _make_contact_value_det, fingerprint in the id's place
+    return ((unsigned long long)(red_float_flip(score) >> 10) << 22) | ((unsigned long long)fp & RED_FP_MASK);
+}
+NT_DI unsigned long long red_value_spatial(float score, bool inner, int fp) {  // _make_spatial_contact_value_det
+    return ((unsigned long long)(inner ? 1 : 0) << 43) | ((unsigned long long)(red_float_flip(score) >> 11) << 22) |
+           ((unsigned long long)fp & RED_FP_MASK);
+}
+NT_DI int red_get_slot(vec3 n) {  // get_slot, icosahedron: pruned scan over the top cap / belt / bottom cap
+    int lo, hi;
+    if (n.y > 0.65f) { lo = 0; hi = 5; }
+    else if (n.y < -0.65f) { lo = 15; hi = 20; }
+    else if (n.y >= 0.0f) { lo = 0; hi = 15; }
+    else { lo = 5; hi = 20; }
+    int best = lo;
+    float best_dot = dot(n, red_face(lo));
+    for (int i = lo + 1; i < hi; ++i) {
+        const float d = dot(n, red_face(i));
+        if (d > best_dot) { best_dot = d; best = i; }
+    }
+    return best;
+}
+NT_DI void red_face_frame(int b, vec3& u, vec3& v) {  // project_point_to_plane's basis
+    const vec3 fn = red_face(b);
+    const vec3 ref = fabsf(fn.y) < 0.9f ? vec3(0.0f, 1.0f, 0.0f) : vec3(1.0f, 0.0f, 0.0f);
+    u = normalize(ref - dot(ref, fn) * fn);
+    v = cross(fn, u);
+}
+NT_DI int red_voxel_index(vec3 p, const float* lo, const float* hi, const int* res) {  // compute_voxel_index :432-466
+    int vi[3];
+    for (int k = 0; k < 3; ++k) {
+        const float size = hi[k] - lo[k];
+        float rel = 0.0f;
+        if (size > 1e-6f) rel = (vget(p, k) - lo[k]) / size;
+        int q = (int)(rel * (float)res[k]);
+        vi[k] = q < 0 ? 0 : (q > res[k] - 1 ? res[k] - 1 : q);
+    }
+    return vi[0] + vi[1] * res[0] + vi[2] * res[0] * res[1];
+}
+NT_DI void red_encode_oct(vec3 n, float& ex, float& ey) {  // :631-658
+    const float l1 = fabsf(n.x) + fabsf(n.y) + fabsf(n.z);
+    if (l1 < 1.0e-20f) { ex = 0.0f; ey = 0.0f; return; }
+    const float inv = 1.0f / l1;
+    float ox = n.x * inv, oy = n.y * inv;
+    const float oz = n.z * inv;
+    if (oz < 0.0f) {
+        const float sx = ox < 0.0f ? -1.0f : 1.0f, sy = oy < 0.0f ? -1.0f : 1.0f;
+        const float nx = (1.0f - fabsf(oy)) * sx, ny = (1.0f - fabsf(ox)) * sy;
+        ox = nx; oy = ny;
+    }
+    ex = ox; ey = oy;
+}
+NT_DI vec3 red_decode_oct(float ex, float ey) {  // :661-683
+    const float nz = 1.0f - fabsf(ex) - fabsf(ey);
+    float nx = ex, ny = ey;
+    if (nz < 0.0f) {
+        const float sx = nx < 0.0f ? -1.0f : 1.0f, sy = ny < 0.0f ? -1.0f : 1.0f;
+        const float tx = (1.0f - fabsf(ny)) * sx, ty = (1.0f - fabsf(nx)) * sy;
+        nx = tx; ny = ty;
+    }
+    return normalize(vec3(nx, ny, nz));
+}
+NT_DI bool red_near_ulps(float a, float b) {  // _floats_are_near_ulps :141-150
+    if (fabsf(a - b) > 1.0e-8f) return false;
+    const uint32_t x = red_float_flip(a), y = red_float_flip(b);
+    return (x > y ? x - y : y - x) <= 16u;
+}
+// One contact offered to the pair's table (export_and_reduce_contact_centered_two_spatial_depths without the races).
+NT_DI void red_offer(unsigned long long* tbl, vec3 normal, vec3 centered, float depth, float inner_depth, float outer_depth,
+                     vec3 local, const float* lo, const float* hi, const int* res, int fp) {
+    if (!(depth < outer_depth)) return;
+    const bool use_inner = depth < inner_depth;
+    const int b = red_get_slot(normal);
+    vec3 u, v;
+    red_face_frame(b, u, v);
+    const float px = dot(centered, u), py = dot(centered, v);
+    for (int d = 0; d < RED_DIRS; ++d) {
+        const float score = px * RED_DIR[d][0] + py * RED_DIR[d][1];
+        atomicMax(&tbl[b * RED_VALUES + d], red_value_spatial(score, use_inner, fp));
+    }
+    if (use_inner) {
+        const unsigned long long dv = red_value_depth(-depth, fp);
+        atomicMax(&tbl[b * RED_VALUES + RED_DIRS], dv);
+        int vox = red_voxel_index(local, lo, hi, res);
+        vox = vox < 0 ? 0 : (vox > RED_VOXELS - 1 ? RED_VOXELS - 1 : vox);
+        atomicMax(&tbl[(RED_BINS + vox / RED_VALUES) * RED_VALUES + vox % RED_VALUES], dv);
+    }
+}
+struct RedLds {
+    unsigned long long tbl[RED_SLOTS];
+    float pos[RED_SLOTS][4];  // what the reference's buffer holds of a winner: position, depth ...
+    float oct[RED_SLOTS][2];  // ... and the octahedral code of its normal
+    int fp[RED_SLOTS];        // fingerprint of the slot's winner, -1 = empty
+    int src[RED_SLOTS];       // list variant: index of the winner in the caller's list
+    int keep[RED_SLOTS];      // survives the roundoff-twin pass of its entry
+    int first[RED_SLOTS];     // first kept slot holding this fingerprint (exported_flags: a contact leaves once)
+    int base, total;
+};
+// After the winners' records are in LDS: twins, de-duplication, rank by fingerprint.  -> rank of this lane's slot or -1, and
+// L.total survivors; every lane of the workgroup must call it.
+NT_DI int red_finish(RedLds& L) {
+    const int t = threadIdx.x;
+    if (t < RED_ENTRIES) {  // _roundoff_duplicate_bit_for_slot_pair over the 21 slot pairs of the entry
+        int suppressed = 0;
+        const int e0 = t * RED_VALUES;
+        for (int sb = 1; sb < RED_VALUES; ++sb)
+            for (int sa = 0; sa < sb; ++sa) {
+                const int fa = L.fp[e0 + sa], fb = L.fp[e0 + sb];
+                if (fa < 0 || fb < 0 || fa == fb) continue;
+                const float* pa = L.pos[e0 + sa];
+                const float* pb = L.pos[e0 + sb];
+                const bool same = red_near_ulps(pa[0], pb[0]) && red_near_ulps(pa[1], pb[1]) && red_near_ulps(pa[2], pb[2]) &&
+                                  red_near_ulps(pa[3], pb[3]) && red_near_ulps(L.oct[e0 + sa][0], L.oct[e0 + sb][0]) &&
+                                  red_near_ulps(L.oct[e0 + sa][1], L.oct[e0 + sb][1]);
+                if (same) suppressed |= fb < fa ? (1 << sa) : (1 << sb);
+            }
+        for (int sl = 0; sl < RED_VALUES; ++sl) L.keep[e0 + sl] = L.fp[e0 + sl] >= 0 && !((suppressed >> sl) & 1);
+    }
+    __syncthreads();
+    if (t < RED_SLOTS) {
+        int first = L.keep[t];
+        for (int k = 0; k < t && first; ++k)
+            if (L.keep[k] && L.fp[k] == L.fp[t]) first = 0;
+        L.first[t] = first;
+    }
+    __syncthreads();
+    int rank = -1;
+    if (t < RED_SLOTS && L.first[t]) {
+        rank = 0;
+        for (int k = 0; k < RED_SLOTS; ++k) rank += (L.first[k] && L.fp[k] < L.fp[t]) ? 1 : 0;
+    }
+    if (t == 0) {
+        int total = 0;
+        for (int k = 0; k < RED_SLOTS; ++k) total += L.first[k];
+        L.total = total;
+    }
+    __syncthreads();
+    return rank;
+}
+
+// mesh_sdf_collision_global_reduce_kernel (sdf_contact.py:1534-1990) + export_reduced_contacts_kernel, one workgroup per pair.
+__global__ void __launch_bounds__(256) mesh_sdf_collide_reduced_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
+    __shared__ RedLds L;
+    const int t = threadIdx.x;
+    for (int pair_idx = blockIdx.x; pair_idx < a.pair_count; pair_idx += gridDim.x) {
+        const int s0 = a.pairs[2 * pair_idx], s1 = a.pairs[2 * pair_idx + 1];
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
+        __syncthreads();
+        for (int mode = 0; mode < 2; ++mode) {
+            ModeCtx c;
+            if (!mode_setup(a, s0, s1, mode, c)) continue;
+            const int tri_shape = mode == 0 ? s0 : s1;
+            const vec3 midpoint = (c.X_tri.p + c.X_sdf.p) * 0.5f;
+            const float margin_sum = c.tri_margin + c.sdf_margin;
+            const float inner_depth = margin_sum + fminw(c.s.voxel_radius * c.min_scale, c.gap_sum);  // base gap == gap
+            const float outer_depth = margin_sum + c.gap_sum;
+            for (int e = t; e < c.ne; e += blockDim.x) {
+                vec3 pw, n;
+                float dist;
+                if (!edge_contact(a, c, e, mode, pw, n, dist)) continue;
+                const vec3 local = quat_rotate_inv(c.X_tri.q, pw - c.X_tri.p);
+                red_offer(L.tbl, n, pw - midpoint, dist, inner_depth, outer_depth, local, r.shape_aabb_lower + 3 * tri_shape,
+                          r.shape_aabb_upper + 3 * tri_shape, r.shape_voxel_res + 3 * tri_shape, (e << 2) | (mode << 1));
+            }
+        }
+        __syncthreads();
+        vec3 my_n;
+        if (t < RED_SLOTS && L.tbl[t] != 0ull) {  // the winner of slot t, recomputed from its fingerprint
+            const int fp = (int)(L.tbl[t] & RED_FP_MASK);
+            const int mode = (fp >> 1) & 1;
+            ModeCtx c;
+            mode_setup(a, s0, s1, mode, c);
+            vec3 pw;
+            float dist;
+            edge_contact(a, c, fp >> 2, mode, pw, my_n, dist);
+            L.pos[t][0] = pw.x; L.pos[t][1] = pw.y; L.pos[t][2] = pw.z; L.pos[t][3] = dist;
+            red_encode_oct(my_n, L.oct[t][0], L.oct[t][1]);
+            L.fp[t] = fp;
+        }
+        __syncthreads();
+        const int rank = red_finish(L);
+        if (t == 0) L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
+        __syncthreads();
+        if (rank >= 0 && L.base + rank < a.capacity) {
+            const int slot = L.base + rank;
+            const vec3 n = red_decode_oct(L.oct[t][0], L.oct[t][1]);
+            a.out_pair[slot] = pair_idx;
+            a.out_key[slot] = L.fp[t];
+            float* o = a.out_data + 9 * (size_t)slot;
+            o[0] = L.pos[t][0]; o[1] = L.pos[t][1]; o[2] = L.pos[t][2];
+            o[3] = n.x; o[4] = n.y; o[5] = n.z;
+            o[6] = L.pos[t][3];
+            o[7] = a.shape_data[4 * s0 + 3];
+            o[8] = a.shape_data[4 * s1 + 3];
+        }
+        __syncthreads();
+    }
+}
+
+// The same reduction over a caller-supplied unreduced list grouped by shape pair (segment_start): the stage on its own, so that
+// it can be held against the record of the reference's reducer on arbitrary contact sets.
+__global__ void __launch_bounds__(256) contacts_reduce_list_kernel(nt_contact_reduce_list a) {
+    __shared__ RedLds L;
+    const int t = threadIdx.x;
+    for (int seg = blockIdx.x; seg < a.segments; seg += gridDim.x) {
+        const int i0 = a.segment_start[seg], i1 = a.segment_start[seg + 1];
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; L.src[k] = -1; }
+        __syncthreads();
+        for (int i = i0 + t; i < i1; i += blockDim.x)
+            red_offer(L.tbl, vec3(a.normal[3 * i], a.normal[3 * i + 1], a.normal[3 * i + 2]),
+                      vec3(a.centered[3 * i], a.centered[3 * i + 1], a.centered[3 * i + 2]), a.depth[i], a.inner[i], a.outer[i],
+                      vec3(a.local[3 * i], a.local[3 * i + 1], a.local[3 * i + 2]), a.aabb_lo + 3 * i, a.aabb_hi + 3 * i,
+                      a.res + 3 * i, a.fp[i]);
+        __syncthreads();
+        for (int i = i0 + t; i < i1; i += blockDim.x) {  // the winners find their slots through the fingerprint
+            if (!(a.depth[i] < a.outer[i])) continue;
+            const unsigned long long fp = (unsigned long long)a.fp[i] & RED_FP_MASK;
+            for (int k = 0; k < RED_SLOTS; ++k)
+                if (L.tbl[k] != 0ull && (L.tbl[k] & RED_FP_MASK) == fp) L.src[k] = i;
+        }
+        __syncthreads();
+        if (t < RED_SLOTS && L.src[t] >= 0) {
+            const int i = L.src[t];
+            L.pos[t][0] = a.pos[3 * i]; L.pos[t][1] = a.pos[3 * i + 1]; L.pos[t][2] = a.pos[3 * i + 2]; L.pos[t][3] = a.depth[i];
+            red_encode_oct(vec3(a.normal[3 * i], a.normal[3 * i + 1], a.normal[3 * i + 2]), L.oct[t][0], L.oct[t][1]);
+            L.fp[t] = a.fp[i];
+        }
+        __syncthreads();
+        const int rank = red_finish(L);
+        if (t == 0) L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
+        __syncthreads();
+        if (rank >= 0 && L.base + rank < a.capacity) {
+            const int slot = L.base + rank;
+            const vec3 n = red_decode_oct(L.oct[t][0], L.oct[t][1]);
+            a.out_index[slot] = L.src[t];
+            a.out_normal[3 * slot] = n.x; a.out_normal[3 * slot + 1] = n.y; a.out_normal[3 * slot + 2] = n.z;
+        }
+        __syncthreads();
     }
 }
 
@@ -520,6 +831,25 @@ nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* a, void* stream) {
     if (a->pair_count == 0) return NT_OK;
     int blocks = a->pair_count < 2048 ? a->pair_count : 2048;
     hipLaunchKernelGGL(mesh_sdf_collide_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* a, const nt_contact_reduce_shapes* r, void* stream) {
+    if (!a || !r || a->pair_count < 0 || !a->out_count || !a->out_pair || !a->out_key || !a->out_data || a->capacity <= 0)
+        return NT_ERR_INVALID_ARG;
+    if (!r->shape_aabb_lower || !r->shape_aabb_upper || !r->shape_voxel_res) return NT_ERR_INVALID_ARG;
+    if (a->pair_count == 0) return NT_OK;
+    int blocks = a->pair_count < 4096 ? a->pair_count : 4096;
+    hipLaunchKernelGGL(mesh_sdf_collide_reduced_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, *r);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_contacts_reduce_list(const nt_contact_reduce_list* a, void* stream) {
+    if (!a || a->segments < 0 || !a->segment_start || !a->out_count || !a->out_index || !a->out_normal || a->capacity <= 0)
+        return NT_ERR_INVALID_ARG;
+    if (a->segments == 0) return NT_OK;
+    int blocks = a->segments < 4096 ? a->segments : 4096;
+    hipLaunchKernelGGL(contacts_reduce_list_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

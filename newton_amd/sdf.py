@@ -512,3 +512,35 @@ def create_texture_sdf_from_mesh(vertices, indices, *, margin: float = 0.05, nar
                                narrow_band_range=narrow_band_range, max_resolution=max_resolution,
                                target_voxel_size=target_voxel_size, subgrid_size=subgrid_size,
                                quantization_mode=quantization_mode, scale_baked=scale_baked, return_sparse_data=return_sparse_data)
+
+
+def voxel_resolution_from_aabb(aabb_lower, aabb_upper, voxel_budget: int = 100):
+    """Model._shape_voxel_resolution of one shape (builder.py:11544-11570): a near-cubic voxel grid over the shape-local AABB
+    with at most `voxel_budget` cells (NUM_VOXEL_DEPTH_SLOTS of the contact reduction)."""
+    size = np.maximum(np.asarray(aabb_upper, np.float64) - np.asarray(aabb_lower, np.float64), 1e-6)
+    v = max((size[0] * size[1] * size[2] / voxel_budget) ** (1.0 / 3.0), 1e-6)
+    nx, ny, nz = (max(1, round(size[k] / v)) for k in range(3))
+    while nx * ny * nz > voxel_budget:
+        if nx >= ny and nx >= nz and nx > 1:
+            nx -= 1
+        elif ny >= nz and ny > 1:
+            ny -= 1
+        elif nz > 1:
+            nz -= 1
+        else:
+            break
+    return int(nx), int(ny), int(nz)
+
+
+def mesh_reduction_tables(meshes, scales):
+    """Per-shape tables the contact reduction's voxel slots read (builder.py:11600-11611 for GeoType.MESH):
+    shape_collision_aabb_lower / _upper (vertices * scale) and _shape_voxel_resolution.  `meshes`: one vertex array per shape."""
+    lo, hi, res = [], [], []
+    for verts, scale in zip(meshes, scales):
+        verts, scale = np.asarray(verts, np.float64), np.asarray(scale, np.float64)[:3]
+        a, b = verts.min(axis=0) * scale, verts.max(axis=0) * scale
+        a, b = np.minimum(a, b), np.maximum(a, b)
+        lo.append(a)
+        hi.append(b)
+        res.append(voxel_resolution_from_aabb(a, b))
+    return np.asarray(lo, np.float32), np.asarray(hi, np.float32), np.asarray(res, np.int32)

@@ -61,10 +61,13 @@ class DeviceSDF:
 
 
 def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_index, sdfs, shape_edge_range, edge_centers,
-                     edge_halves, capacity: int | None = None, device="cuda:0"):
+                     edge_halves, capacity: int | None = None, device="cuda:0", reduce=None):
     """Run nt_mesh_sdf_collide; returns a dict of numpy arrays sorted by (pair, key): pair, key, center [n,3], normal [n,3],
     distance, margin0, margin1, plus `count` (the atomic counter, which keeps counting past the capacity).
-    `sdfs`: list of DeviceSDF (or None) indexed by shape_sdf_index."""
+    `sdfs`: list of DeviceSDF (or None) indexed by shape_sdf_index.
+    `reduce`: (shape_collision_aabb_lower, shape_collision_aabb_upper, shape_voxel_resolution) -- see
+    newton_amd.sdf.mesh_reduction_tables -- runs nt_mesh_sdf_collide_reduced instead: the reference's global contact reduction
+    (GlobalContactReducer, deterministic packing) fused into the pair's workgroup."""
     torch = _torch()
     lib = _lib.load()
     dev = torch.device(device)
@@ -97,7 +100,13 @@ def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_in
     a.out_count, a.out_pair, a.out_key, a.out_data, a.capacity = (count.data_ptr(), o_pair.data_ptr(), o_key.data_ptr(),
                                                                    o_data.data_ptr(), capacity)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(lib.nt_mesh_sdf_collide(C.byref(a), stream), "nt_mesh_sdf_collide")
+    if reduce is not None:
+        r = _lib.nt_contact_reduce_shapes()
+        t_lo, t_hi, t_res = up(reduce[0], np.float32), up(reduce[1], np.float32), up(reduce[2], np.int32)
+        r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = t_lo.data_ptr(), t_hi.data_ptr(), t_res.data_ptr()
+        _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
+    else:
+        _lib.check(lib.nt_mesh_sdf_collide(C.byref(a), stream), "nt_mesh_sdf_collide")
     torch.cuda.current_stream(dev).synchronize()
     n_total = int(count.item())
     n = min(n_total, capacity)

@@ -184,3 +184,53 @@ def reduce_contacts(c):
     return dict(pair=np.array([k[0] for k in keys], np.int32).reshape(-1, 2), fp=np.array([k[1] for k in keys], np.int32),
                 pos=c["pos"][idx].reshape(-1, 3), depth=c["depth"][idx],
                 normal=np.array([decode_oct(oct_code[k]) for k in keys], np.float32).reshape(-1, 3), index=idx)
+
+
+def _q_rot_inv(q, v):
+    """wp.quat_rotate_inv in float32 (oracle/wp_builtins.h order: v*(2w^2-1) - cross(qv, v)*w*2 + qv*dot(qv, v)*2)."""
+    q, v = np.asarray(q, np.float32), np.asarray(v, np.float32)
+    qv, w = q[:3], q[3]
+    c = np.array([f32(f32(qv[1] * v[2]) - f32(qv[2] * v[1])), f32(f32(qv[2] * v[0]) - f32(qv[0] * v[2])),
+                  f32(f32(qv[0] * v[1]) - f32(qv[1] * v[0]))], np.float32)
+    k = f32(f32(f32(f32(2.0) * w) * w) - f32(1.0))
+    d = _dot3(qv, v)
+    return np.array([f32(f32(f32(v[i] * k) - f32(f32(c[i] * w) * f32(2.0))) + f32(f32(qv[i] * d) * f32(2.0))) for i in range(3)],
+                    np.float32)
+
+
+def reduce_inputs_from_mesh_sdf_contacts(rows, pairs, shape_transform, shape_data, shape_gap, shape_sdf_index, sdfs, aabb_lo,
+                                         aabb_hi, voxel_res):
+    """What mesh_sdf_collision_global_reduce_kernel passes to the reducer for every unreduced contact (sdf_contact.py:1889-1947,
+    non-speculative: base gap == gap).  `rows`: (pair index, key, point, normal, distance, ...) as oracle_sdf.mesh_sdf_collide or
+    the unreduced device kernel return them."""
+    X, D = np.asarray(shape_transform, np.float32), np.asarray(shape_data, np.float32)
+    out = {k: [] for k in ("pair", "pos", "normal", "depth", "fp", "centered", "inner", "outer", "local", "aabb_lo", "aabb_hi", "res")}
+    for row in rows:
+        pair_idx, key, pw, nrm, dist = int(row[0]), int(row[1]), np.asarray(row[2], np.float32), np.asarray(row[3], np.float32), f32(row[4])
+        s0, s1 = (int(x) for x in np.asarray(pairs).reshape(-1, 2)[pair_idx])
+        mode = (key >> 1) & 1
+        tri, sd = (s0, s1) if mode == 0 else (s1, s0)
+        t = sdfs[int(shape_sdf_index[sd])]
+        sdf_scale = np.ones(3, np.float32) if t.scale_baked else D[sd, :3]
+        eps = f32(1.0e-10)
+        g = np.array([s if abs(s) > eps else (eps if s >= 0.0 else -eps) for s in sdf_scale], np.float32)
+        min_scale = f32(np.min(np.abs(g)))
+        gap_sum = f32(f32(shape_gap[s0]) + f32(shape_gap[s1]))
+        margin_sum = f32(D[tri, 3] + D[sd, 3])
+        mid = ((X[tri, :3] + X[sd, :3]) * f32(0.5)).astype(np.float32)
+        out["pair"].append((s0, s1))
+        out["pos"].append(pw)
+        out["normal"].append(nrm)
+        out["depth"].append(dist)
+        out["fp"].append(key)
+        out["centered"].append((pw - mid).astype(np.float32))
+        out["inner"].append(f32(margin_sum + min(f32(f32(t.voxel_radius) * min_scale), gap_sum)))
+        out["outer"].append(f32(margin_sum + gap_sum))
+        out["local"].append(_q_rot_inv(X[tri, 3:], (pw - X[tri, :3]).astype(np.float32)))
+        out["aabb_lo"].append(aabb_lo[tri])
+        out["aabb_hi"].append(aabb_hi[tri])
+        out["res"].append(voxel_res[tri])
+    dt = dict(pair=np.int32, fp=np.int32, res=np.int32)
+    return {k: np.asarray(v, dt.get(k, np.float32)).reshape(len(rows), -1 if k not in ("depth", "fp", "inner", "outer") else 1)
+            .squeeze(-1) if k in ("depth", "fp", "inner", "outer") else np.asarray(v, dt.get(k, np.float32)).reshape(len(rows), -1)
+            for k, v in out.items()}

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(ROOT, "tests")
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 from test_sdf_contact import box_sdf, oracle_contacts, two_box_scene  # noqa: E402
@@ -169,3 +170,92 @@ def test_device_eval_body_contact_consumes_per_contact_stiffness():
     oc.set_properties([ke[s, env] for env, s in live], [kd[s, env] for env, s in live], [mu[s, env] for env, s in live])
     o.semi_implicit_step(os0, os1, o.control(), oc, 1e-3)
     assert np.max(np.abs(s1.body_qd.cpu().numpy() - os1.body_qd)) <= 2e-4 * max(1.0, np.abs(os1.body_qd).max())
+
+
+# ------------------------------------------------------------------------------------------------ global contact reduction
+@pytest.mark.parametrize("name", ["patch", "two_pairs_many_normals", "duplicates_and_ties", "outer_only", "single"])
+def test_device_reduction_kernel_keeps_what_the_reference_reducer_keeps(name):
+    """contacts_reduce_list_kernel on the MI355X against the record of the reference's own reducer
+    (tests/golden/reduce_reference_vectors.npz): survivors, points, distances and exported normals bit for bit."""
+    import ctypes as C
+
+    import torch
+
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import reduce_cases as rc
+    from test_contact_reduction import run_reduce_list
+
+    from newton_amd import _lib as L
+
+    ref = np.load(os.path.join(HERE, "golden", "reduce_reference_vectors.npz"))
+    c = rc.pack(rc.contacts(name))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def to_host(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+    idx, nrm, pair, fp = run_reduce_list(L.load(), c, stream=stream, to_dev=lambda a: torch.from_numpy(a).cuda(), to_host=to_host)
+    o = np.lexsort((fp, pair[:, 1], pair[:, 0]))
+    assert np.array_equal(pair[o], ref[f"{name}/pair"]) and np.array_equal(fp[o], ref[f"{name}/fp"])
+    assert np.array_equal(c["pos"][idx[o]], ref[f"{name}/pos"]) and np.array_equal(c["depth"][idx[o]], ref[f"{name}/depth"])
+    assert np.array_equal(nrm[o], ref[f"{name}/normal"])
+
+
+def test_device_reduced_mesh_sdf_kernel_is_the_reduction_of_the_unreduced_one():
+    """nt_mesh_sdf_collide_reduced against the checker's reduction (oracle_reduce, pinned by the executed reference reducer) of
+    nt_mesh_sdf_collide's own rows on the sphere-on-box scene: bit for bit; and against the float32 checker end to end."""
+    import oracle_reduce as R
+    from test_sdf_contact import check_reduced_against_unreduced, sphere_on_box_scene
+
+    from newton_amd.sdf_device import DeviceSDF, mesh_sdf_collide
+
+    sc = sphere_on_box_scene()
+    dev = [DeviceSDF(t) for t in sc["sdfs"]]
+    args = (sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["sdf_index"], dev, sc["er"], sc["ec"], sc["eh"])
+    u = mesh_sdf_collide(*args)
+    r = mesh_sdf_collide(*args, reduce=(sc["aabb_lo"], sc["aabb_hi"], sc["res"]))
+    pack = lambda d: (d["pair"], d["key"], np.concatenate([d["center"], d["normal"], d["distance"][:, None],  # noqa: E731
+                                                           d["margin0"][:, None], d["margin1"][:, None]], axis=1))
+    n_in, n_out = check_reduced_against_unreduced(sc, pack(u), pack(r))
+    assert n_in > n_out + 50 and r["count"] == n_out
+    rows = oracle_contacts(sc)
+    c = R.reduce_inputs_from_mesh_sdf_contacts(rows, sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["sdf_index"], sc["sdfs"],
+                                               sc["aabb_lo"], sc["aabb_hi"], sc["res"])
+    want = R.reduce_contacts(c)
+    shape_pair = sc["pairs"][r["pair"]]
+    assert np.array_equal(shape_pair, want["pair"]) and np.array_equal(r["key"], want["fp"])
+    assert np.abs(r["center"] - want["pos"]).max() <= 1e-6 and np.abs(r["normal"] - want["normal"]).max() <= 1e-6
+
+
+def test_device_reduced_mesh_sdf_bin_scale():
+    """C5's geometry class: 64 small boxes scattered in a bin, 2 016 pairs in one launch, reduced: twice the same rows; every
+    pair's block is a subset of its unreduced rows, never more than 245, blocks ordered by fingerprint."""
+    from newton_amd.mesh import Mesh, mesh_edge_tables
+    from newton_amd.sdf_device import DeviceSDF, mesh_sdf_collide
+
+    rng = np.random.default_rng(4)
+    n = 64
+    m = Mesh.create_sphere(0.05, 10, 12)
+    ec, eh = mesh_edge_tables(m.vertices, m.indices.reshape(-1, 3))
+    t = S.create_texture_sdf_from_primitive(GeoType.SPHERE, (0.05, 0.05, 0.05), max_resolution=32, margin=0.02,
+                                            narrow_band_range=(-0.03, 0.03))
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    X = np.concatenate([rng.uniform(-0.12, 0.12, size=(n, 3)), q], axis=1).astype(np.float32)
+    pairs = np.array([(a, b) for a in range(n) for b in range(a + 1, n)], dtype=np.int32)
+    data = np.tile(np.array([1, 1, 1, 0.001], dtype=np.float32), (n, 1))
+    gap = np.full(n, 0.01, dtype=np.float32)
+    idx, er = np.zeros(n, dtype=np.int32), np.tile(np.array([0, len(ec)], dtype=np.int32), (n, 1))
+    tables = S.mesh_reduction_tables([m.vertices] * n, [(1, 1, 1)] * n)
+    dev = [DeviceSDF(t)]
+    u = mesh_sdf_collide(pairs, X, data, gap, idx, dev, er, ec, eh)
+    a = mesh_sdf_collide(pairs, X, data, gap, idx, dev, er, ec, eh, reduce=tables)
+    b = mesh_sdf_collide(pairs, X, data, gap, idx, dev, er, ec, eh, reduce=tables)
+    assert 0 < a["count"] == b["count"] < u["count"]
+    for k in ("pair", "key", "center", "normal", "distance"):
+        assert np.array_equal(a[k], b[k])
+    unreduced = set(zip(u["pair"].tolist(), u["key"].tolist()))
+    assert set(zip(a["pair"].tolist(), a["key"].tolist())) <= unreduced
+    assert np.bincount(a["pair"]).max() <= 245
+    assert set(np.unique(a["pair"]).tolist()) == set(np.unique(u["pair"]).tolist())  # no touching pair loses all its contacts

@@ -151,3 +151,96 @@ def test_emulated_mesh_sdf_kernel_matches_the_oracle(emu, dz, mode):
         c, nn, dd = by_key[(int(o_pair[i]), int(o_key[i]))]
         assert np.array_equal(o_data[i, 0:3], c) and o_data[i, 6] == dd  # points and distances bit for bit
         assert np.max(np.abs(o_data[i, 3:6] - nn)) <= 2e-7             # normals: numpy's dot / cross sum in another order
+
+
+# ------------------------------------------------------------------------------------------------ reduced contacts (a24)
+def sphere_on_box_scene(dz=0.985, gap=0.03, margin=0.002, lat=14, lon=18):
+    """A UV-sphere mesh (radius 0.5, ~700 edges, SDF of the sphere primitive) resting in a unit cube's top face (SDF of the box
+    primitive), plus a second, tilted sphere beside it: two shape pairs, hundreds of unreduced contacts in the gap band."""
+    sph, box = Mesh.create_sphere(0.5, lat, lon), Mesh.create_box(0.5, 0.5, 0.5)
+    ec_s, eh_s = mesh_edge_tables(sph.vertices, sph.indices.reshape(-1, 3))
+    ec_b, eh_b = mesh_edge_tables(box.vertices, box.indices.reshape(-1, 3))
+    sdf_s = S.create_texture_sdf_from_primitive(GeoType.SPHERE, (0.5, 0.5, 0.5), max_resolution=32)
+    sdf_b = box_sdf()
+    q = [0.0, np.sin(0.2), 0.0, np.cos(0.2)]
+    X = np.array([[0, 0, 0, 0, 0, 0, 1], [0.03, -0.02, dz, 0, 0, 0, 1], [0.6, 0.1, 0.93, *q]], dtype=np.float32)
+    data = np.array([[1, 1, 1, margin]] * 3, dtype=np.float32)
+    gaps = np.full(3, gap, dtype=np.float32)
+    er = np.array([[0, len(ec_b)], [len(ec_b), len(ec_s)], [len(ec_b), len(ec_s)]], dtype=np.int32)
+    lo, hi, res = S.mesh_reduction_tables([box.vertices, sph.vertices, sph.vertices], [(1, 1, 1)] * 3)
+    return dict(pairs=np.array([[0, 1], [0, 2], [1, 2]], dtype=np.int32), X=X, data=data, gap=gaps,
+                sdf_index=np.array([0, 1, 1], dtype=np.int32), sdfs=[sdf_b, sdf_s], er=er, ec=np.concatenate([ec_b, ec_s]),
+                eh=np.concatenate([eh_b, eh_s]), aabb_lo=lo, aabb_hi=hi, res=res)
+
+
+def _emu_mesh_sdf(emu, sc, reduced, cap=8192):
+    import ctypes as C
+
+    from newton_amd import _lib as L
+
+    descs = [_emu_sdf(emu, t) for t in sc["sdfs"]]
+    table = (L.nt_sdf * len(descs))(*[d for d, _ in descs])
+    count, o_pair, o_key, o_data = np.zeros(1, np.int32), np.full(cap, -1, np.int32), np.zeros(cap, np.int32), np.zeros((cap, 9), np.float32)
+    a = L.nt_mesh_sdf_args()
+    a.pairs, a.pair_count = sc["pairs"].ctypes.data, len(sc["pairs"])
+    a.shape_transform, a.shape_data, a.shape_gap = sc["X"].ctypes.data, sc["data"].ctypes.data, sc["gap"].ctypes.data
+    a.shape_sdf_index, a.sdf_table, a.sdf_count = sc["sdf_index"].ctypes.data, C.addressof(table), len(descs)
+    a.shape_edge_range, a.edge_centers, a.edge_halves = sc["er"].ctypes.data, sc["ec"].ctypes.data, sc["eh"].ctypes.data
+    a.out_count, a.out_pair, a.out_key, a.out_data, a.capacity = count.ctypes.data, o_pair.ctypes.data, o_key.ctypes.data, o_data.ctypes.data, cap
+    if reduced:
+        r = L.nt_contact_reduce_shapes()
+        r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = sc["aabb_lo"].ctypes.data, sc["aabb_hi"].ctypes.data, sc["res"].ctypes.data
+        assert emu.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), None) == 0
+    else:
+        assert emu.nt_mesh_sdf_collide(C.byref(a), None) == 0
+    n = int(count[0])
+    assert n <= cap
+    return o_pair[:n].copy(), o_key[:n].copy(), o_data[:n].copy()
+
+
+def check_reduced_against_unreduced(sc, unreduced, reduced):
+    """The fused reduced kernel against the checker's reduction of the unreduced kernel's own rows: same survivors, points,
+    distances and exported normals bit for bit; blocks contiguous per pair with ascending fingerprints."""
+    import oracle_reduce as R
+
+    u_pair, u_key, u_data = unreduced
+    r_pair, r_key, r_data = reduced
+    rows = [(int(u_pair[i]), int(u_key[i]), u_data[i, 0:3], u_data[i, 3:6], u_data[i, 6]) for i in range(len(u_key))]
+    c = R.reduce_inputs_from_mesh_sdf_contacts(rows, sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["sdf_index"], sc["sdfs"],
+                                               sc["aabb_lo"], sc["aabb_hi"], sc["res"])
+    want = R.reduce_contacts(c)
+    assert 0 < len(want["fp"]) < len(u_key)  # something was reduced away
+    shape_pair = sc["pairs"][r_pair]
+    o = np.lexsort((r_key, shape_pair[:, 1], shape_pair[:, 0]))
+    assert np.array_equal(shape_pair[o], want["pair"]) and np.array_equal(r_key[o], want["fp"])
+    assert np.array_equal(r_data[o, 0:3], want["pos"]) and np.array_equal(r_data[o, 6], want["depth"])
+    assert np.array_equal(r_data[o, 3:6], want["normal"])
+    for p in set(r_pair.tolist()):
+        rows_p = np.flatnonzero(r_pair == p)
+        assert np.array_equal(rows_p, np.arange(rows_p[0], rows_p[-1] + 1)) and np.all(np.diff(r_key[rows_p]) > 0)
+    assert np.all(r_data[:, 7] == sc["data"][sc["pairs"][r_pair, 0], 3]) and np.all(r_data[:, 8] == sc["data"][sc["pairs"][r_pair, 1], 3])
+    return len(u_key), len(r_key)
+
+
+def test_emulated_reduced_mesh_sdf_kernel_is_the_reduction_of_the_unreduced_one(emu):
+    sc = sphere_on_box_scene()
+    n_in, n_out = check_reduced_against_unreduced(sc, _emu_mesh_sdf(emu, sc, False), _emu_mesh_sdf(emu, sc, True))
+    assert n_in > n_out + 50  # 167 unreduced contacts -> 87
+
+
+def test_checker_chain_agrees_with_the_emulated_reduced_kernel(emu):
+    """oracle_sdf.mesh_sdf_collide -> oracle_reduce: the float32 checker end to end (its normals differ from the kernel's in
+    the last bit -- numpy sums dot / cross in another order -- so the survivor set is compared, then the geometry to 2e-7)."""
+    import oracle_reduce as R
+
+    sc = sphere_on_box_scene()
+    rows = oracle_contacts(sc)
+    c = R.reduce_inputs_from_mesh_sdf_contacts(rows, sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["sdf_index"], sc["sdfs"],
+                                               sc["aabb_lo"], sc["aabb_hi"], sc["res"])
+    want = R.reduce_contacts(c)
+    r_pair, r_key, r_data = _emu_mesh_sdf(emu, sc, True)
+    shape_pair = sc["pairs"][r_pair]
+    o = np.lexsort((r_key, shape_pair[:, 1], shape_pair[:, 0]))
+    assert np.array_equal(shape_pair[o], want["pair"]) and np.array_equal(r_key[o], want["fp"])
+    assert np.array_equal(r_data[o, 0:3], want["pos"]) and np.array_equal(r_data[o, 6], want["depth"])
+    assert np.abs(r_data[o, 3:6] - want["normal"]).max() <= 3e-7
