@@ -355,6 +355,9 @@ typedef struct {
     int32_t* out_key;                /* [capacity] */
     float* out_data;                 /* [capacity][9] */
     int32_t capacity;
+    const int32_t* pair_count_device; /* optional: the live pair count in device memory (e.g. a broad phase's candidate
+                                         counter, read by the kernel: no host round trip); pair_count then is the capacity of
+                                         `pairs` and bounds it */
 } nt_mesh_sdf_args;
 nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
 
@@ -369,6 +372,7 @@ typedef struct {
     const float* shape_aabb_lower;   /* [S][3] Model.shape_collision_aabb_lower (shape-local) */
     const float* shape_aabb_upper;   /* [S][3] Model.shape_collision_aabb_upper */
     const int32_t* shape_voxel_res;  /* [S][3] Model._shape_voxel_resolution (builder.py:11544-11570) */
+    int32_t threads;                 /* workgroup size per pair: 64, 128 or 256 (0 = 256); pick ~ the edge count of a mesh */
 } nt_contact_reduce_shapes;
 nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* args, const nt_contact_reduce_shapes* shapes, void* stream);
 

@@ -93,11 +93,12 @@ class nt_mesh_sdf_args(C.Structure):
                 ("shape_gap", C.c_void_p), ("shape_sdf_index", C.c_void_p), ("sdf_table", C.c_void_p), ("sdf_count", C.c_int32),
                 ("shape_edge_range", C.c_void_p), ("edge_centers", C.c_void_p), ("edge_halves", C.c_void_p),
                 ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_data", C.c_void_p),
-                ("capacity", C.c_int32)]
+                ("capacity", C.c_int32), ("pair_count_device", C.c_void_p)]
 
 
 class nt_contact_reduce_shapes(C.Structure):
-    _fields_ = [("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p)]
+    _fields_ = [("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
+                ("threads", C.c_int32)]
 
 
 class nt_contact_reduce_list(C.Structure):

@@ -327,8 +327,15 @@ NT_DI bool edge_contact(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int 
     return true;
 }
 
+NT_DI int live_pair_count(const nt_mesh_sdf_args& a) {
+    if (!a.pair_count_device) return a.pair_count;
+    const int n = *a.pair_count_device;
+    return n < a.pair_count ? n : a.pair_count;
+}
+
 __global__ void __launch_bounds__(256) mesh_sdf_collide_kernel(nt_mesh_sdf_args a) {
-    for (int pair_idx = blockIdx.x; pair_idx < a.pair_count; pair_idx += gridDim.x) {
+    const int pair_count = live_pair_count(a);
+    for (int pair_idx = blockIdx.x; pair_idx < pair_count; pair_idx += gridDim.x) {
         const int s0 = a.pairs[2 * pair_idx], s1 = a.pairs[2 * pair_idx + 1];
         for (int mode = 0; mode < 2; ++mode) {
             ModeCtx c;
@@ -493,13 +500,13 @@ struct RedLds {
     int first[RED_SLOTS];     // first kept slot holding this fingerprint (exported_flags: a contact leaves once)
     int base, total;
 };
-// After the winners' records are in LDS: twins, de-duplication, rank by fingerprint.  -> rank of this lane's slot or -1, and
-// L.total survivors; every lane of the workgroup must call it.
-NT_DI int red_finish(RedLds& L) {
-    const int t = threadIdx.x;
-    if (t < RED_ENTRIES) {  // _roundoff_duplicate_bit_for_slot_pair over the 21 slot pairs of the entry
+// After the winners' records are in LDS: twins, de-duplication, rank by fingerprint.  Leaves L.first[k] (slot k exports a
+// contact), L.keep[k] = its rank among the pair's survivors, L.total; every lane of the workgroup must call it (any size).
+NT_DI void red_finish(RedLds& L) {
+    const int t = threadIdx.x, nt_ = blockDim.x;
+    for (int en = t; en < RED_ENTRIES; en += nt_) {  // _roundoff_duplicate_bit_for_slot_pair over the 21 slot pairs of the entry
         int suppressed = 0;
-        const int e0 = t * RED_VALUES;
+        const int e0 = en * RED_VALUES;
         for (int sb = 1; sb < RED_VALUES; ++sb)
             for (int sa = 0; sa < sb; ++sa) {
                 const int fa = L.fp[e0 + sa], fb = L.fp[e0 + sb];
@@ -514,17 +521,20 @@ NT_DI int red_finish(RedLds& L) {
         for (int sl = 0; sl < RED_VALUES; ++sl) L.keep[e0 + sl] = L.fp[e0 + sl] >= 0 && !((suppressed >> sl) & 1);
     }
     __syncthreads();
-    if (t < RED_SLOTS) {
-        int first = L.keep[t];
-        for (int k = 0; k < t && first; ++k)
-            if (L.keep[k] && L.fp[k] == L.fp[t]) first = 0;
-        L.first[t] = first;
+    for (int k = t; k < RED_SLOTS; k += nt_) {
+        int first = L.keep[k];
+        for (int j = 0; j < k && first; ++j)
+            if (L.keep[j] && L.fp[j] == L.fp[k]) first = 0;
+        L.first[k] = first;
     }
     __syncthreads();
-    int rank = -1;
-    if (t < RED_SLOTS && L.first[t]) {
-        rank = 0;
-        for (int k = 0; k < RED_SLOTS; ++k) rank += (L.first[k] && L.fp[k] < L.fp[t]) ? 1 : 0;
+    for (int k = t; k < RED_SLOTS; k += nt_) {
+        int rank = -1;
+        if (L.first[k]) {
+            rank = 0;
+            for (int j = 0; j < RED_SLOTS; ++j) rank += (L.first[j] && L.fp[j] < L.fp[k]) ? 1 : 0;
+        }
+        L.keep[k] = rank;
     }
     if (t == 0) {
         int total = 0;
@@ -532,14 +542,14 @@ NT_DI int red_finish(RedLds& L) {
         L.total = total;
     }
     __syncthreads();
-    return rank;
 }
 
 // mesh_sdf_collision_global_reduce_kernel (sdf_contact.py:1534-1990) + export_reduced_contacts_kernel, one workgroup per pair.
 __global__ void __launch_bounds__(256) mesh_sdf_collide_reduced_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
     __shared__ RedLds L;
     const int t = threadIdx.x;
-    for (int pair_idx = blockIdx.x; pair_idx < a.pair_count; pair_idx += gridDim.x) {
+    const int pair_count = live_pair_count(a);
+    for (int pair_idx = blockIdx.x; pair_idx < pair_count; pair_idx += gridDim.x) {
         const int s0 = a.pairs[2 * pair_idx], s1 = a.pairs[2 * pair_idx + 1];
         for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
         __syncthreads();
@@ -561,32 +571,33 @@ __global__ void __launch_bounds__(256) mesh_sdf_collide_reduced_kernel(nt_mesh_s
             }
         }
         __syncthreads();
-        vec3 my_n;
-        if (t < RED_SLOTS && L.tbl[t] != 0ull) {  // the winner of slot t, recomputed from its fingerprint
-            const int fp = (int)(L.tbl[t] & RED_FP_MASK);
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k, recomputed from its fingerprint
+            if (L.tbl[k] == 0ull) continue;
+            const int fp = (int)(L.tbl[k] & RED_FP_MASK);
             const int mode = (fp >> 1) & 1;
             ModeCtx c;
             mode_setup(a, s0, s1, mode, c);
-            vec3 pw;
+            vec3 pw, n;
             float dist;
-            edge_contact(a, c, fp >> 2, mode, pw, my_n, dist);
-            L.pos[t][0] = pw.x; L.pos[t][1] = pw.y; L.pos[t][2] = pw.z; L.pos[t][3] = dist;
-            red_encode_oct(my_n, L.oct[t][0], L.oct[t][1]);
-            L.fp[t] = fp;
+            edge_contact(a, c, fp >> 2, mode, pw, n, dist);
+            L.pos[k][0] = pw.x; L.pos[k][1] = pw.y; L.pos[k][2] = pw.z; L.pos[k][3] = dist;
+            red_encode_oct(n, L.oct[k][0], L.oct[k][1]);
+            L.fp[k] = fp;
         }
         __syncthreads();
-        const int rank = red_finish(L);
+        red_finish(L);
         if (t == 0) L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
         __syncthreads();
-        if (rank >= 0 && L.base + rank < a.capacity) {
-            const int slot = L.base + rank;
-            const vec3 n = red_decode_oct(L.oct[t][0], L.oct[t][1]);
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {
+            const int slot = L.base + L.keep[k];
+            if (L.keep[k] < 0 || slot >= a.capacity) continue;
+            const vec3 n = red_decode_oct(L.oct[k][0], L.oct[k][1]);
             a.out_pair[slot] = pair_idx;
-            a.out_key[slot] = L.fp[t];
+            a.out_key[slot] = L.fp[k];
             float* o = a.out_data + 9 * (size_t)slot;
-            o[0] = L.pos[t][0]; o[1] = L.pos[t][1]; o[2] = L.pos[t][2];
+            o[0] = L.pos[k][0]; o[1] = L.pos[k][1]; o[2] = L.pos[k][2];
             o[3] = n.x; o[4] = n.y; o[5] = n.z;
-            o[6] = L.pos[t][3];
+            o[6] = L.pos[k][3];
             o[7] = a.shape_data[4 * s0 + 3];
             o[8] = a.shape_data[4 * s1 + 3];
         }
@@ -616,20 +627,22 @@ __global__ void __launch_bounds__(256) contacts_reduce_list_kernel(nt_contact_re
                 if (L.tbl[k] != 0ull && (L.tbl[k] & RED_FP_MASK) == fp) L.src[k] = i;
         }
         __syncthreads();
-        if (t < RED_SLOTS && L.src[t] >= 0) {
-            const int i = L.src[t];
-            L.pos[t][0] = a.pos[3 * i]; L.pos[t][1] = a.pos[3 * i + 1]; L.pos[t][2] = a.pos[3 * i + 2]; L.pos[t][3] = a.depth[i];
-            red_encode_oct(vec3(a.normal[3 * i], a.normal[3 * i + 1], a.normal[3 * i + 2]), L.oct[t][0], L.oct[t][1]);
-            L.fp[t] = a.fp[i];
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {
+            const int i = L.src[k];
+            if (i < 0) continue;
+            L.pos[k][0] = a.pos[3 * i]; L.pos[k][1] = a.pos[3 * i + 1]; L.pos[k][2] = a.pos[3 * i + 2]; L.pos[k][3] = a.depth[i];
+            red_encode_oct(vec3(a.normal[3 * i], a.normal[3 * i + 1], a.normal[3 * i + 2]), L.oct[k][0], L.oct[k][1]);
+            L.fp[k] = a.fp[i];
         }
         __syncthreads();
-        const int rank = red_finish(L);
+        red_finish(L);
         if (t == 0) L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
         __syncthreads();
-        if (rank >= 0 && L.base + rank < a.capacity) {
-            const int slot = L.base + rank;
-            const vec3 n = red_decode_oct(L.oct[t][0], L.oct[t][1]);
-            a.out_index[slot] = L.src[t];
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {
+            const int slot = L.base + L.keep[k];
+            if (L.keep[k] < 0 || slot >= a.capacity) continue;
+            const vec3 n = red_decode_oct(L.oct[k][0], L.oct[k][1]);
+            a.out_index[slot] = L.src[k];
             a.out_normal[3 * slot] = n.x; a.out_normal[3 * slot + 1] = n.y; a.out_normal[3 * slot + 2] = n.z;
         }
         __syncthreads();
@@ -839,8 +852,11 @@ nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* a, const nt_contac
         return NT_ERR_INVALID_ARG;
     if (!r->shape_aabb_lower || !r->shape_aabb_upper || !r->shape_voxel_res) return NT_ERR_INVALID_ARG;
     if (a->pair_count == 0) return NT_OK;
-    int blocks = a->pair_count < 4096 ? a->pair_count : 4096;
-    hipLaunchKernelGGL(mesh_sdf_collide_reduced_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, *r);
+    // workgroup size: meshes with few edges (C5's hulls have ~40) would leave most of 256 lanes idle in the edge loops; one
+    // wave per pair then, and four times the pairs in flight per CU
+    const int threads = r->threads == 64 || r->threads == 128 || r->threads == 256 ? r->threads : 256;
+    int blocks = a->pair_count < 16384 ? a->pair_count : 16384;  // grid-stride over the pairs
+    hipLaunchKernelGGL(mesh_sdf_collide_reduced_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, *a, *r);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

@@ -166,3 +166,55 @@ def hydro_collide(pairs, shape_transform, shape_data, shape_gap, shape_kh, shape
     pair, key, shapes, data = pair[order], key[order], shapes[order], data[order]
     return {"count": n_total, "pair": pair, "key": key, "shape_a": shapes[:, 0], "shape_b": shapes[:, 1], "center": data[:, 0:3],
             "normal": data[:, 3:6], "distance": data[:, 6], "stiffness": data[:, 7], "area": data[:, 8], "pressure": data[:, 9]}
+
+
+class MeshSdfNarrowPhase:
+    """Device-resident mesh-vs-SDF narrow phase with the global contact reduction: the tables a Model carries for it (per-shape
+    scale / margin, gap, SDF index, edge range, edge tables, local AABB + voxel resolution) are uploaded once; `launch` takes
+    the broad phase's candidate pairs and counter and the shapes' world transforms as device tensors and appends reduced
+    ContactData rows -- no host round trip, everything on the caller's stream.  Mirrors the mesh-mesh leg of
+    NarrowPhase.launch (narrow_phase.py:2588-2760) with reduce_contacts=True, deterministic packing."""
+
+    def __init__(self, shape_data, shape_gap, shape_sdf_index, sdfs, shape_edge_range, edge_centers, edge_halves, reduce_tables,
+                 device="cuda:0"):
+        torch = _torch()
+        self._lib = _lib.load()
+        self.device = torch.device(device)
+
+        def up(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            return torch.from_numpy(a if a.size else np.zeros(1, dtype=dtype)).to(self.device)
+
+        self._sdfs = list(sdfs)
+        table = (_lib.nt_sdf * max(len(sdfs), 1))()
+        for k, s in enumerate(sdfs):
+            if s is not None:
+                table[k] = s.desc
+        self._t = dict(data=up(shape_data, np.float32), gap=up(shape_gap, np.float32), idx=up(shape_sdf_index, np.int32),
+                       er=up(shape_edge_range, np.int32), ec=up(edge_centers, np.float32), eh=up(edge_halves, np.float32),
+                       table=torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(self.device),
+                       lo=up(reduce_tables[0], np.float32), hi=up(reduce_tables[1], np.float32), res=up(reduce_tables[2], np.int32))
+        self.shape_count = int(np.asarray(shape_gap).shape[0])
+
+    def launch(self, shape_transform, pairs, pair_count, out_count, out_pair, out_key, out_data, reduce: bool = True,
+               threads: int = 0):
+        """shape_transform [S,7] float32, pairs [P,2] int32, pair_count [1] int32 (device), outputs as nt_mesh_sdf_args; the
+        caller zeroes out_count."""
+        torch = _torch()
+        t = self._t
+        a = _lib.nt_mesh_sdf_args()
+        a.pairs, a.pair_count, a.pair_count_device = pairs.data_ptr(), int(pairs.shape[0]), pair_count.data_ptr()
+        a.shape_transform, a.shape_data, a.shape_gap = shape_transform.data_ptr(), t["data"].data_ptr(), t["gap"].data_ptr()
+        a.shape_sdf_index, a.sdf_table, a.sdf_count = t["idx"].data_ptr(), t["table"].data_ptr(), len(self._sdfs)
+        a.shape_edge_range, a.edge_centers, a.edge_halves = t["er"].data_ptr(), t["ec"].data_ptr(), t["eh"].data_ptr()
+        a.out_count, a.out_pair, a.out_key, a.out_data, a.capacity = (out_count.data_ptr(), out_pair.data_ptr(),
+                                                                       out_key.data_ptr(), out_data.data_ptr(),
+                                                                       int(out_pair.shape[0]))
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if reduce:
+            r = _lib.nt_contact_reduce_shapes()
+            r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = t["lo"].data_ptr(), t["hi"].data_ptr(), t["res"].data_ptr()
+            r.threads = int(threads)
+            _lib.check(self._lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
+        else:
+            _lib.check(self._lib.nt_mesh_sdf_collide(C.byref(a), stream), "nt_mesh_sdf_collide")

@@ -259,3 +259,37 @@ def test_device_reduced_mesh_sdf_bin_scale():
     assert set(zip(a["pair"].tolist(), a["key"].tolist())) <= unreduced
     assert np.bincount(a["pair"]).max() <= 245
     assert set(np.unique(a["pair"]).tolist()) == set(np.unique(u["pair"]).tolist())  # no touching pair loses all its contacts
+
+
+@pytest.mark.parametrize("threads", [64, 256])
+def test_device_resident_narrow_phase_takes_the_broad_phase_counter(threads):
+    """MeshSdfNarrowPhase.launch: pairs and their live count stay on the device (the SAP broad phase's candidate array and
+    counter), one wave or four per pair: the same rows as the host-driven wrapper, and rows beyond the counter are ignored."""
+    import torch
+    from test_sdf_contact import sphere_on_box_scene
+
+    from newton_amd.sdf_device import DeviceSDF, MeshSdfNarrowPhase, mesh_sdf_collide
+
+    sc = sphere_on_box_scene()
+    dev = [DeviceSDF(t) for t in sc["sdfs"]]
+    want = mesh_sdf_collide(sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["sdf_index"], dev, sc["er"], sc["ec"], sc["eh"],
+                            reduce=(sc["aabb_lo"], sc["aabb_hi"], sc["res"]))
+    nphase = MeshSdfNarrowPhase(sc["data"], sc["gap"], sc["sdf_index"], dev, sc["er"], sc["ec"], sc["eh"],
+                                (sc["aabb_lo"], sc["aabb_hi"], sc["res"]))
+    pairs = torch.zeros((16, 2), dtype=torch.int32, device="cuda:0")
+    pairs[:3] = torch.from_numpy(sc["pairs"]).cuda()
+    pairs[3:] = torch.tensor([0, 1], dtype=torch.int32)  # stale rows past the live count
+    count = torch.tensor([3], dtype=torch.int32, device="cuda:0")
+    cap = 4096
+    o_count = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    o_pair, o_key = torch.zeros(cap, dtype=torch.int32, device="cuda:0"), torch.zeros(cap, dtype=torch.int32, device="cuda:0")
+    o_data = torch.zeros((cap, 9), dtype=torch.float32, device="cuda:0")
+    nphase.launch(torch.from_numpy(sc["X"]).cuda(), pairs, count, o_count, o_pair, o_key, o_data, threads=threads)
+    torch.cuda.synchronize()
+    n = int(o_count.item())
+    assert n == want["count"]
+    o = np.lexsort((o_key[:n].cpu().numpy(), o_pair[:n].cpu().numpy()))
+    assert np.array_equal(o_pair[:n].cpu().numpy()[o], want["pair"]) and np.array_equal(o_key[:n].cpu().numpy()[o], want["key"])
+    d = o_data[:n].cpu().numpy()[o]
+    assert np.array_equal(d[:, 0:3], want["center"]) and np.array_equal(d[:, 3:6], want["normal"])
+    assert np.array_equal(d[:, 6], want["distance"])

@@ -173,7 +173,7 @@ def sphere_on_box_scene(dz=0.985, gap=0.03, margin=0.002, lat=14, lon=18):
                 eh=np.concatenate([eh_b, eh_s]), aabb_lo=lo, aabb_hi=hi, res=res)
 
 
-def _emu_mesh_sdf(emu, sc, reduced, cap=8192):
+def _emu_mesh_sdf(emu, sc, reduced, cap=8192, threads=0):
     import ctypes as C
 
     from newton_amd import _lib as L
@@ -190,6 +190,7 @@ def _emu_mesh_sdf(emu, sc, reduced, cap=8192):
     if reduced:
         r = L.nt_contact_reduce_shapes()
         r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = sc["aabb_lo"].ctypes.data, sc["aabb_hi"].ctypes.data, sc["res"].ctypes.data
+        r.threads = threads
         assert emu.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), None) == 0
     else:
         assert emu.nt_mesh_sdf_collide(C.byref(a), None) == 0
@@ -222,9 +223,10 @@ def check_reduced_against_unreduced(sc, unreduced, reduced):
     return len(u_key), len(r_key)
 
 
-def test_emulated_reduced_mesh_sdf_kernel_is_the_reduction_of_the_unreduced_one(emu):
+@pytest.mark.parametrize("threads", [0, 64, 128])
+def test_emulated_reduced_mesh_sdf_kernel_is_the_reduction_of_the_unreduced_one(emu, threads):
     sc = sphere_on_box_scene()
-    n_in, n_out = check_reduced_against_unreduced(sc, _emu_mesh_sdf(emu, sc, False), _emu_mesh_sdf(emu, sc, True))
+    n_in, n_out = check_reduced_against_unreduced(sc, _emu_mesh_sdf(emu, sc, False), _emu_mesh_sdf(emu, sc, True, threads=threads))
     assert n_in > n_out + 50  # 167 unreduced contacts -> 87
 
 
