@@ -401,6 +401,63 @@ typedef struct {
 } nt_contact_reduce_list;
 nt_status nt_contacts_reduce_list(const nt_contact_reduce_list* args, void* stream);
 
+/* write_contact (newton/_src/sim/collide.py:203-254) for ContactData rows that live outside the environment tiles -- the rows
+ * nt_mesh_sdf_collide(_reduced) emits (out_pair, out_data): body-frame points and offsets, normal, margins in Newton's flat
+ * Contacts layout, row i -> contact i (the input order is kept; a row beyond the pair's gap becomes the inert contact
+ * shape0 = shape1 = -1 that eval_body_contact skips, where the reference would not have appended it). */
+typedef struct {
+    int32_t row_count;               /* rows to write (the capacity when row_count_device is given: rows past the live count
+                                        are left untouched, like Newton's arrays past rigid_contact_count) */
+    const int32_t* row_count_device; /* optional: live row count in device memory (nt_mesh_sdf_args.out_count) */
+    const int32_t* row_pair;         /* [n] index into `pairs` (nt_mesh_sdf_args.out_pair) */
+    const int32_t* pairs;            /* [P][2] shape ids */
+    const float* row_data;           /* [n][9] centre, normal a -> b, distance, margin a, margin b */
+    const float* body_q;             /* [B][7] State.body_q */
+    const int32_t* shape_body;       /* [S] */
+    const float* shape_gap;          /* [S] */
+    int32_t* out_shape0;             /* [n] Contacts.rigid_contact_shape0 ... */
+    int32_t* out_shape1;
+    float* out_point0;               /* [n][3] */
+    float* out_point1;
+    float* out_offset0;
+    float* out_offset1;
+    float* out_normal;
+    float* out_margin0;              /* [n] */
+    float* out_margin1;
+} nt_contact_rows;
+nt_status nt_contact_rows_write(const nt_contact_rows* args, void* stream);
+
+/* eval_body_contact (newton/_src/solvers/semi_implicit/kernels_contact.py:381-556, force_in_world_frame=False) on Newton's
+ * flat arrays, argument for argument: penalty force of every contact row added to body_f (float atomics, like the reference).
+ * Lets SolverSemiImplicit / SolverFeatherstone consume contacts that are not in the fixed-slot tiles: evaluate into State.body_f
+ * after clear_forces, then step. */
+typedef struct {
+    const float* body_q;             /* [B][7] */
+    const float* body_qd;            /* [B][6] linear, angular */
+    const float* body_com;           /* [B][3] */
+    const float* shape_ke;           /* [S] Model.shape_material_ke ... */
+    const float* shape_kd;
+    const float* shape_kf;
+    const float* shape_ka;
+    const float* shape_mu;
+    const int32_t* shape_body;       /* [S] */
+    const int32_t* contact_count;    /* optional [1] device counter; contact_max bounds it */
+    int32_t contact_max;
+    const float* point0;             /* [n][3] */
+    const float* point1;
+    const float* normal;
+    const int32_t* shape0;           /* [n] */
+    const int32_t* shape1;
+    const float* margin0;            /* [n] */
+    const float* margin1;
+    const float* contact_stiffness;  /* optional [n] (Contacts.rigid_contact_stiffness; 0 = use the shape materials) */
+    const float* contact_damping;
+    const float* contact_friction_scale;
+    float friction_smoothing;
+    float* body_f;                   /* [B][6] accumulated */
+} nt_flat_contact_forces;
+nt_status nt_eval_body_contact_flat(const nt_flat_contact_forces* args, void* stream);
+
 /* HydroelasticSDF contact generation, unreduced (sdf_hydroelastic.py:905-1296 launch, :1982-2140 generate, :1823-1928 decode):
  * marching cubes on the iso-pressure surface p_a == p_b (p = -kh * signed depth) of every SDF pair; one contact per face with
  * the per-contact stiffness area * pressure / |separation| (penetrating) or margin_contact_area * k_a k_b / (k_a + k_b)

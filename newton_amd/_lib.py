@@ -108,6 +108,23 @@ class nt_contact_reduce_list(C.Structure):
                 ("out_count", C.c_void_p), ("out_index", C.c_void_p), ("out_normal", C.c_void_p), ("capacity", C.c_int32)]
 
 
+class nt_contact_rows(C.Structure):
+    _fields_ = [("row_count", C.c_int32), ("row_count_device", C.c_void_p), ("row_pair", C.c_void_p), ("pairs", C.c_void_p),
+                ("row_data", C.c_void_p), ("body_q", C.c_void_p), ("shape_body", C.c_void_p), ("shape_gap", C.c_void_p),
+                ("out_shape0", C.c_void_p), ("out_shape1", C.c_void_p), ("out_point0", C.c_void_p), ("out_point1", C.c_void_p),
+                ("out_offset0", C.c_void_p), ("out_offset1", C.c_void_p), ("out_normal", C.c_void_p), ("out_margin0", C.c_void_p),
+                ("out_margin1", C.c_void_p)]
+
+
+class nt_flat_contact_forces(C.Structure):
+    _fields_ = [("body_q", C.c_void_p), ("body_qd", C.c_void_p), ("body_com", C.c_void_p), ("shape_ke", C.c_void_p),
+                ("shape_kd", C.c_void_p), ("shape_kf", C.c_void_p), ("shape_ka", C.c_void_p), ("shape_mu", C.c_void_p),
+                ("shape_body", C.c_void_p), ("contact_count", C.c_void_p), ("contact_max", C.c_int32), ("point0", C.c_void_p),
+                ("point1", C.c_void_p), ("normal", C.c_void_p), ("shape0", C.c_void_p), ("shape1", C.c_void_p),
+                ("margin0", C.c_void_p), ("margin1", C.c_void_p), ("contact_stiffness", C.c_void_p), ("contact_damping", C.c_void_p),
+                ("contact_friction_scale", C.c_void_p), ("friction_smoothing", C.c_float), ("body_f", C.c_void_p)]
+
+
 class nt_contact_history(C.Structure):
     _fields_ = [("prev_pos_world", C.c_void_p), ("prev_normal", C.c_void_p), ("prev_live", C.c_void_p),
                 ("prev_body_frame", C.c_void_p)]
@@ -255,6 +272,8 @@ SYMBOLS = {
     "nt_mesh_sdf_collide": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), _P]),
     "nt_mesh_sdf_collide_reduced": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), C.POINTER(nt_contact_reduce_shapes), _P]),
     "nt_contacts_reduce_list": (C.c_int32, [C.POINTER(nt_contact_reduce_list), _P]),
+    "nt_contact_rows_write": (C.c_int32, [C.POINTER(nt_contact_rows), _P]),
+    "nt_eval_body_contact_flat": (C.c_int32, [C.POINTER(nt_flat_contact_forces), _P]),
     "nt_contacts_match": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts), C.POINTER(nt_contact_history),
                                        C.c_float, C.c_float, _P, _P, _P]),
     "nt_contacts_replay_matched": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),

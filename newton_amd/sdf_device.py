@@ -218,3 +218,166 @@ class MeshSdfNarrowPhase:
             _lib.check(self._lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
         else:
             _lib.check(self._lib.nt_mesh_sdf_collide(C.byref(a), stream), "nt_mesh_sdf_collide")
+
+
+class MeshSdfContactStage:
+    """Mesh-SDF contacts between the mesh-like shapes of a Model, outside the fixed-slot environment tiles: the mesh-mesh leg of
+    CollisionPipeline.collide (newton/_src/sim/collide.py:1925-2050 -> NarrowPhase.launch, narrow_phase.py:2588-2760) with
+    broad_phase="sap", reduce_contacts=True, followed by the contact writer (collide.py:203-254) into Newton's flat Contacts
+    arrays, and the penalty-force consumer SolverSemiImplicit / SolverFeatherstone share (eval_body_contact,
+    semi_implicit/kernels_contact.py:381-556) accumulating into State.body_f.
+
+        stage = MeshSdfContactStage(model)            # shapes: every CONVEX_MESH / MESH shape on a body, SDFs built once
+        state.clear_forces(); stage.collide(state); stage.apply_forces(state); pipe.collide(state, contacts); solver.step(...)
+
+    Every launch is on the current stream; nothing returns to the host (the broad phase's candidate counter and the narrow
+    phase's row counter are read by the next kernel on the device).  The shape pairs handled here must be filtered out of
+    Model.shape_contact_pairs (the tiles would run them through MPR / GJK as well)."""
+
+    def __init__(self, model, shape_ids=None, sdf_resolution: int = 24, sdf_margin: float = 0.02, narrow_band_range=(-0.1, 0.1),
+                 threads: int = 64, pairs_per_shape: int = 12, contacts_per_shape: int = 40, friction_smoothing: float = 1.0):
+        from . import geometry
+        from . import sdf as S
+        from .enums import GeoType
+        from .mesh import mesh_edge_tables
+
+        torch = _torch()
+        self.model = model
+        dm = model.device_model()
+        self.device = dev = dm.device
+        self._lib = _lib.load()
+        stype, sbody = np.asarray(model.shape_type), np.asarray(model.shape_body)
+        if shape_ids is None:
+            shape_ids = [s for s in range(model.shape_count)
+                         if int(stype[s]) in (int(GeoType.CONVEX_MESH), int(GeoType.MESH)) and sbody[s] >= 0]
+        self.shape_ids = ids = np.asarray(shape_ids, dtype=np.int64)
+        n = self.n = len(ids)
+        if n == 0:
+            raise ValueError("MeshSdfContactStage: the model has no mesh shapes on bodies")
+        self.threads, self.friction_smoothing = int(threads), float(friction_smoothing)
+        # unique mesh assets -> edge tables, SDFs, local AABBs / voxel grids (every environment shares them)
+        assets, asset_of = {}, np.zeros(n, dtype=np.int32)
+        scale = np.asarray(model.shape_scale, dtype=np.float32)[ids]
+        ecs, ehs, ranges, sdfs, verts = [], [], [], [], []
+        for k, s in enumerate(ids):
+            src = model.shape_source[int(s)]
+            key = (id(src), tuple(scale[k].tolist()))
+            if key not in assets:
+                assets[key] = len(sdfs)
+                tri = np.asarray(src.indices).reshape(-1, 3)
+                ec, eh = mesh_edge_tables(src.vertices, tri, scale=scale[k])
+                ranges.append((sum(len(e) for e in ecs), len(ec)))
+                ecs.append(ec)
+                ehs.append(eh)
+                v = np.asarray(src.vertices, dtype=np.float64) * scale[k]
+                verts.append(v)
+                sdfs.append(S.create_texture_sdf_from_mesh(v, tri, margin=sdf_margin, narrow_band_range=narrow_band_range,
+                                                           max_resolution=sdf_resolution, scale_baked=True,
+                                                           quantization_mode=S.QuantizationMode.UINT16))
+            asset_of[k] = assets[key]
+        self.sdfs = sdfs
+        lo, hi, res = S.mesh_reduction_tables(verts, [(1.0, 1.0, 1.0)] * len(verts))
+        margin = np.asarray(model.shape_margin, dtype=np.float32)[ids]
+        self.shape_gap = np.asarray(model.shape_gap, dtype=np.float32)[ids]
+        data = np.concatenate([np.ones((n, 3), np.float32), margin[:, None]], axis=1)  # the scale is baked into edges and SDFs
+        self.narrow = MeshSdfNarrowPhase(data, self.shape_gap, asset_of, [DeviceSDF(t, device=dev) for t in sdfs],
+                                         np.asarray(ranges, np.int32)[asset_of], np.concatenate(ecs), np.concatenate(ehs),
+                                         (lo[asset_of], hi[asset_of], res[asset_of]), device=dev)
+        t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, dtype=d)).to(dev)  # noqa: E731
+        corners = np.array([[(lo[a][0], hi[a][0])[i], (lo[a][1], hi[a][1])[j], (lo[a][2], hi[a][2])[l]]
+                            for a in asset_of for i in (0, 1) for j in (0, 1) for l in (0, 1)], np.float32).reshape(n, 8, 3)
+        self._corners = t(corners, np.float32)
+        self._body_of = t(sbody[ids], np.int64)
+        self._shape_body = t(sbody[ids], np.int32)
+        self._local = t(np.asarray(model.shape_transform, np.float32)[ids], np.float32)
+        self._local_identity = bool(np.all(np.asarray(model.shape_transform, np.float32)[ids] == np.array([0, 0, 0, 0, 0, 0, 1], np.float32)))
+        world = np.asarray(model.shape_world, dtype=np.int32)[ids]
+        self._world = t(world, np.int32)
+        self._group = t(np.asarray(model.shape_collision_group, np.int32)[ids], np.int32)
+        self._gap = t(self.shape_gap, np.float32)
+        self._mat = {k: t(np.asarray(getattr(model, "shape_material_" + k), np.float32)[ids], np.float32)
+                     for k in ("ke", "kd", "kf", "ka", "mu")}
+        self._body_com = t(np.asarray(model.body_com, np.float32), np.float32)
+        self._global_id = t(ids, np.int32)
+        self.broad = geometry.BroadPhaseSAP(world, None, device=dev)
+        self.pair_max, self.contact_max = n * int(pairs_per_shape), n * int(contacts_per_shape)
+        i32, f32 = torch.int32, torch.float32
+        self.pairs = torch.zeros((self.pair_max, 2), dtype=i32, device=dev)
+        self.pair_count = torch.zeros(1, dtype=i32, device=dev)
+        self.row_count = torch.zeros(1, dtype=i32, device=dev)
+        self._row_pair, self._row_key = torch.zeros(self.contact_max, dtype=i32, device=dev), torch.zeros(self.contact_max, dtype=i32, device=dev)
+        self._row_data = torch.zeros((self.contact_max, 9), dtype=f32, device=dev)
+        c = self.contact_max
+        self.shape0, self.shape1 = torch.full((c,), -1, dtype=i32, device=dev), torch.full((c,), -1, dtype=i32, device=dev)
+        self.point0, self.point1, self.offset0, self.offset1, self.normal = (torch.zeros((c, 3), dtype=f32, device=dev) for _ in range(5))
+        self.margin0, self.margin1 = torch.zeros(c, dtype=f32, device=dev), torch.zeros(c, dtype=f32, device=dev)
+        self._body_q = None
+
+    # -- Newton-shaped views of the stage's rows (stage-local shape ids -> Model shape ids); rows with shape0 == -1 are inert
+    @property
+    def rigid_contact_count(self):
+        return self.row_count
+
+    def rigid_contact_shapes(self):
+        n = min(int(self.row_count.item()), self.contact_max)
+        g = self._global_id
+        s0, s1 = self.shape0[:n].long(), self.shape1[:n].long()
+        live = s0 >= 0
+        return _torch().where(live, g[s0.clamp(min=0)], -1), _torch().where(live, g[s1.clamp(min=0)], -1)
+
+    def _shape_world_transforms(self, body_q):
+        torch = _torch()
+        bq = body_q[self._body_of]
+        if self._local_identity:
+            return bq.contiguous()
+        p, q, lp, lq = bq[:, :3], bq[:, 3:], self._local[:, :3], self._local[:, 3:]
+        qv, w = q[:, :3], q[:, 3:]
+        rp = lp * (2.0 * w * w - 1.0) + torch.cross(qv, lp, dim=-1) * w * 2.0 + qv * (qv * lp).sum(-1, keepdim=True) * 2.0
+        ax, ay, az, aw = q.unbind(-1)
+        bx, by, bz, bw = lq.unbind(-1)
+        qq = torch.stack([aw * bx + bw * ax + ay * bz - by * az, aw * by + bw * ay + az * bx - bz * ax,
+                          aw * bz + bw * az + ax * by - bx * ay, aw * bw - ax * bx - ay * by - az * bz], dim=-1)
+        return torch.cat([p + rp, qq], dim=-1).contiguous()
+
+    def collide(self, state):
+        """AABBs -> per-world sort-and-sweep -> edge-vs-SDF contacts with the global reduction -> flat contact rows."""
+        torch = _torch()
+        self._body_q = body_q = state.body_q  # [B, 7] AoS copy of the env-major state
+        X = self._shape_world_transforms(body_q)
+        p, q = X[:, None, :3], X[:, None, 3:]
+        qv, w = q[..., :3], q[..., 3:]
+        qv, c = torch.broadcast_tensors(qv, self._corners)
+        world = c * (2.0 * w * w - 1.0) + torch.cross(qv, c, dim=-1) * w * 2.0 + qv * (qv * c).sum(-1, keepdim=True) * 2.0 + p
+        lower, upper = world.amin(dim=1).contiguous(), world.amax(dim=1).contiguous()
+        self.broad.launch(lower, upper, self._gap, self._group, self._world, self.n, self.pairs, self.pair_count)
+        self.row_count.zero_()
+        self.narrow.launch(X, self.pairs, self.pair_count, self.row_count, self._row_pair, self._row_key, self._row_data,
+                           reduce=True, threads=self.threads)
+        a = _lib.nt_contact_rows()
+        a.row_count, a.row_count_device = self.contact_max, self.row_count.data_ptr()
+        a.row_pair, a.pairs, a.row_data = self._row_pair.data_ptr(), self.pairs.data_ptr(), self._row_data.data_ptr()
+        a.body_q, a.shape_body, a.shape_gap = body_q.data_ptr(), self._shape_body.data_ptr(), self._gap.data_ptr()
+        for k in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
+            setattr(a, "out_" + k, getattr(self, k).data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib.nt_contact_rows_write(C.byref(a), stream), "nt_contact_rows_write")
+
+    def apply_forces(self, state):
+        """eval_body_contact over the stage's rows, added to State.body_f (call between clear_forces and the solver step)."""
+        torch = _torch()
+        if self._body_q is None:
+            raise RuntimeError("MeshSdfContactStage.apply_forces before collide")
+        body_qd = state.body_qd
+        body_f = torch.zeros((body_qd.shape[0], 6), dtype=torch.float32, device=self.device)
+        f = _lib.nt_flat_contact_forces()
+        f.body_q, f.body_qd, f.body_com = self._body_q.data_ptr(), body_qd.data_ptr(), self._body_com.data_ptr()
+        m = self._mat
+        f.shape_ke, f.shape_kd, f.shape_kf, f.shape_ka, f.shape_mu = (m[k].data_ptr() for k in ("ke", "kd", "kf", "ka", "mu"))
+        f.shape_body, f.contact_count, f.contact_max = self._shape_body.data_ptr(), self.row_count.data_ptr(), self.contact_max
+        for k in ("point0", "point1", "normal", "shape0", "shape1", "margin0", "margin1"):
+            setattr(f, k, getattr(self, k).data_ptr())
+        f.friction_smoothing, f.body_f = self.friction_smoothing, body_f.data_ptr()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib.nt_eval_body_contact_flat(C.byref(f), stream), "nt_eval_body_contact_flat")
+        state.body_f = state.body_f + body_f
+        return body_f

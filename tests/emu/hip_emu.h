@@ -96,6 +96,11 @@ inline int __shfl(int var, int src_lane) {
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline float atomicAdd(float* p, float v) {  // global_atomic_add_f32
+    float old = *p, want;
+    do { want = old + v; } while (!__atomic_compare_exchange(p, &old, &want, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+    return old;
+}
 inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {  // ds_max_u64 / global_atomic_umax_x2
     unsigned long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}

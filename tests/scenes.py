@@ -298,7 +298,8 @@ def free_child_scene(world_count: int, device=None, seed: int | None = 0, free_r
     return model
 
 
-def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.005, mu=None):
+def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.005, mu=None,
+                   hull_pairs: bool = True, shape_cfg=None):
     """Config C5 without the SDF / hydroelastic contact models: `n_hulls` random convex hulls (16-32 vertices, radius
     U(0.03, 0.06)) dropped into a five-wall bin (ground plane + four static boxes); every hull pair and every hull-wall pair
     is a candidate, so one environment has n(n-1)/2 + 5n pairs (2 336 for 64 hulls) and its per-contact solver records no
@@ -312,6 +313,8 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
     env = nt.ModelBuilder()
     if mu is not None:
         env.default_shape_cfg.mu = float(mu)
+    for k, v in (shape_cfg or {}).items():
+        setattr(env.default_shape_cfg, k, v)
     side = 0.07 * np.ceil(np.sqrt(n_hulls))
     # hulls start on a lattice with 0.135 m pitch (> twice the largest hull radius): no initial interpenetration -- randomly
     # overlapping hulls make XPBD eject them at 10^3 rad/s (oracle and device alike) until the state overflows
@@ -324,6 +327,10 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
         pos = [(ix - 0.5 * (n_side - 1)) * pitch, (iy - 0.5 * (n_side - 1)) * pitch, 0.08 + iz * pitch]
         b = env.add_body(xform=[*pos, *nt._np_math.quat_rpy(*rng.uniform(-1.0, 1.0, size=3))])
         env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(pts))
+    if not hull_pairs:  # hull-hull contacts come from somewhere else (the mesh-SDF stage): only hull-wall pairs stay in the tiles
+        for a in range(n_hulls):
+            for b2 in range(a + 1, n_hulls):
+                env.add_shape_collision_filter_pair(a, b2)
     base_count = min(world_count, 32)
     scene = nt.ModelBuilder()
     scene.replicate(env, base_count)

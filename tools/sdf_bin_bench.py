@@ -22,6 +22,61 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def step_mode(args):
+    """C5 with its SDF contact model, stepped: env-steps/s of {clear_forces, SDF stage collide + forces, tile collide, step}."""
+    import torch
+
+    import newton_amd as nt
+    import scenes
+    from newton_amd import _lib
+    from newton_amd.sdf_device import MeshSdfContactStage
+
+    E, H = args.envs, args.hulls
+    cfg = dict(ke=2.0e3, kd=20.0, kf=200.0, mu=0.5, gap=args.gap)
+    model = scenes.hull_bin_scene(E, H, device="cuda:0", seed=2, hull_pairs=False, shape_cfg=cfg)
+    t0 = time.perf_counter()
+    stage = MeshSdfContactStage(model, sdf_resolution=args.sdf_resolution, threads=args.threads)
+    t_sdf = time.perf_counter() - t0
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverSemiImplicit(model)
+    s0, s1, ctrl = model.state(), model.state(), model.control()
+    dt = 1.0 / 4000.0
+
+    def substep():
+        nonlocal s0, s1
+        s0.clear_forces()
+        stage.collide(s0)
+        stage.apply_forces(s0)
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, ctrl, contacts, dt)
+        s0, s1 = s1, s0
+
+    for _ in range(args.settle_frames * 10):
+        substep()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_sub = args.steps * 10
+    ev0.record()
+    for _ in range(n_sub):
+        substep()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / n_sub
+    q = s0.body_q
+    out = {"workload": f"C5 stepped with its SDF contact model: {E} envs x {H} hulls (mesh + uint16 texture SDF, resolution "
+                       f"{args.sdf_resolution}), per substep clear_forces + [AABBs, SAP, mesh-SDF edge contacts + global reduction, "
+                       "write_contact rows, eval_body_contact into body_f] + tile collide (hull-wall pairs) + SolverSemiImplicit.step, "
+                       f"dt = {dt:g}", "envs": E, "hulls_per_env": H, "ms_per_substep": ms, "env_steps_per_s": E / (ms * 1e-3),
+           "sdf_rows": int(stage.row_count.item()), "candidate_pairs": int(stage.pair_count.item()),
+           "finite": bool(torch.isfinite(q).all().item()), "z_min": float(q[:, 2].min().item()), "z_max": float(q[:, 2].max().item()),
+           "host_s": {"sdf_build": t_sdf}, "threads_per_pair": args.threads, "build_id": _lib.load().nt_build_info().decode()}
+    line = json.dumps(out)
+    print(line)
+    if args.out:
+        open(args.out, "w").write(line + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=2048)
@@ -33,8 +88,12 @@ def main():
     ap.add_argument("--gap", type=float, default=0.005)
     ap.add_argument("--unreduced", action="store_true", help="also time the unreduced kernel")
     ap.add_argument("--threads", type=int, default=64, help="workgroup size per pair of the reduced kernel (64 / 128 / 256)")
+    ap.add_argument("--step", action="store_true", help="instead of the collide-only line: step the scene with SolverSemiImplicit, "
+                    "hull-hull contacts from MeshSdfContactStage (penalty forces into body_f), hull-wall contacts from the tiles")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
+    if args.step:
+        return step_mode(args)
 
     import torch
 
@@ -103,8 +162,8 @@ def main():
     def aabbs():
         p, q = body_q[..., :3], body_q[..., 3:]
         qv, w = q[..., None, :3], q[..., None, 3:]
-        c = t_corners[None]
-        rot = c * (2.0 * w * w - 1.0) + torch.cross(qv.expand_as(c), c, dim=-1) * w * 2.0 + qv * (qv * c).sum(-1, keepdim=True) * 2.0
+        qv, c = torch.broadcast_tensors(qv, t_corners[None])  # [E, H, 8, 3]
+        rot = c * (2.0 * w * w - 1.0) + torch.cross(qv, c, dim=-1) * w * 2.0 + qv * (qv * c).sum(-1, keepdim=True) * 2.0
         world = rot + p[..., None, :]
         return world.amin(dim=2).reshape(n, 3).contiguous(), world.amax(dim=2).reshape(n, 3).contiguous()
 
