@@ -70,6 +70,12 @@ def _xinv(t):
 
 def eval_fk_numpy(model, joint_q, joint_qd):
     """Returns (body_q [B,7], body_qd [B,6]) as float32 arrays."""
+    if getattr(model, "is_heterogeneous", False):  # worlds differ: FK per world group, world-major concatenation (hetero.py)
+        parts = model.world_groups.parts
+        jq = np.split(np.asarray(joint_q, dtype=np.float32), np.cumsum([p.joint_coord_count for p in parts])[:-1])
+        jqd = np.split(np.asarray(joint_qd, dtype=np.float32), np.cumsum([p.joint_dof_count for p in parts])[:-1])
+        res = [eval_fk_numpy(p, a, b) for p, a, b in zip(parts, jq, jqd)]
+        return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
     t = model.env
     E, nb, nj = t.env_count, t.nb, t.nj
     jq = np.asarray(joint_q, dtype=np.float64).reshape(E, t.nc)

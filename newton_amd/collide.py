@@ -328,6 +328,13 @@ class CollisionPipeline:
 
     _BROAD_PHASES = {"explicit": 0, "nxn": 1, "sap": 2, None: 0}
 
+    def __new__(cls, model, **kwargs):
+        if getattr(model, "is_heterogeneous", False):  # one pipeline per world group behind the same surface (hetero.py)
+            from .hetero import GroupedCollisionPipeline  # noqa: PLC0415
+
+            return GroupedCollisionPipeline(cls, model, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, model, *, broad_phase=None, rigid_contact_max=None, reduce_contacts=True, deterministic=False,
                  sdf_hydroelastic_config=None, envs_per_block: int = 0, contact_matching: str = "disabled",
                  contact_matching_pos_threshold: float = 0.0005, contact_matching_normal_dot_threshold: float = 0.995,

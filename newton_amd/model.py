@@ -27,6 +27,17 @@ def _torch():
     return torch
 
 
+def pair_types_analytic(type_a: int, type_b: int) -> bool:
+    """True when the reference's primitive narrow-phase kernel owns this type pair (narrow_phase.py:458-1014); every other
+    supported pair goes through MPR / GJK + manifold in the second launch."""
+    ta, tb = sorted((int(type_a), int(type_b)))
+    if ta == GeoType.PLANE:
+        return tb in (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX)
+    if ta == GeoType.SPHERE:
+        return tb in (GeoType.SPHERE, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.BOX)
+    return ta == GeoType.CAPSULE and tb == GeoType.CAPSULE
+
+
 class EnvTemplate:
     """Env-uniform topology extracted from a replicated model (what ModelBuilder.replicate() produces)."""
 
@@ -205,12 +216,7 @@ class EnvTemplate:
         # precede all convex ones.  Device pairs are stored in that order (stable partition); `pair_order` maps a
         # device pair index back to the per-env position in Model.shape_contact_pairs.
         def analytic(a, b):
-            ta, tb = sorted((int(self.shape_type[a]), int(self.shape_type[b])))
-            if ta == GeoType.PLANE:
-                return tb in (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX)
-            if ta == GeoType.SPHERE:
-                return tb in (GeoType.SPHERE, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.BOX)
-            return ta == GeoType.CAPSULE and tb == GeoType.CAPSULE
+            return pair_types_analytic(int(self.shape_type[a]), int(self.shape_type[b]))
 
         convex_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE,
                         GeoType.CONVEX_MESH)
@@ -463,7 +469,32 @@ class Model:
 
     # -- construction helpers -------------------------------------------------------------------
     def _build_env_template(self):
-        self.env = EnvTemplate(self)
+        """One topology for all worlds -> the EnvTemplate the fused kernels run on.  Worlds that differ (model.py:881-900 permits
+        them) leave ``env`` unset; the model is then served through its world groups (hetero.py)."""
+        self._world_groups = None
+        self._hetero_reason = None
+        try:
+            self.env = EnvTemplate(self)
+        except NotImplementedError as e:
+            if not str(e).startswith("heterogeneous worlds") or self.world_count <= 1:
+                raise
+            self.env = None
+            self._hetero_reason = str(e)
+
+    @property
+    def is_heterogeneous(self) -> bool:
+        return getattr(self, "_hetero_reason", None) is not None
+
+    @property
+    def world_groups(self):
+        """The homogeneous sub-models (maximal runs of worlds with one topology) of a heterogeneous model."""
+        if not self.is_heterogeneous:
+            raise ValueError("world_groups: all worlds of this model share one topology")
+        if self._world_groups is None:
+            from .hetero import WorldGroups  # noqa: PLC0415
+
+            self._world_groups = WorldGroups(self)
+        return self._world_groups
 
     @property
     def is_gpu(self):
@@ -474,6 +505,9 @@ class Model:
             raise _lib.NewtonHipError(
                 f"Model is on device '{self.device}': the solvers / collision pipeline of newton_amd run only on an "
                 "MI355X through libnewton_hip.so (no CPU fallback). Finalize with device='cuda:0'.")
+        if self.is_heterogeneous:
+            raise NotImplementedError(f"{self._hetero_reason}: one device descriptor serves one topology; use the world groups "
+                                      "(model.world_groups, or model.state() / the solver classes, which dispatch to them)")
         if self._dev is None:
             self._dev = DeviceModel(self)
         return self._dev
@@ -523,6 +557,10 @@ class Model:
 
     def notify_model_changed(self):
         """Re-upload per-env parameters after the host arrays were edited."""
+        if self.is_heterogeneous:
+            if self._world_groups is not None:
+                self._world_groups.refresh_parameters()
+            return
         if self._dev is not None:
             self._dev.upload_params(self)
 
@@ -530,11 +568,19 @@ class Model:
     def state(self) -> State:
         from .state import State  # noqa: PLC0415
 
+        if self.is_heterogeneous:
+            from .hetero import _make_state_classes  # noqa: PLC0415
+
+            return _make_state_classes()[0](self)
         return State(self)
 
     def control(self, clone_variables: bool = True) -> Control:
         from .state import Control  # noqa: PLC0415
 
+        if self.is_heterogeneous:
+            from .hetero import _make_state_classes  # noqa: PLC0415
+
+            return _make_state_classes()[1](self)
         return Control(self)
 
     def contacts(self):

@@ -5,6 +5,14 @@ from ..enums import ModelFlags
 
 
 class SolverBase:
+    def __new__(cls, model, *args, **kwargs):
+        # worlds with different topologies: one solver per world group behind the same surface (hetero.py)
+        if getattr(model, "is_heterogeneous", False):
+            from ..hetero import GroupedSolver  # noqa: PLC0415
+
+            return GroupedSolver(cls, model, *args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, model):
         self.model = model
         self.dm = model.device_model()  # raises loudly when the HIP extension / GPU is missing

@@ -104,6 +104,8 @@ def slice_worlds(model, begin: int, end: int, device=None):
     m.shape_label = [model.shape_label[i] for i in keep]
     m.shape_source = [model.shape_source[i] for i in keep]
     m.shape_count = len(keep)
+    m._global_shape_ids = keep.astype(np.int64)  # shape id of the source model for every shape of the slice (hetero.py)
+    m._world_groups = None
     m.shape_collision_filter_pairs = {(int(new_id[a]), int(new_id[b])) for a, b in model.shape_collision_filter_pairs
                                       if new_id[a] >= 0 and new_id[b] >= 0}
     pairs = np.asarray(model.shape_contact_pairs, dtype=np.int64).reshape(-1, 2)
