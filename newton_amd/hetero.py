@@ -108,6 +108,7 @@ class WorldGroups:
             p._requested_state_attributes = model._requested_state_attributes  # shared sets: later requests reach the groups
             p._requested_contact_attributes = model._requested_contact_attributes
         self._streams = None
+        self.concurrent = True  # False: the groups' launches stay on the caller's stream, one after the other
 
     def __len__(self):
         return len(self.parts)
@@ -144,7 +145,7 @@ class WorldGroups:
         a fork from and a join into the caller's current stream."""
         torch = _torch()
         dev = self.parts[0].device
-        if len(self.parts) == 1 or not _real_device(torch):
+        if len(self.parts) == 1 or not self.concurrent or not _real_device(torch):
             for i, p in enumerate(self.parts):
                 fn(i, p)
             return

@@ -299,14 +299,20 @@ def free_child_scene(world_count: int, device=None, seed: int | None = 0, free_r
 
 
 def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.005, mu=None,
-                   hull_pairs: bool = True, shape_cfg=None):
+                   hull_pairs: bool = True, shape_cfg=None, inertia_armature: float = 0.0):
     """Config C5 without the SDF / hydroelastic contact models: `n_hulls` random convex hulls (16-32 vertices, radius
     U(0.03, 0.06)) dropped into a five-wall bin (ground plane + four static boxes); every hull pair and every hull-wall pair
     is a candidate, so one environment has n(n-1)/2 + 5n pairs (2 336 for 64 hulls) and its per-contact solver records no
     longer fit LDS (nt_model.contact_scratch_in_hbm).  Every environment shares the hull set; `jitter` moves each hull of
     each environment by U(-jitter, jitter) m in x, y, z (seeded), so the environments' contact sets differ.  More than 32
     environments are produced by tiling a 32-environment build (newton_amd.worlds.tile_worlds) -- the Python builder
-    would spend minutes on 131 072 bodies."""
+    would spend minutes on 131 072 bodies.
+
+    `inertia_armature` adds that much to the diagonal of every hull's inertia (like the + 0.01 of the reference's quadruped
+    example): the lightest hull weighs 25 g with a smallest principal inertia of 2.8e-6 kg m^2, and the EXPLICIT penalty
+    contacts of SolverSemiImplicit / Featherstone are only stable while kf * r^2 * dt / I < 2 (kf = 200, r = 0.04 m,
+    dt = 1/4000 s gives 28 on the bare hull: it spins up to 200 rad/s on the ground before any hull touches another --
+    measured, profiles/r02h_sdf_stage_sweep.jsonl).  XPBD (implicit positions) needs none."""
     from newton_amd.worlds import slice_worlds, tile_worlds
 
     rng = np.random.default_rng(seed)
@@ -327,6 +333,10 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
         pos = [(ix - 0.5 * (n_side - 1)) * pitch, (iy - 0.5 * (n_side - 1)) * pitch, 0.08 + iz * pitch]
         b = env.add_body(xform=[*pos, *nt._np_math.quat_rpy(*rng.uniform(-1.0, 1.0, size=3))])
         env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(pts))
+    if inertia_armature > 0.0:
+        for b in range(env.body_count):
+            env.body_inertia[b] = env.body_inertia[b] + np.eye(3) * inertia_armature
+            env.body_inv_inertia[b] = np.linalg.inv(env.body_inertia[b])
     if not hull_pairs:  # hull-hull contacts come from somewhere else (the mesh-SDF stage): only hull-wall pairs stay in the tiles
         for a in range(n_hulls):
             for b2 in range(a + 1, n_hulls):
