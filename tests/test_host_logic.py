@@ -64,7 +64,9 @@ def test_collision_filters():
     assert len(b2.finalize().shape_contact_pairs) == 0
 
 
-def test_heterogeneous_worlds_rejected_loudly():
+def test_heterogeneous_worlds_go_through_world_groups():
+    """Worlds that differ in topology (model.py:881-900) finalize into a model served through its world groups
+    (newton_amd/hetero.py); a single device descriptor for it is still refused loudly."""
     a = nt.ModelBuilder()
     a.add_shape_sphere(a.add_body())
     b = nt.ModelBuilder()
@@ -72,8 +74,12 @@ def test_heterogeneous_worlds_rejected_loudly():
     scene = nt.ModelBuilder()
     scene.add_world(a)
     scene.add_world(b)
-    with pytest.raises(NotImplementedError):
-        scene.finalize()
+    model = scene.finalize()
+    assert model.is_heterogeneous and model.env is None
+    assert model.world_groups.ranges == [(0, 1), (1, 2)]
+    model.device = "cuda:0"  # pretend: the refusal must come before any device work
+    with pytest.raises(NotImplementedError, match="heterogeneous worlds"):
+        model.device_model()
 
 
 def test_mixed_scene_template():
