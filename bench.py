@@ -60,6 +60,18 @@ WORKLOADS = {
     "hull_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 1200.0, kernel="xpbd_rollout_kernel<1,true,true>", drop=0.0, settle=30,
                      name="C5 geometry without SDF / hydroelastic: 64 convex hulls (16-32 vertices) in a five-wall bin, all "
                           "2 336 pairs per env through MPR/GJK + manifold, contact records in HBM"),
+    # config C5 with its contact model: every pair through the mesh-SDF leg of CollisionPipeline.collide (candidate pairs per
+    # world -> edge-vs-SDF narrow phase + global reduction -> deterministic rows), SolverXPBD consumes the rows inside its step
+    # kernel.  The collide chain is several launches, so the frame is the reference's loop launch by launch (loop=True)
+    "sdf_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 1200.0, kernel="mesh_sdf_collide_reduced_kernel", drop=0.0, settle=40,
+                    loop=True, envs=2048,
+                    name="C5: 64 convex hulls (16-32 vertices, uint16 texture SDFs) in a five-wall bin of SDF boxes, every pair "
+                         "through the SDF narrow phase + global contact reduction inside CollisionPipeline.collide(broad_phase='sap')"),
+    # the headline scene through the per-call API an RL loop with per-substep control uses: collide and step as separate launches
+    "quadruped_api": dict(solver="xpbd", iterations=2, dt=1e-3, kernel="xpbd_step_kernel<16,false> + collide_kernel<16,false>",
+                          drop=0.22, settle=100, loop=True,
+                          name="Anymal-class quadruped through the per-call API: clear_forces + CollisionPipeline.collide + "
+                               "SolverXPBD.step as separate launches per substep"),
 }
 
 
@@ -137,8 +149,10 @@ def build_shard(workload: str, envs_per_gpu: int, rank: int, world: int, device:
     if envs_per_gpu % base:
         raise SystemExit(f"--envs-per-gpu above {BASE_ENVS} must be a multiple of it")
     total = base * world
-    if workload in ("quadruped", "quadruped_featherstone"):
+    if workload in ("quadruped", "quadruped_featherstone", "quadruped_api"):
         g = scenes.quadruped_scene(total, seed=1)
+    elif workload == "sdf_bin":
+        g = scenes.hull_bin_scene(total, 64, seed=2, sdf=True, mu=0.5)
     elif workload == "quadruped_convex":
         g = scenes.quadruped_convex_scene(total, seed=1)
     elif workload == "box_stack":
@@ -186,7 +200,7 @@ def run(args, rank, local_rank, world, dist):
     dt = W["dt"]
     s0, s1 = model.state(), model.state()
     ctrl = model.control()
-    pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block)
+    pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block, broad_phase="sap" if args.workload == "sdf_bin" else None)
     contacts = pipe.contacts()
     if W["solver"] == "featherstone":
         solver = nt.solvers.SolverFeatherstone(model, envs_per_block=args.envs_per_block)
@@ -198,6 +212,21 @@ def run(args, rank, local_rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    st = [s0, s1]
+
+    class _Frame:  # one frame = SUBSTEPS substeps: the fused rollout launch, or (loop workloads) the reference loop call by call
+        @staticmethod
+        def rollout(*_a):
+            if not W.get("loop"):
+                return solver_.rollout(st[0], st[1], ctrl, contacts, dt, SUBSTEPS)
+            for _ in range(SUBSTEPS):
+                st[0].clear_forces()
+                pipe.collide(st[0], contacts)
+                solver_.step(st[0], st[1], ctrl, contacts, dt)
+                st[0], st[1] = st[1], st[0]
+            return st[0]
+
+    solver_, solver = solver, _Frame
     settle = W["settle"] if args.settle_frames < 0 else args.settle_frames
     t_settle = time.perf_counter()
     for _ in range(settle):  # untimed, outside warm-up: reach the standing regime
@@ -225,8 +254,20 @@ def run(args, rank, local_rank, world, dist):
     dry = os.environ.get("NT_BENCH_DRY_SINGLE_GPU", "0") == "1"
     T = max_over_ranks(T, device=None if dry else device)  # MAX over ranks (no-op at N=1)
 
-    gate = validity_gate(args.workload, model, s0)
+    solver = solver_
+    gate = validity_gate(args.workload, model, st[0] if W.get("loop") else s0)
     c_per_env = float(contacts.rigid_contact_count_per_env.float().mean().item())
+    sdf_info = None
+    if getattr(contacts, "_flat", None) is not None:  # the SDF leg's rows count as contacts of the boundary
+        f = contacts._flat
+        live = int((f.shape0[: int(f.row_start[-1].item())] >= 0).sum().item())
+        c_per_env += live / model.env.env_count
+        sdf_info = pipe._sdf_leg.overflow(f)
+        sdf_info["live_rows"] = live
+        q = (st[0] if W.get("loop") else s0).body_q
+        gate["z_min"], gate["z_max"] = float(q[:, 2].min()), float(q[:, 2].max())
+        gate["ok"] = bool(gate["ok"] and gate["z_min"] > -0.01 and gate["z_max"] < 1.0 and gate["max_linear_speed"] < 3.0
+                          and not sdf_info["overflow"])
     if rank != 0:
         return None
     t = model.env
@@ -236,7 +277,7 @@ def run(args, rank, local_rank, world, dist):
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     epb = int(model.device_model().envs_per_block) if W["solver"] != "featherstone" else 4
     kernel = W["kernel"].replace("<16,", f"<{epb},") if W["solver"] != "featherstone" else W["kernel"]
-    if W["solver"] == "xpbd":  # the launch shape the library really dispatches for this model (name as profilers print it)
+    if W["solver"] == "xpbd" and not W.get("loop"):  # the launch shape the library really dispatches for this model (name as profilers print it)
         import ctypes as C
         from newton_amd import _lib
         dm, shape = model.device_model(), (C.c_int32 * 5)()
@@ -272,6 +313,11 @@ def run(args, rank, local_rank, world, dist):
         },
         "roofline": roof,
     }
+    if W.get("loop"):
+        out["config"]["workload"] = out["config"]["workload"].replace("fused in one rollout launch", "as separate launches (per-call API)")
+        roof["kernel_ms_is"] = "whole frame (every launch of the 10 substeps), not one kernel: see the rocprof kernel stats for the split"
+    if sdf_info is not None:
+        out["sdf_leg"] = sdf_info
     if args.workload != "quadruped":
         out["metric"] = f"env-steps/sec, {args.workload} (secondary; not the BASELINE.json metric)"
     return out
@@ -282,7 +328,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="environments per GPU (0: the workload's default, 4096 unless stated)")
     ap.add_argument("--envs-per-block", type=int, default=0)
     ap.add_argument("--settle-frames", type=int, default=-1, help="untimed frames before warm-up (-1: the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -292,6 +338,8 @@ def main():
                     "headline workload at each size on one GPU and print one JSON line per size + write --sweep-out")
     ap.add_argument("--sweep-out", default=os.path.join(ROOT, "gpurun_out", "env_sweep.json"))
     args = ap.parse_args()
+    if args.envs_per_gpu <= 0:
+        args.envs_per_gpu = WORKLOADS[args.workload].get("envs", ENVS_PER_GPU)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -134,6 +134,32 @@ typedef struct {
     const float* joint_target_qd; /* [nd][ES] */
 } nt_control;
 
+/* Contact rows that do not live in the fixed slots: what the mesh-SDF and hydroelastic legs of CollisionPipeline.collide append
+ * (collide.py:1999 -> narrow_phase.py:2838-3167 -> sdf_contact.py:1534-1990 / sdf_hydroelastic.py:905).  Newton's flat AoS
+ * Contacts layout (contacts.py:227-277), grouped per world: world w owns rows [row_start[w], row_start[w + 1]), inside a world
+ * the rows of one shape pair are consecutive and the pairs ascend in (shape0, shape1).  An inert row carries shape0 = shape1 = -1.
+ * The solvers sum a body's rows in ascending row order through the per-world block lists (no float atomics):
+ * body b of world w touches the row blocks body_blk_list[body_blk_start[w * (nb + 1) + b] .. body_blk_start[w * (nb + 1) + b + 1]),
+ * entry i = { (first_row << 1) | side, row_count }, side 0: b is the body of shape0, 1: of shape1.  All pointers NULL = no such rows. */
+typedef struct {
+    const int32_t* row_start;       /* [env_count + 1] */
+    const int32_t* shape0;          /* [cap] Newton global shape ids */
+    const int32_t* shape1;
+    const float* point0;            /* [cap][3] body frame */
+    const float* point1;
+    const float* offset0;           /* [cap][3] body frame */
+    const float* offset1;
+    const float* normal;            /* [cap][3] world, shape0 -> shape1 */
+    const float* margin0;           /* [cap] */
+    const float* margin1;
+    const float* stiffness;         /* [cap] or NULL: Contacts.rigid_contact_stiffness / _damping / _friction of the rows */
+    const float* damping;
+    const float* friction_scale;
+    const int32_t* body_blk_start;  /* [env_count * (nb + 1)] */
+    const int32_t* body_blk_list;   /* [..][2] */
+    float* cw;                      /* [cap][10] solver scratch: XPBD correction record of every row */
+} nt_flat_rows;
+
 /* Contacts (newton/_src/sim/contacts.py:227-277), fixed slots: slot = pair * cpp + k.
  * Unused slots carry shape0 = shape1 = -1, which every reference consumer skips
  * (xpbd/kernels.py:2201, semi_implicit/kernels_contact.py:425). */
@@ -149,6 +175,13 @@ typedef struct {
                            * overrides the shape-material ke / kd and scales mu in eval_body_contact
                            * (semi_implicit/kernels_contact.py:452-459) -- SolverSemiImplicit and SolverFeatherstone; SolverXPBD
                            * ignores them like the reference (solver_xpbd.py:619-651) */
+    /* optional outputs of nt_collide, indexed by Newton's global shape id: the world transform and the gap-widened world AABB of
+     * every shape as compute_shape_aabbs leaves them (collide.py:283-472: geom_xform, aabb_lower / aabb_upper) -- what the
+     * stages outside the tiles (candidate pairs of the SDF legs, their narrow phases) read.  NULL = not written */
+    float* world_xform;      /* [shape_count][7] */
+    float* world_aabb_lower; /* [shape_count][3] */
+    float* world_aabb_upper; /* [shape_count][3] */
+    nt_flat_rows flat;       /* rows of the SDF legs (all NULL when the model has none) */
 } nt_contacts;
 
 typedef struct {
@@ -358,6 +391,13 @@ typedef struct {
     const int32_t* pair_count_device; /* optional: the live pair count in device memory (e.g. a broad phase's candidate
                                          counter, read by the kernel: no host round trip); pair_count then is the capacity of
                                          `pairs` and bounds it */
+    /* world-region pairs (the collide pipeline, nt_sdf_candidate_pairs): `pairs` holds pairs_per_world entries per world of
+     * which the first (pair_world_prefix[w + 1] - pair_world_prefix[w]) are live; the flat index f of the prefix walks them and
+     * out_pair carries w * pairs_per_world + k.  out_blk [worlds * pairs_per_world][2] receives (raw row offset, row count) of
+     * every live pair -- nt_mesh_sdf_collide_reduced only, whose rows of one pair form one block.  All NULL / 0 otherwise. */
+    const int32_t* pair_world_prefix; /* [worlds + 1] */
+    int32_t worlds, pairs_per_world;
+    int32_t* out_blk;
 } nt_mesh_sdf_args;
 nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
 
@@ -487,6 +527,72 @@ typedef struct {
     int32_t capacity;
 } nt_hydro_args;
 nt_status nt_hydro_collide(const nt_hydro_args* args, void* stream);
+
+/* -------- the mesh-SDF leg of CollisionPipeline.collide as device stages (csrc/nt_sdf_pipeline.hip) --------
+ * collide.py:1999 -> narrow_phase.py:2838-3167: pairs whose two shapes carry a texture SDF and collision edges (not box-box,
+ * narrow_phase.py:620-655) go through the mesh-mesh SDF kernel with the global contact reduction, their contacts are appended
+ * after the primitive / GJK-MPR ones.  Stage order per collide():
+ *   nt_collide (exports nt_contacts.world_xform / world_aabb_*)  ->  nt_sdf_candidate_pairs  ->  nt_mesh_sdf_collide_reduced
+ *   (world-region pairs, block records)  ->  nt_sdf_rows_finalize  ->  rows in nt_contacts.flat, consumed by nt_xpbd_step and,
+ *   through nt_flat_rows_forces, by nt_semi_implicit_step / nt_featherstone_step.
+ * Nothing returns to the host and nothing depends on atomic arrival order: two runs give bit-identical rows. */
+typedef struct {
+    int32_t env_count, env_stride;   /* worlds, env-major stride of the state arrays */
+    int32_t nb, ns;                  /* bodies / env-local shapes per world (nt_model) */
+    int32_t shape_local0;            /* Newton shape id of world 0's first env-local shape */
+    int32_t template_pairs;          /* SDF shape pairs one world can have ... */
+    const int32_t* template_pair;    /* ... [template_pairs][2] template shape ids (< ns: env-local, else ns + rank of a global
+                                        shape), ascending in the Newton ids they map to: group / filter / same-body rules and the
+                                        SDF-pair routing applied on the host once (they are env-uniform) */
+    const int32_t* gshape_id;        /* [ng] Newton ids of the global (world -1) shapes */
+    const int32_t* shape_body;       /* [ns] env-local body of every env-local shape (-1 static) */
+    const float* shape_gap;          /* [shape_count] Model.shape_gap, Newton ids */
+    int32_t pairs_per_world;         /* capacity of a world's candidate list */
+} nt_sdf_scene;
+/* candidate pairs of every world: world_pairs[(w * pairs_per_world + k)][2] = Newton shape ids (shape0 < shape1), ascending;
+ * pair_count[w] keeps counting past pairs_per_world (overflow check), pair_prefix[env_count + 1] = exclusive scan of the
+ * clamped counts = the flat pair index the narrow phase walks. */
+nt_status nt_sdf_candidate_pairs(const nt_sdf_scene* sc, const float* aabb_lower, const float* aabb_upper, int32_t* world_pairs,
+                                 int32_t* pair_count, int32_t* pair_prefix, void* stream);
+typedef struct {
+    const int32_t* pair_count;   /* [env_count] */
+    const int32_t* world_pairs;  /* [env_count * pairs_per_world][2] */
+    const int32_t* blk;          /* [env_count * pairs_per_world][2] (raw row offset, row count) per pair (nt_mesh_sdf_args.out_blk) */
+    int32_t* pair_row;           /* [env_count * pairs_per_world] out: row offset of the pair inside its world */
+    int32_t* row_start;          /* [env_count + 1] out: nt_flat_rows.row_start */
+    const int32_t* raw_count;    /* [1] raw rows appended by the narrow phase */
+    const int32_t* raw_pair;     /* [raw_capacity] world * pairs_per_world + k */
+    const int32_t* raw_key;      /* [raw_capacity] fingerprint (edge << 2 | mode << 1) */
+    const float* raw_data;       /* [raw_capacity][9] centre, normal a -> b, distance, margin a, margin b */
+    int32_t raw_capacity, row_capacity;
+    int32_t* shape0;             /* [row_capacity] out: the nt_flat_rows arrays */
+    int32_t* shape1;
+    float* point0;
+    float* point1;
+    float* offset0;
+    float* offset1;
+    float* normal;
+    float* margin0;
+    float* margin1;
+    int32_t* key;                /* [row_capacity] or NULL: the row's fingerprint (tests, deterministic sort key) */
+} nt_sdf_rows_io;
+/* final row ranges (world-major, pairs ascending, rows in fingerprint order), write_contact (collide.py:166-254) of every raw
+ * row at its final position, and the per-body row-block lists.  body_q: State.body_q, env-major [7][nb][ES].
+ * world_rows [env_count] scratch; body_blk_start [env_count * (nb + 1)], body_blk_list [env_count * 2 * pairs_per_world][2]. */
+nt_status nt_sdf_rows_finalize(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, int32_t* world_rows,
+                               int32_t* body_blk_start, int32_t* body_blk_list, void* stream);
+/* eval_body_contact (semi_implicit/kernels_contact.py:381-556) over the flat rows, every body's wrenches summed in ascending
+ * row order (the reference: float atomics) and ADDED to body_f: call between clear_forces and nt_semi_implicit_step /
+ * nt_featherstone_step on a force buffer the step then reads as State.body_f. */
+typedef struct {
+    const float* body_q;          /* [7][nb][ES] */
+    const float* body_qd;         /* [6][nb][ES] */
+    const float* body_com;        /* nt_model.body_param (rows 0..2 = COM), [..][nb][ES] */
+    const float* shape_material;  /* [shape_count][5] ke, kd, kf, ka, mu by Newton shape id */
+    float friction_smoothing;
+    float* body_f;                /* [6][nb][ES] accumulated */
+} nt_flat_force_params;
+nt_status nt_flat_rows_forces(const nt_sdf_scene* sc, const nt_flat_rows* rows, const nt_flat_force_params* p, void* stream);
 
 /* -------- introspection -------- */
 /* ---- building the descriptor from Newton's own arrays ------------------------------------------------------------------

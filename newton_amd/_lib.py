@@ -57,9 +57,37 @@ class nt_control(C.Structure):
     _fields_ = [("joint_f", C.c_void_p), ("joint_target_q", C.c_void_p), ("joint_target_qd", C.c_void_p)]
 
 
+class nt_flat_rows(C.Structure):
+    _fields_ = [("row_start", C.c_void_p), ("shape0", C.c_void_p), ("shape1", C.c_void_p), ("point0", C.c_void_p),
+                ("point1", C.c_void_p), ("offset0", C.c_void_p), ("offset1", C.c_void_p), ("normal", C.c_void_p),
+                ("margin0", C.c_void_p), ("margin1", C.c_void_p), ("stiffness", C.c_void_p), ("damping", C.c_void_p),
+                ("friction_scale", C.c_void_p), ("body_blk_start", C.c_void_p), ("body_blk_list", C.c_void_p), ("cw", C.c_void_p)]
+
+
 class nt_contacts(C.Structure):
     _fields_ = [("shape0", C.c_void_p), ("shape1", C.c_void_p), ("data", C.c_void_p), ("env_count", C.c_void_p),
-                ("pair_hit", C.c_void_p), ("cw", C.c_void_p), ("prop", C.c_void_p)]
+                ("pair_hit", C.c_void_p), ("cw", C.c_void_p), ("prop", C.c_void_p), ("world_xform", C.c_void_p),
+                ("world_aabb_lower", C.c_void_p), ("world_aabb_upper", C.c_void_p), ("flat", nt_flat_rows)]
+
+
+class nt_sdf_scene(C.Structure):
+    _fields_ = [("env_count", C.c_int32), ("env_stride", C.c_int32), ("nb", C.c_int32), ("ns", C.c_int32),
+                ("shape_local0", C.c_int32), ("template_pairs", C.c_int32), ("template_pair", C.c_void_p),
+                ("gshape_id", C.c_void_p), ("shape_body", C.c_void_p), ("shape_gap", C.c_void_p), ("pairs_per_world", C.c_int32)]
+
+
+class nt_sdf_rows_io(C.Structure):
+    _fields_ = [("pair_count", C.c_void_p), ("world_pairs", C.c_void_p), ("blk", C.c_void_p), ("pair_row", C.c_void_p),
+                ("row_start", C.c_void_p), ("raw_count", C.c_void_p), ("raw_pair", C.c_void_p), ("raw_key", C.c_void_p),
+                ("raw_data", C.c_void_p), ("raw_capacity", C.c_int32), ("row_capacity", C.c_int32), ("shape0", C.c_void_p),
+                ("shape1", C.c_void_p), ("point0", C.c_void_p), ("point1", C.c_void_p), ("offset0", C.c_void_p),
+                ("offset1", C.c_void_p), ("normal", C.c_void_p), ("margin0", C.c_void_p), ("margin1", C.c_void_p),
+                ("key", C.c_void_p)]
+
+
+class nt_flat_force_params(C.Structure):
+    _fields_ = [("body_q", C.c_void_p), ("body_qd", C.c_void_p), ("body_com", C.c_void_p), ("shape_material", C.c_void_p),
+                ("friction_smoothing", C.c_float), ("body_f", C.c_void_p)]
 
 
 class nt_xpbd_params(C.Structure):
@@ -93,7 +121,8 @@ class nt_mesh_sdf_args(C.Structure):
                 ("shape_gap", C.c_void_p), ("shape_sdf_index", C.c_void_p), ("sdf_table", C.c_void_p), ("sdf_count", C.c_int32),
                 ("shape_edge_range", C.c_void_p), ("edge_centers", C.c_void_p), ("edge_halves", C.c_void_p),
                 ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_data", C.c_void_p),
-                ("capacity", C.c_int32), ("pair_count_device", C.c_void_p)]
+                ("capacity", C.c_int32), ("pair_count_device", C.c_void_p), ("pair_world_prefix", C.c_void_p),
+                ("worlds", C.c_int32), ("pairs_per_world", C.c_int32), ("out_blk", C.c_void_p)]
 
 
 class nt_contact_reduce_shapes(C.Structure):
@@ -281,6 +310,9 @@ SYMBOLS = {
     "nt_contacts_save_history": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
                                               C.POINTER(nt_contact_history), _P]),
     "nt_hydro_collide": (C.c_int32, [C.POINTER(nt_hydro_args), _P]),
+    "nt_sdf_candidate_pairs": (C.c_int32, [C.POINTER(nt_sdf_scene), _P, _P, _P, _P, _P, _P]),
+    "nt_sdf_rows_finalize": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_sdf_rows_io), _P, _P, _P, _P, _P]),
+    "nt_flat_rows_forces": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_flat_rows), C.POINTER(nt_flat_force_params), _P]),
 }
 
 _lib = None

@@ -53,6 +53,24 @@ def _clone(x):
     return copy.deepcopy(x)
 
 
+def _box_edge_tables(half_extents):
+    """(edge_centers, edge_halves) of the 12 edges of a box with the given half extents: what the reference gets from
+    Mesh.create_box(1, 1, 1)._build_collision_edges(...) with shape_scale applied (builder.py:11389-11412,12088-12116); the
+    first edge that touches a corner owns it."""
+    h = np.asarray(half_extents, dtype=np.float32)
+    corners = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float32) * h
+    edges = [(a, b) for a in range(8) for b in range(a + 1, 8) if bin(a ^ b).count("1") == 1]
+    centers, halves, seen = [], [], set()
+    for a, b in edges:
+        v0, v1 = corners[a], corners[b]
+        half = (v1 - v0) * np.float32(0.5)
+        own = 4.0 + (a not in seen) + 2.0 * (b not in seen)
+        seen.update((a, b))
+        centers.append([*((v0 + v1) * np.float32(0.5)), np.linalg.norm(half)])
+        halves.append([*half, own])
+    return np.asarray(centers, np.float32), np.asarray(halves, np.float32)
+
+
 @dataclass
 class ShapeConfig:
     """Per-shape collision / material settings (builder.py:491-590 defaults)."""
@@ -75,6 +93,50 @@ class ShapeConfig:
     has_particle_collision: bool = True
     is_visible: bool = True
     kh: float = 1.0e10
+    # texture-SDF / hydroelastic options (builder.py:545-592).  Primitive shapes (BOX) get a generated SDF when a resolution or a
+    # voxel size is set; mesh-backed shapes use the SDF attached with Mesh.build_sdf()
+    sdf_narrow_band_range: tuple = (-0.1, 0.1)
+    sdf_target_voxel_size: float | None = None
+    sdf_max_resolution: int | None = None
+    force_sdf: bool = False
+    sdf_texture_format: str = "uint16"
+    is_hydroelastic: bool = False
+    sdf_padding: float | None = None
+
+    def configure_sdf(self, *, max_resolution=None, target_voxel_size=None, is_hydroelastic: bool = False, kh: float = 1.0e10,
+                      texture_format=None, force_sdf: bool = False):
+        """SDF and hydroelastic options in one place (builder.py:594-642)."""
+        if max_resolution is not None and target_voxel_size is not None:
+            raise ValueError("configure_sdf accepts either max_resolution or target_voxel_size, not both.")
+        self.force_sdf = force_sdf
+        if max_resolution is not None:
+            self.sdf_max_resolution, self.sdf_target_voxel_size = max_resolution, None
+        if target_voxel_size is not None:
+            self.sdf_target_voxel_size, self.sdf_max_resolution = target_voxel_size, None
+        self.is_hydroelastic = is_hydroelastic
+        self.kh = kh
+        if texture_format is not None:
+            self.sdf_texture_format = texture_format
+
+    def validate(self, shape_type=None):
+        """builder.py:644-710 (the checks that concern the options carried here)."""
+        if self.sdf_texture_format not in ("float32", "uint16", "uint8"):
+            raise ValueError(f"Unknown sdf_texture_format {self.sdf_texture_format!r}. Expected one of ['float32', 'uint16', 'uint8'].")
+        if self.sdf_target_voxel_size is not None and not (np.isfinite(self.sdf_target_voxel_size) and self.sdf_target_voxel_size > 0.0):
+            raise ValueError(f"sdf_target_voxel_size must be finite and > 0 (got {self.sdf_target_voxel_size}).")
+        if self.sdf_padding is not None and not (np.isfinite(self.sdf_padding) and self.sdf_padding >= 0.0):
+            raise ValueError(f"sdf_padding must be finite and >= 0 (got {self.sdf_padding}).")
+        inner, outer = self.sdf_narrow_band_range
+        if not (np.isfinite(inner) and np.isfinite(outer) and inner < 0.0 < outer):
+            raise ValueError("sdf_narrow_band_range must contain finite values satisfying inner < 0 < outer "
+                             f"(got {self.sdf_narrow_band_range}).")
+        if self.sdf_max_resolution is not None and self.sdf_target_voxel_size is not None:
+            raise ValueError("Set only one of sdf_max_resolution or sdf_target_voxel_size, not both.")
+        if self.sdf_max_resolution is not None:
+            if self.sdf_max_resolution <= 0:
+                raise ValueError(f"sdf_max_resolution must be > 0 (got {self.sdf_max_resolution}).")
+            if self.sdf_max_resolution % 8 != 0:
+                raise ValueError(f"sdf_max_resolution must be divisible by 8 (got {self.sdf_max_resolution}).")
 
     @property
     def flags(self) -> int:
@@ -85,6 +147,8 @@ class ShapeConfig:
             f |= ShapeFlags.COLLIDE_SHAPES
         if self.has_particle_collision:
             f |= ShapeFlags.COLLIDE_PARTICLES
+        if self.is_hydroelastic:
+            f |= ShapeFlags.HYDROELASTIC
         return int(f)
 
     def copy(self):
@@ -170,6 +234,9 @@ class ModelBuilder:
         self.shape_flags, self.shape_margin, self.shape_gap, self.shape_world, self.shape_label = [], [], [], [], []
         self.shape_collision_group, self.shape_collision_radius = [], []
         self.shape_source: list = []  # Mesh for CONVEX_MESH shapes, else None (shared, never copied)
+        # per-shape SDF options retained until finalize() (builder.py:1322-1333)
+        self.shape_sdf_narrow_band_range, self.shape_sdf_target_voxel_size, self.shape_sdf_max_resolution = [], [], []
+        self.shape_sdf_texture_format, self.shape_sdf_padding = [], []
         self.shape_material_ke, self.shape_material_kd, self.shape_material_kf, self.shape_material_ka = [], [], [], []
         self.shape_material_mu, self.shape_material_restitution = [], []
         self.shape_material_mu_torsional, self.shape_material_mu_rolling, self.shape_material_kh = [], [], []
@@ -479,6 +546,18 @@ class ModelBuilder:
         self.shape_collision_radius.append(compute_shape_radius(type, scale, src))
         self.shape_source.append(src)
         self.shape_world.append(self.current_world)
+        cfg.validate(type)
+        if src is not None and (cfg.sdf_max_resolution is not None or cfg.sdf_target_voxel_size is not None):
+            raise ValueError("Mesh-backed shapes do not use cfg.sdf_* for SDF generation. "
+                             "Build and attach an SDF on the mesh via mesh.build_sdf().")  # builder.py:6544-6558
+        if cfg.is_hydroelastic and src is not None and getattr(src, "sdf", None) is None:
+            raise ValueError("Hydroelastic mesh-backed shapes require mesh.sdf. "
+                             "Call mesh.build_sdf() before adding a mesh-backed hydroelastic shape.")
+        self.shape_sdf_narrow_band_range.append(tuple(cfg.sdf_narrow_band_range))
+        self.shape_sdf_target_voxel_size.append(cfg.sdf_target_voxel_size)
+        self.shape_sdf_max_resolution.append(cfg.sdf_max_resolution)
+        self.shape_sdf_texture_format.append(cfg.sdf_texture_format)
+        self.shape_sdf_padding.append(cfg.sdf_padding)
 
         if cfg.has_shape_collision and cfg.collision_filter_parent:
             for parent_body, joint_idx in self.joint_parents.get(body, ()):
@@ -544,6 +623,80 @@ class ModelBuilder:
             raise ValueError("add_shape_convex_hull() requires a Mesh")
         return self.add_shape(body=body, type=GeoType.CONVEX_MESH, xform=xform, cfg=cfg, scale=scale, label=label, src=mesh)
 
+    def _finalize_sdf(self, m) -> None:
+        """Texture-SDF resources of the finalized model (builder.py:11690-11960 compact SDF table + per-shape index, :12050-12116
+        collision-edge tables, :11544-11611 local AABBs and voxel grids of the contact reduction).  Mesh-backed shapes use the SDF
+        attached with Mesh.build_sdf(); BOX shapes with a resolution / voxel size (or the hydroelastic flag) get a generated one with
+        the scale baked in and the 12 edges of the unit box as collision edges.  Host construction (newton_amd/sdf.py) -- the
+        reference needs a CUDA device for the same tables."""
+        from . import sdf as S  # noqa: PLC0415
+        from .mesh import mesh_edge_tables  # noqa: PLC0415
+
+        n = self.shape_count
+        sdf_index = -np.ones(n, dtype=np.int32)
+        edge_range = np.zeros((n, 2), dtype=np.int32)
+        voxel_res = np.zeros((n, 3), dtype=np.int32)
+        table, cache, edge_cache, ecs, ehs = [], {}, {}, [], []
+        fmt = {"float32": S.QuantizationMode.FLOAT32, "uint16": S.QuantizationMode.UINT16, "uint8": S.QuantizationMode.UINT8}
+        lo_all, hi_all = m.shape_collision_aabb_lower, m.shape_collision_aabb_upper
+        for i in range(n):
+            ty, src, flags = self.shape_type[i], self.shape_source[i], self.shape_flags[i]
+            if not flags & ShapeFlags.COLLIDE_SHAPES:
+                continue
+            scale = tuple(float(x) for x in self.shape_scale[i])
+            hydro = bool(flags & ShapeFlags.HYDROELASTIC)
+            key = edges_of = None
+            if ty in (GeoType.MESH, GeoType.CONVEX_MESH) and src is not None and getattr(src, "sdf", None) is not None:
+                key = ("mesh_sdf", id(src.sdf))
+                make = lambda src=src: src.sdf  # noqa: E731
+                # the SDF carries the scale it was built with; the edges are scaled per shape (shape_scale on an unbaked SDF)
+                edges_of = (id(src), scale if not src.sdf.scale_baked else src.sdf_scale)
+                edge_args = (src.vertices, np.asarray(src.indices).reshape(-1, 3), edges_of[1])
+                if src.sdf.scale_baked and tuple(src.sdf_scale) != scale:
+                    raise ValueError(f"shape {i}: mesh.sdf was built with scale {tuple(src.sdf_scale)} baked in but the shape uses "
+                                     f"scale {scale}; rebuild it with mesh.build_sdf(scale={scale})")
+            elif ty == GeoType.BOX and (self.shape_sdf_max_resolution[i] is not None or self.shape_sdf_target_voxel_size[i] is not None
+                                        or hydro):
+                res, vox = self.shape_sdf_max_resolution[i], self.shape_sdf_target_voxel_size[i]
+                if res is None and vox is None:
+                    res = 64
+                pad = self.shape_sdf_padding[i]
+                if pad is None:
+                    pad = self.shape_gap[i] + (self.shape_margin[i] if hydro else 0.0)
+                band = tuple(self.shape_sdf_narrow_band_range[i])
+                key = ("primitive_generated", int(ty), pad, band, vox, res, scale, self.shape_sdf_texture_format[i])
+                make = lambda ty=ty, scale=scale, pad=pad, band=band, res=res, vox=vox, i=i: S.create_texture_sdf_from_primitive(  # noqa: E731
+                    int(ty), scale, margin=pad, narrow_band_range=band, max_resolution=res, target_voxel_size=vox,
+                    quantization_mode=fmt[self.shape_sdf_texture_format[i]], scale_baked=True)
+                edges_of = ("unit_box", scale)
+                edge_args = (None, None, scale)
+                lo_all[i], hi_all[i] = -np.asarray(scale, np.float32), np.asarray(scale, np.float32)
+            if key is None:
+                continue
+            if key not in cache:
+                cache[key] = len(table)
+                table.append(make())
+            sdf_index[i] = cache[key]
+            if edges_of not in edge_cache:
+                if edges_of[0] == "unit_box":
+                    ec, eh = _box_edge_tables(edge_args[2])
+                else:
+                    ec, eh = mesh_edge_tables(edge_args[0], edge_args[1], scale=edge_args[2])
+                edge_cache[edges_of] = (sum(len(e) for e in ecs), len(ec))
+                ecs.append(ec)
+                ehs.append(eh)
+            edge_range[i] = edge_cache[edges_of]
+            if ty == GeoType.MESH and src is not None:  # local AABB of triangle meshes (CONVEX_MESH has it from the hull table)
+                v = np.asarray(src.vertices, np.float64) * np.asarray(scale, np.float64)
+                lo_all[i], hi_all[i] = v.min(axis=0), v.max(axis=0)
+            voxel_res[i] = S.voxel_resolution_from_aabb(lo_all[i], hi_all[i])
+        m._shape_sdf_index = sdf_index
+        m._texture_sdf_data = table
+        m.shape_edge_range = edge_range
+        m.mesh_edge_centers = np.concatenate(ecs).astype(np.float32) if ecs else np.zeros((0, 4), np.float32)
+        m.mesh_edge_halves = np.concatenate(ehs).astype(np.float32) if ehs else np.zeros((0, 4), np.float32)
+        m._shape_voxel_resolution = voxel_res
+
     # ------------------------------------------------------------------ importers
     def add_urdf(self, source, **kwargs):
         from .urdf import parse_urdf  # noqa: PLC0415
@@ -562,7 +715,8 @@ class ModelBuilder:
                     "shape_label", "shape_collision_group", "shape_collision_radius", "shape_material_ke",
                     "shape_material_kd", "shape_material_kf", "shape_material_ka", "shape_material_mu",
                     "shape_material_restitution", "shape_material_mu_torsional", "shape_material_mu_rolling",
-                    "shape_material_kh"]
+                    "shape_material_kh", "shape_sdf_narrow_band_range", "shape_sdf_target_voxel_size", "shape_sdf_max_resolution",
+                    "shape_sdf_texture_format", "shape_sdf_padding"]
 
     def request_state_attributes(self, *attributes: str) -> None:
         """Extended State attributes to allocate (builder.py request_state_attributes; state.py:77): 'body_parent_f'."""
@@ -799,6 +953,7 @@ class ModelBuilder:
                      "shape_material_kf", "shape_material_ka", "shape_material_mu", "shape_material_restitution",
                      "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_kh"):
             setattr(m, name, arr(getattr(self, name), f32, (S,)))
+        self._finalize_sdf(m)
         m.shape_collision_filter_pairs = set(self.shape_collision_filter_pairs)
         m.shape_contact_pairs = self._find_shape_contact_pairs()
         m.shape_contact_pair_count = len(m.shape_contact_pairs)

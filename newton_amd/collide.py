@@ -13,6 +13,7 @@ import numpy as np
 
 from . import _lib
 from .enums import GeoType, ShapeFlags
+from .sdf_pipeline import SdfLeg, model_has_sdf_pairs, sdf_pair_shape_types_ok
 
 _RIGID_CONTACT_MIN_CAPACITY = 1000  # collide.py: _estimate_rigid_contact_max floor
 
@@ -27,9 +28,12 @@ class Contacts:
     """Rigid contact buffers (contacts.py:227-277).  ``rigid_contact_max`` = env_count * pairs_per_env * cpp."""
 
     def __init__(self, model, rigid_contact_max: int | None = None, sort_by_key: bool = False,
-                 per_contact_shape_properties: bool = False):
+                 per_contact_shape_properties: bool = False, sdf_leg=None):
         torch = _torch()
         self.model = model
+        # rows of the pipeline's mesh-SDF leg (sdf_pipeline.FlatRows): appended after the slot contacts in the flat views
+        self._flat = sdf_leg.new_rows(per_contact_shape_properties) if sdf_leg is not None else None
+        self._sdf_leg = sdf_leg
         # CollisionPipeline(deterministic=True): the flat arrays come out in the reference's sorted order, ascending
         # make_contact_sort_key = (shape0, shape1, sub-contact index) (contact_data.py:60-90, contact_sort.py)
         self.sort_by_key = bool(sort_by_key)
@@ -37,6 +41,9 @@ class Contacts:
         t = model.env
         self._slots = t.np * t.cpp
         self.rigid_contact_max = t.env_count * self._slots if rigid_contact_max is None else int(rigid_contact_max)
+        self._slot_contact_max = self.rigid_contact_max
+        if self._flat is not None:
+            self.rigid_contact_max += self._flat.capacity
         self.soft_contact_max = 0
         ns = max(self._slots, 1)
         dev = dm.device
@@ -76,6 +83,8 @@ class Contacts:
             d.cw = self._cw.data_ptr()
         if self._prop is not None:
             d.prop = self._prop.data_ptr()
+        if self._flat is not None:
+            d.flat = self._flat.desc()
         return d
 
     def set_slot_properties(self, stiffness=None, damping=None, friction_scale=None):
@@ -113,10 +122,20 @@ class Contacts:
         }
         d = self._desc()
         _lib.check(dm.lib.nt_contacts_export(
-            C.byref(dm.desc), C.byref(d), self.rigid_contact_max, e["count"].data_ptr(), e["shape0"].data_ptr(),
+            C.byref(dm.desc), C.byref(d), self._slot_contact_max, e["count"].data_ptr(), e["shape0"].data_ptr(),
             e["shape1"].data_ptr(), e["point0"].data_ptr(), e["point1"].data_ptr(), e["offset0"].data_ptr(),
             e["offset1"].data_ptr(), e["normal"].data_ptr(), e["margin0"].data_ptr(), e["margin1"].data_ptr(),
             self._scan.data_ptr(), dm.stream()), "nt_contacts_export")
+        if self._flat is not None:  # the SDF leg's rows follow (collide.py:1999: its launches come last); inert rows are skipped
+            f = self._flat
+            n0 = min(int(e["count"].item()), self._slot_contact_max)
+            nf = min(int(f.row_start[-1].item()), f.capacity)
+            live = torch.nonzero(f.shape0[:nf] != f.shape1[:nf]).flatten()
+            k = int(live.numel())
+            for name in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
+                e[name][n0:n0 + k] = getattr(f, name)[live]
+            e["count"][0] = n0 + k
+            self._flat_live = live
         self._sort_order = None
         if self.sort_by_key:
             n = min(int(e["count"].item()), cap)
@@ -328,8 +347,8 @@ class CollisionPipeline:
 
     _BROAD_PHASES = {"explicit": 0, "nxn": 1, "sap": 2, None: 0}
 
-    def __new__(cls, model, **kwargs):
-        if getattr(model, "is_heterogeneous", False):  # one pipeline per world group behind the same surface (hetero.py)
+    def __new__(cls, model=None, **kwargs):
+        if model is not None and getattr(model, "is_heterogeneous", False):  # one pipeline per world group behind the same surface (hetero.py)
             from .hetero import GroupedCollisionPipeline  # noqa: PLC0415
 
             return GroupedCollisionPipeline(cls, model, **kwargs)
@@ -338,7 +357,7 @@ class CollisionPipeline:
     def __init__(self, model, *, broad_phase=None, rigid_contact_max=None, reduce_contacts=True, deterministic=False,
                  sdf_hydroelastic_config=None, envs_per_block: int = 0, contact_matching: str = "disabled",
                  contact_matching_pos_threshold: float = 0.0005, contact_matching_normal_dot_threshold: float = 0.995,
-                 contact_report: bool = False, **unsupported):
+                 contact_report: bool = False, sdf_pairs_per_shape: int = 12, sdf_contacts_per_shape: int = 40, **unsupported):
         if unsupported:
             raise NotImplementedError(f"CollisionPipeline options not supported: {sorted(unsupported)}")
         # frame-to-frame matching (collide.py:1126-1129,1253-1268): "latest" fills contacts.rigid_contact_match_index every
@@ -363,6 +382,17 @@ class CollisionPipeline:
         self.params = _lib.nt_collide_params(self._BROAD_PHASES[broad_phase], int(envs_per_block))
         t = model.env
         self._rigid_contact_max = t.env_count * t.np * t.cpp
+        # shape pairs with texture SDFs + collision edges on both sides: the mesh-SDF leg (narrow_phase.py:620-640, 2838-3167)
+        self._sdf_leg = None
+        if model_has_sdf_pairs(model):
+            if not reduce_contacts:
+                raise NotImplementedError("SDF contact pairs need reduce_contacts=True (the unreduced kernel is offered stand-alone: "
+                                          "newton_amd.sdf_device.mesh_sdf_collide)")
+            if contact_matching != "disabled":
+                raise NotImplementedError("contact_matching is not implemented for models with SDF contact pairs")
+            sdf_pair_shape_types_ok(model)
+            self._sdf_leg = SdfLeg(model, pairs_per_shape=sdf_pairs_per_shape, contacts_per_shape=sdf_contacts_per_shape)
+            self._rigid_contact_max += self._sdf_leg.row_capacity
         model.rigid_contact_max = self._rigid_contact_max
         # fixed slots + ordered reductions: results are reproducible either way; deterministic=True additionally orders the
         # flat contact arrays by the reference's contact sort key (collide.py deterministic mode, contact_sort.py)
@@ -379,7 +409,8 @@ class CollisionPipeline:
         return self._rigid_contact_max
 
     def contacts(self, per_contact_shape_properties: bool = False) -> Contacts:
-        c = Contacts(self.model, sort_by_key=self.deterministic, per_contact_shape_properties=per_contact_shape_properties)
+        c = Contacts(self.model, sort_by_key=self.deterministic, per_contact_shape_properties=per_contact_shape_properties,
+                     sdf_leg=self._sdf_leg)
         c._contact_matching_mode = self.contact_matching
         if self._matcher is not None:
             torch = _torch()
@@ -433,8 +464,14 @@ class CollisionPipeline:
             raise ValueError("contacts were created for a different model")
         d_state = state._desc()
         d_ct = contacts._desc()
+        if self._sdf_leg is not None:
+            if contacts._flat is None:
+                raise ValueError("the model has SDF contact pairs: create the Contacts with pipeline.contacts()")
+            self._sdf_leg.export_pointers(d_ct)  # world transforms + AABBs of every shape, for the stages below
         _lib.check(self.dm.lib.nt_collide(C.byref(self.dm.desc), C.byref(d_state), C.byref(d_ct), C.byref(self.params),
                                           self.dm.stream()), "nt_collide")
+        if self._sdf_leg is not None:
+            self._sdf_leg.collide(state, contacts._flat, self.dm.stream())
         contacts._generation += 1
         if self._matcher is not None:
             self._match(state, contacts)

@@ -108,10 +108,20 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
 
 template <int EPB>
 NT_DI void shape_item(const Ctx<EPB>& c, const int s);
+NT_DI void store_shape_world(const nt_contacts& ct, int gid, const xform& X, vec3 lo, vec3 hi);
+template <int EPB>
+NT_DI void store_global_shapes_world(const Ctx<EPB>& c);
 template <int EPB>
 NT_DI void phase_shapes(const Ctx<EPB>& c) {
+    store_global_shapes_world(c);
     if (!c.valid) return;
-    for (int s = c.slot; s < c.a.m.ns; s += c.nslot) shape_item(c, s);
+    const bool out = c.a.ct.world_xform != nullptr;  // only the stand-alone collide launch exports (never the fused rollouts)
+    for (int s = c.slot; s < c.a.m.ns; s += c.nslot) {
+        shape_item(c, s);
+        if (out)
+            store_shape_world(c.a.ct, c.newton_shape_id(s), c.lxf(c.L.sx, 0, c.a.m.ns, s), c.lv3(c.L.sa, 0, c.a.m.ns, s),
+                              c.lv3(c.L.sa, 3, c.a.m.ns, s));
+    }
 }
 template <int EPB>
 NT_DI void shape_item(const Ctx<EPB>& c, const int s) {
@@ -126,6 +136,28 @@ NT_DI void shape_item(const Ctx<EPB>& c, const int s) {
         c.st_lxf(c.L.sx, m.ns, s, X);
         c.st_lv3(c.L.sa, 0, m.ns, s, lo);
         c.st_lv3(c.L.sa, 3, m.ns, s, hi);
+    }
+}
+// geom_xform / aabb_lower / aabb_upper of compute_shape_aabbs for the stages outside the tiles (nt_contacts.world_*)
+NT_DI void store_shape_world(const nt_contacts& ct, int gid, const xform& X, vec3 lo, vec3 hi) {
+    float* x = ct.world_xform + 7 * (size_t)gid;
+    x[0] = X.p.x; x[1] = X.p.y; x[2] = X.p.z; x[3] = X.q.x; x[4] = X.q.y; x[5] = X.q.z; x[6] = X.q.w;
+    float* l = ct.world_aabb_lower + 3 * (size_t)gid;
+    float* u = ct.world_aabb_upper + 3 * (size_t)gid;
+    l[0] = lo.x; l[1] = lo.y; l[2] = lo.z;
+    u[0] = hi.x; u[1] = hi.y; u[2] = hi.z;
+}
+// the static global (world -1) shapes: written once per launch by the first workgroup
+template <int EPB>
+NT_DI void store_global_shapes_world(const Ctx<EPB>& c) {
+    const nt_model& m = c.a.m;
+    if (!c.a.ct.world_xform || blockIdx.x != 0) return;
+    for (int s = m.ns + (int)threadIdx.x; s < m.ns + m.ng; s += blockDim.x) {
+        xform X = c.shape_local_xform(s);
+        vec3 lo, hi;
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP),
+                   m.shape_mesh_bounds + 6 * s, lo, hi);
+        store_shape_world(c.a.ct, c.newton_shape_id(s), X, lo, hi);
     }
 }
 

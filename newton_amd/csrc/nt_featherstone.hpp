@@ -958,15 +958,15 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     const KArgs& a = c.a;
     const nt_model& m = a.m;
     const int nj = m.nj, nb = m.nb;
-    const int skip = a.debug_skip;  // timing ablation only (NT_DEBUG_SKIP): results are meaningless when set
+    NT_SKIP_DECL(a);  // timing ablation builds only (-DNT_ABLATION): results are meaningless when set
     NT_TICK(10);
     // eval_rigid_fk: joint transforms for all joints at once, then level by level (a joint's parent body is final one
     // level earlier)
-    if (c.valid && !(skip & 1))
+    if (c.valid && !NT_SKIP(1))
         for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
     __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
-        if (c.valid && !(skip & 1))
+        if (c.valid && !NT_SKIP(1))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_fk_item(f, j);
         __syncthreads();
@@ -979,16 +979,16 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     __syncthreads();
     NT_TICK(12);
     // eval_rigid_id
-    if (c.valid && !(skip & 2))
+    if (c.valid && !NT_SKIP(2))
         for (int j = c.slot; j < nj; j += c.nslot) fs_motion_pre_item(f, j);
     __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
-        if (c.valid && !(skip & 2))
+        if (c.valid && !NT_SKIP(2))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_motion_item(f, j);
         __syncthreads();
     }
-    if (c.valid && !(skip & 2))
+    if (c.valid && !NT_SKIP(2))
         for (int j = c.slot; j < nj; j += c.nslot) fs_motion_post_item(f, j);
     __syncthreads();
     NT_TICK(13);
@@ -996,7 +996,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     if (a.has_contacts) {
         Ctx<EPB> cc = c;
         cc.L.si_cw.off = F.cw;
-        if (c.valid && !(skip & 4))
+        if (c.valid && !NT_SKIP(4))
             for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) si_contact_item(cc, s);
         __syncthreads();
     }
@@ -1006,7 +1006,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     NT_TICK(14);
     // eval_rigid_tau, deepest level first
     for (int lvl = max_depth; lvl >= 0; --lvl) {
-        if (c.valid && !(skip & 8))
+        if (c.valid && !NT_SKIP(8))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_tau_item(f, j);
         __syncthreads();
@@ -1027,11 +1027,11 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     const bool update_mass = fs_update_mass(c, substep);
     float* cache = a.fp.mass_matrix_cache;
     if (update_mass) {
-        if (c.valid && !(skip & 16))
+        if (c.valid && !NT_SKIP(16))
             for (int i = c.slot; i < nj * W; i += c.nslot) fs_P_item(f, i);
         __syncthreads();
         NT_TICK(16);
-        if (c.valid && !(skip & 32))
+        if (c.valid && !NT_SKIP(32))
             for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
     } else if (c.valid) {  // the factor of the last rebuild
         for (int r = c.slot; r < m.nd * W; r += c.nslot) f.f(F.H, r) = cache[(size_t)r * c.ES + c.env];
@@ -1040,7 +1040,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     NT_TICK(17);
     {
         const int G = (64 / EPB) < c.nslot ? (64 / EPB) : c.nslot;
-        if (c.valid && !(skip & 64) && c.slot < G)
+        if (c.valid && !NT_SKIP(64) && c.slot < G)
             for (int k = 0; k < m.na; ++k) fs_solve_coop(f, k, c.slot, G, update_mass);
     }
     __syncthreads();
@@ -1058,11 +1058,11 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     __syncthreads();
     NT_TICK(19);
     // FK with velocity conversion -> public body_q / body_qd
-    if (c.valid && !(skip & 128))
+    if (c.valid && !NT_SKIP(128))
         for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
     __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
-        if (c.valid && !(skip & 128))
+        if (c.valid && !NT_SKIP(128))
             for (int j = c.slot; j < nj; j += c.nslot)
                 if (f.depth[j] == lvl) fs_fk_vel_item<EPB, false>(f, j);
         __syncthreads();

@@ -233,11 +233,13 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
     if (max_threads <= 0) max_threads = max_threads_for(epb);
     int nslot = slots_for(a.m, epb, max_threads);
     a.nslot = nslot;
+#ifdef NT_ABLATION
     {
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("NT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; }
         a.debug_skip = dbg;
     }
+#endif
     int threads = ((nslot * epb + 63) / 64) * 64;
     size_t lds_bytes = (size_t)(semi ? L.rows_semi : L.rows_per_env) * 4 * epb + (size_t)topo_ints(a.m) * 4 + (size_t)L.uni_floats * 4;
     if (lds_bytes > LDS_BYTES_PER_CU) return NT_ERR_UNSUPPORTED;
@@ -362,13 +364,15 @@ nt_status nt_clear_forces(const nt_model* m, nt_state* s, void* stream) {
 
 nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const nt_collide_params* p, void* stream) {
     if (!model_ok(m) || !s || !c || !s->body_q) return NT_ERR_INVALID_ARG;
-    if (m->np == 0) return NT_OK;
+    if (m->np == 0 && !c->world_xform) return NT_OK;
+    if (c->world_xform && (!c->world_aabb_lower || !c->world_aabb_upper)) return NT_ERR_INVALID_ARG;
     KArgs a = {};
     a.m = *m;
     a.s_in = *s;
     a.ct = *c;
     int epb = pick_epb(*m, p ? p->envs_per_block : 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
+    if (m->np == 0) return NT_DISPATCH_EPB(shapes_export_kernel, a, epb, (hipStream_t)stream);  // every pair lives outside the tiles
     if (m->contact_scratch_in_hbm)
         return m->np_analytic < m->np ? launch(collide_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(collide_kernel<1, false, true>, a, 1, (hipStream_t)stream);
@@ -387,14 +391,14 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
     a.s_out = *s_out;
     a.c = *ctrl;
     if (c) a.ct = *c;
-    a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
+    a.has_contacts = (c != nullptr && (m->np > 0 || c->flat.row_start)) ? 1 : 0;  // fixed slots and / or rows of the SDF legs
     a.p = *p;
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     int epb = pick_epb(*m, envs_per_block, xpbd_keeps_prestep_state(*p));
     if (!epb) return NT_ERR_UNSUPPORTED;
     if (m->contact_scratch_in_hbm) {
-        if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
+        if (a.has_contacts && m->np > 0 && !a.ct.cw) return NT_ERR_INVALID_ARG;
         return launch(xpbd_step_kernel<1, true>, a, 1, (hipStream_t)stream);
     }
     return NT_DISPATCH_EPB(xpbd_step_kernel, a, epb, (hipStream_t)stream);
@@ -504,10 +508,12 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
 // shared launch logic of the Featherstone kernels (step / rollout)
 static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, bool rollout, hipStream_t stream) {
     if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;  // XPBD / collide only
+#ifdef NT_ABLATION
     {
         const char* e = getenv("NT_DEBUG_SKIP");
         a.debug_skip = e ? atoi(e) : 0;
     }
+#endif
     const FsLayout F = make_fs_layout(*m, make_layout(*m, false));
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     auto fits = [&](int epb) { return (size_t)F.rows * 4 * epb + shared_ints * 4 <= LDS_BYTES_PER_CU; };

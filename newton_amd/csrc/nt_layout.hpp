@@ -143,6 +143,16 @@ __host__ __device__ inline bool xpbd_keeps_prestep_state(const nt_xpbd_params& p
     return p.enable_restitution != 0 || p.compute_body_velocity_from_position_delta != 0;
 }
 
+// Phase ablation exists only in throw-away measurement builds (-DNT_ABLATION, tools/xpbd_ablation.sh, tools/fs_ablation.sh): the
+// product library carries no work-skipping switch.
+#ifdef NT_ABLATION
+#define NT_SKIP_DECL(args) const int nt_skip_mask = (args).debug_skip
+#define NT_SKIP(bit) ((nt_skip_mask & (bit)) != 0)
+#else
+#define NT_SKIP_DECL(args) ((void)0)
+#define NT_SKIP(bit) false
+#endif
+
 struct KArgs {
     nt_model m;
     nt_state s_in, s_out;
@@ -157,7 +167,9 @@ struct KArgs {
     int substeps;
     int has_contacts;
     int nslot;       // slot-threads per environment
-    int debug_skip;  // ablation bitmask (NT_DEBUG_SKIP env var): 1 collide, 2 forces+integrate, 4 contacts, 8 joints, 16 apply
+#ifdef NT_ABLATION
+    int debug_skip;  // measurement builds only (tools/xpbd_ablation.sh): 1 collide, 2 forces+integrate, 4 contacts, 8 joints, 16 apply
+#endif
 };
 
 // env-uniform topology, staged once per workgroup into LDS (block-shared ints behind the per-env rows)

@@ -328,9 +328,21 @@ NT_DI bool edge_contact(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int 
 }
 
 NT_DI int live_pair_count(const nt_mesh_sdf_args& a) {
+    if (a.pair_world_prefix) return a.pair_world_prefix[a.worlds];
     if (!a.pair_count_device) return a.pair_count;
     const int n = *a.pair_count_device;
     return n < a.pair_count ? n : a.pair_count;
+}
+// world-region pairs: flat live index f -> position w * pairs_per_world + k in `pairs` (identity for a plain list)
+NT_DI int pair_slot(const nt_mesh_sdf_args& a, int f) {
+    if (!a.pair_world_prefix) return f;
+    int lo = 0, hi = a.worlds;  // the last world whose prefix is <= f
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.pair_world_prefix[mid] <= f) lo = mid;
+        else hi = mid;
+    }
+    return lo * a.pairs_per_world + (f - a.pair_world_prefix[lo]);
 }
 
 __global__ void __launch_bounds__(256) mesh_sdf_collide_kernel(nt_mesh_sdf_args a) {
@@ -549,8 +561,9 @@ __global__ void __launch_bounds__(256) mesh_sdf_collide_reduced_kernel(nt_mesh_s
     __shared__ RedLds L;
     const int t = threadIdx.x;
     const int pair_count = live_pair_count(a);
-    for (int pair_idx = blockIdx.x; pair_idx < pair_count; pair_idx += gridDim.x) {
-        const int s0 = a.pairs[2 * pair_idx], s1 = a.pairs[2 * pair_idx + 1];
+    for (int f = blockIdx.x; f < pair_count; f += gridDim.x) {
+        const int pair_idx = pair_slot(a, f);
+        const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
         for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
         __syncthreads();
         for (int mode = 0; mode < 2; ++mode) {
@@ -586,7 +599,14 @@ __global__ void __launch_bounds__(256) mesh_sdf_collide_reduced_kernel(nt_mesh_s
         }
         __syncthreads();
         red_finish(L);
-        if (t == 0) L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
+        if (t == 0) {
+            L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
+            if (a.out_blk) {  // the pair's block: rows past the capacity do not exist for the consumers
+                const int room = a.capacity - L.base;
+                a.out_blk[2 * (size_t)pair_idx] = L.base;
+                a.out_blk[2 * (size_t)pair_idx + 1] = L.total < room ? L.total : (room > 0 ? room : 0);
+            }
+        }
         __syncthreads();
         for (int k = t; k < RED_SLOTS; k += blockDim.x) {
             const int slot = L.base + L.keep[k];
@@ -851,11 +871,16 @@ nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* a, const nt_contac
     if (!a || !r || a->pair_count < 0 || !a->out_count || !a->out_pair || !a->out_key || !a->out_data || a->capacity <= 0)
         return NT_ERR_INVALID_ARG;
     if (!r->shape_aabb_lower || !r->shape_aabb_upper || !r->shape_voxel_res) return NT_ERR_INVALID_ARG;
-    if (a->pair_count == 0) return NT_OK;
+    if (a->pair_count == 0 && !a->pair_world_prefix) return NT_OK;
     // workgroup size: meshes with few edges (C5's hulls have ~40) would leave most of 256 lanes idle in the edge loops; one
     // wave per pair then, and four times the pairs in flight per CU
     const int threads = r->threads == 64 || r->threads == 128 || r->threads == 256 ? r->threads : 256;
     int blocks = a->pair_count < 16384 ? a->pair_count : 16384;  // grid-stride over the pairs
+    if (a->pair_world_prefix) {
+        if (a->worlds <= 0 || a->pairs_per_world <= 0) return NT_ERR_INVALID_ARG;
+        const long long cap = (long long)a->worlds * a->pairs_per_world;
+        blocks = cap < 16384 ? (int)cap : 16384;
+    }
     hipLaunchKernelGGL(mesh_sdf_collide_reduced_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, *a, *r);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }

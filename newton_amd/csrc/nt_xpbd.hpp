@@ -223,6 +223,150 @@ NT_DI void cw_st3(const Ctx<EPB>& c, int comp, int ncs, int slot, vec3 v) {
 // ------------------------------------------------------------------------------------------------
 // XPBD: solve_body_contact_positions (xpbd/kernels.py:2164-2399); one lane per contact slot.
 // ------------------------------------------------------------------------------------------------
+// The geometry of one contact as the position solve reads it: a fixed slot of the environment tile (env-major SoA in HBM) or a
+// flat row of the SDF legs (Newton's AoS arrays).  Offsets are only fetched when friction is active, like the reference.
+template <int EPB>
+struct SlotRecord {
+    const Ctx<EPB>& c;
+    const float* D;
+    int ncs, slot;
+    NT_DI vec3 point0() const { return c.gv3(D, CD_POINT0, ncs, slot); }
+    NT_DI vec3 point1() const { return c.gv3(D, CD_POINT1, ncs, slot); }
+    NT_DI vec3 offset0() const { return c.gv3(D, CD_OFFSET0, ncs, slot); }
+    NT_DI vec3 offset1() const { return c.gv3(D, CD_OFFSET1, ncs, slot); }
+    NT_DI vec3 normal() const { return c.gv3(D, CD_NORMAL, ncs, slot); }
+    NT_DI float margins() const { return D[c.g(CD_MARGIN0, ncs, slot)] + D[c.g(CD_MARGIN1, ncs, slot)]; }
+};
+struct FlatRecord {
+    const nt_flat_rows& f;
+    int r;
+    static NT_DI vec3 ld(const float* p, int r) { return vec3(p[3 * (size_t)r], p[3 * (size_t)r + 1], p[3 * (size_t)r + 2]); }
+    NT_DI vec3 point0() const { return ld(f.point0, r); }
+    NT_DI vec3 point1() const { return ld(f.point1, r); }
+    NT_DI vec3 offset0() const { return ld(f.offset0, r); }
+    NT_DI vec3 offset1() const { return ld(f.offset1, r); }
+    NT_DI vec3 normal() const { return ld(f.normal, r); }
+    NT_DI float margins() const { return f.margin0[r] + f.margin1[r]; }
+};
+
+// solve_body_contact_positions (xpbd/kernels.py:2164-2399) for one live contact between body_a / body_b (-1: static); returns
+// false when the contact is separated (no correction).  lin_delta_b is the exact negation of lin_delta_a.
+template <int EPB, class REC>
+NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int shape_b, int body_a, int body_b, vec3& lin_delta_a,
+                         vec3& ang_delta_a, vec3& ang_delta_b) {
+    const float dt = c.a.dt, relaxation = c.a.p.rigid_contact_relaxation;
+    xform X_wb_a, X_wb_b;
+    if (body_a >= 0) X_wb_a = c.body_q(body_a);
+    if (body_b >= 0) X_wb_b = c.body_q(body_b);
+    vec3 point0 = rec.point0(), point1 = rec.point1();
+    vec3 bx_a = xform_point(X_wb_a, point0);
+    vec3 bx_b = xform_point(X_wb_b, point1);
+    vec3 n = rec.normal();
+    float d = dot(n, bx_b - bx_a) - rec.margins();
+    if (!(d < 0.0f)) return false;
+    vec3 lin_delta_b;
+    float m_inv_a = 0.0f, m_inv_b = 0.0f;
+    vec3 wc_a(0.0f), wc_b(0.0f), omega_a(0.0f), omega_b(0.0f);  // world COM (origin for static shapes)
+    if (body_a >= 0) {
+        wc_a = c.world_com(body_a);
+        m_inv_a = c.inv_mass(body_a);
+        omega_a = c.body_w(body_a);
+    }
+    if (body_b >= 0) {
+        wc_b = c.world_com(body_b);
+        m_inv_b = c.inv_mass(body_b);
+        omega_b = c.body_w(body_b);
+    }
+    auto wq_a = [&](vec3 v) { return body_a >= 0 ? c.w_quad(body_a, v) : 0.0f; };
+    auto wq_b = [&](vec3 v) { return body_b >= 0 ? c.w_quad(body_b, v) : 0.0f; };
+    int mat_nonzero = 0;
+    float mu = 0.0f, mu_torsional = 0.0f, mu_rolling = 0.0f;
+    if (shape_a >= 0) {
+        mat_nonzero += 1;
+        mu += c.shape_f(shape_a, SP_MU);
+        mu_torsional += c.shape_f(shape_a, SP_MU_TORSIONAL);
+        mu_rolling += c.shape_f(shape_a, SP_MU_ROLLING);
+    }
+    if (shape_b >= 0) {
+        mat_nonzero += 1;
+        mu += c.shape_f(shape_b, SP_MU);
+        mu_torsional += c.shape_f(shape_b, SP_MU_TORSIONAL);
+        mu_rolling += c.shape_f(shape_b, SP_MU_ROLLING);
+    }
+    if (mat_nonzero > 0) {
+        mu /= float(mat_nonzero);
+        mu_torsional /= float(mat_nonzero);
+        mu_rolling /= float(mat_nonzero);
+    }
+    vec3 r_a = bx_a - wc_a;
+    vec3 r_b = bx_b - wc_b;
+    vec3 angular_a = -cross(r_a, n);
+    vec3 angular_b = cross(r_b, n);
+
+    float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, wq_a(angular_a), wq_b(angular_b), relaxation, dt);
+    lin_delta_a = -n * lambda_n;
+    lin_delta_b = n * lambda_n;
+    ang_delta_a = angular_a * lambda_n;
+    ang_delta_b = angular_b * lambda_n;
+
+    if (mu > 0.0f) {
+        vec3 offset_a = rec.offset0(), offset_b = rec.offset1();
+        bx_a = xform_point(X_wb_a, point0 + offset_a);
+        bx_b = xform_point(X_wb_b, point1 + offset_b);
+        vec3 delta = bx_b - bx_a;
+        vec3 friction_delta = delta - dot(n, delta) * n;
+        r_a = bx_a - wc_a;
+        r_b = bx_b - wc_b;
+        vec3 rel_v_kin_t(0.0f);
+        if (body_a >= 0 && (c.T.body_flags[body_a] & BODY_KINEMATIC) != 0) {
+            vec3 v_a = velocity_at_point(spatial(c.body_v(body_a), omega_a), r_a);
+            rel_v_kin_t = rel_v_kin_t - (v_a - dot(n, v_a) * n);
+        }
+        if (body_b >= 0 && (c.T.body_flags[body_b] & BODY_KINEMATIC) != 0) {
+            vec3 v_b = velocity_at_point(spatial(c.body_v(body_b), omega_b), r_b);
+            rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
+        }
+        friction_delta += rel_v_kin_t * dt;
+        vec3 perp = normalize(friction_delta);
+        angular_a = -cross(r_a, perp);
+        angular_b = cross(r_b, perp);
+        float err = length(friction_delta);
+        if (err > 0.0f) {
+            float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, wq_a(angular_a),
+                                                       wq_b(angular_b), relaxation, dt);
+            lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
+            lin_delta_a -= perp * lambda_fr;
+            lin_delta_b += perp * lambda_fr;
+            ang_delta_a += angular_a * lambda_fr;
+            ang_delta_b += angular_b * lambda_fr;
+        }
+    }
+    vec3 delta_omega = omega_b - omega_a;
+    if (mu_torsional > 0.0f) {
+        float err = dot(delta_omega, n) * dt;
+        if (fabsf(err) > 0.0f) {
+            vec3 lin(0.0f);
+            float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-n), wq_b(n), relaxation, dt);
+            lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
+            ang_delta_a -= n * lt;
+            ang_delta_b += n * lt;
+        }
+    }
+    if (mu_rolling > 0.0f) {
+        delta_omega -= dot(n, delta_omega) * n;
+        float err = length(delta_omega) * dt;
+        if (err > 0.0f) {
+            vec3 lin(0.0f);
+            vec3 roll_n = normalize(delta_omega);
+            float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-roll_n), wq_b(roll_n), relaxation, dt);
+            lr = fmaxw(lr, -lambda_n * mu_rolling);
+            ang_delta_a -= roll_n * lr;
+            ang_delta_b += roll_n * lr;
+        }
+    }
+    return true;
+}
+
 // FUSED: the collide phase of the same kernel left the live-contact count of every pair in LDS, and the (type-sorted)
 // shape order of a pair is static, so neither the liveness test nor the shape ids need the global contact arrays.
 template <int EPB, bool FUSED, class CW = CwLds>
@@ -230,10 +374,8 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
     const int cpp = m.cpp, ncs = m.np * cpp;
-    const float dt = c.a.dt, relaxation = c.a.p.rigid_contact_relaxation;
-    const float* D = ct.data;
     float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
-    vec3 lin_delta_a, ang_delta_a, lin_delta_b, ang_delta_b;
+    vec3 lin_delta_a, ang_delta_a, ang_delta_b;
 
     bool live;
     int shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
@@ -261,125 +403,38 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
         body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         live = body_a != body_b;
     }
-    if (live) {
-        xform X_wb_a, X_wb_b;
-        if (body_a >= 0) X_wb_a = c.body_q(body_a);
-        if (body_b >= 0) X_wb_b = c.body_q(body_b);
-        vec3 point0 = c.gv3(D, CD_POINT0, ncs, slot), point1 = c.gv3(D, CD_POINT1, ncs, slot);
-        vec3 bx_a = xform_point(X_wb_a, point0);
-        vec3 bx_b = xform_point(X_wb_b, point1);
-        vec3 n = c.gv3(D, CD_NORMAL, ncs, slot);
-        float d = dot(n, bx_b - bx_a) - (D[c.g(CD_MARGIN0, ncs, slot)] + D[c.g(CD_MARGIN1, ncs, slot)]);
-        if (d < 0.0f) {
-            float m_inv_a = 0.0f, m_inv_b = 0.0f;
-            vec3 wc_a(0.0f), wc_b(0.0f), omega_a(0.0f), omega_b(0.0f);  // world COM (origin for static shapes)
-            if (body_a >= 0) {
-                wc_a = c.world_com(body_a);
-                m_inv_a = c.inv_mass(body_a);
-                omega_a = c.body_w(body_a);
-            }
-            if (body_b >= 0) {
-                wc_b = c.world_com(body_b);
-                m_inv_b = c.inv_mass(body_b);
-                omega_b = c.body_w(body_b);
-            }
-            auto wq_a = [&](vec3 v) { return body_a >= 0 ? c.w_quad(body_a, v) : 0.0f; };
-            auto wq_b = [&](vec3 v) { return body_b >= 0 ? c.w_quad(body_b, v) : 0.0f; };
-            int mat_nonzero = 0;
-            float mu = 0.0f, mu_torsional = 0.0f, mu_rolling = 0.0f;
-            if (shape_a >= 0) {
-                mat_nonzero += 1;
-                mu += c.shape_f(shape_a, SP_MU);
-                mu_torsional += c.shape_f(shape_a, SP_MU_TORSIONAL);
-                mu_rolling += c.shape_f(shape_a, SP_MU_ROLLING);
-            }
-            if (shape_b >= 0) {
-                mat_nonzero += 1;
-                mu += c.shape_f(shape_b, SP_MU);
-                mu_torsional += c.shape_f(shape_b, SP_MU_TORSIONAL);
-                mu_rolling += c.shape_f(shape_b, SP_MU_ROLLING);
-            }
-            if (mat_nonzero > 0) {
-                mu /= float(mat_nonzero);
-                mu_torsional /= float(mat_nonzero);
-                mu_rolling /= float(mat_nonzero);
-            }
-            vec3 r_a = bx_a - wc_a;
-            vec3 r_b = bx_b - wc_b;
-            vec3 angular_a = -cross(r_a, n);
-            vec3 angular_b = cross(r_b, n);
-
-            float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, wq_a(angular_a), wq_b(angular_b), relaxation, dt);
-            lin_delta_a = -n * lambda_n;
-            lin_delta_b = n * lambda_n;
-            ang_delta_a = angular_a * lambda_n;
-            ang_delta_b = angular_b * lambda_n;
-
-            if (mu > 0.0f) {
-                vec3 offset_a = c.gv3(D, CD_OFFSET0, ncs, slot), offset_b = c.gv3(D, CD_OFFSET1, ncs, slot);
-                bx_a = xform_point(X_wb_a, point0 + offset_a);
-                bx_b = xform_point(X_wb_b, point1 + offset_b);
-                vec3 delta = bx_b - bx_a;
-                vec3 friction_delta = delta - dot(n, delta) * n;
-                r_a = bx_a - wc_a;
-                r_b = bx_b - wc_b;
-                vec3 rel_v_kin_t(0.0f);
-                if (body_a >= 0 && (c.T.body_flags[body_a] & BODY_KINEMATIC) != 0) {
-                    vec3 v_a = velocity_at_point(spatial(c.body_v(body_a), omega_a), r_a);
-                    rel_v_kin_t = rel_v_kin_t - (v_a - dot(n, v_a) * n);
-                }
-                if (body_b >= 0 && (c.T.body_flags[body_b] & BODY_KINEMATIC) != 0) {
-                    vec3 v_b = velocity_at_point(spatial(c.body_v(body_b), omega_b), r_b);
-                    rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
-                }
-                friction_delta += rel_v_kin_t * dt;
-                vec3 perp = normalize(friction_delta);
-                angular_a = -cross(r_a, perp);
-                angular_b = cross(r_b, perp);
-                float err = length(friction_delta);
-                if (err > 0.0f) {
-                    float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, wq_a(angular_a),
-                                                               wq_b(angular_b), relaxation, dt);
-                    lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
-                    lin_delta_a -= perp * lambda_fr;
-                    lin_delta_b += perp * lambda_fr;
-                    ang_delta_a += angular_a * lambda_fr;
-                    ang_delta_b += angular_b * lambda_fr;
-                }
-            }
-            vec3 delta_omega = omega_b - omega_a;
-            if (mu_torsional > 0.0f) {
-                float err = dot(delta_omega, n) * dt;
-                if (fabsf(err) > 0.0f) {
-                    vec3 lin(0.0f);
-                    float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-n), wq_b(n), relaxation, dt);
-                    lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
-                    ang_delta_a -= n * lt;
-                    ang_delta_b += n * lt;
-                }
-            }
-            if (mu_rolling > 0.0f) {
-                delta_omega -= dot(n, delta_omega) * n;
-                float err = length(delta_omega) * dt;
-                if (err > 0.0f) {
-                    vec3 lin(0.0f);
-                    vec3 roll_n = normalize(delta_omega);
-                    float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-roll_n), wq_b(roll_n), relaxation, dt);
-                    lr = fmaxw(lr, -lambda_n * mu_rolling);
-                    ang_delta_a -= roll_n * lr;
-                    ang_delta_b += roll_n * lr;
-                }
-            }
-            has_a = body_a >= 0 ? 1.0f : 0.0f;
-            has_b = body_b >= 0 ? 1.0f : 0.0f;
-            a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
-        }
+    if (live && contact_solve(c, SlotRecord<EPB>{c, ct.data, ncs, slot}, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a,
+                              ang_delta_b)) {
+        has_a = body_a >= 0 ? 1.0f : 0.0f;
+        has_b = body_b >= 0 ? 1.0f : 0.0f;
+        a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
     }
     // lin_delta_b == -lin_delta_a bit for bit (IEEE negation commutes with every rounding above), so only one is stored
     cw_st3<CW, NC_CWX>(c, 0, ncs, slot, lin_delta_a);
     cw_st3<CW, NC_CWX>(c, CWX_ANG_A, ncs, slot, ang_delta_a);
     cw_st3<CW, NC_CWX>(c, CWX_ANG_B, ncs, slot, ang_delta_b);
     CW::template at<NC_CWX>(c, CWX_FLAGS, ncs, slot) = has_a + 2.0f * has_b + 4.0f * a_is_pair_a;
+}
+// The same solve for a row of the SDF legs (nt_contacts.flat): the record goes to flat.cw[row][10] (lin_a, ang_a, ang_b,
+// flags: bit 0 the row corrects shape0's body, bit 1 shape1's body).  The launch-by-launch step kernels only.
+template <int EPB>
+NT_DI void flat_contact_item(const Ctx<EPB>& c, const int r) {
+    const nt_flat_rows& f = c.a.ct.flat;
+    float flags = 0.0f;
+    vec3 lin_delta_a, ang_delta_a, ang_delta_b;
+    const int gid_a = f.shape0[r], gid_b = f.shape1[r];
+    if (gid_a != gid_b) {
+        const int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1, shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+        const int body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1, body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
+        if (body_a != body_b &&
+            contact_solve(c, FlatRecord{f, r}, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b))
+            flags = (body_a >= 0 ? 1.0f : 0.0f) + (body_b >= 0 ? 2.0f : 0.0f);
+    }
+    float* o = f.cw + CWX_FLOATS * (size_t)r;
+    o[0] = lin_delta_a.x; o[1] = lin_delta_a.y; o[2] = lin_delta_a.z;
+    o[CWX_ANG_A] = ang_delta_a.x; o[CWX_ANG_A + 1] = ang_delta_a.y; o[CWX_ANG_A + 2] = ang_delta_a.z;
+    o[CWX_ANG_B] = ang_delta_b.x; o[CWX_ANG_B + 1] = ang_delta_b.y; o[CWX_ANG_B + 2] = ang_delta_b.z;
+    o[CWX_FLAGS] = flags;
 }
 // flags of an XPBD correction record: does it touch the body on `side` of its pair (0: owner of pair_a's shape), and as
 // the contact's shape0 ("a") or shape1?
@@ -411,6 +466,9 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
         }
     } else {
         for (int s = c.slot; s < np * cpp; s += c.nslot) contact_item<EPB, FUSED, CW>(c, s);
+        if (const nt_flat_rows& f = c.a.ct.flat; f.row_start)  // rows of the SDF legs, appended after the slots like the
+            for (int r = f.row_start[c.env] + c.slot; r < f.row_start[c.env + 1]; r += c.nslot)  // reference's later launches
+                flat_contact_item(c, r);
     }
 }
 
@@ -441,6 +499,24 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
                     dlin += sd.is_a ? lin : -lin;
                     dang += cw_v3<CW, NC_CWX>(c, sd.is_a ? CWX_ANG_A : CWX_ANG_B, ncs, slot);
                     inv_weight += 1.0f;
+                }
+            }
+        }
+        if constexpr (!FUSED) {
+            if (const nt_flat_rows& f = c.a.ct.flat; f.row_start) {  // then the SDF legs' rows, ascending row order
+                const int* bs = f.body_blk_start + (size_t)c.env * (nb + 1) + b;
+                for (int i = bs[0]; i < bs[1]; ++i) {
+                    const int code = f.body_blk_list[2 * (size_t)i], count = f.body_blk_list[2 * (size_t)i + 1];
+                    const int r0 = code >> 1, side = code & 1;
+                    for (int r = r0; r < r0 + count; ++r) {
+                        const float* w = f.cw + CWX_FLOATS * (size_t)r;
+                        if (((int)w[CWX_FLAGS] & (side ? 2 : 1)) == 0) continue;
+                        const vec3 lin(w[0], w[1], w[2]);
+                        const float* a = w + (side ? CWX_ANG_B : CWX_ANG_A);
+                        dlin += side ? -lin : lin;
+                        dang += vec3(a[0], a[1], a[2]);
+                        inv_weight += 1.0f;
+                    }
                 }
             }
         }
@@ -1036,7 +1112,8 @@ __device__ unsigned long long nt_phase_clock[32];
 // ------------------------------------------------------------------------------------------------
 template <int EPB, bool CVX>
 NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
-    if (c.a.debug_skip & 1) return;
+    NT_SKIP_DECL(c.a);
+    if (NT_SKIP(1)) return;
     const bool compact = pairs_compacted(c);
     if (compact && c.valid && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0)) = 0;
     phase_shapes(c);
@@ -1074,14 +1151,14 @@ NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
 template <int EPB, bool FUSED, class CW = CwLds, bool PROLOGUE_DONE = false>
 NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
-    const int skip = c.a.debug_skip;
+    NT_SKIP_DECL(c.a);
     const bool restitution = c.a.p.enable_restitution && c.a.has_contacts;
     const bool vel_from_delta = c.a.p.compute_body_velocity_from_position_delta != 0;
     if (!PROLOGUE_DONE && (restitution || vel_from_delta) && c.valid)  // body_q_init / body_qd_init: the state the step starts from
         for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
     const bool rep_joints = !FUSED && c.a.rep.joint_impulse != nullptr;
     const bool rep_contacts = !FUSED && c.a.rep.contact_impulse != nullptr && c.a.has_contacts;
-    if (!PROLOGUE_DONE && !(skip & 2)) {
+    if (!PROLOGUE_DONE && !NT_SKIP(2)) {
         phase_joint_forces(c, forces_are_zero);
         __syncthreads();
         NT_TICK(3);
@@ -1092,20 +1169,20 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
     for (int it = 0; it < c.a.p.iterations; ++it) {
         if (c.a.has_contacts) {
-            if (!(skip & 4)) phase_contacts<EPB, FUSED, CW>(c);
+            if (!NT_SKIP(4)) phase_contacts<EPB, FUSED, CW>(c);
             __syncthreads();
             NT_TICK(5);
             if (rep_contacts) report_contact_iteration<EPB, CW>(c, it == 0);
-            if (!(skip & 16)) phase_apply<EPB, true, CW, FUSED>(c);
+            if (!NT_SKIP(16)) phase_apply<EPB, true, CW, FUSED>(c);
             __syncthreads();
             NT_TICK(6);
         }
         if (m.nj > 0) {
-            if (!(skip & 8)) phase_joints(c);
+            if (!NT_SKIP(8)) phase_joints(c);
             __syncthreads();
             NT_TICK(7);
             if (rep_joints) report_joint_iteration(c);
-            if (!(skip & 16)) phase_apply<EPB, false>(c);
+            if (!NT_SKIP(16)) phase_apply<EPB, false>(c);
             __syncthreads();
             NT_TICK(8);
         }
@@ -1152,7 +1229,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
 template <int EPB, bool CVX>
 NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     const nt_model& m = c.a.m;
-    const int skip = c.a.debug_skip;
+    NT_SKIP_DECL(c.a);
     const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;  // slots per wave
     const bool restitution = (c.a.p.enable_restitution && c.a.has_contacts) || c.a.p.compute_body_velocity_from_position_delta != 0;
     // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
@@ -1161,20 +1238,20 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
         if (compact && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0)) = 0;
         if (restitution)
             for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
-        if (!(skip & 2)) seed_body_forces(c, true);
+        if (!NT_SKIP(2)) seed_body_forces(c, true);
         const int S0 = ((m.ns + spw - 1) / spw) * spw;
         for (int i = c.slot; i < S0 + m.nj; i += c.nslot) {
             if (i < m.ns) {
-                if (!(skip & 1)) shape_item(c, i);
+                if (!NT_SKIP(1)) shape_item(c, i);
             } else if (i >= S0) {
-                if (!(skip & 2)) joint_force_item(c, i - S0);
+                if (!NT_SKIP(2)) joint_force_item(c, i - S0);
             }
         }
     }
     __syncthreads();
     NT_TICK(1);
     // -- interval 2: one lane per candidate pair (broad phase test, primitive pair / MPR-GJK manifold, admission)
-    if (!(skip & 1)) {
+    if (!NT_SKIP(1)) {
         if (compact) {
             phase_pair_broad_staged(c);
             __syncthreads();
@@ -1186,7 +1263,7 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
     __syncthreads();
     NT_TICK(2);
     // -- interval 3: contact records of the analytic pairs (one lane per slot) || live-contact prefix (few lanes per env)
-    if (!(skip & 1) && c.valid) {
+    if (!NT_SKIP(1) && c.valid) {
         const int nas = m.np_analytic * m.cpp;
         const int P0 = ((nas + spw - 1) / spw) * spw;
         const bool one_level = m.np <= 64;
@@ -1201,13 +1278,13 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
         }
     }
     __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
-    if (!(skip & 1) && m.np > 64) {
+    if (!NT_SKIP(1) && m.np > 64) {
         phase_pair_prefix_scan(c, c.L.sx.off, last_substep, false);
         __syncthreads();
     }
     NT_TICK(3);
     // -- interval 4: integrate_bodies
-    if (!(skip & 2)) phase_integrate<EPB, false>(c);
+    if (!NT_SKIP(2)) phase_integrate<EPB, false>(c);
     __syncthreads();
     NT_TICK(4);
     do_xpbd_step<EPB, true, CwLds, true>(c, true);
@@ -1221,6 +1298,18 @@ __global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     load_params(c, false);
     __syncthreads();
     do_collide<EPB, CVX>(c, true);
+}
+
+// compute_shape_aabbs alone (models whose every pair belongs to a stage outside the tiles: the launch only exports
+// nt_contacts.world_xform / world_aabb_*)
+template <int EPB>
+__global__ void __launch_bounds__((EPB & 255) <= 8 ? 256 : 512) shapes_export_kernel(KArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    Ctx<EPB> c(a, lds, -1, false);
+    load_state(c, a.s_in);
+    load_params(c, false);
+    __syncthreads();
+    phase_shapes(c);
 }
 
 template <int EPB, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>

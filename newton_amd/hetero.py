@@ -228,6 +228,18 @@ class _Composite:
             setattr(c, name, v)
 
 
+def _split_world_mask(world_mask, groups):
+    """Per-group pieces of a world mask of length world_count or the reference's world_count + 1 (trailing global-entity
+    slot, core/reset.py:13-60); None stays None."""
+    if world_mask is None:
+        return None
+    sizes = [e - b for b, e in groups.ranges]
+    n = int(world_mask.shape[0]) if hasattr(world_mask, "shape") else len(world_mask)
+    if n not in (sum(sizes), sum(sizes) + 1):
+        raise ValueError(f"'world_mask' length {n} must equal model.world_count + 1 ({sum(sizes) + 1})")
+    return _split(world_mask[: sum(sizes)], sizes)
+
+
 def _composite_property(name):
     return property(lambda self: self._get(name), lambda self, v: self._set(name, v))
 
@@ -275,6 +287,12 @@ def _make_state_classes():
             for c, o in zip(self.parts, other.parts):
                 c.assign(o)
 
+        def reset(self, source, world_mask=None):
+            """State.reset over the groups (solver.py:344-375): the mask is cut at the group boundaries."""
+            masks = _split_world_mask(world_mask, self.groups)
+            for i, (c, o) in enumerate(zip(self.parts, source.parts)):
+                c.reset(o, None if masks is None else masks[i])
+
     class GroupedControl(_Composite):
         """Control of a heterogeneous model (control.py:31-68)."""
 
@@ -309,16 +327,24 @@ class GroupedContacts:
         dev = parts[0]._shape0.device
         self._analytic = torch.from_numpy(tab).to(dev)
         self._types = [torch.as_tensor(np.asarray(c.model.shape_type), dtype=torch.int64, device=dev) for c in parts]
+        self._gids = [torch.as_tensor(np.asarray(c.model._global_shape_ids), dtype=torch.int64, device=dev) for c in parts]
+        self._seg_cache = (None, None)  # (generations, segments): one host sync per group and per collide, not per field read
+        self._row_cache = {}
 
     def _segments(self):
         """Per group (row count, analytic row count) of its current export."""
         torch = _torch()
+        gen = tuple(c._generation for c in self.parts)
+        if self._seg_cache[0] == gen:
+            return self._seg_cache[1]
         seg = []
         for c, ty in zip(self.parts, self._types):
             n = min(int(c.rigid_contact_count.cpu().numpy()[0]), c.rigid_contact_max)
             a, b = c.rigid_contact_shape0[:n].to(torch.int64), c.rigid_contact_shape1[:n].to(torch.int64)
             na = int(self._analytic[ty[a], ty[b]].sum().item()) if n and not c.sort_by_key else n
             seg.append((n, na))
+        self._seg_cache = (gen, seg)
+        self._row_cache = {}
         return seg
 
     @property
@@ -326,21 +352,26 @@ class GroupedContacts:
         torch = _torch()
         return torch.stack([c.rigid_contact_count.reshape(-1)[0] for c in self.parts]).sum().reshape(1).to(torch.int32)
 
-    def _rows(self, get, translate=False):
+    def _rows(self, get, translate=False, key=None):
         torch = _torch()
+        seg = self._segments()
+        if key is not None and key in self._row_cache:
+            return self._row_cache[key]
         first, second = [], []
-        for c, (n, na) in zip(self.parts, self._segments()):
+        for c, ids, (n, na) in zip(self.parts, self._gids, seg):
             v = get(c)[:n]
             if translate:
-                ids = torch.as_tensor(c.model._global_shape_ids, dtype=torch.int64, device=v.device)
                 v = ids[v.to(torch.int64)].to(torch.int32)
             first.append(v[:na])
             second.append(v[na:])
-        return torch.cat(first + second)
+        out = torch.cat(first + second)
+        if key is not None:
+            self._row_cache[key] = out
+        return out
 
     @staticmethod
     def _field(name, translate=False):
-        return property(lambda self: self._rows(lambda c: getattr(c, name), translate))
+        return property(lambda self: self._rows(lambda c: getattr(c, name), translate, key=name))
 
     @property
     def rigid_contact_count_per_env(self):
@@ -371,6 +402,12 @@ class GroupedCollisionPipeline:
         self.groups: WorldGroups = model.world_groups
         if kwargs.get("rigid_contact_max") is not None:
             raise NotImplementedError("heterogeneous worlds: rigid_contact_max is derived per world group")
+        # a group's sorted export is group-local: with a world -1 shape (ground plane) in the pairs its rows would sit inside
+        # every group instead of in one global (shape0, shape1) block, and match indices would be group-local row numbers
+        for opt, off in (("deterministic", False), ("contact_matching", "disabled"), ("contact_report", False)):
+            if kwargs.get(opt, off) != off:
+                raise NotImplementedError(f"heterogeneous worlds: CollisionPipeline({opt}=...) is not supported; build the worlds "
+                                          "with one topology (ModelBuilder.replicate) to use it")
         self.groups.sync_host()
         self.parts = [cls(p, **kwargs) for p in self.groups.parts]
         self.deterministic = self.parts[0].deterministic
@@ -383,10 +420,9 @@ class GroupedCollisionPipeline:
         return GroupedContacts(self.model, [p.contacts(**kwargs) for p in self.parts])
 
     def reset_contact_matching(self, world_mask=None):
-        if world_mask is not None:
-            masks = _split(world_mask, [e - b for b, e in self.groups.ranges])
+        masks = _split_world_mask(world_mask, self.groups)
         for i, p in enumerate(self.parts):
-            p.reset_contact_matching(None if world_mask is None else masks[i])
+            p.reset_contact_matching(None if masks is None else masks[i])
 
     def collide(self, state, contacts, **kwargs):
         self.groups.run(lambda i, _p: self.parts[i].collide(state.parts[i], contacts.parts[i], **kwargs))
@@ -434,6 +470,6 @@ class GroupedSolver:
             s.notify_model_changed(flags)
 
     def reset(self, state, world_mask=None, flags=None):
-        masks = None if world_mask is None else _split(world_mask, [e - b for b, e in self.groups.ranges])
+        masks = _split_world_mask(world_mask, self.groups)
         for i, s in enumerate(self.parts):
             s.reset(state.parts[i], None if masks is None else masks[i], flags)

@@ -37,12 +37,42 @@ class Mesh:
         self.is_solid = is_solid
         self.maxhullvert = maxhullvert
         self.has_inertia = False
+        self.sdf = None        # TextureSDF attached by build_sdf()
+        self.sdf_scale = None  # the scale baked into it (None: unbaked)
         self.mass, self.com, self.inertia = 1.0, np.zeros(3), np.eye(3)
         if compute_inertia:
             if not is_solid:
                 raise NotImplementedError("hollow meshes are not supported")
             self.mass, self.com, self.inertia = solid_mesh_mass_properties(self.vertices, self.indices)
             self.has_inertia = True
+
+    def build_sdf(self, *, device=None, narrow_band_range=None, target_voxel_size=None, max_resolution=None, margin=None,
+                  shape_margin: float = 0.0, scale=None, texture_format: str = "uint16", **unsupported):
+        """Build and attach the sparse texture SDF of this mesh (Mesh.build_sdf, geometry/types.py:820-1010): what
+        ModelBuilder.finalize() registers in Model._texture_sdf_data for every shape that uses the mesh, which routes its pairs
+        with other SDF shapes through the mesh-SDF narrow phase.  Host construction (newton_amd.sdf); `scale` bakes a shape
+        scale into the grid.  The reference's edge simplification options and on-disk cache are not offered."""
+        from . import sdf as S  # noqa: PLC0415
+
+        unsupported = {k: v for k, v in unsupported.items() if k not in ("sign_method", "paired_samples") or v not in ("auto", True)}
+        if unsupported or shape_margin != 0.0:
+            raise NotImplementedError(f"Mesh.build_sdf options not supported: {sorted(unsupported) or ['shape_margin']}")
+        fmt = {"float32": S.QuantizationMode.FLOAT32, "uint16": S.QuantizationMode.UINT16, "uint8": S.QuantizationMode.UINT8}
+        if texture_format not in fmt:
+            raise ValueError(f"Unknown texture_format {texture_format!r}. Expected one of {list(fmt)}.")
+        if max_resolution is not None and max_resolution % 8 != 0:
+            raise ValueError(f"max_resolution must be divisible by 8 (got {max_resolution}).")
+        if max_resolution is None and target_voxel_size is None:
+            max_resolution = 64
+        sc = (1.0, 1.0, 1.0) if scale is None else tuple(float(x) for x in scale)
+        v = np.asarray(self.vertices, dtype=np.float64) * np.asarray(sc, dtype=np.float64)
+        self.sdf = S.create_texture_sdf_from_mesh(v, np.asarray(self.indices).reshape(-1, 3), margin=0.05 if margin is None else margin,
+                                                  narrow_band_range=narrow_band_range or (-0.1, 0.1), max_resolution=max_resolution,
+                                                  target_voxel_size=target_voxel_size, quantization_mode=fmt[texture_format],
+                                                  scale_baked=scale is not None)
+        self.sdf_scale = sc if scale is not None else None
+        self.sdf._construction_padding = 0.05 if margin is None else margin
+        return self.sdf
 
     @staticmethod
     def create_box(hx: float, hy: float, hz: float, *, duplicate_vertices: bool = False, compute_normals: bool = False,

@@ -209,6 +209,29 @@ class EnvTemplate:
         else:
             self.pair_a = np.zeros(0, dtype=np.int32)
             self.pair_b = np.zeros(0, dtype=np.int32)
+        # Pairs whose two shapes carry a texture SDF and collision edges (not box-box) leave the primitive / GJK-MPR path: the
+        # reference routes them to its mesh-mesh SDF kernel (narrow_phase.py:620-640).  They are not tile pairs; the pipeline's
+        # SDF leg walks them per world (newton_amd/sdf_pipeline.py), in ascending Newton (shape0, shape1) order.
+        n_all = len(np.asarray(m.shape_type))
+        sdf_idx = np.asarray(getattr(m, "_shape_sdf_index", None) if getattr(m, "_shape_sdf_index", None) is not None
+                             else -np.ones(n_all), dtype=np.int32)
+        e_rng = np.asarray(getattr(m, "shape_edge_range", None) if getattr(m, "shape_edge_range", None) is not None
+                           else np.zeros((n_all, 2)), dtype=np.int32).reshape(n_all, 2)
+        self.shape_sdf_index = shape_uniform(sdf_idx, "shape SDF index")
+        self.shape_edge_count = shape_uniform(e_rng[:, 1], "shape collision-edge count")
+        has_sdf = (self.shape_sdf_index >= 0) & (self.shape_edge_count > 0)
+        is_sdf_pair = np.array([has_sdf[a] and has_sdf[b] and not (self.shape_type[a] == GeoType.BOX and self.shape_type[b] == GeoType.BOX)
+                                for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
+
+        def newton_id0(l):  # Newton id of template shape l in world 0 (the order is the same in every world)
+            return L0 + l if l < ns else int(shape_glob[l - ns])
+
+        sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b))
+              for a, b in zip(self.pair_a[is_sdf_pair], self.pair_b[is_sdf_pair])]
+        sp.sort()
+        self.sdf_pair = np.asarray([[a, b] if newton_id0(a) < newton_id0(b) else [b, a] for _, _, a, b in sp], dtype=np.int32).reshape(-1, 2)
+        self.tile_pair_index = np.flatnonzero(~is_sdf_pair)  # positions of the tile pairs in one world's shape_contact_pairs slice
+        self.pair_a, self.pair_b = self.pair_a[~is_sdf_pair], self.pair_b[~is_sdf_pair]
         self.np = len(self.pair_a)
 
         # The reference writes analytic-primitive contacts in its first narrow-phase kernel and queues every other

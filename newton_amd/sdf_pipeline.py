@@ -1,0 +1,201 @@
+"""The mesh-SDF leg of CollisionPipeline.collide (newton/_src/sim/collide.py:1999 -> geometry/narrow_phase.py:2838-3167 ->
+sdf_contact.py:1534-1990): shape pairs whose two shapes carry a texture SDF and collision edges go through the edge-vs-SDF narrow
+phase with the global contact reduction, and their contacts are appended after the primitive / GJK-MPR ones.
+
+Device stages (csrc/nt_sdf_pipeline.hip, csrc/nt_sdf.hip), all on the caller's stream, nothing returns to the host:
+
+    nt_collide               exports world transforms + gap-widened AABBs of every shape (the tile kernel's compute_shape_aabbs)
+    nt_sdf_candidate_pairs   per world: ordered compaction of the world's SDF pair list against those AABBs + scan over worlds
+    nt_mesh_sdf_collide_reduced   one workgroup per candidate pair: edges vs SDF both ways, 245-slot reduction table in LDS
+    nt_sdf_rows_finalize     final row ranges (world-major, pairs ascending, fingerprint order), write_contact, per-body row blocks
+
+The rows live in ``FlatRows`` (owned by the Contacts object): Newton's flat contact arrays, deterministic -- two runs give
+bit-identical rows -- and consumable by SolverXPBD (inside the step kernel) and SolverSemiImplicit / SolverFeatherstone
+(nt_flat_rows_forces: ordered per-body sums, no float atomics)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .enums import GeoType
+
+
+def _torch():
+    import torch  # noqa: PLC0415
+
+    return torch
+
+
+def model_has_sdf_pairs(model) -> bool:
+    return len(getattr(model.env, "sdf_pair", ())) > 0
+
+
+class FlatRows:
+    """Contact rows outside the fixed slots (nt_flat_rows): Newton's AoS arrays + per-world ranges + per-body row blocks."""
+
+    def __init__(self, model, capacity: int, pairs_per_world: int, per_contact_shape_properties: bool = False):
+        torch = _torch()
+        t = model.env
+        dev = model.device_model().device
+        i32, f32 = torch.int32, torch.float32
+        self.capacity = c = int(capacity)
+        self.row_start = torch.zeros(t.env_count + 1, dtype=i32, device=dev)
+        self.shape0 = torch.full((c,), -1, dtype=i32, device=dev)
+        self.shape1 = torch.full((c,), -1, dtype=i32, device=dev)
+        self.point0, self.point1, self.offset0, self.offset1, self.normal = (torch.zeros((c, 3), dtype=f32, device=dev) for _ in range(5))
+        self.margin0, self.margin1 = torch.zeros(c, dtype=f32, device=dev), torch.zeros(c, dtype=f32, device=dev)
+        self.key = torch.zeros(c, dtype=i32, device=dev)
+        self.stiffness = self.damping = self.friction_scale = None
+        if per_contact_shape_properties:
+            self.stiffness, self.damping, self.friction_scale = (torch.zeros(c, dtype=f32, device=dev) for _ in range(3))
+        self.body_blk_start = torch.zeros(t.env_count * (t.nb + 1), dtype=i32, device=dev)
+        self.body_blk_list = torch.zeros((t.env_count * 2 * pairs_per_world, 2), dtype=i32, device=dev)
+        self.cw = torch.zeros((c, 10), dtype=f32, device=dev)
+
+    def desc(self) -> _lib.nt_flat_rows:
+        d = _lib.nt_flat_rows()
+        for k in ("row_start", "shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1",
+                  "body_blk_start", "body_blk_list", "cw"):
+            setattr(d, k, getattr(self, k).data_ptr())
+        if self.stiffness is not None:
+            d.stiffness, d.damping, d.friction_scale = (self.stiffness.data_ptr(), self.damping.data_ptr(),
+                                                        self.friction_scale.data_ptr())
+        return d
+
+
+class SdfLeg:
+    """Model-level tables + per-pipeline work buffers of the mesh-SDF leg."""
+
+    def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64):
+        from .sdf_device import DeviceSDF  # noqa: PLC0415
+
+        torch = _torch()
+        self.model = model
+        dm = self.dm = model.device_model()
+        self.lib = dm.lib
+        dev = self.device = dm.device
+        t = self.t = model.env
+        S = model.shape_count
+        self.threads = int(threads)
+
+        def up(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            return torch.from_numpy(a if a.size else np.zeros(1, dtype=dtype)).to(dev)
+
+        # shapes of one world that take part (for the capacities)
+        used = np.unique(t.sdf_pair.reshape(-1))
+        n_shapes = max(int((used < t.ns).sum()), 1)
+        self.pairs_per_world = int(min(len(t.sdf_pair), max(16, n_shapes * int(pairs_per_shape))))
+        self.rows_per_world = int(max(64, n_shapes * int(contacts_per_shape)))
+        E, PPW = t.env_count, self.pairs_per_world
+        self.row_capacity = E * self.rows_per_world
+        # Newton-id tables
+        scale = np.asarray(model.shape_scale, np.float32)
+        self._shape_data = up(np.concatenate([scale, np.asarray(model.shape_margin, np.float32)[:, None]], axis=1), np.float32)
+        self._shape_gap = up(model.shape_gap, np.float32)
+        self._sdf_index = up(model._shape_sdf_index, np.int32)
+        self._edge_range = up(model.shape_edge_range, np.int32)
+        self._edge_centers, self._edge_halves = up(model.mesh_edge_centers, np.float32), up(model.mesh_edge_halves, np.float32)
+        self._sdfs = [DeviceSDF(s, device=dev) for s in model._texture_sdf_data]
+        table = (_lib.nt_sdf * max(len(self._sdfs), 1))()
+        for k, s in enumerate(self._sdfs):
+            table[k] = s.desc
+        self._sdf_table = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(dev)
+        self._red_lo, self._red_hi = up(model.shape_collision_aabb_lower, np.float32), up(model.shape_collision_aabb_upper, np.float32)
+        self._red_res = up(model._shape_voxel_resolution, np.int32)
+        mat = np.stack([np.asarray(getattr(model, "shape_material_" + k), np.float32) for k in ("ke", "kd", "kf", "ka", "mu")], axis=1)
+        self._material = up(mat, np.float32)
+        # scene (template) tables
+        self._template_pair = up(t.sdf_pair, np.int32)
+        self._gshape_id = up(t.gshape_id, np.int32)
+        self._shape_body = up(t.shape_body[: t.ns], np.int32)
+        sc = _lib.nt_sdf_scene()
+        sc.env_count, sc.env_stride, sc.nb, sc.ns, sc.shape_local0 = E, t.env_stride, t.nb, t.ns, t.shape_local0
+        sc.template_pairs, sc.template_pair = len(t.sdf_pair), self._template_pair.data_ptr()
+        sc.gshape_id, sc.shape_body, sc.shape_gap = self._gshape_id.data_ptr(), self._shape_body.data_ptr(), self._shape_gap.data_ptr()
+        sc.pairs_per_world = PPW
+        self.scene = sc
+        # work buffers
+        i32, f32 = torch.int32, torch.float32
+        self.world_xform = torch.zeros((S, 7), dtype=f32, device=dev)
+        self.aabb_lower, self.aabb_upper = torch.zeros((S, 3), dtype=f32, device=dev), torch.zeros((S, 3), dtype=f32, device=dev)
+        self.world_pairs = torch.zeros((E * PPW, 2), dtype=i32, device=dev)
+        self.pair_count = torch.zeros(E, dtype=i32, device=dev)
+        self.pair_prefix = torch.zeros(E + 1, dtype=i32, device=dev)
+        self.blk = torch.zeros((E * PPW, 2), dtype=i32, device=dev)
+        self.pair_row = torch.zeros(E * PPW, dtype=i32, device=dev)
+        self.world_rows = torch.zeros(E, dtype=i32, device=dev)
+        self.raw_count = torch.zeros(1, dtype=i32, device=dev)
+        self.raw_pair = torch.zeros(self.row_capacity, dtype=i32, device=dev)
+        self.raw_key = torch.zeros(self.row_capacity, dtype=i32, device=dev)
+        self.raw_data = torch.zeros((self.row_capacity, 9), dtype=f32, device=dev)
+
+    def new_rows(self, per_contact_shape_properties: bool = False) -> FlatRows:
+        return FlatRows(self.model, self.row_capacity, self.pairs_per_world, per_contact_shape_properties)
+
+    def export_pointers(self, d: _lib.nt_contacts) -> None:
+        """Ask nt_collide for the shapes' world transforms and AABBs."""
+        d.world_xform, d.world_aabb_lower, d.world_aabb_upper = (self.world_xform.data_ptr(), self.aabb_lower.data_ptr(),
+                                                                 self.aabb_upper.data_ptr())
+
+    def collide(self, state, rows: FlatRows, stream) -> None:
+        """Candidate pairs -> narrow phase + reduction -> final rows.  nt_collide has run on `state` (world_xform / AABBs)."""
+        lib, sc = self.lib, self.scene
+        _lib.check(lib.nt_sdf_candidate_pairs(C.byref(sc), self.aabb_lower.data_ptr(), self.aabb_upper.data_ptr(),
+                                              self.world_pairs.data_ptr(), self.pair_count.data_ptr(), self.pair_prefix.data_ptr(),
+                                              stream), "nt_sdf_candidate_pairs")
+        self.raw_count.zero_()
+        a = _lib.nt_mesh_sdf_args()
+        a.pairs, a.pair_count = self.world_pairs.data_ptr(), int(self.world_pairs.shape[0])
+        a.shape_transform, a.shape_data, a.shape_gap = self.world_xform.data_ptr(), self._shape_data.data_ptr(), self._shape_gap.data_ptr()
+        a.shape_sdf_index, a.sdf_table, a.sdf_count = self._sdf_index.data_ptr(), self._sdf_table.data_ptr(), len(self._sdfs)
+        a.shape_edge_range, a.edge_centers, a.edge_halves = (self._edge_range.data_ptr(), self._edge_centers.data_ptr(),
+                                                             self._edge_halves.data_ptr())
+        a.out_count, a.out_pair, a.out_key, a.out_data = (self.raw_count.data_ptr(), self.raw_pair.data_ptr(),
+                                                          self.raw_key.data_ptr(), self.raw_data.data_ptr())
+        a.capacity = self.row_capacity
+        a.pair_world_prefix, a.worlds, a.pairs_per_world, a.out_blk = (self.pair_prefix.data_ptr(), sc.env_count,
+                                                                       sc.pairs_per_world, self.blk.data_ptr())
+        r = _lib.nt_contact_reduce_shapes()
+        r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = self._red_lo.data_ptr(), self._red_hi.data_ptr(), self._red_res.data_ptr()
+        r.threads = self.threads
+        _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
+        io = _lib.nt_sdf_rows_io()
+        io.pair_count, io.world_pairs, io.blk, io.pair_row = (self.pair_count.data_ptr(), self.world_pairs.data_ptr(),
+                                                              self.blk.data_ptr(), self.pair_row.data_ptr())
+        io.row_start, io.raw_count, io.raw_pair, io.raw_key, io.raw_data = (rows.row_start.data_ptr(), self.raw_count.data_ptr(),
+                                                                            self.raw_pair.data_ptr(), self.raw_key.data_ptr(),
+                                                                            self.raw_data.data_ptr())
+        io.raw_capacity, io.row_capacity = self.row_capacity, rows.capacity
+        for k in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1", "key"):
+            setattr(io, k, getattr(rows, k).data_ptr())
+        _lib.check(lib.nt_sdf_rows_finalize(C.byref(sc), C.byref(io), state._soa["body_q"].data_ptr(), self.world_rows.data_ptr(),
+                                            rows.body_blk_start.data_ptr(), rows.body_blk_list.data_ptr(), stream),
+                   "nt_sdf_rows_finalize")
+
+    def overflow(self, rows: FlatRows) -> dict:
+        """Host check (tests / benches, synchronises): did any world exceed its candidate capacity, or the rows their buffer?"""
+        pc = int(self.pair_count.max().item()) if self.pair_count.numel() else 0
+        raw, total = int(self.raw_count.item()), int(rows.row_start[-1].item())
+        return {"pairs_per_world_max": pc, "pairs_per_world_capacity": self.pairs_per_world, "raw_rows": raw, "rows": total,
+                "row_capacity": rows.capacity, "overflow": pc > self.pairs_per_world or raw > self.row_capacity or total > rows.capacity}
+
+    def add_forces(self, state, rows: FlatRows, body_f, friction_smoothing: float, stream) -> None:
+        """eval_body_contact over the rows, ordered per-body sums ADDED to `body_f` (env-major [6][nb][ES])."""
+        p = _lib.nt_flat_force_params()
+        p.body_q, p.body_qd = state._soa["body_q"].data_ptr(), state._soa["body_qd"].data_ptr()
+        p.body_com = self.dm.params["body_param"].data_ptr()
+        p.shape_material, p.friction_smoothing, p.body_f = self._material.data_ptr(), float(friction_smoothing), body_f.data_ptr()
+        d = rows.desc()
+        _lib.check(self.lib.nt_flat_rows_forces(C.byref(self.scene), C.byref(d), C.byref(p), stream), "nt_flat_rows_forces")
+
+
+def sdf_pair_shape_types_ok(model) -> None:
+    """The SDF leg handles MESH / CONVEX_MESH / BOX shapes (texture SDF + collision edges); heightfields are out of scope."""
+    t = model.env
+    for a, b in t.sdf_pair:
+        for s in (a, b):
+            if int(t.shape_type[s]) not in (int(GeoType.MESH), int(GeoType.CONVEX_MESH), int(GeoType.BOX)):
+                raise NotImplementedError(f"SDF contact pairs with shape type {GeoType(int(t.shape_type[s])).name} are not supported")

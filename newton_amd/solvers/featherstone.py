@@ -62,6 +62,7 @@ class SolverFeatherstone(SolverBase):
             control = self._control
         p = self._params()
         d_in, d_out, d_c = state_in._desc(), state_out._desc(), control._desc()
+        d_in = self._state_desc_with_sdf_forces(state_in, contacts, self.friction_smoothing)
         d_ct = contacts._desc() if contacts is not None else None
         _lib.check(dm.lib.nt_featherstone_step(C.byref(dm.desc), C.byref(p), C.byref(d_in), C.byref(d_out), C.byref(d_c),
                                                C.byref(d_ct) if d_ct is not None else None, float(dt),
@@ -89,6 +90,9 @@ class SolverFeatherstone(SolverBase):
             if not hasattr(self, "_control"):
                 self._control = self.model.control()
             control = self._control
+        if getattr(contacts, "_sdf_leg", None) is not None:
+            raise NotImplementedError("SolverFeatherstone.rollout: models with SDF contact pairs step launch by launch "
+                                      "(pipeline.collide + solver.step)")
         p = self._params()
         cp = _lib.nt_collide_params(0, self.envs_per_block)
         d0, d1, d_c, d_ct = state_0._desc(), state_1._desc(), control._desc(), contacts._desc()

@@ -35,6 +35,7 @@ class SolverSemiImplicit(SolverBase):
         p = _lib.nt_semi_implicit_params(float(self.angular_damping), float(self.friction_smoothing),
                                          float(self.joint_attach_ke), float(self.joint_attach_kd))
         d_in, d_out, d_c = state_in._desc(), state_out._desc(), control._desc()
+        d_in = self._state_desc_with_sdf_forces(state_in, contacts, self.friction_smoothing)
         d_ct = contacts._desc() if contacts is not None else None
         _lib.check(dm.lib.nt_semi_implicit_step(C.byref(dm.desc), C.byref(p), C.byref(d_in), C.byref(d_out), C.byref(d_c),
                                                 C.byref(d_ct) if d_ct is not None else None, float(dt),

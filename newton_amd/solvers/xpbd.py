@@ -59,6 +59,11 @@ class SolverXPBD(SolverBase):
         rep = _lib.nt_xpbd_report()
         reporting = False
         self._contact_impulse = None
+        if contacts is not None and getattr(contacts, "_flat", None) is not None and (
+                self.enable_restitution or contacts.force is not None or self.compute_body_velocity_from_position_delta):
+            # the SDF leg's rows take part in the position solve; the optional passes walk the fixed slots only
+            raise NotImplementedError("enable_restitution / contacts.force / compute_body_velocity_from_position_delta are not "
+                                      "implemented for models with SDF contact pairs")
         if contacts is not None and contacts.force is not None:
             rep.contact_impulse = contacts._impulse.data_ptr()
             self._contact_impulse = contacts._impulse
@@ -106,13 +111,19 @@ class SolverXPBD(SolverBase):
         if control is None:
             control = self._default_control()
         cp = collide_params if collide_params is not None else _lib.nt_collide_params(0, self.envs_per_block)
-        if contacts.force is not None or state_0._parent_f is not None or state_1._parent_f is not None:
-            # the reporting outputs only exist in the per-substep kernel: run the reference loop launch by launch
+        leg = getattr(contacts, "_sdf_leg", None)
+        if contacts.force is not None or state_0._parent_f is not None or state_1._parent_f is not None or leg is not None:
+            # the reporting outputs only exist in the per-substep kernel, and the SDF leg of collide() is a chain of launches
+            # of its own: run the reference loop launch by launch
             for _ in range(int(substeps)):
                 state_0.clear_forces()
                 d_s, d_ct = state_0._desc(), contacts._desc()
+                if leg is not None:
+                    leg.export_pointers(d_ct)
                 _lib.check(dm.lib.nt_collide(C.byref(dm.desc), C.byref(d_s), C.byref(d_ct), C.byref(cp), dm.stream()),
                            "nt_collide")
+                if leg is not None:
+                    leg.collide(state_0, contacts._flat, dm.stream())
                 contacts._generation += 1
                 self.step(state_0, state_1, control, contacts, dt)
                 state_0, state_1 = state_1, state_0

@@ -22,7 +22,8 @@ _SHAPE = ("shape_transform", "shape_type", "shape_scale", "shape_flags", "shape_
           "shape_mesh_count", "shape_collision_aabb_lower", "shape_collision_aabb_upper", "shape_margin", "shape_gap",
           "shape_collision_radius", "shape_material_ke", "shape_material_kd", "shape_material_kf", "shape_material_ka",
           "shape_material_mu", "shape_material_restitution", "shape_material_mu_torsional", "shape_material_mu_rolling",
-          "shape_material_kh")
+          "shape_material_kh", "_shape_sdf_index", "shape_edge_range", "_shape_voxel_resolution")
+# (the SDF table Model._texture_sdf_data and the edge tables mesh_edge_centers / _halves are shared assets: copied by reference)
 
 
 def _span(world_arr, b, e):
@@ -98,7 +99,8 @@ def slice_worlds(model, begin: int, end: int, device=None):
     new_id = -np.ones(model.shape_count + 1, dtype=np.int64)
     new_id[keep] = np.arange(len(keep))
     for k in _SHAPE:
-        setattr(m, k, np.array(np.asarray(getattr(model, k))[keep]))
+        if getattr(model, k, None) is not None:
+            setattr(m, k, np.array(np.asarray(getattr(model, k))[keep]))
     m.shape_body = shift(np.asarray(model.shape_body)[keep], b0)
     m.shape_world = np.where(sw[keep] >= 0, sw[keep] - begin, -1).astype(np.int32)
     m.shape_label = [model.shape_label[i] for i in keep]
@@ -183,7 +185,8 @@ def tile_worlds(model, reps: int, device=None, filter_pairs: bool = True):
     copy_of = np.concatenate([np.zeros(len(front), dtype=np.int64), np.repeat(np.arange(reps), nloc),
                               np.zeros(len(back), dtype=np.int64)])
     for k in _SHAPE:
-        setattr(m, k, np.array(np.asarray(getattr(model, k))[order]))
+        if getattr(model, k, None) is not None:
+            setattr(m, k, np.array(np.asarray(getattr(model, k))[order]))
     sb = np.asarray(model.shape_body)[order].astype(np.int64)
     m.shape_body = np.where(sb >= 0, sb + copy_of * B, sb).astype(np.int32)
     m.shape_world = np.where(sw[order] >= 0, sw[order] + copy_of * W, -1).astype(np.int32)

@@ -188,19 +188,32 @@ def edge_search(sdf: OracleSDF, v0, v1, midpoint_sdf, precision_target):
     return f32(best_f), (v0 + e * f32(best_t)).astype(f32), best_endpoint
 
 
+def _dot3(a, b):  # wp.dot: left to right, one float32 rounding per operation (np.dot may reorder / fuse through BLAS)
+    return f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+
+
+def _cross3(a, b):
+    return np.array([f32(f32(a[1] * b[2]) - f32(a[2] * b[1])), f32(f32(a[2] * b[0]) - f32(a[0] * b[2])),
+                     f32(f32(a[0] * b[1]) - f32(a[1] * b[0]))], dtype=f32)
+
+
 def _q_rot(q, v):
     """wp.quat_rotate in float32 (oracle/wp_builtins.h order: v*(2w^2-1) + cross(qv, v)*w*2 + qv*dot(qv, v)*2)."""
     q, v = np.asarray(q, dtype=f32), np.asarray(v, dtype=f32)
     qv, w = q[:3], q[3]
-    c = np.cross(qv, v).astype(f32)
-    return (v * f32(f32(f32(2.0) * w) * w - f32(1.0)) + c * w * f32(2.0) + qv * f32(np.dot(qv, v)) * f32(2.0)).astype(f32)
+    c, d = _cross3(qv, v), _dot3(qv, v)
+    k = f32(f32(f32(f32(2.0) * w) * w) - f32(1.0))
+    return np.array([f32(f32(f32(v[i] * k) + f32(f32(c[i] * w) * f32(2.0))) + f32(f32(qv[i] * d) * f32(2.0))) for i in range(3)],
+                    dtype=f32)
 
 
 def _q_mul(a, b):
     a, b = np.asarray(a, dtype=f32), np.asarray(b, dtype=f32)
-    return np.array([a[3] * b[0] + b[3] * a[0] + a[1] * b[2] - b[1] * a[2], a[3] * b[1] + b[3] * a[1] + a[2] * b[0] - b[2] * a[0],
-                     a[3] * b[2] + b[3] * a[2] + a[0] * b[1] - b[0] * a[1], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]],
-                    dtype=f32)
+    m = lambda x, y: f32(x * y)  # noqa: E731
+    return np.array([f32(f32(f32(m(a[3], b[0]) + m(b[3], a[0])) + m(a[1], b[2])) - m(b[1], a[2])),
+                     f32(f32(f32(m(a[3], b[1]) + m(b[3], a[1])) + m(a[2], b[0])) - m(b[2], a[0])),
+                     f32(f32(f32(m(a[3], b[2]) + m(b[3], a[2])) + m(a[0], b[1])) - m(b[0], a[1])),
+                     f32(f32(f32(m(a[3], b[3]) - m(a[0], b[0])) - m(a[1], b[1])) - m(a[2], b[2]))], dtype=f32)
 
 
 def _x_mul(a, b):  # transform_multiply
@@ -266,10 +279,10 @@ def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_in
                 consistent = True
                 if dist_approx < inner:
                     ic = ((v0 + v1) * f32(0.5)).astype(f32)
-                    ir = f32(np.sqrt(f32(np.dot(v1 - v0, v1 - v0))) * f32(0.5))
+                    ir = f32(np.sqrt(_dot3(v1 - v0, v1 - v0)) * f32(0.5))
                     cr = f32(ir + f32(inner / min_scale))
                     icl = np.minimum(np.maximum(ic, o.lo), o.hi)
-                    if f32(np.dot(ic - icl, ic - icl)) > f32(cr * cr):
+                    if _dot3(ic - icl, ic - icl) > f32(cr * cr):
                         consistent = False
                     else:
                         consistent = bool(mid <= cr)
@@ -282,12 +295,12 @@ def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_in
                 point = (p_u * sdf_scale).astype(f32)
                 pw = _x_point(X_sdf, point)
                 dw = _q_rot(X_sdf[3:], direction)
-                dl2 = f32(np.dot(dw, dw))
+                dl2 = _dot3(dw, dw)
                 if dl2 > 0.0:
                     dw = (dw * (f32(1.0) / np.sqrt(dl2))).astype(f32)
                 else:
                     fb = pw - X_sdf[:3]
-                    fl2 = f32(np.dot(fb, fb))
+                    fl2 = _dot3(fb, fb)
                     dw = (fb * (f32(1.0) / np.sqrt(fl2))).astype(f32) if fl2 > 0.0 else np.array([0.0, 1.0, 0.0], dtype=f32)
                 n = -dw if mode == 0 else dw
                 out.append((pair_idx, (e << 2) | (mode << 1), pw, n.astype(f32), dist, f32(D[s0, 3]), f32(D[s1, 3])))

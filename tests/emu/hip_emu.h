@@ -93,6 +93,15 @@ inline int __shfl(int var, int src_lane) {
     emu_wave_sync(lanes);
     return v;
 }
+inline int __shfl_up(int var, unsigned delta) {
+    emu::WaveSlot& w = emu::wave_slots()[threadIdx.x / 64];
+    const unsigned lanes = blockDim.x - (threadIdx.x / 64) * 64 < 64 ? blockDim.x - (threadIdx.x / 64) * 64 : 64;
+    w.values[__lane_id()] = var;
+    emu_wave_sync(lanes);
+    int v = __lane_id() >= delta ? w.values[__lane_id() - delta] : var;
+    emu_wave_sync(lanes);
+    return v;
+}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

@@ -299,7 +299,8 @@ def free_child_scene(world_count: int, device=None, seed: int | None = 0, free_r
 
 
 def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.005, mu=None,
-                   hull_pairs: bool = True, shape_cfg=None, inertia_armature: float = 0.0):
+                   hull_pairs: bool = True, shape_cfg=None, inertia_armature: float = 0.0, sdf: bool = False,
+                   sdf_resolution: int = 24):
     """Config C5 without the SDF / hydroelastic contact models: `n_hulls` random convex hulls (16-32 vertices, radius
     U(0.03, 0.06)) dropped into a five-wall bin (ground plane + four static boxes); every hull pair and every hull-wall pair
     is a candidate, so one environment has n(n-1)/2 + 5n pairs (2 336 for 64 hulls) and its per-contact solver records no
@@ -315,6 +316,9 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
     measured, profiles/r02h_sdf_stage_sweep.jsonl).  XPBD (implicit positions) needs none."""
     from newton_amd.worlds import slice_worlds, tile_worlds
 
+    # sdf=True: config C5 with its contact model -- every hull carries a uint16 texture SDF (Mesh.build_sdf) and the five walls of
+    # the bin are static boxes with generated SDFs (ShapeConfig.configure_sdf), so EVERY pair (hull-hull, hull-wall) takes the
+    # mesh-SDF leg of CollisionPipeline.collide and the environment tiles carry no pair at all
     rng = np.random.default_rng(seed)
     env = nt.ModelBuilder()
     if mu is not None:
@@ -332,7 +336,10 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
         ix, iy, iz = k % n_side, (k // n_side) % n_side, k // (n_side * n_side)
         pos = [(ix - 0.5 * (n_side - 1)) * pitch, (iy - 0.5 * (n_side - 1)) * pitch, 0.08 + iz * pitch]
         b = env.add_body(xform=[*pos, *nt._np_math.quat_rpy(*rng.uniform(-1.0, 1.0, size=3))])
-        env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(pts))
+        mesh = nt.Mesh.convex_hull_of(pts)
+        if sdf:
+            mesh.build_sdf(max_resolution=sdf_resolution, margin=0.02, narrow_band_range=(-0.1, 0.1), texture_format="uint16")
+        env.add_shape_convex_hull(b, mesh=mesh)
     if inertia_armature > 0.0:
         for b in range(env.body_count):
             env.body_inertia[b] = env.body_inertia[b] + np.eye(3) * inertia_armature
@@ -344,11 +351,21 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
     base_count = min(world_count, 32)
     scene = nt.ModelBuilder()
     scene.replicate(env, base_count)
-    scene.add_ground_plane()
     w = 0.5 * side + 0.1
+    wall_cfg = None
+    if sdf:
+        wall_cfg = scene.default_shape_cfg.copy()
+        for k, v in (shape_cfg or {}).items():
+            setattr(wall_cfg, k, v)
+        if mu is not None:
+            wall_cfg.mu = float(mu)
+        wall_cfg.configure_sdf(max_resolution=64)
+        scene.add_shape_box(-1, xform=[0.0, 0.0, -0.05, 0.0, 0.0, 0.0, 1.0], hx=w + 0.06, hy=w + 0.06, hz=0.05, cfg=wall_cfg)
+    else:
+        scene.add_ground_plane()
     for sx, sy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
         scene.add_shape_box(-1, xform=[w * sx, w * sy, 0.3, 0.0, 0.0, 0.0, 1.0], hx=0.03 if sx else w + 0.03,
-                            hy=0.03 if sy else w + 0.03, hz=0.3)
+                            hy=0.03 if sy else w + 0.03, hz=0.3, cfg=wall_cfg)
     model = scene.finalize(device=device)
     if world_count > base_count:
         reps = -(-world_count // base_count)

@@ -1,0 +1,278 @@
+"""The mesh-SDF leg INSIDE CollisionPipeline.collide on the MI355X (collide.py:1999 ->
+narrow_phase.py:2838-3167): rows against the float32 checker chain, run-to-run bit identity, and the three solvers consuming
+the rows (XPBD inside its step kernel, SemiImplicit / Featherstone through the ordered force gather)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")
+
+
+def _rows(contacts):
+    f = contacts._flat
+    n = int(f.row_start[-1].item())
+    d = {k: getattr(f, k)[:n].cpu().numpy() for k in (*FIELDS, "key")}
+    d["row_start"] = f.row_start.cpu().numpy()
+    return d
+
+
+@pytest.mark.parametrize("walls", [False, True])
+def test_collide_rows_match_the_checker_chain(walls):
+    import newton_amd as nt
+    from sdf_pipeline_checker import checker_rows, sdf_scene
+
+    E = 3
+    model = sdf_scene(E, 5, device="cuda:0", walls=walls)
+    assert len(model.env.sdf_pair) == (10 + (10 if walls else 0)) and model.env.np == 5  # hull-hull (+ hull-wall) vs hull-plane
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    contacts = pipe.contacts()
+    state = model.state()
+    pipe.collide(state, contacts)
+    got = _rows(contacts)
+    ov = pipe._sdf_leg.overflow(contacts._flat)
+    assert not ov["overflow"], ov
+    leg = pipe._sdf_leg
+    X, lo, hi = leg.world_xform.cpu().numpy(), leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    want, cand, (Xc, loc, hic) = checker_rows(model, np.asarray(model.body_q), world_xform=X, aabbs=(lo, hi))
+    # the exported world transforms / AABBs themselves (compute_shape_aabbs): against the C++ checker
+    finite = np.abs(loc) < 1e5
+    assert np.abs(X - Xc).max() <= 1e-6 and np.abs(lo - loc)[finite].max() <= 1e-6 and np.abs(hi - hic)[np.abs(hic) < 1e5].max() <= 1e-6
+    # candidate pairs: exact, in order, per world
+    pc = pipe._sdf_leg.pair_count.cpu().numpy()
+    wp = pipe._sdf_leg.world_pairs.cpu().numpy().reshape(E, -1, 2)
+    for w in range(E):
+        assert pc[w] == len(cand[w]) and [tuple(p) for p in wp[w, : pc[w]]] == cand[w], w
+    assert sum(len(c) for c in cand) > 0
+    # rows: ids, fingerprints, per-world ranges exact; geometry to 1e-5
+    assert len(want["key"]) == len(got["key"]) > 0
+    assert np.array_equal(got["row_start"], np.concatenate([[0], np.cumsum(np.bincount(want["world"], minlength=E))]))
+    assert np.array_equal(got["key"], want["key"])
+    for k in ("shape0", "shape1"):
+        assert np.array_equal(got[k], want[k]), k
+    for k in FIELDS[2:]:  # same shape transforms in, same rows out
+        assert np.abs(got[k] - want[k]).max() <= 2e-6, (k, np.abs(got[k] - want[k]).max())
+    # Newton-shaped view: the slot contacts first, then the live rows
+    n_slots = int(contacts.rigid_contact_count_per_env.sum().item())
+    live = got["shape0"] != got["shape1"]
+    assert int(contacts.rigid_contact_count.item()) == n_slots + int(live.sum())
+    assert np.array_equal(contacts.rigid_contact_shape0.cpu().numpy()[n_slots:n_slots + int(live.sum())], got["shape0"][live])
+
+
+def test_collide_twice_is_bitwise_identical_and_blocks_cover_the_rows():
+    import newton_amd as nt
+    from sdf_pipeline_checker import sdf_scene
+
+    E = 4
+    model = sdf_scene(E, 6, device="cuda:0", walls=True, seed=9)
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    c1, c2 = pipe.contacts(), pipe.contacts()
+    state = model.state()
+    pipe.collide(state, c1)
+    pipe.collide(state, c2)
+    a, b = _rows(c1), _rows(c2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # every live row sits in exactly the blocks of its two bodies (dynamic ones), ascending
+    t = model.env
+    f = c1._flat
+    bs, bl = f.body_blk_start.cpu().numpy().reshape(E, t.nb + 1), f.body_blk_list.cpu().numpy()
+    seen = {}
+    for w in range(E):
+        for body in range(t.nb):
+            last = -1
+            for i in range(bs[w, body], bs[w, body + 1]):
+                r0, side, cnt = bl[i, 0] >> 1, bl[i, 0] & 1, bl[i, 1]
+                assert r0 > last and a["row_start"][w] <= r0 and r0 + cnt <= a["row_start"][w + 1]
+                last = r0
+                for r in range(r0, r0 + cnt):
+                    seen.setdefault(r, []).append((body, side))
+    sb = np.asarray(model.shape_body)
+    for r in range(len(a["key"])):
+        want = []
+        for side, s in enumerate((a["shape0"][r], a["shape1"][r])):
+            pass
+        # the blocks list a pair's rows whether or not a row was gap-rejected; check the live ones
+        if a["shape0"][r] != a["shape1"][r]:
+            w = int(np.searchsorted(a["row_start"], r, side="right") - 1)
+            for side, s in enumerate((a["shape0"][r], a["shape1"][r])):
+                if sb[s] >= 0:
+                    want.append((int(sb[s]) - w * t.nb, side))
+            assert sorted(seen.get(r, [])) == sorted(want), r
+
+
+def _oracle_contacts_with_rows(model, o, body_q, rows):
+    """Checker contacts = its own slot contacts (tile pairs) + the product's SDF rows appended (live ones)."""
+    oc = o.contacts(cmax=max(1000, model.shape_contact_pair_count * 5) + len(rows["key"]))
+    o.collide(body_q, oc)
+    n = int(oc.count[0])
+    live = np.flatnonzero(rows["shape0"] != rows["shape1"])
+    for k in FIELDS:
+        getattr(oc, k)[n:n + len(live)] = rows[k][live]
+    oc.count[0] = n + len(live)
+    return oc
+
+
+def _pile(model, seed=3):
+    """Push the hulls of every world together so that the SDF rows carry penetrating contacts."""
+    q = np.asarray(model.body_q).copy()
+    t = model.env
+    c = q[:, :3].reshape(t.env_count, t.nb, 3)
+    c[:, :, :2] *= 0.4
+    q[:, :3] = c.reshape(-1, 3)
+    model.body_q = q
+    model.joint_q.reshape(-1, 7)[:, :3] = q[:, :3]
+
+
+def test_xpbd_step_consumes_the_rows_like_the_checker():
+    import torch
+
+    import newton_amd as nt
+    from oracle_bridge import Oracle, OracleState
+    from sdf_pipeline_checker import sdf_scene
+
+    E = 3
+    model = sdf_scene(E, 5, device="cuda:0", seed=11)
+    _pile(model)
+    # the SDF pairs are not tile pairs: the checker must not run them through MPR / GJK either
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    contacts = pipe.contacts()
+    s0, s1 = model.state(), model.state()
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    pipe.collide(s0, contacts)
+    rows = _rows(contacts)
+    assert (rows["shape0"] != rows["shape1"]).sum() > 5
+    solver.step(s0, s1, model.control(), contacts, 1.0e-3)
+    torch.cuda.synchronize()
+    host = _host_twin_without_sdf_pairs(model)
+    o = Oracle(host)
+    oc = _oracle_contacts_with_rows(host, o, np.asarray(model.body_q), rows)
+    os0, os1 = OracleState(host), OracleState(host)
+    o.xpbd_step(os0, os1, o.control(), oc, 1.0e-3, iterations=2)
+    dq = np.abs(s1.body_q.cpu().numpy() - os1.body_q).max()
+    dv = np.abs(s1.body_qd.cpu().numpy() - os1.body_qd).max()
+    moved = np.abs(os1.body_q - np.asarray(model.body_q)).max()
+    assert dq <= 1e-5 and dv <= 5e-3 and moved > 1e-4, (dq, dv, moved)
+    # without the rows the checker ends elsewhere: the rows did take part
+    oc2 = o.contacts()
+    o.collide(np.asarray(model.body_q), oc2)
+    ot0, ot1 = OracleState(host), OracleState(host)
+    o.xpbd_step(ot0, ot1, o.control(), oc2, 1.0e-3, iterations=2)
+    assert np.abs(ot1.body_q - os1.body_q).max() > 1e-5
+
+
+def _host_twin_without_sdf_pairs(model):
+    """A shallow host copy of the model whose shape_contact_pairs hold only the tile pairs (what the checker's collide walks)."""
+    import copy
+
+    t = model.env
+    host = copy.copy(model)
+    pairs = np.asarray(model.shape_contact_pairs).reshape(t.env_count, -1, 2)
+    host.shape_contact_pairs = np.ascontiguousarray(pairs[:, t.tile_pair_index].reshape(-1, 2))
+    host.shape_contact_pair_count = len(host.shape_contact_pairs)
+    return host
+
+
+@pytest.mark.parametrize("solver_name", ["semi_implicit", "featherstone"])
+def test_penalty_solvers_consume_the_rows_like_the_checker(solver_name):
+    import torch
+
+    import newton_amd as nt
+    from oracle_bridge import Oracle, OracleState
+    from sdf_pipeline_checker import sdf_scene
+
+    E = 3
+    model = sdf_scene(E, 5, device="cuda:0", seed=12)
+    _pile(model)
+    if solver_name == "semi_implicit":  # (SolverFeatherstone rebuilds body_qd from joint_qd: its rows are evaluated at rest)
+        model.body_qd = np.random.default_rng(0).uniform(-0.2, 0.2, size=(model.body_count, 6)).astype(np.float32)
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    contacts = pipe.contacts()
+    s0, s1 = model.state(), model.state()
+    cls = nt.solvers.SolverSemiImplicit if solver_name == "semi_implicit" else nt.solvers.SolverFeatherstone
+    solver = cls(model)
+    pipe.collide(s0, contacts)
+    rows = _rows(contacts)
+    f_before = s0.body_f.cpu().numpy().copy()
+    solver.step(s0, s1, model.control(), contacts, 2.5e-4)
+    torch.cuda.synchronize()
+    assert np.array_equal(s0.body_f.cpu().numpy(), f_before)  # state_in.body_f is not touched
+    host = _host_twin_without_sdf_pairs(model)
+    o = Oracle(host)
+    oc = _oracle_contacts_with_rows(host, o, np.asarray(model.body_q), rows)
+    os0, os1 = OracleState(host), OracleState(host)
+    if solver_name == "semi_implicit":
+        o.semi_implicit_step(os0, os1, o.control(), oc, 2.5e-4)
+    else:
+        o.featherstone_step(os0, os1, o.control(), oc, 2.5e-4)
+    dq = np.abs(s1.body_q.cpu().numpy() - os1.body_q).max()
+    dv = np.abs(s1.body_qd.cpu().numpy() - os1.body_qd).max()
+    assert dq <= 1e-5 and dv <= 2e-3, (dq, dv)
+    oc2 = o.contacts()
+    o.collide(np.asarray(model.body_q), oc2)
+    ot0, ot1 = OracleState(host), OracleState(host)
+    (o.semi_implicit_step if solver_name == "semi_implicit" else o.featherstone_step)(ot0, ot1, o.control(), oc2, 2.5e-4)
+    assert np.abs(ot1.body_qd - os1.body_qd).max() > 1e-3  # the rows' forces are in the result
+
+
+def test_config_c5_rows_at_full_size():
+    """Config C5 at its stated size -- 2 048 worlds x 64 hulls with uint16 texture SDFs in a bin of five SDF boxes, every pair
+    through the SDF leg -- settled with SolverXPBD consuming the rows: two collide() calls give bit-identical rows, no capacity is
+    exceeded, the pile is at rest inside the bin, and the rows of sampled worlds equal the float32 checker chain (ids, fingerprints
+    and counts exact; geometry 2e-6 on the device's own shape transforms, which are held against the checker's to 1e-6)."""
+    import torch
+
+    import newton_amd as nt
+    import scenes
+    from sdf_pipeline_checker import checker_rows
+
+    E = 2048
+    model = scenes.hull_bin_scene(E, 64, device="cuda:0", seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005))
+    t = model.env
+    assert t.np == 0 and len(t.sdf_pair) == 64 * 63 // 2 + 64 * 5
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    c1, c2 = pipe.contacts(), pipe.contacts()
+    s0, s1, ctrl = model.state(), model.state(), model.control()
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    for _ in range(600):  # 0.5 s: the hulls drop 2 cm onto the floor and each other
+        s0.clear_forces()
+        pipe.collide(s0, c1)
+        solver.step(s0, s1, ctrl, c1, 1.0 / 1200.0)
+        s0, s1 = s1, s0
+    pipe.collide(s0, c1)
+    pipe.collide(s0, c2)
+    torch.cuda.synchronize()
+    a, b = _rows(c1), _rows(c2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    ov = pipe._sdf_leg.overflow(c1._flat)
+    assert not ov["overflow"] and ov["rows"] > 20 * E, ov
+    q, qd = s0.body_q.cpu().numpy(), s0.body_qd.cpu().numpy()
+    assert np.isfinite(q).all() and q[:, 2].min() > 0.0 and q[:, 2].max() < 0.6 and np.abs(q[:, :2]).max() < 0.45
+    assert np.median(np.linalg.norm(qd[:, :3], axis=1)) < 0.05
+    # sampled worlds against the checker: a slice of the model with the settled poses
+    from newton_amd.worlds import slice_worlds
+
+    leg = pipe._sdf_leg
+    X, lo, hi = leg.world_xform.cpu().numpy(), leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    pc = leg.pair_count.cpu().numpy()
+    for w in range(0, E, 128):  # 16 worlds across the batch
+        sub = slice_worlds(model, w, w + 1)
+        ids = np.asarray(sub._global_shape_ids)
+        bq = q[w * t.nb:(w + 1) * t.nb]
+        want, cand, (Xc, loc, hic) = checker_rows(sub, bq, world_xform=X[ids], aabbs=(lo[ids], hi[ids]))
+        assert np.abs(X[ids] - Xc).max() <= 1e-6 and np.abs(lo[ids] - loc).max() <= 1e-6 and np.abs(hi[ids] - hic).max() <= 1e-6
+        r0, r1 = a["row_start"][w], a["row_start"][w + 1]
+        assert pc[w] == len(cand[0]) and r1 - r0 == len(want["key"]) > 0, (w, pc[w], len(cand[0]), r1 - r0, len(want["key"]))
+        assert np.array_equal(a["key"][r0:r1], want["key"])
+        back = {int(g): k for k, g in enumerate(ids)}
+        for k in ("shape0", "shape1"):
+            got = np.array([back[int(s)] if s >= 0 else -1 for s in a[k][r0:r1]])
+            assert np.array_equal(got, want[k]), (w, k)
+        for k in FIELDS[2:]:
+            assert np.abs(a[k][r0:r1] - want[k]).max() <= 2e-6, (w, k, np.abs(a[k][r0:r1] - want[k]).max())
