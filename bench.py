@@ -66,7 +66,7 @@ WORKLOADS = {
     "sdf_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 1200.0, kernel="mesh_sdf_collide_reduced_kernel", drop=0.0, settle=40,
                     loop=True, envs=2048,
                     name="C5: 64 convex hulls (16-32 vertices, uint16 texture SDFs) in a five-wall bin of SDF boxes, every pair "
-                         "through the SDF narrow phase + global contact reduction inside CollisionPipeline.collide(broad_phase='sap')"),
+                         "through the SDF narrow phase + global contact reduction inside CollisionPipeline.collide(broad_phase='sap'), contact gap 5 mm"),
     # the headline scene through the per-call API an RL loop with per-substep control uses: collide and step as separate launches
     "quadruped_api": dict(solver="xpbd", iterations=2, dt=1e-3, kernel="xpbd_step_kernel<16,false> + collide_kernel<16,false>",
                           drop=0.22, settle=100, loop=True,
@@ -152,7 +152,8 @@ def build_shard(workload: str, envs_per_gpu: int, rank: int, world: int, device:
     if workload in ("quadruped", "quadruped_featherstone", "quadruped_api"):
         g = scenes.quadruped_scene(total, seed=1)
     elif workload == "sdf_bin":
-        g = scenes.hull_bin_scene(total, 64, seed=2, sdf=True, mu=0.5)
+        # contact gap 5 mm (Newton's default rigid_gap of 0.1 m is larger than a hull: every pair of the bin would be a candidate)
+        g = scenes.hull_bin_scene(total, 64, seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005))
     elif workload == "quadruped_convex":
         g = scenes.quadruped_convex_scene(total, seed=1)
     elif workload == "box_stack":

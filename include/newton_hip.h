@@ -366,6 +366,10 @@ typedef struct {
  * [n][3]; either output may be NULL. */
 nt_status nt_sdf_sample(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist /*[n]*/, float* out_grad /*[n][3]*/,
                         void* stream);
+/* texture_sample_sdf_hw (:1533-1538): the one-fetch sampler of the mesh-SDF narrow phase (value only) */
+nt_status nt_sdf_sample_hw(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist /*[n]*/, void* stream);
+/* texture_sample_sdf_at_voxel (:1220-1228): exact value at integer fine-grid vertices ijk [n][3] (hydroelastic corner values) */
+nt_status nt_sdf_sample_voxels(const nt_sdf* sdf, const int32_t* ijk, int32_t n, float* out_dist /*[n]*/, void* stream);
 
 /* mesh_sdf_collision_kernel (sdf_contact.py:1098-1515, reduce_contacts=False): every edge of one shape of a pair against the
  * SDF of the other, both ways.  Flat Newton arrays; contacts are appended (atomic counter, which keeps counting past

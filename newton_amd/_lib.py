@@ -298,6 +298,8 @@ SYMBOLS = {
     "nt_pick_envs_per_block": (C.c_int32, [C.POINTER(nt_model), C.c_int32]),
     "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
     "nt_sdf_sample": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P, _P]),
+    "nt_sdf_sample_hw": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P]),
+    "nt_sdf_sample_voxels": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P]),
     "nt_mesh_sdf_collide": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), _P]),
     "nt_mesh_sdf_collide_reduced": (C.c_int32, [C.POINTER(nt_mesh_sdf_args), C.POINTER(nt_contact_reduce_shapes), _P]),
     "nt_contacts_reduce_list": (C.c_int32, [C.POINTER(nt_contact_reduce_list), _P]),

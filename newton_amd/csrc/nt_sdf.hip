@@ -2,8 +2,9 @@
 //
 // Reference behaviour (paths under /root/reference/newton/_src/geometry):
 //   sampling        sdf_texture.py:786-828 (_locate_cell_coords), :1008-1126 (_texture_sample_sdf_variant: software trilinear
-//                   over point-sampled texels, |p - clamp(p)| extension outside the box), :1619-1697 (centred-difference
-//                   gradient with half-voxel steps, clamp-direction gradient outside the box)
+//                   over point-sampled texels, |p - clamp(p)| extension outside the box; nt_sdf_sample's value, the hydroelastic
+//                   kernel), :1415-1538 (the one-fetch "hardware" sampler the mesh-SDF narrow phase uses), :1619-1697
+//                   (centred-difference gradient from six such fetches, clamp-direction gradient outside the box)
 //   edge search     sdf_contact.py:704-938 (do_edge_sdf_collision: symmetric golden pair + <= 3 Brent steps + endpoint checks)
 //   pair kernel     sdf_contact.py:1098-1515 (mesh_sdf_collision_kernel, reduce_contacts=False variant: both modes of a pair,
 //                   edge bounding-sphere cull against the SDF box and the midpoint value, inner-cull consistency, corner
@@ -101,6 +102,61 @@ NT_DI float sample_clamped(const nt_sdf& s, vec3 clamped, float diff_mag) {
     return val + diff_mag;
 }
 
+// The "hardware" fetch of the mesh-SDF narrow phase (sdf_texture.py:1415-1461, _texture_sample_sdf_hw_clamped_variant): ONE
+// filtered texture sample at a fractional coordinate -- block origin + 0.5 + t for a subgrid cell, coarse cell + 0.5 + t for a
+// linear cell -- which the texture unit (on Warp's CPU device: a float32 software filter) resolves as the trilinear blend of the
+// eight texels around (u - 0.5): i0 = floor(u - 0.5), t' = (u - 0.5) - i0, CLAMP addressing.  The coordinate round trip is kept
+// (it costs the low bits of t, so the result differs from the software sampler above in the last place); plain global loads.
+NT_DI float fetch_linear(const nt_sdf& s, bool coarse, float ux, float uy, float uz) {
+    const float x = ux - 0.5f, y = uy - 0.5f, z = uz - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
+    const float tx = x - fx0, ty = y - fy0, tz = z - fz0;
+    const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+    float v000, v100, v010, v110, v001, v101, v011, v111;
+    if (coarse) {
+        const int sx = s.cx + 1, sy = s.cy + 1, sz = s.cz + 1;
+        const int xa = clampi(x0, 0, sx - 1), xb = clampi(x0 + 1, 0, sx - 1), ya = clampi(y0, 0, sy - 1), yb = clampi(y0 + 1, 0, sy - 1),
+                  za = clampi(z0, 0, sz - 1), zb = clampi(z0 + 1, 0, sz - 1);
+        const float* g = s.coarse;
+        auto at = [&](int xx, int yy, int zz) { return g[((size_t)zz * sy + yy) * sx + xx]; };
+        v000 = at(xa, ya, za); v100 = at(xb, ya, za); v010 = at(xa, yb, za); v110 = at(xb, yb, za);
+        v001 = at(xa, ya, zb); v101 = at(xb, ya, zb); v011 = at(xa, yb, zb); v111 = at(xb, yb, zb);
+    } else {
+        const int T = s.tex_size;
+        const int xa = clampi(x0, 0, T - 1), xb = clampi(x0 + 1, 0, T - 1), ya = clampi(y0, 0, T - 1), yb = clampi(y0 + 1, 0, T - 1),
+                  za = clampi(z0, 0, T - 1), zb = clampi(z0 + 1, 0, T - 1);
+        v000 = texel(s, xa, ya, za); v100 = texel(s, xb, ya, za); v010 = texel(s, xa, yb, za); v110 = texel(s, xb, yb, za);
+        v001 = texel(s, xa, ya, zb); v101 = texel(s, xb, ya, zb); v011 = texel(s, xa, yb, zb); v111 = texel(s, xb, yb, zb);
+    }
+    const float c00 = v000 + (v100 - v000) * tx;
+    const float c10 = v010 + (v110 - v010) * tx;
+    const float c01 = v001 + (v101 - v001) * tx;
+    const float c11 = v011 + (v111 - v011) * tx;
+    const float c0 = c00 + (c10 - c00) * ty;
+    const float c1 = c01 + (c11 - c01) * ty;
+    return c0 + (c1 - c0) * tz;
+}
+NT_DI float sample_hw_clamped(const nt_sdf& s, vec3 clamped, float diff_mag) {
+    const vec3 lo(s.box_lower[0], s.box_lower[1], s.box_lower[2]);
+    const vec3 f = cw_mul(clamped - lo, vec3(s.inv_dx[0], s.inv_dx[1], s.inv_dx[2]));
+    const Cell c = locate(s, f);
+    float val;
+    if (c.slot >= SLOT_LINEAR) {
+        const float f2c = 1.0f / (float)s.subgrid_size;
+        const float cx = (float)c.bx, cy = (float)c.by, cz = (float)c.bz;
+        const float fx = ((float)c.ix + c.tx) * f2c, fy = ((float)c.iy + c.ty) * f2c, fz = ((float)c.iz + c.tz) * f2c;
+        val = fetch_linear(s, true, cx + (fx - cx) + 0.5f, cy + (fy - cy) + 0.5f, cz + (fz - cz) + 0.5f);
+    } else {
+        const float ssf = (float)s.subgrid_size, samples = (float)(s.subgrid_size + 1);
+        const float bx = (float)(c.slot & 0x3FFu), by = (float)((c.slot >> 10) & 0x3FFu), bz = (float)((c.slot >> 20) & 0x3FFu);
+        const float lx = (float)c.ix - (float)c.bx * ssf, ly = (float)c.iy - (float)c.by * ssf, lz = (float)c.iz - (float)c.bz * ssf;
+        const float ox = bx * samples + lx + 0.5f, oy = by * samples + ly + 0.5f, oz = bz * samples + lz + 0.5f;
+        const float raw = fetch_linear(s, false, ox + c.tx, oy + c.ty, oz + c.tz);
+        val = raw * s.value_range + s.min_value;
+    }
+    return val + diff_mag;
+}
+
 NT_DI vec3 clamp_to_box(const nt_sdf& s, vec3 p) {
     return vec3(clampf(p.x, s.box_lower[0], s.box_upper[0]), clampf(p.y, s.box_lower[1], s.box_upper[1]),
                 clampf(p.z, s.box_lower[2], s.box_upper[2]));
@@ -109,6 +165,13 @@ NT_DI float sample(const nt_sdf& s, vec3 p) {  // texture_sample_sdf
     vec3 c = clamp_to_box(s, p);
     vec3 d = p - c;
     return sample_clamped(s, c, sqrtf(dot(d, d)));
+}
+NT_DI float sample_hw(const nt_sdf& s, vec3 p) {  // texture_sample_sdf_hw (:1495-1538)
+    vec3 c = clamp_to_box(s, p);
+    vec3 d = p - c;
+    float mag = 0.0f;
+    if (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f) mag = sqrtf(dot(d, d));
+    return sample_hw_clamped(s, c, mag);
 }
 // _texture_sample_sdf_grad_hw_impl_variant: centred differences with half-voxel steps inside the box, the clamp direction outside
 NT_DI vec3 sample_grad(const nt_sdf& s, vec3 p) {
@@ -131,7 +194,8 @@ NT_DI vec3 sample_grad(const nt_sdf& s, vec3 p) {
         vec3 q0 = p0, q1 = p1;
         vset(q0, a, c0);
         vset(q1, a, c1);
-        const float v0 = sample_clamped(s, q0, sqrtf(d0 * d0)), v1 = sample_clamped(s, q1, sqrtf(d1 * d1));
+        const float s0 = d0 * d0, s1 = d1 * d1;  // diff_sq of the clamped-pair fetch (:1267-1352): no root when it is zero
+        const float v0 = sample_hw_clamped(s, q0, s0 != 0.0f ? sqrtf(s0) : 0.0f), v1 = sample_hw_clamped(s, q1, s1 != 0.0f ? sqrtf(s1) : 0.0f);
         vset(g, a, (v0 - v1) * s.inv_dx[a]);
     }
     return g;
@@ -148,6 +212,16 @@ __global__ void sdf_sample_kernel(nt_sdf s, const float* __restrict__ pts, int n
     }
 }
 
+__global__ void sdf_sample_hw_kernel(nt_sdf s, const float* __restrict__ pts, int n, float* __restrict__ dist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dist[i] = sample_hw(s, vec3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+}
+NT_DI float sample_at_voxel(const nt_sdf& s, int ix, int iy, int iz);
+__global__ void sdf_sample_voxels_kernel(nt_sdf s, const int* __restrict__ ijk, int n, float* __restrict__ dist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dist[i] = sample_at_voxel(s, ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2]);
+}
+
 // do_edge_sdf_collision (texture path): deepest point of the edge v0 -> v1 in the SDF; returns (distance, t, endpoint code)
 NT_DI void edge_search(const nt_sdf& s, vec3 v0, vec3 v1, float midpoint_sdf, float precision_target, float& best_f, vec3& best_p,
                        int& best_endpoint) {
@@ -161,7 +235,7 @@ NT_DI void edge_search(const nt_sdf& s, vec3 v0, vec3 v1, float midpoint_sdf, fl
     float fx = midpoint_sdf, fw = fx, fv = fx, d_step = 0.0f, e_step = 0.0f;
     if (tol_floor < 0.25f) {
         const float offset = 0.5f * golden, left = 0.5f - offset, right = 0.5f + offset;
-        const float f_left = sample(s, v0 + dir * left), f_right = sample(s, v0 + dir * right);
+        const float f_left = sample_hw(s, v0 + dir * left), f_right = sample_hw(s, v0 + dir * right);
         if (f_left < fx && f_left <= f_right) {
             b = 0.5f; x = left; fx = f_left; w = 0.5f; fw = midpoint_sdf; v = right; fv = f_right;
         } else if (f_right < fx) {
@@ -200,7 +274,7 @@ NT_DI void edge_search(const nt_sdf& s, vec3 v0, vec3 v1, float midpoint_sdf, fl
         float u;
         if (fabsf(d_step) >= tol) u = x + d_step;
         else u = d_step > 0.0f ? x + tol : x - tol;
-        const float fu = sample(s, v0 + dir * u);
+        const float fu = sample_hw(s, v0 + dir * u);
         if (fu <= fx) {
             if (u < x) b = x;
             else a = x;
@@ -219,11 +293,11 @@ NT_DI void edge_search(const nt_sdf& s, vec3 v0, vec3 v1, float midpoint_sdf, fl
     float best_t = x;
     best_f = fx;
     if (a == 0.0f) {
-        const float fe = sample(s, v0);
+        const float fe = sample_hw(s, v0);
         if (fe < best_f) { best_t = 0.0f; best_f = fe; best_endpoint = 1; }
     }
     if (b == 1.0f) {
-        const float fe = sample(s, v0 + dir * 1.0f);
+        const float fe = sample_hw(s, v0 + dir * 1.0f);
         if (fe < best_f) { best_t = 1.0f; best_f = fe; best_endpoint = 2; }
     }
     best_p = v0 + dir * best_t;
@@ -285,7 +359,7 @@ NT_DI bool edge_contact(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int 
     const vec3 cl = vmin(vmax(center, c.blo), c.bhi);
     const float d2 = length_sq(center - cl);
     if (d2 > threshold * threshold) return false;
-    const float mid = sample_clamped(s, cl, d2 > 0.0f ? sqrtf(d2) : 0.0f);
+    const float mid = sample_hw_clamped(s, cl, d2 > 0.0f ? sqrtf(d2) : 0.0f);
     if (!(mid <= threshold)) return false;
     // the edge in the SDF's unscaled space + its corner ownership
     const vec3 c_loc = xform_point(c.X_m2s, vec3(ec[0], ec[1], ec[2]));
@@ -856,6 +930,20 @@ nt_status nt_sdf_sample(const nt_sdf* sdf, const float* points, int32_t n, float
     if (!sdf || !points || n <= 0 || (!out_dist && !out_grad) || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;
     if (sdf->quantization != 4 && sdf->quantization != 2 && sdf->quantization != 1) return NT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(sdf_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *sdf, points, n, out_dist, out_grad);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_sdf_sample_hw(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist, void* stream) {
+    if (!sdf || !points || n <= 0 || !out_dist || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;
+    if (sdf->quantization != 4 && sdf->quantization != 2 && sdf->quantization != 1) return NT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sdf_sample_hw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *sdf, points, n, out_dist);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_sdf_sample_voxels(const nt_sdf* sdf, const int32_t* ijk, int32_t n, float* out_dist, void* stream) {
+    if (!sdf || !ijk || n <= 0 || !out_dist || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;
+    if (sdf->quantization != 4 && sdf->quantization != 2 && sdf->quantization != 1) return NT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sdf_sample_voxels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *sdf, ijk, n, out_dist);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

@@ -2,13 +2,16 @@
 and mesh-vs-SDF narrow phase.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 
 Follows, function by function (paths under /root/reference/newton/_src/geometry):
-  sample / sample_clamped   sdf_texture.py:786-828 (_locate_cell_coords) + :1008-1126 (_texture_sample_sdf_variant)
-  sample_grad_fd            sdf_texture.py:1619-1697 (_texture_sample_sdf_grad_hw_impl_variant; the hardware-filtered fetches of the
-                            CUDA path become the float trilinear blend Warp's CPU textures perform)
+  sample / sample_clamped   sdf_texture.py:786-828 (_locate_cell_coords) + :1008-1126 (_texture_sample_sdf_variant, software trilinear)
+  sample_hw(_clamped)       sdf_texture.py:1415-1538 (one filtered fetch at a fractional texture coordinate: what the mesh-SDF narrow
+                            phase samples with; on Warp's CPU device a float trilinear blend)
+  sample_grad_fd            sdf_texture.py:1619-1697 (_texture_sample_sdf_grad_hw_impl_variant: six hw fetches, centred differences)
   edge_search               sdf_contact.py:704-938 (do_edge_sdf_collision, texture-only variant: golden pair + 3 Brent steps)
   mesh_sdf_collide          sdf_contact.py:1098-1515 (mesh_sdf_collision_kernel with reduce_contacts=False), helpers :80-135,154-182
-All arithmetic in numpy.float32, one operation per statement, in the reference's order.  PARITY UNPINNED at bit level like the rest
-of the oracle (warp-lang is not installable here); pinned at tolerance level by the reference's tables in tests/test_sdf_*.py.
+All arithmetic in numpy.float32, one operation per statement, in the reference's order.  PINNED by tests/golden/sdf_reference_vectors.npz
+(tests/golden/make_sdf_reference_vectors.py EXECUTES the reference's samplers, do_edge_sdf_collision and mesh_sdf_collision_kernel on
+the stand-in of tests/golden/refshim): tests/test_sdf_reference_vectors.py holds every function below against that record bit for
+bit.  What stays restated is Warp's native texture fetch and vector builtins (not part of /root/reference).
 """
 from __future__ import annotations
 
@@ -81,6 +84,74 @@ class OracleSDF:
         dsq = f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2]))
         return self.sample_clamped(c, np.sqrt(dsq))
 
+    # ---- the "hardware" samplers the mesh-SDF narrow phase uses (sdf_texture.py:1267-1557): ONE filtered fetch at a fractional
+    # texture coordinate.  On Warp's CPU device the fetch is a float32 trilinear blend of the eight texels around
+    # (u - 0.5, v - 0.5, w - 0.5) -- restated in tests/golden/refshim/warp.texture_sample; the coordinate round trip
+    # (block origin + 0.5 + t, then - 0.5, floor, fraction) is part of the result: it costs the low bits of t.
+    def _fetch(self, tex, norm, dims, u):
+        c = []
+        for k in range(3):
+            x = f32(f32(u[k]) - f32(0.5))
+            i0 = int(np.floor(x))
+            c.append((i0, f32(x - f32(i0))))
+        (x0, tx), (y0, ty), (z0, tz) = c
+
+        def t(dx, dy, dz):
+            x, y, z = (min(max(v, 0), n - 1) for v, n in zip((x0 + dx, y0 + dy, z0 + dz), dims))
+            return f32(f32(tex[z, y, x]) * norm) if norm is not None else f32(tex[z, y, x])
+
+        c00 = f32(t(0, 0, 0) + f32(f32(t(1, 0, 0) - t(0, 0, 0)) * tx))
+        c10 = f32(t(0, 1, 0) + f32(f32(t(1, 1, 0) - t(0, 1, 0)) * tx))
+        c01 = f32(t(0, 0, 1) + f32(f32(t(1, 0, 1) - t(0, 0, 1)) * tx))
+        c11 = f32(t(0, 1, 1) + f32(f32(t(1, 1, 1) - t(0, 1, 1)) * tx))
+        c0 = f32(c00 + f32(f32(c10 - c00) * ty))
+        c1 = f32(c01 + f32(f32(c11 - c01) * ty))
+        return f32(c0 + f32(f32(c1 - c0) * tz))
+
+    def sample_hw_clamped(self, clamped, diff_mag):
+        """_texture_sample_sdf_hw_clamped_variant (:1415-1461)."""
+        t = self.t
+        f = (clamped - self.lo) * self.inv_dx
+        ssf = f32(self.ss)
+        fv = [f32(self.cx) * ssf, f32(self.cy) * ssf, f32(self.cz) * ssf]
+        fc = [_clampf(f[k], 0.0, fv[k]) for k in range(3)]
+        i = [min(max(int(np.floor(fc[k])), 0), int(fv[k]) - 1) for k in range(3)]
+        tt = [f32(fc[k] - f32(i[k])) for k in range(3)]
+        f2c = f32(1.0) / ssf
+        b = [min(max(int(f32(i[k]) * f2c), 0), (self.cx, self.cy, self.cz)[k] - 1) for k in range(3)]
+        slot = t.slots[b[0], b[1], b[2]]
+        if slot >= SLOT_LINEAR:
+            u = []
+            for k in range(3):
+                cf = f32(f32(f32(i[k]) + tt[k]) * f2c)
+                cb = f32(b[k])
+                u.append(f32(f32(cb + f32(cf - cb)) + f32(0.5)))
+            g = t.coarse
+            val = self._fetch(g, None, (g.shape[2], g.shape[1], g.shape[0]), u)
+        else:
+            s = int(slot)
+            samples = f32(self.ss + 1)
+            blk = [f32(s & 0x3FF), f32((s >> 10) & 0x3FF), f32((s >> 20) & 0x3FF)]
+            u = []
+            for k in range(3):
+                l = f32(f32(i[k]) - f32(f32(b[k]) * ssf))
+                o = f32(f32(f32(blk[k] * samples) + l) + f32(0.5))
+                u.append(f32(o + tt[k]))
+            sg = t.subgrid
+            raw = self._fetch(sg, None if sg.dtype == np.float32 else self.scale, (sg.shape[2], sg.shape[1], sg.shape[0]), u)
+            val = f32(f32(raw * self.vrange) + self.vmin)
+        return f32(val + f32(diff_mag))
+
+    def sample_hw(self, p):
+        """texture_sample_sdf_hw (:1495-1538)."""
+        p = np.asarray(p, dtype=f32)
+        c = self.clamp(p)
+        d = p - c
+        mag = f32(0.0)
+        if d[0] != 0.0 or d[1] != 0.0 or d[2] != 0.0:
+            mag = np.sqrt(f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2])))
+        return self.sample_hw_clamped(c, mag)
+
     def sample_grad_fd(self, p):
         p = np.asarray(p, dtype=f32)
         c = self.clamp(p)
@@ -99,8 +170,8 @@ class OracleSDF:
             d0, d1 = f32(p0[a] - c0), f32(p1[a] - c1)
             q0, q1 = p0.copy(), p1.copy()
             q0[a], q1[a] = c0, c1
-            v0 = self.sample_clamped(q0, np.sqrt(f32(d0 * d0)))
-            v1 = self.sample_clamped(q1, np.sqrt(f32(d1 * d1)))
+            v0 = self.sample_hw_clamped(q0, np.sqrt(f32(d0 * d0)) if f32(d0 * d0) != 0.0 else f32(0.0))
+            v1 = self.sample_hw_clamped(q1, np.sqrt(f32(d1 * d1)) if f32(d1 * d1) != 0.0 else f32(0.0))
             g[a] = f32(f32(v0 - v1) * self.inv_dx[a])
         return g
 
@@ -115,7 +186,7 @@ def edge_search(sdf: OracleSDF, v0, v1, midpoint_sdf, precision_target):
     if len_sq > 0.0:
         inv_len = f32(1.0) / np.sqrt(len_sq)
     tol_floor = f32(f32(f32(0.5) * f32(precision_target)) * inv_len)
-    at = lambda t: sdf.sample(v0 + e * f32(t))  # noqa: E731
+    at = lambda t: sdf.sample_hw(v0 + e * f32(t))  # noqa: E731
     a, b, x, w, v = f32(0.0), f32(1.0), f32(0.5), f32(0.5), f32(0.5)
     fx = f32(midpoint_sdf)
     fw = fv = fx
@@ -267,7 +338,7 @@ def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_in
                 d2 = f32(f32(f32(dd[0] * dd[0]) + f32(dd[1] * dd[1])) + f32(dd[2] * dd[2]))
                 if d2 > f32(threshold * threshold):
                     continue
-                mid = o.sample_clamped(cl, np.sqrt(d2) if d2 > 0.0 else f32(0.0))
+                mid = o.sample_hw_clamped(cl, np.sqrt(d2) if d2 > 0.0 else f32(0.0))
                 if not (mid <= threshold):
                     continue
                 c_loc = _x_point(X_m2s, ec[:3])

@@ -129,6 +129,27 @@ class _CopyOnAssign(ast.NodeTransformer):
         return self._wrap(node) if node.value is not None else node
 
 
+class _F32Literals(ast.NodeTransformer):
+    """Warp compiles every float literal and every `float(x)` of kernel code to float32.  Python keeps them as 64-bit floats, and
+    a chain of pure-literal locals (`golden = 0.38...; offset = 0.5 * golden; left = 0.5 - offset; m = 0.5 * (a + b)` in
+    do_edge_sdf_collision) would silently run in double precision.  Opt-in per module (install(f32_literals=...)): literals become
+    `__wp_f32__(c)` and `float(x)` calls become `__wp_f32__(x)`; the bare name `float` (annotations, dtype arguments) is left alone."""
+
+    def visit_Constant(self, node):
+        if isinstance(node.value, float):
+            return ast.copy_location(ast.Call(func=ast.Name(id="__wp_f32__", ctx=ast.Load()), args=[node], keywords=[]), node)
+        return node
+
+    def visit_Call(self, node):
+        self.generic_visit(node)
+        if isinstance(node.func, ast.Name) and node.func.id == "float" and len(node.args) == 1 and not node.keywords:
+            node.func = ast.copy_location(ast.Name(id="__wp_f32__", ctx=ast.Load()), node.func)
+        return node
+
+
+_F32_MODULES = set()
+
+
 class _ValueSemanticsLoader(importlib.abc.Loader):
     def __init__(self, name, path):
         self.name, self.path = name, path
@@ -138,7 +159,10 @@ class _ValueSemanticsLoader(importlib.abc.Loader):
 
     def exec_module(self, module):
         src = open(self.path).read()
-        tree = ast.fix_missing_locations(_CopyOnAssign().visit(ast.parse(src, self.path)))
+        tree = ast.parse(src, self.path)
+        if self.name in _F32_MODULES:
+            tree = _F32Literals().visit(tree)
+        tree = ast.fix_missing_locations(_CopyOnAssign().visit(tree))
         module.__file__ = self.path
         exec(compile(tree, self.path, "exec"), module.__dict__)
 
@@ -169,7 +193,7 @@ class _PkgLoader:
         pass
 
 
-def install(dummies=None, execute=("newton._src.math",), dummy_modules=()):
+def install(dummies=None, execute=("newton._src.math",), dummy_modules=(), f32_literals=()):
     here = os.path.dirname(os.path.abspath(__file__))
     if here not in sys.path:
         sys.path.insert(0, here)  # makes `import warp` find tests/golden/refshim/warp
@@ -178,4 +202,6 @@ def install(dummies=None, execute=("newton._src.math",), dummy_modules=()):
     import warp
 
     builtins.__wp_val__ = warp._val
+    builtins.__wp_f32__ = warp.f32
+    _F32_MODULES.update(f32_literals)
     sys.meta_path.insert(0, _Finder(dummies or {}, execute, dummy_modules))

@@ -1145,3 +1145,102 @@ _sys.modules["warp._src.utils"].array_scan = _array_scan
 _sys.modules["warp.types"].matrix = _make_matrix
 vec = _make_vector
 mat = _make_matrix
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# 3-D textures (sdf_texture.py): wp.Texture3D + wp.texture_sample as Warp's CPU device evaluates them -- software filtering in
+# float32.  Warp's native sampler (warp/native/texture.h) is not part of /root/reference, so the arithmetic is restated:
+#   * unnormalised coordinates, texel centres at i + 0.5: x = u - 0.5, i0 = floor(x), t = x - i0, CLAMP addressing of i0 and i0 + 1;
+#   * normalised integer formats return value * (1 / 65535) resp. (1 / 255) in float32;
+#   * LINEAR filter = the nested blend a + (b - a) * t along x, then y, then z (the order the reference's own software blend
+#     `_trilinear` uses); sampling at i + 0.5 has t == 0 and returns the texel exactly, whatever the blend form.
+# The reference's software samplers (texture_sample_sdf, _grad, _at_voxel) only ever sample at texel centres, so they do not
+# depend on the blend form; its "hw" samplers do (on a GPU: the texture unit's 8-bit weights, which no CPU restatement matches).
+# ------------------------------------------------------------------------------------------------------------------------------
+class Texture3D:
+    """data: numpy array [depth, height, width] (float32 / uint16 / uint8) or [depth, height, width, 2] for paired storage."""
+
+    def __init__(self, data=None, width=0, height=0, depth=0, num_channels=1, dtype=None, normalized_coords=False, filter_mode=None,
+                 address_mode=None, device=None, **kw):
+        if data is None:
+            self.data, self.width, self.height, self.depth, self.num_channels = None, 0, 0, 0, num_channels
+            return
+        d = _np.asarray(data)
+        self.data = d
+        self.depth, self.height, self.width = d.shape[0], d.shape[1], d.shape[2]
+        self.num_channels = d.shape[3] if d.ndim == 4 else 1
+        self._norm = {_np.dtype(_np.uint16): f32(1.0) / f32(65535.0), _np.dtype(_np.uint8): f32(1.0) / f32(255.0)}.get(d.dtype)
+
+    def _texel(self, x, y, z, ch=0):
+        x = 0 if x < 0 else (self.width - 1 if x > self.width - 1 else x)
+        y = 0 if y < 0 else (self.height - 1 if y > self.height - 1 else y)
+        z = 0 if z < 0 else (self.depth - 1 if z > self.depth - 1 else z)
+        v = self.data[z, y, x] if self.data.ndim == 3 else self.data[z, y, x, ch]
+        return f32(v) * self._norm if self._norm is not None else f32(v)
+
+
+def texture_sample(tex, uvw, dtype=float):
+    def one(ch):
+        c = []
+        for u in (uvw[0], uvw[1], uvw[2]):
+            x = _s(u) - f32(0.5)
+            i0 = int(_np.floor(x))
+            c.append((i0, x - f32(i0)))
+        (x0, tx), (y0, ty), (z0, tz) = c
+        t = lambda dx, dy, dz: tex._texel(x0 + dx, y0 + dy, z0 + dz, ch)  # noqa: E731
+        c00 = t(0, 0, 0) + (t(1, 0, 0) - t(0, 0, 0)) * tx
+        c10 = t(0, 1, 0) + (t(1, 1, 0) - t(0, 1, 0)) * tx
+        c01 = t(0, 0, 1) + (t(1, 0, 1) - t(0, 0, 1)) * tx
+        c11 = t(0, 1, 1) + (t(1, 1, 1) - t(0, 1, 1)) * tx
+        c0 = c00 + (c10 - c00) * ty
+        c1 = c01 + (c11 - c01) * ty
+        return c0 + (c1 - c0) * tz
+
+    if dtype in (float, float32):
+        return one(0)
+    return vec2(one(0), one(1))
+
+
+class _Array3(list):
+    """wp.array3d of scalars backed by a numpy array: a[x, y, z]."""
+
+    def __init__(self, data):
+        super().__init__()
+        self._d = _np.asarray(data)
+
+    def __getitem__(self, ijk): return self._d[ijk]
+    def __setitem__(self, ijk, v): self._d[ijk] = v
+
+    @property
+    def shape(self): return self._d.shape
+
+
+array3d = array
+
+
+def to_array3d(data):
+    return _Array3(data)
+
+
+# tile stacks of the mesh-SDF kernels as ONE lane sees them (block_dim() == 1 on the CPU device): push with a predicate, pop one
+class _TileStack:
+    def __init__(self, capacity): self.items, self.capacity = [], capacity
+
+
+def tile_stack(capacity=0, dtype=None, **kw): return _TileStack(capacity)
+def tile_stack_count(s): return len(s.items)
+def tile_stack_clear(s): s.items.clear()
+
+
+def tile_stack_push(s, value, pred):
+    if pred:
+        s.items.append(_val(value))
+
+
+def tile_stack_pop(s):
+    if s.items:
+        return s.items.pop(), 0
+    return None, -1
+
+
+def tile_extract(tile, i): return tile[i]
