@@ -402,6 +402,8 @@ typedef struct {
     const int32_t* pair_world_prefix; /* [worlds + 1] */
     int32_t worlds, pairs_per_world;
     int32_t* out_blk;
+    const uint8_t* pair_kind;         /* [worlds * pairs_per_world] or NULL: only pairs of kind 0 are processed (1 = hydroelastic pair,
+                                         nt_hydro_pairs) */
 } nt_mesh_sdf_args;
 nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
 
@@ -417,6 +419,10 @@ typedef struct {
     const float* shape_aabb_upper;   /* [S][3] Model.shape_collision_aabb_upper */
     const int32_t* shape_voxel_res;  /* [S][3] Model._shape_voxel_resolution (builder.py:11544-11570) */
     int32_t threads;                 /* workgroup size per pair: 64, 128 or 256 (0 = 256); pick ~ the edge count of a mesh */
+    const float* shape_edge_radius_max; /* [S] or NULL: largest mesh_edge_centers radius (w component) among the shape's collision
+                                           edges.  Lets the kernel skip a (pair, mode) whose edge carrier's local AABB, seen from the
+                                           SDF shape, lies beyond the cull threshold of its longest edge -- no edge could pass
+                                           edge culling (sdf_contact.py:1318-1340), so the result is unchanged */
 } nt_contact_reduce_shapes;
 nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* args, const nt_contact_reduce_shapes* shapes, void* stream);
 
@@ -529,8 +535,21 @@ typedef struct {
     int32_t* out_shapes;             /* [capacity][2] */
     float* out_data;                 /* [capacity][10] */
     int32_t capacity;
+    /* ---- nt_hydro_pairs only (the collide pipeline: world-region pairs as in nt_mesh_sdf_args) ---- */
+    const int32_t* pair_world_prefix; /* [worlds + 1] */
+    int32_t worlds, pairs_per_world;
+    const uint8_t* pair_kind;        /* [worlds * pairs_per_world]: 1 = hydroelastic pair (both shapes HYDROELASTIC), others skipped */
+    int32_t* out_pairs_normalized;   /* [worlds * pairs_per_world][2] or NULL: (shape_a, shape_b) after the finer-SDF-is-B swap */
+    int32_t* out_blk;                /* [worlds * pairs_per_world][2]: (0, rows of the pair) */
+    int32_t* out_rank;               /* [capacity] rank of the row inside its pair (rows of a pair are not contiguous) */
+    float* out_stiffness;            /* [capacity] Contacts.rigid_contact_stiffness of the row; out_data is then [capacity][9]:
+                                        centre, normal a -> b, margin-relative separation, 0, 0 (the pipeline's raw row) */
 } nt_hydro_args;
 nt_status nt_hydro_collide(const nt_hydro_args* args, void* stream);
+/* HydroelasticSDF.launch (sdf_hydroelastic.py:905-1296, reduce_contacts=False) inside the collide pipeline: SAT of the SDF boxes,
+ * the octree over the finer SDF's blocks (8 / 4 / 2 / 1 voxels, pressure-interval pruning :1444-1700) in LDS, marching cubes
+ * on the surviving voxels, one contact row per face with its rank inside the pair (nt_sdf_rows_finalize places the rows). */
+nt_status nt_hydro_pairs(const nt_hydro_args* args, void* stream);
 
 /* -------- the mesh-SDF leg of CollisionPipeline.collide as device stages (csrc/nt_sdf_pipeline.hip) --------
  * collide.py:1999 -> narrow_phase.py:2838-3167: pairs whose two shapes carry a texture SDF and collision edges (not box-box,
@@ -552,6 +571,9 @@ typedef struct {
     const int32_t* shape_body;       /* [ns] env-local body of every env-local shape (-1 static) */
     const float* shape_gap;          /* [shape_count] Model.shape_gap, Newton ids */
     int32_t pairs_per_world;         /* capacity of a world's candidate list */
+    const uint8_t* template_kind;    /* [template_pairs] or NULL (all 0): 0 = mesh-SDF edge contacts, 1 = hydroelastic (both shapes carry
+                                        ShapeFlags.HYDROELASTIC: narrow_phase.py:531-538) */
+    uint8_t* world_pair_kind;        /* [env_count * pairs_per_world] out of nt_sdf_candidate_pairs when template_kind is given */
 } nt_sdf_scene;
 /* candidate pairs of every world: world_pairs[(w * pairs_per_world + k)][2] = Newton shape ids (shape0 < shape1), ascending;
  * pair_count[w] keeps counting past pairs_per_world (overflow check), pair_prefix[env_count + 1] = exclusive scan of the
@@ -579,6 +601,12 @@ typedef struct {
     float* margin0;
     float* margin1;
     int32_t* key;                /* [row_capacity] or NULL: the row's fingerprint (tests, deterministic sort key) */
+    const int32_t* raw_rank;     /* [raw_capacity] or NULL: rank of the raw row inside its pair, for rows whose pair kind is 1 (their
+                                    blocks are not contiguous: nt_hydro_pairs); kind-0 rows use raw index - block offset */
+    const float* raw_stiffness;  /* [raw_capacity] or NULL: per-contact stiffness of kind-1 rows */
+    float* stiffness;            /* [row_capacity] or NULL: out, nt_flat_rows.stiffness / damping / friction_scale: the hydroelastic */
+    float* damping;              /*   rows carry their stiffness and zero damping / friction scale (ContactData defaults), */
+    float* friction_scale;       /*   mesh-SDF rows zeros (collide.py:196-199) */
 } nt_sdf_rows_io;
 /* final row ranges (world-major, pairs ascending, rows in fingerprint order), write_contact (collide.py:166-254) of every raw
  * row at its final position, and the per-body row-block lists.  body_q: State.body_q, env-major [7][nb][ES].

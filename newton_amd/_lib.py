@@ -73,7 +73,8 @@ class nt_contacts(C.Structure):
 class nt_sdf_scene(C.Structure):
     _fields_ = [("env_count", C.c_int32), ("env_stride", C.c_int32), ("nb", C.c_int32), ("ns", C.c_int32),
                 ("shape_local0", C.c_int32), ("template_pairs", C.c_int32), ("template_pair", C.c_void_p),
-                ("gshape_id", C.c_void_p), ("shape_body", C.c_void_p), ("shape_gap", C.c_void_p), ("pairs_per_world", C.c_int32)]
+                ("gshape_id", C.c_void_p), ("shape_body", C.c_void_p), ("shape_gap", C.c_void_p), ("pairs_per_world", C.c_int32),
+                ("template_kind", C.c_void_p), ("world_pair_kind", C.c_void_p)]
 
 
 class nt_sdf_rows_io(C.Structure):
@@ -82,7 +83,8 @@ class nt_sdf_rows_io(C.Structure):
                 ("raw_data", C.c_void_p), ("raw_capacity", C.c_int32), ("row_capacity", C.c_int32), ("shape0", C.c_void_p),
                 ("shape1", C.c_void_p), ("point0", C.c_void_p), ("point1", C.c_void_p), ("offset0", C.c_void_p),
                 ("offset1", C.c_void_p), ("normal", C.c_void_p), ("margin0", C.c_void_p), ("margin1", C.c_void_p),
-                ("key", C.c_void_p)]
+                ("key", C.c_void_p), ("raw_rank", C.c_void_p), ("raw_stiffness", C.c_void_p), ("stiffness", C.c_void_p),
+                ("damping", C.c_void_p), ("friction_scale", C.c_void_p)]
 
 
 class nt_flat_force_params(C.Structure):
@@ -122,12 +124,12 @@ class nt_mesh_sdf_args(C.Structure):
                 ("shape_edge_range", C.c_void_p), ("edge_centers", C.c_void_p), ("edge_halves", C.c_void_p),
                 ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_data", C.c_void_p),
                 ("capacity", C.c_int32), ("pair_count_device", C.c_void_p), ("pair_world_prefix", C.c_void_p),
-                ("worlds", C.c_int32), ("pairs_per_world", C.c_int32), ("out_blk", C.c_void_p)]
+                ("worlds", C.c_int32), ("pairs_per_world", C.c_int32), ("out_blk", C.c_void_p), ("pair_kind", C.c_void_p)]
 
 
 class nt_contact_reduce_shapes(C.Structure):
     _fields_ = [("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
-                ("threads", C.c_int32)]
+                ("threads", C.c_int32), ("shape_edge_radius_max", C.c_void_p)]
 
 
 class nt_contact_reduce_list(C.Structure):
@@ -165,7 +167,9 @@ class nt_hydro_args(C.Structure):
                 ("sdf_count", C.c_int32), ("tri_range", C.c_void_p), ("flat_edge_verts", C.c_void_p),
                 ("margin_contact_area", C.c_float), ("edge_clamp_min", C.c_float), ("out_count", C.c_void_p),
                 ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_shapes", C.c_void_p), ("out_data", C.c_void_p),
-                ("capacity", C.c_int32)]
+                ("capacity", C.c_int32), ("pair_world_prefix", C.c_void_p), ("worlds", C.c_int32), ("pairs_per_world", C.c_int32),
+                ("pair_kind", C.c_void_p), ("out_pairs_normalized", C.c_void_p), ("out_blk", C.c_void_p), ("out_rank", C.c_void_p),
+                ("out_stiffness", C.c_void_p)]
 
 
 class nt_semi_implicit_params(C.Structure):
@@ -312,6 +316,7 @@ SYMBOLS = {
     "nt_contacts_save_history": (C.c_int32, [C.POINTER(nt_model), C.POINTER(nt_state), C.POINTER(nt_contacts),
                                               C.POINTER(nt_contact_history), _P]),
     "nt_hydro_collide": (C.c_int32, [C.POINTER(nt_hydro_args), _P]),
+    "nt_hydro_pairs": (C.c_int32, [C.POINTER(nt_hydro_args), _P]),
     "nt_sdf_candidate_pairs": (C.c_int32, [C.POINTER(nt_sdf_scene), _P, _P, _P, _P, _P, _P]),
     "nt_sdf_rows_finalize": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_sdf_rows_io), _P, _P, _P, _P, _P]),
     "nt_flat_rows_forces": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_flat_rows), C.POINTER(nt_flat_force_params), _P]),

@@ -655,8 +655,9 @@ class ModelBuilder:
                 if src.sdf.scale_baked and tuple(src.sdf_scale) != scale:
                     raise ValueError(f"shape {i}: mesh.sdf was built with scale {tuple(src.sdf_scale)} baked in but the shape uses "
                                      f"scale {scale}; rebuild it with mesh.build_sdf(scale={scale})")
-            elif ty == GeoType.BOX and (self.shape_sdf_max_resolution[i] is not None or self.shape_sdf_target_voxel_size[i] is not None
-                                        or hydro):
+            elif (ty == GeoType.BOX and (self.shape_sdf_max_resolution[i] is not None or self.shape_sdf_target_voxel_size[i] is not None)) \
+                    or (hydro and ty in (GeoType.BOX, GeoType.SPHERE, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.ELLIPSOID, GeoType.CONE)):
+                # generated primitive SDF, scale baked (builder.py:11822-11870): boxes on request, any primitive when hydroelastic
                 res, vox = self.shape_sdf_max_resolution[i], self.shape_sdf_target_voxel_size[i]
                 if res is None and vox is None:
                     res = 64
@@ -668,15 +669,20 @@ class ModelBuilder:
                 make = lambda ty=ty, scale=scale, pad=pad, band=band, res=res, vox=vox, i=i: S.create_texture_sdf_from_primitive(  # noqa: E731
                     int(ty), scale, margin=pad, narrow_band_range=band, max_resolution=res, target_voxel_size=vox,
                     quantization_mode=fmt[self.shape_sdf_texture_format[i]], scale_baked=True)
-                edges_of = ("unit_box", scale)
-                edge_args = (None, None, scale)
-                lo_all[i], hi_all[i] = -np.asarray(scale, np.float32), np.asarray(scale, np.float32)
+                if ty == GeoType.BOX:  # the 12 edges of the unit box carry the mesh-SDF edge contacts of planar-faced shapes
+                    edges_of = ("unit_box", scale)
+                    edge_args = (None, None, scale)
+                ext = S.primitive_extents(int(ty), scale)
+                lo_all[i], hi_all[i] = np.asarray(ext[0], np.float32), np.asarray(ext[1], np.float32)
             if key is None:
                 continue
             if key not in cache:
                 cache[key] = len(table)
                 table.append(make())
             sdf_index[i] = cache[key]
+            voxel_res[i] = S.voxel_resolution_from_aabb(lo_all[i], hi_all[i])
+            if edges_of is None:
+                continue
             if edges_of not in edge_cache:
                 if edges_of[0] == "unit_box":
                     ec, eh = _box_edge_tables(edge_args[2])

@@ -370,8 +370,6 @@ class CollisionPipeline:
             raise ValueError(f"contact_matching_normal_dot_threshold must be in [-1, 1], got {contact_matching_normal_dot_threshold}")
         if contact_report and contact_matching == "disabled":
             raise ValueError('contact_report=True requires contact_matching != "disabled"')
-        if sdf_hydroelastic_config is not None:
-            raise NotImplementedError("hydroelastic contacts are not implemented yet (SURVEY.md section 8, row a25)")
         if broad_phase not in self._BROAD_PHASES:
             raise ValueError(f"broad_phase must be one of 'nxn', 'sap', 'explicit', got {broad_phase!r}")
         self.model = model
@@ -391,7 +389,8 @@ class CollisionPipeline:
             if contact_matching != "disabled":
                 raise NotImplementedError("contact_matching is not implemented for models with SDF contact pairs")
             sdf_pair_shape_types_ok(model)
-            self._sdf_leg = SdfLeg(model, pairs_per_shape=sdf_pairs_per_shape, contacts_per_shape=sdf_contacts_per_shape)
+            self._sdf_leg = SdfLeg(model, pairs_per_shape=sdf_pairs_per_shape, contacts_per_shape=sdf_contacts_per_shape,
+                                   hydro_config=sdf_hydroelastic_config)
             self._rigid_contact_max += self._sdf_leg.row_capacity
         model.rigid_contact_max = self._rigid_contact_max
         # fixed slots + ordered reductions: results are reproducible either way; deterministic=True additionally orders the

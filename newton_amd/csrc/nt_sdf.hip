@@ -347,20 +347,24 @@ NT_DI bool mode_setup(const nt_mesh_sdf_args& a, int s0, int s1, int mode, ModeC
     c.bhi = vec3(c.s.box_upper[0], c.s.box_upper[1], c.s.box_upper[2]);
     return true;
 }
-// One edge of the "triangle" shape against the other shape's SDF (sdf_contact.py:1288-1480): cull, Brent search, inner-cull
-// consistency, corner ownership, gradient.  -> world point, normal shape0 -> shape1, distance.
-NT_DI bool edge_contact(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int mode, vec3& pw, vec3& n, float& dist) {
-    const nt_sdf& s = c.s;
+// One edge of the "triangle" shape against the other shape's SDF (sdf_contact.py:1288-1480), in two steps so that the reduced
+// kernel can compact the survivors of the cull before the (long) search:
+//   edge_cull      bounding sphere of the edge against the SDF box, then against the value at its (clamped) midpoint
+//   edge_resolve   Brent search, inner-cull consistency, corner ownership, gradient -> world point, normal shape0 -> shape1, distance
+NT_DI bool edge_cull(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, float& mid) {
     const float* ec = a.edge_centers + 4 * (size_t)(c.e0 + e);
-    const float* eh = a.edge_halves + 4 * (size_t)(c.e0 + e);
-    // cull: bounding sphere of the edge against the SDF box, then against the midpoint value
     const vec3 center = cw_mul(xform_point(c.X_m2s, vec3(ec[0], ec[1], ec[2])), c.inv_scale);
     const float threshold = ec[3] * c.radius_scale + c.thr_unscaled;
     const vec3 cl = vmin(vmax(center, c.blo), c.bhi);
     const float d2 = length_sq(center - cl);
     if (d2 > threshold * threshold) return false;
-    const float mid = sample_hw_clamped(s, cl, d2 > 0.0f ? sqrtf(d2) : 0.0f);
-    if (!(mid <= threshold)) return false;
+    mid = sample_hw_clamped(c.s, cl, d2 > 0.0f ? sqrtf(d2) : 0.0f);
+    return mid <= threshold;
+}
+NT_DI bool edge_resolve(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int mode, float mid, vec3& pw, vec3& n, float& dist) {
+    const nt_sdf& s = c.s;
+    const float* ec = a.edge_centers + 4 * (size_t)(c.e0 + e);
+    const float* eh = a.edge_halves + 4 * (size_t)(c.e0 + e);
     // the edge in the SDF's unscaled space + its corner ownership
     const vec3 c_loc = xform_point(c.X_m2s, vec3(ec[0], ec[1], ec[2]));
     const vec3 h_loc = xform_vector(c.X_m2s, vec3(eh[0], eh[1], eh[2]));
@@ -399,6 +403,26 @@ NT_DI bool edge_contact(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int 
     }
     n = mode == 0 ? -dw : dw;
     return true;
+}
+NT_DI bool edge_contact(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, int mode, vec3& pw, vec3& n, float& dist) {
+    float mid;
+    return edge_cull(a, c, e, mid) && edge_resolve(a, c, e, mode, mid, pw, n, dist);
+}
+// Can ANY edge of the "triangle" shape pass the cull?  Every edge lies inside the shape's local AABB (the reduction tables carry
+// it, scale applied); its image in the SDF's unscaled space is bounded by the AABB of the eight transformed corners, and an edge
+// whose bounding sphere is farther than its threshold from the SDF box is rejected by edge_cull.  Conservative (never rejects a
+// mode that has a surviving edge): the slack is edge_cull's threshold for the shape's longest edge.
+NT_DI bool mode_can_touch(const ModeCtx& c, const float* lo, const float* hi, float max_edge_radius) {
+    vec3 mn(1e30f, 1e30f, 1e30f), mx(-1e30f, -1e30f, -1e30f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const vec3 q = cw_mul(xform_point(c.X_m2s, vec3((k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2])), c.inv_scale);
+        mn = vmin(mn, q);
+        mx = vmax(mx, q);
+    }
+    const float t = (max_edge_radius * c.radius_scale + c.thr_unscaled) * 1.0001f + 1e-6f;  // edge_cull's largest threshold
+    return mn.x <= c.bhi.x + t && mx.x >= c.blo.x - t && mn.y <= c.bhi.y + t && mx.y >= c.blo.y - t && mn.z <= c.bhi.z + t &&
+           mx.z >= c.blo.z - t;
 }
 
 NT_DI int live_pair_count(const nt_mesh_sdf_args& a) {
@@ -631,44 +655,111 @@ NT_DI void red_finish(RedLds& L) {
 }
 
 // mesh_sdf_collision_global_reduce_kernel (sdf_contact.py:1534-1990) + export_reduced_contacts_kernel, one workgroup per pair.
-__global__ void __launch_bounds__(256) mesh_sdf_collide_reduced_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
+// Per mode: (1) every lane culls edges and the survivors are compacted into an LDS list (the reference's cooperative tile
+// stack), (2) the lanes walk that list densely -- Brent search, consistency, ownership, gradient -- keep each contact's record
+// in LDS and offer it to the pair's table.  After both modes the <= 245 winners read their record back through the fingerprint
+// (a list overflow -- meshes with hundreds of near edges -- falls back to recomputing the winner: same instructions, same bits).
+constexpr int HIT_CAP = 128;
+constexpr int SLOT_LDS = 512;
+struct HitLds {
+    int fp[HIT_CAP];       // fingerprint of the survivor (edge << 2 | mode << 1); -1 once the resolve rejected it
+    float mid[HIT_CAP];    // SDF value at its clamped midpoint (edge_cull)
+    float pos[HIT_CAP][4]; // resolved contact: world point, distance
+    float oct[HIT_CAP][2]; // octahedral code of its normal
+    int n;                 // survivors appended so far (may exceed HIT_CAP: the excess was processed on the spot)
+};
+#ifndef NT_SDF_WAVES_PER_EU  // measurement builds (tools/build_variant.py -DNT_SDF_WAVES_PER_EU=n) cap the registers for n waves per SIMD
+#define NT_SDF_OCCUPANCY
+#else
+#define NT_SDF_OCCUPANCY __attribute__((amdgpu_waves_per_eu(NT_SDF_WAVES_PER_EU, NT_SDF_WAVES_PER_EU)))
+#endif
+__global__ void __launch_bounds__(256) NT_SDF_OCCUPANCY mesh_sdf_collide_reduced_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
     __shared__ RedLds L;
+    __shared__ HitLds H;
+    __shared__ uint32_t slot_lds[SLOT_LDS];  // the SDF's indirection table of the current mode (every sample reads it first)
     const int t = threadIdx.x;
     const int pair_count = live_pair_count(a);
     for (int f = blockIdx.x; f < pair_count; f += gridDim.x) {
         const int pair_idx = pair_slot(a, f);
+        if (a.pair_kind && a.pair_kind[pair_idx] != 0) continue;  // another leg's pair (uniform)
         const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
         for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
+        if (t == 0) H.n = 0;
         __syncthreads();
         for (int mode = 0; mode < 2; ++mode) {
             ModeCtx c;
             if (!mode_setup(a, s0, s1, mode, c)) continue;
             const int tri_shape = mode == 0 ? s0 : s1;
+            if (r.shape_edge_radius_max && !mode_can_touch(c, r.shape_aabb_lower + 3 * tri_shape, r.shape_aabb_upper + 3 * tri_shape,
+                                                           r.shape_edge_radius_max[tri_shape]))
+                continue;
             const vec3 midpoint = (c.X_tri.p + c.X_sdf.p) * 0.5f;
             const float margin_sum = c.tri_margin + c.sdf_margin;
             const float inner_depth = margin_sum + fminw(c.s.voxel_radius * c.min_scale, c.gap_sum);  // base gap == gap
             const float outer_depth = margin_sum + c.gap_sum;
-            for (int e = t; e < c.ne; e += blockDim.x) {
-                vec3 pw, n;
-                float dist;
-                if (!edge_contact(a, c, e, mode, pw, n, dist)) continue;
+            auto offer = [&](int fp, vec3 pw, vec3 n, float dist) {
                 const vec3 local = quat_rotate_inv(c.X_tri.q, pw - c.X_tri.p);
                 red_offer(L.tbl, n, pw - midpoint, dist, inner_depth, outer_depth, local, r.shape_aabb_lower + 3 * tri_shape,
-                          r.shape_aabb_upper + 3 * tri_shape, r.shape_voxel_res + 3 * tri_shape, (e << 2) | (mode << 1));
+                          r.shape_aabb_upper + 3 * tri_shape, r.shape_voxel_res + 3 * tri_shape, fp);
+            };
+            const int seg = H.n < HIT_CAP ? H.n : HIT_CAP;  // this mode's survivors start here (uniform: read after a barrier)
+            // A sample is two dependent reads (indirection slot, then texels); with the small slot table in LDS only the texel
+            // fetch pays a trip to L2.  (The winner pass below recomputes through the global table: same values.)
+            const int n_slots = c.s.cx * c.s.cy * c.s.cz;
+            if (n_slots <= SLOT_LDS) {
+                for (int k = t; k < n_slots; k += blockDim.x) slot_lds[k] = c.s.slots[k];
+                c.s.slots = slot_lds;
             }
+            __syncthreads();
+            for (int e = t; e < c.ne; e += blockDim.x) {
+                float mid;
+                if (!edge_cull(a, c, e, mid)) continue;
+                const int fp = (e << 2) | (mode << 1);
+                const int i = atomicAdd(&H.n, 1);
+                if (i < HIT_CAP) {
+                    H.fp[i] = fp;
+                    H.mid[i] = mid;
+                } else {  // list full: resolve on the spot, the winner pass recomputes it if it wins
+                    vec3 pw, n;
+                    float dist;
+                    if (edge_resolve(a, c, e, mode, mid, pw, n, dist)) offer(fp, pw, n, dist);
+                }
+            }
+            __syncthreads();
+            const int end = H.n < HIT_CAP ? H.n : HIT_CAP;
+            for (int i = seg + t; i < end; i += blockDim.x) {
+                const int fp = H.fp[i];
+                vec3 pw, n;
+                float dist;
+                if (edge_resolve(a, c, fp >> 2, mode, H.mid[i], pw, n, dist)) {
+                    H.pos[i][0] = pw.x; H.pos[i][1] = pw.y; H.pos[i][2] = pw.z; H.pos[i][3] = dist;
+                    red_encode_oct(n, H.oct[i][0], H.oct[i][1]);
+                    offer(fp, pw, n, dist);
+                } else {
+                    H.fp[i] = -1;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k, recomputed from its fingerprint
+        const int hits = H.n < HIT_CAP ? H.n : HIT_CAP;
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k: its record from the list, else recomputed
             if (L.tbl[k] == 0ull) continue;
             const int fp = (int)(L.tbl[k] & RED_FP_MASK);
-            const int mode = (fp >> 1) & 1;
-            ModeCtx c;
-            mode_setup(a, s0, s1, mode, c);
-            vec3 pw, n;
-            float dist;
-            edge_contact(a, c, fp >> 2, mode, pw, n, dist);
-            L.pos[k][0] = pw.x; L.pos[k][1] = pw.y; L.pos[k][2] = pw.z; L.pos[k][3] = dist;
-            red_encode_oct(n, L.oct[k][0], L.oct[k][1]);
+            int i = 0;
+            while (i < hits && H.fp[i] != fp) ++i;
+            if (i < hits) {
+                L.pos[k][0] = H.pos[i][0]; L.pos[k][1] = H.pos[i][1]; L.pos[k][2] = H.pos[i][2]; L.pos[k][3] = H.pos[i][3];
+                L.oct[k][0] = H.oct[i][0]; L.oct[k][1] = H.oct[i][1];
+            } else {
+                const int mode = (fp >> 1) & 1;
+                ModeCtx c;
+                mode_setup(a, s0, s1, mode, c);
+                vec3 pw, n;
+                float dist;
+                edge_contact(a, c, fp >> 2, mode, pw, n, dist);
+                L.pos[k][0] = pw.x; L.pos[k][1] = pw.y; L.pos[k][2] = pw.z; L.pos[k][3] = dist;
+                red_encode_oct(n, L.oct[k][0], L.oct[k][1]);
+            }
             L.fp[k] = fp;
         }
         __syncthreads();
@@ -911,6 +1002,342 @@ __global__ void __launch_bounds__(256) hydro_collide_kernel(nt_hydro_args a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// HydroelasticSDF.launch (sdf_hydroelastic.py:905-1296) for the collide pipeline, one workgroup per shape pair:
+//   broad phase      broadphase_collision_pairs_count (:1330-1376): SAT of the two SDF boxes, the finer SDF becomes shape B,
+//                    every 8^3 subgrid of B is a block
+//   octree           count_iso_voxels_block / count_iso_voxel_children + scatter_iso_subblock (:1444-1700): blocks of 8, 4, 2, 1
+//                    voxels survive while the pressure intervals of the two shapes over the block (1-Lipschitz bound of either
+//                    SDF around the block centre) can still meet and the centre is within 2 r + gap of both surfaces
+//   faces            generate_contacts_kernel without pre-pruning (:1982-2180) + decode_contacts_kernel (:1823-1928): marching
+//                    cubes on p_a == p_b in every surviving voxel, one contact per face, stiffness area * pressure / |separation|
+// The reference runs each level as count -> scan -> scatter launches over device-wide buffers.  Here the pair's workgroup walks
+// B's blocks itself: the level-8 test for all blocks at once, then per surviving block the three lower levels as bit masks in
+// LDS (8 / 64 / 512 lanes), an ordered compaction of the surviving voxels -- the order the reference's ordered scatter produces:
+// (block, child of 4, child of 2, voxel), children by x + 2 y + 4 z -- and marching cubes on them.  Faces leave through one
+// atomic per block of voxels; every row carries its rank inside the pair, so the final placement is deterministic.
+// Fingerprint = (rank of the voxel in the pair's traversal) * 5 + face: the reference numbers voxels across ALL pairs in the
+// arrival order of its pair list, which changes from run to run; inside a pair the order is the same.
+// ------------------------------------------------------------------------------------------------
+constexpr int HYDRO_MAX_BLOCKS = 4096;
+struct HydroLds {
+    unsigned char blk[HYDRO_MAX_BLOCKS];  // level-8 survivors
+    unsigned char l4[8], l2[64], l1[512];
+    int vox[512];                         // surviving voxels of the current block, traversal order
+    int wsum[4];
+    int n_vox, n_face, base, collide;
+    int pair_vox, pair_face;              // running totals of the pair
+};
+struct HydroPair {
+    nt_sdf A, B;
+    int sa, sb;
+    xform X_b, X_b2a;
+    float gap_sum, margin_a, margin_b, kh_a, kh_b;
+};
+// one octree node of shape B: cube of `size` voxels at (x, y, z) (count_iso_voxels_block's body)
+NT_DI bool hydro_node_survives(const HydroPair& p, int x, int y, int z, int size) {
+    const nt_sdf& A = p.A;
+    const nt_sdf& B = p.B;
+    const float r = (float)size * B.voxel_radius;
+    const float h = 0.5f * (float)size;
+    const vec3 centre((float)x + h, (float)y + h, (float)z + h);
+    const vec3 local_b = vec3(B.box_lower[0], B.box_lower[1], B.box_lower[2]) +
+                         cw_mul(centre, vec3(B.voxel_size[0], B.voxel_size[1], B.voxel_size[2]));
+    const vec3 point_a = xform_point(p.X_b2a, local_b);
+    const float vb = (size & 1) == 0 ? sample_at_voxel(B, x + size / 2, y + size / 2, z + size / 2) : sample(B, local_b);
+    const float va = sample(A, point_a);
+    if (vb != vb || va != va) return false;
+    const float eva = va - p.margin_a, evb = vb - p.margin_b;
+    if (eva + evb > 2.0f * r + p.gap_sum) return false;
+    const float pa_lo = -p.kh_a * (eva + r), pa_hi = -p.kh_a * (eva - r);  // linear_pressure (:237-248)
+    const float pb_lo = -p.kh_b * (evb + r), pb_hi = -p.kh_b * (evb - r);
+    return !(pa_hi < pb_lo || pb_hi < pa_lo);
+}
+// sat_box_intersection (collision_core.py:1281-1374) of the two SDF boxes
+NT_DI bool hydro_sat(const xform& Ta, vec3 ea, const xform& Tb, vec3 eb) {
+    vec3 axa[3] = {quat_rotate(Ta.q, vec3(1.0f, 0.0f, 0.0f)), quat_rotate(Ta.q, vec3(0.0f, 1.0f, 0.0f)), quat_rotate(Ta.q, vec3(0.0f, 0.0f, 1.0f))};
+    vec3 axb[3] = {quat_rotate(Tb.q, vec3(1.0f, 0.0f, 0.0f)), quat_rotate(Tb.q, vec3(0.0f, 1.0f, 0.0f)), quat_rotate(Tb.q, vec3(0.0f, 0.0f, 1.0f))};
+    auto separated = [&](vec3 axis) {
+        const float len = length(axis);
+        if (len < 1e-8f) return false;
+        const vec3 n = axis / len;
+        auto project = [&](const xform& T, const vec3* ax, vec3 e, float& lo, float& hi) {
+            const float c = dot(T.p, n);
+            float ext = 0.0f;
+            ext += e.x * fabsf(dot(ax[0], n));
+            ext += e.y * fabsf(dot(ax[1], n));
+            ext += e.z * fabsf(dot(ax[2], n));
+            lo = c - ext;
+            hi = c + ext;
+        };
+        float la, ha, lb, hb;
+        project(Ta, axa, ea, la, ha);
+        project(Tb, axb, eb, lb, hb);
+        return ha < lb || hb < la;
+    };
+    for (int i = 0; i < 3; ++i)
+        if (separated(axa[i])) return false;
+    for (int i = 0; i < 3; ++i)
+        if (separated(axb[i])) return false;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            if (separated(cross(axa[i], axb[j]))) return false;
+    return true;
+}
+struct HydroFace { vec3 pos; float oct0, oct1, depth, stiff; };
+// marching cubes of one voxel of B (mc_iterate_voxel_vertices :1716-1798, mc_calc_face_texture :282-362, the face filters and the
+// decode of the unreduced path); returns the number of faces kept (<= 5), in face order
+NT_DI int hydro_voxel_faces(const nt_hydro_args& a, const HydroPair& p, int x, int y, int z, HydroFace* out, int* face_id) {
+    const nt_sdf& A = p.A;
+    const nt_sdf& B = p.B;
+    const vec3 vs(B.voxel_size[0], B.voxel_size[1], B.voxel_size[2]), blo(B.box_lower[0], B.box_lower[1], B.box_lower[2]);
+    const vec3 base_b = blo + cw_mul(vec3((float)x, (float)y, (float)z), vs);
+    const vec3 base_a = xform_point(p.X_b2a, base_b);
+    const vec3 step_x = xform_vector(p.X_b2a, vec3(vs.x, 0.0f, 0.0f)), step_y = xform_vector(p.X_b2a, vec3(0.0f, vs.y, 0.0f)),
+               step_z = xform_vector(p.X_b2a, vec3(0.0f, 0.0f, vs.z));
+    float cv[8], cself[8], cother[8];
+    int cube = 0;
+    bool any_gap = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ox = mc_cx(i), oy = mc_cy(i), oz = mc_cz(i);
+        const vec3 pa = base_a + (float)ox * step_x + (float)oy * step_y + (float)oz * step_z;
+        const float v_self = sample_at_voxel(B, x + ox, y + oy, z + oz);
+        const float v_other = sample(A, pa);
+        if (v_self != v_self || v_other != v_other) return 0;
+        const float es = v_self - p.margin_b, eo = v_other - p.margin_a;
+        const float vd = (-p.kh_a * eo) - (-p.kh_b * es);
+        cv[i] = vd; cself[i] = es; cother[i] = eo;
+        if (vd < 0.0f) cube |= 1 << i;
+        if (es + eo <= p.gap_sum) any_gap = true;
+    }
+    if (!any_gap) return 0;
+    const int t0 = a.tri_range[cube], t1 = a.tri_range[cube + 1];
+    const float cmin = a.edge_clamp_min, cmax = 1.0f - a.edge_clamp_min;
+    int kept = 0;
+    for (int fi = 0; fi < (t1 - t0) / 3; ++fi) {
+        vec3 fv[3];
+        float vsdf[3], vsep[3];
+        int n_in = 0;
+#pragma unroll
+        for (int vi = 0; vi < 3; ++vi) {
+            const int ca = a.flat_edge_verts[2 * (t0 + 3 * fi + vi)], cb = a.flat_edge_verts[2 * (t0 + 3 * fi + vi) + 1];
+            auto sel = [](const float* v, int k) {  // value select, no private array indexing
+                return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : k == 4 ? v[4] : k == 5 ? v[5] : k == 6 ? v[6] : v[7];
+            };
+            const float va0 = sel(cv, ca), va1 = sel(cv, cb);
+            const float vd = va1 - va0;
+            const float t = fabsf(vd) < 1.0e-10f ? 0.5f : clampf((0.0f - va0) / vd, cmin, cmax);
+            const vec3 p0((float)mc_cx(ca), (float)mc_cy(ca), (float)mc_cz(ca)), p1((float)mc_cx(cb), (float)mc_cy(cb), (float)mc_cz(cb));
+            const vec3 vol = p0 + t * (p1 - p0) + vec3((float)x, (float)y, (float)z);
+            fv[vi] = blo + cw_mul(vol, vs);
+            const float s_self = sel(cself, ca) + t * (sel(cself, cb) - sel(cself, ca));
+            const float s_other = sel(cother, ca) + t * (sel(cother, cb) - sel(cother, ca));
+            vsdf[vi] = s_self;
+            vsep[vi] = s_self + s_other;
+            if (vsep[vi] < 0.0f) n_in += 1;
+        }
+        const vec3 n = cross(fv[1] - fv[0], fv[2] - fv[0]);
+        const float n_sq = dot(n, n);
+        float garea = 0.0f;
+        vec3 normal(0.0f, 0.0f, 1.0f);
+        if (!(n_sq < 1.0e-20f)) {
+            const float inv = 1.0f / sqrtf(n_sq);
+            normal = n * inv;
+            garea = (n_sq * inv) * 0.5f;
+        }
+        const vec3 center = ((fv[0] + fv[1]) + fv[2]) / 3.0f;
+        const float adj = ((vsdf[0] + vsdf[1]) + vsdf[2]) / 3.0f;
+        const float sep = ((vsep[0] + vsep[1]) + vsep[2]) / 3.0f;
+        const float farea = garea * triangle_fraction(vsep[0], vsep[1], vsep[2], n_in);
+        if (garea <= 0.0f) continue;
+        if (!(sep < 0.0f) && sep > p.gap_sum) continue;  // classify_hydroelastic_contact > 0
+        const float pressure = sep < 0.0f ? fmaxw(-p.kh_b * adj, 0.0f) : 0.0f;
+        const float area = sep < 0.0f ? farea : garea;
+        float stiff;
+        if (sep < 0.0f) stiff = area * pressure / fmaxw(-sep, 1e-20f);
+        else {
+            const float den = p.kh_a + p.kh_b;
+            stiff = a.margin_contact_area * (den <= 0.0f ? 0.0f : (p.kh_a * p.kh_b) / den);
+        }
+        HydroFace& f = out[kept];
+        f.pos = center;  // B's frame; the buffer keeps the normal as its octahedral code (export_hydroelastic_contact_to_buffer)
+        red_encode_oct(normal, f.oct0, f.oct1);
+        f.depth = sep;
+        f.stiff = stiff;
+        face_id[kept] = fi;
+        kept += 1;
+    }
+    return kept;
+}
+
+__global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
+    __shared__ HydroLds L;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int pair_total = a.pair_world_prefix[a.worlds];
+    for (int f = blockIdx.x; f < pair_total; f += gridDim.x) {
+        int lo = 0, hi = a.worlds;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.pair_world_prefix[mid] <= f) lo = mid;
+            else hi = mid;
+        }
+        const int pair_idx = lo * a.pairs_per_world + (f - a.pair_world_prefix[lo]);
+        if (a.pair_kind[pair_idx] != 1) continue;
+        HydroPair p;
+        p.sa = a.pairs[2 * (size_t)pair_idx];
+        p.sb = a.pairs[2 * (size_t)pair_idx + 1];
+        int ia = a.shape_sdf_index[p.sa], ib = a.shape_sdf_index[p.sb];
+        bool ok = ia >= 0 && ib >= 0 && ia < a.sdf_count && ib < a.sdf_count;
+        if (ok) {
+            p.A = a.sdf_table[ia];
+            p.B = a.sdf_table[ib];
+            ok = p.A.cx > 0 && p.B.cx > 0;
+        }
+        __syncthreads();
+        if (t == 0) {
+            L.pair_vox = 0;
+            L.pair_face = 0;
+            L.collide = 0;
+            if (ok) {  // SAT of the two SDF boxes (centred transforms), before the finer-is-B swap like the reference
+                const xform Xa = load_xform(a.shape_transform + 7 * p.sa), Xb = load_xform(a.shape_transform + 7 * p.sb);
+                const vec3 alo(p.A.box_lower[0], p.A.box_lower[1], p.A.box_lower[2]), ahi(p.A.box_upper[0], p.A.box_upper[1], p.A.box_upper[2]);
+                const vec3 blo(p.B.box_lower[0], p.B.box_lower[1], p.B.box_lower[2]), bhi(p.B.box_upper[0], p.B.box_upper[1], p.B.box_upper[2]);
+                const xform Ca = Xa * xform(0.5f * (alo + ahi), quat(0.0f, 0.0f, 0.0f, 1.0f));
+                const xform Cb = Xb * xform(0.5f * (blo + bhi), quat(0.0f, 0.0f, 0.0f, 1.0f));
+                L.collide = hydro_sat(Ca, 0.5f * (ahi - alo), Cb, 0.5f * (bhi - blo)) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (ok && p.B.voxel_radius > p.A.voxel_radius) {  // keep the finer SDF as shape B (:1362-1366)
+            const int s_ = p.sa; p.sa = p.sb; p.sb = s_;
+            const nt_sdf tmp = p.A; p.A = p.B; p.B = tmp;
+        }
+        if (t == 0 && a.out_pairs_normalized) {
+            a.out_pairs_normalized[2 * (size_t)pair_idx] = p.sa;
+            a.out_pairs_normalized[2 * (size_t)pair_idx + 1] = p.sb;
+        }
+        const int nbx = ok ? p.B.cx : 0, nby = ok ? p.B.cy : 0, nbz = ok ? p.B.cz : 0;
+        const int nblocks = nbx * nby * nbz;
+        if (ok && L.collide && nblocks <= HYDRO_MAX_BLOCKS) {
+            p.gap_sum = a.shape_gap[p.sa] + a.shape_gap[p.sb];
+            p.margin_a = a.shape_data[4 * p.sa + 3];
+            p.margin_b = a.shape_data[4 * p.sb + 3];
+            p.kh_a = a.shape_kh[p.sa];
+            p.kh_b = a.shape_kh[p.sb];
+            p.X_b = load_xform(a.shape_transform + 7 * p.sb);
+            p.X_b2a = xform_inverse(load_xform(a.shape_transform + 7 * p.sa)) * p.X_b;
+            const int sgs = p.B.subgrid_size;  // 8
+            for (int b = t; b < nblocks; b += blockDim.x) {  // level 8: block b = (bz * nby + by) * nbx + bx
+                const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
+                L.blk[b] = hydro_node_survives(p, bx * sgs, by * sgs, bz * sgs, sgs) ? 1 : 0;
+            }
+            __syncthreads();
+            for (int b = 0; b < nblocks; ++b) {
+                if (!L.blk[b]) continue;  // uniform
+                const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
+                const int x0 = bx * sgs, y0 = by * sgs, z0 = bz * sgs;
+                auto child = [](int code, int& cx, int& cy, int& cz) { cx = code & 1; cy = (code >> 1) & 1; cz = (code >> 2) & 1; };
+                if (t < 8) {
+                    int cx, cy, cz;
+                    child(t, cx, cy, cz);
+                    L.l4[t] = hydro_node_survives(p, x0 + 4 * cx, y0 + 4 * cy, z0 + 4 * cz, 4) ? 1 : 0;
+                }
+                __syncthreads();
+                if (t < 64) {
+                    int ax, ay, az, bx_, by_, bz_;
+                    child(t >> 3, ax, ay, az);
+                    child(t & 7, bx_, by_, bz_);
+                    L.l2[t] = L.l4[t >> 3] && hydro_node_survives(p, x0 + 4 * ax + 2 * bx_, y0 + 4 * ay + 2 * by_, z0 + 4 * az + 2 * bz_, 2) ? 1 : 0;
+                }
+                __syncthreads();
+                for (int j = t; j < 512; j += blockDim.x) {
+                    int ax, ay, az, bx_, by_, bz_, cx, cy, cz;
+                    child(j >> 6, ax, ay, az);
+                    child((j >> 3) & 7, bx_, by_, bz_);
+                    child(j & 7, cx, cy, cz);
+                    L.l1[j] = L.l2[j >> 3] && hydro_node_survives(p, x0 + 4 * ax + 2 * bx_ + cx, y0 + 4 * ay + 2 * by_ + cy, z0 + 4 * az + 2 * bz_ + cz, 1) ? 1 : 0;
+                }
+                __syncthreads();
+                // ordered compaction of the block's surviving voxels (two passes of 256 over the 512 flags)
+                if (t == 0) L.n_vox = 0;
+                __syncthreads();
+                for (int j0 = 0; j0 < 512; j0 += 256) {
+                    const int j = j0 + t;
+                    const bool hit = t < 256 && L.l1[j] != 0;
+                    const unsigned long long mask = __ballot(hit);
+                    if (lane == 0) L.wsum[wave] = __popcll(mask);
+                    __syncthreads();
+                    int off = L.n_vox;
+                    for (int k = 0; k < wave; ++k) off += L.wsum[k];
+                    if (hit) L.vox[off + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                    __syncthreads();
+                    if (t == 0) L.n_vox += L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+                    __syncthreads();
+                }
+                const int n_vox = L.n_vox;
+                for (int i0 = 0; i0 < n_vox; i0 += 256) {  // marching cubes, one lane per voxel, faces leave in voxel order
+                    const int i = i0 + t;
+                    HydroFace faces[5];
+                    int face_id[5];
+                    int kept = 0, vx = 0;
+                    if (t < 256 && i < n_vox) {
+                        const int j = L.vox[i];
+                        int ax, ay, az, bx_, by_, bz_, cx, cy, cz;
+                        child(j >> 6, ax, ay, az);
+                        child((j >> 3) & 7, bx_, by_, bz_);
+                        child(j & 7, cx, cy, cz);
+                        kept = hydro_voxel_faces(a, p, x0 + 4 * ax + 2 * bx_ + cx, y0 + 4 * ay + 2 * by_ + cy, z0 + 4 * az + 2 * bz_ + cz, faces, face_id);
+                        vx = 1;
+                    }
+                    (void)vx;
+                    int x = kept;  // inclusive scan of the kept counts over the workgroup
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int y = __shfl_up(x, d);
+                        if (lane >= d) x += y;
+                    }
+                    if (lane == 63) L.wsum[wave] = x;
+                    __syncthreads();
+                    int before = x - kept;
+                    for (int k = 0; k < wave; ++k) before += L.wsum[k];
+                    if (t == 0) {
+                        const int total = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+                        L.n_face = total;
+                        L.base = total > 0 ? atomicAdd(a.out_count, total) : 0;
+                    }
+                    __syncthreads();
+                    for (int k = 0; k < kept; ++k) {
+                        const int slot = L.base + before + k;
+                        if (slot >= a.capacity) continue;
+                        const HydroFace& fc = faces[k];
+                        const vec3 nrm = red_decode_oct(fc.oct0, fc.oct1);
+                        const vec3 pw = xform_point(p.X_b, fc.pos), nw = xform_vector(p.X_b, nrm);
+                        a.out_pair[slot] = pair_idx;
+                        a.out_key[slot] = (L.pair_vox + i) * 5 + face_id[k];
+                        a.out_rank[slot] = L.pair_face + before + k;
+                        float* o = a.out_data + 9 * (size_t)slot;
+                        o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; o[3] = nw.x; o[4] = nw.y; o[5] = nw.z;
+                        o[6] = fc.depth; o[7] = 0.0f; o[8] = 0.0f;
+                        a.out_stiffness[slot] = fc.stiff;
+                    }
+                    __syncthreads();
+                    if (t == 0) L.pair_face += L.n_face;
+                    __syncthreads();
+                }
+                if (t == 0) L.pair_vox += n_vox;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            const int total = L.pair_face;
+            a.out_blk[2 * (size_t)pair_idx] = 0;
+            a.out_blk[2 * (size_t)pair_idx + 1] = total;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -923,6 +1350,19 @@ nt_status nt_hydro_collide(const nt_hydro_args* a, void* stream) {
     if (a->pair_count == 0) return NT_OK;
     int blocks = a->pair_count < 2048 ? a->pair_count : 2048;
     hipLaunchKernelGGL(hydro_collide_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
+    if (!a || !a->pairs || !a->pair_world_prefix || a->worlds <= 0 || a->pairs_per_world <= 0 || !a->pair_kind || !a->out_blk ||
+        !a->out_rank || !a->out_stiffness || !a->out_count || !a->out_pair || !a->out_key || !a->out_data || a->capacity <= 0 ||
+        !a->tri_range || !a->flat_edge_verts || !a->shape_kh || !a->shape_transform || !a->shape_data || !a->shape_gap ||
+        !a->shape_sdf_index || !a->sdf_table)
+        return NT_ERR_INVALID_ARG;
+    if (!(a->edge_clamp_min >= 0.0f && a->edge_clamp_min <= 0.5f)) return NT_ERR_INVALID_ARG;
+    const long long cap = (long long)a->worlds * a->pairs_per_world;
+    const int blocks = cap < 16384 ? (int)cap : 16384;
+    hipLaunchKernelGGL(hydro_pairs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256) sdf_pairs_kernel(nt_sdf_scene sc, const f
             if (idx < sc.pairs_per_world) {
                 world_pairs[2 * ((size_t)w * sc.pairs_per_world + idx)] = s1;
                 world_pairs[2 * ((size_t)w * sc.pairs_per_world + idx) + 1] = s2;
+                if (sc.template_kind) sc.world_pair_kind[(size_t)w * sc.pairs_per_world + idx] = sc.template_kind[p];
             }
         }
         __syncthreads();
@@ -158,7 +159,10 @@ __global__ void __launch_bounds__(256) sdf_rows_write_kernel(nt_sdf_scene sc, nt
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int idx = io.raw_pair[i];  // world * PPW + k
         const int w = idx / sc.pairs_per_world;
-        const int dst = io.row_start[w] + io.pair_row[idx] + (i - io.blk[2 * (size_t)idx]);
+        const bool hydro = sc.template_kind && sc.world_pair_kind[idx] == 1;  // rows of nt_hydro_pairs: ranked, pre-admitted
+        const int rank = hydro ? io.raw_rank[i] : i - io.blk[2 * (size_t)idx];
+        if (rank >= io.blk[2 * (size_t)idx + 1]) continue;
+        const int dst = io.row_start[w] + io.pair_row[idx] + rank;
         if (dst >= io.row_capacity) continue;
         const int shape_a = io.world_pairs[2 * (size_t)idx], shape_b = io.world_pairs[2 * (size_t)idx + 1];
         const float* d = io.raw_data + 9 * (size_t)i;
@@ -173,7 +177,8 @@ __global__ void __launch_bounds__(256) sdf_rows_write_kernel(nt_sdf_scene sc, nt
         int sa = -1, sb = -1;
         vec3 p0, p1, o0, o1, nrm;
         float m0 = 0.0f, m1 = 0.0f;
-        if (!(sep > sc.shape_gap[shape_a] + sc.shape_gap[shape_b])) {
+        // decode_contacts_kernel hands its rows to the writer with a reserved index: no gap test (collide.py:246-252)
+        if (hydro || !(sep > sc.shape_gap[shape_a] + sc.shape_gap[shape_b])) {
             sa = shape_a;
             sb = shape_b;
             const int ba = shape_body_of(sc, sa, w), bb = shape_body_of(sc, sb, w);
@@ -197,6 +202,11 @@ __global__ void __launch_bounds__(256) sdf_rows_write_kernel(nt_sdf_scene sc, nt
         io.margin0[dst] = m0;
         io.margin1[dst] = m1;
         if (io.key) io.key[dst] = io.raw_key[i];
+        if (io.stiffness) {
+            io.stiffness[dst] = hydro && io.raw_stiffness ? io.raw_stiffness[i] : 0.0f;
+            io.damping[dst] = 0.0f;
+            io.friction_scale[dst] = 0.0f;
+        }
     }
 }
 
@@ -382,6 +392,8 @@ nt_status nt_sdf_rows_finalize(const nt_sdf_scene* sc, const nt_sdf_rows_io* io,
         !io->margin0 || !io->margin1 || io->raw_capacity <= 0 || io->row_capacity <= 0)
         return NT_ERR_INVALID_ARG;
     if (sc->nb > 1024) return NT_ERR_UNSUPPORTED;
+    if (io->stiffness && (!io->damping || !io->friction_scale)) return NT_ERR_INVALID_ARG;
+    if (sc->template_kind && (!sc->world_pair_kind || !io->raw_rank)) return NT_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sdf_world_rows_kernel, dim3(sc->env_count), dim3(256), 0, st, *sc, io->pair_count, io->blk, io->pair_row, world_rows);
     hipLaunchKernelGGL(scan_worlds_kernel, dim3(1), dim3(1024), 0, st, world_rows, io->row_start, sc->env_count, 0x7fffffff);

@@ -219,3 +219,40 @@ class BroadPhaseExplicit(_BroadPhaseBase):
         _lib.check(self._lib.nt_broadphase_explicit(C.byref(v), shape_pairs.data_ptr(), int(shape_pair_count),
                                                     candidate_pair.data_ptr(), candidate_pair_count.data_ptr(), cap,
                                                     self._stream()), "nt_broadphase_explicit")
+
+
+class HydroelasticSDF:
+    """newton.geometry.HydroelasticSDF (sdf_hydroelastic.py:365-560): the configuration object ``CollisionPipeline(
+    sdf_hydroelastic_config=HydroelasticSDF.Config(...))`` takes.  The stages themselves are device kernels of the collide pipeline
+    (csrc/nt_sdf.hip: nt_hydro_pairs); the buffer-sizing knobs of the reference (buffer_fraction, buffer_mult_*, grid_size) have
+    no counterpart -- the octree of a pair lives in the LDS of the pair's workgroup -- and are accepted and ignored."""
+
+    from dataclasses import dataclass as _dataclass
+
+    @_dataclass
+    class Config:
+        reduce_contacts: bool = True
+        pre_prune_contacts: bool = True
+        buffer_fraction: float = 1.0
+        buffer_mult_broad: int = 1
+        buffer_mult_iso: int = 1
+        buffer_mult_contact: int = 1
+        contact_buffer_fraction: float = 0.5
+        contact_reduction_hashtable_size_factor: float = 0.25
+        grid_size: int = 256 * 8 * 128
+        output_contact_surface: bool = False
+        normal_matching: bool = True
+        anchor_contact: bool = False
+        moment_matching: bool = False
+        margin_contact_area: float = 1.0e-2
+        pressure_func: object = None
+        pressure_data: object = None
+        mc_edge_clamp_min: float = 0.02
+
+        def __post_init__(self):
+            if not (0.0 <= self.mc_edge_clamp_min <= 0.5):
+                raise ValueError(f"mc_edge_clamp_min must be in [0.0, 0.5], got {self.mc_edge_clamp_min}")
+            if not (0.0 < self.buffer_fraction <= 1.0):
+                raise ValueError(f"buffer_fraction must be in (0, 1], got {self.buffer_fraction}")
+            if self.moment_matching:
+                self.anchor_contact = True

@@ -220,16 +220,22 @@ class EnvTemplate:
         self.shape_sdf_index = shape_uniform(sdf_idx, "shape SDF index")
         self.shape_edge_count = shape_uniform(e_rng[:, 1], "shape collision-edge count")
         has_sdf = (self.shape_sdf_index >= 0) & (self.shape_edge_count > 0)
-        is_sdf_pair = np.array([has_sdf[a] and has_sdf[b] and not (self.shape_type[a] == GeoType.BOX and self.shape_type[b] == GeoType.BOX)
-                                for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
+        # both shapes hydroelastic (ShapeFlags.HYDROELASTIC) with SDFs: the SDF-SDF leg, tested first (narrow_phase.py:531-538)
+        hydro = ((self.shape_flags & int(ShapeFlags.HYDROELASTIC)) != 0) & (self.shape_sdf_index >= 0)
+        is_hydro_pair = np.array([hydro[a] and hydro[b] for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
+        is_sdf_pair = is_hydro_pair | np.array(
+            [has_sdf[a] and has_sdf[b] and not (self.shape_type[a] == GeoType.BOX and self.shape_type[b] == GeoType.BOX)
+             for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
 
         def newton_id0(l):  # Newton id of template shape l in world 0 (the order is the same in every world)
             return L0 + l if l < ns else int(shape_glob[l - ns])
 
-        sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b))
-              for a, b in zip(self.pair_a[is_sdf_pair], self.pair_b[is_sdf_pair])]
+        sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b), bool(h))
+              for a, b, h in zip(self.pair_a[is_sdf_pair], self.pair_b[is_sdf_pair], is_hydro_pair[is_sdf_pair])]
         sp.sort()
-        self.sdf_pair = np.asarray([[a, b] if newton_id0(a) < newton_id0(b) else [b, a] for _, _, a, b in sp], dtype=np.int32).reshape(-1, 2)
+        self.sdf_pair = np.asarray([[a, b] if newton_id0(a) < newton_id0(b) else [b, a] for _, _, a, b, _ in sp], dtype=np.int32).reshape(-1, 2)
+        self.sdf_pair_hydro = np.asarray([h for *_, h in sp], dtype=bool)  # hydroelastic when the pipeline enables it
+        self.sdf_pair_has_edges = np.asarray([bool(has_sdf[a] and has_sdf[b]) for _, _, a, b, _ in sp], dtype=bool)
         self.tile_pair_index = np.flatnonzero(~is_sdf_pair)  # positions of the tile pairs in one world's shape_contact_pairs slice
         self.pair_a, self.pair_b = self.pair_a[~is_sdf_pair], self.pair_b[~is_sdf_pair]
         self.np = len(self.pair_a)

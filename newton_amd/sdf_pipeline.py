@@ -68,7 +68,7 @@ class FlatRows:
 class SdfLeg:
     """Model-level tables + per-pipeline work buffers of the mesh-SDF leg."""
 
-    def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64):
+    def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64, hydro_config=None):
         from .sdf_device import DeviceSDF  # noqa: PLC0415
 
         torch = _torch()
@@ -105,6 +105,8 @@ class SdfLeg:
         self._sdf_table = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(dev)
         self._red_lo, self._red_hi = up(model.shape_collision_aabb_lower, np.float32), up(model.shape_collision_aabb_upper, np.float32)
         self._red_res = up(model._shape_voxel_resolution, np.int32)
+        er, ecr = np.asarray(model.shape_edge_range, np.int64).reshape(-1, 2), np.asarray(model.mesh_edge_centers, np.float32).reshape(-1, 4)
+        self._edge_rmax = up([float(ecr[a:a + n, 3].max()) if n > 0 else 0.0 for a, n in er], np.float32)
         mat = np.stack([np.asarray(getattr(model, "shape_material_" + k), np.float32) for k in ("ke", "kd", "kf", "ka", "mu")], axis=1)
         self._material = up(mat, np.float32)
         # scene (template) tables
@@ -116,6 +118,29 @@ class SdfLeg:
         sc.template_pairs, sc.template_pair = len(t.sdf_pair), self._template_pair.data_ptr()
         sc.gshape_id, sc.shape_body, sc.shape_gap = self._gshape_id.data_ptr(), self._shape_body.data_ptr(), self._shape_gap.data_ptr()
         sc.pairs_per_world = PPW
+        # pair kinds: with a hydroelastic configuration the pairs of two HYDROELASTIC shapes take the SDF-SDF leg (kind 1)
+        self.hydro = hydro_config
+        kind = (t.sdf_pair_hydro if hydro_config is not None else np.zeros(len(t.sdf_pair), bool)).astype(np.uint8)
+        if np.any((kind == 0) & ~t.sdf_pair_has_edges):
+            raise NotImplementedError("pairs of hydroelastic shapes without collision edges need CollisionPipeline(sdf_hydroelastic_config=...)")
+        self.has_hydro_pairs = bool(kind.any())
+        self._template_kind = up(kind, np.uint8)
+        self.world_pair_kind = torch.zeros(E * PPW, dtype=torch.uint8, device=dev)
+        if self.has_hydro_pairs:
+            from .mc_tables import tables  # noqa: PLC0415
+
+            if hydro_config.reduce_contacts:
+                raise NotImplementedError("HydroelasticSDF.Config(reduce_contacts=True) is not implemented: pass reduce_contacts=False "
+                                          "(every marching-cubes face becomes a contact row)")
+            if hydro_config.pressure_func is not None:
+                raise NotImplementedError("custom pressure_func callbacks are not supported (linear pressure -kh * depth only)")
+            sc.template_kind, sc.world_pair_kind = self._template_kind.data_ptr(), self.world_pair_kind.data_ptr()
+            tri_range, flat = tables()
+            self._mc_tri, self._mc_edges = up(tri_range, np.int32), up(flat, np.uint8)
+            self._shape_kh = up(model.shape_material_kh, np.float32)
+            nblocks = max(int(np.prod(s.slots.shape)) for s in model._texture_sdf_data)
+            if nblocks > 4096:
+                raise NotImplementedError(f"hydroelastic SDFs with more than 4096 subgrid blocks ({nblocks}) are not supported")
         self.scene = sc
         # work buffers
         i32, f32 = torch.int32, torch.float32
@@ -131,9 +156,12 @@ class SdfLeg:
         self.raw_pair = torch.zeros(self.row_capacity, dtype=i32, device=dev)
         self.raw_key = torch.zeros(self.row_capacity, dtype=i32, device=dev)
         self.raw_data = torch.zeros((self.row_capacity, 9), dtype=f32, device=dev)
+        self.raw_rank = torch.zeros(self.row_capacity if self.has_hydro_pairs else 1, dtype=i32, device=dev)
+        self.raw_stiffness = torch.zeros(self.row_capacity if self.has_hydro_pairs else 1, dtype=f32, device=dev)
 
     def new_rows(self, per_contact_shape_properties: bool = False) -> FlatRows:
-        return FlatRows(self.model, self.row_capacity, self.pairs_per_world, per_contact_shape_properties)
+        # hydroelastic rows carry Contacts.rigid_contact_stiffness: allocated whenever the leg can produce them
+        return FlatRows(self.model, self.row_capacity, self.pairs_per_world, per_contact_shape_properties or self.has_hydro_pairs)
 
     def export_pointers(self, d: _lib.nt_contacts) -> None:
         """Ask nt_collide for the shapes' world transforms and AABBs."""
@@ -160,8 +188,27 @@ class SdfLeg:
                                                                        sc.pairs_per_world, self.blk.data_ptr())
         r = _lib.nt_contact_reduce_shapes()
         r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = self._red_lo.data_ptr(), self._red_hi.data_ptr(), self._red_res.data_ptr()
-        r.threads = self.threads
-        _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
+        r.threads, r.shape_edge_radius_max = self.threads, self._edge_rmax.data_ptr()
+        if self.has_hydro_pairs:
+            a.pair_kind = self.world_pair_kind.data_ptr()
+        if not bool(np.all(self.t.sdf_pair_hydro)) or not self.has_hydro_pairs:
+            _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
+        if self.has_hydro_pairs:
+            h = _lib.nt_hydro_args()
+            h.pairs, h.pair_count = self.world_pairs.data_ptr(), int(self.world_pairs.shape[0])
+            h.shape_transform, h.shape_data, h.shape_gap, h.shape_kh = (self.world_xform.data_ptr(), self._shape_data.data_ptr(),
+                                                                        self._shape_gap.data_ptr(), self._shape_kh.data_ptr())
+            h.shape_sdf_index, h.sdf_table, h.sdf_count = self._sdf_index.data_ptr(), self._sdf_table.data_ptr(), len(self._sdfs)
+            h.tri_range, h.flat_edge_verts = self._mc_tri.data_ptr(), self._mc_edges.data_ptr()
+            h.margin_contact_area, h.edge_clamp_min = float(self.hydro.margin_contact_area), float(self.hydro.mc_edge_clamp_min)
+            h.out_count, h.out_pair, h.out_key, h.out_data, h.capacity = (self.raw_count.data_ptr(), self.raw_pair.data_ptr(),
+                                                                          self.raw_key.data_ptr(), self.raw_data.data_ptr(),
+                                                                          self.row_capacity)
+            h.pair_world_prefix, h.worlds, h.pairs_per_world = self.pair_prefix.data_ptr(), sc.env_count, sc.pairs_per_world
+            h.pair_kind, h.out_pairs_normalized, h.out_blk = (self.world_pair_kind.data_ptr(), self.world_pairs.data_ptr(),
+                                                              self.blk.data_ptr())
+            h.out_rank, h.out_stiffness = self.raw_rank.data_ptr(), self.raw_stiffness.data_ptr()
+            _lib.check(lib.nt_hydro_pairs(C.byref(h), stream), "nt_hydro_pairs")
         io = _lib.nt_sdf_rows_io()
         io.pair_count, io.world_pairs, io.blk, io.pair_row = (self.pair_count.data_ptr(), self.world_pairs.data_ptr(),
                                                               self.blk.data_ptr(), self.pair_row.data_ptr())
@@ -171,6 +218,10 @@ class SdfLeg:
         io.raw_capacity, io.row_capacity = self.row_capacity, rows.capacity
         for k in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1", "key"):
             setattr(io, k, getattr(rows, k).data_ptr())
+        if self.has_hydro_pairs:
+            io.raw_rank, io.raw_stiffness = self.raw_rank.data_ptr(), self.raw_stiffness.data_ptr()
+        if rows.stiffness is not None:
+            io.stiffness, io.damping, io.friction_scale = rows.stiffness.data_ptr(), rows.damping.data_ptr(), rows.friction_scale.data_ptr()
         _lib.check(lib.nt_sdf_rows_finalize(C.byref(sc), C.byref(io), state._soa["body_q"].data_ptr(), self.world_rows.data_ptr(),
                                             rows.body_blk_start.data_ptr(), rows.body_blk_list.data_ptr(), stream),
                    "nt_sdf_rows_finalize")
@@ -195,7 +246,7 @@ class SdfLeg:
 def sdf_pair_shape_types_ok(model) -> None:
     """The SDF leg handles MESH / CONVEX_MESH / BOX shapes (texture SDF + collision edges); heightfields are out of scope."""
     t = model.env
-    for a, b in t.sdf_pair:
+    for (a, b), hydro in zip(t.sdf_pair, t.sdf_pair_hydro):
         for s in (a, b):
-            if int(t.shape_type[s]) not in (int(GeoType.MESH), int(GeoType.CONVEX_MESH), int(GeoType.BOX)):
+            if not hydro and int(t.shape_type[s]) not in (int(GeoType.MESH), int(GeoType.CONVEX_MESH), int(GeoType.BOX)):
                 raise NotImplementedError(f"SDF contact pairs with shape type {GeoType(int(t.shape_type[s])).name} are not supported")

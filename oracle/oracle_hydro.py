@@ -154,3 +154,228 @@ def hydro_collide(pairs, shape_transform, shape_data, shape_gap, shape_kh, sdfs,
                         out.append((pair_idx, ((z * ny + y) * nx + x) * MAX_MC_FACES_PER_VOXEL + fi, int(sa), int(sb),
                                     _x_point(X_b, center), _q_rot(X_b[3:], normal), sep, stiff, area, pressure))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The staged pipeline of HydroelasticSDF.launch (reduce_contacts=False), pair by pair, in the reference's ordered-scatter order.
+# PINNED by tests/golden/hydro_reference_vectors.npz (tests/golden/make_hydro_reference_vectors.py executes the reference's
+# broadphase_collision_pairs_count, count_iso_voxels_block (4 levels), scatter_iso_subblock, generate_contacts_kernel and
+# decode_contacts_kernel on the stand-in of tests/golden/refshim; the marching-cubes case tables are newton_amd/mc_tables.py on
+# both sides, Warp's own wp.MarchingCubes tables are not part of /root/reference).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _dot3(a, b):
+    return f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+
+
+def _cross3(a, b):
+    return np.array([f32(f32(a[1] * b[2]) - f32(a[2] * b[1])), f32(f32(a[2] * b[0]) - f32(a[0] * b[2])),
+                     f32(f32(a[0] * b[1]) - f32(a[1] * b[0]))], dtype=f32)
+
+
+def sat_box_intersection(Ta, ea, Tb, eb):
+    """collision_core.py:1281-1374."""
+    ex = [np.array(v, f32) for v in ((1, 0, 0), (0, 1, 0), (0, 0, 1))]
+    axa, axb = [_q_rot(Ta[3:], e) for e in ex], [_q_rot(Tb[3:], e) for e in ex]
+
+    def project(T, ax, e, n):
+        c = _dot3(T[:3], n)
+        ext = f32(0.0)
+        for k in range(3):
+            ext = f32(ext + f32(f32(e[k]) * abs(_dot3(ax[k], n))))
+        return f32(c - ext), f32(c + ext)
+
+    def separated(axis):
+        ln = np.sqrt(_dot3(axis, axis))
+        if ln < f32(1e-8):
+            return False
+        n = (axis / ln).astype(f32)
+        la, ha = project(Ta, axa, ea, n)
+        lb, hb = project(Tb, axb, eb, n)
+        return bool(ha < lb or hb < la)
+
+    for a in axa:
+        if separated(a):
+            return False
+    for b in axb:
+        if separated(b):
+            return False
+    for a in axa:
+        for b in axb:
+            if separated(_cross3(a, b)):
+                return False
+    return True
+
+
+def encode_oct(n):
+    """contact_reduction_global.py:631-658."""
+    l1 = f32(f32(abs(n[0]) + abs(n[1])) + abs(n[2]))
+    if l1 < f32(1.0e-20):
+        return f32(0.0), f32(0.0)
+    inv = f32(f32(1.0) / l1)
+    ox, oy, oz = f32(n[0] * inv), f32(n[1] * inv), f32(n[2] * inv)
+    if oz < 0.0:
+        sx, sy = (f32(-1.0) if ox < 0.0 else f32(1.0)), (f32(-1.0) if oy < 0.0 else f32(1.0))
+        ox, oy = f32(f32(f32(1.0) - abs(oy)) * sx), f32(f32(f32(1.0) - abs(ox)) * sy)
+    return ox, oy
+
+
+def decode_oct(ex, ey):
+    """contact_reduction_global.py:661-683."""
+    nz = f32(f32(f32(1.0) - abs(ex)) - abs(ey))
+    nx, ny = f32(ex), f32(ey)
+    if nz < 0.0:
+        sx, sy = (f32(-1.0) if nx < 0.0 else f32(1.0)), (f32(-1.0) if ny < 0.0 else f32(1.0))
+        nx, ny = f32(f32(f32(1.0) - abs(ny)) * sx), f32(f32(f32(1.0) - abs(nx)) * sy)
+    v = np.array([nx, ny, nz], f32)
+    ln = np.sqrt(_dot3(v, v))
+    return (v / ln).astype(f32) if ln > 0.0 else v
+
+
+def _node_survives(oa, ob, ta, tb, X_b2a, x, y, z, size, margin_a, margin_b, kh_a, kh_b, gap_sum):
+    """count_iso_voxels_block's test of one cube of `size` voxels of B (sdf_hydroelastic.py:1499-1560)."""
+    r = f32(f32(size) * f32(tb.voxel_radius))
+    h = f32(f32(0.5) * f32(size))
+    centre = np.array([f32(f32(x) + h), f32(f32(y) + h), f32(f32(z) + h)], f32)
+    local_b = (ob.lo + centre * tb.voxel_size.astype(f32)).astype(f32)
+    point_a = _x_point(X_b2a, local_b)
+    vb = tb.sample_at_voxel([[x + size // 2, y + size // 2, z + size // 2]])[0] if size % 2 == 0 else ob.sample(local_b)
+    va = oa.sample(point_a)
+    if np.isnan(vb) or np.isnan(va):
+        return False
+    eva, evb = f32(va - margin_a), f32(vb - margin_b)
+    if f32(eva + evb) > f32(f32(f32(2.0) * r) + gap_sum):
+        return False
+    pa_lo, pa_hi = f32(-kh_a * f32(eva + r)), f32(-kh_a * f32(eva - r))
+    pb_lo, pb_hi = f32(-kh_b * f32(evb + r)), f32(-kh_b * f32(evb - r))
+    return not (pa_hi < pb_lo or pb_hi < pa_lo)
+
+
+def hydro_pipeline(pairs, shape_transform, shape_data, shape_gap, shape_kh, sdfs, tables, margin_contact_area=1.0e-2,
+                   edge_clamp_min=0.02):
+    """-> (rows, voxels): rows = list of (pair_idx, fingerprint, shape_a, shape_b, centre_world[3], normal_world[3], separation,
+    stiffness) in (pair, voxel traversal, face) order with fingerprint = pair-local voxel rank * 5 + face; voxels = per pair the
+    surviving (x, y, z) list in traversal order.  `sdfs[s]`: TextureSDF of shape s."""
+    X = np.asarray(shape_transform, dtype=f32)
+    D = np.asarray(shape_data, dtype=f32)
+    rows, vox_all = [], []
+    for pair_idx, (sa, sb) in enumerate(np.asarray(pairs).reshape(-1, 2)):
+        sa, sb = int(sa), int(sb)
+        ta, tb = sdfs[sa], sdfs[sb]
+        vox = []
+        vox_all.append(vox)
+        if ta is None or tb is None:
+            continue
+        lo_a, hi_a, lo_b, hi_b = (np.asarray(v, f32) for v in (ta.box_lower, ta.box_upper, tb.box_lower, tb.box_upper))
+        ident = np.array([0, 0, 0, 1], f32)
+        Ca = _x_mul(X[sa], np.concatenate([(f32(0.5) * (lo_a + hi_a)).astype(f32), ident]))
+        Cb = _x_mul(X[sb], np.concatenate([(f32(0.5) * (lo_b + hi_b)).astype(f32), ident]))
+        collide = sat_box_intersection(Ca, (f32(0.5) * (hi_a - lo_a)).astype(f32), Cb, (f32(0.5) * (hi_b - lo_b)).astype(f32))
+        if tb.voxel_radius > ta.voxel_radius:  # keep the finer SDF as shape B
+            sa, sb, ta, tb = sb, sa, tb, ta
+        if not collide:
+            continue
+        oa, ob = OracleSDF(ta), OracleSDF(tb)
+        gap_sum = f32(f32(shape_gap[sa]) + f32(shape_gap[sb]))
+        margin_a, margin_b = D[sa, 3], D[sb, 3]
+        kh_a, kh_b = f32(shape_kh[sa]), f32(shape_kh[sb])
+        X_b = X[sb]
+        X_b2a = _x_mul(_x_inv(X[sa]), X_b)
+        nbx, nby, nbz = (int(c) for c in tb.slots.shape)
+        sgs = int(tb.subgrid_size)
+        args = (oa, ob, ta, tb, X_b2a)
+        tail = (margin_a, margin_b, kh_a, kh_b, gap_sum)
+        code = lambda c: (c & 1, (c >> 1) & 1, (c >> 2) & 1)  # noqa: E731
+        for bz in range(nbz):
+            for by in range(nby):
+                for bx in range(nbx):
+                    x0, y0, z0 = bx * sgs, by * sgs, bz * sgs
+                    if not _node_survives(*args, x0, y0, z0, sgs, *tail):
+                        continue
+                    for c4 in range(8):
+                        a = code(c4)
+                        p4 = (x0 + 4 * a[0], y0 + 4 * a[1], z0 + 4 * a[2])
+                        if not _node_survives(*args, *p4, 4, *tail):
+                            continue
+                        for c2 in range(8):
+                            b = code(c2)
+                            p2 = (p4[0] + 2 * b[0], p4[1] + 2 * b[1], p4[2] + 2 * b[2])
+                            if not _node_survives(*args, *p2, 2, *tail):
+                                continue
+                            for c1 in range(8):
+                                c = code(c1)
+                                p1 = (p2[0] + c[0], p2[1] + c[1], p2[2] + c[2])
+                                if _node_survives(*args, *p1, 1, *tail):
+                                    vox.append(p1)
+        for rank, (x, y, z) in enumerate(vox):
+            for fi, center, normal, sep, stiff in _voxel_faces(oa, ob, ta, tb, X_b2a, x, y, z, tables, *tail, margin_contact_area,
+                                                              edge_clamp_min):
+                e = encode_oct(normal)
+                rows.append((pair_idx, rank * MAX_MC_FACES_PER_VOXEL + fi, sa, sb, _x_point(X_b, center), _q_rot(X_b[3:], decode_oct(*e)),
+                             sep, stiff))
+    return rows, vox_all
+
+
+def _voxel_faces(oa, ob, ta, tb, X_b2a, x, y, z, tables, margin_a, margin_b, kh_a, kh_b, gap_sum, margin_contact_area, edge_clamp_min):
+    """mc_iterate_voxel_vertices + mc_calc_face_texture + the face filters / stiffness of generate + decode for one voxel of B:
+    yields (face index, centre in B's frame, normal in B's frame, separation, stiffness)."""
+    tri_range, flat = tables
+    cmin, cmax = f32(edge_clamp_min), f32(1.0 - edge_clamp_min)
+    vs = tb.voxel_size.astype(f32)
+    step = [_q_rot(X_b2a[3:], np.array([vs[0], 0, 0], dtype=f32)), _q_rot(X_b2a[3:], np.array([0, vs[1], 0], dtype=f32)),
+            _q_rot(X_b2a[3:], np.array([0, 0, vs[2]], dtype=f32))]
+    base_b = (ob.lo + np.array([x, y, z], dtype=f32) * vs).astype(f32)
+    base_a = _x_point(X_b2a, base_b)
+    cube, any_gap = 0, False
+    cv, cs_self, cs_other = np.zeros(8, f32), np.zeros(8, f32), np.zeros(8, f32)
+    for i in range(8):
+        ox, oy, oz = CORNER[0][i], CORNER[1][i], CORNER[2][i]
+        pa = (((base_a + f32(ox) * step[0]).astype(f32) + f32(oy) * step[1]).astype(f32) + f32(oz) * step[2]).astype(f32)
+        v_self = tb.sample_at_voxel([[x + ox, y + oy, z + oz]])[0]
+        v_other = oa.sample(pa)
+        if np.isnan(v_self) or np.isnan(v_other):
+            return
+        es, eo = f32(v_self - margin_b), f32(v_other - margin_a)
+        vd = f32(f32(-kh_a * eo) - f32(-kh_b * es))
+        cv[i], cs_self[i], cs_other[i] = vd, es, eo
+        if vd < 0.0:
+            cube |= 1 << i
+        if f32(es + eo) <= gap_sum:
+            any_gap = True
+    if not any_gap:
+        return
+    t0, t1 = int(tri_range[cube]), int(tri_range[cube + 1])
+    for fi in range((t1 - t0) // 3):
+        verts, v_sdf, v_sep, n_in = np.zeros((3, 3), f32), np.zeros(3, f32), np.zeros(3, f32), 0
+        for vi in range(3):
+            a, b = int(flat[t0 + 3 * fi + vi][0]), int(flat[t0 + 3 * fi + vi][1])
+            vd = f32(cv[b] - cv[a])
+            t = f32(0.5) if abs(vd) < MC_EDGE_VAL_DIFF_EPS else min(max(f32(f32(f32(0.0) - cv[a]) / vd), cmin), cmax)
+            p0 = np.array([CORNER[0][a], CORNER[1][a], CORNER[2][a]], dtype=f32)
+            p1 = np.array([CORNER[0][b], CORNER[1][b], CORNER[2][b]], dtype=f32)
+            vol = ((p0 + (t * (p1 - p0)).astype(f32)).astype(f32) + np.array([x, y, z], dtype=f32)).astype(f32)
+            verts[vi] = (ob.lo + (vol * vs).astype(f32)).astype(f32)
+            s_self = f32(cs_self[a] + f32(t * f32(cs_self[b] - cs_self[a])))
+            s_other = f32(cs_other[a] + f32(t * f32(cs_other[b] - cs_other[a])))
+            v_sdf[vi], v_sep[vi] = s_self, f32(s_self + s_other)
+            if v_sep[vi] < 0.0:
+                n_in += 1
+        n = _cross3((verts[1] - verts[0]).astype(f32), (verts[2] - verts[0]).astype(f32))
+        n_sq = _dot3(n, n)
+        if n_sq < MC_DEGENERATE_N_SQ_EPS:
+            garea, normal = f32(0.0), np.array([0, 0, 1], dtype=f32)
+        else:
+            inv = f32(f32(1.0) / np.sqrt(n_sq))
+            normal, garea = (n * inv).astype(f32), f32(f32(n_sq * inv) * f32(0.5))
+        center = (((verts[0] + verts[1]).astype(f32) + verts[2]).astype(f32) / f32(3.0)).astype(f32)
+        adj = f32(f32(f32(v_sdf[0] + v_sdf[1]) + v_sdf[2]) / f32(3.0))
+        sep = f32(f32(f32(v_sep[0] + v_sep[1]) + v_sep[2]) / f32(3.0))
+        farea = f32(garea * triangle_fraction(v_sep, n_in))
+        if garea <= 0.0 or classify(sep, gap_sum) > 0:
+            continue
+        pressure = max(f32(-kh_b * adj), f32(0.0)) if sep < 0.0 else f32(0.0)
+        area = farea if sep < 0.0 else garea
+        if sep < 0.0:
+            stiff = f32(f32(area * pressure) / max(f32(-sep), EPS_SMALL))
+        else:
+            stiff = f32(f32(margin_contact_area) * effective_stiffness(kh_a, kh_b))
+        yield fi, center, normal, sep, stiff

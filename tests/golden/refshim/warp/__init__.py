@@ -126,11 +126,23 @@ class _ivec:
     def __getitem__(self, i): return self.v[i]
     def __setitem__(self, i, x): self.v[i] = int(x)
     def __len__(self): return self.N
+    def __iter__(self): return iter(self.v)
+    def __add__(self, o): return type(self)(*[a_ + int(b_) for a_, b_ in zip(self.v, o)])
+    def __sub__(self, o): return type(self)(*[a_ - int(b_) for a_, b_ in zip(self.v, o)])
+    def __mul__(self, k): return type(self)(*[a_ * int(k) for a_ in self.v])
+    __rmul__ = __mul__
+    x = property(lambda self: self.v[0])
+    y = property(lambda self: self.v[1])
+    z = property(lambda self: self.v[2])
 
 
 class vec2i(_ivec): N = 2
 class vec3i(_ivec): N = 3
 class vec4i(_ivec): N = 4
+class vec3us(_ivec): N = 3   # unsigned 16- / 32- / 8-bit integer vectors (sdf_hydroelastic.py voxel records): plain ints here
+class vec3ui(_ivec): N = 3
+class vec3ub(_ivec): N = 3
+class vec2ub(_ivec): N = 2
 
 
 def dot(a, b):
@@ -892,6 +904,7 @@ _NATIVE["float_flip"] = _float_flip  # contact_reduction.py
 _NATIVE["_unpack_contact_id_fast"] = lambda packed: int(int(packed) & 0xFFFFFFFF)  # contact_reduction_global.py
 _NATIVE["_unpack_contact_id_det"] = lambda packed: int(int(packed) & 0xFFFFF)
 _NATIVE["_sdf_rsqrt_rn"] = lambda value: f32(1.0) / _np.sqrt(_s(value))
+_NATIVE["_hydro_rsqrt_approx"] = lambda value: f32(1.0) / _np.sqrt(_s(value))  # sdf_hydroelastic.py:92-103, CPU branch
 
 
 # tile primitives as one serial lane sees them (the export kernel of the global contact reducer does all of its work on lane 0
@@ -954,7 +967,7 @@ def struct(cls):
 
 vec2f = vec2
 _SIZEOF.update({vec2: 8, vec3: 12, vec4: 16, quat: 16, transform: 28, spatial_vector: 24, float: 4, int: 4, float32: 4, int32: 4})
-_VALUE_TYPES = (vec3, vec2, vec4, quat, mat33, transform, spatial_vector, spatial_matrix, vec2i, vec3i, vec4i)
+_VALUE_TYPES = (vec3, vec2, vec4, quat, mat33, transform, spatial_vector, spatial_matrix, vec2i, vec3i, vec4i, vec3us, vec3ui, vec3ub, vec2ub)
 
 
 def constant(x): return x

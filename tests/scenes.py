@@ -300,7 +300,7 @@ def free_child_scene(world_count: int, device=None, seed: int | None = 0, free_r
 
 def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int = 2, jitter: float = 0.005, mu=None,
                    hull_pairs: bool = True, shape_cfg=None, inertia_armature: float = 0.0, sdf: bool = False,
-                   sdf_resolution: int = 24):
+                   sdf_resolution: int = 24, hydroelastic: bool = False, kh: float = 1.0e10):
     """Config C5 without the SDF / hydroelastic contact models: `n_hulls` random convex hulls (16-32 vertices, radius
     U(0.03, 0.06)) dropped into a five-wall bin (ground plane + four static boxes); every hull pair and every hull-wall pair
     is a candidate, so one environment has n(n-1)/2 + 5n pairs (2 336 for 64 hulls) and its per-contact solver records no
@@ -325,6 +325,8 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
         env.default_shape_cfg.mu = float(mu)
     for k, v in (shape_cfg or {}).items():
         setattr(env.default_shape_cfg, k, v)
+    if hydroelastic:  # config C5's second contact model: every shape HYDROELASTIC, kh = 1e10 (builder.py:571)
+        env.default_shape_cfg.is_hydroelastic, env.default_shape_cfg.kh = True, float(kh)
     side = 0.07 * np.ceil(np.sqrt(n_hulls))
     # hulls start on a lattice with 0.135 m pitch (> twice the largest hull radius): no initial interpenetration -- randomly
     # overlapping hulls make XPBD eject them at 10^3 rad/s (oracle and device alike) until the state overflows
@@ -359,7 +361,7 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
             setattr(wall_cfg, k, v)
         if mu is not None:
             wall_cfg.mu = float(mu)
-        wall_cfg.configure_sdf(max_resolution=64)
+        wall_cfg.configure_sdf(max_resolution=64, is_hydroelastic=hydroelastic, kh=float(kh))
         scene.add_shape_box(-1, xform=[0.0, 0.0, -0.05, 0.0, 0.0, 0.0, 1.0], hx=w + 0.06, hy=w + 0.06, hz=0.05, cfg=wall_cfg)
     else:
         scene.add_ground_plane()

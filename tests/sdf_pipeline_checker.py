@@ -54,11 +54,13 @@ def sdf_scene(world_count, n_hulls=5, device=None, seed=5, sdf_resolution=16, wa
     return model
 
 
-def checker_rows(model, body_q, world_xform=None, aabbs=None):
+def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None):
     """-> (rows dict in product order incl. `world`, `key`; candidate pairs per world [list of (a, b)]; the checker's world
     transforms and AABBs).  `world_xform` / `aabbs`: use the device's own exported arrays instead (the caller holds them against
     the checker's separately) -- the centred-difference SDF gradient amplifies a last-bit difference of a shape transform to
-    1e-5 in the normal, which would blur the comparison of everything downstream."""
+    1e-5 in the normal, which would blur the comparison of everything downstream.
+    `kinds` (bool per template SDF pair, True = hydroelastic): those pairs are listed in the candidates -- which then hold
+    ((shape0, shape1), kind) tuples -- but produce no edge-contact rows here (oracle_hydro.hydro_pipeline covers them)."""
     t = model.env
     o = Oracle(model)
     oc = o.contacts()
@@ -87,12 +89,14 @@ def checker_rows(model, body_q, world_xform=None, aabbs=None):
     out = {k: [] for k in ("world", "key", "shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")}
     cand = []
     for w in range(t.env_count):
-        pairs = []
-        for a, b in t.sdf_pair:
+        pairs, tagged = [], []
+        for k, (a, b) in enumerate(t.sdf_pair):
             s1, s2 = sorted((gid(int(a), w), gid(int(b), w)))
             if np.all(lo[s1] <= hi[s2]) and np.all(hi[s1] >= lo[s2]):
-                pairs.append((s1, s2))
-        cand.append(pairs)
+                tagged.append(((s1, s2), bool(kinds[k]) if kinds is not None else False))
+                if kinds is None or not kinds[k]:
+                    pairs.append((s1, s2))
+        cand.append(tagged if kinds is not None else pairs)
         if not pairs:
             continue
         pr = np.asarray(pairs, np.int32)

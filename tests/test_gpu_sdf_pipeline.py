@@ -276,3 +276,144 @@ def test_config_c5_rows_at_full_size():
             assert np.array_equal(got, want[k]), (w, k)
         for k in FIELDS[2:]:
             assert np.abs(a[k][r0:r1] - want[k]).max() <= 2e-6, (w, k, np.abs(a[k][r0:r1] - want[k]).max())
+
+
+def hydro_scene(world_count, device=None, seed=21):
+    """Per world: a hydroelastic box pad, a hydroelastic sphere pressed into it and a hydroelastic hull (mesh SDF) resting on the pad;
+    a second, non-hydroelastic hull with an SDF touches the first hull (mesh-SDF edge contacts, the pipeline's other leg)."""
+    import newton_amd as nt
+
+    rng = np.random.default_rng(seed)
+    env = nt.ModelBuilder()
+    env.default_shape_cfg.gap = 0.01
+    hyd = env.default_shape_cfg.copy()
+    hyd.configure_sdf(max_resolution=16, is_hydroelastic=True, kh=2.0e7)
+    pad = env.add_body(xform=[0, 0, 0.05, 0, 0, 0, 1])
+    env.add_shape_box(pad, hx=0.2, hy=0.2, hz=0.05, cfg=hyd)
+    ball = env.add_body(xform=[0.04, -0.03, 0.155, *nt._np_math.quat_rpy(0.2, -0.1, 0.3)])
+    env.add_shape_sphere(ball, radius=0.06, cfg=hyd)
+    pts = rng.normal(size=(12, 3))
+    pts *= 0.06 / np.linalg.norm(pts, axis=1).max()
+    mesh = nt.Mesh.convex_hull_of(pts)
+    mesh.build_sdf(max_resolution=16, margin=0.02, narrow_band_range=(-0.05, 0.05))
+    hcfg = env.default_shape_cfg.copy()
+    hcfg.is_hydroelastic, hcfg.kh = True, 5.0e7
+    hull = env.add_body(xform=[-0.1, 0.08, 0.14, *nt._np_math.quat_rpy(0.4, 0.2, -0.3)])
+    env.add_shape_convex_hull(hull, mesh=mesh, cfg=hcfg)
+    mesh2 = nt.Mesh.convex_hull_of(pts * 0.9)
+    mesh2.build_sdf(max_resolution=16, margin=0.02, narrow_band_range=(-0.05, 0.05))
+    other = env.add_body(xform=[-0.1, 0.17, 0.16, *nt._np_math.quat_rpy(-0.3, 0.1, 0.5)])
+    env.add_shape_convex_hull(other, mesh=mesh2)
+    scene = nt.ModelBuilder()
+    scene.default_shape_cfg.gap = 0.01
+    scene.replicate(env, world_count)
+    scene.add_ground_plane()
+    model = scene.finalize(device=device)
+    off = np.random.default_rng(seed + 1).uniform(-0.003, 0.003, size=(model.body_count, 3)).astype(np.float32)
+    model.body_q[:, :3] += off
+    model.joint_q.reshape(-1, 7)[:, :3] += off
+    return model
+
+
+def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_solver():
+    """CollisionPipeline(sdf_hydroelastic_config=HydroelasticSDF.Config(reduce_contacts=False)): pairs of two HYDROELASTIC shapes take
+    the SDF-SDF leg (SAT, octree, marching cubes: rows with Contacts.rigid_contact_stiffness), other SDF pairs the edge leg, both in
+    one row set; against the checker chain (oracle_hydro.hydro_pipeline is pinned by the executed reference), two runs bitwise,
+    and SolverSemiImplicit consuming the per-contact stiffness like the checker's eval_body_contact."""
+    import torch
+
+    import newton_amd as nt
+    from oracle_bridge import Oracle, OracleState
+    from sdf_pipeline_checker import checker_rows  # (puts oracle/ on the path)
+
+    import oracle_flat_contacts as F
+    import oracle_hydro as H
+
+    from newton_amd.mc_tables import tables
+
+    E = 2
+    model = hydro_scene(E, device="cuda:0")
+    t = model.env
+    # hydroelastic: pad-ball, pad-hull, ball-hull | edge contacts: pad-other, hull-other | tiles: ball-other (MPR / GJK) + four plane pairs
+    assert t.sdf_pair_hydro.sum() == 3 and (~t.sdf_pair_hydro).sum() == 2 and t.np == 5
+    cfg = nt.geometry.HydroelasticSDF.Config(reduce_contacts=False)
+    pipe = nt.CollisionPipeline(model, broad_phase="sap", sdf_hydroelastic_config=cfg, sdf_contacts_per_shape=400)
+    c1, c2 = pipe.contacts(), pipe.contacts()
+    s0, s1 = model.state(), model.state()
+    pipe.collide(s0, c1)
+    pipe.collide(s0, c2)
+    torch.cuda.synchronize()
+    a, b = _rows(c1), _rows(c2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    f = c1._flat
+    n = len(a["key"])
+    stiff = f.stiffness[:n].cpu().numpy()
+    assert np.array_equal(stiff, c2._flat.stiffness[:n].cpu().numpy())
+    assert not pipe._sdf_leg.overflow(f)["overflow"]
+    # ---- the checker chain on the device's shape transforms
+    leg = pipe._sdf_leg
+    X, lo, hi = leg.world_xform.cpu().numpy(), leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    mesh_rows, cand, _ = checker_rows(model, np.asarray(model.body_q), world_xform=X, aabbs=(lo, hi), kinds=t.sdf_pair_hydro)
+    tr, fl = tables()
+    tab = (np.asarray(tr), np.asarray(fl).reshape(-1, 2))
+    data = np.concatenate([np.asarray(model.shape_scale, np.float32), np.asarray(model.shape_margin, np.float32)[:, None]], axis=1)
+    gap, kh = np.asarray(model.shape_gap, np.float32), np.asarray(model.shape_material_kh, np.float32)
+    sdfs = [model._texture_sdf_data[i] if i >= 0 else None for i in np.asarray(model._shape_sdf_index)]
+    want = {k: [] for k in ("world", "key", "shape0", "shape1", "point0", "normal", "stiffness")}
+    for w in range(E):
+        hp = [p for p, kind in cand[w] if kind]
+        rows, _ = H.hydro_pipeline(np.asarray(hp, np.int32), X, data, gap, kh, sdfs, tab) if hp else ([], None)
+        per_pair = {}
+        for r in rows:
+            per_pair.setdefault(hp[r[0]], []).append(r)
+        m = {k: np.asarray(v)[np.asarray(mesh_rows["world"]) == w] for k, v in mesh_rows.items()}
+        for p, kind in cand[w]:  # pairs ascending; a pair's rows: hydro faces in traversal order / edge contacts in fingerprint order
+            if kind:
+                rs = per_pair.get(p, [])
+                raw = dict(key=np.array([r[1] for r in rs]), shape_a=np.array([r[2] for r in rs]), shape_b=np.array([r[3] for r in rs]),
+                           center=np.array([r[4] for r in rs], np.float32).reshape(-1, 3), normal=np.array([r[5] for r in rs], np.float32).reshape(-1, 3),
+                           distance=np.array([r[6] for r in rs], np.float32), margin_a=np.zeros(len(rs), np.float32), margin_b=np.zeros(len(rs), np.float32))
+                wr = F.write_rows(raw, np.asarray(model.body_q, np.float32), np.asarray(model.shape_body), np.full(model.shape_count, 1e9, np.float32))
+                want["world"] += [w] * len(rs)
+                want["key"] += [r[1] for r in rs]
+                want["stiffness"] += [r[7] for r in rs]
+                for k in ("shape0", "shape1", "point0", "normal"):
+                    want[k] += list(wr[k])
+            else:
+                sel = (m["shape0"] == p[0]) & (m["shape1"] == p[1]) if len(m["key"]) else np.zeros(0, bool)
+                want["world"] += [w] * int(sel.sum())
+                want["key"] += m["key"][sel].tolist()
+                want["stiffness"] += [0.0] * int(sel.sum())
+                for k in ("shape0", "shape1", "point0", "normal"):
+                    want[k] += list(m[k][sel])
+    assert len(want["key"]) == n > 100 and (np.asarray(want["stiffness"]) > 0).sum() > 50 and (np.asarray(want["stiffness"]) == 0).sum() > 0
+    assert np.array_equal(a["key"], np.asarray(want["key"])) and np.array_equal(a["shape0"], np.asarray(want["shape0"]))
+    assert np.array_equal(a["shape1"], np.asarray(want["shape1"]))
+    assert np.abs(a["point0"] - np.asarray(want["point0"])).max() <= 2e-6 and np.abs(a["normal"] - np.asarray(want["normal"])).max() <= 2e-6
+    ws = np.asarray(want["stiffness"], np.float32)
+    assert np.abs(stiff - ws).max() <= 1e-5 * np.abs(ws).max()
+    # ---- SolverSemiImplicit consumes the per-contact stiffness (kernels_contact.py:452-459) like the checker
+    solver = nt.solvers.SolverSemiImplicit(model)
+    solver.step(s0, s1, model.control(), c1, 1.0e-4)
+    torch.cuda.synchronize()
+    host = _host_twin_without_sdf_pairs(model)
+    o = Oracle(host)
+    oc = o.contacts(cmax=max(1000, host.shape_contact_pair_count * 5) + n)
+    o.collide(np.asarray(model.body_q), oc)
+    n0 = int(oc.count[0])
+    for k in FIELDS:
+        getattr(oc, k)[n0:n0 + n] = a[k]
+    oc.count[0] = n0 + n
+    st = np.zeros(oc.max, np.float32)
+    st[n0:n0 + n] = stiff
+    oc.set_properties(st, np.zeros(oc.max, np.float32), np.zeros(oc.max, np.float32))
+    os0, os1 = OracleState(host), OracleState(host)
+    o.semi_implicit_step(os0, os1, o.control(), oc, 1.0e-4)
+    dq, dv = np.abs(s1.body_q.cpu().numpy() - os1.body_q).max(), np.abs(s1.body_qd.cpu().numpy() - os1.body_qd).max()
+    assert dq <= 1e-5 and dv <= 1e-3 * max(1.0, np.abs(os1.body_qd).max()), (dq, dv)
+    oc2 = o.contacts()
+    o.collide(np.asarray(model.body_q), oc2)
+    ot0, ot1 = OracleState(host), OracleState(host)
+    o.semi_implicit_step(ot0, ot1, o.control(), oc2, 1.0e-4)
+    assert np.abs(ot1.body_qd - os1.body_qd).max() > 1e-3  # the hydroelastic patches push

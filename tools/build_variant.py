@@ -14,8 +14,28 @@ import __graft_entry__ as g  # noqa: E402
 
 out = os.path.abspath(sys.argv[1])
 os.makedirs(os.path.dirname(out), exist_ok=True)
-flags = [f for f in g.HIP_FLAGS] + sys.argv[2:]
-srcs = [os.path.join(g.CSRC, u) for u in g.UNITS]
-cmd = [g.HIPCC, *flags, f'-DNT_BUILD_ID="variant{"".join(sys.argv[2:])}"', *srcs, "-o", out]
-print(" ".join(cmd), flush=True)
-subprocess.run(cmd, check=True)
+# --units a.hip,b.hip: only these translation units see the extra flags; the others are linked from the product's cached objects
+only = None
+extra = []
+for a in sys.argv[2:]:
+    if a.startswith("--units="):
+        only = a.split("=", 1)[1].split(",")
+    else:
+        extra.append(a)
+flags = [f for f in g.HIP_FLAGS] + extra
+objs = []
+tmp = os.path.join(os.path.dirname(out), "_variant_obj")
+os.makedirs(tmp, exist_ok=True)
+compile_flags = [f for f in flags if f != "-shared"] + ["-c"]
+for u in g.UNITS:
+    if only is None or u in only:
+        obj = os.path.join(tmp, os.path.basename(out) + "." + u.replace(".hip", ".o"))
+        cmd = [g.HIPCC, *compile_flags, f'-DNT_BUILD_ID="variant{"".join(extra)}"', os.path.join(g.CSRC, u), "-o", obj]
+        print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    else:
+        key = g.source_hash() if u == "nt_build_id.hip" else g._unit_hash(u)
+        objs.append(os.path.join(g.OBJ_DIR, f"{u.replace('.hip', '')}.{key}.o"))
+subprocess.run([g.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], check=True)
+print("built", out)
