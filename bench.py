@@ -141,8 +141,9 @@ def cpu_baseline(envs_per_core=256, sample_substeps=2500, max_cores=32):
 
 
 def build_shard(workload: str, envs_per_gpu: int, rank: int, world: int, device: str):
-    """This rank's shard of ONE global model (same seeds on every rank), sliced with shard_range; shards above BASE_ENVS
-    environments are tiled from the rank's BASE_ENVS-env slice (10^5..10^6 envs would take minutes in the Python builder)."""
+    """This rank's shard of ONE global model (same seeds on every rank): worlds shard_range(total, rank, world) of it.  The
+    quadruped workloads build only those worlds; shards above BASE_ENVS environments are tiled from the rank's BASE_ENVS-env slice
+    (10^5..10^6 envs would take minutes in the Python builder)."""
     import newton_amd as nt
     from newton_amd.sharding import shard_model
     from newton_amd.worlds import tile_worlds
@@ -152,20 +153,31 @@ def build_shard(workload: str, envs_per_gpu: int, rank: int, world: int, device:
     if envs_per_gpu % base:
         raise SystemExit(f"--envs-per-gpu above {BASE_ENVS} must be a multiple of it")
     total = base * world
-    if workload in ("quadruped", "quadruped_featherstone", "quadruped_api"):
-        g = scenes.quadruped_scene(total, seed=1)
-    elif workload == "hydro_bin":
+    drop = WORKLOADS[workload]["drop"]
+    if workload in ("quadruped", "quadruped_featherstone", "quadruped_api", "quadruped_convex"):
+        # the rank builds ONLY its own worlds of the global scene (per-world jitter drawn for all worlds, sliced): the same model
+        # shard_model(global, rank, world) gives (tests/test_sharding_gloo.py), without 23 s of Python builder per rank at 8 x 4096
+        from newton_amd.sharding import shard_range
+
+        b, e = shard_range(total, rank, world)
+        fn = scenes.quadruped_convex_scene if workload == "quadruped_convex" else scenes.quadruped_scene
+        m = fn(total, seed=1, world_range=(b, e))
+        if drop > 0.0:
+            m.joint_q.reshape(e - b, -1)[:, 2] -= drop
+            m.body_q, m.body_qd = nt.articulation.eval_fk_numpy(m, m.joint_q, m.joint_qd)
+        m = shard_model(m, 0, 1, device=device)
+        if envs_per_gpu > base:
+            m = tile_worlds(m, envs_per_gpu // base, device=device, filter_pairs=False)
+        return m
+    if workload == "hydro_bin":
         g = scenes.hull_bin_scene(total, 64, seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005), hydroelastic=True)
     elif workload == "sdf_bin":
         # contact gap 5 mm (Newton's default rigid_gap of 0.1 m is larger than a hull: every pair of the bin would be a candidate)
         g = scenes.hull_bin_scene(total, 64, seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005))
-    elif workload == "quadruped_convex":
-        g = scenes.quadruped_convex_scene(total, seed=1)
     elif workload == "box_stack":
         g = scenes.box_stack_scene(total, seed=1)
     else:
         g = scenes.hull_bin_scene(total, 64, seed=2)
-    drop = WORKLOADS[workload]["drop"]
     if drop > 0.0:  # feet onto the ground: the free fall from z = 0.7 is not the regime the metric is quoted on
         g.joint_q.reshape(total, -1)[:, 2] -= drop
         g.body_q, g.body_qd = nt.articulation.eval_fk_numpy(g, g.joint_q, g.joint_qd)

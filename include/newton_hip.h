@@ -404,6 +404,17 @@ typedef struct {
     int32_t* out_blk;
     const uint8_t* pair_kind;         /* [worlds * pairs_per_world] or NULL: only pairs of kind 0 are processed (1 = hydroelastic pair,
                                          nt_hydro_pairs) */
+    /* staged variant of nt_mesh_sdf_collide_reduced (same rows, bit for bit): the edges that survive culling are compacted over ALL
+     * pairs into one list, searched one lane per survivor, then reduced per pair -- three dense launches instead of one workgroup
+     * per pair.  Scratch of the call; hit_count above hit_capacity afterwards = survivors were dropped (size it up).  All NULL / 0:
+     * the single-kernel variant. */
+    int32_t* hit_count;               /* [1] */
+    int32_t* hit_pair;                /* [hit_capacity] position in `pairs` */
+    int32_t* hit_fp;                  /* [hit_capacity] (edge << 2) | (mode << 1), -1 once the search rejected it */
+    float* hit_rec;                   /* [hit_capacity][8] midpoint value, then world point, distance, normal */
+    int32_t* hit_blk;                 /* [pairs][2 modes][2] (offset, count) of each (pair, mode)'s block in the list; `pairs` counts
+                                         worlds * pairs_per_world positions for world-region pairs, pair_count otherwise */
+    int32_t hit_capacity;
 } nt_mesh_sdf_args;
 nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
 

@@ -124,7 +124,9 @@ class nt_mesh_sdf_args(C.Structure):
                 ("shape_edge_range", C.c_void_p), ("edge_centers", C.c_void_p), ("edge_halves", C.c_void_p),
                 ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_data", C.c_void_p),
                 ("capacity", C.c_int32), ("pair_count_device", C.c_void_p), ("pair_world_prefix", C.c_void_p),
-                ("worlds", C.c_int32), ("pairs_per_world", C.c_int32), ("out_blk", C.c_void_p), ("pair_kind", C.c_void_p)]
+                ("worlds", C.c_int32), ("pairs_per_world", C.c_int32), ("out_blk", C.c_void_p), ("pair_kind", C.c_void_p),
+                ("hit_count", C.c_void_p), ("hit_pair", C.c_void_p), ("hit_fp", C.c_void_p), ("hit_rec", C.c_void_p),
+                ("hit_blk", C.c_void_p), ("hit_capacity", C.c_int32)]
 
 
 class nt_contact_reduce_shapes(C.Structure):

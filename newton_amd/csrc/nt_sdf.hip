@@ -608,48 +608,67 @@ struct RedLds {
     int src[RED_SLOTS];       // list variant: index of the winner in the caller's list
     int keep[RED_SLOTS];      // survives the roundoff-twin pass of its entry
     int first[RED_SLOTS];     // first kept slot holding this fingerprint (exported_flags: a contact leaves once)
+    int srcidx[RED_SLOTS];    // list variant: the winner's list index, kept across red_finish (which compacts into src)
     int base, total;
 };
 // After the winners' records are in LDS: twins, de-duplication, rank by fingerprint.  Leaves L.first[k] (slot k exports a
 // contact), L.keep[k] = its rank among the pair's survivors, L.total; every lane of the workgroup must call it (any size).
+// The quadratic steps (first occurrence of a fingerprint, rank among the survivors) only walk the OCCUPIED slots: a pair keeps a
+// few dozen winners at most, usually a handful, and a pair without any winner skips them altogether.
 NT_DI void red_finish(RedLds& L) {
     const int t = threadIdx.x, nt_ = blockDim.x;
+    if (t == 0) L.total = 0;
     for (int en = t; en < RED_ENTRIES; en += nt_) {  // _roundoff_duplicate_bit_for_slot_pair over the 21 slot pairs of the entry
-        int suppressed = 0;
+        int suppressed = 0, filled = 0;
         const int e0 = en * RED_VALUES;
-        for (int sb = 1; sb < RED_VALUES; ++sb)
-            for (int sa = 0; sa < sb; ++sa) {
-                const int fa = L.fp[e0 + sa], fb = L.fp[e0 + sb];
-                if (fa < 0 || fb < 0 || fa == fb) continue;
-                const float* pa = L.pos[e0 + sa];
-                const float* pb = L.pos[e0 + sb];
-                const bool same = red_near_ulps(pa[0], pb[0]) && red_near_ulps(pa[1], pb[1]) && red_near_ulps(pa[2], pb[2]) &&
-                                  red_near_ulps(pa[3], pb[3]) && red_near_ulps(L.oct[e0 + sa][0], L.oct[e0 + sb][0]) &&
-                                  red_near_ulps(L.oct[e0 + sa][1], L.oct[e0 + sb][1]);
-                if (same) suppressed |= fb < fa ? (1 << sa) : (1 << sb);
-            }
-        for (int sl = 0; sl < RED_VALUES; ++sl) L.keep[e0 + sl] = L.fp[e0 + sl] >= 0 && !((suppressed >> sl) & 1);
+        for (int sl = 0; sl < RED_VALUES; ++sl) filled += L.fp[e0 + sl] >= 0 ? 1 : 0;
+        if (filled >= 2)
+            for (int sb = 1; sb < RED_VALUES; ++sb)
+                for (int sa = 0; sa < sb; ++sa) {
+                    const int fa = L.fp[e0 + sa], fb = L.fp[e0 + sb];
+                    if (fa < 0 || fb < 0 || fa == fb) continue;
+                    const float* pa = L.pos[e0 + sa];
+                    const float* pb = L.pos[e0 + sb];
+                    const bool same = red_near_ulps(pa[0], pb[0]) && red_near_ulps(pa[1], pb[1]) && red_near_ulps(pa[2], pb[2]) &&
+                                      red_near_ulps(pa[3], pb[3]) && red_near_ulps(L.oct[e0 + sa][0], L.oct[e0 + sb][0]) &&
+                                      red_near_ulps(L.oct[e0 + sa][1], L.oct[e0 + sb][1]);
+                    if (same) suppressed |= fb < fa ? (1 << sa) : (1 << sb);
+                }
+        for (int sl = 0; sl < RED_VALUES; ++sl) {
+            L.keep[e0 + sl] = L.fp[e0 + sl] >= 0 && !((suppressed >> sl) & 1);
+            L.first[e0 + sl] = 0;
+        }
     }
     __syncthreads();
-    for (int k = t; k < RED_SLOTS; k += nt_) {
-        int first = L.keep[k];
-        for (int j = 0; j < k && first; ++j)
-            if (L.keep[j] && L.fp[j] == L.fp[k]) first = 0;
+    // the kept slots, compacted in ascending slot order into L.src (free here: the list variant has consumed it)
+    if (t == 0) {
+        int n = 0;
+        for (int k = 0; k < RED_SLOTS; ++k)
+            if (L.keep[k]) L.src[n++] = k;
+        L.base = n;
+    }
+    __syncthreads();
+    const int n_occ = L.base;
+    for (int i = t; i < n_occ; i += nt_) {
+        const int k = L.src[i];
+        int first = 1;
+        for (int j = 0; j < i && first; ++j)
+            if (L.fp[L.src[j]] == L.fp[k]) first = 0;
         L.first[k] = first;
     }
     __syncthreads();
-    for (int k = t; k < RED_SLOTS; k += nt_) {
-        int rank = -1;
-        if (L.first[k]) {
-            rank = 0;
-            for (int j = 0; j < RED_SLOTS; ++j) rank += (L.first[j] && L.fp[j] < L.fp[k]) ? 1 : 0;
+    for (int k = t; k < RED_SLOTS; k += nt_) L.keep[k] = -1;
+    __syncthreads();
+    for (int i = t; i < n_occ; i += nt_) {
+        const int k = L.src[i];
+        if (!L.first[k]) continue;
+        int rank = 0;
+        for (int j = 0; j < n_occ; ++j) {
+            const int kj = L.src[j];
+            rank += (L.first[kj] && L.fp[kj] < L.fp[k]) ? 1 : 0;
         }
         L.keep[k] = rank;
-    }
-    if (t == 0) {
-        int total = 0;
-        for (int k = 0; k < RED_SLOTS; ++k) total += L.first[k];
-        L.total = total;
+        atomicAdd(&L.total, 1);
     }
     __syncthreads();
 }
@@ -742,6 +761,11 @@ __global__ void __launch_bounds__(256) NT_SDF_OCCUPANCY mesh_sdf_collide_reduced
             __syncthreads();
         }
         const int hits = H.n < HIT_CAP ? H.n : HIT_CAP;
+        if (H.n == 0) {  // no edge survived the cull (most candidate pairs of a pile): no rows, nothing to reduce (uniform)
+            if (t == 0 && a.out_blk) { a.out_blk[2 * (size_t)pair_idx] = 0; a.out_blk[2 * (size_t)pair_idx + 1] = 0; }
+            __syncthreads();
+            continue;
+        }
         for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k: its record from the list, else recomputed
             if (L.tbl[k] == 0ull) continue;
             const int fp = (int)(L.tbl[k] & RED_FP_MASK);
@@ -760,6 +784,162 @@ __global__ void __launch_bounds__(256) NT_SDF_OCCUPANCY mesh_sdf_collide_reduced
                 L.pos[k][0] = pw.x; L.pos[k][1] = pw.y; L.pos[k][2] = pw.z; L.pos[k][3] = dist;
                 red_encode_oct(n, L.oct[k][0], L.oct[k][1]);
             }
+            L.fp[k] = fp;
+        }
+        __syncthreads();
+        red_finish(L);
+        if (t == 0) {
+            L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
+            if (a.out_blk) {  // the pair's block: rows past the capacity do not exist for the consumers
+                const int room = a.capacity - L.base;
+                a.out_blk[2 * (size_t)pair_idx] = L.base;
+                a.out_blk[2 * (size_t)pair_idx + 1] = L.total < room ? L.total : (room > 0 ? room : 0);
+            }
+        }
+        __syncthreads();
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {
+            const int slot = L.base + L.keep[k];
+            if (L.keep[k] < 0 || slot >= a.capacity) continue;
+            const vec3 n = red_decode_oct(L.oct[k][0], L.oct[k][1]);
+            a.out_pair[slot] = pair_idx;
+            a.out_key[slot] = L.fp[k];
+            float* o = a.out_data + 9 * (size_t)slot;
+            o[0] = L.pos[k][0]; o[1] = L.pos[k][1]; o[2] = L.pos[k][2];
+            o[3] = n.x; o[4] = n.y; o[5] = n.z;
+            o[6] = L.pos[k][3];
+            o[7] = a.shape_data[4 * s0 + 3];
+            o[8] = a.shape_data[4 * s1 + 3];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- the same contacts in three dense stages (nt_mesh_sdf_args.hit_*): a pile's candidate pairs mostly have no surviving edge and
+// the survivors of one pair fill a few lanes of a wave, so the one-workgroup-per-pair kernel above spends its time in latency
+// chains on nearly empty waves.  Here every stage is flat over its own population:
+//   sdf_cull_kernel     one wave per (pair, mode): edge culling, survivors compacted by ballot into ONE list (a contiguous block per
+//                       (pair, mode), reserved with one atomic) -- no LDS, no barriers
+//   sdf_resolve_kernel  one lane per survivor: Brent search + gradient -> world point, normal, distance (or rejected)
+//   sdf_reduce_kernel   one workgroup per pair that has survivors: table, winners (records read from the list instead of being
+//                       recomputed), twins / duplicates / ranks, rows
+// Same arithmetic per edge and an order-independent table (atomicMax on keys that carry the fingerprint): the rows are those of
+// the single kernel bit for bit, whatever order the blocks land in the list.
+__global__ void __launch_bounds__(256) sdf_cull_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
+    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int pair_count = live_pair_count(a);
+    for (int u = blockIdx.x * waves + (threadIdx.x >> 6); u < 2 * pair_count; u += gridDim.x * waves) {
+        const int mode = u & 1;
+        const int pair_idx = pair_slot(a, u >> 1);
+        int* blk = a.hit_blk + 2 * (2 * (size_t)pair_idx + mode);
+        bool run = !(a.pair_kind && a.pair_kind[pair_idx] != 0);
+        const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
+        ModeCtx c;
+        run = run && mode_setup(a, s0, s1, mode, c);
+        if (run && r.shape_edge_radius_max) {
+            const int tri_shape = mode == 0 ? s0 : s1;
+            run = mode_can_touch(c, r.shape_aabb_lower + 3 * tri_shape, r.shape_aabb_upper + 3 * tri_shape,
+                                 r.shape_edge_radius_max[tri_shape]);
+        }
+        if (!run) {  // wave-uniform
+            if (lane == 0) { blk[0] = 0; blk[1] = 0; }
+            continue;
+        }
+        const int iters = (c.ne + 63) >> 6;
+        bool hit0 = false;
+        float mid0 = 0.0f;
+        int total = 0;
+        for (int it = 0; it < iters; ++it) {  // pass 1: how many survive (the block must be reserved in one piece)
+            const int e = it * 64 + lane;
+            float mid = 0.0f;
+            const bool hit = e < c.ne && edge_cull(a, c, e, mid);
+            if (it == 0) { hit0 = hit; mid0 = mid; }
+            total += __popcll(__ballot(hit));
+        }
+        int base = 0;
+        if (lane == 0 && total > 0) base = atomicAdd(a.hit_count, total);
+        base = __shfl(base, 0);
+        const int room = a.hit_capacity - base;
+        if (lane == 0) { blk[0] = base; blk[1] = total < room ? total : (room > 0 ? room : 0); }
+        if (total == 0) continue;
+        int at = base;
+        for (int it = 0; it < iters; ++it) {  // pass 2: write (meshes with more than 64 edges cull their later edges again)
+            const int e = it * 64 + lane;
+            float mid = mid0;
+            const bool hit = it == 0 ? hit0 : (e < c.ne && edge_cull(a, c, e, mid));
+            const unsigned long long m = __ballot(hit);
+            const int i = at + __popcll(m & below);
+            if (hit && i < a.hit_capacity) {
+                a.hit_pair[i] = pair_idx;
+                a.hit_fp[i] = (e << 2) | (mode << 1);
+                a.hit_rec[8 * (size_t)i] = mid;
+            }
+            at += __popcll(m);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) sdf_resolve_kernel(nt_mesh_sdf_args a) {
+    const int n = *a.hit_count < a.hit_capacity ? *a.hit_count : a.hit_capacity;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int pair_idx = a.hit_pair[i], fp = a.hit_fp[i], mode = (fp >> 1) & 1;
+        ModeCtx c;
+        mode_setup(a, a.pairs[2 * (size_t)pair_idx], a.pairs[2 * (size_t)pair_idx + 1], mode, c);
+        float* rec = a.hit_rec + 8 * (size_t)i;
+        vec3 pw, nrm;
+        float dist;
+        if (edge_resolve(a, c, fp >> 2, mode, rec[0], pw, nrm, dist)) {
+            rec[0] = pw.x; rec[1] = pw.y; rec[2] = pw.z; rec[3] = dist;
+            rec[4] = nrm.x; rec[5] = nrm.y; rec[6] = nrm.z;
+        } else {
+            a.hit_fp[i] = -1;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
+    __shared__ RedLds L;
+    const int t = threadIdx.x;
+    const int pair_count = live_pair_count(a);
+    for (int f = blockIdx.x; f < pair_count; f += gridDim.x) {
+        const int pair_idx = pair_slot(a, f);
+        if (a.pair_kind && a.pair_kind[pair_idx] != 0) continue;  // another leg's pair (uniform)
+        const int* blk = a.hit_blk + 4 * (size_t)pair_idx;
+        if (blk[1] + blk[3] == 0) {  // no edge survived the cull: no rows (uniform)
+            if (t == 0 && a.out_blk) { a.out_blk[2 * (size_t)pair_idx] = 0; a.out_blk[2 * (size_t)pair_idx + 1] = 0; }
+            continue;
+        }
+        const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
+        __syncthreads();
+        for (int mode = 0; mode < 2; ++mode) {
+            const int off = blk[2 * mode], cnt = blk[2 * mode + 1];
+            if (cnt == 0) continue;
+            ModeCtx c;
+            mode_setup(a, s0, s1, mode, c);
+            const int tri_shape = mode == 0 ? s0 : s1;
+            const vec3 midpoint = (c.X_tri.p + c.X_sdf.p) * 0.5f;
+            const float margin_sum = c.tri_margin + c.sdf_margin;
+            const float inner_depth = margin_sum + fminw(c.s.voxel_radius * c.min_scale, c.gap_sum);  // base gap == gap
+            const float outer_depth = margin_sum + c.gap_sum;
+            for (int i = off + t; i < off + cnt; i += blockDim.x) {
+                const int fp = a.hit_fp[i];
+                if (fp < 0) continue;
+                const float* rec = a.hit_rec + 8 * (size_t)i;
+                const vec3 pw(rec[0], rec[1], rec[2]), nrm(rec[4], rec[5], rec[6]);
+                const vec3 local = quat_rotate_inv(c.X_tri.q, pw - c.X_tri.p);
+                red_offer(L.tbl, nrm, pw - midpoint, rec[3], inner_depth, outer_depth, local, r.shape_aabb_lower + 3 * tri_shape,
+                          r.shape_aabb_upper + 3 * tri_shape, r.shape_voxel_res + 3 * tri_shape, fp);
+            }
+        }
+        __syncthreads();
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k: its record from the pair's blocks
+            if (L.tbl[k] == 0ull) continue;
+            const int fp = (int)(L.tbl[k] & RED_FP_MASK);
+            const int mode = (fp >> 1) & 1;
+            int i = blk[2 * mode];
+            while (a.hit_fp[i] != fp) ++i;  // it is there: the table only holds fingerprints offered from these blocks
+            const float* rec = a.hit_rec + 8 * (size_t)i;
+            L.pos[k][0] = rec[0]; L.pos[k][1] = rec[1]; L.pos[k][2] = rec[2]; L.pos[k][3] = rec[3];
+            red_encode_oct(vec3(rec[4], rec[5], rec[6]), L.oct[k][0], L.oct[k][1]);
             L.fp[k] = fp;
         }
         __syncthreads();
@@ -820,6 +1000,8 @@ __global__ void __launch_bounds__(256) contacts_reduce_list_kernel(nt_contact_re
             L.fp[k] = a.fp[i];
         }
         __syncthreads();
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) L.srcidx[k] = L.src[k];  // red_finish compacts into L.src
+        __syncthreads();
         red_finish(L);
         if (t == 0) L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
         __syncthreads();
@@ -827,7 +1009,7 @@ __global__ void __launch_bounds__(256) contacts_reduce_list_kernel(nt_contact_re
             const int slot = L.base + L.keep[k];
             if (L.keep[k] < 0 || slot >= a.capacity) continue;
             const vec3 n = red_decode_oct(L.oct[k][0], L.oct[k][1]);
-            a.out_index[slot] = L.src[k];
+            a.out_index[slot] = L.srcidx[k];
             a.out_normal[3 * slot] = n.x; a.out_normal[3 * slot + 1] = n.y; a.out_normal[3 * slot + 2] = n.z;
         }
         __syncthreads();
@@ -1408,6 +1590,24 @@ nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* a, const nt_contac
         if (a->worlds <= 0 || a->pairs_per_world <= 0) return NT_ERR_INVALID_ARG;
         const long long cap = (long long)a->worlds * a->pairs_per_world;
         blocks = cap < 16384 ? (int)cap : 16384;
+    }
+    if (a->hit_count) {  // the staged variant: cull -> resolve -> reduce, each dense over its own population
+        if (!a->hit_pair || !a->hit_fp || !a->hit_rec || !a->hit_blk || a->hit_capacity <= 0) return NT_ERR_INVALID_ARG;
+        if (hipMemsetAsync(a->hit_count, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return NT_ERR_LAUNCH;
+        const long long units = 2 * (a->pair_world_prefix ? (long long)a->worlds * a->pairs_per_world : (long long)a->pair_count);
+        // grid-stride kernels: the grids only bound the parallelism (tests/emu runs every lane as an OS thread and caps them)
+#ifdef NT_EMULATED_GRID
+        const long long cull_cap = NT_EMULATED_GRID, res_cap = NT_EMULATED_GRID;
+        if (blocks > NT_EMULATED_GRID) blocks = NT_EMULATED_GRID;
+#else
+        const long long cull_cap = 8192, res_cap = 4096;
+#endif
+        const int cull_blocks = (int)((units + 3) / 4 < cull_cap ? (units + 3) / 4 : cull_cap);  // 4 waves = 4 (pair, mode) units per workgroup
+        hipLaunchKernelGGL(sdf_cull_kernel, dim3(cull_blocks), dim3(256), 0, (hipStream_t)stream, *a, *r);
+        const long long res_blocks = ((long long)a->hit_capacity + 255) / 256;
+        hipLaunchKernelGGL(sdf_resolve_kernel, dim3((int)(res_blocks < res_cap ? res_blocks : res_cap)), dim3(256), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(sdf_reduce_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *a, *r);
+        return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(mesh_sdf_collide_reduced_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, *a, *r);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;

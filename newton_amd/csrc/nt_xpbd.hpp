@@ -7,6 +7,41 @@
 // ------------------------------------------------------------------------------------------------
 // XPBD: apply_joint_forces (xpbd/kernels.py:945-1075)
 // ------------------------------------------------------------------------------------------------
+// Division inside the XPBD projection phases (contacts / joints / apply / integrate).  Product build: IEEE division, the literal
+// operation of the reference.  -DNT_XPBD_FAST_MATH (measurement variant, tools/build_variant.py): v_rcp_f32 + multiply and
+// v_sqrt_f32 -- 1 ulp instead of correctly rounded, 2 instructions instead of ~11 per division.
+#ifdef NT_XPBD_FAST_MATH
+NT_DI float xrcp(float x) { return __builtin_amdgcn_rcpf(x); }
+NT_DI float xdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
+NT_DI float xrcp(float x) { return 1.0f / x; }
+NT_DI float xdiv(float a, float b) { return a / b; }
+#endif
+#ifdef NT_XPBD_FAST_MATH
+NT_DI float xsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32 (1 ulp) instead of the correctly rounded expansion
+#else
+NT_DI float xsqrt(float x) { return sqrtf(x); }
+#endif
+NT_DI float xlength(vec3 a) { return xsqrt(dot(a, a)); }
+NT_DI float xlength(quat a) { return xsqrt(dot(a, a)); }
+NT_DI vec3 xdiv(vec3 a, float s) {
+#ifdef NT_XPBD_FAST_MATH
+    const float r = __builtin_amdgcn_rcpf(s);
+    return vec3(a.x * r, a.y * r, a.z * r);
+#else
+    return a / s;
+#endif
+}
+NT_DI vec3 xnormalize(vec3 a) {
+    float l = xlength(a);
+    if (l > 0.0f) return xdiv(a, l);
+    return vec3();
+}
+NT_DI quat xnormalize(quat q) {
+    float l = xlength(q);
+    if (l > 0.0f) return q * xrcp(l);
+    return quat(0.f, 0.f, 0.f, 1.f);
+}
 template <int EPB>
 NT_DI void joint_force_item(const Ctx<EPB>& c, const int j);
 template <int EPB>
@@ -132,7 +167,7 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     vec3 wb = quat_rotate_inv(r0, w0);
     vec3 tb = quat_rotate_inv(r0, t0) - cross(wb, inertia * wb);
     vec3 w1 = quat_rotate(r0, wb + inv_inertia * tb * dt);
-    quat r1 = normalize(r0 + quat(w1, 0.0f) * r0 * 0.5f * dt);
+    quat r1 = xnormalize(r0 + quat(w1, 0.0f) * r0 * 0.5f * dt);
     w1 *= 1.0f - c.a.angular_damping * dt;
     c.st_lxf(c.L.bq, nb, b, xform(x1 - quat_rotate(r1, com), r1));
     c.st_lv3(c.L.bqd, 0, nb, b, v1);
@@ -165,7 +200,7 @@ NT_DI float contact_constraint_delta(float err, float m_inv_a, float m_inv_b, ve
     denom += wq_a;
     denom += wq_b;
     float delta_lambda = -err;
-    if (denom > 0.0f) delta_lambda /= dt * denom;
+    if (denom > 0.0f) delta_lambda = xdiv(delta_lambda, dt * denom);
     return delta_lambda * relaxation;
 }
 
@@ -179,7 +214,7 @@ NT_DI float positional_correction(float err, float derr, float m_inv_a, float m_
     float alpha = compliance;
     float gamma = compliance * damping;
     float delta_lambda = -(err + alpha * lambda_in + gamma * derr);
-    if (denom + alpha > 0.0f) delta_lambda /= (dt + gamma) * denom + alpha / dt;
+    if (denom + alpha > 0.0f) delta_lambda = xdiv(delta_lambda, (dt + gamma) * denom + xdiv(alpha, dt));
     return delta_lambda;
 }
 
@@ -191,7 +226,7 @@ NT_DI float angular_correction(float err, float derr, float wq_a, float wq_b, fl
     float alpha = compliance;
     float gamma = compliance * damping;
     float delta_lambda = -(err + alpha * lambda_in + gamma * derr);
-    if (denom + alpha > 0.0f) delta_lambda /= (dt + gamma) * denom + alpha / dt;
+    if (denom + alpha > 0.0f) delta_lambda = xdiv(delta_lambda, (dt + gamma) * denom + xdiv(alpha, dt));
     return delta_lambda;
 }
 
@@ -327,10 +362,10 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
             rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
         }
         friction_delta += rel_v_kin_t * dt;
-        vec3 perp = normalize(friction_delta);
+        vec3 perp = xnormalize(friction_delta);
         angular_a = -cross(r_a, perp);
         angular_b = cross(r_b, perp);
-        float err = length(friction_delta);
+        float err = xlength(friction_delta);
         if (err > 0.0f) {
             float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, wq_a(angular_a),
                                                        wq_b(angular_b), relaxation, dt);
@@ -354,10 +389,10 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
     }
     if (mu_rolling > 0.0f) {
         delta_omega -= dot(n, delta_omega) * n;
-        float err = length(delta_omega) * dt;
+        float err = xlength(delta_omega) * dt;
         if (err > 0.0f) {
             vec3 lin(0.0f);
-            vec3 roll_n = normalize(delta_omega);
+            vec3 roll_n = xnormalize(delta_omega);
             float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-roll_n), wq_b(roll_n), relaxation, dt);
             lr = fmaxw(lr, -lambda_n * mu_rolling);
             ang_delta_a -= roll_n * lr;
@@ -543,7 +578,7 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     quat q0 = tf.q;
     float weight = 1.0f;
     if (FROM_CONTACTS && c.a.p.rigid_contact_con_weighting) {
-        if (inv_weight > 0.0f) weight = 1.0f / inv_weight;
+        if (inv_weight > 0.0f) weight = xrcp(inv_weight);
     }
     vec3 dp = dlin * (inv_m * weight);
     vec3 dq = dang * weight;
@@ -552,7 +587,7 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     vec3 tb = cross(dwb, body_I * (wb + dwb)) + cross(wb, body_I * dwb);
     vec3 dw1 = quat_rotate(q0, dwb - (dt * inv_I) * tb);
     quat q1 = q0 + 0.5f * quat(dw1 * dt, 0.0f) * q0;
-    q1 = normalize(q1);
+    q1 = xnormalize(q1);
     vec3 com = c.com(b);
     vec3 x_com = p0 + quat_rotate(q0, com);
     vec3 p1 = x_com + dp * dt;
@@ -560,8 +595,8 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
     c.st_lxf(c.L.bq, nb, b, xform(p1, q1));
     vec3 v1 = v0 + dp;
     vec3 w1 = w0 + dw1;
-    if (length(v1) < 1e-4f) v1 = vec3(0.0f);
-    if (length(w1) < 1e-4f) w1 = vec3(0.0f);
+    if (xlength(v1) < 1e-4f) v1 = vec3(0.0f);
+    if (xlength(w1) < 1e-4f) w1 = vec3(0.0f);
     c.st_lv3(c.L.bqd, 0, nb, b, v1);
     c.st_lv3(c.L.bqd, 3, nb, b, w1);
     c.update_body_derived(b);
@@ -610,12 +645,12 @@ NT_DI AxisData gather_axes(const Ctx<EPB>& c, int count, int axis_idx0, int targ
             }
         }
     }
-    if (ke_w.x > 0.0f) tp.x /= ke_w.x;
-    if (ke_w.y > 0.0f) tp.y /= ke_w.y;
-    if (ke_w.z > 0.0f) tp.z /= ke_w.z;
-    if (kd_w.x > 0.0f) tv.x /= kd_w.x;
-    if (kd_w.y > 0.0f) tv.y /= kd_w.y;
-    if (kd_w.z > 0.0f) tv.z /= kd_w.z;
+    if (ke_w.x > 0.0f) tp.x = xdiv(tp.x, ke_w.x);
+    if (ke_w.y > 0.0f) tp.y = xdiv(tp.y, ke_w.y);
+    if (ke_w.z > 0.0f) tp.z = xdiv(tp.z, ke_w.z);
+    if (kd_w.x > 0.0f) tv.x = xdiv(tv.x, kd_w.x);
+    if (kd_w.y > 0.0f) tv.y = xdiv(tv.y, kd_w.y);
+    if (kd_w.z > 0.0f) tv.z = xdiv(tv.z, kd_w.z);
     A.target_pos = tp; A.stiffness = ke_w; A.target_vel = tv; A.damping = kd_w;
     return A;
 }
@@ -681,7 +716,7 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
                 if (fabsf(err) > 1e-9f) {
                     vec3 linear_c;
                     if (d > 1e-9f) {
-                        linear_c = anchor_delta / d;
+                        linear_c = xdiv(anchor_delta, d);
                     } else {
                         vec3 com_delta = world_com_c - world_com_p;
                         if (length_sq(com_delta) > 1e-18f) linear_c = normalize(com_delta);
@@ -693,7 +728,7 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
                     float derr = dot(linear_p, vel_p) + dot(linear_c, vel_c) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
                     float compliance = P.joint_linear_compliance;
                     float ke = c.dof(DP_TARGET_KE, axis_start);
-                    if (ke > 0.0f) compliance = 1.0f / ke;
+                    if (ke > 0.0f) compliance = xrcp(ke);
                     float damping = c.dof(DP_TARGET_KD, axis_start);
                     float d_lambda = positional_correction(err, derr, m_inv_p, m_inv_c, linear_p, linear_c, wq_p(angular_p),
                                                            wq_c(angular_c), 0.0f, compliance, damping, dt);
@@ -734,8 +769,8 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
                 else {
                     float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
                     float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
-                    if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
-                    else if (dm > 0.0f) { compliance = 1.0f / dm; damping = dm; }
+                    if (st > 0.0f) { err = e - target_pos; compliance = xrcp(st); damping = dm; }
+                    else if (dm > 0.0f) { compliance = xrcp(dm); damping = dm; }
                 }
                 if (fabsf(err) > 1e-9f || fabsf(derr_rel) > 1e-9f) {
                     float d_lambda = positional_correction(err, derr_rel, m_inv_p, m_inv_c, linear_p, linear_c, wq_p(angular_p),
@@ -782,10 +817,10 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
 
         if (dot(q_p, q_c) < 0.0f) q_c = q_c * -1.0f;
         quat rel_q = quat_inverse(q_p) * q_c;
-        quat qtwist = normalize(quat(rel_q.x, 0.0f, 0.0f, rel_q.w));
+        quat qtwist = xnormalize(quat(rel_q.x, 0.0f, 0.0f, rel_q.w));
         quat qswing = rel_q * quat_inverse(qtwist);
-        float s = sqrtf(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
-        float invs = 1.0f / s;
+        float s = xsqrt(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
+        float invs = xrcp(s);
         float invscube = invs * invs * invs;
         float err_0 = 2.0f * asinf(clampf(qtwist.x, -1.0f, 1.0f));
         float err_1 = qswing.y, err_2 = qswing.z;
@@ -794,12 +829,12 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
                     rel_q.x * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube);
         quat grad_2(rel_q.w * (rel_q.w * rel_q.y - rel_q.x * rel_q.z) * invscube, rel_q.x * invs, rel_q.w * invs,
                     rel_q.x * (rel_q.z * rel_q.x - rel_q.w * rel_q.y) * invscube);
-        grad_0 = grad_0 * (2.0f / fabsf(qtwist.w));
+        grad_0 = grad_0 * xdiv(2.0f, fabsf(qtwist.w));
         float swing_sq = qswing.w * qswing.w;
         if (swing_sq + 1.0e-4f < 1.0f) {
-            float d = sqrtf(1.0f - qswing.w * qswing.w);
+            float d = xsqrt(1.0f - qswing.w * qswing.w);
             float theta = 2.0f * acosf(clampf(qswing.w, -1.0f, 1.0f));
-            float scale = theta / d;
+            float scale = xdiv(theta, d);
             err_1 *= scale;
             err_2 *= scale;
             grad_1 = grad_1 * scale;
@@ -817,15 +852,15 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
             float err = 0.0f;
             float compliance = P.joint_angular_compliance;
             float damping = 0.0f;
-            float derr_rel = derr - vget(A.target_vel, dim) * length(angular_c);
+            float derr_rel = derr - vget(A.target_vel, dim) * xlength(angular_c);
             float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
             if (e < lower) err = e - lower;
             else if (e > upper) err = e - upper;
             else {
                 float target_pos = clampf(vget(A.target_pos, dim), lower, upper);
                 float st = vget(A.stiffness, dim), dm = vget(A.damping, dim);
-                if (st > 0.0f) { err = e - target_pos; compliance = 1.0f / st; damping = dm; }
-                else if (dm > 0.0f) { damping = dm; compliance = 1.0f / dm; }
+                if (st > 0.0f) { err = e - target_pos; compliance = xrcp(st); damping = dm; }
+                else if (dm > 0.0f) { damping = dm; compliance = xrcp(dm); }
             }
             float wqp = id_p >= 0 ? c.w_quad(id_p, angular_p) : 0.0f;
             float d_lambda = angular_correction(err, derr_rel, wqp, c.w_quad(id_c, angular_c), 0.0f, compliance, damping, dt) *

@@ -61,13 +61,14 @@ class DeviceSDF:
 
 
 def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_index, sdfs, shape_edge_range, edge_centers,
-                     edge_halves, capacity: int | None = None, device="cuda:0", reduce=None):
+                     edge_halves, capacity: int | None = None, device="cuda:0", reduce=None, staged: bool = False):
     """Run nt_mesh_sdf_collide; returns a dict of numpy arrays sorted by (pair, key): pair, key, center [n,3], normal [n,3],
     distance, margin0, margin1, plus `count` (the atomic counter, which keeps counting past the capacity).
     `sdfs`: list of DeviceSDF (or None) indexed by shape_sdf_index.
     `reduce`: (shape_collision_aabb_lower, shape_collision_aabb_upper, shape_voxel_resolution) -- see
     newton_amd.sdf.mesh_reduction_tables -- runs nt_mesh_sdf_collide_reduced instead: the reference's global contact reduction
-    (GlobalContactReducer, deterministic packing) fused into the pair's workgroup."""
+    (GlobalContactReducer, deterministic packing) fused into the pair's workgroup; `staged` selects the three dense launches
+    (cull over all pairs -> one lane per survivor -> reduction per pair) that the collide pipeline uses: same rows."""
     torch = _torch()
     lib = _lib.load()
     dev = torch.device(device)
@@ -104,6 +105,15 @@ def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_in
         r = _lib.nt_contact_reduce_shapes()
         t_lo, t_hi, t_res = up(reduce[0], np.float32), up(reduce[1], np.float32), up(reduce[2], np.int32)
         r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = t_lo.data_ptr(), t_hi.data_ptr(), t_res.data_ptr()
+        if staged:
+            er = np.asarray(shape_edge_range, dtype=np.int64).reshape(-1, 2)
+            hcap = int(sum(er[p, 1] + er[q, 1] for p, q in pairs_np)) + 1  # at most every edge of both modes survives
+            h_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            h_pair, h_fp = torch.zeros(hcap, dtype=torch.int32, device=dev), torch.zeros(hcap, dtype=torch.int32, device=dev)
+            h_rec = torch.zeros((hcap, 8), dtype=torch.float32, device=dev)
+            h_blk = torch.zeros((max(len(pairs_np), 1), 2, 2), dtype=torch.int32, device=dev)
+            a.hit_count, a.hit_pair, a.hit_fp, a.hit_rec, a.hit_blk, a.hit_capacity = (
+                h_count.data_ptr(), h_pair.data_ptr(), h_fp.data_ptr(), h_rec.data_ptr(), h_blk.data_ptr(), hcap)
         _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
     else:
         _lib.check(lib.nt_mesh_sdf_collide(C.byref(a), stream), "nt_mesh_sdf_collide")

@@ -15,6 +15,7 @@ bit-identical rows -- and consumable by SolverXPBD (inside the step kernel) and 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -68,7 +69,8 @@ class FlatRows:
 class SdfLeg:
     """Model-level tables + per-pipeline work buffers of the mesh-SDF leg."""
 
-    def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64, hydro_config=None):
+    def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64, hydro_config=None,
+                 staged: bool = True, survivors_per_row: int = 2):
         from .sdf_device import DeviceSDF  # noqa: PLC0415
 
         torch = _torch()
@@ -156,6 +158,15 @@ class SdfLeg:
         self.raw_pair = torch.zeros(self.row_capacity, dtype=i32, device=dev)
         self.raw_key = torch.zeros(self.row_capacity, dtype=i32, device=dev)
         self.raw_data = torch.zeros((self.row_capacity, 9), dtype=f32, device=dev)
+        # staged narrow phase (cull -> resolve -> reduce): the list of culling survivors over all pairs
+        self.staged = bool(staged) and os.environ.get("NT_SDF_STAGED", "1") != "0"
+        self.hit_capacity = self.row_capacity * int(survivors_per_row) if self.staged else 0
+        if self.staged:
+            self.hit_count = torch.zeros(1, dtype=i32, device=dev)
+            self.hit_pair = torch.zeros(self.hit_capacity, dtype=i32, device=dev)
+            self.hit_fp = torch.zeros(self.hit_capacity, dtype=i32, device=dev)
+            self.hit_rec = torch.zeros((self.hit_capacity, 8), dtype=f32, device=dev)
+            self.hit_blk = torch.zeros((E * PPW, 2, 2), dtype=i32, device=dev)
         self.raw_rank = torch.zeros(self.row_capacity if self.has_hydro_pairs else 1, dtype=i32, device=dev)
         self.raw_stiffness = torch.zeros(self.row_capacity if self.has_hydro_pairs else 1, dtype=f32, device=dev)
 
@@ -191,6 +202,10 @@ class SdfLeg:
         r.threads, r.shape_edge_radius_max = self.threads, self._edge_rmax.data_ptr()
         if self.has_hydro_pairs:
             a.pair_kind = self.world_pair_kind.data_ptr()
+        if self.staged:
+            a.hit_count, a.hit_pair, a.hit_fp, a.hit_rec, a.hit_blk, a.hit_capacity = (
+                self.hit_count.data_ptr(), self.hit_pair.data_ptr(), self.hit_fp.data_ptr(), self.hit_rec.data_ptr(),
+                self.hit_blk.data_ptr(), self.hit_capacity)
         if not bool(np.all(self.t.sdf_pair_hydro)) or not self.has_hydro_pairs:
             _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
         if self.has_hydro_pairs:
@@ -230,8 +245,10 @@ class SdfLeg:
         """Host check (tests / benches, synchronises): did any world exceed its candidate capacity, or the rows their buffer?"""
         pc = int(self.pair_count.max().item()) if self.pair_count.numel() else 0
         raw, total = int(self.raw_count.item()), int(rows.row_start[-1].item())
+        hits = int(self.hit_count.item()) if self.staged else 0
         return {"pairs_per_world_max": pc, "pairs_per_world_capacity": self.pairs_per_world, "raw_rows": raw, "rows": total,
-                "row_capacity": rows.capacity, "overflow": pc > self.pairs_per_world or raw > self.row_capacity or total > rows.capacity}
+                "row_capacity": rows.capacity, "cull_survivors": hits, "survivor_capacity": self.hit_capacity,
+                "overflow": pc > self.pairs_per_world or raw > self.row_capacity or total > rows.capacity or hits > self.hit_capacity}
 
     def add_forces(self, state, rows: FlatRows, body_f, friction_smoothing: float, stream) -> None:
         """eval_body_contact over the rows, ordered per-body sums ADDED to `body_f` (env-major [6][nb][ES])."""

@@ -36,25 +36,26 @@ def shard_model(model, rank: int, world: int, device=None):
     return slice_worlds(model, b, e, device=device)
 
 
-def max_over_ranks(value: float, device=None) -> float:
-    """MAX all-reduce of a host scalar (the bench's timing contract). No-op without a process group."""
+def max_over_ranks(value: float, device=None, force_collective: bool = False) -> float:
+    """MAX all-reduce of a host scalar (the bench's timing contract). No-op without a process group (or with one rank, unless
+    `force_collective`: the single-rank RCCL smoke test)."""
     import torch  # noqa: PLC0415
     import torch.distributed as dist  # noqa: PLC0415
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def gather_body_state(body_q, body_qd):
+def gather_body_state(body_q, body_qd, force_collective: bool = False):
     """all_gather the per-rank AoS body_q [B_r, 7] / body_qd [B_r, 6] tensors into rank-ordered global arrays
     (= the unsharded model's world-major order, because shards are contiguous env ranges)."""
     import torch  # noqa: PLC0415
     import torch.distributed as dist  # noqa: PLC0415
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return body_q, body_qd
     world = dist.get_world_size()
     counts = torch.zeros(world, dtype=torch.int64, device=body_q.device)

@@ -29,6 +29,8 @@ def transform(text: str) -> str:
     text = text.replace("extern __shared__ __align__(16) float lds[];", "float* lds = emu::dynamic_lds();")
     text = text.replace('#include "../../include/newton_hip.h"', f'#include "{os.path.join(ROOT, "include", "newton_hip.h")}"')
     text, n = WAVE_SYNC.subn(WAVE_SYNC_EMU, text)
+    # only under -DNT_XPBD_FAST_MATH (a measurement variant, never built here)
+    text = text.replace("__builtin_amdgcn_rcpf", "emu_rcpf").replace("__builtin_amdgcn_sqrtf", "sqrtf")
     return text
 
 
@@ -46,7 +48,7 @@ def build(force: bool = False) -> str:
         text = transform(open(os.path.join(CSRC, f)).read()).replace('#include "nt_broadphase_core.hpp"', '#include "nt_broadphase_core.hpp"')
         assert "hip_runtime" not in text and "__builtin_amdgcn" not in text, f
         open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w").write(text)
-    cmd = ["g++", "-std=c++20", "-O1", "-DNT_ALL_SHAPES", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
+    cmd = ["g++", "-std=c++20", "-O1", "-DNT_ALL_SHAPES", "-DNT_EMULATED_GRID=4", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
            f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(OUT, "nt_broadphase.cpp"),
            *([os.path.join(OUT, "nt_sdf.cpp")] if "nt_sdf.hip" in files else []),
            *([os.path.join(OUT, "nt_build_id.cpp")] if "nt_build_id.hip" in files else []),

@@ -73,12 +73,18 @@ def quadruped_builder(colliders: str = "cylinder"):
 
 
 def quadruped_scene(world_count: int, device=None, seed: int | None = 1, height_jitter: float = 0.05,
-                    colliders: str = "cylinder", ground: str = "plane"):
+                    colliders: str = "cylinder", ground: str = "plane", world_range=None):
     """C3/C4 scene: `world_count` quadrupeds + one global ground plane.  Per-env root-height jitter U(0, jitter)
     (seeded) de-correlates the environments.  colliders="box" + ground="box" is C4's convex-convex
     variant: box links on a static 2 m x 2 m x 0.5 m slab whose top face is z = 0 (MPR portals on a 100 m slab are
     conditioned 1e4 : 1 in fp32 -- a 6e-8 pose difference moved its contact normals by 7e-4), so all 13 candidate pairs of an
-    environment are box-box and go through MPR/GJK + the manifold (narrow_phase.py:642-655)."""
+    environment are box-box and go through MPR/GJK + the manifold (narrow_phase.py:642-655).
+    `world_range = (begin, end)`: build only worlds [begin, end) of the `world_count`-world scene -- the same model
+    newton_amd.sharding.shard_model cuts out of the global one (the per-world jitter is drawn for all worlds and sliced), without
+    paying the Python builder for the other ranks' worlds."""
+    total = world_count
+    begin, end = (0, world_count) if world_range is None else world_range
+    world_count = end - begin
     q = quadruped_builder(colliders)
     scene = nt.ModelBuilder()
     scene.replicate(q, world_count)
@@ -92,15 +98,16 @@ def quadruped_scene(world_count: int, device=None, seed: int | None = 1, height_
     if seed is not None and height_jitter > 0.0:
         rng = np.random.default_rng(seed)
         jq = model.joint_q.reshape(world_count, -1)
-        jq[:, 2] += rng.uniform(0.0, height_jitter, size=world_count).astype(np.float32)
+        jq[:, 2] += rng.uniform(0.0, height_jitter, size=total).astype(np.float32)[begin:end]
     bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
     model.body_q, model.body_qd = bq, bqd
     return model
 
 
-def quadruped_convex_scene(world_count: int, device=None, seed: int | None = 1, height_jitter: float = 0.05):
+def quadruped_convex_scene(world_count: int, device=None, seed: int | None = 1, height_jitter: float = 0.05, world_range=None):
     """Config C4, convex-convex variant (box links on a box slab)."""
-    return quadruped_scene(world_count, device=device, seed=seed, height_jitter=height_jitter, colliders="box", ground="box")
+    return quadruped_scene(world_count, device=device, seed=seed, height_jitter=height_jitter, colliders="box", ground="box",
+                           world_range=world_range)
 
 
 def box_stack_scene(world_count: int, n_boxes: int = 8, device=None, seed: int | None = 0, jitter: float = 1e-3):

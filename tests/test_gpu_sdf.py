@@ -215,6 +215,8 @@ def test_device_reduced_mesh_sdf_kernel_is_the_reduction_of_the_unreduced_one():
     args = (sc["pairs"], sc["X"], sc["data"], sc["gap"], sc["sdf_index"], dev, sc["er"], sc["ec"], sc["eh"])
     u = mesh_sdf_collide(*args)
     r = mesh_sdf_collide(*args, reduce=(sc["aabb_lo"], sc["aabb_hi"], sc["res"]))
+    r2 = mesh_sdf_collide(*args, reduce=(sc["aabb_lo"], sc["aabb_hi"], sc["res"]), staged=True)
+    assert all(np.array_equal(r[k], r2[k]) for k in r)
     pack = lambda d: (d["pair"], d["key"], np.concatenate([d["center"], d["normal"], d["distance"][:, None],  # noqa: E731
                                                            d["margin0"][:, None], d["margin1"][:, None]], axis=1))
     n_in, n_out = check_reduced_against_unreduced(sc, pack(u), pack(r))
@@ -255,6 +257,11 @@ def test_device_reduced_mesh_sdf_bin_scale():
     assert 0 < a["count"] == b["count"] < u["count"]
     for k in ("pair", "key", "center", "normal", "distance"):
         assert np.array_equal(a[k], b[k])
+    # the staged variant (cull over all pairs -> one lane per survivor -> reduction per pair; 324 edges = six rounds per wave)
+    c = mesh_sdf_collide(pairs, X, data, gap, idx, dev, er, ec, eh, reduce=tables, staged=True)
+    assert c["count"] == a["count"]
+    for k in ("pair", "key", "center", "normal", "distance", "margin0", "margin1"):
+        assert np.array_equal(a[k], c[k]), k
     unreduced = set(zip(u["pair"].tolist(), u["key"].tolist()))
     assert set(zip(a["pair"].tolist(), a["key"].tolist())) <= unreduced
     assert np.bincount(a["pair"]).max() <= 245

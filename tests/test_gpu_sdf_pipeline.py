@@ -106,6 +106,31 @@ def test_collide_twice_is_bitwise_identical_and_blocks_cover_the_rows():
             assert sorted(seen.get(r, [])) == sorted(want), r
 
 
+def test_staged_narrow_phase_gives_the_rows_of_the_single_kernel(monkeypatch):
+    """The dense three-stage narrow phase (cull over all pairs -> one lane per survivor -> reduction per pair; the default) and
+    the one-workgroup-per-pair kernel produce the same rows bit for bit, and the survivor list reports its fill."""
+    import newton_amd as nt
+    from sdf_pipeline_checker import sdf_scene
+
+    model = sdf_scene(3, 7, device="cuda:0", walls=True, seed=4)
+    _pile(model)
+    state = model.state()
+    rows = {}
+    for staged in ("1", "0"):
+        monkeypatch.setenv("NT_SDF_STAGED", staged)
+        pipe = nt.CollisionPipeline(model, broad_phase="sap")
+        assert pipe._sdf_leg.staged == (staged == "1")
+        c = pipe.contacts()
+        pipe.collide(state, c)
+        rows[staged] = _rows(c)
+        info = pipe._sdf_leg.overflow(c._flat)
+        assert not info["overflow"]
+        if staged == "1":
+            assert info["cull_survivors"] >= info["raw_rows"] > 0
+    for k in rows["1"]:
+        assert np.array_equal(rows["1"][k], rows["0"][k]), k
+
+
 def _oracle_contacts_with_rows(model, o, body_q, rows):
     """Checker contacts = its own slot contacts (tile pairs) + the product's SDF rows appended (live ones)."""
     oc = o.contacts(cmax=max(1000, model.shape_contact_pair_count * 5) + len(rows["key"]))

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dbg = os.path.join(ROOT, "build_ab", "libnewton_timing.so")  # prebuilt off the GPU box (saves ~3 GPU-minutes) when present
+dbg = os.environ.get("NEWTON_HIP_LIB") or os.path.join(ROOT, "build_ab", "libnewton_timing.so")  # prebuilt off the GPU box (tools/build_variant.py ... -DNT_PHASE_TIMING)
 if not os.path.exists(dbg):
     dbg = "/tmp/libnewton_hip_timing.so"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
