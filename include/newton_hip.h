@@ -404,17 +404,25 @@ typedef struct {
     int32_t* out_blk;
     const uint8_t* pair_kind;         /* [worlds * pairs_per_world] or NULL: only pairs of kind 0 are processed (1 = hydroelastic pair,
                                          nt_hydro_pairs) */
-    /* staged variant of nt_mesh_sdf_collide_reduced (same rows, bit for bit): the edges that survive culling are compacted over ALL
-     * pairs into one list, searched one lane per survivor, then reduced per pair -- three dense launches instead of one workgroup
-     * per pair.  Scratch of the call; hit_count above hit_capacity afterwards = survivors were dropped (size it up).  All NULL / 0:
-     * the single-kernel variant. */
-    int32_t* hit_count;               /* [1] */
+    /* staged variant of nt_mesh_sdf_collide_reduced (same rows, bit for bit): the edge-independent part of every live pair is
+     * evaluated one lane per pair, the edges that survive culling are compacted over ALL pairs into one list, searched one lane
+     * per survivor, then reduced per pair that has any -- four dense launches instead of one workgroup per pair, and no counter
+     * that every pair hits.  Scratch of the call.  The survivor list is cut into hit_stripe_count equal stripes, each filled by
+     * the waves that map to it; hit_count[0] > 0 afterwards = that many survivors found their stripe full and were dropped (size
+     * hit_capacity up).  With out_blk (world-region pairs) a pair's rows are written from the START OF ITS SURVIVOR BLOCK in the
+     * out_* arrays -- `capacity` must be >= hit_capacity, out_count is not touched, out_blk carries (offset, count); without
+     * out_blk the rows are appended through out_count as in the single kernel.  All NULL / 0: the single kernel.
+     * `pairs` below counts worlds * pairs_per_world positions for world-region pairs, pair_count otherwise. */
+    int32_t* hit_count;               /* [4] dropped survivors, runnable pairs, stripes in use (<= hit_stripe_count: a small call uses
+                                         fewer, each hit_capacity / that long), spare */
+    int32_t* hit_stripes;             /* [hit_stripe_count * 16] fill of every stripe (one counter per 64 bytes; zeroed by the call) */
+    int32_t hit_stripe_count;
+    int32_t hit_capacity;
     int32_t* hit_pair;                /* [hit_capacity] position in `pairs` */
     int32_t* hit_fp;                  /* [hit_capacity] (edge << 2) | (mode << 1), -1 once the search rejected it */
     float* hit_rec;                   /* [hit_capacity][8] midpoint value, then world point, distance, normal */
-    int32_t* hit_blk;                 /* [pairs][2 modes][2] (offset, count) of each (pair, mode)'s block in the list; `pairs` counts
-                                         worlds * pairs_per_world positions for world-region pairs, pair_count otherwise */
-    int32_t hit_capacity;
+    int32_t* hit_blk;                 /* [pairs][2 modes][2] (offset, count) of each (pair, mode)'s block in the list */
+    float* unit_ctx;                  /* [pairs][2][24] per runnable pair and mode: transform into the SDF's space, thresholds, edges */
 } nt_mesh_sdf_args;
 nt_status nt_mesh_sdf_collide(const nt_mesh_sdf_args* args, void* stream);
 
@@ -618,6 +626,9 @@ typedef struct {
     float* stiffness;            /* [row_capacity] or NULL: out, nt_flat_rows.stiffness / damping / friction_scale: the hydroelastic */
     float* damping;              /*   rows carry their stiffness and zero damping / friction scale (ContactData defaults), */
     float* friction_scale;       /*   mesh-SDF rows zeros (collide.py:196-199) */
+    int32_t raw_base;            /* raw rows [0, raw_base) are the blocks the staged narrow phase placed at the start of each pair's
+                                    survivor block (nt_mesh_sdf_args.hit_capacity; gaps in between), rows appended through raw_count
+                                    start at raw_base (the counter is initialised to it); 0: every raw row was appended */
 } nt_sdf_rows_io;
 /* final row ranges (world-major, pairs ascending, rows in fingerprint order), write_contact (collide.py:166-254) of every raw
  * row at its final position, and the per-body row-block lists.  body_q: State.body_q, env-major [7][nb][ES].

@@ -84,7 +84,7 @@ class nt_sdf_rows_io(C.Structure):
                 ("shape1", C.c_void_p), ("point0", C.c_void_p), ("point1", C.c_void_p), ("offset0", C.c_void_p),
                 ("offset1", C.c_void_p), ("normal", C.c_void_p), ("margin0", C.c_void_p), ("margin1", C.c_void_p),
                 ("key", C.c_void_p), ("raw_rank", C.c_void_p), ("raw_stiffness", C.c_void_p), ("stiffness", C.c_void_p),
-                ("damping", C.c_void_p), ("friction_scale", C.c_void_p)]
+                ("damping", C.c_void_p), ("friction_scale", C.c_void_p), ("raw_base", C.c_int32)]
 
 
 class nt_flat_force_params(C.Structure):
@@ -125,8 +125,9 @@ class nt_mesh_sdf_args(C.Structure):
                 ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_data", C.c_void_p),
                 ("capacity", C.c_int32), ("pair_count_device", C.c_void_p), ("pair_world_prefix", C.c_void_p),
                 ("worlds", C.c_int32), ("pairs_per_world", C.c_int32), ("out_blk", C.c_void_p), ("pair_kind", C.c_void_p),
-                ("hit_count", C.c_void_p), ("hit_pair", C.c_void_p), ("hit_fp", C.c_void_p), ("hit_rec", C.c_void_p),
-                ("hit_blk", C.c_void_p), ("hit_capacity", C.c_int32)]
+                ("hit_count", C.c_void_p), ("hit_stripes", C.c_void_p), ("hit_stripe_count", C.c_int32), ("hit_capacity", C.c_int32),
+                ("hit_pair", C.c_void_p), ("hit_fp", C.c_void_p), ("hit_rec", C.c_void_p), ("hit_blk", C.c_void_p),
+                ("unit_ctx", C.c_void_p)]
 
 
 class nt_contact_reduce_shapes(C.Structure):

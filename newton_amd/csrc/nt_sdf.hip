@@ -351,7 +351,8 @@ NT_DI bool mode_setup(const nt_mesh_sdf_args& a, int s0, int s1, int mode, ModeC
 // kernel can compact the survivors of the cull before the (long) search:
 //   edge_cull      bounding sphere of the edge against the SDF box, then against the value at its (clamped) midpoint
 //   edge_resolve   Brent search, inner-cull consistency, corner ownership, gradient -> world point, normal shape0 -> shape1, distance
-NT_DI bool edge_cull(const nt_mesh_sdf_args& a, const ModeCtx& c, int e, float& mid) {
+template <class CTX>
+NT_DI bool edge_cull(const nt_mesh_sdf_args& a, const CTX& c, int e, float& mid) {
     const float* ec = a.edge_centers + 4 * (size_t)(c.e0 + e);
     const vec3 center = cw_mul(xform_point(c.X_m2s, vec3(ec[0], ec[1], ec[2])), c.inv_scale);
     const float threshold = ec[3] * c.radius_scale + c.thr_unscaled;
@@ -641,11 +642,17 @@ NT_DI void red_finish(RedLds& L) {
     }
     __syncthreads();
     // the kept slots, compacted in ascending slot order into L.src (free here: the list variant has consumed it)
-    if (t == 0) {
+    if (t < 64) {  // the first wave: ballot prefix over rounds of 64 slots
+        const unsigned long long below = (1ull << t) - 1ull;
         int n = 0;
-        for (int k = 0; k < RED_SLOTS; ++k)
-            if (L.keep[k]) L.src[n++] = k;
-        L.base = n;
+        for (int k0 = 0; k0 < RED_SLOTS; k0 += 64) {
+            const int k = k0 + t;
+            const bool kept = k < RED_SLOTS && L.keep[k];
+            const unsigned long long m = __ballot(kept);
+            if (kept) L.src[n + __popcll(m & below)] = k;
+            n += __popcll(m);
+        }
+        if (t == 0) L.base = n;
     }
     __syncthreads();
     const int n_occ = L.base;
@@ -814,73 +821,177 @@ __global__ void __launch_bounds__(256) NT_SDF_OCCUPANCY mesh_sdf_collide_reduced
     }
 }
 
-// ---- the same contacts in three dense stages (nt_mesh_sdf_args.hit_*): a pile's candidate pairs mostly have no surviving edge and
-// the survivors of one pair fill a few lanes of a wave, so the one-workgroup-per-pair kernel above spends its time in latency
-// chains on nearly empty waves.  Here every stage is flat over its own population:
-//   sdf_cull_kernel     one wave per (pair, mode): edge culling, survivors compacted by ballot into ONE list (a contiguous block per
-//                       (pair, mode), reserved with one atomic) -- no LDS, no barriers
+// ---- the same contacts in dense stages (nt_mesh_sdf_args.hit_*): a pile's candidate pairs mostly have no surviving edge and the
+// survivors of one pair fill a few lanes of a wave, so the one-workgroup-per-pair kernel above spends its time in latency chains
+// (pair lookup -> shapes -> transforms -> SDF descriptor -> edge -> indirection slot -> texels) on nearly empty waves, and every
+// pair with rows pays an atomic on ONE counter (measured: the serialised same-address atomics alone cost more than the arithmetic).
+// Here every stage is flat over its own population and no counter is shared by more than a few hundred waves:
+//   sdf_units_kernel    one LANE per live pair: everything that does not depend on the edge (mode_setup, mode_can_touch of both
+//                       modes), runnable pairs compacted into a context list (one atomic per wave); clears the pair's block entry
+//   sdf_cull_kernel     one wave per runnable pair: contexts by broadcast reads, edge culling of both modes, survivors compacted
+//                       by ballot into the wave's STRIPE of the survivor list (one contiguous block per pair, mode 0 first;
+//                       `hit_stripes` counters, one per 64 bytes)
 //   sdf_resolve_kernel  one lane per survivor: Brent search + gradient -> world point, normal, distance (or rejected)
-//   sdf_reduce_kernel   one workgroup per pair that has survivors: table, winners (records read from the list instead of being
-//                       recomputed), twins / duplicates / ranks, rows
+//   sdf_reduce_kernel   one workgroup per runnable pair that has survivors: table, winners (records read from the list instead of
+//                       being recomputed), twins / duplicates / ranks; with out_blk the rows go to the START OF THE PAIR'S
+//                       SURVIVOR BLOCK (a pair never has more rows than survivors): no counter at all
 // Same arithmetic per edge and an order-independent table (atomicMax on keys that carry the fingerprint): the rows are those of
-// the single kernel bit for bit, whatever order the blocks land in the list.
-__global__ void __launch_bounds__(256) sdf_cull_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
-    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+// the single kernel bit for bit, whatever order the blocks land in the lists.
+constexpr int UNIT_WORDS = 24;  // CullCtx in HBM: X_m2s[7] inv_scale[3] blo[3] bhi[3] thr_unscaled radius_scale | e0 ne sdf_idx pair | inner outer
+constexpr int STRIPE_PAD = 16;  // ints between stripe counters (64 bytes: one counter per cache line / atomic unit)
+struct CullCtx {
+    nt_sdf s;
+    int e0, ne;
+    vec3 inv_scale, blo, bhi;
+    xform X_m2s;
+    float thr_unscaled, radius_scale;
+};
+enum { CNT_UNITS = 1 };  // nt_mesh_sdf_args.hit_count[4]: [0] survivors beyond a stripe's room (dropped), [1] runnable pairs, [2] stripes in use
+__global__ void __launch_bounds__(256) sdf_units_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
+    const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int pair_count = live_pair_count(a);
-    for (int u = blockIdx.x * waves + (threadIdx.x >> 6); u < 2 * pair_count; u += gridDim.x * waves) {
-        const int mode = u & 1;
-        const int pair_idx = pair_slot(a, u >> 1);
-        int* blk = a.hit_blk + 2 * (2 * (size_t)pair_idx + mode);
-        bool run = !(a.pair_kind && a.pair_kind[pair_idx] != 0);
-        const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
-        ModeCtx c;
-        run = run && mode_setup(a, s0, s1, mode, c);
-        if (run && r.shape_edge_radius_max) {
-            const int tri_shape = mode == 0 ? s0 : s1;
-            run = mode_can_touch(c, r.shape_aabb_lower + 3 * tri_shape, r.shape_aabb_upper + 3 * tri_shape,
-                                 r.shape_edge_radius_max[tri_shape]);
-        }
-        if (!run) {  // wave-uniform
-            if (lane == 0) { blk[0] = 0; blk[1] = 0; }
-            continue;
-        }
-        const int iters = (c.ne + 63) >> 6;
-        bool hit0 = false;
-        float mid0 = 0.0f;
-        int total = 0;
-        for (int it = 0; it < iters; ++it) {  // pass 1: how many survive (the block must be reserved in one piece)
-            const int e = it * 64 + lane;
-            float mid = 0.0f;
-            const bool hit = e < c.ne && edge_cull(a, c, e, mid);
-            if (it == 0) { hit0 = hit; mid0 = mid; }
-            total += __popcll(__ballot(hit));
-        }
-        int base = 0;
-        if (lane == 0 && total > 0) base = atomicAdd(a.hit_count, total);
-        base = __shfl(base, 0);
-        const int room = a.hit_capacity - base;
-        if (lane == 0) { blk[0] = base; blk[1] = total < room ? total : (room > 0 ? room : 0); }
-        if (total == 0) continue;
-        int at = base;
-        for (int it = 0; it < iters; ++it) {  // pass 2: write (meshes with more than 64 edges cull their later edges again)
-            const int e = it * 64 + lane;
-            float mid = mid0;
-            const bool hit = it == 0 ? hit0 : (e < c.ne && edge_cull(a, c, e, mid));
-            const unsigned long long m = __ballot(hit);
-            const int i = at + __popcll(m & below);
-            if (hit && i < a.hit_capacity) {
-                a.hit_pair[i] = pair_idx;
-                a.hit_fp[i] = (e << 2) | (mode << 1);
-                a.hit_rec[8 * (size_t)i] = mid;
+    const long long cap = a.pair_world_prefix ? (long long)a.worlds * a.pairs_per_world : (long long)a.pair_count;
+    const int plain_live = a.pair_world_prefix ? 0 : live_pair_count(a);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.hit_count[2] = a.hit_stripe_count;  // the stripes this call uses
+    // every wave walks whole rounds (the ballot below needs all 64 lanes)
+    for (long long base = ((long long)blockIdx.x * blockDim.x + threadIdx.x - lane); base < cap; base += (long long)gridDim.x * blockDim.x) {
+        const long long u = base + lane;
+        bool live = u < cap;
+        const int pair_idx = live ? (int)u : 0;
+        if (live) {
+            if (a.pair_world_prefix) {
+                const int w = pair_idx / a.pairs_per_world, k = pair_idx - w * a.pairs_per_world;
+                live = k < a.pair_world_prefix[w + 1] - a.pair_world_prefix[w];
+            } else {
+                live = pair_idx < plain_live;
             }
-            at += __popcll(m);
+        }
+        live = live && !(a.pair_kind && a.pair_kind[pair_idx] != 0);  // another leg's pair
+        bool run[2] = {false, false};
+        ModeCtx c[2];
+        if (live) {
+            int* blk = a.hit_blk + 4 * (size_t)pair_idx;
+            blk[0] = 0; blk[1] = 0; blk[2] = 0; blk[3] = 0;
+            if (a.out_blk) { a.out_blk[2 * (size_t)pair_idx] = 0; a.out_blk[2 * (size_t)pair_idx + 1] = 0; }
+            const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
+            for (int mode = 0; mode < 2; ++mode) {
+                run[mode] = mode_setup(a, s0, s1, mode, c[mode]);
+                if (run[mode] && r.shape_edge_radius_max) {
+                    const int tri_shape = mode == 0 ? s0 : s1;
+                    run[mode] = mode_can_touch(c[mode], r.shape_aabb_lower + 3 * tri_shape, r.shape_aabb_upper + 3 * tri_shape,
+                                               r.shape_edge_radius_max[tri_shape]);
+                }
+            }
+        }
+        const bool any = run[0] || run[1];
+        const unsigned long long m = __ballot(any);
+        int at = 0;
+        if (lane == 0 && m) at = atomicAdd(a.hit_count + CNT_UNITS, __popcll(m));
+        at = __shfl(at, 0) + __popcll(m & below);
+        if (any) {
+            for (int mode = 0; mode < 2; ++mode) {
+                const ModeCtx& k = c[mode];
+                float* o = a.unit_ctx + UNIT_WORDS * (2 * (size_t)at + mode);
+                int* oi = reinterpret_cast<int*>(o);
+                if (!run[mode]) { oi[19] = 0; oi[21] = pair_idx; continue; }  // no edges: the mode is skipped
+                o[0] = k.X_m2s.p.x; o[1] = k.X_m2s.p.y; o[2] = k.X_m2s.p.z;
+                o[3] = k.X_m2s.q.x; o[4] = k.X_m2s.q.y; o[5] = k.X_m2s.q.z; o[6] = k.X_m2s.q.w;
+                o[7] = k.inv_scale.x; o[8] = k.inv_scale.y; o[9] = k.inv_scale.z;
+                o[10] = k.blo.x; o[11] = k.blo.y; o[12] = k.blo.z;
+                o[13] = k.bhi.x; o[14] = k.bhi.y; o[15] = k.bhi.z;
+                o[16] = k.thr_unscaled; o[17] = k.radius_scale;
+                const float margin_sum = k.tri_margin + k.sdf_margin;
+                o[22] = margin_sum + fminw(k.s.voxel_radius * k.min_scale, k.gap_sum);  // the reduction's inner depth (base gap == gap)
+                o[23] = margin_sum + k.gap_sum;                                         // ... and outer depth
+                oi[18] = k.e0; oi[19] = k.ne;
+                oi[20] = a.shape_sdf_index[mode == 0 ? a.pairs[2 * (size_t)pair_idx + 1] : a.pairs[2 * (size_t)pair_idx]];
+                oi[21] = pair_idx;
+            }
         }
     }
 }
-__global__ void __launch_bounds__(256) sdf_resolve_kernel(nt_mesh_sdf_args a) {
-    const int n = *a.hit_count < a.hit_capacity ? *a.hit_count : a.hit_capacity;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+NT_DI void cull_ctx_load(const nt_mesh_sdf_args& a, const float* o, CullCtx& c) {
+    const int* oi = reinterpret_cast<const int*>(o);
+    c.ne = oi[19];
+    if (c.ne == 0) return;
+    c.X_m2s = xform(vec3(o[0], o[1], o[2]), quat(o[3], o[4], o[5], o[6]));
+    c.inv_scale = vec3(o[7], o[8], o[9]);
+    c.blo = vec3(o[10], o[11], o[12]);
+    c.bhi = vec3(o[13], o[14], o[15]);
+    c.thr_unscaled = o[16];
+    c.radius_scale = o[17];
+    c.e0 = oi[18];
+    c.s = a.sdf_table[oi[20]];
+}
+__global__ void __launch_bounds__(256) sdf_cull_kernel(nt_mesh_sdf_args a) {
+    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int units = a.hit_count[CNT_UNITS];
+    const int wave_id = blockIdx.x * waves + (threadIdx.x >> 6);
+    const int stripe = wave_id % a.hit_stripe_count;
+    const int slice = a.hit_capacity / a.hit_stripe_count;
+    for (int u = wave_id; u < units; u += gridDim.x * waves) {
+        const float* o = a.unit_ctx + UNIT_WORDS * 2 * (size_t)u;
+        const int pair_idx = reinterpret_cast<const int*>(o)[21];
+        bool hit0[2] = {false, false};
+        float mid0[2] = {0.0f, 0.0f};
+        int total[2] = {0, 0};
+        for (int mode = 0; mode < 2; ++mode) {  // pass 1: how many survive (the pair's block is reserved in one piece)
+            CullCtx c;
+            cull_ctx_load(a, o + UNIT_WORDS * mode, c);
+            const int iters = (c.ne + 63) >> 6;
+            for (int it = 0; it < iters; ++it) {
+                const int e = it * 64 + lane;
+                float mid = 0.0f;
+                const bool hit = e < c.ne && edge_cull(a, c, e, mid);
+                if (it == 0) { hit0[mode] = hit; mid0[mode] = mid; }
+                total[mode] += __popcll(__ballot(hit));
+            }
+        }
+        const int sum = total[0] + total[1];
+        if (sum == 0) continue;  // wave-uniform; the pair's block entry is already zero
+        int base = 0;
+        if (lane == 0) {
+            const int at = atomicAdd(a.hit_stripes + STRIPE_PAD * stripe, sum);
+            int room = slice - at;
+            room = room < 0 ? 0 : room;
+            if (room < sum) atomicAdd(a.hit_count, sum - room);  // dropped survivors: reported, the caller sizes the list up
+            base = stripe * slice + at;
+            int* blk = a.hit_blk + 4 * (size_t)pair_idx;
+            const int n0 = total[0] < room ? total[0] : room, n1 = total[1] < room - n0 ? total[1] : room - n0;
+            blk[0] = base; blk[1] = n0; blk[2] = base + n0; blk[3] = n1;
+        }
+        base = __shfl(base, 0);
+        const int end = (stripe + 1) * slice;
+        int at = base;
+        for (int mode = 0; mode < 2; ++mode) {  // pass 2: write (meshes with more than 64 edges cull their later edges again)
+            if (total[mode] == 0) continue;
+            CullCtx c;
+            cull_ctx_load(a, o + UNIT_WORDS * mode, c);
+            const int iters = (c.ne + 63) >> 6;
+            for (int it = 0; it < iters; ++it) {
+                const int e = it * 64 + lane;
+                float mid = mid0[mode];
+                const bool hit = it == 0 ? hit0[mode] : (e < c.ne && edge_cull(a, c, e, mid));
+                const unsigned long long m = __ballot(hit);
+                const int i = at + __popcll(m & below);
+                if (hit && i < end) {
+                    a.hit_pair[i] = pair_idx;
+                    a.hit_fp[i] = (e << 2) | (mode << 1);
+                    a.hit_rec[8 * (size_t)i] = mid;
+                }
+                at += __popcll(m);
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) sdf_resolve_kernel(nt_mesh_sdf_args a) {  // grid = stripes x blocks per stripe
+    const int stripe = blockIdx.x % a.hit_stripe_count, xb = blockIdx.x / a.hit_stripe_count, nxb = gridDim.x / a.hit_stripe_count;
+    const int slice = a.hit_capacity / a.hit_stripe_count;
+    int n = a.hit_stripes[STRIPE_PAD * stripe];
+    n = n < slice ? n : slice;
+    for (int j = xb * blockDim.x + threadIdx.x; j < n; j += nxb * blockDim.x) {
+        const int i = stripe * slice + j;
         const int pair_idx = a.hit_pair[i], fp = a.hit_fp[i], mode = (fp >> 1) & 1;
         ModeCtx c;
         mode_setup(a, a.pairs[2 * (size_t)pair_idx], a.pairs[2 * (size_t)pair_idx + 1], mode, c);
@@ -895,49 +1006,58 @@ __global__ void __launch_bounds__(256) sdf_resolve_kernel(nt_mesh_sdf_args a) {
         }
     }
 }
+constexpr int RED_FP_CACHE = 128;  // fingerprints of a pair's survivors kept in LDS for the winners' lookup
 __global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
     __shared__ RedLds L;
+    __shared__ int hfp[RED_FP_CACHE];
+    __shared__ int any;
     const int t = threadIdx.x;
-    const int pair_count = live_pair_count(a);
-    for (int f = blockIdx.x; f < pair_count; f += gridDim.x) {
-        const int pair_idx = pair_slot(a, f);
-        if (a.pair_kind && a.pair_kind[pair_idx] != 0) continue;  // another leg's pair (uniform)
+    const int units = a.hit_count[CNT_UNITS];
+    for (int f = blockIdx.x; f < units; f += gridDim.x) {
+        const int pair_idx = reinterpret_cast<const int*>(a.unit_ctx + UNIT_WORDS * 2 * (size_t)f)[21];
         const int* blk = a.hit_blk + 4 * (size_t)pair_idx;
-        if (blk[1] + blk[3] == 0) {  // no edge survived the cull: no rows (uniform)
-            if (t == 0 && a.out_blk) { a.out_blk[2 * (size_t)pair_idx] = 0; a.out_blk[2 * (size_t)pair_idx + 1] = 0; }
-            continue;
-        }
+        const int off0 = blk[0], cnt0 = blk[1], off1 = blk[2], cnt1 = blk[3];
+        if (cnt0 + cnt1 == 0) continue;  // no edge survived the cull: no rows (uniform; out_blk is already zero)
         const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
         for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
+        if (t == 0) any = 0;
         __syncthreads();
+        const xform X0 = load_xform(a.shape_transform + 7 * s0), X1 = load_xform(a.shape_transform + 7 * s1);
+        const vec3 midpoint = (X0.p + X1.p) * 0.5f;  // (X_tri.p + X_sdf.p) / 2 of either mode
         for (int mode = 0; mode < 2; ++mode) {
-            const int off = blk[2 * mode], cnt = blk[2 * mode + 1];
+            const int off = mode == 0 ? off0 : off1, cnt = mode == 0 ? cnt0 : cnt1;
             if (cnt == 0) continue;
-            ModeCtx c;
-            mode_setup(a, s0, s1, mode, c);
+            const float* uc = a.unit_ctx + UNIT_WORDS * (2 * (size_t)f + mode);
+            const float inner_depth = uc[22], outer_depth = uc[23];
             const int tri_shape = mode == 0 ? s0 : s1;
-            const vec3 midpoint = (c.X_tri.p + c.X_sdf.p) * 0.5f;
-            const float margin_sum = c.tri_margin + c.sdf_margin;
-            const float inner_depth = margin_sum + fminw(c.s.voxel_radius * c.min_scale, c.gap_sum);  // base gap == gap
-            const float outer_depth = margin_sum + c.gap_sum;
-            for (int i = off + t; i < off + cnt; i += blockDim.x) {
-                const int fp = a.hit_fp[i];
+            const xform X_tri = mode == 0 ? X0 : X1;
+            for (int j = t; j < cnt; j += blockDim.x) {
+                const int i = off + j, fp = a.hit_fp[i];
+                const int h = (mode == 0 ? 0 : cnt0) + j;  // position among the pair's survivors
+                if (h < RED_FP_CACHE) hfp[h] = fp;
                 if (fp < 0) continue;
                 const float* rec = a.hit_rec + 8 * (size_t)i;
                 const vec3 pw(rec[0], rec[1], rec[2]), nrm(rec[4], rec[5], rec[6]);
-                const vec3 local = quat_rotate_inv(c.X_tri.q, pw - c.X_tri.p);
+                const vec3 local = quat_rotate_inv(X_tri.q, pw - X_tri.p);
+                if (rec[3] < outer_depth) any = 1;  // benign race: every writer stores 1
                 red_offer(L.tbl, nrm, pw - midpoint, rec[3], inner_depth, outer_depth, local, r.shape_aabb_lower + 3 * tri_shape,
                           r.shape_aabb_upper + 3 * tri_shape, r.shape_voxel_res + 3 * tri_shape, fp);
             }
         }
         __syncthreads();
+        if (!any) {  // every survivor was rejected by the search or lies beyond the outer depth: no rows (uniform; out_blk is zero)
+            __syncthreads();
+            continue;
+        }
         for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k: its record from the pair's blocks
             if (L.tbl[k] == 0ull) continue;
             const int fp = (int)(L.tbl[k] & RED_FP_MASK);
-            const int mode = (fp >> 1) & 1;
-            int i = blk[2 * mode];
-            while (a.hit_fp[i] != fp) ++i;  // it is there: the table only holds fingerprints offered from these blocks
-            const float* rec = a.hit_rec + 8 * (size_t)i;
+            const int total = cnt0 + cnt1, cached = total < RED_FP_CACHE ? total : RED_FP_CACHE;
+            int h = 0;
+            while (h < cached && hfp[h] != fp) ++h;
+            if (h == cached)  // beyond the cache: the table only holds fingerprints offered from these blocks, so it is there
+                while (a.hit_fp[h < cnt0 ? off0 + h : off1 + (h - cnt0)] != fp) ++h;
+            const float* rec = a.hit_rec + 8 * (size_t)(h < cnt0 ? off0 + h : off1 + (h - cnt0));
             L.pos[k][0] = rec[0]; L.pos[k][1] = rec[1]; L.pos[k][2] = rec[2]; L.pos[k][3] = rec[3];
             red_encode_oct(vec3(rec[4], rec[5], rec[6]), L.oct[k][0], L.oct[k][1]);
             L.fp[k] = fp;
@@ -945,11 +1065,12 @@ __global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_
         __syncthreads();
         red_finish(L);
         if (t == 0) {
-            L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
-            if (a.out_blk) {  // the pair's block: rows past the capacity do not exist for the consumers
-                const int room = a.capacity - L.base;
-                a.out_blk[2 * (size_t)pair_idx] = L.base;
-                a.out_blk[2 * (size_t)pair_idx + 1] = L.total < room ? L.total : (room > 0 ? room : 0);
+            if (a.out_blk) {  // the pair's rows start where its survivors do (rows <= survivors): no counter
+                L.base = off0;
+                a.out_blk[2 * (size_t)pair_idx] = off0;
+                a.out_blk[2 * (size_t)pair_idx + 1] = L.total;
+            } else {
+                L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
             }
         }
         __syncthreads();
@@ -1591,22 +1712,38 @@ nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* a, const nt_contac
         const long long cap = (long long)a->worlds * a->pairs_per_world;
         blocks = cap < 16384 ? (int)cap : 16384;
     }
-    if (a->hit_count) {  // the staged variant: cull -> resolve -> reduce, each dense over its own population
-        if (!a->hit_pair || !a->hit_fp || !a->hit_rec || !a->hit_blk || a->hit_capacity <= 0) return NT_ERR_INVALID_ARG;
-        if (hipMemsetAsync(a->hit_count, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return NT_ERR_LAUNCH;
-        const long long units = 2 * (a->pair_world_prefix ? (long long)a->worlds * a->pairs_per_world : (long long)a->pair_count);
+    if (a->hit_count) {  // the staged variant: units -> cull -> resolve -> reduce, each dense over its own population
+        if (!a->hit_pair || !a->hit_fp || !a->hit_rec || !a->hit_blk || a->hit_capacity <= 0 || !a->unit_ctx || !a->hit_stripes ||
+            a->hit_stripe_count <= 0 || a->hit_capacity < a->hit_stripe_count)
+            return NT_ERR_INVALID_ARG;
+        // with out_blk the rows live in the survivor list's index space: the row arrays must span it
+        if (a->out_blk && a->capacity < a->hit_capacity) return NT_ERR_INVALID_ARG;
+        nt_mesh_sdf_args k = *a;
         // grid-stride kernels: the grids only bound the parallelism (tests/emu runs every lane as an OS thread and caps them)
 #ifdef NT_EMULATED_GRID
-        const long long cull_cap = NT_EMULATED_GRID, res_cap = NT_EMULATED_GRID;
+        const long long grid_cap = NT_EMULATED_GRID;
         if (blocks > NT_EMULATED_GRID) blocks = NT_EMULATED_GRID;
+        if (k.hit_stripe_count > 3) k.hit_stripe_count = 3;
 #else
-        const long long cull_cap = 8192, res_cap = 4096;
+        const long long grid_cap = 8192;
 #endif
-        const int cull_blocks = (int)((units + 3) / 4 < cull_cap ? (units + 3) / 4 : cull_cap);  // 4 waves = 4 (pair, mode) units per workgroup
-        hipLaunchKernelGGL(sdf_cull_kernel, dim3(cull_blocks), dim3(256), 0, (hipStream_t)stream, *a, *r);
-        const long long res_blocks = ((long long)a->hit_capacity + 255) / 256;
-        hipLaunchKernelGGL(sdf_resolve_kernel, dim3((int)(res_blocks < res_cap ? res_blocks : res_cap)), dim3(256), 0, (hipStream_t)stream, *a);
-        hipLaunchKernelGGL(sdf_reduce_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *a, *r);
+        const long long pairs = k.pair_world_prefix ? (long long)k.worlds * k.pairs_per_world : (long long)k.pair_count;
+        auto grid = [&](long long work_items, int per_block) {
+            const long long b = (work_items + per_block - 1) / per_block;
+            return (unsigned)(b < 1 ? 1 : (b < grid_cap ? b : grid_cap));
+        };
+        // every stripe is shared by at least 8 of the cull kernel's waves (a small scene uses one stripe = the whole list);
+        // the units kernel leaves the count in hit_count[2]
+        const long long cull_waves = 4ll * grid(pairs, 4);
+        if (k.hit_stripe_count > cull_waves / 8) k.hit_stripe_count = (int)(cull_waves / 8 > 1 ? cull_waves / 8 : 1);
+        hipStream_t st = (hipStream_t)stream;
+        if (hipMemsetAsync(k.hit_count, 0, 4 * sizeof(int32_t), st) != hipSuccess ||
+            hipMemsetAsync(k.hit_stripes, 0, (size_t)a->hit_stripe_count * STRIPE_PAD * sizeof(int32_t), st) != hipSuccess)
+            return NT_ERR_LAUNCH;
+        hipLaunchKernelGGL(sdf_units_kernel, dim3(grid(pairs, 256)), dim3(256), 0, st, k, *r);
+        hipLaunchKernelGGL(sdf_cull_kernel, dim3(grid(pairs, 4)), dim3(256), 0, st, k);  // one wave per runnable pair
+        hipLaunchKernelGGL(sdf_resolve_kernel, dim3(grid(k.hit_capacity / k.hit_stripe_count, 256) * k.hit_stripe_count), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(sdf_reduce_kernel, dim3(blocks), dim3(64), 0, st, k, *r);
         return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(mesh_sdf_collide_reduced_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, *a, *r);

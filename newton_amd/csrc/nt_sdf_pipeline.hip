@@ -152,61 +152,81 @@ NT_DI xform body_xform(const float* body_q, int nb, int ES, int b, int env) {  /
     return xform(vec3(at(0), at(1), at(2)), quat(at(3), at(4), at(5), at(6)));
 }
 
-// write_contact (collide.py:166-254) of every raw ContactData row at its final, deterministic position
+// write_contact (collide.py:166-254) of one raw ContactData row i of pair position idx (world w) at its final, deterministic position
+NT_DI void write_row(const nt_sdf_scene& sc, const nt_sdf_rows_io& io, const float* __restrict__ body_q, int idx, int w, int i,
+                     int rank, bool hydro) {
+    if (rank >= io.blk[2 * (size_t)idx + 1]) return;
+    const int dst = io.row_start[w] + io.pair_row[idx] + rank;
+    if (dst >= io.row_capacity) return;
+    const int shape_a = io.world_pairs[2 * (size_t)idx], shape_b = io.world_pairs[2 * (size_t)idx + 1];
+    const float* d = io.raw_data + 9 * (size_t)i;
+    const float dist = d[6], margin_a = d[7], margin_b = d[8];
+    const float ra = 0.0f, rb = 0.0f;  // SDF / mesh shapes have no effective radius (compute_effective_radius)
+    const float total = ra + rb + margin_a + margin_b;
+    const vec3 nab = normalize(ld3(d + 3));
+    const vec3 center = ld3(d);
+    const vec3 aw = center - nab * (0.5f * dist + ra);
+    const vec3 bw = center + nab * (0.5f * dist + rb);
+    const float sep = dot(bw - aw, nab) - total;
+    int sa = -1, sb = -1;
+    vec3 p0, p1, o0, o1, nrm;
+    float m0 = 0.0f, m1 = 0.0f;
+    // decode_contacts_kernel hands its rows to the writer with a reserved index: no gap test (collide.py:246-252)
+    if (hydro || !(sep > sc.shape_gap[shape_a] + sc.shape_gap[shape_b])) {
+        sa = shape_a;
+        sb = shape_b;
+        const int ba = shape_body_of(sc, sa, w), bb = shape_body_of(sc, sb, w);
+        const xform Xa = ba < 0 ? xform() : xform_inverse(body_xform(body_q, sc.nb, sc.env_stride, ba, w));
+        const xform Xb = bb < 0 ? xform() : xform_inverse(body_xform(body_q, sc.nb, sc.env_stride, bb, w));
+        m0 = ra + margin_a;
+        m1 = rb + margin_b;
+        p0 = xform_point(Xa, aw);
+        p1 = xform_point(Xb, bw);
+        o0 = xform_vector(Xa, m0 * nab);
+        o1 = xform_vector(Xb, -m1 * nab);
+        nrm = nab;
+    }
+    io.shape0[dst] = sa;
+    io.shape1[dst] = sb;
+    st3(io.point0 + 3 * (size_t)dst, p0);
+    st3(io.point1 + 3 * (size_t)dst, p1);
+    st3(io.offset0 + 3 * (size_t)dst, o0);
+    st3(io.offset1 + 3 * (size_t)dst, o1);
+    st3(io.normal + 3 * (size_t)dst, nrm);
+    io.margin0[dst] = m0;
+    io.margin1[dst] = m1;
+    if (io.key) io.key[dst] = io.raw_key[i];
+    if (io.stiffness) {
+        io.stiffness[dst] = hydro && io.raw_stiffness ? io.raw_stiffness[i] : 0.0f;
+        io.damping[dst] = 0.0f;
+        io.friction_scale[dst] = 0.0f;
+    }
+}
+// Raw rows come in two regions: [0, raw_base) holds the blocks the staged narrow phase wrote at the start of each pair's survivor
+// block (gaps in between: walked pair by pair, eight lanes per candidate position); [raw_base, *raw_count) holds rows appended
+// through the counter (single-kernel narrow phase, hydroelastic leg: ranked), one lane per row.
 __global__ void __launch_bounds__(256) sdf_rows_write_kernel(nt_sdf_scene sc, nt_sdf_rows_io io, const float* __restrict__ body_q) {
+    if (io.raw_base > 0) {
+        const long long groups = (long long)sc.env_count * sc.pairs_per_world;
+        const int sub = threadIdx.x & 7;
+        for (long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; g < groups; g += ((long long)gridDim.x * blockDim.x) >> 3) {
+            const int idx = (int)g;  // world * PPW + k
+            const int w = idx / sc.pairs_per_world;
+            int live = io.pair_count[w];
+            live = live < sc.pairs_per_world ? live : sc.pairs_per_world;
+            if (idx - w * sc.pairs_per_world >= live) continue;
+            if (sc.template_kind && sc.world_pair_kind[idx] == 1) continue;  // appended rows
+            const int off = io.blk[2 * (size_t)idx], cnt = io.blk[2 * (size_t)idx + 1];
+            for (int i = off + sub; i < off + cnt && i < io.raw_base; i += 8) write_row(sc, io, body_q, idx, w, i, i - off, false);
+        }
+    }
     int n = *io.raw_count;
     n = n < io.raw_capacity ? n : io.raw_capacity;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = io.raw_base + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int idx = io.raw_pair[i];  // world * PPW + k
         const int w = idx / sc.pairs_per_world;
         const bool hydro = sc.template_kind && sc.world_pair_kind[idx] == 1;  // rows of nt_hydro_pairs: ranked, pre-admitted
-        const int rank = hydro ? io.raw_rank[i] : i - io.blk[2 * (size_t)idx];
-        if (rank >= io.blk[2 * (size_t)idx + 1]) continue;
-        const int dst = io.row_start[w] + io.pair_row[idx] + rank;
-        if (dst >= io.row_capacity) continue;
-        const int shape_a = io.world_pairs[2 * (size_t)idx], shape_b = io.world_pairs[2 * (size_t)idx + 1];
-        const float* d = io.raw_data + 9 * (size_t)i;
-        const float dist = d[6], margin_a = d[7], margin_b = d[8];
-        const float ra = 0.0f, rb = 0.0f;  // SDF / mesh shapes have no effective radius (compute_effective_radius)
-        const float total = ra + rb + margin_a + margin_b;
-        const vec3 nab = normalize(ld3(d + 3));
-        const vec3 center = ld3(d);
-        const vec3 aw = center - nab * (0.5f * dist + ra);
-        const vec3 bw = center + nab * (0.5f * dist + rb);
-        const float sep = dot(bw - aw, nab) - total;
-        int sa = -1, sb = -1;
-        vec3 p0, p1, o0, o1, nrm;
-        float m0 = 0.0f, m1 = 0.0f;
-        // decode_contacts_kernel hands its rows to the writer with a reserved index: no gap test (collide.py:246-252)
-        if (hydro || !(sep > sc.shape_gap[shape_a] + sc.shape_gap[shape_b])) {
-            sa = shape_a;
-            sb = shape_b;
-            const int ba = shape_body_of(sc, sa, w), bb = shape_body_of(sc, sb, w);
-            const xform Xa = ba < 0 ? xform() : xform_inverse(body_xform(body_q, sc.nb, sc.env_stride, ba, w));
-            const xform Xb = bb < 0 ? xform() : xform_inverse(body_xform(body_q, sc.nb, sc.env_stride, bb, w));
-            m0 = ra + margin_a;
-            m1 = rb + margin_b;
-            p0 = xform_point(Xa, aw);
-            p1 = xform_point(Xb, bw);
-            o0 = xform_vector(Xa, m0 * nab);
-            o1 = xform_vector(Xb, -m1 * nab);
-            nrm = nab;
-        }
-        io.shape0[dst] = sa;
-        io.shape1[dst] = sb;
-        st3(io.point0 + 3 * (size_t)dst, p0);
-        st3(io.point1 + 3 * (size_t)dst, p1);
-        st3(io.offset0 + 3 * (size_t)dst, o0);
-        st3(io.offset1 + 3 * (size_t)dst, o1);
-        st3(io.normal + 3 * (size_t)dst, nrm);
-        io.margin0[dst] = m0;
-        io.margin1[dst] = m1;
-        if (io.key) io.key[dst] = io.raw_key[i];
-        if (io.stiffness) {
-            io.stiffness[dst] = hydro && io.raw_stiffness ? io.raw_stiffness[i] : 0.0f;
-            io.damping[dst] = 0.0f;
-            io.friction_scale[dst] = 0.0f;
-        }
+        write_row(sc, io, body_q, idx, w, i, hydro ? io.raw_rank[i] : i - io.blk[2 * (size_t)idx], hydro);
     }
 }
 
@@ -397,8 +417,12 @@ nt_status nt_sdf_rows_finalize(const nt_sdf_scene* sc, const nt_sdf_rows_io* io,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sdf_world_rows_kernel, dim3(sc->env_count), dim3(256), 0, st, *sc, io->pair_count, io->blk, io->pair_row, world_rows);
     hipLaunchKernelGGL(scan_worlds_kernel, dim3(1), dim3(1024), 0, st, world_rows, io->row_start, sc->env_count, 0x7fffffff);
-    int blocks = (io->raw_capacity + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    long long wb = ((long long)sc->env_count * sc->pairs_per_world * 8 + 255) / 256;
+#ifdef NT_EMULATED_GRID
+    int blocks = (int)(wb < NT_EMULATED_GRID ? wb : NT_EMULATED_GRID);
+#else
+    int blocks = (int)(wb < 16384 ? wb : 16384);
+#endif
     hipLaunchKernelGGL(sdf_rows_write_kernel, dim3(blocks), dim3(256), 0, st, *sc, *io, body_q);
     hipLaunchKernelGGL(sdf_body_blocks_kernel, dim3(sc->env_count), dim3(256), 0, st, *sc, *io, body_blk_start, body_blk_list);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;

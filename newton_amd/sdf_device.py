@@ -107,17 +107,25 @@ def mesh_sdf_collide(pairs, shape_transform, shape_data, shape_gap, shape_sdf_in
         r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = t_lo.data_ptr(), t_hi.data_ptr(), t_res.data_ptr()
         if staged:
             er = np.asarray(shape_edge_range, dtype=np.int64).reshape(-1, 2)
-            hcap = int(sum(er[p, 1] + er[q, 1] for p, q in pairs_np)) + 1  # at most every edge of both modes survives
-            h_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            stripes = 4
+            # at most every edge of both modes survives; four times that, so that no stripe of an uneven deal runs full
+            hcap = (int(sum(er[p, 1] + er[q, 1] for p, q in pairs_np)) + stripes) * 4 // stripes * stripes
+            npairs = max(len(pairs_np), 1)
+            h_count = torch.zeros(4, dtype=torch.int32, device=dev)
+            h_stripes = torch.zeros(stripes * 16, dtype=torch.int32, device=dev)
+            u_ctx = torch.zeros((npairs, 2, 24), dtype=torch.float32, device=dev)
             h_pair, h_fp = torch.zeros(hcap, dtype=torch.int32, device=dev), torch.zeros(hcap, dtype=torch.int32, device=dev)
             h_rec = torch.zeros((hcap, 8), dtype=torch.float32, device=dev)
-            h_blk = torch.zeros((max(len(pairs_np), 1), 2, 2), dtype=torch.int32, device=dev)
-            a.hit_count, a.hit_pair, a.hit_fp, a.hit_rec, a.hit_blk, a.hit_capacity = (
-                h_count.data_ptr(), h_pair.data_ptr(), h_fp.data_ptr(), h_rec.data_ptr(), h_blk.data_ptr(), hcap)
+            h_blk = torch.zeros((npairs, 2, 2), dtype=torch.int32, device=dev)
+            a.hit_count, a.hit_stripes, a.hit_stripe_count, a.hit_capacity = h_count.data_ptr(), h_stripes.data_ptr(), stripes, hcap
+            a.hit_pair, a.hit_fp, a.hit_rec, a.hit_blk, a.unit_ctx = (h_pair.data_ptr(), h_fp.data_ptr(), h_rec.data_ptr(),
+                                                                      h_blk.data_ptr(), u_ctx.data_ptr())
         _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
     else:
         _lib.check(lib.nt_mesh_sdf_collide(C.byref(a), stream), "nt_mesh_sdf_collide")
     torch.cuda.current_stream(dev).synchronize()
+    if reduce is not None and staged and int(h_count[0].item()) != 0:
+        raise RuntimeError("staged mesh-SDF narrow phase dropped survivors (a stripe of the list ran full)")
     n_total = int(count.item())
     n = min(n_total, capacity)
     pair, key, data = o_pair[:n].cpu().numpy(), o_key[:n].cpu().numpy(), o_data[:n].cpu().numpy()

@@ -155,20 +155,27 @@ class SdfLeg:
         self.pair_row = torch.zeros(E * PPW, dtype=i32, device=dev)
         self.world_rows = torch.zeros(E, dtype=i32, device=dev)
         self.raw_count = torch.zeros(1, dtype=i32, device=dev)
-        self.raw_pair = torch.zeros(self.row_capacity, dtype=i32, device=dev)
-        self.raw_key = torch.zeros(self.row_capacity, dtype=i32, device=dev)
-        self.raw_data = torch.zeros((self.row_capacity, 9), dtype=f32, device=dev)
-        # staged narrow phase (cull -> resolve -> reduce): the list of culling survivors over all pairs
+        # staged narrow phase (units -> cull -> resolve -> reduce): the list of culling survivors over all pairs, in stripes; the
+        # reduced rows of a pair are written from the start of its survivor block, so the raw row arrays span the list (the
+        # hydroelastic leg appends its rows behind it through the counter)
         self.staged = bool(staged) and os.environ.get("NT_SDF_STAGED", "1") != "0"
-        self.hit_capacity = self.row_capacity * int(survivors_per_row) if self.staged else 0
+        self.hit_stripe_count = 1024
+        self.hit_capacity = 0
         if self.staged:
-            self.hit_count = torch.zeros(1, dtype=i32, device=dev)
+            self.hit_capacity = -(-self.row_capacity * int(survivors_per_row) // self.hit_stripe_count) * self.hit_stripe_count
+            self.hit_count = torch.zeros(4, dtype=i32, device=dev)
+            self.hit_stripes = torch.zeros(self.hit_stripe_count * 16, dtype=i32, device=dev)
+            self.unit_ctx = torch.zeros((E * PPW, 2, 24), dtype=f32, device=dev)
             self.hit_pair = torch.zeros(self.hit_capacity, dtype=i32, device=dev)
             self.hit_fp = torch.zeros(self.hit_capacity, dtype=i32, device=dev)
             self.hit_rec = torch.zeros((self.hit_capacity, 8), dtype=f32, device=dev)
             self.hit_blk = torch.zeros((E * PPW, 2, 2), dtype=i32, device=dev)
-        self.raw_rank = torch.zeros(self.row_capacity if self.has_hydro_pairs else 1, dtype=i32, device=dev)
-        self.raw_stiffness = torch.zeros(self.row_capacity if self.has_hydro_pairs else 1, dtype=f32, device=dev)
+        self.raw_capacity = self.hit_capacity + self.row_capacity
+        self.raw_pair = torch.zeros(self.raw_capacity, dtype=i32, device=dev)
+        self.raw_key = torch.zeros(self.raw_capacity, dtype=i32, device=dev)
+        self.raw_data = torch.zeros((self.raw_capacity, 9), dtype=f32, device=dev)
+        self.raw_rank = torch.zeros(self.raw_capacity if self.has_hydro_pairs else 1, dtype=i32, device=dev)
+        self.raw_stiffness = torch.zeros(self.raw_capacity if self.has_hydro_pairs else 1, dtype=f32, device=dev)
 
     def new_rows(self, per_contact_shape_properties: bool = False) -> FlatRows:
         # hydroelastic rows carry Contacts.rigid_contact_stiffness: allocated whenever the leg can produce them
@@ -185,7 +192,7 @@ class SdfLeg:
         _lib.check(lib.nt_sdf_candidate_pairs(C.byref(sc), self.aabb_lower.data_ptr(), self.aabb_upper.data_ptr(),
                                               self.world_pairs.data_ptr(), self.pair_count.data_ptr(), self.pair_prefix.data_ptr(),
                                               stream), "nt_sdf_candidate_pairs")
-        self.raw_count.zero_()
+        self.raw_count.fill_(self.hit_capacity)  # rows appended through the counter (single kernel, hydroelastic leg) start here
         a = _lib.nt_mesh_sdf_args()
         a.pairs, a.pair_count = self.world_pairs.data_ptr(), int(self.world_pairs.shape[0])
         a.shape_transform, a.shape_data, a.shape_gap = self.world_xform.data_ptr(), self._shape_data.data_ptr(), self._shape_gap.data_ptr()
@@ -194,7 +201,7 @@ class SdfLeg:
                                                              self._edge_halves.data_ptr())
         a.out_count, a.out_pair, a.out_key, a.out_data = (self.raw_count.data_ptr(), self.raw_pair.data_ptr(),
                                                           self.raw_key.data_ptr(), self.raw_data.data_ptr())
-        a.capacity = self.row_capacity
+        a.capacity = self.raw_capacity
         a.pair_world_prefix, a.worlds, a.pairs_per_world, a.out_blk = (self.pair_prefix.data_ptr(), sc.env_count,
                                                                        sc.pairs_per_world, self.blk.data_ptr())
         r = _lib.nt_contact_reduce_shapes()
@@ -203,9 +210,11 @@ class SdfLeg:
         if self.has_hydro_pairs:
             a.pair_kind = self.world_pair_kind.data_ptr()
         if self.staged:
-            a.hit_count, a.hit_pair, a.hit_fp, a.hit_rec, a.hit_blk, a.hit_capacity = (
-                self.hit_count.data_ptr(), self.hit_pair.data_ptr(), self.hit_fp.data_ptr(), self.hit_rec.data_ptr(),
-                self.hit_blk.data_ptr(), self.hit_capacity)
+            a.hit_count, a.hit_stripes, a.hit_stripe_count, a.hit_capacity = (
+                self.hit_count.data_ptr(), self.hit_stripes.data_ptr(), self.hit_stripe_count, self.hit_capacity)
+            a.hit_pair, a.hit_fp, a.hit_rec, a.hit_blk, a.unit_ctx = (
+                self.hit_pair.data_ptr(), self.hit_fp.data_ptr(), self.hit_rec.data_ptr(), self.hit_blk.data_ptr(),
+                self.unit_ctx.data_ptr())
         if not bool(np.all(self.t.sdf_pair_hydro)) or not self.has_hydro_pairs:
             _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
         if self.has_hydro_pairs:
@@ -218,7 +227,7 @@ class SdfLeg:
             h.margin_contact_area, h.edge_clamp_min = float(self.hydro.margin_contact_area), float(self.hydro.mc_edge_clamp_min)
             h.out_count, h.out_pair, h.out_key, h.out_data, h.capacity = (self.raw_count.data_ptr(), self.raw_pair.data_ptr(),
                                                                           self.raw_key.data_ptr(), self.raw_data.data_ptr(),
-                                                                          self.row_capacity)
+                                                                          self.raw_capacity)
             h.pair_world_prefix, h.worlds, h.pairs_per_world = self.pair_prefix.data_ptr(), sc.env_count, sc.pairs_per_world
             h.pair_kind, h.out_pairs_normalized, h.out_blk = (self.world_pair_kind.data_ptr(), self.world_pairs.data_ptr(),
                                                               self.blk.data_ptr())
@@ -230,7 +239,8 @@ class SdfLeg:
         io.row_start, io.raw_count, io.raw_pair, io.raw_key, io.raw_data = (rows.row_start.data_ptr(), self.raw_count.data_ptr(),
                                                                             self.raw_pair.data_ptr(), self.raw_key.data_ptr(),
                                                                             self.raw_data.data_ptr())
-        io.raw_capacity, io.row_capacity = self.row_capacity, rows.capacity
+        io.raw_capacity, io.row_capacity = self.raw_capacity, rows.capacity
+        io.raw_base = self.hit_capacity
         for k in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1", "key"):
             setattr(io, k, getattr(rows, k).data_ptr())
         if self.has_hydro_pairs:
@@ -244,11 +254,20 @@ class SdfLeg:
     def overflow(self, rows: FlatRows) -> dict:
         """Host check (tests / benches, synchronises): did any world exceed its candidate capacity, or the rows their buffer?"""
         pc = int(self.pair_count.max().item()) if self.pair_count.numel() else 0
-        raw, total = int(self.raw_count.item()), int(rows.row_start[-1].item())
-        hits = int(self.hit_count.item()) if self.staged else 0
-        return {"pairs_per_world_max": pc, "pairs_per_world_capacity": self.pairs_per_world, "raw_rows": raw, "rows": total,
-                "row_capacity": rows.capacity, "cull_survivors": hits, "survivor_capacity": self.hit_capacity,
-                "overflow": pc > self.pairs_per_world or raw > self.row_capacity or total > rows.capacity or hits > self.hit_capacity}
+        appended = int(self.raw_count.item()) - self.hit_capacity  # rows that came through the counter
+        total = int(rows.row_start[-1].item())
+        info = {"pairs_per_world_max": pc, "pairs_per_world_capacity": self.pairs_per_world, "appended_rows": appended,
+                "rows": total, "row_capacity": rows.capacity}
+        over = pc > self.pairs_per_world or appended > self.row_capacity or total > rows.capacity
+        if self.staged:
+            fill = self.hit_stripes[::16]
+            info["cull_survivors"], info["survivor_capacity"] = int(fill.sum().item()), self.hit_capacity
+            info["stripe_fill_max"] = int(fill.max().item())
+            info["stripe_capacity"] = self.hit_capacity // max(int(self.hit_count[2].item()), 1)
+            info["dropped_survivors"] = int(self.hit_count[0].item())
+            over = over or info["dropped_survivors"] > 0
+        info["overflow"] = bool(over)
+        return info
 
     def add_forces(self, state, rows: FlatRows, body_f, friction_smoothing: float, stream) -> None:
         """eval_body_contact over the rows, ordered per-body sums ADDED to `body_f` (env-major [6][nb][ES])."""

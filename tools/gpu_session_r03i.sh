@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-3 GPU session I: staged SDF narrow phase with striped survivor list, rows in survivor space; population statistics.
+set -u
+R=$PWD; O=$R/gpurun_out; mkdir -p $O
+export TMPDIR=/tmp
+( timeout 900 python -m pytest tests -m gpu -q -k "sdf or hydro" 2>&1 | tail -15 ) > $O/r03i_gputests_sdf.log
+( timeout 600 python bench.py --no-cpu-baseline --workload sdf_bin --steps 10 --warmup 3 2>&1 | grep -v amdgpu.ids | tail -1 ) > $O/r03i_bench_sdf_bin_staged.json
+( timeout 600 python tools/sdf_leg_stats.py 2048 40 2>&1 | grep -v amdgpu.ids | tail -1 ) > $O/r03i_sdf_leg_stats.json
+( timeout 600 python bench.py --no-cpu-baseline --workload hydro_bin --steps 5 --warmup 2 2>&1 | grep -v amdgpu.ids | tail -1 ) > $O/r03i_bench_hydro_bin.json
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/r03i_prof -o sdf --output-format csv -- python $R/bench.py --no-cpu-baseline --workload sdf_bin --steps 5 --warmup 2 > $O/r03i_prof.log 2>&1
+f=$(find $O/r03i_prof -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -24 "$f" > $O/r03i_kernel_stats_sdf_bin_2048.csv
+rm -rf $O/r03i_prof
+echo done > $O/r03i_done
