@@ -261,6 +261,16 @@ def run(args, rank, local_rank, world, dist):
         for _ in range(20):
             solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
         torch.cuda.synchronize()
+    graph = None
+    if args.graph and W.get("loop"):
+        graph = nt.graph.capture(lambda: solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS), warmup=0)
+
+        class _Replay:
+            @staticmethod
+            def rollout(*_a):
+                graph.launch()
+
+        solver = _Replay
     for _ in range(args.warmup):
         solver.rollout(s0, s1, ctrl, contacts, dt, SUBSTEPS)
     barrier()
@@ -336,7 +346,9 @@ def run(args, rank, local_rank, world, dist):
         "roofline": roof,
     }
     if W.get("loop"):
-        out["config"]["workload"] = out["config"]["workload"].replace("fused in one rollout launch", "as separate launches (per-call API)")
+        out["config"]["workload"] = out["config"]["workload"].replace(
+            "fused in one rollout launch", "as separate launches (per-call API)" + (", the frame replayed as one hipGraph" if args.graph else ""))
+        out["config"]["hip_graph"] = bool(args.graph)
         roof["kernel_ms_is"] = "whole frame (every launch of the 10 substeps), not one kernel: see the rocprof kernel stats for the split"
     if sdf_info is not None:
         out["sdf_leg"] = sdf_info
@@ -354,6 +366,9 @@ def main():
     ap.add_argument("--envs-per-block", type=int, default=0)
     ap.add_argument("--settle-frames", type=int, default=-1, help="untimed frames before warm-up (-1: the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="call-by-call workloads (quadruped_api, sdf_bin, hydro_bin): record the frame's launches into one hipGraph "
+                         "after settling and replay it per step, as the reference's examples do with wp.ScopedCapture")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="quadruped",
                     help="quadruped = the BASELINE.json metric (default); the others are secondary measurements")
     ap.add_argument("--sweep", default="", help="comma-separated env counts (e.g. 4096,16384,65536,262144,1048576): run the "

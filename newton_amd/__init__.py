@@ -5,7 +5,7 @@ Model / State / Control / Contacts / ModelBuilder / CollisionPipeline / eval_fk 
 """
 from . import builder as _builder_mod
 from . import solvers
-from . import geometry, selection, utils, viewer
+from . import geometry, graph, selection, utils, viewer
 from .articulation import eval_fk
 from .builder import JointDofConfig, ModelBuilder, ShapeConfig
 from .collide import CollisionPipeline, ContactMatcher, Contacts

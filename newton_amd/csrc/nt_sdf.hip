@@ -612,29 +612,46 @@ struct RedLds {
     int srcidx[RED_SLOTS];    // list variant: the winner's list index, kept across red_finish (which compacts into src)
     int base, total;
 };
+
 // After the winners' records are in LDS: twins, de-duplication, rank by fingerprint.  Leaves L.first[k] (slot k exports a
 // contact), L.keep[k] = its rank among the pair's survivors, L.total; every lane of the workgroup must call it (any size).
 // The quadratic steps (first occurrence of a fingerprint, rank among the survivors) only walk the OCCUPIED slots: a pair keeps a
 // few dozen winners at most, usually a handful, and a pair without any winner skips them altogether.
-NT_DI void red_finish(RedLds& L) {
+struct RedLdsRec {  // records of RedLds
+    const RedLds& L;
+    NT_DI void operator()(int k, float* o) const {
+        o[0] = L.pos[k][0]; o[1] = L.pos[k][1]; o[2] = L.pos[k][2]; o[3] = L.pos[k][3];
+        o[4] = L.oct[k][0]; o[5] = L.oct[k][1];
+    }
+};
+// `rec(slot, out[6])` hands out the winner's record (position, depth, octahedral normal code): LDS arrays (RedLds) or the survivor
+// list in HBM (RedLdsIdx: the staged reduction keeps only an index per slot, which more than doubles the pairs in flight per CU).
+template <class LDS, class REC>
+NT_DI void red_finish(LDS& L, REC rec) {
     const int t = threadIdx.x, nt_ = blockDim.x;
     if (t == 0) L.total = 0;
     for (int en = t; en < RED_ENTRIES; en += nt_) {  // _roundoff_duplicate_bit_for_slot_pair over the 21 slot pairs of the entry
         int suppressed = 0, filled = 0;
         const int e0 = en * RED_VALUES;
         for (int sl = 0; sl < RED_VALUES; ++sl) filled += L.fp[e0 + sl] >= 0 ? 1 : 0;
-        if (filled >= 2)
+        if (filled >= 2) {
+            float rc[RED_VALUES][6];  // the entry's records first (one batch of loads), then the comparisons in registers
+#pragma unroll
+            for (int sl = 0; sl < RED_VALUES; ++sl)
+                if (L.fp[e0 + sl] >= 0) rec(e0 + sl, rc[sl]);
+#pragma unroll
             for (int sb = 1; sb < RED_VALUES; ++sb)
+#pragma unroll
                 for (int sa = 0; sa < sb; ++sa) {
                     const int fa = L.fp[e0 + sa], fb = L.fp[e0 + sb];
                     if (fa < 0 || fb < 0 || fa == fb) continue;
-                    const float* pa = L.pos[e0 + sa];
-                    const float* pb = L.pos[e0 + sb];
+                    const float* pa = rc[sa];
+                    const float* pb = rc[sb];
                     const bool same = red_near_ulps(pa[0], pb[0]) && red_near_ulps(pa[1], pb[1]) && red_near_ulps(pa[2], pb[2]) &&
-                                      red_near_ulps(pa[3], pb[3]) && red_near_ulps(L.oct[e0 + sa][0], L.oct[e0 + sb][0]) &&
-                                      red_near_ulps(L.oct[e0 + sa][1], L.oct[e0 + sb][1]);
+                                      red_near_ulps(pa[3], pb[3]) && red_near_ulps(pa[4], pb[4]) && red_near_ulps(pa[5], pb[5]);
                     if (same) suppressed |= fb < fa ? (1 << sa) : (1 << sb);
                 }
+        }
         for (int sl = 0; sl < RED_VALUES; ++sl) {
             L.keep[e0 + sl] = L.fp[e0 + sl] >= 0 && !((suppressed >> sl) & 1);
             L.first[e0 + sl] = 0;
@@ -794,7 +811,7 @@ __global__ void __launch_bounds__(256) NT_SDF_OCCUPANCY mesh_sdf_collide_reduced
             L.fp[k] = fp;
         }
         __syncthreads();
-        red_finish(L);
+        red_finish(L, RedLdsRec{L});
         if (t == 0) {
             L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
             if (a.out_blk) {  // the pair's block: rows past the capacity do not exist for the consumers
@@ -874,6 +891,7 @@ __global__ void __launch_bounds__(256) sdf_units_kernel(nt_mesh_sdf_args a, nt_c
             blk[0] = 0; blk[1] = 0; blk[2] = 0; blk[3] = 0;
             if (a.out_blk) { a.out_blk[2 * (size_t)pair_idx] = 0; a.out_blk[2 * (size_t)pair_idx + 1] = 0; }
             const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
+#pragma unroll
             for (int mode = 0; mode < 2; ++mode) {
                 run[mode] = mode_setup(a, s0, s1, mode, c[mode]);
                 if (run[mode] && r.shape_edge_radius_max) {
@@ -889,6 +907,7 @@ __global__ void __launch_bounds__(256) sdf_units_kernel(nt_mesh_sdf_args a, nt_c
         if (lane == 0 && m) at = atomicAdd(a.hit_count + CNT_UNITS, __popcll(m));
         at = __shfl(at, 0) + __popcll(m & below);
         if (any) {
+#pragma unroll
             for (int mode = 0; mode < 2; ++mode) {
                 const ModeCtx& k = c[mode];
                 float* o = a.unit_ctx + UNIT_WORDS * (2 * (size_t)at + mode);
@@ -921,21 +940,34 @@ NT_DI void cull_ctx_load(const nt_mesh_sdf_args& a, const float* o, CullCtx& c) 
     c.thr_unscaled = o[16];
     c.radius_scale = o[17];
     c.e0 = oi[18];
-    c.s = a.sdf_table[oi[20]];
+    c.s = a.sdf_table[__builtin_amdgcn_readfirstlane(oi[20])];
 }
-__global__ void __launch_bounds__(256) sdf_cull_kernel(nt_mesh_sdf_args a) {
+#ifdef NT_SDF_CULL_WAVES  // measurement builds: cap the registers for n waves per SIMD (measured: 5 / 6 / 8 waves spill and lose 4 / 12 / 23 %)
+#define NT_SDF_CULL_OCC __attribute__((amdgpu_waves_per_eu(NT_SDF_CULL_WAVES, NT_SDF_CULL_WAVES)))
+#else
+#define NT_SDF_CULL_OCC
+#endif
+#ifndef NT_SDF_RESOLVE_WAVES
+#define NT_SDF_RESOLVE_WAVES 4  // measured (MI355X, C5): 136 VGPR / 3 waves per SIMD 360 k env-steps/s, capped at 128 / 4 waves 381 k
+#endif
+#define NT_SDF_RESOLVE_OCC __attribute__((amdgpu_waves_per_eu(NT_SDF_RESOLVE_WAVES, NT_SDF_RESOLVE_WAVES)))
+__global__ void __launch_bounds__(256) NT_SDF_CULL_OCC sdf_cull_kernel(nt_mesh_sdf_args a) {
     const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int units = a.hit_count[CNT_UNITS];
     const int wave_id = blockIdx.x * waves + (threadIdx.x >> 6);
     const int stripe = wave_id % a.hit_stripe_count;
     const int slice = a.hit_capacity / a.hit_stripe_count;
-    for (int u = wave_id; u < units; u += gridDim.x * waves) {
+    for (int uv = wave_id; uv < units; uv += gridDim.x * waves) {
+        // the unit is the wave's: telling the compiler so turns the context / SDF descriptor loads into scalar loads (SGPRs
+        // instead of ~90 VGPRs of broadcast data: more waves per SIMD to hide the sample latency behind)
+        const int u = __builtin_amdgcn_readfirstlane(uv);
         const float* o = a.unit_ctx + UNIT_WORDS * 2 * (size_t)u;
         const int pair_idx = reinterpret_cast<const int*>(o)[21];
         bool hit0[2] = {false, false};
         float mid0[2] = {0.0f, 0.0f};
         int total[2] = {0, 0};
+#pragma unroll
         for (int mode = 0; mode < 2; ++mode) {  // pass 1: how many survive (the pair's block is reserved in one piece)
             CullCtx c;
             cull_ctx_load(a, o + UNIT_WORDS * mode, c);
@@ -964,6 +996,7 @@ __global__ void __launch_bounds__(256) sdf_cull_kernel(nt_mesh_sdf_args a) {
         base = __shfl(base, 0);
         const int end = (stripe + 1) * slice;
         int at = base;
+#pragma unroll
         for (int mode = 0; mode < 2; ++mode) {  // pass 2: write (meshes with more than 64 edges cull their later edges again)
             if (total[mode] == 0) continue;
             CullCtx c;
@@ -985,7 +1018,7 @@ __global__ void __launch_bounds__(256) sdf_cull_kernel(nt_mesh_sdf_args a) {
         }
     }
 }
-__global__ void __launch_bounds__(256) sdf_resolve_kernel(nt_mesh_sdf_args a) {  // grid = stripes x blocks per stripe
+__global__ void __launch_bounds__(256) NT_SDF_RESOLVE_OCC sdf_resolve_kernel(nt_mesh_sdf_args a) {  // grid = stripes x blocks per stripe
     const int stripe = blockIdx.x % a.hit_stripe_count, xb = blockIdx.x / a.hit_stripe_count, nxb = gridDim.x / a.hit_stripe_count;
     const int slice = a.hit_capacity / a.hit_stripe_count;
     int n = a.hit_stripes[STRIPE_PAD * stripe];
@@ -1007,8 +1040,26 @@ __global__ void __launch_bounds__(256) sdf_resolve_kernel(nt_mesh_sdf_args a) { 
     }
 }
 constexpr int RED_FP_CACHE = 128;  // fingerprints of a pair's survivors kept in LDS for the winners' lookup
+struct RedLdsIdx {  // the pair's table with ONE INDEX per slot instead of a record: 22 B per slot, 5.9 KB with the cache below
+    unsigned long long tbl[RED_SLOTS];
+    int fp[RED_SLOTS];     // fingerprint of the slot's winner, -1 = empty
+    int hid[RED_SLOTS];    // ... and where its record sits in the survivor list
+    short src[RED_SLOTS];  // red_finish: kept slots, compacted
+    short keep[RED_SLOTS]; // survives the roundoff-twin pass, then its rank among the pair's rows (-1: none)
+    short first[RED_SLOTS];
+    int base, total;
+};
+struct RedIdxRec {  // records through the index: world point, distance from the list, the normal's octahedral code recomputed
+    const RedLdsIdx& L;
+    const float* hit_rec;
+    NT_DI void operator()(int k, float* o) const {
+        const float* rec = hit_rec + 8 * (size_t)L.hid[k];
+        o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2]; o[3] = rec[3];
+        red_encode_oct(vec3(rec[4], rec[5], rec[6]), o[4], o[5]);
+    }
+};
 __global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
-    __shared__ RedLds L;
+    __shared__ RedLdsIdx L;
     __shared__ int hfp[RED_FP_CACHE];
     __shared__ int any;
     const int t = threadIdx.x;
@@ -1049,7 +1100,7 @@ __global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_
             __syncthreads();
             continue;
         }
-        for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k: its record from the pair's blocks
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {  // the winner of slot k: where its record sits in the pair's blocks
             if (L.tbl[k] == 0ull) continue;
             const int fp = (int)(L.tbl[k] & RED_FP_MASK);
             const int total = cnt0 + cnt1, cached = total < RED_FP_CACHE ? total : RED_FP_CACHE;
@@ -1057,13 +1108,11 @@ __global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_
             while (h < cached && hfp[h] != fp) ++h;
             if (h == cached)  // beyond the cache: the table only holds fingerprints offered from these blocks, so it is there
                 while (a.hit_fp[h < cnt0 ? off0 + h : off1 + (h - cnt0)] != fp) ++h;
-            const float* rec = a.hit_rec + 8 * (size_t)(h < cnt0 ? off0 + h : off1 + (h - cnt0));
-            L.pos[k][0] = rec[0]; L.pos[k][1] = rec[1]; L.pos[k][2] = rec[2]; L.pos[k][3] = rec[3];
-            red_encode_oct(vec3(rec[4], rec[5], rec[6]), L.oct[k][0], L.oct[k][1]);
+            L.hid[k] = h < cnt0 ? off0 + h : off1 + (h - cnt0);
             L.fp[k] = fp;
         }
         __syncthreads();
-        red_finish(L);
+        red_finish(L, RedIdxRec{L, a.hit_rec});
         if (t == 0) {
             if (a.out_blk) {  // the pair's rows start where its survivors do (rows <= survivors): no counter
                 L.base = off0;
@@ -1077,13 +1126,16 @@ __global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_
         for (int k = t; k < RED_SLOTS; k += blockDim.x) {
             const int slot = L.base + L.keep[k];
             if (L.keep[k] < 0 || slot >= a.capacity) continue;
-            const vec3 n = red_decode_oct(L.oct[k][0], L.oct[k][1]);
+            const float* rec = a.hit_rec + 8 * (size_t)L.hid[k];
+            float ox, oy;
+            red_encode_oct(vec3(rec[4], rec[5], rec[6]), ox, oy);
+            const vec3 n = red_decode_oct(ox, oy);
             a.out_pair[slot] = pair_idx;
             a.out_key[slot] = L.fp[k];
             float* o = a.out_data + 9 * (size_t)slot;
-            o[0] = L.pos[k][0]; o[1] = L.pos[k][1]; o[2] = L.pos[k][2];
+            o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2];
             o[3] = n.x; o[4] = n.y; o[5] = n.z;
-            o[6] = L.pos[k][3];
+            o[6] = rec[3];
             o[7] = a.shape_data[4 * s0 + 3];
             o[8] = a.shape_data[4 * s1 + 3];
         }
@@ -1123,7 +1175,7 @@ __global__ void __launch_bounds__(256) contacts_reduce_list_kernel(nt_contact_re
         __syncthreads();
         for (int k = t; k < RED_SLOTS; k += blockDim.x) L.srcidx[k] = L.src[k];  // red_finish compacts into L.src
         __syncthreads();
-        red_finish(L);
+        red_finish(L, RedLdsRec{L});
         if (t == 0) L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
         __syncthreads();
         for (int k = t; k < RED_SLOTS; k += blockDim.x) {

@@ -31,6 +31,7 @@ def transform(text: str) -> str:
     text, n = WAVE_SYNC.subn(WAVE_SYNC_EMU, text)
     # only under -DNT_XPBD_FAST_MATH (a measurement variant, never built here)
     text = text.replace("__builtin_amdgcn_rcpf", "emu_rcpf").replace("__builtin_amdgcn_sqrtf", "sqrtf")
+    text = text.replace("__builtin_amdgcn_readfirstlane", "emu_uniform")  # a wave-uniform value: itself
     return text
 
 

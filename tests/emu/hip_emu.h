@@ -103,6 +103,7 @@ inline int __shfl_up(int var, unsigned delta) {
     return v;
 }
 inline float emu_rcpf(float x) { return 1.0f / x; }
+inline int emu_uniform(int x) { return x; }  // __builtin_amdgcn_readfirstlane of a wave-uniform value
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
