@@ -97,13 +97,16 @@ def build_id() -> str:
 def measured_traffic(workload: str, envs: int):
     """HBM bytes per launch from the PMC passes (tools/pmc_traffic.py), only if they were taken on THIS build of the
     library (same nt_build_info source hash) for this workload and env count; otherwise None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        rec = json.load(open(path)).get(f"{workload}@{envs}")
-        if rec and rec.get("build_id") == build_id():
-            return rec
-    except Exception:
-        pass
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):  # newest round first
+        try:
+            rec = json.load(open(path)).get(f"{workload}@{envs}")
+            if rec and rec.get("build_id") == build_id():
+                rec["source"] = "profiles/" + os.path.basename(path)
+                return rec
+        except Exception:
+            pass
     return None
 
 
@@ -329,7 +332,7 @@ def run(args, rank, local_rank, world, dist):
     if rec is not None:  # counters taken on this very build (tools/pmc_traffic.py): bytes that really moved
         roof["traffic"] = rec["bytes_per_launch"]
         roof["frac_measured"] = min(rec["bytes_per_launch"], launch_bytes) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
-        roof["traffic_source"] = "profiles/r02_pmc_traffic.json"
+        roof["traffic_source"] = rec["source"]
     out = {
         "metric": "env-steps/sec at 4096 batched envs (Anymal, XPBD)", "value": total_env_steps / T, "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * T / args.steps,

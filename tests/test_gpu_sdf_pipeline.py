@@ -131,6 +131,65 @@ def test_staged_narrow_phase_gives_the_rows_of_the_single_kernel(monkeypatch):
         assert np.array_equal(rows["1"][k], rows["0"][k]), k
 
 
+def test_survivor_list_overflow_is_reported_and_harmless():
+    """A survivor list that is too small drops survivors without touching anything outside its stripes: the call reports it
+    (`dropped_survivors`, `overflow`), the rows that remain are well-formed, and a second pipeline with the default
+    capacity on the same state is unaffected."""
+    import newton_amd as nt
+    from sdf_pipeline_checker import sdf_scene
+
+    model = sdf_scene(3, 7, device="cuda:0", walls=True, seed=4)
+    _pile(model)
+    state = model.state()
+    full_pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    full = full_pipe.contacts()
+    full_pipe.collide(state, full)
+    want = _rows(full)
+    assert not full_pipe._sdf_leg.overflow(full._flat)["overflow"]
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    leg = pipe._sdf_leg
+    # shrink the survivor list of this leg to a handful of entries (same buffers, smaller declared capacity)
+    leg.hit_capacity, leg.hit_stripe_count = 16, 2
+    leg.raw_capacity = leg.hit_capacity + leg.row_capacity
+    c = pipe.contacts()
+    pipe.collide(state, c)
+    info = leg.overflow(c._flat)
+    assert info["dropped_survivors"] > 0 and info["overflow"], info
+    got = _rows(c)
+    live = got["shape0"] != got["shape1"]
+    # (with survivors missing other contacts may win a pair's slots: the rows are valid contacts, not a subset of the full result)
+    assert live.sum() < (want["shape0"] != want["shape1"]).sum()
+    assert np.isfinite(got["point0"][live]).all() and np.isfinite(got["normal"][live]).all()
+    assert got["shape0"][live].min() >= 0 and got["shape1"][live].max() < model.shape_count
+    again = full_pipe.contacts()
+    full_pipe.collide(state, again)
+    b = _rows(again)
+    for k in want:
+        assert np.array_equal(want[k], b[k]), k
+
+
+def test_worlds_without_candidates_give_no_rows():
+    """Hulls far apart: no candidate pair survives the AABB test, every stage runs on an empty population."""
+    import newton_amd as nt
+    from sdf_pipeline_checker import sdf_scene
+
+    model = sdf_scene(2, 5, device="cuda:0", walls=False, seed=11)
+    q = np.asarray(model.body_q).copy()
+    t = model.env
+    c = q[:, :3].reshape(t.env_count, t.nb, 3)
+    c[:, :, 0] = np.arange(t.nb)[None, :] * 5.0  # 5 m apart
+    c[:, :, 2] = 3.0
+    q[:, :3] = c.reshape(-1, 3)
+    model.body_q = q
+    model.joint_q.reshape(-1, 7)[:, :3] = q[:, :3]
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    contacts = pipe.contacts()
+    pipe.collide(model.state(), contacts)
+    info = pipe._sdf_leg.overflow(contacts._flat)
+    assert info["rows"] == 0 and info["pairs_per_world_max"] == 0 and not info["overflow"], info
+    assert info["cull_survivors"] == 0
+
+
 def _oracle_contacts_with_rows(model, o, body_q, rows):
     """Checker contacts = its own slot contacts (tile pairs) + the product's SDF rows appended (live ones)."""
     oc = o.contacts(cmax=max(1000, model.shape_contact_pair_count * 5) + len(rows["key"]))
