@@ -18,6 +18,7 @@ b timeout 600 python bench.py --no-cpu-baseline --workload hydro_bin --steps 5 -
 ( timeout 300 python tools/pmc_sq.py quadruped 2>&1 | tail -30 ) > $O/r03k_pmc_sq.log
 ( timeout 300 python tools/pmc_sq.py quadruped@65536 2>&1 | tail -30 ) > $O/r03k_pmc_sq_65536.log
 rm -rf $O/pmc_sq_*/ $O/pmc_quadruped_*/ 2>/dev/null
+cp $O/r03_pmc_traffic.json $R/profiles/r03_pmc_traffic.json 2>/dev/null
 b timeout 120 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/r03k_bench_with_traffic.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/r03k_prof_q -o q --output-format csv -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/r03k_prof_q.log 2>&1
