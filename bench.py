@@ -67,9 +67,13 @@ WORKLOADS = {
                     loop=True, envs=2048,
                     name="C5: 64 convex hulls (16-32 vertices, uint16 texture SDFs) in a five-wall bin of SDF boxes, every pair "
                          "through the SDF narrow phase + global contact reduction inside CollisionPipeline.collide(broad_phase='sap'), contact gap 5 mm"),
-    "hydro_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 1200.0, kernel="hydro_pairs_kernel", drop=0.0, settle=40, loop=True, envs=256,
+    "hydro_bin": dict(solver="xpbd", iterations=2, dt=1.0 / 1200.0, kernel="hydro_pairs_kernel<true>", drop=0.0, settle=40, loop=True, envs=256,
                       name="C5 with hydroelastic contacts: the same bin, every shape HYDROELASTIC (kh = 1e10): every pair through the "
-                           "SDF-SDF leg (SAT, octree in LDS, marching cubes; HydroelasticSDF.Config(reduce_contacts=False)), contact gap 5 mm"),
+                           "SDF-SDF leg (SAT, octree in LDS, marching cubes) with HydroelasticSDF.Config() as it comes (reduce_contacts, "
+                           "pre_prune_contacts, normal_matching), contact gap 5 mm"),
+    "hydro_bin_faces": dict(solver="xpbd", iterations=2, dt=1.0 / 1200.0, kernel="hydro_pairs_kernel<false>", drop=0.0, settle=40, loop=True,
+                            envs=256,
+                            name="the hydroelastic bin with HydroelasticSDF.Config(reduce_contacts=False): every marching-cubes face is a contact row"),
     # the headline scene through the per-call API an RL loop with per-substep control uses: collide and step as separate launches
     "quadruped_api": dict(solver="xpbd", iterations=2, dt=1e-3, kernel="xpbd_step_kernel<16,false> + collide_kernel<16,false>",
                           drop=0.22, settle=100, loop=True,
@@ -172,7 +176,7 @@ def build_shard(workload: str, envs_per_gpu: int, rank: int, world: int, device:
         if envs_per_gpu > base:
             m = tile_worlds(m, envs_per_gpu // base, device=device, filter_pairs=False)
         return m
-    if workload == "hydro_bin":
+    if workload in ("hydro_bin", "hydro_bin_faces"):
         g = scenes.hull_bin_scene(total, 64, seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005), hydroelastic=True)
     elif workload == "sdf_bin":
         # contact gap 5 mm (Newton's default rigid_gap of 0.1 m is larger than a hull: every pair of the bin would be a candidate)
@@ -223,9 +227,11 @@ def run(args, rank, local_rank, world, dist):
     ctrl = model.control()
     extra = {}
     if args.workload == "hydro_bin":
+        extra = dict(sdf_hydroelastic_config=nt.geometry.HydroelasticSDF.Config(), sdf_contacts_per_shape=400, sdf_hydro_faces_per_shape=600)
+    elif args.workload == "hydro_bin_faces":
         extra = dict(sdf_hydroelastic_config=nt.geometry.HydroelasticSDF.Config(reduce_contacts=False), sdf_contacts_per_shape=400)
     pipe = nt.CollisionPipeline(model, envs_per_block=args.envs_per_block,
-                                broad_phase="sap" if args.workload in ("sdf_bin", "hydro_bin") else None, **extra)
+                                broad_phase="sap" if args.workload in ("sdf_bin", "hydro_bin", "hydro_bin_faces") else None, **extra)
     contacts = pipe.contacts()
     if W["solver"] == "featherstone":
         solver = nt.solvers.SolverFeatherstone(model, envs_per_block=args.envs_per_block)

@@ -563,6 +563,22 @@ typedef struct {
     int32_t* out_rank;               /* [capacity] rank of the row inside its pair (rows of a pair are not contiguous) */
     float* out_stiffness;            /* [capacity] Contacts.rigid_contact_stiffness of the row; out_data is then [capacity][9]:
                                         centre, normal a -> b, margin-relative separation, 0, 0 (the pipeline's raw row) */
+    /* ---- reduce_contacts = True (HydroelasticSDF.Config defaults; contact_reduction_hydroelastic.py): every pair's faces are
+     * buffered, aggregated per normal bin (force, centre of pressure, depth-volume), optionally pruned voxel by voxel
+     * (two strongest penetrating faces + the closest non-penetrating one), ranked in the pair's table (20 normal bins x
+     * (6 spatial extremes + deepest) + 100 voxel slots, + 100 speculative voxel slots), and the winners leave with the bin's
+     * aggregate stiffness |agg force| / sum of their depths and, with normal matching, normals rotated so that their weighted sum is
+     * the aggregate force direction.  The non-deterministic variant of the reference evaluated in thread order (contact ids follow the
+     * face order, sums the contact order); anchor contacts / moment matching are not offered.  The pair's rows are contiguous,
+     * out_blk = (0, rows), out_rank = position in the pair's export order.  All 0 / NULL: unreduced. */
+    int32_t reduce;                  /* bit 0: reduce, bit 1: pre_prune_contacts, bit 2: normal_matching */
+    const float* shape_aabb_lower;   /* [S][3] Model.shape_collision_aabb_lower (shape-local) */
+    const float* shape_aabb_upper;   /* [S][3] */
+    const int32_t* shape_voxel_res;  /* [S][3] Model._shape_voxel_resolution */
+    int32_t* face_count;             /* [2] scratch: faces buffered, pairs whose chunk list overflowed (zero both first) */
+    float* face_rec;                 /* [face_capacity][12] scratch */
+    int32_t face_capacity;
+    float* out_friction;             /* [capacity] or NULL: Contacts.rigid_contact_friction of the row (1 for reduced rows) */
 } nt_hydro_args;
 nt_status nt_hydro_collide(const nt_hydro_args* args, void* stream);
 /* HydroelasticSDF.launch (sdf_hydroelastic.py:905-1296, reduce_contacts=False) inside the collide pipeline: SAT of the SDF boxes,
@@ -623,6 +639,7 @@ typedef struct {
     const int32_t* raw_rank;     /* [raw_capacity] or NULL: rank of the raw row inside its pair, for rows whose pair kind is 1 (their
                                     blocks are not contiguous: nt_hydro_pairs); kind-0 rows use raw index - block offset */
     const float* raw_stiffness;  /* [raw_capacity] or NULL: per-contact stiffness of kind-1 rows */
+    const float* raw_friction;   /* [raw_capacity] or NULL: per-contact friction scale of kind-1 rows (reduced hydroelastic rows: 1) */
     float* stiffness;            /* [row_capacity] or NULL: out, nt_flat_rows.stiffness / damping / friction_scale: the hydroelastic */
     float* damping;              /*   rows carry their stiffness and zero damping / friction scale (ContactData defaults), */
     float* friction_scale;       /*   mesh-SDF rows zeros (collide.py:196-199) */

@@ -83,7 +83,7 @@ class nt_sdf_rows_io(C.Structure):
                 ("raw_data", C.c_void_p), ("raw_capacity", C.c_int32), ("row_capacity", C.c_int32), ("shape0", C.c_void_p),
                 ("shape1", C.c_void_p), ("point0", C.c_void_p), ("point1", C.c_void_p), ("offset0", C.c_void_p),
                 ("offset1", C.c_void_p), ("normal", C.c_void_p), ("margin0", C.c_void_p), ("margin1", C.c_void_p),
-                ("key", C.c_void_p), ("raw_rank", C.c_void_p), ("raw_stiffness", C.c_void_p), ("stiffness", C.c_void_p),
+                ("key", C.c_void_p), ("raw_rank", C.c_void_p), ("raw_stiffness", C.c_void_p), ("raw_friction", C.c_void_p), ("stiffness", C.c_void_p),
                 ("damping", C.c_void_p), ("friction_scale", C.c_void_p), ("raw_base", C.c_int32)]
 
 
@@ -172,7 +172,9 @@ class nt_hydro_args(C.Structure):
                 ("out_pair", C.c_void_p), ("out_key", C.c_void_p), ("out_shapes", C.c_void_p), ("out_data", C.c_void_p),
                 ("capacity", C.c_int32), ("pair_world_prefix", C.c_void_p), ("worlds", C.c_int32), ("pairs_per_world", C.c_int32),
                 ("pair_kind", C.c_void_p), ("out_pairs_normalized", C.c_void_p), ("out_blk", C.c_void_p), ("out_rank", C.c_void_p),
-                ("out_stiffness", C.c_void_p)]
+                ("out_stiffness", C.c_void_p),
+                ("reduce", C.c_int32), ("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
+                ("face_count", C.c_void_p), ("face_rec", C.c_void_p), ("face_capacity", C.c_int32), ("out_friction", C.c_void_p)]
 
 
 class nt_semi_implicit_params(C.Structure):

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/newton_hip.h"
 #include "nt_math.hpp"
 
@@ -1440,7 +1442,7 @@ NT_DI bool hydro_sat(const xform& Ta, vec3 ea, const xform& Tb, vec3 eb) {
             if (separated(cross(axa[i], axb[j]))) return false;
     return true;
 }
-struct HydroFace { vec3 pos; float oct0, oct1, depth, stiff; };
+struct HydroFace { vec3 pos; float oct0, oct1, depth, stiff; vec3 normal; float area, pressure; };  // normal / area / pressure: reduction only
 // marching cubes of one voxel of B (mc_iterate_voxel_vertices :1716-1798, mc_calc_face_texture :282-362, the face filters and the
 // decode of the unreduced path); returns the number of faces kept (<= 5), in face order
 NT_DI int hydro_voxel_faces(const nt_hydro_args& a, const HydroPair& p, int x, int y, int z, HydroFace* out, int* face_id) {
@@ -1521,14 +1523,300 @@ NT_DI int hydro_voxel_faces(const nt_hydro_args& a, const HydroPair& p, int x, i
         red_encode_oct(normal, f.oct0, f.oct1);
         f.depth = sep;
         f.stiff = stiff;
+        f.normal = normal;
+        f.area = area;
+        f.pressure = pressure;
         face_id[kept] = fi;
         kept += 1;
     }
     return kept;
 }
 
+// ---- reduce_contacts = True: what the workgroup keeps of a pair between the face pass and the reduction (see hydro_reduce_pair)
+constexpr int HYDRO_CHUNK_CAP = 1024;  // face blocks of one pair (one per 256 voxels that carry faces)
+constexpr int HYDRO_ENTRIES = 50;      // 20 normal bins + 15 voxel groups + 15 speculative voxel groups
+constexpr int HYDRO_STAGE = 256;
+constexpr int HYDRO_FACE_WORDS = 12;   // centre[3] normal[3] separation area pressure | key | contact id << 5 | normal bin | pad
+struct HydroRedLds {
+    int chunk[HYDRO_CHUNK_CAP][2];
+    float agg[RED_BINS][10];                      // agg_force[3] weighted_pos_sum[3] weight_sum agg_depth_volume[3]
+    float tdepth[RED_BINS], tnormal[RED_BINS][3]; // total_depth_reduced / total_normal_reduced
+    unsigned long long tbl[HYDRO_ENTRIES][RED_VALUES];
+    int tslot[HYDRO_ENTRIES][RED_VALUES];         // where the winner's face record sits
+    unsigned int ekey[HYDRO_ENTRIES];             // first use of the entry (hashtable insertion order), ~0u = never
+    int order[HYDRO_ENTRIES], ucount[HYDRO_ENTRIES], ubase[HYDRO_ENTRIES], n_entries;
+    float wpen[HYDRO_ENTRIES * RED_VALUES], wn[HYDRO_ENTRIES * RED_VALUES][3];
+    int wnbin[HYDRO_ENTRIES * RED_VALUES];
+    unsigned char wuniq[HYDRO_ENTRIES * RED_VALUES];
+    int n_chunk, pair_kept, overflow, rows, row_base;
+    float stage[HYDRO_STAGE][9];  // a tile of face records for the ordered aggregate sums
+    signed char stage_bin[HYDRO_STAGE];
+};
+NT_DI unsigned long long hydro_value(float score, int cid) {  // _make_contact_value_fast
+    return ((unsigned long long)red_float_flip(score) << 32) | (unsigned long long)(unsigned int)cid;
+}
+NT_DI int hydro_entry_of_voxel(int vox, bool speculative) { return (speculative ? RED_BINS + 15 : RED_BINS) + vox / RED_VALUES; }
+NT_DI quat hydro_matching_rotation(vec3 nsum, vec3 agg, float agg_mag) {  // _compute_normal_matching_rotation :261-292
+    quat q(0.0f, 0.0f, 0.0f, 1.0f);
+    const float sel_mag = length(nsum);
+    if (sel_mag > 1e-8f && agg_mag > 1e-20f) {
+        const vec3 sel = nsum / sel_mag, ad = agg / agg_mag;
+        const vec3 cr = cross(sel, ad);
+        const float cr_mag = length(cr), d = dot(sel, ad);
+        bool have = false;
+        vec3 axis;
+        float angle = 0.0f;
+        if (cr_mag > 1e-8f) {
+            axis = cr / cr_mag;
+            angle = acosf(fminw(fmaxw(d, -1.0f), 1.0f));
+            have = true;
+        } else if (d < 0.0f) {
+            vec3 perp(1.0f, 0.0f, 0.0f);
+            if (fabsf(dot(sel, perp)) > 0.9f) perp = vec3(0.0f, 1.0f, 0.0f);
+            axis = normalize(cross(sel, perp));
+            angle = 3.14159265359f;
+            have = true;
+        }
+        if (have) {  // wp.quat_from_axis_angle
+            const float half = angle * 0.5f, sn = sinf(half);
+            q = quat(axis.x * sn, axis.y * sn, axis.z * sn, cosf(half));
+        }
+    }
+    return q;
+}
+// The reduction of ONE pair after its faces are in a.face_rec (blocks listed in R.chunk, face order): aggregates per normal bin
+// (ordered sums, one lane per bin), table registration of the buffered contacts, winners, reduced depth sums in the hashtable's
+// insertion order, export.  contact_reduction_hydroelastic.py:596-755 (reduce), :756-850 (accumulate depth), :983-1460 (export).
+NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
+    const int t = threadIdx.x, nt_ = blockDim.x;
+    const bool normal_matching = (a.reduce & 4) != 0;
+    for (int k = t; k < HYDRO_ENTRIES * RED_VALUES; k += nt_) {
+        R.tbl[k / RED_VALUES][k % RED_VALUES] = 0ull;
+        R.tslot[k / RED_VALUES][k % RED_VALUES] = -1;
+        R.wuniq[k] = 0;
+    }
+    for (int k = t; k < HYDRO_ENTRIES; k += nt_) { R.ekey[k] = ~0u; R.ucount[k] = 0; }
+    __syncthreads();
+    // ---- aggregates of ALL penetrating faces per (exact-normal) bin, face order: lane = bin.  The faces pass through LDS in tiles
+    // (every lane loads one record, coalesced) so that the twenty summing lanes walk LDS instead of paying an HBM round trip per face
+    {
+        vec3 force, wps, adv;
+        float ws = 0.0f;
+        unsigned int first = ~0u;
+        int rank = 0;
+        for (int c = 0; c < R.n_chunk; ++c) {
+            const int base = R.chunk[c][0], cnt = R.chunk[c][1];
+            for (int k0 = 0; k0 < cnt; k0 += HYDRO_STAGE) {
+                const int m = cnt - k0 < HYDRO_STAGE ? cnt - k0 : HYDRO_STAGE;
+                for (int k = t; k < m; k += nt_) {
+                    const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + k0 + k);
+                    float* o = R.stage[k];
+                    o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2]; o[3] = rec[3]; o[4] = rec[4]; o[5] = rec[5];
+                    o[6] = rec[6]; o[7] = rec[7]; o[8] = rec[8];
+                    R.stage_bin[k] = rec[6] < 0.0f ? (reinterpret_cast<const int*>(rec)[10] & 31) : -1;
+                }
+                __syncthreads();
+                if (t < RED_BINS)
+                    for (int k = 0; k < m; ++k) {
+                        if (R.stage_bin[k] != t) continue;
+                        const float* rec = R.stage[k];
+                        const vec3 n(rec[3], rec[4], rec[5]), ctr(rec[0], rec[1], rec[2]);
+                        const float fw = rec[7] * rec[8];
+                        force += fw * n;
+                        wps += fw * ctr;
+                        ws += fw;
+                        adv += (rec[7] * (-rec[6])) * n;
+                        if (first == ~0u) first = (unsigned int)(rank + k);
+                    }
+                rank += m;
+                __syncthreads();
+            }
+        }
+      if (t < RED_BINS) {
+        float* g = R.agg[t];
+        g[0] = force.x; g[1] = force.y; g[2] = force.z; g[3] = wps.x; g[4] = wps.y; g[5] = wps.z; g[6] = ws;
+        g[7] = adv.x; g[8] = adv.y; g[9] = adv.z;
+        R.tdepth[t] = 0.0f;
+        R.tnormal[t][0] = R.tnormal[t][1] = R.tnormal[t][2] = 0.0f;
+        if (first != ~0u) R.ekey[t] = first;
+      }
+    }
+    __syncthreads();
+    // ---- table registration (pass 0) and the winners' record positions (pass 1), one lane per buffered contact
+    const float* lo = a.shape_aabb_lower + 3 * p.sb;
+    const float* hi = a.shape_aabb_upper + 3 * p.sb;
+    const float aabb_size = length(vec3(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]));
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int c = 0; c < R.n_chunk; ++c) {
+            const int base = R.chunk[c][0], cnt = R.chunk[c][1];
+            for (int k = t; k < cnt; k += nt_) {
+                const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + k);
+                const int cid = reinterpret_cast<const int*>(rec)[10] >> 5;
+                if (cid <= 0) continue;
+                const unsigned int ucid = (unsigned int)cid;
+                auto offer = [&](int e, int s, float score, unsigned int key) {
+                    if (pass == 0) {
+                        atomicMax(&R.tbl[e][s], hydro_value(score, cid));
+                        atomicMin(&R.ekey[e], key);
+                    } else if ((unsigned int)(R.tbl[e][s] & 0xFFFFFFFFull) == ucid) {
+                        R.tslot[e][s] = base + k;
+                    }
+                };
+                const vec3 ctr(rec[0], rec[1], rec[2]);
+                const float depth = rec[6];
+                float ox, oy;
+                red_encode_oct(vec3(rec[3], rec[4], rec[5]), ox, oy);
+                const vec3 n = red_decode_oct(ox, oy);
+                int vox = red_voxel_index(ctr, lo, hi, a.shape_voxel_res + 3 * p.sb);
+                vox = vox < 0 ? 0 : (vox > RED_VOXELS - 1 ? RED_VOXELS - 1 : vox);
+                const unsigned int key = (1u << 30) + 2u * ucid;
+                if (!(depth < 0.0f)) {  // speculative contacts compete in their own voxel groups
+                    offer(hydro_entry_of_voxel(vox, true), vox % RED_VALUES, -depth, key);
+                    continue;
+                }
+                const int b = red_get_slot(n);
+                if (depth < 0.0001f * aabb_size) {  // BETA_THRESHOLD
+                    const float* g = R.agg[b];
+                    const vec3 anchor = vec3(g[3], g[4], g[5]) / g[6];
+                    vec3 u, v;
+                    red_face_frame(b, u, v);
+                    const vec3 rel = ctr - anchor;
+                    const float px = dot(rel, u), py = dot(rel, v), pen_w = fmaxw(-depth, 0.0f);
+                    for (int d = 0; d < RED_DIRS; ++d) offer(b, d, (px * RED_DIR[d][0] + py * RED_DIR[d][1]) * pen_w, key);
+                }
+                offer(b, RED_DIRS, -depth, key);
+                offer(hydro_entry_of_voxel(vox, false), vox % RED_VALUES, -depth, key + 1u);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- winners: unique contacts of every entry in slot order, their depth / decoded normal / normal bin
+    for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {
+        const int e = i / RED_VALUES, sl = i % RED_VALUES;
+        const unsigned long long v = R.tbl[e][sl];
+        if (v == 0ull) continue;
+        bool uniq = true;
+        for (int s2 = 0; s2 < sl; ++s2) uniq = uniq && (R.tbl[e][s2] & 0xFFFFFFFFull) != (v & 0xFFFFFFFFull);
+        if (!uniq) continue;
+        const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)R.tslot[e][sl];
+        float ox, oy;
+        red_encode_oct(vec3(rec[3], rec[4], rec[5]), ox, oy);
+        const vec3 n = red_decode_oct(ox, oy);
+        R.wuniq[i] = 1;
+        R.wpen[i] = -rec[6];
+        R.wn[i][0] = n.x; R.wn[i][1] = n.y; R.wn[i][2] = n.z;
+        R.wnbin[i] = e < RED_BINS ? e : (rec[6] < 0.0f ? red_get_slot(n) : -1);
+        atomicAdd(&R.ucount[e], 1);
+    }
+    __syncthreads();
+    // ---- entries in insertion order; reduced depth / normal sums in that order (one lane: <= 350 short steps on LDS)
+    if (t < HYDRO_ENTRIES) {
+        int rank = -1;
+        if (R.ekey[t] != ~0u) {
+            rank = 0;
+            for (int e2 = 0; e2 < HYDRO_ENTRIES; ++e2) rank += (R.ekey[e2] < R.ekey[t]) ? 1 : 0;  // keys are distinct
+            R.order[rank] = t;
+        }
+    }
+    if (t == 0) {
+        int n = 0;
+        for (int e = 0; e < HYDRO_ENTRIES; ++e) n += R.ekey[e] != ~0u ? 1 : 0;
+        R.n_entries = n;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int rows = 0;
+        for (int r = 0; r < R.n_entries; ++r) {
+            const int e = R.order[r];
+            R.ubase[e] = rows;
+            rows += R.ucount[e];
+            for (int sl = 0; sl < RED_VALUES; ++sl) {
+                const int i = e * RED_VALUES + sl;
+                if (!R.wuniq[i] || !(R.wpen[i] > 0.0f) || R.wnbin[i] < 0) continue;  // depth < 0 <=> pen > 0
+                const int nb = R.wnbin[i];
+                const float pen = R.wpen[i];
+                R.tdepth[nb] += pen;
+                R.tnormal[nb][0] += pen * R.wn[i][0];
+                R.tnormal[nb][1] += pen * R.wn[i][1];
+                R.tnormal[nb][2] += pen * R.wn[i][2];
+            }
+        }
+        R.rows = rows;
+        R.row_base = rows > 0 ? atomicAdd(a.out_count, rows) : 0;
+    }
+    __syncthreads();
+    // ---- export
+    const float den = p.kh_a + p.kh_b;
+    const float mca_k = a.margin_contact_area * (den <= 0.0f ? 0.0f : (p.kh_a * p.kh_b) / den);
+    auto bin_values = [&](int b, vec3& agg, float& agg_mag, bool& reliable, float& eff) {
+        const float* g = R.agg[b];
+        agg = vec3(g[0], g[1], g[2]);
+        agg_mag = length(agg);
+        reliable = length(vec3(g[7], g[8], g[9])) > 1e-8f && agg_mag > 1e-20f;
+        const vec3 ns(R.tnormal[b][0], R.tnormal[b][1], R.tnormal[b][2]);
+        if (normal_matching) {
+            eff = length(ns);
+            if (eff < 1e-8f) eff = R.tdepth[b];
+        } else {
+            eff = R.tdepth[b];
+        }
+    };
+    for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {
+        if (!R.wuniq[i]) continue;
+        const int e = i / RED_VALUES, sl = i % RED_VALUES;
+        int idx = 0;
+        for (int s2 = 0; s2 < sl; ++s2) idx += R.wuniq[e * RED_VALUES + s2];
+        const int rank = R.ubase[e] + idx, slot = R.row_base + rank;
+        if (slot >= a.capacity) continue;
+        const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)R.tslot[e][sl];
+        const float depth = rec[6];
+        const vec3 n(R.wn[i][0], R.wn[i][1], R.wn[i][2]);
+        vec3 final_n = n;
+        float stiff;
+        vec3 agg;
+        float agg_mag = 0.0f, eff = 0.0f;
+        bool reliable = false;
+        if (e < RED_BINS) bin_values(e, agg, agg_mag, reliable, eff);
+        if (reliable) {
+            if (normal_matching && depth < 0.0f)
+                final_n = normalize(quat_rotate(hydro_matching_rotation(vec3(R.tnormal[e][0], R.tnormal[e][1], R.tnormal[e][2]), agg, agg_mag), n));
+            const float shared = (agg_mag > 1e-20f && eff > 0.0f) ? agg_mag / eff : 0.0f;
+            stiff = shared;
+            if (shared == 0.0f) stiff = depth < 0.0f ? rec[7] * rec[8] / fmaxw(-depth, 1e-20f) : mca_k;
+        } else {
+            const int nb = R.wnbin[i];
+            if (nb >= 0 && depth < 0.0f) {
+                vec3 t_agg;
+                float t_mag, t_eff;
+                bool t_rel;
+                bin_values(nb, t_agg, t_mag, t_rel, t_eff);
+                if (normal_matching && t_rel)
+                    final_n = normalize(quat_rotate(hydro_matching_rotation(vec3(R.tnormal[nb][0], R.tnormal[nb][1], R.tnormal[nb][2]), t_agg, t_mag), n));
+                stiff = (t_mag > 1e-20f && t_eff > 0.0f) ? t_mag / t_eff : rec[7] * rec[8] / fmaxw(-depth, 1e-20f);
+            } else if (depth < 0.0f) {
+                stiff = rec[7] * rec[8] / fmaxw(-depth, 1e-20f);
+            } else {
+                stiff = mca_k;
+            }
+        }
+        if (!(depth < 0.0f)) stiff = mca_k;
+        const vec3 pw = xform_point(p.X_b, vec3(rec[0], rec[1], rec[2])), nw = xform_vector(p.X_b, final_n);
+        a.out_pair[slot] = pair_idx;
+        a.out_key[slot] = reinterpret_cast<const int*>(rec)[9];
+        a.out_rank[slot] = rank;
+        float* o = a.out_data + 9 * (size_t)slot;
+        o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; o[3] = nw.x; o[4] = nw.y; o[5] = nw.z;
+        o[6] = depth; o[7] = 0.0f; o[8] = 0.0f;
+        a.out_stiffness[slot] = stiff;
+        if (a.out_friction) a.out_friction[slot] = 1.0f;
+    }
+    __syncthreads();
+}
+
+template <bool REDUCE>
 __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
     __shared__ HydroLds L;
+    __shared__ typename std::conditional<REDUCE, HydroRedLds, int>::type R;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int pair_total = a.pair_world_prefix[a.worlds];
     for (int f = blockIdx.x; f < pair_total; f += gridDim.x) {
@@ -1555,6 +1843,7 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
             L.pair_vox = 0;
             L.pair_face = 0;
             L.collide = 0;
+            if constexpr (REDUCE) { R.n_chunk = 0; R.pair_kept = 0; R.overflow = 0; R.rows = 0; }
             if (ok) {  // SAT of the two SDF boxes (centred transforms), before the finer-is-B swap like the reference
                 const xform Xa = load_xform(a.shape_transform + 7 * p.sa), Xb = load_xform(a.shape_transform + 7 * p.sb);
                 const vec3 alo(p.A.box_lower[0], p.A.box_lower[1], p.A.box_lower[2]), ahi(p.A.box_upper[0], p.A.box_upper[1], p.A.box_upper[2]);
@@ -1656,6 +1945,84 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
                     __syncthreads();
                     int before = x - kept;
                     for (int k = 0; k < wave; ++k) before += L.wsum[k];
+                    if constexpr (REDUCE) {
+                        // buffered contacts of this voxel in buffer order: every face, or (pre_prune) the two strongest penetrating
+                        // faces and the closest non-penetrating one (sdf_hydroelastic.py:2156-2312)
+                        int sel[3] = {-1, -1, -1};
+                        const bool prune = (a.reduce & 2) != 0;
+                        if (prune) {
+                            float s0 = 0.0f, s1 = 0.0f, best_np = 1.0e10f;
+                            for (int k = 0; k < kept; ++k) {
+                                const HydroFace& fc = faces[k];
+                                if (fc.depth < 0.0f) {
+                                    const float score = fc.area * fc.pressure;
+                                    if (sel[0] < 0 || score > s0) { sel[1] = sel[0]; s1 = s0; sel[0] = k; s0 = score; }
+                                    else if (sel[1] < 0 || score > s1) { sel[1] = k; s1 = score; }
+                                } else if (fc.depth < best_np) {
+                                    best_np = fc.depth;
+                                    sel[2] = k;
+                                }
+                            }
+                        }
+                        const int nsel = prune ? (sel[0] >= 0) + (sel[1] >= 0) + (sel[2] >= 0) : kept;
+                        int xs = nsel;  // inclusive scan of the buffered counts (contact ids follow the voxel order)
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const int y = __shfl_up(xs, d);
+                            if (lane >= d) xs += y;
+                        }
+                        __syncthreads();  // (wsum is read above by every lane)
+                        if (lane == 63) L.wsum[wave] = xs;
+                        __syncthreads();
+                        int before_sel = xs - nsel;
+                        for (int k = 0; k < wave; ++k) before_sel += L.wsum[k];
+                        const int sel_total = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+                        __syncthreads();
+                        // the chunk's block of face records
+                        if (lane == 63) L.wsum[wave] = x;
+                        __syncthreads();
+                        if (t == 0) {
+                            const int total = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+                            L.n_face = total;
+                            L.base = total > 0 ? atomicAdd(a.face_count, total) : 0;
+                            if (total > 0) {
+                                if (R.n_chunk < HYDRO_CHUNK_CAP && L.base + total <= a.face_capacity) {
+                                    R.chunk[R.n_chunk][0] = L.base;
+                                    R.chunk[R.n_chunk][1] = total;
+                                    R.n_chunk += 1;
+                                } else {
+                                    R.overflow = 1;  // the pair loses these faces: reported through face_count[1]
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        for (int k = 0; k < kept; ++k) {
+                            const int slot = L.base + before + k;
+                            if (slot >= a.face_capacity) continue;
+                            const HydroFace& fc = faces[k];
+                            int cid = 0;
+                            if (!prune) cid = L.pair_face + before + k + 1;
+                            else {
+                                int ord = 0;
+                                for (int j = 0; j < 3; ++j) {
+                                    if (sel[j] == k) cid = R.pair_kept + before_sel + ord + 1;
+                                    ord += sel[j] >= 0 ? 1 : 0;
+                                }
+                            }
+                            float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)slot;
+                            o[0] = fc.pos.x; o[1] = fc.pos.y; o[2] = fc.pos.z;
+                            o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
+                            o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
+                            int* oi = reinterpret_cast<int*>(o);
+                            oi[9] = (L.pair_vox + i) * 5 + face_id[k];
+                            oi[10] = (cid << 5) | red_get_slot(fc.normal);
+                            oi[11] = 0;
+                        }
+                        __threadfence();
+                        __syncthreads();
+                        if (t == 0) { L.pair_face += L.n_face; R.pair_kept += sel_total; }
+                        __syncthreads();
+                        continue;
+                    }
                     if (t == 0) {
                         const int total = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
                         L.n_face = total;
@@ -1685,7 +2052,15 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
             }
         }
         __syncthreads();
-        if (t == 0) {
+        if constexpr (REDUCE) {
+            if (L.pair_face > 0) hydro_reduce_pair(a, p, pair_idx, R);  // (uniform)
+            if (t == 0) {
+                if (R.overflow) atomicAdd(a.face_count + 1, 1);
+                a.out_blk[2 * (size_t)pair_idx] = 0;
+                a.out_blk[2 * (size_t)pair_idx + 1] = L.pair_face > 0 ? R.rows : 0;
+            }
+            __syncthreads();
+        } else if (t == 0) {
             const int total = L.pair_face;
             a.out_blk[2 * (size_t)pair_idx] = 0;
             a.out_blk[2 * (size_t)pair_idx + 1] = total;
@@ -1717,7 +2092,18 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
     if (!(a->edge_clamp_min >= 0.0f && a->edge_clamp_min <= 0.5f)) return NT_ERR_INVALID_ARG;
     const long long cap = (long long)a->worlds * a->pairs_per_world;
     const int blocks = cap < 16384 ? (int)cap : 16384;
-    hipLaunchKernelGGL(hydro_pairs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->reduce & 1) {
+        if (!a->shape_aabb_lower || !a->shape_aabb_upper || !a->shape_voxel_res || !a->face_count || !a->face_rec || a->face_capacity <= 0)
+            return NT_ERR_INVALID_ARG;
+#ifdef NT_EMULATED_GRID
+        const int rblocks = blocks < NT_EMULATED_GRID ? blocks : NT_EMULATED_GRID;
+#else
+        const int rblocks = blocks;
+#endif
+        hipLaunchKernelGGL(hydro_pairs_kernel<true>, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
+    } else {
+        hipLaunchKernelGGL(hydro_pairs_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    }
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

@@ -199,7 +199,7 @@ NT_DI void write_row(const nt_sdf_scene& sc, const nt_sdf_rows_io& io, const flo
     if (io.stiffness) {
         io.stiffness[dst] = hydro && io.raw_stiffness ? io.raw_stiffness[i] : 0.0f;
         io.damping[dst] = 0.0f;
-        io.friction_scale[dst] = 0.0f;
+        io.friction_scale[dst] = hydro && io.raw_friction ? io.raw_friction[i] : 0.0f;
     }
 }
 // Raw rows come in two regions: [0, raw_base) holds the blocks the staged narrow phase wrote at the start of each pair's survivor

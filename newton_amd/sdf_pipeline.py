@@ -70,7 +70,7 @@ class SdfLeg:
     """Model-level tables + per-pipeline work buffers of the mesh-SDF leg."""
 
     def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64, hydro_config=None,
-                 staged: bool = True, survivors_per_row: int = 2):
+                 staged: bool = True, survivors_per_row: int = 2, hydro_faces_per_shape: int = 400):
         from .sdf_device import DeviceSDF  # noqa: PLC0415
 
         torch = _torch()
@@ -126,14 +126,18 @@ class SdfLeg:
         if np.any((kind == 0) & ~t.sdf_pair_has_edges):
             raise NotImplementedError("pairs of hydroelastic shapes without collision edges need CollisionPipeline(sdf_hydroelastic_config=...)")
         self.has_hydro_pairs = bool(kind.any())
+        self.hydro_reduce, self.face_capacity = 0, 0
         self._template_kind = up(kind, np.uint8)
         self.world_pair_kind = torch.zeros(E * PPW, dtype=torch.uint8, device=dev)
         if self.has_hydro_pairs:
             from .mc_tables import tables  # noqa: PLC0415
 
-            if hydro_config.reduce_contacts:
-                raise NotImplementedError("HydroelasticSDF.Config(reduce_contacts=True) is not implemented: pass reduce_contacts=False "
-                                          "(every marching-cubes face becomes a contact row)")
+            if hydro_config.reduce_contacts and (hydro_config.anchor_contact or hydro_config.moment_matching):
+                raise NotImplementedError("HydroelasticSDF.Config(anchor_contact / moment_matching) are not implemented "
+                                          "(the reduction offers pre_prune_contacts and normal_matching)")
+            self.hydro_reduce = (1 | (2 if hydro_config.pre_prune_contacts else 0) | (4 if hydro_config.normal_matching else 0)
+                                 if hydro_config.reduce_contacts else 0)
+            self.face_capacity = E * n_shapes * int(hydro_faces_per_shape) if self.hydro_reduce else 0
             if hydro_config.pressure_func is not None:
                 raise NotImplementedError("custom pressure_func callbacks are not supported (linear pressure -kh * depth only)")
             sc.template_kind, sc.world_pair_kind = self._template_kind.data_ptr(), self.world_pair_kind.data_ptr()
@@ -176,6 +180,10 @@ class SdfLeg:
         self.raw_data = torch.zeros((self.raw_capacity, 9), dtype=f32, device=dev)
         self.raw_rank = torch.zeros(self.raw_capacity if self.has_hydro_pairs else 1, dtype=i32, device=dev)
         self.raw_stiffness = torch.zeros(self.raw_capacity if self.has_hydro_pairs else 1, dtype=f32, device=dev)
+        if self.has_hydro_pairs and self.hydro_reduce:  # the reduction's face buffer (scratch of a call) + per-row friction scale
+            self.face_count = torch.zeros(2, dtype=i32, device=dev)
+            self.face_rec = torch.zeros((self.face_capacity, 12), dtype=f32, device=dev)
+            self.raw_friction = torch.zeros(self.raw_capacity, dtype=f32, device=dev)
 
     def new_rows(self, per_contact_shape_properties: bool = False) -> FlatRows:
         # hydroelastic rows carry Contacts.rigid_contact_stiffness: allocated whenever the leg can produce them
@@ -232,6 +240,13 @@ class SdfLeg:
             h.pair_kind, h.out_pairs_normalized, h.out_blk = (self.world_pair_kind.data_ptr(), self.world_pairs.data_ptr(),
                                                               self.blk.data_ptr())
             h.out_rank, h.out_stiffness = self.raw_rank.data_ptr(), self.raw_stiffness.data_ptr()
+            if self.hydro_reduce:
+                self.face_count.zero_()
+                h.reduce = self.hydro_reduce
+                h.shape_aabb_lower, h.shape_aabb_upper, h.shape_voxel_res = (self._red_lo.data_ptr(), self._red_hi.data_ptr(),
+                                                                              self._red_res.data_ptr())
+                h.face_count, h.face_rec, h.face_capacity = self.face_count.data_ptr(), self.face_rec.data_ptr(), self.face_capacity
+                h.out_friction = self.raw_friction.data_ptr()
             _lib.check(lib.nt_hydro_pairs(C.byref(h), stream), "nt_hydro_pairs")
         io = _lib.nt_sdf_rows_io()
         io.pair_count, io.world_pairs, io.blk, io.pair_row = (self.pair_count.data_ptr(), self.world_pairs.data_ptr(),
@@ -245,6 +260,8 @@ class SdfLeg:
             setattr(io, k, getattr(rows, k).data_ptr())
         if self.has_hydro_pairs:
             io.raw_rank, io.raw_stiffness = self.raw_rank.data_ptr(), self.raw_stiffness.data_ptr()
+            if self.hydro_reduce:
+                io.raw_friction = self.raw_friction.data_ptr()
         if rows.stiffness is not None:
             io.stiffness, io.damping, io.friction_scale = rows.stiffness.data_ptr(), rows.damping.data_ptr(), rows.friction_scale.data_ptr()
         _lib.check(lib.nt_sdf_rows_finalize(C.byref(sc), C.byref(io), state._soa["body_q"].data_ptr(), self.world_rows.data_ptr(),
@@ -259,6 +276,10 @@ class SdfLeg:
         info = {"pairs_per_world_max": pc, "pairs_per_world_capacity": self.pairs_per_world, "appended_rows": appended,
                 "rows": total, "row_capacity": rows.capacity}
         over = pc > self.pairs_per_world or appended > self.row_capacity or total > rows.capacity
+        if self.has_hydro_pairs and self.hydro_reduce:
+            info["hydro_faces"], info["hydro_face_capacity"] = int(self.face_count[0].item()), self.face_capacity
+            info["hydro_pairs_truncated"] = int(self.face_count[1].item())
+            over = over or info["hydro_faces"] > self.face_capacity or info["hydro_pairs_truncated"] > 0
         if self.staged:
             fill = self.hit_stripes[::16]
             info["cull_survivors"], info["survivor_capacity"] = int(fill.sum().item()), self.hit_capacity

@@ -251,10 +251,13 @@ def _node_survives(oa, ob, ta, tb, X_b2a, x, y, z, size, margin_a, margin_b, kh_
 
 
 def hydro_pipeline(pairs, shape_transform, shape_data, shape_gap, shape_kh, sdfs, tables, margin_contact_area=1.0e-2,
-                   edge_clamp_min=0.02):
+                   edge_clamp_min=0.02, reduce=None):
     """-> (rows, voxels): rows = list of (pair_idx, fingerprint, shape_a, shape_b, centre_world[3], normal_world[3], separation,
     stiffness) in (pair, voxel traversal, face) order with fingerprint = pair-local voxel rank * 5 + face; voxels = per pair the
-    surviving (x, y, z) list in traversal order.  `sdfs[s]`: TextureSDF of shape s."""
+    surviving (x, y, z) list in traversal order.  `sdfs[s]`: TextureSDF of shape s.
+    reduce = dict(aabb_lo [S,3], aabb_hi [S,3], res [S,3], pre_prune=True, normal_matching=True): the reduce_contacts=True path
+    (reduce_pair_faces): rows then are (pair_idx, fingerprint, shape_a, shape_b, centre, normal, separation, stiffness,
+    friction scale) in export order."""
     X = np.asarray(shape_transform, dtype=f32)
     D = np.asarray(shape_data, dtype=f32)
     rows, vox_all = [], []
@@ -306,6 +309,18 @@ def hydro_pipeline(pairs, shape_transform, shape_data, shape_gap, shape_kh, sdfs
                                 p1 = (p2[0] + c[0], p2[1] + c[1], p2[2] + c[2])
                                 if _node_survives(*args, *p1, 1, *tail):
                                     vox.append(p1)
+        if reduce is not None:
+            faces = []
+            for rank, (x, y, z) in enumerate(vox):
+                for fi, center, normal, sep, _stiff, farea, garea, pressure in _voxel_faces(
+                        oa, ob, ta, tb, X_b2a, x, y, z, tables, *tail, margin_contact_area, edge_clamp_min, full=True):
+                    faces.append(dict(voxel=rank, fp=rank * MAX_MC_FACES_PER_VOXEL + fi, center=center, normal=normal, sep=sep,
+                                      farea=farea, garea=garea, pressure=pressure))
+            for fp, pw, nw, depth, stiff, fscale in reduce_pair_faces(faces, X_b, effective_stiffness(kh_a, kh_b), margin_contact_area,
+                                                                    reduce["aabb_lo"][sb], reduce["aabb_hi"][sb], reduce["res"][sb],
+                                                                    reduce.get("pre_prune", True), reduce.get("normal_matching", True)):
+                rows.append((pair_idx, fp, sa, sb, pw, nw, depth, stiff, fscale))
+            continue
         for rank, (x, y, z) in enumerate(vox):
             for fi, center, normal, sep, stiff in _voxel_faces(oa, ob, ta, tb, X_b2a, x, y, z, tables, *tail, margin_contact_area,
                                                               edge_clamp_min):
@@ -315,7 +330,224 @@ def hydro_pipeline(pairs, shape_transform, shape_data, shape_gap, shape_kh, sdfs
     return rows, vox_all
 
 
-def _voxel_faces(oa, ob, ta, tb, X_b2a, x, y, z, tables, margin_a, margin_b, kh_a, kh_b, gap_sum, margin_contact_area, edge_clamp_min):
+# ---- reduce_contacts=True: aggregates per normal bin in the generate kernel (sdf_hydroelastic.py:2131-2154), local-first pruning
+# (:2156-2312), HydroelasticContactReduction.reduce / export (contact_reduction_hydroelastic.py:596-755, 756-850, 983-1460) for ONE
+# shape pair, the non-deterministic variant (winners ranked by score | contact id, float sums) executed in thread order: contact ids
+# follow the face order, hashtable entries their first use, sums the contact / entry order.  Default options only: no anchor
+# contacts, no moment matching (friction scale 1).
+PRE_PRUNE_MAX_PENETRATING = 2
+BETA_THRESHOLD = f32(0.0001)
+SPECULATIVE_BIN_OFFSET = 128
+EPS_LARGE = f32(1e-8)
+MAXVAL = f32(1.0e10)
+
+
+def _vadd(a, b):
+    return np.array([f32(a[k] + b[k]) for k in range(3)], f32)
+
+
+def _vscale(a, s):
+    return np.array([f32(a[k] * s) for k in range(3)], f32)
+
+
+def _vlen(a):
+    return np.sqrt(_dot3(a, a), dtype=f32)
+
+
+def _value_fast(score, cid):  # _make_contact_value_fast: float_flip(score) << 32 | contact id
+    from oracle_reduce import float_flip  # noqa: PLC0415
+
+    return (float_flip(f32(score)) << 32) | cid
+
+
+def _normal_matching_rotation(nsum, agg, agg_mag):
+    """_compute_normal_matching_rotation (:261-292) -> quaternion (x, y, z, w)."""
+    q = np.array([0, 0, 0, 1], f32)
+    sel_mag = _vlen(nsum)
+    if sel_mag > EPS_LARGE and agg_mag > EPS_SMALL:
+        sel = np.array([f32(nsum[k] / sel_mag) for k in range(3)], f32)
+        ad = np.array([f32(agg[k] / agg_mag) for k in range(3)], f32)
+        cr = _cross3(sel, ad)
+        cr_mag = _vlen(cr)
+        d = _dot3(sel, ad)
+        axis, angle = None, None
+        if cr_mag > EPS_LARGE:
+            axis = np.array([f32(cr[k] / cr_mag) for k in range(3)], f32)
+            angle = np.arccos(min(max(d, f32(-1.0)), f32(1.0)), dtype=f32)
+        elif d < 0.0:
+            perp = np.array([1, 0, 0], f32)
+            if abs(_dot3(sel, perp)) > f32(0.9):
+                perp = np.array([0, 1, 0], f32)
+            c2 = _cross3(sel, perp)
+            l2 = _vlen(c2)
+            axis = np.array([f32(c2[k] / l2) for k in range(3)], f32) if l2 > 0 else np.zeros(3, f32)
+            angle = f32(3.14159265359)
+        if axis is not None:  # wp.quat_from_axis_angle
+            half = f32(angle * f32(0.5))
+            w, sn = np.cos(half, dtype=f32), np.sin(half, dtype=f32)
+            q = np.array([f32(axis[0] * sn), f32(axis[1] * sn), f32(axis[2] * sn), w], f32)
+    return q
+
+
+def _normalize(v):
+    ln = _vlen(v)
+    return np.array([f32(v[k] / ln) for k in range(3)], f32) if ln > 0 else np.zeros(3, f32)
+
+
+def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, res, pre_prune=True, normal_matching=True):
+    """-> rows [(fingerprint, world point, world normal, separation, stiffness, friction scale)] in export order (entries in
+    first-use order, winners in slot order)."""
+    from oracle_reduce import FACE_FRAMES, NUM_NORMAL_BINS, NUM_SPATIAL_DIRECTIONS, SPATIAL_DIRS, VALUES_PER_KEY, get_slot, voxel_index  # noqa: PLC0415
+    from oracle_reduce import decode_oct as dec2  # noqa: PLC0415
+    from oracle_reduce import encode_oct as enc2  # noqa: PLC0415
+
+    entries = {}  # bin id -> dict(slots, agg...)   (insertion order = hashtable active-slot order)
+
+    def entry(bin_id):
+        if bin_id not in entries:
+            entries[bin_id] = dict(bin=bin_id, slots=[0] * VALUES_PER_KEY, agg_force=np.zeros(3, f32), wps=np.zeros(3, f32), ws=f32(0.0),
+                                   adv=np.zeros(3, f32), total_depth=f32(0.0), total_normal=np.zeros(3, f32))
+        return entries[bin_id]
+
+    # ---- generate: aggregates over ALL penetrating faces, buffer = all faces or the voxel-local selection
+    buf = []  # contacts: dict(center, oct, sep, area, pressure, fp)
+    by_voxel = {}
+    for f in faces:
+        by_voxel.setdefault(f["voxel"], []).append(f)
+    for vox in sorted(by_voxel):
+        pen = [None, None]
+        nonpen, nonpen_depth = None, MAXVAL
+        for f in by_voxel[vox]:
+            if f["sep"] < 0.0:
+                e = entry(get_slot(f["normal"]))
+                fw = f32(f["farea"] * f["pressure"])
+                e["agg_force"] = _vadd(e["agg_force"], _vscale(f["normal"], fw))
+                e["wps"] = _vadd(e["wps"], _vscale(f["center"], fw))
+                e["ws"] = f32(e["ws"] + fw)
+                e["adv"] = _vadd(e["adv"], _vscale(f["normal"], f32(f["farea"] * f32(-f["sep"]))))
+            if not pre_prune:
+                buf.append(dict(center=f["center"], oct=enc2(f["normal"]), sep=f["sep"], area=f["farea"] if f["sep"] < 0.0 else f["garea"],
+                                pressure=f["pressure"], fp=f["fp"]))
+                continue
+            if f["sep"] < 0.0:
+                score = f32(f["farea"] * f["pressure"])
+                c = dict(center=f["center"], oct=enc2(f["normal"]), sep=f["sep"], area=f["farea"], pressure=f["pressure"], fp=f["fp"], score=score)
+                if pen[0] is None or score > pen[0]["score"]:
+                    pen[1], pen[0] = pen[0], c
+                elif pen[1] is None or score > pen[1]["score"]:
+                    pen[1] = c
+            elif f["sep"] < nonpen_depth:
+                nonpen_depth = f["sep"]
+                nonpen = dict(center=f["center"], oct=enc2(f["normal"]), sep=f["sep"], area=f["garea"], pressure=f32(0.0), fp=f["fp"])
+        if pre_prune:
+            buf.extend(c for c in (pen[0], pen[1], nonpen) if c is not None)
+    # ---- reduce: register every buffered contact (contact id = position + 1)
+    lo, hi = np.asarray(aabb_lo, f32), np.asarray(aabb_hi, f32)
+    aabb_size = _vlen(np.array([f32(hi[k] - lo[k]) for k in range(3)], f32))
+    nbin_of = {}
+    for i, c in enumerate(buf):
+        cid = i + 1
+        n = dec2(c["oct"])
+        depth = c["sep"]
+        vox = min(max(voxel_index(c["center"], lo, hi, res), 0), 99)
+        if depth >= 0.0:
+            e = entry(SPECULATIVE_BIN_OFFSET + vox // VALUES_PER_KEY)
+            e["slots"][vox % VALUES_PER_KEY] = max(e["slots"][vox % VALUES_PER_KEY], _value_fast(f32(-depth), cid))
+            continue
+        b = get_slot(n)
+        e = entry(b)
+        nbin_of[cid] = b
+        if depth < f32(BETA_THRESHOLD * aabb_size):
+            with np.errstate(all="ignore"):
+                anchor = np.array([f32(e["wps"][k] / e["ws"]) for k in range(3)], f32)
+            rel = np.array([f32(c["center"][k] - anchor[k]) for k in range(3)], f32)
+            u, v = FACE_FRAMES[b]
+            p2 = (_dot3(rel, u), _dot3(rel, v))
+            pen_w = max(f32(-depth), f32(0.0))
+            for d in range(NUM_SPATIAL_DIRECTIONS):
+                score = f32(f32(f32(p2[0] * SPATIAL_DIRS[d][0]) + f32(p2[1] * SPATIAL_DIRS[d][1])) * pen_w)
+                e["slots"][d] = max(e["slots"][d], _value_fast(score, cid))
+        e["slots"][NUM_SPATIAL_DIRECTIONS] = max(e["slots"][NUM_SPATIAL_DIRECTIONS], _value_fast(f32(-depth), cid))
+        ev = entry(NUM_NORMAL_BINS + vox // VALUES_PER_KEY)
+        ev["slots"][vox % VALUES_PER_KEY] = max(ev["slots"][vox % VALUES_PER_KEY], _value_fast(f32(-depth), cid))
+
+    def winners(e):
+        out = []
+        for v in e["slots"]:
+            if v and (v & 0xFFFFFFFF) not in out:
+                out.append(v & 0xFFFFFFFF)
+        return out
+
+    # ---- accumulate_reduced_depth_kernel
+    for e in entries.values():
+        for cid in winners(e):
+            c = buf[cid - 1]
+            if c["sep"] < 0.0:
+                nb = e["bin"] if e["bin"] < NUM_NORMAL_BINS else nbin_of.get(cid, -1)
+                if nb >= 0:
+                    pen = f32(-c["sep"])
+                    t = entries[nb]
+                    t["total_depth"] = f32(t["total_depth"] + pen)
+                    t["total_normal"] = _vadd(t["total_normal"], _vscale(dec2(c["oct"]), pen))
+    # ---- export
+    rows = []
+    mca_k = f32(f32(margin_contact_area) * k_eff)
+    for e in entries.values():
+        ids = winners(e)
+        if not ids:
+            continue
+        agg_mag = _vlen(e["agg_force"])
+        reliable = bool(_vlen(e["adv"]) > EPS_LARGE and agg_mag > EPS_SMALL)
+        rot = np.array([0, 0, 0, 1], f32)
+        if normal_matching and reliable:
+            rot = _normal_matching_rotation(e["total_normal"], e["agg_force"], agg_mag)
+        if normal_matching:
+            eff = _vlen(e["total_normal"])
+            if eff < EPS_LARGE:
+                eff = e["total_depth"]
+        else:
+            eff = e["total_depth"]
+        shared = f32(agg_mag / eff) if (agg_mag > EPS_SMALL and eff > 0.0) else f32(0.0)
+        for cid in ids:
+            c = buf[cid - 1]
+            depth, n = c["sep"], dec2(c["oct"])
+            final = n
+            if reliable:
+                if normal_matching and depth < 0.0:
+                    final = _normalize(_q_rot(rot, n))
+                stiff = shared
+                if shared == 0.0:
+                    stiff = f32(f32(c["area"] * c["pressure"]) / max(f32(-depth), EPS_SMALL)) if depth < 0.0 else mca_k
+            else:
+                nb = nbin_of.get(cid, -1)
+                if nb >= 0 and depth < 0.0:
+                    t = entries[nb]
+                    t_mag = _vlen(t["agg_force"])
+                    t_rel = bool(_vlen(t["adv"]) > EPS_LARGE and t_mag > EPS_SMALL)
+                    if normal_matching and t_rel:
+                        final = _normalize(_q_rot(_normal_matching_rotation(t["total_normal"], t["agg_force"], t_mag), n))
+                    if normal_matching:
+                        t_eff = _vlen(t["total_normal"])
+                        if t_eff < EPS_LARGE:
+                            t_eff = t["total_depth"]
+                    else:
+                        t_eff = t["total_depth"]
+                    if t_mag > EPS_SMALL and t_eff > 0.0:
+                        stiff = f32(t_mag / t_eff)
+                    else:
+                        stiff = f32(f32(c["area"] * c["pressure"]) / max(f32(-depth), EPS_SMALL))
+                elif depth < 0.0:
+                    stiff = f32(f32(c["area"] * c["pressure"]) / max(f32(-depth), EPS_SMALL))
+                else:
+                    stiff = mca_k
+            if depth >= 0.0:
+                stiff = mca_k
+            rows.append((c["fp"], _x_point(X_b, c["center"]), _q_rot(X_b[3:], final), depth, stiff, f32(1.0)))
+    return rows
+
+
+def _voxel_faces(oa, ob, ta, tb, X_b2a, x, y, z, tables, margin_a, margin_b, kh_a, kh_b, gap_sum, margin_contact_area, edge_clamp_min,
+                 full=False):
     """mc_iterate_voxel_vertices + mc_calc_face_texture + the face filters / stiffness of generate + decode for one voxel of B:
     yields (face index, centre in B's frame, normal in B's frame, separation, stiffness)."""
     tri_range, flat = tables
@@ -378,4 +610,7 @@ def _voxel_faces(oa, ob, ta, tb, X_b2a, x, y, z, tables, margin_a, margin_b, kh_
             stiff = f32(f32(area * pressure) / max(f32(-sep), EPS_SMALL))
         else:
             stiff = f32(f32(margin_contact_area) * effective_stiffness(kh_a, kh_b))
-        yield fi, center, normal, sep, stiff
+        if full:
+            yield fi, center, normal, sep, stiff, farea, garea, pressure
+        else:
+            yield fi, center, normal, sep, stiff

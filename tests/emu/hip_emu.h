@@ -118,6 +118,13 @@ inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
     return old;
 }
 
+inline unsigned int atomicMin(unsigned int* p, unsigned int v) {  // ds_min_u32
+    unsigned int old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
 template <typename K>
 inline hipError_t hipFuncSetAttribute(K, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }

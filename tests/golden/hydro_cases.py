@@ -23,4 +23,8 @@ def scenes():
                                         data=np.array([[1, 1, 1, 0.004], [1, 1, 1, 0.002], [1, 1, 1, 0.0]], np.float32),
                                         gap=np.array([0.02, 0.01, 0.01], np.float32), kh=np.array([2.0e7, 1.0e8, 1.0e8], np.float32),
                                         sdfs=[box, sph_fine, sph_fine])
+    for sc in out.values():  # tables the hydroelastic reduction reads: local AABBs (the SDF boxes here) + voxel grids
+        sc["aabb_lo"] = np.array([t.box_lower for t in sc["sdfs"]], np.float32)
+        sc["aabb_hi"] = np.array([t.box_upper for t in sc["sdfs"]], np.float32)
+        sc["res"] = np.array([[5, 4, 3]] * len(sc["sdfs"]), np.int32)
     return out

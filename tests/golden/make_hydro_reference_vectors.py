@@ -112,8 +112,43 @@ def run(s, margin_contact_area=1.0e-2, edge_clamp_min=0.02):
     wp.launch(dec, dim=1, inputs=[1, rd.contact_count, pdata.shape_kh, X, gap, rd.position_depth, rd.normal, rd.shape_pairs,
                                   rd.contact_fingerprints, rd.contact_area, rd.contact_pressure, reducer.capacity], outputs=[w])
     rows = np.asarray(_rows, np.float64).reshape(-1, 12)
-    return dict(normalized=np.array([[int(p[0]), int(p[1])] for p in norm], np.int32).reshape(-1, 2), blocks=nblk.numpy().astype(np.int32),
+    reduced = {}
+    cr = importlib.import_module("newton._src.geometry.contact_reduction_hydroelastic")
+    lo, hi = A(s["aabb_lo"], wp.vec3), A(s["aabb_hi"], wp.vec3)
+    res = wp.Array([wp.vec3i(int(a), int(b), int(c)) for a, b, c in s["res"]])
+    for tag, pre_prune, normal_matching in (("prune_nm", True, True), ("full_nm", False, True), ("prune_plain", True, False)):
+        # generate (aggregates per normal bin, optional local-first pruning) -> reduce -> export, the non-deterministic variant
+        # executed sequentially: contact ids, hashtable entries and float sums in thread order
+        red = cr.HydroelasticContactReduction(capacity=max(16 * n_in, 64), device="cpu", writer_func=recording_writer_reduced,
+                                              config=cr.HydroelasticReductionConfig(normal_matching=normal_matching,
+                                                                                     margin_contact_area=margin_contact_area),
+                                              deterministic=False)
+        red.clear()
+        rd2 = red.get_data_struct()
+        gen2 = hy.get_generate_contacts_kernel(False, pre_prune=pre_prune, deterministic_reduction=False, pressure_func=hy.linear_pressure,
+                                               mc_edge_clamp_min=edge_clamp_min, paired_samples=False)
+        wp.launch(gen2, dim=1, inputs=[1, A(np.array([n_in], np.int32), int), sdf_data, shape_data, X, Xinv, pdata, records, norm,
+                                       A(np.asarray(tri_range, np.int32), int), flat_tab, gap, max(n_in, 1), rd2, lo, hi, res],
+                  outputs=[wp.zeros(0, dtype=wp.vec3), wp.zeros(0, dtype=float), wp.zeros(0, dtype=wp.vec2i)])
+        n_buf = int(rd2.contact_count.numpy()[0])
+        red.reduce(pdata.shape_kh, X, lo, hi, res, 1)
+        w2 = _Writer()
+        w2.contact_count, w2.contact_max = wp.zeros(1, dtype=int), 1 << 30
+        del _rows[:]
+        red.export(pdata.shape_kh, gap, X, w2, 1)
+        r2 = np.asarray(_rows, np.float64).reshape(-1, 13)
+        reduced[f"reduced_{tag}/rows"] = r2.astype(np.float32)
+        reduced[f"reduced_{tag}/ids"] = r2[:, :3].astype(np.int64)
+        reduced[f"reduced_{tag}/buffered"] = np.array([n_buf], np.int32)
+    return dict(**reduced, normalized=np.array([[int(p[0]), int(p[1])] for p in norm], np.int32).reshape(-1, 2), blocks=nblk.numpy().astype(np.int32),
                 levels=np.asarray(levels, np.int32), voxels=vox, rows=rows.astype(np.float32), ids=rows[:, :3].astype(np.int64))
+
+
+@wp.func
+def recording_writer_reduced(c, writer_data, output_index):
+    _rows.append((int(c.shape_a), int(c.shape_b), int(c.sort_sub_key), *[float(x) for x in c.contact_point_center],
+                  *[float(x) for x in c.contact_normal_a_to_b], float(c.contact_distance), float(c.contact_stiffness), float(c.gap_sum),
+                  float(c.contact_friction_scale)))
 
 
 def main():

@@ -1048,6 +1048,8 @@ def mesh_get(mesh_id):
 
 def _make_vector(length=None, dtype=None, *a, **k):
     n = length if length is not None else a[0]
+    if dtype is not None and "int" in getattr(dtype, "__name__", str(dtype)):  # integer components (contact id lists)
+        return type(f"vec{n}i_", (_ivec,), {"N": n})
 
     class _Vec:
         __array_ufunc__ = None

@@ -399,11 +399,14 @@ def hydro_scene(world_count, device=None, seed=21):
     return model
 
 
-def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_solver():
+@pytest.mark.parametrize("reduce", [False, True])
+def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_solver(reduce):
     """CollisionPipeline(sdf_hydroelastic_config=HydroelasticSDF.Config(reduce_contacts=False)): pairs of two HYDROELASTIC shapes take
     the SDF-SDF leg (SAT, octree, marching cubes: rows with Contacts.rigid_contact_stiffness), other SDF pairs the edge leg, both in
     one row set; against the checker chain (oracle_hydro.hydro_pipeline is pinned by the executed reference), two runs bitwise,
-    and SolverSemiImplicit consuming the per-contact stiffness like the checker's eval_body_contact."""
+    and SolverSemiImplicit consuming the per-contact stiffness like the checker's eval_body_contact.
+    reduce: HydroelasticSDF.Config() as it comes (reduce_contacts, pre_prune_contacts, normal_matching): per-bin aggregates, voxel-
+    local pruning, the pair's table, winners with the aggregate stiffness and matched normals (contact_reduction_hydroelastic.py)."""
     import torch
 
     import newton_amd as nt
@@ -420,7 +423,7 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     t = model.env
     # hydroelastic: pad-ball, pad-hull, ball-hull | edge contacts: pad-other, hull-other | tiles: ball-other (MPR / GJK) + four plane pairs
     assert t.sdf_pair_hydro.sum() == 3 and (~t.sdf_pair_hydro).sum() == 2 and t.np == 5
-    cfg = nt.geometry.HydroelasticSDF.Config(reduce_contacts=False)
+    cfg = nt.geometry.HydroelasticSDF.Config() if reduce else nt.geometry.HydroelasticSDF.Config(reduce_contacts=False)
     pipe = nt.CollisionPipeline(model, broad_phase="sap", sdf_hydroelastic_config=cfg, sdf_contacts_per_shape=400)
     c1, c2 = pipe.contacts(), pipe.contacts()
     s0, s1 = model.state(), model.state()
@@ -447,7 +450,9 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     want = {k: [] for k in ("world", "key", "shape0", "shape1", "point0", "normal", "stiffness")}
     for w in range(E):
         hp = [p for p, kind in cand[w] if kind]
-        rows, _ = H.hydro_pipeline(np.asarray(hp, np.int32), X, data, gap, kh, sdfs, tab) if hp else ([], None)
+        red = dict(aabb_lo=np.asarray(model.shape_collision_aabb_lower, np.float32), aabb_hi=np.asarray(model.shape_collision_aabb_upper, np.float32),
+                   res=np.asarray(model._shape_voxel_resolution, np.int32), pre_prune=True, normal_matching=True) if reduce else None
+        rows, _ = H.hydro_pipeline(np.asarray(hp, np.int32), X, data, gap, kh, sdfs, tab, reduce=red) if hp else ([], None)
         per_pair = {}
         for r in rows:
             per_pair.setdefault(hp[r[0]], []).append(r)
@@ -471,12 +476,15 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
                 want["stiffness"] += [0.0] * int(sel.sum())
                 for k in ("shape0", "shape1", "point0", "normal"):
                     want[k] += list(m[k][sel])
-    assert len(want["key"]) == n > 100 and (np.asarray(want["stiffness"]) > 0).sum() > 50 and (np.asarray(want["stiffness"]) == 0).sum() > 0
+    lim = (20, 10) if reduce else (100, 50)
+    assert len(want["key"]) == n > lim[0] and (np.asarray(want["stiffness"]) > 0).sum() > lim[1] and (np.asarray(want["stiffness"]) == 0).sum() > 0
     assert np.array_equal(a["key"], np.asarray(want["key"])) and np.array_equal(a["shape0"], np.asarray(want["shape0"]))
     assert np.array_equal(a["shape1"], np.asarray(want["shape1"]))
     assert np.abs(a["point0"] - np.asarray(want["point0"])).max() <= 2e-6 and np.abs(a["normal"] - np.asarray(want["normal"])).max() <= 2e-6
     ws = np.asarray(want["stiffness"], np.float32)
     assert np.abs(stiff - ws).max() <= 1e-5 * np.abs(ws).max()
+    fric = f.friction_scale[:n].cpu().numpy()
+    assert np.array_equal(fric, np.where((ws > 0) & reduce, 1.0, 0.0).astype(np.float32))  # reduced hydroelastic rows carry scale 1
     # ---- SolverSemiImplicit consumes the per-contact stiffness (kernels_contact.py:452-459) like the checker
     solver = nt.solvers.SolverSemiImplicit(model)
     solver.step(s0, s1, model.control(), c1, 1.0e-4)
@@ -491,7 +499,9 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     oc.count[0] = n0 + n
     st = np.zeros(oc.max, np.float32)
     st[n0:n0 + n] = stiff
-    oc.set_properties(st, np.zeros(oc.max, np.float32), np.zeros(oc.max, np.float32))
+    fr = np.zeros(oc.max, np.float32)
+    fr[n0:n0 + n] = fric
+    oc.set_properties(st, np.zeros(oc.max, np.float32), fr)
     os0, os1 = OracleState(host), OracleState(host)
     o.semi_implicit_step(os0, os1, o.control(), oc, 1.0e-4)
     dq, dv = np.abs(s1.body_q.cpu().numpy() - os1.body_q).max(), np.abs(s1.body_qd.cpu().numpy() - os1.body_qd).max()
