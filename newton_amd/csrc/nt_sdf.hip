@@ -1539,6 +1539,8 @@ constexpr int HYDRO_STAGE = 256;
 constexpr int HYDRO_FACE_WORDS = 12;   // centre[3] normal[3] separation area pressure | key | contact id << 5 | normal bin | pad
 struct HydroRedLds {
     int chunk[HYDRO_CHUNK_CAP][2];
+    int cstart[HYDRO_CHUNK_CAP];                  // rank of the block's first face inside the pair (blocks are small and scattered:
+                                                  // the passes below walk the pair's faces by RANK, all lanes busy, not block by block)
     float agg[RED_BINS][10];                      // agg_force[3] weighted_pos_sum[3] weight_sum agg_depth_volume[3]
     float tdepth[RED_BINS], tnormal[RED_BINS][3]; // total_depth_reduced / total_normal_reduced
     unsigned long long tbl[HYDRO_ENTRIES][RED_VALUES];
@@ -1548,7 +1550,8 @@ struct HydroRedLds {
     float wpen[HYDRO_ENTRIES * RED_VALUES], wn[HYDRO_ENTRIES * RED_VALUES][3];
     int wnbin[HYDRO_ENTRIES * RED_VALUES];
     unsigned char wuniq[HYDRO_ENTRIES * RED_VALUES];
-    int n_chunk, pair_kept, overflow, rows, row_base;
+    short seq[HYDRO_ENTRIES * RED_VALUES];
+    int n_chunk, n_faces, pair_kept, overflow, rows, row_base;
     float stage[HYDRO_STAGE][9];  // a tile of face records for the ordered aggregate sums
     signed char stage_bin[HYDRO_STAGE];
 };
@@ -1590,6 +1593,15 @@ NT_DI quat hydro_matching_rotation(vec3 nsum, vec3 agg, float agg_mag) {  // _co
 NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
     const int t = threadIdx.x, nt_ = blockDim.x;
     const bool normal_matching = (a.reduce & 4) != 0;
+    auto face_slot = [&](int rank) {  // rank of a face inside the pair -> its record (the last block that starts at or before it)
+        int lo = 0, hi = R.n_chunk;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (R.cstart[mid] <= rank) lo = mid;
+            else hi = mid;
+        }
+        return R.chunk[lo][0] + (rank - R.cstart[lo]);
+    };
     for (int k = t; k < HYDRO_ENTRIES * RED_VALUES; k += nt_) {
         R.tbl[k / RED_VALUES][k % RED_VALUES] = 0ull;
         R.tslot[k / RED_VALUES][k % RED_VALUES] = -1;
@@ -1603,34 +1615,33 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         vec3 force, wps, adv;
         float ws = 0.0f;
         unsigned int first = ~0u;
-        int rank = 0;
-        for (int c = 0; c < R.n_chunk; ++c) {
-            const int base = R.chunk[c][0], cnt = R.chunk[c][1];
-            for (int k0 = 0; k0 < cnt; k0 += HYDRO_STAGE) {
-                const int m = cnt - k0 < HYDRO_STAGE ? cnt - k0 : HYDRO_STAGE;
-                for (int k = t; k < m; k += nt_) {
-                    const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + k0 + k);
-                    float* o = R.stage[k];
-                    o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2]; o[3] = rec[3]; o[4] = rec[4]; o[5] = rec[5];
-                    o[6] = rec[6]; o[7] = rec[7]; o[8] = rec[8];
-                    R.stage_bin[k] = rec[6] < 0.0f ? (reinterpret_cast<const int*>(rec)[10] & 31) : -1;
-                }
-                __syncthreads();
-                if (t < RED_BINS)
-                    for (int k = 0; k < m; ++k) {
-                        if (R.stage_bin[k] != t) continue;
-                        const float* rec = R.stage[k];
-                        const vec3 n(rec[3], rec[4], rec[5]), ctr(rec[0], rec[1], rec[2]);
-                        const float fw = rec[7] * rec[8];
-                        force += fw * n;
-                        wps += fw * ctr;
-                        ws += fw;
-                        adv += (rec[7] * (-rec[6])) * n;
-                        if (first == ~0u) first = (unsigned int)(rank + k);
-                    }
-                rank += m;
-                __syncthreads();
+        for (int r0 = 0; r0 < R.n_faces; r0 += HYDRO_STAGE) {
+            const int m = R.n_faces - r0 < HYDRO_STAGE ? R.n_faces - r0 : HYDRO_STAGE;
+            for (int k = t; k < m; k += nt_) {
+                const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(r0 + k);
+                float* o = R.stage[k];
+                o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2]; o[3] = rec[3]; o[4] = rec[4]; o[5] = rec[5];
+                o[6] = rec[6]; o[7] = rec[7]; o[8] = rec[8];
+                R.stage_bin[k] = rec[6] < 0.0f ? (reinterpret_cast<const int*>(rec)[10] & 31) : -1;
             }
+            __syncthreads();
+#ifndef NT_HYDRO_SKIP_AGG
+            if (t < RED_BINS)
+#else
+            if (false)
+#endif
+                for (int k = 0; k < m; ++k) {
+                    if (R.stage_bin[k] != t) continue;
+                    const float* rec = R.stage[k];
+                    const vec3 n(rec[3], rec[4], rec[5]), ctr(rec[0], rec[1], rec[2]);
+                    const float fw = rec[7] * rec[8];
+                    force += fw * n;
+                    wps += fw * ctr;
+                    ws += fw;
+                    adv += (rec[7] * (-rec[6])) * n;
+                    if (first == ~0u) first = (unsigned int)(r0 + k);
+                }
+            __syncthreads();
         }
       if (t < RED_BINS) {
         float* g = R.agg[t];
@@ -1642,15 +1653,18 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
       }
     }
     __syncthreads();
+#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 1
+    return;
+#endif
     // ---- table registration (pass 0) and the winners' record positions (pass 1), one lane per buffered contact
     const float* lo = a.shape_aabb_lower + 3 * p.sb;
     const float* hi = a.shape_aabb_upper + 3 * p.sb;
     const float aabb_size = length(vec3(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]));
     for (int pass = 0; pass < 2; ++pass) {
-        for (int c = 0; c < R.n_chunk; ++c) {
-            const int base = R.chunk[c][0], cnt = R.chunk[c][1];
-            for (int k = t; k < cnt; k += nt_) {
-                const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + k);
+        {
+            for (int j = t; j < R.n_faces; j += nt_) {
+                const int fslot = face_slot(j);
+                const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)fslot;
                 const int cid = reinterpret_cast<const int*>(rec)[10] >> 5;
                 if (cid <= 0) continue;
                 const unsigned int ucid = (unsigned int)cid;
@@ -1659,7 +1673,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
                         atomicMax(&R.tbl[e][s], hydro_value(score, cid));
                         atomicMin(&R.ekey[e], key);
                     } else if ((unsigned int)(R.tbl[e][s] & 0xFFFFFFFFull) == ucid) {
-                        R.tslot[e][s] = base + k;
+                        R.tslot[e][s] = fslot;
                     }
                 };
                 const vec3 ctr(rec[0], rec[1], rec[2]);
@@ -1690,6 +1704,9 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         }
         __syncthreads();
     }
+#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 2
+    return;
+#endif
     // ---- winners: unique contacts of every entry in slot order, their depth / decoded normal / normal bin
     for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {
         const int e = i / RED_VALUES, sl = i % RED_VALUES;
@@ -1709,6 +1726,9 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         atomicAdd(&R.ucount[e], 1);
     }
     __syncthreads();
+#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 3
+    return;
+#endif
     // ---- entries in insertion order; reduced depth / normal sums in that order (one lane: <= 350 short steps on LDS)
     if (t < HYDRO_ENTRIES) {
         int rank = -1;
@@ -1730,21 +1750,35 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
             const int e = R.order[r];
             R.ubase[e] = rows;
             rows += R.ucount[e];
-            for (int sl = 0; sl < RED_VALUES; ++sl) {
-                const int i = e * RED_VALUES + sl;
-                if (!R.wuniq[i] || !(R.wpen[i] > 0.0f) || R.wnbin[i] < 0) continue;  // depth < 0 <=> pen > 0
-                const int nb = R.wnbin[i];
-                const float pen = R.wpen[i];
-                R.tdepth[nb] += pen;
-                R.tnormal[nb][0] += pen * R.wn[i][0];
-                R.tnormal[nb][1] += pen * R.wn[i][1];
-                R.tnormal[nb][2] += pen * R.wn[i][2];
-            }
         }
         R.rows = rows;
         R.row_base = rows > 0 ? atomicAdd(a.out_count, rows) : 0;
     }
     __syncthreads();
+    for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {  // the winners in export order (entry order, then slot order)
+        if (!R.wuniq[i]) continue;
+        const int e = i / RED_VALUES, sl = i % RED_VALUES;
+        int idx = 0;
+        for (int s2 = 0; s2 < sl; ++s2) idx += R.wuniq[e * RED_VALUES + s2];
+        R.seq[R.ubase[e] + idx] = (short)i;
+    }
+    __syncthreads();
+    if (t == 0) {  // ... whose depths / normals are summed per normal bin in that order: a short serial walk (the pair's rows)
+        for (int r = 0; r < R.rows; ++r) {
+            const int i = R.seq[r];
+            if (!(R.wpen[i] > 0.0f) || R.wnbin[i] < 0) continue;  // depth < 0 <=> pen > 0
+            const int nb = R.wnbin[i];
+            const float pen = R.wpen[i];
+            R.tdepth[nb] += pen;
+            R.tnormal[nb][0] += pen * R.wn[i][0];
+            R.tnormal[nb][1] += pen * R.wn[i][1];
+            R.tnormal[nb][2] += pen * R.wn[i][2];
+        }
+    }
+    __syncthreads();
+#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 4
+    return;
+#endif
     // ---- export
     const float den = p.kh_a + p.kh_b;
     const float mca_k = a.margin_contact_area * (den <= 0.0f ? 0.0f : (p.kh_a * p.kh_b) / den);
@@ -1843,7 +1877,7 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
             L.pair_vox = 0;
             L.pair_face = 0;
             L.collide = 0;
-            if constexpr (REDUCE) { R.n_chunk = 0; R.pair_kept = 0; R.overflow = 0; R.rows = 0; }
+            if constexpr (REDUCE) { R.n_chunk = 0; R.n_faces = 0; R.pair_kept = 0; R.overflow = 0; R.rows = 0; }
             if (ok) {  // SAT of the two SDF boxes (centred transforms), before the finer-is-B swap like the reference
                 const xform Xa = load_xform(a.shape_transform + 7 * p.sa), Xb = load_xform(a.shape_transform + 7 * p.sb);
                 const vec3 alo(p.A.box_lower[0], p.A.box_lower[1], p.A.box_lower[2]), ahi(p.A.box_upper[0], p.A.box_upper[1], p.A.box_upper[2]);
@@ -1988,6 +2022,8 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
                                 if (R.n_chunk < HYDRO_CHUNK_CAP && L.base + total <= a.face_capacity) {
                                     R.chunk[R.n_chunk][0] = L.base;
                                     R.chunk[R.n_chunk][1] = total;
+                                    R.cstart[R.n_chunk] = R.n_faces;
+                                    R.n_faces += total;
                                     R.n_chunk += 1;
                                 } else {
                                     R.overflow = 1;  // the pair loses these faces: reported through face_count[1]
@@ -2053,7 +2089,9 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
         }
         __syncthreads();
         if constexpr (REDUCE) {
+#ifndef NT_HYDRO_SKIP_REDUCE  // (measurement builds)
             if (L.pair_face > 0) hydro_reduce_pair(a, p, pair_idx, R);  // (uniform)
+#endif
             if (t == 0) {
                 if (R.overflow) atomicAdd(a.face_count + 1, 1);
                 a.out_blk[2 * (size_t)pair_idx] = 0;

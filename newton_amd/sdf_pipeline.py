@@ -274,7 +274,8 @@ class SdfLeg:
         appended = int(self.raw_count.item()) - self.hit_capacity  # rows that came through the counter
         total = int(rows.row_start[-1].item())
         info = {"pairs_per_world_max": pc, "pairs_per_world_capacity": self.pairs_per_world, "appended_rows": appended,
-                "rows": total, "row_capacity": rows.capacity}
+                "rows": total, "row_capacity": rows.capacity, "candidate_pairs": int(self.pair_prefix[-1].item()),
+                "pairs_with_rows": int((self.blk[:, 1] > 0).sum().item())}
         over = pc > self.pairs_per_world or appended > self.row_capacity or total > rows.capacity
         if self.has_hydro_pairs and self.hydro_reduce:
             info["hydro_faces"], info["hydro_face_capacity"] = int(self.face_count[0].item()), self.face_capacity

@@ -7,7 +7,11 @@ The reference finds the voxels that carry iso-surface faces with a block broad p
 restatement visits every voxel of the finer SDF's grid inside the other SDF's box, which yields the same voxel set as long as
 that search has no false negatives (its purpose).  Marching-cubes case tables: newton_amd/mc_tables.py (Warp's own table is not
 in /root/reference; triangulations of a case may differ, the surface does not).  The octahedral normal encoding of the contact
-buffer (a storage format) is skipped.  Only tests/ may import this."""
+buffer (a storage format) is skipped.  The reduce_contacts=True path (per-bin aggregates, local-first pruning,
+HydroelasticContactReduction.reduce / export of contact_reduction_hydroelastic.py) is restated in reduce_pair_faces below.
+PINNED: tests/golden/hydro_reference_vectors.npz holds the outputs of the reference's own kernels executed on the stand-in
+(make_hydro_reference_vectors.py); hydro_pipeline reproduces them bit for bit, reduced and unreduced
+(tests/test_hydro_reference_vectors.py).  Only tests/ may import this."""
 from __future__ import annotations
 
 import os
