@@ -1532,6 +1532,19 @@ NT_DI int hydro_voxel_faces(const nt_hydro_args& a, const HydroPair& p, int x, i
     return kept;
 }
 
+#ifdef NT_HYDRO_TIMING  // measurement builds (tools/hydro_timing.py): cycles of workgroup lane 0 per phase, summed over all pairs
+__device__ unsigned long long nt_hydro_timing[16];
+#define NT_HT(i, t_last)                                                  \
+    do {                                                                  \
+        if (threadIdx.x == 0) {                                           \
+            const unsigned long long now_ = clock64();                    \
+            atomicAdd(&nt_hydro_timing[i], now_ - (t_last));              \
+            (t_last) = now_;                                              \
+        }                                                                 \
+    } while (0)
+#else
+#define NT_HT(i, t_last) do { } while (0)
+#endif
 // ---- reduce_contacts = True: what the workgroup keeps of a pair between the face pass and the reduction (see hydro_reduce_pair)
 constexpr int HYDRO_CHUNK_CAP = 1024;  // face blocks of one pair (one per 256 voxels that carry faces)
 constexpr int HYDRO_ENTRIES = 50;      // 20 normal bins + 15 voxel groups + 15 speculative voxel groups
@@ -1593,6 +1606,9 @@ NT_DI quat hydro_matching_rotation(vec3 nsum, vec3 agg, float agg_mag) {  // _co
 NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
     const int t = threadIdx.x, nt_ = blockDim.x;
     const bool normal_matching = (a.reduce & 4) != 0;
+#ifdef NT_HYDRO_TIMING
+    unsigned long long ht = clock64();
+#endif
     auto face_slot = [&](int rank) {  // rank of a face inside the pair -> its record (the last block that starts at or before it)
         int lo = 0, hi = R.n_chunk;
         while (hi - lo > 1) {
@@ -1625,11 +1641,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
                 R.stage_bin[k] = rec[6] < 0.0f ? (reinterpret_cast<const int*>(rec)[10] & 31) : -1;
             }
             __syncthreads();
-#ifndef NT_HYDRO_SKIP_AGG
             if (t < RED_BINS)
-#else
-            if (false)
-#endif
                 for (int k = 0; k < m; ++k) {
                     if (R.stage_bin[k] != t) continue;
                     const float* rec = R.stage[k];
@@ -1653,9 +1665,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
       }
     }
     __syncthreads();
-#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 1
-    return;
-#endif
+    NT_HT(1, ht);
     // ---- table registration (pass 0) and the winners' record positions (pass 1), one lane per buffered contact
     const float* lo = a.shape_aabb_lower + 3 * p.sb;
     const float* hi = a.shape_aabb_upper + 3 * p.sb;
@@ -1704,9 +1714,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         }
         __syncthreads();
     }
-#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 2
-    return;
-#endif
+    NT_HT(2, ht);
     // ---- winners: unique contacts of every entry in slot order, their depth / decoded normal / normal bin
     for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {
         const int e = i / RED_VALUES, sl = i % RED_VALUES;
@@ -1726,9 +1734,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         atomicAdd(&R.ucount[e], 1);
     }
     __syncthreads();
-#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 3
-    return;
-#endif
+    NT_HT(3, ht);
     // ---- entries in insertion order; reduced depth / normal sums in that order (one lane: <= 350 short steps on LDS)
     if (t < HYDRO_ENTRIES) {
         int rank = -1;
@@ -1776,9 +1782,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         }
     }
     __syncthreads();
-#if defined(NT_HYDRO_STOP_AFTER) && NT_HYDRO_STOP_AFTER == 4
-    return;
-#endif
+    NT_HT(4, ht);
     // ---- export
     const float den = p.kh_a + p.kh_b;
     const float mca_k = a.margin_contact_area * (den <= 0.0f ? 0.0f : (p.kh_a * p.kh_b) / den);
@@ -1845,6 +1849,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         if (a.out_friction) a.out_friction[slot] = 1.0f;
     }
     __syncthreads();
+    NT_HT(5, ht);
 }
 
 template <bool REDUCE>
@@ -1862,6 +1867,9 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
         }
         const int pair_idx = lo * a.pairs_per_world + (f - a.pair_world_prefix[lo]);
         if (a.pair_kind[pair_idx] != 1) continue;
+#ifdef NT_HYDRO_TIMING
+        unsigned long long hk = clock64();
+#endif
         HydroPair p;
         p.sa = a.pairs[2 * (size_t)pair_idx];
         p.sb = a.pairs[2 * (size_t)pair_idx + 1];
@@ -2053,8 +2061,7 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
                             oi[10] = (cid << 5) | red_get_slot(fc.normal);
                             oi[11] = 0;
                         }
-                        __threadfence();
-                        __syncthreads();
+                        __syncthreads();  // (no device-scope fence here: it would drop the L1 the SDF samples of the next voxels hit)
                         if (t == 0) { L.pair_face += L.n_face; R.pair_kept += sel_total; }
                         __syncthreads();
                         continue;
@@ -2088,10 +2095,16 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
             }
         }
         __syncthreads();
+        NT_HT(0, hk);
         if constexpr (REDUCE) {
-#ifndef NT_HYDRO_SKIP_REDUCE  // (measurement builds)
-            if (L.pair_face > 0) hydro_reduce_pair(a, p, pair_idx, R);  // (uniform)
+#ifdef NT_HYDRO_TIMING
+            if (t == 0) { atomicAdd(&nt_hydro_timing[8], 1ull); if (L.pair_face > 0) { atomicAdd(&nt_hydro_timing[9], 1ull); atomicAdd(&nt_hydro_timing[10], (unsigned long long)R.n_chunk); } }
 #endif
+            if (L.pair_face > 0) {  // (uniform)
+                __threadfence();  // the pair's face records, written by all lanes, are read back by other lanes below
+                __syncthreads();
+                hydro_reduce_pair(a, p, pair_idx, R);
+            }
             if (t == 0) {
                 if (R.overflow) atomicAdd(a.face_count + 1, 1);
                 a.out_blk[2 * (size_t)pair_idx] = 0;
@@ -2121,6 +2134,11 @@ nt_status nt_hydro_collide(const nt_hydro_args* a, void* stream) {
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 
+#ifdef NT_HYDRO_TIMING
+nt_status nt_hydro_timing_read(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(nt_hydro_timing), sizeof(unsigned long long) * 16) == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+#endif
 nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
     if (!a || !a->pairs || !a->pair_world_prefix || a->worlds <= 0 || a->pairs_per_world <= 0 || !a->pair_kind || !a->out_blk ||
         !a->out_rank || !a->out_stiffness || !a->out_count || !a->out_pair || !a->out_key || !a->out_data || a->capacity <= 0 ||
