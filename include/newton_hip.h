@@ -569,9 +569,11 @@ typedef struct {
      * (6 spatial extremes + deepest) + 100 voxel slots, + 100 speculative voxel slots), and the winners leave with the bin's
      * aggregate stiffness |agg force| / sum of their depths and, with normal matching, normals rotated so that their weighted sum is
      * the aggregate force direction.  The non-deterministic variant of the reference evaluated in thread order (contact ids follow the
-     * face order, sums the contact order); anchor contacts / moment matching are not offered.  The pair's rows are contiguous,
+     * face order, sums the contact order).  The pair's rows are contiguous,
      * out_blk = (0, rows), out_rank = position in the pair's export order.  All 0 / NULL: unreduced. */
-    int32_t reduce;                  /* bit 0: reduce, bit 1: pre_prune_contacts, bit 2: normal_matching */
+    int32_t reduce;                  /* bit 0: reduce, bit 1: pre_prune_contacts, bit 2: normal_matching, bit 3: anchor_contact (an
+                                        extra row per normal bin at its centre of pressure, key 0x400000 | bin), bit 4: moment_matching
+                                        (friction scales that preserve the bin's friction moment; implies anchors) */
     const float* shape_aabb_lower;   /* [S][3] Model.shape_collision_aabb_lower (shape-local) */
     const float* shape_aabb_upper;   /* [S][3] */
     const int32_t* shape_voxel_res;  /* [S][3] Model._shape_voxel_resolution */

@@ -1564,6 +1564,10 @@ struct HydroRedLds {
     int wnbin[HYDRO_ENTRIES * RED_VALUES];
     unsigned char wuniq[HYDRO_ENTRIES * RED_VALUES];
     short seq[HYDRO_ENTRIES * RED_VALUES];
+    float m_unr[RED_BINS], s1[RED_BINS], s2[RED_BINS];  // moment matching: unreduced / reduced friction moments per normal bin
+    float wlever[HYDRO_ENTRIES * RED_VALUES];           // ... lever arm of a winner about its bin's centre of pressure
+    float max_pen[HYDRO_ENTRIES];                        // deepest winner of the entry
+    unsigned char anchor[HYDRO_ENTRIES];                 // the entry exports an anchor contact
     int n_chunk, n_faces, pair_kept, overflow, rows, row_base;
     float stage[HYDRO_STAGE][9];  // a tile of face records for the ordered aggregate sums
     signed char stage_bin[HYDRO_STAGE];
@@ -1603,9 +1607,11 @@ NT_DI quat hydro_matching_rotation(vec3 nsum, vec3 agg, float agg_mag) {  // _co
 // The reduction of ONE pair after its faces are in a.face_rec (blocks listed in R.chunk, face order): aggregates per normal bin
 // (ordered sums, one lane per bin), table registration of the buffered contacts, winners, reduced depth sums in the hashtable's
 // insertion order, export.  contact_reduction_hydroelastic.py:596-755 (reduce), :756-850 (accumulate depth), :983-1460 (export).
+struct EntryExport { vec3 anchor_pos; float shared, alpha, l_avg, uniform_fs, anchor_fs; };
 NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
     const int t = threadIdx.x, nt_ = blockDim.x;
-    const bool normal_matching = (a.reduce & 4) != 0;
+    const bool normal_matching = (a.reduce & 4) != 0, moment_matching = (a.reduce & 16) != 0;
+    const bool anchor_contact = (a.reduce & 8) != 0 || moment_matching;
 #ifdef NT_HYDRO_TIMING
     unsigned long long ht = clock64();
 #endif
@@ -1664,7 +1670,42 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         if (first != ~0u) R.ekey[t] = first;
       }
     }
+    if (t < RED_BINS) R.m_unr[t] = R.s1[t] = R.s2[t] = 0.0f;
     __syncthreads();
+    if (moment_matching) {
+        // unreduced friction moment of every buffered penetrating contact about its bin's centre of pressure (:717-727), summed per
+        // bin in CONTACT order.  Contact ids follow the voxels but, inside a pruned voxel, not the faces: word 11 of the record at
+        // rank (cid - 1) receives the rank of contact cid, then the contacts pass through LDS in tiles like the faces above.
+        for (int j = t; j < R.n_faces; j += nt_) {
+            const int cid = reinterpret_cast<const int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(j))[10] >> 5;
+            if (cid > 0) reinterpret_cast<int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(cid - 1))[11] = j;
+        }
+        __threadfence();
+        __syncthreads();
+        for (int c0 = 0; c0 < R.pair_kept; c0 += HYDRO_STAGE) {
+            const int m = R.pair_kept - c0 < HYDRO_STAGE ? R.pair_kept - c0 : HYDRO_STAGE;
+            for (int k = t; k < m; k += nt_) {
+                const int rank = reinterpret_cast<const int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(c0 + k))[11];
+                const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(rank);
+                R.stage_bin[k] = -1;
+                if (!(rec[6] < 0.0f)) continue;
+                float ox, oy;
+                red_encode_oct(vec3(rec[3], rec[4], rec[5]), ox, oy);
+                const vec3 n = red_decode_oct(ox, oy);
+                const int b = red_get_slot(n);
+                const float* g = R.agg[b];
+                if (!(g[6] > 1e-20f)) continue;
+                const vec3 anchor_pos = vec3(g[3], g[4], g[5]) / g[6];
+                R.stage[k][0] = rec[7] * rec[8] * length(cross(vec3(rec[0], rec[1], rec[2]) - anchor_pos, n));
+                R.stage_bin[k] = (signed char)b;
+            }
+            __syncthreads();
+            if (t < RED_BINS)
+                for (int k = 0; k < m; ++k)
+                    if (R.stage_bin[k] == t) R.m_unr[t] += R.stage[k][0];
+            __syncthreads();
+        }
+    }
     NT_HT(1, ht);
     // ---- table registration (pass 0) and the winners' record positions (pass 1), one lane per buffered contact
     const float* lo = a.shape_aabb_lower + 3 * p.sb;
@@ -1722,13 +1763,13 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         if (v == 0ull) continue;
         bool uniq = true;
         for (int s2 = 0; s2 < sl; ++s2) uniq = uniq && (R.tbl[e][s2] & 0xFFFFFFFFull) != (v & 0xFFFFFFFFull);
-        if (!uniq) continue;
         const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)R.tslot[e][sl];
+        R.wpen[i] = -rec[6];  // (every occupied slot: a voxel entry reads its bin's deepest-contact slot)
+        if (!uniq) continue;
         float ox, oy;
         red_encode_oct(vec3(rec[3], rec[4], rec[5]), ox, oy);
         const vec3 n = red_decode_oct(ox, oy);
         R.wuniq[i] = 1;
-        R.wpen[i] = -rec[6];
         R.wn[i][0] = n.x; R.wn[i][1] = n.y; R.wn[i][2] = n.z;
         R.wnbin[i] = e < RED_BINS ? e : (rec[6] < 0.0f ? red_get_slot(n) : -1);
         atomicAdd(&R.ucount[e], 1);
@@ -1737,6 +1778,16 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
     NT_HT(3, ht);
     // ---- entries in insertion order; reduced depth / normal sums in that order (one lane: <= 350 short steps on LDS)
     if (t < HYDRO_ENTRIES) {
+        float mp = 0.0f;
+        for (int sl = 0; sl < RED_VALUES; ++sl)
+            if (R.wuniq[t * RED_VALUES + sl] && R.wpen[t * RED_VALUES + sl] > 0.0f) mp = fmaxw(mp, R.wpen[t * RED_VALUES + sl]);
+        R.max_pen[t] = mp;
+        bool anc = false;
+        if (anchor_contact && t < RED_BINS && R.ucount[t] > 0) {  // reliable aggregate direction, a penetrating winner, a weight
+            const float* g = R.agg[t];
+            anc = length(vec3(g[7], g[8], g[9])) > 1e-8f && length(vec3(g[0], g[1], g[2])) > 1e-20f && mp > 0.0f && g[6] > 1e-20f;
+        }
+        R.anchor[t] = anc ? 1 : 0;
         int rank = -1;
         if (R.ekey[t] != ~0u) {
             rank = 0;
@@ -1755,13 +1806,14 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         for (int r = 0; r < R.n_entries; ++r) {
             const int e = R.order[r];
             R.ubase[e] = rows;
-            rows += R.ucount[e];
+            rows += R.ucount[e] + R.anchor[e];
         }
         R.rows = rows;
         R.row_base = rows > 0 ? atomicAdd(a.out_count, rows) : 0;
     }
     __syncthreads();
     for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {  // the winners in export order (entry order, then slot order)
+        if (i % RED_VALUES == 0 && R.anchor[i / RED_VALUES]) R.seq[R.ubase[i / RED_VALUES] + R.ucount[i / RED_VALUES]] = -1;  // its anchor
         if (!R.wuniq[i]) continue;
         const int e = i / RED_VALUES, sl = i % RED_VALUES;
         int idx = 0;
@@ -1772,7 +1824,7 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
     if (t == 0) {  // ... whose depths / normals are summed per normal bin in that order: a short serial walk (the pair's rows)
         for (int r = 0; r < R.rows; ++r) {
             const int i = R.seq[r];
-            if (!(R.wpen[i] > 0.0f) || R.wnbin[i] < 0) continue;  // depth < 0 <=> pen > 0
+            if (i < 0 || !(R.wpen[i] > 0.0f) || R.wnbin[i] < 0) continue;  // depth < 0 <=> pen > 0
             const int nb = R.wnbin[i];
             const float pen = R.wpen[i];
             R.tdepth[nb] += pen;
@@ -1786,6 +1838,38 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
     // ---- export
     const float den = p.kh_a + p.kh_b;
     const float mca_k = a.margin_contact_area * (den <= 0.0f ? 0.0f : (p.kh_a * p.kh_b) / den);
+    auto matched_normal = [&](int nb, vec3 n) {  // the winner's normal after its bin's matching rotation (gate: reliable direction)
+        const float* g = R.agg[nb];
+        const vec3 agg(g[0], g[1], g[2]);
+        const float mag = length(agg);
+        if (normal_matching && length(vec3(g[7], g[8], g[9])) > 1e-8f && mag > 1e-20f)
+            return normalize(quat_rotate(hydro_matching_rotation(vec3(R.tnormal[nb][0], R.tnormal[nb][1], R.tnormal[nb][2]), agg, mag), n));
+        return n;
+    };
+    if (moment_matching) {  // accumulate_moments_kernel :852-980
+        for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {
+            R.wlever[i] = -1.0f;
+            if (!R.wuniq[i] || !(R.wpen[i] > 0.0f) || R.wnbin[i] < 0) continue;
+            const int nb = R.wnbin[i];
+            const float* g = R.agg[nb];
+            if (!(g[6] > 1e-20f)) continue;
+            const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)R.tslot[i / RED_VALUES][i % RED_VALUES];
+            const vec3 anchor_pos = vec3(g[3], g[4], g[5]) / g[6];
+            const vec3 rn = matched_normal(nb, vec3(R.wn[i][0], R.wn[i][1], R.wn[i][2]));
+            R.wlever[i] = length(cross(vec3(rec[0], rec[1], rec[2]) - anchor_pos, rn));
+        }
+        __syncthreads();
+        if (t == 0)
+            for (int r = 0; r < R.rows; ++r) {
+                const int i = R.seq[r];
+                if (i < 0 || R.wlever[i] < 0.0f) continue;
+                const int nb = R.wnbin[i];
+                const float pl = R.wpen[i] * R.wlever[i];
+                R.s1[nb] += pl;
+                R.s2[nb] += pl * R.wlever[i];
+            }
+        __syncthreads();
+    }
     auto bin_values = [&](int b, vec3& agg, float& agg_mag, bool& reliable, float& eff) {
         const float* g = R.agg[b];
         agg = vec3(g[0], g[1], g[2]);
@@ -1799,6 +1883,34 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
             eff = R.tdepth[b];
         }
     };
+    // what a normal-bin entry with a reliable aggregate direction shares among its rows (export kernel :1141-1251)
+    auto entry_export = [&](int e, float agg_mag, float eff) {
+        EntryExport x;
+        const float* g = R.agg[e];
+        const int add_anchor = R.anchor[e];
+        const float anchor_depth = R.max_pen[e];
+        if (add_anchor) x.anchor_pos = vec3(g[3], g[4], g[5]) / g[6];
+        const float tdwa = eff + (float)add_anchor * anchor_depth;
+        x.shared = (agg_mag > 1e-20f && tdwa > 0.0f) ? agg_mag / tdwa : 0.0f;
+        x.alpha = 0.0f; x.l_avg = 0.0f; x.uniform_fs = 1.0f; x.anchor_fs = 1.0f;
+        if (moment_matching) {
+            const float m_unr = R.m_unr[e], m_red = R.s1[e], m_red2 = R.s2[e];
+            const float s0 = R.tdepth[e] + (float)add_anchor * anchor_depth;
+            if (m_unr > 1e-20f && s0 > 1e-20f && m_red > 1e-20f && agg_mag > 1e-20f) {
+                const float m_target = m_unr * tdwa / agg_mag;
+                if (m_target < m_red) {
+                    x.uniform_fs = m_target / m_red;
+                } else {
+                    x.l_avg = m_red / s0;
+                    const float variance = m_red2 * s0 - m_red * m_red;
+                    if (variance > 1e-20f) x.alpha = fminw(fmaxw((m_target - m_red) * m_red / variance, 0.0f), 1.0f);
+                }
+            }
+            if (add_anchor == 1 && anchor_depth > 0.0f)
+                x.anchor_fs = fmaxw(1e-2f, 1.0f + (R.tdepth[e] / anchor_depth) * (1.0f - x.uniform_fs) - x.alpha);
+        }
+        return x;
+    };
     for (int i = t; i < HYDRO_ENTRIES * RED_VALUES; i += nt_) {
         if (!R.wuniq[i]) continue;
         const int e = i / RED_VALUES, sl = i % RED_VALUES;
@@ -1810,17 +1922,25 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         const float depth = rec[6];
         const vec3 n(R.wn[i][0], R.wn[i][1], R.wn[i][2]);
         vec3 final_n = n;
-        float stiff;
+        float stiff, fscale = 1.0f;
         vec3 agg;
         float agg_mag = 0.0f, eff = 0.0f;
         bool reliable = false;
         if (e < RED_BINS) bin_values(e, agg, agg_mag, reliable, eff);
         if (reliable) {
+            EntryExport x = entry_export(e, agg_mag, eff);
             if (normal_matching && depth < 0.0f)
                 final_n = normalize(quat_rotate(hydro_matching_rotation(vec3(R.tnormal[e][0], R.tnormal[e][1], R.tnormal[e][2]), agg, agg_mag), n));
-            const float shared = (agg_mag > 1e-20f && eff > 0.0f) ? agg_mag / eff : 0.0f;
-            stiff = shared;
-            if (shared == 0.0f) stiff = depth < 0.0f ? rec[7] * rec[8] / fmaxw(-depth, 1e-20f) : mca_k;
+            stiff = x.shared;
+            if (x.shared == 0.0f) stiff = depth < 0.0f ? rec[7] * rec[8] / fmaxw(-depth, 1e-20f) : mca_k;
+            if (moment_matching && depth < 0.0f) {
+                if (x.l_avg > 1e-20f) {
+                    const float lever = length(cross(vec3(rec[0], rec[1], rec[2]) - x.anchor_pos, final_n));
+                    fscale = fmaxw(1e-2f, 1.0f + x.alpha * (lever - x.l_avg) / x.l_avg);
+                } else {
+                    fscale = x.uniform_fs;
+                }
+            }
         } else {
             const int nb = R.wnbin[i];
             if (nb >= 0 && depth < 0.0f) {
@@ -1830,14 +1950,36 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
                 bin_values(nb, t_agg, t_mag, t_rel, t_eff);
                 if (normal_matching && t_rel)
                     final_n = normalize(quat_rotate(hydro_matching_rotation(vec3(R.tnormal[nb][0], R.tnormal[nb][1], R.tnormal[nb][2]), t_agg, t_mag), n));
+                float t_anchor_depth = 0.0f;
+                if (anchor_contact && t_rel) {  // the bin's deepest contact (its max-depth slot) sets the anchor's depth
+                    if (R.tbl[nb][RED_DIRS] != 0ull && R.wpen[nb * RED_VALUES + RED_DIRS] > 0.0f) t_anchor_depth = R.wpen[nb * RED_VALUES + RED_DIRS];
+                    if (R.agg[nb][6] > 1e-20f && t_anchor_depth > 0.0f) t_eff = t_eff + t_anchor_depth;
+                }
                 stiff = (t_mag > 1e-20f && t_eff > 0.0f) ? t_mag / t_eff : rec[7] * rec[8] / fmaxw(-depth, 1e-20f);
+                if (moment_matching) {
+                    const float v_unr = R.m_unr[nb], v_s1 = R.s1[nb], v_s2 = R.s2[nb], v_s0 = R.tdepth[nb] + t_anchor_depth;
+                    if (v_unr > 1e-20f && v_s0 > 1e-20f && v_s1 > 1e-20f && t_mag > 1e-20f) {
+                        const float v_target = v_unr * t_eff / t_mag;
+                        if (v_target < v_s1) {
+                            fscale = v_target / v_s1;
+                        } else {
+                            const float v_lavg = v_s1 / v_s0, v_var = v_s2 * v_s0 - v_s1 * v_s1;
+                            float v_alpha = 0.0f;
+                            if (v_var > 1e-20f) v_alpha = fminw(fmaxw((v_target - v_s1) * v_s1 / v_var, 0.0f), 1.0f);
+                            vec3 v_anchor;
+                            if (R.agg[nb][6] > 1e-20f) v_anchor = vec3(R.agg[nb][3], R.agg[nb][4], R.agg[nb][5]) / R.agg[nb][6];
+                            const float v_lever = length(cross(vec3(rec[0], rec[1], rec[2]) - v_anchor, final_n));
+                            if (v_lavg > 1e-20f) fscale = fmaxw(1e-2f, 1.0f + v_alpha * (v_lever - v_lavg) / v_lavg);
+                        }
+                    }
+                }
             } else if (depth < 0.0f) {
                 stiff = rec[7] * rec[8] / fmaxw(-depth, 1e-20f);
             } else {
                 stiff = mca_k;
             }
         }
-        if (!(depth < 0.0f)) stiff = mca_k;
+        if (!(depth < 0.0f)) { stiff = mca_k; fscale = 1.0f; }
         const vec3 pw = xform_point(p.X_b, vec3(rec[0], rec[1], rec[2])), nw = xform_vector(p.X_b, final_n);
         a.out_pair[slot] = pair_idx;
         a.out_key[slot] = reinterpret_cast<const int*>(rec)[9];
@@ -1846,7 +1988,26 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
         o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; o[3] = nw.x; o[4] = nw.y; o[5] = nw.z;
         o[6] = depth; o[7] = 0.0f; o[8] = 0.0f;
         a.out_stiffness[slot] = stiff;
-        if (a.out_friction) a.out_friction[slot] = 1.0f;
+        if (a.out_friction) a.out_friction[slot] = fscale;
+    }
+    if (anchor_contact && t < RED_BINS && R.anchor[t]) {  // the entry's anchor contact: centre of pressure, aggregate force direction
+        vec3 agg;
+        float agg_mag, eff;
+        bool reliable;
+        bin_values(t, agg, agg_mag, reliable, eff);
+        const EntryExport x = entry_export(t, agg_mag, eff);
+        const int rank = R.ubase[t] + R.ucount[t], slot = R.row_base + rank;
+        if (slot < a.capacity) {
+            const vec3 pw = xform_point(p.X_b, x.anchor_pos), nw = xform_vector(p.X_b, normalize(agg));
+            a.out_pair[slot] = pair_idx;
+            a.out_key[slot] = 0x400000 | t;
+            a.out_rank[slot] = rank;
+            float* o = a.out_data + 9 * (size_t)slot;
+            o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; o[3] = nw.x; o[4] = nw.y; o[5] = nw.z;
+            o[6] = -R.max_pen[t]; o[7] = 0.0f; o[8] = 0.0f;
+            a.out_stiffness[slot] = x.shared;
+            if (a.out_friction) a.out_friction[slot] = x.anchor_fs;
+        }
     }
     __syncthreads();
     NT_HT(5, ht);

@@ -132,11 +132,9 @@ class SdfLeg:
         if self.has_hydro_pairs:
             from .mc_tables import tables  # noqa: PLC0415
 
-            if hydro_config.reduce_contacts and (hydro_config.anchor_contact or hydro_config.moment_matching):
-                raise NotImplementedError("HydroelasticSDF.Config(anchor_contact / moment_matching) are not implemented "
-                                          "(the reduction offers pre_prune_contacts and normal_matching)")
-            self.hydro_reduce = (1 | (2 if hydro_config.pre_prune_contacts else 0) | (4 if hydro_config.normal_matching else 0)
-                                 if hydro_config.reduce_contacts else 0)
+            self.hydro_reduce = (1 | (2 if hydro_config.pre_prune_contacts else 0) | (4 if hydro_config.normal_matching else 0) |
+                                 (8 if hydro_config.anchor_contact or hydro_config.moment_matching else 0) |
+                                 (16 if hydro_config.moment_matching else 0) if hydro_config.reduce_contacts else 0)
             self.face_capacity = E * n_shapes * int(hydro_faces_per_shape) if self.hydro_reduce else 0
             if hydro_config.pressure_func is not None:
                 raise NotImplementedError("custom pressure_func callbacks are not supported (linear pressure -kh * depth only)")

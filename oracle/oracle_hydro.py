@@ -322,7 +322,8 @@ def hydro_pipeline(pairs, shape_transform, shape_data, shape_gap, shape_kh, sdfs
                                       farea=farea, garea=garea, pressure=pressure))
             for fp, pw, nw, depth, stiff, fscale in reduce_pair_faces(faces, X_b, effective_stiffness(kh_a, kh_b), margin_contact_area,
                                                                     reduce["aabb_lo"][sb], reduce["aabb_hi"][sb], reduce["res"][sb],
-                                                                    reduce.get("pre_prune", True), reduce.get("normal_matching", True)):
+                                                                    reduce.get("pre_prune", True), reduce.get("normal_matching", True),
+                                                                    reduce.get("anchor_contact", False), reduce.get("moment_matching", False)):
                 rows.append((pair_idx, fp, sa, sb, pw, nw, depth, stiff, fscale))
             continue
         for rank, (x, y, z) in enumerate(vox):
@@ -398,9 +399,14 @@ def _normalize(v):
     return np.array([f32(v[k] / ln) for k in range(3)], f32) if ln > 0 else np.zeros(3, f32)
 
 
-def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, res, pre_prune=True, normal_matching=True):
+MIN_FRICTION_SCALE = f32(1e-2)
+
+
+def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, res, pre_prune=True, normal_matching=True,
+                      anchor_contact=False, moment_matching=False):
     """-> rows [(fingerprint, world point, world normal, separation, stiffness, friction scale)] in export order (entries in
-    first-use order, winners in slot order)."""
+    first-use order, winners in slot order, the entry's anchor contact last: fingerprint 0x400000 | bin)."""
+    anchor_contact = anchor_contact or moment_matching
     from oracle_reduce import FACE_FRAMES, NUM_NORMAL_BINS, NUM_SPATIAL_DIRECTIONS, SPATIAL_DIRS, VALUES_PER_KEY, get_slot, voxel_index  # noqa: PLC0415
     from oracle_reduce import decode_oct as dec2  # noqa: PLC0415
     from oracle_reduce import encode_oct as enc2  # noqa: PLC0415
@@ -410,7 +416,8 @@ def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, 
     def entry(bin_id):
         if bin_id not in entries:
             entries[bin_id] = dict(bin=bin_id, slots=[0] * VALUES_PER_KEY, agg_force=np.zeros(3, f32), wps=np.zeros(3, f32), ws=f32(0.0),
-                                   adv=np.zeros(3, f32), total_depth=f32(0.0), total_normal=np.zeros(3, f32))
+                                   adv=np.zeros(3, f32), total_depth=f32(0.0), total_normal=np.zeros(3, f32), m_unr=f32(0.0),
+                                   s1=f32(0.0), s2=f32(0.0))
         return entries[bin_id]
 
     # ---- generate: aggregates over ALL penetrating faces, buffer = all faces or the voxel-local selection
@@ -472,6 +479,10 @@ def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, 
                 score = f32(f32(f32(p2[0] * SPATIAL_DIRS[d][0]) + f32(p2[1] * SPATIAL_DIRS[d][1])) * pen_w)
                 e["slots"][d] = max(e["slots"][d], _value_fast(score, cid))
         e["slots"][NUM_SPATIAL_DIRECTIONS] = max(e["slots"][NUM_SPATIAL_DIRECTIONS], _value_fast(f32(-depth), cid))
+        if moment_matching and e["ws"] > EPS_SMALL:  # unreduced friction moment about the centre of pressure (:717-727)
+            anchor = np.array([f32(e["wps"][k] / e["ws"]) for k in range(3)], f32)
+            lever = _vlen(_cross3(np.array([f32(c["center"][k] - anchor[k]) for k in range(3)], f32), n))
+            e["m_unr"] = f32(e["m_unr"] + f32(f32(c["area"] * c["pressure"]) * lever))
         ev = entry(NUM_NORMAL_BINS + vox // VALUES_PER_KEY)
         ev["slots"][vox % VALUES_PER_KEY] = max(ev["slots"][vox % VALUES_PER_KEY], _value_fast(f32(-depth), cid))
 
@@ -493,6 +504,33 @@ def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, 
                     t = entries[nb]
                     t["total_depth"] = f32(t["total_depth"] + pen)
                     t["total_normal"] = _vadd(t["total_normal"], _vscale(dec2(c["oct"]), pen))
+    def reliable_of(t):
+        mag = _vlen(t["agg_force"])
+        return mag, bool(_vlen(t["adv"]) > EPS_LARGE and mag > EPS_SMALL)
+
+    # ---- accumulate_moments_kernel (:852-980): reduced friction moments S1 = sum pen * lever, S2 = sum pen * lever^2
+    if moment_matching:
+        for e in entries.values():
+            for cid in winners(e):
+                c = buf[cid - 1]
+                if not c["sep"] < 0.0:
+                    continue
+                nb = e["bin"] if e["bin"] < NUM_NORMAL_BINS else nbin_of.get(cid, -1)
+                if nb < 0:
+                    continue
+                t = entries[nb]
+                if not t["ws"] > EPS_SMALL:
+                    continue
+                anchor = np.array([f32(t["wps"][k] / t["ws"]) for k in range(3)], f32)
+                n = dec2(c["oct"])
+                if normal_matching:
+                    mag, rel = reliable_of(t)
+                    if rel:
+                        n = _normalize(_q_rot(_normal_matching_rotation(t["total_normal"], t["agg_force"], mag), n))
+                lever = _vlen(_cross3(np.array([f32(c["center"][k] - anchor[k]) for k in range(3)], f32), n))
+                pen = f32(-c["sep"])
+                t["s1"] = f32(t["s1"] + f32(pen * lever))
+                t["s2"] = f32(t["s2"] + f32(f32(pen * lever) * lever))
     # ---- export
     rows = []
     mca_k = f32(f32(margin_contact_area) * k_eff)
@@ -500,8 +538,16 @@ def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, 
         ids = winners(e)
         if not ids:
             continue
-        agg_mag = _vlen(e["agg_force"])
-        reliable = bool(_vlen(e["adv"]) > EPS_LARGE and agg_mag > EPS_SMALL)
+        agg_mag, reliable = reliable_of(e)
+        max_pen = f32(0.0)
+        for cid in ids:
+            if buf[cid - 1]["sep"] < 0.0:
+                max_pen = max(max_pen, f32(-buf[cid - 1]["sep"]))
+        add_anchor, anchor_pos = 0, np.zeros(3, f32)
+        if anchor_contact and reliable and max_pen > 0.0 and e["ws"] > EPS_SMALL:
+            anchor_pos = np.array([f32(e["wps"][k] / e["ws"]) for k in range(3)], f32)
+            add_anchor = 1
+        anchor_depth = max_pen
         rot = np.array([0, 0, 0, 1], f32)
         if normal_matching and reliable:
             rot = _normal_matching_rotation(e["total_normal"], e["agg_force"], agg_mag)
@@ -511,42 +557,96 @@ def reduce_pair_faces(faces, X_b, k_eff, margin_contact_area, aabb_lo, aabb_hi, 
                 eff = e["total_depth"]
         else:
             eff = e["total_depth"]
-        shared = f32(agg_mag / eff) if (agg_mag > EPS_SMALL and eff > 0.0) else f32(0.0)
+        tdwa = f32(eff + f32(f32(add_anchor) * anchor_depth))
+        shared = f32(agg_mag / tdwa) if (agg_mag > EPS_SMALL and tdwa > 0.0) else f32(0.0)
+        alpha, l_avg, uniform_fs, anchor_fs = f32(0.0), f32(0.0), f32(1.0), f32(1.0)
+        if moment_matching:
+            m_unr, m_red, m_red2 = e["m_unr"], e["s1"], e["s2"]
+            s0 = f32(e["total_depth"] + f32(f32(add_anchor) * anchor_depth))
+            if m_unr > EPS_SMALL and s0 > EPS_SMALL and m_red > EPS_SMALL and agg_mag > EPS_SMALL:
+                m_target = f32(f32(m_unr * tdwa) / agg_mag)
+                if m_target < m_red:
+                    uniform_fs = f32(m_target / m_red)
+                else:
+                    l_avg = f32(m_red / s0)
+                    variance = f32(f32(m_red2 * s0) - f32(m_red * m_red))
+                    if variance > EPS_SMALL:
+                        alpha = min(max(f32(f32(f32(m_target - m_red) * m_red) / variance), f32(0.0)), f32(1.0))
+            if add_anchor == 1 and anchor_depth > 0.0:
+                anchor_fs = max(MIN_FRICTION_SCALE,
+                                f32(f32(f32(1.0) + f32(f32(e["total_depth"] / anchor_depth) * f32(f32(1.0) - uniform_fs))) - alpha))
         for cid in ids:
             c = buf[cid - 1]
             depth, n = c["sep"], dec2(c["oct"])
             final = n
+            fscale = f32(1.0)
             if reliable:
                 if normal_matching and depth < 0.0:
                     final = _normalize(_q_rot(rot, n))
                 stiff = shared
                 if shared == 0.0:
                     stiff = f32(f32(c["area"] * c["pressure"]) / max(f32(-depth), EPS_SMALL)) if depth < 0.0 else mca_k
+                if moment_matching and depth < 0.0:
+                    if l_avg > EPS_SMALL:
+                        lever = _vlen(_cross3(np.array([f32(c["center"][k] - anchor_pos[k]) for k in range(3)], f32), final))
+                        fscale = max(MIN_FRICTION_SCALE, f32(f32(1.0) + f32(f32(alpha * f32(lever - l_avg)) / l_avg)))
+                    else:
+                        fscale = uniform_fs
             else:
                 nb = nbin_of.get(cid, -1)
                 if nb >= 0 and depth < 0.0:
                     t = entries[nb]
-                    t_mag = _vlen(t["agg_force"])
-                    t_rel = bool(_vlen(t["adv"]) > EPS_LARGE and t_mag > EPS_SMALL)
+                    t_mag, t_rel = reliable_of(t)
                     if normal_matching and t_rel:
                         final = _normalize(_q_rot(_normal_matching_rotation(t["total_normal"], t["agg_force"], t_mag), n))
                     if normal_matching:
-                        t_eff = _vlen(t["total_normal"])
-                        if t_eff < EPS_LARGE:
-                            t_eff = t["total_depth"]
+                        t_eff0 = _vlen(t["total_normal"])
+                        if t_eff0 < EPS_LARGE:
+                            t_eff0 = t["total_depth"]
                     else:
-                        t_eff = t["total_depth"]
+                        t_eff0 = t["total_depth"]
+                    t_eff, t_anchor_depth = t_eff0, f32(0.0)
+                    if anchor_contact and t_rel:
+                        v = t["slots"][NUM_SPATIAL_DIRECTIONS]
+                        if v:
+                            md = buf[(v & 0xFFFFFFFF) - 1]["sep"]
+                            if md < 0.0:
+                                t_anchor_depth = f32(-md)
+                        if t["ws"] > EPS_SMALL and t_anchor_depth > 0.0:
+                            t_eff = f32(t_eff0 + t_anchor_depth)
                     if t_mag > EPS_SMALL and t_eff > 0.0:
                         stiff = f32(t_mag / t_eff)
                     else:
                         stiff = f32(f32(c["area"] * c["pressure"]) / max(f32(-depth), EPS_SMALL))
+                    if moment_matching:
+                        v_unr, v_s1, v_s2 = t["m_unr"], t["s1"], t["s2"]
+                        v_s0 = f32(t["total_depth"] + t_anchor_depth)
+                        if v_unr > EPS_SMALL and v_s0 > EPS_SMALL and v_s1 > EPS_SMALL and t_mag > EPS_SMALL:
+                            v_target = f32(f32(v_unr * t_eff) / t_mag)
+                            if v_target < v_s1:
+                                fscale = f32(v_target / v_s1)
+                            else:
+                                v_lavg = f32(v_s1 / v_s0)
+                                v_var = f32(f32(v_s2 * v_s0) - f32(v_s1 * v_s1))
+                                v_alpha = f32(0.0)
+                                if v_var > EPS_SMALL:
+                                    v_alpha = min(max(f32(f32(f32(v_target - v_s1) * v_s1) / v_var), f32(0.0)), f32(1.0))
+                                v_anchor = np.zeros(3, f32)
+                                if t["ws"] > EPS_SMALL:
+                                    v_anchor = np.array([f32(t["wps"][k] / t["ws"]) for k in range(3)], f32)
+                                v_lever = _vlen(_cross3(np.array([f32(c["center"][k] - v_anchor[k]) for k in range(3)], f32), final))
+                                if v_lavg > EPS_SMALL:
+                                    fscale = max(MIN_FRICTION_SCALE, f32(f32(1.0) + f32(f32(v_alpha * f32(v_lever - v_lavg)) / v_lavg)))
                 elif depth < 0.0:
                     stiff = f32(f32(c["area"] * c["pressure"]) / max(f32(-depth), EPS_SMALL))
                 else:
                     stiff = mca_k
             if depth >= 0.0:
-                stiff = mca_k
-            rows.append((c["fp"], _x_point(X_b, c["center"]), _q_rot(X_b[3:], final), depth, stiff, f32(1.0)))
+                stiff, fscale = mca_k, f32(1.0)
+            rows.append((c["fp"], _x_point(X_b, c["center"]), _q_rot(X_b[3:], final), depth, stiff, fscale))
+        if add_anchor == 1:
+            rows.append((0x400000 | e["bin"], _x_point(X_b, anchor_pos), _q_rot(X_b[3:], _normalize(e["agg_force"])), f32(-anchor_depth),
+                         shared, anchor_fs))
     return rows
 
 

@@ -116,11 +116,15 @@ def run(s, margin_contact_area=1.0e-2, edge_clamp_min=0.02):
     cr = importlib.import_module("newton._src.geometry.contact_reduction_hydroelastic")
     lo, hi = A(s["aabb_lo"], wp.vec3), A(s["aabb_hi"], wp.vec3)
     res = wp.Array([wp.vec3i(int(a), int(b), int(c)) for a, b, c in s["res"]])
-    for tag, pre_prune, normal_matching in (("prune_nm", True, True), ("full_nm", False, True), ("prune_plain", True, False)):
+    for tag, pre_prune, normal_matching, anchor, moment in (("prune_nm", True, True, False, False), ("full_nm", False, True, False, False),
+                                                            ("prune_plain", True, False, False, False),
+                                                            ("prune_anchor", True, True, True, False), ("prune_moment", True, True, False, True),
+                                                            ("full_moment_plain", False, False, False, True)):
         # generate (aggregates per normal bin, optional local-first pruning) -> reduce -> export, the non-deterministic variant
         # executed sequentially: contact ids, hashtable entries and float sums in thread order
         red = cr.HydroelasticContactReduction(capacity=max(16 * n_in, 64), device="cpu", writer_func=recording_writer_reduced,
-                                              config=cr.HydroelasticReductionConfig(normal_matching=normal_matching,
+                                              config=cr.HydroelasticReductionConfig(normal_matching=normal_matching, anchor_contact=anchor,
+                                                                                     moment_matching=moment,
                                                                                      margin_contact_area=margin_contact_area),
                                               deterministic=False)
         red.clear()

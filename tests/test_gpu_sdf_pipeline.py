@@ -399,7 +399,7 @@ def hydro_scene(world_count, device=None, seed=21):
     return model
 
 
-@pytest.mark.parametrize("reduce", [False, True])
+@pytest.mark.parametrize("reduce", [False, True, "moment"])
 def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_solver(reduce):
     """CollisionPipeline(sdf_hydroelastic_config=HydroelasticSDF.Config(reduce_contacts=False)): pairs of two HYDROELASTIC shapes take
     the SDF-SDF leg (SAT, octree, marching cubes: rows with Contacts.rigid_contact_stiffness), other SDF pairs the edge leg, both in
@@ -423,7 +423,7 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     t = model.env
     # hydroelastic: pad-ball, pad-hull, ball-hull | edge contacts: pad-other, hull-other | tiles: ball-other (MPR / GJK) + four plane pairs
     assert t.sdf_pair_hydro.sum() == 3 and (~t.sdf_pair_hydro).sum() == 2 and t.np == 5
-    cfg = nt.geometry.HydroelasticSDF.Config() if reduce else nt.geometry.HydroelasticSDF.Config(reduce_contacts=False)
+    cfg = nt.geometry.HydroelasticSDF.Config(moment_matching=reduce == "moment") if reduce else nt.geometry.HydroelasticSDF.Config(reduce_contacts=False)
     pipe = nt.CollisionPipeline(model, broad_phase="sap", sdf_hydroelastic_config=cfg, sdf_contacts_per_shape=400)
     c1, c2 = pipe.contacts(), pipe.contacts()
     s0, s1 = model.state(), model.state()
@@ -447,11 +447,12 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     data = np.concatenate([np.asarray(model.shape_scale, np.float32), np.asarray(model.shape_margin, np.float32)[:, None]], axis=1)
     gap, kh = np.asarray(model.shape_gap, np.float32), np.asarray(model.shape_material_kh, np.float32)
     sdfs = [model._texture_sdf_data[i] if i >= 0 else None for i in np.asarray(model._shape_sdf_index)]
-    want = {k: [] for k in ("world", "key", "shape0", "shape1", "point0", "normal", "stiffness")}
+    want = {k: [] for k in ("world", "key", "shape0", "shape1", "point0", "normal", "stiffness", "friction")}
     for w in range(E):
         hp = [p for p, kind in cand[w] if kind]
         red = dict(aabb_lo=np.asarray(model.shape_collision_aabb_lower, np.float32), aabb_hi=np.asarray(model.shape_collision_aabb_upper, np.float32),
-                   res=np.asarray(model._shape_voxel_resolution, np.int32), pre_prune=True, normal_matching=True) if reduce else None
+                   res=np.asarray(model._shape_voxel_resolution, np.int32), pre_prune=True, normal_matching=True,
+                   moment_matching=reduce == "moment") if reduce else None
         rows, _ = H.hydro_pipeline(np.asarray(hp, np.int32), X, data, gap, kh, sdfs, tab, reduce=red) if hp else ([], None)
         per_pair = {}
         for r in rows:
@@ -467,6 +468,7 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
                 want["world"] += [w] * len(rs)
                 want["key"] += [r[1] for r in rs]
                 want["stiffness"] += [r[7] for r in rs]
+                want["friction"] += [r[8] if reduce else 0.0 for r in rs]
                 for k in ("shape0", "shape1", "point0", "normal"):
                     want[k] += list(wr[k])
             else:
@@ -474,6 +476,7 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
                 want["world"] += [w] * int(sel.sum())
                 want["key"] += m["key"][sel].tolist()
                 want["stiffness"] += [0.0] * int(sel.sum())
+                want["friction"] += [0.0] * int(sel.sum())
                 for k in ("shape0", "shape1", "point0", "normal"):
                     want[k] += list(m[k][sel])
     lim = (20, 10) if reduce else (100, 50)
@@ -484,7 +487,12 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     ws = np.asarray(want["stiffness"], np.float32)
     assert np.abs(stiff - ws).max() <= 1e-5 * np.abs(ws).max()
     fric = f.friction_scale[:n].cpu().numpy()
-    assert np.array_equal(fric, np.where((ws > 0) & reduce, 1.0, 0.0).astype(np.float32))  # reduced hydroelastic rows carry scale 1
+    if reduce == "moment":  # anchors (key 0x400000 | bin) and friction scales that preserve the bins' friction moments
+        wf = np.asarray(want["friction"], np.float32)
+        assert (np.asarray(want["key"]) >= 0x400000).sum() >= 2 and (np.abs(wf[wf > 0] - 1.0) > 1e-3).sum() > 5
+        assert np.abs(fric - wf).max() <= 2e-5
+    else:
+        assert np.array_equal(fric, np.where((ws > 0) & bool(reduce), 1.0, 0.0).astype(np.float32))  # reduced rows carry scale 1
     # ---- SolverSemiImplicit consumes the per-contact stiffness (kernels_contact.py:452-459) like the checker
     solver = nt.solvers.SolverSemiImplicit(model)
     solver.step(s0, s1, model.control(), c1, 1.0e-4)

@@ -51,7 +51,10 @@ def test_checker_pipeline_is_the_executed_reference(name):
 
 
 REDUCED = {"prune_nm": dict(pre_prune=True, normal_matching=True), "full_nm": dict(pre_prune=False, normal_matching=True),
-           "prune_plain": dict(pre_prune=True, normal_matching=False)}
+           "prune_plain": dict(pre_prune=True, normal_matching=False),
+           "prune_anchor": dict(pre_prune=True, normal_matching=True, anchor_contact=True),
+           "prune_moment": dict(pre_prune=True, normal_matching=True, moment_matching=True),
+           "full_moment_plain": dict(pre_prune=False, normal_matching=False, moment_matching=True)}
 
 
 def _check_reduced_rows(name, tag, rows, vox_counts, tol=0.0):
@@ -115,7 +118,8 @@ def run_hydro_pairs(lib, s, make_sdf, ptr, cap=4096, reduce=None):
     a.pair_world_prefix, a.worlds, a.pairs_per_world, a.pair_kind = dev["prefix"][0], 1, n, dev["kind"][0]
     a.out_pairs_normalized, a.out_blk, a.out_rank, a.out_stiffness = dev["norm"][0], dev["blk"][0], dev["o_rank"][0], dev["o_stiff"][0]
     if reduce is not None:
-        a.reduce = 1 | (2 if reduce["pre_prune"] else 0) | (4 if reduce["normal_matching"] else 0)
+        a.reduce = (1 | (2 if reduce["pre_prune"] else 0) | (4 if reduce["normal_matching"] else 0) |
+                    (8 if reduce.get("anchor_contact") else 0) | (16 if reduce.get("moment_matching") else 0))
         a.shape_aabb_lower, a.shape_aabb_upper, a.shape_voxel_res = dev["lo"][0], dev["hi"][0], dev["res"][0]
         a.face_count, a.face_rec, a.face_capacity, a.out_friction = dev["f_count"][0], dev["f_rec"][0], cap, dev["o_fric"][0]
     assert lib.nt_hydro_pairs(C.byref(a), None) == 0
