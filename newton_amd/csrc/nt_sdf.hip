@@ -1608,10 +1608,14 @@ NT_DI quat hydro_matching_rotation(vec3 nsum, vec3 agg, float agg_mag) {  // _co
 // (ordered sums, one lane per bin), table registration of the buffered contacts, winners, reduced depth sums in the hashtable's
 // insertion order, export.  contact_reduction_hydroelastic.py:596-755 (reduce), :756-850 (accumulate depth), :983-1460 (export).
 struct EntryExport { vec3 anchor_pos; float shared, alpha, l_avg, uniform_fs, anchor_fs; };
-NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
+// EXTRAS: anchor contacts / moment matching compiled in.  The default options do not use them, and inlined next to the face pass
+// their registers push the kernel past 256 VGPR -- one workgroup per CU instead of two (measured: 309 -> 577 ms per hydro_bin
+// frame); the instance that has them is therefore called, not inlined.
+template <bool EXTRAS>
+NT_DI void hydro_reduce_pair_impl(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
     const int t = threadIdx.x, nt_ = blockDim.x;
-    const bool normal_matching = (a.reduce & 4) != 0, moment_matching = (a.reduce & 16) != 0;
-    const bool anchor_contact = (a.reduce & 8) != 0 || moment_matching;
+    const bool normal_matching = (a.reduce & 4) != 0, moment_matching = EXTRAS && (a.reduce & 16) != 0;
+    const bool anchor_contact = EXTRAS && ((a.reduce & 8) != 0 || moment_matching);
 #ifdef NT_HYDRO_TIMING
     unsigned long long ht = clock64();
 #endif
@@ -2013,7 +2017,14 @@ NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pai
     NT_HT(5, ht);
 }
 
-template <bool REDUCE>
+NT_DI void hydro_reduce_pair(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
+    hydro_reduce_pair_impl<false>(a, p, pair_idx, R);
+}
+__device__ __attribute__((noinline)) void hydro_reduce_pair_extras(const nt_hydro_args& a, const HydroPair& p, int pair_idx, HydroRedLds& R) {
+    hydro_reduce_pair_impl<true>(a, p, pair_idx, R);
+}
+
+template <bool REDUCE, bool EXTRAS = false>
 __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
     __shared__ HydroLds L;
     __shared__ typename std::conditional<REDUCE, HydroRedLds, int>::type R;
@@ -2264,7 +2275,8 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
             if (L.pair_face > 0) {  // (uniform)
                 __threadfence();  // the pair's face records, written by all lanes, are read back by other lanes below
                 __syncthreads();
-                hydro_reduce_pair(a, p, pair_idx, R);
+                if constexpr (EXTRAS) hydro_reduce_pair_extras(a, p, pair_idx, R);
+                else hydro_reduce_pair(a, p, pair_idx, R);
             }
             if (t == 0) {
                 if (R.overflow) atomicAdd(a.face_count + 1, 1);
@@ -2317,7 +2329,8 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
 #else
         const int rblocks = blocks;
 #endif
-        hipLaunchKernelGGL(hydro_pairs_kernel<true>, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
+        if (a->reduce & (8 | 16)) hipLaunchKernelGGL((hydro_pairs_kernel<true, true>), dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL((hydro_pairs_kernel<true, false>), dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
     } else {
         hipLaunchKernelGGL(hydro_pairs_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
     }
