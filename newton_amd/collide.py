@@ -126,6 +126,17 @@ class Contacts:
             e["shape1"].data_ptr(), e["point0"].data_ptr(), e["point1"].data_ptr(), e["offset0"].data_ptr(),
             e["offset1"].data_ptr(), e["normal"].data_ptr(), e["margin0"].data_ptr(), e["margin1"].data_ptr(),
             self._scan.data_ptr(), dm.stream()), "nt_contacts_export")
+        has_prop = self._prop is not None or (self._flat is not None and self._flat.stiffness is not None)
+        if has_prop:  # Contacts.rigid_contact_stiffness / _damping / _friction (contacts.py:227-277), zero = shape materials
+            for name in ("stiffness", "damping", "friction"):
+                e[name] = torch.zeros((cap,), dtype=torch.float32, device=dev)
+            if self._prop is not None:  # slot overrides, in the export's (env, slot) order of the live slots
+                t = self.model.env
+                live_slots = (self._shape0[: self._slots, : t.env_count] != self._shape1[: self._slots, : t.env_count]).T
+                es = torch.nonzero(live_slots)
+                ns_ = min(int(es.shape[0]), self._slot_contact_max)
+                for k, name in enumerate(("stiffness", "damping", "friction")):
+                    e[name][:ns_] = self._prop[k][es[:ns_, 1], es[:ns_, 0]]
         if self._flat is not None:  # the SDF leg's rows follow (collide.py:1999: its launches come last); inert rows are skipped
             f = self._flat
             n0 = min(int(e["count"].item()), self._slot_contact_max)
@@ -134,6 +145,10 @@ class Contacts:
             k = int(live.numel())
             for name in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
                 e[name][n0:n0 + k] = getattr(f, name)[live]
+            if f.stiffness is not None:
+                e["stiffness"][n0:n0 + k] = f.stiffness[live]
+                e["damping"][n0:n0 + k] = f.damping[live]
+                e["friction"][n0:n0 + k] = f.friction_scale[live]
             e["count"][0] = n0 + k
             self._flat_live = live
         self._sort_order = None
@@ -168,6 +183,10 @@ class Contacts:
     rigid_contact_normal = property(lambda self: self._exported()["normal"])
     rigid_contact_margin0 = property(lambda self: self._exported()["margin0"])
     rigid_contact_margin1 = property(lambda self: self._exported()["margin1"])
+    # per-contact overrides (None unless the contacts carry them: per_contact_shape_properties or hydroelastic rows)
+    rigid_contact_stiffness = property(lambda self: self._exported().get("stiffness"))
+    rigid_contact_damping = property(lambda self: self._exported().get("damping"))
+    rigid_contact_friction = property(lambda self: self._exported().get("friction"))
 
     @property
     def rigid_contact_count_per_env(self):
