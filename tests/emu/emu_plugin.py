@@ -80,6 +80,7 @@ class _Event:
 
 torch.cuda.Event = _Event
 torch.cuda.is_available = lambda: True
+torch.cuda._newton_emulated = True  # tests that only make sense on the device (full-size scenes, hipGraph capture) skip on it
 torch.cuda.current_stream = lambda device=None: _Stream()
 torch.cuda.synchronize = lambda device=None: None
 torch.cuda.set_device = lambda device: None

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 def _needs_device():
     import torch
 
-    if not torch.cuda.is_available():
+    if not torch.cuda.is_available() or getattr(torch.cuda, "_newton_emulated", False):
         pytest.skip("hipGraph capture needs the device (not emulated)")
 
 

@@ -311,6 +311,8 @@ def test_config_c5_rows_at_full_size():
     and counts exact; geometry 2e-6 on the device's own shape transforms, which are held against the checker's to 1e-6)."""
     import torch
 
+    if getattr(torch.cuda, "_newton_emulated", False):
+        pytest.skip("2 048 worlds x 64 hulls: device only (hours in emulation)")
     import newton_amd as nt
     import scenes
     from sdf_pipeline_checker import checker_rows
