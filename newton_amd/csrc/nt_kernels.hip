@@ -232,6 +232,9 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
     LdsLayout L = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni);
     if (max_threads <= 0) max_threads = max_threads_for(epb);
     int nslot = slots_for(a.m, epb, max_threads);
+    // rows of the SDF legs (nt_contacts.flat) are walked by the environment's slot-lanes too: hundreds per environment in a pile,
+    // far more than the tile's own populations ask for -- give them every lane the workgroup may have
+    if (a.ct.flat.row_start) nslot = max_threads / epb;
     a.nslot = nslot;
 #ifdef NT_ABLATION
     {
