@@ -6,8 +6,12 @@ Device stages (csrc/nt_sdf_pipeline.hip, csrc/nt_sdf.hip), all on the caller's s
 
     nt_collide               exports world transforms + gap-widened AABBs of every shape (the tile kernel's compute_shape_aabbs)
     nt_sdf_candidate_pairs   per world: ordered compaction of the world's SDF pair list against those AABBs + scan over worlds
-    nt_mesh_sdf_collide_reduced   one workgroup per candidate pair: edges vs SDF both ways, 245-slot reduction table in LDS
-    nt_sdf_rows_finalize     final row ranges (world-major, pairs ascending, fingerprint order), write_contact, per-body row blocks
+    nt_mesh_sdf_collide_reduced   edges vs SDF both ways + the 245-slot reduction table per pair, in four dense stages: a lane per
+                             pair (edge-independent setup), a wave per runnable pair (culling; survivors into a striped list), a
+                             lane per survivor (Brent search), a workgroup per pair with survivors (reduction in LDS)
+    nt_hydro_pairs           pairs of two hydroelastic shapes (CollisionPipeline(sdf_hydroelastic_config=...)): SAT, octree, marching
+                             cubes; every face as a row, or the reference's hydroelastic contact reduction (Config defaults)
+    nt_sdf_rows_finalize     final row ranges (world-major, pairs ascending, fingerprint / rank order), write_contact, per-body row blocks
 
 The rows live in ``FlatRows`` (owned by the Contacts object): Newton's flat contact arrays, deterministic -- two runs give
 bit-identical rows -- and consumable by SolverXPBD (inside the step kernel) and SolverSemiImplicit / SolverFeatherstone
