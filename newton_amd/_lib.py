@@ -10,9 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _DEFAULT_LIB = os.path.join(_HERE, "libnewton_hip.so")
-# NEWTON_HIP_LIB: measurement / test use only (A/B of kernel builds, tools/phase_timing.py, the no-GPU dry run of the GPU test
-# files on tests/emu).  load() says so on stderr whenever the override is in effect; deployments use the in-tree library.
-LIB_PATH = os.environ.get("NEWTON_HIP_LIB", _DEFAULT_LIB)
+# The product loads the in-tree library and nothing else: no environment override.  Measurement tools and the no-GPU dry run of the
+# GPU test files point the loader elsewhere from OUTSIDE the package, before the first load() (tools/with_lib.py,
+# tests/emu/emu_plugin.py assign LIB_PATH); load() says so on stderr whenever that happened.
+LIB_PATH = _DEFAULT_LIB
 
 NT_CONTACT_FLOATS = 17
 NT_BODY_PARAM_FLOATS = 23
@@ -346,7 +347,8 @@ def load():
     if os.path.abspath(LIB_PATH) != os.path.abspath(_DEFAULT_LIB):
         import sys
 
-        print(f"[newton_amd] NEWTON_HIP_LIB override in effect ({LIB_PATH}): measurement / test use only", file=sys.stderr)
+        print(f"[newton_amd] library path reassigned by a tool / test harness ({LIB_PATH}): measurement / test use only",
+              file=sys.stderr)
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # missing libamdhip64 etc.

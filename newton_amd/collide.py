@@ -32,6 +32,11 @@ class Contacts:
         torch = _torch()
         self.model = model
         # rows of the pipeline's mesh-SDF leg (sdf_pipeline.FlatRows): appended after the slot contacts in the flat views
+        if sdf_leg is None and model_has_sdf_pairs(model):
+            # the SDF pairs are not in the tile pair list (model.py EnvTemplate.sdf_pair): a Contacts built without the
+            # pipeline's leg would silently carry no contact for them
+            raise ValueError("this model routes shape pairs through the SDF legs: create its Contacts with "
+                             "CollisionPipeline(model).contacts(), not Contacts(model)")
         self._flat = sdf_leg.new_rows(per_contact_shape_properties) if sdf_leg is not None else None
         self._sdf_leg = sdf_leg
         # CollisionPipeline(deterministic=True): the flat arrays come out in the reference's sorted order, ascending
@@ -203,10 +208,22 @@ class Contacts:
         out[:, torch.as_tensor(t.pair_order, device=hit.device)] = hit
         return out
 
+    def invalidate_views(self):
+        """The device buffers were rewritten behind this object's back (a hipGraph replay of recorded collide launches): drop the
+        cached flat views."""
+        self._generation += 1
+
     def clear(self):
+        """No contacts (contacts.py:227-277 Contacts.clear zeroes the counts): the slots, and the rows of the SDF legs with the
+        per-world ranges and per-body block lists the solvers walk."""
         self._shape0.fill_(-1)
         self._shape1.fill_(-1)
         self._env_count.zero_()
+        if getattr(self, "_flat", None) is not None:
+            self._flat.row_start.zero_()
+            self._flat.body_blk_start.zero_()
+            self._flat.shape0.fill_(-1)
+            self._flat.shape1.fill_(-1)
         self._generation += 1
 
 

@@ -88,8 +88,11 @@ __global__ void __launch_bounds__(256) sdf_pairs_kernel(nt_sdf_scene sc, const f
 }
 
 // exclusive scan of min(in[i], clamp) over n <= a few 10^5 entries by ONE workgroup (per-world counts: n = world_count);
-// out[n] = total.  1024 lanes, tiles of 1024 with a running carry.
-__global__ void __launch_bounds__(1024) scan_worlds_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n, int clamp) {
+// out[n] = total.  1024 lanes, tiles of 1024 with a running carry.  Every output is limited to `cap` (the capacity of the array the
+// prefix indexes): a consumer that walks [out[i], out[i + 1]) stays inside the array whatever the counts say; the unclamped
+// counts stay in `in` for the host's overflow report.
+__global__ void __launch_bounds__(1024) scan_worlds_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n, int clamp,
+                                                           int cap) {
     __shared__ int wsum[16];
     __shared__ int carry;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -108,12 +111,12 @@ __global__ void __launch_bounds__(1024) scan_worlds_kernel(const int32_t* __rest
         __syncthreads();
         int off = carry;
         for (int k = 0; k < wave; ++k) off += wsum[k];
-        if (i < n) out[i] = off + x - v;
+        if (i < n) out[i] = (off + x - v) < cap ? (off + x - v) : cap;
         __syncthreads();
         if (t == 1023) carry = off + x;
         __syncthreads();
     }
-    if (t == 0) out[n] = carry;
+    if (t == 0) out[n] = carry < cap ? carry : cap;
 }
 
 // per world: local exclusive scan of its pairs' row counts -> pair_row[w * PPW + k] (row offset inside the world), world_rows[w]
@@ -246,7 +249,9 @@ __global__ void __launch_bounds__(256) sdf_body_blocks_kernel(nt_sdf_scene sc, n
         pa[k] = shape_body_of(sc, io.world_pairs[2 * idx], w);
         pb[k] = shape_body_of(sc, io.world_pairs[2 * idx + 1], w);
         pr[k] = row0 + io.pair_row[idx];
-        pc[k] = io.blk[2 * idx + 1];
+        int c = io.blk[2 * idx + 1];  // a block ends where the row arrays do (rows beyond the capacity were never written)
+        c = c < io.row_capacity - pr[k] ? c : io.row_capacity - pr[k];
+        pc[k] = c > 0 ? c : 0;
     }
     __syncthreads();
     const int nb = sc.nb;  // <= 1024 (checked by the entry point)
@@ -400,7 +405,7 @@ nt_status nt_sdf_candidate_pairs(const nt_sdf_scene* sc, const float* aabb_lower
     hipLaunchKernelGGL(sdf_pairs_kernel, dim3(sc->env_count), dim3(256), 0, (hipStream_t)stream, *sc, aabb_lower, aabb_upper,
                        world_pairs, pair_count);
     hipLaunchKernelGGL(scan_worlds_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pair_count, pair_prefix, sc->env_count,
-                       sc->pairs_per_world);
+                       sc->pairs_per_world, 0x7fffffff);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 
@@ -412,11 +417,19 @@ nt_status nt_sdf_rows_finalize(const nt_sdf_scene* sc, const nt_sdf_rows_io* io,
         !io->margin0 || !io->margin1 || io->raw_capacity <= 0 || io->row_capacity <= 0)
         return NT_ERR_INVALID_ARG;
     if (sc->nb > 1024) return NT_ERR_UNSUPPORTED;
+    if (sc->pairs_per_world > BLK_PAIRS_LDS) return NT_ERR_UNSUPPORTED;  // sdf_body_blocks_kernel stages a world's pair list in LDS
     if (io->stiffness && (!io->damping || !io->friction_scale)) return NT_ERR_INVALID_ARG;
     if (sc->template_kind && (!sc->world_pair_kind || !io->raw_rank)) return NT_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sdf_world_rows_kernel, dim3(sc->env_count), dim3(256), 0, st, *sc, io->pair_count, io->blk, io->pair_row, world_rows);
-    hipLaunchKernelGGL(scan_worlds_kernel, dim3(1), dim3(1024), 0, st, world_rows, io->row_start, sc->env_count, 0x7fffffff);
+    // rows that no writer reaches (raw rows dropped by a full raw buffer, rows of a frame that had more of them) must not survive
+    // from the previous call: every consumer skips a row with shape0 == shape1
+    if (hipMemsetAsync(io->shape0, 0xff, sizeof(int32_t) * (size_t)io->row_capacity, st) != hipSuccess ||
+        hipMemsetAsync(io->shape1, 0xff, sizeof(int32_t) * (size_t)io->row_capacity, st) != hipSuccess)
+        return NT_ERR_LAUNCH;
+    // row_start is limited to the row capacity: [row_start[w], row_start[w + 1]) never leaves the FlatRows arrays
+    hipLaunchKernelGGL(scan_worlds_kernel, dim3(1), dim3(1024), 0, st, world_rows, io->row_start, sc->env_count, 0x7fffffff,
+                       io->row_capacity);
     long long wb = ((long long)sc->env_count * sc->pairs_per_world * 8 + 255) / 256;
 #ifdef NT_EMULATED_GRID
     int blocks = (int)(wb < NT_EMULATED_GRID ? wb : NT_EMULATED_GRID);

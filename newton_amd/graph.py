@@ -8,13 +8,17 @@ substep -- records into one hipGraph and replays as ONE host call.
         graph.launch()
 
 `simulate` must leave the Python-side state as it found it (e.g. an even number of state swaps, as the examples do): replay
-repeats the recorded launches on the recorded buffers."""
+repeats the recorded launches on the recorded buffers.  Pass the frame's Contacts objects as `contacts=`: a replay re-runs the
+recorded collide launches without going through `CollisionPipeline.collide`, so `launch()` invalidates their cached flat views
+(`rigid_contact_count`, `rigid_contact_shape0`, ...) the way `collide()` does."""
 from __future__ import annotations
 
 
 class CapturedGraph:
-    def __init__(self, fn, warmup: int = 1, device=None):
+    def __init__(self, fn, warmup: int = 1, device=None, contacts=()):
         import torch  # noqa: PLC0415
+
+        self._contacts = tuple(contacts) if isinstance(contacts, (tuple, list)) else (contacts,)
 
         if not torch.cuda.is_available():
             raise RuntimeError("newton_amd.graph.capture needs a GPU (hipGraph capture)")
@@ -30,8 +34,11 @@ class CapturedGraph:
 
     def launch(self) -> None:
         self.graph.replay()
+        for c in self._contacts:  # the replayed collide launches rewrote the device buffers behind the cached exports
+            c.invalidate_views()
 
 
-def capture(fn, warmup: int = 1, device=None) -> CapturedGraph:
-    """Record `fn()` (a frame of collide / step calls) into a hipGraph; `.launch()` replays it."""
-    return CapturedGraph(fn, warmup=warmup, device=device)
+def capture(fn, warmup: int = 1, device=None, contacts=()) -> CapturedGraph:
+    """Record `fn()` (a frame of collide / step calls) into a hipGraph; `.launch()` replays it and invalidates the cached flat
+    views of `contacts` (one Contacts or a sequence of them)."""
+    return CapturedGraph(fn, warmup=warmup, device=device, contacts=contacts)

@@ -387,6 +387,10 @@ class GroupedContacts:
         for c in self.parts:
             c.clear()
 
+    def invalidate_views(self):
+        for c in self.parts:
+            c.invalidate_views()
+
 
 GroupedContacts.rigid_contact_shape0 = GroupedContacts._field("rigid_contact_shape0", True)
 GroupedContacts.rigid_contact_shape1 = GroupedContacts._field("rigid_contact_shape1", True)

@@ -274,7 +274,7 @@ class SdfLeg:
         """Host check (tests / benches, synchronises): did any world exceed its candidate capacity, or the rows their buffer?"""
         pc = int(self.pair_count.max().item()) if self.pair_count.numel() else 0
         appended = int(self.raw_count.item()) - self.hit_capacity  # rows that came through the counter
-        total = int(rows.row_start[-1].item())
+        total = int(self.world_rows.sum().item())  # unclamped: row_start itself never leaves the row arrays
         info = {"pairs_per_world_max": pc, "pairs_per_world_capacity": self.pairs_per_world, "appended_rows": appended,
                 "rows": total, "row_capacity": rows.capacity, "candidate_pairs": int(self.pair_prefix[-1].item()),
                 "pairs_with_rows": int((self.blk[:, 1] > 0).sum().item())}

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- pytest plugin that lets the `-m gpu` test files run on a machine WITHOUT a GPU, against the
 emulated kernel library (build.py): the product's Python path (DeviceModel, State, Contacts, CollisionPipeline, the solver
 classes) is exercised unchanged, its "cuda" tensors are redirected to host memory and libnewton_hip.so is replaced by
-libnewton_emu.so through the product's own NEWTON_HIP_LIB override.
+libnewton_emu.so by assigning newton_amd._lib.LIB_PATH before the first load().
 
     python -m pytest -p emu_plugin -m gpu tests/test_gpu_parity_xpbd.py     (with tests/emu on PYTHONPATH)
     python tests/emu/run_gpu_tests_emulated.py                              (the curated subset)
@@ -15,9 +15,15 @@ sys.path.insert(0, HERE)
 
 import build  # noqa: E402
 
-os.environ["NEWTON_HIP_LIB"] = build.build()  # read by newton_amd._lib at import time
+_EMU_LIB = build.build()
 
 import torch  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from newton_amd import _lib as _product_loader  # noqa: E402
+
+assert _product_loader._lib is None, "emu_plugin must be imported before the product library is loaded"
+_product_loader.LIB_PATH = _EMU_LIB
 
 
 def _cpu(dev):

@@ -9,7 +9,11 @@ import numpy as np
 
 import newton_amd as nt
 
-_LEGS = [("LF", 0.2999, 0.104, 1.0), ("RF", 0.2999, -0.104, -1.0), ("LH", -0.2999, 0.104, 1.0), ("RH", -0.2999, -0.104, -1.0)]
+# (leg, HAA x, HAA y, HAA yaw, HFE yaw sign, HFE y offset): newton/examples/assets/quadruped.urdf:24-29,86-91,148-153,210-215 (HAA
+# origins; the hind legs are mounted turned by rpy = "0 0 3.1415") and :44-47,106-109,168-171,230-233 (HFE origins; the hind
+# legs' y offsets are flipped with the mount)
+_LEGS = [("LF", 0.2999, 0.104, "0", 1.0, 0.05), ("RF", 0.2999, -0.104, "0", -1.0, -0.05),
+         ("LH", -0.2999, 0.104, "3.1415", 1.0, -0.05), ("RH", -0.2999, -0.104, "3.1415", -1.0, 0.05)]
 _HALF_PI = "1.57079632679"
 
 
@@ -34,14 +38,14 @@ def _quadruped_urdf_cylinders() -> str:
     out = ['<?xml version="1.0" encoding="utf-8"?>', '<robot name="quadruped">',
            '<link name="base"><collision><origin rpy="0 %s 0" xyz="0 0 0"/><geometry><cylinder length="0.75" radius="0.1"/>'
            '</geometry></collision></link>' % _HALF_PI]
-    for leg, x, y, sgn in _LEGS:
+    for leg, x, y, haa_yaw, sgn, hfe_y in _LEGS:
         out.append(f'<joint name="{leg}_HAA" type="revolute"><parent link="base"/><child link="{leg}_HAA"/><axis xyz="1 0 0"/>'
-                   f'<limit effort="80.0" velocity="20."/><origin rpy="0 0 0" xyz="{x} {y} 0.0"/></joint>')
+                   f'<limit effort="80.0" velocity="20."/><origin rpy="0 0 {haa_yaw}" xyz="{x} {y} 0.0"/></joint>')
         out.append(f'<link name="{leg}_HAA"><collision><origin rpy="{_HALF_PI} 0 0" xyz="0 0 0"/><geometry>'
                    '<cylinder length="0.05" radius="0.04"/></geometry></collision></link>')
         yaw = _HALF_PI if sgn > 0 else "-" + _HALF_PI
         out.append(f'<joint name="{leg}_HFE" type="revolute"><parent link="{leg}_HAA"/><child link="{leg}_THIGH"/>'
-                   f'<origin rpy="0 0 {yaw}" xyz="0 {0.05 * sgn} 0"/><axis xyz="1 0 0"/><limit effort="80.0" velocity="20."/>'
+                   f'<origin rpy="0 0 {yaw}" xyz="0 {hfe_y} 0"/><axis xyz="1 0 0"/><limit effort="80.0" velocity="20."/>'
                    '<dynamics damping="0.0" friction="0.0"/></joint>')
         out.append(f'<link name="{leg}_THIGH"><collision><origin rpy="0 0 0" xyz="0 0 -0.125"/><geometry>'
                    '<cylinder length="0.25" radius="0.02"/></geometry></collision></link>')

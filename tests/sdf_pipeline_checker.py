@@ -54,7 +54,7 @@ def sdf_scene(world_count, n_hulls=5, device=None, seed=5, sdf_resolution=16, wa
     return model
 
 
-def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None):
+def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None, worlds=None):
     """-> (rows dict in product order incl. `world`, `key`; candidate pairs per world [list of (a, b)]; the checker's world
     transforms and AABBs).  `world_xform` / `aabbs`: use the device's own exported arrays instead (the caller holds them against
     the checker's separately) -- the centred-difference SDF gradient amplifies a last-bit difference of a shape transform to
@@ -90,6 +90,9 @@ def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None):
     cand = []
     for w in range(t.env_count):
         pairs, tagged = [], []
+        if worlds is not None and w not in worlds:
+            cand.append([])
+            continue
         for k, (a, b) in enumerate(t.sdf_pair):
             s1, s2 = sorted((gid(int(a), w), gid(int(b), w)))
             if np.all(lo[s1] <= hi[s2]) and np.all(hi[s1] >= lo[s2]):
@@ -116,3 +119,57 @@ def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None):
         for name in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
             out[name] += list(wr[name])
     return {k: np.asarray(v) for k, v in out.items()}, cand, (X_checker, lo_checker, hi_checker)
+
+
+def hydro_checker_rows(model, body_q, world_xform, aabbs, reduce, worlds=None):
+    """The rows CollisionPipeline.collide emits for a model with hydroelastic pairs, from the checker chain
+    (oracle_hydro.hydro_pipeline: SAT, octree, marching cubes, optional reduction; the mesh-SDF edge leg for the other SDF pairs;
+    write_contact): dict of world / key / shape0 / shape1 / point0 / normal / stiffness / friction in the product's row order
+    (world-major, pairs ascending; a hydroelastic pair's faces in traversal order resp. the reduction's export order, an edge
+    pair's contacts in fingerprint order).  `reduce`: False, True (HydroelasticSDF.Config() as it comes) or "moment".
+    `worlds`: only these worlds (their candidates are still taken from the given AABBs)."""
+    import oracle_hydro as H
+
+    from newton_amd.mc_tables import tables
+
+    t = model.env
+    X, (lo, hi) = np.asarray(world_xform, np.float32), aabbs
+    mesh_rows, cand, _ = checker_rows(model, np.asarray(body_q), world_xform=X, aabbs=(lo, hi), kinds=t.sdf_pair_hydro, worlds=worlds)
+    tr, fl = tables()
+    tab = (np.asarray(tr), np.asarray(fl).reshape(-1, 2))
+    data = np.concatenate([np.asarray(model.shape_scale, np.float32), np.asarray(model.shape_margin, np.float32)[:, None]], axis=1)
+    gap, kh = np.asarray(model.shape_gap, np.float32), np.asarray(model.shape_material_kh, np.float32)
+    sdfs = [model._texture_sdf_data[i] if i >= 0 else None for i in np.asarray(model._shape_sdf_index)]
+    want = {k: [] for k in ("world", "key", "shape0", "shape1", "point0", "normal", "stiffness", "friction")}
+    for w in (range(t.env_count) if worlds is None else worlds):
+        hp = [p for p, kind in cand[w] if kind]
+        red = dict(aabb_lo=np.asarray(model.shape_collision_aabb_lower, np.float32), aabb_hi=np.asarray(model.shape_collision_aabb_upper, np.float32),
+                   res=np.asarray(model._shape_voxel_resolution, np.int32), pre_prune=True, normal_matching=True,
+                   moment_matching=reduce == "moment") if reduce else None
+        rows, _ = H.hydro_pipeline(np.asarray(hp, np.int32), X, data, gap, kh, sdfs, tab, reduce=red) if hp else ([], None)
+        per_pair = {}
+        for r in rows:
+            per_pair.setdefault(hp[r[0]], []).append(r)
+        m = {k: np.asarray(v)[np.asarray(mesh_rows["world"]) == w] for k, v in mesh_rows.items()}
+        for p, kind in cand[w]:
+            if kind:
+                rs = per_pair.get(p, [])
+                raw = dict(key=np.array([r[1] for r in rs]), shape_a=np.array([r[2] for r in rs]), shape_b=np.array([r[3] for r in rs]),
+                           center=np.array([r[4] for r in rs], np.float32).reshape(-1, 3), normal=np.array([r[5] for r in rs], np.float32).reshape(-1, 3),
+                           distance=np.array([r[6] for r in rs], np.float32), margin_a=np.zeros(len(rs), np.float32), margin_b=np.zeros(len(rs), np.float32))
+                wr = F.write_rows(raw, np.asarray(body_q, np.float32), np.asarray(model.shape_body), np.full(model.shape_count, 1e9, np.float32))
+                want["world"] += [w] * len(rs)
+                want["key"] += [r[1] for r in rs]
+                want["stiffness"] += [r[7] for r in rs]
+                want["friction"] += [r[8] if reduce else 0.0 for r in rs]
+                for k in ("shape0", "shape1", "point0", "normal"):
+                    want[k] += list(wr[k])
+            else:
+                sel = (m["shape0"] == p[0]) & (m["shape1"] == p[1]) if len(m["key"]) else np.zeros(0, bool)
+                want["world"] += [w] * int(sel.sum())
+                want["key"] += m["key"][sel].tolist()
+                want["stiffness"] += [0.0] * int(sel.sum())
+                want["friction"] += [0.0] * int(sel.sum())
+                for k in ("shape0", "shape1", "point0", "normal"):
+                    want[k] += list(m[k][sel])
+    return want, cand

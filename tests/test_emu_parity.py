@@ -56,7 +56,7 @@ def test_xpbd_quadruped_step(H, n_env, epb):
     from scenes import quadruped_scene
 
     model = quadruped_scene(n_env)
-    _lower(model, 0.24)
+    _lower(model, 0.26)
     rng = np.random.default_rng(7)
     model.body_qd = (model.body_qd + rng.normal(0, 0.2, size=model.body_qd.shape)).astype(np.float32)
     jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
@@ -77,7 +77,7 @@ def test_xpbd_rollout_equals_loop_and_oracle(H):
     from scenes import quadruped_scene
 
     model = quadruped_scene(20)
-    _lower(model, 0.22)
+    _lower(model, 0.24)
     em = H.EmuModel(model)
     ctrl, ct = H.EmuControl(em), H.EmuContacts(em)
     out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1e-3, 7)
@@ -157,7 +157,7 @@ def test_restitution_and_reporting(H):
 
     model = quadruped_scene(6)
     model.request_state_attributes("body_parent_f")
-    _lower(model, 0.24)
+    _lower(model, 0.26)
     rng = np.random.default_rng(3)
     model.body_qd = (model.body_qd + rng.normal(0, 0.3, size=model.body_qd.shape)).astype(np.float32)
     jf = rng.normal(0, 5.0, size=model.joint_dof_count).astype(np.float32)
@@ -215,7 +215,7 @@ def test_featherstone_step_and_rollout(H, n_env, epb):
 
     model = quadruped_scene(n_env)
     model.request_state_attributes("body_parent_f")
-    _lower(model, 0.24)
+    _lower(model, 0.26)
     rng = np.random.default_rng(11)
     model.joint_qd = (model.joint_qd + rng.normal(0, 0.3, size=model.joint_qd.shape)).astype(np.float32)
     jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
@@ -267,10 +267,12 @@ def test_featherstone_kinematic_root_and_zoo(H):
 
 
 def test_emulated_library_is_test_only():
-    """The product loader resolves only newton_amd/libnewton_hip.so (or an explicit NEWTON_HIP_LIB override)."""
+    """The product loader resolves only newton_amd/libnewton_hip.so: no environment override, no reference to the emulated
+    library anywhere in the package."""
     from newton_amd import _lib
 
     assert "emu" not in os.path.basename(_lib.LIB_PATH)
+    assert "environ" not in open(_lib.__file__).read()
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "newton_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
@@ -458,7 +460,7 @@ def test_velocity_from_position_delta(H):
     for model, dt, rest, lower in ((quadruped_scene(5, seed=21), 1e-3, False, True), (quadruped_scene(3, seed=22), 1e-3, True, True),
                                    (pendulum_scene(3, seed=4), 2e-3, False, False), (hull_bin_scene(2, 40), 1.0 / 600.0, True, False)):
         if lower:
-            _lower(model, 0.23)
+            _lower(model, 0.25)
         em = H.EmuModel(model)
         s0, s1, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
         plain = H.EmuState(em)

@@ -9,7 +9,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TESTS = os.path.join(ROOT, "tests")
 ENV = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(TESTS, "emu"), ROOT, os.environ.get("PYTHONPATH", "")]))
-ENV.pop("NEWTON_HIP_LIB", None)
 
 
 def test_gpu_test_files_dry_run(oracle_lib):

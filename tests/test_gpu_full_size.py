@@ -40,7 +40,7 @@ def test_c4_4096_quadrupeds_one_frame_vs_oracle(lowered):
 
     nt, model, o = _setup(quadruped_scene, 4096, seed=1)
     if lowered:
-        _lower_quadrupeds(nt, model, 0.24)
+        _lower_quadrupeds(nt, model, 0.26)
     s0, s1 = model.state(), model.state()
     pipe = nt.CollisionPipeline(model)
     contacts = pipe.contacts()
@@ -79,7 +79,7 @@ def test_c4_env_result_is_independent_of_batch_and_tile():
 
     def run(n, epb):
         model = quadruped_scene(n, device="cuda:0", seed=1)
-        _lower_quadrupeds(nt, model, 0.22)
+        _lower_quadrupeds(nt, model, 0.24)
         s0, s1 = model.state(), model.state()
         contacts = nt.CollisionPipeline(model, envs_per_block=epb).contacts()
         out = nt.solvers.SolverXPBD(model, iterations=2, envs_per_block=epb).rollout(s0, s1, None, contacts, DT, 10)
@@ -95,13 +95,18 @@ def test_c4_env_result_is_independent_of_batch_and_tile():
         assert np.array_equal(qd, qd_full[:n]), (n, epb)
 
 
-def test_c3_4096_quadrupeds_featherstone_frame_vs_oracle():
-    """Config C3 at full size: SolverFeatherstone, 4096 envs, 10 fused substeps of PD hold in free flight (the feet touch down
-    later: the chaotic impact phase is covered step-wise in test_gpu_parity_featherstone.py)."""
+@pytest.mark.parametrize("lowered", [False, True])
+def test_c3_4096_quadrupeds_featherstone_frame_vs_oracle(lowered):
+    """Config C3 at full size: SolverFeatherstone, 4096 envs, 10 fused substeps of PD hold -- in free flight, and `lowered`
+    with the feet pressed into the ground so that every environment carries live penalty contacts for the whole frame
+    (eval_body_contact through the fused rollout; the chaotic impact phase is covered step-wise in
+    test_gpu_parity_featherstone.py)."""
     from oracle_bridge import OracleState
     from scenes import quadruped_scene
 
-    nt, model, o = _setup(quadruped_scene, 4096, seed=1)
+    nt, model, o = _setup(quadruped_scene, N_C4, seed=1)
+    if lowered:
+        _lower_quadrupeds(nt, model, 0.26)
     s0, s1 = model.state(), model.state()
     contacts = nt.CollisionPipeline(model).contacts()
     out = nt.solvers.SolverFeatherstone(model).rollout(s0, s1, None, contacts, DT, 10)
@@ -109,17 +114,29 @@ def test_c3_4096_quadrupeds_featherstone_frame_vs_oracle():
     os0, os1 = OracleState(model), OracleState(model)
     oc = o.contacts()
     c = o.control()
+    live = []
     for _ in range(10):
         os0.body_f[:] = 0
         o.collide(os0.body_q, oc)
+        live.append(int(oc.count[0]))
         o.featherstone_step(os0, os1, c, oc, DT)
         os0, os1 = os1, os0
+    if lowered:
+        assert min(live) >= N_C4 * 4, live  # every substep of the frame has contacts in every environment
     assert _rel(out.joint_q.cpu().numpy(), os0.joint_q) <= 1e-4
-    tol.check("c3_4096_quadrupeds_featherstone_frame", out.body_q.cpu().numpy(), out.body_qd.cpu().numpy(), os0.body_q,
-              os0.body_qd, pos=1e-6, rot=1e-6, lin_vel=1e-5, ang_vel=1e-5)  # measured: 3e-12 / 6e-8 / 1.7e-7 / 5.9e-8
+    # free flight measured 3e-12 / 6e-8 / 1.7e-7 / 5.9e-8; with live contacts the penalty forces (ke = 2.5e3 x depth differences
+    # of a few position ulps) enter the velocities, so they are gated like the XPBD frame
+    kw = dict(pos=1e-6, rot=1e-6, lin_vel=1e-5, ang_vel=1e-5) if not lowered else dict(pos=1e-5, rot=1e-5, lin_vel=1e-4,
+                                                                                      ang_vel=1e-4)
+    tol.check(f"c3_4096_quadrupeds_featherstone_frame lowered={lowered}", out.body_q.cpu().numpy(), out.body_qd.cpu().numpy(),
+              os0.body_q, os0.body_qd, **kw)
     jqd, jqd_ref = out.joint_qd.cpu().numpy(), os0.joint_qd
     assert float(np.max(np.abs(jqd - jqd_ref) / np.maximum(np.abs(jqd_ref), 0.05))) <= 1e-3
-    assert np.array_equal(contacts.rigid_contact_count_per_env.cpu().numpy(), _per_env_counts(model, oc))
+    got, want = contacts.rigid_contact_count_per_env.cpu().numpy(), _per_env_counts(model, oc)
+    if lowered:  # contacts of the 10th substep come from states that already differ by rounding (as in the C4 frame test)
+        assert np.mean(got == want) >= 0.999 and abs(int(got.sum()) - int(want.sum())) <= 8
+    else:
+        assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("broad_phase", ["explicit", "nxn"])
@@ -167,7 +184,7 @@ def test_c4_convex_variant_4096_box_quadrupeds_vs_oracle():
 
     nt, model, o = _setup(quadruped_convex_scene, N_C4, seed=1)
     assert model.env.np_analytic == 0 and model.env.np == 13 and model.env.cpp == 5
-    _lower_quadrupeds(nt, model, 0.24)
+    _lower_quadrupeds(nt, model, 0.26)
     s0, s1 = model.state(), model.state()
     pipe = nt.CollisionPipeline(model)
     contacts = pipe.contacts()

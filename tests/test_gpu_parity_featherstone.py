@@ -40,7 +40,7 @@ def test_quadruped_single_step(n_env, epb):
     from scenes import quadruped_scene
 
     nt, model, o = _setup(quadruped_scene, n_env)
-    _lower_quadrupeds(nt, model, 0.24)
+    _lower_quadrupeds(nt, model, 0.26)
     rng = np.random.default_rng(11)
     model.joint_qd = (model.joint_qd + rng.normal(0, 0.3, size=model.joint_qd.shape)).astype(np.float32)
     jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)
@@ -74,7 +74,7 @@ def test_quadruped_impact_phase_stepwise():
     from scenes import quadruped_scene
 
     nt, model, o = _setup(quadruped_scene, 6)
-    _lower_quadrupeds(nt, model, 0.2)
+    _lower_quadrupeds(nt, model, 0.22)
     s0, s1 = model.state(), model.state()
     pipe = nt.CollisionPipeline(model)
     contacts = pipe.contacts()
@@ -170,7 +170,7 @@ def test_rollout_bitwise_equals_api_loop():
     from scenes import quadruped_scene
 
     nt, model, _ = _setup(quadruped_scene, 21)
-    _lower_quadrupeds(nt, model, 0.21)
+    _lower_quadrupeds(nt, model, 0.23)
     pipe = nt.CollisionPipeline(model)
     contacts = pipe.contacts()
     solver = nt.solvers.SolverFeatherstone(model)
@@ -194,7 +194,7 @@ def test_body_parent_f_matches_oracle_step_and_rollout():
 
     nt, model, o = _setup(quadruped_scene, 37)
     model.request_state_attributes("body_parent_f")
-    _lower_quadrupeds(nt, model, 0.24)
+    _lower_quadrupeds(nt, model, 0.26)
     rng = np.random.default_rng(5)
     model.joint_qd = (model.joint_qd + rng.normal(0, 0.3, size=model.joint_qd.shape)).astype(np.float32)
     jf = rng.normal(0, 2.0, size=model.joint_dof_count).astype(np.float32)

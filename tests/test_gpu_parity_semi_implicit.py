@@ -46,7 +46,7 @@ def test_quadruped_semi_implicit_with_contacts():
 
     model = quadruped_scene(21, device="cuda:0")
     E = model.world_count
-    model.joint_q.reshape(E, -1)[:, 2] -= 0.24
+    model.joint_q.reshape(E, -1)[:, 2] -= 0.26
     bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
     model.body_q, model.body_qd = bq, bqd
     rng = np.random.default_rng(3)

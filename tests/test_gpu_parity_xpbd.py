@@ -64,7 +64,7 @@ def test_quadruped_single_step(n_env, epb):
     from scenes import quadruped_scene
 
     nt, model, o = _setup(quadruped_scene, n_env)
-    _lower_quadrupeds(nt, model, 0.24)
+    _lower_quadrupeds(nt, model, 0.26)
     rng = np.random.default_rng(7)
     model.body_qd = (model.body_qd + rng.normal(0, 0.2, size=model.body_qd.shape)).astype(np.float32)
     s0, s1 = model.state(), model.state()
@@ -95,7 +95,7 @@ def test_quadruped_rollout_100_substeps():
 
     n_env = 48
     nt, model, o = _setup(quadruped_scene, n_env)
-    _lower_quadrupeds(nt, model, 0.2)
+    _lower_quadrupeds(nt, model, 0.22)
     dt = 1e-3
     pipe = nt.CollisionPipeline(model)
     contacts = pipe.contacts()
@@ -402,7 +402,7 @@ def test_reported_contact_force_and_parent_force_match_oracle(n_env, epb):
     nt, model, o = _setup(quadruped_scene, n_env)
     model.request_state_attributes("body_parent_f")
     model.request_contact_attributes("force")
-    _lower_quadrupeds(nt, model, 0.24)
+    _lower_quadrupeds(nt, model, 0.26)
     rng = np.random.default_rng(11)
     model.body_qd = (model.body_qd + rng.normal(0, 0.2, size=model.body_qd.shape)).astype(np.float32)
     joint_f = rng.normal(0, 5.0, size=model.joint_dof_count).astype(np.float32)

@@ -10,6 +10,8 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
+N_C5 = int(os.environ.get("NT_FULL_SIZE_C5_ENVS", "2048"))  # BASELINE.json config 5's world count
+C5_SETTLE_STEPS = int(os.environ.get("NT_C5_SETTLE_STEPS", "600"))  # (both shrunk only by the emulated dry run of this file)
 
 FIELDS = ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")
 
@@ -168,6 +170,68 @@ def test_survivor_list_overflow_is_reported_and_harmless():
         assert np.array_equal(want[k], b[k]), k
 
 
+def test_row_capacity_overflow_is_reported_and_memory_safe():
+    """More rows than the FlatRows arrays hold: the per-world ranges and the per-body block lists stop at the capacity (nothing
+    is read or written behind the arrays), the call reports it, rows beyond the declared capacity keep their sentinel, and the
+    solvers step on what was kept.  A frame with fewer rows afterwards leaves no stale row alive."""
+    import torch
+
+    import newton_amd as nt
+    from sdf_pipeline_checker import sdf_scene
+
+    model = sdf_scene(3, 7, device="cuda:0", walls=True, seed=4)
+    _pile(model)
+    state, out = model.state(), model.state()
+    full_pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    full = full_pipe.contacts()
+    full_pipe.collide(state, full)
+    n_full = int(full._flat.row_start[-1].item())
+    assert n_full > 40 and not full_pipe._sdf_leg.overflow(full._flat)["overflow"]
+
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    c = pipe.contacts()
+    f = c._flat
+    cap = n_full // 3  # the declared capacity ends inside the second world's rows; the buffers behind it are the real ones
+    f.capacity = cap
+    for k in FIELDS[2:]:
+        getattr(f, k)[cap:] = 777.0  # canaries behind the declared capacity
+    f.shape0[cap:] = -7
+    f.shape1[cap:] = -7
+    f.cw[cap:] = 777.0
+    pipe.collide(state, c)
+    info = pipe._sdf_leg.overflow(f)
+    assert info["overflow"] and info["rows"] == n_full and info["row_capacity"] == cap, info
+    rs = f.row_start.cpu().numpy()
+    assert rs[-1] == cap and np.all(np.diff(rs) >= 0) and rs.max() <= cap
+    for k in FIELDS[2:]:
+        assert bool((getattr(f, k)[cap:] == 777.0).all()), k
+    assert bool((f.shape0[cap:] == -7).all()) and bool((f.shape1[cap:] == -7).all())
+    # the kept rows are the first `cap` rows of the full result, bit for bit
+    want, got = _rows(full), _rows(c)
+    for k in FIELDS:
+        assert np.array_equal(got[k], want[k][:cap]), k
+    # every block of every body ends inside the arrays
+    t = model.env
+    bs = f.body_blk_start.cpu().numpy().reshape(t.env_count, t.nb + 1)
+    bl = f.body_blk_list.cpu().numpy()
+    for w in range(t.env_count):
+        for i in range(bs[w, 0], bs[w, -1]):
+            r0, count = bl[i, 0] >> 1, bl[i, 1]
+            assert count > 0 and r0 + count <= cap, (w, i, r0, count)
+    nt.solvers.SolverXPBD(model, iterations=2).step(state, out, None, c, 1e-3)
+    torch.cuda.synchronize()
+    assert np.isfinite(out.body_q.cpu().numpy()).all()
+    assert bool((f.cw[cap:] == 777.0).all())  # the step's correction records stay inside as well
+    # next frame: hulls far apart -> no rows; nothing of the crowded frame survives
+    q = np.asarray(model.body_q).copy()
+    q[:, :2] *= 50.0
+    q[:, 2] += 3.0 + 5.0 * np.tile(np.arange(t.nb), t.env_count)  # also off the walls and off each other
+    far = model.state()
+    far.body_q = q
+    pipe.collide(far, c)
+    assert int(f.row_start[-1].item()) == 0 and bool((f.shape0[:cap] == -1).all()) and bool((f.shape1[:cap] == -1).all())
+
+
 def test_worlds_without_candidates_give_no_rows():
     """Hulls far apart: no candidate pair survives the AABB test, every stage runs on an empty population."""
     import newton_amd as nt
@@ -304,6 +368,36 @@ def test_penalty_solvers_consume_the_rows_like_the_checker(solver_name):
     assert np.abs(ot1.body_qd - os1.body_qd).max() > 1e-3  # the rows' forces are in the result
 
 
+_C5_PILE = {}
+
+
+def _c5_settled_pile(E):
+    """Config C5's pile at rest: E worlds x 64 hulls dropped into the bin and settled for 0.5 s by SolverXPBD on the rows of the
+    mesh-SDF leg (600 collide + step substeps at dt = 1/1200; both C5 tests start from these poses) -> (model, pipe, state)."""
+    import newton_amd as nt
+    import scenes
+
+    if E not in _C5_PILE:
+        model = scenes.hull_bin_scene(E, 64, device="cuda:0", seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005))
+        if C5_SETTLE_STEPS < 100:  # emulated dry run of the test logic only: no time to fall, squeeze the start lattice instead
+            q = np.asarray(model.body_q).copy()
+            q[:, :2] *= 0.63
+            q[:, 2] = 0.045 + (q[:, 2] - 0.08) * 0.63
+            model.body_q = q
+            model.joint_q.reshape(-1, 7)[:, :3] = q[:, :3]
+        pipe = nt.CollisionPipeline(model, broad_phase="sap")
+        c1 = pipe.contacts()
+        s0, s1, ctrl = model.state(), model.state(), model.control()
+        solver = nt.solvers.SolverXPBD(model, iterations=2)
+        for _ in range(C5_SETTLE_STEPS):  # 0.5 s: the hulls drop 2 cm onto the floor and each other
+            s0.clear_forces()
+            pipe.collide(s0, c1)
+            solver.step(s0, s1, ctrl, c1, 1.0 / 1200.0)
+            s0, s1 = s1, s0
+        _C5_PILE[E] = (model, pipe, s0)
+    return _C5_PILE[E]
+
+
 def test_config_c5_rows_at_full_size():
     """Config C5 at its stated size -- 2 048 worlds x 64 hulls with uint16 texture SDFs in a bin of five SDF boxes, every pair
     through the SDF leg -- settled with SolverXPBD consuming the rows: two collide() calls give bit-identical rows, no capacity is
@@ -311,25 +405,15 @@ def test_config_c5_rows_at_full_size():
     and counts exact; geometry 2e-6 on the device's own shape transforms, which are held against the checker's to 1e-6)."""
     import torch
 
-    if getattr(torch.cuda, "_newton_emulated", False):
+    if getattr(torch.cuda, "_newton_emulated", False) and N_C5 > 4:
         pytest.skip("2 048 worlds x 64 hulls: device only (hours in emulation)")
-    import newton_amd as nt
-    import scenes
     from sdf_pipeline_checker import checker_rows
 
-    E = 2048
-    model = scenes.hull_bin_scene(E, 64, device="cuda:0", seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005))
+    E = N_C5
+    model, pipe, s0 = _c5_settled_pile(E)
     t = model.env
     assert t.np == 0 and len(t.sdf_pair) == 64 * 63 // 2 + 64 * 5
-    pipe = nt.CollisionPipeline(model, broad_phase="sap")
     c1, c2 = pipe.contacts(), pipe.contacts()
-    s0, s1, ctrl = model.state(), model.state(), model.control()
-    solver = nt.solvers.SolverXPBD(model, iterations=2)
-    for _ in range(600):  # 0.5 s: the hulls drop 2 cm onto the floor and each other
-        s0.clear_forces()
-        pipe.collide(s0, c1)
-        solver.step(s0, s1, ctrl, c1, 1.0 / 1200.0)
-        s0, s1 = s1, s0
     pipe.collide(s0, c1)
     pipe.collide(s0, c2)
     torch.cuda.synchronize()
@@ -347,7 +431,7 @@ def test_config_c5_rows_at_full_size():
     leg = pipe._sdf_leg
     X, lo, hi = leg.world_xform.cpu().numpy(), leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
     pc = leg.pair_count.cpu().numpy()
-    for w in range(0, E, 128):  # 16 worlds across the batch
+    for w in range(0, E, max(E // 16, 1)):  # 16 worlds across the batch
         sub = slice_worlds(model, w, w + 1)
         ids = np.asarray(sub._global_shape_ids)
         bq = q[w * t.nb:(w + 1) * t.nb]
@@ -362,6 +446,71 @@ def test_config_c5_rows_at_full_size():
             assert np.array_equal(got, want[k]), (w, k)
         for k in FIELDS[2:]:
             assert np.abs(a[k][r0:r1] - want[k]).max() <= 2e-6, (w, k, np.abs(a[k][r0:r1] - want[k]).max())
+
+
+def test_config_c5_hydroelastic_rows_at_full_size():
+    """The hydroelastic half of config C5 at its stated size -- 2 048 worlds x 64 hulls + five walls, every shape HYDROELASTIC
+    (kh = 1e10), HydroelasticSDF.Config() as it comes (reduce_contacts, pre_prune_contacts, normal_matching) -- on the settled pile
+    of the test above: two collide() calls give bit-identical rows, stiffnesses and friction scales, no capacity is exceeded
+    (SdfLeg.overflow()), and the rows of sampled worlds equal the checker chain oracle_hydro.hydro_pipeline (pinned by the executed
+    reference, tests/test_hydro_reference_vectors.py): ids, keys, order and counts exact, geometry 2e-6, stiffness 1e-5 relative.
+    Reference: sdf_hydroelastic.py:905-1296, contact_reduction_hydroelastic.py:1683-1913."""
+    import torch
+
+    if getattr(torch.cuda, "_newton_emulated", False) and N_C5 > 4:
+        pytest.skip("2 048 worlds x 64 hulls: device only (hours in emulation)")
+    import newton_amd as nt
+    import scenes
+    from newton_amd.worlds import slice_worlds
+    from sdf_pipeline_checker import hydro_checker_rows
+
+    E = N_C5
+    _, _, settled = _c5_settled_pile(E)
+    q = settled.body_q.cpu().numpy()
+    model = scenes.hull_bin_scene(E, 64, device="cuda:0", seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005), hydroelastic=True)
+    t = model.env
+    assert t.np == 0 and len(t.sdf_pair) == 64 * 63 // 2 + 64 * 5 and bool(np.all(t.sdf_pair_hydro))
+    pipe = nt.CollisionPipeline(model, broad_phase="sap", sdf_hydroelastic_config=nt.geometry.HydroelasticSDF.Config(),
+                                sdf_contacts_per_shape=400)
+    c1, c2 = pipe.contacts(), pipe.contacts()
+    s0 = model.state()
+    s0.body_q = q
+    pipe.collide(s0, c1)
+    pipe.collide(s0, c2)
+    torch.cuda.synchronize()
+    a, b = _rows(c1), _rows(c2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    f = c1._flat
+    n = len(a["key"])
+    stiff, fric = f.stiffness[:n].cpu().numpy(), f.friction_scale[:n].cpu().numpy()
+    assert np.array_equal(stiff, c2._flat.stiffness[:n].cpu().numpy()) and np.array_equal(fric, c2._flat.friction_scale[:n].cpu().numpy())
+    ov = pipe._sdf_leg.overflow(f)
+    assert not ov["overflow"] and ov["rows"] == n > 20 * E and ov["hydro_faces"] > 100 * E, ov
+    live = a["shape0"] != a["shape1"]
+    assert live.all() and (stiff > 0).all() and np.isfinite(a["point0"]).all() and np.isfinite(a["normal"]).all()
+    assert np.abs(np.linalg.norm(a["normal"], axis=1) - 1.0).max() < 1e-5
+    # sampled worlds against the checker chain, on the device's own shape transforms (held against the checker's to 1e-6)
+    leg = pipe._sdf_leg
+    X, lo, hi = leg.world_xform.cpu().numpy(), leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    pc = leg.pair_count.cpu().numpy()
+    for w in range(E // 8, E, max(E // 4, 1)):  # 4 worlds across the batch (the numpy checker needs ~20 s per world)
+        sub = slice_worlds(model, w, w + 1)
+        ids = np.asarray(sub._global_shape_ids)
+        bq = q[w * t.nb:(w + 1) * t.nb]
+        want, cand = hydro_checker_rows(sub, bq, X[ids], (lo[ids], hi[ids]), True)
+        r0, r1 = a["row_start"][w], a["row_start"][w + 1]
+        assert pc[w] == len(cand[0]) and r1 - r0 == len(want["key"]) > 20, (w, pc[w], len(cand[0]), r1 - r0, len(want["key"]))
+        assert np.array_equal(a["key"][r0:r1], np.asarray(want["key"]))
+        back = {int(g): k for k, g in enumerate(ids)}
+        for k in ("shape0", "shape1"):
+            got = np.array([back[int(s)] for s in a[k][r0:r1]])
+            assert np.array_equal(got, np.asarray(want[k])), (w, k)
+        assert np.abs(a["point0"][r0:r1] - np.asarray(want["point0"])).max() <= 2e-6, w
+        assert np.abs(a["normal"][r0:r1] - np.asarray(want["normal"])).max() <= 2e-6, w
+        ws = np.asarray(want["stiffness"], np.float32)
+        assert np.abs(stiff[r0:r1] - ws).max() <= 1e-5 * np.abs(ws).max(), w
+        assert np.array_equal(fric[r0:r1], np.ones(r1 - r0, np.float32))
 
 
 def hydro_scene(world_count, device=None, seed=21):
@@ -413,12 +562,7 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
 
     import newton_amd as nt
     from oracle_bridge import Oracle, OracleState
-    from sdf_pipeline_checker import checker_rows  # (puts oracle/ on the path)
-
-    import oracle_flat_contacts as F
-    import oracle_hydro as H
-
-    from newton_amd.mc_tables import tables
+    from sdf_pipeline_checker import hydro_checker_rows  # (puts oracle/ on the path)
 
     E = 2
     model = hydro_scene(E, device="cuda:0")
@@ -443,44 +587,7 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     # ---- the checker chain on the device's shape transforms
     leg = pipe._sdf_leg
     X, lo, hi = leg.world_xform.cpu().numpy(), leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
-    mesh_rows, cand, _ = checker_rows(model, np.asarray(model.body_q), world_xform=X, aabbs=(lo, hi), kinds=t.sdf_pair_hydro)
-    tr, fl = tables()
-    tab = (np.asarray(tr), np.asarray(fl).reshape(-1, 2))
-    data = np.concatenate([np.asarray(model.shape_scale, np.float32), np.asarray(model.shape_margin, np.float32)[:, None]], axis=1)
-    gap, kh = np.asarray(model.shape_gap, np.float32), np.asarray(model.shape_material_kh, np.float32)
-    sdfs = [model._texture_sdf_data[i] if i >= 0 else None for i in np.asarray(model._shape_sdf_index)]
-    want = {k: [] for k in ("world", "key", "shape0", "shape1", "point0", "normal", "stiffness", "friction")}
-    for w in range(E):
-        hp = [p for p, kind in cand[w] if kind]
-        red = dict(aabb_lo=np.asarray(model.shape_collision_aabb_lower, np.float32), aabb_hi=np.asarray(model.shape_collision_aabb_upper, np.float32),
-                   res=np.asarray(model._shape_voxel_resolution, np.int32), pre_prune=True, normal_matching=True,
-                   moment_matching=reduce == "moment") if reduce else None
-        rows, _ = H.hydro_pipeline(np.asarray(hp, np.int32), X, data, gap, kh, sdfs, tab, reduce=red) if hp else ([], None)
-        per_pair = {}
-        for r in rows:
-            per_pair.setdefault(hp[r[0]], []).append(r)
-        m = {k: np.asarray(v)[np.asarray(mesh_rows["world"]) == w] for k, v in mesh_rows.items()}
-        for p, kind in cand[w]:  # pairs ascending; a pair's rows: hydro faces in traversal order / edge contacts in fingerprint order
-            if kind:
-                rs = per_pair.get(p, [])
-                raw = dict(key=np.array([r[1] for r in rs]), shape_a=np.array([r[2] for r in rs]), shape_b=np.array([r[3] for r in rs]),
-                           center=np.array([r[4] for r in rs], np.float32).reshape(-1, 3), normal=np.array([r[5] for r in rs], np.float32).reshape(-1, 3),
-                           distance=np.array([r[6] for r in rs], np.float32), margin_a=np.zeros(len(rs), np.float32), margin_b=np.zeros(len(rs), np.float32))
-                wr = F.write_rows(raw, np.asarray(model.body_q, np.float32), np.asarray(model.shape_body), np.full(model.shape_count, 1e9, np.float32))
-                want["world"] += [w] * len(rs)
-                want["key"] += [r[1] for r in rs]
-                want["stiffness"] += [r[7] for r in rs]
-                want["friction"] += [r[8] if reduce else 0.0 for r in rs]
-                for k in ("shape0", "shape1", "point0", "normal"):
-                    want[k] += list(wr[k])
-            else:
-                sel = (m["shape0"] == p[0]) & (m["shape1"] == p[1]) if len(m["key"]) else np.zeros(0, bool)
-                want["world"] += [w] * int(sel.sum())
-                want["key"] += m["key"][sel].tolist()
-                want["stiffness"] += [0.0] * int(sel.sum())
-                want["friction"] += [0.0] * int(sel.sum())
-                for k in ("shape0", "shape1", "point0", "normal"):
-                    want[k] += list(m[k][sel])
+    want, _ = hydro_checker_rows(model, np.asarray(model.body_q), X, (lo, hi), reduce)
     lim = (20, 10) if reduce else (100, 50)
     assert len(want["key"]) == n > lim[0] and (np.asarray(want["stiffness"]) > 0).sum() > lim[1] and (np.asarray(want["stiffness"]) == 0).sum() > 0
     assert np.array_equal(a["key"], np.asarray(want["key"])) and np.array_equal(a["shape0"], np.asarray(want["shape0"]))

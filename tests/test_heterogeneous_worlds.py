@@ -56,7 +56,7 @@ def mixed_model(layout, device=None, seed=5):
         j = np.flatnonzero(jw == w)
         if model.joint_type[j[0]] == nt.JointType.FREE and len(j) == 13:
             q0 = int(model.joint_q_start[j[0]])
-            model.joint_q[q0 + 2] -= 0.24 - rng.uniform(0.0, 0.003)
+            model.joint_q[q0 + 2] -= 0.26 - rng.uniform(0.0, 0.003)
     bq, bqd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
     model.body_q = bq
     model.body_qd = (bqd + rng.normal(0.0, 0.05, size=bqd.shape)).astype(np.float32)

@@ -32,6 +32,30 @@ def test_quadruped_model_matches_survey_counts():
     assert model.gravity.shape == (5, 3) and np.allclose(model.gravity[:, 2], -9.81)
 
 
+def test_quadruped_scene_is_the_reference_asset():
+    """The bench / test quadruped carries the numbers of newton/examples/assets/quadruped.urdf exactly -- joint origins (the hind
+    legs' HAA mounts are turned by rpy "0 0 3.1415" and their HFE offsets flipped, :148-215), axes, limits, collision
+    geometry -- checked against tests/golden/quadruped_asset.json (the reference file read with ElementTree by
+    tests/golden/make_quadruped_asset_vectors.py, independent of newton_amd.urdf)."""
+    import json
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_quadruped_asset_vectors import asset_numbers
+    from scenes import quadruped_urdf
+
+    with open(os.path.join(ROOT, "tests", "golden", "quadruped_asset.json")) as f:
+        want = json.load(f)
+    got = asset_numbers(quadruped_urdf())
+    assert [j["name"] for j in got["joints"]] == [j["name"] for j in want["joints"]]
+    assert [k["name"] for k in got["links"]] == [k["name"] for k in want["links"]]
+    for g, w in zip(got["joints"], want["joints"]):
+        assert g == w, (g, w)
+    for g, w in zip(got["links"], want["links"]):
+        assert g == w, (g, w)
+    assert want["joints"][6]["rpy"] == [0.0, 0.0, 3.1415] and want["joints"][7]["xyz"] == [0.0, -0.05, 0.0]
+
+
 def test_box_stack_pairs_and_cpp():
     model = box_stack_scene(2, n_boxes=8, seed=None)
     t = model.env

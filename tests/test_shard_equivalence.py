@@ -32,7 +32,7 @@ def _global_model(n):
     from scenes import quadruped_scene
 
     model = quadruped_scene(n, seed=1)
-    _lower(model, 0.23)
+    _lower(model, 0.25)
     rng = np.random.default_rng(11)
     model.body_qd = (model.body_qd + rng.normal(0, 0.1, size=model.body_qd.shape)).astype(np.float32)
     return model

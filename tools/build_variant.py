@@ -2,7 +2,7 @@
 """Build a throw-away measurement variant of libnewton_hip.so with extra -D flags (never the product library):
     python tools/build_variant.py build_ab/libnewton_ablation.so -DNT_ABLATION
     python tools/build_variant.py build_ab/libnewton_timing.so -DNT_PHASE_TIMING
-Use it through the loader's NEWTON_HIP_LIB override (announced on stderr).  Run here (hipcc cross-compiles) so that no GPU-minutes
+Use it through tools/with_lib.py (the product loader has no override; the reassignment is announced on stderr).  Run here (hipcc cross-compiles) so that no GPU-minutes
 go into compiling."""
 import os
 import subprocess

@@ -13,7 +13,7 @@ from scenes import quadruped_scene  # noqa: E402
 from test_gpu_parity_xpbd import _lower_quadrupeds  # noqa: E402
 
 model = quadruped_scene(int(sys.argv[2]) if len(sys.argv) > 2 else 3, device="cuda:0")
-_lower_quadrupeds(nt, model, 0.2)
+_lower_quadrupeds(nt, model, 0.22)
 o = Oracle(model)
 s0, s1 = model.state(), model.state()
 pipe = nt.CollisionPipeline(model)

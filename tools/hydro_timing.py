@@ -1,4 +1,4 @@
-"""Where hydro_pairs_kernel<true> spends its cycles (measurement tool, GPU box): run with NEWTON_HIP_LIB pointing at a library built
+"""Where hydro_pairs_kernel<true> spends its cycles (measurement tool, GPU box): run through tools/with_lib.py on a library built
 with -DNT_HYDRO_TIMING (tools/build_variant.py); same physics as the product (the build only adds timestamps)."""
 import ctypes as C
 import json

@@ -2,7 +2,7 @@
 """Per-phase cycle accounting of xpbd_rollout_kernel (run ON the GPU box).
 
 Builds a throw-away debug library with -DNT_PHASE_TIMING (workgroup 0 / thread 0 accumulates cycle deltas at every
-phase barrier), runs the bench workload through it (NEWTON_HIP_LIB override) and prints the share of each phase.
+phase barrier), runs the bench workload through it (newton_amd._lib.LIB_PATH assigned before the first load) and prints the share of each phase.
 """
 import ctypes as C
 import os
@@ -10,19 +10,20 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dbg = os.environ.get("NEWTON_HIP_LIB") or os.path.join(ROOT, "build_ab", "libnewton_timing.so")  # prebuilt off the GPU box (tools/build_variant.py ... -DNT_PHASE_TIMING)
+dbg = os.environ.get("VARIANT_LIB") or os.path.join(ROOT, "build_ab", "libnewton_timing.so")  # prebuilt off the GPU box (tools/build_variant.py ... -DNT_PHASE_TIMING)
 if not os.path.exists(dbg):
     dbg = "/tmp/libnewton_hip_timing.so"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-Os", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                     "-fPIC", "-shared", "-DNT_PHASE_TIMING", os.path.join(ROOT, "newton_amd/csrc/nt_kernels.hip"),
                     os.path.join(ROOT, "newton_amd/csrc/nt_broadphase.hip"), "-o", dbg], check=True)
-os.environ["NEWTON_HIP_LIB"] = dbg
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import newton_amd as nt  # noqa: E402
 from newton_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = dbg
 from scenes import quadruped_scene  # noqa: E402
 
 lib = _lib.load()
@@ -33,7 +34,7 @@ if BOX:
     model = box_stack_scene(int(sys.argv[2]) if len(sys.argv) > 2 else 256, device="cuda:0", seed=1)
 else:
     model = quadruped_scene(4096, device="cuda:0", seed=1)
-    model.joint_q.reshape(4096, -1)[:, 2] -= 0.22  # feet on the ground: the standing regime the bench measures
+    model.joint_q.reshape(4096, -1)[:, 2] -= 0.24  # feet on the ground: the standing regime the bench measures
     model.body_q, model.body_qd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
 s0, s1 = model.state(), model.state()
 pipe = nt.CollisionPipeline(model)
