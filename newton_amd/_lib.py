@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _DEFAULT_LIB = os.path.join(_HERE, "libnewton_hip.so")
-# The product loads the in-tree library and nothing else: no environment override.  Measurement tools and the no-GPU dry run of the
+# The product loads the in-tree library and nothing else: no override of any kind read from outside the package.  Measurement tools and the no-GPU dry run of the
 # GPU test files point the loader elsewhere from OUTSIDE the package, before the first load() (tools/with_lib.py,
 # tests/emu/emu_plugin.py assign LIB_PATH); load() says so on stderr whenever that happened.
 LIB_PATH = _DEFAULT_LIB
@@ -175,7 +175,9 @@ class nt_hydro_args(C.Structure):
                 ("pair_kind", C.c_void_p), ("out_pairs_normalized", C.c_void_p), ("out_blk", C.c_void_p), ("out_rank", C.c_void_p),
                 ("out_stiffness", C.c_void_p),
                 ("reduce", C.c_int32), ("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
-                ("face_count", C.c_void_p), ("face_rec", C.c_void_p), ("face_capacity", C.c_int32), ("out_friction", C.c_void_p)]
+                ("face_count", C.c_void_p), ("face_rec", C.c_void_p), ("face_capacity", C.c_int32), ("out_friction", C.c_void_p),
+                ("stage_count", C.c_void_p), ("stage_queue", C.c_void_p), ("stage_queue_capacity", C.c_int32),
+                ("stage_chunk_capacity", C.c_int32), ("stage_pair", C.c_void_p), ("stage_item", C.c_void_p), ("stage_chunk", C.c_void_p)]
 
 
 class nt_semi_implicit_params(C.Structure):

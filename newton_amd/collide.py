@@ -394,7 +394,7 @@ class CollisionPipeline:
                  sdf_hydroelastic_config=None, envs_per_block: int = 0, contact_matching: str = "disabled",
                  contact_matching_pos_threshold: float = 0.0005, contact_matching_normal_dot_threshold: float = 0.995,
                  contact_report: bool = False, sdf_pairs_per_shape: int = 12, sdf_contacts_per_shape: int = 40,
-                 sdf_hydro_faces_per_shape: int = 400, **unsupported):
+                 sdf_hydro_faces_per_shape: int = 400, sdf_hydro_staged: bool = True, **unsupported):
         if unsupported:
             raise NotImplementedError(f"CollisionPipeline options not supported: {sorted(unsupported)}")
         # frame-to-frame matching (collide.py:1126-1129,1253-1268): "latest" fills contacts.rigid_contact_match_index every
@@ -427,7 +427,8 @@ class CollisionPipeline:
                 raise NotImplementedError("contact_matching is not implemented for models with SDF contact pairs")
             sdf_pair_shape_types_ok(model)
             self._sdf_leg = SdfLeg(model, pairs_per_shape=sdf_pairs_per_shape, contacts_per_shape=sdf_contacts_per_shape,
-                                   hydro_config=sdf_hydroelastic_config, hydro_faces_per_shape=sdf_hydro_faces_per_shape)
+                                   hydro_config=sdf_hydroelastic_config, hydro_faces_per_shape=sdf_hydro_faces_per_shape,
+                                   hydro_staged=sdf_hydro_staged)
             self._rigid_contact_max += self._sdf_leg.row_capacity
         model.rigid_contact_max = self._rigid_contact_max
         # fixed slots + ordered reductions: results are reproducible either way; deterministic=True additionally orders the

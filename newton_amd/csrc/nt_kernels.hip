@@ -28,15 +28,51 @@
 #include "nt_primitives.hpp"
 #include "nt_convex.hpp"
 
-using namespace nt;
+// Two arithmetic namespaces in one translation unit (the fused kernels run both on the same LDS tile):
+//  * ieee  -- nt:: helpers, -ffp-contract=off, correctly rounded division / sqrt: everything that decides pair sets, contact
+//             counts and contact geometry (shape transforms, AABBs, broad phase, primitive / MPR-GJK narrow phase, the contact
+//             writer), SolverSemiImplicit and SolverFeatherstone.  CollisionPipeline.collide stays bit-identical to the contact
+//             arrays the reference's own kernels produce (tests/golden/collide_reference_vectors.npz).
+//  * fused -- ntf:: helpers (a second copy of nt_math.hpp) + the XPBD phases of nt_xpbd.hpp under `#pragma clang fp
+//             contract(fast)` and -DNT_XPBD_FAST_MATH: a * b + c contracts to v_fma_f32, the divisions / square roots of the
+//             projection phases are v_rcp_f32 / v_sqrt_f32 (1 ulp).  Within SURVEY.md 8(c)'s contract (1e-5 single step, 1e-4
+//             rollout against the reference); measured on the MI355X headline: 0.363 -> 0.308 ms per 10-substep launch for the whole
+//             kernel (profiles/r04a_*).  clang attaches the contraction permission to an operation where it is WRITTEN, hence the
+//             second copy of the helpers instead of a flag.
+// The step and the rollout kernels share the fused phases, so a rollout stays bitwise equal to the call-by-call loop.
+#define NT_MATH_NS ntf
+#pragma clang fp contract(fast)
+#include "nt_math.hpp"
+#pragma clang fp contract(off)
+#undef NT_MATH_NS
 
 namespace {
 
 #include "nt_layout.hpp"
+
+namespace ieee {
+using namespace nt;
+#include "nt_ctx.hpp"
 #include "nt_collide.hpp"
 #include "nt_xpbd.hpp"
+}  // namespace ieee
+
+#pragma clang fp contract(fast)
+namespace fused {
+using namespace ntf;
+#define NT_XPBD_FAST_MATH
+#include "nt_ctx.hpp"
+#include "nt_xpbd.hpp"
+#undef NT_XPBD_FAST_MATH
+}  // namespace fused
+#pragma clang fp contract(off)
+
+namespace ieee {
+#include "nt_xpbd_kernels.hpp"
 #include "nt_semi_implicit.hpp"
 #include "nt_featherstone.hpp"
+}  // namespace ieee
+using namespace ieee;
 
 __global__ void clear_forces_kernel(float* body_f, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

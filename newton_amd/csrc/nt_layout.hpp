@@ -1,7 +1,7 @@
-// nt_layout.hpp -- row constants, LDS layout, kernel arguments, block-shared topology tables, the per-lane context (Ctx) and the
-// HBM <-> LDS staging helpers of the fused gfx950 kernels.
-// Included by nt_kernels.hip inside its anonymous namespace, in this order: nt_layout.hpp, nt_collide.hpp, nt_xpbd.hpp,
-// nt_semi_implicit.hpp, nt_featherstone.hpp (one translation unit; the split is for reading, not for separate compilation).
+// nt_layout.hpp -- row constants, LDS layout, kernel arguments and the block-shared topology tables of the fused gfx950 kernels:
+// everything that carries no vector-math type.  The per-lane context (Ctx) and the HBM <-> LDS staging helpers are nt_ctx.hpp.
+// Included ONCE by nt_kernels.hip at the top of its anonymous namespace; nt_ctx.hpp / nt_xpbd.hpp are then included once per
+// arithmetic namespace (`ieee`: nt:: helpers, no contraction; `fused`: ntf:: helpers, a * b + c may contract -- see nt_kernels.hip).
 #pragma once
 
 enum JointType : int { JT_PRISMATIC = 0, JT_REVOLUTE = 1, JT_BALL = 2, JT_FIXED = 3, JT_FREE = 4, JT_DISTANCE = 5, JT_D6 = 6, JT_ROD = 7 };
@@ -185,287 +185,20 @@ __host__ __device__ inline int topo_ints(const nt_model& m) {
            NT_SHAPE_PARAM_FLOATS * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 0);
 }
 
-// The tile code EPB of every kernel template carries the environments per workgroup in its low byte and the
-// uniform-parameter flag NT_UNI in bit 8: Ctx<EPB>::N is the count, Ctx<EPB>::UNI the flag.
-constexpr int NT_UNI = 256;
-template <int EPB>
-struct Ctx {
-    static constexpr int N = EPB & 255;
-    static constexpr bool UNI = (EPB & NT_UNI) != 0;
-    const KArgs& a;
-    Topo T;
-    float* lds;
-    float* up;  // UNI: the block-shared parameter copy [L.uni_floats], behind the topology
-    LdsLayout L;
-    int e, slot, env, nslot;
-    int tslot;  // start of the item loop of phases with fewer items than slot-threads.  Identity: dealing consecutive items to
-                // DIFFERENT waves (13 bodies x 16 envs on all 8 waves instead of 4) was measured and lost 13 % on the headline
-                // (87.4 vs 100.8 M env-steps/s) -- twice the wave-instructions cost more than the second wave per SIMD hides
-    bool big;  // contact records in HBM, manifold polygon scratch per lane (compile-time constant at every construction site)
-    int ES;
-    bool valid;
-
-    // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
-    NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
-        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI);
-        if (rows < 0) rows = L.rows_per_env;
-        e = threadIdx.x % N;
-        slot = threadIdx.x / N;
-        nslot = a.nslot;
-        env = blockIdx.x * N + e;
-        ES = a.m.env_stride;
-        valid = env < a.m.env_count && slot < nslot;
-        tslot = slot;
-        const nt_model& m = a.m;
-        int* ti = reinterpret_cast<int*>(lds + (size_t)rows * N);
-        int o = 0;
-        auto take = [&](const int*& dst, const int32_t* src, int n) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) ti[o + i] = src[i];
-            dst = ti + o;
-            o += n;
-        };
-        take(T.body_flags, m.body_flags, m.nb);
-        take(T.joint_type, m.joint_type, m.nj);
-        take(T.joint_enabled, m.joint_enabled, m.nj);
-        take(T.joint_parent, m.joint_parent, m.nj);
-        take(T.joint_child, m.joint_child, m.nj);
-        take(T.joint_q_start, m.joint_q_start, m.nj);
-        take(T.joint_qd_start, m.joint_qd_start, m.nj);
-        take(T.joint_tq_start, m.joint_tq_start, m.nj);
-        take(T.joint_lin_count, m.joint_lin_count, m.nj);
-        take(T.joint_ang_count, m.joint_ang_count, m.nj);
-        take(T.shape_body, m.shape_body, m.ns + m.ng);
-        take(T.shape_type, m.shape_type, m.ns + m.ng);
-        take(T.shape_flags, m.shape_flags, m.ns + m.ng);
-        take(T.shape_group, m.shape_group, m.ns + m.ng);
-        take(T.pair_a, m.pair_a, m.np);
-        take(T.pair_b, m.pair_b, m.np);
-        take(T.body_joint_start, m.body_joint_start, m.nb + 1);
-        take(T.body_joint_list, m.body_joint_list, 2 * m.nj);  // padded to 2*nj entries by the host
-        take(T.body_pair_start, m.body_pair_start, m.nb + 1);
-        take(T.body_pair_list, m.body_pair_list, 2 * m.np);    // padded to 2*np entries by the host
-        take(T.shape_mesh_start, m.shape_mesh_start, m.ns + m.ng);
-        take(T.shape_mesh_count, m.shape_mesh_count, m.ns + m.ng);
-        take(T.gshape_id, m.gshape_id, m.ng);
-        {
-            float* g = reinterpret_cast<float*>(ti + o);
-            for (int i = threadIdx.x; i < NT_SHAPE_PARAM_FLOATS * m.ng; i += blockDim.x) g[i] = m.gshape_param[i];
-            T.gshape = g;
-            o += NT_SHAPE_PARAM_FLOATS * m.ng;
-        }
-        T.hit_count = ti + o;
-        T.hit_list = ti + o + 1;
-        up = reinterpret_cast<float*>(ti + topo_ints(m));
-    }
-    // LDS element (comp, s) of a slot-major field.  `n` (the slot count of the [comp][n] HBM twin) is not needed here; the
-    // argument stays so that every access reads like its global-memory counterpart g(comp, n, s)
-    template <int NC>
-    NT_DI float& l(Fld<NC> f, int comp, int /*n*/, int s) const { return lds[(f.off + s * NC + comp) * N + e]; }
-    // parameter element (fields bp / jp / dp / sp): per-environment row, or the block-shared copy of a uniform tile
-    template <int NC>
-    NT_DI float pl(Fld<NC> f, int comp, int /*n*/, int s) const {
-        if constexpr (UNI) return up[f.off + s * NC + comp];
-        else return lds[(f.off + s * NC + comp) * N + e];
-    }
-    template <int NC>
-    NT_DI vec3 plv3(Fld<NC> f, int comp0, int n, int s) const {
-        return vec3(pl(f, comp0, n, s), pl(f, comp0 + 1, n, s), pl(f, comp0 + 2, n, s));
-    }
-    template <int NC>
-    NT_DI xform plxf(Fld<NC> f, int comp0, int n, int s) const {
-        return xform(plv3(f, comp0, n, s),
-                     quat(pl(f, comp0 + 3, n, s), pl(f, comp0 + 4, n, s), pl(f, comp0 + 5, n, s), pl(f, comp0 + 6, n, s)));
-    }
-    template <int NC>
-    NT_DI mat33 plm33(Fld<NC> f, int comp0, int n, int s) const {
-        return mat33(pl(f, comp0, n, s), pl(f, comp0 + 1, n, s), pl(f, comp0 + 2, n, s), pl(f, comp0 + 3, n, s),
-                     pl(f, comp0 + 4, n, s), pl(f, comp0 + 5, n, s), pl(f, comp0 + 6, n, s), pl(f, comp0 + 7, n, s),
-                     pl(f, comp0 + 8, n, s));
-    }
-    NT_DI size_t g(int comp, int n, int s) const { return (size_t)(comp * n + s) * ES + env; }
-
-    template <int NC>
-    NT_DI vec3 lv3(Fld<NC> f, int comp0, int n, int s) const {
-        return vec3(l(f, comp0, n, s), l(f, comp0 + 1, n, s), l(f, comp0 + 2, n, s));
-    }
-    template <int NC>
-    NT_DI void st_lv3(Fld<NC> f, int comp0, int n, int s, vec3 v) const {
-        l(f, comp0, n, s) = v.x; l(f, comp0 + 1, n, s) = v.y; l(f, comp0 + 2, n, s) = v.z;
-    }
-    template <int NC>
-    NT_DI xform lxf(Fld<NC> f, int comp0, int n, int s) const {
-        return xform(lv3(f, comp0, n, s),
-                     quat(l(f, comp0 + 3, n, s), l(f, comp0 + 4, n, s), l(f, comp0 + 5, n, s), l(f, comp0 + 6, n, s)));
-    }
-    template <int NC>
-    NT_DI void st_lxf(Fld<NC> f, int n, int s, const xform& t) const {
-        l(f, 0, n, s) = t.p.x; l(f, 1, n, s) = t.p.y; l(f, 2, n, s) = t.p.z;
-        l(f, 3, n, s) = t.q.x; l(f, 4, n, s) = t.q.y; l(f, 5, n, s) = t.q.z; l(f, 6, n, s) = t.q.w;
-    }
-    template <int NC>
-    NT_DI mat33 lm33(Fld<NC> f, int comp0, int n, int s) const {
-        return mat33(l(f, comp0, n, s), l(f, comp0 + 1, n, s), l(f, comp0 + 2, n, s), l(f, comp0 + 3, n, s),
-                     l(f, comp0 + 4, n, s), l(f, comp0 + 5, n, s), l(f, comp0 + 6, n, s), l(f, comp0 + 7, n, s),
-                     l(f, comp0 + 8, n, s));
-    }
-    NT_DI vec3 gravity() const { return lv3(L.grav, 0, 1, 0); }
-    // component-major [comp][n] arrays at a plain row offset (a solver's own scratch, e.g. SolverFeatherstone's)
-    NT_DI float& l(int off, int comp, int n, int s) const { return lds[(off + comp * n + s) * N + e]; }
-    NT_DI vec3 lv3(int off, int comp0, int n, int s) const {
-        return vec3(l(off, comp0, n, s), l(off, comp0 + 1, n, s), l(off, comp0 + 2, n, s));
-    }
-    NT_DI void st_lv3(int off, int comp0, int n, int s, vec3 v) const {
-        l(off, comp0, n, s) = v.x; l(off, comp0 + 1, n, s) = v.y; l(off, comp0 + 2, n, s) = v.z;
-    }
-    NT_DI xform lxf(int off, int comp0, int n, int s) const {
-        return xform(lv3(off, comp0, n, s),
-                     quat(l(off, comp0 + 3, n, s), l(off, comp0 + 4, n, s), l(off, comp0 + 5, n, s), l(off, comp0 + 6, n, s)));
-    }
-    NT_DI void st_lxf(int off, int n, int s, const xform& t) const {
-        l(off, 0, n, s) = t.p.x; l(off, 1, n, s) = t.p.y; l(off, 2, n, s) = t.p.z;
-        l(off, 3, n, s) = t.q.x; l(off, 4, n, s) = t.q.y; l(off, 5, n, s) = t.q.z; l(off, 6, n, s) = t.q.w;
-    }
-    NT_DI vec3 gv3(const float* base, int comp0, int n, int s) const {
-        return vec3(base[g(comp0, n, s)], base[g(comp0 + 1, n, s)], base[g(comp0 + 2, n, s)]);
-    }
-
-    NT_DI xform body_q(int b) const { return lxf(L.bq, 0, a.m.nb, b); }
-    NT_DI quat body_rot(int b) const {
-        const int nb = a.m.nb;
-        return quat(l(L.bq, 3, nb, b), l(L.bq, 4, nb, b), l(L.bq, 5, nb, b), l(L.bq, 6, nb, b));
-    }
-    NT_DI vec3 body_v(int b) const { return lv3(L.bqd, 0, a.m.nb, b); }
-    NT_DI vec3 body_w(int b) const { return lv3(L.bqd, 3, a.m.nb, b); }
-    NT_DI float inv_mass(int b) const { return pl(L.bp, BP_INV_MASS, a.m.nb, b); }
-    NT_DI mat33 inv_inertia(int b) const { return plm33(L.bp, BP_INV_INERTIA, a.m.nb, b); }
-    NT_DI mat33 inertia(int b) const { return plm33(L.bp, BP_INERTIA, a.m.nb, b); }
-    NT_DI vec3 com(int b) const { return plv3(L.bp, BP_COM, a.m.nb, b); }
-    NT_DI vec3 world_com(int b) const { return lv3(L.bd, 0, a.m.nb, b); }
-    // a^T (R I^-1 R^T) a for body b (world-frame inverse inertia, symmetric 6-float tile in LDS)
-    NT_DI float w_quad(int b, vec3 v) const {
-        const int nb = a.m.nb;
-        float xx = l(L.bd, 3, nb, b), xy = l(L.bd, 4, nb, b), xz = l(L.bd, 5, nb, b);
-        float yy = l(L.bd, 6, nb, b), yz = l(L.bd, 7, nb, b), zz = l(L.bd, 8, nb, b);
-        vec3 wv(xx * v.x + xy * v.y + xz * v.z, xy * v.x + yy * v.y + yz * v.z, xz * v.x + yz * v.y + zz * v.z);
-        return dot(v, wv);
-    }
-    NT_DI void update_body_derived(int b) const {
-        const int nb = a.m.nb;
-        xform X = body_q(b);
-        st_lv3(L.bd, 0, nb, b, xform_point(X, com(b)));
-        mat33 R = quat_to_matrix(X.q);
-        mat33 Ii = inv_inertia(b);
-        // T = I^-1 R^T ; W = R T
-        vec3 t0 = Ii * vec3(R.m00, R.m01, R.m02), t1 = Ii * vec3(R.m10, R.m11, R.m12), t2 = Ii * vec3(R.m20, R.m21, R.m22);
-        vec3 r0(R.m00, R.m01, R.m02), r1(R.m10, R.m11, R.m12), r2(R.m20, R.m21, R.m22);
-        l(L.bd, 3, nb, b) = dot(r0, t0); l(L.bd, 4, nb, b) = dot(r0, t1); l(L.bd, 5, nb, b) = dot(r0, t2);
-        l(L.bd, 6, nb, b) = dot(r1, t1); l(L.bd, 7, nb, b) = dot(r1, t2); l(L.bd, 8, nb, b) = dot(r2, t2);
-    }
-    NT_DI float dof(int row, int d) const { return pl(L.dp, row, a.m.nd, d); }
-    NT_DI vec3 dof_axis(int d) const { return plv3(L.dp, DP_AXIS, a.m.nd, d); }
-
-    // shape accessors: s < ns local (per-env params in LDS), otherwise the env-uniform global table
-    NT_DI float shape_f(int s, int comp) const {
-        if (s < a.m.ns) return pl(L.sp, comp, a.m.ns, s);
-        return T.gshape[(s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp];
-    }
-    NT_DI vec3 shape_scale(int s) const { return vec3(shape_f(s, SP_SCALE), shape_f(s, SP_SCALE + 1), shape_f(s, SP_SCALE + 2)); }
-    NT_DI xform shape_local_xform(int s) const {
-        return xform(vec3(shape_f(s, 0), shape_f(s, 1), shape_f(s, 2)), quat(shape_f(s, 3), shape_f(s, 4), shape_f(s, 5), shape_f(s, 6)));
-    }
-    NT_DI int newton_shape_id(int s) const {  // flat Newton shape index
-        return s < a.m.ns ? a.m.shape_local0 + env * a.m.ns + s : T.gshape_id[s - a.m.ns];
-    }
-    NT_DI int local_shape_id(int gid) const {
-        int rel = gid - a.m.shape_local0 - env * a.m.ns;
-        if (rel >= 0 && rel < a.m.ns) return rel;
-        int g = 0;
-        for (int k = 0; k < a.m.ng; ++k)
-            if (T.gshape_id[k] == gid) g = k;
-        return a.m.ns + g;
-    }
-};
-
 // ------------------------------------------------------------------------------------------------
-// HBM <-> LDS staging
+// optional per-phase cycle accounting (-DNT_PHASE_TIMING, tools/phase_timing.py): workgroup 0 / thread 0 accumulates the
+// s_memtime delta of every phase; never compiled into the product library
 // ------------------------------------------------------------------------------------------------
-// field [ncomp][n][ES] in HBM <-> slot-major rows in LDS
-template <int EPB, int NC>
-NT_DI void stage_rows(const Ctx<EPB>& c, Fld<NC> f, const float* src, int ncomp, int n) {
-    for (int comp = 0; comp < ncomp; ++comp)
-        for (int s = c.slot; s < n; s += c.nslot) c.l(f, comp, n, s) = src[c.g(comp, n, s)];
-}
-template <int EPB, int NC>
-NT_DI void unstage_rows(const Ctx<EPB>& c, Fld<NC> f, float* dst, int ncomp, int n) {
-    for (int comp = 0; comp < ncomp; ++comp)
-        for (int s = c.slot; s < n; s += c.nslot) dst[c.g(comp, n, s)] = c.l(f, comp, n, s);
-}
-// plain rows (a solver's own [row] arrays)
-template <int EPB>
-NT_DI void stage_rows(const Ctx<EPB>& c, int lds_off, const float* src, int rows) {
-    for (int r = c.slot; r < rows; r += c.nslot) c.lds[(lds_off + r) * Ctx<EPB>::N + c.e] = src[(size_t)r * c.ES + c.env];
-}
-template <int EPB>
-NT_DI void unstage_rows(const Ctx<EPB>& c, int lds_off, float* dst, int rows) {
-    for (int r = c.slot; r < rows; r += c.nslot) dst[(size_t)r * c.ES + c.env] = c.lds[(lds_off + r) * Ctx<EPB>::N + c.e];
-}
-
-template <int EPB>
-NT_DI void load_state(const Ctx<EPB>& c, const nt_state& s) {
-    if (!c.valid) return;
-    stage_rows(c, c.L.bq, s.body_q, 7, c.a.m.nb);
-    stage_rows(c, c.L.bqd, s.body_qd, 6, c.a.m.nb);
-}
-template <int EPB>
-NT_DI void store_state(const Ctx<EPB>& c, const nt_state& s) {
-    if (!c.valid) return;
-    unstage_rows(c, c.L.bq, s.body_q, 7, c.a.m.nb);
-    unstage_rows(c, c.L.bqd, s.body_qd, 6, c.a.m.nb);
-}
-// parameters and controls: read once per kernel
-template <int EPB>
-NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
-    const nt_model& m = c.a.m;
-    const int nb = m.nb;
-    // body params carry the effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
-    auto body_value = [&](int comp, int b, size_t col) {
-        float v = m.body_param[(size_t)(comp * nb + b) * c.ES + col];
-        bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
-        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
-        return v;
-    };
-    if constexpr (Ctx<EPB>::UNI) {
-        // one copy per workgroup, read from the tile's first environment (the host vouches that all columns are equal)
-        const size_t col = (size_t)blockIdx.x * Ctx<EPB>::N;
-        for (int r = threadIdx.x; r < NT_BODY_PARAM_FLOATS * nb; r += blockDim.x) {
-            int comp = r / nb, b = r - comp * nb;
-            c.up[c.L.bp.off + b * NC_BP + comp] = body_value(comp, b, col);
-        }
-        for (int r = threadIdx.x; r < NT_JOINT_PARAM_FLOATS * m.nj; r += blockDim.x) {
-            int comp = r / m.nj, j = r - comp * m.nj;
-            c.up[c.L.jp.off + j * NC_JP + comp] = m.joint_param[(size_t)r * c.ES + col];
-        }
-        for (int r = threadIdx.x; r < NT_DOF_PARAM_FLOATS * m.nd; r += blockDim.x) {
-            int comp = r / m.nd, d = r - comp * m.nd;
-            c.up[c.L.dp.off + d * NC_DP + comp] = m.dof_param[(size_t)r * c.ES + col];
-        }
-        for (int r = threadIdx.x; r < NT_SHAPE_PARAM_FLOATS * m.ns; r += blockDim.x) {
-            int comp = r / m.ns, sh = r - comp * m.ns;
-            c.up[c.L.sp.off + sh * NC_SP + comp] = m.shape_param[(size_t)r * c.ES + col];
-        }
-    }
-    if (!c.valid) return;
-    if constexpr (!Ctx<EPB>::UNI) {
-        for (int comp = 0; comp < NT_BODY_PARAM_FLOATS; ++comp)
-            for (int b = c.slot; b < nb; b += c.nslot) c.lds[(c.L.bp.off + b * NC_BP + comp) * Ctx<EPB>::N + c.e] = body_value(comp, b, c.env);
-        stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS, m.nj);
-        stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS, m.nd);
-        stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS, m.ns);
-    }
-    stage_rows(c, c.L.grav, m.gravity, 3, 1);
-    if (with_control) {
-        stage_rows(c, c.L.cf, c.a.c.joint_f, 1, m.nd);
-        stage_rows(c, c.L.ctq, c.a.c.joint_target_q, 1, m.ntq);
-        stage_rows(c, c.L.ctqd, c.a.c.joint_target_qd, 1, m.nd);
-    }
-}
+#ifdef NT_PHASE_TIMING
+__device__ unsigned long long nt_phase_clock[32];
+#define NT_TICK(slot)                                                                  \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            unsigned long long now = __builtin_readcyclecounter();                     \
+            nt_phase_clock[slot] += now - nt_phase_clock[31];                          \
+            nt_phase_clock[31] = now;                                                  \
+        }                                                                              \
+    } while (0)
+#else
+#define NT_TICK(slot) do { } while (0)
+#endif

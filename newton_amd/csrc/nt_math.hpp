@@ -2,12 +2,26 @@
 // Semantics follow the warp-lang builtins Newton's kernels call (quat xyzw, transform = (p, q),
 // zero-safe normalize) -- see DESIGN.md "arithmetic conventions".  Compiled with -ffp-contract=off:
 // every +,-,*,/ and sqrt is a single correctly-rounded IEEE operation, in source order.
-#pragma once
+//
+// The file can be included a second time under another namespace (`#define NT_MATH_NS ntf` + `#pragma clang fp contract(fast)`
+// around the include): clang attaches the contraction permission to every fmul / fadd where it is WRITTEN, so code that may fuse
+// a * b + c into v_fma_f32 needs its own copy of these helpers -- nt_kernels.hip does that for the XPBD projection phases
+// (namespace ntf), while everything that decides pair sets, contact counts and contact geometry keeps namespace nt.
 #include <hip/hip_runtime.h>
 
-namespace nt {
-
+#ifndef NT_DI
 #define NT_DI __device__ __forceinline__
+#endif
+#ifndef NT_MATH_NS
+#define NT_MATH_NS nt
+#define NT_MATH_NS_IS_DEFAULT
+#endif
+#if (defined(NT_MATH_NS_IS_DEFAULT) && !defined(NT_MATH_HPP_DEFAULT_DONE)) || !defined(NT_MATH_NS_IS_DEFAULT)
+#ifdef NT_MATH_NS_IS_DEFAULT
+#define NT_MATH_HPP_DEFAULT_DONE
+#endif
+
+namespace NT_MATH_NS {
 
 struct vec3 {
     float x, y, z;
@@ -207,4 +221,9 @@ NT_DI spatial operator-(const spatial& a, const spatial& b) { return spatial(a.t
 NT_DI spatial operator*(const spatial& a, float s) { return spatial(a.top * s, a.bottom * s); }
 NT_DI vec3 velocity_at_point(const spatial& qd, vec3 r) { return cross(qd.bottom, r) + qd.top; }
 
-}  // namespace nt
+}  // namespace NT_MATH_NS
+#endif
+#ifdef NT_MATH_NS_IS_DEFAULT
+#undef NT_MATH_NS_IS_DEFAULT
+#undef NT_MATH_NS
+#endif

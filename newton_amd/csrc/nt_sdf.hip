@@ -2292,6 +2292,399 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The reduce_contacts = True pipeline in DENSE STAGES (nt_hydro_args.stage_*; hydro_pairs_kernel<true> above gives a 256-lane
+// workgroup to every pair and walks its blocks one after the other: in a pile a pair has a handful of surviving 8^3 blocks with a
+// few dozen iso voxels each, so most lanes idle through ten workgroup barriers per block, and the two nt_sdf descriptors held per
+// lane cost 247 VGPR).  Here the population of every stage is its own grid and the unit of work is a WAVE:
+//   hydro_stage_blocks_kernel   wave per hydroelastic candidate pair: SAT, finer-SDF-is-B, the level-8 test of all of B's blocks
+//                               (64 per round, ballot masks in LDS); the surviving blocks leave as one contiguous run of
+//                               (pair, block) items in block order (one atomic per pair) -> stage_queue, stage_pair = (first item,
+//                               items)
+//   hydro_stage_faces_kernel    wave per item: levels 4 / 2 / 1 as ballot masks (8 lanes, 64 lanes, then the children of the
+//                               surviving level-2 nodes dealt 64 at a time), voxels compacted in traversal order into the wave's
+//                               LDS list, marching cubes 64 voxels per round; a round's faces are one chunk of the face buffer (one
+//                               atomic) recorded in stage_chunk = (first face, faces, buffered contacts, voxels); ids inside a
+//                               record are relative to the chunk.  No workgroup barrier anywhere; the pair's descriptors are
+//                               wave-uniform (scalar registers).
+//   hydro_stage_reduce_kernel   workgroup per pair with items: lists the pair's chunks in (block, round) order -- the traversal order
+//                               of the single kernel --, rebases the records' voxel ranks and contact ids by the running totals, and
+//                               runs the same hydro_reduce_pair on them.
+// Faces, ids, order and rows are those of hydro_pairs_kernel<true>: the voxel order inside a block, the block order inside a pair
+// and every arithmetic operation are unchanged; only who computes what moved.
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifdef NT_EMULATED_GRID
+#define HY_WAVE_SYNC() emu_wave_sync(64)
+#else
+#define HY_WAVE_SYNC() HY_WAVE_SYNC_HW()
+#endif
+#define HY_WAVE_SYNC_HW()                                      \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
+NT_DI int hy_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// flat pair index f (world-major over the clamped per-world counts) -> world * pairs_per_world + k
+NT_DI int hydro_pair_of_flat(const nt_hydro_args& a, int f) {
+    int lo = 0, hi = a.worlds;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.pair_world_prefix[mid] <= f) lo = mid;
+        else hi = mid;
+    }
+    return lo * a.pairs_per_world + (f - a.pair_world_prefix[lo]);
+}
+// the pair as the face pass sees it (descriptors, finer-is-B swap, relative transform); false: no SDF on one side
+NT_DI bool hydro_pair_load(const nt_hydro_args& a, int pair_idx, HydroPair& p, bool with_sat, bool& collide) {
+    p.sa = a.pairs[2 * (size_t)pair_idx];
+    p.sb = a.pairs[2 * (size_t)pair_idx + 1];
+    const int ia = a.shape_sdf_index[p.sa], ib = a.shape_sdf_index[p.sb];
+    bool ok = ia >= 0 && ib >= 0 && ia < a.sdf_count && ib < a.sdf_count;
+    if (ok) {
+        p.A = a.sdf_table[ia];
+        p.B = a.sdf_table[ib];
+        ok = p.A.cx > 0 && p.B.cx > 0;
+    }
+    collide = false;
+    if (!ok) return false;
+    if (with_sat) {  // SAT of the two SDF boxes (centred transforms), before the finer-is-B swap like the reference
+        const xform Xa = load_xform(a.shape_transform + 7 * p.sa), Xb = load_xform(a.shape_transform + 7 * p.sb);
+        const vec3 alo(p.A.box_lower[0], p.A.box_lower[1], p.A.box_lower[2]), ahi(p.A.box_upper[0], p.A.box_upper[1], p.A.box_upper[2]);
+        const vec3 blo(p.B.box_lower[0], p.B.box_lower[1], p.B.box_lower[2]), bhi(p.B.box_upper[0], p.B.box_upper[1], p.B.box_upper[2]);
+        const xform Ca = Xa * xform(0.5f * (alo + ahi), quat(0.0f, 0.0f, 0.0f, 1.0f));
+        const xform Cb = Xb * xform(0.5f * (blo + bhi), quat(0.0f, 0.0f, 0.0f, 1.0f));
+        collide = hydro_sat(Ca, 0.5f * (ahi - alo), Cb, 0.5f * (bhi - blo));
+    }
+    if (p.B.voxel_radius > p.A.voxel_radius) {  // keep the finer SDF as shape B (:1362-1366)
+        const int s_ = p.sa; p.sa = p.sb; p.sb = s_;
+        const nt_sdf tmp = p.A; p.A = p.B; p.B = tmp;
+    }
+    p.gap_sum = a.shape_gap[p.sa] + a.shape_gap[p.sb];
+    p.margin_a = a.shape_data[4 * p.sa + 3];
+    p.margin_b = a.shape_data[4 * p.sb + 3];
+    p.kh_a = a.shape_kh[p.sa];
+    p.kh_b = a.shape_kh[p.sb];
+    p.X_b = load_xform(a.shape_transform + 7 * p.sb);
+    p.X_b2a = xform_inverse(load_xform(a.shape_transform + 7 * p.sa)) * p.X_b;
+    return true;
+}
+NT_DI void hy_child(int code, int& cx, int& cy, int& cz) { cx = code & 1; cy = (code >> 1) & 1; cz = (code >> 2) & 1; }
+// voxel j of a block (traversal code: child of 4 | child of 2 | voxel, three bits each) -> offset inside the block
+NT_DI void hy_voxel(int j, int& x, int& y, int& z) {
+    int ax, ay, az, bx, by, bz, cx, cy, cz;
+    hy_child(j >> 6, ax, ay, az);
+    hy_child((j >> 3) & 7, bx, by, bz);
+    hy_child(j & 7, cx, cy, cz);
+    x = 4 * ax + 2 * bx + cx; y = 4 * ay + 2 * by + cy; z = 4 * az + 2 * bz + cz;
+}
+constexpr int HY_STAGE_WAVES = 4;  // waves per workgroup of the wave-per-unit stages (independent: no workgroup barrier)
+struct HyWaveBlocks { unsigned long long mask[HYDRO_MAX_BLOCKS / 64]; };
+struct HyWaveFaces { unsigned char l2[64]; unsigned short vox[512]; };
+
+// counters (stage_count): [0] queue items, [1] chunk records, [2] units lost to a full queue / chunk pool (-> overflow report)
+__global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel(nt_hydro_args a) {
+    __shared__ HyWaveBlocks W[HY_STAGE_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HyWaveBlocks& w = W[wave];
+    const int pair_total = a.pair_world_prefix[a.worlds];
+    for (int f = blockIdx.x * HY_STAGE_WAVES + wave; f < pair_total; f += gridDim.x * HY_STAGE_WAVES) {
+        const int pair_idx = hy_uniform(hydro_pair_of_flat(a, f));
+        if (a.pair_kind[pair_idx] != 1) continue;
+        HydroPair p;
+        bool collide;
+        const bool ok = hydro_pair_load(a, pair_idx, p, true, collide);
+        if (lane == 0 && a.out_pairs_normalized) {
+            a.out_pairs_normalized[2 * (size_t)pair_idx] = p.sa;
+            a.out_pairs_normalized[2 * (size_t)pair_idx + 1] = p.sb;
+        }
+        int q0 = 0, total = 0;
+        const int nbx = ok ? p.B.cx : 0, nby = ok ? p.B.cy : 0, nbz = ok ? p.B.cz : 0;
+        const int nblocks = nbx * nby * nbz;
+        if (ok && collide && nblocks <= HYDRO_MAX_BLOCKS) {
+            const int sgs = p.B.subgrid_size;  // 8
+            const int rounds = (nblocks + 63) >> 6;
+            for (int r = 0; r < rounds; ++r) {  // level 8: block b = (bz * nby + by) * nbx + bx
+                const int b = r * 64 + lane;
+                bool s = false;
+                if (b < nblocks) {
+                    const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
+                    s = hydro_node_survives(p, bx * sgs, by * sgs, bz * sgs, sgs);
+                }
+                const unsigned long long m = __ballot(s);
+                if (lane == 0) w.mask[r] = m;
+                total += __popcll(m);
+            }
+            HY_WAVE_SYNC();
+            if (total > 0) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(a.stage_count, total);
+                q0 = hy_uniform(__shfl(base, 0));
+                if (q0 + total > a.stage_queue_capacity) {  // the pair's blocks do not fit the queue: it contributes nothing, reported
+                    if (lane == 0) atomicAdd(a.stage_count + 2, 1);
+                    total = 0;
+                } else {
+                    int off = 0;
+                    for (int r = 0; r < rounds; ++r) {
+                        const unsigned long long m = w.mask[r];
+                        if ((m >> lane) & 1ull) {
+                            const int q = q0 + off + __popcll(m & ((1ull << lane) - 1ull));
+                            a.stage_queue[2 * (size_t)q] = pair_idx;
+                            a.stage_queue[2 * (size_t)q + 1] = r * 64 + lane;
+                        }
+                        off += __popcll(m);
+                    }
+                }
+            }
+            HY_WAVE_SYNC();
+        }
+        if (lane == 0) {
+            a.stage_pair[2 * (size_t)pair_idx] = q0;
+            a.stage_pair[2 * (size_t)pair_idx + 1] = total;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_faces_kernel(nt_hydro_args a) {
+    __shared__ HyWaveFaces W[HY_STAGE_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HyWaveFaces& w = W[wave];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int n_items = a.stage_count[0];
+    n_items = n_items < a.stage_queue_capacity ? n_items : a.stage_queue_capacity;
+    const bool prune = (a.reduce & 2) != 0;
+    for (int q = blockIdx.x * HY_STAGE_WAVES + wave; q < n_items; q += gridDim.x * HY_STAGE_WAVES) {
+        const int pair_idx = hy_uniform(a.stage_queue[2 * (size_t)q]), b = hy_uniform(a.stage_queue[2 * (size_t)q + 1]);
+        HydroPair p;
+        bool collide;
+        hydro_pair_load(a, pair_idx, p, false, collide);
+        const int nbx = p.B.cx, nby = p.B.cy, sgs = p.B.subgrid_size;
+        const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
+        const int x0 = bx * sgs, y0 = by * sgs, z0 = bz * sgs;
+        // ---- levels 4 and 2 as ballot masks
+        bool s4 = false;
+        if (lane < 8) {
+            int cx, cy, cz;
+            hy_child(lane, cx, cy, cz);
+            s4 = hydro_node_survives(p, x0 + 4 * cx, y0 + 4 * cy, z0 + 4 * cz, 4);
+        }
+        const unsigned long long m4 = __ballot(s4);
+        bool s2 = false;
+        if ((m4 >> (lane >> 3)) & 1ull) {
+            int ax, ay, az, bx_, by_, bz_;
+            hy_child(lane >> 3, ax, ay, az);
+            hy_child(lane & 7, bx_, by_, bz_);
+            s2 = hydro_node_survives(p, x0 + 4 * ax + 2 * bx_, y0 + 4 * ay + 2 * by_, z0 + 4 * az + 2 * bz_, 2);
+        }
+        const unsigned long long m2 = __ballot(s2);
+        const int n2 = __popcll(m2);
+        if (s2) w.l2[__popcll(m2 & lt)] = (unsigned char)lane;
+        HY_WAVE_SYNC();
+        // ---- level 1: the eight children of every surviving level-2 node, 64 tests per round, survivors in traversal order
+        int n_vox = 0;
+        for (int i0 = 0; i0 < 8 * n2; i0 += 64) {
+            const int i = i0 + lane;
+            bool s1 = false;
+            int j = 0;
+            if (i < 8 * n2) {
+                j = (int)w.l2[i >> 3] * 8 + (i & 7);
+                int vx, vy, vz;
+                hy_voxel(j, vx, vy, vz);
+                s1 = hydro_node_survives(p, x0 + vx, y0 + vy, z0 + vz, 1);
+            }
+            const unsigned long long m1 = __ballot(s1);
+            if (s1) w.vox[n_vox + __popcll(m1 & lt)] = (unsigned short)j;
+            n_vox += __popcll(m1);
+        }
+        HY_WAVE_SYNC();
+        const int nb = (n_vox + 63) >> 6;
+        int chunk0 = 0;
+        if (nb > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.stage_count + 1, nb);
+            chunk0 = hy_uniform(__shfl(base, 0));
+        }
+        const bool chunks_ok = chunk0 + nb <= a.stage_chunk_capacity;
+        if (lane == 0) {
+            if (!chunks_ok) atomicAdd(a.stage_count + 2, 1);
+            a.stage_item[2 * (size_t)q] = chunk0;
+            a.stage_item[2 * (size_t)q + 1] = chunks_ok ? nb : 0;
+        }
+        if (!chunks_ok) continue;
+        // ---- marching cubes, one lane per voxel, 64 voxels per round = one chunk of face records
+        for (int k = 0; k < nb; ++k) {
+            const int i = k * 64 + lane;
+            HydroFace faces[5];
+            int face_id[5];
+            int kept = 0;
+            if (i < n_vox) {
+                int vx, vy, vz;
+                hy_voxel((int)w.vox[i], vx, vy, vz);
+                kept = hydro_voxel_faces(a, p, x0 + vx, y0 + vy, z0 + vz, faces, face_id);
+            }
+            // buffered contacts of this voxel in buffer order: every face, or (pre_prune) the two strongest penetrating faces and the
+            // closest non-penetrating one (sdf_hydroelastic.py:2156-2312)
+            int sel[3] = {-1, -1, -1};
+            if (prune) {
+                float sc0 = 0.0f, sc1 = 0.0f, best_np = 1.0e10f;
+                for (int kk = 0; kk < kept; ++kk) {
+                    const HydroFace& fc = faces[kk];
+                    if (fc.depth < 0.0f) {
+                        const float score = fc.area * fc.pressure;
+                        if (sel[0] < 0 || score > sc0) { sel[1] = sel[0]; sc1 = sc0; sel[0] = kk; sc0 = score; }
+                        else if (sel[1] < 0 || score > sc1) { sel[1] = kk; sc1 = score; }
+                    } else if (fc.depth < best_np) {
+                        best_np = fc.depth;
+                        sel[2] = kk;
+                    }
+                }
+            }
+            const int nsel = prune ? (sel[0] >= 0) + (sel[1] >= 0) + (sel[2] >= 0) : kept;
+            int x = kept, xs = nsel;  // inclusive scans over the wave
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d), ys = __shfl_up(xs, d);
+                if (lane >= d) { x += y; xs += ys; }
+            }
+            const int total = hy_uniform(__shfl(x, 63)), sel_total = hy_uniform(__shfl(xs, 63));
+            const int before = x - kept, before_sel = xs - nsel;
+            int base = 0;
+            if (lane == 0 && total > 0) base = atomicAdd(a.face_count, total);
+            base = hy_uniform(__shfl(base, 0));
+            const bool fits = base + total <= a.face_capacity;
+            if (lane == 0) {
+                int* c = a.stage_chunk + 4 * (size_t)(chunk0 + k);
+                c[0] = base;
+                c[1] = fits ? total : -total;  // negative: the faces did not fit the buffer (counted, not stored)
+                c[2] = sel_total;
+                c[3] = (n_vox - k * 64) < 64 ? (n_vox - k * 64) : 64;
+            }
+            if (!fits) continue;
+            for (int kk = 0; kk < kept; ++kk) {
+                const int slot = base + before + kk;
+                const HydroFace& fc = faces[kk];
+                int cid = 0;  // contact id, relative to the chunk (the reduce stage adds what came before in the pair)
+                if (!prune) cid = before + kk + 1;
+                else {
+                    int ord = 0;
+                    for (int jj = 0; jj < 3; ++jj) {
+                        if (sel[jj] == kk) cid = before_sel + ord + 1;
+                        ord += sel[jj] >= 0 ? 1 : 0;
+                    }
+                }
+                float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)slot;
+                o[0] = fc.pos.x; o[1] = fc.pos.y; o[2] = fc.pos.z;
+                o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
+                o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
+                int* oi = reinterpret_cast<int*>(o);
+                oi[9] = lane * 5 + face_id[kk];  // voxel rank inside the CHUNK (rebased by the reduce stage)
+                oi[10] = (cid << 5) | red_get_slot(fc.normal);
+                oi[11] = 0;
+            }
+        }
+        HY_WAVE_SYNC();  // the next item reuses the wave's LDS lists
+    }
+}
+
+template <bool EXTRAS>
+__global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a) {
+    __shared__ HydroRedLds R;
+    __shared__ int idbase[HYDRO_CHUNK_CAP], voxbase[HYDRO_CHUNK_CAP];  // contact ids / voxels of the pair in front of each listed chunk
+    constexpr int HY_ITEM_TILE = 128;
+    __shared__ int item_c0[HY_ITEM_TILE], item_nc[HY_ITEM_TILE + 1], n_raw;
+    const int t = threadIdx.x;
+    const int pair_total = a.pair_world_prefix[a.worlds];
+    const bool prune = (a.reduce & 2) != 0;
+    for (int f = blockIdx.x; f < pair_total; f += gridDim.x) {
+        const int pair_idx = hydro_pair_of_flat(a, f);
+        if (a.pair_kind[pair_idx] != 1) continue;
+        const int q0 = a.stage_pair[2 * (size_t)pair_idx], nq = a.stage_pair[2 * (size_t)pair_idx + 1];
+        __syncthreads();
+#ifdef NT_POISON_LDS  // (tests/emu: every pair starts from garbage LDS, as on a CU that ran other workgroups before)
+        if (t == 0) memset((void*)&R, 0xCD, sizeof(R));
+        __syncthreads();
+#endif
+        // ---- the pair's chunk records, (block, round) order: items and records are fetched by all lanes (they sit wherever the
+        // face stage's atomics put them), then lane 0 folds them into the chunk list on LDS copies
+        if (t == 0) { R.n_chunk = 0; R.n_faces = 0; R.pair_kept = 0; R.overflow = 0; R.rows = 0; n_raw = 0; }
+        __syncthreads();
+        for (int q_tile = 0; q_tile < nq; q_tile += HY_ITEM_TILE) {
+            const int m = nq - q_tile < HY_ITEM_TILE ? nq - q_tile : HY_ITEM_TILE;
+            if (t < m) {
+                item_c0[t] = a.stage_item[2 * (size_t)(q0 + q_tile + t)];
+                item_nc[t] = a.stage_item[2 * (size_t)(q0 + q_tile + t) + 1];
+            }
+            __syncthreads();
+            if (t == 0) {
+                int run = n_raw;
+                for (int k = 0; k < m; ++k) { const int nc = item_nc[k]; item_nc[k] = run; run += nc; }  // -> first raw index of the item
+                item_nc[m] = run;
+                if (run > HYDRO_CHUNK_CAP) { R.overflow = 1; run = HYDRO_CHUNK_CAP; }
+                n_raw = run;
+            }
+            __syncthreads();
+            const int first = item_nc[0], last = n_raw;
+            for (int g = first + t; g < last; g += blockDim.x) {
+                int k = 0;
+                while (k + 1 < m && item_nc[k + 1] <= g) ++k;
+                const int* rec = a.stage_chunk + 4 * (size_t)(item_c0[k] + (g - item_nc[k]));
+                R.chunk[g][0] = rec[0]; R.chunk[g][1] = rec[1];
+                idbase[g] = rec[2]; voxbase[g] = rec[3];
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            int vox = 0, faces_all = 0, n = 0;
+            for (int g = 0; g < n_raw; ++g) {  // in place: n <= g
+                const int base = R.chunk[g][0], signed_total = R.chunk[g][1], kept = idbase[g], nv = voxbase[g];
+                const int total = signed_total < 0 ? -signed_total : signed_total;
+                if (total > 0) {
+                    if (signed_total > 0) {
+                        R.chunk[n][0] = base;
+                        R.chunk[n][1] = total;
+                        R.cstart[n] = R.n_faces;
+                        idbase[n] = prune ? R.pair_kept : faces_all;
+                        voxbase[n] = vox;
+                        R.n_faces += total;
+                        n += 1;
+                    } else {
+                        R.overflow = 1;  // the pair loses these faces: reported through face_count[1]
+                    }
+                }
+                faces_all += total;
+                R.pair_kept += kept;
+                vox += nv;
+            }
+            R.n_chunk = n;
+        }
+        __syncthreads();
+        if (R.n_faces > 0) {  // (uniform)
+            // rebase the chunk-relative voxel ranks and contact ids: (pair_vox + i) * 5 + face, pair_kept / pair_face + ... + 1
+            for (int c = 0; c < R.n_chunk; ++c) {
+                const int add_key = 5 * voxbase[c], add_cid = idbase[c] << 5;
+                for (int k = t; k < R.chunk[c][1]; k += blockDim.x) {
+                    int* oi = reinterpret_cast<int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)(R.chunk[c][0] + k));
+                    oi[9] += add_key;
+                    if (oi[10] >> 5) oi[10] += add_cid;
+                }
+            }
+            __threadfence();  // the records, written by all lanes, are read back by other lanes below
+            __syncthreads();
+            HydroPair p;
+            bool collide;
+            hydro_pair_load(a, pair_idx, p, false, collide);
+            if constexpr (EXTRAS) hydro_reduce_pair_extras(a, p, pair_idx, R);
+            else hydro_reduce_pair(a, p, pair_idx, R);
+        }
+        if (t == 0) {
+            if (R.overflow) atomicAdd(a.face_count + 1, 1);
+            a.out_blk[2 * (size_t)pair_idx] = 0;
+            a.out_blk[2 * (size_t)pair_idx + 1] = R.n_faces > 0 ? R.rows : 0;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -2329,7 +2722,25 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
 #else
         const int rblocks = blocks;
 #endif
-        if (a->reduce & (8 | 16)) hipLaunchKernelGGL((hydro_pairs_kernel<true, true>), dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
+        if (a->stage_count) {  // dense stages: wave per pair -> wave per (pair, block) -> workgroup per pair with faces
+            if (!a->stage_queue || !a->stage_pair || !a->stage_item || !a->stage_chunk || a->stage_queue_capacity <= 0 ||
+                a->stage_chunk_capacity <= 0)
+                return NT_ERR_INVALID_ARG;
+            hipStream_t st = (hipStream_t)stream;
+            if (hipMemsetAsync(a->stage_count, 0, 4 * sizeof(int32_t), st) != hipSuccess) return NT_ERR_LAUNCH;
+#ifdef NT_EMULATED_GRID
+            const int wgrid = NT_EMULATED_GRID, igrid = NT_EMULATED_GRID;
+#else
+            const long long wb = (cap + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
+            const int wgrid = (int)(wb < 16384 ? wb : 16384);
+            const long long ib = ((long long)a->stage_queue_capacity + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
+            const int igrid = (int)(ib < 8192 ? ib : 8192);  // grid-stride over the items the first stage queued (count on the device)
+#endif
+            hipLaunchKernelGGL(hydro_stage_blocks_kernel, dim3(wgrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);
+            hipLaunchKernelGGL(hydro_stage_faces_kernel, dim3(igrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);
+            if (a->reduce & (8 | 16)) hipLaunchKernelGGL(hydro_stage_reduce_kernel<true>, dim3(rblocks), dim3(256), 0, st, *a);
+            else hipLaunchKernelGGL(hydro_stage_reduce_kernel<false>, dim3(rblocks), dim3(256), 0, st, *a);
+        } else if (a->reduce & (8 | 16)) hipLaunchKernelGGL((hydro_pairs_kernel<true, true>), dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
         else hipLaunchKernelGGL((hydro_pairs_kernel<true, false>), dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
     } else {
         hipLaunchKernelGGL(hydro_pairs_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);

@@ -1,14 +1,14 @@
 // nt_xpbd.hpp -- SolverXPBD phases (joint forces, integrate, contacts, apply, joints, restitution, optional reporting) and the
-// collide / step / rollout kernels.
-// Included by nt_kernels.hip inside its anonymous namespace, in this order: nt_layout.hpp, nt_collide.hpp, nt_xpbd.hpp,
-// nt_semi_implicit.hpp, nt_featherstone.hpp (one translation unit; the split is for reading, not for separate compilation).
-#pragma once
+// step control flow do_xpbd_step.  The collide / step / rollout kernels are nt_xpbd_kernels.hpp.
+// No include guard: nt_kernels.hip includes this file once per arithmetic namespace -- `ieee` (the shared integrator / force
+// helpers SolverSemiImplicit and SolverFeatherstone use; literal operation order) and `fused` (what the XPBD kernels run:
+// NT_XPBD_FAST_MATH + contraction, see the top of nt_kernels.hip).
 
 // ------------------------------------------------------------------------------------------------
 // XPBD: apply_joint_forces (xpbd/kernels.py:945-1075)
 // ------------------------------------------------------------------------------------------------
-// Division inside the XPBD projection phases (contacts / joints / apply / integrate).  Product build: IEEE division, the literal
-// operation of the reference.  -DNT_XPBD_FAST_MATH (measurement variant, tools/build_variant.py): v_rcp_f32 + multiply and
+// Division inside the XPBD projection phases (contacts / joints / apply / integrate).  Namespace ieee: IEEE division, the literal
+// operation of the reference.  Namespace fused (NT_XPBD_FAST_MATH, what the XPBD kernels run): v_rcp_f32 + multiply and
 // v_sqrt_f32 -- 1 ulp instead of correctly rounded, 2 instructions instead of ~11 per division.
 #ifdef NT_XPBD_FAST_MATH
 NT_DI float xrcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -1124,63 +1124,6 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// optional per-phase cycle accounting (-DNT_PHASE_TIMING, tools/phase_timing.py): workgroup 0 / thread 0 accumulates the
-// s_memtime delta of every phase; never compiled into the product library
-// ------------------------------------------------------------------------------------------------
-#ifdef NT_PHASE_TIMING
-__device__ unsigned long long nt_phase_clock[32];
-#define NT_TICK(slot)                                                                  \
-    do {                                                                               \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
-            unsigned long long now = __builtin_readcyclecounter();                     \
-            nt_phase_clock[slot] += now - nt_phase_clock[31];                          \
-            nt_phase_clock[31] = now;                                                  \
-        }                                                                              \
-    } while (0)
-#else
-#define NT_TICK(slot) do { } while (0)
-#endif
-
-// ------------------------------------------------------------------------------------------------
-// kernels
-// ------------------------------------------------------------------------------------------------
-template <int EPB, bool CVX>
-NT_DI void do_collide(const Ctx<EPB>& c, bool count_contacts) {
-    NT_SKIP_DECL(c.a);
-    if (NT_SKIP(1)) return;
-    const bool compact = pairs_compacted(c);
-    if (compact && c.valid && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0)) = 0;
-    phase_shapes(c);
-    __syncthreads();
-    NT_TICK(1);
-    if (c.big) {
-        phase_pairs_big_broad(c);  // pair-heavy tile: compact the candidates first, no candidate staging (19 rows per pair)
-        phase_pairs_big_narrow<EPB, CVX>(c);
-    } else {
-        if (compact) {
-            phase_pair_broad_staged(c);
-            __syncthreads();
-            phase_pair_narrow_staged<EPB, CVX>(c);
-        } else {
-            phase_pair_eval<EPB, CVX>(c);
-        }
-        __syncthreads();
-        phase_contact_write(c);
-    }
-    __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
-    NT_TICK(2);
-    // live-contact prefix for the fused solver phases + (last substep / standalone collide) the per-env totals; scratch =
-    // the shape-transform rows of the collide scratch, dead once the pairs are done
-    const bool one_level = c.a.m.np <= 64;
-    if (!one_level) {
-        phase_pair_prefix_partials(c, c.L.sx.off);
-        __syncthreads();
-    }
-    phase_pair_prefix_scan(c, c.L.sx.off, count_contacts, one_level);
-    __syncthreads();
-}
-
 // SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
 // PROLOGUE_DONE: the caller (do_fused_substep) already saved the pre-step state, applied the joint forces and integrated
 template <int EPB, bool FUSED, class CW = CwLds, bool PROLOGUE_DONE = false>
@@ -1253,141 +1196,3 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     }
 }
 
-// THREADS / MINW: workgroup size and minimum waves per SIMD the register allocator must leave room for
-// (k workgroups of THREADS threads per CU <=> MINW = k * THREADS / 256); chosen per model by the launch code
-// One substep of the fused rollout on the staged tiles: { clear_forces; collide; SolverXPBD.step } with the independent
-// 13-item phases of the two halves sharing barrier intervals.  The shape phase and the joint-force phase both read only the
-// incoming state (collide.py:283-472 / xpbd/kernels.py:945-1075) and write disjoint scratch (layout: forces behind the
-// collide scratch), so they run side by side on different waves; the contact-record stage, the live-contact prefix and
-// nothing else follow; integrate_bodies comes last because the records are converted into the frames of the incoming
-// body poses (collide.py:166-204).  Arithmetic and summation orders are those of do_collide + do_xpbd_step, bit for bit.
-template <int EPB, bool CVX>
-NT_DI void do_fused_substep(const Ctx<EPB>& c, bool last_substep) {
-    const nt_model& m = c.a.m;
-    NT_SKIP_DECL(c.a);
-    const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;  // slots per wave
-    const bool restitution = (c.a.p.enable_restitution && c.a.has_contacts) || c.a.p.compute_body_velocity_from_position_delta != 0;
-    // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
-    const bool compact = pairs_compacted(c);
-    if (c.valid) {
-        if (compact && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0)) = 0;
-        if (restitution)
-            for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
-        if (!NT_SKIP(2)) seed_body_forces(c, true);
-        const int S0 = ((m.ns + spw - 1) / spw) * spw;
-        for (int i = c.slot; i < S0 + m.nj; i += c.nslot) {
-            if (i < m.ns) {
-                if (!NT_SKIP(1)) shape_item(c, i);
-            } else if (i >= S0) {
-                if (!NT_SKIP(2)) joint_force_item(c, i - S0);
-            }
-        }
-    }
-    __syncthreads();
-    NT_TICK(1);
-    // -- interval 2: one lane per candidate pair (broad phase test, primitive pair / MPR-GJK manifold, admission)
-    if (!NT_SKIP(1)) {
-        if (compact) {
-            phase_pair_broad_staged(c);
-            __syncthreads();
-            phase_pair_narrow_staged<EPB, CVX>(c);
-        } else {
-            phase_pair_eval<EPB, CVX>(c);
-        }
-    }
-    __syncthreads();
-    NT_TICK(2);
-    // -- interval 3: contact records of the analytic pairs (one lane per slot) || live-contact prefix (few lanes per env)
-    if (!NT_SKIP(1) && c.valid) {
-        const int nas = m.np_analytic * m.cpp;
-        const int P0 = ((nas + spw - 1) / spw) * spw;
-        const bool one_level = m.np <= 64;
-        if (one_level) {
-            for (int i = c.slot; i < P0 + NT_PREFIX_LANES; i += c.nslot) {
-                if (i < nas) contact_write_item(c, i);
-                else if (i >= P0) prefix_lane(c, i - P0, c.L.sx.off, last_substep, true);
-            }
-        } else {
-            for (int s = c.slot; s < nas; s += c.nslot) contact_write_item(c, s);
-            phase_pair_prefix_partials(c, c.L.sx.off);
-        }
-    }
-    __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
-    if (!NT_SKIP(1) && m.np > 64) {
-        phase_pair_prefix_scan(c, c.L.sx.off, last_substep, false);
-        __syncthreads();
-    }
-    NT_TICK(3);
-    // -- interval 4: integrate_bodies
-    if (!NT_SKIP(2)) phase_integrate<EPB, false>(c);
-    __syncthreads();
-    NT_TICK(4);
-    do_xpbd_step<EPB, true, CwLds, true>(c, true);
-}
-
-template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>
-__global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds, -1, BIG);
-    load_state(c, a.s_in);
-    load_params(c, false);
-    __syncthreads();
-    do_collide<EPB, CVX>(c, true);
-}
-
-// compute_shape_aabbs alone (models whose every pair belongs to a stage outside the tiles: the launch only exports
-// nt_contacts.world_xform / world_aabb_*)
-template <int EPB>
-__global__ void __launch_bounds__((EPB & 255) <= 8 ? 256 : 512) shapes_export_kernel(KArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds, -1, false);
-    load_state(c, a.s_in);
-    load_params(c, false);
-    __syncthreads();
-    phase_shapes(c);
-}
-
-template <int EPB, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>
-__global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds, -1, BIG);
-    load_state(c, a.s_in);
-    load_params(c, true);
-    __syncthreads();
-    phase_body_derived(c);
-    __syncthreads();
-    if constexpr (BIG) do_xpbd_step<EPB, false, CwHbm>(c, false);
-    else do_xpbd_step<EPB, false>(c, false);
-    store_state(c, a.s_out);
-}
-
-// substeps x { clear_forces; collide; step; swap } with state and parameters resident in LDS across substeps.
-// Only the final state is stored (into s0 for an even number of substeps, s1 for odd, like the reference's
-// pointer swap); body_f of both states is zeroed as clear_forces would leave it.
-template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>
-__global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    Ctx<EPB> c(a, lds, -1, BIG);
-    const int nb = a.m.nb;
-    load_state(c, a.s_in);
-    load_params(c, true);
-    if (c.valid)
-        for (int r = c.slot; r < 6 * nb; r += c.nslot) {
-            a.s_in.body_f[(size_t)r * c.ES + c.env] = 0.0f;
-            a.s_out.body_f[(size_t)r * c.ES + c.env] = 0.0f;
-        }
-    __syncthreads();
-    phase_body_derived(c);
-    __syncthreads();
-    NT_TICK(0);
-    for (int s = 0; s < a.substeps; ++s) {
-        if constexpr (BIG) {
-            do_collide<EPB, CVX>(c, s == a.substeps - 1);
-            do_xpbd_step<EPB, true, CwHbm>(c, true);
-        } else {
-            do_fused_substep<EPB, CVX>(c, s == a.substeps - 1);
-        }
-    }
-    store_state(c, (a.substeps & 1) ? a.s_out : a.s_in);
-    NT_TICK(9);
-}

@@ -74,7 +74,8 @@ class SdfLeg:
     """Model-level tables + per-pipeline work buffers of the mesh-SDF leg."""
 
     def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64, hydro_config=None,
-                 staged: bool = True, survivors_per_row: int = 2, hydro_faces_per_shape: int = 400):
+                 staged: bool = True, survivors_per_row: int = 2, hydro_faces_per_shape: int = 400, hydro_staged: bool = True,
+                 hydro_blocks_per_pair: int = 4):
         from .sdf_device import DeviceSDF  # noqa: PLC0415
 
         torch = _torch()
@@ -130,7 +131,7 @@ class SdfLeg:
         if np.any((kind == 0) & ~t.sdf_pair_has_edges):
             raise NotImplementedError("pairs of hydroelastic shapes without collision edges need CollisionPipeline(sdf_hydroelastic_config=...)")
         self.has_hydro_pairs = bool(kind.any())
-        self.hydro_reduce, self.face_capacity = 0, 0
+        self.hydro_reduce, self.face_capacity, self.hydro_staged = 0, 0, False
         self._template_kind = up(kind, np.uint8)
         self.world_pair_kind = torch.zeros(E * PPW, dtype=torch.uint8, device=dev)
         if self.has_hydro_pairs:
@@ -186,6 +187,16 @@ class SdfLeg:
             self.face_count = torch.zeros(2, dtype=i32, device=dev)
             self.face_rec = torch.zeros((self.face_capacity, 12), dtype=f32, device=dev)
             self.raw_friction = torch.zeros(self.raw_capacity, dtype=f32, device=dev)
+            # dense stages of the reduced pipeline (nt_hydro_args.stage_*): (pair, block) queue, its per-item / per-64-voxel records
+            self.hydro_staged = bool(hydro_staged)
+            if self.hydro_staged:
+                self.stage_queue_capacity = max(E * PPW * int(hydro_blocks_per_pair), 1024)
+                self.stage_chunk_capacity = 2 * self.stage_queue_capacity
+                self.stage_count = torch.zeros(4, dtype=i32, device=dev)
+                self.stage_queue = torch.zeros((self.stage_queue_capacity, 2), dtype=i32, device=dev)
+                self.stage_item = torch.zeros((self.stage_queue_capacity, 2), dtype=i32, device=dev)
+                self.stage_pair = torch.zeros((E * PPW, 2), dtype=i32, device=dev)
+                self.stage_chunk = torch.zeros((self.stage_chunk_capacity, 4), dtype=i32, device=dev)
 
     def new_rows(self, per_contact_shape_properties: bool = False) -> FlatRows:
         # hydroelastic rows carry Contacts.rigid_contact_stiffness: allocated whenever the leg can produce them
@@ -249,6 +260,11 @@ class SdfLeg:
                                                                               self._red_res.data_ptr())
                 h.face_count, h.face_rec, h.face_capacity = self.face_count.data_ptr(), self.face_rec.data_ptr(), self.face_capacity
                 h.out_friction = self.raw_friction.data_ptr()
+                if self.hydro_staged:
+                    h.stage_count, h.stage_queue, h.stage_queue_capacity = (self.stage_count.data_ptr(), self.stage_queue.data_ptr(),
+                                                                            self.stage_queue_capacity)
+                    h.stage_pair, h.stage_item = self.stage_pair.data_ptr(), self.stage_item.data_ptr()
+                    h.stage_chunk, h.stage_chunk_capacity = self.stage_chunk.data_ptr(), self.stage_chunk_capacity
             _lib.check(lib.nt_hydro_pairs(C.byref(h), stream), "nt_hydro_pairs")
         io = _lib.nt_sdf_rows_io()
         io.pair_count, io.world_pairs, io.blk, io.pair_row = (self.pair_count.data_ptr(), self.world_pairs.data_ptr(),
@@ -283,6 +299,12 @@ class SdfLeg:
             info["hydro_faces"], info["hydro_face_capacity"] = int(self.face_count[0].item()), self.face_capacity
             info["hydro_pairs_truncated"] = int(self.face_count[1].item())
             over = over or info["hydro_faces"] > self.face_capacity or info["hydro_pairs_truncated"] > 0
+            if self.hydro_staged:
+                sc = self.stage_count.cpu().numpy()
+                info["hydro_blocks"], info["hydro_block_capacity"] = int(sc[0]), self.stage_queue_capacity
+                info["hydro_chunks"], info["hydro_chunk_capacity"] = int(sc[1]), self.stage_chunk_capacity
+                info["hydro_units_dropped"] = int(sc[2])
+                over = over or int(sc[2]) > 0
         if self.staged:
             fill = self.hit_stripes[::16]
             info["cull_survivors"], info["survivor_capacity"] = int(fill.sum().item()), self.hit_capacity

@@ -15,11 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "newton_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
-FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_collide.hpp", "nt_xpbd.hpp",
+FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_ctx.hpp", "nt_collide.hpp", "nt_xpbd.hpp", "nt_xpbd_kernels.hpp",
          "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip",
          "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip"]
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
+HY_SYNC = re.compile(r"#define HY_WAVE_SYNC_HW\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
 WAVE_SYNC_EMU = ("#define FS_WAVE_SYNC() emu_wave_sync((unsigned)(G * (((int)c.a.m.env_count - (int)blockIdx.x * EPB) < EPB ? "
                  "((int)c.a.m.env_count - (int)blockIdx.x * EPB) : EPB)))")
 
@@ -29,6 +30,7 @@ def transform(text: str) -> str:
     text = text.replace("extern __shared__ __align__(16) float lds[];", "float* lds = emu::dynamic_lds();")
     text = text.replace('#include "../../include/newton_hip.h"', f'#include "{os.path.join(ROOT, "include", "newton_hip.h")}"')
     text, n = WAVE_SYNC.subn(WAVE_SYNC_EMU, text)
+    text = HY_SYNC.sub("#define HY_WAVE_SYNC_HW() emu_wave_sync(64)", text)  # wave-level LDS ordering of the staged hydroelastic kernels
     # only under -DNT_XPBD_FAST_MATH (a measurement variant, never built here)
     text = text.replace("__builtin_amdgcn_rcpf", "emu_rcpf").replace("__builtin_amdgcn_sqrtf", "sqrtf")
     text = text.replace("__builtin_amdgcn_readfirstlane", "emu_uniform")  # a wave-uniform value: itself
@@ -49,7 +51,7 @@ def build(force: bool = False) -> str:
         text = transform(open(os.path.join(CSRC, f)).read()).replace('#include "nt_broadphase_core.hpp"', '#include "nt_broadphase_core.hpp"')
         assert "hip_runtime" not in text and "__builtin_amdgcn" not in text, f
         open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w").write(text)
-    cmd = ["g++", "-std=c++20", "-O1", "-DNT_ALL_SHAPES", "-DNT_EMULATED_GRID=4", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
+    cmd = ["g++", "-std=c++20", "-O1", "-DNT_ALL_SHAPES", "-DNT_EMULATED_GRID=4", "-DNT_POISON_LDS", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
            f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(OUT, "nt_broadphase.cpp"),
            *([os.path.join(OUT, "nt_sdf.cpp")] if "nt_sdf.hip" in files else []),
            *([os.path.join(OUT, "nt_build_id.cpp")] if "nt_build_id.hip" in files else []),

@@ -471,11 +471,13 @@ def test_config_c5_hydroelastic_rows_at_full_size():
     t = model.env
     assert t.np == 0 and len(t.sdf_pair) == 64 * 63 // 2 + 64 * 5 and bool(np.all(t.sdf_pair_hydro))
     pipe = nt.CollisionPipeline(model, broad_phase="sap", sdf_hydroelastic_config=nt.geometry.HydroelasticSDF.Config(),
-                                sdf_contacts_per_shape=400)
+                                sdf_contacts_per_shape=400, sdf_hydro_faces_per_shape=1000)
     c1, c2 = pipe.contacts(), pipe.contacts()
     s0 = model.state()
     s0.body_q = q
     pipe.collide(s0, c1)
+    ov = pipe._sdf_leg.overflow(c1._flat)
+    assert not ov["overflow"], ov  # (a full face buffer drops faces in arrival order: nothing below would be deterministic)
     pipe.collide(s0, c2)
     torch.cuda.synchronize()
     a, b = _rows(c1), _rows(c2)
