@@ -394,9 +394,14 @@ class CollisionPipeline:
                  sdf_hydroelastic_config=None, envs_per_block: int = 0, contact_matching: str = "disabled",
                  contact_matching_pos_threshold: float = 0.0005, contact_matching_normal_dot_threshold: float = 0.995,
                  contact_report: bool = False, sdf_pairs_per_shape: int = 12, sdf_contacts_per_shape: int = 40,
-                 sdf_hydro_faces_per_shape: int = 400, sdf_hydro_staged: bool = True, **unsupported):
+                 sdf_hydro_faces_per_shape: int = 400, sdf_hydro_staged: bool = True, speculative_config=None, **unsupported):
         if unsupported:
             raise NotImplementedError(f"CollisionPipeline options not supported: {sorted(unsupported)}")
+        # collide.py:1087-1132,1239-1246,1823-1836: None disables speculative contacts, and `collide(dt=...)` is then ignored, exactly
+        # what this pipeline does; a config asks for swept AABBs + write_contact_speculative (collide.py:258-280), which are not built
+        if speculative_config is not None:
+            raise NotImplementedError("speculative contacts (CollisionPipeline(speculative_config=...)) are not supported; "
+                                      "pass None (the reference's default: collide(dt=...) is then ignored)")
         # frame-to-frame matching (collide.py:1126-1129,1253-1268): "latest" fills contacts.rigid_contact_match_index every
         # collide(); "sticky" additionally replays last frame's contact geometry on matched rows that still touch
         if contact_matching not in ("disabled", "latest", "sticky"):

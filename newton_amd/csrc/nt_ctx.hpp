@@ -71,6 +71,16 @@ struct Ctx {
         }
         T.hit_count = ti + o;
         T.hit_list = ti + o + 1;
+        T.pair_desc = ti + o;  // (the two tables exclude each other)
+        if (!m.contact_scratch_in_hbm) {
+            for (int i = threadIdx.x; i < m.np; i += blockDim.x) {
+                int sa = m.pair_a[i], sb = m.pair_b[i], swapped = 0;
+                if (m.shape_type[sa] > m.shape_type[sb]) { const int t_ = sa; sa = sb; sb = t_; swapped = 1; }
+                ti[o + 4 * i] = sa; ti[o + 4 * i + 1] = sb;
+                ti[o + 4 * i + 2] = m.shape_body[sa];
+                ti[o + 4 * i + 3] = (m.shape_body[sb] & 0x3fffffff) | (swapped << 30);
+            }
+        }
         up = reinterpret_cast<float*>(ti + topo_ints(m));
     }
     // the same lane seen from the other arithmetic namespace (ieee::Ctx <-> fused::Ctx): no staging, every member copied

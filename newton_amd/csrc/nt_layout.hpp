@@ -53,6 +53,8 @@ struct LdsLayout {
     Fld<9> bd;         // body-derived [nb][9]: world COM (3) + world-frame inverse inertia R I^-1 R^T (xx xy xz yy yz zz)
     Fld<1> pm;         // live contacts per pair [np] (written by the collide phase, read by the fused solver phases)
     Fld<1> px;         // exclusive prefix of pm [np + 1]: live contact i of the env is (pair p, sub-contact i - px[p])
+    Fld<1> lt;         // the environment's live contacts [np * cpp], compacted: entry i = pair << 4 | sub-contact (int bits), written
+                       // with the prefix; the fused contact phases read it instead of searching px (not in the pair-heavy tile)
     // scratch union
     int u;
     Fld<7> sx, sa;     // collide: shape world xform [ns][7], aabb [ns][6 (+1)]
@@ -115,6 +117,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.bd.off = o; o += 9 * m.nb;
     L.pm.off = o; o += m.np;
     L.px.off = o; o += m.np + 1;
+    L.lt.off = o; o += big ? 0 : m.np * m.cpp;
     L.u = o;
     const int coll = place_collide_scratch(L, m, L.u, big);
     // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase
@@ -177,12 +180,15 @@ struct Topo {
     const int *body_flags, *joint_type, *joint_enabled, *joint_parent, *joint_child, *joint_q_start, *joint_qd_start,
         *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
         *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count, *gshape_id;
+    // [np][4] (not in the pair-heavy tile): a pair as the contact phases need it -- shape0, shape1 in the narrow phase's type-sorted
+    // order (narrow_phase.py:525-528), their bodies (-1 static), bit 30 of the last word: shape0 is the pair's second shape
+    const int* pair_desc;
     const float* gshape;  // [ng][NT_SHAPE_PARAM_FLOATS] parameters of the global (world -1) shapes, block-shared copy
     int *hit_count, *hit_list;  // pair-heavy tile only: the environment's compacted candidate list (1 + np ints)
 };
 __host__ __device__ inline int topo_ints(const nt_model& m) {
     return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np + m.ng +
-           NT_SHAPE_PARAM_FLOATS * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 0);
+           NT_SHAPE_PARAM_FLOATS * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 4 * m.np);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1444,8 +1444,12 @@ NT_DI bool hydro_sat(const xform& Ta, vec3 ea, const xform& Tb, vec3 eb) {
 }
 struct HydroFace { vec3 pos; float oct0, oct1, depth, stiff; vec3 normal; float area, pressure; };  // normal / area / pressure: reduction only
 // marching cubes of one voxel of B (mc_iterate_voxel_vertices :1716-1798, mc_calc_face_texture :282-362, the face filters and the
-// decode of the unreduced path); returns the number of faces kept (<= 5), in face order
-NT_DI int hydro_voxel_faces(const nt_hydro_args& a, const HydroPair& p, int x, int y, int z, HydroFace* out, int* face_id) {
+// decode of the unreduced path) in two parts: the corner samples of the voxel, and the evaluation of ONE face of its case.
+struct HydroCorners {
+    float cv[8], cself[8], cother[8];
+    int t0, nfaces;  // triangle range of the marching-cubes case, faces of the case (0: nothing to do)
+};
+NT_DI void hydro_voxel_corners(const nt_hydro_args& a, const HydroPair& p, int x, int y, int z, HydroCorners& c) {
     const nt_sdf& A = p.A;
     const nt_sdf& B = p.B;
     const vec3 vs(B.voxel_size[0], B.voxel_size[1], B.voxel_size[2]), blo(B.box_lower[0], B.box_lower[1], B.box_lower[2]);
@@ -1453,82 +1457,95 @@ NT_DI int hydro_voxel_faces(const nt_hydro_args& a, const HydroPair& p, int x, i
     const vec3 base_a = xform_point(p.X_b2a, base_b);
     const vec3 step_x = xform_vector(p.X_b2a, vec3(vs.x, 0.0f, 0.0f)), step_y = xform_vector(p.X_b2a, vec3(0.0f, vs.y, 0.0f)),
                step_z = xform_vector(p.X_b2a, vec3(0.0f, 0.0f, vs.z));
-    float cv[8], cself[8], cother[8];
     int cube = 0;
     bool any_gap = false;
+    c.nfaces = 0;
+    c.t0 = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ox = mc_cx(i), oy = mc_cy(i), oz = mc_cz(i);
         const vec3 pa = base_a + (float)ox * step_x + (float)oy * step_y + (float)oz * step_z;
         const float v_self = sample_at_voxel(B, x + ox, y + oy, z + oz);
         const float v_other = sample(A, pa);
-        if (v_self != v_self || v_other != v_other) return 0;
+        if (v_self != v_self || v_other != v_other) return;
         const float es = v_self - p.margin_b, eo = v_other - p.margin_a;
         const float vd = (-p.kh_a * eo) - (-p.kh_b * es);
-        cv[i] = vd; cself[i] = es; cother[i] = eo;
+        c.cv[i] = vd; c.cself[i] = es; c.cother[i] = eo;
         if (vd < 0.0f) cube |= 1 << i;
         if (es + eo <= p.gap_sum) any_gap = true;
     }
-    if (!any_gap) return 0;
-    const int t0 = a.tri_range[cube], t1 = a.tri_range[cube + 1];
+    if (!any_gap) return;
+    c.t0 = a.tri_range[cube];
+    c.nfaces = (a.tri_range[cube + 1] - c.t0) / 3;
+}
+// face fi of the voxel's case; false: filtered out (degenerate, or beyond the gap band)
+NT_DI bool hydro_voxel_face(const nt_hydro_args& a, const HydroPair& p, int x, int y, int z, const HydroCorners& c, int fi, HydroFace& f) {
+    const nt_sdf& B = p.B;
+    const vec3 vs(B.voxel_size[0], B.voxel_size[1], B.voxel_size[2]), blo(B.box_lower[0], B.box_lower[1], B.box_lower[2]);
     const float cmin = a.edge_clamp_min, cmax = 1.0f - a.edge_clamp_min;
-    int kept = 0;
-    for (int fi = 0; fi < (t1 - t0) / 3; ++fi) {
-        vec3 fv[3];
-        float vsdf[3], vsep[3];
-        int n_in = 0;
+    vec3 fv[3];
+    float vsdf[3], vsep[3];
+    int n_in = 0;
 #pragma unroll
-        for (int vi = 0; vi < 3; ++vi) {
-            const int ca = a.flat_edge_verts[2 * (t0 + 3 * fi + vi)], cb = a.flat_edge_verts[2 * (t0 + 3 * fi + vi) + 1];
-            auto sel = [](const float* v, int k) {  // value select, no private array indexing
-                return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : k == 4 ? v[4] : k == 5 ? v[5] : k == 6 ? v[6] : v[7];
-            };
-            const float va0 = sel(cv, ca), va1 = sel(cv, cb);
-            const float vd = va1 - va0;
-            const float t = fabsf(vd) < 1.0e-10f ? 0.5f : clampf((0.0f - va0) / vd, cmin, cmax);
-            const vec3 p0((float)mc_cx(ca), (float)mc_cy(ca), (float)mc_cz(ca)), p1((float)mc_cx(cb), (float)mc_cy(cb), (float)mc_cz(cb));
-            const vec3 vol = p0 + t * (p1 - p0) + vec3((float)x, (float)y, (float)z);
-            fv[vi] = blo + cw_mul(vol, vs);
-            const float s_self = sel(cself, ca) + t * (sel(cself, cb) - sel(cself, ca));
-            const float s_other = sel(cother, ca) + t * (sel(cother, cb) - sel(cother, ca));
-            vsdf[vi] = s_self;
-            vsep[vi] = s_self + s_other;
-            if (vsep[vi] < 0.0f) n_in += 1;
-        }
-        const vec3 n = cross(fv[1] - fv[0], fv[2] - fv[0]);
-        const float n_sq = dot(n, n);
-        float garea = 0.0f;
-        vec3 normal(0.0f, 0.0f, 1.0f);
-        if (!(n_sq < 1.0e-20f)) {
-            const float inv = 1.0f / sqrtf(n_sq);
-            normal = n * inv;
-            garea = (n_sq * inv) * 0.5f;
-        }
-        const vec3 center = ((fv[0] + fv[1]) + fv[2]) / 3.0f;
-        const float adj = ((vsdf[0] + vsdf[1]) + vsdf[2]) / 3.0f;
-        const float sep = ((vsep[0] + vsep[1]) + vsep[2]) / 3.0f;
-        const float farea = garea * triangle_fraction(vsep[0], vsep[1], vsep[2], n_in);
-        if (garea <= 0.0f) continue;
-        if (!(sep < 0.0f) && sep > p.gap_sum) continue;  // classify_hydroelastic_contact > 0
-        const float pressure = sep < 0.0f ? fmaxw(-p.kh_b * adj, 0.0f) : 0.0f;
-        const float area = sep < 0.0f ? farea : garea;
-        float stiff;
-        if (sep < 0.0f) stiff = area * pressure / fmaxw(-sep, 1e-20f);
-        else {
-            const float den = p.kh_a + p.kh_b;
-            stiff = a.margin_contact_area * (den <= 0.0f ? 0.0f : (p.kh_a * p.kh_b) / den);
-        }
-        HydroFace& f = out[kept];
-        f.pos = center;  // B's frame; the buffer keeps the normal as its octahedral code (export_hydroelastic_contact_to_buffer)
-        red_encode_oct(normal, f.oct0, f.oct1);
-        f.depth = sep;
-        f.stiff = stiff;
-        f.normal = normal;
-        f.area = area;
-        f.pressure = pressure;
-        face_id[kept] = fi;
-        kept += 1;
+    for (int vi = 0; vi < 3; ++vi) {
+        const int ca = a.flat_edge_verts[2 * (c.t0 + 3 * fi + vi)], cb = a.flat_edge_verts[2 * (c.t0 + 3 * fi + vi) + 1];
+        auto sel = [](const float* v, int k) {  // value select, no private array indexing
+            return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : k == 4 ? v[4] : k == 5 ? v[5] : k == 6 ? v[6] : v[7];
+        };
+        const float va0 = sel(c.cv, ca), va1 = sel(c.cv, cb);
+        const float vd = va1 - va0;
+        const float t = fabsf(vd) < 1.0e-10f ? 0.5f : clampf((0.0f - va0) / vd, cmin, cmax);
+        const vec3 p0((float)mc_cx(ca), (float)mc_cy(ca), (float)mc_cz(ca)), p1((float)mc_cx(cb), (float)mc_cy(cb), (float)mc_cz(cb));
+        const vec3 vol = p0 + t * (p1 - p0) + vec3((float)x, (float)y, (float)z);
+        fv[vi] = blo + cw_mul(vol, vs);
+        const float s_self = sel(c.cself, ca) + t * (sel(c.cself, cb) - sel(c.cself, ca));
+        const float s_other = sel(c.cother, ca) + t * (sel(c.cother, cb) - sel(c.cother, ca));
+        vsdf[vi] = s_self;
+        vsep[vi] = s_self + s_other;
+        if (vsep[vi] < 0.0f) n_in += 1;
     }
+    const vec3 n = cross(fv[1] - fv[0], fv[2] - fv[0]);
+    const float n_sq = dot(n, n);
+    float garea = 0.0f;
+    vec3 normal(0.0f, 0.0f, 1.0f);
+    if (!(n_sq < 1.0e-20f)) {
+        const float inv = 1.0f / sqrtf(n_sq);
+        normal = n * inv;
+        garea = (n_sq * inv) * 0.5f;
+    }
+    const vec3 center = ((fv[0] + fv[1]) + fv[2]) / 3.0f;
+    const float adj = ((vsdf[0] + vsdf[1]) + vsdf[2]) / 3.0f;
+    const float sep = ((vsep[0] + vsep[1]) + vsep[2]) / 3.0f;
+    const float farea = garea * triangle_fraction(vsep[0], vsep[1], vsep[2], n_in);
+    if (garea <= 0.0f) return false;
+    if (!(sep < 0.0f) && sep > p.gap_sum) return false;  // classify_hydroelastic_contact > 0
+    const float pressure = sep < 0.0f ? fmaxw(-p.kh_b * adj, 0.0f) : 0.0f;
+    const float area = sep < 0.0f ? farea : garea;
+    float stiff;
+    if (sep < 0.0f) stiff = area * pressure / fmaxw(-sep, 1e-20f);
+    else {
+        const float den = p.kh_a + p.kh_b;
+        stiff = a.margin_contact_area * (den <= 0.0f ? 0.0f : (p.kh_a * p.kh_b) / den);
+    }
+    f.pos = center;  // B's frame; the buffer keeps the normal as its octahedral code (export_hydroelastic_contact_to_buffer)
+    red_encode_oct(normal, f.oct0, f.oct1);
+    f.depth = sep;
+    f.stiff = stiff;
+    f.normal = normal;
+    f.area = area;
+    f.pressure = pressure;
+    return true;
+}
+// all faces of a voxel at once (the one-workgroup-per-pair kernels); returns the number kept (<= 5), in face order
+NT_DI int hydro_voxel_faces(const nt_hydro_args& a, const HydroPair& p, int x, int y, int z, HydroFace* out, int* face_id) {
+    HydroCorners c;
+    hydro_voxel_corners(a, p, x, y, z, c);
+    int kept = 0;
+    for (int fi = 0; fi < c.nfaces; ++fi)
+        if (hydro_voxel_face(a, p, x, y, z, c, fi, out[kept])) {
+            face_id[kept] = fi;
+            kept += 1;
+        }
     return kept;
 }
 
@@ -2302,12 +2319,12 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
 //                               (64 per round, ballot masks in LDS); the surviving blocks leave as one contiguous run of
 //                               (pair, block) items in block order (one atomic per pair) -> stage_queue, stage_pair = (first item,
 //                               items)
-//   hydro_stage_faces_kernel    wave per item: levels 4 / 2 / 1 as ballot masks (8 lanes, 64 lanes, then the children of the
-//                               surviving level-2 nodes dealt 64 at a time), voxels compacted in traversal order into the wave's
-//                               LDS list, marching cubes 64 voxels per round; a round's faces are one chunk of the face buffer (one
-//                               atomic) recorded in stage_chunk = (first face, faces, buffered contacts, voxels); ids inside a
-//                               record are relative to the chunk.  No workgroup barrier anywhere; the pair's descriptors are
-//                               wave-uniform (scalar registers).
+//   hydro_stage_faces_kernel    wave per UNIT = up to four consecutive blocks of one pair, sixteen lanes per block: levels 4 / 2 / 1
+//                               as group ballots (the children of the survivors dealt sixteen at a time), voxels compacted in
+//                               traversal order into the group's LDS list, marching cubes sixteen voxels per round; a round's
+//                               faces are one chunk of the face buffer (one atomic) recorded in stage_chunk = (first face, faces,
+//                               buffered contacts, voxels); ids inside a record are relative to the chunk.  No workgroup barrier
+//                               anywhere; the pair's descriptors are wave-uniform (scalar registers).
 //   hydro_stage_reduce_kernel   workgroup per pair with items: lists the pair's chunks in (block, round) order -- the traversal order
 //                               of the single kernel --, rebases the records' voxel ranks and contact ids by the running totals, and
 //                               runs the same hydro_reduce_pair on them.
@@ -2380,10 +2397,12 @@ NT_DI void hy_voxel(int j, int& x, int& y, int& z) {
     x = 4 * ax + 2 * bx + cx; y = 4 * ay + 2 * by + cy; z = 4 * az + 2 * bz + cz;
 }
 constexpr int HY_STAGE_WAVES = 4;  // waves per workgroup of the wave-per-unit stages (independent: no workgroup barrier)
+constexpr int HY_GROUPS = 4, HY_GL = 64 / HY_GROUPS;  // the face stage gives a lane group of 16 to every block of a unit
 struct HyWaveBlocks { unsigned long long mask[HYDRO_MAX_BLOCKS / 64]; };
-struct HyWaveFaces { unsigned char l2[64]; unsigned short vox[512]; };
+struct HyGroupFaces { unsigned char l4[8], l2[64]; unsigned short vox[512]; };
 
-// counters (stage_count): [0] queue items, [1] chunk records, [2] units lost to a full queue / chunk pool (-> overflow report)
+// counters (stage_count): [0] queue items, [1] chunk records, [2] pairs / blocks lost to a full queue / chunk pool (-> overflow
+// report), [3] work units of the face stage
 __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel(nt_hydro_args a) {
     __shared__ HyWaveBlocks W[HY_STAGE_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2443,48 +2462,84 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel
             a.stage_pair[2 * (size_t)pair_idx] = q0;
             a.stage_pair[2 * (size_t)pair_idx + 1] = total;
         }
+        // work units of the face stage: up to HY_GROUPS consecutive blocks of ONE pair (the pair's descriptors stay wave-uniform)
+        const int nu = (total + HY_GROUPS - 1) / HY_GROUPS;
+        if (nu > 0) {
+            int ub = 0;
+            if (lane == 0) ub = atomicAdd(a.stage_count + 3, nu);
+            ub = hy_uniform(__shfl(ub, 0));
+            for (int u = lane; u < nu; u += 64) {  // (the unit list shares the queue's capacity: units <= items)
+                a.stage_unit[2 * (size_t)(ub + u)] = pair_idx;
+                a.stage_unit[2 * (size_t)(ub + u) + 1] = q0 + u * HY_GROUPS;
+            }
+        }
     }
 }
 
-__global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_faces_kernel(nt_hydro_args a) {
-    __shared__ HyWaveFaces W[HY_STAGE_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    HyWaveFaces& w = W[wave];
-    const unsigned long long lt = (1ull << lane) - 1ull;
+// One wave per unit = up to four blocks of one pair, a group of sixteen lanes each.  A surviving block of a pile carries about a
+// dozen iso voxels: a whole wave per block left four lanes in five idle in every phase.  Group-local ballots are slices of the
+// wave ballot, group-local scans are width-16 shuffles; every loop runs while ANY group has work, so the wave stays converged.
+#ifdef NT_HYDRO_FACES_WAVES  // measurement builds: cap the registers for this many waves per SIMD
+#define NT_HYDRO_FACES_OCC __attribute__((amdgpu_waves_per_eu(NT_HYDRO_FACES_WAVES, NT_HYDRO_FACES_WAVES)))
+#else
+#define NT_HYDRO_FACES_OCC
+#endif
+__global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_stage_faces_kernel(nt_hydro_args a) {
+    __shared__ HyGroupFaces W[HY_STAGE_WAVES][HY_GROUPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / HY_GL, gl = lane % HY_GL;
+    HyGroupFaces& w = W[wave][g];
+    const unsigned int glt = (1u << gl) - 1u;
+    auto gballot = [&](bool v) { return (unsigned int)((__ballot(v) >> (HY_GL * g)) & ((1ull << HY_GL) - 1ull)); };
+    int n_units = a.stage_count[3];
+    n_units = n_units < a.stage_queue_capacity ? n_units : a.stage_queue_capacity;
     int n_items = a.stage_count[0];
     n_items = n_items < a.stage_queue_capacity ? n_items : a.stage_queue_capacity;
     const bool prune = (a.reduce & 2) != 0;
-    for (int q = blockIdx.x * HY_STAGE_WAVES + wave; q < n_items; q += gridDim.x * HY_STAGE_WAVES) {
-        const int pair_idx = hy_uniform(a.stage_queue[2 * (size_t)q]), b = hy_uniform(a.stage_queue[2 * (size_t)q + 1]);
+    for (int u = blockIdx.x * HY_STAGE_WAVES + wave; u < n_units; u += gridDim.x * HY_STAGE_WAVES) {
+        const int pair_idx = hy_uniform(a.stage_unit[2 * (size_t)u]), qf = hy_uniform(a.stage_unit[2 * (size_t)u + 1]);
+        const int q_end = hy_uniform(a.stage_pair[2 * (size_t)pair_idx] + a.stage_pair[2 * (size_t)pair_idx + 1]);
         HydroPair p;
         bool collide;
         hydro_pair_load(a, pair_idx, p, false, collide);
+        const int q = qf + g;
+        const bool have = q < q_end && q < n_items;  // this group's block
+        const int b = have ? a.stage_queue[2 * (size_t)q + 1] : 0;
         const int nbx = p.B.cx, nby = p.B.cy, sgs = p.B.subgrid_size;
         const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
         const int x0 = bx * sgs, y0 = by * sgs, z0 = bz * sgs;
-        // ---- levels 4 and 2 as ballot masks
+        // ---- level 4: lanes 0..7 of the group
         bool s4 = false;
-        if (lane < 8) {
+        if (have && gl < 8) {
             int cx, cy, cz;
-            hy_child(lane, cx, cy, cz);
+            hy_child(gl, cx, cy, cz);
             s4 = hydro_node_survives(p, x0 + 4 * cx, y0 + 4 * cy, z0 + 4 * cz, 4);
         }
-        const unsigned long long m4 = __ballot(s4);
-        bool s2 = false;
-        if ((m4 >> (lane >> 3)) & 1ull) {
-            int ax, ay, az, bx_, by_, bz_;
-            hy_child(lane >> 3, ax, ay, az);
-            hy_child(lane & 7, bx_, by_, bz_);
-            s2 = hydro_node_survives(p, x0 + 4 * ax + 2 * bx_, y0 + 4 * ay + 2 * by_, z0 + 4 * az + 2 * bz_, 2);
-        }
-        const unsigned long long m2 = __ballot(s2);
-        const int n2 = __popcll(m2);
-        if (s2) w.l2[__popcll(m2 & lt)] = (unsigned char)lane;
+        const unsigned int m4 = gballot(s4);
+        const int n4 = __popc(m4);
+        if (s4) w.l4[__popc(m4 & glt)] = (unsigned char)gl;
         HY_WAVE_SYNC();
-        // ---- level 1: the eight children of every surviving level-2 node, 64 tests per round, survivors in traversal order
+        // ---- level 2: the eight children of every surviving level-4 node, sixteen tests per round, survivors in traversal order
+        int n2 = 0;
+        for (int i0 = 0; __any(i0 < 8 * n4); i0 += HY_GL) {
+            const int i = i0 + gl;
+            bool s2 = false;
+            int t2 = 0;
+            if (i < 8 * n4) {
+                t2 = (int)w.l4[i >> 3] * 8 + (i & 7);  // level-2 node code: child of 4 << 3 | child of 2
+                int ax, ay, az, bx_, by_, bz_;
+                hy_child(t2 >> 3, ax, ay, az);
+                hy_child(t2 & 7, bx_, by_, bz_);
+                s2 = hydro_node_survives(p, x0 + 4 * ax + 2 * bx_, y0 + 4 * ay + 2 * by_, z0 + 4 * az + 2 * bz_, 2);
+            }
+            const unsigned int m2 = gballot(s2);
+            if (s2) w.l2[n2 + __popc(m2 & glt)] = (unsigned char)t2;
+            n2 += __popc(m2);
+        }
+        HY_WAVE_SYNC();
+        // ---- level 1
         int n_vox = 0;
-        for (int i0 = 0; i0 < 8 * n2; i0 += 64) {
-            const int i = i0 + lane;
+        for (int i0 = 0; __any(i0 < 8 * n2); i0 += HY_GL) {
+            const int i = i0 + gl;
             bool s1 = false;
             int j = 0;
             if (i < 8 * n2) {
@@ -2493,96 +2548,104 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_faces_kernel(
                 hy_voxel(j, vx, vy, vz);
                 s1 = hydro_node_survives(p, x0 + vx, y0 + vy, z0 + vz, 1);
             }
-            const unsigned long long m1 = __ballot(s1);
-            if (s1) w.vox[n_vox + __popcll(m1 & lt)] = (unsigned short)j;
-            n_vox += __popcll(m1);
+            const unsigned int m1 = gballot(s1);
+            if (s1) w.vox[n_vox + __popc(m1 & glt)] = (unsigned short)j;
+            n_vox += __popc(m1);
         }
         HY_WAVE_SYNC();
-        const int nb = (n_vox + 63) >> 6;
+        // ---- chunk records of the block: one per sixteen voxels
+        const int nb = (n_vox + HY_GL - 1) / HY_GL;
         int chunk0 = 0;
-        if (nb > 0) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(a.stage_count + 1, nb);
-            chunk0 = hy_uniform(__shfl(base, 0));
-        }
+        if (gl == 0 && nb > 0) chunk0 = atomicAdd(a.stage_count + 1, nb);
+        chunk0 = __shfl(chunk0, 0, HY_GL);
         const bool chunks_ok = chunk0 + nb <= a.stage_chunk_capacity;
-        if (lane == 0) {
+        if (have && gl == 0) {
             if (!chunks_ok) atomicAdd(a.stage_count + 2, 1);
             a.stage_item[2 * (size_t)q] = chunk0;
             a.stage_item[2 * (size_t)q + 1] = chunks_ok ? nb : 0;
         }
-        if (!chunks_ok) continue;
-        // ---- marching cubes, one lane per voxel, 64 voxels per round = one chunk of face records
-        for (int k = 0; k < nb; ++k) {
-            const int i = k * 64 + lane;
-            HydroFace faces[5];
-            int face_id[5];
-            int kept = 0;
-            if (i < n_vox) {
-                int vx, vy, vz;
+        const int rounds = chunks_ok ? nb : 0;
+        // ---- marching cubes, one lane per voxel, sixteen voxels per round = one chunk of face records.  Two passes over a voxel's
+        // (<= 5) faces -- count / rank, then write -- instead of holding five face records per lane: half the registers, twice the
+        // waves in flight on a kernel that waits for SDF samples.
+        for (int k = 0; __any(k < rounds); ++k) {
+            const int i = k * HY_GL + gl;
+            const bool mine = k < rounds && i < n_vox;
+            HydroCorners cn;
+            cn.nfaces = 0;
+            int vx = 0, vy = 0, vz = 0;
+            if (mine) {
                 hy_voxel((int)w.vox[i], vx, vy, vz);
-                kept = hydro_voxel_faces(a, p, x0 + vx, y0 + vy, z0 + vz, faces, face_id);
+                vx += x0; vy += y0; vz += z0;
+                hydro_voxel_corners(a, p, vx, vy, vz, cn);
             }
-            // buffered contacts of this voxel in buffer order: every face, or (pre_prune) the two strongest penetrating faces and the
-            // closest non-penetrating one (sdf_hydroelastic.py:2156-2312)
-            int sel[3] = {-1, -1, -1};
-            if (prune) {
-                float sc0 = 0.0f, sc1 = 0.0f, best_np = 1.0e10f;
-                for (int kk = 0; kk < kept; ++kk) {
-                    const HydroFace& fc = faces[kk];
+            // pass 1: which faces stay, and (pre_prune) the two strongest penetrating faces + the closest non-penetrating one
+            int keep_mask = 0, kept = 0, sel0 = -1, sel1 = -1, sel2 = -1;
+            float sc0 = 0.0f, sc1 = 0.0f, best_np = 1.0e10f;
+            for (int fi = 0; fi < cn.nfaces; ++fi) {
+                HydroFace fc;
+                if (!hydro_voxel_face(a, p, vx, vy, vz, cn, fi, fc)) continue;
+                keep_mask |= 1 << fi;
+                if (prune) {  // (sdf_hydroelastic.py:2156-2312; indices are ordinals among the kept faces)
                     if (fc.depth < 0.0f) {
                         const float score = fc.area * fc.pressure;
-                        if (sel[0] < 0 || score > sc0) { sel[1] = sel[0]; sc1 = sc0; sel[0] = kk; sc0 = score; }
-                        else if (sel[1] < 0 || score > sc1) { sel[1] = kk; sc1 = score; }
+                        if (sel0 < 0 || score > sc0) { sel1 = sel0; sc1 = sc0; sel0 = kept; sc0 = score; }
+                        else if (sel1 < 0 || score > sc1) { sel1 = kept; sc1 = score; }
                     } else if (fc.depth < best_np) {
                         best_np = fc.depth;
-                        sel[2] = kk;
+                        sel2 = kept;
                     }
                 }
+                kept += 1;
             }
-            const int nsel = prune ? (sel[0] >= 0) + (sel[1] >= 0) + (sel[2] >= 0) : kept;
-            int x = kept, xs = nsel;  // inclusive scans over the wave
-            for (int d = 1; d < 64; d <<= 1) {
-                const int y = __shfl_up(x, d), ys = __shfl_up(xs, d);
-                if (lane >= d) { x += y; xs += ys; }
+            const int nsel = prune ? (sel0 >= 0) + (sel1 >= 0) + (sel2 >= 0) : kept;
+            int x = kept, xs = nsel;  // inclusive scans over the group
+            for (int d = 1; d < HY_GL; d <<= 1) {
+                const int y = __shfl_up(x, d, HY_GL), ys = __shfl_up(xs, d, HY_GL);
+                if (gl >= d) { x += y; xs += ys; }
             }
-            const int total = hy_uniform(__shfl(x, 63)), sel_total = hy_uniform(__shfl(xs, 63));
+            const int total = __shfl(x, HY_GL - 1, HY_GL), sel_total = __shfl(xs, HY_GL - 1, HY_GL);
             const int before = x - kept, before_sel = xs - nsel;
             int base = 0;
-            if (lane == 0 && total > 0) base = atomicAdd(a.face_count, total);
-            base = hy_uniform(__shfl(base, 0));
+            if (gl == 0 && total > 0) base = atomicAdd(a.face_count, total);
+            base = __shfl(base, 0, HY_GL);
             const bool fits = base + total <= a.face_capacity;
-            if (lane == 0) {
+            if (k < rounds && gl == 0) {
                 int* c = a.stage_chunk + 4 * (size_t)(chunk0 + k);
                 c[0] = base;
                 c[1] = fits ? total : -total;  // negative: the faces did not fit the buffer (counted, not stored)
                 c[2] = sel_total;
-                c[3] = (n_vox - k * 64) < 64 ? (n_vox - k * 64) : 64;
+                c[3] = (n_vox - k * HY_GL) < HY_GL ? (n_vox - k * HY_GL) : HY_GL;
             }
-            if (!fits) continue;
-            for (int kk = 0; kk < kept; ++kk) {
-                const int slot = base + before + kk;
-                const HydroFace& fc = faces[kk];
+            if (!fits || kept == 0) continue;
+            // pass 2: the kept faces again, straight into their records
+            int ord = 0;
+            for (int fi = 0; fi < cn.nfaces; ++fi) {
+                if (!((keep_mask >> fi) & 1)) continue;
+                HydroFace fc;
+                hydro_voxel_face(a, p, vx, vy, vz, cn, fi, fc);
                 int cid = 0;  // contact id, relative to the chunk (the reduce stage adds what came before in the pair)
-                if (!prune) cid = before + kk + 1;
+                if (!prune) cid = before + ord + 1;
                 else {
-                    int ord = 0;
-                    for (int jj = 0; jj < 3; ++jj) {
-                        if (sel[jj] == kk) cid = before_sel + ord + 1;
-                        ord += sel[jj] >= 0 ? 1 : 0;
-                    }
+                    int rank = 0;
+                    if (sel0 == ord) cid = before_sel + rank + 1;
+                    rank += sel0 >= 0 ? 1 : 0;
+                    if (sel1 == ord) cid = before_sel + rank + 1;
+                    rank += sel1 >= 0 ? 1 : 0;
+                    if (sel2 == ord) cid = before_sel + rank + 1;
                 }
-                float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)slot;
+                float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + before + ord);
                 o[0] = fc.pos.x; o[1] = fc.pos.y; o[2] = fc.pos.z;
                 o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
                 o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
                 int* oi = reinterpret_cast<int*>(o);
-                oi[9] = lane * 5 + face_id[kk];  // voxel rank inside the CHUNK (rebased by the reduce stage)
+                oi[9] = gl * 5 + fi;  // voxel rank inside the CHUNK (rebased by the reduce stage)
                 oi[10] = (cid << 5) | red_get_slot(fc.normal);
                 oi[11] = 0;
+                ord += 1;
             }
         }
-        HY_WAVE_SYNC();  // the next item reuses the wave's LDS lists
+        HY_WAVE_SYNC();  // the next unit reuses the groups' LDS lists
     }
 }
 
@@ -2723,7 +2786,7 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
         const int rblocks = blocks;
 #endif
         if (a->stage_count) {  // dense stages: wave per pair -> wave per (pair, block) -> workgroup per pair with faces
-            if (!a->stage_queue || !a->stage_pair || !a->stage_item || !a->stage_chunk || a->stage_queue_capacity <= 0 ||
+            if (!a->stage_queue || !a->stage_pair || !a->stage_item || !a->stage_chunk || !a->stage_unit || a->stage_queue_capacity <= 0 ||
                 a->stage_chunk_capacity <= 0)
                 return NT_ERR_INVALID_ARG;
             hipStream_t st = (hipStream_t)stream;
@@ -2734,7 +2797,7 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
             const long long wb = (cap + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
             const int wgrid = (int)(wb < 16384 ? wb : 16384);
             const long long ib = ((long long)a->stage_queue_capacity + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
-            const int igrid = (int)(ib < 8192 ? ib : 8192);  // grid-stride over the items the first stage queued (count on the device)
+            const int igrid = (int)(ib < 8192 ? ib : 8192);  // grid-stride over the units the first stage queued (count on the device)
 #endif
             hipLaunchKernelGGL(hydro_stage_blocks_kernel, dim3(wgrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);
             hipLaunchKernelGGL(hydro_stage_faces_kernel, dim3(igrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);

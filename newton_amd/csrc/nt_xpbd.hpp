@@ -404,8 +404,11 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
 
 // FUSED: the collide phase of the same kernel left the live-contact count of every pair in LDS, and the (type-sorted)
 // shape order of a pair is static, so neither the liveness test nor the shape ids need the global contact arrays.
+// live_pair >= 0 (fused, staged tiles): the slot is live contact (live_pair, slot - live_pair * cpp) straight from the compacted
+// list, its shapes and bodies come from the pair descriptor -- one LDS round instead of the prefix search and the
+// pair -> shape -> type / body chain.
 template <int EPB, bool FUSED, class CW = CwLds>
-NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
+NT_DI void contact_item(const Ctx<EPB>& c, const int slot, const int live_pair = -1) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
     const int cpp = m.cpp, ncs = m.np * cpp;
@@ -414,7 +417,16 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
 
     bool live;
     int shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
-    if (FUSED) {
+    bool swapped = false, described = false;
+    if (FUSED && live_pair >= 0) {
+        const int* d = c.T.pair_desc + 4 * live_pair;
+        shape_a = d[0]; shape_b = d[1]; body_a = d[2];
+        const int w = d[3];
+        swapped = (w & (1 << 30)) != 0;
+        body_b = (w << 2) >> 2;  // sign-extend the 30-bit body index
+        live = body_a != body_b;
+        described = true;
+    } else if (FUSED) {
         const int p = slot / cpp, k = slot - p * cpp;
         live = k < (int)c.l(c.L.pm, 0, m.np, p);
         if (live) {
@@ -433,7 +445,7 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
             shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
         }
     }
-    if (live) {
+    if (live && !described) {
         body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1;
         body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         live = body_a != body_b;
@@ -442,7 +454,8 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot) {
                               ang_delta_b)) {
         has_a = body_a >= 0 ? 1.0f : 0.0f;
         has_b = body_b >= 0 ? 1.0f : 0.0f;
-        a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
+        if (described) a_is_pair_a = swapped ? 0.0f : 1.0f;
+        else a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
     }
     // lin_delta_b == -lin_delta_a bit for bit (IEEE negation commutes with every rounding above), so only one is stored
     cw_st3<CW, NC_CWX>(c, 0, ncs, slot, lin_delta_a);
@@ -490,6 +503,13 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
         // lane i takes the environment's i-th live contact (L.px: exclusive prefix of the per-pair live counts); records
         // of dead slots are never written and never read (apply_item stops at the pair's live count)
         const int total = (int)c.l(c.L.px, 0, 1, np);
+        if (!c.big) {  // the compacted list written with the prefix: no search
+            for (int i = c.tslot; i < total; i += c.nslot) {
+                const int e = *reinterpret_cast<const int*>(&c.l(c.L.lt, 0, 1, i));
+                contact_item<EPB, FUSED, CW>(c, (e >> 4) * cpp + (e & 15), e >> 4);
+            }
+            return;
+        }
         for (int i = c.tslot; i < total; i += c.nslot) {
             int lo = 0, hi = np;  // the last pair whose prefix is <= i
             while (hi - lo > 1) {

@@ -93,6 +93,26 @@ inline int __shfl(int var, int src_lane) {
     emu_wave_sync(lanes);
     return v;
 }
+inline int __popc(unsigned int x) { return __builtin_popcount(x); }
+// width-limited forms: the wave is cut into segments of `width` lanes (a power of two), lane indices are segment-relative
+inline int __shfl(int var, int src_lane, int width) {
+    emu::WaveSlot& w = emu::wave_slots()[threadIdx.x / 64];
+    const unsigned lanes = blockDim.x - (threadIdx.x / 64) * 64 < 64 ? blockDim.x - (threadIdx.x / 64) * 64 : 64;
+    w.values[__lane_id()] = var;
+    emu_wave_sync(lanes);
+    int v = w.values[(__lane_id() / width) * width + (src_lane % width)];
+    emu_wave_sync(lanes);
+    return v;
+}
+inline int __shfl_up(int var, unsigned delta, int width) {
+    emu::WaveSlot& w = emu::wave_slots()[threadIdx.x / 64];
+    const unsigned lanes = blockDim.x - (threadIdx.x / 64) * 64 < 64 ? blockDim.x - (threadIdx.x / 64) * 64 : 64;
+    w.values[__lane_id()] = var;
+    emu_wave_sync(lanes);
+    int v = (__lane_id() % width) >= delta ? w.values[__lane_id() - delta] : var;
+    emu_wave_sync(lanes);
+    return v;
+}
 inline int __shfl_up(int var, unsigned delta) {
     emu::WaveSlot& w = emu::wave_slots()[threadIdx.x / 64];
     const unsigned lanes = blockDim.x - (threadIdx.x / 64) * 64 < 64 ? blockDim.x - (threadIdx.x / 64) * 64 : 64;

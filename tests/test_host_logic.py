@@ -130,15 +130,16 @@ def test_c_abi_exports_every_declared_symbol():
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp, m.np_analytic = 18, 18, 4, 13
     # slot-major fields with odd strides (even component counts padded by one row):
-    # persistent rows 1348 (state (7 + 7) * 13 = 182 + body 23 * 13 = 299 + joint 15 * 13 = 195 + dof 11 * 18 = 198 + shape 21 * 13 = 273
-    # + control 54 + gravity 3 + derived 117 + per-pair live counts 13 + their exclusive prefix 14)
+    # persistent rows 1400 (state (7 + 7) * 13 = 182 + body 23 * 13 = 299 + joint 15 * 13 = 195 + dof 11 * 18 = 198 + shape 21 * 13 = 273
+    # + control 54 + gravity 3 + derived 117 + per-pair live counts 13 + their exclusive prefix 14 + the compacted live-contact
+    # list 13 * 4 = 52)
     # + XPBD scratch max(collide 14 * 13 + 13 = 195 + staged candidates 19 * 13 + hit list 13 + 1 = 456, the forces 7 * 13 + 13 * 13 behind it = 716,
     #   joints 22 * 13 = 286, correction records 11 * 52 = 572); the restitution scratch (182 + 15-float records) only when enabled
-    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1348 + 716)
+    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1400 + 716)
     # Featherstone: generalized state 127 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1171,
     # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780, collide scratch 429)
     m.nc, m.na, m.max_art_dofs = 19, 1, 18
-    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1348 + 1171 + 1728)
+    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1400 + 1171 + 1728)
 
 
 def test_no_silent_cpu_fallback():
@@ -303,3 +304,14 @@ def test_viewer_null_and_state_recorder(tmp_path):
     for k in range(5):
         ring.record(s)
     assert ring.get_frame_count() == 2
+
+
+def test_speculative_contacts_are_rejected_loudly_and_none_is_accepted():
+    """collide.py:1132,1239-1246: speculative_config=None (the default) disables speculative contacts -- accepted; a config object
+    is refused before any device work (no silent fallback to plain contacts)."""
+    import inspect
+
+    sig = inspect.signature(nt.CollisionPipeline.__init__)
+    assert sig.parameters["speculative_config"].default is None
+    src = inspect.getsource(nt.CollisionPipeline.__init__)
+    assert src.index("speculative_config is not None") < src.index("_BROAD_PHASES")  # refused before anything else is touched
