@@ -586,15 +586,15 @@ typedef struct {
      * 4 / 2 / 1 and marching cubes, a workgroup per pair with faces reduces them; faces, ids, order and rows are unchanged.
      * Scratch only, nothing to initialise (the call zeroes stage_count); a full queue / chunk pool drops whole pairs / blocks and
      * counts them in stage_count[2] (report it like face_count[1]). */
-    int32_t* stage_count;            /* [4]: queue items, chunk records, dropped pairs / blocks, work units */
+    int32_t* stage_count;            /* [8]: queue items, chunk records, dropped pairs / blocks, -, pairs with blocks, - */
     int32_t* stage_queue;            /* [stage_queue_capacity][2] (pair = world * pairs_per_world + k, block of shape B) */
     int32_t stage_queue_capacity;
     int32_t stage_chunk_capacity;
     int32_t* stage_pair;             /* [worlds * pairs_per_world][2] (first queue item, items) of every hydroelastic pair */
     int32_t* stage_item;             /* [stage_queue_capacity][2] (first chunk record, records) of every queue item */
     int32_t* stage_chunk;            /* [stage_chunk_capacity][4] (first face, faces (negative: not stored), buffered contacts, voxels)
-                                        per 16 iso voxels of a block */
-    int32_t* stage_unit;             /* [stage_queue_capacity][2] (pair, first queue item): up to 4 consecutive blocks of one pair */
+                                        per 64 iso voxels of a block */
+    int32_t* stage_active;           /* [worlds * pairs_per_world] the pairs that queued blocks (arrival order; each writes its own rows) */
 } nt_hydro_args;
 nt_status nt_hydro_collide(const nt_hydro_args* args, void* stream);
 /* HydroelasticSDF.launch (sdf_hydroelastic.py:905-1296, reduce_contacts=False) inside the collide pipeline: SAT of the SDF boxes,

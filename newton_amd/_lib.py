@@ -177,7 +177,7 @@ class nt_hydro_args(C.Structure):
                 ("reduce", C.c_int32), ("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
                 ("face_count", C.c_void_p), ("face_rec", C.c_void_p), ("face_capacity", C.c_int32), ("out_friction", C.c_void_p),
                 ("stage_count", C.c_void_p), ("stage_queue", C.c_void_p), ("stage_queue_capacity", C.c_int32),
-                ("stage_chunk_capacity", C.c_int32), ("stage_pair", C.c_void_p), ("stage_item", C.c_void_p), ("stage_chunk", C.c_void_p), ("stage_unit", C.c_void_p)]
+                ("stage_chunk_capacity", C.c_int32), ("stage_pair", C.c_void_p), ("stage_item", C.c_void_p), ("stage_chunk", C.c_void_p), ("stage_active", C.c_void_p)]
 
 
 class nt_semi_implicit_params(C.Structure):

@@ -38,6 +38,28 @@ NT_DI float texel(const nt_sdf& s, int x, int y, int z) {  // subgrid "texture" 
     return (float)reinterpret_cast<const uint8_t*>(s.subgrid)[i] * (1.0f / 255.0f);
 }
 
+// two x-adjacent texels (x, x + 1 in the same row) with ONE load: the uint16 / uint8 formats pack them into a dword / a word
+// (2-byte aligned dword loads are legal on gfx950), float32 into a dwordx2.  Same values as two texel() calls, half the requests
+// of a sampler whose eight taps are four such pairs.
+NT_DI void texel_pair(const nt_sdf& s, int x, int y, int z, float& v0, float& v1) {
+    const size_t i = ((size_t)z * s.tex_size + y) * s.tex_size + x;
+    if (s.quantization == 4) {
+        float w[2];
+        __builtin_memcpy(w, reinterpret_cast<const float*>(s.subgrid) + i, 8);
+        v0 = w[0]; v1 = w[1];
+    } else if (s.quantization == 2) {
+        uint32_t w;
+        __builtin_memcpy(&w, reinterpret_cast<const uint16_t*>(s.subgrid) + i, 4);
+        v0 = (float)(w & 0xFFFFu) * (1.0f / 65535.0f);
+        v1 = (float)(w >> 16) * (1.0f / 65535.0f);
+    } else {
+        uint16_t w;
+        __builtin_memcpy(&w, reinterpret_cast<const uint8_t*>(s.subgrid) + i, 2);
+        v0 = (float)(w & 0xFFu) * (1.0f / 255.0f);
+        v1 = (float)(w >> 8) * (1.0f / 255.0f);
+    }
+}
+
 struct Cell {
     int ix, iy, iz, bx, by, bz;
     float tx, ty, tz;
@@ -88,10 +110,10 @@ NT_DI float sample_clamped(const nt_sdf& s, vec3 clamped, float diff_mag) {
         const int ox = (int)(c.slot & 0x3FFu) * spd + (c.ix - c.bx * s.subgrid_size);
         const int oy = (int)((c.slot >> 10) & 0x3FFu) * spd + (c.iy - c.by * s.subgrid_size);
         const int oz = (int)((c.slot >> 20) & 0x3FFu) * spd + (c.iz - c.bz * s.subgrid_size);
-        v000 = texel(s, ox, oy, oz); v100 = texel(s, ox + 1, oy, oz);
-        v010 = texel(s, ox, oy + 1, oz); v110 = texel(s, ox + 1, oy + 1, oz);
-        v001 = texel(s, ox, oy, oz + 1); v101 = texel(s, ox + 1, oy, oz + 1);
-        v011 = texel(s, ox, oy + 1, oz + 1); v111 = texel(s, ox + 1, oy + 1, oz + 1);
+        texel_pair(s, ox, oy, oz, v000, v100);  // (ox + 1 <= the block's last sample: the cell index inside the block is < subgrid_size)
+        texel_pair(s, ox, oy + 1, oz, v010, v110);
+        texel_pair(s, ox, oy, oz + 1, v001, v101);
+        texel_pair(s, ox, oy + 1, oz + 1, v011, v111);
     }
     float c00 = v000 + (v100 - v000) * tx;
     float c10 = v010 + (v110 - v010) * tx;
@@ -127,8 +149,13 @@ NT_DI float fetch_linear(const nt_sdf& s, bool coarse, float ux, float uy, float
         const int T = s.tex_size;
         const int xa = clampi(x0, 0, T - 1), xb = clampi(x0 + 1, 0, T - 1), ya = clampi(y0, 0, T - 1), yb = clampi(y0 + 1, 0, T - 1),
                   za = clampi(z0, 0, T - 1), zb = clampi(z0 + 1, 0, T - 1);
-        v000 = texel(s, xa, ya, za); v100 = texel(s, xb, ya, za); v010 = texel(s, xa, yb, za); v110 = texel(s, xb, yb, za);
-        v001 = texel(s, xa, ya, zb); v101 = texel(s, xb, ya, zb); v011 = texel(s, xa, yb, zb); v111 = texel(s, xb, yb, zb);
+        if (xb == xa + 1) {  // (always, except at the clamped border of the texture)
+            texel_pair(s, xa, ya, za, v000, v100); texel_pair(s, xa, yb, za, v010, v110);
+            texel_pair(s, xa, ya, zb, v001, v101); texel_pair(s, xa, yb, zb, v011, v111);
+        } else {
+            v000 = texel(s, xa, ya, za); v100 = texel(s, xb, ya, za); v010 = texel(s, xa, yb, za); v110 = texel(s, xb, yb, za);
+            v001 = texel(s, xa, ya, zb); v101 = texel(s, xb, ya, zb); v011 = texel(s, xa, yb, zb); v111 = texel(s, xb, yb, zb);
+        }
     }
     const float c00 = v000 + (v100 - v000) * tx;
     const float c10 = v010 + (v110 - v010) * tx;
@@ -1449,6 +1476,39 @@ struct HydroCorners {
     float cv[8], cself[8], cother[8];
     int t0, nfaces;  // triangle range of the marching-cubes case, faces of the case (0: nothing to do)
 };
+// one corner of a voxel: the two margin-relative signed distances (shape B at the voxel corner, shape A at the same point)
+NT_DI void hydro_corner_sample(const HydroPair& p, int x, int y, int z, int i, float& es, float& eo) {
+    const nt_sdf& A = p.A;
+    const nt_sdf& B = p.B;
+    const vec3 vs(B.voxel_size[0], B.voxel_size[1], B.voxel_size[2]), blo(B.box_lower[0], B.box_lower[1], B.box_lower[2]);
+    const vec3 base_b = blo + cw_mul(vec3((float)x, (float)y, (float)z), vs);
+    const vec3 base_a = xform_point(p.X_b2a, base_b);
+    const vec3 step_x = xform_vector(p.X_b2a, vec3(vs.x, 0.0f, 0.0f)), step_y = xform_vector(p.X_b2a, vec3(0.0f, vs.y, 0.0f)),
+               step_z = xform_vector(p.X_b2a, vec3(0.0f, 0.0f, vs.z));
+    const int ox = mc_cx(i), oy = mc_cy(i), oz = mc_cz(i);
+    const vec3 pa = base_a + (float)ox * step_x + (float)oy * step_y + (float)oz * step_z;
+    es = sample_at_voxel(B, x + ox, y + oy, z + oz) - p.margin_b;
+    eo = sample(A, pa) - p.margin_a;
+}
+// the voxel's marching-cubes case from its eight corner samples (es[i], eo[i] as hydro_corner_sample returns them)
+NT_DI void hydro_voxel_classify(const nt_hydro_args& a, const HydroPair& p, const float* es8, const float* eo8, HydroCorners& c) {
+    int cube = 0;
+    bool any_gap = false, nan = false;
+    c.nfaces = 0;
+    c.t0 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float es = es8[i], eo = eo8[i];
+        if (es != es || eo != eo) nan = true;  // (v - margin is NaN exactly when v is)
+        const float vd = (-p.kh_a * eo) - (-p.kh_b * es);
+        c.cv[i] = vd; c.cself[i] = es; c.cother[i] = eo;
+        if (vd < 0.0f) cube |= 1 << i;
+        if (es + eo <= p.gap_sum) any_gap = true;
+    }
+    if (nan || !any_gap) return;
+    c.t0 = a.tri_range[cube];
+    c.nfaces = (a.tri_range[cube + 1] - c.t0) / 3;
+}
 NT_DI void hydro_voxel_corners(const nt_hydro_args& a, const HydroPair& p, int x, int y, int z, HydroCorners& c) {
     const nt_sdf& A = p.A;
     const nt_sdf& B = p.B;
@@ -1563,9 +1623,9 @@ __device__ unsigned long long nt_hydro_timing[16];
 #define NT_HT(i, t_last) do { } while (0)
 #endif
 // ---- reduce_contacts = True: what the workgroup keeps of a pair between the face pass and the reduction (see hydro_reduce_pair)
-constexpr int HYDRO_CHUNK_CAP = 1024;  // face blocks of one pair (one per 256 voxels that carry faces)
+constexpr int HYDRO_CHUNK_CAP = 384;   // face blocks of one pair (staged: one per 16 iso voxels; single kernel: one per 256)
 constexpr int HYDRO_ENTRIES = 50;      // 20 normal bins + 15 voxel groups + 15 speculative voxel groups
-constexpr int HYDRO_STAGE = 256;
+constexpr int HYDRO_STAGE = 128;
 constexpr int HYDRO_FACE_WORDS = 12;   // centre[3] normal[3] separation area pressure | key | contact id << 5 | normal bin | pad
 struct HydroRedLds {
     int chunk[HYDRO_CHUNK_CAP][2];
@@ -2319,12 +2379,13 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
 //                               (64 per round, ballot masks in LDS); the surviving blocks leave as one contiguous run of
 //                               (pair, block) items in block order (one atomic per pair) -> stage_queue, stage_pair = (first item,
 //                               items)
-//   hydro_stage_faces_kernel    wave per UNIT = up to four consecutive blocks of one pair, sixteen lanes per block: levels 4 / 2 / 1
-//                               as group ballots (the children of the survivors dealt sixteen at a time), voxels compacted in
-//                               traversal order into the group's LDS list, marching cubes sixteen voxels per round; a round's
-//                               faces are one chunk of the face buffer (one atomic) recorded in stage_chunk = (first face, faces,
-//                               buffered contacts, voxels); ids inside a record are relative to the chunk.  No workgroup barrier
-//                               anywhere; the pair's descriptors are wave-uniform (scalar registers).
+//   hydro_stage_faces_kernel    wave per item: levels 4 / 2 / 1 as ballot masks (8 lanes, 64 lanes, then the children of the
+//                               surviving level-2 nodes dealt 64 at a time), voxels compacted in traversal order into the wave's
+//                               LDS list; marching cubes 64 voxels per round: the corner samples one lane per (voxel, corner)
+//                               through LDS, then one lane per voxel for the case and its faces (two passes: rank, write); a
+//                               round's faces are one chunk of the face buffer (one atomic) recorded in stage_chunk = (first face,
+//                               faces, buffered contacts, voxels); ids inside a record are relative to the chunk.  No workgroup
+//                               barrier anywhere; the pair's descriptors are wave-uniform (scalar registers).
 //   hydro_stage_reduce_kernel   workgroup per pair with items: lists the pair's chunks in (block, round) order -- the traversal order
 //                               of the single kernel --, rebases the records' voxel ranks and contact ids by the running totals, and
 //                               runs the same hydro_reduce_pair on them.
@@ -2397,12 +2458,21 @@ NT_DI void hy_voxel(int j, int& x, int& y, int& z) {
     x = 4 * ax + 2 * bx + cx; y = 4 * ay + 2 * by + cy; z = 4 * az + 2 * bz + cz;
 }
 constexpr int HY_STAGE_WAVES = 4;  // waves per workgroup of the wave-per-unit stages (independent: no workgroup barrier)
-constexpr int HY_GROUPS = 4, HY_GL = 64 / HY_GROUPS;  // the face stage gives a lane group of 16 to every block of a unit
+constexpr int HY_ROUND = 64;       // iso voxels per marching-cubes round = per chunk of face records
 struct HyWaveBlocks { unsigned long long mask[HYDRO_MAX_BLOCKS / 64]; };
-struct HyGroupFaces { unsigned char l4[8], l2[64]; unsigned short vox[512]; };
+struct HyWaveFaces {
+    unsigned char l2[64];
+    unsigned short vox[512];
+    float es[8 * HY_ROUND], eo[8 * HY_ROUND];  // corner samples of the round's voxels: [voxel][corner]
+};
+#ifdef NT_HYDRO_FACES_WAVES  // measurement builds: cap the registers for this many waves per SIMD
+#define NT_HYDRO_FACES_OCC __attribute__((amdgpu_waves_per_eu(NT_HYDRO_FACES_WAVES, NT_HYDRO_FACES_WAVES)))
+#else
+#define NT_HYDRO_FACES_OCC
+#endif
 
 // counters (stage_count): [0] queue items, [1] chunk records, [2] pairs / blocks lost to a full queue / chunk pool (-> overflow
-// report), [3] work units of the face stage
+// report), [3] -, [4] pairs with queued blocks (stage_active)
 __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel(nt_hydro_args a) {
     __shared__ HyWaveBlocks W[HY_STAGE_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2461,85 +2531,58 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel
         if (lane == 0) {
             a.stage_pair[2 * (size_t)pair_idx] = q0;
             a.stage_pair[2 * (size_t)pair_idx + 1] = total;
-        }
-        // work units of the face stage: up to HY_GROUPS consecutive blocks of ONE pair (the pair's descriptors stay wave-uniform)
-        const int nu = (total + HY_GROUPS - 1) / HY_GROUPS;
-        if (nu > 0) {
-            int ub = 0;
-            if (lane == 0) ub = atomicAdd(a.stage_count + 3, nu);
-            ub = hy_uniform(__shfl(ub, 0));
-            for (int u = lane; u < nu; u += 64) {  // (the unit list shares the queue's capacity: units <= items)
-                a.stage_unit[2 * (size_t)(ub + u)] = pair_idx;
-                a.stage_unit[2 * (size_t)(ub + u) + 1] = q0 + u * HY_GROUPS;
+            if (total > 0) {  // the reduce stage only visits pairs that queued blocks
+                a.stage_active[atomicAdd(a.stage_count + 4, 1)] = pair_idx;
+            } else {
+                a.out_blk[2 * (size_t)pair_idx] = 0;
+                a.out_blk[2 * (size_t)pair_idx + 1] = 0;
             }
         }
     }
 }
 
-// One wave per unit = up to four blocks of one pair, a group of sixteen lanes each.  A surviving block of a pile carries about a
-// dozen iso voxels: a whole wave per block left four lanes in five idle in every phase.  Group-local ballots are slices of the
-// wave ballot, group-local scans are width-16 shuffles; every loop runs while ANY group has work, so the wave stays converged.
-#ifdef NT_HYDRO_FACES_WAVES  // measurement builds: cap the registers for this many waves per SIMD
-#define NT_HYDRO_FACES_OCC __attribute__((amdgpu_waves_per_eu(NT_HYDRO_FACES_WAVES, NT_HYDRO_FACES_WAVES)))
-#else
-#define NT_HYDRO_FACES_OCC
-#endif
+// One wave per (pair, block) item.  (Measured alternative, profiles/r04e_*: four blocks per wave on 16-lane groups -- better lane
+// utilisation, but 121 instead of 90 ms per collide at C5's size: the lanes of a wave then sample four distant SDF regions at once
+// and the texel requests of one instruction stop sharing cache lines.  The stage is bound by texel requests, not by lanes.)
 __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_stage_faces_kernel(nt_hydro_args a) {
-    __shared__ HyGroupFaces W[HY_STAGE_WAVES][HY_GROUPS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / HY_GL, gl = lane % HY_GL;
-    HyGroupFaces& w = W[wave][g];
-    const unsigned int glt = (1u << gl) - 1u;
-    auto gballot = [&](bool v) { return (unsigned int)((__ballot(v) >> (HY_GL * g)) & ((1ull << HY_GL) - 1ull)); };
-    int n_units = a.stage_count[3];
-    n_units = n_units < a.stage_queue_capacity ? n_units : a.stage_queue_capacity;
+    __shared__ HyWaveFaces W[HY_STAGE_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HyWaveFaces& w = W[wave];
+    const unsigned long long lt = (1ull << lane) - 1ull;
     int n_items = a.stage_count[0];
     n_items = n_items < a.stage_queue_capacity ? n_items : a.stage_queue_capacity;
     const bool prune = (a.reduce & 2) != 0;
-    for (int u = blockIdx.x * HY_STAGE_WAVES + wave; u < n_units; u += gridDim.x * HY_STAGE_WAVES) {
-        const int pair_idx = hy_uniform(a.stage_unit[2 * (size_t)u]), qf = hy_uniform(a.stage_unit[2 * (size_t)u + 1]);
-        const int q_end = hy_uniform(a.stage_pair[2 * (size_t)pair_idx] + a.stage_pair[2 * (size_t)pair_idx + 1]);
+    for (int q = blockIdx.x * HY_STAGE_WAVES + wave; q < n_items; q += gridDim.x * HY_STAGE_WAVES) {
+        const int pair_idx = hy_uniform(a.stage_queue[2 * (size_t)q]), b = hy_uniform(a.stage_queue[2 * (size_t)q + 1]);
         HydroPair p;
         bool collide;
         hydro_pair_load(a, pair_idx, p, false, collide);
-        const int q = qf + g;
-        const bool have = q < q_end && q < n_items;  // this group's block
-        const int b = have ? a.stage_queue[2 * (size_t)q + 1] : 0;
         const int nbx = p.B.cx, nby = p.B.cy, sgs = p.B.subgrid_size;
         const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
         const int x0 = bx * sgs, y0 = by * sgs, z0 = bz * sgs;
-        // ---- level 4: lanes 0..7 of the group
+        // ---- levels 4 and 2 as ballot masks
         bool s4 = false;
-        if (have && gl < 8) {
+        if (lane < 8) {
             int cx, cy, cz;
-            hy_child(gl, cx, cy, cz);
+            hy_child(lane, cx, cy, cz);
             s4 = hydro_node_survives(p, x0 + 4 * cx, y0 + 4 * cy, z0 + 4 * cz, 4);
         }
-        const unsigned int m4 = gballot(s4);
-        const int n4 = __popc(m4);
-        if (s4) w.l4[__popc(m4 & glt)] = (unsigned char)gl;
-        HY_WAVE_SYNC();
-        // ---- level 2: the eight children of every surviving level-4 node, sixteen tests per round, survivors in traversal order
-        int n2 = 0;
-        for (int i0 = 0; __any(i0 < 8 * n4); i0 += HY_GL) {
-            const int i = i0 + gl;
-            bool s2 = false;
-            int t2 = 0;
-            if (i < 8 * n4) {
-                t2 = (int)w.l4[i >> 3] * 8 + (i & 7);  // level-2 node code: child of 4 << 3 | child of 2
-                int ax, ay, az, bx_, by_, bz_;
-                hy_child(t2 >> 3, ax, ay, az);
-                hy_child(t2 & 7, bx_, by_, bz_);
-                s2 = hydro_node_survives(p, x0 + 4 * ax + 2 * bx_, y0 + 4 * ay + 2 * by_, z0 + 4 * az + 2 * bz_, 2);
-            }
-            const unsigned int m2 = gballot(s2);
-            if (s2) w.l2[n2 + __popc(m2 & glt)] = (unsigned char)t2;
-            n2 += __popc(m2);
+        const unsigned long long m4 = __ballot(s4);
+        bool s2 = false;
+        if ((m4 >> (lane >> 3)) & 1ull) {
+            int ax, ay, az, bx_, by_, bz_;
+            hy_child(lane >> 3, ax, ay, az);
+            hy_child(lane & 7, bx_, by_, bz_);
+            s2 = hydro_node_survives(p, x0 + 4 * ax + 2 * bx_, y0 + 4 * ay + 2 * by_, z0 + 4 * az + 2 * bz_, 2);
         }
+        const unsigned long long m2 = __ballot(s2);
+        const int n2 = __popcll(m2);
+        if (s2) w.l2[__popcll(m2 & lt)] = (unsigned char)lane;
         HY_WAVE_SYNC();
-        // ---- level 1
+        // ---- level 1: the eight children of every surviving level-2 node, 64 tests per round, survivors in traversal order
         int n_vox = 0;
-        for (int i0 = 0; __any(i0 < 8 * n2); i0 += HY_GL) {
-            const int i = i0 + gl;
+        for (int i0 = 0; i0 < 8 * n2; i0 += 64) {
+            const int i = i0 + lane;
             bool s1 = false;
             int j = 0;
             if (i < 8 * n2) {
@@ -2548,36 +2591,56 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
                 hy_voxel(j, vx, vy, vz);
                 s1 = hydro_node_survives(p, x0 + vx, y0 + vy, z0 + vz, 1);
             }
-            const unsigned int m1 = gballot(s1);
-            if (s1) w.vox[n_vox + __popc(m1 & glt)] = (unsigned short)j;
-            n_vox += __popc(m1);
+            const unsigned long long m1 = __ballot(s1);
+            if (s1) w.vox[n_vox + __popcll(m1 & lt)] = (unsigned short)j;
+            n_vox += __popcll(m1);
         }
         HY_WAVE_SYNC();
-        // ---- chunk records of the block: one per sixteen voxels
-        const int nb = (n_vox + HY_GL - 1) / HY_GL;
+        const int nb = (n_vox + HY_ROUND - 1) / HY_ROUND;
         int chunk0 = 0;
-        if (gl == 0 && nb > 0) chunk0 = atomicAdd(a.stage_count + 1, nb);
-        chunk0 = __shfl(chunk0, 0, HY_GL);
+        if (nb > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.stage_count + 1, nb);
+            chunk0 = hy_uniform(__shfl(base, 0));
+        }
         const bool chunks_ok = chunk0 + nb <= a.stage_chunk_capacity;
-        if (have && gl == 0) {
+        if (lane == 0) {
             if (!chunks_ok) atomicAdd(a.stage_count + 2, 1);
             a.stage_item[2 * (size_t)q] = chunk0;
             a.stage_item[2 * (size_t)q + 1] = chunks_ok ? nb : 0;
         }
-        const int rounds = chunks_ok ? nb : 0;
-        // ---- marching cubes, one lane per voxel, sixteen voxels per round = one chunk of face records.  Two passes over a voxel's
-        // (<= 5) faces -- count / rank, then write -- instead of holding five face records per lane: half the registers, twice the
-        // waves in flight on a kernel that waits for SDF samples.
-        for (int k = 0; __any(k < rounds); ++k) {
-            const int i = k * HY_GL + gl;
-            const bool mine = k < rounds && i < n_vox;
+        if (!chunks_ok) continue;
+        // ---- marching cubes, HY_ROUND voxels per round = one chunk of face records.
+        // (a) the corner samples: one lane per (voxel, corner) -- a block of a pile carries about a dozen iso voxels, so a lane per
+        //     voxel would sample on a fifth of the wave, eight dependent samples deep; the values go through LDS;
+        // (b) one lane per voxel: the case, then two passes over its (<= 5) faces -- count / rank, then write -- instead of
+        //     holding five face records per lane.
+        for (int k = 0; k < nb; ++k) {
+            const int v0 = k * HY_ROUND;
+            const int nv = (n_vox - v0) < HY_ROUND ? (n_vox - v0) : HY_ROUND;
+            for (int t0 = 0; t0 < 8 * nv; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < 8 * nv) {
+                    int vx, vy, vz;
+                    hy_voxel((int)w.vox[v0 + (t >> 3)], vx, vy, vz);
+                    float es, eo;
+                    hydro_corner_sample(p, x0 + vx, y0 + vy, z0 + vz, t & 7, es, eo);
+                    w.es[t] = es;
+                    w.eo[t] = eo;
+                }
+            }
+            HY_WAVE_SYNC();
+            const bool mine = lane < nv;
             HydroCorners cn;
             cn.nfaces = 0;
             int vx = 0, vy = 0, vz = 0;
             if (mine) {
-                hy_voxel((int)w.vox[i], vx, vy, vz);
+                hy_voxel((int)w.vox[v0 + lane], vx, vy, vz);
                 vx += x0; vy += y0; vz += z0;
-                hydro_voxel_corners(a, p, vx, vy, vz, cn);
+                float es8[8], eo8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { es8[i] = w.es[8 * lane + i]; eo8[i] = w.eo[8 * lane + i]; }
+                hydro_voxel_classify(a, p, es8, eo8, cn);
             }
             // pass 1: which faces stay, and (pre_prune) the two strongest penetrating faces + the closest non-penetrating one
             int keep_mask = 0, kept = 0, sel0 = -1, sel1 = -1, sel2 = -1;
@@ -2599,24 +2662,25 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
                 kept += 1;
             }
             const int nsel = prune ? (sel0 >= 0) + (sel1 >= 0) + (sel2 >= 0) : kept;
-            int x = kept, xs = nsel;  // inclusive scans over the group
-            for (int d = 1; d < HY_GL; d <<= 1) {
-                const int y = __shfl_up(x, d, HY_GL), ys = __shfl_up(xs, d, HY_GL);
-                if (gl >= d) { x += y; xs += ys; }
+            int x = kept, xs = nsel;  // inclusive scans over the wave
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d), ys = __shfl_up(xs, d);
+                if (lane >= d) { x += y; xs += ys; }
             }
-            const int total = __shfl(x, HY_GL - 1, HY_GL), sel_total = __shfl(xs, HY_GL - 1, HY_GL);
+            const int total = hy_uniform(__shfl(x, 63)), sel_total = hy_uniform(__shfl(xs, 63));
             const int before = x - kept, before_sel = xs - nsel;
             int base = 0;
-            if (gl == 0 && total > 0) base = atomicAdd(a.face_count, total);
-            base = __shfl(base, 0, HY_GL);
+            if (lane == 0 && total > 0) base = atomicAdd(a.face_count, total);
+            base = hy_uniform(__shfl(base, 0));
             const bool fits = base + total <= a.face_capacity;
-            if (k < rounds && gl == 0) {
+            if (lane == 0) {
                 int* c = a.stage_chunk + 4 * (size_t)(chunk0 + k);
                 c[0] = base;
                 c[1] = fits ? total : -total;  // negative: the faces did not fit the buffer (counted, not stored)
                 c[2] = sel_total;
-                c[3] = (n_vox - k * HY_GL) < HY_GL ? (n_vox - k * HY_GL) : HY_GL;
+                c[3] = nv;
             }
+            HY_WAVE_SYNC();  // (the next round overwrites the corner samples)
             if (!fits || kept == 0) continue;
             // pass 2: the kept faces again, straight into their records
             int ord = 0;
@@ -2639,13 +2703,13 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
                 o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
                 o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
                 int* oi = reinterpret_cast<int*>(o);
-                oi[9] = gl * 5 + fi;  // voxel rank inside the CHUNK (rebased by the reduce stage)
+                oi[9] = lane * 5 + fi;  // voxel rank inside the CHUNK (rebased by the reduce stage)
                 oi[10] = (cid << 5) | red_get_slot(fc.normal);
                 oi[11] = 0;
                 ord += 1;
             }
         }
-        HY_WAVE_SYNC();  // the next unit reuses the groups' LDS lists
+        HY_WAVE_SYNC();  // the next item reuses the wave's LDS lists
     }
 }
 
@@ -2656,11 +2720,10 @@ __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a
     constexpr int HY_ITEM_TILE = 128;
     __shared__ int item_c0[HY_ITEM_TILE], item_nc[HY_ITEM_TILE + 1], n_raw;
     const int t = threadIdx.x;
-    const int pair_total = a.pair_world_prefix[a.worlds];
+    const int n_active = a.stage_count[4];
     const bool prune = (a.reduce & 2) != 0;
-    for (int f = blockIdx.x; f < pair_total; f += gridDim.x) {
-        const int pair_idx = hydro_pair_of_flat(a, f);
-        if (a.pair_kind[pair_idx] != 1) continue;
+    for (int f = blockIdx.x; f < n_active; f += gridDim.x) {
+        const int pair_idx = a.stage_active[f];
         const int q0 = a.stage_pair[2 * (size_t)pair_idx], nq = a.stage_pair[2 * (size_t)pair_idx + 1];
         __syncthreads();
 #ifdef NT_POISON_LDS  // (tests/emu: every pair starts from garbage LDS, as on a CU that ran other workgroups before)
@@ -2786,18 +2849,18 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
         const int rblocks = blocks;
 #endif
         if (a->stage_count) {  // dense stages: wave per pair -> wave per (pair, block) -> workgroup per pair with faces
-            if (!a->stage_queue || !a->stage_pair || !a->stage_item || !a->stage_chunk || !a->stage_unit || a->stage_queue_capacity <= 0 ||
+            if (!a->stage_queue || !a->stage_pair || !a->stage_item || !a->stage_chunk || !a->stage_active || a->stage_queue_capacity <= 0 ||
                 a->stage_chunk_capacity <= 0)
                 return NT_ERR_INVALID_ARG;
             hipStream_t st = (hipStream_t)stream;
-            if (hipMemsetAsync(a->stage_count, 0, 4 * sizeof(int32_t), st) != hipSuccess) return NT_ERR_LAUNCH;
+            if (hipMemsetAsync(a->stage_count, 0, 8 * sizeof(int32_t), st) != hipSuccess) return NT_ERR_LAUNCH;
 #ifdef NT_EMULATED_GRID
             const int wgrid = NT_EMULATED_GRID, igrid = NT_EMULATED_GRID;
 #else
             const long long wb = (cap + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
             const int wgrid = (int)(wb < 16384 ? wb : 16384);
             const long long ib = ((long long)a->stage_queue_capacity + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
-            const int igrid = (int)(ib < 8192 ? ib : 8192);  // grid-stride over the units the first stage queued (count on the device)
+            const int igrid = (int)(ib < 8192 ? ib : 8192);  // grid-stride over the items the first stage queued (count on the device)
 #endif
             hipLaunchKernelGGL(hydro_stage_blocks_kernel, dim3(wgrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);
             hipLaunchKernelGGL(hydro_stage_faces_kernel, dim3(igrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);

@@ -192,10 +192,10 @@ class SdfLeg:
             if self.hydro_staged:
                 self.stage_queue_capacity = max(E * PPW * int(hydro_blocks_per_pair), 1024)
                 self.stage_chunk_capacity = 2 * self.stage_queue_capacity
-                self.stage_count = torch.zeros(4, dtype=i32, device=dev)
+                self.stage_count = torch.zeros(8, dtype=i32, device=dev)
+                self.stage_active = torch.zeros(E * PPW, dtype=i32, device=dev)
                 self.stage_queue = torch.zeros((self.stage_queue_capacity, 2), dtype=i32, device=dev)
                 self.stage_item = torch.zeros((self.stage_queue_capacity, 2), dtype=i32, device=dev)
-                self.stage_unit = torch.zeros((self.stage_queue_capacity, 2), dtype=i32, device=dev)
                 self.stage_pair = torch.zeros((E * PPW, 2), dtype=i32, device=dev)
                 self.stage_chunk = torch.zeros((self.stage_chunk_capacity, 4), dtype=i32, device=dev)
 
@@ -264,7 +264,8 @@ class SdfLeg:
                 if self.hydro_staged:
                     h.stage_count, h.stage_queue, h.stage_queue_capacity = (self.stage_count.data_ptr(), self.stage_queue.data_ptr(),
                                                                             self.stage_queue_capacity)
-                    h.stage_pair, h.stage_item, h.stage_unit = self.stage_pair.data_ptr(), self.stage_item.data_ptr(), self.stage_unit.data_ptr()
+                    h.stage_pair, h.stage_item = self.stage_pair.data_ptr(), self.stage_item.data_ptr()
+                    h.stage_active = self.stage_active.data_ptr()
                     h.stage_chunk, h.stage_chunk_capacity = self.stage_chunk.data_ptr(), self.stage_chunk_capacity
             _lib.check(lib.nt_hydro_pairs(C.byref(h), stream), "nt_hydro_pairs")
         io = _lib.nt_sdf_rows_io()
