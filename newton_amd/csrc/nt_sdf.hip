@@ -2459,7 +2459,6 @@ NT_DI void hy_voxel(int j, int& x, int& y, int& z) {
 }
 constexpr int HY_STAGE_WAVES = 4;  // waves per workgroup of the wave-per-unit stages (independent: no workgroup barrier)
 constexpr int HY_ROUND = 64;       // iso voxels per marching-cubes round = per chunk of face records
-struct HyWaveBlocks { unsigned long long mask[HYDRO_MAX_BLOCKS / 64]; };
 struct HyWaveFaces {
     unsigned char l2[64];
     unsigned short vox[512];
@@ -2473,71 +2472,102 @@ struct HyWaveFaces {
 
 // counters (stage_count): [0] queue items, [1] chunk records, [2] pairs / blocks lost to a full queue / chunk pool (-> overflow
 // report), [3] -, [4] pairs with queued blocks (stage_active)
+// A wave takes HY_BATCH consecutive pairs at a time and allocates for all of them with ONE atomic per counter: half a million
+// same-address atomics (one per pair and counter) were most of this stage's 11 ms at C5's size (22 ns each, serialised in L2).
+constexpr int HY_BATCH = 8;
+struct HyWaveBatch {
+    unsigned long long mask[HY_BATCH][HYDRO_MAX_BLOCKS / 64];
+    int pair[HY_BATCH], total[HY_BATCH], rounds[HY_BATCH];
+};
 __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel(nt_hydro_args a) {
-    __shared__ HyWaveBlocks W[HY_STAGE_WAVES];
+    __shared__ HyWaveBatch W[HY_STAGE_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    HyWaveBlocks& w = W[wave];
+    HyWaveBatch& w = W[wave];
     const int pair_total = a.pair_world_prefix[a.worlds];
-    for (int f = blockIdx.x * HY_STAGE_WAVES + wave; f < pair_total; f += gridDim.x * HY_STAGE_WAVES) {
-        const int pair_idx = hy_uniform(hydro_pair_of_flat(a, f));
-        if (a.pair_kind[pair_idx] != 1) continue;
-        HydroPair p;
-        bool collide;
-        const bool ok = hydro_pair_load(a, pair_idx, p, true, collide);
-        if (lane == 0 && a.out_pairs_normalized) {
-            a.out_pairs_normalized[2 * (size_t)pair_idx] = p.sa;
-            a.out_pairs_normalized[2 * (size_t)pair_idx + 1] = p.sb;
-        }
-        int q0 = 0, total = 0;
-        const int nbx = ok ? p.B.cx : 0, nby = ok ? p.B.cy : 0, nbz = ok ? p.B.cz : 0;
-        const int nblocks = nbx * nby * nbz;
-        if (ok && collide && nblocks <= HYDRO_MAX_BLOCKS) {
-            const int sgs = p.B.subgrid_size;  // 8
-            const int rounds = (nblocks + 63) >> 6;
-            for (int r = 0; r < rounds; ++r) {  // level 8: block b = (bz * nby + by) * nbx + bx
-                const int b = r * 64 + lane;
-                bool s = false;
-                if (b < nblocks) {
-                    const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
-                    s = hydro_node_survives(p, bx * sgs, by * sgs, bz * sgs, sgs);
-                }
-                const unsigned long long m = __ballot(s);
-                if (lane == 0) w.mask[r] = m;
-                total += __popcll(m);
+    for (int f0 = (blockIdx.x * HY_STAGE_WAVES + wave) * HY_BATCH; f0 < pair_total; f0 += gridDim.x * HY_STAGE_WAVES * HY_BATCH) {
+        int sum = 0, active = 0;
+        for (int s = 0; s < HY_BATCH; ++s) {  // ---- level 8 of every pair of the batch; survivors as ballot masks in LDS
+            const int f = f0 + s;
+            int pair_idx = -1, total = 0, rounds = 0;
+            if (f < pair_total) {
+                pair_idx = hy_uniform(hydro_pair_of_flat(a, f));
+                if (a.pair_kind[pair_idx] != 1) pair_idx = -1;
             }
-            HY_WAVE_SYNC();
-            if (total > 0) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(a.stage_count, total);
-                q0 = hy_uniform(__shfl(base, 0));
-                if (q0 + total > a.stage_queue_capacity) {  // the pair's blocks do not fit the queue: it contributes nothing, reported
-                    if (lane == 0) atomicAdd(a.stage_count + 2, 1);
-                    total = 0;
-                } else {
-                    int off = 0;
-                    for (int r = 0; r < rounds; ++r) {
-                        const unsigned long long m = w.mask[r];
-                        if ((m >> lane) & 1ull) {
-                            const int q = q0 + off + __popcll(m & ((1ull << lane) - 1ull));
-                            a.stage_queue[2 * (size_t)q] = pair_idx;
-                            a.stage_queue[2 * (size_t)q + 1] = r * 64 + lane;
+            if (pair_idx >= 0) {
+                HydroPair p;
+                bool collide;
+                const bool ok = hydro_pair_load(a, pair_idx, p, true, collide);
+                if (lane == 0 && a.out_pairs_normalized) {
+                    a.out_pairs_normalized[2 * (size_t)pair_idx] = p.sa;
+                    a.out_pairs_normalized[2 * (size_t)pair_idx + 1] = p.sb;
+                }
+                const int nbx = ok ? p.B.cx : 0, nby = ok ? p.B.cy : 0, nbz = ok ? p.B.cz : 0;
+                const int nblocks = nbx * nby * nbz;
+                if (ok && collide && nblocks <= HYDRO_MAX_BLOCKS) {
+                    const int sgs = p.B.subgrid_size;  // 8
+                    rounds = (nblocks + 63) >> 6;
+                    for (int r = 0; r < rounds; ++r) {  // block b = (bz * nby + by) * nbx + bx
+                        const int b = r * 64 + lane;
+                        bool sv = false;
+                        if (b < nblocks) {
+                            const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
+                            sv = hydro_node_survives(p, bx * sgs, by * sgs, bz * sgs, sgs);
                         }
-                        off += __popcll(m);
+                        const unsigned long long m = __ballot(sv);
+                        if (lane == 0) w.mask[s][r] = m;
+                        total += __popcll(m);
                     }
                 }
             }
-            HY_WAVE_SYNC();
+            if (lane == 0) { w.pair[s] = pair_idx; w.total[s] = total; w.rounds[s] = rounds; }
+            sum += total;
+            active += total > 0 ? 1 : 0;
         }
+        HY_WAVE_SYNC();
+        int qb = 0, ab = 0;
         if (lane == 0) {
-            a.stage_pair[2 * (size_t)pair_idx] = q0;
-            a.stage_pair[2 * (size_t)pair_idx + 1] = total;
-            if (total > 0) {  // the reduce stage only visits pairs that queued blocks
-                a.stage_active[atomicAdd(a.stage_count + 4, 1)] = pair_idx;
-            } else {
-                a.out_blk[2 * (size_t)pair_idx] = 0;
-                a.out_blk[2 * (size_t)pair_idx + 1] = 0;
-            }
+            if (sum > 0) qb = atomicAdd(a.stage_count, sum);
+            if (active > 0) ab = atomicAdd(a.stage_count + 4, active);
         }
+        qb = hy_uniform(__shfl(qb, 0));
+        ab = hy_uniform(__shfl(ab, 0));
+        for (int s = 0; s < HY_BATCH; ++s) {  // ---- the pairs' items: contiguous runs in block order
+            const int pair_idx = w.pair[s];
+            if (pair_idx < 0) continue;  // (uniform)
+            int total = w.total[s];
+            const int q0 = qb;
+            qb += total;
+            if (total > 0 && q0 + total > a.stage_queue_capacity) {  // does not fit the queue: the pair contributes nothing, reported
+                if (lane == 0) atomicAdd(a.stage_count + 2, 1);
+                if (lane == 0) a.stage_active[ab] = pair_idx;  // (keeps the active list dense; the pair has no items)
+                ab += 1;
+                total = 0;
+                if (lane == 0) { a.stage_pair[2 * (size_t)pair_idx] = 0; a.stage_pair[2 * (size_t)pair_idx + 1] = 0; }
+                continue;
+            }
+            int off = 0;
+            for (int r = 0; r < w.rounds[s] && total > 0; ++r) {
+                const unsigned long long m = w.mask[s][r];
+                if ((m >> lane) & 1ull) {
+                    const int q = q0 + off + __popcll(m & ((1ull << lane) - 1ull));
+                    a.stage_queue[2 * (size_t)q] = pair_idx;
+                    a.stage_queue[2 * (size_t)q + 1] = r * 64 + lane;
+                }
+                off += __popcll(m);
+            }
+            if (lane == 0) {
+                a.stage_pair[2 * (size_t)pair_idx] = q0;
+                a.stage_pair[2 * (size_t)pair_idx + 1] = total;
+                if (total > 0) {  // the reduce stage only visits pairs that queued blocks
+                    a.stage_active[ab] = pair_idx;
+                } else {
+                    a.out_blk[2 * (size_t)pair_idx] = 0;
+                    a.out_blk[2 * (size_t)pair_idx + 1] = 0;
+                }
+            }
+            ab += total > 0 ? 1 : 0;
+        }
+        HY_WAVE_SYNC();  // the next batch reuses the wave's LDS
     }
 }
 
@@ -2732,6 +2762,9 @@ __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a
 #endif
         // ---- the pair's chunk records, (block, round) order: items and records are fetched by all lanes (they sit wherever the
         // face stage's atomics put them), then lane 0 folds them into the chunk list on LDS copies
+#ifdef NT_HYDRO_TIMING
+        unsigned long long hk = clock64();
+#endif
         if (t == 0) { R.n_chunk = 0; R.n_faces = 0; R.pair_kept = 0; R.overflow = 0; R.rows = 0; n_raw = 0; }
         __syncthreads();
         for (int q_tile = 0; q_tile < nq; q_tile += HY_ITEM_TILE) {
@@ -2784,6 +2817,7 @@ __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a
             R.n_chunk = n;
         }
         __syncthreads();
+        NT_HT(6, hk);
         if (R.n_faces > 0) {  // (uniform)
             // rebase the chunk-relative voxel ranks and contact ids: (pair_vox + i) * 5 + face, pair_kept / pair_face + ... + 1
             for (int c = 0; c < R.n_chunk; ++c) {
@@ -2799,6 +2833,10 @@ __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a
             HydroPair p;
             bool collide;
             hydro_pair_load(a, pair_idx, p, false, collide);
+            NT_HT(7, hk);
+#ifdef NT_HYDRO_TIMING
+            if (t == 0) { atomicAdd(&nt_hydro_timing[9], 1ull); atomicAdd(&nt_hydro_timing[10], (unsigned long long)R.n_chunk); }
+#endif
             if constexpr (EXTRAS) hydro_reduce_pair_extras(a, p, pair_idx, R);
             else hydro_reduce_pair(a, p, pair_idx, R);
         }
@@ -2857,7 +2895,7 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
 #ifdef NT_EMULATED_GRID
             const int wgrid = NT_EMULATED_GRID, igrid = NT_EMULATED_GRID;
 #else
-            const long long wb = (cap + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
+            const long long wb = (cap + HY_STAGE_WAVES * HY_BATCH - 1) / (HY_STAGE_WAVES * HY_BATCH);
             const int wgrid = (int)(wb < 16384 ? wb : 16384);
             const long long ib = ((long long)a->stage_queue_capacity + HY_STAGE_WAVES - 1) / HY_STAGE_WAVES;
             const int igrid = (int)(ib < 8192 ? ib : 8192);  // grid-stride over the items the first stage queued (count on the device)

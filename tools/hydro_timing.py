@@ -21,7 +21,7 @@ def main():
     faces_only = len(sys.argv) > 1 and sys.argv[1] == "faces"
     pipe = nt.CollisionPipeline(model, broad_phase="sap",
                                 sdf_hydroelastic_config=nt.geometry.HydroelasticSDF.Config(reduce_contacts=not faces_only),
-                                sdf_contacts_per_shape=400, sdf_hydro_faces_per_shape=600)
+                                sdf_contacts_per_shape=400, sdf_hydro_faces_per_shape=1000)
     contacts = pipe.contacts()
     solver = nt.solvers.SolverXPBD(model, iterations=2)
     s0, s1, ctrl = model.state(), model.state(), model.control()
@@ -52,10 +52,11 @@ def main():
     b = read()
     d = [y - x for x, y in zip(a, b)]
     n = frames * bench.SUBSTEPS
-    names = ["face pass (SAT, octree, marching cubes, records)", "reduce: aggregates", "reduce: table passes", "reduce: winners",
-             "reduce: order + depth sums", "reduce: export"]
+    names = ["face pass (single kernel only: SAT, octree, marching cubes, records)", "reduce: aggregates", "reduce: table passes",
+             "reduce: winners", "reduce: order + depth sums", "reduce: export", "staged reduce: chunk records of the pair",
+             "staged reduce: rebase + fence + pair descriptors"]
     out = {"collides": n, "pairs_per_collide": d[8] / n, "active_pairs_per_collide": d[9] / n, "face_blocks_per_collide": d[10] / n,
-           "cycles_per_collide": {names[i]: d[i] / n for i in range(6)}, "info": pipe._sdf_leg.overflow(contacts._flat)}
+           "cycles_per_collide": {names[i]: d[i] / n for i in range(8)}, "info": pipe._sdf_leg.overflow(contacts._flat)}
     print(json.dumps(out))
 
 
