@@ -1,7 +1,10 @@
 // SolverFeatherstone for gfx950: one workgroup owns EPB environments; generalized state, motion subspaces, spatial
 // inertias, the articulation's joint-space inertia H and its Cholesky factor all live in LDS (the reference streams
 // J, M, P = M J, H and L through HBM: solver_featherstone.py:771-934).
-// Included inside nt_kernels.hip's anonymous namespace (uses Ctx / KArgs / LdsLayout / si_contact_item / si_dof_force).
+// The phases (this file) are included by nt_kernels.hip once per arithmetic namespace after nt_ctx.hpp / nt_xpbd.hpp /
+// nt_semi_implicit.hpp (they use Ctx / KArgs / si_contact_item / si_dof_force): `fused` is what the step / rollout kernels run
+// (a * b + c contracts: the dense H = S^T P products, the Cholesky and the substitutions are chains of multiply-adds), `ieee` serves
+// eval_fk.  FsLayout lives in nt_layout.hpp, the kernels in nt_featherstone_kernels.hpp.
 //
 // Reference (restated):
 //   jcalc_transform / jcalc_motion / jcalc_tau / jcalc_integrate   newton/_src/solvers/featherstone/kernels.py:142-630
@@ -15,56 +18,6 @@
 // J[b,r,i] * (I_b S_j)[r] -- the zero entries of the dense J / M the reference multiplies through add exact zeros.
 // Scope: PRISMATIC, REVOLUTE, BALL, FIXED, FREE / DISTANCE (root and descendant), D6; body l of an articulation is the child
 // of its joint l (the reference's eval_rigid_mass indexes body_I_s by joint index, kernels.py:1466-1480).
-
-struct FsLayout {
-    int jq, qdi, qdo, jfi, tau, qdd;  // joint_q [nc], internal qd in / out [nd], joint_f internal, tau, qdd [nd]
-    int qdp;                          // public joint_qd [nd] (stays in LDS across the substeps of a rollout)
-    int qcom, org;                    // body COM world position [3][nb], solve origin [3][nb]
-    int S;                            // motion subspace columns [6][nd]
-    int Is;                           // spatial inertia in the solve frame [36][nb]
-    int vs, as, fs, ft;               // v_s, a_s, (f_b - f_g), total subtree wrench per joint [6][nb] each
-    int bfx;                          // external wrench buffer body_f_ext [6][nb]
-    int cw;                           // contact wrenches [CW_FLOATS][np*cpp]        (union with P/H)
-    int P, H;                         // P[b][jl] = I_b S_j [6][nb][W];  H / L [nd][W]
-    int rows;
-};
-__host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsLayout& L) {
-    FsLayout F;
-    int o = L.u;
-    F.jq = o; o += m.nc;
-    F.qdi = o; o += m.nd;
-    F.qdo = o; o += m.nd;
-    F.jfi = o; o += m.nd;
-    F.tau = o; o += m.nd;
-    F.qdd = o; o += m.nd;
-    F.qdp = o; o += m.nd;
-    F.qcom = o; o += 3 * m.nb;
-    F.org = o; o += 3 * m.nb;
-    F.S = o; o += 6 * m.nd;
-    F.Is = o; o += 36 * m.nb;
-    F.vs = o; o += 6 * m.nb;
-    F.as = o; o += 6 * m.nb;
-    F.fs = o; o += 6 * m.nb;
-    F.ft = o; o += 6 * m.nb;
-    F.bfx = o; o += 6 * m.nb;
-    F.cw = o;
-    F.P = o;
-    F.H = F.P + 6 * m.nb * m.max_art_dofs;
-    int solve = 6 * m.nb * m.max_art_dofs + m.nd * m.max_art_dofs;
-    int contacts = NC_CW * m.np * m.cpp;
-    // the fused rollout runs the collide phases on this union too (shape transforms / AABBs, pair counts, manifold polygon
-    // scratch, staged candidates)
-    LdsLayout tmp = L;
-    int coll = place_collide_scratch(tmp, m, F.cw, false);
-    o += imax(imax(solve, contacts), coll);
-    F.rows = o;
-    return F;
-}
-// block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint (3 * nj), joint of
-// each dof (nd), and per joint a bit mask of the joints on its root path, itself included (nj * ceil(nj / 32))
-__host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }
-// then per joint whether the end-of-step refresh of descendant FREE / DISTANCE joints reaches it (nj) and whether any does (1)
-__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m) + m.nj + 1; }
 
 template <int EPB>
 struct FsCtx {
@@ -609,11 +562,14 @@ NT_DI void fs_H_item(const FsCtx<EPB>& f, int item) {
 // others at the next instruction without a workgroup barrier.  Row i belongs to lane i % G.  Every sum runs in the
 // reference's order (k ascending), so the factor and the solution are bit-identical to the serial algorithm.
 // compiler-level ordering of LDS traffic between lanes of one wave (no hardware barrier is needed: see below)
+#ifndef FS_WAVE_SYNC_DEFINED
+#define FS_WAVE_SYNC_DEFINED
 #define FS_WAVE_SYNC()                                        \
     do {                                                      \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
         __builtin_amdgcn_wave_barrier();                      \
     } while (0)
+#endif
 
 // factor = false: H holds the factor of an earlier step (update_mass_matrix_interval > 1), only the substitutions run
 template <int EPB>
@@ -1112,115 +1068,3 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     NT_TICK(21);
 }
 
-template <int EPB>
-__global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    const nt_model& m = a.m;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false));
-    Ctx<EPB> c(a, lds, F.rows);  // topology ints are staged behind the Featherstone rows
-    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
-    __syncthreads();
-    fs_build_tables(c, extra);
-    FsCtx<EPB> f(c, extra);
-    int max_depth = 0;
-    for (int j = 0; j < m.nj; ++j) max_depth = imax(max_depth, f.depth[j]);
-    load_params(c, true);
-    if (c.valid) {
-        stage_rows(c, F.jq, a.s_in.joint_q, m.nc);
-        stage_rows(c, F.qdp, a.s_in.joint_qd, m.nd);
-    }
-    __syncthreads();
-    fs_substep(c, f, F, max_depth, false, true, a.s_out.body_parent_f);
-    if (c.valid) {
-        unstage_rows(c, F.jq, a.s_out.joint_q, m.nc);
-        unstage_rows(c, F.qdp, a.s_out.joint_qd, m.nd);
-    }
-    store_state(c, a.s_out);
-}
-
-// substeps x { clear_forces; CollisionPipeline.collide; SolverFeatherstone.step; swap } in one launch: generalized and
-// maximal state, parameters and all Featherstone intermediates stay in LDS; only the contacts touch HBM per substep.
-// The result lands in s_in (= s0) for an even number of substeps and in s_out (= s1) for an odd one.
-template <int EPB, bool CVX>
-__global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    const nt_model& m = a.m;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false));
-    Ctx<EPB> c(a, lds, F.rows);
-    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
-    __syncthreads();
-    fs_build_tables(c, extra);
-    FsCtx<EPB> f(c, extra);
-    int max_depth = 0;
-    for (int j = 0; j < m.nj; ++j) max_depth = imax(max_depth, f.depth[j]);
-    load_state(c, a.s_in);
-    load_params(c, true);
-    if (c.valid) {
-        stage_rows(c, F.jq, a.s_in.joint_q, m.nc);
-        stage_rows(c, F.qdp, a.s_in.joint_qd, m.nd);
-        for (int r = c.slot; r < 6 * m.nb; r += c.nslot) {
-            a.s_in.body_f[(size_t)r * c.ES + c.env] = 0.0f;
-            a.s_out.body_f[(size_t)r * c.ES + c.env] = 0.0f;
-        }
-    }
-    __syncthreads();
-    // the collide phases use the (dead at that point) P / H / contact-wrench union as their scratch
-    Ctx<EPB> cc = c;
-    place_collide_scratch(cc.L, m, F.cw, false);
-    const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
-    for (int s = 0; s < a.substeps; ++s) {
-        do_collide<EPB, CVX>(cc, s == a.substeps - 1);
-        fs_substep(c, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr, s);
-    }
-    if (c.valid) {
-        unstage_rows(c, F.jq, res.joint_q, m.nc);
-        unstage_rows(c, F.qdp, res.joint_qd, m.nd);
-    }
-    store_state(c, res);
-}
-
-// newton.eval_fk(model, joint_q, joint_qd, state) (newton/_src/sim/articulation.py:423-573): body_q / body_qd from
-// generalized coordinates, all articulations, level by level.
-template <int EPB>
-__global__ void __launch_bounds__(256) eval_fk_kernel(KArgs a, const float* joint_q, const float* joint_qd) {
-    extern __shared__ __align__(16) float lds[];
-    const nt_model& m = a.m;
-    const int nj = m.nj;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false));
-    Ctx<EPB> c(a, lds, F.rows);
-    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
-    __syncthreads();
-    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
-        int p = c.T.joint_parent[j], anc = -1;
-        if (p >= 0)
-            for (int k = 0; k < nj; ++k)
-                if (c.T.joint_child[k] == p) anc = k;
-        extra[j] = anc;
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
-        int d = 0, k = extra[j];
-        while (k >= 0) { d += 1; k = extra[k]; }
-        extra[nj + j] = d;
-    }
-    __syncthreads();
-    FsCtx<EPB> f(c, extra);
-    int max_depth = 0;
-    for (int j = 0; j < nj; ++j) max_depth = imax(max_depth, f.depth[j]);
-    load_params(c, false);
-    if (c.valid) {
-        stage_rows(c, F.jq, joint_q, m.nc);
-        stage_rows(c, F.qdo, joint_qd, m.nd);
-    }
-    __syncthreads();
-    if (c.valid)
-        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
-    __syncthreads();
-    for (int lvl = 0; lvl <= max_depth; ++lvl) {
-        if (c.valid)
-            for (int j = c.slot; j < nj; j += c.nslot)
-                if (f.depth[j] == lvl) fs_fk_vel_item<EPB, true>(f, j);
-        __syncthreads();
-    }
-    store_state(c, a.s_out);
-}

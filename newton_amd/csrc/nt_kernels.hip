@@ -31,9 +31,9 @@
 // Two arithmetic namespaces in one translation unit (the fused kernels run both on the same LDS tile):
 //  * ieee  -- nt:: helpers, -ffp-contract=off, correctly rounded division / sqrt: everything that decides pair sets, contact
 //             counts and contact geometry (shape transforms, AABBs, broad phase, primitive / MPR-GJK narrow phase, the contact
-//             writer), SolverSemiImplicit and SolverFeatherstone.  CollisionPipeline.collide stays bit-identical to the contact
-//             arrays the reference's own kernels produce (tests/golden/collide_reference_vectors.npz).
-//  * fused -- ntf:: helpers (a second copy of nt_math.hpp) + the XPBD phases of nt_xpbd.hpp under `#pragma clang fp
+//             writer), SolverSemiImplicit and eval_fk.  CollisionPipeline.collide stays bit-identical to the contact arrays the
+//             reference's own kernels produce (tests/golden/collide_reference_vectors.npz).
+//  * fused -- ntf:: helpers (a second copy of nt_math.hpp) + the XPBD phases of nt_xpbd.hpp and SolverFeatherstone's phases under `#pragma clang fp
 //             contract(fast)` and -DNT_XPBD_FAST_MATH: a * b + c contracts to v_fma_f32, the divisions / square roots of the
 //             projection phases are v_rcp_f32 / v_sqrt_f32 (1 ulp).  Within SURVEY.md 8(c)'s contract (1e-5 single step, 1e-4
 //             rollout against the reference); measured on the MI355X headline: 0.363 -> 0.308 ms per 10-substep launch for the whole
@@ -55,6 +55,10 @@ using namespace nt;
 #include "nt_ctx.hpp"
 #include "nt_collide.hpp"
 #include "nt_xpbd.hpp"
+#define NT_SI_PHASES_ONLY  // (the SolverSemiImplicit kernel itself follows below, once)
+#include "nt_semi_implicit.hpp"
+#undef NT_SI_PHASES_ONLY
+#include "nt_featherstone.hpp"
 }  // namespace ieee
 
 #pragma clang fp contract(fast)
@@ -64,13 +68,19 @@ using namespace ntf;
 #include "nt_ctx.hpp"
 #include "nt_xpbd.hpp"
 #undef NT_XPBD_FAST_MATH
+#define NT_SI_PHASES_ONLY
+#include "nt_semi_implicit.hpp"  // si_contact_item / si_dof_force as SolverFeatherstone's phases use them
+#undef NT_SI_PHASES_ONLY
+#include "nt_featherstone.hpp"
 }  // namespace fused
 #pragma clang fp contract(off)
 
 namespace ieee {
 #include "nt_xpbd_kernels.hpp"
+#define NT_SI_KERNEL_ONLY
 #include "nt_semi_implicit.hpp"
-#include "nt_featherstone.hpp"
+#undef NT_SI_KERNEL_ONLY
+#include "nt_featherstone_kernels.hpp"
 }  // namespace ieee
 using namespace ieee;
 

@@ -208,3 +208,58 @@ __device__ unsigned long long nt_phase_clock[32];
 #else
 #define NT_TICK(slot) do { } while (0)
 #endif
+
+// ------------------------------------------------------------------------------------------------
+// SolverFeatherstone's LDS layout (rows behind the persistent block of the XPBD layout) and the sizes of its block-shared tables;
+// no vector-math type, shared by both arithmetic namespaces and the host launch code (the phases are nt_featherstone.hpp)
+// ------------------------------------------------------------------------------------------------
+struct FsLayout {
+    int jq, qdi, qdo, jfi, tau, qdd;  // joint_q [nc], internal qd in / out [nd], joint_f internal, tau, qdd [nd]
+    int qdp;                          // public joint_qd [nd] (stays in LDS across the substeps of a rollout)
+    int qcom, org;                    // body COM world position [3][nb], solve origin [3][nb]
+    int S;                            // motion subspace columns [6][nd]
+    int Is;                           // spatial inertia in the solve frame [36][nb]
+    int vs, as, fs, ft;               // v_s, a_s, (f_b - f_g), total subtree wrench per joint [6][nb] each
+    int bfx;                          // external wrench buffer body_f_ext [6][nb]
+    int cw;                           // contact wrenches [CW_FLOATS][np*cpp]        (union with P/H)
+    int P, H;                         // P[b][jl] = I_b S_j [6][nb][W];  H / L [nd][W]
+    int rows;
+};
+__host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsLayout& L) {
+    FsLayout F;
+    int o = L.u;
+    F.jq = o; o += m.nc;
+    F.qdi = o; o += m.nd;
+    F.qdo = o; o += m.nd;
+    F.jfi = o; o += m.nd;
+    F.tau = o; o += m.nd;
+    F.qdd = o; o += m.nd;
+    F.qdp = o; o += m.nd;
+    F.qcom = o; o += 3 * m.nb;
+    F.org = o; o += 3 * m.nb;
+    F.S = o; o += 6 * m.nd;
+    F.Is = o; o += 36 * m.nb;
+    F.vs = o; o += 6 * m.nb;
+    F.as = o; o += 6 * m.nb;
+    F.fs = o; o += 6 * m.nb;
+    F.ft = o; o += 6 * m.nb;
+    F.bfx = o; o += 6 * m.nb;
+    F.cw = o;
+    F.P = o;
+    F.H = F.P + 6 * m.nb * m.max_art_dofs;
+    int solve = 6 * m.nb * m.max_art_dofs + m.nd * m.max_art_dofs;
+    int contacts = NC_CW * m.np * m.cpp;
+    // the fused rollout runs the collide phases on this union too (shape transforms / AABBs, pair counts, manifold polygon
+    // scratch, staged candidates)
+    LdsLayout tmp = L;
+    int coll = place_collide_scratch(tmp, m, F.cw, false);
+    o += imax(imax(solve, contacts), coll);
+    F.rows = o;
+    return F;
+}
+// block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint (3 * nj), joint of
+// each dof (nd), and per joint a bit mask of the joints on its root path, itself included (nj * ceil(nj / 32))
+__host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }
+// then per joint whether the end-of-step refresh of descendant FREE / DISTANCE joints reaches it (nj) and whether any does (1)
+__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m) + m.nj + 1; }
+

@@ -1631,6 +1631,9 @@ struct HydroRedLds {
     int chunk[HYDRO_CHUNK_CAP][2];
     int cstart[HYDRO_CHUNK_CAP];                  // rank of the block's first face inside the pair (blocks are small and scattered:
                                                   // the passes below walk the pair's faces by RANK, all lanes busy, not block by block)
+    int idbase[HYDRO_CHUNK_CAP], voxbase[HYDRO_CHUNK_CAP];  // what to add to the contact ids / voxel ranks stored in a block's records
+                                                  // (staged face pass: they are relative to the block; single kernel: zero)
+    int tkey[HYDRO_ENTRIES][RED_VALUES];          // the winner's key (voxel rank * 5 + face)
     float agg[RED_BINS][10];                      // agg_force[3] weighted_pos_sum[3] weight_sum agg_depth_volume[3]
     float tdepth[RED_BINS], tnormal[RED_BINS][3]; // total_depth_reduced / total_normal_reduced
     unsigned long long tbl[HYDRO_ENTRIES][RED_VALUES];
@@ -1696,14 +1699,23 @@ NT_DI void hydro_reduce_pair_impl(const nt_hydro_args& a, const HydroPair& p, in
 #ifdef NT_HYDRO_TIMING
     unsigned long long ht = clock64();
 #endif
-    auto face_slot = [&](int rank) {  // rank of a face inside the pair -> its record (the last block that starts at or before it)
+    auto face_block = [&](int rank) {  // rank of a face inside the pair -> the last block that starts at or before it
         int lo = 0, hi = R.n_chunk;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (R.cstart[mid] <= rank) lo = mid;
             else hi = mid;
         }
+        return lo;
+    };
+    auto face_slot = [&](int rank) {  // ... -> its record
+        const int lo = face_block(rank);
         return R.chunk[lo][0] + (rank - R.cstart[lo]);
+    };
+    auto face_cid = [&](int rank) {  // ... -> its contact id inside the pair (0: not buffered)
+        const int lo = face_block(rank);
+        const int cid = reinterpret_cast<const int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)(R.chunk[lo][0] + (rank - R.cstart[lo])))[10] >> 5;
+        return cid > 0 ? cid + R.idbase[lo] : 0;
     };
     for (int k = t; k < HYDRO_ENTRIES * RED_VALUES; k += nt_) {
         R.tbl[k / RED_VALUES][k % RED_VALUES] = 0ull;
@@ -1758,7 +1770,7 @@ NT_DI void hydro_reduce_pair_impl(const nt_hydro_args& a, const HydroPair& p, in
         // bin in CONTACT order.  Contact ids follow the voxels but, inside a pruned voxel, not the faces: word 11 of the record at
         // rank (cid - 1) receives the rank of contact cid, then the contacts pass through LDS in tiles like the faces above.
         for (int j = t; j < R.n_faces; j += nt_) {
-            const int cid = reinterpret_cast<const int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(j))[10] >> 5;
+            const int cid = face_cid(j);
             if (cid > 0) reinterpret_cast<int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(cid - 1))[11] = j;
         }
         __threadfence();
@@ -1795,17 +1807,21 @@ NT_DI void hydro_reduce_pair_impl(const nt_hydro_args& a, const HydroPair& p, in
     for (int pass = 0; pass < 2; ++pass) {
         {
             for (int j = t; j < R.n_faces; j += nt_) {
-                const int fslot = face_slot(j);
+                const int blk = face_block(j);
+                const int fslot = R.chunk[blk][0] + (j - R.cstart[blk]);
                 const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)fslot;
-                const int cid = reinterpret_cast<const int*>(rec)[10] >> 5;
+                int cid = reinterpret_cast<const int*>(rec)[10] >> 5;
                 if (cid <= 0) continue;
+                cid += R.idbase[blk];
                 const unsigned int ucid = (unsigned int)cid;
+                const int face_key = reinterpret_cast<const int*>(rec)[9] + 5 * R.voxbase[blk];
                 auto offer = [&](int e, int s, float score, unsigned int key) {
                     if (pass == 0) {
                         atomicMax(&R.tbl[e][s], hydro_value(score, cid));
                         atomicMin(&R.ekey[e], key);
                     } else if ((unsigned int)(R.tbl[e][s] & 0xFFFFFFFFull) == ucid) {
                         R.tslot[e][s] = fslot;
+                        R.tkey[e][s] = face_key;
                     }
                 };
                 const vec3 ctr(rec[0], rec[1], rec[2]);
@@ -2063,7 +2079,7 @@ NT_DI void hydro_reduce_pair_impl(const nt_hydro_args& a, const HydroPair& p, in
         if (!(depth < 0.0f)) { stiff = mca_k; fscale = 1.0f; }
         const vec3 pw = xform_point(p.X_b, vec3(rec[0], rec[1], rec[2])), nw = xform_vector(p.X_b, final_n);
         a.out_pair[slot] = pair_idx;
-        a.out_key[slot] = reinterpret_cast<const int*>(rec)[9];
+        a.out_key[slot] = R.tkey[e][sl];
         a.out_rank[slot] = rank;
         float* o = a.out_data + 9 * (size_t)slot;
         o[0] = pw.x; o[1] = pw.y; o[2] = pw.z; o[3] = nw.x; o[4] = nw.y; o[5] = nw.z;
@@ -2280,6 +2296,8 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
                                     R.chunk[R.n_chunk][0] = L.base;
                                     R.chunk[R.n_chunk][1] = total;
                                     R.cstart[R.n_chunk] = R.n_faces;
+                                    R.idbase[R.n_chunk] = 0;  // (this kernel writes pair-absolute ids and voxel ranks)
+                                    R.voxbase[R.n_chunk] = 0;
                                     R.n_faces += total;
                                     R.n_chunk += 1;
                                 } else {
@@ -2387,7 +2405,7 @@ __global__ void __launch_bounds__(256) hydro_pairs_kernel(nt_hydro_args a) {
 //                               faces, buffered contacts, voxels); ids inside a record are relative to the chunk.  No workgroup
 //                               barrier anywhere; the pair's descriptors are wave-uniform (scalar registers).
 //   hydro_stage_reduce_kernel   workgroup per pair with items: lists the pair's chunks in (block, round) order -- the traversal order
-//                               of the single kernel --, rebases the records' voxel ranks and contact ids by the running totals, and
+//                               of the single kernel -- with the running totals that turn a record's block-relative voxel rank and contact id into the pair's, and
 //                               runs the same hydro_reduce_pair on them.
 // Faces, ids, order and rows are those of hydro_pairs_kernel<true>: the voxel order inside a block, the block order inside a pair
 // and every arithmetic operation are unchanged; only who computes what moved.
@@ -2746,7 +2764,8 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
 template <bool EXTRAS>
 __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a) {
     __shared__ HydroRedLds R;
-    __shared__ int idbase[HYDRO_CHUNK_CAP], voxbase[HYDRO_CHUNK_CAP];  // contact ids / voxels of the pair in front of each listed chunk
+    int* const idbase = R.idbase;    // contact ids / voxels of the pair in front of each listed chunk
+    int* const voxbase = R.voxbase;
     constexpr int HY_ITEM_TILE = 128;
     __shared__ int item_c0[HY_ITEM_TILE], item_nc[HY_ITEM_TILE + 1], n_raw;
     const int t = threadIdx.x;
@@ -2819,17 +2838,8 @@ __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a
         __syncthreads();
         NT_HT(6, hk);
         if (R.n_faces > 0) {  // (uniform)
-            // rebase the chunk-relative voxel ranks and contact ids: (pair_vox + i) * 5 + face, pair_kept / pair_face + ... + 1
-            for (int c = 0; c < R.n_chunk; ++c) {
-                const int add_key = 5 * voxbase[c], add_cid = idbase[c] << 5;
-                for (int k = t; k < R.chunk[c][1]; k += blockDim.x) {
-                    int* oi = reinterpret_cast<int*>(a.face_rec + HYDRO_FACE_WORDS * (size_t)(R.chunk[c][0] + k));
-                    oi[9] += add_key;
-                    if (oi[10] >> 5) oi[10] += add_cid;
-                }
-            }
-            __threadfence();  // the records, written by all lanes, are read back by other lanes below
-            __syncthreads();
+            // (the records keep their block-relative voxel ranks and contact ids: hydro_reduce_pair adds R.voxbase / R.idbase where it
+            // reads them -- a rewrite of the records plus the device-scope fence it needs was 29 % of this stage's cycles)
             HydroPair p;
             bool collide;
             hydro_pair_load(a, pair_idx, p, false, collide);

@@ -1,7 +1,9 @@
 // nt_semi_implicit.hpp -- SolverSemiImplicit phases (penalty joints, penalty contacts) and its step kernel.
 // Included by nt_kernels.hip inside its anonymous namespace, in this order: nt_layout.hpp, nt_collide.hpp, nt_xpbd.hpp,
 // nt_semi_implicit.hpp, nt_featherstone.hpp (one translation unit; the split is for reading, not for separate compilation).
-#pragma once
+// No include guard: nt_kernels.hip includes the PHASES (NT_SI_PHASES_ONLY) once per arithmetic namespace -- SolverFeatherstone shares
+// si_contact_item / si_dof_force -- and the kernel (NT_SI_KERNEL_ONLY) once, in namespace ieee.
+#ifndef NT_SI_KERNEL_ONLY
 
 // ------------------------------------------------------------------------------------------------
 // SolverSemiImplicit (solver_semi_implicit.py:123-217): penalty joints + penalty contacts -> integrate_bodies
@@ -252,7 +254,8 @@ NT_DI void si_contact_item(const Ctx<EPB>& c, const int slot) {
     c.l(c.L.si_cw, 13, ncs, slot) = has_b;
     c.l(c.L.si_cw, 14, ncs, slot) = a_is_pair_a;
 }
-
+#endif  // !NT_SI_KERNEL_ONLY
+#ifndef NT_SI_PHASES_ONLY
 template <int EPB>
 __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
@@ -281,3 +284,4 @@ __global__ void __launch_bounds__(EPB <= 8 ? 256 : 512) semi_implicit_step_kerne
     __syncthreads();
     store_state(c, a.s_out);
 }
+#endif
