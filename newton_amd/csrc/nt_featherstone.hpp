@@ -1,10 +1,8 @@
 // SolverFeatherstone for gfx950: one workgroup owns EPB environments; generalized state, motion subspaces, spatial
 // inertias, the articulation's joint-space inertia H and its Cholesky factor all live in LDS (the reference streams
 // J, M, P = M J, H and L through HBM: solver_featherstone.py:771-934).
-// The phases (this file) are included by nt_kernels.hip once per arithmetic namespace after nt_ctx.hpp / nt_xpbd.hpp /
-// nt_semi_implicit.hpp (they use Ctx / KArgs / si_contact_item / si_dof_force): `fused` is what the step / rollout kernels run
-// (a * b + c contracts: the dense H = S^T P products, the Cholesky and the substitutions are chains of multiply-adds), `ieee` serves
-// eval_fk.  FsLayout lives in nt_layout.hpp, the kernels in nt_featherstone_kernels.hpp.
+// The phases (this file) are included by nt_kernels.hip in namespace ieee after nt_ctx.hpp / nt_xpbd.hpp / nt_semi_implicit.hpp (they
+// use Ctx / KArgs / si_contact_item / si_dof_force).  FsLayout lives in nt_layout.hpp, the kernels in nt_featherstone_kernels.hpp.
 //
 // Reference (restated):
 //   jcalc_transform / jcalc_motion / jcalc_tau / jcalc_integrate   newton/_src/solvers/featherstone/kernels.py:142-630

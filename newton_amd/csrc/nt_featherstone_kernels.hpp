@@ -1,5 +1,7 @@
-// nt_featherstone_kernels.hpp -- SolverFeatherstone's step / rollout kernels and eval_fk (namespace ieee): staging and the collide
-// phases here, the solver phases of nt_featherstone.hpp in namespace fused (eval_fk: ieee).
+// nt_featherstone_kernels.hpp -- SolverFeatherstone's step / rollout kernels and eval_fk, namespace ieee like the phases of
+// nt_featherstone.hpp they run.  (Measured, profiles/r04h_*: the phases compiled in namespace fused -- contraction + fast division --
+// pass the whole GPU suite but C3 does not move, 25.6 vs 26.7 M env-steps/s: the solver waits on LDS round trips of H / L and on the
+// level-synchronous barriers, not on arithmetic.  The literal operation order stays.)
 #pragma once
 
 template <int EPB>
@@ -11,8 +13,7 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
     __syncthreads();
     fs_build_tables(c, extra);
-    const fused::Ctx<EPB> cf(c, 0);
-    fused::FsCtx<EPB> f(cf, extra);
+    FsCtx<EPB> f(c, extra);
     int max_depth = 0;
     for (int j = 0; j < m.nj; ++j) max_depth = imax(max_depth, f.depth[j]);
     load_params(c, true);
@@ -21,7 +22,7 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
         stage_rows(c, F.qdp, a.s_in.joint_qd, m.nd);
     }
     __syncthreads();
-    fused::fs_substep(cf, f, F, max_depth, false, true, a.s_out.body_parent_f);
+    fs_substep(c, f, F, max_depth, false, true, a.s_out.body_parent_f);
     if (c.valid) {
         unstage_rows(c, F.jq, a.s_out.joint_q, m.nc);
         unstage_rows(c, F.qdp, a.s_out.joint_qd, m.nd);
@@ -41,8 +42,7 @@ __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
     __syncthreads();
     fs_build_tables(c, extra);
-    const fused::Ctx<EPB> cf(c, 0);
-    fused::FsCtx<EPB> f(cf, extra);
+    FsCtx<EPB> f(c, extra);
     int max_depth = 0;
     for (int j = 0; j < m.nj; ++j) max_depth = imax(max_depth, f.depth[j]);
     load_state(c, a.s_in);
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(cc, s == a.substeps - 1);
-        fused::fs_substep(cf, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr, s);
+        fs_substep(c, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr, s);
     }
     if (c.valid) {
         unstage_rows(c, F.jq, res.joint_q, m.nc);

@@ -31,9 +31,9 @@
 // Two arithmetic namespaces in one translation unit (the fused kernels run both on the same LDS tile):
 //  * ieee  -- nt:: helpers, -ffp-contract=off, correctly rounded division / sqrt: everything that decides pair sets, contact
 //             counts and contact geometry (shape transforms, AABBs, broad phase, primitive / MPR-GJK narrow phase, the contact
-//             writer), SolverSemiImplicit and eval_fk.  CollisionPipeline.collide stays bit-identical to the contact arrays the
-//             reference's own kernels produce (tests/golden/collide_reference_vectors.npz).
-//  * fused -- ntf:: helpers (a second copy of nt_math.hpp) + the XPBD phases of nt_xpbd.hpp and SolverFeatherstone's phases under `#pragma clang fp
+//             writer), SolverSemiImplicit and SolverFeatherstone.  CollisionPipeline.collide stays bit-identical to the contact
+//             arrays the reference's own kernels produce (tests/golden/collide_reference_vectors.npz).
+//  * fused -- ntf:: helpers (a second copy of nt_math.hpp) + the XPBD phases of nt_xpbd.hpp under `#pragma clang fp
 //             contract(fast)` and -DNT_XPBD_FAST_MATH: a * b + c contracts to v_fma_f32, the divisions / square roots of the
 //             projection phases are v_rcp_f32 / v_sqrt_f32 (1 ulp).  Within SURVEY.md 8(c)'s contract (1e-5 single step, 1e-4
 //             rollout against the reference); measured on the MI355X headline: 0.363 -> 0.308 ms per 10-substep launch for the whole
@@ -68,10 +68,6 @@ using namespace ntf;
 #include "nt_ctx.hpp"
 #include "nt_xpbd.hpp"
 #undef NT_XPBD_FAST_MATH
-#define NT_SI_PHASES_ONLY
-#include "nt_semi_implicit.hpp"  // si_contact_item / si_dof_force as SolverFeatherstone's phases use them
-#undef NT_SI_PHASES_ONLY
-#include "nt_featherstone.hpp"
 }  // namespace fused
 #pragma clang fp contract(off)
 
@@ -422,6 +418,10 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
     int epb = pick_epb(*m, p ? p->envs_per_block : 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
     if (m->np == 0) return NT_DISPATCH_EPB(shapes_export_kernel, a, epb, (hipStream_t)stream);  // every pair lives outside the tiles
+    // uniform-parameter tile: models whose environments share their parameters stage ONE copy per workgroup instead of 3.8 KB per
+    // environment per launch (the per-call API pays the parameter staging in every kernel; the fused rollout once per frame)
+    if (m->params_uniform && !m->contact_scratch_in_hbm && m->np_analytic == m->np && epb == 16 && epb_fits(*m, 16, false, true))
+        return launch(collide_kernel<16 + NT_UNI, false>, a, 16, (hipStream_t)stream, 0, false, true);
     if (m->contact_scratch_in_hbm)
         return m->np_analytic < m->np ? launch(collide_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(collide_kernel<1, false, true>, a, 1, (hipStream_t)stream);
@@ -450,6 +450,8 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
         if (a.has_contacts && m->np > 0 && !a.ct.cw) return NT_ERR_INVALID_ARG;
         return launch(xpbd_step_kernel<1, true>, a, 1, (hipStream_t)stream);
     }
+    if (m->params_uniform && !xpbd_keeps_prestep_state(*p) && epb == 16 && epb_fits(*m, 16, false, true))
+        return launch(xpbd_step_kernel<16 + NT_UNI>, a, 16, (hipStream_t)stream, 0, false, true);
     return NT_DISPATCH_EPB(xpbd_step_kernel, a, epb, (hipStream_t)stream);
 }
 
