@@ -146,8 +146,38 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
     __syncthreads();
     fused::phase_body_derived(cf);
     __syncthreads();
-    if constexpr (BIG) fused::do_xpbd_step<EPB, false, fused::CwHbm>(cf, false);
-    else fused::do_xpbd_step<EPB, false>(cf, false);
+    if constexpr (BIG) {
+        fused::do_xpbd_step<EPB, false, fused::CwHbm>(cf, false);
+    } else {
+        // Without reporting outputs and SDF rows the step runs the contact phases of the fused rollout: the live slots of every pair
+        // (a pair's contacts fill its slots from the front: collide.py's writer order) are counted from the Contacts buffers, turned
+        // into the live prefix + compacted list, and only live contacts are solved / summed -- instead of all np * cpp slots with
+        // their shape ids re-read from HBM in every iteration (the standing quadruped: 16 of 52).
+        const bool compact = a.has_contacts && !a.ct.flat.row_start && !a.rep.joint_impulse && !a.rep.contact_impulse && !a.s_out.body_parent_f;
+        if (compact) {
+            const int np = a.m.np, cpp = a.m.cpp;
+            if (c.valid)
+                for (int p = c.slot; p < np; p += c.nslot) {
+                    int n = 0;
+                    for (int k = 0; k < cpp; ++k) {
+                        const size_t gi = (size_t)(p * cpp + k) * c.ES + c.env;
+                        n += a.ct.shape0[gi] != a.ct.shape1[gi] ? 1 : 0;
+                    }
+                    c.l(c.L.pm, 0, np, p) = (float)n;
+                }
+            __syncthreads();
+            const bool one_level = np <= 64;
+            if (!one_level) {
+                phase_pair_prefix_partials(c, c.L.sx.off);
+                __syncthreads();
+            }
+            phase_pair_prefix_scan(c, c.L.sx.off, false, one_level);
+            __syncthreads();
+            fused::do_xpbd_step<EPB, true>(cf, false);
+        } else {
+            fused::do_xpbd_step<EPB, false>(cf, false);
+        }
+    }
     store_state(c, a.s_out);
 }
 
