@@ -482,7 +482,7 @@ NT_DI void prefix_lane(const Ctx<EPB>& c, int lane, int partial, bool store_env_
     for (int p = lane * chunk; p < np && p < (lane + 1) * chunk; ++p) {
         c.l(c.L.px, 0, 1, p) = (float)acc;
         const int live = (int)c.l(c.L.pm, 0, np, p);
-        if (!c.big)  // the compacted live-contact list of the fused contact phases (entry: pair << 4 | sub-contact)
+        if (c.L.has_lt)  // the compacted live-contact list of the fused contact phases (entry: pair << 4 | sub-contact)
             for (int k = 0; k < live; ++k) *reinterpret_cast<int*>(&c.l(c.L.lt, 0, 1, acc + k)) = (p << 4) | k;
         acc += live;
     }

@@ -23,7 +23,7 @@ struct Ctx {
 
     // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
     NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
-        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI);
+        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI, rows < 0);  // (rows >= 0: another solver's layout, no live list)
         if (rows < 0) rows = L.rows_per_env;
         e = threadIdx.x % N;
         slot = threadIdx.x / N;
@@ -35,39 +35,42 @@ struct Ctx {
         const nt_model& m = a.m;
         int* ti = reinterpret_cast<int*>(lds + (size_t)rows * N);
         int o = 0;
-        auto take = [&](const int*& dst, const int32_t* src, int n) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) ti[o + i] = src[i];
-            dst = ti + o;
-            o += n;
-        };
-        take(T.body_flags, m.body_flags, m.nb);
-        take(T.joint_type, m.joint_type, m.nj);
-        take(T.joint_enabled, m.joint_enabled, m.nj);
-        take(T.joint_parent, m.joint_parent, m.nj);
-        take(T.joint_child, m.joint_child, m.nj);
-        take(T.joint_q_start, m.joint_q_start, m.nj);
-        take(T.joint_qd_start, m.joint_qd_start, m.nj);
-        take(T.joint_tq_start, m.joint_tq_start, m.nj);
-        take(T.joint_lin_count, m.joint_lin_count, m.nj);
-        take(T.joint_ang_count, m.joint_ang_count, m.nj);
-        take(T.shape_body, m.shape_body, m.ns + m.ng);
-        take(T.shape_type, m.shape_type, m.ns + m.ng);
-        take(T.shape_flags, m.shape_flags, m.ns + m.ng);
-        take(T.shape_group, m.shape_group, m.ns + m.ng);
-        take(T.pair_a, m.pair_a, m.np);
-        take(T.pair_b, m.pair_b, m.np);
-        take(T.body_joint_start, m.body_joint_start, m.nb + 1);
-        take(T.body_joint_list, m.body_joint_list, 2 * m.nj);  // padded to 2*nj entries by the host
-        take(T.body_pair_start, m.body_pair_start, m.nb + 1);
-        take(T.body_pair_list, m.body_pair_list, 2 * m.np);    // padded to 2*np entries by the host
-        take(T.shape_mesh_start, m.shape_mesh_start, m.ns + m.ng);
-        take(T.shape_mesh_count, m.shape_mesh_count, m.ns + m.ng);
-        take(T.gshape_id, m.gshape_id, m.ng);
+        // The 24 env-uniform tables are fetched FIRST -- every thread one element of each, all loads in flight together -- and
+        // written to LDS afterwards.  (One copy loop per table compiles to load / s_waitcnt vmcnt(0) / ds_write per table: 24
+        // serialised memory round trips, ~25 us per launch -- most of what a per-call collide / step kernel took, 8 % of a
+        // 10-substep rollout launch.)  Tables longer than the workgroup finish in a tail loop.
+        constexpr int NT_TOPO_TABLES = 23;
+        const int32_t* const srcs[NT_TOPO_TABLES] = {
+            m.body_flags, m.joint_type, m.joint_enabled, m.joint_parent, m.joint_child, m.joint_q_start, m.joint_qd_start, m.joint_tq_start,
+            m.joint_lin_count, m.joint_ang_count, m.shape_body, m.shape_type, m.shape_flags, m.shape_group, m.pair_a, m.pair_b,
+            m.body_joint_start, m.body_joint_list, m.body_pair_start, m.body_pair_list, m.shape_mesh_start, m.shape_mesh_count, m.gshape_id};
+        const int nsg = m.ns + m.ng;
+        const int lens[NT_TOPO_TABLES] = {m.nb, m.nj, m.nj, m.nj, m.nj, m.nj, m.nj, m.nj, m.nj, m.nj, nsg, nsg, nsg, nsg, m.np, m.np,
+                                          m.nb + 1, 2 * m.nj /* padded by the host */, m.nb + 1, 2 * m.np /* padded */, nsg, nsg, m.ng};
+        const int** const dsts[NT_TOPO_TABLES] = {
+            &T.body_flags, &T.joint_type, &T.joint_enabled, &T.joint_parent, &T.joint_child, &T.joint_q_start, &T.joint_qd_start,
+            &T.joint_tq_start, &T.joint_lin_count, &T.joint_ang_count, &T.shape_body, &T.shape_type, &T.shape_flags, &T.shape_group,
+            &T.pair_a, &T.pair_b, &T.body_joint_start, &T.body_joint_list, &T.body_pair_start, &T.body_pair_list, &T.shape_mesh_start,
+            &T.shape_mesh_count, &T.gshape_id};
+        int first[NT_TOPO_TABLES];
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NT_TOPO_TABLES; ++k) first[k] = tid < lens[k] ? srcs[k][tid] : 0;
+        const int ngf = NT_SHAPE_PARAM_FLOATS * m.ng;
+        const float gfirst = tid < ngf ? m.gshape_param[tid] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < NT_TOPO_TABLES; ++k) {
+            if (tid < lens[k]) ti[o + tid] = first[k];
+            for (int i = tid + (int)blockDim.x; i < lens[k]; i += blockDim.x) ti[o + i] = srcs[k][i];
+            *dsts[k] = ti + o;
+            o += lens[k];
+        }
         {
             float* g = reinterpret_cast<float*>(ti + o);
-            for (int i = threadIdx.x; i < NT_SHAPE_PARAM_FLOATS * m.ng; i += blockDim.x) g[i] = m.gshape_param[i];
+            if (tid < ngf) g[tid] = gfirst;
+            for (int i = tid + (int)blockDim.x; i < ngf; i += blockDim.x) g[i] = m.gshape_param[i];
             T.gshape = g;
-            o += NT_SHAPE_PARAM_FLOATS * m.ng;
+            o += ngf;
         }
         T.hit_count = ti + o;
         T.hit_list = ti + o + 1;
@@ -221,10 +224,19 @@ struct Ctx {
 // HBM <-> LDS staging
 // ------------------------------------------------------------------------------------------------
 // field [ncomp][n][ES] in HBM <-> slot-major rows in LDS
+// (loads in batches of eight before the LDS writes: a load / wait / write per row is one memory round trip per row)
+constexpr int NT_STAGE_BATCH = 8;
 template <int EPB, int NC>
 NT_DI void stage_rows(const Ctx<EPB>& c, Fld<NC> f, const float* src, int ncomp, int n) {
-    for (int comp = 0; comp < ncomp; ++comp)
-        for (int s = c.slot; s < n; s += c.nslot) c.l(f, comp, n, s) = src[c.g(comp, n, s)];
+    for (int s = c.slot; s < n; s += c.nslot)
+        for (int c0 = 0; c0 < ncomp; c0 += NT_STAGE_BATCH) {
+            float v[NT_STAGE_BATCH];
+#pragma unroll
+            for (int k = 0; k < NT_STAGE_BATCH; ++k) v[k] = c0 + k < ncomp ? src[c.g(c0 + k, n, s)] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < NT_STAGE_BATCH; ++k)
+                if (c0 + k < ncomp) c.l(f, c0 + k, n, s) = v[k];
+        }
 }
 template <int EPB, int NC>
 NT_DI void unstage_rows(const Ctx<EPB>& c, Fld<NC> f, float* dst, int ncomp, int n) {
@@ -234,7 +246,14 @@ NT_DI void unstage_rows(const Ctx<EPB>& c, Fld<NC> f, float* dst, int ncomp, int
 // plain rows (a solver's own [row] arrays)
 template <int EPB>
 NT_DI void stage_rows(const Ctx<EPB>& c, int lds_off, const float* src, int rows) {
-    for (int r = c.slot; r < rows; r += c.nslot) c.lds[(lds_off + r) * Ctx<EPB>::N + c.e] = src[(size_t)r * c.ES + c.env];
+    for (int r0 = c.slot; r0 < rows; r0 += NT_STAGE_BATCH * c.nslot) {
+        float v[NT_STAGE_BATCH];
+#pragma unroll
+        for (int k = 0; k < NT_STAGE_BATCH; ++k) v[k] = r0 + k * c.nslot < rows ? src[(size_t)(r0 + k * c.nslot) * c.ES + c.env] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < NT_STAGE_BATCH; ++k)
+            if (r0 + k * c.nslot < rows) c.lds[(lds_off + r0 + k * c.nslot) * Ctx<EPB>::N + c.e] = v[k];
+    }
 }
 template <int EPB>
 NT_DI void unstage_rows(const Ctx<EPB>& c, int lds_off, float* dst, int rows) {
@@ -287,8 +306,15 @@ NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
     }
     if (!c.valid) return;
     if constexpr (!Ctx<EPB>::UNI) {
-        for (int comp = 0; comp < NT_BODY_PARAM_FLOATS; ++comp)
-            for (int b = c.slot; b < nb; b += c.nslot) c.lds[(c.L.bp.off + b * NC_BP + comp) * Ctx<EPB>::N + c.e] = body_value(comp, b, c.env);
+        for (int b = c.slot; b < nb; b += c.nslot)
+            for (int c0 = 0; c0 < NT_BODY_PARAM_FLOATS; c0 += NT_STAGE_BATCH) {
+                float v[NT_STAGE_BATCH];
+#pragma unroll
+                for (int k = 0; k < NT_STAGE_BATCH; ++k) v[k] = c0 + k < NT_BODY_PARAM_FLOATS ? body_value(c0 + k, b, c.env) : 0.0f;
+#pragma unroll
+                for (int k = 0; k < NT_STAGE_BATCH; ++k)
+                    if (c0 + k < NT_BODY_PARAM_FLOATS) c.lds[(c.L.bp.off + b * NC_BP + c0 + k) * Ctx<EPB>::N + c.e] = v[k];
+            }
         stage_rows(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS, m.nj);
         stage_rows(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS, m.nd);
         stage_rows(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS, m.ns);

@@ -8,7 +8,7 @@ template <int EPB>
 __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     const nt_model& m = a.m;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false));
+    const FsLayout F = make_fs_layout(m, make_layout(m, false, false, false, false));
     Ctx<EPB> c(a, lds, F.rows);  // topology ints are staged behind the Featherstone rows
     int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
     __syncthreads();
@@ -37,7 +37,7 @@ template <int EPB, bool CVX>
 __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     const nt_model& m = a.m;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false));
+    const FsLayout F = make_fs_layout(m, make_layout(m, false, false, false, false));
     Ctx<EPB> c(a, lds, F.rows);
     int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
     __syncthreads();
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) eval_fk_kernel(KArgs a, const float* join
     extern __shared__ __align__(16) float lds[];
     const nt_model& m = a.m;
     const int nj = m.nj;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false));
+    const FsLayout F = make_fs_layout(m, make_layout(m, false, false, false, false));
     Ctx<EPB> c(a, lds, F.rows);
     int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
     __syncthreads();

@@ -565,7 +565,7 @@ static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, 
         a.debug_skip = e ? atoi(e) : 0;
     }
 #endif
-    const FsLayout F = make_fs_layout(*m, make_layout(*m, false));
+    const FsLayout F = make_fs_layout(*m, make_layout(*m, false, false, false, false));
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     auto fits = [&](int epb) { return (size_t)F.rows * 4 * epb + shared_ints * 4 <= LDS_BYTES_PER_CU; };
     int epb = 0;
@@ -654,7 +654,7 @@ nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_param
 
 int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m) {
     if (!m) return -1;
-    return make_fs_layout(*m, make_layout(*m, false)).rows * 4;
+    return make_fs_layout(*m, make_layout(*m, false, false, false, false)).rows * 4;
 }
 
 nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint_qd, nt_state* out, void* stream) {
@@ -663,7 +663,7 @@ nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint
     KArgs a = {};
     a.m = *m;
     a.s_out = *out;
-    const FsLayout F = make_fs_layout(*m, make_layout(*m, false));
+    const FsLayout F = make_fs_layout(*m, make_layout(*m, false, false, false, false));
     const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
     int epb = 0;
     const int cands[4] = {16, 8, 4, 1};

@@ -54,7 +54,11 @@ struct LdsLayout {
     Fld<1> pm;         // live contacts per pair [np] (written by the collide phase, read by the fused solver phases)
     Fld<1> px;         // exclusive prefix of pm [np + 1]: live contact i of the env is (pair p, sub-contact i - px[p])
     Fld<1> lt;         // the environment's live contacts [np * cpp], compacted: entry i = pair << 4 | sub-contact (int bits), written
-                       // with the prefix; the fused contact phases read it instead of searching px (not in the pair-heavy tile)
+                       // with the prefix; the fused contact phases read it instead of searching px.  Only where has_lt: the XPBD /
+                       // collide layout of analytic-only models on the staged tiles (np * cpp rows per environment cost the convex
+                       // models a tile size -- C2 fell from 16 to 8 environments per workgroup, 45 -> 20 M env-steps/s -- and the
+                       // other solvers never read it)
+    int has_lt;
     // scratch union
     int u;
     Fld<7> sx, sa;     // collide: shape world xform [ns][7], aabb [ns][6 (+1)]
@@ -99,7 +103,7 @@ __host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_mode
 // in every environment, so the workgroup keeps ONE copy (block-shared, broadcast reads) and an environment's LDS footprint
 // drops by 936 rows on the headline quadruped: 32 environments fit a CU instead of 16
 __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false,
-                                                 const bool uni = false) {
+                                                 const bool uni = false, const bool live_list = true) {
     LdsLayout L;
     int o = 0, ou = 0;
     L.bq.off = o; o += 7 * m.nb;
@@ -117,7 +121,8 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.bd.off = o; o += 9 * m.nb;
     L.pm.off = o; o += m.np;
     L.px.off = o; o += m.np + 1;
-    L.lt.off = o; o += big ? 0 : m.np * m.cpp;
+    L.has_lt = live_list && !big && m.np_analytic == m.np;
+    L.lt.off = o; o += L.has_lt ? m.np * m.cpp : 0;
     L.u = o;
     const int coll = place_collide_scratch(L, m, L.u, big);
     // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase

@@ -503,7 +503,7 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
         // lane i takes the environment's i-th live contact (L.px: exclusive prefix of the per-pair live counts); records
         // of dead slots are never written and never read (apply_item stops at the pair's live count)
         const int total = (int)c.l(c.L.px, 0, 1, np);
-        if (!c.big) {  // the compacted list written with the prefix: no search
+        if (c.L.has_lt) {  // the compacted list written with the prefix: no search
             for (int i = c.tslot; i < total; i += c.nslot) {
                 const int e = *reinterpret_cast<const int*>(&c.l(c.L.lt, 0, 1, i));
                 contact_item<EPB, FUSED, CW>(c, (e >> 4) * cpp + (e & 15), e >> 4);

@@ -139,7 +139,7 @@ def test_c_abi_exports_every_declared_symbol():
     # Featherstone: generalized state 127 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1171,
     # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780, collide scratch 429)
     m.nc, m.na, m.max_art_dofs = 19, 1, 18
-    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1400 + 1171 + 1728)
+    assert lib.nt_featherstone_lds_bytes_per_env(C.byref(m)) == 4 * (1348 + 1171 + 1728)  # (no live-contact list in this layout)
 
 
 def test_no_silent_cpu_fallback():
