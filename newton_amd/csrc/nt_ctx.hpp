@@ -272,6 +272,64 @@ NT_DI void store_state(const Ctx<EPB>& c, const nt_state& s) {
     unstage_rows(c, c.L.bq, s.body_q, 7, c.a.m.nb);
     unstage_rows(c, c.L.bqd, s.body_qd, 6, c.a.m.nb);
 }
+// ---- first-trip batches: the first item a lane owns in a field (s = slot), all components at once.  A kernel's whole tile -- state,
+// parameters, controls -- is fetched as ONE batch of loads followed by the LDS writes (load_tile); items beyond the first trip
+// (fields longer than the slot-thread count) follow through stage_rows_rest.
+template <int NCOMP, int EPB>
+NT_DI void first_load(const Ctx<EPB>& c, const float* src, int n, float (&v)[NCOMP]) {
+#pragma unroll
+    for (int k = 0; k < NCOMP; ++k) v[k] = c.slot < n ? src[c.g(k, n, c.slot)] : 0.0f;
+}
+template <int NCOMP, int EPB, int NC>
+NT_DI void first_store(const Ctx<EPB>& c, Fld<NC> f, int n, const float (&v)[NCOMP]) {
+    if (c.slot < n) {
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) c.l(f, k, n, c.slot) = v[k];
+    }
+}
+template <int EPB, int NC>
+NT_DI void stage_rows_rest(const Ctx<EPB>& c, Fld<NC> f, const float* src, int ncomp, int n) {
+    for (int s = c.slot + c.nslot; s < n; s += c.nslot)
+        for (int c0 = 0; c0 < ncomp; c0 += NT_STAGE_BATCH) {
+            float v[NT_STAGE_BATCH];
+#pragma unroll
+            for (int k = 0; k < NT_STAGE_BATCH; ++k) v[k] = c0 + k < ncomp ? src[c.g(c0 + k, n, s)] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < NT_STAGE_BATCH; ++k)
+                if (c0 + k < ncomp) c.l(f, c0 + k, n, s) = v[k];
+        }
+}
+
+// the block-shared parameter copy of a uniform-parameter tile: one copy per workgroup, read from the tile's first environment (the
+// host vouches that all columns are equal)
+template <int EPB>
+NT_DI void load_uniform_params(const Ctx<EPB>& c) {
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    auto body_value = [&](int comp, int b, size_t col) {
+        float v = m.body_param[(size_t)(comp * nb + b) * c.ES + col];
+        bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
+        if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
+        return v;
+    };
+    const size_t col = (size_t)blockIdx.x * Ctx<EPB>::N;
+    const int nbp = NT_BODY_PARAM_FLOATS * nb, njp = NT_JOINT_PARAM_FLOATS * m.nj, ndp = NT_DOF_PARAM_FLOATS * m.nd,
+              nsp = NT_SHAPE_PARAM_FLOATS * m.ns;
+    const int r0 = threadIdx.x;
+    // first trip of the four tables as one batch of loads, then the rest
+    const float vb = r0 < nbp ? body_value(r0 / nb, r0 % nb, col) : 0.0f;
+    const float vj = r0 < njp ? m.joint_param[(size_t)r0 * c.ES + col] : 0.0f;
+    const float vd = r0 < ndp ? m.dof_param[(size_t)r0 * c.ES + col] : 0.0f;
+    const float vs = r0 < nsp ? m.shape_param[(size_t)r0 * c.ES + col] : 0.0f;
+    if (r0 < nbp) c.up[c.L.bp.off + (r0 % nb) * NC_BP + r0 / nb] = vb;
+    if (r0 < njp) c.up[c.L.jp.off + (r0 % m.nj) * NC_JP + r0 / m.nj] = vj;
+    if (r0 < ndp) c.up[c.L.dp.off + (r0 % m.nd) * NC_DP + r0 / m.nd] = vd;
+    if (r0 < nsp) c.up[c.L.sp.off + (r0 % m.ns) * NC_SP + r0 / m.ns] = vs;
+    for (int r = r0 + blockDim.x; r < nbp; r += blockDim.x) c.up[c.L.bp.off + (r % nb) * NC_BP + r / nb] = body_value(r / nb, r % nb, col);
+    for (int r = r0 + blockDim.x; r < njp; r += blockDim.x) c.up[c.L.jp.off + (r % m.nj) * NC_JP + r / m.nj] = m.joint_param[(size_t)r * c.ES + col];
+    for (int r = r0 + blockDim.x; r < ndp; r += blockDim.x) c.up[c.L.dp.off + (r % m.nd) * NC_DP + r / m.nd] = m.dof_param[(size_t)r * c.ES + col];
+    for (int r = r0 + blockDim.x; r < nsp; r += blockDim.x) c.up[c.L.sp.off + (r % m.ns) * NC_SP + r / m.ns] = m.shape_param[(size_t)r * c.ES + col];
+}
 // parameters and controls: read once per kernel
 template <int EPB>
 NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
@@ -284,26 +342,7 @@ NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
         if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;  // (global copy: the LDS topology is not published yet)
         return v;
     };
-    if constexpr (Ctx<EPB>::UNI) {
-        // one copy per workgroup, read from the tile's first environment (the host vouches that all columns are equal)
-        const size_t col = (size_t)blockIdx.x * Ctx<EPB>::N;
-        for (int r = threadIdx.x; r < NT_BODY_PARAM_FLOATS * nb; r += blockDim.x) {
-            int comp = r / nb, b = r - comp * nb;
-            c.up[c.L.bp.off + b * NC_BP + comp] = body_value(comp, b, col);
-        }
-        for (int r = threadIdx.x; r < NT_JOINT_PARAM_FLOATS * m.nj; r += blockDim.x) {
-            int comp = r / m.nj, j = r - comp * m.nj;
-            c.up[c.L.jp.off + j * NC_JP + comp] = m.joint_param[(size_t)r * c.ES + col];
-        }
-        for (int r = threadIdx.x; r < NT_DOF_PARAM_FLOATS * m.nd; r += blockDim.x) {
-            int comp = r / m.nd, d = r - comp * m.nd;
-            c.up[c.L.dp.off + d * NC_DP + comp] = m.dof_param[(size_t)r * c.ES + col];
-        }
-        for (int r = threadIdx.x; r < NT_SHAPE_PARAM_FLOATS * m.ns; r += blockDim.x) {
-            int comp = r / m.ns, sh = r - comp * m.ns;
-            c.up[c.L.sp.off + sh * NC_SP + comp] = m.shape_param[(size_t)r * c.ES + col];
-        }
-    }
+    if constexpr (Ctx<EPB>::UNI) load_uniform_params(c);
     if (!c.valid) return;
     if constexpr (!Ctx<EPB>::UNI) {
         for (int b = c.slot; b < nb; b += c.nslot)
@@ -324,5 +363,78 @@ NT_DI void load_params(const Ctx<EPB>& c, bool with_control) {
         stage_rows(c, c.L.cf, c.a.c.joint_f, 1, m.nd);
         stage_rows(c, c.L.ctq, c.a.c.joint_target_q, 1, m.ntq);
         stage_rows(c, c.L.ctqd, c.a.c.joint_target_qd, 1, m.nd);
+    }
+}
+
+// state (optional) + parameters + gravity + controls of the lane's environment in one batch of loads (see first_load): what the XPBD /
+// collide kernels call instead of load_state + load_params
+template <int EPB>
+NT_DI void load_tile(const Ctx<EPB>& c, const nt_state* state, bool with_control) {
+    const nt_model& m = c.a.m;
+    const int nb = m.nb;
+    constexpr bool UNI = Ctx<EPB>::UNI;
+    if constexpr (UNI) load_uniform_params(c);  // (the block-shared parameter copy: workgroup-strided loops)
+    if (!c.valid) return;
+    float vq[7], vqd[6], vbp[NT_BODY_PARAM_FLOATS], vjp[NT_JOINT_PARAM_FLOATS], vdp[NT_DOF_PARAM_FLOATS], vsp[NT_SHAPE_PARAM_FLOATS];
+    float vg = 0.0f, vcf = 0.0f, vctq = 0.0f, vctqd = 0.0f;
+    int flags = 0;
+    if (state) {
+        first_load(c, state->body_q, nb, vq);
+        first_load(c, state->body_qd, nb, vqd);
+    }
+    if constexpr (!UNI) {
+        first_load(c, m.body_param, nb, vbp);
+        if (c.slot < nb) flags = m.body_flags[c.slot];
+        first_load(c, m.joint_param, m.nj, vjp);
+        first_load(c, m.dof_param, m.nd, vdp);
+        first_load(c, m.shape_param, m.ns, vsp);
+    }
+    if (c.slot < 3) vg = m.gravity[(size_t)c.slot * c.ES + c.env];
+    if (with_control) {
+        if (c.slot < m.nd) { vcf = c.a.c.joint_f[c.g(0, m.nd, c.slot)]; vctqd = c.a.c.joint_target_qd[c.g(0, m.nd, c.slot)]; }
+        if (c.slot < m.ntq) vctq = c.a.c.joint_target_q[c.g(0, m.ntq, c.slot)];
+    }
+    // ---- writes
+    if (state) {
+        first_store(c, c.L.bq, nb, vq);
+        first_store(c, c.L.bqd, nb, vqd);
+    }
+    if constexpr (!UNI) {
+        if (flags & BODY_KINEMATIC) {  // effective (kinematic => 0) inverse mass / inertia (solver.py:173-187)
+            vbp[BP_INV_MASS] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) vbp[BP_INV_INERTIA + k] = 0.0f;
+        }
+        first_store(c, c.L.bp, nb, vbp);
+        first_store(c, c.L.jp, m.nj, vjp);
+        first_store(c, c.L.dp, m.nd, vdp);
+        first_store(c, c.L.sp, m.ns, vsp);
+    }
+    if (c.slot < 3) c.l(c.L.grav, c.slot, 1, 0) = vg;
+    if (with_control) {
+        if (c.slot < m.nd) { c.l(c.L.cf, 0, m.nd, c.slot) = vcf; c.l(c.L.ctqd, 0, m.nd, c.slot) = vctqd; }
+        if (c.slot < m.ntq) c.l(c.L.ctq, 0, m.ntq, c.slot) = vctq;
+    }
+    // ---- items beyond the first trip
+    if (state) {
+        stage_rows_rest(c, c.L.bq, state->body_q, 7, nb);
+        stage_rows_rest(c, c.L.bqd, state->body_qd, 6, nb);
+    }
+    if constexpr (!UNI) {
+        for (int b = c.slot + c.nslot; b < nb; b += c.nslot)
+            for (int comp = 0; comp < NT_BODY_PARAM_FLOATS; ++comp) {
+                float v = m.body_param[(size_t)(comp * nb + b) * c.ES + c.env];
+                const bool inv_row = comp == BP_INV_MASS || (comp >= BP_INV_INERTIA && comp < BP_INV_INERTIA + 9);
+                if (inv_row && (m.body_flags[b] & BODY_KINEMATIC)) v = 0.0f;
+                c.lds[(c.L.bp.off + b * NC_BP + comp) * Ctx<EPB>::N + c.e] = v;
+            }
+        stage_rows_rest(c, c.L.jp, m.joint_param, NT_JOINT_PARAM_FLOATS, m.nj);
+        stage_rows_rest(c, c.L.dp, m.dof_param, NT_DOF_PARAM_FLOATS, m.nd);
+        stage_rows_rest(c, c.L.sp, m.shape_param, NT_SHAPE_PARAM_FLOATS, m.ns);
+    }
+    if (with_control) {
+        stage_rows_rest(c, c.L.cf, c.a.c.joint_f, 1, m.nd);
+        stage_rows_rest(c, c.L.ctq, c.a.c.joint_target_q, 1, m.ntq);
+        stage_rows_rest(c, c.L.ctqd, c.a.c.joint_target_qd, 1, m.nd);
     }
 }

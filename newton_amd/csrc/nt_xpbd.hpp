@@ -286,6 +286,25 @@ struct FlatRecord {
 
 // solve_body_contact_positions (xpbd/kernels.py:2164-2399) for one live contact between body_a / body_b (-1: static); returns
 // false when the contact is separated (no correction).  lin_delta_b is the exact negation of lin_delta_a.
+// a contact record fetched as a whole: the seventeen loads of a record leave together (one memory round trip; fetched field by field
+// where the solve first needs it -- the offsets inside the friction branch -- a slot record cost three dependent L2 round trips per
+// contact phase on a wave that has nothing else to run)
+struct LoadedRecord {
+    vec3 p0, p1, o0, o1, n;
+    float m;
+    NT_DI vec3 point0() const { return p0; }
+    NT_DI vec3 point1() const { return p1; }
+    NT_DI vec3 offset0() const { return o0; }
+    NT_DI vec3 offset1() const { return o1; }
+    NT_DI vec3 normal() const { return n; }
+    NT_DI float margins() const { return m; }
+};
+template <class REC>
+NT_DI LoadedRecord load_record(const REC& r) {
+    LoadedRecord L;
+    L.p0 = r.point0(); L.p1 = r.point1(); L.n = r.normal(); L.o0 = r.offset0(); L.o1 = r.offset1(); L.m = r.margins();
+    return L;
+}
 template <int EPB, class REC>
 NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int shape_b, int body_a, int body_b, vec3& lin_delta_a,
                          vec3& ang_delta_a, vec3& ang_delta_b) {
@@ -418,7 +437,9 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot, const int live_pair =
     bool live;
     int shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
     bool swapped = false, described = false;
+    LoadedRecord rec;
     if (FUSED && live_pair >= 0) {
+        rec = load_record(SlotRecord<EPB>{c, ct.data, ncs, slot});  // (a listed contact is live: fetch before anything depends on LDS)
         const int* d = c.T.pair_desc + 4 * live_pair;
         shape_a = d[0]; shape_b = d[1]; body_a = d[2];
         const int w = d[3];
@@ -450,8 +471,8 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot, const int live_pair =
         body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         live = body_a != body_b;
     }
-    if (live && contact_solve(c, SlotRecord<EPB>{c, ct.data, ncs, slot}, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a,
-                              ang_delta_b)) {
+    if (live && !described) rec = load_record(SlotRecord<EPB>{c, ct.data, ncs, slot});
+    if (live && contact_solve(c, rec, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b)) {
         has_a = body_a >= 0 ? 1.0f : 0.0f;
         has_b = body_b >= 0 ? 1.0f : 0.0f;
         if (described) a_is_pair_a = swapped ? 0.0f : 1.0f;
@@ -475,7 +496,7 @@ NT_DI void flat_contact_item(const Ctx<EPB>& c, const int r) {
         const int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1, shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
         const int body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1, body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         if (body_a != body_b &&
-            contact_solve(c, FlatRecord{f, r}, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b))
+            contact_solve(c, load_record(FlatRecord{f, r}), shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b))
             flags = (body_a >= 0 ? 1.0f : 0.0f) + (body_b >= 0 ? 2.0f : 0.0f);
     }
     float* o = f.cw + CWX_FLOATS * (size_t)r;

@@ -118,8 +118,7 @@ template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ?
 __global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
-    load_state(c, a.s_in);
-    load_params(c, false);
+    load_tile(c, &a.s_in, false);
     __syncthreads();
     do_collide<EPB, CVX>(c, true);
 }
@@ -130,8 +129,7 @@ template <int EPB>
 __global__ void __launch_bounds__((EPB & 255) <= 8 ? 256 : 512) shapes_export_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, false);
-    load_state(c, a.s_in);
-    load_params(c, false);
+    load_tile(c, &a.s_in, false);
     __syncthreads();
     phase_shapes(c);
 }
@@ -141,8 +139,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
     const fused::Ctx<EPB> cf(c, 0);
-    load_state(c, a.s_in);
-    load_params(c, true);
+    load_tile(c, &a.s_in, true);
     __syncthreads();
     fused::phase_body_derived(cf);
     __syncthreads();
@@ -190,8 +187,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     Ctx<EPB> c(a, lds, -1, BIG);
     const fused::Ctx<EPB> cf(c, 0);
     const int nb = a.m.nb;
-    load_state(c, a.s_in);
-    load_params(c, true);
+    load_tile(c, &a.s_in, true);
     if (c.valid)
         for (int r = c.slot; r < 6 * nb; r += c.nslot) {
             a.s_in.body_f[(size_t)r * c.ES + c.env] = 0.0f;
