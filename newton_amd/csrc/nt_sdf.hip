@@ -2600,11 +2600,21 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
     int n_items = a.stage_count[0];
     n_items = n_items < a.stage_queue_capacity ? n_items : a.stage_queue_capacity;
     const bool prune = (a.reduce & 2) != 0;
-    for (int q = blockIdx.x * HY_STAGE_WAVES + wave; q < n_items; q += gridDim.x * HY_STAGE_WAVES) {
+    // a wave takes a CONTIGUOUS run of items: a pair's blocks are consecutive in the queue, so the pair's descriptors (three dependent
+    // memory round trips + the relative transform) are fetched once per pair, not once per block
+    const int total_waves = gridDim.x * HY_STAGE_WAVES;
+    const int per_wave = (n_items + total_waves - 1) / total_waves;
+    const int q_begin = (blockIdx.x * HY_STAGE_WAVES + wave) * per_wave;
+    const int q_end = q_begin + per_wave < n_items ? q_begin + per_wave : n_items;
+    HydroPair p;
+    int loaded_pair = -1;
+    for (int q = q_begin; q < q_end; ++q) {
         const int pair_idx = hy_uniform(a.stage_queue[2 * (size_t)q]), b = hy_uniform(a.stage_queue[2 * (size_t)q + 1]);
-        HydroPair p;
-        bool collide;
-        hydro_pair_load(a, pair_idx, p, false, collide);
+        if (pair_idx != loaded_pair) {  // (uniform)
+            bool collide;
+            hydro_pair_load(a, pair_idx, p, false, collide);
+            loaded_pair = pair_idx;
+        }
         const int nbx = p.B.cx, nby = p.B.cy, sgs = p.B.subgrid_size;
         const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
         const int x0 = bx * sgs, y0 = by * sgs, z0 = bz * sgs;
