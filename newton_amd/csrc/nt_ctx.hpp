@@ -376,7 +376,7 @@ NT_DI void load_tile(const Ctx<EPB>& c, const nt_state* state, bool with_control
     if constexpr (UNI) load_uniform_params(c);  // (the block-shared parameter copy: workgroup-strided loops)
     if (!c.valid) return;
     float vq[7], vqd[6], vbp[NT_BODY_PARAM_FLOATS], vjp[NT_JOINT_PARAM_FLOATS], vdp[NT_DOF_PARAM_FLOATS], vsp[NT_SHAPE_PARAM_FLOATS];
-    float vg = 0.0f, vcf = 0.0f, vctq = 0.0f, vctqd = 0.0f;
+    float vg[3] = {0.0f, 0.0f, 0.0f}, vcf = 0.0f, vctq = 0.0f, vctqd = 0.0f;
     int flags = 0;
     if (state) {
         first_load(c, state->body_q, nb, vq);
@@ -389,7 +389,10 @@ NT_DI void load_tile(const Ctx<EPB>& c, const nt_state* state, bool with_control
         first_load(c, m.dof_param, m.nd, vdp);
         first_load(c, m.shape_param, m.ns, vsp);
     }
-    if (c.slot < 3) vg = m.gravity[(size_t)c.slot * c.ES + c.env];
+    if (c.slot == 0) {  // (one item of three components: tiny models run with fewer than three slot-threads per environment)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vg[k] = m.gravity[(size_t)k * c.ES + c.env];
+    }
     if (with_control) {
         if (c.slot < m.nd) { vcf = c.a.c.joint_f[c.g(0, m.nd, c.slot)]; vctqd = c.a.c.joint_target_qd[c.g(0, m.nd, c.slot)]; }
         if (c.slot < m.ntq) vctq = c.a.c.joint_target_q[c.g(0, m.ntq, c.slot)];
@@ -410,7 +413,10 @@ NT_DI void load_tile(const Ctx<EPB>& c, const nt_state* state, bool with_control
         first_store(c, c.L.dp, m.nd, vdp);
         first_store(c, c.L.sp, m.ns, vsp);
     }
-    if (c.slot < 3) c.l(c.L.grav, c.slot, 1, 0) = vg;
+    if (c.slot == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c.l(c.L.grav, k, 1, 0) = vg[k];
+    }
     if (with_control) {
         if (c.slot < m.nd) { c.l(c.L.cf, 0, m.nd, c.slot) = vcf; c.l(c.L.ctqd, 0, m.nd, c.slot) = vctqd; }
         if (c.slot < m.ntq) c.l(c.L.ctq, 0, m.ntq, c.slot) = vctq;
