@@ -760,6 +760,22 @@ nt_status nt_model_refresh_params(nt_model_handle* h, const nt_newton_model* src
 void nt_model_destroy(nt_model_handle* h);
 const char* nt_model_last_error(void);           /* detail of the last NT_ERR_* of the nt_model_* calls on this thread */
 
+/* -------- hipGraph capture of a frame (csrc/nt_graph.hip) --------
+ * The reference's examples wrap simulate() -- clear_forces / collide / step per substep -- in wp.ScopedCapture and replay it with
+ * wp.capture_launch (newton/examples/basic/example_basic_urdf.py:112-141).  Every entry point above launches on the caller's stream,
+ * owns no memory and never reads back, so the same calls record into one hipGraph:
+ *     nt_graph_capture_begin(stream);  <the frame's nt_* calls on `stream`>;  nt_graph_capture_end(stream, &g);
+ *     nt_graph_launch(g, stream);  ...  nt_graph_destroy(g);
+ * `stream` must be a created stream (not the legacy default stream).  Issue the frame once before capturing: the first launch of a
+ * kernel whose tile needs more than 48 KB of LDS sets a function attribute, which is not a stream operation.  Replay repeats the
+ * recorded launches on the recorded buffers: the frame must leave the caller's state pointers as it found them (an even number of
+ * state swaps). */
+typedef struct nt_graph nt_graph;
+nt_status nt_graph_capture_begin(void* stream);
+nt_status nt_graph_capture_end(void* stream, nt_graph** out);
+nt_status nt_graph_launch(nt_graph* graph, void* stream);
+void nt_graph_destroy(nt_graph* graph);
+
 const char* nt_error_string(nt_status s);
 const char* nt_build_info(void);                 /* "gfx950 ..." */
 /* environments per workgroup the stepping kernels would use for this model (requested: 0 = auto), 0 if the working set

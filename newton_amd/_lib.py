@@ -309,6 +309,10 @@ SYMBOLS = {
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
     "nt_pick_envs_per_block": (C.c_int32, [C.POINTER(nt_model), C.c_int32]),
     "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
+    "nt_graph_capture_begin": (C.c_int32, [_P]),
+    "nt_graph_capture_end": (C.c_int32, [_P, C.POINTER(_P)]),
+    "nt_graph_launch": (C.c_int32, [_P, _P]),
+    "nt_graph_destroy": (None, [_P]),
     "nt_sdf_sample": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P, _P]),
     "nt_sdf_sample_hw": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P]),
     "nt_sdf_sample_voxels": (C.c_int32, [C.POINTER(nt_sdf), _P, C.c_int32, _P, _P]),

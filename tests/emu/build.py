@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
 FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_ctx.hpp", "nt_collide.hpp", "nt_xpbd.hpp", "nt_xpbd_kernels.hpp",
          "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_featherstone_kernels.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip",
-         "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip"]
+         "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip", "nt_graph.hip"]
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
 HY_SYNC = re.compile(r"#define HY_WAVE_SYNC_HW\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
@@ -57,6 +57,7 @@ def build(force: bool = False) -> str:
            *([os.path.join(OUT, "nt_build_id.cpp")] if "nt_build_id.hip" in files else []),
            *([os.path.join(OUT, "nt_match.cpp")] if "nt_match.hip" in files else []),
            *([os.path.join(OUT, "nt_model_build.cpp")] if "nt_model_build.hip" in files else []),
+           *([os.path.join(OUT, "nt_graph.cpp")] if "nt_graph.hip" in files else []),
            *([os.path.join(OUT, "nt_flat_contacts.cpp")] if "nt_flat_contacts.hip" in files else []),
            *([os.path.join(OUT, "nt_sdf_pipeline.cpp")] if "nt_sdf_pipeline.hip" in files else []), "-o", LIB]
     subprocess.run(cmd, check=True)

@@ -23,8 +23,10 @@ def _frame(model, pipe, solver, st, ctrl, contacts, dt, substeps):
     return simulate
 
 
+@pytest.mark.parametrize("backend", ["torch", "abi"])
 @pytest.mark.parametrize("scene", ["quadruped", "sdf"])
-def test_captured_frame_replays_bit_identically(scene):
+def test_captured_frame_replays_bit_identically(scene, backend):
+    """backend "abi": the C ABI's own capture helper (nt_graph_capture_begin / _end / _launch), what a host without torch binds."""
     _needs_device()
     import torch
 
@@ -49,8 +51,13 @@ def test_captured_frame_replays_bit_identically(scene):
             for _ in range(frames):
                 simulate()
         else:
-            g = nt.graph.capture(simulate, warmup=0)  # the capture pass itself is frame 1 (it launches nothing: replay does)
-            for _ in range(frames):
+            if backend == "torch":
+                g = nt.graph.capture(simulate, warmup=0)  # the capture pass itself is frame 1 (it launches nothing: replay does)
+                n_replays = frames
+            else:  # the ABI helper runs the frame once for real before recording it (kernel attributes are set on first use)
+                g = nt.graph.capture(simulate, warmup=1, backend="abi", contacts=contacts)
+                n_replays = frames - 1
+            for _ in range(n_replays):
                 g.launch()
         torch.cuda.synchronize()
         out[mode] = (st[0].body_q.cpu().numpy().copy(), st[0].body_qd.cpu().numpy().copy())
