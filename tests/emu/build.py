@@ -38,7 +38,20 @@ def transform(text: str) -> str:
 
 
 def build(force: bool = False) -> str:
+    """(serialised by a file lock: pytest-xdist workers that find a stale library would otherwise rebuild it at the same time and load
+    each other's half-written output)"""
+    import fcntl
+
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool) -> str:
     files = [f for f in FILES if os.path.exists(os.path.join(CSRC, f))]  # (tools/emu_bitcheck.py builds older revisions too)
     srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "hip_emu.h"),
                                                      os.path.abspath(__file__),

@@ -27,6 +27,8 @@ struct dim3 {
     dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 typedef void* hipStream_t;
+typedef void* hipGraph_t;      // (nt_graph.hip: handle types only -- the capture entry points answer NT_ERR_UNSUPPORTED under emulation)
+typedef void* hipGraphExec_t;
 enum hipError_t { hipSuccess = 0, hipErrorEmu = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
