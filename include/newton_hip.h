@@ -681,6 +681,38 @@ typedef struct {
 } nt_flat_force_params;
 nt_status nt_flat_rows_forces(const nt_sdf_scene* sc, const nt_flat_rows* rows, const nt_flat_force_params* p, void* stream);
 
+/* Frame-to-frame matching of the SDF legs' rows (newton/_src/geometry/contact_match.py:266-391 match + resolve, :442-480 save,
+ * :530-562 sticky replay; called from CollisionPipeline.collide, collide.py:2033-2135, like nt_contacts_match for the slots).
+ * The reference binary-searches the previous frame's key-sorted contacts for the (shape0, shape1) range; the rows are already
+ * grouped per (world, candidate pair) in ascending pair order, so the range is the previous frame's row block of the same pair,
+ * found by a binary search in that world's previous candidate list.  Claims race through a packed 64-bit atomic min exactly as
+ * in the reference (distance, then the low 32 key bits = shape1's low 9 bits << 23 | fingerprint's low 23 bits).
+ * All arrays are device memory owned by the caller and zero-initialised before the first call. */
+typedef struct {
+    int32_t* prev_row_start;           /* [env_count + 1] */
+    int32_t* prev_pair_count;          /* [env_count] (clamped to pairs_per_world); 0 = the world has no history (reset) */
+    int32_t* prev_world_pairs;         /* [env_count * pairs_per_world][2] */
+    int32_t* prev_pair_row;            /* [env_count * pairs_per_world] */
+    int32_t* prev_pair_rows;           /* [env_count * pairs_per_world] rows of the pair (clamped to the row arrays) */
+    uint8_t* prev_live;                /* [row_capacity] the row was a contact (shape0 != shape1) */
+    float* prev_pos_world;             /* [row_capacity][3] world-space midpoint of the two contact points */
+    float* prev_normal;                /* [row_capacity][3] */
+    float* prev_body_frame;            /* [row_capacity][12] point0, point1, offset0, offset1 of the record used last frame, or NULL
+                                          (sticky mode only) */
+    unsigned long long* prev_claim;    /* [row_capacity] claim words, reset by nt_flat_rows_save_history */
+} nt_flat_history;
+/* match_index [row_capacity]: for every live row of this frame the ROW index of the matched previous row, -1 (MATCH_NOT_FOUND:
+ * the pair had no contact last frame) or -2 (MATCH_BROKEN: nothing within the thresholds, or lost the race); inert rows -1.
+ * io: the struct nt_sdf_rows_finalize was called with (pair tables + the row arrays).  body_q: env-major [7][nb][ES]. */
+nt_status nt_flat_rows_match(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, const nt_flat_history* h,
+                             float pos_threshold, float normal_dot_threshold, int32_t* match_index, void* stream);
+/* sticky mode: matched rows that still touch (fresh gap <= 0) take last frame's body-frame points, offsets and normal */
+nt_status nt_flat_rows_replay_matched(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, const nt_flat_history* h,
+                                      const int32_t* match_index, void* stream);
+/* persist this frame's rows (after the replay) as the next frame's history */
+nt_status nt_flat_rows_save_history(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, const nt_flat_history* h,
+                                    void* stream);
+
 /* -------- introspection -------- */
 /* ---- building the descriptor from Newton's own arrays ------------------------------------------------------------------
  * nt_model above is the device-side view (env-major SoA, env-uniform topology).  A binding that holds a finalized

@@ -88,6 +88,13 @@ class nt_sdf_rows_io(C.Structure):
                 ("damping", C.c_void_p), ("friction_scale", C.c_void_p), ("raw_base", C.c_int32)]
 
 
+class nt_flat_history(C.Structure):
+    _fields_ = [("prev_row_start", C.c_void_p), ("prev_pair_count", C.c_void_p), ("prev_world_pairs", C.c_void_p),
+                ("prev_pair_row", C.c_void_p), ("prev_pair_rows", C.c_void_p), ("prev_live", C.c_void_p),
+                ("prev_pos_world", C.c_void_p), ("prev_normal", C.c_void_p), ("prev_body_frame", C.c_void_p),
+                ("prev_claim", C.c_void_p)]
+
+
 class nt_flat_force_params(C.Structure):
     _fields_ = [("body_q", C.c_void_p), ("body_qd", C.c_void_p), ("body_com", C.c_void_p), ("shape_material", C.c_void_p),
                 ("friction_smoothing", C.c_float), ("body_f", C.c_void_p)]
@@ -332,6 +339,10 @@ SYMBOLS = {
     "nt_sdf_candidate_pairs": (C.c_int32, [C.POINTER(nt_sdf_scene), _P, _P, _P, _P, _P, _P]),
     "nt_sdf_rows_finalize": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_sdf_rows_io), _P, _P, _P, _P, _P]),
     "nt_flat_rows_forces": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_flat_rows), C.POINTER(nt_flat_force_params), _P]),
+    "nt_flat_rows_match": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_sdf_rows_io), _P, C.POINTER(nt_flat_history), C.c_float,
+                                       C.c_float, _P, _P]),
+    "nt_flat_rows_replay_matched": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_sdf_rows_io), _P, C.POINTER(nt_flat_history), _P, _P]),
+    "nt_flat_rows_save_history": (C.c_int32, [C.POINTER(nt_sdf_scene), C.POINTER(nt_sdf_rows_io), _P, C.POINTER(nt_flat_history), _P]),
 }
 
 _lib = None

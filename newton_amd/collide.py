@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .enums import GeoType, ShapeFlags
-from .sdf_pipeline import SdfLeg, model_has_sdf_pairs, sdf_pair_shape_types_ok
+from .sdf_pipeline import FlatRowMatcher, SdfLeg, model_has_sdf_pairs, sdf_pair_shape_types_ok
 
 _RIGID_CONTACT_MIN_CAPACITY = 1000  # collide.py: _estimate_rigid_contact_max floor
 
@@ -155,7 +155,7 @@ class Contacts:
                 e["damping"][n0:n0 + k] = f.damping[live]
                 e["friction"][n0:n0 + k] = f.friction_scale[live]
             e["count"][0] = n0 + k
-            self._flat_live = live
+            self._flat_live, self._flat_n0 = live, n0
         self._sort_order = None
         if self.sort_by_key:
             n = min(int(e["count"].item()), cap)
@@ -236,9 +236,13 @@ class ContactMatcher:
 
     MATCH_NOT_FOUND, MATCH_BROKEN = -1, -2
 
-    def __init__(self, model, pos_threshold: float = 0.0005, normal_dot_threshold: float = 0.995, sticky: bool = False):
+    def __init__(self, model, pos_threshold: float = 0.0005, normal_dot_threshold: float = 0.995, sticky: bool = False,
+                 sdf_leg=None):
         torch = _torch()
         self.model = model
+        # the rows of the mesh-SDF leg are matched on their own (world, pair) blocks (sdf_pipeline.FlatRowMatcher)
+        self._rows = FlatRowMatcher(sdf_leg, sticky=sticky) if sdf_leg is not None else None
+        self._prev_flat_rows = None  # export-order index of every previous row
         self.dm = model.device_model()
         t = model.env
         ns, dev = max(t.np * t.cpp, 1), self.dm.device
@@ -261,6 +265,8 @@ class ContactMatcher:
         """Forget the history of the selected worlds (all when None): their next contacts report MATCH_NOT_FOUND."""
         torch = _torch()
         t = self.model.env
+        if self._rows is not None:
+            self._rows.reset(world_mask)
         if world_mask is None:
             self._live.zero_()
             self._reset_mask = None
@@ -277,6 +283,9 @@ class ContactMatcher:
         if self._prev_flat is not None and n > 0:
             keep = (self._prev_flat >= 0) & (self._live[: t.np * t.cpp, : t.env_count] != 0)
             alive[self._prev_flat[keep]] = True
+        if self._rows is not None and self._prev_flat_rows is not None and n > 0:
+            keep = self._rows.previous_rows_alive() & (self._prev_flat_rows >= 0)
+            alive[self._prev_flat_rows[keep]] = True
         return alive[:n]
 
     def _flat_index(self, live):
@@ -314,13 +323,22 @@ class ContactMatcher:
             env = torch.arange(E, device=m.device)[None, :].expand_as(slot)
             m = torch.where(m >= 0, self._prev_flat[slot, env], m)
         n = int(live_now[:, :E].sum().item())
-        out = torch.full((max(n, 1),), -1, dtype=torch.int32, device=m.device)
+        order = contacts.export_order()  # deterministic mode re-orders the flat rows: follow it
+        k, mr = 0, None
+        if self._rows is not None:  # the SDF leg's live rows follow the slot contacts in the raw export order
+            live_rows = contacts._flat_live
+            k = int(live_rows.numel())
+            mr = self._rows.match(state, contacts._flat, self.pos_threshold, self.normal_dot_threshold)[live_rows].to(torch.int64)
+            if self._prev_flat_rows is not None:
+                mr = torch.where(mr >= 0, self._prev_flat_rows[mr.clamp(min=0)], mr)
+        out = torch.full((max(n + k, 1),), -1, dtype=torch.int32, device=m.device)
         sel = flat_now >= 0
         out[flat_now[sel]] = m[sel].to(torch.int32)
-        order = contacts.export_order()  # deterministic mode re-orders the flat rows: follow it
+        if k:
+            out[n:n + k] = mr.to(torch.int32)
         if order is not None:
             out[: order.numel()] = out[: order.numel()][order]
-        return out[:n]
+        return out[:n + k]
 
     def replay_matched(self, state, contacts):
         """Sticky mode (contact_match.py:933-996): matched contacts that still touch keep last frame's body-frame points,
@@ -331,6 +349,8 @@ class ContactMatcher:
         d_s, d_c = state._desc(), contacts._desc()
         _lib.check(dm.lib.nt_contacts_replay_matched(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h),
                                                      self._match.data_ptr(), dm.stream()), "nt_contacts_replay_matched")
+        if self._rows is not None:
+            self._rows.replay_matched(state, contacts._flat)
         contacts._generation += 1
 
     def save_sorted_state(self, state, contacts):
@@ -341,12 +361,20 @@ class ContactMatcher:
                    "nt_contacts_save_history")
         self._prev_flat = self._flat_index(self._live[: t.np * t.cpp])
         order = contacts.export_order()
+        torch = _torch()
+        if self._rows is not None:
+            self._rows.save_history(state, contacts._flat)
+            live_rows, n0 = contacts._flat_live, contacts._flat_n0
+            self._prev_flat_rows = torch.full((contacts._flat.capacity,), -1, dtype=torch.int64, device=live_rows.device)
+            self._prev_flat_rows[live_rows] = n0 + torch.arange(live_rows.numel(), device=live_rows.device)
         if order is not None:  # flat rows were permuted by the key sort: rank of every raw row in the sorted order
-            torch = _torch()
             rank = torch.empty_like(order)
             rank[order] = torch.arange(order.numel(), device=order.device)
             ok = self._prev_flat >= 0
             self._prev_flat[ok] = rank[self._prev_flat[ok]]
+            if self._prev_flat_rows is not None:
+                ok = self._prev_flat_rows >= 0
+                self._prev_flat_rows[ok] = rank[self._prev_flat_rows[ok]]
 
 
 def estimate_rigid_contact_max(model) -> int:
@@ -428,12 +456,13 @@ class CollisionPipeline:
             if not reduce_contacts:
                 raise NotImplementedError("SDF contact pairs need reduce_contacts=True (the unreduced kernel is offered stand-alone: "
                                           "newton_amd.sdf_device.mesh_sdf_collide)")
-            if contact_matching != "disabled":
-                raise NotImplementedError("contact_matching is not implemented for models with SDF contact pairs")
             sdf_pair_shape_types_ok(model)
             self._sdf_leg = SdfLeg(model, pairs_per_shape=sdf_pairs_per_shape, contacts_per_shape=sdf_contacts_per_shape,
                                    hydro_config=sdf_hydroelastic_config, hydro_faces_per_shape=sdf_hydro_faces_per_shape,
                                    hydro_staged=sdf_hydro_staged)
+            if contact_matching != "disabled" and self._sdf_leg.has_hydro_pairs:
+                # the reference matcher does not cover hydroelastic contacts either (contact_match.py:497-501)
+                raise NotImplementedError("contact_matching is not supported for hydroelastic contact pairs")
             self._rigid_contact_max += self._sdf_leg.row_capacity
         model.rigid_contact_max = self._rigid_contact_max
         # fixed slots + ordered reductions: results are reproducible either way; deterministic=True additionally orders the
@@ -443,7 +472,8 @@ class CollisionPipeline:
         self.contact_matching, self.contact_report = contact_matching, bool(contact_report)
         self.deterministic = bool(deterministic) or contact_matching != "disabled"
         self._matcher = (ContactMatcher(model, contact_matching_pos_threshold, contact_matching_normal_dot_threshold,
-                                        sticky=contact_matching == "sticky") if contact_matching != "disabled" else None)
+                                        sticky=contact_matching == "sticky", sdf_leg=self._sdf_leg)
+                         if contact_matching != "disabled" else None)
         self._prev_count = 0
 
     @property

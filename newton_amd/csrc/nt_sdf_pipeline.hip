@@ -390,9 +390,198 @@ __global__ void __launch_bounds__(256) flat_rows_forces_kernel(nt_sdf_scene sc, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// frame-to-frame matching of the rows (geometry/contact_match.py:266-391,442-480,530-562).  Eight lanes per (world, candidate pair),
+// the grouping of sdf_rows_write_kernel: a pair's rows of this frame and of the previous one are two short contiguous blocks.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int MATCH_NOT_FOUND = -1, MATCH_BROKEN = -2;
+constexpr unsigned long long CLAIM_SENTINEL = ~0ull;
+
+struct PairBlock { int w, s0, s1, row0, rows; };
+NT_DI bool pair_block(const nt_sdf_scene& sc, const nt_sdf_rows_io& io, int idx, PairBlock& b) {
+    b.w = idx / sc.pairs_per_world;
+    int live = io.pair_count[b.w];
+    live = live < sc.pairs_per_world ? live : sc.pairs_per_world;
+    if (idx - b.w * sc.pairs_per_world >= live) return false;
+    b.s0 = io.world_pairs[2 * (size_t)idx];
+    b.s1 = io.world_pairs[2 * (size_t)idx + 1];
+    b.row0 = io.row_start[b.w] + io.pair_row[idx];
+    int c = (sc.template_kind && sc.world_pair_kind[idx] == 1) ? 0 : io.blk[2 * (size_t)idx + 1];  // hydroelastic rows do not match
+    c = c < io.row_capacity - b.row0 ? c : io.row_capacity - b.row0;
+    b.rows = c > 0 ? c : 0;
+    return true;
+}
+NT_DI bool row_live(const nt_sdf_rows_io& io, int r) { return io.shape0[r] >= 0 && io.shape0[r] != io.shape1[r]; }
+// world-space contact points of row r (body-frame records through the body transforms of world w)
+NT_DI void row_points_world(const nt_sdf_scene& sc, const nt_sdf_rows_io& io, const float* __restrict__ body_q, int w, int r, vec3& p0,
+                            vec3& p1) {
+    p0 = ld3(io.point0 + 3 * (size_t)r);
+    p1 = ld3(io.point1 + 3 * (size_t)r);
+    const int b0 = shape_body_of(sc, io.shape0[r], w), b1 = shape_body_of(sc, io.shape1[r], w);
+    if (b0 >= 0) p0 = xform_point(body_xform(body_q, sc.nb, sc.env_stride, b0, w), p0);
+    if (b1 >= 0) p1 = xform_point(body_xform(body_q, sc.nb, sc.env_stride, b1, w), p1);
+}
+// low 32 bits of the reference's sort key (contact_data.py:60-90): shape1's low 9 bits, then the 23-bit sub key (the fingerprint)
+NT_DI unsigned key_low32(const nt_sdf_rows_io& io, int r, int rank) {
+    const unsigned sub = io.key ? (unsigned)io.key[r] : (unsigned)rank;
+    return (((unsigned)io.shape1[r] & 0x1FFu) << 23) | (sub & 0x7FFFFFu);
+}
+// _pack_claim: float_flip(dist_sq) of a non-negative float in the high word, the key bits in the low word
+NT_DI unsigned long long pack_claim(float dist_sq, unsigned key_low) {
+    const unsigned flipped = __float_as_uint(dist_sq) ^ ((unsigned)(-(int)(__float_as_uint(dist_sq) >> 31)) | 0x80000000u);
+    return ((unsigned long long)flipped << 32) | key_low;
+}
+#define NT_FOR_PAIR_GROUPS(sc, g)                                                                                     \
+    for (long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3,                                       \
+                   g##_n = (long long)(sc).env_count * (sc).pairs_per_world;                                          \
+         g < g##_n; g += ((long long)gridDim.x * blockDim.x) >> 3)
+
+// pass 1 (_match_contacts_kernel): the closest previous row of the same shape pair within the thresholds, and a claim on it
+__global__ void __launch_bounds__(256) flat_rows_match_kernel(nt_sdf_scene sc, nt_sdf_rows_io io, const float* __restrict__ body_q,
+                                                              nt_flat_history h, float pos_threshold_sq, float normal_dot_threshold,
+                                                              int32_t* __restrict__ match_index) {
+    const int sub = threadIdx.x & 7;
+    NT_FOR_PAIR_GROUPS(sc, g) {
+        PairBlock b;
+        if (!pair_block(sc, io, (int)g, b)) continue;
+        // the previous frame's block of this shape pair: its world's candidate list is ascending in (shape0, shape1)
+        const size_t base = (size_t)b.w * sc.pairs_per_world;
+        const int n_prev = h.prev_pair_count[b.w];
+        int lo = 0, hi = n_prev;
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            const int a0 = h.prev_world_pairs[2 * (base + mid)], a1 = h.prev_world_pairs[2 * (base + mid) + 1];
+            if (a0 < b.s0 || (a0 == b.s0 && a1 < b.s1)) lo = mid + 1; else hi = mid;
+        }
+        int prow0 = 0, prows = 0;
+        if (lo < n_prev && h.prev_world_pairs[2 * (base + lo)] == b.s0 && h.prev_world_pairs[2 * (base + lo) + 1] == b.s1) {
+            prow0 = h.prev_row_start[b.w] + h.prev_pair_row[base + lo];
+            prows = h.prev_pair_rows[base + lo];
+        }
+        bool any_prev = false;  // the key range of the pair counts contacts, not inert rows
+        for (int j = 0; j < prows && !any_prev; ++j) any_prev = h.prev_live[prow0 + j] != 0;
+        for (int r = b.row0 + sub; r < b.row0 + b.rows; r += 8) {
+            if (!row_live(io, r) || !any_prev) { match_index[r] = MATCH_NOT_FOUND; continue; }
+            vec3 p0, p1;
+            row_points_world(sc, io, body_q, b.w, r, p0, p1);
+            const vec3 pos = 0.5f * (p0 + p1), n = ld3(io.normal + 3 * (size_t)r);
+            int best = -1;
+            float best_dist_sq = pos_threshold_sq;
+            for (int j = prow0; j < prow0 + prows; ++j) {
+                if (!h.prev_live[j]) continue;
+                const vec3 d = pos - ld3(h.prev_pos_world + 3 * (size_t)j);
+                const float dist_sq = dot(d, d);
+                if (dist_sq <= best_dist_sq && dot(n, ld3(h.prev_normal + 3 * (size_t)j)) >= normal_dot_threshold) {
+                    best_dist_sq = dist_sq;
+                    best = j;
+                }
+            }
+            if (best >= 0) {
+                match_index[r] = best;
+                atomicMin(h.prev_claim + best, pack_claim(best_dist_sq, key_low32(io, r, r - b.row0)));
+            } else {
+                match_index[r] = MATCH_BROKEN;
+            }
+        }
+    }
+}
+// pass 2 (_resolve_claims_kernel): the claim word names the winner by its key bits; everyone else is MATCH_BROKEN
+__global__ void __launch_bounds__(256) flat_rows_resolve_kernel(nt_sdf_scene sc, nt_sdf_rows_io io, nt_flat_history h,
+                                                                int32_t* __restrict__ match_index) {
+    const int sub = threadIdx.x & 7;
+    NT_FOR_PAIR_GROUPS(sc, g) {
+        PairBlock b;
+        if (!pair_block(sc, io, (int)g, b)) continue;
+        for (int r = b.row0 + sub; r < b.row0 + b.rows; r += 8) {
+            const int cand = match_index[r];
+            if (cand < 0) continue;
+            if ((unsigned)(h.prev_claim[cand] & 0xFFFFFFFFull) != key_low32(io, r, r - b.row0)) match_index[r] = MATCH_BROKEN;
+        }
+    }
+}
+// _replay_matched_kernel: matched rows that still touch keep the record used last frame
+__global__ void __launch_bounds__(256) flat_rows_replay_kernel(nt_sdf_scene sc, nt_sdf_rows_io io, const float* __restrict__ body_q,
+                                                               nt_flat_history h, const int32_t* __restrict__ match_index) {
+    const int sub = threadIdx.x & 7;
+    NT_FOR_PAIR_GROUPS(sc, g) {
+        PairBlock b;
+        if (!pair_block(sc, io, (int)g, b)) continue;
+        for (int r = b.row0 + sub; r < b.row0 + b.rows; r += 8) {
+            if (!row_live(io, r)) continue;
+            const int m = match_index[r];
+            if (m < 0) continue;
+            vec3 p0, p1;
+            row_points_world(sc, io, body_q, b.w, r, p0, p1);
+            const float fresh_gap = dot(p1 - p0, ld3(io.normal + 3 * (size_t)r)) - (io.margin0[r] + io.margin1[r]);
+            if (fresh_gap > 0.0f) continue;
+            const float* f = h.prev_body_frame + 12 * (size_t)m;
+            st3(io.point0 + 3 * (size_t)r, ld3(f));
+            st3(io.point1 + 3 * (size_t)r, ld3(f + 3));
+            st3(io.offset0 + 3 * (size_t)r, ld3(f + 6));
+            st3(io.offset1 + 3 * (size_t)r, ld3(f + 9));
+            st3(io.normal + 3 * (size_t)r, ld3(h.prev_normal + 3 * (size_t)m));
+        }
+    }
+}
+// _save_sorted_state_kernel: this frame's pair tables, midpoints, normals (and body-frame records) become the history
+__global__ void __launch_bounds__(256) flat_rows_save_kernel(nt_sdf_scene sc, nt_sdf_rows_io io, const float* __restrict__ body_q,
+                                                             nt_flat_history h) {
+    const int sub = threadIdx.x & 7;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w <= sc.env_count; w += gridDim.x * blockDim.x) {
+        h.prev_row_start[w] = io.row_start[w];
+        if (w < sc.env_count) {
+            const int c = io.pair_count[w];
+            h.prev_pair_count[w] = c < sc.pairs_per_world ? c : sc.pairs_per_world;
+        }
+    }
+    NT_FOR_PAIR_GROUPS(sc, g) {
+        PairBlock b;
+        if (!pair_block(sc, io, (int)g, b)) continue;
+        if (sub == 0) {
+            h.prev_world_pairs[2 * (size_t)g] = b.s0;
+            h.prev_world_pairs[2 * (size_t)g + 1] = b.s1;
+            h.prev_pair_row[g] = io.pair_row[g];
+            h.prev_pair_rows[g] = b.rows;
+        }
+        for (int r = b.row0 + sub; r < b.row0 + b.rows; r += 8) {
+            const bool live = row_live(io, r);
+            h.prev_live[r] = live ? 1 : 0;
+            h.prev_claim[r] = CLAIM_SENTINEL;
+            if (!live) continue;
+            vec3 p0, p1;
+            row_points_world(sc, io, body_q, b.w, r, p0, p1);
+            st3(h.prev_pos_world + 3 * (size_t)r, 0.5f * (p0 + p1));
+            st3(h.prev_normal + 3 * (size_t)r, ld3(io.normal + 3 * (size_t)r));
+            if (h.prev_body_frame) {
+                float* f = h.prev_body_frame + 12 * (size_t)r;
+                st3(f, ld3(io.point0 + 3 * (size_t)r));
+                st3(f + 3, ld3(io.point1 + 3 * (size_t)r));
+                st3(f + 6, ld3(io.offset0 + 3 * (size_t)r));
+                st3(f + 9, ld3(io.offset1 + 3 * (size_t)r));
+            }
+        }
+    }
+}
+
 bool scene_ok(const nt_sdf_scene* sc) {
     return sc && sc->env_count > 0 && sc->env_stride >= sc->env_count && sc->nb >= 0 && sc->ns >= 0 && sc->pairs_per_world > 0 &&
            sc->template_pairs >= 0 && (sc->template_pairs == 0 || sc->template_pair) && sc->shape_body && sc->shape_gap;
+}
+
+bool match_args_ok(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, const nt_flat_history* h) {
+    return scene_ok(sc) && io && body_q && h && io->pair_count && io->world_pairs && io->blk && io->pair_row && io->row_start &&
+           io->shape0 && io->shape1 && io->point0 && io->point1 && io->offset0 && io->offset1 && io->normal && io->margin0 &&
+           io->margin1 && io->row_capacity > 0 && h->prev_row_start && h->prev_pair_count && h->prev_world_pairs && h->prev_pair_row &&
+           h->prev_pair_rows && h->prev_live && h->prev_pos_world && h->prev_normal && h->prev_claim &&
+           (!sc->template_kind || sc->world_pair_kind);
+}
+int pair_group_blocks(const nt_sdf_scene* sc) {
+    const long long wb = ((long long)sc->env_count * sc->pairs_per_world * 8 + 255) / 256;
+#ifdef NT_EMULATED_GRID
+    return (int)(wb < NT_EMULATED_GRID ? wb : NT_EMULATED_GRID);
+#else
+    return (int)(wb < 16384 ? wb : 16384);
+#endif
 }
 
 }  // namespace
@@ -448,6 +637,35 @@ nt_status nt_flat_rows_forces(const nt_sdf_scene* sc, const nt_flat_rows* rows, 
         return NT_ERR_INVALID_ARG;
     if (rows->stiffness && (!rows->damping || !rows->friction_scale)) return NT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(flat_rows_forces_kernel, dim3(sc->env_count), dim3(256), 0, (hipStream_t)stream, *sc, *rows, *p);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_flat_rows_match(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, const nt_flat_history* h,
+                             float pos_threshold, float normal_dot_threshold, int32_t* match_index, void* stream) {
+    if (!match_args_ok(sc, io, body_q, h) || !match_index || !(pos_threshold >= 0.0f)) return NT_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(match_index, 0xff, sizeof(int32_t) * (size_t)io->row_capacity, st) != hipSuccess) return NT_ERR_LAUNCH;
+    const int blocks = pair_group_blocks(sc);
+    hipLaunchKernelGGL(flat_rows_match_kernel, dim3(blocks), dim3(256), 0, st, *sc, *io, body_q, *h, pos_threshold * pos_threshold,
+                       normal_dot_threshold, match_index);
+    hipLaunchKernelGGL(flat_rows_resolve_kernel, dim3(blocks), dim3(256), 0, st, *sc, *io, *h, match_index);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_flat_rows_replay_matched(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, const nt_flat_history* h,
+                                      const int32_t* match_index, void* stream) {
+    if (!match_args_ok(sc, io, body_q, h) || !match_index || !h->prev_body_frame) return NT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(flat_rows_replay_kernel, dim3(pair_group_blocks(sc)), dim3(256), 0, (hipStream_t)stream, *sc, *io, body_q, *h,
+                       match_index);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_flat_rows_save_history(const nt_sdf_scene* sc, const nt_sdf_rows_io* io, const float* body_q, const nt_flat_history* h,
+                                    void* stream) {
+    if (!match_args_ok(sc, io, body_q, h)) return NT_ERR_INVALID_ARG;
+    // rows outside this frame's pair blocks are not contacts of the history
+    if (hipMemsetAsync(h->prev_live, 0, (size_t)io->row_capacity, (hipStream_t)stream) != hipSuccess) return NT_ERR_LAUNCH;
+    hipLaunchKernelGGL(flat_rows_save_kernel, dim3(pair_group_blocks(sc)), dim3(256), 0, (hipStream_t)stream, *sc, *io, body_q, *h);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

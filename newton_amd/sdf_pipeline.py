@@ -287,6 +287,7 @@ class SdfLeg:
         _lib.check(lib.nt_sdf_rows_finalize(C.byref(sc), C.byref(io), state._soa["body_q"].data_ptr(), self.world_rows.data_ptr(),
                                             rows.body_blk_start.data_ptr(), rows.body_blk_list.data_ptr(), stream),
                    "nt_sdf_rows_finalize")
+        self._io, self._io_rows = io, rows  # the pair tables + row arrays of this frame, for FlatRowMatcher
 
     def overflow(self, rows: FlatRows) -> dict:
         """Host check (tests / benches, synchronises): did any world exceed its candidate capacity, or the rows their buffer?"""
@@ -325,6 +326,78 @@ class SdfLeg:
         p.shape_material, p.friction_smoothing, p.body_f = self._material.data_ptr(), float(friction_smoothing), body_f.data_ptr()
         d = rows.desc()
         _lib.check(self.lib.nt_flat_rows_forces(C.byref(self.scene), C.byref(d), C.byref(p), stream), "nt_flat_rows_forces")
+
+
+class FlatRowMatcher:
+    """Frame-to-frame matching of the SDF leg's rows (newton/_src/geometry/contact_match.py:602-1055 on the part of the contact
+    list the mesh-SDF kernels produce): nt_flat_rows_match / _replay_matched / _save_history on the (world, pair) row blocks.
+    Results are ROW indices of the previous frame; collide.ContactMatcher maps them into the exported contact order."""
+
+    def __init__(self, leg: "SdfLeg", sticky: bool = False):
+        torch = _torch()
+        self.leg = leg
+        dev, E, PPW, cap = leg.device, leg.t.env_count, leg.pairs_per_world, leg.row_capacity
+        i32, f32 = torch.int32, torch.float32
+        self.prev_row_start = torch.zeros(E + 1, dtype=i32, device=dev)
+        self.prev_pair_count = torch.zeros(E, dtype=i32, device=dev)
+        self.prev_world_pairs = torch.zeros((E * PPW, 2), dtype=i32, device=dev)
+        self.prev_pair_row = torch.zeros(E * PPW, dtype=i32, device=dev)
+        self.prev_pair_rows = torch.zeros(E * PPW, dtype=i32, device=dev)
+        self.prev_live = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.prev_pos_world = torch.zeros((cap, 3), dtype=f32, device=dev)
+        self.prev_normal = torch.zeros((cap, 3), dtype=f32, device=dev)
+        self.prev_claim = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+        self.prev_body_frame = torch.zeros((cap, 12), dtype=f32, device=dev) if sticky else None
+        self.match_index = torch.full((cap,), -1, dtype=i32, device=dev)
+        self.sticky = bool(sticky)
+        h = _lib.nt_flat_history()
+        for k in ("prev_row_start", "prev_pair_count", "prev_world_pairs", "prev_pair_row", "prev_pair_rows", "prev_live",
+                  "prev_pos_world", "prev_normal", "prev_claim"):
+            setattr(h, k, getattr(self, k).data_ptr())
+        if sticky:
+            h.prev_body_frame = self.prev_body_frame.data_ptr()
+        self._h = h
+
+    def reset(self, world_mask=None) -> None:
+        """Forget the history of the selected worlds (all when None): a world without previous pairs matches nothing."""
+        if world_mask is None:
+            self.prev_pair_count.zero_()
+        else:
+            torch = _torch()
+            m = torch.as_tensor(world_mask, device=self.leg.device).bool()[: self.leg.t.env_count]
+            self.prev_pair_count[m] = 0
+
+    def _args(self, state, rows):
+        leg = self.leg
+        if getattr(leg, "_io_rows", None) is not rows:
+            raise ValueError("FlatRowMatcher: collide() has not run on these Contacts")
+        return C.byref(leg.scene), C.byref(leg._io), state._soa["body_q"].data_ptr(), C.byref(self._h)
+
+    def match(self, state, rows, pos_threshold: float, normal_dot_threshold: float):
+        """-> int32 [row_capacity]: previous ROW index, -1 (not found / inert row) or -2 (broken) for every row of this frame."""
+        sc, io, q, h = self._args(state, rows)
+        _lib.check(self.leg.lib.nt_flat_rows_match(sc, io, q, h, float(pos_threshold), float(normal_dot_threshold),
+                                                   self.match_index.data_ptr(), self.leg.dm.stream()), "nt_flat_rows_match")
+        return self.match_index
+
+    def replay_matched(self, state, rows) -> None:
+        sc, io, q, h = self._args(state, rows)
+        _lib.check(self.leg.lib.nt_flat_rows_replay_matched(sc, io, q, h, self.match_index.data_ptr(), self.leg.dm.stream()),
+                   "nt_flat_rows_replay_matched")
+
+    def save_history(self, state, rows) -> None:
+        sc, io, q, h = self._args(state, rows)
+        _lib.check(self.leg.lib.nt_flat_rows_save_history(sc, io, q, h, self.leg.dm.stream()), "nt_flat_rows_save_history")
+
+    def previous_rows_alive(self):
+        """bool [row_capacity]: rows of the previous frame that were contacts and whose world still has its history."""
+        torch = _torch()
+        cap = self.prev_live.numel()
+        world = torch.bucketize(torch.arange(cap, device=self.prev_live.device), self.prev_row_start[1:].to(torch.int64), right=True)
+        E = self.leg.t.env_count
+        has = torch.zeros(E + 1, dtype=torch.bool, device=self.prev_live.device)
+        has[:E] = self.prev_pair_count > 0
+        return (self.prev_live != 0) & has[world.clamp(max=E)]
 
 
 def sdf_pair_shape_types_ok(model) -> None:

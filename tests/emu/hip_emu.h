@@ -145,6 +145,12 @@ inline unsigned int atomicMin(unsigned int* p, unsigned int v) {  // ds_min_u32
     while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
     return old;
 }
+inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) {  // global_atomic_umin_x2
+    unsigned long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
+inline unsigned int __float_as_uint(float f) { unsigned int u; __builtin_memcpy(&u, &f, 4); return u; }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 template <typename K>

@@ -193,3 +193,107 @@ def test_sticky_replay_reproduces_the_reference_matcher(H, name, frames):
         H.check(H.lib().nt_contacts_save_history(C.byref(em.desc), C.byref(ds), C.byref(dc), C.byref(hist), None), "save")
         prev_ids = ids
     assert replayed > 0 or name != "box_stack"
+
+
+def test_row_matcher_thresholds_race_ties_and_inert_rows(H):
+    """nt_flat_rows_match / _save_history / _replay_matched (the SDF legs' rows: contact_match.py:266-391,442-562) on hand-made row
+    blocks, against oracle_match: a static world with three candidate pairs; inert rows inside a block; two new rows racing for one
+    previous row (nearer wins, equal distance -> smaller key bits); a pair that was not a candidate last frame; sticky replay of
+    touching matches only."""
+    import oracle_match as O
+
+    from newton_amd import _lib as L
+
+    lib = H.lib()
+    E, PPW, cap = 1, 4, 32
+    i32, f32 = np.int32, np.float32
+    sc = L.nt_sdf_scene()
+    shape_body = np.full(8, -1, i32)  # all shapes static: body-frame points are world points
+    gap = np.zeros(16, f32)
+    tp = np.zeros((1, 2), i32)
+    gshape = np.zeros(1, i32)
+    sc.env_count, sc.env_stride, sc.nb, sc.ns, sc.shape_local0 = E, 64, 1, 8, 0
+    sc.template_pairs, sc.template_pair, sc.gshape_id = 1, tp.ctypes.data, gshape.ctypes.data
+    sc.shape_body, sc.shape_gap, sc.pairs_per_world = shape_body.ctypes.data, gap.ctypes.data, PPW
+    body_q = np.zeros((7, 1, 64), f32)
+    body_q[6] = 1.0
+
+    def frame(pairs):
+        """pairs: [(s0, s1, [(key, point, normal, live)])] -> the io struct + its arrays"""
+        a = dict(pair_count=np.array([len(pairs)], i32), world_pairs=np.zeros((E * PPW, 2), i32), blk=np.zeros((E * PPW, 2), i32),
+                 pair_row=np.zeros(E * PPW, i32), row_start=np.zeros(E + 1, i32), shape0=np.full(cap, -1, i32),
+                 shape1=np.full(cap, -1, i32), point0=np.zeros((cap, 3), f32), point1=np.zeros((cap, 3), f32),
+                 offset0=np.zeros((cap, 3), f32), offset1=np.zeros((cap, 3), f32), normal=np.zeros((cap, 3), f32),
+                 margin0=np.zeros(cap, f32), margin1=np.zeros(cap, f32), key=np.zeros(cap, i32))
+        r = 0
+        for k, (s0, s1, rows) in enumerate(pairs):
+            a["world_pairs"][k] = (s0, s1)
+            a["blk"][k] = (0, len(rows))
+            a["pair_row"][k] = r
+            for key, pt, nrm, live in rows:
+                if live:
+                    a["shape0"][r], a["shape1"][r] = s0, s1
+                a["point0"][r] = a["point1"][r] = pt
+                a["offset0"][r] = (r, 0, 0)
+                a["normal"][r] = nrm
+                a["key"][r] = key
+                r += 1
+        a["row_start"][1] = r
+        io = L.nt_sdf_rows_io()
+        for k, v in a.items():
+            setattr(io, k, v.ctypes.data)
+        io.raw_capacity, io.row_capacity = 1, cap
+        return io, a
+
+    hist = dict(prev_row_start=np.zeros(E + 1, i32), prev_pair_count=np.zeros(E, i32), prev_world_pairs=np.zeros((E * PPW, 2), i32),
+                prev_pair_row=np.zeros(E * PPW, i32), prev_pair_rows=np.zeros(E * PPW, i32), prev_live=np.zeros(cap, np.uint8),
+                prev_pos_world=np.zeros((cap, 3), f32), prev_normal=np.zeros((cap, 3), f32), prev_body_frame=np.zeros((cap, 12), f32),
+                prev_claim=np.full(cap, -1, np.int64))
+    h = L.nt_flat_history()
+    for k, v in hist.items():
+        setattr(h, k, v.ctypes.data)
+    up, side = (0.0, 0.0, 1.0), (1.0, 0.0, 0.0)
+    prev_pairs = [(1, 2, [(8, (0.0, 0.0, 0.0), up, True), (12, (0.1, 0.0, 0.0), up, False), (16, (0.2, 0.0, 0.0), up, True)]),
+                  (1, 5, [(4, (1.0, 0.0, 0.0), up, True), (8, (1.0, 0.01, 0.0), up, True)]),
+                  (3, 4, [(4, (2.0, 0.0, 0.0), up, True)])]
+    io0, a0 = frame(prev_pairs)
+    H.check(lib.nt_flat_rows_save_history(C.byref(sc), C.byref(io0), body_q.ctypes.data, C.byref(h), None), "save")
+    assert list(hist["prev_live"][:6]) == [1, 0, 1, 1, 1, 1] and np.all(hist["prev_claim"][:6] == -1)
+    new_pairs = [
+        # pair (1,2): row near prev row 0 (0.2 mm), a second row nearer to it (0.1 mm) -> the first loses the race; a row next to
+        # the INERT previous row (no candidate within 0.5 mm -> broken); a row on prev row 2 with a turned normal (broken)
+        (1, 2, [(40, (0.0002, 0.0, 0.0), up, True), (44, (0.0, 0.0001, 0.0), up, True), (48, (0.1, 0.0, 0.0), up, True),
+                (52, (0.2, 0.0, 0.0), side, True)]),
+        # pair (1,5): two rows at equal distance from prev row 3 -> the smaller key wins the tie, the other is broken; an inert row
+        (1, 5, [(24, (1.0, 0.0, 0.0003), up, True), (20, (1.0, 0.0, -0.0003), up, True), (28, (1.0, 0.0, 0.0), up, False)]),
+        # pair (2,6): was not a candidate last frame -> not found;  pair (3,4): matches
+        (2, 6, [(4, (3.0, 0.0, 0.0), up, True)]),
+        (3, 4, [(4, (2.0, 0.0001, 0.0), up, True)])]
+    io1, a1 = frame(new_pairs)
+    m = np.full(cap, -7, i32)
+    H.check(lib.nt_flat_rows_match(C.byref(sc), C.byref(io1), body_q.ctypes.data, C.byref(h), 0.0005, 0.995, m.ctypes.data, None), "match")
+    assert list(m[:9]) == [-2, 0, -2, -2, -2, 3, -1, -1, 5], m[:9]
+    # the oracle on the flat view of the same rows
+    def flat(a):
+        live = np.flatnonzero(a["shape0"] >= 0)
+        keys = np.array([O.sort_key(a["shape0"][r], a["shape1"][r], a["key"][r]) for r in live], np.int64)
+        return live, keys, a["point0"][live], a["normal"][live]
+    pl, pk, pp, pn = flat(a0)
+    nl, nk, npos, nn = flat(a1)
+    want = O.match(nk, npos, nn, pk, pp, pn)
+    assert np.array_equal(np.where(m[nl] >= 0, np.searchsorted(pl, np.maximum(m[nl], 0)), m[nl]), want)
+    # sticky replay: matched rows whose fresh gap <= 0 take the saved record (all margins 0, points coincide: gap = 0 -> replayed)
+    a1["margin0"][8] = -1.0  # row 8's fresh gap becomes +1: it keeps its own record
+    H.check(lib.nt_flat_rows_replay_matched(C.byref(sc), C.byref(io1), body_q.ctypes.data, C.byref(h), m.ctypes.data, None), "replay")
+    assert np.array_equal(a1["point0"][1], a0["point0"][0]) and np.array_equal(a1["offset0"][1], a0["offset0"][0])
+    assert np.array_equal(a1["point0"][5], a0["point0"][3]) and a1["offset0"][5][0] == 3.0
+    assert a1["point0"][8][1] == np.float32(0.0001) and a1["offset0"][8][0] == 8.0  # not replayed
+    assert a1["point0"][0][0] == np.float32(0.0002)  # broken rows keep the fresh record
+    # a world whose history was forgotten (prev_pair_count = 0) matches nothing
+    hist["prev_pair_count"][0] = 0
+    H.check(lib.nt_flat_rows_match(C.byref(sc), C.byref(io1), body_q.ctypes.data, C.byref(h), 0.0005, 0.995, m.ctypes.data, None), "match")
+    assert np.all(m[:9] == -1)
+    # argument checks
+    assert lib.nt_flat_rows_match(C.byref(sc), C.byref(io1), None, C.byref(h), 0.0005, 0.995, m.ctypes.data, None) != 0
+    h.prev_body_frame = None
+    assert lib.nt_flat_rows_replay_matched(C.byref(sc), C.byref(io1), body_q.ctypes.data, C.byref(h), m.ctypes.data, None) != 0

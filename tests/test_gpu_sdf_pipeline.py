@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 
 pytestmark = pytest.mark.gpu
 N_C5 = int(os.environ.get("NT_FULL_SIZE_C5_ENVS", "2048"))  # BASELINE.json config 5's world count
@@ -631,3 +632,159 @@ def test_hydroelastic_rows_inside_collide_and_their_stiffness_in_the_penalty_sol
     ot0, ot1 = OracleState(host), OracleState(host)
     o.semi_implicit_step(ot0, ot1, o.control(), oc2, 1.0e-4)
     assert np.abs(ot1.body_qd - os1.body_qd).max() > 1e-3  # the hydroelastic patches push
+
+
+# ---- frame-to-frame matching over the rows (contact_match.py:266-391,442-562; collide.py:2033-2135) -----------------------------
+def _exported_with_keys(contacts, state, shape_body):
+    """The exported (deterministically ordered) contact list with the reference's sort keys: sub key = sub-contact index for slot
+    contacts (consecutive within a pair), the row fingerprint for the SDF leg's rows."""
+    import oracle_match as O
+
+    n = int(contacts.rigid_contact_count.cpu().numpy()[0])
+    f = {k: getattr(contacts, "rigid_contact_" + k).cpu().numpy()[:n].copy() for k in FIELDS}
+    order = contacts.export_order()
+    raw = order.cpu().numpy()[:n] if order is not None else np.arange(n)
+    n0, live = contacts._flat_n0, contacts._flat_live.cpu().numpy()
+    rowkey = contacts._flat.key.cpu().numpy()
+    pair = f["shape0"].astype(np.int64) * (1 << 32) + f["shape1"]
+    sub = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        if raw[i] >= n0:
+            sub[i] = rowkey[live[raw[i] - n0]]
+        else:
+            sub[i] = sub[i - 1] + 1 if i > 0 and pair[i] == pair[i - 1] else 0
+    keys = np.array([O.sort_key(a, b, k) for a, b, k in zip(f["shape0"], f["shape1"], sub)], dtype=np.int64)
+    assert np.all(np.diff(keys >> 23) >= 0)  # ascending (shape0, shape1): the deterministic order
+    mid = O.midpoints(state.body_q.cpu().numpy(), shape_body, f["shape0"], f["shape1"], f["point0"], f["point1"])
+    return n, keys, mid, f, raw >= n0
+
+
+def test_contact_matching_latest_covers_the_sdf_rows_with_report():
+    """CollisionPipeline(contact_matching="latest", contact_report=True) on a model whose hull-hull pairs take the mesh-SDF leg:
+    rigid_contact_match_index over slot contacts AND rows equals oracle_match on the exported arrays, frame after frame; the
+    new / broken reports follow from it; reset_contact_matching(world_mask) forgets the selected worlds only."""
+    import torch
+
+    import newton_amd as nt
+    import oracle_match as O
+    from sdf_pipeline_checker import sdf_scene
+
+    E = 3
+    model = sdf_scene(E, 5, device="cuda:0", seed=11)
+    _pile(model)
+    pipe = nt.CollisionPipeline(model, broad_phase="sap", contact_matching="latest", contact_report=True,
+                                contact_matching_pos_threshold=0.004, contact_matching_normal_dot_threshold=0.9)
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    s0, s1 = model.state(), model.state()
+    shape_body = np.asarray(model.shape_body)
+    prev = None
+    matched_rows = broken_rows = 0
+    for frame in range(5):
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        torch.cuda.synchronize()
+        n, keys, mid, f, is_row = _exported_with_keys(contacts, s0, shape_body)
+        assert is_row.sum() > 5 and (~is_row).sum() > 0
+        got = contacts.rigid_contact_match_index.cpu().numpy()[:n]
+        new_n = int(contacts.rigid_contact_new_count.cpu().numpy()[0])
+        assert np.array_equal(np.sort(contacts.rigid_contact_new_indices.cpu().numpy()[:new_n]), np.flatnonzero(got < 0))
+        if prev is None:
+            assert np.all(got == -1) and int(contacts.rigid_contact_broken_count.cpu().numpy()[0]) == 0
+        else:
+            want = O.match(keys, mid, f["normal"], *prev, pos_threshold=0.004, normal_dot_threshold=0.9)
+            assert np.array_equal(got, want), (frame, np.flatnonzero(got != want)[:10], got[got != want][:10], want[got != want][:10])
+            matched_rows += int((want[is_row] >= 0).sum())
+            broken_rows += int((want[is_row] == -2).sum())
+            bn = int(contacts.rigid_contact_broken_count.cpu().numpy()[0])
+            broken = np.sort(contacts.rigid_contact_broken_indices.cpu().numpy()[:bn])
+            assert np.array_equal(broken, np.setdiff1d(np.arange(len(prev[0])), want[want >= 0]))
+        prev = (keys, mid, f["normal"])
+        solver.step(s0, s1, None, contacts, 1.0e-3)
+        s0, s1 = s1, s0
+    assert matched_rows > 10, (matched_rows, broken_rows)
+    # forget world 1 only: its contacts (slots and rows) report MATCH_NOT_FOUND, the other worlds keep matching
+    mask = np.array([False, True, False])
+    pipe.reset_contact_matching(mask)
+    s0.clear_forces()
+    pipe.collide(s0, contacts)
+    n, keys, mid, f, is_row = _exported_with_keys(contacts, s0, shape_body)
+    got = contacts.rigid_contact_match_index.cpu().numpy()[:n]
+    world = np.asarray(model.shape_world)[np.maximum(f["shape0"], f["shape1"])]
+    assert np.all(got[world == 1] == -1) and (got[(world != 1) & is_row] >= 0).sum() > 0
+    keep = np.asarray(model.shape_world)[(prev[0] >> 23) & 0xFFFFF] != 1
+    want = O.match(keys, mid, f["normal"], prev[0][keep], prev[1][keep], prev[2][keep], pos_threshold=0.004, normal_dot_threshold=0.9)
+    remap = np.flatnonzero(keep)
+    assert np.array_equal(got, np.where(want >= 0, remap[np.maximum(want, 0)], want))
+    bn = int(contacts.rigid_contact_broken_count.cpu().numpy()[0])
+    assert np.all(keep[contacts.rigid_contact_broken_indices.cpu().numpy()[:bn]])  # rows of the reset world are not "broken"
+    pipe.reset_contact_matching()
+    pipe.collide(s0, contacts)
+    assert np.all(contacts.rigid_contact_match_index.cpu().numpy()[: int(contacts.rigid_contact_count.item())] == -1)
+
+
+def test_contact_matching_sticky_replays_matched_sdf_rows():
+    """contact_matching="sticky" with SDF rows: a matched contact that still touches keeps last frame's body-frame points, offsets
+    and normal (contact_match.py:530-562); everything else is the fresh record (a second, non-sticky pipeline on the same state)."""
+    import torch
+
+    import newton_amd as nt
+    import oracle_match as O
+    from sdf_pipeline_checker import sdf_scene
+
+    E = 2
+    model = sdf_scene(E, 5, device="cuda:0", seed=11)
+    _pile(model)
+    kw = dict(broad_phase="sap", contact_matching_pos_threshold=0.004, contact_matching_normal_dot_threshold=0.9)
+    pipe = nt.CollisionPipeline(model, contact_matching="sticky", **kw)
+    fresh_pipe = nt.CollisionPipeline(model, deterministic=True, broad_phase="sap")
+    contacts, fresh = pipe.contacts(), fresh_pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    s0, s1 = model.state(), model.state()
+    shape_body = np.asarray(model.shape_body)
+    prev = prev_f = None
+    replayed_rows = 0
+    for frame in range(5):
+        s0.clear_forces()
+        fresh_pipe.collide(s0, fresh)
+        pipe.collide(s0, contacts)
+        torch.cuda.synchronize()
+        n, keys, _, f, is_row = _exported_with_keys(contacts, s0, shape_body)
+        nf, fkeys, fmid, ff, _ = _exported_with_keys(fresh, s0, shape_body)
+        assert n == nf and np.array_equal(keys, fkeys)
+        got = contacts.rigid_contact_match_index.cpu().numpy()[:n]
+        if prev is None:
+            assert np.all(got == -1)
+        else:  # matching runs on the fresh records against the records saved (after their own replay) last frame
+            want = O.match(fkeys, fmid, ff["normal"], *prev, pos_threshold=0.004, normal_dot_threshold=0.9)
+            assert np.array_equal(got, want)
+        q = s0.body_q.cpu().numpy()
+        for i in range(n):
+            same = all(np.array_equal(f[k][i], ff[k][i]) for k in FIELDS)
+            if got[i] < 0:
+                assert same, (frame, i)
+                continue
+            p = O.midpoints(q, shape_body, [ff["shape0"][i]] * 2, [ff["shape0"][i], ff["shape1"][i]], [ff["point0"][i]] * 2,
+                            [ff["point0"][i], ff["point1"][i]])  # row 0: p0 world (both points equal), row 1: the midpoint
+            p0w = p[0]
+            p1w = 2.0 * p[1] - p0w
+            gap = float(np.dot(p1w - p0w, ff["normal"][i]) - (ff["margin0"][i] + ff["margin1"][i]))
+            if same and gap > -1e-6:
+                continue
+            assert gap <= 1e-6, (frame, i, gap)
+            for k in ("point0", "point1", "offset0", "offset1", "normal"):
+                assert np.array_equal(f[k][i], prev_f[k][got[i]]), (frame, i, k)
+            replayed_rows += int(is_row[i])
+        mid = O.midpoints(q, shape_body, f["shape0"], f["shape1"], f["point0"], f["point1"])
+        prev, prev_f = (keys, mid, f["normal"]), f
+        solver.step(s0, s1, None, contacts, 1.0e-3)
+        s0, s1 = s1, s0
+    assert replayed_rows > 5, replayed_rows
+
+
+def test_contact_matching_is_refused_for_hydroelastic_pairs():
+    import newton_amd as nt
+
+    model = hydro_scene(2, device="cuda:0")
+    with pytest.raises(NotImplementedError, match="hydroelastic"):
+        nt.CollisionPipeline(model, contact_matching="latest", sdf_hydroelastic_config=nt.geometry.HydroelasticSDF.Config())
