@@ -224,6 +224,12 @@ typedef struct {
     int32_t step_index;
     int32_t force_update;
     float* mass_matrix_cache;
+    /* 0 (default): tree-structured mass matrix -- composite rigid body inertias (H_ij = S_j^T I^c_i S_i for dof j on dof i's root
+     * path, structural zeros elsewhere) and the sparse L^T D L factorisation that follows the dof tree (no fill-in), worked level by
+     * level by the whole workgroup; within the 1e-5 single-step contract of the reference's dense path, not bit-identical to it.
+     * 1: the reference's own operation order -- H = J^T (M J) over the dense lower triangle, dense_cholesky, dense_subs
+     * (kernels.py:1466-1501,1690-1797), the same role use_tile_gemm / fuse_cholesky play in the reference constructor. */
+    int32_t dense_mass_matrix;
 } nt_featherstone_params;
 
 typedef struct {

@@ -194,7 +194,8 @@ class nt_semi_implicit_params(C.Structure):
 
 class nt_featherstone_params(C.Structure):
     _fields_ = [("angular_damping", C.c_float), ("friction_smoothing", C.c_float), ("update_mass_matrix_interval", C.c_int32),
-                ("step_index", C.c_int32), ("force_update", C.c_int32), ("mass_matrix_cache", C.c_void_p)]
+                ("step_index", C.c_int32), ("force_update", C.c_int32), ("mass_matrix_cache", C.c_void_p),
+                ("dense_mass_matrix", C.c_int32)]
 
 
 class nt_collide_params(C.Structure):

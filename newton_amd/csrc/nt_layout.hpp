@@ -228,6 +228,7 @@ struct FsLayout {
     int bfx;                          // external wrench buffer body_f_ext [6][nb]
     int cw;                           // contact wrenches [CW_FLOATS][np*cpp]        (union with P/H)
     int P, H;                         // P[b][jl] = I_b S_j [6][nb][W];  H / L [nd][W]
+    int Ic, Pd;                       // tree-structured mass matrix (in the P region): composite inertias [36][nb], I^c S_d [6][nd]
     int rows;
 };
 __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsLayout& L) {
@@ -251,8 +252,11 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
     F.bfx = o; o += 6 * m.nb;
     F.cw = o;
     F.P = o;
-    F.H = F.P + 6 * m.nb * m.max_art_dofs;
-    int solve = 6 * m.nb * m.max_art_dofs + m.nd * m.max_art_dofs;
+    F.Ic = F.P;
+    F.Pd = F.P + 36 * m.nb;
+    const int pregion = imax(6 * m.nb * m.max_art_dofs, 36 * m.nb + 6 * m.nd);
+    F.H = F.P + pregion;
+    int solve = pregion + m.nd * m.max_art_dofs;
     int contacts = NC_CW * m.np * m.cpp;
     // the fused rollout runs the collide phases on this union too (shape transforms / AABBs, pair counts, manifold polygon
     // scratch, staged candidates)
@@ -266,5 +270,12 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
 // each dof (nd), and per joint a bit mask of the joints on its root path, itself included (nj * ceil(nj / 32))
 __host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }
 // then per joint whether the end-of-step refresh of descendant FREE / DISTANCE joints reaches it (nj) and whether any does (1)
-__host__ __device__ inline int fs_topo_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m) + m.nj + 1; }
+__host__ __device__ inline int fs_topo_base_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m) + m.nj + 1; }
+// then the dof tree of the tree-structured factorisation: per dof a bit mask of its ancestor dofs, itself included
+// (nd * ceil(nd / 32)), depth (nd), parent dof (nd), first dof of the dof's articulation (nd), the dofs ordered by depth (nd) with the level starts
+// (nd + 2), deepest level (1)
+__host__ __device__ inline int fs_dof_words(const nt_model& m) { return (m.nd + 31) / 32; }
+__host__ __device__ inline int fs_topo_ints(const nt_model& m) {
+    return fs_topo_base_ints(m) + m.nd * fs_dof_words(m) + 5 * m.nd + 3;
+}
 

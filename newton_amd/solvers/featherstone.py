@@ -22,8 +22,14 @@ from .solver import SolverBase
 class SolverFeatherstone(SolverBase):
     def __init__(self, model, *, angular_damping: float = 0.05, update_mass_matrix_interval: int = 1,
                  friction_smoothing: float = 1.0, use_tile_gemm: bool = False, fuse_cholesky: bool = True,
-                 envs_per_block: int = 0):
+                 envs_per_block: int = 0, mass_matrix: str = "tree"):
         super().__init__(model)
+        # "tree" (default): composite-inertia H and the dof-tree L^T D L factorisation (nt_featherstone_params.dense_mass_matrix
+        # = 0; same solution within the 1e-5 contract); "dense": the reference's operation order (H = J^T M J over the dense
+        # lower triangle, dense_cholesky, dense_subs), as close to the reference's bits as the kernels get
+        if mass_matrix not in ("tree", "dense"):
+            raise ValueError(f"mass_matrix must be 'tree' or 'dense', got {mass_matrix!r}")
+        self.mass_matrix = mass_matrix
         t = model.env
         if int(update_mass_matrix_interval) < 1:
             raise ValueError("update_mass_matrix_interval must be >= 1")
@@ -72,6 +78,7 @@ class SolverFeatherstone(SolverBase):
 
     def _params(self):
         p = _lib.nt_featherstone_params(float(self.angular_damping), float(self.friction_smoothing))
+        p.dense_mass_matrix = 1 if self.mass_matrix == "dense" else 0
         if self._factor_cache is not None:
             p.update_mass_matrix_interval, p.step_index = self.update_mass_matrix_interval, self._step
             p.force_update, p.mass_matrix_cache = int(self._mass_matrix_dirty), self._factor_cache.data_ptr()

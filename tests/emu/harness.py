@@ -209,16 +209,19 @@ def semi_implicit_step(em, s_in, s_out, control, contacts, dt, epb=0, angular_da
                                       C.byref(dct) if dct is not None else None, float(dt), epb, None), "nt_semi_implicit_step")
 
 
-def featherstone_step(em, s_in, s_out, control, contacts, dt, epb=0, angular_damping=0.05, friction_smoothing=1.0):
+def featherstone_step(em, s_in, s_out, control, contacts, dt, epb=0, angular_damping=0.05, friction_smoothing=1.0, dense=False):
     p = L.nt_featherstone_params(angular_damping, friction_smoothing)
+    p.dense_mass_matrix = int(dense)
     di, do_, dc = s_in.desc(), s_out.desc(), control.desc()
     dct = contacts.desc() if contacts is not None else None
     check(lib().nt_featherstone_step(C.byref(em.desc), C.byref(p), C.byref(di), C.byref(do_), C.byref(dc),
                                      C.byref(dct) if dct is not None else None, float(dt), epb, None), "nt_featherstone_step")
 
 
-def featherstone_rollout(em, s0, s1, control, contacts, dt, substeps, epb=0, angular_damping=0.05, friction_smoothing=1.0):
+def featherstone_rollout(em, s0, s1, control, contacts, dt, substeps, epb=0, angular_damping=0.05, friction_smoothing=1.0,
+                         dense=False):
     p, cp = L.nt_featherstone_params(angular_damping, friction_smoothing), L.nt_collide_params(0, epb)
+    p.dense_mass_matrix = int(dense)
     d0, d1, dc, dct = s0.desc(), s1.desc(), control.desc(), contacts.desc()
     check(lib().nt_featherstone_rollout(C.byref(em.desc), C.byref(p), C.byref(cp), C.byref(d0), C.byref(d1), C.byref(dc),
                                         C.byref(dct), float(dt), int(substeps), None), "nt_featherstone_rollout")

@@ -125,8 +125,10 @@ def test_c3_4096_quadrupeds_featherstone_frame_vs_oracle():
     assert np.array_equal(contacts.rigid_contact_count_per_env.cpu().numpy(), _per_env_counts(model, oc))
 
 
-def test_c3_4096_quadrupeds_featherstone_frame_with_live_contacts():
-    """Config C3 at full size WITH contacts: the feet of all 4096 robots pressed into the ground, the 10 substeps of one frame.
+@pytest.mark.parametrize("mass_matrix", ["tree", "dense"])
+def test_c3_4096_quadrupeds_featherstone_frame_with_live_contacts(mass_matrix):
+    """(Both mass-matrix modes of SolverFeatherstone: the default tree-structured one and the reference's dense operation order,
+    at the same gates.)  Config C3 at full size WITH contacts: the feet of all 4096 robots pressed into the ground, the 10 substeps of one frame.
     SolverFeatherstone's contacts are explicit penalty forces (ke ~ 1e4 on light feet): they amplify a rounding difference 3 - 10x
     per substep (tests/test_gpu_parity_featherstone.py::test_quadruped_impact_phase_stepwise; measured here: an open-loop frame
     ends 1.4e-3 apart in joint_q), so the frame is compared substep by substep from the oracle's state -- every substep on
@@ -141,7 +143,7 @@ def test_c3_4096_quadrupeds_featherstone_frame_with_live_contacts():
     s0, s1 = model.state(), model.state()
     pipe = nt.CollisionPipeline(model)
     contacts = pipe.contacts()
-    solver = nt.solvers.SolverFeatherstone(model)
+    solver = nt.solvers.SolverFeatherstone(model, mass_matrix=mass_matrix)
     os0, os1 = OracleState(model), OracleState(model)
     oc, c = o.contacts(), o.control()
     for k in range(10):
@@ -165,7 +167,7 @@ def test_c3_4096_quadrupeds_featherstone_frame_with_live_contacts():
         worst = int(np.argmax(ev))
         info = dict(step=k, q_max=float(eq.max()), v_max=float(ev.max()), q_out=int((eq > 1e-5).sum()), v_out=int((ev > 5e-4).sum()),
                     worst_env=worst, worst_env_speed=float(np.abs(wv[worst]).max()))
-        print("[c3 live contacts]", info)
+        print(f"[c3 live contacts, mass_matrix={mass_matrix}]", info)
         assert (eq > 1e-5).sum() <= 0.002 * E and (ev > 5e-4).sum() <= 0.002 * E, info
         assert eq.max() <= 2e-4 and ev.max() <= 0.05, info
         assert _rel(s1.body_q.cpu().numpy(), os1.body_q) <= 2e-4, k
