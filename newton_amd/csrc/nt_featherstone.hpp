@@ -27,11 +27,11 @@ struct FsCtx {
     const unsigned* childmask;     // [nj][words] joints whose parent body is this joint's child
     const int* refresh;            // [nj] joint index >= first descendant FREE / DISTANCE joint of its articulation; [nj] = any
     int words;
-    // dof tree of the tree-structured factorisation (fs_build_tables): ancestor masks, depth, parent, first dof of the articulation,
-    // dofs ordered by depth with the level starts, deepest level
-    const unsigned* dmask;
-    const int *ddepth, *dpar, *dof0, *lvl_list, *lvl_start;
-    int dwords, dmaxd;
+    // dof tree of the tree-structured factorisation (fs_build_tables; nt_layout.hpp fs_topo_ints): 64-bit masks as (lo, hi) pairs
+    const unsigned *t_below, *t_above, *t_lvl, *t_jbelow;
+    const int *ddepth, *rowbase, *ent;
+    int nnz, dmaxd;
+    bool tree_ok;
     NT_DI FsCtx(const Ctx<EPB>& c_, int* extra) : c(c_) {
         F = make_fs_layout(c.a.m, c.L);
         const int nj = c.a.m.nj;
@@ -44,18 +44,19 @@ struct FsCtx {
         childmask = pathmask + nj * words;
         refresh = reinterpret_cast<const int*>(childmask + nj * words);
         const int nd = c.a.m.nd;
+        tree_ok = fs_tree_ok(c.a.m);
         const int* tr = extra + fs_topo_base_ints(c.a.m);
-        dwords = fs_dof_words(c.a.m);
-        dmask = reinterpret_cast<const unsigned*>(tr);
-        ddepth = tr + nd * dwords;
-        dpar = ddepth + nd;
-        dof0 = dpar + nd;
-        lvl_list = dof0 + nd;
-        lvl_start = lvl_list + nd;
-        dmaxd = lvl_start[nd + 2];
+        t_below = reinterpret_cast<const unsigned*>(tr);
+        t_above = t_below + 2 * nd;
+        t_lvl = t_above + 2 * nd;
+        t_jbelow = t_lvl + 2 * (nd + 1);
+        ddepth = reinterpret_cast<const int*>(t_jbelow + 2 * nj);
+        rowbase = ddepth + nd;
+        nnz = tree_ok ? rowbase[nd] : 0;
+        dmaxd = tree_ok ? rowbase[nd + 1] : 0;
+        ent = rowbase + nd + 2;
     }
-    // is dof `j` on the root path of dof `i` (or `i` itself)?
-    NT_DI bool dof_anc(int j, int i) const { return (dmask[i * dwords + (j >> 5)] >> (j & 31)) & 1u; }
+    static NT_DI unsigned long long m64(const unsigned* p, int i) { return (unsigned long long)p[2 * i] | ((unsigned long long)p[2 * i + 1] << 32); }
     // FREE / DISTANCE joint below the root whose child is dynamic (solver_featherstone.py:229-237)
     NT_DI bool descendant_free(int j) const {
         const int t = c.T.joint_type[j];
@@ -579,17 +580,19 @@ NT_DI void fs_H_item(const FsCtx<EPB>& f, int item) {
 // joint-space inertia and the same solution up to rounding (the 1e-5 contract), with the work of a 4-legged 18-dof robot cut
 // from 171 dense entries x 13 bodies and 18 sequential pivots to 117 entries and 9 dof-tree levels worked by the whole workgroup.
 
-// I^c_l = sum of I_b over the bodies b whose root path holds joint l (ascending b); item = l * 36 + r
+// I^c_l = sum of I_b over the bodies b of joint l's subtree (ascending b); item = l * 36 + r
 template <int EPB>
 NT_DI void fs_Ic_item(const FsCtx<EPB>& f, int item) {
     const Ctx<EPB>& c = f.c;
-    const nt_model& m = c.a.m;
-    const int nb = m.nb;
+    const int nb = c.a.m.nb;
     const int l = item / 36, r = item - l * 36;
-    const int art_j1 = m.art_start[f.art[l] + 1];
+    unsigned long long sub = f.m64(f.t_jbelow, l);
     float sum = 0.0f;
-    for (int b = l; b < art_j1; ++b)
-        if (f.on_path(l, b)) sum += c.l(f.F.Is, r, nb, b);
+    while (sub) {
+        const int b = __ffsll((long long)sub) - 1;
+        sub &= sub - 1;
+        sum += c.l(f.F.Is, r, nb, b);
+    }
     c.l(f.F.Ic, r, nb, l) = sum;
 }
 // Pd[d] = I^c_joint(d) S_d; item = d * 6 + i
@@ -606,108 +609,29 @@ NT_DI void fs_Pd_item(const FsCtx<EPB>& f, int item) {
     for (int k = 0; k < 6; ++k) sum += c.l(f.F.Ic, i * 6 + k, nb, l) * fs_sget(S, k);
     c.l(f.F.Pd, i, nd, d) = sum;
 }
-// H[i][jl] = S_j^T Pd[i] (+ armature on the diagonal) for dof j on dof i's root path, zero elsewhere; item = i * W + jl
+// H[i][j] = S_j^T Pd[i] (+ armature on the diagonal) for the entries (i, j): dof j on dof i's root path; the structural zeros of
+// the lower triangle are never stored or read
 template <int EPB>
-NT_DI void fs_Ht_item(const FsCtx<EPB>& f, int item) {
+NT_DI void fs_Ht_item(const FsCtx<EPB>& f, int e) {
     const Ctx<EPB>& c = f.c;
-    const nt_model& m = c.a.m;
-    const int W = m.max_art_dofs, nd = m.nd;
-    const int i = item / W, jl = item - i * W;
-    const int j = f.dof0[i] + jl;
-    if (j > i) return;
+    const int nd = c.a.m.nd;
+    const int en = f.ent[e], i = en & 255, j = en >> 8;
+    const spatial S_j = f.sp6(f.F.S, nd, j);
     float h = 0.0f;
-    if (f.dof_anc(j, i)) {
-        const spatial S_j = f.sp6(f.F.S, nd, j);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) h += fs_sget(S_j, r) * c.l(f.F.Pd, r, nd, i);
-        if (j == i) h += c.dof(DP_ARMATURE, i);
+    for (int r = 0; r < 6; ++r) h += fs_sget(S_j, r) * c.l(f.F.Pd, r, nd, i);
+    if (j == i) {
+        h += c.dof(DP_ARMATURE, i);
+        if (f.m64(f.t_below, i) == 0ull) h = 1.0f / h;  // a leaf dof: D_i is final as built (fs_solve_tree keeps 1 / D on the diagonal)
     }
-    c.l(f.F.H, 0, 1, i * W + jl) = h;
+    c.l(f.F.H, 0, 1, f.rowbase[i] + j) = h;
 }
-// L^T D L in place (row i keeps U[i][j] = D_i L[i][j] for the dofs j above i, the diagonal 1 / D_i) and the three substitutions,
-// every dof-tree level a workgroup phase: entries of shallower rows collect the updates of the level's dofs in ascending dof order,
-// so the result does not depend on the lane count.  Called by every thread of the workgroup (barriers inside).
-template <int EPB>
-NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
-    const Ctx<EPB>& c = f.c;
-    const nt_model& m = c.a.m;
-    const int W = m.max_art_dofs, nd = m.nd, maxd = f.dmaxd;
-    float* lds = c.lds;
-    const int e = c.e;
-    auto A = [&](int i, int j) -> float& { return lds[(f.F.H + i * W + (j - f.dof0[i])) * EPB + e]; };  // j on i's root path
-    auto X = [&](int i) -> float& { return lds[(f.F.qdd + i) * EPB + e]; };
-    if (factor) {
-        if (c.valid)
-            for (int t = f.lvl_start[maxd] + c.slot; t < f.lvl_start[maxd + 1]; t += c.nslot) {
-                const int k = f.lvl_list[t];
-                A(k, k) = 1.0f / A(k, k);
-            }
-        __syncthreads();
-        for (int d = maxd; d >= 1; --d) {
-            const int k0 = f.lvl_start[d], k1 = f.lvl_start[d + 1];
-            if (c.valid)
-                for (int item = c.slot; item < nd * W; item += c.nslot) {
-                    const int i = item / W, j = f.dof0[i] + (item - i * W);
-                    if (j > i || f.ddepth[i] >= d || !f.dof_anc(j, i)) continue;
-                    float h = A(i, j);
-                    bool touched = false;
-                    for (int t = k0; t < k1; ++t) {
-                        const int k = f.lvl_list[t];
-                        if (f.dof_anc(i, k)) {  // k is at a deeper level: a strict descendant
-                            h -= A(k, i) * A(k, j) * A(k, k);
-                            touched = true;
-                        }
-                    }
-                    if (i == j && f.ddepth[i] == d - 1) {  // every deeper level has been subtracted: D_i is final
-                        h = 1.0f / h;
-                        touched = true;
-                    }
-                    if (touched) A(i, j) = h;
-                }
-            __syncthreads();
-        }
-    }
-    // L^T y = tau, leaves first
-    if (c.valid)
-        for (int i = c.slot; i < nd; i += c.nslot) X(i) = f.f(f.F.tau, i);
-    __syncthreads();
-    for (int d = maxd; d >= 1; --d) {
-        const int k0 = f.lvl_start[d], k1 = f.lvl_start[d + 1];
-        if (c.valid)
-            for (int j = c.slot; j < nd; j += c.nslot) {
-                if (f.ddepth[j] >= d) continue;
-                float s = X(j);
-                bool touched = false;
-                for (int t = k0; t < k1; ++t) {
-                    const int k = f.lvl_list[t];
-                    if (f.dof_anc(j, k)) {
-                        s -= A(k, j) * (A(k, k) * X(k));
-                        touched = true;
-                    }
-                }
-                if (touched) X(j) = s;
-            }
-        __syncthreads();
-    }
-    // x_i = (y_i - sum over the dofs j above i of U[i][j] x_j) / D_i, root first
-    for (int d = 0; d <= maxd; ++d) {
-        if (c.valid)
-            for (int t = f.lvl_start[d] + c.slot; t < f.lvl_start[d + 1]; t += c.nslot) {
-                const int i = f.lvl_list[t];
-                float s = X(i);
-                for (int j = f.dpar[i]; j >= 0; j = f.dpar[j]) s -= A(i, j) * X(j);
-                X(i) = s * A(i, i);
-            }
-        __syncthreads();
-    }
-}
-
-// dense_cholesky (in place over the lower triangle of H) + dense_subs for one articulation (kernels.py:1690-1797),
-// worked by the G = 64 / EPB slot-lanes of the environment that share wavefront 0 (tid = env + EPB * slot): the lanes
-// run in lockstep, LDS operations of one wave complete in order, so a value written by one lane is visible to the
-// others at the next instruction without a workgroup barrier.  Row i belongs to lane i % G.  Every sum runs in the
-// reference's order (k ascending), so the factor and the solution are bit-identical to the serial algorithm.
-// compiler-level ordering of LDS traffic between lanes of one wave (no hardware barrier is needed: see below)
+// L^T D L in place (row i keeps U[i][j] = D_i L[i][j] for the dofs j above i, the diagonal 1 / D_i) and the three substitutions.
+// Every dof-tree level is one workgroup phase, leaves first: the rows of the level's dofs are final, so an entry of a shallower row
+// collects their updates (bit scan of descendants & level, ascending dof order: the result does not depend on the lane count) and,
+// in the same phase, y = L^-T tau collects the level's terms.  The last substitution walks root to leaves on the lanes an
+// environment owns in wavefront 0 (tid = env + EPB * slot), ordered by wave-level fences like fs_solve_coop below.
+// Called by every thread of the workgroup (barriers inside).
 #ifndef FS_WAVE_SYNC_DEFINED
 #define FS_WAVE_SYNC_DEFINED
 #define FS_WAVE_SYNC()                                        \
@@ -716,6 +640,81 @@ NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
         __builtin_amdgcn_wave_barrier();                      \
     } while (0)
 #endif
+template <int EPB>
+NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nd = m.nd, maxd = f.dmaxd, nnz = f.nnz;
+    float* lds = c.lds;
+    const int e = c.e;
+    auto A = [&](int off) -> float& { return lds[(f.F.H + off) * EPB + e]; };  // off = rowbase[i] + j, j on i's root path
+    auto X = [&](int i) -> float& { return lds[(f.F.qdd + i) * EPB + e]; };
+    if (c.valid)
+        for (int i = c.slot; i < nd; i += c.nslot) X(i) = f.f(f.F.tau, i);
+    __syncthreads();
+    for (int d = maxd; d >= 1; --d) {
+        const unsigned long long at = f.m64(f.t_lvl, d);
+        if (c.valid) {
+            for (int t = c.slot; factor && t < nnz; t += c.nslot) {
+                const int en = f.ent[t], i = en & 255, j = en >> 8;
+                unsigned long long ks = f.m64(f.t_below, i) & at;
+                if (!ks) continue;
+                const int off = f.rowbase[i] + j;
+                float h = A(off);
+                while (ks) {
+                    const int k = __ffsll((long long)ks) - 1;
+                    ks &= ks - 1;
+                    const int rb = f.rowbase[k];
+                    h -= A(rb + i) * A(rb + j) * A(rb + k);  // the diagonal of a finished row holds 1 / D_k
+                }
+                // the dofs directly above this level have now collected every level below them: D_i is final
+                if (i == j && f.ddepth[i] == d - 1) h = 1.0f / h;
+                A(off) = h;
+            }
+            // L^T y = tau: y_j -= sum over the level's dofs k below j of L[k][j] y_k, L[k][j] = U[k][j] / D_k
+            for (int j = c.slot; j < nd; j += c.nslot) {
+                unsigned long long ks = f.m64(f.t_below, j) & at;
+                if (!ks) continue;
+                float s = X(j);
+                while (ks) {
+                    const int k = __ffsll((long long)ks) - 1;
+                    ks &= ks - 1;
+                    const int rb = f.rowbase[k];
+                    s -= A(rb + j) * (A(rb + k) * X(k));
+                }
+                X(j) = s;
+            }
+        }
+        __syncthreads();
+    }
+    // x_i = (y_i - sum over the dofs j above i of U[i][j] x_j) / D_i, root first, on wavefront 0
+    const int G = (64 / EPB) < c.nslot ? (64 / EPB) : c.nslot;
+    if (c.valid && c.slot < G)
+        for (int d = 0; d <= maxd; ++d) {
+            const unsigned long long at = f.m64(f.t_lvl, d);
+            for (int i = c.slot; i < nd; i += G) {
+                if (!((at >> i) & 1ull)) continue;
+                const int rb = f.rowbase[i];
+                unsigned long long up = f.m64(f.t_above, i);
+                float s = X(i);
+                while (up) {
+                    const int j = __ffsll((long long)up) - 1;
+                    up &= up - 1;
+                    s -= A(rb + j) * X(j);
+                }
+                X(i) = s * A(rb + i);
+            }
+            FS_WAVE_SYNC();
+        }
+}
+
+// dense_cholesky (in place over the lower triangle of H) + dense_subs for one articulation (kernels.py:1690-1797),
+// worked by the G = 64 / EPB slot-lanes of the environment that share wavefront 0 (tid = env + EPB * slot): the lanes
+// run in lockstep, LDS operations of one wave complete in order, so a value written by one lane is visible to the
+// others at the next instruction without a workgroup barrier.  Row i belongs to lane i % G.  Every sum runs in the
+// reference's order (k ascending), so the factor and the solution are bit-identical to the serial algorithm.
+// compiler-level ordering of LDS traffic between lanes of one wave (no hardware barrier is needed: see below)
+// (FS_WAVE_SYNC, defined above fs_solve_tree)
 
 // factor = false: H holds the factor of an earlier step (update_mass_matrix_interval > 1), only the substitutions run
 template <int EPB>
@@ -1043,13 +1042,17 @@ NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
         }
     }
     __syncthreads();
-    {   // the dof tree: a joint's dofs form a chain, its first dof hangs below the last dof of the nearest ancestor joint that has any
-        const int nd = m.nd, dw = fs_dof_words(m);
-        int* tr = extra + fs_topo_base_ints(m);
-        unsigned* dmask = reinterpret_cast<unsigned*>(tr);
-        int *ddepth = tr + nd * dw, *dpar = ddepth + nd, *dof0 = dpar + nd, *lvl_list = dof0 + nd, *lvl_start = lvl_list + nd;
+    if (fs_tree_ok(m)) {  // the dof tree: a joint's dofs form a chain, its first dof hangs below the last dof of the nearest ancestor
+                          // joint that has any
+        const int nd = m.nd, W = m.max_art_dofs;
+        unsigned* below = reinterpret_cast<unsigned*>(extra + fs_topo_base_ints(m));
+        unsigned *above = below + 2 * nd, *lvl = above + 2 * nd, *jbelow = lvl + 2 * (nd + 1);
+        int *ddepth = reinterpret_cast<int*>(jbelow + 2 * nj), *rowbase = ddepth + nd, *ent = rowbase + nd + 2;
+        int* dpar = ent;  // scratch until the entries are written
         const int* dof_joint = extra + 3 * nj;
         auto qd_end = [&](int k) { return k + 1 < nj ? c.T.joint_qd_start[k + 1] : nd; };
+        auto put64 = [](unsigned* p, int i, unsigned long long v) { p[2 * i] = (unsigned)v; p[2 * i + 1] = (unsigned)(v >> 32); };
+        auto get64 = [](const unsigned* p, int i) { return (unsigned long long)p[2 * i] | ((unsigned long long)p[2 * i + 1] << 32); };
         for (int d = threadIdx.x; d < nd; d += blockDim.x) {
             const int j = dof_joint[d];
             int p = d - 1;
@@ -1059,35 +1062,60 @@ NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
                 p = k >= 0 ? qd_end(k) - 1 : -1;
             }
             dpar[d] = p;
-            dof0[d] = c.T.joint_qd_start[m.art_start[extra[2 * nj + j]]];
         }
         __syncthreads();
         for (int d = threadIdx.x; d < nd; d += blockDim.x) {
-            unsigned* mask = dmask + d * dw;
-            for (int w = 0; w < dw; ++w) mask[w] = 0u;
-            mask[d >> 5] |= 1u << (d & 31);
+            unsigned long long up = 0ull;
             int depth = 0;
             for (int k = dpar[d]; k >= 0; k = dpar[k]) {
                 depth += 1;
-                mask[k >> 5] |= 1u << (k & 31);
+                up |= 1ull << k;
             }
+            put64(above, d, up);
             ddepth[d] = depth;
         }
         __syncthreads();
-        for (int d = threadIdx.x; d < nd; d += blockDim.x) {  // counting sort by depth, ascending dof index within a level
-            int rank = 0;
-            for (int k = 0; k < nd; ++k) rank += (ddepth[k] < ddepth[d] || (ddepth[k] == ddepth[d] && k < d)) ? 1 : 0;
-            lvl_list[rank] = d;
+        for (int d = threadIdx.x; d < nd; d += blockDim.x) {
+            unsigned long long down = 0ull;
+            for (int k = 0; k < nd; ++k)
+                if ((get64(above, k) >> d) & 1ull) down |= 1ull << k;
+            put64(below, d, down);
+            rowbase[d] = d * W - c.T.joint_qd_start[m.art_start[extra[2 * nj + dof_joint[d]]]];
         }
-        for (int l = threadIdx.x; l <= nd + 1; l += blockDim.x) {
-            int below = 0;
-            for (int k = 0; k < nd; ++k) below += ddepth[k] < l ? 1 : 0;
-            lvl_start[l] = below;
+        for (int l = threadIdx.x; l <= nd; l += blockDim.x) {
+            unsigned long long at = 0ull;
+            for (int k = 0; k < nd; ++k)
+                if (ddepth[k] == l) at |= 1ull << k;
+            put64(lvl, l, at);
         }
+        for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+            const unsigned* pm = reinterpret_cast<const unsigned*>(extra + 3 * nj + m.nd);
+            const int words = fs_mask_words(m);
+            unsigned long long sub = 0ull;
+            for (int b = 0; b < nj; ++b)
+                if ((pm[b * words + (j >> 5)] >> (j & 31)) & 1u) sub |= 1ull << b;
+            put64(jbelow, j, sub);
+        }
+        __syncthreads();  // (dpar is dead from here on: the entries overwrite it)
         if (threadIdx.x == 0) {
-            int mx = 0;
-            for (int k = 0; k < nd; ++k) mx = ddepth[k] > mx ? ddepth[k] : mx;
-            lvl_start[nd + 2] = mx;
+            int mx = 0, cnt = 0;
+            for (int k = 0; k < nd; ++k) {
+                mx = ddepth[k] > mx ? ddepth[k] : mx;
+                cnt += ddepth[k] + 1;
+            }
+            rowbase[nd] = cnt;
+            rowbase[nd + 1] = mx;
+        }
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+            int off = 0;
+            for (int k = 0; k < i; ++k) off += ddepth[k] + 1;
+            unsigned long long up = get64(above, i);
+            while (up) {
+                const int j = __ffsll((long long)up) - 1;
+                up &= up - 1;
+                ent[off++] = i | (j << 8);
+            }
+            ent[off] = i | (i << 8);
         }
         __syncthreads();
     }
@@ -1176,7 +1204,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     const int W = m.max_art_dofs;
     const bool update_mass = fs_update_mass(c, substep);
     float* cache = a.fp.mass_matrix_cache;
-    const bool tree = a.fp.dense_mass_matrix == 0;  // block-uniform
+    const bool tree = a.fp.dense_mass_matrix == 0 && f.tree_ok;  // block-uniform
     if (update_mass && tree) {
         if (c.valid && !NT_SKIP(16))
             for (int i = c.slot; i < nj * 36; i += c.nslot) fs_Ic_item(f, i);
@@ -1186,7 +1214,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         __syncthreads();
         NT_TICK(16);
         if (c.valid && !NT_SKIP(32))
-            for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_Ht_item(f, i);
+            for (int i = c.slot; i < f.nnz; i += c.nslot) fs_Ht_item(f, i);
     } else if (update_mass) {
         if (c.valid && !NT_SKIP(16))
             for (int i = c.slot; i < nj * W; i += c.nslot) fs_P_item(f, i);

@@ -271,11 +271,13 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
 __host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }
 // then per joint whether the end-of-step refresh of descendant FREE / DISTANCE joints reaches it (nj) and whether any does (1)
 __host__ __device__ inline int fs_topo_base_ints(const nt_model& m) { return 3 * m.nj + m.nd + 2 * m.nj * fs_mask_words(m) + m.nj + 1; }
-// then the dof tree of the tree-structured factorisation: per dof a bit mask of its ancestor dofs, itself included
-// (nd * ceil(nd / 32)), depth (nd), parent dof (nd), first dof of the dof's articulation (nd), the dofs ordered by depth (nd) with the level starts
-// (nd + 2), deepest level (1)
-__host__ __device__ inline int fs_dof_words(const nt_model& m) { return (m.nd + 31) / 32; }
+// then the dof tree of the tree-structured factorisation (models with at most 64 dofs and 64 joints; larger ones take the dense
+// path): 64-bit masks as (lo, hi) pairs -- per dof its strict descendants and strict ancestors, per level its dofs, per joint the
+// joints of its subtree --, per dof its depth and the offset of its H row, {entry count, deepest level}, and the non-zero entries
+// (i, j) of H's lower triangle packed as i | j << 8
+__host__ __device__ inline bool fs_tree_ok(const nt_model& m) { return m.nd >= 1 && m.nd <= 64 && m.nj <= 64; }
 __host__ __device__ inline int fs_topo_ints(const nt_model& m) {
-    return fs_topo_base_ints(m) + m.nd * fs_dof_words(m) + 5 * m.nd + 3;
+    const int tree = fs_tree_ok(m) ? 4 * m.nd + 2 * (m.nd + 1) + 2 * m.nj + 2 * m.nd + 2 + m.nd * (m.nd + 1) / 2 : 0;
+    return fs_topo_base_ints(m) + tree;
 }
 

@@ -40,7 +40,7 @@ s0, s1 = model.state(), model.state()
 pipe = nt.CollisionPipeline(model)
 contacts = pipe.contacts()
 FS = len(sys.argv) > 1 and sys.argv[1] == "featherstone"
-solver = nt.solvers.SolverFeatherstone(model) if FS else nt.solvers.SolverXPBD(model, iterations=4 if BOX else 2)
+solver = nt.solvers.SolverFeatherstone(model, mass_matrix=(sys.argv[2] if len(sys.argv) > 2 else "tree")) if FS else nt.solvers.SolverXPBD(model, iterations=4 if BOX else 2)
 for _ in range(100):
     solver.rollout(s0, s1, None, contacts, 1e-3, 10)
 torch.cuda.synchronize()
@@ -54,7 +54,7 @@ torch.cuda.synchronize()
 raw.nt_debug_phase_clocks(buf)
 if FS:
     names = {10: "collide (+ previous tail)", 11: "FK", 12: "to internal qd", 13: "RNEA forward (pre + levels)", 14: "contacts + f_ext",
-             15: "RNEA backward (tau)", 16: "P = I S", 17: "H = S^T P", 18: "Cholesky + solve", 19: "integrate", 20: "FK + velocities",
+             15: "RNEA backward (tau)", 16: "P = I S (tree: I^c, I^c S)", 17: "H", 18: "factorise + solve", 19: "integrate", 20: "FK + velocities",
              21: "to public qd"}
     tot = sum(buf[i] for i in names)
     for i in sorted(names):
