@@ -588,10 +588,21 @@ NT_DI void fs_Ic_item(const FsCtx<EPB>& f, int item) {
     const int l = item / 36, r = item - l * 36;
     unsigned long long sub = f.m64(f.t_jbelow, l);
     float sum = 0.0f;
-    while (sub) {
-        const int b = __ffsll((long long)sub) - 1;
-        sub &= sub - 1;
-        sum += c.l(f.F.Is, r, nb, b);
+    while (sub) {  // four bodies per round: the loads are issued together, the additions stay in ascending body order
+        int b[4];
+        bool on[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            on[q] = sub != 0ull;
+            b[q] = on[q] ? __ffsll((long long)sub) - 1 : l;
+            sub &= sub - 1;  // (0 stays 0)
+        }
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = c.l(f.F.Is, r, nb, b[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (on[q]) sum += v[q];
     }
     c.l(f.F.Ic, r, nb, l) = sum;
 }
@@ -644,45 +655,82 @@ template <int EPB>
 NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
-    const int nd = m.nd, maxd = f.dmaxd, nnz = f.nnz;
+    const int nd = m.nd, W = m.max_art_dofs, maxd = f.dmaxd, nnz = f.nnz;
     float* lds = c.lds;
     const int e = c.e;
     auto A = [&](int off) -> float& { return lds[(f.F.H + off) * EPB + e]; };  // off = rowbase[i] + j, j on i's root path
     auto X = [&](int i) -> float& { return lds[(f.F.qdd + i) * EPB + e]; };
+    const bool single = m.na == 1;  // one articulation: row k of H starts at k * W
+    auto row = [&](int k) { return single ? k * W : f.rowbase[k]; };
+    // the entries and the dof this lane owns, decoded once per step (the tables are block-shared LDS: a dependent read per level
+    // and entry was most of the first version's time)
+    constexpr int TE = 2;
+    const bool cached = nnz <= TE * c.nslot && nd <= c.nslot;
+    int e_i[TE], e_j[TE], e_off[TE], e_dd[TE];
+    unsigned long long e_below[TE];
+#pragma unroll
+    for (int u = 0; u < TE; ++u) {
+        const int t = c.slot + u * c.nslot;
+        const bool on = cached && t < nnz;
+        const int en = on ? f.ent[t] : 0;
+        e_i[u] = en & 255;
+        e_j[u] = en >> 8;
+        e_below[u] = on ? f.m64(f.t_below, e_i[u]) : 0ull;
+        e_off[u] = row(e_i[u]) + e_j[u];
+        e_dd[u] = e_i[u] == e_j[u] ? f.ddepth[e_i[u]] : -2;
+    }
+    const int my = c.slot < nd ? c.slot : 0;
+    const unsigned long long my_below = (cached && c.slot < nd) ? f.m64(f.t_below, my) : 0ull;
+    // one update of entry (i, j) [or of y_j when i < 0] by the dofs `ks` of the current level, two dofs per round
+    auto collect = [&](float h, unsigned long long ks, int i, int j) {
+        while (ks) {
+            const int k0 = __ffsll((long long)ks) - 1;
+            ks &= ks - 1;
+            const bool two = ks != 0ull;
+            const int k1 = two ? __ffsll((long long)ks) - 1 : k0;
+            ks &= ks - 1;
+            const int r0 = row(k0), r1 = row(k1);
+            if (i >= 0) {
+                const float a0 = A(r0 + i), b0 = A(r0 + j), d0 = A(r0 + k0), a1 = A(r1 + i), b1 = A(r1 + j), d1 = A(r1 + k1);
+                h -= a0 * b0 * d0;  // the diagonal of a finished row holds 1 / D_k
+                if (two) h -= a1 * b1 * d1;
+            } else {
+                const float b0 = A(r0 + j), d0 = A(r0 + k0), x0 = X(k0), b1 = A(r1 + j), d1 = A(r1 + k1), x1 = X(k1);
+                h -= b0 * (d0 * x0);
+                if (two) h -= b1 * (d1 * x1);
+            }
+        }
+        return h;
+    };
     if (c.valid)
         for (int i = c.slot; i < nd; i += c.nslot) X(i) = f.f(f.F.tau, i);
     __syncthreads();
     for (int d = maxd; d >= 1; --d) {
         const unsigned long long at = f.m64(f.t_lvl, d);
-        if (c.valid) {
+        if (c.valid && cached) {
+#pragma unroll
+            for (int u = 0; u < TE; ++u) {
+                const unsigned long long ks = e_below[u] & at;
+                if (!factor || !ks) continue;
+                float h = collect(A(e_off[u]), ks, e_i[u], e_j[u]);
+                if (e_dd[u] == d - 1) h = 1.0f / h;  // the dofs directly above this level have collected every level below: D_i is final
+                A(e_off[u]) = h;
+            }
+            const unsigned long long ks = my_below & at;
+            if (ks) X(my) = collect(X(my), ks, -1, my);  // L^T y = tau: y_j -= sum of L[k][j] y_k, L[k][j] = U[k][j] / D_k
+        } else if (c.valid) {
             for (int t = c.slot; factor && t < nnz; t += c.nslot) {
                 const int en = f.ent[t], i = en & 255, j = en >> 8;
-                unsigned long long ks = f.m64(f.t_below, i) & at;
+                const unsigned long long ks = f.m64(f.t_below, i) & at;
                 if (!ks) continue;
-                const int off = f.rowbase[i] + j;
-                float h = A(off);
-                while (ks) {
-                    const int k = __ffsll((long long)ks) - 1;
-                    ks &= ks - 1;
-                    const int rb = f.rowbase[k];
-                    h -= A(rb + i) * A(rb + j) * A(rb + k);  // the diagonal of a finished row holds 1 / D_k
-                }
-                // the dofs directly above this level have now collected every level below them: D_i is final
+                const int off = row(i) + j;
+                float h = collect(A(off), ks, i, j);
                 if (i == j && f.ddepth[i] == d - 1) h = 1.0f / h;
                 A(off) = h;
             }
-            // L^T y = tau: y_j -= sum over the level's dofs k below j of L[k][j] y_k, L[k][j] = U[k][j] / D_k
             for (int j = c.slot; j < nd; j += c.nslot) {
-                unsigned long long ks = f.m64(f.t_below, j) & at;
-                if (!ks) continue;
-                float s = X(j);
-                while (ks) {
-                    const int k = __ffsll((long long)ks) - 1;
-                    ks &= ks - 1;
-                    const int rb = f.rowbase[k];
-                    s -= A(rb + j) * (A(rb + k) * X(k));
-                }
-                X(j) = s;
+                const unsigned long long ks = f.m64(f.t_below, j) & at;
+                if (ks) X(j) = collect(X(j), ks, -1, j);
             }
         }
         __syncthreads();
@@ -694,13 +742,24 @@ NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
             const unsigned long long at = f.m64(f.t_lvl, d);
             for (int i = c.slot; i < nd; i += G) {
                 if (!((at >> i) & 1ull)) continue;
-                const int rb = f.rowbase[i];
+                const int rb = row(i);
                 unsigned long long up = f.m64(f.t_above, i);
                 float s = X(i);
-                while (up) {
-                    const int j = __ffsll((long long)up) - 1;
-                    up &= up - 1;
-                    s -= A(rb + j) * X(j);
+                while (up) {  // four ancestors per round, ascending
+                    int j[4];
+                    bool on[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        on[q] = up != 0ull;
+                        j[q] = on[q] ? __ffsll((long long)up) - 1 : i;
+                        up &= up - 1;
+                    }
+                    float a[4], x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a[q] = A(rb + j[q]); x[q] = X(j[q]); }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (on[q]) s -= a[q] * x[q];
                 }
                 X(i) = s * A(rb + i);
             }
