@@ -1,4 +1,4 @@
-"""ctypes binding of libnewton_hip.so (the C ABI declared in include/newton_hip.h).
+"""ctypes binding of libnewton_hip.so (the C ABI declared in include/newton_hip.h and include/newton_hip_broadphase.h).
 
 The product path has NO CPU fallback: if the shared library is missing or cannot be loaded, every
 solver / collision entry point raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``.
@@ -118,6 +118,11 @@ class nt_broadphase_in(C.Structure):
                 ("shape_body", C.c_void_p), ("body_flags", C.c_void_p)]
 
 
+class nt_broadphase_motion(C.Structure):
+    """include/newton_hip_broadphase.h: per-shape displacement of the swept broad phases."""
+    _fields_ = [("displacement", C.c_void_p), ("sort_axis_displacement_limit", C.c_float)]
+
+
 class nt_sdf(C.Structure):
     _fields_ = [("coarse", C.c_void_p), ("subgrid", C.c_void_p), ("slots", C.c_void_p), ("cx", C.c_int32), ("cy", C.c_int32),
                 ("cz", C.c_int32), ("tex_size", C.c_int32), ("subgrid_size", C.c_int32), ("quantization", C.c_int32),
@@ -202,7 +207,7 @@ class nt_collide_params(C.Structure):
     _fields_ = [("broad_phase", C.c_int32), ("envs_per_block", C.c_int32)]
 
 
-# every symbol include/newton_hip.h declares: name -> (restype, argtypes)
+# every symbol include/*.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 class nt_newton_model(C.Structure):
     """Flat newton.Model arrays handed to nt_model_create (host pointers), include/newton_hip.h."""
@@ -312,6 +317,13 @@ SYMBOLS = {
     "nt_broadphase_sap_device": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                                _P, _P, C.c_int32, _P]),
     "nt_broadphase_explicit": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, C.c_int32, _P, _P, C.c_int32, _P]),
+    # include/newton_hip_broadphase.h
+    "nt_broadphase_nxn_swept": (C.c_int32, [C.POINTER(nt_broadphase_in), C.POINTER(nt_broadphase_motion), _P, _P, C.c_int32, C.c_int32,
+                                            C.c_int32, _P, _P, C.c_int32, _P]),
+    "nt_broadphase_sap_device_swept": (C.c_int32, [C.POINTER(nt_broadphase_in), C.POINTER(nt_broadphase_motion), _P, _P, C.c_int32,
+                                                   C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
+    "nt_broadphase_explicit_swept": (C.c_int32, [C.POINTER(nt_broadphase_in), C.POINTER(nt_broadphase_motion), _P, C.c_int32, _P, _P,
+                                                 C.c_int32, _P]),
     "nt_error_string": (C.c_char_p, [C.c_int32]),
     "nt_build_info": (C.c_char_p, []),
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),

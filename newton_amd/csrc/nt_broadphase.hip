@@ -9,10 +9,14 @@
 // the i-side AABB stays in registers.  SAP walks a map sorted by the x interval start inside each segment and stops at the
 // first later shape whose interval starts past its own end.  Candidate pairs are appended through one wave-aggregated
 // atomic per wave and iteration; the counter keeps counting past capacity like the reference (broad_phase_common.py:204-218).
+// Swept mode (the *_swept entry points, include/newton_hip_broadphase.h): with a per-shape displacement the pair test is
+// check_aabb_overlap_moving (broad_phase_common.py:41-85) and the SAP interval of a shape is extended by its (capped)
+// displacement along the sort axis (_sap_project_aabb, broad_phase_sap.py:44-79) -- the speculative-contact broad phase.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/newton_hip.h"
+#include "../../include/newton_hip_broadphase.h"
 
 #define NT_BP_HD __host__ __device__
 #include "nt_broadphase_core.hpp"
@@ -90,7 +94,7 @@ __global__ void __launch_bounds__(256) broadphase_segment_kernel(BpArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int SAP_TILE = 4096;  // shapes per world segment that fit the LDS sort (32 KB of keys + positions)
 
-__device__ inline void sap_project(const BpView& v, int s, float& lo, float& hi) {
+__device__ inline void sap_project(const BpView& v, int s, float limit, float& lo, float& hi) {
     const float dx = 0.5935f, dy = 0.7790f, dz = 0.1235f;
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     const float ax = dx * inv, ay = dy * inv, az = dz * inv;
@@ -102,11 +106,18 @@ __device__ inline void sap_project(const BpView& v, int s, float& lo, float& hi)
     const float center = ax * (0.5f * (l[0] + u[0])) + ay * (0.5f * (l[1] + u[1])) + az * (0.5f * (l[2] + u[2]));
     lo = center - radius;
     hi = center + radius;
+    if (v.displacement) {  // swept interval: the shape's own motion along the axis, capped by sort_axis_displacement_limit
+        const float* d = v.displacement + 3 * s;
+        float pd = ax * d[0] + ay * d[1] + az * d[2];
+        if (limit >= 0.0f) pd = fminf(fmaxf(pd, -limit), limit);
+        lo += fminf(pd, 0.0f);
+        hi += fmaxf(pd, 0.0f);
+    }
 }
 
 __global__ void __launch_bounds__(256) sap_sort_kernel(BpView v, const int32_t* __restrict__ map, const int32_t* __restrict__ slice_ends,
                                                        int32_t* __restrict__ sorted_map, float* __restrict__ proj /*[2][map_len]*/,
-                                                       int map_len) {
+                                                       int map_len, float limit) {
     __shared__ float key[SAP_TILE];
     __shared__ int pos[SAP_TILE];
     const int seg = blockIdx.x;
@@ -117,7 +128,7 @@ __global__ void __launch_bounds__(256) sap_sort_kernel(BpView v, const int32_t* 
     while (np2 < n) np2 <<= 1;
     for (int i = threadIdx.x; i < np2; i += blockDim.x) {
         float lo = 1.0e30f, hi;
-        if (i < n) sap_project(v, map[begin + i], lo, hi);
+        if (i < n) sap_project(v, map[begin + i], limit, lo, hi);
         key[i] = lo;
         pos[i] = i;
     }
@@ -142,7 +153,7 @@ __global__ void __launch_bounds__(256) sap_sort_kernel(BpView v, const int32_t* 
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int s = map[begin + pos[i]];
         float lo, hi;
-        sap_project(v, s, lo, hi);
+        sap_project(v, s, limit, lo, hi);
         sorted_map[begin + i] = s;
         proj[begin + i] = lo;
         proj[map_len + begin + i] = hi;
@@ -189,7 +200,7 @@ __global__ void __launch_bounds__(256) broadphase_explicit_kernel(BpView v, cons
     if (t < n_pairs) {
         s1 = list[2 * t];
         s2 = list[2 * t + 1];
-        hit = !bp_immovable_filtered(v, s1, s2) && bp_overlap(v, s1, s2);
+        hit = !bp_immovable_filtered(v, s1, s2) && bp_overlap_moving(v, s1, s2);
     }
     bp_append(hit, s1, s2, pairs, count, cap);
 }
@@ -199,8 +210,9 @@ bool bp_in_ok(const nt_broadphase_in* in) {
            (in->num_filter_pairs == 0 || in->filter_pairs);
 }
 
-BpView make_view(const nt_broadphase_in* in) {
+BpView make_view(const nt_broadphase_in* in, const nt_broadphase_motion* motion = nullptr) {
     BpView v;
+    v.displacement = motion ? motion->displacement : nullptr;
     v.lower = in->lower; v.upper = in->upper; v.gap = in->gap; v.group = in->group; v.world = in->world;
     v.filter_pairs = in->filter_pairs; v.num_filter_pairs = in->num_filter_pairs;
     v.shape_body = in->shape_body; v.body_flags = in->body_flags;
@@ -209,18 +221,48 @@ BpView make_view(const nt_broadphase_in* in) {
 }
 
 template <bool SAP>
-nt_status launch_segments(const nt_broadphase_in* in, const int32_t* map, const int32_t* slice_ends, int32_t segments,
+nt_status launch_segments(const nt_broadphase_in* in, const nt_broadphase_motion* motion, const int32_t* map, const int32_t* slice_ends, int32_t segments,
                           int32_t num_regular, int32_t map_len, int32_t* pairs, int32_t* count, int32_t cap, void* stream) {
     if (!bp_in_ok(in) || !count || cap < 0 || (cap > 0 && !pairs) || segments < 0 || map_len < 0) return NT_ERR_INVALID_ARG;
     if (map_len == 0 || segments == 0) return NT_OK;
     if (!map || !slice_ends) return NT_ERR_INVALID_ARG;
     BpArgs a;
-    a.v = make_view(in);
+    a.v = make_view(in, motion);
     a.map = map; a.slice_ends = slice_ends; a.segments = segments; a.num_regular = num_regular; a.map_len = map_len;
     a.pairs = pairs; a.count = count; a.cap = cap;
     hipLaunchKernelGGL(broadphase_segment_kernel<SAP>, dim3((map_len + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
+
+nt_status sap_device(const nt_broadphase_in* in, const nt_broadphase_motion* motion, const int32_t* index_map,
+                     const int32_t* slice_ends, int32_t segments, int32_t num_regular_worlds, int32_t map_len, int32_t max_segment,
+                     int32_t* sorted_map, float* projections, int32_t* pairs, int32_t* count, int32_t cap, void* stream) {
+    if (!bp_in_ok(in) || !count || cap < 0 || (cap > 0 && !pairs) || segments < 0 || map_len < 0) return NT_ERR_INVALID_ARG;
+    if (map_len == 0 || segments == 0) return NT_OK;
+    if (!index_map || !slice_ends || !sorted_map || !projections) return NT_ERR_INVALID_ARG;
+    if (max_segment > SAP_TILE) return NT_ERR_UNSUPPORTED;  // a world with more shapes than the LDS sort tile
+    BpArgs a;
+    a.v = make_view(in, motion);
+    a.map = sorted_map; a.slice_ends = slice_ends; a.segments = segments; a.num_regular = num_regular_worlds; a.map_len = map_len;
+    a.pairs = pairs; a.count = count; a.cap = cap;
+    const float limit = motion ? motion->sort_axis_displacement_limit : -1.0f;
+    hipLaunchKernelGGL(sap_sort_kernel, dim3(segments), dim3(256), 0, (hipStream_t)stream, a.v, index_map, slice_ends, sorted_map,
+                       projections, map_len, limit);
+    hipLaunchKernelGGL(sap_sweep_kernel, dim3((map_len + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, projections);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status explicit_pairs(const nt_broadphase_in* in, const nt_broadphase_motion* motion, const int32_t* pair_list, int32_t n_pairs,
+                         int32_t* pairs, int32_t* count, int32_t cap, void* stream) {
+    if (!in || !in->lower || !in->upper || !count || n_pairs < 0 || cap < 0 || (cap > 0 && !pairs)) return NT_ERR_INVALID_ARG;
+    if (n_pairs == 0) return NT_OK;
+    if (!pair_list) return NT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(broadphase_explicit_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       make_view(in, motion), pair_list, n_pairs, pairs, count, cap);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+bool motion_ok(const nt_broadphase_motion* m) { return m && m->displacement; }
 
 }  // namespace
 
@@ -229,41 +271,49 @@ extern "C" {
 nt_status nt_broadphase_nxn(const nt_broadphase_in* in, const int32_t* index_map, const int32_t* slice_ends, int32_t segments,
                             int32_t num_regular_worlds, int32_t map_len, int32_t* pairs, int32_t* count, int32_t cap,
                             void* stream) {
-    return launch_segments<false>(in, index_map, slice_ends, segments, num_regular_worlds, map_len, pairs, count, cap, stream);
+    return launch_segments<false>(in, nullptr, index_map, slice_ends, segments, num_regular_worlds, map_len, pairs, count, cap, stream);
 }
 
 nt_status nt_broadphase_sap(const nt_broadphase_in* in, const int32_t* sorted_map, const int32_t* slice_ends, int32_t segments,
                             int32_t num_regular_worlds, int32_t map_len, int32_t* pairs, int32_t* count, int32_t cap,
                             void* stream) {
-    return launch_segments<true>(in, sorted_map, slice_ends, segments, num_regular_worlds, map_len, pairs, count, cap, stream);
+    return launch_segments<true>(in, nullptr, sorted_map, slice_ends, segments, num_regular_worlds, map_len, pairs, count, cap, stream);
 }
 
 nt_status nt_broadphase_sap_device(const nt_broadphase_in* in, const int32_t* index_map, const int32_t* slice_ends,
                                    int32_t segments, int32_t num_regular_worlds, int32_t map_len, int32_t max_segment,
                                    int32_t* sorted_map, float* projections, int32_t* pairs, int32_t* count, int32_t cap,
                                    void* stream) {
-    if (!bp_in_ok(in) || !count || cap < 0 || (cap > 0 && !pairs) || segments < 0 || map_len < 0) return NT_ERR_INVALID_ARG;
-    if (map_len == 0 || segments == 0) return NT_OK;
-    if (!index_map || !slice_ends || !sorted_map || !projections) return NT_ERR_INVALID_ARG;
-    if (max_segment > SAP_TILE) return NT_ERR_UNSUPPORTED;  // a world with more shapes than the LDS sort tile
-    BpArgs a;
-    a.v = make_view(in);
-    a.map = sorted_map; a.slice_ends = slice_ends; a.segments = segments; a.num_regular = num_regular_worlds; a.map_len = map_len;
-    a.pairs = pairs; a.count = count; a.cap = cap;
-    hipLaunchKernelGGL(sap_sort_kernel, dim3(segments), dim3(256), 0, (hipStream_t)stream, a.v, index_map, slice_ends, sorted_map,
-                       projections, map_len);
-    hipLaunchKernelGGL(sap_sweep_kernel, dim3((map_len + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, projections);
-    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+    return sap_device(in, nullptr, index_map, slice_ends, segments, num_regular_worlds, map_len, max_segment, sorted_map,
+                      projections, pairs, count, cap, stream);
 }
 
 nt_status nt_broadphase_explicit(const nt_broadphase_in* in, const int32_t* pair_list, int32_t n_pairs, int32_t* pairs,
                                  int32_t* count, int32_t cap, void* stream) {
-    if (!in || !in->lower || !in->upper || !count || n_pairs < 0 || cap < 0 || (cap > 0 && !pairs)) return NT_ERR_INVALID_ARG;
-    if (n_pairs == 0) return NT_OK;
-    if (!pair_list) return NT_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(broadphase_explicit_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, make_view(in),
-                       pair_list, n_pairs, pairs, count, cap);
-    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+    return explicit_pairs(in, nullptr, pair_list, n_pairs, pairs, count, cap, stream);
+}
+
+// ---- swept variants (include/newton_hip_broadphase.h) ----
+nt_status nt_broadphase_nxn_swept(const nt_broadphase_in* in, const nt_broadphase_motion* motion, const int32_t* index_map,
+                                  const int32_t* slice_ends, int32_t segments, int32_t num_regular_worlds, int32_t map_len,
+                                  int32_t* pairs, int32_t* count, int32_t cap, void* stream) {
+    if (!motion_ok(motion)) return NT_ERR_INVALID_ARG;
+    return launch_segments<false>(in, motion, index_map, slice_ends, segments, num_regular_worlds, map_len, pairs, count, cap, stream);
+}
+
+nt_status nt_broadphase_sap_device_swept(const nt_broadphase_in* in, const nt_broadphase_motion* motion, const int32_t* index_map,
+                                         const int32_t* slice_ends, int32_t segments, int32_t num_regular_worlds, int32_t map_len,
+                                         int32_t max_segment, int32_t* sorted_map, float* projections, int32_t* pairs,
+                                         int32_t* count, int32_t cap, void* stream) {
+    if (!motion_ok(motion)) return NT_ERR_INVALID_ARG;
+    return sap_device(in, motion, index_map, slice_ends, segments, num_regular_worlds, map_len, max_segment, sorted_map,
+                      projections, pairs, count, cap, stream);
+}
+
+nt_status nt_broadphase_explicit_swept(const nt_broadphase_in* in, const nt_broadphase_motion* motion, const int32_t* pair_list,
+                                       int32_t n_pairs, int32_t* pairs, int32_t* count, int32_t cap, void* stream) {
+    if (!motion_ok(motion)) return NT_ERR_INVALID_ARG;
+    return explicit_pairs(in, motion, pair_list, n_pairs, pairs, count, cap, stream);
 }
 
 }  // extern "C"

@@ -2,6 +2,7 @@
 // (tools/broadphase_host_check.cpp) can run the very same lane program on the CPU, without a GPU.
 //   test_group_pair / test_world_and_group_pair   newton/_src/geometry/broad_phase_common.py:220-268
 //   check_aabb_overlap                            broad_phase_common.py:20-38
+//   check_aabb_overlap_moving                     broad_phase_common.py:41-85 (swept AABBs of the speculative-contact mode)
 //   is_pair_excluded                              broad_phase_common.py:132-162
 //   is_shape_pair_immovable_filtered              broad_phase_common.py:165-201
 #pragma once
@@ -22,6 +23,7 @@ struct BpView {
     const int32_t* shape_body;  // nullptr: no immovable filtering
     const int32_t* body_flags;  // nullptr: static-static only
     int32_t include_static_kinematic_pairs;
+    const float* displacement;  // [n][3] world-space motion over the collision-update interval, or nullptr (static test)
 };
 
 NT_BP_HD inline bool bp_group_pair(int a, int b) {
@@ -67,6 +69,36 @@ NT_BP_HD inline bool bp_overlap(const BpView& v, int s1, int s2) {
            u1[2] >= l2[2] - c;
 }
 
+// Swept test: do the two gap-widened boxes overlap at ONE time of the unit interval while each translates by its own
+// displacement?  Slab clipping of the relative motion per axis, in the reference's operand order (box1 = the smaller index).
+NT_BP_HD inline bool bp_overlap_moving(const BpView& v, int s1, int s2) {
+    if (!v.displacement) return bp_overlap(v, s1, s2);
+    float c = 0.0f;
+    if (v.gap) c = v.gap[s1] + v.gap[s2];
+    const float *l1 = v.lower + 3 * s1, *u1 = v.upper + 3 * s1, *l2 = v.lower + 3 * s2, *u2 = v.upper + 3 * s2;
+    const float *d1 = v.displacement + 3 * s1, *d2 = v.displacement + 3 * s2;
+    float enter = 0.0f, exit_time = 1.0f;
+    for (int axis = 0; axis < 3; ++axis) {
+        const float lower1 = l1[axis], upper1 = u1[axis];
+        const float lower2 = l2[axis] - c, upper2 = u2[axis] + c;
+        const float delta = d1[axis] - d2[axis];
+        if (delta == 0.0f) {
+            if (lower1 > upper2 || upper1 < lower2) return false;
+        } else {
+            float axis_enter = (lower2 - upper1) / delta, axis_exit = (upper2 - lower1) / delta;
+            if (axis_enter > axis_exit) {
+                const float tmp = axis_enter;
+                axis_enter = axis_exit;
+                axis_exit = tmp;
+            }
+            enter = enter > axis_enter ? enter : axis_enter;  // wp.max / wp.min
+            exit_time = exit_time < axis_exit ? exit_time : axis_exit;
+            if (enter > exit_time) return false;
+        }
+    }
+    return true;
+}
+
 // full candidate test of the N x N / SAP kernels for two shapes of one world segment (broad_phase_nxn.py:172-218);
 // on success (s1, s2) is the canonical pair
 NT_BP_HD inline bool bp_candidate(const BpView& v, int sa, int sb, bool dedicated_global_segment, int& s1, int& s2) {
@@ -76,7 +108,7 @@ NT_BP_HD inline bool bp_candidate(const BpView& v, int sa, int sb, bool dedicate
     if (w1 == -1 && w2 == -1 && !dedicated_global_segment) return false;
     if (!bp_world_and_group_pair(w1, w2, v.group[s1], v.group[s2])) return false;
     if (bp_immovable_filtered(v, s1, s2)) return false;
-    if (!bp_overlap(v, s1, s2)) return false;
+    if (!bp_overlap_moving(v, s1, s2)) return false;
     if (v.num_filter_pairs > 0 && bp_excluded(v, s1, s2)) return false;
     return true;
 }

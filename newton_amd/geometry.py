@@ -94,10 +94,14 @@ class _BroadPhaseBase:
     def _view(self, lower, upper, gap, group, world, filter_pairs, num_filter_pairs, shape_body, body_flags,
               include_static_kinematic_pairs, shape_displacement):
         torch = _torch()
-        if shape_displacement is not None and shape_displacement.numel() > 0:
-            raise NotImplementedError("swept AABB tests (shape_displacement) are not implemented")
         v = _lib.nt_broadphase_in()
         keep = [_check(lower, torch.float32, "shape_lower"), _check(upper, torch.float32, "shape_upper")]
+        if shape_displacement is not None:
+            # broad_phase_nxn.py:389-393,511-515 / broad_phase_sap.py:722-726: one displacement per shape bound
+            if shape_displacement.shape[0] != lower.shape[0]:
+                raise ValueError("shape_displacement length must match the shape bounds "
+                                 f"({lower.shape[0]}), got {shape_displacement.shape[0]}")
+            keep.append(_check(shape_displacement, torch.float32, "shape_displacement"))
         v.lower, v.upper = lower.data_ptr(), upper.data_ptr()
         if gap is not None and gap.numel() > 0:
             keep.append(_check(gap, torch.float32, "shape_gap"))
@@ -123,6 +127,25 @@ class _BroadPhaseBase:
                 keep.append(_check(body_flags, torch.int32, "body_flags"))
                 v.body_flags = body_flags.data_ptr()
         return v, keep
+
+    @staticmethod
+    def _motion(shape_displacement, sort_axis_displacement_limit=None):
+        """-> nt_broadphase_motion for the *_swept entry points (include/newton_hip_broadphase.h), or None for the static test
+        (no array, or no shapes: check_aabb_overlap_moving falls back to check_aabb_overlap on an empty array,
+        broad_phase_common.py:51-54)."""
+        if sort_axis_displacement_limit is None:
+            limit = -1.0  # broad_phase_sap.py:727-728: uncapped
+        else:
+            if not np.isfinite(sort_axis_displacement_limit) or sort_axis_displacement_limit < 0.0:
+                raise ValueError("sort_axis_displacement_limit must be a non-negative finite number, "
+                                 f"got {sort_axis_displacement_limit!r}")
+            limit = float(sort_axis_displacement_limit)
+        if shape_displacement is None or shape_displacement.numel() == 0:
+            return None
+        m = _lib.nt_broadphase_motion()
+        m.displacement = shape_displacement.data_ptr()
+        m.sort_axis_displacement_limit = limit
+        return m
 
     @staticmethod
     def _out(candidate_pair, candidate_pair_count, skip_count_zero):
@@ -165,10 +188,12 @@ class BroadPhaseAllPairs(_BroadPhaseBase):
         v, keep = self._view(shape_lower, shape_upper, shape_gap, shape_collision_group, shape_world, filter_pairs,
                              num_filter_pairs, shape_body, body_flags, include_static_kinematic_pairs, shape_displacement)
         m = self._map_for_launch(keep, shape_lower, shape_gap)
-        fn = getattr(self._lib, self._entry)
-        _lib.check(fn(C.byref(v), m.data_ptr(), self.world_slice_ends.data_ptr(), int(self.world_slice_ends.shape[0]),
-                      int(self.num_regular_worlds), int(m.shape[0]), candidate_pair.data_ptr(),
-                      candidate_pair_count.data_ptr(), cap, self._stream()), self._entry)
+        motion = self._motion(shape_displacement)
+        entry = self._entry if motion is None else self._entry + "_swept"
+        head = (C.byref(v),) if motion is None else (C.byref(v), C.byref(motion))
+        _lib.check(getattr(self._lib, entry)(*head, m.data_ptr(), self.world_slice_ends.data_ptr(),
+                                             int(self.world_slice_ends.shape[0]), int(self.num_regular_worlds), int(m.shape[0]),
+                                             candidate_pair.data_ptr(), candidate_pair_count.data_ptr(), cap, self._stream()), entry)
 
 
 class BroadPhaseSAP(BroadPhaseAllPairs):
@@ -198,11 +223,13 @@ class BroadPhaseSAP(BroadPhaseAllPairs):
         cap = self._out(candidate_pair, candidate_pair_count, skip_count_zero)
         v, keep = self._view(shape_lower, shape_upper, shape_gap, shape_collision_group, shape_world, filter_pairs,
                              num_filter_pairs, shape_body, body_flags, include_static_kinematic_pairs, shape_displacement)
-        _lib.check(self._lib.nt_broadphase_sap_device(
-            C.byref(v), self.world_index_map.data_ptr(), self.world_slice_ends.data_ptr(), int(self.world_slice_ends.shape[0]),
+        motion = self._motion(shape_displacement, sort_axis_displacement_limit)
+        entry = "nt_broadphase_sap_device" if motion is None else "nt_broadphase_sap_device_swept"
+        head = (C.byref(v),) if motion is None else (C.byref(v), C.byref(motion))
+        _lib.check(getattr(self._lib, entry)(
+            *head, self.world_index_map.data_ptr(), self.world_slice_ends.data_ptr(), int(self.world_slice_ends.shape[0]),
             int(self.num_regular_worlds), int(self.world_index_map.shape[0]), self._max_segment, self._sorted_map.data_ptr(),
-            self._proj.data_ptr(), candidate_pair.data_ptr(), candidate_pair_count.data_ptr(), cap, self._stream()),
-            "nt_broadphase_sap_device")
+            self._proj.data_ptr(), candidate_pair.data_ptr(), candidate_pair_count.data_ptr(), cap, self._stream()), entry)
 
 
 class BroadPhaseExplicit(_BroadPhaseBase):
@@ -216,9 +243,11 @@ class BroadPhaseExplicit(_BroadPhaseBase):
         v, keep = self._view(shape_lower, shape_upper, shape_gap, None, None, None, 0, shape_body, body_flags,
                              include_static_kinematic_pairs, shape_displacement)
         _check(shape_pairs, torch.int32, "shape_pairs")
-        _lib.check(self._lib.nt_broadphase_explicit(C.byref(v), shape_pairs.data_ptr(), int(shape_pair_count),
-                                                    candidate_pair.data_ptr(), candidate_pair_count.data_ptr(), cap,
-                                                    self._stream()), "nt_broadphase_explicit")
+        motion = self._motion(shape_displacement)
+        entry = "nt_broadphase_explicit" if motion is None else "nt_broadphase_explicit_swept"
+        head = (C.byref(v),) if motion is None else (C.byref(v), C.byref(motion))
+        _lib.check(getattr(self._lib, entry)(*head, shape_pairs.data_ptr(), int(shape_pair_count), candidate_pair.data_ptr(),
+                                             candidate_pair_count.data_ptr(), cap, self._stream()), entry)
 
 
 class HydroelasticSDF:

@@ -29,6 +29,8 @@ def transform(text: str) -> str:
     text = text.replace("#include <hip/hip_runtime.h>", '#include "hip_emu.h"')
     text = text.replace("extern __shared__ __align__(16) float lds[];", "float* lds = emu::dynamic_lds();")
     text = text.replace('#include "../../include/newton_hip.h"', f'#include "{os.path.join(ROOT, "include", "newton_hip.h")}"')
+    text = text.replace('#include "../../include/newton_hip_broadphase.h"',
+                        f'#include "{os.path.join(ROOT, "include", "newton_hip_broadphase.h")}"')
     text, n = WAVE_SYNC.subn(WAVE_SYNC_EMU, text)
     text = HY_SYNC.sub("#define HY_WAVE_SYNC_HW() emu_wave_sync(64)", text)  # wave-level LDS ordering of the staged hydroelastic kernels
     # only under -DNT_XPBD_FAST_MATH (a measurement variant, never built here)
@@ -55,7 +57,8 @@ def _build_locked(force: bool) -> str:
     files = [f for f in FILES if os.path.exists(os.path.join(CSRC, f))]  # (tools/emu_bitcheck.py builds older revisions too)
     srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "hip_emu.h"),
                                                      os.path.abspath(__file__),
-                                                     os.path.join(ROOT, "include", "newton_hip.h")]
+                                                     os.path.join(ROOT, "include", "newton_hip.h"),
+                                                     os.path.join(ROOT, "include", "newton_hip_broadphase.h")]
     digest = hashlib.sha1(b"".join(open(s, "rb").read() for s in srcs)).hexdigest()
     stamp = os.path.join(OUT, "stamp")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:

@@ -28,4 +28,16 @@ def variants(name):
     shape_body = rng.integers(-1, nb, size=n).astype(np.int32)
     body_flags = np.where(rng.random(nb) < 0.4, 1, 0).astype(np.int32)
     out["immovable"] = dict(base, shape_body=shape_body, body_flags=body_flags, include=False)
+    # swept AABBs (speculative-contact broad phase): a displacement per shape of the order of the box spacing; "swept_capped"
+    # additionally caps the projected displacement of the sort-and-sweep intervals (sort_axis_displacement_limit), which drops
+    # fast pairs from the SAP result but not from N x N; "swept_filtered" adds excluded pairs and the immovable filter
+    rng = np.random.default_rng(1000 + len(name))
+    disp = (rng.standard_normal((n, 3)) * 0.6).astype(np.float32)
+    disp[rng.random(n) < 0.25] = 0.0          # resting shapes: the delta == 0 branch on every axis of some pairs
+    disp[rng.random(n) < 0.2, 1] = 0.0        # axis-aligned motion: delta == 0 on a single axis
+    out["swept"] = dict(base, displacement=disp, limit=None)
+    out["swept_capped"] = dict(base, displacement=disp, limit=0.05)
+    out["swept_capped_zero"] = dict(base, displacement=disp, limit=0.0)  # intervals not extended at all: the most pairs lost
+    out["swept_filtered"] = dict(base, displacement=disp, limit=None, filter_pairs=fp, shape_body=shape_body, body_flags=body_flags,
+                                 include=False)
     return out

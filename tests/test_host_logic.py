@@ -115,8 +115,9 @@ def test_mixed_scene_template():
 
 
 def test_c_abi_exports_every_declared_symbol():
-    """The shared library loads without a GPU and exports exactly what include/newton_hip.h declares."""
-    header = open(os.path.join(ROOT, "include", "newton_hip.h")).read()
+    """The shared library loads without a GPU and exports exactly what include/*.h declare."""
+    inc = os.path.join(ROOT, "include")
+    header = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     declared = set(re.findall(r"\b(nt_[a-z_0-9]+)\s*\(", header))
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     lib = _lib.load()
@@ -315,3 +316,26 @@ def test_speculative_contacts_are_rejected_loudly_and_none_is_accepted():
     assert sig.parameters["speculative_config"].default is None
     src = inspect.getsource(nt.CollisionPipeline.__init__)
     assert src.index("speculative_config is not None") < src.index("_BROAD_PHASES")  # refused before anything else is touched
+
+
+def test_pmc_traffic_is_only_attached_to_the_code_object_it_was_measured_on(monkeypatch):
+    """bench.measured_traffic trusts a counter record when it carries the loaded library's build id, or when the stepping
+    translation unit (nt_kernels.hip + its headers + newton_hip.h + flags: the rollout kernel's code object) is byte-identical to
+    the one of the measured build (`step_unit`); a library that is not the build of this tree, or an edited stepping unit, gets none."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    import bench
+
+    assert bench.build_id().endswith("src " + g.source_hash())  # the loaded library is the build of this tree
+    assert bench.step_unit_id() == g.step_unit_id()
+    rec = bench.measured_traffic("quadruped", 4096)
+    if rec is not None:
+        assert rec["build_id"] == bench.build_id() or rec["step_unit"] == g.step_unit_id()
+        assert 0.0 < rec["bytes_per_launch"] < 359342080.0  # below the algorithmic bytes: the rollout keeps its state in LDS
+    monkeypatch.setattr(g, "step_unit_id", lambda: "0" * 12)  # an edited stepping unit
+    rec = bench.measured_traffic("quadruped", 4096)
+    assert rec is None or rec["build_id"] == bench.build_id()
+    monkeypatch.setattr(g, "source_hash", lambda: "f" * 12)  # a library that does not belong to these sources
+    assert bench.step_unit_id() is None

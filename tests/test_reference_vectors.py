@@ -221,3 +221,52 @@ def test_broad_phase_checker_reproduces_the_reference_classes(oracle_lib, name, 
                                              len(out))
     want = ref[f"{key}/explicit_pairs"]
     assert count == len(want) and np.array_equal(out[:count], want)
+
+
+@pytest.mark.parametrize("variant", ["swept", "swept_capped", "swept_capped_zero", "swept_filtered"])
+@pytest.mark.parametrize("name", ["single_world", "multiple_worlds", "shape_flags", "per_shape_gap"])
+def test_broad_phase_checker_reproduces_the_reference_classes_with_displacements(oracle_lib, name, variant):
+    """Swept AABBs (the broad phase of the speculative-contact mode): the reference classes launched with shape_displacement --
+    check_aabb_overlap_moving (broad_phase_common.py:41-85) -- and, for BroadPhaseSAP, sort_axis_displacement_limit
+    (_sap_project_aabb, broad_phase_sap.py:44-79: a capped extension of the projected interval loses fast pairs, which the checker
+    must lose as well).  N x N and explicit in append order, sort-and-sweep as a set."""
+    import ctypes as C
+
+    import broadphase_cases as bc
+    from test_broad_phase_standalone import _oracle
+
+    ref = np.load(BP_VEC)
+    v = bc.variants(name)[variant]
+    key = f"{name}/{variant}"
+    kw = dict(filter_pairs=v["filter_pairs"], shape_body=v["shape_body"], body_flags=v["body_flags"], include=v["include"],
+              displacement=v["displacement"])
+    args = (v["lower"], v["upper"], v["gap"], v["group"], v["world"], v["flags"])
+    count, pairs = _oracle(oracle_lib, "nxn", *args, **kw)
+    want = ref[f"{key}/nxn_pairs"]
+    assert len(want) > 5 and count == len(want) and np.array_equal(pairs, want)
+    assert not np.array_equal(want, ref[f"{name}/plain/nxn_pairs"])  # the displacements change the result
+    count, pairs = _oracle(oracle_lib, "sap", *args, limit=v["limit"], **kw)
+    want = ref[f"{key}/sap_pairs"]
+    assert count == len(want) and len({tuple(p) for p in pairs}) == count
+    assert {tuple(p) for p in pairs} == {tuple(p) for p in want}
+    ep = np.ascontiguousarray(v["explicit_pairs"], np.int32)
+    out = np.zeros((len(ep) + 1, 2), np.int32)
+    fi, ii = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    p = lambda a, t: a.ctypes.data_as(t) if a is not None else None  # noqa: E731
+    disp = np.ascontiguousarray(v["displacement"], np.float32)
+    oracle_lib.o_broadphase_explicit_swept.restype = C.c_int
+    count = oracle_lib.o_broadphase_explicit_swept(p(v["lower"], fi), p(v["upper"], fi), p(v["gap"], fi), p(ep, ii), len(ep),
+                                                   p(v["shape_body"], ii), p(v["body_flags"], ii), int(v["include"]), p(disp, fi),
+                                                   p(out, ii), len(out))
+    want = ref[f"{key}/explicit_pairs"]
+    assert count == len(want) and np.array_equal(out[:count], want)
+
+
+def test_capped_sort_axis_extension_loses_pairs_in_the_reference_too():
+    """The record itself: with sort_axis_displacement_limit the reference's SAP returns a strict subset of its N x N result on
+    the gap case (the projected intervals decide which pairs are tested), and the same set without the cap."""
+    ref = np.load(BP_VEC)
+    s = lambda k: {tuple(p) for p in ref[k]}  # noqa: E731
+    assert s("per_shape_gap/swept/sap_pairs") == s("per_shape_gap/swept/nxn_pairs")
+    assert s("per_shape_gap/swept_capped/sap_pairs") < s("per_shape_gap/swept_capped/nxn_pairs")
+    assert s("per_shape_gap/swept_capped_zero/sap_pairs") < s("per_shape_gap/swept_capped/sap_pairs")

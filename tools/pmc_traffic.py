@@ -75,7 +75,10 @@ def main():
     for spec in sys.argv[1:] or ["quadruped@4096"]:
         workload, _, envs = spec.partition("@")
         envs = int(envs or 4096)
-        rec = {"build_id": build_id(), "workload": workload, "envs": envs, "kernel": KERNEL[workload], "substeps_per_launch": 10}
+        import __graft_entry__ as g  # noqa: PLC0415  (ROOT is on sys.path after build_id())
+
+        rec = {"build_id": build_id(), "step_unit": g.step_unit_id(), "workload": workload, "envs": envs, "kernel": KERNEL[workload],
+               "substeps_per_launch": 10}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cal, roll = run_pass(counter, workload, envs)
             cal_kib = sum(cal[-2:]) / 2          # steady-state calibration launches
