@@ -23,6 +23,7 @@ f32 = np.float32
 NUM_NORMAL_BINS, NUM_SPATIAL_DIRECTIONS, NUM_VOXEL_DEPTH_SLOTS = 20, 6, 100
 VALUES_PER_KEY = NUM_SPATIAL_DIRECTIONS + 1
 SCORE_SHIFT, FINGERPRINT_MASK = 10, (1 << 22) - 1
+BETA_THRESHOLD = 0.0001  # contact_reduction_global.py:89
 NUM_ENTRIES = NUM_NORMAL_BINS + (NUM_VOXEL_DEPTH_SLOTS + VALUES_PER_KEY - 1) // VALUES_PER_KEY  # 20 normal bins + 15 voxel groups
 
 FACE_NORMALS = np.array([  # contact_reduction.py:170-191
@@ -160,6 +161,12 @@ def reduce_contacts(c):
             vox = min(max(voxel_index(c["local"][i], c["aabb_lo"][i], c["aabb_hi"][i], c["res"][i]), 0), NUM_VOXEL_DEPTH_SLOTS - 1)
             vs = table.setdefault((pair, NUM_NORMAL_BINS + vox // VALUES_PER_KEY), [0] * VALUES_PER_KEY)
             vs[vox % VALUES_PER_KEY] = max(vs[vox % VALUES_PER_KEY], value_depth(f32(-depth), fp))
+    return _export(c, table, by_fp)
+
+
+def _export(c, table, by_fp):
+    """export_reduced_contacts_kernel (:2098-2290): roundoff twins inside an entry, every surviving contact once, sorted by
+    (shape a, shape b, fingerprint); the exported normal is the decoded octahedral code."""
     # what the buffer holds of a contact: position, depth, the octahedral code of the normal
     oct_code = {k: encode_oct(c["normal"][i].astype(np.float32)) for k, i in by_fp.items()}
     keep = set()
@@ -184,6 +191,41 @@ def reduce_contacts(c):
     return dict(pair=np.array([k[0] for k in keys], np.int32).reshape(-1, 2), fp=np.array([k[1] for k in keys], np.int32),
                 pos=c["pos"][idx].reshape(-1, 3), depth=c["depth"][idx],
                 normal=np.array([decode_oct(oct_code[k]) for k in keys], np.float32).reshape(-1, 3), index=idx)
+
+
+def reduce_buffered_contacts(c):
+    """reduce_contact_in_hashtable (:1246-1346) over a buffered contact list -- the variant behind write_contact_to_reducer
+    (mesh-plane, mesh / heightfield triangles), NOT the centred two-depth one above.  c: pair, pos, normal, depth, fp and, per
+    contact, shape a's world transform `xform_a` [7] with its local AABB / voxel resolution (aabb_lo, aabb_hi, res).
+      * the normal that picks the bin is the buffered one (encode_oct -> decode_oct), the point is projected uncentred;
+      * the six directional slots only take contacts with depth < beta * |aabb diagonal| (beta = 1e-4), value (score, fp);
+      * the bin's max-depth slot and the voxel slot (point in shape a's frame) take every contact, value (-depth, fp)."""
+    import oracle_mesh_plane as omp  # noqa: PLC0415  (transform helpers in the pinned operand order)
+
+    n = len(c["fp"])
+    table, by_fp = {}, {}
+    for i in range(n):
+        depth = f32(c["depth"][i])
+        pair, fp = (int(c["pair"][i][0]), int(c["pair"][i][1])), int(c["fp"][i])
+        by_fp[(pair, fp)] = i
+        pos = c["pos"][i].astype(np.float32)
+        nrm = decode_oct(encode_oct(c["normal"][i].astype(np.float32)))
+        lo, hi = c["aabb_lo"][i].astype(np.float32), c["aabb_hi"][i].astype(np.float32)
+        b = get_slot(nrm)
+        u, v = FACE_FRAMES[b]
+        p2 = (_dot3(pos, u), _dot3(pos, v))
+        slots = table.setdefault((pair, b), [0] * VALUES_PER_KEY)
+        diag = (hi - lo).astype(np.float32)
+        if depth < f32(f32(BETA_THRESHOLD) * np.sqrt(_dot3(diag, diag), dtype=np.float32)):
+            for d in range(NUM_SPATIAL_DIRECTIONS):
+                score = f32(f32(p2[0] * SPATIAL_DIRS[d][0]) + f32(p2[1] * SPATIAL_DIRS[d][1]))
+                slots[d] = max(slots[d], value_depth(score, fp))
+        slots[NUM_SPATIAL_DIRECTIONS] = max(slots[NUM_SPATIAL_DIRECTIONS], value_depth(f32(-depth), fp))
+        local = np.asarray(omp.transform_point(omp.transform_inverse(c["xform_a"][i]), pos), np.float32)
+        vox = min(max(voxel_index(local, lo, hi, c["res"][i]), 0), NUM_VOXEL_DEPTH_SLOTS - 1)
+        vs = table.setdefault((pair, NUM_NORMAL_BINS + vox // VALUES_PER_KEY), [0] * VALUES_PER_KEY)
+        vs[vox % VALUES_PER_KEY] = max(vs[vox % VALUES_PER_KEY], value_depth(f32(-depth), fp))
+    return _export(c, table, by_fp)
 
 
 def _q_rot_inv(q, v):

@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "newton_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
 FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_ctx.hpp", "nt_collide.hpp", "nt_xpbd.hpp", "nt_xpbd_kernels.hpp",
-         "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_featherstone_kernels.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip",
+         "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_featherstone_kernels.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip", "nt_contact_reduce.hpp",
          "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip", "nt_graph.hip"]
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
