@@ -1,0 +1,56 @@
+/* newton_hip_mesh.h -- mesh legs of CollisionPipeline.collide that work on mesh VERTICES (extension of newton_hip.h).
+ *
+ * Reference interface replaced (paths relative to /root/reference/newton/_src/geometry):
+ *   pair routing        narrow_phase.py:618-631   a MESH against an INFINITE plane (scale x = y = 0) leaves the primitive / GJK
+ *                                                 path for `shape_pairs_mesh_plane`, stored as (mesh, plane)
+ *   contact generation  narrow_phase.py:1744-1992 narrow_phase_process_mesh_plane_contacts(_reduce)_kernel: one lane per mesh
+ *                                                 vertex -- world position, projection on the plane through the plane's frame,
+ *                                                 distance = (v - proj) . n, admitted when distance < gap sum + margin sum,
+ *                                                 contact centre = midpoint, normal = -n (mesh -> plane), sort_sub_key = vertex
+ *   reduction           contact_reduction_global.py:2059-2096 write_contact_to_reducer, :1246-1346 reduce_contact_in_hashtable
+ *                                                 (the BUFFERED variant: uncentred projection, directional slots only for
+ *                                                 depth < 1e-4 |aabb(mesh)|, max-depth and voxel slots for every contact),
+ *                                                 :2098-2290 export_reduced_contacts_kernel
+ * Output = ContactData rows in the form nt_mesh_sdf_collide_reduced emits them (newton_hip.h): one contiguous block per pair,
+ * rows in ascending vertex order -- what nt_sdf_rows_finalize / nt_contact_rows_write turn into Newton's contact arrays.
+ * Same conventions as newton_hip.h: device pointers owned by the caller, work enqueued on `stream`, no allocation. */
+#ifndef NEWTON_HIP_MESH_H
+#define NEWTON_HIP_MESH_H
+
+#include "newton_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t* pairs;                    /* [pair_count][2] shape ids, or the per-world candidate regions [worlds * pairs_per_world][2]
+                                          of nt_sdf_candidate_pairs; rewritten in place as (mesh, plane) for the pairs processed */
+    int32_t pair_count;                /* plain list: number of pairs (pair_world_prefix == NULL) */
+    const int32_t* pair_world_prefix;  /* [worlds + 1] exclusive prefix of the live pairs per world, or NULL for a plain list */
+    int32_t worlds, pairs_per_world;
+    const uint8_t* pair_kind;          /* [pairs] or NULL: when given only pairs of kind NT_PAIR_KIND_MESH_PLANE are processed */
+    const int32_t* shape_type;         /* [S] GeoType (PLANE = 1, MESH = 8): which shape of a pair is the plane */
+    const float* shape_transform;      /* [S][7] world transforms */
+    const float* shape_data;           /* [S][4] scale xyz, margin */
+    const float* shape_gap;            /* [S] */
+    const int32_t* shape_vertex_range; /* [S][2] (first vertex, vertex count) of a mesh shape in `vertices` */
+    const float* vertices;             /* [V][3] mesh-local, unscaled (wp.Mesh.points) */
+    const float* shape_aabb_lower;     /* [S][3] Model.shape_collision_aabb_lower / _upper: the mesh's scaled local AABB */
+    const float* shape_aabb_upper;
+    const int32_t* shape_voxel_res;    /* [S][3] Model.shape_voxel_resolution */
+    int32_t reduce;                    /* 1: the global contact reduction (CollisionPipeline default); 0: every admitted vertex */
+    int32_t* out_count;                /* [1] rows appended so far (the caller sets the start; keeps counting past capacity) */
+    int32_t* out_pair;                 /* [capacity] pair position of the row */
+    int32_t* out_key;                  /* [capacity] vertex index (ContactData.sort_sub_key) */
+    float* out_data;                   /* [capacity][9] centre, normal mesh -> plane, distance, margin mesh, margin plane */
+    int32_t capacity;
+    int32_t* out_blk;                  /* [pairs][2] (first row, row count) of the pair's block; written for every processed pair */
+} nt_mesh_plane_args;
+#define NT_PAIR_KIND_MESH_PLANE 2      /* nt_sdf_scene.template_kind / world_pair_kind: 0 mesh-SDF edges, 1 hydroelastic */
+nt_status nt_mesh_plane_pairs(const nt_mesh_plane_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

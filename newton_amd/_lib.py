@@ -1,4 +1,4 @@
-"""ctypes binding of libnewton_hip.so (the C ABI declared in include/newton_hip.h and include/newton_hip_broadphase.h).
+"""ctypes binding of libnewton_hip.so (the C ABI declared in include/newton_hip.h, include/newton_hip_broadphase.h and include/newton_hip_mesh.h).
 
 The product path has NO CPU fallback: if the shared library is missing or cannot be loaded, every
 solver / collision entry point raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``.
@@ -121,6 +121,16 @@ class nt_broadphase_in(C.Structure):
 class nt_broadphase_motion(C.Structure):
     """include/newton_hip_broadphase.h: per-shape displacement of the swept broad phases."""
     _fields_ = [("displacement", C.c_void_p), ("sort_axis_displacement_limit", C.c_float)]
+
+
+class nt_mesh_plane_args(C.Structure):
+    """include/newton_hip_mesh.h: MESH vs infinite plane (vertex leg)."""
+    _fields_ = [("pairs", C.c_void_p), ("pair_count", C.c_int32), ("pair_world_prefix", C.c_void_p), ("worlds", C.c_int32),
+                ("pairs_per_world", C.c_int32), ("pair_kind", C.c_void_p), ("shape_type", C.c_void_p), ("shape_transform", C.c_void_p),
+                ("shape_data", C.c_void_p), ("shape_gap", C.c_void_p), ("shape_vertex_range", C.c_void_p), ("vertices", C.c_void_p),
+                ("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
+                ("reduce", C.c_int32), ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p),
+                ("out_data", C.c_void_p), ("capacity", C.c_int32), ("out_blk", C.c_void_p)]
 
 
 class nt_sdf(C.Structure):
@@ -317,6 +327,8 @@ SYMBOLS = {
     "nt_broadphase_sap_device": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                                _P, _P, C.c_int32, _P]),
     "nt_broadphase_explicit": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, C.c_int32, _P, _P, C.c_int32, _P]),
+    # include/newton_hip_mesh.h
+    "nt_mesh_plane_pairs": (C.c_int32, [C.POINTER(nt_mesh_plane_args), _P]),
     # include/newton_hip_broadphase.h
     "nt_broadphase_nxn_swept": (C.c_int32, [C.POINTER(nt_broadphase_in), C.POINTER(nt_broadphase_motion), _P, _P, C.c_int32, C.c_int32,
                                             C.c_int32, _P, _P, C.c_int32, _P]),

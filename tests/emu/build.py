@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
 FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_ctx.hpp", "nt_collide.hpp", "nt_xpbd.hpp", "nt_xpbd_kernels.hpp",
          "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_featherstone_kernels.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip", "nt_contact_reduce.hpp",
-         "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip", "nt_graph.hip"]
+         "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip", "nt_graph.hip", "nt_mesh_plane.hip"]
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
 HY_SYNC = re.compile(r"#define HY_WAVE_SYNC_HW\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
@@ -29,8 +29,8 @@ def transform(text: str) -> str:
     text = text.replace("#include <hip/hip_runtime.h>", '#include "hip_emu.h"')
     text = text.replace("extern __shared__ __align__(16) float lds[];", "float* lds = emu::dynamic_lds();")
     text = text.replace('#include "../../include/newton_hip.h"', f'#include "{os.path.join(ROOT, "include", "newton_hip.h")}"')
-    text = text.replace('#include "../../include/newton_hip_broadphase.h"',
-                        f'#include "{os.path.join(ROOT, "include", "newton_hip_broadphase.h")}"')
+    for ext in ("broadphase", "mesh"):
+        text = text.replace(f'#include "../../include/newton_hip_{ext}.h"', f'#include "{os.path.join(ROOT, "include", f"newton_hip_{ext}.h")}"')
     text, n = WAVE_SYNC.subn(WAVE_SYNC_EMU, text)
     text = HY_SYNC.sub("#define HY_WAVE_SYNC_HW() emu_wave_sync(64)", text)  # wave-level LDS ordering of the staged hydroelastic kernels
     # only under -DNT_XPBD_FAST_MATH (a measurement variant, never built here)
@@ -58,7 +58,8 @@ def _build_locked(force: bool) -> str:
     srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "hip_emu.h"),
                                                      os.path.abspath(__file__),
                                                      os.path.join(ROOT, "include", "newton_hip.h"),
-                                                     os.path.join(ROOT, "include", "newton_hip_broadphase.h")]
+                                                     os.path.join(ROOT, "include", "newton_hip_broadphase.h"),
+                                                     os.path.join(ROOT, "include", "newton_hip_mesh.h")]
     digest = hashlib.sha1(b"".join(open(s, "rb").read() for s in srcs)).hexdigest()
     stamp = os.path.join(OUT, "stamp")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
@@ -75,7 +76,8 @@ def _build_locked(force: bool) -> str:
            *([os.path.join(OUT, "nt_model_build.cpp")] if "nt_model_build.hip" in files else []),
            *([os.path.join(OUT, "nt_graph.cpp")] if "nt_graph.hip" in files else []),
            *([os.path.join(OUT, "nt_flat_contacts.cpp")] if "nt_flat_contacts.hip" in files else []),
-           *([os.path.join(OUT, "nt_sdf_pipeline.cpp")] if "nt_sdf_pipeline.hip" in files else []), "-o", LIB]
+           *([os.path.join(OUT, "nt_sdf_pipeline.cpp")] if "nt_sdf_pipeline.hip" in files else []),
+           *([os.path.join(OUT, "nt_mesh_plane.cpp")] if "nt_mesh_plane.hip" in files else []), "-o", LIB]
     subprocess.run(cmd, check=True)
     open(stamp, "w").write(digest)
     return LIB
