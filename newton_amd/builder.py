@@ -623,6 +623,14 @@ class ModelBuilder:
             raise ValueError("add_shape_convex_hull() requires a Mesh")
         return self.add_shape(body=body, type=GeoType.CONVEX_MESH, xform=xform, cfg=cfg, scale=scale, label=label, src=mesh)
 
+    def add_shape_mesh(self, body, *, xform=None, mesh=None, scale=None, cfg=None, label=None) -> int:
+        """Triangle-mesh collision shape (builder.py:7158-7198).  Collides with infinite planes through its vertices
+        (narrow_phase.py:618-631,1744-1992) and, with an SDF attached (``mesh.build_sdf``), with other SDF shapes through the
+        mesh-SDF leg; mesh-vs-primitive pairs (triangle leg) are refused at finalize()."""
+        if mesh is None:
+            raise ValueError("add_shape_mesh() requires a Mesh")
+        return self.add_shape(body=body, type=GeoType.MESH, xform=xform, cfg=cfg, scale=scale, label=label, src=mesh)
+
     def _finalize_sdf(self, m) -> None:
         """Texture-SDF resources of the finalized model (builder.py:11690-11960 compact SDF table + per-shape index, :12050-12116
         collision-edge tables, :11544-11611 local AABBs and voxel grids of the contact reduction).  Mesh-backed shapes use the SDF
@@ -675,6 +683,8 @@ class ModelBuilder:
                 ext = S.primitive_extents(int(ty), scale)
                 lo_all[i], hi_all[i] = np.asarray(ext[0], np.float32), np.asarray(ext[1], np.float32)
             if key is None:
+                if ty == GeoType.MESH and src is not None:  # the contact reduction's voxel grid of a mesh without an SDF (vertex leg)
+                    voxel_res[i] = S.voxel_resolution_from_aabb(lo_all[i], hi_all[i])
                 continue
             if key not in cache:
                 cache[key] = len(table)
@@ -936,7 +946,7 @@ class ModelBuilder:
         uniq, starts, counts, points = {}, [], [], []
         lo_all, hi_all = np.zeros((S, 3), dtype=f32), np.zeros((S, 3), dtype=f32)
         for i, src in enumerate(self.shape_source):
-            if self.shape_type[i] != GeoType.CONVEX_MESH or src is None:
+            if self.shape_type[i] not in (GeoType.CONVEX_MESH, GeoType.MESH) or src is None:
                 starts.append(-1)
                 counts.append(0)
                 continue
@@ -951,6 +961,19 @@ class ModelBuilder:
             sc = np.asarray(self.shape_scale[i], dtype=f32).astype(np.float64)  # the device multiplies in fp32
             lo, hi = v.min(axis=0) * sc, v.max(axis=0) * sc
             lo_all[i], hi_all[i] = np.minimum(lo, hi), np.maximum(lo, hi)
+        # triangle meshes: wp.Mesh.points as they are (the vertex index is the contact fingerprint of the mesh-plane leg,
+        # narrow_phase.py:1969), each distinct Mesh once
+        vuniq, vranges, vpoints = {}, np.zeros((S, 2), dtype=i32), []
+        for i, src in enumerate(self.shape_source):
+            if self.shape_type[i] != GeoType.MESH or src is None:
+                continue
+            if id(src) not in vuniq:
+                v = np.asarray(src.vertices, dtype=f32).reshape(-1, 3)
+                vuniq[id(src)] = (sum(len(p) for p in vpoints), len(v))
+                vpoints.append(v)
+            vranges[i] = vuniq[id(src)]
+        m.mesh_vertex_range = vranges
+        m.mesh_vertices = (np.concatenate(vpoints) if vpoints else np.zeros((0, 3))).astype(f32).reshape(-1, 3)
         m.shape_mesh_start = np.asarray(starts, dtype=i32).reshape(S)
         m.shape_mesh_count = np.asarray(counts, dtype=i32).reshape(S)
         m.mesh_points = (np.concatenate(points) if points else np.zeros((0, 3))).astype(f32).reshape(-1, 3)

@@ -54,10 +54,10 @@ def compute_inertia_shape(geo_type, scale, density, src=None):
         Ia = 3 / 20 * m * r * r + 3 / 80 * m * h * h
         Ib = 3 / 10 * m * r * r
         return m, np.array([0.0, 0.0, -h / 4.0]), np.diag([Ia, Ia, Ib])
-    if geo_type == GeoType.CONVEX_MESH:
-        # scaled unit-density mass properties of the source mesh (newton/_src/geometry/inertia.py:726-757)
+    if geo_type in (GeoType.CONVEX_MESH, GeoType.MESH):
+        # scaled unit-density mass properties of the source mesh (newton/_src/geometry/inertia.py:726-757: MESH and CONVEX_MESH alike)
         if src is None:
-            raise ValueError("convex hull shapes need a Mesh")
+            raise ValueError("mesh and convex hull shapes need a Mesh")
         if not src.has_inertia:  # fall back to the mass properties of the scaled geometry (inertia.py:759-764)
             from .mesh import solid_mesh_mass_properties  # noqa: PLC0415
 
@@ -83,7 +83,7 @@ def transform_inertia(mass, inertia, offset, quat):
 
 
 def compute_shape_radius(geo_type, scale, src=None):
-    if geo_type == GeoType.CONVEX_MESH:  # bounding sphere of the scaled local AABB (geometry/utils.py:86-98)
+    if geo_type in (GeoType.CONVEX_MESH, GeoType.MESH):  # bounding sphere of the scaled local AABB (geometry/utils.py:86-98)
         verts = np.asarray(src.vertices, dtype=np.float64) * np.asarray(scale, dtype=np.float64)
         return float(0.5 * np.linalg.norm(verts.max(axis=0) - verts.min(axis=0)))
     sx, sy, sz = (abs(float(s)) for s in scale)

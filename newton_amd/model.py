@@ -160,6 +160,10 @@ class EnvTemplate:
             return np.concatenate([loc[0], a[shape_glob]]).astype(np.int32)
 
         self.shape_type = shape_uniform(m.shape_type, "shape_type")
+        # The tile kernels see a triangle mesh as what compute_shape_aabbs makes of it -- a shape with a pre-computed local AABB
+        # (collide.py:421-445, the branch MESH and CONVEX_MESH share): their table carries CONVEX_MESH for it (AABB from the vertex
+        # bounds below).  A MESH never is a tile PAIR: its pairs go to the SDF / vertex legs or are refused further down.
+        self.tile_shape_type = np.where(self.shape_type == int(GeoType.MESH), int(GeoType.CONVEX_MESH), self.shape_type).astype(np.int32)
         self.shape_flags = shape_uniform(m.shape_flags, "shape_flags")
         self.shape_group = shape_uniform(m.shape_collision_group, "shape_collision_group")
         # convex-hull vertex slices (shared Mesh assets => identical in every world) + unscaled hull bounds per shape
@@ -230,12 +234,27 @@ class EnvTemplate:
         def newton_id0(l):  # Newton id of template shape l in world 0 (the order is the same in every world)
             return L0 + l if l < ns else int(shape_glob[l - ns])
 
-        sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b), bool(h))
-              for a, b, h in zip(self.pair_a[is_sdf_pair], self.pair_b[is_sdf_pair], is_hydro_pair[is_sdf_pair])]
+        # a triangle mesh against an INFINITE plane (scale x = y = 0) is tested vertex by vertex (narrow_phase.py:618-631, after the
+        # mesh-mesh / SDF-edge rule above): the vertex leg of the pipeline (csrc/nt_mesh_plane.hip), not a tile pair either
+        scale_all = np.asarray(m.shape_scale, dtype=np.float32).reshape(-1, 3)
+
+        def infinite_plane(l):
+            return int(self.shape_type[l]) == GeoType.PLANE and scale_all[newton_id0(l), 0] == 0.0 and scale_all[newton_id0(l), 1] == 0.0
+
+        def tri_mesh(l):
+            return int(self.shape_type[l]) == GeoType.MESH
+
+        is_mesh_plane_pair = ~is_sdf_pair & np.array([(infinite_plane(a) and tri_mesh(b)) or (infinite_plane(b) and tri_mesh(a))
+                                                      for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
+        is_sdf_pair = is_sdf_pair | is_mesh_plane_pair
+        sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b), bool(h), bool(mp))
+              for a, b, h, mp in zip(self.pair_a[is_sdf_pair], self.pair_b[is_sdf_pair], is_hydro_pair[is_sdf_pair],
+                                     is_mesh_plane_pair[is_sdf_pair])]
         sp.sort()
-        self.sdf_pair = np.asarray([[a, b] if newton_id0(a) < newton_id0(b) else [b, a] for _, _, a, b, _ in sp], dtype=np.int32).reshape(-1, 2)
-        self.sdf_pair_hydro = np.asarray([h for *_, h in sp], dtype=bool)  # hydroelastic when the pipeline enables it
-        self.sdf_pair_has_edges = np.asarray([bool(has_sdf[a] and has_sdf[b]) for _, _, a, b, _ in sp], dtype=bool)
+        self.sdf_pair = np.asarray([[a, b] if newton_id0(a) < newton_id0(b) else [b, a] for _, _, a, b, *_ in sp], dtype=np.int32).reshape(-1, 2)
+        self.sdf_pair_hydro = np.asarray([h for *_, h, _ in sp], dtype=bool)  # hydroelastic when the pipeline enables it
+        self.sdf_pair_mesh_plane = np.asarray([mp for *_, mp in sp], dtype=bool)  # the vertex leg (pair kind 2)
+        self.sdf_pair_has_edges = np.asarray([bool(has_sdf[a] and has_sdf[b]) for _, _, a, b, *_ in sp], dtype=bool)
         self.tile_pair_index = np.flatnonzero(~is_sdf_pair)  # positions of the tile pairs in one world's shape_contact_pairs slice
         self.pair_a, self.pair_b = self.pair_a[~is_sdf_pair], self.pair_b[~is_sdf_pair]
         self.np = len(self.pair_a)
@@ -397,6 +416,7 @@ class DeviceModel:
             "joint_qd_start", "joint_tq_start", "joint_lin_count", "joint_ang_count", "shape_body", "shape_type",
             "shape_flags", "shape_group", "pair_a", "pair_b", "body_joint_start", "body_joint_list", "body_pair_start",
             "body_pair_list", "art_start", "shape_mesh_start", "shape_mesh_count", "gshape_id")}
+        self.topology["shape_type"] = dev_i32(t.tile_shape_type)  # (triangle meshes as pre-computed-AABB shapes, see EnvTemplate)
         self.mesh_tables = {"mesh_points": dev_f32(t.mesh_points), "shape_mesh_bounds": dev_f32(t.shape_mesh_bounds)}
         self.params = {}
         self.upload_params(model)

@@ -128,12 +128,28 @@ class SdfLeg:
         # pair kinds: with a hydroelastic configuration the pairs of two HYDROELASTIC shapes take the SDF-SDF leg (kind 1)
         self.hydro = hydro_config
         kind = (t.sdf_pair_hydro if hydro_config is not None else np.zeros(len(t.sdf_pair), bool)).astype(np.uint8)
+        # (triangle mesh, infinite plane): the vertex leg (kind 2, NT_PAIR_KIND_MESH_PLANE; include/newton_hip_mesh.h)
+        mesh_plane = np.asarray(getattr(t, "sdf_pair_mesh_plane", np.zeros(len(t.sdf_pair), bool)), bool)
+        kind[mesh_plane] = 2
         if np.any((kind == 0) & ~t.sdf_pair_has_edges):
             raise NotImplementedError("pairs of hydroelastic shapes without collision edges need CollisionPipeline(sdf_hydroelastic_config=...)")
-        self.has_hydro_pairs = bool(kind.any())
+        self.has_hydro_pairs = bool((kind == 1).any())
+        self.has_mesh_plane_pairs = bool((kind == 2).any())
+        self.has_edge_pairs = bool((kind == 0).any())
+        self.mesh_plane_reduce = True  # CollisionPipeline(reduce_contacts=...): set by the pipeline
         self.hydro_reduce, self.face_capacity, self.hydro_staged = 0, 0, False
         self._template_kind = up(kind, np.uint8)
         self.world_pair_kind = torch.zeros(E * PPW, dtype=torch.uint8, device=dev)
+        if self.has_mesh_plane_pairs:
+            sc.template_kind, sc.world_pair_kind = self._template_kind.data_ptr(), self.world_pair_kind.data_ptr()
+            self._shape_type = up(model.shape_type, np.int32)
+            self._vertex_range = up(model.mesh_vertex_range, np.int32)
+            self._vertices = up(model.mesh_vertices, np.float32)
+            # rows a world can get from its vertex pairs: every vertex when the reduction is off, else the reduction's table
+            mp_rows = sum(int(model.mesh_vertex_range[t.shape_local0 + l if l < t.ns else int(t.gshape_id[l - t.ns]), 1])
+                          for pr in t.sdf_pair[mesh_plane] for l in pr)
+            self.rows_per_world = max(self.rows_per_world, mp_rows + 64)
+            self.row_capacity = E * self.rows_per_world
         if self.has_hydro_pairs:
             from .mc_tables import tables  # noqa: PLC0415
 
@@ -229,7 +245,7 @@ class SdfLeg:
         r = _lib.nt_contact_reduce_shapes()
         r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = self._red_lo.data_ptr(), self._red_hi.data_ptr(), self._red_res.data_ptr()
         r.threads, r.shape_edge_radius_max = self.threads, self._edge_rmax.data_ptr()
-        if self.has_hydro_pairs:
+        if self.has_hydro_pairs or self.has_mesh_plane_pairs:
             a.pair_kind = self.world_pair_kind.data_ptr()
         if self.staged:
             a.hit_count, a.hit_stripes, a.hit_stripe_count, a.hit_capacity = (
@@ -237,8 +253,24 @@ class SdfLeg:
             a.hit_pair, a.hit_fp, a.hit_rec, a.hit_blk, a.unit_ctx = (
                 self.hit_pair.data_ptr(), self.hit_fp.data_ptr(), self.hit_rec.data_ptr(), self.hit_blk.data_ptr(),
                 self.unit_ctx.data_ptr())
-        if not bool(np.all(self.t.sdf_pair_hydro)) or not self.has_hydro_pairs:
+        if self.has_edge_pairs:
             _lib.check(lib.nt_mesh_sdf_collide_reduced(C.byref(a), C.byref(r), stream), "nt_mesh_sdf_collide_reduced")
+        if self.has_mesh_plane_pairs:  # (triangle mesh, infinite plane): rows appended through the counter, one block per pair
+            mp = _lib.nt_mesh_plane_args()
+            mp.pairs, mp.pair_world_prefix, mp.worlds, mp.pairs_per_world = (self.world_pairs.data_ptr(), self.pair_prefix.data_ptr(),
+                                                                           sc.env_count, sc.pairs_per_world)
+            mp.pair_kind, mp.shape_type = self.world_pair_kind.data_ptr(), self._shape_type.data_ptr()
+            mp.shape_transform, mp.shape_data, mp.shape_gap = (self.world_xform.data_ptr(), self._shape_data.data_ptr(),
+                                                               self._shape_gap.data_ptr())
+            mp.shape_vertex_range, mp.vertices = self._vertex_range.data_ptr(), self._vertices.data_ptr()
+            mp.shape_aabb_lower, mp.shape_aabb_upper, mp.shape_voxel_res = (self._red_lo.data_ptr(), self._red_hi.data_ptr(),
+                                                                            self._red_res.data_ptr())
+            mp.reduce = int(bool(self.mesh_plane_reduce))
+            mp.out_count, mp.out_pair, mp.out_key, mp.out_data, mp.capacity = (self.raw_count.data_ptr(), self.raw_pair.data_ptr(),
+                                                                              self.raw_key.data_ptr(), self.raw_data.data_ptr(),
+                                                                              self.raw_capacity)
+            mp.out_blk = self.blk.data_ptr()
+            _lib.check(lib.nt_mesh_plane_pairs(C.byref(mp), stream), "nt_mesh_plane_pairs")
         if self.has_hydro_pairs:
             h = _lib.nt_hydro_args()
             h.pairs, h.pair_count = self.world_pairs.data_ptr(), int(self.world_pairs.shape[0])
@@ -278,7 +310,7 @@ class SdfLeg:
         io.raw_base = self.hit_capacity
         for k in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1", "key"):
             setattr(io, k, getattr(rows, k).data_ptr())
-        if self.has_hydro_pairs:
+        if self.has_hydro_pairs or self.has_mesh_plane_pairs:  # (pair kinds in play: the writer asks for the rank array)
             io.raw_rank, io.raw_stiffness = self.raw_rank.data_ptr(), self.raw_stiffness.data_ptr()
             if self.hydro_reduce:
                 io.raw_friction = self.raw_friction.data_ptr()
@@ -403,7 +435,10 @@ class FlatRowMatcher:
 def sdf_pair_shape_types_ok(model) -> None:
     """The SDF leg handles MESH / CONVEX_MESH / BOX shapes (texture SDF + collision edges); heightfields are out of scope."""
     t = model.env
-    for (a, b), hydro in zip(t.sdf_pair, t.sdf_pair_hydro):
+    mesh_plane = getattr(t, "sdf_pair_mesh_plane", np.zeros(len(t.sdf_pair), bool))
+    for (a, b), hydro, mp in zip(t.sdf_pair, t.sdf_pair_hydro, mesh_plane):
+        if mp:
+            continue
         for s in (a, b):
             if not hydro and int(t.shape_type[s]) not in (int(GeoType.MESH), int(GeoType.CONVEX_MESH), int(GeoType.BOX)):
                 raise NotImplementedError(f"SDF contact pairs with shape type {GeoType(int(t.shape_type[s])).name} are not supported")

@@ -1,0 +1,167 @@
+"""Triangle meshes on an infinite ground plane THROUGH CollisionPipeline.collide (SURVEY.md section 8 row a24's mesh legs;
+narrow_phase.py:618-631 routing, :1744-1992 vertex kernels, contact_reduction_global.py:1246-1346 the buffered reducer): the rows
+of the vertex leg (csrc/nt_mesh_plane.hip as pair kind 2 of the SDF leg) against the checker chain -- oracle_mesh_plane (pinned by
+the executed reference, tests/test_mesh_plane.py) + write_contact -- then the solvers consuming them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")
+
+
+def _rows(contacts):
+    f = contacts._flat
+    n = int(f.row_start[-1].item())
+    d = {k: getattr(f, k)[:n].cpu().numpy() for k in (*FIELDS, "key")}
+    d["row_start"] = f.row_start.cpu().numpy()
+    return d
+
+
+def mesh_scene(worlds, kind="box", device="cuda:0", ground_first=False, margin=0.0, gap=0.004, tilt=0.01, seed=3):
+    """One free body per world carrying a triangle mesh (a box with per-face vertices = three coincident vertices per corner, or a
+    UV sphere), resting slightly inside the ground plane with a small per-world tilt."""
+    import newton_amd as nt
+
+    rng = np.random.default_rng(seed)
+    if kind == "box":
+        hull = nt.Mesh.create_box(0.1, 0.08, 0.05)  # every corner three times (per-face vertices of a render mesh): roundoff twins
+        mesh, h = nt.Mesh(np.concatenate([hull.vertices] * 3), hull.indices), 0.05
+    else:
+        mesh, h = nt.Mesh.create_sphere(0.08, 12, 16), 0.08
+    env = nt.ModelBuilder()
+    env.default_shape_cfg.gap = gap
+    env.default_shape_cfg.margin = margin
+    b = env.add_body(xform=[0.0, 0.0, h - 0.0008, 0.0, 0.0, 0.0, 1.0])
+    env.add_shape_mesh(b, mesh=mesh)
+    scene = nt.ModelBuilder()
+    scene.default_shape_cfg.gap = gap
+    if ground_first:
+        scene.add_ground_plane()
+    scene.replicate(env, worlds)
+    if not ground_first:
+        scene.add_ground_plane()
+    model = scene.finalize(device=device)
+    for w in range(worlds):  # per-world pose: small tilt + offset (the worlds then differ in which vertices touch)
+        q = nt._np_math.quat_rpy(*(rng.uniform(-tilt, tilt, size=2)), rng.uniform(-1.0, 1.0))
+        model.body_q[w, 3:] = q
+        model.body_q[w, :2] = rng.uniform(-0.3, 0.3, size=2)
+        model.joint_q.reshape(-1, 7)[w] = model.body_q[w]
+    return model
+
+
+def checker_rows(model, leg, body_q):
+    """The rows the pipeline must emit, world-major, from the device's own exported shape transforms (oracle_mesh_plane ->
+    oracle_flat_contacts.write_rows)."""
+    import oracle_flat_contacts as F
+    import oracle_mesh_plane as omp
+
+    t = model.env
+    X = leg.world_xform.cpu().numpy()
+    data = np.concatenate([np.asarray(model.shape_scale, np.float32), np.asarray(model.shape_margin, np.float32)[:, None]], axis=1)
+    s = dict(shape_transform=X, shape_data=data, shape_gap=np.asarray(model.shape_gap, np.float32),
+             aabb_lo=np.asarray(model.shape_collision_aabb_lower, np.float32), aabb_hi=np.asarray(model.shape_collision_aabb_upper, np.float32),
+             res=np.asarray(model._shape_voxel_resolution, np.int32), vertex_start=model.mesh_vertex_range[:, 0],
+             vertex_count=model.mesh_vertex_range[:, 1], vertices=model.mesh_vertices)
+
+    def gid(l, w):
+        return t.shape_local0 + w * t.ns + l if l < t.ns else int(t.gshape_id[l - t.ns])
+
+    out = {k: [] for k in ("world", "key", *FIELDS)}
+    for w in range(t.env_count):
+        for (a, b), mp in zip(t.sdf_pair, t.sdf_pair_mesh_plane):
+            assert mp
+            ga, gb = gid(int(a), w), gid(int(b), w)
+            mesh, plane = (ga, gb) if s["vertex_count"][ga] > 0 else (gb, ga)
+            red = omp.mesh_plane_rows(dict(s, pairs=np.array([[mesh, plane]], np.int32)))
+            n = len(red["fp"])
+            if n == 0:
+                continue
+            raw = dict(key=red["fp"], shape_a=red["pair"][:, 0], shape_b=red["pair"][:, 1], center=red["pos"], normal=red["normal"],
+                       distance=red["depth"], margin_a=red["margin_a"], margin_b=red["margin_b"])
+            wr = F.write_rows(raw, np.asarray(body_q, np.float32), np.asarray(model.shape_body), s["shape_gap"])
+            out["world"] += [w] * n
+            out["key"] += red["fp"].tolist()
+            for name in FIELDS:
+                out[name] += list(wr[name])
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("kind,ground_first,margin", [("box", False, 0.0), ("sphere", True, 0.001)])
+def test_collide_rows_of_meshes_on_the_ground_match_the_checker(kind, ground_first, margin):
+    import newton_amd as nt
+
+    E = 6
+    model = mesh_scene(E, kind, ground_first=ground_first, margin=margin)
+    t = model.env
+    assert t.np == 0 and len(t.sdf_pair) == 1 and bool(t.sdf_pair_mesh_plane.all())  # the one pair takes the vertex leg
+    assert int(t.tile_shape_type[0]) == int(nt.GeoType.CONVEX_MESH) and int(t.shape_type[0]) == int(nt.GeoType.MESH)
+    pipe = nt.CollisionPipeline(model, broad_phase="nxn")
+    c1, c2 = pipe.contacts(), pipe.contacts()
+    state = model.state()
+    pipe.collide(state, c1)
+    pipe.collide(state, c2)
+    got, again = _rows(c1), _rows(c2)
+    for k in got:  # two collide() calls: bit-identical rows
+        assert np.array_equal(got[k], again[k]), k
+    leg = pipe._sdf_leg
+    assert not leg.overflow(c1._flat)["overflow"]
+    want = checker_rows(model, leg, model.body_q)
+    assert len(want["key"]) == len(got["key"]) > 3 * E
+    assert np.array_equal(got["row_start"], np.concatenate([[0], np.cumsum(np.bincount(want["world"], minlength=E))]))
+    assert np.array_equal(got["key"], want["key"])
+    for k in ("shape0", "shape1"):
+        assert np.array_equal(got[k], want[k]), k
+    plane = model.shape_count - 1 if not ground_first else 0
+    assert np.all(got["shape1"] == plane) and np.all(got["shape0"] != plane)  # (mesh, plane) whatever the id order
+    for k in FIELDS[2:]:  # same shape transforms in -> same rows out
+        assert np.abs(got[k] - want[k]).max() <= 2e-6, (k, np.abs(got[k] - want[k]).max())
+    # the world AABB of the mesh the tiles exported = its local AABB rotated (compute_shape_aabbs' pre-computed-AABB branch): it
+    # must contain every vertex; and Newton's flat view lists the rows
+    X = leg.world_xform.cpu().numpy()
+    lo, hi = leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    import oracle_mesh_plane as omp
+
+    for w in (0, E - 1):
+        sid = t.shape_local0 + w * t.ns
+        v = np.array([omp.transform_point(X[sid], p * np.asarray(model.shape_scale[sid], np.float32)) for p in model.mesh_vertices])
+        assert np.all(v >= lo[sid] - 1e-6) and np.all(v <= hi[sid] + 1e-6)
+        assert np.all(hi[sid] - lo[sid] < 0.5)
+    assert int(c1.rigid_contact_count.item()) == int((got["shape0"] != got["shape1"]).sum())
+    # reduce_contacts=False: every vertex within margin + gap is a row
+    pipe2 = nt.CollisionPipeline(model, broad_phase="nxn", reduce_contacts=False)
+    c3 = pipe2.contacts()
+    pipe2.collide(state, c3)
+    assert int(c3._flat.row_start[-1].item()) > len(got["key"])
+
+
+def test_mesh_boxes_settle_on_the_ground_under_every_solver():
+    """The rows feed the solvers like any SDF row: a mesh box dropped from 2 mm comes to rest on its bottom face."""
+    import newton_amd as nt
+
+    E = 4
+    for make, dt, steps in ((lambda m: nt.solvers.SolverXPBD(m, iterations=4), 1.0 / 600.0, 300),
+                            (lambda m: nt.solvers.SolverSemiImplicit(m), 1.0 / 4000.0, 1200)):
+        model = mesh_scene(E, "box", tilt=0.0, gap=0.002)
+        model.body_q[:, 2] += 0.002
+        model.joint_q.reshape(-1, 7)[:, 2] += 0.002
+        for k in ("ke", "kd", "kf", "mu"):
+            getattr(model, "shape_material_" + k)[:] = {"ke": 2.0e4, "kd": 50.0, "kf": 50.0, "mu": 0.5}[k]
+        solver = make(model)
+        pipe = nt.CollisionPipeline(model, broad_phase="nxn")
+        contacts = pipe.contacts()
+        s0, s1 = model.state(), model.state()
+        for _ in range(steps):
+            s0.clear_forces()
+            pipe.collide(s0, contacts)
+            solver.step(s0, s1, None, contacts, dt)
+            s0, s1 = s1, s0
+        q, qd = s0.body_q.cpu().numpy(), s0.body_qd.cpu().numpy()
+        assert np.all(np.isfinite(q)) and np.all(np.abs(q[:, 2] - 0.05) < 2e-3), (type(solver).__name__, q[:, 2])
+        assert np.abs(qd).max() < 0.05, (type(solver).__name__, np.abs(qd).max())

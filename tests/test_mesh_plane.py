@@ -281,3 +281,33 @@ def test_hip_mesh_plane_many_worlds_unreduced_and_overflow():
             assert np.array_equal(data_h[r0:r0 + cnt, 0:3], ref[f"{name}/pos"][sel])
             assert np.array_equal(data_h[r0:r0 + cnt, 6], ref[f"{name}/depth"][sel])
     assert np.all(blk_h.reshape(W, PPW, 2)[:, 2:] == -7)  # slots past a world's live pairs stay untouched
+
+
+@pytest.mark.gpu
+def test_hip_mesh_plane_python_entry():
+    """newton_amd.mesh_plane.mesh_plane_contacts (the stand-alone host entry) = the record; host tensors are refused."""
+    import torch
+
+    from newton_amd.enums import GeoType
+    from newton_amd.mesh_plane import mesh_plane_contacts
+
+    ref = np.load(VEC)
+    name = "cube_flat"
+    s = mc.scene(name)
+    d = lambda x, t: torch.as_tensor(np.ascontiguousarray(x), dtype=t, device="cuda:0")  # noqa: E731
+    stype = np.where(s["vertex_count"] > 0, int(GeoType.MESH), int(GeoType.PLANE))
+    args = [d(np.sort(s["pairs"], axis=1), torch.int32), d(stype, torch.int32), d(s["shape_transform"], torch.float32),
+            d(s["shape_data"], torch.float32), d(s["shape_gap"], torch.float32),
+            d(np.stack([s["vertex_start"], s["vertex_count"]], axis=1), torch.int32), d(s["vertices"], torch.float32),
+            d(s["aabb_lo"], torch.float32), d(s["aabb_hi"], torch.float32), d(s["res"], torch.int32)]
+    out = mesh_plane_contacts(*args)
+    n = int(out["count"].item())
+    assert n == len(ref[f"{name}/fp"]) and args[0].cpu().numpy().tolist() == s["pairs"].tolist()
+    r0, cnt = out["blk"].cpu().numpy()[0]
+    assert cnt == n and np.array_equal(out["vertex"].cpu().numpy()[r0:r0 + cnt], ref[f"{name}/fp"])
+    assert np.array_equal(out["data"].cpu().numpy()[r0:r0 + cnt, 0:3], ref[f"{name}/pos"])
+    from newton_amd import _lib
+
+    if os.path.abspath(_lib.LIB_PATH) == os.path.abspath(_lib._DEFAULT_LIB):  # (the CPU emulator's "cuda" tensors are host tensors)
+        with pytest.raises(TypeError):
+            mesh_plane_contacts(args[0].cpu(), *args[1:])
