@@ -2,8 +2,8 @@
 contact_reduction_global.py:1246-1346,2059-2290 the buffered reduction + export): ``mesh_plane_contacts`` runs
 ``nt_mesh_plane_pairs`` (csrc/nt_mesh_plane.hip, include/newton_hip_mesh.h) on torch CUDA tensors in Newton's flat layout and
 returns the ContactData rows per pair -- the rows ``nt_contact_rows_write`` / ``nt_sdf_rows_finalize`` turn into Newton's contact
-arrays.  Not yet a leg of ``CollisionPipeline.collide``: the tile kernels' shape phase has no AABB for GeoType.MESH shapes
-(DESIGN.md section 7), so models with such pairs are still refused by ``newton_amd/model.py``.  No CPU fallback."""
+arrays.  Inside ``CollisionPipeline.collide`` the same entry point runs as pair kind 2 of the SDF leg
+(``newton_amd/sdf_pipeline.py``); this module is the stand-alone form on caller-provided arrays.  No CPU fallback."""
 from __future__ import annotations
 
 import ctypes as C

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 GPU session U (build src 914b806b3066 = session S's stepping / SDF / matching units byte for byte + the swept broad-phase
-# entry points in nt_broadphase.hip): smoke, headline line with the cpu baseline (PMC traffic attached through the stepping-unit
+# Round-4 GPU session U (build src 2161716a98a2 = session S's stepping unit byte for byte (e9e5f0b2fc6f), nt_sdf.hip with identical
+# device code (its reducer helpers moved to nt_contact_reduce.hpp) + the swept broad-phase entry points + the mesh vertex leg): smoke, headline line with the cpu baseline (PMC traffic attached through the stepping-unit
 # hash e9e5f0b2fc6f), driver-shape line, kernel stats of the headline.  Bounded to ~90 s of box time (what is left of the round).
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
