@@ -65,8 +65,8 @@ class EmuModel:
         d.env_count, d.env_stride = t.env_count, t.env_stride
         d.nb, d.nj, d.nd, d.nc, d.ntq, d.ns, d.ng, d.np, d.cpp = t.nb, t.nj, t.nd, t.nc, t.ntq, t.ns, t.ng, t.np, t.cpp
         d.np_analytic, d.na, d.max_art_dofs, d.shape_local0 = t.np_analytic, t.na, t.max_art_dofs, t.shape_local0
-        for k in self.TOPOLOGY:
-            self.keep[k] = i32(getattr(t, k))
+        for k in self.TOPOLOGY:  # (the tiles' shape-type table: triangle meshes as pre-computed-AABB shapes, like DeviceModel)
+            self.keep[k] = i32(getattr(t, "tile_shape_type" if k == "shape_type" else k))
         self.keep["mesh_points"], self.keep["shape_mesh_bounds"] = f32(t.mesh_points), f32(t.shape_mesh_bounds)
         packed = pack_param_arrays(model, t)
         d.params_uniform = params_uniform(packed, t.env_count)
