@@ -339,3 +339,47 @@ def test_pmc_traffic_is_only_attached_to_the_code_object_it_was_measured_on(monk
     assert rec is None or rec["build_id"] == bench.build_id()
     monkeypatch.setattr(g, "source_hash", lambda: "f" * 12)  # a library that does not belong to these sources
     assert bench.step_unit_id() is None
+
+
+def test_triangle_mesh_shapes_route_to_the_vertex_leg_or_are_refused():
+    """ModelBuilder.add_shape_mesh (builder.py:7158-7198): mass properties like a convex hull's (inertia.py:726-757 treats MESH and
+    CONVEX_MESH alike), local AABB / voxel grid / collision radius of the scaled vertices, the vertex table un-deduplicated (the
+    vertex index is the contact fingerprint); a (MESH, infinite plane) pair leaves the tiles for the vertex leg
+    (narrow_phase.py:618-631) while the tiles keep the mesh as a pre-computed-AABB shape; mesh-vs-primitive pairs (triangle leg)
+    and a finite plane are refused at finalize."""
+    hull = nt.Mesh.create_box(0.1, 0.08, 0.05)
+    mesh = nt.Mesh(np.concatenate([hull.vertices] * 3), hull.indices)  # per-face vertices of a render mesh: every corner three times
+
+    def scene(extra=None, plane=True, scale=(1.0, 1.0, 1.0)):
+        env = nt.ModelBuilder()
+        b = env.add_body(xform=[0, 0, 0.05, 0, 0, 0, 1])
+        env.add_shape_mesh(b, mesh=mesh, scale=scale)
+        if extra:
+            extra(env)
+        s = nt.ModelBuilder()
+        s.replicate(env, 3)
+        if plane:
+            s.add_ground_plane()
+        return s.finalize(device=None)
+
+    m = scene(scale=(1.0, 2.0, 1.0))
+    t = m.env
+    assert t.np == 0 and t.sdf_pair.tolist() == [[0, 1]] and t.sdf_pair_mesh_plane.tolist() == [True] and not t.sdf_pair_hydro.any()
+    assert t.shape_type.tolist() == [int(GeoType.MESH), int(GeoType.PLANE)]
+    assert t.tile_shape_type.tolist() == [int(GeoType.CONVEX_MESH), int(GeoType.PLANE)]
+    assert m.mesh_vertex_range.tolist() == [[0, 24]] * 3 + [[0, 0]] and m.mesh_vertices.shape == (24, 3)  # one shared, full table
+    assert np.allclose(m.shape_collision_aabb_lower[0], [-0.1, -0.16, -0.05]) and np.allclose(m.shape_collision_aabb_upper[1], [0.1, 0.16, 0.05])
+    assert int(np.prod(m._shape_voxel_resolution[0])) in range(60, 101) and m._shape_voxel_resolution[3].tolist() == [0, 0, 0]
+    assert np.isclose(m.shape_collision_radius[0], 0.5 * np.linalg.norm([0.2, 0.32, 0.1]))
+    vol = 0.2 * 0.32 * 0.1
+    assert np.isclose(m.body_mass[0], 1000.0 * vol, rtol=1e-5)  # default density, the scaled box
+    # non-uniform scale: the reference's own rule I_xx' = I_xx (sy^2 + sz^2) / 2 |sx sy sz| density (inertia.py:744-746), not the
+    # exact tensor of the stretched box
+    I0xx = (0.2 * 0.16 * 0.1) / 12.0 * (0.16 ** 2 + 0.1 ** 2)
+    assert np.isclose(np.asarray(m.body_inertia[0]).reshape(3, 3)[0, 0], I0xx * (2.0 ** 2 + 1.0) / 2.0 * 2.0 * 1000.0, rtol=1e-4)
+    assert nt.sdf_pipeline.model_has_sdf_pairs(m)
+    with pytest.raises(NotImplementedError, match="no analytic path"):  # a sphere next to the mesh: the triangle leg is not built
+        scene(lambda env: env.add_shape_sphere(env.add_body(xform=[0.3, 0, 0.05, 0, 0, 0, 1]), radius=0.05))
+    with pytest.raises(NotImplementedError, match="no analytic path"):  # a FINITE plane is a convex shape: triangle leg again
+        scene(lambda env: env.add_shape(body=-1, type=GeoType.PLANE, scale=(1.0, 1.0, 0.0)), plane=False)
+    assert len(scene(plane=False).env.sdf_pair) == 0  # nothing to collide with: no legs at all
