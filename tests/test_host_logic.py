@@ -383,3 +383,10 @@ def test_triangle_mesh_shapes_route_to_the_vertex_leg_or_are_refused():
     with pytest.raises(NotImplementedError, match="no analytic path"):  # a FINITE plane is a convex shape: triangle leg again
         scene(lambda env: env.add_shape(body=-1, type=GeoType.PLANE, scale=(1.0, 1.0, 0.0)), plane=False)
     assert len(scene(plane=False).env.sdf_pair) == 0  # nothing to collide with: no legs at all
+    # env-range shards / world groups / tiled copies keep the per-shape vertex ranges (the vertex table itself is a shared asset)
+    from newton_amd.worlds import slice_worlds, tile_worlds
+
+    part, twice = slice_worlds(m, 1, 3), tile_worlds(m, 2)
+    assert part.mesh_vertex_range.tolist() == [[0, 24]] * 2 + [[0, 0]] and part.mesh_vertices is m.mesh_vertices
+    assert part.env.env_count == 2 and part.env.sdf_pair_mesh_plane.tolist() == [True]
+    assert twice.mesh_vertex_range.shape == (7, 2) and twice.env.env_count == 6 and twice.env.sdf_pair_mesh_plane.tolist() == [True]
