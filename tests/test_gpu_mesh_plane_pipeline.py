@@ -165,3 +165,39 @@ def test_mesh_boxes_settle_on_the_ground_under_every_solver():
         q, qd = s0.body_q.cpu().numpy(), s0.body_qd.cpu().numpy()
         assert np.all(np.isfinite(q)) and np.all(np.abs(q[:, 2] - 0.05) < 2e-3), (type(solver).__name__, q[:, 2])
         assert np.abs(qd).max() < 0.05, (type(solver).__name__, np.abs(qd).max())
+
+
+def test_mesh_box_on_ground_like_the_reference_test():
+    """newton/tests/test_rigid_contact.py:512-605 (test_mesh_box_on_ground), call for call: ground plane first, a unit mesh box
+    (Mesh.create_box, compute_inertia=False -> mass properties from the triangles) resting with its bottom face on z = 0, SolverXPBD
+    iterations=2, CollisionPipeline defaults, 60 frames of 10 substeps at 1/600 s: stays at z ~ 0.5 with every velocity below 0.01."""
+    import newton_amd as nt
+
+    builder = nt.ModelBuilder()
+    builder.default_shape_cfg.ke = 1.0e5
+    builder.default_shape_cfg.kd = 1.0e3
+    builder.default_shape_cfg.mu = 0.5
+    builder.add_ground_plane()
+    box_half = 0.5
+    box_mesh = nt.Mesh.create_box(box_half, box_half, box_half, duplicate_vertices=False, compute_normals=False, compute_uvs=False,
+                                  compute_inertia=False)
+    body = builder.add_body(xform=[0.0, 0.0, box_half, 0.0, 0.0, 0.0, 1.0])
+    builder.add_shape_mesh(body=body, mesh=box_mesh)
+    model = builder.finalize(device="cuda:0")
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    state_0, state_1 = model.state(), model.state()
+    control = model.control()
+    pipeline = nt.CollisionPipeline(model)
+    contacts = pipeline.contacts()
+    nt.eval_fk(model, model.joint_q, model.joint_qd, state_0)
+    sim_dt, substeps = 1.0 / 60.0, 10
+    for _ in range(60):
+        for _ in range(substeps):
+            state_0.clear_forces()
+            pipeline.collide(state_0, contacts)
+            solver.step(state_0, state_1, control, contacts, sim_dt / substeps)
+            state_0, state_1 = state_1, state_0
+    q, qd = state_0.body_q.cpu().numpy()[body], state_0.body_qd.cpu().numpy()[body]
+    assert box_half * 0.9 < q[2] < box_half * 1.1, q
+    assert np.all(np.abs(qd) < 0.01), qd
+    assert int(contacts.rigid_contact_count.item()) == 4  # the four bottom corners
