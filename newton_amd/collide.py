@@ -310,9 +310,10 @@ class ContactMatcher:
         dm, t = self.dm, self.model.env
         d_s, d_c = state._desc(), contacts._desc()
         mask_ptr = self._reset_mask.data_ptr() if self._reset_mask is not None else None
-        _lib.check(dm.lib.nt_contacts_match(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h), self.pos_threshold,
-                                            self.normal_dot_threshold, mask_ptr, self._match.data_ptr(), dm.stream()),
-                   "nt_contacts_match")
+        if t.np * t.cpp > 0:  # (a model whose pairs all take the SDF / vertex legs has no slot contacts to match)
+            _lib.check(dm.lib.nt_contacts_match(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h), self.pos_threshold,
+                                                self.normal_dot_threshold, mask_ptr, self._match.data_ptr(), dm.stream()),
+                       "nt_contacts_match")
         self._reset_mask = None
         E = t.env_count
         live_now = (contacts._shape0[: t.np * t.cpp] >= 0) & (contacts._shape0[: t.np * t.cpp] != contacts._shape1[: t.np * t.cpp])
@@ -347,8 +348,9 @@ class ContactMatcher:
             raise ValueError("replay_matched requires ContactMatcher(sticky=True)")
         dm = self.dm
         d_s, d_c = state._desc(), contacts._desc()
-        _lib.check(dm.lib.nt_contacts_replay_matched(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h),
-                                                     self._match.data_ptr(), dm.stream()), "nt_contacts_replay_matched")
+        if self.model.env.np * self.model.env.cpp > 0:
+            _lib.check(dm.lib.nt_contacts_replay_matched(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h),
+                                                         self._match.data_ptr(), dm.stream()), "nt_contacts_replay_matched")
         if self._rows is not None:
             self._rows.replay_matched(state, contacts._flat)
         contacts._generation += 1
@@ -357,8 +359,9 @@ class ContactMatcher:
         """Persist this frame's contacts as the next frame's history (call after match, with the state they were made on)."""
         dm, t = self.dm, self.model.env
         d_s, d_c = state._desc(), contacts._desc()
-        _lib.check(dm.lib.nt_contacts_save_history(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h), dm.stream()),
-                   "nt_contacts_save_history")
+        if t.np * t.cpp > 0:
+            _lib.check(dm.lib.nt_contacts_save_history(C.byref(dm.desc), C.byref(d_s), C.byref(d_c), C.byref(self._h), dm.stream()),
+                       "nt_contacts_save_history")
         self._prev_flat = self._flat_index(self._live[: t.np * t.cpp])
         order = contacts.export_order()
         torch = _torch()

@@ -27,10 +27,10 @@ def test_smoke_dry_run(oracle_lib):
 
 def test_mesh_on_ground_pipeline_dry_run(oracle_lib):
     """Triangle meshes on the ground plane through CollisionPipeline.collide (the vertex leg as pair kind 2 of the SDF leg): the row
-    tests of tests/test_gpu_mesh_plane_pipeline.py on the emulated library -- builder, pair routing, the tile's MESH-as-local-AABB
+    and matching tests of tests/test_gpu_mesh_plane_pipeline.py on the emulated library -- builder, pair routing, the tile's MESH-as-local-AABB
     shape, nt_mesh_plane_pairs, nt_sdf_rows_finalize -- against the checker chain.  (The settle test of that file takes half an hour
     of emulation and stays with the device.)"""
     r = subprocess.run([sys.executable, "-m", "pytest", "-p", "emu_plugin", "-m", "gpu", "-q", "-x", "test_gpu_mesh_plane_pipeline.py",
-                        "-k", "rows_of_meshes"], cwd=TESTS, env=ENV, capture_output=True, text=True, timeout=900)
+                        "-k", "rows_of_meshes or matching"], cwd=TESTS, env=ENV, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout
+    assert "3 passed" in r.stdout

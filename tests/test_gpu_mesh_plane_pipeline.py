@@ -201,3 +201,41 @@ def test_mesh_box_on_ground_like_the_reference_test():
     assert box_half * 0.9 < q[2] < box_half * 1.1, q
     assert np.all(np.abs(qd) < 0.01), qd
     assert int(contacts.rigid_contact_count.item()) == 4  # the four bottom corners
+
+
+def test_contact_matching_and_deterministic_order_over_vertex_rows():
+    """contact_matching="latest" + contact_report on a model whose only pairs take the vertex leg (no slot contacts at all: the
+    slot matcher has nothing to do, the row matcher carries the frame): first frame MATCH_NOT_FOUND, an unchanged second frame
+    matches row for row with nothing new or broken; moving one world's body breaks / renews its rows only; deterministic=True
+    keeps the (shape0, shape1, vertex) order."""
+    import newton_amd as nt
+
+    E = 3
+    model = mesh_scene(E, "box")
+    pipe = nt.CollisionPipeline(model, broad_phase="nxn", contact_matching="latest", contact_report=True)
+    c = pipe.contacts()
+    state = model.state()
+    pipe.collide(state, c)
+    n = int(c.rigid_contact_count.item())
+    assert n >= 3 * E and np.all(c.rigid_contact_match_index[:n].cpu().numpy() == -1)
+    pipe.collide(state, c)
+    assert int(c.rigid_contact_count.item()) == n
+    assert np.array_equal(c.rigid_contact_match_index[:n].cpu().numpy(), np.arange(n))
+    assert int(c.rigid_contact_new_count.item()) == 0 and int(c.rigid_contact_broken_count.item()) == 0
+    s0, s1 = c.rigid_contact_shape0[:n].cpu().numpy(), c.rigid_contact_shape1[:n].cpu().numpy()
+    assert np.all(np.diff(s0) >= 0) and np.all(s1 == model.shape_count - 1)
+    # world 1 moves sideways by more than the position threshold: its rows are new, the others still match
+    q = state.body_q.cpu().numpy().copy()
+    q[1, 0] += 0.05
+    state.body_q = q  # (the State setter takes Newton's AoS array, host or device)
+    pipe.collide(state, c)
+    mi = c.rigid_contact_match_index[: int(c.rigid_contact_count.item())].cpu().numpy()
+    s0 = c.rigid_contact_shape0[: len(mi)].cpu().numpy()
+    assert np.all(mi[s0 == 1] < 0) and np.all(mi[s0 != 1] >= 0)
+    assert int(c.rigid_contact_new_count.item()) == int((s0 == 1).sum())
+    det = nt.CollisionPipeline(model, broad_phase="nxn", deterministic=True)
+    cd = det.contacts()
+    det.collide(state, cd)
+    nd = int(cd.rigid_contact_count.item())
+    key = cd.rigid_contact_shape0[:nd].cpu().numpy().astype(np.int64) * 10_000 + cd._flat.key[:nd].cpu().numpy()
+    assert nd == len(mi) and np.all(np.diff(key) > 0)
