@@ -239,3 +239,52 @@ def test_contact_matching_and_deterministic_order_over_vertex_rows():
     nd = int(cd.rigid_contact_count.item())
     key = cd.rigid_contact_shape0[:nd].cpu().numpy().astype(np.int64) * 10_000 + cd._flat.key[:nd].cpu().numpy()
     assert nd == len(mi) and np.all(np.diff(key) > 0)
+
+
+def test_mesh_worlds_inside_heterogeneous_models():
+    """Worlds that differ in topology (a mesh box here, a mesh sphere plus a primitive box there) run as world groups
+    (newton_amd/hetero.py): every group has its own vertex leg, the flat contact arrays keep Newton's shape ids -- slot contacts of
+    the primitive boxes first, then the mesh rows as (mesh, plane) -- and the bodies stay on the ground under XPBD."""
+    import newton_amd as nt
+
+    hull = nt.Mesh.create_box(0.1, 0.08, 0.05)
+    box_mesh = nt.Mesh(np.concatenate([hull.vertices] * 3), hull.indices)
+    sphere_mesh = nt.Mesh.create_sphere(0.08, 8, 10)
+
+    def env(mesh, h, extra=False):
+        e = nt.ModelBuilder()
+        e.default_shape_cfg.gap = 0.004
+        b = e.add_body(xform=[0, 0, h - 0.0008, 0, 0, 0, 1])
+        e.add_shape_mesh(b, mesh=mesh)
+        if extra:
+            b2 = e.add_body(xform=[0.5, 0, 0.05, 0, 0, 0, 1])
+            e.add_shape_box(b2, hx=0.05, hy=0.05, hz=0.05)
+            e.add_shape_collision_filter_pair(0, 1)  # (a mesh-vs-box pair would need the triangle leg)
+        return e
+
+    scene = nt.ModelBuilder()
+    scene.default_shape_cfg.gap = 0.004
+    for k in range(4):
+        scene.add_world(env(box_mesh, 0.05) if k % 2 == 0 else env(sphere_mesh, 0.08, extra=True))
+    scene.add_ground_plane()
+    model = scene.finalize(device="cuda:0")
+    plane = model.shape_count - 1
+    meshes = [s for s in range(model.shape_count) if int(model.shape_type[s]) == int(nt.GeoType.MESH)]
+    assert meshes == [0, 1, 3, 4]
+    pipe = nt.CollisionPipeline(model, broad_phase="nxn")
+    c = pipe.contacts()
+    s0, s1 = model.state(), model.state()
+    pipe.collide(s0, c)
+    n = int(c.rigid_contact_count.item())
+    a, b = c.rigid_contact_shape0[:n].cpu().numpy(), c.rigid_contact_shape1[:n].cpu().numpy()
+    slot = np.isin(b, [2, 5])  # the primitive boxes: (plane, box) slot contacts, four corners each
+    assert slot.sum() == 8 and np.all(a[slot] == plane) and np.all(np.flatnonzero(slot) < 8)
+    assert np.all(b[~slot] == plane) and sorted(set(a[~slot].tolist())) == meshes  # every mesh touches the ground, as (mesh, plane)
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    for _ in range(60):
+        s0.clear_forces()
+        pipe.collide(s0, c)
+        solver.step(s0, s1, None, c, 1.0 / 600.0)
+        s0, s1 = s1, s0
+    z = s0.body_q.cpu().numpy()[:, 2]
+    assert np.all(np.abs(z - np.array([0.05, 0.08, 0.05, 0.05, 0.08, 0.05])) < 3e-3), z
