@@ -390,3 +390,38 @@ def hull_bin_scene(world_count: int, n_hulls: int = 64, device=None, seed: int =
         model.body_q[:, :3] += off
         model.joint_q.reshape(-1, 7)[:, :3] += off
     return model
+
+
+def mesh_ground_scene(world_count: int, n_meshes: int = 8, device=None, seed: int = 4, jitter: float = 0.01, gap: float = 0.004):
+    """`n_meshes` triangle-mesh bodies per world resting on the infinite ground plane, spaced so that they never meet (the mesh-vs-
+    mesh / mesh-vs-primitive legs are not built): alternately a UV sphere of 32 x 32 = 994 vertices and a box whose corners appear
+    three times (per-face vertices of a render mesh).  Every (mesh, plane) pair goes through the vertex leg of
+    CollisionPipeline.collide; worlds differ by a seeded pose jitter.  bench.py --workload mesh_ground."""
+    import newton_amd as nt
+
+    rng = np.random.default_rng(seed)
+    hull = nt.Mesh.create_box(0.1, 0.08, 0.05)
+    box = nt.Mesh(np.concatenate([hull.vertices] * 3), hull.indices)
+    sphere = nt.Mesh.create_sphere(0.08, 32, 32)
+    env = nt.ModelBuilder()
+    env.default_shape_cfg.gap = gap
+    env.default_shape_cfg.mu = 0.5
+    side = int(np.ceil(np.sqrt(n_meshes)))
+    shapes = []
+    for k in range(n_meshes):
+        mesh, h = (sphere, 0.08) if k % 2 == 0 else (box, 0.05)
+        b = env.add_body(xform=[0.5 * (k % side), 0.5 * (k // side), h - 0.0005, 0.0, 0.0, 0.0, 1.0])
+        shapes.append(env.add_shape_mesh(b, mesh=mesh))
+    for i in range(n_meshes):  # the meshes are too far apart to touch: no mesh-mesh candidate pairs at all
+        for j in range(i + 1, n_meshes):
+            env.add_shape_collision_filter_pair(shapes[i], shapes[j])
+    scene = nt.ModelBuilder()
+    scene.default_shape_cfg.gap = gap
+    scene.replicate(env, world_count)
+    scene.add_ground_plane()
+    model = scene.finalize(device=device)
+    if jitter > 0.0:
+        off = rng.uniform(-jitter, jitter, size=(model.body_count, 2)).astype(np.float32)
+        model.body_q[:, :2] += off
+        model.joint_q.reshape(-1, 7)[:, :2] += off
+    return model
