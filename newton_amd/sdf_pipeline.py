@@ -145,6 +145,9 @@ class SdfLeg:
             self._shape_type = up(model.shape_type, np.int32)
             self._vertex_range = up(model.mesh_vertex_range, np.int32)
             self._vertices = up(model.mesh_vertices, np.float32)
+            if int(np.asarray(model.mesh_vertex_range)[:, 1].max()) >= (1 << 22):
+                # the reduction's packed values carry the vertex index in 22 bits (contact_reduction_global.py: FINGERPRINT bits)
+                raise NotImplementedError("triangle meshes with 2^22 or more vertices are not supported by the vertex leg")
             # rows a world can get from its vertex pairs: every vertex when the reduction is off, else the reduction's table
             mp_rows = sum(int(model.mesh_vertex_range[t.shape_local0 + l if l < t.ns else int(t.gshape_id[l - t.ns]), 1])
                           for pr in t.sdf_pair[mesh_plane] for l in pr)
