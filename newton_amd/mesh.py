@@ -77,8 +77,27 @@ class Mesh:
     @staticmethod
     def create_box(hx: float, hy: float, hz: float, *, duplicate_vertices: bool = False, compute_normals: bool = False,
                    compute_uvs: bool = False, compute_inertia: bool = True) -> Mesh:
-        """newton.Mesh.create_box signature (geometry/types.py); only the 8 corners matter for collision, so the rendering
-        options (duplicated per-face vertices, normals, uvs) are accepted and ignored."""
+        """newton.Mesh.create_box signature (geometry/types.py:560-620).  duplicate_vertices=True builds the reference's per-face
+        vertex table (utils/mesh.py:2044-2065: faces -x, +x, -y, +y, -z, +z, four corners each, cycling (-,-), (-,+), (+,+), (+,-)
+        over the face's two other axes) -- the vertex ORDER matters once the mesh collides vertex by vertex (add_shape_mesh: the
+        vertex index is the contact fingerprint); pinned by tests/golden/mesh_box_tables.json.  The default keeps this package's
+        8-corner hull (convex hulls de-duplicate anyway; normals / uvs are rendering data: accepted and ignored)."""
+        if duplicate_vertices:
+            h = (float(hx), float(hy), float(hz))
+            cyc = ((-1, -1), (-1, 1), (1, 1), (1, -1))
+            verts, tris = [], []
+            for axis in range(3):
+                u, v = [k for k in range(3) if k != axis]
+                for sign in (-1, 1):
+                    base = len(verts)
+                    for cu, cv in cyc:
+                        p = [0.0, 0.0, 0.0]
+                        p[axis], p[u], p[v] = sign * h[axis], cu * h[u], cv * h[v]
+                        verts.append(p)
+                    forward = (sign < 0) != (axis == 1)  # outward winding: x- / y+ / z- list the cycle as it is
+                    tris += [(base, base + 1, base + 2), (base, base + 2, base + 3)] if forward else \
+                        [(base, base + 2, base + 1), (base, base + 3, base + 2)]
+            return Mesh(np.asarray(verts, dtype=np.float32), np.asarray(tris, dtype=np.int32), compute_inertia=compute_inertia)
         s = np.array([hx, hy, hz], dtype=np.float64)
         v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float64) * s
         return Mesh.convex_hull_of(v)

@@ -390,3 +390,18 @@ def test_triangle_mesh_shapes_route_to_the_vertex_leg_or_are_refused():
     assert part.mesh_vertex_range.tolist() == [[0, 24]] * 2 + [[0, 0]] and part.mesh_vertices is m.mesh_vertices
     assert part.env.env_count == 2 and part.env.sdf_pair_mesh_plane.tolist() == [True]
     assert twice.mesh_vertex_range.shape == (7, 2) and twice.env.env_count == 6 and twice.env.sdf_pair_mesh_plane.tolist() == [True]
+
+
+def test_create_box_with_duplicated_vertices_is_the_reference_table():
+    """Mesh.create_box(duplicate_vertices=True) = create_mesh_box of the reference, vertex for vertex and triangle for triangle
+    (tests/golden/mesh_box_tables.json, recorded by executing newton/_src/utils/mesh.py:2034-2131); outward winding: the solid
+    mass properties are the box's."""
+    import json
+
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "mesh_box_tables.json")))["duplicated"]
+    m = nt.Mesh.create_box(0.5, 0.25, 0.125, duplicate_vertices=True)
+    assert np.array_equal(m.vertices, np.asarray(ref["positions"], np.float32))
+    assert m.indices.tolist() == ref["indices"]
+    assert np.isclose(m.mass, 1.0 * 0.5 * 0.25) and np.allclose(m.com, 0.0, atol=1e-7)  # unit density x (2 hx)(2 hy)(2 hz)
+    assert np.isclose(m.inertia[0, 0], m.mass / 12.0 * (0.5 ** 2 + 0.25 ** 2), rtol=1e-5)
+    assert len(nt.Mesh.create_box(0.5, 0.25, 0.125).vertices) == 8  # the default: this package's 8-corner hull
