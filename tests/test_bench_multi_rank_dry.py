@@ -69,3 +69,30 @@ def test_bench_rejects_a_world_size_that_does_not_match(oracle_lib):
     outs = _launch(1, "--gpus 2 --steps 1 --warmup 0 --envs-per-gpu 16 --settle-frames 0 --no-cpu-baseline", timeout=300)
     rc, o, e = outs[0]
     assert rc != 0 and "WORLD_SIZE=1" in (o + e)
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher(oracle_lib):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (no torch.distributed.run around it): bench.py starts the two
+    ranks itself (one process per GPU, 127.0.0.1 rendezvous) and the command prints exactly ONE JSON line -- rank 0's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NT_BENCH_DRY_SINGLE_GPU="1", NT_EMU=EMU, NT_ROOT=ROOT,
+               PYTHONPATH=os.pathsep.join([os.path.join(EMU, "site"), env.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "16",
+                        "--settle-frames", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["config"]["parallelism"] == "env-shard x2" and d["scaling"] == "weak"
+    total = 2 * 16 * d["config"]["substeps_per_step"] * d["steps"]
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-6 * d["value"]
+
+
+def test_a_failing_rank_ends_the_self_spawned_job(oracle_lib):
+    """A rank that dies takes the job down with a non-zero exit code instead of leaving the other rank in the barrier."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NT_BENCH_DRY_SINGLE_GPU="1", NT_EMU=EMU, NT_ROOT=ROOT, NT_BENCH_FAIL_RANK="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(EMU, "site"), env.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--envs-per-gpu", "16",
+                        "--settle-frames", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not _json_lines(r.stdout)
