@@ -187,8 +187,8 @@ NT_DI void write_contact_slot(const Ctx<EPB>& c, int slot, int sa, int sb, vec3 
     const nt_contacts& ct = c.a.ct;
     const int ncs = c.a.m.np * c.a.m.cpp;
     int ba = c.T.shape_body[sa], bb = c.T.shape_body[sb];
-    xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q(ba));
-    xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q(bb));
+    xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q_in(ba));
+    xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q_in(bb));
     float off_a = ra + margin_a, off_b = rb + margin_b;
     vec3 aw = center - n * (0.5f * dist + ra);
     vec3 bw = center + n * (0.5f * dist + rb);
@@ -238,7 +238,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
     shape_world(c, sa, Xa, loa, hia);
     shape_world(c, sb, Xb, lob, hib);
     bool hit = KNOWN_HIT || (loa.x <= hib.x && hia.x >= lob.x && loa.y <= hib.y && hia.y >= lob.y && loa.z <= hib.z && hia.z >= lob.z);
-    if (!KNOWN_HIT) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+    if (!KNOWN_HIT && c.hbm_out) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
     int nvalid = 0;
     if (hit) {
         int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
@@ -339,6 +339,64 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
     }
     c.l(c.L.pc, 0, m.np, p) = (float)nvalid;
     c.l(c.L.pm, 0, m.np, p) = (float)nvalid;
+    if (STAGED && c.lds_records && nvalid > 0) {
+        // LDS-record tiles: the pair lane appends its live contacts to the environment's list itself (one LDS atomic), so no prefix
+        // pass exists.  The ORDER of the list varies with the waves' timing and does not matter: every contact owns its slot's record
+        // (L.cr / L.cw) and the body lanes sum in slot order.
+        const int base = atomicAdd(reinterpret_cast<int*>(&c.l(c.L.lc, 0, 1, 0)), nvalid);
+        for (int k = 0; k < nvalid; ++k) *reinterpret_cast<int*>(&c.l(c.L.lt, 0, 1, base + k)) = (p << 4) | k;
+    }
+}
+// LDS-record tiles, second stage: lane i converts the environment's i-th LIVE contact (L.lt) into the body-frame record of its slot in
+// L.cr -- one pass over the live contacts (16 for the standing quadruped) instead of two over all np * cpp slots, no HBM store and no
+// prefix lanes.  Same arithmetic as write_contact_slot.
+template <int EPB>
+NT_DI void contact_record_item_lds(const Ctx<EPB>& c, const int entry) {
+    const nt_model& m = c.a.m;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    const int p = entry >> 4, k = entry & 15, slot = p * cpp + k;
+    const int* d = c.T.pair_desc + 4 * p;  // type-sorted shapes + their bodies
+    const int sa = d[0], sb = d[1], ba = d[2], bb = (d[3] << 2) >> 2;
+    const int ta = c.T.shape_type[sa], tb = c.T.shape_type[sb];
+    const float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? c.shape_f(sa, SP_SCALE) : 0.0f;
+    const float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? c.shape_f(sb, SP_SCALE) : 0.0f;
+    const vec3 n = c.lv3(c.L.st, 0, m.np, p);
+    const vec3 center = c.lv3(c.L.st, 3 + 4 * k, m.np, p);
+    const float dist = c.l(c.L.st, 6 + 4 * k, m.np, p);
+    const xform Xbw_a = ba < 0 ? xform() : xform_inverse(c.body_q_in(ba));
+    const xform Xbw_b = bb < 0 ? xform() : xform_inverse(c.body_q_in(bb));
+    const float off_a = ra + c.shape_f(sa, SP_MARGIN), off_b = rb + c.shape_f(sb, SP_MARGIN);
+    const vec3 aw = center - n * (0.5f * dist + ra);
+    const vec3 bw = center + n * (0.5f * dist + rb);
+    c.st_lv3(c.L.cr, CD_POINT0, ncs, slot, xform_point(Xbw_a, aw));
+    c.st_lv3(c.L.cr, CD_POINT1, ncs, slot, xform_point(Xbw_b, bw));
+    c.st_lv3(c.L.cr, CD_OFFSET0, ncs, slot, xform_vector(Xbw_a, off_a * n));
+    c.st_lv3(c.L.cr, CD_OFFSET1, ncs, slot, xform_vector(Xbw_b, -off_b * n));
+    c.st_lv3(c.L.cr, CD_NORMAL, ncs, slot, n);
+    c.l(c.L.cr, CD_MARGIN0, ncs, slot) = off_a;
+    c.l(c.L.cr, CD_MARGIN1, ncs, slot) = off_b;
+}
+// ... and at the last substep of the launch the Contacts buffers in HBM receive them (one lane per slot: ids + record, or -1 ids)
+template <int EPB>
+NT_DI void contact_export_item_lds(const Ctx<EPB>& c, const int slot) {
+    const nt_model& m = c.a.m;
+    const nt_contacts& ct = c.a.ct;
+    const int cpp = m.cpp, ncs = m.np * cpp;
+    const int p = slot / cpp, k = slot - p * cpp;
+    const size_t gi = (size_t)slot * c.ES + c.env;
+    if (k < (int)c.l(c.L.pm, 0, m.np, p)) {
+        const int* d = c.T.pair_desc + 4 * p;
+        ct.shape0[gi] = c.newton_shape_id(d[0]);
+        ct.shape1[gi] = c.newton_shape_id(d[1]);
+        float v[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) v[i] = c.l(c.L.cr, i, ncs, slot);
+#pragma unroll
+        for (int i = 0; i < 17; ++i) ct.data[c.g(i, ncs, slot)] = v[i];
+    } else {
+        ct.shape0[gi] = -1;
+        ct.shape1[gi] = -1;
+    }
 }
 // second stage, analytic pairs only: contact slot (p, k) <- the pair's k-th admitted candidate
 template <int EPB>
@@ -420,7 +478,7 @@ NT_DI void phase_pair_broad_staged(const Ctx<EPB>& c) {
     int* count = reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0));
     for (int p = c.slot; p < m.np; p += c.nslot) {
         const bool hit = pair_aabb_hit(c, p);
-        ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+        if (c.hbm_out) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
         if (hit) {
             *reinterpret_cast<int*>(&c.l(c.L.hl, 0, m.np, atomicAdd(count, 1))) = p;
         } else {

@@ -17,13 +17,20 @@ struct Ctx {
     int tslot;  // start of the item loop of phases with fewer items than slot-threads.  Identity: dealing consecutive items to
                 // DIFFERENT waves (13 bodies x 16 envs on all 8 waves instead of 4) was measured and lost 13 % on the headline
                 // (87.4 vs 100.8 M env-steps/s) -- twice the wave-instructions cost more than the second wave per SIMD hides
+    int pose_in_off;  // rows of the poses the contact writer converts into (collide.py:166-204: the step's incoming poses): L.bq, or the
+                      // snapshot L.xiq while integrate_bodies runs beside the pair phase of a fused rollout
+    bool lds_records;  // NT_TILE_LDS_RECORDS granted: the contact records of this launch live in L.cr
+    bool hbm_out;      // the collide phases write the Contacts buffers in HBM (always, except the non-final substeps of an LDS-record rollout)
     bool big;  // contact records in HBM, manifold polygon scratch per lane (compile-time constant at every construction site)
     int ES;
     bool valid;
 
     // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
     NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
-        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI, rows < 0);  // (rows >= 0: another solver's layout, no live list)
+        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI, rows < 0, a.tile_opts);  // (rows >= 0: another solver's layout, no live list)
+        pose_in_off = L.bq.off;
+        lds_records = rows < 0 && (a.tile_opts & NT_TILE_LDS_RECORDS) != 0;
+        hbm_out = true;
         if (rows < 0) rows = L.rows_per_env;
         e = threadIdx.x % N;
         slot = threadIdx.x / N;
@@ -89,7 +96,8 @@ struct Ctx {
     // the same lane seen from the other arithmetic namespace (ieee::Ctx <-> fused::Ctx): no staging, every member copied
     template <class OtherCtx>
     NT_DI explicit Ctx(const OtherCtx& o, int /*tag*/)
-        : a(o.a), T(o.T), lds(o.lds), up(o.up), L(o.L), e(o.e), slot(o.slot), env(o.env), nslot(o.nslot), tslot(o.tslot), big(o.big),
+        : a(o.a), T(o.T), lds(o.lds), up(o.up), L(o.L), e(o.e), slot(o.slot), env(o.env), nslot(o.nslot), tslot(o.tslot),
+          pose_in_off(o.pose_in_off), lds_records(o.lds_records), hbm_out(o.hbm_out), big(o.big),
           ES(o.ES), valid(o.valid) {}
     // LDS element (comp, s) of a slot-major field.  `n` (the slot count of the [comp][n] HBM twin) is not needed here; the
     // argument stays so that every access reads like its global-memory counterpart g(comp, n, s)
@@ -164,6 +172,7 @@ struct Ctx {
     }
 
     NT_DI xform body_q(int b) const { return lxf(L.bq, 0, a.m.nb, b); }
+    NT_DI xform body_q_in(int b) const { return lxf(Fld<7>{pose_in_off}, 0, a.m.nb, b); }
     NT_DI quat body_rot(int b) const {
         const int nb = a.m.nb;
         return quat(l(L.bq, 3, nb, b), l(L.bq, 4, nb, b), l(L.bq, 5, nb, b), l(L.bq, 6, nb, b));
@@ -184,10 +193,16 @@ struct Ctx {
         return dot(v, wv);
     }
     NT_DI void update_body_derived(int b) const {
-        const int nb = a.m.nb;
         xform X = body_q(b);
-        st_lv3(L.bd, 0, nb, b, xform_point(X, com(b)));
-        mat33 R = quat_to_matrix(X.q);
+        update_world_com(b, X);
+        update_body_w(b, X.q);
+    }
+    // world COM of body b at pose X (the first three rows of the body-derived tile)
+    NT_DI void update_world_com(int b, const xform& X) const { st_lv3(L.bd, 0, a.m.nb, b, xform_point(X, com(b))); }
+    // W = R I^-1 R^T of body b at rotation q (rows 3..8 of the tile)
+    NT_DI void update_body_w(int b, quat q) const {
+        const int nb = a.m.nb;
+        mat33 R = quat_to_matrix(q);
         mat33 Ii = inv_inertia(b);
         // T = I^-1 R^T ; W = R T
         vec3 t0 = Ii * vec3(R.m00, R.m01, R.m02), t1 = Ii * vec3(R.m10, R.m11, R.m12), t2 = Ii * vec3(R.m20, R.m21, R.m22);

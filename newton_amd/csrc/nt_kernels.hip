@@ -269,9 +269,22 @@ int pick_epb(const nt_model& m, int requested, bool restitution = false) {
 }
 
 // semi: the SolverSemiImplicit kernel (own scratch layout); max_threads: the kernel's THREADS template argument
+// a.tile_opts on entry: the NT_TILE_* layout extras the kernel can use (nt_xpbd_rollout asks); granted only while the tile still fits
+// the CU, and the kernel sees what was granted
 template <typename K>
 nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false, bool uni = false) {
-    LdsLayout L = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni);
+    int tile_opts = a.tile_opts;
+    auto tile_bytes = [&](int opts) {
+        LdsLayout Lo = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni, opts);
+        return (size_t)Lo.rows_per_env * 4 * epb + (size_t)topo_ints(a.m) * 4 + (size_t)Lo.uni_floats * 4;
+    };
+    if (semi) tile_opts = 0;
+    if ((tile_opts & NT_TILE_LDS_RECORDS) &&
+        (a.m.np_analytic != a.m.np || a.m.contact_scratch_in_hbm || xpbd_keeps_prestep_state(a.p) || tile_bytes(tile_opts) > LDS_BYTES_PER_CU))
+        tile_opts &= ~NT_TILE_LDS_RECORDS;
+    if (tile_bytes(tile_opts) > LDS_BYTES_PER_CU) tile_opts = 0;
+    a.tile_opts = tile_opts;
+    LdsLayout L = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni, tile_opts);
     if (max_threads <= 0) max_threads = max_threads_for(epb);
     int nslot = slots_for(a.m, epb, max_threads);
     // rows of the SDF legs (nt_contacts.flat) are walked by the environment's slot-lanes too: hundreds per environment in a pile,
@@ -312,10 +325,13 @@ inline bool xpbd_cfg_override(XpbdCfg& c) {
 #ifdef NT_ALL_SHAPES
 #define NT_XPBD_ROLLOUT_SHAPES(X) \
     X(16, 512, 1, 0) X(16, 256, 1, 0) X(8, 256, 2, 0) \
-    X(16, 256, 2, 1) X(16, 512, 2, 1) X(16, 512, 4, 1) X(32, 512, 1, 1) X(8, 128, 4, 1) X(8, 256, 4, 1)
+    X(16, 256, 2, 1) X(16, 512, 1, 1) X(16, 512, 2, 1) X(16, 512, 4, 1) X(32, 512, 1, 1) X(8, 128, 4, 1) X(8, 256, 4, 1)
 #define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1) X(16, 256, 2, 1)
+#elif defined(NT_DEV_FAST)
+#define NT_XPBD_ROLLOUT_SHAPES(X) X(16, 512, 1, 0) X(32, 512, 1, 1) X(16, 512, 1, 1)
+#define NT_XPBD_ROLLOUT_SHAPES_CVX(X)
 #else
-#define NT_XPBD_ROLLOUT_SHAPES(X) X(16, 512, 1, 0) X(32, 512, 1, 1) X(16, 256, 2, 1)
+#define NT_XPBD_ROLLOUT_SHAPES(X) X(16, 512, 1, 0) X(32, 512, 1, 1) X(16, 512, 1, 1)
 #define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1)
 #endif
 // convex (MPR / GJK) variants of the uniform-parameter tile: the parameter diet lets two 8-environment workgroups (or one of 16)
@@ -324,6 +340,17 @@ inline bool xpbd_cfg_override(XpbdCfg& c) {
 // MI355X, quadruped: 4096 envs 78 vs 92 M env-steps/s for the 16-env per-environment tile -- half the CUs idle; 8192 envs 158
 // vs 101 M; 65536 envs 157 vs 99 M.  2 x (16, 256) per CU: 144-149 M)
 constexpr XpbdCfg NT_XPBD_UNI_DEFAULT = {32, 512, 1, 1, 0};
+// ... and below that size: the uniform tile of 16 (one per CU up to 4 096 environments).  Same kernels as the per-environment tile with
+// the parameters read by broadcast from one block-shared copy: 3 % faster at 4 096 environments (profiles/r05c_ab.txt), and the 89 KB of
+// LDS it leaves free hold the tile extras of the fused rollout (NT_TILE_*)
+constexpr XpbdCfg NT_XPBD_UNI_SMALL = {16, 512, 1, 1, 0};
+// the analytic rollout shape of a uniform-parameter model (false: the per-environment tiles)
+inline bool pick_uni_shape(const nt_model& m, bool rest, const nt_collide_params* cp, XpbdCfg& c) {
+    if (!m.params_uniform || rest || (cp != nullptr && cp->envs_per_block != 0)) return false;
+    if (m.env_count >= 256 * NT_XPBD_UNI_DEFAULT.epb && epb_fits(m, NT_XPBD_UNI_DEFAULT.epb, rest, true)) { c = NT_XPBD_UNI_DEFAULT; return true; }
+    if (epb_fits(m, NT_XPBD_UNI_SMALL.epb, rest, true) && m.env_count >= NT_XPBD_UNI_SMALL.epb) { c = NT_XPBD_UNI_SMALL; return true; }
+    return false;
+}
 nt_status launch_xpbd_rollout_shape(const KArgs& a, XpbdCfg c, hipStream_t stream) {
 #define X(E, T, W, U) \
     if (!c.cvx && c.epb == E && c.threads == T && c.minw == W && c.uni == U) \
@@ -345,6 +372,14 @@ inline bool pick_cvx_uni_shape(const nt_model& m, bool rest, XpbdCfg& c) {
     return false;
 }
 
+// -DNT_DEV_FAST (measurement builds of tools/build_variant.py only, never the product): just the headline's kernels -- the analytic
+// XPBD rollout shapes and the 16-environment collide / step kernels -- so that a kernel experiment compiles in a minute instead of six.
+// Everything else answers NT_ERR_UNSUPPORTED.
+#ifdef NT_DEV_FAST
+#define NT_DISPATCH_EPB(KERNEL, args, epb, stream) ((epb) == 16 ? launch(KERNEL<16>, args, 16, stream) : NT_ERR_UNSUPPORTED)
+#define NT_DISPATCH_EPB_CVX(KERNEL, m, args, epb, stream) \
+    ((m).np_analytic < (m).np || (epb) != 16 ? NT_ERR_UNSUPPORTED : launch(KERNEL<16, false>, args, 16, stream))
+#else
 #define NT_DISPATCH_EPB(KERNEL, args, epb, stream)                                      \
     ((epb) == 64 ? launch(KERNEL<64>, args, 64, stream)                                 \
      : (epb) == 32 ? launch(KERNEL<32>, args, 32, stream)                               \
@@ -364,6 +399,7 @@ inline bool pick_cvx_uni_shape(const nt_model& m, bool rest, XpbdCfg& c) {
          ? ((epb) >= 16 ? launch(KERNEL<16, true>, args, 16, stream)                                   \
             : ((epb) == 8 || (epb) == 4) ? launch(KERNEL<8, true>, args, 8, stream) : launch(KERNEL<1, true>, args, 1, stream)) \
          : NT_DISPATCH_EPB2(KERNEL, false, args, epb, stream))
+#endif
 
 bool model_ok(const nt_model* m) {
     return m && m->env_count > 0 && m->env_stride >= m->env_count && (m->env_stride % 64) == 0 && m->nb > 0 &&
@@ -422,9 +458,13 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
     // environment per launch (the per-call API pays the parameter staging in every kernel; the fused rollout once per frame)
     if (m->params_uniform && !m->contact_scratch_in_hbm && m->np_analytic == m->np && epb == 16 && epb_fits(*m, 16, false, true))
         return launch(collide_kernel<16 + NT_UNI, false>, a, 16, (hipStream_t)stream, 0, false, true);
+#ifdef NT_DEV_FAST
+    if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;
+#else
     if (m->contact_scratch_in_hbm)
         return m->np_analytic < m->np ? launch(collide_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(collide_kernel<1, false, true>, a, 1, (hipStream_t)stream);
+#endif
     return NT_DISPATCH_EPB_CVX(collide_kernel, *m, a, epb, (hipStream_t)stream);
 }
 
@@ -446,10 +486,14 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
     a.dt = dt;
     int epb = pick_epb(*m, envs_per_block, xpbd_keeps_prestep_state(*p));
     if (!epb) return NT_ERR_UNSUPPORTED;
+#ifdef NT_DEV_FAST
+    if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;
+#else
     if (m->contact_scratch_in_hbm) {
         if (a.has_contacts && m->np > 0 && !a.ct.cw) return NT_ERR_INVALID_ARG;
         return launch(xpbd_step_kernel<1, true>, a, 1, (hipStream_t)stream);
     }
+#endif
     if (m->params_uniform && !xpbd_keeps_prestep_state(*p) && epb == 16 && epb_fits(*m, 16, false, true))
         return launch(xpbd_step_kernel<16 + NT_UNI>, a, 16, (hipStream_t)stream, 0, false, true);
     return NT_DISPATCH_EPB(xpbd_step_kernel, a, epb, (hipStream_t)stream);
@@ -469,14 +513,19 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     a.substeps = substeps;
+    a.tile_opts = NT_TILE_POSE_SNAPSHOT | NT_TILE_LDS_RECORDS;  // (request; launch() grants what the tile has room for)
     const bool rest = xpbd_keeps_prestep_state(*p);
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0, rest);
     if (!epb) return NT_ERR_UNSUPPORTED;
+#ifdef NT_DEV_FAST
+    if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;
+#else
     if (m->contact_scratch_in_hbm) {
         if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
         return m->np_analytic < m->np ? launch(xpbd_rollout_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(xpbd_rollout_kernel<1, false, true>, a, 1, (hipStream_t)stream);
     }
+#endif
     if (m->np_analytic < m->np) {  // convex models: uniform-parameter tiles when the parameters allow
         XpbdCfg c;
         if (xpbd_cfg_override(c) && c.cvx) {
@@ -492,10 +541,7 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
             if ((c.uni && (!m->params_uniform || rest)) || !epb_fits(*m, c.epb, rest, c.uni != 0)) return NT_ERR_UNSUPPORTED;
             return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
         }
-        c = NT_XPBD_UNI_DEFAULT;
-        if (m->params_uniform && !rest && m->env_count >= 256 * c.epb && epb_fits(*m, c.epb, rest, true) &&
-            (cp == nullptr || cp->envs_per_block == 0))
-            return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
+        if (pick_uni_shape(*m, rest, cp, c)) return launch_xpbd_rollout_shape(a, c, (hipStream_t)stream);
     }
     return NT_DISPATCH_EPB_CVX(xpbd_rollout_kernel, *m, a, epb, (hipStream_t)stream);
 }
@@ -511,9 +557,7 @@ nt_status nt_xpbd_rollout_shape(const nt_model* m, const nt_xpbd_params* p, cons
     else if (!cvx) {
         XpbdCfg o;
         if (xpbd_cfg_override(o) && !o.cvx) c = o;
-        else if (m->params_uniform && !rest && m->env_count >= 256 * NT_XPBD_UNI_DEFAULT.epb &&
-                 epb_fits(*m, NT_XPBD_UNI_DEFAULT.epb, rest, true) && (cp == nullptr || cp->envs_per_block == 0))
-            c = NT_XPBD_UNI_DEFAULT;
+        else if (pick_uni_shape(*m, rest, cp, o)) c = o;
         else if (epb == 4) c.epb = 8;
     } else {
         XpbdCfg o;
@@ -542,6 +586,9 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;  // XPBD / collide only
+#ifdef NT_DEV_FAST
+    return NT_ERR_UNSUPPORTED;
+#else
     int epb = pick_epb(*m, envs_per_block);
     if (!epb) return NT_ERR_UNSUPPORTED;
     if ((size_t)make_layout_host(*m).rows_semi * 4 * epb + (size_t)topo_ints(*m) * 4 > LDS_BYTES_PER_CU) {
@@ -554,11 +601,15 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
          : epb == 16 ? launch(semi_implicit_step_kernel<16>, a, 16, (hipStream_t)stream, 0, true)
          : epb == 8 ? launch(semi_implicit_step_kernel<8>, a, 8, (hipStream_t)stream, 0, true)
                     : launch(semi_implicit_step_kernel<1>, a, 1, (hipStream_t)stream, 0, true);
+#endif
 }
 
 // shared launch logic of the Featherstone kernels (step / rollout)
 static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, bool rollout, hipStream_t stream) {
     if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;  // XPBD / collide only
+#ifdef NT_DEV_FAST
+    return NT_ERR_UNSUPPORTED;
+#else
 #ifdef NT_ABLATION
     {
         const char* e = getenv("NT_DEBUG_SKIP");
@@ -609,6 +660,7 @@ static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, 
     if (epb == 8) return go(featherstone_rollout_kernel<8, false>);
     if (epb == 4) return go(featherstone_rollout_kernel<4, false>);
     return go(featherstone_rollout_kernel<1, false>);
+#endif
 }
 
 static bool fs_state_ok(const nt_state* s) { return s && s->joint_q && s->joint_qd && s->body_q && s->body_qd; }
@@ -660,6 +712,9 @@ int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m) {
 nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint_qd, nt_state* out, void* stream) {
     if (!model_ok(m) || !joint_q || !joint_qd || !out || !out->body_q || !out->body_qd) return NT_ERR_INVALID_ARG;
     if (m->nj <= 0) return NT_ERR_UNSUPPORTED;
+#ifdef NT_DEV_FAST
+    return NT_ERR_UNSUPPORTED;
+#else
     KArgs a = {};
     a.m = *m;
     a.s_out = *out;
@@ -686,6 +741,7 @@ nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint
     if (epb == 8) return go(eval_fk_kernel<8>);
     if (epb == 4) return go(eval_fk_kernel<4>);
     return go(eval_fk_kernel<1>);
+#endif
 }
 
 #ifdef NT_PHASE_TIMING

@@ -59,6 +59,8 @@ struct LdsLayout {
                        // models a tile size -- C2 fell from 16 to 8 environments per workgroup, 45 -> 20 M env-steps/s -- and the
                        // other solvers never read it)
     int has_lt;
+    Fld<1> lc;         // [1] number of live contacts appended to lt so far (int bits; LDS-record tiles: the pair lanes append with an atomic)
+    Fld<17> cr;        // contact records [np * cpp][17] in LDS (NT_TILE_LDS_RECORDS; behind the snapshot rows)
     // scratch union
     int u;
     Fld<7> sx, sa;     // collide: shape world xform [ns][7], aabb [ns][6 (+1)]
@@ -102,8 +104,11 @@ __host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_mode
 // uni: nt_model.params_uniform models on a uniform-parameter tile -- the body / joint / dof / shape parameters are identical
 // in every environment, so the workgroup keeps ONE copy (block-shared, broadcast reads) and an environment's LDS footprint
 // drops by 936 rows on the headline quadruped: 32 environments fit a CU instead of 16
+// opts: NT_TILE_* bits the launch code granted (KArgs::tile_opts; only the fused XPBD rollout asks for any)
+constexpr int NT_TILE_POSE_SNAPSHOT = 1;  // keep the substep's incoming body poses (L.xiq) so that integrate_bodies can run beside the pair phase
+constexpr int NT_TILE_LDS_RECORDS = 2;    // the contact records of a fused rollout live in LDS (L.cr); Contacts in HBM get the last substep's only
 __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false,
-                                                 const bool uni = false, const bool live_list = true) {
+                                                 const bool uni = false, const bool live_list = true, const int opts = 0) {
     LdsLayout L;
     int o = 0, ou = 0;
     L.bq.off = o; o += 7 * m.nb;
@@ -123,6 +128,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.px.off = o; o += m.np + 1;
     L.has_lt = live_list && !big && m.np_analytic == m.np;
     L.lt.off = o; o += L.has_lt ? m.np * m.cpp : 0;
+    L.lc.off = o; o += 1;
     L.u = o;
     const int coll = place_collide_scratch(L, m, L.u, big);
     // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase
@@ -138,12 +144,15 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     int semi = 7 * m.nb + 13 * m.nj + NC_CW * m.np * m.cpp;
     int xpbd = imax(imax(imax(coll, forces), imax(joints, contacts)), NT_MIN_SCRATCH_ROWS);
     L.xiq.off = L.u + xpbd; L.xiqd.off = L.xiq.off + 7 * m.nb;
-    L.rows_per_env = L.u + xpbd + (restitution ? 14 * m.nb : 0);
+    const bool snapshot = restitution || (opts & NT_TILE_POSE_SNAPSHOT) != 0;  // poses (7 rows per body), + velocities with restitution
+    L.rows_per_env = L.u + xpbd + (snapshot ? 7 * m.nb : 0) + (restitution ? 7 * m.nb : 0);
+    L.cr.off = L.rows_per_env;
+    if ((opts & NT_TILE_LDS_RECORDS) && L.has_lt && !restitution) L.rows_per_env += 17 * m.np * m.cpp;
     L.rows_semi = L.u + semi;
     return L;
 }
-inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false, bool uni = false) {
-    return make_layout(m, m.contact_scratch_in_hbm != 0, restitution, uni);
+inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false, bool uni = false, int opts = 0) {
+    return make_layout(m, m.contact_scratch_in_hbm != 0, restitution, uni, true, opts);
 }
 
 // the pre-step state snapshot (and the wide contact records) exist for restitution and for velocities from position deltas
@@ -175,6 +184,7 @@ struct KArgs {
     int substeps;
     int has_contacts;
     int nslot;       // slot-threads per environment
+    int tile_opts;   // NT_TILE_* bits of the LDS layout (set by the launch code when the tile still fits the CU)
 #ifdef NT_ABLATION
     int debug_skip;  // measurement builds only (tools/xpbd_ablation.sh): 1 collide, 2 forces+integrate, 4 contacts, 8 joints, 16 apply
 #endif

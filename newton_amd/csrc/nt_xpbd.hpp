@@ -174,6 +174,93 @@ NT_DI void integrate_item(const Ctx<EPB>& c, const int b) {
     c.st_lv3(c.L.bqd, 3, nb, b, w1);
     c.update_body_derived(b);
 }
+// ------------------------------------------------------------------------------------------------
+// XPBD body phases on LINEAR and ANGULAR lanes.
+// Inside a SolverXPBD step the linear state of a body is its world COM (rows 0..2 of the body-derived tile L.bd): integrate_bodies and
+// apply_body_deltas both move x_com = p + R(q) com and only then subtract R(q1) com again (solver.py:100-118, xpbd/kernels.py:915-921),
+// so between integrate and the step's last apply the COM is advanced directly (x_com += dp dt, no dependence on the new rotation) and
+// the body origin p (L.bq rows 0..2) is rebuilt once, by the last apply: p = x_com - R(q1) com, followed by the same
+// world_com = xform_point((p, q1), com) every kernel entry computes -- so the state a rollout carries from substep to substep is
+// bit for bit the state the call-by-call loop reloads from HBM.  Consumers inside the step (contact / joint rows) read (world COM, q).
+// With x_com as the state the linear half (forces / corrections -> v, x_com) and the angular half (-> omega, q, W = R I^-1 R^T) of a
+// body are independent programs: when the workgroup has idle waves (13 bodies x 16 environments fill 4 of its 8) they run side by side
+// on different waves -- slots [0, nb) angular, slots [S0, S0 + nb) linear, S0 on a wave boundary.  A wave issues one dependent VALU
+// instruction per ~8 cycles while the SIMD can start one every 2 (profiles/r05a_valu_issue.jsonl), so two half-length programs on two
+// waves take about half the time of one.  Same arithmetic per quantity in both forms: split and unsplit tiles agree bit for bit.
+// ------------------------------------------------------------------------------------------------
+// does an apply phase follow integrate_bodies in this step (else integrate rebuilds the body origins itself)
+NT_DI bool xpbd_applies_follow(const KArgs& a) { return a.p.iterations > 0 && (a.has_contacts != 0 || a.m.nj > 0); }
+template <int EPB>
+NT_DI int body_lane_split(const Ctx<EPB>& c) {  // S0 if the linear lanes fit behind the angular ones, else 0 (one lane per body)
+    const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;
+    const int S0 = ((c.a.m.nb + spw - 1) / spw) * spw;
+    return S0 + c.a.m.nb <= c.nslot ? S0 : 0;
+}
+// integrate_bodies (solver.py:63-170) of SolverXPBD.  need_p: no apply phase follows in this step -- rebuild the body origin here
+// (both halves on one lane).
+template <int EPB>
+NT_DI void xpbd_integrate_item(const Ctx<EPB>& c, const int b, const bool do_lin, const bool do_ang, const bool need_p) {
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nj = m.nj;
+    vec3 f0, t0;
+    if (do_lin) f0 = c.lv3(c.L.bf, 0, nb, b);
+    if (do_ang) t0 = c.lv3(c.L.bf, 3, nb, b);
+    for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
+        const int code = c.T.body_joint_list[i];
+        const int j = code >> 1, row = (code & 1) ? 6 : 0;
+        if (do_lin) {
+            const vec3 f = c.lv3(c.L.jf, row, nj, j);
+            if (code & 1) f0 += f;
+            else f0 -= f;
+        }
+        if (do_ang) {
+            const vec3 t = c.lv3(c.L.jf, row + 3, nj, j);
+            if (code & 1) t0 += t;
+            else t0 -= t;
+        }
+    }
+    if (c.T.body_flags[b] & BODY_KINEMATIC) return;  // pass through unchanged
+    const float dt = c.a.dt;
+    vec3 x1;
+    quat r1;
+    if (do_lin) {
+        const vec3 v0 = c.body_v(b);
+        const float inv_mass = c.inv_mass(b);
+        const vec3 v1 = v0 + (f0 * inv_mass + c.gravity() * nonzero(inv_mass)) * dt;
+        x1 = c.world_com(b) + v1 * dt;
+        c.st_lv3(c.L.bqd, 0, nb, b, v1);
+        c.st_lv3(c.L.bd, 0, nb, b, x1);
+    }
+    if (do_ang) {
+        const quat r0 = c.body_rot(b);
+        const vec3 w0 = c.body_w(b);
+        const mat33 inertia = c.inertia(b), inv_inertia = c.inv_inertia(b);
+        const vec3 wb = quat_rotate_inv(r0, w0);
+        const vec3 tb = quat_rotate_inv(r0, t0) - cross(wb, inertia * wb);
+        vec3 w1 = quat_rotate(r0, wb + inv_inertia * tb * dt);
+        r1 = xnormalize(r0 + quat(w1, 0.0f) * r0 * 0.5f * dt);
+        w1 *= 1.0f - c.a.angular_damping * dt;
+        c.l(c.L.bq, 3, nb, b) = r1.x; c.l(c.L.bq, 4, nb, b) = r1.y; c.l(c.L.bq, 5, nb, b) = r1.z; c.l(c.L.bq, 6, nb, b) = r1.w;
+        c.st_lv3(c.L.bqd, 3, nb, b, w1);
+        c.update_body_w(b, r1);
+    }
+    if (need_p) {
+        const xform X(x1 - quat_rotate(r1, c.com(b)), r1);
+        c.st_lv3(c.L.bq, 0, nb, b, X.p);
+        c.update_world_com(b, X);
+    }
+}
+template <int EPB>
+NT_DI void phase_xpbd_integrate(const Ctx<EPB>& c, const bool need_p) {
+    if (!c.valid) return;
+    const int nb = c.a.m.nb, S0 = need_p ? 0 : body_lane_split(c);
+    if (S0) {
+        if (c.slot < nb) xpbd_integrate_item(c, c.slot, false, true, false);
+        else if (c.slot >= S0 && c.slot < S0 + nb) xpbd_integrate_item(c, c.slot - S0, true, false, false);
+    } else {
+        for (int b = c.tslot; b < nb; b += c.nslot) xpbd_integrate_item(c, b, true, true, need_p);
+    }
+}
 template <int EPB>
 NT_DI void phase_body_derived(const Ctx<EPB>& c) {
     if (!c.valid) return;
@@ -272,6 +359,17 @@ struct SlotRecord {
     NT_DI vec3 normal() const { return c.gv3(D, CD_NORMAL, ncs, slot); }
     NT_DI float margins() const { return D[c.g(CD_MARGIN0, ncs, slot)] + D[c.g(CD_MARGIN1, ncs, slot)]; }
 };
+template <int EPB>
+struct LdsRecord {  // the slot's record in L.cr (LDS-record tiles of the fused rollout)
+    const Ctx<EPB>& c;
+    int ncs, slot;
+    NT_DI vec3 point0() const { return c.lv3(c.L.cr, CD_POINT0, ncs, slot); }
+    NT_DI vec3 point1() const { return c.lv3(c.L.cr, CD_POINT1, ncs, slot); }
+    NT_DI vec3 offset0() const { return c.lv3(c.L.cr, CD_OFFSET0, ncs, slot); }
+    NT_DI vec3 offset1() const { return c.lv3(c.L.cr, CD_OFFSET1, ncs, slot); }
+    NT_DI vec3 normal() const { return c.lv3(c.L.cr, CD_NORMAL, ncs, slot); }
+    NT_DI float margins() const { return c.l(c.L.cr, CD_MARGIN0, ncs, slot) + c.l(c.L.cr, CD_MARGIN1, ncs, slot); }
+};
 struct FlatRecord {
     const nt_flat_rows& f;
     int r;
@@ -309,25 +407,38 @@ template <int EPB, class REC>
 NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int shape_b, int body_a, int body_b, vec3& lin_delta_a,
                          vec3& ang_delta_a, vec3& ang_delta_b) {
     const float dt = c.a.dt, relaxation = c.a.p.rigid_contact_relaxation;
-    xform X_wb_a, X_wb_b;
-    if (body_a >= 0) X_wb_a = c.body_q(body_a);
-    if (body_b >= 0) X_wb_b = c.body_q(body_b);
+    // a body inside the step is (world COM, rotation): the origin p is stale between integrate and the last apply (see the body
+    // phases above).  A contact point p + R x becomes x_com + R (x - com); its lever arm about the COM is the rotated part alone.
+    quat q_a, q_b;
+    vec3 wc_a(0.0f), wc_b(0.0f), com_a(0.0f), com_b(0.0f);  // world COM / body-frame COM (origin for static shapes)
+    if (body_a >= 0) {
+        q_a = c.body_rot(body_a);
+        wc_a = c.world_com(body_a);
+        com_a = c.com(body_a);
+    }
+    if (body_b >= 0) {
+        q_b = c.body_rot(body_b);
+        wc_b = c.world_com(body_b);
+        com_b = c.com(body_b);
+    }
+    auto rot_a = [&](vec3 v) { return body_a >= 0 ? quat_rotate(q_a, v) : v; };
+    auto rot_b = [&](vec3 v) { return body_b >= 0 ? quat_rotate(q_b, v) : v; };
     vec3 point0 = rec.point0(), point1 = rec.point1();
-    vec3 bx_a = xform_point(X_wb_a, point0);
-    vec3 bx_b = xform_point(X_wb_b, point1);
+    vec3 r_a = rot_a(point0 - com_a);
+    vec3 r_b = rot_b(point1 - com_b);
+    vec3 bx_a = wc_a + r_a;
+    vec3 bx_b = wc_b + r_b;
     vec3 n = rec.normal();
     float d = dot(n, bx_b - bx_a) - rec.margins();
     if (!(d < 0.0f)) return false;
     vec3 lin_delta_b;
     float m_inv_a = 0.0f, m_inv_b = 0.0f;
-    vec3 wc_a(0.0f), wc_b(0.0f), omega_a(0.0f), omega_b(0.0f);  // world COM (origin for static shapes)
+    vec3 omega_a(0.0f), omega_b(0.0f);
     if (body_a >= 0) {
-        wc_a = c.world_com(body_a);
         m_inv_a = c.inv_mass(body_a);
         omega_a = c.body_w(body_a);
     }
     if (body_b >= 0) {
-        wc_b = c.world_com(body_b);
         m_inv_b = c.inv_mass(body_b);
         omega_b = c.body_w(body_b);
     }
@@ -347,13 +458,11 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
         mu_torsional += c.shape_f(shape_b, SP_MU_TORSIONAL);
         mu_rolling += c.shape_f(shape_b, SP_MU_ROLLING);
     }
-    if (mat_nonzero > 0) {
-        mu /= float(mat_nonzero);
-        mu_torsional /= float(mat_nonzero);
-        mu_rolling /= float(mat_nonzero);
+    if (mat_nonzero > 1) {  // the mean of one or two shapes' coefficients: x / 2 == x * 0.5 exactly, x / 1 == x
+        mu *= 0.5f;
+        mu_torsional *= 0.5f;
+        mu_rolling *= 0.5f;
     }
-    vec3 r_a = bx_a - wc_a;
-    vec3 r_b = bx_b - wc_b;
     vec3 angular_a = -cross(r_a, n);
     vec3 angular_b = cross(r_b, n);
 
@@ -365,12 +474,12 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
 
     if (mu > 0.0f) {
         vec3 offset_a = rec.offset0(), offset_b = rec.offset1();
-        bx_a = xform_point(X_wb_a, point0 + offset_a);
-        bx_b = xform_point(X_wb_b, point1 + offset_b);
+        r_a = rot_a((point0 + offset_a) - com_a);
+        r_b = rot_b((point1 + offset_b) - com_b);
+        bx_a = wc_a + r_a;
+        bx_b = wc_b + r_b;
         vec3 delta = bx_b - bx_a;
         vec3 friction_delta = delta - dot(n, delta) * n;
-        r_a = bx_a - wc_a;
-        r_b = bx_b - wc_b;
         vec3 rel_v_kin_t(0.0f);
         if (body_a >= 0 && (c.T.body_flags[body_a] & BODY_KINEMATIC) != 0) {
             vec3 v_a = velocity_at_point(spatial(c.body_v(body_a), omega_a), r_a);
@@ -439,7 +548,8 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot, const int live_pair =
     bool swapped = false, described = false;
     LoadedRecord rec;
     if (FUSED && live_pair >= 0) {
-        rec = load_record(SlotRecord<EPB>{c, ct.data, ncs, slot});  // (a listed contact is live: fetch before anything depends on LDS)
+        if (c.lds_records) rec = load_record(LdsRecord<EPB>{c, ncs, slot});
+        else rec = load_record(SlotRecord<EPB>{c, ct.data, ncs, slot});  // (a listed contact is live: fetch before anything depends on LDS)
         const int* d = c.T.pair_desc + 4 * live_pair;
         shape_a = d[0]; shape_b = d[1]; body_a = d[2];
         const int w = d[3];
@@ -552,12 +662,26 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
 // XPBD: apply_body_deltas (xpbd/kernels.py:864-933).  FROM_CONTACTS: sum contact corrections (+ contact counts)
 // in ascending contact order; otherwise sum joint corrections in ascending joint order.
 // ------------------------------------------------------------------------------------------------
+// do_lin / do_ang: the halves this lane runs (both on tiles without idle waves).  last: the step's last apply -- the angular lane
+// (it holds q1) also rebuilds the body origin p and the entry-form world COM, the linear lane leaves the COM alone.
+constexpr int NT_APPLY_SLOTS = 5;   // contact slots of a pair fetched together (cpp <= 5)
+constexpr int NT_APPLY_JOINTS = 4;  // incident joints fetched together; longer lists finish in a loop
 template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false>
-NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
+NT_DI void apply_item(const Ctx<EPB>& c, const int b, const bool do_lin, const bool do_ang, const bool last) {
     const nt_model& m = c.a.m;
     const int nb = m.nb;
+    const bool need_p = last && do_ang;
+    const bool want_lin = do_lin || need_p;
     float inv_m = c.inv_mass(b);
-    if (inv_m == 0.0f) return;  // pass-through
+    if (inv_m == 0.0f) {  // pass-through; an immovable body that integrate_bodies still moved (v != 0) gets its origin back
+        if (need_p && !(c.T.body_flags[b] & BODY_KINEMATIC)) {
+            const quat q = c.body_rot(b);
+            const xform X(c.world_com(b) - quat_rotate(q, c.com(b)), q);
+            c.st_lv3(c.L.bq, 0, nb, b, X.p);
+            c.update_world_com(b, X);
+        }
+        return;
+    }
 
     vec3 dlin, dang;
     float inv_weight = 0.0f;
@@ -567,15 +691,34 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
             int code = c.T.body_pair_list[i];
             int p = code >> 1, side = code & 1;  // side 0: this body owns pair_a's shape
             const int live = FUSED ? (int)c.l(c.L.pm, 0, m.np, p) : cpp;  // fused: only live slots carry a record
-            for (int k = 0; k < live; ++k) {
-                int slot = p * cpp + k;
-                const CwxSide sd = cwx_side<CW>(c, ncs, slot, side);
-                if (sd.has) {
-                    vec3 lin = cw_v3<CW, NC_CWX>(c, 0, ncs, slot);
-                    dlin += sd.is_a ? lin : -lin;
-                    dang += cw_v3<CW, NC_CWX>(c, sd.is_a ? CWX_ANG_A : CWX_ANG_B, ncs, slot);
+            // the pair's slots together: one LDS round for the flags, one for the records (a load / wait / branch per slot cost the
+            // feet of the standing quadruped eight dependent rounds per apply); summed in ascending slot order as before
+            // (named records, not arrays: the optimiser leaves conditionally written struct arrays in scratch memory; loads
+            // unconditional from a clamped slot and predicated at the add: branches would split the batch into one round trip each)
+            struct Slot { vec3 lin, ang; bool has, isa; };
+            auto slot_of = [&](int k) { return p * cpp + (k < cpp ? k : cpp - 1); };
+            auto fetch_flags = [&](int k) { return (int)CW::template at<NC_CWX>(c, CWX_FLAGS, ncs, slot_of(k)); };
+            auto fetch = [&](int k, int fl) {
+                Slot s;
+                if (k >= live) fl = 0;
+                s.isa = (side == 0) == ((fl & 4) != 0);  // this body is the contact's "a" iff (side == 0) == (shape0 is pair_a's shape)
+                s.has = (fl & (s.isa ? 1 : 2)) != 0;
+                if (want_lin) s.lin = cw_v3<CW, NC_CWX>(c, 0, ncs, slot_of(k));
+                if (do_ang) s.ang = cw_v3<CW, NC_CWX>(c, s.isa ? CWX_ANG_A : CWX_ANG_B, ncs, slot_of(k));
+                return s;
+            };
+            auto add = [&](const Slot& s) {
+                if (s.has) {
+                    if (want_lin) dlin += s.isa ? s.lin : -s.lin;
+                    if (do_ang) dang += s.ang;
                     inv_weight += 1.0f;
                 }
+            };
+            static_assert(NT_APPLY_SLOTS == 5, "five named slots below");
+            if (live > 0) {
+                const int f0 = fetch_flags(0), f1 = fetch_flags(1), f2 = fetch_flags(2), f3 = fetch_flags(3), f4 = fetch_flags(4);
+                const Slot s0 = fetch(0, f0), s1 = fetch(1, f1), s2 = fetch(2, f2), s3 = fetch(3, f3), s4 = fetch(4, f4);
+                add(s0); add(s1); add(s2); add(s3); add(s4);
             }
         }
         if constexpr (!FUSED) {
@@ -597,55 +740,91 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b) {
             }
         }
     } else {
+        // ascending joint order; per (joint, side): the linear lane's record (lin, ang of the linear rows) + the angular lane's
+        // summed row terms (angular_p = -angular_c).  The first NT_APPLY_JOINTS entries of the list leave as one batch of loads.
         const int nj = m.nj;
-        for (int i = c.T.body_joint_start[b]; i < c.T.body_joint_start[b + 1]; ++i) {
-            int code = c.T.body_joint_list[i];
-            int j = code >> 1, side = code & 1;  // side 1: this body is the joint's child
-            vec3 jl = c.lv3(c.L.jl, side * 6, nj, j);
-            vec3 ja = c.lv3(c.L.jl, side * 6 + 3, nj, j);
-            vec3 t0 = c.lv3(c.L.ja, 0, nj, j), t1 = c.lv3(c.L.ja, 3, nj, j), t2 = c.lv3(c.L.ja, 6, nj, j);
-            if (side == 0) { t0 = -t0; t1 = -t1; t2 = -t2; }  // angular_p = -angular_c
-            ja = ((ja + t0) + t1) + t2;
-            dlin += jl;
-            dang += ja;
+        const int i0 = c.T.body_joint_start[b], n = c.T.body_joint_start[b + 1] - i0;
+        // (loads unconditional from a clamped entry, predicated at the add: one batch of loads for the codes, one for the records)
+        struct Inc { vec3 lin, ang, t; int code; };
+        auto fetch_code = [&](int k) { return c.T.body_joint_list[k < n ? i0 + k : 0]; };
+        auto fetch = [&](int code) {
+            Inc r;
+            r.code = code;
+            const int j = code >> 1, side = code & 1;  // side 1: this body is the joint's child
+            if (want_lin) r.lin = c.lv3(c.L.jl, side * 6, nj, j);
+            if (do_ang) {
+                r.ang = c.lv3(c.L.jl, side * 6 + 3, nj, j);
+                r.t = c.lv3(c.L.ja, 0, nj, j);
+            }
+            return r;
+        };
+        auto add = [&](int k, const Inc& r) {
+            if (k < n) {
+                if (want_lin) dlin += r.lin;
+                if (do_ang) dang += r.ang + ((r.code & 1) ? r.t : -r.t);
+            }
+        };
+        static_assert(NT_APPLY_JOINTS == 4, "four named entries below");
+        const int c0 = fetch_code(0), c1 = fetch_code(1), c2 = fetch_code(2), c3 = fetch_code(3);
+        const Inc r0 = fetch(c0), r1 = fetch(c1), r2 = fetch(c2), r3 = fetch(c3);
+        add(0, r0); add(1, r1); add(2, r2); add(3, r3);
+        for (int i = i0 + NT_APPLY_JOINTS; i < i0 + n; ++i) {
+            const int cd = c.T.body_joint_list[i];
+            const int j = cd >> 1, side = cd & 1;
+            if (want_lin) dlin += c.lv3(c.L.jl, side * 6, nj, j);
+            if (do_ang) {
+                const vec3 t = c.lv3(c.L.ja, 0, nj, j);
+                dang += c.lv3(c.L.jl, side * 6 + 3, nj, j) + (side ? t : -t);
+            }
         }
     }
-    mat33 inv_I = c.inv_inertia(b);
-    mat33 body_I = c.inertia(b);
-    xform tf = c.body_q(b);
-    vec3 v0 = c.body_v(b), w0 = c.body_w(b);
     const float dt = c.a.dt;
-    vec3 p0 = tf.p;
-    quat q0 = tf.q;
     float weight = 1.0f;
     if (FROM_CONTACTS && c.a.p.rigid_contact_con_weighting) {
         if (inv_weight > 0.0f) weight = xrcp(inv_weight);
     }
-    vec3 dp = dlin * (inv_m * weight);
-    vec3 dq = dang * weight;
-    vec3 wb = quat_rotate_inv(q0, w0);
-    vec3 dwb = inv_I * quat_rotate_inv(q0, dq);
-    vec3 tb = cross(dwb, body_I * (wb + dwb)) + cross(wb, body_I * dwb);
-    vec3 dw1 = quat_rotate(q0, dwb - (dt * inv_I) * tb);
-    quat q1 = q0 + 0.5f * quat(dw1 * dt, 0.0f) * q0;
-    q1 = xnormalize(q1);
-    vec3 com = c.com(b);
-    vec3 x_com = p0 + quat_rotate(q0, com);
-    vec3 p1 = x_com + dp * dt;
-    p1 -= quat_rotate(q1, com);
-    c.st_lxf(c.L.bq, nb, b, xform(p1, q1));
-    vec3 v1 = v0 + dp;
-    vec3 w1 = w0 + dw1;
-    if (xlength(v1) < 1e-4f) v1 = vec3(0.0f);
-    if (xlength(w1) < 1e-4f) w1 = vec3(0.0f);
-    c.st_lv3(c.L.bqd, 0, nb, b, v1);
-    c.st_lv3(c.L.bqd, 3, nb, b, w1);
-    c.update_body_derived(b);
+    vec3 dp;
+    if (want_lin) dp = dlin * (inv_m * weight);
+    quat q1;
+    if (do_ang) {
+        const mat33 inv_I = c.inv_inertia(b), body_I = c.inertia(b);
+        const quat q0 = c.body_rot(b);
+        const vec3 w0 = c.body_w(b);
+        vec3 dq = dang * weight;
+        vec3 wb = quat_rotate_inv(q0, w0);
+        vec3 dwb = inv_I * quat_rotate_inv(q0, dq);
+        vec3 tb = cross(dwb, body_I * (wb + dwb)) + cross(wb, body_I * dwb);
+        vec3 dw1 = quat_rotate(q0, dwb - (dt * inv_I) * tb);
+        q1 = q0 + 0.5f * quat(dw1 * dt, 0.0f) * q0;
+        q1 = xnormalize(q1);
+        vec3 w1 = w0 + dw1;
+        if (xlength(w1) < 1e-4f) w1 = vec3(0.0f);
+        c.l(c.L.bq, 3, nb, b) = q1.x; c.l(c.L.bq, 4, nb, b) = q1.y; c.l(c.L.bq, 5, nb, b) = q1.z; c.l(c.L.bq, 6, nb, b) = q1.w;
+        c.st_lv3(c.L.bqd, 3, nb, b, w1);
+        c.update_body_w(b, q1);
+    }
+    if (do_lin) {
+        vec3 v1 = c.body_v(b) + dp;
+        if (xlength(v1) < 1e-4f) v1 = vec3(0.0f);
+        c.st_lv3(c.L.bqd, 0, nb, b, v1);
+        if (!last) c.st_lv3(c.L.bd, 0, nb, b, c.world_com(b) + dp * dt);
+    }
+    if (need_p) {
+        const xform X((c.world_com(b) + dp * dt) - quat_rotate(q1, c.com(b)), q1);
+        c.st_lv3(c.L.bq, 0, nb, b, X.p);
+        c.update_world_com(b, X);
+    }
 }
 template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false>
-NT_DI void phase_apply(const Ctx<EPB>& c) {
+NT_DI void phase_apply(const Ctx<EPB>& c, const bool last) {
     if (!c.valid) return;
-    for (int b = c.tslot; b < c.a.m.nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, b);
+    const int nb = c.a.m.nb, S0 = body_lane_split(c);
+    if (S0) {
+        if (c.slot < nb) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, c.slot, false, true, last);
+        else if (c.slot >= S0 && c.slot < S0 + nb) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, c.slot - S0, true, false, last);
+    } else {
+        for (int b = c.tslot; b < nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, b, true, true, last);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -725,14 +904,18 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
         xform X_wp = X_pj;
         vec3 world_com_p = X_pj.p;  // transform_point(pose_p = X_pj, com_p = 0) for world-attached joints
         vec3 vel_p(0.0f), omega_p(0.0f);
+        // a body inside the step is (world COM, rotation), its origin is stale (see the body phases): the joint frame
+        // pose * X_j = (p + R x_j, q q_j) is built as (x_com + R (x_j - com), q q_j)
         if (id_p >= 0) {
-            X_wp = c.body_q(id_p) * X_wp;
+            const quat qb = c.body_rot(id_p);
             world_com_p = c.world_com(id_p);
+            X_wp = xform(world_com_p + quat_rotate(qb, X_pj.p - c.com(id_p)), qb * X_pj.q);
             vel_p = c.body_v(id_p);
             omega_p = c.body_w(id_p);
         }
-        xform X_wc = c.body_q(id_c) * X_cj;
         vec3 world_com_c = c.world_com(id_c);
+        const quat qbc = c.body_rot(id_c);
+        xform X_wc(world_com_c + quat_rotate(qbc, X_cj.p - c.com(id_c)), qbc * X_cj.q);
         vec3 vel_c = c.body_v(id_c), omega_c = c.body_w(id_c);
         auto wq_p = [&](vec3 v) { return id_p >= 0 ? c.w_quad(id_p, v) : 0.0f; };
         auto wq_c = [&](vec3 v) { return c.w_quad(id_c, v); };
@@ -836,7 +1019,7 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
     const int nj = m.nj;
     const nt_xpbd_params& P = c.a.p;
     const float dt = c.a.dt;
-    vec3 t0, t1, t2;  // angular_c * d_lambda for the three angular rows (parent gets the negation)
+    vec3 t0, t1, t2;  // angular_c * d_lambda for the three angular rows (parent gets the negation); stored as their sum
     int id_p, id_c;
     float m_inv_p, m_inv_c;
     const int type = c.T.joint_type[j];
@@ -912,9 +1095,7 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
             else t2 = t;
         }
     }
-    c.st_lv3(c.L.ja, 0, nj, j, t0);
-    c.st_lv3(c.L.ja, 3, nj, j, t1);
-    c.st_lv3(c.L.ja, 6, nj, j, t2);
+    c.st_lv3(c.L.ja, 0, nj, j, (t0 + t1) + t2);
 }
 
 // apply_rigid_restitution (xpbd/kernels.py:2583-2728) for one contact slot; velocity deltas go to the per-contact record
@@ -1066,7 +1247,7 @@ NT_DI void report_joint_iteration(const Ctx<EPB>& c) {
         float m_inv_p, m_inv_c;
         if (!joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) continue;
         vec3 jl = c.lv3(c.L.jl, 6, nj, j);
-        vec3 ja = ((c.lv3(c.L.jl, 9, nj, j) + c.lv3(c.L.ja, 0, nj, j)) + c.lv3(c.L.ja, 3, nj, j)) + c.lv3(c.L.ja, 6, nj, j);
+        vec3 ja = c.lv3(c.L.jl, 9, nj, j) + c.lv3(c.L.ja, 0, nj, j);
         J[c.g(0, nj, j)] += jl.x; J[c.g(1, nj, j)] += jl.y; J[c.g(2, nj, j)] += jl.z;
         J[c.g(3, nj, j)] += ja.x; J[c.g(4, nj, j)] += ja.y; J[c.g(5, nj, j)] += ja.z;
     }
@@ -1182,17 +1363,19 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
         __syncthreads();
         NT_TICK(3);
         if (rep_joints) report_joint_forces(c);
-        phase_integrate<EPB, false>(c);
+        phase_xpbd_integrate(c, !xpbd_applies_follow(c.a));
         __syncthreads();
         NT_TICK(4);
     }
-    for (int it = 0; it < c.a.p.iterations; ++it) {
+    const int iterations = c.a.p.iterations;
+    for (int it = 0; it < iterations; ++it) {
+        const bool last_it = it == iterations - 1;
         if (c.a.has_contacts) {
             if (!NT_SKIP(4)) phase_contacts<EPB, FUSED, CW>(c);
             __syncthreads();
             NT_TICK(5);
             if (rep_contacts) report_contact_iteration<EPB, CW>(c, it == 0);
-            if (!NT_SKIP(16)) phase_apply<EPB, true, CW, FUSED>(c);
+            if (!NT_SKIP(16)) phase_apply<EPB, true, CW, FUSED>(c, last_it && m.nj <= 0);
             __syncthreads();
             NT_TICK(6);
         }
@@ -1201,7 +1384,7 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             __syncthreads();
             NT_TICK(7);
             if (rep_joints) report_joint_iteration(c);
-            if (!NT_SKIP(16)) phase_apply<EPB, false>(c);
+            if (!NT_SKIP(16)) phase_apply<EPB, false>(c, last_it);
             __syncthreads();
             NT_TICK(8);
         }

@@ -58,10 +58,15 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, const fused::Ctx<EPB>& cf, bool l
     const bool restitution = (c.a.p.enable_restitution && c.a.has_contacts) || c.a.p.compute_body_velocity_from_position_delta != 0;
     // -- interval 1: shapes (slots [0, ns)) || joint forces (slots [S0, S0 + nj), S0 on a wave boundary) + body_f_tmp = 0
     const bool compact = pairs_compacted(c);
+    // integrate_bodies beside the pair phase (its 13 lanes on the waves the 13 pair lanes leave idle; the pair phase is the longer of
+    // the two): the contact writer then converts into the snapshot of the incoming poses (c.pose_in_off) taken in interval 1
+    const int I0 = ((m.np + spw - 1) / spw) * spw;
+    const bool overlap = c.pose_in_off != c.L.bq.off;
     if (c.valid) {
         if (compact && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.hc, 0, 1, 0)) = 0;
-        if (restitution)
-            for (int r = c.slot; r < 14 * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
+        if (c.lds_records && c.slot == 0) *reinterpret_cast<int*>(&c.l(c.L.lc, 0, 1, 0)) = 0;
+        if (restitution || overlap)
+            for (int r = c.slot; r < (restitution ? 14 : 7) * m.nb; r += c.nslot) c.lds[(c.L.xiq.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
         if (!NT_SKIP(2)) fused::seed_body_forces(cf, true);
         const int S0 = ((m.ns + spw - 1) / spw) * spw;
         for (int i = c.slot; i < S0 + m.nj; i += c.nslot) {
@@ -80,6 +85,8 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, const fused::Ctx<EPB>& cf, bool l
             phase_pair_broad_staged(c);
             __syncthreads();
             phase_pair_narrow_staged<EPB, CVX>(c);
+        } else if (overlap && c.slot >= I0) {
+            if (c.valid && c.slot < I0 + m.nb && !NT_SKIP(2)) fused::xpbd_integrate_item(cf, c.slot - I0, true, true, !fused::xpbd_applies_follow(c.a));
         } else {
             phase_pair_eval<EPB, CVX>(c);
         }
@@ -87,7 +94,15 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, const fused::Ctx<EPB>& cf, bool l
     __syncthreads();
     NT_TICK(2);
     // -- interval 3: contact records of the analytic pairs (one lane per slot) || live-contact prefix (few lanes per env)
-    if (!NT_SKIP(1) && c.valid) {
+    if (!NT_SKIP(1) && c.valid && c.lds_records) {
+        // LDS-record tiles: one lane per LIVE contact (the pair lanes built the list), records into L.cr
+        const int total = *reinterpret_cast<const int*>(&c.l(c.L.lc, 0, 1, 0));
+        for (int i = c.slot; i < total; i += c.nslot) contact_record_item_lds(c, *reinterpret_cast<const int*>(&c.l(c.L.lt, 0, 1, i)));
+        if (c.slot == c.nslot - 1) {
+            c.l(c.L.px, 0, 1, m.np) = (float)total;
+            if (last_substep) c.a.ct.env_count[c.env] = total;  // per-env totals: an API-boundary output
+        }
+    } else if (!NT_SKIP(1) && c.valid) {
         const int nas = m.np_analytic * m.cpp;
         const int P0 = ((nas + spw - 1) / spw) * spw;
         const bool one_level = m.np <= 64;
@@ -102,14 +117,18 @@ NT_DI void do_fused_substep(const Ctx<EPB>& c, const fused::Ctx<EPB>& cf, bool l
         }
     }
     __syncthreads();  // also publishes the contact records (global memory) to the block's contact lanes
-    if (!NT_SKIP(1) && m.np > 64) {
+    if (!NT_SKIP(1) && m.np > 64 && !c.lds_records) {
         phase_pair_prefix_scan(c, c.L.sx.off, last_substep, false);
         __syncthreads();
     }
+    if (c.lds_records && last_substep && c.valid)  // the launch's Contacts output (reads L.cr / L.pm only: no barrier needed behind it)
+        for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) contact_export_item_lds(c, s);
     NT_TICK(3);
-    // -- interval 4: integrate_bodies
-    if (!NT_SKIP(2)) fused::phase_integrate<EPB, false>(cf);
-    __syncthreads();
+    // -- interval 4: integrate_bodies (unless it ran beside the pairs)
+    if (!overlap) {
+        if (!NT_SKIP(2)) fused::phase_xpbd_integrate(cf, !fused::xpbd_applies_follow(c.a));
+        __syncthreads();
+    }
     NT_TICK(4);
     fused::do_xpbd_step<EPB, true, fused::CwLds, true>(cf, true);
 }
@@ -185,6 +204,11 @@ template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ?
 __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
+    if constexpr (!BIG) {  // (the layout holds the snapshot rows, the pairs fit one pass and the integrate lanes fit behind them)
+        constexpr int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;
+        if ((a.tile_opts & NT_TILE_POSE_SNAPSHOT) && a.m.np <= a.nslot && ((a.m.np + spw - 1) / spw) * spw + a.m.nb <= a.nslot)
+            c.pose_in_off = c.L.xiq.off;
+    }
     const fused::Ctx<EPB> cf(c, 0);
     const int nb = a.m.nb;
     load_tile(c, &a.s_in, true);
@@ -198,6 +222,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     __syncthreads();
     NT_TICK(0);
     for (int s = 0; s < a.substeps; ++s) {
+        c.hbm_out = !c.lds_records || s == a.substeps - 1;
         if constexpr (BIG) {
             do_collide<EPB, CVX>(c, s == a.substeps - 1);
             fused::do_xpbd_step<EPB, true, fused::CwHbm>(cf, true);

@@ -36,6 +36,13 @@ for u in g.UNITS:
         objs.append(obj)
     else:
         key = g.source_hash() if u == "nt_build_id.hip" else g._unit_hash(u)
-        objs.append(os.path.join(g.OBJ_DIR, f"{u.replace('.hip', '')}.{key}.o"))
+        obj = os.path.join(g.OBJ_DIR, f"{u.replace('.hip', '')}.{key}.o")
+        if not os.path.exists(obj):  # the product was not rebuilt since this unit (or, for nt_build_id.hip, any unit) changed
+            base = [f for f in g.HIP_FLAGS if f != "-shared"] + ["-c"]
+            cmd = [g.HIPCC, *base, f'-DNT_BUILD_ID="{g.source_hash()}"', os.path.join(g.CSRC, u), "-o", obj]
+            print(" ".join(cmd), flush=True)
+            os.makedirs(g.OBJ_DIR, exist_ok=True)
+            subprocess.run(cmd, check=True)
+        objs.append(obj)
 subprocess.run([g.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], check=True)
 print("built", out)

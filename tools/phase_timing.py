@@ -33,8 +33,9 @@ if BOX:
 
     model = box_stack_scene(int(sys.argv[2]) if len(sys.argv) > 2 else 256, device="cuda:0", seed=1)
 else:
-    model = quadruped_scene(4096, device="cuda:0", seed=1)
-    model.joint_q.reshape(4096, -1)[:, 2] -= 0.24  # feet on the ground: the standing regime the bench measures
+    NENV = int(os.environ.get("NT_TIMING_ENVS", "4096"))
+    model = quadruped_scene(NENV, device="cuda:0", seed=1)
+    model.joint_q.reshape(NENV, -1)[:, 2] -= 0.24  # feet on the ground: the standing regime the bench measures
     model.body_q, model.body_qd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
 s0, s1 = model.state(), model.state()
 pipe = nt.CollisionPipeline(model)
@@ -64,7 +65,8 @@ if FS:
 names = {0: "prologue (load + derived)", 1: "shapes/AABB || joint forces", 2: "pair evaluation (1 lane / pair)",
          3: "contact records || live prefix", 4: "integrate",
          5: "contacts", 6: "apply (contacts)", 7: "joints", 8: "apply (joints)", 9: "epilogue (count + store)"}
+buf[0] = 0  # (the first tick has no predecessor: the prologue figure is meaningless)
 tot = sum(buf[i] for i in range(10))
-for i in range(10):
+for i in range(1, 10):
     print(f"{names[i]:32s} {buf[i] / N:12.0f} cycles/launch  {100.0 * buf[i] / tot:5.1f} %")
 print(f"{'total':32s} {tot / N:12.0f} cycles/launch (s_memtime ticks of workgroup 0)")
