@@ -128,7 +128,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.px.off = o; o += m.np + 1;
     L.has_lt = live_list && !big && m.np_analytic == m.np;
     L.lt.off = o; o += L.has_lt ? m.np * m.cpp : 0;
-    L.lc.off = o; o += 1;
+    L.lc.off = o; o += L.has_lt ? 1 : 0;
     L.u = o;
     const int coll = place_collide_scratch(L, m, L.u, big);
     // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase

@@ -444,17 +444,20 @@ __global__ void __launch_bounds__(256) flat_rows_match_kernel(nt_sdf_scene sc, n
     NT_FOR_PAIR_GROUPS(sc, g) {
         PairBlock b;
         if (!pair_block(sc, io, (int)g, b)) continue;
-        // the previous frame's block of this shape pair: its world's candidate list is ascending in (shape0, shape1)
+        // the previous frame's block of this shape pair: its world's candidate list is ascending in the canonical (min, max) shape
+        // order.  The history stores, and the search compares, that canonical key: the vertex leg rewrites a (mesh, plane) pair of the
+        // live list in contact orientation, which is (max, min) when the plane was added first (nt_mesh_plane.hip)
         const size_t base = (size_t)b.w * sc.pairs_per_world;
         const int n_prev = h.prev_pair_count[b.w];
+        const int k0 = b.s0 < b.s1 ? b.s0 : b.s1, k1 = b.s0 < b.s1 ? b.s1 : b.s0;
         int lo = 0, hi = n_prev;
         while (lo < hi) {
             const int mid = lo + (hi - lo) / 2;
             const int a0 = h.prev_world_pairs[2 * (base + mid)], a1 = h.prev_world_pairs[2 * (base + mid) + 1];
-            if (a0 < b.s0 || (a0 == b.s0 && a1 < b.s1)) lo = mid + 1; else hi = mid;
+            if (a0 < k0 || (a0 == k0 && a1 < k1)) lo = mid + 1; else hi = mid;
         }
         int prow0 = 0, prows = 0;
-        if (lo < n_prev && h.prev_world_pairs[2 * (base + lo)] == b.s0 && h.prev_world_pairs[2 * (base + lo) + 1] == b.s1) {
+        if (lo < n_prev && h.prev_world_pairs[2 * (base + lo)] == k0 && h.prev_world_pairs[2 * (base + lo) + 1] == k1) {
             prow0 = h.prev_row_start[b.w] + h.prev_pair_row[base + lo];
             prows = h.prev_pair_rows[base + lo];
         }
@@ -538,8 +541,8 @@ __global__ void __launch_bounds__(256) flat_rows_save_kernel(nt_sdf_scene sc, nt
         PairBlock b;
         if (!pair_block(sc, io, (int)g, b)) continue;
         if (sub == 0) {
-            h.prev_world_pairs[2 * (size_t)g] = b.s0;
-            h.prev_world_pairs[2 * (size_t)g + 1] = b.s1;
+            h.prev_world_pairs[2 * (size_t)g] = b.s0 < b.s1 ? b.s0 : b.s1;  // canonical key (see flat_rows_match_kernel)
+            h.prev_world_pairs[2 * (size_t)g + 1] = b.s0 < b.s1 ? b.s1 : b.s0;
             h.prev_pair_row[g] = io.pair_row[g];
             h.prev_pair_rows[g] = b.rows;
         }

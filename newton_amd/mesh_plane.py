@@ -31,6 +31,10 @@ def mesh_plane_contacts(pairs, shape_type, shape_transform, shape_data, shape_ga
             raise TypeError(f"{name} must be a contiguous CUDA tensor of dtype {dt}")
     dev = pairs.device
     P = int(pairs.shape[0])
+    if reduce_contacts and int(shape_vertex_range[:, 1].max().item()) >= (1 << 22):
+        # the reduction's packed values carry the vertex index in 22 bits (contact_reduction_global.py: FINGERPRINT bits): larger
+        # meshes would alias in the table and the winners would be recomputed from truncated indices
+        raise NotImplementedError("reduce_contacts=True supports triangle meshes with fewer than 2^22 vertices")
     if capacity is None:
         capacity = int(shape_vertex_range[:, 1].sum().item()) * max(P, 1)
     out = dict(count=torch.zeros(1, dtype=i32, device=dev), blk=torch.zeros((max(P, 1), 2), dtype=i32, device=dev),

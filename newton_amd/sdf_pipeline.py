@@ -151,7 +151,9 @@ class SdfLeg:
             # rows a world can get from its vertex pairs: every vertex when the reduction is off, else the reduction's table
             mp_rows = sum(int(model.mesh_vertex_range[t.shape_local0 + l if l < t.ns else int(t.gshape_id[l - t.ns]), 1])
                           for pr in t.sdf_pair[mesh_plane] for l in pr)
-            self.rows_per_world = max(self.rows_per_world, mp_rows + 64)
+            # the vertex rows come ON TOP of the other legs' rows: a world with both kinds of pairs shares one row budget
+            other_rows = self.rows_per_world if (self.has_edge_pairs or self.has_hydro_pairs) else 0
+            self.rows_per_world = max(self.rows_per_world, other_rows + mp_rows + 64)
             self.row_capacity = E * self.rows_per_world
         if self.has_hydro_pairs:
             from .mc_tables import tables  # noqa: PLC0415

@@ -33,4 +33,4 @@ def test_mesh_on_ground_pipeline_dry_run(oracle_lib):
     r = subprocess.run([sys.executable, "-m", "pytest", "-p", "emu_plugin", "-m", "gpu", "-q", "-x", "test_gpu_mesh_plane_pipeline.py",
                         "-k", "rows_of_meshes or matching"], cwd=TESTS, env=ENV, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "3 passed" in r.stdout
+    assert "4 passed" in r.stdout

@@ -66,11 +66,47 @@ def test_c4_4096_quadrupeds_one_frame_vs_oracle(lowered):
         # MI355X: median 7e-8, p99 6.4e-7, one environment of 4096 a threshold event apart at 3.0e-4)
         tol.check_rollout(f"c4_4096_quadrupeds_frame lowered={lowered}", q, qd, oout.body_q, oout.body_qd, model.env.nb, **gates)
     assert np.all(np.abs(np.linalg.norm(q[:, 3:], axis=1) - 1.0) < 1e-5)
+    if lowered:
+        _explain_c4_outliers(nt, model, o, q, qd)
     # contacts of the 10th substep come from states that already differ by rounding: a contact sitting within ~1e-6 of
     # the gap threshold may flip in a handful of the 4096 x 13 pairs, everything else must agree exactly
     got, want = contacts.rigid_contact_count_per_env.cpu().numpy(), _per_env_counts(model, oc)
     assert np.mean(got == want) >= 0.999
     assert abs(int(got.sum()) - int(want.sum())) <= 8
+
+
+def _explain_c4_outliers(nt, model, o, q_frame, qd_frame):
+    """The outlier allowance of check_rollout, tested (tolerances.explain_rollout_outliers): the frame again substep by substep on
+    the device (ten one-substep rollouts: bitwise the ten-substep launch) and on the oracle, then every environment beyond 1e-5 must
+    re-join the oracle when the oracle restarts from the device's own state next to the environment's first divergent substep."""
+    from oracle_bridge import OracleState
+
+    s0, s1 = model.state(), model.state()
+    contacts = nt.CollisionPipeline(model).contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=2)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    gpu, ora = [(s0.body_q.cpu().numpy().copy(), s0.body_qd.cpu().numpy().copy())], [(os0.body_q.copy(), os0.body_qd.copy())]
+    a, b, oa, ob = s0, s1, os0, os1
+    for _ in range(10):
+        out = solver.rollout(a, b, None, contacts, DT, 1)
+        a, b = (b, a) if out is b else (a, b)
+        gpu.append((a.body_q.cpu().numpy().copy(), a.body_qd.cpu().numpy().copy()))
+        oout = o.xpbd_rollout(oa, ob, o.control(), oc, DT, 1, iterations=2)
+        oa, ob = (ob, oa) if oout is ob else (oa, ob)
+        ora.append((oa.body_q.copy(), oa.body_qd.copy()))
+    assert np.array_equal(gpu[10][0], q_frame) and np.array_equal(gpu[10][1], qd_frame)  # ten launches of one substep == one of ten
+
+    def restart(k, q, qd):
+        ra, rb = OracleState(model), OracleState(model)
+        ra.body_q[:], ra.body_qd[:] = q, qd
+        states = []
+        for _ in range(10 - k):
+            rout = o.xpbd_rollout(ra, rb, o.control(), oc, DT, 1, iterations=2)
+            ra, rb = (rb, ra) if rout is rb else (ra, rb)
+            states.append((ra.body_q.copy(), ra.body_qd.copy()))
+        return states
+
+    return tol.explain_rollout_outliers("c4_4096_quadrupeds_frame lowered=True", gpu, ora, restart, model.env.nb)
 
 
 def test_c4_env_result_is_independent_of_batch_and_tile():

@@ -241,6 +241,40 @@ def test_contact_matching_and_deterministic_order_over_vertex_rows():
     assert nd == len(mi) and np.all(np.diff(key) > 0)
 
 
+def test_contact_matching_with_the_planes_before_and_after_the_meshes():
+    """the vertex leg rewrites a candidate pair as (mesh, plane); with a ground plane added FIRST (shape 0) and a
+    second plane added last, a world's candidate list [(0, 1), (0, 2), (1, 3), (2, 3)] becomes [(1, 0), (2, 0), (1, 3), (2, 3)] --
+    no longer ascending in (shape0, shape1).  The row matcher searches the previous frame's list on the canonical (min, max) key, so an
+    unchanged second frame still matches every row."""
+    import newton_amd as nt
+
+    hull = nt.Mesh.create_box(0.1, 0.08, 0.05)
+    mesh = nt.Mesh(np.concatenate([hull.vertices] * 3), hull.indices)
+    env = nt.ModelBuilder()
+    env.default_shape_cfg.gap = 0.004
+    b = env.add_body(xform=[0.0, 0.0, 0.05 - 0.0008, 0.0, 0.0, 0.0, 1.0])
+    env.add_shape_mesh(b, mesh=mesh)
+    env.add_shape_mesh(b, mesh=mesh, xform=[0.3, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+    env.add_shape_collision_filter_pair(0, 1)
+    scene = nt.ModelBuilder()
+    scene.default_shape_cfg.gap = 0.004
+    scene.add_ground_plane()
+    scene.replicate(env, 2)
+    scene.add_ground_plane()
+    model = scene.finalize(device="cuda:0")
+    pipe = nt.CollisionPipeline(model, broad_phase="nxn", contact_matching="latest", contact_report=True)
+    c = pipe.contacts()
+    state = model.state()
+    pipe.collide(state, c)
+    n = int(c.rigid_contact_count.item())
+    assert n >= 2 * 2 * 2 * 4  # two worlds x two meshes x two planes x four bottom corners
+    assert np.all(c.rigid_contact_match_index[:n].cpu().numpy() == -1)
+    pipe.collide(state, c)
+    assert int(c.rigid_contact_count.item()) == n
+    assert np.array_equal(c.rigid_contact_match_index[:n].cpu().numpy(), np.arange(n))
+    assert int(c.rigid_contact_new_count.item()) == 0 and int(c.rigid_contact_broken_count.item()) == 0
+
+
 def test_mesh_worlds_inside_heterogeneous_models():
     """Worlds that differ in topology (a mesh box here, a mesh sphere plus a primitive box there) run as world groups
     (newton_amd/hetero.py): every group has its own vertex leg, the flat contact arrays keep Newton's shape ids -- slot contacts of

@@ -131,12 +131,12 @@ def test_c_abi_exports_every_declared_symbol():
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp, m.np_analytic = 18, 18, 4, 13
     # slot-major fields with odd strides (even component counts padded by one row):
-    # persistent rows 1400 (state (7 + 7) * 13 = 182 + body 23 * 13 = 299 + joint 15 * 13 = 195 + dof 11 * 18 = 198 + shape 21 * 13 = 273
+    # persistent rows 1401 (state (7 + 7) * 13 = 182 + body 23 * 13 = 299 + joint 15 * 13 = 195 + dof 11 * 18 = 198 + shape 21 * 13 = 273
     # + control 54 + gravity 3 + derived 117 + per-pair live counts 13 + their exclusive prefix 14 + the compacted live-contact
-    # list 13 * 4 = 52)
+    # list 13 * 4 = 52 + its atomic append counter 1)
     # + XPBD scratch max(collide 14 * 13 + 13 = 195 + staged candidates 19 * 13 + hit list 13 + 1 = 456, the forces 7 * 13 + 13 * 13 behind it = 716,
     #   joints 22 * 13 = 286, correction records 11 * 52 = 572); the restitution scratch (182 + 15-float records) only when enabled
-    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1400 + 716)
+    assert lib.nt_lds_bytes_per_env(C.byref(m)) == 4 * (1401 + 716)
     # Featherstone: generalized state 127 + COM/origin 78 + S 108 + I_s 468 + v/a/f/ft 312 + f_ext 78 = 1171,
     # + max(P 6*13*18 + H 18*18 = 1728, contact wrenches 780, collide scratch 429)
     m.nc, m.na, m.max_art_dofs = 19, 1, 18
