@@ -329,7 +329,11 @@ inline bool xpbd_cfg_override(XpbdCfg& c) {
 #define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1) X(16, 256, 2, 1)
 #elif defined(NT_DEV_FAST)
 #define NT_XPBD_ROLLOUT_SHAPES(X) X(16, 512, 1, 0) X(32, 512, 1, 1) X(16, 512, 1, 1)
+#ifdef NT_DEV_CVX  // (+ the convex uniform tile of 16: the 8-box stacks and the box-foot quadruped)
+#define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(16, 512, 1, 1)
+#else
 #define NT_XPBD_ROLLOUT_SHAPES_CVX(X)
+#endif
 #else
 #define NT_XPBD_ROLLOUT_SHAPES(X) X(16, 512, 1, 0) X(32, 512, 1, 1) X(16, 512, 1, 1)
 #define NT_XPBD_ROLLOUT_SHAPES_CVX(X) X(8, 256, 2, 1) X(16, 512, 1, 1)

@@ -137,6 +137,7 @@ template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ?
 __global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
+    c.lds_records = false;  // (compile-time facts for this kernel: the LDS-record code folds away)
     load_tile(c, &a.s_in, false);
     __syncthreads();
     do_collide<EPB, CVX>(c, true);
@@ -148,6 +149,7 @@ template <int EPB>
 __global__ void __launch_bounds__((EPB & 255) <= 8 ? 256 : 512) shapes_export_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, false);
+    c.lds_records = false;
     load_tile(c, &a.s_in, false);
     __syncthreads();
     phase_shapes(c);
@@ -157,6 +159,7 @@ template <int EPB, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512
 __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
+    c.lds_records = false;
     const fused::Ctx<EPB> cf(c, 0);
     load_tile(c, &a.s_in, true);
     __syncthreads();
@@ -204,6 +207,7 @@ template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ?
 __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     Ctx<EPB> c(a, lds, -1, BIG);
+    if constexpr (CVX || BIG) c.lds_records = false;  // (granted to analytic-only staged tiles alone: folds the LDS-record code away here)
     if constexpr (!BIG) {  // (the layout holds the snapshot rows, the pairs fit one pass and the integrate lanes fit behind them)
         constexpr int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;
         if ((a.tile_opts & NT_TILE_POSE_SNAPSHOT) && a.m.np <= a.nslot && ((a.m.np + spw - 1) / spw) * spw + a.m.nb <= a.nslot)

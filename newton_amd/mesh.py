@@ -75,13 +75,24 @@ class Mesh:
         return self.sdf
 
     @staticmethod
-    def create_box(hx: float, hy: float, hz: float, *, duplicate_vertices: bool = False, compute_normals: bool = False,
-                   compute_uvs: bool = False, compute_inertia: bool = True) -> Mesh:
+    def create_box(hx: float, hy: float | None = None, hz: float | None = None, *, duplicate_vertices: bool = False,
+                   compute_normals: bool = False, compute_uvs: bool = False, compute_inertia: bool = True,
+                   reference_layout: bool = False) -> Mesh:
         """newton.Mesh.create_box signature (geometry/types.py:560-620).  duplicate_vertices=True builds the reference's per-face
         vertex table (utils/mesh.py:2044-2065: faces -x, +x, -y, +y, -z, +z, four corners each, cycling (-,-), (-,+), (+,+), (+,-)
         over the face's two other axes) -- the vertex ORDER matters once the mesh collides vertex by vertex (add_shape_mesh: the
         vertex index is the contact fingerprint); pinned by tests/golden/mesh_box_tables.json.  The default keeps this package's
-        8-corner hull (convex hulls de-duplicate anyway; normals / uvs are rendering data: accepted and ignored)."""
+        8-corner hull (convex hulls de-duplicate anyway; normals / uvs are rendering data: accepted and ignored);
+        reference_layout=True with duplicate_vertices=False gives the reference's shared-vertex table instead (utils/mesh.py:2066-2100:
+        the z- ring counter-clockwise from (-, -), then the z+ ring; same pin) -- same solid, the reference's contact fingerprints."""
+        hy = hx if hy is None else hy
+        hz = hx if hz is None else hz
+        if reference_layout and not duplicate_vertices:
+            ring = ((-1, -1), (1, -1), (1, 1), (-1, 1))
+            verts = [(sx * hx, sy * hy, sz * hz) for sz in (-1, 1) for sx, sy in ring]
+            quads = ((4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (0, 4, 7, 3), (1, 2, 6, 5))  # z+, y-, y+, x-, x+
+            tris = [(0, 2, 1), (0, 3, 2)] + [t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))]  # (z- first)
+            return Mesh(np.asarray(verts, dtype=np.float32), np.asarray(tris, dtype=np.int32), compute_inertia=compute_inertia)
         if duplicate_vertices:
             h = (float(hx), float(hy), float(hz))
             cyc = ((-1, -1), (-1, 1), (1, 1), (1, -1))
@@ -103,8 +114,26 @@ class Mesh:
         return Mesh.convex_hull_of(v)
 
     @staticmethod
-    def create_sphere(radius: float = 1.0, num_latitudes: int = 32, num_longitudes: int = 32, compute_inertia: bool = True) -> Mesh:
-        """UV sphere (poles + latitude rings), outward winding -- the vertex set newton.Mesh.create_sphere produces."""
+    def create_sphere(radius: float = 1.0, num_latitudes: int = 32, num_longitudes: int = 32, compute_inertia: bool = True,
+                      reference_layout: bool = False) -> Mesh:
+        """UV sphere, outward winding.  Default: poles + latitude rings about +z, every vertex once (2 + (lat - 1) * lon).
+        reference_layout=True: the reference's own table (utils/mesh.py:1026-1075 behind newton.Mesh.create_sphere) -- the
+        (lat + 1) x (lon + 1) grid about +y with the seam column and the poles repeated, two triangles per grid cell (degenerate at
+        the poles) -- vertex for vertex, so that a mesh sphere colliding vertex by vertex carries the reference's contact
+        fingerprints (pinned by tests/golden/mesh_box_tables.json, recorded by executing the reference function)."""
+        if reference_layout:
+            verts, tris = [], []
+            for i in range(num_latitudes + 1):
+                th = i * np.pi / num_latitudes
+                for j in range(num_longitudes + 1):
+                    ph = j * 2 * np.pi / num_longitudes
+                    verts.append((np.cos(ph) * np.sin(th) * radius, np.cos(th) * radius, np.sin(ph) * np.sin(th) * radius))
+            for i in range(num_latitudes):
+                for j in range(num_longitudes):
+                    a = i * (num_longitudes + 1) + j
+                    b = a + num_longitudes + 1
+                    tris += [(a, a + 1, b), (b, a + 1, b + 1)]
+            return Mesh(np.asarray(verts, dtype=np.float32), np.asarray(tris, dtype=np.int32), compute_inertia=compute_inertia)
         verts = [(0.0, 0.0, radius)]
         for i in range(1, num_latitudes):
             th = np.pi * i / num_latitudes

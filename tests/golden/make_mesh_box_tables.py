@@ -20,5 +20,9 @@ out = {}
 for dup in (True, False):
     p, i, _, _ = mesh.create_mesh_box(0.5, 0.25, 0.125, duplicate_vertices=dup, compute_normals=False, compute_uvs=False)
     out["duplicated" if dup else "shared"] = {"positions": [[float(x) for x in v] for v in p], "indices": [int(x) for x in i]}
+# ... and create_mesh_sphere (utils/mesh.py:1026-1075, behind newton.Mesh.create_sphere): the (lat + 1) x (lon + 1) grid, y up,
+# seam and poles repeated
+p, i, _, _ = mesh.create_mesh_sphere(0.5, num_latitudes=4, num_longitudes=6, compute_normals=False, compute_uvs=False)
+out["sphere_4x6"] = {"positions": [[float(x) for x in v] for v in p], "indices": [int(x) for x in i]}
 json.dump(out, open(os.path.join(HERE, "mesh_box_tables.json"), "w"), indent=1)
 print({k: (len(v["positions"]), len(v["indices"])) for k, v in out.items()})

@@ -405,3 +405,11 @@ def test_create_box_with_duplicated_vertices_is_the_reference_table():
     assert np.isclose(m.mass, 1.0 * 0.5 * 0.25) and np.allclose(m.com, 0.0, atol=1e-7)  # unit density x (2 hx)(2 hy)(2 hz)
     assert np.isclose(m.inertia[0, 0], m.mass / 12.0 * (0.5 ** 2 + 0.25 ** 2), rtol=1e-5)
     assert len(nt.Mesh.create_box(0.5, 0.25, 0.125).vertices) == 8  # the default: this package's 8-corner hull
+    # reference_layout=True: the reference's shared-vertex box and its (lat + 1) x (lon + 1) sphere grid, vertex for vertex
+    tables = json.load(open(os.path.join(ROOT, "tests", "golden", "mesh_box_tables.json")))
+    m = nt.Mesh.create_box(0.5, 0.25, 0.125, reference_layout=True)
+    assert np.array_equal(np.asarray(m.vertices, np.float32), np.asarray(tables["shared"]["positions"], np.float32))
+    assert np.array_equal(np.asarray(m.indices).reshape(-1), np.asarray(tables["shared"]["indices"]))
+    m = nt.Mesh.create_sphere(0.5, 4, 6, reference_layout=True, compute_inertia=False)
+    assert np.array_equal(np.asarray(m.vertices, np.float32), np.asarray(tables["sphere_4x6"]["positions"], np.float32))
+    assert np.array_equal(np.asarray(m.indices).reshape(-1), np.asarray(tables["sphere_4x6"]["indices"]))
