@@ -161,6 +161,22 @@ NT_DI void store_global_shapes_world(const Ctx<EPB>& c) {
     }
 }
 
+// The global (world -1) shapes are static: their world transform and gap-widened AABB (an infinite plane's costs three IEEE
+// divisions) are computed once per launch by the workgroup's last threads into the block-shared T.gworld, one barrier before the
+// first pair phase reads them -- instead of by every pair lane in every substep.  Same function, same bits.
+template <int EPB>
+NT_DI void stage_global_world(const Ctx<EPB>& c) {
+    const nt_model& m = c.a.m;
+    const int k = (int)blockDim.x - 1 - (int)threadIdx.x;
+    if (k >= m.ng) return;
+    const int s = m.ns + k;
+    xform X = c.shape_local_xform(s);
+    vec3 lo, hi;
+    shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), m.shape_mesh_bounds + 6 * s, lo, hi);
+    float* g = c.T.gworld + 13 * k;
+    g[0] = X.p.x; g[1] = X.p.y; g[2] = X.p.z; g[3] = X.q.x; g[4] = X.q.y; g[5] = X.q.z; g[6] = X.q.w;
+    g[7] = lo.x; g[8] = lo.y; g[9] = lo.z; g[10] = hi.x; g[11] = hi.y; g[12] = hi.z;
+}
 template <int EPB>
 NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {
     const nt_model& m = c.a.m;
@@ -168,6 +184,11 @@ NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {
         X = c.lxf(c.L.sx, 0, m.ns, s);
         lo = c.lv3(c.L.sa, 0, m.ns, s);
         hi = c.lv3(c.L.sa, 3, m.ns, s);
+    } else if (c.gworld_ready) {
+        const float* g = c.T.gworld + 13 * (s - m.ns);
+        X = xform(vec3(g[0], g[1], g[2]), quat(g[3], g[4], g[5], g[6]));
+        lo = vec3(g[7], g[8], g[9]);
+        hi = vec3(g[10], g[11], g[12]);
     } else {
         X = c.shape_local_xform(s);  // global shapes are static (shape_body == -1)
         shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP),

@@ -19,6 +19,7 @@ struct Ctx {
                 // (87.4 vs 100.8 M env-steps/s) -- twice the wave-instructions cost more than the second wave per SIMD hides
     int pose_in_off;  // rows of the poses the contact writer converts into (collide.py:166-204: the step's incoming poses): L.bq, or the
                       // snapshot L.xiq while integrate_bodies runs beside the pair phase of a fused rollout
+    bool gworld_ready;  // T.gworld holds the global shapes' world transforms / AABBs (stage_global_world ran, a barrier ago)
     bool lds_records;  // NT_TILE_LDS_RECORDS granted: the contact records of this launch live in L.cr
     bool hbm_out;      // the collide phases write the Contacts buffers in HBM (always, except the non-final substeps of an LDS-record rollout)
     bool big;  // contact records in HBM, manifold polygon scratch per lane (compile-time constant at every construction site)
@@ -79,6 +80,9 @@ struct Ctx {
             T.gshape = g;
             o += ngf;
         }
+        T.gworld = reinterpret_cast<float*>(ti + o);
+        o += 13 * m.ng;
+        gworld_ready = false;
         T.hit_count = ti + o;
         T.hit_list = ti + o + 1;
         T.pair_desc = ti + o;  // (the two tables exclude each other)
@@ -97,7 +101,7 @@ struct Ctx {
     template <class OtherCtx>
     NT_DI explicit Ctx(const OtherCtx& o, int /*tag*/)
         : a(o.a), T(o.T), lds(o.lds), up(o.up), L(o.L), e(o.e), slot(o.slot), env(o.env), nslot(o.nslot), tslot(o.tslot),
-          pose_in_off(o.pose_in_off), lds_records(o.lds_records), hbm_out(o.hbm_out), big(o.big),
+          pose_in_off(o.pose_in_off), gworld_ready(o.gworld_ready), lds_records(o.lds_records), hbm_out(o.hbm_out), big(o.big),
           ES(o.ES), valid(o.valid) {}
     // LDS element (comp, s) of a slot-major field.  `n` (the slot count of the [comp][n] HBM twin) is not needed here; the
     // argument stays so that every access reads like its global-memory counterpart g(comp, n, s)

@@ -199,11 +199,12 @@ struct Topo {
     // order (narrow_phase.py:525-528), their bodies (-1 static), bit 30 of the last word: shape0 is the pair's second shape
     const int* pair_desc;
     const float* gshape;  // [ng][NT_SHAPE_PARAM_FLOATS] parameters of the global (world -1) shapes, block-shared copy
+    float* gworld;        // [ng][13] world transform + gap-widened AABB of the global shapes (static: staged once per launch)
     int *hit_count, *hit_list;  // pair-heavy tile only: the environment's compacted candidate list (1 + np ints)
 };
 __host__ __device__ inline int topo_ints(const nt_model& m) {
     return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np + m.ng +
-           NT_SHAPE_PARAM_FLOATS * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 4 * m.np);
+           NT_SHAPE_PARAM_FLOATS * m.ng + 13 * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 4 * m.np);
 }
 
 // ------------------------------------------------------------------------------------------------

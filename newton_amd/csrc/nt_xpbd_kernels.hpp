@@ -140,6 +140,8 @@ __global__ void __launch_bounds__(THREADS, MINW) collide_kernel(KArgs a) {
     c.lds_records = false;  // (compile-time facts for this kernel: the LDS-record code folds away)
     load_tile(c, &a.s_in, false);
     __syncthreads();
+    stage_global_world(c);  // (beside the shape phase; the pair phase behind its barrier reads it)
+    c.gworld_ready = true;
     do_collide<EPB, CVX>(c, true);
 }
 
@@ -223,6 +225,8 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
         }
     __syncthreads();
     fused::phase_body_derived(cf);
+    stage_global_world(c);  // (the topology tables it reads were published by the barrier above)
+    c.gworld_ready = true;
     __syncthreads();
     NT_TICK(0);
     for (int s = 0; s < a.substeps; ++s) {
