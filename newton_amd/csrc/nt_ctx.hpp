@@ -83,6 +83,8 @@ struct Ctx {
         T.gworld = reinterpret_cast<float*>(ti + o);
         o += 13 * m.ng;
         gworld_ready = false;
+        T.joint_inc = ti + o;  // (filled by stage_joint_inc, one barrier after the tables above are published)
+        o += 2 * m.nj;
         T.hit_count = ti + o;
         T.hit_list = ti + o + 1;
         T.pair_desc = ti + o;  // (the two tables exclude each other)
@@ -175,6 +177,18 @@ struct Ctx {
         return vec3(base[g(comp0, n, s)], base[g(comp0 + 1, n, s)], base[g(comp0 + 2, n, s)]);
     }
 
+    // inverse of body_joint_list: position of code (j << 1 | side) in the list, -1 for the world side of a root joint.  Reads the
+    // block-shared copy of the list, i.e. runs one barrier after the constructor; the XPBD joint phases are barriers later still
+    NT_DI void stage_joint_inc() const {
+        const int nlist = a.m.nj > 0 ? T.body_joint_start[a.m.nb] : 0;
+        int* inv = const_cast<int*>(T.joint_inc);
+        for (int i = threadIdx.x; i < 2 * a.m.nj; i += blockDim.x) {
+            int at = -1;
+            for (int k = 0; k < nlist; ++k)
+                if (T.body_joint_list[k] == i) at = k;
+            inv[i] = at;
+        }
+    }
     NT_DI xform body_q(int b) const { return lxf(L.bq, 0, a.m.nb, b); }
     NT_DI xform body_q_in(int b) const { return lxf(Fld<7>{pose_in_off}, 0, a.m.nb, b); }
     NT_DI quat body_rot(int b) const {

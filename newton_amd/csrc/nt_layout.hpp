@@ -70,8 +70,9 @@ struct LdsLayout {
     Fld<1> hl, hc;     // collide: the environment's compacted broad-phase hits [np] + their count [1] (staged tiles, int bits)
     Fld<7> bf;         // forces: body_f_tmp [nb][6 (+1)]
     Fld<13> jf;        // forces: joint wrenches [nj][12 (+1)]
-    Fld<13> jl;        // joints: linear-part corrections [nj][12 (+1)]
-    Fld<9> ja;         // joints: angular-part child terms [nj][9]
+    Fld<9> ji;         // joints: corrections in body-incidence order [2 nj][9] -- entry i of Topo::body_joint_list (a (joint, side)):
+                       // lin (3), ang of the linear rows (3) from the joint's linear lane, summed angular-row terms (3, sign applied)
+                       // from its angular lane; a body's entries are contiguous: its lane sums them from ONE base address
     Fld<NC_CWX> cw;    // contacts: XPBD per-contact corrections [np*cpp][10 (+1)]
     Fld<NC_CW> cwr;    // the same rows as 15-float records (XPBD restitution pass)
     Fld<7> si_bf; Fld<13> si_jf; Fld<NC_CW> si_cw;  // semi-implicit: body_f_tmp + joint wrenches + contact wrenches, all live together
@@ -135,8 +136,8 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     // and the joint-force phase in the same barrier interval (different waves); the pair-heavy tile keeps the overlap
     L.bf.off = big ? L.u : L.u + coll; L.jf.off = L.bf.off + 7 * m.nb;
     int forces = (big ? 0 : coll) + 7 * m.nb + 13 * m.nj;
-    L.jl.off = L.u; L.ja.off = L.jl.off + 13 * m.nj;
-    int joints = 22 * m.nj;
+    L.ji.off = L.u;
+    int joints = 18 * m.nj;
     L.cw.off = L.u; L.cwr.off = L.u;
     // big: the records live in nt_contacts.cw (HBM)
     int contacts = big ? 0 : (restitution ? NC_CW : NC_CWX) * m.np * m.cpp;
@@ -195,6 +196,7 @@ struct Topo {
     const int *body_flags, *joint_type, *joint_enabled, *joint_parent, *joint_child, *joint_q_start, *joint_qd_start,
         *joint_tq_start, *joint_lin_count, *joint_ang_count, *shape_body, *shape_type, *shape_flags, *shape_group, *pair_a,
         *pair_b, *body_joint_start, *body_joint_list, *body_pair_start, *body_pair_list, *shape_mesh_start, *shape_mesh_count, *gshape_id;
+    const int* joint_inc;  // [2 nj] inverse of body_joint_list: position of (joint j, side) = code j << 1 | side in the list, -1 (world side)
     // [np][4] (not in the pair-heavy tile): a pair as the contact phases need it -- shape0, shape1 in the narrow phase's type-sorted
     // order (narrow_phase.py:525-528), their bodies (-1 static), bit 30 of the last word: shape0 is the pair's second shape
     const int* pair_desc;
@@ -204,7 +206,7 @@ struct Topo {
 };
 __host__ __device__ inline int topo_ints(const nt_model& m) {
     return m.nb + 9 * m.nj + 6 * (m.ns + m.ng) + 2 * m.np + 2 * (m.nb + 1) + 2 * m.nj + 2 * m.np + m.ng +
-           NT_SHAPE_PARAM_FLOATS * m.ng + 13 * m.ng + (m.contact_scratch_in_hbm ? 1 + m.np : 4 * m.np);
+           NT_SHAPE_PARAM_FLOATS * m.ng + 13 * m.ng + 2 * m.nj + (m.contact_scratch_in_hbm ? 1 + m.np : 4 * m.np);
 }
 
 // ------------------------------------------------------------------------------------------------

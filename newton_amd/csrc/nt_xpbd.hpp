@@ -740,42 +740,36 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b, const bool do_lin, const b
             }
         }
     } else {
-        // ascending joint order; per (joint, side): the linear lane's record (lin, ang of the linear rows) + the angular lane's
-        // summed row terms (angular_p = -angular_c).  The first NT_APPLY_JOINTS entries of the list leave as one batch of loads.
-        const int nj = m.nj;
+        // ascending joint order: the body's entries of L.ji are contiguous (joint lanes write them in incidence order, the
+        // angular-row term already signed), so they are summed from ONE base address with immediate offsets -- the first
+        // NT_APPLY_JOINTS as one batch of loads (clamped entry, predicated add), longer lists in a loop
+        const int nj2 = 2 * m.nj;
         const int i0 = c.T.body_joint_start[b], n = c.T.body_joint_start[b + 1] - i0;
-        // (loads unconditional from a clamped entry, predicated at the add: one batch of loads for the codes, one for the records)
-        struct Inc { vec3 lin, ang, t; int code; };
-        auto fetch_code = [&](int k) { return c.T.body_joint_list[k < n ? i0 + k : 0]; };
-        auto fetch = [&](int code) {
+        struct Inc { vec3 lin, ang, t; };
+        auto fetch = [&](int k) {
             Inc r;
-            r.code = code;
-            const int j = code >> 1, side = code & 1;  // side 1: this body is the joint's child
-            if (want_lin) r.lin = c.lv3(c.L.jl, side * 6, nj, j);
+            const int i = i0 + k;  // (entries past the body's own are loaded and ignored: rows of the same scratch block)
+            if (want_lin) r.lin = c.lv3(c.L.ji, 0, nj2, i);
             if (do_ang) {
-                r.ang = c.lv3(c.L.jl, side * 6 + 3, nj, j);
-                r.t = c.lv3(c.L.ja, 0, nj, j);
+                r.ang = c.lv3(c.L.ji, 3, nj2, i);
+                r.t = c.lv3(c.L.ji, 6, nj2, i);
             }
             return r;
         };
         auto add = [&](int k, const Inc& r) {
             if (k < n) {
                 if (want_lin) dlin += r.lin;
-                if (do_ang) dang += r.ang + ((r.code & 1) ? r.t : -r.t);
+                if (do_ang) dang += r.ang + r.t;
             }
         };
         static_assert(NT_APPLY_JOINTS == 4, "four named entries below");
-        const int c0 = fetch_code(0), c1 = fetch_code(1), c2 = fetch_code(2), c3 = fetch_code(3);
-        const Inc r0 = fetch(c0), r1 = fetch(c1), r2 = fetch(c2), r3 = fetch(c3);
-        add(0, r0); add(1, r1); add(2, r2); add(3, r3);
+        if (n > 0) {
+            const Inc r0 = fetch(0), r1 = fetch(1), r2 = fetch(2), r3 = fetch(3);
+            add(0, r0); add(1, r1); add(2, r2); add(3, r3);
+        }
         for (int i = i0 + NT_APPLY_JOINTS; i < i0 + n; ++i) {
-            const int cd = c.T.body_joint_list[i];
-            const int j = cd >> 1, side = cd & 1;
-            if (want_lin) dlin += c.lv3(c.L.jl, side * 6, nj, j);
-            if (do_ang) {
-                const vec3 t = c.lv3(c.L.ja, 0, nj, j);
-                dang += c.lv3(c.L.jl, side * 6 + 3, nj, j) + (side ? t : -t);
-            }
+            if (want_lin) dlin += c.lv3(c.L.ji, 0, nj2, i);
+            if (do_ang) dang += c.lv3(c.L.ji, 3, nj2, i) + c.lv3(c.L.ji, 6, nj2, i);
         }
     }
     const float dt = c.a.dt;
@@ -1007,10 +1001,15 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
             }
         }
     }
-    c.st_lv3(c.L.jl, 0, nj, j, lin_delta_p);
-    c.st_lv3(c.L.jl, 3, nj, j, ang_delta_p);
-    c.st_lv3(c.L.jl, 6, nj, j, lin_delta_c);
-    c.st_lv3(c.L.jl, 9, nj, j, ang_delta_c);
+    const int ip = c.T.joint_inc[2 * j], ic = c.T.joint_inc[2 * j + 1];  // the (joint, side) entries of the two bodies' lists
+    if (ip >= 0) {
+        c.st_lv3(c.L.ji, 0, 2 * nj, ip, lin_delta_p);
+        c.st_lv3(c.L.ji, 3, 2 * nj, ip, ang_delta_p);
+    }
+    if (ic >= 0) {
+        c.st_lv3(c.L.ji, 0, 2 * nj, ic, lin_delta_c);
+        c.st_lv3(c.L.ji, 3, 2 * nj, ic, ang_delta_c);
+    }
 }
 
 template <int EPB>
@@ -1095,7 +1094,10 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
             else t2 = t;
         }
     }
-    c.st_lv3(c.L.ja, 0, nj, j, (t0 + t1) + t2);
+    const vec3 t = (t0 + t1) + t2;  // (angular_p = -angular_c: the parent's entry gets the negation)
+    const int ip = c.T.joint_inc[2 * j], ic = c.T.joint_inc[2 * j + 1];
+    if (ip >= 0) c.st_lv3(c.L.ji, 6, 2 * nj, ip, -t);
+    if (ic >= 0) c.st_lv3(c.L.ji, 6, 2 * nj, ic, t);
 }
 
 // apply_rigid_restitution (xpbd/kernels.py:2583-2728) for one contact slot; velocity deltas go to the per-contact record
@@ -1246,8 +1248,9 @@ NT_DI void report_joint_iteration(const Ctx<EPB>& c) {
         int id_p, id_c;
         float m_inv_p, m_inv_c;
         if (!joint_live(c, j, id_p, id_c, m_inv_p, m_inv_c)) continue;
-        vec3 jl = c.lv3(c.L.jl, 6, nj, j);
-        vec3 ja = c.lv3(c.L.jl, 9, nj, j) + c.lv3(c.L.ja, 0, nj, j);
+        const int ic = c.T.joint_inc[2 * j + 1];  // the child body's entry of this joint
+        vec3 jl = c.lv3(c.L.ji, 0, 2 * nj, ic);
+        vec3 ja = c.lv3(c.L.ji, 3, 2 * nj, ic) + c.lv3(c.L.ji, 6, 2 * nj, ic);
         J[c.g(0, nj, j)] += jl.x; J[c.g(1, nj, j)] += jl.y; J[c.g(2, nj, j)] += jl.z;
         J[c.g(3, nj, j)] += ja.x; J[c.g(4, nj, j)] += ja.y; J[c.g(5, nj, j)] += ja.z;
     }
@@ -1340,9 +1343,10 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
     // instead of their sum in the wave that used to straddle the boundary
     const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;
     const int A0 = ((nj + spw - 1) / spw) * spw;
+    NT_SKIP_DECL(c.a);  // (measurement builds: 32 skips the linear-row lanes, 64 the angular-row lanes)
     for (int i = c.slot; i < A0 + nj; i += c.nslot) {
-        if (i < nj) joint_linear_item(c, i);
-        else if (i >= A0) joint_angular_item(c, i - A0);
+        if (i < nj) { if (!NT_SKIP(32)) joint_linear_item(c, i); }
+        else if (i >= A0) { if (!NT_SKIP(64)) joint_angular_item(c, i - A0); }
     }
 }
 

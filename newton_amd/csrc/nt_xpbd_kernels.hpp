@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
     load_tile(c, &a.s_in, true);
     __syncthreads();
     fused::phase_body_derived(cf);
+    c.stage_joint_inc();
     __syncthreads();
     if constexpr (BIG) {
         fused::do_xpbd_step<EPB, false, fused::CwHbm>(cf, false);
@@ -225,6 +226,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
         }
     __syncthreads();
     fused::phase_body_derived(cf);
+    c.stage_joint_inc();
     stage_global_world(c);  // (the topology tables it reads were published by the barrier above)
     c.gworld_ready = true;
     __syncthreads();
