@@ -202,6 +202,18 @@ struct Ctx {
     NT_DI mat33 inertia(int b) const { return plm33(L.bp, BP_INERTIA, a.m.nb, b); }
     NT_DI vec3 com(int b) const { return plv3(L.bp, BP_COM, a.m.nb, b); }
     NT_DI vec3 world_com(int b) const { return lv3(L.bd, 0, a.m.nb, b); }
+    // the world-frame inverse inertia tile of body b as a value (six floats fetched once, then any number of quadratic forms)
+    struct Wsym {
+        float xx, xy, xz, yy, yz, zz;
+        NT_DI float quad(vec3 v) const {
+            vec3 wv(xx * v.x + xy * v.y + xz * v.z, xy * v.x + yy * v.y + yz * v.z, xz * v.x + yz * v.y + zz * v.z);
+            return dot(v, wv);
+        }
+    };
+    NT_DI Wsym w_tile(int b) const {
+        const int nb = a.m.nb;
+        return Wsym{l(L.bd, 3, nb, b), l(L.bd, 4, nb, b), l(L.bd, 5, nb, b), l(L.bd, 6, nb, b), l(L.bd, 7, nb, b), l(L.bd, 8, nb, b)};
+    }
     // a^T (R I^-1 R^T) a for body b (world-frame inverse inertia, symmetric 6-float tile in LDS)
     NT_DI float w_quad(int b, vec3 v) const {
         const int nb = a.m.nb;
@@ -235,6 +247,15 @@ struct Ctx {
     NT_DI float shape_f(int s, int comp) const {
         if (s < a.m.ns) return pl(L.sp, comp, a.m.ns, s);
         return T.gshape[(s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp];
+    }
+    // the same value through ONE load from a selected LDS address (no branch between the two tables: the loads of a phase's operands
+    // then leave as one batch)
+    NT_DI float shape_f_sel(int s, int comp) const {
+        const float* local;
+        if constexpr (UNI) local = up + (L.sp.off + s * NC_SP + comp);
+        else local = lds + ((L.sp.off + s * NC_SP + comp) * N + e);
+        const float* global = T.gshape + ((s - a.m.ns) * NT_SHAPE_PARAM_FLOATS + comp);
+        return *(s < a.m.ns ? local : global);
     }
     NT_DI vec3 shape_scale(int s) const { return vec3(shape_f(s, SP_SCALE), shape_f(s, SP_SCALE + 1), shape_f(s, SP_SCALE + 2)); }
     NT_DI xform shape_local_xform(int s) const {

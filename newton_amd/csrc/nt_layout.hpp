@@ -223,8 +223,13 @@ __device__ unsigned long long nt_phase_clock[32];
             nt_phase_clock[31] = now;                                                  \
         }                                                                              \
     } while (0)
+#define NT_TICK_START()                                                                \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) nt_phase_clock[31] = __builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define NT_TICK(slot) do { } while (0)
+#define NT_TICK_START() do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------

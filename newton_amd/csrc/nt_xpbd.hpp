@@ -287,7 +287,7 @@ NT_DI float contact_constraint_delta(float err, float m_inv_a, float m_inv_b, ve
     denom += wq_a;
     denom += wq_b;
     float delta_lambda = -err;
-    if (denom > 0.0f) delta_lambda = xdiv(delta_lambda, dt * denom);
+    delta_lambda = denom > 0.0f ? xdiv(delta_lambda, dt * denom) : delta_lambda;
     return delta_lambda * relaxation;
 }
 
@@ -403,129 +403,113 @@ NT_DI LoadedRecord load_record(const REC& r) {
     L.p0 = r.point0(); L.p1 = r.point1(); L.n = r.normal(); L.o0 = r.offset0(); L.o1 = r.offset1(); L.m = r.margins();
     return L;
 }
+// Written load-first and branch-free: every LDS operand of both bodies and both shapes is fetched from clamped indices before
+// the first use (a static side is selected to identity / zero afterwards: its rotation leaves a vector unchanged and its zero W tile
+// makes every quadratic form vanish), the optional rows are computed unconditionally and their multiplier selected to zero.  A
+// phase whose lanes own a SIMD alone cannot hide an LDS round trip (68 cycles, profiles/r05a_valu_issue.jsonl); the branchy form
+// took ~45 dependent round trips per contact, this one four.
 template <int EPB, class REC>
 NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int shape_b, int body_a, int body_b, vec3& lin_delta_a,
                          vec3& ang_delta_a, vec3& ang_delta_b) {
     const float dt = c.a.dt, relaxation = c.a.p.rigid_contact_relaxation;
+    const bool ha = body_a >= 0, hb = body_b >= 0, sha = shape_a >= 0, shb = shape_b >= 0;
+    const int ba = ha ? body_a : 0, bb = hb ? body_b : 0, sa = sha ? shape_a : 0, sb = shb ? shape_b : 0;
     // a body inside the step is (world COM, rotation): the origin p is stale between integrate and the last apply (see the body
     // phases above).  A contact point p + R x becomes x_com + R (x - com); its lever arm about the COM is the rotated part alone.
-    quat q_a, q_b;
-    vec3 wc_a(0.0f), wc_b(0.0f), com_a(0.0f), com_b(0.0f);  // world COM / body-frame COM (origin for static shapes)
-    if (body_a >= 0) {
-        q_a = c.body_rot(body_a);
-        wc_a = c.world_com(body_a);
-        com_a = c.com(body_a);
+    quat q_a = c.body_rot(ba), q_b = c.body_rot(bb);
+    vec3 wc_a = c.world_com(ba), wc_b = c.world_com(bb), com_a = c.com(ba), com_b = c.com(bb);
+    vec3 omega_a = c.body_w(ba), omega_b = c.body_w(bb), vel_a = c.body_v(ba), vel_b = c.body_v(bb);
+    float m_inv_a = c.inv_mass(ba), m_inv_b = c.inv_mass(bb);
+    typename Ctx<EPB>::Wsym W_a = c.w_tile(ba), W_b = c.w_tile(bb);
+    bool kin_a = (c.T.body_flags[ba] & BODY_KINEMATIC) != 0, kin_b = (c.T.body_flags[bb] & BODY_KINEMATIC) != 0;
+    float mu_a = c.shape_f_sel(sa, SP_MU), mu_b = c.shape_f_sel(sb, SP_MU);
+    float mut_a = c.shape_f_sel(sa, SP_MU_TORSIONAL), mut_b = c.shape_f_sel(sb, SP_MU_TORSIONAL);
+    float mur_a = c.shape_f_sel(sa, SP_MU_ROLLING), mur_b = c.shape_f_sel(sb, SP_MU_ROLLING);
+    const vec3 point0 = rec.point0(), point1 = rec.point1(), n = rec.normal();
+    const vec3 offset_a = rec.offset0(), offset_b = rec.offset1();
+    const float margins = rec.margins();
+    if (!ha) {  // static side: identity pose at the origin, no mass, no velocity
+        q_a = quat(0.0f, 0.0f, 0.0f, 1.0f); wc_a = vec3(0.0f); com_a = vec3(0.0f); omega_a = vec3(0.0f); vel_a = vec3(0.0f);
+        m_inv_a = 0.0f; W_a = typename Ctx<EPB>::Wsym{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; kin_a = false;
     }
-    if (body_b >= 0) {
-        q_b = c.body_rot(body_b);
-        wc_b = c.world_com(body_b);
-        com_b = c.com(body_b);
+    if (!hb) {
+        q_b = quat(0.0f, 0.0f, 0.0f, 1.0f); wc_b = vec3(0.0f); com_b = vec3(0.0f); omega_b = vec3(0.0f); vel_b = vec3(0.0f);
+        m_inv_b = 0.0f; W_b = typename Ctx<EPB>::Wsym{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; kin_b = false;
     }
-    auto rot_a = [&](vec3 v) { return body_a >= 0 ? quat_rotate(q_a, v) : v; };
-    auto rot_b = [&](vec3 v) { return body_b >= 0 ? quat_rotate(q_b, v) : v; };
-    vec3 point0 = rec.point0(), point1 = rec.point1();
-    vec3 r_a = rot_a(point0 - com_a);
-    vec3 r_b = rot_b(point1 - com_b);
-    vec3 bx_a = wc_a + r_a;
-    vec3 bx_b = wc_b + r_b;
-    vec3 n = rec.normal();
-    float d = dot(n, bx_b - bx_a) - rec.margins();
-    if (!(d < 0.0f)) return false;
-    vec3 lin_delta_b;
-    float m_inv_a = 0.0f, m_inv_b = 0.0f;
-    vec3 omega_a(0.0f), omega_b(0.0f);
-    if (body_a >= 0) {
-        m_inv_a = c.inv_mass(body_a);
-        omega_a = c.body_w(body_a);
-    }
-    if (body_b >= 0) {
-        m_inv_b = c.inv_mass(body_b);
-        omega_b = c.body_w(body_b);
-    }
-    auto wq_a = [&](vec3 v) { return body_a >= 0 ? c.w_quad(body_a, v) : 0.0f; };
-    auto wq_b = [&](vec3 v) { return body_b >= 0 ? c.w_quad(body_b, v) : 0.0f; };
-    int mat_nonzero = 0;
-    float mu = 0.0f, mu_torsional = 0.0f, mu_rolling = 0.0f;
-    if (shape_a >= 0) {
-        mat_nonzero += 1;
-        mu += c.shape_f(shape_a, SP_MU);
-        mu_torsional += c.shape_f(shape_a, SP_MU_TORSIONAL);
-        mu_rolling += c.shape_f(shape_a, SP_MU_ROLLING);
-    }
-    if (shape_b >= 0) {
-        mat_nonzero += 1;
-        mu += c.shape_f(shape_b, SP_MU);
-        mu_torsional += c.shape_f(shape_b, SP_MU_TORSIONAL);
-        mu_rolling += c.shape_f(shape_b, SP_MU_ROLLING);
-    }
-    if (mat_nonzero > 1) {  // the mean of one or two shapes' coefficients: x / 2 == x * 0.5 exactly, x / 1 == x
+    if (!sha) { mu_a = 0.0f; mut_a = 0.0f; mur_a = 0.0f; }
+    if (!shb) { mu_b = 0.0f; mut_b = 0.0f; mur_b = 0.0f; }
+    float mu = mu_a + mu_b, mu_torsional = mut_a + mut_b, mu_rolling = mur_a + mur_b;
+    if (sha && shb) {  // the mean of one or two shapes' coefficients: x / 2 == x * 0.5 exactly, x / 1 == x
         mu *= 0.5f;
         mu_torsional *= 0.5f;
         mu_rolling *= 0.5f;
     }
+    vec3 r_a = quat_rotate(q_a, point0 - com_a);
+    vec3 r_b = quat_rotate(q_b, point1 - com_b);
+    vec3 bx_a = wc_a + r_a;
+    vec3 bx_b = wc_b + r_b;
+    float d = dot(n, bx_b - bx_a) - margins;
+    if (!(d < 0.0f)) return false;
+    vec3 lin_delta_b;
     vec3 angular_a = -cross(r_a, n);
     vec3 angular_b = cross(r_b, n);
 
-    float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, wq_a(angular_a), wq_b(angular_b), relaxation, dt);
+    float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, W_a.quad(angular_a), W_b.quad(angular_b), relaxation, dt);
     lin_delta_a = -n * lambda_n;
     lin_delta_b = n * lambda_n;
     ang_delta_a = angular_a * lambda_n;
     ang_delta_b = angular_b * lambda_n;
 
-    if (mu > 0.0f) {
-        vec3 offset_a = rec.offset0(), offset_b = rec.offset1();
-        r_a = rot_a((point0 + offset_a) - com_a);
-        r_b = rot_b((point1 + offset_b) - com_b);
+    {  // friction row (applies when mu > 0 and the tangential error is non-zero)
+        r_a = quat_rotate(q_a, (point0 + offset_a) - com_a);
+        r_b = quat_rotate(q_b, (point1 + offset_b) - com_b);
         bx_a = wc_a + r_a;
         bx_b = wc_b + r_b;
         vec3 delta = bx_b - bx_a;
         vec3 friction_delta = delta - dot(n, delta) * n;
         vec3 rel_v_kin_t(0.0f);
-        if (body_a >= 0 && (c.T.body_flags[body_a] & BODY_KINEMATIC) != 0) {
-            vec3 v_a = velocity_at_point(spatial(c.body_v(body_a), omega_a), r_a);
-            rel_v_kin_t = rel_v_kin_t - (v_a - dot(n, v_a) * n);
-        }
-        if (body_b >= 0 && (c.T.body_flags[body_b] & BODY_KINEMATIC) != 0) {
-            vec3 v_b = velocity_at_point(spatial(c.body_v(body_b), omega_b), r_b);
-            rel_v_kin_t = rel_v_kin_t + (v_b - dot(n, v_b) * n);
+        {
+            vec3 v_a = velocity_at_point(spatial(vel_a, omega_a), r_a);
+            vec3 t_a = v_a - dot(n, v_a) * n;
+            if (kin_a) rel_v_kin_t = rel_v_kin_t - t_a;
+            vec3 v_b = velocity_at_point(spatial(vel_b, omega_b), r_b);
+            vec3 t_b = v_b - dot(n, v_b) * n;
+            if (kin_b) rel_v_kin_t = rel_v_kin_t + t_b;
         }
         friction_delta += rel_v_kin_t * dt;
-        vec3 perp = xnormalize(friction_delta);
+        const float err = xlength(friction_delta);
+        const vec3 perp = vsel(err > 0.0f, xdiv(friction_delta, err), vec3());  // xnormalize, as a select
         angular_a = -cross(r_a, perp);
         angular_b = cross(r_b, perp);
-        float err = xlength(friction_delta);
-        if (err > 0.0f) {
-            float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, wq_a(angular_a),
-                                                       wq_b(angular_b), relaxation, dt);
-            lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
-            lin_delta_a -= perp * lambda_fr;
-            lin_delta_b += perp * lambda_fr;
-            ang_delta_a += angular_a * lambda_fr;
-            ang_delta_b += angular_b * lambda_fr;
-        }
+        float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, W_a.quad(angular_a), W_b.quad(angular_b),
+                                                   relaxation, dt);
+        lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
+        if (!(mu > 0.0f && err > 0.0f)) lambda_fr = 0.0f;
+        lin_delta_a -= perp * lambda_fr;
+        lin_delta_b += perp * lambda_fr;
+        ang_delta_a += angular_a * lambda_fr;
+        ang_delta_b += angular_b * lambda_fr;
     }
     vec3 delta_omega = omega_b - omega_a;
-    if (mu_torsional > 0.0f) {
+    const vec3 lin0(0.0f);
+    {  // torsional friction about the normal (v^T W v is even in v: one quadratic form per body serves -n and n)
         float err = dot(delta_omega, n) * dt;
-        if (fabsf(err) > 0.0f) {
-            vec3 lin(0.0f);
-            float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-n), wq_b(n), relaxation, dt);
-            lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
-            ang_delta_a -= n * lt;
-            ang_delta_b += n * lt;
-        }
+        float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin0, lin0, W_a.quad(n), W_b.quad(n), relaxation, dt);
+        lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
+        if (!(mu_torsional > 0.0f && fabsf(err) > 0.0f)) lt = 0.0f;
+        ang_delta_a -= n * lt;
+        ang_delta_b += n * lt;
     }
-    if (mu_rolling > 0.0f) {
+    {  // rolling friction about the tangential relative spin
         delta_omega -= dot(n, delta_omega) * n;
-        float err = xlength(delta_omega) * dt;
-        if (err > 0.0f) {
-            vec3 lin(0.0f);
-            vec3 roll_n = xnormalize(delta_omega);
-            float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin, lin, wq_a(-roll_n), wq_b(roll_n), relaxation, dt);
-            lr = fmaxw(lr, -lambda_n * mu_rolling);
-            ang_delta_a -= roll_n * lr;
-            ang_delta_b += roll_n * lr;
-        }
+        const float len = xlength(delta_omega);
+        const float err = len * dt;
+        const vec3 roll_n = vsel(len > 0.0f, xdiv(delta_omega, len), vec3());  // xnormalize, as a select
+        float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin0, lin0, W_a.quad(roll_n), W_b.quad(roll_n), relaxation, dt);
+        lr = fmaxw(lr, -lambda_n * mu_rolling);
+        if (!(mu_rolling > 0.0f && err > 0.0f)) lr = 0.0f;
+        ang_delta_a -= roll_n * lr;
+        ang_delta_b += roll_n * lr;
     }
     return true;
 }

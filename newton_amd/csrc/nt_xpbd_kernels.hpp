@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
 template <int EPB, bool CVX, bool BIG = false, int THREADS = ((EPB & 255) <= 8 ? 256 : 512), int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
+    NT_TICK_START();
     Ctx<EPB> c(a, lds, -1, BIG);
     if constexpr (CVX || BIG) c.lds_records = false;  // (granted to analytic-only staged tiles alone: folds the LDS-record code away here)
     if constexpr (!BIG) {  // (the layout holds the snapshot rows, the pairs fit one pass and the integrate lanes fit behind them)

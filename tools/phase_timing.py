@@ -65,8 +65,7 @@ if FS:
 names = {0: "prologue (load + derived)", 1: "shapes/AABB || joint forces", 2: "pair evaluation (1 lane / pair)",
          3: "contact records || live prefix", 4: "integrate",
          5: "contacts", 6: "apply (contacts)", 7: "joints", 8: "apply (joints)", 9: "epilogue (count + store)"}
-buf[0] = 0  # (the first tick has no predecessor: the prologue figure is meaningless)
 tot = sum(buf[i] for i in range(10))
-for i in range(1, 10):
+for i in range(10):
     print(f"{names[i]:32s} {buf[i] / N:12.0f} cycles/launch  {100.0 * buf[i] / tot:5.1f} %")
 print(f"{'total':32s} {tot / N:12.0f} cycles/launch (s_memtime ticks of workgroup 0)")
