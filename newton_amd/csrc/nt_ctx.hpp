@@ -19,6 +19,8 @@ struct Ctx {
                 // (87.4 vs 100.8 M env-steps/s) -- twice the wave-instructions cost more than the second wave per SIMD hides
     int pose_in_off;  // rows of the poses the contact writer converts into (collide.py:166-204: the step's incoming poses): L.bq, or the
                       // snapshot L.xiq while integrate_bodies runs beside the pair phase of a fused rollout
+    bool lane_split;    // the XPBD body phases may run on linear / angular lanes (false in the convex kernels: they sit at the register
+                        // limit, and the second copy of the body phases costs them more in spills than the idle waves give back)
     bool gworld_ready;  // T.gworld holds the global shapes' world transforms / AABBs (stage_global_world ran, a barrier ago)
     bool lds_records;  // NT_TILE_LDS_RECORDS granted: the contact records of this launch live in L.cr
     bool hbm_out;      // the collide phases write the Contacts buffers in HBM (always, except the non-final substeps of an LDS-record rollout)
@@ -83,6 +85,7 @@ struct Ctx {
         T.gworld = reinterpret_cast<float*>(ti + o);
         o += 13 * m.ng;
         gworld_ready = false;
+        lane_split = true;
         T.joint_inc = ti + o;  // (filled by stage_joint_inc, one barrier after the tables above are published)
         o += 2 * m.nj;
         T.hit_count = ti + o;
@@ -103,7 +106,7 @@ struct Ctx {
     template <class OtherCtx>
     NT_DI explicit Ctx(const OtherCtx& o, int /*tag*/)
         : a(o.a), T(o.T), lds(o.lds), up(o.up), L(o.L), e(o.e), slot(o.slot), env(o.env), nslot(o.nslot), tslot(o.tslot),
-          pose_in_off(o.pose_in_off), gworld_ready(o.gworld_ready), lds_records(o.lds_records), hbm_out(o.hbm_out), big(o.big),
+          pose_in_off(o.pose_in_off), lane_split(o.lane_split), gworld_ready(o.gworld_ready), lds_records(o.lds_records), hbm_out(o.hbm_out), big(o.big),
           ES(o.ES), valid(o.valid) {}
     // LDS element (comp, s) of a slot-major field.  `n` (the slot count of the [comp][n] HBM twin) is not needed here; the
     // argument stays so that every access reads like its global-memory counterpart g(comp, n, s)

@@ -194,7 +194,7 @@ template <int EPB>
 NT_DI int body_lane_split(const Ctx<EPB>& c) {  // S0 if the linear lanes fit behind the angular ones, else 0 (one lane per body)
     const int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;
     const int S0 = ((c.a.m.nb + spw - 1) / spw) * spw;
-    return S0 + c.a.m.nb <= c.nslot ? S0 : 0;
+    return c.lane_split && S0 + c.a.m.nb <= c.nslot ? S0 : 0;
 }
 // integrate_bodies (solver.py:63-170) of SolverXPBD.  need_p: no apply phase follows in this step -- rebuild the body origin here
 // (both halves on one lane).
