@@ -59,6 +59,8 @@ __global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
     // the collide phases use the (dead at that point) P / H / contact-wrench union as their scratch
     Ctx<EPB> cc = c;
     place_collide_scratch(cc.L, m, F.cw, false);
+    stage_global_world(cc);  // (static shapes: transform + AABB once per launch; the first pair phase is a barrier away)
+    cc.gworld_ready = true;
     const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(cc, s == a.substeps - 1);
