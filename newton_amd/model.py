@@ -383,8 +383,61 @@ def choose_contact_scratch(lib, desc) -> None:
             desc.contact_scratch_in_hbm = 0  # does not fit either way: the launches report NT_ERR_UNSUPPORTED
 
 
+def newton_model_struct(model):
+    """nt_newton_model (include/newton_hip.h) over the flat arrays of a finalized Model -- the arguments of nt_model_create /
+    nt_model_refresh_params, i.e. exactly what a Newton host hands over -- plus the numpy buffers that must stay alive while the C
+    side reads them."""
+    keep = []
+
+    def i32(a):
+        x = np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+        keep.append(x)
+        return x.ctypes.data
+
+    def f32(a):
+        x = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+        keep.append(x)
+        return x.ctypes.data
+
+    m, s = model, _lib.nt_newton_model()
+    s.world_count = m.world_count
+    s.body_count, s.joint_count, s.shape_count = len(m.body_world), len(m.joint_world), len(m.shape_type)
+    s.joint_dof_count, s.joint_coord_count, s.joint_target_q_count = m.joint_dof_count, m.joint_coord_count, len(m.joint_target_q)
+    s.articulation_count = int(getattr(m, "articulation_count", 0))
+    pairs = np.asarray(m.shape_contact_pairs, dtype=np.int32).reshape(-1, 2)
+    s.shape_contact_pair_count = len(pairs)
+    pts = np.asarray(getattr(m, "mesh_points", np.zeros((0, 3))), dtype=np.float32).reshape(-1, 3)
+    s.mesh_point_count = len(pts)
+    g = np.asarray(m.gravity, dtype=np.float32).reshape(-1, 3)
+    s.gravity_count = len(g)
+    for k in ("body_world", "body_flags", "joint_world", "joint_type", "joint_parent", "joint_child", "joint_q_start",
+              "joint_qd_start", "joint_target_q_start", "joint_dof_dim", "shape_world", "shape_body", "shape_type", "shape_flags",
+              "shape_collision_group"):
+        setattr(s, k, i32(getattr(m, k)))
+    s.joint_enabled = i32(np.asarray(m.joint_enabled, dtype=np.int32))
+    if s.articulation_count:
+        s.articulation_start, s.articulation_end = i32(m.articulation_start), i32(m.articulation_end)
+    for k in ("body_com", "body_mass", "body_inv_mass", "body_inertia", "body_inv_inertia", "joint_X_p", "joint_X_c", "joint_axis",
+              "joint_limit_lower", "joint_limit_upper", "joint_target_ke", "joint_target_kd", "joint_limit_ke", "joint_limit_kd",
+              "joint_armature", "joint_damping", "shape_transform", "shape_scale", "shape_margin", "shape_gap", "shape_material_mu",
+              "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_ke", "shape_material_kd",
+              "shape_material_kf", "shape_material_ka", "shape_material_restitution"):
+        setattr(s, k, f32(getattr(m, k)))
+    s.shape_contact_pairs = i32(pairs)
+    if hasattr(m, "shape_mesh_start"):
+        s.shape_mesh_start, s.shape_mesh_count = i32(m.shape_mesh_start), i32(m.shape_mesh_count)
+    s.mesh_points, s.gravity = f32(pts), f32(g)
+    return s, keep
+
+
 class DeviceModel:
-    """Device-resident env-major SoA copy of a Model + the nt_model descriptor passed across the C ABI."""
+    """Device-resident env-major SoA copy of a Model + the nt_model descriptor passed across the C ABI.
+
+    The descriptor the kernels get is the one ``nt_model_create`` builds in C from the model's flat arrays
+    (csrc/nt_model_build.hip) -- the entry point a non-Python Newton host binds -- for every model whose pairs all live in the
+    environment tiles; models with SDF / hydroelastic / mesh-vertex pairs (routing the C builder does not do yet) keep the tables
+    built here in Python (`EnvTemplate`, `pack_param_arrays`), which tests/test_model_build.py holds equal to the C ones table by
+    table."""
 
     def __init__(self, model: Model):
         torch = _torch()
@@ -435,10 +488,41 @@ class DeviceModel:
         d.params_uniform = self._params_uniform
         choose_contact_scratch(self.lib, d)
         self.desc = d
+        self._c_handle = None
+        if self._c_builder_eligible(model):
+            # the C ABI's own builder: flat Newton arrays in, device descriptor out (the Python tables above stay as the host-side
+            # mirror: world slicing, the SDF legs and the tests read them)
+            src, keep = newton_model_struct(model)
+            h = C.c_void_p()
+            rc = self.lib.nt_model_create(C.byref(src), 1, C.byref(h))
+            if rc != 0:
+                raise _lib.NewtonHipError(f"nt_model_create: {self.lib.nt_model_last_error().decode()}")
+            self._c_handle = h
+            cd = _lib.nt_model()
+            C.memmove(C.byref(cd), self.lib.nt_model_get(h), C.sizeof(cd))
+            assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride) == \
+                (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride)
+            self.desc = cd
         # environments per workgroup the collide / XPBD / SemiImplicit kernels will use (0: the working set of one
         # environment does not fit the CU's LDS in either mode)
         self.envs_per_block = int(self.lib.nt_pick_envs_per_block(C.byref(d), 0))
         self.lds_bytes_per_env = int(self.lib.nt_lds_bytes_per_env(C.byref(d)))
+
+    USE_C_BUILDER = True  # (tests flip it to compare the two builders end to end)
+
+    def _c_builder_eligible(self, model) -> bool:
+        t = self.t
+        if len(getattr(t, "sdf_pair", ())) > 0 or not DeviceModel.USE_C_BUILDER:
+            return False
+        return bool(np.array_equal(np.asarray(t.tile_shape_type), np.asarray(t.shape_type)))  # (no triangle mesh shown to the tiles as a hull)
+
+    def __del__(self):
+        h, self._c_handle = getattr(self, "_c_handle", None), None
+        if h is not None and self.lib is not None:
+            try:
+                self.lib.nt_model_destroy(h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def require_fit(self, what: str):
         if self.envs_per_block == 0:
@@ -494,6 +578,12 @@ class DeviceModel:
                 self.params[k].copy_(torch.from_numpy(v).reshape(self.params[k].shape))
             else:
                 self.params[k] = torch.from_numpy(v).to(self.device)
+        if getattr(self, "_c_handle", None) is not None:  # Model.notify_model_changed(): the C-built tables follow
+            src, keep = newton_model_struct(model)
+            rc = self.lib.nt_model_refresh_params(self._c_handle, C.byref(src))
+            if rc != 0:
+                raise _lib.NewtonHipError(f"nt_model_refresh_params: {self.lib.nt_model_last_error().decode()}")
+            C.memmove(C.byref(self.desc), self.lib.nt_model_get(self._c_handle), C.sizeof(self.desc))
 
     def stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)

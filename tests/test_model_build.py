@@ -12,48 +12,10 @@ from newton_amd.model import pack_param_arrays, params_uniform
 
 
 def _newton_arrays(model):
-    """nt_newton_model over the flat arrays of a finalized Model (+ the numpy buffers that must stay alive)."""
-    keep = []
+    """nt_newton_model over the flat arrays of a finalized Model (the product's own marshalling: newton_amd.model.newton_model_struct)."""
+    from newton_amd.model import newton_model_struct
 
-    def i32(a, shape=None):
-        x = np.ascontiguousarray(np.asarray(a), dtype=np.int32)
-        keep.append(x)
-        return x.ctypes.data
-
-    def f32(a):
-        x = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
-        keep.append(x)
-        return x.ctypes.data
-
-    m, s = model, _lib.nt_newton_model()
-    s.world_count = m.world_count
-    s.body_count, s.joint_count, s.shape_count = len(m.body_world), len(m.joint_world), len(m.shape_type)
-    s.joint_dof_count, s.joint_coord_count, s.joint_target_q_count = m.joint_dof_count, m.joint_coord_count, len(m.joint_target_q)
-    s.articulation_count = int(getattr(m, "articulation_count", 0))
-    pairs = np.asarray(m.shape_contact_pairs, dtype=np.int32).reshape(-1, 2)
-    s.shape_contact_pair_count = len(pairs)
-    pts = np.asarray(getattr(m, "mesh_points", np.zeros((0, 3))), dtype=np.float32).reshape(-1, 3)
-    s.mesh_point_count = len(pts)
-    g = np.asarray(m.gravity, dtype=np.float32).reshape(-1, 3)
-    s.gravity_count = len(g)
-    for k in ("body_world", "body_flags", "joint_world", "joint_type", "joint_parent", "joint_child", "joint_q_start",
-              "joint_qd_start", "joint_target_q_start", "joint_dof_dim", "shape_world", "shape_body", "shape_type", "shape_flags",
-              "shape_collision_group"):
-        setattr(s, k, i32(getattr(m, k)))
-    s.joint_enabled = i32(np.asarray(m.joint_enabled, dtype=np.int32))
-    if s.articulation_count:
-        s.articulation_start, s.articulation_end = i32(m.articulation_start), i32(m.articulation_end)
-    for k in ("body_com", "body_mass", "body_inv_mass", "body_inertia", "body_inv_inertia", "joint_X_p", "joint_X_c", "joint_axis",
-              "joint_limit_lower", "joint_limit_upper", "joint_target_ke", "joint_target_kd", "joint_limit_ke", "joint_limit_kd",
-              "joint_armature", "joint_damping", "shape_transform", "shape_scale", "shape_margin", "shape_gap", "shape_material_mu",
-              "shape_material_mu_torsional", "shape_material_mu_rolling", "shape_material_ke", "shape_material_kd",
-              "shape_material_kf", "shape_material_ka", "shape_material_restitution"):
-        setattr(s, k, f32(getattr(m, k)))
-    s.shape_contact_pairs = i32(pairs)
-    if hasattr(m, "shape_mesh_start"):
-        s.shape_mesh_start, s.shape_mesh_count = i32(m.shape_mesh_start), i32(m.shape_mesh_count)
-    s.mesh_points, s.gravity = f32(pts), f32(g)
-    return s, keep
+    return newton_model_struct(model)
 
 
 def _arr(ptr, n, ctype=C.c_int32):

@@ -68,6 +68,8 @@ def build_id():
 
 
 def main():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, "r05_pmc_traffic.json")
     res = json.load(open(path)) if os.path.exists(path) else {}
