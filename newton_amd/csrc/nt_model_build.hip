@@ -452,6 +452,26 @@ nt_status nt_model_refresh_params(nt_model_handle* h, const nt_newton_model* src
         update(d.body_param, P.body); update(d.gravity, P.gravity); update(d.joint_param, P.joint); update(d.dof_param, P.dof);
         update(d.shape_param, P.shape); update(d.gshape_param, P.gshape);
         d.params_uniform = P.uniform;
+        // the env-uniform FLAG tables a runtime edit may touch (Model.notify_model_changed: body_flags, joint_enabled, shape_flags,
+        // shape_collision_group); edits that break their uniformity across worlds answer NT_ERR_UNSUPPORTED like nt_model_create
+        const int E = d.env_count;
+        auto update_i = [&](const int32_t* dst, const std::vector<int32_t>& v) {
+            if (v.empty()) return;
+            if (h->on_device) {
+                if (hipMemcpy((void*)dst, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) throw Fail{NT_ERR_LAUNCH, "hipMemcpy failed"};
+            } else {
+                memcpy((void*)dst, v.data(), v.size() * 4);
+            }
+        };
+        auto shape_table = [&](const int32_t* a, const char* what) {
+            std::vector<int32_t> t = d.ns ? uniform_table(a + d.shape_local0, E, d.ns, 0, false, what) : std::vector<int32_t>();
+            for (int g : gshape_id) t.push_back(a[g]);
+            return t;
+        };
+        if (src->body_flags) update_i(d.body_flags, uniform_table(src->body_flags, E, d.nb, 0, false, "body_flags"));
+        if (src->joint_enabled && d.nj) update_i(d.joint_enabled, uniform_table(src->joint_enabled, E, d.nj, 0, false, "joint_enabled"));
+        if (src->shape_flags) update_i(d.shape_flags, shape_table(src->shape_flags, "shape_flags"));
+        if (src->shape_collision_group) update_i(d.shape_group, shape_table(src->shape_collision_group, "shape_collision_group"));
     });
 }
 

@@ -895,8 +895,12 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
         const quat qbc = c.body_rot(id_c);
         xform X_wc(world_com_c + quat_rotate(qbc, X_cj.p - c.com(id_c)), qbc * X_cj.q);
         vec3 vel_c = c.body_v(id_c), omega_c = c.body_w(id_c);
-        auto wq_p = [&](vec3 v) { return id_p >= 0 ? c.w_quad(id_p, v) : 0.0f; };
-        auto wq_c = [&](vec3 v) { return c.w_quad(id_c, v); };
+        // (the two W tiles once, not six floats per row and body: a world-attached parent gets the zero tile)
+        typename Ctx<EPB>::Wsym W_p = c.w_tile(id_p >= 0 ? id_p : 0);
+        const typename Ctx<EPB>::Wsym W_c = c.w_tile(id_c);
+        if (id_p < 0) W_p = typename Ctx<EPB>::Wsym{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        auto wq_p = [&](vec3 v) { return W_p.quad(v); };
+        auto wq_c = [&](vec3 v) { return W_c.quad(v); };
 
         xform rel_pose = xform_inverse(X_wp) * X_wc;
         vec3 rel_p = rel_pose.p;
@@ -1021,6 +1025,9 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
         int axis_start = c.T.joint_qd_start[j];
         int target_axis_start = c.T.joint_tq_start[j];
         int lin_count = c.T.joint_lin_count[j], ang_count = c.T.joint_ang_count[j];
+        typename Ctx<EPB>::Wsym W_p = c.w_tile(id_p >= 0 ? id_p : 0);  // (once, not per row)
+        const typename Ctx<EPB>::Wsym W_c = c.w_tile(id_c);
+        if (id_p < 0) W_p = typename Ctx<EPB>::Wsym{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
         if (dot(q_p, q_c) < 0.0f) q_c = q_c * -1.0f;
         quat rel_q = quat_inverse(q_p) * q_c;
@@ -1069,8 +1076,7 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
                 if (st > 0.0f) { err = e - target_pos; compliance = xrcp(st); damping = dm; }
                 else if (dm > 0.0f) { damping = dm; compliance = xrcp(dm); }
             }
-            float wqp = id_p >= 0 ? c.w_quad(id_p, angular_p) : 0.0f;
-            float d_lambda = angular_correction(err, derr_rel, wqp, c.w_quad(id_c, angular_c), 0.0f, compliance, damping, dt) *
+            float d_lambda = angular_correction(err, derr_rel, W_p.quad(angular_p), W_c.quad(angular_c), 0.0f, compliance, damping, dt) *
                              P.joint_angular_relaxation;
             vec3 t = angular_c * d_lambda;
             if (dim == 0) t0 = t;

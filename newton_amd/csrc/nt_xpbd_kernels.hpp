@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     NT_TICK_START();
     Ctx<EPB> c(a, lds, -1, BIG);
     if constexpr (CVX || BIG) c.lds_records = false;  // (granted to analytic-only staged tiles alone: folds the LDS-record code away here)
-    if constexpr (CVX || Ctx<EPB>::N >= 32) c.lane_split = false;  // (32-environment tiles have no idle waves to split onto)
+    c.lane_split = !(CVX || Ctx<EPB>::N >= 32);  // (a compile-time fact per kernel; 32-environment tiles have no idle waves to split onto)
     if constexpr (!BIG) {  // (the layout holds the snapshot rows, the pairs fit one pass and the integrate lanes fit behind them)
         constexpr int spw = 64 / Ctx<EPB>::N > 0 ? 64 / Ctx<EPB>::N : 1;
         if ((a.tile_opts & NT_TILE_POSE_SNAPSHOT) && a.m.np <= a.nslot && ((a.m.np + spw - 1) / spw) * spw + a.m.nb <= a.nslot)

@@ -494,7 +494,8 @@ class DeviceModel:
             # mirror: world slicing, the SDF legs and the tests read them)
             src, keep = newton_model_struct(model)
             h = C.c_void_p()
-            rc = self.lib.nt_model_create(C.byref(src), 1, C.byref(h))
+            with torch.cuda.device(self.device):  # (the handle's tables are allocated on the calling thread's current HIP device)
+                rc = self.lib.nt_model_create(C.byref(src), 1, C.byref(h))
             if rc != 0:
                 raise _lib.NewtonHipError(f"nt_model_create: {self.lib.nt_model_last_error().decode()}")
             self._c_handle = h
@@ -580,7 +581,8 @@ class DeviceModel:
                 self.params[k] = torch.from_numpy(v).to(self.device)
         if getattr(self, "_c_handle", None) is not None:  # Model.notify_model_changed(): the C-built tables follow
             src, keep = newton_model_struct(model)
-            rc = self.lib.nt_model_refresh_params(self._c_handle, C.byref(src))
+            with torch.cuda.device(self.device):
+                rc = self.lib.nt_model_refresh_params(self._c_handle, C.byref(src))
             if rc != 0:
                 raise _lib.NewtonHipError(f"nt_model_refresh_params: {self.lib.nt_model_last_error().decode()}")
             C.memmove(C.byref(self.desc), self.lib.nt_model_get(self._c_handle), C.sizeof(self.desc))

@@ -91,6 +91,20 @@ torch.cuda.current_stream = lambda device=None: _Stream()
 torch.cuda.synchronize = lambda device=None: None
 torch.cuda.set_device = lambda device: None
 
+
+class _DeviceCtx:  # `with torch.cuda.device(d):` -- one (emulated) device, nothing to switch
+    def __init__(self, device=None):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+torch.cuda.device = _DeviceCtx
+
 import newton_amd.model as _model  # noqa: E402
 
 _real_dm_init = _model.DeviceModel.__init__

@@ -85,6 +85,19 @@ def test_c_helper_reproduces_the_python_descriptor(name):
             packed = pack_param_arrays(model, t)
             got = _arr(d.body_param, packed["body_param"].size, C.c_float)
             assert np.array_equal(got, packed["body_param"].reshape(-1)) and d.params_uniform == 0
+        # ... and the env-uniform flag tables follow a runtime edit too (joint_enabled / body_flags / shape_flags / collision groups)
+        if t.nj:
+            model.joint_enabled = np.array(model.joint_enabled, copy=True)
+            model.joint_enabled[t.nj - 1::t.nj] = False  # the last joint of every world
+            src3, keep3 = _newton_arrays(model)
+            assert lib.nt_model_refresh_params(h, C.byref(src3)) == 0
+            want = np.ones(t.nj, dtype=np.int32)
+            want[:] = np.asarray(model.joint_enabled, dtype=np.int32)[: t.nj]
+            assert np.array_equal(_arr(d.joint_enabled, t.nj), want) and want[-1] == 0
+            model.joint_enabled[t.nj - 1] = True  # one world differs: refused with a reason
+            src4, keep4 = _newton_arrays(model)
+            if t.env_count > 1:
+                assert lib.nt_model_refresh_params(h, C.byref(src4)) != 0 and b"joint_enabled" in lib.nt_model_last_error()
     finally:
         lib.nt_model_destroy(h)
 
