@@ -247,6 +247,42 @@ def test_featherstone_step_and_rollout(H, n_env, epb):
     assert np.array_equal(out.joint_q, a.joint_q) and np.array_equal(out.body_q, a.body_q)
 
 
+@pytest.mark.parametrize("lowered,substeps,tol", [(False, 60, 2e-6), (True, 10, 2e-4)])
+def test_featherstone_tree_and_dense_orders_stay_together_over_a_rollout(H, lowered, substeps, tol):
+    """SolverFeatherstone defaults to the tree-structured mass matrix (composite inertias + leaf-first L^T D L), which
+    is within the single-step contract of the reference's dense order but not bit-identical to it.  Bound the drift where it could
+    accumulate -- open-loop rollouts of both orders from the same state: 60 substeps of quadrupeds swinging their legs in the air
+    (smooth dynamics: the two factorisations must stay within a few ulps of accumulated rounding), and 10 substeps with the feet in
+    the ground (the explicit penalty contacts amplify ANY rounding difference 3-10x per substep -- DESIGN.md section 4 -- so the
+    bound there is the one the dense order itself keeps against the checker)."""
+    from oracle_bridge import Oracle, OracleState
+    from scenes import quadruped_scene
+
+    model = quadruped_scene(4)
+    if lowered:
+        _lower(model, 0.25)
+    rng = np.random.default_rng(5)
+    model.joint_qd = (model.joint_qd + rng.normal(0, 0.2, size=model.joint_qd.shape)).astype(np.float32)
+    em = H.EmuModel(model)
+    res = {}
+    for dense in (False, True):
+        ctrl, ct = H.EmuControl(em), H.EmuContacts(em)
+        out = H.featherstone_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1e-3, substeps, dense=dense)
+        res[dense] = (out.aos("joint_q").copy(), int(ct.env_count.sum()))
+    assert (res[False][1] > 0) == lowered and (res[True][1] > 0) == lowered
+    d_orders = float(np.max(np.abs(res[False][0] - res[True][0])))
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    for _ in range(substeps):
+        o.collide(os0.body_q, oc)
+        o.featherstone_step(os0, os1, o.control(), oc, 1e-3)
+        os0, os1 = os1, os0
+    d_tree = float(np.max(np.abs(res[False][0] - os0.joint_q)))
+    d_dense = float(np.max(np.abs(res[True][0] - os0.joint_q)))
+    print(f"[featherstone orders] lowered={lowered} substeps={substeps}: tree-dense {d_orders:.2e}, tree-checker {d_tree:.2e}, dense-checker {d_dense:.2e}")
+    assert d_orders <= tol and d_tree <= tol and d_dense <= tol, (d_orders, d_tree, d_dense)
+
+
 def test_featherstone_kinematic_root_and_zoo(H):
     from oracle_bridge import Oracle, OracleState
     from scenes import joint_zoo_scene
