@@ -448,6 +448,10 @@ typedef struct {
                                            edges.  Lets the kernel skip a (pair, mode) whose edge carrier's local AABB, seen from the
                                            SDF shape, lies beyond the cull threshold of its longest edge -- no edge could pass
                                            edge culling (sdf_contact.py:1318-1340), so the result is unchanged */
+    int32_t keep_all;                /* 1 = no reduction (CollisionPipeline(reduce_contacts=False), narrow_phase.py:3044,3097-3130 launching
+                                        mesh_sdf_collision_kernel): every contact the edge search admits -- nt_mesh_sdf_collide's set --
+                                        as one block per pair, ascending fingerprint, the search's own normal.  Staged variant with
+                                        out_blk only (NT_ERR_UNSUPPORTED otherwise) */
 } nt_contact_reduce_shapes;
 nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* args, const nt_contact_reduce_shapes* shapes, void* stream);
 

@@ -155,7 +155,7 @@ class nt_mesh_sdf_args(C.Structure):
 
 class nt_contact_reduce_shapes(C.Structure):
     _fields_ = [("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
-                ("threads", C.c_int32), ("shape_edge_radius_max", C.c_void_p)]
+                ("threads", C.c_int32), ("shape_edge_radius_max", C.c_void_p), ("keep_all", C.c_int32)]
 
 
 class nt_contact_reduce_list(C.Structure):

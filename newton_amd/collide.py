@@ -456,15 +456,14 @@ class CollisionPipeline:
         # shape pairs with texture SDFs + collision edges on both sides: the mesh-SDF leg (narrow_phase.py:620-640, 2838-3167)
         self._sdf_leg = None
         if model_has_sdf_pairs(model):
-            only_vertex_pairs = bool(np.all(getattr(model.env, "sdf_pair_mesh_plane", False)))
-            if not reduce_contacts and not only_vertex_pairs:
-                raise NotImplementedError("SDF contact pairs need reduce_contacts=True (the unreduced kernel is offered stand-alone: "
-                                          "newton_amd.sdf_device.mesh_sdf_collide)")
             sdf_pair_shape_types_ok(model)
             self._sdf_leg = SdfLeg(model, pairs_per_shape=sdf_pairs_per_shape, contacts_per_shape=sdf_contacts_per_shape,
                                    hydro_config=sdf_hydroelastic_config, hydro_faces_per_shape=sdf_hydro_faces_per_shape,
                                    hydro_staged=sdf_hydro_staged)
             self._sdf_leg.mesh_plane_reduce = bool(reduce_contacts)  # (triangle mesh, plane) pairs: every admitted vertex when off
+            # edge pairs: every contact the edge search admits when off (narrow_phase.py:3044,3097-3130 launches mesh_sdf_collision_kernel
+            # instead of the global-reduce kernel); size sdf_contacts_per_shape for it, an overflow is reported by the leg
+            self._sdf_leg.edge_reduce = bool(reduce_contacts)
             if contact_matching != "disabled" and self._sdf_leg.has_hydro_pairs:
                 # the reference matcher does not cover hydroelastic contacts either (contact_match.py:497-501)
                 raise NotImplementedError("contact_matching is not supported for hydroelastic contact pairs")

@@ -964,6 +964,61 @@ __global__ void __launch_bounds__(256) sdf_reduce_kernel(nt_mesh_sdf_args a, nt_
     }
 }
 
+// nt_contact_reduce_shapes.keep_all: the last stage of reduce_contacts=False (mesh_sdf_collision_kernel's contact set,
+// sdf_contact.py:1098-1515: every edge the search admits) -- one wave per runnable pair walks the pair's survivor block and writes
+// the admitted records as rows from the START of the block, ascending fingerprint (the two modes' lists are each ascending in the
+// edge, so a row's place is its rank in its own list plus the admitted entries of the other list below its fingerprint).  The
+// normal is the search's own (the octahedral round trip belongs to the reducer's export).
+__global__ void __launch_bounds__(64) sdf_keep_all_kernel(nt_mesh_sdf_args a) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int units = a.hit_count[CNT_UNITS];
+    for (int f = blockIdx.x; f < units; f += gridDim.x) {
+        const int pair_idx = reinterpret_cast<const int*>(a.unit_ctx + UNIT_WORDS * 2 * (size_t)f)[21];
+        const int* blk = a.hit_blk + 4 * (size_t)pair_idx;
+        const int off0 = blk[0], cnt0 = blk[1], off1 = blk[2], cnt1 = blk[3];
+        if (cnt0 + cnt1 == 0) continue;  // uniform; out_blk is already zero
+        const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
+        const float m0 = a.shape_data[4 * s0 + 3], m1 = a.shape_data[4 * s1 + 3];
+        int total = 0;
+        for (int mode = 0; mode < 2; ++mode) {
+            const int off = mode == 0 ? off0 : off1, cnt = mode == 0 ? cnt0 : cnt1;
+            const int ooff = mode == 0 ? off1 : off0, ocnt = mode == 0 ? cnt1 : cnt0;
+            int run = 0;
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                const int j = j0 + lane;
+                const int fp = j < cnt ? a.hit_fp[off + j] : -1;
+                const unsigned long long m = __ballot(fp >= 0);
+                if (fp >= 0) {
+                    int less = 0;
+                    for (int k = 0; k < ocnt; ++k) {
+                        const int fo = a.hit_fp[ooff + k];
+                        less += (fo >= 0 && fo < fp) ? 1 : 0;
+                    }
+                    const int slot = off0 + run + __popcll(m & below) + less;
+                    if (slot < a.capacity) {
+                        const float* rec = a.hit_rec + 8 * (size_t)(off + j);
+                        a.out_pair[slot] = pair_idx;
+                        a.out_key[slot] = fp;
+                        float* o = a.out_data + 9 * (size_t)slot;
+                        o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2];
+                        o[3] = rec[4]; o[4] = rec[5]; o[5] = rec[6];
+                        o[6] = rec[3];
+                        o[7] = m0;
+                        o[8] = m1;
+                    }
+                }
+                run += __popcll(m);
+            }
+            total += run;
+        }
+        if (lane == 0) {
+            a.out_blk[2 * (size_t)pair_idx] = off0;
+            a.out_blk[2 * (size_t)pair_idx + 1] = total;
+        }
+    }
+}
+
 // The same reduction over a caller-supplied unreduced list grouped by shape pair (segment_start): the stage on its own, so that
 // it can be held against the record of the reference's reducer on arbitrary contact sets.
 __global__ void __launch_bounds__(256) contacts_reduce_list_kernel(nt_contact_reduce_list a) {
@@ -2773,6 +2828,7 @@ nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* a, const nt_contac
             return NT_ERR_INVALID_ARG;
         // with out_blk the rows live in the survivor list's index space: the row arrays must span it
         if (a->out_blk && a->capacity < a->hit_capacity) return NT_ERR_INVALID_ARG;
+        if (r->keep_all && !a->out_blk) return NT_ERR_UNSUPPORTED;
         nt_mesh_sdf_args k = *a;
         // grid-stride kernels: the grids only bound the parallelism (tests/emu runs every lane as an OS thread and caps them)
 #ifdef NT_EMULATED_GRID
@@ -2798,9 +2854,11 @@ nt_status nt_mesh_sdf_collide_reduced(const nt_mesh_sdf_args* a, const nt_contac
         hipLaunchKernelGGL(sdf_units_kernel, dim3(grid(pairs, 256)), dim3(256), 0, st, k, *r);
         hipLaunchKernelGGL(sdf_cull_kernel, dim3(grid(pairs, 4)), dim3(256), 0, st, k);  // one wave per runnable pair
         hipLaunchKernelGGL(sdf_resolve_kernel, dim3(grid(k.hit_capacity / k.hit_stripe_count, 256) * k.hit_stripe_count), dim3(256), 0, st, k);
-        hipLaunchKernelGGL(sdf_reduce_kernel, dim3(blocks), dim3(64), 0, st, k, *r);
+        if (r->keep_all) hipLaunchKernelGGL(sdf_keep_all_kernel, dim3(blocks), dim3(64), 0, st, k);
+        else hipLaunchKernelGGL(sdf_reduce_kernel, dim3(blocks), dim3(64), 0, st, k, *r);
         return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
     }
+    if (r->keep_all) return NT_ERR_UNSUPPORTED;  // every contact: the staged variant with out_blk only
     hipLaunchKernelGGL(mesh_sdf_collide_reduced_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, *a, *r);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }

@@ -137,6 +137,7 @@ class SdfLeg:
         self.has_mesh_plane_pairs = bool((kind == 2).any())
         self.has_edge_pairs = bool((kind == 0).any())
         self.mesh_plane_reduce = True  # CollisionPipeline(reduce_contacts=...): set by the pipeline
+        self.edge_reduce = True  # ... and the edge leg: False = every contact the edge search admits (keep_all), staged variant
         self.hydro_reduce, self.face_capacity, self.hydro_staged = 0, 0, False
         self._template_kind = up(kind, np.uint8)
         self.world_pair_kind = torch.zeros(E * PPW, dtype=torch.uint8, device=dev)
@@ -250,6 +251,10 @@ class SdfLeg:
         r = _lib.nt_contact_reduce_shapes()
         r.shape_aabb_lower, r.shape_aabb_upper, r.shape_voxel_res = self._red_lo.data_ptr(), self._red_hi.data_ptr(), self._red_res.data_ptr()
         r.threads, r.shape_edge_radius_max = self.threads, self._edge_rmax.data_ptr()
+        if not self.edge_reduce:
+            if not self.staged:
+                raise NotImplementedError("reduce_contacts=False with mesh-SDF pairs runs the staged narrow phase (NT_SDF_STAGED=0 is set)")
+            r.keep_all = 1
         if self.has_hydro_pairs or self.has_mesh_plane_pairs:
             a.pair_kind = self.world_pair_kind.data_ptr()
         if self.staged:

@@ -54,13 +54,15 @@ def sdf_scene(world_count, n_hulls=5, device=None, seed=5, sdf_resolution=16, wa
     return model
 
 
-def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None, worlds=None):
+def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None, worlds=None, reduce=True):
     """-> (rows dict in product order incl. `world`, `key`; candidate pairs per world [list of (a, b)]; the checker's world
     transforms and AABBs).  `world_xform` / `aabbs`: use the device's own exported arrays instead (the caller holds them against
     the checker's separately) -- the centred-difference SDF gradient amplifies a last-bit difference of a shape transform to
     1e-5 in the normal, which would blur the comparison of everything downstream.
     `kinds` (bool per template SDF pair, True = hydroelastic): those pairs are listed in the candidates -- which then hold
-    ((shape0, shape1), kind) tuples -- but produce no edge-contact rows here (oracle_hydro.hydro_pipeline covers them)."""
+    ((shape0, shape1), kind) tuples -- but produce no edge-contact rows here (oracle_hydro.hydro_pipeline covers them).
+    `reduce=False`: CollisionPipeline(reduce_contacts=False) -- every contact of mesh_sdf_collision_kernel, per pair in ascending
+    fingerprint (the order Newton's deterministic sort gives them), the kernel's own normal."""
     t = model.env
     o = Oracle(model)
     oc = o.contacts()
@@ -106,8 +108,15 @@ def checker_rows(model, body_q, world_xform=None, aabbs=None, kinds=None, worlds
         rows = O.mesh_sdf_collide(pr, X, data, gap, idx, sdfs, er, ec, eh)
         if not rows:
             continue
-        c = R.reduce_inputs_from_mesh_sdf_contacts(rows, pr, X, data, gap, idx, sdfs, alo, ahi, res)
-        red = R.reduce_contacts(c)
+        if not reduce:
+            rows = sorted(rows, key=lambda r: (int(r[0]), int(r[1])))
+            pi = np.asarray([int(r[0]) for r in rows])
+            red = dict(fp=np.asarray([int(r[1]) for r in rows], np.int32), pair=pr[pi], pos=np.asarray([r[2] for r in rows], np.float32),
+                       normal=np.asarray([r[3] for r in rows], np.float32), depth=np.asarray([r[4] for r in rows], np.float32),
+                       index=None)
+        else:
+            c = R.reduce_inputs_from_mesh_sdf_contacts(rows, pr, X, data, gap, idx, sdfs, alo, ahi, res)
+            red = R.reduce_contacts(c)
         k = red["index"]
         raw = dict(key=red["fp"], shape_a=red["pair"][:, 0], shape_b=red["pair"][:, 1], center=red["pos"], normal=red["normal"],
                    distance=red["depth"], margin_a=data[red["pair"][:, 0], 3], margin_b=data[red["pair"][:, 1], 3])

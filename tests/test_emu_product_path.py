@@ -34,3 +34,12 @@ def test_mesh_on_ground_pipeline_dry_run(oracle_lib):
                         "-k", "rows_of_meshes or matching"], cwd=TESTS, env=ENV, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "4 passed" in r.stdout
+
+
+def test_unreduced_sdf_rows_dry_run(oracle_lib):
+    """CollisionPipeline(reduce_contacts=False) with mesh-SDF pairs (the keep-all last stage of the staged narrow phase) on the
+    emulated library against the checker's unreduced contacts: tests/test_gpu_sdf_pipeline.py's test, unchanged."""
+    r = subprocess.run([sys.executable, "-m", "pytest", "-p", "emu_plugin", "-m", "gpu", "-q", "-x", "test_gpu_sdf_pipeline.py",
+                        "-k", "unreduced"], cwd=TESTS, env=ENV, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout

@@ -134,6 +134,67 @@ def test_staged_narrow_phase_gives_the_rows_of_the_single_kernel(monkeypatch):
         assert np.array_equal(rows["1"][k], rows["0"][k]), k
 
 
+def test_unreduced_rows_are_every_contact_of_the_edge_search():
+    """CollisionPipeline(reduce_contacts=False) with mesh-SDF pairs (narrow_phase.py:3044,3097-3130: mesh_sdf_collision_kernel
+    writes every contact): the rows are the checker's unreduced contacts -- ids and fingerprints exact, in ascending fingerprint
+    per pair, the search's own normal -- the reduced rows are a subset of them with the same geometry up to the reducer's
+    octahedral normal, a second call is bitwise identical, and the matcher takes the rows."""
+    import newton_amd as nt
+    from sdf_pipeline_checker import checker_rows, sdf_scene
+
+    E = 3
+    model = sdf_scene(E, 6, device="cuda:0", walls=True, seed=9)
+    _pile(model)
+    state = model.state()
+    pipe = nt.CollisionPipeline(model, broad_phase="sap", reduce_contacts=False, sdf_contacts_per_shape=240,
+                                contact_matching="latest")
+    contacts = pipe.contacts()
+    pipe.collide(state, contacts)
+    got = _rows(contacts)
+    ov = pipe._sdf_leg.overflow(contacts._flat)
+    assert not ov["overflow"], ov
+    leg = pipe._sdf_leg
+    X, lo, hi = leg.world_xform.cpu().numpy(), leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    want, _, _ = checker_rows(model, state.body_q.cpu().numpy(), world_xform=X, aabbs=(lo, hi), reduce=False)
+    assert len(want["key"]) == len(got["key"]) > 0
+    assert np.array_equal(got["row_start"], np.concatenate([[0], np.cumsum(np.bincount(want["world"], minlength=E))]))
+    assert np.array_equal(got["key"], want["key"])
+    for k in ("shape0", "shape1"):
+        assert np.array_equal(got[k], want[k]), k
+    for k in FIELDS[2:]:
+        assert np.abs(got[k] - want[k]).max() <= 2e-6, (k, np.abs(got[k] - want[k]).max())
+    # both modes are present and interleave in the fingerprint order of at least one pair
+    assert ((got["key"] >> 1) & 1).min() == 0 and ((got["key"] >> 1) & 1).max() == 1
+    # the reduced pipeline keeps a subset: same (pair, fingerprint), same points; fewer rows where a pair has many contacts
+    red_pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    rc = red_pipe.contacts()
+    red_pipe.collide(state, rc)
+    red = _rows(rc)
+    assert 0 < len(red["key"]) <= len(got["key"])
+    at = {(int(a), int(b), int(k)): i for i, (a, b, k) in enumerate(zip(got["shape0"], got["shape1"], got["key"]))}
+    assert len(at) == len(got["key"])  # a fingerprint once per pair
+    idx = np.asarray([at[(int(a), int(b), int(k))] for a, b, k in zip(red["shape0"], red["shape1"], red["key"])])
+    for k in ("point0", "point1"):
+        assert np.abs(got[k][idx] - red[k]).max() <= 1e-3, k  # (the points shift with the normal's octahedral round trip)
+    assert np.einsum("ij,ij->i", got["normal"][idx], red["normal"]).min() > 0.9999
+    # run to run
+    pipe2 = nt.CollisionPipeline(model, broad_phase="sap", reduce_contacts=False, sdf_contacts_per_shape=240)
+    again = pipe2.contacts()
+    pipe2.collide(state, again)
+    second = _rows(again)
+    for k in got:
+        assert np.array_equal(got[k], second[k]), k
+    # the matcher over unreduced rows: an unchanged second frame matches every live row to itself
+    pipe.collide(state, contacts)
+    f = contacts._flat
+    n = int(f.row_start[-1].item())
+    live = (f.shape0[:n] != f.shape1[:n]).cpu().numpy()
+    mi = contacts.rigid_contact_match_index.cpu().numpy()
+    n_slots = int(contacts.rigid_contact_count_per_env.sum().item())
+    row_mi = mi[n_slots:n_slots + int(live.sum())]
+    assert (row_mi != -1).all() and (row_mi >= 0).mean() > 0.95  # (coincident twins of two edges may lose their claim: -2)
+
+
 def test_survivor_list_overflow_is_reported_and_harmless():
     """A survivor list that is too small drops survivors without touching anything outside its stripes: the call reports it
     (`dropped_survivors`, `overflow`), the rows that remain are well-formed, and a second pipeline with the default
