@@ -791,12 +791,23 @@ typedef struct {
     const int32_t* shape_mesh_count;   /* [shape_count] or NULL */
     const float* mesh_points;          /* [mesh_point_count][3] unscaled hull vertices of the shared Mesh assets */
     const float* gravity;              /* [gravity_count][3]: one row per world, the last one for the global world (model.py:1300-1304) */
+    /* pair routing out of the tiles (narrow_phase.py:531-538,618-640); NULL = no shape has a texture SDF / collision edges */
+    const int32_t* shape_sdf_index;    /* [shape_count] Model._shape_sdf_index: index into the texture-SDF table or -1 */
+    const int32_t* shape_edge_range;   /* [shape_count][2] Model.shape_edge_range: (first, count) of the shape's collision edges */
 } nt_newton_model;
 typedef struct nt_model_handle nt_model_handle;
 nt_status nt_model_create(const nt_newton_model* src, int32_t on_device, nt_model_handle** out);
 const nt_model* nt_model_get(const nt_model_handle* h);
-/* position of every device pair in one world's slice of Model.shape_contact_pairs ([np] int64; analytic pairs come first) */
+/* position of every device (tile) pair in one world's slice of Model.shape_contact_pairs ([np] int64; analytic pairs come first) */
 nt_status nt_model_pair_order(const nt_model_handle* h, int64_t* out);
+/* The pairs of one world that leave the tiles, for the pipeline's SDF leg (nt_sdf_scene.template_pair / template_kind): *count of
+ * them, and -- where the pointers are not NULL -- pairs [count][2] as template shape ids (env-local shape < ns, else ns + rank in
+ * nt_model.gshape_id; ordered by ascending Newton (shape0, shape1), shape0 first), kind [count] (0 = both shapes carry a texture SDF
+ * and collision edges, not box-box: mesh-SDF edge contacts; 1 = both shapes hydroelastic with SDFs: the SDF-SDF leg when the
+ * pipeline enables it; 2 = (triangle mesh, infinite plane): vertex leg) and has_edges [count] (both shapes carry SDF + edges: what
+ * a kind-1 pair falls back to without a hydroelastic configuration).  A MESH shape appears to the tiles as a CONVEX_MESH over its
+ * vertex bounds (AABB only); MESH pairs that are none of the above return NT_ERR_UNSUPPORTED from nt_model_create. */
+nt_status nt_model_sdf_pairs(const nt_model_handle* h, int32_t* count, int32_t* pairs, uint8_t* kind, uint8_t* has_edges);
 /* Model.notify_model_changed(): re-pack the parameter tables (same topology) and refresh params_uniform */
 nt_status nt_model_refresh_params(nt_model_handle* h, const nt_newton_model* src);
 void nt_model_destroy(nt_model_handle* h);

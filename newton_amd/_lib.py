@@ -284,6 +284,8 @@ class nt_newton_model(C.Structure):
         ("shape_mesh_count", _P),
         ("mesh_points", _P),
         ("gravity", _P),
+        ("shape_sdf_index", _P),
+        ("shape_edge_range", _P),
     ]
 
 
@@ -291,6 +293,7 @@ SYMBOLS = {
     "nt_model_create": (C.c_int32, [C.POINTER(nt_newton_model), C.c_int32, C.POINTER(_P)]),
     "nt_model_get": (C.POINTER(nt_model), [_P]),
     "nt_model_pair_order": (C.c_int32, [_P, C.POINTER(C.c_int64)]),
+    "nt_model_sdf_pairs": (C.c_int32, [_P, C.POINTER(C.c_int32), _P, _P, _P]),
     "nt_model_refresh_params": (C.c_int32, [_P, C.POINTER(nt_newton_model)]),
     "nt_model_destroy": (None, [_P]),
     "nt_model_last_error": (C.c_char_p, []),

@@ -29,7 +29,8 @@ struct Fail {
 [[noreturn]] void unsupported(const std::string& w) { throw Fail{NT_ERR_UNSUPPORTED, w}; }
 [[noreturn]] void invalid(const std::string& w) { throw Fail{NT_ERR_INVALID_ARG, w}; }
 
-enum { GEO_PLANE = 1, GEO_SPHERE = 3, GEO_CAPSULE = 4, GEO_ELLIPSOID = 5, GEO_CYLINDER = 6, GEO_BOX = 7, GEO_CONE = 9, GEO_CONVEX_MESH = 10 };
+enum { GEO_PLANE = 1, GEO_SPHERE = 3, GEO_CAPSULE = 4, GEO_ELLIPSOID = 5, GEO_CYLINDER = 6, GEO_BOX = 7, GEO_MESH = 8, GEO_CONE = 9, GEO_CONVEX_MESH = 10 };
+constexpr int SHAPE_HYDROELASTIC = 1 << 4;  // ShapeFlags.HYDROELASTIC
 constexpr int BODY_KINEMATIC = 2;
 
 bool analytic_pair(int ta, int tb) {  // narrow_phase.py:642-655: pairs with a closed-form primitive routine
@@ -53,6 +54,8 @@ struct nt_model_handle {
     std::vector<std::vector<float>> ftab;
     std::vector<void*> dev;
     std::vector<int64_t> pair_order;
+    std::vector<int32_t> sdf_pairs;  // pairs that leave the tiles: [n][2] template shape ids
+    std::vector<uint8_t> sdf_kind, sdf_has_edges;
 
     const int32_t* put(const std::vector<int32_t>& v) {
         itab.push_back(v.empty() ? std::vector<int32_t>(1, 0) : v);
@@ -274,8 +277,17 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
     std::vector<int32_t> shape_body = shape_table(s.shape_body, nb, true, "shape_body");
     std::vector<int32_t> shape_type = shape_table(s.shape_type, 0, false, "shape_type");
     d.shape_body = h.put(shape_body);
-    d.shape_type = h.put(shape_type);
-    d.shape_flags = h.put(shape_table(s.shape_flags, 0, false, "shape_flags"));
+    {
+        // The tiles see a triangle mesh as what compute_shape_aabbs makes of it -- a shape with a pre-computed local AABB
+        // (collide.py:421-445, the branch MESH and CONVEX_MESH share): their table carries CONVEX_MESH for it.  A MESH never is a
+        // tile PAIR: its pairs go to the SDF / vertex legs below or are refused.
+        std::vector<int32_t> tile_type = shape_type;
+        for (int32_t& t : tile_type)
+            if (t == GEO_MESH) t = GEO_CONVEX_MESH;
+        d.shape_type = h.put(tile_type);
+    }
+    std::vector<int32_t> shape_flags_tab = shape_table(s.shape_flags, 0, false, "shape_flags");
+    d.shape_flags = h.put(shape_flags_tab);
     d.shape_group = h.put(shape_table(s.shape_collision_group, 0, false, "shape_collision_group"));
     {
         std::vector<int32_t> none_start(NS, -1), none_count(NS, 0);
@@ -327,20 +339,62 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
             if (i >= (size_t)npair && (la[i] != la[k] || lb[i] != lb[k])) unsupported("heterogeneous worlds: candidate pairs differ between worlds");
         }
         la.resize(npair); lb.resize(npair);
+        // Pairs that leave the primitive / GJK-MPR path (narrow_phase.py:531-538,618-640): both shapes hydroelastic with SDFs (the
+        // SDF-SDF leg when the pipeline enables it), both shapes with a texture SDF and collision edges unless box-box (mesh-SDF
+        // edge contacts), a triangle mesh against an INFINITE plane (vertex leg).  Not tile pairs: listed for the pipeline's SDF leg
+        // in ascending Newton (shape0, shape1) order, nt_model_sdf_pairs.
+        {
+            std::vector<int32_t> none_idx(NS, -1), edge_cnt(NS, 0);
+            if (s.shape_edge_range)
+                for (int i = 0; i < NS; ++i) edge_cnt[i] = s.shape_edge_range[2 * (size_t)i + 1];
+            const std::vector<int32_t> sdf_idx = shape_table(s.shape_sdf_index ? s.shape_sdf_index : none_idx.data(), 0, false, "shape SDF index");
+            const std::vector<int32_t> edges = shape_table(edge_cnt.data(), 0, false, "shape collision-edge count");
+            auto newton_id0 = [&](int l) { return l < ns ? L0 + l : gshape_id[l - ns]; };
+            auto has_sdf = [&](int l) { return sdf_idx[l] >= 0 && edges[l] > 0; };
+            auto hydro = [&](int l) { return (shape_flags_tab[l] & SHAPE_HYDROELASTIC) != 0 && sdf_idx[l] >= 0; };
+            auto infinite_plane = [&](int l) {
+                const float* sc = s.shape_scale + 3 * (size_t)newton_id0(l);
+                return shape_type[l] == GEO_PLANE && sc[0] == 0.0f && sc[1] == 0.0f;
+            };
+            struct Routed { int id0, id1, a, b, kind, edges; };
+            std::vector<Routed> routed;
+            std::vector<int32_t> ta, tb;
+            std::vector<int64_t> tile_pos;
+            for (int p = 0; p < npair; ++p) {
+                const int a = la[p], b = lb[p];
+                int kind = -1;
+                if (hydro(a) && hydro(b)) kind = 1;
+                else if (has_sdf(a) && has_sdf(b) && !(shape_type[a] == GEO_BOX && shape_type[b] == GEO_BOX)) kind = 0;
+                else if ((infinite_plane(a) && shape_type[b] == GEO_MESH) || (infinite_plane(b) && shape_type[a] == GEO_MESH)) kind = 2;
+                if (kind < 0) { ta.push_back(a); tb.push_back(b); tile_pos.push_back(p); continue; }
+                const int ia = newton_id0(a), ib = newton_id0(b);
+                routed.push_back(ia < ib ? Routed{ia, ib, a, b, kind, has_sdf(a) && has_sdf(b)} : Routed{ib, ia, b, a, kind, has_sdf(a) && has_sdf(b)});
+            }
+            std::stable_sort(routed.begin(), routed.end(), [](const Routed& x, const Routed& y) { return x.id0 != y.id0 ? x.id0 < y.id0 : x.id1 < y.id1; });
+            for (const Routed& r : routed) {
+                h.sdf_pairs.push_back(r.a); h.sdf_pairs.push_back(r.b);
+                h.sdf_kind.push_back((uint8_t)r.kind);
+                h.sdf_has_edges.push_back((uint8_t)r.edges);
+            }
+            la = ta; lb = tb;
+            h.pair_order = tile_pos;  // (position of every tile pair in the world's slice; permuted by the partition below)
+        }
+        const std::vector<int64_t> tile_pos = h.pair_order;
+        const int ntile = (int)la.size();
         // The reference writes analytic-primitive contacts in its first narrow-phase kernel and queues every other pair for the
         // GJK/MPR kernel (narrow_phase.py:642-655,1004-1014): device pairs are stored analytic first (stable partition)
         std::vector<int64_t> order;
         for (int pass = 0; pass < 2; ++pass)
-            for (int p = 0; p < npair; ++p) {
+            for (int p = 0; p < ntile; ++p) {
                 int ta = shape_type[la[p]], tb = shape_type[lb[p]];
                 bool an = analytic_pair(ta, tb);
                 if (pass == 0 && !an && ((ta == GEO_PLANE && tb == GEO_PLANE) || !(convex_type(ta) && convex_type(tb))))
                     unsupported("a collision pair has no analytic path and is outside the convex (MPR/GJK) scope of this build");
-                if (an == (pass == 0)) { order.push_back(p); pa.push_back(la[p]); pb.push_back(lb[p]); }
+                if (an == (pass == 0)) { order.push_back(tile_pos[p]); pa.push_back(la[p]); pb.push_back(lb[p]); }
                 if (pass == 0 && an) d.np_analytic += 1;
             }
         h.pair_order = order;
-        d.np = npair;
+        d.np = ntile;
         d.cpp = d.np_analytic == d.np ? 4 : 5;
         d.pair_a = h.put(pa);
         d.pair_b = h.put(pb);
@@ -425,6 +479,17 @@ const nt_model* nt_model_get(const nt_model_handle* h) { return h ? &h->desc : n
 nt_status nt_model_pair_order(const nt_model_handle* h, int64_t* out) {
     if (!h || !out) return NT_ERR_INVALID_ARG;
     for (size_t i = 0; i < h->pair_order.size(); ++i) out[i] = h->pair_order[i];
+    return NT_OK;
+}
+
+nt_status nt_model_sdf_pairs(const nt_model_handle* h, int32_t* count, int32_t* pairs, uint8_t* kind, uint8_t* has_edges) {
+    if (!h || !count) return NT_ERR_INVALID_ARG;
+    *count = (int32_t)h->sdf_kind.size();
+    for (size_t i = 0; i < h->sdf_kind.size(); ++i) {
+        if (pairs) { pairs[2 * i] = h->sdf_pairs[2 * i]; pairs[2 * i + 1] = h->sdf_pairs[2 * i + 1]; }
+        if (kind) kind[i] = h->sdf_kind[i];
+        if (has_edges) has_edges[i] = h->sdf_has_edges[i];
+    }
     return NT_OK;
 }
 

@@ -427,17 +427,31 @@ def newton_model_struct(model):
     if hasattr(m, "shape_mesh_start"):
         s.shape_mesh_start, s.shape_mesh_count = i32(m.shape_mesh_start), i32(m.shape_mesh_count)
     s.mesh_points, s.gravity = f32(pts), f32(g)
+    if getattr(m, "_shape_sdf_index", None) is not None:
+        s.shape_sdf_index = i32(m._shape_sdf_index)
+    if getattr(m, "shape_edge_range", None) is not None:
+        s.shape_edge_range = i32(np.asarray(m.shape_edge_range).reshape(-1, 2))
     return s, keep
+
+
+def c_sdf_pairs(lib, handle):
+    """nt_model_sdf_pairs: the pairs of one world the C builder routed out of the tiles -> (pairs [n, 2], kind [n], has_edges [n])."""
+    n = C.c_int32()
+    _lib.check(lib.nt_model_sdf_pairs(handle, C.byref(n), None, None, None), "nt_model_sdf_pairs")
+    pairs, kind, edges = np.zeros((n.value, 2), np.int32), np.zeros(n.value, np.uint8), np.zeros(n.value, np.uint8)
+    if n.value:
+        _lib.check(lib.nt_model_sdf_pairs(handle, C.byref(n), pairs.ctypes.data, kind.ctypes.data, edges.ctypes.data), "nt_model_sdf_pairs")
+    return pairs, kind, edges
 
 
 class DeviceModel:
     """Device-resident env-major SoA copy of a Model + the nt_model descriptor passed across the C ABI.
 
     The descriptor the kernels get is the one ``nt_model_create`` builds in C from the model's flat arrays
-    (csrc/nt_model_build.hip) -- the entry point a non-Python Newton host binds -- for every model whose pairs all live in the
-    environment tiles; models with SDF / hydroelastic / mesh-vertex pairs (routing the C builder does not do yet) keep the tables
-    built here in Python (`EnvTemplate`, `pack_param_arrays`), which tests/test_model_build.py holds equal to the C ones table by
-    table."""
+    (csrc/nt_model_build.hip) -- the entry point a non-Python Newton host binds -- including the routing of SDF / hydroelastic /
+    mesh-vertex pairs out of the tiles (``nt_model_sdf_pairs``).  The tables built here in Python (`EnvTemplate`,
+    `pack_param_arrays`) stay as the host-side mirror (world slicing, the SDF legs and the tests read them); tests/test_model_build.py
+    holds them equal to the C ones table by table, and the constructor compares the pair routing of the two on every model."""
 
     def __init__(self, model: Model):
         torch = _torch()
@@ -503,6 +517,12 @@ class DeviceModel:
             C.memmove(C.byref(cd), self.lib.nt_model_get(h), C.sizeof(cd))
             assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride) == \
                 (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride)
+            # pairs routed out of the tiles: the SDF legs read the Python mirror (t.sdf_pair ...), the kernels the C tables
+            sp, kind, edges = c_sdf_pairs(self.lib, h)
+            want_kind = np.where(t.sdf_pair_hydro, 1, np.where(t.sdf_pair_mesh_plane, 2, 0)).astype(np.uint8) if len(t.sdf_pair) else kind[:0]
+            if not (np.array_equal(sp, np.asarray(t.sdf_pair).reshape(-1, 2)) and np.array_equal(kind, want_kind)
+                    and np.array_equal(edges.astype(bool), np.asarray(t.sdf_pair_has_edges, dtype=bool))):
+                raise _lib.NewtonHipError("nt_model_create routed the SDF / vertex pairs differently from the host mirror")
             self.desc = cd
         # environments per workgroup the collide / XPBD / SemiImplicit kernels will use (0: the working set of one
         # environment does not fit the CU's LDS in either mode)
@@ -512,10 +532,7 @@ class DeviceModel:
     USE_C_BUILDER = True  # (tests flip it to compare the two builders end to end)
 
     def _c_builder_eligible(self, model) -> bool:
-        t = self.t
-        if len(getattr(t, "sdf_pair", ())) > 0 or not DeviceModel.USE_C_BUILDER:
-            return False
-        return bool(np.array_equal(np.asarray(t.tile_shape_type), np.asarray(t.shape_type)))  # (no triangle mesh shown to the tiles as a hull)
+        return bool(DeviceModel.USE_C_BUILDER)
 
     def __del__(self):
         h, self._c_handle = getattr(self, "_c_handle", None), None

@@ -34,7 +34,25 @@ def _scenes():
         "box_stack": lambda: box_stack_scene(3, n_boxes=4, seed=1),
         "pendulum": lambda: pendulum_scene(6, seed=2),
         "hull_bin": lambda: hull_bin_scene(2, n_hulls=6),
+        # pairs routed out of the tiles (narrow_phase.py:531-538,618-640): mesh-SDF edge pairs incl. static walls, hydroelastic
+        # pairs, (triangle mesh, infinite plane) vertex pairs with the plane before and after the meshes
+        "sdf_pile": lambda: _sdf_scene(3, 4, walls=True),
+        "hydro_bin": lambda: hull_bin_scene(2, 5, seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005), hydroelastic=True),
+        "mesh_ground": lambda: _mesh_scene(3, ground_first=False),
+        "mesh_ground_first": lambda: _mesh_scene(2, ground_first=True),
     }
+
+
+def _sdf_scene(*a, **k):
+    from sdf_pipeline_checker import sdf_scene
+
+    return sdf_scene(*a, device=None, **k)
+
+
+def _mesh_scene(worlds, ground_first):
+    from test_gpu_mesh_plane_pipeline import mesh_scene
+
+    return mesh_scene(worlds, kind="box", device=None, ground_first=ground_first)
 
 
 @pytest.mark.parametrize("name", list(_scenes()))
@@ -58,7 +76,8 @@ def test_c_helper_reproduces_the_python_descriptor(name):
                  "body_joint_list": 2 * t.nj, "body_pair_start": t.nb + 1, "body_pair_list": 2 * t.np, "art_start": t.na + 1,
                  "shape_mesh_start": t.ns + t.ng, "shape_mesh_count": t.ns + t.ng, "gshape_id": t.ng}
         for k, n in sizes.items():
-            assert np.array_equal(_arr(getattr(d, k), n), np.asarray(getattr(t, k), dtype=np.int32)[:n]), k
+            want = t.tile_shape_type if k == "shape_type" else getattr(t, k)  # (a triangle mesh: a pre-computed-AABB shape to the tiles)
+            assert np.array_equal(_arr(getattr(d, k), n), np.asarray(want, dtype=np.int32)[:n]), k
         assert np.array_equal(_arr(d.mesh_points, 3 * len(t.mesh_points), C.c_float), t.mesh_points.reshape(-1))
         assert np.array_equal(_arr(d.shape_mesh_bounds, 6 * (t.ns + t.ng), C.c_float), t.shape_mesh_bounds.reshape(-1))
         packed = pack_param_arrays(model, t)
@@ -68,7 +87,16 @@ def test_c_helper_reproduces_the_python_descriptor(name):
         assert d.params_uniform == params_uniform(packed, t.env_count)
         order = np.zeros(t.np, dtype=np.int64)
         assert lib.nt_model_pair_order(h, order.ctypes.data_as(C.POINTER(C.c_int64))) == 0
-        assert np.array_equal(order, t.pair_order)
+        assert np.array_equal(order, np.asarray(t.tile_pair_index)[t.pair_order])  # positions in the world's shape_contact_pairs slice
+        # the pairs that leave the tiles, their kinds and order: what the pipeline's SDF leg walks per world
+        from newton_amd.model import c_sdf_pairs
+
+        sp, kind, edges = c_sdf_pairs(lib, h)
+        assert np.array_equal(sp, np.asarray(t.sdf_pair).reshape(-1, 2))
+        assert np.array_equal(kind == 1, t.sdf_pair_hydro) and np.array_equal(kind == 2, t.sdf_pair_mesh_plane)
+        assert np.array_equal(edges.astype(bool), t.sdf_pair_has_edges)
+        if name in ("sdf_pile", "hydro_bin", "mesh_ground", "mesh_ground_first"):
+            assert len(sp) > 0 and set(kind.tolist()) == {dict(sdf_pile=0, hydro_bin=1).get(name, 2)}
         # the mode choice for pair-heavy scenes is the library's own
         from newton_amd.model import choose_contact_scratch
 
