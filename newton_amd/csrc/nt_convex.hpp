@@ -15,6 +15,9 @@
 namespace nt {
 
 #define NT_DEV __device__
+#ifndef NT_HULL_BATCH
+#define NT_HULL_BATCH 8  // hull vertices fetched per round of the CONVEX_MESH support scan (support_map)
+#endif
 NT_DI int imin(int a, int b) { return a < b ? a : b; }
 
 struct Geom {
@@ -79,18 +82,33 @@ NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
     if (g.type == GEO_PLANE) return support_map_plane(g.scale, direction);
     if (g.type == GEO_CONVEX_MESH) {
         // support_function.py:152-171: furthest vertex; ties keep the first one
+        // NT_HULL_BATCH vertices per round: their loads are issued together (one memory round trip per round instead of one per
+        // vertex -- the scan is a chain of dependent global loads otherwise, and it is most of a hull pair's MPR / manifold time);
+        // the comparisons stay in ascending vertex order, so the first furthest vertex wins as in the serial loop.  Rounds past
+        // the end re-read the last vertex: its dot product cannot beat the maximum it already entered.  The winner's
+        // coordinates travel with the maximum (no reload by index at the end).
         vec3 scaled_dir = cw_mul(direction, g.scale);
         float max_dot = -1.0e10f;
-        int best_idx = 0;
-        for (int i = 0; i < g.count; ++i) {
-            float dot_val = dot(vec3(g.points[3 * i], g.points[3 * i + 1], g.points[3 * i + 2]), scaled_dir);
-            if (dot_val > max_dot) {
-                max_dot = dot_val;
-                best_idx = i;
+        vec3 best;
+        if (g.count > 0) best = vec3(g.points[0], g.points[1], g.points[2]);  // best_idx = 0 unless a vertex beats -1e10
+        const int last = g.count - 1;
+        for (int i0 = 0; i0 < g.count; i0 += NT_HULL_BATCH) {
+            vec3 p[NT_HULL_BATCH];
+#pragma unroll
+            for (int q = 0; q < NT_HULL_BATCH; ++q) {
+                const int i = imin(i0 + q, last);
+                p[q] = vec3(g.points[3 * i], g.points[3 * i + 1], g.points[3 * i + 2]);
+            }
+#pragma unroll
+            for (int q = 0; q < NT_HULL_BATCH; ++q) {
+                float dot_val = dot(p[q], scaled_dir);
+                if (dot_val > max_dot) {
+                    max_dot = dot_val;
+                    best = p[q];
+                }
             }
         }
-        if (g.count > 0)
-            result = cw_mul(vec3(g.points[3 * best_idx], g.points[3 * best_idx + 1], g.points[3 * best_idx + 2]), g.scale);
+        if (g.count > 0) result = cw_mul(best, g.scale);
     } else if (g.type == GEO_BOX) {
         result = support_map_box(g, direction);
     } else if (g.type == GEO_SPHERE) {

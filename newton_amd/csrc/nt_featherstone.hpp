@@ -216,7 +216,11 @@ NT_DI void fs_to_internal_item(const FsCtx<EPB>& f, int j) {
     for (int i = qs; i < qe; ++i) f.f(f.F.jfi, i) = 0.0f;
 }
 
-// transform_spatial_inertia (kernels.py:66-139): T^T I T with T = [[R, skew(p) R], [0, R]] of the inverse transform
+// transform_spatial_inertia (kernels.py:66-139): T^T I T with T = [[R, skew(p) R], [0, R]] of the inverse transform and
+// I = diag(m 1, I_b).  The reference multiplies the dense 6 x 6 matrices; here every sum keeps the reference's ascending-k order but
+// only the terms whose T / I factor is not a structural zero.  Bit-identical for finite inputs: a dropped term is 0 * x = +-0, a sum
+// that starts at +0 cannot become -0, and s + (+-0) = s -- 330 instead of 920 VALU operations per body and substep (contraction
+// is off in this namespace, the compiler may not fold 0 * x).
 NT_DI void fs_transform_spatial_inertia(const xform& t, float mass, const mat33& Ib, mat66& out) {
     xform t_inv = xform_inverse(t);
     quat q = t_inv.q;
@@ -224,56 +228,52 @@ NT_DI void fs_transform_spatial_inertia(const xform& t, float mass, const mat33&
     vec3 r1 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
     vec3 r2 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
     vec3 r3 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
-    float R[3][3] = {{r1.x, r2.x, r3.x}, {r1.y, r2.y, r3.y}, {r1.z, r2.z, r3.z}};
-    float K[3][3] = {{0.0f, -p.z, p.y}, {p.z, 0.0f, -p.x}, {-p.y, p.x, 0.0f}};
-    float S[3][3];
+    const float R[3][3] = {{r1.x, r2.x, r3.x}, {r1.y, r2.y, r3.y}, {r1.z, r2.z, r3.z}};
+    const float K[3][3] = {{0.0f, -p.z, p.y}, {p.z, 0.0f, -p.x}, {-p.y, p.x, 0.0f}};
+    float S[3][3];  // skew(p) R: the diagonal of skew(p) is a structural zero
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             float sum = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sum += K[i][k] * R[k][j];
+            for (int k = 0; k < 3; ++k)
+                if (k != i) sum += K[i][k] * R[k][j];
             S[i][j] = sum;
         }
-    mat66 T, I;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            T.a[i][j] = 0.0f;
-            I.a[i][j] = 0.0f;
-        }
     const float Im[3][3] = {{Ib.m00, Ib.m01, Ib.m02}, {Ib.m10, Ib.m11, Ib.m12}, {Ib.m20, Ib.m21, Ib.m22}};
+    // A = T^T I: A[i][j] = sum_k T[k][i] I[k][j].  Blocks: [R^T m | 0; S^T m | R^T I_b]
+    float Amm[3][3], Asm[3][3], Arr[3][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        I.a[i][i] = mass;
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            T.a[i][j] = R[i][j];
-            T.a[i][j + 3] = S[i][j];
-            T.a[i + 3][j + 3] = R[i][j];
-            I.a[i + 3][j + 3] = Im[i][j];
-        }
-    }
-    mat66 A;  // T^T I
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
+            Amm[i][j] = 0.0f + R[j][i] * mass;  // the one k with I[k][j] != 0 is k = j
+            Asm[i][j] = 0.0f + S[j][i] * mass;
             float sum = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) sum += T.a[k][i] * I.a[k][j];
-            A.a[i][j] = sum;
+            for (int k = 0; k < 3; ++k) sum += R[k][i] * Im[k][j];
+            Arr[i][j] = sum;
         }
+    // out = A T: out[i][j] = sum_k A[i][k] T[k][j]
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float sum = 0.0f;
+        for (int j = 0; j < 3; ++j) {
+            float s00 = 0.0f, s10 = 0.0f, s01 = 0.0f, s11 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) sum += A.a[i][k] * T.a[k][j];
-            out.a[i][j] = sum;
+            for (int k = 0; k < 3; ++k) {
+                s00 += Amm[i][k] * R[k][j];
+                s10 += Asm[i][k] * R[k][j];
+                s01 += Amm[i][k] * S[k][j];  // (A[i][3..5] = 0 for i < 3: the lower half of the sum is dropped)
+                s11 += Asm[i][k] * S[k][j];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s11 += Arr[i][k] * R[k][j];
+            out.a[i][j] = s00;
+            out.a[i + 3][j] = s10;
+            out.a[i][j + 3] = s01;
+            out.a[i + 3][j + 3] = s11;
         }
 }
 
@@ -1014,9 +1014,13 @@ NT_DI void fs_fk_vel_item(const FsCtx<EPB>& f, int j) {
         linear_joint_origin = linear_joint_world + cross(angular_joint_world, child_origin_offset_world);
     }
     vec3 v_origin = v_parent_origin + linear_joint_origin, w = w_parent + angular_joint_world;
+    const vec3 r_com = xform_vector(X_wc, c.com(child));
     c.st_lxf(c.L.bq, nb, child, X_wc);
-    c.st_lv3(c.L.bqd, 0, nb, child, cross(w, xform_vector(X_wc, c.com(child))) + v_origin);
+    c.st_lv3(c.L.bqd, 0, nb, child, cross(w, r_com) + v_origin);
     c.st_lv3(c.L.bqd, 3, nb, child, w);
+    // the COM world position fs_fk_item would store for these poses (X_wc * (com, 1)).p: the next substep of a rollout starts
+    // from this pass instead of repeating eval_rigid_fk on the same joint_q (fs_substep, fk_is_current)
+    if (!PUBLIC) c.st_lv3(f.F.qcom, 0, nb, child, X_wc.p + r_com);
 }
 
 // convert_free_distance_joint_qd_internal_to_public (kernels.py:1015-1066) straight into state_out.joint_qd
@@ -1198,15 +1202,20 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     NT_SKIP_DECL(a);  // timing ablation builds only (-DNT_ABLATION): results are meaningless when set
     NT_TICK(10);
     // eval_rigid_fk: joint transforms for all joints at once, then level by level (a joint's parent body is final one
-    // level earlier)
-    if (c.valid && !NT_SKIP(1))
-        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
-    __syncthreads();
-    for (int lvl = 0; lvl <= max_depth; ++lvl) {
+    // level earlier).  Substeps >= 1 of a rollout skip it: body_q and the COM positions in LDS are the previous substep's FK with
+    // velocity conversion of the same joint_q -- the same expressions on the same inputs, bit for bit (rollout == loop stays a
+    // bitwise test) -- unless that substep ended with the descendant FREE / DISTANCE pose correction, which rewrites poses.
+    const bool fk_is_current = substep > 0 && !publish_fk && !f.any_descendant_free();  // block-uniform
+    if (!fk_is_current) {
         if (c.valid && !NT_SKIP(1))
-            for (int j = c.slot; j < nj; j += c.nslot)
-                if (f.depth[j] == lvl) fs_fk_item(f, j);
+            for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
         __syncthreads();
+        for (int lvl = 0; lvl <= max_depth; ++lvl) {
+            if (c.valid && !NT_SKIP(1))
+                for (int j = c.slot; j < nj; j += c.nslot)
+                    if (f.depth[j] == lvl) fs_fk_item(f, j);
+            __syncthreads();
+        }
     }
     NT_TICK(11);
     // state_in.body_q is refreshed by the reference step (solver_featherstone.py:492-514): publish it when distinct

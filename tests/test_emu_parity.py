@@ -245,6 +245,8 @@ def test_featherstone_step_and_rollout(H, n_env, epb):
         H.featherstone_step(em, a, b, ctrl, ct, 1e-3, epb=epb)
         a, b = b, a
     assert np.array_equal(out.joint_q, a.joint_q) and np.array_equal(out.body_q, a.body_q)
+    # (substeps >= 1 of the rollout start from the previous substep's FK instead of repeating eval_rigid_fk: same bits)
+    assert np.array_equal(out.joint_qd, a.joint_qd) and np.array_equal(out.body_qd, a.body_qd)
 
 
 @pytest.mark.parametrize("lowered,substeps,tol", [(False, 60, 2e-6), (True, 10, 2e-4)])
