@@ -28,7 +28,12 @@ from scenes import quadruped_scene  # noqa: E402
 
 lib = _lib.load()
 BOX = len(sys.argv) > 1 and sys.argv[1] == "box_stack"
-if BOX:
+HULL = len(sys.argv) > 1 and sys.argv[1] == "hull_bin"  # config C5's geometry on the pair-heavy tile (bench.py --workload hull_bin)
+if HULL:
+    from scenes import hull_bin_scene  # noqa: E402
+
+    model = hull_bin_scene(int(sys.argv[2]) if len(sys.argv) > 2 else 512, 64, seed=2, device="cuda:0")
+elif BOX:
     from scenes import box_stack_scene  # noqa: E402
 
     model = box_stack_scene(int(sys.argv[2]) if len(sys.argv) > 2 else 256, device="cuda:0", seed=1)
@@ -42,15 +47,16 @@ pipe = nt.CollisionPipeline(model)
 contacts = pipe.contacts()
 FS = len(sys.argv) > 1 and sys.argv[1] == "featherstone"
 solver = nt.solvers.SolverFeatherstone(model, mass_matrix=(sys.argv[2] if len(sys.argv) > 2 else "tree")) if FS else nt.solvers.SolverXPBD(model, iterations=4 if BOX else 2)
-for _ in range(100):
-    solver.rollout(s0, s1, None, contacts, 1e-3, 10)
+DT = 1.0 / 1200.0 if HULL else 1e-3
+for _ in range(30 if HULL else 100):
+    solver.rollout(s0, s1, None, contacts, DT, 10)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 32)()
 raw = C.CDLL(dbg)
 raw.nt_debug_phase_clocks(buf)
-N = 50
+N = 10 if HULL else 50
 for _ in range(N):
-    solver.rollout(s0, s1, None, contacts, 1e-3, 10)
+    solver.rollout(s0, s1, None, contacts, DT, 10)
 torch.cuda.synchronize()
 raw.nt_debug_phase_clocks(buf)
 if FS:
