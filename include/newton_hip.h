@@ -77,6 +77,9 @@ typedef struct {
     int32_t params_uniform; /* 1: body_param / joint_param / dof_param / shape_param hold the same values in every environment
                             (replicated worlds, newton.ModelBuilder.replicate without per-world randomisation).  The XPBD rollout
                             then keeps ONE block-shared copy per workgroup in LDS; 0 is always valid */
+    int32_t mesh_vertex_count; /* V: vertices in mesh_points (occupies what used to be alignment padding).  The pair-heavy tile stages
+                            the hull vertices in LDS when they fit next to the environment (support-map scans then read LDS instead of
+                            chasing global loads); 0 is always valid (vertices stay in global memory) */
     /* topology, int32, env-uniform */
     const int32_t* body_flags;          /* [nb]   BodyFlags */
     const int32_t* joint_type;          /* [nj]   JointType */
@@ -169,7 +172,8 @@ typedef struct {
     float* data;          /* [NT_CONTACT_FLOATS][np*cpp][ES] */
     int32_t* env_count;   /* [ES] contacts emitted per env (== per-env slice of rigid_contact_count) */
     uint8_t* pair_hit;    /* [np][ES] 1 if the pair passed the broad phase (candidate pair set, per env) */
-    float* cw;            /* [15][np*cpp][ES] solver scratch, only when nt_model.contact_scratch_in_hbm (else NULL) */
+    float* cw;            /* 15 * np*cpp * ES floats of solver scratch, only when nt_model.contact_scratch_in_hbm (else NULL); layout
+                           * internal to the kernels: one contiguous record per (environment, contact slot) */
     const float* prop;    /* [3][np*cpp][ES] or NULL: per-contact stiffness, damping, friction scale
                            * (Contacts.rigid_contact_stiffness / _damping / _friction, contacts.py:227-277); a value > 0
                            * overrides the shape-material ke / kd and scales mu in eval_body_contact

@@ -519,6 +519,8 @@ class ModelBuilder:
         if type in (GeoType.SPHERE, GeoType.BOX, GeoType.CAPSULE, GeoType.CYLINDER, GeoType.ELLIPSOID, GeoType.PLANE,
                     GeoType.CONE):
             scale = tuple(abs(float(s)) for s in scale)
+            if type == GeoType.CYLINDER and scale[2] != 0.0 and scale[2] < scale[1]:  # (builder.py:6590-6591)
+                raise ValueError(f"Cylinder barrel radius must be zero or at least the half-height; got scale={scale}.")
         self.shape_body.append(body)
         shape = self.shape_count  # shape_type not yet appended
         if cfg.has_shape_collision:
@@ -608,8 +610,10 @@ class ModelBuilder:
         return self.add_shape(body=body, type=GeoType.CAPSULE, xform=xform, cfg=cfg, scale=(radius, half_height, 0.0),
                               label=label)
 
-    def add_shape_cylinder(self, body, *, xform=None, radius=1.0, half_height=0.5, cfg=None, label=None) -> int:
-        return self.add_shape(body=body, type=GeoType.CYLINDER, xform=xform, cfg=cfg, scale=(radius, half_height, 0.0),
+    def add_shape_cylinder(self, body, *, xform=None, radius=1.0, half_height=0.5, barrel_radius=0.0, cfg=None, label=None) -> int:
+        """Cylinder along Z (builder.py:7041-7100).  ``barrel_radius`` [m]: radius of the symmetric circular arc revolved about the
+        axis to form the side; 0.0 = straight sides, otherwise at least ``half_height``."""
+        return self.add_shape(body=body, type=GeoType.CYLINDER, xform=xform, cfg=cfg, scale=(radius, half_height, barrel_radius),
                               label=label)
 
     def add_shape_cone(self, body, *, xform=None, radius=1.0, half_height=0.5, cfg=None, label=None) -> int:

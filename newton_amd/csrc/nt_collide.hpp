@@ -274,6 +274,20 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
         float margin_a = c.shape_f(sa, SP_MARGIN), margin_b = c.shape_f(sb, SP_MARGIN);
         float gap_sum = c.shape_f(sa, SP_GAP) + c.shape_f(sb, SP_GAP);
         bool to_gjk = ta >= GEO_ELLIPSOID || tb == GEO_CONE || (ta == GEO_CAPSULE && tb > GEO_CAPSULE);
+        bool barrel_on_cap = false;
+        if constexpr (CVX) {
+            // barrel cylinders (scale.z = radius of the side arc): sphere pairs always take MPR / GJK (narrow_phase.py:847,999), plane pairs
+            // unless the cylinder rests on an end cap (narrow_phase.py:682-686) -- decided per environment and substep.  The host stores
+            // such pairs with the convex ones (they own manifold slots); both outcomes are written by the convex branch below
+            if (tb == GEO_CYLINDER && scale_b.z != 0.0f && p >= m.np_analytic && (ta == GEO_SPHERE || ta == GEO_PLANE)) {
+                to_gjk = true;
+                if (ta == GEO_PLANE) {
+                    barrel_on_cap = true;
+                    if (scale_b.z > 0.0f)
+                        barrel_on_cap = fabsf(dot(quat_rotate(Xa.q, vec3(0.0f, 0.0f, 1.0f)), quat_rotate(Xb.q, vec3(0.0f, 0.0f, 1.0f)))) * scale_b.z >= scale_b.y;
+                }
+            }
+        }
         if (!to_gjk) {
             float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
             float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
@@ -313,20 +327,37 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
         if constexpr (CVX) {
             if (p >= m.np_analytic) {
                 ConvexContacts cc;
+                if (barrel_on_cap) {
+                    // the analytic plane-cylinder routine on the end cap, admitted like the primitive kernel admits (narrow_phase.py:791-797,
+                    // 872-955); the writer below is shared with the manifold's contacts
+                    Contacts4 k4;
+                    plane_cylinder(quat_rotate(Xa.q, vec3(0.0f, 0.0f, 1.0f)), Xa.p, Xb.p, quat_rotate(Xb.q, vec3(0.0f, 0.0f, 1.0f)), scale_b.x, scale_b.y, k4);
+                    cc.normal = k4.normal;
+                    cc.count = 0;
+                    const vec3 n = normalize(k4.normal);
+                    for (int i = 0; i < 4; ++i) {
+                        const float dist = k4.dist(i);
+                        if (dist < NT_MAXVAL) {
+                            const vec3 center = k4.pos(i);
+                            const vec3 aw = center - n * (0.5f * dist + 0.0f), bw = center + n * (0.5f * dist + 0.0f);
+                            if (dot(bw - aw, n) - (0.0f + 0.0f + margin_a + margin_b) <= gap_sum) cc.push(center, dist);
+                        }
+                    }
+                }
                 Geom ga, gb;
                 ga.type = ta; ga.scale = scale_a;
                 gb.type = tb; gb.scale = scale_b;
                 if (ta == GEO_PLANE) ga.scale = vec3(scale_a.x * 0.5f, scale_a.y * 0.5f, 0.0f);
                 if (tb == GEO_PLANE) gb.scale = vec3(scale_b.x * 0.5f, scale_b.y * 0.5f, 0.0f);
                 if (ta == GEO_CONVEX_MESH) {
-                    ga.points = m.mesh_points + 3 * c.T.shape_mesh_start[sa];
+                    ga.points = c.mesh_pts + 3 * c.T.shape_mesh_start[sa];
                     ga.count = c.T.shape_mesh_count[sa];
                     const float* mb = m.shape_mesh_bounds + 6 * sa;
                     ga.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)) +
                                         vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)));
                 }
                 if (tb == GEO_CONVEX_MESH) {
-                    gb.points = m.mesh_points + 3 * c.T.shape_mesh_start[sb];
+                    gb.points = c.mesh_pts + 3 * c.T.shape_mesh_start[sb];
                     gb.count = c.T.shape_mesh_count[sb];
                     const float* mb = m.shape_mesh_bounds + 6 * sb;
                     gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +
@@ -335,7 +366,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                 PolyRef poly;  // manifold polygon scratch: per convex pair, or (pair-heavy tile) per lane
                 poly.base = &c.lds[(c.L.poly + 20 * (c.big ? c.slot : p - m.np_analytic)) * Ctx<EPB>::N + c.e];
                 poly.stride = Ctx<EPB>::N;
-                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
+                if (!barrel_on_cap) convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
                 float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
                 vec3 n = normalize(cc.normal);

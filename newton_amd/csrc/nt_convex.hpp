@@ -7,7 +7,7 @@
 //   build_manifold + clipping helpers                 newton/_src/geometry/multicontact.py:28-956
 //   post_process_axial_on_discrete_contact            newton/_src/geometry/collision_core.py:173-278
 //   write_contact gap test                            newton/_src/sim/collide.py:206-254
-// Scope: BOX, SPHERE, CAPSULE, ELLIPSOID, straight CYLINDER, CONE.
+// Scope: BOX, SPHERE, CAPSULE, ELLIPSOID, CYLINDER (straight and barrel), CONE, CONVEX_MESH, finite PLANE.
 #pragma once
 #include "nt_math.hpp"
 #include "nt_primitives.hpp"
@@ -139,19 +139,37 @@ NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
             result = vec3(a, 0.0f, 0.0f);
         }
     } else if (g.type == GEO_CYLINDER) {
-        float radius = g.scale.x, half_height = g.scale.y;
+        float radius = g.scale.x, half_height = g.scale.y, barrel_radius = g.scale.z;
         vec3 dir_xy(direction.x, direction.y, 0.0f);
         float l2 = length_sq(dir_xy);
-        vec3 lateral;
-        if (l2 > eps) {
-            vec3 n_xy = dir_xy * support_rsqrt_rn(l2);
-            lateral = vec3(n_xy.x * radius, n_xy.y * radius, 0.0f);
+        if (barrel_radius == 0.0f) {
+            vec3 lateral;
+            if (l2 > eps) {
+                vec3 n_xy = dir_xy * support_rsqrt_rn(l2);
+                lateral = vec3(n_xy.x * radius, n_xy.y * radius, 0.0f);
+            } else {
+                lateral = vec3(radius, 0.0f, 0.0f);
+            }
+            if (direction.z > 0.0f) result = vec3(lateral.x, lateral.y, half_height);
+            else if (direction.z < 0.0f) result = vec3(lateral.x, lateral.y, -half_height);
+            else result = lateral;
         } else {
-            lateral = vec3(radius, 0.0f, 0.0f);
+            // barrel cylinder (support_function.py:284-305): the side profile is a circular arc of radius barrel_radius about the
+            // axis; the support point sits where the arc's normal matches the direction, clamped to the end caps
+            vec3 n_xy(1.0f, 0.0f, 0.0f);
+            if (l2 > eps) n_xy = dir_xy / sqrtf(l2);
+            float direction_len = sqrtf(l2 + direction.z * direction.z);
+            float support_z = 0.0f;
+            if (direction_len > eps) support_z = clampf(barrel_radius * direction.z / direction_len, -half_height, half_height);
+            float barrel_radius_sq = barrel_radius * barrel_radius, half_height_sq = half_height * half_height;
+            float support_z_sq = support_z * support_z;
+            float end_offset = sqrtf(barrel_radius_sq - half_height_sq);
+            float support_offset = sqrtf(fmaxw(barrel_radius_sq - support_z_sq, 0.0f));
+            float offset_sum = support_offset + end_offset;
+            float support_radius = radius;
+            if (offset_sum > eps) support_radius += (half_height_sq - support_z_sq) / offset_sum;
+            result = vec3(n_xy.x * support_radius, n_xy.y * support_radius, support_z);
         }
-        if (direction.z > 0.0f) result = vec3(lateral.x, lateral.y, half_height);
-        else if (direction.z < 0.0f) result = vec3(lateral.x, lateral.y, -half_height);
-        else result = lateral;
     } else if (g.type == GEO_CONE) {
         float radius = g.scale.x, half_height = g.scale.y;
         vec3 apex(0.0f, 0.0f, half_height);

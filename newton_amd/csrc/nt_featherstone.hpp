@@ -280,8 +280,10 @@ NT_DI void fs_transform_spatial_inertia(const xform& t, float mass, const mat33&
 // compute_link_velocity (kernels.py:764-866) incl. jcalc_motion (kernels.py:242-380), split in two:
 // (1) everything that does not depend on the parent's velocity -- motion subspace columns S, the joint velocity v_j_s
 //     and the solve-frame spatial inertia I_s -- runs for all joints at once;
+// do_motion: S, v_j_s, c_app_s; do_inertia: solve origin + I_s.  The two halves share nothing but their inputs, so a workgroup
+// with idle slot lanes runs them side by side (fs_substep); together they are the reference's per-joint program.
 template <int EPB>
-NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
+NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j, const bool do_motion = true, const bool do_inertia = true) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
     const int nb = m.nb, nd = m.nd;
@@ -296,6 +298,17 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
         int rt = c.T.joint_type[root];
         if (rt == JT_FREE || rt == JT_DISTANCE) solve_origin = f.v3(f.F.qcom, 0, nb, c.T.joint_child[root]);
     }
+    if (do_inertia) {
+        vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - solve_origin;
+        c.st_lv3(f.F.org, 0, nb, child, solve_origin);
+        mat66 I_s;
+        fs_transform_spatial_inertia(xform(x_com_s, c.body_rot(child)), c.pl(c.L.bp, BP_MASS, nb, child), c.inertia(child), I_s);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c.l(f.F.Is, i * 6 + k, nb, child) = I_s.a[i][k];
+    }
+    if (!do_motion) return;
     xform X_wpj = c.plxf(c.L.jp, 0, m.nj, j);
     if (parent >= 0) X_wpj = c.body_q(parent) * X_wpj;
     xform X_sc(X_wpj.p - solve_origin, X_wpj.q);
@@ -368,14 +381,6 @@ NT_DI void fs_motion_pre_item(const FsCtx<EPB>& f, int j) {
     }
     f.st6(f.F.ft, nb, j, v_j_s);  // parked in the (still unused) subtree-wrench rows until the level pass picks it up
     f.st6(f.F.as, nb, child, c_app_s);  // the level pass adds it to the child's acceleration (zero except multi-angular D6)
-    vec3 x_com_s = f.v3(f.F.qcom, 0, nb, child) - solve_origin;
-    c.st_lv3(f.F.org, 0, nb, child, solve_origin);
-    mat66 I_s;
-    fs_transform_spatial_inertia(xform(x_com_s, c.body_rot(child)), c.pl(c.L.bp, BP_MASS, nb, child), c.inertia(child), I_s);
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c.l(f.F.Is, i * 6 + k, nb, child) = I_s.a[i][k];
 }
 
 // (2) the velocity / acceleration recurrence, one tree level at a time (a handful of adds and two cross products);
@@ -435,8 +440,9 @@ NT_DI void fs_body_force_item(const FsCtx<EPB>& f, int b, bool forces_are_zero) 
         t0 = c.gv3(c.a.s_in.body_f, 3, nb, b);
     }
     for (int j = 0; j < m.nj; ++j) {
+        if (c.T.joint_child[j] != b) continue;  // (one LDS read per joint instead of two; a body has one inbound joint)
         int type = c.T.joint_type[j];
-        if ((type == JT_FREE || type == JT_DISTANCE) && c.T.joint_child[j] == b) {
+        if (type == JT_FREE || type == JT_DISTANCE) {
             int qs = c.T.joint_qd_start[j];
             f0 += vec3(c.l(c.L.cf, 0, 1, qs), c.l(c.L.cf, 0, 1, qs + 1), c.l(c.L.cf, 0, 1, qs + 2));
             t0 += vec3(c.l(c.L.cf, 0, 1, qs + 3), c.l(c.L.cf, 0, 1, qs + 4), c.l(c.L.cf, 0, 1, qs + 5));
@@ -1220,13 +1226,17 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     NT_TICK(11);
     // state_in.body_q is refreshed by the reference step (solver_featherstone.py:492-514): publish it when distinct
     if (publish_fk && c.valid && a.s_in.body_q != a.s_out.body_q) unstage_rows(c, c.L.bq, a.s_in.body_q, 7, nb);
-    if (c.valid)
-        for (int j = c.slot; j < nj; j += c.nslot) fs_to_internal_item(f, j);
-    __syncthreads();
+    // public -> internal velocities, then eval_rigid_id's per-joint preparation in the same barrier interval: a joint's lane reads
+    // the internal speeds of its own dofs only.  With 2 nj slot lanes the spatial-inertia half runs on lanes [nj, 2 nj)
     NT_TICK(12);
-    // eval_rigid_id
-    if (c.valid && !NT_SKIP(2))
-        for (int j = c.slot; j < nj; j += c.nslot) fs_motion_pre_item(f, j);
+    if (c.valid) {
+        const bool split = c.nslot >= 2 * nj;
+        for (int j = c.slot; j < nj; j += c.nslot) {
+            fs_to_internal_item(f, j);
+            if (!NT_SKIP(2)) fs_motion_pre_item(f, j, true, !split);
+        }
+        if (split && c.slot >= nj && c.slot < 2 * nj && !NT_SKIP(2)) fs_motion_pre_item(f, c.slot - nj, false, true);
+    }
     __syncthreads();
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid && !NT_SKIP(2))
@@ -1310,20 +1320,25 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     const bool desc_free = f.any_descendant_free();  // block-uniform
     const Fld<7> bq_prev{F.fs};                      // f_b - f_g and the subtree wrenches (12 nb rows) are dead by now
     if (c.valid) {
-        for (int j = c.slot; j < nj; j += c.nslot) fs_integrate_item(f, j);
+        for (int j = c.slot; j < nj; j += c.nslot) {
+            fs_integrate_item(f, j);
+            if (!NT_SKIP(128)) fs_joint_xform_item(f, j);  // the joint transform of the new joint_q (this lane wrote it): no barrier between
+        }
         if (desc_free)  // descendant_body_q_prev (solver_featherstone.py:481,514-516): the poses of the start-of-step FK
             for (int r = c.slot; r < 7 * nb; r += c.nslot) c.lds[(bq_prev.off + r) * Ctx<EPB>::N + c.e] = c.lds[(c.L.bq.off + r) * Ctx<EPB>::N + c.e];
     }
     __syncthreads();
     NT_TICK(19);
-    // FK with velocity conversion -> public body_q / body_qd
-    if (c.valid && !NT_SKIP(128))
-        for (int j = c.slot; j < nj; j += c.nslot) fs_joint_xform_item(f, j);
-    __syncthreads();
+    // FK with velocity conversion -> public body_q / body_qd; without descendant FREE / DISTANCE joints (their pose correction comes
+    // first) a joint's lane converts its velocities to the public convention right behind its FK item: the poses it reads -- its
+    // child's and its parent's -- are final then
     for (int lvl = 0; lvl <= max_depth; ++lvl) {
         if (c.valid && !NT_SKIP(128))
             for (int j = c.slot; j < nj; j += c.nslot)
-                if (f.depth[j] == lvl) fs_fk_vel_item<EPB, false>(f, j);
+                if (f.depth[j] == lvl) {
+                    fs_fk_vel_item<EPB, false>(f, j);
+                    if (!desc_free) fs_to_public_item(f, j);
+                }
         __syncthreads();
     }
     if (desc_free) {  // solver_featherstone.py:1006-1046
@@ -1365,9 +1380,11 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         }
     }
     NT_TICK(20);
-    if (c.valid)
-        for (int j = c.slot; j < nj; j += c.nslot) fs_to_public_item(f, j);
-    __syncthreads();
+    if (desc_free) {
+        if (c.valid)
+            for (int j = c.slot; j < nj; j += c.nslot) fs_to_public_item(f, j);
+        __syncthreads();
+    }
     NT_TICK(21);
 }
 

@@ -297,6 +297,7 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
         d.shape_mesh_count = h.put(mc);
         std::vector<float> pts(s.mesh_points, s.mesh_points + 3 * (size_t)s.mesh_point_count);
         d.mesh_points = h.put(pts);
+        d.mesh_vertex_count = s.mesh_point_count;
         std::vector<float> bounds((size_t)(ns + ng) * 6, 0.0f);
         for (int k = 0; k < ns + ng; ++k) {
             if (mc[k] <= 0) continue;
@@ -383,11 +384,22 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
         const int ntile = (int)la.size();
         // The reference writes analytic-primitive contacts in its first narrow-phase kernel and queues every other pair for the
         // GJK/MPR kernel (narrow_phase.py:642-655,1004-1014): device pairs are stored analytic first (stable partition)
+        // barrel cylinders (scale.z != 0, builder.py:7050-7089): their plane / sphere pairs have no fixed analytic route
+        // (narrow_phase.py:682-686,847) and are stored with the convex pairs; the kernel decides per environment and substep
+        std::vector<char> barrel(ns + ng, 0);
+        for (int l = 0; l < ns + ng; ++l) {
+            if (shape_type[l] != GEO_CYLINDER) continue;
+            const int id0 = l < ns ? L0 + l : gshape_id[l - ns];
+            barrel[l] = s.shape_scale[3 * (size_t)id0 + 2] != 0.0f;
+            for (int w = 1; l < ns && w < d.env_count; ++w)
+                if ((s.shape_scale[3 * ((size_t)id0 + (size_t)w * ns) + 2] != 0.0f) != (barrel[l] != 0))
+                    unsupported("heterogeneous worlds: a cylinder is a barrel in some worlds and straight in others");
+        }
         std::vector<int64_t> order;
         for (int pass = 0; pass < 2; ++pass)
             for (int p = 0; p < ntile; ++p) {
                 int ta = shape_type[la[p]], tb = shape_type[lb[p]];
-                bool an = analytic_pair(ta, tb);
+                bool an = analytic_pair(ta, tb) && !barrel[la[p]] && !barrel[lb[p]];
                 if (pass == 0 && !an && ((ta == GEO_PLANE && tb == GEO_PLANE) || !(convex_type(ta) && convex_type(tb))))
                     unsupported("a collision pair has no analytic path and is outside the convex (MPR/GJK) scope of this build");
                 if (an == (pass == 0)) { order.push_back(tile_pos[p]); pa.push_back(la[p]); pb.push_back(lb[p]); }

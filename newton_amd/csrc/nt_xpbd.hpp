@@ -319,7 +319,9 @@ NT_DI float angular_correction(float err, float derr, float wq_a, float wq_b, fl
 
 // ------------------------------------------------------------------------------------------------
 // where the per-contact correction records (CW_FLOATS rows per contact slot) live: in LDS (default), or -- for pair-heavy
-// scenes whose records do not fit the CU's LDS (nt_model.contact_scratch_in_hbm) -- in nt_contacts.cw, env-major in HBM
+// scenes whose records do not fit the CU's LDS (nt_model.contact_scratch_in_hbm) -- in nt_contacts.cw in HBM, one contiguous record
+// per (environment, slot): that tile runs ONE environment per workgroup, so the env-major SoA of the other buffers would put every
+// float of a record (and every slot of a pair) in its own cache line and DRAM page -- 35 lines per pair in the apply phase instead of 4
 // ------------------------------------------------------------------------------------------------
 // NC: record stride of the LDS copy (NC_CWX for the position solve, NC_CW for the restitution pass)
 struct CwLds {
@@ -328,7 +330,10 @@ struct CwLds {
 };
 struct CwHbm {
     template <int NC, int EPB>
-    static NT_DI float& at(const Ctx<EPB>& c, int comp, int ncs, int slot) { return c.a.ct.cw[c.g(comp, ncs, slot)]; }
+    static NT_DI float& at(const Ctx<EPB>& c, int comp, int ncs, int slot) {
+        static_assert(NC <= CW_FLOATS, "nt_contacts.cw holds CW_FLOATS floats per (environment, slot)");
+        return c.a.ct.cw[((size_t)c.env * ncs + slot) * NC + comp];
+    }
 };
 template <class CW, int NC, int EPB>
 NT_DI vec3 cw_v3(const Ctx<EPB>& c, int comp, int ncs, int slot) {

@@ -33,9 +33,22 @@ def compute_inertia_shape(geo_type, scale, density, src=None):
         Ia = mc * (0.25 * r * r + (1.0 / 12.0) * h * h) + ms * (0.4 * r * r + 0.375 * r * h + 0.25 * h * h)
         Ib = (mc * 0.5 + ms * 0.4) * r * r
         return m, np.zeros(3), np.diag([Ia, Ia, Ib])
+    if geo_type == GeoType.CYLINDER and sz != 0.0:
+        # barrel cylinder (geometry/inertia.py:166-185): solid of revolution of the arc profile, 32-point Gauss-Legendre in z
+        if sz < sy:
+            raise ValueError("barrel_radius must be zero or at least half_height")
+        nodes, wts = np.polynomial.legendre.leggauss(32)
+        z, weights = sy * nodes, sy * wts
+        end_offset = np.sqrt(sz * sz - sy * sy)
+        profile_offset = np.sqrt(np.maximum(sz * sz - z * z, 0.0))
+        radius_profile = sx + (sy * sy - z * z) / (profile_offset + end_offset)
+        r2 = radius_profile * radius_profile
+        r4 = r2 * r2
+        m = float(density * np.pi * np.dot(weights, r2))
+        Ia = float(0.5 * density * np.pi * np.dot(weights, r4))
+        Ir = float(density * np.pi * np.dot(weights, 0.25 * r4 + r2 * z * z))
+        return m, np.zeros(3), np.diag([Ir, Ir, Ia])
     if geo_type == GeoType.CYLINDER:
-        if sz != 0.0:
-            raise NotImplementedError("barrel cylinders are not supported by this builder subset")
         r, h = sx, 2.0 * sy
         m = density * np.pi * r * r * h
         Ir = 1.0 / 12.0 * m * (3.0 * r * r + h * h)

@@ -263,8 +263,21 @@ class EnvTemplate:
         # pair for the GJK/MPR kernel (narrow_phase.py:642-655,1004-1014), so in append order all analytic contacts
         # precede all convex ones.  Device pairs are stored in that order (stable partition); `pair_order` maps a
         # device pair index back to the per-env position in Model.shape_contact_pairs.
+        # Barrel cylinders (scale z = radius of the side arc, builder.py:7050-7089): a plane pair is analytic only while the cylinder
+        # rests on an end cap, a sphere pair never (narrow_phase.py:682-686,847) -- no fixed route, so they sit with the convex pairs
+        # (manifold slots) and the kernel decides per environment and substep.
+        def barrel(l):
+            if int(self.shape_type[l]) != GeoType.CYLINDER:
+                return False
+            z = scale_all[newton_id0(l) + (np.arange(E) * ns if l < ns else 0), 2] != 0.0
+            if not np.all(z == z.flat[0]):
+                raise NotImplementedError("heterogeneous worlds: a cylinder is a barrel in some worlds and straight in others")
+            return bool(z.flat[0])
+
+        is_barrel = np.array([barrel(l) for l in range(ns + self.ng)], dtype=bool)
+
         def analytic(a, b):
-            return pair_types_analytic(int(self.shape_type[a]), int(self.shape_type[b]))
+            return pair_types_analytic(int(self.shape_type[a]), int(self.shape_type[b])) and not (is_barrel[a] or is_barrel[b])
 
         convex_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE,
                         GeoType.CONVEX_MESH)
@@ -500,6 +513,7 @@ class DeviceModel:
         for k, v in self.mesh_tables.items():
             setattr(d, k, v.data_ptr())
         d.params_uniform = self._params_uniform
+        d.mesh_vertex_count = int(np.asarray(t.mesh_points).size // 3)
         choose_contact_scratch(self.lib, d)
         self.desc = d
         self._c_handle = None
@@ -515,8 +529,8 @@ class DeviceModel:
             self._c_handle = h
             cd = _lib.nt_model()
             C.memmove(C.byref(cd), self.lib.nt_model_get(h), C.sizeof(cd))
-            assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride) == \
-                (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride)
+            assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride, cd.mesh_vertex_count) == \
+                (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride, d.mesh_vertex_count)
             # pairs routed out of the tiles: the SDF legs read the Python mirror (t.sdf_pair ...), the kernels the C tables
             sp, kind, edges = c_sdf_pairs(self.lib, h)
             want_kind = np.where(t.sdf_pair_hydro, 1, np.where(t.sdf_pair_mesh_plane, 2, 0)).astype(np.uint8) if len(t.sdf_pair) else kind[:0]

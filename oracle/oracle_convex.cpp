@@ -112,19 +112,41 @@ vec3 support_map(const Geom& g, vec3 direction) {
             result = vec3(a, 0.0f, 0.0f);
         }
     } else if (g.type == GEO_CYLINDER) {
-        float radius = g.scale.x, half_height = g.scale.y;
+        float radius = g.scale.x, half_height = g.scale.y, barrel_radius = g.scale.z;
         vec3 dir_xy(direction.x, direction.y, 0.0f);
         float l2 = length_sq(dir_xy);
-        vec3 lateral;
-        if (l2 > eps) {
-            vec3 n_xy = dir_xy * support_rsqrt_rn(l2);
-            lateral = vec3(n_xy.x * radius, n_xy.y * radius, 0.0f);
+        if (barrel_radius == 0.0f) {
+            vec3 lateral;
+            if (l2 > eps) {
+                vec3 n_xy = dir_xy * support_rsqrt_rn(l2);
+                lateral = vec3(n_xy.x * radius, n_xy.y * radius, 0.0f);
+            } else {
+                lateral = vec3(radius, 0.0f, 0.0f);
+            }
+            if (direction.z > 0.0f) result = vec3(lateral.x, lateral.y, half_height);
+            else if (direction.z < 0.0f) result = vec3(lateral.x, lateral.y, -half_height);
+            else result = lateral;
         } else {
-            lateral = vec3(radius, 0.0f, 0.0f);
+            // barrel cylinder: the side profile is a circular arc of radius barrel_radius revolved about Z
+            // (support_function.py:284-305)
+            vec3 n_xy(1.0f, 0.0f, 0.0f);
+            if (l2 > eps) {
+                float dir_xy_len = std::sqrt(l2);
+                n_xy = dir_xy / dir_xy_len;
+            }
+            float direction_len = std::sqrt(l2 + direction.z * direction.z);
+            float support_z = 0.0f;
+            if (direction_len > eps) support_z = clampf(barrel_radius * direction.z / direction_len, -half_height, half_height);
+            float barrel_radius_sq = barrel_radius * barrel_radius;
+            float half_height_sq = half_height * half_height;
+            float support_z_sq = support_z * support_z;
+            float end_offset = std::sqrt(barrel_radius_sq - half_height_sq);
+            float support_offset = std::sqrt(fmaxw(barrel_radius_sq - support_z_sq, 0.0f));
+            float offset_sum = support_offset + end_offset;
+            float support_radius = radius;
+            if (offset_sum > eps) support_radius += (half_height_sq - support_z_sq) / offset_sum;
+            result = vec3(n_xy.x * support_radius, n_xy.y * support_radius, support_z);
         }
-        if (direction.z > 0.0f) result = vec3(lateral.x, lateral.y, half_height);
-        else if (direction.z < 0.0f) result = vec3(lateral.x, lateral.y, -half_height);
-        else result = lateral;
     } else if (g.type == GEO_CONE) {
         float radius = g.scale.x, half_height = g.scale.y;
         vec3 apex(0.0f, 0.0f, half_height);
@@ -1043,8 +1065,6 @@ int convex_pair_contacts(const o_model* m, int shape_a, int shape_b, const float
     if (is_infinite_plane_b) return 0;                          // cannot happen after type sorting
     // finite planes are rectangles with their own support map (support_function.py:334-345); meshes etc. are not restated
     if (!(P.ga.type == GEO_PLANE || supported_type(P.ga.type)) || !supported_type(P.gb.type)) return 0;
-    if (P.ga.type == GEO_CYLINDER && P.ga.scale.z != 0.0f) return 0;  // barrel cylinders: not restated
-    if (P.gb.type == GEO_CYLINDER && P.gb.scale.z != 0.0f) return 0;
     bind_mesh(m, shape_a, P.ga);
     bind_mesh(m, shape_b, P.gb);
     P.margin_a = geom_data[4 * shape_a + 3];

@@ -5,7 +5,9 @@ primitive narrow phase (create_narrow_phase_primitive_kernel, newton/_src/geomet
 manifold narrow phase (create_narrow_phase_kernel_gjk_mpr, :1017-1219) and the pipeline's contact writer (write_contact,
 collide.py:166-254), on the candidate pairs of the in-repo checker's broad phase.  tests/test_reference_vectors.py compares
 the checker's collide() (AABBs, contact ids, body-frame points, offsets, normals, margins, append order) with the record.
-Run from the repo root:  python tests/golden/make_collide_reference_vectors.py"""
+Run from the repo root:  python tests/golden/make_collide_reference_vectors.py            (collide_reference_vectors.npz)
+                         python tests/golden/make_collide_reference_vectors.py --barrel   (collide_barrel_reference_vectors.npz:
+                         the barrel-cylinder scenes of collide_cases.barrel_cases())"""
 import importlib
 import os
 import sys
@@ -103,7 +105,8 @@ def main():
     import oracle_bridge as ob
 
     blob = {}
-    for name, make in cc.cases().items():
+    barrel = "--barrel" in sys.argv  # the barrel-cylinder scenes live in their own record (collide_barrel_reference_vectors.npz)
+    for name, make in (cc.barrel_cases() if barrel else cc.cases()).items():
         model, body_q = make()
         orc = ob.Oracle(model)
         ct = orc.contacts()
@@ -115,7 +118,7 @@ def main():
         blob[f"{name}/body_q"] = np.asarray(body_q, np.float32)
         for k, v in res.items():
             blob[f"{name}/{k}"] = v
-    np.savez_compressed(os.path.join(HERE, "collide_reference_vectors.npz"), **blob)
+    np.savez_compressed(os.path.join(HERE, "collide_barrel_reference_vectors.npz" if barrel else "collide_reference_vectors.npz"), **blob)
     print("wrote", len(blob), "arrays")
 
 

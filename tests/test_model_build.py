@@ -3,6 +3,7 @@ from newton.Model's flat arrays, against the Python host logic that does the sam
 (newton_amd/model.py: EnvTemplate, pack_param_arrays, params_uniform) -- every table, on several scenes, in host memory
 (on_device = 0: no GPU needed).  The reference arrays it consumes are the Model attributes of newton/_src/sim/model.py:808-1364."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -40,7 +41,18 @@ def _scenes():
         "hydro_bin": lambda: hull_bin_scene(2, 5, seed=2, sdf=True, mu=0.5, shape_cfg=dict(gap=0.005), hydroelastic=True),
         "mesh_ground": lambda: _mesh_scene(3, ground_first=False),
         "mesh_ground_first": lambda: _mesh_scene(2, ground_first=True),
+        # barrel cylinders: their plane / sphere pairs have no fixed analytic route and sit with the convex pairs
+        "barrel_cylinders": lambda: _barrel_scene(),
     }
+
+
+def _barrel_scene():
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import collide_cases as cc
+
+    return cc.barrel_cases()["barrel_wide"]()[0]
 
 
 def _sdf_scene(*a, **k):
@@ -85,6 +97,9 @@ def test_c_helper_reproduces_the_python_descriptor(name):
             got = _arr(getattr(d, k), v.size, C.c_float)
             assert np.array_equal(got.view(np.int32), np.ascontiguousarray(v, dtype=np.float32).reshape(-1).view(np.int32)), k
         assert d.params_uniform == params_uniform(packed, t.env_count)
+        assert d.mesh_vertex_count == len(t.mesh_points)
+        if name == "barrel_cylinders":  # 7 overlapping pairs (5 of them convex by type, + barrel-sphere) and 5 barrels on the plane
+            assert (t.np, t.np_analytic) == (12, 0)
         order = np.zeros(t.np, dtype=np.int64)
         assert lib.nt_model_pair_order(h, order.ctypes.data_as(C.POINTER(C.c_int64))) == 0
         assert np.array_equal(order, np.asarray(t.tile_pair_index)[t.pair_order])  # positions in the world's shape_contact_pairs slice

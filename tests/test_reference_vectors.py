@@ -129,6 +129,32 @@ def test_checker_collide_reproduces_the_reference_collision_kernels(oracle_lib, 
     assert all(v <= 2e-6 for v in err.values()), err
 
 
+@pytest.mark.parametrize("name", ["barrel_wide", "barrel_tight"])
+def test_checker_collide_reproduces_the_reference_on_barrel_cylinders(oracle_lib, name):
+    """Barrel cylinders (support_function.py:284-305; plane route narrow_phase.py:682-686, sphere route :847,999): the record of
+    make_collide_reference_vectors.py --barrel (the reference's kernels, executed) against the checker, same append order."""
+    import collide_cases as cc
+    import oracle_bridge as ob
+
+    ref = np.load(os.path.join(HERE, "golden", "collide_barrel_reference_vectors.npz"))
+    model, _ = cc.barrel_cases()[name]()
+    body_q = ref[f"{name}/body_q"]
+    orc = ob.Oracle(model)
+    ct = orc.contacts()
+    pairs, lo, hi = orc.collide(body_q, ct)
+    assert np.array_equal(np.asarray(pairs, np.int32), ref[f"{name}/pairs"])
+    n = int(ref[f"{name}/count"][0])
+    assert int(ct.count[0]) == n and n > 0
+    assert 0 < int(ref[f"{name}/count_analytic"][0]) < n and len(ref[f"{name}/gjk_pairs"]) > 0  # both routes of the plane pairs occur
+    assert np.array_equal(ct.shape0[:n], ref[f"{name}/shape0"]) and np.array_equal(ct.shape1[:n], ref[f"{name}/shape1"])
+    finite = np.abs(ref[f"{name}/aabb_lower"]) < 1e5
+    err = {"aabb": max(np.abs(lo - ref[f"{name}/aabb_lower"])[finite].max(), np.abs(hi - ref[f"{name}/aabb_upper"])[finite].max())}
+    for k in ("point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1"):
+        err[k] = float(np.abs(getattr(ct, k)[:n] - ref[f"{name}/{k}"]).max())
+    print(name, "contacts", n, "max abs error vs the reference kernels:", {k: float("%.3g" % v) for k, v in err.items()})
+    assert all(v <= 2e-6 for v in err.values()), err
+
+
 @pytest.mark.parametrize("name", ["joint_zoo", "joint_zoo_free_root", "quadruped", "pendulum"])
 def test_checker_eval_fk_reproduces_the_reference(oracle_lib, name):
     """newton.eval_fk of the reference (articulation.py:500-573, executed on the stand-in) vs the checker's o_eval_fk and the

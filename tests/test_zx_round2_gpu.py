@@ -316,6 +316,43 @@ def test_hip_collide_against_reference_collision_vectors(name):
     assert all(v <= 1e-5 for v in err.values()), err
 
 
+@pytest.mark.parametrize("name", ["barrel_wide", "barrel_tight"])
+def test_hip_collide_against_reference_vectors_of_barrel_cylinders(name):
+    """Barrel cylinders on the device against the executed reference (make_collide_reference_vectors.py --barrel).  A plane pair of a
+    barrel is analytic only while it rests on an end cap (narrow_phase.py:682-686): the tile stores it with the convex pairs and
+    decides per substep, so its analytic contacts are exported inside the convex group -- compared pair by pair (the order INSIDE a
+    pair is the reference's); CollisionPipeline(deterministic=True) gives the reference's sorted order either way."""
+    import os
+    import sys
+
+    import torch
+
+    import newton_amd as nt
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import collide_cases as cc
+
+    ref = np.load(os.path.join(here, "golden", "collide_barrel_reference_vectors.npz"))
+    host, _ = cc.barrel_cases()[name]()
+    model = _to_device(host)
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    s = model.state()
+    s.body_q = torch.from_numpy(ref[f"{name}/body_q"])
+    pipe.collide(s, contacts)
+    torch.cuda.synchronize()
+    n = int(ref[f"{name}/count"][0])
+    assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == n
+    get = lambda k: getattr(contacts, "rigid_contact_" + k).cpu().numpy()[:n]  # noqa: E731
+    key = lambda a, b: np.lexsort((np.arange(n), b, a))  # noqa: E731  (stable: by pair, append order inside the pair)
+    mine, theirs = key(get("shape0"), get("shape1")), key(ref[f"{name}/shape0"], ref[f"{name}/shape1"])
+    assert np.array_equal(get("shape0")[mine], ref[f"{name}/shape0"][theirs]) and np.array_equal(get("shape1")[mine], ref[f"{name}/shape1"][theirs])
+    err = {k: float(np.abs(get(k)[mine] - ref[f"{name}/{k}"][theirs]).max()) for k in ("point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1")}
+    print(name, "HIP collide vs reference kernels (barrel cylinders):", {k: float("%.3g" % v) for k, v in err.items()})
+    assert all(v <= 1e-5 for v in err.values()), err
+
+
 def test_featherstone_rollout_with_a_mass_matrix_interval_is_the_step_loop():
     """update_mass_matrix_interval = 3: the fused rollout (substep index inside the launch) and the launch-by-launch loop
     rebuild the mass matrix on the same steps and agree bit for bit; interval 1 gives a different (fresher) result."""
