@@ -325,25 +325,31 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                 }
         }
         if constexpr (CVX) {
-            if (p >= m.np_analytic) {
-                ConvexContacts cc;
-                if (barrel_on_cap) {
-                    // the analytic plane-cylinder routine on the end cap, admitted like the primitive kernel admits (narrow_phase.py:791-797,
-                    // 872-955); the writer below is shared with the manifold's contacts
-                    Contacts4 k4;
-                    plane_cylinder(quat_rotate(Xa.q, vec3(0.0f, 0.0f, 1.0f)), Xa.p, Xb.p, quat_rotate(Xb.q, vec3(0.0f, 0.0f, 1.0f)), scale_b.x, scale_b.y, k4);
-                    cc.normal = k4.normal;
-                    cc.count = 0;
-                    const vec3 n = normalize(k4.normal);
-                    for (int i = 0; i < 4; ++i) {
-                        const float dist = k4.dist(i);
-                        if (dist < NT_MAXVAL) {
-                            const vec3 center = k4.pos(i);
-                            const vec3 aw = center - n * (0.5f * dist + 0.0f), bw = center + n * (0.5f * dist + 0.0f);
-                            if (dot(bw - aw, n) - (0.0f + 0.0f + margin_a + margin_b) <= gap_sum) cc.push(center, dist);
-                        }
-                    }
+            if (barrel_on_cap) {
+                // a barrel cylinder resting on an end cap: the analytic plane-cylinder routine, admitted like the primitive kernel admits
+                // (narrow_phase.py:791-797,872-955), written by this lane into the pair's manifold slots.  Kept apart from the convex
+                // branch below (one rolled loop, one writer): sharing its ConvexContacts record cost the convex rollouts 7 %
+                Contacts4 k4;
+                plane_cylinder(quat_rotate(Xa.q, vec3(0.0f, 0.0f, 1.0f)), Xa.p, Xb.p, quat_rotate(Xb.q, vec3(0.0f, 0.0f, 1.0f)), scale_b.x, scale_b.y, k4);
+                const vec3 n = normalize(k4.normal);
+#pragma nounroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dist = k4.dist(i);
+                    if (!(dist < NT_MAXVAL)) continue;
+                    const vec3 center = k4.pos(i);
+                    const vec3 aw = center - n * (0.5f * dist + 0.0f), bw = center + n * (0.5f * dist + 0.0f);
+                    if (!(dot(bw - aw, n) - (0.0f + 0.0f + margin_a + margin_b) <= gap_sum)) continue;
+                    write_contact_slot(c, p * cpp + nvalid, sa, sb, center, n, dist, 0.0f, 0.0f, margin_a, margin_b);
+                    nvalid += 1;
                 }
+                for (int i = nvalid; i < cpp; ++i) {
+                    size_t gi = (size_t)(p * cpp + i) * c.ES + c.env;
+                    ct.shape0[gi] = -1;
+                    ct.shape1[gi] = -1;
+                }
+            }
+            if (p >= m.np_analytic && !barrel_on_cap) {
+                ConvexContacts cc;
                 Geom ga, gb;
                 ga.type = ta; ga.scale = scale_a;
                 gb.type = tb; gb.scale = scale_b;
@@ -366,7 +372,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                 PolyRef poly;  // manifold polygon scratch: per convex pair, or (pair-heavy tile) per lane
                 poly.base = &c.lds[(c.L.poly + 20 * (c.big ? c.slot : p - m.np_analytic)) * Ctx<EPB>::N + c.e];
                 poly.stride = Ctx<EPB>::N;
-                if (!barrel_on_cap) convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
+                convex_pair(ga, gb, Xa, Xb, margin_a, margin_b, gap_sum, lob, hib, poly, cc);
                 float ra = (ta == GEO_SPHERE || ta == GEO_CAPSULE) ? scale_a.x : 0.0f;
                 float rb = (tb == GEO_SPHERE || tb == GEO_CAPSULE) ? scale_b.x : 0.0f;
                 vec3 n = normalize(cc.normal);

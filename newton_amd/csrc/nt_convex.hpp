@@ -75,6 +75,32 @@ NT_DEV vec3 support_map_plane(vec3 half, vec3 direction) {
     return vec3(sx * half.x, sy * half.y, 0.0f);
 }
 
+// barrel cylinder (support_function.py:284-305): the side profile is a circular arc of radius barrel_radius about the axis; the
+// support point sits where the arc's normal matches the direction, clamped to the end caps
+#ifdef NT_BARREL_NOINLINE  // measurement builds: the branch as a call (registers of the MPR loops untouched by it)
+__device__ __attribute__((noinline))
+#else
+NT_DEV
+#endif
+vec3 support_map_barrel(float radius, float half_height, float barrel_radius, vec3 direction) {
+    const float eps = 1.0e-12f;
+    vec3 dir_xy(direction.x, direction.y, 0.0f);
+    float l2 = length_sq(dir_xy);
+    vec3 n_xy(1.0f, 0.0f, 0.0f);
+    if (l2 > eps) n_xy = dir_xy / sqrtf(l2);
+    float direction_len = sqrtf(l2 + direction.z * direction.z);
+    float support_z = 0.0f;
+    if (direction_len > eps) support_z = clampf(barrel_radius * direction.z / direction_len, -half_height, half_height);
+    float barrel_radius_sq = barrel_radius * barrel_radius, half_height_sq = half_height * half_height;
+    float support_z_sq = support_z * support_z;
+    float end_offset = sqrtf(barrel_radius_sq - half_height_sq);
+    float support_offset = sqrtf(fmaxw(barrel_radius_sq - support_z_sq, 0.0f));
+    float offset_sum = support_offset + end_offset;
+    float support_radius = radius;
+    if (offset_sum > eps) support_radius += (half_height_sq - support_z_sq) / offset_sum;
+    return vec3(n_xy.x * support_radius, n_xy.y * support_radius, support_z);
+}
+
 // support_function.py:131-350
 NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
@@ -154,21 +180,7 @@ NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
             else if (direction.z < 0.0f) result = vec3(lateral.x, lateral.y, -half_height);
             else result = lateral;
         } else {
-            // barrel cylinder (support_function.py:284-305): the side profile is a circular arc of radius barrel_radius about the
-            // axis; the support point sits where the arc's normal matches the direction, clamped to the end caps
-            vec3 n_xy(1.0f, 0.0f, 0.0f);
-            if (l2 > eps) n_xy = dir_xy / sqrtf(l2);
-            float direction_len = sqrtf(l2 + direction.z * direction.z);
-            float support_z = 0.0f;
-            if (direction_len > eps) support_z = clampf(barrel_radius * direction.z / direction_len, -half_height, half_height);
-            float barrel_radius_sq = barrel_radius * barrel_radius, half_height_sq = half_height * half_height;
-            float support_z_sq = support_z * support_z;
-            float end_offset = sqrtf(barrel_radius_sq - half_height_sq);
-            float support_offset = sqrtf(fmaxw(barrel_radius_sq - support_z_sq, 0.0f));
-            float offset_sum = support_offset + end_offset;
-            float support_radius = radius;
-            if (offset_sum > eps) support_radius += (half_height_sq - support_z_sq) / offset_sum;
-            result = vec3(n_xy.x * support_radius, n_xy.y * support_radius, support_z);
+            result = support_map_barrel(radius, half_height, barrel_radius, direction);
         }
     } else if (g.type == GEO_CONE) {
         float radius = g.scale.x, half_height = g.scale.y;

@@ -274,6 +274,9 @@ int pick_epb(const nt_model& m, int requested, bool restitution = false) {
 template <typename K>
 nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false, bool uni = false) {
     // NT_TILE_LDS_MESH moves no layout row (the vertex copy sits behind the topology): granted last, when the rest is settled
+#ifdef NT_NO_LDS_MESH  // measurement builds: hull vertices stay in global memory
+    a.tile_opts &= ~NT_TILE_LDS_MESH;
+#endif
     const bool want_mesh = (a.tile_opts & NT_TILE_LDS_MESH) && a.m.contact_scratch_in_hbm && a.m.mesh_vertex_count > 0 && a.m.mesh_points && !semi;
     int tile_opts = a.tile_opts & ~NT_TILE_LDS_MESH;
     auto tile_bytes = [&](int opts) {

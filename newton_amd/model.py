@@ -529,8 +529,9 @@ class DeviceModel:
             self._c_handle = h
             cd = _lib.nt_model()
             C.memmove(C.byref(cd), self.lib.nt_model_get(h), C.sizeof(cd))
-            assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride, cd.mesh_vertex_count) == \
-                (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride, d.mesh_vertex_count)
+            assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride) == \
+                (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride)
+            assert cd.mesh_vertex_count in (0, d.mesh_vertex_count)  # (0: an older library; the vertices then stay in global memory)
             # pairs routed out of the tiles: the SDF legs read the Python mirror (t.sdf_pair ...), the kernels the C tables
             sp, kind, edges = c_sdf_pairs(self.lib, h)
             want_kind = np.where(t.sdf_pair_hydro, 1, np.where(t.sdf_pair_mesh_plane, 2, 0)).astype(np.uint8) if len(t.sdf_pair) else kind[:0]
