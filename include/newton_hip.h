@@ -77,9 +77,6 @@ typedef struct {
     int32_t params_uniform; /* 1: body_param / joint_param / dof_param / shape_param hold the same values in every environment
                             (replicated worlds, newton.ModelBuilder.replicate without per-world randomisation).  The XPBD rollout
                             then keeps ONE block-shared copy per workgroup in LDS; 0 is always valid */
-    int32_t mesh_vertex_count; /* V: vertices in mesh_points (occupies what used to be alignment padding).  The pair-heavy tile stages
-                            the hull vertices in LDS when they fit next to the environment (support-map scans then read LDS instead of
-                            chasing global loads); 0 is always valid (vertices stay in global memory) */
     /* topology, int32, env-uniform */
     const int32_t* body_flags;          /* [nb]   BodyFlags */
     const int32_t* joint_type;          /* [nj]   JointType */

@@ -33,7 +33,7 @@ class nt_model(C.Structure):
         ("cpp", C.c_int32),
         ("np_analytic", C.c_int32), ("na", C.c_int32), ("max_art_dofs", C.c_int32), ("shape_local0", C.c_int32),
         ("contact_scratch_in_hbm", C.c_int32),
-        ("params_uniform", C.c_int32), ("mesh_vertex_count", C.c_int32),
+        ("params_uniform", C.c_int32),
         ("body_flags", C.c_void_p), ("joint_type", C.c_void_p), ("joint_enabled", C.c_void_p),
         ("joint_parent", C.c_void_p), ("joint_child", C.c_void_p), ("joint_q_start", C.c_void_p),
         ("joint_qd_start", C.c_void_p), ("joint_tq_start", C.c_void_p), ("joint_lin_count", C.c_void_p),

@@ -356,14 +356,14 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                 if (ta == GEO_PLANE) ga.scale = vec3(scale_a.x * 0.5f, scale_a.y * 0.5f, 0.0f);
                 if (tb == GEO_PLANE) gb.scale = vec3(scale_b.x * 0.5f, scale_b.y * 0.5f, 0.0f);
                 if (ta == GEO_CONVEX_MESH) {
-                    ga.points = c.mesh_pts + 3 * c.T.shape_mesh_start[sa];
+                    ga.points = m.mesh_points + 3 * c.T.shape_mesh_start[sa];
                     ga.count = c.T.shape_mesh_count[sa];
                     const float* mb = m.shape_mesh_bounds + 6 * sa;
                     ga.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)) +
                                         vmax(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_a), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_a)));
                 }
                 if (tb == GEO_CONVEX_MESH) {
-                    gb.points = c.mesh_pts + 3 * c.T.shape_mesh_start[sb];
+                    gb.points = m.mesh_points + 3 * c.T.shape_mesh_start[sb];
                     gb.count = c.T.shape_mesh_count[sb];
                     const float* mb = m.shape_mesh_bounds + 6 * sb;
                     gb.center = 0.5f * (vmin(cw_mul(vec3(mb[0], mb[1], mb[2]), scale_b), cw_mul(vec3(mb[3], mb[4], mb[5]), scale_b)) +

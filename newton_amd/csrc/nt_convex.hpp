@@ -75,14 +75,49 @@ NT_DEV vec3 support_map_plane(vec3 half, vec3 direction) {
     return vec3(sx * half.x, sy * half.y, 0.0f);
 }
 
-// barrel cylinder (support_function.py:284-305): the side profile is a circular arc of radius barrel_radius about the axis; the
-// support point sits where the arc's normal matches the direction, clamped to the end caps
-#ifdef NT_BARREL_NOINLINE  // measurement builds: the branch as a call (registers of the MPR loops untouched by it)
+// support_function.py:152-171: furthest vertex of a convex hull; ties keep the first one.
+// NT_HULL_BATCH vertices per round: their loads are issued together (one memory round trip per round instead of one per vertex -- the
+// scan is a chain of dependent global loads otherwise); the comparisons stay in ascending vertex order, so the first furthest vertex
+// wins as in the serial loop.  Rounds past the end re-read the last vertex: its dot product cannot beat the maximum it already
+// entered.  The winner's coordinates travel with the maximum (no reload by index at the end).
+#ifdef NT_HULL_NOINLINE  // measurement builds: the scan as a call (its 24 vertex registers out of the MPR loops of box pairs)
 __device__ __attribute__((noinline))
 #else
 NT_DEV
 #endif
-vec3 support_map_barrel(float radius, float half_height, float barrel_radius, vec3 direction) {
+vec3 support_map_hull(const float* points, int count, vec3 scale, vec3 direction) {
+    vec3 result(0.0f);
+    vec3 scaled_dir = cw_mul(direction, scale);
+    float max_dot = -1.0e10f;
+    vec3 best;
+    if (count > 0) best = vec3(points[0], points[1], points[2]);  // best_idx = 0 unless a vertex beats -1e10
+    const int last = count - 1;
+    for (int i0 = 0; i0 < count; i0 += NT_HULL_BATCH) {
+        vec3 p[NT_HULL_BATCH];
+#pragma unroll
+        for (int q = 0; q < NT_HULL_BATCH; ++q) {
+            const int i = imin(i0 + q, last);
+            p[q] = vec3(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+        }
+#pragma unroll
+        for (int q = 0; q < NT_HULL_BATCH; ++q) {
+            float dot_val = dot(p[q], scaled_dir);
+            if (dot_val > max_dot) {
+                max_dot = dot_val;
+                best = p[q];
+            }
+        }
+    }
+    if (count > 0) result = cw_mul(best, scale);
+    return result;
+}
+
+// barrel cylinder (support_function.py:284-305): the side profile is a circular arc of radius barrel_radius about the axis; the
+// support point sits where the arc's normal matches the direction, clamped to the end caps
+// A CALL, not inlined: its three IEEE square roots and divisions inlined into every support query of the MPR / GJK / manifold loops
+// cost the convex rollouts 10 % (592 instead of 256 bytes of scratch per lane; profiles/r05K_ab.txt) -- shapes that are not barrels
+// never take the branch.
+__device__ __attribute__((noinline)) vec3 support_map_barrel(float radius, float half_height, float barrel_radius, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 dir_xy(direction.x, direction.y, 0.0f);
     float l2 = length_sq(dir_xy);
@@ -101,56 +136,29 @@ vec3 support_map_barrel(float radius, float half_height, float barrel_radius, ve
     return vec3(n_xy.x * support_radius, n_xy.y * support_radius, support_z);
 }
 
-// support_function.py:131-350
-NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
+// the curved primitives of support_function.py:173-350 (sphere, capsule, ellipsoid, cylinder, cone)
+#ifdef NT_SUPPORT_REST_NOINLINE  // measurement builds: a call (box pairs never take it)
+__device__ __attribute__((noinline))
+#else
+NT_DEV
+#endif
+vec3 support_map_rest(int type, vec3 scale, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
-    if (g.type == GEO_PLANE) return support_map_plane(g.scale, direction);
-    if (g.type == GEO_CONVEX_MESH) {
-        // support_function.py:152-171: furthest vertex; ties keep the first one
-        // NT_HULL_BATCH vertices per round: their loads are issued together (one memory round trip per round instead of one per
-        // vertex -- the scan is a chain of dependent global loads otherwise, and it is most of a hull pair's MPR / manifold time);
-        // the comparisons stay in ascending vertex order, so the first furthest vertex wins as in the serial loop.  Rounds past
-        // the end re-read the last vertex: its dot product cannot beat the maximum it already entered.  The winner's
-        // coordinates travel with the maximum (no reload by index at the end).
-        vec3 scaled_dir = cw_mul(direction, g.scale);
-        float max_dot = -1.0e10f;
-        vec3 best;
-        if (g.count > 0) best = vec3(g.points[0], g.points[1], g.points[2]);  // best_idx = 0 unless a vertex beats -1e10
-        const int last = g.count - 1;
-        for (int i0 = 0; i0 < g.count; i0 += NT_HULL_BATCH) {
-            vec3 p[NT_HULL_BATCH];
-#pragma unroll
-            for (int q = 0; q < NT_HULL_BATCH; ++q) {
-                const int i = imin(i0 + q, last);
-                p[q] = vec3(g.points[3 * i], g.points[3 * i + 1], g.points[3 * i + 2]);
-            }
-#pragma unroll
-            for (int q = 0; q < NT_HULL_BATCH; ++q) {
-                float dot_val = dot(p[q], scaled_dir);
-                if (dot_val > max_dot) {
-                    max_dot = dot_val;
-                    best = p[q];
-                }
-            }
-        }
-        if (g.count > 0) result = cw_mul(best, g.scale);
-    } else if (g.type == GEO_BOX) {
-        result = support_map_box(g, direction);
-    } else if (g.type == GEO_SPHERE) {
-        float radius = g.scale.x;
+    if (type == GEO_SPHERE) {
+        float radius = scale.x;
         float l2 = length_sq(direction);
         vec3 n = l2 > eps ? direction * support_rsqrt_rn(l2) : vec3(1.0f, 0.0f, 0.0f);
         result = n * radius;
-    } else if (g.type == GEO_CAPSULE) {
-        float radius = g.scale.x, half_height = g.scale.y;
+    } else if (type == GEO_CAPSULE) {
+        float radius = scale.x, half_height = scale.y;
         float l2 = length_sq(direction);
         vec3 n = l2 > eps ? direction * support_rsqrt_rn(l2) : vec3(1.0f, 0.0f, 0.0f);
         result = n * radius;
         if (direction.z >= 0.0f) result = result + vec3(0.0f, 0.0f, half_height);
         else result = result + vec3(0.0f, 0.0f, -half_height);
-    } else if (g.type == GEO_ELLIPSOID) {
-        float a = g.scale.x, b = g.scale.y, c = g.scale.z;
+    } else if (type == GEO_ELLIPSOID) {
+        float a = scale.x, b = scale.y, c = scale.z;
         float l2 = length_sq(direction);
         if (l2 > eps) {
             float adx = a * direction.x, bdy = b * direction.y, cdz = c * direction.z;
@@ -164,8 +172,8 @@ NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
         } else {
             result = vec3(a, 0.0f, 0.0f);
         }
-    } else if (g.type == GEO_CYLINDER) {
-        float radius = g.scale.x, half_height = g.scale.y, barrel_radius = g.scale.z;
+    } else if (type == GEO_CYLINDER) {
+        float radius = scale.x, half_height = scale.y, barrel_radius = scale.z;
         vec3 dir_xy(direction.x, direction.y, 0.0f);
         float l2 = length_sq(dir_xy);
         if (barrel_radius == 0.0f) {
@@ -182,8 +190,8 @@ NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
         } else {
             result = support_map_barrel(radius, half_height, barrel_radius, direction);
         }
-    } else if (g.type == GEO_CONE) {
-        float radius = g.scale.x, half_height = g.scale.y;
+    } else if (type == GEO_CONE) {
+        float radius = scale.x, half_height = scale.y;
         vec3 apex(0.0f, 0.0f, half_height);
         vec3 dir_xy(direction.x, direction.y, 0.0f);
         float dir_xy_len = length(dir_xy);
@@ -201,6 +209,14 @@ NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
         }
     }
     return result;
+}
+
+// support_function.py:131-350
+NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
+    if (g.type == GEO_PLANE) return support_map_plane(g.scale, direction);
+    if (g.type == GEO_CONVEX_MESH) return support_map_hull(g.points, g.count, g.scale, direction);
+    if (g.type == GEO_BOX) return support_map_box(g, direction);
+    return support_map_rest(g.type, g.scale, direction);
 }
 
 // create_shape_support_function(center_ties=True), support_function.py:399-431

@@ -12,7 +12,6 @@ struct Ctx {
     Topo T;
     float* lds;
     float* up;  // UNI: the block-shared parameter copy [L.uni_floats], behind the topology
-    const float* mesh_pts;  // hull vertex table [V][3]: nt_model.mesh_points, or its LDS copy (NT_TILE_LDS_MESH, pair-heavy tile)
     LdsLayout L;
     int e, slot, env, nslot;
     int tslot;  // start of the item loop of phases with fewer items than slot-threads.  Identity: dealing consecutive items to
@@ -102,19 +101,11 @@ struct Ctx {
             }
         }
         up = reinterpret_cast<float*>(ti + topo_ints(m));
-        mesh_pts = m.mesh_points;
-        if (big_ && (a.tile_opts & NT_TILE_LDS_MESH)) {
-            // every lane of this tile works a different hull pair, and a support-map scan is a chain of vertex fetches: from LDS a
-            // round costs ~70 cycles instead of an L2 round trip (published by the barrier that follows the constructor)
-            float* mp = up + L.uni_floats;
-            for (int i = threadIdx.x; i < 3 * m.mesh_vertex_count; i += blockDim.x) mp[i] = m.mesh_points[i];
-            mesh_pts = mp;
-        }
     }
     // the same lane seen from the other arithmetic namespace (ieee::Ctx <-> fused::Ctx): no staging, every member copied
     template <class OtherCtx>
     NT_DI explicit Ctx(const OtherCtx& o, int /*tag*/)
-        : a(o.a), T(o.T), lds(o.lds), up(o.up), mesh_pts(o.mesh_pts), L(o.L), e(o.e), slot(o.slot), env(o.env), nslot(o.nslot), tslot(o.tslot),
+        : a(o.a), T(o.T), lds(o.lds), up(o.up), L(o.L), e(o.e), slot(o.slot), env(o.env), nslot(o.nslot), tslot(o.tslot),
           pose_in_off(o.pose_in_off), lane_split(o.lane_split), gworld_ready(o.gworld_ready), lds_records(o.lds_records), hbm_out(o.hbm_out), big(o.big),
           ES(o.ES), valid(o.valid) {}
     // LDS element (comp, s) of a slot-major field.  `n` (the slot count of the [comp][n] HBM twin) is not needed here; the

@@ -273,12 +273,7 @@ int pick_epb(const nt_model& m, int requested, bool restitution = false) {
 // the CU, and the kernel sees what was granted
 template <typename K>
 nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false, bool uni = false) {
-    // NT_TILE_LDS_MESH moves no layout row (the vertex copy sits behind the topology): granted last, when the rest is settled
-#ifdef NT_NO_LDS_MESH  // measurement builds: hull vertices stay in global memory
-    a.tile_opts &= ~NT_TILE_LDS_MESH;
-#endif
-    const bool want_mesh = (a.tile_opts & NT_TILE_LDS_MESH) && a.m.contact_scratch_in_hbm && a.m.mesh_vertex_count > 0 && a.m.mesh_points && !semi;
-    int tile_opts = a.tile_opts & ~NT_TILE_LDS_MESH;
+    int tile_opts = a.tile_opts;
     auto tile_bytes = [&](int opts) {
         LdsLayout Lo = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni, opts);
         return (size_t)Lo.rows_per_env * 4 * epb + (size_t)topo_ints(a.m) * 4 + (size_t)Lo.uni_floats * 4;
@@ -306,10 +301,6 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
     int threads = ((nslot * epb + 63) / 64) * 64;
     size_t lds_bytes = (size_t)(semi ? L.rows_semi : L.rows_per_env) * 4 * epb + (size_t)topo_ints(a.m) * 4 + (size_t)L.uni_floats * 4;
     if (lds_bytes > LDS_BYTES_PER_CU) return NT_ERR_UNSUPPORTED;
-    if (want_mesh && lds_bytes + 12 * (size_t)a.m.mesh_vertex_count <= LDS_BYTES_PER_CU) {
-        a.tile_opts |= NT_TILE_LDS_MESH;
-        lds_bytes += 12 * (size_t)a.m.mesh_vertex_count;
-    }
     int blocks = (a.m.env_count + epb - 1) / epb;
     if (lds_bytes > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
@@ -464,7 +455,6 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
     a.m = *m;
     a.s_in = *s;
     a.ct = *c;
-    a.tile_opts = NT_TILE_LDS_MESH;  // (request: the pair-heavy tile stages the hull vertices in LDS when they fit)
     int epb = pick_epb(*m, p ? p->envs_per_block : 0);
     if (!epb) return NT_ERR_UNSUPPORTED;
     if (m->np == 0) return NT_DISPATCH_EPB(shapes_export_kernel, a, epb, (hipStream_t)stream);  // every pair lives outside the tiles
@@ -527,7 +517,7 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
     a.angular_damping = p->angular_damping;
     a.dt = dt;
     a.substeps = substeps;
-    a.tile_opts = NT_TILE_POSE_SNAPSHOT | NT_TILE_LDS_RECORDS | NT_TILE_LDS_MESH;  // (request; launch() grants what the tile has room for)
+    a.tile_opts = NT_TILE_POSE_SNAPSHOT | NT_TILE_LDS_RECORDS;  // (request; launch() grants what the tile has room for)
     const bool rest = xpbd_keeps_prestep_state(*p);
     int epb = pick_epb(*m, cp ? cp->envs_per_block : 0, rest);
     if (!epb) return NT_ERR_UNSUPPORTED;

@@ -108,8 +108,6 @@ __host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_mode
 // opts: NT_TILE_* bits the launch code granted (KArgs::tile_opts; only the fused XPBD rollout asks for any)
 constexpr int NT_TILE_POSE_SNAPSHOT = 1;  // keep the substep's incoming body poses (L.xiq) so that integrate_bodies can run beside the pair phase
 constexpr int NT_TILE_LDS_RECORDS = 2;    // the contact records of a fused rollout live in LDS (L.cr); Contacts in HBM get the last substep's only
-constexpr int NT_TILE_LDS_MESH = 4;       // pair-heavy tile: the hull vertex table (nt_model.mesh_points) is staged in LDS behind the topology
-                                          // (kernels that collide ask; no layout row moves: the copy sits behind everything else)
 __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false,
                                                  const bool uni = false, const bool live_list = true, const int opts = 0) {
     LdsLayout L;

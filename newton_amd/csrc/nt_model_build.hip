@@ -297,7 +297,6 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
         d.shape_mesh_count = h.put(mc);
         std::vector<float> pts(s.mesh_points, s.mesh_points + 3 * (size_t)s.mesh_point_count);
         d.mesh_points = h.put(pts);
-        d.mesh_vertex_count = s.mesh_point_count;
         std::vector<float> bounds((size_t)(ns + ng) * 6, 0.0f);
         for (int k = 0; k < ns + ng; ++k) {
             if (mc[k] <= 0) continue;

@@ -513,7 +513,6 @@ class DeviceModel:
         for k, v in self.mesh_tables.items():
             setattr(d, k, v.data_ptr())
         d.params_uniform = self._params_uniform
-        d.mesh_vertex_count = int(np.asarray(t.mesh_points).size // 3)
         choose_contact_scratch(self.lib, d)
         self.desc = d
         self._c_handle = None
@@ -531,7 +530,6 @@ class DeviceModel:
             C.memmove(C.byref(cd), self.lib.nt_model_get(h), C.sizeof(cd))
             assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride) == \
                 (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride)
-            assert cd.mesh_vertex_count in (0, d.mesh_vertex_count)  # (0: an older library; the vertices then stay in global memory)
             # pairs routed out of the tiles: the SDF legs read the Python mirror (t.sdf_pair ...), the kernels the C tables
             sp, kind, edges = c_sdf_pairs(self.lib, h)
             want_kind = np.where(t.sdf_pair_hydro, 1, np.where(t.sdf_pair_mesh_plane, 2, 0)).astype(np.uint8) if len(t.sdf_pair) else kind[:0]

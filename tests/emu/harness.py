@@ -70,7 +70,6 @@ class EmuModel:
         self.keep["mesh_points"], self.keep["shape_mesh_bounds"] = f32(t.mesh_points), f32(t.shape_mesh_bounds)
         packed = pack_param_arrays(model, t)
         d.params_uniform = params_uniform(packed, t.env_count)
-        d.mesh_vertex_count = int(np.asarray(t.mesh_points).size // 3)
         for k, v in packed.items():
             self.keep[k] = f32(v)
         for k, v in self.keep.items():

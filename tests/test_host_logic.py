@@ -126,7 +126,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.nt_build_info()
     assert lib.nt_error_string(0) == b"ok"
     # struct layouts agree with the header (field count + size)
-    assert C.sizeof(_lib.nt_model) == 18 * 4 + 32 * 8  # 18 int32 and 32 pointers
+    assert C.sizeof(_lib.nt_model) == 17 * 4 + 4 + 32 * 8  # 17 int32 (+ 4 B alignment pad) and 32 pointers
     m = _lib.nt_model()
     m.nb, m.nj, m.np, m.ns = 13, 13, 13, 13
     m.nd, m.ntq, m.cpp, m.np_analytic = 18, 18, 4, 13

@@ -97,7 +97,6 @@ def test_c_helper_reproduces_the_python_descriptor(name):
             got = _arr(getattr(d, k), v.size, C.c_float)
             assert np.array_equal(got.view(np.int32), np.ascontiguousarray(v, dtype=np.float32).reshape(-1).view(np.int32)), k
         assert d.params_uniform == params_uniform(packed, t.env_count)
-        assert d.mesh_vertex_count == len(t.mesh_points)
         if name == "barrel_cylinders":  # 7 overlapping pairs (5 of them convex by type, + barrel-sphere) and 5 barrels on the plane
             assert (t.np, t.np_analytic) == (12, 0)
         order = np.zeros(t.np, dtype=np.int64)
