@@ -470,15 +470,15 @@ NT_DI void fs_body_force_item(const FsCtx<EPB>& f, int b, bool forces_are_zero) 
     c.st_lv3(f.F.bfx, 3, nb, b, t0);
 }
 
-// eval_rigid_tau for one joint (kernels.py:1320-1419); children of the joint's body were processed one level deeper
+// eval_rigid_tau (kernels.py:1320-1419) in two parts.  (1) The subtree wrench of one joint, deepest level first: children of the
+// joint's body were processed one level deeper.  (2) fs_tau_dof_item: the projection on the motion subspace + drives, one lane per DOF
+// once every wrench is final -- the six dofs of a floating base no longer queue on their joint's lane inside the level sweep.
 template <int EPB>
 NT_DI void fs_tau_item(const FsCtx<EPB>& f, int j) {
     const Ctx<EPB>& c = f.c;
     const nt_model& m = c.a.m;
-    const int nb = m.nb, nd = m.nd;
-    const int type = c.T.joint_type[j], child = c.T.joint_child[j];
-    const int dof_start = c.T.joint_qd_start[j], coord_start = c.T.joint_q_start[j], tq_start = c.T.joint_tq_start[j];
-    const int lin = c.T.joint_lin_count[j], ang = c.T.joint_ang_count[j];
+    const int nb = m.nb;
+    const int child = c.T.joint_child[j];
     // body_ft_s[child]: the reference walks joints in descending index and accumulates into the parent
     spatial f_t_s;
     for (int w = f.words - 1; w >= 0; --w) {  // children in descending joint order, straight from the bit mask
@@ -494,27 +494,27 @@ NT_DI void fs_tau_item(const FsCtx<EPB>& f, int j) {
     spatial f_ext(-force, -(torque_com + cross(x_com_s, force)));
     spatial f_s = f.sp6(f.F.fs, nb, child) + f_t_s + f_ext;
     f.st6(f.F.ft, nb, j, f_s);
-    auto sdot = [&](int d) {
-        spatial S = f.sp6(f.F.S, nd, d);
-        float s = 0.0f;
+}
+template <int EPB>
+NT_DI void fs_tau_dof_item(const FsCtx<EPB>& f, int d) {
+    const Ctx<EPB>& c = f.c;
+    const nt_model& m = c.a.m;
+    const int nb = m.nb, nd = m.nd;
+    const int j = f.dof_joint[d];
+    const int type = c.T.joint_type[j];
+    const int i = d - c.T.joint_qd_start[j];
+    const spatial f_s = f.sp6(f.F.ft, nb, j), S = f.sp6(f.F.S, nd, d);
+    float sdot = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s += fs_sget(S, i) * fs_sget(f_s, i);
-        return s;
-    };
+    for (int r = 0; r < 6; ++r) sdot += fs_sget(S, r) * fs_sget(f_s, r);
     if (type == JT_BALL) {
-        for (int i = 0; i < 3; ++i) {
-            int d = dof_start + i;
-            float passive_f = -c.dof(DP_DAMPING, d) * f.f(f.F.qdi, d);
-            f.f(f.F.tau, d) = -sdot(d) + f.f(f.F.jfi, d) + passive_f;
-        }
+        float passive_f = -c.dof(DP_DAMPING, d) * f.f(f.F.qdi, d);
+        f.f(f.F.tau, d) = -sdot + f.f(f.F.jfi, d) + passive_f;
     } else if (type == JT_FREE || type == JT_DISTANCE) {
-        for (int i = 0; i < 6; ++i) f.f(f.F.tau, dof_start + i) = -sdot(dof_start + i) + f.f(f.F.jfi, dof_start + i);
+        f.f(f.F.tau, d) = -sdot + f.f(f.F.jfi, d);
     } else if (type == JT_PRISMATIC || type == JT_REVOLUTE || type == JT_D6) {
-        for (int i = 0; i < lin + ang; ++i) {
-            int d = dof_start + i;
-            float drive_f = si_dof_force(c, d, tq_start + i, f.f(f.F.jq, coord_start + i), f.f(f.F.qdi, d));
-            f.f(f.F.tau, d) = -sdot(d) + drive_f + f.f(f.F.jfi, d);
-        }
+        float drive_f = si_dof_force(c, d, c.T.joint_tq_start[j] + i, f.f(f.F.jq, c.T.joint_q_start[j] + i), f.f(f.F.qdi, d));
+        f.f(f.F.tau, d) = -sdot + drive_f + f.f(f.F.jfi, d);
     }
 }
 
@@ -1283,6 +1283,9 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
     const bool update_mass = fs_update_mass(c, substep);
     float* cache = a.fp.mass_matrix_cache;
     const bool tree = a.fp.dense_mass_matrix == 0 && f.tree_ok;  // block-uniform
+    // eval_rigid_tau, part 2: one lane per dof, in the barrier interval of the mass-matrix build (tau is first read by the solve)
+    if (c.valid && !NT_SKIP(8))
+        for (int d = c.slot; d < m.nd; d += c.nslot) fs_tau_dof_item(f, d);
     if (update_mass && tree) {
         if (c.valid && !NT_SKIP(16))
             for (int i = c.slot; i < nj * 36; i += c.nslot) fs_Ic_item(f, i);

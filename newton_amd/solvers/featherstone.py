@@ -97,9 +97,21 @@ class SolverFeatherstone(SolverBase):
             if not hasattr(self, "_control"):
                 self._control = self.model.control()
             control = self._control
-        if getattr(contacts, "_sdf_leg", None) is not None:
-            raise NotImplementedError("SolverFeatherstone.rollout: models with SDF contact pairs step launch by launch "
-                                      "(pipeline.collide + solver.step)")
+        leg = getattr(contacts, "_sdf_leg", None)
+        if leg is not None:
+            # the SDF legs of collide() are a chain of launches of their own (newton_amd/sdf_pipeline.py): run the reference loop
+            # launch by launch, like SolverXPBD.rollout does for such models
+            cp = _lib.nt_collide_params(0, self.envs_per_block)
+            for _ in range(int(substeps)):
+                state_0.clear_forces()
+                d_s, d_ct = state_0._desc(), contacts._desc()
+                leg.export_pointers(d_ct)
+                _lib.check(dm.lib.nt_collide(C.byref(dm.desc), C.byref(d_s), C.byref(d_ct), C.byref(cp), dm.stream()), "nt_collide")
+                leg.collide(state_0, contacts._flat, dm.stream())
+                contacts._generation += 1
+                self.step(state_0, state_1, control, contacts, dt)
+                state_0, state_1 = state_1, state_0
+            return state_0
         p = self._params()
         cp = _lib.nt_collide_params(0, self.envs_per_block)
         d0, d1, d_c, d_ct = state_0._desc(), state_1._desc(), control._desc(), contacts._desc()

@@ -430,6 +430,39 @@ def test_penalty_solvers_consume_the_rows_like_the_checker(solver_name):
     assert np.abs(ot1.body_qd - os1.body_qd).max() > 1e-3  # the rows' forces are in the result
 
 
+def test_featherstone_rollout_with_sdf_pairs_is_the_launch_by_launch_loop():
+    """SolverFeatherstone.rollout on a model whose pairs go through the mesh-SDF leg: the frame is the reference's loop
+    (clear_forces, collide incl. the SDF leg, step, swap), bit for bit what the caller's own loop produces."""
+    import torch
+
+    import newton_amd as nt
+    from sdf_pipeline_checker import sdf_scene
+
+    def run(fused):
+        model = sdf_scene(3, 5, device="cuda:0", seed=12)
+        _pile(model)
+        pipe = nt.CollisionPipeline(model, broad_phase="sap")
+        contacts = pipe.contacts()
+        s0, s1 = model.state(), model.state()
+        solver = nt.solvers.SolverFeatherstone(model)
+        if fused:
+            out = solver.rollout(s0, s1, None, contacts, 2.5e-4, 5)
+        else:
+            for _ in range(5):
+                s0.clear_forces()
+                pipe.collide(s0, contacts)
+                solver.step(s0, s1, None, contacts, 2.5e-4)
+                s0, s1 = s1, s0
+            out = s0
+        torch.cuda.synchronize()
+        assert int(_rows(contacts)["row_start"][-1]) > 0  # the SDF leg produced rows: the frame went through it
+        return out.joint_q.cpu().numpy().copy(), out.body_q.cpu().numpy().copy(), out.body_qd.cpu().numpy().copy()
+
+    a, b = run(True), run(False)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert np.isfinite(a[1]).all()
+
+
 _C5_PILE = {}
 
 

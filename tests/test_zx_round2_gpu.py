@@ -353,6 +353,57 @@ def test_hip_collide_against_reference_vectors_of_barrel_cylinders(name):
     assert all(v <= 1e-5 for v in err.values()), err
 
 
+def test_barrel_cylinders_fused_rollout_tracks_the_oracle_and_equals_the_loop():
+    """The barrel scene through SolverXPBD: the fused rollout is bitwise the collide / step loop and follows the oracle (whose contact
+    order is the reference's; the on-cap contacts of a barrel sit in the convex group on the device: summation order only)."""
+    import os
+    import sys
+
+    import torch
+
+    import newton_amd as nt
+    from oracle_bridge import Oracle, OracleState
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import collide_cases as cc
+
+    host, _ = cc.barrel_cases()["barrel_wide"]()
+    dt, n = 1e-3, 12
+
+    def device(fused):
+        model = _to_device(host)
+        pipe = nt.CollisionPipeline(model)
+        contacts = pipe.contacts()
+        solver = nt.solvers.SolverXPBD(model, iterations=2)
+        a, b = model.state(), model.state()
+        if fused:
+            out = solver.rollout(a, b, None, contacts, dt, n)
+        else:
+            for _ in range(n):
+                a.clear_forces()
+                pipe.collide(a, contacts)
+                solver.step(a, b, None, contacts, dt)
+                a, b = b, a
+            out = a
+        torch.cuda.synchronize()
+        return out.body_q.cpu().numpy().copy(), out.body_qd.cpu().numpy().copy()
+
+    fq, fv = device(True)
+    lq, lv = device(False)
+    assert np.array_equal(fq, lq) and np.array_equal(fv, lv)
+    o = Oracle(host)
+    a, b = OracleState(host), OracleState(host)
+    for _ in range(n):
+        ct = o.contacts()
+        o.collide(a.body_q, ct)
+        o.xpbd_step(a, b, o.control(), ct if ct.count[0] else None, dt, iterations=2)
+        a, b = b, a
+    dq = float(np.abs(fq - a.body_q).max())
+    print("barrel scene, 12 substeps: max |dq| vs the oracle", dq)
+    assert dq <= 1e-4
+
+
 def test_featherstone_rollout_with_a_mass_matrix_interval_is_the_step_loop():
     """update_mass_matrix_interval = 3: the fused rollout (substep index inside the launch) and the launch-by-launch loop
     rebuild the mass matrix on the same steps and agree bit for bit; interval 1 gives a different (fresher) result."""
