@@ -30,7 +30,10 @@ struct Ctx {
 
     // rows: float rows per env in front of the block-shared topology ints (-1: the XPBD / collide layout)
     NT_DI Ctx(const KArgs& a_, float* lds_, int rows = -1, const bool big_ = false) : a(a_), lds(lds_), big(big_) {
-        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI, rows < 0, a.tile_opts);  // (rows >= 0: another solver's layout, no live list)
+        // (rows >= 0: another solver's layout, no live list; the pair-heavy tile sizes its per-lane polygon scratch by the workgroup
+        // the launch code chose: 256 lanes, or NT_BIG_SCENE_LANES_WIDE when they fit)
+        L = make_layout(a.m, big_, xpbd_keeps_prestep_state(a.p), UNI, rows < 0, a.tile_opts,
+                        big_ && (int)blockDim.x > NT_BIG_SCENE_LANES ? NT_BIG_SCENE_LANES_WIDE : NT_BIG_SCENE_LANES);
         pose_in_off = L.bq.off;
         lds_records = rows < 0 && (a.tile_opts & NT_TILE_LDS_RECORDS) != 0;
         hbm_out = true;

@@ -248,6 +248,13 @@ bool epb_fits(const nt_model& m, int epb, bool restitution = false, bool uni = f
     return tile_lds_bytes(m, epb, restitution, uni) <= LDS_BYTES_PER_CU;
 }
 
+// pair-heavy tile: does the workgroup of NT_BIG_SCENE_LANES_WIDE lanes (20 rows of polygon scratch each) still fit the CU?
+bool big_wide_fits(const nt_model& m, bool restitution) {
+    if (!m.contact_scratch_in_hbm || m.np_analytic == m.np) return false;  // (only the convex kernels carry the wide form)
+    LdsLayout L = make_layout_host(m, restitution, false, 0, NT_BIG_SCENE_LANES_WIDE);
+    return (size_t)L.rows_per_env * 4 + (size_t)topo_ints(m) * 4 <= LDS_BYTES_PER_CU;
+}
+
 int pick_epb(const nt_model& m, int requested, bool restitution = false) {
     // pair-heavy scenes (contact records in HBM) only have the one-environment-per-workgroup kernels
     if (m.contact_scratch_in_hbm) return (requested == 0 || requested == 1) && epb_fits(m, 1, restitution) ? 1 : 0;
@@ -275,7 +282,7 @@ template <typename K>
 nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads = 0, bool semi = false, bool uni = false) {
     int tile_opts = a.tile_opts;
     auto tile_bytes = [&](int opts) {
-        LdsLayout Lo = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni, opts);
+        LdsLayout Lo = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni, opts, NT_BIG_SCENE_LANES);
         return (size_t)Lo.rows_per_env * 4 * epb + (size_t)topo_ints(a.m) * 4 + (size_t)Lo.uni_floats * 4;
     };
     if (semi) tile_opts = 0;
@@ -284,7 +291,6 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
         tile_opts &= ~NT_TILE_LDS_RECORDS;
     if (tile_bytes(tile_opts) > LDS_BYTES_PER_CU) tile_opts = 0;
     a.tile_opts = tile_opts;
-    LdsLayout L = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni, tile_opts);
     if (max_threads <= 0) max_threads = max_threads_for(epb);
     int nslot = slots_for(a.m, epb, max_threads);
     // rows of the SDF legs (nt_contacts.flat) are walked by the environment's slot-lanes too: hundreds per environment in a pile,
@@ -299,6 +305,9 @@ nt_status launch(K kernel, KArgs a, int epb, hipStream_t stream, int max_threads
     }
 #endif
     int threads = ((nslot * epb + 63) / 64) * 64;
+    // the pair-heavy tile's wide workgroup (the caller checked the fit): the kernel sizes its per-lane polygon scratch by blockDim.x
+    const int big_lanes = a.m.contact_scratch_in_hbm && threads > NT_BIG_SCENE_LANES ? NT_BIG_SCENE_LANES_WIDE : NT_BIG_SCENE_LANES;
+    LdsLayout L = make_layout_host(a.m, xpbd_keeps_prestep_state(a.p), uni, tile_opts, big_lanes);
     size_t lds_bytes = (size_t)(semi ? L.rows_semi : L.rows_per_env) * 4 * epb + (size_t)topo_ints(a.m) * 4 + (size_t)L.uni_floats * 4;
     if (lds_bytes > LDS_BYTES_PER_CU) return NT_ERR_UNSUPPORTED;
     int blocks = (a.m.env_count + epb - 1) / epb;
@@ -465,6 +474,8 @@ nt_status nt_collide(const nt_model* m, const nt_state* s, nt_contacts* c, const
 #ifdef NT_DEV_FAST
     if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;
 #else
+    if (m->contact_scratch_in_hbm && big_wide_fits(*m, false))
+        return launch(collide_kernel<1, true, true, NT_BIG_SCENE_LANES_WIDE>, a, 1, (hipStream_t)stream, NT_BIG_SCENE_LANES_WIDE);
     if (m->contact_scratch_in_hbm)
         return m->np_analytic < m->np ? launch(collide_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(collide_kernel<1, false, true>, a, 1, (hipStream_t)stream);
@@ -526,6 +537,8 @@ nt_status nt_xpbd_rollout(const nt_model* m, const nt_xpbd_params* p, const nt_c
 #else
     if (m->contact_scratch_in_hbm) {
         if (a.has_contacts && !a.ct.cw) return NT_ERR_INVALID_ARG;
+        if (big_wide_fits(*m, rest))
+            return launch(xpbd_rollout_kernel<1, true, true, NT_BIG_SCENE_LANES_WIDE>, a, 1, (hipStream_t)stream, NT_BIG_SCENE_LANES_WIDE);
         return m->np_analytic < m->np ? launch(xpbd_rollout_kernel<1, true, true>, a, 1, (hipStream_t)stream)
                                       : launch(xpbd_rollout_kernel<1, false, true>, a, 1, (hipStream_t)stream);
     }
@@ -557,7 +570,7 @@ nt_status nt_xpbd_rollout_shape(const nt_model* m, const nt_xpbd_params* p, cons
     if (!epb) return NT_ERR_UNSUPPORTED;
     const bool cvx = m->np_analytic < m->np, big = m->contact_scratch_in_hbm != 0;
     XpbdCfg c = {epb, max_threads_for(epb), 1, 0, 0};
-    if (big) c = {1, 256, 1, 0, 0};
+    if (big) c = {1, big_wide_fits(*m, rest) ? NT_BIG_SCENE_LANES_WIDE : NT_BIG_SCENE_LANES, 1, 0, 0};
     else if (!cvx) {
         XpbdCfg o;
         if (xpbd_cfg_override(o) && !o.cvx) c = o;

@@ -82,16 +82,22 @@ struct LdsLayout {
     int rows_semi;     // SolverSemiImplicit kernel (its wrench records share the scratch with body_f_tmp + joint wrenches)
 };
 
-constexpr int NT_BIG_SCENE_LANES = 256;  // workgroup size of the one-environment-per-workgroup tile
+constexpr int NT_BIG_SCENE_LANES = 256;  // workgroup size of the pair-heavy one-environment-per-workgroup tile ...
+constexpr int NT_BIG_SCENE_LANES_WIDE = 384;  // ... and its wide form, taken when 20 more rows of manifold polygon scratch per extra lane
+                                              // still fit the CU: two of the four SIMDs then interleave two waves (the pair phase is a
+                                              // chain of dependent MPR / GJK iterations: config C5's geometry 65.2 -> 53.4 ms per frame
+                                              // same-box, profiles/r05M_ab.txt).  512 lanes do not fit C5 (168 KB)
 constexpr int NT_MIN_SCRATCH_ROWS = 8;   // the live-contact prefix parks up to 8 partial sums in the scratch union
 
 // collide scratch at row `base`: shape transforms / AABBs, pair counts, manifold polygon scratch (+ staged candidates);
 // returns its size in rows.  SolverFeatherstone's fused rollout places the same block inside its own union
-__host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_model& m, const int base, const bool big) {
+// big_lanes: lanes of the pair-heavy tile's workgroup (each owns a polygon scratch block)
+__host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_model& m, const int base, const bool big,
+                                                     const int big_lanes = NT_BIG_SCENE_LANES) {
     L.sx.off = base; L.sa.off = L.sx.off + 7 * m.ns; L.pc.off = L.sa.off + 7 * m.ns;
     L.poly = L.pc.off + m.np;
     // manifold polygon scratch: 20 rows per convex pair, or (pair-heavy scenes, one environment per workgroup) per lane
-    int coll = 14 * m.ns + m.np + 20 * (big ? NT_BIG_SCENE_LANES : (m.np - m.np_analytic));
+    int coll = 14 * m.ns + m.np + 20 * (big ? big_lanes : (m.np - m.np_analytic));
     L.st.off = base + coll;
     if (!big) coll += 19 * m.np;
     L.hl.off = base + coll; L.hc.off = L.hl.off + m.np;
@@ -109,7 +115,8 @@ __host__ __device__ inline int place_collide_scratch(LdsLayout& L, const nt_mode
 constexpr int NT_TILE_POSE_SNAPSHOT = 1;  // keep the substep's incoming body poses (L.xiq) so that integrate_bodies can run beside the pair phase
 constexpr int NT_TILE_LDS_RECORDS = 2;    // the contact records of a fused rollout live in LDS (L.cr); Contacts in HBM get the last substep's only
 __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool big, const bool restitution = false,
-                                                 const bool uni = false, const bool live_list = true, const int opts = 0) {
+                                                 const bool uni = false, const bool live_list = true, const int opts = 0,
+                                                 const int big_lanes = NT_BIG_SCENE_LANES) {
     LdsLayout L;
     int o = 0, ou = 0;
     L.bq.off = o; o += 7 * m.nb;
@@ -131,7 +138,7 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.lt.off = o; o += L.has_lt ? m.np * m.cpp : 0;
     L.lc.off = o; o += L.has_lt ? 1 : 0;
     L.u = o;
-    const int coll = place_collide_scratch(L, m, L.u, big);
+    const int coll = place_collide_scratch(L, m, L.u, big, big_lanes);
     // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase
     // and the joint-force phase in the same barrier interval (different waves); the pair-heavy tile keeps the overlap
     L.bf.off = big ? L.u : L.u + coll; L.jf.off = L.bf.off + 7 * m.nb;
@@ -152,8 +159,8 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.rows_semi = L.u + semi;
     return L;
 }
-inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false, bool uni = false, int opts = 0) {
-    return make_layout(m, m.contact_scratch_in_hbm != 0, restitution, uni, true, opts);
+inline LdsLayout make_layout_host(const nt_model& m, bool restitution = false, bool uni = false, int opts = 0, int big_lanes = NT_BIG_SCENE_LANES) {
+    return make_layout(m, m.contact_scratch_in_hbm != 0, restitution, uni, true, opts, big_lanes);
 }
 
 // the pre-step state snapshot (and the wide contact records) exist for restitution and for velocities from position deltas

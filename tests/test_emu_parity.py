@@ -358,6 +358,16 @@ def test_pair_heavy_scene_keeps_contact_records_in_hbm(H, n_hulls, n_env):
     # the other solvers refuse this mode instead of overflowing LDS
     with pytest.raises(RuntimeError):
         H.semi_implicit_step(em, s0, s1, ctrl, ct, 1e-4)
+    # the tile takes its wide workgroup (384 lanes, 20 rows of polygon scratch each) while that still fits the CU -- it does for
+    # config C5's 64 hulls (158 KB of 160) -- and says so
+    import ctypes as C
+
+    from newton_amd import _lib
+
+    shape = (C.c_int32 * 5)()
+    p = _lib.nt_xpbd_params(2, 0.4, 0.4, 0.0, 0.0, 0.8, 1, 0.0, 0, 0)
+    assert H.lib().nt_xpbd_rollout_shape(C.byref(em.desc), C.byref(p), None, shape) == 0
+    assert list(shape)[:2] == [1, 384] and shape[4] == 3  # one environment per workgroup, 384 lanes, convex + pair-heavy
 
 
 def test_boundary_helpers(H):
