@@ -97,8 +97,15 @@ def test_c_helper_reproduces_the_python_descriptor(name):
             got = _arr(getattr(d, k), v.size, C.c_float)
             assert np.array_equal(got.view(np.int32), np.ascontiguousarray(v, dtype=np.float32).reshape(-1).view(np.int32)), k
         assert d.params_uniform == params_uniform(packed, t.env_count)
-        if name == "barrel_cylinders":  # 7 overlapping pairs (5 of them convex by type, + barrel-sphere) and 5 barrels on the plane
-            assert (t.np, t.np_analytic) == (12, 0)
+        if name == "barrel_cylinders":  # no pair of the analytic group holds a barrel; (plane, barrel) and (sphere, barrel) pairs exist
+            scale = np.asarray(model.shape_scale, dtype=np.float32).reshape(-1, 3)
+            ids = [t.shape_local0 + l if l < t.ns else int(t.gshape_id[l - t.ns]) for l in range(t.ns + t.ng)]
+            barrel = np.array([int(t.shape_type[l]) == 6 and scale[ids[l], 2] != 0.0 for l in range(t.ns + t.ng)])
+            pa, pb = np.asarray(t.pair_a), np.asarray(t.pair_b)
+            assert barrel.sum() >= 13 and not (barrel[pa[:t.np_analytic]] | barrel[pb[:t.np_analytic]]).any()
+            kinds = {tuple(sorted((int(t.shape_type[a]), int(t.shape_type[b])))) for a, b in zip(pa[t.np_analytic:], pb[t.np_analytic:])
+                     if barrel[a] or barrel[b]}
+            assert (1, 6) in kinds and (3, 6) in kinds  # (PLANE, CYLINDER), (SPHERE, CYLINDER) in the convex group
         order = np.zeros(t.np, dtype=np.int64)
         assert lib.nt_model_pair_order(h, order.ctypes.data_as(C.POINTER(C.c_int64))) == 0
         assert np.array_equal(order, np.asarray(t.tile_pair_index)[t.pair_order])  # positions in the world's shape_contact_pairs slice
