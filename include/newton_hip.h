@@ -158,6 +158,12 @@ typedef struct {
     const int32_t* body_blk_start;  /* [env_count * (nb + 1)] */
     const int32_t* body_blk_list;   /* [..][2] */
     float* cw;                      /* [cap][10] solver scratch: XPBD correction record of every row */
+    float* impulse;                 /* [cap][6] or NULL: with nt_xpbd_report.contact_impulse, nt_xpbd_step accumulates the rows' weighted
+                                     * impulses here (accumulate_weighted_contact_impulse, xpbd/kernels.py:2403-2461) -- the rows follow the
+                                     * slot contacts in Contacts.force: force[n_slot_contacts + k] = impulse[k-th live row] / dt
+                                     * (convert_contact_impulse_to_force, :2464-2494) */
+    float* restitution;             /* [cap][14] or NULL: scratch of the restitution pass over the rows (required with
+                                     * nt_xpbd_params.enable_restitution when rows exist; without it the pass covers the slots only) */
 } nt_flat_rows;
 
 /* Contacts (newton/_src/sim/contacts.py:227-277), fixed slots: slot = pair * cpp + k.

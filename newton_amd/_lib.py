@@ -62,7 +62,8 @@ class nt_flat_rows(C.Structure):
     _fields_ = [("row_start", C.c_void_p), ("shape0", C.c_void_p), ("shape1", C.c_void_p), ("point0", C.c_void_p),
                 ("point1", C.c_void_p), ("offset0", C.c_void_p), ("offset1", C.c_void_p), ("normal", C.c_void_p),
                 ("margin0", C.c_void_p), ("margin1", C.c_void_p), ("stiffness", C.c_void_p), ("damping", C.c_void_p),
-                ("friction_scale", C.c_void_p), ("body_blk_start", C.c_void_p), ("body_blk_list", C.c_void_p), ("cw", C.c_void_p)]
+                ("friction_scale", C.c_void_p), ("body_blk_start", C.c_void_p), ("body_blk_list", C.c_void_p), ("cw", C.c_void_p),
+                ("impulse", C.c_void_p), ("restitution", C.c_void_p)]
 
 
 class nt_contacts(C.Structure):

@@ -487,6 +487,8 @@ nt_status nt_xpbd_step(const nt_model* m, const nt_xpbd_params* p, nt_state* s_i
                        const nt_contacts* c, float dt, int32_t envs_per_block, const nt_xpbd_report* report, void* stream) {
     if (!model_ok(m) || !p || !s_in || !s_out || !ctrl) return NT_ERR_INVALID_ARG;
     if (s_out->body_parent_f && m->nj > 0 && !(report && report->joint_impulse)) return NT_ERR_INVALID_ARG;
+    // the restitution pass covers the rows of the SDF legs through their own records: refuse to skip them silently
+    if (p->enable_restitution && c && c->flat.row_start && !c->flat.restitution) return NT_ERR_INVALID_ARG;
     KArgs a = {};
     if (report) a.rep = *report;
     if (!s_out->body_parent_f || m->nj == 0) a.rep.joint_impulse = nullptr;

@@ -1095,105 +1095,132 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
     if (ic >= 0) c.st_lv3(c.L.ji, 6, 2 * nj, ic, t);
 }
 
-// apply_rigid_restitution (xpbd/kernels.py:2583-2728) for one contact slot; velocity deltas go to the per-contact record
+// apply_rigid_restitution (xpbd/kernels.py:2583-2728) for one contact: the velocity deltas of its two bodies
+struct RestitutionOut {
+    vec3 lin_a, ang_a, lin_b, ang_b;
+    float has_a, has_b;
+    int shape_a;
+};
+// gid_a / gid_b: Newton shape ids of the contact; px_a / px_b: point + offset in the bodies' frames; n: world normal
+template <int EPB>
+NT_DI RestitutionOut restitution_solve(const Ctx<EPB>& c, int gid_a, int gid_b, vec3 px_a, vec3 px_b, vec3 n) {
+    const int nb = c.a.m.nb;
+    const float dt = c.a.dt;
+    RestitutionOut o;
+    o.has_a = 0.0f; o.has_b = 0.0f; o.shape_a = -1;
+    if (gid_a == gid_b) return o;
+    int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
+    int shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+    o.shape_a = shape_a;
+    int body_a = -1, body_b = -1, mat_nonzero = 0;
+    float restitution = 0.0f;
+    if (shape_a >= 0) {
+        mat_nonzero += 1;
+        restitution += c.shape_f(shape_a, SP_RESTITUTION);
+        body_a = c.T.shape_body[shape_a];
+    }
+    if (shape_b >= 0) {
+        mat_nonzero += 1;
+        restitution += c.shape_f(shape_b, SP_RESTITUTION);
+        body_b = c.T.shape_body[shape_b];
+    }
+    if (mat_nonzero > 0) restitution /= float(mat_nonzero);
+    if (body_a == body_b) return o;
+    float m_inv_a = 0.0f, m_inv_b = 0.0f;
+    mat33 I_inv_a, I_inv_b;
+    xform X_a_prev, X_b_prev;
+    vec3 com_a(0.0f), com_b(0.0f);
+    auto prev_q = [&](int b) { return c.lxf(c.L.xiq, 0, nb, b); };
+    auto prev_qd = [&](int b) { return spatial(c.lv3(c.L.xiqd, 0, nb, b), c.lv3(c.L.xiqd, 3, nb, b)); };
+    if (body_a >= 0) {
+        X_a_prev = prev_q(body_a);
+        m_inv_a = c.inv_mass(body_a);
+        I_inv_a = c.inv_inertia(body_a);
+        com_a = c.com(body_a);
+    }
+    if (body_b >= 0) {
+        X_b_prev = prev_q(body_b);
+        m_inv_b = c.inv_mass(body_b);
+        I_inv_b = c.inv_inertia(body_b);
+        com_b = c.com(body_b);
+    }
+    vec3 bx_a = xform_point(X_a_prev, px_a);
+    vec3 bx_b = xform_point(X_b_prev, px_b);
+    float d = dot(n, bx_b - bx_a);
+    if (!(d < 0.0f)) return o;
+    vec3 r_a = bx_a - xform_point(X_a_prev, com_a);
+    vec3 r_b = bx_b - xform_point(X_b_prev, com_b);
+    vec3 gravity = c.gravity();
+    vec3 rxn_a(0.0f), rxn_b(0.0f), v_a(0.0f), v_b(0.0f), v_a_new(0.0f), v_b_new(0.0f);
+    float inv_mass = 0.0f;
+    if (body_a >= 0) {
+        v_a = velocity_at_point(prev_qd(body_a), r_a) + gravity * dt;
+        v_a_new = velocity_at_point(spatial(c.body_v(body_a), c.body_w(body_a)), r_a);
+        rxn_a = quat_rotate_inv(X_a_prev.q, cross(r_a, n));
+        inv_mass += m_inv_a + dot(rxn_a, I_inv_a * rxn_a);
+    }
+    if (body_b >= 0) {
+        v_b = velocity_at_point(prev_qd(body_b), r_b) + gravity * dt;
+        v_b_new = velocity_at_point(spatial(c.body_v(body_b), c.body_w(body_b)), r_b);
+        rxn_b = quat_rotate_inv(X_b_prev.q, cross(r_b, n));
+        inv_mass += m_inv_b + dot(rxn_b, I_inv_b * rxn_b);
+    }
+    float rel_vel_old = dot(n, v_b - v_a);
+    float rel_vel_new = dot(n, v_b_new - v_a_new);
+    if (inv_mass != 0.0f && rel_vel_old < 0.0f) {
+        float dv = (-rel_vel_new - restitution * rel_vel_old) / inv_mass;
+        if (body_a >= 0) {
+            float dv_a = -dv;
+            o.lin_a = n * m_inv_a * dv_a;
+            o.ang_a = quat_rotate(X_a_prev.q, I_inv_a * rxn_a * dv_a);
+            o.has_a = 1.0f;
+        }
+        if (body_b >= 0) {
+            o.lin_b = n * m_inv_b * dv;
+            o.ang_b = quat_rotate(X_b_prev.q, I_inv_b * rxn_b * dv);
+            o.has_b = 1.0f;
+        }
+    }
+    return o;
+}
+// ... for one contact slot; velocity deltas go to the per-contact record
 template <int EPB, class CW = CwLds>
 NT_DI void restitution_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
-    const int cpp = m.cpp, ncs = m.np * cpp, nb = m.nb;
-    const float dt = c.a.dt;
+    const int cpp = m.cpp, ncs = m.np * cpp;
     const float* D = ct.data;
-    float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
-    vec3 lin_a, ang_a, lin_b, ang_b;
     size_t gi = (size_t)slot * c.ES + c.env;
-    int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
-    if (gid_a != gid_b) {
-        int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1;
-        int shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
-        int body_a = -1, body_b = -1, mat_nonzero = 0;
-        float restitution = 0.0f;
-        if (shape_a >= 0) {
-            mat_nonzero += 1;
-            restitution += c.shape_f(shape_a, SP_RESTITUTION);
-            body_a = c.T.shape_body[shape_a];
-        }
-        if (shape_b >= 0) {
-            mat_nonzero += 1;
-            restitution += c.shape_f(shape_b, SP_RESTITUTION);
-            body_b = c.T.shape_body[shape_b];
-        }
-        if (mat_nonzero > 0) restitution /= float(mat_nonzero);
-        if (body_a != body_b) {
-            float m_inv_a = 0.0f, m_inv_b = 0.0f;
-            mat33 I_inv_a, I_inv_b;
-            xform X_a_prev, X_b_prev;
-            vec3 com_a(0.0f), com_b(0.0f);
-            auto prev_q = [&](int b) { return c.lxf(c.L.xiq, 0, nb, b); };
-            auto prev_qd = [&](int b) { return spatial(c.lv3(c.L.xiqd, 0, nb, b), c.lv3(c.L.xiqd, 3, nb, b)); };
-            if (body_a >= 0) {
-                X_a_prev = prev_q(body_a);
-                m_inv_a = c.inv_mass(body_a);
-                I_inv_a = c.inv_inertia(body_a);
-                com_a = c.com(body_a);
-            }
-            if (body_b >= 0) {
-                X_b_prev = prev_q(body_b);
-                m_inv_b = c.inv_mass(body_b);
-                I_inv_b = c.inv_inertia(body_b);
-                com_b = c.com(body_b);
-            }
-            vec3 bx_a = xform_point(X_a_prev, c.gv3(D, CD_POINT0, ncs, slot) + c.gv3(D, CD_OFFSET0, ncs, slot));
-            vec3 bx_b = xform_point(X_b_prev, c.gv3(D, CD_POINT1, ncs, slot) + c.gv3(D, CD_OFFSET1, ncs, slot));
-            vec3 n = c.gv3(D, CD_NORMAL, ncs, slot);
-            float d = dot(n, bx_b - bx_a);
-            if (d < 0.0f) {
-                vec3 r_a = bx_a - xform_point(X_a_prev, com_a);
-                vec3 r_b = bx_b - xform_point(X_b_prev, com_b);
-                vec3 gravity = c.gravity();
-                vec3 rxn_a(0.0f), rxn_b(0.0f), v_a(0.0f), v_b(0.0f), v_a_new(0.0f), v_b_new(0.0f);
-                float inv_mass = 0.0f;
-                if (body_a >= 0) {
-                    v_a = velocity_at_point(prev_qd(body_a), r_a) + gravity * dt;
-                    v_a_new = velocity_at_point(spatial(c.body_v(body_a), c.body_w(body_a)), r_a);
-                    rxn_a = quat_rotate_inv(X_a_prev.q, cross(r_a, n));
-                    inv_mass += m_inv_a + dot(rxn_a, I_inv_a * rxn_a);
-                }
-                if (body_b >= 0) {
-                    v_b = velocity_at_point(prev_qd(body_b), r_b) + gravity * dt;
-                    v_b_new = velocity_at_point(spatial(c.body_v(body_b), c.body_w(body_b)), r_b);
-                    rxn_b = quat_rotate_inv(X_b_prev.q, cross(r_b, n));
-                    inv_mass += m_inv_b + dot(rxn_b, I_inv_b * rxn_b);
-                }
-                float rel_vel_old = dot(n, v_b - v_a);
-                float rel_vel_new = dot(n, v_b_new - v_a_new);
-                if (inv_mass != 0.0f && rel_vel_old < 0.0f) {
-                    float dv = (-rel_vel_new - restitution * rel_vel_old) / inv_mass;
-                    if (body_a >= 0) {
-                        float dv_a = -dv;
-                        lin_a = n * m_inv_a * dv_a;
-                        ang_a = quat_rotate(X_a_prev.q, I_inv_a * rxn_a * dv_a);
-                        has_a = 1.0f;
-                    }
-                    if (body_b >= 0) {
-                        lin_b = n * m_inv_b * dv;
-                        ang_b = quat_rotate(X_b_prev.q, I_inv_b * rxn_b * dv);
-                        has_b = 1.0f;
-                    }
-                    a_is_pair_a = (shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f;
-                }
-            }
-        }
-    }
-    cw_st3<CW, NC_CW>(c, 0, ncs, slot, lin_a);
-    cw_st3<CW, NC_CW>(c, 3, ncs, slot, ang_a);
-    cw_st3<CW, NC_CW>(c, 6, ncs, slot, lin_b);
-    cw_st3<CW, NC_CW>(c, 9, ncs, slot, ang_b);
-    CW::template at<NC_CW>(c, 12, ncs, slot) = has_a;
-    CW::template at<NC_CW>(c, 13, ncs, slot) = has_b;
+    const int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+    RestitutionOut o;
+    o.has_a = 0.0f; o.has_b = 0.0f; o.shape_a = -1;
+    if (gid_a != gid_b)
+        o = restitution_solve(c, gid_a, gid_b, c.gv3(D, CD_POINT0, ncs, slot) + c.gv3(D, CD_OFFSET0, ncs, slot),
+                              c.gv3(D, CD_POINT1, ncs, slot) + c.gv3(D, CD_OFFSET1, ncs, slot), c.gv3(D, CD_NORMAL, ncs, slot));
+    const float a_is_pair_a = (o.has_a != 0.0f || o.has_b != 0.0f) ? ((o.shape_a == c.T.pair_a[slot / cpp]) ? 1.0f : 0.0f) : 1.0f;
+    cw_st3<CW, NC_CW>(c, 0, ncs, slot, o.lin_a);
+    cw_st3<CW, NC_CW>(c, 3, ncs, slot, o.ang_a);
+    cw_st3<CW, NC_CW>(c, 6, ncs, slot, o.lin_b);
+    cw_st3<CW, NC_CW>(c, 9, ncs, slot, o.ang_b);
+    CW::template at<NC_CW>(c, 12, ncs, slot) = o.has_a;
+    CW::template at<NC_CW>(c, 13, ncs, slot) = o.has_b;
     CW::template at<NC_CW>(c, 14, ncs, slot) = a_is_pair_a;
 }
+// ... and for one row of the SDF legs: nt_flat_rows.restitution[row][14] = lin_a, ang_a, lin_b, ang_b, has_a, has_b
+constexpr int FLAT_REST_FLOATS = 14;
+template <int EPB>
+NT_DI void restitution_flat_item(const Ctx<EPB>& c, const int r) {
+    const nt_flat_rows& f = c.a.ct.flat;
+    const RestitutionOut o = restitution_solve(c, f.shape0[r], f.shape1[r], FlatRecord::ld(f.point0, r) + FlatRecord::ld(f.offset0, r),
+                                               FlatRecord::ld(f.point1, r) + FlatRecord::ld(f.offset1, r), FlatRecord::ld(f.normal, r));
+    float* w = f.restitution + FLAT_REST_FLOATS * (size_t)r;
+    w[0] = o.lin_a.x; w[1] = o.lin_a.y; w[2] = o.lin_a.z; w[3] = o.ang_a.x; w[4] = o.ang_a.y; w[5] = o.ang_a.z;
+    w[6] = o.lin_b.x; w[7] = o.lin_b.y; w[8] = o.lin_b.z; w[9] = o.ang_b.x; w[10] = o.ang_b.y; w[11] = o.ang_b.z;
+    w[12] = o.has_a; w[13] = o.has_b;
+}
 // apply_body_delta_velocities (xpbd/kernels.py:936-942): body lane sums its contacts' velocity deltas in contact order
-template <int EPB, class CW = CwLds>
+// ROWS: the launch-by-launch step kernel, whose Contacts may carry rows of the SDF legs (the fused rollouts never do)
+template <int EPB, class CW = CwLds, bool ROWS = false>
 NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
     const nt_model& m = c.a.m;
     const int cpp = m.cpp, ncs = m.np * cpp, nb = m.nb;
@@ -1207,6 +1234,21 @@ NT_DI void restitution_apply_item(const Ctx<EPB>& c, const int b) {
             if (CW::template at<NC_CW>(c, is_a ? 12 : 13, ncs, slot) != 0.0f) {
                 dv += cw_v3<CW, NC_CW>(c, is_a ? 0 : 6, ncs, slot);
                 dw += cw_v3<CW, NC_CW>(c, is_a ? 3 : 9, ncs, slot);
+            }
+        }
+    }
+    if constexpr (ROWS)
+    if (const nt_flat_rows& f = c.a.ct.flat; f.row_start && f.restitution) {  // then the SDF legs' rows, ascending row order
+        const int* bs = f.body_blk_start + (size_t)c.env * (nb + 1) + b;
+        for (int i = bs[0]; i < bs[1]; ++i) {
+            const int code = f.body_blk_list[2 * (size_t)i], count = f.body_blk_list[2 * (size_t)i + 1];
+            const int r0 = code >> 1, side = code & 1;  // side 0: the body of the rows' shape0
+            for (int r = r0; r < r0 + count; ++r) {
+                const float* w = f.restitution + FLAT_REST_FLOATS * (size_t)r;
+                if (w[side ? 13 : 12] != 0.0f) {
+                    dv += vec3(w[side ? 6 : 0], w[side ? 7 : 1], w[side ? 8 : 2]);
+                    dw += vec3(w[side ? 9 : 3], w[side ? 10 : 4], w[side ? 11 : 5]);
+                }
             }
         }
     }
@@ -1273,12 +1315,22 @@ NT_DI void report_parent_f(const Ctx<EPB>& c) {
         out[c.g(3, nb, b)] = t.x; out[c.g(4, nb, b)] = t.y; out[c.g(5, nb, b)] = t.z;
     }
 }
-// number of active contacts on body b in this iteration (constraint_inv_weight[b], xpbd/kernels.py:2287-2291)
+// number of active contacts on body b in this iteration (constraint_inv_weight[b], xpbd/kernels.py:2287-2291): the slots, and the rows
+// of the SDF legs that correct it (the same rows apply_item sums)
 template <int EPB, class CW = CwLds>
 NT_DI float report_body_contact_count(const Ctx<EPB>& c, int b) {
     const nt_model& m = c.a.m;
     const int cpp = m.cpp, ncs = m.np * cpp;
     float n = 0.0f;
+    if (const nt_flat_rows& f = c.a.ct.flat; f.row_start) {
+        const int* bs = f.body_blk_start + (size_t)c.env * (m.nb + 1) + b;
+        for (int i = bs[0]; i < bs[1]; ++i) {
+            const int code = f.body_blk_list[2 * (size_t)i], count = f.body_blk_list[2 * (size_t)i + 1];
+            const int r0 = code >> 1, side = code & 1;
+            for (int r = r0; r < r0 + count; ++r)
+                if ((int)f.cw[CWX_FLOATS * (size_t)r + CWX_FLAGS] & (side ? 2 : 1)) n += 1.0f;
+        }
+    }
     for (int i = c.T.body_pair_start[b]; i < c.T.body_pair_start[b + 1]; ++i) {
         int code = c.T.body_pair_list[i];
         int p = code >> 1, side = code & 1;
@@ -1329,6 +1381,43 @@ NT_DI void report_contact_iteration(const Ctx<EPB>& c, bool first) {
     }
 }
 
+// the same accumulation for the rows of the SDF legs: flat.impulse[row] (+)= (lin_delta_a, ang_delta_a) * weight
+template <int EPB, class CW = CwLds>
+NT_DI void report_flat_rows_iteration(const Ctx<EPB>& c, bool first) {
+    const nt_flat_rows& f = c.a.ct.flat;
+    if (!c.valid || !f.row_start || !f.impulse) return;
+    for (int r = f.row_start[c.env] + c.slot; r < f.row_start[c.env + 1]; r += c.nslot) {
+        const float* w = f.cw + CWX_FLOATS * (size_t)r;
+        const int flags = (int)w[CWX_FLAGS];
+        const bool has = (flags & 3) != 0;
+        vec3 lin, ang;
+        if (has) {
+            float weight = 1.0f;
+            if (c.a.p.rigid_contact_con_weighting) {
+                const int gid_a = f.shape0[r], gid_b = f.shape1[r];
+                const int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1, shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
+                const int body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1, body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
+                float n_a = body_a >= 0 ? report_body_contact_count<EPB, CW>(c, body_a) : 0.0f;
+                float n_b = body_b >= 0 ? report_body_contact_count<EPB, CW>(c, body_b) : 0.0f;
+                float n_sum = n_a + n_b;
+                if (n_sum > 0.0f) {
+                    if (n_a == 0.0f) weight = 1.0f / n_b;
+                    else if (n_b == 0.0f) weight = 1.0f / n_a;
+                    else weight = 2.0f / n_sum;
+                }
+            }
+            lin = vec3(w[0], w[1], w[2]) * weight;
+            ang = vec3(w[CWX_ANG_A], w[CWX_ANG_A + 1], w[CWX_ANG_A + 2]) * weight;
+        }
+        float* I = f.impulse + 6 * (size_t)r;
+        if (first) {
+            I[0] = lin.x; I[1] = lin.y; I[2] = lin.z; I[3] = ang.x; I[4] = ang.y; I[5] = ang.z;
+        } else if (has) {
+            I[0] += lin.x; I[1] += lin.y; I[2] += lin.z; I[3] += ang.x; I[4] += ang.y; I[5] += ang.z;
+        }
+    }
+}
+
 template <int EPB>
 NT_DI void phase_joints(const Ctx<EPB>& c) {
     if (!c.valid) return;
@@ -1373,7 +1462,10 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
             if (!NT_SKIP(4)) phase_contacts<EPB, FUSED, CW>(c);
             __syncthreads();
             NT_TICK(5);
-            if (rep_contacts) report_contact_iteration<EPB, CW>(c, it == 0);
+            if (rep_contacts) {
+                report_contact_iteration<EPB, CW>(c, it == 0);
+                if constexpr (!FUSED) report_flat_rows_iteration<EPB, CW>(c, it == 0);
+            }
             if (!NT_SKIP(16)) phase_apply<EPB, true, CW, FUSED>(c, last_it && m.nj <= 0);
             __syncthreads();
             NT_TICK(6);
@@ -1406,10 +1498,14 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     if (restitution) {  // solver_xpbd.py:784-858
         if (c.valid)
             for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) restitution_item<EPB, CW>(c, s);
+        if constexpr (!FUSED) {
+            if (const nt_flat_rows& f = c.a.ct.flat; c.valid && f.row_start && f.restitution)
+                for (int r = f.row_start[c.env] + c.slot; r < f.row_start[c.env + 1]; r += c.nslot) restitution_flat_item(c, r);
+        }
         __syncthreads();
         if (c.valid)
             for (int b = c.slot; b < m.nb; b += c.nslot)
-                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item<EPB, CW>(c, b);
+                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item<EPB, CW, !FUSED>(c, b);
         __syncthreads();
     }
     if (!FUSED && c.a.s_out.body_parent_f) {

@@ -58,12 +58,25 @@ class FlatRows:
         self.body_blk_start = torch.zeros(t.env_count * (t.nb + 1), dtype=i32, device=dev)
         self.body_blk_list = torch.zeros((t.env_count * 2 * pairs_per_world, 2), dtype=i32, device=dev)
         self.cw = torch.zeros((c, 10), dtype=f32, device=dev)
+        # Contacts.force requested (contacts.py:170-226): SolverXPBD accumulates the rows' weighted impulses here
+        self.impulse = (torch.zeros((c, 6), dtype=f32, device=dev)
+                        if "force" in model.get_requested_contact_attributes() else None)
+        self.restitution = None  # [cap][14] scratch of SolverXPBD(enable_restitution=True), allocated on first use
+
+    def restitution_scratch(self):
+        if self.restitution is None:
+            self.restitution = _torch().zeros((self.capacity, 14), dtype=_torch().float32, device=self.cw.device)
+        return self.restitution
 
     def desc(self) -> _lib.nt_flat_rows:
         d = _lib.nt_flat_rows()
         for k in ("row_start", "shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1",
                   "body_blk_start", "body_blk_list", "cw"):
             setattr(d, k, getattr(self, k).data_ptr())
+        if self.impulse is not None:
+            d.impulse = self.impulse.data_ptr()
+        if self.restitution is not None:
+            d.restitution = self.restitution.data_ptr()
         if self.stiffness is not None:
             d.stiffness, d.damping, d.friction_scale = (self.stiffness.data_ptr(), self.damping.data_ptr(),
                                                         self.friction_scale.data_ptr())

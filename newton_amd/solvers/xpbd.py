@@ -53,17 +53,16 @@ class SolverXPBD(SolverBase):
             control = self._default_control()
         p = self._params()
         d_in, d_out, d_c = state_in._desc(), state_out._desc(), control._desc()
+        if contacts is not None and getattr(contacts, "_flat", None) is not None and self.enable_restitution:
+            # the SDF leg's rows take part in every pass: the position solve, Contacts.force (nt_flat_rows.impulse), the body-level
+            # velocity update and the restitution pass (its per-row records: nt_flat_rows.restitution)
+            contacts._flat.restitution_scratch()
         d_ct = contacts._desc() if contacts is not None else None
         # optional reporting (solver_xpbd.py:368-386): per-contact impulses when contacts.force was requested, per-joint
         # impulses when state_out carries body_parent_f
         rep = _lib.nt_xpbd_report()
         reporting = False
         self._contact_impulse = None
-        if contacts is not None and getattr(contacts, "_flat", None) is not None and (
-                self.enable_restitution or contacts.force is not None or self.compute_body_velocity_from_position_delta):
-            # the SDF leg's rows take part in the position solve; the optional passes walk the fixed slots only
-            raise NotImplementedError("enable_restitution / contacts.force / compute_body_velocity_from_position_delta are not "
-                                      "implemented for models with SDF contact pairs")
         if contacts is not None and contacts.force is not None:
             rep.contact_impulse = contacts._impulse.data_ptr()
             self._contact_impulse = contacts._impulse
@@ -97,6 +96,15 @@ class SolverXPBD(SolverBase):
                                                    float(self._last_dt), int(contacts.rigid_contact_max),
                                                    contacts.force.data_ptr(), contacts._scan.data_ptr(), dm.stream()),
                    "nt_contacts_export_force")
+        # the rows of the SDF legs follow the slot contacts in the flat arrays (collide.py:1999): force = impulse / dt
+        # (convert_contact_impulse_to_force, xpbd/kernels.py:2464-2494)
+        f = getattr(contacts, "_flat", None)
+        if f is not None and f.impulse is not None:
+            contacts._exported()
+            live, n0 = contacts._flat_live, contacts._flat_n0
+            k = min(int(live.numel()), int(contacts.force.shape[0]) - n0)
+            if k > 0:
+                contacts.force[n0:n0 + k] = f.impulse[live[:k]] * (1.0 / float(self._last_dt))
         # CollisionPipeline(deterministic=True) re-orders the rigid_contact_* rows by the contact key: force[i] must stay the
         # force of rigid_contact_shape0/1[i] (the reference sorts before the solver runs, so its indices agree by construction)
         order = contacts.export_order()

@@ -376,6 +376,68 @@ def test_xpbd_step_consumes_the_rows_like_the_checker():
     assert np.abs(ot1.body_q - os1.body_q).max() > 1e-5
 
 
+@pytest.mark.parametrize("what", ["contact_force", "velocity_from_delta", "restitution"])
+def test_xpbd_reporting_and_velocity_update_include_the_rows(what):
+    """SolverXPBD on a model whose pairs go through the mesh-SDF leg: Contacts.force covers the rows (their weighted impulses,
+    accumulate_weighted_contact_impulse xpbd/kernels.py:2403-2461; constraint_inv_weight counts slots and rows alike) and
+    compute_body_velocity_from_position_delta works on the rows' corrections, and the restitution pass (apply_rigid_restitution,
+    xpbd/kernels.py:2583-2728) walks the rows behind the slots -- against the checker on the same contact list."""
+    import torch
+
+    import newton_amd as nt
+    from oracle_bridge import Oracle, OracleState
+    from sdf_pipeline_checker import sdf_scene
+
+    model = sdf_scene(3, 5, device="cuda:0", seed=11)
+    if what == "contact_force":
+        model.request_contact_attributes("force")
+    _pile(model)
+    if what == "restitution":  # approaching hulls with bouncy materials: the pass has something to do
+        rng = np.random.default_rng(5)
+        qd = np.zeros((model.body_count, 6), np.float32)
+        qd[:, :3] = -2.0 * np.asarray(model.body_q)[:, :3] * np.array([1.0, 1.0, 0.0], np.float32) + rng.normal(0.0, 0.05, (model.body_count, 3))
+        model.body_qd = qd
+        model.joint_qd = qd.reshape(-1).copy()
+        model.shape_material_restitution = np.full(model.shape_count, 0.6, np.float32)
+    pipe = nt.CollisionPipeline(model, broad_phase="sap")
+    contacts = pipe.contacts()
+    s0, s1 = model.state(), model.state()
+    solver = nt.solvers.SolverXPBD(model, iterations=3, enable_restitution=what == "restitution")
+    solver.compute_body_velocity_from_position_delta = what == "velocity_from_delta"
+    pipe.collide(s0, contacts)
+    rows = _rows(contacts)
+    n_rows = int((rows["shape0"] != rows["shape1"]).sum())
+    assert n_rows > 5
+    dt = 1.0e-3
+    solver.step(s0, s1, model.control(), contacts, dt)
+    host = _host_twin_without_sdf_pairs(model)
+    o = Oracle(host)
+    oc = _oracle_contacts_with_rows(host, o, np.asarray(model.body_q), rows)
+    n = int(oc.count[0])
+    os0, os1 = OracleState(host), OracleState(host)
+    want = np.zeros((oc.max, 6), np.float32)
+    o.xpbd_step(os0, os1, o.control(), oc, dt, iterations=3, contact_force_out=want if what == "contact_force" else None,
+                compute_body_velocity_from_position_delta=what == "velocity_from_delta", enable_restitution=what == "restitution")
+    torch.cuda.synchronize()
+    dq = np.abs(s1.body_q.cpu().numpy() - os1.body_q).max()
+    dv = np.abs(s1.body_qd.cpu().numpy() - os1.body_qd).max()
+    assert dq <= 1e-5 and dv <= 5e-3, (dq, dv)
+    if what == "contact_force":
+        solver.update_contacts(contacts)
+        assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == n
+        assert np.array_equal(contacts.rigid_contact_shape0.cpu().numpy()[:n], oc.shape0[:n])
+        got = contacts.force.cpu().numpy()[:n]
+        scale = np.abs(want[:n]).max()
+        assert scale > 0 and np.abs(want[n - n_rows:n]).max() > 1e-3 * scale  # the rows carry force
+        assert np.abs(got - want[:n]).max() <= 2e-3 * scale, (np.abs(got - want[:n]).max(), scale)
+    elif what == "velocity_from_delta":
+        assert np.abs(os1.body_qd).max() > 1e-3  # velocities rebuilt from the position change the rows caused
+    else:  # the checker without restitution ends with other velocities: the pass acted on the rows
+        ot0, ot1 = OracleState(host), OracleState(host)
+        o.xpbd_step(ot0, ot1, o.control(), oc, dt, iterations=3)
+        assert np.abs(ot1.body_qd - os1.body_qd).max() > 1e-2
+
+
 def _host_twin_without_sdf_pairs(model):
     """A shallow host copy of the model whose shape_contact_pairs hold only the tile pairs (what the checker's collide walks)."""
     import copy
