@@ -56,9 +56,34 @@ def _capped_cone_z(bottom_radius, top_radius, half_height, p):
     return sign * np.sqrt(np.minimum(ca0 * ca0 + ca1 * ca1, cb0 * cb0 + cb1 * cb1))
 
 
+def _barrel_cylinder_z(radius, half_height, barrel_radius, p):
+    """`_sdf_barrel_cylinder_data_z` (geometry/kernels.py:347-383): exact signed distance to a z-up barrel cylinder -- the closer of the
+    circular side arc (clamped to where it meets the end ring) and the end disk in the radial / axial half plane."""
+    radial = np.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2)
+    z_abs = np.abs(p[:, 2])
+    end_radial_offset = np.sqrt(max(barrel_radius * barrel_radius - half_height * half_height, 0.0))
+    center = radius - end_radial_offset
+    d0, d1 = radial - center, z_abs
+    dl = np.sqrt(d0 * d0 + d1 * d1)
+    far = dl > 1.0e-8
+    safe = np.where(far, dl, 1.0)
+    arc_radial = np.where(far, center + barrel_radius * d0 / safe, center + barrel_radius)
+    arc_z = np.where(far, barrel_radius * d1 / safe, 0.0)
+    on_cap = arc_radial - center < end_radial_offset
+    arc_radial = np.where(on_cap, radius, arc_radial)
+    arc_z = np.where(on_cap, half_height, arc_z)
+    arc_distance = np.sqrt((radial - arc_radial) ** 2 + (z_abs - arc_z) ** 2)
+    cap_radial = np.minimum(radial, radius)
+    cap_distance = np.sqrt((radial - cap_radial) ** 2 + (z_abs - half_height) ** 2)
+    distance = np.minimum(cap_distance, arc_distance)
+    profile_radius = center + np.sqrt(np.maximum(barrel_radius * barrel_radius - z_abs * z_abs, 0.0))
+    inside = (z_abs <= half_height) & (radial <= profile_radius)
+    return np.where(inside, -distance, distance)
+
+
 def primitive_sdf(shape_type: int, scale, points) -> np.ndarray:
     """`_query_primitive_sdf`: signed distance of points [N,3] to the primitive in its local frame (z-up capsule / cylinder /
-    cone; barrel cylinders are not restated)."""
+    cone, incl. barrel cylinders)."""
     p = np.asarray(points, dtype=np.float64).reshape(-1, 3)
     s = [float(x) for x in scale]
     t = int(shape_type)
@@ -73,7 +98,7 @@ def primitive_sdf(shape_type: int, scale, points) -> np.ndarray:
         return np.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2 + dz ** 2) - r
     if t == GeoType.CYLINDER:
         if len(s) > 2 and s[2] > 0.0:
-            raise NotImplementedError("barrel cylinders are outside the SDF scope of this build")
+            return _barrel_cylinder_z(s[0], s[1], s[2], p)
         dx = np.linalg.norm(p[:, :2], axis=1) - s[0]
         dy = np.abs(p[:, 2]) - s[1]
         return np.minimum(np.maximum(dx, dy), 0.0) + np.sqrt(np.maximum(dx, 0.0) ** 2 + np.maximum(dy, 0.0) ** 2)
@@ -98,6 +123,9 @@ def primitive_extents(shape_type: int, scale):
         e = s[:3]
     elif t == GeoType.CAPSULE:
         e = [s[0], s[0], s[1] + s[0]]
+    elif t == GeoType.CYLINDER and len(s) > 2 and s[2] > 0.0:  # barrel: the side arc bulges past the end radius
+        r = s[0] + s[2] - (s[2] ** 2 - s[1] ** 2) ** 0.5
+        e = [r, r, s[1]]
     elif t in (GeoType.CYLINDER, GeoType.CONE):
         e = [s[0], s[0], s[1]]
     else:

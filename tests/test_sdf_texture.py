@@ -124,3 +124,18 @@ def test_primitive_sdfs_known_points():
     assert abs(f(GeoType.CYLINDER, (0.2, 0.5, 0), (0.5, 0, 0)) - 0.3) < 1e-12 and abs(f(GeoType.CYLINDER, (0.2, 0.5, 0), (0, 0, 0.7)) - 0.2) < 1e-12
     assert abs(f(GeoType.CONE, (0.3, 0.4, 0), (0, 0, 0.9)) - 0.5) < 1e-12 and f(GeoType.CONE, (0.3, 0.4, 0), (0, 0, -0.2)) < 0
     assert abs(f(GeoType.ELLIPSOID, (1.0, 0.5, 0.25), (2.0, 0, 0)) - 1.0) < 1e-9
+
+
+def test_barrel_cylinder_sdf_matches_the_executed_reference():
+    """tests/golden/make_barrel_sdf_vectors.py ran the reference's sdf_cylinder(..., barrel_radius) (geometry/kernels.py:347-447) on
+    seeded points around three barrels; the host SDF the texture builder samples must agree (float32 reference vs float64 here)."""
+    import os
+
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "barrel_sdf_reference_vectors.npz"))
+    for name in ("wide", "tight", "flat"):
+        scale, pts, want = ref[f"{name}/scale"], ref[f"{name}/points"], ref[f"{name}/distance"]
+        got = S.primitive_sdf(GeoType.CYLINDER, scale, pts)
+        assert (want < 0).sum() > 40 and (want > 0).sum() > 40
+        assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())) + 1e-6, (name, np.abs(got - want).max())
+    lo, hi = S.primitive_extents(GeoType.CYLINDER, (0.05, 0.08, 0.13))
+    assert abs(hi[0] - (0.05 + 0.13 - (0.13 ** 2 - 0.08 ** 2) ** 0.5)) < 1e-12 and hi[2] == 0.08 and np.array_equal(lo, -hi)
