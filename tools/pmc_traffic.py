@@ -20,7 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 CAL_FLOATS = 64 * 1024 * 1024  # 256 MiB read + 256 MiB written: past the 256 MiB Infinity Cache
 KERNEL = {"quadruped": "xpbd_rollout", "quadruped_convex": "xpbd_rollout", "box_stack": "xpbd_rollout", "hull_bin": "xpbd_rollout",
-          "quadruped_featherstone": "featherstone_rollout"}
+          "quadruped_featherstone": "featherstone_rollout",
+          # the staged legs of collide(): one launch of the named kernel per substep (the 10 averaged launches = the last timed frame)
+          "hydro_bin": "hydro_stage_faces", "sdf_bin": "sdf_reduce"}
 
 WORKLOAD = r'''
 import sys, ctypes as C
@@ -80,7 +82,7 @@ def main():
         import __graft_entry__ as g  # noqa: PLC0415  (ROOT is on sys.path after build_id())
 
         rec = {"build_id": build_id(), "step_unit": g.step_unit_id(), "workload": workload, "envs": envs, "kernel": KERNEL[workload],
-               "substeps_per_launch": 10}
+               "substeps_per_launch": 1 if workload in ("hydro_bin", "sdf_bin") else 10}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cal, roll = run_pass(counter, workload, envs)
             cal_kib = sum(cal[-2:]) / 2          # steady-state calibration launches
