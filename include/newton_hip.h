@@ -177,6 +177,11 @@ typedef struct {
     uint8_t* pair_hit;    /* [np][ES] 1 if the pair passed the broad phase (candidate pair set, per env) */
     float* cw;            /* 15 * np*cpp * ES floats of solver scratch, only when nt_model.contact_scratch_in_hbm (else NULL); layout
                            * internal to the kernels: one contiguous record per (environment, contact slot) */
+    float* cr;            /* env_count * np*cpp * 32 floats or NULL: scratch of the pair-heavy fused rollout (nt_model.contact_scratch_in_hbm):
+                           * the contact records of a substep as one 128-byte line per (environment, slot) -- that tile runs one
+                           * environment per workgroup, where the env-major `data` costs a cache line per float (measured: 150 GB of
+                           * HBM traffic per launch on config C5's geometry, 30 x the algorithmic bytes).  With it the substeps before the
+                           * last write no Contacts buffer at all; shape0 / shape1 / data receive the last substep's contacts as always */
     const float* prop;    /* [3][np*cpp][ES] or NULL: per-contact stiffness, damping, friction scale
                            * (Contacts.rigid_contact_stiffness / _damping / _friction, contacts.py:227-277); a value > 0
                            * overrides the shape-material ke / kd and scales mu in eval_body_contact

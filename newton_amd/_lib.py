@@ -68,7 +68,7 @@ class nt_flat_rows(C.Structure):
 
 class nt_contacts(C.Structure):
     _fields_ = [("shape0", C.c_void_p), ("shape1", C.c_void_p), ("data", C.c_void_p), ("env_count", C.c_void_p),
-                ("pair_hit", C.c_void_p), ("cw", C.c_void_p), ("prop", C.c_void_p), ("world_xform", C.c_void_p),
+                ("pair_hit", C.c_void_p), ("cw", C.c_void_p), ("cr", C.c_void_p), ("prop", C.c_void_p), ("world_xform", C.c_void_p),
                 ("world_aabb_lower", C.c_void_p), ("world_aabb_upper", C.c_void_p), ("flat", nt_flat_rows)]
 
 

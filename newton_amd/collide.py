@@ -61,6 +61,9 @@ class Contacts:
         # pair-heavy scenes keep the solvers' per-contact records here instead of LDS (nt_model.contact_scratch_in_hbm)
         self._cw = (torch.zeros((15, ns, t.env_stride), dtype=torch.float32, device=dev)
                     if dm.desc.contact_scratch_in_hbm else None)
+        # ... and the fused rollout of that tile its contact records, one 128-byte line per (environment, slot) (nt_contacts.cr)
+        self._cr = (torch.zeros((t.env_count, ns, 32), dtype=torch.float32, device=dev)
+                    if dm.desc.contact_scratch_in_hbm else None)
         # optional per-contact stiffness / damping / friction scale (contacts.py:227-277: rigid_contact_stiffness, _damping,
         # _friction; allocated with per_contact_shape_properties, e.g. for hydroelastic faces), slot layout [3][slots][ES];
         # a positive entry overrides the shape materials in eval_body_contact (SemiImplicit / Featherstone)
@@ -86,6 +89,8 @@ class Contacts:
         d.pair_hit = self._pair_hit.data_ptr()
         if self._cw is not None:
             d.cw = self._cw.data_ptr()
+        if self._cr is not None:
+            d.cr = self._cr.data_ptr()
         if self._prop is not None:
             d.prop = self._prop.data_ptr()
         if self._flat is not None:

@@ -213,12 +213,23 @@ NT_DI void write_contact_slot(const Ctx<EPB>& c, int slot, int sa, int sb, vec3 
     float off_a = ra + margin_a, off_b = rb + margin_b;
     vec3 aw = center - n * (0.5f * dist + ra);
     vec3 bw = center + n * (0.5f * dist + rb);
+    vec3 p0 = xform_point(Xbw_a, aw), p1 = xform_point(Xbw_b, bw);
+    vec3 o0 = xform_vector(Xbw_a, off_a * n), o1 = xform_vector(Xbw_b, -off_b * n);
+    if (c.big && c.aos_records) {  // the pair-heavy rollout's own copy: one line per slot, read back by its contact phases
+        float* o = ct.cr + ((size_t)c.env * ncs + slot) * NT_CR_STRIDE;
+        o[CD_POINT0] = p0.x; o[CD_POINT0 + 1] = p0.y; o[CD_POINT0 + 2] = p0.z;
+        o[CD_POINT1] = p1.x; o[CD_POINT1 + 1] = p1.y; o[CD_POINT1 + 2] = p1.z;
+        o[CD_OFFSET0] = o0.x; o[CD_OFFSET0 + 1] = o0.y; o[CD_OFFSET0 + 2] = o0.z;
+        o[CD_OFFSET1] = o1.x; o[CD_OFFSET1 + 1] = o1.y; o[CD_OFFSET1 + 2] = o1.z;
+        o[CD_NORMAL] = n.x; o[CD_NORMAL + 1] = n.y; o[CD_NORMAL + 2] = n.z;
+        o[CD_MARGIN0] = off_a;
+        o[CD_MARGIN1] = off_b;
+        if (!c.hbm_out) return;  // (the Contacts buffers get the last substep's contacts only)
+    }
     size_t gi = (size_t)slot * c.ES + c.env;
     ct.shape0[gi] = c.newton_shape_id(sa);
     ct.shape1[gi] = c.newton_shape_id(sb);
     float* D = ct.data;
-    vec3 p0 = xform_point(Xbw_a, aw), p1 = xform_point(Xbw_b, bw);
-    vec3 o0 = xform_vector(Xbw_a, off_a * n), o1 = xform_vector(Xbw_b, -off_b * n);
     D[c.g(CD_POINT0 + 0, ncs, slot)] = p0.x; D[c.g(CD_POINT0 + 1, ncs, slot)] = p0.y; D[c.g(CD_POINT0 + 2, ncs, slot)] = p0.z;
     D[c.g(CD_POINT1 + 0, ncs, slot)] = p1.x; D[c.g(CD_POINT1 + 1, ncs, slot)] = p1.y; D[c.g(CD_POINT1 + 2, ncs, slot)] = p1.z;
     D[c.g(CD_OFFSET0 + 0, ncs, slot)] = o0.x; D[c.g(CD_OFFSET0 + 1, ncs, slot)] = o0.y; D[c.g(CD_OFFSET0 + 2, ncs, slot)] = o0.z;
@@ -318,7 +329,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                 nvalid += ok ? 1 : 0;
             }
             if constexpr (!STAGED)
-                for (int i = nvalid; i < cpp; ++i) {
+                for (int i = nvalid; (!c.big || c.hbm_out) && i < cpp; ++i) {
                     size_t gi = (size_t)(p * cpp + i) * c.ES + c.env;
                     ct.shape0[gi] = -1;
                     ct.shape1[gi] = -1;
@@ -342,7 +353,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                     write_contact_slot(c, p * cpp + nvalid, sa, sb, center, n, dist, 0.0f, 0.0f, margin_a, margin_b);
                     nvalid += 1;
                 }
-                for (int i = nvalid; i < cpp; ++i) {
+                for (int i = nvalid; (!c.big || c.hbm_out) && i < cpp; ++i) {
                     size_t gi = (size_t)(p * cpp + i) * c.ES + c.env;
                     ct.shape0[gi] = -1;
                     ct.shape1[gi] = -1;
@@ -380,7 +391,7 @@ NT_DI void pair_eval_item(const Ctx<EPB>& c, const int p) {
                 for (int i = 0; i < cpp; ++i) {
                     if (i < nvalid) {
                         write_contact_slot(c, p * cpp + i, sa, sb, cc.center(i), n, cc.distance(i), ra, rb, margin_a, margin_b);
-                    } else {
+                    } else if (!c.big || c.hbm_out) {
                         size_t gi = (size_t)(p * cpp + i) * c.ES + c.env;
                         ct.shape0[gi] = -1;
                         ct.shape1[gi] = -1;
@@ -495,11 +506,11 @@ NT_DI void phase_pairs_big_broad(const Ctx<EPB>& c) {
     if (c.valid)
         for (int p = c.slot; p < m.np; p += c.nslot) {
             const bool hit = pair_aabb_hit(c, p);
-            ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
+            if (c.hbm_out) ct.pair_hit[(size_t)p * c.ES + c.env] = hit ? 1 : 0;
             if (hit) {
                 c.T.hit_list[atomicAdd(c.T.hit_count, 1)] = p;
             } else {
-                for (int i = 0; i < m.cpp; ++i) {
+                for (int i = 0; c.hbm_out && i < m.cpp; ++i) {
                     size_t gi = (size_t)(p * m.cpp + i) * c.ES + c.env;
                     ct.shape0[gi] = -1;
                     ct.shape1[gi] = -1;

@@ -24,6 +24,8 @@ struct Ctx {
     bool gworld_ready;  // T.gworld holds the global shapes' world transforms / AABBs (stage_global_world ran, a barrier ago)
     bool lds_records;  // NT_TILE_LDS_RECORDS granted: the contact records of this launch live in L.cr
     bool hbm_out;      // the collide phases write the Contacts buffers in HBM (always, except the non-final substeps of an LDS-record rollout)
+    bool aos_records;  // pair-heavy fused rollout: the substep's contact records live in nt_contacts.cr (one line per slot); hbm_out then
+                       // only holds for the last substep
     bool big;  // contact records in HBM, manifold polygon scratch per lane (compile-time constant at every construction site)
     int ES;
     bool valid;
@@ -37,6 +39,7 @@ struct Ctx {
         pose_in_off = L.bq.off;
         lds_records = rows < 0 && (a.tile_opts & NT_TILE_LDS_RECORDS) != 0;
         hbm_out = true;
+        aos_records = false;
         if (rows < 0) rows = L.rows_per_env;
         e = threadIdx.x % N;
         slot = threadIdx.x / N;
@@ -109,7 +112,7 @@ struct Ctx {
     template <class OtherCtx>
     NT_DI explicit Ctx(const OtherCtx& o, int /*tag*/)
         : a(o.a), T(o.T), lds(o.lds), up(o.up), L(o.L), e(o.e), slot(o.slot), env(o.env), nslot(o.nslot), tslot(o.tslot),
-          pose_in_off(o.pose_in_off), lane_split(o.lane_split), gworld_ready(o.gworld_ready), lds_records(o.lds_records), hbm_out(o.hbm_out), big(o.big),
+          pose_in_off(o.pose_in_off), lane_split(o.lane_split), gworld_ready(o.gworld_ready), lds_records(o.lds_records), hbm_out(o.hbm_out), aos_records(o.aos_records), big(o.big),
           ES(o.ES), valid(o.valid) {}
     // LDS element (comp, s) of a slot-major field.  `n` (the slot count of the [comp][n] HBM twin) is not needed here; the
     // argument stays so that every access reads like its global-memory counterpart g(comp, n, s)

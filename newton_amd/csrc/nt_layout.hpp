@@ -82,6 +82,7 @@ struct LdsLayout {
     int rows_semi;     // SolverSemiImplicit kernel (its wrench records share the scratch with body_f_tmp + joint wrenches)
 };
 
+constexpr int NT_CR_STRIDE = 32;  // floats per (environment, slot) record of nt_contacts.cr: 17 used, one 128-byte line
 constexpr int NT_BIG_SCENE_LANES = 256;  // workgroup size of the pair-heavy one-environment-per-workgroup tile ...
 constexpr int NT_BIG_SCENE_LANES_WIDE = 384;  // ... and its wide form, taken when 20 more rows of manifold polygon scratch per extra lane
                                               // still fit the CU: two of the four SIMDs then interleave two waves (the pair phase is a

@@ -375,6 +375,16 @@ struct LdsRecord {  // the slot's record in L.cr (LDS-record tiles of the fused 
     NT_DI vec3 normal() const { return c.lv3(c.L.cr, CD_NORMAL, ncs, slot); }
     NT_DI float margins() const { return c.l(c.L.cr, CD_MARGIN0, ncs, slot) + c.l(c.L.cr, CD_MARGIN1, ncs, slot); }
 };
+template <int EPB>
+struct AosRecord {  // the slot's line of nt_contacts.cr (pair-heavy fused rollout)
+    const float* o;
+    NT_DI vec3 point0() const { return vec3(o[CD_POINT0], o[CD_POINT0 + 1], o[CD_POINT0 + 2]); }
+    NT_DI vec3 point1() const { return vec3(o[CD_POINT1], o[CD_POINT1 + 1], o[CD_POINT1 + 2]); }
+    NT_DI vec3 offset0() const { return vec3(o[CD_OFFSET0], o[CD_OFFSET0 + 1], o[CD_OFFSET0 + 2]); }
+    NT_DI vec3 offset1() const { return vec3(o[CD_OFFSET1], o[CD_OFFSET1 + 1], o[CD_OFFSET1 + 2]); }
+    NT_DI vec3 normal() const { return vec3(o[CD_NORMAL], o[CD_NORMAL + 1], o[CD_NORMAL + 2]); }
+    NT_DI float margins() const { return o[CD_MARGIN0] + o[CD_MARGIN1]; }
+};
 struct FlatRecord {
     const nt_flat_rows& f;
     int r;
@@ -570,7 +580,10 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot, const int live_pair =
         body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         live = body_a != body_b;
     }
-    if (live && !described) rec = load_record(SlotRecord<EPB>{c, ct.data, ncs, slot});
+    if (live && !described) {
+        if (FUSED && c.big && c.aos_records) rec = load_record(AosRecord<EPB>{ct.cr + ((size_t)c.env * ncs + slot) * NT_CR_STRIDE});
+        else rec = load_record(SlotRecord<EPB>{c, ct.data, ncs, slot});
+    }
     if (live && contact_solve(c, rec, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b)) {
         has_a = body_a >= 0 ? 1.0f : 0.0f;
         has_b = body_b >= 0 ? 1.0f : 0.0f;

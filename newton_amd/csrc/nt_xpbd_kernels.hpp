@@ -218,6 +218,9 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
         if ((a.tile_opts & NT_TILE_POSE_SNAPSHOT) && a.m.np <= a.nslot && ((a.m.np + spw - 1) / spw) * spw + a.m.nb <= a.nslot)
             c.pose_in_off = c.L.xiq.off;
     }
+    // pair-heavy tile: the substeps' contact records go through nt_contacts.cr, the Contacts buffers get the last substep's (the plain
+    // position solve only: restitution reads the API layout)
+    if constexpr (BIG) c.aos_records = a.ct.cr != nullptr && !xpbd_keeps_prestep_state(a.p);
     const fused::Ctx<EPB> cf(c, 0);
     const int nb = a.m.nb;
     load_tile(c, &a.s_in, true);
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_rollout_kernel(KArgs a) {
     __syncthreads();
     NT_TICK(0);
     for (int s = 0; s < a.substeps; ++s) {
-        c.hbm_out = !c.lds_records || s == a.substeps - 1;
+        c.hbm_out = !(c.lds_records || c.aos_records) || s == a.substeps - 1;
         if constexpr (BIG) {
             do_collide<EPB, CVX>(c, s == a.substeps - 1);
             fused::do_xpbd_step<EPB, true, fused::CwHbm>(cf, true);

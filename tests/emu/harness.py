@@ -142,6 +142,7 @@ class EmuContacts:
         self.pair_hit = np.zeros((max(t.np, 1), t.env_stride), dtype=np.uint8)
         self.scan = np.zeros(4 * (t.env_stride + 1), dtype=np.int32)
         self.cw = np.zeros((15, ns, t.env_stride), dtype=np.float32) if em.desc.contact_scratch_in_hbm else None
+        self.cr = np.zeros((t.env_count, ns, 32), dtype=np.float32) if em.desc.contact_scratch_in_hbm else None
         self.rigid_contact_max = t.env_count * t.np * t.cpp
         self.prop = None  # optional per-slot stiffness / damping / friction scale [3][ns][ES]
 
@@ -151,6 +152,8 @@ class EmuContacts:
         d.env_count, d.pair_hit = _ptr(self.env_count), _ptr(self.pair_hit)
         if self.cw is not None:
             d.cw = _ptr(self.cw)
+        if self.cr is not None:
+            d.cr = _ptr(self.cr)
         if self.prop is not None:
             d.prop = _ptr(self.prop)
         return d

@@ -348,10 +348,17 @@ def test_pair_heavy_scene_keeps_contact_records_in_hbm(H, n_hulls, n_env):
     assert _close(s0.aos("body_q"), os0.body_q, 1e-5) and _close(s0.aos("body_qd"), os0.body_qd, 2e-4)
     if n_env > 1:  # fused rollout == launch-by-launch loop, bitwise
         out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1.0 / 600.0, 3)
+        # (the rollout keeps its substeps' records in nt_contacts.cr and writes the Contacts buffers at the last substep only)
+        ids0, ids1, data, hit = ct.shape0.copy(), ct.shape1.copy(), ct.data.copy(), ct.pair_hit.copy()
         a, b = H.EmuState(em), H.EmuState(em)
-        for _ in range(3):
+        for k in range(3):
             a.body_f[:] = 0
             H.collide(em, a, ct)
+            if k == 2:  # the Contacts the rollout left are those of its last collide
+                E = model.env.env_count
+                live = ct.shape0[:, :E] != ct.shape1[:, :E]
+                assert np.array_equal(ids0[:, :E], ct.shape0[:, :E]) and np.array_equal(ids1[:, :E], ct.shape1[:, :E])
+                assert np.array_equal(hit[:, :E], ct.pair_hit[:, :E]) and np.array_equal(data[:, :, :E][:, live], ct.data[:, :, :E][:, live])
             H.xpbd_step(em, a, b, ctrl, ct, 1.0 / 600.0)
             a, b = b, a
         assert np.array_equal(out.body_q, a.body_q) and np.array_equal(out.body_qd, a.body_qd)
