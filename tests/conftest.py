@@ -13,6 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The no-GPU suite (`-m "not gpu"`) spends its time in the emulated kernels -- one OS thread per GPU thread, mostly waiting on
+    barriers -- and its tests are independent (the emulator build is behind a file lock, the multi-process tests take OS-assigned
+    ports): hand it to pytest-xdist when that is installed and nobody chose a worker count (18.5 min -> 80 s on 8 cores).  Runs that
+    select GPU tests are never parallelised (one device); NT_TEST_SERIAL=1 keeps this suite serial too."""
+    if os.environ.get("NT_TEST_SERIAL") or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if "not gpu" not in (config.getoption("markexpr", "") or "") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
+    if getattr(config.option, "numprocesses", None) in (None, 0) and getattr(config.option, "dist", "no") == "no":
+        n = min(8, max(1, (os.cpu_count() or 1) - 2))
+        if n >= 3:
+            config.option.numprocesses = n
+    return None
+
+
 def _has_gpu():
     try:
         import torch
