@@ -23,7 +23,9 @@ def pytest_cmdline_main(config):
         return None
     if "not gpu" not in (config.getoption("markexpr", "") or "") or os.environ.get("PYTEST_XDIST_WORKER"):
         return None
-    if getattr(config.option, "numprocesses", None) in (None, 0) and getattr(config.option, "dist", "no") == "no":
+    explicit = any(a == "-n" or a.startswith("-n") and a[2:3].isdigit() or a.startswith("--numprocesses") or a.startswith("--dist")
+                   for a in config.invocation_params.args)  # (the caller chose: -n 0 means serial)
+    if not explicit and getattr(config.option, "numprocesses", None) in (None, 0) and getattr(config.option, "dist", "no") == "no":
         n = min(8, max(1, (os.cpu_count() or 1) - 2))
         if n >= 3:
             config.option.numprocesses = n
