@@ -61,7 +61,8 @@ class Contacts:
         # pair-heavy scenes keep the solvers' per-contact records here instead of LDS (nt_model.contact_scratch_in_hbm)
         self._cw = (torch.zeros((15, ns, t.env_stride), dtype=torch.float32, device=dev)
                     if dm.desc.contact_scratch_in_hbm else None)
-        # ... and the fused rollout of that tile its contact records, one 128-byte line per (environment, slot) (nt_contacts.cr)
+        # ... and the fused rollout of that tile its contact records, one 128-byte line per (environment, slot) (nt_contacts.cr; 3 GB
+        # for config C5's geometry at 2 048 worlds.  Allocated here, not on first use: a first rollout may sit inside a hipGraph capture)
         self._cr = (torch.zeros((t.env_count, ns, 32), dtype=torch.float32, device=dev)
                     if dm.desc.contact_scratch_in_hbm else None)
         # optional per-contact stiffness / damping / friction scale (contacts.py:227-277: rigid_contact_stiffness, _damping,
