@@ -850,6 +850,10 @@ int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m);
 int32_t nt_lds_bytes_per_env(const nt_model* m); /* LDS footprint of one env in the step kernels */
 /* dst[i] = src[i], 4 B/lane coalesced: known-byte-count kernel used to calibrate the HBM PMC counters */
 nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream);
+/* dst[i] = src[i] in 16 B per lane (src / dst 16-byte aligned, n a multiple of 4): the streaming copy bench.py times to print the
+ * HBM bandwidth this box reaches (2 n 4 bytes per call) beside the 8 TB/s vendor figure the roofline fraction is quoted against
+ * (BASELINE.md section 5).  Measurement aid, no reference counterpart. */
+nt_status nt_bandwidth_probe(const float* src, float* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -345,6 +345,7 @@ SYMBOLS = {
     "nt_lds_bytes_per_env": (C.c_int32, [C.POINTER(nt_model)]),
     "nt_pick_envs_per_block": (C.c_int32, [C.POINTER(nt_model), C.c_int32]),
     "nt_calibration_copy": (C.c_int32, [_P, _P, C.c_int64, _P]),
+    "nt_bandwidth_probe": (C.c_int32, [_P, _P, C.c_int64, _P]),
     "nt_graph_capture_begin": (C.c_int32, [_P]),
     "nt_graph_capture_end": (C.c_int32, [_P, C.POINTER(_P)]),
     "nt_graph_launch": (C.c_int32, [_P, _P]),

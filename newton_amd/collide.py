@@ -61,10 +61,12 @@ class Contacts:
         # pair-heavy scenes keep the solvers' per-contact records here instead of LDS (nt_model.contact_scratch_in_hbm)
         self._cw = (torch.zeros((15, ns, t.env_stride), dtype=torch.float32, device=dev)
                     if dm.desc.contact_scratch_in_hbm else None)
-        # ... and the fused rollout of that tile its contact records, one 128-byte line per (environment, slot) (nt_contacts.cr; 3 GB
-        # for config C5's geometry at 2 048 worlds.  Allocated here, not on first use: a first rollout may sit inside a hipGraph capture)
-        self._cr = (torch.zeros((t.env_count, ns, 32), dtype=torch.float32, device=dev)
-                    if dm.desc.contact_scratch_in_hbm else None)
+        # ... and the fused XPBD rollout of that tile its contact records, one 128-byte line per (environment, slot) (nt_contacts.cr: 3 GB
+        # for config C5's geometry at 2 048 worlds).  Only that rollout reads them, so they are allocated by prepare_rollout() -- which
+        # SolverXPBD.rollout calls on first use and newton_amd.graph.capture before it records -- not for collide-only / per-step /
+        # restitution / SDF-leg users (the kernels fall back to the Contacts buffers while nt_contacts.cr is NULL)
+        self._cr = None
+        self._cr_shape = (t.env_count, ns, 32) if dm.desc.contact_scratch_in_hbm else None
         # optional per-contact stiffness / damping / friction scale (contacts.py:227-277: rigid_contact_stiffness, _damping,
         # _friction; allocated with per_contact_shape_properties, e.g. for hydroelastic faces), slot layout [3][slots][ES];
         # a positive entry overrides the shape materials in eval_body_contact (SemiImplicit / Featherstone)
@@ -80,6 +82,16 @@ class Contacts:
         if "force" in model.get_requested_contact_attributes():
             self.force = torch.zeros((max(self.rigid_contact_max, 1), 6), dtype=torch.float32, device=dev)
             self._impulse = torch.zeros((6, ns, t.env_stride), dtype=torch.float32, device=dev)
+
+    def prepare_rollout(self) -> None:
+        """Allocate what only the fused XPBD rollout of a pair-heavy scene reads (nt_contacts.cr).  Idempotent; call it before a hipGraph
+        capture that records a first rollout (a capture must not allocate; newton_amd.graph.capture does it for its `contacts`).  Inside a
+        capture that nobody prepared the rollout runs without the buffer (same results, more HBM traffic)."""
+        if self._cr is None and self._cr_shape is not None:
+            torch = _torch()
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return
+            self._cr = torch.zeros(self._cr_shape, dtype=torch.float32, device=self._data.device)
 
     def _desc(self) -> _lib.nt_contacts:
         d = _lib.nt_contacts()

@@ -14,7 +14,7 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
     vec3 mv(effective_gap, effective_gap, effective_gap);
     bool infinite_plane = (geo_type == GEO_PLANE) && (scale.x == 0.0f && scale.y == 0.0f);
     if (infinite_plane) {
-        vec3 normal = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        vec3 normal = quat_rotate_ez(q);
         const float H = 1.0e6f;
         vec3 he(H, H, H);
         lo = pos - he - mv;
@@ -35,21 +35,21 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
     if (geo_type == GEO_SPHERE) {
         he = vec3(scale.x, scale.x, scale.x);
     } else if (geo_type == GEO_BOX) {
-        vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
-        vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
-        vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        vec3 r0 = quat_rotate_ex(q);
+        vec3 r1 = quat_rotate_ey(q);
+        vec3 r2 = quat_rotate_ez(q);
         he = vec3(fabsf(r0.x) * scale.x + fabsf(r1.x) * scale.y + fabsf(r2.x) * scale.z,
                   fabsf(r0.y) * scale.x + fabsf(r1.y) * scale.y + fabsf(r2.y) * scale.z,
                   fabsf(r0.z) * scale.x + fabsf(r1.z) * scale.y + fabsf(r2.z) * scale.z);
     } else if (geo_type == GEO_CAPSULE) {
-        vec3 axis = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        vec3 axis = quat_rotate_ez(q);
         he = vec3(scale.x, scale.x, scale.x) + vabs(axis) * scale.y;
     } else if (geo_type == GEO_CYLINDER) {
         float radius = scale.x, hh = scale.y, barrel = scale.z;
         if (barrel >= hh && barrel > 0.0f) radius += (hh * hh) / (barrel + sqrtf(barrel * barrel - hh * hh));
-        vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
-        vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
-        vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        vec3 r0 = quat_rotate_ex(q);
+        vec3 r1 = quat_rotate_ey(q);
+        vec3 r2 = quat_rotate_ez(q);
         he = vec3(radius * sqrtf(r0.x * r0.x + r1.x * r1.x) + hh * fabsf(r2.x),
                   radius * sqrtf(r0.y * r0.y + r1.y * r1.y) + hh * fabsf(r2.y),
                   radius * sqrtf(r0.z * r0.z + r1.z * r1.z) + hh * fabsf(r2.z));
@@ -61,9 +61,9 @@ NT_DI void shape_aabb(int geo_type, const xform& X, vec3 scale, float effective_
         vec3 center = (local_lo + local_hi) * 0.5f;
         vec3 half = (local_hi - local_lo) * 0.5f;
         vec3 world_center = quat_rotate(q, center) + pos;
-        vec3 r0 = quat_rotate(q, vec3(1.0f, 0.0f, 0.0f));
-        vec3 r1 = quat_rotate(q, vec3(0.0f, 1.0f, 0.0f));
-        vec3 r2 = quat_rotate(q, vec3(0.0f, 0.0f, 1.0f));
+        vec3 r0 = quat_rotate_ex(q);
+        vec3 r1 = quat_rotate_ey(q);
+        vec3 r2 = quat_rotate_ez(q);
         vec3 world_half(fabsf(r0.x) * half.x + fabsf(r1.x) * half.y + fabsf(r2.x) * half.z,
                         fabsf(r0.y) * half.x + fabsf(r1.y) * half.y + fabsf(r2.y) * half.z,
                         fabsf(r0.z) * half.x + fabsf(r1.z) * half.y + fabsf(r2.z) * half.z);
@@ -167,15 +167,16 @@ NT_DI void store_global_shapes_world(const Ctx<EPB>& c) {
 template <int EPB>
 NT_DI void stage_global_world(const Ctx<EPB>& c) {
     const nt_model& m = c.a.m;
-    const int k = (int)blockDim.x - 1 - (int)threadIdx.x;
-    if (k >= m.ng) return;
-    const int s = m.ns + k;
-    xform X = c.shape_local_xform(s);
-    vec3 lo, hi;
-    shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), m.shape_mesh_bounds + 6 * s, lo, hi);
-    float* g = c.T.gworld + 13 * k;
-    g[0] = X.p.x; g[1] = X.p.y; g[2] = X.p.z; g[3] = X.q.x; g[4] = X.q.y; g[5] = X.q.z; g[6] = X.q.w;
-    g[7] = lo.x; g[8] = lo.y; g[9] = lo.z; g[10] = hi.x; g[11] = hi.y; g[12] = hi.z;
+    // (workgroup-strided: a scene may carry more global shapes than the workgroup has lanes -- 64 in the narrow Featherstone tiles)
+    for (int k = (int)blockDim.x - 1 - (int)threadIdx.x; k < m.ng; k += (int)blockDim.x) {
+        const int s = m.ns + k;
+        xform X = c.shape_local_xform(s);
+        vec3 lo, hi;
+        shape_aabb(c.T.shape_type[s], X, c.shape_scale(s), c.shape_f(s, SP_MARGIN) + c.shape_f(s, SP_GAP), m.shape_mesh_bounds + 6 * s, lo, hi);
+        float* g = c.T.gworld + 13 * k;
+        g[0] = X.p.x; g[1] = X.p.y; g[2] = X.p.z; g[3] = X.q.x; g[4] = X.q.y; g[5] = X.q.z; g[6] = X.q.w;
+        g[7] = lo.x; g[8] = lo.y; g[9] = lo.z; g[10] = hi.x; g[11] = hi.y; g[12] = hi.z;
+    }
 }
 template <int EPB>
 NT_DI void shape_world(const Ctx<EPB>& c, int s, xform& X, vec3& lo, vec3& hi) {

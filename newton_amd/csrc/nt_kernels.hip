@@ -94,6 +94,18 @@ __global__ void calibration_copy_kernel(const float* __restrict__ src, float* __
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// the same copy in 16 B per lane, grid-strided over 16 workgroups per CU: the streaming rate of this box (bench.py prints it as
+// roofline.hbm_peak_measured beside the vendor peak)
+__global__ void __launch_bounds__(256) bandwidth_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // four loads in flight per lane
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 // masked env-column copy: dst[row][env] = src[row][env] for every env whose mask byte is non-zero (RL-style world reset)
 __global__ void masked_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, const uint8_t* __restrict__ mask,
                                    int rows, int E, int ES) {
@@ -791,6 +803,17 @@ nt_status nt_state_reset(const nt_model* m, nt_state* dst, const nt_state* src, 
 nt_status nt_calibration_copy(const float* src, float* dst, int64_t n, void* stream) {
     if (!src || !dst || n <= 0) return NT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(calibration_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, src, dst, (size_t)n);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}
+
+nt_status nt_bandwidth_probe(const float* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0 || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return NT_ERR_INVALID_ARG;
+#ifdef NT_EMULATED_GRID
+    const int blocks = NT_EMULATED_GRID;
+#else
+    const int blocks = 4096;
+#endif
+    hipLaunchKernelGGL(bandwidth_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)n / 4);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
 

@@ -274,36 +274,36 @@ NT_DI bool primitive_pair(int type_a, int type_b, const xform& Xa, const xform& 
 
     bool use_plane_cylinder = plane_a && cylinder_b;
     if (use_plane_cylinder && sb.z > 0.0f) {
-        vec3 pn = quat_rotate(Xa.q, ez);
-        vec3 ca = quat_rotate(Xb.q, ez);
+        vec3 pn = quat_rotate_ez(Xa.q);
+        vec3 ca = quat_rotate_ez(Xb.q);
         use_plane_cylinder = fabsf(dot(pn, ca)) * sb.z >= sb.y;
     }
     if (plane_a && sphere_b) {
-        vec3 pn = quat_rotate(Xa.q, ez);
+        vec3 pn = quat_rotate_ez(Xa.q);
         plane_sphere(pn, Xa.p, Xb.p, sb.x, out.d0, out.p0);
         out.normal = pn;
     } else if (plane_a && ellipsoid_b) {
-        plane_ellipsoid(quat_rotate(Xa.q, ez), Xa.p, Xb.p, quat_to_matrix(Xb.q), sb, out);
+        plane_ellipsoid(quat_rotate_ez(Xa.q), Xa.p, Xb.p, quat_to_matrix(Xb.q), sb, out);
     } else if (plane_a && box_b) {
-        plane_box(quat_rotate(Xa.q, ez), Xa.p, Xb.p, quat_to_matrix(Xb.q), sb, box_margin, out);
+        plane_box(quat_rotate_ez(Xa.q), Xa.p, Xb.p, quat_to_matrix(Xb.q), sb, box_margin, out);
     } else if (sphere_a && sphere_b) {
         sphere_sphere(Xa.p, sa.x, Xb.p, sb.x, out.d0, out.p0, out.normal);
     } else if (plane_a && capsule_b) {
-        vec3 pn = quat_rotate(Xa.q, ez);
-        vec3 seg = quat_rotate(Xb.q, ez) * sb.y;
+        vec3 pn = quat_rotate_ez(Xa.q);
+        vec3 seg = quat_rotate_ez(Xb.q) * sb.y;
         plane_sphere(pn, Xa.p, Xb.p + seg, sb.x, out.d0, out.p0);
         plane_sphere(pn, Xa.p, Xb.p - seg, sb.x, out.d1, out.p1);
         out.normal = pn;
     } else if (use_plane_cylinder) {
-        plane_cylinder(quat_rotate(Xa.q, ez), Xa.p, Xb.p, quat_rotate(Xb.q, ez), sb.x, sb.y, out);
+        plane_cylinder(quat_rotate_ez(Xa.q), Xa.p, Xb.p, quat_rotate_ez(Xb.q), sb.x, sb.y, out);
     } else if (sphere_a && capsule_b) {
-        vec3 seg = quat_rotate(Xb.q, ez) * sb.y;
+        vec3 seg = quat_rotate_ez(Xb.q) * sb.y;
         vec3 pt = closest_segment_point(Xb.p - seg, Xb.p + seg, Xa.p);
         sphere_sphere(Xa.p, sa.x, pt, sb.x, out.d0, out.p0, out.normal);
     } else if (capsule_a && capsule_b) {
-        capsule_capsule(Xa.p, quat_rotate(Xa.q, ez), sa.x, sa.y, Xb.p, quat_rotate(Xb.q, ez), sb.x, sb.y, out);
+        capsule_capsule(Xa.p, quat_rotate_ez(Xa.q), sa.x, sa.y, Xb.p, quat_rotate_ez(Xb.q), sb.x, sb.y, out);
     } else if (sphere_a && cylinder_b && sb.z == 0.0f) {
-        sphere_cylinder(Xa.p, sa.x, Xb.p, quat_rotate(Xb.q, ez), sb.x, sb.y, out.d0, out.p0, out.normal);
+        sphere_cylinder(Xa.p, sa.x, Xb.p, quat_rotate_ez(Xb.q), sb.x, sb.y, out.d0, out.p0, out.normal);
     } else if (sphere_a && box_b) {
         sphere_box(Xa.p, sa.x, Xb.p, quat_to_matrix(Xb.q), sb, out.d0, out.p0, out.normal);
     }

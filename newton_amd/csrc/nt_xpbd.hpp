@@ -425,7 +425,7 @@ NT_DI LoadedRecord load_record(const REC& r) {
 // took ~45 dependent round trips per contact, this one four.
 template <int EPB, class REC>
 NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int shape_b, int body_a, int body_b, vec3& lin_delta_a,
-                         vec3& ang_delta_a, vec3& ang_delta_b) {
+                         vec3& ang_delta_a, vec3& ang_delta_b, const bool full_a) {
     const float dt = c.a.dt, relaxation = c.a.p.rigid_contact_relaxation;
     const bool ha = body_a >= 0, hb = body_b >= 0, sha = shape_a >= 0, shb = shape_b >= 0;
     const int ba = ha ? body_a : 0, bb = hb ? body_b : 0, sa = sha ? shape_a : 0, sb = shb ? shape_b : 0;
@@ -459,45 +459,77 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
         mu_torsional *= 0.5f;
         mu_rolling *= 0.5f;
     }
-    vec3 r_a = quat_rotate(q_a, point0 - com_a);
-    vec3 r_b = quat_rotate(q_b, point1 - com_b);
-    vec3 bx_a = wc_a + r_a;
-    vec3 bx_b = wc_b + r_b;
+    // A static side (ground, fixed geometry: most contacts of a walking scene) has the identity pose, a zero W tile and zero velocities:
+    // its contact point is the record's point, its quadratic forms and velocity terms vanish and its corrections are never applied
+    // (has_a / has_b clear) -- the arithmetic below is skipped for it, by a branch the wave takes only if one of its contacts has a
+    // moving body on that side (operands stay fetched up front: the loads above leave as one batch either way).  full_a: the
+    // caller reports Contacts.force, which carries (lin_delta_a, ang_delta_a) of a static shape0 too (xpbd/kernels.py:2394-2395).
+    const bool ca = ha || full_a;
+    vec3 r_a, r_b, angular_a, angular_b;
+    vec3 bx_a = point0, bx_b = point1;
+    float wq_a = 0.0f, wq_b = 0.0f;
+    if (ca) {
+        r_a = quat_rotate(q_a, point0 - com_a);
+        bx_a = wc_a + r_a;
+    }
+    if (hb) {
+        r_b = quat_rotate(q_b, point1 - com_b);
+        bx_b = wc_b + r_b;
+    }
     float d = dot(n, bx_b - bx_a) - margins;
     if (!(d < 0.0f)) return false;
     vec3 lin_delta_b;
-    vec3 angular_a = -cross(r_a, n);
-    vec3 angular_b = cross(r_b, n);
+    if (ca) {
+        angular_a = -cross(r_a, n);
+        wq_a = W_a.quad(angular_a);
+    }
+    if (hb) {
+        angular_b = cross(r_b, n);
+        wq_b = W_b.quad(angular_b);
+    }
 
-    float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, W_a.quad(angular_a), W_b.quad(angular_b), relaxation, dt);
+    float lambda_n = contact_constraint_delta(d, m_inv_a, m_inv_b, -n, n, wq_a, wq_b, relaxation, dt);
     lin_delta_a = -n * lambda_n;
     lin_delta_b = n * lambda_n;
     ang_delta_a = angular_a * lambda_n;
     ang_delta_b = angular_b * lambda_n;
 
     {  // friction row (applies when mu > 0 and the tangential error is non-zero)
-        r_a = quat_rotate(q_a, (point0 + offset_a) - com_a);
-        r_b = quat_rotate(q_b, (point1 + offset_b) - com_b);
-        bx_a = wc_a + r_a;
-        bx_b = wc_b + r_b;
+        bx_a = point0 + offset_a;
+        bx_b = point1 + offset_b;
+        if (ca) {
+            r_a = quat_rotate(q_a, bx_a - com_a);
+            bx_a = wc_a + r_a;
+        }
+        if (hb) {
+            r_b = quat_rotate(q_b, bx_b - com_b);
+            bx_b = wc_b + r_b;
+        }
         vec3 delta = bx_b - bx_a;
         vec3 friction_delta = delta - dot(n, delta) * n;
-        vec3 rel_v_kin_t(0.0f);
-        {
+        if (kin_a || kin_b) {  // a kinematic body drags the contact along: its tangential velocity enters the error
+            vec3 rel_v_kin_t(0.0f);
             vec3 v_a = velocity_at_point(spatial(vel_a, omega_a), r_a);
             vec3 t_a = v_a - dot(n, v_a) * n;
             if (kin_a) rel_v_kin_t = rel_v_kin_t - t_a;
             vec3 v_b = velocity_at_point(spatial(vel_b, omega_b), r_b);
             vec3 t_b = v_b - dot(n, v_b) * n;
             if (kin_b) rel_v_kin_t = rel_v_kin_t + t_b;
+            friction_delta += rel_v_kin_t * dt;
         }
-        friction_delta += rel_v_kin_t * dt;
         const float err = xlength(friction_delta);
         const vec3 perp = vsel(err > 0.0f, xdiv(friction_delta, err), vec3());  // xnormalize, as a select
-        angular_a = -cross(r_a, perp);
-        angular_b = cross(r_b, perp);
-        float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, W_a.quad(angular_a), W_b.quad(angular_b),
-                                                   relaxation, dt);
+        wq_a = 0.0f; wq_b = 0.0f;
+        angular_a = vec3(); angular_b = vec3();
+        if (ca) {
+            angular_a = -cross(r_a, perp);
+            wq_a = W_a.quad(angular_a);
+        }
+        if (hb) {
+            angular_b = cross(r_b, perp);
+            wq_b = W_b.quad(angular_b);
+        }
+        float lambda_fr = contact_constraint_delta(err, m_inv_a, m_inv_b, -perp, perp, wq_a, wq_b, relaxation, dt);
         lambda_fr = fmaxw(lambda_fr, -lambda_n * mu);
         if (!(mu > 0.0f && err > 0.0f)) lambda_fr = 0.0f;
         lin_delta_a -= perp * lambda_fr;
@@ -509,7 +541,9 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
     const vec3 lin0(0.0f);
     {  // torsional friction about the normal (v^T W v is even in v: one quadratic form per body serves -n and n)
         float err = dot(delta_omega, n) * dt;
-        float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin0, lin0, W_a.quad(n), W_b.quad(n), relaxation, dt);
+        wq_a = ca ? W_a.quad(n) : 0.0f;
+        wq_b = hb ? W_b.quad(n) : 0.0f;
+        float lt = contact_constraint_delta(err, m_inv_a, m_inv_b, lin0, lin0, wq_a, wq_b, relaxation, dt);
         lt = clampf(lt, -lambda_n * mu_torsional, lambda_n * mu_torsional);
         if (!(mu_torsional > 0.0f && fabsf(err) > 0.0f)) lt = 0.0f;
         ang_delta_a -= n * lt;
@@ -520,7 +554,9 @@ NT_DI bool contact_solve(const Ctx<EPB>& c, const REC& rec, int shape_a, int sha
         const float len = xlength(delta_omega);
         const float err = len * dt;
         const vec3 roll_n = vsel(len > 0.0f, xdiv(delta_omega, len), vec3());  // xnormalize, as a select
-        float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin0, lin0, W_a.quad(roll_n), W_b.quad(roll_n), relaxation, dt);
+        wq_a = ca ? W_a.quad(roll_n) : 0.0f;
+        wq_b = hb ? W_b.quad(roll_n) : 0.0f;
+        float lr = contact_constraint_delta(err, m_inv_a, m_inv_b, lin0, lin0, wq_a, wq_b, relaxation, dt);
         lr = fmaxw(lr, -lambda_n * mu_rolling);
         if (!(mu_rolling > 0.0f && err > 0.0f)) lr = 0.0f;
         ang_delta_a -= roll_n * lr;
@@ -584,7 +620,8 @@ NT_DI void contact_item(const Ctx<EPB>& c, const int slot, const int live_pair =
         if (FUSED && c.big && c.aos_records) rec = load_record(AosRecord<EPB>{ct.cr + ((size_t)c.env * ncs + slot) * NT_CR_STRIDE});
         else rec = load_record(SlotRecord<EPB>{c, ct.data, ncs, slot});
     }
-    if (live && contact_solve(c, rec, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b)) {
+    if (live && contact_solve(c, rec, shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b,
+                              !FUSED && c.a.rep.contact_impulse != nullptr)) {
         has_a = body_a >= 0 ? 1.0f : 0.0f;
         has_b = body_b >= 0 ? 1.0f : 0.0f;
         if (described) a_is_pair_a = swapped ? 0.0f : 1.0f;
@@ -608,7 +645,8 @@ NT_DI void flat_contact_item(const Ctx<EPB>& c, const int r) {
         const int shape_a = gid_a >= 0 ? c.local_shape_id(gid_a) : -1, shape_b = gid_b >= 0 ? c.local_shape_id(gid_b) : -1;
         const int body_a = shape_a >= 0 ? c.T.shape_body[shape_a] : -1, body_b = shape_b >= 0 ? c.T.shape_body[shape_b] : -1;
         if (body_a != body_b &&
-            contact_solve(c, load_record(FlatRecord{f, r}), shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b))
+            contact_solve(c, load_record(FlatRecord{f, r}), shape_a, shape_b, body_a, body_b, lin_delta_a, ang_delta_a, ang_delta_b,
+                          c.a.rep.contact_impulse != nullptr))
             flags = (body_a >= 0 ? 1.0f : 0.0f) + (body_b >= 0 ? 2.0f : 0.0f);
     }
     float* o = f.cw + CWX_FLOATS * (size_t)r;
@@ -975,6 +1013,8 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
             mat33 frame_p = quat_to_matrix(X_wp.q);
             vec3 r_p = xform_point(X_wp, projected_rel_p) - world_com_p;
             vec3 r_c = x_c - world_com_c;
+            const vec3 dvel = vel_c - vel_p;  // linear_p = -linear_c: the two linear velocity terms are one dot product
+            vec3 lin_c_sum;                   // ... and the parent's linear correction the exact negation of the child's
 #pragma unroll
             for (int dim = 0; dim < 3; ++dim) {
                 float e = vget(rel_p, dim);
@@ -982,7 +1022,7 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
                 vec3 linear_p = -linear_c;
                 vec3 angular_p = -cross(r_p, linear_c);
                 vec3 angular_c = cross(r_c, linear_c);
-                float derr = dot(linear_p, vel_p) + dot(linear_c, vel_c) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
+                float derr = dot(linear_c, dvel) + dot(angular_p, omega_p) + dot(angular_c, omega_c);
                 float err = 0.0f;
                 float compliance = P.joint_linear_compliance;
                 float damping = 0.0f;
@@ -999,12 +1039,13 @@ NT_DI void joint_linear_item(const Ctx<EPB>& c, const int j) {
                 if (fabsf(err) > 1e-9f || fabsf(derr_rel) > 1e-9f) {
                     float d_lambda = positional_correction(err, derr_rel, m_inv_p, m_inv_c, linear_p, linear_c, wq_p(angular_p),
                                                            wq_c(angular_c), 0.0f, compliance, damping, dt);
-                    lin_delta_p += linear_p * (d_lambda * P.joint_linear_relaxation);
                     ang_delta_p += angular_p * (d_lambda * P.joint_angular_relaxation);
-                    lin_delta_c += linear_c * (d_lambda * P.joint_linear_relaxation);
+                    lin_c_sum += linear_c * (d_lambda * P.joint_linear_relaxation);
                     ang_delta_c += angular_c * (d_lambda * P.joint_angular_relaxation);
                 }
             }
+            lin_delta_c = lin_c_sum;
+            lin_delta_p = -lin_c_sum;
         }
     }
     const int ip = c.T.joint_inc[2 * j], ic = c.T.joint_inc[2 * j + 1];  // the (joint, side) entries of the two bodies' lists
@@ -1049,19 +1090,26 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
 
         if (dot(q_p, q_c) < 0.0f) q_c = q_c * -1.0f;
         quat rel_q = quat_inverse(q_p) * q_c;
-        quat qtwist = xnormalize(quat(rel_q.x, 0.0f, 0.0f, rel_q.w));
-        quat qswing = rel_q * quat_inverse(qtwist);
+        // twist about x / swing: the twist quaternion (x, 0, 0, w) / |(x, w)| and the products with it written out -- a general
+        // quaternion product multiplies by its literal zeros (IEEE rules forbid folding x * 0), and its norm is the `s` below
         float s = xsqrt(rel_q.x * rel_q.x + rel_q.w * rel_q.w);
         float invs = xrcp(s);
+        const bool has_twist = s > 0.0f;
+        const float tx = has_twist ? rel_q.x * invs : 0.0f, tw = has_twist ? rel_q.w * invs : 1.0f;  // qtwist = (tx, 0, 0, tw)
+        // qswing = rel_q * conj(qtwist)
+        const quat qswing(rel_q.x * tw - rel_q.w * tx, rel_q.y * tw - rel_q.z * tx, rel_q.z * tw + rel_q.y * tx, rel_q.w * tw + rel_q.x * tx);
         float invscube = invs * invs * invs;
-        float err_0 = 2.0f * asinf(clampf(qtwist.x, -1.0f, 1.0f));
+        float err_0 = 2.0f * asinf(clampf(tx, -1.0f, 1.0f));
         float err_1 = qswing.y, err_2 = qswing.z;
-        quat grad_0(invs - rel_q.x * rel_q.x * invscube, 0.0f, 0.0f, -(rel_q.w * rel_q.x) * invscube);
+        float g0x = invs - rel_q.x * rel_q.x * invscube, g0w = -(rel_q.w * rel_q.x) * invscube;  // grad_0 = (g0x, 0, 0, g0w)
         quat grad_1(-rel_q.w * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube, rel_q.w * invs, -rel_q.x * invs,
                     rel_q.x * (rel_q.w * rel_q.z + rel_q.x * rel_q.y) * invscube);
         quat grad_2(rel_q.w * (rel_q.w * rel_q.y - rel_q.x * rel_q.z) * invscube, rel_q.x * invs, rel_q.w * invs,
                     rel_q.x * (rel_q.z * rel_q.x - rel_q.w * rel_q.y) * invscube);
-        grad_0 = grad_0 * xdiv(2.0f, fabsf(qtwist.w));
+        {
+            const float k = xdiv(2.0f, fabsf(tw));
+            g0x *= k; g0w *= k;
+        }
         float swing_sq = qswing.w * qswing.w;
         if (swing_sq + 1.0e-4f < 1.0f) {
             float d = xsqrt(1.0f - qswing.w * qswing.w);
@@ -1073,18 +1121,27 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
             grad_2 = grad_2 * scale;
         }
         AxisData A = gather_axes(c, ang_count, axis_start + lin_count, target_axis_start + lin_count);
+        // angular_p = -angular_c in every row: the two bodies' quadratic forms are one form of the summed tiles (v^T W v is even in
+        // v), and the two velocity terms one dot product with the relative spin
+        const typename Ctx<EPB>::Wsym W_pc{W_p.xx + W_c.xx, W_p.xy + W_c.xy, W_p.xz + W_c.xz, W_p.yy + W_c.yy, W_p.yz + W_c.yz, W_p.zz + W_c.zz};
+        const vec3 domega = omega_c - omega_p;
+        const quat qci = quat_inverse(q_c);
 #pragma unroll
         for (int dim = 0; dim < 3; ++dim) {
             float e = dim == 0 ? err_0 : (dim == 1 ? err_1 : err_2);
-            quat grad = dim == 0 ? grad_0 : (dim == 1 ? grad_1 : grad_2);
-            quat quat_c = 0.5f * q_p * grad * quat_inverse(q_c);
-            vec3 angular_c(quat_c.x, quat_c.y, quat_c.z);
-            vec3 angular_p = -angular_c;
-            float derr = dot(angular_p, omega_p) + dot(angular_c, omega_c);
+            // the vector part of 0.5 q_p * grad * conj(q_c)
+            quat pg;
+            if (dim == 0) pg = quat(q_p.w * g0x + g0w * q_p.x, g0w * q_p.y + q_p.z * g0x, g0w * q_p.z - g0x * q_p.y, q_p.w * g0w - q_p.x * g0x);
+            else pg = q_p * (dim == 1 ? grad_1 : grad_2);
+            const quat quat_c = pg * qci;
+            vec3 angular_c(0.5f * quat_c.x, 0.5f * quat_c.y, 0.5f * quat_c.z);
+            float derr = dot(angular_c, domega);
             float err = 0.0f;
             float compliance = P.joint_angular_compliance;
             float damping = 0.0f;
-            float derr_rel = derr - vget(A.target_vel, dim) * xlength(angular_c);
+            const float tv = vget(A.target_vel, dim);
+            float derr_rel = derr;
+            if (tv != 0.0f) derr_rel -= tv * xlength(angular_c);
             float lower = vget(A.lower, dim), upper = vget(A.upper, dim);
             if (e < lower) err = e - lower;
             else if (e > upper) err = e - upper;
@@ -1094,7 +1151,7 @@ NT_DI void joint_angular_item(const Ctx<EPB>& c, const int j) {
                 if (st > 0.0f) { err = e - target_pos; compliance = xrcp(st); damping = dm; }
                 else if (dm > 0.0f) { damping = dm; compliance = xrcp(dm); }
             }
-            float d_lambda = angular_correction(err, derr_rel, W_p.quad(angular_p), W_c.quad(angular_c), 0.0f, compliance, damping, dt) *
+            float d_lambda = angular_correction(err, derr_rel, W_pc.quad(angular_c), 0.0f, 0.0f, compliance, damping, dt) *
                              P.joint_angular_relaxation;
             vec3 t = angular_c * d_lambda;
             if (dim == 0) t0 = t;

@@ -26,6 +26,9 @@ class CapturedGraph:
         if backend not in ("torch", "abi"):
             raise ValueError(f"backend must be 'torch' or 'abi', got {backend!r}")
         self._abi = None
+        for c in self._contacts:  # (buffers the fused rollout allocates on first use: a capture must not allocate)
+            if hasattr(c, "prepare_rollout"):
+                c.prepare_rollout()
         if backend == "abi":
             self._init_abi(fn, warmup, device)
             return

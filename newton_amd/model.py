@@ -491,15 +491,21 @@ class DeviceModel:
             self._keep.append(x)
             return x
 
-        self.topology = {k: dev_i32(getattr(t, k)) for k in (
-            "body_flags", "joint_type", "joint_enabled", "joint_parent", "joint_child", "joint_q_start",
-            "joint_qd_start", "joint_tq_start", "joint_lin_count", "joint_ang_count", "shape_body", "shape_type",
-            "shape_flags", "shape_group", "pair_a", "pair_b", "body_joint_start", "body_joint_list", "body_pair_start",
-            "body_pair_list", "art_start", "shape_mesh_start", "shape_mesh_count", "gshape_id")}
-        self.topology["shape_type"] = dev_i32(t.tile_shape_type)  # (triangle meshes as pre-computed-AABB shapes, see EnvTemplate)
-        self.mesh_tables = {"mesh_points": dev_f32(t.mesh_points), "shape_mesh_bounds": dev_f32(t.shape_mesh_bounds)}
-        self.params = {}
-        self.upload_params(model)
+        # The tables the kernels read live in ONE place on the device: the handle nt_model_create builds (below).  The Python-built
+        # tables are uploaded only when that builder is switched off (tests compare the two end to end); otherwise they stay on the
+        # host as the mirror (world slicing, the SDF legs, tests) -- uploading both kept every per-env parameter table twice.
+        self._c_handle = None
+        use_c = self._c_builder_eligible(model)
+        self.topology, self.mesh_tables, self.params = {}, {}, {}
+        if not use_c:
+            self.topology = {k: dev_i32(getattr(t, k)) for k in (
+                "body_flags", "joint_type", "joint_enabled", "joint_parent", "joint_child", "joint_q_start",
+                "joint_qd_start", "joint_tq_start", "joint_lin_count", "joint_ang_count", "shape_body", "shape_type",
+                "shape_flags", "shape_group", "pair_a", "pair_b", "body_joint_start", "body_joint_list", "body_pair_start",
+                "body_pair_list", "art_start", "shape_mesh_start", "shape_mesh_count", "gshape_id")}
+            self.topology["shape_type"] = dev_i32(t.tile_shape_type)  # (triangle meshes as pre-computed-AABB shapes, see EnvTemplate)
+            self.mesh_tables = {"mesh_points": dev_f32(t.mesh_points), "shape_mesh_bounds": dev_f32(t.shape_mesh_bounds)}
+        self.upload_params(model, to_device=not use_c)
         d = _lib.nt_model()
         d.env_count, d.env_stride = E, ES
         d.nb, d.nj, d.nd, d.nc, d.ntq, d.ns, d.ng, d.np, d.cpp = t.nb, t.nj, t.nd, t.nc, t.ntq, t.ns, t.ng, t.np, t.cpp
@@ -515,8 +521,7 @@ class DeviceModel:
         d.params_uniform = self._params_uniform
         choose_contact_scratch(self.lib, d)
         self.desc = d
-        self._c_handle = None
-        if self._c_builder_eligible(model):
+        if use_c:
             # the C ABI's own builder: flat Newton arrays in, device descriptor out (the Python tables above stay as the host-side
             # mirror: world slicing, the SDF legs and the tests read them)
             src, keep = newton_model_struct(model)
@@ -528,8 +533,10 @@ class DeviceModel:
             self._c_handle = h
             cd = _lib.nt_model()
             C.memmove(C.byref(cd), self.lib.nt_model_get(h), C.sizeof(cd))
-            assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride) == \
-                (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride)
+            assert (cd.nb, cd.nj, cd.np, cd.ns, cd.ng, cd.cpp, cd.np_analytic, cd.env_count, cd.env_stride, cd.contact_scratch_in_hbm,
+                    cd.params_uniform) == \
+                (d.nb, d.nj, d.np, d.ns, d.ng, d.cpp, d.np_analytic, d.env_count, d.env_stride, d.contact_scratch_in_hbm,
+                 d.params_uniform), "nt_model_create and the host mirror disagree on the model's sizes / tile mode"
             # pairs routed out of the tiles: the SDF legs read the Python mirror (t.sdf_pair ...), the kernels the C tables
             sp, kind, edges = c_sdf_pairs(self.lib, h)
             want_kind = np.where(t.sdf_pair_hydro, 1, np.where(t.sdf_pair_mesh_plane, 2, 0)).astype(np.uint8) if len(t.sdf_pair) else kind[:0]
@@ -539,8 +546,8 @@ class DeviceModel:
             self.desc = cd
         # environments per workgroup the collide / XPBD / SemiImplicit kernels will use (0: the working set of one
         # environment does not fit the CU's LDS in either mode)
-        self.envs_per_block = int(self.lib.nt_pick_envs_per_block(C.byref(d), 0))
-        self.lds_bytes_per_env = int(self.lib.nt_lds_bytes_per_env(C.byref(d)))
+        self.envs_per_block = int(self.lib.nt_pick_envs_per_block(C.byref(self.desc), 0))  # (of the descriptor the kernels launch with)
+        self.lds_bytes_per_env = int(self.lib.nt_lds_bytes_per_env(C.byref(self.desc)))
 
     USE_C_BUILDER = True  # (tests flip it to compare the two builders end to end)
 
@@ -588,21 +595,24 @@ class DeviceModel:
         for k, v in new.items():
             if not np.array_equal(v, getattr(t, k)):
                 setattr(t, k, v)
-                if v.size:
+                if v.size and k in self.topology:  # (the Python-built device tables, when they exist)
                     self.topology[k][: v.size].copy_(torch.from_numpy(v))
         if nj and not np.array_equal(uniform(model.joint_type, nj, "joint_type"), t.joint_type):
             raise NotImplementedError("joint_type changed after finalize(): rebuild the model (the kernels' topology tables "
                                       "are static)")
 
-    def upload_params(self, model: Model):
-        """(Re)build the per-env parameter SoA arrays from the model's AoS numpy arrays."""
+    def upload_params(self, model: Model, to_device=None):
+        """(Re)build the per-env parameter SoA arrays from the model's AoS numpy arrays.  to_device: also keep them on the device
+        (default: only when the Python-built descriptor is the one in use -- with the C handle its own tables are refreshed)."""
         torch = _torch()
+        if to_device is None:
+            to_device = getattr(self, "_c_handle", None) is None
         self.refresh_flags(model)
         new = pack_param_arrays(model, self.t)
         self._params_uniform = params_uniform(new, self.t.env_count)
         if getattr(self, "desc", None) is not None:
             self.desc.params_uniform = self._params_uniform
-        for k, v in new.items():
+        for k, v in (new.items() if to_device else ()):
             if v.size == 0:
                 v = np.zeros(1, dtype=np.float32)
             if k in self.params and self.params[k].numel() == v.size:

@@ -377,7 +377,7 @@ class SdfLeg:
         """eval_body_contact over the rows, ordered per-body sums ADDED to `body_f` (env-major [6][nb][ES])."""
         p = _lib.nt_flat_force_params()
         p.body_q, p.body_qd = state._soa["body_q"].data_ptr(), state._soa["body_qd"].data_ptr()
-        p.body_com = self.dm.params["body_param"].data_ptr()
+        p.body_com = self.dm.desc.body_param  # (the descriptor's own table: rows BP_COM.. of body_param)
         p.shape_material, p.friction_smoothing, p.body_f = self._material.data_ptr(), float(friction_smoothing), body_f.data_ptr()
         d = rows.desc()
         _lib.check(self.lib.nt_flat_rows_forces(C.byref(self.scene), C.byref(d), C.byref(p), stream), "nt_flat_rows_forces")

@@ -137,6 +137,7 @@ class SolverXPBD(SolverBase):
                 state_0, state_1 = state_1, state_0
             return state_0
         p = self._params()
+        contacts.prepare_rollout()  # (pair-heavy scenes: the rollout's own contact records, allocated on first use)
         d0, d1, d_c, d_ct = state_0._desc(), state_1._desc(), control._desc(), contacts._desc()
         _lib.check(dm.lib.nt_xpbd_rollout(C.byref(dm.desc), C.byref(p), C.byref(cp), C.byref(d0), C.byref(d1), C.byref(d_c),
                                           C.byref(d_ct), float(dt), int(substeps), dm.stream()), "nt_xpbd_rollout")

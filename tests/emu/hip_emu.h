@@ -26,6 +26,7 @@ struct dim3 {
     unsigned x, y, z;
     dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
+struct alignas(16) float4 { float x, y, z, w; };
 typedef void* hipStream_t;
 typedef void* hipGraph_t;      // (nt_graph.hip: handle types only -- the capture entry points answer NT_ERR_UNSUPPORTED under emulation)
 typedef void* hipGraphExec_t;

@@ -226,6 +226,11 @@ def log(x): return _np.log(_s(x))
 def pow(x, y): return _np.power(_s(x), _s(y))  # noqa: A001
 def floor(x): return _np.floor(_s(x))
 def mod(a, b): return _np.fmod(a, b)
+def quat_to_euler(*_a, **_k):
+    # un-vendored Warp builtin (warp/native/quat.h, Bernardes & Viollet 2022): NOT restated here -- a second restatement by the same
+    # author would pin nothing.  Callers of the fixture generators record the case as skipped (D6 joints with 2-3 angular axes in the
+    # penalty solvers: newton/_src/math/spatial.py:150-176).
+    raise NotImplementedError("wp.quat_to_euler: un-vendored Warp builtin, not restated in the stand-in")
 def isnan(x): return _np.isnan(x)
 def isfinite(x): return _np.isfinite(x)
 def where(c, a, b): return a if c else b

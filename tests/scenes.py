@@ -163,6 +163,30 @@ def mixed_primitive_scene(world_count: int, device=None, seed: int = 3):
     return model
 
 
+def tiled_floor_scene(world_count: int, tiles: int = 600, device=None, seed: int = 5, per_env: int = 2):
+    """`tiles` static boxes (world -1: global shapes, one row along +x, 0.2 m apart) and `per_env` free spheres per world resting on
+    tiles spread over the whole row -- more global shapes than any tile kernel's workgroup has lanes (64 ... 512), so the
+    per-launch staging of the global shapes' world data (nt_collide.hpp: stage_global_world) has to loop."""
+    rng = np.random.default_rng(seed)
+    env = nt.ModelBuilder()
+    for _ in range(per_env):
+        b = env.add_body(xform=[0.0, 0.0, 0.145, 0.0, 0.0, 0.0, 1.0])
+        env.add_shape_sphere(b, radius=0.05)
+    scene = nt.ModelBuilder()
+    scene.replicate(env, world_count)
+    for k in range(tiles):
+        scene.add_shape_box(-1, xform=[0.2 * k, 0.0, 0.05, 0.0, 0.0, 0.0, 1.0], hx=0.09, hy=0.09, hz=0.05)
+    model = scene.finalize(device=device)
+    # every sphere over its own tile: the first / last tiles and a spread in between (indices beyond every workgroup size included)
+    idx = rng.integers(0, tiles, size=model.body_count)
+    idx[0], idx[-1] = tiles - 1, 0
+    off = rng.uniform(-0.03, 0.03, size=(model.body_count, 2)).astype(np.float32)
+    model.body_q[:, 0] = (0.2 * idx).astype(np.float32) + off[:, 0]
+    model.body_q[:, 1] = off[:, 1]
+    model.joint_q.reshape(-1, 7)[:, :2] = model.body_q[:, :2]
+    return model
+
+
 def pendulum_scene(world_count: int, device=None, seed: int | None = None):
     """C1 scene: double pendulum of newton/examples/basic/example_basic_pendulum.py:34-64 (2 box links hx=1, hy=hz=0.1,
     revolute-Y joints, first anchor at (0,0,5) rotated -90 deg about Z) + ground plane; optional per-env joint-angle jitter."""

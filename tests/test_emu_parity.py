@@ -153,6 +153,32 @@ def test_large_scene_runs_one_environment_per_workgroup(H):
         s0, s1, os0, os1 = s1, s0, os1, os0
 
 
+@pytest.mark.parametrize("tiles,per_env,n_env", [(600, 1, 3), (600, 2, 2), (150, 1, 5)])
+def test_more_global_shapes_than_workgroup_lanes(H, tiles, per_env, n_env):
+    """stage_global_world stages the static (world -1) shapes' transforms / AABBs once per launch: with more of them than the
+    workgroup has lanes (64 ... 512) the staging has to loop, or the pairs against the shapes beyond the workgroup size read
+    uninitialised LDS.  Spheres rest on tiles spread over the whole row, the first and the last included."""
+    from oracle_bridge import Oracle, OracleState
+    from scenes import tiled_floor_scene
+
+    model = tiled_floor_scene(n_env, tiles=tiles, per_env=per_env)
+    em = H.EmuModel(model)
+    s0, s1, ct, ctrl = H.EmuState(em), H.EmuState(em), H.EmuContacts(em), H.EmuControl(em)
+    o = Oracle(model)
+    os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
+    H.collide(em, s0, ct)
+    o.collide(os0.body_q, oc)
+    assert _same_contacts(ct, oc) >= n_env * per_env  # every sphere touches its own tile (+ the neighbours the default gap admits)
+    sh1 = ct.export()["shape1"][: n_env * per_env]
+    assert sh1.max() >= model.shape_count - tiles + min(tiles - 1, 512) or tiles < 512  # a tile beyond the widest workgroup is hit
+    # the fused rollout stages them once per launch too
+    out = H.xpbd_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, H.EmuContacts(em), 1e-3, 4)
+    oout = o.xpbd_rollout(OracleState(model), OracleState(model), o.control(), o.contacts(), 1e-3, 4)
+    assert _close(out.aos("body_q"), oout.body_q, 1e-5) and _close(out.aos("body_qd"), oout.body_qd, 1e-3)
+    # ... and the spheres stay on their tiles (a missed tile lets them fall 4 mm in 4 ms -- far beyond the tolerance above)
+    assert float(np.min(out.aos("body_q")[:, 2])) > 0.14
+
+
 def test_restitution_and_reporting(H):
     from oracle_bridge import Oracle, OracleState
     from scenes import quadruped_scene

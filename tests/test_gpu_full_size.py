@@ -87,7 +87,8 @@ def _explain_c4_outliers(nt, model, o, q_frame, qd_frame):
     os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
     gpu, ora = [(s0.body_q.cpu().numpy().copy(), s0.body_qd.cpu().numpy().copy())], [(os0.body_q.copy(), os0.body_qd.copy())]
     a, b, oa, ob = s0, s1, os0, os1
-    for _ in range(10):
+    TAIL = 2  # substeps past the frame: an environment that first parts from the oracle in the frame's LAST substep re-joins in these
+    for _ in range(10 + TAIL):
         out = solver.rollout(a, b, None, contacts, DT, 1)
         a, b = (b, a) if out is b else (a, b)
         gpu.append((a.body_q.cpu().numpy().copy(), a.body_qd.cpu().numpy().copy()))
@@ -100,13 +101,13 @@ def _explain_c4_outliers(nt, model, o, q_frame, qd_frame):
         ra, rb = OracleState(model), OracleState(model)
         ra.body_q[:], ra.body_qd[:] = q, qd
         states = []
-        for _ in range(10 - k):
+        for _ in range(10 + TAIL - k):
             rout = o.xpbd_rollout(ra, rb, o.control(), oc, DT, 1, iterations=2)
             ra, rb = (rb, ra) if rout is rb else (ra, rb)
             states.append((ra.body_q.copy(), ra.body_qd.copy()))
         return states
 
-    return tol.explain_rollout_outliers("c4_4096_quadrupeds_frame lowered=True", gpu, ora, restart, model.env.nb)
+    return tol.explain_rollout_outliers("c4_4096_quadrupeds_frame lowered=True", gpu, ora, restart, model.env.nb, frame=10)
 
 
 def test_c4_env_result_is_independent_of_batch_and_tile():

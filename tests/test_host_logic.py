@@ -413,3 +413,54 @@ def test_create_box_with_duplicated_vertices_is_the_reference_table():
     m = nt.Mesh.create_sphere(0.5, 4, 6, reference_layout=True, compute_inertia=False)
     assert np.array_equal(np.asarray(m.vertices, np.float32), np.asarray(tables["sphere_4x6"]["positions"], np.float32))
     assert np.array_equal(np.asarray(m.indices).reshape(-1), np.asarray(tables["sphere_4x6"]["indices"]))
+
+
+def test_outlier_explainer_needs_substeps_after_the_first_divergence():
+    """tests/tolerances.py:explain_rollout_outliers on synthetic trajectories: an environment that parts from the checker in the
+    LAST substep of the trajectories cannot be verified to re-join and is reported as unexplained (it used to pass as class B
+    unchecked: ADVICE round 5); with substeps past the compared frame the same event is classified by an actual re-join check."""
+    import pytest as _pytest
+
+    import tolerances as tol
+
+    nb, E, N = 2, 3, 4
+    base = np.zeros((E * nb, 7))
+    base[:, 0] = np.arange(E * nb) + 1.0
+    base[:, 6] = 1.0
+    qd = np.zeros((E * nb, 6))
+
+    def traj(n_sub, jump_env=None, jump_at=None, jump=0.0):
+        out = []
+        for k in range(n_sub + 1):
+            q = base.copy()
+            q[:, 0] += 1e-3 * k
+            if jump_env is not None and k >= jump_at:
+                q[jump_env * nb, 0] += jump
+            out.append((q, qd.copy()))
+        return out
+
+    # the device jumps by 1e-3 in env 1 at substep N (a threshold event inside that substep: class B).  The checker never makes the jump
+    # itself; restarted from a state that already carries it, it carries it on
+    def restart(n_sub):
+        def f(k0, q, _qd):
+            carried = q[nb, 0] - (base[nb, 0] + 1e-3 * k0)
+            out = []
+            for k in range(k0 + 1, n_sub + 1):
+                r = base.copy()
+                r[:, 0] += 1e-3 * k
+                r[nb, 0] += carried
+                out.append((r, qd.copy()))
+            return out
+        return f
+
+    gpu, ora = traj(N, 1, N, 1e-3), traj(N)
+    with _pytest.raises(AssertionError, match="do not re-join"):  # first divergence in the last substep: nothing left to re-join in
+        tol.explain_rollout_outliers("synthetic", gpu, ora, restart(N), nb)
+    gpu, ora = traj(N + 2, 1, N, 1e-3), traj(N + 2)
+    res = tol.explain_rollout_outliers("synthetic", gpu, ora, restart(N + 2), nb, frame=N)
+    assert res["outliers"] == 1 and res["class_a"] == 0 and res["class_b"] == 1 and not res["unexplained"]
+    # a device that keeps drifting after the event does not re-join from identical states: a real discrepancy
+    gpu = traj(N + 2, 1, N, 1e-3)
+    gpu[N + 2][0][nb, 0] += 1e-3
+    with _pytest.raises(AssertionError, match="do not re-join"):
+        tol.explain_rollout_outliers("synthetic", gpu, ora, restart(N + 2), nb, frame=N)

@@ -81,3 +81,69 @@ def test_eval_fk_selection_on_device():
         got_q, got_qd = s.body_q.cpu().numpy(), s.body_qd.cpu().numpy()
         assert np.allclose(got_q[sel], full_q[sel], atol=1e-6) and np.allclose(got_qd[sel], full_qd[sel], atol=1e-5)
         assert np.array_equal(got_q[~sel], base_q[~sel])
+
+
+def _fuzz_names():
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fuzz_reference_cases as fc
+
+    return [f"fuzz/{('xpbd' if i % 10 < 6 else 'semi' if i % 10 < 8 else 'fs')}_{fc.SEED0 + i}" for i in range(fc.N_CASES)]
+
+
+@pytest.mark.parametrize("name", _fuzz_names())
+def test_hip_path_against_fuzz_reference_vectors(name):
+    """The HIP path against the executed reference on the seeded RANDOM scenes of tests/golden/fuzz_reference_cases.py (the checker's
+    twin: tests/test_fuzz_reference_vectors.py), teacher-forced step by step.  Random joint trees over every joint type, mixed
+    colliders, random solver options, speeds of several hundred rad/s: contact counts exact, state within the single-step contract
+    scaled by the state's own magnitude (a nearly satisfied joint row amplifies rounding in later iterations; XPBD velocities are
+    position differences / dt)."""
+    import os
+
+    import torch
+
+    import fuzz_reference_cases as fc
+    import newton_amd as nt
+    import reference_cases as rc
+    from test_zx_round2_gpu import _to_device
+
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_reference_vectors.npz"))
+    if name in {s.split(":")[0] for s in ref["skipped"].tolist()}:
+        pytest.skip("the reference run needs an un-vendored Warp builtin")
+    case = fc.cases()[name]
+    kind = case.get("solver", "xpbd")
+    case_dev = dict(case)
+    scene = case["scene"]
+    case_dev["scene"] = lambda: _to_device(scene())
+    model = rc.prepare(case_dev)
+    if kind == "xpbd":
+        solver = nt.solvers.SolverXPBD(model, **case["kw"])
+    elif kind == "semi_implicit":
+        solver = nt.solvers.SolverSemiImplicit(model, **case["kw"])
+    else:
+        solver = nt.solvers.SolverFeatherstone(model, mass_matrix="dense", **case["kw"])
+    pipe = nt.CollisionPipeline(model)
+    contacts = pipe.contacts()
+    s0, s1 = model.state(), model.state()
+    worst = np.zeros(4)
+    for k in range(case["steps"]):
+        s0.body_q, s0.body_qd = torch.from_numpy(ref[f"{name}/body_q{k}"]), torch.from_numpy(ref[f"{name}/body_qd{k}"])
+        if kind == "featherstone":
+            s0.joint_q, s0.joint_qd = torch.from_numpy(ref[f"{name}/joint_q{k}"]), torch.from_numpy(ref[f"{name}/joint_qd{k}"])
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == int(ref[f"{name}/contacts{k}"][0])
+        solver.step(s0, s1, None, contacts, case["dt"])
+        torch.cuda.synchronize()
+        q, qd = s1.body_q.cpu().numpy(), s1.body_qd.cpu().numpy()
+        q_ref, qd_ref = ref[f"{name}/body_q{k + 1}"], ref[f"{name}/body_qd{k + 1}"]
+        rot = np.minimum(np.abs(q[:, 3:] - q_ref[:, 3:]).max(axis=1), np.abs(q[:, 3:] + q_ref[:, 3:]).max(axis=1)).max()
+        worst = np.maximum(worst, [np.abs(q[:, :3] - q_ref[:, :3]).max(), rot, np.abs(qd[:, :3] - qd_ref[:, :3]).max(),
+                                   np.abs(qd[:, 3:] - qd_ref[:, 3:]).max()])
+    vmax = max(1.0, float(np.abs(ref[f"{name}/body_qd{case['steps']}"]).max()))
+    print(name, "HIP vs reference run: pos %.3g rot %.3g lin vel %.3g ang vel %.3g (max |qd| %.3g)" % (*worst, vmax))
+    pos_tol = 5e-5 if kind == "xpbd" else 1e-5
+    vel_tol = (5e-5 / case["dt"] if kind == "xpbd" else 1e-3) * vmax
+    assert worst[0] <= pos_tol and worst[1] <= pos_tol and worst[2] <= vel_tol and worst[3] <= 10.0 * vel_tol, worst

@@ -119,7 +119,7 @@ def env_errors(q, q_ref, bodies_per_env):
     return pos.reshape(E, bodies_per_env).max(axis=1), rot.reshape(E, bodies_per_env).max(axis=1)
 
 
-def explain_rollout_outliers(name, gpu_traj, oracle_traj, restart, bodies_per_env, *, gate=1e-5):
+def explain_rollout_outliers(name, gpu_traj, oracle_traj, restart, bodies_per_env, *, gate=1e-5, frame=None):
     """Turns check_rollout's outlier allowance from an assertion into a test.
 
     gpu_traj[k] / oracle_traj[k] = (body_q, body_qd) after k substeps of the same open-loop frame (k = 0: the common start);
@@ -131,8 +131,14 @@ def explain_rollout_outliers(name, gpu_traj, oracle_traj, restart, bodies_per_en
         carried one of them over a threshold (contact separation sign, gap admission, the 1e-4 speed cut-off) one substep earlier --
       * or, failing that, of substep k -- class B: the threshold fell inside substep k itself (the two evaluate the same
         comparison on intermediate values one ulp apart), and from the state after the event they agree again.
-    Anything else is a real discrepancy and fails.  Returns {"outliers", "class_a", "class_b", "first_substep"}."""
-    N = len(gpu_traj) - 1
+    Anything else is a real discrepancy and fails.  Returns {"outliers", "class_a", "class_b", "first_substep"}.
+
+    `frame`: the substep whose state is the compared frame (default: the last one of the trajectories).  Callers pass trajectories
+    that run a few substeps PAST the frame, so that an environment whose first divergent substep is the frame's last one still has
+    substeps left to re-join in: without them a class B verdict at k == frame would be an assertion, not a check."""
+    M = len(gpu_traj) - 1  # substeps available for the re-join checks
+    N = M if frame is None else int(frame)
+    assert 1 <= N <= M
     pos, rot = env_errors(gpu_traj[N][0], oracle_traj[N][0], bodies_per_env)
     outliers = np.nonzero((pos > gate) | (rot > gate))[0]
     first = {}
@@ -159,7 +165,10 @@ def explain_rollout_outliers(name, gpu_traj, oracle_traj, restart, bodies_per_en
         if ok:
             res["class_a"] += 1
             continue
-        ok, wb = (True, 0.0) if k == N else rejoins(e, k)
+        if k == M:  # no substep left to verify a re-join in: not explained (callers run the trajectories past the frame)
+            res["unexplained"].append({"env": e, "first_substep": k, "from_k_minus_1": wa, "from_k": None})
+            continue
+        ok, wb = rejoins(e, k)
         if ok:
             res["class_b"] += 1
         else:

@@ -20,6 +20,8 @@ extra = []
 for a in sys.argv[2:]:
     if a.startswith("--units="):
         only = a.split("=", 1)[1].split(",")
+    elif a == "--no-unit-flags":
+        pass
     else:
         extra.append(a)
 flags = [f for f in g.HIP_FLAGS] + extra
@@ -30,7 +32,8 @@ compile_flags = [f for f in flags if f != "-shared"] + ["-c"]
 for u in g.UNITS:
     if only is None or u in only:
         obj = os.path.join(tmp, os.path.basename(out) + "." + u.replace(".hip", ".o"))
-        cmd = [g.HIPCC, *compile_flags, f'-DNT_BUILD_ID="variant{"".join(extra)}"', os.path.join(g.CSRC, u), "-o", obj]
+        uf = [] if "--no-unit-flags" in sys.argv else g.unit_flags(u)  # (the product's per-unit flags, unless the variant is about them)
+        cmd = [g.HIPCC, *compile_flags, *uf, f'-DNT_BUILD_ID="variant{"".join(extra)}"', os.path.join(g.CSRC, u), "-o", obj]
         print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         objs.append(obj)
@@ -39,7 +42,7 @@ for u in g.UNITS:
         obj = os.path.join(g.OBJ_DIR, f"{u.replace('.hip', '')}.{key}.o")
         if not os.path.exists(obj):  # the product was not rebuilt since this unit (or, for nt_build_id.hip, any unit) changed
             base = [f for f in g.HIP_FLAGS if f != "-shared"] + ["-c"]
-            cmd = [g.HIPCC, *base, f'-DNT_BUILD_ID="{g.source_hash()}"', os.path.join(g.CSRC, u), "-o", obj]
+            cmd = [g.HIPCC, *base, *g.unit_flags(u), f'-DNT_BUILD_ID="{g.source_hash()}"', os.path.join(g.CSRC, u), "-o", obj]
             print(" ".join(cmd), flush=True)
             os.makedirs(g.OBJ_DIR, exist_ok=True)
             subprocess.run(cmd, check=True)

@@ -24,6 +24,9 @@ import newton_amd as nt  # noqa: E402
 from newton_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = dbg
+for _name in ("nt_bandwidth_probe",):  # (a variant built from older sources may lack entry points added since)
+    if _name.encode() not in open(dbg, "rb").read():
+        _lib.SYMBOLS.pop(_name, None)
 from scenes import quadruped_scene  # noqa: E402
 
 lib = _lib.load()

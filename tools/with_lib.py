@@ -24,6 +24,12 @@ def main():
 
     assert _lib._lib is None
     _lib.LIB_PATH = lib
+    # a variant built from older sources may lack entry points added since (measurement aids only): drop them from the loader's table
+    # (looked up in the file, not by loading it: the library must be loaded AFTER torch so that both share one HIP runtime)
+    blob = open(lib, "rb").read()
+    for name in ("nt_bandwidth_probe",):
+        if name.encode() not in blob:
+            _lib.SYMBOLS.pop(name, None)
     if sys.argv[2] == "-m":
         sys.argv = sys.argv[3:]
         runpy.run_module(sys.argv[0], run_name="__main__", alter_sys=True)
