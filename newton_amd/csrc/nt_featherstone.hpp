@@ -32,8 +32,9 @@ struct FsCtx {
     const int *ddepth, *rowbase, *ent;
     int nnz, dmaxd;
     bool tree_ok;
+    static constexpr int N = Ctx<EPB>::N;  // environments per workgroup (the tile code EPB may carry the uniform-parameter bit)
     NT_DI FsCtx(const Ctx<EPB>& c_, int* extra) : c(c_) {
-        F = make_fs_layout(c.a.m, c.L);
+        F = make_fs_layout(c.a.m, c.L, fs_tree_mode(c.a));
         const int nj = c.a.m.nj;
         anc = extra;
         depth = extra + nj;
@@ -65,7 +66,7 @@ struct FsCtx {
     NT_DI bool any_descendant_free() const { return refresh[c.a.m.nj] != 0; }
     // is joint `a` on the root path of joint `l` (or `l` itself)?
     NT_DI bool on_path(int a, int l) const { return (pathmask[l * words + (a >> 5)] >> (a & 31)) & 1u; }
-    NT_DI float& f(int off, int idx) const { return c.lds[(off + idx) * EPB + c.e]; }
+    NT_DI float& f(int off, int idx) const { return c.lds[(off + idx) * N + c.e]; }
     NT_DI vec3 v3(int off, int comp0, int n, int s) const { return c.lv3(off, comp0, n, s); }
     NT_DI spatial sp6(int off, int n, int s) const { return spatial(c.lv3(off, 0, n, s), c.lv3(off, 3, n, s)); }
     NT_DI void st6(int off, int n, int s, const spatial& x) const {
@@ -664,10 +665,11 @@ NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
     const int nd = m.nd, W = m.max_art_dofs, maxd = f.dmaxd, nnz = f.nnz;
     float* lds = c.lds;
     const int e = c.e;
-    auto A = [&](int off) -> float& { return lds[(f.F.H + off) * EPB + e]; };  // off = rowbase[i] + j, j on i's root path
-    auto X = [&](int i) -> float& { return lds[(f.F.qdd + i) * EPB + e]; };
-    const bool single = m.na == 1;  // one articulation: row k of H starts at k * W
-    auto row = [&](int k) { return single ? k * W : f.rowbase[k]; };
+    constexpr int N = Ctx<EPB>::N;
+    auto A = [&](int off) -> float& { return lds[(f.F.H + off) * N + e]; };  // off = rowbase[i] + j, j on i's root path
+    auto X = [&](int i) -> float& { return lds[(f.F.qdd + i) * N + e]; };
+    const bool single = m.na == 1;  // one articulation: row k of the packed lower triangle starts at k (k + 1) / 2 (no table read)
+    auto row = [&](int k) { return single ? (k * (k + 1)) / 2 : f.rowbase[k]; };
     // the entries and the dof this lane owns, decoded once per step (the tables are block-shared LDS: a dependent read per level
     // and entry was most of the first version's time)
     constexpr int TE = 2;
@@ -742,7 +744,7 @@ NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
         __syncthreads();
     }
     // x_i = (y_i - sum over the dofs j above i of U[i][j] x_j) / D_i, root first, on wavefront 0
-    const int G = (64 / EPB) < c.nslot ? (64 / EPB) : c.nslot;
+    const int G = (64 / Ctx<EPB>::N) < c.nslot ? (64 / Ctx<EPB>::N) : c.nslot;
     if (c.valid && c.slot < G)
         for (int d = 0; d <= maxd; ++d) {
             const unsigned long long at = f.m64(f.t_lvl, d);
@@ -793,8 +795,8 @@ NT_DI void fs_solve_coop(const FsCtx<EPB>& f, int a, int lane, int G, const bool
     const int n = d1 - d0;
     float* lds = c.lds;
     const int e = c.e;
-    auto A = [&](int i, int j) -> float& { return lds[(f.F.H + (d0 + i) * W + j) * EPB + e]; };
-    auto X = [&](int i) -> float& { return lds[(f.F.qdd + d0 + i) * EPB + e]; };
+    auto A = [&](int i, int j) -> float& { return lds[(f.F.H + (d0 + i) * W + j) * Ctx<EPB>::N + e]; };
+    auto X = [&](int i) -> float& { return lds[(f.F.qdd + d0 + i) * Ctx<EPB>::N + e]; };
     for (int j = 0; factor && j < n; ++j) {
         float s = A(j, j) + c.dof(DP_ARMATURE, d0 + j);  // every lane evaluates the pivot (no broadcast needed)
         {
@@ -1149,7 +1151,19 @@ NT_DI void fs_build_tables(const Ctx<EPB>& c, int* extra) {
             for (int k = 0; k < nd; ++k)
                 if ((get64(above, k) >> d) & 1ull) down |= 1ull << k;
             put64(below, d, down);
-            rowbase[d] = d * W - c.T.joint_qd_start[m.art_start[extra[2 * nj + dof_joint[d]]]];
+            // row d of the articulation's H, packed lower triangle: local row dl starts at dl (dl + 1) / 2 behind the triangles of the
+            // articulations in front, minus the articulation's first dof so that rowbase[d] + j addresses column j (an absolute dof)
+            {
+                const int art = extra[2 * nj + dof_joint[d]];
+                int base = 0;
+                for (int k = 0; k < art; ++k) {
+                    const int j0 = m.art_start[k], j1 = m.art_start[k + 1];
+                    const int n_k = (j1 < nj ? c.T.joint_qd_start[j1] : nd) - c.T.joint_qd_start[j0];
+                    base += n_k * (n_k + 1) / 2;
+                }
+                const int d0 = c.T.joint_qd_start[m.art_start[art]], dl = d - d0;
+                rowbase[d] = base + dl * (dl + 1) / 2 - d0;
+            }
         }
         for (int l = threadIdx.x; l <= nd; l += blockDim.x) {
             unsigned long long at = 0ull;
@@ -1304,20 +1318,20 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         if (c.valid && !NT_SKIP(32))
             for (int i = c.slot; i < m.nd * W; i += c.nslot) fs_H_item(f, i);
     } else if (c.valid) {  // the factor of the last rebuild
-        for (int r = c.slot; r < m.nd * W; r += c.nslot) f.f(F.H, r) = cache[(size_t)r * c.ES + c.env];
+        for (int r = c.slot; r < (tree ? fs_tree_nnz_bound(m) : m.nd * W); r += c.nslot) f.f(F.H, r) = cache[(size_t)r * c.ES + c.env];
     }
     __syncthreads();
     NT_TICK(17);
     if (tree) {
         fs_solve_tree(f, update_mass);
     } else {
-        const int G = (64 / EPB) < c.nslot ? (64 / EPB) : c.nslot;
+        const int G = (64 / Ctx<EPB>::N) < c.nslot ? (64 / Ctx<EPB>::N) : c.nslot;
         if (c.valid && !NT_SKIP(64) && c.slot < G)
             for (int k = 0; k < m.na; ++k) fs_solve_coop(f, k, c.slot, G, update_mass);
     }
     __syncthreads();
     if (update_mass && cache && a.fp.update_mass_matrix_interval > 1 && c.valid)
-        for (int r = c.slot; r < m.nd * W; r += c.nslot) cache[(size_t)r * c.ES + c.env] = f.f(F.H, r);
+        for (int r = c.slot; r < (tree ? fs_tree_nnz_bound(m) : m.nd * W); r += c.nslot) cache[(size_t)r * c.ES + c.env] = f.f(F.H, r);
     NT_TICK(18);
     // integrate_generalized_joints
     const bool desc_free = f.any_descendant_free();  // block-uniform

@@ -4,13 +4,27 @@
 // level-synchronous barriers, not on arithmetic.  The literal operation order stays.)
 #pragma once
 
+// the LDS layout of a launch (host twin: fs_launch): persistent block of the XPBD layout without its body-derived tile, per-environment
+// parameters or ONE block-shared copy (tile code EPB with NT_UNI), dense or tree-structured mass-matrix region (fs_tree_mode)
+template <int EPB>
+NT_DI FsLayout fs_kernel_layout(const KArgs& a) {
+    return make_fs_layout(a.m, make_layout(a.m, false, false, Ctx<EPB>::UNI, false), fs_tree_mode(a));
+}
+// workgroup memory: [F.rows x N floats][topology ints][Featherstone ints][uniform-parameter floats]
+template <int EPB>
+NT_DI int* fs_place_tables(Ctx<EPB>& c, float* lds, const FsLayout& F) {
+    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * Ctx<EPB>::N) + topo_ints(c.a.m);
+    c.up = reinterpret_cast<float*>(extra + fs_topo_ints(c.a.m));  // (Ctx put it behind the topology ints, where `extra` lives here)
+    return extra;
+}
+
 template <int EPB>
 __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     const nt_model& m = a.m;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false, false, false, false));
+    const FsLayout F = fs_kernel_layout<EPB>(a);
     Ctx<EPB> c(a, lds, F.rows);  // topology ints are staged behind the Featherstone rows
-    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
+    int* extra = fs_place_tables(c, lds, F);
     __syncthreads();
     fs_build_tables(c, extra);
     FsCtx<EPB> f(c, extra);
@@ -33,13 +47,14 @@ __global__ void __launch_bounds__(256) featherstone_step_kernel(KArgs a) {
 // substeps x { clear_forces; CollisionPipeline.collide; SolverFeatherstone.step; swap } in one launch: generalized and
 // maximal state, parameters and all Featherstone intermediates stay in LDS; only the contacts touch HBM per substep.
 // The result lands in s_in (= s0) for an even number of substeps and in s_out (= s1) for an odd one.
-template <int EPB, bool CVX>
-__global__ void __launch_bounds__(256) featherstone_rollout_kernel(KArgs a) {
+// THREADS: workgroup size (512 for the 16-environment uniform-parameter tile: 32 lanes per environment)
+template <int EPB, bool CVX, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS) featherstone_rollout_kernel(KArgs a) {
     extern __shared__ __align__(16) float lds[];
     const nt_model& m = a.m;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false, false, false, false));
+    const FsLayout F = fs_kernel_layout<EPB>(a);
     Ctx<EPB> c(a, lds, F.rows);
-    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
+    int* extra = fs_place_tables(c, lds, F);
     __syncthreads();
     fs_build_tables(c, extra);
     FsCtx<EPB> f(c, extra);
@@ -80,9 +95,9 @@ __global__ void __launch_bounds__(256) eval_fk_kernel(KArgs a, const float* join
     extern __shared__ __align__(16) float lds[];
     const nt_model& m = a.m;
     const int nj = m.nj;
-    const FsLayout F = make_fs_layout(m, make_layout(m, false, false, false, false));
+    const FsLayout F = fs_kernel_layout<EPB>(a);
     Ctx<EPB> c(a, lds, F.rows);
-    int* extra = reinterpret_cast<int*>(lds + (size_t)F.rows * EPB) + topo_ints(m);
+    int* extra = fs_place_tables(c, lds, F);
     __syncthreads();
     for (int j = threadIdx.x; j < nj; j += blockDim.x) {
         int p = c.T.joint_parent[j], anc = -1;

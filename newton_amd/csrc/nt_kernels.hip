@@ -18,67 +18,9 @@
 //  * no MFMA: the largest dense object on this path is a 3x3 inertia.
 //
 // Reference behaviour (file:line under /root/reference) is cited per phase.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-
-#include "../../include/newton_hip.h"
-#include "nt_math.hpp"
-#include "nt_primitives.hpp"
-#include "nt_convex.hpp"
-
-// Two arithmetic namespaces in one translation unit (the fused kernels run both on the same LDS tile):
-//  * ieee  -- nt:: helpers, -ffp-contract=off, correctly rounded division / sqrt: everything that decides pair sets, contact
-//             counts and contact geometry (shape transforms, AABBs, broad phase, primitive / MPR-GJK narrow phase, the contact
-//             writer), SolverSemiImplicit and SolverFeatherstone.  CollisionPipeline.collide stays bit-identical to the contact
-//             arrays the reference's own kernels produce (tests/golden/collide_reference_vectors.npz).
-//  * fused -- ntf:: helpers (a second copy of nt_math.hpp) + the XPBD phases of nt_xpbd.hpp under `#pragma clang fp
-//             contract(fast)` and -DNT_XPBD_FAST_MATH: a * b + c contracts to v_fma_f32, the divisions / square roots of the
-//             projection phases are v_rcp_f32 / v_sqrt_f32 (1 ulp).  Within SURVEY.md 8(c)'s contract (1e-5 single step, 1e-4
-//             rollout against the reference); measured on the MI355X headline: 0.363 -> 0.308 ms per 10-substep launch for the whole
-//             kernel (profiles/r04a_*).  clang attaches the contraction permission to an operation where it is WRITTEN, hence the
-//             second copy of the helpers instead of a flag.
-// The step and the rollout kernels share the fused phases, so a rollout stays bitwise equal to the call-by-call loop.
-#define NT_MATH_NS ntf
-#pragma clang fp contract(fast)
-#include "nt_math.hpp"
-#pragma clang fp contract(off)
-#undef NT_MATH_NS
+#include "nt_step_preamble.hpp"
 
 namespace {
-
-#include "nt_layout.hpp"
-
-namespace ieee {
-using namespace nt;
-#include "nt_ctx.hpp"
-#include "nt_collide.hpp"
-#include "nt_xpbd.hpp"
-#define NT_SI_PHASES_ONLY  // (the SolverSemiImplicit kernel itself follows below, once)
-#include "nt_semi_implicit.hpp"
-#undef NT_SI_PHASES_ONLY
-#include "nt_featherstone.hpp"
-}  // namespace ieee
-
-#pragma clang fp contract(fast)
-namespace fused {
-using namespace ntf;
-#define NT_XPBD_FAST_MATH
-#include "nt_ctx.hpp"
-#include "nt_xpbd.hpp"
-#undef NT_XPBD_FAST_MATH
-}  // namespace fused
-#pragma clang fp contract(off)
-
-namespace ieee {
-#include "nt_xpbd_kernels.hpp"
-#define NT_SI_KERNEL_ONLY
-#include "nt_semi_implicit.hpp"
-#undef NT_SI_KERNEL_ONLY
-#include "nt_featherstone_kernels.hpp"
-}  // namespace ieee
-using namespace ieee;
 
 __global__ void clear_forces_kernel(float* body_f, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,14 +36,18 @@ __global__ void calibration_copy_kernel(const float* __restrict__ src, float* __
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
-// the same copy in 16 B per lane, grid-strided over 16 workgroups per CU: the streaming rate of this box (bench.py prints it as
-// roofline.hbm_peak_measured beside the vendor peak)
+// the same copy in 16 B per lane, eight loads in flight per lane, one trip per lane at the sizes bench.py uses (tools/microbench/
+// hbm_copy.hip, profiles/r06H_hbm_copy.jsonl: 5.65 TB/s in this shape, 4.6 TB/s grid-strided over 4 096 workgroups, hipMemcpy 5.5 TB/s,
+// read-only 6.1 TB/s): the streaming rate of this box (bench.py prints it as roofline.hbm_peak_measured beside the vendor peak)
 __global__ void __launch_bounds__(256) bandwidth_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {  // four loads in flight per lane
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[i + k * stride] = v[k];
     }
     for (; i < n4; i += stride) dst[i] = src[i];
 }
@@ -242,7 +188,6 @@ __global__ void contacts_export_force_kernel(nt_model m, nt_contacts c, const fl
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 inline int max_threads_for(int epb) { return epb <= 8 ? 256 : 512; }
-constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
 // slot-threads per env: enough for the widest per-env population (contact slots, joint parts, bodies, shapes,
 // pairs), capped by the block size; phases with more items than slot-threads loop.
@@ -426,11 +371,6 @@ inline bool pick_cvx_uni_shape(const nt_model& m, bool rest, XpbdCfg& c) {
          : NT_DISPATCH_EPB2(KERNEL, false, args, epb, stream))
 #endif
 
-bool model_ok(const nt_model* m) {
-    return m && m->env_count > 0 && m->env_stride >= m->env_count && (m->env_stride % 64) == 0 && m->nb > 0 &&
-           (m->cpp == 4 || m->cpp == 5) && m->np_analytic >= 0 && m->np_analytic <= m->np &&
-           (m->np_analytic == m->np || m->cpp == 5);
-}
 
 }  // namespace
 
@@ -635,146 +575,6 @@ nt_status nt_semi_implicit_step(const nt_model* m, const nt_semi_implicit_params
 #endif
 }
 
-// shared launch logic of the Featherstone kernels (step / rollout)
-static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, bool rollout, hipStream_t stream) {
-    if (m->contact_scratch_in_hbm) return NT_ERR_UNSUPPORTED;  // XPBD / collide only
-#ifdef NT_DEV_FAST
-    return NT_ERR_UNSUPPORTED;
-#else
-#ifdef NT_ABLATION
-    {
-        const char* e = getenv("NT_DEBUG_SKIP");
-        a.debug_skip = e ? atoi(e) : 0;
-    }
-#endif
-    const FsLayout F = make_fs_layout(*m, make_layout(*m, false, false, false, false));
-    const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
-    auto fits = [&](int epb) { return (size_t)F.rows * 4 * epb + shared_ints * 4 <= LDS_BYTES_PER_CU; };
-    int epb = 0;
-    if (envs_per_block == 1 || envs_per_block == 4 || envs_per_block == 8 || envs_per_block == 16) {
-        epb = fits(envs_per_block) ? envs_per_block : 0;
-    } else {
-        // measured on MI355X (4096 quadrupeds): 4 envs per workgroup (16 cooperating lanes per env in the Cholesky wave,
-        // two resident workgroups per CU) beats 8; 16 rarely fits; articulations too large for 4 (P + H alone are
-        // (6 nj + nd) x max_art_dofs floats per environment) run one environment per workgroup, 64 lanes in the Cholesky wave
-        const int cands[4] = {4, 8, 16, 1};
-        for (int i = 0; i < 4 && !epb; ++i)
-            if (fits(cands[i])) epb = cands[i];
-    }
-    if (!epb) return NT_ERR_UNSUPPORTED;
-    const bool cvx = m->np_analytic < m->np;
-    if (rollout && cvx && epb == 16) epb = 8;  // the convex rollout is only instantiated for 4 / 8 envs per workgroup
-    int want = imax(imax(m->nb, m->nj), imax(m->np * m->cpp, imax(m->nj, m->nd) * m->max_art_dofs));
-    int cap = 256 / epb;
-    a.nslot = want < cap ? want : cap;
-    int threads = ((a.nslot * epb + 63) / 64) * 64;
-    size_t lds_bytes = (size_t)F.rows * 4 * epb + shared_ints * 4;
-    int blocks = (m->env_count + epb - 1) / epb;
-    auto go = [&](auto kernel) -> nt_status {
-        if (lds_bytes > 48 * 1024 &&
-            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return NT_ERR_LAUNCH;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, a);
-        return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
-    };
-    if (!rollout) {
-        if (epb == 16) return go(featherstone_step_kernel<16>);
-        if (epb == 8) return go(featherstone_step_kernel<8>);
-        if (epb == 4) return go(featherstone_step_kernel<4>);
-        return go(featherstone_step_kernel<1>);
-    }
-    if (cvx) {
-        if (epb == 8) return go(featherstone_rollout_kernel<8, true>);
-        return epb == 4 ? go(featherstone_rollout_kernel<4, true>) : go(featherstone_rollout_kernel<1, true>);
-    }
-    if (epb == 16) return go(featherstone_rollout_kernel<16, false>);
-    if (epb == 8) return go(featherstone_rollout_kernel<8, false>);
-    if (epb == 4) return go(featherstone_rollout_kernel<4, false>);
-    return go(featherstone_rollout_kernel<1, false>);
-#endif
-}
-
-static bool fs_state_ok(const nt_state* s) { return s && s->joint_q && s->joint_qd && s->body_q && s->body_qd; }
-
-nt_status nt_featherstone_step(const nt_model* m, const nt_featherstone_params* p, nt_state* s_in, nt_state* s_out,
-                                const nt_control* ctrl, const nt_contacts* c, float dt, int32_t envs_per_block, void* stream) {
-    if (!model_ok(m) || !p || !ctrl || !fs_state_ok(s_in) || !fs_state_ok(s_out)) return NT_ERR_INVALID_ARG;
-    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs < 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
-    KArgs a = {};
-    a.m = *m;
-    a.s_in = *s_in;
-    a.s_out = *s_out;
-    a.c = *ctrl;
-    if (c) a.ct = *c;
-    a.has_contacts = (c != nullptr && m->np > 0) ? 1 : 0;
-    a.sp.friction_smoothing = p->friction_smoothing;
-    a.fp = *p;
-    a.angular_damping = p->angular_damping;
-    a.dt = dt;
-    return fs_launch(m, a, envs_per_block, false, (hipStream_t)stream);
-}
-
-nt_status nt_featherstone_rollout(const nt_model* m, const nt_featherstone_params* p, const nt_collide_params* cp, nt_state* s0,
-                                   nt_state* s1, const nt_control* ctrl, nt_contacts* c, float dt, int32_t substeps,
-                                   void* stream) {
-    if (!model_ok(m) || !p || !ctrl || !c || !fs_state_ok(s0) || !fs_state_ok(s1) || !s0->body_f || !s1->body_f || substeps <= 0)
-        return NT_ERR_INVALID_ARG;
-    if (m->nj <= 0 || m->na <= 0 || m->max_art_dofs < 0 || !m->art_start) return NT_ERR_UNSUPPORTED;
-    KArgs a = {};
-    a.m = *m;
-    a.s_in = *s0;
-    a.s_out = *s1;
-    a.c = *ctrl;
-    a.ct = *c;
-    a.has_contacts = m->np > 0 ? 1 : 0;
-    a.sp.friction_smoothing = p->friction_smoothing;
-    a.fp = *p;
-    a.angular_damping = p->angular_damping;
-    a.dt = dt;
-    a.substeps = substeps;
-    return fs_launch(m, a, cp ? cp->envs_per_block : 0, true, (hipStream_t)stream);
-}
-
-int32_t nt_featherstone_lds_bytes_per_env(const nt_model* m) {
-    if (!m) return -1;
-    return make_fs_layout(*m, make_layout(*m, false, false, false, false)).rows * 4;
-}
-
-nt_status nt_eval_fk(const nt_model* m, const float* joint_q, const float* joint_qd, nt_state* out, void* stream) {
-    if (!model_ok(m) || !joint_q || !joint_qd || !out || !out->body_q || !out->body_qd) return NT_ERR_INVALID_ARG;
-    if (m->nj <= 0) return NT_ERR_UNSUPPORTED;
-#ifdef NT_DEV_FAST
-    return NT_ERR_UNSUPPORTED;
-#else
-    KArgs a = {};
-    a.m = *m;
-    a.s_out = *out;
-    const FsLayout F = make_fs_layout(*m, make_layout(*m, false, false, false, false));
-    const size_t shared_ints = (size_t)topo_ints(*m) + fs_topo_ints(*m);
-    int epb = 0;
-    const int cands[4] = {16, 8, 4, 1};
-    for (int i = 0; i < 4 && !epb; ++i)
-        if ((size_t)F.rows * 4 * cands[i] + shared_ints * 4 <= LDS_BYTES_PER_CU) epb = cands[i];
-    if (!epb) return NT_ERR_UNSUPPORTED;
-    int want = imax(m->nb, m->nj), cap = 256 / epb;
-    a.nslot = want < cap ? want : cap;
-    int threads = ((a.nslot * epb + 63) / 64) * 64;
-    size_t lds_bytes = (size_t)F.rows * 4 * epb + shared_ints * 4;
-    int blocks = (m->env_count + epb - 1) / epb;
-    auto go = [&](auto kernel) -> nt_status {
-        if (lds_bytes > 48 * 1024 &&
-            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return NT_ERR_LAUNCH;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, a, joint_q, joint_qd);
-        return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
-    };
-    if (epb == 16) return go(eval_fk_kernel<16>);
-    if (epb == 8) return go(eval_fk_kernel<8>);
-    if (epb == 4) return go(eval_fk_kernel<4>);
-    return go(eval_fk_kernel<1>);
-#endif
-}
-
 #ifdef NT_PHASE_TIMING
 // debug build only: read and reset the phase cycle counters
 int nt_debug_phase_clocks(unsigned long long* out) {
@@ -811,7 +611,8 @@ nt_status nt_bandwidth_probe(const float* src, float* dst, int64_t n, void* stre
 #ifdef NT_EMULATED_GRID
     const int blocks = NT_EMULATED_GRID;
 #else
-    const int blocks = 4096;
+    size_t want = ((size_t)n / 4 + 256 * 8 - 1) / (256 * 8);  // one trip of eight 16-byte accesses per lane
+    const int blocks = (int)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
 #endif
     hipLaunchKernelGGL(bandwidth_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)n / 4);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;

@@ -132,12 +132,12 @@ __host__ __device__ inline LdsLayout make_layout(const nt_model& m, const bool b
     L.ctq.off = o; o += m.ntq;
     L.ctqd.off = o; o += m.nd;
     L.grav.off = o; o += 3;
-    L.bd.off = o; o += 9 * m.nb;
     L.pm.off = o; o += m.np;
     L.px.off = o; o += m.np + 1;
     L.has_lt = live_list && !big && m.np_analytic == m.np;
     L.lt.off = o; o += L.has_lt ? m.np * m.cpp : 0;
     L.lc.off = o; o += L.has_lt ? 1 : 0;
+    L.bd.off = o; o += 9 * m.nb;  // (last of the persistent block: SolverFeatherstone's layout, which never reads it, starts here)
     L.u = o;
     const int coll = place_collide_scratch(L, m, L.u, big, big_lanes);
     // staged tiles: the force scratch sits BEHIND the collide scratch, so that the fused rollout can run the shape phase
@@ -257,9 +257,14 @@ struct FsLayout {
     int Ic, Pd;                       // tree-structured mass matrix (in the P region): composite inertias [36][nb], I^c S_d [6][nd]
     int rows;
 };
-__host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsLayout& L) {
+// tree: the tree-structured mass matrix is in use (nt_featherstone_params.dense_mass_matrix == 0 on a model fs_tree_ok accepts): the
+// solve then needs the composite inertias + I^c S (36 nb + 6 nd rows) and the nnz packed entries of H instead of the dense P
+// (6 nb W) and H (nd W) -- 948 rows less on the quadruped, which together with the uniform-parameter tile lets 16 environments share
+// a CU (round 6).  Host launch code and kernels must pass the same flag.
+__host__ __device__ inline int fs_tree_nnz_bound(const nt_model& m) { return m.nd * (m.nd + 1) / 2; }
+__host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsLayout& L, const bool tree = false, const int tree_nnz = -1) {
     FsLayout F;
-    int o = L.u;
+    int o = L.bd.off;  // (the body-derived tile of the XPBD layout is not part of this solver's working set)
     F.jq = o; o += m.nc;
     F.qdi = o; o += m.nd;
     F.qdo = o; o += m.nd;
@@ -280,9 +285,10 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
     F.P = o;
     F.Ic = F.P;
     F.Pd = F.P + 36 * m.nb;
-    const int pregion = imax(6 * m.nb * m.max_art_dofs, 36 * m.nb + 6 * m.nd);
+    const int pregion = tree ? 36 * m.nb + 6 * m.nd : imax(6 * m.nb * m.max_art_dofs, 36 * m.nb + 6 * m.nd);
     F.H = F.P + pregion;
-    int solve = pregion + m.nd * m.max_art_dofs;
+    const int hregion = tree ? (tree_nnz >= 0 ? tree_nnz : fs_tree_nnz_bound(m)) : m.nd * m.max_art_dofs;
+    int solve = pregion + hregion;
     int contacts = NC_CW * m.np * m.cpp;
     // the fused rollout runs the collide phases on this union too (shape transforms / AABBs, pair counts, manifold polygon
     // scratch, staged candidates)
@@ -292,6 +298,9 @@ __host__ __device__ inline FsLayout make_fs_layout(const nt_model& m, const LdsL
     F.rows = o;
     return F;
 }
+// the layout flag of a launch: the tree-structured mass matrix is requested and the model qualifies (KArgs is declared above)
+__host__ __device__ inline bool fs_tree_ok(const nt_model& m);
+__host__ __device__ inline bool fs_tree_mode(const KArgs& a) { return a.fp.dense_mass_matrix == 0 && fs_tree_ok(a.m); }
 // block-shared ints behind the staged topology: joint ancestor, joint depth, articulation of joint (3 * nj), joint of
 // each dof (nd), and per joint a bit mask of the joints on its root path, itself included (nj * ceil(nj / 32))
 __host__ __device__ inline int fs_mask_words(const nt_model& m) { return (m.nj + 31) / 32; }

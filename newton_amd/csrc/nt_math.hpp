@@ -94,8 +94,11 @@ NT_DI quat normalize(quat q) {
     return quat(0.f, 0.f, 0.f, 1.f);
 }
 NT_DI quat quat_inverse(quat q) { return quat(-q.x, -q.y, -q.z, q.w); }
-#ifdef NT_MATH_NS_IS_DEFAULT
-// wp.quat_rotate / wp.quat_rotate_inv, literal operation order (what the collide phases and the penalty solvers restate bit for bit)
+// wp.quat_rotate / wp.quat_rotate_inv, literal operation order -- in BOTH copies of this file.  (Round 6 measured the two-cross-product
+// form v + 2 (w c + q x c), c = q x v, in the XPBD copy: 18 operations instead of ~30, equally accurate against the exact rotation
+// (1.2e-6 vs 0.9e-6 at |v| ~ 3) -- but a few ulps AWAY from the checker's literal form in every rotation, which the reference's ramp
+// line-up (cubes resting on single MPR contacts, 1.5 - 2.5 m from the origin) amplifies to 2.3e-5 m per step against 1.2e-5 with the
+// literal form, for +1.6 % on the headline.  Parity margin kept; profiles/r06F_ramp_rotation_ab.txt.)
 NT_DI vec3 quat_rotate(quat q, vec3 v) {
     vec3 qv(q.x, q.y, q.z);
     return v * (2.0f * q.w * q.w - 1.0f) + cross(qv, v) * q.w * 2.0f + qv * dot(qv, v) * 2.0f;
@@ -104,24 +107,6 @@ NT_DI vec3 quat_rotate_inv(quat q, vec3 v) {
     vec3 qv(q.x, q.y, q.z);
     return v * (2.0f * q.w * q.w - 1.0f) - cross(qv, v) * q.w * 2.0f + qv * dot(qv, v) * 2.0f;
 }
-#else
-// The second copy (namespace ntf: the XPBD projection phases, tolerance contract instead of bit parity) rotates
-// through two cross products, v' = v + 2 (w c + q x c) with c = q x v: 18 fused operations instead of ~30 -- the same rotation
-// for a unit quaternion (the literal form's v (2 w^2 - 1) + 2 q (q.v) equals v + 2 q x (q x v) when |q| = 1; body rotations are
-// normalised by every integrator / apply phase, joint frames by the builder).
-NT_DI vec3 quat_rotate(quat q, vec3 v) {
-    const vec3 qv(q.x, q.y, q.z);
-    const vec3 c = cross(qv, v);
-    const vec3 u = cross(qv, c);
-    return vec3(v.x + 2.0f * (q.w * c.x + u.x), v.y + 2.0f * (q.w * c.y + u.y), v.z + 2.0f * (q.w * c.z + u.z));
-}
-NT_DI vec3 quat_rotate_inv(quat q, vec3 v) {
-    const vec3 qv(q.x, q.y, q.z);
-    const vec3 c = cross(qv, v);
-    const vec3 u = cross(qv, c);
-    return vec3(v.x + 2.0f * (u.x - q.w * c.x), v.y + 2.0f * (u.y - q.w * c.y), v.z + 2.0f * (u.z - q.w * c.z));
-}
-#endif
 // quat_rotate(q, e_x / e_y / e_z) with the multiplications by the unit vector's literal zeros and ones carried out by hand: every
 // non-zero term keeps the literal form's operation and rounding ((2 w) w - 1 on the diagonal, (a b) 2 for the products, the
 // cross term added before the dot term), so the result is bit-identical to the general form for finite inputs, up to the sign of
@@ -167,7 +152,7 @@ NT_DI mat33 matrix_from_cols(vec3 c0, vec3 c1, vec3 c2) {
 NT_DI vec3 mat_col(const mat33& A, int j) {
     return j == 0 ? vec3(A.m00, A.m10, A.m20) : (j == 1 ? vec3(A.m01, A.m11, A.m21) : vec3(A.m02, A.m12, A.m22));
 }
-#ifdef NT_MATH_NS_IS_DEFAULT
+#if defined(NT_MATH_NS_IS_DEFAULT) || defined(NT_XPBD_IEEE)
 NT_DI mat33 quat_to_matrix(quat q) {
     vec3 c0 = quat_rotate(q, vec3(1.f, 0.f, 0.f));
     vec3 c1 = quat_rotate(q, vec3(0.f, 1.f, 0.f));

@@ -666,7 +666,9 @@ NT_DI CwxSide cwx_side(const Ctx<EPB>& c, int ncs, int slot, int side) {
     r.has = (f & (r.is_a ? 1 : 2)) != 0;
     return r;
 }
-template <int EPB, bool FUSED, class CW = CwLds>
+// ROWS: the Contacts may carry rows of the SDF legs (nt_contacts.flat) behind the slots -- the launch-by-launch step kernels; the fused
+// rollouts never do and compile without that code
+template <int EPB, bool FUSED, class CW = CwLds, bool ROWS = !FUSED>
 NT_DI void phase_contacts(const Ctx<EPB>& c) {
     if (!c.valid) return;
     const int np = c.a.m.np, cpp = c.a.m.cpp;
@@ -679,19 +681,21 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
                 const int e = *reinterpret_cast<const int*>(&c.l(c.L.lt, 0, 1, i));
                 contact_item<EPB, FUSED, CW>(c, (e >> 4) * cpp + (e & 15), e >> 4);
             }
-            return;
-        }
-        for (int i = c.tslot; i < total; i += c.nslot) {
-            int lo = 0, hi = np;  // the last pair whose prefix is <= i
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if ((int)c.l(c.L.px, 0, 1, mid) <= i) lo = mid;
-                else hi = mid;
+        } else {
+            for (int i = c.tslot; i < total; i += c.nslot) {
+                int lo = 0, hi = np;  // the last pair whose prefix is <= i
+                while (hi - lo > 1) {
+                    int mid = (lo + hi) >> 1;
+                    if ((int)c.l(c.L.px, 0, 1, mid) <= i) lo = mid;
+                    else hi = mid;
+                }
+                contact_item<EPB, FUSED, CW>(c, lo * cpp + (i - (int)c.l(c.L.px, 0, 1, lo)));
             }
-            contact_item<EPB, FUSED, CW>(c, lo * cpp + (i - (int)c.l(c.L.px, 0, 1, lo)));
         }
     } else {
         for (int s = c.slot; s < np * cpp; s += c.nslot) contact_item<EPB, FUSED, CW>(c, s);
+    }
+    if constexpr (ROWS) {
         if (const nt_flat_rows& f = c.a.ct.flat; f.row_start)  // rows of the SDF legs, appended after the slots like the
             for (int r = f.row_start[c.env] + c.slot; r < f.row_start[c.env + 1]; r += c.nslot)  // reference's later launches
                 flat_contact_item(c, r);
@@ -706,7 +710,7 @@ NT_DI void phase_contacts(const Ctx<EPB>& c) {
 // (it holds q1) also rebuilds the body origin p and the entry-form world COM, the linear lane leaves the COM alone.
 constexpr int NT_APPLY_SLOTS = 5;   // contact slots of a pair fetched together (cpp <= 5)
 constexpr int NT_APPLY_JOINTS = 4;  // incident joints fetched together; longer lists finish in a loop
-template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false>
+template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false, bool ROWS = !FUSED>
 NT_DI void apply_item(const Ctx<EPB>& c, const int b, const bool do_lin, const bool do_ang, const bool last) {
     const nt_model& m = c.a.m;
     const int nb = m.nb;
@@ -761,7 +765,7 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b, const bool do_lin, const b
                 add(s0); add(s1); add(s2); add(s3); add(s4);
             }
         }
-        if constexpr (!FUSED) {
+        if constexpr (ROWS) {
             if (const nt_flat_rows& f = c.a.ct.flat; f.row_start) {  // then the SDF legs' rows, ascending row order
                 const int* bs = f.body_blk_start + (size_t)c.env * (nb + 1) + b;
                 for (int i = bs[0]; i < bs[1]; ++i) {
@@ -849,15 +853,15 @@ NT_DI void apply_item(const Ctx<EPB>& c, const int b, const bool do_lin, const b
         c.update_world_com(b, X);
     }
 }
-template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false>
+template <int EPB, bool FROM_CONTACTS, class CW = CwLds, bool FUSED = false, bool ROWS = !FUSED>
 NT_DI void phase_apply(const Ctx<EPB>& c, const bool last) {
     if (!c.valid) return;
     const int nb = c.a.m.nb, S0 = body_lane_split(c);
     if (S0) {
-        if (c.slot < nb) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, c.slot, false, true, last);
-        else if (c.slot >= S0 && c.slot < S0 + nb) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, c.slot - S0, true, false, last);
+        if (c.slot < nb) apply_item<EPB, FROM_CONTACTS, CW, FUSED, ROWS>(c, c.slot, false, true, last);
+        else if (c.slot >= S0 && c.slot < S0 + nb) apply_item<EPB, FROM_CONTACTS, CW, FUSED, ROWS>(c, c.slot - S0, true, false, last);
     } else {
-        for (int b = c.tslot; b < nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW, FUSED>(c, b, true, true, last);
+        for (int b = c.tslot; b < nb; b += c.nslot) apply_item<EPB, FROM_CONTACTS, CW, FUSED, ROWS>(c, b, true, true, last);
     }
 }
 
@@ -1506,7 +1510,8 @@ NT_DI void phase_joints(const Ctx<EPB>& c) {
 
 // SolverXPBD.step control flow (solver_xpbd.py:329-862), rigid-only model
 // PROLOGUE_DONE: the caller (do_fused_substep) already saved the pre-step state, applied the joint forces and integrated
-template <int EPB, bool FUSED, class CW = CwLds, bool PROLOGUE_DONE = false>
+// ROWS: see phase_contacts (a step kernel that compacts its live slots like the fused rollouts AND walks the rows of the SDF legs)
+template <int EPB, bool FUSED, class CW = CwLds, bool PROLOGUE_DONE = false, bool ROWS = !FUSED>
 NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     const nt_model& m = c.a.m;
     NT_SKIP_DECL(c.a);
@@ -1529,14 +1534,14 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     for (int it = 0; it < iterations; ++it) {
         const bool last_it = it == iterations - 1;
         if (c.a.has_contacts) {
-            if (!NT_SKIP(4)) phase_contacts<EPB, FUSED, CW>(c);
+            if (!NT_SKIP(4)) phase_contacts<EPB, FUSED, CW, ROWS>(c);
             __syncthreads();
             NT_TICK(5);
             if (rep_contacts) {
                 report_contact_iteration<EPB, CW>(c, it == 0);
                 if constexpr (!FUSED) report_flat_rows_iteration<EPB, CW>(c, it == 0);
             }
-            if (!NT_SKIP(16)) phase_apply<EPB, true, CW, FUSED>(c, last_it && m.nj <= 0);
+            if (!NT_SKIP(16)) phase_apply<EPB, true, CW, FUSED, ROWS>(c, last_it && m.nj <= 0);
             __syncthreads();
             NT_TICK(6);
         }
@@ -1568,14 +1573,14 @@ NT_DI void do_xpbd_step(const Ctx<EPB>& c, bool forces_are_zero) {
     if (restitution) {  // solver_xpbd.py:784-858
         if (c.valid)
             for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) restitution_item<EPB, CW>(c, s);
-        if constexpr (!FUSED) {
+        if constexpr (ROWS) {
             if (const nt_flat_rows& f = c.a.ct.flat; c.valid && f.row_start && f.restitution)
                 for (int r = f.row_start[c.env] + c.slot; r < f.row_start[c.env + 1]; r += c.nslot) restitution_flat_item(c, r);
         }
         __syncthreads();
         if (c.valid)
             for (int b = c.slot; b < m.nb; b += c.nslot)
-                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item<EPB, CW, !FUSED>(c, b);
+                if (!(c.T.body_flags[b] & BODY_KINEMATIC)) restitution_apply_item<EPB, CW, ROWS>(c, b);
         __syncthreads();
     }
     if (!FUSED && c.a.s_out.body_parent_f) {

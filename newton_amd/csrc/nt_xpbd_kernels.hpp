@@ -168,14 +168,16 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
     fused::phase_body_derived(cf);
     c.stage_joint_inc();
     __syncthreads();
-    if constexpr (BIG) {
-        fused::do_xpbd_step<EPB, false, fused::CwHbm>(cf, false);
-    } else {
-        // Without reporting outputs and SDF rows the step runs the contact phases of the fused rollout: the live slots of every pair
+    {
+        using CW = std::conditional_t<BIG, fused::CwHbm, fused::CwLds>;  // where the per-contact correction records live
+        // Without reporting outputs the step runs the contact phases of the fused rollout: the live slots of every pair
         // (a pair's contacts fill its slots from the front: collide.py's writer order) are counted from the Contacts buffers, turned
-        // into the live prefix + compacted list, and only live contacts are solved / summed -- instead of all np * cpp slots with
-        // their shape ids re-read from HBM in every iteration (the standing quadruped: 16 of 52).
-        const bool compact = a.has_contacts && !a.ct.flat.row_start && !a.rep.joint_impulse && !a.rep.contact_impulse && !a.s_out.body_parent_f;
+        // into the live prefix (+ compacted list where the layout has one), and only live contacts are solved / summed -- instead of
+        // all np * cpp slots with their shape ids re-read from HBM in every iteration (the standing quadruped: 16 of 52).
+        // Rows of the SDF legs do not stand in the way (round 6): the compacted slots are solved first, the rows behind them, the body
+        // lanes sum slots then rows -- the order of the uncompacted step (config C5's bin: 1 600 wall slots per world, a handful live;
+        // their ids were re-read from HBM in both iterations, one 128-byte line per 4-byte id with one world per workgroup).
+        const bool compact = a.has_contacts && a.m.np > 0 && !a.rep.joint_impulse && !a.rep.contact_impulse && !a.s_out.body_parent_f;
         if (compact) {
             const int np = a.m.np, cpp = a.m.cpp;
             if (c.valid)
@@ -195,9 +197,10 @@ __global__ void __launch_bounds__(THREADS, MINW) xpbd_step_kernel(KArgs a) {
             }
             phase_pair_prefix_scan(c, c.L.sx.off, false, one_level);
             __syncthreads();
-            fused::do_xpbd_step<EPB, true>(cf, false);
+            if (a.ct.flat.row_start) fused::do_xpbd_step<EPB, true, CW, false, true>(cf, false);
+            else fused::do_xpbd_step<EPB, true, CW>(cf, false);
         } else {
-            fused::do_xpbd_step<EPB, false>(cf, false);
+            fused::do_xpbd_step<EPB, false, CW>(cf, false);
         }
     }
     store_state(c, a.s_out);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "newton_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
-FILES = ["nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_ctx.hpp", "nt_collide.hpp", "nt_xpbd.hpp", "nt_xpbd_kernels.hpp",
+FILES = ["nt_step_preamble.hpp", "nt_featherstone.hip", "nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_ctx.hpp", "nt_collide.hpp", "nt_xpbd.hpp", "nt_xpbd_kernels.hpp",
          "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_featherstone_kernels.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip", "nt_contact_reduce.hpp",
          "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip", "nt_graph.hip", "nt_mesh_plane.hip"]
 
@@ -69,7 +69,11 @@ def _build_locked(force: bool) -> str:
         assert "hip_runtime" not in text and "__builtin_amdgcn" not in text, f
         open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w").write(text)
     cmd = ["g++", "-std=c++20", "-O1", "-DNT_ALL_SHAPES", "-DNT_EMULATED_GRID=4", "-DNT_POISON_LDS", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-w",
+           # the two stepping units (nt_kernels / nt_featherstone) both carry the plain (non-inline) __device__ helpers of nt_convex.hpp: on
+           # the device each code object has its own copy, on the host they are identical external definitions
+           "-Wl,--allow-multiple-definition",
            f"-I{HERE}", os.path.join(OUT, "nt_kernels.cpp"), os.path.join(OUT, "nt_broadphase.cpp"),
+           *([os.path.join(OUT, "nt_featherstone.cpp")] if "nt_featherstone.hip" in files else []),
            *([os.path.join(OUT, "nt_sdf.cpp")] if "nt_sdf.hip" in files else []),
            *([os.path.join(OUT, "nt_build_id.cpp")] if "nt_build_id.hip" in files else []),
            *([os.path.join(OUT, "nt_match.cpp")] if "nt_match.hip" in files else []),

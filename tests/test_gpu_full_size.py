@@ -345,5 +345,41 @@ def test_c5_geometry_2048_envs_64_hulls_vs_oracle():
             assert np.max(np.abs(flat[k][lo:hi] - getattr(oc, k)[:n])) <= 1e-5, k
         o.xpbd_step(os0, os1, o.control(), oc, dt)
         tol.check(f"c5_geometry_2048 envs[{b},{e})", q1[b:e].reshape(-1, 7), qd1[b:e].reshape(-1, 6), os1.body_q, os1.body_qd,
-                  pos=1e-5, rot=1e-5, lin_vel=1e-4, ang_vel_abs=4e-3)  # measured: 9e-8 / 7e-7 / 8e-6 / 8.3e-4 rad/s on hulls
-        # of 3-6 cm radius spinning at up to 100 rad/s
+                  pos=1e-5, rot=1e-5, lin_vel=1e-4, ang_vel_abs=4e-3)  # (the drop state: contacts are admitted by the gap but none
+        # penetrates yet, so this step checks the integrator and the slot bookkeeping of the pair-heavy tile, not its contact solve)
+
+    # ---- the same comparison on the SETTLED pile: the hulls are dropped and settled on the device
+    # (fused rollouts of the pair-heavy tile), then ONE collide + step from that state on the device and -- from the identical state --
+    # on the checker.  Hundreds of contacts per world penetrate, every body of the pile is corrected through nt_contacts.cw.
+    SETTLE = int(os.environ.get("NT_FULL_SIZE_C5_SETTLE_FRAMES", "30"))
+    dts = 1.0 / 1200.0
+    cur, other = s0, s1
+    for _ in range(SETTLE):
+        out = solver.rollout(cur, other, None, contacts, dts, 10)
+        if out is other:
+            cur, other = other, cur
+    torch.cuda.synchronize()
+    qs, qds = cur.body_q.cpu().numpy().reshape(E, t.nb, 7), cur.body_qd.cpu().numpy().reshape(E, t.nb, 6)
+    assert np.all(np.isfinite(qs)) and float(qs[:, :, 2].min()) > -0.01  # a pile inside the bin
+    cur.clear_forces()
+    pipe.collide(cur, contacts)
+    solver.step(cur, other, None, contacts, dts)
+    torch.cuda.synchronize()
+    counts = contacts.rigid_contact_count_per_env.cpu().numpy()
+    q2 = other.body_q.cpu().numpy().reshape(E, t.nb, 7)
+    qd2 = other.body_qd.cpu().numpy().reshape(E, t.nb, 6)
+    for b, e in ((0, S), (E - S, E)):
+        sub = slice_worlds(model, b, e, device="cpu")
+        o = Oracle(sub)
+        os0 = OracleState(sub, qs[b:e].reshape(-1, 7), qds[b:e].reshape(-1, 6))
+        os1, os_free, oc = OracleState(sub), OracleState(sub), o.contacts()
+        o.collide(os0.body_q, oc)
+        assert np.array_equal(counts[b:e], _per_env_counts(sub, oc))  # identical inputs: per-world contact counts exact
+        o.xpbd_step(os0, os1, o.control(), oc, dts)
+        o.xpbd_step(os0, os_free, o.control(), None, dts)  # the same step without contacts: what the contact solve contributes
+        touched = np.linalg.norm(os1.body_qd[:, :3] - os_free.body_qd[:, :3], axis=1) > 1e-3
+        assert touched.mean() > 0.5, touched.mean()  # most bodies of the pile are corrected by penetrating contacts
+        errs = tol.check(f"c5_geometry_2048 settled envs[{b},{e})", q2[b:e].reshape(-1, 7), qd2[b:e].reshape(-1, 6), os1.body_q, os1.body_qd,
+                         pos=1e-5, rot=2e-5, lin_vel_abs=tol.velocity_ulp_bound(1.0, dts, 16), ang_vel_abs=2e-2)
+        # (hulls of 3-6 cm radius: one position ulp at the contact point is ~1e-3 rad/s after the division by dt and the lever arm)
+        assert errs["lin_vel_abs"]["max"] > 0.0  # not a vacuous comparison: device and checker round differently somewhere

@@ -97,6 +97,7 @@ def test_ramp_lineup_hip_matches_oracle_and_stays_put():
     s0, s1 = model_gpu.state(), model_gpu.state()
     os0, os1, oc = OracleState(model), OracleState(model), o.contacts()
     dt = 1.0 / 600.0
+    worst = 0.0
     for k in range(20):
         s0.body_q, s0.body_qd = os0.body_q, os0.body_qd  # teacher forcing: both start every step from the oracle's state
         s0.clear_forces()
@@ -107,8 +108,13 @@ def test_ramp_lineup_hip_matches_oracle_and_stays_put():
         o.xpbd_step(os0, os1, o.control(), oc, dt, iterations=2)
         assert int(contacts.rigid_contact_count.cpu().numpy()[0]) == int(oc.count[0]), k
         got, want = s1.body_q.cpu().numpy(), os1.body_q
-        assert np.max(np.abs(got - want)) <= 2e-5, k
+        worst = max(worst, float(np.max(np.abs(got - want))))
+        print(f"[ramp] step {k}: max |dq| {float(np.max(np.abs(got - want))):.3g}")
         os0, os1 = os1, os0
+    # single steps from identical inputs, bodies 0.5 - 2.5 m from the origin (1e-5 relative, the contract, is 2.5e-5 here).  Measured:
+    # 1.2e-5; the worst body is a cube resting on ONE
+    # MPR contact whose lever arm turns an ulp of the correction into 1e-5 of position
+    assert worst <= 2e-5, worst
     # stability on the HIP path
     s0, s1 = model_gpu.state(), model_gpu.state()
     q_initial = s0.body_q.cpu().numpy().copy()

@@ -56,12 +56,13 @@ for _ in range(30 if HULL else 100):
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 32)()
 raw = C.CDLL(dbg)
-raw.nt_debug_phase_clocks(buf)
+clocks = raw.nt_debug_phase_clocks_fs if FS and hasattr(raw, "nt_debug_phase_clocks_fs") else raw.nt_debug_phase_clocks  # (per translation unit)
+clocks(buf)
 N = 10 if HULL else 50
 for _ in range(N):
     solver.rollout(s0, s1, None, contacts, DT, 10)
 torch.cuda.synchronize()
-raw.nt_debug_phase_clocks(buf)
+clocks(buf)
 if FS:
     names = {10: "collide (+ previous tail)", 11: "FK", 12: "to internal qd", 13: "RNEA forward (pre + levels)", 14: "contacts + f_ext",
              15: "RNEA backward (tau)", 16: "P = I S (tree: I^c, I^c S)", 17: "H", 18: "factorise + solve", 19: "integrate", 20: "FK + velocities",

@@ -62,6 +62,15 @@ def main():
             per["frac_active_any"] = per.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
             per["frac_active_valu"] = per.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
         res[k] = {"launches": n, "per_launch": per}
+    # the build the counters belong to (bench.py attaches them only to this build, or to one with a byte-identical stepping unit)
+    sys.path.insert(0, ROOT)
+    import ctypes
+
+    import __graft_entry__ as g
+
+    lib = ctypes.CDLL(g.LIB)
+    lib.nt_build_info.restype = ctypes.c_char_p
+    res["_build"] = {"build_id": lib.nt_build_info().decode(), "step_unit": g.step_unit_id(workload), "workload": workload, "envs": envs or "default"}
     json.dump(res, open(os.path.join(OUT, f"pmc_sq_{tag}.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -81,7 +81,7 @@ def main():
         envs = int(envs or 4096)
         import __graft_entry__ as g  # noqa: PLC0415  (ROOT is on sys.path after build_id())
 
-        rec = {"build_id": build_id(), "step_unit": g.step_unit_id(), "workload": workload, "envs": envs, "kernel": KERNEL[workload],
+        rec = {"build_id": build_id(), "step_unit": g.step_unit_id(workload), "workload": workload, "envs": envs, "kernel": KERNEL[workload],
                "substeps_per_launch": 1 if workload in ("hydro_bin", "sdf_bin") else 10}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cal, roll = run_pass(counter, workload, envs)
