@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) sdf_rows_write_kernel(nt_sdf_scene sc, nt
 }
 
 // per world: the row blocks of every body, ascending.  Lane = body; the world's pair list is staged in LDS.
-constexpr int BLK_PAIRS_LDS = 2048;
+constexpr int BLK_PAIRS_LDS = 2560;  // (config C5 at Newton's default gap: all 2 336 pairs of a world are candidates)
 __global__ void __launch_bounds__(256) sdf_body_blocks_kernel(nt_sdf_scene sc, nt_sdf_rows_io io, int32_t* __restrict__ body_blk_start,
                                                              int32_t* __restrict__ body_blk_list) {
     __shared__ int pa[BLK_PAIRS_LDS], pb[BLK_PAIRS_LDS], pr[BLK_PAIRS_LDS], pc[BLK_PAIRS_LDS];

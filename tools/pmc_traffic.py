@@ -5,7 +5,7 @@ Two separate passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass: MI355X_
 each over the same command: a known-byte-count calibration copy (4 B/lane coalesced, our access pattern) followed by
 bench.py rollouts.  Counters are in KiB; the calibration ratio (known bytes / reported bytes) corrects the gfx950
 FETCH_SIZE under-count.  Each record carries the library's source hash (nt_build_info), so bench.py only trusts a record
-taken on the build it is running.  Appends to gpurun_out/r05_pmc_traffic.json (copy it to profiles/ to commit it).
+taken on the build it is running.  Appends to gpurun_out/r06_pmc_traffic.json (NT_PMC_OUT overrides the name; copy it to profiles/ to commit it).
 
 usage (from the repo root on the GPU box):  python tools/pmc_traffic.py [workload[@envs] ...]      default: quadruped@4096
 """
@@ -73,7 +73,7 @@ def main():
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, "r05_pmc_traffic.json")
+    path = os.path.join(OUT, os.environ.get("NT_PMC_OUT", "r06_pmc_traffic.json"))
     res = json.load(open(path)) if os.path.exists(path) else {}
     known = CAL_FLOATS * 4
     for spec in sys.argv[1:] or ["quadruped@4096"]:
