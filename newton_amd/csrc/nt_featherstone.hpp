@@ -587,31 +587,34 @@ NT_DI void fs_H_item(const FsCtx<EPB>& f, int item) {
 // joint-space inertia and the same solution up to rounding (the 1e-5 contract), with the work of a 4-legged 18-dof robot cut
 // from 171 dense entries x 13 bodies and 18 sequential pivots to 117 entries and 9 dof-tree levels worked by the whole workgroup.
 
-// I^c_l = sum of I_b over the bodies b of joint l's subtree (ascending b); item = l * 36 + r
+// I^c_l = sum of I_b over the bodies b of joint l's subtree (ascending b); item = l * 6 + row: the six entries of one row of the
+// 6 x 6 tile per lane (round 6: one ENTRY per lane was 36 nj items of item decode + mask fetch + a dependent load each -- 15 trips on
+// the 32 lanes per environment of the 16-environment tile; a row per lane is 2.4 trips with six independent sums in flight).  Every
+// entry is still summed in ascending body order: the same bits.
 template <int EPB>
 NT_DI void fs_Ic_item(const FsCtx<EPB>& f, int item) {
     const Ctx<EPB>& c = f.c;
     const int nb = c.a.m.nb;
-    const int l = item / 36, r = item - l * 36;
+    const int l = item / 6, r0 = (item - l * 6) * 6;
     unsigned long long sub = f.m64(f.t_jbelow, l);
-    float sum = 0.0f;
-    while (sub) {  // four bodies per round: the loads are issued together, the additions stay in ascending body order
-        int b[4];
-        bool on[4];
+    float sum[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    while (sub) {  // two bodies per round: twelve loads issued together, the additions stay in ascending body order
+        const int b0 = __ffsll((long long)sub) - 1;
+        sub &= sub - 1;
+        const bool two = sub != 0ull;
+        const int b1 = two ? __ffsll((long long)sub) - 1 : b0;
+        sub &= sub - 1;  // (0 stays 0)
+        float v0[6], v1[6];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            on[q] = sub != 0ull;
-            b[q] = on[q] ? __ffsll((long long)sub) - 1 : l;
-            sub &= sub - 1;  // (0 stays 0)
+        for (int k = 0; k < 6; ++k) { v0[k] = c.l(f.F.Is, r0 + k, nb, b0); v1[k] = c.l(f.F.Is, r0 + k, nb, b1); }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            sum[k] += v0[k];
+            if (two) sum[k] += v1[k];
         }
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = c.l(f.F.Is, r, nb, b[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (on[q]) sum += v[q];
     }
-    c.l(f.F.Ic, r, nb, l) = sum;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.l(f.F.Ic, r0 + k, nb, l) = sum[k];
 }
 // Pd[d] = I^c_joint(d) S_d; item = d * 6 + i
 template <int EPB>
@@ -672,7 +675,7 @@ NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
     auto row = [&](int k) { return single ? (k * (k + 1)) / 2 : f.rowbase[k]; };
     // the entries and the dof this lane owns, decoded once per step (the tables are block-shared LDS: a dependent read per level
     // and entry was most of the first version's time)
-    constexpr int TE = 2;
+    constexpr int TE = 4;  // (entries per lane: 117 entries of the quadruped on the 32 lanes per environment of the 16-environment tile)
     const bool cached = nnz <= TE * c.nslot && nd <= c.nslot;
     int e_i[TE], e_j[TE], e_off[TE], e_dd[TE];
     unsigned long long e_below[TE];
@@ -715,6 +718,9 @@ NT_DI void fs_solve_tree(const FsCtx<EPB>& f, const bool factor) {
     __syncthreads();
     for (int d = maxd; d >= 1; --d) {
         const unsigned long long at = f.m64(f.t_lvl, d);
+        // (Measured and rejected, round 6: the runs of single-dof levels -- the six dofs of a FREE root -- worked by ONE lane per environment
+        // without the level barriers: factorise + solve 410 k -> 498 k cycles per launch, 69.4 -> 65.2 M env-steps/s; the 35 entries of such a
+        // run are 35 dependent LDS round trips on one lane, the level-parallel form spreads them.  profiles/r06K_*.)
         if (c.valid && cached) {
 #pragma unroll
             for (int u = 0; u < TE; ++u) {
@@ -1302,7 +1308,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         for (int d = c.slot; d < m.nd; d += c.nslot) fs_tau_dof_item(f, d);
     if (update_mass && tree) {
         if (c.valid && !NT_SKIP(16))
-            for (int i = c.slot; i < nj * 36; i += c.nslot) fs_Ic_item(f, i);
+            for (int i = c.slot; i < nj * 6; i += c.nslot) fs_Ic_item(f, i);
         __syncthreads();
         if (c.valid && !NT_SKIP(16))
             for (int i = c.slot; i < m.nd * 6; i += c.nslot) fs_Pd_item(f, i);
