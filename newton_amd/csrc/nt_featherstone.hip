@@ -28,8 +28,9 @@ static nt_status fs_launch(const nt_model* m, KArgs& a, int32_t envs_per_block, 
     // 16 per CU in one 512-lane workgroup -- 4 096 environments in ONE round of 256 workgroups instead of two rounds of 1 024 x 4.
     const LdsLayout Lu = make_layout(*m, false, false, true, false);
     const FsLayout Fu = make_fs_layout(*m, Lu, tree);
-    const bool uni16 = rollout && !cvx && m->params_uniform && (envs_per_block == 0 || envs_per_block == 16) && m->env_count > 2048 &&  // (up to 2 048 environments the tiles of 4 are ONE round
-                       // of 512 workgroups already and keep all 64 lanes per environment: 37.6 vs 32.6 M env-steps/s, profiles/r06H_ab_workloads.txt)
+    // (automatic from 2 049 environments: up to 2 048 the tiles of 4 are ONE round of 512 workgroups already and keep all 64 lanes per
+    // environment -- 37.6 vs 32.6 M env-steps/s, profiles/r06H_ab_workloads.txt; envs_per_block = 16 asks for it at any size)
+    const bool uni16 = rollout && !cvx && m->params_uniform && (envs_per_block == 16 || (envs_per_block == 0 && m->env_count > 2048)) &&
                        (size_t)Fu.rows * 4 * 16 + shared_ints * 4 + (size_t)Lu.uni_floats * 4 <= LDS_BYTES_PER_CU;
     int epb = 0;
     if (uni16) {

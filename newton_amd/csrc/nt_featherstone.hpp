@@ -1219,7 +1219,8 @@ NT_DI bool fs_update_mass(const Ctx<EPB>& c, int substep) {
     return ((p.step_index + substep) % p.update_mass_matrix_interval) == 0;
 }
 // One SolverFeatherstone.step on the state resident in LDS (joint_q in F.jq, public joint_qd in F.qdp).
-template <int EPB>
+// ROLLOUT: called by the fused rollout, whose collide phases ran a barrier ago in the same kernel (si_contact_item<FUSED>)
+template <int EPB, bool ROLLOUT = false>
 NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F, int max_depth, bool forces_are_zero,
                       bool publish_fk, float* parent_f_out, const int substep = 0) {
     const KArgs& a = c.a;
@@ -1273,7 +1274,7 @@ NT_DI void fs_substep(const Ctx<EPB>& c, const FsCtx<EPB>& f, const FsLayout& F,
         Ctx<EPB> cc = c;
         cc.L.si_cw.off = F.cw;
         if (c.valid && !NT_SKIP(4))
-            for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) si_contact_item(cc, s);
+            for (int s = c.slot; s < m.np * m.cpp; s += c.nslot) si_contact_item<EPB, ROLLOUT>(cc, s);
         __syncthreads();
     }
     if (c.valid)

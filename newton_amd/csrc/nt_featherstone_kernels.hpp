@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(THREADS) featherstone_rollout_kernel(KArgs a) 
     const nt_state& res = (a.substeps & 1) ? a.s_out : a.s_in;
     for (int s = 0; s < a.substeps; ++s) {
         do_collide<EPB, CVX>(cc, s == a.substeps - 1);
-        fs_substep(c, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr, s);
+        fs_substep<EPB, true>(c, f, F, max_depth, true, false, s == a.substeps - 1 ? res.body_parent_f : nullptr, s);
     }
     if (c.valid) {
         unstage_rows(c, F.jq, res.joint_q, m.nc);

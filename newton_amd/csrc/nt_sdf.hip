@@ -2328,6 +2328,12 @@ struct HyWaveFaces {
     unsigned char l2[64];
     unsigned short vox[512];
     float es[8 * HY_ROUND], eo[8 * HY_ROUND];  // corner samples of the round's voxels: [voxel][corner]
+    // face-per-lane rounds (see hydro_stage_faces_kernel): the round's candidate faces as (voxel lane << 3 | face), what the face lanes
+    // report to their voxel's lane, and what the voxel lanes answer
+    unsigned short face_list[64];
+    int fkeep[64];
+    float fdepth[64], fscore[64];
+    int vbefore[64], vbefore_sel[64], vsel[64];
 };
 #ifdef NT_HYDRO_FACES_WAVES  // measurement builds: cap the registers for this many waves per SIMD
 #define NT_HYDRO_FACES_OCC __attribute__((amdgpu_waves_per_eu(NT_HYDRO_FACES_WAVES, NT_HYDRO_FACES_WAVES)))
@@ -2439,8 +2445,24 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel
 // One wave per (pair, block) item.  (Measured alternative, profiles/r04e_*: four blocks per wave on 16-lane groups -- better lane
 // utilisation, but 121 instead of 90 ms per collide at C5's size: the lanes of a wave then sample four distant SDF regions at once
 // and the texel requests of one instruction stop sharing cache lines.  The stage is bound by texel requests, not by lanes.)
-__global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_stage_faces_kernel(nt_hydro_args a) {
+constexpr int HY_MC_EDGE_BYTES = 2 * 2460;  // marching-cubes case tables: 820 triangles x 3 vertices x (corner, corner), newton_amd.mc_tables
+__global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_stage_faces_kernel(nt_hydro_args a_) {
     __shared__ HyWaveFaces W[HY_STAGE_WAVES];
+    // the case tables in LDS (round 6): every face of every voxel fetches six table bytes behind the case's range -- dependent GLOBAL loads
+    // (cache hits, but hundreds of cycles each) on a stage that holds two waves per SIMD; 6 KB of LDS per workgroup
+    __shared__ int s_tri[257];
+    __shared__ unsigned char s_edge[HY_MC_EDGE_BYTES];
+    nt_hydro_args a = a_;
+    {
+        const int nbytes = 2 * a_.tri_range[256];
+        if (nbytes <= HY_MC_EDGE_BYTES) {  // (else: an unexpected table, keep reading it from global memory)
+            for (int i = threadIdx.x; i < 257; i += blockDim.x) s_tri[i] = a_.tri_range[i];
+            for (int i = threadIdx.x; i < nbytes; i += blockDim.x) s_edge[i] = a_.flat_edge_verts[i];
+            a.tri_range = s_tri;
+            a.flat_edge_verts = s_edge;
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     HyWaveFaces& w = W[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -2501,6 +2523,9 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
             n_vox += __popcll(m1);
         }
         HY_WAVE_SYNC();
+#ifdef NT_HYDRO_SKIP_MC  // measurement builds only: the octree levels alone (no marching cubes, no faces: results are meaningless)
+        n_vox = 0;
+#endif
         const int nb = (n_vox + HY_ROUND - 1) / HY_ROUND;
         int chunk0 = 0;
         if (nb > 0) {
@@ -2547,6 +2572,117 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
                 for (int i = 0; i < 8; ++i) { es8[i] = w.es[8 * lane + i]; eo8[i] = w.eo[8 * lane + i]; }
                 hydro_voxel_classify(a, p, es8, eo8, cn);
             }
+#ifdef NT_HYDRO_SKIP_FACES  // measurement builds only: corner samples + classification, no faces (results are meaningless)
+            cn.nfaces = 0;
+#endif
+            // ---- face-per-lane round (round 6).  A block of a pile carries ~11 iso voxels with ~2 faces each: one lane per VOXEL walking
+            // its <= 5 faces twice (rank, then write) kept 17 % of the lanes busy for ten serial face evaluations -- 38 of the stage's 66 ms
+            // (profiles/r06T_*).  When the round's candidate faces fit the wave (nearly always) every face gets its own lane and is
+            // evaluated ONCE: the face lanes report (kept, depth, score) to their voxel's lane, which runs the reference's selection loop
+            // over them in face order and answers with the voxel's offsets; ids, order and records are those of the two-pass form below.
+            {
+                const int nfv = mine ? cn.nfaces : 0;
+                int fx = nfv;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int y = __shfl_up(fx, d);
+                    if (lane >= d) fx += y;
+                }
+                const int F = hy_uniform(__shfl(fx, 63)), fb = fx - nfv;
+                if (F <= 64) {
+                    for (int fi = 0; fi < nfv; ++fi) w.face_list[fb + fi] = (unsigned short)((lane << 3) | fi);
+                    HY_WAVE_SYNC();
+                    // face lanes
+                    const bool is_face = lane < F;
+                    HydroFace fc;
+                    bool ok = false;
+                    int fv_ = 0, ffi = 0;
+                    if (is_face) {
+                        const int code = (int)w.face_list[lane];
+                        fv_ = code >> 3; ffi = code & 7;
+                        int ux, uy, uz;
+                        hy_voxel((int)w.vox[v0 + fv_], ux, uy, uz);
+                        float es8[8], eo8[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { es8[i] = w.es[8 * fv_ + i]; eo8[i] = w.eo[8 * fv_ + i]; }
+                        HydroCorners fcn;
+                        hydro_voxel_classify(a, p, es8, eo8, fcn);
+                        ok = hydro_voxel_face(a, p, ux + x0, uy + y0, uz + z0, fcn, ffi, fc);
+                        w.fkeep[lane] = ok ? 1 : 0;
+                        w.fdepth[lane] = ok ? fc.depth : 0.0f;
+                        w.fscore[lane] = ok ? fc.area * fc.pressure : 0.0f;
+                    }
+                    const unsigned long long keepmask = __ballot(ok);
+                    HY_WAVE_SYNC();
+                    // voxel lanes: the selection loop of the two-pass form over the reported faces
+                    int kept = 0, sel0 = -1, sel1 = -1, sel2 = -1;
+                    float sc0 = 0.0f, sc1 = 0.0f, best_np = 1.0e10f;
+                    for (int fi = 0; fi < nfv; ++fi) {
+                        if (!w.fkeep[fb + fi]) continue;
+                        if (prune) {
+                            const float depth = w.fdepth[fb + fi];
+                            if (depth < 0.0f) {
+                                const float score = w.fscore[fb + fi];
+                                if (sel0 < 0 || score > sc0) { sel1 = sel0; sc1 = sc0; sel0 = kept; sc0 = score; }
+                                else if (sel1 < 0 || score > sc1) { sel1 = kept; sc1 = score; }
+                            } else if (depth < best_np) {
+                                best_np = depth;
+                                sel2 = kept;
+                            }
+                        }
+                        kept += 1;
+                    }
+                    const int nsel = prune ? (sel0 >= 0) + (sel1 >= 0) + (sel2 >= 0) : kept;
+                    int x = kept, xs = nsel;  // inclusive scans over the wave
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int y = __shfl_up(x, d), ys = __shfl_up(xs, d);
+                        if (lane >= d) { x += y; xs += ys; }
+                    }
+                    const int total = hy_uniform(__shfl(x, 63)), sel_total = hy_uniform(__shfl(xs, 63));
+                    w.vbefore[lane] = x - kept;
+                    w.vbefore_sel[lane] = xs - nsel;
+                    w.vsel[lane] = ((sel0 + 1) & 15) | (((sel1 + 1) & 15) << 4) | (((sel2 + 1) & 15) << 8);
+                    int base = 0;
+                    if (lane == 0 && total > 0) base = atomicAdd(a.face_count, total);
+                    base = hy_uniform(__shfl(base, 0));
+                    const bool fits = base + total <= a.face_capacity;
+                    if (lane == 0) {
+                        int* c = a.stage_chunk + 4 * (size_t)(chunk0 + k);
+                        c[0] = base;
+                        c[1] = fits ? total : -total;  // negative: the faces did not fit the buffer (counted, not stored)
+                        c[2] = sel_total;
+                        c[3] = nv;
+                    }
+                    HY_WAVE_SYNC();
+                    if (fits && ok) {
+                        const int first = lane - ffi;  // the voxel's first face lane
+                        const unsigned long long mine_mask = ((1ull << ffi) - 1ull) << first;
+                        const int ord = __popcll(keepmask & mine_mask);
+                        const int vs_ = w.vsel[fv_], s0 = (vs_ & 15) - 1, s1 = ((vs_ >> 4) & 15) - 1, s2 = ((vs_ >> 8) & 15) - 1;
+                        int cid = 0;  // contact id, relative to the chunk (the reduce stage adds what came before in the pair)
+                        if (!prune) cid = w.vbefore[fv_] + ord + 1;
+                        else {
+                            const int bs = w.vbefore_sel[fv_];
+                            int rank = 0;
+                            if (s0 == ord) cid = bs + rank + 1;
+                            rank += s0 >= 0 ? 1 : 0;
+                            if (s1 == ord) cid = bs + rank + 1;
+                            rank += s1 >= 0 ? 1 : 0;
+                            if (s2 == ord) cid = bs + rank + 1;
+                        }
+                        float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + w.vbefore[fv_] + ord);
+                        o[0] = fc.pos.x; o[1] = fc.pos.y; o[2] = fc.pos.z;
+                        o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
+                        o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
+                        int* oi = reinterpret_cast<int*>(o);
+                        oi[9] = fv_ * 5 + ffi;  // voxel rank inside the CHUNK (rebased by the reduce stage)
+                        oi[10] = (cid << 5) | red_get_slot(fc.normal);
+                        oi[11] = 0;
+                    }
+                    HY_WAVE_SYNC();  // (the next round overwrites the corner samples and the lists)
+                    continue;
+                }
+            }
+            // ---- two-pass form (rounds with more than 64 candidate faces)
             // pass 1: which faces stay, and (pre_prune) the two strongest penetrating faces + the closest non-penetrating one
             int keep_mask = 0, kept = 0, sel0 = -1, sel1 = -1, sel2 = -1;
             float sc0 = 0.0f, sc1 = 0.0f, best_np = 1.0e10f;
@@ -2587,6 +2723,9 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
             }
             HY_WAVE_SYNC();  // (the next round overwrites the corner samples)
             if (!fits || kept == 0) continue;
+#ifdef NT_HYDRO_SKIP_PASS2  // measurement builds only: no second face pass, no face records
+            continue;
+#endif
             // pass 2: the kept faces again, straight into their records
             int ord = 0;
             for (int fi = 0; fi < cn.nfaces; ++fi) {

@@ -166,7 +166,10 @@ NT_DI void si_joint_item(const Ctx<EPB>& c, const int j) {
 
 // eval_body_contact (semi_implicit/kernels_contact.py:381-556), one lane per contact slot: publishes f_total and the
 // torques about both bodies' COMs; the body lane subtracts for shape0's body and adds for shape1's body.
-template <int EPB>
+// FUSED: the collide phases of the SAME kernel just ran (SolverFeatherstone's rollout): a pair's live contacts fill its slots from the
+// front and their number is in L.pm, the (type-sorted) shapes of a pair are static -- neither the liveness test nor the shape ids need the
+// Contacts buffers in HBM (one dependent global round trip less per contact phase, and no id -> local shape search)
+template <int EPB, bool FUSED = false>
 NT_DI void si_contact_item(const Ctx<EPB>& c, const int slot) {
     const nt_model& m = c.a.m;
     const nt_contacts& ct = c.a.ct;
@@ -174,20 +177,31 @@ NT_DI void si_contact_item(const Ctx<EPB>& c, const int slot) {
     const float* D = ct.data;
     float has_a = 0.0f, has_b = 0.0f, a_is_pair_a = 1.0f;
     vec3 f_total, tq_a, tq_b;
-    size_t gi = (size_t)slot * c.ES + c.env;
-    int gid_a = ct.shape0[gi], gid_b = ct.shape1[gi];
+    int gid_a = -1, gid_b = -1, fused_a = -1, fused_b = -1;
+    if constexpr (FUSED) {
+        const int p = slot / cpp, k = slot - p * cpp;
+        if (k < (int)c.l(c.L.pm, 0, m.np, p)) {
+            fused_a = c.T.pair_a[p];
+            fused_b = c.T.pair_b[p];
+            if (c.T.shape_type[fused_a] > c.T.shape_type[fused_b]) { const int t_ = fused_a; fused_a = fused_b; fused_b = t_; }  // narrow_phase.py:525-528
+            gid_a = 0; gid_b = 1;  // (live: any two distinct non-negative ids)
+        }
+    } else {
+        const size_t gi = (size_t)slot * c.ES + c.env;
+        gid_a = ct.shape0[gi]; gid_b = ct.shape1[gi];
+    }
     if (gid_a != gid_b) {
         float ke = 0.0f, kd = 0.0f, kf = 0.0f, ka = 0.0f, mu = 0.0f;
         int mat_nonzero = 0, shape_a = -1, shape_b = -1, body_a = -1, body_b = -1;
         if (gid_a >= 0) {
-            shape_a = c.local_shape_id(gid_a);
+            shape_a = FUSED ? fused_a : c.local_shape_id(gid_a);
             mat_nonzero += 1;
             ke += c.shape_f(shape_a, SP_KE); kd += c.shape_f(shape_a, SP_KD); kf += c.shape_f(shape_a, SP_KF);
             ka += c.shape_f(shape_a, SP_KA); mu += c.shape_f(shape_a, SP_MU);
             body_a = c.T.shape_body[shape_a];
         }
         if (gid_b >= 0) {
-            shape_b = c.local_shape_id(gid_b);
+            shape_b = FUSED ? fused_b : c.local_shape_id(gid_b);
             mat_nonzero += 1;
             ke += c.shape_f(shape_b, SP_KE); kd += c.shape_f(shape_b, SP_KD); kf += c.shape_f(shape_b, SP_KF);
             ka += c.shape_f(shape_b, SP_KA); mu += c.shape_f(shape_b, SP_MU);

@@ -21,8 +21,9 @@ FILES = ["nt_step_preamble.hpp", "nt_featherstone.hip", "nt_math.hpp", "nt_primi
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
 HY_SYNC = re.compile(r"#define HY_WAVE_SYNC_HW\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
-WAVE_SYNC_EMU = ("#define FS_WAVE_SYNC() emu_wave_sync((unsigned)(G * (((int)c.a.m.env_count - (int)blockIdx.x * EPB) < EPB ? "
-                 "((int)c.a.m.env_count - (int)blockIdx.x * EPB) : EPB)))")
+# (EPB is the tile code: environments per workgroup in its low byte, the uniform-parameter flag in bit 8)
+WAVE_SYNC_EMU = ("#define FS_WAVE_SYNC() emu_wave_sync((unsigned)(G * (((int)c.a.m.env_count - (int)blockIdx.x * (EPB & 255)) < (EPB & 255) ? "
+                 "((int)c.a.m.env_count - (int)blockIdx.x * (EPB & 255)) : (EPB & 255))))")
 
 
 def transform(text: str) -> str:

@@ -275,6 +275,33 @@ def test_featherstone_step_and_rollout(H, n_env, epb):
     assert np.array_equal(out.joint_qd, a.joint_qd) and np.array_equal(out.body_qd, a.body_qd)
 
 
+def test_featherstone_uniform_tile_of_16_is_bitwise_the_tiles_of_4(H):
+    """Round 6: SolverFeatherstone's rollout keeps 16 environments per workgroup when the parameters are uniform (one block-shared
+    parameter copy, the tree mode's own solve region with a packed H, 32 lanes per environment: nt_featherstone.hip).  Same arithmetic per
+    quantity, other layout and lane count: the result must be BITWISE the one of the per-environment tiles of 4 -- on a second, partly
+    filled workgroup too (17 environments), with live contacts."""
+    from scenes import quadruped_scene
+
+    model = quadruped_scene(17)
+    _lower(model, 0.26)
+    rng = np.random.default_rng(3)
+    model.joint_qd = (model.joint_qd + rng.normal(0, 0.3, size=model.joint_qd.shape)).astype(np.float32)
+    em = H.EmuModel(model)
+    assert em.desc.params_uniform == 1
+    jf = np.tile(rng.normal(0, 2.0, size=model.joint_dof_count // 17).astype(np.float32), 17)  # (uniform controls are not required; same per env here)
+    ctrl = H.EmuControl(em, joint_f=jf)
+    outs = []
+    for epb in (4, 16):
+        ct = H.EmuContacts(em)
+        out = H.featherstone_rollout(em, H.EmuState(em), H.EmuState(em), ctrl, ct, 1e-3, 3, epb=epb)
+        outs.append((out.joint_q.copy(), out.joint_qd.copy(), out.body_q.copy(), out.body_qd.copy(), ct.export()))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert np.array_equal(a, b)
+    assert int(outs[0][4]["count"][0]) == int(outs[1][4]["count"][0]) > 0
+    for k in ("shape0", "shape1", "point0", "normal"):
+        assert np.array_equal(outs[0][4][k], outs[1][4][k]), k
+
+
 @pytest.mark.parametrize("lowered,substeps,tol", [(False, 60, 2e-6), (True, 10, 2e-4)])
 def test_featherstone_tree_and_dense_orders_stay_together_over_a_rollout(H, lowered, substeps, tol):
     """SolverFeatherstone defaults to the tree-structured mass matrix (composite inertias + leaf-first L^T D L), which

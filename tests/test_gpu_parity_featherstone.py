@@ -187,6 +187,33 @@ def test_rollout_bitwise_equals_api_loop():
         assert np.array_equal(getattr(res, name).cpu().numpy(), getattr(s0, name).cpu().numpy()), name
 
 
+def test_uniform_tile_of_16_is_bitwise_the_tiles_of_4_at_full_size():
+    """Round 6: from 2 049 uniform-parameter environments up the rollout keeps 16 environments per workgroup (block-shared parameters,
+    tree-mode solve region, 32 lanes per environment).  At BASELINE.json's size the automatic choice, the explicit request and the
+    per-environment tiles of 4 give the same bits, frame after frame, with all feet in the ground."""
+    import ctypes as C
+
+    from scenes import quadruped_scene
+
+    nt, model, _ = _setup(quadruped_scene, 4096)
+    _lower_quadrupeds(nt, model, 0.24)
+    results = []
+    for epb in (4, 0, 16):
+        pipe = nt.CollisionPipeline(model)
+        contacts = pipe.contacts()
+        solver = nt.solvers.SolverFeatherstone(model, envs_per_block=epb)
+        r0, r1 = model.state(), model.state()
+        for _ in range(3):
+            res = solver.rollout(r0, r1, None, contacts, 1e-3, 10)
+            assert res is r0
+        results.append({k: getattr(r0, k).cpu().numpy().copy() for k in ("joint_q", "joint_qd", "body_q", "body_qd")})
+        assert int(contacts.rigid_contact_count.cpu().numpy()[0]) >= 4096 * 4
+    for other in results[1:]:
+        for k, v in results[0].items():
+            assert np.array_equal(v, other[k]), k
+    assert np.all(np.isfinite(results[0]["body_q"]))
+
+
 def test_body_parent_f_matches_oracle_step_and_rollout():
     """State.body_parent_f (compute_body_parent_f, featherstone/kernels.py:2371-2416) of a contact-loaded quadruped step vs
     the oracle (<= 1e-4 of the largest wrench); the fused rollout reports the last substep's wrenches bit-identically."""

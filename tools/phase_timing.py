@@ -42,7 +42,12 @@ elif BOX:
     model = box_stack_scene(int(sys.argv[2]) if len(sys.argv) > 2 else 256, device="cuda:0", seed=1)
 else:
     NENV = int(os.environ.get("NT_TIMING_ENVS", "4096"))
-    model = quadruped_scene(NENV, device="cuda:0", seed=1)
+    if len(sys.argv) > 1 and sys.argv[1] == "quadruped_convex":  # config C4's convex-convex variant (box links on a box slab)
+        from scenes import quadruped_convex_scene  # noqa: E402
+
+        model = quadruped_convex_scene(NENV, device="cuda:0", seed=1)
+    else:
+        model = quadruped_scene(NENV, device="cuda:0", seed=1)
     model.joint_q.reshape(NENV, -1)[:, 2] -= 0.24  # feet on the ground: the standing regime the bench measures
     model.body_q, model.body_qd = nt.articulation.eval_fk_numpy(model, model.joint_q, model.joint_qd)
 s0, s1 = model.state(), model.state()
