@@ -2324,16 +2324,20 @@ NT_DI void hy_voxel(int j, int& x, int& y, int& z) {
 }
 constexpr int HY_STAGE_WAVES = 4;  // waves per workgroup of the wave-per-unit stages (independent: no workgroup barrier)
 constexpr int HY_ROUND = 64;       // iso voxels per marching-cubes round = per chunk of face records
+constexpr int HY_ITEMS = 8;                 // (pair, block) items of one pair a wave walks together (level 4: eight lanes per item)
+constexpr int HY_VOX_CAP = 768;             // iso voxels of a batch held in LDS (>= 512: a batch of one item always fits)
+constexpr int HY_FACE_CAP = 5 * HY_ROUND;   // candidate faces of a round
 struct HyWaveFaces {
-    unsigned char l2[64];
-    unsigned short vox[512];
-    float es[8 * HY_ROUND], eo[8 * HY_ROUND];  // corner samples of the round's voxels: [voxel][corner]
-    // face-per-lane rounds (see hydro_stage_faces_kernel): the round's candidate faces as (voxel lane << 3 | face), what the face lanes
-    // report to their voxel's lane, and what the voxel lanes answer
-    unsigned short face_list[64];
-    int fkeep[64];
-    float fdepth[64], fscore[64];
-    int vbefore[64], vbefore_sel[64], vsel[64];
+    int ox[HY_ITEMS], oy[HY_ITEMS], oz[HY_ITEMS];  // first voxel of every item's block
+    unsigned char l4[64];                          // surviving level-4 nodes, traversal order: item << 3 | child
+    unsigned short l2[64 * HY_ITEMS];              // surviving level-2 nodes: item << 6 | child of 4 << 3 | child of 2
+    unsigned short vox[HY_VOX_CAP];                // iso voxels: item << 9 | (child of 4, child of 2, voxel)
+    float es[8 * HY_ROUND], eo[8 * HY_ROUND];      // corner samples of the round's voxels: [voxel][corner]
+    // the round's candidate faces (voxel lane << 3 | face), what the face lanes report to their voxel's lane, what the voxel lanes answer
+    unsigned short face_list[HY_FACE_CAP];
+    unsigned char fkeep[HY_FACE_CAP];
+    float fdepth[HY_FACE_CAP], fscore[HY_FACE_CAP];
+    int vfirst[64], vbefore[64], vbefore_sel[64], vsel[64];
 };
 #ifdef NT_HYDRO_FACES_WAVES  // measurement builds: cap the registers for this many waves per SIMD
 #define NT_HYDRO_FACES_OCC __attribute__((amdgpu_waves_per_eu(NT_HYDRO_FACES_WAVES, NT_HYDRO_FACES_WAVES)))
@@ -2442,14 +2446,21 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) hydro_stage_blocks_kernel
     }
 }
 
-// One wave per (pair, block) item.  (Measured alternative, profiles/r04e_*: four blocks per wave on 16-lane groups -- better lane
-// utilisation, but 121 instead of 90 ms per collide at C5's size: the lanes of a wave then sample four distant SDF regions at once
-// and the texel requests of one instruction stop sharing cache lines.  The stage is bound by texel requests, not by lanes.)
+// One wave per BATCH of up to HY_ITEMS consecutive (pair, block) items of one pair (round 6).  The item-per-wave form of rounds 4-5
+// walked every item as its own chain -- level 4 on 8 lanes, level 2, level 1, the corner samples of ~11 iso voxels, their ~2 faces each
+// -- six to ten dependent sample round trips deep on a fifth of the lanes, at the two waves per SIMD the registers leave
+// (profiles/r06Q..r06U: 66.8 ms per collide at C5's size; octree 13.4, corner samples + cases 14.6, faces 38.8 -> 23 with a lane per face).
+// A batch shares the pair's descriptors (scalar registers) and its lanes sample neighbouring blocks of the same two SDFs, so every
+// level is ONE dense list over the batch: level 4 on 8 lanes per item, the children of the survivors dealt 64 at a time, the iso voxels of
+// all items compacted in (item, traversal) order, marching cubes 64 voxels per round whatever item they belong to, a lane per candidate
+// face.  A round's faces are one chunk of the face buffer (one atomic; voxel ranks and contact ids inside a record are relative to
+// the chunk); the batch's chunks are one run of stage_chunk (one atomic) booked on its first item -- the reduce stage lists a pair's
+// chunks item by item, so the faces keep the order of the single kernel: (block, child of 4, child of 2, voxel, face).
+// (The alternative measured in round 4, profiles/r04e_*: four blocks per wave on fixed 16-lane groups, 121 instead of 90 ms.)
 constexpr int HY_MC_EDGE_BYTES = 2 * 2460;  // marching-cubes case tables: 820 triangles x 3 vertices x (corner, corner), newton_amd.mc_tables
 __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_stage_faces_kernel(nt_hydro_args a_) {
     __shared__ HyWaveFaces W[HY_STAGE_WAVES];
-    // the case tables in LDS (round 6): every face of every voxel fetches six table bytes behind the case's range -- dependent GLOBAL loads
-    // (cache hits, but hundreds of cycles each) on a stage that holds two waves per SIMD; 6 KB of LDS per workgroup
+    // the case tables in LDS: every face fetches six table bytes behind its case's range -- dependent GLOBAL loads otherwise
     __shared__ int s_tri[257];
     __shared__ unsigned char s_edge[HY_MC_EDGE_BYTES];
     nt_hydro_args a = a_;
@@ -2470,56 +2481,89 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
     n_items = n_items < a.stage_queue_capacity ? n_items : a.stage_queue_capacity;
     const bool prune = (a.reduce & 2) != 0;
     // a wave takes a CONTIGUOUS run of items: a pair's blocks are consecutive in the queue, so the pair's descriptors (three dependent
-    // memory round trips + the relative transform) are fetched once per pair, not once per block
+    // memory round trips + the relative transform) are fetched once per pair and run, and a batch is the next items of the same pair
     const int total_waves = gridDim.x * HY_STAGE_WAVES;
     const int per_wave = (n_items + total_waves - 1) / total_waves;
     const int q_begin = (blockIdx.x * HY_STAGE_WAVES + wave) * per_wave;
     const int q_end = q_begin + per_wave < n_items ? q_begin + per_wave : n_items;
     HydroPair p;
     int loaded_pair = -1;
-    for (int q = q_begin; q < q_end; ++q) {
-        const int pair_idx = hy_uniform(a.stage_queue[2 * (size_t)q]), b = hy_uniform(a.stage_queue[2 * (size_t)q + 1]);
+    int q = q_begin;
+    while (q < q_end) {
+        // ---- the batch: items q .. q + nI - 1 (same pair), their block origins
+        int my_pair = -1, my_block = 0;
+        if (lane < HY_ITEMS && q + lane < q_end) {
+            my_pair = a.stage_queue[2 * (size_t)(q + lane)];
+            my_block = a.stage_queue[2 * (size_t)(q + lane) + 1];
+        }
+        const int pair_idx = hy_uniform(__shfl(my_pair, 0));
         if (pair_idx != loaded_pair) {  // (uniform)
             bool collide;
             hydro_pair_load(a, pair_idx, p, false, collide);
             loaded_pair = pair_idx;
         }
-        const int nbx = p.B.cx, nby = p.B.cy, sgs = p.B.subgrid_size;
-        const int bz = b / (nbx * nby), rem = b - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
-        const int x0 = bx * sgs, y0 = by * sgs, z0 = bz * sgs;
-        // ---- levels 4 and 2 as ballot masks
-        bool s4 = false;
-        if (lane < 8) {
-            int cx, cy, cz;
-            hy_child(lane, cx, cy, cz);
-            s4 = hydro_node_survives(p, x0 + 4 * cx, y0 + 4 * cy, z0 + 4 * cz, 4);
+        const unsigned long long same = __ballot(my_pair == pair_idx);  // (bit 0 is set)
+        int nI = hy_uniform(__builtin_ctzll(~same));
+        const int q0 = q;
+        {
+            const int nbx = p.B.cx, nby = p.B.cy, sgs = p.B.subgrid_size;
+            if (lane < nI) {
+                const int bz = my_block / (nbx * nby), rem = my_block - bz * nbx * nby, by = rem / nbx, bx = rem - by * nbx;
+                w.ox[lane] = bx * sgs; w.oy[lane] = by * sgs; w.oz[lane] = bz * sgs;
+            }
         }
-        const unsigned long long m4 = __ballot(s4);
-        bool s2 = false;
-        if ((m4 >> (lane >> 3)) & 1ull) {
-            int ax, ay, az, bx_, by_, bz_;
-            hy_child(lane >> 3, ax, ay, az);
-            hy_child(lane & 7, bx_, by_, bz_);
-            s2 = hydro_node_survives(p, x0 + 4 * ax + 2 * bx_, y0 + 4 * ay + 2 * by_, z0 + 4 * az + 2 * bz_, 2);
-        }
-        const unsigned long long m2 = __ballot(s2);
-        const int n2 = __popcll(m2);
-        if (s2) w.l2[__popcll(m2 & lt)] = (unsigned char)lane;
         HY_WAVE_SYNC();
+        // ---- levels 4 and 2: the batch's surviving nodes as dense lists.  The voxel list bounds the batch: when the level-2 survivors
+        // could leave more iso voxels than it holds, the batch is halved and walked again (one item always fits)
+        int n2 = 0;
+        for (;;) {
+            bool s4 = false;
+            if ((lane >> 3) < nI) {
+                int cx, cy, cz;
+                hy_child(lane & 7, cx, cy, cz);
+                s4 = hydro_node_survives(p, w.ox[lane >> 3] + 4 * cx, w.oy[lane >> 3] + 4 * cy, w.oz[lane >> 3] + 4 * cz, 4);
+            }
+            const unsigned long long m4 = __ballot(s4);
+            const int n4 = __popcll(m4);
+            if (s4) w.l4[__popcll(m4 & lt)] = (unsigned char)lane;
+            HY_WAVE_SYNC();
+            n2 = 0;
+            for (int t0 = 0; t0 < 8 * n4; t0 += 64) {
+                const int t = t0 + lane;
+                bool s2 = false;
+                int code = 0;
+                if (t < 8 * n4) {
+                    const int e = (int)w.l4[t >> 3], it = e >> 3;
+                    int ax, ay, az, bx_, by_, bz_;
+                    hy_child(e & 7, ax, ay, az);
+                    hy_child(t & 7, bx_, by_, bz_);
+                    s2 = hydro_node_survives(p, w.ox[it] + 4 * ax + 2 * bx_, w.oy[it] + 4 * ay + 2 * by_, w.oz[it] + 4 * az + 2 * bz_, 2);
+                    code = (e << 3) | (t & 7);
+                }
+                const unsigned long long m2 = __ballot(s2);
+                if (s2) w.l2[n2 + __popcll(m2 & lt)] = (unsigned short)code;
+                n2 += __popcll(m2);
+            }
+            HY_WAVE_SYNC();
+            if (8 * n2 <= HY_VOX_CAP || nI == 1) break;
+            nI = nI >> 1;
+        }
+        q = q0 + nI;
         // ---- level 1: the eight children of every surviving level-2 node, 64 tests per round, survivors in traversal order
         int n_vox = 0;
         for (int i0 = 0; i0 < 8 * n2; i0 += 64) {
             const int i = i0 + lane;
             bool s1 = false;
-            int j = 0;
+            int code = 0;
             if (i < 8 * n2) {
-                j = (int)w.l2[i >> 3] * 8 + (i & 7);
+                const int e2 = (int)w.l2[i >> 3], it = e2 >> 6, j = ((e2 & 63) << 3) | (i & 7);
                 int vx, vy, vz;
                 hy_voxel(j, vx, vy, vz);
-                s1 = hydro_node_survives(p, x0 + vx, y0 + vy, z0 + vz, 1);
+                s1 = hydro_node_survives(p, w.ox[it] + vx, w.oy[it] + vy, w.oz[it] + vz, 1);
+                code = (it << 9) | j;
             }
             const unsigned long long m1 = __ballot(s1);
-            if (s1) w.vox[n_vox + __popcll(m1 & lt)] = (unsigned short)j;
+            if (s1) w.vox[n_vox + __popcll(m1 & lt)] = (unsigned short)code;
             n_vox += __popcll(m1);
         }
         HY_WAVE_SYNC();
@@ -2530,173 +2574,106 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
         int chunk0 = 0;
         if (nb > 0) {
             int base = 0;
+#ifdef NT_HYDRO_FAKE_ALLOC  // measurement builds only: no shared counters (regions overlap: results are meaningless)
+            base = (int)(((long long)q0 * 2) % (a.stage_chunk_capacity - 16));
+#else
             if (lane == 0) base = atomicAdd(a.stage_count + 1, nb);
+#endif
             chunk0 = hy_uniform(__shfl(base, 0));
         }
         const bool chunks_ok = chunk0 + nb <= a.stage_chunk_capacity;
-        if (lane == 0) {
-            if (!chunks_ok) atomicAdd(a.stage_count + 2, 1);
-            a.stage_item[2 * (size_t)q] = chunk0;
-            a.stage_item[2 * (size_t)q + 1] = chunks_ok ? nb : 0;
+        if (lane == 0 && !chunks_ok) atomicAdd(a.stage_count + 2, 1);
+        if (lane < nI) {  // the batch's chunks are booked on its first item
+            a.stage_item[2 * (size_t)(q0 + lane)] = chunk0;
+            a.stage_item[2 * (size_t)(q0 + lane) + 1] = (lane == 0 && chunks_ok) ? nb : 0;
         }
         if (!chunks_ok) continue;
-        // ---- marching cubes, HY_ROUND voxels per round = one chunk of face records.
-        // (a) the corner samples: one lane per (voxel, corner) -- a block of a pile carries about a dozen iso voxels, so a lane per
-        //     voxel would sample on a fifth of the wave, eight dependent samples deep; the values go through LDS;
-        // (b) one lane per voxel: the case, then two passes over its (<= 5) faces -- count / rank, then write -- instead of
-        //     holding five face records per lane.
+        // ---- marching cubes, HY_ROUND voxels per round = one chunk of face records:
+        // (a) the corner samples, one lane per (voxel, corner), through LDS;
+        // (b) one lane per voxel: the case and its candidate faces (<= 5);
+        // (c) one lane per candidate face, 64 per sub-round: the face lanes report (kept, depth, score) to their voxel's lane, which
+        //     runs the reference's selection loop over them in face order and answers with the voxel's offsets; the face lanes write.
+        //     The faces of the first sub-round stay in registers, the later ones (a round with more than 64 candidates) are evaluated
+        //     again for the write.
         for (int k = 0; k < nb; ++k) {
             const int v0 = k * HY_ROUND;
             const int nv = (n_vox - v0) < HY_ROUND ? (n_vox - v0) : HY_ROUND;
             for (int t0 = 0; t0 < 8 * nv; t0 += 64) {
                 const int t = t0 + lane;
                 if (t < 8 * nv) {
+                    const int code = (int)w.vox[v0 + (t >> 3)], it = code >> 9;
                     int vx, vy, vz;
-                    hy_voxel((int)w.vox[v0 + (t >> 3)], vx, vy, vz);
+                    hy_voxel(code & 511, vx, vy, vz);
                     float es, eo;
-                    hydro_corner_sample(p, x0 + vx, y0 + vy, z0 + vz, t & 7, es, eo);
+                    hydro_corner_sample(p, w.ox[it] + vx, w.oy[it] + vy, w.oz[it] + vz, t & 7, es, eo);
                     w.es[t] = es;
                     w.eo[t] = eo;
                 }
             }
             HY_WAVE_SYNC();
             const bool mine = lane < nv;
-            HydroCorners cn;
-            cn.nfaces = 0;
-            int vx = 0, vy = 0, vz = 0;
+            int nfv = 0;
             if (mine) {
-                hy_voxel((int)w.vox[v0 + lane], vx, vy, vz);
-                vx += x0; vy += y0; vz += z0;
+                HydroCorners cn;
                 float es8[8], eo8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { es8[i] = w.es[8 * lane + i]; eo8[i] = w.eo[8 * lane + i]; }
                 hydro_voxel_classify(a, p, es8, eo8, cn);
+                nfv = cn.nfaces;
             }
 #ifdef NT_HYDRO_SKIP_FACES  // measurement builds only: corner samples + classification, no faces (results are meaningless)
-            cn.nfaces = 0;
+            nfv = 0;
 #endif
-            // ---- face-per-lane round (round 6).  A block of a pile carries ~11 iso voxels with ~2 faces each: one lane per VOXEL walking
-            // its <= 5 faces twice (rank, then write) kept 17 % of the lanes busy for ten serial face evaluations -- 38 of the stage's 66 ms
-            // (profiles/r06T_*).  When the round's candidate faces fit the wave (nearly always) every face gets its own lane and is
-            // evaluated ONCE: the face lanes report (kept, depth, score) to their voxel's lane, which runs the reference's selection loop
-            // over them in face order and answers with the voxel's offsets; ids, order and records are those of the two-pass form below.
-            {
-                const int nfv = mine ? cn.nfaces : 0;
-                int fx = nfv;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int y = __shfl_up(fx, d);
-                    if (lane >= d) fx += y;
-                }
-                const int F = hy_uniform(__shfl(fx, 63)), fb = fx - nfv;
-                if (F <= 64) {
-                    for (int fi = 0; fi < nfv; ++fi) w.face_list[fb + fi] = (unsigned short)((lane << 3) | fi);
-                    HY_WAVE_SYNC();
-                    // face lanes
-                    const bool is_face = lane < F;
-                    HydroFace fc;
-                    bool ok = false;
-                    int fv_ = 0, ffi = 0;
-                    if (is_face) {
-                        const int code = (int)w.face_list[lane];
-                        fv_ = code >> 3; ffi = code & 7;
-                        int ux, uy, uz;
-                        hy_voxel((int)w.vox[v0 + fv_], ux, uy, uz);
-                        float es8[8], eo8[8];
+            int fx = nfv;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(fx, d);
+                if (lane >= d) fx += y;
+            }
+            const int F = hy_uniform(__shfl(fx, 63)), fb = fx - nfv;
+            for (int fi = 0; fi < nfv; ++fi) w.face_list[fb + fi] = (unsigned short)((lane << 3) | fi);
+            w.vfirst[lane] = fb;
+            HY_WAVE_SYNC();
+            // face lanes, first visit: evaluate, report
+            auto face_of = [&](int fidx, HydroFace& fc) {
+                const int code = (int)w.face_list[fidx];
+                const int fv_ = code >> 3, ffi = code & 7;
+                const int vcode = (int)w.vox[v0 + fv_], it = vcode >> 9;
+                int ux, uy, uz;
+                hy_voxel(vcode & 511, ux, uy, uz);
+                float es8[8], eo8[8];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) { es8[i] = w.es[8 * fv_ + i]; eo8[i] = w.eo[8 * fv_ + i]; }
-                        HydroCorners fcn;
-                        hydro_voxel_classify(a, p, es8, eo8, fcn);
-                        ok = hydro_voxel_face(a, p, ux + x0, uy + y0, uz + z0, fcn, ffi, fc);
-                        w.fkeep[lane] = ok ? 1 : 0;
-                        w.fdepth[lane] = ok ? fc.depth : 0.0f;
-                        w.fscore[lane] = ok ? fc.area * fc.pressure : 0.0f;
-                    }
-                    const unsigned long long keepmask = __ballot(ok);
-                    HY_WAVE_SYNC();
-                    // voxel lanes: the selection loop of the two-pass form over the reported faces
-                    int kept = 0, sel0 = -1, sel1 = -1, sel2 = -1;
-                    float sc0 = 0.0f, sc1 = 0.0f, best_np = 1.0e10f;
-                    for (int fi = 0; fi < nfv; ++fi) {
-                        if (!w.fkeep[fb + fi]) continue;
-                        if (prune) {
-                            const float depth = w.fdepth[fb + fi];
-                            if (depth < 0.0f) {
-                                const float score = w.fscore[fb + fi];
-                                if (sel0 < 0 || score > sc0) { sel1 = sel0; sc1 = sc0; sel0 = kept; sc0 = score; }
-                                else if (sel1 < 0 || score > sc1) { sel1 = kept; sc1 = score; }
-                            } else if (depth < best_np) {
-                                best_np = depth;
-                                sel2 = kept;
-                            }
-                        }
-                        kept += 1;
-                    }
-                    const int nsel = prune ? (sel0 >= 0) + (sel1 >= 0) + (sel2 >= 0) : kept;
-                    int x = kept, xs = nsel;  // inclusive scans over the wave
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const int y = __shfl_up(x, d), ys = __shfl_up(xs, d);
-                        if (lane >= d) { x += y; xs += ys; }
-                    }
-                    const int total = hy_uniform(__shfl(x, 63)), sel_total = hy_uniform(__shfl(xs, 63));
-                    w.vbefore[lane] = x - kept;
-                    w.vbefore_sel[lane] = xs - nsel;
-                    w.vsel[lane] = ((sel0 + 1) & 15) | (((sel1 + 1) & 15) << 4) | (((sel2 + 1) & 15) << 8);
-                    int base = 0;
-                    if (lane == 0 && total > 0) base = atomicAdd(a.face_count, total);
-                    base = hy_uniform(__shfl(base, 0));
-                    const bool fits = base + total <= a.face_capacity;
-                    if (lane == 0) {
-                        int* c = a.stage_chunk + 4 * (size_t)(chunk0 + k);
-                        c[0] = base;
-                        c[1] = fits ? total : -total;  // negative: the faces did not fit the buffer (counted, not stored)
-                        c[2] = sel_total;
-                        c[3] = nv;
-                    }
-                    HY_WAVE_SYNC();
-                    if (fits && ok) {
-                        const int first = lane - ffi;  // the voxel's first face lane
-                        const unsigned long long mine_mask = ((1ull << ffi) - 1ull) << first;
-                        const int ord = __popcll(keepmask & mine_mask);
-                        const int vs_ = w.vsel[fv_], s0 = (vs_ & 15) - 1, s1 = ((vs_ >> 4) & 15) - 1, s2 = ((vs_ >> 8) & 15) - 1;
-                        int cid = 0;  // contact id, relative to the chunk (the reduce stage adds what came before in the pair)
-                        if (!prune) cid = w.vbefore[fv_] + ord + 1;
-                        else {
-                            const int bs = w.vbefore_sel[fv_];
-                            int rank = 0;
-                            if (s0 == ord) cid = bs + rank + 1;
-                            rank += s0 >= 0 ? 1 : 0;
-                            if (s1 == ord) cid = bs + rank + 1;
-                            rank += s1 >= 0 ? 1 : 0;
-                            if (s2 == ord) cid = bs + rank + 1;
-                        }
-                        float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + w.vbefore[fv_] + ord);
-                        o[0] = fc.pos.x; o[1] = fc.pos.y; o[2] = fc.pos.z;
-                        o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
-                        o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
-                        int* oi = reinterpret_cast<int*>(o);
-                        oi[9] = fv_ * 5 + ffi;  // voxel rank inside the CHUNK (rebased by the reduce stage)
-                        oi[10] = (cid << 5) | red_get_slot(fc.normal);
-                        oi[11] = 0;
-                    }
-                    HY_WAVE_SYNC();  // (the next round overwrites the corner samples and the lists)
-                    continue;
+                for (int i = 0; i < 8; ++i) { es8[i] = w.es[8 * fv_ + i]; eo8[i] = w.eo[8 * fv_ + i]; }
+                HydroCorners fcn;
+                hydro_voxel_classify(a, p, es8, eo8, fcn);
+                return hydro_voxel_face(a, p, ux + w.ox[it], uy + w.oy[it], uz + w.oz[it], fcn, ffi, fc);
+            };
+            HydroFace fc0;
+            for (int f0 = 0; f0 < F; f0 += 64) {
+                const int fidx = f0 + lane;
+                if (fidx < F) {
+                    HydroFace fc;
+                    const bool ok = face_of(fidx, fc);
+                    w.fkeep[fidx] = ok ? 1 : 0;
+                    w.fdepth[fidx] = ok ? fc.depth : 0.0f;
+                    w.fscore[fidx] = ok ? fc.area * fc.pressure : 0.0f;
+                    if (f0 == 0) fc0 = fc;
                 }
             }
-            // ---- two-pass form (rounds with more than 64 candidate faces)
-            // pass 1: which faces stay, and (pre_prune) the two strongest penetrating faces + the closest non-penetrating one
-            int keep_mask = 0, kept = 0, sel0 = -1, sel1 = -1, sel2 = -1;
+            HY_WAVE_SYNC();
+            // voxel lanes: which faces stay, and (pre_prune) the two strongest penetrating faces + the closest non-penetrating one
+            // (sdf_hydroelastic.py:2156-2312; indices are ordinals among the kept faces)
+            int kept = 0, sel0 = -1, sel1 = -1, sel2 = -1;
             float sc0 = 0.0f, sc1 = 0.0f, best_np = 1.0e10f;
-            for (int fi = 0; fi < cn.nfaces; ++fi) {
-                HydroFace fc;
-                if (!hydro_voxel_face(a, p, vx, vy, vz, cn, fi, fc)) continue;
-                keep_mask |= 1 << fi;
-                if (prune) {  // (sdf_hydroelastic.py:2156-2312; indices are ordinals among the kept faces)
-                    if (fc.depth < 0.0f) {
-                        const float score = fc.area * fc.pressure;
+            for (int fi = 0; fi < nfv; ++fi) {
+                if (!w.fkeep[fb + fi]) continue;
+                if (prune) {
+                    const float depth = w.fdepth[fb + fi];
+                    if (depth < 0.0f) {
+                        const float score = w.fscore[fb + fi];
                         if (sel0 < 0 || score > sc0) { sel1 = sel0; sc1 = sc0; sel0 = kept; sc0 = score; }
                         else if (sel1 < 0 || score > sc1) { sel1 = kept; sc1 = score; }
-                    } else if (fc.depth < best_np) {
-                        best_np = fc.depth;
+                    } else if (depth < best_np) {
+                        best_np = depth;
                         sel2 = kept;
                     }
                 }
@@ -2709,9 +2686,15 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
                 if (lane >= d) { x += y; xs += ys; }
             }
             const int total = hy_uniform(__shfl(x, 63)), sel_total = hy_uniform(__shfl(xs, 63));
-            const int before = x - kept, before_sel = xs - nsel;
+            w.vbefore[lane] = x - kept;
+            w.vbefore_sel[lane] = xs - nsel;
+            w.vsel[lane] = ((sel0 + 1) & 15) | (((sel1 + 1) & 15) << 4) | (((sel2 + 1) & 15) << 8);
             int base = 0;
+#ifdef NT_HYDRO_FAKE_ALLOC
+            base = (int)(((long long)(q0 + k) * 64) % (a.face_capacity - 512));
+#else
             if (lane == 0 && total > 0) base = atomicAdd(a.face_count, total);
+#endif
             base = hy_uniform(__shfl(base, 0));
             const bool fits = base + total <= a.face_capacity;
             if (lane == 0) {
@@ -2721,39 +2704,43 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
                 c[2] = sel_total;
                 c[3] = nv;
             }
-            HY_WAVE_SYNC();  // (the next round overwrites the corner samples)
-            if (!fits || kept == 0) continue;
-#ifdef NT_HYDRO_SKIP_PASS2  // measurement builds only: no second face pass, no face records
-            continue;
-#endif
-            // pass 2: the kept faces again, straight into their records
-            int ord = 0;
-            for (int fi = 0; fi < cn.nfaces; ++fi) {
-                if (!((keep_mask >> fi) & 1)) continue;
-                HydroFace fc;
-                hydro_voxel_face(a, p, vx, vy, vz, cn, fi, fc);
-                int cid = 0;  // contact id, relative to the chunk (the reduce stage adds what came before in the pair)
-                if (!prune) cid = before + ord + 1;
-                else {
-                    int rank = 0;
-                    if (sel0 == ord) cid = before_sel + rank + 1;
-                    rank += sel0 >= 0 ? 1 : 0;
-                    if (sel1 == ord) cid = before_sel + rank + 1;
-                    rank += sel1 >= 0 ? 1 : 0;
-                    if (sel2 == ord) cid = before_sel + rank + 1;
+            HY_WAVE_SYNC();
+            // face lanes, second visit: the kept faces into their records
+            if (fits) {
+                for (int f0 = 0; f0 < F; f0 += 64) {
+                    const int fidx = f0 + lane;
+                    if (fidx >= F || !w.fkeep[fidx]) continue;
+                    HydroFace fc = fc0;
+                    if (f0 != 0) face_of(fidx, fc);
+                    const int code = (int)w.face_list[fidx];
+                    const int fv_ = code >> 3, ffi = code & 7, first = w.vfirst[fv_];
+                    int ord = 0;
+                    for (int g = 0; g < ffi; ++g) ord += (int)w.fkeep[first + g];
+                    const int vs_ = w.vsel[fv_], s0 = (vs_ & 15) - 1, s1 = ((vs_ >> 4) & 15) - 1, s2 = ((vs_ >> 8) & 15) - 1;
+                    int cid = 0;  // contact id, relative to the chunk (the reduce stage adds what came before in the pair)
+                    if (!prune) cid = w.vbefore[fv_] + ord + 1;
+                    else {
+                        const int bs = w.vbefore_sel[fv_];
+                        int rank = 0;
+                        if (s0 == ord) cid = bs + rank + 1;
+                        rank += s0 >= 0 ? 1 : 0;
+                        if (s1 == ord) cid = bs + rank + 1;
+                        rank += s1 >= 0 ? 1 : 0;
+                        if (s2 == ord) cid = bs + rank + 1;
+                    }
+                    float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + w.vbefore[fv_] + ord);
+                    o[0] = fc.pos.x; o[1] = fc.pos.y; o[2] = fc.pos.z;
+                    o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
+                    o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
+                    int* oi = reinterpret_cast<int*>(o);
+                    oi[9] = fv_ * 5 + ffi;  // voxel rank inside the CHUNK (rebased by the reduce stage)
+                    oi[10] = (cid << 5) | red_get_slot(fc.normal);
+                    oi[11] = 0;
                 }
-                float* o = a.face_rec + HYDRO_FACE_WORDS * (size_t)(base + before + ord);
-                o[0] = fc.pos.x; o[1] = fc.pos.y; o[2] = fc.pos.z;
-                o[3] = fc.normal.x; o[4] = fc.normal.y; o[5] = fc.normal.z;
-                o[6] = fc.depth; o[7] = fc.area; o[8] = fc.pressure;
-                int* oi = reinterpret_cast<int*>(o);
-                oi[9] = lane * 5 + fi;  // voxel rank inside the CHUNK (rebased by the reduce stage)
-                oi[10] = (cid << 5) | red_get_slot(fc.normal);
-                oi[11] = 0;
-                ord += 1;
             }
+            HY_WAVE_SYNC();  // (the next round overwrites the corner samples and the lists)
         }
-        HY_WAVE_SYNC();  // the next item reuses the wave's LDS lists
+        HY_WAVE_SYNC();  // the next batch reuses the wave's LDS lists
     }
 }
 
