@@ -50,6 +50,52 @@ typedef struct {
 #define NT_PAIR_KIND_MESH_PLANE 2      /* nt_sdf_scene.template_kind / world_pair_kind: 0 mesh-SDF edges, 1 hydroelastic */
 nt_status nt_mesh_plane_pairs(const nt_mesh_plane_args* args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * The triangle leg: a MESH that does not take the SDF route against a convex primitive (sphere, capsule, ellipsoid, cylinder, box,
+ * cone).  Reference interface replaced (paths relative to /root/reference/newton/_src/geometry):
+ *   pair routing        narrow_phase.py:633-638    `shape_pairs_mesh`: a mesh against a non-mesh shape that took no earlier route
+ *   midphase            narrow_phase.py:1455-1568 narrow_phase_find_mesh_triangle_overlaps_kernel -> collision_core.py:996-1180
+ *                                                 (query AABB from the convex shape's support function in the unscaled mesh frame,
+ *                                                 widened by (margin + gap) / |scale|; mesh BVH query; front-face test)
+ *   contact generation  contact_reduction_global.py:2299-2403 mesh_triangle_contacts_to_reducer_kernel (reduce_contacts=True) and
+ *                                                 narrow_phase.py:1571-1665 (reduce_contacts=False): world-space triangle, back-face
+ *                                                 culling, GJK / MPR + manifold with GeoTypeEx.TRIANGLE as shape A,
+ *                                                 sort_sub_key = (((triangle << 1) | 1) << 3) | manifold index
+ *   reduction           contact_reduction_global.py:2059-2096, :1246-1346, :2098-2290 (the buffered variant, as nt_mesh_plane_pairs)
+ * The BVH is replaced by a scan over the mesh's triangles (same candidate set: every triangle whose float32 bounds touch the query
+ * box).  Output = ContactData rows like nt_mesh_plane_pairs: one contiguous block per pair, rows in ascending sort_sub_key order;
+ * under `reduce` they are the reducer's survivors BEFORE the writer's gap test (nt_sdf_rows_finalize / nt_contact_rows_write apply
+ * it, with the effective radii of `out_radius`), without it every generated contact.
+ * --------------------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t* pairs;                    /* as nt_mesh_plane_args.pairs; rewritten in place as (mesh, convex) for the pairs processed */
+    int32_t pair_count;
+    const int32_t* pair_world_prefix;  /* [worlds + 1] or NULL for a plain list */
+    int32_t worlds, pairs_per_world;
+    const uint8_t* pair_kind;          /* [pairs] or NULL: when given only pairs of kind NT_PAIR_KIND_MESH_TRIANGLE are processed */
+    const int32_t* shape_type;         /* [S] GeoType (MESH = 8; the partner: SPHERE 3, CAPSULE 4, ELLIPSOID 5, CYLINDER 6, BOX 7, CONE 9) */
+    const float* shape_transform;      /* [S][7] world transforms */
+    const float* shape_data;           /* [S][4] scale xyz, margin */
+    const float* shape_gap;            /* [S] */
+    const int32_t* shape_vertex_range; /* [S][2] (first vertex, vertex count) of a mesh shape in `vertices` */
+    const int32_t* shape_triangle_range; /* [S][2] (first triangle, triangle count < 2^18) of a mesh shape in `indices` */
+    const float* vertices;             /* [V][3] mesh-local, unscaled (wp.Mesh.points) */
+    const int32_t* indices;            /* [T][3] vertex ids relative to the shape's first vertex (wp.Mesh.indices) */
+    const float* shape_aabb_lower;     /* [S][3] Model.shape_collision_aabb_lower / _upper (reduce: the mesh's scaled local AABB) */
+    const float* shape_aabb_upper;
+    const int32_t* shape_voxel_res;    /* [S][3] Model.shape_voxel_resolution (reduce) */
+    int32_t reduce;                    /* 1: the global contact reduction (CollisionPipeline default); 0: every generated contact */
+    int32_t* out_count;                /* [1] rows appended so far (the caller sets the start; keeps counting past capacity) */
+    int32_t* out_pair;                 /* [capacity] pair position of the row */
+    int32_t* out_key;                  /* [capacity] sort_sub_key of the contact */
+    float* out_data;                   /* [capacity][9] centre, normal mesh -> convex, distance, margin mesh, margin convex */
+    float* out_radius;                 /* [capacity][2] or NULL: effective radii (0, sphere / capsule radius) of the export */
+    int32_t capacity;
+    int32_t* out_blk;                  /* [pairs][2] (first row, row count) of the pair's block; written for every processed pair */
+} nt_mesh_triangle_args;
+#define NT_PAIR_KIND_MESH_TRIANGLE 3
+nt_status nt_mesh_triangle_pairs(const nt_mesh_triangle_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,17 @@ class nt_mesh_plane_args(C.Structure):
                 ("out_data", C.c_void_p), ("capacity", C.c_int32), ("out_blk", C.c_void_p)]
 
 
+class nt_mesh_triangle_args(C.Structure):
+    """include/newton_hip_mesh.h: MESH vs convex primitive (triangle leg)."""
+    _fields_ = [("pairs", C.c_void_p), ("pair_count", C.c_int32), ("pair_world_prefix", C.c_void_p), ("worlds", C.c_int32),
+                ("pairs_per_world", C.c_int32), ("pair_kind", C.c_void_p), ("shape_type", C.c_void_p), ("shape_transform", C.c_void_p),
+                ("shape_data", C.c_void_p), ("shape_gap", C.c_void_p), ("shape_vertex_range", C.c_void_p),
+                ("shape_triangle_range", C.c_void_p), ("vertices", C.c_void_p), ("indices", C.c_void_p),
+                ("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
+                ("reduce", C.c_int32), ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p),
+                ("out_data", C.c_void_p), ("out_radius", C.c_void_p), ("capacity", C.c_int32), ("out_blk", C.c_void_p)]
+
+
 class nt_sdf(C.Structure):
     _fields_ = [("coarse", C.c_void_p), ("subgrid", C.c_void_p), ("slots", C.c_void_p), ("cx", C.c_int32), ("cy", C.c_int32),
                 ("cz", C.c_int32), ("tex_size", C.c_int32), ("subgrid_size", C.c_int32), ("quantization", C.c_int32),
@@ -334,6 +345,7 @@ SYMBOLS = {
     "nt_broadphase_explicit": (C.c_int32, [C.POINTER(nt_broadphase_in), _P, C.c_int32, _P, _P, C.c_int32, _P]),
     # include/newton_hip_mesh.h
     "nt_mesh_plane_pairs": (C.c_int32, [C.POINTER(nt_mesh_plane_args), _P]),
+    "nt_mesh_triangle_pairs": (C.c_int32, [C.POINTER(nt_mesh_triangle_args), _P]),
     # include/newton_hip_broadphase.h
     "nt_broadphase_nxn_swept": (C.c_int32, [C.POINTER(nt_broadphase_in), C.POINTER(nt_broadphase_motion), _P, _P, C.c_int32, C.c_int32,
                                             C.c_int32, _P, _P, C.c_int32, _P]),

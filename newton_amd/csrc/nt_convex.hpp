@@ -19,6 +19,13 @@ namespace nt {
 #define NT_HULL_BATCH 8  // hull vertices fetched per round of the CONVEX_MESH support scan (support_map)
 #endif
 NT_DI int imin(int a, int b) { return a < b ? a : b; }
+// The mesh-triangle leg (nt_mesh_triangle.hip) defines NT_CONVEX_WITH_TRIANGLES = 1 before including this header: GeoTypeEx.TRIANGLE
+// as shape A (support map, Minkowski seed, is_discrete_shape) and contacts buffered without the writer's gap test
+// (write_contact_to_reducer).  Every other translation unit compiles the branches away.
+#ifndef NT_CONVEX_WITH_TRIANGLES
+#define NT_CONVEX_WITH_TRIANGLES 0
+#endif
+constexpr int GEO_TRIANGLE = 1000;  // support_function.py:58: vertex A at the origin, B - A in `scale`, C - A in `aux`
 
 struct Geom {
     int type;
@@ -26,6 +33,9 @@ struct Geom {
     const float* points;  // CONVEX_MESH: vertex slice [count][3] (unscaled, env-uniform, global memory)
     int count;
     vec3 center;          // interior point that seeds MPR / GJK (collision_core.py:690, narrow_phase.py:1102-1105)
+#if NT_CONVEX_WITH_TRIANGLES
+    vec3 aux;             // TRIANGLE: C - A (GenericShapeData.auxiliary)
+#endif
     NT_DI Geom() : type(0), points(nullptr), count(0) {}
 };
 struct vec2 {
@@ -211,8 +221,117 @@ vec3 support_map_rest(int type, vec3 scale, vec3 direction) {
     return result;
 }
 
+#if NT_CONVEX_WITH_TRIANGLES
+// support_function.py:174-191: the vertex furthest along the direction; ties prefer a, then b
+NT_DEV vec3 support_map_triangle(const Geom& g, vec3 direction) {
+    const vec3 tri_a(0.0f), tri_b = g.scale, tri_c = g.aux;
+    const float dot_a = dot(tri_a, direction), dot_b = dot(tri_b, direction), dot_c = dot(tri_c, direction);
+    if (dot_a >= dot_b && dot_a >= dot_c) return tri_a;
+    if (dot_b >= dot_c) return tri_b;
+    return tri_c;
+}
+// support_function.py:647-745
+NT_DEV vec3 closest_point_on_triangle(vec3 p, vec3 tri_a, vec3 tri_b, vec3 tri_c) {
+    const vec3 ab = tri_b - tri_a, ac = tri_c - tri_a;
+    const float ab_sq = dot(ab, ab), ac_sq = dot(ac, ac);
+    const float EPS2 = 1.0e-20f;
+    const vec3 triangle_normal = cross(ab, ac);
+    if (dot(triangle_normal, triangle_normal) < EPS2) {
+        const vec3 bc = tri_c - tri_b;
+        const float bc_sq = dot(bc, bc);
+        if (ab_sq >= ac_sq && ab_sq >= bc_sq) {
+            if (ab_sq < EPS2) return tri_a;
+            const float t = clampf(dot(p - tri_a, ab) / ab_sq, 0.0f, 1.0f);
+            return tri_a + t * ab;
+        } else if (ac_sq >= bc_sq) {
+            const float t = clampf(dot(p - tri_a, ac) / ac_sq, 0.0f, 1.0f);
+            return tri_a + t * ac;
+        } else {
+            const float t = clampf(dot(p - tri_b, bc) / bc_sq, 0.0f, 1.0f);
+            return tri_b + t * bc;
+        }
+    }
+    const vec3 ap = p - tri_a;
+    const float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0.0f && d2 <= 0.0f) return tri_a;
+    const vec3 bp = p - tri_b;
+    const float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0.0f && d4 <= d3) return tri_b;
+    const vec3 cp = p - tri_c;
+    const float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0.0f && d5 <= d6) return tri_c;
+    const float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+        const float v = d1 / (d1 - d3);
+        return tri_a + v * ab;
+    }
+    const float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+        const float w = d2 / (d2 - d6);
+        return tri_a + w * ac;
+    }
+    const float va = d3 * d6 - d5 * d4;
+    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        return tri_b + w * (tri_c - tri_b);
+    }
+    const float denom = 1.0f / (va + vb + vc);
+    const float v = vb * denom, w = vc * denom;
+    return tri_a + v * ab + w * ac;
+}
+// support_function.py:467-502: a triangle's Minkowski seed is the point of the triangle nearest B's centre, nudged to the centroid
+NT_DEV vec3 adjust_minkowski_center(const Geom& ga, vec3 center_b_world, vec3 center_b_to_a) {
+    if (ga.type != GEO_TRIANGLE) return center_b_to_a;
+    const vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
+    const vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
+    const float face_normal_length_sq = length_sq(face_normal);
+    vec3 projection = closest_point_on_triangle(center_b_world, tri_a, tri_b, tri_c);
+    if (face_normal_length_sq < 1.0e-20f) return projection - center_b_world;
+    const vec3 face_normal_unit = face_normal / sqrtf(face_normal_length_sq);
+    const float signed_plane_distance = dot(center_b_world - tri_a, face_normal_unit);
+    const vec3 plane_projection = center_b_world - signed_plane_distance * face_normal_unit;
+    const bool inside_face = dot(cross(tri_b - tri_a, plane_projection - tri_a), face_normal) >= 0.0f &&
+                             dot(cross(tri_c - tri_b, plane_projection - tri_b), face_normal) >= 0.0f &&
+                             dot(cross(tri_a - tri_c, plane_projection - tri_c), face_normal) >= 0.0f;
+    if (inside_face) {
+        projection = plane_projection;
+        center_b_to_a = -signed_plane_distance * face_normal_unit;
+    } else {
+        center_b_to_a = projection - center_b_world;
+    }
+    vec3 to_centroid = (tri_a + tri_b + tri_c) / 3.0f - projection;
+    to_centroid = to_centroid - dot(to_centroid, face_normal_unit) * face_normal_unit;
+    const float distance_to_centroid = length(to_centroid);
+    if (distance_to_centroid > 1.0e-12f) {
+        const float nudge_distance = 0.01f * fminw(distance_to_centroid, fabsf(signed_plane_distance));
+        center_b_to_a = center_b_to_a + to_centroid * (nudge_distance / distance_to_centroid);
+    }
+    return center_b_to_a;
+}
+// support_function.py:505-538
+NT_DEV vec3 minkowski_center_fallback(const Geom& ga, vec3 center_b_world) {
+    if (ga.type != GEO_TRIANGLE) return vec3(0.0f);
+    const vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
+    vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
+    const float face_normal_length_sq = length_sq(face_normal);
+    if (face_normal_length_sq < 1.0e-20f) return vec3(0.0f);
+    face_normal = face_normal / sqrtf(face_normal_length_sq);
+    const vec3 projection = closest_point_on_triangle(center_b_world, tri_a, tri_b, tri_c);
+    vec3 to_centroid = (tri_a + tri_b + tri_c) / 3.0f - projection;
+    to_centroid = to_centroid - dot(to_centroid, face_normal) * face_normal;
+    const float to_centroid_length_sq = length_sq(to_centroid);
+    vec3 fallback_direction = -face_normal;
+    if (dot(center_b_world - projection, face_normal) < 0.0f) fallback_direction = face_normal;
+    if (to_centroid_length_sq > 1.0e-20f) fallback_direction = fallback_direction + 0.01f * to_centroid / sqrtf(to_centroid_length_sq);
+    return normalize(fallback_direction) * 1.0e-5f;
+}
+#endif
+
 // support_function.py:131-350
 NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
+#if NT_CONVEX_WITH_TRIANGLES
+    if (g.type == GEO_TRIANGLE) return support_map_triangle(g, direction);
+#endif
     if (g.type == GEO_PLANE) return support_map_plane(g.scale, direction);
     if (g.type == GEO_CONVEX_MESH) return support_map_hull(g.points, g.count, g.scale, direction);
     if (g.type == GEO_BOX) return support_map_box(g, direction);
@@ -265,9 +384,15 @@ NT_DEV bool solve_mpr_core(const Geom& ga, const Geom& gb, quat orientation_b, v
     Vert v0;  // create_shape_center_function(use_precomputed_center=True) (support_function.py:541-598)
     v0.B = position_b + quat_rotate(orientation_b, gb.center);
     v0.BtoA = ga.center - v0.B;
+#if NT_CONVEX_WITH_TRIANGLES
+    v0.BtoA = adjust_minkowski_center(ga, v0.B, v0.BtoA);
+#endif
     normal = v0.BtoA;
     if (length_sq(normal) < NUMERIC_EPSILON) {
         v0.BtoA = vec3(0.0f);  // fallback() is zero for non-triangle shapes
+#if NT_CONVEX_WITH_TRIANGLES
+        v0.BtoA = minkowski_center_fallback(ga, v0.B);
+#endif
         if (length_sq(v0.BtoA) < NUMERIC_EPSILON) {
             float best_dot = -1.0e30f;
             vec3 best_dir(1.0f, 0.0f, 0.0f);
@@ -548,6 +673,9 @@ NT_DEV bool solve_closest_distance_core(const Geom& ga, const Geom& gb, quat ori
     unsigned usage = 0;
     int iter_count = MAX_ITER;
     vec3 v = ga.center - (position_b + quat_rotate(orientation_b, gb.center));  // center.BtoA
+#if NT_CONVEX_WITH_TRIANGLES
+    v = adjust_minkowski_center(ga, position_b + quat_rotate(orientation_b, gb.center), v);
+#endif
     float dist_sq = length_sq(v);
     vec3 last_search_dir(1.0f, 0.0f, 0.0f);
     while (iter_count > 0) {
@@ -953,6 +1081,9 @@ struct PairCtx {
     float radius_eff_a, radius_eff_b, margin_a, margin_b, contact_gap;
     ConvexContacts* out;
     PolyRef poly;  // LDS scratch for the manifold clipper
+#if NT_CONVEX_WITH_TRIANGLES
+    bool raw;      // write_contact_to_reducer: every generated contact is kept, no gap test (contact_reduction_global.py:2059-2096)
+#endif
 };
 
 // collision_core.py:173-278
@@ -968,7 +1099,8 @@ NT_DEV ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a,
         c.distance = c.distance - P.radius_eff_b;
     }
     // is_discrete_shape (collision_core.py:39-48): shapes with flat polygon faces
-    bool is_discrete_a = type_a == GEO_BOX || type_a == GEO_CONVEX_MESH || type_a == GEO_PLANE;
+    bool is_discrete_a = type_a == GEO_BOX || type_a == GEO_CONVEX_MESH || type_a == GEO_PLANE ||
+                         (NT_CONVEX_WITH_TRIANGLES && type_a == GEO_TRIANGLE);
     bool is_discrete_b = type_b == GEO_BOX || type_b == GEO_CONVEX_MESH || type_b == GEO_PLANE;
     bool is_axial_a = type_a == GEO_CYLINDER || type_a == GEO_CONE;
     bool is_axial_b = type_b == GEO_CYLINDER || type_b == GEO_CONE;
@@ -1023,6 +1155,9 @@ NT_DEV void emit(PairCtx& P, ContactOut c, vec3 pos_a, quat rot_a, vec3 pos_b, q
     vec3 b_world = c.center + n * (0.5f * c.distance + P.radius_eff_b);
     float distance = dot(b_world - a_world, n);
     float d = distance - total_separation_needed;
+#if NT_CONVEX_WITH_TRIANGLES
+    if (!P.raw)
+#endif
     if (d > P.contact_gap) return;
     ConvexContacts& o = *P.out;
     o.normal = c.normal;
@@ -1193,5 +1328,65 @@ NT_DI void convex_pair(const Geom& geom_a, const Geom& geom_b, xform Xa, const x
     }
     build_manifold(P, orientation_a, position_a, rel_q, rel_p, point_a, point_b, normal);
 }
+
+#if NT_CONVEX_WITH_TRIANGLES
+// mesh_triangle_contacts_to_reducer_kernel's call of compute_gjk_mpr_contacts (contact_reduction_global.py:2385-2403): shape A is a
+// world-space triangle (v0 at pos_a, identity rotation), shape B a convex primitive; contacts come back in emission order, UNFILTERED
+// (their index is the low three bits of the fingerprint).  Post-processing as post_process_triangle_contact: the TRIANGLE_PRISM edit
+// does not apply, the axial projection does (a triangle is a discrete shape).
+NT_DI void triangle_pair(vec3 edge_ab, vec3 edge_ac, vec3 pos_a, const Geom& geom_b, const xform& Xb, float margin_a, float margin_b,
+                         float rigid_gap, PolyRef poly, ConvexContacts& out) {
+    out.count = 0;
+    PairCtx P;
+    P.out = &out;
+    P.poly = poly;
+    P.raw = true;
+    P.ga.type = GEO_TRIANGLE;
+    P.ga.scale = edge_ab;
+    P.ga.aux = edge_ac;
+    P.ga.center = vec3(0.0f);
+    P.gb = geom_b;
+    P.margin_a = margin_a; P.margin_b = margin_b;
+    P.contact_gap = rigid_gap;
+    const int type_b = P.gb.type;
+    P.radius_eff_a = 0.0f;
+    P.radius_eff_b = 0.0f;
+    const float small_radius = 0.0001f;
+    if (type_b == GEO_SPHERE || type_b == GEO_CAPSULE) {
+        P.radius_eff_b = P.gb.scale.x;
+        P.gb.scale.x = small_radius;
+    }
+    const float contact_threshold = rigid_gap + P.radius_eff_a + P.radius_eff_b + margin_a + margin_b;
+    const bool skip_multi_contact = type_b == GEO_SPHERE || type_b == GEO_ELLIPSOID;
+    const quat orientation_a(0.0f, 0.0f, 0.0f, 1.0f), orientation_b = Xb.q;
+    const vec3 position_a = pos_a, position_b = Xb.p;
+    const quat rel_q = quat_inverse(orientation_a) * orientation_b;
+    const vec3 rel_p = quat_rotate_inv(orientation_a, position_b - position_a);
+    const float margin_sum = margin_a + margin_b;
+    const float eps = 1.0e-4f;
+    const float enlarge = margin_sum <= 0.0f ? eps : (margin_sum < eps ? 2.0f * eps : 0.0f);
+    vec3 point_a, point_b, normal;
+    float penetration, signed_distance;
+    const bool collision = solve_mpr_core(P.ga, P.gb, rel_q, rel_p, enlarge, point_a, point_b, normal, penetration);
+    if (collision) {
+        signed_distance = -penetration + enlarge;
+        const float half_enlarge = enlarge * 0.5f;
+        point_a = point_a - normal * half_enlarge;
+        point_b = point_b + normal * half_enlarge;
+    } else {
+        solve_closest_distance_core(P.ga, P.gb, rel_q, rel_p, 0.0f, point_a, point_b, normal, signed_distance);
+    }
+    if (skip_multi_contact || signed_distance > contact_threshold) {
+        ContactOut c;
+        const vec3 point = 0.5f * (point_a + point_b);
+        c.center = quat_rotate(orientation_a, point) + position_a;
+        c.normal = quat_rotate(orientation_a, normal);
+        c.distance = signed_distance;
+        emit(P, c, position_a, orientation_a, position_b, orientation_b);
+        return;
+    }
+    build_manifold(P, orientation_a, position_a, rel_q, rel_p, point_a, point_b, normal);
+}
+#endif
 
 }  // namespace nt

@@ -1,0 +1,358 @@
+// nt_mesh_triangle.hip -- MESH (no SDF route) vs convex primitive for gfx950: the triangle leg of CollisionPipeline.collide
+// (include/newton_hip_mesh.h).
+//
+// Reference behaviour (paths under /root/reference/newton/_src/geometry):
+//   routing      narrow_phase.py:633-638        a MESH against a non-mesh shape that took none of the earlier routes -> shape_pairs_mesh
+//   midphase     narrow_phase.py:1455-1568, collision_core.py:996-1180   the convex shape's support-function AABB in the mesh frame
+//                (compute_tight_aabb_from_support :452-548), unscaled (aabb_to_unscaled :924-956), widened by (margin + gap) / |scale|,
+//                mesh query, front-face test against the convex shape's origin -> (mesh, convex, triangle) triples
+//   contacts     contact_reduction_global.py:2299-2403 (reduce_contacts=True) / narrow_phase.py:1571-1665: the triangle in world space
+//                (collision_core.py:1218-1276; mirror parity swaps two vertices), back-face culling, GJK / MPR + manifold
+//                (compute_gjk_mpr_contacts with the TRIANGLE support map, support_function.py:174-191, and the triangle's Minkowski
+//                seed :467-538), fingerprint = (((triangle << 1) | 1) << 3) | manifold index
+//   reduction    contact_reduction_global.py:2059-2096 (write_contact_to_reducer: every contact is buffered, no gap test),
+//                :1246-1346 (reduce_contact_in_hashtable, beta = 1e-4), :2098-2290 (export: roundoff twins, every contact once)
+//
+// MI355X design.  The reference runs four launches over device-wide buffers (midphase -> triangle list, contacts -> contact buffer,
+// hashtable registration, export).  Here one workgroup owns a pair.  Its 256 lanes scan the mesh's triangles 256 at a time -- 36 B
+// of indices + vertices per triangle, shared by every world of a replicated scene (L2 hits after the first world); Warp's BVH is
+// replaced by that scan: a tree walk is a dependent-load chain per lane, the scan is a coalesced stream, and the set it returns is
+// the set the BVH query returns (every triangle whose bounds touch the query box).  Survivors are ballot-compacted into an LDS list
+// in ascending triangle order; once 256 are waiting (or the scan ends) every lane takes one triangle through MPR / GJK and the
+// manifold (nt_convex.hpp, the code of the convex tiles) and offers its contacts to the pair's 245-slot reduction table in LDS
+// (ds_max_u64, nt_contact_reduce.hpp).  The <= 245 winners recompute their record from (triangle, manifold index) -- same
+// instructions, same bits -- so there is no contact buffer, no hashtable and no atomics on shared counters except one row
+// allocation per pair.  Rows leave as one contiguous block per pair in ascending fingerprint order (what deterministic=True sorts
+// into).  reduce = 0: every generated contact is a row (counted in a first pass, written in a second).
+// Bound: the dependent MPR / GJK iterations of the survivors (one lane per triangle), not the scan.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/newton_hip.h"
+#include "../../include/newton_hip_mesh.h"
+// This unit compiles its OWN variant of nt_convex.hpp (triangle support, unfiltered contacts).  On the device every translation unit
+// is its own code object; the host build of the emulator (tests/emu) links all units into one library, where the plain __device__
+// functions of the header would collide with the stepping units' copies -- so this unit's math + convex code lives in namespace nt_tri.
+#define NT_CONVEX_WITH_TRIANGLES 1
+#define nt nt_tri
+#include "nt_math.hpp"
+#include "nt_convex.hpp"
+
+using namespace nt;
+
+namespace {
+
+#include "nt_contact_reduce.hpp"
+
+constexpr float RED_BETA = 0.0001f;  // contact_reduction_global.py:89 BETA_THRESHOLD
+constexpr int MT_THREADS = 256;
+constexpr int MT_LIST = 2 * MT_THREADS;  // candidate triangles waiting for a batch
+
+NT_DI xform ld_xform(const float* p) { return xform(vec3(p[0], p[1], p[2]), quat(p[3], p[4], p[5], p[6])); }
+NT_DI vec3 ld_vec3(const float* p) { return vec3(p[0], p[1], p[2]); }
+
+NT_DI int mt_live_pairs(const nt_mesh_triangle_args& a) { return a.pair_world_prefix ? a.pair_world_prefix[a.worlds] : a.pair_count; }
+NT_DI int mt_pair_slot(const nt_mesh_triangle_args& a, int f) {  // flat live index -> position w * pairs_per_world + k
+    if (!a.pair_world_prefix) return f;
+    int lo = 0, hi = a.worlds;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.pair_world_prefix[mid] <= f) lo = mid;
+        else hi = mid;
+    }
+    return lo * a.pairs_per_world + (f - a.pair_world_prefix[lo]);
+}
+
+struct PairSetup {  // what every triangle of the pair shares
+    xform X_mesh, X_convex;
+    vec3 mesh_scale, q_lo, q_hi, center_in_bvh;
+    Geom gb;  // the convex shape as extract_shape_data hands it over
+    float margin_mesh, margin_convex, gap_sum, radius_b;
+    int mesh, convex, v0, t0, nt_;
+    bool mirrored;
+};
+
+NT_DI void pair_setup(const nt_mesh_triangle_args& a, int s0, int s1, PairSetup& c) {
+    const bool mesh_first = a.shape_type[s0] == GEO_MESH;
+    c.mesh = mesh_first ? s0 : s1;
+    c.convex = mesh_first ? s1 : s0;
+    c.X_mesh = ld_xform(a.shape_transform + 7 * (size_t)c.mesh);
+    c.X_convex = ld_xform(a.shape_transform + 7 * (size_t)c.convex);
+    const float* dm = a.shape_data + 4 * (size_t)c.mesh;
+    const float* dc = a.shape_data + 4 * (size_t)c.convex;
+    c.mesh_scale = vec3(dm[0], dm[1], dm[2]);
+    c.margin_mesh = dm[3];
+    c.margin_convex = dc[3];
+    c.gap_sum = a.shape_gap[c.convex] + a.shape_gap[c.mesh];
+    const float contact_threshold = c.gap_sum + c.margin_convex + c.margin_mesh;
+    c.gb = Geom();
+    c.gb.type = a.shape_type[c.convex];
+    c.gb.scale = vec3(dc[0], dc[1], dc[2]);
+    c.gb.center = vec3(0.0f);
+    c.gb.aux = vec3(0.0f);
+    c.radius_b = (c.gb.type == GEO_SPHERE || c.gb.type == GEO_CAPSULE) ? dc[0] : 0.0f;  // compute_effective_radius of the export
+    // _compute_mesh_vs_convex_query_aabb (collision_core.py:996-1040)
+    const xform X_mesh_shape = xform_inverse(c.X_mesh) * c.X_convex;
+    const vec3 pos_in_mesh = X_mesh_shape.p;
+    const mat33 rt = transpose(quat_to_matrix(X_mesh_shape.q));
+    const vec3 local_x(rt.m00, rt.m10, rt.m20), local_y(rt.m01, rt.m11, rt.m21), local_z(rt.m02, rt.m12, rt.m22);
+    const float max_x = dot(local_x, support_map(c.gb, local_x));
+    const float max_y = dot(local_y, support_map(c.gb, local_y));
+    const float max_z = dot(local_z, support_map(c.gb, local_z));
+    const float min_x = dot(local_x, support_map(c.gb, -local_x));
+    const float min_y = dot(local_y, support_map(c.gb, -local_y));
+    const float min_z = dot(local_z, support_map(c.gb, -local_z));
+    const vec3 aabb_lower = vec3(min_x, min_y, min_z) + pos_in_mesh, aabb_upper = vec3(max_x, max_y, max_z) + pos_in_mesh;
+    const float eps = 1.0e-12f;
+    auto guarded = [&](float s) { return fabsf(s) > eps ? s : (s >= 0.0f ? eps : -eps); };
+    const vec3 inv_scale(1.0f / guarded(c.mesh_scale.x), 1.0f / guarded(c.mesh_scale.y), 1.0f / guarded(c.mesh_scale.z));
+    const vec3 l0 = cw_mul(aabb_lower, inv_scale), l1 = cw_mul(aabb_upper, inv_scale);
+    const vec3 margin_vec(contact_threshold / fmaxw(fabsf(c.mesh_scale.x), 1.0e-12f), contact_threshold / fmaxw(fabsf(c.mesh_scale.y), 1.0e-12f),
+                          contact_threshold / fmaxw(fabsf(c.mesh_scale.z), 1.0e-12f));
+    c.q_lo = vmin(l0, l1) - margin_vec;
+    c.q_hi = vmax(l0, l1) + margin_vec;
+    c.center_in_bvh = cw_mul(pos_in_mesh, inv_scale);
+    c.v0 = a.shape_vertex_range[2 * (size_t)c.mesh];
+    c.t0 = a.shape_triangle_range[2 * (size_t)c.mesh];
+    c.nt_ = a.shape_triangle_range[2 * (size_t)c.mesh + 1];
+    c.mirrored = c.mesh_scale.x * c.mesh_scale.y * c.mesh_scale.z < 0.0f;
+}
+
+// the midphase's verdict on triangle ti: its bounds touch the query box and it faces the convex shape's origin
+NT_DI bool triangle_candidate(const nt_mesh_triangle_args& a, const PairSetup& c, int ti) {
+    const int* idx = a.indices + 3 * (size_t)(c.t0 + ti);
+    const vec3 v0 = ld_vec3(a.vertices + 3 * (size_t)(c.v0 + idx[0])), v1 = ld_vec3(a.vertices + 3 * (size_t)(c.v0 + idx[1])),
+               v2 = ld_vec3(a.vertices + 3 * (size_t)(c.v0 + idx[2]));
+    const vec3 tlo = vmin(v0, vmin(v1, v2)), thi = vmax(v0, vmax(v1, v2));
+    if (tlo.x > c.q_hi.x || tlo.y > c.q_hi.y || tlo.z > c.q_hi.z || thi.x < c.q_lo.x || thi.y < c.q_lo.y || thi.z < c.q_lo.z) return false;
+    const vec3 face_normal = cross(v1 - v0, v2 - v0);  // _mesh_triangle_is_front_facing_local: unscaled frame, stored winding
+    return !(dot(face_normal, c.center_in_bvh - v0) < 0.0f);
+}
+
+// the contacts of triangle ti (emission order, unfiltered); false: culled as a back face in world space
+NT_DI bool triangle_contacts(const nt_mesh_triangle_args& a, const PairSetup& c, int ti, PolyRef poly, ConvexContacts& out) {
+    const int* idx = a.indices + 3 * (size_t)(c.t0 + ti);
+    const int i0 = idx[0], i1 = c.mirrored ? idx[2] : idx[1], i2 = c.mirrored ? idx[1] : idx[2];
+    // get_triangle_shape_from_mesh (collision_core.py:1218-1276)
+    const vec3 v0_world = xform_point(c.X_mesh, cw_mul(ld_vec3(a.vertices + 3 * (size_t)(c.v0 + i0)), c.mesh_scale));
+    const vec3 v1_world = xform_point(c.X_mesh, cw_mul(ld_vec3(a.vertices + 3 * (size_t)(c.v0 + i1)), c.mesh_scale));
+    const vec3 v2_world = xform_point(c.X_mesh, cw_mul(ld_vec3(a.vertices + 3 * (size_t)(c.v0 + i2)), c.mesh_scale));
+    const vec3 ab = v1_world - v0_world, ac = v2_world - v0_world;
+    out.count = 0;
+    // back-face culling (contact_reduction_global.py:2368-2375)
+    if (dot(cross(ab, ac), c.X_convex.p - v0_world) < 0.0f) return false;
+    triangle_pair(ab, ac, v0_world, c.gb, c.X_convex, c.margin_mesh, c.margin_convex, c.gap_sum, poly, out);
+    return true;
+}
+
+// reduce_contact_in_hashtable for one buffered contact (position, octahedral-coded normal, depth) of the pair
+NT_DI void red_offer_buffered(unsigned long long* tbl, vec3 normal_decoded, vec3 position, float depth, const xform& X_a_inv,
+                              const float* lo, const float* hi, const int* res, int fp) {
+    const int b = red_get_slot(normal_decoded);
+    vec3 u, v;
+    red_face_frame(b, u, v);
+    const float px = dot(position, u), py = dot(position, v);
+    const vec3 diag(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    if (depth < RED_BETA * length(diag)) {
+        for (int d = 0; d < RED_DIRS; ++d) {
+            const float score = px * RED_DIR[d][0] + py * RED_DIR[d][1];
+            atomicMax(&tbl[b * RED_VALUES + d], red_value_depth(score, fp));
+        }
+    }
+    const unsigned long long dv = red_value_depth(-depth, fp);
+    atomicMax(&tbl[b * RED_VALUES + RED_DIRS], dv);
+    int vox = red_voxel_index(xform_point(X_a_inv, position), lo, hi, res);
+    vox = vox < 0 ? 0 : (vox > RED_VOXELS - 1 ? RED_VOXELS - 1 : vox);
+    atomicMax(&tbl[(RED_BINS + vox / RED_VALUES) * RED_VALUES + vox % RED_VALUES], dv);
+}
+
+NT_DI void write_row(const nt_mesh_triangle_args& a, const PairSetup& c, int slot, int pair_idx, int fp, vec3 centre, vec3 normal, float dist) {
+    a.out_pair[slot] = pair_idx;
+    a.out_key[slot] = fp;
+    float* o = a.out_data + 9 * (size_t)slot;
+    o[0] = centre.x; o[1] = centre.y; o[2] = centre.z;
+    o[3] = normal.x; o[4] = normal.y; o[5] = normal.z;
+    o[6] = dist;
+    o[7] = c.margin_mesh;
+    o[8] = c.margin_convex;
+    if (a.out_radius) {
+        a.out_radius[2 * (size_t)slot] = 0.0f;
+        a.out_radius[2 * (size_t)slot + 1] = c.radius_b;
+    }
+}
+
+struct MtLds {
+    RedLds red;
+    int list[MT_LIST];  // candidate triangles, ascending
+    float poly[20 * MT_THREADS];  // manifold clipper scratch: 10 x vec2 per lane, lane-strided
+    int wave_hits[MT_THREADS / 64];
+    int waiting;        // candidates in `list`
+    int rows;           // reduce = 0: contacts generated so far (pass 0: count; pass 1: rank of the next batch)
+};
+
+__global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh_triangle_args a) {
+    __shared__ MtLds S;
+    RedLds& L = S.red;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const PolyRef poly{S.poly + t, MT_THREADS};
+    const int live = mt_live_pairs(a);
+    for (int f = blockIdx.x; f < live; f += gridDim.x) {
+        const int pair_idx = mt_pair_slot(a, f);
+        if (a.pair_kind && a.pair_kind[pair_idx] != NT_PAIR_KIND_MESH_TRIANGLE) continue;  // another leg's pair (uniform)
+        const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
+        PairSetup c;
+        pair_setup(a, s0, s1, c);
+        __syncthreads();  // every lane has read the pair before it is rewritten as (mesh, convex)
+        if (t == 0) { a.pairs[2 * (size_t)pair_idx] = c.mesh; a.pairs[2 * (size_t)pair_idx + 1] = c.convex; }
+        const xform X_mesh_inv = xform_inverse(c.X_mesh);
+        const float* lo = a.shape_aabb_lower ? a.shape_aabb_lower + 3 * (size_t)c.mesh : nullptr;
+        const float* hi = a.shape_aabb_upper ? a.shape_aabb_upper + 3 * (size_t)c.mesh : nullptr;
+        const int* res = a.shape_voxel_res ? a.shape_voxel_res + 3 * (size_t)c.mesh : nullptr;
+        if (a.reduce)
+            for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
+        const int passes = a.reduce ? 1 : 2;  // reduce = 0: pass 0 counts the pair's contacts, pass 1 writes them behind its base
+        for (int pass = 0; pass < passes; ++pass) {
+            if (t == 0) { S.waiting = 0; S.rows = 0; }
+            __syncthreads();
+            for (int r0 = 0; r0 < c.nt_ || S.waiting > 0; r0 += MT_THREADS) {  // (uniform: S.waiting is read between barriers)
+                // ---- scan: the next 256 triangles against the query box, survivors appended in ascending order
+                if (r0 < c.nt_) {
+                    const int ti = r0 + t;
+                    const bool hit = ti < c.nt_ && triangle_candidate(a, c, ti);
+                    const unsigned long long m = __ballot(hit);
+                    if (lane == 0) S.wave_hits[wave] = __popcll(m);
+                    __syncthreads();
+                    int off = S.waiting;
+                    for (int k = 0; k < wave; ++k) off += S.wave_hits[k];
+                    if (hit) S.list[off + __popcll(m & ((1ull << lane) - 1ull))] = ti;
+                    __syncthreads();
+                    if (t == 0) {
+                        int n = S.waiting;
+                        for (int k = 0; k < MT_THREADS / 64; ++k) n += S.wave_hits[k];
+                        S.waiting = n;
+                    }
+                    __syncthreads();
+                }
+                const int waiting = S.waiting;
+                const bool last = r0 + MT_THREADS >= c.nt_;
+                if (waiting < MT_THREADS && !(last && waiting > 0)) continue;  // (uniform) keep scanning until a full batch waits
+                // ---- batch: one lane per waiting triangle
+                const int nb = waiting < MT_THREADS ? waiting : MT_THREADS;
+                ConvexContacts cc;
+                cc.count = 0;
+                int ti = -1;
+                if (t < nb) {
+                    ti = S.list[t];
+                    triangle_contacts(a, c, ti, poly, cc);
+                }
+                if (a.reduce) {
+                    float ox, oy;
+                    red_encode_oct(cc.normal, ox, oy);  // (the buffer holds the normal as its octahedral code)
+                    const vec3 normal_buffered = red_decode_oct(ox, oy);
+                    for (int i = 0; i < cc.count; ++i)
+                        red_offer_buffered(L.tbl, normal_buffered, cc.center(i), cc.distance(i), X_mesh_inv, lo, hi, res, (ti << 4) | 8 | i);
+                } else {
+                    // exclusive prefix of the lanes' contact counts over the workgroup, in lane (= triangle) order
+                    int x = cc.count;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int y = __shfl_up(x, d);
+                        if (lane >= d) x += y;
+                    }
+                    if (lane == 63) S.wave_hits[wave] = x;
+                    __syncthreads();
+                    int before = S.rows + x - cc.count;
+                    for (int k = 0; k < wave; ++k) before += S.wave_hits[k];
+                    if (pass == 1)
+                        for (int i = 0; i < cc.count; ++i) {
+                            const int slot = L.base + before + i;
+                            if (slot < a.capacity) write_row(a, c, slot, pair_idx, (ti << 4) | 8 | i, cc.center(i), cc.normal, cc.distance(i));
+                        }
+                    __syncthreads();
+                    if (t == 0) {
+                        int n = S.rows;
+                        for (int k = 0; k < MT_THREADS / 64; ++k) n += S.wave_hits[k];
+                        S.rows = n;
+                    }
+                }
+                __syncthreads();
+                // the triangles still waiting move to the front of the list
+                const int left = waiting - nb;
+                int moved = -1;
+                if (t < left) moved = S.list[nb + t];
+                __syncthreads();
+                if (t < left) S.list[t] = moved;
+                if (t == 0) S.waiting = left;
+                __syncthreads();
+                if (last && left == 0) break;
+            }
+            __syncthreads();
+            if (!a.reduce && pass == 0) {
+                const int counted = S.rows;
+                if (t == 0) {
+                    L.base = counted > 0 ? atomicAdd(a.out_count, counted) : 0;
+                    const int room = a.capacity - L.base;
+                    a.out_blk[2 * (size_t)pair_idx] = L.base;
+                    a.out_blk[2 * (size_t)pair_idx + 1] = counted < room ? counted : (room > 0 ? room : 0);
+                }
+                __syncthreads();
+                if (counted == 0) break;
+            }
+        }
+        if (!a.reduce) {
+            __syncthreads();
+            continue;
+        }
+        __syncthreads();
+        // ---- the winner of slot k: its record recomputed from (triangle, manifold index)
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {
+            if (L.tbl[k] == 0ull) continue;
+            const int fp = (int)(L.tbl[k] & RED_FP_MASK);
+            ConvexContacts cc;
+            triangle_contacts(a, c, fp >> 4, poly, cc);
+            const int i = fp & 7;
+            const vec3 centre = cc.center(i);
+            float ox, oy;
+            red_encode_oct(cc.normal, ox, oy);
+            L.pos[k][0] = centre.x; L.pos[k][1] = centre.y; L.pos[k][2] = centre.z; L.pos[k][3] = cc.distance(i);
+            L.oct[k][0] = ox; L.oct[k][1] = oy;
+            L.fp[k] = fp;
+        }
+        __syncthreads();
+        red_finish(L, RedLdsRec{L});
+        if (t == 0) {
+            L.base = L.total > 0 ? atomicAdd(a.out_count, L.total) : 0;
+            const int room = a.capacity - L.base;
+            a.out_blk[2 * (size_t)pair_idx] = L.base;
+            a.out_blk[2 * (size_t)pair_idx + 1] = L.total < room ? L.total : (room > 0 ? room : 0);
+        }
+        __syncthreads();
+        for (int k = t; k < RED_SLOTS; k += blockDim.x) {
+            const int slot = L.base + L.keep[k];
+            if (L.keep[k] < 0 || slot >= a.capacity) continue;
+            write_row(a, c, slot, pair_idx, L.fp[k], vec3(L.pos[k][0], L.pos[k][1], L.pos[k][2]), red_decode_oct(L.oct[k][0], L.oct[k][1]),
+                      L.pos[k][3]);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" nt_status nt_mesh_triangle_pairs(const nt_mesh_triangle_args* a, void* stream) {
+    if (!a || !a->pairs || !a->shape_type || !a->shape_transform || !a->shape_data || !a->shape_gap || !a->shape_vertex_range ||
+        !a->shape_triangle_range || !a->vertices || !a->indices || !a->out_count || !a->out_pair || !a->out_key || !a->out_data ||
+        !a->out_blk || a->capacity < 0)
+        return NT_ERR_INVALID_ARG;
+    if (a->reduce && (!a->shape_aabb_lower || !a->shape_aabb_upper || !a->shape_voxel_res)) return NT_ERR_INVALID_ARG;
+    if (a->pair_world_prefix ? (a->worlds <= 0 || a->pairs_per_world <= 0) : a->pair_count < 0) return NT_ERR_INVALID_ARG;
+    long long blocks = a->pair_world_prefix ? (long long)a->worlds * a->pairs_per_world : (long long)a->pair_count;
+    if (blocks == 0) return NT_OK;
+#ifdef NT_EMULATED_GRID
+    const long long grid_cap = NT_EMULATED_GRID;
+#else
+    const long long grid_cap = 8192;
+#endif
+    if (blocks > grid_cap) blocks = grid_cap;
+    hipLaunchKernelGGL(mesh_triangle_pairs_kernel, dim3((unsigned)blocks), dim3(MT_THREADS), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
+}

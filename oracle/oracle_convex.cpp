@@ -13,6 +13,8 @@
 // Scope: BOX, SPHERE, CAPSULE, ELLIPSOID, CYLINDER (straight), CONE; infinite-plane proxies, convex meshes and
 // triangles are not restated (pairs with them produce no contacts here).
 #include <algorithm>
+#include <initializer_list>
+#include <vector>
 
 #include "oracle_common.h"
 
@@ -24,12 +26,14 @@ using namespace orc;
 
 namespace {
 
+constexpr int GEO_TRIANGLE = 1000;  // GeoTypeEx.TRIANGLE (support_function.py:58): vertex A at the origin, B - A in scale, C - A in aux
 struct Geom {
     int type;
     vec3 scale;
     const float* points = nullptr;  // CONVEX_MESH: vertex slice [count][3] (unscaled)
     int count = 0;
     vec3 center;                    // interior point used to seed MPR / GJK (collision_core.py:690, narrow_phase.py:1102-1105)
+    vec3 aux;                       // TRIANGLE: C - A (GenericShapeData.auxiliary)
 };
 struct vec2 {
     float x, y;
@@ -63,6 +67,14 @@ vec3 support_map_box(const Geom& g, vec3 d) {
 vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
+    if (g.type == GEO_TRIANGLE) {
+        // support_function.py:174-191: the vertex furthest along the direction; ties prefer a, then b
+        vec3 tri_a(0.0f), tri_b = g.scale, tri_c = g.aux;
+        float dot_a = dot(tri_a, direction), dot_b = dot(tri_b, direction), dot_c = dot(tri_c, direction);
+        if (dot_a >= dot_b && dot_a >= dot_c) return tri_a;
+        if (dot_b >= dot_c) return tri_b;
+        return tri_c;
+    }
     if (g.type == GEO_PLANE) {
         // support_function.py:334-345: finite rectangle in XY (half-width scale.x, half-length scale.y), normal +Z
         float sx = direction[0] >= 0.0f ? 1.0f : -1.0f;
@@ -183,6 +195,102 @@ vec3 shape_support_centered(const Geom& g, vec3 direction) {
     return support_map(g, direction);
 }
 
+// support_function.py:647-745
+vec3 closest_point_on_triangle(vec3 p, vec3 tri_a, vec3 tri_b, vec3 tri_c) {
+    vec3 ab = tri_b - tri_a, ac = tri_c - tri_a;
+    float ab_sq = dot(ab, ab), ac_sq = dot(ac, ac);
+    const float EPS2 = 1.0e-20f;
+    vec3 triangle_normal = cross(ab, ac);
+    if (dot(triangle_normal, triangle_normal) < EPS2) {
+        vec3 bc = tri_c - tri_b;
+        float bc_sq = dot(bc, bc);
+        if (ab_sq >= ac_sq && ab_sq >= bc_sq) {
+            if (ab_sq < EPS2) return tri_a;
+            float t = clampf(dot(p - tri_a, ab) / ab_sq, 0.0f, 1.0f);
+            return tri_a + t * ab;
+        } else if (ac_sq >= bc_sq) {
+            float t = clampf(dot(p - tri_a, ac) / ac_sq, 0.0f, 1.0f);
+            return tri_a + t * ac;
+        } else {
+            float t = clampf(dot(p - tri_b, bc) / bc_sq, 0.0f, 1.0f);
+            return tri_b + t * bc;
+        }
+    }
+    vec3 ap = p - tri_a;
+    float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0.0f && d2 <= 0.0f) return tri_a;
+    vec3 bp = p - tri_b;
+    float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0.0f && d4 <= d3) return tri_b;
+    vec3 cp = p - tri_c;
+    float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0.0f && d5 <= d6) return tri_c;
+    float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+        float v = d1 / (d1 - d3);
+        return tri_a + v * ab;
+    }
+    float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+        float w = d2 / (d2 - d6);
+        return tri_a + w * ac;
+    }
+    float va = d3 * d6 - d5 * d4;
+    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+        float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        return tri_b + w * (tri_c - tri_b);
+    }
+    float denom = 1.0f / (va + vb + vc);
+    float v = vb * denom, w = vc * denom;
+    return tri_a + v * ab + w * ac;
+}
+// support_function.py:467-502: a triangle's Minkowski seed is the point of the triangle nearest B's centre, nudged to the centroid
+vec3 adjust_minkowski_center(const Geom& ga, vec3 center_b_world, vec3 center_b_to_a) {
+    if (ga.type != GEO_TRIANGLE) return center_b_to_a;
+    vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
+    vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
+    float face_normal_length_sq = length_sq(face_normal);
+    vec3 projection = closest_point_on_triangle(center_b_world, tri_a, tri_b, tri_c);
+    if (face_normal_length_sq < 1.0e-20f) return projection - center_b_world;
+    vec3 face_normal_unit = face_normal / std::sqrt(face_normal_length_sq);
+    float signed_plane_distance = dot(center_b_world - tri_a, face_normal_unit);
+    vec3 plane_projection = center_b_world - signed_plane_distance * face_normal_unit;
+    bool inside_face = dot(cross(tri_b - tri_a, plane_projection - tri_a), face_normal) >= 0.0f &&
+                       dot(cross(tri_c - tri_b, plane_projection - tri_b), face_normal) >= 0.0f &&
+                       dot(cross(tri_a - tri_c, plane_projection - tri_c), face_normal) >= 0.0f;
+    if (inside_face) {
+        projection = plane_projection;
+        center_b_to_a = -signed_plane_distance * face_normal_unit;
+    } else {
+        center_b_to_a = projection - center_b_world;
+    }
+    vec3 to_centroid = (tri_a + tri_b + tri_c) / 3.0f - projection;
+    to_centroid = to_centroid - dot(to_centroid, face_normal_unit) * face_normal_unit;
+    float distance_to_centroid = length(to_centroid);
+    if (distance_to_centroid > 1.0e-12f) {
+        float nudge_distance = 0.01f * fminw(distance_to_centroid, std::fabs(signed_plane_distance));
+        center_b_to_a = center_b_to_a + to_centroid * (nudge_distance / distance_to_centroid);
+    }
+    return center_b_to_a;
+}
+// support_function.py:505-538
+vec3 minkowski_center_fallback(const Geom& ga, vec3 center_b_world) {
+    if (ga.type != GEO_TRIANGLE) return vec3(0.0f);
+    vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
+    vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
+    float face_normal_length_sq = length_sq(face_normal);
+    if (face_normal_length_sq < 1.0e-20f) return vec3(0.0f);
+    face_normal = face_normal / std::sqrt(face_normal_length_sq);
+    vec3 projection = closest_point_on_triangle(center_b_world, tri_a, tri_b, tri_c);
+    vec3 to_centroid = (tri_a + tri_b + tri_c) / 3.0f - projection;
+    to_centroid = to_centroid - dot(to_centroid, face_normal) * face_normal;
+    float to_centroid_length_sq = length_sq(to_centroid);
+    vec3 fallback_direction = -face_normal;
+    if (dot(center_b_world - projection, face_normal) < 0.0f) fallback_direction = face_normal;
+    if (to_centroid_length_sq > 1.0e-20f) fallback_direction = fallback_direction + 0.01f * to_centroid / std::sqrt(to_centroid_length_sq);
+    return normalize(fallback_direction) * 1.0e-5f;
+}
+
 // mpr.py:100-160; CENTERED selects the tie-centred box support used by MPR's own support map
 template <bool CENTERED>
 Vert minkowski_support(const Geom& ga, const Geom& gb, vec3 direction, quat orientation_b, vec3 position_b, float extend) {
@@ -213,10 +321,10 @@ bool solve_mpr_core(const Geom& ga, const Geom& gb, quat orientation_b, vec3 pos
     point_b = vec3(0.0f);
     Vert v0;  // create_shape_center_function(use_precomputed_center=True) (support_function.py:541-598)
     v0.B = position_b + quat_rotate(orientation_b, gb.center);
-    v0.BtoA = ga.center - v0.B;
+    v0.BtoA = adjust_minkowski_center(ga, v0.B, ga.center - v0.B);
     normal = v0.BtoA;
     if (length_sq(normal) < NUMERIC_EPSILON) {
-        v0.BtoA = vec3(0.0f);  // fallback() is zero for non-triangle shapes
+        v0.BtoA = minkowski_center_fallback(ga, v0.B);  // zero for non-triangle shapes
         if (length_sq(v0.BtoA) < NUMERIC_EPSILON) {
             float best_dot = -1.0e30f;
             vec3 best_dir(1.0f, 0.0f, 0.0f);
@@ -482,7 +590,8 @@ bool solve_closest_distance_core(const Geom& ga, const Geom& gb, quat orientatio
     vec4f4 bary;
     uint32_t usage = 0;
     int iter_count = MAX_ITER;
-    vec3 v = ga.center - (position_b + quat_rotate(orientation_b, gb.center));  // center.BtoA
+    vec3 center_b = position_b + quat_rotate(orientation_b, gb.center);
+    vec3 v = adjust_minkowski_center(ga, center_b, ga.center - center_b);  // center.BtoA
     float dist_sq = length_sq(v);
     vec3 last_search_dir(1.0f, 0.0f, 0.0f);
     while (iter_count > 0) {
@@ -870,6 +979,10 @@ struct PairCtx {
     Geom ga, gb;  // geometry as seen by GJK/MPR (sphere/capsule radii shrunk to 1e-4)
     float radius_eff_a, radius_eff_b, margin_a, margin_b;
     int written;
+    // write_contact_to_reducer instead of write_contact (the mesh-triangle leg): every generated contact is buffered as
+    // (centre, normal, distance, fingerprint) with NO gap test; fingerprint = (sort_sub_key << 3) | emission index
+    std::vector<float>* raw = nullptr;
+    int sort_sub_key = 0;
 };
 
 // collision_core.py:173-278
@@ -884,7 +997,7 @@ ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a, quat r
         c.center = c.center - normal * (P.radius_eff_b * 0.5f);
         c.distance = c.distance - P.radius_eff_b;
     }
-    auto discrete = [](int t) { return t == GEO_BOX || t == GEO_CONVEX_MESH || t == GEO_PLANE; };
+    auto discrete = [](int t) { return t == GEO_BOX || t == GEO_CONVEX_MESH || t == GEO_PLANE || t == GEO_TRIANGLE; };
     bool is_discrete_a = discrete(type_a), is_discrete_b = discrete(type_b);
     bool is_axial_a = type_a == GEO_CYLINDER || type_a == GEO_CONE;
     bool is_axial_b = type_b == GEO_CYLINDER || type_b == GEO_CONE;
@@ -930,7 +1043,13 @@ ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a, quat r
 
 // write_contact(output_index = -1) (collide.py:206-254)
 void emit(PairCtx& P, ContactOut c, vec3 pos_a, quat rot_a, vec3 pos_b, quat rot_b) {
-    c = post_process_axial(c, P, pos_a, rot_a, pos_b, rot_b);
+    c = post_process_axial(c, P, pos_a, rot_a, pos_b, rot_b);  // (post_process_triangle_contact only edits TRIANGLE_PRISM contacts)
+    if (P.raw) {
+        const float key = (float)((P.sort_sub_key << 3) | P.written);  // (exact: keys of the test scenes stay below 2^24)
+        for (float v : {c.center.x, c.center.y, c.center.z, c.normal.x, c.normal.y, c.normal.z, c.distance, key}) P.raw->push_back(v);
+        P.written += 1;
+        return;
+    }
     float total_separation_needed = P.radius_eff_a + P.radius_eff_b + P.margin_a + P.margin_b;
     vec3 n = normalize(c.normal);
     vec3 a_world = c.center - n * (0.5f * c.distance + P.radius_eff_a);
@@ -1142,6 +1261,159 @@ int convex_pair_contacts(const o_model* m, int shape_a, int shape_b, const float
     return P.written;
 }
 }  // namespace orc
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The mesh-vs-convex leg (SURVEY.md section 8 rows a19 / a20 on triangle meshes):
+//   midphase   collision_core.py:996-1180  _compute_mesh_vs_convex_query_aabb (compute_tight_aabb_from_support :452-548 in the scaled
+//              mesh frame, aabb_to_unscaled :924-956, margin + gap per axis), the mesh query, _mesh_triangle_is_front_facing_local
+//   contacts   contact_reduction_global.py:2299-2403 mesh_triangle_contacts_to_reducer_kernel (get_triangle_shape_from_mesh
+//              collision_core.py:1218-1276, back-face culling, compute_gjk_mpr_contacts with the TRIANGLE support map and Minkowski
+//              seed) written with write_contact_to_reducer (:2059-2096)
+// Warp's BVH is native code: the query here tests every triangle's float32 bounds against the query box, ends inclusive (the set a
+// BVH walk returns; triangle order does not matter to the consumers).  CONVEX_MESH partners are not restated.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+void tight_aabb_from_support(const Geom& g, quat orientation, vec3 center_pos, vec3& lo, vec3& hi) {
+    mat33 rot_mat_t = transpose(quat_to_matrix(orientation));
+    vec3 local_x(rot_mat_t(0, 0), rot_mat_t(1, 0), rot_mat_t(2, 0)), local_y(rot_mat_t(0, 1), rot_mat_t(1, 1), rot_mat_t(2, 1)),
+        local_z(rot_mat_t(0, 2), rot_mat_t(1, 2), rot_mat_t(2, 2));
+    float max_x = dot(local_x, support_map(g, local_x));
+    float max_y = dot(local_y, support_map(g, local_y));
+    float max_z = dot(local_z, support_map(g, local_z));
+    float min_x = dot(local_x, support_map(g, -local_x));
+    float min_y = dot(local_y, support_map(g, -local_y));
+    float min_z = dot(local_z, support_map(g, -local_z));
+    lo = vec3(min_x, min_y, min_z) + center_pos;
+    hi = vec3(max_x, max_y, max_z) + center_pos;
+}
+}  // namespace
+
+// -> number of buffered contacts (rows of `out` [cap][10]: mesh shape, convex shape, fingerprint, centre[3], normal[3], distance;
+// counts past cap).  `tri_out` [tri_cap][3] receives the (mesh, convex, triangle) triples of the midphase, *n_tri their number.
+extern "C" int o_mesh_triangle_contacts(int n_pairs, const int* pairs, const int* shape_type, const float* shape_transform,
+                                        const float* shape_data, const float* shape_gap, const int* vertex_start,
+                                        const int* tri_start, const int* tri_count, const float* vertices, const int* indices,
+                                        int* tri_out, int tri_cap, int* n_tri, float* out, int cap) {
+    int nt = 0, nc = 0;
+    for (int k = 0; k < n_pairs; ++k) {
+        int shape_a = pairs[2 * k], shape_b = pairs[2 * k + 1];
+        int mesh_shape, non_mesh_shape;
+        if (shape_type[shape_a] == GEO_MESH && shape_type[shape_b] != GEO_MESH) { mesh_shape = shape_a; non_mesh_shape = shape_b; }
+        else if (shape_type[shape_b] == GEO_MESH && shape_type[shape_a] != GEO_MESH) { mesh_shape = shape_b; non_mesh_shape = shape_a; }
+        else continue;
+        if (tri_count[mesh_shape] <= 0) continue;
+        transform X_mesh_ws = ldx(shape_transform, mesh_shape), X_ws = ldx(shape_transform, non_mesh_shape);
+        float gap_sum = shape_gap[non_mesh_shape] + shape_gap[mesh_shape];
+        float margin_non_mesh = shape_data[4 * non_mesh_shape + 3], margin_mesh = shape_data[4 * mesh_shape + 3];
+        float contact_threshold = gap_sum + margin_non_mesh + margin_mesh;
+        // _compute_mesh_vs_convex_query_aabb
+        transform X_mesh_sw = transform_inverse(X_mesh_ws);
+        transform X_mesh_shape = X_mesh_sw * X_ws;
+        vec3 pos_in_mesh = X_mesh_shape.p;
+        Geom gq;
+        gq.type = shape_type[non_mesh_shape];
+        gq.scale = vec3(shape_data[4 * non_mesh_shape], shape_data[4 * non_mesh_shape + 1], shape_data[4 * non_mesh_shape + 2]);
+        vec3 aabb_lower, aabb_upper;
+        tight_aabb_from_support(gq, X_mesh_shape.q, pos_in_mesh, aabb_lower, aabb_upper);
+        vec3 mesh_scale(shape_data[4 * mesh_shape], shape_data[4 * mesh_shape + 1], shape_data[4 * mesh_shape + 2]);
+        const float eps = 1.0e-12f;
+        auto guarded = [&](float s) { return std::fabs(s) > eps ? s : (s >= 0.0f ? eps : -eps); };
+        vec3 inv_scale(1.0f / guarded(mesh_scale.x), 1.0f / guarded(mesh_scale.y), 1.0f / guarded(mesh_scale.z));
+        vec3 l0 = cw_mul(aabb_lower, inv_scale), l1 = cw_mul(aabb_upper, inv_scale);
+        vec3 q_lo = vmin(l0, l1), q_hi = vmax(l0, l1);
+        vec3 margin_vec(contact_threshold / fmaxw(std::fabs(mesh_scale.x), 1.0e-12f), contact_threshold / fmaxw(std::fabs(mesh_scale.y), 1.0e-12f),
+                        contact_threshold / fmaxw(std::fabs(mesh_scale.z), 1.0e-12f));
+        q_lo = q_lo - margin_vec;
+        q_hi = q_hi + margin_vec;
+        vec3 center_in_bvh = cw_mul(pos_in_mesh, inv_scale);
+        const float* pts = vertices + 3 * vertex_start[mesh_shape];
+        const int* idx = indices + 3 * tri_start[mesh_shape];
+        // shape B of every triangle pair (extract_shape_data)
+        Geom gb0;
+        gb0.type = gq.type;
+        gb0.scale = gq.scale;
+        float margin_offset_b = margin_non_mesh, margin_offset_a = margin_mesh;
+        for (int t = 0; t < tri_count[mesh_shape]; ++t) {
+            int idx0 = idx[3 * t], idx1 = idx[3 * t + 1], idx2 = idx[3 * t + 2];
+            vec3 v0 = ld3(pts, idx0), v1 = ld3(pts, idx1), v2 = ld3(pts, idx2);
+            vec3 tlo = vmin(v0, vmin(v1, v2)), thi = vmax(v0, vmax(v1, v2));
+            if (tlo.x > q_hi.x || tlo.y > q_hi.y || tlo.z > q_hi.z || thi.x < q_lo.x || thi.y < q_lo.y || thi.z < q_lo.z) continue;
+            // _mesh_triangle_is_front_facing_local (unscaled mesh frame, the stored winding)
+            vec3 face_normal_l = cross(v1 - v0, v2 - v0);
+            if (dot(face_normal_l, center_in_bvh - v0) < 0.0f) continue;
+            if (nt < tri_cap) { tri_out[3 * nt] = mesh_shape; tri_out[3 * nt + 1] = non_mesh_shape; tri_out[3 * nt + 2] = t; }
+            nt += 1;
+            // get_triangle_shape_from_mesh
+            if (mesh_scale.x * mesh_scale.y * mesh_scale.z < 0.0f) std::swap(idx1, idx2);
+            vec3 v0_world = transform_point(X_mesh_ws, cw_mul(ld3(pts, idx0), mesh_scale));
+            vec3 v1_world = transform_point(X_mesh_ws, cw_mul(ld3(pts, idx1), mesh_scale));
+            vec3 v2_world = transform_point(X_mesh_ws, cw_mul(ld3(pts, idx2), mesh_scale));
+            PairCtx P;
+            P.m = nullptr; P.body_q = nullptr; P.ct = nullptr; P.shape_a = mesh_shape; P.shape_b = non_mesh_shape; P.written = 0;
+            P.ga.type = GEO_TRIANGLE;
+            P.ga.scale = v1_world - v0_world;
+            P.ga.aux = v2_world - v0_world;
+            P.gb = gb0;
+            vec3 pos_a = v0_world, pos_b = X_ws.p;
+            quat quat_a = quat_identity(), quat_b = X_ws.q;
+            // back-face culling (contact_reduction_global.py:2368-2375)
+            vec3 face_normal = cross(P.ga.scale, P.ga.aux);
+            if (dot(face_normal, pos_b - pos_a) < 0.0f) continue;
+            std::vector<float> raw;
+            P.raw = &raw;
+            P.sort_sub_key = (t << 1) | 1;
+            P.margin_a = margin_offset_a;
+            P.margin_b = margin_offset_b;
+            // compute_gjk_mpr_contacts + solve_convex_multi_contact (as convex_pair_contacts above)
+            P.radius_eff_a = 0.0f;
+            P.radius_eff_b = 0.0f;
+            const float small_radius = 0.0001f;
+            if (P.gb.type == GEO_SPHERE || P.gb.type == GEO_CAPSULE) {
+                P.radius_eff_b = P.gb.scale.x;
+                P.gb.scale.x = small_radius;
+            }
+            float rigid_gap = shape_gap[mesh_shape] + shape_gap[non_mesh_shape];
+            float threshold = rigid_gap + P.radius_eff_a + P.radius_eff_b + P.margin_a + P.margin_b;
+            bool skip_multi_contact = P.gb.type == GEO_SPHERE || P.gb.type == GEO_ELLIPSOID;
+            quat rel_q = quat_inverse(quat_a) * quat_b;
+            vec3 rel_p = quat_rotate_inv(quat_a, pos_b - pos_a);
+            float margin_sum = P.margin_a + P.margin_b;
+            const float e4 = 1.0e-4f;
+            float enlarge = margin_sum <= 0.0f ? e4 : (margin_sum < e4 ? 2.0f * e4 : 0.0f);
+            vec3 point_a, point_b, normal;
+            float penetration, signed_distance;
+            bool collision = solve_mpr_core(P.ga, P.gb, rel_q, rel_p, enlarge, point_a, point_b, normal, penetration);
+            if (collision) {
+                signed_distance = -penetration + enlarge;
+                float half_enlarge = enlarge * 0.5f;
+                point_a = point_a - normal * half_enlarge;
+                point_b = point_b + normal * half_enlarge;
+            } else {
+                solve_closest_distance_core(P.ga, P.gb, rel_q, rel_p, 0.0f, point_a, point_b, normal, signed_distance);
+            }
+            if (skip_multi_contact || signed_distance > threshold) {
+                ContactOut c;
+                vec3 point = 0.5f * (point_a + point_b);
+                c.center = quat_rotate(quat_a, point) + pos_a;
+                c.normal = quat_rotate(quat_a, normal);
+                c.distance = signed_distance;
+                emit(P, c, pos_a, quat_a, pos_b, quat_b);
+            } else {
+                build_manifold(P, quat_a, pos_a, rel_q, rel_p, point_a, point_b, normal);
+            }
+            for (size_t r = 0; r + 8 <= raw.size(); r += 8) {
+                if (nc < cap) {
+                    float* o = out + 10 * (size_t)nc;
+                    o[0] = (float)mesh_shape; o[1] = (float)non_mesh_shape; o[2] = raw[r + 7];
+                    for (int j = 0; j < 7; ++j) o[3 + j] = raw[r + j];
+                }
+                nc += 1;
+            }
+        }
+    }
+    *n_tri = nt;
+    return nc;
+}
 
 // probes for the known-answer tests (reference: newton/tests/test_mpr.py, test_gjk.py)
 extern "C" int o_probe_mpr(int type_a, int type_b, const float* xf_a, const float* xf_b, const float* scale_a, const float* scale_b,

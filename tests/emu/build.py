@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libnewton_emu.so")
 FILES = ["nt_step_preamble.hpp", "nt_featherstone.hip", "nt_math.hpp", "nt_primitives.hpp", "nt_convex.hpp", "nt_layout.hpp", "nt_ctx.hpp", "nt_collide.hpp", "nt_xpbd.hpp", "nt_xpbd_kernels.hpp",
          "nt_semi_implicit.hpp", "nt_featherstone.hpp", "nt_featherstone_kernels.hpp", "nt_kernels.hip", "nt_broadphase_core.hpp", "nt_broadphase.hip", "nt_contact_reduce.hpp",
-         "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip", "nt_graph.hip", "nt_mesh_plane.hip"]
+         "nt_sdf.hip", "nt_build_id.hip", "nt_match.hip", "nt_model_build.hip", "nt_flat_contacts.hip", "nt_sdf_pipeline.hip", "nt_graph.hip", "nt_mesh_plane.hip", "nt_mesh_triangle.hip"]
 
 WAVE_SYNC = re.compile(r"#define FS_WAVE_SYNC\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
 HY_SYNC = re.compile(r"#define HY_WAVE_SYNC_HW\(\)\s*\\\n(?:.*\\\n)*.*while \(0\)")
@@ -82,7 +82,8 @@ def _build_locked(force: bool) -> str:
            *([os.path.join(OUT, "nt_graph.cpp")] if "nt_graph.hip" in files else []),
            *([os.path.join(OUT, "nt_flat_contacts.cpp")] if "nt_flat_contacts.hip" in files else []),
            *([os.path.join(OUT, "nt_sdf_pipeline.cpp")] if "nt_sdf_pipeline.hip" in files else []),
-           *([os.path.join(OUT, "nt_mesh_plane.cpp")] if "nt_mesh_plane.hip" in files else []), "-o", LIB]
+           *([os.path.join(OUT, "nt_mesh_plane.cpp")] if "nt_mesh_plane.hip" in files else []),
+           *([os.path.join(OUT, "nt_mesh_triangle.cpp")] if "nt_mesh_triangle.hip" in files else []), "-o", LIB]
     subprocess.run(cmd, check=True)
     open(stamp, "w").write(digest)
     return LIB

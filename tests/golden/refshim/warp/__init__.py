@@ -1051,6 +1051,48 @@ def mesh_get(mesh_id):
     return Mesh._registry[int(mesh_id)]
 
 
+# wp.mesh_query_aabb / the tiled form (collision_core.py:1144-1180) as ONE lane of a block of one sees them (block_dim() == 1 on
+# the CPU device).  Warp walks its BVH and tests every primitive's own float32 bounds against the query box, both ends inclusive;
+# the stand-in tests the same per-triangle bounds for every triangle in index order -- the same SET, BVH order is not reproduced
+# (the callers here are order-free: triangle pairs feed a reduction / a sort by key).
+class _MeshAabbQuery:
+    def __init__(self, mesh_id, lower, upper):
+        m = mesh_get(mesh_id)
+        pts = _np.array([[float(c) for c in x] for x in m.points], dtype=_np.float32).reshape(-1, 3)
+        idx = _np.array([int(i) for i in m.indices], dtype=_np.int64).reshape(-1, 3)
+        lo = _np.array([float(c) for c in lower], dtype=_np.float32)
+        hi = _np.array([float(c) for c in upper], dtype=_np.float32)
+        self.hits = []
+        for t, tri in enumerate(idx):
+            tl, th = pts[tri].min(axis=0), pts[tri].max(axis=0)
+            if not (_np.any(tl > hi) or _np.any(th < lo)):
+                self.hits.append(t)
+        self.cursor = 0
+
+
+def mesh_query_aabb(mesh_id, lower, upper): return _MeshAabbQuery(mesh_id, lower, upper)
+def tile_mesh_query_aabb(mesh_id, lower, upper): return _MeshAabbQuery(mesh_id, lower, upper)
+def tile_query_valid(q): return q.cursor < len(q.hits)
+
+
+def tile_mesh_query_aabb_next(q):
+    t = q.hits[q.cursor] if q.cursor < len(q.hits) else -1
+    q.cursor += 1
+    return [t]
+
+
+def untile(t): return t[0]
+def tile(x, **kw): return [x]
+
+
+def tile_scan_inclusive(t):
+    out, run = [], 0
+    for v in t:
+        run = run + v
+        out.append(run)
+    return out
+
+
 def _make_vector(length=None, dtype=None, *a, **k):
     n = length if length is not None else a[0]
     if dtype is not None and "int" in getattr(dtype, "__name__", str(dtype)):  # integer components (contact id lists)
