@@ -693,6 +693,8 @@ typedef struct {
     int32_t raw_base;            /* raw rows [0, raw_base) are the blocks the staged narrow phase placed at the start of each pair's
                                     survivor block (nt_mesh_sdf_args.hit_capacity; gaps in between), rows appended through raw_count
                                     start at raw_base (the counter is initialised to it); 0: every raw row was appended */
+    const float* raw_radius;     /* [raw_capacity][2] or NULL: effective radii (a, b) the export hands to write_contact for the rows of
+                                    pair kind 3 (nt_mesh_triangle_args.out_radius: a sphere / capsule partner); every other row: 0 */
 } nt_sdf_rows_io;
 /* final row ranges (world-major, pairs ascending, rows in fingerprint order), write_contact (collide.py:166-254) of every raw
  * row at its final position, and the per-body row-block lists.  body_q: State.body_q, env-major [7][nb][ES].

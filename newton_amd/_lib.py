@@ -86,7 +86,7 @@ class nt_sdf_rows_io(C.Structure):
                 ("shape1", C.c_void_p), ("point0", C.c_void_p), ("point1", C.c_void_p), ("offset0", C.c_void_p),
                 ("offset1", C.c_void_p), ("normal", C.c_void_p), ("margin0", C.c_void_p), ("margin1", C.c_void_p),
                 ("key", C.c_void_p), ("raw_rank", C.c_void_p), ("raw_stiffness", C.c_void_p), ("raw_friction", C.c_void_p), ("stiffness", C.c_void_p),
-                ("damping", C.c_void_p), ("friction_scale", C.c_void_p), ("raw_base", C.c_int32)]
+                ("damping", C.c_void_p), ("friction_scale", C.c_void_p), ("raw_base", C.c_int32), ("raw_radius", C.c_void_p)]
 
 
 class nt_flat_history(C.Structure):

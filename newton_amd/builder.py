@@ -630,7 +630,7 @@ class ModelBuilder:
     def add_shape_mesh(self, body, *, xform=None, mesh=None, scale=None, cfg=None, label=None) -> int:
         """Triangle-mesh collision shape (builder.py:7158-7198).  Collides with infinite planes through its vertices
         (narrow_phase.py:618-631,1744-1992) and, with an SDF attached (``mesh.build_sdf``), with other SDF shapes through the
-        mesh-SDF leg; mesh-vs-primitive pairs (triangle leg) are refused at finalize()."""
+        mesh-SDF leg; against convex primitives through its triangles (narrow_phase.py:633-638,1455-1665: the triangle leg)."""
         if mesh is None:
             raise ValueError("add_shape_mesh() requires a Mesh")
         return self.add_shape(body=body, type=GeoType.MESH, xform=xform, cfg=cfg, scale=scale, label=label, src=mesh)
@@ -967,7 +967,10 @@ class ModelBuilder:
             lo_all[i], hi_all[i] = np.minimum(lo, hi), np.maximum(lo, hi)
         # triangle meshes: wp.Mesh.points as they are (the vertex index is the contact fingerprint of the mesh-plane leg,
         # narrow_phase.py:1969), each distinct Mesh once
+        # ... and wp.Mesh.indices (vertex ids relative to the mesh's first vertex): the triangle leg scans them (mesh vs convex
+        # primitive, collision_core.py:1218-1276; the triangle index is part of the contact fingerprint)
         vuniq, vranges, vpoints = {}, np.zeros((S, 2), dtype=i32), []
+        tuniq, tranges, tindices = {}, np.zeros((S, 2), dtype=i32), []
         for i, src in enumerate(self.shape_source):
             if self.shape_type[i] != GeoType.MESH or src is None:
                 continue
@@ -975,9 +978,15 @@ class ModelBuilder:
                 v = np.asarray(src.vertices, dtype=f32).reshape(-1, 3)
                 vuniq[id(src)] = (sum(len(p) for p in vpoints), len(v))
                 vpoints.append(v)
+                tri = np.asarray(src.indices, dtype=i32).reshape(-1, 3)
+                tuniq[id(src)] = (sum(len(p) for p in tindices), len(tri))
+                tindices.append(tri)
             vranges[i] = vuniq[id(src)]
+            tranges[i] = tuniq[id(src)]
         m.mesh_vertex_range = vranges
         m.mesh_vertices = (np.concatenate(vpoints) if vpoints else np.zeros((0, 3))).astype(f32).reshape(-1, 3)
+        m.mesh_triangle_range = tranges
+        m.mesh_indices = (np.concatenate(tindices) if tindices else np.zeros((0, 3))).astype(i32).reshape(-1, 3)
         m.shape_mesh_start = np.asarray(starts, dtype=i32).reshape(S)
         m.shape_mesh_count = np.asarray(counts, dtype=i32).reshape(S)
         m.mesh_points = (np.concatenate(points) if points else np.zeros((0, 3))).astype(f32).reshape(-1, 3)

@@ -477,8 +477,10 @@ class CollisionPipeline:
             sdf_pair_shape_types_ok(model)
             self._sdf_leg = SdfLeg(model, pairs_per_shape=sdf_pairs_per_shape, contacts_per_shape=sdf_contacts_per_shape,
                                    hydro_config=sdf_hydroelastic_config, hydro_faces_per_shape=sdf_hydro_faces_per_shape,
-                                   hydro_staged=sdf_hydro_staged)
-            self._sdf_leg.mesh_plane_reduce = bool(reduce_contacts)  # (triangle mesh, plane) pairs: every admitted vertex when off
+                                   hydro_staged=sdf_hydro_staged,
+                                   # (triangle mesh, convex primitive) pairs: 245 reduction slots per pair, every generated contact when off
+                                   triangle_rows_per_pair=245 if reduce_contacts else (1 << 30))
+            self._sdf_leg.mesh_plane_reduce = bool(reduce_contacts)  # (triangle mesh, plane / primitive) pairs: every contact when off
             # edge pairs: every contact the edge search admits when off (narrow_phase.py:3044,3097-3130 launches mesh_sdf_collision_kernel
             # instead of the global-reduce kernel); size sdf_contacts_per_shape for it, an overflow is reported by the leg
             self._sdf_leg.edge_reduce = bool(reduce_contacts)

@@ -341,7 +341,7 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
         la.resize(npair); lb.resize(npair);
         // Pairs that leave the primitive / GJK-MPR path (narrow_phase.py:531-538,618-640): both shapes hydroelastic with SDFs (the
         // SDF-SDF leg when the pipeline enables it), both shapes with a texture SDF and collision edges unless box-box (mesh-SDF
-        // edge contacts), a triangle mesh against an INFINITE plane (vertex leg).  Not tile pairs: listed for the pipeline's SDF leg
+        // edge contacts), a triangle mesh against an INFINITE plane (vertex leg) or against a convex primitive (triangle leg).  Not tile pairs: listed for the pipeline's SDF leg
         // in ascending Newton (shape0, shape1) order, nt_model_sdf_pairs.
         {
             std::vector<int32_t> none_idx(NS, -1), edge_cnt(NS, 0);
@@ -356,6 +356,11 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
                 const float* sc = s.shape_scale + 3 * (size_t)newton_id0(l);
                 return shape_type[l] == GEO_PLANE && sc[0] == 0.0f && sc[1] == 0.0f;
             };
+            // a triangle mesh against a convex primitive (narrow_phase.py:633-638 `shape_pairs_mesh`): the triangle leg, pair kind 3
+            auto tri_partner = [&](int l) {
+                const int ty = shape_type[l];
+                return ty == GEO_SPHERE || ty == GEO_CAPSULE || ty == GEO_ELLIPSOID || ty == GEO_CYLINDER || ty == GEO_BOX || ty == GEO_CONE;
+            };
             struct Routed { int id0, id1, a, b, kind, edges; };
             std::vector<Routed> routed;
             std::vector<int32_t> ta, tb;
@@ -366,6 +371,7 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
                 if (hydro(a) && hydro(b)) kind = 1;
                 else if (has_sdf(a) && has_sdf(b) && !(shape_type[a] == GEO_BOX && shape_type[b] == GEO_BOX)) kind = 0;
                 else if ((infinite_plane(a) && shape_type[b] == GEO_MESH) || (infinite_plane(b) && shape_type[a] == GEO_MESH)) kind = 2;
+                else if ((shape_type[a] == GEO_MESH && tri_partner(b)) || (shape_type[b] == GEO_MESH && tri_partner(a))) kind = 3;
                 if (kind < 0) { ta.push_back(a); tb.push_back(b); tile_pos.push_back(p); continue; }
                 const int ia = newton_id0(a), ib = newton_id0(b);
                 routed.push_back(ia < ib ? Routed{ia, ib, a, b, kind, has_sdf(a) && has_sdf(b)} : Routed{ib, ia, b, a, kind, has_sdf(a) && has_sdf(b)});

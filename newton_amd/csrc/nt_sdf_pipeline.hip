@@ -164,7 +164,9 @@ NT_DI void write_row(const nt_sdf_scene& sc, const nt_sdf_rows_io& io, const flo
     const int shape_a = io.world_pairs[2 * (size_t)idx], shape_b = io.world_pairs[2 * (size_t)idx + 1];
     const float* d = io.raw_data + 9 * (size_t)i;
     const float dist = d[6], margin_a = d[7], margin_b = d[8];
-    const float ra = 0.0f, rb = 0.0f;  // SDF / mesh shapes have no effective radius (compute_effective_radius)
+    // SDF / mesh shapes have no effective radius (compute_effective_radius); the triangle leg's partner can be a sphere / capsule
+    const bool tri = io.raw_radius && sc.template_kind && sc.world_pair_kind[idx] == 3;
+    const float ra = tri ? io.raw_radius[2 * (size_t)i] : 0.0f, rb = tri ? io.raw_radius[2 * (size_t)i + 1] : 0.0f;
     const float total = ra + rb + margin_a + margin_b;
     const vec3 nab = normalize(ld3(d + 3));
     const vec3 center = ld3(d);

@@ -247,14 +247,25 @@ class EnvTemplate:
         is_mesh_plane_pair = ~is_sdf_pair & np.array([(infinite_plane(a) and tri_mesh(b)) or (infinite_plane(b) and tri_mesh(a))
                                                       for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
         is_sdf_pair = is_sdf_pair | is_mesh_plane_pair
-        sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b), bool(h), bool(mp))
-              for a, b, h, mp in zip(self.pair_a[is_sdf_pair], self.pair_b[is_sdf_pair], is_hydro_pair[is_sdf_pair],
-                                     is_mesh_plane_pair[is_sdf_pair])]
+        # a triangle mesh against a convex primitive (narrow_phase.py:633-638 `shape_pairs_mesh`, after the rules above): the triangle
+        # leg of the pipeline (csrc/nt_mesh_triangle.hip, pair kind 3) -- midphase over the mesh's triangles, GJK / MPR per triangle
+        tri_partner_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE)
+
+        def tri_partner(l):
+            return int(self.shape_type[l]) in tri_partner_types
+
+        is_mesh_tri_pair = ~is_sdf_pair & np.array([(tri_mesh(a) and tri_partner(b)) or (tri_mesh(b) and tri_partner(a))
+                                                    for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
+        is_sdf_pair = is_sdf_pair | is_mesh_tri_pair
+        sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b), bool(h), bool(mp), bool(mt))
+              for a, b, h, mp, mt in zip(self.pair_a[is_sdf_pair], self.pair_b[is_sdf_pair], is_hydro_pair[is_sdf_pair],
+                                         is_mesh_plane_pair[is_sdf_pair], is_mesh_tri_pair[is_sdf_pair])]
         sp.sort()
-        self.sdf_pair = np.asarray([[a, b] if newton_id0(a) < newton_id0(b) else [b, a] for _, _, a, b, *_ in sp], dtype=np.int32).reshape(-1, 2)
-        self.sdf_pair_hydro = np.asarray([h for *_, h, _ in sp], dtype=bool)  # hydroelastic when the pipeline enables it
-        self.sdf_pair_mesh_plane = np.asarray([mp for *_, mp in sp], dtype=bool)  # the vertex leg (pair kind 2)
-        self.sdf_pair_has_edges = np.asarray([bool(has_sdf[a] and has_sdf[b]) for _, _, a, b, *_ in sp], dtype=bool)
+        self.sdf_pair = np.asarray([[r[2], r[3]] if newton_id0(r[2]) < newton_id0(r[3]) else [r[3], r[2]] for r in sp], dtype=np.int32).reshape(-1, 2)
+        self.sdf_pair_hydro = np.asarray([r[4] for r in sp], dtype=bool)  # hydroelastic when the pipeline enables it
+        self.sdf_pair_mesh_plane = np.asarray([r[5] for r in sp], dtype=bool)  # the vertex leg (pair kind 2)
+        self.sdf_pair_mesh_tri = np.asarray([r[6] for r in sp], dtype=bool)  # the triangle leg (pair kind 3)
+        self.sdf_pair_has_edges = np.asarray([bool(has_sdf[r[2]] and has_sdf[r[3]]) for r in sp], dtype=bool)
         self.tile_pair_index = np.flatnonzero(~is_sdf_pair)  # positions of the tile pairs in one world's shape_contact_pairs slice
         self.pair_a, self.pair_b = self.pair_a[~is_sdf_pair], self.pair_b[~is_sdf_pair]
         self.np = len(self.pair_a)
@@ -539,7 +550,8 @@ class DeviceModel:
                  d.params_uniform), "nt_model_create and the host mirror disagree on the model's sizes / tile mode"
             # pairs routed out of the tiles: the SDF legs read the Python mirror (t.sdf_pair ...), the kernels the C tables
             sp, kind, edges = c_sdf_pairs(self.lib, h)
-            want_kind = np.where(t.sdf_pair_hydro, 1, np.where(t.sdf_pair_mesh_plane, 2, 0)).astype(np.uint8) if len(t.sdf_pair) else kind[:0]
+            want_kind = (np.where(t.sdf_pair_hydro, 1, np.where(t.sdf_pair_mesh_plane, 2, np.where(t.sdf_pair_mesh_tri, 3, 0))).astype(np.uint8)
+                         if len(t.sdf_pair) else kind[:0])
             if not (np.array_equal(sp, np.asarray(t.sdf_pair).reshape(-1, 2)) and np.array_equal(kind, want_kind)
                     and np.array_equal(edges.astype(bool), np.asarray(t.sdf_pair_has_edges, dtype=bool))):
                 raise _lib.NewtonHipError("nt_model_create routed the SDF / vertex pairs differently from the host mirror")

@@ -88,7 +88,7 @@ class SdfLeg:
 
     def __init__(self, model, pairs_per_shape: int = 12, contacts_per_shape: int = 40, threads: int = 64, hydro_config=None,
                  staged: bool = True, survivors_per_row: int = 2, hydro_faces_per_shape: int = 400, hydro_staged: bool = True,
-                 hydro_blocks_per_pair: int = 4):
+                 hydro_blocks_per_pair: int = 4, triangle_rows_per_pair: int = 245):
         from .sdf_device import DeviceSDF  # noqa: PLC0415
 
         torch = _torch()
@@ -144,10 +144,14 @@ class SdfLeg:
         # (triangle mesh, infinite plane): the vertex leg (kind 2, NT_PAIR_KIND_MESH_PLANE; include/newton_hip_mesh.h)
         mesh_plane = np.asarray(getattr(t, "sdf_pair_mesh_plane", np.zeros(len(t.sdf_pair), bool)), bool)
         kind[mesh_plane] = 2
+        # (triangle mesh, convex primitive): the triangle leg (kind 3, NT_PAIR_KIND_MESH_TRIANGLE; include/newton_hip_mesh.h)
+        mesh_tri = np.asarray(getattr(t, "sdf_pair_mesh_tri", np.zeros(len(t.sdf_pair), bool)), bool)
+        kind[mesh_tri] = 3
         if np.any((kind == 0) & ~t.sdf_pair_has_edges):
             raise NotImplementedError("pairs of hydroelastic shapes without collision edges need CollisionPipeline(sdf_hydroelastic_config=...)")
         self.has_hydro_pairs = bool((kind == 1).any())
         self.has_mesh_plane_pairs = bool((kind == 2).any())
+        self.has_mesh_tri_pairs = bool((kind == 3).any())
         self.has_edge_pairs = bool((kind == 0).any())
         self.mesh_plane_reduce = True  # CollisionPipeline(reduce_contacts=...): set by the pipeline
         self.edge_reduce = True  # ... and the edge leg: False = every contact the edge search admits (keep_all), staged variant
@@ -168,6 +172,27 @@ class SdfLeg:
             # the vertex rows come ON TOP of the other legs' rows: a world with both kinds of pairs shares one row budget
             other_rows = self.rows_per_world if (self.has_edge_pairs or self.has_hydro_pairs) else 0
             self.rows_per_world = max(self.rows_per_world, other_rows + mp_rows + 64)
+            self.row_capacity = E * self.rows_per_world
+        if self.has_mesh_tri_pairs:
+            sc.template_kind, sc.world_pair_kind = self._template_kind.data_ptr(), self.world_pair_kind.data_ptr()
+            self._shape_type = up(model.shape_type, np.int32)
+            self._vertex_range = up(model.mesh_vertex_range, np.int32)
+            self._vertices = up(model.mesh_vertices, np.float32)
+            self._triangle_range = up(model.mesh_triangle_range, np.int32)
+            self._indices = up(model.mesh_indices, np.int32)
+            ntri_max = int(np.asarray(model.mesh_triangle_range)[:, 1].max())
+            if ntri_max >= (1 << 18):
+                # the reduction's packed values carry the fingerprint (triangle << 4 | 8 | manifold index) in 22 bits
+                raise NotImplementedError("triangle meshes with 2^18 or more triangles are not supported by the triangle leg")
+
+            def tri_count(l):
+                return int(model.mesh_triangle_range[t.shape_local0 + l if l < t.ns else int(t.gshape_id[l - t.ns]), 1])
+
+            # rows a world can get from its triangle pairs: the reduction's table per pair (245 slots), bounded by 5 contacts per
+            # triangle; CollisionPipeline(reduce_contacts=False) passes triangle_rows_per_pair for the unreduced budget
+            per_pair = [min(5 * max(tri_count(int(a)), tri_count(int(b))), int(triangle_rows_per_pair)) for a, b in t.sdf_pair[mesh_tri]]
+            other_rows = self.rows_per_world if (self.has_edge_pairs or self.has_hydro_pairs or self.has_mesh_plane_pairs) else 0
+            self.rows_per_world = max(self.rows_per_world, other_rows + sum(per_pair) + 64)
             self.row_capacity = E * self.rows_per_world
         if self.has_hydro_pairs:
             from .mc_tables import tables  # noqa: PLC0415
@@ -216,6 +241,7 @@ class SdfLeg:
         self.raw_pair = torch.zeros(self.raw_capacity, dtype=i32, device=dev)
         self.raw_key = torch.zeros(self.raw_capacity, dtype=i32, device=dev)
         self.raw_data = torch.zeros((self.raw_capacity, 9), dtype=f32, device=dev)
+        self.raw_radius = torch.zeros((self.raw_capacity, 2), dtype=f32, device=dev) if self.has_mesh_tri_pairs else None
         self.raw_rank = torch.zeros(self.raw_capacity if self.has_hydro_pairs else 1, dtype=i32, device=dev)
         self.raw_stiffness = torch.zeros(self.raw_capacity if self.has_hydro_pairs else 1, dtype=f32, device=dev)
         if self.has_hydro_pairs and self.hydro_reduce:  # the reduction's face buffer (scratch of a call) + per-row friction scale
@@ -268,7 +294,7 @@ class SdfLeg:
             if not self.staged:
                 raise NotImplementedError("reduce_contacts=False with mesh-SDF pairs runs the staged narrow phase (NT_SDF_STAGED=0 is set)")
             r.keep_all = 1
-        if self.has_hydro_pairs or self.has_mesh_plane_pairs:
+        if self.has_hydro_pairs or self.has_mesh_plane_pairs or self.has_mesh_tri_pairs:
             a.pair_kind = self.world_pair_kind.data_ptr()
         if self.staged:
             a.hit_count, a.hit_stripes, a.hit_stripe_count, a.hit_capacity = (
@@ -294,6 +320,23 @@ class SdfLeg:
                                                                               self.raw_capacity)
             mp.out_blk = self.blk.data_ptr()
             _lib.check(lib.nt_mesh_plane_pairs(C.byref(mp), stream), "nt_mesh_plane_pairs")
+        if self.has_mesh_tri_pairs:  # (triangle mesh, convex primitive): rows appended through the counter, one block per pair
+            mt = _lib.nt_mesh_triangle_args()
+            mt.pairs, mt.pair_world_prefix, mt.worlds, mt.pairs_per_world = (self.world_pairs.data_ptr(), self.pair_prefix.data_ptr(),
+                                                                           sc.env_count, sc.pairs_per_world)
+            mt.pair_kind, mt.shape_type = self.world_pair_kind.data_ptr(), self._shape_type.data_ptr()
+            mt.shape_transform, mt.shape_data, mt.shape_gap = (self.world_xform.data_ptr(), self._shape_data.data_ptr(),
+                                                               self._shape_gap.data_ptr())
+            mt.shape_vertex_range, mt.vertices = self._vertex_range.data_ptr(), self._vertices.data_ptr()
+            mt.shape_triangle_range, mt.indices = self._triangle_range.data_ptr(), self._indices.data_ptr()
+            mt.shape_aabb_lower, mt.shape_aabb_upper, mt.shape_voxel_res = (self._red_lo.data_ptr(), self._red_hi.data_ptr(),
+                                                                            self._red_res.data_ptr())
+            mt.reduce = int(bool(self.mesh_plane_reduce))
+            mt.out_count, mt.out_pair, mt.out_key, mt.out_data, mt.capacity = (self.raw_count.data_ptr(), self.raw_pair.data_ptr(),
+                                                                              self.raw_key.data_ptr(), self.raw_data.data_ptr(),
+                                                                              self.raw_capacity)
+            mt.out_radius, mt.out_blk = self.raw_radius.data_ptr(), self.blk.data_ptr()
+            _lib.check(lib.nt_mesh_triangle_pairs(C.byref(mt), stream), "nt_mesh_triangle_pairs")
         if self.has_hydro_pairs:
             h = _lib.nt_hydro_args()
             h.pairs, h.pair_count = self.world_pairs.data_ptr(), int(self.world_pairs.shape[0])
@@ -333,7 +376,9 @@ class SdfLeg:
         io.raw_base = self.hit_capacity
         for k in ("shape0", "shape1", "point0", "point1", "offset0", "offset1", "normal", "margin0", "margin1", "key"):
             setattr(io, k, getattr(rows, k).data_ptr())
-        if self.has_hydro_pairs or self.has_mesh_plane_pairs:  # (pair kinds in play: the writer asks for the rank array)
+        if self.raw_radius is not None:
+            io.raw_radius = self.raw_radius.data_ptr()
+        if self.has_hydro_pairs or self.has_mesh_plane_pairs or self.has_mesh_tri_pairs:  # (pair kinds in play: the writer asks for the rank array)
             io.raw_rank, io.raw_stiffness = self.raw_rank.data_ptr(), self.raw_stiffness.data_ptr()
             if self.hydro_reduce:
                 io.raw_friction = self.raw_friction.data_ptr()
@@ -459,7 +504,8 @@ def sdf_pair_shape_types_ok(model) -> None:
     """The SDF leg handles MESH / CONVEX_MESH / BOX shapes (texture SDF + collision edges); heightfields are out of scope."""
     t = model.env
     mesh_plane = getattr(t, "sdf_pair_mesh_plane", np.zeros(len(t.sdf_pair), bool))
-    for (a, b), hydro, mp in zip(t.sdf_pair, t.sdf_pair_hydro, mesh_plane):
+    mesh_tri = getattr(t, "sdf_pair_mesh_tri", np.zeros(len(t.sdf_pair), bool))
+    for (a, b), hydro, mp in zip(t.sdf_pair, t.sdf_pair_hydro, mesh_plane | mesh_tri):
         if mp:
             continue
         for s in (a, b):

@@ -56,21 +56,23 @@ def write_rows(rows, body_q, shape_body, shape_gap):
     for i in range(n):
         sa, sb = int(rows["shape_a"][i]), int(rows["shape_b"][i])
         ma, mb, dist = f32(rows["margin_a"][i]), f32(rows["margin_b"][i]), f32(rows["distance"][i])
-        total = f32(f32(f32(f32(0.0) + f32(0.0)) + ma) + mb)
+        # effective radii (compute_effective_radius): zero for SDF / mesh shapes; the triangle leg's partner can be a sphere / capsule
+        ra = f32(rows["radius_a"][i]) if "radius_a" in rows else f32(0.0)
+        rb = f32(rows["radius_b"][i]) if "radius_b" in rows else f32(0.0)
+        total = f32(f32(f32(ra + rb) + ma) + mb)
         nr = rows["normal"][i].astype(np.float32)
         ln = np.sqrt(_dot(nr, nr), dtype=np.float32)
         nab = (nr / ln).astype(np.float32) if ln > 0 else np.zeros(3, np.float32)
         c = rows["center"][i].astype(np.float32)
-        half = f32(f32(f32(0.5) * dist) + f32(0.0))
-        aw = (c - nab * half).astype(np.float32)
-        bw = (c + nab * half).astype(np.float32)
+        aw = (c - nab * f32(f32(f32(0.5) * dist) + ra)).astype(np.float32)
+        bw = (c + nab * f32(f32(f32(0.5) * dist) + rb)).astype(np.float32)
         sep = f32(_dot((bw - aw).astype(np.float32), nab) - total)
         if sep > f32(f32(shape_gap[sa]) + f32(shape_gap[sb])):
             continue
         ba, bb = int(shape_body[sa]), int(shape_body[sb])
         Xa = IDENT if ba < 0 else _x_inv(body_q[ba].astype(np.float32))
         Xb = IDENT if bb < 0 else _x_inv(body_q[bb].astype(np.float32))
-        m0, m1 = f32(f32(0.0) + ma), f32(f32(0.0) + mb)
+        m0, m1 = f32(ra + ma), f32(rb + mb)
         out["accepted"][i] = True
         out["shape0"][i], out["shape1"][i] = sa, sb
         out["point0"][i], out["point1"][i] = _x_point(Xa, aw), _x_point(Xb, bw)

@@ -343,12 +343,12 @@ def test_pmc_traffic_is_only_attached_to_the_code_object_it_was_measured_on(monk
     assert bench.step_unit_id() is None
 
 
-def test_triangle_mesh_shapes_route_to_the_vertex_leg_or_are_refused():
+def test_triangle_mesh_shapes_route_to_the_vertex_leg_the_triangle_leg_or_are_refused():
     """ModelBuilder.add_shape_mesh (builder.py:7158-7198): mass properties like a convex hull's (inertia.py:726-757 treats MESH and
     CONVEX_MESH alike), local AABB / voxel grid / collision radius of the scaled vertices, the vertex table un-deduplicated (the
     vertex index is the contact fingerprint); a (MESH, infinite plane) pair leaves the tiles for the vertex leg
-    (narrow_phase.py:618-631) while the tiles keep the mesh as a pre-computed-AABB shape; mesh-vs-primitive pairs (triangle leg)
-    and a finite plane are refused at finalize."""
+    (narrow_phase.py:618-631) while the tiles keep the mesh as a pre-computed-AABB shape; a (MESH, convex primitive) pair leaves them
+    for the triangle leg (narrow_phase.py:633-638, pair kind 3); a finite plane or a second mesh without SDFs is refused at finalize."""
     hull = nt.Mesh.create_box(0.1, 0.08, 0.05)
     mesh = nt.Mesh(np.concatenate([hull.vertices] * 3), hull.indices)  # per-face vertices of a render mesh: every corner three times
 
@@ -380,9 +380,13 @@ def test_triangle_mesh_shapes_route_to_the_vertex_leg_or_are_refused():
     I0xx = (0.2 * 0.16 * 0.1) / 12.0 * (0.16 ** 2 + 0.1 ** 2)
     assert np.isclose(np.asarray(m.body_inertia[0]).reshape(3, 3)[0, 0], I0xx * (2.0 ** 2 + 1.0) / 2.0 * 2.0 * 1000.0, rtol=1e-4)
     assert nt.sdf_pipeline.model_has_sdf_pairs(m)
-    with pytest.raises(NotImplementedError, match="no analytic path"):  # a sphere next to the mesh: the triangle leg is not built
-        scene(lambda env: env.add_shape_sphere(env.add_body(xform=[0.3, 0, 0.05, 0, 0, 0, 1]), radius=0.05))
-    with pytest.raises(NotImplementedError, match="no analytic path"):  # a FINITE plane is a convex shape: triangle leg again
+    # a sphere next to the mesh: (mesh, sphere) takes the triangle leg, (mesh, plane) the vertex leg, (sphere, plane) stays a tile pair
+    ms = scene(lambda env: env.add_shape_sphere(env.add_body(xform=[0.3, 0, 0.05, 0, 0, 0, 1]), radius=0.05))
+    assert ms.env.np == 1 and ms.env.sdf_pair.tolist() == [[0, 1], [0, 2]]
+    assert ms.env.sdf_pair_mesh_tri.tolist() == [True, False] and ms.env.sdf_pair_mesh_plane.tolist() == [False, True]
+    assert ms.mesh_triangle_range.tolist() == [[0, 12], [0, 0]] * 3 + [[0, 0]] and ms.mesh_indices.shape == (12, 3)
+    assert int(ms.mesh_indices.max()) == 7  # wp.Mesh.indices as given (this mesh lists every corner three times and indexes the first copy)
+    with pytest.raises(NotImplementedError, match="no analytic path"):  # a FINITE plane is a convex shape the triangle leg does not take
         scene(lambda env: env.add_shape(body=-1, type=GeoType.PLANE, scale=(1.0, 1.0, 0.0)), plane=False)
     assert len(scene(plane=False).env.sdf_pair) == 0  # nothing to collide with: no legs at all
     # env-range shards / world groups / tiled copies keep the per-shape vertex ranges (the vertex table itself is a shared asset)
@@ -391,6 +395,7 @@ def test_triangle_mesh_shapes_route_to_the_vertex_leg_or_are_refused():
     part, twice = slice_worlds(m, 1, 3), tile_worlds(m, 2)
     assert part.mesh_vertex_range.tolist() == [[0, 24]] * 2 + [[0, 0]] and part.mesh_vertices is m.mesh_vertices
     assert part.env.env_count == 2 and part.env.sdf_pair_mesh_plane.tolist() == [True]
+    assert part.mesh_triangle_range.tolist() == [[0, 12]] * 2 + [[0, 0]] and part.mesh_indices is m.mesh_indices
     assert twice.mesh_vertex_range.shape == (7, 2) and twice.env.env_count == 6 and twice.env.sdf_pair_mesh_plane.tolist() == [True]
 
 
