@@ -92,7 +92,12 @@ typedef struct {
     float* out_radius;                 /* [capacity][2] or NULL: effective radii (0, sphere / capsule radius) of the export */
     int32_t capacity;
     int32_t* out_blk;                  /* [pairs][2] (first row, row count) of the pair's block; written for every processed pair */
+    const float* block_bounds;         /* [blocks][6] or NULL: (lower xyz, upper xyz) of the unscaled vertices of every block of
+                                          NT_MESH_TRIANGLE_BLOCK consecutive triangles of a mesh (the last block of a mesh is short);
+                                          the scan skips blocks that miss the query box -- same candidate set, fewer rounds */
+    const int32_t* shape_block_start;  /* [S] or NULL (both or neither): first block of a mesh shape in `block_bounds` */
 } nt_mesh_triangle_args;
+#define NT_MESH_TRIANGLE_BLOCK 64
 #define NT_PAIR_KIND_MESH_TRIANGLE 3
 nt_status nt_mesh_triangle_pairs(const nt_mesh_triangle_args* args, void* stream);
 

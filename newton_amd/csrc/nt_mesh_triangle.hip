@@ -14,11 +14,13 @@
 //                :1246-1346 (reduce_contact_in_hashtable, beta = 1e-4), :2098-2290 (export: roundoff twins, every contact once)
 //
 // MI355X design.  The reference runs four launches over device-wide buffers (midphase -> triangle list, contacts -> contact buffer,
-// hashtable registration, export).  Here one workgroup owns a pair.  Its 256 lanes scan the mesh's triangles 256 at a time -- 36 B
+// hashtable registration, export).  Here one workgroup -- ONE WAVE -- owns a pair.  Its lanes scan the mesh's triangles 64 at a time -- 36 B
 // of indices + vertices per triangle, shared by every world of a replicated scene (L2 hits after the first world); Warp's BVH is
 // replaced by that scan: a tree walk is a dependent-load chain per lane, the scan is a coalesced stream, and the set it returns is
-// the set the BVH query returns (every triangle whose bounds touch the query box).  Survivors are ballot-compacted into an LDS list
-// in ascending triangle order; once 256 are waiting (or the scan ends) every lane takes one triangle through MPR / GJK and the
+// the set the BVH query returns (every triangle whose bounds touch the query box); with the optional bounds of every 64 consecutive
+// triangles (a one-level hierarchy over the index order, built once on the host) the scan first drops the blocks that miss the
+// box -- same set, 32 rounds -> 2 on an 8 192-triangle terrain.  Survivors are ballot-compacted into an LDS list
+// in ascending triangle order; once a wave's worth is waiting (or the scan ends) every lane takes one triangle through MPR / GJK and the
 // manifold (nt_convex.hpp, the code of the convex tiles) and offers its contacts to the pair's 245-slot reduction table in LDS
 // (ds_max_u64, nt_contact_reduce.hpp).  The <= 245 winners recompute their record from (triangle, manifold index) -- same
 // instructions, same bits -- so there is no contact buffer, no hashtable and no atomics on shared counters except one row
@@ -27,6 +29,7 @@
 // Bound: the dependent MPR / GJK iterations of the survivors (one lane per triangle), not the scan.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/newton_hip.h"
 #include "../../include/newton_hip_mesh.h"
@@ -45,8 +48,10 @@ namespace {
 #include "nt_contact_reduce.hpp"
 
 constexpr float RED_BETA = 0.0001f;  // contact_reduction_global.py:89 BETA_THRESHOLD
-constexpr int MT_THREADS = 256;
-constexpr int MT_LIST = 2 * MT_THREADS;  // candidate triangles waiting for a batch
+// Lanes per workgroup (= per pair).  A pair of a pile or of a body on a terrain has a few dozen candidate triangles: with 256 lanes one
+// wave of four runs MPR while three idle, and 251 VGPRs leave room for two such workgroups per CU.  One WAVE per pair keeps eight
+// pairs per CU in flight (26 KB of LDS each).  256 lanes remain as a launch shape for measurements (NT_MESH_TRIANGLE_THREADS=256).
+constexpr int MT_DEFAULT_THREADS = 64;
 
 NT_DI xform ld_xform(const float* p) { return xform(vec3(p[0], p[1], p[2]), quat(p[3], p[4], p[5], p[6])); }
 NT_DI vec3 ld_vec3(const float* p) { return vec3(p[0], p[1], p[2]); }
@@ -181,17 +186,22 @@ NT_DI void write_row(const nt_mesh_triangle_args& a, const PairSetup& c, int slo
     }
 }
 
+template <int MT_THREADS>
 struct MtLds {
     RedLds red;
-    int list[MT_LIST];  // candidate triangles, ascending
+    int list[2 * MT_THREADS];  // candidate triangles waiting for a batch, ascending
+    unsigned short hblk[(1 << 18) / NT_MESH_TRIANGLE_BLOCK];  // blocks of the mesh that touch the query box, ascending
+    int n_hblk;
     float poly[20 * MT_THREADS];  // manifold clipper scratch: 10 x vec2 per lane, lane-strided
     int wave_hits[MT_THREADS / 64];
     int waiting;        // candidates in `list`
     int rows;           // reduce = 0: contacts generated so far (pass 0: count; pass 1: rank of the next batch)
 };
 
+template <int MT_THREADS>
 __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh_triangle_args a) {
-    __shared__ MtLds S;
+    constexpr int MT_WAVES = MT_THREADS / 64;
+    __shared__ MtLds<MT_THREADS> S;
     RedLds& L = S.red;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const PolyRef poly{S.poly + t, MT_THREADS};
@@ -210,14 +220,50 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
         const int* res = a.shape_voxel_res ? a.shape_voxel_res + 3 * (size_t)c.mesh : nullptr;
         if (a.reduce)
             for (int k = t; k < RED_SLOTS; k += blockDim.x) { L.tbl[k] = 0ull; L.fp[k] = -1; L.keep[k] = 0; }
+        // ---- block bounds (optional): the blocks of 64 consecutive triangles whose bounds touch the query box, ascending.  A
+        // triangle that touches the box lies in a block that does, so the candidate set is the full scan's; spatially coherent index
+        // orders (grids, most exported meshes) leave a handful of blocks of a large mesh
+        const bool use_blocks = a.block_bounds != nullptr && a.shape_block_start != nullptr;
+        int n_hblk = 0;
+        if (use_blocks) {
+            const int nblk = (c.nt_ + NT_MESH_TRIANGLE_BLOCK - 1) / NT_MESH_TRIANGLE_BLOCK;
+            const float* bb = a.block_bounds + 6 * (size_t)a.shape_block_start[c.mesh];
+            if (t == 0) S.n_hblk = 0;
+            __syncthreads();
+            for (int b0 = 0; b0 < nblk; b0 += MT_THREADS) {
+                const int b = b0 + t;
+                bool hit = false;
+                if (b < nblk) {
+                    const float* o = bb + 6 * (size_t)b;
+                    hit = !(o[0] > c.q_hi.x || o[1] > c.q_hi.y || o[2] > c.q_hi.z || o[3] < c.q_lo.x || o[4] < c.q_lo.y || o[5] < c.q_lo.z);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (lane == 0) S.wave_hits[wave] = __popcll(m);
+                __syncthreads();
+                int off = S.n_hblk;
+                for (int k = 0; k < wave; ++k) off += S.wave_hits[k];
+                if (hit) S.hblk[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)b;
+                __syncthreads();
+                if (t == 0) {
+                    int n = S.n_hblk;
+                    for (int k = 0; k < MT_THREADS / 64; ++k) n += S.wave_hits[k];
+                    S.n_hblk = n;
+                }
+                __syncthreads();
+            }
+            n_hblk = S.n_hblk;
+        }
+        const int n_rounds = use_blocks ? (n_hblk + MT_WAVES - 1) / MT_WAVES : (c.nt_ + MT_THREADS - 1) / MT_THREADS;
         const int passes = a.reduce ? 1 : 2;  // reduce = 0: pass 0 counts the pair's contacts, pass 1 writes them behind its base
         for (int pass = 0; pass < passes; ++pass) {
             if (t == 0) { S.waiting = 0; S.rows = 0; }
             __syncthreads();
-            for (int r0 = 0; r0 < c.nt_ || S.waiting > 0; r0 += MT_THREADS) {  // (uniform: S.waiting is read between barriers)
-                // ---- scan: the next 256 triangles against the query box, survivors appended in ascending order
-                if (r0 < c.nt_) {
-                    const int ti = r0 + t;
+            for (int r = 0; r < n_rounds || S.waiting > 0; ++r) {  // (uniform: S.waiting is read between barriers)
+                // ---- scan: the next triangles (a workgroup's worth of the mesh, or one surviving block per wave) against the query box, survivors
+                // appended in ascending order
+                if (r < n_rounds) {
+                    int ti = r * MT_THREADS + t;
+                    if (use_blocks) ti = MT_WAVES * r + wave < n_hblk ? (int)S.hblk[MT_WAVES * r + wave] * NT_MESH_TRIANGLE_BLOCK + lane : c.nt_;
                     const bool hit = ti < c.nt_ && triangle_candidate(a, c, ti);
                     const unsigned long long m = __ballot(hit);
                     if (lane == 0) S.wave_hits[wave] = __popcll(m);
@@ -234,7 +280,7 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
                     __syncthreads();
                 }
                 const int waiting = S.waiting;
-                const bool last = r0 + MT_THREADS >= c.nt_;
+                const bool last = r + 1 >= n_rounds;
                 if (waiting < MT_THREADS && !(last && waiting > 0)) continue;  // (uniform) keep scanning until a full batch waits
                 // ---- batch: one lane per waiting triangle
                 const int nb = waiting < MT_THREADS ? waiting : MT_THREADS;
@@ -345,14 +391,20 @@ extern "C" nt_status nt_mesh_triangle_pairs(const nt_mesh_triangle_args* a, void
         return NT_ERR_INVALID_ARG;
     if (a->reduce && (!a->shape_aabb_lower || !a->shape_aabb_upper || !a->shape_voxel_res)) return NT_ERR_INVALID_ARG;
     if (a->pair_world_prefix ? (a->worlds <= 0 || a->pairs_per_world <= 0) : a->pair_count < 0) return NT_ERR_INVALID_ARG;
+    if ((a->block_bounds == nullptr) != (a->shape_block_start == nullptr)) return NT_ERR_INVALID_ARG;
     long long blocks = a->pair_world_prefix ? (long long)a->worlds * a->pairs_per_world : (long long)a->pair_count;
     if (blocks == 0) return NT_OK;
 #ifdef NT_EMULATED_GRID
     const long long grid_cap = NT_EMULATED_GRID;
 #else
-    const long long grid_cap = 8192;
+    const long long grid_cap = 32768;
 #endif
     if (blocks > grid_cap) blocks = grid_cap;
-    hipLaunchKernelGGL(mesh_triangle_pairs_kernel, dim3((unsigned)blocks), dim3(MT_THREADS), 0, (hipStream_t)stream, *a);
+    static const int threads = [] {  // (read once: a launch shape for measurements, not an API)
+        const char* e = getenv("NT_MESH_TRIANGLE_THREADS");
+        return e && atoi(e) == 256 ? 256 : MT_DEFAULT_THREADS;
+    }();
+    if (threads == 256) hipLaunchKernelGGL(mesh_triangle_pairs_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(mesh_triangle_pairs_kernel<64>, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, *a);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }

@@ -236,3 +236,21 @@ def mesh_edge_tables(vertices, indices, scale=(1.0, 1.0, 1.0)):
     code = (4.0 + owns[:, 0].astype(np.float32) + 2.0 * owns[:, 1]).reshape(-1, 1)
     return (np.ascontiguousarray(np.concatenate([centers, radii], axis=1), dtype=np.float32),
             np.ascontiguousarray(np.concatenate([halves, code], axis=1), dtype=np.float32))
+
+
+TRIANGLE_BLOCK = 64  # NT_MESH_TRIANGLE_BLOCK (include/newton_hip_mesh.h)
+
+
+def triangle_block_bounds(vertices, indices, block: int = TRIANGLE_BLOCK) -> np.ndarray:
+    """Bounds of every `block` consecutive triangles of a mesh: [ceil(T / block)][6] float32 (lower xyz, upper xyz) of the UNSCALED
+    vertices -- min / max only, so the values are exact.  The triangle leg (csrc/nt_mesh_triangle.hip) skips the blocks that miss a
+    pair's query box before it tests triangles: the host-built stand-in for the upper levels of the reference's mesh BVH
+    (collision_core.py:1144-1180 queries wp.Mesh's), over the mesh's own index order."""
+    v = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)
+    tri = np.asarray(indices, dtype=np.int64).reshape(-1, 3)
+    n = -(-len(tri) // block)
+    out = np.zeros((n, 6), dtype=np.float32)
+    for b in range(n):
+        p = v[tri[b * block:(b + 1) * block].reshape(-1)]
+        out[b, :3], out[b, 3:] = p.min(axis=0), p.max(axis=0)
+    return out

@@ -180,6 +180,23 @@ class SdfLeg:
             self._vertices = up(model.mesh_vertices, np.float32)
             self._triangle_range = up(model.mesh_triangle_range, np.int32)
             self._indices = up(model.mesh_indices, np.int32)
+            # bounds of every 64 consecutive triangles, one table per distinct mesh (shapes sharing a mesh share its blocks)
+            from .mesh import triangle_block_bounds  # noqa: PLC0415
+
+            vr, tr = np.asarray(model.mesh_vertex_range).reshape(-1, 2), np.asarray(model.mesh_triangle_range).reshape(-1, 2)
+            blk_start, blk_of, tables, n_blk = np.zeros(S, np.int32), {}, [], 0
+            for i in range(S):
+                if tr[i, 1] <= 0:
+                    continue
+                key = (int(vr[i, 0]), int(tr[i, 0]), int(tr[i, 1]))
+                if key not in blk_of:
+                    blk_of[key] = n_blk
+                    tables.append(triangle_block_bounds(np.asarray(model.mesh_vertices)[vr[i, 0]:vr[i, 0] + vr[i, 1]],
+                                                        np.asarray(model.mesh_indices)[tr[i, 0]:tr[i, 0] + tr[i, 1]]))
+                    n_blk += len(tables[-1])
+                blk_start[i] = blk_of[key]
+            self._block_bounds = up(np.concatenate(tables) if tables else np.zeros((1, 6), np.float32), np.float32)
+            self._block_start = up(blk_start, np.int32)
             ntri_max = int(np.asarray(model.mesh_triangle_range)[:, 1].max())
             if ntri_max >= (1 << 18):
                 # the reduction's packed values carry the fingerprint (triangle << 4 | 8 | manifold index) in 22 bits
@@ -336,6 +353,8 @@ class SdfLeg:
                                                                               self.raw_key.data_ptr(), self.raw_data.data_ptr(),
                                                                               self.raw_capacity)
             mt.out_radius, mt.out_blk = self.raw_radius.data_ptr(), self.blk.data_ptr()
+            if os.environ.get("NT_TRIANGLE_BLOCKS", "1") != "0":  # (0: the plain scan over every triangle -- measurements)
+                mt.block_bounds, mt.shape_block_start = self._block_bounds.data_ptr(), self._block_start.data_ptr()
             _lib.check(lib.nt_mesh_triangle_pairs(C.byref(mt), stream), "nt_mesh_triangle_pairs")
         if self.has_hydro_pairs:
             h = _lib.nt_hydro_args()

@@ -449,3 +449,62 @@ def mesh_ground_scene(world_count: int, n_meshes: int = 8, device=None, seed: in
         model.body_q[:, :2] += off
         model.joint_q.reshape(-1, 7)[:, :2] += off
     return model
+
+
+def terrain_height(x, y):
+    return 0.012 * np.sin(4.0 * x) * np.cos(3.0 * y)
+
+
+def terrain_scene(world_count: int, n_shapes: int = 8, device=None, seed: int = 6, cells: int = 64, half: float = 1.6, gap: float = 0.004):
+    """`n_shapes` convex primitives per world (box, sphere, capsule, cylinder in turn) resting on ONE shared static terrain: a triangle
+    mesh of cells x cells x 2 triangles (a global shape without an SDF).  Every (primitive, terrain) pair goes through the triangle leg
+    of CollisionPipeline.collide (narrow_phase.py:633-638,1455-1665: midphase over the mesh's triangles, GJK / MPR + manifold per
+    triangle, the global contact reduction); the primitives are filtered against each other.  Worlds differ by a seeded pose jitter.
+    bench.py --workload terrain."""
+    import newton_amd as nt
+
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-half, half, cells + 1)
+    pts = np.array([(x, y, terrain_height(x, y)) for y in xs for x in xs], np.float32)
+    idx = []
+    for j in range(cells):
+        for i in range(cells):
+            a, b, c, d = j * (cells + 1) + i, j * (cells + 1) + i + 1, (j + 1) * (cells + 1) + i, (j + 1) * (cells + 1) + i + 1
+            idx += [a, b, d, a, d, c]
+    terrain = nt.Mesh(pts, np.array(idx, np.int32))
+    env = nt.ModelBuilder()
+    env.default_shape_cfg.gap = gap
+    env.default_shape_cfg.mu = 0.5
+    side = int(np.ceil(np.sqrt(n_shapes)))
+    shapes, halves = [], []
+    for k in range(n_shapes):
+        b = env.add_body(xform=[0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0])
+        kind = k % 4
+        if kind == 0:
+            shapes.append(env.add_shape_box(b, hx=0.08, hy=0.06, hz=0.05)); halves.append(0.05)
+        elif kind == 1:
+            shapes.append(env.add_shape_sphere(b, radius=0.06)); halves.append(0.06)
+        elif kind == 2:
+            shapes.append(env.add_shape_capsule(b, radius=0.04, half_height=0.08)); halves.append(0.04)
+        else:
+            shapes.append(env.add_shape_cylinder(b, radius=0.05, half_height=0.05)); halves.append(0.05)
+    for i in range(n_shapes):
+        for j in range(i + 1, n_shapes):
+            env.add_shape_collision_filter_pair(shapes[i], shapes[j])
+    scene = nt.ModelBuilder()
+    scene.default_shape_cfg.gap = gap
+    scene.default_shape_cfg.mu = 0.5
+    scene.replicate(env, world_count)
+    scene.add_shape_mesh(-1, mesh=terrain)
+    model = scene.finalize(device=device)
+    pitch = 2.0 * half / (side + 1)
+    for w in range(world_count):
+        for k in range(n_shapes):
+            x = -half + pitch * (1 + k % side) + rng.uniform(-0.05, 0.05)
+            y = -half + pitch * (1 + k // side) + rng.uniform(-0.05, 0.05)
+            q = nt._np_math.quat_rpy(0.0, np.pi / 2 if k % 4 == 2 else 0.0, rng.uniform(-1.0, 1.0))  # capsules lie on their side
+            i = w * n_shapes + k
+            model.body_q[i, :3] = [x, y, terrain_height(x, y) + halves[k] + 0.006]  # (a 6 mm drop: the slopes are gentle, 4 %)
+            model.body_q[i, 3:] = q
+            model.joint_q.reshape(-1, 7)[i] = model.body_q[i]
+    return model

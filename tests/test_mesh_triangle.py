@@ -75,7 +75,8 @@ def test_checker_keeps_the_contacts_the_reference_reducer_keeps(name):
 
 
 # ------------------------------------------------------------------------------------------------ the HIP kernel (nt_mesh_triangle.hip)
-def run_mesh_triangle(lib, s, reduce=1, capacity=None, start=0, stream=None, to_dev=None, to_host=None, world_regions=False):
+def run_mesh_triangle(lib, s, reduce=1, capacity=None, start=0, stream=None, to_dev=None, to_host=None, world_regions=False,
+                      blocks=False):
     """nt_mesh_triangle_pairs over a scene of mesh_triangle_cases (host arrays for the emulated library; the device twin passes
     converters).  The pairs go in as the candidate lists hold them -- (smaller id, larger id) -- and must come back as (mesh, convex).
     world_regions: the same pairs laid out as ONE world's region of 2 * len(pairs) slots with interleaved foreign pairs (kind 0),
@@ -117,6 +118,17 @@ def run_mesh_triangle(lib, s, reduce=1, capacity=None, start=0, stream=None, to_
     a.out_data, a.capacity = put("odata", np.zeros((capacity, 9), np.float32)), capacity
     a.out_radius = put("oradius", np.full((capacity, 2), -1.0, np.float32))
     a.out_blk = put("blk", np.full((slots, 2), -7, np.int32))
+    if blocks:  # the bounds of every 64 consecutive triangles: the scan skips blocks that miss the query box (same candidates)
+        from newton_amd.mesh import triangle_block_bounds
+
+        tabs, bstart, nb = [], np.zeros(len(s["shape_gap"]), np.int32), 0
+        for k in range(len(s["shape_gap"])):
+            if s["tri_count"][k] > 0:
+                v0, nv, t0, nt = int(s["vertex_start"][k]), int(s["vertex_count"][k]), int(s["tri_start"][k]), int(s["tri_count"][k])
+                tabs.append(triangle_block_bounds(s["vertices"][v0:v0 + nv], s["indices"][t0:t0 + nt]))
+                bstart[k] = nb
+                nb += len(tabs[-1])
+        a.block_bounds, a.shape_block_start = put("bb", np.concatenate(tabs)), put("bs", bstart)
     rc = lib.nt_mesh_triangle_pairs(C.byref(a), stream)
     assert rc == 0, rc
     h = {k: np.asarray(to_host(v)) for k, v in keep.items()}
@@ -181,7 +193,7 @@ def test_emulated_kernel_matches_the_record(emu, name, reduce):
     s = mc.scene(name)
     out = run_mesh_triangle(emu, s, reduce=reduce)
     assert check_against_record(name, *out, ref, s, reduce=reduce) > 0
-    out = run_mesh_triangle(emu, s, reduce=reduce, start=5, world_regions=True)
+    out = run_mesh_triangle(emu, s, reduce=reduce, start=5, world_regions=True, blocks=True)  # ... and the block bounds in front
     check_against_record(name, *out, ref, s, slot_of=lambda k: 2 * k + 1, start=5, reduce=reduce)
     assert np.all(out[1][0::2] == -7) and np.all(out[0][0::2] == 0)  # foreign pairs untouched
 
@@ -210,7 +222,7 @@ def test_hip_mesh_triangle_reproduces_the_reference_leg(name, reduce):
     s = mc.scene(name)
     first = run_mesh_triangle(lib, s, reduce=reduce, stream=stream, to_dev=dev, to_host=host)
     assert check_against_record(name, *first, ref, s, reduce=reduce) > 0
-    out = run_mesh_triangle(lib, s, reduce=reduce, stream=stream, to_dev=dev, to_host=host, world_regions=True, start=5)
+    out = run_mesh_triangle(lib, s, reduce=reduce, stream=stream, to_dev=dev, to_host=host, world_regions=True, start=5, blocks=True)
     check_against_record(name, *out, ref, s, slot_of=lambda k: 2 * k + 1, start=5, reduce=reduce)
     again = run_mesh_triangle(lib, s, reduce=reduce, stream=stream, to_dev=dev, to_host=host)
     for k in range(len(s["pairs"])):  # the block's position may differ between runs, its rows may not
@@ -230,7 +242,7 @@ def _large_mesh_many_batches(lib, **conv):
     s["pairs"] = np.array([[1, 0]], np.int32)
     triples, c = om.triangle_contacts(s)
     assert len(triples) > 520  # three batches at least
-    _, blk, rows, total = run_mesh_triangle(lib, s, reduce=0, **conv)
+    _, blk, rows, total = run_mesh_triangle(lib, s, reduce=0, blocks=True, **conv)  # (450 blocks: two rounds of the block pass)
     r0, cnt = blk[0]
     assert total == cnt == len(c["fp"]) and np.array_equal(rows["key"][r0:r0 + cnt], c["fp"])
     assert np.array_equal(rows["data"][r0:r0 + cnt, 0:3], c["pos"]) and np.array_equal(rows["data"][r0:r0 + cnt, 6], c["depth"])
