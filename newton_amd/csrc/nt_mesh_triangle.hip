@@ -22,9 +22,9 @@
 // box -- same set, 32 rounds -> 2 on an 8 192-triangle terrain.  Survivors are ballot-compacted into an LDS list
 // in ascending triangle order; once a wave's worth is waiting (or the scan ends) every lane takes one triangle through MPR / GJK and the
 // manifold (nt_convex.hpp, the code of the convex tiles) and offers its contacts to the pair's 245-slot reduction table in LDS
-// (ds_max_u64, nt_contact_reduce.hpp).  The <= 245 winners recompute their record from (triangle, manifold index) -- same
-// instructions, same bits -- so there is no contact buffer, no hashtable and no atomics on shared counters except one row
-// allocation per pair.  Rows leave as one contiguous block per pair in ascending fingerprint order (what deterministic=True sorts
+// (ds_max_u64, nt_contact_reduce.hpp).  The <= 245 winners take their record from the LDS copy of the pair's (usually only) batch,
+// or recompute it from (triangle, manifold index) when the pair had several -- same instructions, same bits -- so there is no
+// contact buffer in HBM, no hashtable and no atomics on shared counters except one row allocation per pair.  Rows leave as one contiguous block per pair in ascending fingerprint order (what deterministic=True sorts
 // into).  reduce = 0: every generated contact is a row (counted in a first pass, written in a second).
 // Bound: the dependent MPR / GJK iterations of the survivors (one lane per triangle), not the scan.
 #include <hip/hip_runtime.h>
@@ -193,6 +193,8 @@ struct MtLds {
     unsigned short hblk[(1 << 18) / NT_MESH_TRIANGLE_BLOCK];  // blocks of the mesh that touch the query box, ascending
     int n_hblk;
     float poly[20 * MT_THREADS];  // manifold clipper scratch: 10 x vec2 per lane, lane-strided
+    float rec[22 * MT_THREADS];   // the first batch's contacts, lane-strided: octahedral normal code, 5 x (centre, distance)
+    int batch_tri[MT_THREADS];    // ... and its triangles (ascending)
     int wave_hits[MT_THREADS / 64];
     int waiting;        // candidates in `list`
     int rows;           // reduce = 0: contacts generated so far (pass 0: count; pass 1: rank of the next batch)
@@ -255,6 +257,7 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
         }
         const int n_rounds = use_blocks ? (n_hblk + MT_WAVES - 1) / MT_WAVES : (c.nt_ + MT_THREADS - 1) / MT_THREADS;
         const int passes = a.reduce ? 1 : 2;  // reduce = 0: pass 0 counts the pair's contacts, pass 1 writes them behind its base
+        int batches = 0, batch_n = 0;  // (uniform) batches of this pair so far, triangles of the first one
         for (int pass = 0; pass < passes; ++pass) {
             if (t == 0) { S.waiting = 0; S.rows = 0; }
             __syncthreads();
@@ -297,6 +300,20 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
                     const vec3 normal_buffered = red_decode_oct(ox, oy);
                     for (int i = 0; i < cc.count; ++i)
                         red_offer_buffered(L.tbl, normal_buffered, cc.center(i), cc.distance(i), X_mesh_inv, lo, hi, res, (ti << 4) | 8 | i);
+                    // the FIRST batch's contacts stay in LDS: a pair that needs no second batch (the usual case) hands its winners
+                    // their records from here instead of running MPR / GJK for them again
+                    if (batches == 0 && t < nb) {
+                        S.batch_tri[t] = ti;
+                        float* rcd = S.rec + t;
+                        rcd[0] = ox; rcd[MT_THREADS] = oy;
+                        for (int i = 0; i < cc.count; ++i) {
+                            const vec3 ctr = cc.center(i);
+                            rcd[(2 + 4 * i) * MT_THREADS] = ctr.x; rcd[(3 + 4 * i) * MT_THREADS] = ctr.y;
+                            rcd[(4 + 4 * i) * MT_THREADS] = ctr.z; rcd[(5 + 4 * i) * MT_THREADS] = cc.distance(i);
+                        }
+                    }
+                    if (batches == 0) batch_n = nb;
+                    batches += 1;
                 } else {
                     // exclusive prefix of the lanes' contact counts over the workgroup, in lane (= triangle) order
                     int x = cc.count;
@@ -349,10 +366,26 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
             continue;
         }
         __syncthreads();
-        // ---- the winner of slot k: its record recomputed from (triangle, manifold index)
+        // ---- the winner of slot k: its record from the first batch's LDS copy (the pair had one batch: found by its triangle in the
+        // batch's ascending list), else recomputed from (triangle, manifold index) -- the same instructions, the same bits
         for (int k = t; k < RED_SLOTS; k += blockDim.x) {
             if (L.tbl[k] == 0ull) continue;
             const int fp = (int)(L.tbl[k] & RED_FP_MASK);
+            if (batches == 1) {
+                const int tri = fp >> 4, i = fp & 7;
+                int lo_ = 0, hi_ = batch_n - 1;
+                while (lo_ < hi_) {
+                    const int mid = (lo_ + hi_) >> 1;
+                    if (S.batch_tri[mid] < tri) lo_ = mid + 1;
+                    else hi_ = mid;
+                }
+                const float* rcd = S.rec + lo_;
+                L.pos[k][0] = rcd[(2 + 4 * i) * MT_THREADS]; L.pos[k][1] = rcd[(3 + 4 * i) * MT_THREADS];
+                L.pos[k][2] = rcd[(4 + 4 * i) * MT_THREADS]; L.pos[k][3] = rcd[(5 + 4 * i) * MT_THREADS];
+                L.oct[k][0] = rcd[0]; L.oct[k][1] = rcd[MT_THREADS];
+                L.fp[k] = fp;
+                continue;
+            }
             ConvexContacts cc;
             triangle_contacts(a, c, fp >> 4, poly, cc);
             const int i = fp & 7;
