@@ -52,7 +52,7 @@ nt_status nt_mesh_plane_pairs(const nt_mesh_plane_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * The triangle leg: a MESH that does not take the SDF route against a convex primitive (sphere, capsule, ellipsoid, cylinder, box,
- * cone).  Reference interface replaced (paths relative to /root/reference/newton/_src/geometry):
+ * cone) or a convex hull (CONVEX_MESH).  Reference interface replaced (paths relative to /root/reference/newton/_src/geometry):
  *   pair routing        narrow_phase.py:633-638    `shape_pairs_mesh`: a mesh against a non-mesh shape that took no earlier route
  *   midphase            narrow_phase.py:1455-1568 narrow_phase_find_mesh_triangle_overlaps_kernel -> collision_core.py:996-1180
  *                                                 (query AABB from the convex shape's support function in the unscaled mesh frame,
@@ -73,7 +73,8 @@ typedef struct {
     const int32_t* pair_world_prefix;  /* [worlds + 1] or NULL for a plain list */
     int32_t worlds, pairs_per_world;
     const uint8_t* pair_kind;          /* [pairs] or NULL: when given only pairs of kind NT_PAIR_KIND_MESH_TRIANGLE are processed */
-    const int32_t* shape_type;         /* [S] GeoType (MESH = 8; the partner: SPHERE 3, CAPSULE 4, ELLIPSOID 5, CYLINDER 6, BOX 7, CONE 9) */
+    const int32_t* shape_type;         /* [S] GeoType (MESH = 8; the partner: SPHERE 3, CAPSULE 4, ELLIPSOID 5, CYLINDER 6, BOX 7, CONE 9,
+                                          CONVEX_MESH 10 with `hull_points`) */
     const float* shape_transform;      /* [S][7] world transforms */
     const float* shape_data;           /* [S][4] scale xyz, margin */
     const float* shape_gap;            /* [S] */
@@ -96,6 +97,9 @@ typedef struct {
                                           NT_MESH_TRIANGLE_BLOCK consecutive triangles of a mesh (the last block of a mesh is short);
                                           the scan skips blocks that miss the query box -- same candidate set, fewer rounds */
     const int32_t* shape_block_start;  /* [S] or NULL (both or neither): first block of a mesh shape in `block_bounds` */
+    const float* hull_points;          /* [H][3] or NULL: vertex tables of the CONVEX_MESH partners (wp.Mesh.points of a hull, unscaled;
+                                          Model.mesh_points); without it pairs with a CONVEX_MESH are skipped */
+    const int32_t* shape_hull_range;   /* [S][2] or NULL (both or neither): (first vertex, vertex count) of a CONVEX_MESH shape */
 } nt_mesh_triangle_args;
 #define NT_MESH_TRIANGLE_BLOCK 64
 #define NT_PAIR_KIND_MESH_TRIANGLE 3

@@ -143,7 +143,8 @@ class nt_mesh_triangle_args(C.Structure):
                 ("shape_aabb_lower", C.c_void_p), ("shape_aabb_upper", C.c_void_p), ("shape_voxel_res", C.c_void_p),
                 ("reduce", C.c_int32), ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p),
                 ("out_data", C.c_void_p), ("out_radius", C.c_void_p), ("capacity", C.c_int32), ("out_blk", C.c_void_p),
-                ("block_bounds", C.c_void_p), ("shape_block_start", C.c_void_p)]
+                ("block_bounds", C.c_void_p), ("shape_block_start", C.c_void_p), ("hull_points", C.c_void_p),
+                ("shape_hull_range", C.c_void_p)]
 
 
 class nt_sdf(C.Structure):

@@ -1,4 +1,4 @@
-// nt_mesh_triangle.hip -- MESH (no SDF route) vs convex primitive for gfx950: the triangle leg of CollisionPipeline.collide
+// nt_mesh_triangle.hip -- MESH (no SDF route) vs convex primitive / convex hull for gfx950: the triangle leg of CollisionPipeline.collide
 // (include/newton_hip_mesh.h).
 //
 // Reference behaviour (paths under /root/reference/newton/_src/geometry):
@@ -96,17 +96,43 @@ NT_DI void pair_setup(const nt_mesh_triangle_args& a, int s0, int s1, PairSetup&
     c.gb.center = vec3(0.0f);
     c.gb.aux = vec3(0.0f);
     c.radius_b = (c.gb.type == GEO_SPHERE || c.gb.type == GEO_CAPSULE) ? dc[0] : 0.0f;  // compute_effective_radius of the export
+    if (c.gb.type == GEO_CONVEX_MESH) {  // extract_shape_data: the hull's vertex table; _shape_center (support_function.py:448-464):
+        c.gb.points = a.hull_points + 3 * (size_t)a.shape_hull_range[2 * (size_t)c.convex];  // the centre of its scaled bounds seeds MPR / GJK
+        c.gb.count = a.shape_hull_range[2 * (size_t)c.convex + 1];
+        const vec3 first = cw_mul(ld_vec3(c.gb.points), c.gb.scale);
+        vec3 lower = first, upper = first;
+        for (int i = 1; i < c.gb.count; ++i) {
+            const vec3 point = cw_mul(ld_vec3(c.gb.points + 3 * (size_t)i), c.gb.scale);
+            lower = vmin(lower, point);
+            upper = vmax(upper, point);
+        }
+        c.gb.center = 0.5f * (lower + upper);
+    }
     // _compute_mesh_vs_convex_query_aabb (collision_core.py:996-1040)
     const xform X_mesh_shape = xform_inverse(c.X_mesh) * c.X_convex;
     const vec3 pos_in_mesh = X_mesh_shape.p;
     const mat33 rt = transpose(quat_to_matrix(X_mesh_shape.q));
     const vec3 local_x(rt.m00, rt.m10, rt.m20), local_y(rt.m01, rt.m11, rt.m21), local_z(rt.m02, rt.m12, rt.m22);
-    const float max_x = dot(local_x, support_map(c.gb, local_x));
-    const float max_y = dot(local_y, support_map(c.gb, local_y));
-    const float max_z = dot(local_z, support_map(c.gb, local_z));
-    const float min_x = dot(local_x, support_map(c.gb, -local_x));
-    const float min_y = dot(local_y, support_map(c.gb, -local_y));
-    const float min_z = dot(local_z, support_map(c.gb, -local_z));
+    float max_x, max_y, max_z, min_x, min_y, min_z;
+    if (c.gb.type == GEO_CONVEX_MESH) {  // collision_core.py:491-523: one pass over the hull's vertices, axes pre-scaled
+        const vec3 scaled_x = cw_mul(local_x, c.gb.scale), scaled_y = cw_mul(local_y, c.gb.scale), scaled_z = cw_mul(local_z, c.gb.scale);
+        min_x = min_y = min_z = 1.0e10f;
+        max_x = max_y = max_z = -1.0e10f;
+        for (int i = 0; i < c.gb.count; ++i) {
+            const vec3 p = ld_vec3(c.gb.points + 3 * (size_t)i);
+            const float vx = dot(p, scaled_x), vy = dot(p, scaled_y), vz = dot(p, scaled_z);
+            min_x = fminw(min_x, vx); max_x = fmaxw(max_x, vx);
+            min_y = fminw(min_y, vy); max_y = fmaxw(max_y, vy);
+            min_z = fminw(min_z, vz); max_z = fmaxw(max_z, vz);
+        }
+    } else {
+        max_x = dot(local_x, support_map(c.gb, local_x));
+        max_y = dot(local_y, support_map(c.gb, local_y));
+        max_z = dot(local_z, support_map(c.gb, local_z));
+        min_x = dot(local_x, support_map(c.gb, -local_x));
+        min_y = dot(local_y, support_map(c.gb, -local_y));
+        min_z = dot(local_z, support_map(c.gb, -local_z));
+    }
     const vec3 aabb_lower = vec3(min_x, min_y, min_z) + pos_in_mesh, aabb_upper = vec3(max_x, max_y, max_z) + pos_in_mesh;
     const float eps = 1.0e-12f;
     auto guarded = [&](float s) { return fabsf(s) > eps ? s : (s >= 0.0f ? eps : -eps); };
@@ -212,6 +238,7 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
         const int pair_idx = mt_pair_slot(a, f);
         if (a.pair_kind && a.pair_kind[pair_idx] != NT_PAIR_KIND_MESH_TRIANGLE) continue;  // another leg's pair (uniform)
         const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
+        if (!a.hull_points && (a.shape_type[s0] == GEO_CONVEX_MESH || a.shape_type[s1] == GEO_CONVEX_MESH)) continue;  // (uniform) no hull table
         PairSetup c;
         pair_setup(a, s0, s1, c);
         __syncthreads();  // every lane has read the pair before it is rewritten as (mesh, convex)
@@ -425,6 +452,7 @@ extern "C" nt_status nt_mesh_triangle_pairs(const nt_mesh_triangle_args* a, void
     if (a->reduce && (!a->shape_aabb_lower || !a->shape_aabb_upper || !a->shape_voxel_res)) return NT_ERR_INVALID_ARG;
     if (a->pair_world_prefix ? (a->worlds <= 0 || a->pairs_per_world <= 0) : a->pair_count < 0) return NT_ERR_INVALID_ARG;
     if ((a->block_bounds == nullptr) != (a->shape_block_start == nullptr)) return NT_ERR_INVALID_ARG;
+    if ((a->hull_points == nullptr) != (a->shape_hull_range == nullptr)) return NT_ERR_INVALID_ARG;
     long long blocks = a->pair_world_prefix ? (long long)a->worlds * a->pairs_per_world : (long long)a->pair_count;
     if (blocks == 0) return NT_OK;
 #ifdef NT_EMULATED_GRID

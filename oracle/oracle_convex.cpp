@@ -1270,13 +1270,27 @@ int convex_pair_contacts(const o_model* m, int shape_a, int shape_b, const float
 //              collision_core.py:1218-1276, back-face culling, compute_gjk_mpr_contacts with the TRIANGLE support map and Minkowski
 //              seed) written with write_contact_to_reducer (:2059-2096)
 // Warp's BVH is native code: the query here tests every triangle's float32 bounds against the query box, ends inclusive (the set a
-// BVH walk returns; triangle order does not matter to the consumers).  CONVEX_MESH partners are not restated.
+// BVH walk returns; triangle order does not matter to the consumers).  Partners: the primitives and CONVEX_MESH hulls.
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
 void tight_aabb_from_support(const Geom& g, quat orientation, vec3 center_pos, vec3& lo, vec3& hi) {
     mat33 rot_mat_t = transpose(quat_to_matrix(orientation));
     vec3 local_x(rot_mat_t(0, 0), rot_mat_t(1, 0), rot_mat_t(2, 0)), local_y(rot_mat_t(0, 1), rot_mat_t(1, 1), rot_mat_t(2, 1)),
         local_z(rot_mat_t(0, 2), rot_mat_t(1, 2), rot_mat_t(2, 2));
+    if (g.type == GEO_CONVEX_MESH) {  // collision_core.py:491-523: one pass over the hull's vertices, axes pre-scaled
+        vec3 scaled_x = cw_mul(local_x, g.scale), scaled_y = cw_mul(local_y, g.scale), scaled_z = cw_mul(local_z, g.scale);
+        float min_x = 1.0e10f, max_x = -1.0e10f, min_y = 1.0e10f, max_y = -1.0e10f, min_z = 1.0e10f, max_z = -1.0e10f;
+        for (int i = 0; i < g.count; ++i) {
+            vec3 p = ld3(g.points, i);
+            float vx = dot(p, scaled_x), vy = dot(p, scaled_y), vz = dot(p, scaled_z);
+            min_x = fminw(min_x, vx); max_x = fmaxw(max_x, vx);
+            min_y = fminw(min_y, vy); max_y = fmaxw(max_y, vy);
+            min_z = fminw(min_z, vz); max_z = fmaxw(max_z, vz);
+        }
+        lo = vec3(min_x, min_y, min_z) + center_pos;
+        hi = vec3(max_x, max_y, max_z) + center_pos;
+        return;
+    }
     float max_x = dot(local_x, support_map(g, local_x));
     float max_y = dot(local_y, support_map(g, local_y));
     float max_z = dot(local_z, support_map(g, local_z));
@@ -1293,6 +1307,7 @@ void tight_aabb_from_support(const Geom& g, quat orientation, vec3 center_pos, v
 extern "C" int o_mesh_triangle_contacts(int n_pairs, const int* pairs, const int* shape_type, const float* shape_transform,
                                         const float* shape_data, const float* shape_gap, const int* vertex_start,
                                         const int* tri_start, const int* tri_count, const float* vertices, const int* indices,
+                                        const int* hull_start, const int* hull_count, const float* hull_points,
                                         int* tri_out, int tri_cap, int* n_tri, float* out, int cap) {
     int nt = 0, nc = 0;
     for (int k = 0; k < n_pairs; ++k) {
@@ -1313,6 +1328,18 @@ extern "C" int o_mesh_triangle_contacts(int n_pairs, const int* pairs, const int
         Geom gq;
         gq.type = shape_type[non_mesh_shape];
         gq.scale = vec3(shape_data[4 * non_mesh_shape], shape_data[4 * non_mesh_shape + 1], shape_data[4 * non_mesh_shape + 2]);
+        if (gq.type == GEO_CONVEX_MESH) {  // extract_shape_data: the hull's vertex table; _shape_center (support_function.py:448-464):
+            if (!hull_points || hull_count[non_mesh_shape] <= 0) continue;  // the centre of its scaled bounds seeds MPR / GJK
+            gq.points = hull_points + 3 * hull_start[non_mesh_shape];
+            gq.count = hull_count[non_mesh_shape];
+            vec3 first = cw_mul(ld3(gq.points, 0), gq.scale), lower = first, upper = first;
+            for (int i = 1; i < gq.count; ++i) {
+                vec3 point = cw_mul(ld3(gq.points, i), gq.scale);
+                lower = vmin(lower, point);
+                upper = vmax(upper, point);
+            }
+            gq.center = 0.5f * (lower + upper);
+        }
         vec3 aabb_lower, aabb_upper;
         tight_aabb_from_support(gq, X_mesh_shape.q, pos_in_mesh, aabb_lower, aabb_upper);
         vec3 mesh_scale(shape_data[4 * mesh_shape], shape_data[4 * mesh_shape + 1], shape_data[4 * mesh_shape + 2]);
@@ -1329,9 +1356,7 @@ extern "C" int o_mesh_triangle_contacts(int n_pairs, const int* pairs, const int
         const float* pts = vertices + 3 * vertex_start[mesh_shape];
         const int* idx = indices + 3 * tri_start[mesh_shape];
         // shape B of every triangle pair (extract_shape_data)
-        Geom gb0;
-        gb0.type = gq.type;
-        gb0.scale = gq.scale;
+        Geom gb0 = gq;
         float margin_offset_b = margin_non_mesh, margin_offset_a = margin_mesh;
         for (int t = 0; t < tri_count[mesh_shape]; ++t) {
             int idx0 = idx[3 * t], idx1 = idx[3 * t + 1], idx2 = idx[3 * t + 2];

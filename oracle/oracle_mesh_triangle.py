@@ -48,7 +48,11 @@ def triangle_contacts(s):
     n = lib.o_mesh_triangle_contacts(len(pairs), p(pairs, np.int32), p(s["shape_type"], np.int32), p(s["shape_transform"], np.float32),
                                      p(s["shape_data"], np.float32), p(s["shape_gap"], np.float32), p(s["vertex_start"], np.int32),
                                      p(s["tri_start"], np.int32), p(s["tri_count"], np.int32), p(s["vertices"], np.float32),
-                                     p(s["indices"], np.int32), tri_out.ctypes.data_as(C.c_void_p), tri_cap, C.byref(n_tri),
+                                     p(s["indices"], np.int32),
+                                     p(s.get("hull_start", np.zeros(len(s["shape_gap"]), np.int32)), np.int32),
+                                     p(s.get("hull_count", np.zeros(len(s["shape_gap"]), np.int32)), np.int32),
+                                     p(s["hull_points"] if len(s.get("hull_points", ())) else np.zeros((1, 3), np.float32), np.float32),
+                                     tri_out.ctypes.data_as(C.c_void_p), tri_cap, C.byref(n_tri),
                                      out.ctypes.data_as(C.c_void_p), cap)
     assert n <= cap and n_tri.value <= tri_cap
     triples = tri_out[: n_tri.value]

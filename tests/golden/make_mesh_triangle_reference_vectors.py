@@ -88,6 +88,9 @@ def run(s, reverse):
             v0, nv, t0, nt = int(s["vertex_start"][k]), int(s["vertex_count"][k]), int(s["tri_start"][k]), int(s["tri_count"][k])
             source[k] = wp.Mesh(points=A(s["vertices"][v0:v0 + nv], wp.vec3),
                                 indices=A(s["indices"][t0:t0 + nt].reshape(-1), wp.int32)).id
+        elif s["hull_count"][k] > 0:  # CONVEX_MESH partner: wp.Mesh.points of the hull
+            h0, nh = int(s["hull_start"][k]), int(s["hull_count"][k])
+            source[k] = wp.Mesh(points=A(s["hull_points"][h0:h0 + nh], wp.vec3)).id
     P = len(s["pairs"])
     max_tri = int(s["tri_count"].sum()) * max(P, 1) + 8
     xf = A(s["shape_transform"], wp.transform)

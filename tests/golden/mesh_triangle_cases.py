@@ -11,9 +11,9 @@ from mesh_plane_cases import _quat
 from reduce_cases import voxel_resolution
 
 CASES = ["box_on_grid", "sphere_on_terrain", "capsule_margins_scaled", "cylinder_and_cone", "mirrored_mesh", "ellipsoid_in_bowl",
-         "separated"]
+         "separated", "hulls_on_terrain"]
 # GeoType values (newton/_src/geometry/types.py)
-SPHERE, CAPSULE, ELLIPSOID, CYLINDER, BOX, MESH, CONE = 3, 4, 5, 6, 7, 8, 9
+SPHERE, CAPSULE, ELLIPSOID, CYLINDER, BOX, MESH, CONE, CONVEX_MESH = 3, 4, 5, 6, 7, 8, 9, 10
 
 
 def grid_mesh(nx, ny, sx, sy, height=None):
@@ -47,10 +47,18 @@ def _tables(shapes):
                shape_gap=np.array([s["gap"] for s in shapes], np.float32),
                aabb_lo=np.zeros((S, 3), np.float32), aabb_hi=np.zeros((S, 3), np.float32), res=np.ones((S, 3), np.int32),
                vertex_start=np.zeros(S, np.int32), vertex_count=np.zeros(S, np.int32),
-               tri_start=np.zeros(S, np.int32), tri_count=np.zeros(S, np.int32))
-    verts, tris = [], []
-    nv = nt = 0
+               tri_start=np.zeros(S, np.int32), tri_count=np.zeros(S, np.int32),
+               hull_start=np.zeros(S, np.int32), hull_count=np.zeros(S, np.int32))
+    verts, tris, hulls = [], [], []
+    nv = nt = nh = 0
     for k, s in enumerate(shapes):
+        if s.get("hull") is not None:  # CONVEX_MESH partner: its vertex table (wp.Mesh.points of the hull), scaled local AABB
+            h = np.asarray(s["hull"], np.float32)
+            sc = np.asarray(s["scale"], np.float32)
+            out["aabb_lo"][k], out["aabb_hi"][k] = (h * sc).min(axis=0), (h * sc).max(axis=0)
+            out["hull_start"][k], out["hull_count"][k] = nh, len(h)
+            hulls.append(h)
+            nh += len(h)
         if s.get("points") is None:
             continue
         p, t = np.asarray(s["points"], np.float32), np.asarray(s["tris"], np.int32)
@@ -66,6 +74,7 @@ def _tables(shapes):
         nt += len(t)
     out["vertices"] = np.concatenate(verts).astype(np.float32) if verts else np.zeros((0, 3), np.float32)
     out["indices"] = np.concatenate(tris).astype(np.int32) if tris else np.zeros((0, 3), np.int32)  # mesh-local vertex ids
+    out["hull_points"] = np.concatenate(hulls).astype(np.float32) if hulls else np.zeros((0, 3), np.float32)
     return out
 
 
@@ -77,8 +86,8 @@ def scene(name):
     def mesh(points, tris, xform, scale=(1, 1, 1), margin=0.0, gap=0.002):
         return dict(type=MESH, points=points, tris=tris, xform=xform, scale=list(scale), margin=margin, gap=gap)
 
-    def prim(t, xform, scale, margin=0.0, gap=0.002):
-        return dict(type=t, xform=xform, scale=list(scale), margin=margin, gap=gap)
+    def prim(t, xform, scale, margin=0.0, gap=0.002, hull=None):
+        return dict(type=t, xform=xform, scale=list(scale), margin=margin, gap=gap, hull=hull)
 
     if name == "box_on_grid":  # a box resting 1 mm inside a flat 8 x 8 grid, slightly rotated: face manifolds on many triangles
         p, t = grid_mesh(8, 8, 0.4, 0.4)
@@ -113,6 +122,18 @@ def scene(name):
         shapes = [mesh(p, t, [0, 0, 0, *ident], gap=0.004),
                   prim(ELLIPSOID, [0.0, 0.0, 0.049, *_quat((1, 0, 0), 0.1)], (0.16, 0.12, 0.05), gap=0.004)]
         pairs = [(1, 0)]
+    elif name == "hulls_on_terrain":  # two convex hulls (a 20-vertex polytope, non-uniformly scaled; a wedge) on a bumpy terrain:
+        # face, edge and vertex contacts; the hull's Minkowski seed is the centre of its scaled bounds, not its origin
+        rng = np.random.default_rng(77)
+        d = rng.normal(size=(20, 3))
+        poly = (d / np.linalg.norm(d, axis=1, keepdims=True) * 0.08 + np.array([0.01, -0.005, 0.02])).astype(np.float32)
+        wedge = np.array([(-0.1, -0.06, 0.0), (0.1, -0.06, 0.0), (0.1, 0.06, 0.0), (-0.1, 0.06, 0.0), (-0.1, -0.06, 0.07), (-0.1, 0.06, 0.07)],
+                         np.float32)
+        p, t = grid_mesh(12, 12, 0.5, 0.5, height=lambda x, y: 0.015 * np.sin(9 * x) * np.cos(7 * y))
+        shapes = [mesh(p, t, [0, 0, 0, *_quat((0, 1, 0), 0.05)], gap=0.003),
+                  prim(CONVEX_MESH, [-0.2, 0.1, 0.062, *_quat((1, 0.3, 0.2), 0.5)], (1.0, 0.8, 1.2), hull=poly, gap=0.003),
+                  prim(CONVEX_MESH, [0.2, -0.1, 0.004, *_quat((0, 0, 1), 0.7)], (1.0, 1.0, 1.0), hull=wedge, margin=0.001, gap=0.002)]
+        pairs = [(0, 1), (0, 2)]
     else:  # a V-shaped valley of large triangles: their bounds overlap the box's query AABB, the surfaces stay 5 cm away -- every
         # triangle pair buffers ONE contact beyond margin + gap (the writer's gap test drops them after the reduction)
         p, t = grid_mesh(2, 2, 0.4, 0.4, height=lambda x, y: 0.3 * abs(x))

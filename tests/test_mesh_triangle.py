@@ -118,6 +118,9 @@ def run_mesh_triangle(lib, s, reduce=1, capacity=None, start=0, stream=None, to_
     a.out_data, a.capacity = put("odata", np.zeros((capacity, 9), np.float32)), capacity
     a.out_radius = put("oradius", np.full((capacity, 2), -1.0, np.float32))
     a.out_blk = put("blk", np.full((slots, 2), -7, np.int32))
+    if int(s["hull_count"].sum()) > 0:  # CONVEX_MESH partners: their vertex tables
+        a.hull_points = put("hp", s["hull_points"])
+        a.shape_hull_range = put("hr", np.stack([s["hull_start"], s["hull_count"]], axis=1).astype(np.int32))
     if blocks:  # the bounds of every 64 consecutive triangles: the scan skips blocks that miss the query box (same candidates)
         from newton_amd.mesh import triangle_block_bounds
 
