@@ -367,9 +367,7 @@ nt_status nt_broadphase_explicit(const nt_broadphase_in* in, const int32_t* pair
  * TextureSDFData (:126-160) with the CUDA textures replaced by the plain arrays they hold: a coarse float grid sampled at the
  * subgrid corners, packed (subgrid_size+1)^3 blocks for the narrow band (float32 / uint16 / uint8, :487-690) and the
  * indirection slots (10-bit block coordinates, 0xFFFFFFFF = empty, 0xFFFFFFFE = "use the coarse grid", :44-45).
- * Built on the host by newton_amd.sdf (create_texture_sdf_from_mesh / _primitive). All pointers are device pointers into GLOBAL
- * memory, and each array is smaller than 4 GiB: the samplers address them with 32-bit byte offsets (tex_size <= 1625 for float32
- * texels; the standalone entry points that take one nt_sdf on the host check it and return NT_ERR_INVALID_ARG). */
+ * Built on the host by newton_amd.sdf (create_texture_sdf_from_mesh / _primitive). All pointers are device pointers. */
 typedef struct {
     const float* coarse;       /* [cz+1][cy+1][cx+1] */
     const void* subgrid;       /* [tex_size]^3, z-major; element type by `quantization` */
@@ -381,13 +379,6 @@ typedef struct {
     int32_t scale_baked;       /* the shape scale is already inside the SDF values */
     float box_lower[3], box_upper[3], inv_dx[3], voxel_size[3];
     float voxel_radius, min_value, value_range;
-    /* layout of `subgrid` (round 6).  0: the reference's texture, [tex_size]^3 z-major -- a (subgrid_size+1)^3 block is then
-     * (subgrid_size+1)^2 separate rows, one cache line each.  1: block-linear -- block (sx, sy, sz) of the texture (the slot's 10-bit
-     * coordinates) starts at ((sz * tex_blocks + sy) * tex_blocks + sx) * (subgrid_size+1)^3 elements and holds its texels
-     * [lz][ly][lx]: the same values at other addresses, a block in a dozen consecutive lines (newton_amd.sdf_device uploads this
-     * form).  tex_blocks = tex_size / (subgrid_size+1); spd_magic = ceil(2^16 / (subgrid_size+1)): x / (subgrid_size+1) ==
-     * (x * spd_magic) >> 16 for every texel coordinate.  Zero-initialised descriptors keep layout 0. */
-    int32_t subgrid_layout, tex_blocks, spd_magic;
 } nt_sdf;
 /* texture_sample_sdf (:1129-1135) and the centred-difference gradient of the narrow phase (:1619-1697) at local points
  * [n][3]; either output may be NULL. */

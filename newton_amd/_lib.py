@@ -152,8 +152,7 @@ class nt_sdf(C.Structure):
                 ("cz", C.c_int32), ("tex_size", C.c_int32), ("subgrid_size", C.c_int32), ("quantization", C.c_int32),
                 ("scale_baked", C.c_int32), ("box_lower", C.c_float * 3), ("box_upper", C.c_float * 3),
                 ("inv_dx", C.c_float * 3), ("voxel_size", C.c_float * 3), ("voxel_radius", C.c_float),
-                ("min_value", C.c_float), ("value_range", C.c_float), ("subgrid_layout", C.c_int32), ("tex_blocks", C.c_int32),
-                ("spd_magic", C.c_int32)]
+                ("min_value", C.c_float), ("value_range", C.c_float)]
 
 
 class nt_mesh_sdf_args(C.Structure):

@@ -31,117 +31,35 @@ namespace {
 
 constexpr uint32_t SLOT_LINEAR = 0xFFFFFFFEu;
 
-// Loads of SDF data (indirection slots, subgrid texels, coarse grid) as GLOBAL loads.  The descriptors arrive through memory, so the
-// pointers inside them are generic to the compiler and every sample compiled to flat_load -- which counts on the LDS counter too: a
-// wave's s_waitcnt lgkmcnt(0) in front of an LDS read then also waits for the texel fetch in flight, in kernels that keep their lists
-// in LDS (round 6).  Texel indices are 32-bit: tex_size^3 < 2^32 (newton_amd.sdf_device checks it), 64-bit multiplies cost four
-// quarter-rate instructions each on a stage bound by instruction issue.
-// ldg_*(base, byte offset): the offset is 32-bit (every SDF array is below 4 GiB: newton_amd.sdf_device checks it), so a load through a
-// wave-uniform descriptor is `global_load v, v_offset, s[base]` with no address arithmetic at all.
-#ifdef NT_EMULATED_GRID
-template <class T>
-NT_DI T ldg_at(const void* base, uint32_t boff) { T w; __builtin_memcpy(&w, (const char*)base + boff, sizeof(T)); return w; }
-NT_DI uint32_t ldg_u32_a2(const void* base, uint32_t boff) { return ldg_at<uint32_t>(base, boff); }
-NT_DI uint16_t ldg_u16_a1(const void* base, uint32_t boff) { return ldg_at<uint16_t>(base, boff); }
-NT_DI void ldg_f32x2_a4(const void* base, uint32_t boff, float& v0, float& v1) { v0 = ldg_at<float>(base, boff); v1 = ldg_at<float>(base, boff + 4); }
-#else
-#define NT_GLOBAL __attribute__((address_space(1)))
-typedef uint32_t __attribute__((aligned(2))) nt_u32_a2;                    // two uint16 texels, 2-byte aligned
-typedef uint16_t __attribute__((aligned(1))) nt_u16_a1;                    // two uint8 texels
-typedef float nt_f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));  // two float32 texels, 4-byte aligned
-template <class T>
-NT_DI T ldg_at(const void* base, uint32_t boff) { return *(const NT_GLOBAL T*)((const NT_GLOBAL char*)base + boff); }
-NT_DI uint32_t ldg_u32_a2(const void* base, uint32_t boff) { return *(const NT_GLOBAL nt_u32_a2*)((const NT_GLOBAL char*)base + boff); }
-NT_DI uint16_t ldg_u16_a1(const void* base, uint32_t boff) { return *(const NT_GLOBAL nt_u16_a1*)((const NT_GLOBAL char*)base + boff); }
-NT_DI void ldg_f32x2_a4(const void* base, uint32_t boff, float& v0, float& v1) {
-    const nt_f32x2_a4 w = *(const NT_GLOBAL nt_f32x2_a4*)((const NT_GLOBAL char*)base + boff);
-    v0 = w.x; v1 = w.y;
-}
-#endif
-// a * b + c for operands below 2^24 (v_mad_u32_u24: full rate; the 32-bit multiply is a quarter-rate instruction).  Below 4 GiB per
-// array a texture has tex_size <= 1625, so z * tex_size + y < 2^24 like every coarse-grid index
-#ifdef NT_EMULATED_GRID
-NT_DI uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
-#else
-NT_DI uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
-#endif
-// element index of texel (x, y, z) of the subgrid texture.  Block-linear layout (nt_sdf.subgrid_layout, newton_hip.h): the block
-// the texel belongs to, then its place inside the block -- a wave's taps around one surface patch then share a dozen cache lines
-// instead of one line per (y, z) row of the texture.
-NT_DI uint32_t texel_index_in_block(const nt_sdf& s, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t lx, uint32_t ly, uint32_t lz) {
-    const uint32_t spd = (uint32_t)s.subgrid_size + 1u, nb = (uint32_t)s.tex_blocks;
-    const uint32_t blk = mad24(mad24(sz, nb, sy), nb, sx), loc = mad24(mad24(lz, spd, ly), spd, lx);
-    return mad24(blk, spd * spd * spd, loc);  // (blocks < 2^24 / spd^3 ... checked on the host: sdf_fits_32bit_offsets)
-}
-NT_DI uint32_t texel_index(const nt_sdf& s, int x, int y, int z) {
-    if (s.subgrid_layout == 1) {
-        const uint32_t spd = (uint32_t)s.subgrid_size + 1u, mg = (uint32_t)s.spd_magic;
-        const uint32_t sx = mad24((uint32_t)x, mg, 0u) >> 16, sy = mad24((uint32_t)y, mg, 0u) >> 16, sz = mad24((uint32_t)z, mg, 0u) >> 16;
-        return texel_index_in_block(s, sx, sy, sz, (uint32_t)x - sx * spd, (uint32_t)y - sy * spd, (uint32_t)z - sz * spd);
-    }
-    const uint32_t T = (uint32_t)s.tex_size;
-    return mad24(mad24((uint32_t)z, T, (uint32_t)y), T, (uint32_t)x);
-}
-// texel (x + 1, y, z) follows (x, y, z) in memory: always in the texture layout (callers stay inside a row), inside a block otherwise
-NT_DI bool texel_pair_adjacent(const nt_sdf& s, int x) {
-    if (s.subgrid_layout != 1) return true;
-    const uint32_t spd = (uint32_t)s.subgrid_size + 1u, sx = mad24((uint32_t)x, (uint32_t)s.spd_magic, 0u) >> 16;
-    return (uint32_t)x - sx * spd + 1u < spd;
-}
-NT_DI uint32_t slot_at(const nt_sdf& s, int bx, int by, int bz) {  // the indirection slot of coarse cell (bx, by, bz)
-    return ldg_at<uint32_t>(s.slots, 4u * mad24(mad24((uint32_t)bx, (uint32_t)s.cy, (uint32_t)by), (uint32_t)s.cz, (uint32_t)bz));
+NT_DI float texel(const nt_sdf& s, int x, int y, int z) {  // subgrid "texture" read at texel (x, y, z), normalised formats -> [0,1]
+    const size_t i = ((size_t)z * s.tex_size + y) * s.tex_size + x;
+    if (s.quantization == 4) return reinterpret_cast<const float*>(s.subgrid)[i];
+    if (s.quantization == 2) return (float)reinterpret_cast<const uint16_t*>(s.subgrid)[i] * (1.0f / 65535.0f);
+    return (float)reinterpret_cast<const uint8_t*>(s.subgrid)[i] * (1.0f / 255.0f);
 }
 
-NT_DI float texel_i(const nt_sdf& s, uint32_t i) {  // element i of the subgrid array, normalised formats -> [0,1]
-    if (s.quantization == 4) return ldg_at<float>(s.subgrid, 4u * i);
-    if (s.quantization == 2) return (float)ldg_at<uint16_t>(s.subgrid, 2u * i) * (1.0f / 65535.0f);
-    return (float)ldg_at<uint8_t>(s.subgrid, i) * (1.0f / 255.0f);
-}
-NT_DI float texel(const nt_sdf& s, int x, int y, int z) { return texel_i(s, texel_index(s, x, y, z)); }  // texel (x, y, z) of the texture
-
-// two x-adjacent texels (elements i, i + 1) with ONE load: the uint16 / uint8 formats pack them into a dword / a word
+// two x-adjacent texels (x, x + 1 in the same row) with ONE load: the uint16 / uint8 formats pack them into a dword / a word
 // (2-byte aligned dword loads are legal on gfx950), float32 into a dwordx2.  Same values as two texel() calls, half the requests
 // of a sampler whose eight taps are four such pairs.
-NT_DI void texel_pair_i(const nt_sdf& s, uint32_t i, float& v0, float& v1) {
+NT_DI void texel_pair(const nt_sdf& s, int x, int y, int z, float& v0, float& v1) {
+    const size_t i = ((size_t)z * s.tex_size + y) * s.tex_size + x;
     if (s.quantization == 4) {
-        ldg_f32x2_a4(s.subgrid, 4u * i, v0, v1);
+        float w[2];
+        __builtin_memcpy(w, reinterpret_cast<const float*>(s.subgrid) + i, 8);
+        v0 = w[0]; v1 = w[1];
     } else if (s.quantization == 2) {
-        const uint32_t w = ldg_u32_a2(s.subgrid, 2u * i);
+        uint32_t w;
+        __builtin_memcpy(&w, reinterpret_cast<const uint16_t*>(s.subgrid) + i, 4);
         v0 = (float)(w & 0xFFFFu) * (1.0f / 65535.0f);
         v1 = (float)(w >> 16) * (1.0f / 65535.0f);
     } else {
-        const uint16_t w = ldg_u16_a1(s.subgrid, i);
+        uint16_t w;
+        __builtin_memcpy(&w, reinterpret_cast<const uint8_t*>(s.subgrid) + i, 2);
         v0 = (float)(w & 0xFFu) * (1.0f / 255.0f);
         v1 = (float)(w >> 8) * (1.0f / 255.0f);
     }
 }
-NT_DI void texel_pair(const nt_sdf& s, int x, int y, int z, float& v0, float& v1) { texel_pair_i(s, texel_index(s, x, y, z), v0, v1); }
-// texel (lx, ly, lz) of the block an indirection slot names, and the element strides of one step in y / z from there
-NT_DI uint32_t texel_index_slot(const nt_sdf& s, uint32_t slot, int lx, int ly, int lz, uint32_t& row, uint32_t& plane) {
-    const uint32_t sx = slot & 0x3FFu, sy = (slot >> 10) & 0x3FFu, sz = (slot >> 20) & 0x3FFu, spd = (uint32_t)s.subgrid_size + 1u;
-    if (s.subgrid_layout == 1) {
-        row = spd;
-        plane = spd * spd;
-        return texel_index_in_block(s, sx, sy, sz, (uint32_t)lx, (uint32_t)ly, (uint32_t)lz);
-    }
-    const uint32_t T = (uint32_t)s.tex_size;
-    row = T;
-    plane = T * T;
-    return mad24(mad24(mad24(sz, spd, (uint32_t)lz), T, mad24(sy, spd, (uint32_t)ly)), T, mad24(sx, spd, (uint32_t)lx));
-}
 
-// host side: every array of the descriptor below 4 GiB (the samplers' 32-bit byte offsets)
-inline bool sdf_fits_32bit_offsets(const nt_sdf& s) {
-    const unsigned long long T = (unsigned long long)(s.tex_size > 0 ? s.tex_size : 0), lim = 1ull << 32;
-    const unsigned long long coarse = 4ull * (unsigned long long)(s.cx + 1) * (unsigned long long)(s.cy + 1) * (unsigned long long)(s.cz + 1);
-    if (s.subgrid_layout == 1) {  // block-linear: the block count and spd^3 are operands of a 24-bit multiply
-        const unsigned long long spd = (unsigned long long)s.subgrid_size + 1ull, nb = (unsigned long long)(s.tex_blocks > 0 ? s.tex_blocks : 0);
-        if (nb * spd != T || nb * nb * nb >= (1ull << 24) || spd * spd * spd >= (1ull << 24) || (unsigned long long)s.spd_magic != ((1ull << 16) + spd - 1ull) / spd) return false;
-    } else if (s.subgrid_layout != 0) {
-        return false;
-    }
-    return T * T * T * (unsigned long long)s.quantization < lim && coarse < lim;
-}
 struct Cell {
     int ix, iy, iz, bx, by, bz;
     float tx, ty, tz;
@@ -164,7 +82,7 @@ NT_DI Cell locate(const nt_sdf& s, vec3 f) {  // _locate_cell
     c.bx = clampi((int)((float)c.ix * f2c), 0, s.cx - 1);
     c.by = clampi((int)((float)c.iy * f2c), 0, s.cy - 1);
     c.bz = clampi((int)((float)c.iz * f2c), 0, s.cz - 1);
-    c.slot = slot_at(s, c.bx, c.by, c.bz);
+    c.slot = s.slots[((size_t)c.bx * s.cy + c.by) * s.cz + c.bz];
     return c;
 }
 
@@ -182,20 +100,20 @@ NT_DI float sample_clamped(const nt_sdf& s, vec3 clamped, float diff_mag) {
         ty = ((float)c.iy + c.ty) * f2c - (float)c.by;
         tz = ((float)c.iz + c.tz) * f2c - (float)c.bz;
         const int sx = s.cx + 1, sy = s.cy + 1;
-        const uint32_t g0 = 4u * mad24(mad24((uint32_t)c.bz, (uint32_t)sy, (uint32_t)c.by), (uint32_t)sx, (uint32_t)c.bx);
-        const uint32_t g1 = g0 + 4u * ((uint32_t)sx * (uint32_t)sy), row = 4u * (uint32_t)sx;
-        v000 = ldg_at<float>(s.coarse, g0); v100 = ldg_at<float>(s.coarse, g0 + 4u);
-        v010 = ldg_at<float>(s.coarse, g0 + row); v110 = ldg_at<float>(s.coarse, g0 + row + 4u);
-        v001 = ldg_at<float>(s.coarse, g1); v101 = ldg_at<float>(s.coarse, g1 + 4u);
-        v011 = ldg_at<float>(s.coarse, g1 + row); v111 = ldg_at<float>(s.coarse, g1 + row + 4u);
+        const float* g = s.coarse + ((size_t)c.bz * sy + c.by) * sx + c.bx;
+        v000 = g[0]; v100 = g[1]; v010 = g[sx]; v110 = g[sx + 1];
+        g += (size_t)sx * sy;
+        v001 = g[0]; v101 = g[1]; v011 = g[sx]; v111 = g[sx + 1];
     } else {
         needs_scale = true;
-        uint32_t row, plane;
-        const uint32_t i0 = texel_index_slot(s, c.slot, c.ix - c.bx * s.subgrid_size, c.iy - c.by * s.subgrid_size, c.iz - c.bz * s.subgrid_size, row, plane);
-        texel_pair_i(s, i0, v000, v100);  // (x + 1 <= the block's last sample: the cell index inside the block is < subgrid_size)
-        texel_pair_i(s, i0 + row, v010, v110);
-        texel_pair_i(s, i0 + plane, v001, v101);
-        texel_pair_i(s, i0 + plane + row, v011, v111);
+        const int spd = s.subgrid_size + 1;
+        const int ox = (int)(c.slot & 0x3FFu) * spd + (c.ix - c.bx * s.subgrid_size);
+        const int oy = (int)((c.slot >> 10) & 0x3FFu) * spd + (c.iy - c.by * s.subgrid_size);
+        const int oz = (int)((c.slot >> 20) & 0x3FFu) * spd + (c.iz - c.bz * s.subgrid_size);
+        texel_pair(s, ox, oy, oz, v000, v100);  // (ox + 1 <= the block's last sample: the cell index inside the block is < subgrid_size)
+        texel_pair(s, ox, oy + 1, oz, v010, v110);
+        texel_pair(s, ox, oy, oz + 1, v001, v101);
+        texel_pair(s, ox, oy + 1, oz + 1, v011, v111);
     }
     float c00 = v000 + (v100 - v000) * tx;
     float c10 = v010 + (v110 - v010) * tx;
@@ -224,14 +142,14 @@ NT_DI float fetch_linear(const nt_sdf& s, bool coarse, float ux, float uy, float
         const int xa = clampi(x0, 0, sx - 1), xb = clampi(x0 + 1, 0, sx - 1), ya = clampi(y0, 0, sy - 1), yb = clampi(y0 + 1, 0, sy - 1),
                   za = clampi(z0, 0, sz - 1), zb = clampi(z0 + 1, 0, sz - 1);
         const float* g = s.coarse;
-        auto at = [&](int xx, int yy, int zz) { return ldg_at<float>(g, 4u * mad24(mad24((uint32_t)zz, (uint32_t)sy, (uint32_t)yy), (uint32_t)sx, (uint32_t)xx)); };
+        auto at = [&](int xx, int yy, int zz) { return g[((size_t)zz * sy + yy) * sx + xx]; };
         v000 = at(xa, ya, za); v100 = at(xb, ya, za); v010 = at(xa, yb, za); v110 = at(xb, yb, za);
         v001 = at(xa, ya, zb); v101 = at(xb, ya, zb); v011 = at(xa, yb, zb); v111 = at(xb, yb, zb);
     } else {
         const int T = s.tex_size;
         const int xa = clampi(x0, 0, T - 1), xb = clampi(x0 + 1, 0, T - 1), ya = clampi(y0, 0, T - 1), yb = clampi(y0 + 1, 0, T - 1),
                   za = clampi(z0, 0, T - 1), zb = clampi(z0 + 1, 0, T - 1);
-        if (xb == xa + 1 && texel_pair_adjacent(s, xa)) {  // (else: the clamped border of the texture / the last texel of a block)
+        if (xb == xa + 1) {  // (always, except at the clamped border of the texture)
             texel_pair(s, xa, ya, za, v000, v100); texel_pair(s, xa, yb, za, v010, v110);
             texel_pair(s, xa, ya, zb, v001, v101); texel_pair(s, xa, yb, zb, v011, v111);
         } else {
@@ -606,6 +524,7 @@ __global__ void __launch_bounds__(256) mesh_sdf_collide_kernel(nt_mesh_sdf_args 
 // in LDS and offer it to the pair's table.  After both modes the <= 245 winners read their record back through the fingerprint
 // (a list overflow -- meshes with hundreds of near edges -- falls back to recomputing the winner: same instructions, same bits).
 constexpr int HIT_CAP = 128;
+constexpr int SLOT_LDS = 512;
 struct HitLds {
     int fp[HIT_CAP];       // fingerprint of the survivor (edge << 2 | mode << 1); -1 once the resolve rejected it
     float mid[HIT_CAP];    // SDF value at its clamped midpoint (edge_cull)
@@ -621,6 +540,7 @@ struct HitLds {
 __global__ void __launch_bounds__(256) NT_SDF_OCCUPANCY mesh_sdf_collide_reduced_kernel(nt_mesh_sdf_args a, nt_contact_reduce_shapes r) {
     __shared__ RedLds L;
     __shared__ HitLds H;
+    __shared__ uint32_t slot_lds[SLOT_LDS];  // the SDF's indirection table of the current mode (every sample reads it first)
     const int t = threadIdx.x;
     const int pair_count = live_pair_count(a);
     for (int f = blockIdx.x; f < pair_count; f += gridDim.x) {
@@ -647,8 +567,13 @@ __global__ void __launch_bounds__(256) NT_SDF_OCCUPANCY mesh_sdf_collide_reduced
                           r.shape_aabb_upper + 3 * tri_shape, r.shape_voxel_res + 3 * tri_shape, fp);
             };
             const int seg = H.n < HIT_CAP ? H.n : HIT_CAP;  // this mode's survivors start here (uniform: read after a barrier)
-            // (rounds 3-5 copied the SDF's indirection table into LDS here; the samplers read SDF data with global loads since round 6,
-            // and the dense stages below replaced this kernel on the product path)
+            // A sample is two dependent reads (indirection slot, then texels); with the small slot table in LDS only the texel
+            // fetch pays a trip to L2.  (The winner pass below recomputes through the global table: same values.)
+            const int n_slots = c.s.cx * c.s.cy * c.s.cz;
+            if (n_slots <= SLOT_LDS) {
+                for (int k = t; k < n_slots; k += blockDim.x) slot_lds[k] = c.s.slots[k];
+                c.s.slots = slot_lds;
+            }
             __syncthreads();
             for (int e = t; e < c.ne; e += blockDim.x) {
                 float mid;
@@ -1151,10 +1076,13 @@ NT_DI float sample_at_voxel(const nt_sdf& s, int ix, int iy, int iz) {  // textu
     const float f2c = 1.0f / (float)s.subgrid_size;
     const int bx = clampi((int)((float)ix * f2c), 0, s.cx - 1), by = clampi((int)((float)iy * f2c), 0, s.cy - 1),
               bz = clampi((int)((float)iz * f2c), 0, s.cz - 1);
-    const uint32_t slot = slot_at(s, bx, by, bz);
+    const uint32_t slot = s.slots[((size_t)bx * s.cy + by) * s.cz + bz];
     if (slot < SLOT_LINEAR) {
-        uint32_t row, plane;
-        return texel_i(s, texel_index_slot(s, slot, ix - bx * s.subgrid_size, iy - by * s.subgrid_size, iz - bz * s.subgrid_size, row, plane)) * s.value_range + s.min_value;
+        const int spd = s.subgrid_size + 1;
+        const int ox = (int)(slot & 0x3FFu) * spd + (ix - bx * s.subgrid_size);
+        const int oy = (int)((slot >> 10) & 0x3FFu) * spd + (iy - by * s.subgrid_size);
+        const int oz = (int)((slot >> 20) & 0x3FFu) * spd + (iz - bz * s.subgrid_size);
+        return texel(s, ox, oy, oz) * s.value_range + s.min_value;
     }
     return sample(s, vec3(s.box_lower[0] + (float)ix * s.voxel_size[0], s.box_lower[1] + (float)iy * s.voxel_size[1],
                           s.box_lower[2] + (float)iz * s.voxel_size[2]));
@@ -1337,7 +1265,6 @@ struct HydroPair {
     int sa, sb;
     xform X_b, X_b2a;
     float gap_sum, margin_a, margin_b, kh_a, kh_b;
-    vec3 step_x, step_y, step_z;  // B's voxel steps in A's frame (hydro_pair_load; the corner sampler of the staged face pass)
 };
 // one octree node of shape B: cube of `size` voxels at (x, y, z) (count_iso_voxels_block's body)
 NT_DI bool hydro_node_survives(const HydroPair& p, int x, int y, int z, int size) {
@@ -1403,8 +1330,10 @@ NT_DI void hydro_corner_sample(const HydroPair& p, int x, int y, int z, int i, f
     const vec3 vs(B.voxel_size[0], B.voxel_size[1], B.voxel_size[2]), blo(B.box_lower[0], B.box_lower[1], B.box_lower[2]);
     const vec3 base_b = blo + cw_mul(vec3((float)x, (float)y, (float)z), vs);
     const vec3 base_a = xform_point(p.X_b2a, base_b);
+    const vec3 step_x = xform_vector(p.X_b2a, vec3(vs.x, 0.0f, 0.0f)), step_y = xform_vector(p.X_b2a, vec3(0.0f, vs.y, 0.0f)),
+               step_z = xform_vector(p.X_b2a, vec3(0.0f, 0.0f, vs.z));
     const int ox = mc_cx(i), oy = mc_cy(i), oz = mc_cz(i);
-    const vec3 pa = base_a + (float)ox * p.step_x + (float)oy * p.step_y + (float)oz * p.step_z;  // (the steps: once per pair)
+    const vec3 pa = base_a + (float)ox * step_x + (float)oy * step_y + (float)oz * step_z;
     es = sample_at_voxel(B, x + ox, y + oy, z + oz) - p.margin_b;
     eo = sample(A, pa) - p.margin_a;
 }
@@ -1567,7 +1496,7 @@ struct HydroRedLds {
     float max_pen[HYDRO_ENTRIES];                        // deepest winner of the entry
     unsigned char anchor[HYDRO_ENTRIES];                 // the entry exports an anchor contact
     int n_chunk, n_faces, pair_kept, overflow, rows, row_base;
-    float stage[HYDRO_STAGE][10];  // a tile of faces for the ordered aggregate sums: the ten addends of every face
+    float stage[HYDRO_STAGE][9];  // a tile of face records for the ordered aggregate sums
     signed char stage_bin[HYDRO_STAGE];
 };
 NT_DI unsigned long long hydro_value(float score, int cid) {  // _make_contact_value_fast
@@ -1642,51 +1571,44 @@ NT_DI void hydro_reduce_pair_impl(const nt_hydro_args& a, const HydroPair& p, in
     }
     for (int k = t; k < HYDRO_ENTRIES; k += nt_) { R.ekey[k] = ~0u; R.ucount[k] = 0; }
     __syncthreads();
-    // ---- aggregates of ALL penetrating faces per (exact-normal) bin, face order.  The faces pass through LDS in tiles (every lane
-    // loads one record, coalesced) so that the summing lanes walk LDS instead of paying an HBM round trip per face.
-    // One lane per (bin, component) -- 200 of the workgroup's 256 -- adds the tile's addends of its bin in face order: the same sequence
-    // of additions per component as one lane per bin walking ten sums (rounds 3-5), but a face costs the summing lanes one compare and
-    // one add instead of nine LDS reads and thirteen operations on the lane of the bin the pair's faces crowd into (round 6: the
-    // aggregates were a quarter of this stage, profiles/r04g_hydro_timing.json).  The loading lane forms the addends:
-    // agg_force = sum fw n, weighted_pos_sum = sum fw centre, weight_sum = sum fw, agg_depth_volume = sum (area * -depth) n.
+    // ---- aggregates of ALL penetrating faces per (exact-normal) bin, face order: lane = bin.  The faces pass through LDS in tiles
+    // (every lane loads one record, coalesced) so that the twenty summing lanes walk LDS instead of paying an HBM round trip per face
     {
-        const int my_bin = t / 10, my_comp = t - 10 * my_bin;
-        float acc = 0.0f;
+        vec3 force, wps, adv;
+        float ws = 0.0f;
         unsigned int first = ~0u;
         for (int r0 = 0; r0 < R.n_faces; r0 += HYDRO_STAGE) {
             const int m = R.n_faces - r0 < HYDRO_STAGE ? R.n_faces - r0 : HYDRO_STAGE;
             for (int k = t; k < m; k += nt_) {
                 const float* rec = a.face_rec + HYDRO_FACE_WORDS * (size_t)face_slot(r0 + k);
                 float* o = R.stage[k];
-                const vec3 n(rec[3], rec[4], rec[5]), ctr(rec[0], rec[1], rec[2]);
-                const float fw = rec[7] * rec[8];
-                const vec3 f = fw * n, wp = fw * ctr, dv = (rec[7] * (-rec[6])) * n;
-                o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = wp.x; o[4] = wp.y; o[5] = wp.z; o[6] = fw;
-                o[7] = dv.x; o[8] = dv.y; o[9] = dv.z;
+                o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2]; o[3] = rec[3]; o[4] = rec[4]; o[5] = rec[5];
+                o[6] = rec[6]; o[7] = rec[7]; o[8] = rec[8];
                 R.stage_bin[k] = rec[6] < 0.0f ? (reinterpret_cast<const int*>(rec)[10] & 31) : -1;
             }
             __syncthreads();
-            if (my_bin < RED_BINS) {
-#pragma unroll 4
+            if (t < RED_BINS)
                 for (int k = 0; k < m; ++k) {
-                    const int b = R.stage_bin[k];
-                    const float v = R.stage[k][my_comp];
-                    if (b == my_bin) {
-                        acc += v;
-                        if (first == ~0u) first = (unsigned int)(r0 + k);
-                    }
+                    if (R.stage_bin[k] != t) continue;
+                    const float* rec = R.stage[k];
+                    const vec3 n(rec[3], rec[4], rec[5]), ctr(rec[0], rec[1], rec[2]);
+                    const float fw = rec[7] * rec[8];
+                    force += fw * n;
+                    wps += fw * ctr;
+                    ws += fw;
+                    adv += (rec[7] * (-rec[6])) * n;
+                    if (first == ~0u) first = (unsigned int)(r0 + k);
                 }
-            }
             __syncthreads();
         }
-        if (my_bin < RED_BINS) {
-            R.agg[my_bin][my_comp] = acc;
-            if (my_comp == 0) {
-                R.tdepth[my_bin] = 0.0f;
-                R.tnormal[my_bin][0] = R.tnormal[my_bin][1] = R.tnormal[my_bin][2] = 0.0f;
-                if (first != ~0u) R.ekey[my_bin] = first;
-            }
-        }
+      if (t < RED_BINS) {
+        float* g = R.agg[t];
+        g[0] = force.x; g[1] = force.y; g[2] = force.z; g[3] = wps.x; g[4] = wps.y; g[5] = wps.z; g[6] = ws;
+        g[7] = adv.x; g[8] = adv.y; g[9] = adv.z;
+        R.tdepth[t] = 0.0f;
+        R.tnormal[t][0] = R.tnormal[t][1] = R.tnormal[t][2] = 0.0f;
+        if (first != ~0u) R.ekey[t] = first;
+      }
     }
     if (t < RED_BINS) R.m_unr[t] = R.s1[t] = R.s2[t] = 0.0f;
     __syncthreads();
@@ -2389,9 +2311,6 @@ NT_DI bool hydro_pair_load(const nt_hydro_args& a, int pair_idx, HydroPair& p, b
     p.kh_b = a.shape_kh[p.sb];
     p.X_b = load_xform(a.shape_transform + 7 * p.sb);
     p.X_b2a = xform_inverse(load_xform(a.shape_transform + 7 * p.sa)) * p.X_b;
-    p.step_x = xform_vector(p.X_b2a, vec3(p.B.voxel_size[0], 0.0f, 0.0f));
-    p.step_y = xform_vector(p.X_b2a, vec3(0.0f, p.B.voxel_size[1], 0.0f));
-    p.step_z = xform_vector(p.X_b2a, vec3(0.0f, 0.0f, p.B.voxel_size[2]));
     return true;
 }
 NT_DI void hy_child(int code, int& cx, int& cy, int& cz) { cx = code & 1; cy = (code >> 1) & 1; cz = (code >> 2) & 1; }
@@ -2405,20 +2324,12 @@ NT_DI void hy_voxel(int j, int& x, int& y, int& z) {
 }
 constexpr int HY_STAGE_WAVES = 4;  // waves per workgroup of the wave-per-unit stages (independent: no workgroup barrier)
 constexpr int HY_ROUND = 64;       // iso voxels per marching-cubes round = per chunk of face records
-#ifndef NT_HY_ITEMS
-#define NT_HY_ITEMS 8
-#endif
-constexpr int HY_ITEMS = NT_HY_ITEMS;       // (pair, block) items of one pair a wave walks together (level 4: eight lanes per item; <= 16: item ids are four bits)
-#ifdef NT_HY_UNROLL  // measurement builds: two rounds of the level-1 / corner loops in flight
-#define HY_UNROLL _Pragma("unroll 2")
-#else
-#define HY_UNROLL
-#endif
+constexpr int HY_ITEMS = 8;                 // (pair, block) items of one pair a wave walks together (level 4: eight lanes per item)
 constexpr int HY_VOX_CAP = 768;             // iso voxels of a batch held in LDS (>= 512: a batch of one item always fits)
 constexpr int HY_FACE_CAP = 5 * HY_ROUND;   // candidate faces of a round
 struct HyWaveFaces {
     int ox[HY_ITEMS], oy[HY_ITEMS], oz[HY_ITEMS];  // first voxel of every item's block
-    unsigned char l4[8 * HY_ITEMS];                // surviving level-4 nodes, traversal order: item << 3 | child
+    unsigned char l4[64];                          // surviving level-4 nodes, traversal order: item << 3 | child
     unsigned short l2[64 * HY_ITEMS];              // surviving level-2 nodes: item << 6 | child of 4 << 3 | child of 2
     unsigned short vox[HY_VOX_CAP];                // iso voxels: item << 9 | (child of 4, child of 2, voxel)
     float es[8 * HY_ROUND], eo[8 * HY_ROUND];      // corner samples of the round's voxels: [voxel][corner]
@@ -2606,19 +2517,15 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
         // could leave more iso voxels than it holds, the batch is halved and walked again (one item always fits)
         int n2 = 0;
         for (;;) {
-            int n4 = 0;
-            for (int t0 = 0; t0 < 8 * nI; t0 += 64) {
-                const int t = t0 + lane;
-                bool s4 = false;
-                if (t < 8 * nI) {
-                    int cx, cy, cz;
-                    hy_child(t & 7, cx, cy, cz);
-                    s4 = hydro_node_survives(p, w.ox[t >> 3] + 4 * cx, w.oy[t >> 3] + 4 * cy, w.oz[t >> 3] + 4 * cz, 4);
-                }
-                const unsigned long long m4 = __ballot(s4);
-                if (s4) w.l4[n4 + __popcll(m4 & lt)] = (unsigned char)t;
-                n4 += __popcll(m4);
+            bool s4 = false;
+            if ((lane >> 3) < nI) {
+                int cx, cy, cz;
+                hy_child(lane & 7, cx, cy, cz);
+                s4 = hydro_node_survives(p, w.ox[lane >> 3] + 4 * cx, w.oy[lane >> 3] + 4 * cy, w.oz[lane >> 3] + 4 * cz, 4);
             }
+            const unsigned long long m4 = __ballot(s4);
+            const int n4 = __popcll(m4);
+            if (s4) w.l4[__popcll(m4 & lt)] = (unsigned char)lane;
             HY_WAVE_SYNC();
             n2 = 0;
             for (int t0 = 0; t0 < 8 * n4; t0 += 64) {
@@ -2644,7 +2551,6 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
         q = q0 + nI;
         // ---- level 1: the eight children of every surviving level-2 node, 64 tests per round, survivors in traversal order
         int n_vox = 0;
-        HY_UNROLL
         for (int i0 = 0; i0 < 8 * n2; i0 += 64) {
             const int i = i0 + lane;
             bool s1 = false;
@@ -2692,7 +2598,6 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
         for (int k = 0; k < nb; ++k) {
             const int v0 = k * HY_ROUND;
             const int nv = (n_vox - v0) < HY_ROUND ? (n_vox - v0) : HY_ROUND;
-            HY_UNROLL
             for (int t0 = 0; t0 < 8 * nv; t0 += 64) {
                 const int t = t0 + lane;
                 if (t < 8 * nv) {
@@ -3003,7 +2908,6 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
 nt_status nt_sdf_sample(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist, float* out_grad, void* stream) {
     if (!sdf || !points || n <= 0 || (!out_dist && !out_grad) || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;
     if (sdf->quantization != 4 && sdf->quantization != 2 && sdf->quantization != 1) return NT_ERR_INVALID_ARG;
-    if (!sdf_fits_32bit_offsets(*sdf)) return NT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(sdf_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *sdf, points, n, out_dist, out_grad);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
@@ -3011,7 +2915,6 @@ nt_status nt_sdf_sample(const nt_sdf* sdf, const float* points, int32_t n, float
 nt_status nt_sdf_sample_hw(const nt_sdf* sdf, const float* points, int32_t n, float* out_dist, void* stream) {
     if (!sdf || !points || n <= 0 || !out_dist || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;
     if (sdf->quantization != 4 && sdf->quantization != 2 && sdf->quantization != 1) return NT_ERR_INVALID_ARG;
-    if (!sdf_fits_32bit_offsets(*sdf)) return NT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(sdf_sample_hw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *sdf, points, n, out_dist);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }
@@ -3019,7 +2922,6 @@ nt_status nt_sdf_sample_hw(const nt_sdf* sdf, const float* points, int32_t n, fl
 nt_status nt_sdf_sample_voxels(const nt_sdf* sdf, const int32_t* ijk, int32_t n, float* out_dist, void* stream) {
     if (!sdf || !ijk || n <= 0 || !out_dist || !sdf->coarse || !sdf->slots || sdf->cx <= 0) return NT_ERR_INVALID_ARG;
     if (sdf->quantization != 4 && sdf->quantization != 2 && sdf->quantization != 1) return NT_ERR_INVALID_ARG;
-    if (!sdf_fits_32bit_offsets(*sdf)) return NT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(sdf_sample_voxels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *sdf, ijk, n, out_dist);
     return hipGetLastError() == hipSuccess ? NT_OK : NT_ERR_LAUNCH;
 }

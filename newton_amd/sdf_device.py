@@ -7,7 +7,6 @@ and ordered afterwards by the reference's contact sort key (pair, edge, mode) --
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 
@@ -28,20 +27,8 @@ class DeviceSDF:
         torch = _torch()
         self.host = sdf
         self.device = torch.device(device)
-        # the kernels address every SDF array with 32-bit byte offsets (nt_sdf.hip, ldg_at): each array stays below 4 GiB
-        for name in ("coarse", "subgrid", "slots"):
-            if np.asarray(getattr(sdf, name)).nbytes >= 2 ** 32:
-                raise ValueError(f"TextureSDF.{name} holds {np.asarray(getattr(sdf, name)).nbytes} bytes; the device samplers address below 4 GiB per array")
         self.coarse = torch.from_numpy(np.ascontiguousarray(sdf.coarse)).to(self.device)
         sub = np.ascontiguousarray(sdf.subgrid)
-        # block-linear upload (nt_sdf.subgrid_layout = 1, include/newton_hip.h): every (subgrid_size+1)^3 block of the reference's
-        # [z][y][x] texture becomes one contiguous run [bz][by][bx][lz][ly][lx] -- the same values, a dozen cache lines per block
-        # instead of one per texel row.  NT_SDF_LAYOUT=0 keeps the texture layout (measurements, tests of the other branch).
-        spd, T = int(sdf.subgrid_size) + 1, int(sub.shape[0])
-        self.layout = 1 if (os.environ.get("NT_SDF_LAYOUT", "1") != "0" and T % spd == 0 and T // spd >= 1 and sub.ndim == 3) else 0
-        if self.layout == 1:
-            nb = T // spd
-            sub = np.ascontiguousarray(sub.reshape(nb, spd, nb, spd, nb, spd).transpose(0, 2, 4, 1, 3, 5))
         if sub.dtype == np.uint16:  # torch has no uint16 arithmetic, but the bytes are all the kernel needs
             self.subgrid = torch.from_numpy(sub.view(np.int16)).to(self.device)
         else:
@@ -52,7 +39,6 @@ class DeviceSDF:
         d.cx, d.cy, d.cz = (int(x) for x in sdf.slots.shape)
         d.tex_size, d.subgrid_size = int(sdf.subgrid.shape[0]), int(sdf.subgrid_size)
         d.quantization, d.scale_baked = int(sdf.quantization_mode), int(bool(sdf.scale_baked))
-        d.subgrid_layout, d.tex_blocks, d.spd_magic = self.layout, (T // spd if self.layout == 1 else 0), ((1 << 16) + spd - 1) // spd
         for k in range(3):
             d.box_lower[k], d.box_upper[k] = float(sdf.box_lower[k]), float(sdf.box_upper[k])
             d.inv_dx[k], d.voxel_size[k] = float(sdf.inv_dx[k]), float(sdf.voxel_size[k])
