@@ -359,7 +359,8 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
             // a triangle mesh against a convex primitive (narrow_phase.py:633-638 `shape_pairs_mesh`): the triangle leg, pair kind 3
             auto tri_partner = [&](int l) {
                 const int ty = shape_type[l];
-                return ty == GEO_SPHERE || ty == GEO_CAPSULE || ty == GEO_ELLIPSOID || ty == GEO_CYLINDER || ty == GEO_BOX || ty == GEO_CONE;
+                return ty == GEO_SPHERE || ty == GEO_CAPSULE || ty == GEO_ELLIPSOID || ty == GEO_CYLINDER || ty == GEO_BOX || ty == GEO_CONE ||
+                       ty == GEO_CONVEX_MESH;
             };
             struct Routed { int id0, id1, a, b, kind, edges; };
             std::vector<Routed> routed;

@@ -249,7 +249,8 @@ class EnvTemplate:
         is_sdf_pair = is_sdf_pair | is_mesh_plane_pair
         # a triangle mesh against a convex primitive (narrow_phase.py:633-638 `shape_pairs_mesh`, after the rules above): the triangle
         # leg of the pipeline (csrc/nt_mesh_triangle.hip, pair kind 3) -- midphase over the mesh's triangles, GJK / MPR per triangle
-        tri_partner_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE)
+        tri_partner_types = (GeoType.SPHERE, GeoType.CAPSULE, GeoType.ELLIPSOID, GeoType.CYLINDER, GeoType.BOX, GeoType.CONE,
+                             GeoType.CONVEX_MESH)
 
         def tri_partner(l):
             return int(self.shape_type[l]) in tri_partner_types

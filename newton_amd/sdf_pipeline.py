@@ -197,6 +197,9 @@ class SdfLeg:
                 blk_start[i] = blk_of[key]
             self._block_bounds = up(np.concatenate(tables) if tables else np.zeros((1, 6), np.float32), np.float32)
             self._block_start = up(blk_start, np.int32)
+            # CONVEX_MESH partners: the hulls' vertex tables (Model.mesh_points: every distinct hull once, deduplicated vertices)
+            self._hull_range = up(np.stack([np.asarray(model.shape_mesh_start, np.int32), np.asarray(model.shape_mesh_count, np.int32)], axis=1), np.int32)
+            self._hull_points = up(model.mesh_points, np.float32)
             ntri_max = int(np.asarray(model.mesh_triangle_range)[:, 1].max())
             if ntri_max >= (1 << 18):
                 # the reduction's packed values carry the fingerprint (triangle << 4 | 8 | manifold index) in 22 bits
@@ -353,6 +356,7 @@ class SdfLeg:
                                                                               self.raw_key.data_ptr(), self.raw_data.data_ptr(),
                                                                               self.raw_capacity)
             mt.out_radius, mt.out_blk = self.raw_radius.data_ptr(), self.blk.data_ptr()
+            mt.hull_points, mt.shape_hull_range = self._hull_points.data_ptr(), self._hull_range.data_ptr()
             if os.environ.get("NT_TRIANGLE_BLOCKS", "1") != "0":  # (0: the plain scan over every triangle -- measurements)
                 mt.block_bounds, mt.shape_block_start = self._block_bounds.data_ptr(), self._block_start.data_ptr()
             _lib.check(lib.nt_mesh_triangle_pairs(C.byref(mt), stream), "nt_mesh_triangle_pairs")

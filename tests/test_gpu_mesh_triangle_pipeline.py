@@ -30,15 +30,15 @@ def terrain_height(x, y):
     return 0.02 * np.sin(5.0 * x) * np.cos(4.0 * y)
 
 
-def terrain_scene(worlds, kinds=("box", "sphere", "capsule"), device="cuda:0", gap=0.004, margin=0.0, seed=5, drop=0.0):
+def terrain_scene(worlds, kinds=("box", "sphere", "capsule", "hull"), device="cuda:0", gap=0.004, margin=0.0, seed=5, drop=0.0):
     """Every world: one free body per kind resting slightly inside a shared static terrain mesh (a global shape)."""
     import mesh_triangle_cases as mc
     import newton_amd as nt
 
     rng = np.random.default_rng(seed)
-    p, t = mc.grid_mesh(24, 24, 1.2, 1.2, height=terrain_height)
+    p, t = mc.grid_mesh(32, 32, 1.6, 1.6, height=terrain_height)
     terrain = nt.Mesh(p, t.reshape(-1))
-    half = dict(box=0.05, sphere=0.06, capsule=0.04, cylinder=0.05)
+    half = dict(box=0.05, sphere=0.06, capsule=0.04, cylinder=0.05, hull=0.04)
     env = nt.ModelBuilder()
     env.default_shape_cfg.gap = gap
     env.default_shape_cfg.margin = margin
@@ -50,6 +50,10 @@ def terrain_scene(worlds, kinds=("box", "sphere", "capsule"), device="cuda:0", g
             env.add_shape_sphere(b, radius=0.06)
         elif kind == "capsule":
             env.add_shape_capsule(b, radius=0.04, half_height=0.08)
+        elif kind == "hull":  # a convex hull (CONVEX_MESH): a wedge-topped box of 10 vertices
+            pts = np.array([(sx * 0.07, sy * 0.05, sz * 0.04) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)] +
+                           [(0.0, -0.03, 0.06), (0.0, 0.03, 0.06)], np.float32)
+            env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(pts))
         else:
             env.add_shape_cylinder(b, radius=0.05, half_height=0.05)
     scene = nt.ModelBuilder()
@@ -61,7 +65,7 @@ def terrain_scene(worlds, kinds=("box", "sphere", "capsule"), device="cuda:0", g
     nbody = len(kinds)
     for w in range(worlds):
         for k, kind in enumerate(kinds):
-            x, y = 0.5 * k - 0.5 + rng.uniform(-0.1, 0.1), rng.uniform(-0.4, 0.4)
+            x, y = 0.5 * k - 0.75 + rng.uniform(-0.1, 0.1), rng.uniform(-0.4, 0.4)
             q = nt._np_math.quat_rpy(*(rng.uniform(-0.05, 0.05, size=2)), rng.uniform(-1.0, 1.0))
             if kind == "capsule":  # lying on its side
                 q = nt._np_math.quat_rpy(0.0, np.pi / 2 + rng.uniform(-0.03, 0.03), rng.uniform(-1.0, 1.0))
@@ -86,7 +90,10 @@ def checker_rows(model, leg, body_q):
              aabb_lo=np.asarray(model.shape_collision_aabb_lower, np.float32), aabb_hi=np.asarray(model.shape_collision_aabb_upper, np.float32),
              res=np.asarray(model._shape_voxel_resolution, np.int32), vertex_start=model.mesh_vertex_range[:, 0],
              vertex_count=model.mesh_vertex_range[:, 1], tri_start=model.mesh_triangle_range[:, 0],
-             tri_count=model.mesh_triangle_range[:, 1], vertices=model.mesh_vertices, indices=model.mesh_indices)
+             tri_count=model.mesh_triangle_range[:, 1], vertices=model.mesh_vertices, indices=model.mesh_indices,
+             hull_start=np.asarray(model.shape_mesh_start, np.int32),
+             hull_count=np.where(np.asarray(model.shape_type) == 10, np.asarray(model.shape_mesh_count), 0).astype(np.int32),
+             hull_points=np.asarray(model.mesh_points, np.float32))
 
     def gid(l, w):
         return t.shape_local0 + w * t.ns + l if l < t.ns else int(t.gshape_id[l - t.ns])
@@ -121,8 +128,8 @@ def test_collide_rows_of_primitives_on_a_terrain_match_the_checker(margin):
     E = 5
     model = terrain_scene(E, margin=margin)
     t = model.env
-    assert len(t.sdf_pair) == 3 and bool(t.sdf_pair_mesh_tri.all())  # (box | sphere | capsule, terrain): the triangle leg
-    assert t.np == 3  # the three primitive-primitive pairs stay in the tiles
+    assert len(t.sdf_pair) == 4 and bool(t.sdf_pair_mesh_tri.all())  # (box | sphere | capsule | hull, terrain): the triangle leg
+    assert t.np == 6  # the six pairs among the four convex shapes stay in the tiles
     pipe = nt.CollisionPipeline(model, broad_phase="nxn")
     c1, c2 = pipe.contacts(), pipe.contacts()
     state = model.state()
@@ -134,14 +141,14 @@ def test_collide_rows_of_primitives_on_a_terrain_match_the_checker(margin):
     leg = pipe._sdf_leg
     assert not leg.overflow(c1._flat)["overflow"]
     want = checker_rows(model, leg, model.body_q)
-    assert len(want["key"]) == len(got["key"]) > 3 * E
+    assert len(want["key"]) == len(got["key"]) > 4 * E
     assert np.array_equal(got["row_start"], np.concatenate([[0], np.cumsum(np.bincount(want["world"], minlength=E))]))
     assert np.array_equal(got["key"], want["key"])
     for k in ("shape0", "shape1"):
         assert np.array_equal(got[k], want[k]), k
     terrain = model.shape_count - 1
     live = got["shape0"] >= 0
-    assert live.sum() >= 3 * E and np.all(got["shape0"][live] == terrain) and np.all(got["shape1"][live] != terrain)  # (mesh, convex)
+    assert live.sum() >= 4 * E and np.all(got["shape0"][live] == terrain) and np.all(got["shape1"][live] != terrain)  # (mesh, convex)
     for k in FIELDS[2:]:  # same shape transforms in -> same rows out
         assert np.abs(got[k] - want[k]).max() <= 2e-6, (k, np.abs(got[k] - want[k]).max())
     # the sphere / capsule rows carry the effective radius in their margins (write_contact: offset magnitude = radius + margin)
@@ -166,7 +173,7 @@ def test_xpbd_settles_primitives_on_the_terrain():
     import newton_amd as nt
 
     E = 16
-    model = terrain_scene(E, kinds=("box", "sphere", "capsule", "cylinder"), drop=0.02)
+    model = terrain_scene(E, kinds=("box", "sphere", "capsule", "cylinder", "hull"), drop=0.02)
     pipe = nt.CollisionPipeline(model, broad_phase="nxn")
     contacts = pipe.contacts()
     solver = nt.solvers.SolverXPBD(model, iterations=4)
@@ -183,5 +190,5 @@ def test_xpbd_settles_primitives_on_the_terrain():
     ground = terrain_height(q[:, 0], q[:, 1])
     assert np.all(q[:, 2] > ground + 0.02), (q[:, 2] - ground).min()   # resting on the surface (smallest half extent 0.04)
     assert np.all(q[:, 2] < ground + 0.12)
-    assert np.all(np.abs(q[:, :2]) < 1.15)                             # still over the terrain
+    assert np.all(np.abs(q[:, :2]) < 1.55)                             # still over the terrain
     assert np.median(np.abs(qd[:, :3]).max(axis=1)) < 0.05             # at rest (spheres may still roll slowly down a slope)
