@@ -76,7 +76,7 @@ def terrain_scene(worlds, kinds=("box", "sphere", "capsule", "hull"), device="cu
     return model
 
 
-def checker_rows(model, leg, body_q):
+def checker_rows(model, leg, body_q, worlds=None):
     """The rows the pipeline must emit, world-major, from the device's own exported shape transforms (oracle_mesh_triangle ->
     oracle_flat_contacts.write_rows)."""
     import oracle_flat_contacts as F
@@ -99,8 +99,8 @@ def checker_rows(model, leg, body_q):
         return t.shape_local0 + w * t.ns + l if l < t.ns else int(t.gshape_id[l - t.ns])
 
     out = {k: [] for k in ("world", "key", *FIELDS)}
-    for w in range(t.env_count):
-        lo, hi = leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    lo, hi = leg.aabb_lower.cpu().numpy(), leg.aabb_upper.cpu().numpy()
+    for w in (range(t.env_count) if worlds is None else worlds):
         for (a, b), mt in zip(t.sdf_pair, t.sdf_pair_mesh_tri):
             assert mt
             ga, gb = gid(int(a), w), gid(int(b), w)
@@ -192,3 +192,48 @@ def test_xpbd_settles_primitives_on_the_terrain():
     assert np.all(q[:, 2] < ground + 0.12)
     assert np.all(np.abs(q[:, :2]) < 1.55)                             # still over the terrain
     assert np.median(np.abs(qd[:, :3]).max(axis=1)) < 0.05             # at rest (spheres may still roll slowly down a slope)
+
+
+def test_terrain_2048_worlds_rows_vs_checker_and_matching():
+    """The bench's terrain scene at full size (2 048 worlds x 8 primitives on one 8 192-triangle terrain = 16 384 triangle-leg pairs
+    per collide): two collide() calls give bit-identical rows, nothing overflows, sampled worlds equal the checker chain row for
+    row, and frame-to-frame matching (contact_matching="latest") finds the previous frame's rows again after a small motion."""
+    import newton_amd as nt
+    import scenes
+
+    E = 2048
+    model = scenes.terrain_scene(E, 8, device="cuda:0", seed=6)
+    t = model.env
+    assert len(t.sdf_pair) == 8 and bool(t.sdf_pair_mesh_tri.all()) and t.np == 0
+    pipe = nt.CollisionPipeline(model, broad_phase="sap", contact_matching="latest")
+    c1, c2 = pipe.contacts(), pipe.contacts()
+    state = model.state()
+    state.body_q[:, 2] -= 0.007  # the scene starts 6 mm above the surface: 1 mm inside for this test
+    pipe.collide(state, c1)
+    first = _rows(c1)
+    leg = pipe._sdf_leg
+    info = leg.overflow(c1._flat)
+    assert not info["overflow"], info
+    assert info["candidate_pairs"] == 8 * E
+    live = first["shape0"] >= 0
+    assert live.sum() > 8 * E  # every primitive touches the terrain with at least one contact, most with several
+    sample = [0, 1, 777, 2047]
+    q = state.body_q.cpu().numpy().reshape(-1, 7)
+    want = checker_rows(model, leg, q, worlds=sample)
+    rs = first["row_start"]
+    got_idx = np.concatenate([np.arange(rs[w], rs[w + 1]) for w in sample])
+    assert len(want["key"]) == len(got_idx)
+    assert np.array_equal(first["key"][got_idx], want["key"])
+    for k in ("shape0", "shape1"):
+        assert np.array_equal(first[k][got_idx], want[k]), k
+    for k in FIELDS[2:]:
+        assert np.abs(first[k][got_idx] - want[k]).max() <= 2e-6, (k, np.abs(first[k][got_idx] - want[k]).max())
+    # second frame: every body moved by 0.2 mm -- the rows keep their fingerprints, the matcher finds them
+    state.body_q[:, 0] += 0.0002
+    pipe.collide(state, c2)
+    second = _rows(c2)
+    assert len(second["key"]) > 0
+    mi = c2.rigid_contact_match_index
+    n2 = int(c2.rigid_contact_count.item())
+    matched = int((mi[:n2] >= 0).sum().item())
+    assert matched > 0.8 * n2, (matched, n2)
