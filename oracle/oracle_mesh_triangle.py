@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY (never imported by newton_amd/ or by bench.py's timed path).
 
-The reference's mesh-vs-convex leg (a triangle mesh WITHOUT the SDF route against a primitive) on the CPU:
+The reference's mesh-vs-convex leg (a triangle mesh WITHOUT the SDF route against a primitive or a convex hull) on the CPU:
 
   * midphase + contact generation   liboracle.so `o_mesh_triangle_contacts` (oracle/oracle_convex.cpp): the C++ restatement of
                                     collision_core.py:996-1180 (query AABB from the support function, front-face test),
@@ -9,7 +9,7 @@ The reference's mesh-vs-convex leg (a triangle mesh WITHOUT the SDF route agains
   * buffering                       contact_reduction_global.py:2059-2096 (write_contact_to_reducer: no gap test)
   * reduction + export              oracle_reduce.reduce_buffered_contacts (reduce_contact_in_hashtable :1246-1346 + the export)
 
-Pinned by tests/golden/mesh_triangle_reference_vectors.npz, the record of the reference's own kernels executed on seven scenes
+Pinned by tests/golden/mesh_triangle_reference_vectors.npz, the record of the reference's own kernels executed on eight scenes
 (tests/golden/make_mesh_triangle_reference_vectors.py).  Warp's BVH is native code and not restated: the triangle set of a query is
 every triangle whose float32 bounds touch the query box (parity of the SET is what the record pins)."""
 import ctypes as C

@@ -22,7 +22,7 @@ CAL_FLOATS = 64 * 1024 * 1024  # 256 MiB read + 256 MiB written: past the 256 Mi
 KERNEL = {"quadruped": "xpbd_rollout", "quadruped_convex": "xpbd_rollout", "box_stack": "xpbd_rollout", "hull_bin": "xpbd_rollout",
           "quadruped_featherstone": "featherstone_rollout",
           # the staged legs of collide(): one launch of the named kernel per substep (the 10 averaged launches = the last timed frame)
-          "hydro_bin": "hydro_stage_faces", "sdf_bin": "sdf_reduce"}
+          "hydro_bin": "hydro_stage_faces", "sdf_bin": "sdf_reduce", "terrain": "mesh_triangle_pairs", "mesh_ground": "mesh_plane_pairs"}
 
 WORKLOAD = r'''
 import sys, ctypes as C
