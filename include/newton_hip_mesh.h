@@ -67,6 +67,12 @@ nt_status nt_mesh_plane_pairs(const nt_mesh_plane_args* args, void* stream);
  * under `reduce` they are the reducer's survivors BEFORE the writer's gap test (nt_sdf_rows_finalize / nt_contact_rows_write apply
  * it, with the effective radii of `out_radius`), without it every generated contact.
  * --------------------------------------------------------------------------------------------------------------------------- */
+/* HeightfieldData (newton/_src/utils/heightfield.py:141-156): a grid of nrow x ncol normalised elevations in [0, 1] at
+ * `elevations[data_offset + row * ncol + col]`, spanning [-hx, hx] x [-hy, hy], world z = min_z + h (max_z - min_z). */
+typedef struct {
+    int32_t data_offset, nrow, ncol;
+    float hx, hy, min_z, max_z;
+} nt_heightfield;
 typedef struct {
     int32_t* pairs;                    /* as nt_mesh_plane_args.pairs; rewritten in place as (mesh, convex) for the pairs processed */
     int32_t pair_count;
@@ -100,6 +106,16 @@ typedef struct {
     const float* hull_points;          /* [H][3] or NULL: vertex tables of the CONVEX_MESH partners (wp.Mesh.points of a hull, unscaled;
                                           Model.mesh_points); without it pairs with a CONVEX_MESH are skipped */
     const int32_t* shape_hull_range;   /* [S][2] or NULL (both or neither): (first vertex, vertex count) of a CONVEX_MESH shape */
+    /* heightfields (GeoType.HFIELD = 2) as the mesh-like shape of a pair: narrow_phase.py:553-583 routes (heightfield, convex) pairs to
+     * the same triangle kernels -- heightfield_vs_convex_midphase (utils/heightfield.py:366-462: the partner's LOCAL AABB
+     * `shape_aabb_lower / _upper` as an oriented box in the heightfield frame -> a cell range, two triangles per cell) and
+     * get_triangle_shape_from_heightfield (:280-363: GeoTypeEx.TRIANGLE_PRISM, the triangle extruded 1 m along the field's -Z, MPR /
+     * GJK in the heightfield frame; penetrating contacts move to the physical face, collision_core.py:280-322).
+     * sort_sub_key = ((((row * (ncol - 1) + col) * 2 + tri_sub) << 1 | 1) << 3) | manifold index; 2 (nrow - 1)(ncol - 1) < 2^18.
+     * All three NULL: no heightfield pairs (they are skipped); the mesh tables may be NULL when only heightfields collide. */
+    const int32_t* shape_heightfield_index; /* [S] index into `heightfields`, -1 for other shapes (Model.shape_heightfield_index) */
+    const nt_heightfield* heightfields;     /* [H] */
+    const float* elevations;                /* concatenated normalised elevation grids */
 } nt_mesh_triangle_args;
 #define NT_MESH_TRIANGLE_BLOCK 64
 #define NT_PAIR_KIND_MESH_TRIANGLE 3

@@ -10,7 +10,7 @@ from .articulation import eval_fk
 from .builder import JointDofConfig, ModelBuilder, ShapeConfig
 from .collide import CollisionPipeline, ContactMatcher, Contacts
 from .enums import BodyFlags, GeoType, JointType, ModelFlags, ShapeFlags, StateFlags
-from .mesh import Mesh
+from .mesh import Heightfield, Mesh
 from .model import Model
 from .state import Control, State
 
@@ -28,7 +28,7 @@ def set_use_coord_layout_targets(value: bool):
     _builder_mod.use_coord_layout_targets = bool(value)
 
 
-__all__ = ["BodyFlags", "CollisionPipeline", "ContactMatcher", "Contacts", "Control", "GeoType", "JointDofConfig", "JointType", "Mesh", "Model",
+__all__ = ["BodyFlags", "CollisionPipeline", "ContactMatcher", "Contacts", "Control", "GeoType", "Heightfield", "JointDofConfig", "JointType", "Mesh", "Model",
            "ModelBuilder", "ModelFlags", "ShapeConfig", "ShapeFlags", "State", "StateFlags", "eval_fk", "geometry", "selection", "viewer",
            "solvers",
            "set_use_coord_layout_targets"]

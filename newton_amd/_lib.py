@@ -134,6 +134,12 @@ class nt_mesh_plane_args(C.Structure):
                 ("out_data", C.c_void_p), ("capacity", C.c_int32), ("out_blk", C.c_void_p)]
 
 
+class nt_heightfield(C.Structure):
+    """include/newton_hip_mesh.h: HeightfieldData (utils/heightfield.py:141-156)."""
+    _fields_ = [("data_offset", C.c_int32), ("nrow", C.c_int32), ("ncol", C.c_int32), ("hx", C.c_float), ("hy", C.c_float),
+                ("min_z", C.c_float), ("max_z", C.c_float)]
+
+
 class nt_mesh_triangle_args(C.Structure):
     """include/newton_hip_mesh.h: MESH vs convex primitive (triangle leg)."""
     _fields_ = [("pairs", C.c_void_p), ("pair_count", C.c_int32), ("pair_world_prefix", C.c_void_p), ("worlds", C.c_int32),
@@ -144,7 +150,8 @@ class nt_mesh_triangle_args(C.Structure):
                 ("reduce", C.c_int32), ("out_count", C.c_void_p), ("out_pair", C.c_void_p), ("out_key", C.c_void_p),
                 ("out_data", C.c_void_p), ("out_radius", C.c_void_p), ("capacity", C.c_int32), ("out_blk", C.c_void_p),
                 ("block_bounds", C.c_void_p), ("shape_block_start", C.c_void_p), ("hull_points", C.c_void_p),
-                ("shape_hull_range", C.c_void_p)]
+                ("shape_hull_range", C.c_void_p), ("shape_heightfield_index", C.c_void_p), ("heightfields", C.c_void_p),
+                ("elevations", C.c_void_p)]
 
 
 class nt_sdf(C.Structure):

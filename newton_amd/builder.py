@@ -635,6 +635,19 @@ class ModelBuilder:
             raise ValueError("add_shape_mesh() requires a Mesh")
         return self.add_shape(body=body, type=GeoType.MESH, xform=xform, cfg=cfg, scale=scale, label=label, src=mesh)
 
+    def add_shape_heightfield(self, *, xform=None, heightfield=None, scale=None, cfg=None, label=None) -> int:
+        """Static heightfield terrain (builder.py add_shape_heightfield; geometry/types.py:2240-2340).  Collides with convex primitives
+        and hulls cell by cell through the triangle leg (narrow_phase.py:553-583, utils/heightfield.py:280-462).  The cells ignore the
+        shape scale in the reference's kernels (get_triangle_shape_from_heightfield reads hx / hy / min_z / max_z only): scale must be 1."""
+        if heightfield is None:
+            raise ValueError("add_shape_heightfield() requires a Heightfield")
+        if scale is not None and tuple(float(x) for x in scale) != (1.0, 1.0, 1.0):
+            raise NotImplementedError("heightfield shapes take scale (1, 1, 1): the collision kernels read the field's own extents")
+        if 2 * (heightfield.nrow - 1) * (heightfield.ncol - 1) >= (1 << 18):
+            raise NotImplementedError("heightfields with 2^18 or more triangles are not supported (the triangle index is part of the "
+                                      "22-bit contact fingerprint of the reduction)")
+        return self.add_shape(body=-1, type=GeoType.HFIELD, xform=xform, cfg=cfg, scale=(1.0, 1.0, 1.0), label=label, src=heightfield)
+
     def _finalize_sdf(self, m) -> None:
         """Texture-SDF resources of the finalized model (builder.py:11690-11960 compact SDF table + per-shape index, :12050-12116
         collision-edge tables, :11544-11611 local AABBs and voxel grids of the contact reduction).  Mesh-backed shapes use the SDF
@@ -687,7 +700,7 @@ class ModelBuilder:
                 ext = S.primitive_extents(int(ty), scale)
                 lo_all[i], hi_all[i] = np.asarray(ext[0], np.float32), np.asarray(ext[1], np.float32)
             if key is None:
-                if ty == GeoType.MESH and src is not None:  # the contact reduction's voxel grid of a mesh without an SDF (vertex leg)
+                if ty in (GeoType.MESH, GeoType.HFIELD) and src is not None:  # the reduction's voxel grid of a mesh / heightfield without an SDF
                     voxel_res[i] = S.voxel_resolution_from_aabb(lo_all[i], hi_all[i])
                 continue
             if key not in cache:
@@ -950,9 +963,18 @@ class ModelBuilder:
         uniq, starts, counts, points = {}, [], [], []
         lo_all, hi_all = np.zeros((S, 3), dtype=f32), np.zeros((S, 3), dtype=f32)
         for i, src in enumerate(self.shape_source):
-            if self.shape_type[i] not in (GeoType.CONVEX_MESH, GeoType.MESH) or src is None:
+            if self.shape_type[i] not in (GeoType.CONVEX_MESH, GeoType.MESH, GeoType.HFIELD) or src is None:
                 starts.append(-1)
                 counts.append(0)
+                # local AABB of a primitive (builder.py:11601-11652): what the heightfield midphase reads of the partner shape
+                ty, (sx, sy, sz) = self.shape_type[i], (float(x) for x in self.shape_scale[i])
+                ext = {GeoType.SPHERE: (sx, sx, sx), GeoType.BOX: (sx, sy, sz), GeoType.ELLIPSOID: (sx, sy, sz), GeoType.CAPSULE: (sx, sx, sy + sx),
+                       GeoType.CONE: (sx, sx, sy)}.get(ty)
+                if ty == GeoType.CYLINDER:
+                    r = sx + ((sy * sy) / (sz + np.sqrt(sz * sz - sy * sy)) if sz > 0.0 else 0.0)
+                    ext = (r, r, sy)
+                if ext is not None:
+                    lo_all[i], hi_all[i] = -np.asarray(ext, f32), np.asarray(ext, f32)
                 continue
             if id(src) not in uniq:
                 v = deduplicate_vertices(src)
@@ -987,6 +1009,21 @@ class ModelBuilder:
         m.mesh_vertices = (np.concatenate(vpoints) if vpoints else np.zeros((0, 3))).astype(f32).reshape(-1, 3)
         m.mesh_triangle_range = tranges
         m.mesh_indices = (np.concatenate(tindices) if tindices else np.zeros((0, 3))).astype(i32).reshape(-1, 3)
+        # heightfields: HeightfieldData per distinct Heightfield + the concatenated normalised elevation grids (builder.py finalize,
+        # utils/heightfield.py:141-156)
+        huniq, hidx, hdata, helev = {}, -np.ones(S, dtype=i32), [], []
+        for i, src in enumerate(self.shape_source):
+            if self.shape_type[i] != GeoType.HFIELD or src is None:
+                continue
+            if id(src) not in huniq:
+                huniq[id(src)] = len(hdata)
+                hdata.append((sum(len(e) for e in helev), src.nrow, src.ncol, src.hx, src.hy, src.min_z, src.max_z))
+                helev.append(np.asarray(src.data, dtype=f32).reshape(-1))
+            hidx[i] = huniq[id(src)]
+        m.shape_heightfield_index = hidx
+        m.heightfield_data = hdata  # (data_offset, nrow, ncol, hx, hy, min_z, max_z)
+        m.heightfield_elevations = (np.concatenate(helev) if helev else np.zeros(0)).astype(f32)
+        m.heightfield_count = len(hdata)
         m.shape_mesh_start = np.asarray(starts, dtype=i32).reshape(S)
         m.shape_mesh_count = np.asarray(counts, dtype=i32).reshape(S)
         m.mesh_points = (np.concatenate(points) if points else np.zeros((0, 3))).astype(f32).reshape(-1, 3)

@@ -26,6 +26,7 @@ NT_DI int imin(int a, int b) { return a < b ? a : b; }
 #define NT_CONVEX_WITH_TRIANGLES 0
 #endif
 constexpr int GEO_TRIANGLE = 1000;  // support_function.py:58: vertex A at the origin, B - A in `scale`, C - A in `aux`
+constexpr int GEO_TRIANGLE_PRISM = 1001;  // :59,193-200: a heightfield cell's triangle extruded 1 m along -Z of the heightfield frame
 
 struct Geom {
     int type;
@@ -226,9 +227,11 @@ vec3 support_map_rest(int type, vec3 scale, vec3 direction) {
 NT_DEV vec3 support_map_triangle(const Geom& g, vec3 direction) {
     const vec3 tri_a(0.0f), tri_b = g.scale, tri_c = g.aux;
     const float dot_a = dot(tri_a, direction), dot_b = dot(tri_b, direction), dot_c = dot(tri_c, direction);
-    if (dot_a >= dot_b && dot_a >= dot_c) return tri_a;
-    if (dot_b >= dot_c) return tri_b;
-    return tri_c;
+    vec3 result = tri_c;
+    if (dot_a >= dot_b && dot_a >= dot_c) result = tri_a;
+    else if (dot_b >= dot_c) result = tri_b;
+    if (g.type == GEO_TRIANGLE_PRISM && direction.z < 0.0f) result = result + vec3(0.0f, 0.0f, -1.0f);  // (:193-200)
+    return result;
 }
 // support_function.py:647-745
 NT_DEV vec3 closest_point_on_triangle(vec3 p, vec3 tri_a, vec3 tri_b, vec3 tri_c) {
@@ -281,7 +284,7 @@ NT_DEV vec3 closest_point_on_triangle(vec3 p, vec3 tri_a, vec3 tri_b, vec3 tri_c
 }
 // support_function.py:467-502: a triangle's Minkowski seed is the point of the triangle nearest B's centre, nudged to the centroid
 NT_DEV vec3 adjust_minkowski_center(const Geom& ga, vec3 center_b_world, vec3 center_b_to_a) {
-    if (ga.type != GEO_TRIANGLE) return center_b_to_a;
+    if (ga.type != GEO_TRIANGLE && ga.type != GEO_TRIANGLE_PRISM) return center_b_to_a;
     const vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
     const vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
     const float face_normal_length_sq = length_sq(face_normal);
@@ -310,7 +313,7 @@ NT_DEV vec3 adjust_minkowski_center(const Geom& ga, vec3 center_b_world, vec3 ce
 }
 // support_function.py:505-538
 NT_DEV vec3 minkowski_center_fallback(const Geom& ga, vec3 center_b_world) {
-    if (ga.type != GEO_TRIANGLE) return vec3(0.0f);
+    if (ga.type != GEO_TRIANGLE && ga.type != GEO_TRIANGLE_PRISM) return vec3(0.0f);
     const vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
     vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
     const float face_normal_length_sq = length_sq(face_normal);
@@ -330,7 +333,7 @@ NT_DEV vec3 minkowski_center_fallback(const Geom& ga, vec3 center_b_world) {
 // support_function.py:131-350
 NT_DEV vec3 support_map(const Geom& g, vec3 direction) {
 #if NT_CONVEX_WITH_TRIANGLES
-    if (g.type == GEO_TRIANGLE) return support_map_triangle(g, direction);
+    if (g.type == GEO_TRIANGLE || g.type == GEO_TRIANGLE_PRISM) return support_map_triangle(g, direction);
 #endif
     if (g.type == GEO_PLANE) return support_map_plane(g.scale, direction);
     if (g.type == GEO_CONVEX_MESH) return support_map_hull(g.points, g.count, g.scale, direction);
@@ -1060,6 +1063,14 @@ struct ConvexContacts {
     vec3 c0, c1, c2, c3, c4;
     float d0, d1, d2, d3, d4;
     vec3 normal;  // shared by every contact of the pair (world frame, as generated)
+#if NT_CONVEX_WITH_TRIANGLES
+    vec3 n0, n1, n2, n3, n4;  // ... except in the triangle leg: a heightfield prism's penetrating contacts take the face normal
+    NT_DI void set_normal(vec3 n) {  // (of the contact the next push() appends)
+        const int k = count;
+        n0 = vsel(k == 0, n, n0); n1 = vsel(k == 1, n, n1); n2 = vsel(k == 2, n, n2); n3 = vsel(k == 3, n, n3); n4 = vsel(k == 4, n, n4);
+    }
+    NT_DI vec3 normal_of(int i) const { return vsel(i == 0, n0, vsel(i == 1, n1, vsel(i == 2, n2, vsel(i == 3, n3, n4)))); }
+#endif
     int count;
     // value selects on every field (see vsel in nt_math.hpp: an if-chain of stores or a ternary on lvalues turns into an
     // address select and pins the record in scratch memory)
@@ -1100,7 +1111,7 @@ NT_DEV ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a,
     }
     // is_discrete_shape (collision_core.py:39-48): shapes with flat polygon faces
     bool is_discrete_a = type_a == GEO_BOX || type_a == GEO_CONVEX_MESH || type_a == GEO_PLANE ||
-                         (NT_CONVEX_WITH_TRIANGLES && type_a == GEO_TRIANGLE);
+                         (NT_CONVEX_WITH_TRIANGLES && (type_a == GEO_TRIANGLE || type_a == GEO_TRIANGLE_PRISM));
     bool is_discrete_b = type_b == GEO_BOX || type_b == GEO_CONVEX_MESH || type_b == GEO_PLANE;
     bool is_axial_a = type_a == GEO_CYLINDER || type_a == GEO_CONE;
     bool is_axial_b = type_b == GEO_CYLINDER || type_b == GEO_CONE;
@@ -1148,6 +1159,28 @@ NT_DEV ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a,
 
 // write_contact(output_index = -1) (collide.py:206-254)
 NT_DEV void emit(PairCtx& P, ContactOut c, vec3 pos_a, quat rot_a, vec3 pos_b, quat rot_b) {
+#if NT_CONVEX_WITH_TRIANGLES
+    if (P.ga.type == GEO_TRIANGLE_PRISM && c.distance < 0.0f) {
+        // post_process_triangle_contact (collision_core.py:280-322): a penetrating contact of a heightfield prism moves to the
+        // physical triangle face -- normal = the face normal (up), distance along it
+        vec3 normal_local = cross(P.ga.scale, P.ga.aux);
+        const float normal_length_sq = length_sq(normal_local);
+        if (normal_length_sq >= 1.0e-20f) {
+            normal_local = normal_local / sqrtf(normal_length_sq);
+            if (normal_local.z < 0.0f) normal_local = -normal_local;
+            const vec3 normal_world = quat_rotate(rot_a, normal_local);
+            const vec3 point_b_world = c.center + 0.5f * c.distance * c.normal;
+            const vec3 point_b_local = quat_rotate_inv(rot_a, point_b_world - pos_a);
+            const vec3 projected_b = point_b_local - dot(point_b_local, normal_local) * normal_local;
+            const vec3 point_a = closest_point_on_triangle(projected_b, vec3(0.0f), P.ga.scale, P.ga.aux);
+            float distance = 0.0f;
+            if (length_sq(point_a - projected_b) < 1.0e-10f) distance = dot(point_b_local - point_a, normal_local);
+            c.center = quat_rotate(rot_a, point_a) + pos_a + 0.5f * distance * normal_world;
+            c.normal = normal_world;
+            c.distance = distance;
+        }
+    }
+#endif
     c = post_process_axial(c, P, pos_a, rot_a, pos_b, rot_b);
     float total_separation_needed = P.radius_eff_a + P.radius_eff_b + P.margin_a + P.margin_b;
     vec3 n = normalize(c.normal);
@@ -1161,6 +1194,9 @@ NT_DEV void emit(PairCtx& P, ContactOut c, vec3 pos_a, quat rot_a, vec3 pos_b, q
     if (d > P.contact_gap) return;
     ConvexContacts& o = *P.out;
     o.normal = c.normal;
+#if NT_CONVEX_WITH_TRIANGLES
+    o.set_normal(c.normal);
+#endif
     o.push(c.center, c.distance);
 }
 
@@ -1331,17 +1367,17 @@ NT_DI void convex_pair(const Geom& geom_a, const Geom& geom_b, xform Xa, const x
 
 #if NT_CONVEX_WITH_TRIANGLES
 // mesh_triangle_contacts_to_reducer_kernel's call of compute_gjk_mpr_contacts (contact_reduction_global.py:2385-2403): shape A is a
-// world-space triangle (v0 at pos_a, identity rotation), shape B a convex primitive; contacts come back in emission order, UNFILTERED
-// (their index is the low three bits of the fingerprint).  Post-processing as post_process_triangle_contact: the TRIANGLE_PRISM edit
-// does not apply, the axial projection does (a triangle is a discrete shape).
-NT_DI void triangle_pair(vec3 edge_ab, vec3 edge_ac, vec3 pos_a, const Geom& geom_b, const xform& Xb, float margin_a, float margin_b,
-                         float rigid_gap, PolyRef poly, ConvexContacts& out) {
+// world-space triangle (v0 at pos_a, identity rotation) or a heightfield cell's prism (edges in the heightfield frame, its rotation),
+// shape B a convex shape; contacts come back in emission order, UNFILTERED (their index is the low three bits of the fingerprint).
+// Post-processing as post_process_triangle_contact: the TRIANGLE_PRISM edit in emit(), then the axial projection (both are discrete).
+NT_DI void triangle_pair(int type_a, vec3 edge_ab, vec3 edge_ac, vec3 pos_a, quat rot_a, const Geom& geom_b, const xform& Xb, float margin_a,
+                         float margin_b, float rigid_gap, PolyRef poly, ConvexContacts& out) {
     out.count = 0;
     PairCtx P;
     P.out = &out;
     P.poly = poly;
     P.raw = true;
-    P.ga.type = GEO_TRIANGLE;
+    P.ga.type = type_a;  // TRIANGLE (world-space edges, identity rotation) or TRIANGLE_PRISM (heightfield-local edges, its rotation)
     P.ga.scale = edge_ab;
     P.ga.aux = edge_ac;
     P.ga.center = vec3(0.0f);
@@ -1358,7 +1394,7 @@ NT_DI void triangle_pair(vec3 edge_ab, vec3 edge_ac, vec3 pos_a, const Geom& geo
     }
     const float contact_threshold = rigid_gap + P.radius_eff_a + P.radius_eff_b + margin_a + margin_b;
     const bool skip_multi_contact = type_b == GEO_SPHERE || type_b == GEO_ELLIPSOID;
-    const quat orientation_a(0.0f, 0.0f, 0.0f, 1.0f), orientation_b = Xb.q;
+    const quat orientation_a = rot_a, orientation_b = Xb.q;
     const vec3 position_a = pos_a, position_b = Xb.p;
     const quat rel_q = quat_inverse(orientation_a) * orientation_b;
     const vec3 rel_p = quat_rotate_inv(orientation_a, position_b - position_a);

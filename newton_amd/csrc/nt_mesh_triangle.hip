@@ -1,4 +1,4 @@
-// nt_mesh_triangle.hip -- MESH (no SDF route) vs convex primitive / convex hull for gfx950: the triangle leg of CollisionPipeline.collide
+// nt_mesh_triangle.hip -- MESH (no SDF route) and HEIGHTFIELD vs convex primitive / convex hull for gfx950: the triangle leg of CollisionPipeline.collide
 // (include/newton_hip_mesh.h).
 //
 // Reference behaviour (paths under /root/reference/newton/_src/geometry):
@@ -55,6 +55,7 @@ constexpr int MT_DEFAULT_THREADS = 64;
 
 NT_DI xform ld_xform(const float* p) { return xform(vec3(p[0], p[1], p[2]), quat(p[3], p[4], p[5], p[6])); }
 NT_DI vec3 ld_vec3(const float* p) { return vec3(p[0], p[1], p[2]); }
+NT_DI int imax(int a, int b) { return a > b ? a : b; }
 
 NT_DI int mt_live_pairs(const nt_mesh_triangle_args& a) { return a.pair_world_prefix ? a.pair_world_prefix[a.worlds] : a.pair_count; }
 NT_DI int mt_pair_slot(const nt_mesh_triangle_args& a, int f) {  // flat live index -> position w * pairs_per_world + k
@@ -75,10 +76,15 @@ struct PairSetup {  // what every triangle of the pair shares
     float margin_mesh, margin_convex, gap_sum, radius_b;
     int mesh, convex, v0, t0, nt_;
     bool mirrored;
+    // heightfield pairs (`mesh` is the heightfield shape): the cell range of the midphase, the field's grid
+    bool hfield;
+    int row_min, col_min, n_cols, hf_cols, hf_ncol, hf_offset;  // cells [row_min ..][col_min .. col_min + n_cols), hf_cols = ncol - 1
+    float hx, hy, dx, dy, min_z, z_range;
 };
 
 NT_DI void pair_setup(const nt_mesh_triangle_args& a, int s0, int s1, PairSetup& c) {
-    const bool mesh_first = a.shape_type[s0] == GEO_MESH;
+    c.hfield = a.shape_heightfield_index != nullptr && (a.shape_type[s0] == GEO_HFIELD || a.shape_type[s1] == GEO_HFIELD);
+    const bool mesh_first = c.hfield ? a.shape_type[s0] == GEO_HFIELD : a.shape_type[s0] == GEO_MESH;
     c.mesh = mesh_first ? s0 : s1;
     c.convex = mesh_first ? s1 : s0;
     c.X_mesh = ld_xform(a.shape_transform + 7 * (size_t)c.mesh);
@@ -107,6 +113,42 @@ NT_DI void pair_setup(const nt_mesh_triangle_args& a, int s0, int s1, PairSetup&
             upper = vmax(upper, point);
         }
         c.gb.center = 0.5f * (lower + upper);
+    }
+    c.mirrored = false;
+    c.v0 = c.t0 = 0;
+    if (c.hfield) {
+        // heightfield_vs_convex_midphase (utils/heightfield.py:366-462): the partner's LOCAL AABB (Model.shape_collision_aabb_*) as an
+        // oriented box in the heightfield frame, its axis-aligned hull widened by margin + gap, mapped to a cell range
+        const nt_heightfield hd = a.heightfields[a.shape_heightfield_index[c.mesh]];
+        const xform X_other_in_hfield = xform_inverse(c.X_mesh) * c.X_convex;
+        const vec3 other_pos = X_other_in_hfield.p;
+        const quat other_rot = X_other_in_hfield.q;
+        const vec3 local_lo = ld_vec3(a.shape_aabb_lower + 3 * (size_t)c.convex), local_hi = ld_vec3(a.shape_aabb_upper + 3 * (size_t)c.convex);
+        const vec3 local_center = 0.5f * (local_lo + local_hi), local_half = 0.5f * (local_hi - local_lo);
+        const vec3 center_in_hfield = quat_rotate(other_rot, local_center) + other_pos;
+        const vec3 r0 = quat_rotate(other_rot, vec3(1.0f, 0.0f, 0.0f)), r1 = quat_rotate(other_rot, vec3(0.0f, 1.0f, 0.0f)),
+                   r2 = quat_rotate(other_rot, vec3(0.0f, 0.0f, 1.0f));
+        const vec3 half_in_hfield(fabsf(r0.x) * local_half.x + fabsf(r1.x) * local_half.y + fabsf(r2.x) * local_half.z,
+                                  fabsf(r0.y) * local_half.x + fabsf(r1.y) * local_half.y + fabsf(r2.y) * local_half.z,
+                                  fabsf(r0.z) * local_half.x + fabsf(r1.z) * local_half.y + fabsf(r2.z) * local_half.z);
+        const float margin_sum = c.margin_mesh + c.margin_convex;
+        const float threshold = (a.shape_gap[c.mesh] + a.shape_gap[c.convex]) + margin_sum;
+        const vec3 threshold_vec(threshold, threshold, threshold);
+        const vec3 q_lo = center_in_hfield - half_in_hfield - threshold_vec, q_hi = center_in_hfield + half_in_hfield + threshold_vec;
+        c.hx = hd.hx; c.hy = hd.hy;
+        c.dx = 2.0f * hd.hx / (float)(hd.ncol - 1);
+        c.dy = 2.0f * hd.hy / (float)(hd.nrow - 1);
+        const int col_min = imax((int)floorf((q_lo.x + hd.hx) / c.dx), 0), col_max = imin((int)floorf((q_hi.x + hd.hx) / c.dx), hd.ncol - 2);
+        const int row_min = imax((int)floorf((q_lo.y + hd.hy) / c.dy), 0), row_max = imin((int)floorf((q_hi.y + hd.hy) / c.dy), hd.nrow - 2);
+        c.row_min = row_min; c.col_min = col_min;
+        c.n_cols = col_max >= col_min ? col_max - col_min + 1 : 0;
+        const int n_rows = row_max >= row_min ? row_max - row_min + 1 : 0;
+        c.nt_ = 2 * n_rows * c.n_cols;  // candidates: both triangles of every cell of the range (no bounds test)
+        c.hf_cols = hd.ncol - 1; c.hf_ncol = hd.ncol; c.hf_offset = hd.data_offset;
+        c.min_z = hd.min_z; c.z_range = hd.max_z - hd.min_z;
+        c.gap_sum = a.shape_gap[c.mesh] + a.shape_gap[c.convex];
+        c.mesh_scale = vec3(1.0f, 1.0f, 1.0f);
+        return;
     }
     // _compute_mesh_vs_convex_query_aabb (collision_core.py:996-1040)
     const xform X_mesh_shape = xform_inverse(c.X_mesh) * c.X_convex;
@@ -148,6 +190,11 @@ NT_DI void pair_setup(const nt_mesh_triangle_args& a, int s0, int s1, PairSetup&
     c.nt_ = a.shape_triangle_range[2 * (size_t)c.mesh + 1];
     c.mirrored = c.mesh_scale.x * c.mesh_scale.y * c.mesh_scale.z < 0.0f;
 }
+// candidate j of a heightfield pair -> packed triangle index (row * (ncol - 1) + col) * 2 + tri_sub, ascending in j
+NT_DI int hfield_candidate(const PairSetup& c, int j) {
+    const int cell = j >> 1, r = c.row_min + cell / c.n_cols, col = c.col_min + cell % c.n_cols;
+    return (r * c.hf_cols + col) * 2 + (j & 1);
+}
 
 // the midphase's verdict on triangle ti: its bounds touch the query box and it faces the convex shape's origin
 NT_DI bool triangle_candidate(const nt_mesh_triangle_args& a, const PairSetup& c, int ti) {
@@ -162,6 +209,21 @@ NT_DI bool triangle_candidate(const nt_mesh_triangle_args& a, const PairSetup& c
 
 // the contacts of triangle ti (emission order, unfiltered); false: culled as a back face in world space
 NT_DI bool triangle_contacts(const nt_mesh_triangle_args& a, const PairSetup& c, int ti, PolyRef poly, ConvexContacts& out) {
+    if (c.hfield) {
+        // get_triangle_shape_from_heightfield (utils/heightfield.py:280-363): cell (row, col), tri_sub 0 = (p00, p10, p11), 1 = (p00, p11, p01);
+        // a TRIANGLE_PRISM with its edges in the heightfield frame, MPR / GJK run in that frame (rotation = the heightfield's)
+        const int cell_idx = ti / 2, tri_sub = ti - cell_idx * 2, row = cell_idx / c.hf_cols, col = cell_idx - row * c.hf_cols;
+        const float x0 = -c.hx + (float)col * c.dx, x1 = x0 + c.dx, y0 = -c.hy + (float)row * c.dy, y1 = y0 + c.dy;
+        const float* e = a.elevations + c.hf_offset;
+        const float h00 = e[row * c.hf_ncol + col], h10 = e[row * c.hf_ncol + (col + 1)], h01 = e[(row + 1) * c.hf_ncol + col],
+                    h11 = e[(row + 1) * c.hf_ncol + (col + 1)];
+        const float z00 = c.min_z + h00 * c.z_range, z10 = c.min_z + h10 * c.z_range, z01 = c.min_z + h01 * c.z_range, z11 = c.min_z + h11 * c.z_range;
+        const vec3 p00(x0, y0, z00), p10(x1, y0, z10), p01(x0, y1, z01), p11(x1, y1, z11);
+        const vec3 v0_local = p00, v1_local = tri_sub == 0 ? p10 : p11, v2_local = tri_sub == 0 ? p11 : p01;
+        triangle_pair(GEO_TRIANGLE_PRISM, v1_local - v0_local, v2_local - v0_local, xform_point(c.X_mesh, v0_local), c.X_mesh.q, c.gb, c.X_convex,
+                      c.margin_mesh, c.margin_convex, c.gap_sum, poly, out);
+        return true;
+    }
     const int* idx = a.indices + 3 * (size_t)(c.t0 + ti);
     const int i0 = idx[0], i1 = c.mirrored ? idx[2] : idx[1], i2 = c.mirrored ? idx[1] : idx[2];
     // get_triangle_shape_from_mesh (collision_core.py:1218-1276)
@@ -172,7 +234,7 @@ NT_DI bool triangle_contacts(const nt_mesh_triangle_args& a, const PairSetup& c,
     out.count = 0;
     // back-face culling (contact_reduction_global.py:2368-2375)
     if (dot(cross(ab, ac), c.X_convex.p - v0_world) < 0.0f) return false;
-    triangle_pair(ab, ac, v0_world, c.gb, c.X_convex, c.margin_mesh, c.margin_convex, c.gap_sum, poly, out);
+    triangle_pair(GEO_TRIANGLE, ab, ac, v0_world, quat(0.0f, 0.0f, 0.0f, 1.0f), c.gb, c.X_convex, c.margin_mesh, c.margin_convex, c.gap_sum, poly, out);
     return true;
 }
 
@@ -219,7 +281,7 @@ struct MtLds {
     unsigned short hblk[(1 << 18) / NT_MESH_TRIANGLE_BLOCK];  // blocks of the mesh that touch the query box, ascending
     int n_hblk;
     float poly[20 * MT_THREADS];  // manifold clipper scratch: 10 x vec2 per lane, lane-strided
-    float rec[22 * MT_THREADS];   // the first batch's contacts, lane-strided: octahedral normal code, 5 x (centre, distance)
+    float rec[30 * MT_THREADS];   // the first batch's contacts, lane-strided: 5 x (centre, distance, octahedral normal code)
     int batch_tri[MT_THREADS];    // ... and its triangles (ascending)
     int wave_hits[MT_THREADS / 64];
     int waiting;        // candidates in `list`
@@ -239,6 +301,12 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
         if (a.pair_kind && a.pair_kind[pair_idx] != NT_PAIR_KIND_MESH_TRIANGLE) continue;  // another leg's pair (uniform)
         const int s0 = a.pairs[2 * (size_t)pair_idx], s1 = a.pairs[2 * (size_t)pair_idx + 1];
         if (!a.hull_points && (a.shape_type[s0] == GEO_CONVEX_MESH || a.shape_type[s1] == GEO_CONVEX_MESH)) continue;  // (uniform) no hull table
+        {   // (uniform) a heightfield pair without the heightfield tables / a mesh pair without the mesh tables / two mesh-like shapes
+            const int ty0 = a.shape_type[s0], ty1 = a.shape_type[s1];
+            const bool hf = ty0 == GEO_HFIELD || ty1 == GEO_HFIELD, ms = ty0 == GEO_MESH || ty1 == GEO_MESH;
+            if ((hf && (!a.shape_heightfield_index || ms || ty0 == ty1)) || (!hf && (!ms || !a.indices || ty0 == ty1))) continue;
+            if (hf && a.shape_heightfield_index[ty0 == GEO_HFIELD ? s0 : s1] < 0) continue;
+        }
         PairSetup c;
         pair_setup(a, s0, s1, c);
         __syncthreads();  // every lane has read the pair before it is rewritten as (mesh, convex)
@@ -252,7 +320,7 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
         // ---- block bounds (optional): the blocks of 64 consecutive triangles whose bounds touch the query box, ascending.  A
         // triangle that touches the box lies in a block that does, so the candidate set is the full scan's; spatially coherent index
         // orders (grids, most exported meshes) leave a handful of blocks of a large mesh
-        const bool use_blocks = a.block_bounds != nullptr && a.shape_block_start != nullptr;
+        const bool use_blocks = a.block_bounds != nullptr && a.shape_block_start != nullptr && !c.hfield;
         int n_hblk = 0;
         if (use_blocks) {
             const int nblk = (c.nt_ + NT_MESH_TRIANGLE_BLOCK - 1) / NT_MESH_TRIANGLE_BLOCK;
@@ -294,7 +362,9 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
                 if (r < n_rounds) {
                     int ti = r * MT_THREADS + t;
                     if (use_blocks) ti = MT_WAVES * r + wave < n_hblk ? (int)S.hblk[MT_WAVES * r + wave] * NT_MESH_TRIANGLE_BLOCK + lane : c.nt_;
-                    const bool hit = ti < c.nt_ && triangle_candidate(a, c, ti);
+                    bool hit = ti < c.nt_;
+                    if (hit && c.hfield) ti = hfield_candidate(c, ti);  // (every cell of the range is a candidate)
+                    else hit = hit && triangle_candidate(a, c, ti);
                     const unsigned long long m = __ballot(hit);
                     if (lane == 0) S.wave_hits[wave] = __popcll(m);
                     __syncthreads();
@@ -322,21 +392,22 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
                     triangle_contacts(a, c, ti, poly, cc);
                 }
                 if (a.reduce) {
-                    float ox, oy;
-                    red_encode_oct(cc.normal, ox, oy);  // (the buffer holds the normal as its octahedral code)
-                    const vec3 normal_buffered = red_decode_oct(ox, oy);
-                    for (int i = 0; i < cc.count; ++i)
-                        red_offer_buffered(L.tbl, normal_buffered, cc.center(i), cc.distance(i), X_mesh_inv, lo, hi, res, (ti << 4) | 8 | i);
+                    for (int i = 0; i < cc.count; ++i) {
+                        float ox, oy;
+                        red_encode_oct(cc.normal_of(i), ox, oy);  // (the buffer holds the normal as its octahedral code)
+                        red_offer_buffered(L.tbl, red_decode_oct(ox, oy), cc.center(i), cc.distance(i), X_mesh_inv, lo, hi, res, (ti << 4) | 8 | i);
+                    }
                     // the FIRST batch's contacts stay in LDS: a pair that needs no second batch (the usual case) hands its winners
                     // their records from here instead of running MPR / GJK for them again
                     if (batches == 0 && t < nb) {
                         S.batch_tri[t] = ti;
                         float* rcd = S.rec + t;
-                        rcd[0] = ox; rcd[MT_THREADS] = oy;
                         for (int i = 0; i < cc.count; ++i) {
                             const vec3 ctr = cc.center(i);
-                            rcd[(2 + 4 * i) * MT_THREADS] = ctr.x; rcd[(3 + 4 * i) * MT_THREADS] = ctr.y;
-                            rcd[(4 + 4 * i) * MT_THREADS] = ctr.z; rcd[(5 + 4 * i) * MT_THREADS] = cc.distance(i);
+                            float ox, oy;
+                            red_encode_oct(cc.normal_of(i), ox, oy);
+                            rcd[(6 * i) * MT_THREADS] = ctr.x; rcd[(6 * i + 1) * MT_THREADS] = ctr.y; rcd[(6 * i + 2) * MT_THREADS] = ctr.z;
+                            rcd[(6 * i + 3) * MT_THREADS] = cc.distance(i); rcd[(6 * i + 4) * MT_THREADS] = ox; rcd[(6 * i + 5) * MT_THREADS] = oy;
                         }
                     }
                     if (batches == 0) batch_n = nb;
@@ -355,7 +426,7 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
                     if (pass == 1)
                         for (int i = 0; i < cc.count; ++i) {
                             const int slot = L.base + before + i;
-                            if (slot < a.capacity) write_row(a, c, slot, pair_idx, (ti << 4) | 8 | i, cc.center(i), cc.normal, cc.distance(i));
+                            if (slot < a.capacity) write_row(a, c, slot, pair_idx, (ti << 4) | 8 | i, cc.center(i), cc.normal_of(i), cc.distance(i));
                         }
                     __syncthreads();
                     if (t == 0) {
@@ -407,9 +478,9 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
                     else hi_ = mid;
                 }
                 const float* rcd = S.rec + lo_;
-                L.pos[k][0] = rcd[(2 + 4 * i) * MT_THREADS]; L.pos[k][1] = rcd[(3 + 4 * i) * MT_THREADS];
-                L.pos[k][2] = rcd[(4 + 4 * i) * MT_THREADS]; L.pos[k][3] = rcd[(5 + 4 * i) * MT_THREADS];
-                L.oct[k][0] = rcd[0]; L.oct[k][1] = rcd[MT_THREADS];
+                L.pos[k][0] = rcd[(6 * i) * MT_THREADS]; L.pos[k][1] = rcd[(6 * i + 1) * MT_THREADS];
+                L.pos[k][2] = rcd[(6 * i + 2) * MT_THREADS]; L.pos[k][3] = rcd[(6 * i + 3) * MT_THREADS];
+                L.oct[k][0] = rcd[(6 * i + 4) * MT_THREADS]; L.oct[k][1] = rcd[(6 * i + 5) * MT_THREADS];
                 L.fp[k] = fp;
                 continue;
             }
@@ -418,7 +489,7 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
             const int i = fp & 7;
             const vec3 centre = cc.center(i);
             float ox, oy;
-            red_encode_oct(cc.normal, ox, oy);
+            red_encode_oct(cc.normal_of(i), ox, oy);
             L.pos[k][0] = centre.x; L.pos[k][1] = centre.y; L.pos[k][2] = centre.z; L.pos[k][3] = cc.distance(i);
             L.oct[k][0] = ox; L.oct[k][1] = oy;
             L.fp[k] = fp;
@@ -445,14 +516,15 @@ __global__ void __launch_bounds__(MT_THREADS) mesh_triangle_pairs_kernel(nt_mesh
 }  // namespace
 
 extern "C" nt_status nt_mesh_triangle_pairs(const nt_mesh_triangle_args* a, void* stream) {
-    if (!a || !a->pairs || !a->shape_type || !a->shape_transform || !a->shape_data || !a->shape_gap || !a->shape_vertex_range ||
-        !a->shape_triangle_range || !a->vertices || !a->indices || !a->out_count || !a->out_pair || !a->out_key || !a->out_data ||
+    if (!a || !a->pairs || !a->shape_type || !a->shape_transform || !a->shape_data || !a->shape_gap ||
+        (!a->shape_heightfield_index && (!a->shape_vertex_range || !a->shape_triangle_range || !a->vertices || !a->indices)) || !a->out_count || !a->out_pair || !a->out_key || !a->out_data ||
         !a->out_blk || a->capacity < 0)
         return NT_ERR_INVALID_ARG;
     if (a->reduce && (!a->shape_aabb_lower || !a->shape_aabb_upper || !a->shape_voxel_res)) return NT_ERR_INVALID_ARG;
     if (a->pair_world_prefix ? (a->worlds <= 0 || a->pairs_per_world <= 0) : a->pair_count < 0) return NT_ERR_INVALID_ARG;
     if ((a->block_bounds == nullptr) != (a->shape_block_start == nullptr)) return NT_ERR_INVALID_ARG;
     if ((a->hull_points == nullptr) != (a->shape_hull_range == nullptr)) return NT_ERR_INVALID_ARG;
+    if (a->shape_heightfield_index && (!a->heightfields || !a->elevations || !a->shape_aabb_lower || !a->shape_aabb_upper)) return NT_ERR_INVALID_ARG;
     long long blocks = a->pair_world_prefix ? (long long)a->worlds * a->pairs_per_world : (long long)a->pair_count;
     if (blocks == 0) return NT_OK;
 #ifdef NT_EMULATED_GRID

@@ -29,7 +29,7 @@ struct Fail {
 [[noreturn]] void unsupported(const std::string& w) { throw Fail{NT_ERR_UNSUPPORTED, w}; }
 [[noreturn]] void invalid(const std::string& w) { throw Fail{NT_ERR_INVALID_ARG, w}; }
 
-enum { GEO_PLANE = 1, GEO_SPHERE = 3, GEO_CAPSULE = 4, GEO_ELLIPSOID = 5, GEO_CYLINDER = 6, GEO_BOX = 7, GEO_MESH = 8, GEO_CONE = 9, GEO_CONVEX_MESH = 10 };
+enum { GEO_PLANE = 1, GEO_HFIELD = 2, GEO_SPHERE = 3, GEO_CAPSULE = 4, GEO_ELLIPSOID = 5, GEO_CYLINDER = 6, GEO_BOX = 7, GEO_MESH = 8, GEO_CONE = 9, GEO_CONVEX_MESH = 10 };
 constexpr int SHAPE_HYDROELASTIC = 1 << 4;  // ShapeFlags.HYDROELASTIC
 constexpr int BODY_KINEMATIC = 2;
 
@@ -283,7 +283,7 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
         // tile PAIR: its pairs go to the SDF / vertex legs below or are refused.
         std::vector<int32_t> tile_type = shape_type;
         for (int32_t& t : tile_type)
-            if (t == GEO_MESH) t = GEO_CONVEX_MESH;
+            if (t == GEO_MESH || t == GEO_HFIELD) t = GEO_CONVEX_MESH;
         d.shape_type = h.put(tile_type);
     }
     std::vector<int32_t> shape_flags_tab = shape_table(s.shape_flags, 0, false, "shape_flags");
@@ -362,6 +362,7 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
                 return ty == GEO_SPHERE || ty == GEO_CAPSULE || ty == GEO_ELLIPSOID || ty == GEO_CYLINDER || ty == GEO_BOX || ty == GEO_CONE ||
                        ty == GEO_CONVEX_MESH;
             };
+            auto mesh_like = [&](int l) { return shape_type[l] == GEO_MESH || shape_type[l] == GEO_HFIELD; };  // (narrow_phase.py:553-583)
             struct Routed { int id0, id1, a, b, kind, edges; };
             std::vector<Routed> routed;
             std::vector<int32_t> ta, tb;
@@ -372,7 +373,7 @@ void build(const nt_newton_model& s, nt_model_handle& h) {
                 if (hydro(a) && hydro(b)) kind = 1;
                 else if (has_sdf(a) && has_sdf(b) && !(shape_type[a] == GEO_BOX && shape_type[b] == GEO_BOX)) kind = 0;
                 else if ((infinite_plane(a) && shape_type[b] == GEO_MESH) || (infinite_plane(b) && shape_type[a] == GEO_MESH)) kind = 2;
-                else if ((shape_type[a] == GEO_MESH && tri_partner(b)) || (shape_type[b] == GEO_MESH && tri_partner(a))) kind = 3;
+                else if ((mesh_like(a) && tri_partner(b)) || (mesh_like(b) && tri_partner(a))) kind = 3;
                 if (kind < 0) { ta.push_back(a); tb.push_back(b); tile_pos.push_back(p); continue; }
                 const int ia = newton_id0(a), ib = newton_id0(b);
                 routed.push_back(ia < ib ? Routed{ia, ib, a, b, kind, has_sdf(a) && has_sdf(b)} : Routed{ib, ia, b, a, kind, has_sdf(a) && has_sdf(b)});

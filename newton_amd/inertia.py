@@ -96,7 +96,7 @@ def transform_inertia(mass, inertia, offset, quat):
 
 
 def compute_shape_radius(geo_type, scale, src=None):
-    if geo_type in (GeoType.CONVEX_MESH, GeoType.MESH):  # bounding sphere of the scaled local AABB (geometry/utils.py:86-98)
+    if geo_type in (GeoType.CONVEX_MESH, GeoType.MESH, GeoType.HFIELD):  # bounding sphere of the scaled local AABB (geometry/utils.py:86-98)
         verts = np.asarray(src.vertices, dtype=np.float64) * np.asarray(scale, dtype=np.float64)
         return float(0.5 * np.linalg.norm(verts.max(axis=0) - verts.min(axis=0)))
     sx, sy, sz = (abs(float(s)) for s in scale)

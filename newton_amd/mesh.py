@@ -254,3 +254,34 @@ def triangle_block_bounds(vertices, indices, block: int = TRIANGLE_BLOCK) -> np.
         p = v[tri[b * block:(b + 1) * block].reshape(-1)]
         out[b, :3], out[b, 3:] = p.min(axis=0), p.max(axis=0)
     return out
+
+
+class Heightfield:
+    """newton.Heightfield (geometry/types.py:2240-2340): a 2-D elevation grid for terrain.  The data is normalised to [0, 1];
+    min_z / max_z give the world-space range (derived from the data when both are omitted); the grid spans [-hx, hx] x [-hy, hy],
+    rows along Y, columns along X.  Always static.  Collides with convex shapes cell by cell (two TRIANGLE_PRISM triangles per cell,
+    utils/heightfield.py:280-462) through the triangle leg of CollisionPipeline."""
+
+    def __init__(self, data, nrow: int, ncol: int, hx: float = 1.0, hy: float = 1.0, min_z=None, max_z=None):
+        if nrow < 2 or ncol < 2:
+            raise ValueError(f"Heightfield requires nrow >= 2 and ncol >= 2, got nrow={nrow}, ncol={ncol}")
+        if (min_z is None) != (max_z is None):
+            raise ValueError("min_z and max_z must both be provided or both omitted")
+        raw = np.array(data, dtype=np.float32).reshape(nrow, ncol)
+        d_min, d_max = float(raw.min()), float(raw.max())
+        self._data = (raw - d_min) / (d_max - d_min) if d_max > d_min else np.zeros_like(raw)
+        self.nrow, self.ncol, self.hx, self.hy = int(nrow), int(ncol), float(hx), float(hy)
+        self.min_z = d_min if min_z is None else float(min_z)
+        self.max_z = d_max if max_z is None else float(max_z)
+        self.is_solid, self.has_inertia, self.mass = True, False, 0.0
+
+    @property
+    def data(self):
+        """The normalised [0, 1] elevation data, [nrow][ncol]."""
+        return self._data
+
+    @property
+    def vertices(self):
+        """The eight corners of the field's bounding box: what the tiles need of a heightfield (a pre-computed local AABB)."""
+        return np.array([(sx * self.hx, sy * self.hy, z) for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for z in (self.min_z, self.max_z)],
+                        dtype=np.float32)

@@ -163,7 +163,8 @@ class EnvTemplate:
         # The tile kernels see a triangle mesh as what compute_shape_aabbs makes of it -- a shape with a pre-computed local AABB
         # (collide.py:421-445, the branch MESH and CONVEX_MESH share): their table carries CONVEX_MESH for it (AABB from the vertex
         # bounds below).  A MESH never is a tile PAIR: its pairs go to the SDF / vertex legs or are refused further down.
-        self.tile_shape_type = np.where(self.shape_type == int(GeoType.MESH), int(GeoType.CONVEX_MESH), self.shape_type).astype(np.int32)
+        self.tile_shape_type = np.where((self.shape_type == int(GeoType.MESH)) | (self.shape_type == int(GeoType.HFIELD)), int(GeoType.CONVEX_MESH),
+                                        self.shape_type).astype(np.int32)  # (a heightfield likewise: its bounding box, collide.py:348)
         self.shape_flags = shape_uniform(m.shape_flags, "shape_flags")
         self.shape_group = shape_uniform(m.shape_collision_group, "shape_collision_group")
         # convex-hull vertex slices (shared Mesh assets => identical in every world) + unscaled hull bounds per shape
@@ -244,6 +245,9 @@ class EnvTemplate:
         def tri_mesh(l):
             return int(self.shape_type[l]) == GeoType.MESH
 
+        def mesh_like(l):  # a triangle mesh or a heightfield (narrow_phase.py:553-583: the same triangle kernels, cell by cell)
+            return int(self.shape_type[l]) in (GeoType.MESH, GeoType.HFIELD)
+
         is_mesh_plane_pair = ~is_sdf_pair & np.array([(infinite_plane(a) and tri_mesh(b)) or (infinite_plane(b) and tri_mesh(a))
                                                       for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
         is_sdf_pair = is_sdf_pair | is_mesh_plane_pair
@@ -255,7 +259,7 @@ class EnvTemplate:
         def tri_partner(l):
             return int(self.shape_type[l]) in tri_partner_types
 
-        is_mesh_tri_pair = ~is_sdf_pair & np.array([(tri_mesh(a) and tri_partner(b)) or (tri_mesh(b) and tri_partner(a))
+        is_mesh_tri_pair = ~is_sdf_pair & np.array([(mesh_like(a) and tri_partner(b)) or (mesh_like(b) and tri_partner(a))
                                                     for a, b in zip(self.pair_a, self.pair_b)], dtype=bool)
         is_sdf_pair = is_sdf_pair | is_mesh_tri_pair
         sp = [(min(newton_id0(a), newton_id0(b)), max(newton_id0(a), newton_id0(b)), int(a), int(b), bool(h), bool(mp), bool(mt))

@@ -205,8 +205,23 @@ class SdfLeg:
                 # the reduction's packed values carry the fingerprint (triangle << 4 | 8 | manifold index) in 22 bits
                 raise NotImplementedError("triangle meshes with 2^18 or more triangles are not supported by the triangle leg")
 
+            # heightfields as the mesh-like shape of a pair: HeightfieldData records + elevation grids (include/newton_hip_mesh.h)
+            self._hf_index = self._hf_data = self._hf_elev = None
+            hf_tris = np.zeros(S, np.int64)
+            if int(getattr(model, "heightfield_count", 0)) > 0:
+                hf = (_lib.nt_heightfield * model.heightfield_count)()
+                for k, (off, nrow, ncol, hx, hy, zlo, zhi) in enumerate(model.heightfield_data):
+                    hf[k] = _lib.nt_heightfield(int(off), int(nrow), int(ncol), float(hx), float(hy), float(zlo), float(zhi))
+                self._hf_data = torch.from_numpy(np.frombuffer(bytes(hf), dtype=np.uint8).copy()).to(dev)
+                self._hf_index = up(model.shape_heightfield_index, np.int32)
+                self._hf_elev = up(model.heightfield_elevations, np.float32)
+                for i, h in enumerate(np.asarray(model.shape_heightfield_index)):
+                    if h >= 0:
+                        hf_tris[i] = 2 * (model.heightfield_data[h][1] - 1) * (model.heightfield_data[h][2] - 1)
+
             def tri_count(l):
-                return int(model.mesh_triangle_range[t.shape_local0 + l if l < t.ns else int(t.gshape_id[l - t.ns]), 1])
+                i = t.shape_local0 + l if l < t.ns else int(t.gshape_id[l - t.ns])
+                return int(model.mesh_triangle_range[i, 1]) + int(hf_tris[i])
 
             # rows a world can get from its triangle pairs: the reduction's table per pair (245 slots), bounded by 5 contacts per
             # triangle; CollisionPipeline(reduce_contacts=False) passes triangle_rows_per_pair for the unreduced budget
@@ -357,6 +372,9 @@ class SdfLeg:
                                                                               self.raw_capacity)
             mt.out_radius, mt.out_blk = self.raw_radius.data_ptr(), self.blk.data_ptr()
             mt.hull_points, mt.shape_hull_range = self._hull_points.data_ptr(), self._hull_range.data_ptr()
+            if self._hf_index is not None:
+                mt.shape_heightfield_index, mt.heightfields, mt.elevations = (self._hf_index.data_ptr(), self._hf_data.data_ptr(),
+                                                                              self._hf_elev.data_ptr())
             if os.environ.get("NT_TRIANGLE_BLOCKS", "1") != "0":  # (0: the plain scan over every triangle -- measurements)
                 mt.block_bounds, mt.shape_block_start = self._block_bounds.data_ptr(), self._block_start.data_ptr()
             _lib.check(lib.nt_mesh_triangle_pairs(C.byref(mt), stream), "nt_mesh_triangle_pairs")

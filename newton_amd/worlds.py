@@ -22,7 +22,7 @@ _SHAPE = ("shape_transform", "shape_type", "shape_scale", "shape_flags", "shape_
           "shape_mesh_count", "shape_collision_aabb_lower", "shape_collision_aabb_upper", "shape_margin", "shape_gap",
           "shape_collision_radius", "shape_material_ke", "shape_material_kd", "shape_material_kf", "shape_material_ka",
           "shape_material_mu", "shape_material_restitution", "shape_material_mu_torsional", "shape_material_mu_rolling",
-          "shape_material_kh", "_shape_sdf_index", "shape_edge_range", "_shape_voxel_resolution", "mesh_vertex_range", "mesh_triangle_range")
+          "shape_material_kh", "_shape_sdf_index", "shape_edge_range", "_shape_voxel_resolution", "mesh_vertex_range", "mesh_triangle_range", "shape_heightfield_index")
 # (the SDF table Model._texture_sdf_data, the edge tables mesh_edge_centers / _halves and the triangle meshes' vertex table
 # mesh_vertices / index table mesh_indices are shared assets: copied by reference)
 

@@ -27,6 +27,7 @@ using namespace orc;
 namespace {
 
 constexpr int GEO_TRIANGLE = 1000;  // GeoTypeEx.TRIANGLE (support_function.py:58): vertex A at the origin, B - A in scale, C - A in aux
+constexpr int GEO_TRIANGLE_PRISM = 1001;  // a heightfield cell's triangle, extruded 1 m along -Z of the heightfield frame (:59,193-200)
 struct Geom {
     int type;
     vec3 scale;
@@ -67,13 +68,15 @@ vec3 support_map_box(const Geom& g, vec3 d) {
 vec3 support_map(const Geom& g, vec3 direction) {
     const float eps = 1.0e-12f;
     vec3 result(0.0f);
-    if (g.type == GEO_TRIANGLE) {
-        // support_function.py:174-191: the vertex furthest along the direction; ties prefer a, then b
+    if (g.type == GEO_TRIANGLE || g.type == GEO_TRIANGLE_PRISM) {
+        // support_function.py:174-200: the vertex furthest along the direction; ties prefer a, then b; the prism adds its 1 m depth
         vec3 tri_a(0.0f), tri_b = g.scale, tri_c = g.aux;
         float dot_a = dot(tri_a, direction), dot_b = dot(tri_b, direction), dot_c = dot(tri_c, direction);
-        if (dot_a >= dot_b && dot_a >= dot_c) return tri_a;
-        if (dot_b >= dot_c) return tri_b;
-        return tri_c;
+        if (dot_a >= dot_b && dot_a >= dot_c) result = tri_a;
+        else if (dot_b >= dot_c) result = tri_b;
+        else result = tri_c;
+        if (g.type == GEO_TRIANGLE_PRISM && direction.z < 0.0f) result = result + vec3(0.0f, 0.0f, -1.0f);
+        return result;
     }
     if (g.type == GEO_PLANE) {
         // support_function.py:334-345: finite rectangle in XY (half-width scale.x, half-length scale.y), normal +Z
@@ -246,7 +249,7 @@ vec3 closest_point_on_triangle(vec3 p, vec3 tri_a, vec3 tri_b, vec3 tri_c) {
 }
 // support_function.py:467-502: a triangle's Minkowski seed is the point of the triangle nearest B's centre, nudged to the centroid
 vec3 adjust_minkowski_center(const Geom& ga, vec3 center_b_world, vec3 center_b_to_a) {
-    if (ga.type != GEO_TRIANGLE) return center_b_to_a;
+    if (ga.type != GEO_TRIANGLE && ga.type != GEO_TRIANGLE_PRISM) return center_b_to_a;
     vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
     vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
     float face_normal_length_sq = length_sq(face_normal);
@@ -275,7 +278,7 @@ vec3 adjust_minkowski_center(const Geom& ga, vec3 center_b_world, vec3 center_b_
 }
 // support_function.py:505-538
 vec3 minkowski_center_fallback(const Geom& ga, vec3 center_b_world) {
-    if (ga.type != GEO_TRIANGLE) return vec3(0.0f);
+    if (ga.type != GEO_TRIANGLE && ga.type != GEO_TRIANGLE_PRISM) return vec3(0.0f);
     vec3 tri_a(0.0f), tri_b = ga.scale, tri_c = ga.aux;
     vec3 face_normal = cross(tri_b - tri_a, tri_c - tri_a);
     float face_normal_length_sq = length_sq(face_normal);
@@ -997,7 +1000,7 @@ ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a, quat r
         c.center = c.center - normal * (P.radius_eff_b * 0.5f);
         c.distance = c.distance - P.radius_eff_b;
     }
-    auto discrete = [](int t) { return t == GEO_BOX || t == GEO_CONVEX_MESH || t == GEO_PLANE || t == GEO_TRIANGLE; };
+    auto discrete = [](int t) { return t == GEO_BOX || t == GEO_CONVEX_MESH || t == GEO_PLANE || t == GEO_TRIANGLE || t == GEO_TRIANGLE_PRISM; };
     bool is_discrete_a = discrete(type_a), is_discrete_b = discrete(type_b);
     bool is_axial_a = type_a == GEO_CYLINDER || type_a == GEO_CONE;
     bool is_axial_b = type_b == GEO_CYLINDER || type_b == GEO_CONE;
@@ -1043,7 +1046,27 @@ ContactOut post_process_axial(ContactOut c, const PairCtx& P, vec3 pos_a, quat r
 
 // write_contact(output_index = -1) (collide.py:206-254)
 void emit(PairCtx& P, ContactOut c, vec3 pos_a, quat rot_a, vec3 pos_b, quat rot_b) {
-    c = post_process_axial(c, P, pos_a, rot_a, pos_b, rot_b);  // (post_process_triangle_contact only edits TRIANGLE_PRISM contacts)
+    if (P.ga.type == GEO_TRIANGLE_PRISM && c.distance < 0.0f) {
+        // post_process_triangle_contact (collision_core.py:280-322): a penetrating contact of a heightfield prism moves to the
+        // physical triangle face -- normal = the face normal (up), distance along it
+        vec3 normal_local = cross(P.ga.scale, P.ga.aux);
+        float normal_length_sq = length_sq(normal_local);
+        if (normal_length_sq >= 1.0e-20f) {
+            normal_local = normal_local / std::sqrt(normal_length_sq);
+            if (normal_local.z < 0.0f) normal_local = -normal_local;
+            vec3 normal_world = quat_rotate(rot_a, normal_local);
+            vec3 point_b_world = c.center + 0.5f * c.distance * c.normal;
+            vec3 point_b_local = quat_rotate_inv(rot_a, point_b_world - pos_a);
+            vec3 projected_b = point_b_local - dot(point_b_local, normal_local) * normal_local;
+            vec3 point_a = closest_point_on_triangle(projected_b, vec3(0.0f), P.ga.scale, P.ga.aux);
+            float distance = 0.0f;
+            if (length_sq(point_a - projected_b) < 1.0e-10f) distance = dot(point_b_local - point_a, normal_local);
+            c.center = quat_rotate(rot_a, point_a) + pos_a + 0.5f * distance * normal_world;
+            c.normal = normal_world;
+            c.distance = distance;
+        }
+    }
+    c = post_process_axial(c, P, pos_a, rot_a, pos_b, rot_b);
     if (P.raw) {
         const float key = (float)((P.sort_sub_key << 3) | P.written);  // (exact: keys of the test scenes stay below 2^24)
         for (float v : {c.center.x, c.center.y, c.center.z, c.normal.x, c.normal.y, c.normal.z, c.distance, key}) P.raw->push_back(v);
@@ -1308,10 +1331,134 @@ extern "C" int o_mesh_triangle_contacts(int n_pairs, const int* pairs, const int
                                         const float* shape_data, const float* shape_gap, const int* vertex_start,
                                         const int* tri_start, const int* tri_count, const float* vertices, const int* indices,
                                         const int* hull_start, const int* hull_count, const float* hull_points,
-                                        int* tri_out, int tri_cap, int* n_tri, float* out, int cap) {
+                                        const int* hf_index, const float* hf_table, const float* hf_elev, const float* aabb_lo,
+                                        const float* aabb_hi, int* tri_out, int tri_cap, int* n_tri, float* out, int cap) {
     int nt = 0, nc = 0;
+    // one (triangle | prism, convex) pair through compute_gjk_mpr_contacts, contacts appended to `out`
+    auto gjk_mpr_contacts = [&](PairCtx& P, vec3 pos_a, quat quat_a, vec3 pos_b, quat quat_b, float rigid_gap, int sort_sub_key) {
+        std::vector<float> raw;
+        P.raw = &raw;
+        P.sort_sub_key = sort_sub_key;
+        P.radius_eff_a = 0.0f;
+        P.radius_eff_b = 0.0f;
+        const float small_radius = 0.0001f;
+        if (P.gb.type == GEO_SPHERE || P.gb.type == GEO_CAPSULE) {
+            P.radius_eff_b = P.gb.scale.x;
+            P.gb.scale.x = small_radius;
+        }
+        float threshold = rigid_gap + P.radius_eff_a + P.radius_eff_b + P.margin_a + P.margin_b;
+        bool skip_multi_contact = P.gb.type == GEO_SPHERE || P.gb.type == GEO_ELLIPSOID;
+        quat rel_q = quat_inverse(quat_a) * quat_b;
+        vec3 rel_p = quat_rotate_inv(quat_a, pos_b - pos_a);
+        float margin_sum = P.margin_a + P.margin_b;
+        const float e4 = 1.0e-4f;
+        float enlarge = margin_sum <= 0.0f ? e4 : (margin_sum < e4 ? 2.0f * e4 : 0.0f);
+        vec3 point_a, point_b, normal;
+        float penetration, signed_distance;
+        bool collision = solve_mpr_core(P.ga, P.gb, rel_q, rel_p, enlarge, point_a, point_b, normal, penetration);
+        if (collision) {
+            signed_distance = -penetration + enlarge;
+            float half_enlarge = enlarge * 0.5f;
+            point_a = point_a - normal * half_enlarge;
+            point_b = point_b + normal * half_enlarge;
+        } else {
+            solve_closest_distance_core(P.ga, P.gb, rel_q, rel_p, 0.0f, point_a, point_b, normal, signed_distance);
+        }
+        if (skip_multi_contact || signed_distance > threshold) {
+            ContactOut c;
+            vec3 point = 0.5f * (point_a + point_b);
+            c.center = quat_rotate(quat_a, point) + pos_a;
+            c.normal = quat_rotate(quat_a, normal);
+            c.distance = signed_distance;
+            emit(P, c, pos_a, quat_a, pos_b, quat_b);
+        } else {
+            build_manifold(P, quat_a, pos_a, rel_q, rel_p, point_a, point_b, normal);
+        }
+        for (size_t r = 0; r + 8 <= raw.size(); r += 8) {
+            if (nc < cap) {
+                float* o = out + 10 * (size_t)nc;
+                o[0] = (float)P.shape_a; o[1] = (float)P.shape_b; o[2] = raw[r + 7];
+                for (int j = 0; j < 7; ++j) o[3 + j] = raw[r + j];
+            }
+            nc += 1;
+        }
+    };
+    auto convex_geom = [&](int shape, Geom& g) {  // extract_shape_data (+ _shape_center of a hull); false: a hull without its table
+        g.type = shape_type[shape];
+        g.scale = vec3(shape_data[4 * shape], shape_data[4 * shape + 1], shape_data[4 * shape + 2]);
+        if (g.type == GEO_CONVEX_MESH) {
+            if (!hull_points || hull_count[shape] <= 0) return false;
+            g.points = hull_points + 3 * hull_start[shape];
+            g.count = hull_count[shape];
+            vec3 first = cw_mul(ld3(g.points, 0), g.scale), lower = first, upper = first;
+            for (int i = 1; i < g.count; ++i) {
+                vec3 point = cw_mul(ld3(g.points, i), g.scale);
+                lower = vmin(lower, point);
+                upper = vmax(upper, point);
+            }
+            g.center = 0.5f * (lower + upper);
+        }
+        return true;
+    };
     for (int k = 0; k < n_pairs; ++k) {
         int shape_a = pairs[2 * k], shape_b = pairs[2 * k + 1];
+        if (hf_index && (shape_type[shape_a] == GEO_HFIELD || shape_type[shape_b] == GEO_HFIELD)) {
+            // ---- heightfield vs convex (narrow_phase.py:553-583 routing; utils/heightfield.py:366-462 midphase, :280-363 cells)
+            int hfield_shape = shape_type[shape_a] == GEO_HFIELD ? shape_a : shape_b;
+            int other_shape = shape_type[shape_a] == GEO_HFIELD ? shape_b : shape_a;
+            if (shape_type[other_shape] == GEO_HFIELD || shape_type[other_shape] == GEO_MESH || hf_index[hfield_shape] < 0) continue;
+            const float* hd = hf_table + 7 * hf_index[hfield_shape];
+            int data_offset = (int)hd[0], nrow = (int)hd[1], ncol = (int)hd[2];
+            float hx = hd[3], hy = hd[4], min_z = hd[5], max_z = hd[6];
+            transform X_hfield_ws = ldx(shape_transform, hfield_shape), X_other_ws = ldx(shape_transform, other_shape);
+            transform X_other_in_hfield = transform_inverse(X_hfield_ws) * X_other_ws;
+            vec3 other_pos = X_other_in_hfield.p;
+            quat other_rot = X_other_in_hfield.q;
+            vec3 local_lo = ld3(aabb_lo, other_shape), local_hi = ld3(aabb_hi, other_shape);
+            vec3 local_center = 0.5f * (local_lo + local_hi), local_half = 0.5f * (local_hi - local_lo);
+            vec3 center_in_hfield = quat_rotate(other_rot, local_center) + other_pos;
+            vec3 r0 = quat_rotate(other_rot, vec3(1.0f, 0.0f, 0.0f)), r1 = quat_rotate(other_rot, vec3(0.0f, 1.0f, 0.0f)),
+                 r2 = quat_rotate(other_rot, vec3(0.0f, 0.0f, 1.0f));
+            vec3 half_in_hfield(std::fabs(r0.x) * local_half.x + std::fabs(r1.x) * local_half.y + std::fabs(r2.x) * local_half.z,
+                                std::fabs(r0.y) * local_half.x + std::fabs(r1.y) * local_half.y + std::fabs(r2.y) * local_half.z,
+                                std::fabs(r0.z) * local_half.x + std::fabs(r1.z) * local_half.y + std::fabs(r2.z) * local_half.z);
+            float gap_sum = shape_gap[hfield_shape] + shape_gap[other_shape];
+            float margin_sum = shape_data[4 * hfield_shape + 3] + shape_data[4 * other_shape + 3];
+            float contact_threshold = gap_sum + margin_sum;
+            vec3 threshold_vec(contact_threshold, contact_threshold, contact_threshold);
+            vec3 q_lo = center_in_hfield - half_in_hfield - threshold_vec, q_hi = center_in_hfield + half_in_hfield + threshold_vec;
+            float dx = 2.0f * hx / (float)(ncol - 1), dy = 2.0f * hy / (float)(nrow - 1);
+            int col_min = std::max((int)std::floor((q_lo.x + hx) / dx), 0), col_max = std::min((int)std::floor((q_hi.x + hx) / dx), ncol - 2);
+            int row_min = std::max((int)std::floor((q_lo.y + hy) / dy), 0), row_max = std::min((int)std::floor((q_hi.y + hy) / dy), nrow - 2);
+            int cols = ncol - 1;
+            Geom gb0;
+            if (!convex_geom(other_shape, gb0)) continue;
+            float z_range = max_z - min_z;
+            for (int r = row_min; r <= row_max; ++r)
+                for (int c = col_min; c <= col_max; ++c)
+                    for (int tri_sub = 0; tri_sub < 2; ++tri_sub) {
+                        int tri_idx = (r * cols + c) * 2 + tri_sub;
+                        if (nt < tri_cap) { tri_out[3 * nt] = hfield_shape; tri_out[3 * nt + 1] = other_shape; tri_out[3 * nt + 2] = tri_idx; }
+                        nt += 1;
+                        // get_triangle_shape_from_heightfield
+                        float x0 = -hx + (float)c * dx, x1 = x0 + dx, y0 = -hy + (float)r * dy, y1 = y0 + dy;
+                        const float* e = hf_elev + data_offset;
+                        float h00 = e[r * ncol + c], h10 = e[r * ncol + (c + 1)], h01 = e[(r + 1) * ncol + c], h11 = e[(r + 1) * ncol + (c + 1)];
+                        float z00 = min_z + h00 * z_range, z10 = min_z + h10 * z_range, z01 = min_z + h01 * z_range, z11 = min_z + h11 * z_range;
+                        vec3 p00(x0, y0, z00), p10(x1, y0, z10), p01(x0, y1, z01), p11(x1, y1, z11);
+                        vec3 v0_local = p00, v1_local = tri_sub == 0 ? p10 : p11, v2_local = tri_sub == 0 ? p11 : p01;
+                        PairCtx P;
+                        P.m = nullptr; P.body_q = nullptr; P.ct = nullptr; P.shape_a = hfield_shape; P.shape_b = other_shape; P.written = 0;
+                        P.ga.type = GEO_TRIANGLE_PRISM;
+                        P.ga.scale = v1_local - v0_local;
+                        P.ga.aux = v2_local - v0_local;
+                        P.gb = gb0;
+                        P.margin_a = shape_data[4 * hfield_shape + 3];
+                        P.margin_b = shape_data[4 * other_shape + 3];
+                        gjk_mpr_contacts(P, transform_point(X_hfield_ws, v0_local), X_hfield_ws.q, X_other_ws.p, X_other_ws.q, gap_sum, (tri_idx << 1) | 1);
+                    }
+            continue;
+        }
         int mesh_shape, non_mesh_shape;
         if (shape_type[shape_a] == GEO_MESH && shape_type[shape_b] != GEO_MESH) { mesh_shape = shape_a; non_mesh_shape = shape_b; }
         else if (shape_type[shape_b] == GEO_MESH && shape_type[shape_a] != GEO_MESH) { mesh_shape = shape_b; non_mesh_shape = shape_a; }

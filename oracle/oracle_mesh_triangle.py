@@ -42,7 +42,8 @@ def triangle_contacts(s):
         return x.ctypes.data_as(C.c_void_p)
 
     pairs = np.asarray(s["pairs"], np.int32).reshape(-1, 2)
-    tri_cap = int(s["tri_count"].sum()) * max(len(pairs), 1) + 8
+    hf_tris = int(sum(2 * (int(r) - 1) * (int(c) - 1) for _, r, c, *_ in s.get("hf_table", ())))
+    tri_cap = (int(s["tri_count"].sum()) + hf_tris) * max(len(pairs), 1) + 8
     cap = 8 * tri_cap
     tri_out, out, n_tri = np.zeros((tri_cap, 3), np.int32), np.zeros((cap, 10), np.float32), C.c_int(0)
     n = lib.o_mesh_triangle_contacts(len(pairs), p(pairs, np.int32), p(s["shape_type"], np.int32), p(s["shape_transform"], np.float32),
@@ -52,6 +53,10 @@ def triangle_contacts(s):
                                      p(s.get("hull_start", np.zeros(len(s["shape_gap"]), np.int32)), np.int32),
                                      p(s.get("hull_count", np.zeros(len(s["shape_gap"]), np.int32)), np.int32),
                                      p(s["hull_points"] if len(s.get("hull_points", ())) else np.zeros((1, 3), np.float32), np.float32),
+                                     p(s.get("hf_index", np.full(len(s["shape_gap"]), -1, np.int32)), np.int32),
+                                     p(s["hf_table"] if len(s.get("hf_table", ())) else np.zeros((1, 7), np.float32), np.float32),
+                                     p(s["hf_elev"] if len(s.get("hf_elev", ())) else np.zeros(1, np.float32), np.float32),
+                                     p(s["aabb_lo"], np.float32), p(s["aabb_hi"], np.float32),
                                      tri_out.ctypes.data_as(C.c_void_p), tri_cap, C.byref(n_tri),
                                      out.ctypes.data_as(C.c_void_p), cap)
     assert n <= cap and n_tri.value <= tri_cap

@@ -92,12 +92,18 @@ def run(s, reverse):
             h0, nh = int(s["hull_start"][k]), int(s["hull_count"][k])
             source[k] = wp.Mesh(points=A(s["hull_points"][h0:h0 + nh], wp.vec3)).id
     P = len(s["pairs"])
-    max_tri = int(s["tri_count"].sum()) * max(P, 1) + 8
+    max_tri = (int(s["tri_count"].sum()) + int(sum(2 * (r - 1) * (c - 1) for _, r, c, *_ in s["hf_table"]))) * max(P, 1) + 8
     xf = A(s["shape_transform"], wp.transform)
     types, data, gap = A(s["shape_type"], wp.int32), A(s["shape_data"], wp.vec4), A(s["shape_gap"], wp.float32)
     src = A(source, wp.uint64)
     lo, hi, res = A(s["aabb_lo"], wp.vec3), A(s["aabb_hi"], wp.vec3), A(s["res"], wp.vec3i)
-    hf_index, hf_data, hf_elev = A(np.full(S, -1, np.int32), wp.int32), wp.Array(), wp.Array()
+    hf = importlib.import_module("newton._src.utils.heightfield")
+    hf_index, hf_data, hf_elev = A(s["hf_index"], wp.int32), wp.Array(), A(s["hf_elev"], wp.float32)
+    for off, nrow, ncol, hx, hy, zlo, zhi in s["hf_table"]:
+        d = hf.HeightfieldData()
+        d.data_offset, d.nrow, d.ncol = int(off), int(nrow), int(ncol)
+        d.hx, d.hy, d.min_z, d.max_z = (np.float32(v) for v in (hx, hy, zlo, zhi))
+        hf_data.append(d)
     tri_pairs = wp.zeros(max_tri, dtype=wp.vec3i)
     tri_count = A(np.zeros(1, np.int32), wp.int32)
     wp.launch(narrow.narrow_phase_find_mesh_triangle_overlaps_kernel, dim=[P, 1],
@@ -137,12 +143,12 @@ def main():
     import mesh_triangle_cases as mc
 
     rec = {}
-    for name in mc.CASES:
+    for name in mc.CASES + mc.HF_CASES:
         s = mc.scene(name)
         triples, buffered, fwd = run(s, False)
         _, _, rev = run(s, True)
         assert fwd == rev, name
-        print(f"{name}: {int(s['tri_count'].sum())} triangles, {len(triples)} triangle pairs, {len(buffered['fp'])} buffered contacts, "
+        print(f"{name}: {int(s['tri_count'].sum()) + int(sum(2 * (r - 1) * (c - 1) for _, r, c, *_ in s['hf_table']))} triangles, {len(triples)} triangle pairs, {len(buffered['fp'])} buffered contacts, "
               f"{len(fwd)} after the reduction")
         rec[f"{name}/tri_pairs"] = triples
         for k, v in buffered.items():

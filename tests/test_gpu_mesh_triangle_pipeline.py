@@ -93,7 +93,9 @@ def checker_rows(model, leg, body_q, worlds=None):
              tri_count=model.mesh_triangle_range[:, 1], vertices=model.mesh_vertices, indices=model.mesh_indices,
              hull_start=np.asarray(model.shape_mesh_start, np.int32),
              hull_count=np.where(np.asarray(model.shape_type) == 10, np.asarray(model.shape_mesh_count), 0).astype(np.int32),
-             hull_points=np.asarray(model.mesh_points, np.float32))
+             hull_points=np.asarray(model.mesh_points, np.float32),
+             hf_index=np.asarray(model.shape_heightfield_index, np.int32),
+             hf_table=np.asarray(model.heightfield_data, np.float32).reshape(-1, 7), hf_elev=np.asarray(model.heightfield_elevations, np.float32))
 
     def gid(l, w):
         return t.shape_local0 + w * t.ns + l if l < t.ns else int(t.gshape_id[l - t.ns])
@@ -237,3 +239,111 @@ def test_terrain_2048_worlds_rows_vs_checker_and_matching():
     n2 = int(c2.rigid_contact_count.item())
     matched = int((mi[:n2] >= 0).sum().item())
     assert matched > 0.8 * n2, (matched, n2)
+
+
+def hfield_scene(worlds, kinds=("box", "sphere", "capsule", "hull", "cylinder"), device="cuda:0", gap=0.004, margin=0.0, seed=9, drop=0.0,
+                 tilt=0.0):
+    """Every world: one free body per kind resting slightly inside ONE shared static heightfield (nt.Heightfield, a global shape)."""
+    import newton_amd as nt
+
+    rng = np.random.default_rng(seed)
+    nrow, ncol, hx, hy = 33, 41, 2.0, 1.6
+    xs, ys = np.linspace(-hx, hx, ncol), np.linspace(-hy, hy, nrow)
+    raw = np.array([[terrain_height(x, y) for x in xs] for y in ys], np.float32)
+    field = nt.Heightfield(raw, nrow, ncol, hx=hx, hy=hy)
+    half = dict(box=0.05, sphere=0.06, capsule=0.04, cylinder=0.05, hull=0.04)
+    env = nt.ModelBuilder()
+    env.default_shape_cfg.gap = gap
+    env.default_shape_cfg.margin = margin
+    for k, kind in enumerate(kinds):
+        b = env.add_body(xform=[0.4 * k - 0.4, 0.0, 0.2, 0.0, 0.0, 0.0, 1.0])
+        if kind == "box":
+            env.add_shape_box(b, hx=0.08, hy=0.06, hz=0.05)
+        elif kind == "sphere":
+            env.add_shape_sphere(b, radius=0.06)
+        elif kind == "capsule":
+            env.add_shape_capsule(b, radius=0.04, half_height=0.08)
+        elif kind == "hull":
+            pts = np.array([(sx * 0.07, sy * 0.05, sz * 0.04) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)] +
+                           [(0.0, -0.03, 0.06), (0.0, 0.03, 0.06)], np.float32)
+            env.add_shape_convex_hull(b, mesh=nt.Mesh.convex_hull_of(pts))
+        else:
+            env.add_shape_cylinder(b, radius=0.05, half_height=0.05)
+    scene = nt.ModelBuilder()
+    scene.default_shape_cfg.gap = gap
+    scene.default_shape_cfg.margin = margin
+    scene.replicate(env, worlds)
+    q_field = nt._np_math.quat_rpy(tilt, 0.0, 0.0)
+    scene.add_shape_heightfield(heightfield=field, xform=[0.0, 0.0, 0.0, *q_field])
+    model = scene.finalize(device=device)
+    nbody = len(kinds)
+    for w in range(worlds):
+        for k, kind in enumerate(kinds):
+            x, y = 0.6 * k - 1.2 + rng.uniform(-0.1, 0.1), rng.uniform(-0.8, 0.8)
+            q = nt._np_math.quat_rpy(*(rng.uniform(-0.05, 0.05, size=2)), rng.uniform(-1.0, 1.0))
+            if kind == "capsule":
+                q = nt._np_math.quat_rpy(0.0, np.pi / 2 + rng.uniform(-0.03, 0.03), rng.uniform(-1.0, 1.0))
+            i = w * nbody + k
+            # (the field's bilinear-ish surface at the grid resolution: the analytic height is within a millimetre of it)
+            p_local = np.array([x, y, terrain_height(x, y) + half[kind] - 0.001 + drop])
+            model.body_q[i, :3] = nt._np_math.quat_rotate(q_field, p_local) if tilt else p_local
+            model.body_q[i, 3:] = nt._np_math.quat_mul(q_field, q) if tilt else q
+            model.joint_q.reshape(-1, 7)[i] = model.body_q[i]
+    return model
+
+
+@pytest.mark.parametrize("tilt,margin", [(0.0, 0.0), (0.15, 0.001)])
+def test_collide_rows_of_shapes_on_a_heightfield_match_the_checker(tilt, margin):
+    """GeoType.HFIELD through the triangle leg (narrow_phase.py:553-583, utils/heightfield.py:280-462): the grid-cell midphase from the
+    partner's local AABB, TRIANGLE_PRISM cells, penetrating contacts moved to the physical face -- rows vs the checker chain."""
+    import newton_amd as nt
+
+    E = 4
+    model = hfield_scene(E, tilt=tilt, margin=margin)
+    t = model.env
+    assert len(t.sdf_pair) == 5 and bool(t.sdf_pair_mesh_tri.all())
+    assert int(t.shape_type[-1]) == int(nt.GeoType.HFIELD) and int(t.tile_shape_type[-1]) == int(nt.GeoType.CONVEX_MESH)
+    pipe = nt.CollisionPipeline(model, broad_phase="nxn")
+    c1, c2 = pipe.contacts(), pipe.contacts()
+    state = model.state()
+    pipe.collide(state, c1)
+    pipe.collide(state, c2)
+    got, again = _rows(c1), _rows(c2)
+    for k in got:
+        assert np.array_equal(got[k], again[k]), k
+    leg = pipe._sdf_leg
+    assert not leg.overflow(c1._flat)["overflow"]
+    want = checker_rows(model, leg, model.body_q)
+    assert len(want["key"]) == len(got["key"]) > 5 * E
+    assert np.array_equal(got["key"], want["key"])
+    for k in ("shape0", "shape1"):
+        assert np.array_equal(got[k], want[k]), k
+    field = model.shape_count - 1
+    live = got["shape0"] >= 0
+    assert live.sum() >= 5 * E and np.all(got["shape0"][live] == field)  # (heightfield, convex)
+    for k in FIELDS[2:]:
+        assert np.abs(got[k] - want[k]).max() <= 2e-6, (k, np.abs(got[k] - want[k]).max())
+
+
+def test_xpbd_settles_shapes_on_a_heightfield():
+    import newton_amd as nt
+
+    E = 16
+    model = hfield_scene(E, drop=0.02)
+    pipe = nt.CollisionPipeline(model, broad_phase="nxn")
+    contacts = pipe.contacts()
+    solver = nt.solvers.SolverXPBD(model, iterations=4)
+    s0, s1 = model.state(), model.state()
+    dt = 1.0 / 600.0
+    for _ in range(600):
+        s0.clear_forces()
+        pipe.collide(s0, contacts)
+        solver.step(s0, s1, None, contacts, dt)
+        s0, s1 = s1, s0
+    q = s0.body_q.cpu().numpy().reshape(-1, 7)
+    qd = s0.body_qd.cpu().numpy().reshape(-1, 6)
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(qd))
+    ground = terrain_height(q[:, 0], q[:, 1])
+    assert np.all(q[:, 2] > ground + 0.02), (q[:, 2] - ground).min()
+    assert np.all(q[:, 2] < ground + 0.12)
+    assert np.median(np.abs(qd[:, :3]).max(axis=1)) < 0.05

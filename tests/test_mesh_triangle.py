@@ -22,7 +22,7 @@ VEC = os.path.join(HERE, "golden", "mesh_triangle_reference_vectors.npz")
 import mesh_triangle_cases as mc  # noqa: E402
 
 
-@pytest.mark.parametrize("name", mc.CASES)
+@pytest.mark.parametrize("name", mc.CASES + mc.HF_CASES)
 def test_checker_finds_the_triangles_the_reference_midphase_finds(name):
     """(mesh, convex, triangle) triples: the support-function AABB in the unscaled mesh frame, widened by margin + gap, against
     every triangle's bounds, minus the back faces -- the same set."""
@@ -34,7 +34,7 @@ def test_checker_finds_the_triangles_the_reference_midphase_finds(name):
     assert len(triples) > 0
 
 
-@pytest.mark.parametrize("name", mc.CASES)
+@pytest.mark.parametrize("name", mc.CASES + mc.HF_CASES)
 def test_checker_buffers_the_contacts_the_reference_kernel_buffers(name):
     """Per (mesh, convex) pair in fingerprint order: which triangles produce which manifold contacts, centre, distance and the
     octahedral code of the normal -- bit for bit (MPR / GJK with the TRIANGLE support map and Minkowski seed, build_manifold)."""
@@ -54,7 +54,7 @@ def test_checker_buffers_the_contacts_the_reference_kernel_buffers(name):
         assert np.any(np.bincount(tri) >= 3)  # face manifolds: several contacts per triangle
 
 
-@pytest.mark.parametrize("name", mc.CASES)
+@pytest.mark.parametrize("name", mc.CASES + mc.HF_CASES)
 def test_checker_keeps_the_contacts_the_reference_reducer_keeps(name):
     """reduce_contact_in_hashtable + export_reduced_contacts_kernel executed in two arrival orders vs reduce_buffered_contacts:
     the same survivors, bit-identical geometry, the margins / effective radii / gap sum the writer receives."""
@@ -109,19 +109,28 @@ def run_mesh_triangle(lib, s, reduce=1, capacity=None, start=0, stream=None, to_
                                                                    put("data", s["shape_data"]), put("gap", s["shape_gap"]))
     a.shape_vertex_range = put("vr", np.stack([s["vertex_start"], s["vertex_count"]], axis=1).astype(np.int32))
     a.shape_triangle_range = put("tr", np.stack([s["tri_start"], s["tri_count"]], axis=1).astype(np.int32))
-    a.vertices, a.indices = put("verts", s["vertices"]), put("idx", s["indices"])
+    a.vertices = put("verts", s["vertices"] if len(s["vertices"]) else np.zeros((1, 3), np.float32))
+    a.indices = put("idx", s["indices"] if len(s["indices"]) else np.zeros((1, 3), np.int32))
     a.shape_aabb_lower, a.shape_aabb_upper, a.shape_voxel_res = put("lo", s["aabb_lo"]), put("hi", s["aabb_hi"]), put("res", s["res"])
     a.reduce = int(reduce)
-    capacity = 5 * int(s["tri_count"].sum()) * max(P, 1) + 8 + start if capacity is None else capacity
+    n_tri = int(s["tri_count"].sum()) + int(sum(2 * (int(r) - 1) * (int(c) - 1) for _, r, c, *_ in s["hf_table"]))
+    capacity = 5 * n_tri * max(P, 1) + 8 + start if capacity is None else capacity
     a.out_count = put("count", np.array([start], np.int32))
     a.out_pair, a.out_key = put("opair", np.full(capacity, -1, np.int32)), put("okey", np.full(capacity, -1, np.int32))
     a.out_data, a.capacity = put("odata", np.zeros((capacity, 9), np.float32)), capacity
     a.out_radius = put("oradius", np.full((capacity, 2), -1.0, np.float32))
     a.out_blk = put("blk", np.full((slots, 2), -7, np.int32))
+    if len(s["hf_table"]) > 0:  # heightfields: HeightfieldData records + the concatenated elevation grids
+        hf = np.zeros(len(s["hf_table"]), dtype=[("data_offset", "<i4"), ("nrow", "<i4"), ("ncol", "<i4"), ("hx", "<f4"), ("hy", "<f4"),
+                                                 ("min_z", "<f4"), ("max_z", "<f4")])
+        for k, row in enumerate(s["hf_table"]):
+            hf[k] = (int(row[0]), int(row[1]), int(row[2]), row[3], row[4], row[5], row[6])
+        a.shape_heightfield_index, a.elevations = put("hfi", s["hf_index"]), put("hfe", s["hf_elev"])
+        a.heightfields = put("hfd", hf.view(np.uint8).reshape(len(hf), 28))
     if int(s["hull_count"].sum()) > 0:  # CONVEX_MESH partners: their vertex tables
         a.hull_points = put("hp", s["hull_points"])
         a.shape_hull_range = put("hr", np.stack([s["hull_start"], s["hull_count"]], axis=1).astype(np.int32))
-    if blocks:  # the bounds of every 64 consecutive triangles: the scan skips blocks that miss the query box (same candidates)
+    if blocks and int(s["tri_count"].sum()) > 0:  # the bounds of every 64 consecutive triangles: the scan skips blocks that miss the query box (same candidates)
         from newton_amd.mesh import triangle_block_bounds
 
         tabs, bstart, nb = [], np.zeros(len(s["shape_gap"]), np.int32), 0
@@ -147,7 +156,7 @@ def check_against_record(name, out_pairs, blk, rows, total, ref, s, slot_of=lamb
     pre = "" if reduce else "buffered_"
     n_ref = 0
     for k, (sa, sb) in enumerate(np.asarray(s["pairs"], np.int32)):
-        mesh, convex = (sa, sb) if s["shape_type"][sa] == mc.MESH else (sb, sa)
+        mesh, convex = (sa, sb) if s["shape_type"][sa] in (mc.MESH, mc.HFIELD) else (sb, sa)
         slot = slot_of(k)
         assert tuple(out_pairs[slot]) == (mesh, convex)  # normalised to (mesh, convex) whatever the id order
         rp = ref[f"{name}/{pre}pair"]
@@ -186,7 +195,7 @@ def emu():
 
 
 @pytest.mark.parametrize("reduce", [1, 0])
-@pytest.mark.parametrize("name", mc.CASES)
+@pytest.mark.parametrize("name", mc.CASES + mc.HF_CASES)
 def test_emulated_kernel_matches_the_record(emu, name, reduce):
     """The HIP source of nt_mesh_triangle_pairs compiled for the host (tests/emu) against the executed reference: the triangle scan,
     batches of waiting triangles, MPR / GJK + manifold per lane, the LDS reduction table with winners recomputed from (triangle,
@@ -210,7 +219,7 @@ def test_emulated_kernel_counts_past_the_capacity(emu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("reduce", [1, 0])
-@pytest.mark.parametrize("name", mc.CASES)
+@pytest.mark.parametrize("name", mc.CASES + mc.HF_CASES)
 def test_hip_mesh_triangle_reproduces_the_reference_leg(name, reduce):
     """nt_mesh_triangle_pairs on the MI355X against the executed reference, bit for bit; twice on the same buffers -> identical."""
     import torch
