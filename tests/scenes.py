@@ -455,12 +455,13 @@ def terrain_height(x, y):
     return 0.012 * np.sin(4.0 * x) * np.cos(3.0 * y)
 
 
-def terrain_scene(world_count: int, n_shapes: int = 8, device=None, seed: int = 6, cells: int = 64, half: float = 1.6, gap: float = 0.004):
+def terrain_scene(world_count: int, n_shapes: int = 8, device=None, seed: int = 6, cells: int = 64, half: float = 1.6, gap: float = 0.004,
+                  heightfield: bool = False):
     """`n_shapes` convex primitives per world (box, sphere, capsule, cylinder in turn) resting on ONE shared static terrain: a triangle
     mesh of cells x cells x 2 triangles (a global shape without an SDF).  Every (primitive, terrain) pair goes through the triangle leg
     of CollisionPipeline.collide (narrow_phase.py:633-638,1455-1665: midphase over the mesh's triangles, GJK / MPR + manifold per
     triangle, the global contact reduction); the primitives are filtered against each other.  Worlds differ by a seeded pose jitter.
-    bench.py --workload terrain."""
+    bench.py --workload terrain; heightfield=True: the same surface as a GeoType.HFIELD shape (--workload terrain_hfield)."""
     import newton_amd as nt
 
     rng = np.random.default_rng(seed)
@@ -495,7 +496,11 @@ def terrain_scene(world_count: int, n_shapes: int = 8, device=None, seed: int = 
     scene.default_shape_cfg.gap = gap
     scene.default_shape_cfg.mu = 0.5
     scene.replicate(env, world_count)
-    scene.add_shape_mesh(-1, mesh=terrain)
+    if heightfield:  # the same surface as a newton.Heightfield (GeoType.HFIELD): grid-cell midphase, TRIANGLE_PRISM cells
+        raw = np.array([[terrain_height(x, y) for x in xs] for y in xs], np.float32)
+        scene.add_shape_heightfield(heightfield=nt.Heightfield(raw, cells + 1, cells + 1, hx=half, hy=half))
+    else:
+        scene.add_shape_mesh(-1, mesh=terrain)
     model = scene.finalize(device=device)
     pitch = 2.0 * half / (side + 1)
     for w in range(world_count):

@@ -471,3 +471,38 @@ def test_outlier_explainer_needs_substeps_after_the_first_divergence():
     gpu[N + 2][0][nb, 0] += 1e-3
     with _pytest.raises(AssertionError, match="do not re-join"):
         tol.explain_rollout_outliers("synthetic", gpu, ora, restart(N + 2), nb, frame=N)
+
+
+def test_heightfield_shapes_route_to_the_triangle_leg():
+    """ModelBuilder.add_shape_heightfield (geometry/types.py:2240-2340, builder.py:11653-11660): a static GeoType.HFIELD shape with the
+    field's bounding box as local AABB (the tiles keep it as a pre-computed-AABB shape), HeightfieldData + normalised elevations in
+    the model, (heightfield, convex) pairs routed to pair kind 3 (narrow_phase.py:553-583); primitives carry their local AABBs
+    (builder.py:11601-11652: what the heightfield midphase reads of the partner)."""
+    xs, ys = np.linspace(-1.0, 1.0, 21), np.linspace(-0.8, 0.8, 17)
+    raw = np.array([[0.5 + 0.03 * np.sin(4 * x) * np.cos(3 * y) for x in xs] for y in ys], np.float32)
+    field = nt.Heightfield(raw, 17, 21, hx=1.0, hy=0.8)
+    assert field.data.min() == 0.0 and field.data.max() == 1.0 and np.isclose(field.min_z, raw.min()) and np.isclose(field.max_z, raw.max())
+    env = nt.ModelBuilder()
+    env.add_shape_box(env.add_body(xform=[0, 0, 0.6, 0, 0, 0, 1]), hx=0.05, hy=0.04, hz=0.03)
+    env.add_shape_capsule(env.add_body(xform=[0.3, 0, 0.6, 0, 0, 0, 1]), radius=0.02, half_height=0.05)
+    s = nt.ModelBuilder()
+    s.replicate(env, 3)
+    s.add_shape_heightfield(heightfield=field)
+    m = s.finalize(device=None)
+    t = m.env
+    assert t.np == 1 and t.sdf_pair.tolist() == [[0, 2], [1, 2]] and t.sdf_pair_mesh_tri.tolist() == [True, True]
+    assert t.shape_type.tolist() == [int(GeoType.BOX), int(GeoType.CAPSULE), int(GeoType.HFIELD)]
+    assert t.tile_shape_type.tolist() == [int(GeoType.BOX), int(GeoType.CAPSULE), int(GeoType.CONVEX_MESH)]
+    assert m.shape_heightfield_index.tolist() == [-1] * 6 + [0] and m.heightfield_count == 1
+    off, nrow, ncol, hx, hy, zlo, zhi = m.heightfield_data[0]
+    assert (off, nrow, ncol, hx, hy) == (0, 17, 21, 1.0, 0.8) and m.heightfield_elevations.shape == (17 * 21,)
+    assert np.allclose(m.shape_collision_aabb_lower[6], [-1.0, -0.8, zlo]) and np.allclose(m.shape_collision_aabb_upper[6], [1.0, 0.8, zhi])
+    assert int(np.prod(m._shape_voxel_resolution[6])) in range(50, 101)
+    assert np.allclose(m.shape_collision_aabb_upper[0], [0.05, 0.04, 0.03]) and np.allclose(m.shape_collision_aabb_upper[1], [0.02, 0.02, 0.07])
+    assert int(m.shape_body[6]) == -1
+    with pytest.raises(NotImplementedError, match="scale"):
+        nt.ModelBuilder().add_shape_heightfield(heightfield=field, scale=(2.0, 1.0, 1.0))
+    from newton_amd.worlds import slice_worlds
+
+    part = slice_worlds(m, 1, 3)
+    assert part.shape_heightfield_index.tolist() == [-1] * 4 + [0] and part.env.sdf_pair_mesh_tri.tolist() == [True, True]
