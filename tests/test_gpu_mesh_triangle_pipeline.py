@@ -347,3 +347,32 @@ def test_xpbd_settles_shapes_on_a_heightfield():
     assert np.all(q[:, 2] > ground + 0.02), (q[:, 2] - ground).min()
     assert np.all(q[:, 2] < ground + 0.12)
     assert np.median(np.abs(qd[:, :3]).max(axis=1)) < 0.05
+
+
+@pytest.mark.parametrize("surface", ["mesh", "heightfield"])
+def test_penalty_solvers_consume_the_triangle_rows(surface):
+    """The rows feed SolverSemiImplicit and SolverFeatherstone like any SDF row (nt_flat_rows_forces: ordered per-body sums): boxes
+    and spheres dropped from 5 mm onto the terrain come to rest on it under the penalty contact model."""
+    import newton_amd as nt
+
+    E = 4
+    for make, dt, steps in ((lambda m: nt.solvers.SolverSemiImplicit(m), 1.0 / 4000.0, 1600),
+                            (lambda m: nt.solvers.SolverFeatherstone(m), 1.0 / 4000.0, 1600)):
+        model = (terrain_scene if surface == "mesh" else hfield_scene)(E, kinds=("box", "sphere"), drop=0.006)
+        for k in ("ke", "kd", "kf", "mu"):
+            getattr(model, "shape_material_" + k)[:] = {"ke": 2.0e4, "kd": 50.0, "kf": 50.0, "mu": 0.5}[k]
+        solver = make(model)
+        pipe = nt.CollisionPipeline(model, broad_phase="nxn")
+        contacts = pipe.contacts()
+        s0, s1 = model.state(), model.state()
+        for _ in range(steps):
+            s0.clear_forces()
+            pipe.collide(s0, contacts)
+            solver.step(s0, s1, None, contacts, dt)
+            s0, s1 = s1, s0
+        q, qd = s0.body_q.cpu().numpy().reshape(-1, 7), s0.body_qd.cpu().numpy().reshape(-1, 6)
+        name = type(solver).__name__
+        assert np.all(np.isfinite(q)) and np.all(np.isfinite(qd)), name
+        h = q[:, 2] - terrain_height(q[:, 0], q[:, 1])
+        assert np.all(h > 0.03) and np.all(h < 0.08), (name, h)   # half extents 0.05 / 0.06: resting on the surface
+        assert np.abs(qd[:, :3]).max() < 0.3, (name, np.abs(qd[:, :3]).max())
