@@ -19,6 +19,7 @@
 // sort key (pair, edge, mode) rides along so the host can order them deterministically.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -2744,6 +2745,7 @@ __global__ void __launch_bounds__(64 * HY_STAGE_WAVES) NT_HYDRO_FACES_OCC hydro_
     }
 }
 
+constexpr int HY_REDUCE_THREADS = 128;  // same-box ABAB on hydro_bin: 256 lanes 545.5 ms per frame, 128 lanes 528.9, 64 lanes 556.7 (profiles/r06AH*_ab.txt)
 template <bool EXTRAS>
 __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a) {
     __shared__ HydroRedLds R;
@@ -2771,9 +2773,9 @@ __global__ void __launch_bounds__(256) hydro_stage_reduce_kernel(nt_hydro_args a
         __syncthreads();
         for (int q_tile = 0; q_tile < nq; q_tile += HY_ITEM_TILE) {
             const int m = nq - q_tile < HY_ITEM_TILE ? nq - q_tile : HY_ITEM_TILE;
-            if (t < m) {
-                item_c0[t] = a.stage_item[2 * (size_t)(q0 + q_tile + t)];
-                item_nc[t] = a.stage_item[2 * (size_t)(q0 + q_tile + t) + 1];
+            for (int k = t; k < m; k += blockDim.x) {  // (any workgroup size from one wave up)
+                item_c0[k] = a.stage_item[2 * (size_t)(q0 + q_tile + k)];
+                item_nc[k] = a.stage_item[2 * (size_t)(q0 + q_tile + k) + 1];
             }
             __syncthreads();
             if (t == 0) {
@@ -2895,8 +2897,14 @@ nt_status nt_hydro_pairs(const nt_hydro_args* a, void* stream) {
 #endif
             hipLaunchKernelGGL(hydro_stage_blocks_kernel, dim3(wgrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);
             hipLaunchKernelGGL(hydro_stage_faces_kernel, dim3(igrid), dim3(64 * HY_STAGE_WAVES), 0, st, *a);
-            if (a->reduce & (8 | 16)) hipLaunchKernelGGL(hydro_stage_reduce_kernel<true>, dim3(rblocks), dim3(256), 0, st, *a);
-            else hipLaunchKernelGGL(hydro_stage_reduce_kernel<false>, dim3(rblocks), dim3(256), 0, st, *a);
+            // lanes per pair of the reduce stage: a pile's pair has a few dozen faces (NT_HYDRO_REDUCE_THREADS: measurements)
+            static const int rthreads = [] {
+                const char* e = getenv("NT_HYDRO_REDUCE_THREADS");
+                const int v = e ? atoi(e) : HY_REDUCE_THREADS;
+                return v == 64 || v == 128 || v == 256 ? v : HY_REDUCE_THREADS;
+            }();
+            if (a->reduce & (8 | 16)) hipLaunchKernelGGL(hydro_stage_reduce_kernel<true>, dim3(rblocks), dim3(rthreads), 0, st, *a);
+            else hipLaunchKernelGGL(hydro_stage_reduce_kernel<false>, dim3(rblocks), dim3(rthreads), 0, st, *a);
         } else if (a->reduce & (8 | 16)) hipLaunchKernelGGL((hydro_pairs_kernel<true, true>), dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
         else hipLaunchKernelGGL((hydro_pairs_kernel<true, false>), dim3(rblocks), dim3(256), 0, (hipStream_t)stream, *a);
     } else {
