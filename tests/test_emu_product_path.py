@@ -43,3 +43,15 @@ def test_unreduced_sdf_rows_dry_run(oracle_lib):
                         "-k", "unreduced"], cwd=TESTS, env=ENV, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "1 passed" in r.stdout
+
+
+def test_triangle_leg_pipeline_dry_run(oracle_lib):
+    """Convex shapes on a triangle-mesh terrain and on a heightfield through CollisionPipeline.collide (the triangle leg as pair kind 3
+    of the SDF leg): the row tests of tests/test_gpu_mesh_triangle_pipeline.py on the emulated library -- builder (nt.Heightfield, hull
+    tables, block bounds), pair routing on the host and in nt_model_create, nt_mesh_triangle_pairs, nt_sdf_rows_finalize with the
+    partner's effective radius -- against the checker chain.  (The settle tests of that file stay with the device.)"""
+    r = subprocess.run([sys.executable, "-m", "pytest", "-p", "emu_plugin", "-m", "gpu", "-q", "-x", "test_gpu_mesh_triangle_pipeline.py",
+                        "-k", "rows_of_primitives or rows_of_shapes_on_a_heightfield"], cwd=TESTS, env=ENV, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "4 passed" in r.stdout
